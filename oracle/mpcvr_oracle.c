@@ -1,0 +1,977 @@
+/*
+ * mpcvr_oracle.c — plain-C CPU restatement of the MPC Video Renderer shader video processor
+ * (convert -> separable resize -> final pass/dither).  See mpcvr_oracle.h for the status header:
+ * TEST INFRASTRUCTURE ONLY; parameter maths pinned against the real csputils.cpp (oracle/_ref),
+ * HLSL arithmetic "parity unpinned" (no reference tests / no D3D here).
+ *
+ * Build: gcc -O2 -std=c11 -ffp-contract=off [-fopenmp] (see oracle/Makefile).  fp-contract is off
+ * so every a*b+c below is two IEEE roundings — the restatement is then independent of the host ISA.
+ *
+ * D3D11 semantics modelled explicitly (functional spec):
+ *   UNORM load  v/(2^n-1);  point sample floor(u*W) clamped;  linear sample with exact 1/4-step
+ *   weights;  float->UNORM store floor(sat(x)*(2^n-1)+0.5);  float->fp16 round-to-nearest-even;
+ *   saturate;  frac;  pow(x,y)=exp2(y*log2(x)).
+ */
+#include "mpcvr_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* small helpers                                                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+static inline int   clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline float saturatef(float x) { return (x != x) ? 0.0f : (x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x)); }
+/* HLSL pow: exp2(y*log2(x)) (d3dcompiler lowers pow to log/mul/exp). */
+static inline float hlsl_pow(float x, float y) { return exp2f(y * log2f(x)); }
+
+static int g_threads = 0;
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return g_threads > 0 ? g_threads : omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void orc_set_num_threads(int n) { g_threads = n; }
+#ifdef _OPENMP
+#define ORC_PAR_FOR _Pragma("omp parallel for schedule(static) num_threads(orc_num_threads())")
+#else
+#define ORC_PAR_FOR
+#endif
+
+/* fp32 -> fp16 round-to-nearest-even -> fp32 (D3D11 float32->float16 store conversion). */
+static uint16_t float_to_half_bits(float f)
+{
+    uint32_t x; memcpy(&x, &f, 4);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t mant = x & 0x007fffffu;
+    int32_t  exp  = (int32_t)((x >> 23) & 0xff);
+    if (exp == 0xff) return (uint16_t)(sign | 0x7c00u | (mant ? 0x200u : 0));   /* inf / nan */
+    int32_t e = exp - 127 + 15;
+    if (e >= 0x1f) return (uint16_t)(sign | 0x7c00u);                            /* overflow -> inf */
+    if (e <= 0) {                                                                /* subnormal / zero */
+        if (e < -10) return (uint16_t)sign;
+        mant |= 0x00800000u;
+        uint32_t shift = (uint32_t)(14 - e);
+        uint32_t h = mant >> shift;
+        uint32_t rem = mant & ((1u << shift) - 1u);
+        uint32_t half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1u))) h++;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((uint32_t)e << 10) | (mant >> 13);
+    uint32_t rem = mant & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;                      /* may carry into exp: ok */
+    return (uint16_t)(sign | h);
+}
+float orc_half_bits_to_float(uint16_t h)
+{
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1f, mant = h & 0x3ffu, x;
+    if (exp == 0) {
+        if (!mant) x = sign;
+        else { int e = -1; do { mant <<= 1; e++; } while (!(mant & 0x400u));
+               x = sign | ((uint32_t)(127 - 15 - e) << 23) | ((mant & 0x3ffu) << 13); }
+    } else if (exp == 0x1f) x = sign | 0x7f800000u | (mant << 13);
+    else x = sign | ((exp - 15 + 127) << 23) | (mant << 13);
+    float f; memcpy(&f, &x, 4); return f;
+}
+float orc_half_round(float x) { return orc_half_bits_to_float(float_to_half_bits(x)); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* formats — Helper.cpp:295-359 (s_FmtConvMapping, DX11PlaneConfig_t)                          */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int cformat;
+    int planes;        /* 2 = Y + interleaved UV, 3 = Y,U,V */
+    int bytes;         /* bytes per sample: 1 (R8) or 2 (R16) */
+    int div_w, div_h;  /* chroma divisors (DX11PlaneConfig_t) */
+    int packsize;      /* Packsize */
+    int pitch_coeff;   /* PitchCoeff: lines = H*coeff/2 */
+    int subsampling;   /* 420/422/444 */
+    int cdepth;        /* CDepth */
+    int shift;         /* CopyPlane10to16 (<<6) on upload — Helper.cpp:386-391,789-803 */
+    int v_first;       /* YV12/YV16/YV24: second plane is V — Shaders.cpp:159-165 */
+} fmt_info;
+
+static const fmt_info s_fmts[] = {
+    {ORC_CF_NV12,      2, 1, 2, 2, 1, 3, 420,  8, 0, 0},
+    {ORC_CF_P010,      2, 2, 2, 2, 2, 3, 420, 16, 0, 0},
+    {ORC_CF_P016,      2, 2, 2, 2, 2, 3, 420, 16, 0, 0},
+    {ORC_CF_P210,      2, 2, 2, 1, 2, 4, 422, 16, 0, 0},
+    {ORC_CF_P216,      2, 2, 2, 1, 2, 4, 422, 16, 0, 0},
+    {ORC_CF_YV12,      3, 1, 2, 2, 1, 3, 420,  8, 0, 1},
+    {ORC_CF_YV16,      3, 1, 2, 1, 1, 4, 422,  8, 0, 1},
+    {ORC_CF_YV24,      3, 1, 1, 1, 1, 6, 444,  8, 0, 1},
+    {ORC_CF_YUV420P8,  3, 1, 2, 2, 1, 3, 420,  8, 0, 0},
+    {ORC_CF_YUV422P8,  3, 1, 2, 1, 1, 4, 422,  8, 0, 0},
+    {ORC_CF_YUV444P8,  3, 1, 1, 1, 1, 6, 444,  8, 0, 0},
+    {ORC_CF_YUV420P10, 3, 2, 2, 2, 2, 3, 420, 10, 6, 0},
+    {ORC_CF_YUV420P16, 3, 2, 2, 2, 2, 3, 420, 16, 0, 0},
+    {ORC_CF_YUV422P10, 3, 2, 2, 1, 2, 4, 422, 10, 6, 0},
+    {ORC_CF_YUV422P16, 3, 2, 2, 1, 2, 4, 422, 16, 0, 0},
+    {ORC_CF_YUV444P10, 3, 2, 1, 1, 2, 6, 444, 10, 6, 0},
+    {ORC_CF_YUV444P16, 3, 2, 1, 1, 2, 6, 444, 16, 0, 0},
+};
+static const fmt_info *find_fmt(int cf)
+{
+    for (size_t i = 0; i < sizeof(s_fmts) / sizeof(s_fmts[0]); i++)
+        if (s_fmts[i].cformat == cf) return &s_fmts[i];
+    return NULL;
+}
+
+/* pitch / lines rules — DX11VideoProcessor.cpp:1789-1803 */
+size_t orc_frame_bytes(int cformat, int width, int height, int *pitch_out)
+{
+    const fmt_info *f = find_fmt(cformat);
+    if (!f) return 0;
+    int pitch = width * f->packsize;
+    if (cformat == ORC_CF_NV12) pitch = (pitch + 3) & ~3;          /* ALIGN(m_srcPitch, 4) */
+    if (pitch_out) *pitch_out = pitch;
+    return (size_t)pitch * (size_t)(height * f->pitch_coeff / 2);   /* m_srcLines */
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* DXVA2_ExtendedFormat — dxva2api.h bit layout (LSB first): SampleFormat:8, ChromaSubsampling:4, */
+/* NominalRange:3, TransferMatrix:3, Lighting:4, Primaries:5, TransferFunction:5                  */
+/* ------------------------------------------------------------------------------------------ */
+#define EXF_CHROMA(v)   (((v) >> 8)  & 0xf)
+#define EXF_RANGE(v)    (((v) >> 12) & 0x7)
+#define EXF_MATRIX(v)   (((v) >> 15) & 0x7)
+#define EXF_LIGHT(v)    (((v) >> 18) & 0xf)
+#define EXF_PRIM(v)     (((v) >> 22) & 0x1f)
+#define EXF_TRC(v)      (((v) >> 27) & 0x1f)
+static inline uint32_t exf_set(uint32_t v, int shift, uint32_t mask, uint32_t x)
+{ return (v & ~(mask << shift)) | ((x & mask) << shift); }
+
+enum { CHROMA_MPEG1 = 1, CHROMA_MPEG2 = 5, CHROMA_COSITED = 7 };
+enum { RANGE_0_255 = 1, RANGE_16_235 = 2 };
+enum { MATRIX_709 = 1, MATRIX_601 = 2, MATRIX_240M = 3, MATRIX_2020 = 4, MATRIX_YCGCO = 7 };
+enum { PRIM_709 = 2, PRIM_470M = 3, PRIM_470BG = 4, PRIM_170M = 5, PRIM_240M = 6, PRIM_2020 = 9, PRIM_DCIP3 = 11 };
+enum { TRC_10 = 1, TRC_18 = 2, TRC_20 = 3, TRC_22 = 4, TRC_709 = 5, TRC_240M = 6, TRC_SRGB = 7, TRC_28 = 8,
+       TRC_26 = 14, TRC_2084 = 15, TRC_HLG = 16 };
+
+/* SpecifyExtendedFormat — Helper.cpp:1169-1211 (CS_YUV branch; every format here is YUV) */
+uint32_t orc_specify_extfmt(uint32_t v, int cformat, int w, int h)
+{
+    const fmt_info *f = find_fmt(cformat);
+    if (!f) return v;
+    if (f->subsampling != 420)            v = exf_set(v, 8, 0xf, 0);
+    else if (EXF_CHROMA(v) == 0)          v = exf_set(v, 8, 0xf, CHROMA_MPEG2);
+    if (EXF_RANGE(v) == 0)                v = exf_set(v, 12, 0x7, RANGE_16_235);
+    if (EXF_MATRIX(v) == 0)               v = exf_set(v, 15, 0x7, (w <= 1024 && h <= 576) ? MATRIX_601 : MATRIX_709);
+    if (EXF_LIGHT(v) == 0)                v = exf_set(v, 18, 0xf, 3 /* dim */);
+    if (EXF_PRIM(v) == 0)                 v = exf_set(v, 22, 0x1f, PRIM_709);
+    if (EXF_TRC(v) == 0)                  v = exf_set(v, 27, 0x1f, TRC_709);
+    return v;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* csputils restatement — csputils.cpp:341-509 (mp_get_csp_mul, luma_coeffs, mp_get_csp_matrix) */
+/* mp_csp: 1=BT_601 2=BT_709 3=SMPTE_240M 4=BT_2020_NC 8=YCGCO ; levels: 1=TV 2=PC            */
+/* ------------------------------------------------------------------------------------------ */
+static void luma_coeffs(float m[3][3], float lr, float lg, float lb)
+{   /* csputils.cpp:380-389 — all in float, exactly as the initialiser list evaluates */
+    m[0][0] = 1; m[0][1] = 0;                        m[0][2] = 2 * (1 - lr);
+    m[1][0] = 1; m[1][1] = -2 * (1 - lb) * lb / lg;  m[1][2] = -2 * (1 - lr) * lr / lg;
+    m[2][0] = 1; m[2][1] = 2 * (1 - lb);             m[2][2] = 0;
+}
+
+void orc_csp_matrix(int space, int levels_in, int bits, float brightness, float contrast,
+                    float hue, float saturation, int gray, float mo[9], float co[3])
+{
+    float m[3][3];
+    if (space <= 0 || space >= 9) space = 1;               /* AUTO -> BT_601 (csputils.cpp:395-396) */
+    if (levels_in <= 0 || levels_in >= 3) levels_in = 1;   /* AUTO -> TV */
+    switch (space) {
+    case 1: luma_coeffs(m, 0.299f,  0.587f,  0.114f);  break;
+    case 2: luma_coeffs(m, 0.2126f, 0.7152f, 0.0722f); break;
+    case 3: luma_coeffs(m, 0.2122f, 0.7013f, 0.0865f); break;
+    case 4: luma_coeffs(m, 0.2627f, 0.6780f, 0.0593f); break;
+    case 8: { const float y[3][3] = {{1, -1, 1}, {1, 1, 0}, {1, -1, -1}}; memcpy(m, y, sizeof(y)); break; }
+    default: luma_coeffs(m, 0.299f, 0.587f, 0.114f); break; /* other spaces never reach this path */
+    }
+    if (space >= 1 && space <= 4) {                         /* csputils.cpp:447-459 */
+        float huecos = gray ? 0 : saturation * cosf(hue);
+        float huesin = gray ? 0 : saturation * sinf(hue);
+        for (int i = 0; i < 3; i++) {
+            float u = m[i][1], v = m[i][2];
+            m[i][1] = huecos * u - huesin * v;
+            m[i][2] = huesin * u + huecos * v;
+        }
+    }
+    /* mp_get_csp_mul(colorspace, input_bits, texture_bits) with input_bits == texture_bits == CDepth
+       (DX11VideoProcessor.cpp:845): (1<<bits) / ((1<<bits) - 1.) * 255 / 256   — csputils.cpp:357 */
+    double mul = (double)(1LL << bits) / ((double)(1LL << bits) - 1.) * 255 / 256;
+    double s = mul / 255;
+    double ymin, ymax, cmax, cmid;
+    if (levels_in == 1) { ymin = 16 * s; ymax = 235 * s; cmax = 240 * s; cmid = 128 * s; }
+    else                { ymin = 0 * s;  ymax = 255 * s; cmax = 255 * s; cmid = 128 * s; }
+    const double rgbmin = 0, rgbmax = 1;                     /* levels_out = PC */
+    double ymul = (rgbmax - rgbmin) / (ymax - ymin);
+    double cmul = (rgbmax - rgbmin) / (cmax - cmid) / 2;
+    ymul *= contrast;
+    cmul *= contrast;
+    for (int i = 0; i < 3; i++) {
+        m[i][0] = (float)(m[i][0] * ymul);
+        m[i][1] = (float)(m[i][1] * cmul);
+        m[i][2] = (float)(m[i][2] * cmul);
+        float uv = m[i][1] + m[i][2];                        /* float + float, as written */
+        co[i] = (float)(rgbmin - m[i][0] * ymin - uv * cmid + brightness);
+    }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) mo[i * 3 + j] = m[i][j];
+}
+
+/* set_colorspace — Helper.cpp:949-1004 (only the fields the matrix uses) */
+static void extfmt_to_csp(uint32_t v, int *space, int *levels)
+{
+    switch (EXF_RANGE(v)) { case RANGE_0_255: *levels = 2; break; case RANGE_16_235: *levels = 1; break; default: *levels = 0; }
+    switch (EXF_MATRIX(v)) {
+    case MATRIX_709: *space = 2; break;  case MATRIX_601: *space = 1; break;
+    case MATRIX_240M: *space = 3; break; case MATRIX_2020: *space = 4; break;
+    case MATRIX_YCGCO: *space = 8; break; default: *space = 0;
+    }
+}
+
+static void resolve_rect(const orc_params *p, int r[4])
+{
+    memcpy(r, p->src_rect, sizeof(int) * 4);
+    if (!r[0] && !r[1] && !r[2] && !r[3]) { r[2] = p->width; r[3] = p->height; }
+}
+
+/* SetShaderConvertColorParams — DX11VideoProcessor.cpp:813-887 */
+int orc_color_matrix(const orc_params *p, float out[12])
+{
+    const fmt_info *f = find_fmt(p->cformat);
+    if (!f) return -1;
+    int r[4]; resolve_rect(p, r);
+    uint32_t ex = orc_specify_extfmt(p->exfmt, p->cformat, r[2] - r[0], r[3] - r[1]);
+    int space, levels; extfmt_to_csp(ex, &space, &levels);
+    float brightness = p->brightness / 255;                              /* :839 */
+    float contrast = p->contrast;                                        /* :840 */
+    float hue = (float)(p->hue / 180 * acos(-1));                        /* :841 */
+    float m[9], c[3];
+    orc_csp_matrix(space, levels, f->cdepth, brightness, contrast, hue, p->saturation, 0, m, c);
+    memcpy(out, m, sizeof(m)); memcpy(out + 9, c, sizeof(c));
+    return 0;
+}
+
+float orc_luminance_scale(int nits) { return 10000.0f / nits; }          /* :891 */
+
+/* ------------------------------------------------------------------------------------------ */
+/* gamut matrix — csputils.cpp:10-49 (invert/mul), :51-200 (primaries), :228-259 (rgb2xyz), :549-557 */
+/* mp_csp_prim: 3=BT_709 4=BT_2020                                                             */
+/* ------------------------------------------------------------------------------------------ */
+static void invert3x3(float m[3][3])
+{
+    float m00 = m[0][0], m01 = m[0][1], m02 = m[0][2],
+          m10 = m[1][0], m11 = m[1][1], m12 = m[1][2],
+          m20 = m[2][0], m21 = m[2][1], m22 = m[2][2];
+    m[0][0] =  (m11 * m22 - m21 * m12);
+    m[0][1] = -(m01 * m22 - m21 * m02);
+    m[0][2] =  (m01 * m12 - m11 * m02);
+    m[1][0] = -(m10 * m22 - m20 * m12);
+    m[1][1] =  (m00 * m22 - m20 * m02);
+    m[1][2] = -(m00 * m12 - m10 * m02);
+    m[2][0] =  (m10 * m21 - m20 * m11);
+    m[2][1] = -(m00 * m21 - m20 * m01);
+    m[2][2] =  (m00 * m11 - m10 * m01);
+    float det = m00 * m[0][0] + m10 * m[0][1] + m20 * m[0][2];
+    det = 1.0f / det;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) m[i][j] *= det;
+}
+static void mul3x3(float a[3][3], float b[3][3])
+{
+    float a00 = a[0][0], a01 = a[0][1], a02 = a[0][2],
+          a10 = a[1][0], a11 = a[1][1], a12 = a[1][2],
+          a20 = a[2][0], a21 = a[2][1], a22 = a[2][2];
+    for (int i = 0; i < 3; i++) {
+        a[0][i] = a00 * b[0][i] + a01 * b[1][i] + a02 * b[2][i];
+        a[1][i] = a10 * b[0][i] + a11 * b[1][i] + a12 * b[2][i];
+        a[2][i] = a20 * b[0][i] + a21 * b[1][i] + a22 * b[2][i];
+    }
+}
+typedef struct { float rx, ry, gx, gy, bx, by, wx, wy; } prim_t;
+static prim_t primaries(int prim)
+{
+    const float d65x = 0.31271f, d65y = 0.32902f;                         /* csputils.cpp:73 */
+    switch (prim) {
+    case 4:  { prim_t p = {0.708f, 0.292f, 0.170f, 0.797f, 0.131f, 0.046f, d65x, d65y}; return p; }
+    case 2:  { prim_t p = {0.640f, 0.330f, 0.290f, 0.600f, 0.150f, 0.060f, d65x, d65y}; return p; } /* 601-625 */
+    case 1:  { prim_t p = {0.630f, 0.340f, 0.310f, 0.595f, 0.155f, 0.070f, d65x, d65y}; return p; } /* 601-525 */
+    default: { prim_t p = {0.640f, 0.330f, 0.300f, 0.600f, 0.150f, 0.060f, d65x, d65y}; return p; } /* 709 */
+    }
+}
+static void rgb2xyz(prim_t s, float m[3][3])
+{
+    float S[3], X[4], Z[4];
+    X[0] = s.rx / s.ry; X[1] = s.gx / s.gy; X[2] = s.bx / s.by; X[3] = s.wx / s.wy;
+    Z[0] = (1 - s.rx - s.ry) / s.ry; Z[1] = (1 - s.gx - s.gy) / s.gy;
+    Z[2] = (1 - s.bx - s.by) / s.by; Z[3] = (1 - s.wx - s.wy) / s.wy;
+    for (int i = 0; i < 3; i++) { m[0][i] = X[i]; m[1][i] = 1; m[2][i] = Z[i]; }
+    invert3x3(m);
+    for (int i = 0; i < 3; i++) S[i] = m[i][0] * X[3] + m[i][1] * 1 + m[i][2] * Z[3];
+    for (int i = 0; i < 3; i++) { m[0][i] = S[i] * X[i]; m[1][i] = S[i] * 1; m[2][i] = S[i] * Z[i]; }
+}
+void orc_gamut_matrix(int prim_in, int prim_out, float out[9])
+{
+    float in[3][3], m[3][3];
+    rgb2xyz(primaries(prim_in), in);
+    rgb2xyz(primaries(prim_out), m);
+    invert3x3(m);
+    mul3x3(m, in);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) out[i * 3 + j] = m[i][j];
+}
+void orc_gamut_2020_to_709(float out[9]) { orc_gamut_matrix(4, 3, out); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* shader device functions                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+/* Shaders/convert/st2084.hlsl:1-5 */
+#define ST2084_m1 (2610.0f / (4096.0f * 4.0f))
+#define ST2084_m2 ((2523.0f / 4096.0f) * 128.0f)
+#define ST2084_c1 (3424.0f / 4096.0f)
+#define ST2084_c2 ((2413.0f / 4096.0f) * 32.0f)
+#define ST2084_c3 ((2392.0f / 4096.0f) * 32.0f)
+
+float orc_st2084_to_linear(float x, float factor)       /* st2084.hlsl:9-16 */
+{
+    x = hlsl_pow(x, 1.0f / ST2084_m2);
+    x = fmaxf(x - ST2084_c1, 0.0f) / (ST2084_c2 - ST2084_c3 * x);
+    x = hlsl_pow(x, 1.0f / ST2084_m1);
+    x *= factor;
+    return x;
+}
+float orc_linear_to_st2084(float x, float divider)      /* st2084.hlsl:18-25 */
+{
+    x /= divider;
+    x = hlsl_pow(x, ST2084_m1);
+    x = (ST2084_c1 + ST2084_c2 * x) / (1.0f + ST2084_c3 * x);
+    x = hlsl_pow(x, ST2084_m2);
+    return x;
+}
+void orc_hlg_to_linear(float rgb[3])                    /* hlg.hlsl:1-20 */
+{
+    const float B67_a = 0.17883277f, B67_b = 0.28466892f, B67_c = 0.55991073f, B67_inv_r2 = 4.0f;
+    for (int i = 0; i < 3; i++)
+        rgb[i] = (rgb[i] <= 0.5f) ? rgb[i] * rgb[i] * B67_inv_r2 : expf((rgb[i] - B67_c) / B67_a) + B67_b;
+    float ootf_ys = 2000.0f * (0.2627f * rgb[0] + 0.6780f * rgb[1] + 0.0593f * rgb[2]);
+    float g = hlsl_pow(ootf_ys, 0.2f);
+    for (int i = 0; i < 3; i++) rgb[i] *= g;
+}
+float orc_hable(float x)                                /* hdr_tone_mapping.hlsl:1-6 */
+{
+    const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+    return ((x * (A * x + (C * B)) + (D * E)) / (x * (A * x + B) + (D * F))) - E / F;
+}
+void orc_tonemap_hable(float rgb[3])                    /* hdr_tone_mapping.hlsl:8-13 */
+{
+    const float div = orc_hable(4.8f);
+    for (int i = 0; i < 3; i++) rgb[i] = orc_hable(rgb[i]) / div;
+}
+
+static void mat3_apply(const float m[9], float rgb[3])
+{   /* HLSL mul(float3x3, float3): row dot products, left-to-right */
+    float r = m[0] * rgb[0] + m[1] * rgb[1] + m[2] * rgb[2];
+    float g = m[3] * rgb[0] + m[4] * rgb[1] + m[5] * rgb[2];
+    float b = m[6] * rgb[0] + m[7] * rgb[1] + m[8] * rgb[2];
+    rgb[0] = r; rgb[1] = g; rgb[2] = b;
+}
+
+/* The tail GetShaderConvertColor appends after "//convert color" — Shaders.cpp:861-923.
+ * (alpha follows the same scalar ops in HLSL but is forced to 1 by every store format; not modelled) */
+void orc_hdr_tail(float rgb[3], int trc, int prim, int convert_to_sdr, float lum_scale)
+{
+    float gm[9];
+    const int bt2020 = (prim == PRIM_2020);
+    const int hdr2sdr = convert_to_sdr && (trc == TRC_2084 || trc == TRC_HLG);        /* :614 */
+    int is_linear = 0;
+    if (hdr2sdr) {
+        if (trc == TRC_HLG) {                                                          /* :862-868 */
+            for (int i = 0; i < 3; i++) rgb[i] = saturatef(rgb[i]);
+            orc_hlg_to_linear(rgb);
+            for (int i = 0; i < 3; i++) rgb[i] = orc_linear_to_st2084(rgb[i], 1000.0f);
+        }
+        for (int i = 0; i < 3; i++) rgb[i] = saturatef(rgb[i]);                        /* :870-872 */
+        for (int i = 0; i < 3; i++) rgb[i] = orc_st2084_to_linear(rgb[i], lum_scale);  /* :879 */
+        orc_tonemap_hable(rgb);                                                        /* :880 */
+        orc_gamut_2020_to_709(gm); mat3_apply(gm, rgb);                                /* :881 */
+        is_linear = 1;
+    } else if (bt2020) {                                                               /* :892-915 */
+        float g = 0;
+        switch (trc) {
+        case TRC_10: g = 1.0f; break;  /* emitted text is not valid HLSL; treated as "nothing" */
+        case TRC_18: g = 1.8f; break;
+        case TRC_20: g = 2.0f; break;
+        case TRC_HLG: case TRC_22: case TRC_709: case TRC_240M: case TRC_SRGB: g = 2.2f; break;
+        case TRC_28: g = 2.8f; break;
+        case TRC_26: g = 2.6f; break;
+        default: g = 0; break;
+        }
+        if (g != 0) {
+            for (int i = 0; i < 3; i++) rgb[i] = saturatef(rgb[i]);
+            if (trc != TRC_10) for (int i = 0; i < 3; i++) rgb[i] = hlsl_pow(rgb[i], g);
+            orc_gamut_2020_to_709(gm); mat3_apply(gm, rgb);
+            is_linear = 1;
+        }
+    }
+    if (is_linear)                                                                     /* :917-923 */
+        for (int i = 0; i < 3; i++) rgb[i] = hlsl_pow(saturatef(rgb[i]), 1.0f / 2.2f);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* resize weights                                                                             */
+/* ------------------------------------------------------------------------------------------ */
+#define HLSL_PI 3.14159265358979323846f   /* acos(-1.) folded to fp32 */
+
+int orc_upscale_weights(int method, float t, float w[6])
+{
+    switch (method) {
+    case ORC_UP_MITCHELL: {                         /* ps_interpolation_spline4.hlsl:46-51 */
+        float t2 = t * t, t3 = t * t2;
+        const float a[4] = {1.f / 18.f, 16.f / 18.f, 1.f / 18.f, 0.f / 18.f};
+        const float b[4] = {-.5f, 0.f, .5f, 0.f};
+        const float c[4] = {5.f / 6.f, -12.f / 6.f, 9.f / 6.f, -2.f / 6.f};
+        const float d[4] = {-7.f / 18.f, 21.f / 18.f, -21.f / 18.f, 7.f / 18.f};
+        for (int i = 0; i < 4; i++) w[i] = a[i] + b[i] * t + c[i] * t2 + d[i] * t3;
+        return 4;
+    }
+    case ORC_UP_CATMULLROM: {                       /* ps_interpolation_spline4.hlsl:52-54 */
+        float t2 = t * t, t3 = t * t2;
+        const float b[4] = {-.5f, 0.f, .5f, 0.f};
+        const float c[4] = {1.f, -2.5f, 2.f, -.5f};
+        const float d[4] = {-.5f, 1.5f, -1.5f, .5f};
+        for (int i = 0; i < 4; i++) w[i] = b[i] * t + c[i] * t2 + d[i] * t3;
+        w[1] += 1.f;
+        return 4;
+    }
+    case ORC_UP_LANCZOS2: {                         /* ps_interpolation_lanczos2.hlsl:31-56 */
+        if (t == 0.0f) { w[0] = 0; w[1] = 1; w[2] = 0; w[3] = 0; return 4; }   /* "return Q1" */
+        float ws[4] = {1.f + t, 0.f + t, 1.f - t, 2.f - t};
+        float s = 0;
+        for (int i = 0; i < 4; i++) {
+            float a = ws[i] * HLSL_PI;
+            w[i] = sinf(a) * sinf(a * .5f) / (ws[i] * ws[i] * HLSL_PI * HLSL_PI * .5f);
+        }
+        s = w[0] + w[1] + w[2] + w[3];              /* dot(1., w) */
+        float wc = 1.f - s;
+        w[1] += wc * (1.f - t);
+        w[2] += wc * t;
+        return 4;
+    }
+    case ORC_UP_LANCZOS3: {                         /* ps_interpolation_lanczos3.hlsl:31-64 */
+        if (t == 0.0f) { w[0] = w[1] = 0; w[2] = 1; w[3] = w[4] = w[5] = 0; return 6; } /* "return Q2" */
+        const float k0[3] = {2.f, 1.f, 0.f}, k1[3] = {1.f, 2.f, 3.f};
+        float w0[3], w1[3];
+        for (int i = 0; i < 3; i++) {
+            float a0 = k0[i] * HLSL_PI + t * HLSL_PI, a1 = k1[i] * HLSL_PI - t * HLSL_PI;
+            float a0s = a0 * .5f, a1s = a1 * .5f;
+            w0[i] = sinf(a0) * sinf(a0s) / (a0 * a0s);
+            w1[i] = sinf(a1) * sinf(a1s) / (a1 * a1s);
+        }
+        float s = (w0[0] + w1[0]) + (w0[1] + w1[1]) + (w0[2] + w1[2]);   /* dot(1., w0 + w1) */
+        float wc = 1.f - s;
+        w0[2] += wc * (1.f - t);
+        w1[0] += wc * t;
+        w[0] = w0[0]; w[1] = w0[1]; w[2] = w0[2]; w[3] = w1[0]; w[4] = w1[1]; w[5] = w1[2];
+        return 6;
+    }
+    default: return 0;
+    }
+}
+
+/* Shaders/resize/convolution_filters.hlsl:7-86 ; FILTER/A per compile_shaders.cmd:92-103 */
+float orc_downscale_filter(int method, float x, float *support)
+{
+    switch (method) {
+    case ORC_DOWN_BOX:
+        if (support) *support = 0.5f;
+        return (x >= -0.5f && x < 0.5f) ? 1.0f : 0.0f;
+    case ORC_DOWN_BILINEAR:
+        if (support) *support = 1.0f;
+        if (x < 0.0f) x = -x;
+        return (x < 1.0f) ? 1.0f - x : 0.0f;
+    case ORC_DOWN_HAMMING:
+        if (support) *support = 1.0f;
+        if (x < 0.0f) x = -x;
+        if (x == 0.0f) return 1.0f;
+        if (x >= 1.0f) return 0.0f;
+        x *= HLSL_PI;
+        return sinf(x) / x * (0.54f + 0.46f * cosf(x));
+    case ORC_DOWN_BICUBIC:
+    case ORC_DOWN_BICUBIC_SHARP: {
+        const float A = (method == ORC_DOWN_BICUBIC) ? -0.5f : -1.5f;
+        if (support) *support = 2.0f;
+        if (x < 0.0f) x = -x;
+        if (x < 1.0f) return ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1;
+        if (x < 2.0f) return (((x - 5) * x + 8) * x - 4) * A;
+        return 0.0f;
+    }
+    case ORC_DOWN_LANCZOS: {
+        if (support) *support = 3.0f;
+        if (-3.0f <= x && x < 3.0f) {
+            float a = x, b = x / 3;
+            float sa = (a == 0.0f) ? 1.0f : sinf(a * HLSL_PI) / (a * HLSL_PI);
+            float sb = (b == 0.0f) ? 1.0f : sinf(b * HLSL_PI) / (b * HLSL_PI);
+            return sa * sb;
+        }
+        return 0.0f;
+    }
+    default:
+        if (support) *support = 0;
+        return 0;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* images and store formats                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { int w, h; float *p; } img_t;   /* RGBA fp32, values as a later texture read returns them */
+
+static int img_alloc(img_t *im, int w, int h)
+{
+    im->w = w; im->h = h;
+    im->p = (float *)malloc((size_t)w * h * 4 * sizeof(float));
+    return im->p ? 0 : -1;
+}
+static void img_free(img_t *im) { free(im->p); im->p = NULL; }
+
+enum { FMT_BGRA8 = 8, FMT_RGB10A2 = 10, FMT_RGBA16F = 16 };
+
+/* float -> UNORM n store then UNORM load: floor(sat(x)*(2^n-1)+0.5) / (2^n-1) */
+static inline float unorm_round(float x, float maxv)
+{
+    float q = floorf(saturatef(x) * maxv + 0.5f);
+    return q / maxv;
+}
+/* value a render-target write leaves in a texture of format fmt */
+static inline void store_fmt(int fmt, const float in[4], float out[4])
+{
+    switch (fmt) {
+    case FMT_BGRA8:   for (int i = 0; i < 4; i++) out[i] = unorm_round(in[i], 255.0f); break;
+    case FMT_RGB10A2: for (int i = 0; i < 3; i++) out[i] = unorm_round(in[i], 1023.0f);
+                      out[3] = unorm_round(in[3], 3.0f); break;
+    default:          for (int i = 0; i < 4; i++) out[i] = orc_half_round(in[i]); break;
+    }
+}
+
+/* UpdateTexParams — DX11VideoProcessor.cpp:1143-1155 */
+static int internal_format(int iTexFormat, int cdepth)
+{
+    switch (iTexFormat) {
+    case ORC_TEXFMT_8INT: return FMT_BGRA8;
+    case ORC_TEXFMT_10INT: return FMT_RGB10A2;
+    case ORC_TEXFMT_16FLOAT: return FMT_RGBA16F;
+    default: return cdepth > 8 ? FMT_RGB10A2 : FMT_BGRA8;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* convert pass — Shaders.cpp:82-329 (ShaderGetPixels, DX11 branch), :593-930                   */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const fmt_info *f;
+    const uint8_t *plane[3];
+    int pitch[3];
+    int w, h;          /* luma texture size */
+    int cw, ch;        /* chroma texture size */
+} src_tex;
+
+/* texel fetch with clamp addressing + UNORM load; CopyPlane10to16 shift applied (Helper.cpp:789-803) */
+static inline float load_luma(const src_tex *s, int x, int y)
+{
+    x = clampi(x, 0, s->w - 1); y = clampi(y, 0, s->h - 1);
+    if (s->f->bytes == 1) return (float)s->plane[0][(size_t)y * s->pitch[0] + x] / 255.0f;
+    uint16_t v = ((const uint16_t *)(s->plane[0] + (size_t)y * s->pitch[0]))[x];
+    v = (uint16_t)(v << s->f->shift);
+    return (float)v / 65535.0f;
+}
+/* c: 0 = U, 1 = V */
+static inline float load_chroma(const src_tex *s, int c, int x, int y)
+{
+    x = clampi(x, 0, s->cw - 1); y = clampi(y, 0, s->ch - 1);
+    if (s->f->planes == 2) {
+        if (s->f->bytes == 1) return (float)s->plane[1][(size_t)y * s->pitch[1] + 2 * x + c] / 255.0f;
+        uint16_t v = ((const uint16_t *)(s->plane[1] + (size_t)y * s->pitch[1]))[2 * x + c];
+        return (float)v / 65535.0f;
+    }
+    int pl = s->f->v_first ? (c == 0 ? 2 : 1) : (c == 0 ? 1 : 2);     /* Shaders.cpp:159-165 */
+    if (s->f->bytes == 1) return (float)s->plane[pl][(size_t)y * s->pitch[pl] + x] / 255.0f;
+    uint16_t v = ((const uint16_t *)(s->plane[pl] + (size_t)y * s->pitch[pl]))[x];
+    v = (uint16_t)(v << s->f->shift);
+    return (float)v / 65535.0f;
+}
+
+/* D3D11 linear sample at unnormalised texel coordinate (u,v) = texcoord*size: taps floor(u-.5),+1 with
+ * weights frac(u-.5); all positions on this path are multiples of 1/4 so the 8-bit weight precision
+ * of the fixed-function filter is exact. */
+static inline float sample_chroma_linear(const src_tex *s, int c, float u, float v)
+{
+    float fu = u - 0.5f, fv = v - 0.5f;
+    float iu = floorf(fu), iv = floorf(fv);
+    float wx = fu - iu, wy = fv - iv;
+    int x0 = (int)iu, y0 = (int)iv;
+    float c00 = load_chroma(s, c, x0, y0),     c10 = load_chroma(s, c, x0 + 1, y0);
+    float c01 = load_chroma(s, c, x0, y0 + 1), c11 = load_chroma(s, c, x0 + 1, y0 + 1);
+    float top = c00 * (1.0f - wx) + c10 * wx;
+    float bot = c01 * (1.0f - wx) + c11 * wx;
+    return top * (1.0f - wy) + bot * wy;
+}
+
+static void catmull_weights(float t, float w[4])      /* Shaders.cpp:66-72 */
+{
+    float t2 = t * t, t3 = t * t2;
+    w[0] = t2 - (t3 + t) / 2;
+    w[1] = t3 * 1.5f + 1 - t2 * 2.5f;
+    w[2] = t2 * 2 + t / 2 - t3 * 1.5f;
+    w[3] = (t3 - t2) / 2;
+}
+
+/* chroma for luma pixel (sx,sy) of the source texture */
+static void fetch_chroma(const src_tex *s, int chroma_loc, int chroma_scaling, int sx, int sy, float uv[2])
+{
+    const int sub = s->f->subsampling;
+    if (chroma_scaling == ORC_CHROMA_NEAREST || sub == 444) {            /* Shaders.cpp:239-241,282-287 */
+        int cx = sx / s->f->div_w, cy = sy / s->f->div_h;                 /* floor((sx+.5)/div) */
+        uv[0] = load_chroma(s, 0, cx, cy); uv[1] = load_chroma(s, 1, cx, cy);
+        return;
+    }
+    if (chroma_scaling == ORC_CHROMA_CATMULLROM && sub == 420) {         /* :242-251,288-299 */
+        /* t = frac(Tex*(wh*0.5)) + off ; Tex*(wh/2) = ((sx+.5)/2, (sy+.5)/2) */
+        float tx = (sx & 1) ? 0.75f : 0.25f, ty = (sy & 1) ? 0.75f : 0.25f;
+        switch (chroma_loc) {                                            /* strChromaPos2 :121-137 */
+        case CHROMA_COSITED: tx += -0.25f; ty += -0.25f; break;
+        case CHROMA_MPEG1:   tx += -0.5f;  ty += -0.5f;  break;
+        default:             tx += -0.25f; ty += -0.5f;  break;
+        }
+        float wx[4], wy[4]; catmull_weights(tx, wx); catmull_weights(ty, wy);
+        int bx = sx >> 1, by = sy >> 1;
+        for (int c = 0; c < 2; c++) {
+            float Q[4];
+            for (int y = 0; y < 4; y++) {
+                float c0 = load_chroma(s, c, bx - 1, by + y - 1), c1 = load_chroma(s, c, bx, by + y - 1);
+                float c2 = load_chroma(s, c, bx + 1, by + y - 1), c3 = load_chroma(s, c, bx + 2, by + y - 1);
+                Q[y] = c0 * wx[0] + c1 * wx[1] + c2 * wx[2] + c3 * wx[3];   /* code_Bicubic_UV :74-79 */
+            }
+            uv[c] = Q[0] * wy[0] + Q[1] * wy[1] + Q[2] * wy[2] + Q[3] * wy[3];
+        }
+        return;
+    }
+    if (chroma_scaling == ORC_CHROMA_CATMULLROM && sub == 422) {         /* :252-264,300-318 */
+        if ((sx & 1) == 0) {                                             /* fmod(Tex.x*w,2) < 1 */
+            uv[0] = load_chroma(s, 0, sx >> 1, sy); uv[1] = load_chroma(s, 1, sx >> 1, sy);
+        } else {
+            int k = (sx - 1) >> 1;
+            for (int c = 0; c < 2; c++) {
+                float c0 = load_chroma(s, c, k - 1, sy), c1 = load_chroma(s, c, k, sy);
+                float c2 = load_chroma(s, c, k + 1, sy), c3 = load_chroma(s, c, k + 2, sy);
+                uv[c] = (9 * (c1 + c2) - (c0 + c3)) * 0.0625f;          /* CATMULLROM_05 :145 */
+            }
+        }
+        return;
+    }
+    /* CHROMA_Bilinear :265-270,319-325 : texUV.Sample(sampL, Tex + strChromaPos) */
+    float u = (sx + 0.5f) / (float)s->f->div_w, v = (sy + 0.5f) / (float)s->f->div_h;   /* Tex * chroma size */
+    if (sub == 420) {
+        switch (chroma_loc) {                                            /* strChromaPos :121-137 */
+        case CHROMA_COSITED: u += 0.25f; v += 0.25f; break;              /* +(dx/2, dy/2) in chroma texels */
+        case CHROMA_MPEG1:   break;
+        default:             u += 0.25f; break;                          /* +(dx/2, 0) */
+        }
+    } else {                                                             /* 422 :139-142 */
+        u += 0.25f;
+    }
+    uv[0] = sample_chroma_linear(s, 0, u, v);
+    uv[1] = sample_chroma_linear(s, 1, u, v);
+}
+
+typedef struct {
+    src_tex tex;
+    int rect[4];
+    uint32_t exfmt;
+    float cm[12];
+    float lum_scale;
+    int internal_fmt;
+} convert_ctx;
+
+static int setup_convert(const orc_params *p, const uint8_t *src, int src_pitch, convert_ctx *c)
+{
+    const fmt_info *f = find_fmt(p->cformat);
+    if (!f || src_pitch <= 0) return -1;
+    if ((f->div_w == 2 && (p->width & 1)) || (f->div_h == 2 && (p->height & 1))) return -2;
+    memset(c, 0, sizeof(*c));
+    resolve_rect(p, c->rect);
+    if (c->rect[0] < 0 || c->rect[1] < 0 || c->rect[2] > p->width || c->rect[3] > p->height ||
+        c->rect[2] <= c->rect[0] || c->rect[3] <= c->rect[1]) return -3;
+    c->tex.f = f; c->tex.w = p->width; c->tex.h = p->height;
+    c->tex.cw = p->width / f->div_w; c->tex.ch = p->height / f->div_h;
+    /* MemCopyToTexSrcVideo plane walk — DX11VideoProcessor.cpp:1213-1252 */
+    c->tex.plane[0] = src; c->tex.pitch[0] = src_pitch;
+    int cpitch = (f->planes == 3) ? src_pitch / f->div_w : src_pitch;
+    c->tex.plane[1] = src + (size_t)src_pitch * p->height; c->tex.pitch[1] = cpitch;
+    c->tex.plane[2] = c->tex.plane[1] + (size_t)cpitch * c->tex.ch; c->tex.pitch[2] = cpitch;
+    c->exfmt = orc_specify_extfmt(p->exfmt, p->cformat, c->rect[2] - c->rect[0], c->rect[3] - c->rect[1]);
+    if (orc_color_matrix(p, c->cm)) return -1;
+    c->lum_scale = orc_luminance_scale(p->iSDRDisplayNits);
+    c->internal_fmt = internal_format(p->iTexFormat, f->cdepth);
+    return 0;
+}
+
+static void convert_pass(const orc_params *p, const convert_ctx *c, img_t *out)
+{
+    const int rw = c->rect[2] - c->rect[0], rh = c->rect[3] - c->rect[1];
+    const int trc = EXF_TRC(c->exfmt), prim = EXF_PRIM(c->exfmt), cloc = EXF_CHROMA(c->exfmt);
+    const float *cm = c->cm;
+    ORC_PAR_FOR
+    for (int j = 0; j < rh; j++) {
+        for (int i = 0; i < rw; i++) {
+            int sx = c->rect[0] + i, sy = c->rect[1] + j;
+            float y = load_luma(&c->tex, sx, sy);                                  /* :231,274 */
+            float uv[2];
+            fetch_chroma(&c->tex, cloc, p->iChromaScaling, sx, sy, uv);
+            /* color.rgb = float3(mul(cm_r,color), mul(cm_g,color), mul(cm_b,color)) + cm_c  (:820) */
+            float rgb[3];
+            rgb[0] = (cm[0] * y + cm[1] * uv[0] + cm[2] * uv[1]) + cm[9];
+            rgb[1] = (cm[3] * y + cm[4] * uv[0] + cm[5] * uv[1]) + cm[10];
+            rgb[2] = (cm[6] * y + cm[7] * uv[0] + cm[8] * uv[1]) + cm[11];
+            orc_hdr_tail(rgb, trc, prim, p->bConvertToSdr, c->lum_scale);
+            float px[4] = {rgb[0], rgb[1], rgb[2], 1.0f};
+            store_fmt(c->internal_fmt, px, out->p + ((size_t)j * rw + i) * 4);
+        }
+    }
+}
+
+int orc_convert_only(const orc_params *p, const uint8_t *src, int src_pitch, float *rgba_out)
+{
+    convert_ctx c;
+    int rc = setup_convert(p, src, src_pitch, &c);
+    if (rc) return rc;
+    img_t out = {c.rect[2] - c.rect[0], c.rect[3] - c.rect[1], rgba_out};
+    convert_pass(p, &c, &out);
+    return c.internal_fmt;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* resize passes — DX11VideoProcessor.cpp:3103-3187, :332-377 + Shaders/d3d11/ps_interpolation_*, */
+/* ps_convolution.hlsl                                                                        */
+/* ------------------------------------------------------------------------------------------ */
+enum { RS_NONE = 0, RS_UP, RS_DOWN };
+typedef struct { int kind; int method; } resizer_t;
+
+/* one output index along the filtered axis: tap indices (already clamped) + weights */
+#define ORC_MAX_TAPS 128
+typedef struct { int n; int idx[ORC_MAX_TAPS]; float w[ORC_MAX_TAPS]; float wsum; int normalise; } taps_t;
+
+/* Tex[AXIS]*wh[AXIS] for output i: interpolated texcoord (src_l + (i+.5)*srcLen/dstLen)/texLen times texLen */
+static inline float axis_center(int src_l, int i, float scale) { return (float)src_l + ((float)i + 0.5f) * scale; }
+
+static int build_taps(resizer_t rs, int src_l, int i, float scale, int tex_len, uint32_t flags, taps_t *t)
+{
+    float center = axis_center(src_l, i, scale);
+    t->normalise = 0; t->wsum = 1;
+    if (rs.kind == RS_UP) {
+        float pos = center - 0.5f;                       /* ps_interpolation_*.hlsl: pos = Tex*wh - 0.5 */
+        float fr = pos - floorf(pos);                    /* frac(pos) */
+        pos = pos - fr;
+        int base = (int)pos;
+        float w[6];
+        int n = orc_upscale_weights(rs.method, fr, w);
+        if (n == 4) {                                    /* Q0..Q3 at pos-0.5 .. pos+2.5 => texels base-1..base+2 */
+            t->n = 4;
+            for (int k = 0; k < 4; k++) { t->idx[k] = clampi(base - 1 + k, 0, tex_len - 1); t->w[k] = w[k]; }
+        } else if (n == 6) {
+            /* D3D11 ps_interpolation_lanczos3.hlsl:33-34,42-43 samples Q1 at pos-1.5 (same texel as Q0);
+             * the D3D9 twin uses pos-0.5 (Shaders/d3d9/interpolation_lanczos3.hlsl:28-29). */
+            static const int off11[6] = {-2, -2, 0, 1, 2, 3}, off9[6] = {-2, -1, 0, 1, 2, 3};
+            const int *off = (flags & ORC_FLAG_LANCZOS3_FIXED) ? off9 : off11;
+            t->n = 6;
+            for (int k = 0; k < 6; k++) { t->idx[k] = clampi(base + off[k], 0, tex_len - 1); t->w[k] = w[k]; }
+        } else return -1;
+        return 0;
+    }
+    if (rs.kind == RS_DOWN) {                            /* ps_convolution.hlsl:23-50 */
+        float support0; (void)orc_downscale_filter(rs.method, 0.0f, &support0);
+        float support = support0 * scale;
+        float ss = 1.0f / scale;
+        float pos = center + 0.5f;
+        int low = (int)floorf(pos - support);
+        int high = (int)ceilf(pos + support);
+        if (high - low > ORC_MAX_TAPS) return -1;
+        float ww = 0.0f; int n = 0;
+        for (int k = low; k < high; k++) {
+            float w = orc_downscale_filter(rs.method, ((float)k - pos + 0.5f) * ss, NULL);
+            ww += w;
+            t->idx[n] = clampi(k, 0, tex_len - 1); t->w[n] = w; n++;
+        }
+        t->n = n; t->wsum = ww; t->normalise = 1;
+        return 0;
+    }
+    /* no shader on this axis: the pass point-samples Tex => nearest */
+    t->n = 1; t->idx[0] = clampi((int)floorf(center), 0, tex_len - 1); t->w[0] = 1.0f;
+    return 0;
+}
+
+/* One TextureResizeShader draw filtering `axis`; the other axis is point-sampled with (o_l, o_scale).
+ * in: source texture (whole); f_l/f_scale: src rect origin & srcLen/dstLen on the filtered axis. */
+static int resize_pass(const img_t *in, img_t *out, int axis, resizer_t rs,
+                       int f_l, float f_scale, int o_l, float o_scale, uint32_t flags, int store)
+{
+    const int flen = axis == 0 ? out->w : out->h;
+    const int tex_len = axis == 0 ? in->w : in->h;
+    taps_t *taps = (taps_t *)malloc(sizeof(taps_t) * (size_t)flen);
+    if (!taps) return -1;
+    for (int i = 0; i < flen; i++)
+        if (build_taps(rs, f_l, i, f_scale, tex_len, flags, &taps[i])) { free(taps); return -2; }
+    const int olen = axis == 0 ? out->h : out->w;
+    const int otex = axis == 0 ? in->h : in->w;
+    int *oidx = (int *)malloc(sizeof(int) * (size_t)olen);
+    if (!oidx) { free(taps); return -1; }
+    for (int i = 0; i < olen; i++) oidx[i] = clampi((int)floorf(axis_center(o_l, i, o_scale)), 0, otex - 1);
+
+    ORC_PAR_FOR
+    for (int y = 0; y < out->h; y++) {
+        for (int x = 0; x < out->w; x++) {
+            const taps_t *t = &taps[axis == 0 ? x : y];
+            float acc[4] = {0, 0, 0, 0};
+            for (int k = 0; k < t->n; k++) {
+                int sx = axis == 0 ? t->idx[k] : oidx[x];
+                int sy = axis == 0 ? oidx[y] : t->idx[k];
+                const float *q = in->p + ((size_t)sy * in->w + sx) * 4;
+                if (k == 0 && !t->normalise) { for (int c = 0; c < 4; c++) acc[c] = t->w[0] * q[c]; }
+                else for (int c = 0; c < 4; c++) acc[c] = acc[c] + t->w[k] * q[c];
+            }
+            if (t->normalise) for (int c = 0; c < 4; c++) acc[c] = acc[c] / t->wsum;
+            store_fmt(store, acc, out->p + ((size_t)y * out->w + x) * 4);
+        }
+    }
+    free(oidx); free(taps);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Process — DX11VideoProcessor.cpp:3285-3424 (shader path, rotation 0, no flip)               */
+/* ------------------------------------------------------------------------------------------ */
+static inline uint32_t pack_out(int out_fmt, const float v[4])
+{
+    if (out_fmt == ORC_OUT_RGB10A2) {
+        uint32_t r = (uint32_t)floorf(saturatef(v[0]) * 1023.0f + 0.5f);
+        uint32_t g = (uint32_t)floorf(saturatef(v[1]) * 1023.0f + 0.5f);
+        uint32_t b = (uint32_t)floorf(saturatef(v[2]) * 1023.0f + 0.5f);
+        uint32_t a = (uint32_t)floorf(saturatef(v[3]) * 3.0f + 0.5f);
+        return r | (g << 10) | (b << 20) | (a << 30);        /* DXGI_FORMAT_R10G10B10A2_UNORM */
+    }
+    uint32_t r = (uint32_t)floorf(saturatef(v[0]) * 255.0f + 0.5f);
+    uint32_t g = (uint32_t)floorf(saturatef(v[1]) * 255.0f + 0.5f);
+    uint32_t b = (uint32_t)floorf(saturatef(v[2]) * 255.0f + 0.5f);
+    uint32_t a = (uint32_t)floorf(saturatef(v[3]) * 255.0f + 0.5f);
+    return b | (g << 8) | (r << 16) | (a << 24);             /* DXGI_FORMAT_B8G8R8A8_UNORM */
+}
+
+void orc_params_default(orc_params *p)
+{   /* Settings_t::SetDefault — IVideoRenderer.h:140-185 */
+    memset(p, 0, sizeof(*p));
+    p->iTexFormat = ORC_TEXFMT_AUTOINT;
+    p->iChromaScaling = ORC_CHROMA_BILINEAR;
+    p->iUpscaling = ORC_UP_CATMULLROM;
+    p->iDownscaling = ORC_DOWN_HAMMING;
+    p->bInterpolateAt50pct = 1;
+    p->bUseDither = 1;
+    p->bConvertToSdr = 1;
+    p->iSDRDisplayNits = 125;
+    p->output_format = ORC_OUT_BGRA8;
+    p->contrast = 1.0f; p->saturation = 1.0f;
+}
+
+int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
+                const uint16_t *dither_f16, uint8_t *dst, int dst_pitch)
+{
+    convert_ctx c;
+    int rc = setup_convert(p, src, src_pitch, &c);
+    if (rc) return rc;
+    const int internal = c.internal_fmt;
+    const int w1 = c.rect[2] - c.rect[0], h1 = c.rect[3] - c.rect[1];
+    const int dl = p->video_rect[0], dt = p->video_rect[1];
+    const int w2 = p->video_rect[2] - dl, h2 = p->video_rect[3] - dt;
+    if (w2 <= 0 || h2 <= 0 || p->window_w <= 0 || p->window_h <= 0) return -4;
+
+    /* UpdatePostScaleTexures :2894-2912 */
+    const int swap_fmt = (p->output_format == ORC_OUT_RGB10A2) ? FMT_RGB10A2 : FMT_BGRA8;
+    const int need_dither = (swap_fmt == FMT_BGRA8 && internal != FMT_BGRA8) ||
+                            (swap_fmt == FMT_RGB10A2 && internal == FMT_RGBA16F);
+    const int final_pass = p->bUseDither && need_dither && dither_f16 != NULL;
+    const float quant = (swap_fmt == FMT_RGB10A2) ? 1023.0f : 255.0f;     /* ps_final_pass QUANTIZATION */
+
+    /* ConvertColorPass -> m_TexConvertOutput (w1 x h1, internal format); rSrc = whole texture :3316-3319 */
+    img_t conv = {0}, mid = {0}, post = {0};
+    if (img_alloc(&conv, w1, h1)) return -5;
+    convert_pass(p, &c, &conv);
+
+    /* ResizeShaderPass :3103-3187 — pick per-axis shader */
+    const int k = p->bInterpolateAt50pct ? 2 : 1;
+    if (p->iUpscaling == ORC_UP_JINC2) { img_free(&conv); return -6; }
+    resizer_t up = {p->iUpscaling == ORC_UP_NEAREST ? RS_NONE : RS_UP, p->iUpscaling};
+    resizer_t down = {RS_DOWN, p->iDownscaling};
+    resizer_t none = {RS_NONE, 0};
+    resizer_t rx = (w1 == w2) ? none : (w1 > k * w2) ? down : up;
+    resizer_t ry = (h1 == h2) ? none : (h1 > k * h2) ? down : up;
+    const float sx = (float)w1 / (float)w2, sy = (float)h1 / (float)h2;   /* constants[1] :353 */
+    /* destination format of the last resize draw: post-scale texture (internal) if a final pass
+       follows, else the render target itself (:3334-3352, :3417-3419) */
+    const int last_store = final_pass ? internal : swap_fmt;
+
+    const img_t *result = &conv;
+    int result_fmt = internal;
+    if (rx.kind != RS_NONE && ry.kind != RS_NONE) {
+        /* two passes through fp16 m_TexResize (w2 x h1) :3143-3167 */
+        if (img_alloc(&mid, w2, h1) || img_alloc(&post, w2, h2)) { rc = -5; goto done; }
+        if ((rc = resize_pass(&conv, &mid, 0, rx, 0, sx, 0, 1.0f, p->flags, FMT_RGBA16F))) goto done;
+        if ((rc = resize_pass(&mid, &post, 1, ry, 0, sy, 0, 1.0f, p->flags, last_store))) goto done;
+        result = &post; result_fmt = last_store;
+    } else if (rx.kind != RS_NONE || ry.kind != RS_NONE || w1 != w2 || h1 != h2) {
+        /* one pass; the unfiltered axis is point sampled (nearest when its size changes) :3169-3177 */
+        if (img_alloc(&post, w2, h2)) { rc = -5; goto done; }
+        if (rx.kind != RS_NONE || (ry.kind == RS_NONE && w1 != w2))
+            rc = resize_pass(&conv, &post, 0, rx, 0, sx, 0, sy, p->flags, last_store);
+        else
+            rc = resize_pass(&conv, &post, 1, ry, 0, sy, 0, sx, p->flags, last_store);
+        if (rc) goto done;
+        result = &post; result_fmt = last_store;
+    } else if (!final_pass) {
+        /* TextureCopyRect with ps_simple into the render target :3178-3181 */
+        if (img_alloc(&post, w2, h2)) { rc = -5; goto done; }
+        for (size_t i = 0; i < (size_t)w2 * h2; i++) store_fmt(swap_fmt, conv.p + i * 4, post.p + i * 4);
+        result = &post; result_fmt = swap_fmt;
+    }
+    (void)result_fmt;
+
+    /* FinalPass :3189-3233 + ps_final_pass.hlsl:23-31, or plain store into the render target */
+    ORC_PAR_FOR
+    for (int y = 0; y < h2; y++) {
+        int wy = dt + y;
+        if (wy < 0 || wy >= p->window_h) continue;
+        for (int x = 0; x < w2; x++) {
+            int wx = dl + x;
+            if (wx < 0 || wx >= p->window_w) continue;
+            const float *q = result->p + ((size_t)y * w2 + x) * 4;
+            float v[4] = {q[0], q[1], q[2], q[3]};
+            if (final_pass) {
+                /* sampler WRAP+POINT, ditherCoordScale = texSize/32 => texel (wx mod 32, wy mod 32) */
+                float d = orc_half_bits_to_float(dither_f16[(wy & 31) * 32 + (wx & 31)]);
+                for (int ch = 0; ch < 4; ch++) v[ch] = floorf(v[ch] * quant + d) / quant;
+            }
+            uint32_t px = pack_out(p->output_format, v);
+            memcpy(dst + (size_t)wy * dst_pitch + (size_t)wx * 4, &px, 4);
+        }
+    }
+    rc = 0;
+done:
+    img_free(&conv); img_free(&mid); img_free(&post);
+    return rc;
+}

@@ -1,0 +1,127 @@
+/*
+ * mpcvr_oracle.h — CPU restatement of MPC Video Renderer's *shader video processor*
+ * frame path (convert -> resize -> final/dither).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ may be linked, imported or executed by the
+ * product (videorenderer_amd/).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * `cpu_baseline` leg use it, and only as the checker / reported baseline.
+ *
+ * Parity status: the reference holds NO tests or golden vectors for this path and its arithmetic
+ * executes inside Direct3D 11 (HLSL compiled by d3dcompiler_47 / fxc), neither of which exists in
+ * this environment.  The parameter maths (csputils matrices) is pinned against the REAL reference
+ * code compiled from /root/reference/Source/csputils.cpp into oracle/_ref/ (see oracle/Makefile);
+ * the per-pixel HLSL arithmetic is "parity unpinned" (restated literally, D3D11 functional-spec
+ * semantics modelled explicitly: UNORM load/store, point/bilinear sampling, fp16 RNE).
+ *
+ * Every function cites the reference file:line it restates (paths relative to /root/reference).
+ */
+#ifndef MPCVR_ORACLE_H
+#define MPCVR_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ColorFormat_t numeric values — Source/Helper.h:86-127 (enum order is the table index). */
+enum {
+    ORC_CF_NV12 = 1, ORC_CF_P010 = 2, ORC_CF_P016 = 3,
+    ORC_CF_P210 = 6, ORC_CF_P216 = 7,
+    ORC_CF_YV12 = 14, ORC_CF_YV16 = 15, ORC_CF_YV24 = 16,
+    ORC_CF_YUV420P8 = 17, ORC_CF_YUV422P8 = 18, ORC_CF_YUV444P8 = 19,
+    ORC_CF_YUV420P10 = 20, ORC_CF_YUV420P16 = 21,
+    ORC_CF_YUV422P10 = 22, ORC_CF_YUV422P16 = 23,
+    ORC_CF_YUV444P10 = 24, ORC_CF_YUV444P16 = 25
+};
+
+/* Settings enums — Source/IVideoRenderer.h:25-72 (identical numeric values). */
+enum { ORC_TEXFMT_AUTOINT = 0, ORC_TEXFMT_8INT = 8, ORC_TEXFMT_10INT = 10, ORC_TEXFMT_16FLOAT = 16 };
+enum { ORC_CHROMA_NEAREST = 0, ORC_CHROMA_BILINEAR = 1, ORC_CHROMA_CATMULLROM = 2 };
+enum { ORC_UP_NEAREST = 0, ORC_UP_MITCHELL = 1, ORC_UP_CATMULLROM = 2, ORC_UP_LANCZOS2 = 3,
+       ORC_UP_LANCZOS3 = 4, ORC_UP_JINC2 = 5 };
+enum { ORC_DOWN_BOX = 0, ORC_DOWN_BILINEAR = 1, ORC_DOWN_HAMMING = 2, ORC_DOWN_BICUBIC = 3,
+       ORC_DOWN_BICUBIC_SHARP = 4, ORC_DOWN_LANCZOS = 5 };
+
+enum { ORC_OUT_BGRA8 = 0, ORC_OUT_RGB10A2 = 1 };   /* stands in for m_SwapChainFmt */
+
+/* flag: use the D3D9 twin's correct Lanczos3 tap layout instead of the D3D11 one (quirk Q1). */
+#define ORC_FLAG_LANCZOS3_FIXED 1u
+
+typedef struct orc_params {
+    int32_t  cformat;          /* ORC_CF_* */
+    int32_t  width, height;    /* frame size (biWidth, |biHeight|) */
+    int32_t  src_rect[4];      /* l,t,r,b ; all zero => whole frame (DX11VideoProcessor.cpp:1821-1823) */
+    uint32_t exfmt;            /* DXVA2_ExtendedFormat.value as delivered by the decoder; 0 fields defaulted */
+    /* Settings_t subset (IVideoRenderer.h:104-135) */
+    int32_t  iTexFormat, iChromaScaling, iUpscaling, iDownscaling;
+    int32_t  bInterpolateAt50pct, bUseDither, bConvertToSdr, iSDRDisplayNits;
+    int32_t  output_format;    /* ORC_OUT_* */
+    /* ProcAmp (DX11VideoProcessor.cpp:839-842): brightness -100..100, contrast 0..2, hue deg, sat 0..2 */
+    float    brightness, contrast, hue, saturation;
+    /* geometry */
+    int32_t  window_w, window_h;   /* m_windowRect = (0,0,w,h): size of the render target */
+    int32_t  video_rect[4];        /* m_videoRect l,t,r,b inside the window (dstRect of Process) */
+    uint32_t flags;
+} orc_params;
+
+void orc_params_default(orc_params *p);
+
+/* ---- parameter maths (pins) ---- */
+/* DXVA2_ExtendedFormat after SpecifyExtendedFormat — Helper.cpp:1169-1211 */
+uint32_t orc_specify_extfmt(uint32_t exfmt, int cformat, int rect_w, int rect_h);
+/* cm_r, cm_g, cm_b (3 each) + cm_c (3) = 12 floats — DX11VideoProcessor.cpp:813-887 + csputils.cpp:392-509 */
+int  orc_color_matrix(const orc_params *p, float out12[12]);
+/* generic mp_get_csp_matrix restatement; space/levels use mp_csp / mp_csp_levels numeric values */
+void orc_csp_matrix(int space, int levels_in, int bits, float brightness, float contrast,
+                    float hue, float saturation, int gray, float m[9], float c[3]);
+/* GetColorspaceGamutConversionMatrix(BT.2020 -> BT.709) — csputils.cpp:549-557 */
+void orc_gamut_2020_to_709(float m[9]);
+void orc_gamut_matrix(int prim_in, int prim_out, float m[9]);
+float orc_luminance_scale(int sdr_nits);   /* DX11VideoProcessor.cpp:889-905 */
+
+/* ---- shader device functions (pins) ---- */
+float orc_st2084_to_linear(float x, float factor);   /* Shaders/convert/st2084.hlsl:9-16 */
+float orc_linear_to_st2084(float x, float divider);  /* st2084.hlsl:18-25 */
+void  orc_hlg_to_linear(float rgb[3]);               /* Shaders/convert/hlg.hlsl:1-20 */
+float orc_hable(float x);                            /* Shaders/convert/hdr_tone_mapping.hlsl:1-6 */
+void  orc_tonemap_hable(float rgb[3]);               /* hdr_tone_mapping.hlsl:8-13 */
+/* HDR tail of the generated convert shader on one RGB triple — Shaders.cpp:861-923.
+ * transfer = DXVA2/MF VideoTransferFunction code, primaries likewise. */
+void  orc_hdr_tail(float rgb[3], int transfer, int primaries, int convert_to_sdr, float lum_scale);
+
+/* resize weights for fractional phase t: upscalers give 4 or 6 taps; returns tap count.
+ * ps_interpolation_spline4.hlsl:46-57, ps_interpolation_lanczos2.hlsl:46-51, ps_interpolation_lanczos3.hlsl:50-59 */
+int   orc_upscale_weights(int iUpscaling, float t, float w[6]);
+/* downscale kernel value — Shaders/resize/convolution_filters.hlsl:7-86 */
+float orc_downscale_filter(int iDownscaling, float x, float *support);
+
+float orc_half_round(float x);             /* fp32 -> fp16 (RNE) -> fp32 */
+float orc_half_bits_to_float(uint16_t h);
+
+/* ---- the path ---- */
+/* Bytes of one input frame in the reference's sample layout (DX11VideoProcessor.cpp:1789-1803). */
+size_t orc_frame_bytes(int cformat, int width, int height, int *pitch_out);
+
+/* Whole Process() on the shader path — DX11VideoProcessor.cpp:3285-3424.
+ * src: the media-sample bytes (planes back to back, MemCopyToTexSrcVideo layout :1213-1252), src_pitch >0.
+ * dither_f16: the 32x32 fp16 threshold table (Source/res/dither32x32float16.bin).
+ * dst: window_w x window_h pixels, 4 bytes each (B8G8R8A8 or R10G10B10A2), dst_pitch bytes.
+ *      Pixels outside the video rect are left untouched.
+ * returns 0 on success, <0 on unsupported input. */
+int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
+                const uint16_t *dither_f16, uint8_t *dst, int dst_pitch);
+
+/* Convert pass only: writes the m_TexConvertOutput contents as float RGBA (already quantised to the
+ * internal format), rect_w*rect_h*4 floats.  Returns internal format (8,10,16) or <0. */
+int orc_convert_only(const orc_params *p, const uint8_t *src, int src_pitch, float *rgba_out);
+
+/* number of OpenMP threads the oracle will use (1 if built without OpenMP) */
+int orc_num_threads(void);
+void orc_set_num_threads(int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

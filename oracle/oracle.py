@@ -1,0 +1,171 @@
+"""ctypes loader for the CPU oracle (oracle/mpcvr_oracle.c) and, when built, the real-reference
+csputils library (oracle/_ref/libref_csputils.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg — never by the product package (videorenderer_amd/).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "libmpcvr_oracle.so")
+REF_PATH = os.path.join(HERE, "_ref", "libref_csputils.so")
+REFERENCE_ROOT = "/root/reference"
+DITHER_PATH = os.path.join(os.path.dirname(HERE), "videorenderer_amd", "data", "dither32x32float16.bin")
+
+# ColorFormat_t values (Source/Helper.h:86-127)
+CF = dict(NV12=1, P010=2, P016=3, P210=6, P216=7, YV12=14, YV16=15, YV24=16,
+          YUV420P8=17, YUV422P8=18, YUV444P8=19, YUV420P10=20, YUV420P16=21,
+          YUV422P10=22, YUV422P16=23, YUV444P10=24, YUV444P16=25)
+
+
+class OrcParams(C.Structure):
+    _fields_ = [
+        ("cformat", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+        ("src_rect", C.c_int32 * 4), ("exfmt", C.c_uint32),
+        ("iTexFormat", C.c_int32), ("iChromaScaling", C.c_int32),
+        ("iUpscaling", C.c_int32), ("iDownscaling", C.c_int32),
+        ("bInterpolateAt50pct", C.c_int32), ("bUseDither", C.c_int32),
+        ("bConvertToSdr", C.c_int32), ("iSDRDisplayNits", C.c_int32),
+        ("output_format", C.c_int32),
+        ("brightness", C.c_float), ("contrast", C.c_float), ("hue", C.c_float), ("saturation", C.c_float),
+        ("window_w", C.c_int32), ("window_h", C.c_int32), ("video_rect", C.c_int32 * 4),
+        ("flags", C.c_uint32),
+    ]
+
+
+def make_extfmt(chroma=0, nominal_range=0, matrix=0, lighting=0, primaries=0, transfer=0, sample_format=0):
+    """Pack a DXVA2_ExtendedFormat.value (dxva2api.h bit layout, LSB first)."""
+    return ((sample_format & 0xff) | ((chroma & 0xf) << 8) | ((nominal_range & 0x7) << 12) |
+            ((matrix & 0x7) << 15) | ((lighting & 0xf) << 18) | ((primaries & 0x1f) << 22) |
+            ((transfer & 0x1f) << 27))
+
+
+def build(ref=True, quiet=True):
+    """Compile the oracle (always) and oracle/_ref (only when /root/reference is mounted)."""
+    out = subprocess.DEVNULL if quiet else None
+    subprocess.check_call(["make", "-C", HERE], stdout=out)
+    if ref and os.path.isdir(os.path.join(REFERENCE_ROOT, "Source")):
+        subprocess.check_call(["make", "-C", HERE, "ref"], stdout=out)
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build(ref=False)
+        L = C.CDLL(LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        L.orc_params_default.argtypes = [C.POINTER(OrcParams)]
+        L.orc_specify_extfmt.restype = C.c_uint32
+        L.orc_specify_extfmt.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int]
+        L.orc_color_matrix.argtypes = [C.POINTER(OrcParams), fp]
+        L.orc_csp_matrix.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                     C.c_int, fp, fp]
+        L.orc_gamut_matrix.argtypes = [C.c_int, C.c_int, fp]
+        L.orc_gamut_2020_to_709.argtypes = [fp]
+        L.orc_luminance_scale.restype = C.c_float
+        L.orc_luminance_scale.argtypes = [C.c_int]
+        for name in ("orc_st2084_to_linear", "orc_linear_to_st2084"):
+            getattr(L, name).restype = C.c_float
+            getattr(L, name).argtypes = [C.c_float, C.c_float]
+        L.orc_hable.restype = C.c_float
+        L.orc_hable.argtypes = [C.c_float]
+        L.orc_hlg_to_linear.argtypes = [fp]
+        L.orc_tonemap_hable.argtypes = [fp]
+        L.orc_hdr_tail.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_float]
+        L.orc_upscale_weights.restype = C.c_int
+        L.orc_upscale_weights.argtypes = [C.c_int, C.c_float, fp]
+        L.orc_downscale_filter.restype = C.c_float
+        L.orc_downscale_filter.argtypes = [C.c_int, C.c_float, fp]
+        L.orc_half_round.restype = C.c_float
+        L.orc_half_round.argtypes = [C.c_float]
+        L.orc_frame_bytes.restype = C.c_size_t
+        L.orc_frame_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.orc_process.restype = C.c_int
+        L.orc_process.argtypes = [C.POINTER(OrcParams), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_convert_only.restype = C.c_int
+        L.orc_convert_only.argtypes = [C.POINTER(OrcParams), C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        _lib = L
+    return _lib
+
+
+def ref():
+    """The real csputils.cpp (compiled from /root/reference) or None when not built."""
+    global _ref
+    if _ref is None and os.path.exists(REF_PATH):
+        R = C.CDLL(REF_PATH)
+        fp = C.POINTER(C.c_float)
+        R.ref_csp_matrix.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                     C.c_int, fp, fp]
+        R.ref_gamut_matrix.argtypes = [C.c_int, C.c_int, fp]
+        _ref = R
+    return _ref
+
+
+def default_params(**kw):
+    p = OrcParams()
+    lib().orc_params_default(C.byref(p))
+    set_params(p, **kw)
+    return p
+
+
+def set_params(p, **kw):
+    for k, v in kw.items():
+        if k in ("src_rect", "video_rect"):
+            getattr(p, k)[:] = list(v)
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def dither_table():
+    return np.fromfile(DITHER_PATH, dtype=np.uint16)
+
+
+def frame_bytes(cformat, w, h):
+    pitch = C.c_int(0)
+    n = lib().orc_frame_bytes(cformat, w, h, C.byref(pitch))
+    return int(n), pitch.value
+
+
+def color_matrix(p):
+    out = (C.c_float * 12)()
+    rc = lib().orc_color_matrix(C.byref(p), out)
+    assert rc == 0
+    return np.array(out, dtype=np.float32)
+
+
+def process(p, frame, pitch, dither=None, dst=None):
+    """Run the whole path; returns (window_h, window_w, 4) uint8 (or (h,w) uint32 for RGB10A2)."""
+    frame = np.ascontiguousarray(frame).view(np.uint8).ravel()
+    if dither is None:
+        dither = dither_table()
+    if dst is None:
+        dst = np.zeros((p.window_h, p.window_w, 4), dtype=np.uint8)
+    rc = lib().orc_process(C.byref(p), frame.ctypes.data, pitch, dither.ctypes.data,
+                           dst.ctypes.data, p.window_w * 4)
+    if rc != 0:
+        raise RuntimeError(f"orc_process failed: {rc}")
+    return dst
+
+
+def convert_only(p, frame, pitch):
+    frame = np.ascontiguousarray(frame).view(np.uint8).ravel()
+    r = list(p.src_rect)
+    if not any(r):
+        r = [0, 0, p.width, p.height]
+    out = np.zeros((r[3] - r[1], r[2] - r[0], 4), dtype=np.float32)
+    fmt = lib().orc_convert_only(C.byref(p), frame.ctypes.data, pitch, out.ctypes.data)
+    if fmt < 0:
+        raise RuntimeError(f"orc_convert_only failed: {fmt}")
+    return out, fmt
