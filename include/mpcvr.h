@@ -1,0 +1,214 @@
+/*
+ * mpcvr.h — C-ABI of the MI355X-native shader video processor (libmpcvr.so).
+ *
+ * Drop-in boundary for ONE path of MPC Video Renderer: CDX11VideoProcessor::Process on the shader
+ * video processor (convert -> resize -> final pass/dither).  The reference has no FFI; its narrowest
+ * waist is the C++ virtual class CVideoProcessor (Source/VideoProcessor.h:40-296) as implemented by
+ * CDX11VideoProcessor (Source/DX11VideoProcessor.h:256-384).  Each export below names the method it
+ * replaces (file:line relative to the reference tree).  Plain pointers and sizes only.
+ *
+ * Conventions (mirroring the reference):
+ *   - return type int32_t == HRESULT sign convention: 0 = S_OK, 1 = S_FALSE ("ok, nothing done"),
+ *     negative = failure (MPCVR_E_*).
+ *   - the processor owns all device resources; input sample memory is borrowed for the duration of
+ *     mpcvr_copy_sample; output goes to caller-owned memory.
+ *   - NOT re-entrant: one caller at a time per context (the reference serialises every entry under
+ *     m_RendererLock, VideoRenderer.cpp:443-444,579-586).  Work is asynchronous on the context's HIP
+ *     stream unless stated otherwise.
+ */
+#ifndef MPCVR_H
+#define MPCVR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPCVR_S_OK            0
+#define MPCVR_S_FALSE         1
+#define MPCVR_E_FAIL          ((int32_t)0x80004005)
+#define MPCVR_E_POINTER       ((int32_t)0x80004003)
+#define MPCVR_E_INVALIDARG    ((int32_t)0x80070057)
+#define MPCVR_E_UNEXPECTED    ((int32_t)0x8000FFFF)
+#define MPCVR_E_NOTIMPL       ((int32_t)0x80004001)
+#define MPCVR_E_OUTOFMEMORY   ((int32_t)0x8007000E)
+#define MPCVR_E_NOT_VALID_STATE ((int32_t)0x8007139F)
+
+/* ColorFormat_t — Source/Helper.h:86-127 (same numeric values; the formats this build accepts). */
+enum mpcvr_cformat {
+    MPCVR_CF_NONE = 0,
+    MPCVR_CF_NV12 = 1, MPCVR_CF_P010 = 2, MPCVR_CF_P016 = 3,
+    MPCVR_CF_P210 = 6, MPCVR_CF_P216 = 7,
+    MPCVR_CF_YV12 = 14, MPCVR_CF_YV16 = 15, MPCVR_CF_YV24 = 16,
+    MPCVR_CF_YUV420P8 = 17, MPCVR_CF_YUV422P8 = 18, MPCVR_CF_YUV444P8 = 19,
+    MPCVR_CF_YUV420P10 = 20, MPCVR_CF_YUV420P16 = 21,
+    MPCVR_CF_YUV422P10 = 22, MPCVR_CF_YUV422P16 = 23,
+    MPCVR_CF_YUV444P10 = 24, MPCVR_CF_YUV444P16 = 25
+};
+
+/* Settings enums — Source/IVideoRenderer.h:25-72 (identical values). */
+enum { MPCVR_TEXFMT_AUTOINT = 0, MPCVR_TEXFMT_8INT = 8, MPCVR_TEXFMT_10INT = 10, MPCVR_TEXFMT_16FLOAT = 16 };
+enum { MPCVR_CHROMA_Nearest = 0, MPCVR_CHROMA_Bilinear = 1, MPCVR_CHROMA_CatmullRom = 2 };
+enum { MPCVR_UPSCALE_Nearest = 0, MPCVR_UPSCALE_Mitchell = 1, MPCVR_UPSCALE_CatmullRom = 2,
+       MPCVR_UPSCALE_Lanczos2 = 3, MPCVR_UPSCALE_Lanczos3 = 4, MPCVR_UPSCALE_Jinc2 = 5 };
+enum { MPCVR_DOWNSCALE_Box = 0, MPCVR_DOWNSCALE_Bilinear = 1, MPCVR_DOWNSCALE_Hamming = 2,
+       MPCVR_DOWNSCALE_Bicubic = 3, MPCVR_DOWNSCALE_BicubicSharp = 4, MPCVR_DOWNSCALE_Lanczos = 5 };
+
+/* Render-target format: stands in for the display-driven m_SwapChainFmt decision
+ * (DX11VideoProcessor.cpp:1476-1478, Preferred10BitOutput DX11VideoProcessor.h:290-292). */
+enum { MPCVR_OUT_BGRA8 = 0, MPCVR_OUT_RGB10A2 = 1 };
+
+/* mpcvr_settings.flags */
+#define MPCVR_FLAG_LANCZOS3_FIXED   0x1u  /* use the D3D9 twin's tap layout instead of the D3D11 shader's (quirk Q1) */
+#define MPCVR_FLAG_NO_FUSED         0x2u  /* force the pass-per-kernel path (debug / A-B) */
+#define MPCVR_FLAG_NO_LUT           0x4u  /* fused path: evaluate the PQ->SDR chain in ALU instead of the LDS table */
+#define MPCVR_FLAG_NO_FAST_CONVERT  0x8u  /* fused path: per-pixel generic convert (debug / A-B) */
+
+/* Subset of Settings_t (IVideoRenderer.h:104-135) that reaches the shader path; same field names. */
+typedef struct mpcvr_settings {
+    int32_t  iTexFormat;          /* MPCVR_TEXFMT_*            default AUTOINT   */
+    int32_t  iChromaScaling;      /* MPCVR_CHROMA_*            default Bilinear  */
+    int32_t  iUpscaling;          /* MPCVR_UPSCALE_*           default CatmullRom*/
+    int32_t  iDownscaling;        /* MPCVR_DOWNSCALE_*         default Hamming   */
+    int32_t  bInterpolateAt50pct; /*                           default 1         */
+    int32_t  bUseDither;          /*                           default 1         */
+    int32_t  bDeintBlend;         /* accepted, must be 0 (progressive frames only) */
+    int32_t  bConvertToSdr;       /*                           default 1         */
+    int32_t  iSDRDisplayNits;     /* 25..400                   default 125       */
+    int32_t  output_format;       /* MPCVR_OUT_*               default BGRA8     */
+    uint32_t flags;
+} mpcvr_settings;
+
+typedef struct mpcvr_rect { int32_t left, top, right, bottom; } mpcvr_rect;
+
+/* mem_kind for mpcvr_copy_sample */
+enum { MPCVR_MEM_HOST = 0, MPCVR_MEM_DEVICE = 1 };
+
+/* ProcAmp flags — DXVA2_ProcAmp_* bit values */
+#define MPCVR_PROCAMP_BRIGHTNESS 0x1
+#define MPCVR_PROCAMP_CONTRAST   0x2
+#define MPCVR_PROCAMP_HUE        0x4
+#define MPCVR_PROCAMP_SATURATION 0x8
+
+typedef struct mpcvr_ctx mpcvr_ctx;
+
+/* Settings_t::SetDefault — IVideoRenderer.h:140-185 */
+int32_t mpcvr_settings_default(mpcvr_settings *s);
+
+/* ctor + Init — DX11VideoProcessor.cpp:381,547.  `device` = HIP device ordinal. */
+int32_t mpcvr_create(const mpcvr_settings *settings, int32_t device, mpcvr_ctx **out);
+int32_t mpcvr_destroy(mpcvr_ctx *ctx);
+
+/* Use an externally owned hipStream_t (e.g. torch's current stream) for all work; NULL = own stream. */
+int32_t mpcvr_set_stream(mpcvr_ctx *ctx, void *hip_stream);
+int32_t mpcvr_synchronize(mpcvr_ctx *ctx);
+
+/* VerifyMediaType + InitMediaType — DX11VideoProcessor.cpp:1569,1742.
+ * cformat: ColorFormat_t value; width/height: biWidth/|biHeight|; pitch: bytes per luma row of the
+ * samples that will be handed to mpcvr_copy_sample (0 => the reference's rule, :1789-1803);
+ * src_rect: rcSource (NULL or empty => whole frame, :1821-1823);
+ * extfmt: DXVA2_ExtendedFormat.value from the media type (0 fields are defaulted per
+ * SpecifyExtendedFormat, Helper.cpp:1169-1211).  Returns S_OK, or E_INVALIDARG/E_NOTIMPL. */
+int32_t mpcvr_set_input(mpcvr_ctx *ctx, int32_t cformat, int32_t width, int32_t height, int32_t pitch,
+                        const mpcvr_rect *src_rect, uint32_t extfmt);
+
+/* SetVideoRect / SetWindowRect — DX11VideoProcessor.cpp:3426-3451.  Window rect = render-target size. */
+int32_t mpcvr_set_video_rect(mpcvr_ctx *ctx, const mpcvr_rect *video_rect);
+int32_t mpcvr_set_window_rect(mpcvr_ctx *ctx, const mpcvr_rect *window_rect);
+/* SetRotation (DX11VideoProcessor.cpp:4052) / SetFlip (VideoProcessor.h:210): only 0 / false are
+ * implemented in this build; other values return E_NOTIMPL. */
+int32_t mpcvr_set_rotation(mpcvr_ctx *ctx, int32_t degrees);
+int32_t mpcvr_set_flip(mpcvr_ctx *ctx, int32_t flip);
+
+/* Configure — DX11VideoProcessor.cpp:3800-4050: diff each field, rebuild only what changed. */
+int32_t mpcvr_configure(mpcvr_ctx *ctx, const mpcvr_settings *settings);
+
+/* SetProcAmpValues — DX11VideoProcessor.cpp:4506-4537; ranges Helper.cpp:182-187
+ * (brightness -100..100, contrast 0..2, hue -180..180, saturation 0..2). */
+int32_t mpcvr_set_procamp(mpcvr_ctx *ctx, uint32_t flags, float brightness, float contrast,
+                          float hue, float saturation);
+
+/* CopySample / MemCopyToTexSrcVideo — DX11VideoProcessor.cpp:2202,1213-1252.
+ * data: one media sample (planes back to back); pitch: luma row pitch in bytes (>0).
+ * MPCVR_MEM_HOST: staged through pinned memory and uploaded (applies CopyPlane10to16's <<6 on the
+ * device side).  MPCVR_MEM_DEVICE: zero-copy — the pointer is used in place and must stay valid until
+ * the following process/render call has completed (mirrors the IMediaSampleD3D11 branch :2528-2569). */
+int32_t mpcvr_copy_sample(mpcvr_ctx *ctx, const void *data, int32_t pitch, int32_t mem_kind);
+
+/* Process — DX11VideoProcessor.cpp:3285-3424.  dst: DEVICE pointer to a window_w x window_h render
+ * target, 4 bytes per pixel (B8G8R8A8 or R10G10B10A2), dst_pitch bytes per row.  src_rect must be
+ * NULL or the input's source rect (the reference overrides it with the convert texture, :3316-3319);
+ * dst_rect NULL => the context's video rect.  Pixels outside dst_rect are not written. */
+int32_t mpcvr_process(mpcvr_ctx *ctx, void *dst_dev, int32_t dst_pitch, const mpcvr_rect *src_rect,
+                      const mpcvr_rect *dst_rect, int32_t second_field);
+
+/* Render minus Present — DX11VideoProcessor.cpp:2599-2813: Process into the context-owned back buffer. */
+int32_t mpcvr_render(mpcvr_ctx *ctx, int32_t field);
+/* Device pointer / pitch of the context-owned back buffer written by mpcvr_render. */
+int32_t mpcvr_get_backbuffer(mpcvr_ctx *ctx, void **dev_ptr, int32_t *pitch, int32_t *width, int32_t *height);
+
+/* GetCurentImage — DX11VideoProcessor.cpp:3493-3608: source-rect-sized BGRX snapshot into host memory.
+ * Two-call size protocol (VideoRenderer.cpp:979-988): host_bgra == NULL => *size receives the bytes
+ * needed (rect_w*rect_h*4); otherwise *size must be >= that.  Synchronous. */
+int32_t mpcvr_get_current_image(mpcvr_ctx *ctx, void *host_bgra, size_t *size);
+
+/* Flush (DX11VideoProcessor.cpp:4074) / Reset (:3453). */
+int32_t mpcvr_flush(mpcvr_ctx *ctx);
+int32_t mpcvr_reset(mpcvr_ctx *ctx);
+
+/* Extension (not in the reference): n frames in one launch sequence to escape the launch-bound
+ * regime.  srcs[i]: DEVICE sample pointers (layout/pitch as declared by mpcvr_set_input);
+ * dsts[i]: DEVICE render targets (dst_pitch each). */
+int32_t mpcvr_process_batch(mpcvr_ctx *ctx, int32_t n, const void *const *srcs, void *const *dsts,
+                            int32_t dst_pitch);
+
+/* Multi-GPU: the parameter blob (colour matrix, luminance scale, gamut matrix, resize phase weights,
+ * dither table) a rank-0 context computes and every other rank adopts after an RCCL broadcast.
+ * Two-call size protocol. */
+int32_t mpcvr_get_param_blob(mpcvr_ctx *ctx, void *buf, size_t *size);
+int32_t mpcvr_set_param_blob(mpcvr_ctx *ctx, const void *buf, size_t size);
+
+/* Introspection used by tests / stats (GetVPInfo analogue, DX11VideoProcessor.cpp:4100+). */
+int32_t mpcvr_get_color_matrix(mpcvr_ctx *ctx, float out12[12]);     /* cm_r, cm_g, cm_b, cm_c */
+int32_t mpcvr_get_extfmt(mpcvr_ctx *ctx, uint32_t *extfmt);           /* after SpecifyExtendedFormat */
+int32_t mpcvr_get_frame_bytes(mpcvr_ctx *ctx, size_t *bytes, int32_t *pitch);
+int32_t mpcvr_get_path_info(mpcvr_ctx *ctx, char *buf, size_t buf_size); /* e.g. "fused_up2x" / "passes:convert,resizeX,resizeY+final" */
+const char *mpcvr_last_error(mpcvr_ctx *ctx);
+const char *mpcvr_version(void);
+
+/* Timing of the last process/render on the context stream (hipEvent pair), milliseconds.
+ * Mirrors m_RenderStats.paintticks (DX11VideoProcessor.cpp:2790).  Synchronises the stream. */
+int32_t mpcvr_get_last_process_ms(mpcvr_ctx *ctx, float *ms);
+
+/* ---- host-side parameter maths, usable without a context or a GPU --------------------------------
+ * The CPU work the reference does before touching the device.  Each mirrors a reference host function. */
+/* pitch / byte size of one media sample — DX11VideoProcessor.cpp:1789-1803 (m_srcPitch, m_srcLines) */
+int32_t mpcvr_plan_frame_layout(int32_t cformat, int32_t width, int32_t height, int32_t *pitch, size_t *bytes);
+/* SpecifyExtendedFormat (Helper.cpp:1169-1211) + SetShaderConvertColorParams (DX11VideoProcessor.cpp:813-887)
+ * -> mp_get_csp_matrix (csputils.cpp:392-509).  ProcAmp in DXVA2 units. */
+int32_t mpcvr_plan_color_matrix(int32_t cformat, int32_t rect_w, int32_t rect_h, uint32_t extfmt,
+                                float brightness, float contrast, float hue, float saturation,
+                                float out12[12], uint32_t *extfmt_out);
+/* GetColorspaceGamutConversionMatrix(BT.2020 -> BT.709) — csputils.cpp:549-557 */
+int32_t mpcvr_plan_gamut_2020_to_709(float out9[9]);
+/* the fused path's tone-map LUT: i/1023 -> Hable(ST2084ToLinear(x, lum_scale)) / hable(4.8) */
+int32_t mpcvr_plan_pq_lut(float lum_scale, float out1024[1024]);
+/* ps_interpolation_{spline4,lanczos2,lanczos3}.hlsl weights for phase t; returns the tap count (4/6) or 0 */
+int32_t mpcvr_plan_upscale_weights(int32_t iUpscaling, float t, float w6[6]);
+/* tap table of one TextureResizeShader draw (DX11VideoProcessor.cpp:332-377): kind 0 = point sample,
+ * 1 = upscale shader `method` (MPCVR_UPSCALE_*), 2 = ps_convolution with MPCVR_DOWNSCALE_* `method`.
+ * idx/w: [n_out*cap_taps >= n_out*ntaps], dense with stride *ntaps; S_FALSE when cap_taps is too small. */
+int32_t mpcvr_plan_axis_taps(int32_t kind, int32_t method, int32_t src_l, int32_t src_len, int32_t n_out,
+                             int32_t tex_len, uint32_t flags, int32_t cap_taps, int32_t *idx, float *w,
+                             float *wsum, int32_t *ntaps, int32_t *normalise);
+/* which draws Process() would issue (UpdateTexParams :1143, UpdatePostScaleTexures :2894, ResizeShaderPass :3103) */
+int32_t mpcvr_plan_describe(const mpcvr_settings *s, int32_t cformat, int32_t rect_w, int32_t rect_h,
+                            const mpcvr_rect *video_rect, int32_t window_w, int32_t window_h,
+                            char *buf, size_t buf_size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCVR_H */

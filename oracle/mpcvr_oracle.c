@@ -818,6 +818,18 @@ static int build_taps(resizer_t rs, int src_l, int i, float scale, int tex_len, 
     return 0;
 }
 
+int orc_axis_taps(int kind, int method, int src_l, int src_len, int n_out, int tex_len, uint32_t flags,
+                  int i, int32_t *idx, float *w, float *wsum)
+{
+    taps_t t;
+    resizer_t rs = {kind, method};
+    float scale = (float)src_len / (float)n_out;
+    if (build_taps(rs, src_l, i, scale, tex_len, flags, &t)) return -1;
+    for (int k = 0; k < t.n; k++) { idx[k] = t.idx[k]; w[k] = t.w[k]; }
+    if (wsum) *wsum = t.wsum;
+    return t.n;
+}
+
 /* One TextureResizeShader draw filtering `axis`; the other axis is point-sampled with (o_l, o_scale).
  * in: source texture (whole); f_l/f_scale: src rect origin & srcLen/dstLen on the filtered axis. */
 static int resize_pass(const img_t *in, img_t *out, int axis, resizer_t rs,

@@ -97,6 +97,12 @@ int   orc_upscale_weights(int iUpscaling, float t, float w[6]);
 /* downscale kernel value — Shaders/resize/convolution_filters.hlsl:7-86 */
 float orc_downscale_filter(int iDownscaling, float x, float *support);
 
+/* taps of output index i of one TextureResizeShader draw along one axis (DX11VideoProcessor.cpp:332-377):
+ * kind 0 = point sample, 1 = upscale shader, 2 = ps_convolution; scale = src_len/n_out as in the cbuffer.
+ * idx/w need room for 128 entries.  Returns the tap count, <0 when unsupported; *wsum = sum (kind 2). */
+int   orc_axis_taps(int kind, int method, int src_l, int src_len, int n_out, int tex_len, uint32_t flags,
+                    int i, int32_t *idx, float *w, float *wsum);
+
 float orc_half_round(float x);             /* fp32 -> fp16 (RNE) -> fp32 */
 float orc_half_bits_to_float(uint16_t h);
 

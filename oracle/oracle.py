@@ -85,6 +85,9 @@ def lib():
         L.orc_upscale_weights.argtypes = [C.c_int, C.c_float, fp]
         L.orc_downscale_filter.restype = C.c_float
         L.orc_downscale_filter.argtypes = [C.c_int, C.c_float, fp]
+        L.orc_axis_taps.restype = C.c_int
+        L.orc_axis_taps.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int,
+                                    C.POINTER(C.c_int32), fp, fp]
         L.orc_half_round.restype = C.c_float
         L.orc_half_round.argtypes = [C.c_float]
         L.orc_frame_bytes.restype = C.c_size_t

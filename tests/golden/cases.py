@@ -1,0 +1,127 @@
+"""Named parity cases shared by the CPU golden-hash test and the GPU parity tests.
+
+Each case = BASELINE.json config (at a size the oracle finishes in well under a second) or an edge
+case of the path (ragged sizes, crops, clipping, every scaler / chroma mode / format family).
+"""
+import numpy as np
+
+from videorenderer_amd import synth
+
+# DXVA2_ExtendedFormat field values (Helper.cpp:1215-1223)
+MPEG1, MPEG2, COSITED = 1, 5, 7
+FULL, TV = 1, 2
+M709, M601, M240, M2020, MYCGCO = 1, 2, 3, 4, 7
+P709, P2020 = 2, 9
+T22, T709, TSRGB, T26, TPQ, THLG = 4, 5, 7, 14, 15, 16
+
+
+def ext(chroma=0, rng=0, matrix=0, prim=0, trc=0):
+    return ((chroma & 0xf) << 8) | ((rng & 7) << 12) | ((matrix & 7) << 15) | ((prim & 0x1f) << 22) | ((trc & 0x1f) << 27)
+
+
+HDR10 = ext(MPEG2, TV, M2020, P2020, TPQ)
+HLG = ext(MPEG2, TV, M2020, P2020, THLG)
+
+# name -> dict(cformat, w, h, kind, seed, dst=(w2,h2), + optional: exfmt, settings overrides, src_rect,
+#              window=(w,h), offset=(x,y), procamp=(b,c,h,s), pitch)
+GOLDEN_CASES = {
+    # ---- BASELINE.json configs, reduced size ----
+    "c1_nv12_bt709_passthrough": dict(cformat=1, w=128, h=72, kind="structure", seed=1, dst=(128, 72), exfmt=ext(matrix=M709)),
+    "c2_yuv420p10_catmull_2x": dict(cformat=20, w=96, h=54, kind="structure", seed=2, dst=(192, 108), exfmt=ext(matrix=M709), iUpscaling=2),
+    "c3_p010_lanczos3_2x": dict(cformat=2, w=128, h=72, kind="structure", seed=3, dst=(256, 144), exfmt=ext(matrix=M709), iUpscaling=4),
+    "c3hdr_p010_pq_lanczos3_2x": dict(cformat=2, w=128, h=72, kind="hdr", seed=4, dst=(256, 144), exfmt=HDR10, iUpscaling=4),
+    "c4_p010_pq_mitchell_2x": dict(cformat=2, w=128, h=72, kind="hdr", seed=5, dst=(256, 144), exfmt=HDR10, iUpscaling=1),
+    "c5_p010_hlg_lanczos3_2x": dict(cformat=2, w=128, h=72, kind="hdr", seed=6, dst=(256, 144), exfmt=HLG, iUpscaling=4),
+    # ---- noise through the headline pipeline (worst case for rounding) ----
+    "noise_p010_pq_lanczos3_2x": dict(cformat=2, w=248, h=40, kind="noise", seed=7, dst=(496, 80), exfmt=HDR10, iUpscaling=4),
+    "noise_p010_sdr_lanczos2_2x": dict(cformat=2, w=136, h=24, kind="noise", seed=8, dst=(272, 48), exfmt=ext(matrix=M709), iUpscaling=3),
+    "noise_nv12_catmull_2x": dict(cformat=1, w=64, h=40, kind="noise", seed=9, dst=(128, 80), exfmt=ext(matrix=M709), iUpscaling=2),
+    # ---- scalers ----
+    "up_1p5x_lanczos3": dict(cformat=2, w=64, h=48, kind="structure", seed=10, dst=(96, 72), iUpscaling=4),
+    "up_3x_mitchell_fixedflag": dict(cformat=2, w=40, h=24, kind="noise", seed=11, dst=(120, 72), iUpscaling=4, flags=1),
+    "mild_down_uses_upscaler": dict(cformat=1, w=96, h=64, kind="structure", seed=12, dst=(60, 40), iUpscaling=2),
+    "down_hamming_3x": dict(cformat=2, w=192, h=96, kind="structure", seed=13, dst=(64, 32), iDownscaling=2),
+    "down_lanczos_2p5x": dict(cformat=2, w=160, h=100, kind="noise", seed=14, dst=(64, 40), iDownscaling=5),
+    "down_box_bilinear_mix": dict(cformat=1, w=128, h=96, kind="noise", seed=15, dst=(32, 40), iDownscaling=0, bInterpolateAt50pct=0),
+    "down_bicubic_sharp": dict(cformat=1, w=128, h=96, kind="structure", seed=16, dst=(48, 36), iDownscaling=4),
+    "down_bilinear_x_up_y": dict(cformat=2, w=128, h=32, kind="structure", seed=17, dst=(40, 64), iDownscaling=1, iUpscaling=1),
+    "nearest_2x": dict(cformat=1, w=32, h=24, kind="noise", seed=18, dst=(64, 48), iUpscaling=0),
+    "x_only_resize": dict(cformat=2, w=48, h=32, kind="structure", seed=19, dst=(96, 32), iUpscaling=2),
+    "y_only_resize": dict(cformat=2, w=48, h=32, kind="structure", seed=20, dst=(48, 80), iUpscaling=3),
+    # ---- geometry ----
+    "crop_offset_letterbox": dict(cformat=2, w=96, h=64, kind="structure", seed=21, src_rect=(16, 8, 80, 56), dst=(128, 96),
+                                  window=(200, 150), offset=(36, 27), iUpscaling=4),
+    "clipped_by_window": dict(cformat=1, w=64, h=48, kind="structure", seed=22, dst=(128, 96), window=(90, 70), offset=(-20, -13), iUpscaling=2),
+    "same_size_with_offset_dither": dict(cformat=2, w=64, h=32, kind="noise", seed=23, dst=(64, 32), window=(100, 60), offset=(5, 9)),
+    "tiny_8x8": dict(cformat=2, w=8, h=8, kind="noise", seed=24, dst=(16, 16), iUpscaling=4),
+    "ragged_2x": dict(cformat=2, w=250, h=22, kind="noise", seed=25, dst=(500, 44), iUpscaling=4, exfmt=HDR10),
+    # ---- formats / chroma ----
+    "p016_fullrange": dict(cformat=3, w=64, h=32, kind="noise", seed=26, dst=(128, 64), exfmt=ext(MPEG2, FULL, M709), iUpscaling=2, full_range=True),
+    "yv12_bt601_sd": dict(cformat=14, w=64, h=48, kind="structure", seed=27, dst=(64, 48)),
+    "yuv420p8_cosited": dict(cformat=17, w=64, h=32, kind="noise", seed=28, dst=(128, 64), exfmt=ext(COSITED, TV, M709), iUpscaling=2),
+    "yuv420p16_mpeg1": dict(cformat=21, w=64, h=32, kind="noise", seed=29, dst=(128, 64), exfmt=ext(MPEG1, TV, M709), iUpscaling=4),
+    "p010_cosited_pq": dict(cformat=2, w=64, h=32, kind="noise", seed=30, dst=(128, 64), exfmt=ext(COSITED, TV, M2020, P2020, TPQ), iUpscaling=4),
+    "p210_422": dict(cformat=6, w=64, h=32, kind="structure", seed=31, dst=(96, 48), iUpscaling=2),
+    "yv16_422_catmull_chroma": dict(cformat=15, w=64, h=32, kind="noise", seed=32, dst=(64, 32), iChromaScaling=2),
+    "yuv422p10_bilinear": dict(cformat=22, w=64, h=32, kind="noise", seed=33, dst=(128, 64), iUpscaling=1),
+    "yv24_444": dict(cformat=16, w=48, h=32, kind="noise", seed=34, dst=(72, 48), iUpscaling=2),
+    "yuv444p10": dict(cformat=24, w=48, h=32, kind="structure", seed=35, dst=(96, 64), iUpscaling=4),
+    "yuv444p16_down": dict(cformat=25, w=96, h=64, kind="noise", seed=36, dst=(30, 20)),
+    "nv12_chroma_nearest": dict(cformat=1, w=64, h=32, kind="noise", seed=37, dst=(128, 64), iChromaScaling=0, iUpscaling=2),
+    "p010_chroma_catmull": dict(cformat=2, w=64, h=32, kind="noise", seed=38, dst=(128, 64), iChromaScaling=2, iUpscaling=4),
+    "yuv420p10_chroma_catmull_cosited": dict(cformat=20, w=64, h=32, kind="noise", seed=39, dst=(64, 32), iChromaScaling=2, exfmt=ext(COSITED, TV, M709)),
+    # ---- colour / settings ----
+    "bt2020_sdr_gamma_gamut": dict(cformat=2, w=64, h=32, kind="structure", seed=40, dst=(128, 64), exfmt=ext(MPEG2, TV, M2020, P2020, T709), iUpscaling=2),
+    "bt2020_gamma26": dict(cformat=2, w=64, h=32, kind="noise", seed=41, dst=(64, 32), exfmt=ext(MPEG2, TV, M2020, P2020, T26)),
+    "pq_no_convert_to_sdr": dict(cformat=2, w=64, h=32, kind="hdr", seed=42, dst=(128, 64), exfmt=HDR10, bConvertToSdr=0, iUpscaling=4),
+    "hlg_no_convert_bt2020": dict(cformat=2, w=64, h=32, kind="hdr", seed=43, dst=(64, 32), exfmt=HLG, bConvertToSdr=0),
+    "pq_200nits": dict(cformat=2, w=64, h=32, kind="hdr", seed=44, dst=(128, 64), exfmt=HDR10, iSDRDisplayNits=200, iUpscaling=1),
+    "ycgco": dict(cformat=19, w=48, h=32, kind="noise", seed=45, dst=(48, 32), exfmt=ext(0, FULL, MYCGCO)),
+    "smpte240m": dict(cformat=1, w=64, h=32, kind="noise", seed=46, dst=(64, 32), exfmt=ext(MPEG2, TV, M240)),
+    "procamp": dict(cformat=1, w=64, h=32, kind="structure", seed=47, dst=(128, 64), procamp=(12.0, 1.15, 25.0, 0.8), iUpscaling=2),
+    "texfmt_16f_dither": dict(cformat=2, w=64, h=32, kind="noise", seed=48, dst=(128, 64), iTexFormat=16, iUpscaling=4, exfmt=HDR10),
+    "texfmt_16f_out10": dict(cformat=2, w=64, h=32, kind="noise", seed=49, dst=(96, 48), iTexFormat=16, output_format=1, iUpscaling=2),
+    "texfmt_10_out10_no_final": dict(cformat=2, w=64, h=32, kind="noise", seed=50, dst=(128, 64), output_format=1, iUpscaling=4),
+    "texfmt_8_forced_on_10bit": dict(cformat=2, w=64, h=32, kind="structure", seed=51, dst=(128, 64), iTexFormat=8, iUpscaling=2),
+    "texfmt_10_on_8bit_dither": dict(cformat=1, w=64, h=32, kind="structure", seed=52, dst=(128, 64), iTexFormat=10, iUpscaling=2),
+    "dither_off_10bit": dict(cformat=2, w=64, h=32, kind="structure", seed=53, dst=(128, 64), bUseDither=0, iUpscaling=4),
+    "nv12_pitch_padded": dict(cformat=1, w=62, h=32, kind="noise", seed=54, dst=(124, 64), iUpscaling=2),
+    "p010_pitch_padded": dict(cformat=2, w=64, h=32, kind="noise", seed=55, dst=(128, 64), iUpscaling=4, pitch=160),
+}
+
+SETTING_KEYS = ("iTexFormat", "iChromaScaling", "iUpscaling", "iDownscaling", "bInterpolateAt50pct",
+                "bUseDither", "bConvertToSdr", "iSDRDisplayNits", "output_format", "flags")
+
+
+def case_geometry(c):
+    w2, h2 = c["dst"]
+    ww, wh = c.get("window", (w2, h2))
+    ox, oy = c.get("offset", (0, 0))
+    return (ww, wh), (ox, oy, ox + w2, oy + h2)
+
+
+def case_frame(c):
+    return synth.make_frame(c["cformat"], c["w"], c["h"], c["kind"], seed=c["seed"], pitch=c.get("pitch"),
+                            full_range=c.get("full_range", False))
+
+
+def oracle_params(oracle, c):
+    (ww, wh), vr = case_geometry(c)
+    kw = {k: c[k] for k in SETTING_KEYS if k in c}
+    p = oracle.default_params(cformat=c["cformat"], width=c["w"], height=c["h"], exfmt=c.get("exfmt", 0),
+                              window_w=ww, window_h=wh, video_rect=vr, **kw)
+    if "src_rect" in c:
+        oracle.set_params(p, src_rect=c["src_rect"])
+    if "procamp" in c:
+        b, ct, h, s = c["procamp"]
+        oracle.set_params(p, brightness=b, contrast=ct, hue=h, saturation=s)
+    return p
+
+
+def run_case(oracle, name, background=0):
+    """Oracle output for a named case: (window_h, window_w, 4) uint8; untouched pixels = background."""
+    c = GOLDEN_CASES[name]
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    dst = np.full((p.window_h, p.window_w, 4), background, dtype=np.uint8)
+    return oracle.process(p, frame, pitch, dst=dst)

@@ -1,0 +1,167 @@
+"""Host-side logic of the product (videorenderer_amd/csrc/vp_plan.cpp) against the oracle and the real
+reference fixtures — no GPU involved: these are the parameter computations the reference also does on
+the CPU (SetShaderConvertColorParams, SpecifyExtendedFormat, resize constants, pass selection)."""
+import ctypes as C
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from tests.golden.cases import GOLDEN_CASES, SETTING_KEYS, case_geometry, oracle_params
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def bits(v):
+    return struct.unpack("<I", struct.pack("<f", v))[0]
+
+
+def test_color_matrix_matches_oracle_bit_exact(mpcvr, oracle):
+    rng = np.random.default_rng(11)
+    from videorenderer_amd import api
+    for cf in (1, 2, 3, 6, 14, 16, 17, 19, 20, 21, 22, 24, 25):
+        for _ in range(24):
+            ex = oracle.make_extfmt(chroma=int(rng.choice([0, 1, 5, 7])), nominal_range=int(rng.choice([0, 1, 2])),
+                                    matrix=int(rng.choice([0, 1, 2, 3, 4, 7])), primaries=int(rng.choice([0, 2, 9])),
+                                    transfer=int(rng.choice([0, 4, 5, 15, 16])))
+            w, h = int(rng.choice([640, 1024, 1920, 3840])), int(rng.choice([480, 576, 1080, 2160]))
+            b, ct, hu, s = rng.uniform(-100, 100), rng.uniform(0, 2), rng.uniform(-180, 180), rng.uniform(0, 2)
+            if rng.random() < 0.3:
+                b, ct, hu, s = 0.0, 1.0, 0.0, 1.0
+            got, ex_out = api.plan_color_matrix(cf, w, h, ex, b, ct, hu, s)
+            p = oracle.default_params(cformat=cf, width=w, height=h, exfmt=ex, brightness=b, contrast=ct, hue=hu, saturation=s)
+            want = oracle.color_matrix(p)
+            assert [bits(v) for v in got] == [bits(float(v)) for v in want], (cf, hex(ex), w, h)
+            assert ex_out == oracle.lib().orc_specify_extfmt(ex, cf, w, h)
+
+
+def test_color_matrix_matches_reference_fixtures(mpcvr):
+    """The committed outputs of the REAL csputils.cpp (tests/golden/csputils_ref.json) through the product path."""
+    from videorenderer_amd import api
+    with open(os.path.join(HERE, "golden", "csputils_ref.json")) as f:
+        g = json.load(f)
+    f32 = lambda b: struct.unpack("<f", struct.pack("<I", b))[0]
+    # product inputs are DXVA2 codes: matrix code -> mp_csp, range -> levels, CDepth via the format
+    space_to_matrix = {1: 2, 2: 1, 3: 3, 4: 4, 8: 7}
+    fmt_for_bits = {8: 1, 10: 20, 16: 2}
+    checked = 0
+    for case in g["csp_matrix"]:
+        if case["space"] not in space_to_matrix or case["levels"] == 0:
+            continue
+        # only the default ProcAmp can be expressed exactly in DXVA2 units (brightness*255 etc. round-trips differ)
+        if (f32(case["brightness"]), f32(case["contrast"]), f32(case["hue"]), f32(case["saturation"])) != (0.0, 1.0, 0.0, 1.0):
+            continue
+        ex = api.make_extfmt(nominal_range=2 if case["levels"] == 1 else 1, matrix=space_to_matrix[case["space"]])
+        got, _ = api.plan_color_matrix(fmt_for_bits[case["bits"]], 1920, 1080, ex)
+        assert [bits(v) for v in got[:9]] == case["m"] and [bits(v) for v in got[9:]] == case["c"], case
+        checked += 1
+    assert checked >= 25
+    assert [bits(v) for v in api.plan_gamut_2020_to_709()] == g["gamut_2020_to_709"]
+
+
+def test_upscale_weights_match_oracle(mpcvr, oracle):
+    from videorenderer_amd import api
+    w = (C.c_float * 6)()
+    for method in (1, 2, 3, 4):
+        for t in list(np.linspace(0, 1, 41, dtype=np.float32)[:-1]) + [0.25, 0.75]:
+            n = oracle.lib().orc_upscale_weights(method, float(t), w)
+            got = api.plan_upscale_weights(method, float(t))
+            assert len(got) == n and [bits(v) for v in got] == [bits(v) for v in w[:n]]
+
+
+@pytest.mark.parametrize("kind,method,src_l,src_len,n_out,tex_len,flags", [
+    (1, 4, 0, 128, 256, 128, 0), (1, 4, 0, 128, 256, 128, 1), (1, 2, 0, 100, 150, 100, 0), (1, 1, 0, 64, 50, 64, 0),
+    (1, 3, 0, 33, 100, 33, 0), (2, 2, 0, 192, 64, 192, 0), (2, 5, 0, 160, 64, 160, 0), (2, 0, 0, 128, 32, 128, 0),
+    (2, 1, 0, 128, 40, 128, 0), (2, 3, 0, 200, 31, 200, 0), (2, 4, 0, 96, 36, 96, 0), (0, 0, 0, 32, 64, 32, 0),
+    (0, 0, 0, 96, 30, 96, 0), (1, 4, 0, 3840, 7680, 3840, 0), (2, 5, 0, 3840, 1280, 3840, 0),
+])
+def test_axis_taps_match_oracle(mpcvr, oracle, kind, method, src_l, src_len, n_out, tex_len, flags):
+    from videorenderer_amd import api
+    I, W, WS = api.plan_axis_taps(kind, method, src_l, src_len, n_out, tex_len, flags)
+    idx = (C.c_int32 * 128)()
+    w = (C.c_float * 128)()
+    ws = C.c_float()
+    step = max(1, n_out // 257)
+    for i in list(range(0, n_out, step)) + [n_out - 1]:
+        n = oracle.lib().orc_axis_taps(kind, method, src_l, src_len, n_out, tex_len, flags, i, idx, w, C.byref(ws))
+        assert n > 0
+        assert I[i][:n] == list(idx[:n]), (i, I[i], list(idx[:n]))
+        assert [bits(v) for v in W[i][:n]] == [bits(v) for v in w[:n]], i
+        assert all(v == 0.0 for v in W[i][n:])          # padding taps carry zero weight
+        if WS is not None:
+            assert bits(WS[i]) == bits(ws.value)
+
+
+def test_frame_layout(mpcvr, oracle):
+    from videorenderer_amd import api
+    for cf in oracle.CF.values():
+        for (w, h) in ((1920, 1080), (62, 32), (3840, 2160)):
+            if cf in (1, 2, 3, 14, 17, 20, 21) and (w % 2 or h % 2):
+                continue
+            assert api.plan_frame_layout(cf, w, h) == oracle.frame_bytes(cf, w, h)
+    assert api.plan_frame_layout(1, 1920, 1080) == (3110400, 1920)
+    assert api.plan_frame_layout(2, 3840, 2160) == (24883200, 7680)
+    assert api.plan_frame_layout(20, 1920, 1080) == (6220800, 3840)
+    with pytest.raises(api.MpcvrError):
+        api.plan_frame_layout(4, 64, 64)          # YUY2: not in this build
+
+
+def test_pq_lut(mpcvr, oracle):
+    from videorenderer_amd import api
+    lut = np.array(api.plan_pq_lut(80.0), dtype=np.float32)
+    L = oracle.lib()
+    div = L.orc_hable(4.8)
+    for i in (0, 1, 100, 511, 767, 1022, 1023):
+        want = L.orc_hable(L.orc_st2084_to_linear(np.float32(i) / np.float32(1023), 80.0)) / div
+        assert abs(lut[i] - want) <= 2e-6 * max(1.0, abs(want))
+    assert np.all(np.diff(lut) >= 0)
+
+
+def test_pass_plan_matches_reference_rules(mpcvr):
+    from videorenderer_amd import api
+    s = api.default_settings()
+    d = lambda cf, w, h, vr, ww, wh, st=s: api.plan_describe(st, cf, w, h, vr, ww, wh)
+    # C1: 8-bit source, no resize -> BGRA8 internal, never dithers (DX11VideoProcessor.cpp:2896-2900)
+    assert d(1, 1920, 1080, (0, 0, 1920, 1080), 1920, 1080) == "passes:convert,copy;internal=8;swap=8;final=0"
+    # C2/C3: exact 2x of a 10/16-bit 4:2:0 source -> fused kernel, RGB10A2 internal, final pass on
+    assert d(20, 1920, 1080, (0, 0, 3840, 2160), 3840, 2160).startswith("fused_up2x;internal=10;swap=8;final=1")
+    assert d(2, 3840, 2160, (0, 0, 7680, 4320), 7680, 4320, s.copy(iUpscaling=4)).startswith("fused_up2x")
+    assert d(2, 3840, 2160, (0, 0, 7680, 4320), 7680, 4320, s.copy(iUpscaling=4, flags=api.FLAG_NO_FUSED)) == \
+        "passes:convert,resizeX,resizeY+final;internal=10;swap=8;final=1"
+    # not exactly 2x / partly outside the window / Catmull chroma -> pass-per-kernel path
+    assert d(2, 1920, 1080, (0, 0, 2880, 1620), 2880, 1620).startswith("passes:convert,resizeX,resizeY+final")
+    assert d(2, 1920, 1080, (-10, 0, 3830, 2160), 3840, 2160).startswith("passes:")
+    assert d(2, 1920, 1080, (0, 0, 3840, 2160), 3840, 2160, s.copy(iChromaScaling=2)).startswith("passes:")
+    # one-axis and nearest
+    assert d(2, 1920, 1080, (0, 0, 3840, 1080), 3840, 1080).startswith("passes:convert,resizeX+final")
+    assert d(2, 1920, 1080, (0, 0, 1920, 540), 1920, 540).startswith("passes:convert,resizeY+final")
+    assert d(1, 640, 360, (0, 0, 1280, 720), 1280, 720, s.copy(iUpscaling=0)).startswith("passes:convert,resizeX;")
+    # 10-bit swap chain: no final pass with RGB10A2 internal, final pass with fp16 internal
+    assert d(2, 64, 64, (0, 0, 64, 64), 64, 64, s.copy(output_format=1)).endswith("final=0")
+    assert d(2, 64, 64, (0, 0, 64, 64), 64, 64, s.copy(output_format=1, iTexFormat=16)).endswith("internal=16;swap=10;final=1")
+    assert d(2, 64, 64, (0, 0, 64, 64), 64, 64, s.copy(bUseDither=0)).endswith("final=0")
+    with pytest.raises(api.MpcvrError):
+        d(2, 64, 64, (0, 0, 128, 128), 128, 128, s.copy(iUpscaling=5))      # Jinc2
+
+
+def test_settings_default_matches_reference(mpcvr):
+    from videorenderer_amd import api
+    s = api.default_settings()
+    # Settings_t::SetDefault — IVideoRenderer.h:140-185
+    assert (s.iTexFormat, s.iChromaScaling, s.iUpscaling, s.iDownscaling) == (0, 1, 2, 2)
+    assert (s.bInterpolateAt50pct, s.bUseDither, s.bDeintBlend, s.bConvertToSdr, s.iSDRDisplayNits) == (1, 1, 0, 1, 125)
+
+
+def test_every_case_has_a_plan(mpcvr):
+    """The planner accepts every named parity case (so the GPU tests exercise real passes)."""
+    from videorenderer_amd import api
+    kinds = set()
+    for name, c in GOLDEN_CASES.items():
+        s = api.default_settings(**{k: c[k] for k in SETTING_KEYS if k in c})
+        (ww, wh), vr = case_geometry(c)
+        r = c.get("src_rect", (0, 0, c["w"], c["h"]))
+        kinds.add(api.plan_describe(s, c["cformat"], r[2] - r[0], r[3] - r[1], vr, ww, wh).split(";")[0])
+    assert {"fused_up2x", "passes:convert,copy", "passes:convert,final", "passes:convert,resizeX,resizeY+final",
+            "passes:convert,resizeX,resizeY"} <= kinds

@@ -1,0 +1,412 @@
+"""Pins for the CPU oracle (oracle/mpcvr_oracle.c).
+
+The reference holds no tests or golden vectors for this path, so the pins are
+manufactured: (1) csputils matrices from the REAL reference code, live via oracle/_ref
+and as committed fixtures (tests/golden/csputils_ref.json); (2) dither sha256 + permutation property;
+(3) resize phase weights; (4) grey-ramp PQ/HLG->SDR values; (5) chroma-siting weight tables;
+(6) golden hashes of whole-frame oracle outputs on the seeded synthetic inputs.
+"""
+import ctypes as C
+import hashlib
+import json
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def f32(bits):
+    return struct.unpack("<f", struct.pack("<I", bits))[0]
+
+
+def csp(lib, fn, *args):
+    m = (C.c_float * 9)()
+    c = (C.c_float * 3)()
+    getattr(lib, fn)(*args, m, c)
+    return np.array(m, dtype=np.float32), np.array(c, dtype=np.float32)
+
+
+# ---------------------------------------------------------------- (1) csputils
+def test_csp_matrix_matches_reference_fixtures(oracle):
+    with open(os.path.join(HERE, "golden", "csputils_ref.json")) as f:
+        g = json.load(f)
+    assert len(g["csp_matrix"]) >= 200
+    for case in g["csp_matrix"]:
+        m, c = csp(oracle.lib(), "orc_csp_matrix", case["space"], case["levels"], case["bits"],
+                   f32(case["brightness"]), f32(case["contrast"]), f32(case["hue"]), f32(case["saturation"]), 0)
+        assert [int(v) for v in m.view(np.uint32)] == case["m"], case
+        assert [int(v) for v in c.view(np.uint32)] == case["c"], case
+    gm = (C.c_float * 9)()
+    oracle.lib().orc_gamut_2020_to_709(gm)
+    assert [int(v) for v in np.array(gm, dtype=np.float32).view(np.uint32)] == g["gamut_2020_to_709"]
+
+
+def test_csp_matrix_matches_live_reference(oracle):
+    R = oracle.ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    rng = np.random.default_rng(7)
+    for space in (0, 1, 2, 3, 4, 8):
+        for levels in (0, 1, 2):
+            for bits in (8, 10, 16):
+                for _ in range(8):
+                    b, ct = rng.uniform(-100, 100) / 255, rng.uniform(0, 2)
+                    h, s = rng.uniform(-np.pi, np.pi), rng.uniform(0, 2)
+                    a = csp(oracle.lib(), "orc_csp_matrix", space, levels, bits, b, ct, h, s, 0)
+                    r = csp(R, "ref_csp_matrix", space, levels, bits, b, ct, h, s, 0)
+                    assert np.array_equal(a[0], r[0]) and np.array_equal(a[1], r[1])
+
+
+def test_known_answer_matrices(oracle):
+    # SURVEY.md §8a-3, computed there with the real code
+    m, c = csp(oracle.lib(), "orc_csp_matrix", 2, 1, 8, 0, 1, 0, 1, 0)
+    assert np.allclose(m[:3], [1.16438353, 0, 1.79274106], rtol=0, atol=1e-7) and abs(c[0] + 0.972945094) < 1e-7
+    m, c = csp(oracle.lib(), "orc_csp_matrix", 2, 1, 10, 0, 1, 0, 1, 0)
+    assert np.allclose(m[:3], [1.16780818, 0, 1.79801381], rtol=0, atol=1e-7) and abs(c[0] + 0.972945035) < 1e-7
+    m, c = csp(oracle.lib(), "orc_csp_matrix", 4, 1, 16, 0, 1, 0, 1, 0)
+    assert np.allclose(m, [1.16893196, 0, 1.68523157, 1.16893196, -0.188057855, -0.652965128,
+                           1.16893196, 2.15013862, 0], rtol=0, atol=2e-7)
+    assert np.allclose(c, [-0.915687978, 0.347458541, -1.14814508], rtol=0, atol=2e-7)
+    g = (C.c_float * 9)()
+    oracle.lib().orc_gamut_2020_to_709(g)
+    assert np.allclose(np.array(g), [1.66049695, -0.587656736, -0.0728399456, -0.124547064, 1.13289523,
+                                     -0.0083479844, -0.0181536824, -0.100597292, 1.11875105], rtol=0, atol=1e-7)
+
+
+def test_color_matrix_from_extfmt(oracle):
+    # P010 BT.2020 / PQ / TV range -> the 16-bit BT.2020NC matrix; NV12 with nothing declared -> BT.709 TV (HD)
+    ex = oracle.make_extfmt(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15)
+    p = oracle.default_params(cformat=oracle.CF["P010"], width=3840, height=2160, exfmt=ex)
+    cm = oracle.color_matrix(p)
+    assert abs(cm[0] - 1.16893196) < 2e-7 and abs(cm[2] - 1.68523157) < 2e-7
+    p = oracle.default_params(cformat=oracle.CF["NV12"], width=1920, height=1080, exfmt=0)
+    cm = oracle.color_matrix(p)
+    assert abs(cm[0] - 1.16438353) < 1e-7 and abs(cm[2] - 1.79274106) < 1e-7
+    p = oracle.default_params(cformat=oracle.CF["NV12"], width=720, height=576, exfmt=0)      # SD -> BT.601
+    cm = oracle.color_matrix(p)
+    assert abs(cm[2] - 1.59602678) < 2e-7
+
+
+def test_specify_extended_format_defaults(oracle):
+    L = oracle.lib()
+    v = L.orc_specify_extfmt(0, oracle.CF["NV12"], 1920, 1080)
+    f = lambda sh, m: (v >> sh) & m
+    assert (f(8, 0xf), f(12, 7), f(15, 7), f(18, 0xf), f(22, 0x1f), f(27, 0x1f)) == (5, 2, 1, 3, 2, 5)
+    v = L.orc_specify_extfmt(0, oracle.CF["NV12"], 720, 480)
+    assert (v >> 15) & 7 == 2
+    v = L.orc_specify_extfmt(oracle.make_extfmt(chroma=7), oracle.CF["YUV444P10"], 1920, 1080)
+    assert (v >> 8) & 0xf == 0          # non-4:2:0 => chroma siting cleared (Helper.cpp:1176-1178)
+
+
+# ---------------------------------------------------------------- (2) dither
+def test_dither_table_bit_exact(oracle):
+    raw = open(oracle.DITHER_PATH, "rb").read()
+    assert hashlib.sha256(raw).hexdigest() == "24b5048f1390879d3435072f6e48b62b042fd4787b33bfac5e6d9bc84ec28e7c"
+    d = np.frombuffer(raw, dtype=np.float16).astype(np.float64)
+    assert sorted((d * 1024).round().astype(int).tolist()) == list(range(1024))
+    ref = "/root/reference/Source/res/dither32x32float16.bin"
+    if os.path.exists(ref):
+        assert open(ref, "rb").read() == raw
+    # the table compiled into the product library
+    inc = open(os.path.join(ROOT, "videorenderer_amd", "csrc", "dither_table.inc")).read()
+    vals = [int(x, 16) for x in re.findall(r"0x[0-9a-fA-F]{4}", inc.split("\n", 3)[3])]
+    assert np.array(vals, dtype=np.uint16).tobytes() == raw
+
+
+# ---------------------------------------------------------------- (3) weights
+PINS_T025 = {   # SURVEY.md §8a-6, fp32 as written, t = 0.25
+    4: [-0.01083153, -0.08472481, 0.89105344, 0.23991315, -0.01790517, -0.01750513],
+    3: [-0.08472481, 0.86980093, 0.23282897, -0.01790517],
+    2: [-0.0703125, 0.8671875, 0.2265625, -0.0234375],
+    1: [-0.0234375, 0.78211808, 0.25607640, -0.01475694],
+}
+
+
+def up_weights(oracle, method, t):
+    w = (C.c_float * 6)()
+    n = oracle.lib().orc_upscale_weights(method, t, w)
+    return np.array(w[:n], dtype=np.float32)
+
+
+@pytest.mark.parametrize("method", [1, 2, 3, 4])
+def test_upscale_weight_pins(oracle, method):
+    w = up_weights(oracle, method, 0.25)
+    assert np.allclose(w, PINS_T025[method], rtol=0, atol=2e-8 + 6e-8)
+    # t = 0.75 is the mirror image
+    assert np.allclose(up_weights(oracle, method, 0.75), w[::-1], rtol=0, atol=2e-7)
+    for t in np.linspace(0.01, 0.99, 50, dtype=np.float32):
+        assert abs(float(np.sum(up_weights(oracle, method, float(t)).astype(np.float64))) - 1.0) < 4e-7
+    if method >= 3:     # "case t == 0 is required to return the centre sample"
+        w0 = up_weights(oracle, method, 0.0)
+        assert w0.sum() == 1.0 and np.count_nonzero(w0) == 1
+
+
+def test_downscale_filters(oracle):
+    L = oracle.lib()
+    sup = C.c_float()
+    expected_support = {0: 0.5, 1: 1.0, 2: 1.0, 3: 2.0, 4: 2.0, 5: 3.0}
+    for m, s in expected_support.items():
+        assert L.orc_downscale_filter(m, 0.0, C.byref(sup)) == 1.0
+        assert sup.value == s
+        assert L.orc_downscale_filter(m, s + 0.01, None) == 0.0
+    assert L.orc_downscale_filter(1, 0.25, None) == 0.75
+    assert abs(L.orc_downscale_filter(2, 0.5, None) - (np.sin(np.pi / 2) / (np.pi / 2) * 0.54)) < 1e-6
+    assert abs(L.orc_downscale_filter(3, 1.5, None) - (-0.0625)) < 1e-7       # bicubic a=-0.5
+    assert abs(L.orc_downscale_filter(4, 1.5, None) - (-0.1875)) < 1e-7       # a=-1.5
+
+
+def test_lanczos3_quirk_taps(oracle):
+    """Q1: the D3D11 shader samples Q1 at Q0's coordinate; the fixed flag restores base-1."""
+    idx = (C.c_int32 * 128)()
+    w = (C.c_float * 128)()
+    n = oracle.lib().orc_axis_taps(1, 4, 0, 100, 200, 100, 0, 51, idx, w, None)   # odd output 51: base = 25
+    assert n == 6 and list(idx[:6]) == [23, 23, 25, 26, 27, 28]
+    n = oracle.lib().orc_axis_taps(1, 4, 0, 100, 200, 100, 1, 51, idx, w, None)
+    assert list(idx[:6]) == [23, 24, 25, 26, 27, 28]
+    n = oracle.lib().orc_axis_taps(1, 4, 0, 100, 200, 100, 0, 50, idx, w, None)   # even output 50: base = 24, t = .75
+    assert list(idx[:6]) == [22, 22, 24, 25, 26, 27]
+    assert np.allclose(np.array(w[:6]), PINS_T025[4][::-1], atol=2e-7)
+    # clamp-to-edge of the whole texture
+    n = oracle.lib().orc_axis_taps(1, 2, 0, 100, 200, 100, 0, 0, idx, w, None)    # Catmull, output 0: base = -1
+    assert list(idx[:4]) == [0, 0, 0, 1]
+
+
+# ---------------------------------------------------------------- (4) HDR tails
+def test_pq_hlg_grey_pins(oracle):
+    L = oracle.lib()
+    tail = lambda v, trc: (lambda a: (L.orc_hdr_tail(a, trc, 9, 1, 80.0), a[0])[1])((C.c_float * 3)(v, v, v))
+    assert abs(L.orc_st2084_to_linear(0.5, 80.0) - 0.737949) < 2e-6
+    assert abs(tail(0.5, 15) * 255 - 149.8) < 0.05
+    assert abs(tail(0.58, 15) * 255 - 195.45) < 0.05
+    assert tail(0.75, 15) == 1.0 and tail(1.0, 15) == 1.0
+    # hable(0) = D*E/(D*F) - E/F leaves an fp32 residual that pow(1/2.2) lifts to ~2.6e-4 (< half a 10-bit LSB)
+    assert 0.0 <= tail(0.0, 15) < 4.9e-4
+    assert abs(tail(0.5, 16) * 255 - 113.65) < 0.05
+    assert abs(tail(0.75, 16) * 255 - 189.76) < 0.05
+    assert abs(L.orc_hable(4.8) - 0.55875593) < 1e-6
+    assert L.orc_luminance_scale(125) == 80.0
+    # PQ round trip
+    for x in (0.1, 0.3, 0.6, 0.9):
+        assert abs(L.orc_linear_to_st2084(L.orc_st2084_to_linear(x, 1000.0), 1000.0) - x) < 2e-5
+    # SDR BT.2020 gamma path: grey stays grey (gamut rows sum to 1), pow 2.2 then pow 1/2.2
+    a = (C.c_float * 3)(0.5, 0.5, 0.5)
+    L.orc_hdr_tail(a, 5, 9, 1, 80.0)
+    assert max(abs(v - 0.5) for v in a) < 2e-6
+    # no tail for BT.709 SDR
+    a = (C.c_float * 3)(0.25, 1.5, -0.5)
+    L.orc_hdr_tail(a, 5, 2, 1, 80.0)
+    assert list(a) == [0.25, 1.5, -0.5]
+
+
+def test_hlsl_constants_against_reference_text(oracle):
+    base = "/root/reference/Shaders/convert"
+    if not os.path.isdir(base):
+        pytest.skip("reference not mounted")
+    src = open(os.path.join(base, "st2084.hlsl")).read()
+    consts = {}
+    for name, expr in re.findall(r"static const float (ST2084_\w+)\s*=\s*([^;]+);", src):
+        consts[name] = eval(expr.replace("f", ""))
+    x = np.float64(0.6)
+    p = x ** (1.0 / consts["ST2084_m2"])
+    p = max(p - consts["ST2084_c1"], 0) / (consts["ST2084_c2"] - consts["ST2084_c3"] * p)
+    ref = p ** (1.0 / consts["ST2084_m1"]) * 80.0
+    assert abs(oracle.lib().orc_st2084_to_linear(0.6, 80.0) - ref) < 1e-4 * ref
+    hl = open(os.path.join(base, "hlg.hlsl")).read()
+    a, b, c = (float(re.search(r"B67_%s = ([0-9.]+)" % k, hl).group(1)) for k in "abc")
+    v = (C.c_float * 3)(0.8, 0.8, 0.8)
+    oracle.lib().orc_hlg_to_linear(v)
+    lin = np.exp((0.8 - c) / a) + b
+    assert abs(v[0] - lin * (2000.0 * lin) ** 0.2) < 1e-4 * v[0]
+
+
+# ---------------------------------------------------------------- half rounding
+def test_half_round_matches_ieee(oracle):
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.uniform(-2, 2, 4000), rng.uniform(-1e-4, 1e-4, 1000), [0.0, 1.0, 65504.0, 1e-8, 0.99975586]])
+    for x in xs.astype(np.float32):
+        assert oracle.lib().orc_half_round(float(x)) == float(np.float32(np.float16(x)))
+
+
+# ---------------------------------------------------------------- (5) chroma siting
+def _nv12_with_chroma_impulse(w, h, cx, cy):
+    buf = np.full(w * h * 3 // 2, 128, dtype=np.uint8)
+    buf[: w * h] = 126
+    uv = buf[w * h:].reshape(h // 2, w)
+    uv[cy, 2 * cx] = 228          # U impulse (+100)
+    return buf
+
+
+@pytest.mark.parametrize("chroma_loc,hw,vw", [
+    (5, {8: 1.0, 9: 0.5, 7: 0.5}, {8: 0.75, 9: 0.75, 7: 0.25, 10: 0.25}),          # MPEG-2
+    (7, {8: 1.0, 9: 0.5, 7: 0.5}, {8: 1.0, 9: 0.5, 7: 0.5}),                       # co-sited
+    (1, {8: 0.75, 9: 0.75, 7: 0.25, 10: 0.25}, {8: 0.75, 9: 0.75, 7: 0.25, 10: 0.25}),   # MPEG-1
+])
+def test_bilinear_chroma_siting_weights(oracle, chroma_loc, hw, vw):
+    """Impulse at chroma texel (4,4): the blue channel carries weight_x * weight_y of the impulse."""
+    w, h = 32, 32
+    frame = _nv12_with_chroma_impulse(w, h, 4, 4)
+    p = oracle.default_params(cformat=oracle.CF["NV12"], width=w, height=h,
+                              exfmt=oracle.make_extfmt(chroma=chroma_loc, nominal_range=1, matrix=1),
+                              iTexFormat=16)
+    out, fmt = oracle.convert_only(p, frame, w)
+    assert fmt == 16
+    base = out[0, 0, 2]
+    cm = oracle.color_matrix(p)
+    gain = cm[7] * (100.0 / 255.0)           # cm_b[1] * dU
+    resp = (out[:, :, 2] - base) / gain
+    for y in range(4, 14):
+        for x in range(4, 14):
+            expect = hw.get(x, 0.0) * vw.get(y, 0.0)
+            assert abs(resp[y, x] - expect) < 2e-3, (x, y, resp[y, x], expect)
+
+
+def test_nearest_and_catmull_chroma(oracle):
+    w, h = 32, 32
+    frame = _nv12_with_chroma_impulse(w, h, 4, 4)
+    ex = oracle.make_extfmt(chroma=5, nominal_range=1, matrix=1)
+    p = oracle.default_params(cformat=oracle.CF["NV12"], width=w, height=h, exfmt=ex, iTexFormat=16, iChromaScaling=0)
+    out, _ = oracle.convert_only(p, frame, w)
+    d = out[:, :, 2] - out[0, 0, 2]
+    assert np.count_nonzero(np.abs(d) > 1e-3) == 4 and abs(d[8, 8] - d[9, 9]) < 1e-6      # 2x2 block
+    p = oracle.default_params(cformat=oracle.CF["NV12"], width=w, height=h, exfmt=ex, iTexFormat=16, iChromaScaling=2)
+    out, _ = oracle.convert_only(p, frame, w)
+    d = (out[:, :, 2] - out[0, 0, 2])
+    # Catmull-Rom 4:2:0: 4x4 chroma taps => support of 8x8 luma px around the impulse, weights sum to 1 per phase
+    nz = np.argwhere(np.abs(d) > 1e-4)
+    assert nz[:, 0].min() >= 4 and nz[:, 0].max() <= 13 and nz[:, 1].min() >= 4 and nz[:, 1].max() <= 13
+    tot = d.sum() / d[8:10, 8:10].sum()
+    assert 0.5 < tot < 2.0
+
+
+# ---------------------------------------------------------------- whole path behaviour
+def _grey_p010(w, h, code10):
+    n, pitch = w * h * 3, w * 2
+    buf = np.zeros(n // 2, dtype=np.uint16)
+    buf[: w * h] = code10 << 6
+    buf[w * h:] = 512 << 6
+    return buf.view(np.uint8), pitch
+
+
+def test_constant_frame_through_whole_path(oracle):
+    """A flat grey frame stays flat through convert, Lanczos3 2x and dither; alpha is 255."""
+    w, h = 48, 32
+    frame, pitch = _grey_p010(w, h, 502)
+    p = oracle.default_params(cformat=oracle.CF["P010"], width=w, height=h, iUpscaling=4,
+                              window_w=2 * w, window_h=2 * h, video_rect=(0, 0, 2 * w, 2 * h))
+    out = oracle.process(p, frame, pitch)
+    assert out.shape == (2 * h, 2 * w, 4) and (out[..., 3] == 255).all()
+    # (502-64)/876 = 0.5 -> 10-bit 511.5 -> rounds to 512/1023 -> *255 = 127.62: dither gives 127 or 128
+    assert set(np.unique(out[..., :3]).tolist()) <= {127, 128}
+    frac128 = (out[..., 1] == 128).mean()
+    assert abs(frac128 - 0.62) < 0.05
+    # identical thresholds for B, G, R of a pixel
+    assert (out[..., 0] == out[..., 1]).all() and (out[..., 1] == out[..., 2]).all()
+    # dither pattern has period 32 in window coordinates
+    assert np.array_equal(out[:32, :32], out[32:64, 32:64])
+
+
+def test_8bit_source_never_dithers_and_passthrough(oracle):
+    """C1: NV12 -> BGRA8, no resize, internal BGRA8 => no final pass (DX11VideoProcessor.cpp:2896-2900)."""
+    from videorenderer_amd import synth
+    w, h = 64, 48
+    frame, pitch = synth.make_frame(1, w, h, "structure", seed=1)
+    p = oracle.default_params(cformat=1, width=w, height=h, window_w=w, window_h=h, video_rect=(0, 0, w, h))
+    a = oracle.process(p, frame, pitch)
+    p.bUseDither = 0
+    b = oracle.process(p, frame, pitch)
+    assert np.array_equal(a, b)
+    conv, fmt = oracle.convert_only(p, frame, pitch)
+    assert fmt == 8
+    assert np.array_equal(a[..., 2], np.round(conv[..., 0] * 255).astype(np.uint8))     # R
+    assert np.array_equal(a[..., 0], np.round(conv[..., 2] * 255).astype(np.uint8))     # B
+
+
+def test_window_placement_and_clipping(oracle):
+    from videorenderer_amd import synth
+    w, h = 32, 16
+    frame, pitch = synth.make_frame(2, w, h, "structure", seed=2)
+    full = oracle.process(oracle.default_params(cformat=2, width=w, height=h, window_w=2 * w, window_h=2 * h,
+                                                video_rect=(0, 0, 2 * w, 2 * h)), frame, pitch)
+    # letterboxed inside a bigger window at an offset that is a multiple of 32 (dither phase preserved)
+    p = oracle.default_params(cformat=2, width=w, height=h, window_w=160, window_h=128, video_rect=(32, 64, 32 + 2 * w, 64 + 2 * h))
+    dst = np.full((128, 160, 4), 7, dtype=np.uint8)
+    out = oracle.process(p, frame, pitch, dst=dst)
+    assert np.array_equal(out[64:64 + 2 * h, 32:32 + 2 * w], full)
+    mask = np.ones((128, 160), bool)
+    mask[64:64 + 2 * h, 32:32 + 2 * w] = False
+    assert (out[mask] == 7).all()
+    # partially outside the window: visible part identical modulo the dither phase -> compare undithered
+    p0 = oracle.default_params(cformat=2, width=w, height=h, window_w=2 * w, window_h=2 * h, video_rect=(0, 0, 2 * w, 2 * h), bUseDither=0)
+    ref = oracle.process(p0, frame, pitch)
+    p1 = oracle.default_params(cformat=2, width=w, height=h, window_w=40, window_h=20, video_rect=(-10, -6, -10 + 2 * w, -6 + 2 * h), bUseDither=0)
+    clip = oracle.process(p1, frame, pitch)
+    assert np.array_equal(clip, ref[6:26, 10:50])
+
+
+def test_src_rect_crop(oracle):
+    from videorenderer_amd import synth
+    w, h = 64, 32
+    frame, pitch = synth.make_frame(1, w, h, "structure", seed=3)
+    whole = oracle.process(oracle.default_params(cformat=1, width=w, height=h, window_w=w, window_h=h, video_rect=(0, 0, w, h)), frame, pitch)
+    p = oracle.default_params(cformat=1, width=w, height=h, src_rect=(16, 8, 48, 24), exfmt=oracle.make_extfmt(matrix=1),
+                              window_w=32, window_h=16, video_rect=(0, 0, 32, 16))
+    crop = oracle.process(p, frame, pitch)
+    # (full frame at 64x32 defaults to BT.601 (SD); pin both to BT.709 for the comparison)
+    whole709 = oracle.process(oracle.default_params(cformat=1, width=w, height=h, exfmt=oracle.make_extfmt(matrix=1),
+                                                    window_w=w, window_h=h, video_rect=(0, 0, w, h)), frame, pitch)
+    assert np.array_equal(crop, whole709[8:24, 16:48])
+    assert not np.array_equal(whole, whole709)
+
+
+def test_resizer_selection_rules(oracle):
+    """ResizeShaderPass :3108-3126: downscale shader only below 50 % when bInterpolateAt50pct."""
+    from videorenderer_amd import synth
+    w, h = 64, 64
+    frame, pitch = synth.make_frame(1, w, h, "noise", seed=4)
+    def run(dw, dh, **kw):
+        p = oracle.default_params(cformat=1, width=w, height=h, window_w=dw, window_h=dh, video_rect=(0, 0, dw, dh), **kw)
+        return oracle.process(p, frame, pitch)
+    # 64 -> 40 is within 50 %: the *upscale* shader is used, so changing iDownscaling must not matter
+    assert np.array_equal(run(40, 40, iDownscaling=0), run(40, 40, iDownscaling=5))
+    assert not np.array_equal(run(40, 40, iUpscaling=1), run(40, 40, iUpscaling=4))
+    # 64 -> 24 is beyond: convolution shader, iUpscaling must not matter
+    assert np.array_equal(run(24, 24, iUpscaling=1), run(24, 24, iUpscaling=4))
+    assert not np.array_equal(run(24, 24, iDownscaling=0), run(24, 24, iDownscaling=5))
+    # with bInterpolateAt50pct off every shrink uses the convolution
+    assert not np.array_equal(run(40, 40, iDownscaling=0, bInterpolateAt50pct=0), run(40, 40, iDownscaling=5, bInterpolateAt50pct=0))
+    # nearest upscale = pixel replication
+    big = run(128, 128, iUpscaling=0)
+    small = run(64, 64)
+    assert np.array_equal(big[::2, ::2], small) and np.array_equal(big[1::2, 1::2], small)
+    # one-axis resize
+    assert run(128, 64, iUpscaling=2).shape == (64, 128, 4)
+    with pytest.raises(RuntimeError):
+        run(128, 128, iUpscaling=5)          # Jinc2: not implemented
+
+
+def test_rgb10a2_output(oracle):
+    from videorenderer_amd import synth
+    w, h = 32, 16
+    frame, pitch = synth.make_frame(2, w, h, "structure", seed=5)
+    p = oracle.default_params(cformat=2, width=w, height=h, window_w=w, window_h=h, video_rect=(0, 0, w, h), output_format=1)
+    dst = np.zeros((h, w, 4), dtype=np.uint8)
+    out = oracle.process(p, frame, pitch, dst=dst).view(np.uint32)[..., 0]
+    assert ((out >> 30) == 3).all()
+    conv, fmt = oracle.convert_only(p, frame, pitch)
+    assert fmt == 10
+    assert np.array_equal(out & 1023, np.round(conv[..., 0] * 1023).astype(np.uint32))
+
+
+# ---------------------------------------------------------------- (6) golden hashes
+def test_oracle_golden_hashes(oracle):
+    from tests.golden.cases import GOLDEN_CASES, run_case
+    with open(os.path.join(HERE, "golden", "oracle_hashes.json")) as f:
+        want = json.load(f)
+    for name in GOLDEN_CASES:
+        out = run_case(oracle, name)
+        assert hashlib.sha256(out.tobytes()).hexdigest() == want[name], name

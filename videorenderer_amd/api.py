@@ -1,0 +1,393 @@
+"""Host-side mirror of the reference's video-processor interface over the C-ABI (include/mpcvr.h).
+
+`VideoProcessor` follows CVideoProcessor / CDX11VideoProcessor (Source/VideoProcessor.h:171-236,
+Source/DX11VideoProcessor.h:256-384): same method names, argument meaning and HRESULT-style error
+behaviour, so the parity tests read like calls into the reference.  All arithmetic happens in
+libmpcvr.so (hand-written HIP for gfx950); there is NO CPU fallback — a missing library or a missing
+GPU raises.  PyTorch only supplies device memory and streams.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmpcvr.so")
+
+S_OK, S_FALSE = 0, 1
+E_FAIL = -2147467259          # 0x80004005
+E_POINTER = -2147467261       # 0x80004003
+E_INVALIDARG = -2147024809    # 0x80070057
+E_UNEXPECTED = -2147418113    # 0x8000FFFF
+E_NOTIMPL = -2147467263       # 0x80004001
+E_OUTOFMEMORY = -2147024882   # 0x8007000E
+E_NOT_VALID_STATE = -2147019873  # 0x8007139F
+
+# ColorFormat_t (Source/Helper.h:86-127)
+CF_NV12, CF_P010, CF_P016 = 1, 2, 3
+CF_P210, CF_P216 = 6, 7
+CF_YV12, CF_YV16, CF_YV24 = 14, 15, 16
+CF_YUV420P8, CF_YUV422P8, CF_YUV444P8 = 17, 18, 19
+CF_YUV420P10, CF_YUV420P16, CF_YUV422P10, CF_YUV422P16, CF_YUV444P10, CF_YUV444P16 = 20, 21, 22, 23, 24, 25
+
+# Settings enums (Source/IVideoRenderer.h:25-72)
+TEXFMT_AUTOINT, TEXFMT_8INT, TEXFMT_10INT, TEXFMT_16FLOAT = 0, 8, 10, 16
+CHROMA_Nearest, CHROMA_Bilinear, CHROMA_CatmullRom = 0, 1, 2
+UPSCALE_Nearest, UPSCALE_Mitchell, UPSCALE_CatmullRom, UPSCALE_Lanczos2, UPSCALE_Lanczos3, UPSCALE_Jinc2 = range(6)
+DOWNSCALE_Box, DOWNSCALE_Bilinear, DOWNSCALE_Hamming, DOWNSCALE_Bicubic, DOWNSCALE_BicubicSharp, DOWNSCALE_Lanczos = range(6)
+OUT_BGRA8, OUT_RGB10A2 = 0, 1
+FLAG_LANCZOS3_FIXED, FLAG_NO_FUSED, FLAG_NO_LUT, FLAG_NO_FAST_CONVERT = 1, 2, 4, 8
+MEM_HOST, MEM_DEVICE = 0, 1
+PROCAMP_BRIGHTNESS, PROCAMP_CONTRAST, PROCAMP_HUE, PROCAMP_SATURATION = 1, 2, 4, 8
+
+# DXVA2_ExtendedFormat codes used by the reference (Helper.cpp:1215-1223)
+CHROMA_LOC_MPEG1, CHROMA_LOC_MPEG2, CHROMA_LOC_COSITED = 1, 5, 7
+RANGE_0_255, RANGE_16_235 = 1, 2
+MATRIX_BT709, MATRIX_BT601, MATRIX_SMPTE240M, MATRIX_BT2020, MATRIX_YCGCO = 1, 2, 3, 4, 7
+PRIM_BT709, PRIM_BT2020 = 2, 9
+TRC_22, TRC_709, TRC_SRGB, TRC_PQ, TRC_HLG = 4, 5, 7, 15, 16
+
+
+def make_extfmt(chroma=0, nominal_range=0, matrix=0, lighting=0, primaries=0, transfer=0, sample_format=0):
+    """Pack DXVA2_ExtendedFormat.value (dxva2api.h bit layout, LSB first)."""
+    return ((sample_format & 0xff) | ((chroma & 0xf) << 8) | ((nominal_range & 0x7) << 12) |
+            ((matrix & 0x7) << 15) | ((lighting & 0xf) << 18) | ((primaries & 0x1f) << 22) |
+            ((transfer & 0x1f) << 27))
+
+
+class Settings(C.Structure):
+    """mpcvr_settings == the subset of Settings_t (IVideoRenderer.h:104-135) that reaches this path."""
+    _fields_ = [("iTexFormat", C.c_int32), ("iChromaScaling", C.c_int32), ("iUpscaling", C.c_int32),
+                ("iDownscaling", C.c_int32), ("bInterpolateAt50pct", C.c_int32), ("bUseDither", C.c_int32),
+                ("bDeintBlend", C.c_int32), ("bConvertToSdr", C.c_int32), ("iSDRDisplayNits", C.c_int32),
+                ("output_format", C.c_int32), ("flags", C.c_uint32)]
+
+    def copy(self, **kw):
+        s = Settings()
+        C.memmove(C.byref(s), C.byref(self), C.sizeof(Settings))
+        for k, v in kw.items():
+            setattr(s, k, v)
+        return s
+
+
+class Rect(C.Structure):
+    _fields_ = [("left", C.c_int32), ("top", C.c_int32), ("right", C.c_int32), ("bottom", C.c_int32)]
+
+
+class MpcvrError(RuntimeError):
+    def __init__(self, hr, msg):
+        super().__init__(f"HRESULT 0x{hr & 0xffffffff:08X}: {msg}")
+        self.hr = hr
+
+
+EXPORTS = [
+    "mpcvr_settings_default", "mpcvr_create", "mpcvr_destroy", "mpcvr_set_stream", "mpcvr_synchronize",
+    "mpcvr_set_input", "mpcvr_set_video_rect", "mpcvr_set_window_rect", "mpcvr_set_rotation", "mpcvr_set_flip",
+    "mpcvr_configure", "mpcvr_set_procamp", "mpcvr_copy_sample", "mpcvr_process", "mpcvr_render",
+    "mpcvr_get_backbuffer", "mpcvr_get_current_image", "mpcvr_flush", "mpcvr_reset", "mpcvr_process_batch",
+    "mpcvr_get_param_blob", "mpcvr_set_param_blob", "mpcvr_get_color_matrix", "mpcvr_get_extfmt",
+    "mpcvr_get_frame_bytes", "mpcvr_get_path_info", "mpcvr_last_error", "mpcvr_version",
+    "mpcvr_get_last_process_ms",
+    "mpcvr_plan_frame_layout", "mpcvr_plan_color_matrix", "mpcvr_plan_gamut_2020_to_709", "mpcvr_plan_pq_lut",
+    "mpcvr_plan_upscale_weights", "mpcvr_plan_axis_taps", "mpcvr_plan_describe",
+]
+
+_lib = None
+
+
+def load_library():
+    """dlopen libmpcvr.so.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -m videorenderer_amd.build` "
+                           "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u32, f = C.c_void_p, C.c_int32, C.c_uint32, C.c_float
+    P = C.POINTER
+    sig = {
+        "mpcvr_settings_default": [P(Settings)],
+        "mpcvr_create": [P(Settings), i32, P(vp)],
+        "mpcvr_destroy": [vp],
+        "mpcvr_set_stream": [vp, vp],
+        "mpcvr_synchronize": [vp],
+        "mpcvr_set_input": [vp, i32, i32, i32, i32, P(Rect), u32],
+        "mpcvr_set_video_rect": [vp, P(Rect)],
+        "mpcvr_set_window_rect": [vp, P(Rect)],
+        "mpcvr_set_rotation": [vp, i32],
+        "mpcvr_set_flip": [vp, i32],
+        "mpcvr_configure": [vp, P(Settings)],
+        "mpcvr_set_procamp": [vp, u32, f, f, f, f],
+        "mpcvr_copy_sample": [vp, vp, i32, i32],
+        "mpcvr_process": [vp, vp, i32, P(Rect), P(Rect), i32],
+        "mpcvr_render": [vp, i32],
+        "mpcvr_get_backbuffer": [vp, P(vp), P(i32), P(i32), P(i32)],
+        "mpcvr_get_current_image": [vp, vp, P(C.c_size_t)],
+        "mpcvr_flush": [vp],
+        "mpcvr_reset": [vp],
+        "mpcvr_process_batch": [vp, i32, P(vp), P(vp), i32],
+        "mpcvr_get_param_blob": [vp, vp, P(C.c_size_t)],
+        "mpcvr_set_param_blob": [vp, vp, C.c_size_t],
+        "mpcvr_get_color_matrix": [vp, P(f)],
+        "mpcvr_get_extfmt": [vp, P(u32)],
+        "mpcvr_get_frame_bytes": [vp, P(C.c_size_t), P(i32)],
+        "mpcvr_get_path_info": [vp, C.c_char_p, C.c_size_t],
+        "mpcvr_get_last_process_ms": [vp, P(f)],
+        "mpcvr_plan_frame_layout": [i32, i32, i32, P(i32), P(C.c_size_t)],
+        "mpcvr_plan_color_matrix": [i32, i32, i32, u32, f, f, f, f, P(f), P(u32)],
+        "mpcvr_plan_gamut_2020_to_709": [P(f)],
+        "mpcvr_plan_pq_lut": [f, P(f)],
+        "mpcvr_plan_upscale_weights": [i32, f, P(f)],
+        "mpcvr_plan_axis_taps": [i32, i32, i32, i32, i32, i32, u32, i32, P(i32), P(f), P(f), P(i32), P(i32)],
+        "mpcvr_plan_describe": [P(Settings), i32, i32, i32, P(Rect), i32, i32, C.c_char_p, C.c_size_t],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = i32
+    L.mpcvr_last_error.argtypes = [vp]
+    L.mpcvr_last_error.restype = C.c_char_p
+    L.mpcvr_version.argtypes = []
+    L.mpcvr_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def default_settings(**kw):
+    s = Settings()
+    load_library().mpcvr_settings_default(C.byref(s))
+    for k, v in kw.items():
+        setattr(s, k, v)
+    return s
+
+
+# ---- host-side parameter maths (no context, no GPU) ------------------------------------------------
+def plan_frame_layout(cformat, width, height):
+    pitch, nbytes = C.c_int32(), C.c_size_t()
+    hr = load_library().mpcvr_plan_frame_layout(cformat, width, height, C.byref(pitch), C.byref(nbytes))
+    if hr < 0:
+        raise MpcvrError(hr, "mpcvr_plan_frame_layout")
+    return nbytes.value, pitch.value
+
+
+def plan_color_matrix(cformat, rect_w, rect_h, extfmt=0, brightness=0.0, contrast=1.0, hue=0.0, saturation=1.0):
+    out = (C.c_float * 12)()
+    ex = C.c_uint32()
+    hr = load_library().mpcvr_plan_color_matrix(cformat, rect_w, rect_h, extfmt, brightness, contrast, hue,
+                                                saturation, out, C.byref(ex))
+    if hr < 0:
+        raise MpcvrError(hr, "mpcvr_plan_color_matrix")
+    return list(out), ex.value
+
+
+def plan_gamut_2020_to_709():
+    out = (C.c_float * 9)()
+    load_library().mpcvr_plan_gamut_2020_to_709(out)
+    return list(out)
+
+
+def plan_pq_lut(lum_scale):
+    out = (C.c_float * 1024)()
+    load_library().mpcvr_plan_pq_lut(lum_scale, out)
+    return list(out)
+
+
+def plan_upscale_weights(method, t):
+    w = (C.c_float * 6)()
+    n = load_library().mpcvr_plan_upscale_weights(method, t, w)
+    return list(w)[:n]
+
+
+def plan_axis_taps(kind, method, src_l, src_len, n_out, tex_len, flags=0, cap_taps=160):
+    """Returns (idx[n_out][ntaps], w[n_out][ntaps], wsum[n_out] or None) as nested lists."""
+    idx = (C.c_int32 * (n_out * cap_taps))()
+    w = (C.c_float * (n_out * cap_taps))()
+    ws = (C.c_float * n_out)()
+    nt, norm = C.c_int32(), C.c_int32()
+    hr = load_library().mpcvr_plan_axis_taps(kind, method, src_l, src_len, n_out, tex_len, flags, cap_taps,
+                                             idx, w, ws, C.byref(nt), C.byref(norm))
+    if hr != 0:
+        raise MpcvrError(hr, "mpcvr_plan_axis_taps")
+    n = nt.value
+    I = [list(idx[i * n:(i + 1) * n]) for i in range(n_out)]
+    W = [list(w[i * n:(i + 1) * n]) for i in range(n_out)]
+    return I, W, (list(ws) if norm.value else None)
+
+
+def plan_describe(settings, cformat, rect_w, rect_h, video_rect, window_w, window_h):
+    buf = C.create_string_buffer(256)
+    hr = load_library().mpcvr_plan_describe(C.byref(settings), cformat, rect_w, rect_h, C.byref(Rect(*video_rect)),
+                                            window_w, window_h, buf, 256)
+    if hr < 0:
+        raise MpcvrError(hr, buf.value.decode())
+    return buf.value.decode()
+
+
+def _ptr(x):
+    """Device/host address of a torch tensor, numpy array or int."""
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    if hasattr(x, "ctypes"):
+        return x.ctypes.data
+    return int(x)
+
+
+class VideoProcessor:
+    """One processor context on one GPU (not re-entrant, like the reference under m_RendererLock)."""
+
+    def __init__(self, settings=None, device=0, use_torch_stream=True):
+        self._L = load_library()
+        self._ctx = C.c_void_p()
+        self.settings = settings.copy() if settings is not None else default_settings()
+        hr = self._L.mpcvr_create(C.byref(self.settings), device, C.byref(self._ctx))
+        if hr < 0:
+            self._ctx = C.c_void_p()
+            raise MpcvrError(hr, "mpcvr_create failed (is a HIP device visible?)")
+        self.device = device
+        self._keep = []
+        if use_torch_stream:
+            import torch
+            with torch.cuda.device(device):
+                self.SetStream(torch.cuda.current_stream().cuda_stream)
+
+    # -- plumbing --------------------------------------------------------------------------------
+    def _check(self, hr, allow_false=True):
+        if hr < 0:
+            raise MpcvrError(hr, self._L.mpcvr_last_error(self._ctx).decode())
+        return hr
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._L.mpcvr_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def SetStream(self, hip_stream):
+        return self._check(self._L.mpcvr_set_stream(self._ctx, C.c_void_p(hip_stream or 0)))
+
+    def Synchronize(self):
+        return self._check(self._L.mpcvr_synchronize(self._ctx))
+
+    # -- CVideoProcessor surface -------------------------------------------------------------------
+    def InitMediaType(self, cformat, width, height, pitch=0, src_rect=None, extfmt=0):
+        """VerifyMediaType + InitMediaType (DX11VideoProcessor.cpp:1569,1742)."""
+        r = Rect(*src_rect) if src_rect is not None else None
+        return self._check(self._L.mpcvr_set_input(self._ctx, cformat, width, height, pitch,
+                                                   C.byref(r) if r is not None else None, extfmt))
+
+    def SetVideoRect(self, rect):
+        return self._check(self._L.mpcvr_set_video_rect(self._ctx, C.byref(Rect(*rect))))
+
+    def SetWindowRect(self, rect):
+        return self._check(self._L.mpcvr_set_window_rect(self._ctx, C.byref(Rect(*rect))))
+
+    def SetRotation(self, value):
+        return self._check(self._L.mpcvr_set_rotation(self._ctx, value))
+
+    def SetFlip(self, value):
+        return self._check(self._L.mpcvr_set_flip(self._ctx, int(bool(value))))
+
+    def Configure(self, settings):
+        hr = self._check(self._L.mpcvr_configure(self._ctx, C.byref(settings)))
+        self.settings = settings.copy()
+        return hr
+
+    def SetProcAmpValues(self, brightness=None, contrast=None, hue=None, saturation=None):
+        flags = 0
+        vals = []
+        for bit, v, d in ((1, brightness, 0.0), (2, contrast, 1.0), (4, hue, 0.0), (8, saturation, 1.0)):
+            if v is not None:
+                flags |= bit
+            vals.append(d if v is None else float(v))
+        return self._check(self._L.mpcvr_set_procamp(self._ctx, flags, *vals))
+
+    def CopySample(self, data, pitch=None, mem_kind=None):
+        """CopySample (DX11VideoProcessor.cpp:2202): host array => upload; CUDA/HIP tensor => zero-copy."""
+        if pitch is None:
+            pitch = self.GetFrameBytes()[1]
+        if mem_kind is None:
+            mem_kind = MEM_DEVICE if (hasattr(data, "is_cuda") and data.is_cuda) else MEM_HOST
+        self._keep = [data]
+        return self._check(self._L.mpcvr_copy_sample(self._ctx, C.c_void_p(_ptr(data)), pitch, mem_kind))
+
+    def Process(self, render_target, rt_pitch, src_rect=None, dst_rect=None, second=False):
+        """Process (DX11VideoProcessor.cpp:3285). render_target: device tensor/pointer."""
+        s = Rect(*src_rect) if src_rect is not None else None
+        d = Rect(*dst_rect) if dst_rect is not None else None
+        return self._check(self._L.mpcvr_process(self._ctx, C.c_void_p(_ptr(render_target)), rt_pitch,
+                                                 C.byref(s) if s is not None else None,
+                                                 C.byref(d) if d is not None else None, int(second)))
+
+    def Render(self, field=1):
+        return self._check(self._L.mpcvr_render(self._ctx, field))
+
+    def GetBackBuffer(self):
+        p, pitch, w, h = C.c_void_p(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._L.mpcvr_get_backbuffer(self._ctx, C.byref(p), C.byref(pitch), C.byref(w), C.byref(h)))
+        return p.value, pitch.value, w.value, h.value
+
+    def GetCurentImage(self):
+        """GetCurentImage (DX11VideoProcessor.cpp:3493): BGRX snapshot at source-rect size -> numpy."""
+        import numpy as np
+        size = C.c_size_t(0)
+        self._check(self._L.mpcvr_get_current_image(self._ctx, None, C.byref(size)))
+        buf = np.empty(size.value, dtype=np.uint8)
+        self._check(self._L.mpcvr_get_current_image(self._ctx, C.c_void_p(buf.ctypes.data), C.byref(size)))
+        return buf
+
+    def ProcessBatch(self, srcs, dsts, rt_pitch):
+        n = len(srcs)
+        assert n == len(dsts) and n > 0
+        sa = (C.c_void_p * n)(*[_ptr(s) for s in srcs])
+        da = (C.c_void_p * n)(*[_ptr(d) for d in dsts])
+        self._keep = [srcs, dsts]
+        return self._check(self._L.mpcvr_process_batch(self._ctx, n, sa, da, rt_pitch))
+
+    def Flush(self):
+        return self._check(self._L.mpcvr_flush(self._ctx))
+
+    def Reset(self):
+        return self._check(self._L.mpcvr_reset(self._ctx))
+
+    # -- introspection ---------------------------------------------------------------------------
+    def GetParamBlob(self):
+        size = C.c_size_t(0)
+        self._check(self._L.mpcvr_get_param_blob(self._ctx, None, C.byref(size)))
+        buf = (C.c_uint8 * size.value)()
+        self._check(self._L.mpcvr_get_param_blob(self._ctx, buf, C.byref(size)))
+        return bytes(buf)
+
+    def SetParamBlob(self, blob):
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        return self._check(self._L.mpcvr_set_param_blob(self._ctx, buf, len(blob)))
+
+    def GetColorMatrix(self):
+        out = (C.c_float * 12)()
+        self._check(self._L.mpcvr_get_color_matrix(self._ctx, out))
+        return list(out)
+
+    def GetExtFmt(self):
+        v = C.c_uint32()
+        self._check(self._L.mpcvr_get_extfmt(self._ctx, C.byref(v)))
+        return v.value
+
+    def GetFrameBytes(self):
+        n, p = C.c_size_t(), C.c_int32()
+        self._check(self._L.mpcvr_get_frame_bytes(self._ctx, C.byref(n), C.byref(p)))
+        return n.value, p.value
+
+    def GetVPInfo(self):
+        buf = C.create_string_buffer(256)
+        self._check(self._L.mpcvr_get_path_info(self._ctx, buf, 256))
+        return buf.value.decode()
+
+    def GetLastProcessMs(self):
+        ms = C.c_float()
+        self._check(self._L.mpcvr_get_last_process_ms(self._ctx, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,70 @@
+"""Build libmpcvr.so (HIP kernels + C-ABI) in-tree with hipcc for gfx950.
+
+    python -m videorenderer_amd.build        # or: from videorenderer_amd.build import build; build()
+
+The shared library lands next to this file (videorenderer_amd/libmpcvr.so); it is git-ignored but
+travels with gpurun snapshots.  No torch involvement: the library links only libamdhip64.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libmpcvr.so")
+BUILD = os.path.join(HERE, "_build")
+ARCH = "gfx950"
+
+# (source, extra flags).  vp_kernels.hip and the host planner are built with -ffp-contract=off so the
+# pass-per-kernel path rounds exactly like the CPU oracle; the fused path may contract.
+SOURCES = [
+    ("vp_plan.cpp", ["-ffp-contract=off"]),
+    ("hip_video_processor.cpp", []),
+    ("mpcvr_capi.cpp", []),
+    ("vp_kernels.hip", ["-ffp-contract=off"]),
+    ("vp_fused.hip", []),
+]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _newer(src, dst):
+    return not os.path.exists(dst) or os.path.getmtime(src) > os.path.getmtime(dst)
+
+
+def build(force=False, verbose=False):
+    hipcc = _hipcc()
+    os.makedirs(BUILD, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "mpcvr.h"))
+    hdr_mtime = max(os.path.getmtime(h) for h in headers)
+    objs = []
+    common = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+    for name, extra in SOURCES:
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(BUILD, name + ".o")
+        objs.append(obj)
+        if force or _newer(src, obj) or os.path.getmtime(obj) < hdr_mtime:
+            cmd = [hipcc, "-c", src, "-o", obj] + common + extra
+            if name.endswith(".cpp"):
+                cmd += ["-x", "hip"]          # host files include hip_runtime.h for launch types
+                cmd = [hipcc, "-x", "hip", "-c", src, "-o", obj] + common + extra
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+    if force or any(_newer(o, OUT) for o in objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,712 @@
+// hip_video_processor.cpp — pass sequencing and resource management of the shader video processor on
+// HIP.  Restates the control flow of CDX11VideoProcessor::{InitMediaType, Configure, CopySample,
+// Process, ConvertColorPass, ResizeShaderPass, FinalPass, GetCurentImage}
+// (Source/DX11VideoProcessor.cpp) without the D3D11 plumbing.
+#include "hip_video_processor.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+
+namespace mpcvr {
+
+static const uint16_t kDitherTable[1024] = {
+#include "dither_table.inc"
+};
+
+// parameter blob exchanged between ranks (mpcvr_get/set_param_blob)
+struct ParamBlob {
+    uint32_t magic;          // 'MPVB'
+    uint32_t version;
+    float cm[12];
+    float lum_scale;
+    float gamut[9];
+    int32_t tail;
+    float gamma;
+    Up2xWeights upx, upy;
+    uint16_t dither[1024];
+    float pq_lut[1024];      // tone-map LUT (valid when tail == PQ->SDR)
+};
+static const uint32_t kBlobMagic = 0x4256504du;
+
+// ------------------------------------------------------------------------------------------------
+hipError_t DevBuffer::CheckCreate(size_t bytes)
+{
+    if (bytes <= size && ptr) return hipSuccess;
+    Release();
+    hipError_t e = hipMalloc(&ptr, bytes);
+    if (e == hipSuccess) size = bytes; else ptr = nullptr;
+    return e;
+}
+void DevBuffer::Release()
+{
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr; size = 0;
+}
+
+CHipVideoProcessor::CHipVideoProcessor() { std::memcpy(m_ditherHost, kDitherTable, sizeof(m_ditherHost)); }
+
+CHipVideoProcessor::~CHipVideoProcessor()
+{
+    if (!m_bInit) return;
+    (void)hipSetDevice(m_device);
+    if (m_stream) (void)hipStreamSynchronize(m_stream);
+    for (DevBuffer *b : {&m_TexSrcVideo, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
+                         &m_pqLut, &m_tapsXi, &m_tapsXw, &m_tapsXs, &m_tapsYi, &m_tapsYw, &m_tapsYs, &m_otherX, &m_otherY, &m_frames})
+        b->Release();
+    if (m_pinned) (void)hipHostFree(m_pinned);
+    if (m_framesPinned) (void)hipHostFree(m_framesPinned);
+    if (m_evStart) (void)hipEventDestroy(m_evStart);
+    if (m_evStop) (void)hipEventDestroy(m_evStop);
+    if (m_ownStream && m_stream) (void)hipStreamDestroy(m_stream);
+}
+
+HRESULT CHipVideoProcessor::Fail(HRESULT hr, const std::string &msg)
+{
+    m_lastError = msg;
+    return hr;
+}
+
+HRESULT CHipVideoProcessor::CheckHip(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return MPCVR_S_OK;
+    return Fail(e == hipErrorOutOfMemory ? MPCVR_E_OUTOFMEMORY : MPCVR_E_FAIL,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+
+static bool ValidSettings(const mpcvr_settings &s, std::string *why)
+{
+    auto bad = [&](const char *m) { *why = m; return false; };
+    if (s.iTexFormat != MPCVR_TEXFMT_AUTOINT && s.iTexFormat != MPCVR_TEXFMT_8INT &&
+        s.iTexFormat != MPCVR_TEXFMT_10INT && s.iTexFormat != MPCVR_TEXFMT_16FLOAT) return bad("iTexFormat");
+    if (s.iChromaScaling < 0 || s.iChromaScaling > MPCVR_CHROMA_CatmullRom) return bad("iChromaScaling");
+    if (s.iUpscaling < 0 || s.iUpscaling > MPCVR_UPSCALE_Jinc2) return bad("iUpscaling");
+    if (s.iDownscaling < 0 || s.iDownscaling > MPCVR_DOWNSCALE_Lanczos) return bad("iDownscaling");
+    if (s.iSDRDisplayNits < 25 || s.iSDRDisplayNits > 400) return bad("iSDRDisplayNits");   // IVideoRenderer.h:87-90
+    if (s.output_format != MPCVR_OUT_BGRA8 && s.output_format != MPCVR_OUT_RGB10A2) return bad("output_format");
+    return true;
+}
+
+HRESULT CHipVideoProcessor::Init(int device, const mpcvr_settings &settings)
+{
+    std::string why;
+    if (!ValidSettings(settings, &why)) return Fail(MPCVR_E_INVALIDARG, "invalid settings: " + why);
+    if (settings.bDeintBlend) return Fail(MPCVR_E_NOTIMPL, "bDeintBlend: interlaced blend is not implemented");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return Fail(MPCVR_E_FAIL, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (device < 0 || device >= count) return Fail(MPCVR_E_INVALIDARG, "device ordinal out of range");
+    m_device = device;
+    HRESULT hr;
+    if ((hr = CheckHip(hipSetDevice(device), "hipSetDevice"))) return hr;
+    if ((hr = CheckHip(hipStreamCreateWithFlags(&m_stream, hipStreamNonBlocking), "hipStreamCreate"))) return hr;
+    m_ownStream = true;
+    if ((hr = CheckHip(hipEventCreate(&m_evStart), "hipEventCreate"))) return hr;
+    if ((hr = CheckHip(hipEventCreate(&m_evStop), "hipEventCreate"))) return hr;
+    // dither texture load — DX11VideoProcessor.cpp:1414-1440
+    if ((hr = CheckHip(m_dither.CheckCreate(sizeof(m_ditherHost)), "dither alloc"))) return hr;
+    if ((hr = CheckHip(hipMemcpy(m_dither.ptr, m_ditherHost, sizeof(m_ditherHost), hipMemcpyHostToDevice), "dither upload"))) return hr;
+    m_cfg = settings;
+    m_bInit = true;
+    return MPCVR_S_OK;
+}
+
+HRESULT CHipVideoProcessor::SetStream(hipStream_t s)
+{
+    if (!m_bInit) return Fail(MPCVR_E_NOT_VALID_STATE, "not initialised");
+    (void)hipSetDevice(m_device);
+    if (m_stream) (void)hipStreamSynchronize(m_stream);
+    if (m_ownStream && m_stream) (void)hipStreamDestroy(m_stream);
+    m_ownStream = false;
+    m_stream = s;
+    if (!s) {
+        HRESULT hr = CheckHip(hipStreamCreateWithFlags(&m_stream, hipStreamNonBlocking), "hipStreamCreate");
+        if (hr) return hr;
+        m_ownStream = true;
+    }
+    return MPCVR_S_OK;
+}
+
+HRESULT CHipVideoProcessor::Synchronize()
+{
+    if (!m_bInit) return Fail(MPCVR_E_NOT_VALID_STATE, "not initialised");
+    (void)hipSetDevice(m_device);
+    return CheckHip(hipStreamSynchronize(m_stream), "hipStreamSynchronize");
+}
+
+// ------------------------------------------------------------------------------------------------
+// InitMediaType — DX11VideoProcessor.cpp:1742-1959 (shader-path half: InitializeTexVP :2018-2047)
+// ------------------------------------------------------------------------------------------------
+HRESULT CHipVideoProcessor::InitMediaType(int cformat, int width, int height, int pitch, const CRect *srcRect, uint32_t extfmt)
+{
+    if (!m_bInit) return Fail(MPCVR_E_NOT_VALID_STATE, "not initialised");
+    const FmtConvParams *f = GetFmtConvParams(cformat);
+    if (!f) return Fail(MPCVR_E_NOTIMPL, "colour format not supported by this build");
+    if (width <= 0 || height <= 0 || width > 16384 || height > 16384) return Fail(MPCVR_E_INVALIDARG, "bad frame size");
+    if ((f->div_w == 2 && (width & 1)) || (f->div_h == 2 && (height & 1)))
+        return Fail(MPCVR_E_INVALIDARG, "subsampled formats need even dimensions");
+    const int defPitch = DefaultPitch(*f, width);
+    if (pitch == 0) pitch = defPitch;
+    if (pitch < width * f->Packsize) return Fail(MPCVR_E_INVALIDARG, "pitch smaller than a row");
+    if (f->bytes == 2 && (pitch & 1)) return Fail(MPCVR_E_INVALIDARG, "16-bit formats need an even pitch");
+    CRect r = srcRect ? *srcRect : CRect();
+    if (r.IsRectNull()) r = CRect(0, 0, width, height);                        // :1821-1823
+    if (r.left < 0 || r.top < 0 || r.right > width || r.bottom > height || r.Width() <= 0 || r.Height() <= 0)
+        return Fail(MPCVR_E_INVALIDARG, "source rect outside the frame");
+
+    m_srcParams = f;
+    m_srcWidth = width; m_srcHeight = height;
+    m_srcPitch = pitch;
+    m_srcLines = SourceLines(*f, height);
+    m_srcRect = r;
+    m_srcRectWidth = r.Width(); m_srcRectHeight = r.Height();
+    m_decExFmt.value = extfmt;
+    m_srcExFmt = SpecifyExtendedFormat(m_decExFmt, *f, m_srcRectWidth, m_srcRectHeight);   // :1827
+    m_blobOverride = false;
+    if (m_videoRect.IsRectNull()) m_videoRect = CRect(0, 0, m_srcRectWidth, m_srcRectHeight);
+    if (m_windowRect.IsRectNull()) m_windowRect = CRect(0, 0, m_videoRect.right, m_videoRect.bottom);
+    SetShaderConvertColorParams();
+    SetShaderLuminanceParams();
+    m_curSample = nullptr;
+    m_planDirty = true;
+    return MPCVR_S_OK;
+}
+
+void CHipVideoProcessor::SetShaderConvertColorParams()
+{
+    if (!m_srcParams || m_blobOverride) return;
+    ComputeColorMatrix(m_srcExFmt, *m_srcParams, m_procAmp, m_cm);
+    ComputeGamut2020to709(m_gamut);
+    SelectTail(m_srcExFmt, m_cfg.bConvertToSdr != 0, &m_tail, &m_gamma);
+}
+
+void CHipVideoProcessor::SetShaderLuminanceParams()
+{
+    if (m_blobOverride) return;
+    m_lumScale = 10000.0f / m_cfg.iSDRDisplayNits;                              // :891
+}
+
+HRESULT CHipVideoProcessor::SetVideoRect(const CRect &r)
+{
+    if (r.Width() <= 0 || r.Height() <= 0) return Fail(MPCVR_E_INVALIDARG, "empty video rect");
+    if (r != m_videoRect) { m_videoRect = r; m_planDirty = true; }
+    return MPCVR_S_OK;
+}
+
+HRESULT CHipVideoProcessor::SetWindowRect(const CRect &r)
+{
+    if (r.Width() <= 0 || r.Height() <= 0) return Fail(MPCVR_E_INVALIDARG, "empty window rect");
+    const CRect w(0, 0, r.Width(), r.Height());
+    if (w != m_windowRect) { m_windowRect = w; m_planDirty = true; }
+    return MPCVR_S_OK;
+}
+
+HRESULT CHipVideoProcessor::SetRotation(int value)
+{
+    if (value != 0) return Fail(MPCVR_E_NOTIMPL, "rotation is not implemented in this build");
+    m_iRotation = 0;
+    return MPCVR_S_OK;
+}
+
+HRESULT CHipVideoProcessor::SetFlip(bool value)
+{
+    if (value) return Fail(MPCVR_E_NOTIMPL, "flip is not implemented in this build");
+    m_bFlip = false;
+    return MPCVR_S_OK;
+}
+
+// Configure — DX11VideoProcessor.cpp:3800-4050: diff, then rebuild only what changed
+HRESULT CHipVideoProcessor::Configure(const mpcvr_settings &c)
+{
+    if (!m_bInit) return Fail(MPCVR_E_NOT_VALID_STATE, "not initialised");
+    std::string why;
+    if (!ValidSettings(c, &why)) return Fail(MPCVR_E_INVALIDARG, "invalid settings: " + why);
+    if (c.bDeintBlend) return Fail(MPCVR_E_NOTIMPL, "bDeintBlend: interlaced blend is not implemented");
+    bool changeConvertShader = false, changeLuminance = false, changePlan = false;
+    if (c.iTexFormat != m_cfg.iTexFormat) changePlan = true;
+    if (c.iChromaScaling != m_cfg.iChromaScaling) changeConvertShader = true;
+    if (c.iUpscaling != m_cfg.iUpscaling || c.iDownscaling != m_cfg.iDownscaling ||
+        c.bInterpolateAt50pct != m_cfg.bInterpolateAt50pct) changePlan = true;
+    if (c.bUseDither != m_cfg.bUseDither || c.output_format != m_cfg.output_format || c.flags != m_cfg.flags) changePlan = true;
+    if (c.bConvertToSdr != m_cfg.bConvertToSdr) changeConvertShader = true;
+    if (c.iSDRDisplayNits != m_cfg.iSDRDisplayNits) changeLuminance = true;
+    m_cfg = c;
+    if (changeConvertShader || changeLuminance) m_blobOverride = false;
+    if (changeConvertShader) { SetShaderConvertColorParams(); changePlan = true; }
+    if (changeLuminance) { SetShaderLuminanceParams(); changePlan = true; }
+    if (changePlan) m_planDirty = true;
+    return (changeConvertShader || changeLuminance || changePlan) ? MPCVR_S_OK : MPCVR_S_FALSE;
+}
+
+// SetProcAmpValues — DX11VideoProcessor.cpp:4506-4537 (clamped to the ranges of Helper.cpp:182-187)
+HRESULT CHipVideoProcessor::SetProcAmpValues(uint32_t flags, float b, float c, float h, float s)
+{
+    auto clampf = [](float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    if (flags & MPCVR_PROCAMP_BRIGHTNESS) m_procAmp.brightness = clampf(b, -100.f, 100.f);
+    if (flags & MPCVR_PROCAMP_CONTRAST) m_procAmp.contrast = clampf(c, 0.f, 2.f);
+    if (flags & MPCVR_PROCAMP_HUE) m_procAmp.hue = clampf(h, -180.f, 180.f);
+    if (flags & MPCVR_PROCAMP_SATURATION) m_procAmp.saturation = clampf(s, 0.f, 2.f);
+    m_blobOverride = false;
+    SetShaderConvertColorParams();
+    m_planDirty = true;
+    return MPCVR_S_OK;
+}
+
+static size_t SurfBytesPerPixel(int fmt) { return fmt == SF_RGBA16F ? 8 : 4; }
+
+HRESULT CHipVideoProcessor::UploadTaps(const HostAxisTaps &h, DevBuffer &bi, DevBuffer &bw, DevBuffer &bs, AxisTaps *out)
+{
+    HRESULT hr;
+    if ((hr = CheckHip(bi.CheckCreate(h.idx.size() * sizeof(int32_t)), "taps alloc"))) return hr;
+    if ((hr = CheckHip(bw.CheckCreate(h.w.size() * sizeof(float)), "taps alloc"))) return hr;
+    if ((hr = CheckHip(hipMemcpy(bi.ptr, h.idx.data(), h.idx.size() * sizeof(int32_t), hipMemcpyHostToDevice), "taps upload"))) return hr;
+    if ((hr = CheckHip(hipMemcpy(bw.ptr, h.w.data(), h.w.size() * sizeof(float), hipMemcpyHostToDevice), "taps upload"))) return hr;
+    out->idx = (const int32_t *)bi.ptr; out->w = (const float *)bw.ptr; out->wsum = nullptr;
+    if (h.normalise) {
+        if ((hr = CheckHip(bs.CheckCreate(h.wsum.size() * sizeof(float)), "taps alloc"))) return hr;
+        if ((hr = CheckHip(hipMemcpy(bs.ptr, h.wsum.data(), h.wsum.size() * sizeof(float), hipMemcpyHostToDevice), "taps upload"))) return hr;
+        out->wsum = (const float *)bs.ptr;
+    }
+    out->ntaps = h.ntaps; out->normalise = h.normalise;
+    return MPCVR_S_OK;
+}
+
+HRESULT CHipVideoProcessor::UploadIndex(const std::vector<int32_t> &v, DevBuffer &b)
+{
+    HRESULT hr;
+    if ((hr = CheckHip(b.CheckCreate(v.size() * sizeof(int32_t)), "index alloc"))) return hr;
+    return CheckHip(hipMemcpy(b.ptr, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice), "index upload");
+}
+
+// UpdateTexures (:2869-2892) + UpdatePostScaleTexures (:2894-2912) + the per-axis shader choice of
+// ResizeShaderPass (:3103-3133), evaluated once per geometry/settings change instead of per frame.
+HRESULT CHipVideoProcessor::UpdatePlan()
+{
+    if (!m_srcParams) return Fail(MPCVR_E_NOT_VALID_STATE, "InitMediaType has not been called");
+    (void)hipSetDevice(m_device);
+    (void)hipStreamSynchronize(m_stream);    // resources below may still be in use
+    const int w1 = m_srcRectWidth, h1 = m_srcRectHeight;
+    const int w2 = m_videoRect.Width(), h2 = m_videoRect.Height();
+    {
+        const PlanGeometry g{w1, h1, m_videoRect.left, m_videoRect.top, m_videoRect.right, m_videoRect.bottom,
+                             m_windowRect.Width(), m_windowRect.Height()};
+        std::string why;
+        if (!DecidePlan(m_cfg.iTexFormat, m_cfg.iChromaScaling, m_cfg.iUpscaling, m_cfg.iDownscaling,
+                        m_cfg.bInterpolateAt50pct, m_cfg.bUseDither, m_cfg.output_format, m_cfg.flags,
+                        *m_srcParams, g, &m_plan, &why))
+            return Fail(MPCVR_E_NOTIMPL, why);
+    }
+
+    HRESULT hr;
+    // m_TexConvertOutput: srcRect-sized, internal format (:2889-2890)
+    const size_t convPitch = (size_t)w1 * SurfBytesPerPixel(m_plan.internal_fmt);
+    if ((hr = CheckHip(m_TexConvertOutput.CheckCreate(convPitch * h1), "m_TexConvertOutput"))) return hr;
+
+    HostAxisTaps hx, hy;
+    std::vector<int32_t> ox, oy;
+    if (m_plan.two_pass) {
+        // m_TexResize: fp16, dst width x src height (:3143-3160)
+        if ((hr = CheckHip(m_TexResize.CheckCreate((size_t)w2 * 8 * h1), "m_TexResize"))) return hr;
+        if (!BuildAxisTaps(m_plan.rx, 0, w1, w2, w1, m_cfg.flags, &hx) ||
+            !BuildAxisTaps(m_plan.ry, 0, h1, h2, h1, m_cfg.flags, &hy))
+            return Fail(MPCVR_E_NOTIMPL, "resize ratio outside the supported range");
+        BuildPointIndex(0, h1, h1, h1, &ox);     // X pass: rows map 1:1
+        BuildPointIndex(0, w2, w2, w2, &oy);     // Y pass: columns map 1:1
+        if ((hr = UploadTaps(hx, m_tapsXi, m_tapsXw, m_tapsXs, &m_tapsX))) return hr;
+        if ((hr = UploadTaps(hy, m_tapsYi, m_tapsYw, m_tapsYs, &m_tapsY))) return hr;
+        if ((hr = UploadIndex(ox, m_otherX))) return hr;
+        if ((hr = UploadIndex(oy, m_otherY))) return hr;
+    } else if (m_plan.one_pass) {
+        if (m_plan.one_pass_axis == 0) {
+            if (!BuildAxisTaps(m_plan.rx, 0, w1, w2, w1, m_cfg.flags, &hx)) return Fail(MPCVR_E_NOTIMPL, "resize ratio outside the supported range");
+            BuildPointIndex(0, h1, h2, h1, &ox);
+            if ((hr = UploadTaps(hx, m_tapsXi, m_tapsXw, m_tapsXs, &m_tapsX))) return hr;
+            if ((hr = UploadIndex(ox, m_otherX))) return hr;
+        } else {
+            if (!BuildAxisTaps(m_plan.ry, 0, h1, h2, h1, m_cfg.flags, &hy)) return Fail(MPCVR_E_NOTIMPL, "resize ratio outside the supported range");
+            BuildPointIndex(0, w1, w2, w1, &oy);
+            if ((hr = UploadTaps(hy, m_tapsYi, m_tapsYw, m_tapsYs, &m_tapsY))) return hr;
+            if ((hr = UploadIndex(oy, m_otherY))) return hr;
+        }
+    }
+
+    if (m_plan.fused_up2x) {
+        if (!m_blobOverride || m_upX.ntaps == 0) {
+            float w[6];
+            const int n = UpscaleWeights(m_cfg.iUpscaling, 0.75f, w);
+            m_upX.ntaps = n; std::memset(m_upX.w_even, 0, sizeof(m_upX.w_even)); std::memset(m_upX.w_odd, 0, sizeof(m_upX.w_odd));
+            std::memcpy(m_upX.w_even, w, sizeof(float) * n);
+            UpscaleWeights(m_cfg.iUpscaling, 0.25f, w);
+            std::memcpy(m_upX.w_odd, w, sizeof(float) * n);
+            m_upX.q1_quirk = (n == 6 && !(m_cfg.flags & MPCVR_FLAG_LANCZOS3_FIXED)) ? 1 : 0;
+            m_upY = m_upX;
+        }
+        if (m_tail == TAIL_PQ_TO_SDR) {
+            if (!m_blobOverride) BuildPqSdrLut(m_lumScale, m_pqLutHost);
+            if ((hr = CheckHip(m_pqLut.CheckCreate(sizeof(m_pqLutHost)), "pq lut"))) return hr;
+            if ((hr = CheckHip(hipMemcpy(m_pqLut.ptr, m_pqLutHost, sizeof(m_pqLutHost), hipMemcpyHostToDevice), "pq lut upload"))) return hr;
+            m_pqLutValid = true;
+        } else {
+            m_pqLutValid = false;
+        }
+        FusedParams fp{};
+        FillFusedParams(nullptr, nullptr, 0, &fp);
+        m_plan.fused_up2x = FusedUp2xSupported(fp);
+    }
+    m_planDirty = false;
+    return MPCVR_S_OK;
+}
+
+void CHipVideoProcessor::FillConvertParams(const uint8_t *sample, ConvertParams *P) const
+{
+    const FmtConvParams &f = *m_srcParams;
+    std::memset(P, 0, sizeof(*P));
+    // plane walk of MemCopyToTexSrcVideo — DX11VideoProcessor.cpp:1213-1252
+    const int cromaH = m_srcHeight / f.div_h;
+    const int cromaPitch = (f.planes == 3) ? m_srcPitch / f.div_w : m_srcPitch;
+    P->plane[0] = sample;
+    P->plane[1] = sample ? sample + (size_t)m_srcPitch * m_srcHeight : nullptr;
+    P->plane[2] = sample ? P->plane[1] + (size_t)cromaPitch * cromaH : nullptr;
+    P->pitch[0] = m_srcPitch; P->pitch[1] = cromaPitch; P->pitch[2] = cromaPitch;
+    P->tex_w = m_srcWidth; P->tex_h = m_srcHeight;
+    P->cw = m_srcWidth / f.div_w; P->ch = cromaH;
+    P->rect_l = m_srcRect.left; P->rect_t = m_srcRect.top;
+    P->out_w = m_srcRectWidth; P->out_h = m_srcRectHeight;
+    P->fmt.planes = f.planes; P->fmt.bytes = f.bytes; P->fmt.div_w = f.div_w; P->fmt.div_h = f.div_h;
+    P->fmt.shift = f.shift; P->fmt.v_first = f.v_first; P->fmt.subsampling = f.Subsampling; P->fmt.cdepth = f.CDepth;
+    P->chroma_scaling = m_cfg.iChromaScaling;
+    switch (m_srcExFmt.VideoChromaSubsampling()) {          // Shaders.cpp:121-137
+    case 7: P->chroma_loc = CLOC_COSITED; break;
+    case 1: P->chroma_loc = CLOC_MPEG1; break;
+    default: P->chroma_loc = CLOC_MPEG2; break;
+    }
+    P->tail = m_tail; P->gamma = m_gamma;
+    std::memcpy(P->cm, m_cm, sizeof(m_cm));
+    P->lum_scale = m_lumScale;
+    std::memcpy(P->gamut, m_gamut, sizeof(m_gamut));
+    P->out_fmt = m_plan.internal_fmt;
+}
+
+StoreParams CHipVideoProcessor::MakeStore(void *dst, int pitch, int dstFmt, bool rt) const
+{
+    StoreParams s{};
+    s.dst = dst; s.dst_pitch = pitch; s.dst_fmt = dstFmt;
+    s.mode = ST_SURFACE; s.mid_fmt = m_plan.internal_fmt; s.quant = m_plan.quant;
+    s.dither = (const uint16_t *)m_dither.ptr;
+    if (rt) {
+        s.off_x = m_videoRect.left; s.off_y = m_videoRect.top;
+        s.clip_w = m_windowRect.Width(); s.clip_h = m_windowRect.Height();
+        if (m_plan.final_pass) s.mode = ST_FINAL;
+    }
+    return s;
+}
+
+void CHipVideoProcessor::FillFusedParams(const uint8_t *sample, void *rt, int rtPitch, FusedParams *fp) const
+{
+    FillConvertParams(sample, &fp->conv);
+    fp->plane_off[0] = 0;
+    fp->plane_off[1] = (size_t)m_srcPitch * m_srcHeight;
+    fp->plane_off[2] = fp->plane_off[1] + (size_t)fp->conv.pitch[1] * fp->conv.ch;
+    fp->wx = m_upX; fp->wy = m_upY;
+    fp->out_w = m_videoRect.Width(); fp->out_h = m_videoRect.Height();
+    fp->store = MakeStore(rt, rtPitch, m_plan.swap_fmt, true);
+    const bool no_lut = (m_cfg.flags & MPCVR_FLAG_NO_LUT) != 0;
+    fp->pq_lut = (m_pqLutValid && !no_lut) ? (const float *)m_pqLut.ptr : nullptr;
+    // vectorised convert: dword loads need 4-byte aligned rows and a source rect starting on a 4-px boundary
+    fp->fast_convert = (m_srcRect.left % 4 == 0) && (m_srcRect.top % 2 == 0) && (m_srcPitch % 4 == 0) &&
+                       (fp->conv.pitch[1] % 4 == 0) && (fp->plane_off[1] % 4 == 0) && (fp->plane_off[2] % 4 == 0) &&
+                       !(m_cfg.flags & MPCVR_FLAG_NO_FAST_CONVERT);
+}
+
+// ------------------------------------------------------------------------------------------------
+// CopySample — DX11VideoProcessor.cpp:2202-2597 (memory branch -> MemCopyToTexSrcVideo :1213-1252)
+// ------------------------------------------------------------------------------------------------
+HRESULT CHipVideoProcessor::CopySample(const void *data, int pitch, int memKind)
+{
+    if (!m_bInit || !m_srcParams) return Fail(MPCVR_E_NOT_VALID_STATE, "InitMediaType has not been called");
+    if (!data) return Fail(MPCVR_E_POINTER, "null sample");
+    if (pitch != m_srcPitch) return Fail(MPCVR_E_UNEXPECTED, "sample pitch differs from the media type");   // :2545
+    (void)hipSetDevice(m_device);
+    const size_t bytes = (size_t)m_srcPitch * m_srcLines;
+    if (memKind == MPCVR_MEM_DEVICE) {               // zero-copy, cf. the IMediaSampleD3D11 branch :2528-2569
+        m_curSample = (const uint8_t *)data;
+        return MPCVR_S_OK;
+    }
+    if (memKind != MPCVR_MEM_HOST) return Fail(MPCVR_E_INVALIDARG, "mem_kind");
+    HRESULT hr;
+    if ((hr = CheckHip(m_TexSrcVideo.CheckCreate(bytes), "m_TexSrcVideo"))) return hr;
+    if (m_pinnedSize < bytes) {
+        if (m_pinned) (void)hipHostFree(m_pinned);
+        m_pinned = nullptr; m_pinnedSize = 0;
+        if ((hr = CheckHip(hipHostMalloc(&m_pinned, bytes, hipHostMallocDefault), "pinned staging"))) return hr;
+        m_pinnedSize = bytes;
+    }
+    // the staging buffer may still feed the previous upload
+    if ((hr = CheckHip(hipStreamSynchronize(m_stream), "sync before staging"))) return hr;
+    std::memcpy(m_pinned, data, bytes);              // CopyPlaneAsIs (Helper.cpp:414-428); the <<6 of CopyPlane10to16 happens at load
+    if ((hr = CheckHip(hipMemcpyAsync(m_TexSrcVideo.ptr, m_pinned, bytes, hipMemcpyHostToDevice, m_stream), "upload"))) return hr;
+    m_curSample = (const uint8_t *)m_TexSrcVideo.ptr;
+    return MPCVR_S_OK;
+}
+
+HRESULT CHipVideoProcessor::ConvertColorPass(const uint8_t *sample)
+{
+    ConvertParams P;
+    FillConvertParams(sample, &P);
+    Surface out{m_TexConvertOutput.ptr, (int)(m_srcRectWidth * SurfBytesPerPixel(m_plan.internal_fmt)),
+                m_srcRectWidth, m_srcRectHeight, m_plan.internal_fmt};
+    return CheckHip(LaunchConvert(P, out, m_stream), "k_convert");
+}
+
+// ResizeShaderPass (:3103-3187) with FinalPass (:3189-3233) folded into the epilogue of the last draw
+HRESULT CHipVideoProcessor::ResizeShaderPass(void *rt, int rtPitch)
+{
+    const int w1 = m_srcRectWidth, h1 = m_srcRectHeight, w2 = m_videoRect.Width(), h2 = m_videoRect.Height();
+    Surface conv{m_TexConvertOutput.ptr, (int)(w1 * SurfBytesPerPixel(m_plan.internal_fmt)), w1, h1, m_plan.internal_fmt};
+    const StoreParams last = MakeStore(rt, rtPitch, m_plan.swap_fmt, true);
+    HRESULT hr;
+    if (m_plan.two_pass) {
+        Surface mid{m_TexResize.ptr, w2 * 8, w2, h1, SF_RGBA16F};
+        StoreParams st = MakeStore(mid.ptr, mid.pitch, SF_RGBA16F, false);
+        if ((hr = CheckHip(LaunchResize(0, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, h1, st, m_stream), "k_resize<X>"))) return hr;
+        return CheckHip(LaunchResize(1, mid, m_tapsY, (const int32_t *)m_otherY.ptr, w2, h2, last, m_stream), "k_resize<Y>");
+    }
+    if (m_plan.one_pass) {
+        if (m_plan.one_pass_axis == 0)
+            return CheckHip(LaunchResize(0, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, h2, last, m_stream), "k_resize<X>");
+        return CheckHip(LaunchResize(1, conv, m_tapsY, (const int32_t *)m_otherY.ptr, w2, h2, last, m_stream), "k_resize<Y>");
+    }
+    return CheckHip(LaunchCopy(conv, w2, h2, last, m_stream), "k_copy");
+}
+
+HRESULT CHipVideoProcessor::ProcessOne(const uint8_t *sample, void *rt, int rtPitch)
+{
+    HRESULT hr;
+    if (m_plan.fused_up2x) {
+        FusedParams fp{};
+        FillFusedParams(sample, rt, rtPitch, &fp);
+        if (((uintptr_t)sample & 3) != 0) fp.fast_convert = 0;
+        const FusedFrame fr{sample, rt};        // a single frame travels by value in the kernel arguments
+        return CheckHip(LaunchFusedUp2x(fp, nullptr, fr, 1, m_stream), "k_fused_up2x");
+    }
+    if ((hr = ConvertColorPass(sample))) return hr;
+    return ResizeShaderPass(rt, rtPitch);
+}
+
+// Process — DX11VideoProcessor.cpp:3285-3424
+HRESULT CHipVideoProcessor::Process(void *pRenderTarget, int rtPitch, const CRect *srcRect, const CRect *dstRect, bool /*second*/)
+{
+    if (!m_bInit || !m_srcParams) return Fail(MPCVR_E_NOT_VALID_STATE, "InitMediaType has not been called");
+    if (!pRenderTarget) return Fail(MPCVR_E_POINTER, "null render target");
+    if (!m_curSample) return Fail(MPCVR_E_NOT_VALID_STATE, "no sample: call CopySample first");
+    if (srcRect && !srcRect->IsRectNull() && *srcRect != m_srcRect)
+        return Fail(MPCVR_E_INVALIDARG, "src_rect must equal the input's source rect");
+    (void)hipSetDevice(m_device);
+    HRESULT hr;
+    if (dstRect && !dstRect->IsRectNull()) { if ((hr = SetVideoRect(*dstRect))) return hr; }
+    if (rtPitch < m_windowRect.Width() * 4) return Fail(MPCVR_E_INVALIDARG, "render-target pitch smaller than a row");
+    if (m_planDirty && (hr = UpdatePlan())) return hr;
+    (void)hipEventRecord(m_evStart, m_stream);
+    hr = ProcessOne(m_curSample, pRenderTarget, rtPitch);
+    (void)hipEventRecord(m_evStop, m_stream);
+    m_timed = true;
+    return hr;
+}
+
+HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *const *dsts, int rtPitch)
+{
+    if (!m_bInit || !m_srcParams) return Fail(MPCVR_E_NOT_VALID_STATE, "InitMediaType has not been called");
+    if (n <= 0 || !srcs || !dsts) return Fail(MPCVR_E_INVALIDARG, "empty batch");
+    if (rtPitch < m_windowRect.Width() * 4) return Fail(MPCVR_E_INVALIDARG, "render-target pitch smaller than a row");
+    (void)hipSetDevice(m_device);
+    HRESULT hr;
+    if (m_planDirty && (hr = UpdatePlan())) return hr;
+    for (int i = 0; i < n; i++)
+        if (!srcs[i] || !dsts[i]) return Fail(MPCVR_E_POINTER, "null frame in batch");
+    if (!m_plan.fused_up2x) {
+        (void)hipEventRecord(m_evStart, m_stream);
+        for (int i = 0; i < n; i++)
+            if ((hr = ProcessOne((const uint8_t *)srcs[i], dsts[i], rtPitch))) return hr;
+        (void)hipEventRecord(m_evStop, m_stream);
+        m_timed = true;
+        return MPCVR_S_OK;
+    }
+    // one launch for the whole batch
+    if ((size_t)n > m_framesPinnedCount) {
+        if (m_framesPinned) (void)hipHostFree(m_framesPinned);
+        m_framesPinned = nullptr; m_framesPinnedCount = 0;
+        if ((hr = CheckHip(hipHostMalloc(&m_framesPinned, sizeof(FusedFrame) * n, hipHostMallocDefault), "frames pinned"))) return hr;
+        m_framesPinnedCount = n;
+    }
+    if ((hr = CheckHip(m_frames.CheckCreate(sizeof(FusedFrame) * (size_t)(n < 64 ? 64 : n)), "frames"))) return hr;
+    if ((hr = CheckHip(hipStreamSynchronize(m_stream), "sync before frame table"))) return hr;
+    FusedFrame *fr = (FusedFrame *)m_framesPinned;
+    for (int i = 0; i < n; i++) { fr[i].src = (const uint8_t *)srcs[i]; fr[i].dst = dsts[i]; }
+    if ((hr = CheckHip(hipMemcpyAsync(m_frames.ptr, fr, sizeof(FusedFrame) * n, hipMemcpyHostToDevice, m_stream), "frame table"))) return hr;
+    FusedParams fp{};
+    FillFusedParams((const uint8_t *)srcs[0], nullptr, rtPitch, &fp);
+    for (int i = 0; i < n; i++)
+        if (((uintptr_t)srcs[i] & 3) != 0) fp.fast_convert = 0;
+    (void)hipEventRecord(m_evStart, m_stream);
+    hr = CheckHip(LaunchFusedUp2x(fp, (const FusedFrame *)m_frames.ptr, FusedFrame{nullptr, nullptr}, n, m_stream), "k_fused_up2x");
+    (void)hipEventRecord(m_evStop, m_stream);
+    m_timed = true;
+    return hr;
+}
+
+// Render minus Present — DX11VideoProcessor.cpp:2599-2813
+HRESULT CHipVideoProcessor::Render(int /*field*/)
+{
+    if (!m_bInit || !m_srcParams) return Fail(MPCVR_E_NOT_VALID_STATE, "InitMediaType has not been called");
+    if (!m_curSample) return MPCVR_S_FALSE;          // nothing to draw (cf. :2603-2606)
+    (void)hipSetDevice(m_device);
+    const int w = m_windowRect.Width(), h = m_windowRect.Height();
+    const size_t bytes = (size_t)w * 4 * h;
+    HRESULT hr;
+    const bool fresh = m_BackBuffer.size < bytes || !m_BackBuffer.ptr;
+    if ((hr = CheckHip(m_BackBuffer.CheckCreate(bytes), "back buffer"))) return hr;
+    // ClearRenderTargetView to black (:2622) — only the letterbox area survives Process
+    if (fresh || m_videoRect != CRect(0, 0, w, h))
+        if ((hr = CheckHip(hipMemsetAsync(m_BackBuffer.ptr, 0, bytes, m_stream), "clear"))) return hr;
+    return Process(m_BackBuffer.ptr, w * 4, nullptr, nullptr, false);
+}
+
+HRESULT CHipVideoProcessor::GetBackBuffer(void **ptr, int *pitch, int *w, int *h)
+{
+    if (!m_BackBuffer.ptr) return Fail(MPCVR_E_NOT_VALID_STATE, "Render has not been called");
+    if (ptr) *ptr = m_BackBuffer.ptr;
+    if (pitch) *pitch = m_windowRect.Width() * 4;
+    if (w) *w = m_windowRect.Width();
+    if (h) *h = m_windowRect.Height();
+    return MPCVR_S_OK;
+}
+
+// GetCurentImage — DX11VideoProcessor.cpp:3493-3608
+HRESULT CHipVideoProcessor::GetCurentImage(void *hostBGRA, size_t *size)
+{
+    if (!size) return Fail(MPCVR_E_POINTER, "null size");
+    if (!m_bInit || !m_srcParams) return Fail(MPCVR_E_NOT_VALID_STATE, "InitMediaType has not been called");
+    const int w = m_srcRectWidth, h = m_srcRectHeight;      // no anamorphic / rotation support here
+    const size_t need = (size_t)w * 4 * h;
+    if (!hostBGRA) { *size = need; return MPCVR_S_OK; }
+    if (*size < need) { *size = need; return Fail(MPCVR_E_INVALIDARG, "buffer too small"); }
+    if (!m_curSample) return Fail(MPCVR_E_NOT_VALID_STATE, "no sample");
+    (void)hipSetDevice(m_device);
+    HRESULT hr;
+    if ((hr = CheckHip(m_Snapshot.CheckCreate(need), "snapshot"))) return hr;
+    // temporarily point video/window rect at the image (:3549-3553), B8G8R8X8 target (:3518)
+    const CRect backupVid = m_videoRect, backupWnd = m_windowRect;
+    const int backupOut = m_cfg.output_format;
+    m_videoRect = CRect(0, 0, w, h); m_windowRect = m_videoRect; m_cfg.output_format = MPCVR_OUT_BGRA8;
+    m_planDirty = true;
+    hr = Process(m_Snapshot.ptr, w * 4, nullptr, nullptr, false);
+    m_videoRect = backupVid; m_windowRect = backupWnd; m_cfg.output_format = backupOut;
+    m_planDirty = true;
+    if (hr) return hr;
+    if ((hr = CheckHip(hipMemcpyAsync(hostBGRA, m_Snapshot.ptr, need, hipMemcpyDeviceToHost, m_stream), "readback"))) return hr;
+    if ((hr = CheckHip(hipStreamSynchronize(m_stream), "readback sync"))) return hr;
+    *size = need;
+    return MPCVR_S_OK;
+}
+
+void CHipVideoProcessor::Flush()
+{
+    if (m_bInit) { (void)hipSetDevice(m_device); (void)hipStreamSynchronize(m_stream); }
+    m_curSample = nullptr;
+}
+
+HRESULT CHipVideoProcessor::Reset()
+{
+    Flush();
+    m_planDirty = true;
+    return MPCVR_S_OK;
+}
+
+HRESULT CHipVideoProcessor::GetParamBlob(void *buf, size_t *size)
+{
+    if (!size) return Fail(MPCVR_E_POINTER, "null size");
+    if (!m_srcParams) return Fail(MPCVR_E_NOT_VALID_STATE, "InitMediaType has not been called");
+    if (!buf) { *size = sizeof(ParamBlob); return MPCVR_S_OK; }
+    if (*size < sizeof(ParamBlob)) { *size = sizeof(ParamBlob); return Fail(MPCVR_E_INVALIDARG, "buffer too small"); }
+    HRESULT hr;
+    if (m_planDirty && (hr = UpdatePlan())) return hr;
+    ParamBlob b{};
+    b.magic = kBlobMagic; b.version = 1;
+    std::memcpy(b.cm, m_cm, sizeof(m_cm));
+    b.lum_scale = m_lumScale;
+    std::memcpy(b.gamut, m_gamut, sizeof(m_gamut));
+    b.tail = m_tail; b.gamma = m_gamma;
+    b.upx = m_upX; b.upy = m_upY;
+    std::memcpy(b.dither, m_ditherHost, sizeof(m_ditherHost));
+    if (m_tail == TAIL_PQ_TO_SDR) BuildPqSdrLut(m_lumScale, b.pq_lut);
+    std::memcpy(buf, &b, sizeof(b));
+    *size = sizeof(b);
+    return MPCVR_S_OK;
+}
+
+HRESULT CHipVideoProcessor::SetParamBlob(const void *buf, size_t size)
+{
+    if (!buf) return Fail(MPCVR_E_POINTER, "null blob");
+    if (size < sizeof(ParamBlob)) return Fail(MPCVR_E_INVALIDARG, "blob too small");
+    if (!m_bInit || !m_srcParams) return Fail(MPCVR_E_NOT_VALID_STATE, "InitMediaType has not been called");
+    ParamBlob b;
+    std::memcpy(&b, buf, sizeof(b));
+    if (b.magic != kBlobMagic || b.version != 1) return Fail(MPCVR_E_INVALIDARG, "bad blob magic/version");
+    (void)hipSetDevice(m_device);
+    std::memcpy(m_cm, b.cm, sizeof(m_cm));
+    m_lumScale = b.lum_scale;
+    std::memcpy(m_gamut, b.gamut, sizeof(m_gamut));
+    m_tail = b.tail; m_gamma = b.gamma;
+    m_upX = b.upx; m_upY = b.upy;
+    std::memcpy(m_ditherHost, b.dither, sizeof(m_ditherHost));
+    std::memcpy(m_pqLutHost, b.pq_lut, sizeof(m_pqLutHost));
+    HRESULT hr;
+    if ((hr = CheckHip(hipStreamSynchronize(m_stream), "sync"))) return hr;
+    if ((hr = CheckHip(hipMemcpy(m_dither.ptr, m_ditherHost, sizeof(m_ditherHost), hipMemcpyHostToDevice), "dither upload"))) return hr;
+    m_blobOverride = true;
+    m_planDirty = true;
+    return MPCVR_S_OK;
+}
+
+HRESULT CHipVideoProcessor::GetColorMatrix(float out[12])
+{
+    if (!m_srcParams) return Fail(MPCVR_E_NOT_VALID_STATE, "InitMediaType has not been called");
+    std::memcpy(out, m_cm, sizeof(m_cm));
+    return MPCVR_S_OK;
+}
+
+HRESULT CHipVideoProcessor::GetExtFmt(uint32_t *v)
+{
+    if (!m_srcParams) return Fail(MPCVR_E_NOT_VALID_STATE, "InitMediaType has not been called");
+    *v = m_srcExFmt.value;
+    return MPCVR_S_OK;
+}
+
+HRESULT CHipVideoProcessor::GetFrameBytes(size_t *bytes, int *pitch)
+{
+    if (!m_srcParams) return Fail(MPCVR_E_NOT_VALID_STATE, "InitMediaType has not been called");
+    if (bytes) *bytes = (size_t)m_srcPitch * m_srcLines;
+    if (pitch) *pitch = m_srcPitch;
+    return MPCVR_S_OK;
+}
+
+std::string CHipVideoProcessor::GetPathInfo()
+{
+    if (!m_srcParams) return "uninitialised";
+    if (m_planDirty && UpdatePlan() != MPCVR_S_OK) return "error: " + m_lastError;
+    return m_plan.describe();
+}
+
+HRESULT CHipVideoProcessor::GetLastProcessMs(float *ms)
+{
+    if (!ms) return Fail(MPCVR_E_POINTER, "null");
+    if (!m_timed) return Fail(MPCVR_E_NOT_VALID_STATE, "nothing timed yet");
+    (void)hipSetDevice(m_device);
+    HRESULT hr;
+    if ((hr = CheckHip(hipEventSynchronize(m_evStop), "event sync"))) return hr;
+    return CheckHip(hipEventElapsedTime(ms, m_evStart, m_evStop), "event elapsed");
+}
+
+}  // namespace mpcvr

@@ -1,0 +1,145 @@
+// hip_video_processor.h — CHipVideoProcessor: the MI355X-native stand-in for the shader path of
+// CDX11VideoProcessor (Source/DX11VideoProcessor.h:256-384).  Method names follow the reference's
+// so the call sites in CMpcVideoRenderer map one-to-one; the D3D11 device/swap-chain/OSD/subtitle
+// members have no counterpart here (out of scope).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mpcvr.h"
+#include "vp_launch.h"
+#include "vp_params.h"
+#include "vp_plan.h"
+
+namespace mpcvr {
+
+typedef int32_t HRESULT;
+
+struct CRect {
+    int left = 0, top = 0, right = 0, bottom = 0;
+    CRect() = default;
+    CRect(int l, int t, int r, int b) : left(l), top(t), right(r), bottom(b) {}
+    int Width() const { return right - left; }
+    int Height() const { return bottom - top; }
+    bool IsRectNull() const { return !left && !top && !right && !bottom; }
+    bool operator==(const CRect &o) const { return left == o.left && top == o.top && right == o.right && bottom == o.bottom; }
+    bool operator!=(const CRect &o) const { return !(*this == o); }
+};
+
+// device allocation that only grows (CheckCreate analogue of Tex2D_t, DX11Helper.h:37-90)
+struct DevBuffer {
+    void *ptr = nullptr;
+    size_t size = 0;
+    hipError_t CheckCreate(size_t bytes);
+    void Release();
+};
+
+class CHipVideoProcessor {
+public:
+    CHipVideoProcessor();
+    ~CHipVideoProcessor();
+
+    HRESULT Init(int device, const mpcvr_settings &settings);                 // ctor + Init (:381,547)
+    HRESULT SetStream(hipStream_t s);
+    HRESULT Synchronize();
+
+    HRESULT InitMediaType(int cformat, int width, int height, int pitch, const CRect *srcRect, uint32_t extfmt); // :1742
+    HRESULT SetVideoRect(const CRect &videoRect);                             // :3426
+    HRESULT SetWindowRect(const CRect &windowRect);                           // :3433
+    HRESULT SetRotation(int value);                                           // :4052
+    HRESULT SetFlip(bool value);                                              // VideoProcessor.h:210
+    HRESULT Configure(const mpcvr_settings &config);                          // :3800
+    HRESULT SetProcAmpValues(uint32_t flags, float b, float c, float h, float s); // :4506
+
+    HRESULT CopySample(const void *data, int pitch, int memKind);             // :2202 / MemCopyToTexSrcVideo :1213
+    HRESULT Process(void *pRenderTarget, int rtPitch, const CRect *srcRect, const CRect *dstRect, bool second); // :3285
+    HRESULT Render(int field);                                                // :2599 minus Present
+    HRESULT GetBackBuffer(void **ptr, int *pitch, int *w, int *h);
+    HRESULT GetCurentImage(void *hostBGRA, size_t *size);                     // :3493
+    HRESULT ProcessBatch(int n, const void *const *srcs, void *const *dsts, int rtPitch);
+    void Flush();                                                             // :4074
+    HRESULT Reset();                                                          // :3453
+
+    HRESULT GetParamBlob(void *buf, size_t *size);
+    HRESULT SetParamBlob(const void *buf, size_t size);
+    HRESULT GetColorMatrix(float out[12]);
+    HRESULT GetExtFmt(uint32_t *v);
+    HRESULT GetFrameBytes(size_t *bytes, int *pitch);
+    std::string GetPathInfo();
+    HRESULT GetLastProcessMs(float *ms);
+    const char *LastError() const { return m_lastError.c_str(); }
+
+private:
+    HRESULT Fail(HRESULT hr, const std::string &msg);
+    HRESULT CheckHip(hipError_t e, const char *what);
+    bool IsInit() const { return m_bInit; }
+
+    // mirrors of the reference's private helpers
+    void SetShaderConvertColorParams();                  // :813
+    void SetShaderLuminanceParams();                     // :889
+    HRESULT UpdatePlan();                                // UpdateTexures/UpdatePostScaleTexures/Update*scalingShaders
+    HRESULT ConvertColorPass(const uint8_t *sample);     // :3048
+    HRESULT ResizeShaderPass(void *rt, int rtPitch);     // :3103 (+ FinalPass :3189 fused into the last draw)
+    HRESULT ProcessOne(const uint8_t *sample, void *rt, int rtPitch);
+    HRESULT UploadTaps(const HostAxisTaps &h, DevBuffer &bi, DevBuffer &bw, DevBuffer &bs, AxisTaps *out);
+    HRESULT UploadIndex(const std::vector<int32_t> &v, DevBuffer &b);
+    void FillConvertParams(const uint8_t *sample, ConvertParams *P) const;
+    StoreParams MakeStore(void *dst, int pitch, int dstFmt, bool rt) const;
+    void FillFusedParams(const uint8_t *sample, void *rt, int rtPitch, FusedParams *fp) const;
+
+    bool m_bInit = false;
+    int m_device = 0;
+    hipStream_t m_stream = nullptr;
+    bool m_ownStream = false;
+    hipEvent_t m_evStart = nullptr, m_evStop = nullptr;
+    bool m_timed = false;
+    std::string m_lastError;
+
+    // settings (Settings_t mirror)
+    mpcvr_settings m_cfg{};
+    ProcAmp m_procAmp;
+    int m_iRotation = 0;
+    bool m_bFlip = false;
+
+    // input
+    const FmtConvParams *m_srcParams = nullptr;
+    int m_srcWidth = 0, m_srcHeight = 0, m_srcPitch = 0, m_srcLines = 0;
+    CRect m_srcRect;
+    int m_srcRectWidth = 0, m_srcRectHeight = 0;
+    ExtFmt m_decExFmt{0}, m_srcExFmt{0};
+    CRect m_videoRect, m_windowRect;
+
+    // constants (PS_COLOR_TRANSFORM, PS_PARAMETERS, matrix_conv_prim)
+    float m_cm[12] = {0};
+    float m_lumScale = 80.0f;
+    float m_gamut[9] = {0};
+    int m_tail = TAIL_NONE;
+    float m_gamma = 1.0f;
+    bool m_blobOverride = false;
+
+    // plan
+    bool m_planDirty = true;
+    PassPlan m_plan;
+    Up2xWeights m_upX{}, m_upY{};
+
+    // device resources
+    DevBuffer m_TexSrcVideo;       // uploaded sample
+    void *m_pinned = nullptr;      // pinned staging for uploads
+    size_t m_pinnedSize = 0;
+    const uint8_t *m_curSample = nullptr;   // device pointer of the current sample (own buffer or zero-copy)
+    DevBuffer m_TexConvertOutput, m_TexResize, m_BackBuffer, m_Snapshot;
+    DevBuffer m_dither;
+    DevBuffer m_pqLut;             // 1024 floats (fused path tone-map table)
+    float m_pqLutHost[1024];
+    bool m_pqLutValid = false;
+    DevBuffer m_tapsXi, m_tapsXw, m_tapsXs, m_tapsYi, m_tapsYw, m_tapsYs, m_otherX, m_otherY;
+    AxisTaps m_tapsX{}, m_tapsY{};
+    DevBuffer m_frames;            // FusedFrame[n]
+    void *m_framesPinned = nullptr;
+    size_t m_framesPinnedCount = 0;
+    uint16_t m_ditherHost[1024];
+};
+
+}  // namespace mpcvr

@@ -1,0 +1,239 @@
+// mpcvr_capi.cpp — extern "C" surface of libmpcvr.so (include/mpcvr.h) over CHipVideoProcessor.
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/mpcvr.h"
+#include "hip_video_processor.h"
+
+using mpcvr::CHipVideoProcessor;
+using mpcvr::CRect;
+
+struct mpcvr_ctx {
+    CHipVideoProcessor vp;
+};
+
+static inline CRect ToRect(const mpcvr_rect *r) { return r ? CRect(r->left, r->top, r->right, r->bottom) : CRect(); }
+
+extern "C" {
+
+int32_t mpcvr_settings_default(mpcvr_settings *s)
+{   // Settings_t::SetDefault — IVideoRenderer.h:140-185
+    if (!s) return MPCVR_E_POINTER;
+    std::memset(s, 0, sizeof(*s));
+    s->iTexFormat = MPCVR_TEXFMT_AUTOINT;
+    s->iChromaScaling = MPCVR_CHROMA_Bilinear;
+    s->iUpscaling = MPCVR_UPSCALE_CatmullRom;
+    s->iDownscaling = MPCVR_DOWNSCALE_Hamming;
+    s->bInterpolateAt50pct = 1;
+    s->bUseDither = 1;
+    s->bDeintBlend = 0;
+    s->bConvertToSdr = 1;
+    s->iSDRDisplayNits = 125;
+    s->output_format = MPCVR_OUT_BGRA8;
+    s->flags = 0;
+    return MPCVR_S_OK;
+}
+
+int32_t mpcvr_create(const mpcvr_settings *settings, int32_t device, mpcvr_ctx **out)
+{
+    if (!out) return MPCVR_E_POINTER;
+    *out = nullptr;
+    mpcvr_settings def;
+    mpcvr_settings_default(&def);
+    mpcvr_ctx *ctx = new (std::nothrow) mpcvr_ctx();
+    if (!ctx) return MPCVR_E_OUTOFMEMORY;
+    const int32_t hr = ctx->vp.Init(device, settings ? *settings : def);
+    if (hr < 0) {
+        std::fprintf(stderr, "mpcvr_create: %s\n", ctx->vp.LastError());
+        delete ctx;
+        return hr;
+    }
+    *out = ctx;
+    return MPCVR_S_OK;
+}
+
+int32_t mpcvr_destroy(mpcvr_ctx *ctx)
+{
+    if (!ctx) return MPCVR_E_POINTER;
+    delete ctx;
+    return MPCVR_S_OK;
+}
+
+#define CTX_OR_FAIL() do { if (!ctx) return MPCVR_E_POINTER; } while (0)
+
+int32_t mpcvr_set_stream(mpcvr_ctx *ctx, void *hip_stream) { CTX_OR_FAIL(); return ctx->vp.SetStream((hipStream_t)hip_stream); }
+int32_t mpcvr_synchronize(mpcvr_ctx *ctx) { CTX_OR_FAIL(); return ctx->vp.Synchronize(); }
+
+int32_t mpcvr_set_input(mpcvr_ctx *ctx, int32_t cformat, int32_t width, int32_t height, int32_t pitch,
+                        const mpcvr_rect *src_rect, uint32_t extfmt)
+{
+    CTX_OR_FAIL();
+    const CRect r = ToRect(src_rect);
+    return ctx->vp.InitMediaType(cformat, width, height, pitch, src_rect ? &r : nullptr, extfmt);
+}
+
+int32_t mpcvr_set_video_rect(mpcvr_ctx *ctx, const mpcvr_rect *r) { CTX_OR_FAIL(); if (!r) return MPCVR_E_POINTER; return ctx->vp.SetVideoRect(ToRect(r)); }
+int32_t mpcvr_set_window_rect(mpcvr_ctx *ctx, const mpcvr_rect *r) { CTX_OR_FAIL(); if (!r) return MPCVR_E_POINTER; return ctx->vp.SetWindowRect(ToRect(r)); }
+int32_t mpcvr_set_rotation(mpcvr_ctx *ctx, int32_t degrees) { CTX_OR_FAIL(); return ctx->vp.SetRotation(degrees); }
+int32_t mpcvr_set_flip(mpcvr_ctx *ctx, int32_t flip) { CTX_OR_FAIL(); return ctx->vp.SetFlip(flip != 0); }
+
+int32_t mpcvr_configure(mpcvr_ctx *ctx, const mpcvr_settings *settings)
+{
+    CTX_OR_FAIL();
+    if (!settings) return MPCVR_E_POINTER;
+    return ctx->vp.Configure(*settings);
+}
+
+int32_t mpcvr_set_procamp(mpcvr_ctx *ctx, uint32_t flags, float brightness, float contrast, float hue, float saturation)
+{
+    CTX_OR_FAIL();
+    return ctx->vp.SetProcAmpValues(flags, brightness, contrast, hue, saturation);
+}
+
+int32_t mpcvr_copy_sample(mpcvr_ctx *ctx, const void *data, int32_t pitch, int32_t mem_kind)
+{
+    CTX_OR_FAIL();
+    return ctx->vp.CopySample(data, pitch, mem_kind);
+}
+
+int32_t mpcvr_process(mpcvr_ctx *ctx, void *dst_dev, int32_t dst_pitch, const mpcvr_rect *src_rect,
+                      const mpcvr_rect *dst_rect, int32_t second_field)
+{
+    CTX_OR_FAIL();
+    const CRect s = ToRect(src_rect), d = ToRect(dst_rect);
+    return ctx->vp.Process(dst_dev, dst_pitch, src_rect ? &s : nullptr, dst_rect ? &d : nullptr, second_field != 0);
+}
+
+int32_t mpcvr_render(mpcvr_ctx *ctx, int32_t field) { CTX_OR_FAIL(); return ctx->vp.Render(field); }
+
+int32_t mpcvr_get_backbuffer(mpcvr_ctx *ctx, void **dev_ptr, int32_t *pitch, int32_t *width, int32_t *height)
+{
+    CTX_OR_FAIL();
+    return ctx->vp.GetBackBuffer(dev_ptr, pitch, width, height);
+}
+
+int32_t mpcvr_get_current_image(mpcvr_ctx *ctx, void *host_bgra, size_t *size) { CTX_OR_FAIL(); return ctx->vp.GetCurentImage(host_bgra, size); }
+int32_t mpcvr_flush(mpcvr_ctx *ctx) { CTX_OR_FAIL(); ctx->vp.Flush(); return MPCVR_S_OK; }
+int32_t mpcvr_reset(mpcvr_ctx *ctx) { CTX_OR_FAIL(); return ctx->vp.Reset(); }
+
+int32_t mpcvr_process_batch(mpcvr_ctx *ctx, int32_t n, const void *const *srcs, void *const *dsts, int32_t dst_pitch)
+{
+    CTX_OR_FAIL();
+    return ctx->vp.ProcessBatch(n, srcs, dsts, dst_pitch);
+}
+
+int32_t mpcvr_get_param_blob(mpcvr_ctx *ctx, void *buf, size_t *size) { CTX_OR_FAIL(); return ctx->vp.GetParamBlob(buf, size); }
+int32_t mpcvr_set_param_blob(mpcvr_ctx *ctx, const void *buf, size_t size) { CTX_OR_FAIL(); return ctx->vp.SetParamBlob(buf, size); }
+
+int32_t mpcvr_get_color_matrix(mpcvr_ctx *ctx, float out12[12]) { CTX_OR_FAIL(); if (!out12) return MPCVR_E_POINTER; return ctx->vp.GetColorMatrix(out12); }
+int32_t mpcvr_get_extfmt(mpcvr_ctx *ctx, uint32_t *extfmt) { CTX_OR_FAIL(); if (!extfmt) return MPCVR_E_POINTER; return ctx->vp.GetExtFmt(extfmt); }
+int32_t mpcvr_get_frame_bytes(mpcvr_ctx *ctx, size_t *bytes, int32_t *pitch) { CTX_OR_FAIL(); return ctx->vp.GetFrameBytes(bytes, pitch); }
+
+int32_t mpcvr_get_path_info(mpcvr_ctx *ctx, char *buf, size_t buf_size)
+{
+    CTX_OR_FAIL();
+    if (!buf || !buf_size) return MPCVR_E_POINTER;
+    const std::string s = ctx->vp.GetPathInfo();
+    std::snprintf(buf, buf_size, "%s", s.c_str());
+    return MPCVR_S_OK;
+}
+
+const char *mpcvr_last_error(mpcvr_ctx *ctx) { return ctx ? ctx->vp.LastError() : "null context"; }
+const char *mpcvr_version(void) { return "mpcvr-mi355x 0.1 (gfx950)"; }
+
+int32_t mpcvr_get_last_process_ms(mpcvr_ctx *ctx, float *ms) { CTX_OR_FAIL(); return ctx->vp.GetLastProcessMs(ms); }
+
+}  // extern "C"
+
+// ---- host-side parameter maths without a context (no GPU needed) --------------------------------
+// What the reference computes on the CPU before it ever touches the device: format table, extended
+// format defaults, colour / gamut matrices, resize weights, tap tables and the pass plan.
+#include "vp_plan.h"
+
+extern "C" {
+
+int32_t mpcvr_plan_frame_layout(int32_t cformat, int32_t width, int32_t height, int32_t *pitch, size_t *bytes)
+{
+    const mpcvr::FmtConvParams *f = mpcvr::GetFmtConvParams(cformat);
+    if (!f) return MPCVR_E_NOTIMPL;
+    const int p = mpcvr::DefaultPitch(*f, width);
+    if (pitch) *pitch = p;
+    if (bytes) *bytes = (size_t)p * mpcvr::SourceLines(*f, height);
+    return MPCVR_S_OK;
+}
+
+int32_t mpcvr_plan_color_matrix(int32_t cformat, int32_t rect_w, int32_t rect_h, uint32_t extfmt,
+                                float brightness, float contrast, float hue, float saturation,
+                                float out12[12], uint32_t *extfmt_out)
+{
+    const mpcvr::FmtConvParams *f = mpcvr::GetFmtConvParams(cformat);
+    if (!f) return MPCVR_E_NOTIMPL;
+    if (!out12) return MPCVR_E_POINTER;
+    const mpcvr::ExtFmt ex = mpcvr::SpecifyExtendedFormat(mpcvr::ExtFmt{extfmt}, *f, rect_w, rect_h);
+    mpcvr::ProcAmp pa;
+    pa.brightness = brightness; pa.contrast = contrast; pa.hue = hue; pa.saturation = saturation;
+    mpcvr::ComputeColorMatrix(ex, *f, pa, out12);
+    if (extfmt_out) *extfmt_out = ex.value;
+    return MPCVR_S_OK;
+}
+
+int32_t mpcvr_plan_gamut_2020_to_709(float out9[9])
+{
+    if (!out9) return MPCVR_E_POINTER;
+    mpcvr::ComputeGamut2020to709(out9);
+    return MPCVR_S_OK;
+}
+
+int32_t mpcvr_plan_pq_lut(float lum_scale, float out1024[1024])
+{
+    if (!out1024) return MPCVR_E_POINTER;
+    mpcvr::BuildPqSdrLut(lum_scale, out1024);
+    return MPCVR_S_OK;
+}
+
+int32_t mpcvr_plan_upscale_weights(int32_t iUpscaling, float t, float w6[6])
+{
+    if (!w6) return MPCVR_E_POINTER;
+    return mpcvr::UpscaleWeights(iUpscaling, t, w6);      // tap count (4/6) or 0
+}
+
+int32_t mpcvr_plan_axis_taps(int32_t kind, int32_t method, int32_t src_l, int32_t src_len, int32_t n_out,
+                             int32_t tex_len, uint32_t flags, int32_t cap_taps, int32_t *idx, float *w,
+                             float *wsum, int32_t *ntaps, int32_t *normalise)
+{
+    if (!ntaps) return MPCVR_E_POINTER;
+    if (n_out <= 0 || src_len <= 0 || tex_len <= 0) return MPCVR_E_INVALIDARG;
+    mpcvr::HostAxisTaps h;
+    if (!mpcvr::BuildAxisTaps(mpcvr::Resizer{kind, method}, src_l, src_len, n_out, tex_len, flags, &h)) return MPCVR_E_NOTIMPL;
+    *ntaps = h.ntaps;
+    if (normalise) *normalise = h.normalise;
+    if (h.ntaps > cap_taps) return MPCVR_S_FALSE;          // caller's buffers too small: only *ntaps is valid
+    if (idx) std::memcpy(idx, h.idx.data(), h.idx.size() * sizeof(int32_t));
+    if (w) std::memcpy(w, h.w.data(), h.w.size() * sizeof(float));
+    if (wsum && h.normalise) std::memcpy(wsum, h.wsum.data(), h.wsum.size() * sizeof(float));
+    return MPCVR_S_OK;
+}
+
+int32_t mpcvr_plan_describe(const mpcvr_settings *s, int32_t cformat, int32_t rect_w, int32_t rect_h,
+                            const mpcvr_rect *video_rect, int32_t window_w, int32_t window_h,
+                            char *buf, size_t buf_size)
+{
+    if (!s || !video_rect || !buf || !buf_size) return MPCVR_E_POINTER;
+    const mpcvr::FmtConvParams *f = mpcvr::GetFmtConvParams(cformat);
+    if (!f) return MPCVR_E_NOTIMPL;
+    const mpcvr::PlanGeometry g{rect_w, rect_h, video_rect->left, video_rect->top, video_rect->right,
+                                video_rect->bottom, window_w, window_h};
+    mpcvr::PassPlan plan;
+    std::string why;
+    if (!mpcvr::DecidePlan(s->iTexFormat, s->iChromaScaling, s->iUpscaling, s->iDownscaling, s->bInterpolateAt50pct,
+                           s->bUseDither, s->output_format, s->flags, *f, g, &plan, &why)) {
+        std::snprintf(buf, buf_size, "%s", why.c_str());
+        return MPCVR_E_NOTIMPL;
+    }
+    std::snprintf(buf, buf_size, "%s;internal=%d;swap=%d;final=%d", plan.describe().c_str(), plan.internal_fmt,
+                  plan.swap_fmt, plan.final_pass ? 1 : 0);
+    return MPCVR_S_OK;
+}
+
+}  // extern "C"

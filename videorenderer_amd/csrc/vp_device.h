@@ -1,0 +1,204 @@
+// vp_device.h — device functions shared by all kernels: texel loads, the HLSL include library
+// restated for CDNA4 (Shaders/convert/*.hlsl), store-format rounding, ps_final_pass.
+#pragma once
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include "vp_params.h"
+
+namespace mpcvr {
+
+struct f3 { float x, y, z; };
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+__device__ __forceinline__ float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }   // NaN -> 0
+
+// HLSL pow(x, y) = exp2(y * log2(x)); raw v_log_f32 / v_exp_f32 (≈1 ulp each), log2(0) = -inf -> 0.
+__device__ __forceinline__ float hlsl_pow(float x, float y)
+{
+    return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+}
+
+// ---- Shaders/convert/st2084.hlsl:1-25 ----
+#define MPCVR_ST2084_m1 (2610.0f / (4096.0f * 4.0f))
+#define MPCVR_ST2084_m2 ((2523.0f / 4096.0f) * 128.0f)
+#define MPCVR_ST2084_c1 (3424.0f / 4096.0f)
+#define MPCVR_ST2084_c2 ((2413.0f / 4096.0f) * 32.0f)
+#define MPCVR_ST2084_c3 ((2392.0f / 4096.0f) * 32.0f)
+
+__device__ __forceinline__ float st2084_to_linear(float x, float factor)
+{
+    x = hlsl_pow(x, 1.0f / MPCVR_ST2084_m2);
+    x = fmaxf(x - MPCVR_ST2084_c1, 0.0f) / (MPCVR_ST2084_c2 - MPCVR_ST2084_c3 * x);
+    x = hlsl_pow(x, 1.0f / MPCVR_ST2084_m1);
+    return x * factor;
+}
+__device__ __forceinline__ float linear_to_st2084(float x, float divider)
+{
+    x = x / divider;
+    x = hlsl_pow(x, MPCVR_ST2084_m1);
+    x = (MPCVR_ST2084_c1 + MPCVR_ST2084_c2 * x) / (1.0f + MPCVR_ST2084_c3 * x);
+    return hlsl_pow(x, MPCVR_ST2084_m2);
+}
+
+// ---- Shaders/convert/hlg.hlsl:1-20 ----
+__device__ __forceinline__ float inverse_hlg(float v)
+{
+    const float a = 0.17883277f, b = 0.28466892f, c = 0.55991073f;
+    return (v <= 0.5f) ? v * v * 4.0f : __expf((v - c) / a) + b;
+}
+__device__ __forceinline__ f3 hlg_to_linear(f3 v)
+{
+    v.x = inverse_hlg(v.x); v.y = inverse_hlg(v.y); v.z = inverse_hlg(v.z);
+    const float ys = 2000.0f * (0.2627f * v.x + 0.6780f * v.y + 0.0593f * v.z);
+    const float g = hlsl_pow(ys, 0.2f);
+    v.x *= g; v.y *= g; v.z *= g;
+    return v;
+}
+
+// ---- Shaders/convert/hdr_tone_mapping.hlsl:1-13 ----
+__device__ __forceinline__ float hable(float x)
+{
+    const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+    return ((x * (A * x + (C * B)) + (D * E)) / (x * (A * x + B) + (D * F))) - E / F;
+}
+// hable(4.8) folded in fp32 exactly like `static const float3 HABLE_DIV = hable(4.8)`
+__device__ __forceinline__ float hable_div()
+{
+    const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f, x = 4.8f;
+    return ((x * (A * x + (C * B)) + (D * E)) / (x * (A * x + B) + (D * F))) - E / F;
+}
+
+__device__ __forceinline__ f3 mat3_mul(const float *m, f3 v)
+{
+    f3 r;
+    r.x = m[0] * v.x + m[1] * v.y + m[2] * v.z;
+    r.y = m[3] * v.x + m[4] * v.y + m[5] * v.z;
+    r.z = m[6] * v.x + m[7] * v.y + m[8] * v.z;
+    return r;
+}
+
+// The tail GetShaderConvertColor appends after "//convert color" — Shaders.cpp:861-923
+__device__ __forceinline__ f3 hdr_tail(f3 c, int tail, float gamma, float lum_scale, const float *gamut)
+{
+    if (tail == TAIL_NONE) return c;
+    if (tail == TAIL_PQ_TO_SDR || tail == TAIL_HLG_TO_SDR) {
+        if (tail == TAIL_HLG_TO_SDR) {
+            c.x = saturate(c.x); c.y = saturate(c.y); c.z = saturate(c.z);
+            c = hlg_to_linear(c);
+            c.x = linear_to_st2084(c.x, 1000.0f); c.y = linear_to_st2084(c.y, 1000.0f); c.z = linear_to_st2084(c.z, 1000.0f);
+        }
+        c.x = st2084_to_linear(saturate(c.x), lum_scale);
+        c.y = st2084_to_linear(saturate(c.y), lum_scale);
+        c.z = st2084_to_linear(saturate(c.z), lum_scale);
+        const float div = hable_div();
+        c.x = hable(c.x) / div; c.y = hable(c.y) / div; c.z = hable(c.z) / div;
+        c = mat3_mul(gamut, c);
+    } else {   // TAIL_GAMMA_GAMUT
+        c.x = saturate(c.x); c.y = saturate(c.y); c.z = saturate(c.z);
+        if (gamma != 1.0f) { c.x = hlsl_pow(c.x, gamma); c.y = hlsl_pow(c.y, gamma); c.z = hlsl_pow(c.z, gamma); }
+        c = mat3_mul(gamut, c);
+    }
+    c.x = hlsl_pow(saturate(c.x), 1.0f / 2.2f);
+    c.y = hlsl_pow(saturate(c.y), 1.0f / 2.2f);
+    c.z = hlsl_pow(saturate(c.z), 1.0f / 2.2f);
+    return c;
+}
+
+// ---- source texel loads: UNORM8/16 -> float, clamp addressing, CopyPlane10to16 shift on the fly ----
+__device__ __forceinline__ float load_sample(const uint8_t *plane, int pitch, int bytes, int shift, int x, int y)
+{
+    const uint8_t *row = plane + (size_t)y * pitch;
+    if (bytes == 1) return (float)row[x] / 255.0f;
+    const unsigned v = (((const uint16_t *)row)[x] << shift) & 0xffffu;
+    return (float)v / 65535.0f;
+}
+__device__ __forceinline__ float load_luma(const ConvertParams &P, int x, int y)
+{
+    x = clampi(x, 0, P.tex_w - 1); y = clampi(y, 0, P.tex_h - 1);
+    return load_sample(P.plane[0], P.pitch[0], P.fmt.bytes, P.fmt.shift, x, y);
+}
+// c: 0 = U, 1 = V   (constant plane indices only: dynamic indexing would push the params into scratch)
+__device__ __forceinline__ float load_chroma(const ConvertParams &P, int c, int x, int y)
+{
+    x = clampi(x, 0, P.cw - 1); y = clampi(y, 0, P.ch - 1);
+    if (P.fmt.planes == 2)      // interleaved UV: no shift (P010/P016/P21x carry MSB-aligned data)
+        return load_sample(P.plane[1], P.pitch[1], P.fmt.bytes, 0, 2 * x + c, y);
+    const bool second = (c == 0) == (P.fmt.v_first != 0);                       // Shaders.cpp:159-165
+    const uint8_t *pl = second ? P.plane[2] : P.plane[1];
+    return load_sample(pl, P.pitch[1], P.fmt.bytes, P.fmt.shift, x, y);
+}
+
+// ---- store-format rounding ----
+__device__ __forceinline__ float unorm_q(float x, float maxv) { return floorf(saturate(x) * maxv + 0.5f); }
+__device__ __forceinline__ float half_round(float x) { return __half2float(__float2half_rn(x)); }
+
+// value a texture of format fmt returns after `v` was written to it
+__device__ __forceinline__ f3 round_to_fmt(f3 v, int fmt)
+{
+    if (fmt == SF_BGRA8) { v.x = unorm_q(v.x, 255.0f) / 255.0f; v.y = unorm_q(v.y, 255.0f) / 255.0f; v.z = unorm_q(v.z, 255.0f) / 255.0f; }
+    else if (fmt == SF_RGB10A2) { v.x = unorm_q(v.x, 1023.0f) / 1023.0f; v.y = unorm_q(v.y, 1023.0f) / 1023.0f; v.z = unorm_q(v.z, 1023.0f) / 1023.0f; }
+    else { v.x = half_round(v.x); v.y = half_round(v.y); v.z = half_round(v.z); }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t pack_bgra8(float r, float g, float b)   // already integral 0..255
+{
+    return (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16) | 0xff000000u;
+}
+__device__ __forceinline__ uint32_t pack_rgb10a2(float r, float g, float b)
+{
+    return (uint32_t)r | ((uint32_t)g << 10) | ((uint32_t)b << 20) | 0xc0000000u;
+}
+
+// write v (float RGB, alpha = 1) into a surface of format fmt
+__device__ __forceinline__ void store_surface(void *base, int pitch, int fmt, int x, int y, f3 v)
+{
+    uint8_t *row = (uint8_t *)base + (size_t)y * pitch;
+    if (fmt == SF_BGRA8) ((uint32_t *)row)[x] = pack_bgra8(unorm_q(v.x, 255.0f), unorm_q(v.y, 255.0f), unorm_q(v.z, 255.0f));
+    else if (fmt == SF_RGB10A2) ((uint32_t *)row)[x] = pack_rgb10a2(unorm_q(v.x, 1023.0f), unorm_q(v.y, 1023.0f), unorm_q(v.z, 1023.0f));
+    else {
+        const __half2 lo = __halves2half2(__float2half_rn(v.x), __float2half_rn(v.y));
+        const __half2 hi = __halves2half2(__float2half_rn(v.z), __float2half_rn(1.0f));
+        uint2 u;
+        u.x = *(const uint32_t *)&lo; u.y = *(const uint32_t *)&hi;
+        ((uint2 *)row)[x] = u;
+    }
+}
+
+__device__ __forceinline__ f3 load_surface(const Surface &s, int x, int y)
+{
+    const uint8_t *row = (const uint8_t *)s.ptr + (size_t)y * s.pitch;
+    f3 v;
+    if (s.fmt == SF_BGRA8) {
+        const uint32_t u = ((const uint32_t *)row)[x];
+        v.x = (float)((u >> 16) & 255u) / 255.0f; v.y = (float)((u >> 8) & 255u) / 255.0f; v.z = (float)(u & 255u) / 255.0f;
+    } else if (s.fmt == SF_RGB10A2) {
+        const uint32_t u = ((const uint32_t *)row)[x];
+        v.x = (float)(u & 1023u) / 1023.0f; v.y = (float)((u >> 10) & 1023u) / 1023.0f; v.z = (float)((u >> 20) & 1023u) / 1023.0f;
+    } else {
+        const uint2 u = ((const uint2 *)row)[x];
+        const __half2 lo = *(const __half2 *)&u.x, hi = *(const __half2 *)&u.y;
+        v.x = __low2float(lo); v.y = __high2float(lo); v.z = __low2float(hi);
+    }
+    return v;
+}
+
+// epilogue of the last draw: plain surface store, or m_TexsPostScale rounding + ps_final_pass.hlsl:23-31
+__device__ __forceinline__ void store_epilogue(const StoreParams &S, int x, int y, f3 v)
+{
+    const int wx = x + S.off_x, wy = y + S.off_y;
+    if (S.clip_w > 0 && (wx < 0 || wy < 0 || wx >= S.clip_w || wy >= S.clip_h)) return;
+    if (S.mode == ST_SURFACE) { store_surface(S.dst, S.dst_pitch, S.dst_fmt, wx, wy, v); return; }
+    v = round_to_fmt(v, S.mid_fmt);
+    // sampler WRAP + POINT, ditherCoordScale = texSize/32  =>  texel (wx mod 32, wy mod 32)
+    const float d = __half2float(__ushort_as_half(S.dither[(wy & 31) * 32 + (wx & 31)]));
+    const float q = (float)S.quant;
+    const float r = fminf(fmaxf(floorf(v.x * q + d), 0.0f), q);
+    const float g = fminf(fmaxf(floorf(v.y * q + d), 0.0f), q);
+    const float b = fminf(fmaxf(floorf(v.z * q + d), 0.0f), q);
+    uint32_t *row = (uint32_t *)((uint8_t *)S.dst + (size_t)wy * S.dst_pitch);
+    row[wx] = (S.dst_fmt == SF_RGB10A2) ? pack_rgb10a2(r, g, b) : pack_bgra8(r, g, b);
+}
+
+}  // namespace mpcvr

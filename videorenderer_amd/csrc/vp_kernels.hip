@@ -1,0 +1,85 @@
+// vp_kernels.hip — pass-per-kernel path: one HIP kernel per reference draw call
+// (ConvertColorPass, TextureResizeShader x/y, FinalPass).  Handles every format / scaler / rect the
+// build accepts; intermediates live in HBM exactly where the reference keeps textures.
+// Compiled with -ffp-contract=off: every a*b+c is two roundings, so results are bit-identical to the
+// CPU oracle except through the transcendental instructions.  The fused fast path is vp_fused.hip.
+#include <hip/hip_runtime.h>
+
+#include "vp_convert.h"
+#include "vp_device.h"
+#include "vp_launch.h"
+
+namespace mpcvr {
+
+// ConvertColorPass — DX11VideoProcessor.cpp:3048-3101 : one thread per pixel of m_TexConvertOutput
+__global__ __launch_bounds__(256) void k_convert(ConvertParams P, Surface out)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= P.out_w || j >= P.out_h) return;
+    store_surface(out.ptr, out.pitch, out.fmt, i, j, convert_pixel(P, i, j));
+}
+
+// TextureResizeShader — DX11VideoProcessor.cpp:332-377 with ps_interpolation_* / ps_convolution.
+// AXIS = filtered axis; `other` maps the unfiltered output coordinate to a source texel (point sample).
+template <int AXIS>
+__global__ __launch_bounds__(256) void k_resize(Surface in, AxisTaps taps, const int32_t *__restrict__ other,
+                                               int out_w, int out_h, StoreParams st)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= out_w || y >= out_h) return;
+    const int f = AXIS == 0 ? x : y;
+    const int o = other[AXIS == 0 ? y : x];
+    const int32_t *idx = taps.idx + (size_t)f * taps.ntaps;
+    const float *w = taps.w + (size_t)f * taps.ntaps;
+    f3 acc;
+    {
+        const f3 q = AXIS == 0 ? load_surface(in, idx[0], o) : load_surface(in, o, idx[0]);
+        acc.x = w[0] * q.x; acc.y = w[0] * q.y; acc.z = w[0] * q.z;
+    }
+    for (int k = 1; k < taps.ntaps; k++) {
+        const f3 q = AXIS == 0 ? load_surface(in, idx[k], o) : load_surface(in, o, idx[k]);
+        acc.x = acc.x + w[k] * q.x; acc.y = acc.y + w[k] * q.y; acc.z = acc.z + w[k] * q.z;
+    }
+    if (taps.normalise) {
+        const float ww = taps.wsum[f];
+        acc.x = acc.x / ww; acc.y = acc.y / ww; acc.z = acc.z / ww;
+    }
+    store_epilogue(st, x, y, acc);
+}
+
+// TextureCopyRect(ps_simple) / FinalPass straight from the convert output (no size change)
+__global__ __launch_bounds__(256) void k_copy(Surface in, int out_w, int out_h, StoreParams st)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= out_w || y >= out_h) return;
+    store_epilogue(st, x, y, load_surface(in, x, y));
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline dim3 grid2d(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4, 1); }
+
+hipError_t LaunchConvert(const ConvertParams &P, const Surface &out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_convert, grid2d(P.out_w, P.out_h), dim3(64, 4, 1), 0, s, P, out);
+    return hipGetLastError();
+}
+
+hipError_t LaunchResize(int axis, const Surface &in, const AxisTaps &taps, const int32_t *other,
+                        int out_w, int out_h, const StoreParams &st, hipStream_t s)
+{
+    if (axis == 0)
+        hipLaunchKernelGGL(k_resize<0>, grid2d(out_w, out_h), dim3(64, 4, 1), 0, s, in, taps, other, out_w, out_h, st);
+    else
+        hipLaunchKernelGGL(k_resize<1>, grid2d(out_w, out_h), dim3(64, 4, 1), 0, s, in, taps, other, out_w, out_h, st);
+    return hipGetLastError();
+}
+
+hipError_t LaunchCopy(const Surface &in, int out_w, int out_h, const StoreParams &st, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_copy, grid2d(out_w, out_h), dim3(64, 4, 1), 0, s, in, out_w, out_h, st);
+    return hipGetLastError();
+}
+
+}  // namespace mpcvr

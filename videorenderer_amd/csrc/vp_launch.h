@@ -1,0 +1,33 @@
+// vp_launch.h — host-callable launchers of the HIP kernels (vp_kernels.hip, vp_fused.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "vp_params.h"
+
+namespace mpcvr {
+
+// pass-per-kernel path (vp_kernels.hip)
+hipError_t LaunchConvert(const ConvertParams &P, const Surface &out, hipStream_t s);
+hipError_t LaunchResize(int axis, const Surface &in, const AxisTaps &taps, const int32_t *other,
+                        int out_w, int out_h, const StoreParams &st, hipStream_t s);
+hipError_t LaunchCopy(const Surface &in, int out_w, int out_h, const StoreParams &st, hipStream_t s);
+
+// fused 2x path (vp_fused.hip): convert + X pass + Y pass + final pass in one kernel, n frames per launch.
+struct FusedFrame {
+    const uint8_t *src;   // sample base (planes back to back)
+    void *dst;            // render target base
+};
+struct FusedParams {
+    ConvertParams conv;       // plane pointers are ignored; derived per frame from FusedFrame::src
+    size_t plane_off[3];      // byte offsets of the planes inside a sample
+    Up2xWeights wx, wy;
+    StoreParams store;        // dst ignored; per frame
+    int out_w, out_h;         // 2*conv.out_w, 2*conv.out_h
+    const float *pq_lut;      // device, 1024 floats: x -> Hable(ST2084ToLinear(x)*scale)/hable(4.8); null => ALU
+    int fast_convert;         // layout/alignments allow the vectorised 4-pixel convert
+};
+bool FusedUp2xSupported(const FusedParams &P);
+// frames_dev == nullptr: n_frames must be 1 and `single` is used (no device-side table needed)
+hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
+
+}  // namespace mpcvr

@@ -1,0 +1,92 @@
+// vp_params.h — plain-old-data shared between the host planner (vp_plan.cpp) and the HIP kernels
+// (vp_kernels.hip).  Everything a launch needs travels by value as a kernel argument.
+#pragma once
+#include <stdint.h>
+
+namespace mpcvr {
+
+// surface formats of the intermediate / output textures
+// (m_InternalTexFmt — DX11VideoProcessor.cpp:1143-1155; m_TexResize is always fp16 — :3155)
+enum SurfFmt : int { SF_BGRA8 = 8, SF_RGB10A2 = 10, SF_RGBA16F = 16 };
+
+// what the generated convert shader appends after "//convert color" (Shaders.cpp:861-923)
+enum TailMode : int {
+    TAIL_NONE = 0,
+    TAIL_PQ_TO_SDR = 1,      // saturate, ST2084ToLinear*scale, Hable, 2020->709, saturate, pow 1/2.2
+    TAIL_HLG_TO_SDR = 2,     // saturate, HLGtoLinear, LinearToST2084(/1000), then as PQ
+    TAIL_GAMMA_GAMUT = 3     // saturate, pow(gamma), 2020->709, saturate, pow 1/2.2
+};
+
+enum ChromaLoc : int { CLOC_MPEG2 = 0, CLOC_MPEG1 = 1, CLOC_COSITED = 2 };
+
+struct SrcFormat {
+    int planes;      // 2: Y + interleaved UV ; 3: Y,U,V
+    int bytes;       // 1 or 2 bytes per sample
+    int div_w, div_h;
+    int shift;       // CopyPlane10to16 (<<6) applied on load for 10-bit planar (Helper.cpp:789-803)
+    int v_first;     // YV12 family: 2nd plane holds V
+    int subsampling; // 420 / 422 / 444
+    int cdepth;
+};
+
+struct ConvertParams {
+    const uint8_t *plane[3];
+    int pitch[3];
+    int tex_w, tex_h;        // luma texture size
+    int cw, ch;              // chroma texture size
+    int rect_l, rect_t;      // source rect origin inside the texture
+    int out_w, out_h;        // rect size == convert-output size
+    SrcFormat fmt;
+    int chroma_scaling;      // CHROMA_*
+    int chroma_loc;          // ChromaLoc
+    int tail;                // TailMode
+    float gamma;             // for TAIL_GAMMA_GAMUT (1.0 => skip pow)
+    float cm[12];            // cm_r, cm_g, cm_b, cm_c  (PS_COLOR_TRANSFORM, Shaders.h:25-30)
+    float lum_scale;         // PS_PARAMETERS.LuminanceScale
+    float gamut[9];          // matrix_conv_prim
+    int out_fmt;             // SurfFmt of m_TexConvertOutput
+};
+
+struct Surface {
+    void *ptr;
+    int pitch;      // bytes
+    int w, h;
+    int fmt;        // SurfFmt
+};
+
+// epilogue of a resize / copy draw
+enum StoreMode : int {
+    ST_SURFACE = 0,    // round to the destination surface format (fp16, internal, or RT without final pass)
+    ST_FINAL = 1       // round to `mid_fmt` (m_TexsPostScale), then ps_final_pass -> RT
+};
+
+struct StoreParams {
+    void *dst;          // destination base (window-sized for RT stores, image-sized otherwise)
+    int dst_pitch;
+    int dst_fmt;        // SurfFmt of dst
+    int mode;           // StoreMode
+    int mid_fmt;        // SurfFmt the value passes through before the final pass (ST_FINAL)
+    int quant;          // 255 or 1023 (ps_final_pass QUANTIZATION)
+    int off_x, off_y;   // image (0,0) lands at window pixel (off_x, off_y)
+    int clip_w, clip_h; // window size for clipping (0 => no clipping, dst is image-sized)
+    const uint16_t *dither;  // 32x32 fp16 table (device)
+};
+
+// per-output-index tap tables for one axis (built on the host, vp_plan.cpp)
+struct AxisTaps {
+    const int32_t *idx;   // [n_out * ntaps] clamped source indices
+    const float *w;       // [n_out * ntaps]
+    const float *wsum;    // [n_out] (only when normalise)
+    int ntaps;
+    int normalise;        // ps_convolution: avg /= ww
+};
+
+// 2x fast path: the two phase-weight sets per axis (t = 0.75 for even outputs, 0.25 for odd)
+struct Up2xWeights {
+    int ntaps;            // 4 or 6
+    float w_even[6];      // taps at base-1.. (4) or base-2.. (6), base = k-1 for output 2k
+    float w_odd[6];       // base = k for output 2k+1
+    int q1_quirk;         // Lanczos3 D3D11: tap 1 re-reads tap 0's texel
+};
+
+}  // namespace mpcvr

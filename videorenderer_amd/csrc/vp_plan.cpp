@@ -1,0 +1,496 @@
+// vp_plan.cpp — host-side parameter maths (see vp_plan.h).  Compiled with -ffp-contract=off so the
+// fp32/fp64 expression shapes below round exactly like the reference's MSVC build.
+#include "vp_plan.h"
+
+#include <cmath>
+#include <cstring>
+
+#include "../../include/mpcvr.h"
+
+namespace mpcvr {
+
+// ------------------------------------------------------------------------------------------------
+// formats — Helper.cpp:295-359
+// ------------------------------------------------------------------------------------------------
+static const FmtConvParams kFormats[] = {
+    //  cformat             str          pl by dw dh pack coeff sub  depth shift vfirst
+    {MPCVR_CF_NV12,      "NV12",       2, 1, 2, 2, 1, 3, 420,  8, 0, 0},
+    {MPCVR_CF_P010,      "P010",       2, 2, 2, 2, 2, 3, 420, 16, 0, 0},
+    {MPCVR_CF_P016,      "P016",       2, 2, 2, 2, 2, 3, 420, 16, 0, 0},
+    {MPCVR_CF_P210,      "P210",       2, 2, 2, 1, 2, 4, 422, 16, 0, 0},
+    {MPCVR_CF_P216,      "P216",       2, 2, 2, 1, 2, 4, 422, 16, 0, 0},
+    {MPCVR_CF_YV12,      "YV12",       3, 1, 2, 2, 1, 3, 420,  8, 0, 1},
+    {MPCVR_CF_YV16,      "YV16",       3, 1, 2, 1, 1, 4, 422,  8, 0, 1},
+    {MPCVR_CF_YV24,      "YV24",       3, 1, 1, 1, 1, 6, 444,  8, 0, 1},
+    {MPCVR_CF_YUV420P8,  "YUV420P8",   3, 1, 2, 2, 1, 3, 420,  8, 0, 0},
+    {MPCVR_CF_YUV422P8,  "YUV422P8",   3, 1, 2, 1, 1, 4, 422,  8, 0, 0},
+    {MPCVR_CF_YUV444P8,  "YUV444P8",   3, 1, 1, 1, 1, 6, 444,  8, 0, 0},
+    {MPCVR_CF_YUV420P10, "YUV420P10",  3, 2, 2, 2, 2, 3, 420, 10, 6, 0},
+    {MPCVR_CF_YUV420P16, "YUV420P16",  3, 2, 2, 2, 2, 3, 420, 16, 0, 0},
+    {MPCVR_CF_YUV422P10, "YUV422P10",  3, 2, 2, 1, 2, 4, 422, 10, 6, 0},
+    {MPCVR_CF_YUV422P16, "YUV422P16",  3, 2, 2, 1, 2, 4, 422, 16, 0, 0},
+    {MPCVR_CF_YUV444P10, "YUV444P10",  3, 2, 1, 1, 2, 6, 444, 10, 6, 0},
+    {MPCVR_CF_YUV444P16, "YUV444P16",  3, 2, 1, 1, 2, 6, 444, 16, 0, 0},
+};
+
+const FmtConvParams *GetFmtConvParams(int cformat)
+{
+    for (const auto &f : kFormats)
+        if (f.cformat == cformat) return &f;
+    return nullptr;
+}
+
+int DefaultPitch(const FmtConvParams &f, int width)
+{
+    int pitch = width * f.Packsize;
+    if (f.cformat == MPCVR_CF_NV12) pitch = (pitch + 3) & ~3;
+    return pitch;
+}
+
+int SourceLines(const FmtConvParams &f, int height) { return height * f.PitchCoeff / 2; }
+
+// ------------------------------------------------------------------------------------------------
+// extended format defaults — Helper.cpp:1169-1211 (every accepted format is CS_YUV)
+// ------------------------------------------------------------------------------------------------
+namespace dxva {
+enum { Chroma_MPEG1 = 1, Chroma_MPEG2 = 5, Chroma_Cosited = 7 };
+enum { Range_0_255 = 1, Range_16_235 = 2 };
+enum { Matrix_BT709 = 1, Matrix_BT601 = 2, Matrix_SMPTE240M = 3, Matrix_BT2020_10 = 4, Matrix_YCgCo = 7 };
+enum { Prim_BT709 = 2, Prim_BT2020 = 9 };
+enum { TF_10 = 1, TF_18 = 2, TF_20 = 3, TF_22 = 4, TF_709 = 5, TF_240M = 6, TF_sRGB = 7, TF_28 = 8,
+       TF_26 = 14, TF_2084 = 15, TF_HLG = 16 };
+enum { Lighting_dim = 3 };
+}  // namespace dxva
+
+ExtFmt SpecifyExtendedFormat(ExtFmt ex, const FmtConvParams &f, int w, int h)
+{
+    if (f.Subsampling != 420) ex.set(8, 0xf, 0);
+    else if (ex.VideoChromaSubsampling() == 0) ex.set(8, 0xf, dxva::Chroma_MPEG2);
+    if (ex.NominalRange() == 0) ex.set(12, 0x7, dxva::Range_16_235);
+    if (ex.VideoTransferMatrix() == 0)
+        ex.set(15, 0x7, (w <= 1024 && h <= 576) ? dxva::Matrix_BT601 : dxva::Matrix_BT709);
+    if (ex.VideoLighting() == 0) ex.set(18, 0xf, dxva::Lighting_dim);
+    if (ex.VideoPrimaries() == 0) ex.set(22, 0x1f, dxva::Prim_BT709);
+    if (ex.VideoTransferFunction() == 0) ex.set(27, 0x1f, dxva::TF_709);
+    return ex;
+}
+
+// ------------------------------------------------------------------------------------------------
+// YUV->RGB matrix — mp_get_csp_matrix (csputils.cpp:392-509) specialised to what
+// SetShaderConvertColorParams (DX11VideoProcessor.cpp:813-887) feeds it:
+// levels_out = PC, gamma untouched, input_bits = texture_bits = CDepth.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+enum CspSpace { SP_AUTO = 0, SP_601, SP_709, SP_240M, SP_2020NC, SP_YCGCO };
+
+struct Mat3 { float v[3][3]; };
+
+Mat3 FromLumaWeights(float lr, float lg, float lb)      // csputils.cpp:380-389
+{
+    Mat3 m;
+    m.v[0][0] = 1; m.v[0][1] = 0;                       m.v[0][2] = 2 * (1 - lr);
+    m.v[1][0] = 1; m.v[1][1] = -2 * (1 - lb) * lb / lg; m.v[1][2] = -2 * (1 - lr) * lr / lg;
+    m.v[2][0] = 1; m.v[2][1] = 2 * (1 - lb);            m.v[2][2] = 0;
+    return m;
+}
+
+}  // namespace
+
+void ComputeColorMatrix(const ExtFmt &ex, const FmtConvParams &f, const ProcAmp &pa, float out[12])
+{
+    // set_colorspace — Helper.cpp:949-1004
+    int levels_tv;   // 1 = TV, 0 = PC
+    switch (ex.NominalRange()) {
+    case dxva::Range_0_255: levels_tv = 0; break;
+    default: levels_tv = 1; break;                     // 16-235, and AUTO -> TV (csputils.cpp:397-399)
+    }
+    CspSpace sp;
+    switch (ex.VideoTransferMatrix()) {
+    case dxva::Matrix_BT709: sp = SP_709; break;
+    case dxva::Matrix_BT601: sp = SP_601; break;
+    case dxva::Matrix_SMPTE240M: sp = SP_240M; break;
+    case dxva::Matrix_BT2020_10: sp = SP_2020NC; break;
+    case dxva::Matrix_YCgCo: sp = SP_YCGCO; break;
+    default: sp = SP_601; break;                        // AUTO -> BT.601 (csputils.cpp:395-396)
+    }
+
+    const float brightness = pa.brightness / 255;                              // :839
+    const float contrast = pa.contrast;                                        // :840
+    const float hue = (float)(pa.hue / 180 * std::acos(-1.0));                 // :841
+    const float saturation = pa.saturation;                                    // :842
+
+    Mat3 m;
+    switch (sp) {
+    case SP_709: m = FromLumaWeights(0.2126f, 0.7152f, 0.0722f); break;
+    case SP_240M: m = FromLumaWeights(0.2122f, 0.7013f, 0.0865f); break;
+    case SP_2020NC: m = FromLumaWeights(0.2627f, 0.6780f, 0.0593f); break;
+    case SP_YCGCO: {
+        const float y[3][3] = {{1, -1, 1}, {1, 1, 0}, {1, -1, -1}};
+        std::memcpy(m.v, y, sizeof(y));
+        break;
+    }
+    default: m = FromLumaWeights(0.299f, 0.587f, 0.114f); break;
+    }
+
+    if (sp != SP_YCGCO) {                               // hue rotation + saturation, csputils.cpp:447-459
+        const float hc = saturation * std::cos(hue);    // float overloads, as in the C++ reference
+        const float hs = saturation * std::sin(hue);
+        for (auto &row : m.v) {
+            const float u = row[1], v = row[2];
+            row[1] = hc * u - hs * v;
+            row[2] = hs * u + hc * v;
+        }
+    }
+
+    // mp_get_csp_mul (csputils.cpp:341-358) with input_bits == texture_bits == CDepth (:845)
+    const int bits = f.CDepth;
+    const double full = (double)(1LL << bits);
+    const double s = full / (full - 1.) * 255 / 256 / 255;
+    const double ymin = (levels_tv ? 16 : 0) * s, ymax = (levels_tv ? 235 : 255) * s;
+    const double cmax = (levels_tv ? 240 : 255) * s, cmid = 128 * s;
+    double ymul = (1.0 - 0.0) / (ymax - ymin);
+    double cmul = (1.0 - 0.0) / (cmax - cmid) / 2;
+    ymul *= contrast;
+    cmul *= contrast;
+    for (int i = 0; i < 3; i++) {
+        m.v[i][0] = (float)(m.v[i][0] * ymul);
+        m.v[i][1] = (float)(m.v[i][1] * cmul);
+        m.v[i][2] = (float)(m.v[i][2] * cmul);
+        const float uv = m.v[i][1] + m.v[i][2];
+        out[9 + i] = (float)(0.0 - m.v[i][0] * ymin - uv * cmid + brightness);
+    }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) out[i * 3 + j] = m.v[i][j];
+}
+
+// ------------------------------------------------------------------------------------------------
+// BT.2020 -> BT.709 gamut matrix — csputils.cpp:10-49,228-259,549-557
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+void Invert(float m[3][3])
+{
+    const float a = m[0][0], b = m[0][1], c = m[0][2], d = m[1][0], e = m[1][1], f = m[1][2],
+                g = m[2][0], h = m[2][1], k = m[2][2];
+    m[0][0] = (e * k - h * f);  m[0][1] = -(b * k - h * c); m[0][2] = (b * f - e * c);
+    m[1][0] = -(d * k - g * f); m[1][1] = (a * k - g * c);  m[1][2] = -(a * f - d * c);
+    m[2][0] = (d * h - g * e);  m[2][1] = -(a * h - g * b); m[2][2] = (a * e - d * b);
+    float det = a * m[0][0] + d * m[0][1] + g * m[0][2];
+    det = 1.0f / det;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) m[i][j] *= det;
+}
+
+void MulInPlace(float a[3][3], const float b[3][3])
+{
+    float t[3][3];
+    std::memcpy(t, a, sizeof(t));
+    for (int i = 0; i < 3; i++)
+        for (int r = 0; r < 3; r++) a[r][i] = t[r][0] * b[0][i] + t[r][1] * b[1][i] + t[r][2] * b[2][i];
+}
+
+struct XY { float x, y; };
+struct Prim { XY r, g, b, w; };
+
+void RgbToXyz(const Prim &p, float m[3][3])
+{
+    float X[4] = {p.r.x / p.r.y, p.g.x / p.g.y, p.b.x / p.b.y, p.w.x / p.w.y};
+    float Z[4] = {(1 - p.r.x - p.r.y) / p.r.y, (1 - p.g.x - p.g.y) / p.g.y,
+                  (1 - p.b.x - p.b.y) / p.b.y, (1 - p.w.x - p.w.y) / p.w.y};
+    for (int i = 0; i < 3; i++) { m[0][i] = X[i]; m[1][i] = 1; m[2][i] = Z[i]; }
+    Invert(m);
+    float S[3];
+    for (int i = 0; i < 3; i++) S[i] = m[i][0] * X[3] + m[i][1] * 1 + m[i][2] * Z[3];
+    for (int i = 0; i < 3; i++) { m[0][i] = S[i] * X[i]; m[1][i] = S[i] * 1; m[2][i] = S[i] * Z[i]; }
+}
+
+}  // namespace
+
+void ComputeGamut2020to709(float out[9])
+{
+    const XY d65 = {0.31271f, 0.32902f};
+    const Prim bt2020 = {{0.708f, 0.292f}, {0.170f, 0.797f}, {0.131f, 0.046f}, d65};
+    const Prim bt709 = {{0.640f, 0.330f}, {0.300f, 0.600f}, {0.150f, 0.060f}, d65};
+    float in[3][3], m[3][3];
+    RgbToXyz(bt2020, in);
+    RgbToXyz(bt709, m);
+    Invert(m);
+    MulInPlace(m, in);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) out[i * 3 + j] = m[i][j];
+}
+
+// Shaders.cpp:613-616, 861-915
+void SelectTail(const ExtFmt &ex, bool convert_to_sdr, int *tail, float *gamma)
+{
+    const unsigned tf = ex.VideoTransferFunction();
+    *tail = TAIL_NONE;
+    *gamma = 1.0f;
+    if (convert_to_sdr && tf == dxva::TF_2084) { *tail = TAIL_PQ_TO_SDR; return; }
+    if (convert_to_sdr && tf == dxva::TF_HLG) { *tail = TAIL_HLG_TO_SDR; return; }
+    if (ex.VideoPrimaries() == dxva::Prim_BT2020) {
+        float g = 0;
+        switch (tf) {
+        case dxva::TF_10: g = 1.0f; break;
+        case dxva::TF_18: g = 1.8f; break;
+        case dxva::TF_20: g = 2.0f; break;
+        case dxva::TF_HLG: case dxva::TF_22: case dxva::TF_709: case dxva::TF_240M: case dxva::TF_sRGB: g = 2.2f; break;
+        case dxva::TF_28: g = 2.8f; break;
+        case dxva::TF_26: g = 2.6f; break;
+        default: break;
+        }
+        if (g != 0) { *tail = TAIL_GAMMA_GAMUT; *gamma = g; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PQ -> SDR per-channel table (Shaders/convert/st2084.hlsl:1-16, hdr_tone_mapping.hlsl:1-13)
+// ------------------------------------------------------------------------------------------------
+void BuildPqSdrLut(float lum_scale, float out[1024])
+{
+    const float m1 = 2610.0f / (4096.0f * 4.0f), m2 = (2523.0f / 4096.0f) * 128.0f;
+    const float c1 = 3424.0f / 4096.0f, c2 = (2413.0f / 4096.0f) * 32.0f, c3 = (2392.0f / 4096.0f) * 32.0f;
+    auto hable = [](float x) {
+        const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+        return ((x * (A * x + (C * B)) + (D * E)) / (x * (A * x + B) + (D * F))) - E / F;
+    };
+    const float div = hable(4.8f);
+    for (int i = 0; i < 1024; i++) {
+        float x = (float)i / 1023.0f;
+        x = std::exp2(std::log2(x) * (1.0f / m2));
+        x = std::fmax(x - c1, 0.0f) / (c2 - c3 * x);
+        x = std::exp2(std::log2(x) * (1.0f / m1));
+        x *= lum_scale;
+        out[i] = hable(x) / div;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// resize weights
+// ------------------------------------------------------------------------------------------------
+static const float kPi = 3.14159265358979323846f;   // acos(-1.) as an fp32 constant
+
+int UpscaleWeights(int method, float t, float w[6])
+{
+    const float t2 = t * t, t3 = t * t2;
+    switch (method) {
+    case MPCVR_UPSCALE_Mitchell: {       // ps_interpolation_spline4.hlsl:50-51
+        const float k0[4] = {1.f / 18.f, 16.f / 18.f, 1.f / 18.f, 0.f};
+        const float k1[4] = {-.5f, 0.f, .5f, 0.f};
+        const float k2[4] = {5.f / 6.f, -12.f / 6.f, 9.f / 6.f, -2.f / 6.f};
+        const float k3[4] = {-7.f / 18.f, 21.f / 18.f, -21.f / 18.f, 7.f / 18.f};
+        for (int i = 0; i < 4; i++) w[i] = k0[i] + k1[i] * t + k2[i] * t2 + k3[i] * t3;
+        return 4;
+    }
+    case MPCVR_UPSCALE_CatmullRom: {     // ps_interpolation_spline4.hlsl:52-54
+        const float k1[4] = {-.5f, 0.f, .5f, 0.f};
+        const float k2[4] = {1.f, -2.5f, 2.f, -.5f};
+        const float k3[4] = {-.5f, 1.5f, -1.5f, .5f};
+        for (int i = 0; i < 4; i++) w[i] = k1[i] * t + k2[i] * t2 + k3[i] * t3;
+        w[1] += 1.f;
+        return 4;
+    }
+    case MPCVR_UPSCALE_Lanczos2: {       // ps_interpolation_lanczos2.hlsl:31-56
+        if (t == 0.0f) { w[0] = 0; w[1] = 1; w[2] = 0; w[3] = 0; return 4; }
+        const float d[4] = {1.f + t, 0.f + t, 1.f - t, 2.f - t};
+        for (int i = 0; i < 4; i++) {
+            const float a = d[i] * kPi;
+            w[i] = std::sin(a) * std::sin(a * .5f) / (d[i] * d[i] * kPi * kPi * .5f);
+        }
+        const float wc = 1.f - (w[0] + w[1] + w[2] + w[3]);
+        w[1] += wc * (1.f - t);
+        w[2] += wc * t;
+        return 4;
+    }
+    case MPCVR_UPSCALE_Lanczos3: {       // ps_interpolation_lanczos3.hlsl:31-64
+        if (t == 0.0f) { w[0] = w[1] = 0; w[2] = 1; w[3] = w[4] = w[5] = 0; return 6; }
+        float lo[3], hi[3];
+        for (int i = 0; i < 3; i++) {
+            const float a = (float)(2 - i) * kPi + t * kPi, as = a * .5f;
+            const float b = (float)(1 + i) * kPi - t * kPi, bs = b * .5f;
+            lo[i] = std::sin(a) * std::sin(as) / (a * as);
+            hi[i] = std::sin(b) * std::sin(bs) / (b * bs);
+        }
+        const float wc = 1.f - ((lo[0] + hi[0]) + (lo[1] + hi[1]) + (lo[2] + hi[2]));
+        lo[2] += wc * (1.f - t);
+        hi[0] += wc * t;
+        w[0] = lo[0]; w[1] = lo[1]; w[2] = lo[2]; w[3] = hi[0]; w[4] = hi[1]; w[5] = hi[2];
+        return 6;
+    }
+    default: return 0;
+    }
+}
+
+float DownscaleFilter(int method, float x, float *support)
+{
+    auto sup = [&](float s) { if (support) *support = s; };
+    switch (method) {
+    case MPCVR_DOWNSCALE_Box:
+        sup(0.5f);
+        return (x >= -0.5f && x < 0.5f) ? 1.0f : 0.0f;
+    case MPCVR_DOWNSCALE_Bilinear:
+        sup(1.0f);
+        x = x < 0.0f ? -x : x;
+        return x < 1.0f ? 1.0f - x : 0.0f;
+    case MPCVR_DOWNSCALE_Hamming:
+        sup(1.0f);
+        x = x < 0.0f ? -x : x;
+        if (x == 0.0f) return 1.0f;
+        if (x >= 1.0f) return 0.0f;
+        x *= kPi;
+        return std::sin(x) / x * (0.54f + 0.46f * std::cos(x));
+    case MPCVR_DOWNSCALE_Bicubic:
+    case MPCVR_DOWNSCALE_BicubicSharp: {
+        const float A = method == MPCVR_DOWNSCALE_Bicubic ? -0.5f : -1.5f;   // compile_shaders.cmd:98-101
+        sup(2.0f);
+        x = x < 0.0f ? -x : x;
+        if (x < 1.0f) return ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1;
+        if (x < 2.0f) return (((x - 5) * x + 8) * x - 4) * A;
+        return 0.0f;
+    }
+    case MPCVR_DOWNSCALE_Lanczos: {
+        sup(3.0f);
+        if (!(-3.0f <= x && x < 3.0f)) return 0.0f;
+        auto sinc = [](float v) { if (v == 0.0f) return 1.0f; v *= kPi; return std::sin(v) / v; };
+        return sinc(x) * sinc(x / 3);
+    }
+    default:
+        sup(0.0f);
+        return 0.0f;
+    }
+}
+
+static inline int ClampI(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Tex[AXIS]*wh[AXIS] of output i: src_l + (i + 0.5) * srcLen/dstLen, scale as in the cbuffer (:353)
+static inline float AxisCenter(int src_l, int i, float scale) { return (float)src_l + ((float)i + 0.5f) * scale; }
+
+bool BuildAxisTaps(Resizer rs, int src_l, int src_len, int n_out, int tex_len, uint32_t flags, HostAxisTaps *out)
+{
+    const float scale = (float)src_len / (float)n_out;
+    out->idx.clear(); out->w.clear(); out->wsum.clear();
+    out->normalise = 0;
+    if (rs.kind == RS_NONE) {
+        out->ntaps = 1;
+        out->idx.resize(n_out); out->w.assign(n_out, 1.0f);
+        for (int i = 0; i < n_out; i++)
+            out->idx[i] = ClampI((int)std::floor(AxisCenter(src_l, i, scale)), 0, tex_len - 1);
+        return true;
+    }
+    if (rs.kind == RS_UP) {
+        float probe[6];
+        const int n = UpscaleWeights(rs.method, 0.5f, probe);
+        if (n != 4 && n != 6) return false;
+        out->ntaps = n;
+        out->idx.resize((size_t)n_out * n); out->w.resize((size_t)n_out * n);
+        // D3D11 Lanczos3 reads Q1 from Q0's texel (ps_interpolation_lanczos3.hlsl:33-34,42-43)
+        static const int off4[4] = {-1, 0, 1, 2};
+        static const int off6_d3d11[6] = {-2, -2, 0, 1, 2, 3};
+        static const int off6_fixed[6] = {-2, -1, 0, 1, 2, 3};
+        const int *off = n == 4 ? off4 : ((flags & MPCVR_FLAG_LANCZOS3_FIXED) ? off6_fixed : off6_d3d11);
+        for (int i = 0; i < n_out; i++) {
+            float pos = AxisCenter(src_l, i, scale) - 0.5f;
+            const float t = pos - std::floor(pos);
+            pos -= t;
+            const int base = (int)pos;
+            float w[6];
+            UpscaleWeights(rs.method, t, w);
+            for (int k = 0; k < n; k++) {
+                out->idx[(size_t)i * n + k] = ClampI(base + off[k], 0, tex_len - 1);
+                out->w[(size_t)i * n + k] = w[k];
+            }
+        }
+        return true;
+    }
+    // RS_DOWN — ps_convolution.hlsl:23-50
+    float support0 = 0;
+    DownscaleFilter(rs.method, 0.0f, &support0);
+    const float support = support0 * scale;
+    const float ss = 1.0f / scale;
+    int maxn = 0;
+    std::vector<int> lows(n_out), highs(n_out);
+    for (int i = 0; i < n_out; i++) {
+        const float pos = AxisCenter(src_l, i, scale) + 0.5f;
+        lows[i] = (int)std::floor(pos - support);
+        highs[i] = (int)std::ceil(pos + support);
+        if (highs[i] - lows[i] > maxn) maxn = highs[i] - lows[i];
+    }
+    if (maxn <= 0 || maxn > 128) return false;
+    out->ntaps = maxn;
+    out->normalise = 1;
+    out->idx.assign((size_t)n_out * maxn, 0); out->w.assign((size_t)n_out * maxn, 0.0f); out->wsum.resize(n_out);
+    for (int i = 0; i < n_out; i++) {
+        const float pos = AxisCenter(src_l, i, scale) + 0.5f;
+        float ww = 0.0f;
+        int k = 0;
+        for (int n = lows[i]; n < highs[i]; n++, k++) {
+            const float w = DownscaleFilter(rs.method, ((float)n - pos + 0.5f) * ss, nullptr);
+            ww += w;
+            out->idx[(size_t)i * maxn + k] = ClampI(n, 0, tex_len - 1);
+            out->w[(size_t)i * maxn + k] = w;
+        }
+        for (; k < maxn; k++) out->idx[(size_t)i * maxn + k] = ClampI(lows[i], 0, tex_len - 1);   // w = 0 padding
+        out->wsum[i] = ww;
+    }
+    return true;
+}
+
+void BuildPointIndex(int src_l, int src_len, int n_out, int tex_len, std::vector<int32_t> *out)
+{
+    const float scale = (float)src_len / (float)n_out;
+    out->resize(n_out);
+    for (int i = 0; i < n_out; i++)
+        (*out)[i] = ClampI((int)std::floor(AxisCenter(src_l, i, scale)), 0, tex_len - 1);
+}
+
+bool DecidePlan(int iTexFormat, int iChromaScaling, int iUpscaling, int iDownscaling, int bInterpolateAt50pct,
+                int bUseDither, int output_format, uint32_t flags, const FmtConvParams &f,
+                const PlanGeometry &g, PassPlan *plan, std::string *why)
+{
+    PassPlan p;
+    switch (iTexFormat) {                                   // UpdateTexParams :1143-1155
+    case MPCVR_TEXFMT_8INT: p.internal_fmt = SF_BGRA8; break;
+    case MPCVR_TEXFMT_10INT: p.internal_fmt = SF_RGB10A2; break;
+    case MPCVR_TEXFMT_16FLOAT: p.internal_fmt = SF_RGBA16F; break;
+    default: p.internal_fmt = f.CDepth > 8 ? SF_RGB10A2 : SF_BGRA8; break;
+    }
+    p.swap_fmt = output_format == MPCVR_OUT_RGB10A2 ? SF_RGB10A2 : SF_BGRA8;
+    const bool needDither = (p.swap_fmt == SF_BGRA8 && p.internal_fmt != SF_BGRA8) ||
+                            (p.swap_fmt == SF_RGB10A2 && p.internal_fmt == SF_RGBA16F);   // :2896-2900
+    p.final_pass = bUseDither && needDither;
+    p.quant = p.swap_fmt == SF_RGB10A2 ? 1023 : 255;
+
+    const int w1 = g.w1, h1 = g.h1, w2 = g.vr - g.vl, h2 = g.vb - g.vt;
+    const int k = bInterpolateAt50pct ? 2 : 1;                                            // :3108
+    if (iUpscaling == MPCVR_UPSCALE_Jinc2) { if (why) *why = "Jinc2 upscaler is not implemented"; return false; }
+    const Resizer up{iUpscaling == MPCVR_UPSCALE_Nearest ? RS_NONE : RS_UP, iUpscaling};
+    const Resizer down{RS_DOWN, iDownscaling};
+    const Resizer none{RS_NONE, 0};
+    p.rx = (w1 == w2) ? none : (w1 > k * w2) ? down : up;                                 // :3125-3126
+    p.ry = (h1 == h2) ? none : (h1 > k * h2) ? down : up;
+    p.two_pass = p.rx.kind != RS_NONE && p.ry.kind != RS_NONE;
+    p.one_pass = !p.two_pass && (w1 != w2 || h1 != h2);
+    if (p.one_pass) p.one_pass_axis = (p.rx.kind != RS_NONE || (p.ry.kind == RS_NONE && w1 != w2)) ? 0 : 1;
+    p.copy_only = !p.two_pass && !p.one_pass;
+    // fused 2x candidate: exact 2x on both axes with an interpolation shader, bilinear 4:2:0 chroma,
+    // UNORM internal format, destination fully inside the window
+    p.fused_up2x = !(flags & MPCVR_FLAG_NO_FUSED) && p.two_pass && w2 == 2 * w1 && h2 == 2 * h1 &&
+                   p.rx.kind == RS_UP && p.ry.kind == RS_UP && f.Subsampling == 420 &&
+                   iChromaScaling == MPCVR_CHROMA_Bilinear && p.internal_fmt != SF_RGBA16F &&
+                   g.vl >= 0 && g.vt >= 0 && g.vr <= g.ww && g.vb <= g.wh && w1 >= 8 && h1 >= 8 && !(w1 & 1);
+    *plan = p;
+    return true;
+}
+
+std::string PassPlan::describe() const
+{
+    if (fused_up2x) return "fused_up2x";
+    std::string s = "passes:convert";
+    if (two_pass) s += final_pass ? ",resizeX,resizeY+final" : ",resizeX,resizeY";
+    else if (one_pass) s += std::string(one_pass_axis == 0 ? ",resizeX" : ",resizeY") + (final_pass ? "+final" : "");
+    else s += final_pass ? ",final" : ",copy";
+    return s;
+}
+
+}  // namespace mpcvr

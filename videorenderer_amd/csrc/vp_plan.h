@@ -1,0 +1,102 @@
+// vp_plan.h — host-side parameter maths of the shader video processor: format table, colourspace
+// defaults, YUV->RGB matrix, gamut matrix, pass selection and resize tap tables.
+// Mirrors (does not copy) Source/Helper.cpp, Source/csputils.cpp and the constant set-up in
+// Source/DX11VideoProcessor.cpp; each function cites what it replaces.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "vp_params.h"
+
+namespace mpcvr {
+
+// ---- format table (Helper.cpp:295-359 s_FmtConvMapping) ----
+struct FmtConvParams {
+    int cformat;
+    const char *str;
+    int planes, bytes, div_w, div_h;
+    int Packsize, PitchCoeff;
+    int Subsampling, CDepth;
+    int shift;      // 10-bit planar formats are <<6 by CopyPlane10to16 (Helper.cpp:386-391)
+    int v_first;    // YV12/YV16/YV24
+};
+const FmtConvParams *GetFmtConvParams(int cformat);            // Helper.cpp:361-369
+int DefaultPitch(const FmtConvParams &f, int width);           // DX11VideoProcessor.cpp:1789-1803
+int SourceLines(const FmtConvParams &f, int height);           // m_srcLines
+
+// ---- DXVA2_ExtendedFormat (dxva2api.h layout) ----
+struct ExtFmt {
+    uint32_t value;
+    unsigned SampleFormat() const { return value & 0xff; }
+    unsigned VideoChromaSubsampling() const { return (value >> 8) & 0xf; }
+    unsigned NominalRange() const { return (value >> 12) & 0x7; }
+    unsigned VideoTransferMatrix() const { return (value >> 15) & 0x7; }
+    unsigned VideoLighting() const { return (value >> 18) & 0xf; }
+    unsigned VideoPrimaries() const { return (value >> 22) & 0x1f; }
+    unsigned VideoTransferFunction() const { return (value >> 27) & 0x1f; }
+    void set(int shift, unsigned mask, unsigned v) { value = (value & ~(mask << shift)) | ((v & mask) << shift); }
+};
+ExtFmt SpecifyExtendedFormat(ExtFmt ex, const FmtConvParams &f, int w, int h);   // Helper.cpp:1169-1211
+
+// ---- colour maths ----
+struct ProcAmp { float brightness = 0, contrast = 1, hue = 0, saturation = 1; };  // DXVA2 units
+// SetShaderConvertColorParams (DX11VideoProcessor.cpp:813-887) -> 12 floats cm_r,cm_g,cm_b,cm_c
+void ComputeColorMatrix(const ExtFmt &ex, const FmtConvParams &f, const ProcAmp &pa, float out12[12]);
+// GetColorspaceGamutConversionMatrix(BT2020 -> BT709) (csputils.cpp:549-557)
+void ComputeGamut2020to709(float out9[9]);
+// which HDR tail GetShaderConvertColor emits (Shaders.cpp:613-616, 861-923)
+void SelectTail(const ExtFmt &ex, bool convert_to_sdr, int *tail, float *gamma);
+
+// per-channel PQ->SDR chain saturate -> ST2084ToLinear*LuminanceScale -> Hable/hable(4.8) sampled at
+// i/1023 (st2084.hlsl:9-16, hdr_tone_mapping.hlsl:1-13): the optional tone-map LUT of the fused path
+void BuildPqSdrLut(float lum_scale, float out[1024]);
+
+// ---- resize ----
+enum ResizerKind { RS_NONE = 0, RS_UP = 1, RS_DOWN = 2 };
+struct Resizer { int kind; int method; };
+
+struct HostAxisTaps {
+    int ntaps = 0;
+    int normalise = 0;
+    std::vector<int32_t> idx;
+    std::vector<float> w;
+    std::vector<float> wsum;
+};
+// weights for one fractional phase (ps_interpolation_*.hlsl); returns tap count (4/6) or 0
+int UpscaleWeights(int iUpscaling, float t, float w[6]);
+// convolution kernels (Shaders/resize/convolution_filters.hlsl); *support optional
+float DownscaleFilter(int iDownscaling, float x, float *support);
+// tap table for n_out outputs of one TextureResizeShader draw along one axis
+// (DX11VideoProcessor.cpp:332-377 + the shader bodies).  Returns false if unsupported.
+bool BuildAxisTaps(Resizer rs, int src_l, int src_len, int n_out, int tex_len, uint32_t flags,
+                   HostAxisTaps *out);
+// nearest / identity index map of the unfiltered axis of a draw
+void BuildPointIndex(int src_l, int src_len, int n_out, int tex_len, std::vector<int32_t> *out);
+
+// ---- the pass plan of one Process() (DX11VideoProcessor.cpp:3285-3424, shader path) ----
+struct PassPlan {
+    int internal_fmt = SF_BGRA8;     // UpdateTexParams :1143-1155
+    int swap_fmt = SF_BGRA8;         // render-target format
+    bool final_pass = false;         // UpdatePostScaleTexures :2894-2912
+    int quant = 255;
+    Resizer rx{RS_NONE, 0}, ry{RS_NONE, 0};
+    bool two_pass = false;           // X into fp16 m_TexResize, then Y
+    bool one_pass = false;           // a single draw (one filtered axis, other point-sampled)
+    int one_pass_axis = 0;
+    bool copy_only = false;          // no size change: straight copy / final pass from the convert output
+    bool fused_up2x = false;         // eligible for the fused 2x kernel
+    std::string describe() const;
+};
+
+struct PlanGeometry { int w1, h1;            // source rect size (== convert output)
+                      int vl, vt, vr, vb;    // video rect
+                      int ww, wh; };         // window size
+// Pure decision logic of UpdateTexParams / UpdatePostScaleTexures / ResizeShaderPass (no device work).
+// cfg fields use the Settings_t names; returns false + *why when the combination is not implemented.
+struct mpcvr_settings_fwd;
+bool DecidePlan(int iTexFormat, int iChromaScaling, int iUpscaling, int iDownscaling, int bInterpolateAt50pct,
+                int bUseDither, int output_format, uint32_t flags, const FmtConvParams &f,
+                const PlanGeometry &g, PassPlan *plan, std::string *why);
+
+}  // namespace mpcvr
