@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the shader-video-processor path on MI355X.
+
+Metric (BASELINE.json): 4K frames/sec/GPU for P010 -> Lanczos3 2x -> PQ->SDR -> dither, and % of HBM roofline.
+Workload "c3hdr" (SURVEY.md §8d): 3840x2160 P010 (BT.2020NC, PQ, TV range) -> UPSCALE_Lanczos3 2x (D3D11
+quirks as written) -> 7680x4320 B8G8R8A8 with the 32x32 ordered dither; algorithmic bytes/frame =
+24,883,200 (in) + 132,710,400 (out) = 157,593,600.
+
+A "step" = one pass of the hot path over one batch of `--batch` frames (one mpcvr_process_batch call; the
+fused kernel covers the whole batch in ONE launch).  Inputs are resident in HBM before the timed region; a
+ring of distinct noise frames larger than the 256 MiB Infinity Cache is cycled so no step re-reads cached input.
+
+    python bench.py                       # N=1, finishes in a few minutes incl. the CPU baseline
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+        bench.py --gpus 8 --steps 50 --warmup 5
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+
+WORKLOADS = {
+    # name: (cformat, src_w, src_h, scale, extfmt fields, iUpscaling, description)
+    "c3hdr": dict(cformat=2, w=3840, h=2160, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
+                  iUpscaling=4, desc="4K P010 BT.2020/PQ -> Lanczos3 2x -> PQ->SDR(Hable,125nits) -> ordered dither -> 8K BGRA8"),
+    "c3": dict(cformat=2, w=3840, h=2160, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=1, primaries=2, transfer=5),
+               iUpscaling=4, desc="4K P010 BT.709 SDR -> Lanczos3 2x -> ordered dither -> 8K BGRA8"),
+    "c4": dict(cformat=2, w=3840, h=2160, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
+               iUpscaling=1, desc="4K P010 HDR10 -> Mitchell 2x -> PQ->SDR -> ordered dither -> 8K BGRA8"),
+    "c5": dict(cformat=2, w=3840, h=2160, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=16),
+               iUpscaling=4, desc="4K P010 HLG -> Lanczos3 2x -> HLG->SDR -> ordered dither -> 8K BGRA8"),
+    "c2": dict(cformat=20, w=1920, h=1080, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=1, primaries=2, transfer=5),
+               iUpscaling=2, desc="1080p YUV420P10 BT.709 -> Catmull-Rom 2x -> ordered dither -> 4K BGRA8"),
+    "c3hdr_1080p": dict(cformat=2, w=1920, h=1080, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
+                        iUpscaling=4, desc="1080p P010 BT.2020/PQ -> Lanczos3 2x -> PQ->SDR -> dither -> 4K BGRA8 (alternative reading)"),
+}
+
+
+def noise_frame_gpu(torch, wl, nbytes, pitch, gen):
+    """Legal-range noise directly on the GPU (incompressible; throughput only — parity uses synth.py)."""
+    w, h = wl["w"], wl["h"]
+    if wl["cformat"] == 2:                                   # P010: 10-bit codes in the MSBs
+        y = torch.randint(64, 941, (h, w), device="cuda", generator=gen, dtype=torch.int32) << 6
+        c = torch.randint(64, 961, (h // 2, w), device="cuda", generator=gen, dtype=torch.int32) << 6
+        buf = torch.cat([y.reshape(-1), c.reshape(-1)]).to(torch.int16).view(torch.uint8)
+    elif wl["cformat"] == 20:                                # YUV420P10: raw codes, three planes
+        y = torch.randint(64, 941, (h * w,), device="cuda", generator=gen, dtype=torch.int32)
+        c = torch.randint(64, 961, (2 * (h // 2) * (w // 2),), device="cuda", generator=gen, dtype=torch.int32)
+        buf = torch.cat([y, c]).to(torch.int16).view(torch.uint8)
+    else:
+        raise ValueError("workload format")
+    assert buf.numel() == nbytes, (buf.numel(), nbytes)
+    return buf.contiguous()
+
+
+def cpu_baseline(wl, extfmt, seconds_budget=20.0):
+    """The oracle (our literal C restatement of the reference HLSL; SURVEY.md F1: the reference has NO CPU
+    pixel path) timed on this box's host cores on a bounded sample of the same workload."""
+    try:
+        from oracle import oracle as O
+        import numpy as np
+        from videorenderer_amd import synth
+        O.lib()
+        w, h, s = wl["w"], wl["h"], wl["scale"]
+        frame, pitch = synth.make_frame(wl["cformat"], w, h, "noise", seed=1)
+        p = O.default_params(cformat=wl["cformat"], width=w, height=h, exfmt=extfmt, iUpscaling=wl["iUpscaling"],
+                             window_w=w * s, window_h=h * s, video_rect=(0, 0, w * s, h * s))
+        dst = np.zeros((h * s, w * s, 4), dtype=np.uint8)
+        threads = O.lib().orc_num_threads()
+        t0 = time.perf_counter()
+        O.process(p, frame, pitch, dst=dst)                  # warm-up + first estimate
+        first = time.perf_counter() - t0
+        n = max(1, min(8, int(seconds_budget / max(first, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            O.process(p, frame, pitch, dst=dst)
+        dt = (time.perf_counter() - t0) / n
+        return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": int(threads), "kind": "port",
+                "sample": f"{n} full {w}x{h}->{w*s}x{h*s} frames of the same workload, oracle C (-O3 -msse2 -fopenmp), "
+                          f"{threads} threads, {dt*1e3:.0f} ms/frame"}
+    except Exception as e:      # the baseline is a reported side figure: never fail the bench for it
+        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3hdr", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=8, help="frames per step (per GPU)")
+    ap.add_argument("--ring", type=int, default=16, help="distinct input frames cycled (>= batch)")
+    ap.add_argument("--flags", type=int, default=0, help="mpcvr_settings.flags (2 = pass-per-kernel path)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from videorenderer_amd import api, dist as vdist
+
+    rank, world, local = vdist.init_from_env()
+    if world != max(1, args.gpus) and rank == 0:
+        print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    torch.cuda.set_device(local % torch.cuda.device_count())
+    dev = torch.cuda.current_device()
+
+    wl = WORKLOADS[args.workload]
+    w, h, s = wl["w"], wl["h"], wl["scale"]
+    extfmt = api.make_extfmt(**wl["ext"])
+    settings = api.default_settings(iUpscaling=wl["iUpscaling"], flags=args.flags)
+    vp = api.VideoProcessor(settings, device=dev)
+    vp.InitMediaType(wl["cformat"], w, h, extfmt=extfmt)
+    vp.SetWindowRect((0, 0, w * s, h * s))
+    vp.SetVideoRect((0, 0, w * s, h * s))
+    vdist.sync_params(vp)                                  # RCCL broadcast of rank 0's parameter blob (few KiB)
+    nbytes, pitch = vp.GetFrameBytes()
+    out_bytes = w * s * h * s * 4
+    algo_bytes = nbytes + out_bytes
+
+    ring = max(args.ring, args.batch)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(0x4D50 + rank)
+    srcs = [noise_frame_gpu(torch, wl, nbytes, pitch, gen) for _ in range(ring)]
+    dsts = [torch.empty((h * s, w * s, 4), dtype=torch.uint8, device="cuda") for _ in range(ring)]
+
+    def step(i):
+        k = (i * args.batch) % ring
+        idx = [(k + j) % ring for j in range(args.batch)]
+        vp.ProcessBatch([srcs[j] for j in idx], [dsts[j] for j in idx], w * s * 4)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()                                  # torch's current stream IS the context's stream (SetStream)
+        step(args.warmup + i)
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed = vdist.max_over_ranks(elapsed)
+    launch_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps       # per step == per launch on the fused path
+    launch_ms = vdist.max_over_ranks(launch_ms)
+    path = vp.GetVPInfo()
+
+    if rank == 0:
+        frames = world * args.batch * args.steps
+        fps = frames / elapsed
+        achieved = algo_bytes * args.batch / (launch_ms * 1e-3) / 1e9          # GB/s, algorithmic bytes per launch
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")                  # filled from the rocprofv3 --pmc passes
+        if os.path.exists(tf):
+            try:
+                t = json.load(open(tf)).get(args.workload)
+                if t and t.get("batch") == args.batch:
+                    traffic = t["bytes_per_launch"]
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "4K frames/sec/GPU (P010->Lanczos3 2x->PQ-SDR->dither); % HBM roofline",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 (u16 in, u8 out)", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {wl['desc']}", "frames_per_step_per_gpu": args.batch,
+                       "input_ring_frames": ring, "path": path, "sharding": "frames by index, no data-path collective",
+                       "fps_per_gpu": round(fps / world, 2), "algorithmic_bytes_per_frame": algo_bytes},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel_ms_per_launch": round(launch_ms, 4), "bytes_per_launch": algo_bytes * args.batch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(wl, extfmt)
+        print(json.dumps(res), flush=True)
+    vp.close()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,341 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): |delta| <= 1 LSB per 8-bit channel, dither table/indexing bit-exact.
+Tighter where the arithmetic allows it:
+  * pass-per-kernel path, SDR (no transcendental instruction on the path): BIT-EXACT with the oracle;
+  * pass-per-kernel path with a PQ/HLG/gamma tail: <= 1 LSB, >= 99.5 % of channels identical;
+  * fused 2x kernel (FMA contraction, LDS tone-map LUT): <= 1 LSB, >= 99 % identical.
+"""
+import numpy as np
+import pytest
+
+from tests.golden.cases import GOLDEN_CASES, SETTING_KEYS, case_frame, case_geometry, oracle_params, run_case
+
+pytestmark = pytest.mark.gpu
+
+BG = 7      # background byte of the render target: pixels outside the video rect must stay untouched
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch
+
+
+def has_tail(c):
+    trc = (c.get("exfmt", 0) >> 27) & 0x1f
+    prim = (c.get("exfmt", 0) >> 22) & 0x1f
+    return (trc in (15, 16) and c.get("bConvertToSdr", 1)) or prim == 9
+
+
+def make_vp(mpcvr, c, extra_flags=0):
+    from videorenderer_amd import api
+    kw = {k: c[k] for k in SETTING_KEYS if k in c}
+    kw["flags"] = kw.get("flags", 0) | extra_flags
+    vp = api.VideoProcessor(api.default_settings(**kw))
+    (ww, wh), vr = case_geometry(c)
+    vp.InitMediaType(c["cformat"], c["w"], c["h"], pitch=c.get("pitch", 0), src_rect=c.get("src_rect"), extfmt=c.get("exfmt", 0))
+    vp.SetWindowRect((0, 0, ww, wh))
+    vp.SetVideoRect(vr)
+    if "procamp" in c:
+        vp.SetProcAmpValues(*c["procamp"])
+    return vp, (ww, wh)
+
+
+def run_product(mpcvr, torch, c, extra_flags=0, host_upload=False):
+    vp, (ww, wh) = make_vp(mpcvr, c, extra_flags)
+    frame, pitch = case_frame(c)
+    assert vp.GetFrameBytes() == (frame.size, pitch)
+    dst = torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda")
+    if host_upload:
+        vp.CopySample(frame, pitch)
+    else:
+        dev = torch.from_numpy(frame).cuda()
+        vp.CopySample(dev, pitch)
+    vp.Process(dst, ww * 4)
+    vp.Synchronize()
+    info = vp.GetVPInfo()
+    out = dst.cpu().numpy()
+    vp.close()
+    return out, info
+
+
+def compare(got, want, name, exact=False, min_same=0.99):
+    assert got.shape == want.shape, name
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    same = float((d == 0).mean())
+    assert d.max() <= (0 if exact else 1), f"{name}: max |delta| = {d.max()} ({(d > 1).sum()} channels > 1 LSB, same={same:.5f})"
+    assert same >= min_same, f"{name}: only {same:.5f} of channels identical"
+    return same
+
+
+def compare_rgb10(got, want, name, exact=False):
+    g, w = got.view(np.uint32)[..., 0], want.view(np.uint32)[..., 0]
+    for sh in (0, 10, 20):
+        d = np.abs(((g >> sh) & 1023).astype(np.int32) - ((w >> sh) & 1023).astype(np.int32))
+        assert d.max() <= (0 if exact else 4), f"{name}: 10-bit delta {d.max()}"      # 4/1023 ~ 1/255
+    assert np.array_equal(g >> 30, w >> 30)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(GOLDEN_CASES))
+def test_pass_per_kernel_path_vs_oracle(mpcvr, oracle, torch_cuda, name):
+    from videorenderer_amd import api
+    c = GOLDEN_CASES[name]
+    want = run_case(oracle, name, background=BG)
+    got, info = run_product(mpcvr, torch_cuda, c, extra_flags=api.FLAG_NO_FUSED)
+    assert info.startswith("passes:"), info
+    if c.get("output_format", 0) == 1:
+        compare_rgb10(got, want, name, exact=not has_tail(c))
+    elif has_tail(c):
+        compare(got, want, name, min_same=0.995)
+    else:
+        compare(got, want, name, exact=True)          # no transcendental on the path: bit-exact
+
+
+def _is_exact_2x(c):
+    r = c.get("src_rect", (0, 0, c["w"], c["h"]))
+    return c["dst"] == (2 * (r[2] - r[0]), 2 * (r[3] - r[1]))
+
+
+FUSED = sorted(n for n, c in GOLDEN_CASES.items() if _is_exact_2x(c))
+
+
+@pytest.mark.parametrize("name", FUSED)
+def test_default_path_vs_oracle(mpcvr, oracle, torch_cuda, name):
+    """Default settings: whatever path the planner picks (the fused 2x kernel where eligible)."""
+    c = GOLDEN_CASES[name]
+    want = run_case(oracle, name, background=BG)
+    got, info = run_product(mpcvr, torch_cuda, c)
+    if c.get("output_format", 0) == 1:
+        compare_rgb10(got, want, name)
+    else:
+        compare(got, want, f"{name} [{info}]", min_same=0.99)
+
+
+def test_fused_kernel_is_actually_used(mpcvr, torch_cuda):
+    used = 0
+    for name in FUSED:
+        vp, _ = make_vp(mpcvr, GOLDEN_CASES[name])
+        used += vp.GetVPInfo() == "fused_up2x"
+        vp.close()
+    assert used >= 15
+
+
+@pytest.mark.parametrize("name", ["c3hdr_p010_pq_lanczos3_2x", "noise_p010_pq_lanczos3_2x", "p010_cosited_pq", "yuv420p16_mpeg1",
+                                  "noise_nv12_catmull_2x", "c2_yuv420p10_catmull_2x", "ragged_2x"])
+def test_fused_variants_agree(mpcvr, oracle, torch_cuda, name):
+    """A/B of the fused kernel's internal shortcuts: LUT vs ALU tone-map, vectorised vs per-pixel convert."""
+    from videorenderer_amd import api
+    c = GOLDEN_CASES[name]
+    want = run_case(oracle, name, background=BG)
+    base, info = run_product(mpcvr, torch_cuda, c)
+    assert info == "fused_up2x"
+    for flags in (api.FLAG_NO_LUT, api.FLAG_NO_FAST_CONVERT, api.FLAG_NO_LUT | api.FLAG_NO_FAST_CONVERT):
+        alt, _ = run_product(mpcvr, torch_cuda, c, extra_flags=flags)
+        compare(alt, want, f"{name} flags={flags}", min_same=0.99)
+        compare(alt, base, f"{name} flags={flags} vs default", min_same=0.99)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_host_upload_equals_zero_copy(mpcvr, torch_cuda):
+    for name in ("c3hdr_p010_pq_lanczos3_2x", "c2_yuv420p10_catmull_2x", "down_hamming_3x"):
+        a, _ = run_product(mpcvr, torch_cuda, GOLDEN_CASES[name], host_upload=True)
+        b, _ = run_product(mpcvr, torch_cuda, GOLDEN_CASES[name], host_upload=False)
+        assert np.array_equal(a, b), name
+
+
+def test_get_current_image_and_render(mpcvr, oracle, torch_cuda):
+    """GetCurentImage = Process at source-rect size into a BGRX target (DX11VideoProcessor.cpp:3493-3608);
+    Render clears the letterbox to black and draws into the owned back buffer (:2599-2813)."""
+    torch = torch_cuda
+    c = dict(GOLDEN_CASES["crop_offset_letterbox"])
+    vp, (ww, wh) = make_vp(mpcvr, c)
+    frame, pitch = case_frame(c)
+    vp.CopySample(frame, pitch)
+    snap = vp.GetCurentImage().reshape(48, 64, 4)
+    c2 = dict(c, dst=(64, 48), window=(64, 48), offset=(0, 0))
+    want = oracle_params(oracle, c2)
+    ref = oracle.process(want, frame, pitch)
+    compare(snap, ref, "GetCurentImage", min_same=0.999)
+    # rects are restored afterwards
+    assert vp.Render(1) == 0
+    ptr, bpitch, bw, bh = vp.GetBackBuffer()
+    assert (bw, bh, bpitch) == (ww, wh, ww * 4)
+    vp.Synchronize()
+    back = torch.empty((wh, ww, 4), dtype=torch.uint8, device="cuda")
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(ctypes.c_void_p(back.data_ptr()), ctypes.c_void_p(ptr), ww * wh * 4, 3) == 0
+    full = run_case(oracle, "crop_offset_letterbox", background=0)
+    compare(back.cpu().numpy(), full, "Render", min_same=0.99)
+    vp.close()
+
+
+def test_process_batch_equals_single(mpcvr, torch_cuda):
+    torch = torch_cuda
+    for name, flags in (("noise_p010_pq_lanczos3_2x", 0), ("noise_p010_pq_lanczos3_2x", 2), ("down_lanczos_2p5x", 0)):
+        c = GOLDEN_CASES[name]
+        vp, (ww, wh) = make_vp(mpcvr, c, flags)
+        frames = [torch.from_numpy(case_frame(dict(c, seed=c["seed"] + 100 * i))[0]).cuda() for i in range(5)]
+        pitch = vp.GetFrameBytes()[1]
+        singles = []
+        for f in frames:
+            dst = torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda")
+            vp.CopySample(f, pitch)
+            vp.Process(dst, ww * 4)
+            singles.append(dst)
+        dsts = [torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda") for _ in frames]
+        vp.ProcessBatch(frames, dsts, ww * 4)
+        vp.Synchronize()
+        for i in range(5):
+            assert torch.equal(singles[i], dsts[i]), (name, flags, i)
+        assert not torch.equal(dsts[0], dsts[1])
+        assert vp.GetLastProcessMs() > 0
+        vp.close()
+
+
+def test_param_blob_roundtrip_and_override(mpcvr, torch_cuda):
+    """Rank-0 blob adopted by another context gives identical pixels (the multi-GPU broadcast payload)."""
+    torch = torch_cuda
+    c = GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]
+    a, _ = run_product(mpcvr, torch, c)
+    vp0, _ = make_vp(mpcvr, c)
+    blob = vp0.GetParamBlob()
+    assert 6000 < len(blob) < 16384
+    # the receiving context is deliberately configured with different nits: the blob must win
+    vp1, (ww, wh) = make_vp(mpcvr, dict(c, iSDRDisplayNits=300))
+    vp1.SetParamBlob(blob)
+    frame, pitch = case_frame(c)
+    dst = torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda")
+    vp1.CopySample(frame, pitch)
+    vp1.Process(dst, ww * 4)
+    vp1.Synchronize()
+    assert np.array_equal(dst.cpu().numpy(), a)
+    from videorenderer_amd import api
+    with pytest.raises(api.MpcvrError):
+        vp1.SetParamBlob(b"\0" * len(blob))
+    vp0.close(); vp1.close()
+
+
+def test_configure_rebuilds_only_what_changed(mpcvr, oracle, torch_cuda):
+    torch = torch_cuda
+    from videorenderer_amd import api
+    c = GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]
+    vp, (ww, wh) = make_vp(mpcvr, c)
+    frame, pitch = case_frame(c)
+    vp.CopySample(frame, pitch)
+    assert vp.Configure(vp.settings.copy()) == api.S_FALSE                     # nothing changed
+    assert vp.Configure(vp.settings.copy(iUpscaling=api.UPSCALE_Mitchell, iSDRDisplayNits=200)) == api.S_OK
+    dst = torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda")
+    vp.Process(dst, ww * 4)
+    vp.Synchronize()
+    c2 = dict(c, iUpscaling=1, iSDRDisplayNits=200)
+    p = oracle_params(oracle, c2)
+    compare(dst.cpu().numpy(), oracle.process(p, frame, pitch), "after Configure", min_same=0.99)
+    vp.close()
+
+
+def test_error_behaviour(mpcvr, torch_cuda):
+    torch = torch_cuda
+    from videorenderer_amd import api
+    vp = api.VideoProcessor()
+    dst = torch.zeros((16, 16, 4), dtype=torch.uint8, device="cuda")
+
+    def hr_of(fn):
+        with pytest.raises(api.MpcvrError) as e:
+            fn()
+        return e.value.hr
+
+    assert hr_of(lambda: vp.Process(dst, 64)) == api.E_NOT_VALID_STATE                  # no media type yet
+    assert hr_of(lambda: vp.InitMediaType(4, 64, 64)) == api.E_NOTIMPL                  # YUY2 not in this build
+    assert hr_of(lambda: vp.InitMediaType(1, 63, 64)) == api.E_INVALIDARG               # odd width, 4:2:0
+    assert hr_of(lambda: vp.InitMediaType(1, 64, 64, src_rect=(0, 0, 65, 64))) == api.E_INVALIDARG
+    vp.InitMediaType(1, 64, 64)
+    assert hr_of(lambda: vp.Process(dst, 64)) == api.E_NOT_VALID_STATE                  # no sample yet
+    assert vp.Render(1) == api.S_FALSE                                                  # nothing to draw
+    buf = torch.zeros(64 * 96, dtype=torch.uint8, device="cuda")
+    assert hr_of(lambda: vp.CopySample(buf, 128)) == api.E_UNEXPECTED                   # pitch != media type (:2545)
+    vp.CopySample(buf, 64)
+    assert hr_of(lambda: vp.Process(dst, 8)) == api.E_INVALIDARG                        # RT pitch too small
+    assert hr_of(lambda: vp.Process(dst, 256, src_rect=(0, 0, 32, 32))) == api.E_INVALIDARG
+    assert hr_of(lambda: vp.SetRotation(90)) == api.E_NOTIMPL
+    assert hr_of(lambda: vp.SetFlip(True)) == api.E_NOTIMPL
+    assert hr_of(lambda: vp.Configure(vp.settings.copy(iSDRDisplayNits=5))) == api.E_INVALIDARG
+    assert hr_of(lambda: vp.Configure(vp.settings.copy(iUpscaling=api.UPSCALE_Jinc2)) or vp.Process(dst, 256, dst_rect=(0, 0, 16, 16))) == api.E_NOTIMPL
+    vp.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties + oracle on sampled regions
+# ------------------------------------------------------------------------------------------------
+def _full_size_case(exfmt, iUpscaling, seed):
+    return dict(cformat=2, w=3840, h=2160, kind="noise", seed=seed, dst=(7680, 4320), exfmt=exfmt, iUpscaling=iUpscaling)
+
+
+@pytest.mark.parametrize("label,exfmt,up", [("c3hdr", GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"], 4),
+                                            ("c5_hlg", GOLDEN_CASES["c5_p010_hlg_lanczos3_2x"]["exfmt"], 4),
+                                            ("c4_mitchell", GOLDEN_CASES["c4_p010_pq_mitchell_2x"]["exfmt"], 1)])
+def test_full_size_4k_to_8k(mpcvr, oracle, torch_cuda, label, exfmt, up):
+    """4K P010 -> 8K at BASELINE size: (1) fused kernel vs pass-per-kernel path over all 33 M pixels,
+    (2) oracle on sampled 256x128 source regions (interior, crop-invariance of the path), (3) alpha/shape."""
+    torch = torch_cuda
+    from videorenderer_amd import api
+    c = _full_size_case(exfmt, up, seed=77)
+    frame, pitch = case_frame(c)
+    dev = torch.from_numpy(frame).cuda()
+    outs = {}
+    for flags in (0, api.FLAG_NO_FUSED):
+        vp, (ww, wh) = make_vp(mpcvr, c, flags)
+        dst = torch.empty((wh, ww, 4), dtype=torch.uint8, device="cuda")
+        vp.CopySample(dev, pitch)
+        vp.Process(dst, ww * 4)
+        vp.Synchronize()
+        outs[flags] = dst
+        info = vp.GetVPInfo()
+        assert info == ("fused_up2x" if flags == 0 else "passes:convert,resizeX,resizeY+final")
+        vp.close()
+    fused, general = outs[0], outs[api.FLAG_NO_FUSED]
+    assert bool((fused[..., 3] == 255).all())
+    d = (fused.to(torch.int16) - general.to(torch.int16)).abs()
+    assert int(d.max()) <= 1
+    assert float((d == 0).float().mean()) >= 0.99
+    # oracle on sampled regions: crop offsets are multiples of 16 source px => dither phase 0 in the crop
+    gen = general.cpu().numpy()
+    fus = fused.cpu().numpy()
+    for (x0, y0) in ((0, 0), (1792, 1024), (3584, 2032), (16, 2032), (3584, 0)):
+        cw, ch = 256, 128
+        p = oracle.default_params(cformat=2, width=3840, height=2160, exfmt=exfmt, iUpscaling=up,
+                                  src_rect=(x0, y0, x0 + cw, y0 + ch), window_w=2 * cw, window_h=2 * ch,
+                                  video_rect=(0, 0, 2 * cw, 2 * ch))
+        want = oracle.process(p, frame, pitch)
+        # resize taps of the crop clamp at the crop border: compare the interior only, except where the crop
+        # border coincides with the frame border (then the full frame clamps identically)
+        l = 0 if x0 == 0 else 8
+        t = 0 if y0 == 0 else 8
+        r = 2 * cw if x0 + cw == 3840 else 2 * cw - 8
+        b = 2 * ch if y0 + ch == 2160 else 2 * ch - 8
+        for arr, nm in ((gen, "general"), (fus, "fused")):
+            sub = arr[2 * y0 + t: 2 * y0 + b, 2 * x0 + l: 2 * x0 + r]
+            compare(sub, want[t:b, l:r], f"{label} {nm} region ({x0},{y0})", min_same=0.99)
+
+
+def test_full_size_flat_frame_and_dither_period(mpcvr, torch_cuda):
+    """Constant input at 4K: every pass keeps it constant; the only variation is the 32x32 dither tile."""
+    torch = torch_cuda
+    w, h = 3840, 2160
+    buf = np.zeros(w * h * 3 // 2, dtype=np.uint16)
+    buf[: w * h] = 600 << 6
+    buf[w * h:] = 512 << 6
+    c = dict(cformat=2, w=w, h=h, dst=(2 * w, 2 * h), exfmt=GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"], iUpscaling=4)
+    vp, (ww, wh) = make_vp(mpcvr, c)
+    dst = torch.empty((wh, ww, 4), dtype=torch.uint8, device="cuda")
+    vp.CopySample(torch.from_numpy(buf.view(np.uint8)).cuda(), w * 2)
+    vp.Process(dst, ww * 4)
+    vp.Synchronize()
+    tile = dst[:32, :32]
+    assert int(tile[..., :3].max()) - int(tile[..., :3].min()) <= 1
+    tiled = tile.repeat(wh // 32, ww // 32, 1)
+    assert torch.equal(tiled, dst)
+    vp.close()
