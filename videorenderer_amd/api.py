@@ -186,7 +186,7 @@ def plan_gamut_2020_to_709():
 
 
 def plan_pq_lut(lum_scale):
-    out = (C.c_float * 1024)()
+    out = (C.c_float * 4096)()
     load_library().mpcvr_plan_pq_lut(lum_scale, out)
     return list(out)
 

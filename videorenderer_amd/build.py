@@ -22,7 +22,7 @@ SOURCES = [
     ("vp_plan.cpp", ["-ffp-contract=off"]),
     ("hip_video_processor.cpp", []),
     ("mpcvr_capi.cpp", []),
-    ("vp_kernels.hip", ["-ffp-contract=off"]),
+    ("vp_kernels.hip", ["-ffp-contract=off", "-DMPCVR_EXACT_FP"]),
     ("vp_fused.hip", []),
 ]
 

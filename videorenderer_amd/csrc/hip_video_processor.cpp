@@ -26,7 +26,7 @@ struct ParamBlob {
     float gamma;
     Up2xWeights upx, upy;
     uint16_t dither[1024];
-    float pq_lut[1024];      // tone-map LUT (valid when tail == PQ->SDR)
+    float pq_lut[kPqLutSize];      // tone-map LUT (valid when tail == PQ->SDR)
 };
 static const uint32_t kBlobMagic = 0x4256504du;
 

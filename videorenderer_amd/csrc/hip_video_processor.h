@@ -131,8 +131,8 @@ private:
     const uint8_t *m_curSample = nullptr;   // device pointer of the current sample (own buffer or zero-copy)
     DevBuffer m_TexConvertOutput, m_TexResize, m_BackBuffer, m_Snapshot;
     DevBuffer m_dither;
-    DevBuffer m_pqLut;             // 1024 floats (fused path tone-map table)
-    float m_pqLutHost[1024];
+    DevBuffer m_pqLut;             // kPqLutSize floats (fused path tone-map table)
+    float m_pqLutHost[kPqLutSize];
     bool m_pqLutValid = false;
     DevBuffer m_tapsXi, m_tapsXw, m_tapsXs, m_tapsYi, m_tapsYw, m_tapsYs, m_otherX, m_otherY;
     AxisTaps m_tapsX{}, m_tapsY{};

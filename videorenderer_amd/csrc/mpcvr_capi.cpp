@@ -185,10 +185,11 @@ int32_t mpcvr_plan_gamut_2020_to_709(float out9[9])
     return MPCVR_S_OK;
 }
 
-int32_t mpcvr_plan_pq_lut(float lum_scale, float out1024[1024])
+int32_t mpcvr_plan_pq_lut(float lum_scale, float out4096[4096])
 {
-    if (!out1024) return MPCVR_E_POINTER;
-    mpcvr::BuildPqSdrLut(lum_scale, out1024);
+    static_assert(mpcvr::kPqLutSize == 4096, "header documents 4096 entries");
+    if (!out4096) return MPCVR_E_POINTER;
+    mpcvr::BuildPqSdrLut(lum_scale, out4096);
     return MPCVR_S_OK;
 }
 

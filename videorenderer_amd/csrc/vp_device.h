@@ -13,6 +13,11 @@ struct f3 { float x, y, z; };
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 __device__ __forceinline__ float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }   // NaN -> 0
 
+// The transfer / tone-map chain below is ill-conditioned where the 2020->709 matrix cancels to ~0 and
+// pow(1/2.2) then magnifies the residue, so its expression shapes are kept identical in every
+// translation unit (no FMA contraction): the fused and the pass-per-kernel path then agree bit for bit.
+#pragma clang fp contract(off)
+
 // HLSL pow(x, y) = exp2(y * log2(x)); raw v_log_f32 / v_exp_f32 (≈1 ulp each), log2(0) = -inf -> 0.
 __device__ __forceinline__ float hlsl_pow(float x, float y)
 {
@@ -104,6 +109,10 @@ __device__ __forceinline__ f3 hdr_tail(f3 c, int tail, float gamma, float lum_sc
     c.z = hlsl_pow(saturate(c.z), 1.0f / 2.2f);
     return c;
 }
+
+#ifndef MPCVR_EXACT_FP              // vp_kernels.hip is built -ffp-contract=off -DMPCVR_EXACT_FP and stays off
+#pragma clang fp contract(fast)     // back to the compiler default for HIP device code
+#endif
 
 // ---- source texel loads: UNORM8/16 -> float, clamp addressing, CopyPlane10to16 shift on the fly ----
 __device__ __forceinline__ float load_sample(const uint8_t *plane, int pitch, int bytes, int shift, int x, int y)

@@ -23,7 +23,7 @@ struct FusedParams {
     Up2xWeights wx, wy;
     StoreParams store;        // dst ignored; per frame
     int out_w, out_h;         // 2*conv.out_w, 2*conv.out_h
-    const float *pq_lut;      // device, 1024 floats: x -> Hable(ST2084ToLinear(x)*scale)/hable(4.8); null => ALU
+    const float *pq_lut;      // device, kPqLutSize floats: x -> Hable(ST2084ToLinear(x)*scale)/hable(4.8); null => ALU
     int fast_convert;         // layout/alignments allow the vectorised 4-pixel convert
 };
 bool FusedUp2xSupported(const FusedParams &P);

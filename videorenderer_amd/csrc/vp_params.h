@@ -5,6 +5,10 @@
 
 namespace mpcvr {
 
+// entries of the fused path's PQ->SDR per-channel table (linear interpolation; worst case 0.17 LSB of the
+// 10-bit convert output on saturated colours, where the gamut matrix cancels to near zero)
+constexpr int kPqLutSize = 4096;
+
 // surface formats of the intermediate / output textures
 // (m_InternalTexFmt — DX11VideoProcessor.cpp:1143-1155; m_TexResize is always fp16 — :3155)
 enum SurfFmt : int { SF_BGRA8 = 8, SF_RGB10A2 = 10, SF_RGBA16F = 16 };

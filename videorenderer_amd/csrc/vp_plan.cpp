@@ -247,7 +247,7 @@ void SelectTail(const ExtFmt &ex, bool convert_to_sdr, int *tail, float *gamma)
 // ------------------------------------------------------------------------------------------------
 // PQ -> SDR per-channel table (Shaders/convert/st2084.hlsl:1-16, hdr_tone_mapping.hlsl:1-13)
 // ------------------------------------------------------------------------------------------------
-void BuildPqSdrLut(float lum_scale, float out[1024])
+void BuildPqSdrLut(float lum_scale, float out[kPqLutSize])
 {
     const float m1 = 2610.0f / (4096.0f * 4.0f), m2 = (2523.0f / 4096.0f) * 128.0f;
     const float c1 = 3424.0f / 4096.0f, c2 = (2413.0f / 4096.0f) * 32.0f, c3 = (2392.0f / 4096.0f) * 32.0f;
@@ -256,8 +256,8 @@ void BuildPqSdrLut(float lum_scale, float out[1024])
         return ((x * (A * x + (C * B)) + (D * E)) / (x * (A * x + B) + (D * F))) - E / F;
     };
     const float div = hable(4.8f);
-    for (int i = 0; i < 1024; i++) {
-        float x = (float)i / 1023.0f;
+    for (int i = 0; i < kPqLutSize; i++) {
+        float x = (float)i / (float)(kPqLutSize - 1);
         x = std::exp2(std::log2(x) * (1.0f / m2));
         x = std::fmax(x - c1, 0.0f) / (c2 - c3 * x);
         x = std::exp2(std::log2(x) * (1.0f / m1));

@@ -49,8 +49,8 @@ void ComputeGamut2020to709(float out9[9]);
 void SelectTail(const ExtFmt &ex, bool convert_to_sdr, int *tail, float *gamma);
 
 // per-channel PQ->SDR chain saturate -> ST2084ToLinear*LuminanceScale -> Hable/hable(4.8) sampled at
-// i/1023 (st2084.hlsl:9-16, hdr_tone_mapping.hlsl:1-13): the optional tone-map LUT of the fused path
-void BuildPqSdrLut(float lum_scale, float out[1024]);
+// i/(kPqLutSize-1) (st2084.hlsl:9-16, hdr_tone_mapping.hlsl:1-13): the optional tone-map LUT of the fused path
+void BuildPqSdrLut(float lum_scale, float out[kPqLutSize]);
 
 // ---- resize ----
 enum ResizerKind { RS_NONE = 0, RS_UP = 1, RS_DOWN = 2 };
