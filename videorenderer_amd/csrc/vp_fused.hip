@@ -40,7 +40,7 @@ constexpr int A_FLOATS = 2 * 3 * AW;
 constexpr int LUT_N = kPqLutSize;  // PQ->SDR per-channel table (vp_params.h)
 constexpr int LDS_A = WAVES * A_FLOATS * 4;
 constexpr int LDS_D = 32 * 32 * 2;
-constexpr int LDS_T = LUT_N * 4;
+constexpr int LDS_T = (LUT_N + 4) * 4;   // + a duplicated last entry (and padding)
 
 typedef const __attribute__((address_space(1))) uint8_t *gcptr;
 typedef __attribute__((address_space(1))) uint8_t *gptr;
@@ -61,6 +61,7 @@ struct FusedArgs {
     float gamut[9];
     const float *lut;              // LUT_N floats (device) for TAILK_PQ_LUT
     float maxv, inv_maxv;          // internal UNORM format
+    float q_over_maxv;             // ps_final_pass QUANTIZATION / maxv
     float we[6], wo[6];            // phase weights (even/odd outputs); Q1-merged on the host side of the launch
     int dst_pitch, off_x, off_y;
     int final_pass, out10;
@@ -86,9 +87,9 @@ __device__ __forceinline__ float unorm_to_float(float q, float maxv, float inv)
 
 __device__ __forceinline__ float lut_eval(const float *T, float x)
 {
-    const float t = saturate(x) * (float)(LUT_N - 1);
-    const int i = min((int)t, LUT_N - 2);
-    const float fr = t - (float)i;
+    const float t = saturate(x) * (float)(LUT_N - 1);      // T has LUT_N + 1 entries (last one duplicated)
+    const int i = (int)t;
+    const float fr = __builtin_amdgcn_fractf(t);
     const float a = T[i], b = T[i + 1];
     return fmaf(b - a, fr, a);
 }
@@ -210,8 +211,45 @@ __device__ __forceinline__ uint32_t pack_h2(float a, float b)
 __device__ __forceinline__ float h_lo(uint32_t u) { return __half2float(__ushort_as_half((unsigned short)(u & 0xffffu))); }
 __device__ __forceinline__ float h_hi(uint32_t u) { return __half2float(__ushort_as_half((unsigned short)(u >> 16))); }
 
+// acc' = fp32(half(h2.lo|hi)) * w + acc as ONE v_fma_mix_f32 (the fp16 operand is converted exactly inside the
+// instruction, so this equals cvt + fma bit for bit); CLAMP saturates the result to [0,1] for free.
+// hipcc only forms v_fma_mix_f32 when the converted half has a single use; here every window value feeds an
+// even and an odd output row, which otherwise costs a separate v_cvt_f32_f16 per value.
+template <bool HI, bool FIRST, bool CLAMP>
+__device__ __forceinline__ float mix_fma(uint32_t h2, float w, float acc)
+{
+    float r;
+    if (FIRST) {
+        if (HI) { if (CLAMP) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(r) : "v"(h2), "s"(w));
+                  else       asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "s"(w)); }
+        else    { if (CLAMP) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(r) : "v"(h2), "s"(w));
+                  else       asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "s"(w)); }
+    } else {
+        if (HI) { if (CLAMP) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(r) : "v"(h2), "s"(w), "v"(acc));
+                  else       asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "s"(w), "v"(acc)); }
+        else    { if (CLAMP) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(r) : "v"(h2), "s"(w), "v"(acc));
+                  else       asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "s"(w), "v"(acc)); }
+    }
+    return r;
+}
+
+// one vertical tap chain: sum over the NT window rows of weight * window value, saturated
+template <int NT, int PX>
+__device__ __forceinline__ float ytaps(const uint32_t (&win)[8][3][2], int c, const int (&slot)[6], const float (&w)[6])
+{
+    float acc = 0.0f;
+#pragma unroll
+    for (int tt = 0; tt < NT; tt++) {
+        const uint32_t d = win[slot[tt]][c][PX >> 1];
+        if (tt == 0) acc = mix_fma<(PX & 1) != 0, true, false>(d, w[0], 0.0f);
+        else if (tt == NT - 1) acc = mix_fma<(PX & 1) != 0, false, true>(d, w[tt], acc);
+        else acc = mix_fma<(PX & 1) != 0, false, false>(d, w[tt], acc);
+    }
+    return acc;
+}
+
 template <int NT, int TAIL>
-__global__ __launch_bounds__(256) void k_fused_up2x(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single)
+__global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *Aall = (float *)smem;
@@ -220,7 +258,7 @@ __global__ __launch_bounds__(256) void k_fused_up2x(FusedArgs P, const FusedFram
 
     for (int i = threadIdx.x; i < 1024; i += 256) D[i] = P.dither[i];
     if (TAIL == TAILK_PQ_LUT)
-        for (int i = threadIdx.x; i < LUT_N; i += 256) T[i] = P.lut[i];
+        for (int i = threadIdx.x; i <= LUT_N; i += 256) T[i] = P.lut[min(i, LUT_N - 1)];
     __syncthreads();                                   // the only workgroup barrier: tables visible
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -282,9 +320,9 @@ __global__ __launch_bounds__(256) void k_fused_up2x(FusedArgs P, const FusedFram
                 float q[3][4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {     // store to m_TexConvertOutput (UNORM) and read back
-                    q[0][e] = unorm_to_float(unorm_q(v[e].x, P.maxv), P.maxv, P.inv_maxv);
-                    q[1][e] = unorm_to_float(unorm_q(v[e].y, P.maxv), P.maxv, P.inv_maxv);
-                    q[2][e] = unorm_to_float(unorm_q(v[e].z, P.maxv), P.maxv, P.inv_maxv);
+                    q[0][e] = unorm_q(v[e].x, P.maxv) * P.inv_maxv;       // q/maxv to within 1 ulp
+                    q[1][e] = unorm_q(v[e].y, P.maxv) * P.inv_maxv;
+                    q[2][e] = unorm_q(v[e].z, P.maxv) * P.inv_maxv;
                 }
                 if (!interior) {                  // clamp-to-edge of the convert texture: replicate its border pixel
 #pragma unroll
@@ -348,26 +386,20 @@ __global__ __launch_bounds__(256) void k_fused_up2x(FusedArgs P, const FusedFram
                 for (int kk = 0; kk < 2; kk++) {
                     const int k = a - 3 + kk;                     // source row -> output rows 2k, 2k+1
                     if (k >= s1) break;
-                    float res[2][4][3];
+                    // even: base = k-1 -> row k-1+off = a-6 + (kk+2+off); odd: base = k -> a-6 + (kk+3+off)
+                    int se[6], so[6];
+#pragma unroll
+                    for (int tt = 0; tt < 6; tt++) {
+                        se[tt] = tt < NT ? ((2 * u + 2 + kk + 2 + tap_off<NT>(tt)) & 7) : 0;
+                        so[tt] = tt < NT ? ((2 * u + 2 + kk + 3 + tap_off<NT>(tt)) & 7) : 0;
+                    }
+                    float res[2][4][3];            // saturated Y-pass results
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
-#pragma unroll
-                        for (int px = 0; px < 4; px++) {
-                            float ev = 0.0f, od = 0.0f;
-#pragma unroll
-                            for (int tt = 0; tt < NT; tt++) {
-                                // even: base = k-1 -> row k-1+off = a-6 + (kk+2+off); odd: base = k -> a-6 + (kk+3+off)
-                                const int ie = (2 * u + 2 + kk + 2 + tap_off<NT>(tt)) & 7;
-                                const int io = (2 * u + 2 + kk + 3 + tap_off<NT>(tt)) & 7;
-                                const uint32_t de = win[ie][c][px >> 1], dd = win[io][c][px >> 1];
-                                const float ve = (px & 1) ? h_hi(de) : h_lo(de);
-                                const float vo = (px & 1) ? h_hi(dd) : h_lo(dd);
-                                ev = tt == 0 ? we[0] * ve : fmaf(we[tt], ve, ev);
-                                od = tt == 0 ? wo[0] * vo : fmaf(wo[tt], vo, od);
-                            }
-                            res[0][px][c] = ev;
-                            res[1][px][c] = od;
-                        }
+                        res[0][0][c] = ytaps<NT, 0>(win, c, se, we); res[1][0][c] = ytaps<NT, 0>(win, c, so, wo);
+                        res[0][1][c] = ytaps<NT, 1>(win, c, se, we); res[1][1][c] = ytaps<NT, 1>(win, c, so, wo);
+                        res[0][2][c] = ytaps<NT, 2>(win, c, se, we); res[1][2][c] = ytaps<NT, 2>(win, c, so, wo);
+                        res[0][3][c] = ytaps<NT, 3>(win, c, se, we); res[1][3][c] = ytaps<NT, 3>(win, c, so, wo);
                     }
 #pragma unroll
                     for (int par = 0; par < 2; par++) {
@@ -389,15 +421,18 @@ __global__ __launch_bounds__(256) void k_fused_up2x(FusedArgs P, const FusedFram
                             float c3[3];
 #pragma unroll
                             for (int c = 0; c < 3; c++) {
-                                if (P.final_pass) {
-                                    const float qi = unorm_q(res[par][px][c], P.maxv);              // m_TexsPostScale store
-                                    const float p = unorm_to_float(qi, P.maxv, P.inv_maxv);         // ... and load
-                                    c3[c] = floorf(fmaf(p, P.quant, d4[px]));                       // ps_final_pass.hlsl:29
-                                } else {
-                                    c3[c] = unorm_q(res[par][px][c], P.quant);                      // straight into the RT
-                                }
+                                // res is already saturated (clamp on the last tap).  m_TexsPostScale store/load:
+                                // q = floor(x*maxv + 0.5), p = q/maxv; ps_final_pass.hlsl:29: floor(p*Q + d).
+                                // p*Q is evaluated as q*(Q/maxv) inside one FMA (<= 1 ulp from the two-step form).
+                                const float q = floorf(fmaf(res[par][px][c], P.final_pass ? P.maxv : P.quant, 0.5f));
+                                c3[c] = P.final_pass ? floorf(fmaf(q, P.q_over_maxv, d4[px])) : q;
                             }
-                            pk[px] = P.out10 ? pack_rgb10a2(c3[0], c3[1], c3[2]) : pack_bgra8(c3[0], c3[1], c3[2]);
+                            if (P.out10) pk[px] = pack_rgb10a2(c3[0], c3[1], c3[2]);
+                            else {      // exact small integers: v_cvt_pk_u8_f32 converts and places a byte per instruction
+                                uint32_t v = __builtin_amdgcn_cvt_pk_u8_f32(c3[2], 0, 0xff000000u);      // B
+                                v = __builtin_amdgcn_cvt_pk_u8_f32(c3[1], 1, v);                         // G
+                                pk[px] = __builtin_amdgcn_cvt_pk_u8_f32(c3[0], 2, v);                    // R
+                            }
                         }
                         __attribute__((address_space(1))) uint32_t *dst =
                             (__attribute__((address_space(1))) uint32_t *)(pdst + (size_t)wy * P.dst_pitch) + wx0;
@@ -465,6 +500,7 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     a.lut = P.pq_lut;
     a.maxv = c.out_fmt == SF_RGB10A2 ? 1023.0f : 255.0f;
     a.inv_maxv = 1.0f / a.maxv;
+    a.q_over_maxv = (float)P.store.quant / a.maxv;
     const int nt = P.wx.ntaps;
     for (int t = 0; t < 6; t++) { a.we[t] = P.wx.w_even[t]; a.wo[t] = P.wx.w_odd[t]; }
     int knt = nt;
