@@ -8,16 +8,21 @@
 //   convert output -> UNORM8/10 (m_InternalTexFmt), X pass -> fp16 RNE (:3155), Y pass -> UNORM8/10,
 //   final pass floor(p*Q + dither) (ps_final_pass.hlsl:29).
 //
-// Design: WAVE-AUTONOMOUS STRIPS WITH A REGISTER-RESIDENT VERTICAL WINDOW.
+// Design: WAVE-AUTONOMOUS STRIPS, REGISTER-RESIDENT VERTICAL WINDOW, PACKED FP32 MATH.
 //   Exact 2x => two fixed phases per axis (t = 0.75 for even outputs, base = k-1; t = 0.25 for odd, base = k).
 //   One wavefront owns a strip of S = 120 source columns (240 output columns = 60 lanes x 4 px = one
 //   16-byte store per lane and output row) and marches down a segment of source rows, two rows per
 //   iteration, with no workgroup barrier inside the loop:
-//     stage C  2 rows x 128 px (4-px halo each side): 4 px per lane from raw codes prefetched one iteration
-//              ahead -> this wave's LDS slice A (fp32, already rounded to the internal UNORM format)
-//     stage X  lane l reads A columns 2l..2l+9 and produces the 4 output columns it owns for both new rows;
-//              the fp16-rounded results (m_TexResize) go into an 8-row register window — no LDS, no HBM
-//     stage Y  from the window: 4 output rows x 4 px per lane, UNORM rounding (m_TexsPostScale), dither, store
+//     stage C  lane j converts the 2x2 block {cols 2j,2j+1} x {rows a,a+1} of the 128-column window
+//              (4-px halo each side) from raw codes prefetched one iteration ahead and writes it, rounded to
+//              the internal UNORM format, to this wave's LDS slice A as (row a, row a+1) pairs
+//     stage X  lane l reads columns 2l..2l+9 (5 x ds_read_b128 per channel) and produces the 4 output
+//              columns it owns for BOTH rows at once (v_pk_fma_f32 on the row pairs); the fp16-rounded
+//              results (m_TexResize) enter an 8-row register window — no LDS, no HBM
+//     stage Y  from the window: 4 output rows x 4 px per lane with v_pk_fma_f32 on pixel pairs, UNORM
+//              rounding (m_TexsPostScale), dither, one 16-byte store per row
+//   gfx950 issues one wave64 VALU instruction per ~4 cycles per SIMD whatever its width (measured,
+//   tools/ubench/valu_rate.hip), so v_pk_{fma,mul}_f32 is what doubles the arithmetic rate here.
 //   The four waves of a workgroup share only the read-only tables (dither, PQ->SDR LUT).
 //   Recomputed: the horizontal halo (8 of 128 columns) and 6 rows per segment.
 #include <hip/hip_fp16.h>
@@ -36,14 +41,16 @@ namespace {
 constexpr int S = 120;             // source pixels per strip
 constexpr int AW = 128;            // LDS A row width: rect columns x0-4 .. x0+123
 constexpr int WAVES = 4;           // strips per workgroup
-constexpr int A_FLOATS = 2 * 3 * AW;
+constexpr int A_FLOATS = 3 * AW * 2;   // [ch][col][row a | row a+1]
 constexpr int LUT_N = kPqLutSize;  // PQ->SDR per-channel table (vp_params.h)
 constexpr int LDS_A = WAVES * A_FLOATS * 4;
 constexpr int LDS_D = 32 * 32 * 2;
-constexpr int LDS_T = (LUT_N + 4) * 4;   // + a duplicated last entry (and padding)
+constexpr int LDS_T = LUT_N * 8;   // {value, delta-to-next} pairs
 
 typedef const __attribute__((address_space(1))) uint8_t *gcptr;
 typedef __attribute__((address_space(1))) uint8_t *gptr;
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 enum { TAILK_NONE = 0, TAILK_PQ_LUT = 1, TAILK_ALU = 2 };
 
@@ -62,7 +69,7 @@ struct FusedArgs {
     const float *lut;              // LUT_N floats (device) for TAILK_PQ_LUT
     float maxv, inv_maxv;          // internal UNORM format
     float q_over_maxv;             // ps_final_pass QUANTIZATION / maxv
-    float we[6], wo[6];            // phase weights (even/odd outputs); Q1-merged on the host side of the launch
+    float we[6], wo[6];            // phase weights (even/odd outputs); Q1-folded by the launcher
     int dst_pitch, off_x, off_y;
     int final_pass, out10;
     float quant;
@@ -70,34 +77,36 @@ struct FusedArgs {
     int seg_rows;
 };
 
-// tap offsets relative to `base` (ps_interpolation_*.hlsl); with the D3D11 Lanczos3 quirk Q1 the second
-// tap re-reads the first tap's texel (ps_interpolation_lanczos3.hlsl:33-34): the launcher folds its weight
-// into tap 0 and zeroes it, so the kernel can keep the regular offsets.
-// NT = 5 is that case: taps {-2, 0, 1, 2, 3} with the first weight = w0 + w1 (folded by the launcher).
+// tap offsets relative to `base` (ps_interpolation_*.hlsl).  NT = 5 is the D3D11 Lanczos3 as written (quirk Q1,
+// ps_interpolation_lanczos3.hlsl:33-34: the second tap re-reads the first tap's texel): taps {-2, 0, 1, 2, 3}
+// with the first weight = w0 + w1 (folded by the launcher).
 template <int NT>
 __host__ __device__ constexpr int tap_off(int t) { return NT == 4 ? (t - 1) : NT == 6 ? (t - 2) : (t == 0 ? -2 : t - 1); }
 
-// exact q/maxv (correctly rounded like the UNORM->float load) from the reciprocal: one Newton step
-__device__ __forceinline__ float unorm_to_float(float q, float maxv, float inv)
+__device__ __forceinline__ f2 splat(float x) { return f2{x, x}; }
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 sat2(f2 v) { return f2{saturate(v.x), saturate(v.y)}; }
+// a*b + c saturated to [0,1] in the same instruction (VOP3P clamp bit); `w` is wave-uniform (SGPR pair)
+__device__ __forceinline__ f2 pk_fma_sat_s(f2 w, f2 b, f2 c)
 {
-    const float r0 = q * inv;
-    const float e = fmaf(-r0, maxv, q);
-    return fmaf(e, inv, r0);
+    f2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "s"(w), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ f2 floor2(f2 v) { return f2{floorf(v.x), floorf(v.y)}; }
+
+// {value, delta} table lookup with linear interpolation; x already in [0,1]
+__device__ __forceinline__ float lut_eval(const f2 *T, float x)
+{
+    const float t = x * (float)(LUT_N - 1);
+    const f2 e = T[(int)t];
+    return fmaf(e.y, __builtin_amdgcn_fractf(t), e.x);
 }
 
-__device__ __forceinline__ float lut_eval(const float *T, float x)
-{
-    const float t = saturate(x) * (float)(LUT_N - 1);      // T has LUT_N + 1 entries (last one duplicated)
-    const int i = (int)t;
-    const float fr = __builtin_amdgcn_fractf(t);
-    const float a = T[i], b = T[i + 1];
-    return fmaf(b - a, fr, a);
-}
-
-// raw codes of one 4-pixel group of one source row, prefetched one iteration ahead
+// raw codes of one 2x2 block (cols Xg, Xg+1; two source rows), prefetched one iteration ahead
 struct Raw {
-    uint32_t y0, y1;         // luma: 2 dwords (16-bit) or y0 only (8-bit: 4 bytes)
-    uint32_t c[2][4];        // chroma rows r0/r1, columns c0-1..c0+2: packed (U | V<<16) codes
+    uint32_t y[2];           // luma of the two rows: 2 px each (16-bit: one dword; 8-bit: low 16 bits)
+    uint32_t c[2][2][3];     // [luma row][chroma row r0/r1][cols c0-1, c0, c0+1]: packed (U | V<<16) codes
 };
 
 __device__ __forceinline__ uint32_t ld_u8(gcptr p) { return *p; }
@@ -118,147 +127,103 @@ __device__ __forceinline__ uint32_t ld_uv(const FusedArgs &P, gcptr pu, gcptr pv
     return ld_u8(pu + ro + col) | (ld_u8(pv + ro + col) << 16);
 }
 
-// Xg: first rect column of the group actually fetched (== X for interior groups; clamped at the rect edges)
-__device__ __forceinline__ void load_raw(const FusedArgs &P, gcptr py, gcptr pu, gcptr pv, int Xg, int y, Raw &r)
+// vertical chroma position of source row sy (Shaders.cpp:118-138): v' = (sy+0.5)/2 [+0.25 co-sited] - 0.5
+__device__ __forceinline__ float chroma_v(const FusedArgs &P, int sy) { return ((float)sy + 0.5f) * 0.5f + P.v_off - 0.5f; }
+
+// Xg: first rect column of the block (even, inside the rect); y0,y1: the two (clamped) rect rows
+__device__ __forceinline__ void load_raw(const FusedArgs &P, gcptr py, gcptr pu, gcptr pv, int Xg, int y0, int y1, Raw &r)
 {
-    const int sx0 = P.rect_l + Xg, sy = P.rect_t + y;
-    const gcptr ry = py + (size_t)sy * P.pitch_y;
-    if (P.bytes == 2) {
-        const int i0 = sx0 >> 1, i1 = min(i0 + 1, (P.tex_w >> 1) - 1);
-        r.y0 = ld_u32(ry + 4 * i0);
-        r.y1 = ld_u32(ry + 4 * i1);
-    } else {
-        r.y0 = ld_u32(ry + sx0);          // 4 bytes; sx0 % 4 == 0 and pitch % 4 == 0 (checked on the host)
-        r.y1 = 0;
-    }
-    // vertical chroma position (Shaders.cpp:118-138): v' = (sy+0.5)/2 [+0.25 co-sited] - 0.5
-    const float fv = ((float)sy + 0.5f) * 0.5f + P.v_off - 0.5f;
-    const int iv = (int)floorf(fv);
-    const int r0 = clampi(iv, 0, P.ch - 1), r1 = clampi(iv + 1, 0, P.ch - 1);
+    const int sx0 = P.rect_l + Xg;
     const int c0 = sx0 >> 1;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        if (i == 0 && !P.center_h) { r.c[0][0] = r.c[1][0] = 0; continue; }
-        r.c[0][i] = ld_uv(P, pu, pv, c0 - 1 + i, r0);
-        r.c[1][i] = ld_uv(P, pu, pv, c0 - 1 + i, r1);
-    }
-}
-
-// 4:2:0 bilinear chroma + matrix for the 4 pixels of a group (ShaderGetPixels' CHROMA_Bilinear branch,
-// Shaders.cpp:265-270,319-325): same sample positions and weights, evaluated in code units
-// (vertical lerp first), UNORM scale folded into the matrix.
-template <int TAIL>
-__device__ __forceinline__ void convert4(const FusedArgs &P, const Raw &r, int sy, const float *T, f3 out[4])
-{
-    float Y[4];
-    if (P.bytes == 2) {
-        Y[0] = (float)(r.y0 & 0xffffu); Y[1] = (float)(r.y0 >> 16); Y[2] = (float)(r.y1 & 0xffffu); Y[3] = (float)(r.y1 >> 16);
-    } else {
-        Y[0] = (float)(r.y0 & 0xffu); Y[1] = (float)((r.y0 >> 8) & 0xffu); Y[2] = (float)((r.y0 >> 16) & 0xffu); Y[3] = (float)(r.y0 >> 24);
-    }
-    const float fv = ((float)sy + 0.5f) * 0.5f + P.v_off - 0.5f;
-    const float wy = fv - floorf(fv), wy0 = 1.0f - wy;
-    float U[4], V[4];
+    for (int rr = 0; rr < 2; rr++) {
+        const int sy = P.rect_t + (rr ? y1 : y0);
+        const gcptr ry = py + (size_t)sy * P.pitch_y;
+        r.y[rr] = P.bytes == 2 ? ld_u32(ry + 2 * sx0) : ld_u16(ry + sx0);
+        const int iv = (int)floorf(chroma_v(P, sy));
+        const int r0 = clampi(iv, 0, P.ch - 1), r1 = clampi(iv + 1, 0, P.ch - 1);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        U[i] = fmaf((float)(r.c[1][i] & 0xffffu), wy, (float)(r.c[0][i] & 0xffffu) * wy0);
-        V[i] = fmaf((float)(r.c[1][i] >> 16), wy, (float)(r.c[0][i] >> 16) * wy0);
-    }
-    float Ue[4], Ve[4];
-    if (P.center_h) {       // u' = sx/2 - 0.25
-        Ue[0] = fmaf(U[1], 0.75f, U[0] * 0.25f); Ve[0] = fmaf(V[1], 0.75f, V[0] * 0.25f);
-        Ue[1] = fmaf(U[2], 0.25f, U[1] * 0.75f); Ve[1] = fmaf(V[2], 0.25f, V[1] * 0.75f);
-        Ue[2] = fmaf(U[2], 0.75f, U[1] * 0.25f); Ve[2] = fmaf(V[2], 0.75f, V[1] * 0.25f);
-        Ue[3] = fmaf(U[3], 0.25f, U[2] * 0.75f); Ve[3] = fmaf(V[3], 0.25f, V[2] * 0.75f);
-    } else {                // u' = sx/2
-        Ue[0] = U[1];                          Ve[0] = V[1];
-        Ue[1] = fmaf(U[2], 0.5f, U[1] * 0.5f); Ve[1] = fmaf(V[2], 0.5f, V[1] * 0.5f);
-        Ue[2] = U[2];                          Ve[2] = V[2];
-        Ue[3] = fmaf(U[3], 0.5f, U[2] * 0.5f); Ve[3] = fmaf(V[3], 0.5f, V[2] * 0.5f);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-        f3 v;
-        v.x = fmaf(P.m[0], Y[e], fmaf(P.m[1], Ue[e], fmaf(P.m[2], Ve[e], P.c[0])));
-        v.y = fmaf(P.m[3], Y[e], fmaf(P.m[4], Ue[e], fmaf(P.m[5], Ve[e], P.c[1])));
-        v.z = fmaf(P.m[6], Y[e], fmaf(P.m[7], Ue[e], fmaf(P.m[8], Ve[e], P.c[2])));
-        if (TAIL == TAILK_PQ_LUT) {
-            // Shaders.cpp:870-923: per-channel saturate -> ST2084ToLinear*scale -> Hable/hable(4.8) from the LDS
-            // table, then the 2020->709 matrix, saturate and pow 1/2.2 in ALU
-            const float a = lut_eval(T, v.x), b = lut_eval(T, v.y), c = lut_eval(T, v.z);
-            v.x = fmaf(P.gamut[0], a, fmaf(P.gamut[1], b, P.gamut[2] * c));
-            v.y = fmaf(P.gamut[3], a, fmaf(P.gamut[4], b, P.gamut[5] * c));
-            v.z = fmaf(P.gamut[6], a, fmaf(P.gamut[7], b, P.gamut[8] * c));
-            v.x = hlsl_pow(saturate(v.x), 1.0f / 2.2f);
-            v.y = hlsl_pow(saturate(v.y), 1.0f / 2.2f);
-            v.z = hlsl_pow(saturate(v.z), 1.0f / 2.2f);
-        } else if (TAIL == TAILK_ALU) {
-            v = hdr_tail(v, P.tail, P.gamma, P.lum_scale, P.gamut);
+        for (int i = 0; i < 3; i++) {
+            if (i == 0 && !P.center_h) { r.c[rr][0][0] = r.c[rr][1][0] = 0; continue; }
+            r.c[rr][0][i] = ld_uv(P, pu, pv, c0 - 1 + i, r0);
+            r.c[rr][1][i] = ld_uv(P, pu, pv, c0 - 1 + i, r1);
         }
-        out[e] = v;
     }
 }
 
-__device__ __forceinline__ float sel4(const float v[4], int i)
+// One source row of the block: 4:2:0 bilinear chroma + matrix (+ tail) for the 2 pixels (even, odd column).
+// ShaderGetPixels' CHROMA_Bilinear branch (Shaders.cpp:265-270,319-325): same sample positions and weights,
+// evaluated in code units (vertical lerp first), UNORM scale folded into the matrix.  Results are the three
+// channels as (even px, odd px) pairs, saturated when a tail or the UNORM store requires it anyway.
+template <int TAIL>
+__device__ __forceinline__ void convert_row(const FusedArgs &P, uint32_t yraw, const uint32_t (&c)[2][3], int sy, const f2 *T, f2 out[3])
 {
-    return i == 0 ? v[0] : i == 1 ? v[1] : i == 2 ? v[2] : v[3];
-}
-
-__device__ __forceinline__ uint32_t pack_h2(float a, float b)
-{
-    return (uint32_t)__half_as_ushort(__float2half_rn(a)) | ((uint32_t)__half_as_ushort(__float2half_rn(b)) << 16);
-}
-__device__ __forceinline__ float h_lo(uint32_t u) { return __half2float(__ushort_as_half((unsigned short)(u & 0xffffu))); }
-__device__ __forceinline__ float h_hi(uint32_t u) { return __half2float(__ushort_as_half((unsigned short)(u >> 16))); }
-
-// acc' = fp32(half(h2.lo|hi)) * w + acc as ONE v_fma_mix_f32 (the fp16 operand is converted exactly inside the
-// instruction, so this equals cvt + fma bit for bit); CLAMP saturates the result to [0,1] for free.
-// hipcc only forms v_fma_mix_f32 when the converted half has a single use; here every window value feeds an
-// even and an odd output row, which otherwise costs a separate v_cvt_f32_f16 per value.
-template <bool HI, bool FIRST, bool CLAMP>
-__device__ __forceinline__ float mix_fma(uint32_t h2, float w, float acc)
-{
-    float r;
-    if (FIRST) {
-        if (HI) { if (CLAMP) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(r) : "v"(h2), "s"(w));
-                  else       asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "s"(w)); }
-        else    { if (CLAMP) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(r) : "v"(h2), "s"(w));
-                  else       asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "s"(w)); }
-    } else {
-        if (HI) { if (CLAMP) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(r) : "v"(h2), "s"(w), "v"(acc));
-                  else       asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "s"(w), "v"(acc)); }
-        else    { if (CLAMP) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(r) : "v"(h2), "s"(w), "v"(acc));
-                  else       asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "s"(w), "v"(acc)); }
-    }
-    return r;
-}
-
-// one vertical tap chain: sum over the NT window rows of weight * window value, saturated
-template <int NT, int PX>
-__device__ __forceinline__ float ytaps(const uint32_t (&win)[8][3][2], int c, const int (&slot)[6], const float (&w)[6])
-{
-    float acc = 0.0f;
+    f2 Y;
+    if (P.bytes == 2) Y = f2{(float)(yraw & 0xffffu), (float)(yraw >> 16)};
+    else Y = f2{(float)(yraw & 0xffu), (float)((yraw >> 8) & 0xffu)};
+    const float fv = chroma_v(P, sy);
+    const float wy = fv - floorf(fv);
+    const f2 w1 = splat(wy), w0 = splat(1.0f - wy);
+    f2 UV[3];                                     // (U, V) of chroma columns c0-1, c0, c0+1 after the vertical lerp
 #pragma unroll
-    for (int tt = 0; tt < NT; tt++) {
-        const uint32_t d = win[slot[tt]][c][PX >> 1];
-        if (tt == 0) acc = mix_fma<(PX & 1) != 0, true, false>(d, w[0], 0.0f);
-        else if (tt == NT - 1) acc = mix_fma<(PX & 1) != 0, false, true>(d, w[tt], acc);
-        else acc = mix_fma<(PX & 1) != 0, false, false>(d, w[tt], acc);
+    for (int i = 0; i < 3; i++) {
+        const f2 top = f2{(float)(c[0][i] & 0xffffu), (float)(c[0][i] >> 16)};
+        const f2 bot = f2{(float)(c[1][i] & 0xffffu), (float)(c[1][i] >> 16)};
+        UV[i] = pk_fma(bot, w1, top * w0);
     }
-    return acc;
+    f2 uve, uvo;                                  // (U, V) at the even and the odd luma column
+    if (P.center_h) {                             // u' = sx/2 - 0.25
+        uve = pk_fma(UV[1], splat(0.75f), UV[0] * splat(0.25f));
+        uvo = pk_fma(UV[2], splat(0.25f), UV[1] * splat(0.75f));
+    } else {                                      // u' = sx/2
+        uve = UV[1];
+        uvo = pk_fma(UV[2], splat(0.5f), UV[1] * splat(0.5f));
+    }
+    const f2 U = f2{uve.x, uvo.x}, V = f2{uve.y, uvo.y};
+    f2 rgb[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++)
+        rgb[ch] = pk_fma_sat_s(splat(P.m[3 * ch]), Y, pk_fma(splat(P.m[3 * ch + 1]), U, pk_fma(splat(P.m[3 * ch + 2]), V, splat(P.c[ch]))));   // saturated: every continuation saturates first
+    if (TAIL == TAILK_PQ_LUT) {
+        // Shaders.cpp:870-923: per-channel saturate -> ST2084ToLinear*scale -> Hable/hable(4.8) from the LDS table,
+        // then the 2020->709 matrix, saturate and pow 1/2.2 in ALU
+        f2 lin[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            lin[ch] = f2{lut_eval(T, rgb[ch].x), lut_eval(T, rgb[ch].y)};
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const f2 g = pk_fma_sat_s(splat(P.gamut[3 * ch]), lin[0], pk_fma(splat(P.gamut[3 * ch + 1]), lin[1], splat(P.gamut[3 * ch + 2]) * lin[2]));
+            out[ch] = f2{hlsl_pow(g.x, 1.0f / 2.2f), hlsl_pow(g.y, 1.0f / 2.2f)};
+        }
+    } else if (TAIL == TAILK_ALU) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            f3 v = {rgb[0][e], rgb[1][e], rgb[2][e]};
+            v = hdr_tail(v, P.tail, P.gamma, P.lum_scale, P.gamut);
+            out[0][e] = saturate(v.x); out[1][e] = saturate(v.y); out[2][e] = saturate(v.z);
+        }
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) out[ch] = rgb[ch];
+    }
 }
 
 template <int NT, int TAIL>
-__global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single)
+__global__ __launch_bounds__(256, 2) void k_fused_up2x(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *Aall = (float *)smem;
     unsigned short *D = (unsigned short *)(smem + LDS_A);
-    float *T = (float *)(smem + LDS_A + LDS_D);
+    f2 *T = (f2 *)(smem + LDS_A + LDS_D);
 
     for (int i = threadIdx.x; i < 1024; i += 256) D[i] = P.dither[i];
     if (TAIL == TAILK_PQ_LUT)
-        for (int i = threadIdx.x; i <= LUT_N; i += 256) T[i] = P.lut[min(i, LUT_N - 1)];
+        for (int i = threadIdx.x; i < LUT_N; i += 256) {
+            const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
+            T[i] = f2{v, n - v};
+        }
     __syncthreads();                                   // the only workgroup barrier: tables visible
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -275,11 +240,9 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
     const gcptr pv = (gcptr)(frame.src + P.off_v);
     const gptr pdst = (gptr)frame.dst;
 
-    // stage C role: row (0/1) of the pair and 4-px group; group start X in rect coordinates
-    const int cr = lane >> 5, cj = lane & 31;
-    const int X = x0 - 4 + 4 * cj;
-    const int Xg = clampi(X, 0, (W - 1) & ~3);
-    const bool interior = X >= 0 && X + 3 <= W - 1;
+    // stage C role: A columns 2*lane, 2*lane+1 = rect columns X, X+1; the block is fetched at Xg (inside the rect)
+    const int X = x0 - 4 + 2 * lane;
+    const int Xg = clampi(X, 0, W - 2);
     // stage X / Y role: output columns ox .. ox+3 (rect-relative); lanes 60..63 idle there
     const bool xy_active = lane < 60;
     const int ox = 2 * x0 + 4 * lane;
@@ -287,21 +250,23 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
     const int wx0 = P.off_x + ox;
     const bool d_aligned = (wx0 & 3) == 0;
 
-    float we[6], wo[6];
+    f2 we[6], wo[6];
 #pragma unroll
-    for (int t = 0; t < 6; t++) { we[t] = P.we[t]; wo[t] = P.wo[t]; }
+    for (int t = 0; t < 6; t++) { we[t] = splat(P.we[t]); wo[t] = splat(P.wo[t]); }
+    const f2 maxv2 = splat(P.final_pass ? P.maxv : P.quant), half2v = splat(0.5f), qom2 = splat(P.q_over_maxv);
+    const f2 cmax2 = splat(P.maxv), cinv2 = splat(P.inv_maxv);
 
-    // 8-row window of X-pass results (fp16 x 4 px packed in 2 dwords) per channel
-    uint32_t win[8][3][2];
+    // 8-row window of X-pass results, already rounded through fp16: [row slot][channel][pixel pair]
+    f2 win[8][3][2];
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) win[i][c][0] = win[i][c][1] = 0;
+        for (int c = 0; c < 3; c++) win[i][c][0] = win[i][c][1] = splat(0.0f);
 
     // iteration t adds virtual rows a, a+1 with a = s0 - 3 + 2t; from t = 3 on it emits output rows of k = a-3, a-2
     const int n_iter = (s1 - s0 + 1) / 2 + 3;
     Raw raw;
-    load_raw(P, py, pu, pv, Xg, clampi(s0 - 3 + cr, 0, H - 1), raw);
+    load_raw(P, py, pu, pv, Xg, clampi(s0 - 3, 0, H - 1), clampi(s0 - 2, 0, H - 1), raw);
 
     for (int tb = 0; tb < n_iter; tb += 4) {
 #pragma unroll
@@ -312,68 +277,60 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
 
             // ---------------- stage C ----------------
             {
-                const int y = clampi(a + cr, 0, H - 1);
-                f3 v[4];
-                convert4<TAIL>(P, raw, P.rect_t + y, T, v);
+                f2 r0[3], r1[3];
+                convert_row<TAIL>(P, raw.y[0], raw.c[0], P.rect_t + clampi(a, 0, H - 1), T, r0);
+                convert_row<TAIL>(P, raw.y[1], raw.c[1], P.rect_t + clampi(a + 1, 0, H - 1), T, r1);
                 // prefetch the next pair of rows while this one is processed
-                load_raw(P, py, pu, pv, Xg, clampi(a + 2 + cr, 0, H - 1), raw);
-                float q[3][4];
+                load_raw(P, py, pu, pv, Xg, clampi(a + 2, 0, H - 1), clampi(a + 3, 0, H - 1), raw);
 #pragma unroll
-                for (int e = 0; e < 4; e++) {     // store to m_TexConvertOutput (UNORM) and read back
-                    q[0][e] = unorm_q(v[e].x, P.maxv) * P.inv_maxv;       // q/maxv to within 1 ulp
-                    q[1][e] = unorm_q(v[e].y, P.maxv) * P.inv_maxv;
-                    q[2][e] = unorm_q(v[e].z, P.maxv) * P.inv_maxv;
-                }
-                if (!interior) {                  // clamp-to-edge of the convert texture: replicate its border pixel
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        float s[4];
-#pragma unroll
-                        for (int e = 0; e < 4; e++) s[e] = sel4(q[c], clampi(X + e, 0, W - 1) - Xg);
-#pragma unroll
-                        for (int e = 0; e < 4; e++) q[c][e] = s[e];
+                for (int c = 0; c < 3; c++) {
+                    // store to m_TexConvertOutput (UNORM: floor(sat(x)*maxv + 0.5)) and read back (q/maxv to 1 ulp)
+                    f2 q0 = floor2(pk_fma(r0[c], cmax2, half2v)) * cinv2;
+                    f2 q1 = floor2(pk_fma(r1[c], cmax2, half2v)) * cinv2;
+                    if (X < 0 || X > W - 2) {                                 // clamp-to-edge of the convert texture
+                        if (X < 0) { q0.y = q0.x; q1.y = q1.x; } else { q0.x = q0.y; q1.x = q1.y; }
                     }
+                    // A[ch][col][row]: columns 2l, 2l+1 as (row a, row a+1) pairs = one 16-byte store
+                    *(f4 *)(A + (c * AW + 2 * lane) * 2) = f4{q0.x, q1.x, q0.y, q1.y};
                 }
-#pragma unroll
-                for (int c = 0; c < 3; c++)
-                    *(float4 *)(A + (cr * 3 + c) * AW + 4 * cj) = make_float4(q[c][0], q[c][1], q[c][2], q[c][3]);
             }
             // A is exchanged between lanes of this wave only: LDS operations of one wave execute in order,
-            // the fence keeps the compiler from moving the reads above the writes.
+            // the fences keep the compiler from moving the reads above the writes.
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
             // ---------------- stage X ----------------
             // lane owns output columns 4l..4l+3 = sources k = 2l (e = 0,1), 2l+1 (e = 2,3); A column of source k is k+4.
-            // av[i] = A column 2l+i, i = 0..9  =>  source k' = 2l + i - 4.
+            // av[i] = (row a, row a+1) of A column 2l+i, i = 0..9  =>  source 2l + i - 4.
             if (xy_active) {
 #pragma unroll
-                for (int rr = 0; rr < 2; rr++) {
+                for (int c = 0; c < 3; c++) {
+                    const f4 *ap = (const f4 *)(A + (c * AW + 2 * lane) * 2);
+                    f2 av[10];
 #pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        const float2 *ap = (const float2 *)(A + (rr * 3 + c) * AW + 2 * lane);
-                        float av[10];
+                    for (int i = 0; i < 5; i++) { const f4 p4 = ap[i]; av[2 * i] = f2{p4.x, p4.y}; av[2 * i + 1] = f2{p4.z, p4.w}; }
+                    f2 o[4];                                  // 4 output columns x (row a, row a+1)
 #pragma unroll
-                        for (int i = 0; i < 5; i++) { const float2 p2 = ap[i]; av[2 * i] = p2.x; av[2 * i + 1] = p2.y; }
-                        float o[4];
+                    for (int e = 0; e < 4; e++) {
+                        const int kk = e >> 1;                // source k = 2l + kk  -> av index of k is kk + 4
+                        const bool odd = e & 1;
+                        f2 acc = splat(0.0f);
 #pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const int kk = e >> 1;                 // source k = 2l + kk  -> av index of k is kk + 4
-                            const bool odd = e & 1;
-                            float acc = 0.0f;
-#pragma unroll
-                            for (int tt = 0; tt < NT; tt++) {
-                                // even output 2k: base = k-1; odd output 2k+1: base = k
-                                const int idx = kk + 4 + (odd ? 0 : -1) + tap_off<NT>(tt);
-                                const float w = odd ? wo[tt] : we[tt];
-                                acc = tt == 0 ? w * av[idx] : fmaf(w, av[idx], acc);
-                            }
-                            o[e] = acc;
+                        for (int tt = 0; tt < NT; tt++) {
+                            // even output 2k: base = k-1; odd output 2k+1: base = k
+                            const int idx = kk + 4 + (odd ? 0 : -1) + tap_off<NT>(tt);
+                            const f2 w = odd ? wo[tt] : we[tt];
+                            acc = tt == 0 ? w * av[idx] : pk_fma(w, av[idx], acc);
                         }
-                        win[(2 * u + rr) & 7][c][0] = pack_h2(o[0], o[1]);     // m_TexResize is R16G16B16A16_FLOAT (:3155)
-                        win[(2 * u + rr) & 7][c][1] = pack_h2(o[2], o[3]);
+                        o[e] = acc;
                     }
+                    // m_TexResize is R16G16B16A16_FLOAT (:3155): round to fp16 (RNE), keep the rounded value as fp32
+                    const int sa = (2 * u) & 7, sb = (2 * u + 1) & 7;
+                    win[sa][c][0] = f2{half_round(o[0].x), half_round(o[1].x)};
+                    win[sa][c][1] = f2{half_round(o[2].x), half_round(o[3].x)};
+                    win[sb][c][0] = f2{half_round(o[0].y), half_round(o[1].y)};
+                    win[sb][c][1] = f2{half_round(o[2].y), half_round(o[3].y)};
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -384,54 +341,75 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
             if (t >= 3 && store_ok) {
 #pragma unroll
                 for (int kk = 0; kk < 2; kk++) {
-                    const int k = a - 3 + kk;                     // source row -> output rows 2k, 2k+1
+                    const int k = a - 3 + kk;                     // source row -> output rows 2k (even), 2k+1 (odd)
                     if (k >= s1) break;
-                    // even: base = k-1 -> row k-1+off = a-6 + (kk+2+off); odd: base = k -> a-6 + (kk+3+off)
-                    int se[6], so[6];
-#pragma unroll
-                    for (int tt = 0; tt < 6; tt++) {
-                        se[tt] = tt < NT ? ((2 * u + 2 + kk + 2 + tap_off<NT>(tt)) & 7) : 0;
-                        so[tt] = tt < NT ? ((2 * u + 2 + kk + 3 + tap_off<NT>(tt)) & 7) : 0;
-                    }
-                    float res[2][4][3];            // saturated Y-pass results
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        res[0][0][c] = ytaps<NT, 0>(win, c, se, we); res[1][0][c] = ytaps<NT, 0>(win, c, so, wo);
-                        res[0][1][c] = ytaps<NT, 1>(win, c, se, we); res[1][1][c] = ytaps<NT, 1>(win, c, so, wo);
-                        res[0][2][c] = ytaps<NT, 2>(win, c, se, we); res[1][2][c] = ytaps<NT, 2>(win, c, so, wo);
-                        res[0][3][c] = ytaps<NT, 3>(win, c, se, we); res[1][3][c] = ytaps<NT, 3>(win, c, so, wo);
-                    }
 #pragma unroll
                     for (int par = 0; par < 2; par++) {
+                        // even: base = k-1 -> row k-1+off = a-6 + (kk+2+off); odd: base = k -> a-6 + (kk+3+off)
+                        f2 res[3][2];                             // [channel][pixel pair], saturated
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+#pragma unroll
+                            for (int pp = 0; pp < 2; pp++) {
+                                f2 acc = splat(0.0f);
+#pragma unroll
+                                for (int tt = 0; tt < NT; tt++) {
+                                    const int slot = (2 * u + 2 + kk + 2 + par + tap_off<NT>(tt)) & 7;
+                                    const f2 w = par ? wo[tt] : we[tt];
+                                    if (tt == 0) acc = w * win[slot][c][pp];
+                                    else if (tt == NT - 1) acc = pk_fma_sat_s(w, win[slot][c][pp], acc);
+                                    else acc = pk_fma(w, win[slot][c][pp], acc);
+                                }
+                                res[c][pp] = acc;
+                            }
+                        }
                         const int wy = P.off_y + 2 * k + par;
-                        float d4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                        if (P.final_pass) {           // sampler WRAP+POINT: dither texel (wx mod 32, wy mod 32)
-                            const unsigned short *drow = D + (wy & 31) * 32;
+                        uint32_t pk[4];
+                        if (P.final_pass && !P.out10) {
+                            // m_TexsPostScale store/load: q = floor(x*maxv + 0.5), p = q/maxv; ps_final_pass.hlsl:29:
+                            // floor(p*255 + d).  p*255 is evaluated as q*(255/maxv) inside one FMA (<= 1 ulp from the
+                            // two-step form) and the outer floor is taken by v_cvt_pk_u8_f32's round-to-nearest of
+                            // (x - 0.5 + 2^-17); both shortcuts can only matter within ~1e-5 of an integer.
+                            const unsigned short *drow = D + (wy & 31) * 32;     // sampler WRAP+POINT: texel (wx mod 32, wy mod 32)
+                            float d4[4];
                             if (d_aligned) {
                                 const uint2 dd = *(const uint2 *)(drow + (wx0 & 31));
-                                d4[0] = h_lo(dd.x); d4[1] = h_hi(dd.x); d4[2] = h_lo(dd.y); d4[3] = h_hi(dd.y);
+                                d4[0] = __half2float(__ushort_as_half((unsigned short)(dd.x & 0xffffu))); d4[1] = __half2float(__ushort_as_half((unsigned short)(dd.x >> 16)));
+                                d4[2] = __half2float(__ushort_as_half((unsigned short)(dd.y & 0xffffu))); d4[3] = __half2float(__ushort_as_half((unsigned short)(dd.y >> 16)));
                             } else {
 #pragma unroll
                                 for (int px = 0; px < 4; px++) d4[px] = __half2float(__ushort_as_half(drow[(wx0 + px) & 31]));
                             }
-                        }
-                        uint32_t pk[4];
+                            const float bias = -0.5f + 7.62939453125e-06f;
+                            const f2 d2[2] = {f2{d4[0] + bias, d4[1] + bias}, f2{d4[2] + bias, d4[3] + bias}};
+                            f2 fin[3][2];
 #pragma unroll
-                        for (int px = 0; px < 4; px++) {
-                            float c3[3];
+                            for (int c = 0; c < 3; c++)
 #pragma unroll
-                            for (int c = 0; c < 3; c++) {
-                                // res is already saturated (clamp on the last tap).  m_TexsPostScale store/load:
-                                // q = floor(x*maxv + 0.5), p = q/maxv; ps_final_pass.hlsl:29: floor(p*Q + d).
-                                // p*Q is evaluated as q*(Q/maxv) inside one FMA (<= 1 ulp from the two-step form).
-                                const float q = floorf(fmaf(res[par][px][c], P.final_pass ? P.maxv : P.quant, 0.5f));
-                                c3[c] = P.final_pass ? floorf(fmaf(q, P.q_over_maxv, d4[px])) : q;
+                                for (int pp = 0; pp < 2; pp++)
+                                    fin[c][pp] = pk_fma(floor2(pk_fma(res[c][pp], maxv2, half2v)), qom2, d2[pp]);
+#pragma unroll
+                            for (int px = 0; px < 4; px++) {    // v_cvt_pk_u8_f32: RNE + saturate, one byte per instruction
+                                uint32_t v = __builtin_amdgcn_cvt_pk_u8_f32(fin[2][px >> 1][px & 1], 0, 0xff000000u);   // B
+                                v = __builtin_amdgcn_cvt_pk_u8_f32(fin[1][px >> 1][px & 1], 1, v);                      // G
+                                pk[px] = __builtin_amdgcn_cvt_pk_u8_f32(fin[0][px >> 1][px & 1], 2, v);                 // R
                             }
-                            if (P.out10) pk[px] = pack_rgb10a2(c3[0], c3[1], c3[2]);
-                            else {      // exact small integers: v_cvt_pk_u8_f32 converts and places a byte per instruction
-                                uint32_t v = __builtin_amdgcn_cvt_pk_u8_f32(c3[2], 0, 0xff000000u);      // B
-                                v = __builtin_amdgcn_cvt_pk_u8_f32(c3[1], 1, v);                         // G
-                                pk[px] = __builtin_amdgcn_cvt_pk_u8_f32(c3[0], 2, v);                    // R
+                        } else {
+                            // generic epilogue: no final pass (straight UNORM store into the RT) and/or R10G10B10A2 target
+#pragma unroll
+                            for (int px = 0; px < 4; px++) {
+                                float c3[3];
+#pragma unroll
+                                for (int c = 0; c < 3; c++) {
+                                    const float q = floorf(fmaf(res[c][px >> 1][px & 1], P.final_pass ? P.maxv : P.quant, 0.5f));
+                                    float v = q;
+                                    if (P.final_pass) {
+                                        const float d = __half2float(__ushort_as_half(D[(wy & 31) * 32 + ((wx0 + px) & 31)]));
+                                        v = fminf(fmaxf(floorf(fmaf(q, P.q_over_maxv, d)), 0.0f), P.quant);
+                                    }
+                                    c3[c] = v;
+                                }
+                                pk[px] = P.out10 ? pack_rgb10a2(c3[0], c3[1], c3[2]) : pack_bgra8(c3[0], c3[1], c3[2]);
                             }
                         }
                         __attribute__((address_space(1))) uint32_t *dst =
@@ -514,12 +492,20 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     a.final_pass = P.store.mode == ST_FINAL; a.out10 = P.store.dst_fmt == SF_RGB10A2;
     a.quant = (float)P.store.quant;
     a.dither = P.store.dither;
-    int seg = seg_env > 0 ? seg_env : 72;
+
+    const int strips = (c.out_w + S - 1) / S;
+    // segment height: long segments recompute less (6 rows each), short ones balance the last round of waves;
+    // aim for >= 4 rounds of the ~3072 resident waves
+    int seg = seg_env;
+    if (seg <= 0) {
+        seg = 72;
+        for (int cand : {72, 48, 36, 24})
+            if ((long)strips * ((c.out_h + cand - 1) / cand) * n_frames >= 12288 || cand == 24) { seg = cand; break; }
+    }
     seg = (seg + 1) & ~1;
     if (seg > c.out_h) seg = c.out_h;
     a.seg_rows = seg;
 
-    const int strips = (c.out_w + S - 1) / S;
     const dim3 grid((strips + WAVES - 1) / WAVES, (c.out_h + seg - 1) / seg, n_frames);
     const dim3 block(256, 1, 1);
     const int tailk = c.tail == TAIL_NONE ? TAILK_NONE : (c.tail == TAIL_PQ_TO_SDR && P.pq_lut) ? TAILK_PQ_LUT : TAILK_ALU;
