@@ -95,6 +95,44 @@ __device__ __forceinline__ f2 pk_fma_sat_s(f2 w, f2 b, f2 c)
 }
 __device__ __forceinline__ f2 floor2(f2 v) { return f2{floorf(v.x), floorf(v.y)}; }
 
+// Wave-uniform coefficients live two to an SGPR pair; VOP3P op_sel broadcasts either half to both lanes, so a
+// coefficient costs one SGPR instead of a splatted pair (the kernel is SGPR-bound otherwise: spills cost v_readlane).
+//   r = w.{x|y} * b + c   [saturated to 0..1 when CLAMP]
+template <int HALF, bool CLAMP>
+__device__ __forceinline__ f2 pk_fma_w(f2 w, f2 b, f2 c)
+{
+    f2 r;
+    if (HALF == 0) {
+        if (CLAMP) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] clamp" : "=v"(r) : "s"(w), "v"(b), "v"(c));
+        else       asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "s"(w), "v"(b), "v"(c));
+    } else {
+        if (CLAMP) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] clamp" : "=v"(r) : "s"(w), "v"(b), "v"(c));
+        else       asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "s"(w), "v"(b), "v"(c));
+    }
+    return r;
+}
+template <int HALF>
+__device__ __forceinline__ f2 pk_mul_w(f2 w, f2 b)
+{
+    f2 r;
+    if (HALF == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "s"(w), "v"(b));
+    else           asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "s"(w), "v"(b));
+    return r;
+}
+// tap chain: sum_t w[t] * x[t] with the weights in pairs; the last tap saturates when CLAMP
+template <int NT, bool CLAMP, typename F>
+__device__ __forceinline__ f2 taps(const f2 (&wp)[3], F x)
+{
+    f2 acc = pk_mul_w<0>(wp[0], x(0));
+    acc = pk_fma_w<1, false>(wp[0], x(1), acc);
+    acc = pk_fma_w<0, false>(wp[1], x(2), acc);
+    if (NT == 4) return pk_fma_w<1, CLAMP>(wp[1], x(3), acc);
+    acc = pk_fma_w<1, false>(wp[1], x(3), acc);
+    if (NT == 5) return pk_fma_w<0, CLAMP>(wp[2], x(4), acc);
+    acc = pk_fma_w<0, false>(wp[2], x(4), acc);
+    return pk_fma_w<1, CLAMP>(wp[2], x(5), acc);
+}
+
 // {value, delta} table lookup with linear interpolation; x already in [0,1]
 __device__ __forceinline__ float lut_eval(const f2 *T, float x)
 {
@@ -106,7 +144,7 @@ __device__ __forceinline__ float lut_eval(const f2 *T, float x)
 // raw codes of one 2x2 block (cols Xg, Xg+1; two source rows), prefetched one iteration ahead
 struct Raw {
     uint32_t y[2];           // luma of the two rows: 2 px each (16-bit: one dword; 8-bit: low 16 bits)
-    uint32_t c[2][2][3];     // [luma row][chroma row r0/r1][cols c0-1, c0, c0+1]: packed (U | V<<16) codes
+    uint32_t c[2][3];        // [chroma row n, n+1][cols c0-1, c0, c0+1]: packed (U | V<<16) codes, shared by both luma rows
 };
 
 __device__ __forceinline__ uint32_t ld_u8(gcptr p) { return *p; }
@@ -114,12 +152,13 @@ __device__ __forceinline__ uint32_t ld_u16(gcptr p) { return *(const __attribute
 __device__ __forceinline__ uint32_t ld_u32(gcptr p) { return *(const __attribute__((address_space(1))) uint32_t *)p; }
 
 // chroma texel (col,row) as U | V << 16 (raw codes), clamp addressing on the column
+template <bool P01X>
 __device__ __forceinline__ uint32_t ld_uv(const FusedArgs &P, gcptr pu, gcptr pv, int col, int row)
 {
     col = clampi(col, 0, P.cw - 1);
     const size_t ro = (size_t)row * P.pitch_c;
-    if (P.planes == 2) {
-        if (P.bytes == 2) return ld_u32(pu + ro + 4 * col);
+    if (P01X || P.planes == 2) {
+        if (P01X || P.bytes == 2) return ld_u32(pu + ro + 4 * col);
         const uint32_t d = ld_u16(pu + ro + 2 * col);
         return (d & 0xffu) | ((d >> 8) << 16);
     }
@@ -130,88 +169,93 @@ __device__ __forceinline__ uint32_t ld_uv(const FusedArgs &P, gcptr pu, gcptr pv
 // vertical chroma position of source row sy (Shaders.cpp:118-138): v' = (sy+0.5)/2 [+0.25 co-sited] - 0.5
 __device__ __forceinline__ float chroma_v(const FusedArgs &P, int sy) { return ((float)sy + 0.5f) * 0.5f + P.v_off - 0.5f; }
 
-// Xg: first rect column of the block (even, inside the rect); y0,y1: the two (clamped) rect rows
+// Xg: first rect column of the block (even, inside the rect); y0,y1: the two (clamped) rect rows.
+// The two luma rows of an iteration are (odd, odd+1) source rows — or the same row twice where the rect clamps —
+// (rect top and segment starts are even, host-checked), so for every siting both take their chroma from the same
+// two chroma rows n = floor(v'(row 0)) and n+1.
+template <bool P01X>
 __device__ __forceinline__ void load_raw(const FusedArgs &P, gcptr py, gcptr pu, gcptr pv, int Xg, int y0, int y1, Raw &r)
 {
     const int sx0 = P.rect_l + Xg;
     const int c0 = sx0 >> 1;
-#pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-        const int sy = P.rect_t + (rr ? y1 : y0);
-        const gcptr ry = py + (size_t)sy * P.pitch_y;
-        r.y[rr] = P.bytes == 2 ? ld_u32(ry + 2 * sx0) : ld_u16(ry + sx0);
-        const int iv = (int)floorf(chroma_v(P, sy));
-        const int r0 = clampi(iv, 0, P.ch - 1), r1 = clampi(iv + 1, 0, P.ch - 1);
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            if (i == 0 && !P.center_h) { r.c[rr][0][0] = r.c[rr][1][0] = 0; continue; }
-            r.c[rr][0][i] = ld_uv(P, pu, pv, c0 - 1 + i, r0);
-            r.c[rr][1][i] = ld_uv(P, pu, pv, c0 - 1 + i, r1);
-        }
-    }
-}
-
-// One source row of the block: 4:2:0 bilinear chroma + matrix (+ tail) for the 2 pixels (even, odd column).
-// ShaderGetPixels' CHROMA_Bilinear branch (Shaders.cpp:265-270,319-325): same sample positions and weights,
-// evaluated in code units (vertical lerp first), UNORM scale folded into the matrix.  Results are the three
-// channels as (even px, odd px) pairs, saturated when a tail or the UNORM store requires it anyway.
-template <int TAIL>
-__device__ __forceinline__ void convert_row(const FusedArgs &P, uint32_t yraw, const uint32_t (&c)[2][3], int sy, const f2 *T, f2 out[3])
-{
-    f2 Y;
-    if (P.bytes == 2) Y = f2{(float)(yraw & 0xffffu), (float)(yraw >> 16)};
-    else Y = f2{(float)(yraw & 0xffu), (float)((yraw >> 8) & 0xffu)};
-    const float fv = chroma_v(P, sy);
-    const float wy = fv - floorf(fv);
-    const f2 w1 = splat(wy), w0 = splat(1.0f - wy);
-    f2 UV[3];                                     // (U, V) of chroma columns c0-1, c0, c0+1 after the vertical lerp
+    const int sy0 = P.rect_t + y0, sy1 = P.rect_t + y1;
+    r.y[0] = (P01X || P.bytes == 2) ? ld_u32(py + (size_t)sy0 * P.pitch_y + 2 * sx0) : ld_u16(py + (size_t)sy0 * P.pitch_y + sx0);
+    r.y[1] = (P01X || P.bytes == 2) ? ld_u32(py + (size_t)sy1 * P.pitch_y + 2 * sx0) : ld_u16(py + (size_t)sy1 * P.pitch_y + sx0);
+    const int n = (int)floorf(chroma_v(P, sy0));
+    const int rA = clampi(n, 0, P.ch - 1), rB = clampi(n + 1, 0, P.ch - 1);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        const f2 top = f2{(float)(c[0][i] & 0xffffu), (float)(c[0][i] >> 16)};
-        const f2 bot = f2{(float)(c[1][i] & 0xffffu), (float)(c[1][i] >> 16)};
-        UV[i] = pk_fma(bot, w1, top * w0);
-    }
-    f2 uve, uvo;                                  // (U, V) at the even and the odd luma column
-    if (P.center_h) {                             // u' = sx/2 - 0.25
-        uve = pk_fma(UV[1], splat(0.75f), UV[0] * splat(0.25f));
-        uvo = pk_fma(UV[2], splat(0.25f), UV[1] * splat(0.75f));
-    } else {                                      // u' = sx/2
-        uve = UV[1];
-        uvo = pk_fma(UV[2], splat(0.5f), UV[1] * splat(0.5f));
-    }
-    const f2 U = f2{uve.x, uvo.x}, V = f2{uve.y, uvo.y};
-    f2 rgb[3];
-#pragma unroll
-    for (int ch = 0; ch < 3; ch++)
-        rgb[ch] = pk_fma_sat_s(splat(P.m[3 * ch]), Y, pk_fma(splat(P.m[3 * ch + 1]), U, pk_fma(splat(P.m[3 * ch + 2]), V, splat(P.c[ch]))));   // saturated: every continuation saturates first
-    if (TAIL == TAILK_PQ_LUT) {
-        // Shaders.cpp:870-923: per-channel saturate -> ST2084ToLinear*scale -> Hable/hable(4.8) from the LDS table,
-        // then the 2020->709 matrix, saturate and pow 1/2.2 in ALU
-        f2 lin[3];
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            lin[ch] = f2{lut_eval(T, rgb[ch].x), lut_eval(T, rgb[ch].y)};
-        }
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            const f2 g = pk_fma_sat_s(splat(P.gamut[3 * ch]), lin[0], pk_fma(splat(P.gamut[3 * ch + 1]), lin[1], splat(P.gamut[3 * ch + 2]) * lin[2]));
-            out[ch] = f2{hlsl_pow(g.x, 1.0f / 2.2f), hlsl_pow(g.y, 1.0f / 2.2f)};
-        }
-    } else if (TAIL == TAILK_ALU) {
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-            f3 v = {rgb[0][e], rgb[1][e], rgb[2][e]};
-            v = hdr_tail(v, P.tail, P.gamma, P.lum_scale, P.gamut);
-            out[0][e] = saturate(v.x); out[1][e] = saturate(v.y); out[2][e] = saturate(v.z);
-        }
-    } else {
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) out[ch] = rgb[ch];
+        if (i == 0 && !P.center_h) { r.c[0][0] = r.c[1][0] = 0; continue; }
+        r.c[0][i] = ld_uv<P01X>(P, pu, pv, c0 - 1 + i, rA);
+        r.c[1][i] = ld_uv<P01X>(P, pu, pv, c0 - 1 + i, rB);
     }
 }
 
-template <int NT, int TAIL>
-__global__ __launch_bounds__(256, 2) void k_fused_up2x(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single)
+// The 2x2 block: 4:2:0 bilinear chroma + matrix (+ tail) for (even, odd column) x (row 0, row 1).
+// ShaderGetPixels' CHROMA_Bilinear branch (Shaders.cpp:265-270,319-325): same sample positions and weights,
+// evaluated in code units (vertical lerp first), UNORM scale folded into the matrix.  out[row][ch] = the channel as
+// an (even px, odd px) pair, saturated (every continuation — tail or UNORM store — saturates first).
+template <int TAIL, bool P01X>
+__device__ __forceinline__ void convert_block(const FusedArgs &P, const Raw &r, int sy0, int sy1, const f2 *T, f2 out[2][3])
+{
+    f2 top[3], bot[3];                            // (U, V) codes of chroma rows n, n+1 at columns c0-1, c0, c0+1
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        top[i] = f2{(float)(r.c[0][i] & 0xffffu), (float)(r.c[0][i] >> 16)};
+        bot[i] = f2{(float)(r.c[1][i] & 0xffffu), (float)(r.c[1][i] >> 16)};
+    }
+    const float n = floorf(chroma_v(P, sy0));
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const uint32_t yraw = r.y[rr];
+        f2 Y;
+        if (P01X || P.bytes == 2) Y = f2{(float)(yraw & 0xffffu), (float)(yraw >> 16)};
+        else Y = f2{(float)(yraw & 0xffu), (float)((yraw >> 8) & 0xffu)};
+        const float wy = chroma_v(P, rr ? sy1 : sy0) - n;      // in [0,1]: weight of chroma row n+1
+        const f2 w1 = splat(wy), w0 = splat(1.0f - wy);
+        f2 UV[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) UV[i] = pk_fma(bot[i], w1, top[i] * w0);
+        f2 uve, uvo;                              // (U, V) at the even and the odd luma column
+        if (P.center_h) {                         // u' = sx/2 - 0.25
+            uve = pk_fma(UV[1], splat(0.75f), UV[0] * splat(0.25f));
+            uvo = pk_fma(UV[2], splat(0.25f), UV[1] * splat(0.75f));
+        } else {                                  // u' = sx/2
+            uve = UV[1];
+            uvo = pk_fma(UV[2], splat(0.5f), UV[1] * splat(0.5f));
+        }
+        const f2 U = f2{uve.x, uvo.x}, V = f2{uve.y, uvo.y};
+        f2 rgb[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+            rgb[ch] = pk_fma_sat_s(splat(P.m[3 * ch]), Y, pk_fma(splat(P.m[3 * ch + 1]), U, pk_fma(splat(P.m[3 * ch + 2]), V, splat(P.c[ch]))));
+        if (TAIL == TAILK_PQ_LUT) {
+            // Shaders.cpp:870-923: per-channel saturate -> ST2084ToLinear*scale -> Hable/hable(4.8) from the LDS table,
+            // then the 2020->709 matrix, saturate and pow 1/2.2 in ALU
+            f2 lin[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) lin[ch] = f2{lut_eval(T, rgb[ch].x), lut_eval(T, rgb[ch].y)};
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const f2 g = pk_fma_sat_s(splat(P.gamut[3 * ch]), lin[0], pk_fma(splat(P.gamut[3 * ch + 1]), lin[1], splat(P.gamut[3 * ch + 2]) * lin[2]));
+                out[rr][ch] = f2{hlsl_pow(g.x, 1.0f / 2.2f), hlsl_pow(g.y, 1.0f / 2.2f)};
+            }
+        } else if (TAIL == TAILK_ALU) {
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                f3 v = {rgb[0][e], rgb[1][e], rgb[2][e]};
+                v = hdr_tail(v, P.tail, P.gamma, P.lum_scale, P.gamut);
+                out[rr][0][e] = saturate(v.x); out[rr][1][e] = saturate(v.y); out[rr][2][e] = saturate(v.z);
+            }
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) out[rr][ch] = rgb[ch];
+        }
+    }
+}
+
+template <int NT, int TAIL, bool P01X>
+__global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *Aall = (float *)smem;
@@ -250,9 +294,9 @@ __global__ __launch_bounds__(256, 2) void k_fused_up2x(FusedArgs P, const FusedF
     const int wx0 = P.off_x + ox;
     const bool d_aligned = (wx0 & 3) == 0;
 
-    f2 we[6], wo[6];
-#pragma unroll
-    for (int t = 0; t < 6; t++) { we[t] = splat(P.we[t]); wo[t] = splat(P.wo[t]); }
+    // phase weights, two per SGPR pair: WT[parity][pair]
+    const f2 WT[2][3] = {{f2{P.we[0], P.we[1]}, f2{P.we[2], P.we[3]}, f2{P.we[4], P.we[5]}},
+                        {f2{P.wo[0], P.wo[1]}, f2{P.wo[2], P.wo[3]}, f2{P.wo[4], P.wo[5]}}};
     const f2 maxv2 = splat(P.final_pass ? P.maxv : P.quant), half2v = splat(0.5f), qom2 = splat(P.q_over_maxv);
     const f2 cmax2 = splat(P.maxv), cinv2 = splat(P.inv_maxv);
 
@@ -266,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void k_fused_up2x(FusedArgs P, const FusedF
     // iteration t adds virtual rows a, a+1 with a = s0 - 3 + 2t; from t = 3 on it emits output rows of k = a-3, a-2
     const int n_iter = (s1 - s0 + 1) / 2 + 3;
     Raw raw;
-    load_raw(P, py, pu, pv, Xg, clampi(s0 - 3, 0, H - 1), clampi(s0 - 2, 0, H - 1), raw);
+    load_raw<P01X>(P, py, pu, pv, Xg, clampi(s0 - 3, 0, H - 1), clampi(s0 - 2, 0, H - 1), raw);
 
     for (int tb = 0; tb < n_iter; tb += 4) {
 #pragma unroll
@@ -277,16 +321,15 @@ __global__ __launch_bounds__(256, 2) void k_fused_up2x(FusedArgs P, const FusedF
 
             // ---------------- stage C ----------------
             {
-                f2 r0[3], r1[3];
-                convert_row<TAIL>(P, raw.y[0], raw.c[0], P.rect_t + clampi(a, 0, H - 1), T, r0);
-                convert_row<TAIL>(P, raw.y[1], raw.c[1], P.rect_t + clampi(a + 1, 0, H - 1), T, r1);
+                f2 rc[2][3];
+                convert_block<TAIL, P01X>(P, raw, P.rect_t + clampi(a, 0, H - 1), P.rect_t + clampi(a + 1, 0, H - 1), T, rc);
                 // prefetch the next pair of rows while this one is processed
-                load_raw(P, py, pu, pv, Xg, clampi(a + 2, 0, H - 1), clampi(a + 3, 0, H - 1), raw);
+                load_raw<P01X>(P, py, pu, pv, Xg, clampi(a + 2, 0, H - 1), clampi(a + 3, 0, H - 1), raw);
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     // store to m_TexConvertOutput (UNORM: floor(sat(x)*maxv + 0.5)) and read back (q/maxv to 1 ulp)
-                    f2 q0 = floor2(pk_fma(r0[c], cmax2, half2v)) * cinv2;
-                    f2 q1 = floor2(pk_fma(r1[c], cmax2, half2v)) * cinv2;
+                    f2 q0 = floor2(pk_fma(rc[0][c], cmax2, half2v)) * cinv2;
+                    f2 q1 = floor2(pk_fma(rc[1][c], cmax2, half2v)) * cinv2;
                     if (X < 0 || X > W - 2) {                                 // clamp-to-edge of the convert texture
                         if (X < 0) { q0.y = q0.x; q1.y = q1.x; } else { q0.x = q0.y; q1.x = q1.y; }
                     }
@@ -314,16 +357,8 @@ __global__ __launch_bounds__(256, 2) void k_fused_up2x(FusedArgs P, const FusedF
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const int kk = e >> 1;                // source k = 2l + kk  -> av index of k is kk + 4
-                        const bool odd = e & 1;
-                        f2 acc = splat(0.0f);
-#pragma unroll
-                        for (int tt = 0; tt < NT; tt++) {
-                            // even output 2k: base = k-1; odd output 2k+1: base = k
-                            const int idx = kk + 4 + (odd ? 0 : -1) + tap_off<NT>(tt);
-                            const f2 w = odd ? wo[tt] : we[tt];
-                            acc = tt == 0 ? w * av[idx] : pk_fma(w, av[idx], acc);
-                        }
-                        o[e] = acc;
+                        const int odd = e & 1;                // even output 2k: base = k-1; odd output 2k+1: base = k
+                        o[e] = taps<NT, false>(WT[odd], [&](int tt) { return av[kk + 4 + (odd ? 0 : -1) + tap_off<NT>(tt)]; });
                     }
                     // m_TexResize is R16G16B16A16_FLOAT (:3155): round to fp16 (RNE), keep the rounded value as fp32
                     const int sa = (2 * u) & 7, sb = (2 * u + 1) & 7;
@@ -351,16 +386,7 @@ __global__ __launch_bounds__(256, 2) void k_fused_up2x(FusedArgs P, const FusedF
                         for (int c = 0; c < 3; c++) {
 #pragma unroll
                             for (int pp = 0; pp < 2; pp++) {
-                                f2 acc = splat(0.0f);
-#pragma unroll
-                                for (int tt = 0; tt < NT; tt++) {
-                                    const int slot = (2 * u + 2 + kk + 2 + par + tap_off<NT>(tt)) & 7;
-                                    const f2 w = par ? wo[tt] : we[tt];
-                                    if (tt == 0) acc = w * win[slot][c][pp];
-                                    else if (tt == NT - 1) acc = pk_fma_sat_s(w, win[slot][c][pp], acc);
-                                    else acc = pk_fma(w, win[slot][c][pp], acc);
-                                }
-                                res[c][pp] = acc;
+                                res[c][pp] = taps<NT, true>(WT[par], [&](int tt) { return win[(2 * u + 2 + kk + 2 + par + tap_off<NT>(tt)) & 7][c][pp]; });
                             }
                         }
                         const int wy = P.off_y + 2 * k + par;
@@ -510,7 +536,9 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     const dim3 block(256, 1, 1);
     const int tailk = c.tail == TAIL_NONE ? TAILK_NONE : (c.tail == TAIL_PQ_TO_SDR && P.pq_lut) ? TAILK_PQ_LUT : TAILK_ALU;
     const size_t lds = LDS_A + LDS_D + (tailk == TAILK_PQ_LUT ? LDS_T : 0);
-#define MPCVR_LAUNCH(NT, TK) hipLaunchKernelGGL((k_fused_up2x<NT, TK>), grid, block, lds, s, a, frames_dev, single)
+    const bool p01x = c.fmt.planes == 2 && c.fmt.bytes == 2;
+#define MPCVR_LAUNCH(NT, TK) do { if (p01x) hipLaunchKernelGGL((k_fused_up2x<NT, TK, true>), grid, block, lds, s, a, frames_dev, single); \
+                                  else hipLaunchKernelGGL((k_fused_up2x<NT, TK, false>), grid, block, lds, s, a, frames_dev, single); } while (0)
 #define MPCVR_LAUNCH_NT(NT) \
     do { if (tailk == TAILK_NONE) MPCVR_LAUNCH(NT, TAILK_NONE); else if (tailk == TAILK_PQ_LUT) MPCVR_LAUNCH(NT, TAILK_PQ_LUT); \
          else MPCVR_LAUNCH(NT, TAILK_ALU); } while (0)
