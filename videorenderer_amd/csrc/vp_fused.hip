@@ -44,7 +44,8 @@ constexpr int WAVES = 4;           // strips per workgroup
 constexpr int A_FLOATS = 3 * AW * 2;   // [ch][col][row a | row a+1]
 constexpr int LUT_N = kPqLutSize;  // PQ->SDR per-channel table (vp_params.h)
 constexpr int LDS_A = WAVES * A_FLOATS * 4;
-constexpr int LDS_D = 32 * 32 * 2;
+constexpr int LDS_D = 32 * 32 * 2;      // dither table, fp16 bits (generic epilogue)
+constexpr int LDS_DB = 32 * 32 * 4;     // dither table as fp32 with the -0.5 + 2^-17 rounding bias folded in
 constexpr int LDS_T = LUT_N * 8;   // {value, delta-to-next} pairs
 
 typedef const __attribute__((address_space(1))) uint8_t *gcptr;
@@ -94,6 +95,17 @@ __device__ __forceinline__ f2 pk_fma_sat_s(f2 w, f2 b, f2 c)
     return r;
 }
 __device__ __forceinline__ f2 floor2(f2 v) { return f2{floorf(v.x), floorf(v.y)}; }
+// UNORM store rounding floor(x*maxv + 0.5) for x in [0,1] without v_floor (which has no packed form):
+// x*maxv + 2^23 rounds to an integer in the FMA itself (nearest-even; x*maxv can only tie at x = 0.5, where both
+// conventions give (maxv+1)/2), then 2^23 comes off again — two packed instructions for two values.
+__device__ __forceinline__ f2 unorm_round2(f2 x, f2 maxv2)
+{
+    const f2 big = f2{8388608.0f, 8388608.0f};
+    return pk_fma(x, maxv2, big) - big;
+}
+// fp32 -> fp16 (RNE) -> fp32 for a pair: v_cvt_pk_f16_f32 + two v_cvt_f32_f16
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 half_round2(f2 v) { return __builtin_convertvector(__builtin_convertvector(v, h2v), f2); }
 
 // Wave-uniform coefficients live two to an SGPR pair; VOP3P op_sel broadcasts either half to both lanes, so a
 // coefficient costs one SGPR instead of a splatted pair (the kernel is SGPR-bound otherwise: spills cost v_readlane).
@@ -260,9 +272,14 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *Aall = (float *)smem;
     unsigned short *D = (unsigned short *)(smem + LDS_A);
-    f2 *T = (f2 *)(smem + LDS_A + LDS_D);
+    float *Db = (float *)(smem + LDS_A + LDS_D);
+    f2 *T = (f2 *)(smem + LDS_A + LDS_D + LDS_DB);
 
-    for (int i = threadIdx.x; i < 1024; i += 256) D[i] = P.dither[i];
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        const unsigned short d = P.dither[i];
+        D[i] = d;
+        Db[i] = __half2float(__ushort_as_half(d)) + (-0.5f + 7.62939453125e-06f);
+    }
     if (TAIL == TAILK_PQ_LUT)
         for (int i = threadIdx.x; i < LUT_N; i += 256) {
             const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
@@ -292,7 +309,9 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
     const int ox = 2 * x0 + 4 * lane;
     const bool store_ok = xy_active && ox < 2 * W;
     const int wx0 = P.off_x + ox;
-    const bool d_aligned = (wx0 & 3) == 0;
+    const bool d_aligned = (wx0 & 3) == 0;          // wave-uniform: ox is a multiple of 4
+    const bool st_aligned = d_aligned && ((((uintptr_t)frame.dst) | (uintptr_t)P.dst_pitch) & 15) == 0;
+    const uint32_t lane_off = (uint32_t)wx0 * 4u;
 
     // phase weights, two per SGPR pair: WT[parity][pair]
     const f2 WT[2][3] = {{f2{P.we[0], P.we[1]}, f2{P.we[2], P.we[3]}, f2{P.we[4], P.we[5]}},
@@ -328,8 +347,8 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     // store to m_TexConvertOutput (UNORM: floor(sat(x)*maxv + 0.5)) and read back (q/maxv to 1 ulp)
-                    f2 q0 = floor2(pk_fma(rc[0][c], cmax2, half2v)) * cinv2;
-                    f2 q1 = floor2(pk_fma(rc[1][c], cmax2, half2v)) * cinv2;
+                    f2 q0 = unorm_round2(rc[0][c], cmax2) * cinv2;
+                    f2 q1 = unorm_round2(rc[1][c], cmax2) * cinv2;
                     if (X < 0 || X > W - 2) {                                 // clamp-to-edge of the convert texture
                         if (X < 0) { q0.y = q0.x; q1.y = q1.x; } else { q0.x = q0.y; q1.x = q1.y; }
                     }
@@ -362,10 +381,11 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
                     }
                     // m_TexResize is R16G16B16A16_FLOAT (:3155): round to fp16 (RNE), keep the rounded value as fp32
                     const int sa = (2 * u) & 7, sb = (2 * u + 1) & 7;
-                    win[sa][c][0] = f2{half_round(o[0].x), half_round(o[1].x)};
-                    win[sa][c][1] = f2{half_round(o[2].x), half_round(o[3].x)};
-                    win[sb][c][0] = f2{half_round(o[0].y), half_round(o[1].y)};
-                    win[sb][c][1] = f2{half_round(o[2].y), half_round(o[3].y)};
+                    const f2 h0 = half_round2(o[0]), h1 = half_round2(o[1]), h2 = half_round2(o[2]), h3 = half_round2(o[3]);
+                    win[sa][c][0] = f2{h0.x, h1.x};
+                    win[sa][c][1] = f2{h2.x, h3.x};
+                    win[sb][c][0] = f2{h0.y, h1.y};
+                    win[sb][c][1] = f2{h2.y, h3.y};
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -396,24 +416,21 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
                             // floor(p*255 + d).  p*255 is evaluated as q*(255/maxv) inside one FMA (<= 1 ulp from the
                             // two-step form) and the outer floor is taken by v_cvt_pk_u8_f32's round-to-nearest of
                             // (x - 0.5 + 2^-17); both shortcuts can only matter within ~1e-5 of an integer.
-                            const unsigned short *drow = D + (wy & 31) * 32;     // sampler WRAP+POINT: texel (wx mod 32, wy mod 32)
-                            float d4[4];
+                            const float *drow = Db + (wy & 31) * 32;             // sampler WRAP+POINT: texel (wx mod 32, wy mod 32)
+                            f2 d2[2];                                            // dither + (-0.5 + 2^-17), see Db
                             if (d_aligned) {
-                                const uint2 dd = *(const uint2 *)(drow + (wx0 & 31));
-                                d4[0] = __half2float(__ushort_as_half((unsigned short)(dd.x & 0xffffu))); d4[1] = __half2float(__ushort_as_half((unsigned short)(dd.x >> 16)));
-                                d4[2] = __half2float(__ushort_as_half((unsigned short)(dd.y & 0xffffu))); d4[3] = __half2float(__ushort_as_half((unsigned short)(dd.y >> 16)));
+                                const f4 dd = *(const f4 *)(drow + (wx0 & 31));
+                                d2[0] = f2{dd.x, dd.y}; d2[1] = f2{dd.z, dd.w};
                             } else {
-#pragma unroll
-                                for (int px = 0; px < 4; px++) d4[px] = __half2float(__ushort_as_half(drow[(wx0 + px) & 31]));
+                                d2[0] = f2{drow[wx0 & 31], drow[(wx0 + 1) & 31]};
+                                d2[1] = f2{drow[(wx0 + 2) & 31], drow[(wx0 + 3) & 31]};
                             }
-                            const float bias = -0.5f + 7.62939453125e-06f;
-                            const f2 d2[2] = {f2{d4[0] + bias, d4[1] + bias}, f2{d4[2] + bias, d4[3] + bias}};
                             f2 fin[3][2];
 #pragma unroll
                             for (int c = 0; c < 3; c++)
 #pragma unroll
                                 for (int pp = 0; pp < 2; pp++)
-                                    fin[c][pp] = pk_fma(floor2(pk_fma(res[c][pp], maxv2, half2v)), qom2, d2[pp]);
+                                    fin[c][pp] = pk_fma(unorm_round2(res[c][pp], maxv2), qom2, d2[pp]);
 #pragma unroll
                             for (int px = 0; px < 4; px++) {    // v_cvt_pk_u8_f32: RNE + saturate, one byte per instruction
                                 uint32_t v = __builtin_amdgcn_cvt_pk_u8_f32(fin[2][px >> 1][px & 1], 0, 0xff000000u);   // B
@@ -438,13 +455,15 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
                                 pk[px] = P.out10 ? pack_rgb10a2(c3[0], c3[1], c3[2]) : pack_bgra8(c3[0], c3[1], c3[2]);
                             }
                         }
-                        __attribute__((address_space(1))) uint32_t *dst =
-                            (__attribute__((address_space(1))) uint32_t *)(pdst + (size_t)wy * P.dst_pitch) + wx0;
-                        if ((((uintptr_t)dst) & 15) == 0) {
+                        const gptr rowp = pdst + (size_t)wy * P.dst_pitch;       // wave-uniform row base + per-lane 32-bit offset
+                        if (st_aligned) {
                             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                             u32x4 v4 = {pk[0], pk[1], pk[2], pk[3]};
-                            *(__attribute__((address_space(1))) u32x4 *)dst = v4;
-                        } else { dst[0] = pk[0]; dst[1] = pk[1]; dst[2] = pk[2]; dst[3] = pk[3]; }
+                            *(__attribute__((address_space(1))) u32x4 *)(rowp + lane_off) = v4;
+                        } else {
+                            __attribute__((address_space(1))) uint32_t *dst = (__attribute__((address_space(1))) uint32_t *)(rowp + lane_off);
+                            dst[0] = pk[0]; dst[1] = pk[1]; dst[2] = pk[2]; dst[3] = pk[3];
+                        }
                     }
                 }
             }
@@ -535,7 +554,7 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     const dim3 grid((strips + WAVES - 1) / WAVES, (c.out_h + seg - 1) / seg, n_frames);
     const dim3 block(256, 1, 1);
     const int tailk = c.tail == TAIL_NONE ? TAILK_NONE : (c.tail == TAIL_PQ_TO_SDR && P.pq_lut) ? TAILK_PQ_LUT : TAILK_ALU;
-    const size_t lds = LDS_A + LDS_D + (tailk == TAILK_PQ_LUT ? LDS_T : 0);
+    const size_t lds = LDS_A + LDS_D + LDS_DB + (tailk == TAILK_PQ_LUT ? LDS_T : 0);
     const bool p01x = c.fmt.planes == 2 && c.fmt.bytes == 2;
 #define MPCVR_LAUNCH(NT, TK) do { if (p01x) hipLaunchKernelGGL((k_fused_up2x<NT, TK, true>), grid, block, lds, s, a, frames_dev, single); \
                                   else hipLaunchKernelGGL((k_fused_up2x<NT, TK, false>), grid, block, lds, s, a, frames_dev, single); } while (0)
