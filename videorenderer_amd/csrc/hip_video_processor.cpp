@@ -53,10 +53,14 @@ CHipVideoProcessor::~CHipVideoProcessor()
     (void)hipSetDevice(m_device);
     if (m_stream) (void)hipStreamSynchronize(m_stream);
     for (DevBuffer *b : {&m_TexSrcVideo, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
-                         &m_pqLut, &m_tapsXi, &m_tapsXw, &m_tapsXs, &m_tapsYi, &m_tapsYw, &m_tapsYs, &m_otherX, &m_otherY, &m_frames})
+                         &m_pqLut, &m_tapsXi, &m_tapsXw, &m_tapsXs, &m_tapsYi, &m_tapsYw, &m_tapsYs, &m_otherX, &m_otherY})
         b->Release();
     if (m_pinned) (void)hipHostFree(m_pinned);
-    if (m_framesPinned) (void)hipHostFree(m_framesPinned);
+    for (FrameSlot &fs : m_slots) {
+        fs.dev.Release();
+        if (fs.pinned) (void)hipHostFree(fs.pinned);
+        if (fs.done) (void)hipEventDestroy(fs.done);
+    }
     if (m_evStart) (void)hipEventDestroy(m_evStart);
     if (m_evStop) (void)hipEventDestroy(m_evStop);
     if (m_ownStream && m_stream) (void)hipStreamDestroy(m_stream);
@@ -534,24 +538,32 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
         return MPCVR_S_OK;
     }
     // one launch for the whole batch
-    if ((size_t)n > m_framesPinnedCount) {
-        if (m_framesPinned) (void)hipHostFree(m_framesPinned);
-        m_framesPinned = nullptr; m_framesPinnedCount = 0;
-        if ((hr = CheckHip(hipHostMalloc(&m_framesPinned, sizeof(FusedFrame) * n, hipHostMallocDefault), "frames pinned"))) return hr;
-        m_framesPinnedCount = n;
+    // The frame table travels through a small ring of pinned/device slots so the host can queue several
+    // batches ahead; a slot is reused only after the launch that read it has completed (its event).
+    FrameSlot &slot = m_slots[m_slotNext];
+    m_slotNext = (m_slotNext + 1) % kFrameSlots;
+    if (!slot.done && (hr = CheckHip(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming), "slot event"))) return hr;
+    if (slot.used && (hr = CheckHip(hipEventSynchronize(slot.done), "slot wait"))) return hr;
+    if ((size_t)n > slot.cap) {
+        if (slot.pinned) (void)hipHostFree(slot.pinned);
+        slot.pinned = nullptr; slot.cap = 0;
+        const size_t cap = n < 64 ? 64 : (size_t)n;
+        if ((hr = CheckHip(hipHostMalloc(&slot.pinned, sizeof(FusedFrame) * cap, hipHostMallocDefault), "frames pinned"))) return hr;
+        if ((hr = CheckHip(slot.dev.CheckCreate(sizeof(FusedFrame) * cap), "frames"))) return hr;
+        slot.cap = cap;
     }
-    if ((hr = CheckHip(m_frames.CheckCreate(sizeof(FusedFrame) * (size_t)(n < 64 ? 64 : n)), "frames"))) return hr;
-    if ((hr = CheckHip(hipStreamSynchronize(m_stream), "sync before frame table"))) return hr;
-    FusedFrame *fr = (FusedFrame *)m_framesPinned;
+    FusedFrame *fr = (FusedFrame *)slot.pinned;
     for (int i = 0; i < n; i++) { fr[i].src = (const uint8_t *)srcs[i]; fr[i].dst = dsts[i]; }
-    if ((hr = CheckHip(hipMemcpyAsync(m_frames.ptr, fr, sizeof(FusedFrame) * n, hipMemcpyHostToDevice, m_stream), "frame table"))) return hr;
+    if ((hr = CheckHip(hipMemcpyAsync(slot.dev.ptr, fr, sizeof(FusedFrame) * n, hipMemcpyHostToDevice, m_stream), "frame table"))) return hr;
     FusedParams fp{};
     FillFusedParams((const uint8_t *)srcs[0], nullptr, rtPitch, &fp);
     for (int i = 0; i < n; i++)
         if (((uintptr_t)srcs[i] & 3) != 0) fp.fast_convert = 0;
     (void)hipEventRecord(m_evStart, m_stream);
-    hr = CheckHip(LaunchFusedUp2x(fp, (const FusedFrame *)m_frames.ptr, FusedFrame{nullptr, nullptr}, n, m_stream), "k_fused_up2x");
+    hr = CheckHip(LaunchFusedUp2x(fp, (const FusedFrame *)slot.dev.ptr, FusedFrame{nullptr, nullptr}, n, m_stream), "k_fused_up2x");
     (void)hipEventRecord(m_evStop, m_stream);
+    (void)hipEventRecord(slot.done, m_stream);
+    slot.used = true;
     m_timed = true;
     return hr;
 }

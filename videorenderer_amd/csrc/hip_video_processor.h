@@ -136,9 +136,11 @@ private:
     bool m_pqLutValid = false;
     DevBuffer m_tapsXi, m_tapsXw, m_tapsXs, m_tapsYi, m_tapsYw, m_tapsYs, m_otherX, m_otherY;
     AxisTaps m_tapsX{}, m_tapsY{};
-    DevBuffer m_frames;            // FusedFrame[n]
-    void *m_framesPinned = nullptr;
-    size_t m_framesPinnedCount = 0;
+    // ring of frame-table slots for mpcvr_process_batch (pinned host copy + device copy + completion event)
+    static constexpr int kFrameSlots = 4;
+    struct FrameSlot { void *pinned = nullptr; DevBuffer dev; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; };
+    FrameSlot m_slots[kFrameSlots];
+    int m_slotNext = 0;
     uint16_t m_ditherHost[1024];
 };
 

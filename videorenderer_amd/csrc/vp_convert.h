@@ -93,7 +93,7 @@ __device__ __forceinline__ f3 convert_pixel(const ConvertParams &P, int i, int j
     c.x = (P.cm[0] * y + P.cm[1] * uv[0] + P.cm[2] * uv[1]) + P.cm[9];
     c.y = (P.cm[3] * y + P.cm[4] * uv[0] + P.cm[5] * uv[1]) + P.cm[10];
     c.z = (P.cm[6] * y + P.cm[7] * uv[0] + P.cm[8] * uv[1]) + P.cm[11];
-    return hdr_tail(c, P.tail, P.gamma, P.lum_scale, P.gamut);
+    return hdr_tail(c, P.tail, P.gamma, P.lum_scale, make_mat3(P.gamut));
 }
 
 }  // namespace mpcvr

@@ -74,17 +74,25 @@ __device__ __forceinline__ float hable_div()
     return ((x * (A * x + (C * B)) + (D * E)) / (x * (A * x + B) + (D * F))) - E / F;
 }
 
-__device__ __forceinline__ f3 mat3_mul(const float *m, f3 v)
+struct mat3 { float m[9]; };          // by value: keeps kernel-argument matrices in SGPRs (no address taken)
+__device__ __forceinline__ mat3 make_mat3(const float (&a)[9])
+{
+    mat3 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.m[i] = a[i];
+    return r;
+}
+__device__ __forceinline__ f3 mat3_mul(const mat3 &g, f3 v)
 {
     f3 r;
-    r.x = m[0] * v.x + m[1] * v.y + m[2] * v.z;
-    r.y = m[3] * v.x + m[4] * v.y + m[5] * v.z;
-    r.z = m[6] * v.x + m[7] * v.y + m[8] * v.z;
+    r.x = g.m[0] * v.x + g.m[1] * v.y + g.m[2] * v.z;
+    r.y = g.m[3] * v.x + g.m[4] * v.y + g.m[5] * v.z;
+    r.z = g.m[6] * v.x + g.m[7] * v.y + g.m[8] * v.z;
     return r;
 }
 
 // The tail GetShaderConvertColor appends after "//convert color" — Shaders.cpp:861-923
-__device__ __forceinline__ f3 hdr_tail(f3 c, int tail, float gamma, float lum_scale, const float *gamut)
+__device__ __forceinline__ f3 hdr_tail(f3 c, int tail, float gamma, float lum_scale, const mat3 &gamut)
 {
     if (tail == TAIL_NONE) return c;
     if (tail == TAIL_PQ_TO_SDR || tail == TAIL_HLG_TO_SDR) {

@@ -256,7 +256,7 @@ __device__ __forceinline__ void convert_block(const FusedArgs &P, const Raw &r, 
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 f3 v = {rgb[0][e], rgb[1][e], rgb[2][e]};
-                v = hdr_tail(v, P.tail, P.gamma, P.lum_scale, P.gamut);
+                v = hdr_tail(v, P.tail, P.gamma, P.lum_scale, make_mat3(P.gamut));
                 out[rr][0][e] = saturate(v.x); out[rr][1][e] = saturate(v.y); out[rr][2][e] = saturate(v.z);
             }
         } else {
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
     // phase weights, two per SGPR pair: WT[parity][pair]
     const f2 WT[2][3] = {{f2{P.we[0], P.we[1]}, f2{P.we[2], P.we[3]}, f2{P.we[4], P.we[5]}},
                         {f2{P.wo[0], P.wo[1]}, f2{P.wo[2], P.wo[3]}, f2{P.wo[4], P.wo[5]}}};
-    const f2 maxv2 = splat(P.final_pass ? P.maxv : P.quant), half2v = splat(0.5f), qom2 = splat(P.q_over_maxv);
+    const f2 maxv2 = splat(P.final_pass ? P.maxv : P.quant), qom2 = splat(P.q_over_maxv);
     const f2 cmax2 = splat(P.maxv), cinv2 = splat(P.inv_maxv);
 
     // 8-row window of X-pass results, already rounded through fp16: [row slot][channel][pixel pair]
