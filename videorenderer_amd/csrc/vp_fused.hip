@@ -266,7 +266,8 @@ __device__ __forceinline__ void convert_block(const FusedArgs &P, const Raw &r, 
     }
 }
 
-template <int NT, int TAIL, bool P01X>
+// FASTEPI: B8G8R8A8 target behind a final pass (the common case) — the generic epilogue is compiled out
+template <int NT, int TAIL, bool P01X, bool FASTEPI>
 __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
     // phase weights, two per SGPR pair: WT[parity][pair]
     const f2 WT[2][3] = {{f2{P.we[0], P.we[1]}, f2{P.we[2], P.we[3]}, f2{P.we[4], P.we[5]}},
                         {f2{P.wo[0], P.wo[1]}, f2{P.wo[2], P.wo[3]}, f2{P.wo[4], P.wo[5]}}};
-    const f2 maxv2 = splat(P.final_pass ? P.maxv : P.quant), qom2 = splat(P.q_over_maxv);
+    const f2 maxv2 = splat((FASTEPI || P.final_pass) ? P.maxv : P.quant), qom2 = splat(P.q_over_maxv);
     const f2 cmax2 = splat(P.maxv), cinv2 = splat(P.inv_maxv);
 
     // 8-row window of X-pass results, already rounded through fp16: [row slot][channel][pixel pair]
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
                         }
                         const int wy = P.off_y + 2 * k + par;
                         uint32_t pk[4];
-                        if (P.final_pass && !P.out10) {
+                        if (FASTEPI) {
                             // m_TexsPostScale store/load: q = floor(x*maxv + 0.5), p = q/maxv; ps_final_pass.hlsl:29:
                             // floor(p*255 + d).  p*255 is evaluated as q*(255/maxv) inside one FMA (<= 1 ulp from the
                             // two-step form) and the outer floor is taken by v_cvt_pk_u8_f32's round-to-nearest of
@@ -556,8 +557,10 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     const int tailk = c.tail == TAIL_NONE ? TAILK_NONE : (c.tail == TAIL_PQ_TO_SDR && P.pq_lut) ? TAILK_PQ_LUT : TAILK_ALU;
     const size_t lds = LDS_A + LDS_D + LDS_DB + (tailk == TAILK_PQ_LUT ? LDS_T : 0);
     const bool p01x = c.fmt.planes == 2 && c.fmt.bytes == 2;
-#define MPCVR_LAUNCH(NT, TK) do { if (p01x) hipLaunchKernelGGL((k_fused_up2x<NT, TK, true>), grid, block, lds, s, a, frames_dev, single); \
-                                  else hipLaunchKernelGGL((k_fused_up2x<NT, TK, false>), grid, block, lds, s, a, frames_dev, single); } while (0)
+    const bool fastepi = a.final_pass && !a.out10;
+#define MPCVR_LAUNCH2(NT, TK, PX) do { if (fastepi) hipLaunchKernelGGL((k_fused_up2x<NT, TK, PX, true>), grid, block, lds, s, a, frames_dev, single); \
+                                       else hipLaunchKernelGGL((k_fused_up2x<NT, TK, PX, false>), grid, block, lds, s, a, frames_dev, single); } while (0)
+#define MPCVR_LAUNCH(NT, TK) do { if (p01x) MPCVR_LAUNCH2(NT, TK, true); else MPCVR_LAUNCH2(NT, TK, false); } while (0)
 #define MPCVR_LAUNCH_NT(NT) \
     do { if (tailk == TAILK_NONE) MPCVR_LAUNCH(NT, TAILK_NONE); else if (tailk == TAILK_PQ_LUT) MPCVR_LAUNCH(NT, TAILK_PQ_LUT); \
          else MPCVR_LAUNCH(NT, TAILK_ALU); } while (0)
@@ -566,6 +569,7 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     else MPCVR_LAUNCH_NT(6);
 #undef MPCVR_LAUNCH_NT
 #undef MPCVR_LAUNCH
+#undef MPCVR_LAUNCH2
     return hipGetLastError();
 }
 
