@@ -332,6 +332,29 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
     Raw raw;
     load_raw<P01X>(P, py, pu, pv, Xg, clampi(s0 - 3, 0, H - 1), clampi(s0 - 2, 0, H - 1), raw);
 
+    // stage C for virtual rows ar, ar+1 (whose raw codes were prefetched): convert, write A, prefetch the next pair
+    auto stage_c = [&](int ar) {
+        f2 rc[2][3];
+        convert_block<TAIL, P01X>(P, raw, P.rect_t + clampi(ar, 0, H - 1), P.rect_t + clampi(ar + 1, 0, H - 1), T, rc);
+        load_raw<P01X>(P, py, pu, pv, Xg, clampi(ar + 2, 0, H - 1), clampi(ar + 3, 0, H - 1), raw);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            // store to m_TexConvertOutput (UNORM: floor(sat(x)*maxv + 0.5)) and read back (q/maxv to 1 ulp)
+            f2 q0 = unorm_round2(rc[0][c], cmax2) * cinv2;
+            f2 q1 = unorm_round2(rc[1][c], cmax2) * cinv2;
+            if (X < 0 || X > W - 2) {                                 // clamp-to-edge of the convert texture
+                if (X < 0) { q0.y = q0.x; q1.y = q1.x; } else { q0.x = q0.y; q1.x = q1.y; }
+            }
+            // A[ch][col][row]: columns 2l, 2l+1 as (row a, row a+1) pairs = one 16-byte store
+            *(f4 *)(A + (c * AW + 2 * lane) * 2) = f4{q0.x, q1.x, q0.y, q1.y};
+        }
+    };
+    // Software pipeline: iteration t runs  X(t) -> C(t+1) -> Y(t), so the LDS write->read round trip of A (and the
+    // global prefetch behind it) is covered by the Y stage instead of stalling the wave.  A is exchanged between
+    // lanes of this wave only: LDS operations of one wave execute in order; the fences keep the compiler from
+    // reordering the A reads and writes (which look unrelated thread by thread).
+    stage_c(s0 - 3);
+
     for (int tb = 0; tb < n_iter; tb += 4) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -339,26 +362,6 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
             if (t >= n_iter) break;
             const int a = s0 - 3 + 2 * t;
 
-            // ---------------- stage C ----------------
-            {
-                f2 rc[2][3];
-                convert_block<TAIL, P01X>(P, raw, P.rect_t + clampi(a, 0, H - 1), P.rect_t + clampi(a + 1, 0, H - 1), T, rc);
-                // prefetch the next pair of rows while this one is processed
-                load_raw<P01X>(P, py, pu, pv, Xg, clampi(a + 2, 0, H - 1), clampi(a + 3, 0, H - 1), raw);
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    // store to m_TexConvertOutput (UNORM: floor(sat(x)*maxv + 0.5)) and read back (q/maxv to 1 ulp)
-                    f2 q0 = unorm_round2(rc[0][c], cmax2) * cinv2;
-                    f2 q1 = unorm_round2(rc[1][c], cmax2) * cinv2;
-                    if (X < 0 || X > W - 2) {                                 // clamp-to-edge of the convert texture
-                        if (X < 0) { q0.y = q0.x; q1.y = q1.x; } else { q0.x = q0.y; q1.x = q1.y; }
-                    }
-                    // A[ch][col][row]: columns 2l, 2l+1 as (row a, row a+1) pairs = one 16-byte store
-                    *(f4 *)(A + (c * AW + 2 * lane) * 2) = f4{q0.x, q1.x, q0.y, q1.y};
-                }
-            }
-            // A is exchanged between lanes of this wave only: LDS operations of one wave execute in order,
-            // the fences keep the compiler from moving the reads above the writes.
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -391,6 +394,10 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            // ---------------- stage C of the NEXT iteration ----------------
+            if (t + 1 < n_iter) stage_c(a + 2);
 
             // ---------------- stage Y + final pass ----------------
             // window slot of virtual row r is (r - (s0-3)) & 7; rows a-6 .. a+1 are live: slot(a-6+i) = (2u+2+i) & 7
