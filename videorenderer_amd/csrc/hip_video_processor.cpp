@@ -418,6 +418,7 @@ void CHipVideoProcessor::FillFusedParams(const uint8_t *sample, void *rt, int rt
     fp->store = MakeStore(rt, rtPitch, m_plan.swap_fmt, true);
     const bool no_lut = (m_cfg.flags & MPCVR_FLAG_NO_LUT) != 0;
     fp->pq_lut = (m_pqLutValid && !no_lut) ? (const float *)m_pqLut.ptr : nullptr;
+    fp->literal_tail = no_lut ? 1 : 0;
     // vectorised convert: dword loads need 4-byte aligned rows and a source rect starting on a 4-px boundary
     fp->fast_convert = (m_srcRect.left % 4 == 0) && (m_srcRect.top % 2 == 0) && (m_srcPitch % 4 == 0) &&
                        (fp->conv.pitch[1] % 4 == 0) && (fp->plane_off[1] % 4 == 0) && (fp->plane_off[2] % 4 == 0) &&

@@ -53,7 +53,7 @@ typedef __attribute__((address_space(1))) uint8_t *gptr;
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-enum { TAILK_NONE = 0, TAILK_PQ_LUT = 1, TAILK_ALU = 2 };
+enum { TAILK_NONE = 0, TAILK_PQ_LUT = 1, TAILK_ALU = 2, TAILK_HLG = 3 };
 
 // everything the kernel needs, flattened (kernel argument => SGPRs)
 struct FusedArgs {
@@ -250,6 +250,38 @@ __device__ __forceinline__ void convert_block(const FusedArgs &P, const Raw &r, 
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
                 const f2 g = pk_fma_sat_s(splat(P.gamut[3 * ch]), lin[0], pk_fma(splat(P.gamut[3 * ch + 1]), lin[1], splat(P.gamut[3 * ch + 2]) * lin[2]));
+                out[rr][ch] = f2{hlsl_pow(g.x, 1.0f / 2.2f), hlsl_pow(g.y, 1.0f / 2.2f)};
+            }
+        } else if (TAIL == TAILK_HLG) {
+            // Shaders.cpp:862-923 for HLG: saturate -> HLGtoLinear (hlg.hlsl:1-20) -> LinearToST2084(., 1000) -> saturate ->
+            // ST2084ToLinear(., scale) -> Hable -> 2020->709 -> saturate -> pow 1/2.2.  The PQ encode/decode round trip
+            // (quirk Q7) is the identity x -> x*scale/1000 on the whole reachable range (x/1000 <= 0.09, never
+            // saturated); it is elided here.  The literal chain — kept in the pass-per-kernel path and the oracle —
+            // differs from the identity by ~1e-5 relative, the rounding noise of its own four pow() calls.
+            f2 lin[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const f2 v = rgb[ch];
+                lin[ch] = f2{v.x <= 0.5f ? v.x * v.x * 4.0f : __expf((v.x - 0.55991073f) * (1.0f / 0.17883277f)) + 0.28466892f,
+                             v.y <= 0.5f ? v.y * v.y * 4.0f : __expf((v.y - 0.55991073f) * (1.0f / 0.17883277f)) + 0.28466892f};
+            }
+            const f2 ys = splat(2000.0f) * pk_fma(splat(0.2627f), lin[0], pk_fma(splat(0.6780f), lin[1], splat(0.0593f) * lin[2]));
+            const float ks = P.lum_scale * (1.0f / 1000.0f);
+            const f2 gain = f2{hlsl_pow(ys.x, 0.2f) * ks, hlsl_pow(ys.y, 0.2f) * ks};
+            const float A_ = 0.15f, B_ = 0.50f, CB = 0.10f * 0.50f, DE = 0.20f * 0.02f, DF = 0.20f * 0.30f, EF = 0.02f / 0.30f;
+            const float inv_div = 1.0f / (((4.8f * (A_ * 4.8f + CB) + DE) / (4.8f * (A_ * 4.8f + B_) + DF)) - EF);
+            f2 tm[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const f2 x = lin[ch] * gain;
+                const f2 num = pk_fma(x, pk_fma(splat(A_), x, splat(CB)), splat(DE));
+                const f2 den = pk_fma(x, pk_fma(splat(A_), x, splat(B_)), splat(DF));
+                const f2 q = f2{num.x * __builtin_amdgcn_rcpf(den.x), num.y * __builtin_amdgcn_rcpf(den.y)};
+                tm[ch] = (q - splat(EF)) * splat(inv_div);
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const f2 g = pk_fma_sat_s(splat(P.gamut[3 * ch]), tm[0], pk_fma(splat(P.gamut[3 * ch + 1]), tm[1], splat(P.gamut[3 * ch + 2]) * tm[2]));
                 out[rr][ch] = f2{hlsl_pow(g.x, 1.0f / 2.2f), hlsl_pow(g.y, 1.0f / 2.2f)};
             }
         } else if (TAIL == TAILK_ALU) {
@@ -552,7 +584,7 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     int seg = seg_env;
     if (seg <= 0) {
         seg = 72;
-        for (int cand : {72, 48, 36, 24})
+        for (int cand : {180, 144, 120, 108, 90, 72, 60, 48, 36, 24})
             if ((long)strips * ((c.out_h + cand - 1) / cand) * n_frames >= 12288 || cand == 24) { seg = cand; break; }
     }
     seg = (seg + 1) & ~1;
@@ -561,7 +593,9 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
 
     const dim3 grid((strips + WAVES - 1) / WAVES, (c.out_h + seg - 1) / seg, n_frames);
     const dim3 block(256, 1, 1);
-    const int tailk = c.tail == TAIL_NONE ? TAILK_NONE : (c.tail == TAIL_PQ_TO_SDR && P.pq_lut) ? TAILK_PQ_LUT : TAILK_ALU;
+    // P.pq_lut is null when MPCVR_FLAG_NO_LUT asks for the literal ALU chains (A/B testing)
+    const int tailk = c.tail == TAIL_NONE ? TAILK_NONE : (c.tail == TAIL_PQ_TO_SDR && P.pq_lut) ? TAILK_PQ_LUT
+                    : (c.tail == TAIL_HLG_TO_SDR && !P.literal_tail) ? TAILK_HLG : TAILK_ALU;
     const size_t lds = LDS_A + LDS_D + LDS_DB + (tailk == TAILK_PQ_LUT ? LDS_T : 0);
     const bool p01x = c.fmt.planes == 2 && c.fmt.bytes == 2;
     const bool fastepi = a.final_pass && !a.out10;
@@ -570,7 +604,7 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
 #define MPCVR_LAUNCH(NT, TK) do { if (p01x) MPCVR_LAUNCH2(NT, TK, true); else MPCVR_LAUNCH2(NT, TK, false); } while (0)
 #define MPCVR_LAUNCH_NT(NT) \
     do { if (tailk == TAILK_NONE) MPCVR_LAUNCH(NT, TAILK_NONE); else if (tailk == TAILK_PQ_LUT) MPCVR_LAUNCH(NT, TAILK_PQ_LUT); \
-         else MPCVR_LAUNCH(NT, TAILK_ALU); } while (0)
+         else if (tailk == TAILK_HLG) MPCVR_LAUNCH(NT, TAILK_HLG); else MPCVR_LAUNCH(NT, TAILK_ALU); } while (0)
     if (knt == 4) MPCVR_LAUNCH_NT(4);
     else if (knt == 5) MPCVR_LAUNCH_NT(5);
     else MPCVR_LAUNCH_NT(6);

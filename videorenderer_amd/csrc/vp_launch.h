@@ -24,7 +24,8 @@ struct FusedParams {
     StoreParams store;        // dst ignored; per frame
     int out_w, out_h;         // 2*conv.out_w, 2*conv.out_h
     const float *pq_lut;      // device, kPqLutSize floats: x -> Hable(ST2084ToLinear(x)*scale)/hable(4.8); null => ALU
-    int fast_convert;         // layout/alignments allow the vectorised 4-pixel convert
+    int fast_convert;         // layout/alignments allow the vectorised convert
+    int literal_tail;         // MPCVR_FLAG_NO_LUT: evaluate the HDR tails literally in ALU (no LUT, no algebraic shortcut)
 };
 bool FusedUp2xSupported(const FusedParams &P);
 // frames_dev == nullptr: n_frames must be 1 and `single` is used (no device-side table needed)
