@@ -1,0 +1,144 @@
+// mfma_mix.hip — (1) pins the v_mfma_f32_32x32x16_f16 operand layout, (2) checks the hi/lo fp16 weight split against an
+// fp32 FMA chain on a Toeplitz (Lanczos) product, (3) measures how much VALU work hides beside MFMAs on gfx950.
+//   hipcc --offload-arch=gfx950 -O3 -o mfma_mix mfma_mix.hip && ./mfma_mix
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+// D[32x32] = A[32x16] * B[16x32]; assumed layout: A lane l: row l%32, k = 8*(l/32)+i; B lane l: col l%32, k = 8*(l/32)+i
+__global__ void k_layout(const _Float16 *A, const _Float16 *B, float *D)
+{
+    const int l = threadIdx.x;
+    h8 a, b;
+    for (int i = 0; i < 8; i++) {
+        a[i] = A[(l % 32) * 16 + 8 * (l / 32) + i];
+        b[i] = B[(8 * (l / 32) + i) * 32 + (l % 32)];
+    }
+    f16v c = {};
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+        D[row * 32 + col] = c[r];
+    }
+}
+
+// throughput: NM mfma + NV valu (KIND 0 = v_fma_f32, 1 = v_pk_fma_f32, 2 = v_cvt_pk_u8 style misc) per iteration
+template <int NM, int NV, int KIND>
+__global__ __launch_bounds__(256) void k_mix(float *out, int iters, float s)
+{
+    const int l = threadIdx.x;
+    h8 a, b;
+    for (int i = 0; i < 8; i++) { a[i] = (_Float16)(l * 0.001f + i); b[i] = (_Float16)(i * 0.5f - l * 0.002f); }
+    f16v acc[4] = {};
+    float v[16]; f2 p[16];
+    for (int i = 0; i < 16; i++) { v[i] = l + i; p[i] = f2{(float)l, (float)i}; }
+    const f2 s2 = f2{s, s * 0.5f};
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int m = 0; m < NM; m++) acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[m & 3], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            if (KIND == 0) v[j & 15] = __builtin_fmaf(v[j & 15], s, 1.0f);
+            else p[j & 15] = __builtin_elementwise_fma(p[j & 15], s2, s2);
+        }
+    }
+    float r = 0;
+    for (int m = 0; m < 4; m++) for (int i = 0; i < 16; i++) r += acc[m][i];
+    for (int i = 0; i < 16; i++) r += v[i] + p[i].x + p[i].y;
+    out[blockIdx.x * blockDim.x + l] = r;
+}
+
+template <int NM, int NV, int KIND>
+static void run_mix(const char *name, float *d_out, int blocks)
+{
+    const int iters = 2000;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_mix<NM, NV, KIND>), dim3(blocks), dim3(256), 0, 0, d_out, 10, 0.999f);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_mix<NM, NV, KIND>), dim3(blocks), dim3(256), 0, 0, d_out, iters, 0.999f);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    // waves per SIMD = blocks*4 / (256 CU * 4 SIMD) = blocks/256
+    const double wps = blocks / 256.0;
+    const double ns_per_iter_simd = ms * 1e6 / iters / wps;   // time one SIMD spends per (one wave's) iteration
+    printf("%-28s blocks=%5d  %8.3f ms  %7.2f ns per wave-iteration per SIMD (NM=%d NV=%d)\n", name, blocks, ms, ns_per_iter_simd, NM, NV);
+}
+
+int main()
+{
+    // ---- 1. layout ----
+    std::vector<_Float16> A(32 * 16), B(16 * 32);
+    srand(1);
+    for (auto &x : A) x = (_Float16)((rand() % 2001 - 1000) / 64.0f);
+    for (auto &x : B) x = (_Float16)((rand() % 1024));
+    _Float16 *dA, *dB; float *dD;
+    CK(hipMalloc(&dA, A.size() * 2)); CK(hipMalloc(&dB, B.size() * 2)); CK(hipMalloc(&dD, 32 * 32 * 4));
+    CK(hipMemcpy(dA, A.data(), A.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dB, B.data(), B.size() * 2, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_layout, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+    std::vector<float> D(32 * 32);
+    CK(hipMemcpy(D.data(), dD, D.size() * 4, hipMemcpyDeviceToHost));
+    double maxerr = 0;
+    for (int i = 0; i < 32; i++) for (int j = 0; j < 32; j++) {
+        double ref = 0;
+        for (int k = 0; k < 16; k++) ref += (double)A[i * 16 + k] * (double)B[k * 32 + j];
+        maxerr = fmax(maxerr, fabs(ref - D[i * 32 + j]));
+    }
+    printf("layout check: max |D - ref| = %g (expect ~0)\n", maxerr);
+
+    // ---- 2. hi/lo split on a Lanczos Toeplitz row: out = sum_k w[k]*code[k]/1023 ----
+    {
+        const float w[6] = {-0.01083153f, -0.08472481f, 0.89105344f, 0.23991315f, -0.01790517f, -0.01750513f};
+        std::vector<_Float16> Ah(32 * 16, (_Float16)0), Al(32 * 16, (_Float16)0), Bc(16 * 32);
+        // A row i: taps at k = (i % 8) .. +5  (any placement inside K=16)
+        for (int i = 0; i < 32; i++) for (int t = 0; t < 6; t++) {
+            const float ws = w[t] * (1024.0f / 1023.0f) ;
+            const _Float16 hi = (_Float16)ws; const _Float16 lo = (_Float16)((ws - (float)hi) * 2048.0f);
+            Ah[i * 16 + (i % 8) + t] = hi; Al[i * 16 + (i % 8) + t] = lo;
+        }
+        for (auto &x : Bc) x = (_Float16)(rand() % 1024);
+        std::vector<float> Dh(1024), Dl(1024);
+        CK(hipMemcpy(dB, Bc.data(), Bc.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dA, Ah.data(), Ah.size() * 2, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_layout, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+        CK(hipMemcpy(Dh.data(), dD, 4096, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(dA, Al.data(), Al.size() * 2, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_layout, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+        CK(hipMemcpy(Dl.data(), dD, 4096, hipMemcpyDeviceToHost));
+        double me = 0; int flips = 0;
+        for (int i = 0; i < 32; i++) for (int j = 0; j < 32; j++) {
+            float ref = 0;   // fp32 chain as the shader: sum w*tex, tex = code/1023
+            for (int t = 0; t < 6; t++) ref = fmaf(w[t], (float)Bc[((i % 8) + t) * 32 + j] / 1023.0f, ref);
+            const float got = (Dh[i * 32 + j] + Dl[i * 32 + j] * (1.0f / 2048.0f)) * (1.0f / 1024.0f);
+            me = fmax(me, fabs((double)ref - got));
+            if ((_Float16)ref != (_Float16)got) flips++;
+        }
+        printf("hi/lo split (lo scaled 2^11, two launches): max |diff| = %g, fp16-rounding flips %d / 1024\n", me, flips);
+    }
+
+    // ---- 3. throughput ----
+    float *d_out; CK(hipMalloc(&d_out, 4096 * 256 * 4));
+    for (int blocks : {256, 512, 768}) {
+        run_mix<4, 0, 0>("mfma only x4", d_out, blocks);
+        run_mix<0, 32, 0>("fma x32", d_out, blocks);
+        run_mix<0, 32, 1>("pk_fma x32", d_out, blocks);
+        run_mix<4, 16, 0>("mfma x4 + fma x16", d_out, blocks);
+        run_mix<4, 32, 0>("mfma x4 + fma x32", d_out, blocks);
+        run_mix<4, 16, 1>("mfma x4 + pk_fma x16", d_out, blocks);
+        run_mix<4, 32, 1>("mfma x4 + pk_fma x32", d_out, blocks);
+        run_mix<1, 32, 1>("mfma x1 + pk_fma x32", d_out, blocks);
+        run_mix<1, 32, 0>("mfma x1 + fma x32", d_out, blocks);
+        run_mix<2, 64, 1>("mfma x2 + pk_fma x64", d_out, blocks);
+    }
+    return 0;
+}

@@ -45,7 +45,7 @@ constexpr int A_FLOATS = 3 * AW * 2;   // [ch][col][row a | row a+1]
 constexpr int LUT_N = kPqLutSize;  // PQ->SDR per-channel table (vp_params.h)
 constexpr int LDS_A = WAVES * A_FLOATS * 4;
 constexpr int LDS_D = 32 * 32 * 2;      // dither table, fp16 bits (generic epilogue)
-constexpr int LDS_DB = 32 * 32 * 4;     // dither table as fp32 with the -0.5 + 2^-17 rounding bias folded in
+constexpr int LDS_DB = 32 * 32 * 4;     // dither table as integers j << 14 (d = j/1024) for the FASTEPI epilogue
 constexpr int LDS_T = LUT_N * 8;   // {value, delta-to-next} pairs
 
 typedef const __attribute__((address_space(1))) uint8_t *gcptr;
@@ -63,13 +63,14 @@ struct FusedArgs {
     int rect_l, rect_t, W, H;      // source rect origin and size (== convert-output size)
     int bytes, planes;
     int center_h;                  // MPEG-1 siting: chroma sample centred between luma columns
-    float v_off;                   // +0.25 chroma rows for co-sited
+    int v_off4;                    // vertical chroma offset in quarter chroma rows: 1 for co-sited (+0.25), else 0
     float m[9], c[3];              // colour matrix with the UNORM scale (and CopyPlane10to16 shift) folded in
     int tail; float gamma, lum_scale;
     float gamut[9];
     const float *lut;              // LUT_N floats (device) for TAILK_PQ_LUT
     float maxv, inv_maxv;          // internal UNORM format
     float q_over_maxv;             // ps_final_pass QUANTIZATION / maxv
+    uint32_t epi_mul;              // FASTEPI: ceil(QUANTIZATION * 2^24 / maxv), see the final-pass epilogue
     float we[6], wo[6];            // phase weights (even/odd outputs); Q1-folded by the launcher
     int dst_pitch, off_x, off_y;
     int final_pass, out10;
@@ -145,12 +146,23 @@ __device__ __forceinline__ f2 taps(const f2 (&wp)[3], F x)
     return pk_fma_w<1, CLAMP>(wp[2], x(5), acc);
 }
 
+// coefficient i of a table packed two to an SGPR pair (i is a constant after unrolling)
+template <bool CLAMP>
+__device__ __forceinline__ f2 fma_k(const f2 *K, int i, f2 b, f2 c)
+{
+    return (i & 1) ? pk_fma_w<1, CLAMP>(K[i >> 1], b, c) : pk_fma_w<0, CLAMP>(K[i >> 1], b, c);
+}
+__device__ __forceinline__ f2 mul_k(const f2 *K, int i, f2 b) { return (i & 1) ? pk_mul_w<1>(K[i >> 1], b) : pk_mul_w<0>(K[i >> 1], b); }
+
 // {value, delta} table lookup with linear interpolation; x already in [0,1]
 __device__ __forceinline__ float lut_eval(const f2 *T, float x)
 {
     const float t = x * (float)(LUT_N - 1);
     const f2 e = T[(int)t];
-    return fmaf(e.y, __builtin_amdgcn_fractf(t), e.x);
+    float r;   // plain v_fma_f32: a packed pair would need three v_mov to line its operands up, and v_pk_fma_f32 issues
+               // at half the rate of v_fma_f32 (tools/ubench/mfma_mix.hip), so packing only pays when it is free
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(e.y), "v"(__builtin_amdgcn_fractf(t)), "v"(e.x));
+    return r;
 }
 
 // raw codes of one 2x2 block (cols Xg, Xg+1; two source rows), prefetched one iteration ahead
@@ -178,8 +190,15 @@ __device__ __forceinline__ uint32_t ld_uv(const FusedArgs &P, gcptr pu, gcptr pv
     return ld_u8(pu + ro + col) | (ld_u8(pv + ro + col) << 16);
 }
 
-// vertical chroma position of source row sy (Shaders.cpp:118-138): v' = (sy+0.5)/2 [+0.25 co-sited] - 0.5
-__device__ __forceinline__ float chroma_v(const FusedArgs &P, int sy) { return ((float)sy + 0.5f) * 0.5f + P.v_off - 0.5f; }
+// vertical chroma position of source row sy (Shaders.cpp:118-138): v' = (sy+0.5)/2 [+0.25 co-sited] - 0.5, kept in
+// QUARTER chroma rows as an integer (4v' = 2sy - 1 [+1]) so that the whole siting computation stays on the scalar unit
+__device__ __forceinline__ int chroma_v4(const FusedArgs &P, int sy) { return 2 * sy - 1 + P.v_off4; }
+// fr/4 for fr = 0..4 as a float built from integer selects (wave-uniform => SGPR; no v_cvt/v_mul per iteration)
+__device__ __forceinline__ float quarter(int fr)
+{
+    const uint32_t b = fr <= 0 ? 0u : fr == 1 ? 0x3e800000u : fr == 2 ? 0x3f000000u : fr == 3 ? 0x3f400000u : 0x3f800000u;
+    return __builtin_bit_cast(float, b);
+}
 
 // Xg: first rect column of the block (even, inside the rect); y0,y1: the two (clamped) rect rows.
 // The two luma rows of an iteration are (odd, odd+1) source rows — or the same row twice where the rect clamps —
@@ -193,7 +212,7 @@ __device__ __forceinline__ void load_raw(const FusedArgs &P, gcptr py, gcptr pu,
     const int sy0 = P.rect_t + y0, sy1 = P.rect_t + y1;
     r.y[0] = (P01X || P.bytes == 2) ? ld_u32(py + (size_t)sy0 * P.pitch_y + 2 * sx0) : ld_u16(py + (size_t)sy0 * P.pitch_y + sx0);
     r.y[1] = (P01X || P.bytes == 2) ? ld_u32(py + (size_t)sy1 * P.pitch_y + 2 * sx0) : ld_u16(py + (size_t)sy1 * P.pitch_y + sx0);
-    const int n = (int)floorf(chroma_v(P, sy0));
+    const int n = chroma_v4(P, sy0) >> 2;
     const int rA = clampi(n, 0, P.ch - 1), rB = clampi(n + 1, 0, P.ch - 1);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -205,42 +224,46 @@ __device__ __forceinline__ void load_raw(const FusedArgs &P, gcptr py, gcptr pu,
 
 // The 2x2 block: 4:2:0 bilinear chroma + matrix (+ tail) for (even, odd column) x (row 0, row 1).
 // ShaderGetPixels' CHROMA_Bilinear branch (Shaders.cpp:265-270,319-325): same sample positions and weights,
-// evaluated in code units (vertical lerp first), UNORM scale folded into the matrix.  out[row][ch] = the channel as
-// an (even px, odd px) pair, saturated (every continuation — tail or UNORM store — saturates first).
+// evaluated in code units (vertical lerp first), UNORM scale folded into the matrix.  out[column][ch] = the channel as
+// a (row 0, row 1) pair — the layout LDS slice A wants — saturated (every continuation, tail or UNORM store,
+// saturates first).
 template <int TAIL, bool P01X>
-__device__ __forceinline__ void convert_block(const FusedArgs &P, const Raw &r, int sy0, int sy1, const f2 *T, f2 out[2][3])
+__device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const Raw &r, int sy0, int sy1, const f2 *T, f2 out[2][3])
 {
-    f2 top[3], bot[3];                            // (U, V) codes of chroma rows n, n+1 at columns c0-1, c0, c0+1
+    // vertical weights of chroma rows n (w0) and n+1 (w1) for (row 0, row 1): wave-uniform, one SGPR pair each
+    const int n4 = chroma_v4(P, sy0) & ~3;                 // 4 * floor(v'(row 0))
+    const int fr0 = chroma_v4(P, sy0) - n4, fr1 = chroma_v4(P, sy1) - n4;     // 0..4 quarters
+    const f2 w1 = f2{quarter(fr0), quarter(fr1)}, w0 = f2{quarter(4 - fr0), quarter(4 - fr1)};
+    f2 Uc[3], Vc[3];                              // U, V at chroma columns c0-1, c0, c0+1 as (row 0, row 1) pairs
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        top[i] = f2{(float)(r.c[0][i] & 0xffffu), (float)(r.c[0][i] >> 16)};
-        bot[i] = f2{(float)(r.c[1][i] & 0xffffu), (float)(r.c[1][i] >> 16)};
+        const float tu = (float)(r.c[0][i] & 0xffffu), tv = (float)(r.c[0][i] >> 16);
+        const float bu = (float)(r.c[1][i] & 0xffffu), bv = (float)(r.c[1][i] >> 16);
+        Uc[i] = pk_fma(splat(bu), w1, splat(tu) * w0);
+        Vc[i] = pk_fma(splat(bv), w1, splat(tv) * w0);
     }
-    const float n = floorf(chroma_v(P, sy0));
+    f2 Ycol[2], Ucol[2], Vcol[2];                 // even and odd luma column
+    if (P01X || P.bytes == 2) {
+        Ycol[0] = f2{(float)(r.y[0] & 0xffffu), (float)(r.y[1] & 0xffffu)};
+        Ycol[1] = f2{(float)(r.y[0] >> 16), (float)(r.y[1] >> 16)};
+    } else {
+        Ycol[0] = f2{(float)(r.y[0] & 0xffu), (float)(r.y[1] & 0xffu)};
+        Ycol[1] = f2{(float)((r.y[0] >> 8) & 0xffu), (float)((r.y[1] >> 8) & 0xffu)};
+    }
+    if (P.center_h) {                             // u' = sx/2 - 0.25
+        Ucol[0] = pk_fma(Uc[1], splat(0.75f), Uc[0] * splat(0.25f)); Vcol[0] = pk_fma(Vc[1], splat(0.75f), Vc[0] * splat(0.25f));
+        Ucol[1] = pk_fma(Uc[2], splat(0.25f), Uc[1] * splat(0.75f)); Vcol[1] = pk_fma(Vc[2], splat(0.25f), Vc[1] * splat(0.75f));
+    } else {                                      // u' = sx/2
+        Ucol[0] = Uc[1]; Vcol[0] = Vc[1];
+        Ucol[1] = pk_fma(Uc[2], splat(0.5f), Uc[1] * splat(0.5f)); Vcol[1] = pk_fma(Vc[2], splat(0.5f), Vc[1] * splat(0.5f));
+    }
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-        const uint32_t yraw = r.y[rr];
-        f2 Y;
-        if (P01X || P.bytes == 2) Y = f2{(float)(yraw & 0xffffu), (float)(yraw >> 16)};
-        else Y = f2{(float)(yraw & 0xffu), (float)((yraw >> 8) & 0xffu)};
-        const float wy = chroma_v(P, rr ? sy1 : sy0) - n;      // in [0,1]: weight of chroma row n+1
-        const f2 w1 = splat(wy), w0 = splat(1.0f - wy);
-        f2 UV[3];
-#pragma unroll
-        for (int i = 0; i < 3; i++) UV[i] = pk_fma(bot[i], w1, top[i] * w0);
-        f2 uve, uvo;                              // (U, V) at the even and the odd luma column
-        if (P.center_h) {                         // u' = sx/2 - 0.25
-            uve = pk_fma(UV[1], splat(0.75f), UV[0] * splat(0.25f));
-            uvo = pk_fma(UV[2], splat(0.25f), UV[1] * splat(0.75f));
-        } else {                                  // u' = sx/2
-            uve = UV[1];
-            uvo = pk_fma(UV[2], splat(0.5f), UV[1] * splat(0.5f));
-        }
-        const f2 U = f2{uve.x, uvo.x}, V = f2{uve.y, uvo.y};
+    for (int rr = 0; rr < 2; rr++) {              // rr = luma column of the block
+        const f2 Y = Ycol[rr], U = Ucol[rr], V = Vcol[rr];
         f2 rgb[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ch++)
-            rgb[ch] = pk_fma_sat_s(splat(P.m[3 * ch]), Y, pk_fma(splat(P.m[3 * ch + 1]), U, pk_fma(splat(P.m[3 * ch + 2]), V, splat(P.c[ch]))));
+            rgb[ch] = fma_k<true>(MM, 3 * ch, Y, fma_k<false>(MM, 3 * ch + 1, U, fma_k<false>(MM, 3 * ch + 2, V, splat(P.c[ch]))));
         if (TAIL == TAILK_PQ_LUT) {
             // Shaders.cpp:870-923: per-channel saturate -> ST2084ToLinear*scale -> Hable/hable(4.8) from the LDS table,
             // then the 2020->709 matrix, saturate and pow 1/2.2 in ALU
@@ -249,7 +272,7 @@ __device__ __forceinline__ void convert_block(const FusedArgs &P, const Raw &r, 
             for (int ch = 0; ch < 3; ch++) lin[ch] = f2{lut_eval(T, rgb[ch].x), lut_eval(T, rgb[ch].y)};
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
-                const f2 g = pk_fma_sat_s(splat(P.gamut[3 * ch]), lin[0], pk_fma(splat(P.gamut[3 * ch + 1]), lin[1], splat(P.gamut[3 * ch + 2]) * lin[2]));
+                const f2 g = fma_k<true>(GG, 3 * ch, lin[0], fma_k<false>(GG, 3 * ch + 1, lin[1], mul_k(GG, 3 * ch + 2, lin[2])));
                 out[rr][ch] = f2{hlsl_pow(g.x, 1.0f / 2.2f), hlsl_pow(g.y, 1.0f / 2.2f)};
             }
         } else if (TAIL == TAILK_HLG) {
@@ -281,7 +304,7 @@ __device__ __forceinline__ void convert_block(const FusedArgs &P, const Raw &r, 
             }
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
-                const f2 g = pk_fma_sat_s(splat(P.gamut[3 * ch]), tm[0], pk_fma(splat(P.gamut[3 * ch + 1]), tm[1], splat(P.gamut[3 * ch + 2]) * tm[2]));
+                const f2 g = fma_k<true>(GG, 3 * ch, tm[0], fma_k<false>(GG, 3 * ch + 1, tm[1], mul_k(GG, 3 * ch + 2, tm[2])));
                 out[rr][ch] = f2{hlsl_pow(g.x, 1.0f / 2.2f), hlsl_pow(g.y, 1.0f / 2.2f)};
             }
         } else if (TAIL == TAILK_ALU) {
@@ -305,13 +328,13 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *Aall = (float *)smem;
     unsigned short *D = (unsigned short *)(smem + LDS_A);
-    float *Db = (float *)(smem + LDS_A + LDS_D);
+    uint32_t *Di = (uint32_t *)(smem + LDS_A + LDS_D);
     f2 *T = (f2 *)(smem + LDS_A + LDS_D + LDS_DB);
 
     for (int i = threadIdx.x; i < 1024; i += 256) {
         const unsigned short d = P.dither[i];
         D[i] = d;
-        Db[i] = __half2float(__ushort_as_half(d)) + (-0.5f + 7.62939453125e-06f);
+        Di[i] = (uint32_t)(__half2float(__ushort_as_half(d)) * 1024.0f + 0.5f) << 14;     // d = j/1024 exactly (dither32x32float16.bin)
     }
     if (TAIL == TAILK_PQ_LUT)
         for (int i = threadIdx.x; i < LUT_N; i += 256) {
@@ -337,6 +360,7 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
     // stage C role: A columns 2*lane, 2*lane+1 = rect columns X, X+1; the block is fetched at Xg (inside the rect)
     const int X = x0 - 4 + 2 * lane;
     const int Xg = clampi(X, 0, W - 2);
+    const bool edge_wave = x0 == 0 || x0 + 2 * 63 - 4 > W - 2;      // wave-uniform: some lane's block hangs over the rect
     // stage X / Y role: output columns ox .. ox+3 (rect-relative); lanes 60..63 idle there
     const bool xy_active = lane < 60;
     const int ox = 2 * x0 + 4 * lane;
@@ -349,7 +373,10 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
     // phase weights, two per SGPR pair: WT[parity][pair]
     const f2 WT[2][3] = {{f2{P.we[0], P.we[1]}, f2{P.we[2], P.we[3]}, f2{P.we[4], P.we[5]}},
                         {f2{P.wo[0], P.wo[1]}, f2{P.wo[2], P.wo[3]}, f2{P.wo[4], P.wo[5]}}};
-    const f2 maxv2 = splat((FASTEPI || P.final_pass) ? P.maxv : P.quant), qom2 = splat(P.q_over_maxv);
+    // colour matrix and gamut matrix, two coefficients per SGPR pair
+    const f2 MM[5] = {f2{P.m[0], P.m[1]}, f2{P.m[2], P.m[3]}, f2{P.m[4], P.m[5]}, f2{P.m[6], P.m[7]}, f2{P.m[8], 0.0f}};
+    const f2 GG[5] = {f2{P.gamut[0], P.gamut[1]}, f2{P.gamut[2], P.gamut[3]}, f2{P.gamut[4], P.gamut[5]}, f2{P.gamut[6], P.gamut[7]}, f2{P.gamut[8], 0.0f}};
+    const f2 maxv2 = splat((FASTEPI || P.final_pass) ? P.maxv : P.quant);
     const f2 cmax2 = splat(P.maxv), cinv2 = splat(P.inv_maxv);
 
     // 8-row window of X-pass results, already rounded through fp16: [row slot][channel][pixel pair]
@@ -367,18 +394,20 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
     // stage C for virtual rows ar, ar+1 (whose raw codes were prefetched): convert, write A, prefetch the next pair
     auto stage_c = [&](int ar) {
         f2 rc[2][3];
-        convert_block<TAIL, P01X>(P, raw, P.rect_t + clampi(ar, 0, H - 1), P.rect_t + clampi(ar + 1, 0, H - 1), T, rc);
+        convert_block<TAIL, P01X>(P, MM, GG, raw, P.rect_t + clampi(ar, 0, H - 1), P.rect_t + clampi(ar + 1, 0, H - 1), T, rc);
         load_raw<P01X>(P, py, pu, pv, Xg, clampi(ar + 2, 0, H - 1), clampi(ar + 3, 0, H - 1), raw);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             // store to m_TexConvertOutput (UNORM: floor(sat(x)*maxv + 0.5)) and read back (q/maxv to 1 ulp)
-            f2 q0 = unorm_round2(rc[0][c], cmax2) * cinv2;
-            f2 q1 = unorm_round2(rc[1][c], cmax2) * cinv2;
-            if (X < 0 || X > W - 2) {                                 // clamp-to-edge of the convert texture
-                if (X < 0) { q0.y = q0.x; q1.y = q1.x; } else { q0.x = q0.y; q1.x = q1.y; }
-            }
+            f2 qe = unorm_round2(rc[0][c], cmax2) * cinv2;             // even column, rows (a, a+1)
+            f2 qo = unorm_round2(rc[1][c], cmax2) * cinv2;             // odd column
             // A[ch][col][row]: columns 2l, 2l+1 as (row a, row a+1) pairs = one 16-byte store
-            *(f4 *)(A + (c * AW + 2 * lane) * 2) = f4{q0.x, q1.x, q0.y, q1.y};
+            *(f4 *)(A + (c * AW + 2 * lane) * 2) = f4{qe.x, qe.y, qo.x, qo.y};
+            if (edge_wave) {       // clamp-to-edge of the convert texture: patch the column that hangs over (rare wave;
+                                   // an LDS store so that the compiler keeps it a branch instead of 12 selects per iteration)
+                if (X < 0) *(f2 *)(A + (c * AW + 2 * lane + 1) * 2) = qe;
+                else if (X > W - 2) *(f2 *)(A + (c * AW + 2 * lane) * 2) = qo;
+            }
         }
     };
     // Software pipeline: iteration t runs  X(t) -> C(t+1) -> Y(t), so the LDS write->read round trip of A (and the
@@ -452,30 +481,35 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
                         const int wy = P.off_y + 2 * k + par;
                         uint32_t pk[4];
                         if (FASTEPI) {
-                            // m_TexsPostScale store/load: q = floor(x*maxv + 0.5), p = q/maxv; ps_final_pass.hlsl:29:
-                            // floor(p*255 + d).  p*255 is evaluated as q*(255/maxv) inside one FMA (<= 1 ulp from the
-                            // two-step form) and the outer floor is taken by v_cvt_pk_u8_f32's round-to-nearest of
-                            // (x - 0.5 + 2^-17); both shortcuts can only matter within ~1e-5 of an integer.
-                            const float *drow = Db + (wy & 31) * 32;             // sampler WRAP+POINT: texel (wx mod 32, wy mod 32)
-                            f2 d2[2];                                            // dither + (-0.5 + 2^-17), see Db
+                            // m_TexsPostScale store/load: k = floor(x*maxv + 0.5), p = k/maxv; ps_final_pass.hlsl:29:
+                            // floor(p*255 + d), d = j/1024.  In integers: (k*M + (j << 14)) >> 24 with M = ceil(255*2^24/maxv)
+                            // equals floor(k*255/maxv + j/1024) for every (k, j) (exhaustively checked, tests/test_host_logic.py)
+                            // and differs from the fp32 shader arithmetic in 4 of the 2^20 (k, j) pairs, where fp32 rounds
+                            // the sum up onto an integer.  x*maxv + 2^23 leaves k in the low mantissa bits, which is all
+                            // v_mad_u32_u24 reads; the result byte is the top byte, gathered by two v_perm_b32 per pixel.
+                            const uint32_t *drow = Di + (wy & 31) * 32;          // sampler WRAP+POINT: texel (wx mod 32, wy mod 32)
+                            uint32_t dj[4];
                             if (d_aligned) {
-                                const f4 dd = *(const f4 *)(drow + (wx0 & 31));
-                                d2[0] = f2{dd.x, dd.y}; d2[1] = f2{dd.z, dd.w};
+                                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                                const u32x4 dd = *(const u32x4 *)(drow + (wx0 & 31));
+                                dj[0] = dd.x; dj[1] = dd.y; dj[2] = dd.z; dj[3] = dd.w;
                             } else {
-                                d2[0] = f2{drow[wx0 & 31], drow[(wx0 + 1) & 31]};
-                                d2[1] = f2{drow[(wx0 + 2) & 31], drow[(wx0 + 3) & 31]};
+#pragma unroll
+                                for (int px = 0; px < 4; px++) dj[px] = drow[(wx0 + px) & 31];
                             }
-                            f2 fin[3][2];
+                            const f2 big2 = splat(8388608.0f);
+                            f2 uq[3][2];
 #pragma unroll
                             for (int c = 0; c < 3; c++)
 #pragma unroll
-                                for (int pp = 0; pp < 2; pp++)
-                                    fin[c][pp] = pk_fma(unorm_round2(res[c][pp], maxv2), qom2, d2[pp]);
+                                for (int pp = 0; pp < 2; pp++) uq[c][pp] = pk_fma(res[c][pp], maxv2, big2);
 #pragma unroll
-                            for (int px = 0; px < 4; px++) {    // v_cvt_pk_u8_f32: RNE + saturate, one byte per instruction
-                                uint32_t v = __builtin_amdgcn_cvt_pk_u8_f32(fin[2][px >> 1][px & 1], 0, 0xff000000u);   // B
-                                v = __builtin_amdgcn_cvt_pk_u8_f32(fin[1][px >> 1][px & 1], 1, v);                      // G
-                                pk[px] = __builtin_amdgcn_cvt_pk_u8_f32(fin[0][px >> 1][px & 1], 2, v);                 // R
+                            for (int px = 0; px < 4; px++) {
+                                const uint32_t ib = __umul24(__float_as_uint(uq[2][px >> 1][px & 1]), P.epi_mul) + dj[px];
+                                const uint32_t ig = __umul24(__float_as_uint(uq[1][px >> 1][px & 1]), P.epi_mul) + dj[px];
+                                const uint32_t ir = __umul24(__float_as_uint(uq[0][px >> 1][px & 1]), P.epi_mul) + dj[px];
+                                const uint32_t bg = __builtin_amdgcn_perm(ig, ib, 0x0c0c0703u);    // [B, G, 0, 0]
+                                pk[px] = __builtin_amdgcn_perm(ir, bg, 0x0d070100u);               // [B, G, R, 0xff]
                             }
                         } else {
                             // generic epilogue: no final pass (straight UNORM store into the RT) and/or R10G10B10A2 target
@@ -548,7 +582,7 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     a.rect_l = c.rect_l; a.rect_t = c.rect_t; a.W = c.out_w; a.H = c.out_h;
     a.bytes = c.fmt.bytes; a.planes = c.fmt.planes;
     a.center_h = c.chroma_loc == CLOC_MPEG1;
-    a.v_off = c.chroma_loc == CLOC_COSITED ? 0.25f : 0.0f;
+    a.v_off4 = c.chroma_loc == CLOC_COSITED ? 1 : 0;
     // UNORM scale: v/255, or (v << shift)/65535 for planar data; interleaved UV planes carry no shift
     const float sy = c.fmt.bytes == 1 ? 1.0f / 255.0f : (float)(1 << c.fmt.shift) / 65535.0f;
     const float sc = c.fmt.bytes == 1 ? 1.0f / 255.0f : (float)(1 << (c.fmt.planes == 2 ? 0 : c.fmt.shift)) / 65535.0f;
@@ -564,6 +598,8 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     a.maxv = c.out_fmt == SF_RGB10A2 ? 1023.0f : 255.0f;
     a.inv_maxv = 1.0f / a.maxv;
     a.q_over_maxv = (float)P.store.quant / a.maxv;
+    const uint64_t epi_mul = (((uint64_t)P.store.quant << 24) + (uint64_t)a.maxv - 1) / (uint64_t)a.maxv;
+    a.epi_mul = (uint32_t)epi_mul;
     const int nt = P.wx.ntaps;
     for (int t = 0; t < 6; t++) { a.we[t] = P.wx.w_even[t]; a.wo[t] = P.wx.w_odd[t]; }
     int knt = nt;
@@ -598,7 +634,8 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
                     : (c.tail == TAIL_HLG_TO_SDR && !P.literal_tail) ? TAILK_HLG : TAILK_ALU;
     const size_t lds = LDS_A + LDS_D + LDS_DB + (tailk == TAILK_PQ_LUT ? LDS_T : 0);
     const bool p01x = c.fmt.planes == 2 && c.fmt.bytes == 2;
-    const bool fastepi = a.final_pass && !a.out10;
+    // the integer epilogue needs k*M + (j << 14) < 2^32 and M < 2^24 (true for 10-bit internal -> 8-bit target)
+    const bool fastepi = a.final_pass && !a.out10 && epi_mul < (1u << 24) && (uint64_t)a.maxv * epi_mul + (1023u << 14) < (1ull << 32);
 #define MPCVR_LAUNCH2(NT, TK, PX) do { if (fastepi) hipLaunchKernelGGL((k_fused_up2x<NT, TK, PX, true>), grid, block, lds, s, a, frames_dev, single); \
                                        else hipLaunchKernelGGL((k_fused_up2x<NT, TK, PX, false>), grid, block, lds, s, a, frames_dev, single); } while (0)
 #define MPCVR_LAUNCH(NT, TK) do { if (p01x) MPCVR_LAUNCH2(NT, TK, true); else MPCVR_LAUNCH2(NT, TK, false); } while (0)
