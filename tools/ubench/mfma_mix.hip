@@ -42,18 +42,23 @@ __global__ __launch_bounds__(256) void k_mix(float *out, int iters, float s)
     float v[16]; f2 p[16];
     for (int i = 0; i < 16; i++) { v[i] = l + i; p[i] = f2{(float)l, (float)i}; }
     const f2 s2 = f2{s, s * 0.5f};
+    uint32_t hbits[4] = {0x3c003800u + l, 0x38003c00u + l, 0x3a003b00u, 0x3b003a00u}; uint32_t iv[16]; for (int i = 0; i < 16; i++) iv[i] = l * 3 + i;
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int m = 0; m < NM; m++) acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[m & 3], 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < NV; j++) {
             if (KIND == 0) v[j & 15] = __builtin_fmaf(v[j & 15], s, 1.0f);
+            else if (KIND == 2) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(v[j & 15]) : "s"(s), "v"(hbits[j & 3]));
+            else if (KIND == 3) asm volatile("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(iv[j & 15]) : "v"(iv[(j + 1) & 15]), "v"(hbits[j & 3]));
+            else if (KIND == 4) asm volatile("v_perm_b32 %0, %1, %2, %0" : "+v"(iv[j & 15]) : "v"(iv[(j + 1) & 15]), "v"(hbits[j & 3]));
+            else if (KIND == 5) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "+v"(iv[j & 15]) : "v"(v[(j + 1) & 15]), "v"(v[j & 15]));
             else p[j & 15] = __builtin_elementwise_fma(p[j & 15], s2, s2);
         }
     }
     float r = 0;
     for (int m = 0; m < 4; m++) for (int i = 0; i < 16; i++) r += acc[m][i];
-    for (int i = 0; i < 16; i++) r += v[i] + p[i].x + p[i].y;
+    for (int i = 0; i < 16; i++) r += v[i] + p[i].x + p[i].y + (float)iv[i];
     out[blockIdx.x * blockDim.x + l] = r;
 }
 
@@ -128,6 +133,14 @@ int main()
 
     // ---- 3. throughput ----
     float *d_out; CK(hipMalloc(&d_out, 4096 * 256 * 4));
+    for (int blocks : {768, 1024}) {
+        run_mix<0, 32, 2>("fma_mix x32", d_out, blocks);
+        run_mix<0, 32, 3>("mad_u32_u24 x32", d_out, blocks);
+        run_mix<0, 32, 4>("perm x32", d_out, blocks);
+        run_mix<0, 32, 5>("cvt_pk_f16 x32", d_out, blocks);
+        run_mix<0, 32, 0>("fma x32", d_out, blocks);
+        run_mix<0, 32, 1>("pk_fma x32", d_out, blocks);
+    }
     for (int blocks : {256, 512, 768}) {
         run_mix<4, 0, 0>("mfma only x4", d_out, blocks);
         run_mix<0, 32, 0>("fma x32", d_out, blocks);

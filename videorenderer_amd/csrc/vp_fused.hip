@@ -57,7 +57,7 @@ enum { TAILK_NONE = 0, TAILK_PQ_LUT = 1, TAILK_ALU = 2, TAILK_HLG = 3 };
 
 // everything the kernel needs, flattened (kernel argument => SGPRs)
 struct FusedArgs {
-    size_t off_u, off_v;           // byte offsets of the chroma plane(s) inside a sample (u = interleaved UV when biplanar)
+    uint32_t off_u, off_v;         // byte offsets of the chroma plane(s) inside a sample (u = interleaved UV when biplanar)
     int pitch_y, pitch_c;
     int tex_w, cw, ch;             // luma width, chroma size
     int rect_l, rect_t, W, H;      // source rect origin and size (== convert-output size)
@@ -99,9 +99,10 @@ __device__ __forceinline__ f2 floor2(f2 v) { return f2{floorf(v.x), floorf(v.y)}
 // UNORM store rounding floor(x*maxv + 0.5) for x in [0,1] without v_floor (which has no packed form):
 // x*maxv + 2^23 rounds to an integer in the FMA itself (nearest-even; x*maxv can only tie at x = 0.5, where both
 // conventions give (maxv+1)/2), then 2^23 comes off again — two packed instructions for two values.
-__device__ __forceinline__ f2 unorm_round2(f2 x, f2 maxv2)
+// `big` = splat(2^23) held in a VGPR pair for the whole kernel (the other two operands are VGPR + SGPR; a third
+// constant would be re-materialised with v_mov_b64 at every use).
+__device__ __forceinline__ f2 unorm_round2(f2 x, f2 maxv2, f2 big)
 {
-    const f2 big = f2{8388608.0f, 8388608.0f};
     return pk_fma(x, maxv2, big) - big;
 }
 // fp32 -> fp16 (RNE) -> fp32 for a pair: v_cvt_pk_f16_f32 + two v_cvt_f32_f16
@@ -146,6 +147,20 @@ __device__ __forceinline__ f2 taps(const f2 (&wp)[3], F x)
     return pk_fma_w<1, CLAMP>(wp[2], x(5), acc);
 }
 
+// two independent outputs in lockstep: back-to-back dependent v_pk_fma_f32 cost a wait state each (s_nop)
+template <int NT, bool CLAMP, typename FA, typename FB>
+__device__ __forceinline__ void taps2(const f2 (&wp)[3], FA xa, FB xb, f2 &ra, f2 &rb)
+{
+    f2 a = pk_mul_w<0>(wp[0], xa(0)), b = pk_mul_w<0>(wp[0], xb(0));
+    a = pk_fma_w<1, false>(wp[0], xa(1), a); b = pk_fma_w<1, false>(wp[0], xb(1), b);
+    a = pk_fma_w<0, false>(wp[1], xa(2), a); b = pk_fma_w<0, false>(wp[1], xb(2), b);
+    if (NT == 4) { ra = pk_fma_w<1, CLAMP>(wp[1], xa(3), a); rb = pk_fma_w<1, CLAMP>(wp[1], xb(3), b); return; }
+    a = pk_fma_w<1, false>(wp[1], xa(3), a); b = pk_fma_w<1, false>(wp[1], xb(3), b);
+    if (NT == 5) { ra = pk_fma_w<0, CLAMP>(wp[2], xa(4), a); rb = pk_fma_w<0, CLAMP>(wp[2], xb(4), b); return; }
+    a = pk_fma_w<0, false>(wp[2], xa(4), a); b = pk_fma_w<0, false>(wp[2], xb(4), b);
+    ra = pk_fma_w<1, CLAMP>(wp[2], xa(5), a); rb = pk_fma_w<1, CLAMP>(wp[2], xb(5), b);
+}
+
 // coefficient i of a table packed two to an SGPR pair (i is a constant after unrolling)
 template <bool CLAMP>
 __device__ __forceinline__ f2 fma_k(const f2 *K, int i, f2 b, f2 c)
@@ -175,19 +190,36 @@ __device__ __forceinline__ uint32_t ld_u8(gcptr p) { return *p; }
 __device__ __forceinline__ uint32_t ld_u16(gcptr p) { return *(const __attribute__((address_space(1))) uint16_t *)p; }
 __device__ __forceinline__ uint32_t ld_u32(gcptr p) { return *(const __attribute__((address_space(1))) uint32_t *)p; }
 
-// chroma texel (col,row) as U | V << 16 (raw codes), clamp addressing on the column
+// Addressing: every access is (wave-uniform row base, SGPR pair) + (per-lane 32-bit byte offset that does not change
+// over the rows), so the loads/stores take the saddr form and the loop spends no VALU on 64-bit pointer arithmetic.
+// Row offsets are 32-bit products (the launcher refuses surfaces of 4 GiB and more).
+struct RawAddr {
+    uint32_t yoff;            // luma: byte offset of column Xg inside a row
+    uint32_t coff[3];         // chroma columns c0-1, c0, c0+1 (clamp addressing), byte offset inside a chroma row
+};
+
 template <bool P01X>
-__device__ __forceinline__ uint32_t ld_uv(const FusedArgs &P, gcptr pu, gcptr pv, int col, int row)
+__device__ __forceinline__ void make_raw_addr(const FusedArgs &P, int Xg, RawAddr &ra)
 {
-    col = clampi(col, 0, P.cw - 1);
-    const size_t ro = (size_t)row * P.pitch_c;
+    const int sx0 = P.rect_l + Xg, c0 = sx0 >> 1;
+    const int yb = (P01X || P.bytes == 2) ? 2 : 1;
+    const int cb = (P01X || P.planes == 2) ? 2 * yb : yb;
+    ra.yoff = (uint32_t)(yb * sx0);
+#pragma unroll
+    for (int i = 0; i < 3; i++) ra.coff[i] = (uint32_t)(cb * clampi(c0 - 1 + i, 0, P.cw - 1));
+}
+
+// chroma texel as U | V << 16 (raw codes); pu/pv = row bases
+template <bool P01X>
+__device__ __forceinline__ uint32_t ld_uv(const FusedArgs &P, gcptr pu, gcptr pv, uint32_t off)
+{
     if (P01X || P.planes == 2) {
-        if (P01X || P.bytes == 2) return ld_u32(pu + ro + 4 * col);
-        const uint32_t d = ld_u16(pu + ro + 2 * col);
+        if (P01X || P.bytes == 2) return ld_u32(pu + off);
+        const uint32_t d = ld_u16(pu + off);
         return (d & 0xffu) | ((d >> 8) << 16);
     }
-    if (P.bytes == 2) return ld_u16(pu + ro + 2 * col) | (ld_u16(pv + ro + 2 * col) << 16);
-    return ld_u8(pu + ro + col) | (ld_u8(pv + ro + col) << 16);
+    if (P.bytes == 2) return ld_u16(pu + off) | (ld_u16(pv + off) << 16);
+    return ld_u8(pu + off) | (ld_u8(pv + off) << 16);
 }
 
 // vertical chroma position of source row sy (Shaders.cpp:118-138): v' = (sy+0.5)/2 [+0.25 co-sited] - 0.5, kept in
@@ -200,25 +232,25 @@ __device__ __forceinline__ float quarter(int fr)
     return __builtin_bit_cast(float, b);
 }
 
-// Xg: first rect column of the block (even, inside the rect); y0,y1: the two (clamped) rect rows.
+// y0,y1: the two (clamped) rect rows of the block.
 // The two luma rows of an iteration are (odd, odd+1) source rows — or the same row twice where the rect clamps —
 // (rect top and segment starts are even, host-checked), so for every siting both take their chroma from the same
 // two chroma rows n = floor(v'(row 0)) and n+1.
 template <bool P01X>
-__device__ __forceinline__ void load_raw(const FusedArgs &P, gcptr py, gcptr pu, gcptr pv, int Xg, int y0, int y1, Raw &r)
+__device__ __forceinline__ void load_raw(const FusedArgs &P, gcptr py, const RawAddr &ra, int y0, int y1, Raw &r)
 {
-    const int sx0 = P.rect_l + Xg;
-    const int c0 = sx0 >> 1;
     const int sy0 = P.rect_t + y0, sy1 = P.rect_t + y1;
-    r.y[0] = (P01X || P.bytes == 2) ? ld_u32(py + (size_t)sy0 * P.pitch_y + 2 * sx0) : ld_u16(py + (size_t)sy0 * P.pitch_y + sx0);
-    r.y[1] = (P01X || P.bytes == 2) ? ld_u32(py + (size_t)sy1 * P.pitch_y + 2 * sx0) : ld_u16(py + (size_t)sy1 * P.pitch_y + sx0);
+    const gcptr ry0 = py + (uint32_t)sy0 * (uint32_t)P.pitch_y, ry1 = py + (uint32_t)sy1 * (uint32_t)P.pitch_y;
+    r.y[0] = (P01X || P.bytes == 2) ? ld_u32(ry0 + ra.yoff) : ld_u16(ry0 + ra.yoff);
+    r.y[1] = (P01X || P.bytes == 2) ? ld_u32(ry1 + ra.yoff) : ld_u16(ry1 + ra.yoff);
     const int n = chroma_v4(P, sy0) >> 2;
-    const int rA = clampi(n, 0, P.ch - 1), rB = clampi(n + 1, 0, P.ch - 1);
+    const uint32_t oA = (uint32_t)clampi(n, 0, P.ch - 1) * (uint32_t)P.pitch_c, oB = (uint32_t)clampi(n + 1, 0, P.ch - 1) * (uint32_t)P.pitch_c;
+    const gcptr pu = py + P.off_u, pv = (P01X || P.planes == 2) ? pu : py + P.off_v;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         if (i == 0 && !P.center_h) { r.c[0][0] = r.c[1][0] = 0; continue; }
-        r.c[0][i] = ld_uv<P01X>(P, pu, pv, c0 - 1 + i, rA);
-        r.c[1][i] = ld_uv<P01X>(P, pu, pv, c0 - 1 + i, rB);
+        r.c[0][i] = ld_uv<P01X>(P, pu + oA, pv + oA, ra.coff[i]);
+        r.c[1][i] = ld_uv<P01X>(P, pu + oB, pv + oB, ra.coff[i]);
     }
 }
 
@@ -228,7 +260,7 @@ __device__ __forceinline__ void load_raw(const FusedArgs &P, gcptr py, gcptr pu,
 // a (row 0, row 1) pair — the layout LDS slice A wants — saturated (every continuation, tail or UNORM store,
 // saturates first).
 template <int TAIL, bool P01X>
-__device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const Raw &r, int sy0, int sy1, const f2 *T, f2 out[2][3])
+__device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], const Raw &r, int sy0, int sy1, const f2 *T, f2 out[2][3])
 {
     // vertical weights of chroma rows n (w0) and n+1 (w1) for (row 0, row 1): wave-uniform, one SGPR pair each
     const int n4 = chroma_v4(P, sy0) & ~3;                 // 4 * floor(v'(row 0))
@@ -263,7 +295,7 @@ __device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)
         f2 rgb[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ch++)
-            rgb[ch] = fma_k<true>(MM, 3 * ch, Y, fma_k<false>(MM, 3 * ch + 1, U, fma_k<false>(MM, 3 * ch + 2, V, splat(P.c[ch]))));
+            rgb[ch] = fma_k<true>(MM, 3 * ch, Y, fma_k<false>(MM, 3 * ch + 1, U, fma_k<false>(MM, 3 * ch + 2, V, CC[ch])));
         if (TAIL == TAILK_PQ_LUT) {
             // Shaders.cpp:870-923: per-channel saturate -> ST2084ToLinear*scale -> Hable/hable(4.8) from the LDS table,
             // then the 2020->709 matrix, saturate and pow 1/2.2 in ALU
@@ -351,11 +383,15 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
     const int s1 = min(s0 + P.seg_rows, H);
     float *A = Aall + wave * A_FLOATS;
 
+    // the frame table entry is wave-uniform; readfirstlane tells the compiler so (SGPR bases => saddr loads/stores)
     const FusedFrame frame = frames ? frames[blockIdx.z] : single;
-    const gcptr py = (gcptr)frame.src;
-    const gcptr pu = (gcptr)(frame.src + P.off_u);
-    const gcptr pv = (gcptr)(frame.src + P.off_v);
-    const gptr pdst = (gptr)frame.dst;
+    auto uniform_ptr = [](const void *q) {
+        const uint64_t v = (uint64_t)q;
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    };
+    const uint64_t src_u = uniform_ptr(frame.src), dst_u = uniform_ptr(frame.dst);
+    const gcptr py = (gcptr)src_u;
+    const gptr pdst = (gptr)dst_u;
 
     // stage C role: A columns 2*lane, 2*lane+1 = rect columns X, X+1; the block is fetched at Xg (inside the rect)
     const int X = x0 - 4 + 2 * lane;
@@ -367,7 +403,7 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
     const bool store_ok = xy_active && ox < 2 * W;
     const int wx0 = P.off_x + ox;
     const bool d_aligned = (wx0 & 3) == 0;          // wave-uniform: ox is a multiple of 4
-    const bool st_aligned = d_aligned && ((((uintptr_t)frame.dst) | (uintptr_t)P.dst_pitch) & 15) == 0;
+    const bool st_aligned = d_aligned && (((uintptr_t)dst_u | (uintptr_t)P.dst_pitch) & 15) == 0;
     const uint32_t lane_off = (uint32_t)wx0 * 4u;
 
     // phase weights, two per SGPR pair: WT[parity][pair]
@@ -378,6 +414,10 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
     const f2 GG[5] = {f2{P.gamut[0], P.gamut[1]}, f2{P.gamut[2], P.gamut[3]}, f2{P.gamut[4], P.gamut[5]}, f2{P.gamut[6], P.gamut[7]}, f2{P.gamut[8], 0.0f}};
     const f2 maxv2 = splat((FASTEPI || P.final_pass) ? P.maxv : P.quant);
     const f2 cmax2 = splat(P.maxv), cinv2 = splat(P.inv_maxv);
+    f2 big2 = splat(8388608.0f);                     // 2^23, pinned in VGPRs (see unorm_round2)
+    asm volatile("" : "+v"(big2));
+    f2 CC[3] = {splat(P.c[0]), splat(P.c[1]), splat(P.c[2])};     // matrix offsets: FMA addends must be VGPRs anyway
+    asm volatile("" : "+v"(CC[0]), "+v"(CC[1]), "+v"(CC[2]));
 
     // 8-row window of X-pass results, already rounded through fp16: [row slot][channel][pixel pair]
     f2 win[8][3][2];
@@ -389,18 +429,20 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
     // iteration t adds virtual rows a, a+1 with a = s0 - 3 + 2t; from t = 3 on it emits output rows of k = a-3, a-2
     const int n_iter = (s1 - s0 + 1) / 2 + 3;
     Raw raw;
-    load_raw<P01X>(P, py, pu, pv, Xg, clampi(s0 - 3, 0, H - 1), clampi(s0 - 2, 0, H - 1), raw);
+    RawAddr ra;
+    make_raw_addr<P01X>(P, Xg, ra);
+    load_raw<P01X>(P, py, ra, clampi(s0 - 3, 0, H - 1), clampi(s0 - 2, 0, H - 1), raw);
 
     // stage C for virtual rows ar, ar+1 (whose raw codes were prefetched): convert, write A, prefetch the next pair
     auto stage_c = [&](int ar) {
         f2 rc[2][3];
-        convert_block<TAIL, P01X>(P, MM, GG, raw, P.rect_t + clampi(ar, 0, H - 1), P.rect_t + clampi(ar + 1, 0, H - 1), T, rc);
-        load_raw<P01X>(P, py, pu, pv, Xg, clampi(ar + 2, 0, H - 1), clampi(ar + 3, 0, H - 1), raw);
+        convert_block<TAIL, P01X>(P, MM, GG, CC, raw, P.rect_t + clampi(ar, 0, H - 1), P.rect_t + clampi(ar + 1, 0, H - 1), T, rc);
+        load_raw<P01X>(P, py, ra, clampi(ar + 2, 0, H - 1), clampi(ar + 3, 0, H - 1), raw);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             // store to m_TexConvertOutput (UNORM: floor(sat(x)*maxv + 0.5)) and read back (q/maxv to 1 ulp)
-            f2 qe = unorm_round2(rc[0][c], cmax2) * cinv2;             // even column, rows (a, a+1)
-            f2 qo = unorm_round2(rc[1][c], cmax2) * cinv2;             // odd column
+            f2 qe = unorm_round2(rc[0][c], cmax2, big2) * cinv2;             // even column, rows (a, a+1)
+            f2 qo = unorm_round2(rc[1][c], cmax2, big2) * cinv2;             // odd column
             // A[ch][col][row]: columns 2l, 2l+1 as (row a, row a+1) pairs = one 16-byte store
             *(f4 *)(A + (c * AW + 2 * lane) * 2) = f4{qe.x, qe.y, qo.x, qo.y};
             if (edge_wave) {       // clamp-to-edge of the convert texture: patch the column that hangs over (rare wave;
@@ -439,11 +481,10 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
                     for (int i = 0; i < 5; i++) { const f4 p4 = ap[i]; av[2 * i] = f2{p4.x, p4.y}; av[2 * i + 1] = f2{p4.z, p4.w}; }
                     f2 o[4];                                  // 4 output columns x (row a, row a+1)
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int kk = e >> 1;                // source k = 2l + kk  -> av index of k is kk + 4
-                        const int odd = e & 1;                // even output 2k: base = k-1; odd output 2k+1: base = k
-                        o[e] = taps<NT, false>(WT[odd], [&](int tt) { return av[kk + 4 + (odd ? 0 : -1) + tap_off<NT>(tt)]; });
-                    }
+                    for (int odd = 0; odd < 2; odd++)         // even output 2k: base = k-1; odd output 2k+1: base = k
+                        taps2<NT, false>(WT[odd],             // source k = 2l + kk (kk = 0, 1) -> av index of k is kk + 4
+                                         [&](int tt) { return av[4 + (odd ? 0 : -1) + tap_off<NT>(tt)]; },
+                                         [&](int tt) { return av[5 + (odd ? 0 : -1) + tap_off<NT>(tt)]; }, o[odd], o[2 + odd]);
                     // m_TexResize is R16G16B16A16_FLOAT (:3155): round to fp16 (RNE), keep the rounded value as fp32
                     const int sa = (2 * u) & 7, sb = (2 * u + 1) & 7;
                     const f2 h0 = half_round2(o[0]), h1 = half_round2(o[1]), h2 = half_round2(o[2]), h3 = half_round2(o[3]);
@@ -473,10 +514,9 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
                         f2 res[3][2];                             // [channel][pixel pair], saturated
 #pragma unroll
                         for (int c = 0; c < 3; c++) {
-#pragma unroll
-                            for (int pp = 0; pp < 2; pp++) {
-                                res[c][pp] = taps<NT, true>(WT[par], [&](int tt) { return win[(2 * u + 2 + kk + 2 + par + tap_off<NT>(tt)) & 7][c][pp]; });
-                            }
+                            taps2<NT, true>(WT[par],
+                                            [&](int tt) { return win[(2 * u + 2 + kk + 2 + par + tap_off<NT>(tt)) & 7][c][0]; },
+                                            [&](int tt) { return win[(2 * u + 2 + kk + 2 + par + tap_off<NT>(tt)) & 7][c][1]; }, res[c][0], res[c][1]);
                         }
                         const int wy = P.off_y + 2 * k + par;
                         uint32_t pk[4];
@@ -497,7 +537,6 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
 #pragma unroll
                                 for (int px = 0; px < 4; px++) dj[px] = drow[(wx0 + px) & 31];
                             }
-                            const f2 big2 = splat(8388608.0f);
                             f2 uq[3][2];
 #pragma unroll
                             for (int c = 0; c < 3; c++)
@@ -529,7 +568,7 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
                                 pk[px] = P.out10 ? pack_rgb10a2(c3[0], c3[1], c3[2]) : pack_bgra8(c3[0], c3[1], c3[2]);
                             }
                         }
-                        const gptr rowp = pdst + (size_t)wy * P.dst_pitch;       // wave-uniform row base + per-lane 32-bit offset
+                        const gptr rowp = pdst + (uint32_t)wy * (uint32_t)P.dst_pitch;    // wave-uniform row base + per-lane 32-bit offset
                         if (st_aligned) {
                             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                             u32x4 v4 = {pk[0], pk[1], pk[2], pk[3]};
@@ -564,6 +603,10 @@ bool FusedUp2xSupported(const FusedParams &P)
     if (c.fmt.subsampling != 420 || c.chroma_scaling != 1) return false;
     if (c.out_w < 8 || c.out_h < 8 || (c.out_w & 1) || (c.out_h & 1)) return false;
     if (!P.fast_convert) return false;            // dword loads need aligned rows / rect (host-checked)
+    // 32-bit row offsets inside the kernel
+    if ((uint64_t)c.pitch[0] * (uint64_t)(c.rect_t + c.out_h + 2) >= (1ull << 32)) return false;
+    if ((uint64_t)P.plane_off[1] >= (1ull << 31) || (uint64_t)P.plane_off[2] >= (1ull << 31)) return false;
+    if ((uint64_t)P.store.dst_pitch * (uint64_t)(P.store.off_y + P.out_h) >= (1ull << 32)) return false;
     return true;
 }
 
@@ -575,8 +618,8 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     FusedArgs a;
     std::memset(&a, 0, sizeof(a));
     const bool swap_uv = c.fmt.planes == 3 && c.fmt.v_first;
-    a.off_u = swap_uv ? P.plane_off[2] : P.plane_off[1];
-    a.off_v = swap_uv ? P.plane_off[1] : P.plane_off[2];
+    a.off_u = (uint32_t)(swap_uv ? P.plane_off[2] : P.plane_off[1]);
+    a.off_v = (uint32_t)(swap_uv ? P.plane_off[1] : P.plane_off[2]);
     a.pitch_y = c.pitch[0]; a.pitch_c = c.pitch[1];
     a.tex_w = c.tex_w; a.cw = c.cw; a.ch = c.ch;
     a.rect_l = c.rect_l; a.rect_t = c.rect_t; a.W = c.out_w; a.H = c.out_h;
@@ -632,7 +675,8 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     // P.pq_lut is null when MPCVR_FLAG_NO_LUT asks for the literal ALU chains (A/B testing)
     const int tailk = c.tail == TAIL_NONE ? TAILK_NONE : (c.tail == TAIL_PQ_TO_SDR && P.pq_lut) ? TAILK_PQ_LUT
                     : (c.tail == TAIL_HLG_TO_SDR && !P.literal_tail) ? TAILK_HLG : TAILK_ALU;
-    const size_t lds = LDS_A + LDS_D + LDS_DB + (tailk == TAILK_PQ_LUT ? LDS_T : 0);
+    static const int lds_pad = EnvInt("MPCVR_FUSED_LDS_PAD", 0);   // experiments: lower the occupancy by claiming more LDS
+    const size_t lds = LDS_A + LDS_D + LDS_DB + (tailk == TAILK_PQ_LUT ? LDS_T : 0) + (size_t)lds_pad;
     const bool p01x = c.fmt.planes == 2 && c.fmt.bytes == 2;
     // the integer epilogue needs k*M + (j << 14) < 2^32 and M < 2^24 (true for 10-bit internal -> 8-bit target)
     const bool fastepi = a.final_pass && !a.out10 && epi_mul < (1u << 24) && (uint64_t)a.maxv * epi_mul + (1023u << 14) < (1ull << 32);
