@@ -193,6 +193,10 @@ __device__ __forceinline__ uint32_t ld_u32(gcptr p) { return *(const __attribute
 // Addressing: every access is (wave-uniform row base, SGPR pair) + (per-lane 32-bit byte offset that does not change
 // over the rows), so the loads/stores take the saddr form and the loop spends no VALU on 64-bit pointer arithmetic.
 // Row offsets are 32-bit products (the launcher refuses surfaces of 4 GiB and more).
+// `opaque` hides a loop-invariant 32-bit lane offset from LICM: the zero-extension then stays next to the access and
+// instruction selection folds (uniform base + zext(offset)) into the saddr form instead of a 64-bit VALU add per access.
+__device__ __forceinline__ uint32_t opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
+
 struct RawAddr {
     uint32_t yoff;            // luma: byte offset of column Xg inside a row
     uint32_t coff[3];         // chroma columns c0-1, c0, c0+1 (clamp addressing), byte offset inside a chroma row
@@ -241,16 +245,16 @@ __device__ __forceinline__ void load_raw(const FusedArgs &P, gcptr py, const Raw
 {
     const int sy0 = P.rect_t + y0, sy1 = P.rect_t + y1;
     const gcptr ry0 = py + (uint32_t)sy0 * (uint32_t)P.pitch_y, ry1 = py + (uint32_t)sy1 * (uint32_t)P.pitch_y;
-    r.y[0] = (P01X || P.bytes == 2) ? ld_u32(ry0 + ra.yoff) : ld_u16(ry0 + ra.yoff);
-    r.y[1] = (P01X || P.bytes == 2) ? ld_u32(ry1 + ra.yoff) : ld_u16(ry1 + ra.yoff);
+    r.y[0] = (P01X || P.bytes == 2) ? ld_u32(ry0 + opaque(ra.yoff)) : ld_u16(ry0 + opaque(ra.yoff));
+    r.y[1] = (P01X || P.bytes == 2) ? ld_u32(ry1 + opaque(ra.yoff)) : ld_u16(ry1 + opaque(ra.yoff));
     const int n = chroma_v4(P, sy0) >> 2;
     const uint32_t oA = (uint32_t)clampi(n, 0, P.ch - 1) * (uint32_t)P.pitch_c, oB = (uint32_t)clampi(n + 1, 0, P.ch - 1) * (uint32_t)P.pitch_c;
     const gcptr pu = py + P.off_u, pv = (P01X || P.planes == 2) ? pu : py + P.off_v;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         if (i == 0 && !P.center_h) { r.c[0][0] = r.c[1][0] = 0; continue; }
-        r.c[0][i] = ld_uv<P01X>(P, pu + oA, pv + oA, ra.coff[i]);
-        r.c[1][i] = ld_uv<P01X>(P, pu + oB, pv + oB, ra.coff[i]);
+        r.c[0][i] = ld_uv<P01X>(P, pu + oA, pv + oA, opaque(ra.coff[i]));
+        r.c[1][i] = ld_uv<P01X>(P, pu + oB, pv + oB, opaque(ra.coff[i]));
     }
 }
 
@@ -572,7 +576,7 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
                         if (st_aligned) {
                             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                             u32x4 v4 = {pk[0], pk[1], pk[2], pk[3]};
-                            *(__attribute__((address_space(1))) u32x4 *)(rowp + lane_off) = v4;
+                            *(__attribute__((address_space(1))) u32x4 *)(rowp + opaque(lane_off)) = v4;
                         } else {
                             __attribute__((address_space(1))) uint32_t *dst = (__attribute__((address_space(1))) uint32_t *)(rowp + lane_off);
                             dst[0] = pk[0]; dst[1] = pk[1]; dst[2] = pk[2]; dst[3] = pk[3];
