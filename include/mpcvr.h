@@ -195,6 +195,9 @@ int32_t mpcvr_plan_color_matrix(int32_t cformat, int32_t rect_w, int32_t rect_h,
 int32_t mpcvr_plan_gamut_2020_to_709(float out9[9]);
 /* the fused path's tone-map LUT: i/4095 -> Hable(ST2084ToLinear(x, lum_scale)) / hable(4.8) */
 int32_t mpcvr_plan_pq_lut(float lum_scale, float out4096[4096]);
+/* the fused path's integer form of ps_final_pass.hlsl:29: floor(k*quant/maxv + j/1024) == (k*M + (j << 14)) >> 24;
+ * writes M (0 = not representable, the float epilogue is used) */
+int32_t mpcvr_plan_final_pass_multiplier(int32_t quant, int32_t maxv, uint32_t *multiplier);
 /* ps_interpolation_{spline4,lanczos2,lanczos3}.hlsl weights for phase t; returns the tap count (4/6) or 0 */
 int32_t mpcvr_plan_upscale_weights(int32_t iUpscaling, float t, float w6[6]);
 /* tap table of one TextureResizeShader draw (DX11VideoProcessor.cpp:332-377): kind 0 = point sample,

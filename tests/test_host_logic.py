@@ -166,3 +166,30 @@ def test_every_case_has_a_plan(mpcvr):
         kinds.add(api.plan_describe(s, c["cformat"], r[2] - r[0], r[3] - r[1], vr, ww, wh).split(";")[0])
     assert {"fused_up2x", "passes:convert,copy", "passes:convert,final", "passes:convert,resizeX,resizeY+final",
             "passes:convert,resizeX,resizeY"} <= kinds
+
+
+def test_final_pass_integer_form_is_exhaustively_exact(mpcvr):
+    """The fused kernel's final pass, (k*M + (j << 14)) >> 24, against ps_final_pass.hlsl:29 for every (k, j).
+
+    k = UNORM10 code of m_TexsPostScale, j/1024 = dither texel (dither32x32float16.bin holds exactly these values).
+    It must equal the exact rational floor(k*255/1023 + j/1024) everywhere, and the fp32 shader arithmetic
+    floor(fl(fl(k/1023)*255) + j/1024) in all but the handful of pairs where fp32 rounds the sum up onto an integer.
+    """
+    api = mpcvr
+    M = api.plan_final_pass_multiplier(255, 1023)
+    assert M == -(-255 * 2 ** 24 // 1023) == 4182004
+    k = np.arange(1024, dtype=np.uint64)[:, None]
+    j = np.arange(1024, dtype=np.uint64)[None, :]
+    got = (k * np.uint64(M) + (j << np.uint64(14))) >> np.uint64(24)
+    assert int((k * np.uint64(M) + (j << np.uint64(14))).max()) < 2 ** 32
+    exact = (k * np.uint64(255 * 1024) + j * np.uint64(1023)) // np.uint64(1023 * 1024)
+    assert np.array_equal(got, exact)
+    kf = k.astype(np.float32)
+    p = (kf / np.float32(1023)).astype(np.float32)
+    d = (j.astype(np.float32) / np.float32(1024)).astype(np.float32)
+    shader = np.floor(((p * np.float32(255)).astype(np.float32) + d).astype(np.float32))
+    assert int((got.astype(np.float32) != shader).sum()) <= 8
+    assert int(got.max()) == 255 and int(got.min()) == 0
+    # not representable combinations fall back to the float epilogue
+    assert api.plan_final_pass_multiplier(255, 255) == 0
+    assert api.plan_final_pass_multiplier(1023, 1023) == 0

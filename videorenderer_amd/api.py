@@ -87,7 +87,7 @@ EXPORTS = [
     "mpcvr_get_frame_bytes", "mpcvr_get_path_info", "mpcvr_last_error", "mpcvr_version",
     "mpcvr_get_last_process_ms",
     "mpcvr_plan_frame_layout", "mpcvr_plan_color_matrix", "mpcvr_plan_gamut_2020_to_709", "mpcvr_plan_pq_lut",
-    "mpcvr_plan_upscale_weights", "mpcvr_plan_axis_taps", "mpcvr_plan_describe",
+    "mpcvr_plan_upscale_weights", "mpcvr_plan_axis_taps", "mpcvr_plan_describe", "mpcvr_plan_final_pass_multiplier",
 ]
 
 _lib = None
@@ -136,6 +136,7 @@ def load_library():
         "mpcvr_plan_color_matrix": [i32, i32, i32, u32, f, f, f, f, P(f), P(u32)],
         "mpcvr_plan_gamut_2020_to_709": [P(f)],
         "mpcvr_plan_pq_lut": [f, P(f)],
+        "mpcvr_plan_final_pass_multiplier": [i32, i32, P(u32)],
         "mpcvr_plan_upscale_weights": [i32, f, P(f)],
         "mpcvr_plan_axis_taps": [i32, i32, i32, i32, i32, i32, u32, i32, P(i32), P(f), P(f), P(i32), P(i32)],
         "mpcvr_plan_describe": [P(Settings), i32, i32, i32, P(Rect), i32, i32, C.c_char_p, C.c_size_t],
@@ -189,6 +190,13 @@ def plan_pq_lut(lum_scale):
     out = (C.c_float * 4096)()
     load_library().mpcvr_plan_pq_lut(lum_scale, out)
     return list(out)
+
+
+def plan_final_pass_multiplier(quant, maxv):
+    """M of the fused path's integer final pass, (k*M + (j << 14)) >> 24; 0 when not representable."""
+    m = C.c_uint32(0)
+    load_library().mpcvr_plan_final_pass_multiplier(quant, maxv, C.byref(m))
+    return m.value
 
 
 def plan_upscale_weights(method, t):

@@ -193,6 +193,13 @@ int32_t mpcvr_plan_pq_lut(float lum_scale, float out4096[4096])
     return MPCVR_S_OK;
 }
 
+int32_t mpcvr_plan_final_pass_multiplier(int32_t quant, int32_t maxv, uint32_t *multiplier)
+{
+    if (!multiplier) return MPCVR_E_POINTER;
+    *multiplier = mpcvr::FinalPassMultiplier(quant, maxv);
+    return MPCVR_S_OK;
+}
+
 int32_t mpcvr_plan_upscale_weights(int32_t iUpscaling, float t, float w6[6])
 {
     if (!w6) return MPCVR_E_POINTER;

@@ -33,6 +33,7 @@
 
 #include "vp_device.h"
 #include "vp_launch.h"
+#include "vp_plan.h"
 
 namespace mpcvr {
 
@@ -645,8 +646,7 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     a.maxv = c.out_fmt == SF_RGB10A2 ? 1023.0f : 255.0f;
     a.inv_maxv = 1.0f / a.maxv;
     a.q_over_maxv = (float)P.store.quant / a.maxv;
-    const uint64_t epi_mul = (((uint64_t)P.store.quant << 24) + (uint64_t)a.maxv - 1) / (uint64_t)a.maxv;
-    a.epi_mul = (uint32_t)epi_mul;
+    a.epi_mul = FinalPassMultiplier(P.store.quant, (int)a.maxv);
     const int nt = P.wx.ntaps;
     for (int t = 0; t < 6; t++) { a.we[t] = P.wx.w_even[t]; a.wo[t] = P.wx.w_odd[t]; }
     int knt = nt;
@@ -683,7 +683,7 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     const size_t lds = LDS_A + LDS_D + LDS_DB + (tailk == TAILK_PQ_LUT ? LDS_T : 0) + (size_t)lds_pad;
     const bool p01x = c.fmt.planes == 2 && c.fmt.bytes == 2;
     // the integer epilogue needs k*M + (j << 14) < 2^32 and M < 2^24 (true for 10-bit internal -> 8-bit target)
-    const bool fastepi = a.final_pass && !a.out10 && epi_mul < (1u << 24) && (uint64_t)a.maxv * epi_mul + (1023u << 14) < (1ull << 32);
+    const bool fastepi = a.final_pass && !a.out10 && a.epi_mul != 0;
 #define MPCVR_LAUNCH2(NT, TK, PX) do { if (fastepi) hipLaunchKernelGGL((k_fused_up2x<NT, TK, PX, true>), grid, block, lds, s, a, frames_dev, single); \
                                        else hipLaunchKernelGGL((k_fused_up2x<NT, TK, PX, false>), grid, block, lds, s, a, frames_dev, single); } while (0)
 #define MPCVR_LAUNCH(NT, TK) do { if (p01x) MPCVR_LAUNCH2(NT, TK, true); else MPCVR_LAUNCH2(NT, TK, false); } while (0)

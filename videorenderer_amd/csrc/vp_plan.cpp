@@ -247,6 +247,14 @@ void SelectTail(const ExtFmt &ex, bool convert_to_sdr, int *tail, float *gamma)
 // ------------------------------------------------------------------------------------------------
 // PQ -> SDR per-channel table (Shaders/convert/st2084.hlsl:1-16, hdr_tone_mapping.hlsl:1-13)
 // ------------------------------------------------------------------------------------------------
+uint32_t FinalPassMultiplier(int quant, int maxv)
+{
+    if (quant <= 0 || maxv <= 0) return 0;
+    const uint64_t m = (((uint64_t)quant << 24) + (uint64_t)maxv - 1) / (uint64_t)maxv;
+    if (m >= (1u << 24) || (uint64_t)maxv * m + (1023ull << 14) >= (1ull << 32)) return 0;
+    return (uint32_t)m;
+}
+
 void BuildPqSdrLut(float lum_scale, float out[kPqLutSize])
 {
     const float m1 = 2610.0f / (4096.0f * 4.0f), m2 = (2523.0f / 4096.0f) * 128.0f;
