@@ -40,12 +40,17 @@ extern "C" {
 enum mpcvr_cformat {
     MPCVR_CF_NONE = 0,
     MPCVR_CF_NV12 = 1, MPCVR_CF_P010 = 2, MPCVR_CF_P016 = 3,
+    MPCVR_CF_YUY2 = 4, MPCVR_CF_UYVY = 5,
     MPCVR_CF_P210 = 6, MPCVR_CF_P216 = 7,
+    MPCVR_CF_Y210 = 8, MPCVR_CF_Y216 = 9, MPCVR_CF_V210 = 10,
+    MPCVR_CF_AYUV = 11, MPCVR_CF_Y410 = 12, MPCVR_CF_Y416 = 13,
     MPCVR_CF_YV12 = 14, MPCVR_CF_YV16 = 15, MPCVR_CF_YV24 = 16,
     MPCVR_CF_YUV420P8 = 17, MPCVR_CF_YUV422P8 = 18, MPCVR_CF_YUV444P8 = 19,
     MPCVR_CF_YUV420P10 = 20, MPCVR_CF_YUV420P16 = 21,
     MPCVR_CF_YUV422P10 = 22, MPCVR_CF_YUV422P16 = 23,
-    MPCVR_CF_YUV444P10 = 24, MPCVR_CF_YUV444P16 = 25
+    MPCVR_CF_YUV444P10 = 24, MPCVR_CF_YUV444P16 = 25,
+    MPCVR_CF_GBRP8 = 26, MPCVR_CF_GBRP10 = 27, MPCVR_CF_GBRP16 = 28,
+    MPCVR_CF_Y8 = 37, MPCVR_CF_Y10 = 38, MPCVR_CF_Y16 = 39
 };
 
 /* Settings enums — Source/IVideoRenderer.h:25-72 (identical values). */

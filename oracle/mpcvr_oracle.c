@@ -99,7 +99,14 @@ typedef struct {
     int cdepth;        /* CDepth */
     int shift;         /* CopyPlane10to16 (<<6) on upload — Helper.cpp:386-391,789-803 */
     int v_first;       /* YV12/YV16/YV24: second plane is V — Shaders.cpp:159-165 */
+    int layout;        /* LAY_*: how the single texture of a one-plane format is organised */
+    int cstype;        /* CST_*: ColorSystem_t (Helper.h:129-133) */
+    int ci[4];         /* packed 4:2:2: texel components holding Y0,U,Y1,V (Shaders.cpp:195-229);
+                          packed 4:4:4: components holding Y,U,V after the .zyxw/.yxzw swizzle (:186-193) */
+    int bits10;        /* texel is one R10G10B10A2 dword (Y410) */
 } fmt_info;
+enum { LAY_PLANAR = 0, LAY_PACKED422 = 1, LAY_PACKED444 = 2, LAY_GRAY = 3 };
+enum { CST_YUV = 0, CST_RGB = 1, CST_GRAY = 2 };
 
 static const fmt_info s_fmts[] = {
     {ORC_CF_NV12,      2, 1, 2, 2, 1, 3, 420,  8, 0, 0},
@@ -119,6 +126,24 @@ static const fmt_info s_fmts[] = {
     {ORC_CF_YUV422P16, 3, 2, 2, 1, 2, 4, 422, 16, 0, 0},
     {ORC_CF_YUV444P10, 3, 2, 1, 1, 2, 6, 444, 10, 6, 0},
     {ORC_CF_YUV444P16, 3, 2, 1, 1, 2, 6, 444, 16, 0, 0},
+    /* one RGBA8 / RGBA16 texel = two pixels (DX11Plane_RGBA8 / DX11Plane_RGBA16, Helper.cpp:305-307) */
+    {ORC_CF_YUY2,      1, 1, 2, 1, 2, 2, 422,  8, 0, 0, LAY_PACKED422, CST_YUV, {0, 1, 2, 3}},
+    {ORC_CF_UYVY,      1, 1, 2, 1, 2, 2, 422,  8, 0, 0, LAY_PACKED422, CST_YUV, {1, 0, 3, 2}},
+    {ORC_CF_Y210,      1, 2, 2, 1, 4, 2, 422, 10, 0, 0, LAY_PACKED422, CST_YUV, {0, 1, 2, 3}},
+    {ORC_CF_Y216,      1, 2, 2, 1, 4, 2, 422, 16, 0, 0, LAY_PACKED422, CST_YUV, {0, 1, 2, 3}},
+    {ORC_CF_V210,      1, 2, 2, 1, 0, 2, 422, 10, 0, 0, LAY_PACKED422, CST_YUV, {0, 1, 2, 3}},   /* Y210 after CopyFrameV210 */
+    /* one texel = one pixel; memory order AYUV: V,U,Y,A  Y410: U:10,Y:10,V:10,A:2  Y416: U,Y,V,A */
+    {ORC_CF_AYUV,      1, 1, 1, 1, 4, 2, 444,  8, 0, 0, LAY_PACKED444, CST_YUV, {2, 1, 0, 3}},
+    {ORC_CF_Y410,      1, 4, 1, 1, 4, 2, 444, 10, 0, 0, LAY_PACKED444, CST_YUV, {1, 0, 2, 3}, 1},
+    {ORC_CF_Y416,      1, 2, 1, 1, 8, 2, 444, 16, 0, 0, LAY_PACKED444, CST_YUV, {1, 0, 2, 3}},
+    /* planar RGB: planes G,B,R sampled as texY,texU,texV; matrix columns rotated (DX11VideoProcessor.cpp:863-867) */
+    {ORC_CF_GBRP8,     3, 1, 1, 1, 1, 6, 444,  8, 0, 0, LAY_PLANAR, CST_RGB},
+    {ORC_CF_GBRP10,    3, 2, 1, 1, 2, 6, 444, 10, 6, 0, LAY_PLANAR, CST_RGB},
+    {ORC_CF_GBRP16,    3, 2, 1, 1, 2, 6, 444, 16, 0, 0, LAY_PLANAR, CST_RGB},
+    /* gray: R8 / R16 texture, Sample() returns (Y,0,0,1) */
+    {ORC_CF_Y8,        1, 1, 1, 1, 1, 2, 400,  8, 0, 0, LAY_GRAY, CST_GRAY},
+    {ORC_CF_Y10,       1, 2, 1, 1, 2, 2, 400, 10, 6, 0, LAY_GRAY, CST_GRAY},
+    {ORC_CF_Y16,       1, 2, 1, 1, 2, 2, 400, 16, 0, 0, LAY_GRAY, CST_GRAY},
 };
 static const fmt_info *find_fmt(int cf)
 {
@@ -133,7 +158,8 @@ size_t orc_frame_bytes(int cformat, int width, int height, int *pitch_out)
     const fmt_info *f = find_fmt(cformat);
     if (!f) return 0;
     int pitch = width * f->packsize;
-    if (cformat == ORC_CF_NV12) pitch = (pitch + 3) & ~3;          /* ALIGN(m_srcPitch, 4) */
+    if (cformat == ORC_CF_NV12 || cformat == ORC_CF_Y8) pitch = (pitch + 3) & ~3;   /* ALIGN(m_srcPitch, 4) :1792-1796 */
+    if (cformat == ORC_CF_V210) pitch = (((width + 5) / 6 * 16) + 127) & ~127;        /* :1798-1799 */
     if (pitch_out) *pitch_out = pitch;
     return (size_t)pitch * (size_t)(height * f->pitch_coeff / 2);   /* m_srcLines */
 }
@@ -158,11 +184,13 @@ enum { PRIM_709 = 2, PRIM_470M = 3, PRIM_470BG = 4, PRIM_170M = 5, PRIM_240M = 6
 enum { TRC_10 = 1, TRC_18 = 2, TRC_20 = 3, TRC_22 = 4, TRC_709 = 5, TRC_240M = 6, TRC_SRGB = 7, TRC_28 = 8,
        TRC_26 = 14, TRC_2084 = 15, TRC_HLG = 16 };
 
-/* SpecifyExtendedFormat — Helper.cpp:1169-1211 (CS_YUV branch; every format here is YUV) */
+/* SpecifyExtendedFormat — Helper.cpp:1169-1211: CS_RGB -> 0, CS_YUV -> defaults, CS_GRAY untouched */
 uint32_t orc_specify_extfmt(uint32_t v, int cformat, int w, int h)
 {
     const fmt_info *f = find_fmt(cformat);
     if (!f) return v;
+    if (f->cstype == CST_RGB) return 0;
+    if (f->cstype == CST_GRAY) return v;
     if (f->subsampling != 420)            v = exf_set(v, 8, 0xf, 0);
     else if (EXF_CHROMA(v) == 0)          v = exf_set(v, 8, 0xf, CHROMA_MPEG2);
     if (EXF_RANGE(v) == 0)                v = exf_set(v, 12, 0x7, RANGE_16_235);
@@ -190,7 +218,9 @@ void orc_csp_matrix(int space, int levels_in, int bits, float brightness, float 
     float m[3][3];
     if (space <= 0 || space >= 9) space = 1;               /* AUTO -> BT_601 (csputils.cpp:395-396) */
     if (levels_in <= 0 || levels_in >= 3) levels_in = 1;   /* AUTO -> TV */
+    if (space == 6) levels_in = -1;                        /* MP_CSP_RGB: identity, "anyfull" levels (:416-420) */
     switch (space) {
+    case 6: { const float y[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}; memcpy(m, y, sizeof(y)); break; }
     case 1: luma_coeffs(m, 0.299f,  0.587f,  0.114f);  break;
     case 2: luma_coeffs(m, 0.2126f, 0.7152f, 0.0722f); break;
     case 3: luma_coeffs(m, 0.2122f, 0.7013f, 0.0865f); break;
@@ -210,10 +240,12 @@ void orc_csp_matrix(int space, int levels_in, int bits, float brightness, float 
     /* mp_get_csp_mul(colorspace, input_bits, texture_bits) with input_bits == texture_bits == CDepth
        (DX11VideoProcessor.cpp:845): (1<<bits) / ((1<<bits) - 1.) * 255 / 256   — csputils.cpp:357 */
     double mul = (double)(1LL << bits) / ((double)(1LL << bits) - 1.) * 255 / 256;
+    if (space == 6) mul = ((double)(1LL << bits) - 1.) / ((double)(1LL << bits) - 1.);   /* RGB: full range (:351-353) */
     double s = mul / 255;
     double ymin, ymax, cmax, cmid;
-    if (levels_in == 1) { ymin = 16 * s; ymax = 235 * s; cmax = 240 * s; cmid = 128 * s; }
-    else                { ymin = 0 * s;  ymax = 255 * s; cmax = 255 * s; cmid = 128 * s; }
+    if (levels_in == 1)       { ymin = 16 * s; ymax = 235 * s; cmax = 240 * s; cmid = 128 * s; }
+    else if (levels_in == -1) { ymin = 0 * s;  ymax = 255 * s; cmax = 255 * s / 2; cmid = 0; }   /* anyfull (:474) */
+    else                      { ymin = 0 * s;  ymax = 255 * s; cmax = 255 * s; cmid = 128 * s; }
     const double rgbmin = 0, rgbmax = 1;                     /* levels_out = PC */
     double ymul = (rgbmax - rgbmin) / (ymax - ymin);
     double cmul = (rgbmax - rgbmin) / (cmax - cmid) / 2;
@@ -232,6 +264,7 @@ void orc_csp_matrix(int space, int levels_in, int bits, float brightness, float 
 /* set_colorspace — Helper.cpp:949-1004 (only the fields the matrix uses) */
 static void extfmt_to_csp(uint32_t v, int *space, int *levels)
 {
+    if (v == 0) { *space = 6; *levels = 2; return; }      /* MP_CSP_RGB, PC (:953-957) */
     switch (EXF_RANGE(v)) { case RANGE_0_255: *levels = 2; break; case RANGE_16_235: *levels = 1; break; default: *levels = 0; }
     switch (EXF_MATRIX(v)) {
     case MATRIX_709: *space = 2; break;  case MATRIX_601: *space = 1; break;
@@ -258,7 +291,13 @@ int orc_color_matrix(const orc_params *p, float out[12])
     float contrast = p->contrast;                                        /* :840 */
     float hue = (float)(p->hue / 180 * acos(-1));                        /* :841 */
     float m[9], c[3];
-    orc_csp_matrix(space, levels, f->cdepth, brightness, contrast, hue, p->saturation, 0, m, c);
+    orc_csp_matrix(space, levels, f->cdepth, brightness, contrast, hue, p->saturation, f->cstype == CST_GRAY, m, c);
+    if (f->cstype == CST_RGB && f->layout == LAY_PLANAR) {     /* GBRP: (x,y,z) -> (y,z,x) per row, :863-867 */
+        for (int i = 0; i < 3; i++) { float x = m[3 * i], y = m[3 * i + 1], z = m[3 * i + 2]; m[3 * i] = y; m[3 * i + 1] = z; m[3 * i + 2] = x; }
+    } else if (f->cstype == CST_GRAY) {                        /* :868-873 */
+        m[3] = m[4]; m[4] = 0;
+        m[6] = m[8]; m[8] = 0;
+    }
     memcpy(out, m, sizeof(m)); memcpy(out + 9, c, sizeof(c));
     return 0;
 }
@@ -609,6 +648,21 @@ static inline float load_chroma(const src_tex *s, int c, int x, int y)
     return (float)v / 65535.0f;
 }
 
+/* one-plane formats: component k of texel (tx,y) of the RGBA8 / RGBA16 / R10G10B10A2 texture, clamp addressing */
+static inline float load_packed(const src_tex *s, int tx, int y, int k)
+{
+    const int tw = (s->f->layout == LAY_PACKED422) ? s->w / 2 : s->w;
+    tx = clampi(tx, 0, tw - 1); y = clampi(y, 0, s->h - 1);
+    const uint8_t *row = s->plane[0] + (size_t)y * s->pitch[0];
+    if (s->f->bits10) {
+        uint32_t d = ((const uint32_t *)row)[tx];
+        uint32_t v = k == 3 ? (d >> 30) : ((d >> (10 * k)) & 0x3ffu);
+        return k == 3 ? (float)v / 3.0f : (float)v / 1023.0f;
+    }
+    if (s->f->bytes == 1) return (float)row[4 * tx + k] / 255.0f;
+    return (float)((const uint16_t *)row)[4 * tx + k] / 65535.0f;
+}
+
 /* D3D11 linear sample at unnormalised texel coordinate (u,v) = texcoord*size: taps floor(u-.5),+1 with
  * weights frac(u-.5); all positions on this path are multiples of 1/4 so the 8-bit weight precision
  * of the fixed-function filter is exact. */
@@ -692,8 +746,77 @@ static void fetch_chroma(const src_tex *s, int chroma_loc, int chroma_scaling, i
     uv[1] = sample_chroma_linear(s, 1, u, v);
 }
 
+/* (Y,U,V) — or (G,B,R) / (Y,0,0) — of source pixel (sx,sy): ShaderGetPixels, DX11 branch */
+static void fetch_pixel(const src_tex *s, int chroma_loc, int chroma_scaling, int sx, int sy, float yuv[3])
+{
+    const fmt_info *f = s->f;
+    if (f->layout == LAY_PLANAR) {
+        yuv[0] = load_luma(s, sx, sy);                                    /* :231,274 */
+        fetch_chroma(s, chroma_loc, chroma_scaling, sx, sy, yuv + 1);
+        return;
+    }
+    if (f->layout == LAY_GRAY) {           /* float4 color = tex.Sample(samp, Tex) of an R8/R16 texture (:184) */
+        yuv[0] = load_luma(s, sx, sy); yuv[1] = 0; yuv[2] = 0;
+        return;
+    }
+    if (f->layout == LAY_PACKED444) {      /* .zyxw (AYUV) / .yxzw (Y410, Y416) (:186-193) */
+        yuv[0] = load_packed(s, sx, sy, f->ci[0]); yuv[1] = load_packed(s, sx, sy, f->ci[1]); yuv[2] = load_packed(s, sx, sy, f->ci[2]);
+        return;
+    }
+    /* packed 4:2:2 (:195-229): texel tx = two pixels; even pixel takes the texel's own chroma, the odd pixel the
+       mean with the next texel (or CATMULLROM_05 over texels tx-1..tx+2); Nearest is not distinguished */
+    const int tx = sx >> 1;
+    const int cu = f->ci[1], cv = f->ci[3];
+    if ((sx & 1) == 0) {                   /* fmod(Tex.x*w, 2) < 1.0 */
+        yuv[0] = load_packed(s, tx, sy, f->ci[0]); yuv[1] = load_packed(s, tx, sy, cu); yuv[2] = load_packed(s, tx, sy, cv);
+        return;
+    }
+    yuv[0] = load_packed(s, tx, sy, f->ci[2]);
+    for (int c = 0; c < 2; c++) {
+        const int k = c ? cv : cu;
+        if (chroma_scaling == ORC_CHROMA_CATMULLROM) {
+            float c0 = load_packed(s, tx - 1, sy, k), c1 = load_packed(s, tx, sy, k);
+            float c2 = load_packed(s, tx + 1, sy, k), c3 = load_packed(s, tx + 2, sy, k);
+            yuv[1 + c] = (9 * (c1 + c2) - (c0 + c3)) * 0.0625f;          /* CATMULLROM_05 :145 */
+        } else {
+            yuv[1 + c] = (load_packed(s, tx, sy, k) + load_packed(s, tx + 1, sy, k)) * 0.5f;
+        }
+    }
+}
+
+/* CopyFrameV210 — Helper.cpp:709-748: v210 dwords -> Y210 words (10 bits in the MSBs), two dwords at a time */
+void orc_repack_v210(int lines, uint8_t *dst, int dst_pitch, const uint8_t *src, int src_pitch)
+{
+    const int dq = dst_pitch / 12, dr = dst_pitch % 12, sq = src_pitch / 8, sr = src_pitch % 8;
+    int line_blocks, remainder;
+    if (dq <= sq) { line_blocks = dq; remainder = dr != 0; } else { line_blocks = sq; remainder = sr != 0; }
+    for (int y = 0; y < lines; y++) {
+        const uint32_t *src32 = (const uint32_t *)(src + (size_t)y * src_pitch);
+        uint16_t *dst16 = (uint16_t *)(dst + (size_t)y * dst_pitch);
+        for (int i = 0; i < line_blocks; i++) {
+            uint32_t s0 = *src32++, s1 = *src32++;
+            *dst16++ = (uint16_t)((s0 >> 4) & 0xffc0);
+            *dst16++ = (uint16_t)((s0 << 6) & 0xffc0);
+            *dst16++ = (uint16_t)((s1 << 6) & 0xffc0);
+            *dst16++ = (uint16_t)((s0 >> 14) & 0xffc0);
+            *dst16++ = (uint16_t)((s1 >> 14) & 0xffc0);
+            *dst16++ = (uint16_t)((s1 >> 4) & 0xffc0);
+        }
+        if (remainder) {
+            uint32_t v = *src32++;
+            *dst16++ = (uint16_t)((v >> 4) & 0xffc0);
+            *dst16++ = (uint16_t)((v << 6) & 0xffc0);
+        }
+    }
+}
+/* pitch of the Y210 texture the v210 sample is unpacked into.  The reference uses the driver's mapped pitch of a
+   (W/2) x H R16G16B16A16 texture (>= 4W bytes, typically 256-aligned); the stand-in here is 4W rounded up to whole
+   12-byte groups, so every pixel of the row is converted exactly as with any larger driver pitch. */
+int orc_v210_tex_pitch(int width) { return (4 * width + 11) / 12 * 12; }
+
 typedef struct {
     src_tex tex;
+    void *owned;       /* unpacked v210 */
     int rect[4];
     uint32_t exfmt;
     float cm[12];
@@ -710,6 +833,13 @@ static int setup_convert(const orc_params *p, const uint8_t *src, int src_pitch,
     resolve_rect(p, c->rect);
     if (c->rect[0] < 0 || c->rect[1] < 0 || c->rect[2] > p->width || c->rect[3] > p->height ||
         c->rect[2] <= c->rect[0] || c->rect[3] <= c->rect[1]) return -3;
+    if (p->cformat == ORC_CF_V210) {                       /* GetCopyPlaneFunction -> CopyFrameV210 (Helper.cpp:379-380) */
+        const int tp = orc_v210_tex_pitch(p->width);
+        uint8_t *t = (uint8_t *)calloc((size_t)tp * p->height + 16, 1);
+        if (!t) return -4;
+        orc_repack_v210(p->height, t, tp, src, src_pitch);
+        c->owned = t; src = t; src_pitch = tp;
+    }
     c->tex.f = f; c->tex.w = p->width; c->tex.h = p->height;
     c->tex.cw = p->width / f->div_w; c->tex.ch = p->height / f->div_h;
     /* MemCopyToTexSrcVideo plane walk — DX11VideoProcessor.cpp:1213-1252 */
@@ -718,7 +848,7 @@ static int setup_convert(const orc_params *p, const uint8_t *src, int src_pitch,
     c->tex.plane[1] = src + (size_t)src_pitch * p->height; c->tex.pitch[1] = cpitch;
     c->tex.plane[2] = c->tex.plane[1] + (size_t)cpitch * c->tex.ch; c->tex.pitch[2] = cpitch;
     c->exfmt = orc_specify_extfmt(p->exfmt, p->cformat, c->rect[2] - c->rect[0], c->rect[3] - c->rect[1]);
-    if (orc_color_matrix(p, c->cm)) return -1;
+    if (orc_color_matrix(p, c->cm)) { free(c->owned); c->owned = NULL; return -1; }
     c->lum_scale = orc_luminance_scale(p->iSDRDisplayNits);
     c->internal_fmt = internal_format(p->iTexFormat, f->cdepth);
     return 0;
@@ -733,9 +863,9 @@ static void convert_pass(const orc_params *p, const convert_ctx *c, img_t *out)
     for (int j = 0; j < rh; j++) {
         for (int i = 0; i < rw; i++) {
             int sx = c->rect[0] + i, sy = c->rect[1] + j;
-            float y = load_luma(&c->tex, sx, sy);                                  /* :231,274 */
-            float uv[2];
-            fetch_chroma(&c->tex, cloc, p->iChromaScaling, sx, sy, uv);
+            float yuv[3];
+            fetch_pixel(&c->tex, cloc, p->iChromaScaling, sx, sy, yuv);
+            const float y = yuv[0], *uv = yuv + 1;
             /* color.rgb = float3(mul(cm_r,color), mul(cm_g,color), mul(cm_b,color)) + cm_c  (:820) */
             float rgb[3];
             rgb[0] = (cm[0] * y + cm[1] * uv[0] + cm[2] * uv[1]) + cm[9];
@@ -755,6 +885,7 @@ int orc_convert_only(const orc_params *p, const uint8_t *src, int src_pitch, flo
     if (rc) return rc;
     img_t out = {c.rect[2] - c.rect[0], c.rect[3] - c.rect[1], rgba_out};
     convert_pass(p, &c, &out);
+    free(c.owned);
     return c.internal_fmt;
 }
 
@@ -911,7 +1042,7 @@ int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
     const int w1 = c.rect[2] - c.rect[0], h1 = c.rect[3] - c.rect[1];
     const int dl = p->video_rect[0], dt = p->video_rect[1];
     const int w2 = p->video_rect[2] - dl, h2 = p->video_rect[3] - dt;
-    if (w2 <= 0 || h2 <= 0 || p->window_w <= 0 || p->window_h <= 0) return -4;
+    if (w2 <= 0 || h2 <= 0 || p->window_w <= 0 || p->window_h <= 0) { free(c.owned); return -4; }
 
     /* UpdatePostScaleTexures :2894-2912 */
     const int swap_fmt = (p->output_format == ORC_OUT_RGB10A2) ? FMT_RGB10A2 : FMT_BGRA8;
@@ -922,12 +1053,12 @@ int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
 
     /* ConvertColorPass -> m_TexConvertOutput (w1 x h1, internal format); rSrc = whole texture :3316-3319 */
     img_t conv = {0}, mid = {0}, post = {0};
-    if (img_alloc(&conv, w1, h1)) return -5;
+    if (img_alloc(&conv, w1, h1)) { free(c.owned); return -5; }
     convert_pass(p, &c, &conv);
 
     /* ResizeShaderPass :3103-3187 — pick per-axis shader */
     const int k = p->bInterpolateAt50pct ? 2 : 1;
-    if (p->iUpscaling == ORC_UP_JINC2) { img_free(&conv); return -6; }
+    if (p->iUpscaling == ORC_UP_JINC2) { img_free(&conv); free(c.owned); return -6; }
     resizer_t up = {p->iUpscaling == ORC_UP_NEAREST ? RS_NONE : RS_UP, p->iUpscaling};
     resizer_t down = {RS_DOWN, p->iDownscaling};
     resizer_t none = {RS_NONE, 0};
@@ -985,5 +1116,6 @@ int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
     rc = 0;
 done:
     img_free(&conv); img_free(&mid); img_free(&post);
+    free(c.owned);
     return rc;
 }

@@ -28,12 +28,16 @@ extern "C" {
 /* ColorFormat_t numeric values — Source/Helper.h:86-127 (enum order is the table index). */
 enum {
     ORC_CF_NV12 = 1, ORC_CF_P010 = 2, ORC_CF_P016 = 3,
+    ORC_CF_YUY2 = 4, ORC_CF_UYVY = 5,
     ORC_CF_P210 = 6, ORC_CF_P216 = 7,
+    ORC_CF_Y210 = 8, ORC_CF_Y216 = 9, ORC_CF_V210 = 10, ORC_CF_AYUV = 11, ORC_CF_Y410 = 12, ORC_CF_Y416 = 13,
     ORC_CF_YV12 = 14, ORC_CF_YV16 = 15, ORC_CF_YV24 = 16,
     ORC_CF_YUV420P8 = 17, ORC_CF_YUV422P8 = 18, ORC_CF_YUV444P8 = 19,
     ORC_CF_YUV420P10 = 20, ORC_CF_YUV420P16 = 21,
     ORC_CF_YUV422P10 = 22, ORC_CF_YUV422P16 = 23,
-    ORC_CF_YUV444P10 = 24, ORC_CF_YUV444P16 = 25
+    ORC_CF_YUV444P10 = 24, ORC_CF_YUV444P16 = 25,
+    ORC_CF_GBRP8 = 26, ORC_CF_GBRP10 = 27, ORC_CF_GBRP16 = 28,
+    ORC_CF_Y8 = 37, ORC_CF_Y10 = 38, ORC_CF_Y16 = 39
 };
 
 /* Settings enums — Source/IVideoRenderer.h:25-72 (identical numeric values). */
@@ -109,6 +113,9 @@ float orc_half_bits_to_float(uint16_t h);
 /* ---- the path ---- */
 /* Bytes of one input frame in the reference's sample layout (DX11VideoProcessor.cpp:1789-1803). */
 size_t orc_frame_bytes(int cformat, int width, int height, int *pitch_out);
+/* CopyFrameV210 (Helper.cpp:709-748) and the pitch of the Y210 texture it fills */
+void orc_repack_v210(int lines, uint8_t *dst, int dst_pitch, const uint8_t *src, int src_pitch);
+int orc_v210_tex_pitch(int width);
 
 /* Whole Process() on the shader path — DX11VideoProcessor.cpp:3285-3424.
  * src: the media-sample bytes (planes back to back, MemCopyToTexSrcVideo layout :1213-1252), src_pitch >0.

@@ -13,7 +13,7 @@ extern "C" {
 void ref_csp_matrix(int space, int levels, int bits, float brightness, float contrast,
                     float hue, float saturation, int gray, float m[9], float c[3])
 {
-    mp_csp_params p;
+    mp_csp_params p = {};          // levels_out = AUTO -> PC, is_float = false, as SetShaderConvertColorParams leaves them
     p.color = {};
     p.color.space = (mp_csp)space;
     p.color.levels = (mp_csp_levels)levels;

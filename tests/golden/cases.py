@@ -70,6 +70,23 @@ GOLDEN_CASES = {
     "nv12_chroma_nearest": dict(cformat=1, w=64, h=32, kind="noise", seed=37, dst=(128, 64), iChromaScaling=0, iUpscaling=2),
     "p010_chroma_catmull": dict(cformat=2, w=64, h=32, kind="noise", seed=38, dst=(128, 64), iChromaScaling=2, iUpscaling=4),
     "yuv420p10_chroma_catmull_cosited": dict(cformat=20, w=64, h=32, kind="noise", seed=39, dst=(64, 32), iChromaScaling=2, exfmt=ext(COSITED, TV, M709)),
+    # ---- one-plane formats, planar RGB, gray ----
+    "yuy2_bilinear_2x": dict(cformat=4, w=64, h=32, kind="structure", seed=60, dst=(128, 64), iUpscaling=2),
+    "yuy2_noise_same_size": dict(cformat=4, w=62, h=20, kind="noise", seed=61, dst=(62, 20)),
+    "uyvy_catmull_chroma": dict(cformat=5, w=64, h=32, kind="noise", seed=62, dst=(96, 48), iChromaScaling=2, iUpscaling=1),
+    "y210_lanczos3_2x": dict(cformat=8, w=64, h=32, kind="noise", seed=63, dst=(128, 64), iUpscaling=4),
+    "y216_catmull_chroma_down": dict(cformat=9, w=96, h=48, kind="structure", seed=64, dst=(40, 20), iChromaScaling=2),
+    "v210_2x": dict(cformat=10, w=66, h=24, kind="noise", seed=65, dst=(132, 48), iUpscaling=2),
+    "v210_ragged_width": dict(cformat=10, w=50, h=16, kind="structure", seed=66, dst=(50, 16)),
+    "ayuv_same_size": dict(cformat=11, w=48, h=32, kind="noise", seed=67, dst=(48, 32)),
+    "y410_pq_2x": dict(cformat=12, w=64, h=32, kind="hdr", seed=68, dst=(128, 64), exfmt=ext(0, TV, M2020, P2020, TPQ), iUpscaling=4),
+    "y416_fullrange": dict(cformat=13, w=48, h=32, kind="noise", seed=69, dst=(72, 48), exfmt=ext(0, FULL, M709), iUpscaling=2, full_range=True),
+    "gbrp8_2x": dict(cformat=26, w=48, h=32, kind="noise", seed=70, dst=(96, 64), iUpscaling=2),
+    "gbrp10_procamp": dict(cformat=27, w=48, h=32, kind="structure", seed=71, dst=(48, 32), procamp=(8.0, 1.1, 0.0, 1.0)),
+    "gbrp16_down": dict(cformat=28, w=96, h=64, kind="noise", seed=72, dst=(40, 24)),
+    "y8_gray_2x": dict(cformat=37, w=62, h=32, kind="structure", seed=73, dst=(124, 64), iUpscaling=4),
+    "y10_gray_tv_matrix": dict(cformat=38, w=48, h=32, kind="noise", seed=74, dst=(48, 32), exfmt=ext(0, TV, M709)),
+    "y16_gray_crop": dict(cformat=39, w=64, h=48, kind="structure", seed=75, src_rect=(8, 4, 56, 44), dst=(96, 80), iUpscaling=1),
     # ---- colour / settings ----
     "bt2020_sdr_gamma_gamut": dict(cformat=2, w=64, h=32, kind="structure", seed=40, dst=(128, 64), exfmt=ext(MPEG2, TV, M2020, P2020, T709), iUpscaling=2),
     "bt2020_gamma26": dict(cformat=2, w=64, h=32, kind="noise", seed=41, dst=(64, 32), exfmt=ext(MPEG2, TV, M2020, P2020, T26)),

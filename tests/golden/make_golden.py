@@ -35,10 +35,13 @@ def main():
                 for (b, c, h, s) in procamps:
                     m = (C.c_float * 9)()
                     cc = (C.c_float * 3)()
-                    R.ref_csp_matrix(space, levels, nbits, b, c, h, s, 0, m, cc)
-                    cases.append(dict(space=space, levels=levels, bits=nbits,
-                                      brightness=bits(b), contrast=bits(c), hue=bits(h), saturation=bits(s),
-                                      m=[bits(v) for v in m], c=[bits(v) for v in cc]))
+                    for gray in (0, 1):      # csp_params.gray: CS_GRAY sources (DX11VideoProcessor.cpp:843)
+                        if gray and (b, c, h, s) not in procamps[:2]:
+                            continue
+                        R.ref_csp_matrix(space, levels, nbits, b, c, h, s, gray, m, cc)
+                        cases.append(dict(space=space, levels=levels, bits=nbits, gray=gray,
+                                          brightness=bits(b), contrast=bits(c), hue=bits(h), saturation=bits(s),
+                                          m=[bits(v) for v in m], c=[bits(v) for v in cc]))
     g = (C.c_float * 9)()
     R.ref_gamut_matrix(4, 3, g)          # MP_CSP_PRIM_BT_2020 -> MP_CSP_PRIM_BT_709
     out = dict(source="/root/reference/Source/csputils.cpp via oracle/_ref (real reference code)",

@@ -21,8 +21,8 @@ def bits(v):
 def test_color_matrix_matches_oracle_bit_exact(mpcvr, oracle):
     rng = np.random.default_rng(11)
     from videorenderer_amd import api
-    for cf in (1, 2, 3, 6, 14, 16, 17, 19, 20, 21, 22, 24, 25):
-        for _ in range(24):
+    for cf in (1, 2, 3, 6, 14, 16, 17, 19, 20, 21, 22, 24, 25, 4, 5, 8, 9, 10, 11, 12, 13, 26, 27, 28, 37, 38, 39):
+        for it in range(24):
             ex = oracle.make_extfmt(chroma=int(rng.choice([0, 1, 5, 7])), nominal_range=int(rng.choice([0, 1, 2])),
                                     matrix=int(rng.choice([0, 1, 2, 3, 4, 7])), primaries=int(rng.choice([0, 2, 9])),
                                     transfer=int(rng.choice([0, 4, 5, 15, 16])))
@@ -30,6 +30,8 @@ def test_color_matrix_matches_oracle_bit_exact(mpcvr, oracle):
             b, ct, hu, s = rng.uniform(-100, 100), rng.uniform(0, 2), rng.uniform(-180, 180), rng.uniform(0, 2)
             if rng.random() < 0.3:
                 b, ct, hu, s = 0.0, 1.0, 0.0, 1.0
+            if cf >= 37 and it % 2:
+                ex = 0               # gray sources usually arrive without an extended format => MP_CSP_RGB path
             got, ex_out = api.plan_color_matrix(cf, w, h, ex, b, ct, hu, s)
             p = oracle.default_params(cformat=cf, width=w, height=h, exfmt=ex, brightness=b, contrast=ct, hue=hu, saturation=s)
             want = oracle.color_matrix(p)
@@ -50,14 +52,23 @@ def test_color_matrix_matches_reference_fixtures(mpcvr):
     for case in g["csp_matrix"]:
         if case["space"] not in space_to_matrix or case["levels"] == 0:
             continue
+        gray = case.get("gray", 0)
         # only the default ProcAmp can be expressed exactly in DXVA2 units (brightness*255 etc. round-trips differ)
         if (f32(case["brightness"]), f32(case["contrast"]), f32(case["hue"]), f32(case["saturation"])) != (0.0, 1.0, 0.0, 1.0):
             continue
         ex = api.make_extfmt(nominal_range=2 if case["levels"] == 1 else 1, matrix=space_to_matrix[case["space"]])
-        got, _ = api.plan_color_matrix(fmt_for_bits[case["bits"]], 1920, 1080, ex)
-        assert [bits(v) for v in got[:9]] == case["m"] and [bits(v) for v in got[9:]] == case["c"], case
+        if gray:
+            # CS_GRAY: csp_params.gray, then cm_g.x <- cm_g.y, cm_b.x <- cm_b.z (DX11VideoProcessor.cpp:868-873)
+            got, _ = api.plan_color_matrix({8: 37, 10: 38, 16: 39}[case["bits"]], 1920, 1080, ex)
+            want = list(case["m"])
+            want[3], want[4] = want[4], bits(0.0)
+            want[6], want[8] = want[8], bits(0.0)
+            assert [bits(v) for v in got[:9]] == want and [bits(v) for v in got[9:]] == case["c"], case
+        else:
+            got, _ = api.plan_color_matrix(fmt_for_bits[case["bits"]], 1920, 1080, ex)
+            assert [bits(v) for v in got[:9]] == case["m"] and [bits(v) for v in got[9:]] == case["c"], case
         checked += 1
-    assert checked >= 25
+    assert checked >= 40
     assert [bits(v) for v in api.plan_gamut_2020_to_709()] == g["gamut_2020_to_709"]
 
 
@@ -100,12 +111,19 @@ def test_frame_layout(mpcvr, oracle):
         for (w, h) in ((1920, 1080), (62, 32), (3840, 2160)):
             if cf in (1, 2, 3, 14, 17, 20, 21) and (w % 2 or h % 2):
                 continue
+            if cf == 10 and w == 62:
+                continue
             assert api.plan_frame_layout(cf, w, h) == oracle.frame_bytes(cf, w, h)
     assert api.plan_frame_layout(1, 1920, 1080) == (3110400, 1920)
     assert api.plan_frame_layout(2, 3840, 2160) == (24883200, 7680)
     assert api.plan_frame_layout(20, 1920, 1080) == (6220800, 3840)
+    assert api.plan_frame_layout(4, 1920, 1080) == (1920 * 2 * 1080, 3840)       # YUY2
+    assert api.plan_frame_layout(10, 1920, 1080) == (5120 * 1080, 5120)          # v210: ALIGN((W+5)/6*16, 128)
+    assert api.plan_frame_layout(10, 1280, 720) == (3456 * 720, 3456)
+    assert api.plan_frame_layout(37, 62, 32) == (64 * 32, 64)                    # Y8: ALIGN(W, 4)
+    assert api.plan_frame_layout(26, 64, 32) == (64 * 32 * 3, 64)                # GBRP8: three full planes
     with pytest.raises(api.MpcvrError):
-        api.plan_frame_layout(4, 64, 64)          # YUY2: not in this build
+        api.plan_frame_layout(29, 64, 64)         # RGB24: not in this build
 
 
 def test_pq_lut(mpcvr, oracle):

@@ -38,7 +38,7 @@ def test_csp_matrix_matches_reference_fixtures(oracle):
     assert len(g["csp_matrix"]) >= 200
     for case in g["csp_matrix"]:
         m, c = csp(oracle.lib(), "orc_csp_matrix", case["space"], case["levels"], case["bits"],
-                   f32(case["brightness"]), f32(case["contrast"]), f32(case["hue"]), f32(case["saturation"]), 0)
+                   f32(case["brightness"]), f32(case["contrast"]), f32(case["hue"]), f32(case["saturation"]), case.get("gray", 0))
         assert [int(v) for v in m.view(np.uint32)] == case["m"], case
         assert [int(v) for v in c.view(np.uint32)] == case["c"], case
     gm = (C.c_float * 9)()
@@ -57,9 +57,10 @@ def test_csp_matrix_matches_live_reference(oracle):
                 for _ in range(8):
                     b, ct = rng.uniform(-100, 100) / 255, rng.uniform(0, 2)
                     h, s = rng.uniform(-np.pi, np.pi), rng.uniform(0, 2)
-                    a = csp(oracle.lib(), "orc_csp_matrix", space, levels, bits, b, ct, h, s, 0)
-                    r = csp(R, "ref_csp_matrix", space, levels, bits, b, ct, h, s, 0)
-                    assert np.array_equal(a[0], r[0]) and np.array_equal(a[1], r[1])
+                    for gray in (0, 1):
+                        a = csp(oracle.lib(), "orc_csp_matrix", space, levels, bits, b, ct, h, s, gray)
+                        r = csp(R, "ref_csp_matrix", space, levels, bits, b, ct, h, s, gray)
+                        assert np.array_equal(a[0], r[0]) and np.array_equal(a[1], r[1])
 
 
 def test_known_answer_matrices(oracle):

@@ -140,7 +140,7 @@ def test_fused_variants_agree(mpcvr, oracle, torch_cuda, name):
 
 # ------------------------------------------------------------------------------------------------
 def test_host_upload_equals_zero_copy(mpcvr, torch_cuda):
-    for name in ("c3hdr_p010_pq_lanczos3_2x", "c2_yuv420p10_catmull_2x", "down_hamming_3x"):
+    for name in ("c3hdr_p010_pq_lanczos3_2x", "c2_yuv420p10_catmull_2x", "down_hamming_3x", "v210_2x", "yuy2_bilinear_2x", "gbrp10_procamp"):
         a, _ = run_product(mpcvr, torch_cuda, GOLDEN_CASES[name], host_upload=True)
         b, _ = run_product(mpcvr, torch_cuda, GOLDEN_CASES[name], host_upload=False)
         assert np.array_equal(a, b), name
@@ -249,7 +249,9 @@ def test_error_behaviour(mpcvr, torch_cuda):
         return e.value.hr
 
     assert hr_of(lambda: vp.Process(dst, 64)) == api.E_NOT_VALID_STATE                  # no media type yet
-    assert hr_of(lambda: vp.InitMediaType(4, 64, 64)) == api.E_NOTIMPL                  # YUY2 not in this build
+    assert hr_of(lambda: vp.InitMediaType(29, 64, 64)) == api.E_NOTIMPL                 # RGB24 not in this build
+    assert hr_of(lambda: vp.InitMediaType(4, 63, 64)) == api.E_INVALIDARG               # odd width, packed 4:2:2
+    assert hr_of(lambda: vp.InitMediaType(10, 60, 64, pitch=96)) == api.E_INVALIDARG    # v210 row needs 10 groups of 16 bytes
     assert hr_of(lambda: vp.InitMediaType(1, 63, 64)) == api.E_INVALIDARG               # odd width, 4:2:0
     assert hr_of(lambda: vp.InitMediaType(1, 64, 64, src_rect=(0, 0, 65, 64))) == api.E_INVALIDARG
     vp.InitMediaType(1, 64, 64)

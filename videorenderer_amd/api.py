@@ -23,7 +23,11 @@ E_NOT_VALID_STATE = -2147019873  # 0x8007139F
 
 # ColorFormat_t (Source/Helper.h:86-127)
 CF_NV12, CF_P010, CF_P016 = 1, 2, 3
+CF_YUY2, CF_UYVY = 4, 5
 CF_P210, CF_P216 = 6, 7
+CF_Y210, CF_Y216, CF_V210, CF_AYUV, CF_Y410, CF_Y416 = 8, 9, 10, 11, 12, 13
+CF_GBRP8, CF_GBRP10, CF_GBRP16 = 26, 27, 28
+CF_Y8, CF_Y10, CF_Y16 = 37, 38, 39
 CF_YV12, CF_YV16, CF_YV24 = 14, 15, 16
 CF_YUV420P8, CF_YUV422P8, CF_YUV444P8 = 17, 18, 19
 CF_YUV420P10, CF_YUV420P16, CF_YUV422P10, CF_YUV422P16, CF_YUV444P10, CF_YUV444P16 = 20, 21, 22, 23, 24, 25

@@ -52,7 +52,7 @@ CHipVideoProcessor::~CHipVideoProcessor()
     if (!m_bInit) return;
     (void)hipSetDevice(m_device);
     if (m_stream) (void)hipStreamSynchronize(m_stream);
-    for (DevBuffer *b : {&m_TexSrcVideo, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
+    for (DevBuffer *b : {&m_TexSrcVideo, &m_TexRaw, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
                          &m_pqLut, &m_tapsXi, &m_tapsXw, &m_tapsXs, &m_tapsYi, &m_tapsYw, &m_tapsYs, &m_otherX, &m_otherY})
         b->Release();
     if (m_pinned) (void)hipHostFree(m_pinned);
@@ -154,7 +154,10 @@ HRESULT CHipVideoProcessor::InitMediaType(int cformat, int width, int height, in
     const int defPitch = DefaultPitch(*f, width);
     if (pitch == 0) pitch = defPitch;
     if (pitch < width * f->Packsize) return Fail(MPCVR_E_INVALIDARG, "pitch smaller than a row");
+    if (f->cformat == MPCVR_CF_V210 && (pitch < (width + 5) / 6 * 16 || (pitch & 3)))
+        return Fail(MPCVR_E_INVALIDARG, "v210 pitch smaller than a row of 16-byte groups");
     if (f->bytes == 2 && (pitch & 1)) return Fail(MPCVR_E_INVALIDARG, "16-bit formats need an even pitch");
+    if (f->bytes == 4 && (pitch & 3)) return Fail(MPCVR_E_INVALIDARG, "32-bit texels need a pitch that is a multiple of 4");
     CRect r = srcRect ? *srcRect : CRect();
     if (r.IsRectNull()) r = CRect(0, 0, width, height);                        // :1821-1823
     if (r.left < 0 || r.top < 0 || r.right > width || r.bottom > height || r.Width() <= 0 || r.Height() <= 0)
@@ -363,23 +366,44 @@ HRESULT CHipVideoProcessor::UpdatePlan()
     return MPCVR_S_OK;
 }
 
+int CHipVideoProcessor::TexPitch() const
+{
+    return (m_srcParams && m_srcParams->cformat == MPCVR_CF_V210) ? V210TexPitch(m_srcWidth) : m_srcPitch;
+}
+
+// GetCopyPlaneFunction (Helper.cpp:377-412): every format handled here is copied as is (the <<6 of CopyPlane10to16 is
+// applied when a texel is loaded) except v210, which CopyFrameV210 unpacks into a Y210 texture.
+HRESULT CHipVideoProcessor::PrepareSample(const uint8_t *dev_sample, const uint8_t **tex)
+{
+    if (m_srcParams->cformat != MPCVR_CF_V210) { *tex = dev_sample; return MPCVR_S_OK; }
+    const int tp = TexPitch();
+    HRESULT hr;
+    if ((hr = CheckHip(m_TexSrcVideo.CheckCreate((size_t)tp * m_srcHeight), "m_TexSrcVideo"))) return hr;
+    if ((hr = CheckHip(LaunchRepackV210(dev_sample, m_srcPitch, (uint8_t *)m_TexSrcVideo.ptr, tp, m_srcHeight, m_stream), "k_repack_v210"))) return hr;
+    *tex = (const uint8_t *)m_TexSrcVideo.ptr;
+    return MPCVR_S_OK;
+}
+
 void CHipVideoProcessor::FillConvertParams(const uint8_t *sample, ConvertParams *P) const
 {
     const FmtConvParams &f = *m_srcParams;
     std::memset(P, 0, sizeof(*P));
     // plane walk of MemCopyToTexSrcVideo — DX11VideoProcessor.cpp:1213-1252
+    const int pitch0 = TexPitch();
     const int cromaH = m_srcHeight / f.div_h;
-    const int cromaPitch = (f.planes == 3) ? m_srcPitch / f.div_w : m_srcPitch;
+    const int cromaPitch = (f.planes == 3) ? pitch0 / f.div_w : pitch0;
     P->plane[0] = sample;
-    P->plane[1] = sample ? sample + (size_t)m_srcPitch * m_srcHeight : nullptr;
-    P->plane[2] = sample ? P->plane[1] + (size_t)cromaPitch * cromaH : nullptr;
-    P->pitch[0] = m_srcPitch; P->pitch[1] = cromaPitch; P->pitch[2] = cromaPitch;
+    P->plane[1] = (sample && f.planes > 1) ? sample + (size_t)pitch0 * m_srcHeight : nullptr;
+    P->plane[2] = (sample && f.planes > 2) ? P->plane[1] + (size_t)cromaPitch * cromaH : nullptr;
+    P->pitch[0] = pitch0; P->pitch[1] = cromaPitch; P->pitch[2] = cromaPitch;
     P->tex_w = m_srcWidth; P->tex_h = m_srcHeight;
     P->cw = m_srcWidth / f.div_w; P->ch = cromaH;
     P->rect_l = m_srcRect.left; P->rect_t = m_srcRect.top;
     P->out_w = m_srcRectWidth; P->out_h = m_srcRectHeight;
     P->fmt.planes = f.planes; P->fmt.bytes = f.bytes; P->fmt.div_w = f.div_w; P->fmt.div_h = f.div_h;
     P->fmt.shift = f.shift; P->fmt.v_first = f.v_first; P->fmt.subsampling = f.Subsampling; P->fmt.cdepth = f.CDepth;
+    P->fmt.layout = f.layout; P->fmt.bits10 = f.bits10;
+    for (int k = 0; k < 4; k++) P->fmt.ci[k] = f.ci[k];
     P->chroma_scaling = m_cfg.iChromaScaling;
     switch (m_srcExFmt.VideoChromaSubsampling()) {          // Shaders.cpp:121-137
     case 7: P->chroma_loc = CLOC_COSITED; break;
@@ -435,13 +459,14 @@ HRESULT CHipVideoProcessor::CopySample(const void *data, int pitch, int memKind)
     if (pitch != m_srcPitch) return Fail(MPCVR_E_UNEXPECTED, "sample pitch differs from the media type");   // :2545
     (void)hipSetDevice(m_device);
     const size_t bytes = (size_t)m_srcPitch * m_srcLines;
+    HRESULT hr;
     if (memKind == MPCVR_MEM_DEVICE) {               // zero-copy, cf. the IMediaSampleD3D11 branch :2528-2569
-        m_curSample = (const uint8_t *)data;
-        return MPCVR_S_OK;
+        return PrepareSample((const uint8_t *)data, &m_curSample);
     }
     if (memKind != MPCVR_MEM_HOST) return Fail(MPCVR_E_INVALIDARG, "mem_kind");
-    HRESULT hr;
-    if ((hr = CheckHip(m_TexSrcVideo.CheckCreate(bytes), "m_TexSrcVideo"))) return hr;
+    const bool v210 = m_srcParams->cformat == MPCVR_CF_V210;
+    DevBuffer &upload = v210 ? m_TexRaw : m_TexSrcVideo;
+    if ((hr = CheckHip(upload.CheckCreate(bytes), "upload buffer"))) return hr;
     if (m_pinnedSize < bytes) {
         if (m_pinned) (void)hipHostFree(m_pinned);
         m_pinned = nullptr; m_pinnedSize = 0;
@@ -451,9 +476,8 @@ HRESULT CHipVideoProcessor::CopySample(const void *data, int pitch, int memKind)
     // the staging buffer may still feed the previous upload
     if ((hr = CheckHip(hipStreamSynchronize(m_stream), "sync before staging"))) return hr;
     std::memcpy(m_pinned, data, bytes);              // CopyPlaneAsIs (Helper.cpp:414-428); the <<6 of CopyPlane10to16 happens at load
-    if ((hr = CheckHip(hipMemcpyAsync(m_TexSrcVideo.ptr, m_pinned, bytes, hipMemcpyHostToDevice, m_stream), "upload"))) return hr;
-    m_curSample = (const uint8_t *)m_TexSrcVideo.ptr;
-    return MPCVR_S_OK;
+    if ((hr = CheckHip(hipMemcpyAsync(upload.ptr, m_pinned, bytes, hipMemcpyHostToDevice, m_stream), "upload"))) return hr;
+    return PrepareSample((const uint8_t *)upload.ptr, &m_curSample);
 }
 
 HRESULT CHipVideoProcessor::ConvertColorPass(const uint8_t *sample)
@@ -532,8 +556,11 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
         if (!srcs[i] || !dsts[i]) return Fail(MPCVR_E_POINTER, "null frame in batch");
     if (!m_plan.fused_up2x) {
         (void)hipEventRecord(m_evStart, m_stream);
-        for (int i = 0; i < n; i++)
-            if ((hr = ProcessOne((const uint8_t *)srcs[i], dsts[i], rtPitch))) return hr;
+        for (int i = 0; i < n; i++) {
+            const uint8_t *tex;
+            if ((hr = PrepareSample((const uint8_t *)srcs[i], &tex))) return hr;
+            if ((hr = ProcessOne(tex, dsts[i], rtPitch))) return hr;
+        }
         (void)hipEventRecord(m_evStop, m_stream);
         m_timed = true;
         return MPCVR_S_OK;

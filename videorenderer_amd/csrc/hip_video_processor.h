@@ -85,6 +85,8 @@ private:
     HRESULT ProcessOne(const uint8_t *sample, void *rt, int rtPitch);
     HRESULT UploadTaps(const HostAxisTaps &h, DevBuffer &bi, DevBuffer &bw, DevBuffer &bs, AxisTaps *out);
     HRESULT UploadIndex(const std::vector<int32_t> &v, DevBuffer &b);
+    int TexPitch() const;                              // row pitch of the source texture (differs from the sample's for v210)
+    HRESULT PrepareSample(const uint8_t *dev_sample, const uint8_t **tex);   // device sample -> source texture
     void FillConvertParams(const uint8_t *sample, ConvertParams *P) const;
     StoreParams MakeStore(void *dst, int pitch, int dstFmt, bool rt) const;
     void FillFusedParams(const uint8_t *sample, void *rt, int rtPitch, FusedParams *fp) const;
@@ -125,7 +127,8 @@ private:
     Up2xWeights m_upX{}, m_upY{};
 
     // device resources
-    DevBuffer m_TexSrcVideo;       // uploaded sample
+    DevBuffer m_TexSrcVideo;       // uploaded sample (for v210: the Y210 texture CopyFrameV210 fills)
+    DevBuffer m_TexRaw;            // v210 only: the raw sample before the unpack
     void *m_pinned = nullptr;      // pinned staging for uploads
     size_t m_pinnedSize = 0;
     const uint8_t *m_curSample = nullptr;   // device pointer of the current sample (own buffer or zero-copy)

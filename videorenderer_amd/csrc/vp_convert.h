@@ -82,13 +82,49 @@ __device__ __forceinline__ void fetch_chroma(const ConvertParams &P, int sx, int
     uv[1] = sample_chroma_linear(P, 1, u, v);
 }
 
+// (Y,U,V) — or (G,B,R) / (Y,0,0) — of source pixel (sx,sy): ShaderGetPixels' switch on the plane count / format
+__device__ __forceinline__ void fetch_pixel(const ConvertParams &P, int sx, int sy, float &y, float uv[2])
+{
+    if (P.fmt.layout == LAY_PLANAR) {
+        y = load_luma(P, sx, sy);                                         // :231,274
+        fetch_chroma(P, sx, sy, uv);
+        return;
+    }
+    if (P.fmt.layout == LAY_GRAY) {        // float4 color = tex.Sample(samp, Tex) of an R8/R16 texture (:184)
+        y = load_luma(P, sx, sy); uv[0] = 0; uv[1] = 0;
+        return;
+    }
+    if (P.fmt.layout == LAY_PACKED444) {   // .zyxw (AYUV) / .yxzw (Y410, Y416) (:186-193)
+        y = load_packed(P, sx, sy, P.fmt.ci[0]); uv[0] = load_packed(P, sx, sy, P.fmt.ci[1]); uv[1] = load_packed(P, sx, sy, P.fmt.ci[2]);
+        return;
+    }
+    // packed 4:2:2 (:195-229): the even pixel takes the texel's own chroma, the odd pixel the mean with the next texel
+    // (or CATMULLROM_05 over texels tx-1..tx+2); CHROMA_Nearest is not distinguished from Bilinear
+    const int tx = sx >> 1;
+    const int cu = P.fmt.ci[1], cv = P.fmt.ci[3];
+    if ((sx & 1) == 0) {                   // fmod(Tex.x*w, 2) < 1.0
+        y = load_packed(P, tx, sy, P.fmt.ci[0]); uv[0] = load_packed(P, tx, sy, cu); uv[1] = load_packed(P, tx, sy, cv);
+        return;
+    }
+    y = load_packed(P, tx, sy, P.fmt.ci[2]);
+    for (int c = 0; c < 2; c++) {
+        const int k = c ? cv : cu;
+        if (P.chroma_scaling == 2 /*CatmullRom*/) {
+            const float c0 = load_packed(P, tx - 1, sy, k), c1 = load_packed(P, tx, sy, k);
+            const float c2 = load_packed(P, tx + 1, sy, k), c3 = load_packed(P, tx + 2, sy, k);
+            uv[c] = (9 * (c1 + c2) - (c0 + c3)) * 0.0625f;               // CATMULLROM_05 :145
+        } else {
+            uv[c] = (load_packed(P, tx, sy, k) + load_packed(P, tx + 1, sy, k)) * 0.5f;
+        }
+    }
+}
+
 // one output pixel of the generated convert shader (Shaders.cpp:593-930), before the RT store
 __device__ __forceinline__ f3 convert_pixel(const ConvertParams &P, int i, int j)
 {
     const int sx = P.rect_l + i, sy = P.rect_t + j;
-    const float y = load_luma(P, sx, sy);
-    float uv[2];
-    fetch_chroma(P, sx, sy, uv);
+    float y, uv[2];
+    fetch_pixel(P, sx, sy, y, uv);
     f3 c;
     c.x = (P.cm[0] * y + P.cm[1] * uv[0] + P.cm[2] * uv[1]) + P.cm[9];
     c.y = (P.cm[3] * y + P.cm[4] * uv[0] + P.cm[5] * uv[1]) + P.cm[10];

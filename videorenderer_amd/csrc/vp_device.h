@@ -146,6 +146,20 @@ __device__ __forceinline__ float load_chroma(const ConvertParams &P, int c, int 
     return load_sample(pl, P.pitch[1], P.fmt.bytes, P.fmt.shift, x, y);
 }
 
+// one-plane formats: component k of texel (tx,y) of the RGBA8 / RGBA16 / R10G10B10A2 texture, clamp addressing
+__device__ __forceinline__ float load_packed(const ConvertParams &P, int tx, int y, int k)
+{
+    const int tw = (P.fmt.layout == LAY_PACKED422) ? P.tex_w / 2 : P.tex_w;
+    tx = clampi(tx, 0, tw - 1); y = clampi(y, 0, P.tex_h - 1);
+    const uint8_t *row = P.plane[0] + (size_t)y * P.pitch[0];
+    if (P.fmt.bits10) {
+        const uint32_t d = ((const uint32_t *)row)[tx];
+        return (float)((d >> (10 * k)) & 0x3ffu) / 1023.0f;
+    }
+    if (P.fmt.bytes == 1) return (float)row[4 * tx + k] / 255.0f;
+    return (float)((const uint16_t *)row)[4 * tx + k] / 65535.0f;
+}
+
 // ---- store-format rounding ----
 __device__ __forceinline__ float unorm_q(float x, float maxv) { return floorf(saturate(x) * maxv + 0.5f); }
 __device__ __forceinline__ float half_round(float x) { return __half2float(__float2half_rn(x)); }

@@ -60,6 +60,40 @@ __global__ __launch_bounds__(256) void k_copy(Surface in, int out_w, int out_h, 
 // ------------------------------------------------------------------------------------------------
 static inline dim3 grid2d(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4, 1); }
 
+// CopyFrameV210 (Helper.cpp:709-748) on the device: v210 dwords -> Y210 words (10 bits in the MSBs), one thread per
+// pair of dwords (= 6 words), plus the reference's one-dword remainder at the end of a row
+__global__ __launch_bounds__(256) void k_repack_v210(const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch,
+                                                      int lines, int line_blocks, int remainder)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (y >= lines || i > line_blocks) return;
+    const uint32_t *src32 = (const uint32_t *)(src + (size_t)y * src_pitch) + 2 * i;
+    uint16_t *dst16 = (uint16_t *)(dst + (size_t)y * dst_pitch) + 6 * i;
+    if (i < line_blocks) {
+        const uint32_t s0 = src32[0], s1 = src32[1];
+        dst16[0] = (uint16_t)((s0 >> 4) & 0xffc0);
+        dst16[1] = (uint16_t)((s0 << 6) & 0xffc0);
+        dst16[2] = (uint16_t)((s1 << 6) & 0xffc0);
+        dst16[3] = (uint16_t)((s0 >> 14) & 0xffc0);
+        dst16[4] = (uint16_t)((s1 >> 14) & 0xffc0);
+        dst16[5] = (uint16_t)((s1 >> 4) & 0xffc0);
+    } else if (remainder) {
+        const uint32_t v = src32[0];
+        dst16[0] = (uint16_t)((v >> 4) & 0xffc0);
+        dst16[1] = (uint16_t)((v << 6) & 0xffc0);
+    }
+}
+
+hipError_t LaunchRepackV210(const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int lines, hipStream_t s)
+{
+    const int dq = dst_pitch / 12, dr = dst_pitch % 12, sq = src_pitch / 8, sr = src_pitch % 8;
+    int line_blocks, remainder;
+    if (dq <= sq) { line_blocks = dq; remainder = dr != 0; } else { line_blocks = sq; remainder = sr != 0; }
+    hipLaunchKernelGGL(k_repack_v210, dim3((line_blocks + 1 + 255) / 256, lines, 1), dim3(256, 1, 1), 0, s,
+                       src, src_pitch, dst, dst_pitch, lines, line_blocks, remainder);
+    return hipGetLastError();
+}
+
 hipError_t LaunchConvert(const ConvertParams &P, const Surface &out, hipStream_t s)
 {
     hipLaunchKernelGGL(k_convert, grid2d(P.out_w, P.out_h), dim3(64, 4, 1), 0, s, P, out);

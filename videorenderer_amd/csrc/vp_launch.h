@@ -8,6 +8,8 @@ namespace mpcvr {
 
 // pass-per-kernel path (vp_kernels.hip)
 hipError_t LaunchConvert(const ConvertParams &P, const Surface &out, hipStream_t s);
+// CopyFrameV210 (Helper.cpp:709-748): v210 sample -> Y210-layout texture
+hipError_t LaunchRepackV210(const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int lines, hipStream_t s);
 hipError_t LaunchResize(int axis, const Surface &in, const AxisTaps &taps, const int32_t *other,
                         int out_w, int out_h, const StoreParams &st, hipStream_t s);
 hipError_t LaunchCopy(const Surface &in, int out_w, int out_h, const StoreParams &st, hipStream_t s);

@@ -23,14 +23,26 @@ enum TailMode : int {
 
 enum ChromaLoc : int { CLOC_MPEG2 = 0, CLOC_MPEG1 = 1, CLOC_COSITED = 2 };
 
+// organisation of the source texture(s) — Helper.cpp:295-307 (DX11PlaneConfig_t) and ShaderGetPixels' switch on it
+enum SrcLayout : int {
+    LAY_PLANAR = 0,      // planes 2/3 (also planar RGB: G,B,R sampled as Y,U,V)
+    LAY_PACKED422 = 1,   // one RGBA8/RGBA16 texel = two pixels (YUY2, UYVY, Y210, Y216, v210 after CopyFrameV210)
+    LAY_PACKED444 = 2,   // one texel = one pixel (AYUV, Y410, Y416)
+    LAY_GRAY = 3         // R8/R16: Sample() returns (Y,0,0,1)
+};
+enum ColorSystem : int { CST_YUV = 0, CST_RGB = 1, CST_GRAY = 2 };   // Helper.h:129-133
+
 struct SrcFormat {
-    int planes;      // 2: Y + interleaved UV ; 3: Y,U,V
+    int planes;      // 1: single texture ; 2: Y + interleaved UV ; 3: Y,U,V
     int bytes;       // 1 or 2 bytes per sample
     int div_w, div_h;
     int shift;       // CopyPlane10to16 (<<6) applied on load for 10-bit planar (Helper.cpp:789-803)
     int v_first;     // YV12 family: 2nd plane holds V
-    int subsampling; // 420 / 422 / 444
+    int subsampling; // 420 / 422 / 444 / 400
     int cdepth;
+    int layout;      // SrcLayout
+    int ci[4];       // packed 4:2:2: texel components of Y0,U,Y1,V ; packed 4:4:4: components of Y,U,V
+    int bits10;      // texel is an R10G10B10A2 dword (Y410)
 };
 
 struct ConvertParams {

@@ -31,6 +31,24 @@ static const FmtConvParams kFormats[] = {
     {MPCVR_CF_YUV422P16, "YUV422P16",  3, 2, 2, 1, 2, 4, 422, 16, 0, 0},
     {MPCVR_CF_YUV444P10, "YUV444P10",  3, 2, 1, 1, 2, 6, 444, 10, 6, 0},
     {MPCVR_CF_YUV444P16, "YUV444P16",  3, 2, 1, 1, 2, 6, 444, 16, 0, 0},
+    // one RGBA8 / RGBA16 texel = two pixels (DX11Plane_RGBA8 / DX11Plane_RGBA16); ci = components of Y0,U,Y1,V
+    {MPCVR_CF_YUY2,      "YUY2",       1, 1, 2, 1, 2, 2, 422,  8, 0, 0, LAY_PACKED422, CST_YUV, {0, 1, 2, 3}, 0},
+    {MPCVR_CF_UYVY,      "UYVY",       1, 1, 2, 1, 2, 2, 422,  8, 0, 0, LAY_PACKED422, CST_YUV, {1, 0, 3, 2}, 0},
+    {MPCVR_CF_Y210,      "Y210",       1, 2, 2, 1, 4, 2, 422, 10, 0, 0, LAY_PACKED422, CST_YUV, {0, 1, 2, 3}, 0},
+    {MPCVR_CF_Y216,      "Y216",       1, 2, 2, 1, 4, 2, 422, 16, 0, 0, LAY_PACKED422, CST_YUV, {0, 1, 2, 3}, 0},
+    {MPCVR_CF_V210,      "v210",       1, 2, 2, 1, 0, 2, 422, 10, 0, 0, LAY_PACKED422, CST_YUV, {0, 1, 2, 3}, 0},
+    // one texel = one pixel; memory order AYUV: V,U,Y,A  Y410: U:10,Y:10,V:10,A:2  Y416: U,Y,V,A (Shaders.cpp:186-193)
+    {MPCVR_CF_AYUV,      "AYUV",       1, 1, 1, 1, 4, 2, 444,  8, 0, 0, LAY_PACKED444, CST_YUV, {2, 1, 0, 3}, 0},
+    {MPCVR_CF_Y410,      "Y410",       1, 4, 1, 1, 4, 2, 444, 10, 0, 0, LAY_PACKED444, CST_YUV, {1, 0, 2, 3}, 1},
+    {MPCVR_CF_Y416,      "Y416",       1, 2, 1, 1, 8, 2, 444, 16, 0, 0, LAY_PACKED444, CST_YUV, {1, 0, 2, 3}, 0},
+    // planar RGB: planes G,B,R sampled as texY,texU,texV; matrix columns rotated (DX11VideoProcessor.cpp:863-867)
+    {MPCVR_CF_GBRP8,     "GBRP8",      3, 1, 1, 1, 1, 6, 444,  8, 0, 0, LAY_PLANAR, CST_RGB, {0, 0, 0, 0}, 0},
+    {MPCVR_CF_GBRP10,    "GBRP10",     3, 2, 1, 1, 2, 6, 444, 10, 6, 0, LAY_PLANAR, CST_RGB, {0, 0, 0, 0}, 0},
+    {MPCVR_CF_GBRP16,    "GBRP16",     3, 2, 1, 1, 2, 6, 444, 16, 0, 0, LAY_PLANAR, CST_RGB, {0, 0, 0, 0}, 0},
+    // gray: R8 / R16 texture
+    {MPCVR_CF_Y8,        "Y8",         1, 1, 1, 1, 1, 2, 400,  8, 0, 0, LAY_GRAY, CST_GRAY, {0, 0, 0, 0}, 0},
+    {MPCVR_CF_Y10,       "Y10",        1, 2, 1, 1, 2, 2, 400, 10, 6, 0, LAY_GRAY, CST_GRAY, {0, 0, 0, 0}, 0},
+    {MPCVR_CF_Y16,       "Y16",        1, 2, 1, 1, 2, 2, 400, 16, 0, 0, LAY_GRAY, CST_GRAY, {0, 0, 0, 0}, 0},
 };
 
 const FmtConvParams *GetFmtConvParams(int cformat)
@@ -43,9 +61,12 @@ const FmtConvParams *GetFmtConvParams(int cformat)
 int DefaultPitch(const FmtConvParams &f, int width)
 {
     int pitch = width * f.Packsize;
-    if (f.cformat == MPCVR_CF_NV12) pitch = (pitch + 3) & ~3;
+    if (f.cformat == MPCVR_CF_NV12 || f.cformat == MPCVR_CF_Y8) pitch = (pitch + 3) & ~3;     // :1792-1796
+    if (f.cformat == MPCVR_CF_V210) pitch = (((width + 5) / 6 * 16) + 127) & ~127;            // :1798-1799
     return pitch;
 }
+
+int V210TexPitch(int width) { return (4 * width + 11) / 12 * 12; }
 
 int SourceLines(const FmtConvParams &f, int height) { return height * f.PitchCoeff / 2; }
 
@@ -64,6 +85,8 @@ enum { Lighting_dim = 3 };
 
 ExtFmt SpecifyExtendedFormat(ExtFmt ex, const FmtConvParams &f, int w, int h)
 {
+    if (f.CSType == CST_RGB) { ex.value = 0; return ex; }       // :1171-1173
+    if (f.CSType == CST_GRAY) return ex;                        // neither branch: left as the decoder gave it
     if (f.Subsampling != 420) ex.set(8, 0xf, 0);
     else if (ex.VideoChromaSubsampling() == 0) ex.set(8, 0xf, dxva::Chroma_MPEG2);
     if (ex.NominalRange() == 0) ex.set(12, 0x7, dxva::Range_16_235);
@@ -82,7 +105,7 @@ ExtFmt SpecifyExtendedFormat(ExtFmt ex, const FmtConvParams &f, int w, int h)
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-enum CspSpace { SP_AUTO = 0, SP_601, SP_709, SP_240M, SP_2020NC, SP_YCGCO };
+enum CspSpace { SP_AUTO = 0, SP_601, SP_709, SP_240M, SP_2020NC, SP_YCGCO, SP_RGB };
 
 struct Mat3 { float v[3][3]; };
 
@@ -114,6 +137,8 @@ void ComputeColorMatrix(const ExtFmt &ex, const FmtConvParams &f, const ProcAmp 
     case dxva::Matrix_YCgCo: sp = SP_YCGCO; break;
     default: sp = SP_601; break;                        // AUTO -> BT.601 (csputils.cpp:395-396)
     }
+    if (ex.value == 0) { sp = SP_RGB; levels_tv = 0; }   // set_colorspace: value == 0 => MP_CSP_RGB, PC (Helper.cpp:953-957)
+    const bool gray = f.CSType == CST_GRAY;             // csp_params.gray (:843)
 
     const float brightness = pa.brightness / 255;                              // :839
     const float contrast = pa.contrast;                                        // :840
@@ -130,12 +155,17 @@ void ComputeColorMatrix(const ExtFmt &ex, const FmtConvParams &f, const ProcAmp 
         std::memcpy(m.v, y, sizeof(y));
         break;
     }
+    case SP_RGB: {                                      // csputils.cpp:416-420: identity, levels_in = -1 ("anyfull")
+        const float y[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        std::memcpy(m.v, y, sizeof(y));
+        break;
+    }
     default: m = FromLumaWeights(0.299f, 0.587f, 0.114f); break;
     }
 
-    if (sp != SP_YCGCO) {                               // hue rotation + saturation, csputils.cpp:447-459
-        const float hc = saturation * std::cos(hue);    // float overloads, as in the C++ reference
-        const float hs = saturation * std::sin(hue);
+    if (sp != SP_YCGCO && sp != SP_RGB) {               // hue rotation + saturation, csputils.cpp:447-459
+        const float hc = gray ? 0 : saturation * std::cos(hue);    // float overloads, as in the C++ reference
+        const float hs = gray ? 0 : saturation * std::sin(hue);
         for (auto &row : m.v) {
             const float u = row[1], v = row[2];
             row[1] = hc * u - hs * v;
@@ -146,9 +176,12 @@ void ComputeColorMatrix(const ExtFmt &ex, const FmtConvParams &f, const ProcAmp 
     // mp_get_csp_mul (csputils.cpp:341-358) with input_bits == texture_bits == CDepth (:845)
     const int bits = f.CDepth;
     const double full = (double)(1LL << bits);
-    const double s = full / (full - 1.) * 255 / 256 / 255;
-    const double ymin = (levels_tv ? 16 : 0) * s, ymax = (levels_tv ? 235 : 255) * s;
-    const double cmax = (levels_tv ? 240 : 255) * s, cmid = 128 * s;
+    const double mul = (sp == SP_RGB) ? (full - 1.) / (full - 1.)          // RGB always uses the full range (:351-353)
+                                      : full / (full - 1.) * 255 / 256;
+    const double s = mul / 255;
+    double ymin = (levels_tv ? 16 : 0) * s, ymax = (levels_tv ? 235 : 255) * s;
+    double cmax = (levels_tv ? 240 : 255) * s, cmid = 128 * s;
+    if (sp == SP_RGB) { ymin = 0 * s; ymax = 255 * s; cmax = 255 * s / 2; cmid = 0; }   // anyfull (:474)
     double ymul = (1.0 - 0.0) / (ymax - ymin);
     double cmul = (1.0 - 0.0) / (cmax - cmid) / 2;
     ymul *= contrast;
@@ -159,6 +192,13 @@ void ComputeColorMatrix(const ExtFmt &ex, const FmtConvParams &f, const ProcAmp 
         m.v[i][2] = (float)(m.v[i][2] * cmul);
         const float uv = m.v[i][1] + m.v[i][2];
         out[9 + i] = (float)(0.0 - m.v[i][0] * ymin - uv * cmid + brightness);
+    }
+    // cbuffer fix-ups of SetShaderConvertColorParams (DX11VideoProcessor.cpp:863-873)
+    if (f.CSType == CST_RGB && f.layout == LAY_PLANAR) {          // GBRP: color = (G,B,R) => rows (x,y,z) -> (y,z,x)
+        for (auto &row : m.v) { const float x = row[0], y = row[1], z = row[2]; row[0] = y; row[1] = z; row[2] = x; }
+    } else if (gray) {
+        m.v[1][0] = m.v[1][1]; m.v[1][1] = 0;
+        m.v[2][0] = m.v[2][2]; m.v[2][2] = 0;
     }
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) out[i * 3 + j] = m.v[i][j];

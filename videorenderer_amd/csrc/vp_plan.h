@@ -20,10 +20,18 @@ struct FmtConvParams {
     int Subsampling, CDepth;
     int shift;      // 10-bit planar formats are <<6 by CopyPlane10to16 (Helper.cpp:386-391)
     int v_first;    // YV12/YV16/YV24
+    int layout;     // SrcLayout
+    int CSType;     // ColorSystem
+    int ci[4];      // component order of the packed formats (see SrcFormat)
+    int bits10;     // Y410
 };
 const FmtConvParams *GetFmtConvParams(int cformat);            // Helper.cpp:361-369
 int DefaultPitch(const FmtConvParams &f, int width);           // DX11VideoProcessor.cpp:1789-1803
 int SourceLines(const FmtConvParams &f, int height);           // m_srcLines
+// pitch of the Y210 texture a v210 sample is unpacked into by CopyFrameV210 (Helper.cpp:709-748).  The reference uses
+// the driver's mapped pitch (>= 4W, typically 256-aligned); 4W rounded up to whole 12-byte groups converts every pixel of
+// the row exactly as any larger driver pitch would.
+int V210TexPitch(int width);
 
 // ---- DXVA2_ExtendedFormat (dxva2api.h layout) ----
 struct ExtFmt {

@@ -27,6 +27,17 @@ FORMATS = {
 }
 
 
+# one-plane formats (Helper.cpp:315-324,341-343,356-358): cformat -> (kind, bytes per component, code bits, msb_aligned)
+#   p422: two pixels per RGBA texel; p444: one pixel per texel; gbrp: planar G,B,R; gray: luma only
+PACKED = {
+    4: ("yuy2", 1, 8, False), 5: ("uyvy", 1, 8, False), 8: ("y210", 2, 10, True), 9: ("y210", 2, 16, True),
+    10: ("v210", 0, 10, False),
+    11: ("ayuv", 1, 8, False), 12: ("y410", 4, 10, False), 13: ("y416", 2, 16, True),
+    26: ("gbrp", 1, 8, False), 27: ("gbrp", 2, 10, False), 28: ("gbrp", 2, 16, False),
+    37: ("gray", 1, 8, False), 38: ("gray", 2, 10, False), 39: ("gray", 2, 16, False),
+}
+
+
 def splitmix64(n, seed):
     """n uint64 values of the SplitMix64 stream started at `seed`."""
     with np.errstate(over="ignore"):
@@ -38,6 +49,18 @@ def splitmix64(n, seed):
 
 
 def default_pitch(cformat, w):
+    if cformat in PACKED:
+        kind, nbytes = PACKED[cformat][0], PACKED[cformat][1]
+        if kind in ("yuy2", "uyvy", "y210"):
+            return w * 2 * nbytes
+        if kind == "v210":
+            return (((w + 5) // 6 * 16) + 127) & ~127           # DX11VideoProcessor.cpp:1798-1799
+        if kind in ("ayuv", "y410"):
+            return w * 4
+        if kind == "y416":
+            return w * 8
+        pitch = w * nbytes                                       # gbrp, gray
+        return (pitch + 3) & ~3 if cformat == 37 else pitch      # Y8: ALIGN(pitch, 4) (:1792-1796)
     planes, nbytes = FORMATS[cformat][0], FORMATS[cformat][1]
     pitch = w * nbytes
     if cformat == 1:
@@ -75,8 +98,72 @@ def _planes_float(kind, w, h, cw, ch, seed):
     raise ValueError(kind)
 
 
+def _quantise(y, u, v, code_bits, full_range, rgb=False):
+    scale = 1 << (code_bits - 8)
+    if full_range or rgb:
+        ylo, yhi, clo, chi = 0, (1 << code_bits) - 1, 0, (1 << code_bits) - 1
+    else:
+        ylo, yhi, clo, chi = 16 * scale, 235 * scale, 16 * scale, 240 * scale
+    q = lambda a, lo, hi: np.clip(np.floor(lo + a * (hi - lo) + 0.5), lo, hi).astype(np.uint32)
+    return q(y, ylo, yhi), q(u, clo, chi), q(v, clo, chi)
+
+
+def _make_packed(cformat, w, h, kind, seed, pitch, full_range):
+    fam, nbytes, bits, msb = PACKED[cformat]
+    if pitch is None:
+        pitch = default_pitch(cformat, w)
+    if fam in ("yuy2", "uyvy", "y210", "v210"):
+        cw, ch = w // 2, h
+    elif fam == "gray":
+        cw, ch = 1, 1
+    else:
+        cw, ch = w, h
+    y, u, v = _planes_float(kind, w, h, cw, ch, SEED_BASE + seed)
+    yq, uq, vq = _quantise(y, u, v, bits, full_range, rgb=(fam == "gbrp"))
+    if msb and bits == 10:
+        yq, uq, vq = yq << 6, uq << 6, vq << 6
+    buf = np.zeros(pitch * h * (3 if fam == "gbrp" else 1), dtype=np.uint8)
+    rows = buf[: pitch * h].reshape(h, pitch)
+    if fam in ("yuy2", "uyvy", "y210"):
+        dt = np.uint8 if nbytes == 1 else np.uint16
+        t = rows.view(dt)[:, : 2 * w].reshape(h, w // 2, 4)
+        iy0, iu, iy1, iv = (1, 0, 3, 2) if fam == "uyvy" else (0, 1, 2, 3)
+        t[:, :, iy0] = yq[:, 0::2]; t[:, :, iy1] = yq[:, 1::2]; t[:, :, iu] = uq; t[:, :, iv] = vq
+    elif fam == "v210":
+        # SMPTE v210: 6 pixels in four little-endian dwords of three 10-bit fields (low, mid, high):
+        #   (Cb0,Y0,Cr0) (Y1,Cb1,Y2) (Cr1,Y3,Cb2) (Y4,Cr2,Y5); rows padded to whole groups
+        groups = (w + 5) // 6
+        yp = np.zeros((h, groups * 6), np.uint32); yp[:, :w] = yq
+        up = np.zeros((h, groups * 3), np.uint32); up[:, : w // 2] = uq
+        vp = np.zeros((h, groups * 3), np.uint32); vp[:, : w // 2] = vq
+        yg, ug, vg = yp.reshape(h, groups, 6), up.reshape(h, groups, 3), vp.reshape(h, groups, 3)
+        d = rows.view(np.uint32)[:, : groups * 4].reshape(h, groups, 4)
+        d[:, :, 0] = ug[:, :, 0] | (yg[:, :, 0] << 10) | (vg[:, :, 0] << 20)
+        d[:, :, 1] = yg[:, :, 1] | (ug[:, :, 1] << 10) | (yg[:, :, 2] << 20)
+        d[:, :, 2] = vg[:, :, 1] | (yg[:, :, 3] << 10) | (ug[:, :, 2] << 20)
+        d[:, :, 3] = yg[:, :, 4] | (vg[:, :, 2] << 10) | (yg[:, :, 5] << 20)
+    elif fam == "ayuv":
+        t = rows[:, : 4 * w].reshape(h, w, 4)
+        t[:, :, 0] = vq; t[:, :, 1] = uq; t[:, :, 2] = yq; t[:, :, 3] = 255
+    elif fam == "y410":
+        rows.view(np.uint32)[:, :w] = uq | (yq << 10) | (vq << 20) | np.uint32(3 << 30)
+    elif fam == "y416":
+        t = rows.view(np.uint16)[:, : 4 * w].reshape(h, w, 4)
+        t[:, :, 0] = uq; t[:, :, 1] = yq; t[:, :, 2] = vq; t[:, :, 3] = 65535
+    elif fam == "gbrp":      # planes G, B, R (the "Y,U,V" floats stand in for G,B,R)
+        dt = np.uint8 if nbytes == 1 else np.uint16
+        for i, q in enumerate((yq, uq, vq)):
+            buf[i * pitch * h: (i + 1) * pitch * h].reshape(h, pitch).view(dt)[:, :w] = q.astype(dt)
+    else:                    # gray
+        dt = np.uint8 if nbytes == 1 else np.uint16
+        rows.view(dt)[:, :w] = yq.astype(dt)
+    return buf, pitch
+
+
 def make_frame(cformat, w, h, kind="noise", seed=0, pitch=None, full_range=False):
     """Return (uint8 buffer in the reference sample layout, pitch)."""
+    if cformat in PACKED:
+        return _make_packed(cformat, w, h, kind, seed, pitch, full_range)
     planes, nbytes, dw, dh, bits, msb, v_first = FORMATS[cformat]
     if pitch is None:
         pitch = default_pitch(cformat, w)
