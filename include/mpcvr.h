@@ -79,7 +79,7 @@ typedef struct mpcvr_settings {
     int32_t  iDownscaling;        /* MPCVR_DOWNSCALE_*         default Hamming   */
     int32_t  bInterpolateAt50pct; /*                           default 1         */
     int32_t  bUseDither;          /*                           default 1         */
-    int32_t  bDeintBlend;         /* accepted, must be 0 (progressive frames only) */
+    int32_t  bDeintBlend;         /* blend-deinterlace 4:2:0 samples flagged interlaced (mpcvr_set_sample_format) */
     int32_t  bConvertToSdr;       /*                           default 1         */
     int32_t  iSDRDisplayNits;     /* 25..400                   default 125       */
     int32_t  output_format;       /* MPCVR_OUT_*               default BGRA8     */
@@ -126,6 +126,10 @@ int32_t mpcvr_set_window_rect(mpcvr_ctx *ctx, const mpcvr_rect *window_rect);
  * implemented in this build; other values return E_NOTIMPL. */
 int32_t mpcvr_set_rotation(mpcvr_ctx *ctx, int32_t degrees);
 int32_t mpcvr_set_flip(mpcvr_ctx *ctx, int32_t flip);
+/* m_SampleFormat as CopySample derives it from AM_SAMPLE2_PROPERTIES::dwTypeSpecificFlags (DX11VideoProcessor.cpp:2209-2219):
+ * 0 progressive, 1 interlaced top field first, 2 interlaced bottom field first.  With bDeintBlend an interlaced 4:2:0
+ * sample goes through the blend variant of the convert shader (:3075, Shaders.cpp:232-237). */
+int32_t mpcvr_set_sample_format(mpcvr_ctx *ctx, int32_t frame_format);
 
 /* Configure — DX11VideoProcessor.cpp:3800-4050: diff each field, rebuild only what changed. */
 int32_t mpcvr_configure(mpcvr_ctx *ctx, const mpcvr_settings *settings);

@@ -747,11 +747,15 @@ static void fetch_chroma(const src_tex *s, int chroma_loc, int chroma_scaling, i
 }
 
 /* (Y,U,V) — or (G,B,R) / (Y,0,0) — of source pixel (sx,sy): ShaderGetPixels, DX11 branch */
-static void fetch_pixel(const src_tex *s, int chroma_loc, int chroma_scaling, int sx, int sy, float yuv[3])
+static void fetch_pixel(const src_tex *s, int chroma_loc, int chroma_scaling, int blend_deint, int sx, int sy, float yuv[3])
 {
     const fmt_info *f = s->f;
     if (f->layout == LAY_PLANAR) {
         yuv[0] = load_luma(s, sx, sy);                                    /* :231,274 */
+        if (blend_deint && f->subsampling == 420) {                       /* blendDeint420 :115,232-237,275-280 */
+            float y1 = load_luma(s, sx, sy - 1), y2 = load_luma(s, sx, sy + 1);
+            yuv[0] = (yuv[0] * 2 + y1 + y2) / 4;
+        }
         fetch_chroma(s, chroma_loc, chroma_scaling, sx, sy, yuv + 1);
         return;
     }
@@ -864,7 +868,7 @@ static void convert_pass(const orc_params *p, const convert_ctx *c, img_t *out)
         for (int i = 0; i < rw; i++) {
             int sx = c->rect[0] + i, sy = c->rect[1] + j;
             float yuv[3];
-            fetch_pixel(&c->tex, cloc, p->iChromaScaling, sx, sy, yuv);
+            fetch_pixel(&c->tex, cloc, p->iChromaScaling, p->blend_deint, sx, sy, yuv);
             const float y = yuv[0], *uv = yuv + 1;
             /* color.rgb = float3(mul(cm_r,color), mul(cm_g,color), mul(cm_b,color)) + cm_c  (:820) */
             float rgb[3];

@@ -68,6 +68,9 @@ typedef struct orc_params {
     int32_t  window_w, window_h;   /* m_windowRect = (0,0,w,h): size of the render target */
     int32_t  video_rect[4];        /* m_videoRect l,t,r,b inside the window (dstRect of Process) */
     uint32_t flags;
+    /* m_bDeintBlend && m_SampleFormat != PROGRESSIVE (DX11VideoProcessor.cpp:3075): the 4:2:0 convert shader variant
+       with colorY = (2Y + Y(0,-1) + Y(0,+1)) / 4 (Shaders.cpp:232-237,275-280) */
+    int32_t  blend_deint;
 } orc_params;
 
 void orc_params_default(orc_params *p);

@@ -36,6 +36,7 @@ class OrcParams(C.Structure):
         ("brightness", C.c_float), ("contrast", C.c_float), ("hue", C.c_float), ("saturation", C.c_float),
         ("window_w", C.c_int32), ("window_h", C.c_int32), ("video_rect", C.c_int32 * 4),
         ("flags", C.c_uint32),
+        ("blend_deint", C.c_int32),
     ]
 
 

@@ -87,6 +87,11 @@ GOLDEN_CASES = {
     "y8_gray_2x": dict(cformat=37, w=62, h=32, kind="structure", seed=73, dst=(124, 64), iUpscaling=4),
     "y10_gray_tv_matrix": dict(cformat=38, w=48, h=32, kind="noise", seed=74, dst=(48, 32), exfmt=ext(0, TV, M709)),
     "y16_gray_crop": dict(cformat=39, w=64, h=48, kind="structure", seed=75, src_rect=(8, 4, 56, 44), dst=(96, 80), iUpscaling=1),
+    # ---- blend deinterlace (bDeintBlend on interlaced 4:2:0 samples) ----
+    "nv12_blend_deint": dict(cformat=1, w=64, h=32, kind="structure", seed=80, dst=(64, 32), bDeintBlend=1, sample_format=1),
+    "p010_blend_deint_2x": dict(cformat=2, w=64, h=32, kind="noise", seed=81, dst=(128, 64), iUpscaling=4, bDeintBlend=1, sample_format=2),
+    "yv12_blend_deint_progressive_sample": dict(cformat=14, w=64, h=32, kind="noise", seed=82, dst=(64, 32), bDeintBlend=1, sample_format=0),
+    "yuv422p8_blend_deint_not_420": dict(cformat=18, w=64, h=32, kind="noise", seed=83, dst=(64, 32), bDeintBlend=1, sample_format=1),
     # ---- colour / settings ----
     "bt2020_sdr_gamma_gamut": dict(cformat=2, w=64, h=32, kind="structure", seed=40, dst=(128, 64), exfmt=ext(MPEG2, TV, M2020, P2020, T709), iUpscaling=2),
     "bt2020_gamma26": dict(cformat=2, w=64, h=32, kind="noise", seed=41, dst=(64, 32), exfmt=ext(MPEG2, TV, M2020, P2020, T26)),
@@ -132,6 +137,8 @@ def oracle_params(oracle, c):
     if "procamp" in c:
         b, ct, h, s = c["procamp"]
         oracle.set_params(p, brightness=b, contrast=ct, hue=h, saturation=s)
+    # m_bDeintBlend && m_SampleFormat != PROGRESSIVE (DX11VideoProcessor.cpp:3075); the 4:2:0 check is the oracle's
+    oracle.set_params(p, blend_deint=int(bool(c.get("bDeintBlend", 0)) and c.get("sample_format", 0) != 0))
     return p
 
 

@@ -33,6 +33,8 @@ def make_vp(mpcvr, c, extra_flags=0):
     from videorenderer_amd import api
     kw = {k: c[k] for k in SETTING_KEYS if k in c}
     kw["flags"] = kw.get("flags", 0) | extra_flags
+    if "bDeintBlend" in c:
+        kw["bDeintBlend"] = c["bDeintBlend"]
     vp = api.VideoProcessor(api.default_settings(**kw))
     (ww, wh), vr = case_geometry(c)
     vp.InitMediaType(c["cformat"], c["w"], c["h"], pitch=c.get("pitch", 0), src_rect=c.get("src_rect"), extfmt=c.get("exfmt", 0))
@@ -40,6 +42,8 @@ def make_vp(mpcvr, c, extra_flags=0):
     vp.SetVideoRect(vr)
     if "procamp" in c:
         vp.SetProcAmpValues(*c["procamp"])
+    if "sample_format" in c:
+        vp.SetSampleFormat(c["sample_format"])
     return vp, (ww, wh)
 
 

@@ -84,7 +84,7 @@ class MpcvrError(RuntimeError):
 
 EXPORTS = [
     "mpcvr_settings_default", "mpcvr_create", "mpcvr_destroy", "mpcvr_set_stream", "mpcvr_synchronize",
-    "mpcvr_set_input", "mpcvr_set_video_rect", "mpcvr_set_window_rect", "mpcvr_set_rotation", "mpcvr_set_flip",
+    "mpcvr_set_input", "mpcvr_set_video_rect", "mpcvr_set_window_rect", "mpcvr_set_rotation", "mpcvr_set_flip", "mpcvr_set_sample_format",
     "mpcvr_configure", "mpcvr_set_procamp", "mpcvr_copy_sample", "mpcvr_process", "mpcvr_render",
     "mpcvr_get_backbuffer", "mpcvr_get_current_image", "mpcvr_flush", "mpcvr_reset", "mpcvr_process_batch",
     "mpcvr_get_param_blob", "mpcvr_set_param_blob", "mpcvr_get_color_matrix", "mpcvr_get_extfmt",
@@ -119,6 +119,7 @@ def load_library():
         "mpcvr_set_window_rect": [vp, P(Rect)],
         "mpcvr_set_rotation": [vp, i32],
         "mpcvr_set_flip": [vp, i32],
+        "mpcvr_set_sample_format": [vp, i32],
         "mpcvr_configure": [vp, P(Settings)],
         "mpcvr_set_procamp": [vp, u32, f, f, f, f],
         "mpcvr_copy_sample": [vp, vp, i32, i32],
@@ -304,6 +305,10 @@ class VideoProcessor:
 
     def SetFlip(self, value):
         return self._check(self._L.mpcvr_set_flip(self._ctx, int(bool(value))))
+
+    def SetSampleFormat(self, frame_format):
+        """m_SampleFormat (DX11VideoProcessor.cpp:2209-2219): 0 progressive, 1 interlaced TFF, 2 interlaced BFF."""
+        return self._check(self._L.mpcvr_set_sample_format(self._ctx, int(frame_format)))
 
     def Configure(self, settings):
         hr = self._check(self._L.mpcvr_configure(self._ctx, C.byref(settings)))

@@ -96,7 +96,6 @@ HRESULT CHipVideoProcessor::Init(int device, const mpcvr_settings &settings)
 {
     std::string why;
     if (!ValidSettings(settings, &why)) return Fail(MPCVR_E_INVALIDARG, "invalid settings: " + why);
-    if (settings.bDeintBlend) return Fail(MPCVR_E_NOTIMPL, "bDeintBlend: interlaced blend is not implemented");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -217,6 +216,13 @@ HRESULT CHipVideoProcessor::SetRotation(int value)
     return MPCVR_S_OK;
 }
 
+HRESULT CHipVideoProcessor::SetSampleFormat(int frameFormat)
+{
+    if (frameFormat < 0 || frameFormat > 2) return Fail(MPCVR_E_INVALIDARG, "frame format must be 0 (progressive), 1 (TFF) or 2 (BFF)");
+    if (frameFormat != m_SampleFormat) { m_SampleFormat = frameFormat; m_planDirty = true; }
+    return MPCVR_S_OK;
+}
+
 HRESULT CHipVideoProcessor::SetFlip(bool value)
 {
     if (value) return Fail(MPCVR_E_NOTIMPL, "flip is not implemented in this build");
@@ -230,7 +236,6 @@ HRESULT CHipVideoProcessor::Configure(const mpcvr_settings &c)
     if (!m_bInit) return Fail(MPCVR_E_NOT_VALID_STATE, "not initialised");
     std::string why;
     if (!ValidSettings(c, &why)) return Fail(MPCVR_E_INVALIDARG, "invalid settings: " + why);
-    if (c.bDeintBlend) return Fail(MPCVR_E_NOTIMPL, "bDeintBlend: interlaced blend is not implemented");
     bool changeConvertShader = false, changeLuminance = false, changePlan = false;
     if (c.iTexFormat != m_cfg.iTexFormat) changePlan = true;
     if (c.iChromaScaling != m_cfg.iChromaScaling) changeConvertShader = true;
@@ -238,6 +243,7 @@ HRESULT CHipVideoProcessor::Configure(const mpcvr_settings &c)
         c.bInterpolateAt50pct != m_cfg.bInterpolateAt50pct) changePlan = true;
     if (c.bUseDither != m_cfg.bUseDither || c.output_format != m_cfg.output_format || c.flags != m_cfg.flags) changePlan = true;
     if (c.bConvertToSdr != m_cfg.bConvertToSdr) changeConvertShader = true;
+    if (c.bDeintBlend != m_cfg.bDeintBlend) changePlan = true;
     if (c.iSDRDisplayNits != m_cfg.iSDRDisplayNits) changeLuminance = true;
     m_cfg = c;
     if (changeConvertShader || changeLuminance) m_blobOverride = false;
@@ -402,6 +408,8 @@ void CHipVideoProcessor::FillConvertParams(const uint8_t *sample, ConvertParams 
     P->out_w = m_srcRectWidth; P->out_h = m_srcRectHeight;
     P->fmt.planes = f.planes; P->fmt.bytes = f.bytes; P->fmt.div_w = f.div_w; P->fmt.div_h = f.div_h;
     P->fmt.shift = f.shift; P->fmt.v_first = f.v_first; P->fmt.subsampling = f.Subsampling; P->fmt.cdepth = f.CDepth;
+    // m_pPSConvertColorDeint: 4:2:0 planar/bi-planar only (:2964), used for interlaced samples when bDeintBlend (:3075)
+    P->blend_deint = (m_cfg.bDeintBlend && m_SampleFormat != 0 && f.Subsampling == 420 && f.planes >= 2) ? 1 : 0;
     P->fmt.layout = f.layout; P->fmt.bits10 = f.bits10;
     for (int k = 0; k < 4; k++) P->fmt.ci[k] = f.ci[k];
     P->chroma_scaling = m_cfg.iChromaScaling;

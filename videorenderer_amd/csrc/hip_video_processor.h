@@ -50,6 +50,7 @@ public:
     HRESULT SetWindowRect(const CRect &windowRect);                           // :3433
     HRESULT SetRotation(int value);                                           // :4052
     HRESULT SetFlip(bool value);                                              // VideoProcessor.h:210
+    HRESULT SetSampleFormat(int frameFormat);                                 // m_SampleFormat, :2209-2219
     HRESULT Configure(const mpcvr_settings &config);                          // :3800
     HRESULT SetProcAmpValues(uint32_t flags, float b, float c, float h, float s); // :4506
 
@@ -104,6 +105,7 @@ private:
     ProcAmp m_procAmp;
     int m_iRotation = 0;
     bool m_bFlip = false;
+    int m_SampleFormat = 0;        // 0 progressive, 1 TFF, 2 BFF
 
     // input
     const FmtConvParams *m_srcParams = nullptr;

@@ -87,6 +87,10 @@ __device__ __forceinline__ void fetch_pixel(const ConvertParams &P, int sx, int 
 {
     if (P.fmt.layout == LAY_PLANAR) {
         y = load_luma(P, sx, sy);                                         // :231,274
+        if (P.blend_deint) {                                              // blendDeint420 :232-237,275-280
+            const float y1 = load_luma(P, sx, sy - 1), y2 = load_luma(P, sx, sy + 1);
+            y = (y * 2 + y1 + y2) / 4;
+        }
         fetch_chroma(P, sx, sy, uv);
         return;
     }

@@ -605,7 +605,7 @@ bool FusedUp2xSupported(const FusedParams &P)
     if (P.wy.ntaps != P.wx.ntaps || P.wy.q1_quirk != P.wx.q1_quirk) return false;
     if (std::memcmp(P.wx.w_even, P.wy.w_even, sizeof(P.wx.w_even)) || std::memcmp(P.wx.w_odd, P.wy.w_odd, sizeof(P.wx.w_odd))) return false;
     if (c.out_fmt != SF_BGRA8 && c.out_fmt != SF_RGB10A2) return false;
-    if (c.fmt.subsampling != 420 || c.chroma_scaling != 1) return false;
+    if (c.fmt.subsampling != 420 || c.chroma_scaling != 1 || c.blend_deint) return false;
     if (c.out_w < 8 || c.out_h < 8 || (c.out_w & 1) || (c.out_h & 1)) return false;
     if (!P.fast_convert) return false;            // dword loads need aligned rows / rect (host-checked)
     // 32-bit row offsets inside the kernel

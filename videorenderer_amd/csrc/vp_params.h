@@ -53,6 +53,7 @@ struct ConvertParams {
     int rect_l, rect_t;      // source rect origin inside the texture
     int out_w, out_h;        // rect size == convert-output size
     SrcFormat fmt;
+    int blend_deint;         // blendDeint420 variant of the shader (Shaders.cpp:115,232-237)
     int chroma_scaling;      // CHROMA_*
     int chroma_loc;          // ChromaLoc
     int tail;                // TailMode
