@@ -122,8 +122,9 @@ int32_t mpcvr_set_input(mpcvr_ctx *ctx, int32_t cformat, int32_t width, int32_t 
 /* SetVideoRect / SetWindowRect — DX11VideoProcessor.cpp:3426-3451.  Window rect = render-target size. */
 int32_t mpcvr_set_video_rect(mpcvr_ctx *ctx, const mpcvr_rect *video_rect);
 int32_t mpcvr_set_window_rect(mpcvr_ctx *ctx, const mpcvr_rect *window_rect);
-/* SetRotation (DX11VideoProcessor.cpp:4052) / SetFlip (VideoProcessor.h:210): only 0 / false are
- * implemented in this build; other values return E_NOTIMPL. */
+/* SetRotation (DX11VideoProcessor.cpp:4052) / SetFlip (VideoProcessor.h:210): 0/90/180/270 degrees clockwise and a
+ * horizontal flip of the source, applied in the first resize draw the way FillVertices (:130-179) and ResizeShaderPass
+ * (:3112-3137) set it up; the caller sizes the video rect for the rotated picture.  E_INVALIDARG for other angles. */
 int32_t mpcvr_set_rotation(mpcvr_ctx *ctx, int32_t degrees);
 int32_t mpcvr_set_flip(mpcvr_ctx *ctx, int32_t flip);
 /* m_SampleFormat as CopySample derives it from AM_SAMPLE2_PROPERTIES::dwTypeSpecificFlags (DX11VideoProcessor.cpp:2209-2219):

@@ -907,9 +907,10 @@ typedef struct { int n; int idx[ORC_MAX_TAPS]; float w[ORC_MAX_TAPS]; float wsum
 /* Tex[AXIS]*wh[AXIS] for output i: interpolated texcoord (src_l + (i+.5)*srcLen/dstLen)/texLen times texLen */
 static inline float axis_center(int src_l, int i, float scale) { return (float)src_l + ((float)i + 0.5f) * scale; }
 
-static int build_taps(resizer_t rs, int src_l, int i, float scale, int tex_len, uint32_t flags, taps_t *t)
+/* taps of one output texel whose interpolated coordinate on the filtered axis is `center` (= Tex[AXIS]*wh[AXIS]);
+ * `scale` = the shader constant scale[AXIS] (only ps_convolution reads it) */
+static int build_taps_at(resizer_t rs, float center, float scale, int tex_len, uint32_t flags, taps_t *t)
 {
-    float center = axis_center(src_l, i, scale);
     t->normalise = 0; t->wsum = 1;
     if (rs.kind == RS_UP) {
         float pos = center - 0.5f;                       /* ps_interpolation_*.hlsl: pos = Tex*wh - 0.5 */
@@ -952,6 +953,10 @@ static int build_taps(resizer_t rs, int src_l, int i, float scale, int tex_len, 
     t->n = 1; t->idx[0] = clampi((int)floorf(center), 0, tex_len - 1); t->w[0] = 1.0f;
     return 0;
 }
+static int build_taps(resizer_t rs, int src_l, int i, float scale, int tex_len, uint32_t flags, taps_t *t)
+{
+    return build_taps_at(rs, axis_center(src_l, i, scale), scale, tex_len, flags, t);
+}
 
 int orc_axis_taps(int kind, int method, int src_l, int src_len, int n_out, int tex_len, uint32_t flags,
                   int i, int32_t *idx, float *w, float *wsum)
@@ -965,31 +970,52 @@ int orc_axis_taps(int kind, int method, int src_l, int src_len, int n_out, int t
     return t.n;
 }
 
-/* One TextureResizeShader draw filtering `axis`; the other axis is point-sampled with (o_l, o_scale).
- * in: source texture (whole); f_l/f_scale: src rect origin & srcLen/dstLen on the filtered axis. */
-static int resize_pass(const img_t *in, img_t *out, int axis, resizer_t rs,
-                       int f_l, float f_scale, int o_l, float o_scale, uint32_t flags, int store)
+/* One TextureResizeShader / TextureCopyRect draw of the WHOLE texture `in` onto `out` with the vertex set-up of
+ * FillVertices (DX11VideoProcessor.cpp:130-179): rotation 0/90/180/270 (clockwise) and horizontal flip permute which
+ * texture coordinate runs along which screen axis and in which direction:
+ *     rot   0: U = l + a(r-l)   V = t + b(bm-t)        a = (x+.5)/W', b = (y+.5)/H'
+ *     rot  90: U = l + b(r-l)   V = bm - a(bm-t)
+ *     rot 180: U = r - a(r-l)   V = bm - b(bm-t)
+ *     rot 270: U = r - b(r-l)   V = t + a(bm-t)         flip swaps l and r (:167-169)
+ * tex_axis = texture axis the pixel shader filters (0 = X shaders, 1 = Y shaders, -1 = ps_simple); the other
+ * coordinate is point-sampled.  The shader constant scale[AXIS] is srcRect/dstRect of the SAME-NAMED screen dimension
+ * (:351-354) whatever the rotation, so a rotated ps_convolution draw runs with the other dimension's ratio — as written. */
+static int resize_draw(const img_t *in, img_t *out, int tex_axis, resizer_t rs, int rot, int flip, uint32_t flags, int store)
 {
-    const int flen = axis == 0 ? out->w : out->h;
-    const int tex_len = axis == 0 ? in->w : in->h;
-    taps_t *taps = (taps_t *)malloc(sizeof(taps_t) * (size_t)flen);
-    if (!taps) return -1;
-    for (int i = 0; i < flen; i++)
-        if (build_taps(rs, f_l, i, f_scale, tex_len, flags, &taps[i])) { free(taps); return -2; }
-    const int olen = axis == 0 ? out->h : out->w;
-    const int otex = axis == 0 ? in->h : in->w;
-    int *oidx = (int *)malloc(sizeof(int) * (size_t)olen);
-    if (!oidx) { free(taps); return -1; }
-    for (int i = 0; i < olen; i++) oidx[i] = clampi((int)floorf(axis_center(o_l, i, o_scale)), 0, otex - 1);
+    const int swap = (rot == 90 || rot == 270);
+    /* texture axis and direction along screen x and screen y */
+    const int tax = swap ? 1 : 0, tay = swap ? 0 : 1;
+    int rev_u = (rot == 180 || rot == 270);               /* U runs against its screen axis */
+    const int rev_v = (rot == 90 || rot == 180);
+    if (flip) rev_u = !rev_u;
+    const int rev_x = tax == 0 ? rev_u : rev_v, rev_y = tay == 0 ? rev_u : rev_v;
+    const int len_x = tax == 0 ? in->w : in->h, len_y = tay == 0 ? in->w : in->h;   /* srcRect extent run through by x / y */
+    const float step_x = (float)len_x / (float)out->w, step_y = (float)len_y / (float)out->h;
+    const float cscale = tex_axis == 0 ? (float)in->w / (float)out->w : (float)in->h / (float)out->h;   /* scale[AXIS] */
+    const resizer_t none = {RS_NONE, 0};
 
+    taps_t *tx = (taps_t *)malloc(sizeof(taps_t) * (size_t)out->w);
+    taps_t *ty = (taps_t *)malloc(sizeof(taps_t) * (size_t)out->h);
+    if (!tx || !ty) { free(tx); free(ty); return -1; }
+    for (int i = 0; i < out->w; i++) {
+        const float c = rev_x ? (float)len_x - ((float)i + 0.5f) * step_x : axis_center(0, i, step_x);
+        if (build_taps_at(tax == tex_axis ? rs : none, c, cscale, len_x, flags, &tx[i])) { free(tx); free(ty); return -2; }
+    }
+    for (int i = 0; i < out->h; i++) {
+        const float c = rev_y ? (float)len_y - ((float)i + 0.5f) * step_y : axis_center(0, i, step_y);
+        if (build_taps_at(tay == tex_axis ? rs : none, c, cscale, len_y, flags, &ty[i])) { free(tx); free(ty); return -2; }
+    }
+    const int filt_x = (tax == tex_axis);      /* taps run along screen x; otherwise along screen y (or nowhere) */
     ORC_PAR_FOR
     for (int y = 0; y < out->h; y++) {
         for (int x = 0; x < out->w; x++) {
-            const taps_t *t = &taps[axis == 0 ? x : y];
+            const taps_t *t = filt_x ? &tx[x] : &ty[y];
+            const int o = filt_x ? ty[y].idx[0] : tx[x].idx[0];      /* point-sampled coordinate */
             float acc[4] = {0, 0, 0, 0};
             for (int k = 0; k < t->n; k++) {
-                int sx = axis == 0 ? t->idx[k] : oidx[x];
-                int sy = axis == 0 ? oidx[y] : t->idx[k];
+                /* filtered coordinate is on texture axis (filt_x ? tax : tay) */
+                const int fa = filt_x ? tax : tay;
+                const int sx = fa == 0 ? t->idx[k] : o, sy = fa == 0 ? o : t->idx[k];
                 const float *q = in->p + ((size_t)sy * in->w + sx) * 4;
                 if (k == 0 && !t->normalise) { for (int c = 0; c < 4; c++) acc[c] = t->w[0] * q[c]; }
                 else for (int c = 0; c < 4; c++) acc[c] = acc[c] + t->w[k] * q[c];
@@ -998,12 +1024,12 @@ static int resize_pass(const img_t *in, img_t *out, int axis, resizer_t rs,
             store_fmt(store, acc, out->p + ((size_t)y * out->w + x) * 4);
         }
     }
-    free(oidx); free(taps);
+    free(tx); free(ty);
     return 0;
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* Process — DX11VideoProcessor.cpp:3285-3424 (shader path, rotation 0, no flip)               */
+/* Process — DX11VideoProcessor.cpp:3285-3424 (shader path)                                    */
 /* ------------------------------------------------------------------------------------------ */
 static inline uint32_t pack_out(int out_fmt, const float v[4])
 {
@@ -1063,31 +1089,41 @@ int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
     /* ResizeShaderPass :3103-3187 — pick per-axis shader */
     const int k = p->bInterpolateAt50pct ? 2 : 1;
     if (p->iUpscaling == ORC_UP_JINC2) { img_free(&conv); free(c.owned); return -6; }
+    const int rot = p->rotation, flip = p->flip != 0;
+    if (rot != 0 && rot != 90 && rot != 180 && rot != 270) { img_free(&conv); free(c.owned); return -7; }
+    const int rotated = (rot == 90 || rot == 270);
+    const int sw = rotated ? h1 : w1, sh = rotated ? w1 : h1;            /* w1,h1 of ResizeShaderPass :3112-3123 */
     resizer_t up = {p->iUpscaling == ORC_UP_NEAREST ? RS_NONE : RS_UP, p->iUpscaling};
     resizer_t down = {RS_DOWN, p->iDownscaling};
     resizer_t none = {RS_NONE, 0};
-    resizer_t rx = (w1 == w2) ? none : (w1 > k * w2) ? down : up;
-    resizer_t ry = (h1 == h2) ? none : (h1 > k * h2) ? down : up;
-    const float sx = (float)w1 / (float)w2, sy = (float)h1 / (float)h2;   /* constants[1] :353 */
+    resizer_t rx = (sw == w2) ? none : (sw > k * w2) ? down : up;        /* filters the screen-x direction */
+    resizer_t ry = (sh == h2) ? none : (sh > k * h2) ? down : up;
+    /* texture axis each of them runs on in the rotation-carrying draw: X shaders filter texture X, Y shaders texture Y;
+       rotated: resizerX is a Y shader, and resizerY is a Y shader of the second draw when resizerX exists, else an X
+       shader of the single rotated draw (:3112-3121) */
+    const int ax_first = rotated ? 1 : 0;
     /* destination format of the last resize draw: post-scale texture (internal) if a final pass
        follows, else the render target itself (:3334-3352, :3417-3419) */
     const int last_store = final_pass ? internal : swap_fmt;
+    /* Process :3348-3352: with post-scale steps the resize is skipped when rSrc == dstRect and rotation == 0 (flip alone
+       is then ignored); without them ResizeShaderPass always runs */
+    const int same_rect = (w1 == w2 && h1 == h2 && dl == 0 && dt == 0);
 
     const img_t *result = &conv;
     int result_fmt = internal;
-    if (rx.kind != RS_NONE && ry.kind != RS_NONE) {
-        /* two passes through fp16 m_TexResize (w2 x h1) :3143-3167 */
-        if (img_alloc(&mid, w2, h1) || img_alloc(&post, w2, h2)) { rc = -5; goto done; }
-        if ((rc = resize_pass(&conv, &mid, 0, rx, 0, sx, 0, 1.0f, p->flags, FMT_RGBA16F))) goto done;
-        if ((rc = resize_pass(&mid, &post, 1, ry, 0, sy, 0, 1.0f, p->flags, last_store))) goto done;
+    if (rx.kind != RS_NONE && ry.kind != RS_NONE && !(rotated && rx.kind == ry.kind)) {
+        /* two passes through fp16 m_TexResize (w2 x sh) :3143-3167; the second one is unrotated */
+        if (img_alloc(&mid, w2, sh) || img_alloc(&post, w2, h2)) { rc = -5; goto done; }
+        if ((rc = resize_draw(&conv, &mid, ax_first, rx, rot, flip, p->flags, FMT_RGBA16F))) goto done;
+        if ((rc = resize_draw(&mid, &post, 1, ry, 0, 0, p->flags, last_store))) goto done;
         result = &post; result_fmt = last_store;
-    } else if (rx.kind != RS_NONE || ry.kind != RS_NONE || w1 != w2 || h1 != h2) {
-        /* one pass; the unfiltered axis is point sampled (nearest when its size changes) :3169-3177 */
+    } else if (rx.kind != RS_NONE || ry.kind != RS_NONE || sw != w2 || sh != h2 || rot != 0 || (flip && !(final_pass && same_rect))) {
+        /* one draw: one filtered axis (resizerX == resizerY for a rotated frame scaled the same way on both axes:
+           :3131-3137 draws once, so only texture Y is filtered), or ps_simple (:3169-3181) */
         if (img_alloc(&post, w2, h2)) { rc = -5; goto done; }
-        if (rx.kind != RS_NONE || (ry.kind == RS_NONE && w1 != w2))
-            rc = resize_pass(&conv, &post, 0, rx, 0, sx, 0, sy, p->flags, last_store);
-        else
-            rc = resize_pass(&conv, &post, 1, ry, 0, sy, 0, sx, p->flags, last_store);
+        if (rx.kind != RS_NONE)      rc = resize_draw(&conv, &post, ax_first, rx, rot, flip, p->flags, last_store);
+        else if (ry.kind != RS_NONE) rc = resize_draw(&conv, &post, rotated ? 0 : 1, ry, rot, flip, p->flags, last_store);
+        else                         rc = resize_draw(&conv, &post, -1, none, rot, flip, p->flags, last_store);
         if (rc) goto done;
         result = &post; result_fmt = last_store;
     } else if (!final_pass) {

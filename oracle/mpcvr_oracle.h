@@ -71,6 +71,8 @@ typedef struct orc_params {
     /* m_bDeintBlend && m_SampleFormat != PROGRESSIVE (DX11VideoProcessor.cpp:3075): the 4:2:0 convert shader variant
        with colorY = (2Y + Y(0,-1) + Y(0,+1)) / 4 (Shaders.cpp:232-237,275-280) */
     int32_t  blend_deint;
+    /* m_iRotation (0/90/180/270, clockwise) and m_bFlip (horizontal) of the first resize draw — FillVertices :130-179 */
+    int32_t  rotation, flip;
 } orc_params;
 
 void orc_params_default(orc_params *p);

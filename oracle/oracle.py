@@ -37,6 +37,7 @@ class OrcParams(C.Structure):
         ("window_w", C.c_int32), ("window_h", C.c_int32), ("video_rect", C.c_int32 * 4),
         ("flags", C.c_uint32),
         ("blend_deint", C.c_int32),
+        ("rotation", C.c_int32), ("flip", C.c_int32),
     ]
 
 

@@ -92,6 +92,20 @@ GOLDEN_CASES = {
     "p010_blend_deint_2x": dict(cformat=2, w=64, h=32, kind="noise", seed=81, dst=(128, 64), iUpscaling=4, bDeintBlend=1, sample_format=2),
     "yv12_blend_deint_progressive_sample": dict(cformat=14, w=64, h=32, kind="noise", seed=82, dst=(64, 32), bDeintBlend=1, sample_format=0),
     "yuv422p8_blend_deint_not_420": dict(cformat=18, w=64, h=32, kind="noise", seed=83, dst=(64, 32), bDeintBlend=1, sample_format=1),
+    # ---- rotation / flip of the first resize draw (FillVertices :130-179, ResizeShaderPass :3112-3137) ----
+    "rot90_copy_nv12": dict(cformat=1, w=64, h=40, kind="structure", seed=90, dst=(40, 64), rotation=90),
+    "rot180_lanczos3_2x_dither": dict(cformat=2, w=64, h=32, kind="noise", seed=91, dst=(128, 64), iUpscaling=4, rotation=180),
+    "rot270_down_hamming": dict(cformat=2, w=96, h=64, kind="structure", seed=92, dst=(20, 30), iDownscaling=2, rotation=270),
+    "rot90_same_shader_single_draw": dict(cformat=2, w=48, h=32, kind="noise", seed=93, dst=(64, 96), iUpscaling=2, rotation=90),
+    "rot90_two_pass_down_up": dict(cformat=1, w=96, h=32, kind="structure", seed=94, dst=(48, 40), iUpscaling=1, iDownscaling=5, rotation=90),
+    "rot270_one_axis_only": dict(cformat=1, w=64, h=32, kind="noise", seed=95, dst=(32, 96), iUpscaling=3, rotation=270),
+    "flip_ignored_same_rect_final_pass": dict(cformat=2, w=64, h=32, kind="structure", seed=96, dst=(64, 32), flip=1),
+    "flip_copy_no_final_pass": dict(cformat=1, w=64, h=32, kind="structure", seed=97, dst=(64, 32), flip=1),
+    "flip_offset_rect_final_pass": dict(cformat=2, w=64, h=32, kind="structure", seed=98, dst=(64, 32), window=(80, 48), offset=(8, 8), flip=1),
+    "flip_catmull_1p5x": dict(cformat=2, w=64, h=32, kind="noise", seed=99, dst=(96, 48), iUpscaling=2, flip=1),
+    "rot90_flip_mitchell": dict(cformat=1, w=64, h=48, kind="structure", seed=100, dst=(96, 80), iUpscaling=1, rotation=90, flip=1),
+    "rot180_crop_letterbox": dict(cformat=2, w=96, h=64, kind="structure", seed=101, src_rect=(16, 8, 80, 56), dst=(128, 96),
+                                  window=(200, 150), offset=(36, 27), iUpscaling=4, rotation=180),
     # ---- colour / settings ----
     "bt2020_sdr_gamma_gamut": dict(cformat=2, w=64, h=32, kind="structure", seed=40, dst=(128, 64), exfmt=ext(MPEG2, TV, M2020, P2020, T709), iUpscaling=2),
     "bt2020_gamma26": dict(cformat=2, w=64, h=32, kind="noise", seed=41, dst=(64, 32), exfmt=ext(MPEG2, TV, M2020, P2020, T26)),
@@ -139,6 +153,7 @@ def oracle_params(oracle, c):
         oracle.set_params(p, brightness=b, contrast=ct, hue=h, saturation=s)
     # m_bDeintBlend && m_SampleFormat != PROGRESSIVE (DX11VideoProcessor.cpp:3075); the 4:2:0 check is the oracle's
     oracle.set_params(p, blend_deint=int(bool(c.get("bDeintBlend", 0)) and c.get("sample_format", 0) != 0))
+    oracle.set_params(p, rotation=c.get("rotation", 0), flip=c.get("flip", 0))
     return p
 
 

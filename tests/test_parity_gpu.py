@@ -44,6 +44,10 @@ def make_vp(mpcvr, c, extra_flags=0):
         vp.SetProcAmpValues(*c["procamp"])
     if "sample_format" in c:
         vp.SetSampleFormat(c["sample_format"])
+    if "rotation" in c:
+        vp.SetRotation(c["rotation"])
+    if "flip" in c:
+        vp.SetFlip(bool(c["flip"]))
     return vp, (ww, wh)
 
 
@@ -99,6 +103,8 @@ def test_pass_per_kernel_path_vs_oracle(mpcvr, oracle, torch_cuda, name):
 
 
 def _is_exact_2x(c):
+    if c.get("rotation", 0) in (90, 270):
+        return False
     r = c.get("src_rect", (0, 0, c["w"], c["h"]))
     return c["dst"] == (2 * (r[2] - r[0]), 2 * (r[3] - r[1]))
 
@@ -266,8 +272,8 @@ def test_error_behaviour(mpcvr, torch_cuda):
     vp.CopySample(buf, 64)
     assert hr_of(lambda: vp.Process(dst, 8)) == api.E_INVALIDARG                        # RT pitch too small
     assert hr_of(lambda: vp.Process(dst, 256, src_rect=(0, 0, 32, 32))) == api.E_INVALIDARG
-    assert hr_of(lambda: vp.SetRotation(90)) == api.E_NOTIMPL
-    assert hr_of(lambda: vp.SetFlip(True)) == api.E_NOTIMPL
+    assert hr_of(lambda: vp.SetRotation(45)) == api.E_INVALIDARG
+    assert hr_of(lambda: vp.SetSampleFormat(3)) == api.E_INVALIDARG
     assert hr_of(lambda: vp.Configure(vp.settings.copy(iSDRDisplayNits=5))) == api.E_INVALIDARG
     assert hr_of(lambda: vp.Configure(vp.settings.copy(iUpscaling=api.UPSCALE_Jinc2)) or vp.Process(dst, 256, dst_rect=(0, 0, 16, 16))) == api.E_NOTIMPL
     vp.close()

@@ -211,8 +211,8 @@ HRESULT CHipVideoProcessor::SetWindowRect(const CRect &r)
 
 HRESULT CHipVideoProcessor::SetRotation(int value)
 {
-    if (value != 0) return Fail(MPCVR_E_NOTIMPL, "rotation is not implemented in this build");
-    m_iRotation = 0;
+    if (value != 0 && value != 90 && value != 180 && value != 270) return Fail(MPCVR_E_INVALIDARG, "rotation must be 0, 90, 180 or 270");
+    if (value != m_iRotation) { m_iRotation = value; m_planDirty = true; }
     return MPCVR_S_OK;
 }
 
@@ -225,8 +225,7 @@ HRESULT CHipVideoProcessor::SetSampleFormat(int frameFormat)
 
 HRESULT CHipVideoProcessor::SetFlip(bool value)
 {
-    if (value) return Fail(MPCVR_E_NOTIMPL, "flip is not implemented in this build");
-    m_bFlip = false;
+    if (value != m_bFlip) { m_bFlip = value; m_planDirty = true; }
     return MPCVR_S_OK;
 }
 
@@ -304,7 +303,7 @@ HRESULT CHipVideoProcessor::UpdatePlan()
     const int w2 = m_videoRect.Width(), h2 = m_videoRect.Height();
     {
         const PlanGeometry g{w1, h1, m_videoRect.left, m_videoRect.top, m_videoRect.right, m_videoRect.bottom,
-                             m_windowRect.Width(), m_windowRect.Height()};
+                             m_windowRect.Width(), m_windowRect.Height(), m_iRotation, m_bFlip ? 1 : 0};
         std::string why;
         if (!DecidePlan(m_cfg.iTexFormat, m_cfg.iChromaScaling, m_cfg.iUpscaling, m_cfg.iDownscaling,
                         m_cfg.bInterpolateAt50pct, m_cfg.bUseDither, m_cfg.output_format, m_cfg.flags,
@@ -319,30 +318,48 @@ HRESULT CHipVideoProcessor::UpdatePlan()
 
     HostAxisTaps hx, hy;
     std::vector<int32_t> ox, oy;
-    if (m_plan.two_pass) {
-        // m_TexResize: fp16, dst width x src height (:3143-3160)
-        if ((hr = CheckHip(m_TexResize.CheckCreate((size_t)w2 * 8 * h1), "m_TexResize"))) return hr;
-        if (!BuildAxisTaps(m_plan.rx, 0, w1, w2, w1, m_cfg.flags, &hx) ||
-            !BuildAxisTaps(m_plan.ry, 0, h1, h2, h1, m_cfg.flags, &hy))
-            return Fail(MPCVR_E_NOTIMPL, "resize ratio outside the supported range");
-        BuildPointIndex(0, h1, h1, h1, &ox);     // X pass: rows map 1:1
-        BuildPointIndex(0, w2, w2, w2, &oy);     // Y pass: columns map 1:1
-        if ((hr = UploadTaps(hx, m_tapsXi, m_tapsXw, m_tapsXs, &m_tapsX))) return hr;
-        if ((hr = UploadTaps(hy, m_tapsYi, m_tapsYw, m_tapsYs, &m_tapsY))) return hr;
-        if ((hr = UploadIndex(ox, m_otherX))) return hr;
-        if ((hr = UploadIndex(oy, m_otherY))) return hr;
-    } else if (m_plan.one_pass) {
-        if (m_plan.one_pass_axis == 0) {
-            if (!BuildAxisTaps(m_plan.rx, 0, w1, w2, w1, m_cfg.flags, &hx)) return Fail(MPCVR_E_NOTIMPL, "resize ratio outside the supported range");
-            BuildPointIndex(0, h1, h2, h1, &ox);
-            if ((hr = UploadTaps(hx, m_tapsXi, m_tapsXw, m_tapsXs, &m_tapsX))) return hr;
-            if ((hr = UploadIndex(ox, m_otherX))) return hr;
+    if (m_plan.two_pass || m_plan.one_pass) {
+        // The rotation-carrying draw (TextureResizeShader / TextureCopyRect with FillVertices' rotation and flip,
+        // :130-179): which texture coordinate runs along which screen axis, and in which direction
+        //     rot   0: U = l + a(r-l)  V = t + b(bm-t)      rot  90: U = l + b(r-l)  V = bm - a(bm-t)
+        //     rot 180: U = r - a(r-l)  V = bm - b(bm-t)     rot 270: U = r - b(r-l)  V = t + a(bm-t)     flip: l <-> r
+        const int rot = m_plan.rotation;
+        const bool swap = rot == 90 || rot == 270;
+        const int tax = swap ? 1 : 0;                               // texture axis run through by screen x
+        bool rev_u = rot == 180 || rot == 270;
+        const bool rev_v = rot == 90 || rot == 180;
+        if (m_plan.flip) rev_u = !rev_u;
+        const bool rev_x = tax == 0 ? rev_u : rev_v, rev_y = tax == 0 ? rev_v : rev_u;
+        const int len_x = tax == 0 ? w1 : h1, len_y = tax == 0 ? h1 : w1;       // extent of the convert output along x / y
+        const int outW = w2, outH = m_plan.two_pass ? m_plan.mid_h : h2;
+        const int a = m_plan.first_tex_axis;
+        // scale[AXIS] as TextureResizeShader sets it: srcRect/dstRect of the same-named screen dimension (:351-354)
+        const float cscale = a == 0 ? (float)w1 / (float)outW : (float)h1 / (float)outH;
+        const bool taps_on_x = (a < 0) || (tax == a);               // ps_simple: a 1-tap table along x
+        const Resizer rs = a < 0 ? Resizer{RS_NONE, 0} : m_plan.first_rs;
+        bool ok;
+        if (taps_on_x) {
+            ok = BuildAxisTaps(rs, 0, len_x, outW, len_x, m_cfg.flags, &hx, rev_x, a < 0 ? 0.0f : cscale);
+            BuildPointIndex(0, len_y, outH, len_y, &ox, rev_y);
         } else {
-            if (!BuildAxisTaps(m_plan.ry, 0, h1, h2, h1, m_cfg.flags, &hy)) return Fail(MPCVR_E_NOTIMPL, "resize ratio outside the supported range");
-            BuildPointIndex(0, w1, w2, w1, &oy);
-            if ((hr = UploadTaps(hy, m_tapsYi, m_tapsYw, m_tapsYs, &m_tapsY))) return hr;
-            if ((hr = UploadIndex(oy, m_otherY))) return hr;
+            ok = BuildAxisTaps(rs, 0, len_y, outH, len_y, m_cfg.flags, &hx, rev_y, cscale);
+            BuildPointIndex(0, len_x, outW, len_x, &ox, rev_x);
         }
+        if (!ok) return Fail(MPCVR_E_NOTIMPL, "resize ratio outside the supported range");
+        m_firstAxis = taps_on_x ? 0 : 1;
+        m_firstSwap = swap;
+        if ((hr = UploadTaps(hx, m_tapsXi, m_tapsXw, m_tapsXs, &m_tapsX))) return hr;
+        if ((hr = UploadIndex(ox, m_otherX))) return hr;
+    }
+    if (m_plan.two_pass) {
+        // m_TexResize: fp16, dst width x (source extent along screen y) (:3143-3160); the second draw is unrotated
+        const int mh = m_plan.mid_h;
+        if ((hr = CheckHip(m_TexResize.CheckCreate((size_t)w2 * 8 * mh), "m_TexResize"))) return hr;
+        if (!BuildAxisTaps(m_plan.ry, 0, mh, h2, mh, m_cfg.flags, &hy))
+            return Fail(MPCVR_E_NOTIMPL, "resize ratio outside the supported range");
+        BuildPointIndex(0, w2, w2, w2, &oy);     // Y pass: columns map 1:1
+        if ((hr = UploadTaps(hy, m_tapsYi, m_tapsYw, m_tapsYs, &m_tapsY))) return hr;
+        if ((hr = UploadIndex(oy, m_otherY))) return hr;
     }
 
     if (m_plan.fused_up2x) {
@@ -505,16 +522,13 @@ HRESULT CHipVideoProcessor::ResizeShaderPass(void *rt, int rtPitch)
     const StoreParams last = MakeStore(rt, rtPitch, m_plan.swap_fmt, true);
     HRESULT hr;
     if (m_plan.two_pass) {
-        Surface mid{m_TexResize.ptr, w2 * 8, w2, h1, SF_RGBA16F};
+        Surface mid{m_TexResize.ptr, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
         StoreParams st = MakeStore(mid.ptr, mid.pitch, SF_RGBA16F, false);
-        if ((hr = CheckHip(LaunchResize(0, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, h1, st, m_stream), "k_resize<X>"))) return hr;
-        return CheckHip(LaunchResize(1, mid, m_tapsY, (const int32_t *)m_otherY.ptr, w2, h2, last, m_stream), "k_resize<Y>");
+        if ((hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, m_plan.mid_h, st, m_stream), "k_resize<first>"))) return hr;
+        return CheckHip(LaunchResize(1, false, mid, m_tapsY, (const int32_t *)m_otherY.ptr, w2, h2, last, m_stream), "k_resize<Y>");
     }
-    if (m_plan.one_pass) {
-        if (m_plan.one_pass_axis == 0)
-            return CheckHip(LaunchResize(0, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, h2, last, m_stream), "k_resize<X>");
-        return CheckHip(LaunchResize(1, conv, m_tapsY, (const int32_t *)m_otherY.ptr, w2, h2, last, m_stream), "k_resize<Y>");
-    }
+    if (m_plan.one_pass)
+        return CheckHip(LaunchResize(m_firstAxis, m_firstSwap, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, h2, last, m_stream), "k_resize<one>");
     return CheckHip(LaunchCopy(conv, w2, h2, last, m_stream), "k_copy");
 }
 

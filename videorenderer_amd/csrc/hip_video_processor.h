@@ -106,6 +106,8 @@ private:
     int m_iRotation = 0;
     bool m_bFlip = false;
     int m_SampleFormat = 0;        // 0 progressive, 1 TFF, 2 BFF
+    int m_firstAxis = 0;           // screen axis the first draw's tap table runs along
+    bool m_firstSwap = false;      // rotation 90/270: taps address the other texture axis
 
     // input
     const FmtConvParams *m_srcParams = nullptr;

@@ -21,7 +21,9 @@ __global__ __launch_bounds__(256) void k_convert(ConvertParams P, Surface out)
 
 // TextureResizeShader — DX11VideoProcessor.cpp:332-377 with ps_interpolation_* / ps_convolution.
 // AXIS = filtered axis; `other` maps the unfiltered output coordinate to a source texel (point sample).
-template <int AXIS>
+// AXIS = SCREEN axis the tap table is indexed by; SWAP (rotation 90/270, FillVertices :130-179): the taps address texture
+// rows when they run along screen x (and columns along screen y).
+template <int AXIS, bool SWAP>
 __global__ __launch_bounds__(256) void k_resize(Surface in, AxisTaps taps, const int32_t *__restrict__ other,
                                                int out_w, int out_h, StoreParams st)
 {
@@ -31,13 +33,14 @@ __global__ __launch_bounds__(256) void k_resize(Surface in, AxisTaps taps, const
     const int o = other[AXIS == 0 ? y : x];
     const int32_t *idx = taps.idx + (size_t)f * taps.ntaps;
     const float *w = taps.w + (size_t)f * taps.ntaps;
+    constexpr bool TAPS_ON_TEX_X = (AXIS == 0) != SWAP;
     f3 acc;
     {
-        const f3 q = AXIS == 0 ? load_surface(in, idx[0], o) : load_surface(in, o, idx[0]);
+        const f3 q = TAPS_ON_TEX_X ? load_surface(in, idx[0], o) : load_surface(in, o, idx[0]);
         acc.x = w[0] * q.x; acc.y = w[0] * q.y; acc.z = w[0] * q.z;
     }
     for (int k = 1; k < taps.ntaps; k++) {
-        const f3 q = AXIS == 0 ? load_surface(in, idx[k], o) : load_surface(in, o, idx[k]);
+        const f3 q = TAPS_ON_TEX_X ? load_surface(in, idx[k], o) : load_surface(in, o, idx[k]);
         acc.x = acc.x + w[k] * q.x; acc.y = acc.y + w[k] * q.y; acc.z = acc.z + w[k] * q.z;
     }
     if (taps.normalise) {
@@ -100,13 +103,14 @@ hipError_t LaunchConvert(const ConvertParams &P, const Surface &out, hipStream_t
     return hipGetLastError();
 }
 
-hipError_t LaunchResize(int axis, const Surface &in, const AxisTaps &taps, const int32_t *other,
+hipError_t LaunchResize(int axis, bool swap, const Surface &in, const AxisTaps &taps, const int32_t *other,
                         int out_w, int out_h, const StoreParams &st, hipStream_t s)
 {
-    if (axis == 0)
-        hipLaunchKernelGGL(k_resize<0>, grid2d(out_w, out_h), dim3(64, 4, 1), 0, s, in, taps, other, out_w, out_h, st);
-    else
-        hipLaunchKernelGGL(k_resize<1>, grid2d(out_w, out_h), dim3(64, 4, 1), 0, s, in, taps, other, out_w, out_h, st);
+    const dim3 g = grid2d(out_w, out_h), b(64, 4, 1);
+    if (axis == 0 && !swap) hipLaunchKernelGGL((k_resize<0, false>), g, b, 0, s, in, taps, other, out_w, out_h, st);
+    else if (axis == 0)     hipLaunchKernelGGL((k_resize<0, true>), g, b, 0, s, in, taps, other, out_w, out_h, st);
+    else if (!swap)         hipLaunchKernelGGL((k_resize<1, false>), g, b, 0, s, in, taps, other, out_w, out_h, st);
+    else                    hipLaunchKernelGGL((k_resize<1, true>), g, b, 0, s, in, taps, other, out_w, out_h, st);
     return hipGetLastError();
 }
 

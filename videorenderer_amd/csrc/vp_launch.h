@@ -10,7 +10,8 @@ namespace mpcvr {
 hipError_t LaunchConvert(const ConvertParams &P, const Surface &out, hipStream_t s);
 // CopyFrameV210 (Helper.cpp:709-748): v210 sample -> Y210-layout texture
 hipError_t LaunchRepackV210(const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int lines, hipStream_t s);
-hipError_t LaunchResize(int axis, const Surface &in, const AxisTaps &taps, const int32_t *other,
+// axis = screen axis the tap table runs along; swap = rotation 90/270 (taps address the other texture axis)
+hipError_t LaunchResize(int axis, bool swap, const Surface &in, const AxisTaps &taps, const int32_t *other,
                         int out_w, int out_h, const StoreParams &st, hipStream_t s);
 hipError_t LaunchCopy(const Surface &in, int out_w, int out_h, const StoreParams &st, hipStream_t s);
 

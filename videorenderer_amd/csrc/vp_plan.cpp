@@ -412,11 +412,19 @@ float DownscaleFilter(int method, float x, float *support)
 static inline int ClampI(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // Tex[AXIS]*wh[AXIS] of output i: src_l + (i + 0.5) * srcLen/dstLen, scale as in the cbuffer (:353)
-static inline float AxisCenter(int src_l, int i, float scale) { return (float)src_l + ((float)i + 0.5f) * scale; }
-
-bool BuildAxisTaps(Resizer rs, int src_l, int src_len, int n_out, int tex_len, uint32_t flags, HostAxisTaps *out)
+// Tex[AXIS]*wh[AXIS] of output i: the rasteriser's interpolation of the quad's texture coordinates; `rev` = the
+// coordinate starts at the far edge of the source range (rotation / flip, FillVertices :130-179)
+static inline float AxisCenterDir(int src_l, int src_len, int i, float step, bool rev)
 {
-    const float scale = (float)src_len / (float)n_out;
+    return rev ? (float)(src_l + src_len) - ((float)i + 0.5f) * step : (float)src_l + ((float)i + 0.5f) * step;
+}
+
+bool BuildAxisTaps(Resizer rs, int src_l, int src_len, int n_out, int tex_len, uint32_t flags, HostAxisTaps *out,
+                   bool reversed, float shader_scale)
+{
+    const float step = (float)src_len / (float)n_out;
+    const float scale = shader_scale > 0.0f ? shader_scale : step;     // scale[AXIS] of ps_convolution
+    auto AxisCenter = [&](int l, int i, float) { return AxisCenterDir(l, src_len, i, step, reversed); };
     out->idx.clear(); out->w.clear(); out->wsum.clear();
     out->normalise = 0;
     if (rs.kind == RS_NONE) {
@@ -484,12 +492,12 @@ bool BuildAxisTaps(Resizer rs, int src_l, int src_len, int n_out, int tex_len, u
     return true;
 }
 
-void BuildPointIndex(int src_l, int src_len, int n_out, int tex_len, std::vector<int32_t> *out)
+void BuildPointIndex(int src_l, int src_len, int n_out, int tex_len, std::vector<int32_t> *out, bool reversed)
 {
     const float scale = (float)src_len / (float)n_out;
     out->resize(n_out);
     for (int i = 0; i < n_out; i++)
-        (*out)[i] = ClampI((int)std::floor(AxisCenter(src_l, i, scale)), 0, tex_len - 1);
+        (*out)[i] = ClampI((int)std::floor(AxisCenterDir(src_l, src_len, i, scale, reversed)), 0, tex_len - 1);
 }
 
 bool DecidePlan(int iTexFormat, int iChromaScaling, int iUpscaling, int iDownscaling, int bInterpolateAt50pct,
@@ -509,21 +517,38 @@ bool DecidePlan(int iTexFormat, int iChromaScaling, int iUpscaling, int iDownsca
     p.final_pass = bUseDither && needDither;
     p.quant = p.swap_fmt == SF_RGB10A2 ? 1023 : 255;
 
-    const int w1 = g.w1, h1 = g.h1, w2 = g.vr - g.vl, h2 = g.vb - g.vt;
+    const int w2 = g.vr - g.vl, h2 = g.vb - g.vt;
+    if (g.rotation != 0 && g.rotation != 90 && g.rotation != 180 && g.rotation != 270) { if (why) *why = "rotation must be 0, 90, 180 or 270"; return false; }
+    p.rotation = g.rotation; p.flip = g.flip != 0;
+    const bool rotated = g.rotation == 90 || g.rotation == 270;
+    const int w1 = rotated ? g.h1 : g.w1, h1 = rotated ? g.w1 : g.h1;                     // :3112-3123
     const int k = bInterpolateAt50pct ? 2 : 1;                                            // :3108
     if (iUpscaling == MPCVR_UPSCALE_Jinc2) { if (why) *why = "Jinc2 upscaler is not implemented"; return false; }
     const Resizer up{iUpscaling == MPCVR_UPSCALE_Nearest ? RS_NONE : RS_UP, iUpscaling};
     const Resizer down{RS_DOWN, iDownscaling};
     const Resizer none{RS_NONE, 0};
-    p.rx = (w1 == w2) ? none : (w1 > k * w2) ? down : up;                                 // :3125-3126
+    p.rx = (w1 == w2) ? none : (w1 > k * w2) ? down : up;                                 // :3125-3126 (screen x)
     p.ry = (h1 == h2) ? none : (h1 > k * h2) ? down : up;
-    p.two_pass = p.rx.kind != RS_NONE && p.ry.kind != RS_NONE;
-    p.one_pass = !p.two_pass && (w1 != w2 || h1 != h2);
-    if (p.one_pass) p.one_pass_axis = (p.rx.kind != RS_NONE || (p.ry.kind == RS_NONE && w1 != w2)) ? 0 : 1;
+    // rotated: resizerX and (when it exists) resizerY are both Y shaders; equal shader objects => ONE draw (:3131-3137)
+    const bool same_shader = rotated && p.rx.kind != RS_NONE && p.rx.kind == p.ry.kind;
+    p.two_pass = p.rx.kind != RS_NONE && p.ry.kind != RS_NONE && !same_shader;
+    // Process :3348-3352: with a final pass the resize step is skipped only when rSrc == dstRect and rotation == 0 (a
+    // flip alone is then ignored); without post-scale steps ResizeShaderPass always runs (:3417-3419)
+    const bool same_rect = g.w1 == w2 && g.h1 == h2 && g.vl == 0 && g.vt == 0;
+    const bool need_draw = w1 != w2 || h1 != h2 || g.rotation != 0 || (p.flip && !(p.final_pass && same_rect));
+    p.one_pass = !p.two_pass && need_draw;
+    p.mid_h = h1;
+    if (p.two_pass) { p.first_tex_axis = rotated ? 1 : 0; p.first_rs = p.rx; }
+    else if (p.one_pass) {
+        if (p.rx.kind != RS_NONE) { p.first_tex_axis = rotated ? 1 : 0; p.first_rs = p.rx; }
+        else if (p.ry.kind != RS_NONE) { p.first_tex_axis = rotated ? 0 : 1; p.first_rs = p.ry; }
+        else { p.first_tex_axis = -1; p.first_rs = none; }
+        p.one_pass_axis = (p.rx.kind != RS_NONE || p.ry.kind == RS_NONE) ? 0 : 1;       // screen axis carrying the taps
+    }
     p.copy_only = !p.two_pass && !p.one_pass;
     // fused 2x candidate: exact 2x on both axes with an interpolation shader, bilinear 4:2:0 chroma,
     // UNORM internal format, destination fully inside the window
-    p.fused_up2x = !(flags & MPCVR_FLAG_NO_FUSED) && p.two_pass && w2 == 2 * w1 && h2 == 2 * h1 &&
+    p.fused_up2x = !(flags & MPCVR_FLAG_NO_FUSED) && g.rotation == 0 && !p.flip && p.two_pass && w2 == 2 * w1 && h2 == 2 * h1 &&
                    p.rx.kind == RS_UP && p.ry.kind == RS_UP && f.Subsampling == 420 &&
                    iChromaScaling == MPCVR_CHROMA_Bilinear && p.internal_fmt != SF_RGBA16F &&
                    g.vl >= 0 && g.vt >= 0 && g.vr <= g.ww && g.vb <= g.wh && w1 >= 8 && h1 >= 8 && !(w1 & 1);
@@ -538,6 +563,8 @@ std::string PassPlan::describe() const
     if (two_pass) s += final_pass ? ",resizeX,resizeY+final" : ",resizeX,resizeY";
     else if (one_pass) s += std::string(one_pass_axis == 0 ? ",resizeX" : ",resizeY") + (final_pass ? "+final" : "");
     else s += final_pass ? ",final" : ",copy";
+    if (rotation) s += ";rot" + std::to_string(rotation);
+    if (flip) s += ";flip";
     return s;
 }
 

@@ -81,10 +81,13 @@ int UpscaleWeights(int iUpscaling, float t, float w[6]);
 float DownscaleFilter(int iDownscaling, float x, float *support);
 // tap table for n_out outputs of one TextureResizeShader draw along one axis
 // (DX11VideoProcessor.cpp:332-377 + the shader bodies).  Returns false if unsupported.
+// reversed: the texture coordinate runs from the far edge of the source range backwards (rotation / flip,
+// FillVertices :130-179); shader_scale: the constant scale[AXIS] ps_convolution sees (0 => src_len / n_out; a rotated
+// draw is handed the ratio of the other screen dimension, :351-354).
 bool BuildAxisTaps(Resizer rs, int src_l, int src_len, int n_out, int tex_len, uint32_t flags,
-                   HostAxisTaps *out);
+                   HostAxisTaps *out, bool reversed = false, float shader_scale = 0.0f);
 // nearest / identity index map of the unfiltered axis of a draw
-void BuildPointIndex(int src_l, int src_len, int n_out, int tex_len, std::vector<int32_t> *out);
+void BuildPointIndex(int src_l, int src_len, int n_out, int tex_len, std::vector<int32_t> *out, bool reversed = false);
 
 // ---- the pass plan of one Process() (DX11VideoProcessor.cpp:3285-3424, shader path) ----
 struct PassPlan {
@@ -98,12 +101,19 @@ struct PassPlan {
     int one_pass_axis = 0;
     bool copy_only = false;          // no size change: straight copy / final pass from the convert output
     bool fused_up2x = false;         // eligible for the fused 2x kernel
+    // rotation-carrying (first) draw — FillVertices :130-179, ResizeShaderPass :3112-3137
+    int rotation = 0;                // 0/90/180/270 clockwise
+    bool flip = false;               // horizontal flip of the source
+    int first_tex_axis = -1;         // texture axis the first draw filters: 0 = X shaders, 1 = Y shaders, -1 = ps_simple
+    Resizer first_rs{RS_NONE, 0};
+    int mid_h = 0;                   // height of m_TexResize in the two-pass case (srcRect extent along screen y)
     std::string describe() const;
 };
 
 struct PlanGeometry { int w1, h1;            // source rect size (== convert output)
                       int vl, vt, vr, vb;    // video rect
-                      int ww, wh; };         // window size
+                      int ww, wh;            // window size
+                      int rotation = 0; int flip = 0; };
 // Pure decision logic of UpdateTexParams / UpdatePostScaleTexures / ResizeShaderPass (no device work).
 // cfg fields use the Settings_t names; returns false + *why when the combination is not implemented.
 struct mpcvr_settings_fwd;
