@@ -50,6 +50,8 @@ enum mpcvr_cformat {
     MPCVR_CF_YUV422P10 = 22, MPCVR_CF_YUV422P16 = 23,
     MPCVR_CF_YUV444P10 = 24, MPCVR_CF_YUV444P16 = 25,
     MPCVR_CF_GBRP8 = 26, MPCVR_CF_GBRP10 = 27, MPCVR_CF_GBRP16 = 28,
+    MPCVR_CF_RGB24 = 29, MPCVR_CF_XRGB32 = 30, MPCVR_CF_ARGB32 = 31, MPCVR_CF_r210 = 32,
+    MPCVR_CF_RGB48 = 33, MPCVR_CF_BGR48 = 34, MPCVR_CF_BGRA64 = 35, MPCVR_CF_B64A = 36,
     MPCVR_CF_Y8 = 37, MPCVR_CF_Y10 = 38, MPCVR_CF_Y16 = 39
 };
 

@@ -103,9 +103,11 @@ typedef struct {
     int cstype;        /* CST_*: ColorSystem_t (Helper.h:129-133) */
     int ci[4];         /* packed 4:2:2: texel components holding Y0,U,Y1,V (Shaders.cpp:195-229);
                           packed 4:4:4: components holding Y,U,V after the .zyxw/.yxzw swizzle (:186-193) */
-    int bits10;        /* texel is one R10G10B10A2 dword (Y410) */
+    int bits10;        /* texel is one R10G10B10A2 dword (Y410, r210) */
+    int repack;        /* RPK_*: GetCopyPlaneFunction (Helper.cpp:377-412) for the interleaved RGB formats */
 } fmt_info;
-enum { LAY_PLANAR = 0, LAY_PACKED422 = 1, LAY_PACKED444 = 2, LAY_GRAY = 3 };
+enum { LAY_PLANAR = 0, LAY_PACKED422 = 1, LAY_PACKED444 = 2, LAY_GRAY = 3, LAY_RGB = 4 };
+enum { RPK_NONE = 0, RPK_RGB24, RPK_R210, RPK_RGB48, RPK_BGR48, RPK_BGRA64, RPK_B64A };
 enum { CST_YUV = 0, CST_RGB = 1, CST_GRAY = 2 };
 
 static const fmt_info s_fmts[] = {
@@ -144,6 +146,15 @@ static const fmt_info s_fmts[] = {
     {ORC_CF_Y8,        1, 1, 1, 1, 1, 2, 400,  8, 0, 0, LAY_GRAY, CST_GRAY},
     {ORC_CF_Y10,       1, 2, 1, 1, 2, 2, 400, 10, 6, 0, LAY_GRAY, CST_GRAY},
     {ORC_CF_Y16,       1, 2, 1, 1, 2, 2, 400, 16, 0, 0, LAY_GRAY, CST_GRAY},
+    /* interleaved RGB (Helper.cpp:345-354): texture B8G8R8X8 / R10G10B10A2 / R16G16B16A16; ci = texel components of R,G,B */
+    {ORC_CF_RGB24,     1, 1, 1, 1, 3, 2, 444,  8, 0, 0, LAY_RGB, CST_RGB, {2, 1, 0, 3}, 0, RPK_RGB24},
+    {ORC_CF_XRGB32,    1, 1, 1, 1, 4, 2, 444,  8, 0, 0, LAY_RGB, CST_RGB, {2, 1, 0, 3}, 0, RPK_NONE},
+    {ORC_CF_ARGB32,    1, 1, 1, 1, 4, 2, 444,  8, 0, 0, LAY_RGB, CST_RGB, {2, 1, 0, 3}, 0, RPK_NONE},
+    {ORC_CF_r210,      1, 4, 1, 1, 4, 2, 444, 10, 0, 0, LAY_RGB, CST_RGB, {0, 1, 2, 3}, 1, RPK_R210},
+    {ORC_CF_RGB48,     1, 2, 1, 1, 6, 2, 444, 16, 0, 0, LAY_RGB, CST_RGB, {0, 1, 2, 3}, 0, RPK_RGB48},
+    {ORC_CF_BGR48,     1, 2, 1, 1, 6, 2, 444, 16, 0, 0, LAY_RGB, CST_RGB, {0, 1, 2, 3}, 0, RPK_BGR48},
+    {ORC_CF_BGRA64,    1, 2, 1, 1, 8, 2, 444, 16, 0, 0, LAY_RGB, CST_RGB, {0, 1, 2, 3}, 0, RPK_BGRA64},
+    {ORC_CF_B64A,      1, 2, 1, 1, 8, 2, 444, 16, 0, 0, LAY_RGB, CST_RGB, {0, 1, 2, 3}, 0, RPK_B64A},
 };
 static const fmt_info *find_fmt(int cf)
 {
@@ -158,7 +169,8 @@ size_t orc_frame_bytes(int cformat, int width, int height, int *pitch_out)
     const fmt_info *f = find_fmt(cformat);
     if (!f) return 0;
     int pitch = width * f->packsize;
-    if (cformat == ORC_CF_NV12 || cformat == ORC_CF_Y8) pitch = (pitch + 3) & ~3;   /* ALIGN(m_srcPitch, 4) :1792-1796 */
+    if (cformat == ORC_CF_NV12 || cformat == ORC_CF_Y8 || cformat == ORC_CF_RGB24 || cformat == ORC_CF_BGR48)
+        pitch = (pitch + 3) & ~3;                                                     /* ALIGN(m_srcPitch, 4) :1792-1796 */
     if (cformat == ORC_CF_V210) pitch = (((width + 5) / 6 * 16) + 127) & ~127;        /* :1798-1799 */
     if (pitch_out) *pitch_out = pitch;
     return (size_t)pitch * (size_t)(height * f->pitch_coeff / 2);   /* m_srcLines */
@@ -292,7 +304,7 @@ int orc_color_matrix(const orc_params *p, float out[12])
     float hue = (float)(p->hue / 180 * acos(-1));                        /* :841 */
     float m[9], c[3];
     orc_csp_matrix(space, levels, f->cdepth, brightness, contrast, hue, p->saturation, f->cstype == CST_GRAY, m, c);
-    if (f->cstype == CST_RGB && f->layout == LAY_PLANAR) {     /* GBRP: (x,y,z) -> (y,z,x) per row, :863-867 */
+    if (f->cstype == CST_RGB && f->layout == LAY_PLANAR && f->planes == 3) {     /* GBRP: (x,y,z) -> (y,z,x) per row, :863-867 */
         for (int i = 0; i < 3; i++) { float x = m[3 * i], y = m[3 * i + 1], z = m[3 * i + 2]; m[3 * i] = y; m[3 * i + 1] = z; m[3 * i + 2] = x; }
     } else if (f->cstype == CST_GRAY) {                        /* :868-873 */
         m[3] = m[4]; m[4] = 0;
@@ -763,6 +775,10 @@ static void fetch_pixel(const src_tex *s, int chroma_loc, int chroma_scaling, in
         yuv[0] = load_luma(s, sx, sy); yuv[1] = 0; yuv[2] = 0;
         return;
     }
+    if (f->layout == LAY_RGB) {            /* float4 color = tex.Sample(samp, Tex) (:184): (R,G,B) of the texture */
+        yuv[0] = load_packed(s, sx, sy, f->ci[0]); yuv[1] = load_packed(s, sx, sy, f->ci[1]); yuv[2] = load_packed(s, sx, sy, f->ci[2]);
+        return;
+    }
     if (f->layout == LAY_PACKED444) {      /* .zyxw (AYUV) / .yxzw (Y410, Y416) (:186-193) */
         yuv[0] = load_packed(s, sx, sy, f->ci[0]); yuv[1] = load_packed(s, sx, sy, f->ci[1]); yuv[2] = load_packed(s, sx, sy, f->ci[2]);
         return;
@@ -813,6 +829,84 @@ void orc_repack_v210(int lines, uint8_t *dst, int dst_pitch, const uint8_t *src,
         }
     }
 }
+/* CopyPlaneAsIs / CopyFrameRGB24 / CopyFrameR210 / CopyFrameRGB48 / CopyFrameBGR48 / CopyFrameBGRA64 / CopyFrameB64A —
+ * Helper.cpp:414-428,444-482,548-566,600-707,770-787 restated line by line (src_pitch may be negative: bottom-up DIB) */
+void orc_repack_rgb(int kind, int lines, uint8_t *dst, int dst_pitch, const uint8_t *src, int src_pitch)
+{
+    const int ap = src_pitch < 0 ? -src_pitch : src_pitch;
+    for (int y = 0; y < lines; y++, src += src_pitch, dst += dst_pitch) {
+        if (kind == RPK_NONE) {
+            memcpy(dst, src, (size_t)(ap < dst_pitch ? ap : dst_pitch));
+        } else if (kind == RPK_RGB24) {
+            const unsigned line_pixels = (unsigned)ap / 3, line_pixels4 = line_pixels & ~3u;
+            const uint32_t *src32 = (const uint32_t *)src; uint32_t *dst32 = (uint32_t *)dst;
+            unsigned i = 0;
+            for (; i < line_pixels4; i += 4) {
+                uint32_t sa = *src32++, sb = *src32++, sc = *src32++;
+                *dst32++ = sa; *dst32++ = (sa >> 24) | (sb << 8); *dst32++ = (sb >> 16) | (sc << 16); *dst32++ = sc >> 8;
+            }
+            if (i < line_pixels) {
+                if (line_pixels & 1) { *dst32 = *src32; }
+                else { uint32_t sa = *src32++, sb = *src32; *dst32++ = sa; *dst32 = (sa >> 24) | (sb << 8); }
+            }
+        } else if (kind == RPK_R210) {
+            const unsigned line_pixels = (unsigned)ap / 4;
+            const uint32_t *src32 = (const uint32_t *)src; uint32_t *dst32 = (uint32_t *)dst;
+            for (unsigned i = 0; i < line_pixels; i++) {
+                const uint32_t t = src32[i];
+                uint32_t r = ((t & 0x0000003f) << 4) | ((t & 0x0000f000) >> 12);
+                uint32_t g = ((t & 0x00fc0000) >> 8) | ((t & 0x00000f00) << 8);
+                uint32_t b = ((t & 0xff000000) >> 4) | ((t & 0x00030000) << 12);
+                dst32[i] = r | g | b;
+            }
+        } else if (kind == RPK_RGB48) {
+            const unsigned line_pixels = (unsigned)ap / 6, line_pixels4 = line_pixels & ~3u;
+            const uint64_t *src64 = (const uint64_t *)src; uint64_t *dst64 = (uint64_t *)dst;
+            for (unsigned i = 0; i < line_pixels4; i += 4) {      /* no remainder handling, as written (:552-563) */
+                uint64_t sa = src64[0], sb = src64[1], sc = src64[2];
+                dst64[i + 0] = sa; dst64[i + 1] = (sa >> 48) | (sb << 16); dst64[i + 2] = (sb >> 32) | (sc << 32); dst64[i + 3] = sc >> 16;
+                src64 += 3;
+            }
+        } else if (kind == RPK_BGR48) {
+            const unsigned line_pixels = (unsigned)ap / 6, line_pixels4 = line_pixels & ~3u;
+            const uint64_t *src64 = (const uint64_t *)src; uint64_t *dst64 = (uint64_t *)dst;
+            unsigned i = 0;
+            for (; i < line_pixels4; i += 4) {
+                uint64_t sa = *src64++, sb = *src64++, sc = *src64++;
+                *dst64++ = ((sa & 0xffff) << 32) | (sa & 0xffff0000) | ((sa & 0xffff00000000) >> 32);
+                *dst64++ = ((sa & 0xffff000000000000) >> 16) | ((sb & 0xffff) << 16) | ((sb & 0xffff0000) >> 16);
+                *dst64++ = (sb & 0xffff00000000) | ((sb & 0xffff000000000000) >> 32) | (sc & 0xffff);
+                *dst64++ = ((sc & 0xffff0000) << 16) | ((sc & 0xffff00000000) >> 16) | ((sc & 0xffff000000000000) >> 48);
+            }
+            const unsigned remainder = line_pixels - i;
+            if (remainder) {
+                uint64_t sa = *src64++;
+                *dst64++ = ((sa & 0xffff) << 32) | (sa & 0xffff0000) | ((sa & 0xffff00000000) >> 32);
+                if (remainder == 2) {
+                    uint64_t sb = *(const uint32_t *)src64;
+                    *dst64 = ((sa & 0xffff000000000000) >> 16) | ((sb & 0xffff) << 16) | ((sb & 0xffff0000) >> 16);
+                } else if (remainder == 3) {
+                    uint64_t sb = *src64++;
+                    uint64_t sc = *(const uint32_t *)src64;
+                    *dst64++ = ((sa & 0xffff000000000000) >> 16) | ((sb & 0xffff) << 16) | ((sb & 0xffff0000) >> 16);
+                    *dst64 = (sb & 0xffff00000000) | ((sb & 0xffff000000000000) >> 32) | (sc & 0xffff);
+                }
+            }
+        } else if (kind == RPK_BGRA64) {
+            const unsigned line_pixels = (unsigned)ap / 8;
+            const uint64_t *src64 = (const uint64_t *)src; uint64_t *dst64 = (uint64_t *)dst;
+            for (unsigned i = 0; i < line_pixels; i++)
+                dst64[i] = ((src64[i] & 0x000000000000ffffULL) << 32) | ((src64[i] & 0x0000ffff00000000ULL) >> 32) | (src64[i] & 0xffff0000ffff0000ULL);
+        } else if (kind == RPK_B64A) {
+            const unsigned line_pixels = (unsigned)ap / 8;
+            const uint64_t *src64 = (const uint64_t *)src; uint64_t *dst64 = (uint64_t *)dst;
+            for (unsigned i = 0; i < line_pixels; i++)
+                dst64[i] = ((src64[i] & 0xFF00FF00FF000000ULL) >> 24) + ((src64[i] & 0x00FF00FF00FF0000ULL) >> 8) +
+                           ((src64[i] & 0x000000000000FF00ULL) << 40) + ((src64[i] & 0x00000000000000FFULL) << 56);
+        }
+    }
+}
+
 /* pitch of the Y210 texture the v210 sample is unpacked into.  The reference uses the driver's mapped pitch of a
    (W/2) x H R16G16B16A16 texture (>= 4W bytes, typically 256-aligned); the stand-in here is 4W rounded up to whole
    12-byte groups, so every pixel of the row is converted exactly as with any larger driver pitch. */
@@ -820,7 +914,8 @@ int orc_v210_tex_pitch(int width) { return (4 * width + 11) / 12 * 12; }
 
 typedef struct {
     src_tex tex;
-    void *owned;       /* unpacked v210 */
+    void *owned;       /* unpacked v210 / the RGB texture the sample was copied into */
+    int enable;        /* m_PSConvColorData.bEnable (DX11VideoProcessor.cpp:849-853) */
     int rect[4];
     uint32_t exfmt;
     float cm[12];
@@ -831,7 +926,7 @@ typedef struct {
 static int setup_convert(const orc_params *p, const uint8_t *src, int src_pitch, convert_ctx *c)
 {
     const fmt_info *f = find_fmt(p->cformat);
-    if (!f || src_pitch <= 0) return -1;
+    if (!f || src_pitch == 0 || (src_pitch < 0 && f->layout != LAY_RGB)) return -1;
     if ((f->div_w == 2 && (p->width & 1)) || (f->div_h == 2 && (p->height & 1))) return -2;
     memset(c, 0, sizeof(*c));
     resolve_rect(p, c->rect);
@@ -842,6 +937,20 @@ static int setup_convert(const orc_params *p, const uint8_t *src, int src_pitch,
         uint8_t *t = (uint8_t *)calloc((size_t)tp * p->height + 16, 1);
         if (!t) return -4;
         orc_repack_v210(p->height, t, tp, src, src_pitch);
+        c->owned = t; src = t; src_pitch = tp;
+    }
+    if (f->layout == LAY_RGB) {
+        /* MemCopyToTexSrcVideo :1243-1248: a bottom-up DIB (negative pitch) is walked from its last row */
+        /* texture row: `width` texels; widened when the sample's pitch makes the reference loops copy more pixels per
+           row than that (they land in the padding of the mapped row) */
+        const int tbpp = f->bits10 ? 4 : 4 * f->bytes;
+        const int apitch = src_pitch < 0 ? -src_pitch : src_pitch;
+        const int row_px = apitch / f->packsize + 1 > p->width ? apitch / f->packsize + 1 : p->width;
+        const int tp = row_px * tbpp;
+        uint8_t *t = (uint8_t *)calloc((size_t)tp * p->height + 16, 1);
+        if (!t) return -4;
+        const uint8_t *s0 = (src_pitch < 0) ? src + (ptrdiff_t)src_pitch * (1 - p->height) : src;
+        orc_repack_rgb(f->repack, p->height, t, tp, s0, src_pitch);
         c->owned = t; src = t; src_pitch = tp;
     }
     c->tex.f = f; c->tex.w = p->width; c->tex.h = p->height;
@@ -855,6 +964,9 @@ static int setup_convert(const orc_params *p, const uint8_t *src, int src_pitch,
     if (orc_color_matrix(p, c->cm)) { free(c->owned); c->owned = NULL; return -1; }
     c->lum_scale = orc_luminance_scale(p->iSDRDisplayNits);
     c->internal_fmt = internal_format(p->iTexFormat, f->cdepth);
+    /* :849-853 — interleaved RGB skips the convert draw unless brightness / contrast are set */
+    c->enable = f->cstype == CST_YUV || (f->cstype == CST_RGB && f->planes == 3) || f->cstype == CST_GRAY ||
+                fabsf(p->brightness / 255) > 1e-4f || fabsf(p->contrast - 1.0f) > 1e-4f;
     return 0;
 }
 
@@ -980,8 +1092,11 @@ int orc_axis_taps(int kind, int method, int src_l, int src_len, int n_out, int t
  * tex_axis = texture axis the pixel shader filters (0 = X shaders, 1 = Y shaders, -1 = ps_simple); the other
  * coordinate is point-sampled.  The shader constant scale[AXIS] is srcRect/dstRect of the SAME-NAMED screen dimension
  * (:351-354) whatever the rotation, so a rotated ps_convolution draw runs with the other dimension's ratio — as written. */
-static int resize_draw(const img_t *in, img_t *out, int tex_axis, resizer_t rs, int rot, int flip, uint32_t flags, int store)
+static int resize_draw(const img_t *in, const int rect[4], img_t *out, int tex_axis, resizer_t rs, int rot, int flip, uint32_t flags, int store)
 {
+    const int whole[4] = {0, 0, in->w, in->h};
+    if (!rect) rect = whole;
+    const int rw = rect[2] - rect[0], rh = rect[3] - rect[1];
     const int swap = (rot == 90 || rot == 270);
     /* texture axis and direction along screen x and screen y */
     const int tax = swap ? 1 : 0, tay = swap ? 0 : 1;
@@ -989,21 +1104,23 @@ static int resize_draw(const img_t *in, img_t *out, int tex_axis, resizer_t rs, 
     const int rev_v = (rot == 90 || rot == 180);
     if (flip) rev_u = !rev_u;
     const int rev_x = tax == 0 ? rev_u : rev_v, rev_y = tay == 0 ? rev_u : rev_v;
-    const int len_x = tax == 0 ? in->w : in->h, len_y = tay == 0 ? in->w : in->h;   /* srcRect extent run through by x / y */
+    const int len_x = tax == 0 ? rw : rh, len_y = tay == 0 ? rw : rh;               /* srcRect extent run through by x / y */
+    const int org_x = tax == 0 ? rect[0] : rect[1], org_y = tay == 0 ? rect[0] : rect[1];
+    const int tex_x = tax == 0 ? in->w : in->h, tex_y = tay == 0 ? in->w : in->h;   /* clamp range = whole texture */
     const float step_x = (float)len_x / (float)out->w, step_y = (float)len_y / (float)out->h;
-    const float cscale = tex_axis == 0 ? (float)in->w / (float)out->w : (float)in->h / (float)out->h;   /* scale[AXIS] */
+    const float cscale = tex_axis == 0 ? (float)rw / (float)out->w : (float)rh / (float)out->h;   /* scale[AXIS] */
     const resizer_t none = {RS_NONE, 0};
 
     taps_t *tx = (taps_t *)malloc(sizeof(taps_t) * (size_t)out->w);
     taps_t *ty = (taps_t *)malloc(sizeof(taps_t) * (size_t)out->h);
     if (!tx || !ty) { free(tx); free(ty); return -1; }
     for (int i = 0; i < out->w; i++) {
-        const float c = rev_x ? (float)len_x - ((float)i + 0.5f) * step_x : axis_center(0, i, step_x);
-        if (build_taps_at(tax == tex_axis ? rs : none, c, cscale, len_x, flags, &tx[i])) { free(tx); free(ty); return -2; }
+        const float c = rev_x ? (float)(org_x + len_x) - ((float)i + 0.5f) * step_x : axis_center(org_x, i, step_x);
+        if (build_taps_at(tax == tex_axis ? rs : none, c, cscale, tex_x, flags, &tx[i])) { free(tx); free(ty); return -2; }
     }
     for (int i = 0; i < out->h; i++) {
-        const float c = rev_y ? (float)len_y - ((float)i + 0.5f) * step_y : axis_center(0, i, step_y);
-        if (build_taps_at(tay == tex_axis ? rs : none, c, cscale, len_y, flags, &ty[i])) { free(tx); free(ty); return -2; }
+        const float c = rev_y ? (float)(org_y + len_y) - ((float)i + 0.5f) * step_y : axis_center(org_y, i, step_y);
+        if (build_taps_at(tay == tex_axis ? rs : none, c, cscale, tex_y, flags, &ty[i])) { free(tx); free(ty); return -2; }
     }
     const int filt_x = (tax == tex_axis);      /* taps run along screen x; otherwise along screen y (or nowhere) */
     ORC_PAR_FOR
@@ -1082,9 +1199,22 @@ int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
     const float quant = (swap_fmt == FMT_RGB10A2) ? 1023.0f : 255.0f;     /* ps_final_pass QUANTIZATION */
 
     /* ConvertColorPass -> m_TexConvertOutput (w1 x h1, internal format); rSrc = whole texture :3316-3319 */
+    /* with the convert draw disabled (interleaved RGB, default brightness/contrast) the source texture itself feeds
+       the resize with rSrc = srcRect (:3321-3323) */
     img_t conv = {0}, mid = {0}, post = {0};
-    if (img_alloc(&conv, w1, h1)) { free(c.owned); return -5; }
-    convert_pass(p, &c, &conv);
+    const int *srect = c.enable ? NULL : c.rect;
+    if (c.enable) {
+        if (img_alloc(&conv, w1, h1)) { free(c.owned); return -5; }
+        convert_pass(p, &c, &conv);
+    } else {
+        if (img_alloc(&conv, p->width, p->height)) { free(c.owned); return -5; }
+        for (int y = 0; y < p->height; y++)
+            for (int x = 0; x < p->width; x++) {
+                float *q = conv.p + ((size_t)y * p->width + x) * 4, v[3];
+                fetch_pixel(&c.tex, 0, 0, 0, x, y, v);
+                q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = 1.0f;
+            }
+    }
 
     /* ResizeShaderPass :3103-3187 — pick per-axis shader */
     const int k = p->bInterpolateAt50pct ? 2 : 1;
@@ -1114,22 +1244,25 @@ int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
     if (rx.kind != RS_NONE && ry.kind != RS_NONE && !(rotated && rx.kind == ry.kind)) {
         /* two passes through fp16 m_TexResize (w2 x sh) :3143-3167; the second one is unrotated */
         if (img_alloc(&mid, w2, sh) || img_alloc(&post, w2, h2)) { rc = -5; goto done; }
-        if ((rc = resize_draw(&conv, &mid, ax_first, rx, rot, flip, p->flags, FMT_RGBA16F))) goto done;
-        if ((rc = resize_draw(&mid, &post, 1, ry, 0, 0, p->flags, last_store))) goto done;
+        if ((rc = resize_draw(&conv, srect, &mid, ax_first, rx, rot, flip, p->flags, FMT_RGBA16F))) goto done;
+        if ((rc = resize_draw(&mid, NULL, &post, 1, ry, 0, 0, p->flags, last_store))) goto done;
         result = &post; result_fmt = last_store;
     } else if (rx.kind != RS_NONE || ry.kind != RS_NONE || sw != w2 || sh != h2 || rot != 0 || (flip && !(final_pass && same_rect))) {
         /* one draw: one filtered axis (resizerX == resizerY for a rotated frame scaled the same way on both axes:
            :3131-3137 draws once, so only texture Y is filtered), or ps_simple (:3169-3181) */
         if (img_alloc(&post, w2, h2)) { rc = -5; goto done; }
-        if (rx.kind != RS_NONE)      rc = resize_draw(&conv, &post, ax_first, rx, rot, flip, p->flags, last_store);
-        else if (ry.kind != RS_NONE) rc = resize_draw(&conv, &post, rotated ? 0 : 1, ry, rot, flip, p->flags, last_store);
-        else                         rc = resize_draw(&conv, &post, -1, none, rot, flip, p->flags, last_store);
+        if (rx.kind != RS_NONE)      rc = resize_draw(&conv, srect, &post, ax_first, rx, rot, flip, p->flags, last_store);
+        else if (ry.kind != RS_NONE) rc = resize_draw(&conv, srect, &post, rotated ? 0 : 1, ry, rot, flip, p->flags, last_store);
+        else                         rc = resize_draw(&conv, srect, &post, -1, none, rot, flip, p->flags, last_store);
         if (rc) goto done;
         result = &post; result_fmt = last_store;
     } else if (!final_pass) {
         /* TextureCopyRect with ps_simple into the render target :3178-3181 */
         if (img_alloc(&post, w2, h2)) { rc = -5; goto done; }
-        for (size_t i = 0; i < (size_t)w2 * h2; i++) store_fmt(swap_fmt, conv.p + i * 4, post.p + i * 4);
+        for (int y = 0; y < h2; y++)
+            for (int x = 0; x < w2; x++)
+                store_fmt(swap_fmt, conv.p + ((size_t)(y + (srect ? srect[1] : 0)) * conv.w + x + (srect ? srect[0] : 0)) * 4,
+                          post.p + ((size_t)y * w2 + x) * 4);
         result = &post; result_fmt = swap_fmt;
     }
     (void)result_fmt;
@@ -1142,7 +1275,9 @@ int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
         for (int x = 0; x < w2; x++) {
             int wx = dl + x;
             if (wx < 0 || wx >= p->window_w) continue;
-            const float *q = result->p + ((size_t)y * w2 + x) * 4;
+            /* the final pass reads the source texture itself when nothing was drawn before it (pTex = pInputTexture :3352) */
+            const int ox = (result == &conv && srect) ? srect[0] : 0, oy = (result == &conv && srect) ? srect[1] : 0;
+            const float *q = result->p + ((size_t)(y + oy) * result->w + (x + ox)) * 4;
             float v[4] = {q[0], q[1], q[2], q[3]};
             if (final_pass) {
                 /* sampler WRAP+POINT, ditherCoordScale = texSize/32 => texel (wx mod 32, wy mod 32) */

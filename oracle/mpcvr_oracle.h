@@ -37,6 +37,8 @@ enum {
     ORC_CF_YUV422P10 = 22, ORC_CF_YUV422P16 = 23,
     ORC_CF_YUV444P10 = 24, ORC_CF_YUV444P16 = 25,
     ORC_CF_GBRP8 = 26, ORC_CF_GBRP10 = 27, ORC_CF_GBRP16 = 28,
+    ORC_CF_RGB24 = 29, ORC_CF_XRGB32 = 30, ORC_CF_ARGB32 = 31, ORC_CF_r210 = 32,
+    ORC_CF_RGB48 = 33, ORC_CF_BGR48 = 34, ORC_CF_BGRA64 = 35, ORC_CF_B64A = 36,
     ORC_CF_Y8 = 37, ORC_CF_Y10 = 38, ORC_CF_Y16 = 39
 };
 
@@ -121,6 +123,9 @@ size_t orc_frame_bytes(int cformat, int width, int height, int *pitch_out);
 /* CopyFrameV210 (Helper.cpp:709-748) and the pitch of the Y210 texture it fills */
 void orc_repack_v210(int lines, uint8_t *dst, int dst_pitch, const uint8_t *src, int src_pitch);
 int orc_v210_tex_pitch(int width);
+/* the CopyFrame* functions of the interleaved RGB formats (Helper.cpp:414-707,770-787); kind = RPK_* of the oracle's
+ * format table: 0 as-is, 1 RGB24, 2 r210, 3 RGB48, 4 BGR48, 5 BGRA64, 6 b64a; src_pitch < 0 = bottom-up */
+void orc_repack_rgb(int kind, int lines, uint8_t *dst, int dst_pitch, const uint8_t *src, int src_pitch);
 
 /* Whole Process() on the shader path — DX11VideoProcessor.cpp:3285-3424.
  * src: the media-sample bytes (planes back to back, MemCopyToTexSrcVideo layout :1213-1252), src_pitch >0.

@@ -21,7 +21,8 @@ CF = dict(NV12=1, P010=2, P016=3, P210=6, P216=7, YV12=14, YV16=15, YV24=16,
           YUV420P8=17, YUV422P8=18, YUV444P8=19, YUV420P10=20, YUV420P16=21,
           YUV422P10=22, YUV422P16=23, YUV444P10=24, YUV444P16=25,
           YUY2=4, UYVY=5, Y210=8, Y216=9, V210=10, AYUV=11, Y410=12, Y416=13,
-          GBRP8=26, GBRP10=27, GBRP16=28, Y8=37, Y10=38, Y16=39)
+          GBRP8=26, GBRP10=27, GBRP16=28, Y8=37, Y10=38, Y16=39,
+          RGB24=29, XRGB32=30, ARGB32=31, r210=32, RGB48=33, BGR48=34, BGRA64=35, B64A=36)
 
 
 class OrcParams(C.Structure):

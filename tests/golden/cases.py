@@ -87,6 +87,21 @@ GOLDEN_CASES = {
     "y8_gray_2x": dict(cformat=37, w=62, h=32, kind="structure", seed=73, dst=(124, 64), iUpscaling=4),
     "y10_gray_tv_matrix": dict(cformat=38, w=48, h=32, kind="noise", seed=74, dst=(48, 32), exfmt=ext(0, TV, M709)),
     "y16_gray_crop": dict(cformat=39, w=64, h=48, kind="structure", seed=75, src_rect=(8, 4, 56, 44), dst=(96, 80), iUpscaling=1),
+    # ---- interleaved RGB: no convert draw unless brightness/contrast are set; bottom-up DIBs ----
+    "rgb24_same_size": dict(cformat=29, w=46, h=20, kind="noise", seed=110, dst=(46, 20)),
+    "rgb32_catmull_2x": dict(cformat=30, w=48, h=32, kind="structure", seed=111, dst=(96, 64), iUpscaling=2),
+    "argb32_bottom_up_down": dict(cformat=31, w=96, h=64, kind="structure", seed=112, dst=(40, 28), iDownscaling=2, bottom_up=1),
+    "rgb24_bottom_up_procamp": dict(cformat=29, w=48, h=32, kind="noise", seed=113, dst=(48, 32), procamp=(15.0, 1.2, 40.0, 0.5), bottom_up=1),
+    "rgb32_crop_offset_lanczos3": dict(cformat=30, w=96, h=64, kind="structure", seed=114, src_rect=(16, 8, 80, 56), dst=(128, 96),
+                                       window=(200, 150), offset=(36, 27), iUpscaling=4),
+    "r210_2x_dither": dict(cformat=32, w=48, h=32, kind="noise", seed=115, dst=(96, 64), iUpscaling=4),
+    "r210_same_size_final_pass_on_source": dict(cformat=32, w=48, h=32, kind="structure", seed=116, src_rect=(8, 4, 40, 28), dst=(32, 24)),
+    "rgb48_2x": dict(cformat=33, w=48, h=32, kind="noise", seed=117, dst=(96, 64), iUpscaling=1),
+    "rgb48_width_not_multiple_of_4": dict(cformat=33, w=46, h=16, kind="structure", seed=118, dst=(46, 16)),
+    "bgr48_ragged_same_size": dict(cformat=34, w=46, h=16, kind="noise", seed=119, dst=(46, 16)),
+    "bgra64_rot90": dict(cformat=35, w=48, h=32, kind="structure", seed=120, dst=(32, 48), rotation=90),
+    "b64a_procamp_contrast": dict(cformat=36, w=48, h=32, kind="noise", seed=121, dst=(72, 48), iUpscaling=2, procamp=(0.0, 0.8, 0.0, 1.0)),
+    "rgb32_hue_only_stays_unconverted": dict(cformat=30, w=48, h=32, kind="noise", seed=122, dst=(48, 32), procamp=(0.0, 1.0, 90.0, 0.3)),
     # ---- blend deinterlace (bDeintBlend on interlaced 4:2:0 samples) ----
     "nv12_blend_deint": dict(cformat=1, w=64, h=32, kind="structure", seed=80, dst=(64, 32), bDeintBlend=1, sample_format=1),
     "p010_blend_deint_2x": dict(cformat=2, w=64, h=32, kind="noise", seed=81, dst=(128, 64), iUpscaling=4, bDeintBlend=1, sample_format=2),
@@ -137,8 +152,12 @@ def case_geometry(c):
 
 
 def case_frame(c):
-    return synth.make_frame(c["cformat"], c["w"], c["h"], c["kind"], seed=c["seed"], pitch=c.get("pitch"),
-                            full_range=c.get("full_range", False))
+    frame, pitch = synth.make_frame(c["cformat"], c["w"], c["h"], c["kind"], seed=c["seed"], pitch=c.get("pitch"),
+                                    full_range=c.get("full_range", False))
+    if c.get("bottom_up"):       # BI_RGB with biHeight > 0: rows stored last-first, negative pitch (:1801-1803)
+        frame = np.ascontiguousarray(frame.reshape(c["h"], pitch)[::-1]).reshape(-1)
+        pitch = -pitch
+    return frame, pitch
 
 
 def oracle_params(oracle, c):

@@ -21,7 +21,8 @@ def bits(v):
 def test_color_matrix_matches_oracle_bit_exact(mpcvr, oracle):
     rng = np.random.default_rng(11)
     from videorenderer_amd import api
-    for cf in (1, 2, 3, 6, 14, 16, 17, 19, 20, 21, 22, 24, 25, 4, 5, 8, 9, 10, 11, 12, 13, 26, 27, 28, 37, 38, 39):
+    for cf in (1, 2, 3, 6, 14, 16, 17, 19, 20, 21, 22, 24, 25, 4, 5, 8, 9, 10, 11, 12, 13, 26, 27, 28, 37, 38, 39,
+               29, 30, 32, 33, 36):
         for it in range(24):
             ex = oracle.make_extfmt(chroma=int(rng.choice([0, 1, 5, 7])), nominal_range=int(rng.choice([0, 1, 2])),
                                     matrix=int(rng.choice([0, 1, 2, 3, 4, 7])), primaries=int(rng.choice([0, 2, 9])),
@@ -122,8 +123,10 @@ def test_frame_layout(mpcvr, oracle):
     assert api.plan_frame_layout(10, 1280, 720) == (3456 * 720, 3456)
     assert api.plan_frame_layout(37, 62, 32) == (64 * 32, 64)                    # Y8: ALIGN(W, 4)
     assert api.plan_frame_layout(26, 64, 32) == (64 * 32 * 3, 64)                # GBRP8: three full planes
+    assert api.plan_frame_layout(29, 46, 20) == (140 * 20, 140)                  # RGB24: ALIGN(3W, 4)
+    assert api.plan_frame_layout(34, 45, 8) == (272 * 8, 272)                    # BGR48: ALIGN(6W, 4)
     with pytest.raises(api.MpcvrError):
-        api.plan_frame_layout(29, 64, 64)         # RGB24: not in this build
+        api.plan_frame_layout(40, 64, 64)         # no such ColorFormat_t
 
 
 def test_pq_lut(mpcvr, oracle):

@@ -37,7 +37,10 @@ def make_vp(mpcvr, c, extra_flags=0):
         kw["bDeintBlend"] = c["bDeintBlend"]
     vp = api.VideoProcessor(api.default_settings(**kw))
     (ww, wh), vr = case_geometry(c)
-    vp.InitMediaType(c["cformat"], c["w"], c["h"], pitch=c.get("pitch", 0), src_rect=c.get("src_rect"), extfmt=c.get("exfmt", 0))
+    pitch = c.get("pitch", 0)
+    if c.get("bottom_up"):
+        pitch = -api.plan_frame_layout(c["cformat"], c["w"], c["h"])[1]
+    vp.InitMediaType(c["cformat"], c["w"], c["h"], pitch=pitch, src_rect=c.get("src_rect"), extfmt=c.get("exfmt", 0))
     vp.SetWindowRect((0, 0, ww, wh))
     vp.SetVideoRect(vr)
     if "procamp" in c:
@@ -54,7 +57,7 @@ def make_vp(mpcvr, c, extra_flags=0):
 def run_product(mpcvr, torch, c, extra_flags=0, host_upload=False):
     vp, (ww, wh) = make_vp(mpcvr, c, extra_flags)
     frame, pitch = case_frame(c)
-    assert vp.GetFrameBytes() == (frame.size, pitch)
+    assert vp.GetFrameBytes() == (frame.size, abs(pitch))
     dst = torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda")
     if host_upload:
         vp.CopySample(frame, pitch)
@@ -259,7 +262,8 @@ def test_error_behaviour(mpcvr, torch_cuda):
         return e.value.hr
 
     assert hr_of(lambda: vp.Process(dst, 64)) == api.E_NOT_VALID_STATE                  # no media type yet
-    assert hr_of(lambda: vp.InitMediaType(29, 64, 64)) == api.E_NOTIMPL                 # RGB24 not in this build
+    assert hr_of(lambda: vp.InitMediaType(40, 64, 64)) == api.E_NOTIMPL                 # no such ColorFormat_t
+    assert hr_of(lambda: vp.InitMediaType(1, 64, 64, pitch=-64)) == api.E_INVALIDARG    # bottom-up is an RGB notion
     assert hr_of(lambda: vp.InitMediaType(4, 63, 64)) == api.E_INVALIDARG               # odd width, packed 4:2:2
     assert hr_of(lambda: vp.InitMediaType(10, 60, 64, pitch=96)) == api.E_INVALIDARG    # v210 row needs 10 groups of 16 bytes
     assert hr_of(lambda: vp.InitMediaType(1, 63, 64)) == api.E_INVALIDARG               # odd width, 4:2:0

@@ -28,6 +28,7 @@ CF_P210, CF_P216 = 6, 7
 CF_Y210, CF_Y216, CF_V210, CF_AYUV, CF_Y410, CF_Y416 = 8, 9, 10, 11, 12, 13
 CF_GBRP8, CF_GBRP10, CF_GBRP16 = 26, 27, 28
 CF_Y8, CF_Y10, CF_Y16 = 37, 38, 39
+CF_RGB24, CF_XRGB32, CF_ARGB32, CF_r210, CF_RGB48, CF_BGR48, CF_BGRA64, CF_B64A = 29, 30, 31, 32, 33, 34, 35, 36
 CF_YV12, CF_YV16, CF_YV24 = 14, 15, 16
 CF_YUV420P8, CF_YUV422P8, CF_YUV444P8 = 17, 18, 19
 CF_YUV420P10, CF_YUV420P16, CF_YUV422P10, CF_YUV422P16, CF_YUV444P10, CF_YUV444P16 = 20, 21, 22, 23, 24, 25

@@ -152,6 +152,12 @@ HRESULT CHipVideoProcessor::InitMediaType(int cformat, int width, int height, in
         return Fail(MPCVR_E_INVALIDARG, "subsampled formats need even dimensions");
     const int defPitch = DefaultPitch(*f, width);
     if (pitch == 0) pitch = defPitch;
+    // a bottom-up RGB DIB arrives with a negative pitch (BI_RGB && biHeight > 0 => m_srcPitch = -m_srcPitch, :1801-1803)
+    bool bottomUp = false;
+    if (pitch < 0) {
+        if (f->layout != LAY_RGB) return Fail(MPCVR_E_INVALIDARG, "a negative pitch (bottom-up) is only defined for the RGB formats");
+        bottomUp = true; pitch = -pitch;
+    }
     if (pitch < width * f->Packsize) return Fail(MPCVR_E_INVALIDARG, "pitch smaller than a row");
     if (f->cformat == MPCVR_CF_V210 && (pitch < (width + 5) / 6 * 16 || (pitch & 3)))
         return Fail(MPCVR_E_INVALIDARG, "v210 pitch smaller than a row of 16-byte groups");
@@ -165,6 +171,7 @@ HRESULT CHipVideoProcessor::InitMediaType(int cformat, int width, int height, in
     m_srcParams = f;
     m_srcWidth = width; m_srcHeight = height;
     m_srcPitch = pitch;
+    m_srcBottomUp = bottomUp;
     m_srcLines = SourceLines(*f, height);
     m_srcRect = r;
     m_srcRectWidth = r.Width(); m_srcRectHeight = r.Height();
@@ -303,7 +310,8 @@ HRESULT CHipVideoProcessor::UpdatePlan()
     const int w2 = m_videoRect.Width(), h2 = m_videoRect.Height();
     {
         const PlanGeometry g{w1, h1, m_videoRect.left, m_videoRect.top, m_videoRect.right, m_videoRect.bottom,
-                             m_windowRect.Width(), m_windowRect.Height(), m_iRotation, m_bFlip ? 1 : 0};
+                             m_windowRect.Width(), m_windowRect.Height(), m_iRotation, m_bFlip ? 1 : 0,
+                             ConvertEnabled() ? 1 : 0};
         std::string why;
         if (!DecidePlan(m_cfg.iTexFormat, m_cfg.iChromaScaling, m_cfg.iUpscaling, m_cfg.iDownscaling,
                         m_cfg.bInterpolateAt50pct, m_cfg.bUseDither, m_cfg.output_format, m_cfg.flags,
@@ -330,7 +338,14 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         const bool rev_v = rot == 90 || rot == 180;
         if (m_plan.flip) rev_u = !rev_u;
         const bool rev_x = tax == 0 ? rev_u : rev_v, rev_y = tax == 0 ? rev_v : rev_u;
-        const int len_x = tax == 0 ? w1 : h1, len_y = tax == 0 ? h1 : w1;       // extent of the convert output along x / y
+        const int len_x = tax == 0 ? w1 : h1, len_y = tax == 0 ? h1 : w1;       // extent of the source rect along x / y
+        // source of the draw: the convert output (rect at the origin) or, with the convert draw disabled, the source
+        // texture itself with rSrc = srcRect (:3321-3323); clamp addressing covers the whole texture
+        const bool fromTex = !m_plan.convert;
+        const int ol = fromTex ? m_srcRect.left : 0, ot = fromTex ? m_srcRect.top : 0;
+        const int tw = fromTex ? m_srcWidth : w1, th = fromTex ? m_srcHeight : h1;
+        const int org_x = tax == 0 ? ol : ot, org_y = tax == 0 ? ot : ol;
+        const int tex_x = tax == 0 ? tw : th, tex_y = tax == 0 ? th : tw;
         const int outW = w2, outH = m_plan.two_pass ? m_plan.mid_h : h2;
         const int a = m_plan.first_tex_axis;
         // scale[AXIS] as TextureResizeShader sets it: srcRect/dstRect of the same-named screen dimension (:351-354)
@@ -339,11 +354,11 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         const Resizer rs = a < 0 ? Resizer{RS_NONE, 0} : m_plan.first_rs;
         bool ok;
         if (taps_on_x) {
-            ok = BuildAxisTaps(rs, 0, len_x, outW, len_x, m_cfg.flags, &hx, rev_x, a < 0 ? 0.0f : cscale);
-            BuildPointIndex(0, len_y, outH, len_y, &ox, rev_y);
+            ok = BuildAxisTaps(rs, org_x, len_x, outW, tex_x, m_cfg.flags, &hx, rev_x, a < 0 ? 0.0f : cscale);
+            BuildPointIndex(org_y, len_y, outH, tex_y, &ox, rev_y);
         } else {
-            ok = BuildAxisTaps(rs, 0, len_y, outH, len_y, m_cfg.flags, &hx, rev_y, cscale);
-            BuildPointIndex(0, len_x, outW, len_x, &ox, rev_x);
+            ok = BuildAxisTaps(rs, org_y, len_y, outH, tex_y, m_cfg.flags, &hx, rev_y, cscale);
+            BuildPointIndex(org_x, len_x, outW, tex_x, &ox, rev_x);
         }
         if (!ok) return Fail(MPCVR_E_NOTIMPL, "resize ratio outside the supported range");
         m_firstAxis = taps_on_x ? 0 : 1;
@@ -389,19 +404,43 @@ HRESULT CHipVideoProcessor::UpdatePlan()
     return MPCVR_S_OK;
 }
 
+// m_PSConvColorData.bEnable — DX11VideoProcessor.cpp:849-853: interleaved RGB skips the convert draw unless brightness
+// or contrast are set (hue / saturation do not count)
+bool CHipVideoProcessor::ConvertEnabled() const
+{
+    const FmtConvParams &f = *m_srcParams;
+    if (f.CSType == CST_YUV || f.CSType == CST_GRAY || (f.CSType == CST_RGB && f.planes == 3)) return true;
+    return std::fabs(m_procAmp.brightness / 255) > 1e-4f || std::fabs(m_procAmp.contrast - 1.0f) > 1e-4f;
+}
+
 int CHipVideoProcessor::TexPitch() const
 {
-    return (m_srcParams && m_srcParams->cformat == MPCVR_CF_V210) ? V210TexPitch(m_srcWidth) : m_srcPitch;
+    if (!m_srcParams) return m_srcPitch;
+    if (m_srcParams->cformat == MPCVR_CF_V210) return V210TexPitch(m_srcWidth);
+    if (m_srcParams->layout == LAY_RGB) return m_srcWidth * (m_srcParams->bits10 ? 4 : 4 * m_srcParams->bytes);
+    return m_srcPitch;
 }
+
+// format of the texture an interleaved RGB sample is copied into (Helper.cpp:345-354)
+static int RgbTexFmt(const FmtConvParams &f) { return f.bits10 ? SF_RGB10A2 : (f.bytes == 2 ? SF_RGBA16 : SF_BGRA8); }
 
 // GetCopyPlaneFunction (Helper.cpp:377-412): every format handled here is copied as is (the <<6 of CopyPlane10to16 is
 // applied when a texel is loaded) except v210, which CopyFrameV210 unpacks into a Y210 texture.
 HRESULT CHipVideoProcessor::PrepareSample(const uint8_t *dev_sample, const uint8_t **tex)
 {
-    if (m_srcParams->cformat != MPCVR_CF_V210) { *tex = dev_sample; return MPCVR_S_OK; }
+    if (m_srcParams->cformat != MPCVR_CF_V210 && m_srcParams->layout != LAY_RGB) { *tex = dev_sample; return MPCVR_S_OK; }
     const int tp = TexPitch();
     HRESULT hr;
+    const bool fresh = m_TexSrcVideo.size < (size_t)tp * m_srcHeight || !m_TexSrcVideo.ptr;
     if ((hr = CheckHip(m_TexSrcVideo.CheckCreate((size_t)tp * m_srcHeight), "m_TexSrcVideo"))) return hr;
+    if (m_srcParams->layout == LAY_RGB) {
+        // texels the reference's copy loop never writes (RGB48 remainder) stay zero
+        if (fresh && (hr = CheckHip(hipMemsetAsync(m_TexSrcVideo.ptr, 0, (size_t)tp * m_srcHeight, m_stream), "clear texture"))) return hr;
+        if ((hr = CheckHip(LaunchRepackRgb(m_srcParams->repack, dev_sample, m_srcBottomUp ? -m_srcPitch : m_srcPitch,
+                                           (uint8_t *)m_TexSrcVideo.ptr, tp, m_srcWidth, m_srcHeight, m_stream), "k_repack_rgb"))) return hr;
+        *tex = (const uint8_t *)m_TexSrcVideo.ptr;
+        return MPCVR_S_OK;
+    }
     if ((hr = CheckHip(LaunchRepackV210(dev_sample, m_srcPitch, (uint8_t *)m_TexSrcVideo.ptr, tp, m_srcHeight, m_stream), "k_repack_v210"))) return hr;
     *tex = (const uint8_t *)m_TexSrcVideo.ptr;
     return MPCVR_S_OK;
@@ -481,7 +520,7 @@ HRESULT CHipVideoProcessor::CopySample(const void *data, int pitch, int memKind)
 {
     if (!m_bInit || !m_srcParams) return Fail(MPCVR_E_NOT_VALID_STATE, "InitMediaType has not been called");
     if (!data) return Fail(MPCVR_E_POINTER, "null sample");
-    if (pitch != m_srcPitch) return Fail(MPCVR_E_UNEXPECTED, "sample pitch differs from the media type");   // :2545
+    if (pitch != (m_srcBottomUp ? -m_srcPitch : m_srcPitch)) return Fail(MPCVR_E_UNEXPECTED, "sample pitch differs from the media type");   // :2545
     (void)hipSetDevice(m_device);
     const size_t bytes = (size_t)m_srcPitch * m_srcLines;
     HRESULT hr;
@@ -489,7 +528,7 @@ HRESULT CHipVideoProcessor::CopySample(const void *data, int pitch, int memKind)
         return PrepareSample((const uint8_t *)data, &m_curSample);
     }
     if (memKind != MPCVR_MEM_HOST) return Fail(MPCVR_E_INVALIDARG, "mem_kind");
-    const bool v210 = m_srcParams->cformat == MPCVR_CF_V210;
+    const bool v210 = m_srcParams->cformat == MPCVR_CF_V210 || m_srcParams->layout == LAY_RGB;   // formats with an unpack step
     DevBuffer &upload = v210 ? m_TexRaw : m_TexSrcVideo;
     if ((hr = CheckHip(upload.CheckCreate(bytes), "upload buffer"))) return hr;
     if (m_pinnedSize < bytes) {
@@ -515,10 +554,12 @@ HRESULT CHipVideoProcessor::ConvertColorPass(const uint8_t *sample)
 }
 
 // ResizeShaderPass (:3103-3187) with FinalPass (:3189-3233) folded into the epilogue of the last draw
-HRESULT CHipVideoProcessor::ResizeShaderPass(void *rt, int rtPitch)
+HRESULT CHipVideoProcessor::ResizeShaderPass(void *rt, int rtPitch, const uint8_t *sample)
 {
     const int w1 = m_srcRectWidth, h1 = m_srcRectHeight, w2 = m_videoRect.Width(), h2 = m_videoRect.Height();
     Surface conv{m_TexConvertOutput.ptr, (int)(w1 * SurfBytesPerPixel(m_plan.internal_fmt)), w1, h1, m_plan.internal_fmt};
+    if (!m_plan.convert)      // pInputTexture = &m_TexSrcVideo (:3321-3323)
+        conv = Surface{(void *)sample, TexPitch(), m_srcWidth, m_srcHeight, RgbTexFmt(*m_srcParams)};
     const StoreParams last = MakeStore(rt, rtPitch, m_plan.swap_fmt, true);
     HRESULT hr;
     if (m_plan.two_pass) {
@@ -529,6 +570,14 @@ HRESULT CHipVideoProcessor::ResizeShaderPass(void *rt, int rtPitch)
     }
     if (m_plan.one_pass)
         return CheckHip(LaunchResize(m_firstAxis, m_firstSwap, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, h2, last, m_stream), "k_resize<one>");
+    if (!m_plan.convert) {    // the final pass reads the source rect of the texture (pTex = pInputTexture, :3352)
+        const int bpp = conv.fmt == SF_RGBA16 ? 8 : 4;
+        conv.ptr = (uint8_t *)conv.ptr + (size_t)m_srcRect.top * conv.pitch + (size_t)m_srcRect.left * bpp;
+        conv.w = w1; conv.h = h1;
+        StoreParams direct = last;
+        direct.mid_fmt = conv.fmt;       // nothing was drawn into m_TexsPostScale: the final pass sees the texture's own precision
+        return CheckHip(LaunchCopy(conv, w2, h2, direct, m_stream), "k_copy");
+    }
     return CheckHip(LaunchCopy(conv, w2, h2, last, m_stream), "k_copy");
 }
 
@@ -542,8 +591,8 @@ HRESULT CHipVideoProcessor::ProcessOne(const uint8_t *sample, void *rt, int rtPi
         const FusedFrame fr{sample, rt};        // a single frame travels by value in the kernel arguments
         return CheckHip(LaunchFusedUp2x(fp, nullptr, fr, 1, m_stream), "k_fused_up2x");
     }
-    if ((hr = ConvertColorPass(sample))) return hr;
-    return ResizeShaderPass(rt, rtPitch);
+    if (m_plan.convert && (hr = ConvertColorPass(sample))) return hr;
+    return ResizeShaderPass(rt, rtPitch, sample);
 }
 
 // Process — DX11VideoProcessor.cpp:3285-3424

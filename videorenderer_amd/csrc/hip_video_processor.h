@@ -82,10 +82,11 @@ private:
     void SetShaderLuminanceParams();                     // :889
     HRESULT UpdatePlan();                                // UpdateTexures/UpdatePostScaleTexures/Update*scalingShaders
     HRESULT ConvertColorPass(const uint8_t *sample);     // :3048
-    HRESULT ResizeShaderPass(void *rt, int rtPitch);     // :3103 (+ FinalPass :3189 fused into the last draw)
+    HRESULT ResizeShaderPass(void *rt, int rtPitch, const uint8_t *sample);     // :3103 (+ FinalPass :3189 fused into the last draw)
     HRESULT ProcessOne(const uint8_t *sample, void *rt, int rtPitch);
     HRESULT UploadTaps(const HostAxisTaps &h, DevBuffer &bi, DevBuffer &bw, DevBuffer &bs, AxisTaps *out);
     HRESULT UploadIndex(const std::vector<int32_t> &v, DevBuffer &b);
+    bool ConvertEnabled() const;                       // m_PSConvColorData.bEnable (:849-853)
     int TexPitch() const;                              // row pitch of the source texture (differs from the sample's for v210)
     HRESULT PrepareSample(const uint8_t *dev_sample, const uint8_t **tex);   // device sample -> source texture
     void FillConvertParams(const uint8_t *sample, ConvertParams *P) const;
@@ -112,6 +113,7 @@ private:
     // input
     const FmtConvParams *m_srcParams = nullptr;
     int m_srcWidth = 0, m_srcHeight = 0, m_srcPitch = 0, m_srcLines = 0;
+    bool m_srcBottomUp = false;    // RGB DIB stored bottom-up (negative m_srcPitch in the reference)
     CRect m_srcRect;
     int m_srcRectWidth = 0, m_srcRectHeight = 0;
     ExtFmt m_decExFmt{0}, m_srcExFmt{0};

@@ -98,6 +98,10 @@ __device__ __forceinline__ void fetch_pixel(const ConvertParams &P, int sx, int 
         y = load_luma(P, sx, sy); uv[0] = 0; uv[1] = 0;
         return;
     }
+    if (P.fmt.layout == LAY_RGB) {         // float4 color = tex.Sample(samp, Tex) (:184): (R,G,B) of the texture
+        y = load_packed(P, sx, sy, P.fmt.ci[0]); uv[0] = load_packed(P, sx, sy, P.fmt.ci[1]); uv[1] = load_packed(P, sx, sy, P.fmt.ci[2]);
+        return;
+    }
     if (P.fmt.layout == LAY_PACKED444) {   // .zyxw (AYUV) / .yxzw (Y410, Y416) (:186-193)
         y = load_packed(P, sx, sy, P.fmt.ci[0]); uv[0] = load_packed(P, sx, sy, P.fmt.ci[1]); uv[1] = load_packed(P, sx, sy, P.fmt.ci[2]);
         return;

@@ -169,6 +169,7 @@ __device__ __forceinline__ f3 round_to_fmt(f3 v, int fmt)
 {
     if (fmt == SF_BGRA8) { v.x = unorm_q(v.x, 255.0f) / 255.0f; v.y = unorm_q(v.y, 255.0f) / 255.0f; v.z = unorm_q(v.z, 255.0f) / 255.0f; }
     else if (fmt == SF_RGB10A2) { v.x = unorm_q(v.x, 1023.0f) / 1023.0f; v.y = unorm_q(v.y, 1023.0f) / 1023.0f; v.z = unorm_q(v.z, 1023.0f) / 1023.0f; }
+    else if (fmt == SF_RGBA16) { v.x = unorm_q(v.x, 65535.0f) / 65535.0f; v.y = unorm_q(v.y, 65535.0f) / 65535.0f; v.z = unorm_q(v.z, 65535.0f) / 65535.0f; }
     else { v.x = half_round(v.x); v.y = half_round(v.y); v.z = half_round(v.z); }
     return v;
 }
@@ -207,6 +208,9 @@ __device__ __forceinline__ f3 load_surface(const Surface &s, int x, int y)
     } else if (s.fmt == SF_RGB10A2) {
         const uint32_t u = ((const uint32_t *)row)[x];
         v.x = (float)(u & 1023u) / 1023.0f; v.y = (float)((u >> 10) & 1023u) / 1023.0f; v.z = (float)((u >> 20) & 1023u) / 1023.0f;
+    } else if (s.fmt == SF_RGBA16) {
+        const uint2 u = ((const uint2 *)row)[x];
+        v.x = (float)(u.x & 0xffffu) / 65535.0f; v.y = (float)(u.x >> 16) / 65535.0f; v.z = (float)(u.y & 0xffffu) / 65535.0f;
     } else {
         const uint2 u = ((const uint2 *)row)[x];
         const __half2 lo = *(const __half2 *)&u.x, hi = *(const __half2 *)&u.y;

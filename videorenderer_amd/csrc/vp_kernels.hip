@@ -87,6 +87,59 @@ __global__ __launch_bounds__(256) void k_repack_v210(const uint8_t *src, int src
     }
 }
 
+// The CopyFrame* functions of the interleaved RGB formats (Helper.cpp:444-482 RGB24, 548-566 RGB48, 600-645 BGR48,
+// 647-663 BGRA64, 665-683 b64a, 770-787 r210, 414-428 as-is) as one texel per thread.  `n_px` = pixels the reference loop
+// writes per row (RGB48: whole groups of four only, as written); bottom_up: negative source pitch (:1243-1248).
+__global__ __launch_bounds__(256) void k_repack_rgb(int kind, const uint8_t *src, int src_pitch_abs, int bottom_up,
+                                                     uint8_t *dst, int dst_pitch, int n_px, int lines)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (y >= lines || i >= n_px) return;
+    const uint8_t *srow = src + (size_t)(bottom_up ? lines - 1 - y : y) * src_pitch_abs;
+    uint8_t *drow = dst + (size_t)y * dst_pitch;
+    if (kind == RPK_NONE) { ((uint32_t *)drow)[i] = ((const uint32_t *)srow)[i]; return; }
+    if (kind == RPK_RGB24) {
+        const uint8_t *p = srow + 3 * i;
+        ((uint32_t *)drow)[i] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xff000000u;
+        return;
+    }
+    if (kind == RPK_R210) {
+        const uint32_t t = ((const uint32_t *)srow)[i];
+        const uint32_t r = ((t & 0x0000003fu) << 4) | ((t & 0x0000f000u) >> 12);
+        const uint32_t g = ((t & 0x00fc0000u) >> 8) | ((t & 0x00000f00u) << 8);
+        const uint32_t b = ((t & 0xff000000u) >> 4) | ((t & 0x00030000u) << 12);
+        ((uint32_t *)drow)[i] = r | g | b;
+        return;
+    }
+    uint16_t c0, c1, c2;
+    if (kind == RPK_RGB48 || kind == RPK_BGR48) {
+        const uint16_t *p = (const uint16_t *)srow + 3 * i;
+        c0 = p[0]; c1 = p[1]; c2 = p[2];
+        if (kind == RPK_BGR48) { const uint16_t t = c0; c0 = c2; c2 = t; }
+    } else if (kind == RPK_BGRA64) {
+        const uint16_t *p = (const uint16_t *)srow + 4 * i;
+        c0 = p[2]; c1 = p[1]; c2 = p[0];
+    } else {    // b64a: big-endian words A,R,G,B
+        const uint8_t *p = srow + 8 * i;
+        c0 = (uint16_t)((p[2] << 8) | p[3]); c1 = (uint16_t)((p[4] << 8) | p[5]); c2 = (uint16_t)((p[6] << 8) | p[7]);
+    }
+    uint16_t *d = (uint16_t *)drow + 4 * i;
+    d[0] = c0; d[1] = c1; d[2] = c2; d[3] = 0xffff;
+}
+
+hipError_t LaunchRepackRgb(int kind, const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int width, int lines, hipStream_t s)
+{
+    const int ap = src_pitch < 0 ? -src_pitch : src_pitch;
+    const int bpp = kind == RPK_RGB24 ? 3 : (kind == RPK_RGB48 || kind == RPK_BGR48) ? 6 : (kind == RPK_BGRA64 || kind == RPK_B64A) ? 8 : 4;
+    int n_px = ap / bpp;                                   // line_pixels of the reference loops
+    if (n_px > width) n_px = width;                        // the texture row holds `width` texels
+    if (kind == RPK_RGB48) n_px &= ~3;                     // CopyFrameRGB48 has no remainder branch (:552-563)
+    if (n_px <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_repack_rgb, dim3((n_px + 255) / 256, lines, 1), dim3(256, 1, 1), 0, s,
+                       kind, src, ap, src_pitch < 0 ? 1 : 0, dst, dst_pitch, n_px, lines);
+    return hipGetLastError();
+}
+
 hipError_t LaunchRepackV210(const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int lines, hipStream_t s)
 {
     const int dq = dst_pitch / 12, dr = dst_pitch % 12, sq = src_pitch / 8, sr = src_pitch % 8;

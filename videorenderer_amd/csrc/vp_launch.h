@@ -8,6 +8,8 @@ namespace mpcvr {
 
 // pass-per-kernel path (vp_kernels.hip)
 hipError_t LaunchConvert(const ConvertParams &P, const Surface &out, hipStream_t s);
+// CopyFrameRGB24 / R210 / RGB48 / BGR48 / BGRA64 / B64A / CopyPlaneAsIs: interleaved RGB sample -> its texture
+hipError_t LaunchRepackRgb(int kind, const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int width, int lines, hipStream_t s);
 // CopyFrameV210 (Helper.cpp:709-748): v210 sample -> Y210-layout texture
 hipError_t LaunchRepackV210(const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int lines, hipStream_t s);
 // axis = screen axis the tap table runs along; swap = rotation 90/270 (taps address the other texture axis)

@@ -11,7 +11,8 @@ constexpr int kPqLutSize = 4096;
 
 // surface formats of the intermediate / output textures
 // (m_InternalTexFmt — DX11VideoProcessor.cpp:1143-1155; m_TexResize is always fp16 — :3155)
-enum SurfFmt : int { SF_BGRA8 = 8, SF_RGB10A2 = 10, SF_RGBA16F = 16 };
+// SF_RGBA16 (R16G16B16A16_UNORM) only occurs as the source texture of the 16-bit interleaved RGB formats
+enum SurfFmt : int { SF_BGRA8 = 8, SF_RGB10A2 = 10, SF_RGBA16F = 16, SF_RGBA16 = 17 };
 
 // what the generated convert shader appends after "//convert color" (Shaders.cpp:861-923)
 enum TailMode : int {
@@ -28,8 +29,11 @@ enum SrcLayout : int {
     LAY_PLANAR = 0,      // planes 2/3 (also planar RGB: G,B,R sampled as Y,U,V)
     LAY_PACKED422 = 1,   // one RGBA8/RGBA16 texel = two pixels (YUY2, UYVY, Y210, Y216, v210 after CopyFrameV210)
     LAY_PACKED444 = 2,   // one texel = one pixel (AYUV, Y410, Y416)
-    LAY_GRAY = 3         // R8/R16: Sample() returns (Y,0,0,1)
+    LAY_GRAY = 3,        // R8/R16: Sample() returns (Y,0,0,1)
+    LAY_RGB = 4          // interleaved RGB in a B8G8R8X8 / R10G10B10A2 / R16G16B16A16 texture
 };
+// GetCopyPlaneFunction (Helper.cpp:377-412) for the formats whose upload is not a plain copy
+enum Repack : int { RPK_NONE = 0, RPK_RGB24, RPK_R210, RPK_RGB48, RPK_BGR48, RPK_BGRA64, RPK_B64A };
 enum ColorSystem : int { CST_YUV = 0, CST_RGB = 1, CST_GRAY = 2 };   // Helper.h:129-133
 
 struct SrcFormat {

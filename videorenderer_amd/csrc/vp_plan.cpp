@@ -49,6 +49,15 @@ static const FmtConvParams kFormats[] = {
     {MPCVR_CF_Y8,        "Y8",         1, 1, 1, 1, 1, 2, 400,  8, 0, 0, LAY_GRAY, CST_GRAY, {0, 0, 0, 0}, 0},
     {MPCVR_CF_Y10,       "Y10",        1, 2, 1, 1, 2, 2, 400, 10, 6, 0, LAY_GRAY, CST_GRAY, {0, 0, 0, 0}, 0},
     {MPCVR_CF_Y16,       "Y16",        1, 2, 1, 1, 2, 2, 400, 16, 0, 0, LAY_GRAY, CST_GRAY, {0, 0, 0, 0}, 0},
+    // interleaved RGB (Helper.cpp:345-354): texture B8G8R8X8 / R10G10B10A2 / R16G16B16A16; ci = texel components of R,G,B
+    {MPCVR_CF_RGB24,     "RGB24",      1, 1, 1, 1, 3, 2, 444,  8, 0, 0, LAY_RGB, CST_RGB, {2, 1, 0, 3}, 0, RPK_RGB24},
+    {MPCVR_CF_XRGB32,    "RGB32",      1, 1, 1, 1, 4, 2, 444,  8, 0, 0, LAY_RGB, CST_RGB, {2, 1, 0, 3}, 0, RPK_NONE},
+    {MPCVR_CF_ARGB32,    "ARGB32",     1, 1, 1, 1, 4, 2, 444,  8, 0, 0, LAY_RGB, CST_RGB, {2, 1, 0, 3}, 0, RPK_NONE},
+    {MPCVR_CF_r210,      "r210",       1, 4, 1, 1, 4, 2, 444, 10, 0, 0, LAY_RGB, CST_RGB, {0, 1, 2, 3}, 1, RPK_R210},
+    {MPCVR_CF_RGB48,     "RGB48",      1, 2, 1, 1, 6, 2, 444, 16, 0, 0, LAY_RGB, CST_RGB, {0, 1, 2, 3}, 0, RPK_RGB48},
+    {MPCVR_CF_BGR48,     "BGR48",      1, 2, 1, 1, 6, 2, 444, 16, 0, 0, LAY_RGB, CST_RGB, {0, 1, 2, 3}, 0, RPK_BGR48},
+    {MPCVR_CF_BGRA64,    "BGRA64",     1, 2, 1, 1, 8, 2, 444, 16, 0, 0, LAY_RGB, CST_RGB, {0, 1, 2, 3}, 0, RPK_BGRA64},
+    {MPCVR_CF_B64A,      "b64a",       1, 2, 1, 1, 8, 2, 444, 16, 0, 0, LAY_RGB, CST_RGB, {0, 1, 2, 3}, 0, RPK_B64A},
 };
 
 const FmtConvParams *GetFmtConvParams(int cformat)
@@ -61,7 +70,8 @@ const FmtConvParams *GetFmtConvParams(int cformat)
 int DefaultPitch(const FmtConvParams &f, int width)
 {
     int pitch = width * f.Packsize;
-    if (f.cformat == MPCVR_CF_NV12 || f.cformat == MPCVR_CF_Y8) pitch = (pitch + 3) & ~3;     // :1792-1796
+    if (f.cformat == MPCVR_CF_NV12 || f.cformat == MPCVR_CF_Y8 || f.cformat == MPCVR_CF_RGB24 || f.cformat == MPCVR_CF_BGR48)
+        pitch = (pitch + 3) & ~3;                                                             // :1792-1796
     if (f.cformat == MPCVR_CF_V210) pitch = (((width + 5) / 6 * 16) + 127) & ~127;            // :1798-1799
     return pitch;
 }
@@ -194,7 +204,7 @@ void ComputeColorMatrix(const ExtFmt &ex, const FmtConvParams &f, const ProcAmp 
         out[9 + i] = (float)(0.0 - m.v[i][0] * ymin - uv * cmid + brightness);
     }
     // cbuffer fix-ups of SetShaderConvertColorParams (DX11VideoProcessor.cpp:863-873)
-    if (f.CSType == CST_RGB && f.layout == LAY_PLANAR) {          // GBRP: color = (G,B,R) => rows (x,y,z) -> (y,z,x)
+    if (f.CSType == CST_RGB && f.layout == LAY_PLANAR && f.planes == 3) {    // GBRP: color = (G,B,R) => rows (x,y,z) -> (y,z,x)
         for (auto &row : m.v) { const float x = row[0], y = row[1], z = row[2]; row[0] = y; row[1] = z; row[2] = x; }
     } else if (gray) {
         m.v[1][0] = m.v[1][1]; m.v[1][1] = 0;
@@ -520,6 +530,7 @@ bool DecidePlan(int iTexFormat, int iChromaScaling, int iUpscaling, int iDownsca
     const int w2 = g.vr - g.vl, h2 = g.vb - g.vt;
     if (g.rotation != 0 && g.rotation != 90 && g.rotation != 180 && g.rotation != 270) { if (why) *why = "rotation must be 0, 90, 180 or 270"; return false; }
     p.rotation = g.rotation; p.flip = g.flip != 0;
+    p.convert = g.convert_enabled != 0;
     const bool rotated = g.rotation == 90 || g.rotation == 270;
     const int w1 = rotated ? g.h1 : g.w1, h1 = rotated ? g.w1 : g.h1;                     // :3112-3123
     const int k = bInterpolateAt50pct ? 2 : 1;                                            // :3108
@@ -559,7 +570,7 @@ bool DecidePlan(int iTexFormat, int iChromaScaling, int iUpscaling, int iDownsca
 std::string PassPlan::describe() const
 {
     if (fused_up2x) return "fused_up2x";
-    std::string s = "passes:convert";
+    std::string s = convert ? "passes:convert" : "passes:source";
     if (two_pass) s += final_pass ? ",resizeX,resizeY+final" : ",resizeX,resizeY";
     else if (one_pass) s += std::string(one_pass_axis == 0 ? ",resizeX" : ",resizeY") + (final_pass ? "+final" : "");
     else s += final_pass ? ",final" : ",copy";

@@ -23,7 +23,8 @@ struct FmtConvParams {
     int layout;     // SrcLayout
     int CSType;     // ColorSystem
     int ci[4];      // component order of the packed formats (see SrcFormat)
-    int bits10;     // Y410
+    int bits10;     // Y410, r210
+    int repack;     // Repack
 };
 const FmtConvParams *GetFmtConvParams(int cformat);            // Helper.cpp:361-369
 int DefaultPitch(const FmtConvParams &f, int width);           // DX11VideoProcessor.cpp:1789-1803
@@ -107,13 +108,15 @@ struct PassPlan {
     int first_tex_axis = -1;         // texture axis the first draw filters: 0 = X shaders, 1 = Y shaders, -1 = ps_simple
     Resizer first_rs{RS_NONE, 0};
     int mid_h = 0;                   // height of m_TexResize in the two-pass case (srcRect extent along screen y)
+    bool convert = true;             // ConvertColorPass runs; false: the source texture feeds the resize directly (:3321-3323)
     std::string describe() const;
 };
 
 struct PlanGeometry { int w1, h1;            // source rect size (== convert output)
                       int vl, vt, vr, vb;    // video rect
                       int ww, wh;            // window size
-                      int rotation = 0; int flip = 0; };
+                      int rotation = 0; int flip = 0;
+                      int convert_enabled = 1; };   // m_PSConvColorData.bEnable (:849-853)
 // Pure decision logic of UpdateTexParams / UpdatePostScaleTexures / ResizeShaderPass (no device work).
 // cfg fields use the Settings_t names; returns false + *why when the combination is not implemented.
 struct mpcvr_settings_fwd;

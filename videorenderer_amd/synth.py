@@ -35,7 +35,11 @@ PACKED = {
     11: ("ayuv", 1, 8, False), 12: ("y410", 4, 10, False), 13: ("y416", 2, 16, True),
     26: ("gbrp", 1, 8, False), 27: ("gbrp", 2, 10, False), 28: ("gbrp", 2, 16, False),
     37: ("gray", 1, 8, False), 38: ("gray", 2, 10, False), 39: ("gray", 2, 16, False),
+    # interleaved RGB (Helper.cpp:345-354); the "Y,U,V" floats stand in for R,G,B
+    29: ("rgb24", 1, 8, False), 30: ("rgb32", 1, 8, False), 31: ("rgb32", 1, 8, False), 32: ("r210", 4, 10, False),
+    33: ("rgb48", 2, 16, False), 34: ("bgr48", 2, 16, False), 35: ("bgra64", 2, 16, False), 36: ("b64a", 2, 16, False),
 }
+RGB_FAMILIES = ("rgb24", "rgb32", "r210", "rgb48", "bgr48", "bgra64", "b64a")
 
 
 def splitmix64(n, seed):
@@ -59,6 +63,9 @@ def default_pitch(cformat, w):
             return w * 4
         if kind == "y416":
             return w * 8
+        if kind in RGB_FAMILIES:
+            pitch = w * {"rgb24": 3, "rgb32": 4, "r210": 4, "rgb48": 6, "bgr48": 6, "bgra64": 8, "b64a": 8}[kind]
+            return (pitch + 3) & ~3 if kind in ("rgb24", "bgr48") else pitch       # :1792-1796
         pitch = w * nbytes                                       # gbrp, gray
         return (pitch + 3) & ~3 if cformat == 37 else pitch      # Y8: ALIGN(pitch, 4) (:1792-1796)
     planes, nbytes = FORMATS[cformat][0], FORMATS[cformat][1]
@@ -117,9 +124,9 @@ def _make_packed(cformat, w, h, kind, seed, pitch, full_range):
     elif fam == "gray":
         cw, ch = 1, 1
     else:
-        cw, ch = w, h
+        cw, ch = w, h          # 4:4:4 and RGB: full-resolution "chroma"
     y, u, v = _planes_float(kind, w, h, cw, ch, SEED_BASE + seed)
-    yq, uq, vq = _quantise(y, u, v, bits, full_range, rgb=(fam == "gbrp"))
+    yq, uq, vq = _quantise(y, u, v, bits, full_range, rgb=(fam == "gbrp" or fam in RGB_FAMILIES))
     if msb and bits == 10:
         yq, uq, vq = yq << 6, uq << 6, vq << 6
     buf = np.zeros(pitch * h * (3 if fam == "gbrp" else 1), dtype=np.uint8)
@@ -154,6 +161,26 @@ def _make_packed(cformat, w, h, kind, seed, pitch, full_range):
         dt = np.uint8 if nbytes == 1 else np.uint16
         for i, q in enumerate((yq, uq, vq)):
             buf[i * pitch * h: (i + 1) * pitch * h].reshape(h, pitch).view(dt)[:, :w] = q.astype(dt)
+    elif fam == "rgb24":     # Windows RGB24: B,G,R bytes
+        t = rows[:, : 3 * w].reshape(h, w, 3)
+        t[:, :, 0] = vq; t[:, :, 1] = uq; t[:, :, 2] = yq
+    elif fam == "rgb32":     # B,G,R,X
+        t = rows[:, : 4 * w].reshape(h, w, 4)
+        t[:, :, 0] = vq; t[:, :, 1] = uq; t[:, :, 2] = yq; t[:, :, 3] = 255
+    elif fam == "r210":      # big-endian dword: 2 pad bits, R10, G10, B10
+        word = (yq << 20) | (uq << 10) | vq
+        rows.view(np.uint32)[:, :w] = word.astype(">u4").view(np.uint32)
+    elif fam in ("rgb48", "bgr48"):
+        t = rows.view(np.uint16)[:, : 3 * w].reshape(h, w, 3)
+        a, b_, c_ = (yq, uq, vq) if fam == "rgb48" else (vq, uq, yq)
+        t[:, :, 0] = a; t[:, :, 1] = b_; t[:, :, 2] = c_
+    elif fam == "bgra64":
+        t = rows.view(np.uint16)[:, : 4 * w].reshape(h, w, 4)
+        t[:, :, 0] = vq; t[:, :, 1] = uq; t[:, :, 2] = yq; t[:, :, 3] = 65535
+    elif fam == "b64a":      # big-endian words A,R,G,B
+        t = rows.view(np.uint16)[:, : 4 * w].reshape(h, w, 4)
+        be = lambda a: a.astype(np.uint16).byteswap()
+        t[:, :, 0] = 65535; t[:, :, 1] = be(yq); t[:, :, 2] = be(uq); t[:, :, 3] = be(vq)
     else:                    # gray
         dt = np.uint8 if nbytes == 1 else np.uint16
         rows.view(dt)[:, :w] = yq.astype(dt)
