@@ -1111,6 +1111,52 @@ static int resize_draw(const img_t *in, const int rect[4], img_t *out, int tex_a
     const float cscale = tex_axis == 0 ? (float)rw / (float)out->w : (float)rh / (float)out->h;   /* scale[AXIS] */
     const resizer_t none = {RS_NONE, 0};
 
+    if (rs.kind == RS_UP && rs.method == ORC_UP_JINC2) {
+        /* ps_resize_onepass_jinc2.hlsl:44-101 ("Jinc2m", IDF_PS_11_INTERP_JINC2): ONE 2-D draw — 4x4 texels around the
+           sample position weighted by the windowed jinc of their distance, normalised, then anti-ringing (clamp towards
+           the min/max of the inner 2x2, strength 0.8).  Used for both axes (m_pShaderUpscaleY = m_pShaderUpscaleX, :2921). */
+        const float pi = acosf(-1.0f), wa = 0.416f * pi, wb = 0.985f * pi;
+        ORC_PAR_FOR
+        for (int y = 0; y < out->h; y++) {
+            for (int x = 0; x < out->w; x++) {
+                const float cx = rev_x ? (float)(org_x + len_x) - ((float)x + 0.5f) * step_x : axis_center(org_x, x, step_x);
+                const float cy = rev_y ? (float)(org_y + len_y) - ((float)y + 0.5f) * step_y : axis_center(org_y, y, step_y);
+                const float pcx = tax == 0 ? cx : cy, pcy = tax == 0 ? cy : cx;        /* pc = Tex * wh */
+                const float tcx = floorf(pcx - 0.5f) + 0.5f, tcy = floorf(pcy - 0.5f) + 0.5f;
+                float w[4][4], wsum = 0.0f;
+                const float *c[4][4];
+                for (int j = 0; j < 4; j++) {
+                    float rowsum = 0.0f;
+                    for (int i = 0; i < 4; i++) {
+                        const float vx = (tcx + (float)(i - 1)) - pcx, vy = (tcy + (float)(j - 1)) - pcy;
+                        const float dd = sqrtf(vx * vx + vy * vy);
+                        w[j][i] = (dd == 0.0f) ? wa * wb : sinf(dd * wa) * sinf(dd * wb) / (dd * dd);
+                        rowsum = i == 0 ? w[j][i] : rowsum + w[j][i];
+                        const int sx = clampi((int)floorf(tcx) + i - 1, 0, in->w - 1), sy = clampi((int)floorf(tcy) + j - 1, 0, in->h - 1);
+                        c[j][i] = in->p + ((size_t)sy * in->w + sx) * 4;
+                    }
+                    wsum = j == 0 ? rowsum : wsum + rowsum;
+                }
+                float px[4] = {0, 0, 0, 1.0f};
+                for (int ch = 0; ch < 3; ch++) {
+                    float color = 0.0f;
+                    for (int j = 0; j < 4; j++) {
+                        float r = w[j][0] * c[j][0][ch];
+                        r = r + w[j][1] * c[j][1][ch]; r = r + w[j][2] * c[j][2][ch]; r = r + w[j][3] * c[j][3][ch];
+                        color = j == 0 ? r : color + r;
+                    }
+                    color = color / wsum;
+                    const float mn = fminf(fminf(fminf(c[1][1][ch], c[1][2][ch]), c[2][1][ch]), c[2][2][ch]);
+                    const float mx = fmaxf(fmaxf(fmaxf(c[1][1][ch], c[1][2][ch]), c[2][1][ch]), c[2][2][ch]);
+                    const float cl = fminf(fmaxf(color, mn), mx);
+                    px[ch] = color + 0.8f * (cl - color);                               /* lerp(color, clamp(..), 0.8) */
+                }
+                store_fmt(store, px, out->p + ((size_t)y * out->w + x) * 4);
+            }
+        }
+        return 0;
+    }
+
     taps_t *tx = (taps_t *)malloc(sizeof(taps_t) * (size_t)out->w);
     taps_t *ty = (taps_t *)malloc(sizeof(taps_t) * (size_t)out->h);
     if (!tx || !ty) { free(tx); free(ty); return -1; }
@@ -1218,7 +1264,6 @@ int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
 
     /* ResizeShaderPass :3103-3187 — pick per-axis shader */
     const int k = p->bInterpolateAt50pct ? 2 : 1;
-    if (p->iUpscaling == ORC_UP_JINC2) { img_free(&conv); free(c.owned); return -6; }
     const int rot = p->rotation, flip = p->flip != 0;
     if (rot != 0 && rot != 90 && rot != 180 && rot != 270) { img_free(&conv); free(c.owned); return -7; }
     const int rotated = (rot == 90 || rot == 270);
@@ -1241,7 +1286,9 @@ int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
 
     const img_t *result = &conv;
     int result_fmt = internal;
-    if (rx.kind != RS_NONE && ry.kind != RS_NONE && !(rotated && rx.kind == ry.kind)) {
+    /* resizerX == resizerY (:3131): rotated frames (two Y shaders) or Jinc2, whose one 2-D shader serves both axes (:2921) */
+    const int same_shader = rx.kind != RS_NONE && rx.kind == ry.kind && (rotated || (rx.kind == RS_UP && rx.method == ORC_UP_JINC2));
+    if (rx.kind != RS_NONE && ry.kind != RS_NONE && !same_shader) {
         /* two passes through fp16 m_TexResize (w2 x sh) :3143-3167; the second one is unrotated */
         if (img_alloc(&mid, w2, sh) || img_alloc(&post, w2, h2)) { rc = -5; goto done; }
         if ((rc = resize_draw(&conv, srect, &mid, ax_first, rx, rot, flip, p->flags, FMT_RGBA16F))) goto done;

@@ -48,6 +48,12 @@ GOLDEN_CASES = {
     "nearest_2x": dict(cformat=1, w=32, h=24, kind="noise", seed=18, dst=(64, 48), iUpscaling=0),
     "x_only_resize": dict(cformat=2, w=48, h=32, kind="structure", seed=19, dst=(96, 32), iUpscaling=2),
     "y_only_resize": dict(cformat=2, w=48, h=32, kind="structure", seed=20, dst=(48, 80), iUpscaling=3),
+    # ---- Jinc2m: one 2-D draw for both axes (ps_resize_onepass_jinc2.hlsl, :2921) ----
+    "jinc2_p010_2x_dither": dict(cformat=2, w=64, h=32, kind="structure", seed=130, dst=(128, 64), iUpscaling=5),
+    "jinc2_nv12_noise_1p5x": dict(cformat=1, w=64, h=40, kind="noise", seed=131, dst=(96, 60), iUpscaling=5),
+    "jinc2_x_with_hamming_down_y": dict(cformat=1, w=48, h=96, kind="structure", seed=132, dst=(96, 30), iUpscaling=5, iDownscaling=2),
+    "jinc2_y_only": dict(cformat=2, w=64, h=32, kind="noise", seed=133, dst=(64, 80), iUpscaling=5),
+    "jinc2_rot90_pq": dict(cformat=2, w=48, h=32, kind="hdr", seed=134, dst=(64, 96), iUpscaling=5, rotation=90, exfmt=HDR10),
     # ---- geometry ----
     "crop_offset_letterbox": dict(cformat=2, w=96, h=64, kind="structure", seed=21, src_rect=(16, 8, 80, 56), dst=(128, 96),
                                   window=(200, 150), offset=(36, 27), iUpscaling=4),

@@ -164,8 +164,9 @@ def test_pass_plan_matches_reference_rules(mpcvr):
     assert d(2, 64, 64, (0, 0, 64, 64), 64, 64, s.copy(output_format=1)).endswith("final=0")
     assert d(2, 64, 64, (0, 0, 64, 64), 64, 64, s.copy(output_format=1, iTexFormat=16)).endswith("internal=16;swap=10;final=1")
     assert d(2, 64, 64, (0, 0, 64, 64), 64, 64, s.copy(bUseDither=0)).endswith("final=0")
-    with pytest.raises(api.MpcvrError):
-        d(2, 64, 64, (0, 0, 128, 128), 128, 128, s.copy(iUpscaling=5))      # Jinc2
+    # Jinc2m: one 2-D shader for both axes => a single draw (m_pShaderUpscaleY = m_pShaderUpscaleX, :2921,3131-3137)
+    assert d(2, 64, 64, (0, 0, 128, 128), 128, 128, s.copy(iUpscaling=5)).startswith("passes:convert,resizeX+final")
+    assert d(2, 64, 64, (0, 0, 128, 20), 128, 20, s.copy(iUpscaling=5)).startswith("passes:convert,resizeX,resizeY+final")
 
 
 def test_settings_default_matches_reference(mpcvr):

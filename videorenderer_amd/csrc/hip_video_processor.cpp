@@ -352,7 +352,13 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         const float cscale = a == 0 ? (float)w1 / (float)outW : (float)h1 / (float)outH;
         const bool taps_on_x = (a < 0) || (tax == a);               // ps_simple: a 1-tap table along x
         const Resizer rs = a < 0 ? Resizer{RS_NONE, 0} : m_plan.first_rs;
-        bool ok;
+        m_firstJinc = rs.kind == RS_UP && rs.method == MPCVR_UPSCALE_Jinc2;
+        m_firstCoords = DrawCoords{org_x, len_x, rev_x ? 1 : 0, (float)len_x / (float)outW,
+                                   org_y, len_y, rev_y ? 1 : 0, (float)len_y / (float)outH, swap ? 1 : 0};
+        bool ok = true;
+        if (m_firstJinc) {
+            // the 2-D shader needs no tables
+        } else
         if (taps_on_x) {
             ok = BuildAxisTaps(rs, org_x, len_x, outW, tex_x, m_cfg.flags, &hx, rev_x, a < 0 ? 0.0f : cscale);
             BuildPointIndex(org_y, len_y, outH, tex_y, &ox, rev_y);
@@ -363,18 +369,24 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         if (!ok) return Fail(MPCVR_E_NOTIMPL, "resize ratio outside the supported range");
         m_firstAxis = taps_on_x ? 0 : 1;
         m_firstSwap = swap;
-        if ((hr = UploadTaps(hx, m_tapsXi, m_tapsXw, m_tapsXs, &m_tapsX))) return hr;
-        if ((hr = UploadIndex(ox, m_otherX))) return hr;
+        if (!m_firstJinc) {
+            if ((hr = UploadTaps(hx, m_tapsXi, m_tapsXw, m_tapsXs, &m_tapsX))) return hr;
+            if ((hr = UploadIndex(ox, m_otherX))) return hr;
+        }
     }
     if (m_plan.two_pass) {
         // m_TexResize: fp16, dst width x (source extent along screen y) (:3143-3160); the second draw is unrotated
         const int mh = m_plan.mid_h;
         if ((hr = CheckHip(m_TexResize.CheckCreate((size_t)w2 * 8 * mh), "m_TexResize"))) return hr;
-        if (!BuildAxisTaps(m_plan.ry, 0, mh, h2, mh, m_cfg.flags, &hy))
-            return Fail(MPCVR_E_NOTIMPL, "resize ratio outside the supported range");
-        BuildPointIndex(0, w2, w2, w2, &oy);     // Y pass: columns map 1:1
-        if ((hr = UploadTaps(hy, m_tapsYi, m_tapsYw, m_tapsYs, &m_tapsY))) return hr;
-        if ((hr = UploadIndex(oy, m_otherY))) return hr;
+        m_secondJinc = m_plan.ry.kind == RS_UP && m_plan.ry.method == MPCVR_UPSCALE_Jinc2;
+        m_secondCoords = DrawCoords{0, w2, 0, 1.0f, 0, mh, 0, (float)mh / (float)h2, 0};
+        if (!m_secondJinc) {
+            if (!BuildAxisTaps(m_plan.ry, 0, mh, h2, mh, m_cfg.flags, &hy))
+                return Fail(MPCVR_E_NOTIMPL, "resize ratio outside the supported range");
+            BuildPointIndex(0, w2, w2, w2, &oy);     // Y pass: columns map 1:1
+            if ((hr = UploadTaps(hy, m_tapsYi, m_tapsYw, m_tapsYs, &m_tapsY))) return hr;
+            if ((hr = UploadIndex(oy, m_otherY))) return hr;
+        }
     }
 
     if (m_plan.fused_up2x) {
@@ -565,11 +577,16 @@ HRESULT CHipVideoProcessor::ResizeShaderPass(void *rt, int rtPitch, const uint8_
     if (m_plan.two_pass) {
         Surface mid{m_TexResize.ptr, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
         StoreParams st = MakeStore(mid.ptr, mid.pitch, SF_RGBA16F, false);
-        if ((hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, m_plan.mid_h, st, m_stream), "k_resize<first>"))) return hr;
+        if (m_firstJinc) hr = CheckHip(LaunchJinc2(conv, m_firstCoords, w2, m_plan.mid_h, st, m_stream), "k_jinc2");
+        else hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, m_plan.mid_h, st, m_stream), "k_resize<first>");
+        if (hr) return hr;
+        if (m_secondJinc) return CheckHip(LaunchJinc2(mid, m_secondCoords, w2, h2, last, m_stream), "k_jinc2");
         return CheckHip(LaunchResize(1, false, mid, m_tapsY, (const int32_t *)m_otherY.ptr, w2, h2, last, m_stream), "k_resize<Y>");
     }
-    if (m_plan.one_pass)
+    if (m_plan.one_pass) {
+        if (m_firstJinc) return CheckHip(LaunchJinc2(conv, m_firstCoords, w2, h2, last, m_stream), "k_jinc2");
         return CheckHip(LaunchResize(m_firstAxis, m_firstSwap, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, h2, last, m_stream), "k_resize<one>");
+    }
     if (!m_plan.convert) {    // the final pass reads the source rect of the texture (pTex = pInputTexture, :3352)
         const int bpp = conv.fmt == SF_RGBA16 ? 8 : 4;
         conv.ptr = (uint8_t *)conv.ptr + (size_t)m_srcRect.top * conv.pitch + (size_t)m_srcRect.left * bpp;

@@ -109,6 +109,8 @@ private:
     int m_SampleFormat = 0;        // 0 progressive, 1 TFF, 2 BFF
     int m_firstAxis = 0;           // screen axis the first draw's tap table runs along
     bool m_firstSwap = false;      // rotation 90/270: taps address the other texture axis
+    bool m_firstJinc = false, m_secondJinc = false;    // the draw runs the 2-D Jinc2m shader
+    DrawCoords m_firstCoords{}, m_secondCoords{};
 
     // input
     const FmtConvParams *m_srcParams = nullptr;

@@ -50,6 +50,52 @@ __global__ __launch_bounds__(256) void k_resize(Surface in, AxisTaps taps, const
     store_epilogue(st, x, y, acc);
 }
 
+// ps_resize_onepass_jinc2.hlsl:44-101 ("Jinc2m"): one 2-D draw — 4x4 texels around the sample position weighted by the
+// windowed jinc of their distance, normalised, then anti-ringing towards the min/max of the inner 2x2 (strength 0.8)
+__global__ __launch_bounds__(256) void k_jinc2(Surface in, DrawCoords dc, int out_w, int out_h, StoreParams st)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= out_w || y >= out_h) return;
+    const float pi = 3.14159274101257324f;                 // acos(-1) folded to fp32
+    const float wa = 0.416f * pi, wb = 0.985f * pi;
+    const float cx = dc.rev_x ? (float)(dc.org_x + dc.len_x) - ((float)x + 0.5f) * dc.step_x : (float)dc.org_x + ((float)x + 0.5f) * dc.step_x;
+    const float cy = dc.rev_y ? (float)(dc.org_y + dc.len_y) - ((float)y + 0.5f) * dc.step_y : (float)dc.org_y + ((float)y + 0.5f) * dc.step_y;
+    const float pcx = dc.swap ? cy : cx, pcy = dc.swap ? cx : cy;      // pc = Tex * wh
+    const float tcx = floorf(pcx - 0.5f) + 0.5f, tcy = floorf(pcy - 0.5f) + 0.5f;
+    const int bx = (int)floorf(tcx), by = (int)floorf(tcy);
+    float wsum = 0.0f;
+    f3 color = {0.0f, 0.0f, 0.0f}, mn = {0, 0, 0}, mx = {0, 0, 0};
+    for (int j = 0; j < 4; j++) {
+        float w[4]; f3 c[4];
+        float rowsum = 0.0f;
+        for (int i = 0; i < 4; i++) {
+            const float vx = (tcx + (float)(i - 1)) - pcx, vy = (tcy + (float)(j - 1)) - pcy;
+            const float dd = sqrtf(vx * vx + vy * vy);
+            w[i] = (dd == 0.0f) ? wa * wb : sinf(dd * wa) * sinf(dd * wb) / (dd * dd);
+            rowsum = i == 0 ? w[i] : rowsum + w[i];
+            c[i] = load_surface(in, clampi(bx + i - 1, 0, in.w - 1), clampi(by + j - 1, 0, in.h - 1));
+        }
+        wsum = j == 0 ? rowsum : wsum + rowsum;
+        f3 r;
+        r.x = w[0] * c[0].x; r.x = r.x + w[1] * c[1].x; r.x = r.x + w[2] * c[2].x; r.x = r.x + w[3] * c[3].x;
+        r.y = w[0] * c[0].y; r.y = r.y + w[1] * c[1].y; r.y = r.y + w[2] * c[2].y; r.y = r.y + w[3] * c[3].y;
+        r.z = w[0] * c[0].z; r.z = r.z + w[1] * c[1].z; r.z = r.z + w[2] * c[2].z; r.z = r.z + w[3] * c[3].z;
+        if (j == 0) color = r; else { color.x = color.x + r.x; color.y = color.y + r.y; color.z = color.z + r.z; }
+        if (j == 1) {
+            mn.x = fminf(c[1].x, c[2].x); mn.y = fminf(c[1].y, c[2].y); mn.z = fminf(c[1].z, c[2].z);
+            mx.x = fmaxf(c[1].x, c[2].x); mx.y = fmaxf(c[1].y, c[2].y); mx.z = fmaxf(c[1].z, c[2].z);
+        } else if (j == 2) {
+            mn.x = fminf(fminf(mn.x, c[1].x), c[2].x); mn.y = fminf(fminf(mn.y, c[1].y), c[2].y); mn.z = fminf(fminf(mn.z, c[1].z), c[2].z);
+            mx.x = fmaxf(fmaxf(mx.x, c[1].x), c[2].x); mx.y = fmaxf(fmaxf(mx.y, c[1].y), c[2].y); mx.z = fmaxf(fmaxf(mx.z, c[1].z), c[2].z);
+        }
+    }
+    color.x = color.x / wsum; color.y = color.y / wsum; color.z = color.z / wsum;
+    f3 cl;
+    cl.x = fminf(fmaxf(color.x, mn.x), mx.x); cl.y = fminf(fmaxf(color.y, mn.y), mx.y); cl.z = fminf(fmaxf(color.z, mn.z), mx.z);
+    color.x = color.x + 0.8f * (cl.x - color.x); color.y = color.y + 0.8f * (cl.y - color.y); color.z = color.z + 0.8f * (cl.z - color.z);
+    store_epilogue(st, x, y, color);
+}
+
 // TextureCopyRect(ps_simple) / FinalPass straight from the convert output (no size change)
 __global__ __launch_bounds__(256) void k_copy(Surface in, int out_w, int out_h, StoreParams st)
 {
@@ -164,6 +210,12 @@ hipError_t LaunchResize(int axis, bool swap, const Surface &in, const AxisTaps &
     else if (axis == 0)     hipLaunchKernelGGL((k_resize<0, true>), g, b, 0, s, in, taps, other, out_w, out_h, st);
     else if (!swap)         hipLaunchKernelGGL((k_resize<1, false>), g, b, 0, s, in, taps, other, out_w, out_h, st);
     else                    hipLaunchKernelGGL((k_resize<1, true>), g, b, 0, s, in, taps, other, out_w, out_h, st);
+    return hipGetLastError();
+}
+
+hipError_t LaunchJinc2(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_jinc2, grid2d(out_w, out_h), dim3(64, 4, 1), 0, s, in, dc, out_w, out_h, st);
     return hipGetLastError();
 }
 

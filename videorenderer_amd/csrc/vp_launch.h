@@ -16,6 +16,8 @@ hipError_t LaunchRepackV210(const uint8_t *src, int src_pitch, uint8_t *dst, int
 hipError_t LaunchResize(int axis, bool swap, const Surface &in, const AxisTaps &taps, const int32_t *other,
                         int out_w, int out_h, const StoreParams &st, hipStream_t s);
 hipError_t LaunchCopy(const Surface &in, int out_w, int out_h, const StoreParams &st, hipStream_t s);
+// ps_resize_onepass_jinc2.hlsl: the 2-D Jinc2m draw
+hipError_t LaunchJinc2(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st, hipStream_t s);
 
 // fused 2x path (vp_fused.hip): convert + X pass + Y pass + final pass in one kernel, n frames per launch.
 struct FusedFrame {

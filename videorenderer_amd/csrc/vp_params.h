@@ -93,6 +93,14 @@ struct StoreParams {
     const uint16_t *dither;  // 32x32 fp16 table (device)
 };
 
+// texture coordinate of an output pixel of a (possibly rotated / flipped) draw, per screen axis:
+// c(i) = rev ? (org + len) - (i + .5) * step : org + (i + .5) * step      (FillVertices :130-179)
+struct DrawCoords {
+    int org_x, len_x, rev_x; float step_x;     // run through by screen x
+    int org_y, len_y, rev_y; float step_y;     // run through by screen y
+    int swap;                                  // rotation 90/270: screen x runs along texture Y
+};
+
 // per-output-index tap tables for one axis (built on the host, vp_plan.cpp)
 struct AxisTaps {
     const int32_t *idx;   // [n_out * ntaps] clamped source indices

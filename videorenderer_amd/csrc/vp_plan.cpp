@@ -534,14 +534,15 @@ bool DecidePlan(int iTexFormat, int iChromaScaling, int iUpscaling, int iDownsca
     const bool rotated = g.rotation == 90 || g.rotation == 270;
     const int w1 = rotated ? g.h1 : g.w1, h1 = rotated ? g.w1 : g.h1;                     // :3112-3123
     const int k = bInterpolateAt50pct ? 2 : 1;                                            // :3108
-    if (iUpscaling == MPCVR_UPSCALE_Jinc2) { if (why) *why = "Jinc2 upscaler is not implemented"; return false; }
     const Resizer up{iUpscaling == MPCVR_UPSCALE_Nearest ? RS_NONE : RS_UP, iUpscaling};
     const Resizer down{RS_DOWN, iDownscaling};
     const Resizer none{RS_NONE, 0};
     p.rx = (w1 == w2) ? none : (w1 > k * w2) ? down : up;                                 // :3125-3126 (screen x)
     p.ry = (h1 == h2) ? none : (h1 > k * h2) ? down : up;
     // rotated: resizerX and (when it exists) resizerY are both Y shaders; equal shader objects => ONE draw (:3131-3137)
-    const bool same_shader = rotated && p.rx.kind != RS_NONE && p.rx.kind == p.ry.kind;
+    // ... or Jinc2, whose single 2-D shader serves both axes (m_pShaderUpscaleY = m_pShaderUpscaleX, :2921)
+    const bool same_shader = p.rx.kind != RS_NONE && p.rx.kind == p.ry.kind &&
+                             (rotated || (p.rx.kind == RS_UP && iUpscaling == MPCVR_UPSCALE_Jinc2));
     p.two_pass = p.rx.kind != RS_NONE && p.ry.kind != RS_NONE && !same_shader;
     // Process :3348-3352: with a final pass the resize step is skipped only when rSrc == dstRect and rotation == 0 (a
     // flip alone is then ignored); without post-scale steps ResizeShaderPass always runs (:3417-3419)
