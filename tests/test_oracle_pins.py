@@ -386,8 +386,15 @@ def test_resizer_selection_rules(oracle):
     assert np.array_equal(big[::2, ::2], small) and np.array_equal(big[1::2, 1::2], small)
     # one-axis resize
     assert run(128, 64, iUpscaling=2).shape == (64, 128, 4)
-    with pytest.raises(RuntimeError):
-        run(128, 128, iUpscaling=5)          # Jinc2: not implemented
+    # Jinc2m: a flat field stays flat (weights are normalised, anti-ringing clamps to the local range) and the result
+    # differs from the separable Lanczos3
+    jn = run(128, 128, iUpscaling=5)
+    assert jn.shape == (128, 128, 4) and not np.array_equal(jn, run(128, 128, iUpscaling=4))
+    flat, fp = synth.make_frame(1, w, h, "noise", seed=4)
+    flat[:] = 128
+    p = oracle.default_params(cformat=1, width=w, height=h, window_w=128, window_h=128, video_rect=(0, 0, 128, 128), iUpscaling=5)
+    out = oracle.process(p, flat, fp)
+    assert len(np.unique(out[..., :3].reshape(-1, 3), axis=0)) == 1
 
 
 def test_rgb10a2_output(oracle):
