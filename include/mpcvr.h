@@ -91,7 +91,7 @@ typedef struct mpcvr_settings {
 typedef struct mpcvr_rect { int32_t left, top, right, bottom; } mpcvr_rect;
 
 /* mem_kind for mpcvr_copy_sample */
-enum { MPCVR_MEM_HOST = 0, MPCVR_MEM_DEVICE = 1 };
+enum { MPCVR_MEM_HOST = 0, MPCVR_MEM_DEVICE = 1, MPCVR_MEM_HOST_PINNED = 2 };
 
 /* ProcAmp flags — DXVA2_ProcAmp_* bit values */
 #define MPCVR_PROCAMP_BRIGHTNESS 0x1
@@ -144,8 +144,11 @@ int32_t mpcvr_set_procamp(mpcvr_ctx *ctx, uint32_t flags, float brightness, floa
 
 /* CopySample / MemCopyToTexSrcVideo — DX11VideoProcessor.cpp:2202,1213-1252.
  * data: one media sample (planes back to back); pitch: luma row pitch in bytes (>0).
- * MPCVR_MEM_HOST: staged through pinned memory and uploaded (applies CopyPlane10to16's <<6 on the
- * device side).  MPCVR_MEM_DEVICE: zero-copy — the pointer is used in place and must stay valid until
+ * MPCVR_MEM_HOST: copied into one of three pinned staging buffers and uploaded on a copy stream, so the upload of
+ * sample n+1 overlaps the processing of sample n (CopyPlane10to16's <<6 / CopyFrameV210 / CopyFrameRGB* run on the
+ * device); the caller's buffer is free again when the call returns.  MPCVR_MEM_HOST_PINNED: the buffer is page-locked
+ * (hipHostMalloc / hipHostRegister) and is DMA'd from directly; it must stay untouched until mpcvr_synchronize or the
+ * third following copy_sample.  MPCVR_MEM_DEVICE: zero-copy — the pointer is used in place and must stay valid until
  * the following process/render call has completed (mirrors the IMediaSampleD3D11 branch :2528-2569). */
 int32_t mpcvr_copy_sample(mpcvr_ctx *ctx, const void *data, int32_t pitch, int32_t mem_kind);
 

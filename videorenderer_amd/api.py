@@ -40,7 +40,7 @@ UPSCALE_Nearest, UPSCALE_Mitchell, UPSCALE_CatmullRom, UPSCALE_Lanczos2, UPSCALE
 DOWNSCALE_Box, DOWNSCALE_Bilinear, DOWNSCALE_Hamming, DOWNSCALE_Bicubic, DOWNSCALE_BicubicSharp, DOWNSCALE_Lanczos = range(6)
 OUT_BGRA8, OUT_RGB10A2 = 0, 1
 FLAG_LANCZOS3_FIXED, FLAG_NO_FUSED, FLAG_NO_LUT, FLAG_NO_FAST_CONVERT = 1, 2, 4, 8
-MEM_HOST, MEM_DEVICE = 0, 1
+MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2
 PROCAMP_BRIGHTNESS, PROCAMP_CONTRAST, PROCAMP_HUE, PROCAMP_SATURATION = 1, 2, 4, 8
 
 # DXVA2_ExtendedFormat codes used by the reference (Helper.cpp:1215-1223)

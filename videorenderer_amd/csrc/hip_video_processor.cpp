@@ -55,7 +55,13 @@ CHipVideoProcessor::~CHipVideoProcessor()
     for (DevBuffer *b : {&m_TexSrcVideo, &m_TexRaw, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
                          &m_pqLut, &m_tapsXi, &m_tapsXw, &m_tapsXs, &m_tapsYi, &m_tapsYw, &m_tapsYs, &m_otherX, &m_otherY})
         b->Release();
-    if (m_pinned) (void)hipHostFree(m_pinned);
+    for (UploadSlot &u : m_up) {
+        u.dev.Release();
+        if (u.pinned) (void)hipHostFree(u.pinned);
+        if (u.uploaded) (void)hipEventDestroy(u.uploaded);
+        if (u.consumed) (void)hipEventDestroy(u.consumed);
+    }
+    if (m_copyStream) (void)hipStreamDestroy(m_copyStream);
     for (FrameSlot &fs : m_slots) {
         fs.dev.Release();
         if (fs.pinned) (void)hipHostFree(fs.pinned);
@@ -536,24 +542,49 @@ HRESULT CHipVideoProcessor::CopySample(const void *data, int pitch, int memKind)
     (void)hipSetDevice(m_device);
     const size_t bytes = (size_t)m_srcPitch * m_srcLines;
     HRESULT hr;
+    MarkConsumed();                                  // the previous sample is done with as far as the host is concerned
+    m_curSlot = -1;
     if (memKind == MPCVR_MEM_DEVICE) {               // zero-copy, cf. the IMediaSampleD3D11 branch :2528-2569
         return PrepareSample((const uint8_t *)data, &m_curSample);
     }
-    if (memKind != MPCVR_MEM_HOST) return Fail(MPCVR_E_INVALIDARG, "mem_kind");
-    const bool v210 = m_srcParams->cformat == MPCVR_CF_V210 || m_srcParams->layout == LAY_RGB;   // formats with an unpack step
-    DevBuffer &upload = v210 ? m_TexRaw : m_TexSrcVideo;
-    if ((hr = CheckHip(upload.CheckCreate(bytes), "upload buffer"))) return hr;
-    if (m_pinnedSize < bytes) {
-        if (m_pinned) (void)hipHostFree(m_pinned);
-        m_pinned = nullptr; m_pinnedSize = 0;
-        if ((hr = CheckHip(hipHostMalloc(&m_pinned, bytes, hipHostMallocDefault), "pinned staging"))) return hr;
-        m_pinnedSize = bytes;
+    if (memKind != MPCVR_MEM_HOST && memKind != MPCVR_MEM_HOST_PINNED) return Fail(MPCVR_E_INVALIDARG, "mem_kind");
+    if (!m_copyStream && (hr = CheckHip(hipStreamCreateWithFlags(&m_copyStream, hipStreamNonBlocking), "copy stream"))) return hr;
+    const int si = m_upNext;
+    m_upNext = (m_upNext + 1) % kUploadSlots;
+    UploadSlot &u = m_up[si];
+    if (!u.uploaded) {
+        if ((hr = CheckHip(hipEventCreateWithFlags(&u.uploaded, hipEventDisableTiming), "upload event"))) return hr;
+        if ((hr = CheckHip(hipEventCreateWithFlags(&u.consumed, hipEventDisableTiming), "consume event"))) return hr;
     }
-    // the staging buffer may still feed the previous upload
-    if ((hr = CheckHip(hipStreamSynchronize(m_stream), "sync before staging"))) return hr;
-    std::memcpy(m_pinned, data, bytes);              // CopyPlaneAsIs (Helper.cpp:414-428); the <<6 of CopyPlane10to16 happens at load
-    if ((hr = CheckHip(hipMemcpyAsync(upload.ptr, m_pinned, bytes, hipMemcpyHostToDevice, m_stream), "upload"))) return hr;
-    return PrepareSample((const uint8_t *)upload.ptr, &m_curSample);
+    // the slot's staging / device buffers are free once the work that last used them has completed
+    if (u.inFlight && (hr = CheckHip(hipEventSynchronize(u.consumedRecorded ? u.consumed : u.uploaded), "upload slot wait"))) return hr;
+    if ((hr = CheckHip(u.dev.CheckCreate(bytes), "upload buffer"))) return hr;
+    const void *from = data;
+    if (memKind == MPCVR_MEM_HOST) {
+        if (u.pinnedSize < bytes) {
+            if (u.pinned) (void)hipHostFree(u.pinned);
+            u.pinned = nullptr; u.pinnedSize = 0;
+            if ((hr = CheckHip(hipHostMalloc(&u.pinned, bytes, hipHostMallocDefault), "pinned staging"))) return hr;
+            u.pinnedSize = bytes;
+        }
+        std::memcpy(u.pinned, data, bytes);          // the reference's only per-frame CPU work (MemCopyToTexSrcVideo); the
+        from = u.pinned;                             // <<6 / v210 / RGB repacks happen on the device (PrepareSample)
+    }
+    // the new data must not overtake work of the main stream that still reads this device buffer
+    if ((hr = CheckHip(hipMemcpyAsync(u.dev.ptr, from, bytes, hipMemcpyHostToDevice, m_copyStream), "upload"))) return hr;
+    if ((hr = CheckHip(hipEventRecord(u.uploaded, m_copyStream), "upload event"))) return hr;
+    if ((hr = CheckHip(hipStreamWaitEvent(m_stream, u.uploaded, 0), "stream wait"))) return hr;
+    u.inFlight = true; u.consumedRecorded = false;
+    m_curSlot = si;
+    return PrepareSample((const uint8_t *)u.dev.ptr, &m_curSample);
+}
+
+// a Process / Render that read the current upload slot has been queued: the slot may be recycled after it
+void CHipVideoProcessor::MarkConsumed()
+{
+    if (m_curSlot < 0) return;
+    UploadSlot &u = m_up[m_curSlot];
+    if (u.consumed && hipEventRecord(u.consumed, m_stream) == hipSuccess) u.consumedRecorded = true;
 }
 
 HRESULT CHipVideoProcessor::ConvertColorPass(const uint8_t *sample)
@@ -628,6 +659,7 @@ HRESULT CHipVideoProcessor::Process(void *pRenderTarget, int rtPitch, const CRec
     (void)hipEventRecord(m_evStart, m_stream);
     hr = ProcessOne(m_curSample, pRenderTarget, rtPitch);
     (void)hipEventRecord(m_evStop, m_stream);
+    MarkConsumed();
     m_timed = true;
     return hr;
 }

@@ -137,8 +137,20 @@ private:
     // device resources
     DevBuffer m_TexSrcVideo;       // uploaded sample (for v210: the Y210 texture CopyFrameV210 fills)
     DevBuffer m_TexRaw;            // v210 only: the raw sample before the unpack
-    void *m_pinned = nullptr;      // pinned staging for uploads
-    size_t m_pinnedSize = 0;
+    // upload ring (N3): pinned staging + device buffer per slot, copies on their own stream so that the upload of the
+    // next sample overlaps the processing of the current one
+    struct UploadSlot {
+        void *pinned = nullptr; size_t pinnedSize = 0;
+        DevBuffer dev;
+        hipEvent_t uploaded = nullptr, consumed = nullptr;
+        bool inFlight = false;         // an upload into this slot has been queued
+        bool consumedRecorded = false; // a Process that read it has been queued after that upload
+    };
+    static constexpr int kUploadSlots = 3;
+    UploadSlot m_up[kUploadSlots];
+    int m_upNext = 0, m_curSlot = -1;
+    hipStream_t m_copyStream = nullptr;
+    void MarkConsumed();
     const uint8_t *m_curSample = nullptr;   // device pointer of the current sample (own buffer or zero-copy)
     DevBuffer m_TexConvertOutput, m_TexResize, m_BackBuffer, m_Snapshot;
     DevBuffer m_dither;
