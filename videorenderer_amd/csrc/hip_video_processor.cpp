@@ -525,6 +525,7 @@ void CHipVideoProcessor::FillFusedParams(const uint8_t *sample, void *rt, int rt
     const bool no_lut = (m_cfg.flags & MPCVR_FLAG_NO_LUT) != 0;
     fp->pq_lut = (m_pqLutValid && !no_lut) ? (const float *)m_pqLut.ptr : nullptr;
     fp->literal_tail = no_lut ? 1 : 0;
+    fp->dst_aligned16 = (((uintptr_t)rt) & 15) == 0;        // batches: ProcessBatch checks every target
     // vectorised convert: dword loads need 4-byte aligned rows and a source rect starting on a 4-px boundary
     fp->fast_convert = (m_srcRect.left % 4 == 0) && (m_srcRect.top % 2 == 0) && (m_srcPitch % 4 == 0) &&
                        (fp->conv.pitch[1] % 4 == 0) && (fp->plane_off[1] % 4 == 0) && (fp->plane_off[2] % 4 == 0) &&
@@ -705,8 +706,11 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
     if ((hr = CheckHip(hipMemcpyAsync(slot.dev.ptr, fr, sizeof(FusedFrame) * n, hipMemcpyHostToDevice, m_stream), "frame table"))) return hr;
     FusedParams fp{};
     FillFusedParams((const uint8_t *)srcs[0], nullptr, rtPitch, &fp);
-    for (int i = 0; i < n; i++)
+    fp.dst_aligned16 = 1;
+    for (int i = 0; i < n; i++) {
         if (((uintptr_t)srcs[i] & 3) != 0) fp.fast_convert = 0;
+        if (((uintptr_t)dsts[i] & 15) != 0) fp.dst_aligned16 = 0;
+    }
     (void)hipEventRecord(m_evStart, m_stream);
     hr = CheckHip(LaunchFusedUp2x(fp, (const FusedFrame *)slot.dev.ptr, FusedFrame{nullptr, nullptr}, n, m_stream), "k_fused_up2x");
     (void)hipEventRecord(m_evStop, m_stream);

@@ -233,8 +233,9 @@ __device__ __forceinline__ int chroma_v4(const FusedArgs &P, int sy) { return 2 
 // fr/4 for fr = 0..4 as a float built from integer selects (wave-uniform => SGPR; no v_cvt/v_mul per iteration)
 __device__ __forceinline__ float quarter(int fr)
 {
-    const uint32_t b = fr <= 0 ? 0u : fr == 1 ? 0x3e800000u : fr == 2 ? 0x3f000000u : fr == 3 ? 0x3f400000u : 0x3f800000u;
-    return __builtin_bit_cast(float, b);
+    // float bits of fr/4 = (one byte of a 40-bit table) << 22: 0.25 = 0xFA<<22, 0.5 = 0xFC<<22, 0.75 = 0xFD<<22, 1 = 0xFE<<22
+    const uint64_t table = 0xFEFDFCFA00ull;
+    return __builtin_bit_cast(float, (uint32_t)((table >> (8 * fr)) & 0xffu) << 22);
 }
 
 // y0,y1: the two (clamped) rect rows of the block.
@@ -253,7 +254,7 @@ __device__ __forceinline__ void load_raw(const FusedArgs &P, gcptr py, const Raw
     const gcptr pu = py + P.off_u, pv = (P01X || P.planes == 2) ? pu : py + P.off_v;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        if (i == 0 && !P.center_h) { r.c[0][0] = r.c[1][0] = 0; continue; }
+        if (i == 0 && (P01X || !P.center_h)) { r.c[0][0] = r.c[1][0] = 0; continue; }
         r.c[0][i] = ld_uv<P01X>(P, pu + oA, pv + oA, opaque(ra.coff[i]));
         r.c[1][i] = ld_uv<P01X>(P, pu + oB, pv + oB, opaque(ra.coff[i]));
     }
@@ -287,7 +288,7 @@ __device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)
         Ycol[0] = f2{(float)(r.y[0] & 0xffu), (float)(r.y[1] & 0xffu)};
         Ycol[1] = f2{(float)((r.y[0] >> 8) & 0xffu), (float)((r.y[1] >> 8) & 0xffu)};
     }
-    if (P.center_h) {                             // u' = sx/2 - 0.25
+    if (!P01X && P.center_h) {                    // u' = sx/2 - 0.25 (MPEG-1 siting runs through the generic variant)
         Ucol[0] = pk_fma(Uc[1], splat(0.75f), Uc[0] * splat(0.25f)); Vcol[0] = pk_fma(Vc[1], splat(0.75f), Vc[0] * splat(0.25f));
         Ucol[1] = pk_fma(Uc[2], splat(0.25f), Uc[1] * splat(0.75f)); Vcol[1] = pk_fma(Vc[2], splat(0.25f), Vc[1] * splat(0.75f));
     } else {                                      // u' = sx/2
@@ -511,8 +512,8 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
             if (t >= 3 && store_ok) {
 #pragma unroll
                 for (int kk = 0; kk < 2; kk++) {
-                    const int k = a - 3 + kk;                     // source row -> output rows 2k (even), 2k+1 (odd)
-                    if (k >= s1) break;
+                    const int k = a - 3 + kk;                     // source row -> output rows 2k (even), 2k+1 (odd); k < s1
+                                                                  // because segments hold an even number of rows (host-checked)
 #pragma unroll
                     for (int par = 0; par < 2; par++) {
                         // even: base = k-1 -> row k-1+off = a-6 + (kk+2+off); odd: base = k -> a-6 + (kk+3+off)
@@ -534,13 +535,10 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
                             // v_mad_u32_u24 reads; the result byte is the top byte, gathered by two v_perm_b32 per pixel.
                             const uint32_t *drow = Di + (wy & 31) * 32;          // sampler WRAP+POINT: texel (wx mod 32, wy mod 32)
                             uint32_t dj[4];
-                            if (d_aligned) {
+                            {   // FASTEPI implies off_x % 4 == 0 (launcher): the four texels are one aligned 16-byte read
                                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                                 const u32x4 dd = *(const u32x4 *)(drow + (wx0 & 31));
                                 dj[0] = dd.x; dj[1] = dd.y; dj[2] = dd.z; dj[3] = dd.w;
-                            } else {
-#pragma unroll
-                                for (int px = 0; px < 4; px++) dj[px] = drow[(wx0 + px) & 31];
                             }
                             f2 uq[3][2];
 #pragma unroll
@@ -574,7 +572,7 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
                             }
                         }
                         const gptr rowp = pdst + (uint32_t)wy * (uint32_t)P.dst_pitch;    // wave-uniform row base + per-lane 32-bit offset
-                        if (st_aligned) {
+                        if (FASTEPI || st_aligned) {      // FASTEPI: 16-byte alignment of every row is a launch precondition
                             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                             u32x4 v4 = {pk[0], pk[1], pk[2], pk[3]};
                             *(__attribute__((address_space(1))) u32x4 *)(rowp + opaque(lane_off)) = v4;
@@ -681,9 +679,12 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
                     : (c.tail == TAIL_HLG_TO_SDR && !P.literal_tail) ? TAILK_HLG : TAILK_ALU;
     static const int lds_pad = EnvInt("MPCVR_FUSED_LDS_PAD", 0);   // experiments: lower the occupancy by claiming more LDS
     const size_t lds = LDS_A + LDS_D + LDS_DB + (tailk == TAILK_PQ_LUT ? LDS_T : 0) + (size_t)lds_pad;
-    const bool p01x = c.fmt.planes == 2 && c.fmt.bytes == 2;
+    // the specialised variant: bi-planar 16-bit (P010/P016) with MPEG-2 / co-sited chroma; everything else (8-bit, planar,
+    // MPEG-1 siting) runs through the variant that reads these properties at run time
+    const bool p01x = c.fmt.planes == 2 && c.fmt.bytes == 2 && !a.center_h;
     // the integer epilogue needs k*M + (j << 14) < 2^32 and M < 2^24 (true for 10-bit internal -> 8-bit target)
-    const bool fastepi = a.final_pass && !a.out10 && a.epi_mul != 0;
+    // ... and its 16-byte stores / dither reads need off_x % 4 == 0 and 16-byte aligned rows
+    const bool fastepi = a.final_pass && !a.out10 && a.epi_mul != 0 && P.dst_aligned16 && (a.off_x & 3) == 0 && (a.dst_pitch & 15) == 0;
 #define MPCVR_LAUNCH2(NT, TK, PX) do { if (fastepi) hipLaunchKernelGGL((k_fused_up2x<NT, TK, PX, true>), grid, block, lds, s, a, frames_dev, single); \
                                        else hipLaunchKernelGGL((k_fused_up2x<NT, TK, PX, false>), grid, block, lds, s, a, frames_dev, single); } while (0)
 #define MPCVR_LAUNCH(NT, TK) do { if (p01x) MPCVR_LAUNCH2(NT, TK, true); else MPCVR_LAUNCH2(NT, TK, false); } while (0)

@@ -32,6 +32,7 @@ struct FusedParams {
     int out_w, out_h;         // 2*conv.out_w, 2*conv.out_h
     const float *pq_lut;      // device, kPqLutSize floats: x -> Hable(ST2084ToLinear(x)*scale)/hable(4.8); null => ALU
     int fast_convert;         // layout/alignments allow the vectorised convert
+    int dst_aligned16;        // every render target of the launch starts on a 16-byte boundary
     int literal_tail;         // MPCVR_FLAG_NO_LUT: evaluate the HDR tails literally in ALU (no LUT, no algebraic shortcut)
 };
 bool FusedUp2xSupported(const FusedParams &P);
