@@ -295,19 +295,45 @@ __device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)
         Ucol[0] = Uc[1]; Vcol[0] = Vc[1];
         Ucol[1] = pk_fma(Uc[2], splat(0.5f), Uc[1] * splat(0.5f)); Vcol[1] = pk_fma(Vc[2], splat(0.5f), Vc[1] * splat(0.5f));
     }
+    f2 rgbc[2][3];
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++) {              // rr = luma column of the block
-        const f2 Y = Ycol[rr], U = Ucol[rr], V = Vcol[rr];
-        f2 rgb[3];
+    for (int rr = 0; rr < 2; rr++)                // rr = luma column of the block
 #pragma unroll
         for (int ch = 0; ch < 3; ch++)
-            rgb[ch] = fma_k<true>(MM, 3 * ch, Y, fma_k<false>(MM, 3 * ch + 1, U, fma_k<false>(MM, 3 * ch + 2, V, CC[ch])));
+            rgbc[rr][ch] = fma_k<true>(MM, 3 * ch, Ycol[rr], fma_k<false>(MM, 3 * ch + 1, Ucol[rr], fma_k<false>(MM, 3 * ch + 2, Vcol[rr], CC[ch])));
+    // PQ: all twelve table reads of the block are issued together (their addresses depend only on the matrix results),
+    // so the wave pays one LDS round trip per iteration instead of six
+    f2 linc[2][3];
+    if (TAIL == TAILK_PQ_LUT) {
+        f2 ent[2][3][2]; float frc[2][3][2];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const float t = rgbc[rr][ch][e] * (float)(LUT_N - 1);
+                    frc[rr][ch][e] = __builtin_amdgcn_fractf(t);
+                    ent[rr][ch][e] = T[(int)t];
+                }
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    float r;   // plain v_fma_f32 (see lut_eval)
+                    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(ent[rr][ch][e].y), "v"(frc[rr][ch][e]), "v"(ent[rr][ch][e].x));
+                    linc[rr][ch][e] = r;
+                }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const f2 *rgb = rgbc[rr];
         if (TAIL == TAILK_PQ_LUT) {
             // Shaders.cpp:870-923: per-channel saturate -> ST2084ToLinear*scale -> Hable/hable(4.8) from the LDS table,
             // then the 2020->709 matrix, saturate and pow 1/2.2 in ALU
-            f2 lin[3];
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) lin[ch] = f2{lut_eval(T, rgb[ch].x), lut_eval(T, rgb[ch].y)};
+            const f2 *lin = linc[rr];
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
                 const f2 g = fma_k<true>(GG, 3 * ch, lin[0], fma_k<false>(GG, 3 * ch + 1, lin[1], mul_k(GG, 3 * ch + 2, lin[2])));
