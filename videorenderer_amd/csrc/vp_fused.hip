@@ -505,12 +505,18 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
             // lane owns output columns 4l..4l+3 = sources k = 2l (e = 0,1), 2l+1 (e = 2,3); A column of source k is k+4.
             // av[i] = (row a, row a+1) of A column 2l+i, i = 0..9  =>  source 2l + i - 4.
             if (xy_active) {
+                f4 abuf[2][5];                                // LDS reads of channel c+1 are in flight while channel c is filtered
+#pragma unroll
+                for (int i = 0; i < 5; i++) abuf[0][i] = ((const f4 *)(A + (0 * AW + 2 * lane) * 2))[i];
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    const f4 *ap = (const f4 *)(A + (c * AW + 2 * lane) * 2);
+                    if (c < 2) {
+#pragma unroll
+                        for (int i = 0; i < 5; i++) abuf[(c + 1) & 1][i] = ((const f4 *)(A + ((c + 1) * AW + 2 * lane) * 2))[i];
+                    }
                     f2 av[10];
 #pragma unroll
-                    for (int i = 0; i < 5; i++) { const f4 p4 = ap[i]; av[2 * i] = f2{p4.x, p4.y}; av[2 * i + 1] = f2{p4.z, p4.w}; }
+                    for (int i = 0; i < 5; i++) { const f4 p4 = abuf[c & 1][i]; av[2 * i] = f2{p4.x, p4.y}; av[2 * i + 1] = f2{p4.z, p4.w}; }
                     f2 o[4];                                  // 4 output columns x (row a, row a+1)
 #pragma unroll
                     for (int odd = 0; odd < 2; odd++)         // even output 2k: base = k-1; odd output 2k+1: base = k
@@ -543,6 +549,15 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
 #pragma unroll
                     for (int par = 0; par < 2; par++) {
                         // even: base = k-1 -> row k-1+off = a-6 + (kk+2+off); odd: base = k -> a-6 + (kk+3+off)
+                        const int wy = P.off_y + 2 * k + par;
+                        uint32_t dj[4] = {0, 0, 0, 0};
+                        if (FASTEPI) {  // dither texels of this row first: the LDS round trip hides behind the tap filters.
+                            // sampler WRAP+POINT: texel (wx mod 32, wy mod 32); FASTEPI implies off_x % 4 == 0 (launcher),
+                            // so the four texels are one aligned 16-byte read
+                            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                            const u32x4 dd = *(const u32x4 *)(Di + (wy & 31) * 32 + (wx0 & 31));
+                            dj[0] = dd.x; dj[1] = dd.y; dj[2] = dd.z; dj[3] = dd.w;
+                        }
                         f2 res[3][2];                             // [channel][pixel pair], saturated
 #pragma unroll
                         for (int c = 0; c < 3; c++) {
@@ -550,7 +565,6 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
                                             [&](int tt) { return win[(2 * u + 2 + kk + 2 + par + tap_off<NT>(tt)) & 7][c][0]; },
                                             [&](int tt) { return win[(2 * u + 2 + kk + 2 + par + tap_off<NT>(tt)) & 7][c][1]; }, res[c][0], res[c][1]);
                         }
-                        const int wy = P.off_y + 2 * k + par;
                         uint32_t pk[4];
                         if (FASTEPI) {
                             // m_TexsPostScale store/load: k = floor(x*maxv + 0.5), p = k/maxv; ps_final_pass.hlsl:29:
@@ -559,13 +573,6 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
                             // and differs from the fp32 shader arithmetic in 4 of the 2^20 (k, j) pairs, where fp32 rounds
                             // the sum up onto an integer.  x*maxv + 2^23 leaves k in the low mantissa bits, which is all
                             // v_mad_u32_u24 reads; the result byte is the top byte, gathered by two v_perm_b32 per pixel.
-                            const uint32_t *drow = Di + (wy & 31) * 32;          // sampler WRAP+POINT: texel (wx mod 32, wy mod 32)
-                            uint32_t dj[4];
-                            {   // FASTEPI implies off_x % 4 == 0 (launcher): the four texels are one aligned 16-byte read
-                                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                                const u32x4 dd = *(const u32x4 *)(drow + (wx0 & 31));
-                                dj[0] = dd.x; dj[1] = dd.y; dj[2] = dd.z; dj[3] = dd.w;
-                            }
                             f2 uq[3][2];
 #pragma unroll
                             for (int c = 0; c < 3; c++)
