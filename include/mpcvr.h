@@ -133,6 +133,14 @@ int32_t mpcvr_set_flip(mpcvr_ctx *ctx, int32_t flip);
  * 0 progressive, 1 interlaced top field first, 2 interlaced bottom field first.  With bDeintBlend an interlaced 4:2:0
  * sample goes through the blend variant of the convert shader (:3075, Shaders.cpp:232-237). */
 int32_t mpcvr_set_sample_format(mpcvr_ctx *ctx, int32_t frame_format);
+/* HDR output: `enable` stands in for m_bHdrPassthroughSupport && (m_bHdrPassthrough || m_bHdrLocalToneMapping) — the
+ * display is in HDR10 mode — so PQ sources pass through unconverted and HLG is converted to PQ (convertType,
+ * DX11VideoProcessor.cpp:2948-2950); pick output_format RGB10A2 as the reference's swap chain does.  tone_map_type =
+ * m_iHdrLocalToneMappingType (0 off, 1 ACES, 2 Reinhard, 3 Habel, 4 Moebius, 5 BT.2390, 6 ST 2094-10), display_max_nits =
+ * m_iHdrDisplayMaxNits: ps_hdr10_tonemap.hlsl then runs as a post-scale step once mpcvr_set_hdr_metadata was called. */
+int32_t mpcvr_set_hdr_output(mpcvr_ctx *ctx, int32_t enable, int32_t tone_map_type, float display_max_nits);
+/* the values Render() passes to SetHDR10ShaderParams (:907-917, :2716-2727), sanitised the same way */
+int32_t mpcvr_set_hdr_metadata(mpcvr_ctx *ctx, float min_mastering_nits, float max_mastering_nits, float max_cll, float max_fall);
 
 /* Configure — DX11VideoProcessor.cpp:3800-4050: diff each field, rebuild only what changed. */
 int32_t mpcvr_configure(mpcvr_ctx *ctx, const mpcvr_settings *settings);

@@ -440,10 +440,23 @@ static void mat3_apply(const float m[9], float rgb[3])
  * (alpha follows the same scalar ops in HLSL but is forced to 1 by every store format; not modelled) */
 void orc_hdr_tail(float rgb[3], int trc, int prim, int convert_to_sdr, float lum_scale)
 {
+    orc_hdr_tail_ex(rgb, trc, prim, convert_to_sdr, lum_scale, 0);
+}
+
+/* hdr_output = m_bHdrPassthroughSupport && (m_bHdrPassthrough || m_bHdrLocalToneMapping): convertType
+ * (DX11VideoProcessor.cpp:2948-2950) is then never SHADER_CONVERT_TO_SDR, and SHADER_CONVERT_TO_PQ for HLG */
+void orc_hdr_tail_ex(float rgb[3], int trc, int prim, int convert_to_sdr, float lum_scale, int hdr_output)
+{
     float gm[9];
     const int bt2020 = (prim == PRIM_2020);
-    const int hdr2sdr = convert_to_sdr && (trc == TRC_2084 || trc == TRC_HLG);        /* :614 */
+    const int hdr2sdr = convert_to_sdr && !hdr_output && (trc == TRC_2084 || trc == TRC_HLG);        /* :614, :2948 */
     int is_linear = 0;
+    if (!hdr2sdr && hdr_output && trc == TRC_HLG) {                                    /* bConvertHLGtoPQ :616,885-891 */
+        for (int i = 0; i < 3; i++) rgb[i] = saturatef(rgb[i]);
+        orc_hlg_to_linear(rgb);
+        for (int i = 0; i < 3; i++) rgb[i] = orc_linear_to_st2084(rgb[i], 1000.0f);
+        return;
+    }
     if (hdr2sdr) {
         if (trc == TRC_HLG) {                                                          /* :862-868 */
             for (int i = 0; i < 3; i++) rgb[i] = saturatef(rgb[i]);
@@ -475,6 +488,111 @@ void orc_hdr_tail(float rgb[3], int trc, int prim, int convert_to_sdr, float lum
     }
     if (is_linear)                                                                     /* :917-923 */
         for (int i = 0; i < 3; i++) rgb[i] = hlsl_pow(saturatef(rgb[i]), 1.0f / 2.2f);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* HDR10 -> HDR10 local tone mapping — Shaders/d3d11/ps_hdr10_tonemap.hlsl:272-336 (post-scale step of Process,   */
+/* DX11VideoProcessor.cpp:3359-3367); constants as SetHDR10ShaderParams sanitises them (:907-917).  The Dolby    */
+/* Vision L2 trims (L2Enabled) are not modelled.                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { float min_m, max_m, max_cll, max_fall, display_max; int selection; } hdr_tm_t;
+
+static hdr_tm_t hdr_tm_params(const orc_params *p)
+{
+    hdr_tm_t t = {p->hdr_min_mastering, p->hdr_max_mastering, p->hdr_max_cll, p->hdr_max_fall, p->hdr_display_max_nits, p->hdr_tonemap_type};
+    if (t.min_m <= 0.f) t.min_m = 0.f;
+    if (t.max_m <= 10.f) t.max_m = 1000.f;
+    if (t.max_cll <= 10.f) t.max_cll = t.max_m;
+    if (t.max_fall <= 1.f) t.max_fall = t.max_cll;
+    if (t.display_max < 100.f || t.display_max > 10000.f) t.display_max = 1000.f;
+    if (t.selection < 1 || t.selection > 6) t.selection = 1;
+    return t;
+}
+
+static inline float lerpf(float a, float b, float t) { return a + t * (b - a); }
+static float pl_smoothstep(float e0, float e1, float x)
+{
+    float t = (x - e0) / (e1 - e0);
+    t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+    return t * t * (3.0f - 2.0f * t);
+}
+
+void orc_hdr10_tonemap(float c[3], const orc_params *p)
+{
+    const hdr_tm_t k = hdr_tm_params(p);
+    for (int i = 0; i < 3; i++) c[i] = orc_st2084_to_linear(saturatef(c[i]), 10000.0f);     /* :275-277 */
+    if (k.selection == 5) {                                                                 /* BT2390Tonemap :68-124 */
+        float safe = k.max_cll;
+        if (safe <= 10.0f) safe = k.max_m;
+        if (safe <= 10.0f) safe = 1000.0f;
+        if (!(k.display_max >= safe)) {
+            const float avg = 0.2627f * c[0] + 0.6780f * c[1] + 0.0593f * c[2];
+            if (!(avg <= 0.000001f)) {
+                const float max_pq = orc_linear_to_st2084(safe, 10000.0f), tgt_pq = orc_linear_to_st2084(k.display_max, 10000.0f);
+                const float e1 = orc_linear_to_st2084(avg, 10000.0f);
+                float ks = 1.5f * tgt_pq - 0.5f * max_pq;
+                ks = fmaxf(0.0f, ks);
+                float e2 = e1;
+                if (e1 > ks) {
+                    const float t = (e1 - ks) / fmaxf(1e-6f, max_pq - ks), t2 = t * t, t3 = t2 * t;
+                    e2 = (2.0f * t3 - 3.0f * t2 + 1.0f) * ks + (t3 - 2.0f * t2 + t) * (max_pq - ks) + (-2.0f * t3 + 3.0f * t2) * tgt_pq;
+                }
+                const float lin = orc_st2084_to_linear(e2, 10000.0f);
+                const float g = lin / avg;
+                for (int i = 0; i < 3; i++) c[i] = c[i] * g;
+            }
+        }
+        for (int i = 0; i < 3; i++) c[i] = orc_linear_to_st2084(c[i], 10000.0f);
+        return;
+    }
+    if (k.selection == 6) {                                                                 /* ST209410Tonemap :133-205 */
+        if (!(k.display_max >= k.max_cll)) {
+            const float src_min = orc_linear_to_st2084(k.min_m, 10000.0f), src_max = orc_linear_to_st2084(k.max_cll, 10000.0f);
+            const float src_avg = orc_linear_to_st2084(k.max_fall, 10000.0f);
+            const float dst_min = orc_linear_to_st2084(0.0f, 10000.0f), dst_max = orc_linear_to_st2084(k.display_max, 10000.0f);
+            const float min_knee = 0.1f, max_knee = 0.8f, def_knee = 0.4f, knee_adaptation = 0.4f;
+            const float src_knee_min = lerpf(src_min, src_max, min_knee), src_knee_max = lerpf(src_min, src_max, max_knee);
+            const float dst_knee_min = lerpf(dst_min, dst_max, min_knee), dst_knee_max = lerpf(dst_min, dst_max, max_knee);
+            float src_knee = (k.max_fall > 0.0f) ? src_avg : lerpf(src_min, src_max, def_knee);
+            src_knee = fminf(fmaxf(src_knee, src_knee_min), src_knee_max);
+            const float target = (src_knee - src_min) / (src_max - src_min);
+            const float adapted = lerpf(dst_min, dst_max, target);
+            const float tuning = 1.0f - pl_smoothstep(max_knee, def_knee, target) * pl_smoothstep(min_knee, def_knee, target);
+            const float adaptation = lerpf(knee_adaptation, 1.0f, tuning);
+            float dst_knee = lerpf(src_knee, adapted, adaptation);
+            dst_knee = fminf(fmaxf(dst_knee, dst_knee_min), dst_knee_max);
+            const float x2 = orc_st2084_to_linear(src_knee, 10000.0f), y2 = orc_st2084_to_linear(dst_knee, 10000.0f);
+            const float x1 = k.min_m, x3 = k.max_cll, y1 = 0.0f, y3 = k.display_max;
+            const float m00 = x2 * x3 * (y2 - y3), m01 = x1 * x3 * (y3 - y1), m02 = x1 * x2 * (y1 - y2);
+            const float m10 = x3 * y3 - x2 * y2, m11 = x1 * y1 - x3 * y3, m12 = x2 * y2 - x1 * y1;
+            const float m20 = x3 - x2, m21 = x1 - x3, m22 = x2 - x1;
+            const float coef0 = m00 * y1 + m01 * y2 + m02 * y3, coef1 = m10 * y1 + m11 * y2 + m12 * y3, coef2 = m20 * y1 + m21 * y2 + m22 * y3;
+            const float kk = 1.0f / (x3 * y3 * (x1 - x2) + x2 * y2 * (x3 - x1) + x1 * y1 * (x2 - x3));
+            const float c1 = kk * coef0, c2 = kk * coef1, c3 = kk * coef2;
+            const float xn = 0.2627f * c[0] + 0.6780f * c[1] + 0.0593f * c[2];
+            const float yn = (c1 + c2 * xn) / (1.0f + c3 * xn);
+            const float g = (xn > 0.0f) ? (yn / xn) : 1.0f;
+            for (int i = 0; i < 3; i++) c[i] = c[i] * g;
+        }
+        for (int i = 0; i < 3; i++) c[i] = orc_linear_to_st2084(c[i], 10000.0f);
+        return;
+    }
+    const float base = fmaxf(k.display_max, k.max_m);                                       /* :299-306 */
+    const float eff = fminf(base, k.max_cll);
+    const float fall = fminf(base / k.max_fall, 1.0f);
+    for (int i = 0; i < 3; i++) {
+        float v = c[i] * (1.0f / eff);
+        v = saturatef(v);
+        v = v * fall;
+        if (k.selection == 2) v = v / (1.0f + v);                                                            /* Reinhard :49-52 */
+        else if (k.selection == 3) {                                                                         /* Habel :54-58 */
+            const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+            v = ((v * (A * v + C * B) + D * E) / (v * (A * v + B) + D * F)) - E / F;
+        } else if (k.selection == 4) v = v / (1.0f + v / (k.display_max + 1e-6f));                          /* Moebius :60-65 */
+        else v = (v * (2.51f * v + 0.03f)) / (v * (2.43f * v + 0.59f) + 0.14f);                              /* ACES :34-47 */
+        v = v * k.display_max;
+        c[i] = orc_linear_to_st2084(v, 10000.0f);
+    }
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -987,7 +1105,7 @@ static void convert_pass(const orc_params *p, const convert_ctx *c, img_t *out)
             rgb[0] = (cm[0] * y + cm[1] * uv[0] + cm[2] * uv[1]) + cm[9];
             rgb[1] = (cm[3] * y + cm[4] * uv[0] + cm[5] * uv[1]) + cm[10];
             rgb[2] = (cm[6] * y + cm[7] * uv[0] + cm[8] * uv[1]) + cm[11];
-            orc_hdr_tail(rgb, trc, prim, p->bConvertToSdr, c->lum_scale);
+            orc_hdr_tail_ex(rgb, trc, prim, p->bConvertToSdr, c->lum_scale, p->hdr_output);
             float px[4] = {rgb[0], rgb[1], rgb[2], 1.0f};
             store_fmt(c->internal_fmt, px, out->p + ((size_t)j * rw + i) * 4);
         }
@@ -1242,6 +1360,11 @@ int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
     const int need_dither = (swap_fmt == FMT_BGRA8 && internal != FMT_BGRA8) ||
                             (swap_fmt == FMT_RGB10A2 && internal == FMT_RGBA16F);
     const int final_pass = p->bUseDither && need_dither && dither_f16 != NULL;
+    /* m_pPSHDR10ToneMapping: a post-scale step between the resize and the final pass (:3359-3367), created once the
+       renderer has HDR10 metadata for an HDR source shown in HDR (:2716-2727) */
+    const int trc_src = EXF_TRC(c.exfmt);
+    const int tonemap = p->hdr_output && p->hdr_tonemap_type > 0 && (trc_src == TRC_2084 || trc_src == TRC_HLG);
+    const int has_steps = final_pass || tonemap;
     const float quant = (swap_fmt == FMT_RGB10A2) ? 1023.0f : 255.0f;     /* ps_final_pass QUANTIZATION */
 
     /* ConvertColorPass -> m_TexConvertOutput (w1 x h1, internal format); rSrc = whole texture :3316-3319 */
@@ -1279,7 +1402,7 @@ int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
     const int ax_first = rotated ? 1 : 0;
     /* destination format of the last resize draw: post-scale texture (internal) if a final pass
        follows, else the render target itself (:3334-3352, :3417-3419) */
-    const int last_store = final_pass ? internal : swap_fmt;
+    const int last_store = has_steps ? internal : swap_fmt;
     /* Process :3348-3352: with post-scale steps the resize is skipped when rSrc == dstRect and rotation == 0 (flip alone
        is then ignored); without them ResizeShaderPass always runs */
     const int same_rect = (w1 == w2 && h1 == h2 && dl == 0 && dt == 0);
@@ -1294,7 +1417,7 @@ int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
         if ((rc = resize_draw(&conv, srect, &mid, ax_first, rx, rot, flip, p->flags, FMT_RGBA16F))) goto done;
         if ((rc = resize_draw(&mid, NULL, &post, 1, ry, 0, 0, p->flags, last_store))) goto done;
         result = &post; result_fmt = last_store;
-    } else if (rx.kind != RS_NONE || ry.kind != RS_NONE || sw != w2 || sh != h2 || rot != 0 || (flip && !(final_pass && same_rect))) {
+    } else if (rx.kind != RS_NONE || ry.kind != RS_NONE || sw != w2 || sh != h2 || rot != 0 || (flip && !(has_steps && same_rect))) {
         /* one draw: one filtered axis (resizerX == resizerY for a rotated frame scaled the same way on both axes:
            :3131-3137 draws once, so only texture Y is filtered), or ps_simple (:3169-3181) */
         if (img_alloc(&post, w2, h2)) { rc = -5; goto done; }
@@ -1303,7 +1426,7 @@ int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
         else                         rc = resize_draw(&conv, srect, &post, -1, none, rot, flip, p->flags, last_store);
         if (rc) goto done;
         result = &post; result_fmt = last_store;
-    } else if (!final_pass) {
+    } else if (!has_steps) {
         /* TextureCopyRect with ps_simple into the render target :3178-3181 */
         if (img_alloc(&post, w2, h2)) { rc = -5; goto done; }
         for (int y = 0; y < h2; y++)
@@ -1313,6 +1436,19 @@ int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
         result = &post; result_fmt = swap_fmt;
     }
     (void)result_fmt;
+    img_t tm = {0};
+    if (tonemap) {      /* TextureCopyRect(..., m_pPSHDR10ToneMapping, ...) into the next post-scale texture or the RT */
+        const int ox = (result == &conv && srect) ? srect[0] : 0, oy = (result == &conv && srect) ? srect[1] : 0;
+        if (img_alloc(&tm, w2, h2)) { rc = -5; goto done; }
+        for (int y = 0; y < h2; y++)
+            for (int x = 0; x < w2; x++) {
+                const float *q = result->p + ((size_t)(y + oy) * result->w + (x + ox)) * 4;
+                float v[4] = {q[0], q[1], q[2], 1.0f};
+                orc_hdr10_tonemap(v, p);
+                store_fmt(final_pass ? internal : swap_fmt, v, tm.p + ((size_t)y * w2 + x) * 4);
+            }
+        result = &tm; srect = NULL;
+    }
 
     /* FinalPass :3189-3233 + ps_final_pass.hlsl:23-31, or plain store into the render target */
     ORC_PAR_FOR
@@ -1337,7 +1473,7 @@ int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
     }
     rc = 0;
 done:
-    img_free(&conv); img_free(&mid); img_free(&post);
+    img_free(&conv); img_free(&mid); img_free(&post); img_free(&tm);
     free(c.owned);
     return rc;
 }

@@ -75,9 +75,16 @@ typedef struct orc_params {
     int32_t  blend_deint;
     /* m_iRotation (0/90/180/270, clockwise) and m_bFlip (horizontal) of the first resize draw — FillVertices :130-179 */
     int32_t  rotation, flip;
+    /* HDR output (m_bHdrPassthroughSupport && (m_bHdrPassthrough || m_bHdrLocalToneMapping)): no PQ->SDR, HLG -> PQ
+       (DX11VideoProcessor.cpp:2948-2950); hdr_tonemap_type 1..6 = ps_hdr10_tonemap.hlsl operator (0 = step absent) with
+       the constants of SetHDR10ShaderParams (:907-917) */
+    int32_t  hdr_output, hdr_tonemap_type;
+    float    hdr_display_max_nits, hdr_min_mastering, hdr_max_mastering, hdr_max_cll, hdr_max_fall;
 } orc_params;
 
 void orc_params_default(orc_params *p);
+void orc_hdr_tail_ex(float rgb[3], int trc, int prim, int convert_to_sdr, float lum_scale, int hdr_output);
+void orc_hdr10_tonemap(float rgb[3], const orc_params *p);
 
 /* ---- parameter maths (pins) ---- */
 /* DXVA2_ExtendedFormat after SpecifyExtendedFormat — Helper.cpp:1169-1211 */

@@ -39,6 +39,9 @@ class OrcParams(C.Structure):
         ("flags", C.c_uint32),
         ("blend_deint", C.c_int32),
         ("rotation", C.c_int32), ("flip", C.c_int32),
+        ("hdr_output", C.c_int32), ("hdr_tonemap_type", C.c_int32),
+        ("hdr_display_max_nits", C.c_float), ("hdr_min_mastering", C.c_float), ("hdr_max_mastering", C.c_float),
+        ("hdr_max_cll", C.c_float), ("hdr_max_fall", C.c_float),
     ]
 
 

@@ -54,6 +54,23 @@ GOLDEN_CASES = {
     "jinc2_x_with_hamming_down_y": dict(cformat=1, w=48, h=96, kind="structure", seed=132, dst=(96, 30), iUpscaling=5, iDownscaling=2),
     "jinc2_y_only": dict(cformat=2, w=64, h=32, kind="noise", seed=133, dst=(64, 80), iUpscaling=5),
     "jinc2_rot90_pq": dict(cformat=2, w=48, h=32, kind="hdr", seed=134, dst=(64, 96), iUpscaling=5, rotation=90, exfmt=HDR10),
+    # ---- HDR output: PQ passthrough, HLG -> PQ, ps_hdr10_tonemap post-scale step (N2) ----
+    "hdrout_pq_passthrough_2x": dict(cformat=2, w=64, h=32, kind="hdr", seed=140, dst=(128, 64), exfmt=HDR10, iUpscaling=4, output_format=1, hdr_output=1),
+    "hdrout_hlg_to_pq": dict(cformat=2, w=64, h=32, kind="hdr", seed=141, dst=(64, 32), exfmt=HLG, output_format=1, hdr_output=1),
+    "hdrout_tm1_aces_2x": dict(cformat=2, w=64, h=32, kind="hdr", seed=142, dst=(128, 64), exfmt=HDR10, iUpscaling=4, output_format=1,
+                               hdr_output=1, hdr_tonemap=1, hdr_display=600.0, hdr_meta=(0.005, 1000.0, 1000.0, 400.0)),
+    "hdrout_tm2_reinhard": dict(cformat=2, w=64, h=32, kind="noise", seed=143, dst=(96, 48), exfmt=HDR10, iUpscaling=2, output_format=1,
+                                hdr_output=1, hdr_tonemap=2, hdr_display=800.0, hdr_meta=(0.0, 4000.0, 2000.0, 300.0)),
+    "hdrout_tm3_habel_same_size": dict(cformat=2, w=64, h=32, kind="hdr", seed=144, dst=(64, 32), exfmt=HDR10, output_format=1,
+                                       hdr_output=1, hdr_tonemap=3, hdr_display=1000.0, hdr_meta=(0.01, 1000.0, 0.0, 0.0)),
+    "hdrout_tm4_moebius_bgra8_dither": dict(cformat=2, w=64, h=32, kind="hdr", seed=145, dst=(128, 64), exfmt=HDR10, iUpscaling=1,
+                                            hdr_output=1, hdr_tonemap=4, hdr_display=500.0, hdr_meta=(0.005, 1000.0, 1200.0, 200.0)),
+    "hdrout_tm5_bt2390": dict(cformat=2, w=64, h=32, kind="hdr", seed=146, dst=(128, 64), exfmt=HDR10, iUpscaling=4, output_format=1,
+                              hdr_output=1, hdr_tonemap=5, hdr_display=400.0, hdr_meta=(0.005, 1000.0, 1000.0, 400.0)),
+    "hdrout_tm6_st2094_hlg_fp16": dict(cformat=2, w=64, h=32, kind="hdr", seed=147, dst=(96, 48), exfmt=HLG, iUpscaling=2, output_format=1, iTexFormat=16,
+                                       hdr_output=1, hdr_tonemap=6, hdr_display=600.0, hdr_meta=(0.005, 1000.0, 1000.0, 180.0)),
+    "hdrout_tm5_display_brighter_than_content": dict(cformat=2, w=64, h=32, kind="noise", seed=148, dst=(64, 32), exfmt=HDR10, output_format=1,
+                                                     hdr_output=1, hdr_tonemap=5, hdr_display=2000.0, hdr_meta=(0.005, 1000.0, 1000.0, 400.0)),
     # ---- geometry ----
     "crop_offset_letterbox": dict(cformat=2, w=96, h=64, kind="structure", seed=21, src_rect=(16, 8, 80, 56), dst=(128, 96),
                                   window=(200, 150), offset=(36, 27), iUpscaling=4),
@@ -179,6 +196,10 @@ def oracle_params(oracle, c):
     # m_bDeintBlend && m_SampleFormat != PROGRESSIVE (DX11VideoProcessor.cpp:3075); the 4:2:0 check is the oracle's
     oracle.set_params(p, blend_deint=int(bool(c.get("bDeintBlend", 0)) and c.get("sample_format", 0) != 0))
     oracle.set_params(p, rotation=c.get("rotation", 0), flip=c.get("flip", 0))
+    if c.get("hdr_output"):
+        m = c.get("hdr_meta", (0.0, 0.0, 0.0, 0.0))
+        oracle.set_params(p, hdr_output=1, hdr_tonemap_type=c.get("hdr_tonemap", 0), hdr_display_max_nits=c.get("hdr_display", 1000.0),
+                          hdr_min_mastering=m[0], hdr_max_mastering=m[1], hdr_max_cll=m[2], hdr_max_fall=m[3])
     return p
 
 

@@ -47,6 +47,10 @@ def make_vp(mpcvr, c, extra_flags=0):
         vp.SetProcAmpValues(*c["procamp"])
     if "sample_format" in c:
         vp.SetSampleFormat(c["sample_format"])
+    if c.get("hdr_output"):
+        vp.SetHdrOutput(True, c.get("hdr_tonemap", 0), c.get("hdr_display", 1000.0))
+        if "hdr_meta" in c:
+            vp.SetHdrMetadata(*c["hdr_meta"])
     if "rotation" in c:
         vp.SetRotation(c["rotation"])
     if "flip" in c:

@@ -85,7 +85,7 @@ class MpcvrError(RuntimeError):
 
 EXPORTS = [
     "mpcvr_settings_default", "mpcvr_create", "mpcvr_destroy", "mpcvr_set_stream", "mpcvr_synchronize",
-    "mpcvr_set_input", "mpcvr_set_video_rect", "mpcvr_set_window_rect", "mpcvr_set_rotation", "mpcvr_set_flip", "mpcvr_set_sample_format",
+    "mpcvr_set_input", "mpcvr_set_video_rect", "mpcvr_set_window_rect", "mpcvr_set_rotation", "mpcvr_set_flip", "mpcvr_set_sample_format", "mpcvr_set_hdr_output", "mpcvr_set_hdr_metadata",
     "mpcvr_configure", "mpcvr_set_procamp", "mpcvr_copy_sample", "mpcvr_process", "mpcvr_render",
     "mpcvr_get_backbuffer", "mpcvr_get_current_image", "mpcvr_flush", "mpcvr_reset", "mpcvr_process_batch",
     "mpcvr_get_param_blob", "mpcvr_set_param_blob", "mpcvr_get_color_matrix", "mpcvr_get_extfmt",
@@ -121,6 +121,8 @@ def load_library():
         "mpcvr_set_rotation": [vp, i32],
         "mpcvr_set_flip": [vp, i32],
         "mpcvr_set_sample_format": [vp, i32],
+        "mpcvr_set_hdr_output": [vp, i32, i32, f],
+        "mpcvr_set_hdr_metadata": [vp, f, f, f, f],
         "mpcvr_configure": [vp, P(Settings)],
         "mpcvr_set_procamp": [vp, u32, f, f, f, f],
         "mpcvr_copy_sample": [vp, vp, i32, i32],
@@ -306,6 +308,14 @@ class VideoProcessor:
 
     def SetFlip(self, value):
         return self._check(self._L.mpcvr_set_flip(self._ctx, int(bool(value))))
+
+    def SetHdrOutput(self, enable, tone_map_type=0, display_max_nits=1000.0):
+        """HDR10 display mode (m_bHdrPassthrough / m_bHdrLocalToneMapping, m_iHdrLocalToneMappingType, m_iHdrDisplayMaxNits)."""
+        return self._check(self._L.mpcvr_set_hdr_output(self._ctx, int(bool(enable)), int(tone_map_type), float(display_max_nits)))
+
+    def SetHdrMetadata(self, min_mastering, max_mastering, max_cll, max_fall):
+        """The values Render() hands to SetHDR10ShaderParams (DX11VideoProcessor.cpp:907-917)."""
+        return self._check(self._L.mpcvr_set_hdr_metadata(self._ctx, float(min_mastering), float(max_mastering), float(max_cll), float(max_fall)))
 
     def SetSampleFormat(self, frame_format):
         """m_SampleFormat (DX11VideoProcessor.cpp:2209-2219): 0 progressive, 1 interlaced TFF, 2 interlaced BFF."""

@@ -52,7 +52,7 @@ CHipVideoProcessor::~CHipVideoProcessor()
     if (!m_bInit) return;
     (void)hipSetDevice(m_device);
     if (m_stream) (void)hipStreamSynchronize(m_stream);
-    for (DevBuffer *b : {&m_TexSrcVideo, &m_TexRaw, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
+    for (DevBuffer *b : {&m_TexSrcVideo, &m_TexRaw, &m_TexPost, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
                          &m_pqLut, &m_tapsXi, &m_tapsXw, &m_tapsXs, &m_tapsYi, &m_tapsYw, &m_tapsYs, &m_otherX, &m_otherY})
         b->Release();
     for (UploadSlot &u : m_up) {
@@ -198,7 +198,7 @@ void CHipVideoProcessor::SetShaderConvertColorParams()
     if (!m_srcParams || m_blobOverride) return;
     ComputeColorMatrix(m_srcExFmt, *m_srcParams, m_procAmp, m_cm);
     ComputeGamut2020to709(m_gamut);
-    SelectTail(m_srcExFmt, m_cfg.bConvertToSdr != 0, &m_tail, &m_gamma);
+    SelectTail(m_srcExFmt, m_cfg.bConvertToSdr != 0, &m_tail, &m_gamma, m_hdrOutput);
 }
 
 void CHipVideoProcessor::SetShaderLuminanceParams()
@@ -227,6 +227,50 @@ HRESULT CHipVideoProcessor::SetRotation(int value)
     if (value != 0 && value != 90 && value != 180 && value != 270) return Fail(MPCVR_E_INVALIDARG, "rotation must be 0, 90, 180 or 270");
     if (value != m_iRotation) { m_iRotation = value; m_planDirty = true; }
     return MPCVR_S_OK;
+}
+
+// HDR output: stands in for m_bHdrPassthroughSupport && (m_bHdrPassthrough || m_bHdrLocalToneMapping) — the display is in
+// HDR10 mode, so HDR sources are not converted to SDR (convertType :2948-2950) — plus m_bHdrLocalToneMapping /
+// m_iHdrLocalToneMappingType / m_iHdrDisplayMaxNits
+HRESULT CHipVideoProcessor::SetHdrOutput(bool enable, int toneMapType, float displayMaxNits)
+{
+    if (toneMapType < 0 || toneMapType > 6) return Fail(MPCVR_E_INVALIDARG, "tone mapping type must be 0 (off) .. 6");
+    m_hdrOutput = enable; m_hdrToneMapType = toneMapType; m_hdrDisplayMaxNits = displayMaxNits;
+    UpdateHdrToneMapParams();
+    m_blobOverride = false;
+    SetShaderConvertColorParams();
+    m_planDirty = true;
+    return MPCVR_S_OK;
+}
+
+// the HDR10 metadata Render() hands to SetHDR10ShaderParams (:2716-2727): mastering min/max luminance, MaxCLL, MaxFALL
+HRESULT CHipVideoProcessor::SetHdrMetadata(float minMastering, float maxMastering, float maxCLL, float maxFALL)
+{
+    m_hdrMeta[0] = minMastering; m_hdrMeta[1] = maxMastering; m_hdrMeta[2] = maxCLL; m_hdrMeta[3] = maxFALL;
+    m_hdrMetaValid = true;
+    UpdateHdrToneMapParams();
+    m_planDirty = true;
+    return MPCVR_S_OK;
+}
+
+// SetHDR10ShaderParams — DX11VideoProcessor.cpp:907-917
+void CHipVideoProcessor::UpdateHdrToneMapParams()
+{
+    HdrToneMapParams k{m_hdrMeta[0], m_hdrMeta[1], m_hdrMeta[2], m_hdrMeta[3], m_hdrDisplayMaxNits, m_hdrToneMapType};
+    if (k.min_mastering <= 0.f) k.min_mastering = 0.f;
+    if (k.max_mastering <= 10.f) k.max_mastering = 1000.f;
+    if (k.max_cll <= 10.f) k.max_cll = k.max_mastering;
+    if (k.max_fall <= 1.f) k.max_fall = k.max_cll;
+    if (k.display_max < 100.f || k.display_max > 10000.f) k.display_max = 1000.f;
+    if (k.selection < 1 || k.selection > 6) k.selection = 1;
+    m_hdrTm = k;
+}
+
+// m_pPSHDR10ToneMapping exists once an HDR10/HLG source is shown in HDR with local tone mapping on and metadata known
+bool CHipVideoProcessor::ToneMapActive() const
+{
+    const unsigned tf = m_srcExFmt.VideoTransferFunction();
+    return m_hdrOutput && m_hdrToneMapType > 0 && m_hdrMetaValid && (tf == 15 || tf == 16);
 }
 
 HRESULT CHipVideoProcessor::SetSampleFormat(int frameFormat)
@@ -317,7 +361,7 @@ HRESULT CHipVideoProcessor::UpdatePlan()
     {
         const PlanGeometry g{w1, h1, m_videoRect.left, m_videoRect.top, m_videoRect.right, m_videoRect.bottom,
                              m_windowRect.Width(), m_windowRect.Height(), m_iRotation, m_bFlip ? 1 : 0,
-                             ConvertEnabled() ? 1 : 0};
+                             ConvertEnabled() ? 1 : 0, ToneMapActive() ? 1 : 0};
         std::string why;
         if (!DecidePlan(m_cfg.iTexFormat, m_cfg.iChromaScaling, m_cfg.iUpscaling, m_cfg.iDownscaling,
                         m_cfg.bInterpolateAt50pct, m_cfg.bUseDither, m_cfg.output_format, m_cfg.flags,
@@ -326,6 +370,8 @@ HRESULT CHipVideoProcessor::UpdatePlan()
     }
 
     HRESULT hr;
+    if (m_plan.hdr_tonemap &&
+        (hr = CheckHip(m_TexPost.CheckCreate((size_t)w2 * SurfBytesPerPixel(m_plan.internal_fmt) * h2), "m_TexsPostScale"))) return hr;
     // m_TexConvertOutput: srcRect-sized, internal format (:2889-2890)
     const size_t convPitch = (size_t)w1 * SurfBytesPerPixel(m_plan.internal_fmt);
     if ((hr = CheckHip(m_TexConvertOutput.CheckCreate(convPitch * h1), "m_TexConvertOutput"))) return hr;
@@ -604,30 +650,39 @@ HRESULT CHipVideoProcessor::ResizeShaderPass(void *rt, int rtPitch, const uint8_
     Surface conv{m_TexConvertOutput.ptr, (int)(w1 * SurfBytesPerPixel(m_plan.internal_fmt)), w1, h1, m_plan.internal_fmt};
     if (!m_plan.convert)      // pInputTexture = &m_TexSrcVideo (:3321-3323)
         conv = Surface{(void *)sample, TexPitch(), m_srcWidth, m_srcHeight, RgbTexFmt(*m_srcParams)};
-    const StoreParams last = MakeStore(rt, rtPitch, m_plan.swap_fmt, true);
-    HRESULT hr;
+    const StoreParams final = MakeStore(rt, rtPitch, m_plan.swap_fmt, true);
+    // with the HDR10 tone-mapping step the resize draws into a post-scale texture (internal format, video-rect sized)
+    // and the step itself writes the render target / runs the final pass (:3359-3367)
+    Surface post{m_TexPost.ptr, (int)(w2 * SurfBytesPerPixel(m_plan.internal_fmt)), w2, h2, m_plan.internal_fmt};
+    const StoreParams last = m_plan.hdr_tonemap ? MakeStore(post.ptr, post.pitch, m_plan.internal_fmt, false) : final;
+    HRESULT hr = MPCVR_S_OK;
+    bool drawn = true;
     if (m_plan.two_pass) {
         Surface mid{m_TexResize.ptr, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
         StoreParams st = MakeStore(mid.ptr, mid.pitch, SF_RGBA16F, false);
         if (m_firstJinc) hr = CheckHip(LaunchJinc2(conv, m_firstCoords, w2, m_plan.mid_h, st, m_stream), "k_jinc2");
         else hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, m_plan.mid_h, st, m_stream), "k_resize<first>");
         if (hr) return hr;
-        if (m_secondJinc) return CheckHip(LaunchJinc2(mid, m_secondCoords, w2, h2, last, m_stream), "k_jinc2");
-        return CheckHip(LaunchResize(1, false, mid, m_tapsY, (const int32_t *)m_otherY.ptr, w2, h2, last, m_stream), "k_resize<Y>");
+        if (m_secondJinc) hr = CheckHip(LaunchJinc2(mid, m_secondCoords, w2, h2, last, m_stream), "k_jinc2");
+        else hr = CheckHip(LaunchResize(1, false, mid, m_tapsY, (const int32_t *)m_otherY.ptr, w2, h2, last, m_stream), "k_resize<Y>");
+    } else if (m_plan.one_pass) {
+        if (m_firstJinc) hr = CheckHip(LaunchJinc2(conv, m_firstCoords, w2, h2, last, m_stream), "k_jinc2");
+        else hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, h2, last, m_stream), "k_resize<one>");
+    } else {
+        drawn = false;
+        if (!m_plan.convert) {    // the next step reads the source rect of the texture (pTex = pInputTexture, :3352)
+            const int bpp = conv.fmt == SF_RGBA16 ? 8 : 4;
+            conv.ptr = (uint8_t *)conv.ptr + (size_t)m_srcRect.top * conv.pitch + (size_t)m_srcRect.left * bpp;
+            conv.w = w1; conv.h = h1;
+        }
+        if (!m_plan.hdr_tonemap) {
+            StoreParams direct = final;
+            if (!m_plan.convert) direct.mid_fmt = conv.fmt;   // nothing was drawn into m_TexsPostScale: the final pass sees the texture's own precision
+            return CheckHip(LaunchCopy(conv, w2, h2, direct, m_stream), "k_copy");
+        }
     }
-    if (m_plan.one_pass) {
-        if (m_firstJinc) return CheckHip(LaunchJinc2(conv, m_firstCoords, w2, h2, last, m_stream), "k_jinc2");
-        return CheckHip(LaunchResize(m_firstAxis, m_firstSwap, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, h2, last, m_stream), "k_resize<one>");
-    }
-    if (!m_plan.convert) {    // the final pass reads the source rect of the texture (pTex = pInputTexture, :3352)
-        const int bpp = conv.fmt == SF_RGBA16 ? 8 : 4;
-        conv.ptr = (uint8_t *)conv.ptr + (size_t)m_srcRect.top * conv.pitch + (size_t)m_srcRect.left * bpp;
-        conv.w = w1; conv.h = h1;
-        StoreParams direct = last;
-        direct.mid_fmt = conv.fmt;       // nothing was drawn into m_TexsPostScale: the final pass sees the texture's own precision
-        return CheckHip(LaunchCopy(conv, w2, h2, direct, m_stream), "k_copy");
-    }
-    return CheckHip(LaunchCopy(conv, w2, h2, last, m_stream), "k_copy");
+    if (hr || !m_plan.hdr_tonemap) return hr;
+    return CheckHip(LaunchHdr10ToneMap(drawn ? post : conv, m_hdrTm, w2, h2, final, m_stream), "k_hdr10_tonemap");
 }
 
 HRESULT CHipVideoProcessor::ProcessOne(const uint8_t *sample, void *rt, int rtPitch)

@@ -51,6 +51,8 @@ public:
     HRESULT SetRotation(int value);                                           // :4052
     HRESULT SetFlip(bool value);                                              // VideoProcessor.h:210
     HRESULT SetSampleFormat(int frameFormat);                                 // m_SampleFormat, :2209-2219
+    HRESULT SetHdrOutput(bool enable, int toneMapType, float displayMaxNits);  // m_bHdrPassthrough / m_bHdrLocalToneMapping
+    HRESULT SetHdrMetadata(float minMastering, float maxMastering, float maxCLL, float maxFALL);   // SetHDR10ShaderParams :907
     HRESULT Configure(const mpcvr_settings &config);                          // :3800
     HRESULT SetProcAmpValues(uint32_t flags, float b, float c, float h, float s); // :4506
 
@@ -107,6 +109,12 @@ private:
     int m_iRotation = 0;
     bool m_bFlip = false;
     int m_SampleFormat = 0;        // 0 progressive, 1 TFF, 2 BFF
+    bool m_hdrOutput = false, m_hdrMetaValid = false;
+    int m_hdrToneMapType = 0;
+    float m_hdrDisplayMaxNits = 1000.0f, m_hdrMeta[4] = {0, 0, 0, 0};
+    HdrToneMapParams m_hdrTm{};
+    void UpdateHdrToneMapParams();
+    bool ToneMapActive() const;
     int m_firstAxis = 0;           // screen axis the first draw's tap table runs along
     bool m_firstSwap = false;      // rotation 90/270: taps address the other texture axis
     bool m_firstJinc = false, m_secondJinc = false;    // the draw runs the 2-D Jinc2m shader
@@ -137,6 +145,7 @@ private:
     // device resources
     DevBuffer m_TexSrcVideo;       // uploaded sample (for v210: the Y210 texture CopyFrameV210 fills)
     DevBuffer m_TexRaw;            // v210 only: the raw sample before the unpack
+    DevBuffer m_TexPost;           // m_TexsPostScale stand-in: input of the HDR10 tone-mapping step
     // upload ring (N3): pinned staging + device buffer per slot, copies on their own stream so that the upload of the
     // next sample overlaps the processing of the current one
     struct UploadSlot {

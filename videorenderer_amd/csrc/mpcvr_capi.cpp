@@ -78,6 +78,10 @@ int32_t mpcvr_set_window_rect(mpcvr_ctx *ctx, const mpcvr_rect *r) { CTX_OR_FAIL
 int32_t mpcvr_set_rotation(mpcvr_ctx *ctx, int32_t degrees) { CTX_OR_FAIL(); return ctx->vp.SetRotation(degrees); }
 int32_t mpcvr_set_flip(mpcvr_ctx *ctx, int32_t flip) { CTX_OR_FAIL(); return ctx->vp.SetFlip(flip != 0); }
 int32_t mpcvr_set_sample_format(mpcvr_ctx *ctx, int32_t frame_format) { CTX_OR_FAIL(); return ctx->vp.SetSampleFormat(frame_format); }
+int32_t mpcvr_set_hdr_output(mpcvr_ctx *ctx, int32_t enable, int32_t tone_map_type, float display_max_nits)
+{ CTX_OR_FAIL(); return ctx->vp.SetHdrOutput(enable != 0, tone_map_type, display_max_nits); }
+int32_t mpcvr_set_hdr_metadata(mpcvr_ctx *ctx, float min_mastering_nits, float max_mastering_nits, float max_cll, float max_fall)
+{ CTX_OR_FAIL(); return ctx->vp.SetHdrMetadata(min_mastering_nits, max_mastering_nits, max_cll, max_fall); }
 
 int32_t mpcvr_configure(mpcvr_ctx *ctx, const mpcvr_settings *settings)
 {

@@ -95,6 +95,12 @@ __device__ __forceinline__ f3 mat3_mul(const mat3 &g, f3 v)
 __device__ __forceinline__ f3 hdr_tail(f3 c, int tail, float gamma, float lum_scale, const mat3 &gamut)
 {
     if (tail == TAIL_NONE) return c;
+    if (tail == TAIL_HLG_TO_PQ) {          // bConvertHLGtoPQ (:885-891)
+        c.x = saturate(c.x); c.y = saturate(c.y); c.z = saturate(c.z);
+        c = hlg_to_linear(c);
+        c.x = linear_to_st2084(c.x, 1000.0f); c.y = linear_to_st2084(c.y, 1000.0f); c.z = linear_to_st2084(c.z, 1000.0f);
+        return c;
+    }
     if (tail == TAIL_PQ_TO_SDR || tail == TAIL_HLG_TO_SDR) {
         if (tail == TAIL_HLG_TO_SDR) {
             c.x = saturate(c.x); c.y = saturate(c.y); c.z = saturate(c.z);
@@ -115,6 +121,94 @@ __device__ __forceinline__ f3 hdr_tail(f3 c, int tail, float gamma, float lum_sc
     c.x = hlsl_pow(saturate(c.x), 1.0f / 2.2f);
     c.y = hlsl_pow(saturate(c.y), 1.0f / 2.2f);
     c.z = hlsl_pow(saturate(c.z), 1.0f / 2.2f);
+    return c;
+}
+
+// HDR10 -> HDR10 local tone mapping — Shaders/d3d11/ps_hdr10_tonemap.hlsl:272-336 (Dolby Vision L2 trims not modelled)
+__device__ __forceinline__ float lerp_f(float a, float b, float t) { return a + t * (b - a); }
+__device__ __forceinline__ float pl_smoothstep(float e0, float e1, float x)
+{
+    float t = (x - e0) / (e1 - e0);
+    t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+    return t * t * (3.0f - 2.0f * t);
+}
+__device__ __forceinline__ f3 hdr10_tonemap(f3 c, const HdrToneMapParams &k)
+{
+    c.x = st2084_to_linear(saturate(c.x), 10000.0f); c.y = st2084_to_linear(saturate(c.y), 10000.0f); c.z = st2084_to_linear(saturate(c.z), 10000.0f);
+    if (k.selection == 5) {                                                                 // BT2390Tonemap :68-124
+        float safe = k.max_cll;
+        if (safe <= 10.0f) safe = k.max_mastering;
+        if (safe <= 10.0f) safe = 1000.0f;
+        if (!(k.display_max >= safe)) {
+            const float avg = 0.2627f * c.x + 0.6780f * c.y + 0.0593f * c.z;
+            if (!(avg <= 0.000001f)) {
+                const float max_pq = linear_to_st2084(safe, 10000.0f), tgt_pq = linear_to_st2084(k.display_max, 10000.0f);
+                const float e1 = linear_to_st2084(avg, 10000.0f);
+                float ks = 1.5f * tgt_pq - 0.5f * max_pq;
+                ks = fmaxf(0.0f, ks);
+                float e2 = e1;
+                if (e1 > ks) {
+                    const float t = (e1 - ks) / fmaxf(1e-6f, max_pq - ks), t2 = t * t, t3 = t2 * t;
+                    e2 = (2.0f * t3 - 3.0f * t2 + 1.0f) * ks + (t3 - 2.0f * t2 + t) * (max_pq - ks) + (-2.0f * t3 + 3.0f * t2) * tgt_pq;
+                }
+                const float lin = st2084_to_linear(e2, 10000.0f);
+                const float g = lin / avg;
+                c.x = c.x * g; c.y = c.y * g; c.z = c.z * g;
+            }
+        }
+        c.x = linear_to_st2084(c.x, 10000.0f); c.y = linear_to_st2084(c.y, 10000.0f); c.z = linear_to_st2084(c.z, 10000.0f);
+        return c;
+    }
+    if (k.selection == 6) {                                                                 // ST209410Tonemap :133-205
+        if (!(k.display_max >= k.max_cll)) {
+            const float src_min = linear_to_st2084(k.min_mastering, 10000.0f), src_max = linear_to_st2084(k.max_cll, 10000.0f);
+            const float src_avg = linear_to_st2084(k.max_fall, 10000.0f);
+            const float dst_min = linear_to_st2084(0.0f, 10000.0f), dst_max = linear_to_st2084(k.display_max, 10000.0f);
+            const float min_knee = 0.1f, max_knee = 0.8f, def_knee = 0.4f, knee_adaptation = 0.4f;
+            const float src_knee_min = lerp_f(src_min, src_max, min_knee), src_knee_max = lerp_f(src_min, src_max, max_knee);
+            const float dst_knee_min = lerp_f(dst_min, dst_max, min_knee), dst_knee_max = lerp_f(dst_min, dst_max, max_knee);
+            float src_knee = (k.max_fall > 0.0f) ? src_avg : lerp_f(src_min, src_max, def_knee);
+            src_knee = fminf(fmaxf(src_knee, src_knee_min), src_knee_max);
+            const float target = (src_knee - src_min) / (src_max - src_min);
+            const float adapted = lerp_f(dst_min, dst_max, target);
+            const float tuning = 1.0f - pl_smoothstep(max_knee, def_knee, target) * pl_smoothstep(min_knee, def_knee, target);
+            const float adaptation = lerp_f(knee_adaptation, 1.0f, tuning);
+            float dst_knee = lerp_f(src_knee, adapted, adaptation);
+            dst_knee = fminf(fmaxf(dst_knee, dst_knee_min), dst_knee_max);
+            const float x2 = st2084_to_linear(src_knee, 10000.0f), y2 = st2084_to_linear(dst_knee, 10000.0f);
+            const float x1 = k.min_mastering, x3 = k.max_cll, y1 = 0.0f, y3 = k.display_max;
+            const float m00 = x2 * x3 * (y2 - y3), m01 = x1 * x3 * (y3 - y1), m02 = x1 * x2 * (y1 - y2);
+            const float m10 = x3 * y3 - x2 * y2, m11 = x1 * y1 - x3 * y3, m12 = x2 * y2 - x1 * y1;
+            const float m20 = x3 - x2, m21 = x1 - x3, m22 = x2 - x1;
+            const float coef0 = m00 * y1 + m01 * y2 + m02 * y3, coef1 = m10 * y1 + m11 * y2 + m12 * y3, coef2 = m20 * y1 + m21 * y2 + m22 * y3;
+            const float kk = 1.0f / (x3 * y3 * (x1 - x2) + x2 * y2 * (x3 - x1) + x1 * y1 * (x2 - x3));
+            const float c1 = kk * coef0, c2 = kk * coef1, c3 = kk * coef2;
+            const float xn = 0.2627f * c.x + 0.6780f * c.y + 0.0593f * c.z;
+            const float yn = (c1 + c2 * xn) / (1.0f + c3 * xn);
+            const float g = (xn > 0.0f) ? (yn / xn) : 1.0f;
+            c.x = c.x * g; c.y = c.y * g; c.z = c.z * g;
+        }
+        c.x = linear_to_st2084(c.x, 10000.0f); c.y = linear_to_st2084(c.y, 10000.0f); c.z = linear_to_st2084(c.z, 10000.0f);
+        return c;
+    }
+    const float base = fmaxf(k.display_max, k.max_mastering);                               // :299-306
+    const float eff = fminf(base, k.max_cll);
+    const float fall = fminf(base / k.max_fall, 1.0f);
+    float v[3] = {c.x, c.y, c.z};
+    for (int i = 0; i < 3; i++) {
+        float t = v[i] * (1.0f / eff);
+        t = saturate(t);
+        t = t * fall;
+        if (k.selection == 2) t = t / (1.0f + t);
+        else if (k.selection == 3) {
+            const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+            t = ((t * (A * t + C * B) + D * E) / (t * (A * t + B) + D * F)) - E / F;
+        } else if (k.selection == 4) t = t / (1.0f + t / (k.display_max + 1e-6f));
+        else t = (t * (2.51f * t + 0.03f)) / (t * (2.43f * t + 0.59f) + 0.14f);
+        t = t * k.display_max;
+        v[i] = linear_to_st2084(t, 10000.0f);
+    }
+    c.x = v[0]; c.y = v[1]; c.z = v[2];
     return c;
 }
 

@@ -96,6 +96,14 @@ __global__ __launch_bounds__(256) void k_jinc2(Surface in, DrawCoords dc, int ou
     store_epilogue(st, x, y, color);
 }
 
+// TextureCopyRect(..., m_pPSHDR10ToneMapping, ...) — the HDR10 local tone-mapping post-scale step (:3359-3367)
+__global__ __launch_bounds__(256) void k_hdr10_tonemap(Surface in, HdrToneMapParams tm, int out_w, int out_h, StoreParams st)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= out_w || y >= out_h) return;
+    store_epilogue(st, x, y, hdr10_tonemap(load_surface(in, x, y), tm));
+}
+
 // TextureCopyRect(ps_simple) / FinalPass straight from the convert output (no size change)
 __global__ __launch_bounds__(256) void k_copy(Surface in, int out_w, int out_h, StoreParams st)
 {
@@ -210,6 +218,12 @@ hipError_t LaunchResize(int axis, bool swap, const Surface &in, const AxisTaps &
     else if (axis == 0)     hipLaunchKernelGGL((k_resize<0, true>), g, b, 0, s, in, taps, other, out_w, out_h, st);
     else if (!swap)         hipLaunchKernelGGL((k_resize<1, false>), g, b, 0, s, in, taps, other, out_w, out_h, st);
     else                    hipLaunchKernelGGL((k_resize<1, true>), g, b, 0, s, in, taps, other, out_w, out_h, st);
+    return hipGetLastError();
+}
+
+hipError_t LaunchHdr10ToneMap(const Surface &in, const HdrToneMapParams &tm, int out_w, int out_h, const StoreParams &st, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_hdr10_tonemap, grid2d(out_w, out_h), dim3(64, 4, 1), 0, s, in, tm, out_w, out_h, st);
     return hipGetLastError();
 }
 

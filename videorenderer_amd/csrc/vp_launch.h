@@ -16,6 +16,8 @@ hipError_t LaunchRepackV210(const uint8_t *src, int src_pitch, uint8_t *dst, int
 hipError_t LaunchResize(int axis, bool swap, const Surface &in, const AxisTaps &taps, const int32_t *other,
                         int out_w, int out_h, const StoreParams &st, hipStream_t s);
 hipError_t LaunchCopy(const Surface &in, int out_w, int out_h, const StoreParams &st, hipStream_t s);
+// ps_hdr10_tonemap.hlsl: HDR10 local tone mapping as a post-scale step
+hipError_t LaunchHdr10ToneMap(const Surface &in, const HdrToneMapParams &tm, int out_w, int out_h, const StoreParams &st, hipStream_t s);
 // ps_resize_onepass_jinc2.hlsl: the 2-D Jinc2m draw
 hipError_t LaunchJinc2(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st, hipStream_t s);
 

@@ -19,7 +19,14 @@ enum TailMode : int {
     TAIL_NONE = 0,
     TAIL_PQ_TO_SDR = 1,      // saturate, ST2084ToLinear*scale, Hable, 2020->709, saturate, pow 1/2.2
     TAIL_HLG_TO_SDR = 2,     // saturate, HLGtoLinear, LinearToST2084(/1000), then as PQ
-    TAIL_GAMMA_GAMUT = 3     // saturate, pow(gamma), 2020->709, saturate, pow 1/2.2
+    TAIL_GAMMA_GAMUT = 3,    // saturate, pow(gamma), 2020->709, saturate, pow 1/2.2
+    TAIL_HLG_TO_PQ = 4       // HDR output: saturate, HLGtoLinear, LinearToST2084(/1000)   (SHADER_CONVERT_TO_PQ, :885-891)
+};
+
+// constants of ps_hdr10_tonemap.hlsl as SetHDR10ShaderParams sanitises them (DX11VideoProcessor.cpp:907-917)
+struct HdrToneMapParams {
+    float min_mastering, max_mastering, max_cll, max_fall, display_max;
+    int selection;           // 1 ACES, 2 Reinhard, 3 Habel, 4 Moebius, 5 BT.2390, 6 ST 2094-10
 };
 
 enum ChromaLoc : int { CLOC_MPEG2 = 0, CLOC_MPEG1 = 1, CLOC_COSITED = 2 };

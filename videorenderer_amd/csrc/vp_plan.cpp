@@ -272,11 +272,15 @@ void ComputeGamut2020to709(float out[9])
 }
 
 // Shaders.cpp:613-616, 861-915
-void SelectTail(const ExtFmt &ex, bool convert_to_sdr, int *tail, float *gamma)
+void SelectTail(const ExtFmt &ex, bool convert_to_sdr, int *tail, float *gamma, bool hdr_output)
 {
     const unsigned tf = ex.VideoTransferFunction();
     *tail = TAIL_NONE;
     *gamma = 1.0f;
+    if (hdr_output) {
+        convert_to_sdr = false;                                            // convertType is never TO_SDR (:2948)
+        if (tf == dxva::TF_HLG) { *tail = TAIL_HLG_TO_PQ; return; }         // SHADER_CONVERT_TO_PQ (:2949)
+    }
     if (convert_to_sdr && tf == dxva::TF_2084) { *tail = TAIL_PQ_TO_SDR; return; }
     if (convert_to_sdr && tf == dxva::TF_HLG) { *tail = TAIL_HLG_TO_SDR; return; }
     if (ex.VideoPrimaries() == dxva::Prim_BT2020) {
@@ -531,6 +535,7 @@ bool DecidePlan(int iTexFormat, int iChromaScaling, int iUpscaling, int iDownsca
     if (g.rotation != 0 && g.rotation != 90 && g.rotation != 180 && g.rotation != 270) { if (why) *why = "rotation must be 0, 90, 180 or 270"; return false; }
     p.rotation = g.rotation; p.flip = g.flip != 0;
     p.convert = g.convert_enabled != 0;
+    p.hdr_tonemap = g.hdr_tonemap != 0;
     const bool rotated = g.rotation == 90 || g.rotation == 270;
     const int w1 = rotated ? g.h1 : g.w1, h1 = rotated ? g.w1 : g.h1;                     // :3112-3123
     const int k = bInterpolateAt50pct ? 2 : 1;                                            // :3108
@@ -547,7 +552,8 @@ bool DecidePlan(int iTexFormat, int iChromaScaling, int iUpscaling, int iDownsca
     // Process :3348-3352: with a final pass the resize step is skipped only when rSrc == dstRect and rotation == 0 (a
     // flip alone is then ignored); without post-scale steps ResizeShaderPass always runs (:3417-3419)
     const bool same_rect = g.w1 == w2 && g.h1 == h2 && g.vl == 0 && g.vt == 0;
-    const bool need_draw = w1 != w2 || h1 != h2 || g.rotation != 0 || (p.flip && !(p.final_pass && same_rect));
+    const bool has_steps = p.final_pass || p.hdr_tonemap;                 // GetPostScaleSteps() > 0
+    const bool need_draw = w1 != w2 || h1 != h2 || g.rotation != 0 || (p.flip && !(has_steps && same_rect));
     p.one_pass = !p.two_pass && need_draw;
     p.mid_h = h1;
     if (p.two_pass) { p.first_tex_axis = rotated ? 1 : 0; p.first_rs = p.rx; }
@@ -560,7 +566,7 @@ bool DecidePlan(int iTexFormat, int iChromaScaling, int iUpscaling, int iDownsca
     p.copy_only = !p.two_pass && !p.one_pass;
     // fused 2x candidate: exact 2x on both axes with an interpolation shader, bilinear 4:2:0 chroma,
     // UNORM internal format, destination fully inside the window
-    p.fused_up2x = !(flags & MPCVR_FLAG_NO_FUSED) && g.rotation == 0 && !p.flip && p.two_pass && w2 == 2 * w1 && h2 == 2 * h1 &&
+    p.fused_up2x = !(flags & MPCVR_FLAG_NO_FUSED) && g.rotation == 0 && !p.flip && !p.hdr_tonemap && p.two_pass && w2 == 2 * w1 && h2 == 2 * h1 &&
                    p.rx.kind == RS_UP && p.ry.kind == RS_UP && f.Subsampling == 420 &&
                    iChromaScaling == MPCVR_CHROMA_Bilinear && p.internal_fmt != SF_RGBA16F &&
                    g.vl >= 0 && g.vt >= 0 && g.vr <= g.ww && g.vb <= g.wh && w1 >= 8 && h1 >= 8 && !(w1 & 1);
@@ -575,6 +581,7 @@ std::string PassPlan::describe() const
     if (two_pass) s += final_pass ? ",resizeX,resizeY+final" : ",resizeX,resizeY";
     else if (one_pass) s += std::string(one_pass_axis == 0 ? ",resizeX" : ",resizeY") + (final_pass ? "+final" : "");
     else s += final_pass ? ",final" : ",copy";
+    if (hdr_tonemap) s += ",hdr10tonemap";
     if (rotation) s += ";rot" + std::to_string(rotation);
     if (flip) s += ";flip";
     return s;

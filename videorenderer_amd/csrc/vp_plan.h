@@ -55,7 +55,8 @@ void ComputeColorMatrix(const ExtFmt &ex, const FmtConvParams &f, const ProcAmp 
 // GetColorspaceGamutConversionMatrix(BT2020 -> BT709) (csputils.cpp:549-557)
 void ComputeGamut2020to709(float out9[9]);
 // which HDR tail GetShaderConvertColor emits (Shaders.cpp:613-616, 861-923)
-void SelectTail(const ExtFmt &ex, bool convert_to_sdr, int *tail, float *gamma);
+// hdr_output = m_bHdrPassthroughSupport && (m_bHdrPassthrough || m_bHdrLocalToneMapping): never TO_SDR, HLG -> PQ (:2948-2950)
+void SelectTail(const ExtFmt &ex, bool convert_to_sdr, int *tail, float *gamma, bool hdr_output = false);
 
 // per-channel PQ->SDR chain saturate -> ST2084ToLinear*LuminanceScale -> Hable/hable(4.8) sampled at
 // i/(kPqLutSize-1) (st2084.hlsl:9-16, hdr_tone_mapping.hlsl:1-13): the optional tone-map LUT of the fused path
@@ -108,6 +109,7 @@ struct PassPlan {
     int first_tex_axis = -1;         // texture axis the first draw filters: 0 = X shaders, 1 = Y shaders, -1 = ps_simple
     Resizer first_rs{RS_NONE, 0};
     int mid_h = 0;                   // height of m_TexResize in the two-pass case (srcRect extent along screen y)
+    bool hdr_tonemap = false;        // ps_hdr10_tonemap step between the resize and the final pass / render target
     bool convert = true;             // ConvertColorPass runs; false: the source texture feeds the resize directly (:3321-3323)
     std::string describe() const;
 };
@@ -116,7 +118,8 @@ struct PlanGeometry { int w1, h1;            // source rect size (== convert out
                       int vl, vt, vr, vb;    // video rect
                       int ww, wh;            // window size
                       int rotation = 0; int flip = 0;
-                      int convert_enabled = 1; };   // m_PSConvColorData.bEnable (:849-853)
+                      int convert_enabled = 1;      // m_PSConvColorData.bEnable (:849-853)
+                      int hdr_tonemap = 0; };       // m_pPSHDR10ToneMapping exists: one more post-scale step (:785-787)
 // Pure decision logic of UpdateTexParams / UpdatePostScaleTexures / ResizeShaderPass (no device work).
 // cfg fields use the Settings_t names; returns false + *why when the combination is not implemented.
 struct mpcvr_settings_fwd;
