@@ -21,8 +21,8 @@
 //              results (m_TexResize) enter an 8-row register window — no LDS, no HBM
 //     stage Y  from the window: 4 output rows x 4 px per lane with v_pk_fma_f32 on pixel pairs, UNORM
 //              rounding (m_TexsPostScale), dither, one 16-byte store per row
-//   gfx950 issues one wave64 VALU instruction per ~4 cycles per SIMD whatever its width (measured,
-//   tools/ubench/valu_rate.hip), so v_pk_{fma,mul}_f32 is what doubles the arithmetic rate here.
+//   On gfx950 a wave64 VALU instruction costs ~4 cycles of its SIMD (plain VOP2 fp32 with VGPR operands ~3; measured,
+//   tools/ubench/op_rate.hip), so v_pk_{fma,mul}_f32 with an SGPR weight is the cheapest FMA here: two for the price of one.
 //   The four waves of a workgroup share only the read-only tables (dither, PQ->SDR LUT).
 //   Recomputed: the horizontal halo (8 of 128 columns) and 6 rows per segment.
 #include <hip/hip_fp16.h>
@@ -88,15 +88,6 @@ __host__ __device__ constexpr int tap_off(int t) { return NT == 4 ? (t - 1) : NT
 
 __device__ __forceinline__ f2 splat(float x) { return f2{x, x}; }
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f2 sat2(f2 v) { return f2{saturate(v.x), saturate(v.y)}; }
-// a*b + c saturated to [0,1] in the same instruction (VOP3P clamp bit); `w` is wave-uniform (SGPR pair)
-__device__ __forceinline__ f2 pk_fma_sat_s(f2 w, f2 b, f2 c)
-{
-    f2 r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "s"(w), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ f2 floor2(f2 v) { return f2{floorf(v.x), floorf(v.y)}; }
 // UNORM store rounding floor(x*maxv + 0.5) for x in [0,1] without v_floor (which has no packed form):
 // x*maxv + 2^23 rounds to an integer in the FMA itself (nearest-even; x*maxv can only tie at x = 0.5, where both
 // conventions give (maxv+1)/2), then 2^23 comes off again — two packed instructions for two values.
@@ -169,17 +160,6 @@ __device__ __forceinline__ f2 fma_k(const f2 *K, int i, f2 b, f2 c)
     return (i & 1) ? pk_fma_w<1, CLAMP>(K[i >> 1], b, c) : pk_fma_w<0, CLAMP>(K[i >> 1], b, c);
 }
 __device__ __forceinline__ f2 mul_k(const f2 *K, int i, f2 b) { return (i & 1) ? pk_mul_w<1>(K[i >> 1], b) : pk_mul_w<0>(K[i >> 1], b); }
-
-// {value, delta} table lookup with linear interpolation; x already in [0,1]
-__device__ __forceinline__ float lut_eval(const f2 *T, float x)
-{
-    const float t = x * (float)(LUT_N - 1);
-    const f2 e = T[(int)t];
-    float r;   // plain v_fma_f32: a packed pair would need three v_mov to line its operands up, and v_pk_fma_f32 issues
-               // at half the rate of v_fma_f32 (tools/ubench/mfma_mix.hip), so packing only pays when it is free
-    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(e.y), "v"(__builtin_amdgcn_fractf(t)), "v"(e.x));
-    return r;
-}
 
 // raw codes of one 2x2 block (cols Xg, Xg+1; two source rows), prefetched one iteration ahead
 struct Raw {
@@ -322,7 +302,8 @@ __device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)
             for (int ch = 0; ch < 3; ch++)
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
-                    float r;   // plain v_fma_f32 (see lut_eval)
+                    float r;   // {value, slope} entry: plain v_fma_f32 — a packed pair would need three v_mov to line its operands
+                               // up, and packing only pays when it is free (tools/ubench/op_rate.hip)
                     asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(ent[rr][ch][e].y), "v"(frc[rr][ch][e]), "v"(ent[rr][ch][e].x));
                     linc[rr][ch][e] = r;
                 }
