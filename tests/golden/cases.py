@@ -76,6 +76,10 @@ GOLDEN_CASES = {
                                   window=(200, 150), offset=(36, 27), iUpscaling=4),
     "clipped_by_window": dict(cformat=1, w=64, h=48, kind="structure", seed=22, dst=(128, 96), window=(90, 70), offset=(-20, -13), iUpscaling=2),
     "same_size_with_offset_dither": dict(cformat=2, w=64, h=32, kind="noise", seed=23, dst=(64, 32), window=(100, 60), offset=(5, 9)),
+    "exact_2x_at_unaligned_offset": dict(cformat=2, w=64, h=32, kind="noise", seed=150, dst=(128, 64), window=(140, 80), offset=(5, 3),
+                                         iUpscaling=4, exfmt=HDR10),
+    "exact_2x_at_aligned_offset": dict(cformat=2, w=64, h=32, kind="noise", seed=151, dst=(128, 64), window=(140, 80), offset=(8, 3),
+                                       iUpscaling=4, exfmt=HDR10),
     "tiny_8x8": dict(cformat=2, w=8, h=8, kind="noise", seed=24, dst=(16, 16), iUpscaling=4),
     "ragged_2x": dict(cformat=2, w=250, h=22, kind="noise", seed=25, dst=(500, 44), iUpscaling=4, exfmt=HDR10),
     # ---- formats / chroma ----
