@@ -94,8 +94,8 @@ def cpu_baseline(wl, extfmt, seconds_budget=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3hdr", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=32, help="frames per step (per GPU) = frames per fused launch")
     ap.add_argument("--ring", type=int, default=48, help="distinct input/output frame buffers cycled (>= batch)")
