@@ -5,18 +5,30 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from videorenderer_amd import api
 
+# (name, src w, h, dst w, h, settings, cformat, extfmt kwargs)
 CASES = [("4K P010 PQ -> 1440p (Hamming down) -> SDR", 3840, 2160, 2560, 1440, dict(iDownscaling=2)),
          ("1080p P010 PQ -> 1440p (Lanczos3 1.33x) -> SDR", 1920, 1080, 2560, 1440, dict(iUpscaling=4)),
          ("1080p P010 PQ -> 4K (Lanczos3 2x), pass-per-kernel", 1920, 1080, 3840, 2160, dict(iUpscaling=4, flags=api.FLAG_NO_FUSED)),
          ("1080p P010 PQ -> 4K (Lanczos3 2x), fused", 1920, 1080, 3840, 2160, dict(iUpscaling=4)),
-         ("1080p P010 PQ -> 4K (Jinc2m)", 1920, 1080, 3840, 2160, dict(iUpscaling=5))]
+         ("1080p P010 PQ -> 4K (Jinc2m)", 1920, 1080, 3840, 2160, dict(iUpscaling=5)),
+         ("1080p NV12 BT.709 -> 4K (Lanczos3 2x), fused", 1920, 1080, 3840, 2160, dict(iUpscaling=4), 1, dict(chroma=5, nominal_range=2, matrix=1)),
+         ("1080p YUV420P10 BT.709 -> 4K (Catmull-Rom 2x), fused", 1920, 1080, 3840, 2160, dict(iUpscaling=2), 20, dict(chroma=5, nominal_range=2, matrix=1)),
+         ("4K NV12 BT.709 -> 8K (Lanczos3 2x), fused", 3840, 2160, 7680, 4320, dict(iUpscaling=4), 1, dict(chroma=5, nominal_range=2, matrix=1))]
 ext = api.make_extfmt(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15)
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
-for name, w, h, dw, dh, kw in CASES:
+for case in CASES:
+    name, w, h, dw, dh, kw = case[:6]
+    cf = case[6] if len(case) > 6 else 2
+    ex = api.make_extfmt(**case[7]) if len(case) > 7 else ext
     vp = api.VideoProcessor(api.default_settings(**kw))
-    vp.InitMediaType(2, w, h, extfmt=ext); vp.SetWindowRect((0, 0, dw, dh)); vp.SetVideoRect((0, 0, dw, dh))
+    vp.InitMediaType(cf, w, h, extfmt=ex); vp.SetWindowRect((0, 0, dw, dh)); vp.SetVideoRect((0, 0, dw, dh))
     nb, pitch = vp.GetFrameBytes()
-    srcs = [(torch.randint(64, 941, (nb // 2,), device="cuda", dtype=torch.int32) << 6).to(torch.int16).view(torch.uint8) for _ in range(8)]
+    if cf == 2:
+        srcs = [(torch.randint(64, 941, (nb // 2,), device="cuda", dtype=torch.int32) << 6).to(torch.int16).view(torch.uint8) for _ in range(8)]
+    elif cf == 20:
+        srcs = [torch.randint(64, 941, (nb // 2,), device="cuda", dtype=torch.int32).to(torch.int16).view(torch.uint8) for _ in range(8)]
+    else:
+        srcs = [torch.randint(16, 236, (nb,), device="cuda", dtype=torch.int32).to(torch.uint8) for _ in range(8)]
     dsts = [torch.empty((dh, dw, 4), dtype=torch.uint8, device="cuda") for _ in range(8)]
     n = 16
     for _ in range(2): vp.ProcessBatch(srcs * 2, dsts * 2, dw * 4)

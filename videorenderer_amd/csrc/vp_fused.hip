@@ -55,6 +55,13 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 enum { TAILK_NONE = 0, TAILK_PQ_LUT = 1, TAILK_ALU = 2, TAILK_HLG = 3 };
+// source specialisation: GENERIC reads planes / bytes / siting at run time; P01X = bi-planar 16-bit (P010/P016), NV12 =
+// bi-planar 8-bit, both with MPEG-2 or co-sited chroma (not horizontally centred)
+enum { SRC_GENERIC = 0, SRC_P01X = 1, SRC_NV12 = 2 };
+// epilogue specialisation: DITHER8 = B8G8R8A8 target behind a final pass (integer form); DIRECT8 = B8G8R8A8 target written
+// straight from the Y pass (8-bit sources: no post-scale step); both require 16-byte aligned rows and off_x % 4 == 0
+enum { EPI_GENERIC = 0, EPI_DITHER8 = 1, EPI_DIRECT8 = 2 };
+
 
 // everything the kernel needs, flattened (kernel argument => SGPRs)
 struct FusedArgs {
@@ -79,6 +86,10 @@ struct FusedArgs {
     const uint16_t *dither;
     int seg_rows;
 };
+
+template <int SRC> __device__ __forceinline__ bool src_wide(const FusedArgs &P) { return SRC == SRC_P01X ? true : SRC == SRC_NV12 ? false : P.bytes == 2; }
+template <int SRC> __device__ __forceinline__ bool src_biplanar(const FusedArgs &P) { return SRC != SRC_GENERIC ? true : P.planes == 2; }
+template <int SRC> __device__ __forceinline__ bool src_center(const FusedArgs &P) { return SRC != SRC_GENERIC ? false : P.center_h != 0; }
 
 // tap offsets relative to `base` (ps_interpolation_*.hlsl).  NT = 5 is the D3D11 Lanczos3 as written (quirk Q1,
 // ps_interpolation_lanczos3.hlsl:33-34: the second tap re-reads the first tap's texel): taps {-2, 0, 1, 2, 3}
@@ -183,23 +194,23 @@ struct RawAddr {
     uint32_t coff[3];         // chroma columns c0-1, c0, c0+1 (clamp addressing), byte offset inside a chroma row
 };
 
-template <bool P01X>
+template <int SRC>
 __device__ __forceinline__ void make_raw_addr(const FusedArgs &P, int Xg, RawAddr &ra)
 {
     const int sx0 = P.rect_l + Xg, c0 = sx0 >> 1;
-    const int yb = (P01X || P.bytes == 2) ? 2 : 1;
-    const int cb = (P01X || P.planes == 2) ? 2 * yb : yb;
+    const int yb = src_wide<SRC>(P) ? 2 : 1;
+    const int cb = src_biplanar<SRC>(P) ? 2 * yb : yb;
     ra.yoff = (uint32_t)(yb * sx0);
 #pragma unroll
     for (int i = 0; i < 3; i++) ra.coff[i] = (uint32_t)(cb * clampi(c0 - 1 + i, 0, P.cw - 1));
 }
 
 // chroma texel as U | V << 16 (raw codes); pu/pv = row bases
-template <bool P01X>
+template <int SRC>
 __device__ __forceinline__ uint32_t ld_uv(const FusedArgs &P, gcptr pu, gcptr pv, uint32_t off)
 {
-    if (P01X || P.planes == 2) {
-        if (P01X || P.bytes == 2) return ld_u32(pu + off);
+    if (src_biplanar<SRC>(P)) {
+        if (src_wide<SRC>(P)) return ld_u32(pu + off);
         const uint32_t d = ld_u16(pu + off);
         return (d & 0xffu) | ((d >> 8) << 16);
     }
@@ -222,21 +233,21 @@ __device__ __forceinline__ float quarter(int fr)
 // The two luma rows of an iteration are (odd, odd+1) source rows — or the same row twice where the rect clamps —
 // (rect top and segment starts are even, host-checked), so for every siting both take their chroma from the same
 // two chroma rows n = floor(v'(row 0)) and n+1.
-template <bool P01X>
+template <int SRC>
 __device__ __forceinline__ void load_raw(const FusedArgs &P, gcptr py, const RawAddr &ra, int y0, int y1, Raw &r)
 {
     const int sy0 = P.rect_t + y0, sy1 = P.rect_t + y1;
     const gcptr ry0 = py + (uint32_t)sy0 * (uint32_t)P.pitch_y, ry1 = py + (uint32_t)sy1 * (uint32_t)P.pitch_y;
-    r.y[0] = (P01X || P.bytes == 2) ? ld_u32(ry0 + opaque(ra.yoff)) : ld_u16(ry0 + opaque(ra.yoff));
-    r.y[1] = (P01X || P.bytes == 2) ? ld_u32(ry1 + opaque(ra.yoff)) : ld_u16(ry1 + opaque(ra.yoff));
+    r.y[0] = src_wide<SRC>(P) ? ld_u32(ry0 + opaque(ra.yoff)) : ld_u16(ry0 + opaque(ra.yoff));
+    r.y[1] = src_wide<SRC>(P) ? ld_u32(ry1 + opaque(ra.yoff)) : ld_u16(ry1 + opaque(ra.yoff));
     const int n = chroma_v4(P, sy0) >> 2;
     const uint32_t oA = (uint32_t)clampi(n, 0, P.ch - 1) * (uint32_t)P.pitch_c, oB = (uint32_t)clampi(n + 1, 0, P.ch - 1) * (uint32_t)P.pitch_c;
-    const gcptr pu = py + P.off_u, pv = (P01X || P.planes == 2) ? pu : py + P.off_v;
+    const gcptr pu = py + P.off_u, pv = src_biplanar<SRC>(P) ? pu : py + P.off_v;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        if (i == 0 && (P01X || !P.center_h)) { r.c[0][0] = r.c[1][0] = 0; continue; }
-        r.c[0][i] = ld_uv<P01X>(P, pu + oA, pv + oA, opaque(ra.coff[i]));
-        r.c[1][i] = ld_uv<P01X>(P, pu + oB, pv + oB, opaque(ra.coff[i]));
+        if (i == 0 && !src_center<SRC>(P)) { r.c[0][0] = r.c[1][0] = 0; continue; }
+        r.c[0][i] = ld_uv<SRC>(P, pu + oA, pv + oA, opaque(ra.coff[i]));
+        r.c[1][i] = ld_uv<SRC>(P, pu + oB, pv + oB, opaque(ra.coff[i]));
     }
 }
 
@@ -245,7 +256,7 @@ __device__ __forceinline__ void load_raw(const FusedArgs &P, gcptr py, const Raw
 // evaluated in code units (vertical lerp first), UNORM scale folded into the matrix.  out[column][ch] = the channel as
 // a (row 0, row 1) pair — the layout LDS slice A wants — saturated (every continuation, tail or UNORM store,
 // saturates first).
-template <int TAIL, bool P01X>
+template <int TAIL, int SRC>
 __device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], const Raw &r, int sy0, int sy1, const f2 *T, f2 out[2][3])
 {
     // vertical weights of chroma rows n (w0) and n+1 (w1) for (row 0, row 1): wave-uniform, one SGPR pair each
@@ -261,14 +272,14 @@ __device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)
         Vc[i] = pk_fma(splat(bv), w1, splat(tv) * w0);
     }
     f2 Ycol[2], Ucol[2], Vcol[2];                 // even and odd luma column
-    if (P01X || P.bytes == 2) {
+    if (src_wide<SRC>(P)) {
         Ycol[0] = f2{(float)(r.y[0] & 0xffffu), (float)(r.y[1] & 0xffffu)};
         Ycol[1] = f2{(float)(r.y[0] >> 16), (float)(r.y[1] >> 16)};
     } else {
         Ycol[0] = f2{(float)(r.y[0] & 0xffu), (float)(r.y[1] & 0xffu)};
         Ycol[1] = f2{(float)((r.y[0] >> 8) & 0xffu), (float)((r.y[1] >> 8) & 0xffu)};
     }
-    if (!P01X && P.center_h) {                    // u' = sx/2 - 0.25 (MPEG-1 siting runs through the generic variant)
+    if (src_center<SRC>(P)) {                     // u' = sx/2 - 0.25 (MPEG-1 siting runs through the generic variant)
         Ucol[0] = pk_fma(Uc[1], splat(0.75f), Uc[0] * splat(0.25f)); Vcol[0] = pk_fma(Vc[1], splat(0.75f), Vc[0] * splat(0.25f));
         Ucol[1] = pk_fma(Uc[2], splat(0.25f), Uc[1] * splat(0.75f)); Vcol[1] = pk_fma(Vc[2], splat(0.25f), Vc[1] * splat(0.75f));
     } else {                                      // u' = sx/2
@@ -366,8 +377,7 @@ __device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)
     }
 }
 
-// FASTEPI: B8G8R8A8 target behind a final pass (the common case) — the generic epilogue is compiled out
-template <int NT, int TAIL, bool P01X, bool FASTEPI>
+template <int NT, int TAIL, int SRC, int EPI>
 __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -425,6 +435,7 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
     // colour matrix and gamut matrix, two coefficients per SGPR pair
     const f2 MM[5] = {f2{P.m[0], P.m[1]}, f2{P.m[2], P.m[3]}, f2{P.m[4], P.m[5]}, f2{P.m[6], P.m[7]}, f2{P.m[8], 0.0f}};
     const f2 GG[5] = {f2{P.gamut[0], P.gamut[1]}, f2{P.gamut[2], P.gamut[3]}, f2{P.gamut[4], P.gamut[5]}, f2{P.gamut[6], P.gamut[7]}, f2{P.gamut[8], 0.0f}};
+    constexpr bool FASTEPI = EPI == EPI_DITHER8;     // integer final pass; EPI_DIRECT8 shares its alignment preconditions
     const f2 maxv2 = splat((FASTEPI || P.final_pass) ? P.maxv : P.quant);
     const f2 cmax2 = splat(P.maxv), cinv2 = splat(P.inv_maxv);
     f2 big2 = splat(8388608.0f);                     // 2^23, pinned in VGPRs (see unorm_round2)
@@ -443,14 +454,14 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
     const int n_iter = (s1 - s0 + 1) / 2 + 3;
     Raw raw;
     RawAddr ra;
-    make_raw_addr<P01X>(P, Xg, ra);
-    load_raw<P01X>(P, py, ra, clampi(s0 - 3, 0, H - 1), clampi(s0 - 2, 0, H - 1), raw);
+    make_raw_addr<SRC>(P, Xg, ra);
+    load_raw<SRC>(P, py, ra, clampi(s0 - 3, 0, H - 1), clampi(s0 - 2, 0, H - 1), raw);
 
     // stage C for virtual rows ar, ar+1 (whose raw codes were prefetched): convert, write A, prefetch the next pair
     auto stage_c = [&](int ar) {
         f2 rc[2][3];
-        convert_block<TAIL, P01X>(P, MM, GG, CC, raw, P.rect_t + clampi(ar, 0, H - 1), P.rect_t + clampi(ar + 1, 0, H - 1), T, rc);
-        load_raw<P01X>(P, py, ra, clampi(ar + 2, 0, H - 1), clampi(ar + 3, 0, H - 1), raw);
+        convert_block<TAIL, SRC>(P, MM, GG, CC, raw, P.rect_t + clampi(ar, 0, H - 1), P.rect_t + clampi(ar + 1, 0, H - 1), T, rc);
+        load_raw<SRC>(P, py, ra, clampi(ar + 2, 0, H - 1), clampi(ar + 3, 0, H - 1), raw);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             // store to m_TexConvertOutput (UNORM: floor(sat(x)*maxv + 0.5)) and read back (q/maxv to 1 ulp)
@@ -567,6 +578,20 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
                                 const uint32_t bg = __builtin_amdgcn_perm(ig, ib, 0x0c0c0703u);    // [B, G, 0, 0]
                                 pk[px] = __builtin_amdgcn_perm(ir, bg, 0x0d070100u);               // [B, G, R, 0xff]
                             }
+                        } else if (EPI == EPI_DIRECT8) {
+                            // no post-scale step (8-bit internal format): the Y pass result is stored straight into the
+                            // B8G8R8A8 target, floor(x*255 + 0.5).  x*255 + 2^23 leaves the code in the low mantissa byte;
+                            // two v_perm_b32 gather B,G,R and the opaque alpha.
+                            f2 uq[3][2];
+#pragma unroll
+                            for (int c = 0; c < 3; c++)
+#pragma unroll
+                                for (int pp = 0; pp < 2; pp++) uq[c][pp] = pk_fma(res[c][pp], maxv2, big2);
+#pragma unroll
+                            for (int px = 0; px < 4; px++) {
+                                const uint32_t bg = __builtin_amdgcn_perm(__float_as_uint(uq[1][px >> 1][px & 1]), __float_as_uint(uq[2][px >> 1][px & 1]), 0x0c0c0400u);
+                                pk[px] = __builtin_amdgcn_perm(__float_as_uint(uq[0][px >> 1][px & 1]), bg, 0x0d040100u);
+                            }
                         } else {
                             // generic epilogue: no final pass (straight UNORM store into the RT) and/or R10G10B10A2 target
 #pragma unroll
@@ -586,7 +611,7 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
                             }
                         }
                         const gptr rowp = pdst + (uint32_t)wy * (uint32_t)P.dst_pitch;    // wave-uniform row base + per-lane 32-bit offset
-                        if (FASTEPI || st_aligned) {      // FASTEPI: 16-byte alignment of every row is a launch precondition
+                        if (EPI != EPI_GENERIC || st_aligned) {      // specialised epilogues: 16-byte alignment of every row is a launch precondition
                             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                             u32x4 v4 = {pk[0], pk[1], pk[2], pk[3]};
                             *(__attribute__((address_space(1))) u32x4 *)(rowp + opaque(lane_off)) = v4;
@@ -693,15 +718,25 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
                     : (c.tail == TAIL_HLG_TO_SDR && !P.literal_tail) ? TAILK_HLG : TAILK_ALU;
     static const int lds_pad = EnvInt("MPCVR_FUSED_LDS_PAD", 0);   // experiments: lower the occupancy by claiming more LDS
     const size_t lds = LDS_A + LDS_D + LDS_DB + (tailk == TAILK_PQ_LUT ? LDS_T : 0) + (size_t)lds_pad;
-    // the specialised variant: bi-planar 16-bit (P010/P016) with MPEG-2 / co-sited chroma; everything else (8-bit, planar,
-    // MPEG-1 siting) runs through the variant that reads these properties at run time
-    const bool p01x = c.fmt.planes == 2 && c.fmt.bytes == 2 && !a.center_h;
-    // the integer epilogue needs k*M + (j << 14) < 2^32 and M < 2^24 (true for 10-bit internal -> 8-bit target)
-    // ... and its 16-byte stores / dither reads need off_x % 4 == 0 and 16-byte aligned rows
-    const bool fastepi = a.final_pass && !a.out10 && a.epi_mul != 0 && P.dst_aligned16 && (a.off_x & 3) == 0 && (a.dst_pitch & 15) == 0;
-#define MPCVR_LAUNCH2(NT, TK, PX) do { if (fastepi) hipLaunchKernelGGL((k_fused_up2x<NT, TK, PX, true>), grid, block, lds, s, a, frames_dev, single); \
-                                       else hipLaunchKernelGGL((k_fused_up2x<NT, TK, PX, false>), grid, block, lds, s, a, frames_dev, single); } while (0)
-#define MPCVR_LAUNCH(NT, TK) do { if (p01x) MPCVR_LAUNCH2(NT, TK, true); else MPCVR_LAUNCH2(NT, TK, false); } while (0)
+    // source specialisations: bi-planar 16-bit (P010/P016) and bi-planar 8-bit (NV12) with MPEG-2 / co-sited chroma;
+    // everything else (planar, MPEG-1 siting) runs through the variant that reads these properties at run time
+    const bool biplanar_fast = c.fmt.planes == 2 && !a.center_h;
+    const int srck = (biplanar_fast && c.fmt.bytes == 2) ? SRC_P01X : (biplanar_fast && c.fmt.bytes == 1) ? SRC_NV12 : SRC_GENERIC;
+    // the specialised epilogues use 16-byte stores / dither reads: off_x % 4 == 0 and 16-byte aligned rows; the integer
+    // final pass additionally needs k*M + (j << 14) < 2^32 and M < 2^24 (true for 10-bit internal -> 8-bit target)
+    const bool aligned = P.dst_aligned16 && (a.off_x & 3) == 0 && (a.dst_pitch & 15) == 0;
+    const int epik = !aligned || a.out10 ? EPI_GENERIC
+                   : (a.final_pass && a.epi_mul != 0) ? EPI_DITHER8
+                   : (!a.final_pass && P.store.dst_fmt == SF_BGRA8 && P.store.quant == 255) ? EPI_DIRECT8 : EPI_GENERIC;
+    // instantiated (source, epilogue) pairs: each source with the epilogue it normally meets + the generic one
+#define MPCVR_LAUNCH3(NT, TK, SK, EK) hipLaunchKernelGGL((k_fused_up2x<NT, TK, SK, EK>), grid, block, lds, s, a, frames_dev, single)
+#define MPCVR_LAUNCH(NT, TK) do { \
+        if (srck == SRC_P01X && epik == EPI_DITHER8) MPCVR_LAUNCH3(NT, TK, SRC_P01X, EPI_DITHER8); \
+        else if (srck == SRC_P01X) MPCVR_LAUNCH3(NT, TK, SRC_P01X, EPI_GENERIC); \
+        else if (srck == SRC_NV12 && epik == EPI_DIRECT8) MPCVR_LAUNCH3(NT, TK, SRC_NV12, EPI_DIRECT8); \
+        else if (srck == SRC_NV12) MPCVR_LAUNCH3(NT, TK, SRC_NV12, EPI_GENERIC); \
+        else if (epik == EPI_DITHER8) MPCVR_LAUNCH3(NT, TK, SRC_GENERIC, EPI_DITHER8); \
+        else MPCVR_LAUNCH3(NT, TK, SRC_GENERIC, EPI_GENERIC); } while (0)
 #define MPCVR_LAUNCH_NT(NT) \
     do { if (tailk == TAILK_NONE) MPCVR_LAUNCH(NT, TAILK_NONE); else if (tailk == TAILK_PQ_LUT) MPCVR_LAUNCH(NT, TAILK_PQ_LUT); \
          else if (tailk == TAILK_HLG) MPCVR_LAUNCH(NT, TAILK_HLG); else MPCVR_LAUNCH(NT, TAILK_ALU); } while (0)
@@ -710,7 +745,7 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     else MPCVR_LAUNCH_NT(6);
 #undef MPCVR_LAUNCH_NT
 #undef MPCVR_LAUNCH
-#undef MPCVR_LAUNCH2
+#undef MPCVR_LAUNCH3
     return hipGetLastError();
 }
 
