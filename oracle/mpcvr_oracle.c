@@ -490,6 +490,20 @@ void orc_hdr_tail_ex(float rgb[3], int trc, int prim, int convert_to_sdr, float 
         for (int i = 0; i < 3; i++) rgb[i] = hlsl_pow(saturatef(rgb[i]), 1.0f / 2.2f);
 }
 
+/* Checker for the product's UNORM-load shortcut (vp_device.h unorm_div): q = code*(1/maxv), q' = fma(fma(-q,maxv,code),1/maxv,q)
+ * must equal the IEEE quotient code/maxv this oracle uses, for every integer code in [0, maxv].  Returns the mismatches. */
+int orc_check_unorm_div(int maxv)
+{
+    const float d = (float)maxv, r = 1.0f / d;
+    int bad = 0;
+    for (int x = 0; x <= maxv; x++) {
+        const float xf = (float)x, ref = xf / d, q = xf * r;
+        const float q2 = fmaf(fmaf(-q, d, xf), r, q);
+        if (q2 != ref) bad++;
+    }
+    return bad;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* HDR10 -> HDR10 local tone mapping — Shaders/d3d11/ps_hdr10_tonemap.hlsl:272-336 (post-scale step of Process,   */
 /* DX11VideoProcessor.cpp:3359-3367); constants as SetHDR10ShaderParams sanitises them (:907-917).  The Dolby    */

@@ -130,6 +130,7 @@ size_t orc_frame_bytes(int cformat, int width, int height, int *pitch_out);
 /* CopyFrameV210 (Helper.cpp:709-748) and the pitch of the Y210 texture it fills */
 void orc_repack_v210(int lines, uint8_t *dst, int dst_pitch, const uint8_t *src, int src_pitch);
 int orc_v210_tex_pitch(int width);
+int orc_check_unorm_div(int maxv);   /* mismatches of the product's reciprocal + Newton UNORM load vs code/maxv */
 /* the CopyFrame* functions of the interleaved RGB formats (Helper.cpp:414-707,770-787); kind = RPK_* of the oracle's
  * format table: 0 as-is, 1 RGB24, 2 r210, 3 RGB48, 4 BGR48, 5 BGRA64, 6 b64a; src_pitch < 0 = bottom-up */
 void orc_repack_rgb(int kind, int lines, uint8_t *dst, int dst_pitch, const uint8_t *src, int src_pitch);

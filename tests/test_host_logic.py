@@ -190,6 +190,13 @@ def test_every_case_has_a_plan(mpcvr):
             "passes:convert,resizeX,resizeY"} <= kinds
 
 
+def test_unorm_division_shortcut_is_exact(oracle):
+    """vp_device.h unorm_div (reciprocal + one FMA Newton step) vs the IEEE division, for every UNORM8/10/16 code."""
+    L = oracle.lib()
+    for maxv in (255, 1023, 65535):
+        assert L.orc_check_unorm_div(maxv) == 0, maxv
+
+
 def test_final_pass_integer_form_is_exhaustively_exact(mpcvr):
     """The fused kernel's final pass, (k*M + (j << 14)) >> 24, against ps_final_pass.hlsl:29 for every (k, j).
 

@@ -13,6 +13,18 @@ struct f3 { float x, y, z; };
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 __device__ __forceinline__ float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }   // NaN -> 0
 
+// UNORM load: code / maxv, correctly rounded, for an INTEGER code in [0, maxv] and maxv in {255, 1023, 65535}.
+// q = code * (1/maxv) followed by one Newton correction with two FMAs equals the IEEE division for every such code
+// (exhaustively checked, tests/test_host_logic.py::test_unorm_division_shortcut_is_exact) at 3 instructions instead of
+// the ~10 of the division expansion; results stay bit-identical to the oracle's `code / maxv`.
+template <int MAXV>
+__device__ __forceinline__ float unorm_div(float code)
+{
+    constexpr float d = (float)MAXV, r = 1.0f / (float)MAXV;
+    const float q = code * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, d, code), r, q);
+}
+
 // The transfer / tone-map chain below is ill-conditioned where the 2020->709 matrix cancels to ~0 and
 // pow(1/2.2) then magnifies the residue, so its expression shapes are kept identical in every
 // translation unit (no FMA contraction): the fused and the pass-per-kernel path then agree bit for bit.
@@ -220,9 +232,9 @@ __device__ __forceinline__ f3 hdr10_tonemap(f3 c, const HdrToneMapParams &k)
 __device__ __forceinline__ float load_sample(const uint8_t *plane, int pitch, int bytes, int shift, int x, int y)
 {
     const uint8_t *row = plane + (size_t)y * pitch;
-    if (bytes == 1) return (float)row[x] / 255.0f;
+    if (bytes == 1) return unorm_div<255>((float)row[x]);
     const unsigned v = (((const uint16_t *)row)[x] << shift) & 0xffffu;
-    return (float)v / 65535.0f;
+    return unorm_div<65535>((float)v);
 }
 __device__ __forceinline__ float load_luma(const ConvertParams &P, int x, int y)
 {
@@ -248,10 +260,10 @@ __device__ __forceinline__ float load_packed(const ConvertParams &P, int tx, int
     const uint8_t *row = P.plane[0] + (size_t)y * P.pitch[0];
     if (P.fmt.bits10) {
         const uint32_t d = ((const uint32_t *)row)[tx];
-        return (float)((d >> (10 * k)) & 0x3ffu) / 1023.0f;
+        return unorm_div<1023>((float)((d >> (10 * k)) & 0x3ffu));
     }
-    if (P.fmt.bytes == 1) return (float)row[4 * tx + k] / 255.0f;
-    return (float)((const uint16_t *)row)[4 * tx + k] / 65535.0f;
+    if (P.fmt.bytes == 1) return unorm_div<255>((float)row[4 * tx + k]);
+    return unorm_div<65535>((float)((const uint16_t *)row)[4 * tx + k]);
 }
 
 // ---- store-format rounding ----
@@ -261,9 +273,9 @@ __device__ __forceinline__ float half_round(float x) { return __half2float(__flo
 // value a texture of format fmt returns after `v` was written to it
 __device__ __forceinline__ f3 round_to_fmt(f3 v, int fmt)
 {
-    if (fmt == SF_BGRA8) { v.x = unorm_q(v.x, 255.0f) / 255.0f; v.y = unorm_q(v.y, 255.0f) / 255.0f; v.z = unorm_q(v.z, 255.0f) / 255.0f; }
-    else if (fmt == SF_RGB10A2) { v.x = unorm_q(v.x, 1023.0f) / 1023.0f; v.y = unorm_q(v.y, 1023.0f) / 1023.0f; v.z = unorm_q(v.z, 1023.0f) / 1023.0f; }
-    else if (fmt == SF_RGBA16) { v.x = unorm_q(v.x, 65535.0f) / 65535.0f; v.y = unorm_q(v.y, 65535.0f) / 65535.0f; v.z = unorm_q(v.z, 65535.0f) / 65535.0f; }
+    if (fmt == SF_BGRA8) { v.x = unorm_div<255>(unorm_q(v.x, 255.0f)); v.y = unorm_div<255>(unorm_q(v.y, 255.0f)); v.z = unorm_div<255>(unorm_q(v.z, 255.0f)); }
+    else if (fmt == SF_RGB10A2) { v.x = unorm_div<1023>(unorm_q(v.x, 1023.0f)); v.y = unorm_div<1023>(unorm_q(v.y, 1023.0f)); v.z = unorm_div<1023>(unorm_q(v.z, 1023.0f)); }
+    else if (fmt == SF_RGBA16) { v.x = unorm_div<65535>(unorm_q(v.x, 65535.0f)); v.y = unorm_div<65535>(unorm_q(v.y, 65535.0f)); v.z = unorm_div<65535>(unorm_q(v.z, 65535.0f)); }
     else { v.x = half_round(v.x); v.y = half_round(v.y); v.z = half_round(v.z); }
     return v;
 }
@@ -298,13 +310,13 @@ __device__ __forceinline__ f3 load_surface(const Surface &s, int x, int y)
     f3 v;
     if (s.fmt == SF_BGRA8) {
         const uint32_t u = ((const uint32_t *)row)[x];
-        v.x = (float)((u >> 16) & 255u) / 255.0f; v.y = (float)((u >> 8) & 255u) / 255.0f; v.z = (float)(u & 255u) / 255.0f;
+        v.x = unorm_div<255>((float)((u >> 16) & 255u)); v.y = unorm_div<255>((float)((u >> 8) & 255u)); v.z = unorm_div<255>((float)(u & 255u));
     } else if (s.fmt == SF_RGB10A2) {
         const uint32_t u = ((const uint32_t *)row)[x];
-        v.x = (float)(u & 1023u) / 1023.0f; v.y = (float)((u >> 10) & 1023u) / 1023.0f; v.z = (float)((u >> 20) & 1023u) / 1023.0f;
+        v.x = unorm_div<1023>((float)(u & 1023u)); v.y = unorm_div<1023>((float)((u >> 10) & 1023u)); v.z = unorm_div<1023>((float)((u >> 20) & 1023u));
     } else if (s.fmt == SF_RGBA16) {
         const uint2 u = ((const uint2 *)row)[x];
-        v.x = (float)(u.x & 0xffffu) / 65535.0f; v.y = (float)(u.x >> 16) / 65535.0f; v.z = (float)(u.y & 0xffffu) / 65535.0f;
+        v.x = unorm_div<65535>((float)(u.x & 0xffffu)); v.y = unorm_div<65535>((float)(u.x >> 16)); v.z = unorm_div<65535>((float)(u.y & 0xffffu));
     } else {
         const uint2 u = ((const uint2 *)row)[x];
         const __half2 lo = *(const __half2 *)&u.x, hi = *(const __half2 *)&u.y;
