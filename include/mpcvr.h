@@ -114,7 +114,8 @@ int32_t mpcvr_synchronize(mpcvr_ctx *ctx);
 
 /* VerifyMediaType + InitMediaType — DX11VideoProcessor.cpp:1569,1742.
  * cformat: ColorFormat_t value; width/height: biWidth/|biHeight|; pitch: bytes per luma row of the
- * samples that will be handed to mpcvr_copy_sample (0 => the reference's rule, :1789-1803);
+ * samples that will be handed to mpcvr_copy_sample (0 => the reference's rule, :1789-1803; negative for an RGB format
+ * = bottom-up DIB, the way m_srcPitch goes negative for BI_RGB with biHeight > 0, :1801-1803);
  * src_rect: rcSource (NULL or empty => whole frame, :1821-1823);
  * extfmt: DXVA2_ExtendedFormat.value from the media type (0 fields are defaulted per
  * SpecifyExtendedFormat, Helper.cpp:1169-1211).  Returns S_OK, or E_INVALIDARG/E_NOTIMPL. */
@@ -151,7 +152,8 @@ int32_t mpcvr_set_procamp(mpcvr_ctx *ctx, uint32_t flags, float brightness, floa
                           float hue, float saturation);
 
 /* CopySample / MemCopyToTexSrcVideo — DX11VideoProcessor.cpp:2202,1213-1252.
- * data: one media sample (planes back to back); pitch: luma row pitch in bytes (>0).
+ * data: one media sample (planes back to back); pitch: the row pitch given to mpcvr_set_input (negative for a bottom-up
+ * RGB DIB, whose `data` still points at the lowest address, DX11VideoProcessor.cpp:1243-1248).
  * MPCVR_MEM_HOST: copied into one of three pinned staging buffers and uploaded on a copy stream, so the upload of
  * sample n+1 overlaps the processing of sample n (CopyPlane10to16's <<6 / CopyFrameV210 / CopyFrameRGB* run on the
  * device); the caller's buffer is free again when the call returns.  MPCVR_MEM_HOST_PINNED: the buffer is page-locked
