@@ -363,3 +363,23 @@ def test_full_size_flat_frame_and_dither_period(mpcvr, torch_cuda):
     tiled = tile.repeat(wh // 32, ww // 32, 1)
     assert torch.equal(tiled, dst)
     vp.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("label,c", [
+    ("C1", dict(cformat=1, w=1920, h=1080, kind="structure", seed=201, dst=(1920, 1080), exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
+    ("C2", dict(cformat=20, w=1920, h=1080, kind="noise", seed=202, dst=(3840, 2160), exfmt=GOLDEN_CASES["c2_yuv420p10_catmull_2x"]["exfmt"], iUpscaling=2)),
+    ("C2_nv12_2x", dict(cformat=1, w=1920, h=1080, kind="noise", seed=203, dst=(3840, 2160), exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"], iUpscaling=4)),
+])
+def test_full_size_baseline_configs_whole_frame(mpcvr, oracle, torch_cuda, label, c):
+    """BASELINE.json C1 / C2 (and the everyday NV12 2x) at their full sizes: every output pixel against the oracle."""
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    want = oracle.process(p, frame, pitch)
+    got, info = run_product(mpcvr, torch_cuda, c)
+    if label == "C1":
+        assert info.startswith("passes:convert,copy")
+        compare(got, want, label, exact=True)                 # SDR pass-per-kernel: bit-exact
+    else:
+        assert info == "fused_up2x"
+        compare(got, want, label, min_same=0.99)
