@@ -418,3 +418,62 @@ def test_oracle_golden_hashes(oracle):
     for name in GOLDEN_CASES:
         out = run_case(oracle, name)
         assert hashlib.sha256(out.tobytes()).hexdigest() == want[name], name
+
+
+# ---------------------------------------------------------------- cross-checks between independent oracle paths
+def _conv(oracle, cf, w, h, seed, **kw):
+    from videorenderer_amd import synth
+    fr, pitch = synth.make_frame(cf, w, h, "noise", seed=seed)
+    p = oracle.default_params(cformat=cf, width=w, height=h, window_w=w, window_h=h, video_rect=(0, 0, w, h), **kw)
+    out = oracle.convert_only(p, fr, pitch)
+    return np.asarray(out[0] if isinstance(out, tuple) else out)
+
+
+def _proc(oracle, cf, w, h, dst, seed=5, kind="noise", **kw):
+    from videorenderer_amd import synth
+    fr, pitch = synth.make_frame(cf, w, h, kind, seed=seed)
+    p = oracle.default_params(cformat=cf, width=w, height=h, window_w=dst[0], window_h=dst[1], video_rect=(0, 0, dst[0], dst[1]), **kw)
+    return oracle.process(p, fr, pitch, dst=np.zeros((dst[1], dst[0], 4), np.uint8))
+
+
+def test_packed_formats_equal_their_planar_twins(oracle):
+    """The same samples in a packed container and in planes go through different oracle code (fetch_pixel branches, the
+    v210 unpack) and must convert identically: the reference's packed 4:2:2 'linear' chroma is the planar bilinear one."""
+    pairs = [(4, 18), (5, 18), (8, 22), (9, 23), (10, 22), (11, 19), (13, 25)]     # YUY2, UYVY, Y210, Y216, v210, AYUV, Y416
+    for a, b in pairs:
+        for cs in (1, 2):
+            for (w, h) in ((48, 16), (46, 10)):
+                assert np.array_equal(_conv(oracle, a, w, h, 7, iChromaScaling=cs), _conv(oracle, b, w, h, 7, iChromaScaling=cs)), (a, b, cs, w)
+    # Y410 carries true 10-bit UNORM; the planar 10-bit twin is <<6 in 16 bits with a 10-bit matrix (quirk Q5): close, not equal
+    d = np.abs(_conv(oracle, 12, 48, 16, 7).astype(np.float64) - _conv(oracle, 24, 48, 16, 7).astype(np.float64))
+    assert 0 < d.max() < 3e-3
+
+
+def test_interleaved_rgb_equals_planar_rgb(oracle):
+    """XRGB32 (no convert draw: the source texture feeds the resize) vs GBRP8 (identity matrix through the convert draw)."""
+    perm = lambda g: np.stack([g[..., 2], g[..., 0], g[..., 1], g[..., 3]], -1)    # synth puts (y,u,v) into (G,B,R) resp. (R,G,B)
+    w, h = 48, 20
+    for kw, dst in (({}, (w, h)), (dict(iUpscaling=2), (2 * w, 2 * h)), (dict(brightness=10.0, contrast=1.1), (w, h)),
+                    (dict(src_rect=(8, 2, 40, 18)), (32, 16)), (dict(iDownscaling=2), (16, 8))):
+        assert np.array_equal(_proc(oracle, 30, w, h, dst, **kw), perm(_proc(oracle, 26, w, h, dst, **kw))), kw
+    a = _proc(oracle, 30, w, h, (w, h))
+    for cf in (29, 31):
+        assert np.array_equal(a, _proc(oracle, cf, w, h, (w, h)))                  # RGB24 / ARGB32 containers
+    e = _proc(oracle, 33, w, h, (w, h))
+    for cf in (34, 35, 36):
+        assert np.array_equal(e, _proc(oracle, cf, w, h, (w, h)))                  # BGR48 / BGRA64 / b64a vs RGB48
+
+
+def test_rotation_and_flip_are_pure_permutations_without_scaling(oracle):
+    base = _proc(oracle, 1, 64, 40, (64, 40), kind="structure", seed=3)
+    r = lambda **kw: _proc(oracle, 1, 64, 40, kw.pop("dst"), kind="structure", seed=3, **kw)
+    assert np.array_equal(r(dst=(40, 64), rotation=90), np.rot90(base, -1))       # clockwise
+    assert np.array_equal(r(dst=(64, 40), rotation=180), np.rot90(base, 2))
+    assert np.array_equal(r(dst=(40, 64), rotation=270), np.rot90(base, 1))
+    assert np.array_equal(r(dst=(64, 40), flip=1), base[:, ::-1])
+    assert np.array_equal(r(dst=(40, 64), rotation=90, flip=1), np.rot90(base[:, ::-1], -1))
+    # 180 degrees commutes with a symmetric separable scaler; 90 degrees with the same scaler on both axes is ONE draw
+    # (resizerX == resizerY, DX11VideoProcessor.cpp:3131-3137), so only one axis is filtered — as written
+    up = r(dst=(128, 80), iUpscaling=2)
+    assert np.array_equal(r(dst=(128, 80), rotation=180, iUpscaling=2), np.rot90(up, 2))
+    assert not np.array_equal(r(dst=(80, 128), rotation=90, iUpscaling=2), np.rot90(up, -1))
