@@ -143,6 +143,44 @@ int32_t mpcvr_set_hdr_output(mpcvr_ctx *ctx, int32_t enable, int32_t tone_map_ty
 /* the values Render() passes to SetHDR10ShaderParams (:907-917, :2716-2727), sanitised the same way */
 int32_t mpcvr_set_hdr_metadata(mpcvr_ctx *ctx, float min_mastering_nits, float max_mastering_nits, float max_cll, float max_fall);
 
+/* Dolby Vision RPU of the next sample(s): the fields of MediaSideDataDOVIMetadata (Include/IMediaSideData.h:154-330) the
+ * frame path reads when CopySample finds IID_MediaSideDataDOVIMetadataV2 on the sample (DX11VideoProcessor.cpp:2270-2520).
+ * The reference struct is #pragma pack(1); this one has natural C alignment, the adapter copies field by field.
+ * Extension blocks: the first level-1 block (+ the first level-3 block, if any) and every level-2 block, in
+ * Extensions[] order. */
+typedef struct mpcvr_dovi_curve {
+    uint8_t  num_pivots;            /* [2, 9] */
+    uint8_t  mapping_idc[8];        /* 0 polynomial, 1 mmr */
+    uint8_t  poly_order[8];         /* [1, 2] */
+    uint8_t  mmr_order[8];          /* [1, 3] */
+    uint16_t pivots[9];             /* sorted ascending, bl_bit_depth codes */
+    int64_t  poly_coef[8][3];       /* x^0, x^1, x^2 ; fixed point, coef_log2_denom fractional bits */
+    int64_t  mmr_constant[8];
+    int64_t  mmr_coef[8][3][7];
+} mpcvr_dovi_curve;
+typedef struct mpcvr_dovi_l2 {
+    uint16_t target_max_pq, trim_slope, trim_offset, trim_power, trim_chroma_weight, trim_saturation_gain;
+} mpcvr_dovi_l2;
+typedef struct mpcvr_dovi_metadata {
+    uint8_t  bl_bit_depth, coef_log2_denom;                 /* Header */
+    uint16_t source_max_pq;                                 /* ColorMetadata */
+    uint8_t  l1_present, l3_present;
+    uint16_t l1_min_pq, l1_max_pq, l1_avg_pq, l3_min_pq_offset, l3_max_pq_offset, l3_avg_pq_offset;
+    uint32_t n_l2;                                          /* <= 32 (LAV_DOVI_MAX_EXTENSIONS) */
+    mpcvr_dovi_l2 l2[32];
+    double   ycc_to_rgb_matrix[9], ycc_to_rgb_offset[3], rgb_to_lms_matrix[9];   /* ColorMetadata */
+    mpcvr_dovi_curve curves[3];                             /* Mapping.curves, per component */
+} mpcvr_dovi_metadata;
+/* m_Dovi.msd = *md, m_Dovi.bValid = true: the convert pass reshapes (Y,U,V) through the curves (ShaderDoviReshape[Poly],
+ * Shaders.cpp:531-589), uses ycc_to_rgb_matrix/offset as the colour matrix (SetShaderConvertColorParams :817-834), goes
+ * PQ -> linear -> dovi_lms2rgb x rgb_to_lms_matrix -> PQ (Shaders.cpp:826-859) and continues as a PQ source; level-2 trims
+ * are selected for the display peak of mpcvr_set_hdr_output (:2383-2469) and applied in the convert tail (SDR output) and
+ * the tone-mapping step (HDR output); level 1 (+3) replaces the HDR10 metadata of that step (:2716-2720).
+ * md == NULL ends Dolby Vision mode (m_Dovi = {}).  E_INVALIDARG for what CheckDoviMetadata rejects in the curves
+ * (VideoProcessor.cpp:283-292); the profile checks on the RPU header (:275-281) stay with the adapter.
+ * The fused 2x kernel does not carry this path; Dolby Vision frames take the pass-per-kernel path. */
+int32_t mpcvr_set_dovi_metadata(mpcvr_ctx *ctx, const mpcvr_dovi_metadata *md);
+
 /* Configure — DX11VideoProcessor.cpp:3800-4050: diff each field, rebuild only what changed. */
 int32_t mpcvr_configure(mpcvr_ctx *ctx, const mpcvr_settings *settings);
 
@@ -223,6 +261,13 @@ int32_t mpcvr_plan_pq_lut(float lum_scale, float out4096[4096]);
 /* the fused path's integer form of ps_final_pass.hlsl:29: floor(k*quant/maxv + j/1024) == (k*M + (j << 14)) >> 24;
  * writes M (0 = not representable, the float epilogue is used) */
 int32_t mpcvr_plan_final_pass_multiplier(int32_t quant, int32_t maxv, uint32_t *multiplier);
+/* Dolby Vision host maths.  cb: the PS_DOVI_CURVE cbuffer of SetShaderDoviCurves (:1055-1141) as 3 x 235 floats — per
+ * component pivots[7], coeffs[8][4], mmr[48][4], then {methods, mmr_single, min_order, max_order} as float values;
+ * lms9: dovi_lms2rgb x rgb_to_lms_matrix (Shaders.cpp:826-842); l2k: {ChromaWeight, SaturationGain, TrimSlope, TrimOffset,
+ * TrimPower} of SetDolbyVisionDynamicParams (:954-960) for a display of display_nits, *l2_enabled = L2Enabled;
+ * l1_nits: {min, max, avg} as CopySample stores them (:2347-2372), *l1_present.  Any out pointer may be NULL. */
+int32_t mpcvr_plan_dovi(const mpcvr_dovi_metadata *md, int32_t display_nits, float *cb705, int32_t *has_mmr,
+                        float lms9[9], float l2k[5], int32_t *l2_enabled, uint32_t l1_nits[3], int32_t *l1_present);
 /* ps_interpolation_{spline4,lanczos2,lanczos3}.hlsl weights for phase t; returns the tap count (4/6) or 0 */
 int32_t mpcvr_plan_upscale_weights(int32_t iUpscaling, float t, float w6[6]);
 /* tap table of one TextureResizeShader draw (DX11VideoProcessor.cpp:332-377): kind 0 = point sample,

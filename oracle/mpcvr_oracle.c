@@ -303,6 +303,13 @@ int orc_color_matrix(const orc_params *p, float out[12])
     float contrast = p->contrast;                                        /* :840 */
     float hue = (float)(p->hue / 180 * acos(-1));                        /* :841 */
     float m[9], c[3];
+    if (p->dovi) {                                                       /* :817-834 — hue / saturation are not applied */
+        for (int i = 0; i < 9; i++) m[i] = (float)p->dovi->ycc_to_rgb_matrix[i] * contrast;
+        for (int i = 0; i < 3; i++) {
+            c[i] = brightness;
+            for (int j = 0; j < 3; j++) c[i] = (float)((double)c[i] - (double)m[3 * i + j] * p->dovi->ycc_to_rgb_offset[j]);
+        }
+    } else
     orc_csp_matrix(space, levels, f->cdepth, brightness, contrast, hue, p->saturation, f->cstype == CST_GRAY, m, c);
     if (f->cstype == CST_RGB && f->layout == LAY_PLANAR && f->planes == 3) {     /* GBRP: (x,y,z) -> (y,z,x) per row, :863-867 */
         for (int i = 0; i < 3; i++) { float x = m[3 * i], y = m[3 * i + 1], z = m[3 * i + 2]; m[3 * i] = y; m[3 * i + 1] = z; m[3 * i + 2] = x; }
@@ -445,25 +452,42 @@ void orc_hdr_tail(float rgb[3], int trc, int prim, int convert_to_sdr, float lum
 
 /* hdr_output = m_bHdrPassthroughSupport && (m_bHdrPassthrough || m_bHdrLocalToneMapping): convertType
  * (DX11VideoProcessor.cpp:2948-2950) is then never SHADER_CONVERT_TO_SDR, and SHADER_CONVERT_TO_PQ for HLG */
+typedef struct { int active, l2_enabled; float lms[9], k[5]; } dovi_tail_t;
+static void dovi_trims_convert(float c[3], const float k[5]);
+static void hdr_tail_full(float rgb[3], int trc, int prim, int convert_to_sdr, float lum_scale, int hdr_output, const dovi_tail_t *dv);
+
 void orc_hdr_tail_ex(float rgb[3], int trc, int prim, int convert_to_sdr, float lum_scale, int hdr_output)
 {
+    hdr_tail_full(rgb, trc, prim, convert_to_sdr, lum_scale, hdr_output, NULL);
+}
+
+static void hdr_tail_full(float rgb[3], int trc, int prim, int convert_to_sdr, float lum_scale, int hdr_output, const dovi_tail_t *dv)
+{
     float gm[9];
+    const int dovi = dv && dv->active;
     const int bt2020 = (prim == PRIM_2020);
-    const int hdr2sdr = convert_to_sdr && !hdr_output && (trc == TRC_2084 || trc == TRC_HLG);        /* :614, :2948 */
+    const int hdr2sdr = convert_to_sdr && !hdr_output && (trc == TRC_2084 || trc == TRC_HLG || dovi);   /* :614, :2948 */
+    const int apply_hlg = (trc == TRC_HLG) && !dovi;                                   /* bApplyHLG :615 */
     int is_linear = 0;
-    if (!hdr2sdr && hdr_output && trc == TRC_HLG) {                                    /* bConvertHLGtoPQ :616,885-891 */
+    if (dovi) {                                                                        /* :826-859 */
+        for (int i = 0; i < 3; i++) rgb[i] = orc_st2084_to_linear(fmaxf(rgb[i], 0.0f), 1.0f);
+        mat3_apply(dv->lms, rgb);
+        for (int i = 0; i < 3; i++) rgb[i] = orc_linear_to_st2084(fmaxf(rgb[i], 0.0f), 1.0f);
+    }
+    if (!hdr2sdr && hdr_output && apply_hlg) {                                    /* bConvertHLGtoPQ :616,885-891 */
         for (int i = 0; i < 3; i++) rgb[i] = saturatef(rgb[i]);
         orc_hlg_to_linear(rgb);
         for (int i = 0; i < 3; i++) rgb[i] = orc_linear_to_st2084(rgb[i], 1000.0f);
         return;
     }
     if (hdr2sdr) {
-        if (trc == TRC_HLG) {                                                          /* :862-868 */
+        if (apply_hlg) {                                                               /* :862-868 */
             for (int i = 0; i < 3; i++) rgb[i] = saturatef(rgb[i]);
             orc_hlg_to_linear(rgb);
             for (int i = 0; i < 3; i++) rgb[i] = orc_linear_to_st2084(rgb[i], 1000.0f);
         }
         for (int i = 0; i < 3; i++) rgb[i] = saturatef(rgb[i]);                        /* :870-872 */
+        if (dovi && dv->l2_enabled) dovi_trims_convert(rgb, dv->k);                    /* :873-877 */
         for (int i = 0; i < 3; i++) rgb[i] = orc_st2084_to_linear(rgb[i], lum_scale);  /* :879 */
         orc_tonemap_hable(rgb);                                                        /* :880 */
         orc_gamut_2020_to_709(gm); mat3_apply(gm, rgb);                                /* :881 */
@@ -490,6 +514,239 @@ void orc_hdr_tail_ex(float rgb[3], int trc, int prim, int convert_to_sdr, float 
         for (int i = 0; i < 3; i++) rgb[i] = hlsl_pow(saturatef(rgb[i]), 1.0f / 2.2f);
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* Dolby Vision: reshaping curves, IPT-PQ -> LMS -> RGB, level-2 trims                          */
+/* ------------------------------------------------------------------------------------------ */
+#define DOVI_RESHAPE_POLY 1u
+#define DOVI_RESHAPE_MMR  2u
+
+/* SetShaderDoviCurves — DX11VideoProcessor.cpp:1055-1141.  SetShaderDoviCurvesPoly (:990-1053), used when no piece of any
+ * curve is MMR, fills pivots and polynomial coefficients with the same expressions. */
+void orc_dovi_pack_curves(const orc_dovi *d, orc_dovi_cb cb[3], int *has_mmr_any)
+{
+    memset(cb, 0, sizeof(orc_dovi_cb) * 3);
+    *has_mmr_any = 0;
+    for (int c = 0; c < 3; c++) {
+        const orc_dovi_curve *curve = &d->curves[c];
+        orc_dovi_cb *out = &cb[c];
+        int has_poly = 0, has_mmr = 0, mmr_single = 1;
+        uint32_t mmr_idx = 0, min_order = 3, max_order = 1;
+        const float scale_coef = 1.0f / (1 << d->coef_log2_denom);                       /* :1068 */
+        const int num_coef = curve->num_pivots - 1;
+        for (int i = 0; i < num_coef; i++) {
+            switch (curve->mapping_idc[i]) {
+            case 0:                                                                       /* :1072-1078 */
+                has_poly = 1;
+                out->coeffs[i][0] = scale_coef * curve->poly_coef[i][0];
+                out->coeffs[i][1] = (curve->poly_order[i] >= 1) ? scale_coef * curve->poly_coef[i][1] : 0.0f;
+                out->coeffs[i][2] = (curve->poly_order[i] >= 2) ? scale_coef * curve->poly_coef[i][2] : 0.0f;
+                out->coeffs[i][3] = 0.0f;
+                break;
+            case 1:                                                                       /* :1079-1100 */
+                min_order = (uint32_t)((int)min_order < (int)curve->mmr_order[i] ? (int)min_order : (int)curve->mmr_order[i]);
+                max_order = (uint32_t)((int)max_order > (int)curve->mmr_order[i] ? (int)max_order : (int)curve->mmr_order[i]);
+                mmr_single = !has_mmr;
+                has_mmr = 1;
+                out->coeffs[i][0] = scale_coef * curve->mmr_constant[i];
+                out->coeffs[i][1] = (float)mmr_idx;
+                out->coeffs[i][3] = (float)curve->mmr_order[i];
+                for (int j = 0; j < curve->mmr_order[i]; j++) {
+                    out->mmr[mmr_idx][0] = scale_coef * curve->mmr_coef[i][j][0];
+                    out->mmr[mmr_idx][1] = scale_coef * curve->mmr_coef[i][j][1];
+                    out->mmr[mmr_idx][2] = scale_coef * curve->mmr_coef[i][j][2];
+                    out->mmr[mmr_idx][3] = 0.0f;
+                    mmr_idx++;
+                    out->mmr[mmr_idx][0] = scale_coef * curve->mmr_coef[i][j][3];
+                    out->mmr[mmr_idx][1] = scale_coef * curve->mmr_coef[i][j][4];
+                    out->mmr[mmr_idx][2] = scale_coef * curve->mmr_coef[i][j][5];
+                    out->mmr[mmr_idx][3] = scale_coef * curve->mmr_coef[i][j][6];
+                    mmr_idx++;
+                }
+                break;
+            }
+        }
+        const float scale = 1.0f / ((1 << d->bl_bit_depth) - 1);                         /* :1104 */
+        const int n = curve->num_pivots - 2;
+        for (int i = 0; i < n; i++) out->pivots[i] = scale * curve->pivots[i + 1];
+        for (int i = n; i < 7; i++) out->pivots[i] = 1e9f;
+        if (has_poly) out->methods = DOVI_RESHAPE_POLY;                                  /* :1113-1121 */
+        if (has_mmr) {
+            out->methods |= DOVI_RESHAPE_MMR;
+            out->mmr_single = (uint32_t)mmr_single;
+            out->min_order = min_order;
+            out->max_order = max_order;
+            *has_mmr_any = 1;                                                             /* :2305-2311 */
+        }
+    }
+}
+
+/* reshape_mmr — Shaders.cpp:734-762.  dot() is modelled like mul(): products summed left to right, unfused. */
+static float dovi_reshape_mmr(const orc_dovi_cb *cv, const float coeffs[4], const float sig[3])
+{
+    const uint32_t mmr_idx = cv->mmr_single ? 0u : (uint32_t)coeffs[1];
+    const float (*m)[4] = cv->mmr;
+    float s = coeffs[0];
+    float sigX[4] = {sig[0] * sig[1], sig[0] * sig[2], sig[1] * sig[2], 0.0f};
+    sigX[3] = sigX[0] * sig[2];
+    s += m[mmr_idx][0] * sig[0] + m[mmr_idx][1] * sig[1] + m[mmr_idx][2] * sig[2];
+    s += m[mmr_idx + 1][0] * sigX[0] + m[mmr_idx + 1][1] * sigX[1] + m[mmr_idx + 1][2] * sigX[2] + m[mmr_idx + 1][3] * sigX[3];
+    if (cv->max_order >= 2) {
+        const uint32_t order = (uint32_t)coeffs[3];
+        if (cv->min_order < 2 && order < 2) return s;
+        float sig2[3], sigX2[4];
+        for (int i = 0; i < 3; i++) sig2[i] = sig[i] * sig[i];
+        for (int i = 0; i < 4; i++) sigX2[i] = sigX[i] * sigX[i];
+        s += m[mmr_idx + 2][0] * sig2[0] + m[mmr_idx + 2][1] * sig2[1] + m[mmr_idx + 2][2] * sig2[2];
+        s += m[mmr_idx + 3][0] * sigX2[0] + m[mmr_idx + 3][1] * sigX2[1] + m[mmr_idx + 3][2] * sigX2[2] + m[mmr_idx + 3][3] * sigX2[3];
+        if (cv->max_order == 3) {
+            if (cv->min_order < 3 && order < 3) return s;
+            float sig3[3], sigX3[4];
+            for (int i = 0; i < 3; i++) sig3[i] = sig2[i] * sig[i];
+            for (int i = 0; i < 4; i++) sigX3[i] = sigX2[i] * sigX[i];
+            s += m[mmr_idx + 4][0] * sig3[0] + m[mmr_idx + 4][1] * sig3[1] + m[mmr_idx + 4][2] * sig3[2];
+            s += m[mmr_idx + 5][0] * sigX3[0] + m[mmr_idx + 5][1] * sigX3[1] + m[mmr_idx + 5][2] * sigX3[2] + m[mmr_idx + 5][3] * sigX3[3];
+        }
+    }
+    return s;
+}
+
+/* ShaderDoviReshape (has_mmr) / ShaderDoviReshapePoly — Shaders.cpp:531-589 */
+void orc_dovi_reshape(const orc_dovi_cb cb[3], int has_mmr, float color[3])
+{
+    const float sig[3] = {saturatef(color[0]), saturatef(color[1]), saturatef(color[2])};
+    for (int c = 0; c < 3; c++) {
+        const orc_dovi_cb *cv = &cb[c];
+        float s = sig[c];
+#define DV_TEST(i) (s < cv->pivots[i])
+        const int k = DV_TEST(3) ? (DV_TEST(1) ? (DV_TEST(0) ? 0 : 1) : (DV_TEST(2) ? 2 : 3))
+                                 : (DV_TEST(5) ? (DV_TEST(4) ? 4 : 5) : (DV_TEST(6) ? 6 : 7));
+#undef DV_TEST
+        const float *co = cv->coeffs[k];
+        if (!has_mmr) {
+            s = (co[2] * s + co[1]) * s + co[0];
+        } else if (cv->methods == DOVI_RESHAPE_POLY + DOVI_RESHAPE_MMR) {
+            if (co[3] == 0.0f) s = (co[2] * s + co[1]) * s + co[0];
+            else s = dovi_reshape_mmr(cv, co, sig);
+        } else if (cv->methods == DOVI_RESHAPE_POLY) {
+            s = (co[2] * s + co[1]) * s + co[0];
+        } else {
+            s = dovi_reshape_mmr(cv, co, sig);
+        }
+        color[c] = saturatef(s);
+    }
+}
+
+/* Shaders.cpp:826-842: mat = dovi_lms2rgb x (float)rgb_to_lms_matrix, mul_matrix3x3 of csputils.cpp:531-538 */
+void orc_dovi_lms_matrix(const orc_dovi *d, float out[9])
+{
+    static const float lms2rgb[3][3] = {
+        { 3.06441879f, -2.16597676f,  0.10155818f},
+        {-0.65612108f,  1.78554118f, -0.12943749f},
+        { 0.01736321f, -0.04725154f,  1.03004253f},
+    };
+    float b[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) b[i][j] = (float)d->rgb_to_lms_matrix[i * 3 + j];
+    for (int i = 0; i < 3; i++)
+        for (int r = 0; r < 3; r++)
+            out[r * 3 + i] = lms2rgb[r][0] * b[0][i] + lms2rgb[r][1] * b[1][i] + lms2rgb[r][2] * b[2][i];
+}
+
+/* host-side PQ helpers of CopySample — DX11VideoProcessor.cpp:2324-2345 (libm powf, not the shader pow) */
+static float dovi_pq_to_nits(float x)
+{
+    x = powf(x, 1.0f / ST2084_m2);
+    x = fmaxf(x - ST2084_c1, 0.0f) / (ST2084_c2 - ST2084_c3 * x);
+    x = powf(x, 1.0f / ST2084_m1);
+    return x * 10000.0f;
+}
+static float dovi_nits_to_pq(float y)
+{
+    y /= 10000.0f;
+    y = fmaxf(y, 0.0f);
+    y = powf(y, ST2084_m1);
+    y = (ST2084_c1 + ST2084_c2 * y) / (1.0f + ST2084_c3 * y);
+    return powf(y, ST2084_m2);
+}
+
+int orc_dovi_l1_nits(const orc_dovi *d, uint32_t out[3])                          /* :2347-2372 */
+{
+    out[0] = out[1] = out[2] = 0;
+    if (!d->l1_present) return 0;
+    uint32_t mn = d->l1_min_pq, mx = d->l1_max_pq, av = d->l1_avg_pq;      /* UINT fields */
+    if (d->l3_present) {
+        mn = mn + d->l3_min_pq_offset - 2048;
+        mx = mx + d->l3_max_pq_offset - 2048;
+        av = av + d->l3_avg_pq_offset - 2048;
+    }
+    out[0] = (uint32_t)dovi_pq_to_nits(mn / 4095.f);
+    out[1] = (uint32_t)dovi_pq_to_nits(mx / 4095.f);
+    out[2] = (uint32_t)dovi_pq_to_nits(av / 4095.f);
+    return 1;
+}
+
+static float lerp_std(float a, float b, float t)
+{   /* std::lerp for finite a, b and t in [0,1] (the only range the caller produces): exact at both ends, monotonic */
+    if ((a <= 0 && b >= 0) || (a >= 0 && b <= 0)) return t * b + (1 - t) * a;
+    if (t == 1) return b;
+    const float x = a + t * (b - a);
+    return (t > 1) == (b > a) ? (b < x ? x : b) : (b > x ? x : b);
+}
+
+int orc_dovi_l2_constants(const orc_dovi *d, int display_nits, float k[5])       /* :2383-2469, :954-960 */
+{
+    const float display_pq = dovi_nits_to_pq((float)display_nits);
+    int lower = -1, upper = -1, present = 0;
+    float dl = 1.0f, du = 1.0f;
+    const int n = d->n_l2 > 32 ? 32 : (int)d->n_l2;
+    for (int i = 0; i < n; i++) {
+        present = 1;
+        const float target_pq = d->l2[i].target_max_pq / 4095.0f;
+        if (target_pq <= display_pq) { const float dist = display_pq - target_pq; if (dist < dl) { dl = dist; lower = i; } }
+        else { const float dist = target_pq - display_pq; if (dist < du) { du = dist; upper = i; } }
+    }
+    float l2[5] = {0, 0, 0, 0, 0};      /* m_DoviExtensionMetadata.L2 zero-initialised: chroma, sat, slope, offset, power */
+    if (present) {
+        float t_slope = 1.0f, t_offset = 0.0f, t_power = 1.0f, t_chroma = 0.0f, t_sat = 0.0f;
+        if (lower != -1 && upper != -1) {
+            const orc_dovi_l2 *a = &d->l2[lower], *b = &d->l2[upper];
+            const float lower_pq = a->target_max_pq / 4095.0f, upper_pq = b->target_max_pq / 4095.0f;
+            float w = (upper_pq != lower_pq) ? (display_pq - lower_pq) / (upper_pq - lower_pq) : 0.0f;
+            w = w < 0.0f ? 0.0f : (w > 1.0f ? 1.0f : w);
+            t_slope = lerp_std((float)a->trim_slope, (float)b->trim_slope, w);
+            t_offset = lerp_std((float)a->trim_offset, (float)b->trim_offset, w);
+            t_power = lerp_std((float)a->trim_power, (float)b->trim_power, w);
+            t_chroma = lerp_std((float)a->trim_chroma_weight, (float)b->trim_chroma_weight, w);
+            t_sat = lerp_std((float)a->trim_saturation_gain, (float)b->trim_saturation_gain, w);
+        } else if (lower != -1) {
+            const orc_dovi_l2 *a = &d->l2[lower];
+            const float master_pq = d->source_max_pq / 4095.0f, lower_pq = a->target_max_pq / 4095.0f;
+            float w = (master_pq > lower_pq) ? (display_pq - lower_pq) / (master_pq - lower_pq) : 0.0f;
+            w = w < 0.0f ? 0.0f : (w > 1.0f ? 1.0f : w);
+            t_slope = lerp_std((float)a->trim_slope, 2048.0f, w);
+            t_offset = lerp_std((float)a->trim_offset, 2048.0f, w);
+            t_power = lerp_std((float)a->trim_power, 2048.0f, w);
+            t_chroma = lerp_std((float)a->trim_chroma_weight, 2048.0f, w);
+            t_sat = lerp_std((float)a->trim_saturation_gain, 2048.0f, w);
+        } else if (upper != -1) {
+            const orc_dovi_l2 *b = &d->l2[upper];
+            t_slope = b->trim_slope; t_offset = b->trim_offset; t_power = b->trim_power;
+            t_chroma = b->trim_chroma_weight; t_sat = b->trim_saturation_gain;
+        }
+        l2[0] = t_chroma / 4096.0f; l2[1] = t_sat / 4096.0f;
+        l2[2] = t_slope / 4096.0f; l2[3] = t_offset / 4096.0f; l2[4] = t_power / 4096.0f;
+    }
+    k[0] = l2[0] - 0.5f; k[1] = l2[1] - 0.5f; k[2] = l2[2] + 0.5f; k[3] = l2[3] - 0.5f; k[4] = l2[4] + 0.5f;
+    return present;
+}
+
+/* convert-shader DolbyVisionTrims — Shaders.cpp:766-773 (PQ-coded colour) */
+static void dovi_trims_convert(float c[3], const float k[5])
+{
+    for (int i = 0; i < 3; i++) c[i] = hlsl_pow((c[i] * k[2]) + k[3], k[4]);
+    const float Y = 0.2627f * c[0] + 0.6780f * c[1] + 0.0593f * c[2];
+    for (int i = 0; i < 3; i++) c[i] = c[i] * hlsl_pow((1.0f + k[0]) * c[i] / Y, k[1]);
+}
+
 /* Checker for the product's UNORM-load shortcut (vp_device.h unorm_div): q = code*(1/maxv), q' = fma(fma(-q,maxv,code),1/maxv,q)
  * must equal the IEEE quotient code/maxv this oracle uses, for every integer code in [0, maxv].  Returns the mismatches. */
 int orc_check_unorm_div(int maxv)
@@ -507,13 +764,18 @@ int orc_check_unorm_div(int maxv)
 /* ------------------------------------------------------------------------------------------ */
 /* HDR10 -> HDR10 local tone mapping — Shaders/d3d11/ps_hdr10_tonemap.hlsl:272-336 (post-scale step of Process,   */
 /* DX11VideoProcessor.cpp:3359-3367); constants as SetHDR10ShaderParams sanitises them (:907-917).  The Dolby    */
-/* Vision L2 trims (L2Enabled) are not modelled.                                                                 */
+/* Vision L2 trims (L2Enabled, cbuffer b1 bound at :3362-3364) follow the PQ->linear step.                       */
 /* ------------------------------------------------------------------------------------------ */
 typedef struct { float min_m, max_m, max_cll, max_fall, display_max; int selection; } hdr_tm_t;
 
 static hdr_tm_t hdr_tm_params(const orc_params *p)
 {
     hdr_tm_t t = {p->hdr_min_mastering, p->hdr_max_mastering, p->hdr_max_cll, p->hdr_max_fall, p->hdr_display_max_nits, p->hdr_tonemap_type};
+    uint32_t l1[3];
+    if (p->dovi && orc_dovi_l1_nits(p->dovi, l1)) {          /* DX11VideoProcessor.cpp:2716-2720: L1 min, max, max, avg; type 5 -> 6 */
+        t.min_m = (float)l1[0]; t.max_m = (float)l1[1]; t.max_cll = (float)l1[1]; t.max_fall = (float)l1[2];
+        if (t.selection == 5) t.selection = 6;
+    }
     if (t.min_m <= 0.f) t.min_m = 0.f;
     if (t.max_m <= 10.f) t.max_m = 1000.f;
     if (t.max_cll <= 10.f) t.max_cll = t.max_m;
@@ -535,6 +797,12 @@ void orc_hdr10_tonemap(float c[3], const orc_params *p)
 {
     const hdr_tm_t k = hdr_tm_params(p);
     for (int i = 0; i < 3; i++) c[i] = orc_st2084_to_linear(saturatef(c[i]), 10000.0f);     /* :275-277 */
+    float l2k[5];
+    if (p->dovi && orc_dovi_l2_constants(p->dovi, (int)p->hdr_display_max_nits, l2k)) {     /* L2Enabled: DolbyVisionTrims :257-270 */
+        for (int i = 0; i < 3; i++) c[i] = orc_linear_to_st2084(c[i], 10000.0f);
+        dovi_trims_convert(c, l2k);
+        for (int i = 0; i < 3; i++) c[i] = orc_st2084_to_linear(c[i], 10000.0f);
+    }
     if (k.selection == 5) {                                                                 /* BT2390Tonemap :68-124 */
         float safe = k.max_cll;
         if (safe <= 10.0f) safe = k.max_m;
@@ -1053,6 +1321,10 @@ typedef struct {
     float cm[12];
     float lum_scale;
     int internal_fmt;
+    /* m_Dovi (valid when p->dovi) */
+    orc_dovi_cb dovi_cb[3];
+    int dovi_has_mmr;
+    dovi_tail_t dovi_tail;
 } convert_ctx;
 
 static int setup_convert(const orc_params *p, const uint8_t *src, int src_pitch, convert_ctx *c)
@@ -1099,6 +1371,13 @@ static int setup_convert(const orc_params *p, const uint8_t *src, int src_pitch,
     /* :849-853 — interleaved RGB skips the convert draw unless brightness / contrast are set */
     c->enable = f->cstype == CST_YUV || (f->cstype == CST_RGB && f->planes == 3) || f->cstype == CST_GRAY ||
                 fabsf(p->brightness / 255) > 1e-4f || fabsf(p->contrast - 1.0f) > 1e-4f;
+    if (p->dovi) {
+        c->enable = 1;                                                   /* :834 */
+        orc_dovi_pack_curves(p->dovi, c->dovi_cb, &c->dovi_has_mmr);
+        c->dovi_tail.active = 1;
+        orc_dovi_lms_matrix(p->dovi, c->dovi_tail.lms);
+        c->dovi_tail.l2_enabled = orc_dovi_l2_constants(p->dovi, (int)p->hdr_display_max_nits, c->dovi_tail.k);
+    }
     return 0;
 }
 
@@ -1113,13 +1392,14 @@ static void convert_pass(const orc_params *p, const convert_ctx *c, img_t *out)
             int sx = c->rect[0] + i, sy = c->rect[1] + j;
             float yuv[3];
             fetch_pixel(&c->tex, cloc, p->iChromaScaling, p->blend_deint, sx, sy, yuv);
+            if (p->dovi) orc_dovi_reshape(c->dovi_cb, c->dovi_has_mmr, yuv);       /* Shaders.cpp:786-792 */
             const float y = yuv[0], *uv = yuv + 1;
             /* color.rgb = float3(mul(cm_r,color), mul(cm_g,color), mul(cm_b,color)) + cm_c  (:820) */
             float rgb[3];
             rgb[0] = (cm[0] * y + cm[1] * uv[0] + cm[2] * uv[1]) + cm[9];
             rgb[1] = (cm[3] * y + cm[4] * uv[0] + cm[5] * uv[1]) + cm[10];
             rgb[2] = (cm[6] * y + cm[7] * uv[0] + cm[8] * uv[1]) + cm[11];
-            orc_hdr_tail_ex(rgb, trc, prim, p->bConvertToSdr, c->lum_scale, p->hdr_output);
+            hdr_tail_full(rgb, trc, prim, p->bConvertToSdr, c->lum_scale, p->hdr_output, p->dovi ? &c->dovi_tail : NULL);
             float px[4] = {rgb[0], rgb[1], rgb[2], 1.0f};
             store_fmt(c->internal_fmt, px, out->p + ((size_t)j * rw + i) * 4);
         }
@@ -1377,7 +1657,7 @@ int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
     /* m_pPSHDR10ToneMapping: a post-scale step between the resize and the final pass (:3359-3367), created once the
        renderer has HDR10 metadata for an HDR source shown in HDR (:2716-2727) */
     const int trc_src = EXF_TRC(c.exfmt);
-    const int tonemap = p->hdr_output && p->hdr_tonemap_type > 0 && (trc_src == TRC_2084 || trc_src == TRC_HLG);
+    const int tonemap = p->hdr_output && p->hdr_tonemap_type > 0 && (trc_src == TRC_2084 || trc_src == TRC_HLG || p->dovi);   /* SourceIsHDR() */
     const int has_steps = final_pass || tonemap;
     const float quant = (swap_fmt == FMT_RGB10A2) ? 1023.0f : 255.0f;     /* ps_final_pass QUANTIZATION */
 

@@ -55,6 +55,35 @@ enum { ORC_OUT_BGRA8 = 0, ORC_OUT_RGB10A2 = 1 };   /* stands in for m_SwapChainF
 /* flag: use the D3D9 twin's correct Lanczos3 tap layout instead of the D3D11 one (quirk Q1). */
 #define ORC_FLAG_LANCZOS3_FIXED 1u
 
+/* Dolby Vision RPU data of one frame — the fields of MediaSideDataDOVIMetadata (Include/IMediaSideData.h:154-330) this path
+ * reads: Header.{bl_bit_depth,coef_log2_denom}, Mapping.curves[3], ColorMetadata.{ycc_to_rgb_matrix,ycc_to_rgb_offset,
+ * rgb_to_lms_matrix,source_max_pq} and the level-2 extension blocks.  Natural C alignment (the reference struct is packed;
+ * the adapter copies field by field). */
+typedef struct orc_dovi_curve {
+    uint8_t  num_pivots;            /* [2, 9] */
+    uint8_t  mapping_idc[8];        /* 0 polynomial, 1 mmr */
+    uint8_t  poly_order[8];
+    uint8_t  mmr_order[8];
+    uint16_t pivots[9];
+    int64_t  poly_coef[8][3];
+    int64_t  mmr_constant[8];
+    int64_t  mmr_coef[8][3][7];
+} orc_dovi_curve;
+typedef struct orc_dovi_l2 {
+    uint16_t target_max_pq, trim_slope, trim_offset, trim_power, trim_chroma_weight, trim_saturation_gain;
+} orc_dovi_l2;
+typedef struct orc_dovi {
+    uint8_t  bl_bit_depth, coef_log2_denom;
+    uint16_t source_max_pq;
+    /* level-1 block (per-frame brightness) and the level-3 offsets added to it (DX11VideoProcessor.cpp:2347-2381) */
+    uint8_t  l1_present, l3_present;
+    uint16_t l1_min_pq, l1_max_pq, l1_avg_pq, l3_min_pq_offset, l3_max_pq_offset, l3_avg_pq_offset;
+    uint32_t n_l2;                  /* level-2 blocks in Extensions[] order, at most 32 */
+    orc_dovi_l2 l2[32];
+    double   ycc_to_rgb_matrix[9], ycc_to_rgb_offset[3], rgb_to_lms_matrix[9];
+    orc_dovi_curve curves[3];
+} orc_dovi;
+
 typedef struct orc_params {
     int32_t  cformat;          /* ORC_CF_* */
     int32_t  width, height;    /* frame size (biWidth, |biHeight|) */
@@ -80,11 +109,31 @@ typedef struct orc_params {
        the constants of SetHDR10ShaderParams (:907-917) */
     int32_t  hdr_output, hdr_tonemap_type;
     float    hdr_display_max_nits, hdr_min_mastering, hdr_max_mastering, hdr_max_cll, hdr_max_fall;
+    /* m_Dovi.msd when m_Dovi.bValid (DX11VideoProcessor.cpp:2279-2322), else NULL */
+    const orc_dovi *dovi;
 } orc_params;
 
 void orc_params_default(orc_params *p);
 void orc_hdr_tail_ex(float rgb[3], int trc, int prim, int convert_to_sdr, float lum_scale, int hdr_output);
 void orc_hdr10_tonemap(float rgb[3], const orc_params *p);
+/* ---- Dolby Vision (pins) ---- */
+/* the PS_DOVI_CURVE cbuffer SetShaderDoviCurves packs (DX11VideoProcessor.cpp:1055-1141): per component
+ * pivots[7] + coeffs[8][4] + mmr[48][4] floats + {methods, mmr_single, min_order, max_order}; *has_mmr as :2305-2318 */
+typedef struct orc_dovi_cb {
+    float pivots[7]; float coeffs[8][4]; float mmr[48][4];
+    uint32_t methods, mmr_single, min_order, max_order;
+} orc_dovi_cb;
+void orc_dovi_pack_curves(const orc_dovi *d, orc_dovi_cb cb[3], int *has_mmr);
+/* ShaderDoviReshape / ShaderDoviReshapePoly on one (Y,U,V) triple — Shaders.cpp:531-589, 734-762 */
+void orc_dovi_reshape(const orc_dovi_cb cb[3], int has_mmr, float yuv[3]);
+/* dovi_lms2rgb x rgb_to_lms_matrix — Shaders.cpp:826-842 */
+void orc_dovi_lms_matrix(const orc_dovi *d, float m[9]);
+/* level-2 trim selection for a display of `display_nits` (DX11VideoProcessor.cpp:2383-2469) and the cbuffer
+ * SetDolbyVisionDynamicParams uploads (:954-960): k = {ChromaWeight, SaturationGain, TrimSlope, TrimOffset, TrimPower};
+ * returns L2Enabled */
+int  orc_dovi_l2_constants(const orc_dovi *d, int display_nits, float k[5]);
+/* level 1 (+3) -> nits as CopySample stores them (:2347-2372): out = {min, max, avg}; returns L1.present */
+int  orc_dovi_l1_nits(const orc_dovi *d, uint32_t out[3]);
 
 /* ---- parameter maths (pins) ---- */
 /* DXVA2_ExtendedFormat after SpecifyExtendedFormat — Helper.cpp:1169-1211 */

@@ -25,6 +25,68 @@ CF = dict(NV12=1, P010=2, P016=3, P210=6, P216=7, YV12=14, YV16=15, YV24=16,
           RGB24=29, XRGB32=30, ARGB32=31, r210=32, RGB48=33, BGR48=34, BGRA64=35, B64A=36)
 
 
+class OrcDoviCurve(C.Structure):
+    _fields_ = [
+        ("num_pivots", C.c_uint8), ("mapping_idc", C.c_uint8 * 8), ("poly_order", C.c_uint8 * 8),
+        ("mmr_order", C.c_uint8 * 8), ("pivots", C.c_uint16 * 9),
+        ("poly_coef", (C.c_int64 * 3) * 8), ("mmr_constant", C.c_int64 * 8), ("mmr_coef", ((C.c_int64 * 7) * 3) * 8),
+    ]
+
+
+class OrcDoviL2(C.Structure):
+    _fields_ = [(n, C.c_uint16) for n in ("target_max_pq", "trim_slope", "trim_offset", "trim_power",
+                                          "trim_chroma_weight", "trim_saturation_gain")]
+
+
+class OrcDovi(C.Structure):
+    _fields_ = [
+        ("bl_bit_depth", C.c_uint8), ("coef_log2_denom", C.c_uint8), ("source_max_pq", C.c_uint16),
+        ("l1_present", C.c_uint8), ("l3_present", C.c_uint8),
+        ("l1_min_pq", C.c_uint16), ("l1_max_pq", C.c_uint16), ("l1_avg_pq", C.c_uint16),
+        ("l3_min_pq_offset", C.c_uint16), ("l3_max_pq_offset", C.c_uint16), ("l3_avg_pq_offset", C.c_uint16),
+        ("n_l2", C.c_uint32), ("l2", OrcDoviL2 * 32),
+        ("ycc_to_rgb_matrix", C.c_double * 9), ("ycc_to_rgb_offset", C.c_double * 3), ("rgb_to_lms_matrix", C.c_double * 9),
+        ("curves", OrcDoviCurve * 3),
+    ]
+
+
+class OrcDoviCb(C.Structure):
+    _fields_ = [("pivots", C.c_float * 7), ("coeffs", (C.c_float * 4) * 8), ("mmr", (C.c_float * 4) * 48),
+                ("methods", C.c_uint32), ("mmr_single", C.c_uint32), ("min_order", C.c_uint32), ("max_order", C.c_uint32)]
+
+
+def fill_dovi(st, d):
+    """Fill a (Orc|mpcvr) dovi ctypes struct from the plain dict videorenderer_amd.synth.dovi_metadata() returns."""
+    for k in ("bl_bit_depth", "coef_log2_denom", "source_max_pq", "l1_present", "l3_present", "l1_min_pq", "l1_max_pq",
+              "l1_avg_pq", "l3_min_pq_offset", "l3_max_pq_offset", "l3_avg_pq_offset"):
+        setattr(st, k, int(d.get(k, 0)))
+    l2 = d.get("l2", [])
+    st.n_l2 = len(l2)
+    for i, e in enumerate(l2):
+        for k, v in e.items():
+            setattr(st.l2[i], k, int(v))
+    for k in ("ycc_to_rgb_matrix", "ycc_to_rgb_offset", "rgb_to_lms_matrix"):
+        getattr(st, k)[:] = [float(x) for x in d[k]]
+    for c, cv in enumerate(d["curves"]):
+        o = st.curves[c]
+        o.num_pivots = len(cv["pivots"])
+        o.pivots[:len(cv["pivots"])] = [int(x) for x in cv["pivots"]]
+        for i, piece in enumerate(cv["pieces"]):
+            if "poly" in piece:
+                o.mapping_idc[i] = 0
+                o.poly_order[i] = piece["order"]
+                for j, x in enumerate(piece["poly"]):
+                    o.poly_coef[i][j] = int(x)
+            else:
+                o.mapping_idc[i] = 1
+                o.mmr_order[i] = piece["order"]
+                o.mmr_constant[i] = int(piece["constant"])
+                for j, row in enumerate(piece["mmr"]):
+                    for k, x in enumerate(row):
+                        o.mmr_coef[i][j][k] = int(x)
+    return st
+
+
 class OrcParams(C.Structure):
     _fields_ = [
         ("cformat", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
@@ -42,6 +104,7 @@ class OrcParams(C.Structure):
         ("hdr_output", C.c_int32), ("hdr_tonemap_type", C.c_int32),
         ("hdr_display_max_nits", C.c_float), ("hdr_min_mastering", C.c_float), ("hdr_max_mastering", C.c_float),
         ("hdr_max_cll", C.c_float), ("hdr_max_fall", C.c_float),
+        ("dovi", C.POINTER(OrcDovi)),
     ]
 
 
@@ -104,6 +167,13 @@ def lib():
         L.orc_process.argtypes = [C.POINTER(OrcParams), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_convert_only.restype = C.c_int
         L.orc_convert_only.argtypes = [C.POINTER(OrcParams), C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_dovi_pack_curves.argtypes = [C.POINTER(OrcDovi), C.POINTER(OrcDoviCb), C.POINTER(C.c_int)]
+        L.orc_dovi_reshape.argtypes = [C.POINTER(OrcDoviCb), C.c_int, fp]
+        L.orc_dovi_lms_matrix.argtypes = [C.POINTER(OrcDovi), fp]
+        L.orc_dovi_l2_constants.restype = C.c_int
+        L.orc_dovi_l2_constants.argtypes = [C.POINTER(OrcDovi), C.c_int, fp]
+        L.orc_dovi_l1_nits.restype = C.c_int
+        L.orc_dovi_l1_nits.argtypes = [C.POINTER(OrcDovi), C.POINTER(C.c_uint32)]
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
         _lib = L
@@ -134,6 +204,14 @@ def set_params(p, **kw):
     for k, v in kw.items():
         if k in ("src_rect", "video_rect"):
             getattr(p, k)[:] = list(v)
+        elif k == "dovi":
+            if v is None:
+                p.dovi = None
+                p._dovi_keep = None
+            else:
+                st = fill_dovi(OrcDovi(), v) if isinstance(v, dict) else v
+                p._dovi_keep = st               # keep the pointee alive
+                p.dovi = C.pointer(st)
         else:
             setattr(p, k, v)
     return p

@@ -71,6 +71,26 @@ GOLDEN_CASES = {
                                        hdr_output=1, hdr_tonemap=6, hdr_display=600.0, hdr_meta=(0.005, 1000.0, 1000.0, 180.0)),
     "hdrout_tm5_display_brighter_than_content": dict(cformat=2, w=64, h=32, kind="noise", seed=148, dst=(64, 32), exfmt=HDR10, output_format=1,
                                                      hdr_output=1, hdr_tonemap=5, hdr_display=2000.0, hdr_meta=(0.005, 1000.0, 1000.0, 400.0)),
+    # ---- Dolby Vision (N2): reshaping curves, ycc_to_rgb matrix, PQ -> LMS -> PQ, level-1/2/3 metadata ----
+    "dovi_poly_sdr": dict(cformat=20, w=96, h=54, kind="hdr", seed=150, dst=(96, 54), exfmt=ext(MPEG2, TV), dovi=dict(kind="poly")),
+    "dovi_poly_sdr_l2_between_2x": dict(cformat=2, w=64, h=32, kind="hdr", seed=151, dst=(128, 64), iUpscaling=4, exfmt=ext(MPEG2, TV),
+                                        dovi=dict(kind="poly", l2=(100, 600, 1000)), hdr_display=400.0),
+    "dovi_mmr_sdr_l2_brighter": dict(cformat=20, w=64, h=40, kind="structure", seed=152, dst=(96, 60), iUpscaling=2,
+                                     dovi=dict(kind="mmr", l2=(100,)), hdr_display=1000.0),
+    "dovi_mixed_noise_catmull_chroma": dict(cformat=2, w=64, h=32, kind="noise", seed=153, dst=(64, 32), iChromaScaling=2,
+                                            dovi=dict(kind="mixed", l2=(600, 2000)), hdr_display=300.0),
+    "dovi_identity_hlg_tagged": dict(cformat=2, w=64, h=32, kind="hdr", seed=154, dst=(64, 32), exfmt=HLG, dovi=dict(kind="identity")),
+    "dovi_procamp_down": dict(cformat=20, w=128, h=64, kind="structure", seed=155, dst=(48, 24), iDownscaling=2,
+                              procamp=(12.0, 1.1, 30.0, 1.4), dovi=dict(kind="poly")),
+    "dovi_hdrout_passthrough": dict(cformat=2, w=64, h=32, kind="hdr", seed=156, dst=(128, 64), iUpscaling=4, output_format=1, hdr_output=1,
+                                    dovi=dict(kind="mmr")),
+    "dovi_hdrout_bt2020_gamma_tag": dict(cformat=20, w=64, h=32, kind="hdr", seed=157, dst=(64, 32), output_format=1, hdr_output=1,
+                                         exfmt=ext(MPEG2, TV, M2020, P2020, T709), dovi=dict(kind="poly")),
+    "dovi_hdrout_tm5_l1_l3_l2": dict(cformat=2, w=64, h=32, kind="hdr", seed=158, dst=(96, 48), iUpscaling=2, output_format=1,
+                                     hdr_output=1, hdr_tonemap=5, hdr_display=1000.0, dovi=dict(kind="mmr", l1=True, l3=True, l2=(600, 2000))),
+    "dovi_hdrout_tm3_hdr10_meta": dict(cformat=20, w=64, h=32, kind="noise", seed=159, dst=(64, 32), output_format=1,
+                                       hdr_output=1, hdr_tonemap=3, hdr_display=600.0, hdr_meta=(0.005, 1000.0, 1000.0, 400.0),
+                                       dovi=dict(kind="poly", l2=(100, 1000))),
     # ---- geometry ----
     "crop_offset_letterbox": dict(cformat=2, w=96, h=64, kind="structure", seed=21, src_rect=(16, 8, 80, 56), dst=(128, 96),
                                   window=(200, 150), offset=(36, 27), iUpscaling=4),
@@ -200,6 +220,9 @@ def oracle_params(oracle, c):
     # m_bDeintBlend && m_SampleFormat != PROGRESSIVE (DX11VideoProcessor.cpp:3075); the 4:2:0 check is the oracle's
     oracle.set_params(p, blend_deint=int(bool(c.get("bDeintBlend", 0)) and c.get("sample_format", 0) != 0))
     oracle.set_params(p, rotation=c.get("rotation", 0), flip=c.get("flip", 0))
+    oracle.set_params(p, hdr_display_max_nits=c.get("hdr_display", 1000.0))     # m_iHdrDisplayMaxNits (level-2 selection)
+    if "dovi" in c:
+        oracle.set_params(p, dovi=synth.dovi_metadata(**c["dovi"]))
     if c.get("hdr_output"):
         m = c.get("hdr_meta", (0.0, 0.0, 0.0, 0.0))
         oracle.set_params(p, hdr_output=1, hdr_tonemap_type=c.get("hdr_tonemap", 0), hdr_display_max_nits=c.get("hdr_display", 1000.0),

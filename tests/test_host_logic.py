@@ -222,3 +222,85 @@ def test_final_pass_integer_form_is_exhaustively_exact(mpcvr):
     # not representable combinations fall back to the float epilogue
     assert api.plan_final_pass_multiplier(255, 255) == 0
     assert api.plan_final_pass_multiplier(1023, 1023) == 0
+
+
+# ---------------------------------------------------------------- Dolby Vision host maths
+def _orc_dovi_cb(oracle, md):
+    od = oracle.fill_dovi(oracle.OrcDovi(), md)
+    cb = (oracle.OrcDoviCb * 3)()
+    has_mmr = C.c_int(0)
+    oracle.lib().orc_dovi_pack_curves(C.byref(od), cb, C.byref(has_mmr))
+    flat = np.zeros((3, 235), np.float32)
+    for c in range(3):
+        flat[c, :7] = np.array(cb[c].pivots)
+        flat[c, 7:39] = np.array(cb[c].coeffs).reshape(-1)
+        flat[c, 39:231] = np.array(cb[c].mmr).reshape(-1)
+        flat[c, 231:] = [cb[c].methods, cb[c].mmr_single, cb[c].min_order, cb[c].max_order]
+    return od, flat, has_mmr.value
+
+
+@pytest.mark.parametrize("kind", ["poly", "mmr", "mixed", "identity"])
+def test_dovi_constants_match_oracle_bit_exact(mpcvr, oracle, kind):
+    """SetShaderDoviCurves packing, the LMS matrix, the level-2 selection for several display peaks and the level-1 nits:
+    product host code (vp_dovi.cpp, through mpcvr_plan_dovi) vs the oracle's restatement, as fp32 bit patterns."""
+    from videorenderer_amd import api, synth
+    md = synth.dovi_metadata(kind, l1=True, l3=(kind == "mmr"), l2=(100, 600, 1000))
+    od, want_cb, want_mmr = _orc_dovi_cb(oracle, md)
+    L = oracle.lib()
+    lms = (C.c_float * 9)()
+    L.orc_dovi_lms_matrix(C.byref(od), lms)
+    l1 = (C.c_uint32 * 3)()
+    l1on = L.orc_dovi_l1_nits(C.byref(od), l1)
+    for nits in (50, 100, 350, 600, 800, 1000, 2500, 4000, 9000):
+        got = api.plan_dovi(md, nits)
+        k = (C.c_float * 5)()
+        on = L.orc_dovi_l2_constants(C.byref(od), nits, k)
+        assert np.array_equal(got["cb"].view(np.uint32), want_cb.view(np.uint32))
+        assert got["has_mmr"] == want_mmr == (kind in ("mmr", "mixed"))
+        assert np.array_equal(got["lms"].view(np.uint32), np.array(lms, np.float32).view(np.uint32))
+        assert np.array_equal(got["l2k"].view(np.uint32), np.array(k, np.float32).view(np.uint32)), nits
+        assert got["l2_enabled"] == on == 1
+        assert list(got["l1_nits"]) == list(l1) and got["l1_present"] == l1on == 1
+
+
+def test_dovi_level2_selection_rules(mpcvr):
+    """The three scenarios of CopySample's level-2 block (DX11VideoProcessor.cpp:2383-2469) on hand-made targets."""
+    from videorenderer_amd import api, synth
+    md = synth.dovi_metadata("identity", l2=(100, 1000))
+    lo, hi = md["l2"]
+
+    def raw(e):      # cbuffer layout: chroma_weight-0.5, saturation_gain-0.5, slope+0.5, offset-0.5, power+0.5 (:956-958)
+        return np.array([e["trim_chroma_weight"] / 4096 - 0.5, e["trim_saturation_gain"] / 4096 - 0.5,
+                         e["trim_slope"] / 4096 + 0.5, e["trim_offset"] / 4096 - 0.5, e["trim_power"] / 4096 + 0.5], np.float32)
+    # dimmer than every target: the lowest target as is
+    assert np.allclose(api.plan_dovi(md, 50)["l2k"], raw(lo), atol=1e-7)
+    # exactly on a target
+    assert np.allclose(api.plan_dovi(md, 100)["l2k"], raw(lo), atol=2e-4)
+    # between: a PQ-domain blend, strictly inside the two
+    mid = api.plan_dovi(md, 400)["l2k"]
+    assert np.all((mid >= np.minimum(raw(lo), raw(hi)) - 1e-7) & (mid <= np.maximum(raw(lo), raw(hi)) + 1e-7))
+    assert not np.allclose(mid, raw(lo)) and not np.allclose(mid, raw(hi))
+    # brighter than the mastering display: neutral trims (2048/4096 = 0.5 -> 0, 0, 1, 0, 1)
+    assert np.allclose(api.plan_dovi(md, 9000)["l2k"], [0, 0, 1, 0, 1], atol=1e-7)
+    # no level-2 block: L2Enabled = 0 and the cbuffer of a zeroed L2
+    none = api.plan_dovi(synth.dovi_metadata("identity"), 400)
+    assert none["l2_enabled"] == 0 and np.allclose(none["l2k"], [-0.5, -0.5, 0.5, -0.5, 0.5])
+    assert none["l1_present"] == 0
+
+
+def test_dovi_metadata_validation(mpcvr):
+    """CheckDoviMetadata's curve rules (VideoProcessor.cpp:283-292): num_pivots in [2, 9], mapping_idc <= 1."""
+    from videorenderer_amd import api, synth
+    good = api.DoviMetadata.from_dict(synth.dovi_metadata("mixed"))
+    assert api.load_library().mpcvr_plan_dovi(C.byref(good), 1000, None, None, None, None, None, None, None) == 0
+    for mutate in (lambda m: setattr(m.curves[1], "num_pivots", 1), lambda m: setattr(m.curves[2], "num_pivots", 10),
+                   lambda m: m.curves[0].mapping_idc.__setitem__(2, 2), lambda m: setattr(m, "n_l2", 33)):
+        bad = api.DoviMetadata.from_dict(synth.dovi_metadata("mixed"))
+        mutate(bad)
+        hr = api.load_library().mpcvr_plan_dovi(C.byref(bad), 1000, None, None, None, None, None, None, None)
+        assert hr & 0xffffffff == 0x80070057        # E_INVALIDARG
+    assert api.load_library().mpcvr_plan_dovi(None, 1000, None, None, None, None, None, None, None) & 0xffffffff == 0x80004003
+    # the ctypes mirrors used by the tests have the C layout of include/mpcvr.h / oracle/mpcvr_oracle.h
+    from oracle import oracle as O
+    assert C.sizeof(api.DoviMetadata) == C.sizeof(O.OrcDovi)
+    assert C.sizeof(api.DoviCurve) == 1 + 24 + 1 + 18 + 4 + 8 * (24 + 8 + 168)

@@ -477,3 +477,108 @@ def test_rotation_and_flip_are_pure_permutations_without_scaling(oracle):
     up = r(dst=(128, 80), iUpscaling=2)
     assert np.array_equal(r(dst=(128, 80), rotation=180, iUpscaling=2), np.rot90(up, 2))
     assert not np.array_equal(r(dst=(80, 128), rotation=90, iUpscaling=2), np.rot90(up, -1))
+
+
+# ---------------------------------------------------------------- Dolby Vision
+def _dovi_cb(oracle, md):
+    od = oracle.fill_dovi(oracle.OrcDovi(), md)
+    cb = (oracle.OrcDoviCb * 3)()
+    has_mmr = C.c_int(0)
+    oracle.lib().orc_dovi_pack_curves(C.byref(od), cb, C.byref(has_mmr))
+    return od, cb, has_mmr.value
+
+
+def _dovi_reference_float64(md, yuv):
+    """Independent float64 evaluation of the Dolby Vision reshaping as the RPU defines it (piecewise polynomial /
+    multivariate multiple regression), written from the metadata dict, not from the packed cbuffer."""
+    den = float(1 << md["coef_log2_denom"])
+    maxv = float((1 << md["bl_bit_depth"]) - 1)
+    sig = np.clip(np.asarray(yuv, np.float64), 0, 1)
+    out = np.zeros(3)
+    for c, cv in enumerate(md["curves"]):
+        piv = [p / maxv for p in cv["pivots"]]
+        s = sig[c]
+        k = 0
+        while k + 1 < len(cv["pieces"]) and s >= np.float32(np.float32(1.0 / maxv) * np.float32(cv["pivots"][k + 1])):
+            k += 1
+        piece = cv["pieces"][k]
+        if "poly" in piece:
+            co = [x / den for x in piece["poly"]] + [0, 0]
+            order = piece["order"]
+            v = co[0] + (co[1] * s if order >= 1 else 0) + (co[2] * s * s if order >= 2 else 0)
+        else:
+            v = piece["constant"] / den
+            x = np.array([sig[0], sig[1], sig[2], sig[0] * sig[1], sig[0] * sig[2], sig[1] * sig[2], sig[0] * sig[1] * sig[2]])
+            for o, row in enumerate(piece["mmr"]):
+                v += float(np.dot(np.array(row) / den, x ** (o + 1)))
+        out[c] = min(max(v, 0.0), 1.0)
+        del piv
+    return out
+
+
+@pytest.mark.parametrize("kind", ["poly", "mmr", "mixed"])
+def test_dovi_reshape_against_float64_definition(oracle, kind):
+    """ShaderDoviReshape[Poly] as restated (packed cbuffer, float4 tricks, early returns by order) must agree with the
+    plain definition of the curves evaluated in float64, to fp32 rounding."""
+    from videorenderer_amd import synth
+    md = synth.dovi_metadata(kind)
+    od, cb, has_mmr = _dovi_cb(oracle, md)
+    rng = np.random.default_rng(7)
+    pts = np.concatenate([rng.random((400, 3)), [[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5]],
+                          [[p / 1023.0, 0.3, 0.7] for p in (64, 160, 300, 460, 620, 780, 900)]]).astype(np.float32)
+    worst = 0.0
+    for p in pts:
+        v = (C.c_float * 3)(*p)
+        oracle.lib().orc_dovi_reshape(cb, has_mmr, v)
+        want = _dovi_reference_float64(md, p)
+        worst = max(worst, float(np.abs(np.array(v) - want).max()))
+    assert worst < 2e-6, worst
+
+
+def test_dovi_degenerates_to_hdr10(oracle):
+    """A Dolby Vision stream whose curves are the identity, whose ycc_to_rgb is the BT.2020 limited-range matrix and
+    whose rgb_to_lms undoes dovi_lms2rgb must give the HDR10 result of the same samples (the extra PQ -> linear -> PQ
+    round trip costs at most 1 LSB): pins the order and direction of every Dolby Vision step against the HDR10 path."""
+    from videorenderer_amd import synth
+    w, h = 64, 32
+    exf = (5 << 8) | (2 << 12) | (4 << 15) | (9 << 22) | (15 << 27)
+    fr, pitch = synth.make_frame(20, w, h, "hdr", seed=3)
+    base = oracle.default_params(cformat=20, width=w, height=h, exfmt=exf, window_w=w, window_h=h, video_rect=(0, 0, w, h))
+    ref = oracle.process(base, fr, pitch, dst=np.zeros((h, w, 4), np.uint8))
+    cm = oracle.color_matrix(base).astype(np.float64)
+    m = cm[:9].reshape(3, 3)
+    # c = -m . offset  =>  offset = -m^-1 . c
+    off = -np.linalg.solve(m, cm[9:])
+    lms2rgb = np.array([[3.06441879, -2.16597676, 0.10155818], [-0.65612108, 1.78554118, -0.12943749],
+                        [0.01736321, -0.04725154, 1.03004253]])
+    md = synth.dovi_metadata("identity")
+    md.update(ycc_to_rgb_matrix=m.reshape(-1).tolist(), ycc_to_rgb_offset=off.tolist(),
+              rgb_to_lms_matrix=np.linalg.inv(lms2rgb).reshape(-1).tolist())
+    dv = oracle.default_params(cformat=20, width=w, height=h, exfmt=0, window_w=w, window_h=h, video_rect=(0, 0, w, h), dovi=md)
+    got = oracle.process(dv, fr, pitch, dst=np.zeros((h, w, 4), np.uint8))
+    d = np.abs(got.astype(int) - ref.astype(int))
+    # super-white samples (a channel > 1 before the tail) are clamped per channel by the HDR10 shader but linearised
+    # unclamped by the Dolby Vision one, where fp32 error of the (mathematically identity) matrix times their huge
+    # linear value leaks into the other channels: compare where the converted colour is inside [0, 1]
+    conv = oracle.convert_only(oracle.default_params(cformat=20, width=w, height=h, exfmt=exf & ~(0x1f << 27) & ~(0x1f << 22),
+                                                     window_w=w, window_h=h, video_rect=(0, 0, w, h)), fr, pitch)
+    conv = np.asarray(conv[0] if isinstance(conv, tuple) else conv)[..., :3]
+    inside = np.all(conv < 1.0, axis=-1)       # (stored UNORM: 1.0 means clamped)
+    assert inside.mean() > 0.5
+    assert d[inside].max() <= 1 and (d[inside] == 0).mean() > 0.97, (d[inside].max(), (d[inside] == 0).mean())
+
+
+def test_dovi_l1_nits_and_trims_known_answers(oracle):
+    """PqToLinearNits on the 12-bit codes (ST 2084: code 2081/4095 ~ 100 nits, 3079/4095 ~ 1000 nits) and the
+    level-3 offsets (-2048 bias)."""
+    from videorenderer_amd import synth
+    md = synth.dovi_metadata("identity")
+    md.update(l1_present=1, l1_min_pq=0, l1_max_pq=3079, l1_avg_pq=2081)
+    od = oracle.fill_dovi(oracle.OrcDovi(), md)
+    out = (C.c_uint32 * 3)()
+    assert oracle.lib().orc_dovi_l1_nits(C.byref(od), out) == 1
+    assert out[0] == 0 and 995 <= out[1] <= 1005 and 98 <= out[2] <= 102
+    md.update(l3_present=1, l3_min_pq_offset=2048, l3_max_pq_offset=2048 + (3696 - 3079), l3_avg_pq_offset=2048)
+    od = oracle.fill_dovi(oracle.OrcDovi(), md)
+    assert oracle.lib().orc_dovi_l1_nits(C.byref(od), out) == 1
+    assert 3950 <= out[1] <= 4050 and 98 <= out[2] <= 102        # 3696/4095 ~ 4000 nits

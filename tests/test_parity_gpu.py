@@ -26,7 +26,7 @@ def torch_cuda():
 def has_tail(c):
     trc = (c.get("exfmt", 0) >> 27) & 0x1f
     prim = (c.get("exfmt", 0) >> 22) & 0x1f
-    return (trc in (15, 16) and c.get("bConvertToSdr", 1)) or prim == 9
+    return (trc in (15, 16) and c.get("bConvertToSdr", 1)) or prim == 9 or "dovi" in c
 
 
 def make_vp(mpcvr, c, extra_flags=0):
@@ -51,6 +51,11 @@ def make_vp(mpcvr, c, extra_flags=0):
         vp.SetHdrOutput(True, c.get("hdr_tonemap", 0), c.get("hdr_display", 1000.0))
         if "hdr_meta" in c:
             vp.SetHdrMetadata(*c["hdr_meta"])
+    elif "hdr_display" in c:
+        vp.SetHdrOutput(False, 0, c["hdr_display"])
+    if "dovi" in c:
+        from videorenderer_amd import synth
+        vp.SetDoviMetadata(synth.dovi_metadata(**c["dovi"]))
     if "rotation" in c:
         vp.SetRotation(c["rotation"])
     if "flip" in c:
@@ -251,6 +256,55 @@ def test_configure_rebuilds_only_what_changed(mpcvr, oracle, torch_cuda):
     c2 = dict(c, iUpscaling=1, iSDRDisplayNits=200)
     p = oracle_params(oracle, c2)
     compare(dst.cpu().numpy(), oracle.process(p, frame, pitch), "after Configure", min_same=0.99)
+    vp.close()
+
+
+def test_dovi_metadata_lifecycle(mpcvr, oracle, torch_cuda):
+    """RPUs change from frame to frame: the curves follow the latest one, level-2 trims persist while later RPUs carry none
+    (m_DoviExtensionMetadata.L2 stays present until Flush, DX11VideoProcessor.cpp:2383-2469, :4082), a display-peak change
+    re-selects the trims, and SetDoviMetadata(None) returns to the tagged colourimetry."""
+    torch = torch_cuda
+    from videorenderer_amd import synth
+    c = dict(GOLDEN_CASES["dovi_poly_sdr_l2_between_2x"])
+    vp, (ww, wh) = make_vp(mpcvr, c)
+    frame, pitch = case_frame(c)
+    vp.CopySample(torch.from_numpy(frame).cuda(), pitch)
+
+    def product():
+        dst = torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda")
+        vp.Process(dst, ww * 4)
+        vp.Synchronize()
+        return dst.cpu().numpy()
+
+    def expect(case):
+        p = oracle_params(oracle, case)
+        return oracle.process(p, frame, pitch, dst=np.full((wh, ww, 4), BG, np.uint8))
+
+    assert vp.GetVPInfo().startswith("passes:")                       # never the fused kernel
+    compare(product(), expect(c), "first RPU", min_same=0.99)
+    l2 = c["dovi"]["l2"]
+    vp.SetDoviMetadata(synth.dovi_metadata("mmr"))                    # no level-2 block: the previous trims stay
+    compare(product(), expect(dict(c, dovi=dict(kind="mmr", l2=l2))), "sticky L2", min_same=0.99)
+    vp.SetHdrOutput(False, 0, 900.0)                                  # new display peak, but this RPU has no L2 list to re-select from
+    compare(product(), expect(dict(c, dovi=dict(kind="mmr", l2=l2), hdr_display=400.0)), "sticky L2 after display change", min_same=0.99)
+    vp.Flush()
+    vp.CopySample(torch.from_numpy(frame).cuda(), pitch)
+    vp.SetDoviMetadata(synth.dovi_metadata("mmr"))
+    compare(product(), expect(dict(c, dovi=dict(kind="mmr"))), "after Flush", min_same=0.99)
+    vp.SetDoviMetadata(synth.dovi_metadata("mixed", l2=(100, 600, 1000)))
+    compare(product(), expect(dict(c, dovi=dict(kind="mixed", l2=(100, 600, 1000)), hdr_display=900.0)), "third RPU", min_same=0.99)
+    vp.SetDoviMetadata(None)
+    plain = {k: v for k, v in c.items() if k != "dovi"}
+    compare(product(), expect(plain), "Dolby Vision off", min_same=0.99)
+    assert vp.GetVPInfo() == "fused_up2x"                             # and the fused kernel is eligible again
+    vp.close()
+    # rejected metadata leaves the state alone and reports E_INVALIDARG
+    vp, _ = make_vp(mpcvr, c)
+    bad = synth.dovi_metadata("poly")
+    bad["curves"][0] = dict(bad["curves"][0], num_pivots=12)
+    with pytest.raises(mpcvr.api.MpcvrError) as e:
+        vp.SetDoviMetadata(bad)
+    assert e.value.hr & 0xffffffff == 0x80070057
     vp.close()
 
 

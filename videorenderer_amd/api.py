@@ -77,6 +77,67 @@ class Rect(C.Structure):
     _fields_ = [("left", C.c_int32), ("top", C.c_int32), ("right", C.c_int32), ("bottom", C.c_int32)]
 
 
+class DoviCurve(C.Structure):          # mpcvr_dovi_curve
+    _fields_ = [
+        ("num_pivots", C.c_uint8), ("mapping_idc", C.c_uint8 * 8), ("poly_order", C.c_uint8 * 8),
+        ("mmr_order", C.c_uint8 * 8), ("pivots", C.c_uint16 * 9),
+        ("poly_coef", (C.c_int64 * 3) * 8), ("mmr_constant", C.c_int64 * 8), ("mmr_coef", ((C.c_int64 * 7) * 3) * 8),
+    ]
+
+
+class DoviL2(C.Structure):             # mpcvr_dovi_l2
+    _fields_ = [(n, C.c_uint16) for n in ("target_max_pq", "trim_slope", "trim_offset", "trim_power",
+                                          "trim_chroma_weight", "trim_saturation_gain")]
+
+
+class DoviMetadata(C.Structure):       # mpcvr_dovi_metadata
+    _fields_ = [
+        ("bl_bit_depth", C.c_uint8), ("coef_log2_denom", C.c_uint8), ("source_max_pq", C.c_uint16),
+        ("l1_present", C.c_uint8), ("l3_present", C.c_uint8),
+        ("l1_min_pq", C.c_uint16), ("l1_max_pq", C.c_uint16), ("l1_avg_pq", C.c_uint16),
+        ("l3_min_pq_offset", C.c_uint16), ("l3_max_pq_offset", C.c_uint16), ("l3_avg_pq_offset", C.c_uint16),
+        ("n_l2", C.c_uint32), ("l2", DoviL2 * 32),
+        ("ycc_to_rgb_matrix", C.c_double * 9), ("ycc_to_rgb_offset", C.c_double * 3), ("rgb_to_lms_matrix", C.c_double * 9),
+        ("curves", DoviCurve * 3),
+    ]
+
+    @classmethod
+    def from_dict(cls, d):
+        """Build from the plain-dict form synth.dovi_metadata() produces:
+        {bl_bit_depth, coef_log2_denom, source_max_pq, [l1_*, l3_*], l2: [{target_max_pq, trim_*}...],
+         ycc_to_rgb_matrix[9], ycc_to_rgb_offset[3], rgb_to_lms_matrix[9],
+         curves: 3 x {pivots: [...], pieces: [{order, poly: [c0,c1,c2]} | {order, constant, mmr: [[7]...]}]}}"""
+        st = cls()
+        for k in ("bl_bit_depth", "coef_log2_denom", "source_max_pq", "l1_present", "l3_present", "l1_min_pq",
+                  "l1_max_pq", "l1_avg_pq", "l3_min_pq_offset", "l3_max_pq_offset", "l3_avg_pq_offset"):
+            setattr(st, k, int(d.get(k, 0)))
+        l2 = d.get("l2", [])
+        st.n_l2 = len(l2)
+        for i, e in enumerate(l2[:32]):
+            for k, v in e.items():
+                setattr(st.l2[i], k, int(v))
+        for k in ("ycc_to_rgb_matrix", "ycc_to_rgb_offset", "rgb_to_lms_matrix"):
+            getattr(st, k)[:] = [float(x) for x in d[k]]
+        for c, cv in enumerate(d["curves"]):
+            o = st.curves[c]
+            o.num_pivots = cv.get("num_pivots", len(cv["pivots"]))
+            o.pivots[:len(cv["pivots"])] = [int(x) for x in cv["pivots"]]
+            for i, piece in enumerate(cv["pieces"]):
+                if "poly" in piece:
+                    o.mapping_idc[i] = piece.get("idc", 0)
+                    o.poly_order[i] = piece["order"]
+                    for j, x in enumerate(piece["poly"]):
+                        o.poly_coef[i][j] = int(x)
+                else:
+                    o.mapping_idc[i] = piece.get("idc", 1)
+                    o.mmr_order[i] = piece["order"]
+                    o.mmr_constant[i] = int(piece["constant"])
+                    for j, row in enumerate(piece["mmr"]):
+                        for k, x in enumerate(row):
+                            o.mmr_coef[i][j][k] = int(x)
+        return st
+
+
 class MpcvrError(RuntimeError):
     def __init__(self, hr, msg):
         super().__init__(f"HRESULT 0x{hr & 0xffffffff:08X}: {msg}")
@@ -86,6 +147,7 @@ class MpcvrError(RuntimeError):
 EXPORTS = [
     "mpcvr_settings_default", "mpcvr_create", "mpcvr_destroy", "mpcvr_set_stream", "mpcvr_synchronize",
     "mpcvr_set_input", "mpcvr_set_video_rect", "mpcvr_set_window_rect", "mpcvr_set_rotation", "mpcvr_set_flip", "mpcvr_set_sample_format", "mpcvr_set_hdr_output", "mpcvr_set_hdr_metadata",
+    "mpcvr_set_dovi_metadata", "mpcvr_plan_dovi",
     "mpcvr_configure", "mpcvr_set_procamp", "mpcvr_copy_sample", "mpcvr_process", "mpcvr_render",
     "mpcvr_get_backbuffer", "mpcvr_get_current_image", "mpcvr_flush", "mpcvr_reset", "mpcvr_process_batch",
     "mpcvr_get_param_blob", "mpcvr_set_param_blob", "mpcvr_get_color_matrix", "mpcvr_get_extfmt",
@@ -123,6 +185,8 @@ def load_library():
         "mpcvr_set_sample_format": [vp, i32],
         "mpcvr_set_hdr_output": [vp, i32, i32, f],
         "mpcvr_set_hdr_metadata": [vp, f, f, f, f],
+        "mpcvr_set_dovi_metadata": [vp, P(DoviMetadata)],
+        "mpcvr_plan_dovi": [P(DoviMetadata), i32, P(f), P(i32), P(f), P(f), P(i32), P(u32), P(i32)],
         "mpcvr_configure": [vp, P(Settings)],
         "mpcvr_set_procamp": [vp, u32, f, f, f, f],
         "mpcvr_copy_sample": [vp, vp, i32, i32],
@@ -205,6 +269,21 @@ def plan_final_pass_multiplier(quant, maxv):
     m = C.c_uint32(0)
     load_library().mpcvr_plan_final_pass_multiplier(quant, maxv, C.byref(m))
     return m.value
+
+
+def plan_dovi(md, display_nits=1000):
+    """Host maths of the Dolby Vision path (SetShaderDoviCurves, LMS matrix, level-2 selection, level-1 nits)."""
+    st = md if isinstance(md, DoviMetadata) else DoviMetadata.from_dict(md)
+    cb = (C.c_float * 705)(); lms = (C.c_float * 9)(); l2k = (C.c_float * 5)(); l1 = (C.c_uint32 * 3)()
+    has_mmr, l2on, l1on = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    hr = load_library().mpcvr_plan_dovi(C.byref(st), int(display_nits), cb, C.byref(has_mmr), lms, l2k, C.byref(l2on),
+                                        l1, C.byref(l1on))
+    if hr:
+        raise MpcvrError(hr, "mpcvr_plan_dovi")
+    import numpy as np
+    return dict(cb=np.array(cb, dtype=np.float32).reshape(3, 235), has_mmr=has_mmr.value,
+                lms=np.array(lms, dtype=np.float32), l2k=np.array(l2k, dtype=np.float32), l2_enabled=l2on.value,
+                l1_nits=np.array(l1, dtype=np.uint32), l1_present=l1on.value)
 
 
 def plan_upscale_weights(method, t):
@@ -316,6 +395,13 @@ class VideoProcessor:
     def SetHdrMetadata(self, min_mastering, max_mastering, max_cll, max_fall):
         """The values Render() hands to SetHDR10ShaderParams (DX11VideoProcessor.cpp:907-917)."""
         return self._check(self._L.mpcvr_set_hdr_metadata(self._ctx, float(min_mastering), float(max_mastering), float(max_cll), float(max_fall)))
+
+    def SetDoviMetadata(self, md):
+        """The Dolby Vision RPU of the next sample(s) (CopySample, DX11VideoProcessor.cpp:2270-2520); None ends DoVi mode."""
+        if md is None:
+            return self._check(self._L.mpcvr_set_dovi_metadata(self._ctx, None))
+        st = md if isinstance(md, DoviMetadata) else DoviMetadata.from_dict(md)
+        return self._check(self._L.mpcvr_set_dovi_metadata(self._ctx, C.byref(st)))
 
     def SetSampleFormat(self, frame_format):
         """m_SampleFormat (DX11VideoProcessor.cpp:2209-2219): 0 progressive, 1 interlaced TFF, 2 interlaced BFF."""

@@ -20,6 +20,7 @@ ARCH = "gfx950"
 # pass-per-kernel path rounds exactly like the CPU oracle; the fused path may contract.
 SOURCES = [
     ("vp_plan.cpp", ["-ffp-contract=off"]),
+    ("vp_dovi.cpp", ["-ffp-contract=off", "-std=c++20"]),
     ("hip_video_processor.cpp", []),
     ("mpcvr_capi.cpp", []),
     ("vp_kernels.hip", ["-ffp-contract=off", "-DMPCVR_EXACT_FP"]),

@@ -62,6 +62,11 @@ CHipVideoProcessor::~CHipVideoProcessor()
         if (u.consumed) (void)hipEventDestroy(u.consumed);
     }
     if (m_copyStream) (void)hipStreamDestroy(m_copyStream);
+    m_doviDev.Release();
+    for (DoviSlot &d : m_doviSlots) {
+        if (d.pinned) (void)hipHostFree(d.pinned);
+        if (d.copied) (void)hipEventDestroy(d.copied);
+    }
     for (FrameSlot &fs : m_slots) {
         fs.dev.Release();
         if (fs.pinned) (void)hipHostFree(fs.pinned);
@@ -196,9 +201,10 @@ HRESULT CHipVideoProcessor::InitMediaType(int cformat, int width, int height, in
 void CHipVideoProcessor::SetShaderConvertColorParams()
 {
     if (!m_srcParams || m_blobOverride) return;
-    ComputeColorMatrix(m_srcExFmt, *m_srcParams, m_procAmp, m_cm);
+    if (m_doviValid) DoviColorMatrix(m_doviMd, *m_srcParams, m_procAmp, m_cm);     // :817-834
+    else ComputeColorMatrix(m_srcExFmt, *m_srcParams, m_procAmp, m_cm);
     ComputeGamut2020to709(m_gamut);
-    SelectTail(m_srcExFmt, m_cfg.bConvertToSdr != 0, &m_tail, &m_gamma, m_hdrOutput);
+    SelectTail(m_srcExFmt, m_cfg.bConvertToSdr != 0, &m_tail, &m_gamma, m_hdrOutput, m_doviValid);
 }
 
 void CHipVideoProcessor::SetShaderLuminanceParams()
@@ -240,6 +246,10 @@ HRESULT CHipVideoProcessor::SetHdrOutput(bool enable, int toneMapType, float dis
     m_blobOverride = false;
     SetShaderConvertColorParams();
     m_planDirty = true;
+    if (m_doviValid) {          // the level-2 selection depends on the display peak (:2384)
+        const mpcvr_dovi_metadata md = m_doviMd;
+        return SetDoviMetadata(&md);
+    }
     return MPCVR_S_OK;
 }
 
@@ -257,6 +267,13 @@ HRESULT CHipVideoProcessor::SetHdrMetadata(float minMastering, float maxMasterin
 void CHipVideoProcessor::UpdateHdrToneMapParams()
 {
     HdrToneMapParams k{m_hdrMeta[0], m_hdrMeta[1], m_hdrMeta[2], m_hdrMeta[3], m_hdrDisplayMaxNits, m_hdrToneMapType};
+    if (m_doviValid && m_doviL1Present) {       // Render :2716-2720: L1 min, max, max, avg; BT.2390 -> ST 2094-10
+        k.min_mastering = (float)m_doviL1[0]; k.max_mastering = (float)m_doviL1[1];
+        k.max_cll = (float)m_doviL1[1]; k.max_fall = (float)m_doviL1[2];
+        if (k.selection == 5) k.selection = 6;
+    }
+    k.l2_enabled = (m_doviValid && m_doviL2Present) ? 1 : 0;      // m_pDoViDynamicConstants at b1 (:3362-3364)
+    std::memcpy(k.l2k, m_doviL2Raw, sizeof(k.l2k));
     if (k.min_mastering <= 0.f) k.min_mastering = 0.f;
     if (k.max_mastering <= 10.f) k.max_mastering = 1000.f;
     if (k.max_cll <= 10.f) k.max_cll = k.max_mastering;
@@ -270,7 +287,56 @@ void CHipVideoProcessor::UpdateHdrToneMapParams()
 bool CHipVideoProcessor::ToneMapActive() const
 {
     const unsigned tf = m_srcExFmt.VideoTransferFunction();
+    if (m_doviValid) return m_hdrOutput && m_hdrToneMapType > 0 && (m_hdrMetaValid || m_doviL1Present);     // SourceIsHDR()
     return m_hdrOutput && m_hdrToneMapType > 0 && m_hdrMetaValid && (tf == 15 || tf == 16);
+}
+
+// CopySample, IID_MediaSideDataDOVIMetadataV2 branch — DX11VideoProcessor.cpp:2270-2520
+HRESULT CHipVideoProcessor::SetDoviMetadata(const mpcvr_dovi_metadata *md)
+{
+    if (!m_bInit) return Fail(MPCVR_E_NOT_VALID_STATE, "not initialised");
+    if (!md) {
+        if (m_doviValid) { m_doviValid = false; m_planDirty = true; }
+        m_doviL1Present = m_doviL2Present = false;
+        m_blobOverride = false;
+        SetShaderConvertColorParams();
+        UpdateHdrToneMapParams();
+        return MPCVR_S_OK;
+    }
+    if (!CheckDoviCurves(*md)) return Fail(MPCVR_E_INVALIDARG, "Dolby Vision curves: num_pivots outside [2,9], mapping_idc > 1 or more than 32 level-2 blocks");
+    const bool wasValid = m_doviValid, hadToneMap = m_srcParams && ToneMapActive();
+    m_doviMd = *md;
+    m_doviValid = true;
+    uint32_t l1[3];
+    if (DoviL1Nits(*md, l1)) { m_doviL1Present = true; std::memcpy(m_doviL1, l1, sizeof(l1)); }
+    float k[5];
+    if (DoviL2Constants(*md, (int)m_hdrDisplayMaxNits, k)) { m_doviL2Present = true; std::memcpy(m_doviL2Raw, k, sizeof(k)); }
+    else if (!m_doviL2Present) std::memcpy(m_doviL2Raw, k, sizeof(k));       // the cbuffer of an absent L2 (:956-960)
+    PackDoviCurves(*md, &m_doviHost);
+    DoviLmsMatrix(*md, m_doviHost.lms);
+    m_doviHost.l2_enabled = m_doviL2Present ? 1 : 0;
+    std::memcpy(m_doviHost.l2k, m_doviL2Raw, sizeof(m_doviHost.l2k));
+    m_blobOverride = false;
+    SetShaderConvertColorParams();
+    UpdateHdrToneMapParams();
+    if (!wasValid || (m_srcParams && hadToneMap != ToneMapActive())) m_planDirty = true;
+    return UploadDoviParams();
+}
+
+// the curve / trim constant buffers travel through a small pinned ring so per-frame RPUs never stall the stream
+HRESULT CHipVideoProcessor::UploadDoviParams()
+{
+    (void)hipSetDevice(m_device);
+    HRESULT hr;
+    if ((hr = CheckHip(m_doviDev.CheckCreate(sizeof(DoviParams)), "dovi constants"))) return hr;
+    DoviSlot &slot = m_doviSlots[m_doviSlotNext++ % 4];
+    if (!slot.pinned) {
+        if ((hr = CheckHip(hipHostMalloc((void **)&slot.pinned, sizeof(DoviParams), hipHostMallocDefault), "dovi staging"))) return hr;
+        if ((hr = CheckHip(hipEventCreateWithFlags(&slot.copied, hipEventDisableTiming), "dovi event"))) return hr;
+    } else if ((hr = CheckHip(hipEventSynchronize(slot.copied), "dovi staging wait"))) return hr;
+    *slot.pinned = m_doviHost;
+    if ((hr = CheckHip(hipMemcpyAsync(m_doviDev.ptr, slot.pinned, sizeof(DoviParams), hipMemcpyHostToDevice, m_stream), "dovi upload"))) return hr;
+    return CheckHip(hipEventRecord(slot.copied, m_stream), "dovi event record");
 }
 
 HRESULT CHipVideoProcessor::SetSampleFormat(int frameFormat)
@@ -364,7 +430,8 @@ HRESULT CHipVideoProcessor::UpdatePlan()
                              ConvertEnabled() ? 1 : 0, ToneMapActive() ? 1 : 0};
         std::string why;
         if (!DecidePlan(m_cfg.iTexFormat, m_cfg.iChromaScaling, m_cfg.iUpscaling, m_cfg.iDownscaling,
-                        m_cfg.bInterpolateAt50pct, m_cfg.bUseDither, m_cfg.output_format, m_cfg.flags,
+                        m_cfg.bInterpolateAt50pct, m_cfg.bUseDither, m_cfg.output_format,
+                        m_cfg.flags | (m_doviValid ? MPCVR_FLAG_NO_FUSED : 0u),     // the fused kernel has no reshaping stage
                         *m_srcParams, g, &m_plan, &why))
             return Fail(MPCVR_E_NOTIMPL, why);
     }
@@ -473,6 +540,7 @@ HRESULT CHipVideoProcessor::UpdatePlan()
 bool CHipVideoProcessor::ConvertEnabled() const
 {
     const FmtConvParams &f = *m_srcParams;
+    if (m_doviValid) return true;                                              // :834
     if (f.CSType == CST_YUV || f.CSType == CST_GRAY || (f.CSType == CST_RGB && f.planes == 3)) return true;
     return std::fabs(m_procAmp.brightness / 255) > 1e-4f || std::fabs(m_procAmp.contrast - 1.0f) > 1e-4f;
 }
@@ -543,6 +611,7 @@ void CHipVideoProcessor::FillConvertParams(const uint8_t *sample, ConvertParams 
     P->lum_scale = m_lumScale;
     std::memcpy(P->gamut, m_gamut, sizeof(m_gamut));
     P->out_fmt = m_plan.internal_fmt;
+    P->dovi = m_doviValid ? (const DoviParams *)m_doviDev.ptr : nullptr;
 }
 
 StoreParams CHipVideoProcessor::MakeStore(void *dst, int pitch, int dstFmt, bool rt) const
@@ -834,6 +903,9 @@ void CHipVideoProcessor::Flush()
 {
     if (m_bInit) { (void)hipSetDevice(m_device); (void)hipStreamSynchronize(m_stream); }
     m_curSample = nullptr;
+    // m_DoviExtensionMetadata = {} (:4082): L1 / L2 are forgotten; the uploaded constants change with the next RPU
+    m_doviL1Present = m_doviL2Present = false;
+    std::memset(m_doviL1, 0, sizeof(m_doviL1));
 }
 
 HRESULT CHipVideoProcessor::Reset()

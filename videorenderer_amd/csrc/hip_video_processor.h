@@ -53,6 +53,7 @@ public:
     HRESULT SetSampleFormat(int frameFormat);                                 // m_SampleFormat, :2209-2219
     HRESULT SetHdrOutput(bool enable, int toneMapType, float displayMaxNits);  // m_bHdrPassthrough / m_bHdrLocalToneMapping
     HRESULT SetHdrMetadata(float minMastering, float maxMastering, float maxCLL, float maxFALL);   // SetHDR10ShaderParams :907
+    HRESULT SetDoviMetadata(const mpcvr_dovi_metadata *md);                   // CopySample :2270-2520 (IID_MediaSideDataDOVIMetadataV2)
     HRESULT Configure(const mpcvr_settings &config);                          // :3800
     HRESULT SetProcAmpValues(uint32_t flags, float b, float c, float h, float s); // :4506
 
@@ -114,6 +115,18 @@ private:
     float m_hdrDisplayMaxNits = 1000.0f, m_hdrMeta[4] = {0, 0, 0, 0};
     HdrToneMapParams m_hdrTm{};
     void UpdateHdrToneMapParams();
+    // m_Dovi / m_DoviExtensionMetadata: the RPU of the current sample; L1 / L2 stay as last seen until Flush (:4082)
+    struct DoviSlot { DoviParams *pinned = nullptr; hipEvent_t copied = nullptr; };
+    bool m_doviValid = false;
+    mpcvr_dovi_metadata m_doviMd{};
+    DoviParams m_doviHost{};
+    bool m_doviL1Present = false, m_doviL2Present = false;
+    uint32_t m_doviL1[3] = {0, 0, 0};
+    float m_doviL2Raw[5] = {0, 0, 0, 0, 0};       // cbuffer values for the last level-2 selection
+    DevBuffer m_doviDev;
+    DoviSlot m_doviSlots[4];
+    unsigned m_doviSlotNext = 0;
+    HRESULT UploadDoviParams();
     bool ToneMapActive() const;
     int m_firstAxis = 0;           // screen axis the first draw's tap table runs along
     bool m_firstSwap = false;      // rotation 90/270: taps address the other texture axis

@@ -83,6 +83,9 @@ int32_t mpcvr_set_hdr_output(mpcvr_ctx *ctx, int32_t enable, int32_t tone_map_ty
 int32_t mpcvr_set_hdr_metadata(mpcvr_ctx *ctx, float min_mastering_nits, float max_mastering_nits, float max_cll, float max_fall)
 { CTX_OR_FAIL(); return ctx->vp.SetHdrMetadata(min_mastering_nits, max_mastering_nits, max_cll, max_fall); }
 
+int32_t mpcvr_set_dovi_metadata(mpcvr_ctx *ctx, const mpcvr_dovi_metadata *md)
+{ CTX_OR_FAIL(); return ctx->vp.SetDoviMetadata(md); }
+
 int32_t mpcvr_configure(mpcvr_ctx *ctx, const mpcvr_settings *settings)
 {
     CTX_OR_FAIL();
@@ -202,6 +205,41 @@ int32_t mpcvr_plan_final_pass_multiplier(int32_t quant, int32_t maxv, uint32_t *
 {
     if (!multiplier) return MPCVR_E_POINTER;
     *multiplier = mpcvr::FinalPassMultiplier(quant, maxv);
+    return MPCVR_S_OK;
+}
+
+int32_t mpcvr_plan_dovi(const mpcvr_dovi_metadata *md, int32_t display_nits, float *cb705, int32_t *has_mmr,
+                        float lms9[9], float l2k[5], int32_t *l2_enabled, uint32_t l1_nits[3], int32_t *l1_present)
+{
+    if (!md) return MPCVR_E_POINTER;
+    if (!mpcvr::CheckDoviCurves(*md)) return MPCVR_E_INVALIDARG;
+    if (cb705 || has_mmr) {
+        mpcvr::DoviParams P{};
+        mpcvr::PackDoviCurves(*md, &P);
+        if (has_mmr) *has_mmr = P.has_mmr;
+        if (cb705)
+            for (int c = 0; c < 3; c++) {
+                float *o = cb705 + c * 235;
+                const mpcvr::DoviCurve &cv = P.curves[c];
+                std::memcpy(o, cv.pivots, sizeof(float) * 7);
+                std::memcpy(o + 7, cv.coeffs, sizeof(float) * 32);
+                std::memcpy(o + 39, cv.mmr, sizeof(float) * 192);
+                o[231] = (float)cv.methods; o[232] = (float)cv.mmr_single; o[233] = (float)cv.min_order; o[234] = (float)cv.max_order;
+            }
+    }
+    if (lms9) mpcvr::DoviLmsMatrix(*md, lms9);
+    if (l2k || l2_enabled) {
+        float k[5];
+        const bool on = mpcvr::DoviL2Constants(*md, display_nits, k);
+        if (l2k) std::memcpy(l2k, k, sizeof(k));
+        if (l2_enabled) *l2_enabled = on ? 1 : 0;
+    }
+    if (l1_nits || l1_present) {
+        uint32_t v[3];
+        const bool on = mpcvr::DoviL1Nits(*md, v);
+        if (l1_nits) std::memcpy(l1_nits, v, sizeof(v));
+        if (l1_present) *l1_present = on ? 1 : 0;
+    }
     return MPCVR_S_OK;
 }
 

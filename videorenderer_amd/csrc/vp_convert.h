@@ -133,10 +133,18 @@ __device__ __forceinline__ f3 convert_pixel(const ConvertParams &P, int i, int j
     const int sx = P.rect_l + i, sy = P.rect_t + j;
     float y, uv[2];
     fetch_pixel(P, sx, sy, y, uv);
+    if (P.dovi) {                                   // Shaders.cpp:786-792
+        const f3 r = dovi_reshape(*P.dovi, f3{y, uv[0], uv[1]});
+        y = r.x; uv[0] = r.y; uv[1] = r.z;
+    }
     f3 c;
     c.x = (P.cm[0] * y + P.cm[1] * uv[0] + P.cm[2] * uv[1]) + P.cm[9];
     c.y = (P.cm[3] * y + P.cm[4] * uv[0] + P.cm[5] * uv[1]) + P.cm[10];
     c.z = (P.cm[6] * y + P.cm[7] * uv[0] + P.cm[8] * uv[1]) + P.cm[11];
+    if (P.dovi) {
+        c = dovi_lms_step(*P.dovi, c);
+        return hdr_tail(c, P.tail, P.gamma, P.lum_scale, make_mat3(P.gamut), P.dovi->l2_enabled ? P.dovi->l2k : nullptr);
+    }
     return hdr_tail(c, P.tail, P.gamma, P.lum_scale, make_mat3(P.gamut));
 }
 

@@ -103,8 +103,80 @@ __device__ __forceinline__ f3 mat3_mul(const mat3 &g, f3 v)
     return r;
 }
 
-// The tail GetShaderConvertColor appends after "//convert color" — Shaders.cpp:861-923
-__device__ __forceinline__ f3 hdr_tail(f3 c, int tail, float gamma, float lum_scale, const mat3 &gamut)
+// ---- Dolby Vision ----
+// reshape_mmr — Shaders.cpp:734-762 (dot products summed left to right like mul())
+__device__ __forceinline__ float dovi_reshape_mmr(const DoviCurve &cv, const float co[4], f3 sig)
+{
+    const uint32_t at = cv.mmr_single ? 0u : (uint32_t)co[1];
+    const float (*w)[4] = cv.mmr + at;
+    float s = co[0];
+    float cx[4] = {sig.x * sig.y, sig.x * sig.z, sig.y * sig.z, 0.0f};
+    cx[3] = cx[0] * sig.z;
+    s += w[0][0] * sig.x + w[0][1] * sig.y + w[0][2] * sig.z;
+    s += w[1][0] * cx[0] + w[1][1] * cx[1] + w[1][2] * cx[2] + w[1][3] * cx[3];
+    if (cv.max_order >= 2) {
+        const uint32_t order = (uint32_t)co[3];
+        if (cv.min_order < 2 && order < 2) return s;
+        const f3 s2 = {sig.x * sig.x, sig.y * sig.y, sig.z * sig.z};
+        float cx2[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) cx2[i] = cx[i] * cx[i];
+        s += w[2][0] * s2.x + w[2][1] * s2.y + w[2][2] * s2.z;
+        s += w[3][0] * cx2[0] + w[3][1] * cx2[1] + w[3][2] * cx2[2] + w[3][3] * cx2[3];
+        if (cv.max_order == 3) {
+            if (cv.min_order < 3 && order < 3) return s;
+            s += w[4][0] * (s2.x * sig.x) + w[4][1] * (s2.y * sig.y) + w[4][2] * (s2.z * sig.z);
+            s += w[5][0] * (cx2[0] * cx[0]) + w[5][1] * (cx2[1] * cx[1]) + w[5][2] * (cx2[2] * cx[2]) + w[5][3] * (cx2[3] * cx[3]);
+        }
+    }
+    return s;
+}
+// ShaderDoviReshape / ShaderDoviReshapePoly — Shaders.cpp:531-589: (Y,U,V) through the per-component piecewise curves
+__device__ __forceinline__ f3 dovi_reshape(const DoviParams &D, f3 color)
+{
+    const f3 sig = {saturate(color.x), saturate(color.y), saturate(color.z)};
+    float in[3] = {sig.x, sig.y, sig.z}, out[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const DoviCurve &cv = D.curves[c];
+        float s = in[c];
+        const float *pv = cv.pivots;
+        const int piece = (s < pv[3]) ? ((s < pv[1]) ? ((s < pv[0]) ? 0 : 1) : ((s < pv[2]) ? 2 : 3))
+                                      : ((s < pv[5]) ? ((s < pv[4]) ? 4 : 5) : ((s < pv[6]) ? 6 : 7));
+        const float4 q = *reinterpret_cast<const float4 *>(cv.coeffs[piece]);
+        const float co[4] = {q.x, q.y, q.z, q.w};
+        const bool poly = !D.has_mmr || cv.methods == DOVI_RESHAPE_POLY ||
+                          (cv.methods == DOVI_RESHAPE_POLY + DOVI_RESHAPE_MMR && co[3] == 0.0f);
+        if (poly) s = (co[2] * s + co[1]) * s + co[0];
+        else s = dovi_reshape_mmr(cv, co, sig);
+        out[c] = saturate(s);
+    }
+    return f3{out[0], out[1], out[2]};
+}
+// PQ EOTF -> LMS matrix -> PQ OETF — Shaders.cpp:844-859
+__device__ __forceinline__ f3 dovi_lms_step(const DoviParams &D, f3 c)
+{
+    c.x = st2084_to_linear(fmaxf(c.x, 0.0f), 1.0f); c.y = st2084_to_linear(fmaxf(c.y, 0.0f), 1.0f); c.z = st2084_to_linear(fmaxf(c.z, 0.0f), 1.0f);
+    f3 r;
+    r.x = D.lms[0] * c.x + D.lms[1] * c.y + D.lms[2] * c.z;
+    r.y = D.lms[3] * c.x + D.lms[4] * c.y + D.lms[5] * c.z;
+    r.z = D.lms[6] * c.x + D.lms[7] * c.y + D.lms[8] * c.z;
+    r.x = linear_to_st2084(fmaxf(r.x, 0.0f), 1.0f); r.y = linear_to_st2084(fmaxf(r.y, 0.0f), 1.0f); r.z = linear_to_st2084(fmaxf(r.z, 0.0f), 1.0f);
+    return r;
+}
+// DolbyVisionTrims on PQ-coded colour — Shaders.cpp:766-773; k = {ChromaWeight, SaturationGain, TrimSlope, TrimOffset, TrimPower}
+__device__ __forceinline__ f3 dovi_trims(f3 c, const float *k)
+{
+    c.x = hlsl_pow((c.x * k[2]) + k[3], k[4]); c.y = hlsl_pow((c.y * k[2]) + k[3], k[4]); c.z = hlsl_pow((c.z * k[2]) + k[3], k[4]);
+    const float Y = 0.2627f * c.x + 0.6780f * c.y + 0.0593f * c.z;
+    c.x = c.x * hlsl_pow((1.0f + k[0]) * c.x / Y, k[1]);
+    c.y = c.y * hlsl_pow((1.0f + k[0]) * c.y / Y, k[1]);
+    c.z = c.z * hlsl_pow((1.0f + k[0]) * c.z / Y, k[1]);
+    return c;
+}
+
+// The tail GetShaderConvertColor appends after "//convert color" — Shaders.cpp:861-923; l2k != null: Dolby Vision L2 trims (:873-877)
+__device__ __forceinline__ f3 hdr_tail(f3 c, int tail, float gamma, float lum_scale, const mat3 &gamut, const float *l2k = nullptr)
 {
     if (tail == TAIL_NONE) return c;
     if (tail == TAIL_HLG_TO_PQ) {          // bConvertHLGtoPQ (:885-891)
@@ -119,9 +191,11 @@ __device__ __forceinline__ f3 hdr_tail(f3 c, int tail, float gamma, float lum_sc
             c = hlg_to_linear(c);
             c.x = linear_to_st2084(c.x, 1000.0f); c.y = linear_to_st2084(c.y, 1000.0f); c.z = linear_to_st2084(c.z, 1000.0f);
         }
-        c.x = st2084_to_linear(saturate(c.x), lum_scale);
-        c.y = st2084_to_linear(saturate(c.y), lum_scale);
-        c.z = st2084_to_linear(saturate(c.z), lum_scale);
+        c.x = saturate(c.x); c.y = saturate(c.y); c.z = saturate(c.z);
+        if (l2k) c = dovi_trims(c, l2k);
+        c.x = st2084_to_linear(c.x, lum_scale);
+        c.y = st2084_to_linear(c.y, lum_scale);
+        c.z = st2084_to_linear(c.z, lum_scale);
         const float div = hable_div();
         c.x = hable(c.x) / div; c.y = hable(c.y) / div; c.z = hable(c.z) / div;
         c = mat3_mul(gamut, c);
@@ -136,7 +210,7 @@ __device__ __forceinline__ f3 hdr_tail(f3 c, int tail, float gamma, float lum_sc
     return c;
 }
 
-// HDR10 -> HDR10 local tone mapping — Shaders/d3d11/ps_hdr10_tonemap.hlsl:272-336 (Dolby Vision L2 trims not modelled)
+// HDR10 -> HDR10 local tone mapping — Shaders/d3d11/ps_hdr10_tonemap.hlsl:257-336
 __device__ __forceinline__ float lerp_f(float a, float b, float t) { return a + t * (b - a); }
 __device__ __forceinline__ float pl_smoothstep(float e0, float e1, float x)
 {
@@ -147,6 +221,11 @@ __device__ __forceinline__ float pl_smoothstep(float e0, float e1, float x)
 __device__ __forceinline__ f3 hdr10_tonemap(f3 c, const HdrToneMapParams &k)
 {
     c.x = st2084_to_linear(saturate(c.x), 10000.0f); c.y = st2084_to_linear(saturate(c.y), 10000.0f); c.z = st2084_to_linear(saturate(c.z), 10000.0f);
+    if (k.l2_enabled) {                                                                     // DolbyVisionTrims :257-270
+        c.x = linear_to_st2084(c.x, 10000.0f); c.y = linear_to_st2084(c.y, 10000.0f); c.z = linear_to_st2084(c.z, 10000.0f);
+        c = dovi_trims(c, k.l2k);
+        c.x = st2084_to_linear(c.x, 10000.0f); c.y = st2084_to_linear(c.y, 10000.0f); c.z = st2084_to_linear(c.z, 10000.0f);
+    }
     if (k.selection == 5) {                                                                 // BT2390Tonemap :68-124
         float safe = k.max_cll;
         if (safe <= 10.0f) safe = k.max_mastering;

@@ -27,7 +27,27 @@ enum TailMode : int {
 struct HdrToneMapParams {
     float min_mastering, max_mastering, max_cll, max_fall, display_max;
     int selection;           // 1 ACES, 2 Reinhard, 3 Habel, 4 Moebius, 5 BT.2390, 6 ST 2094-10
+    int l2_enabled;          // DolbyConstants at b1 (DX11VideoProcessor.cpp:3362-3364)
+    float l2k[5];
 };
+
+// Dolby Vision constants of the convert shader: PS_DOVI_CURVE x3 (cbuffer b2, Shaders.cpp:715-727), the LMS matrix baked into
+// the shader text (Shaders.cpp:826-842) and DolbyConstants (cbuffer b3, :751-760).  Lives in device memory, read through
+// ConvertParams::dovi.
+struct DoviCurve {
+    float pivots[7]; float pad0;
+    float coeffs[8][4];
+    float mmr[48][4];
+    uint32_t methods, mmr_single, min_order, max_order;
+};
+struct DoviParams {
+    DoviCurve curves[3];
+    float lms[9];
+    int has_mmr;            // which reshape shader variant was generated (:2305-2318)
+    int l2_enabled;         // L2Enabled
+    float l2k[5];           // ChromaWeight, SaturationGain, TrimSlope, TrimOffset, TrimPower
+};
+enum { DOVI_RESHAPE_POLY = 1, DOVI_RESHAPE_MMR = 2 };
 
 enum ChromaLoc : int { CLOC_MPEG2 = 0, CLOC_MPEG1 = 1, CLOC_COSITED = 2 };
 
@@ -73,6 +93,7 @@ struct ConvertParams {
     float lum_scale;         // PS_PARAMETERS.LuminanceScale
     float gamut[9];          // matrix_conv_prim
     int out_fmt;             // SurfFmt of m_TexConvertOutput
+    const DoviParams *dovi;  // device pointer, null unless m_Dovi.bValid
 };
 
 struct Surface {

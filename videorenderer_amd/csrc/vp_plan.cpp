@@ -272,16 +272,16 @@ void ComputeGamut2020to709(float out[9])
 }
 
 // Shaders.cpp:613-616, 861-915
-void SelectTail(const ExtFmt &ex, bool convert_to_sdr, int *tail, float *gamma, bool hdr_output)
+void SelectTail(const ExtFmt &ex, bool convert_to_sdr, int *tail, float *gamma, bool hdr_output, bool dovi)
 {
     const unsigned tf = ex.VideoTransferFunction();
     *tail = TAIL_NONE;
     *gamma = 1.0f;
     if (hdr_output) {
         convert_to_sdr = false;                                            // convertType is never TO_SDR (:2948)
-        if (tf == dxva::TF_HLG) { *tail = TAIL_HLG_TO_PQ; return; }         // SHADER_CONVERT_TO_PQ (:2949)
+        if (tf == dxva::TF_HLG && !dovi) { *tail = TAIL_HLG_TO_PQ; return; }   // SHADER_CONVERT_TO_PQ (:2949), bApplyHLG (:615)
     }
-    if (convert_to_sdr && tf == dxva::TF_2084) { *tail = TAIL_PQ_TO_SDR; return; }
+    if (convert_to_sdr && (tf == dxva::TF_2084 || dovi)) { *tail = TAIL_PQ_TO_SDR; return; }
     if (convert_to_sdr && tf == dxva::TF_HLG) { *tail = TAIL_HLG_TO_SDR; return; }
     if (ex.VideoPrimaries() == dxva::Prim_BT2020) {
         float g = 0;

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "vp_params.h"
+#include "../../include/mpcvr.h"
 
 namespace mpcvr {
 
@@ -54,9 +55,24 @@ struct ProcAmp { float brightness = 0, contrast = 1, hue = 0, saturation = 1; };
 void ComputeColorMatrix(const ExtFmt &ex, const FmtConvParams &f, const ProcAmp &pa, float out12[12]);
 // GetColorspaceGamutConversionMatrix(BT2020 -> BT709) (csputils.cpp:549-557)
 void ComputeGamut2020to709(float out9[9]);
+// ---- Dolby Vision (vp_dovi.cpp) ----
+// the curve part of CheckDoviMetadata (VideoProcessor.cpp:283-292) with maxReshapeMethon = 1
+bool CheckDoviCurves(const mpcvr_dovi_metadata &md);
+// SetShaderDoviCurves / SetShaderDoviCurvesPoly (DX11VideoProcessor.cpp:990-1141) + has_mmr (:2305-2318)
+void PackDoviCurves(const mpcvr_dovi_metadata &md, DoviParams *out);
+// dovi_lms2rgb x rgb_to_lms_matrix (Shaders.cpp:826-842)
+void DoviLmsMatrix(const mpcvr_dovi_metadata &md, float out9[9]);
+// level-2 selection (:2383-2469) + SetDolbyVisionDynamicParams (:954-960); returns L2.present
+bool DoviL2Constants(const mpcvr_dovi_metadata &md, int display_nits, float k[5]);
+// level 1 (+3) in nits (:2347-2372); returns L1.present
+bool DoviL1Nits(const mpcvr_dovi_metadata &md, uint32_t out[3]);
+// the Dolby Vision branch of SetShaderConvertColorParams (:817-834) + its cbuffer fix-ups (:863-873)
+void DoviColorMatrix(const mpcvr_dovi_metadata &md, const FmtConvParams &f, const ProcAmp &pa, float out12[12]);
+
 // which HDR tail GetShaderConvertColor emits (Shaders.cpp:613-616, 861-923)
 // hdr_output = m_bHdrPassthroughSupport && (m_bHdrPassthrough || m_bHdrLocalToneMapping): never TO_SDR, HLG -> PQ (:2948-2950)
-void SelectTail(const ExtFmt &ex, bool convert_to_sdr, int *tail, float *gamma, bool hdr_output = false);
+// dovi = pDoviMetadata != nullptr: a PQ source whatever the transfer function says, bApplyHLG off (:614-615)
+void SelectTail(const ExtFmt &ex, bool convert_to_sdr, int *tail, float *gamma, bool hdr_output = false, bool dovi = false);
 
 // per-channel PQ->SDR chain saturate -> ST2084ToLinear*LuminanceScale -> Hable/hable(4.8) sampled at
 // i/(kPqLutSize-1) (st2084.hlsl:9-16, hdr_tone_mapping.hlsl:1-13): the optional tone-map LUT of the fused path

@@ -226,3 +226,91 @@ def make_frame(cformat, w, h, kind="noise", seed=0, pitch=None, full_range=False
         p2 = buf[off2: off2 + cpitch * ch].reshape(ch, cpitch).view(dt)
         p2[:, :cw] = second.astype(dt)
     return buf, pitch
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic Dolby Vision RPUs — plain dicts in the shape api.DoviMetadata.from_dict() takes
+# (fields of MediaSideDataDOVIMetadata, Include/IMediaSideData.h:154-330).  The numbers are made up but
+# plausible for a profile-5 (IPTPQc2) stream: fixed-point coefficients with 23 fractional bits, 10-bit base layer.
+# ------------------------------------------------------------------------------------------------
+def _nits_to_pq12(nits):
+    m1, m2 = 2610 / 16384, 2523 / 4096 * 128
+    c1, c2, c3 = 3424 / 4096, 2413 / 4096 * 32, 2392 / 4096 * 32
+    y = (nits / 10000.0) ** m1
+    return int(round(((c1 + c2 * y) / (1 + c3 * y)) ** m2 * 4095))
+
+
+def dovi_metadata(kind="poly", l1=False, l2=(), l3=False):
+    """kind: 'poly' (8 luma pieces of order 1/2, linear chroma), 'mmr' (chroma through one order-3 MMR piece each),
+    'mixed' (a curve mixing polynomial and two MMR pieces of different order), 'identity'.
+    l2: iterable of target nits for which level-2 trim blocks are generated."""
+    den = 23
+    one = 1 << den
+
+    def fx(x):
+        return int(round(x * one))
+
+    ident = dict(pivots=[0, 1023], pieces=[dict(order=1, poly=[0, one, 0])])
+    if kind == "identity":
+        curves = [ident, ident, ident]
+    else:
+        # luma: a gentle S-curve split in 8 pieces, continuous at the pivots (order 0 quirks included: piece 3 is order 1)
+        piv = [0, 64, 160, 300, 460, 620, 780, 900, 1023]
+        pieces = []
+        for i in range(8):
+            x0 = piv[i] / 1023.0
+            a = 0.004 * (i - 3.5)                  # curvature changes sign across the range
+            b = 1.0 - 0.03 * (i - 3.5)
+            c = x0 - (a * x0 + b) * x0 + 0.002 * i
+            if i == 3:
+                pieces.append(dict(order=1, poly=[fx(c), fx(b), fx(0.75)]))      # x^2 term ignored for order 1
+            else:
+                pieces.append(dict(order=2, poly=[fx(c), fx(b), fx(a)]))
+        luma = dict(pivots=piv, pieces=pieces)
+        if kind == "poly":
+            cu = dict(pivots=[0, 512, 1023], pieces=[dict(order=1, poly=[fx(0.01), fx(0.98), 0]),
+                                                     dict(order=2, poly=[fx(-0.015), fx(1.06), fx(-0.04)])])
+            cv = dict(pivots=[0, 1023], pieces=[dict(order=1, poly=[fx(-0.005), fx(1.01), 0])])
+            curves = [luma, cu, cv]
+        else:
+            def mmr_piece(comp, order, bias):
+                rows = []
+                for o in range(order):
+                    w = [0.0] * 7
+                    if o == 0:
+                        w[comp] = 0.97
+                        w[0] += 0.02
+                        w[3] = 0.015; w[4] = -0.01; w[5] = 0.02; w[6] = -0.03
+                    elif o == 1:
+                        w[comp] = 0.04; w[3] = -0.02; w[5] = 0.01; w[6] = 0.05
+                    else:
+                        w[comp] = -0.015; w[4] = 0.03; w[6] = -0.02
+                    rows.append([fx(x) for x in w])
+                return dict(order=order, constant=fx(bias), mmr=rows)
+            if kind == "mmr":
+                cu = dict(pivots=[0, 1023], pieces=[mmr_piece(1, 3, -0.004)])
+                cv = dict(pivots=[0, 1023], pieces=[mmr_piece(2, 3, 0.003)])
+            elif kind == "mixed":
+                cu = dict(pivots=[0, 300, 700, 1023],
+                          pieces=[dict(order=1, poly=[fx(0.004), fx(0.99), 0]), mmr_piece(1, 1, 0.002), mmr_piece(1, 3, -0.003)])
+                cv = dict(pivots=[0, 512, 1023], pieces=[mmr_piece(2, 2, 0.001), mmr_piece(2, 2, -0.002)])
+            else:
+                raise ValueError(kind)
+            curves = [luma, cu, cv]
+    # IPT -> L'M'S' (scaled by 1/8192 in real RPUs) and the crosstalk-removing "rgb_to_lms" of profile 5
+    # (chroma gains reduced to 0.3x so that noise frames, whose chroma spans the whole code range, stay mostly unclipped)
+    ycc = [x / 8192.0 for x in (8192, 240, 504, 8192, -280, 327, 8192, 80, -1663)]
+    c = 0.02
+    xt = np.array([[1 - 2 * c, c, c], [c, 1 - 2 * c, c], [c, c, 1 - 2 * c]])
+    lms = (np.round(np.linalg.inv(xt) * 16384) / 16384).reshape(-1).tolist()
+    md = dict(bl_bit_depth=10, coef_log2_denom=den, source_max_pq=_nits_to_pq12(4000),
+              ycc_to_rgb_matrix=ycc, ycc_to_rgb_offset=[0.0, 0.5, 0.5], rgb_to_lms_matrix=lms, curves=curves, l2=[])
+    for i, nits in enumerate(l2):
+        md["l2"].append(dict(target_max_pq=_nits_to_pq12(nits), trim_slope=2048 + 60 - 25 * i, trim_offset=2048 - 12 + 7 * i,
+                             trim_power=2048 + 40 - 30 * i, trim_chroma_weight=2048 + 100 - 60 * i,
+                             trim_saturation_gain=2048 - 50 + 45 * i))
+    if l1:
+        md.update(l1_present=1, l1_min_pq=62, l1_max_pq=_nits_to_pq12(1400), l1_avg_pq=_nits_to_pq12(60))
+    if l3:
+        md.update(l3_present=1, l3_min_pq_offset=2048 - 10, l3_max_pq_offset=2048 + 90, l3_avg_pq_offset=2048 + 35)
+    return md
