@@ -146,7 +146,10 @@ def test_pass_plan_matches_reference_rules(mpcvr):
     s = api.default_settings()
     d = lambda cf, w, h, vr, ww, wh, st=s: api.plan_describe(st, cf, w, h, vr, ww, wh)
     # C1: 8-bit source, no resize -> BGRA8 internal, never dithers (DX11VideoProcessor.cpp:2896-2900)
-    assert d(1, 1920, 1080, (0, 0, 1920, 1080), 1920, 1080) == "passes:convert,copy;internal=8;swap=8;final=0"
+    assert d(1, 1920, 1080, (0, 0, 1920, 1080), 1920, 1080) == "direct:convert+copy;internal=8;swap=8;final=0"
+    assert d(1, 1920, 1080, (0, 0, 1920, 1080), 1920, 1080, s.copy(flags=api.FLAG_NO_FUSED)) == "passes:convert,copy;internal=8;swap=8;final=0"
+    # same size, 10-bit source: the final pass (dither) rides in the convert kernel's epilogue too
+    assert d(2, 3840, 2160, (0, 0, 3840, 2160), 3840, 2160) == "direct:convert+final;internal=10;swap=8;final=1"
     # C2/C3: exact 2x of a 10/16-bit 4:2:0 source -> fused kernel, RGB10A2 internal, final pass on
     assert d(20, 1920, 1080, (0, 0, 3840, 2160), 3840, 2160).startswith("fused_up2x;internal=10;swap=8;final=1")
     assert d(2, 3840, 2160, (0, 0, 7680, 4320), 7680, 4320, s.copy(iUpscaling=4)).startswith("fused_up2x")
@@ -186,7 +189,7 @@ def test_every_case_has_a_plan(mpcvr):
         (ww, wh), vr = case_geometry(c)
         r = c.get("src_rect", (0, 0, c["w"], c["h"]))
         kinds.add(api.plan_describe(s, c["cformat"], r[2] - r[0], r[3] - r[1], vr, ww, wh).split(";")[0])
-    assert {"fused_up2x", "passes:convert,copy", "passes:convert,final", "passes:convert,resizeX,resizeY+final",
+    assert {"fused_up2x", "direct:convert+copy", "direct:convert+final", "passes:convert,resizeX,resizeY+final",
             "passes:convert,resizeX,resizeY"} <= kinds
 
 

@@ -124,16 +124,46 @@ def _is_exact_2x(c):
 FUSED = sorted(n for n, c in GOLDEN_CASES.items() if _is_exact_2x(c))
 
 
-@pytest.mark.parametrize("name", FUSED)
+@pytest.mark.parametrize("name", sorted(GOLDEN_CASES))
 def test_default_path_vs_oracle(mpcvr, oracle, torch_cuda, name):
-    """Default settings: whatever path the planner picks (the fused 2x kernel where eligible)."""
+    """Default settings: whatever the planner picks — the fused 2x kernel where eligible, else the folded convert /
+    row-tap / column-tap kernels, else the plain ones.  The folded kernels keep the plain kernels' arithmetic, so
+    everything that does not run the fused kernel or a transcendental tail stays bit-exact."""
     c = GOLDEN_CASES[name]
     want = run_case(oracle, name, background=BG)
     got, info = run_product(mpcvr, torch_cuda, c)
+    exact = info != "fused_up2x" and not has_tail(c)
     if c.get("output_format", 0) == 1:
-        compare_rgb10(got, want, name)
+        compare_rgb10(got, want, name, exact=exact)
     else:
-        compare(got, want, f"{name} [{info}]", min_same=0.99)
+        compare(got, want, f"{name} [{info}]", exact=exact, min_same=0.99)
+
+
+def _is_same_size(c):
+    r = c.get("src_rect", (0, 0, c["w"], c["h"]))
+    return c["dst"] == (r[2] - r[0], r[3] - r[1]) and not c.get("rotation", 0) and not c.get("hdr_tonemap", 0)
+
+
+SAME_SIZE = sorted(n for n, c in GOLDEN_CASES.items() if _is_same_size(c))
+
+
+@pytest.mark.parametrize("name", SAME_SIZE)
+def test_direct_convert_vs_oracle(mpcvr, oracle, torch_cuda, name):
+    """Nothing to resize: the default planner folds the copy / final pass into the convert kernel (one launch, no
+    m_TexConvertOutput round trip).  Same bars as the pass-per-kernel path: bit-exact without a transcendental tail."""
+    c = GOLDEN_CASES[name]
+    want = run_case(oracle, name, background=BG)
+    got, info = run_product(mpcvr, torch_cuda, c)
+    if info.startswith("passes:"):          # interleaved RGB without ProcAmp: no convert draw at all, or a flip that needs a draw
+        assert info.startswith("passes:source") or c.get("flip"), info
+    else:
+        assert info.startswith("direct:convert"), info
+    if c.get("output_format", 0) == 1:
+        compare_rgb10(got, want, name, exact=not has_tail(c))
+    elif has_tail(c):
+        compare(got, want, name, min_same=0.995)
+    else:
+        compare(got, want, name, exact=True)
 
 
 def test_fused_kernel_is_actually_used(mpcvr, torch_cuda):
@@ -155,7 +185,7 @@ def test_fused_variants_agree(mpcvr, oracle, torch_cuda, name):
     base, info = run_product(mpcvr, torch_cuda, c)
     assert info == "fused_up2x"
     for flags in (api.FLAG_NO_LUT, api.FLAG_NO_FAST_CONVERT, api.FLAG_NO_LUT | api.FLAG_NO_FAST_CONVERT):
-        alt, _ = run_product(mpcvr, torch_cuda, c, extra_flags=flags)
+        alt, _ = run_product(mpcvr, torch_cuda, c, extra_flags=flags)      # (without the fast convert: the folded pass-per-kernel path)
         compare(alt, want, f"{name} flags={flags}", min_same=0.99)
         compare(alt, base, f"{name} flags={flags} vs default", min_same=0.99)
 
@@ -280,7 +310,7 @@ def test_dovi_metadata_lifecycle(mpcvr, oracle, torch_cuda):
         p = oracle_params(oracle, case)
         return oracle.process(p, frame, pitch, dst=np.full((wh, ww, 4), BG, np.uint8))
 
-    assert vp.GetVPInfo().startswith("passes:")                       # never the fused kernel
+    assert vp.GetVPInfo().startswith("passes:convert,resizeX,resizeY")   # never the fused kernel
     compare(product(), expect(c), "first RPU", min_same=0.99)
     l2 = c["dovi"]["l2"]
     vp.SetDoviMetadata(synth.dovi_metadata("mmr"))                    # no level-2 block: the previous trims stay
@@ -432,7 +462,7 @@ def test_full_size_baseline_configs_whole_frame(mpcvr, oracle, torch_cuda, label
     want = oracle.process(p, frame, pitch)
     got, info = run_product(mpcvr, torch_cuda, c)
     if label == "C1":
-        assert info.startswith("passes:convert,copy")
+        assert info.startswith("direct:convert+copy")
         compare(got, want, label, exact=True)                 # SDR pass-per-kernel: bit-exact
     else:
         assert info == "fused_up2x"

@@ -6,7 +6,11 @@ import torch
 from videorenderer_amd import api
 
 # (name, src w, h, dst w, h, settings, cformat, extfmt kwargs)
-CASES = [("4K P010 PQ -> 1440p (Hamming down) -> SDR", 3840, 2160, 2560, 1440, dict(iDownscaling=2)),
+CASES = [("C1 1080p NV12 BT.709 -> 1080p BGRA8 (no resize)", 1920, 1080, 1920, 1080, dict(), 1, dict(chroma=5, nominal_range=2, matrix=1)),
+         ("C1 pass-per-kernel (convert, copy)", 1920, 1080, 1920, 1080, dict(flags=api.FLAG_NO_FUSED), 1, dict(chroma=5, nominal_range=2, matrix=1)),
+         ("4K P010 PQ -> 4K SDR BGRA8 + dither (no resize)", 3840, 2160, 3840, 2160, dict()),
+         ("4K P010 PQ -> 4K, pass-per-kernel (convert, final)", 3840, 2160, 3840, 2160, dict(flags=api.FLAG_NO_FUSED)),
+         ("4K P010 PQ -> 1440p (Hamming down) -> SDR", 3840, 2160, 2560, 1440, dict(iDownscaling=2)),
          ("1080p P010 PQ -> 1440p (Lanczos3 1.33x) -> SDR", 1920, 1080, 2560, 1440, dict(iUpscaling=4)),
          ("1080p P010 PQ -> 4K (Lanczos3 2x), pass-per-kernel", 1920, 1080, 3840, 2160, dict(iUpscaling=4, flags=api.FLAG_NO_FUSED)),
          ("1080p P010 PQ -> 4K (Lanczos3 2x), fused", 1920, 1080, 3840, 2160, dict(iUpscaling=4)),
@@ -16,7 +20,10 @@ CASES = [("4K P010 PQ -> 1440p (Hamming down) -> SDR", 3840, 2160, 2560, 1440, d
          ("4K NV12 BT.709 -> 8K (Lanczos3 2x), fused", 3840, 2160, 7680, 4320, dict(iUpscaling=4), 1, dict(chroma=5, nominal_range=2, matrix=1))]
 ext = api.make_extfmt(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15)
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
+only = sys.argv[1] if len(sys.argv) > 1 else ""      # substring filter on the case name
 for case in CASES:
+    if only not in case[0]:
+        continue
     name, w, h, dw, dh, kw = case[:6]
     cf = case[6] if len(case) > 6 else 2
     ex = api.make_extfmt(**case[7]) if len(case) > 7 else ext
@@ -29,12 +36,12 @@ for case in CASES:
         srcs = [torch.randint(64, 941, (nb // 2,), device="cuda", dtype=torch.int32).to(torch.int16).view(torch.uint8) for _ in range(8)]
     else:
         srcs = [torch.randint(16, 236, (nb,), device="cuda", dtype=torch.int32).to(torch.uint8) for _ in range(8)]
-    dsts = [torch.empty((dh, dw, 4), dtype=torch.uint8, device="cuda") for _ in range(8)]
     n = 16
-    for _ in range(2): vp.ProcessBatch(srcs * 2, dsts * 2, dw * 4)
+    dsts = [torch.empty((dh, dw, 4), dtype=torch.uint8, device="cuda") for _ in range(n)]     # distinct targets: frames of a batch may overlap
+    for _ in range(2): vp.ProcessBatch(srcs * 2, dsts, dw * 4)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     reps = 10
-    for _ in range(reps): vp.ProcessBatch(srcs * 2, dsts * 2, dw * 4)
+    for _ in range(reps): vp.ProcessBatch(srcs * 2, dsts, dw * 4)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     fps = reps * n / dt
     print(json.dumps({"case": name, "path": vp.GetVPInfo(), "frames_per_s": round(fps, 1),

@@ -6,6 +6,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cmath>
 #include <cstring>
 
@@ -53,7 +55,7 @@ CHipVideoProcessor::~CHipVideoProcessor()
     (void)hipSetDevice(m_device);
     if (m_stream) (void)hipStreamSynchronize(m_stream);
     for (DevBuffer *b : {&m_TexSrcVideo, &m_TexRaw, &m_TexPost, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
-                         &m_pqLut, &m_tapsXi, &m_tapsXw, &m_tapsXs, &m_tapsYi, &m_tapsYw, &m_tapsYs, &m_otherX, &m_otherY})
+                         &m_pqLut, &m_tapsXi, &m_tapsXw, &m_tapsXs, &m_tapsYi, &m_tapsYw, &m_tapsYs, &m_otherX, &m_otherY, &m_tapsXb, &m_tapsYb})
         b->Release();
     for (UploadSlot &u : m_up) {
         u.dev.Release();
@@ -67,6 +69,13 @@ CHipVideoProcessor::~CHipVideoProcessor()
         if (d.pinned) (void)hipHostFree(d.pinned);
         if (d.copied) (void)hipEventDestroy(d.copied);
     }
+    for (int i = 1; i < kLanes; i++) {
+        Lane &l = m_lanes[i];
+        l.conv.Release(); l.mid.Release(); l.post.Release();
+        if (l.done) (void)hipEventDestroy(l.done);
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+    }
+    if (m_fork) (void)hipEventDestroy(m_fork);
     for (FrameSlot &fs : m_slots) {
         fs.dev.Release();
         if (fs.pinned) (void)hipHostFree(fs.pinned);
@@ -391,7 +400,8 @@ HRESULT CHipVideoProcessor::SetProcAmpValues(uint32_t flags, float b, float c, f
 
 static size_t SurfBytesPerPixel(int fmt) { return fmt == SF_RGBA16F ? 8 : 4; }
 
-HRESULT CHipVideoProcessor::UploadTaps(const HostAxisTaps &h, DevBuffer &bi, DevBuffer &bw, DevBuffer &bs, AxisTaps *out)
+HRESULT CHipVideoProcessor::UploadTaps(const HostAxisTaps &h, DevBuffer &bi, DevBuffer &bw, DevBuffer &bs, DevBuffer &bb,
+                                       const std::vector<int32_t> &other, AxisTaps *out)
 {
     HRESULT hr;
     if ((hr = CheckHip(bi.CheckCreate(h.idx.size() * sizeof(int32_t)), "taps alloc"))) return hr;
@@ -405,6 +415,36 @@ HRESULT CHipVideoProcessor::UploadTaps(const HostAxisTaps &h, DevBuffer &bi, Dev
         out->wsum = (const float *)bs.ptr;
     }
     out->ntaps = h.ntaps; out->normalise = h.normalise;
+    // hints for the folded resize kernels: the source window of every block of 64 outputs, and whether the unfiltered
+    // coordinate maps 1:1
+    out->blk_lo = nullptr; out->blk_span = 0; out->idx_t = nullptr; out->w_t = nullptr; out->n_out = 0;
+    const size_t nOut = h.ntaps > 0 ? h.idx.size() / (size_t)h.ntaps : 0;
+    if (nOut > 0) {
+        std::vector<int32_t> lo((nOut + 63) / 64);
+        int span = 0;
+        for (size_t b = 0; b < lo.size(); b++) {
+            const size_t first = b * 64 * (size_t)h.ntaps, last = std::min(nOut, (b + 1) * 64) * (size_t)h.ntaps;
+            const auto mm = std::minmax_element(h.idx.begin() + first, h.idx.begin() + last);
+            lo[b] = *mm.first;
+            span = std::max(span, *mm.second - *mm.first + 1);
+        }
+        // tap-major copies of both tables behind the block table, in the same buffer
+        const size_t off = (lo.size() + 63) / 64 * 64, cnt = h.idx.size();
+        std::vector<int32_t> pack(off + 2 * cnt);
+        std::copy(lo.begin(), lo.end(), pack.begin());
+        for (size_t f = 0; f < nOut; f++)
+            for (int k = 0; k < h.ntaps; k++) {
+                pack[off + (size_t)k * nOut + f] = h.idx[f * h.ntaps + k];
+                std::memcpy(&pack[off + cnt + (size_t)k * nOut + f], &h.w[f * h.ntaps + k], sizeof(float));
+            }
+        if ((hr = CheckHip(bb.CheckCreate(pack.size() * sizeof(int32_t)), "taps alloc"))) return hr;
+        if ((hr = CheckHip(hipMemcpy(bb.ptr, pack.data(), pack.size() * sizeof(int32_t), hipMemcpyHostToDevice), "taps upload"))) return hr;
+        out->blk_lo = (const int32_t *)bb.ptr; out->blk_span = span;
+        out->idx_t = out->blk_lo + off; out->w_t = (const float *)(out->idx_t + cnt); out->n_out = (int)nOut;
+    }
+    out->other_identity = 1;
+    for (size_t i = 0; i < other.size(); i++)
+        if (other[i] != (int32_t)i) { out->other_identity = 0; break; }
     return MPCVR_S_OK;
 }
 
@@ -427,11 +467,11 @@ HRESULT CHipVideoProcessor::UpdatePlan()
     {
         const PlanGeometry g{w1, h1, m_videoRect.left, m_videoRect.top, m_videoRect.right, m_videoRect.bottom,
                              m_windowRect.Width(), m_windowRect.Height(), m_iRotation, m_bFlip ? 1 : 0,
-                             ConvertEnabled() ? 1 : 0, ToneMapActive() ? 1 : 0};
+                             ConvertEnabled() ? 1 : 0, ToneMapActive() ? 1 : 0, m_doviValid ? 1 : 0};
         std::string why;
         if (!DecidePlan(m_cfg.iTexFormat, m_cfg.iChromaScaling, m_cfg.iUpscaling, m_cfg.iDownscaling,
                         m_cfg.bInterpolateAt50pct, m_cfg.bUseDither, m_cfg.output_format,
-                        m_cfg.flags | (m_doviValid ? MPCVR_FLAG_NO_FUSED : 0u),     // the fused kernel has no reshaping stage
+                        m_cfg.flags,
                         *m_srcParams, g, &m_plan, &why))
             return Fail(MPCVR_E_NOTIMPL, why);
     }
@@ -439,9 +479,12 @@ HRESULT CHipVideoProcessor::UpdatePlan()
     HRESULT hr;
     if (m_plan.hdr_tonemap &&
         (hr = CheckHip(m_TexPost.CheckCreate((size_t)w2 * SurfBytesPerPixel(m_plan.internal_fmt) * h2), "m_TexsPostScale"))) return hr;
+    m_postBytes = m_plan.hdr_tonemap ? (size_t)w2 * SurfBytesPerPixel(m_plan.internal_fmt) * h2 : 0;
+    m_midBytes = 0;
     // m_TexConvertOutput: srcRect-sized, internal format (:2889-2890)
     const size_t convPitch = (size_t)w1 * SurfBytesPerPixel(m_plan.internal_fmt);
     if ((hr = CheckHip(m_TexConvertOutput.CheckCreate(convPitch * h1), "m_TexConvertOutput"))) return hr;
+    m_convBytes = convPitch * h1;
 
     HostAxisTaps hx, hy;
     std::vector<int32_t> ox, oy;
@@ -489,7 +532,7 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         m_firstAxis = taps_on_x ? 0 : 1;
         m_firstSwap = swap;
         if (!m_firstJinc) {
-            if ((hr = UploadTaps(hx, m_tapsXi, m_tapsXw, m_tapsXs, &m_tapsX))) return hr;
+            if ((hr = UploadTaps(hx, m_tapsXi, m_tapsXw, m_tapsXs, m_tapsXb, ox, &m_tapsX))) return hr;
             if ((hr = UploadIndex(ox, m_otherX))) return hr;
         }
     }
@@ -497,13 +540,14 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         // m_TexResize: fp16, dst width x (source extent along screen y) (:3143-3160); the second draw is unrotated
         const int mh = m_plan.mid_h;
         if ((hr = CheckHip(m_TexResize.CheckCreate((size_t)w2 * 8 * mh), "m_TexResize"))) return hr;
+        m_midBytes = (size_t)w2 * 8 * mh;
         m_secondJinc = m_plan.ry.kind == RS_UP && m_plan.ry.method == MPCVR_UPSCALE_Jinc2;
         m_secondCoords = DrawCoords{0, w2, 0, 1.0f, 0, mh, 0, (float)mh / (float)h2, 0};
         if (!m_secondJinc) {
             if (!BuildAxisTaps(m_plan.ry, 0, mh, h2, mh, m_cfg.flags, &hy))
                 return Fail(MPCVR_E_NOTIMPL, "resize ratio outside the supported range");
             BuildPointIndex(0, w2, w2, w2, &oy);     // Y pass: columns map 1:1
-            if ((hr = UploadTaps(hy, m_tapsYi, m_tapsYw, m_tapsYs, &m_tapsY))) return hr;
+            if ((hr = UploadTaps(hy, m_tapsYi, m_tapsYw, m_tapsYs, m_tapsYb, oy, &m_tapsY))) return hr;
             if ((hr = UploadIndex(oy, m_otherY))) return hr;
         }
     }
@@ -532,6 +576,29 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         m_plan.fused_up2x = FusedUp2xSupported(fp);
     }
     m_planDirty = false;
+    UseLane(0);
+    return MPCVR_S_OK;
+}
+
+void CHipVideoProcessor::UseLane(int lane)
+{
+    if (lane == 0) { m_run = m_stream; m_runConv = m_TexConvertOutput.ptr; m_runMid = m_TexResize.ptr; m_runPost = m_TexPost.ptr; return; }
+    Lane &l = m_lanes[lane];
+    m_run = l.stream; m_runConv = l.conv.ptr; m_runMid = l.mid.ptr; m_runPost = l.post.ptr;
+}
+
+HRESULT CHipVideoProcessor::PrepareLanes(int lanes)
+{
+    HRESULT hr;
+    if (!m_fork && (hr = CheckHip(hipEventCreateWithFlags(&m_fork, hipEventDisableTiming), "fork event"))) return hr;
+    for (int i = 1; i < lanes; i++) {
+        Lane &l = m_lanes[i];
+        if (!l.stream && (hr = CheckHip(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking), "lane stream"))) return hr;
+        if (!l.done && (hr = CheckHip(hipEventCreateWithFlags(&l.done, hipEventDisableTiming), "lane event"))) return hr;
+        if (m_convBytes && (hr = CheckHip(l.conv.CheckCreate(m_convBytes), "lane convert output"))) return hr;
+        if (m_midBytes && (hr = CheckHip(l.mid.CheckCreate(m_midBytes), "lane resize texture"))) return hr;
+        if (m_postBytes && (hr = CheckHip(l.post.CheckCreate(m_postBytes), "lane post-scale texture"))) return hr;
+    }
     return MPCVR_S_OK;
 }
 
@@ -707,36 +774,37 @@ HRESULT CHipVideoProcessor::ConvertColorPass(const uint8_t *sample)
 {
     ConvertParams P;
     FillConvertParams(sample, &P);
-    Surface out{m_TexConvertOutput.ptr, (int)(m_srcRectWidth * SurfBytesPerPixel(m_plan.internal_fmt)),
+    Surface out{m_runConv, (int)(m_srcRectWidth * SurfBytesPerPixel(m_plan.internal_fmt)),
                 m_srcRectWidth, m_srcRectHeight, m_plan.internal_fmt};
-    return CheckHip(LaunchConvert(P, out, m_stream), "k_convert");
+    return CheckHip(LaunchConvert(P, out, m_run, (m_cfg.flags & MPCVR_FLAG_NO_FUSED) != 0), "k_convert");
 }
 
 // ResizeShaderPass (:3103-3187) with FinalPass (:3189-3233) folded into the epilogue of the last draw
 HRESULT CHipVideoProcessor::ResizeShaderPass(void *rt, int rtPitch, const uint8_t *sample)
 {
     const int w1 = m_srcRectWidth, h1 = m_srcRectHeight, w2 = m_videoRect.Width(), h2 = m_videoRect.Height();
-    Surface conv{m_TexConvertOutput.ptr, (int)(w1 * SurfBytesPerPixel(m_plan.internal_fmt)), w1, h1, m_plan.internal_fmt};
+    Surface conv{m_runConv, (int)(w1 * SurfBytesPerPixel(m_plan.internal_fmt)), w1, h1, m_plan.internal_fmt};
     if (!m_plan.convert)      // pInputTexture = &m_TexSrcVideo (:3321-3323)
         conv = Surface{(void *)sample, TexPitch(), m_srcWidth, m_srcHeight, RgbTexFmt(*m_srcParams)};
     const StoreParams final = MakeStore(rt, rtPitch, m_plan.swap_fmt, true);
     // with the HDR10 tone-mapping step the resize draws into a post-scale texture (internal format, video-rect sized)
     // and the step itself writes the render target / runs the final pass (:3359-3367)
-    Surface post{m_TexPost.ptr, (int)(w2 * SurfBytesPerPixel(m_plan.internal_fmt)), w2, h2, m_plan.internal_fmt};
+    Surface post{m_runPost, (int)(w2 * SurfBytesPerPixel(m_plan.internal_fmt)), w2, h2, m_plan.internal_fmt};
     const StoreParams last = m_plan.hdr_tonemap ? MakeStore(post.ptr, post.pitch, m_plan.internal_fmt, false) : final;
     HRESULT hr = MPCVR_S_OK;
     bool drawn = true;
+    const bool plain = (m_cfg.flags & MPCVR_FLAG_NO_FUSED) != 0;      // keep the whole path on the one-kernel-fits-all versions
     if (m_plan.two_pass) {
-        Surface mid{m_TexResize.ptr, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
+        Surface mid{m_runMid, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
         StoreParams st = MakeStore(mid.ptr, mid.pitch, SF_RGBA16F, false);
-        if (m_firstJinc) hr = CheckHip(LaunchJinc2(conv, m_firstCoords, w2, m_plan.mid_h, st, m_stream), "k_jinc2");
-        else hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, m_plan.mid_h, st, m_stream), "k_resize<first>");
+        if (m_firstJinc) hr = CheckHip(LaunchJinc2(conv, m_firstCoords, w2, m_plan.mid_h, st, m_run), "k_jinc2");
+        else hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, m_plan.mid_h, st, m_run, plain), "k_resize<first>");
         if (hr) return hr;
-        if (m_secondJinc) hr = CheckHip(LaunchJinc2(mid, m_secondCoords, w2, h2, last, m_stream), "k_jinc2");
-        else hr = CheckHip(LaunchResize(1, false, mid, m_tapsY, (const int32_t *)m_otherY.ptr, w2, h2, last, m_stream), "k_resize<Y>");
+        if (m_secondJinc) hr = CheckHip(LaunchJinc2(mid, m_secondCoords, w2, h2, last, m_run), "k_jinc2");
+        else hr = CheckHip(LaunchResize(1, false, mid, m_tapsY, (const int32_t *)m_otherY.ptr, w2, h2, last, m_run, plain), "k_resize<Y>");
     } else if (m_plan.one_pass) {
-        if (m_firstJinc) hr = CheckHip(LaunchJinc2(conv, m_firstCoords, w2, h2, last, m_stream), "k_jinc2");
-        else hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, h2, last, m_stream), "k_resize<one>");
+        if (m_firstJinc) hr = CheckHip(LaunchJinc2(conv, m_firstCoords, w2, h2, last, m_run), "k_jinc2");
+        else hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, h2, last, m_run, plain), "k_resize<one>");
     } else {
         drawn = false;
         if (!m_plan.convert) {    // the next step reads the source rect of the texture (pTex = pInputTexture, :3352)
@@ -747,11 +815,11 @@ HRESULT CHipVideoProcessor::ResizeShaderPass(void *rt, int rtPitch, const uint8_
         if (!m_plan.hdr_tonemap) {
             StoreParams direct = final;
             if (!m_plan.convert) direct.mid_fmt = conv.fmt;   // nothing was drawn into m_TexsPostScale: the final pass sees the texture's own precision
-            return CheckHip(LaunchCopy(conv, w2, h2, direct, m_stream), "k_copy");
+            return CheckHip(LaunchCopy(conv, w2, h2, direct, m_run), "k_copy");
         }
     }
     if (hr || !m_plan.hdr_tonemap) return hr;
-    return CheckHip(LaunchHdr10ToneMap(drawn ? post : conv, m_hdrTm, w2, h2, final, m_stream), "k_hdr10_tonemap");
+    return CheckHip(LaunchHdr10ToneMap(drawn ? post : conv, m_hdrTm, w2, h2, final, m_run), "k_hdr10_tonemap");
 }
 
 HRESULT CHipVideoProcessor::ProcessOne(const uint8_t *sample, void *rt, int rtPitch)
@@ -762,7 +830,12 @@ HRESULT CHipVideoProcessor::ProcessOne(const uint8_t *sample, void *rt, int rtPi
         FillFusedParams(sample, rt, rtPitch, &fp);
         if (((uintptr_t)sample & 3) != 0) fp.fast_convert = 0;
         const FusedFrame fr{sample, rt};        // a single frame travels by value in the kernel arguments
-        return CheckHip(LaunchFusedUp2x(fp, nullptr, fr, 1, m_stream), "k_fused_up2x");
+        return CheckHip(LaunchFusedUp2x(fp, nullptr, fr, 1, m_run), "k_fused_up2x");
+    }
+    if (m_plan.direct_convert) {
+        ConvertParams P;
+        FillConvertParams(sample, &P);
+        return CheckHip(LaunchConvertDirect(P, MakeStore(rt, rtPitch, m_plan.swap_fmt, true), m_run), "k_convert_direct");
     }
     if (m_plan.convert && (hr = ConvertColorPass(sample))) return hr;
     return ResizeShaderPass(rt, rtPitch, sample);
@@ -781,6 +854,7 @@ HRESULT CHipVideoProcessor::Process(void *pRenderTarget, int rtPitch, const CRec
     if (dstRect && !dstRect->IsRectNull()) { if ((hr = SetVideoRect(*dstRect))) return hr; }
     if (rtPitch < m_windowRect.Width() * 4) return Fail(MPCVR_E_INVALIDARG, "render-target pitch smaller than a row");
     if (m_planDirty && (hr = UpdatePlan())) return hr;
+    UseLane(0);
     (void)hipEventRecord(m_evStart, m_stream);
     hr = ProcessOne(m_curSample, pRenderTarget, rtPitch);
     (void)hipEventRecord(m_evStop, m_stream);
@@ -800,12 +874,28 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
     for (int i = 0; i < n; i++)
         if (!srcs[i] || !dsts[i]) return Fail(MPCVR_E_POINTER, "null frame in batch");
     if (!m_plan.fused_up2x) {
+        // samples that are repacked first share m_TexSrcVideo: those batches stay on the context stream
+        const bool repack = m_srcParams->cformat == MPCVR_CF_V210 || m_srcParams->layout == LAY_RGB;
+        const int lanes = (repack || n < 2) ? 1 : std::min(n, (int)kLanes);
+        if (lanes > 1 && (hr = PrepareLanes(lanes))) return hr;
         (void)hipEventRecord(m_evStart, m_stream);
-        for (int i = 0; i < n; i++) {
-            const uint8_t *tex;
-            if ((hr = PrepareSample((const uint8_t *)srcs[i], &tex))) return hr;
-            if ((hr = ProcessOne(tex, dsts[i], rtPitch))) return hr;
+        if (lanes > 1) {
+            if ((hr = CheckHip(hipEventRecord(m_fork, m_stream), "fork"))) return hr;
+            for (int l = 1; l < lanes; l++)
+                if ((hr = CheckHip(hipStreamWaitEvent(m_lanes[l].stream, m_fork, 0), "lane fork"))) return hr;
         }
+        for (int i = 0; i < n && !hr; i++) {
+            const uint8_t *tex;
+            UseLane(i % lanes);
+            if ((hr = PrepareSample((const uint8_t *)srcs[i], &tex))) break;
+            hr = ProcessOne(tex, dsts[i], rtPitch);
+        }
+        UseLane(0);
+        for (int l = 1; l < lanes; l++) {        // join, also on the error path: the context stream stays the only handle
+            (void)hipEventRecord(m_lanes[l].done, m_lanes[l].stream);
+            (void)hipStreamWaitEvent(m_stream, m_lanes[l].done, 0);
+        }
+        if (hr) return hr;
         (void)hipEventRecord(m_evStop, m_stream);
         m_timed = true;
         return MPCVR_S_OK;

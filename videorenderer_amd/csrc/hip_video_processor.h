@@ -87,7 +87,7 @@ private:
     HRESULT ConvertColorPass(const uint8_t *sample);     // :3048
     HRESULT ResizeShaderPass(void *rt, int rtPitch, const uint8_t *sample);     // :3103 (+ FinalPass :3189 fused into the last draw)
     HRESULT ProcessOne(const uint8_t *sample, void *rt, int rtPitch);
-    HRESULT UploadTaps(const HostAxisTaps &h, DevBuffer &bi, DevBuffer &bw, DevBuffer &bs, AxisTaps *out);
+    HRESULT UploadTaps(const HostAxisTaps &h, DevBuffer &bi, DevBuffer &bw, DevBuffer &bs, DevBuffer &bb, const std::vector<int32_t> &other, AxisTaps *out);
     HRESULT UploadIndex(const std::vector<int32_t> &v, DevBuffer &b);
     bool ConvertEnabled() const;                       // m_PSConvColorData.bEnable (:849-853)
     int TexPitch() const;                              // row pitch of the source texture (differs from the sample's for v210)
@@ -179,7 +179,7 @@ private:
     DevBuffer m_pqLut;             // kPqLutSize floats (fused path tone-map table)
     float m_pqLutHost[kPqLutSize];
     bool m_pqLutValid = false;
-    DevBuffer m_tapsXi, m_tapsXw, m_tapsXs, m_tapsYi, m_tapsYw, m_tapsYs, m_otherX, m_otherY;
+    DevBuffer m_tapsXi, m_tapsXw, m_tapsXs, m_tapsYi, m_tapsYw, m_tapsYs, m_otherX, m_otherY, m_tapsXb, m_tapsYb;
     AxisTaps m_tapsX{}, m_tapsY{};
     // ring of frame-table slots for mpcvr_process_batch (pinned host copy + device copy + completion event)
     static constexpr int kFrameSlots = 4;
@@ -187,6 +187,19 @@ private:
     FrameSlot m_slots[kFrameSlots];
     int m_slotNext = 0;
     uint16_t m_ditherHost[1024];
+    // mpcvr_process_batch on the pass-per-kernel path: the frames of a batch are independent, so they are dealt to a few
+    // lanes (stream + private intermediates) whose kernels overlap — a 20 us launch alone cannot keep 256 CUs busy through
+    // its ramp-up and drain.  Lane 0 is the context stream with m_TexConvertOutput / m_TexResize / m_TexPost.
+    static constexpr int kLanes = 4;
+    struct Lane { hipStream_t stream = nullptr; DevBuffer conv, mid, post; hipEvent_t done = nullptr; };
+    Lane m_lanes[kLanes];
+    hipEvent_t m_fork = nullptr;
+    size_t m_convBytes = 0, m_midBytes = 0, m_postBytes = 0;
+    // resources of the frame being processed (lane 0 outside ProcessBatch)
+    hipStream_t m_run = nullptr;
+    void *m_runConv = nullptr, *m_runMid = nullptr, *m_runPost = nullptr;
+    void UseLane(int lane);
+    HRESULT PrepareLanes(int lanes);
 };
 
 }  // namespace mpcvr

@@ -7,6 +7,8 @@
 
 #include "vp_convert.h"
 #include "vp_device.h"
+#include <cstdlib>
+
 #include "vp_launch.h"
 
 namespace mpcvr {
@@ -17,6 +19,37 @@ __global__ __launch_bounds__(256) void k_convert(ConvertParams P, Surface out)
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
     if (i >= P.out_w || j >= P.out_h) return;
     store_surface(out.ptr, out.pitch, out.fmt, i, j, convert_pixel(P, i, j));
+}
+
+// ConvertColorPass + the copy / FinalPass that follows it when nothing is resized (Process :3321-3367 with no resize draw):
+// the value takes the rounding of m_TexConvertOutput in registers and goes straight into the last draw's epilogue
+__global__ __launch_bounds__(256) void k_convert_direct(ConvertParams P, StoreParams st)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= P.out_w || j >= P.out_h) return;
+    store_epilogue(st, i, j, round_to_fmt(convert_pixel(P, i, j), P.out_fmt));
+}
+
+// The same two kernels with the source description folded at compile time for the everyday sources — planar / bi-planar
+// 4:2:0 with bilinear chroma, progressive, no Dolby Vision: the D3D11 path compiles one shader per such combination
+// (GetShaderConvertColor); here the combination becomes template arguments, the per-pixel arithmetic is the generic code's,
+// expression for expression, and only the never-taken branches disappear.
+// OFMT = format of m_TexConvertOutput; DMODE 0: store into it, 1: ST_SURFACE epilogue into the render target (format DFMT),
+// 2: ST_FINAL epilogue (final pass) into the render target.
+template <int PLANES, int BYTES, int TAIL, int OFMT, int DMODE, int DFMT>
+__global__ __launch_bounds__(256) void k_convert_420(ConvertParams P, Surface out, StoreParams st)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= P.out_w || j >= P.out_h) return;
+    P.fmt.layout = LAY_PLANAR; P.fmt.planes = PLANES; P.fmt.bytes = BYTES;
+    P.fmt.subsampling = 420; P.fmt.div_w = 2; P.fmt.div_h = 2;
+    P.chroma_scaling = 1; P.blend_deint = 0; P.dovi = nullptr; P.tail = TAIL;
+    if (BYTES == 1 || PLANES == 2) P.fmt.shift = 0;
+    const f3 v = convert_pixel(P, i, j);
+    if (DMODE == 0) { store_surface(out.ptr, out.pitch, OFMT, i, j, v); return; }
+    st.mode = DMODE == 2 ? ST_FINAL : ST_SURFACE; st.mid_fmt = OFMT; st.dst_fmt = DFMT;
+    st.quant = DFMT == SF_RGB10A2 ? 1023 : 255;
+    store_epilogue(st, i, j, round_to_fmt(v, OFMT));
 }
 
 // TextureResizeShader — DX11VideoProcessor.cpp:332-377 with ps_interpolation_* / ps_convolution.
@@ -48,6 +81,143 @@ __global__ __launch_bounds__(256) void k_resize(Surface in, AxisTaps taps, const
         acc.x = acc.x / ww; acc.y = acc.y / ww; acc.z = acc.z / ww;
     }
     store_epilogue(st, x, y, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// the same draw, folded: tap count, source format and epilogue at compile time; the arithmetic per output pixel is
+// k_resize's, expression for expression (first tap a product, then acc + w*q in tap order).
+// ------------------------------------------------------------------------------------------------
+enum EpiCode : int { EPI_RUNTIME = 0, EPI_TO_FP16 = 1, EPI_FINAL_10_TO_8 = 2, EPI_FINAL_16F_TO_8 = 3, EPI_FINAL_16F_TO_10 = 4,
+                     EPI_TO_BGRA8 = 5, EPI_TO_RGB10 = 6 };
+template <int EPI>
+__device__ __forceinline__ void store_epi(StoreParams st, int x, int y, f3 v)
+{
+    if (EPI == EPI_TO_FP16) { st.mode = ST_SURFACE; st.dst_fmt = SF_RGBA16F; }
+    if (EPI == EPI_FINAL_10_TO_8) { st.mode = ST_FINAL; st.mid_fmt = SF_RGB10A2; st.dst_fmt = SF_BGRA8; st.quant = 255; }
+    if (EPI == EPI_FINAL_16F_TO_8) { st.mode = ST_FINAL; st.mid_fmt = SF_RGBA16F; st.dst_fmt = SF_BGRA8; st.quant = 255; }
+    if (EPI == EPI_FINAL_16F_TO_10) { st.mode = ST_FINAL; st.mid_fmt = SF_RGBA16F; st.dst_fmt = SF_RGB10A2; st.quant = 1023; }
+    if (EPI == EPI_TO_BGRA8) { st.mode = ST_SURFACE; st.dst_fmt = SF_BGRA8; }
+    if (EPI == EPI_TO_RGB10) { st.mode = ST_SURFACE; st.dst_fmt = SF_RGB10A2; }
+    store_epilogue(st, x, y, v);
+}
+static int EpiOf(const StoreParams &st)
+{
+    if (st.mode == ST_SURFACE) return st.dst_fmt == SF_RGBA16F ? EPI_TO_FP16 : st.dst_fmt == SF_BGRA8 ? EPI_TO_BGRA8 : st.dst_fmt == SF_RGB10A2 ? EPI_TO_RGB10 : EPI_RUNTIME;
+    if (st.mid_fmt == SF_RGB10A2 && st.dst_fmt == SF_BGRA8 && st.quant == 255) return EPI_FINAL_10_TO_8;
+    if (st.mid_fmt == SF_RGBA16F && st.dst_fmt == SF_BGRA8 && st.quant == 255) return EPI_FINAL_16F_TO_8;
+    if (st.mid_fmt == SF_RGBA16F && st.dst_fmt == SF_RGB10A2 && st.quant == 1023) return EPI_FINAL_16F_TO_10;
+    return EPI_RUNTIME;
+}
+
+// Both kernels give a thread several output pixels: a wave that loads its arguments, its taps, one texel per tap and the
+// dither texel in sequence and then retires spends its life waiting (four dependent memory latencies for ~85 ALU
+// instructions) and the launch becomes latency x (waves / waves in flight); with 4 pixels per thread every one of those
+// latencies is shared by 4x the loads.
+//
+// taps run down the texture rows, columns map 1:1 (the second draw of every two-pass resize, or a Y-only resize): one
+// output row per block row, so the tap indices and weights of the row are wave-uniform (scalar loads) and every tap
+// is one fully coalesced row read.  A thread owns 4 consecutive columns.
+template <int NT, int INFMT, int EPI, int PX>
+__global__ __launch_bounds__(256) void k_resize_rows(Surface in, AxisTaps taps, int out_w, int out_h, int gx, StoreParams st)
+{
+    // workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give XCD k the k-th contiguous band of
+    // output rows (its taps then re-read rows its own L2 already holds) instead of every 8th row.  1-D grid of
+    // 8 * ceil(gx * out_h / 8) workgroups; logical id = (id mod 8) * (grid / 8) + id / 8 is a bijection on it.
+    const int per = gridDim.x >> 3, lid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int y = lid / gx, bx = lid - y * gx;
+    if (y >= out_h) return;
+    // pixel p of a thread sits 256 columns after pixel p-1: every load of a wave stays one contiguous row segment
+    const int x0 = bx * (256 * PX) + threadIdx.x;
+    if (x0 >= out_w) return;
+    const int nt = NT ? NT : taps.ntaps;
+    const int32_t *idx = taps.idx + (size_t)y * nt;
+    const float *w = taps.w + (size_t)y * nt;
+    in.fmt = INFMT;
+    int xs[PX];
+    f3 acc[PX];
+#pragma unroll
+    for (int p = 0; p < PX; p++) xs[p] = min(x0 + p * 256, out_w - 1);
+#pragma unroll
+    for (int p = 0; p < PX; p++) {
+        const f3 q = load_surface(in, xs[p], idx[0]);
+        acc[p].x = w[0] * q.x; acc[p].y = w[0] * q.y; acc[p].z = w[0] * q.z;
+    }
+#pragma unroll
+    for (int k = 1; k < nt; k++) {
+#pragma unroll
+        for (int p = 0; p < PX; p++) {
+            const f3 q = load_surface(in, xs[p], idx[k]);
+            acc[p].x = acc[p].x + w[k] * q.x; acc[p].y = acc[p].y + w[k] * q.y; acc[p].z = acc[p].z + w[k] * q.z;
+        }
+    }
+    if (taps.normalise) {
+        const float ww = taps.wsum[y];
+#pragma unroll
+        for (int p = 0; p < PX; p++) { acc[p].x = acc[p].x / ww; acc[p].y = acc[p].y / ww; acc[p].z = acc[p].z / ww; }
+    }
+#pragma unroll
+    for (int p = 0; p < PX; p++)
+        if (x0 + p * 256 < out_w) store_epi<EPI>(st, x0 + p * 256, y, acc[p]);
+}
+
+// taps run along the texture columns: a wave owns 64 consecutive outputs of 4 rows, decodes the source texels they touch
+// ONCE into LDS (taps.blk_lo / blk_span, built with the table) and then reads its taps from there, instead of decoding
+// every texel once per tap that uses it; the tap table of an output column is read once for the 4 rows.
+template <int NT, int INFMT, int EPI>
+__global__ __launch_bounds__(256) void k_resize_cols(Surface in, AxisTaps taps, const int32_t *__restrict__ other,
+                                                    int out_w, int out_h, StoreParams st)
+{
+    constexpr int R = 4;
+    __shared__ float4 tile[4][R][kResizeSpanMax];
+    const int lane = threadIdx.x, wv = threadIdx.y;
+    const int x = blockIdx.x * 64 + lane, yb = blockIdx.y * (4 * R) + wv * R;
+    const int nt = NT ? NT : taps.ntaps;
+    in.fmt = INFMT;
+    const int lo = taps.blk_lo[blockIdx.x];
+    const int hi = min(lo + taps.blk_span, in.w);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if (yb + r < out_h) {
+            const int o = other[yb + r];
+            for (int p = lo + lane; p < hi; p += 64) {
+                const f3 q = load_surface(in, p, o);
+                tile[wv][r][p - lo] = make_float4(q.x, q.y, q.z, 0.0f);
+            }
+        }
+    }
+    __syncthreads();
+    if (x >= out_w) return;
+    const int32_t *idx = taps.idx_t + x;
+    const float *w = taps.w_t + x;
+    const size_t n = (size_t)taps.n_out;
+    f3 acc[R];
+    {
+        const int i0 = idx[0] - lo;
+        const float w0 = w[0];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const float4 q = tile[wv][r][i0];
+            acc[r].x = w0 * q.x; acc[r].y = w0 * q.y; acc[r].z = w0 * q.z;
+        }
+    }
+#pragma unroll
+    for (int k = 1; k < nt; k++) {
+        const int ik = idx[k * n] - lo;
+        const float wk = w[k * n];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const float4 q = tile[wv][r][ik];
+            acc[r].x = acc[r].x + wk * q.x; acc[r].y = acc[r].y + wk * q.y; acc[r].z = acc[r].z + wk * q.z;
+        }
+    }
+    if (taps.normalise) {
+        const float ww = taps.wsum[x];
+#pragma unroll
+        for (int r = 0; r < R; r++) { acc[r].x = acc[r].x / ww; acc[r].y = acc[r].y / ww; acc[r].z = acc[r].z / ww; }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        if (yb + r < out_h) store_epi<EPI>(st, x, yb + r, acc[r]);
 }
 
 // ps_resize_onepass_jinc2.hlsl:44-101 ("Jinc2m"): one 2-D draw — 4x4 texels around the sample position weighted by the
@@ -204,15 +374,112 @@ hipError_t LaunchRepackV210(const uint8_t *src, int src_pitch, uint8_t *dst, int
     return hipGetLastError();
 }
 
-hipError_t LaunchConvert(const ConvertParams &P, const Surface &out, hipStream_t s)
+// picks the folded instantiation of k_convert_420 for this source / destination, or returns false
+template <int OFMT, int DMODE, int DFMT>
+static void LaunchConvert420T(const ConvertParams &P, const Surface &out, const StoreParams &st, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_convert, grid2d(P.out_w, P.out_h), dim3(64, 4, 1), 0, s, P, out);
+    const dim3 g = grid2d(P.out_w, P.out_h), b(64, 4, 1);
+#define MPCVR_C420(PL, BY, TL) hipLaunchKernelGGL((k_convert_420<PL, BY, TL, OFMT, DMODE, DFMT>), g, b, 0, s, P, out, st)
+#define MPCVR_C420_T(PL, BY) \
+    switch (P.tail) { case TAIL_NONE: MPCVR_C420(PL, BY, TAIL_NONE); break; case TAIL_PQ_TO_SDR: MPCVR_C420(PL, BY, TAIL_PQ_TO_SDR); break; \
+                      case TAIL_HLG_TO_SDR: MPCVR_C420(PL, BY, TAIL_HLG_TO_SDR); break; default: MPCVR_C420(PL, BY, TAIL_GAMMA_GAMUT); break; }
+    if (P.fmt.planes == 2) { if (P.fmt.bytes == 1) { MPCVR_C420_T(2, 1) } else { MPCVR_C420_T(2, 2) } }
+    else                   { if (P.fmt.bytes == 1) { MPCVR_C420_T(3, 1) } else { MPCVR_C420_T(3, 2) } }
+#undef MPCVR_C420_T
+#undef MPCVR_C420
+}
+
+static bool Convert420Eligible(const ConvertParams &P)
+{
+    return P.fmt.layout == LAY_PLANAR && P.fmt.subsampling == 420 && P.fmt.div_w == 2 && P.fmt.div_h == 2 && P.chroma_scaling == 1 &&
+           !P.blend_deint && !P.dovi && (P.fmt.planes == 2 || P.fmt.planes == 3) && (P.fmt.bytes == 1 || P.fmt.bytes == 2) &&
+           P.tail >= TAIL_NONE && P.tail <= TAIL_GAMMA_GAMUT;
+}
+
+hipError_t LaunchConvert(const ConvertParams &P, const Surface &out, hipStream_t s, bool generic)
+{
+    const StoreParams none{};
+    if (!generic && Convert420Eligible(P) && out.fmt == P.out_fmt) {
+        if (out.fmt == SF_BGRA8) LaunchConvert420T<SF_BGRA8, 0, 0>(P, out, none, s);
+        else if (out.fmt == SF_RGB10A2) LaunchConvert420T<SF_RGB10A2, 0, 0>(P, out, none, s);
+        else if (out.fmt == SF_RGBA16F) LaunchConvert420T<SF_RGBA16F, 0, 0>(P, out, none, s);
+        else generic = true;
+    } else generic = true;
+    if (generic) hipLaunchKernelGGL(k_convert, grid2d(P.out_w, P.out_h), dim3(64, 4, 1), 0, s, P, out);
     return hipGetLastError();
 }
 
-hipError_t LaunchResize(int axis, bool swap, const Surface &in, const AxisTaps &taps, const int32_t *other,
-                        int out_w, int out_h, const StoreParams &st, hipStream_t s)
+hipError_t LaunchConvertDirect(const ConvertParams &P, const StoreParams &st, hipStream_t s)
 {
+    const Surface none{};
+    bool done = false;
+    if (Convert420Eligible(P) && st.mid_fmt == P.out_fmt && st.quant == (st.dst_fmt == SF_RGB10A2 ? 1023 : 255)) {
+        const int o = P.out_fmt, d = st.dst_fmt;
+        done = true;
+        if (st.mode == ST_FINAL && o == SF_RGB10A2 && d == SF_BGRA8) LaunchConvert420T<SF_RGB10A2, 2, SF_BGRA8>(P, none, st, s);
+        else if (st.mode == ST_FINAL && o == SF_RGBA16F && d == SF_BGRA8) LaunchConvert420T<SF_RGBA16F, 2, SF_BGRA8>(P, none, st, s);
+        else if (st.mode == ST_FINAL && o == SF_RGBA16F && d == SF_RGB10A2) LaunchConvert420T<SF_RGBA16F, 2, SF_RGB10A2>(P, none, st, s);
+        else if (st.mode == ST_SURFACE && o == SF_BGRA8 && d == SF_BGRA8) LaunchConvert420T<SF_BGRA8, 1, SF_BGRA8>(P, none, st, s);
+        else if (st.mode == ST_SURFACE && o == SF_RGB10A2 && d == SF_RGB10A2) LaunchConvert420T<SF_RGB10A2, 1, SF_RGB10A2>(P, none, st, s);
+        else done = false;
+    }
+    if (!done) hipLaunchKernelGGL(k_convert_direct, grid2d(P.out_w, P.out_h), dim3(64, 4, 1), 0, s, P, st);
+    return hipGetLastError();
+}
+
+// folded instantiations: NT in {4, 6, runtime}, INFMT in {UNORM8, UNORM10, fp16}, every EpiCode
+template <int NT, int INFMT, int EPI>
+static void LaunchResizeFast(bool rows, const Surface &in, const AxisTaps &taps, const int32_t *other, int out_w, int out_h,
+                             const StoreParams &st, hipStream_t s)
+{
+    static const int px = getenv("MPCVR_ROWS_PX") ? atoi(getenv("MPCVR_ROWS_PX")) : 2;
+    if (rows) {
+        const int per = 256 * px, gx = (out_w + per - 1) / per, grid = (gx * out_h + 7) / 8 * 8;
+        if (px == 1) hipLaunchKernelGGL((k_resize_rows<NT, INFMT, EPI, 1>), dim3(grid, 1, 1), dim3(256, 1, 1), 0, s, in, taps, out_w, out_h, gx, st);
+        else if (px == 2) hipLaunchKernelGGL((k_resize_rows<NT, INFMT, EPI, 2>), dim3(grid, 1, 1), dim3(256, 1, 1), 0, s, in, taps, out_w, out_h, gx, st);
+        else hipLaunchKernelGGL((k_resize_rows<NT, INFMT, EPI, 4>), dim3(grid, 1, 1), dim3(256, 1, 1), 0, s, in, taps, out_w, out_h, gx, st);
+    }
+    else hipLaunchKernelGGL((k_resize_cols<NT, INFMT, EPI>), dim3((out_w + 63) / 64, (out_h + 15) / 16, 1), dim3(64, 4, 1), 0, s, in, taps, other, out_w, out_h, st);
+}
+template <int NT, int INFMT>
+static bool LaunchResizeFastE(int epi, bool rows, const Surface &in, const AxisTaps &taps, const int32_t *other, int out_w, int out_h,
+                              const StoreParams &st, hipStream_t s)
+{
+    switch (epi) {
+    case EPI_TO_FP16: LaunchResizeFast<NT, INFMT, EPI_TO_FP16>(rows, in, taps, other, out_w, out_h, st, s); return true;
+    case EPI_FINAL_10_TO_8: LaunchResizeFast<NT, INFMT, EPI_FINAL_10_TO_8>(rows, in, taps, other, out_w, out_h, st, s); return true;
+    case EPI_FINAL_16F_TO_8: LaunchResizeFast<NT, INFMT, EPI_FINAL_16F_TO_8>(rows, in, taps, other, out_w, out_h, st, s); return true;
+    case EPI_FINAL_16F_TO_10: LaunchResizeFast<NT, INFMT, EPI_FINAL_16F_TO_10>(rows, in, taps, other, out_w, out_h, st, s); return true;
+    case EPI_TO_BGRA8: LaunchResizeFast<NT, INFMT, EPI_TO_BGRA8>(rows, in, taps, other, out_w, out_h, st, s); return true;
+    case EPI_TO_RGB10: LaunchResizeFast<NT, INFMT, EPI_TO_RGB10>(rows, in, taps, other, out_w, out_h, st, s); return true;
+    default: return false;
+    }
+}
+template <int INFMT>
+static bool LaunchResizeFastN(int epi, bool rows, const Surface &in, const AxisTaps &taps, const int32_t *other, int out_w, int out_h,
+                              const StoreParams &st, hipStream_t s)
+{
+    if (taps.ntaps == 4) return LaunchResizeFastE<4, INFMT>(epi, rows, in, taps, other, out_w, out_h, st, s);
+    if (taps.ntaps == 6) return LaunchResizeFastE<6, INFMT>(epi, rows, in, taps, other, out_w, out_h, st, s);
+    return LaunchResizeFastE<0, INFMT>(epi, rows, in, taps, other, out_w, out_h, st, s);
+}
+
+hipError_t LaunchResize(int axis, bool swap, const Surface &in, const AxisTaps &taps, const int32_t *other,
+                        int out_w, int out_h, const StoreParams &st, hipStream_t s, bool generic)
+{
+    if (!generic && !swap) {
+        // taps along screen y with a 1:1 column map -> row kernel; taps along screen x with a block table -> column kernel
+        const bool rows = axis == 1 && taps.other_identity;
+        const bool cols = axis == 0 && taps.blk_lo && taps.idx_t && taps.blk_span > 0 && taps.blk_span <= kResizeSpanMax;
+        const int epi = EpiOf(st);
+        if ((rows || cols) && epi != EPI_RUNTIME) {
+            bool done = false;
+            if (in.fmt == SF_BGRA8) done = LaunchResizeFastN<SF_BGRA8>(epi, rows, in, taps, other, out_w, out_h, st, s);
+            else if (in.fmt == SF_RGB10A2) done = LaunchResizeFastN<SF_RGB10A2>(epi, rows, in, taps, other, out_w, out_h, st, s);
+            else if (in.fmt == SF_RGBA16F) done = LaunchResizeFastN<SF_RGBA16F>(epi, rows, in, taps, other, out_w, out_h, st, s);
+            if (done) return hipGetLastError();
+        }
+    }
     const dim3 g = grid2d(out_w, out_h), b(64, 4, 1);
     if (axis == 0 && !swap) hipLaunchKernelGGL((k_resize<0, false>), g, b, 0, s, in, taps, other, out_w, out_h, st);
     else if (axis == 0)     hipLaunchKernelGGL((k_resize<0, true>), g, b, 0, s, in, taps, other, out_w, out_h, st);

@@ -7,14 +7,16 @@
 namespace mpcvr {
 
 // pass-per-kernel path (vp_kernels.hip)
-hipError_t LaunchConvert(const ConvertParams &P, const Surface &out, hipStream_t s);
+// generic = true: the one-kernel-fits-all version only (MPCVR_FLAG_NO_FUSED keeps the whole path on the plain kernels)
+hipError_t LaunchConvert(const ConvertParams &P, const Surface &out, hipStream_t s, bool generic = false);
+hipError_t LaunchConvertDirect(const ConvertParams &P, const StoreParams &st, hipStream_t s);
 // CopyFrameRGB24 / R210 / RGB48 / BGR48 / BGRA64 / B64A / CopyPlaneAsIs: interleaved RGB sample -> its texture
 hipError_t LaunchRepackRgb(int kind, const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int width, int lines, hipStream_t s);
 // CopyFrameV210 (Helper.cpp:709-748): v210 sample -> Y210-layout texture
 hipError_t LaunchRepackV210(const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int lines, hipStream_t s);
 // axis = screen axis the tap table runs along; swap = rotation 90/270 (taps address the other texture axis)
 hipError_t LaunchResize(int axis, bool swap, const Surface &in, const AxisTaps &taps, const int32_t *other,
-                        int out_w, int out_h, const StoreParams &st, hipStream_t s);
+                        int out_w, int out_h, const StoreParams &st, hipStream_t s, bool generic = false);
 hipError_t LaunchCopy(const Surface &in, int out_w, int out_h, const StoreParams &st, hipStream_t s);
 // ps_hdr10_tonemap.hlsl: HDR10 local tone mapping as a post-scale step
 hipError_t LaunchHdr10ToneMap(const Surface &in, const HdrToneMapParams &tm, int out_w, int out_h, const StoreParams &st, hipStream_t s);

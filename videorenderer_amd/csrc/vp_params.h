@@ -136,7 +136,15 @@ struct AxisTaps {
     const float *wsum;    // [n_out] (only when normalise)
     int ntaps;
     int normalise;        // ps_convolution: avg /= ww
+    // hints for the folded kernels (0 / null: not available, the plain kernel runs)
+    const int32_t *blk_lo;   // [ceil(n_out / 64)] smallest source index any tap of outputs 64b .. 64b+63 touches
+    const int32_t *idx_t;    // [ntaps][n_out] the same tables tap-major: lanes of a wave read consecutive words
+    const float *w_t;
+    int n_out;
+    int blk_span;            // max over blocks of (largest - smallest index + 1); 0 = unknown
+    int other_identity;      // the `other` map of this draw is x -> x (no flip / rotation / source offset)
 };
+enum { kResizeSpanMax = 192 };     // source texels per row one wave stages in LDS for the column-tap kernel (4 rows x 4 waves x 16 B)
 
 // 2x fast path: the two phase-weight sets per axis (t = 0.75 for even outputs, 0.25 for odd)
 struct Up2xWeights {

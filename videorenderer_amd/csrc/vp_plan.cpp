@@ -566,10 +566,11 @@ bool DecidePlan(int iTexFormat, int iChromaScaling, int iUpscaling, int iDownsca
     p.copy_only = !p.two_pass && !p.one_pass;
     // fused 2x candidate: exact 2x on both axes with an interpolation shader, bilinear 4:2:0 chroma,
     // UNORM internal format, destination fully inside the window
-    p.fused_up2x = !(flags & MPCVR_FLAG_NO_FUSED) && g.rotation == 0 && !p.flip && !p.hdr_tonemap && p.two_pass && w2 == 2 * w1 && h2 == 2 * h1 &&
+    p.fused_up2x = !(flags & MPCVR_FLAG_NO_FUSED) && !g.dovi && g.rotation == 0 && !p.flip && !p.hdr_tonemap && p.two_pass && w2 == 2 * w1 && h2 == 2 * h1 &&
                    p.rx.kind == RS_UP && p.ry.kind == RS_UP && f.Subsampling == 420 &&
                    iChromaScaling == MPCVR_CHROMA_Bilinear && p.internal_fmt != SF_RGBA16F &&
                    g.vl >= 0 && g.vt >= 0 && g.vr <= g.ww && g.vb <= g.wh && w1 >= 8 && h1 >= 8 && !(w1 & 1);
+    p.direct_convert = !(flags & MPCVR_FLAG_NO_FUSED) && p.copy_only && p.convert && !p.hdr_tonemap;
     *plan = p;
     return true;
 }
@@ -577,6 +578,7 @@ bool DecidePlan(int iTexFormat, int iChromaScaling, int iUpscaling, int iDownsca
 std::string PassPlan::describe() const
 {
     if (fused_up2x) return "fused_up2x";
+    if (direct_convert) return final_pass ? "direct:convert+final" : "direct:convert+copy";
     std::string s = convert ? "passes:convert" : "passes:source";
     if (two_pass) s += final_pass ? ",resizeX,resizeY+final" : ",resizeX,resizeY";
     else if (one_pass) s += std::string(one_pass_axis == 0 ? ",resizeX" : ",resizeY") + (final_pass ? "+final" : "");

@@ -119,6 +119,8 @@ struct PassPlan {
     int one_pass_axis = 0;
     bool copy_only = false;          // no size change: straight copy / final pass from the convert output
     bool fused_up2x = false;         // eligible for the fused 2x kernel
+    bool direct_convert = false;     // no resize draw and no tone-map step: the convert kernel rounds like m_TexConvertOutput
+                                     // and runs the copy / final pass in its own epilogue (one kernel, no intermediate)
     // rotation-carrying (first) draw — FillVertices :130-179, ResizeShaderPass :3112-3137
     int rotation = 0;                // 0/90/180/270 clockwise
     bool flip = false;               // horizontal flip of the source
@@ -135,7 +137,8 @@ struct PlanGeometry { int w1, h1;            // source rect size (== convert out
                       int ww, wh;            // window size
                       int rotation = 0; int flip = 0;
                       int convert_enabled = 1;      // m_PSConvColorData.bEnable (:849-853)
-                      int hdr_tonemap = 0; };       // m_pPSHDR10ToneMapping exists: one more post-scale step (:785-787)
+                      int hdr_tonemap = 0;          // m_pPSHDR10ToneMapping exists: one more post-scale step (:785-787)
+                      int dovi = 0; };              // m_Dovi.bValid: the convert shader reshapes (the fused 2x kernel has no such stage)
 // Pure decision logic of UpdateTexParams / UpdatePostScaleTexures / ResizeShaderPass (no device work).
 // cfg fields use the Settings_t names; returns false + *why when the combination is not implemented.
 struct mpcvr_settings_fwd;
