@@ -69,9 +69,11 @@ enum { MPCVR_OUT_BGRA8 = 0, MPCVR_OUT_RGB10A2 = 1 };
 
 /* mpcvr_settings.flags */
 #define MPCVR_FLAG_LANCZOS3_FIXED   0x1u  /* use the D3D9 twin's tap layout instead of the D3D11 shader's (quirk Q1) */
-#define MPCVR_FLAG_NO_FUSED         0x2u  /* force the pass-per-kernel path (debug / A-B) */
-#define MPCVR_FLAG_NO_LUT           0x4u  /* fused path: evaluate the PQ->SDR chain in ALU instead of the LDS table */
-#define MPCVR_FLAG_NO_FAST_CONVERT  0x8u  /* fused path: per-pixel generic convert (debug / A-B) */
+#define MPCVR_FLAG_NO_FUSED         0x2u  /* plain pass-per-kernel path only: no fused 2x kernel, no convert+final in one kernel,
+                                             no compile-time-folded kernels, every tail literal (debug / A-B; bit-exact reference) */
+#define MPCVR_FLAG_NO_LUT           0x4u  /* evaluate the PQ->SDR chain in ALU instead of the 4096-entry table (fused and folded kernels) */
+#define MPCVR_FLAG_NO_FAST_CONVERT  0x8u  /* fused 2x kernel off when its vectorised convert would be needed: the folded pass-per-kernel
+                                             path runs instead (debug / A-B) */
 
 /* Subset of Settings_t (IVideoRenderer.h:104-135) that reaches the shader path; same field names. */
 typedef struct mpcvr_settings {

@@ -6,12 +6,15 @@ Tighter where the arithmetic allows it:
   * pass-per-kernel path with a PQ/HLG/gamma tail: <= 1 LSB, >= 99.5 % of channels identical;
   * fused 2x kernel (FMA contraction, LDS tone-map LUT): <= 1 LSB, >= 99 % identical.
 """
+import os
+
 import numpy as np
 import pytest
 
 from tests.golden.cases import GOLDEN_CASES, SETTING_KEYS, case_frame, case_geometry, oracle_params, run_case
 
 pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 BG = 7      # background byte of the render target: pixels outside the video rect must stay untouched
 
@@ -246,6 +249,38 @@ def test_process_batch_equals_single(mpcvr, torch_cuda):
         assert not torch.equal(dsts[0], dsts[1])
         assert vp.GetLastProcessMs() > 0
         vp.close()
+
+
+def test_process_batch_lanes(torch_cuda):
+    """MPCVR_BATCH_LANES=4 (read once per process, hence the subprocess): the frames of a pass-per-kernel batch are dealt to
+    four streams with private intermediates; every frame must equal its single-frame result."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, torch
+        sys.path.insert(0, %r)
+        from tests.golden.cases import GOLDEN_CASES, case_frame, case_geometry
+        from tests.test_parity_gpu import make_vp
+        import videorenderer_amd as V
+        for name in ("down_lanczos_2p5x", "up_1p5x_lanczos3", "c1_nv12_bt709_passthrough", "hdrout_tm2_reinhard"):
+            c = GOLDEN_CASES[name]
+            vp, (ww, wh) = make_vp(V, c)
+            frames = [torch.from_numpy(case_frame(dict(c, seed=c["seed"] + 100 * i))[0]).cuda() for i in range(7)]
+            pitch = vp.GetFrameBytes()[1]
+            singles = []
+            for f in frames:
+                dst = torch.zeros((wh, ww, 4), dtype=torch.uint8, device="cuda")
+                vp.CopySample(f, pitch); vp.Process(dst, ww * 4); singles.append(dst)
+            for rep in range(3):
+                dsts = [torch.zeros((wh, ww, 4), dtype=torch.uint8, device="cuda") for _ in frames]
+                vp.ProcessBatch(frames, dsts, ww * 4)
+                vp.Synchronize()
+                assert all(torch.equal(a, b) for a, b in zip(singles, dsts)), (name, rep)
+            vp.close()
+        print("lanes ok")
+    """) % os.path.dirname(HERE)
+    env = dict(os.environ, MPCVR_BATCH_LANES="4")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "lanes ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_param_blob_roundtrip_and_override(mpcvr, torch_cuda):

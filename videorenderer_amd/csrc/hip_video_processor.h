@@ -187,9 +187,9 @@ private:
     FrameSlot m_slots[kFrameSlots];
     int m_slotNext = 0;
     uint16_t m_ditherHost[1024];
-    // mpcvr_process_batch on the pass-per-kernel path: the frames of a batch are independent, so they are dealt to a few
-    // lanes (stream + private intermediates) whose kernels overlap — a 20 us launch alone cannot keep 256 CUs busy through
-    // its ramp-up and drain.  Lane 0 is the context stream with m_TexConvertOutput / m_TexResize / m_TexPost.
+    // mpcvr_process_batch on the pass-per-kernel path: the frames of a batch are independent, so they can be dealt to a
+    // few lanes (stream + private intermediates) whose kernels overlap (opt-in, MPCVR_BATCH_LANES; see ProcessBatch).
+    // Lane 0 is the context stream with m_TexConvertOutput / m_TexResize / m_TexPost.
     static constexpr int kLanes = 4;
     struct Lane { hipStream_t stream = nullptr; DevBuffer conv, mid, post; hipEvent_t done = nullptr; };
     Lane m_lanes[kLanes];

@@ -145,7 +145,7 @@ __device__ __forceinline__ f3 convert_pixel(const ConvertParams &P, int i, int j
         c = dovi_lms_step(*P.dovi, c);
         return hdr_tail(c, P.tail, P.gamma, P.lum_scale, make_mat3(P.gamut), P.dovi->l2_enabled ? P.dovi->l2k : nullptr);
     }
-    return hdr_tail(c, P.tail, P.gamma, P.lum_scale, make_mat3(P.gamut));
+    return hdr_tail(c, P.tail, P.gamma, P.lum_scale, make_mat3(P.gamut), nullptr, P.tail == TAIL_PQ_TO_SDR ? P.pq_lut : nullptr);
 }
 
 }  // namespace mpcvr

@@ -176,7 +176,18 @@ __device__ __forceinline__ f3 dovi_trims(f3 c, const float *k)
 }
 
 // The tail GetShaderConvertColor appends after "//convert color" — Shaders.cpp:861-923; l2k != null: Dolby Vision L2 trims (:873-877)
-__device__ __forceinline__ f3 hdr_tail(f3 c, int tail, float gamma, float lum_scale, const mat3 &gamut, const float *l2k = nullptr)
+// hable(ST2084ToLinear(x, scale)) / hable(4.8) from the 4096-entry table the fused kernel uses, evaluated the same way
+// (linear interpolation, one FMA): replaces 4 transcendentals and 3 divisions per channel
+__device__ __forceinline__ float pq_sdr_lut(const float *__restrict__ lut, float x)
+{
+    const float t = x * (float)(kPqLutSize - 1);
+    const int i = (int)t;
+    const float v = lut[i], n = lut[min(i + 1, kPqLutSize - 1)];
+    return __builtin_fmaf(n - v, t - (float)i, v);
+}
+
+__device__ __forceinline__ f3 hdr_tail(f3 c, int tail, float gamma, float lum_scale, const mat3 &gamut, const float *l2k = nullptr,
+                                       const float *pq_lut = nullptr)
 {
     if (tail == TAIL_NONE) return c;
     if (tail == TAIL_HLG_TO_PQ) {          // bConvertHLGtoPQ (:885-891)
@@ -193,11 +204,15 @@ __device__ __forceinline__ f3 hdr_tail(f3 c, int tail, float gamma, float lum_sc
         }
         c.x = saturate(c.x); c.y = saturate(c.y); c.z = saturate(c.z);
         if (l2k) c = dovi_trims(c, l2k);
-        c.x = st2084_to_linear(c.x, lum_scale);
-        c.y = st2084_to_linear(c.y, lum_scale);
-        c.z = st2084_to_linear(c.z, lum_scale);
-        const float div = hable_div();
-        c.x = hable(c.x) / div; c.y = hable(c.y) / div; c.z = hable(c.z) / div;
+        if (pq_lut && !l2k) {
+            c.x = pq_sdr_lut(pq_lut, c.x); c.y = pq_sdr_lut(pq_lut, c.y); c.z = pq_sdr_lut(pq_lut, c.z);
+        } else {
+            c.x = st2084_to_linear(c.x, lum_scale);
+            c.y = st2084_to_linear(c.y, lum_scale);
+            c.z = st2084_to_linear(c.z, lum_scale);
+            const float div = hable_div();
+            c.x = hable(c.x) / div; c.y = hable(c.y) / div; c.z = hable(c.z) / div;
+        }
         c = mat3_mul(gamut, c);
     } else {   // TAIL_GAMMA_GAMUT
         c.x = saturate(c.x); c.y = saturate(c.y); c.z = saturate(c.z);

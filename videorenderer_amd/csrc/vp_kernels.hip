@@ -18,6 +18,7 @@ __global__ __launch_bounds__(256) void k_convert(ConvertParams P, Surface out)
 {
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
     if (i >= P.out_w || j >= P.out_h) return;
+    P.pq_lut = nullptr;                    // the plain kernels evaluate every tail literally
     store_surface(out.ptr, out.pitch, out.fmt, i, j, convert_pixel(P, i, j));
 }
 
@@ -27,6 +28,7 @@ __global__ __launch_bounds__(256) void k_convert_direct(ConvertParams P, StorePa
 {
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
     if (i >= P.out_w || j >= P.out_h) return;
+    P.pq_lut = nullptr;
     store_epilogue(st, i, j, round_to_fmt(convert_pixel(P, i, j), P.out_fmt));
 }
 
@@ -45,6 +47,7 @@ __global__ __launch_bounds__(256) void k_convert_420(ConvertParams P, Surface ou
     P.fmt.subsampling = 420; P.fmt.div_w = 2; P.fmt.div_h = 2;
     P.chroma_scaling = 1; P.blend_deint = 0; P.dovi = nullptr; P.tail = TAIL;
     if (BYTES == 1 || PLANES == 2) P.fmt.shift = 0;
+    if (TAIL != TAIL_PQ_TO_SDR) P.pq_lut = nullptr;
     const f3 v = convert_pixel(P, i, j);
     if (DMODE == 0) { store_surface(out.ptr, out.pitch, OFMT, i, j, v); return; }
     st.mode = DMODE == 2 ? ST_FINAL : ST_SURFACE; st.mid_fmt = OFMT; st.dst_fmt = DFMT;

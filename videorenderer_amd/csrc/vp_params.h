@@ -94,6 +94,7 @@ struct ConvertParams {
     float gamut[9];          // matrix_conv_prim
     int out_fmt;             // SurfFmt of m_TexConvertOutput
     const DoviParams *dovi;  // device pointer, null unless m_Dovi.bValid
+    const float *pq_lut;     // device, kPqLutSize floats (BuildPqSdrLut) for the folded convert kernel's PQ->SDR tail; null => ALU chain
 };
 
 struct Surface {
