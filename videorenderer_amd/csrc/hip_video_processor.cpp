@@ -779,6 +779,15 @@ HRESULT CHipVideoProcessor::ConvertColorPass(const uint8_t *sample)
     FillConvertParams(sample, &P);
     Surface out{m_runConv, (int)(m_srcRectWidth * SurfBytesPerPixel(m_plan.internal_fmt)),
                 m_srcRectWidth, m_srcRectHeight, m_plan.internal_fmt};
+    if (!(m_cfg.flags & MPCVR_FLAG_NO_FUSED)) {           // the fused kernel's block convert, when the source qualifies
+        FusedParams fp{};
+        FillFusedParams(sample, out.ptr, out.pitch, &fp);
+        fp.store = MakeStore(out.ptr, out.pitch, out.fmt, false);
+        fp.dst_aligned16 = 1;
+        if (((uintptr_t)sample & 3) != 0) fp.fast_convert = 0;
+        if (ConvertBlocksSupported(fp, false))
+            return CheckHip(LaunchConvertBlocks(fp, nullptr, FusedFrame{sample, out.ptr}, 1, m_run), "k_convert_blocks");
+    }
     return CheckHip(LaunchConvert(P, out, m_run, (m_cfg.flags & MPCVR_FLAG_NO_FUSED) != 0), "k_convert");
 }
 
@@ -836,6 +845,11 @@ HRESULT CHipVideoProcessor::ProcessOne(const uint8_t *sample, void *rt, int rtPi
         return CheckHip(LaunchFusedUp2x(fp, nullptr, fr, 1, m_run), "k_fused_up2x");
     }
     if (m_plan.direct_convert) {
+        FusedParams fp{};
+        FillFusedParams(sample, rt, rtPitch, &fp);
+        if (((uintptr_t)sample & 3) != 0) fp.fast_convert = 0;
+        if (ConvertBlocksSupported(fp, true))
+            return CheckHip(LaunchConvertBlocks(fp, nullptr, FusedFrame{sample, rt}, 1, m_run), "k_convert_blocks");
         ConvertParams P;
         FillConvertParams(sample, &P);
         return CheckHip(LaunchConvertDirect(P, MakeStore(rt, rtPitch, m_plan.swap_fmt, true), m_run), "k_convert_direct");

@@ -626,6 +626,102 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The convert stage on its own (pass-per-kernel path and same-size frames): the 2x2-block convert of the fused kernel —
+// shared chroma fetch, scalar siting, packed matrix, table tone map — without the resize behind it.  A wave owns a strip of
+// 128 rect columns and walks `pairs` row pairs (a, a+1), a odd (so both rows take their chroma from the same two chroma
+// rows); the first and the last pair of a frame clamp to one useful row.
+// FINAL = false: the block is stored as texels of the internal UNORM format (m_TexConvertOutput, or the render target when
+// nothing follows); FINAL = true: 10-bit internal -> ps_final_pass in integers -> B8G8R8A8 (see the fused epilogue).
+// ------------------------------------------------------------------------------------------------
+template <int TAIL, int SRC, bool FINAL>
+__global__ __launch_bounds__(256) void k_convert_blocks(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single, int pairs)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *Di = (uint32_t *)smem;                                   // dither as j << 14 (FINAL)
+    f2 *T = (f2 *)(smem + (FINAL ? 4096 : 0));
+    if (FINAL)
+        for (int i = threadIdx.x; i < 1024; i += 256)
+            Di[i] = (uint32_t)(__half2float(__ushort_as_half(P.dither[i])) * 1024.0f + 0.5f) << 14;
+    if (TAIL == TAILK_PQ_LUT)
+        for (int i = threadIdx.x; i < LUT_N; i += 256) {
+            const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
+            T[i] = f2{v, n - v};
+        }
+    if (FINAL || TAIL == TAILK_PQ_LUT) __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int W = P.W, H = P.H;
+    const int X = blockIdx.x * 128 + 2 * lane;                         // rect columns X, X+1
+    const int pair0 = (blockIdx.y * 4 + wave) * pairs;                 // pair p covers rect rows 2p-1, 2p
+    if (X >= W || 2 * pair0 - 1 >= H) return;
+    const FusedFrame frame = frames ? frames[blockIdx.z] : single;
+    auto uniform_ptr = [](const void *q) {
+        const uint64_t v = (uint64_t)q;
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    };
+    const gcptr py = (gcptr)uniform_ptr(frame.src);
+    const gptr pdst = (gptr)uniform_ptr(frame.dst);
+
+    const f2 MM[5] = {f2{P.m[0], P.m[1]}, f2{P.m[2], P.m[3]}, f2{P.m[4], P.m[5]}, f2{P.m[6], P.m[7]}, f2{P.m[8], 0.0f}};
+    const f2 GG[5] = {f2{P.gamut[0], P.gamut[1]}, f2{P.gamut[2], P.gamut[3]}, f2{P.gamut[4], P.gamut[5]}, f2{P.gamut[6], P.gamut[7]}, f2{P.gamut[8], 0.0f}};
+    const f2 cmax2 = splat(P.maxv);
+    f2 big2 = splat(8388608.0f);
+    asm volatile("" : "+v"(big2));
+    f2 CC[3] = {splat(P.c[0]), splat(P.c[1]), splat(P.c[2])};
+    asm volatile("" : "+v"(CC[0]), "+v"(CC[1]), "+v"(CC[2]));
+
+    RawAddr ra;
+    make_raw_addr<SRC>(P, X, ra);
+    const uint32_t lane_off = (uint32_t)(P.off_x + X) * 4u;
+    Raw raw;
+    {
+        const int a = 2 * pair0 - 1;
+        load_raw<SRC>(P, py, ra, clampi(a, 0, H - 1), clampi(a + 1, 0, H - 1), raw);
+    }
+    for (int p = 0; p < pairs; p++) {
+        const int a = 2 * (pair0 + p) - 1;                             // rows a, a+1
+        if (a >= H) break;
+        f2 rc[2][3];
+        convert_block<TAIL, SRC>(P, MM, GG, CC, raw, P.rect_t + clampi(a, 0, H - 1), P.rect_t + clampi(a + 1, 0, H - 1), T, rc);
+        if (p + 1 < pairs && a + 2 < H)
+            load_raw<SRC>(P, py, ra, clampi(a + 2, 0, H - 1), clampi(a + 3, 0, H - 1), raw);
+        // UNORM store of m_TexConvertOutput: floor(sat(x)*maxv + 0.5); x*maxv + 2^23 leaves the code in the low mantissa bits
+        uint32_t code[2][3][2];                                        // [column][channel][row]
+#pragma unroll
+        for (int col = 0; col < 2; col++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const f2 q = pk_fma(rc[col][c], cmax2, big2);
+                code[col][c][0] = __float_as_uint(q.x) & 0xffffu; code[col][c][1] = __float_as_uint(q.y) & 0xffffu;
+            }
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int y = a + r;
+            if (y < 0 || y >= H) continue;                             // wave-uniform
+            const int wy = P.off_y + y;
+            uint32_t px[2];
+#pragma unroll
+            for (int col = 0; col < 2; col++) {
+                const uint32_t cr = code[col][0][r], cg = code[col][1][r], cb = code[col][2][r];
+                if (FINAL) {
+                    const uint32_t dj = Di[(wy & 31) * 32 + ((P.off_x + X + col) & 31)];
+                    const uint32_t ib = __umul24(cb, P.epi_mul) + dj, ig = __umul24(cg, P.epi_mul) + dj, ir = __umul24(cr, P.epi_mul) + dj;
+                    const uint32_t bg = __builtin_amdgcn_perm(ig, ib, 0x0c0c0703u);
+                    px[col] = __builtin_amdgcn_perm(ir, bg, 0x0d070100u);
+                } else if (P.out10) {
+                    px[col] = cr | (cg << 10) | (cb << 20) | 0xc0000000u;
+                } else {
+                    px[col] = cb | (cg << 8) | (cr << 16) | 0xff000000u;
+                }
+            }
+            const gptr rowp = pdst + (uint32_t)wy * (uint32_t)P.dst_pitch;
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            *(__attribute__((address_space(1))) u32x2 *)(rowp + opaque(lane_off)) = u32x2{px[0], px[1]};
+        }
+    }
+}
+
 int EnvInt(const char *name, int def)
 {
     const char *v = std::getenv(name);
@@ -652,12 +748,10 @@ bool FusedUp2xSupported(const FusedParams &P)
     return true;
 }
 
-hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s)
+// the convert-side and store-side constants both kernels of this file take
+static void FillFusedArgs(const FusedParams &P, FusedArgs &a)
 {
-    static const int seg_env = EnvInt("MPCVR_FUSED_SEG", 0);
-    if (!frames_dev && n_frames != 1) return hipErrorInvalidValue;
     const ConvertParams &c = P.conv;
-    FusedArgs a;
     std::memset(&a, 0, sizeof(a));
     const bool swap_uv = c.fmt.planes == 3 && c.fmt.v_first;
     a.off_u = (uint32_t)(swap_uv ? P.plane_off[2] : P.plane_off[1]);
@@ -684,6 +778,85 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     a.inv_maxv = 1.0f / a.maxv;
     a.q_over_maxv = (float)P.store.quant / a.maxv;
     a.epi_mul = FinalPassMultiplier(P.store.quant, (int)a.maxv);
+    a.dst_pitch = P.store.dst_pitch; a.off_x = P.store.off_x; a.off_y = P.store.off_y;
+    a.final_pass = P.store.mode == ST_FINAL; a.out10 = P.store.dst_fmt == SF_RGB10A2;
+    a.quant = (float)P.store.quant;
+    a.dither = P.store.dither;
+}
+
+static int TailKind(const FusedParams &P)
+{
+    const ConvertParams &c = P.conv;
+    // P.pq_lut is null when MPCVR_FLAG_NO_LUT asks for the literal ALU chains (A/B testing)
+    return c.tail == TAIL_NONE ? TAILK_NONE : (c.tail == TAIL_PQ_TO_SDR && P.pq_lut) ? TAILK_PQ_LUT
+         : (c.tail == TAIL_HLG_TO_SDR && !P.literal_tail) ? TAILK_HLG : TAILK_ALU;
+}
+static int SourceKind(const FusedParams &P)
+{
+    // source specialisations: bi-planar 16-bit (P010/P016) and bi-planar 8-bit (NV12) with MPEG-2 / co-sited chroma;
+    // everything else (planar, MPEG-1 siting) runs through the variant that reads these properties at run time
+    const ConvertParams &c = P.conv;
+    const bool biplanar_fast = c.fmt.planes == 2 && c.chroma_loc != CLOC_MPEG1;
+    return (biplanar_fast && c.fmt.bytes == 2) ? SRC_P01X : (biplanar_fast && c.fmt.bytes == 1) ? SRC_NV12 : SRC_GENERIC;
+}
+
+bool ConvertBlocksSupported(const FusedParams &P, bool to_rt)
+{
+    const ConvertParams &c = P.conv;
+    if (c.out_fmt != SF_BGRA8 && c.out_fmt != SF_RGB10A2) return false;
+    if (c.fmt.layout != LAY_PLANAR || c.fmt.subsampling != 420 || c.chroma_scaling != 1 || c.blend_deint || c.dovi) return false;
+    if (c.out_w < 8 || c.out_h < 2 || (c.out_w & 1) || (c.out_h & 1)) return false;
+    if (!P.fast_convert) return false;
+    if ((uint64_t)c.pitch[0] * (uint64_t)(c.rect_t + c.out_h + 2) >= (1ull << 32)) return false;
+    if ((uint64_t)P.plane_off[1] >= (1ull << 31) || (uint64_t)P.plane_off[2] >= (1ull << 31)) return false;
+    const StoreParams &st = P.store;
+    if ((uint64_t)st.dst_pitch * (uint64_t)(st.off_y + c.out_h) >= (1ull << 32)) return false;
+    if ((st.dst_pitch & 7) || (st.off_x & 1) || !P.dst_aligned16) return false;                 // 8-byte stores
+    if (to_rt) {
+        // the whole rect inside the window (no per-pixel clipping here)
+        if (st.off_x < 0 || st.off_y < 0 || (st.clip_w > 0 && (st.off_x + c.out_w > st.clip_w || st.off_y + c.out_h > st.clip_h))) return false;
+        if (st.mode == ST_FINAL)
+            return c.out_fmt == SF_RGB10A2 && st.mid_fmt == SF_RGB10A2 && st.dst_fmt == SF_BGRA8 && st.quant == 255 &&
+                   FinalPassMultiplier(255, 1023) != 0;
+        return st.dst_fmt == c.out_fmt;                                   // straight copy of the internal-format texels
+    }
+    return st.dst_fmt == c.out_fmt && st.mode == ST_SURFACE;
+}
+
+hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s)
+{
+    if (!frames_dev && n_frames != 1) return hipErrorInvalidValue;
+    FusedArgs a;
+    FillFusedArgs(P, a);
+    const ConvertParams &c = P.conv;
+    const bool fin = P.store.mode == ST_FINAL;
+    const int strips = (c.out_w + 127) / 128, npairs = c.out_h / 2 + 1;
+    // row pairs per wave: enough waves to fill the chip a few times over, few enough to amortise the table staging
+    int pairs = 16;
+    while (pairs > 2 && (long)strips * ((npairs + pairs - 1) / pairs) * n_frames < 8192) pairs >>= 1;
+    const dim3 grid(strips, (npairs + 4 * pairs - 1) / (4 * pairs), n_frames), block(256, 1, 1);
+    const int tailk = TailKind(P), srck = SourceKind(P);
+    const size_t lds = (fin ? 4096 : 0) + (tailk == TAILK_PQ_LUT ? LDS_T : 0);
+#define MPCVR_CB3(TK, SK, FN) hipLaunchKernelGGL((k_convert_blocks<TK, SK, FN>), grid, block, lds, s, a, frames_dev, single, pairs)
+#define MPCVR_CB2(TK, SK) do { if (fin) MPCVR_CB3(TK, SK, true); else MPCVR_CB3(TK, SK, false); } while (0)
+#define MPCVR_CB(TK) do { if (srck == SRC_P01X) MPCVR_CB2(TK, SRC_P01X); else if (srck == SRC_NV12) MPCVR_CB2(TK, SRC_NV12); else MPCVR_CB2(TK, SRC_GENERIC); } while (0)
+    if (tailk == TAILK_NONE) MPCVR_CB(TAILK_NONE);
+    else if (tailk == TAILK_PQ_LUT) MPCVR_CB(TAILK_PQ_LUT);
+    else if (tailk == TAILK_HLG) MPCVR_CB(TAILK_HLG);
+    else MPCVR_CB(TAILK_ALU);
+#undef MPCVR_CB
+#undef MPCVR_CB2
+#undef MPCVR_CB3
+    return hipGetLastError();
+}
+
+hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s)
+{
+    static const int seg_env = EnvInt("MPCVR_FUSED_SEG", 0);
+    if (!frames_dev && n_frames != 1) return hipErrorInvalidValue;
+    const ConvertParams &c = P.conv;
+    FusedArgs a;
+    FillFusedArgs(P, a);
     const int nt = P.wx.ntaps;
     for (int t = 0; t < 6; t++) { a.we[t] = P.wx.w_even[t]; a.wo[t] = P.wx.w_odd[t]; }
     int knt = nt;
@@ -693,10 +866,6 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
         a.we[5] = a.wo[5] = 0.0f;
         knt = 5;
     }
-    a.dst_pitch = P.store.dst_pitch; a.off_x = P.store.off_x; a.off_y = P.store.off_y;
-    a.final_pass = P.store.mode == ST_FINAL; a.out10 = P.store.dst_fmt == SF_RGB10A2;
-    a.quant = (float)P.store.quant;
-    a.dither = P.store.dither;
 
     const int strips = (c.out_w + S - 1) / S;
     // segment height: long segments recompute less (6 rows each), short ones balance the last round of waves;
@@ -713,15 +882,10 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
 
     const dim3 grid((strips + WAVES - 1) / WAVES, (c.out_h + seg - 1) / seg, n_frames);
     const dim3 block(256, 1, 1);
-    // P.pq_lut is null when MPCVR_FLAG_NO_LUT asks for the literal ALU chains (A/B testing)
-    const int tailk = c.tail == TAIL_NONE ? TAILK_NONE : (c.tail == TAIL_PQ_TO_SDR && P.pq_lut) ? TAILK_PQ_LUT
-                    : (c.tail == TAIL_HLG_TO_SDR && !P.literal_tail) ? TAILK_HLG : TAILK_ALU;
+    const int tailk = TailKind(P);
     static const int lds_pad = EnvInt("MPCVR_FUSED_LDS_PAD", 0);   // experiments: lower the occupancy by claiming more LDS
     const size_t lds = LDS_A + LDS_D + LDS_DB + (tailk == TAILK_PQ_LUT ? LDS_T : 0) + (size_t)lds_pad;
-    // source specialisations: bi-planar 16-bit (P010/P016) and bi-planar 8-bit (NV12) with MPEG-2 / co-sited chroma;
-    // everything else (planar, MPEG-1 siting) runs through the variant that reads these properties at run time
-    const bool biplanar_fast = c.fmt.planes == 2 && !a.center_h;
-    const int srck = (biplanar_fast && c.fmt.bytes == 2) ? SRC_P01X : (biplanar_fast && c.fmt.bytes == 1) ? SRC_NV12 : SRC_GENERIC;
+    const int srck = SourceKind(P);
     // the specialised epilogues use 16-byte stores / dither reads: off_x % 4 == 0 and 16-byte aligned rows; the integer
     // final pass additionally needs k*M + (j << 14) < 2^32 and M < 2^24 (true for 10-bit internal -> 8-bit target)
     const bool aligned = P.dst_aligned16 && (a.off_x & 3) == 0 && (a.dst_pitch & 15) == 0;

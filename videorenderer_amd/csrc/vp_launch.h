@@ -40,6 +40,11 @@ struct FusedParams {
     int literal_tail;         // MPCVR_FLAG_NO_LUT: evaluate the HDR tails literally in ALU (no LUT, no algebraic shortcut)
 };
 bool FusedUp2xSupported(const FusedParams &P);
+// the fused kernel's convert stage as a kernel of its own: 2x2 blocks, shared chroma fetch, table tone map.  P.store describes
+// the destination: texels of the internal format (m_TexConvertOutput, or the render target when nothing follows: to_rt), or
+// the final pass into a B8G8R8A8 render target (store.mode == ST_FINAL).  out_w / out_h / wx / wy of P are not used.
+bool ConvertBlocksSupported(const FusedParams &P, bool to_rt);
+hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
 // frames_dev == nullptr: n_frames must be 1 and `single` is used (no device-side table needed)
 hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
 
