@@ -249,9 +249,14 @@ def test_get_current_image_and_render(mpcvr, oracle, torch_cuda):
 
 def test_process_batch_equals_single(mpcvr, torch_cuda):
     torch = torch_cuda
-    for name, flags in (("noise_p010_pq_lanczos3_2x", 0), ("noise_p010_pq_lanczos3_2x", 2), ("down_lanczos_2p5x", 0)):
+    # fused launch, plain per-frame loop, and the whole-batch launches of the pass-per-kernel path (two-pass, one-pass,
+    # same-size direct, 8-bit and 10-bit sources, a source rect, a letterboxed window)
+    for name, flags in (("noise_p010_pq_lanczos3_2x", 0), ("noise_p010_pq_lanczos3_2x", 2), ("down_lanczos_2p5x", 0),
+                        ("up_1p5x_lanczos3", 0), ("x_only_resize", 0), ("y_only_resize", 0), ("c1_nv12_bt709_passthrough", 0),
+                        ("mild_down_uses_upscaler", 0), ("crop_offset_letterbox", 0), ("down_hamming_3x", 0), ("c5_p010_hlg_lanczos3_2x", 8)):
         c = GOLDEN_CASES[name]
         vp, (ww, wh) = make_vp(mpcvr, c, flags)
+        c = dict(c, kind="noise")        # distinct frames whatever the case's own content
         frames = [torch.from_numpy(case_frame(dict(c, seed=c["seed"] + 100 * i))[0]).cuda() for i in range(5)]
         pitch = vp.GetFrameBytes()[1]
         singles = []
@@ -265,8 +270,14 @@ def test_process_batch_equals_single(mpcvr, torch_cuda):
         vp.Synchronize()
         for i in range(5):
             assert torch.equal(singles[i], dsts[i]), (name, flags, i)
-        assert not torch.equal(dsts[0], dsts[1])
+        assert c["kind"] != "noise" or not torch.equal(dsts[0], dsts[1])       # (structure frames ignore the seed)
         assert vp.GetLastProcessMs() > 0
+        # a second batch through the same context (frame-table slots, batched intermediates reused), odd frame count
+        dsts = [torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda") for _ in range(3)]
+        vp.ProcessBatch(frames[2:], dsts, ww * 4)
+        vp.Synchronize()
+        for i in range(3):
+            assert torch.equal(singles[2 + i], dsts[i]), (name, flags, "second batch", i)
         vp.close()
 
 

@@ -55,7 +55,7 @@ CHipVideoProcessor::~CHipVideoProcessor()
     if (!m_bInit) return;
     (void)hipSetDevice(m_device);
     if (m_stream) (void)hipStreamSynchronize(m_stream);
-    for (DevBuffer *b : {&m_TexSrcVideo, &m_TexRaw, &m_TexPost, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
+    for (DevBuffer *b : {&m_batchConv, &m_batchMid, &m_TexSrcVideo, &m_TexRaw, &m_TexPost, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
                          &m_pqLut, &m_tapsXi, &m_tapsXw, &m_tapsXs, &m_tapsYi, &m_tapsYw, &m_tapsYs, &m_otherX, &m_otherY, &m_tapsXb, &m_tapsYb})
         b->Release();
     for (UploadSlot &u : m_up) {
@@ -890,7 +890,18 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
     if (m_planDirty && (hr = UpdatePlan())) return hr;
     for (int i = 0; i < n; i++)
         if (!srcs[i] || !dsts[i]) return Fail(MPCVR_E_POINTER, "null frame in batch");
-    if (!m_plan.fused_up2x) {
+    bool aligned = true, src4 = true;
+    for (int i = 0; i < n; i++) {
+        if (((uintptr_t)srcs[i] & 3) != 0) src4 = false;
+        if (((uintptr_t)dsts[i] & 15) != 0) aligned = false;
+    }
+    // pass-per-kernel path, whole batch per launch: possible when every stage has a kernel with a frame dimension
+    bool batchable = false;
+    if (!m_plan.fused_up2x && n > 1 && src4 && !(m_cfg.flags & (MPCVR_FLAG_NO_FUSED | MPCVR_FLAG_NO_FAST_CONVERT))) {
+        FusedParams a{}, b{};
+        batchable = BatchPlan((const uint8_t *)srcs[0], dsts[0], rtPitch, aligned, &a, &b);
+    }
+    if (!m_plan.fused_up2x && !batchable) {
         // samples that are repacked first share m_TexSrcVideo: those batches stay on the context stream
         const bool repack = m_srcParams->cformat == MPCVR_CF_V210 || m_srcParams->layout == LAY_RGB;
         // MPCVR_BATCH_LANES=2..4 deals the frames to that many streams with private intermediates.  Measured on MI355X:
@@ -939,13 +950,19 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
     FusedFrame *fr = (FusedFrame *)slot.pinned;
     for (int i = 0; i < n; i++) { fr[i].src = (const uint8_t *)srcs[i]; fr[i].dst = dsts[i]; }
     if ((hr = CheckHip(hipMemcpyAsync(slot.dev.ptr, fr, sizeof(FusedFrame) * n, hipMemcpyHostToDevice, m_stream), "frame table"))) return hr;
+    if (batchable) {
+        (void)hipEventRecord(m_evStart, m_stream);
+        hr = ProcessBatchLaunches(n, (const FusedFrame *)slot.dev.ptr, (const uint8_t *)srcs[0], dsts[0], rtPitch, aligned);
+        (void)hipEventRecord(m_evStop, m_stream);
+        (void)hipEventRecord(slot.done, m_stream);
+        slot.used = true;
+        m_timed = true;
+        return hr;
+    }
     FusedParams fp{};
     FillFusedParams((const uint8_t *)srcs[0], nullptr, rtPitch, &fp);
-    fp.dst_aligned16 = 1;
-    for (int i = 0; i < n; i++) {
-        if (((uintptr_t)srcs[i] & 3) != 0) fp.fast_convert = 0;
-        if (((uintptr_t)dsts[i] & 15) != 0) fp.dst_aligned16 = 0;
-    }
+    fp.dst_aligned16 = aligned ? 1 : 0;
+    if (!src4) fp.fast_convert = 0;
     (void)hipEventRecord(m_evStart, m_stream);
     hr = CheckHip(LaunchFusedUp2x(fp, (const FusedFrame *)slot.dev.ptr, FusedFrame{nullptr, nullptr}, n, m_stream), "k_fused_up2x");
     (void)hipEventRecord(m_evStop, m_stream);
@@ -953,6 +970,75 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
     slot.used = true;
     m_timed = true;
     return hr;
+}
+
+// Can this plan run as whole-batch launches?  *conv: the block convert into the (batched) convert output; *direct: the block
+// convert straight into the render targets (same-size frames).  Exactly one of them is used.
+bool CHipVideoProcessor::BatchPlan(const uint8_t *sample0, void *rt0, int rtPitch, bool aligned, FusedParams *conv, FusedParams *direct) const
+{
+    if (m_plan.hdr_tonemap || m_plan.rotation || m_plan.flip || m_firstJinc || m_secondJinc || !m_plan.convert) return false;
+    if (m_srcParams->cformat == MPCVR_CF_V210 || m_srcParams->layout == LAY_RGB) return false;
+    const int w1 = m_srcRectWidth, h1 = m_srcRectHeight, w2 = m_videoRect.Width();
+    if (m_plan.direct_convert) {
+        FillFusedParams(sample0, rt0, rtPitch, direct);
+        direct->dst_aligned16 = aligned ? 1 : 0;
+        return ConvertBlocksSupported(*direct, true);
+    }
+    if (!m_plan.two_pass && !m_plan.one_pass) return false;
+    const int convPitch = (int)(w1 * SurfBytesPerPixel(m_plan.internal_fmt));
+    FillFusedParams(sample0, m_batchConv.ptr, convPitch, conv);
+    conv->store = MakeStore(m_batchConv.ptr, convPitch, m_plan.internal_fmt, false);
+    conv->dst_aligned16 = 1;
+    if (!ConvertBlocksSupported(*conv, false)) return false;
+    const Surface cs{nullptr, convPitch, w1, h1, m_plan.internal_fmt};
+    const StoreParams final = MakeStore(rt0, rtPitch, m_plan.swap_fmt, true);
+    if (m_plan.two_pass) {
+        const Surface mid{nullptr, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
+        return ResizeHasFoldedKernel(m_firstAxis, m_firstSwap, cs, m_tapsX, MakeStore(nullptr, mid.pitch, SF_RGBA16F, false)) &&
+               ResizeHasFoldedKernel(1, false, mid, m_tapsY, final);
+    }
+    return ResizeHasFoldedKernel(m_firstAxis, m_firstSwap, cs, m_tapsX, final);
+}
+
+// convert all -> first draw all -> second draw all, a frame dimension in every grid; the intermediates hold `chunk` frames
+HRESULT CHipVideoProcessor::ProcessBatchLaunches(int n, const FusedFrame *table, const uint8_t *sample0, void *rt0, int rtPitch, bool aligned)
+{
+    HRESULT hr;
+    const int w1 = m_srcRectWidth, h1 = m_srcRectHeight, w2 = m_videoRect.Width(), h2 = m_videoRect.Height();
+    FusedParams conv{}, direct{};
+    if (m_plan.direct_convert) {
+        if (!BatchPlan(sample0, rt0, rtPitch, aligned, &conv, &direct)) return Fail(MPCVR_E_UNEXPECTED, "batch plan changed");
+        return CheckHip(LaunchConvertBlocks(direct, table, FusedFrame{nullptr, nullptr}, n, m_stream), "k_convert_blocks");
+    }
+    // intermediates for up to `chunk` frames (at most ~4 GiB)
+    const size_t per = m_convBytes + m_midBytes;
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)4 << 30) / std::max<size_t>(per, 1)));
+    if ((hr = CheckHip(m_batchConv.CheckCreate(m_convBytes * chunk), "batch convert output"))) return hr;
+    if (m_midBytes && (hr = CheckHip(m_batchMid.CheckCreate(m_midBytes * chunk), "batch resize texture"))) return hr;
+    if (!BatchPlan(sample0, rt0, rtPitch, aligned, &conv, &direct)) return Fail(MPCVR_E_UNEXPECTED, "batch plan changed");
+    const int convPitch = (int)(w1 * SurfBytesPerPixel(m_plan.internal_fmt));
+    const Surface cs{m_batchConv.ptr, convPitch, w1, h1, m_plan.internal_fmt};
+    const StoreParams final = MakeStore(rt0, rtPitch, m_plan.swap_fmt, true);
+    for (int at = 0; at < n; at += chunk) {
+        const int m = std::min(chunk, n - at);
+        const FusedFrame *tab = table + at;
+        // frame z of the chunk: sample from the table, output at m_batchConv + z * m_convBytes
+        conv.store.dst = m_batchConv.ptr;
+        if ((hr = CheckHip(LaunchConvertBlocks(conv, tab, FusedFrame{nullptr, nullptr}, m, m_stream, m_convBytes), "k_convert_blocks"))) return hr;
+        ResizeBatch b1; b1.n = m; b1.in_stride = m_convBytes;
+        if (m_plan.two_pass) {
+            const Surface mid{m_batchMid.ptr, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
+            b1.dst_stride = m_midBytes;
+            if ((hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, cs, m_tapsX, (const int32_t *)m_otherX.ptr, w2, m_plan.mid_h,
+                                            MakeStore(mid.ptr, mid.pitch, SF_RGBA16F, false), m_stream, false, &b1), "k_resize<first>"))) return hr;
+            ResizeBatch b2; b2.n = m; b2.in_stride = m_midBytes; b2.frames = tab;
+            if ((hr = CheckHip(LaunchResize(1, false, mid, m_tapsY, (const int32_t *)m_otherY.ptr, w2, h2, final, m_stream, false, &b2), "k_resize<Y>"))) return hr;
+        } else {
+            b1.frames = tab;
+            if ((hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, cs, m_tapsX, (const int32_t *)m_otherX.ptr, w2, h2, final, m_stream, false, &b1), "k_resize<one>"))) return hr;
+        }
+    }
+    return MPCVR_S_OK;
 }
 
 // Render minus Present — DX11VideoProcessor.cpp:2599-2813

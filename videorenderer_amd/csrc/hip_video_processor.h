@@ -199,6 +199,10 @@ private:
     hipStream_t m_run = nullptr;
     void *m_runConv = nullptr, *m_runMid = nullptr, *m_runPost = nullptr;
     void UseLane(int lane);
+    // whole-batch launches of the pass-per-kernel path (block convert + folded resize kernels with a frame dimension)
+    DevBuffer m_batchConv, m_batchMid;
+    bool BatchPlan(const uint8_t *sample0, void *rt0, int rtPitch, bool aligned, FusedParams *conv, FusedParams *direct) const;
+    HRESULT ProcessBatchLaunches(int n, const FusedFrame *table, const uint8_t *sample0, void *rt0, int rtPitch, bool aligned);
     HRESULT PrepareLanes(int lanes);
 };
 

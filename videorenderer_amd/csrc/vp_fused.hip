@@ -635,7 +635,8 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
 // nothing follows); FINAL = true: 10-bit internal -> ps_final_pass in integers -> B8G8R8A8 (see the fused epilogue).
 // ------------------------------------------------------------------------------------------------
 template <int TAIL, int SRC, bool FINAL>
-__global__ __launch_bounds__(256) void k_convert_blocks(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single, int pairs)
+__global__ __launch_bounds__(256) void k_convert_blocks(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single, int pairs,
+                                                       uint8_t *batch_dst, size_t batch_stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *Di = (uint32_t *)smem;                                   // dither as j << 14 (FINAL)
@@ -661,7 +662,8 @@ __global__ __launch_bounds__(256) void k_convert_blocks(FusedArgs P, const Fused
         return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
     };
     const gcptr py = (gcptr)uniform_ptr(frame.src);
-    const gptr pdst = (gptr)uniform_ptr(frame.dst);
+    // batch_dst: frame z of the launch goes into an intermediate (batch_dst + z * batch_stride) instead of the table's target
+    const gptr pdst = (gptr)uniform_ptr(batch_dst ? (void *)(batch_dst + (size_t)blockIdx.z * batch_stride) : frame.dst);
 
     const f2 MM[5] = {f2{P.m[0], P.m[1]}, f2{P.m[2], P.m[3]}, f2{P.m[4], P.m[5]}, f2{P.m[6], P.m[7]}, f2{P.m[8], 0.0f}};
     const f2 GG[5] = {f2{P.gamut[0], P.gamut[1]}, f2{P.gamut[2], P.gamut[3]}, f2{P.gamut[4], P.gamut[5]}, f2{P.gamut[6], P.gamut[7]}, f2{P.gamut[8], 0.0f}};
@@ -823,8 +825,10 @@ bool ConvertBlocksSupported(const FusedParams &P, bool to_rt)
     return st.dst_fmt == c.out_fmt && st.mode == ST_SURFACE;
 }
 
-hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s)
+hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s,
+                               size_t batch_stride)
 {
+    uint8_t *batch_dst = batch_stride ? (uint8_t *)P.store.dst : nullptr;
     if (!frames_dev && n_frames != 1) return hipErrorInvalidValue;
     FusedArgs a;
     FillFusedArgs(P, a);
@@ -837,7 +841,7 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
     const dim3 grid(strips, (npairs + 4 * pairs - 1) / (4 * pairs), n_frames), block(256, 1, 1);
     const int tailk = TailKind(P), srck = SourceKind(P);
     const size_t lds = (fin ? 4096 : 0) + (tailk == TAILK_PQ_LUT ? LDS_T : 0);
-#define MPCVR_CB3(TK, SK, FN) hipLaunchKernelGGL((k_convert_blocks<TK, SK, FN>), grid, block, lds, s, a, frames_dev, single, pairs)
+#define MPCVR_CB3(TK, SK, FN) hipLaunchKernelGGL((k_convert_blocks<TK, SK, FN>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride)
 #define MPCVR_CB2(TK, SK) do { if (fin) MPCVR_CB3(TK, SK, true); else MPCVR_CB3(TK, SK, false); } while (0)
 #define MPCVR_CB(TK) do { if (srck == SRC_P01X) MPCVR_CB2(TK, SRC_P01X); else if (srck == SRC_NV12) MPCVR_CB2(TK, SRC_NV12); else MPCVR_CB2(TK, SRC_GENERIC); } while (0)
     if (tailk == TAILK_NONE) MPCVR_CB(TAILK_NONE);

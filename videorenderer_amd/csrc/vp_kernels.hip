@@ -121,14 +121,18 @@ static int EpiOf(const StoreParams &st)
 // output row per block row, so the tap indices and weights of the row are wave-uniform (scalar loads) and every tap
 // is one fully coalesced row read.  A thread owns 4 consecutive columns.
 template <int NT, int INFMT, int EPI, int PX>
-__global__ __launch_bounds__(256) void k_resize_rows(Surface in, AxisTaps taps, int out_w, int out_h, int gx, StoreParams st)
+__global__ __launch_bounds__(256) void k_resize_rows(Surface in, AxisTaps taps, int out_w, int out_h, int gx, StoreParams st, ResizeBatch bt)
 {
     // workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give XCD k the k-th contiguous band of
     // output rows (its taps then re-read rows its own L2 already holds) instead of every 8th row.  1-D grid of
     // 8 * ceil(gx * out_h / 8) workgroups; logical id = (id mod 8) * (grid / 8) + id / 8 is a bijection on it.
+    // With a batch the bands run over whole frames: an XCD works on its own frames.
     const int per = gridDim.x >> 3, lid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    const int y = lid / gx, bx = lid - y * gx;
-    if (y >= out_h) return;
+    const int row = lid / gx, bx = lid - row * gx;
+    const int z = row / out_h, y = row - z * out_h;
+    if (z >= bt.n) return;
+    in.ptr = (uint8_t *)in.ptr + (size_t)z * bt.in_stride;
+    st.dst = bt.frames ? bt.frames[z].dst : (void *)((uint8_t *)st.dst + (size_t)z * bt.dst_stride);
     // pixel p of a thread sits 256 columns after pixel p-1: every load of a wave stays one contiguous row segment
     const int x0 = bx * (256 * PX) + threadIdx.x;
     if (x0 >= out_w) return;
@@ -168,10 +172,12 @@ __global__ __launch_bounds__(256) void k_resize_rows(Surface in, AxisTaps taps, 
 // every texel once per tap that uses it; the tap table of an output column is read once for the 4 rows.
 template <int NT, int INFMT, int EPI>
 __global__ __launch_bounds__(256) void k_resize_cols(Surface in, AxisTaps taps, const int32_t *__restrict__ other,
-                                                    int out_w, int out_h, StoreParams st)
+                                                    int out_w, int out_h, StoreParams st, ResizeBatch bt)
 {
     constexpr int R = 4;
     __shared__ float4 tile[4][R][kResizeSpanMax];
+    in.ptr = (uint8_t *)in.ptr + (size_t)blockIdx.z * bt.in_stride;
+    st.dst = bt.frames ? bt.frames[blockIdx.z].dst : (void *)((uint8_t *)st.dst + (size_t)blockIdx.z * bt.dst_stride);
     const int lane = threadIdx.x, wv = threadIdx.y;
     const int x = blockIdx.x * 64 + lane, yb = blockIdx.y * (4 * R) + wv * R;
     const int nt = NT ? NT : taps.ntaps;
@@ -433,56 +439,66 @@ hipError_t LaunchConvertDirect(const ConvertParams &P, const StoreParams &st, hi
 // folded instantiations: NT in {4, 6, runtime}, INFMT in {UNORM8, UNORM10, fp16}, every EpiCode
 template <int NT, int INFMT, int EPI>
 static void LaunchResizeFast(bool rows, const Surface &in, const AxisTaps &taps, const int32_t *other, int out_w, int out_h,
-                             const StoreParams &st, hipStream_t s)
+                             const StoreParams &st, hipStream_t s, const ResizeBatch &bt)
 {
     static const int px = getenv("MPCVR_ROWS_PX") ? atoi(getenv("MPCVR_ROWS_PX")) : 2;
     if (rows) {
-        const int per = 256 * px, gx = (out_w + per - 1) / per, grid = (gx * out_h + 7) / 8 * 8;
-        if (px == 1) hipLaunchKernelGGL((k_resize_rows<NT, INFMT, EPI, 1>), dim3(grid, 1, 1), dim3(256, 1, 1), 0, s, in, taps, out_w, out_h, gx, st);
-        else if (px == 2) hipLaunchKernelGGL((k_resize_rows<NT, INFMT, EPI, 2>), dim3(grid, 1, 1), dim3(256, 1, 1), 0, s, in, taps, out_w, out_h, gx, st);
-        else hipLaunchKernelGGL((k_resize_rows<NT, INFMT, EPI, 4>), dim3(grid, 1, 1), dim3(256, 1, 1), 0, s, in, taps, out_w, out_h, gx, st);
+        const int per = 256 * px, gx = (out_w + per - 1) / per, grid = (gx * out_h * bt.n + 7) / 8 * 8;
+        if (px == 1) hipLaunchKernelGGL((k_resize_rows<NT, INFMT, EPI, 1>), dim3(grid, 1, 1), dim3(256, 1, 1), 0, s, in, taps, out_w, out_h, gx, st, bt);
+        else if (px == 2) hipLaunchKernelGGL((k_resize_rows<NT, INFMT, EPI, 2>), dim3(grid, 1, 1), dim3(256, 1, 1), 0, s, in, taps, out_w, out_h, gx, st, bt);
+        else hipLaunchKernelGGL((k_resize_rows<NT, INFMT, EPI, 4>), dim3(grid, 1, 1), dim3(256, 1, 1), 0, s, in, taps, out_w, out_h, gx, st, bt);
     }
-    else hipLaunchKernelGGL((k_resize_cols<NT, INFMT, EPI>), dim3((out_w + 63) / 64, (out_h + 15) / 16, 1), dim3(64, 4, 1), 0, s, in, taps, other, out_w, out_h, st);
+    else hipLaunchKernelGGL((k_resize_cols<NT, INFMT, EPI>), dim3((out_w + 63) / 64, (out_h + 15) / 16, bt.n), dim3(64, 4, 1), 0, s, in, taps, other, out_w, out_h, st, bt);
 }
 template <int NT, int INFMT>
 static bool LaunchResizeFastE(int epi, bool rows, const Surface &in, const AxisTaps &taps, const int32_t *other, int out_w, int out_h,
-                              const StoreParams &st, hipStream_t s)
+                              const StoreParams &st, hipStream_t s, const ResizeBatch &bt)
 {
     switch (epi) {
-    case EPI_TO_FP16: LaunchResizeFast<NT, INFMT, EPI_TO_FP16>(rows, in, taps, other, out_w, out_h, st, s); return true;
-    case EPI_FINAL_10_TO_8: LaunchResizeFast<NT, INFMT, EPI_FINAL_10_TO_8>(rows, in, taps, other, out_w, out_h, st, s); return true;
-    case EPI_FINAL_16F_TO_8: LaunchResizeFast<NT, INFMT, EPI_FINAL_16F_TO_8>(rows, in, taps, other, out_w, out_h, st, s); return true;
-    case EPI_FINAL_16F_TO_10: LaunchResizeFast<NT, INFMT, EPI_FINAL_16F_TO_10>(rows, in, taps, other, out_w, out_h, st, s); return true;
-    case EPI_TO_BGRA8: LaunchResizeFast<NT, INFMT, EPI_TO_BGRA8>(rows, in, taps, other, out_w, out_h, st, s); return true;
-    case EPI_TO_RGB10: LaunchResizeFast<NT, INFMT, EPI_TO_RGB10>(rows, in, taps, other, out_w, out_h, st, s); return true;
+    case EPI_TO_FP16: LaunchResizeFast<NT, INFMT, EPI_TO_FP16>(rows, in, taps, other, out_w, out_h, st, s, bt); return true;
+    case EPI_FINAL_10_TO_8: LaunchResizeFast<NT, INFMT, EPI_FINAL_10_TO_8>(rows, in, taps, other, out_w, out_h, st, s, bt); return true;
+    case EPI_FINAL_16F_TO_8: LaunchResizeFast<NT, INFMT, EPI_FINAL_16F_TO_8>(rows, in, taps, other, out_w, out_h, st, s, bt); return true;
+    case EPI_FINAL_16F_TO_10: LaunchResizeFast<NT, INFMT, EPI_FINAL_16F_TO_10>(rows, in, taps, other, out_w, out_h, st, s, bt); return true;
+    case EPI_TO_BGRA8: LaunchResizeFast<NT, INFMT, EPI_TO_BGRA8>(rows, in, taps, other, out_w, out_h, st, s, bt); return true;
+    case EPI_TO_RGB10: LaunchResizeFast<NT, INFMT, EPI_TO_RGB10>(rows, in, taps, other, out_w, out_h, st, s, bt); return true;
     default: return false;
     }
 }
 template <int INFMT>
 static bool LaunchResizeFastN(int epi, bool rows, const Surface &in, const AxisTaps &taps, const int32_t *other, int out_w, int out_h,
-                              const StoreParams &st, hipStream_t s)
+                              const StoreParams &st, hipStream_t s, const ResizeBatch &bt)
 {
-    if (taps.ntaps == 4) return LaunchResizeFastE<4, INFMT>(epi, rows, in, taps, other, out_w, out_h, st, s);
-    if (taps.ntaps == 6) return LaunchResizeFastE<6, INFMT>(epi, rows, in, taps, other, out_w, out_h, st, s);
-    return LaunchResizeFastE<0, INFMT>(epi, rows, in, taps, other, out_w, out_h, st, s);
+    if (taps.ntaps == 4) return LaunchResizeFastE<4, INFMT>(epi, rows, in, taps, other, out_w, out_h, st, s, bt);
+    if (taps.ntaps == 6) return LaunchResizeFastE<6, INFMT>(epi, rows, in, taps, other, out_w, out_h, st, s, bt);
+    return LaunchResizeFastE<0, INFMT>(epi, rows, in, taps, other, out_w, out_h, st, s, bt);
+}
+
+// taps along screen y with a 1:1 column map -> row kernel; taps along screen x with a block table -> column kernel
+static bool FoldedRows(int axis, bool swap, const AxisTaps &taps) { return !swap && axis == 1 && taps.other_identity; }
+static bool FoldedCols(int axis, bool swap, const AxisTaps &taps)
+{
+    return !swap && axis == 0 && taps.blk_lo && taps.idx_t && taps.blk_span > 0 && taps.blk_span <= kResizeSpanMax;
+}
+bool ResizeHasFoldedKernel(int axis, bool swap, const Surface &in, const AxisTaps &taps, const StoreParams &st)
+{
+    return (FoldedRows(axis, swap, taps) || FoldedCols(axis, swap, taps)) && EpiOf(st) != EPI_RUNTIME &&
+           (in.fmt == SF_BGRA8 || in.fmt == SF_RGB10A2 || in.fmt == SF_RGBA16F);
 }
 
 hipError_t LaunchResize(int axis, bool swap, const Surface &in, const AxisTaps &taps, const int32_t *other,
-                        int out_w, int out_h, const StoreParams &st, hipStream_t s, bool generic)
+                        int out_w, int out_h, const StoreParams &st, hipStream_t s, bool generic, const ResizeBatch *batch)
 {
-    if (!generic && !swap) {
-        // taps along screen y with a 1:1 column map -> row kernel; taps along screen x with a block table -> column kernel
-        const bool rows = axis == 1 && taps.other_identity;
-        const bool cols = axis == 0 && taps.blk_lo && taps.idx_t && taps.blk_span > 0 && taps.blk_span <= kResizeSpanMax;
+    if (!generic && ResizeHasFoldedKernel(axis, swap, in, taps, st)) {
+        const bool rows = FoldedRows(axis, swap, taps);
         const int epi = EpiOf(st);
-        if ((rows || cols) && epi != EPI_RUNTIME) {
-            bool done = false;
-            if (in.fmt == SF_BGRA8) done = LaunchResizeFastN<SF_BGRA8>(epi, rows, in, taps, other, out_w, out_h, st, s);
-            else if (in.fmt == SF_RGB10A2) done = LaunchResizeFastN<SF_RGB10A2>(epi, rows, in, taps, other, out_w, out_h, st, s);
-            else if (in.fmt == SF_RGBA16F) done = LaunchResizeFastN<SF_RGBA16F>(epi, rows, in, taps, other, out_w, out_h, st, s);
-            if (done) return hipGetLastError();
-        }
+        const ResizeBatch one{}, &bt = batch ? *batch : one;
+        bool done = false;
+        if (in.fmt == SF_BGRA8) done = LaunchResizeFastN<SF_BGRA8>(epi, rows, in, taps, other, out_w, out_h, st, s, bt);
+        else if (in.fmt == SF_RGB10A2) done = LaunchResizeFastN<SF_RGB10A2>(epi, rows, in, taps, other, out_w, out_h, st, s, bt);
+        else if (in.fmt == SF_RGBA16F) done = LaunchResizeFastN<SF_RGBA16F>(epi, rows, in, taps, other, out_w, out_h, st, s, bt);
+        if (done) return hipGetLastError();
     }
+    if (batch && batch->n != 1) return hipErrorNotSupported;
     const dim3 g = grid2d(out_w, out_h), b(64, 4, 1);
     if (axis == 0 && !swap) hipLaunchKernelGGL((k_resize<0, false>), g, b, 0, s, in, taps, other, out_w, out_h, st);
     else if (axis == 0)     hipLaunchKernelGGL((k_resize<0, true>), g, b, 0, s, in, taps, other, out_w, out_h, st);

@@ -15,8 +15,14 @@ hipError_t LaunchRepackRgb(int kind, const uint8_t *src, int src_pitch, uint8_t 
 // CopyFrameV210 (Helper.cpp:709-748): v210 sample -> Y210-layout texture
 hipError_t LaunchRepackV210(const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int lines, hipStream_t s);
 // axis = screen axis the tap table runs along; swap = rotation 90/270 (taps address the other texture axis)
+// batch: n frames per launch (folded kernels only) — frame z reads in.ptr + z * in_stride and writes frames[z].dst when a
+// frame table is given, else st.dst + z * dst_stride.  Returns hipErrorNotSupported when the draw has no folded kernel.
+struct FusedFrame;
+struct ResizeBatch { int n = 1; size_t in_stride = 0, dst_stride = 0; const FusedFrame *frames = nullptr; };
 hipError_t LaunchResize(int axis, bool swap, const Surface &in, const AxisTaps &taps, const int32_t *other,
-                        int out_w, int out_h, const StoreParams &st, hipStream_t s, bool generic = false);
+                        int out_w, int out_h, const StoreParams &st, hipStream_t s, bool generic = false,
+                        const ResizeBatch *batch = nullptr);
+bool ResizeHasFoldedKernel(int axis, bool swap, const Surface &in, const AxisTaps &taps, const StoreParams &st);
 hipError_t LaunchCopy(const Surface &in, int out_w, int out_h, const StoreParams &st, hipStream_t s);
 // ps_hdr10_tonemap.hlsl: HDR10 local tone mapping as a post-scale step
 hipError_t LaunchHdr10ToneMap(const Surface &in, const HdrToneMapParams &tm, int out_w, int out_h, const StoreParams &st, hipStream_t s);
@@ -44,7 +50,9 @@ bool FusedUp2xSupported(const FusedParams &P);
 // the destination: texels of the internal format (m_TexConvertOutput, or the render target when nothing follows: to_rt), or
 // the final pass into a B8G8R8A8 render target (store.mode == ST_FINAL).  out_w / out_h / wx / wy of P are not used.
 bool ConvertBlocksSupported(const FusedParams &P, bool to_rt);
-hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
+// batch_stride != 0: frame z is stored at P.store.dst + z * batch_stride (a batched intermediate) instead of frames[z].dst
+hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s,
+                               size_t batch_stride = 0);
 // frames_dev == nullptr: n_frames must be 1 and `single` is used (no device-side table needed)
 hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
 
