@@ -175,7 +175,11 @@ __global__ __launch_bounds__(256) void k_resize_cols(Surface in, AxisTaps taps, 
                                                     int out_w, int out_h, StoreParams st, ResizeBatch bt)
 {
     constexpr int R = 4;
-    __shared__ float4 tile[4][R][kResizeSpanMax];
+    // [wave][row][span] decoded texels; span = taps.blk_span rounded up (dynamic: upscales need ~70 texels per row, and the
+    // smaller the tile the more workgroups a CU holds — this kernel lives on occupancy, not on ALU)
+    extern __shared__ __attribute__((aligned(16))) unsigned char resize_smem[];
+    const int span = (taps.blk_span + 3) & ~3;
+    float4 *const tile_w = (float4 *)resize_smem + (size_t)threadIdx.y * R * span;
     in.ptr = (uint8_t *)in.ptr + (size_t)blockIdx.z * bt.in_stride;
     st.dst = bt.frames ? bt.frames[blockIdx.z].dst : (void *)((uint8_t *)st.dst + (size_t)blockIdx.z * bt.dst_stride);
     const int lane = threadIdx.x, wv = threadIdx.y;
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256) void k_resize_cols(Surface in, AxisTaps taps, 
             const int o = other[yb + r];
             for (int p = lo + lane; p < hi; p += 64) {
                 const f3 q = load_surface(in, p, o);
-                tile[wv][r][p - lo] = make_float4(q.x, q.y, q.z, 0.0f);
+                tile_w[r * span + (p - lo)] = make_float4(q.x, q.y, q.z, 0.0f);
             }
         }
     }
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(256) void k_resize_cols(Surface in, AxisTaps taps, 
         const float w0 = w[0];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const float4 q = tile[wv][r][i0];
+            const float4 q = tile_w[r * span + i0];
             acc[r].x = w0 * q.x; acc[r].y = w0 * q.y; acc[r].z = w0 * q.z;
         }
     }
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256) void k_resize_cols(Surface in, AxisTaps taps, 
         const float wk = w[k * n];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const float4 q = tile[wv][r][ik];
+            const float4 q = tile_w[r * span + ik];
             acc[r].x = acc[r].x + wk * q.x; acc[r].y = acc[r].y + wk * q.y; acc[r].z = acc[r].z + wk * q.z;
         }
     }
@@ -448,7 +452,8 @@ static void LaunchResizeFast(bool rows, const Surface &in, const AxisTaps &taps,
         else if (px == 2) hipLaunchKernelGGL((k_resize_rows<NT, INFMT, EPI, 2>), dim3(grid, 1, 1), dim3(256, 1, 1), 0, s, in, taps, out_w, out_h, gx, st, bt);
         else hipLaunchKernelGGL((k_resize_rows<NT, INFMT, EPI, 4>), dim3(grid, 1, 1), dim3(256, 1, 1), 0, s, in, taps, out_w, out_h, gx, st, bt);
     }
-    else hipLaunchKernelGGL((k_resize_cols<NT, INFMT, EPI>), dim3((out_w + 63) / 64, (out_h + 15) / 16, bt.n), dim3(64, 4, 1), 0, s, in, taps, other, out_w, out_h, st, bt);
+    else hipLaunchKernelGGL((k_resize_cols<NT, INFMT, EPI>), dim3((out_w + 63) / 64, (out_h + 15) / 16, bt.n), dim3(64, 4, 1),
+                            (size_t)4 * 4 * ((taps.blk_span + 3) & ~3) * sizeof(float4), s, in, taps, other, out_w, out_h, st, bt);
 }
 template <int NT, int INFMT>
 static bool LaunchResizeFastE(int epi, bool rows, const Surface &in, const AxisTaps &taps, const int32_t *other, int out_w, int out_h,
