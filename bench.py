@@ -40,6 +40,11 @@ WORKLOADS = {
                iUpscaling=4, desc="4K P010 HLG -> Lanczos3 2x -> HLG->SDR -> ordered dither -> 8K BGRA8"),
     "c2": dict(cformat=20, w=1920, h=1080, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=1, primaries=2, transfer=5),
                iUpscaling=2, desc="1080p YUV420P10 BT.709 -> Catmull-Rom 2x -> ordered dither -> 4K BGRA8"),
+    # BASELINE.json configs[0] and the native-resolution HDR case: no resize, one block-convert launch per batch
+    "c1": dict(cformat=1, w=1920, h=1080, scale=1, ext=dict(chroma=5, nominal_range=2, matrix=1, primaries=2, transfer=5),
+               iUpscaling=2, desc="1080p NV12 BT.709 -> BGRA8, no resize (BASELINE configs[0])"),
+    "hdr4k": dict(cformat=2, w=3840, h=2160, scale=1, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
+                  iUpscaling=4, desc="4K P010 BT.2020/PQ -> PQ->SDR(Hable,125nits) -> ordered dither -> 4K BGRA8, no resize"),
     "c3hdr_1080p": dict(cformat=2, w=1920, h=1080, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
                         iUpscaling=4, desc="1080p P010 BT.2020/PQ -> Lanczos3 2x -> PQ->SDR -> dither -> 4K BGRA8 (alternative reading)"),
 }
@@ -56,6 +61,10 @@ def noise_frame_gpu(torch, wl, nbytes, pitch, gen):
         y = torch.randint(64, 941, (h * w,), device="cuda", generator=gen, dtype=torch.int32)
         c = torch.randint(64, 961, (2 * (h // 2) * (w // 2),), device="cuda", generator=gen, dtype=torch.int32)
         buf = torch.cat([y, c]).to(torch.int16).view(torch.uint8)
+    elif wl["cformat"] == 1:                                 # NV12: 8-bit codes, luma plane + interleaved chroma
+        y = torch.randint(16, 236, (h * w,), device="cuda", generator=gen, dtype=torch.int32)
+        c = torch.randint(16, 241, ((h // 2) * w,), device="cuda", generator=gen, dtype=torch.int32)
+        buf = torch.cat([y, c]).to(torch.uint8)
     else:
         raise ValueError("workload format")
     assert buf.numel() == nbytes, (buf.numel(), nbytes)
@@ -230,7 +239,9 @@ def main():
             except Exception:
                 traffic = None
         res = {
-            "metric": "4K frames/sec/GPU (P010->Lanczos3 2x->PQ-SDR->dither); % HBM roofline",
+            # BASELINE.json's metric names the default workload; other --workload values are side measurements
+            "metric": ("4K frames/sec/GPU (P010->Lanczos3 2x->PQ-SDR->dither); % HBM roofline" if args.workload == "c3hdr"
+                       else f"frames/sec/GPU ({args.workload}); % HBM roofline"),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (u16 in, u8 out)", "data": "synthetic",

@@ -47,18 +47,23 @@ def build(force=False, verbose=False):
     hdr_mtime = max(os.path.getmtime(h) for h in headers)
     objs = []
     common = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+    jobs = []
     for name, extra in SOURCES:
         src = os.path.join(CSRC, name)
         obj = os.path.join(BUILD, name + ".o")
         objs.append(obj)
         if force or _newer(src, obj) or os.path.getmtime(obj) < hdr_mtime:
-            cmd = [hipcc, "-c", src, "-o", obj] + common + extra
-            if name.endswith(".cpp"):
-                cmd += ["-x", "hip"]          # host files include hip_runtime.h for launch types
-                cmd = [hipcc, "-x", "hip", "-c", src, "-o", obj] + common + extra
+            # host files include hip_runtime.h for launch types: everything goes through -x hip
+            cmd = [hipcc, "-x", "hip", "-c", src, "-o", obj] + common + extra
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
-            subprocess.check_call(cmd)
+            jobs.append(cmd)
+    if jobs:        # the translation units are independent: compile them side by side (the two kernel files dominate)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
+            for rc in pool.map(lambda c: subprocess.run(c).returncode, jobs):
+                if rc != 0:
+                    raise subprocess.CalledProcessError(rc, "hipcc")
     if force or any(_newer(o, OUT) for o in objs):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs
         if verbose:

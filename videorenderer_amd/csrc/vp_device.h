@@ -419,15 +419,39 @@ __device__ __forceinline__ f3 load_surface(const Surface &s, int x, int y)
     return v;
 }
 
+// load_surface split in two, so that a kernel can have the texels of its next row in flight while it filters the current one
+template <int FMT> __device__ __forceinline__ uint2 load_texel_raw(const Surface &s, int x, int y)
+{
+    const uint8_t *row = (const uint8_t *)s.ptr + (size_t)y * s.pitch;
+    if (FMT == SF_BGRA8 || FMT == SF_RGB10A2) return uint2{((const uint32_t *)row)[x], 0u};
+    return ((const uint2 *)row)[x];
+}
+template <int FMT> __device__ __forceinline__ f3 decode_texel(uint2 u)
+{
+    f3 v;
+    if (FMT == SF_BGRA8) {
+        v.x = unorm_div<255>((float)((u.x >> 16) & 255u)); v.y = unorm_div<255>((float)((u.x >> 8) & 255u)); v.z = unorm_div<255>((float)(u.x & 255u));
+    } else if (FMT == SF_RGB10A2) {
+        v.x = unorm_div<1023>((float)(u.x & 1023u)); v.y = unorm_div<1023>((float)((u.x >> 10) & 1023u)); v.z = unorm_div<1023>((float)((u.x >> 20) & 1023u));
+    } else if (FMT == SF_RGBA16) {
+        v.x = unorm_div<65535>((float)(u.x & 0xffffu)); v.y = unorm_div<65535>((float)(u.x >> 16)); v.z = unorm_div<65535>((float)(u.y & 0xffffu));
+    } else {
+        const __half2 lo = *(const __half2 *)&u.x, hi = *(const __half2 *)&u.y;
+        v.x = __low2float(lo); v.y = __high2float(lo); v.z = __low2float(hi);
+    }
+    return v;
+}
+
 // epilogue of the last draw: plain surface store, or m_TexsPostScale rounding + ps_final_pass.hlsl:23-31
-__device__ __forceinline__ void store_epilogue(const StoreParams &S, int x, int y, f3 v)
+// (dither_pre: the dither texel of this pixel, fetched earlier by the caller; < 0 = fetch here)
+__device__ __forceinline__ void store_epilogue(const StoreParams &S, int x, int y, f3 v, int dither_pre = -1)
 {
     const int wx = x + S.off_x, wy = y + S.off_y;
     if (S.clip_w > 0 && (wx < 0 || wy < 0 || wx >= S.clip_w || wy >= S.clip_h)) return;
     if (S.mode == ST_SURFACE) { store_surface(S.dst, S.dst_pitch, S.dst_fmt, wx, wy, v); return; }
     v = round_to_fmt(v, S.mid_fmt);
     // sampler WRAP + POINT, ditherCoordScale = texSize/32  =>  texel (wx mod 32, wy mod 32)
-    const float d = __half2float(__ushort_as_half(S.dither[(wy & 31) * 32 + (wx & 31)]));
+    const float d = __half2float(__ushort_as_half(dither_pre >= 0 ? (unsigned short)dither_pre : S.dither[(wy & 31) * 32 + (wx & 31)]));
     const float q = (float)S.quant;
     const float r = fminf(fmaxf(floorf(v.x * q + d), 0.0f), q);
     const float g = fminf(fmaxf(floorf(v.y * q + d), 0.0f), q);

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_resize(Surface in, AxisTaps taps, const
 enum EpiCode : int { EPI_RUNTIME = 0, EPI_TO_FP16 = 1, EPI_FINAL_10_TO_8 = 2, EPI_FINAL_16F_TO_8 = 3, EPI_FINAL_16F_TO_10 = 4,
                      EPI_TO_BGRA8 = 5, EPI_TO_RGB10 = 6 };
 template <int EPI>
-__device__ __forceinline__ void store_epi(StoreParams st, int x, int y, f3 v)
+__device__ __forceinline__ void store_epi(StoreParams st, int x, int y, f3 v, int dither_pre = -1)
 {
     if (EPI == EPI_TO_FP16) { st.mode = ST_SURFACE; st.dst_fmt = SF_RGBA16F; }
     if (EPI == EPI_FINAL_10_TO_8) { st.mode = ST_FINAL; st.mid_fmt = SF_RGB10A2; st.dst_fmt = SF_BGRA8; st.quant = 255; }
@@ -101,7 +101,7 @@ __device__ __forceinline__ void store_epi(StoreParams st, int x, int y, f3 v)
     if (EPI == EPI_FINAL_16F_TO_10) { st.mode = ST_FINAL; st.mid_fmt = SF_RGBA16F; st.dst_fmt = SF_RGB10A2; st.quant = 1023; }
     if (EPI == EPI_TO_BGRA8) { st.mode = ST_SURFACE; st.dst_fmt = SF_BGRA8; }
     if (EPI == EPI_TO_RGB10) { st.mode = ST_SURFACE; st.dst_fmt = SF_RGB10A2; }
-    store_epilogue(st, x, y, v);
+    store_epilogue(st, x, y, v, dither_pre);
 }
 static int EpiOf(const StoreParams &st)
 {
@@ -123,13 +123,18 @@ static int EpiOf(const StoreParams &st)
 template <int NT, int INFMT, int EPI, int PX>
 __global__ __launch_bounds__(256) void k_resize_rows(Surface in, AxisTaps taps, int out_w, int out_h, int gx, StoreParams st, ResizeBatch bt)
 {
+    // A workgroup owns RW consecutive output rows of its columns and walks them with the texels of the next row already
+    // in flight: one wave = one row would spend its life in four dependent round trips (arguments, tap table, texels,
+    // dither) for ~85 ALU instructions per pixel; here those latencies are paid once per RW rows.
+    constexpr int RW = 8;
     // workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give XCD k the k-th contiguous band of
-    // output rows (its taps then re-read rows its own L2 already holds) instead of every 8th row.  1-D grid of
-    // 8 * ceil(gx * out_h / 8) workgroups; logical id = (id mod 8) * (grid / 8) + id / 8 is a bijection on it.
+    // output rows (its taps then re-read rows its own L2 already holds) instead of every 8th row group.  1-D grid of
+    // 8 * ceil(units / 8) workgroups; logical id = (id mod 8) * (grid / 8) + id / 8 is a bijection on it.
     // With a batch the bands run over whole frames: an XCD works on its own frames.
     const int per = gridDim.x >> 3, lid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    const int row = lid / gx, bx = lid - row * gx;
-    const int z = row / out_h, y = row - z * out_h;
+    const int groups = (out_h + RW - 1) / RW;
+    const int rg = lid / gx, bx = lid - rg * gx;
+    const int z = rg / groups, y0 = (rg - z * groups) * RW;
     if (z >= bt.n) return;
     in.ptr = (uint8_t *)in.ptr + (size_t)z * bt.in_stride;
     st.dst = bt.frames ? bt.frames[z].dst : (void *)((uint8_t *)st.dst + (size_t)z * bt.dst_stride);
@@ -137,34 +142,86 @@ __global__ __launch_bounds__(256) void k_resize_rows(Surface in, AxisTaps taps, 
     const int x0 = bx * (256 * PX) + threadIdx.x;
     if (x0 >= out_w) return;
     const int nt = NT ? NT : taps.ntaps;
-    const int32_t *idx = taps.idx + (size_t)y * nt;
-    const float *w = taps.w + (size_t)y * nt;
-    in.fmt = INFMT;
     int xs[PX];
-    f3 acc[PX];
 #pragma unroll
     for (int p = 0; p < PX; p++) xs[p] = min(x0 + p * 256, out_w - 1);
+    const bool final = EPI == EPI_FINAL_10_TO_8 || EPI == EPI_FINAL_16F_TO_8 || EPI == EPI_FINAL_16F_TO_10;
+
+    if (NT == 0) {          // run-time tap count (convolution downscalers): no register prefetch
+        in.fmt = INFMT;
+        for (int r = 0; r < RW && y0 + r < out_h; r++) {
+            const int y = y0 + r;
+            const int32_t *idx = taps.idx + (size_t)y * nt;
+            const float *w = taps.w + (size_t)y * nt;
+            f3 acc[PX];
 #pragma unroll
-    for (int p = 0; p < PX; p++) {
-        const f3 q = load_surface(in, xs[p], idx[0]);
-        acc[p].x = w[0] * q.x; acc[p].y = w[0] * q.y; acc[p].z = w[0] * q.z;
+            for (int p = 0; p < PX; p++) {
+                const f3 q = load_surface(in, xs[p], idx[0]);
+                acc[p].x = w[0] * q.x; acc[p].y = w[0] * q.y; acc[p].z = w[0] * q.z;
+            }
+            for (int k = 1; k < nt; k++) {
+#pragma unroll
+                for (int p = 0; p < PX; p++) {
+                    const f3 q = load_surface(in, xs[p], idx[k]);
+                    acc[p].x = acc[p].x + w[k] * q.x; acc[p].y = acc[p].y + w[k] * q.y; acc[p].z = acc[p].z + w[k] * q.z;
+                }
+            }
+            if (taps.normalise) {
+                const float ww = taps.wsum[y];
+#pragma unroll
+                for (int p = 0; p < PX; p++) { acc[p].x = acc[p].x / ww; acc[p].y = acc[p].y / ww; acc[p].z = acc[p].z / ww; }
+            }
+#pragma unroll
+            for (int p = 0; p < PX; p++)
+                if (x0 + p * 256 < out_w) store_epi<EPI>(st, x0 + p * 256, y, acc[p]);
+        }
+        return;
     }
+
+    constexpr int NTC = NT ? NT : 1;
+    uint2 raw[2][NTC][PX];
+    int dth[2][PX];
+    auto fetch = [&](int y, int slot) {
+        const int yc = min(y, out_h - 1);
+        const int32_t *idx = taps.idx + (size_t)yc * NTC;
 #pragma unroll
-    for (int k = 1; k < nt; k++) {
+        for (int k = 0; k < NTC; k++)
+#pragma unroll
+            for (int p = 0; p < PX; p++) raw[slot][k][p] = load_texel_raw<INFMT>(in, xs[p], idx[k]);
+#pragma unroll
+        for (int p = 0; p < PX; p++)
+            dth[slot][p] = final ? (int)st.dither[((yc + st.off_y) & 31) * 32 + ((xs[p] + st.off_x) & 31)] : -1;
+    };
+    fetch(y0, 0);
+#pragma unroll
+    for (int r = 0; r < RW; r++) {
+        const int y = y0 + r, cur = r & 1;
+        if (y >= out_h) break;
+        if (r + 1 < RW) fetch(y + 1, cur ^ 1);
+        const float *w = taps.w + (size_t)y * NTC;
+        f3 acc[PX];
 #pragma unroll
         for (int p = 0; p < PX; p++) {
-            const f3 q = load_surface(in, xs[p], idx[k]);
-            acc[p].x = acc[p].x + w[k] * q.x; acc[p].y = acc[p].y + w[k] * q.y; acc[p].z = acc[p].z + w[k] * q.z;
+            const f3 q = decode_texel<INFMT>(raw[cur][0][p]);
+            acc[p].x = w[0] * q.x; acc[p].y = w[0] * q.y; acc[p].z = w[0] * q.z;
         }
-    }
-    if (taps.normalise) {
-        const float ww = taps.wsum[y];
 #pragma unroll
-        for (int p = 0; p < PX; p++) { acc[p].x = acc[p].x / ww; acc[p].y = acc[p].y / ww; acc[p].z = acc[p].z / ww; }
-    }
+        for (int k = 1; k < NTC; k++) {
 #pragma unroll
-    for (int p = 0; p < PX; p++)
-        if (x0 + p * 256 < out_w) store_epi<EPI>(st, x0 + p * 256, y, acc[p]);
+            for (int p = 0; p < PX; p++) {
+                const f3 q = decode_texel<INFMT>(raw[cur][k][p]);
+                acc[p].x = acc[p].x + w[k] * q.x; acc[p].y = acc[p].y + w[k] * q.y; acc[p].z = acc[p].z + w[k] * q.z;
+            }
+        }
+        if (taps.normalise) {
+            const float ww = taps.wsum[y];
+#pragma unroll
+            for (int p = 0; p < PX; p++) { acc[p].x = acc[p].x / ww; acc[p].y = acc[p].y / ww; acc[p].z = acc[p].z / ww; }
+        }
+#pragma unroll
+        for (int p = 0; p < PX; p++)
+            if (x0 + p * 256 < out_w) store_epi<EPI>(st, x0 + p * 256, y, acc[p], dth[cur][p]);
+    }
 }
 
 // taps run along the texture columns: a wave owns 64 consecutive outputs of 4 rows, decodes the source texels they touch
@@ -445,12 +502,10 @@ template <int NT, int INFMT, int EPI>
 static void LaunchResizeFast(bool rows, const Surface &in, const AxisTaps &taps, const int32_t *other, int out_w, int out_h,
                              const StoreParams &st, hipStream_t s, const ResizeBatch &bt)
 {
-    static const int px = getenv("MPCVR_ROWS_PX") ? atoi(getenv("MPCVR_ROWS_PX")) : 2;
     if (rows) {
-        const int per = 256 * px, gx = (out_w + per - 1) / per, grid = (gx * out_h * bt.n + 7) / 8 * 8;
-        if (px == 1) hipLaunchKernelGGL((k_resize_rows<NT, INFMT, EPI, 1>), dim3(grid, 1, 1), dim3(256, 1, 1), 0, s, in, taps, out_w, out_h, gx, st, bt);
-        else if (px == 2) hipLaunchKernelGGL((k_resize_rows<NT, INFMT, EPI, 2>), dim3(grid, 1, 1), dim3(256, 1, 1), 0, s, in, taps, out_w, out_h, gx, st, bt);
-        else hipLaunchKernelGGL((k_resize_rows<NT, INFMT, EPI, 4>), dim3(grid, 1, 1), dim3(256, 1, 1), 0, s, in, taps, out_w, out_h, gx, st, bt);
+        constexpr int PX = 2;        // 1 and 4 measured slower on MI355X (1440p Lanczos3: 335 / 279 / 303 us per 16 frames)
+        const int gx = (out_w + 256 * PX - 1) / (256 * PX), grid = (gx * ((out_h + 7) / 8) * bt.n + 7) / 8 * 8;     // RW = 8 rows per workgroup
+        hipLaunchKernelGGL((k_resize_rows<NT, INFMT, EPI, PX>), dim3(grid, 1, 1), dim3(256, 1, 1), 0, s, in, taps, out_w, out_h, gx, st, bt);
     }
     else hipLaunchKernelGGL((k_resize_cols<NT, INFMT, EPI>), dim3((out_w + 63) / 64, (out_h + 15) / 16, bt.n), dim3(64, 4, 1),
                             (size_t)4 * 4 * ((taps.blk_span + 3) & ~3) * sizeof(float4), s, in, taps, other, out_w, out_h, st, bt);
