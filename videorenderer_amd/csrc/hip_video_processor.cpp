@@ -419,6 +419,7 @@ HRESULT CHipVideoProcessor::UploadTaps(const HostAxisTaps &h, DevBuffer &bi, Dev
     // hints for the folded resize kernels: the source window of every block of 64 outputs, and whether the unfiltered
     // coordinate maps 1:1
     out->blk_lo = nullptr; out->blk_span = 0; out->idx_t = nullptr; out->w_t = nullptr; out->n_out = 0;
+    out->blk8_lo = nullptr; out->blk8_span = 0;
     const size_t nOut = h.ntaps > 0 ? h.idx.size() / (size_t)h.ntaps : 0;
     if (nOut > 0) {
         std::vector<int32_t> lo((nOut + 63) / 64);
@@ -429,9 +430,18 @@ HRESULT CHipVideoProcessor::UploadTaps(const HostAxisTaps &h, DevBuffer &bi, Dev
             lo[b] = *mm.first;
             span = std::max(span, *mm.second - *mm.first + 1);
         }
-        // tap-major copies of both tables behind the block table, in the same buffer
+        std::vector<int32_t> lo8((nOut + 7) / 8);
+        int span8 = 0;
+        for (size_t b = 0; b < lo8.size(); b++) {
+            const size_t first = b * 8 * (size_t)h.ntaps, last = std::min(nOut, (b + 1) * 8) * (size_t)h.ntaps;
+            const auto mm = std::minmax_element(h.idx.begin() + first, h.idx.begin() + last);
+            lo8[b] = *mm.first;
+            span8 = std::max(span8, *mm.second - *mm.first + 1);
+        }
+        // tap-major copies of both tables and the 8-output block table behind the block table, in the same buffer
         const size_t off = (lo.size() + 63) / 64 * 64, cnt = h.idx.size();
-        std::vector<int32_t> pack(off + 2 * cnt);
+        std::vector<int32_t> pack(off + 2 * cnt + lo8.size());
+        std::copy(lo8.begin(), lo8.end(), pack.begin() + off + 2 * cnt);
         std::copy(lo.begin(), lo.end(), pack.begin());
         for (size_t f = 0; f < nOut; f++)
             for (int k = 0; k < h.ntaps; k++) {
@@ -442,6 +452,7 @@ HRESULT CHipVideoProcessor::UploadTaps(const HostAxisTaps &h, DevBuffer &bi, Dev
         if ((hr = CheckHip(hipMemcpy(bb.ptr, pack.data(), pack.size() * sizeof(int32_t), hipMemcpyHostToDevice), "taps upload"))) return hr;
         out->blk_lo = (const int32_t *)bb.ptr; out->blk_span = span;
         out->idx_t = out->blk_lo + off; out->w_t = (const float *)(out->idx_t + cnt); out->n_out = (int)nOut;
+        out->blk8_lo = out->idx_t + 2 * cnt; out->blk8_span = span8;
     }
     out->other_identity = 1;
     for (size_t i = 0; i < other.size(); i++)
