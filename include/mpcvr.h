@@ -225,7 +225,12 @@ int32_t mpcvr_reset(mpcvr_ctx *ctx);
 
 /* Extension (not in the reference): n frames in one launch sequence to escape the launch-bound
  * regime.  srcs[i]: DEVICE sample pointers (layout/pitch as declared by mpcvr_set_input);
- * dsts[i]: DEVICE render targets (dst_pitch each). */
+ * dsts[i]: DEVICE render targets (dst_pitch each).
+ * The frames of a batch are independent of each other: on every path that can, the whole batch runs as one launch per
+ * draw (fused 2x kernel: one launch; pass-per-kernel path with a 4:2:0 source: block convert / X draw / Y draw with a
+ * frame dimension and batched intermediates, <= 4 GiB), otherwise frame by frame.  The targets must therefore be distinct
+ * buffers; completion is in stream order for the batch as a whole.  Dolby Vision metadata, rotation, Jinc2 and the HDR10
+ * tone-mapping step keep the frame-by-frame loop. */
 int32_t mpcvr_process_batch(mpcvr_ctx *ctx, int32_t n, const void *const *srcs, void *const *dsts,
                             int32_t dst_pitch);
 
