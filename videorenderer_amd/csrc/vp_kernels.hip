@@ -313,15 +313,31 @@ __global__ __launch_bounds__(256) void k_resize_cols(Surface in, AxisTaps taps, 
     in.fmt = INFMT;
     const int lo = taps.blk_lo[blockIdx.x];
     const int hi = min(lo + taps.blk_span, in.w);
+    {
+        // all texel reads of the tile first (up to 3 per row: span <= 192), then decode and park them: issued from inside the
+        // per-row loop, each read waited for its own round trip (an ablation put 300 of this kernel's 590 us there)
+        constexpr int IT = (kResizeSpanMax + 63) / 64;
+        uint2 rawv[R][IT];
+        int orow[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        if (yb + r < out_h) {
-            const int o = other[yb + r];
-            for (int p = lo + lane; p < hi; p += 64) {
-                const f3 q = load_surface(in, p, o);
-                tile_w[r * span + (p - lo)] = make_float4(q.x, q.y, q.z, 0.0f);
+        for (int r = 0; r < R; r++) orow[r] = other[min(yb + r, out_h - 1)];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int p = lo + lane + 64 * it;
+                if (p < hi) rawv[r][it] = load_texel_raw<INFMT>(in, p, orow[r]);
             }
-        }
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int p = lo + lane + 64 * it;
+                if (p < hi) {
+                    const f3 q = decode_texel<INFMT>(rawv[r][it]);
+                    tile_w[r * span + (p - lo)] = make_float4(q.x, q.y, q.z, 0.0f);
+                }
+            }
     }
     __syncthreads();
     if (x >= out_w) return;
