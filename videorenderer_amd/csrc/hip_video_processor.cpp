@@ -419,7 +419,7 @@ HRESULT CHipVideoProcessor::UploadTaps(const HostAxisTaps &h, DevBuffer &bi, Dev
     // hints for the folded resize kernels: the source window of every block of 64 outputs, and whether the unfiltered
     // coordinate maps 1:1
     out->blk_lo = nullptr; out->blk_span = 0; out->idx_t = nullptr; out->w_t = nullptr; out->n_out = 0;
-    out->blk8_lo = nullptr; out->blk8_span = 0;
+    out->blk8_lo = nullptr; out->blk8_span = 0; out->blk32_lo = nullptr; out->blk32_span = 0;
     const size_t nOut = h.ntaps > 0 ? h.idx.size() / (size_t)h.ntaps : 0;
     if (nOut > 0) {
         std::vector<int32_t> lo((nOut + 63) / 64);
@@ -438,10 +438,19 @@ HRESULT CHipVideoProcessor::UploadTaps(const HostAxisTaps &h, DevBuffer &bi, Dev
             lo8[b] = *mm.first;
             span8 = std::max(span8, *mm.second - *mm.first + 1);
         }
-        // tap-major copies of both tables and the 8-output block table behind the block table, in the same buffer
+        std::vector<int32_t> lo32((nOut + 31) / 32);
+        int span32 = 0;
+        for (size_t b = 0; b < lo32.size(); b++) {
+            const size_t first = b * 32 * (size_t)h.ntaps, last = std::min(nOut, (b + 1) * 32) * (size_t)h.ntaps;
+            const auto mm = std::minmax_element(h.idx.begin() + first, h.idx.begin() + last);
+            lo32[b] = *mm.first;
+            span32 = std::max(span32, *mm.second - *mm.first + 1);
+        }
+        // tap-major copies of both tables and the 8- / 32-output block tables behind the block table, in the same buffer
         const size_t off = (lo.size() + 63) / 64 * 64, cnt = h.idx.size();
-        std::vector<int32_t> pack(off + 2 * cnt + lo8.size());
+        std::vector<int32_t> pack(off + 2 * cnt + lo8.size() + lo32.size());
         std::copy(lo8.begin(), lo8.end(), pack.begin() + off + 2 * cnt);
+        std::copy(lo32.begin(), lo32.end(), pack.begin() + off + 2 * cnt + lo8.size());
         std::copy(lo.begin(), lo.end(), pack.begin());
         for (size_t f = 0; f < nOut; f++)
             for (int k = 0; k < h.ntaps; k++) {
@@ -453,6 +462,7 @@ HRESULT CHipVideoProcessor::UploadTaps(const HostAxisTaps &h, DevBuffer &bi, Dev
         out->blk_lo = (const int32_t *)bb.ptr; out->blk_span = span;
         out->idx_t = out->blk_lo + off; out->w_t = (const float *)(out->idx_t + cnt); out->n_out = (int)nOut;
         out->blk8_lo = out->idx_t + 2 * cnt; out->blk8_span = span8;
+        out->blk32_lo = out->blk8_lo + lo8.size(); out->blk32_span = span32;
     }
     out->other_identity = 1;
     for (size_t i = 0; i < other.size(); i++)
@@ -817,7 +827,11 @@ HRESULT CHipVideoProcessor::ResizeShaderPass(void *rt, int rtPitch, const uint8_
     HRESULT hr = MPCVR_S_OK;
     bool drawn = true;
     const bool plain = (m_cfg.flags & MPCVR_FLAG_NO_FUSED) != 0;      // keep the whole path on the one-kernel-fits-all versions
-    if (m_plan.two_pass) {
+    if (m_plan.two_pass && !plain && !m_firstJinc && !m_secondJinc && m_firstAxis == 0 && !m_firstSwap &&
+        Resize2DSupported(conv, m_tapsX, m_tapsY, last)) {
+        // both draws in one LDS-tiled kernel: m_TexResize stays on chip
+        hr = CheckHip(LaunchResize2D(conv, m_tapsX, m_tapsY, (const int32_t *)m_otherX.ptr, w2, h2, last, m_run), "k_resize_2d");
+    } else if (m_plan.two_pass) {
         Surface mid{m_runMid, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
         StoreParams st = MakeStore(mid.ptr, mid.pitch, SF_RGBA16F, false);
         if (m_firstJinc) hr = CheckHip(LaunchJinc2(conv, m_firstCoords, w2, m_plan.mid_h, st, m_run), "k_jinc2");
@@ -1004,6 +1018,7 @@ bool CHipVideoProcessor::BatchPlan(const uint8_t *sample0, void *rt0, int rtPitc
     const Surface cs{nullptr, convPitch, w1, h1, m_plan.internal_fmt};
     const StoreParams final = MakeStore(rt0, rtPitch, m_plan.swap_fmt, true);
     if (m_plan.two_pass) {
+        if (m_firstAxis == 0 && !m_firstSwap && Resize2DSupported(cs, m_tapsX, m_tapsY, final)) return true;
         const Surface mid{nullptr, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
         return ResizeHasFoldedKernel(m_firstAxis, m_firstSwap, cs, m_tapsX, MakeStore(nullptr, mid.pitch, SF_RGBA16F, false)) &&
                ResizeHasFoldedKernel(1, false, mid, m_tapsY, final);
@@ -1037,7 +1052,10 @@ HRESULT CHipVideoProcessor::ProcessBatchLaunches(int n, const FusedFrame *table,
         conv.store.dst = m_batchConv.ptr;
         if ((hr = CheckHip(LaunchConvertBlocks(conv, tab, FusedFrame{nullptr, nullptr}, m, m_stream, m_convBytes), "k_convert_blocks"))) return hr;
         ResizeBatch b1; b1.n = m; b1.in_stride = m_convBytes;
-        if (m_plan.two_pass) {
+        if (m_plan.two_pass && m_firstAxis == 0 && !m_firstSwap && Resize2DSupported(cs, m_tapsX, m_tapsY, final)) {
+            b1.frames = tab;
+            if ((hr = CheckHip(LaunchResize2D(cs, m_tapsX, m_tapsY, (const int32_t *)m_otherX.ptr, w2, h2, final, m_stream, &b1), "k_resize_2d"))) return hr;
+        } else if (m_plan.two_pass) {
             const Surface mid{m_batchMid.ptr, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
             b1.dst_stride = m_midBytes;
             if ((hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, cs, m_tapsX, (const int32_t *)m_otherX.ptr, w2, m_plan.mid_h,

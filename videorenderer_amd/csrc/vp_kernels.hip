@@ -374,6 +374,139 @@ __global__ __launch_bounds__(256) void k_resize_cols(Surface in, AxisTaps taps, 
         if (yb + r < out_h) store_epi<EPI>(st, x, yb + r, acc[r]);
 }
 
+// Both draws of a two-pass resize in one kernel, tiled through LDS: a workgroup owns a 64 x 32 tile of the output, runs the X
+// draw for the source rows the tile touches (8 rows at a time: decoded m_TexConvertOutput texels in LDS slice A, taps read
+// from there) and parks its results — rounded to fp16 exactly like m_TexResize — in LDS slice B, then runs the Y draw from B
+// straight into the final pass.  m_TexResize never exists in memory, and the Y draw's taps — the L2 reads the row kernel
+// spends most of its time on — become LDS reads.  Same tap order, same roundings as the two kernels above.
+template <int NT, int INFMT, int EPI>
+__global__ __launch_bounds__(256) void k_resize_2d(Surface in, AxisTaps tx, AxisTaps ty, const int32_t *__restrict__ other,
+                                                  int out_w, int out_h, int tiles_x, int tiles_y, StoreParams st, ResizeBatch bt)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char resize_smem[];
+    constexpr int CH = 8;                                   // source rows per X-draw chunk
+    const int spanX = (tx.blk_span + 3) & ~3, spanY = ty.blk32_span;
+    float4 *const A = (float4 *)resize_smem;                 // [CH][spanX] decoded texels
+    uint2 *const B = (uint2 *)(resize_smem + (size_t)CH * spanX * sizeof(float4));      // [spanY][64] X-draw results as half4
+    // XCD-contiguous tile ranges (see k_resize_rows); with a batch an XCD works on its own frames
+    const int per = gridDim.x >> 3, lid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int tiles = tiles_x * tiles_y, z = lid / tiles;
+    if (z >= bt.n) return;
+    const int t = lid - z * tiles, tyi = t / tiles_x, txi = t - tyi * tiles_x;
+    in.ptr = (uint8_t *)in.ptr + (size_t)z * bt.in_stride;
+    st.dst = bt.frames ? bt.frames[z].dst : (void *)((uint8_t *)st.dst + (size_t)z * bt.dst_stride);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = txi * 64 + lane, xc = min(x, out_w - 1);
+    const int ntx = NT ? NT : tx.ntaps, nty = NT ? NT : ty.ntaps;
+    const int loX = tx.blk_lo[txi], nX = min(tx.blk_span, in.w - loX);
+    const int loY = ty.blk32_lo[tyi], nY = min(spanY, in.h - loY);
+    constexpr int NTC = NT ? NT : 1;
+    // the X taps of this lane's column, once (tap-major tables)
+    int ix[NTC]; float wx[NTC];
+    if (NT) {
+#pragma unroll
+        for (int k = 0; k < NTC; k++) { ix[k] = tx.idx_t[xc + (size_t)k * tx.n_out] - loX; wx[k] = tx.w_t[xc + (size_t)k * tx.n_out]; }
+    }
+    const float wsx = tx.normalise ? tx.wsum[xc] : 1.0f;
+
+    for (int c0 = 0; c0 < nY; c0 += CH) {
+        {   // stage CH source rows: wave w takes rows w and w + 4 of the chunk; every texel read first, then decode + park
+            constexpr int IT = (kResizeSpanMax + 63) / 64;
+            uint2 rawv[2][IT];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int rr = wave + 4 * h;
+                const int o = other[min(loY + c0 + rr, in.h - 1)];
+#pragma unroll
+                for (int it = 0; it < IT; it++) {
+                    const int p = lane + 64 * it;
+                    if (p < nX && c0 + rr < nY) rawv[h][it] = load_texel_raw<INFMT>(in, loX + p, o);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int rr = wave + 4 * h;
+#pragma unroll
+                for (int it = 0; it < IT; it++) {
+                    const int p = lane + 64 * it;
+                    if (p < nX && c0 + rr < nY) {
+                        const f3 q = decode_texel<INFMT>(rawv[h][it]);
+                        A[rr * spanX + p] = make_float4(q.x, q.y, q.z, 0.0f);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // X draw of the chunk: wave w filters rows 2w and 2w + 1
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int rr = wave * 2 + j;
+            if (c0 + rr >= nY) break;
+            f3 acc;
+            if (NT) {
+                const float4 q0 = A[rr * spanX + ix[0]];
+                acc.x = wx[0] * q0.x; acc.y = wx[0] * q0.y; acc.z = wx[0] * q0.z;
+#pragma unroll
+                for (int k = 1; k < NTC; k++) {
+                    const float4 q = A[rr * spanX + ix[k]];
+                    acc.x = acc.x + wx[k] * q.x; acc.y = acc.y + wx[k] * q.y; acc.z = acc.z + wx[k] * q.z;
+                }
+            } else {
+                const float4 q0 = A[rr * spanX + tx.idx_t[xc] - loX];
+                const float w0 = tx.w_t[xc];
+                acc.x = w0 * q0.x; acc.y = w0 * q0.y; acc.z = w0 * q0.z;
+                for (int k = 1; k < ntx; k++) {
+                    const float4 q = A[rr * spanX + tx.idx_t[xc + (size_t)k * tx.n_out] - loX];
+                    const float wk = tx.w_t[xc + (size_t)k * tx.n_out];
+                    acc.x = acc.x + wk * q.x; acc.y = acc.y + wk * q.y; acc.z = acc.z + wk * q.z;
+                }
+            }
+            if (tx.normalise) { acc.x = acc.x / wsx; acc.y = acc.y / wsx; acc.z = acc.z / wsx; }
+            // the store into m_TexResize (fp16, RNE), kept as its bits
+            const __half2 lo = __halves2half2(__float2half_rn(acc.x), __float2half_rn(acc.y));
+            const __half2 hi = __halves2half2(__float2half_rn(acc.z), __float2half_rn(1.0f));
+            uint2 u;
+            u.x = *(const uint32_t *)&lo; u.y = *(const uint32_t *)&hi;
+            B[(c0 + rr) * 64 + lane] = u;
+        }
+        __syncthreads();
+    }
+
+    // Y draw + epilogue: wave w produces output rows 8w .. 8w + 7 of the tile
+    if (x >= out_w) return;
+    const bool final = EPI == EPI_FINAL_10_TO_8 || EPI == EPI_FINAL_16F_TO_8 || EPI == EPI_FINAL_16F_TO_10;
+#pragma unroll 2
+    for (int j = 0; j < 8; j++) {
+        const int y = tyi * 32 + wave * 8 + j;
+        if (y >= out_h) break;
+        const int32_t *idx = ty.idx + (size_t)y * nty;
+        const float *w = ty.w + (size_t)y * nty;
+        const int dth = final ? (int)st.dither[((y + st.off_y) & 31) * 32 + ((x + st.off_x) & 31)] : -1;
+        f3 acc;
+        {
+            const f3 q = decode_texel<SF_RGBA16F>(B[(idx[0] - loY) * 64 + lane]);
+            acc.x = w[0] * q.x; acc.y = w[0] * q.y; acc.z = w[0] * q.z;
+        }
+        if (NT) {
+#pragma unroll
+            for (int k = 1; k < NTC; k++) {
+                const f3 q = decode_texel<SF_RGBA16F>(B[(idx[k] - loY) * 64 + lane]);
+                acc.x = acc.x + w[k] * q.x; acc.y = acc.y + w[k] * q.y; acc.z = acc.z + w[k] * q.z;
+            }
+        } else {
+            for (int k = 1; k < nty; k++) {
+                const f3 q = decode_texel<SF_RGBA16F>(B[(idx[k] - loY) * 64 + lane]);
+                acc.x = acc.x + w[k] * q.x; acc.y = acc.y + w[k] * q.y; acc.z = acc.z + w[k] * q.z;
+            }
+        }
+        if (ty.normalise) {
+            const float ww = ty.wsum[y];
+            acc.x = acc.x / ww; acc.y = acc.y / ww; acc.z = acc.z / ww;
+        }
+        store_epi<EPI>(st, x, y, acc, dth);
+    }
+}
+
 // ps_resize_onepass_jinc2.hlsl:44-101 ("Jinc2m"): one 2-D draw — 4x4 texels around the sample position weighted by the
 // windowed jinc of their distance, normalised, then anti-ringing towards the min/max of the inner 2x2 (strength 0.8)
 __global__ __launch_bounds__(256) void k_jinc2(Surface in, DrawCoords dc, int out_w, int out_h, StoreParams st)
@@ -616,6 +749,55 @@ static bool LaunchResizeFastN(int epi, bool rows, const Surface &in, const AxisT
     if (taps.ntaps == 4) return LaunchResizeFastE<4, INFMT>(epi, rows, in, taps, other, out_w, out_h, st, s, bt);
     if (taps.ntaps == 6) return LaunchResizeFastE<6, INFMT>(epi, rows, in, taps, other, out_w, out_h, st, s, bt);
     return LaunchResizeFastE<0, INFMT>(epi, rows, in, taps, other, out_w, out_h, st, s, bt);
+}
+
+template <int NT, int INFMT>
+static bool LaunchResize2DE(int epi, const Surface &in, const AxisTaps &tx, const AxisTaps &ty, const int32_t *other, int out_w, int out_h,
+                            const StoreParams &st, hipStream_t s, const ResizeBatch &bt)
+{
+    const int tiles_x = (out_w + 63) / 64, tiles_y = (out_h + 31) / 32;
+    const dim3 grid((tiles_x * tiles_y * bt.n + 7) / 8 * 8, 1, 1), block(256, 1, 1);
+    const size_t lds = (size_t)8 * ((tx.blk_span + 3) & ~3) * sizeof(float4) + (size_t)ty.blk32_span * 64 * sizeof(uint2);
+#define MPCVR_R2D(E) hipLaunchKernelGGL((k_resize_2d<NT, INFMT, E>), grid, block, lds, s, in, tx, ty, other, out_w, out_h, tiles_x, tiles_y, st, bt)
+    switch (epi) {
+    case EPI_FINAL_10_TO_8: MPCVR_R2D(EPI_FINAL_10_TO_8); return true;
+    case EPI_FINAL_16F_TO_8: MPCVR_R2D(EPI_FINAL_16F_TO_8); return true;
+    case EPI_FINAL_16F_TO_10: MPCVR_R2D(EPI_FINAL_16F_TO_10); return true;
+    case EPI_TO_BGRA8: MPCVR_R2D(EPI_TO_BGRA8); return true;
+    case EPI_TO_RGB10: MPCVR_R2D(EPI_TO_RGB10); return true;
+    default: return false;
+    }
+#undef MPCVR_R2D
+}
+
+// the tiled two-draw kernel: first draw = column taps of an unrotated source, second draw = row taps with a 1:1 column map,
+// equal tap counts (4 / 6, or run-time), windows that fit LDS
+bool Resize2DSupported(const Surface &in, const AxisTaps &tx, const AxisTaps &ty, const StoreParams &st)
+{
+    const int epi = EpiOf(st);
+    if (epi == EPI_RUNTIME || epi == EPI_TO_FP16) return false;
+    if (in.fmt != SF_BGRA8 && in.fmt != SF_RGB10A2 && in.fmt != SF_RGBA16F) return false;
+    if (!tx.blk_lo || !tx.idx_t || tx.blk_span <= 0 || tx.blk_span > kResizeSpanMax) return false;
+    if (!ty.blk32_lo || !ty.other_identity || ty.blk32_span <= 0 || ty.blk32_span > kResizeTileRowsMax) return false;
+    return true;          // equal tap counts of 4 or 6 get the unrolled instantiation, anything else the run-time loops
+}
+
+hipError_t LaunchResize2D(const Surface &in, const AxisTaps &tx, const AxisTaps &ty, const int32_t *other, int out_w, int out_h,
+                          const StoreParams &st, hipStream_t s, const ResizeBatch *batch)
+{
+    if (!Resize2DSupported(in, tx, ty, st)) return hipErrorNotSupported;
+    const ResizeBatch one{}, &bt = batch ? *batch : one;
+    const int epi = EpiOf(st);
+    const int nt = (tx.ntaps == ty.ntaps && (tx.ntaps == 4 || tx.ntaps == 6)) ? tx.ntaps : 0;
+    bool done = false;
+#define MPCVR_R2D_F(F) (nt == 4 ? LaunchResize2DE<4, F>(epi, in, tx, ty, other, out_w, out_h, st, s, bt) \
+                       : nt == 6 ? LaunchResize2DE<6, F>(epi, in, tx, ty, other, out_w, out_h, st, s, bt) \
+                                 : LaunchResize2DE<0, F>(epi, in, tx, ty, other, out_w, out_h, st, s, bt))
+    if (in.fmt == SF_BGRA8) done = MPCVR_R2D_F(SF_BGRA8);
+    else if (in.fmt == SF_RGB10A2) done = MPCVR_R2D_F(SF_RGB10A2);
+    else done = MPCVR_R2D_F(SF_RGBA16F);
+#undef MPCVR_R2D_F
+    return done ? hipGetLastError() : hipErrorNotSupported;
 }
 
 // taps along screen y with a 1:1 column map -> row kernel; taps along screen x with a block table -> column kernel

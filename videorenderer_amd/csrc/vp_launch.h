@@ -23,6 +23,10 @@ hipError_t LaunchResize(int axis, bool swap, const Surface &in, const AxisTaps &
                         int out_w, int out_h, const StoreParams &st, hipStream_t s, bool generic = false,
                         const ResizeBatch *batch = nullptr);
 bool ResizeHasFoldedKernel(int axis, bool swap, const Surface &in, const AxisTaps &taps, const StoreParams &st);
+// both draws of an unrotated two-pass resize in one LDS-tiled kernel (no m_TexResize in memory); st = the second draw's epilogue
+bool Resize2DSupported(const Surface &in, const AxisTaps &tx, const AxisTaps &ty, const StoreParams &st);
+hipError_t LaunchResize2D(const Surface &in, const AxisTaps &tx, const AxisTaps &ty, const int32_t *other, int out_w, int out_h,
+                          const StoreParams &st, hipStream_t s, const ResizeBatch *batch = nullptr);
 hipError_t LaunchCopy(const Surface &in, int out_w, int out_h, const StoreParams &st, hipStream_t s);
 // ps_hdr10_tonemap.hlsl: HDR10 local tone mapping as a post-scale step
 hipError_t LaunchHdr10ToneMap(const Surface &in, const HdrToneMapParams &tm, int out_w, int out_h, const StoreParams &st, hipStream_t s);
