@@ -10,6 +10,8 @@ CASES = [("C1 1080p NV12 BT.709 -> 1080p BGRA8 (no resize)", 1920, 1080, 1920, 1
          ("C1 pass-per-kernel (convert, copy)", 1920, 1080, 1920, 1080, dict(flags=api.FLAG_NO_FUSED), 1, dict(chroma=5, nominal_range=2, matrix=1)),
          ("4K P010 PQ -> 4K SDR BGRA8 + dither (no resize)", 3840, 2160, 3840, 2160, dict()),
          ("4K P010 PQ -> 4K, pass-per-kernel (convert, final)", 3840, 2160, 3840, 2160, dict(flags=api.FLAG_NO_FUSED)),
+         ("4K P010 Dolby Vision (MMR + L2 trims) -> 4K SDR + dither (no resize)", 3840, 2160, 3840, 2160, dict(), 2, dict(chroma=5, nominal_range=2), "mmr"),
+         ("4K P010 Dolby Vision, plain kernels", 3840, 2160, 3840, 2160, dict(flags=api.FLAG_NO_FUSED), 2, dict(chroma=5, nominal_range=2), "mmr"),
          ("4K P010 PQ -> 1440p (Hamming down) -> SDR", 3840, 2160, 2560, 1440, dict(iDownscaling=2)),
          ("1080p P010 PQ -> 1440p (Lanczos3 1.33x) -> SDR", 1920, 1080, 2560, 1440, dict(iUpscaling=4)),
          ("1080p P010 PQ -> 4K (Lanczos3 2x), pass-per-kernel", 1920, 1080, 3840, 2160, dict(iUpscaling=4, flags=api.FLAG_NO_FUSED)),
@@ -29,6 +31,9 @@ for case in CASES:
     ex = api.make_extfmt(**case[7]) if len(case) > 7 else ext
     vp = api.VideoProcessor(api.default_settings(**kw))
     vp.InitMediaType(cf, w, h, extfmt=ex); vp.SetWindowRect((0, 0, dw, dh)); vp.SetVideoRect((0, 0, dw, dh))
+    if len(case) > 8:
+        from videorenderer_amd import synth
+        vp.SetDoviMetadata(synth.dovi_metadata(case[8], l2=(100, 600, 1000)))
     nb, pitch = vp.GetFrameBytes()
     if cf == 2:
         srcs = [(torch.randint(64, 941, (nb // 2,), device="cuda", dtype=torch.int32) << 6).to(torch.int16).view(torch.uint8) for _ in range(8)]

@@ -38,16 +38,18 @@ __global__ __launch_bounds__(256) void k_convert_direct(ConvertParams P, StorePa
 // expression for expression, and only the never-taken branches disappear.
 // OFMT = format of m_TexConvertOutput; DMODE 0: store into it, 1: ST_SURFACE epilogue into the render target (format DFMT),
 // 2: ST_FINAL epilogue (final pass) into the render target.
-template <int PLANES, int BYTES, int TAIL, int OFMT, int DMODE, int DFMT>
+// DV: Dolby Vision variant (P.dovi stays: reshaping, LMS step, trims) — 16-bit containers with the PQ->SDR tail or none.
+template <int PLANES, int BYTES, int TAIL, int OFMT, int DMODE, int DFMT, bool DV = false>
 __global__ __launch_bounds__(256) void k_convert_420(ConvertParams P, Surface out, StoreParams st)
 {
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
     if (i >= P.out_w || j >= P.out_h) return;
     P.fmt.layout = LAY_PLANAR; P.fmt.planes = PLANES; P.fmt.bytes = BYTES;
     P.fmt.subsampling = 420; P.fmt.div_w = 2; P.fmt.div_h = 2;
-    P.chroma_scaling = 1; P.blend_deint = 0; P.dovi = nullptr; P.tail = TAIL;
+    P.chroma_scaling = 1; P.blend_deint = 0; P.tail = TAIL;
+    if (!DV) P.dovi = nullptr;
     if (BYTES == 1 || PLANES == 2) P.fmt.shift = 0;
-    if (TAIL != TAIL_PQ_TO_SDR) P.pq_lut = nullptr;
+    if (TAIL != TAIL_PQ_TO_SDR || DV) P.pq_lut = nullptr;
     const f3 v = convert_pixel(P, i, j);
     if (DMODE == 0) { store_surface(out.ptr, out.pitch, OFMT, i, j, v); return; }
     st.mode = DMODE == 2 ? ST_FINAL : ST_SURFACE; st.mid_fmt = OFMT; st.dst_fmt = DFMT;
@@ -670,6 +672,13 @@ static void LaunchConvert420T(const ConvertParams &P, const Surface &out, const 
 #define MPCVR_C420_T(PL, BY) \
     switch (P.tail) { case TAIL_NONE: MPCVR_C420(PL, BY, TAIL_NONE); break; case TAIL_PQ_TO_SDR: MPCVR_C420(PL, BY, TAIL_PQ_TO_SDR); break; \
                       case TAIL_HLG_TO_SDR: MPCVR_C420(PL, BY, TAIL_HLG_TO_SDR); break; default: MPCVR_C420(PL, BY, TAIL_GAMMA_GAMUT); break; }
+    if (P.dovi) {         // Convert420Eligible admits Dolby Vision for 16-bit containers with TAIL_NONE / TAIL_PQ_TO_SDR only
+#define MPCVR_C420_DV(PL, TL) hipLaunchKernelGGL((k_convert_420<PL, 2, TL, OFMT, DMODE, DFMT, true>), g, b, 0, s, P, out, st)
+        if (P.fmt.planes == 2) { if (P.tail == TAIL_NONE) MPCVR_C420_DV(2, TAIL_NONE); else MPCVR_C420_DV(2, TAIL_PQ_TO_SDR); }
+        else                   { if (P.tail == TAIL_NONE) MPCVR_C420_DV(3, TAIL_NONE); else MPCVR_C420_DV(3, TAIL_PQ_TO_SDR); }
+#undef MPCVR_C420_DV
+        return;
+    }
     if (P.fmt.planes == 2) { if (P.fmt.bytes == 1) { MPCVR_C420_T(2, 1) } else { MPCVR_C420_T(2, 2) } }
     else                   { if (P.fmt.bytes == 1) { MPCVR_C420_T(3, 1) } else { MPCVR_C420_T(3, 2) } }
 #undef MPCVR_C420_T
@@ -679,8 +688,9 @@ static void LaunchConvert420T(const ConvertParams &P, const Surface &out, const 
 static bool Convert420Eligible(const ConvertParams &P)
 {
     return P.fmt.layout == LAY_PLANAR && P.fmt.subsampling == 420 && P.fmt.div_w == 2 && P.fmt.div_h == 2 && P.chroma_scaling == 1 &&
-           !P.blend_deint && !P.dovi && (P.fmt.planes == 2 || P.fmt.planes == 3) && (P.fmt.bytes == 1 || P.fmt.bytes == 2) &&
-           P.tail >= TAIL_NONE && P.tail <= TAIL_GAMMA_GAMUT;
+           !P.blend_deint && (P.fmt.planes == 2 || P.fmt.planes == 3) && (P.fmt.bytes == 1 || P.fmt.bytes == 2) &&
+           P.tail >= TAIL_NONE && P.tail <= TAIL_GAMMA_GAMUT &&
+           (!P.dovi || (P.fmt.bytes == 2 && (P.tail == TAIL_NONE || P.tail == TAIL_PQ_TO_SDR)));
 }
 
 hipError_t LaunchConvert(const ConvertParams &P, const Surface &out, hipStream_t s, bool generic)
