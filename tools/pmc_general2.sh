@@ -3,9 +3,11 @@
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmcg2; rm -rf $OUT; mkdir -p $OUT
 i=0
-for set in "MemUnitBusy MemUnitStalled WriteUnitStalled VALUBusy" "FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_EA_RDREQ_sum TCC_EA_WRREQ_sum" "TCC_EA_RDREQ_32B_sum TCC_EA_WRREQ_64B_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr"; do
+# one counter family per pass and a hard timeout around every pass: "FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" in ONE pass
+# aborted rocprofv3 on this pool and then sat in its signal handler until gpurun's limit (20 GPU-minutes lost)
+for set in "MemUnitBusy MemUnitStalled WriteUnitStalled VALUBusy" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o p -- python tools/bench_general.py "$1" > $OUT/log$i 2>&1 || tail -3 $OUT/log$i
+  timeout -k 5 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o p -- python tools/bench_general.py "$1" > $OUT/log$i 2>&1 || tail -3 $OUT/log$i
 done
 python - <<'PY'
 import csv, collections, glob

@@ -6,7 +6,7 @@ mkdir -p gpurun_out/gen
 i=0
 for c in "$@"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/gen -o case$i -- python tools/bench_general.py "$c" > gpurun_out/gen/case$i.log 2>&1
+  timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/gen -o case$i -- python tools/bench_general.py "$c" > gpurun_out/gen/case$i.log 2>&1
   grep '"case"' gpurun_out/gen/case$i.log | cut -c1-200
   python - "$i" <<'PY'
 import csv, sys
