@@ -2,7 +2,7 @@
 # tools/pmc_quick.sh [bench args] — one PMC pass (instruction mix) + plain bench; prints VALU instr per wave-iteration
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmcq; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/p -o p -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-host-path "$@" > $OUT/log 2>&1
+timeout -k 5 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/p -o p -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-host-path "$@" > $OUT/log 2>&1
 python - <<'PY'
 import csv, collections
 acc = collections.defaultdict(list)

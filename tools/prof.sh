@@ -7,8 +7,8 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
 BARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-host-path $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-host-path "$@" > $OUT/bench_kt.log 2>&1
-pmc() { n=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$n -o $n -- python bench.py $BARGS > $OUT/bench_$n.log 2>&1; }
+timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-host-path "$@" > $OUT/bench_kt.log 2>&1
+pmc() { n=$1; shift; timeout -k 5 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$n -o $n -- python bench.py $BARGS > $OUT/bench_$n.log 2>&1; }
 pmc pmc1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY
 pmc pmc2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM
 pmc pmc3 FETCH_SIZE
