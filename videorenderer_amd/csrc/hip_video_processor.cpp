@@ -55,7 +55,7 @@ CHipVideoProcessor::~CHipVideoProcessor()
     if (!m_bInit) return;
     (void)hipSetDevice(m_device);
     if (m_stream) (void)hipStreamSynchronize(m_stream);
-    for (DevBuffer *b : {&m_batchConv, &m_batchMid, &m_TexSrcVideo, &m_TexRaw, &m_TexPost, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
+    for (DevBuffer *b : {&m_batchConv, &m_batchMid, &m_jincFirst, &m_jincSecond, &m_TexSrcVideo, &m_TexRaw, &m_TexPost, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
                          &m_pqLut, &m_tapsXi, &m_tapsXw, &m_tapsXs, &m_tapsYi, &m_tapsYw, &m_tapsYs, &m_otherX, &m_otherY, &m_tapsXb, &m_tapsYb})
         b->Release();
     for (UploadSlot &u : m_up) {
@@ -557,6 +557,8 @@ HRESULT CHipVideoProcessor::UpdatePlan()
             if ((hr = UploadTaps(hx, m_tapsXi, m_tapsXw, m_tapsXs, m_tapsXb, ox, &m_tapsX))) return hr;
             if ((hr = UploadIndex(ox, m_otherX))) return hr;
         }
+        m_jincFirstTab = nullptr;
+        if (m_firstJinc && (hr = UploadJincPhases(m_firstCoords, m_jincFirst, &m_jincFirstTab))) return hr;
     }
     if (m_plan.two_pass) {
         // m_TexResize: fp16, dst width x (source extent along screen y) (:3143-3160); the second draw is unrotated
@@ -565,6 +567,8 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         m_midBytes = (size_t)w2 * 8 * mh;
         m_secondJinc = m_plan.ry.kind == RS_UP && m_plan.ry.method == MPCVR_UPSCALE_Jinc2;
         m_secondCoords = DrawCoords{0, w2, 0, 1.0f, 0, mh, 0, (float)mh / (float)h2, 0};
+        m_jincSecondTab = nullptr;
+        if (m_secondJinc && (hr = UploadJincPhases(m_secondCoords, m_jincSecond, &m_jincSecondTab))) return hr;
         if (!m_secondJinc) {
             if (!BuildAxisTaps(m_plan.ry, 0, mh, h2, mh, m_cfg.flags, &hy))
                 return Fail(MPCVR_E_NOTIMPL, "resize ratio outside the supported range");
@@ -600,6 +604,20 @@ HRESULT CHipVideoProcessor::UpdatePlan()
     }
     m_planDirty = false;
     UseLane(0);
+    return MPCVR_S_OK;
+}
+
+// dyadic, unrotated Jinc2m draws take their 16 weights from a phase table (vp_kernels.hip: k_jinc2_phases)
+HRESULT CHipVideoProcessor::UploadJincPhases(const DrawCoords &dc, DevBuffer &buf, const void **tab)
+{
+    *tab = nullptr;
+    if (m_cfg.flags & MPCVR_FLAG_NO_FUSED) return MPCVR_S_OK;
+    std::vector<unsigned char> host(JincPhasesBytes());
+    if (!BuildJincPhases(dc, host.data())) return MPCVR_S_OK;
+    HRESULT hr;
+    if ((hr = CheckHip(buf.CheckCreate(host.size()), "jinc phases"))) return hr;
+    if ((hr = CheckHip(hipMemcpy(buf.ptr, host.data(), host.size(), hipMemcpyHostToDevice), "jinc phases upload"))) return hr;
+    *tab = buf.ptr;
     return MPCVR_S_OK;
 }
 
@@ -834,13 +852,13 @@ HRESULT CHipVideoProcessor::ResizeShaderPass(void *rt, int rtPitch, const uint8_
     } else if (m_plan.two_pass) {
         Surface mid{m_runMid, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
         StoreParams st = MakeStore(mid.ptr, mid.pitch, SF_RGBA16F, false);
-        if (m_firstJinc) hr = CheckHip(LaunchJinc2(conv, m_firstCoords, w2, m_plan.mid_h, st, m_run), "k_jinc2");
+        if (m_firstJinc) hr = CheckHip(LaunchJinc2(conv, m_firstCoords, w2, m_plan.mid_h, st, m_run, m_jincFirstTab), "k_jinc2");
         else hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, m_plan.mid_h, st, m_run, plain), "k_resize<first>");
         if (hr) return hr;
-        if (m_secondJinc) hr = CheckHip(LaunchJinc2(mid, m_secondCoords, w2, h2, last, m_run), "k_jinc2");
+        if (m_secondJinc) hr = CheckHip(LaunchJinc2(mid, m_secondCoords, w2, h2, last, m_run, m_jincSecondTab), "k_jinc2");
         else hr = CheckHip(LaunchResize(1, false, mid, m_tapsY, (const int32_t *)m_otherY.ptr, w2, h2, last, m_run, plain), "k_resize<Y>");
     } else if (m_plan.one_pass) {
-        if (m_firstJinc) hr = CheckHip(LaunchJinc2(conv, m_firstCoords, w2, h2, last, m_run), "k_jinc2");
+        if (m_firstJinc) hr = CheckHip(LaunchJinc2(conv, m_firstCoords, w2, h2, last, m_run, m_jincFirstTab), "k_jinc2");
         else hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, h2, last, m_run, plain), "k_resize<one>");
     } else {
         drawn = false;

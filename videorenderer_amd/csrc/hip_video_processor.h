@@ -201,6 +201,10 @@ private:
     void UseLane(int lane);
     // whole-batch launches of the pass-per-kernel path (block convert + folded resize kernels with a frame dimension)
     DevBuffer m_batchConv, m_batchMid;
+    // Jinc2m phase tables of the first / second draw (null: weights per pixel)
+    DevBuffer m_jincFirst, m_jincSecond;
+    const void *m_jincFirstTab = nullptr, *m_jincSecondTab = nullptr;
+    HRESULT UploadJincPhases(const DrawCoords &dc, DevBuffer &buf, const void **tab);
     bool BatchPlan(const uint8_t *sample0, void *rt0, int rtPitch, bool aligned, FusedParams *conv, FusedParams *direct) const;
     HRESULT ProcessBatchLaunches(int n, const FusedFrame *table, const uint8_t *sample0, void *rt0, int rtPitch, bool aligned);
     HRESULT PrepareLanes(int lanes);

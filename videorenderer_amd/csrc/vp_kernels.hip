@@ -571,6 +571,72 @@ __global__ __launch_bounds__(256) void k_copy(Surface in, int out_w, int out_h, 
     store_epilogue(st, x, y, load_surface(in, x, y));
 }
 
+// Jinc2m at a dyadic ratio (2x, 4x, or an unscaled axis): the sample position's offset from its 4x4 neighbourhood — all
+// the weights depend on — takes 1/step values per axis, exactly (every term of the shader's expression is exact in fp32
+// there), so the 16 weights and their sum come from a <= 4 x 4 phase table built on the host with the shader's own
+// expressions instead of 16 x (sqrt, 2 sin, divide) per pixel.  The accumulation is k_jinc2's, in the same order.
+struct JincPhases { float w[4][4][16]; float wsum[4][4]; int px, py; };     // [phase y][phase x][j * 4 + i]
+__global__ __launch_bounds__(256) void k_jinc2_phases(Surface in, DrawCoords dc, const JincPhases *__restrict__ tab, int out_w, int out_h, StoreParams st)
+{
+    // the 64 x 4 outputs of the workgroup read at most (64 + 4) x (4 + 4) source texels (step <= 1): decoded once into LDS
+    // (with the clamp addressing applied there), the 16 taps of a pixel are LDS reads
+    constexpr int TW = 68, THh = 8;
+    __shared__ float W[16 * 16];
+    __shared__ float WS[16];
+    __shared__ float4 tile[THh * TW];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    W[tid] = (&tab->w[0][0][0])[tid];
+    if (tid < 16) WS[tid] = (&tab->wsum[0][0])[tid];
+    auto base_of = [](int org, int o, float step) {         // floor(tc) of output o, the shader's expression
+        const float pc = (float)org + ((float)o + 0.5f) * step;
+        return (int)floorf(floorf(pc - 0.5f) + 0.5f);
+    };
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
+    const int bx_lo = base_of(dc.org_x, x0, dc.step_x) - 1, bx_hi = base_of(dc.org_x, min(x0 + 63, out_w - 1), dc.step_x) + 2;
+    const int by_lo = base_of(dc.org_y, y0, dc.step_y) - 1, by_hi = base_of(dc.org_y, min(y0 + 3, out_h - 1), dc.step_y) + 2;
+    const int ncols = bx_hi - bx_lo + 1, nrows = by_hi - by_lo + 1;           // <= TW, <= THh
+    for (int t = tid; t < ncols * nrows; t += 256) {
+        const int r = t / ncols, c = t - r * ncols;
+        const f3 q = load_surface(in, clampi(bx_lo + c, 0, in.w - 1), clampi(by_lo + r, 0, in.h - 1));
+        tile[r * TW + c] = make_float4(q.x, q.y, q.z, 0.0f);
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
+    if (x >= out_w || y >= out_h) return;
+    const int bx = base_of(dc.org_x, x, dc.step_x), by = base_of(dc.org_y, y, dc.step_y);
+    const int ph = (y & (tab->py - 1)) * 4 + (x & (tab->px - 1));
+    const float *w = W + ph * 16;
+    const float wsum = WS[ph];
+    f3 color = {0.0f, 0.0f, 0.0f}, mn = {0, 0, 0}, mx = {0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        f3 c[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float4 q = tile[(by + j - 1 - by_lo) * TW + (bx + i - 1 - bx_lo)];
+            c[i] = f3{q.x, q.y, q.z};
+        }
+        const float *wj = w + 4 * j;
+        f3 r;
+        r.x = wj[0] * c[0].x; r.x = r.x + wj[1] * c[1].x; r.x = r.x + wj[2] * c[2].x; r.x = r.x + wj[3] * c[3].x;
+        r.y = wj[0] * c[0].y; r.y = r.y + wj[1] * c[1].y; r.y = r.y + wj[2] * c[2].y; r.y = r.y + wj[3] * c[3].y;
+        r.z = wj[0] * c[0].z; r.z = r.z + wj[1] * c[1].z; r.z = r.z + wj[2] * c[2].z; r.z = r.z + wj[3] * c[3].z;
+        if (j == 0) color = r; else { color.x = color.x + r.x; color.y = color.y + r.y; color.z = color.z + r.z; }
+        if (j == 1) {
+            mn.x = fminf(c[1].x, c[2].x); mn.y = fminf(c[1].y, c[2].y); mn.z = fminf(c[1].z, c[2].z);
+            mx.x = fmaxf(c[1].x, c[2].x); mx.y = fmaxf(c[1].y, c[2].y); mx.z = fmaxf(c[1].z, c[2].z);
+        } else if (j == 2) {
+            mn.x = fminf(fminf(mn.x, c[1].x), c[2].x); mn.y = fminf(fminf(mn.y, c[1].y), c[2].y); mn.z = fminf(fminf(mn.z, c[1].z), c[2].z);
+            mx.x = fmaxf(fmaxf(mx.x, c[1].x), c[2].x); mx.y = fmaxf(fmaxf(mx.y, c[1].y), c[2].y); mx.z = fmaxf(fmaxf(mx.z, c[1].z), c[2].z);
+        }
+    }
+    color.x = color.x / wsum; color.y = color.y / wsum; color.z = color.z / wsum;
+    f3 cl;
+    cl.x = fminf(fmaxf(color.x, mn.x), mx.x); cl.y = fminf(fmaxf(color.y, mn.y), mx.y); cl.z = fminf(fmaxf(color.z, mn.z), mx.z);
+    color.x = color.x + 0.8f * (cl.x - color.x); color.y = color.y + 0.8f * (cl.y - color.y); color.z = color.z + 0.8f * (cl.z - color.z);
+    store_epilogue(st, x, y, color);
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -850,8 +916,43 @@ hipError_t LaunchHdr10ToneMap(const Surface &in, const HdrToneMapParams &tm, int
     return hipGetLastError();
 }
 
-hipError_t LaunchJinc2(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st, hipStream_t s)
+// the phase table of k_jinc2_phases for this draw, or false when the draw is not dyadic / is rotated or mirrored
+bool BuildJincPhases(const DrawCoords &dc, void *out_table)
 {
+    JincPhases &t = *(JincPhases *)out_table;
+    auto period = [](float step) { return step == 1.0f ? 1 : step == 0.5f ? 2 : step == 0.25f ? 4 : 0; };
+    t.px = period(dc.step_x); t.py = period(dc.step_y);
+    if (!t.px || !t.py || dc.swap || dc.rev_x || dc.rev_y) return false;
+    const float pi = 3.14159274101257324f, wa = 0.416f * pi, wb = 0.985f * pi;
+    for (int py = 0; py < 4; py++)
+        for (int px = 0; px < 4; px++) {
+            // the shader's expressions at output (px, py) of a draw starting at the origin (integer origins drop out exactly)
+            const float pcx = ((float)(px % t.px) + 0.5f) * dc.step_x, pcy = ((float)(py % t.py) + 0.5f) * dc.step_y;
+            const float tcx = floorf(pcx - 0.5f) + 0.5f, tcy = floorf(pcy - 0.5f) + 0.5f;
+            float wsum = 0.0f;
+            for (int j = 0; j < 4; j++) {
+                float rowsum = 0.0f;
+                for (int i = 0; i < 4; i++) {
+                    const float vx = (tcx + (float)(i - 1)) - pcx, vy = (tcy + (float)(j - 1)) - pcy;
+                    const float dd = sqrtf(vx * vx + vy * vy);
+                    const float w = (dd == 0.0f) ? wa * wb : sinf(dd * wa) * sinf(dd * wb) / (dd * dd);
+                    t.w[py][px][j * 4 + i] = w;
+                    rowsum = i == 0 ? w : rowsum + w;
+                }
+                wsum = j == 0 ? rowsum : wsum + rowsum;
+            }
+            t.wsum[py][px] = wsum;
+        }
+    return true;
+}
+size_t JincPhasesBytes() { return sizeof(JincPhases); }
+
+hipError_t LaunchJinc2(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st, hipStream_t s, const void *phases_dev)
+{
+    if (phases_dev) {
+        hipLaunchKernelGGL(k_jinc2_phases, grid2d(out_w, out_h), dim3(64, 4, 1), 0, s, in, dc, (const JincPhases *)phases_dev, out_w, out_h, st);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_jinc2, grid2d(out_w, out_h), dim3(64, 4, 1), 0, s, in, dc, out_w, out_h, st);
     return hipGetLastError();
 }

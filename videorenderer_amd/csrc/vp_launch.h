@@ -31,7 +31,11 @@ hipError_t LaunchCopy(const Surface &in, int out_w, int out_h, const StoreParams
 // ps_hdr10_tonemap.hlsl: HDR10 local tone mapping as a post-scale step
 hipError_t LaunchHdr10ToneMap(const Surface &in, const HdrToneMapParams &tm, int out_w, int out_h, const StoreParams &st, hipStream_t s);
 // ps_resize_onepass_jinc2.hlsl: the 2-D Jinc2m draw
-hipError_t LaunchJinc2(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st, hipStream_t s);
+// phases_dev: device copy of the table BuildJincPhases filled (dyadic, unrotated draws: weights per phase instead of per pixel)
+hipError_t LaunchJinc2(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st, hipStream_t s,
+                       const void *phases_dev = nullptr);
+bool BuildJincPhases(const DrawCoords &dc, void *out_table);      // out_table: JincPhasesBytes() bytes of host memory
+size_t JincPhasesBytes();
 
 // fused 2x path (vp_fused.hip): convert + X pass + Y pass + final pass in one kernel, n frames per launch.
 struct FusedFrame {
