@@ -536,3 +536,29 @@ def test_full_size_baseline_configs_whole_frame(mpcvr, oracle, torch_cuda, label
     else:
         assert info == "fused_up2x"
         compare(got, want, label, min_same=0.99)
+
+
+@pytest.mark.parametrize("label,c", [
+    ("p010_1080p_to_1440p_lanczos3", dict(cformat=2, w=1920, h=1080, kind="noise", seed=301, dst=(2560, 1440), iUpscaling=4,
+                                          exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
+    ("nv12_4k_to_1440p_hamming", dict(cformat=1, w=3840, h=2160, kind="noise", seed=302, dst=(2560, 1440), iDownscaling=2,
+                                      exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
+    ("yuv420p10_1080p_to_4k_jinc2", dict(cformat=20, w=1920, h=1080, kind="noise", seed=303, dst=(3840, 2160), iUpscaling=5,
+                                         exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
+])
+def test_full_size_general_ratio_tiers_agree(mpcvr, torch_cuda, label, c):
+    """Everyday geometries at their real sizes, every output pixel, GPU tiers against each other (the oracle would need
+    minutes): the folded / tiled kernels (k_convert_420, k_resize_2d, k_jinc2_phases) must reproduce the plain kernels bit for
+    bit on SDR content — tile edges, XCD bands, ragged last tiles included — and the default planner (block convert) must stay
+    within 1 LSB of them."""
+    from videorenderer_amd import api
+    plain, info_p = run_product(mpcvr, torch_cuda, c, extra_flags=api.FLAG_NO_FUSED)
+    folded, info_f = run_product(mpcvr, torch_cuda, c, extra_flags=api.FLAG_NO_FAST_CONVERT)
+    default, info_d = run_product(mpcvr, torch_cuda, c)
+    assert info_p.startswith("passes:convert") and info_f.startswith("passes:convert") and info_d.startswith("passes:convert")
+    if c.get("iUpscaling") == 5:     # Jinc2m: the phase table holds the host's sinf (= the oracle's), k_jinc2 the device's: last-ulp weights
+        compare(folded, plain, label + " phase table vs per-pixel weights", min_same=0.999)
+    else:
+        assert np.array_equal(plain, folded), f"{label}: folded kernels differ from the plain ones in {(plain != folded).sum()} bytes"
+    compare(default, plain, label + " default vs plain", min_same=0.99)
+
