@@ -13,6 +13,8 @@ CASES = [("C1 1080p NV12 BT.709 -> 1080p BGRA8 (no resize)", 1920, 1080, 1920, 1
          ("4K P010 Dolby Vision (MMR + L2 trims) -> 4K SDR + dither (no resize)", 3840, 2160, 3840, 2160, dict(), 2, dict(chroma=5, nominal_range=2), "mmr"),
          ("4K P010 Dolby Vision, plain kernels", 3840, 2160, 3840, 2160, dict(flags=api.FLAG_NO_FUSED), 2, dict(chroma=5, nominal_range=2), "mmr"),
          ("4K P010 PQ -> 1440p (Hamming down) -> SDR", 3840, 2160, 2560, 1440, dict(iDownscaling=2)),
+         ("4K P010 PQ -> 1080p (Hamming down 2x) -> SDR", 3840, 2160, 1920, 1080, dict(iDownscaling=2)),
+         ("4K NV12 BT.709 -> 1080p (Bicubic down 2x)", 3840, 2160, 1920, 1080, dict(iDownscaling=3), 1, dict(chroma=5, nominal_range=2, matrix=1)),
          ("1080p P010 PQ -> 1440p (Lanczos3 1.33x) -> SDR", 1920, 1080, 2560, 1440, dict(iUpscaling=4)),
          ("1080p P010 PQ -> 4K (Lanczos3 2x), pass-per-kernel", 1920, 1080, 3840, 2160, dict(iUpscaling=4, flags=api.FLAG_NO_FUSED)),
          ("1080p P010 PQ -> 4K (Lanczos3 2x), fused", 1920, 1080, 3840, 2160, dict(iUpscaling=4)),

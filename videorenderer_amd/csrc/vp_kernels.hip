@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_resize_rows(Surface in, AxisTaps taps, 
     }
 
     constexpr int NTC = NT ? NT : 1;
-    // The 8 output rows of the group touch only blk8_span (<= 16) distinct source rows (12 for a 1.33x Lanczos3 instead
+    // The 8 output rows of the group touch only blk8_span (<= 14) distinct source rows (12 for a 1.33x Lanczos3 instead
     // of 8 x 6 tap reads): each lane fetches its columns of those rows ONCE, parks them in LDS — used here as a register
     // file a wave can index with a (wave-uniform) run-time row number; no lane reads another lane's data, so there is no
     // barrier — and takes its taps from there.  (An ablation of this kernel on MI355X, 1440p Lanczos3: without the tap

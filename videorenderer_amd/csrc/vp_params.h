@@ -149,8 +149,8 @@ struct AxisTaps {
     int blk_span;            // max over blocks of (largest - smallest index + 1); 0 = unknown
     int other_identity;      // the `other` map of this draw is x -> x (no flip / rotation / source offset)
 };
-enum { kResizeRowSpanMax = 16 };
-enum { kResizeTileRowsMax = 64 };  // source rows the tiled two-draw kernel keeps per 32 output rows   // source rows the row-tap kernel keeps per lane in LDS for its 8 output rows
+enum { kResizeRowSpanMax = 14 };
+enum { kResizeTileRowsMax = 72 };  // source rows the tiled two-draw kernel keeps per 32 output rows   // source rows the row-tap kernel keeps per lane in LDS for its 8 output rows
 enum { kResizeSpanMax = 192 };     // source texels per row one wave stages in LDS for the column-tap kernel (4 rows x 4 waves x 16 B)
 
 // 2x fast path: the two phase-weight sets per axis (t = 0.75 for even outputs, 0.25 for odd)
