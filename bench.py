@@ -45,6 +45,11 @@ WORKLOADS = {
                iUpscaling=2, desc="1080p NV12 BT.709 -> BGRA8, no resize (BASELINE configs[0])"),
     "hdr4k": dict(cformat=2, w=3840, h=2160, scale=1, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
                   iUpscaling=4, desc="4K P010 BT.2020/PQ -> PQ->SDR(Hable,125nits) -> ordered dither -> 4K BGRA8, no resize"),
+    # everyday non-integer geometries: block convert + tiled two-draw kernel, whole batch per launch
+    "up1440": dict(cformat=2, w=1920, h=1080, scale=1, dst=(2560, 1440), ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
+                   iUpscaling=4, desc="1080p P010 BT.2020/PQ -> Lanczos3 1.33x -> PQ->SDR -> ordered dither -> 1440p BGRA8"),
+    "down1440": dict(cformat=2, w=3840, h=2160, scale=1, dst=(2560, 1440), ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
+                     iUpscaling=4, iDownscaling=2, desc="4K P010 BT.2020/PQ -> Hamming 1.5x down -> PQ->SDR -> ordered dither -> 1440p BGRA8"),
     "c3hdr_1080p": dict(cformat=2, w=1920, h=1080, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
                         iUpscaling=4, desc="1080p P010 BT.2020/PQ -> Lanczos3 2x -> PQ->SDR -> dither -> 4K BGRA8 (alternative reading)"),
 }
@@ -80,10 +85,11 @@ def cpu_baseline(wl, extfmt, seconds_budget=20.0):
         from videorenderer_amd import synth
         O.lib()
         w, h, s = wl["w"], wl["h"], wl["scale"]
+        dw, dh = wl.get("dst", (w * s, h * s))
         frame, pitch = synth.make_frame(wl["cformat"], w, h, "noise", seed=1)
         p = O.default_params(cformat=wl["cformat"], width=w, height=h, exfmt=extfmt, iUpscaling=wl["iUpscaling"],
-                             window_w=w * s, window_h=h * s, video_rect=(0, 0, w * s, h * s))
-        dst = np.zeros((h * s, w * s, 4), dtype=np.uint8)
+                             iDownscaling=wl.get("iDownscaling", 2), window_w=dw, window_h=dh, video_rect=(0, 0, dw, dh))
+        dst = np.zeros((dh, dw, 4), dtype=np.uint8)
         threads = O.lib().orc_num_threads()
         t0 = time.perf_counter()
         O.process(p, frame, pitch, dst=dst)                  # warm-up + first estimate
@@ -94,7 +100,7 @@ def cpu_baseline(wl, extfmt, seconds_budget=20.0):
             O.process(p, frame, pitch, dst=dst)
         dt = (time.perf_counter() - t0) / n
         return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": int(threads), "kind": "port",
-                "sample": f"{n} full {w}x{h}->{w*s}x{h*s} frames of the same workload, oracle C (-O3 -msse2 -fopenmp), "
+                "sample": f"{n} full {w}x{h}->{dw}x{dh} frames of the same workload, oracle C (-O3 -msse2 -fopenmp), "
                           f"{threads} threads, {dt*1e3:.0f} ms/frame"}
     except Exception as e:      # the baseline is a reported side figure: never fail the bench for it
         return {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
@@ -133,8 +139,11 @@ def main():
     if args.scale:
         wl["scale"] = args.scale
     w, h, s = wl["w"], wl["h"], wl["scale"]
+    dw, dh = wl.get("dst", (w * s, h * s))
+    if args.src or args.scale:
+        dw, dh = w * s, h * s
     extfmt = api.make_extfmt(**wl["ext"])
-    settings = api.default_settings(iUpscaling=wl["iUpscaling"], flags=args.flags)
+    settings = api.default_settings(iUpscaling=wl["iUpscaling"], iDownscaling=wl.get("iDownscaling", 2), flags=args.flags)
     # One explicit (non-default) HIP stream shared by torch and the context: the kernels are launched on it and the
     # torch.cuda.Event pairs below are recorded on it, so they bracket exactly the launches of a step.
     stream = torch.cuda.Stream()
@@ -142,23 +151,23 @@ def main():
     vp = api.VideoProcessor(settings, device=dev)          # picks up torch's current stream (mpcvr_set_stream)
     assert stream.cuda_stream != 0
     vp.InitMediaType(wl["cformat"], w, h, extfmt=extfmt)
-    vp.SetWindowRect((0, 0, w * s, h * s))
-    vp.SetVideoRect((0, 0, w * s, h * s))
+    vp.SetWindowRect((0, 0, dw, dh))
+    vp.SetVideoRect((0, 0, dw, dh))
     vdist.sync_params(vp)                                  # RCCL broadcast of rank 0's parameter blob (few KiB)
     nbytes, pitch = vp.GetFrameBytes()
-    out_bytes = w * s * h * s * 4
+    out_bytes = dw * dh * 4
     algo_bytes = nbytes + out_bytes
 
     ring = max(args.ring, args.batch)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(0x4D50 + rank)
     srcs = [noise_frame_gpu(torch, wl, nbytes, pitch, gen) for _ in range(ring)]
-    dsts = [torch.empty((h * s, w * s, 4), dtype=torch.uint8, device="cuda") for _ in range(ring)]
+    dsts = [torch.empty((dh, dw, 4), dtype=torch.uint8, device="cuda") for _ in range(ring)]
 
     def step(i):
         k = (i * args.batch) % ring
         idx = [(k + j) % ring for j in range(args.batch)]
-        vp.ProcessBatch([srcs[j] for j in idx], [dsts[j] for j in idx], w * s * 4)
+        vp.ProcessBatch([srcs[j] for j in idx], [dsts[j] for j in idx], dw * 4)
 
     for i in range(args.warmup):
         step(i)
@@ -211,12 +220,12 @@ def main():
         for label, buf, kind in (("pinned", pinned, api.MEM_HOST_PINNED), ("pageable", pageable, api.MEM_HOST)):
             for i in range(6):
                 vp.CopySample(buf, pitch, kind)
-                vp.Process(dsts[i % ring], w * s * 4)
+                vp.Process(dsts[i % ring], dw * 4)
             vp.Synchronize()
             th = time.perf_counter()
             for i in range(nf):
                 vp.CopySample(buf, pitch, kind)
-                vp.Process(dsts[i % ring], w * s * 4)
+                vp.Process(dsts[i % ring], dw * 4)
             vp.Synchronize()
             res_h[label] = nf / (time.perf_counter() - th)
         host_path = {"frames_per_s_pinned_host_sample": round(res_h["pinned"], 1),
