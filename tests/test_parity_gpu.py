@@ -562,3 +562,77 @@ def test_full_size_general_ratio_tiers_agree(mpcvr, torch_cuda, label, c):
         assert np.array_equal(plain, folded), f"{label}: folded kernels differ from the plain ones in {(plain != folded).sum()} bytes"
     compare(default, plain, label + " default vs plain", min_same=0.99)
 
+
+def _random_case(rng):
+    cformat = int(rng.choice([1, 2, 20, 17, 14]))
+    w, h = int(rng.integers(8, 120)) * 2, int(rng.integers(8, 80)) * 2
+    c = dict(cformat=cformat, w=w, h=h, kind="noise", seed=int(rng.integers(1, 1 << 30)),
+             exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"],
+             iUpscaling=int(rng.choice([1, 2, 3, 4])), iDownscaling=int(rng.integers(0, 6)),
+             bInterpolateAt50pct=int(rng.integers(0, 2)))
+    rw, rh = w, h
+    if rng.random() < 0.5:                       # a source rect, sometimes on the alignment the fast kernels need, sometimes not
+        l = int(rng.integers(0, w // 4)) * (4 if rng.random() < 0.6 else 1)
+        t = int(rng.integers(0, h // 4)) * (2 if rng.random() < 0.6 else 1)
+        r = min(w, l + max(8, int(rng.integers(w // 3, w))))
+        b = min(h, t + max(8, int(rng.integers(h // 3, h))))
+        c["src_rect"] = (l, t, r, b)
+        rw, rh = r - l, b - t
+    fx, fy = (float(rng.uniform(0.45, 2.6)), float(rng.uniform(0.45, 2.6)))
+    if rng.random() < 0.25:
+        fy = fx
+    if rng.random() < 0.15:
+        fx = 1.0
+    if rng.random() < 0.15:
+        fy = 1.0
+    dw, dh = max(4, int(round(rw * fx))), max(4, int(round(rh * fy)))
+    c["dst"] = (dw, dh)
+    if rng.random() < 0.4:                        # letterboxed / partly outside the window
+        ww, wh = dw + int(rng.integers(0, 40)), dh + int(rng.integers(0, 40))
+        ox, oy = int(rng.integers(-12, 24)), int(rng.integers(-12, 24))
+        c["window"] = (max(8, ww), max(8, wh)); c["offset"] = (ox, oy)
+    if rng.random() < 0.2:
+        c["output_format"] = 1
+    if rng.random() < 0.2:
+        c["iTexFormat"] = int(rng.choice([8, 10, 16]))
+    if rng.random() < 0.25:                       # rotated / mirrored first draw (plain kernel) feeding a folded second draw
+        c["rotation"] = int(rng.choice([90, 180, 270]))
+    if rng.random() < 0.15:
+        c["flip"] = 1
+    return c
+
+
+def test_random_geometries_tiers_agree(mpcvr, oracle, torch_cuda):
+    """240 random geometries (sizes, crops, ratios 0.45x .. 2.6x per axis, window offsets and clipping, scaler choices, internal
+    formats, rotations and flips) on SDR content: the folded / tiled kernels must equal the plain kernels bit for bit, the default planner must stay
+    within 1 LSB of them."""
+    from videorenderer_amd import api
+    rng = np.random.default_rng(20260924)
+    paths = set()
+    for n in range(240):
+        c = _random_case(rng)
+        try:
+            plain, _ = run_product(mpcvr, torch_cuda, c, extra_flags=api.FLAG_NO_FUSED)
+        except api.MpcvrError as e:                       # e.g. a ratio outside the supported tap range: same answer on every tier
+            for fl in (api.FLAG_NO_FAST_CONVERT, 0):
+                with pytest.raises(api.MpcvrError):
+                    run_product(mpcvr, torch_cuda, c, extra_flags=fl)
+            continue
+        if n < 80:                                        # ... and the plain kernels must equal the oracle bit for bit
+            frame, pitch = case_frame(c)
+            p = oracle_params(oracle, c)
+            want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+            if c.get("output_format", 0) == 1:
+                compare_rgb10(plain, want, f"random {n} vs oracle {c}", exact=True)
+            else:
+                compare(plain, want, f"random {n} vs oracle {c}", exact=True)
+        folded, _ = run_product(mpcvr, torch_cuda, c, extra_flags=api.FLAG_NO_FAST_CONVERT)
+        default, info = run_product(mpcvr, torch_cuda, c)
+        paths.add(info.split(";")[0])
+        assert np.array_equal(plain, folded), (n, c, int((plain != folded).sum()))
+        if c.get("output_format", 0) == 1:
+            compare_rgb10(default, plain, f"random {n} {c}")
+        else:
+            compare(default, plain, f"random {n} {c}", min_same=0.98)
+    assert len(paths) >= 4, paths
+
