@@ -636,3 +636,47 @@ def test_random_geometries_tiers_agree(mpcvr, oracle, torch_cuda):
             compare(default, plain, f"random {n} {c}", min_same=0.98)
     assert len(paths) >= 4, paths
 
+
+def test_random_formats_and_tails_vs_oracle(mpcvr, oracle, torch_cuda):
+    """120 random (format, colourimetry, chroma mode, geometry) combinations over all 39 ColorFormat_t values, SDR / HDR10 / HLG /
+    BT.2020-gamma tagging, HDR output on or off, through the plain kernels and the default planner against the oracle."""
+    from videorenderer_amd import api
+    from tests.golden.cases import HDR10, HLG, ext, MPEG1, MPEG2, COSITED, TV, FULL, M709, M601, M2020, P709, P2020, T709, T22
+    rng = np.random.default_rng(424242)
+    sdr = [ext(MPEG2, TV, M709), ext(MPEG1, TV, M601), ext(COSITED, FULL, M709, P709, T709), ext(MPEG2, TV, M2020, P2020, T22), 0]
+    refused = 0
+    for n in range(120):
+        c = _random_case(rng)
+        c.pop("rotation", None); c.pop("flip", None)
+        c["cformat"] = int(rng.integers(1, 40))
+        c["exfmt"] = int(rng.choice([HDR10, HLG])) if rng.random() < 0.35 else int(rng.choice(sdr))
+        c["iChromaScaling"] = int(rng.integers(0, 3))
+        if rng.random() < 0.2:
+            c["hdr_output"] = 1; c["output_format"] = 1
+        if c["cformat"] in (29, 30, 31, 32, 33, 34, 35, 36):       # interleaved RGB: the texture copy loops need whole frames
+            c.pop("src_rect", None)
+            c["dst"] = (max(4, int(c["w"] * rng.uniform(0.5, 2.2))), max(4, int(c["h"] * rng.uniform(0.5, 2.2))))
+            c.pop("window", None); c.pop("offset", None)
+        if c["cformat"] == 10:                                     # v210: widths in multiples of 6 keep the test frame simple
+            c["w"] = max(12, c["w"] // 6 * 6); c.pop("src_rect", None)
+            c["dst"] = (max(4, int(c["w"] * rng.uniform(0.5, 2.2))), max(4, int(c["h"] * rng.uniform(0.5, 2.2))))
+            c.pop("window", None); c.pop("offset", None)
+        frame, pitch = case_frame(c)
+        p = oracle_params(oracle, c)
+        want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+        for flags in (api.FLAG_NO_FUSED, 0):
+            try:
+                got, info = run_product(mpcvr, torch_cuda, c, extra_flags=flags)
+            except api.MpcvrError:                        # refused combinations (e.g. odd sizes of subsampled formats) are refused by
+                refused += 1                              # both planners alike
+                continue
+            tail = has_tail(c) or c.get("hdr_output")
+            name = f"random format {n} flags={flags} [{info}] {c}"
+            if c.get("output_format", 0) == 1:
+                compare_rgb10(got, want, name, exact=(flags != 0 and not tail))
+            elif flags != 0 and not tail:
+                compare(got, want, name, exact=True)
+            else:
+                compare(got, want, name, min_same=0.98)
+    assert refused % 2 == 0 and refused <= 24, refused
+
