@@ -183,6 +183,25 @@ typedef struct mpcvr_dovi_metadata {
  * The fused 2x kernel does not carry this path; Dolby Vision frames take the pass-per-kernel path. */
 int32_t mpcvr_set_dovi_metadata(mpcvr_ctx *ctx, const mpcvr_dovi_metadata *md);
 
+/* The correction shaders (m_pPSCorrection, DX11VideoProcessor.cpp:1893-1930): same-size RGB -> RGB passes the reference runs
+ * over the OUTPUT of the fixed-function D3D11 video processor (Process :3354-3357) — BT.2020 / YCgCo matrix fix-ups and the
+ * PQ / HLG tone mapping that path cannot do itself.  The shader video processor of this library never needs them (its
+ * convert pass does all of it before the resize); they are offered as standalone passes over one surface for a host that
+ * decodes / scales elsewhere.  kind = MPCVR_CORR_*; src / dst: DEVICE surfaces of 32-bit texels, fmt = MPCVR_OUT_BGRA8 or
+ * MPCVR_OUT_RGB10A2, w x h texels; sdr_nits = iSDRDisplayNits (LuminanceScale = 10000 / nits, :889-905); stream = a
+ * hipStream_t or NULL.  In place (src == dst) is allowed. */
+#define MPCVR_CORR_FIX_BT2020            1   /* Shaders/d3d11/ps_fix_bt2020.hlsl */
+#define MPCVR_CORR_FIX_YCGCO             2   /* ps_fix_ycgco.hlsl */
+#define MPCVR_CORR_FIXCONVERT_PQ_TO_SDR  3   /* ps_fixconvert_pq_to_sdr.hlsl */
+#define MPCVR_CORR_FIXCONVERT_HLG_TO_SDR 4   /* ps_fixconvert_hlg_to_sdr.hlsl */
+#define MPCVR_CORR_CONVERT_PQ_TO_SDR     5   /* ps_convert_pq_to_sdr.hlsl */
+#define MPCVR_CORR_CONVERT_HLG_TO_PQ     6   /* ps_convert_hlg_to_pq.hlsl */
+int32_t mpcvr_correction_pass(int32_t kind, const void *src, int32_t src_pitch, int32_t src_fmt,
+                              void *dst, int32_t dst_pitch, int32_t dst_fmt, int32_t w, int32_t h, int32_t sdr_nits, void *stream);
+/* the three matrices those shaders fold at compile time, evaluated in fp32: fix_bt2020_matrix and fix_ycgco_matrix (4x4,
+ * row-major) and convert_matrix_2020_to_709 of convert/colorspace_gamut_conversion.hlsl (3x3) */
+int32_t mpcvr_plan_correction_matrices(float fix_bt2020_16[16], float fix_ycgco_16[16], float gamut9[9]);
+
 /* Configure — DX11VideoProcessor.cpp:3800-4050: diff each field, rebuild only what changed. */
 int32_t mpcvr_configure(mpcvr_ctx *ctx, const mpcvr_settings *settings);
 

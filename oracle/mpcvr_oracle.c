@@ -1622,6 +1622,127 @@ static inline uint32_t pack_out(int out_fmt, const float v[4])
     return b | (g << 8) | (r << 16) | (a << 24);             /* DXGI_FORMAT_B8G8R8A8_UNORM */
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* correction passes (m_pPSCorrection)                                                          */
+/* ------------------------------------------------------------------------------------------ */
+/* convert/colorspace_gamut_conversion.hlsl:1-93 (zimg), evaluated in fp32 in the order written */
+static float cg_det2(float a00, float a01, float a10, float a11) { return a00 * a11 - a01 * a10; }
+static void cg_inverse(const float m[3][3], float r[3][3])
+{
+    float det = 0;
+    det += m[0][0] * cg_det2(m[1][1], m[1][2], m[2][1], m[2][2]);
+    det -= m[0][1] * cg_det2(m[1][0], m[1][2], m[2][0], m[2][2]);
+    det += m[0][2] * cg_det2(m[1][0], m[1][1], m[2][0], m[2][1]);
+    r[0][0] = cg_det2(m[1][1], m[1][2], m[2][1], m[2][2]) / det;
+    r[0][1] = cg_det2(m[0][2], m[0][1], m[2][2], m[2][1]) / det;
+    r[0][2] = cg_det2(m[0][1], m[0][2], m[1][1], m[1][2]) / det;
+    r[1][0] = cg_det2(m[1][2], m[1][0], m[2][2], m[2][0]) / det;
+    r[1][1] = cg_det2(m[0][0], m[0][2], m[2][0], m[2][2]) / det;
+    r[1][2] = cg_det2(m[0][2], m[0][0], m[1][2], m[1][0]) / det;
+    r[2][0] = cg_det2(m[1][0], m[1][1], m[2][0], m[2][1]) / det;
+    r[2][1] = cg_det2(m[0][1], m[0][0], m[2][1], m[2][0]) / det;
+    r[2][2] = cg_det2(m[0][0], m[0][1], m[1][0], m[1][1]) / det;
+}
+static void cg_xy_to_xyz(float x, float y, float out[3]) { out[0] = x / y; out[1] = 1.0f; out[2] = (1.0f - x - y) / y; }
+static void cg_rgb_to_xyz(const float prim[3][2], float m[3][3])
+{
+    float rows[3][3], xyz[3][3], inv[3][3], white[3], sv[3];
+    for (int i = 0; i < 3; i++) cg_xy_to_xyz(prim[i][0], prim[i][1], rows[i]);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) xyz[i][j] = rows[j][i];          /* transpose: columns R G B */
+    cg_xy_to_xyz(0.3127f, 0.3290f, white);
+    cg_inverse(xyz, inv);
+    for (int i = 0; i < 3; i++) sv[i] = inv[i][0] * white[0] + inv[i][1] * white[1] + inv[i][2] * white[2];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) m[i][j] = xyz[i][j] * sv[j];     /* row * s, component-wise */
+}
+static void mat4_mul(const float a[16], const float b[16], float c[16])
+{
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            c[i * 4 + j] = a[i * 4 + 0] * b[0 * 4 + j] + a[i * 4 + 1] * b[1 * 4 + j] + a[i * 4 + 2] * b[2 * 4 + j] + a[i * 4 + 3] * b[3 * 4 + j];
+}
+void orc_correction_matrices(float fix2020[16], float fixycgco[16], float gamut[9])
+{
+    /* convert/conv_matrix.hlsl */
+    static const float rgb_ycbcr709[16] = {0.2126f, 0.7152f, 0.0722f, 0.0f, -0.114572f, -0.385428f, 0.5f, 0.0f,
+                                           0.5f, -0.454153f, -0.045847f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    static const float ycbcr2020nc_rgb[16] = {1.0f, 0.0f, 1.4746f, 0.0f, 1.0f, -0.164553f, -0.571353f, 0.0f,
+                                              1.0f, 1.8814f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    static const float ycgco_rgb[16] = {1.0f, -1.0f, 1.0f, 0.0f, 1.0f, 1.0f, 0.0f, 0.0f, 1.0f, -1.0f, -1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    static const float p709[3][2] = {{0.640f, 0.330f}, {0.300f, 0.600f}, {0.150f, 0.060f}};
+    static const float p2020[3][2] = {{0.708f, 0.292f}, {0.170f, 0.797f}, {0.131f, 0.046f}};
+    mat4_mul(ycbcr2020nc_rgb, rgb_ycbcr709, fix2020);        /* ps_fix_bt2020.hlsl:7 */
+    mat4_mul(ycgco_rgb, rgb_ycbcr709, fixycgco);             /* ps_fix_ycgco.hlsl:6 */
+    float m2020[3][3], m709[3][3], inv709[3][3];
+    cg_rgb_to_xyz(p2020, m2020); cg_rgb_to_xyz(p709, m709);
+    cg_inverse(m709, inv709);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            gamut[i * 3 + j] = inv709[i][0] * m2020[0][j] + inv709[i][1] * m2020[1][j] + inv709[i][2] * m2020[2][j];
+}
+
+static void corr_load(const uint8_t *row, int x, int fmt, float c[4])
+{
+    const uint32_t u = ((const uint32_t *)row)[x];
+    if (fmt == 10) { c[0] = (float)(u & 1023u) / 1023.0f; c[1] = (float)((u >> 10) & 1023u) / 1023.0f; c[2] = (float)((u >> 20) & 1023u) / 1023.0f; c[3] = (float)(u >> 30) / 3.0f; }
+    else { c[0] = (float)((u >> 16) & 255u) / 255.0f; c[1] = (float)((u >> 8) & 255u) / 255.0f; c[2] = (float)(u & 255u) / 255.0f; c[3] = (float)(u >> 24) / 255.0f; }
+}
+static void mat4_apply(const float m[16], float c[4])
+{
+    float r[4];
+    for (int i = 0; i < 4; i++) r[i] = m[i * 4] * c[0] + m[i * 4 + 1] * c[1] + m[i * 4 + 2] * c[2] + m[i * 4 + 3] * c[3];
+    memcpy(c, r, sizeof(r));
+}
+
+int orc_correction_pass(int kind, const uint8_t *src, int src_pitch, int src_fmt, uint8_t *dst, int dst_pitch, int dst_fmt,
+                        int w, int h, int sdr_nits)
+{
+    if (kind < 1 || kind > 6 || (src_fmt != 8 && src_fmt != 10) || (dst_fmt != 8 && dst_fmt != 10) || w <= 0 || h <= 0) return -1;
+    float fix2020[16], fixycgco[16], gamut[9];
+    orc_correction_matrices(fix2020, fixycgco, gamut);
+    const float lum = orc_luminance_scale(sdr_nits);                       /* SetShaderLuminanceParams :889-905 */
+    ORC_PAR_FOR
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            float c[4];
+            corr_load(src + (size_t)y * src_pitch, x, src_fmt, c);
+            if (kind == ORC_CORR_FIX_YCGCO) {
+                mat4_apply(fixycgco, c);
+            } else if (kind == ORC_CORR_CONVERT_HLG_TO_PQ) {
+                for (int i = 0; i < 3; i++) c[i] = saturatef(c[i]);
+                orc_hlg_to_linear(c);
+                for (int i = 0; i < 3; i++) c[i] = orc_linear_to_st2084(c[i], 1000.0f);
+            } else {
+                if (kind != ORC_CORR_CONVERT_PQ_TO_SDR) mat4_apply(fix2020, c);
+                for (int i = 0; i < 3; i++) c[i] = saturatef(c[i]);
+                if (kind == ORC_CORR_FIX_BT2020) {
+                    for (int i = 0; i < 3; i++) c[i] = hlsl_pow(c[i], 2.2f);
+                } else {
+                    if (kind == ORC_CORR_FIXCONVERT_HLG_TO_SDR) {
+                        orc_hlg_to_linear(c);
+                        for (int i = 0; i < 3; i++) c[i] = saturatef(orc_linear_to_st2084(c[i], 1000.0f));
+                    }
+                    for (int i = 0; i < 3; i++) c[i] = orc_st2084_to_linear(c[i], lum);
+                    orc_tonemap_hable(c);
+                }
+                mat3_apply(gamut, c);
+                for (int i = 0; i < 3; i++) c[i] = hlsl_pow(saturatef(c[i]), 1.0f / 2.2f);
+            }
+            /* the render target store: UNORM rounding, X8 / A2 left opaque like the swap chain */
+            uint32_t *o = (uint32_t *)(dst + (size_t)y * dst_pitch) + x;
+            if (dst_fmt == 10) {
+                const uint32_t r = (uint32_t)floorf(saturatef(c[0]) * 1023.0f + 0.5f), g = (uint32_t)floorf(saturatef(c[1]) * 1023.0f + 0.5f),
+                               b = (uint32_t)floorf(saturatef(c[2]) * 1023.0f + 0.5f);
+                *o = r | (g << 10) | (b << 20) | 0xc0000000u;
+            } else {
+                const uint32_t r = (uint32_t)floorf(saturatef(c[0]) * 255.0f + 0.5f), g = (uint32_t)floorf(saturatef(c[1]) * 255.0f + 0.5f),
+                               b = (uint32_t)floorf(saturatef(c[2]) * 255.0f + 0.5f);
+                *o = b | (g << 8) | (r << 16) | 0xff000000u;
+            }
+        }
+    }
+    return 0;
+}
+
 void orc_params_default(orc_params *p)
 {   /* Settings_t::SetDefault — IVideoRenderer.h:140-185 */
     memset(p, 0, sizeof(*p));

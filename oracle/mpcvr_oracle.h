@@ -116,6 +116,18 @@ typedef struct orc_params {
 void orc_params_default(orc_params *p);
 void orc_hdr_tail_ex(float rgb[3], int trc, int prim, int convert_to_sdr, float lum_scale, int hdr_output);
 void orc_hdr10_tonemap(float rgb[3], const orc_params *p);
+/* ---- correction passes: the RGB -> RGB shaders of m_pPSCorrection (DX11VideoProcessor.cpp:1893-1930, run by Process at
+ * :3354-3357 as a same-size TextureCopyRect), restated as standalone passes over one surface.
+ * kind: Shaders/d3d11/ps_fix_bt2020.hlsl, ps_fix_ycgco.hlsl, ps_fixconvert_pq_to_sdr.hlsl, ps_fixconvert_hlg_to_sdr.hlsl,
+ * ps_convert_pq_to_sdr.hlsl, ps_convert_hlg_to_pq.hlsl.  fmt: 8 = B8G8R8A8, 10 = R10G10B10A2 (texels are 32-bit).
+ * The matrices the shaders fold at compile time (fix_bt2020_matrix, fix_ycgco_matrix, convert_matrix_2020_to_709 from
+ * convert/colorspace_gamut_conversion.hlsl) are evaluated in fp32 here; fxc's own folding precision is not documented. */
+enum { ORC_CORR_FIX_BT2020 = 1, ORC_CORR_FIX_YCGCO = 2, ORC_CORR_FIXCONVERT_PQ_TO_SDR = 3, ORC_CORR_FIXCONVERT_HLG_TO_SDR = 4,
+       ORC_CORR_CONVERT_PQ_TO_SDR = 5, ORC_CORR_CONVERT_HLG_TO_PQ = 6 };
+int  orc_correction_pass(int kind, const uint8_t *src, int src_pitch, int src_fmt, uint8_t *dst, int dst_pitch, int dst_fmt,
+                         int w, int h, int sdr_nits);
+void orc_correction_matrices(float fix2020[16], float fixycgco[16], float gamut[9]);
+
 /* ---- Dolby Vision (pins) ---- */
 /* the PS_DOVI_CURVE cbuffer SetShaderDoviCurves packs (DX11VideoProcessor.cpp:1055-1141): per component
  * pivots[7] + coeffs[8][4] + mmr[48][4] floats + {methods, mmr_single, min_order, max_order}; *has_mmr as :2305-2318 */

@@ -174,6 +174,9 @@ def lib():
         L.orc_dovi_l2_constants.argtypes = [C.POINTER(OrcDovi), C.c_int, fp]
         L.orc_dovi_l1_nits.restype = C.c_int
         L.orc_dovi_l1_nits.argtypes = [C.POINTER(OrcDovi), C.POINTER(C.c_uint32)]
+        L.orc_correction_pass.restype = C.c_int
+        L.orc_correction_pass.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_correction_matrices.argtypes = [fp, fp, fp]
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
         _lib = L
@@ -232,6 +235,22 @@ def color_matrix(p):
     rc = lib().orc_color_matrix(C.byref(p), out)
     assert rc == 0
     return np.array(out, dtype=np.float32)
+
+
+def correction_pass(kind, src, src_fmt, dst_fmt, sdr_nits=125):
+    """One m_pPSCorrection shader over a (h, w) uint32 surface; fmt 8 = B8G8R8A8, 10 = R10G10B10A2.  Returns (h, w) uint32."""
+    src = np.ascontiguousarray(src, dtype=np.uint32)
+    h, w = src.shape
+    dst = np.zeros((h, w), dtype=np.uint32)
+    rc = lib().orc_correction_pass(kind, src.ctypes.data, w * 4, src_fmt, dst.ctypes.data, w * 4, dst_fmt, w, h, sdr_nits)
+    assert rc == 0, rc
+    return dst
+
+
+def correction_matrices():
+    a, b, g = (C.c_float * 16)(), (C.c_float * 16)(), (C.c_float * 9)()
+    lib().orc_correction_matrices(a, b, g)
+    return np.array(a, np.float32), np.array(b, np.float32), np.array(g, np.float32)
 
 
 def process(p, frame, pitch, dither=None, dst=None):

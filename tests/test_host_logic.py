@@ -307,3 +307,28 @@ def test_dovi_metadata_validation(mpcvr):
     from oracle import oracle as O
     assert C.sizeof(api.DoviMetadata) == C.sizeof(O.OrcDovi)
     assert C.sizeof(api.DoviCurve) == 1 + 24 + 1 + 18 + 4 + 8 * (24 + 8 + 168)
+
+
+# ---------------------------------------------------------------- correction shaders (m_pPSCorrection)
+def test_correction_matrices(mpcvr, oracle):
+    """fix_bt2020_matrix / fix_ycgco_matrix / convert_matrix_2020_to_709 as the correction shaders fold them: product host code
+    vs the oracle bit for bit, and known answers — the HLSL (zimg) derivation of the primaries matrix agrees with csputils'
+    GetColorspaceGamutConversionMatrix to ~2e-5, the fix-up matrices map grey to grey, a YCgCo mis-decode is undone."""
+    from videorenderer_amd import api
+    a, b, g = api.plan_correction_matrices()
+    oa, ob, og = oracle.correction_matrices()
+    assert np.array_equal(np.array(a, np.float32).view(np.uint32), oa.view(np.uint32))
+    assert np.array_equal(np.array(b, np.float32).view(np.uint32), ob.view(np.uint32))
+    assert np.array_equal(np.array(g, np.float32).view(np.uint32), og.view(np.uint32))
+    assert np.allclose(og, api.plan_gamut_2020_to_709(), atol=5e-5)     # (different white-point digits: ~1.6e-5 apart)
+    grey = np.array([0.5, 0.5, 0.5, 1.0], np.float32)
+    for m in (oa, ob):
+        assert np.allclose((m.reshape(4, 4) @ grey)[:3], 0.5, atol=1e-6)
+    # what the D3D11 VP did wrong and the shader undoes: it decoded YCgCo data with the BT.709 matrix
+    ycgco_rgb = np.array([[1, -1, 1], [1, 1, 0], [1, -1, -1]], np.float64)
+    rgb709_from_ycc = np.linalg.inv(np.array([[0.2126, 0.7152, 0.0722], [-0.114572, -0.385428, 0.5], [0.5, -0.454153, -0.045847]]))
+    ycc = np.array([0.4, 0.1, -0.05])                      # some (Y, Cg, Co)
+    wrong = rgb709_from_ycc @ ycc
+    fixed = ob.reshape(4, 4)[:3, :3].astype(np.float64) @ wrong
+    assert np.allclose(fixed, ycgco_rgb @ ycc, atol=1e-5)
+

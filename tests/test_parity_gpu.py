@@ -680,3 +680,32 @@ def test_random_formats_and_tails_vs_oracle(mpcvr, oracle, torch_cuda):
                 compare(got, want, name, min_same=0.98)
     assert refused % 2 == 0 and refused <= 24, refused
 
+
+@pytest.mark.parametrize("kind", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("src_fmt,dst_fmt", [(0, 0), (1, 1), (1, 0)])
+def test_correction_passes_vs_oracle(mpcvr, oracle, torch_cuda, kind, src_fmt, dst_fmt):
+    """The m_pPSCorrection shaders as standalone passes: random surfaces plus the corners of the cube, against the oracle."""
+    torch = torch_cuda
+    from videorenderer_amd import api
+    rng = np.random.default_rng(1000 + kind * 10 + src_fmt * 3 + dst_fmt)
+    w, h = 200, 64
+    src = rng.integers(0, 1 << 32, size=(h, w), dtype=np.uint64).astype(np.uint32)
+    src[0, :8] = [0, 0xffffffff, 0x3ff, 0x3ff << 10, 0x3ff << 20, 0x00ff0000, 0x0000ff00, 0x000000ff]
+    want = oracle.correction_pass(kind, src, 10 if src_fmt else 8, 10 if dst_fmt else 8, sdr_nits=125)
+    d_src = torch.from_numpy(src.view(np.int32)).cuda()
+    d_dst = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    api.correction_pass(kind, d_src, w * 4, src_fmt, d_dst, w * 4, dst_fmt, w, h, sdr_nits=125)
+    torch.cuda.synchronize()
+    got = d_dst.cpu().numpy().view(np.uint32)
+    if dst_fmt:
+        compare_rgb10(got.reshape(h, w, 1).view(np.uint8).reshape(h, w, 4), want.reshape(h, w, 1).view(np.uint8).reshape(h, w, 4),
+                      f"correction {kind}", exact=(kind == 2))
+    else:
+        compare(got.view(np.uint8).reshape(h, w, 4), want.view(np.uint8).reshape(h, w, 4), f"correction {kind}",
+                exact=(kind == 2), min_same=0.99)
+    # in place
+    api.correction_pass(kind, d_src, w * 4, src_fmt, d_src, w * 4, src_fmt, w, h, sdr_nits=125)
+    torch.cuda.synchronize()
+    if src_fmt == dst_fmt:
+        assert np.array_equal(d_src.cpu().numpy().view(np.uint32), got)
+

@@ -147,7 +147,7 @@ class MpcvrError(RuntimeError):
 EXPORTS = [
     "mpcvr_settings_default", "mpcvr_create", "mpcvr_destroy", "mpcvr_set_stream", "mpcvr_synchronize",
     "mpcvr_set_input", "mpcvr_set_video_rect", "mpcvr_set_window_rect", "mpcvr_set_rotation", "mpcvr_set_flip", "mpcvr_set_sample_format", "mpcvr_set_hdr_output", "mpcvr_set_hdr_metadata",
-    "mpcvr_set_dovi_metadata", "mpcvr_plan_dovi",
+    "mpcvr_set_dovi_metadata", "mpcvr_plan_dovi", "mpcvr_correction_pass", "mpcvr_plan_correction_matrices",
     "mpcvr_configure", "mpcvr_set_procamp", "mpcvr_copy_sample", "mpcvr_process", "mpcvr_render",
     "mpcvr_get_backbuffer", "mpcvr_get_current_image", "mpcvr_flush", "mpcvr_reset", "mpcvr_process_batch",
     "mpcvr_get_param_blob", "mpcvr_set_param_blob", "mpcvr_get_color_matrix", "mpcvr_get_extfmt",
@@ -187,6 +187,8 @@ def load_library():
         "mpcvr_set_hdr_metadata": [vp, f, f, f, f],
         "mpcvr_set_dovi_metadata": [vp, P(DoviMetadata)],
         "mpcvr_plan_dovi": [P(DoviMetadata), i32, P(f), P(i32), P(f), P(f), P(i32), P(u32), P(i32)],
+        "mpcvr_correction_pass": [i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp],
+        "mpcvr_plan_correction_matrices": [P(f), P(f), P(f)],
         "mpcvr_configure": [vp, P(Settings)],
         "mpcvr_set_procamp": [vp, u32, f, f, f, f],
         "mpcvr_copy_sample": [vp, vp, i32, i32],
@@ -284,6 +286,27 @@ def plan_dovi(md, display_nits=1000):
     return dict(cb=np.array(cb, dtype=np.float32).reshape(3, 235), has_mmr=has_mmr.value,
                 lms=np.array(lms, dtype=np.float32), l2k=np.array(l2k, dtype=np.float32), l2_enabled=l2on.value,
                 l1_nits=np.array(l1, dtype=np.uint32), l1_present=l1on.value)
+
+
+CORR_FIX_BT2020, CORR_FIX_YCGCO, CORR_FIXCONVERT_PQ_TO_SDR, CORR_FIXCONVERT_HLG_TO_SDR, CORR_CONVERT_PQ_TO_SDR, CORR_CONVERT_HLG_TO_PQ = range(1, 7)
+
+
+def plan_correction_matrices():
+    """fix_bt2020_matrix, fix_ycgco_matrix (4x4) and convert_matrix_2020_to_709 (3x3) of the correction shaders, in fp32."""
+    a, b, g = (C.c_float * 16)(), (C.c_float * 16)(), (C.c_float * 9)()
+    hr = load_library().mpcvr_plan_correction_matrices(a, b, g)
+    if hr:
+        raise MpcvrError(hr, "mpcvr_plan_correction_matrices")
+    return list(a), list(b), list(g)
+
+
+def correction_pass(kind, src, src_pitch, src_fmt, dst, dst_pitch, dst_fmt, w, h, sdr_nits=125, stream=None):
+    """One m_pPSCorrection shader (CORR_*) over a device surface of 32-bit texels; fmt: 0 = BGRA8, 1 = RGB10A2."""
+    hr = load_library().mpcvr_correction_pass(int(kind), C.c_void_p(_ptr(src)), int(src_pitch), int(src_fmt), C.c_void_p(_ptr(dst)),
+                                              int(dst_pitch), int(dst_fmt), int(w), int(h), int(sdr_nits),
+                                              C.c_void_p(stream) if stream else None)
+    if hr:
+        raise MpcvrError(hr, "mpcvr_correction_pass")
 
 
 def plan_upscale_weights(method, t):

@@ -208,6 +208,30 @@ int32_t mpcvr_plan_final_pass_multiplier(int32_t quant, int32_t maxv, uint32_t *
     return MPCVR_S_OK;
 }
 
+int32_t mpcvr_plan_correction_matrices(float fix_bt2020_16[16], float fix_ycgco_16[16], float gamut9[9])
+{
+    if (!fix_bt2020_16 || !fix_ycgco_16 || !gamut9) return MPCVR_E_POINTER;
+    mpcvr::CorrectionMatrices(fix_bt2020_16, fix_ycgco_16, gamut9);
+    return MPCVR_S_OK;
+}
+
+int32_t mpcvr_correction_pass(int32_t kind, const void *src, int32_t src_pitch, int32_t src_fmt,
+                              void *dst, int32_t dst_pitch, int32_t dst_fmt, int32_t w, int32_t h, int32_t sdr_nits, void *stream)
+{
+    if (!src || !dst) return MPCVR_E_POINTER;
+    if (kind < MPCVR_CORR_FIX_BT2020 || kind > MPCVR_CORR_CONVERT_HLG_TO_PQ || w <= 0 || h <= 0 || sdr_nits <= 0 ||
+        src_pitch < w * 4 || dst_pitch < w * 4 || (src_pitch & 3) || (dst_pitch & 3) ||
+        (src_fmt != MPCVR_OUT_BGRA8 && src_fmt != MPCVR_OUT_RGB10A2) || (dst_fmt != MPCVR_OUT_BGRA8 && dst_fmt != MPCVR_OUT_RGB10A2))
+        return MPCVR_E_INVALIDARG;
+    float fix2020[16], fixycgco[16], gamut[9];
+    mpcvr::CorrectionMatrices(fix2020, fixycgco, gamut);
+    const mpcvr::Surface in{const_cast<void *>(src), src_pitch, w, h, src_fmt == MPCVR_OUT_RGB10A2 ? mpcvr::SF_RGB10A2 : mpcvr::SF_BGRA8};
+    const mpcvr::Surface out{dst, dst_pitch, w, h, dst_fmt == MPCVR_OUT_RGB10A2 ? mpcvr::SF_RGB10A2 : mpcvr::SF_BGRA8};
+    const hipError_t e = mpcvr::LaunchCorrection(kind, in, out, kind == MPCVR_CORR_FIX_YCGCO ? fixycgco : fix2020, gamut,
+                                                 10000.0f / (float)sdr_nits, (hipStream_t)stream);
+    return e == hipSuccess ? MPCVR_S_OK : MPCVR_E_FAIL;
+}
+
 int32_t mpcvr_plan_dovi(const mpcvr_dovi_metadata *md, int32_t display_nits, float *cb705, int32_t *has_mmr,
                         float lms9[9], float l2k[5], int32_t *l2_enabled, uint32_t l1_nits[3], int32_t *l1_present)
 {

@@ -184,4 +184,71 @@ void DoviColorMatrix(const mpcvr_dovi_metadata &md, const FmtConvParams &f, cons
         for (int c = 0; c < 3; c++) out[r * 3 + c] = m[r][c];
 }
 
+// ------------------------------------------------------------------------------------------------
+// constants of the correction shaders: mul(ycbcr2020nc_rgb, rgb_ycbcr709), mul(ycgco_rgb, rgb_ycbcr709) (conv_matrix.hlsl) and
+// the BT.2020 -> BT.709 primaries matrix the HLSL derives from the chromaticities (colorspace_gamut_conversion.hlsl, after zimg)
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct M3 { float v[3][3]; };
+float Det2(float a, float b, float c, float d) { return a * d - b * c; }
+M3 Inverse3(const M3 &m)
+{
+    float det = 0;
+    det += m.v[0][0] * Det2(m.v[1][1], m.v[1][2], m.v[2][1], m.v[2][2]);
+    det -= m.v[0][1] * Det2(m.v[1][0], m.v[1][2], m.v[2][0], m.v[2][2]);
+    det += m.v[0][2] * Det2(m.v[1][0], m.v[1][1], m.v[2][0], m.v[2][1]);
+    M3 r;
+    r.v[0][0] = Det2(m.v[1][1], m.v[1][2], m.v[2][1], m.v[2][2]) / det;
+    r.v[0][1] = Det2(m.v[0][2], m.v[0][1], m.v[2][2], m.v[2][1]) / det;
+    r.v[0][2] = Det2(m.v[0][1], m.v[0][2], m.v[1][1], m.v[1][2]) / det;
+    r.v[1][0] = Det2(m.v[1][2], m.v[1][0], m.v[2][2], m.v[2][0]) / det;
+    r.v[1][1] = Det2(m.v[0][0], m.v[0][2], m.v[2][0], m.v[2][2]) / det;
+    r.v[1][2] = Det2(m.v[0][2], m.v[0][0], m.v[1][2], m.v[1][0]) / det;
+    r.v[2][0] = Det2(m.v[1][0], m.v[1][1], m.v[2][0], m.v[2][1]) / det;
+    r.v[2][1] = Det2(m.v[0][1], m.v[0][0], m.v[2][1], m.v[2][0]) / det;
+    r.v[2][2] = Det2(m.v[0][0], m.v[0][1], m.v[1][0], m.v[1][1]) / det;
+    return r;
+}
+void XyToXyz(float x, float y, float o[3]) { o[0] = x / y; o[1] = 1.0f; o[2] = (1.0f - x - y) / y; }
+M3 RgbToXyz(const float prim[3][2])
+{
+    float col[3][3], white[3];
+    for (int i = 0; i < 3; i++) XyToXyz(prim[i][0], prim[i][1], col[i]);
+    M3 xyz;                                     // columns R, G, B
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) xyz.v[r][c] = col[c][r];
+    XyToXyz(0.3127f, 0.3290f, white);
+    const M3 inv = Inverse3(xyz);
+    float s[3];
+    for (int i = 0; i < 3; i++) s[i] = inv.v[i][0] * white[0] + inv.v[i][1] * white[1] + inv.v[i][2] * white[2];
+    M3 m;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) m.v[r][c] = xyz.v[r][c] * s[c];
+    return m;
+}
+void Mul4(const float a[16], const float b[16], float c[16])
+{
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            c[i * 4 + j] = a[i * 4] * b[j] + a[i * 4 + 1] * b[4 + j] + a[i * 4 + 2] * b[8 + j] + a[i * 4 + 3] * b[12 + j];
+}
+}  // namespace
+
+void CorrectionMatrices(float fix2020[16], float fixycgco[16], float gamut[9])
+{
+    static const float kRgbToYcbcr709[16] = {0.2126f, 0.7152f, 0.0722f, 0.0f, -0.114572f, -0.385428f, 0.5f, 0.0f,
+                                             0.5f, -0.454153f, -0.045847f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    static const float kYcbcr2020ToRgb[16] = {1.0f, 0.0f, 1.4746f, 0.0f, 1.0f, -0.164553f, -0.571353f, 0.0f,
+                                              1.0f, 1.8814f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    static const float kYcgcoToRgb[16] = {1.0f, -1.0f, 1.0f, 0.0f, 1.0f, 1.0f, 0.0f, 0.0f, 1.0f, -1.0f, -1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    static const float k709[3][2] = {{0.640f, 0.330f}, {0.300f, 0.600f}, {0.150f, 0.060f}};
+    static const float k2020[3][2] = {{0.708f, 0.292f}, {0.170f, 0.797f}, {0.131f, 0.046f}};
+    Mul4(kYcbcr2020ToRgb, kRgbToYcbcr709, fix2020);
+    Mul4(kYcgcoToRgb, kRgbToYcbcr709, fixycgco);
+    const M3 wide = RgbToXyz(k2020), inv = Inverse3(RgbToXyz(k709));
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++)
+            gamut[r * 3 + c] = inv.v[r][0] * wide.v[0][c] + inv.v[r][1] * wide.v[1][c] + inv.v[r][2] * wide.v[2][c];
+}
+
 }  // namespace mpcvr

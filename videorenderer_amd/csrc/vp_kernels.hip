@@ -8,6 +8,7 @@
 #include "vp_convert.h"
 #include "vp_device.h"
 #include <cstdlib>
+#include <cstring>
 
 #include "vp_launch.h"
 
@@ -637,6 +638,46 @@ __global__ __launch_bounds__(256) void k_jinc2_phases(Surface in, DrawCoords dc,
     store_epilogue(st, x, y, color);
 }
 
+// The correction shaders (m_pPSCorrection: ps_fix_bt2020 / ps_fix_ycgco / ps_fixconvert_pq_to_sdr / ps_fixconvert_hlg_to_sdr /
+// ps_convert_pq_to_sdr / ps_convert_hlg_to_pq) as a same-size pass over one 32-bit surface.  KIND = MPCVR_CORR_*.
+struct CorrParams { float fix[16]; float gamut[9]; float lum_scale; };
+template <int KIND>
+__global__ __launch_bounds__(256) void k_correction(Surface in, Surface out, CorrParams K)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= out.w || y >= out.h) return;
+    f3 c = load_surface(in, x, y);
+    const float a = 1.0f;                                   // alpha never reaches r, g, b (4th matrix column is zero)
+    if (KIND != 5 && KIND != 6) {                           // mul(fix_*_matrix, color)
+        f3 r;
+        r.x = K.fix[0] * c.x + K.fix[1] * c.y + K.fix[2] * c.z + K.fix[3] * a;
+        r.y = K.fix[4] * c.x + K.fix[5] * c.y + K.fix[6] * c.z + K.fix[7] * a;
+        r.z = K.fix[8] * c.x + K.fix[9] * c.y + K.fix[10] * c.z + K.fix[11] * a;
+        c = r;
+    }
+    if (KIND == 6) {                                        // ps_convert_hlg_to_pq.hlsl:15-19
+        c.x = saturate(c.x); c.y = saturate(c.y); c.z = saturate(c.z);
+        c = hlg_to_linear(c);
+        c.x = linear_to_st2084(c.x, 1000.0f); c.y = linear_to_st2084(c.y, 1000.0f); c.z = linear_to_st2084(c.z, 1000.0f);
+    } else if (KIND != 2) {
+        c.x = saturate(c.x); c.y = saturate(c.y); c.z = saturate(c.z);
+        if (KIND == 1) {                                    // ps_fix_bt2020.hlsl:24-25: sRGB to linear
+            c.x = hlsl_pow(c.x, 2.2f); c.y = hlsl_pow(c.y, 2.2f); c.z = hlsl_pow(c.z, 2.2f);
+        } else {
+            if (KIND == 4) {                                // ps_fixconvert_hlg_to_sdr.hlsl:31-34: HLG to PQ
+                c = hlg_to_linear(c);
+                c.x = saturate(linear_to_st2084(c.x, 1000.0f)); c.y = saturate(linear_to_st2084(c.y, 1000.0f)); c.z = saturate(linear_to_st2084(c.z, 1000.0f));
+            }
+            c.x = st2084_to_linear(c.x, K.lum_scale); c.y = st2084_to_linear(c.y, K.lum_scale); c.z = st2084_to_linear(c.z, K.lum_scale);
+            const float div = hable_div();
+            c.x = hable(c.x) / div; c.y = hable(c.y) / div; c.z = hable(c.z) / div;
+        }
+        c = mat3_mul(make_mat3(K.gamut), c);
+        c.x = hlsl_pow(saturate(c.x), 1.0f / 2.2f); c.y = hlsl_pow(saturate(c.y), 1.0f / 2.2f); c.z = hlsl_pow(saturate(c.z), 1.0f / 2.2f);
+    }
+    store_surface(out.ptr, out.pitch, out.fmt, x, y, c);
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -954,6 +995,23 @@ hipError_t LaunchJinc2(const Surface &in, const DrawCoords &dc, int out_w, int o
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_jinc2, grid2d(out_w, out_h), dim3(64, 4, 1), 0, s, in, dc, out_w, out_h, st);
+    return hipGetLastError();
+}
+
+hipError_t LaunchCorrection(int kind, const Surface &in, const Surface &out, const float fix16[16], const float gamut9[9], float lum_scale, hipStream_t s)
+{
+    CorrParams K;
+    std::memcpy(K.fix, fix16, sizeof(K.fix)); std::memcpy(K.gamut, gamut9, sizeof(K.gamut)); K.lum_scale = lum_scale;
+    const dim3 g = grid2d(out.w, out.h), b(64, 4, 1);
+    switch (kind) {
+    case 1: hipLaunchKernelGGL(k_correction<1>, g, b, 0, s, in, out, K); break;
+    case 2: hipLaunchKernelGGL(k_correction<2>, g, b, 0, s, in, out, K); break;
+    case 3: hipLaunchKernelGGL(k_correction<3>, g, b, 0, s, in, out, K); break;
+    case 4: hipLaunchKernelGGL(k_correction<4>, g, b, 0, s, in, out, K); break;
+    case 5: hipLaunchKernelGGL(k_correction<5>, g, b, 0, s, in, out, K); break;
+    case 6: hipLaunchKernelGGL(k_correction<6>, g, b, 0, s, in, out, K); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -55,6 +55,10 @@ struct ProcAmp { float brightness = 0, contrast = 1, hue = 0, saturation = 1; };
 void ComputeColorMatrix(const ExtFmt &ex, const FmtConvParams &f, const ProcAmp &pa, float out12[12]);
 // GetColorspaceGamutConversionMatrix(BT2020 -> BT709) (csputils.cpp:549-557)
 void ComputeGamut2020to709(float out9[9]);
+// the matrices ps_fix_bt2020 / ps_fix_ycgco / ps_(fix)convert_* fold at compile time (conv_matrix.hlsl,
+// colorspace_gamut_conversion.hlsl), in fp32
+void CorrectionMatrices(float fix2020[16], float fixycgco[16], float gamut[9]);
+
 // ---- Dolby Vision (vp_dovi.cpp) ----
 // the curve part of CheckDoviMetadata (VideoProcessor.cpp:283-292) with maxReshapeMethon = 1
 bool CheckDoviCurves(const mpcvr_dovi_metadata &md);
