@@ -709,3 +709,46 @@ def test_correction_passes_vs_oracle(mpcvr, oracle, torch_cuda, kind, src_fmt, d
     if src_fmt == dst_fmt:
         assert np.array_equal(d_src.cpu().numpy().view(np.uint32), got)
 
+
+def test_context_reuse_across_geometries_and_batches(mpcvr, torch_cuda):
+    """One context driven the way a player would: the video rect changes between batches (tiled two-draw kernel -> fused 2x ->
+    same-size direct -> Jinc2m phases -> one-pass), batch sizes vary (1, 2, 33, 70 > the frame-table slot), settings change
+    through Configure, Dolby Vision comes and goes.  Every batch must equal frame-by-frame Process on a fresh context."""
+    torch = torch_cuda
+    from videorenderer_amd import api, synth
+    w, h = 96, 64
+    exf = GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"]
+    frames_np = [synth.make_frame(2, w, h, "noise", seed=900 + i)[0] for i in range(70)]
+    frames = [torch.from_numpy(f).cuda() for f in frames_np]
+    vp = api.VideoProcessor(api.default_settings(iUpscaling=4))
+    vp.InitMediaType(2, w, h, extfmt=exf)
+
+    def reference(settings, dst_wh, n, dovi=None):
+        ref = api.VideoProcessor(settings)
+        ref.InitMediaType(2, w, h, extfmt=exf)
+        ref.SetWindowRect((0, 0) + dst_wh); ref.SetVideoRect((0, 0) + dst_wh)
+        if dovi:
+            ref.SetDoviMetadata(dovi)
+        outs = []
+        for i in range(n):
+            d = torch.zeros((dst_wh[1], dst_wh[0], 4), dtype=torch.uint8, device="cuda")
+            ref.CopySample(frames[i], w * 2); ref.Process(d, dst_wh[0] * 4); outs.append(d)
+        ref.Synchronize(); ref.close()
+        return outs
+
+    steps = [((128, 86), 33, dict(), None), ((192, 128), 2, dict(), None), ((96, 64), 70, dict(), None),
+             ((192, 128), 5, dict(iUpscaling=5), None), ((96, 100), 1, dict(), None), ((144, 96), 7, dict(iUpscaling=1), None),
+             ((144, 96), 4, dict(iUpscaling=1), synth.dovi_metadata("poly", l2=(100, 600))), ((128, 86), 9, dict(iUpscaling=4), None)]
+    for dst_wh, n, cfg, dovi in steps:
+        settings = api.default_settings(iUpscaling=4, **cfg) if "iUpscaling" not in cfg else api.default_settings(**cfg)
+        vp.Configure(settings)
+        vp.SetWindowRect((0, 0) + dst_wh); vp.SetVideoRect((0, 0) + dst_wh)
+        vp.SetDoviMetadata(dovi)
+        dsts = [torch.zeros((dst_wh[1], dst_wh[0], 4), dtype=torch.uint8, device="cuda") for _ in range(n)]
+        vp.ProcessBatch(frames[:n], dsts, dst_wh[0] * 4)
+        vp.Synchronize()
+        want = reference(settings, dst_wh, n, dovi)
+        for i in range(n):
+            assert torch.equal(dsts[i], want[i]), (dst_wh, n, cfg, bool(dovi), i, vp.GetVPInfo())
+    vp.close()
+
