@@ -1,0 +1,24 @@
+#!/bin/bash
+# tools/pmc_traffic.sh <workload> [steps] — HBM traffic of one bench.py workload: FETCH_SIZE and WRITE_SIZE in separate
+# rocprofv3 --pmc passes (kernel-trace only, hard timeouts), summed over the mpcvr kernels and divided by the number of steps
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+W=${1:-c1}; STEPS=${2:-6}; WARM=2
+OUT=gpurun_out/traffic_$W; rm -rf $OUT; mkdir -p $OUT
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 5 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o p -- python bench.py --workload $W --steps $STEPS --warmup $WARM --no-cpu-baseline --no-host-path > $OUT/log_$c 2>&1 || tail -2 $OUT/log_$c
+done
+python - "$W" "$STEPS" "$WARM" <<'PY'
+import csv, glob, sys, json
+w, steps, warm = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+tot = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    s = 0.0; n = 0
+    for f in glob.glob(f"gpurun_out/traffic_{w}/{c}/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if "mpcvr" in r["Kernel_Name"] and r["Counter_Name"] == c:
+                s += float(r["Counter_Value"]); n += 1
+    tot[c] = (s, n)
+launches = steps + warm
+print(json.dumps({"workload": w, "steps_profiled": launches, "fetch_kb_per_step": tot["FETCH_SIZE"][0] / launches,
+                  "write_kb_per_step": tot["WRITE_SIZE"][0] / launches, "dispatches": tot["FETCH_SIZE"][1]}))
+PY
