@@ -750,6 +750,7 @@ void CHipVideoProcessor::FillFusedParams(const uint8_t *sample, void *rt, int rt
     fp->pq_lut = (m_pqLutValid && !no_lut) ? (const float *)m_pqLut.ptr : nullptr;
     fp->literal_tail = no_lut ? 1 : 0;
     fp->dst_aligned16 = (((uintptr_t)rt) & 15) == 0;        // batches: ProcessBatch checks every target
+    fp->src_aligned16 = (((uintptr_t)sample) & 15) == 0;
     // vectorised convert: dword loads need 4-byte aligned rows and a source rect starting on a 4-px boundary
     fp->fast_convert = (m_srcRect.left % 4 == 0) && (m_srcRect.top % 2 == 0) && (m_srcPitch % 4 == 0) &&
                        (fp->conv.pitch[1] % 4 == 0) && (fp->plane_off[1] % 4 == 0) && (fp->plane_off[2] % 4 == 0) &&
@@ -934,7 +935,9 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
     for (int i = 0; i < n; i++)
         if (!srcs[i] || !dsts[i]) return Fail(MPCVR_E_POINTER, "null frame in batch");
     bool aligned = true, src4 = true;
+    m_batchSrc16 = true;
     for (int i = 0; i < n; i++) {
+        if (((uintptr_t)srcs[i] & 15) != 0) m_batchSrc16 = false;
         if (((uintptr_t)srcs[i] & 3) != 0) src4 = false;
         if (((uintptr_t)dsts[i] & 15) != 0) aligned = false;
     }
@@ -1025,6 +1028,7 @@ bool CHipVideoProcessor::BatchPlan(const uint8_t *sample0, void *rt0, int rtPitc
     if (m_plan.direct_convert) {
         FillFusedParams(sample0, rt0, rtPitch, direct);
         direct->dst_aligned16 = aligned ? 1 : 0;
+        direct->src_aligned16 = m_batchSrc16 ? 1 : 0;
         return ConvertBlocksSupported(*direct, true);
     }
     if (!m_plan.two_pass && !m_plan.one_pass) return false;
@@ -1032,6 +1036,7 @@ bool CHipVideoProcessor::BatchPlan(const uint8_t *sample0, void *rt0, int rtPitc
     FillFusedParams(sample0, m_batchConv.ptr, convPitch, conv);
     conv->store = MakeStore(m_batchConv.ptr, convPitch, m_plan.internal_fmt, false);
     conv->dst_aligned16 = 1;
+    conv->src_aligned16 = m_batchSrc16 ? 1 : 0;
     if (!ConvertBlocksSupported(*conv, false)) return false;
     const Surface cs{nullptr, convPitch, w1, h1, m_plan.internal_fmt};
     const StoreParams final = MakeStore(rt0, rtPitch, m_plan.swap_fmt, true);

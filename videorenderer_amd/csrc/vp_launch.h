@@ -53,6 +53,7 @@ struct FusedParams {
     const float *pq_lut;      // device, kPqLutSize floats: x -> Hable(ST2084ToLinear(x)*scale)/hable(4.8); null => ALU
     int fast_convert;         // layout/alignments allow the vectorised convert
     int dst_aligned16;        // every render target of the launch starts on a 16-byte boundary
+    int src_aligned16;        // every sample of the launch starts on a 16-byte boundary (wide block convert)
     int literal_tail;         // MPCVR_FLAG_NO_LUT: evaluate the HDR tails literally in ALU (no LUT, no algebraic shortcut)
 };
 bool FusedUp2xSupported(const FusedParams &P);
