@@ -351,6 +351,13 @@ def _ptr(x):
     return int(x)
 
 
+class PreparedBatch:
+    __slots__ = ("n", "sa", "da", "keep")
+
+    def __init__(self, n, sa, da, keep):
+        self.n, self.sa, self.da, self.keep = n, sa, da, keep
+
+
 class VideoProcessor:
     """One processor context on one GPU (not re-entrant, like the reference under m_RendererLock)."""
 
@@ -479,12 +486,19 @@ class VideoProcessor:
         return buf
 
     def ProcessBatch(self, srcs, dsts, rt_pitch):
+        if isinstance(srcs, PreparedBatch):          # pointer arrays built once (PrepareBatch): nothing per call but the C call
+            return self._check(self._L.mpcvr_process_batch(self._ctx, srcs.n, srcs.sa, srcs.da, rt_pitch))
+        b = self.PrepareBatch(srcs, dsts)
+        self._keep = b
+        return self._check(self._L.mpcvr_process_batch(self._ctx, b.n, b.sa, b.da, rt_pitch))
+
+    @staticmethod
+    def PrepareBatch(srcs, dsts):
+        """The pointer arrays of a batch, for callers that submit the same buffers again and again (a ring): building them
+        costs ~2 us of interpreter time per frame, more than a 1080p frame costs the GPU."""
         n = len(srcs)
         assert n == len(dsts) and n > 0
-        sa = (C.c_void_p * n)(*[_ptr(s) for s in srcs])
-        da = (C.c_void_p * n)(*[_ptr(d) for d in dsts])
-        self._keep = [srcs, dsts]
-        return self._check(self._L.mpcvr_process_batch(self._ctx, n, sa, da, rt_pitch))
+        return PreparedBatch(n, (C.c_void_p * n)(*[_ptr(s) for s in srcs]), (C.c_void_p * n)(*[_ptr(d) for d in dsts]), (srcs, dsts))
 
     def Flush(self):
         return self._check(self._L.mpcvr_flush(self._ctx))

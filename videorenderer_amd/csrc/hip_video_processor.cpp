@@ -947,6 +947,18 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
         FusedParams a{}, b{};
         batchable = BatchPlan((const uint8_t *)srcs[0], dsts[0], rtPitch, aligned, &a, &b);
     }
+    if (batchable && m_plan.direct_convert && n <= 32) {
+        // same-size frames, small batch: one block-convert launch with the frame table in its kernel arguments
+        FusedParams conv{}, direct{};
+        if (!BatchPlan((const uint8_t *)srcs[0], dsts[0], rtPitch, aligned, &conv, &direct)) return Fail(MPCVR_E_UNEXPECTED, "batch plan changed");
+        FusedFrame tab[32];
+        for (int i = 0; i < n; i++) tab[i] = FusedFrame{(const uint8_t *)srcs[i], dsts[i]};
+        (void)hipEventRecord(m_evStart, m_stream);
+        hr = CheckHip(LaunchConvertBlocks(direct, nullptr, FusedFrame{nullptr, nullptr}, n, m_stream, 0, tab), "k_convert_blocks");
+        (void)hipEventRecord(m_evStop, m_stream);
+        m_timed = true;
+        return hr;
+    }
     if (!m_plan.fused_up2x && !batchable) {
         // samples that are repacked first share m_TexSrcVideo: those batches stay on the context stream
         const bool repack = m_srcParams->cformat == MPCVR_CF_V210 || m_srcParams->layout == LAY_RGB;

@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
 // ------------------------------------------------------------------------------------------------
 template <int TAIL, int SRC, bool FINAL>
 __global__ __launch_bounds__(256) void k_convert_blocks(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single, int pairs,
-                                                       uint8_t *batch_dst, size_t batch_stride)
+                                                       uint8_t *batch_dst, size_t batch_stride, FrameTable32 tab)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *Di = (uint32_t *)smem;                                   // dither as j << 14 (FINAL)
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256) void k_convert_blocks(FusedArgs P, const Fused
     const int X = blockIdx.x * 128 + 2 * lane;                         // rect columns X, X+1
     const int pair0 = (blockIdx.y * 4 + wave) * pairs;                 // pair p covers rect rows 2p-1, 2p
     if (X >= W || 2 * pair0 - 1 >= H) return;
-    const FusedFrame frame = frames ? frames[blockIdx.z] : single;
+    const FusedFrame frame = tab.n ? tab.f[blockIdx.z] : frames ? frames[blockIdx.z] : single;     // tab: the table in the kernel arguments
     auto uniform_ptr = [](const void *q) {
         const uint64_t v = (uint64_t)q;
         return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(256) void k_convert_blocks(FusedArgs P, const Fused
 // results; it only changes how the bytes travel.  SRC is SRC_NV12 or SRC_P01X.
 template <int TAIL, int SRC, bool FINAL>
 __global__ __launch_bounds__(256) void k_convert_blocks_wide(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single, int pairs,
-                                                            uint8_t *batch_dst, size_t batch_stride)
+                                                            uint8_t *batch_dst, size_t batch_stride, FrameTable32 tab)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *Di = (uint32_t *)smem;
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(256) void k_convert_blocks_wide(FusedArgs P, const 
     const int X = blockIdx.x * 512 + 8 * lane;                         // rect columns X .. X+7
     const int pair0 = (blockIdx.y * 4 + wave) * pairs;
     if (X >= W || 2 * pair0 - 1 >= H) return;
-    const FusedFrame frame = frames ? frames[blockIdx.z] : single;
+    const FusedFrame frame = tab.n ? tab.f[blockIdx.z] : frames ? frames[blockIdx.z] : single;
     auto uniform_ptr = [](const void *q) {
         const uint64_t v = (uint64_t)q;
         return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
@@ -952,10 +952,17 @@ bool ConvertBlocksSupported(const FusedParams &P, bool to_rt)
 }
 
 hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s,
-                               size_t batch_stride)
+                               size_t batch_stride, const FusedFrame *frames_host)
 {
     uint8_t *batch_dst = batch_stride ? (uint8_t *)P.store.dst : nullptr;
-    if (!frames_dev && n_frames != 1) return hipErrorInvalidValue;
+    // up to 32 frames travel in the kernel arguments (no table upload in front of the launch)
+    FrameTable32 tab;
+    tab.n = 0;
+    if (frames_host && n_frames <= 32) {
+        tab.n = n_frames;
+        for (int i = 0; i < n_frames; i++) tab.f[i] = frames_host[i];
+        for (int i = n_frames; i < 32; i++) tab.f[i] = FusedFrame{nullptr, nullptr};
+    } else if (!frames_dev && n_frames != 1) return hipErrorInvalidValue;
     FusedArgs a;
     FillFusedArgs(P, a);
     const ConvertParams &c = P.conv;
@@ -974,8 +981,8 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
     while (pairs > 2 && (long)strips * ((npairs + pairs - 1) / pairs) * n_frames < (wide ? 4096 : 8192)) pairs >>= 1;
     const dim3 grid(strips, (npairs + 4 * pairs - 1) / (4 * pairs), n_frames), block(256, 1, 1);
     const size_t lds = (fin ? 4096 : 0) + (tailk == TAILK_PQ_LUT ? LDS_T : 0);
-#define MPCVR_CB3(TK, SK, FN) hipLaunchKernelGGL((k_convert_blocks<TK, SK, FN>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride)
-#define MPCVR_CBW(TK, SK, FN) hipLaunchKernelGGL((k_convert_blocks_wide<TK, SK, FN>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride)
+#define MPCVR_CB3(TK, SK, FN) hipLaunchKernelGGL((k_convert_blocks<TK, SK, FN>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab)
+#define MPCVR_CBW(TK, SK, FN) hipLaunchKernelGGL((k_convert_blocks_wide<TK, SK, FN>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab)
 #define MPCVR_CB2(TK, SK) do { if (fin) MPCVR_CB3(TK, SK, true); else MPCVR_CB3(TK, SK, false); } while (0)
 #define MPCVR_CBW2(TK, SK) do { if (fin) MPCVR_CBW(TK, SK, true); else MPCVR_CBW(TK, SK, false); } while (0)
 #define MPCVR_CB(TK) do { if (wide && srck == SRC_P01X) MPCVR_CBW2(TK, SRC_P01X); else if (wide) MPCVR_CBW2(TK, SRC_NV12); \
