@@ -332,3 +332,22 @@ def test_correction_matrices(mpcvr, oracle):
     fixed = ob.reshape(4, 4)[:3, :3].astype(np.float64) @ wrong
     assert np.allclose(fixed, ycgco_rgb @ ycc, atol=1e-5)
 
+
+# ---------------------------------------------------------------- the C-ABI from plain C
+def build_c_demo(tmpdir):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(str(tmpdir), "c_abi_demo")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-std=c99", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "c_abi_demo.c"), "-o", exe,
+                           "-L" + os.path.join(root, "videorenderer_amd"), "-lmpcvr",
+                           "-Wl,-rpath," + os.path.join(root, "videorenderer_amd")])
+    return exe
+
+
+def test_c_abi_links_from_plain_c(mpcvr, tmp_path):
+    """include/mpcvr.h is a C header and libmpcvr.so resolves everything a C program needs: examples/c_abi_demo.c builds
+    with gcc -std=c99 -Werror against them (it runs in the GPU suite)."""
+    exe = build_c_demo(tmp_path)
+    assert os.path.exists(exe)
+

@@ -752,3 +752,32 @@ def test_context_reuse_across_geometries_and_batches(mpcvr, torch_cuda):
             assert torch.equal(dsts[i], want[i]), (dst_wh, n, cfg, bool(dovi), i, vp.GetVPInfo())
     vp.close()
 
+
+def test_c_abi_demo_program(mpcvr, oracle, torch_cuda, tmp_path):
+    """examples/c_abi_demo.c — plain C, host memory in, host memory out — against the oracle on the same frame."""
+    import subprocess
+    from tests.test_host_logic import build_c_demo
+    w, h = 128, 72
+    out = subprocess.run([build_c_demo(tmp_path), str(w), str(h)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    fields = dict(f.split("=") for f in out.stdout.split() if "=" in f)
+    # the demo's frame, rebuilt here
+    frame = np.zeros(w * h * 3 // 2, np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    frame[: w * h] = (16 + (xx * 219) // (w - 1) - (((xx >> 3) ^ (yy >> 3)) & 1) * 8).astype(np.uint8).reshape(-1)
+    cy, cx = np.mgrid[0:h // 2, 0:w // 2]
+    uv = np.zeros((h // 2, w), np.uint8)
+    uv[:, 0::2] = 64 + (cx * 128) // (w // 2)
+    uv[:, 1::2] = 192 - (cy * 128) // (h // 2)
+    frame[w * h:] = uv.reshape(-1)
+    p = oracle.default_params(cformat=1, width=w, height=h, exfmt=(5 << 8) | (2 << 12) | (1 << 15), window_w=w, window_h=h,
+                              video_rect=(0, 0, w, h))
+    want = oracle.process(p, frame, w)
+    want[..., 3] = 255
+    fnv = 2166136261
+    for b in want.tobytes():
+        fnv = ((fnv ^ b) * 16777619) & 0xffffffff
+    assert out.stdout.startswith("direct:convert+copy"), out.stdout
+    assert int(fields["bytes"]) == w * h * 4
+    assert fields["fnv1a"] == f"{fnv:08x}", (out.stdout, f"{fnv:08x}")
+
