@@ -781,3 +781,33 @@ def test_c_abi_demo_program(mpcvr, oracle, torch_cuda, tmp_path):
     assert int(fields["bytes"]) == w * h * 4
     assert fields["fnv1a"] == f"{fnv:08x}", (out.stdout, f"{fnv:08x}")
 
+
+def test_two_contexts_interleaved(mpcvr, torch_cuda):
+    """Two contexts (own streams, different formats and geometries) fed alternately without synchronising in between — a
+    transcoding server's pattern — must give what each gives alone: no state is shared between contexts."""
+    torch = torch_cuda
+    from videorenderer_amd import api, synth
+    specs = [dict(cf=2, w=128, h=72, dst=(256, 144), ext=GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"], st=dict(iUpscaling=4)),
+             dict(cf=1, w=160, h=96, dst=(212, 128), ext=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"], st=dict(iUpscaling=3))]
+    ctxs, frames, alone = [], [], []
+    for sp in specs:
+        vp = api.VideoProcessor(api.default_settings(**sp["st"]))
+        vp.InitMediaType(sp["cf"], sp["w"], sp["h"], extfmt=sp["ext"])
+        vp.SetWindowRect((0, 0) + sp["dst"]); vp.SetVideoRect((0, 0) + sp["dst"])
+        fr = [torch.from_numpy(synth.make_frame(sp["cf"], sp["w"], sp["h"], "noise", seed=700 + i)[0]).cuda() for i in range(6)]
+        outs = [torch.zeros((sp["dst"][1], sp["dst"][0], 4), dtype=torch.uint8, device="cuda") for _ in fr]
+        vp.ProcessBatch(fr, outs, sp["dst"][0] * 4)
+        vp.Synchronize()
+        ctxs.append(vp); frames.append(fr); alone.append(outs)
+    both = [[torch.zeros_like(o) for o in outs] for outs in alone]
+    for rep in range(4):
+        for k in (0, 1, 1, 0):
+            ctxs[k].ProcessBatch(frames[k][rep:rep + 3], both[k][rep:rep + 3], specs[k]["dst"][0] * 4)
+    for vp in ctxs:
+        vp.Synchronize()
+    for k in (0, 1):
+        for i in range(6):
+            assert torch.equal(both[k][i], alone[k][i]), (k, i)
+    for vp in ctxs:
+        vp.close()
+
