@@ -6,12 +6,18 @@
  * product (videorenderer_amd/).  Only tests/, __graft_entry__.smoke() and bench.py's
  * `cpu_baseline` leg use it, and only as the checker / reported baseline.
  *
- * Parity status: the reference holds NO tests or golden vectors for this path and its arithmetic
- * executes inside Direct3D 11 (HLSL compiled by d3dcompiler_47 / fxc), neither of which exists in
- * this environment.  The parameter maths (csputils matrices) is pinned against the REAL reference
- * code compiled from /root/reference/Source/csputils.cpp into oracle/_ref/ (see oracle/Makefile);
- * the per-pixel HLSL arithmetic is "parity unpinned" (restated literally, D3D11 functional-spec
- * semantics modelled explicitly: UNORM load/store, point/bilinear sampling, fp16 RNE).
+ * Parity status: PINNED to the reference.  The reference holds no tests or golden vectors for this path and its
+ * arithmetic executes inside Direct3D 11, so the pins are made from the reference's own code, compiled here where it lies:
+ *   - parameter maths: the REAL Source/csputils.cpp (oracle/_ref/libref_csputils.so), bit-identical, 1000+ cases;
+ *   - per-pixel arithmetic: the REAL HLSL — every fixed shader under Shaders/ that the path draws with, and the convert
+ *     shader text the REAL Source/Shaders.cpp (GetShaderConvertColor) generates — compiled for the CPU behind a small
+ *     Direct3D execution model (oracle/ref_hlsl/, oracle/_ref/libref_hlsl.so) and run through the whole Process():
+ *     this oracle is bit-identical (B, G, R) to it on 162 of 172 golden / pinning cases, within 1 code on 9 more (texture
+ *     coordinates with long mantissas: an ulp of slack in Tex * wh that no fp32 model can remove), and differs by whole
+ *     taps only on the one ill-conditioned box-filter case; recorded in tests/golden/ref_hlsl_pins.json and re-checked live
+ *     (tests/test_ref_hlsl.py).
+ * What stays modelled rather than executed: the D3D11 runtime around the shaders (UNORM load / store rounding, point and
+ * linear sampling, fp16 round-to-nearest-even, pow = exp2(y*log2 x)) and the GPU's own transcendental approximations.
  *
  * Every function cites the reference file:line it restates (paths relative to /root/reference).
  */

@@ -121,6 +121,8 @@ def build(ref=True, quiet=True):
     subprocess.check_call(["make", "-C", HERE], stdout=out)
     if ref and os.path.isdir(os.path.join(REFERENCE_ROOT, "Source")):
         subprocess.check_call(["make", "-C", HERE, "ref"], stdout=out)
+        # the reference's own HLSL (Shaders/*.hlsl + the text Source/Shaders.cpp generates) compiled for the CPU
+        subprocess.check_call(["make", "-C", HERE, "ref-hlsl"], stdout=out)
 
 
 _lib = None

@@ -187,6 +187,25 @@ GOLDEN_CASES = {
     "p010_pitch_padded": dict(cformat=2, w=64, h=32, kind="noise", seed=55, dst=(128, 64), iUpscaling=4, pitch=160),
 }
 
+# ---- pinning cases: used by tests/test_ref_hlsl.py only (oracle vs the reference's own shader text, oracle/ref_hlsl/).
+# Power-of-two sizes and ratios: every texture coordinate is exactly representable, so the reference arithmetic has ONE fp32
+# evaluation and the oracle must reproduce it bit for bit (other ratios carry an ulp of slack in Tex * wh, see the test).
+PINNING_CASES = {}
+for _m, _n in ((1, "mitchell"), (2, "catmull"), (3, "lanczos2"), (4, "lanczos3"), (5, "jinc2"), (0, "nearest")):
+    PINNING_CASES["pin_up2x_" + _n] = dict(cformat=2, w=64, h=32, kind="noise", seed=300 + _m, dst=(128, 64), iUpscaling=_m)
+    PINNING_CASES["pin_up4x_" + _n] = dict(cformat=1, w=32, h=16, kind="noise", seed=310 + _m, dst=(128, 64), iUpscaling=_m)
+    PINNING_CASES["pin_half_via_up_" + _n] = dict(cformat=2, w=128, h=64, kind="noise", seed=320 + _m, dst=(64, 32), iUpscaling=_m)
+for _m, _n in ((0, "box"), (1, "bilinear"), (2, "hamming"), (3, "bicubic"), (4, "bicubic_sharp"), (5, "lanczos")):
+    PINNING_CASES["pin_down4x_" + _n] = dict(cformat=2, w=256, h=128, kind="noise", seed=330 + _m, dst=(64, 32), iDownscaling=_m)
+    PINNING_CASES["pin_down2x_" + _n] = dict(cformat=1, w=128, h=64, kind="noise", seed=340 + _m, dst=(64, 32), iDownscaling=_m,
+                                             bInterpolateAt50pct=0)
+    PINNING_CASES["pin_down8x_x_only_" + _n] = dict(cformat=2, w=512, h=32, kind="noise", seed=350 + _m, dst=(64, 32), iDownscaling=_m)
+for _i, (_cf, _ex) in enumerate(((2, HDR10), (2, HLG), (20, ext(COSITED, TV, M709)), (21, ext(MPEG1, FULL, M2020, P2020, T22)), (1, ext(MPEG2, TV, M601)),
+                                 (6, ext(matrix=M709)), (16, ext(0, FULL, MYCGCO)), (24, HDR10))):
+    for _cs in (0, 1, 2):
+        PINNING_CASES["pin_convert_%d_chroma%d" % (_i, _cs)] = dict(cformat=_cf, w=64, h=32, kind="noise", seed=360 + 3 * _i + _cs, dst=(64, 32),
+                                                                      exfmt=_ex, iChromaScaling=_cs, full_range=(_i in (3, 6)))
+
 SETTING_KEYS = ("iTexFormat", "iChromaScaling", "iUpscaling", "iDownscaling", "bInterpolateAt50pct",
                 "bUseDither", "bConvertToSdr", "iSDRDisplayNits", "output_format", "flags")
 
@@ -232,7 +251,7 @@ def oracle_params(oracle, c):
 
 def run_case(oracle, name, background=0):
     """Oracle output for a named case: (window_h, window_w, 4) uint8; untouched pixels = background."""
-    c = GOLDEN_CASES[name]
+    c = GOLDEN_CASES[name] if name in GOLDEN_CASES else PINNING_CASES[name]
     frame, pitch = case_frame(c)
     p = oracle_params(oracle, c)
     dst = np.full((p.window_h, p.window_w, 4), background, dtype=np.uint8)

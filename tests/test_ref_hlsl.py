@@ -1,0 +1,172 @@
+"""The oracle pinned to the REFERENCE's own shader text (oracle/ref_hlsl/).
+
+The reference has no tests and its arithmetic is HLSL.  oracle/ref_hlsl compiles that HLSL — the fixed shaders
+of /root/reference/Shaders and the convert shader the real Source/Shaders.cpp generates — for the CPU behind a small execution
+model of Direct3D (hlsl_shim.h) and runs the whole Process() with it (ref_pipeline.py).  These tests hold the oracle to it:
+
+  * every comparable golden / pinning case: B, G, R of the oracle's render target against the reference-text result — recorded in
+    tests/golden/ref_hlsl_pins.json (+ the full reference output where the two are not bit-identical), so the check runs without
+    /root/reference; and live whenever oracle/_ref/libref_hlsl.so is built (here, and on the GPU box where it travels);
+  * bar: bit-identical wherever the texture coordinates are exactly representable (all power-of-two "pin_*" cases, every 2x case);
+    <= 1 code otherwise (Tex * wh carries an ulp of slack once (i + .5) * src / dst has a long mantissa; the rasteriser's own
+    interpolation error is of the same size, so no fp32 model can claim more); the one exception is stated below;
+  * alpha is not compared: the reference leaves the shader's A there (not 1 after the float4-wide HLG / Dolby Vision tails) and the
+    swap chain ignores it; the oracle and the product write opaque alpha.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "oracle", "ref_hlsl"))
+
+from tests.golden import cases  # noqa: E402
+from tests.golden.make_ref_hlsl_golden import all_cases, comparable, rgb_channels  # noqa: E402
+
+with open(os.path.join(HERE, "golden", "ref_hlsl_pins.json")) as _f:
+    PINS = json.load(_f)["cases"]
+OUTS = np.load(os.path.join(HERE, "golden", "ref_hlsl_outputs.npz"))
+CASES = {k: v for k, v in all_cases().items() if comparable(v)}
+
+# ps_convolution's box filter tests `x >= -0.5 && x < 0.5` (convolution_filters.hlsl:11-16); at a 2.4x ratio several taps sit on
+# that edge EXACTLY in real arithmetic, so which side they fall on is decided by the last ulp of the interpolated texcoord —
+# different on every GPU.  The whole-tap flips are large; the case is kept to show that, not held to 1 LSB.
+ILL_CONDITIONED = {"down_box_bilinear_mix"}
+
+
+def oracle_rgb(oracle, name):
+    a = cases.run_case(oracle, name)
+    c = CASES[name]
+    if c.get("output_format", 0) == 1:
+        a = a.view(np.uint32).reshape(a.shape[0], a.shape[1])
+    return rgb_channels(a)
+
+
+def sha(ch):
+    return hashlib.sha256(ch.astype(np.uint16).tobytes()).hexdigest()
+
+
+def test_every_comparable_case_is_pinned():
+    assert set(PINS) == set(CASES)
+    assert len(PINS) >= 170
+    exact = [n for n, p in PINS.items() if p["oracle_max"] == 0]
+    assert len(exact) >= 160
+    assert all(PINS[n]["oracle_max"] == 0 for n in cases.PINNING_CASES)          # power-of-two geometry: one fp32 evaluation
+    for n, p in PINS.items():
+        if n not in ILL_CONDITIONED:
+            assert p["oracle_max"] <= 1 and p["oracle_differing"] < 1e-3, (n, p)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_against_recorded_reference_hlsl(oracle, name):
+    pin = PINS[name]
+    got = oracle_rgb(oracle, name)
+    if pin["oracle_max"] == 0:
+        assert sha(got) == pin["rgb_sha256"], "oracle no longer bit-identical to the reference shader text"
+        return
+    ref = rgb_channels(OUTS[name])
+    assert sha(ref) == pin["rgb_sha256"]
+    d = np.abs(got - ref)
+    assert int(d.max()) == pin["oracle_max"] and abs(float((d > 0).mean()) - pin["oracle_differing"]) < 1e-12
+
+
+def _live():
+    import ref_hlsl
+    if not ref_hlsl.available():
+        pytest.skip("oracle/_ref/libref_hlsl.so not built (no /root/reference here)")
+    import ref_pipeline
+    return ref_pipeline
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_against_live_reference_hlsl(oracle, name):
+    RP = _live()
+    c = CASES[name]
+    frame, pitch = cases.case_frame(c)
+    p = cases.oracle_params(oracle, c)
+    try:
+        ref = RP.process(p, frame, pitch)
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    ref = rgb_channels(ref)
+    assert sha(ref) == PINS[name]["rgb_sha256"], "reference-text result changed: regenerate tests/golden/ref_hlsl_pins.json"
+    d = np.abs(oracle_rgb(oracle, name) - ref)
+    assert int(d.max()) == PINS[name]["oracle_max"]
+
+
+def test_headline_convert_shader_is_the_generators_text():
+    """The text comes out of the real GetShaderConvertColor: spot-check SURVEY.md appendix A's lines (Shaders.cpp:819-921)."""
+    RP = _live()
+    import ref_hlsl
+    from oracle import oracle as O
+    p = cases.oracle_params(O, dict(cformat=2, w=3840, h=2160, dst=(7680, 4320), exfmt=cases.HDR10, iUpscaling=4))
+    text = ref_hlsl.convert_shader_text(*RP.convert_args(p))
+    if text is None:
+        pytest.skip("reference tree not mounted")
+    for line in ("#define w 3840", "#define dx (1.0/3840)", "static const float2 wh = {3840, 2160};",
+                 "float2 pos = input.Tex+float2(dx*0.5,0);", "colorUV = texUV.Sample(sampL, pos).rg;",
+                 "color.rgb = float3(mul(cm_r, color.rgb), mul(cm_g, color.rgb), mul(cm_b, color.rgb)) + cm_c;",
+                 "color = ST2084ToLinear(color, LuminanceScale);", "color.rgb = ToneMappingHable(color.rgb);",
+                 "color.rgb = mul(matrix_conv_prim, color.rgb);", "color = pow(color, 1.0/2.2);"):
+        assert line in text, line
+    assert "1.660497, -0.58765674, -0.072839946" in text             # std::format("{}") of the real gamut matrix (:634-645)
+
+
+CORR = {1: "fix_bt2020", 2: "fix_ycgco", 3: "fixconvert_pq_to_sdr", 4: "fixconvert_hlg_to_sdr", 5: "convert_pq_to_sdr", 6: "convert_hlg_to_pq"}
+
+
+@pytest.mark.parametrize("kind", sorted(CORR))
+@pytest.mark.parametrize("fmts", [(8, 8), (10, 10), (10, 8)])
+def test_correction_shaders_against_live_reference_hlsl(oracle, kind, fmts):
+    """m_pPSCorrection shaders (ps_fix_*.hlsl, ps_fixconvert_*.hlsl, ps_convert_*.hlsl) vs orc_correction_pass."""
+    _live()
+    import ref_hlsl as R
+    src_fmt, dst_fmt = fmts
+    rng = np.random.default_rng(100 * kind + src_fmt + dst_fmt)
+    h, w = 24, 64
+    src = rng.integers(0, 2 ** 32, size=(h, w), dtype=np.uint32)
+    got = oracle.correction_pass(kind, src, src_fmt, dst_fmt)
+    tex = np.zeros((h, w, 4), np.float32)
+    if src_fmt == 10:
+        for k in range(3):
+            tex[..., k] = ((src >> (10 * k)) & 1023).astype(np.float32) / np.float32(1023)
+        tex[..., 3] = (src >> 30).astype(np.float32) / np.float32(3)
+    else:
+        for k, sh_ in enumerate((16, 8, 0, 24)):
+            tex[..., k] = ((src >> sh_) & 255).astype(np.float32) / np.float32(255)
+    rt = np.zeros((h, w, 4), np.float32)
+    fn = R.find_shader("ps_" + CORR[kind])
+    lum = R.words(np.float32(10000.0) / np.float32(125), np.float32(0))
+    R.draw(fn, [tex], rt, dst_fmt, (0, 0, w, h), ((0.0, 0.0), (1.0, 0.0), (0.0, 1.0)), samplers=[(0, 0)], cbs=[lum])
+    if dst_fmt == 10:
+        ref = np.stack([np.floor(rt[..., k] * np.float32(1023) + np.float32(0.5)) for k in range(3)], -1).astype(np.int32)
+        gch = np.stack([(got >> (10 * k)) & 1023 for k in range(3)], -1).astype(np.int32)
+    else:
+        ref = np.stack([np.floor(rt[..., k] * np.float32(255) + np.float32(0.5)) for k in range(3)], -1).astype(np.int32)
+        gch = np.stack([(got >> sh_) & 255 for sh_ in (16, 8, 0)], -1).astype(np.int32)
+    d = np.abs(ref - gch)
+    assert d.max() == 0, (int(d.max()), float((d > 0).mean()))
+
+
+# ---- the rewrite itself (host logic; no reference needed) ----
+def test_hlsl2cpp_rules():
+    import hlsl2cpp
+    lit = lambda s: hlsl2cpp._FLOAT_LIT.sub(lambda m: m.group(1) + "f", s)
+    assert lit("a = 1.0 / x + .5 - 2. * 1e-6 + 3.0f + float4x4(1) + v.x2") == "a = 1.0f / x + .5f - 2.f * 1e-6f + 3.0f + float4x4(1) + v.x2"
+    assert lit("#define w 3840") == "#define w 3840"
+    src = ("cbuffer PS_CONSTANTS : register(b0)\n{\n float2 wh;\n float pad[2];\n};\nTexture2D tex : register(t0);\n"
+           "SamplerState samp : register(s0);\nstatic const float k = 0.5;\nstruct PS_INPUT { float4 Pos : SV_POSITION; float2 Tex : TEXCOORD; };\n"
+           "float4 main(PS_INPUT input) : SV_Target\n{\n float3 rgb = tex.Sample(samp, input.Tex).rgb;\n"
+           " rgb = (rgb <= 0.5)\n  ? rgb * 2.0\n  : rgb;\n [unroll(3)]\n for (uint c = 0; c < 3; c++) {}\n return float4(rgb, 1);\n}\n")
+    out = hlsl2cpp.transform(src, "t")
+    assert "float2 wh = hlsl::cb_pop<float2 >(0);" in out and "hlsl::arr<float, 2> pad = hlsl::cb_pop<hlsl::arr<float, 2> >(0);" in out
+    assert "register" not in out and "SV_" not in out and "unroll" not in out and "TEXCOORD" not in out
+    assert "\nconst float k = 0.5f;" in out
+    assert "rgb = hlsl::select((rgb <= 0.5f), (rgb * 2.0f), (rgb));" in out
+    assert "tex.s = &rd__.tex[0];" in out and "samp.filter = rd__.samp_filter[0];" in out
+    assert 'extern "C" void t(const RefDraw* rd__)' in out
