@@ -75,6 +75,10 @@ enum { MPCVR_OUT_BGRA8 = 0, MPCVR_OUT_RGB10A2 = 1 };
 #define MPCVR_FLAG_NO_FAST_CONVERT  0x8u  /* fused 2x kernel off when its vectorised convert would be needed: the folded pass-per-kernel
                                              path runs instead (debug / A-B) */
 
+#define MPCVR_FLAG_FUSED_VALU       0x10u /* fused 2x kernel with its resize taps as packed-fp32 VALU chains (k_fused_up2x) */
+#define MPCVR_FLAG_FUSED_MFMA       0x20u /* fused 2x kernel with its resize taps on the matrix cores (k_fused_up2x_mx); neither flag:
+                                             the library's default (environment MPCVR_FUSED_MX=0/1 overrides it) */
+
 /* Subset of Settings_t (IVideoRenderer.h:104-135) that reaches the shader path; same field names. */
 typedef struct mpcvr_settings {
     int32_t  iTexFormat;          /* MPCVR_TEXFMT_*            default AUTOINT   */
@@ -110,7 +114,10 @@ int32_t mpcvr_settings_default(mpcvr_settings *s);
 int32_t mpcvr_create(const mpcvr_settings *settings, int32_t device, mpcvr_ctx **out);
 int32_t mpcvr_destroy(mpcvr_ctx *ctx);
 
-/* Use an externally owned hipStream_t (e.g. torch's current stream) for all work; NULL = own stream. */
+/* Use an externally owned hipStream_t (e.g. torch's current stream) for all work.  NULL = the context's own stream, which is a
+ * BLOCKING stream (hipStreamDefault): it synchronises implicitly with the legacy null stream, so work a caller queued on stream 0
+ * (NULL is also that stream's handle) stays ordered against mpcvr_copy_sample / mpcvr_process.  Other streams are the caller's to
+ * order (events), as usual. */
 int32_t mpcvr_set_stream(mpcvr_ctx *ctx, void *hip_stream);
 int32_t mpcvr_synchronize(mpcvr_ctx *ctx);
 

@@ -93,11 +93,19 @@ def compare(got, want, name, exact=False, min_same=0.99):
     return same
 
 
-def compare_rgb10(got, want, name, exact=False):
+def compare_rgb10(got, want, name, exact=False, tail=False, min_same=0.99):
+    """R10G10B10A2 render targets carry their own LSB (1/1023): the bar is stated in 10-bit codes, not as the 8-bit bar rescaled.
+    exact: plain / folded kernels without a transcendental tail; otherwise <= 1 code (FMA contraction of the fused / block kernels),
+    <= 2 codes behind a PQ / HLG / gamma tail (pow(x, 1/2.2) has unbounded slope at 0: one ulp of the linear value moves dark
+    10-bit codes by more than one), and >= min_same of the channels identical."""
     g, w = got.view(np.uint32)[..., 0], want.view(np.uint32)[..., 0]
+    lim = 0 if exact else (2 if tail else 1)
+    same = []
     for sh in (0, 10, 20):
         d = np.abs(((g >> sh) & 1023).astype(np.int32) - ((w >> sh) & 1023).astype(np.int32))
-        assert d.max() <= (0 if exact else 4), f"{name}: 10-bit delta {d.max()}"      # 4/1023 ~ 1/255
+        assert d.max() <= lim, f"{name}: 10-bit delta {d.max()} > {lim} ({int((d > lim).sum())} channels)"
+        same.append(float((d == 0).mean()))
+    assert min(same) >= min_same, f"{name}: only {min(same):.5f} of the 10-bit channels identical"
     assert np.array_equal(g >> 30, w >> 30)
 
 
@@ -110,7 +118,7 @@ def test_pass_per_kernel_path_vs_oracle(mpcvr, oracle, torch_cuda, name):
     got, info = run_product(mpcvr, torch_cuda, c, extra_flags=api.FLAG_NO_FUSED)
     assert info.startswith("passes:"), info
     if c.get("output_format", 0) == 1:
-        compare_rgb10(got, want, name, exact=not has_tail(c))
+        compare_rgb10(got, want, name, exact=not has_tail(c), tail=has_tail(c), min_same=0.995)
     elif has_tail(c):
         compare(got, want, name, min_same=0.995)
     else:
@@ -137,7 +145,7 @@ def test_default_path_vs_oracle(mpcvr, oracle, torch_cuda, name):
     got, info = run_product(mpcvr, torch_cuda, c)
     # 4:2:0 sources may go through the fused kernel or its block convert (FMA contraction, scale folded into the matrix)
     if c.get("output_format", 0) == 1:
-        compare_rgb10(got, want, name)
+        compare_rgb10(got, want, name, tail=has_tail(c))
     else:
         compare(got, want, f"{name} [{info}]", min_same=0.99)
 
@@ -186,6 +194,33 @@ def test_direct_convert_vs_oracle(mpcvr, oracle, torch_cuda, name):
         compare(got, want, name, min_same=0.99)
     else:
         compare(got, want, name, exact=True)
+
+
+@pytest.mark.parametrize("engine", ["valu", "mfma"])
+@pytest.mark.parametrize("name", FUSED)
+def test_fused_kernel_both_tap_engines_vs_oracle(mpcvr, oracle, torch_cuda, name, engine):
+    """Every exact-2x golden case through k_fused_up2x (packed-fp32 taps) AND k_fused_up2x_mx (taps on the matrix cores):
+    each against the oracle, whichever of the two is the library default."""
+    from videorenderer_amd import api
+    c = GOLDEN_CASES[name]
+    want = run_case(oracle, name, background=BG)
+    got, info = run_product(mpcvr, torch_cuda, c, extra_flags=api.FLAG_FUSED_MFMA if engine == "mfma" else api.FLAG_FUSED_VALU)
+    if c.get("output_format", 0) == 1:
+        compare_rgb10(got, want, f"{name} [{info}/{engine}]", tail=has_tail(c))
+    else:
+        compare(got, want, f"{name} [{info}/{engine}]", min_same=0.99)
+
+
+def test_mfma_operand_layout_probe():
+    """tools/ubench/mfma_owncol (built in-tree, travels with the snapshot): the 'own column' operand layout the matrix-core
+    kernel relies on, checked against a per-lane scalar reference on asymmetric data."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "tools", "ubench", "mfma_owncol")
+    if not os.path.exists(exe):
+        pytest.skip("tools/ubench/mfma_owncol not built")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300).stdout
+    print(out)
+    assert "own-column layout" in out and "(OK)" in out, out
 
 
 def test_fused_kernel_is_actually_used(mpcvr, torch_cuda):
@@ -444,54 +479,32 @@ def _full_size_case(exfmt, iUpscaling, seed):
 
 
 @pytest.mark.parametrize("label,exfmt,up", [("c3hdr", GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"], 4),
+                                            ("c3_sdr", GOLDEN_CASES["c3_p010_lanczos3_2x"]["exfmt"], 4),
                                             ("c5_hlg", GOLDEN_CASES["c5_p010_hlg_lanczos3_2x"]["exfmt"], 4),
                                             ("c4_mitchell", GOLDEN_CASES["c4_p010_pq_mitchell_2x"]["exfmt"], 1)])
 def test_full_size_4k_to_8k(mpcvr, oracle, torch_cuda, label, exfmt, up):
-    """4K P010 -> 8K at BASELINE size: (1) fused kernel vs pass-per-kernel path over all 33 M pixels,
-    (2) oracle on sampled 256x128 source regions (interior, crop-invariance of the path), (3) alpha/shape."""
+    """BASELINE.json configs 3 / 4 / 5 at their real size, 4K P010 -> 8K: EVERY one of the 33 M output pixels of the fused kernel
+    (both tap engines) and of the pass-per-kernel path against the oracle (which is pinned to the reference's own HLSL,
+    tests/test_ref_hlsl.py).  <= 1 LSB each; the two GPU paths are not compared with each other."""
     torch = torch_cuda
     from videorenderer_amd import api
     c = _full_size_case(exfmt, up, seed=77)
     frame, pitch = case_frame(c)
+    want = oracle.process(oracle_params(oracle, c), frame, pitch)
     dev = torch.from_numpy(frame).cuda()
-    outs = {}
-    for flags in (0, api.FLAG_NO_FUSED):
+    for flags, path, min_same in ((api.FLAG_FUSED_VALU, "fused_up2x", 0.99), (api.FLAG_FUSED_MFMA, "fused_up2x", 0.99),
+                                  (api.FLAG_NO_FUSED, "passes:convert,resizeX,resizeY+final", 0.995 if label != "c3_sdr" else 1.0)):
         vp, (ww, wh) = make_vp(mpcvr, c, flags)
         dst = torch.empty((wh, ww, 4), dtype=torch.uint8, device="cuda")
         vp.CopySample(dev, pitch)
         vp.Process(dst, ww * 4)
         vp.Synchronize()
-        outs[flags] = dst
-        info = vp.GetVPInfo()
-        assert info == ("fused_up2x" if flags == 0 else "passes:convert,resizeX,resizeY+final")
+        assert vp.GetVPInfo() == path
         vp.close()
-    fused, general = outs[0], outs[api.FLAG_NO_FUSED]
-    assert bool((fused[..., 3] == 255).all())
-    # cross-check of the two GPU paths over every pixel.  Each is held to <= 1 LSB against the ORACLE below;
-    # against each other 2 LSB can occur on the handful of saturated dark pixels where the 2020->709 matrix
-    # cancels to ~1e-6 and pow(1/2.2) magnifies a 1-ulp difference (ill-conditioned in fp32 on any device).
-    d = (fused.to(torch.int16) - general.to(torch.int16)).abs()
-    assert int(d.max()) <= 2
-    assert int((d > 1).sum()) <= 16, int((d > 1).sum())
-    assert float((d == 0).float().mean()) >= 0.99
-    # oracle on sampled regions: crop offsets are multiples of 16 source px => dither phase 0 in the crop
-    gen = general.cpu().numpy()
-    fus = fused.cpu().numpy()
-    for (x0, y0) in ((0, 0), (1792, 1024), (3584, 2032), (16, 2032), (3584, 0)):
-        cw, ch = 256, 128
-        p = oracle.default_params(cformat=2, width=3840, height=2160, exfmt=exfmt, iUpscaling=up,
-                                  src_rect=(x0, y0, x0 + cw, y0 + ch), window_w=2 * cw, window_h=2 * ch,
-                                  video_rect=(0, 0, 2 * cw, 2 * ch))
-        want = oracle.process(p, frame, pitch)
-        # resize taps of the crop clamp at the crop border: compare the interior only, except where the crop
-        # border coincides with the frame border (then the full frame clamps identically)
-        l = 0 if x0 == 0 else 8
-        t = 0 if y0 == 0 else 8
-        r = 2 * cw if x0 + cw == 3840 else 2 * cw - 8
-        b = 2 * ch if y0 + ch == 2160 else 2 * ch - 8
-        for arr, nm in ((gen, "general"), (fus, "fused")):
-            sub = arr[2 * y0 + t: 2 * y0 + b, 2 * x0 + l: 2 * x0 + r]
-            compare(sub, want[t:b, l:r], f"{label} {nm} region ({x0},{y0})", min_same=0.99)
+        got = dst.cpu().numpy()
+        assert bool((got[..., 3] == 255).all())
+        same = compare(got, want, f"{label} flags={flags}", exact=(min_same == 1.0), min_same=min_same)
+        print(f"{label} flags={flags}: identical channels {same:.6f}")
 
 
 def test_full_size_flat_frame_and_dither_period(mpcvr, torch_cuda):
@@ -811,3 +824,146 @@ def test_two_contexts_interleaved(mpcvr, torch_cuda):
     for vp in ctxs:
         vp.close()
 
+# ------------------------------------------------------------------------------------------------
+# device samples that do not start on a dword; rotated / HDR snapshots
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["c3hdr_p010_pq_lanczos3_2x", "c1_nv12_bt709_passthrough", "up_1p5x_lanczos3", "noise_nv12_catmull_2x"])
+def test_misaligned_device_sample(mpcvr, torch_cuda, name):
+    """A zero-copy sample at +2 / +1 bytes from an allocation: the kernels' dword loads never see it — the sample is copied
+    into the context's own texture first (the reference copies EVERY decoder sample, :2563-2569).  Single frames and batches."""
+    torch = torch_cuda
+    c = GOLDEN_CASES[name]
+    frame, pitch = case_frame(c)
+    want, info = run_product(mpcvr, torch, c)
+    for shift in (2, 1):
+        vp, (ww, wh) = make_vp(mpcvr, c)
+        big = torch.zeros(frame.size + 64, dtype=torch.uint8, device="cuda")
+        big[shift:shift + frame.size] = torch.from_numpy(frame).cuda()
+        sample = big[shift:shift + frame.size]
+        assert sample.data_ptr() % 4 == shift
+        dst = torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda")
+        vp.CopySample(sample, pitch)
+        vp.Process(dst, ww * 4)
+        vp.Synchronize()
+        assert np.array_equal(dst.cpu().numpy(), want), f"{name} +{shift}"
+        dsts = [torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda") for _ in range(3)]
+        vp.ProcessBatch([sample, torch.from_numpy(frame).cuda(), sample], dsts, ww * 4)
+        vp.Synchronize()
+        for d in dsts:
+            assert np.array_equal(d.cpu().numpy(), want), f"{name} +{shift} batch"
+        vp.close()
+
+
+def test_get_current_image_rotated_and_hdr(mpcvr, oracle, torch_cuda):
+    """GetCurentImage swaps width and height for 90 / 270 degrees (:3500-3502) and shows an HDR source as SDR even while the
+    processor is in HDR-output mode (m_bHdrPassthrough cleared around the draw, :3530-3545)."""
+    c = dict(GOLDEN_CASES["rot90_copy_nv12"])
+    vp, _ = make_vp(mpcvr, c)
+    frame, pitch = case_frame(c)
+    vp.CopySample(frame, pitch)
+    snap = vp.GetCurentImage()
+    assert snap.size == 64 * 40 * 4
+    snap = snap.reshape(64, 40, 4)                                   # 64 x 40 source, rotated: 40 wide, 64 high
+    want = oracle.process(oracle_params(oracle, dict(c, dst=(40, 64))), frame, pitch)
+    compare(snap, want, "rotated GetCurentImage", min_same=0.999)
+    vp.close()
+    c = dict(GOLDEN_CASES["hdrout_pq_passthrough_2x"])
+    vp, _ = make_vp(mpcvr, c)
+    frame, pitch = case_frame(c)
+    vp.CopySample(frame, pitch)
+    snap = vp.GetCurentImage().reshape(32, 64, 4)
+    sdr = dict(c, dst=(64, 32), output_format=0)
+    sdr.pop("hdr_output")
+    want = oracle.process(oracle_params(oracle, sdr), frame, pitch)
+    compare(snap, want, "HDR-mode GetCurentImage is SDR", min_same=0.99)
+    # ... and the processor is back in HDR-output mode afterwards
+    got, _ = run_product(mpcvr, torch_cuda, c)
+    assert got.shape[0] == 64
+    vp.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# N > 1 on the one GPU of this box: two ranks over gloo (MPCVR_DIST_BACKEND), the real parameter blob, the real bench.py
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_worker(rank, world, port, q):
+    import hashlib
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MPCVR_DIST_BACKEND="gloo")
+    import torch
+    from videorenderer_amd import api, dist as vdist
+    from tests.golden.cases import GOLDEN_CASES as G, case_frame as cf
+    vdist.init_from_env()
+    torch.cuda.set_device(0)
+    c = G["c3hdr_p010_pq_lanczos3_2x"]
+    # rank 1 is configured DIFFERENTLY on purpose (display nits, scaler): after sync_params it must render like rank 0
+    st = api.default_settings(iUpscaling=4 if rank == 0 else 1, iSDRDisplayNits=125 if rank == 0 else 300)
+    vp = api.VideoProcessor(st, device=0)
+    vp.InitMediaType(c["cformat"], c["w"], c["h"], extfmt=c["exfmt"])
+    w2, h2 = c["dst"]
+    vp.SetWindowRect((0, 0, w2, h2))
+    vp.SetVideoRect((0, 0, w2, h2))
+    frame, pitch = cf(c)
+
+    def render():
+        dst = torch.zeros((h2, w2, 4), dtype=torch.uint8, device="cuda")
+        vp.CopySample(torch.from_numpy(frame).cuda(), pitch)
+        vp.Process(dst, w2 * 4)
+        vp.Synchronize()
+        return hashlib.sha256(dst.cpu().numpy().tobytes()).hexdigest()
+    before = render()
+    vdist.sync_params(vp)                      # the real mpcvr_get_param_blob payload, broadcast from rank 0
+    after = render()
+    shard = vdist.shard_frames(7, rank, world)
+    q.put((rank, before, after, shard))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+    vp.close()
+
+
+def test_two_ranks_share_rank0_parameters(mpcvr, torch_cuda):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, b0, a0, s0), (_, b1, a1, s1) = res
+    assert b0 != b1, "the two ranks were configured differently"
+    assert a0 == b0, "rank 0 keeps its own parameters"
+    assert a1 == a0, "rank 1 renders with rank 0's parameter blob after sync_params"
+    assert sorted(s0 + s1) == list(range(7))
+
+
+def test_bench_two_ranks_one_gpu(mpcvr, torch_cuda):
+    """bench.py's N > 1 branch end to end (torchrun launch line of the driver, barriers, max-over-ranks timing, rank-0 JSON)
+    with two ranks sharing this box's one GPU over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MPCVR_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--ring", "2", "--src", "256x144", "--no-cpu-baseline", "--no-host-path"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["scaling"] == "weak"
+    assert r["value"] > 0 and r["config"]["path"] == "fused_up2x"
+    assert abs(r["config"]["fps_per_gpu"] * 2 - r["value"]) < 1e-2 * r["value"]

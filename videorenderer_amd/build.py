@@ -25,6 +25,7 @@ SOURCES = [
     ("mpcvr_capi.cpp", []),
     ("vp_kernels.hip", ["-ffp-contract=off", "-DMPCVR_EXACT_FP"]),
     ("vp_fused.hip", []),
+    ("vp_fused_mx.hip", []),
 ]
 
 

@@ -52,7 +52,8 @@ CHipVideoProcessor::CHipVideoProcessor() { std::memcpy(m_ditherHost, kDitherTabl
 
 CHipVideoProcessor::~CHipVideoProcessor()
 {
-    if (!m_bInit) return;
+    // runs after a failed Init as well (the stream / events / dither buffer may exist already): every handle below is guarded
+    if (!m_bInit && !m_stream && !m_evStart && !m_evStop && !m_dither.ptr) return;
     (void)hipSetDevice(m_device);
     if (m_stream) (void)hipStreamSynchronize(m_stream);
     for (DevBuffer *b : {&m_batchConv, &m_batchMid, &m_jincFirst, &m_jincSecond, &m_TexSrcVideo, &m_TexRaw, &m_TexPost, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
@@ -125,7 +126,9 @@ HRESULT CHipVideoProcessor::Init(int device, const mpcvr_settings &settings)
     m_device = device;
     HRESULT hr;
     if ((hr = CheckHip(hipSetDevice(device), "hipSetDevice"))) return hr;
-    if ((hr = CheckHip(hipStreamCreateWithFlags(&m_stream, hipStreamNonBlocking), "hipStreamCreate"))) return hr;
+    // the context's own stream is a BLOCKING stream: it orders itself against the legacy null stream, so a caller that
+    // prepares samples / render targets on stream 0 (torch's default stream) and never hands over a stream is still ordered
+    if ((hr = CheckHip(hipStreamCreateWithFlags(&m_stream, hipStreamDefault), "hipStreamCreate"))) return hr;
     m_ownStream = true;
     if ((hr = CheckHip(hipEventCreate(&m_evStart), "hipEventCreate"))) return hr;
     if ((hr = CheckHip(hipEventCreate(&m_evStop), "hipEventCreate"))) return hr;
@@ -146,7 +149,8 @@ HRESULT CHipVideoProcessor::SetStream(hipStream_t s)
     m_ownStream = false;
     m_stream = s;
     if (!s) {
-        HRESULT hr = CheckHip(hipStreamCreateWithFlags(&m_stream, hipStreamNonBlocking), "hipStreamCreate");
+        // NULL (which is also the handle of the legacy default stream) = the context's own BLOCKING stream, see Init
+        HRESULT hr = CheckHip(hipStreamCreateWithFlags(&m_stream, hipStreamDefault), "hipStreamCreate");
         if (hr) return hr;
         m_ownStream = true;
     }
@@ -668,9 +672,19 @@ static int RgbTexFmt(const FmtConvParams &f) { return f.bits10 ? SF_RGB10A2 : (f
 // applied when a texel is loaded) except v210, which CopyFrameV210 unpacks into a Y210 texture.
 HRESULT CHipVideoProcessor::PrepareSample(const uint8_t *dev_sample, const uint8_t **tex)
 {
-    if (m_srcParams->cformat != MPCVR_CF_V210 && m_srcParams->layout != LAY_RGB) { *tex = dev_sample; return MPCVR_S_OK; }
-    const int tp = TexPitch();
     HRESULT hr;
+    if (m_srcParams->cformat != MPCVR_CF_V210 && m_srcParams->layout != LAY_RGB) {
+        if (((uintptr_t)dev_sample & 3) == 0) { *tex = dev_sample; return MPCVR_S_OK; }
+        // a device sample that does not start on a dword: the kernels read rows with 4- / 16-byte loads, so it is copied into
+        // the context's own texture first — what the reference does with EVERY decoder-owned sample (CopySubresourceRegion,
+        // DX11VideoProcessor.cpp:2563-2569)
+        const size_t bytes = (size_t)m_srcPitch * m_srcLines;
+        if ((hr = CheckHip(m_TexSrcVideo.CheckCreate(bytes), "m_TexSrcVideo"))) return hr;
+        if ((hr = CheckHip(hipMemcpyAsync(m_TexSrcVideo.ptr, dev_sample, bytes, hipMemcpyDeviceToDevice, m_stream), "sample copy"))) return hr;
+        *tex = (const uint8_t *)m_TexSrcVideo.ptr;
+        return MPCVR_S_OK;
+    }
+    const int tp = TexPitch();
     const bool fresh = m_TexSrcVideo.size < (size_t)tp * m_srcHeight || !m_TexSrcVideo.ptr;
     if ((hr = CheckHip(m_TexSrcVideo.CheckCreate((size_t)tp * m_srcHeight), "m_TexSrcVideo"))) return hr;
     if (m_srcParams->layout == LAY_RGB) {
@@ -749,6 +763,7 @@ void CHipVideoProcessor::FillFusedParams(const uint8_t *sample, void *rt, int rt
     const bool no_lut = (m_cfg.flags & MPCVR_FLAG_NO_LUT) != 0;
     fp->pq_lut = (m_pqLutValid && !no_lut) ? (const float *)m_pqLut.ptr : nullptr;
     fp->literal_tail = no_lut ? 1 : 0;
+    fp->taps_mfma = (m_cfg.flags & MPCVR_FLAG_FUSED_MFMA) ? 1 : (m_cfg.flags & MPCVR_FLAG_FUSED_VALU) ? 0 : -1;
     fp->dst_aligned16 = (((uintptr_t)rt) & 15) == 0;        // batches: ProcessBatch checks every target
     fp->src_aligned16 = (((uintptr_t)sample) & 15) == 0;
     // vectorised convert: dword loads need 4-byte aligned rows and a source rect starting on a 4-px boundary
@@ -824,7 +839,6 @@ HRESULT CHipVideoProcessor::ConvertColorPass(const uint8_t *sample)
         FillFusedParams(sample, out.ptr, out.pitch, &fp);
         fp.store = MakeStore(out.ptr, out.pitch, out.fmt, false);
         fp.dst_aligned16 = 1;
-        if (((uintptr_t)sample & 3) != 0) fp.fast_convert = 0;
         if (ConvertBlocksSupported(fp, false))
             return CheckHip(LaunchConvertBlocks(fp, nullptr, FusedFrame{sample, out.ptr}, 1, m_run), "k_convert_blocks");
     }
@@ -884,14 +898,12 @@ HRESULT CHipVideoProcessor::ProcessOne(const uint8_t *sample, void *rt, int rtPi
     if (m_plan.fused_up2x) {
         FusedParams fp{};
         FillFusedParams(sample, rt, rtPitch, &fp);
-        if (((uintptr_t)sample & 3) != 0) fp.fast_convert = 0;
         const FusedFrame fr{sample, rt};        // a single frame travels by value in the kernel arguments
         return CheckHip(LaunchFusedUp2x(fp, nullptr, fr, 1, m_run), "k_fused_up2x");
     }
     if (m_plan.direct_convert) {
         FusedParams fp{};
         FillFusedParams(sample, rt, rtPitch, &fp);
-        if (((uintptr_t)sample & 3) != 0) fp.fast_convert = 0;
         if (ConvertBlocksSupported(fp, true))
             return CheckHip(LaunchConvertBlocks(fp, nullptr, FusedFrame{sample, rt}, 1, m_run), "k_convert_blocks");
         ConvertParams P;
@@ -959,9 +971,10 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
         m_timed = true;
         return hr;
     }
-    if (!m_plan.fused_up2x && !batchable) {
-        // samples that are repacked first share m_TexSrcVideo: those batches stay on the context stream
-        const bool repack = m_srcParams->cformat == MPCVR_CF_V210 || m_srcParams->layout == LAY_RGB;
+    if ((!m_plan.fused_up2x && !batchable) || !src4) {
+        // samples that are repacked (or, not starting on a dword, copied) first share m_TexSrcVideo: those batches stay on the
+        // context stream, frame by frame
+        const bool repack = m_srcParams->cformat == MPCVR_CF_V210 || m_srcParams->layout == LAY_RGB || !src4;
         // MPCVR_BATCH_LANES=2..4 deals the frames to that many streams with private intermediates.  Measured on MI355X:
         // +5..10 % on the two-pass resize geometries, -15 % on 1080p same-size (fork/join events cost more than the
         // overlap returns), so one lane is the default.
@@ -1020,7 +1033,6 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
     FusedParams fp{};
     FillFusedParams((const uint8_t *)srcs[0], nullptr, rtPitch, &fp);
     fp.dst_aligned16 = aligned ? 1 : 0;
-    if (!src4) fp.fast_convert = 0;
     (void)hipEventRecord(m_evStart, m_stream);
     hr = CheckHip(LaunchFusedUp2x(fp, (const FusedFrame *)slot.dev.ptr, FusedFrame{nullptr, nullptr}, n, m_stream), "k_fused_up2x");
     (void)hipEventRecord(m_evStop, m_stream);
@@ -1137,7 +1149,8 @@ HRESULT CHipVideoProcessor::GetCurentImage(void *hostBGRA, size_t *size)
 {
     if (!size) return Fail(MPCVR_E_POINTER, "null size");
     if (!m_bInit || !m_srcParams) return Fail(MPCVR_E_NOT_VALID_STATE, "InitMediaType has not been called");
-    const int w = m_srcRectWidth, h = m_srcRectHeight;      // no anamorphic / rotation support here
+    int w = m_srcRectWidth, h = m_srcRectHeight;            // no anamorphic sources here (m_srcAnamorphic :3497-3499)
+    if (m_iRotation == 90 || m_iRotation == 270) std::swap(w, h);     // :3500-3502
     const size_t need = (size_t)w * 4 * h;
     if (!hostBGRA) { *size = need; return MPCVR_S_OK; }
     if (*size < need) { *size = need; return Fail(MPCVR_E_INVALIDARG, "buffer too small"); }
@@ -1148,10 +1161,16 @@ HRESULT CHipVideoProcessor::GetCurentImage(void *hostBGRA, size_t *size)
     // temporarily point video/window rect at the image (:3549-3553), B8G8R8X8 target (:3518)
     const CRect backupVid = m_videoRect, backupWnd = m_windowRect;
     const int backupOut = m_cfg.output_format;
+    // an HDR source shown in HDR is snapshot as SDR: m_bHdrPassthrough / m_bHdrLocalToneMapping are cleared around the draw and
+    // the convert shader rebuilt with the PQ / HLG -> SDR tail (:3530-3545, restored :3562-3580)
+    const bool backupHdr = m_hdrOutput;
+    const bool backupOverride = m_blobOverride;
+    if (m_hdrOutput) { m_hdrOutput = false; m_blobOverride = false; SetShaderConvertColorParams(); UpdateHdrToneMapParams(); }
     m_videoRect = CRect(0, 0, w, h); m_windowRect = m_videoRect; m_cfg.output_format = MPCVR_OUT_BGRA8;
     m_planDirty = true;
     hr = Process(m_Snapshot.ptr, w * 4, nullptr, nullptr, false);
     m_videoRect = backupVid; m_windowRect = backupWnd; m_cfg.output_format = backupOut;
+    if (backupHdr) { m_hdrOutput = true; SetShaderConvertColorParams(); UpdateHdrToneMapParams(); m_blobOverride = backupOverride; }
     m_planDirty = true;
     if (hr) return hr;
     if ((hr = CheckHip(hipMemcpyAsync(hostBGRA, m_Snapshot.ptr, need, hipMemcpyDeviceToHost, m_stream), "readback"))) return hr;
@@ -1206,6 +1225,12 @@ HRESULT CHipVideoProcessor::SetParamBlob(const void *buf, size_t size)
     ParamBlob b;
     std::memcpy(&b, buf, sizeof(b));
     if (b.magic != kBlobMagic || b.version != 1) return Fail(MPCVR_E_INVALIDARG, "bad blob magic/version");
+    // the blob crosses a process boundary (rank 0's broadcast): nothing in it is trusted to index or select kernels unchecked
+    if (b.tail < TAIL_NONE || b.tail > TAIL_HLG_TO_PQ) return Fail(MPCVR_E_INVALIDARG, "blob: tail kind out of range");
+    for (const Up2xWeights *w : {&b.upx, &b.upy})
+        if ((w->ntaps != 0 && w->ntaps != 4 && w->ntaps != 6) || (w->q1_quirk != 0 && w->q1_quirk != 1))
+            return Fail(MPCVR_E_INVALIDARG, "blob: phase-weight table malformed");
+    if (!(b.lum_scale > 0.0f) || !(b.gamma > 0.0f || b.tail != TAIL_GAMMA_GAMUT)) return Fail(MPCVR_E_INVALIDARG, "blob: luminance scale / gamma");
     (void)hipSetDevice(m_device);
     std::memcpy(m_cm, b.cm, sizeof(m_cm));
     m_lumScale = b.lum_scale;

@@ -9,12 +9,18 @@
 
 namespace mpcvr {
 
+// RPU fields arrive from untrusted media: everything that indexes or shifts below is range-checked here (the reference checks
+// num_pivots / mapping_idc only, DX11VideoProcessor.cpp:2279-2322; its shader loops are bounded by the cbuffer layout instead)
 bool CheckDoviCurves(const mpcvr_dovi_metadata &md)
 {
+    if (md.coef_log2_denom > 31 || md.bl_bit_depth < 8 || md.bl_bit_depth > 16) return false;      // 1 << n below
     for (const auto &curve : md.curves) {
         if (curve.num_pivots < 2 || curve.num_pivots > 9) return false;
-        for (int i = 0; i < int(curve.num_pivots - 1); i++)
+        for (int i = 0; i < int(curve.num_pivots - 1); i++) {
             if (curve.mapping_idc[i] > 1) return false;
+            if (curve.mapping_idc[i] == 0 && curve.poly_order[i] > 2) return false;                  // poly_coef[piece][3]
+            if (curve.mapping_idc[i] == 1 && (curve.mmr_order[i] < 1 || curve.mmr_order[i] > 3)) return false;   // mmr_coef[piece][3][7]
+        }
     }
     return md.n_l2 <= 32;
 }
@@ -23,8 +29,8 @@ void PackDoviCurves(const mpcvr_dovi_metadata &md, DoviParams *dst)
 {
     std::memset(dst->curves, 0, sizeof(dst->curves));
     dst->has_mmr = 0;
-    const float coefScale = 1.0f / (1 << md.coef_log2_denom);
-    const float codeScale = 1.0f / ((1 << md.bl_bit_depth) - 1);
+    const float coefScale = 1.0f / (float)(1u << (md.coef_log2_denom & 31));
+    const float codeScale = 1.0f / (float)((1u << (md.bl_bit_depth & 31)) - 1);
     for (int c = 0; c < 3; c++) {
         const mpcvr_dovi_curve &in = md.curves[c];
         DoviCurve &cv = dst->curves[c];
@@ -49,7 +55,7 @@ void PackDoviCurves(const mpcvr_dovi_metadata &md, DoviParams *dst)
                 co[0] = coefScale * in.mmr_constant[piece];
                 co[1] = (float)slot;                            // first float4 of this piece's weights
                 co[3] = (float)order;
-                for (int o = 0; o < order; o++) {               // two float4 per order: (3 + pad) and 4 weights
+                for (int o = 0; o < order && o < 3 && slot + 2 <= 48; o++) {    // two float4 per order: (3 + pad) and 4 weights; 48 = mmr[]
                     const int64_t *w = in.mmr_coef[piece][o];
                     float *a = cv.mmr[slot++], *b = cv.mmr[slot++];
                     a[0] = coefScale * w[0]; a[1] = coefScale * w[1]; a[2] = coefScale * w[2]; a[3] = 0.0f;

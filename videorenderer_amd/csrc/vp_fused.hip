@@ -25,357 +25,11 @@
 //   tools/ubench/op_rate.hip), so v_pk_{fma,mul}_f32 with an SGPR weight is the cheapest FMA here: two for the price of one.
 //   The four waves of a workgroup share only the read-only tables (dither, PQ->SDR LUT).
 //   Recomputed: the horizontal halo (8 of 128 columns) and 6 rows per segment.
-#include <hip/hip_fp16.h>
-#include <hip/hip_runtime.h>
-
-#include <cstdlib>
-#include <cstring>
-
-#include "vp_device.h"
-#include "vp_launch.h"
-#include "vp_plan.h"
+#include "vp_fused_dev.h"
 
 namespace mpcvr {
 
 namespace {
-
-constexpr int S = 120;             // source pixels per strip
-constexpr int AW = 128;            // LDS A row width: rect columns x0-4 .. x0+123
-constexpr int WAVES = 4;           // strips per workgroup
-constexpr int A_FLOATS = 3 * AW * 2;   // [ch][col][row a | row a+1]
-constexpr int LUT_N = kPqLutSize;  // PQ->SDR per-channel table (vp_params.h)
-constexpr int LDS_A = WAVES * A_FLOATS * 4;
-constexpr int LDS_D = 32 * 32 * 2;      // dither table, fp16 bits (generic epilogue)
-constexpr int LDS_DB = 32 * 32 * 4;     // dither table as integers j << 14 (d = j/1024) for the FASTEPI epilogue
-constexpr int LDS_T = LUT_N * 8;   // {value, delta-to-next} pairs
-
-typedef const __attribute__((address_space(1))) uint8_t *gcptr;
-typedef __attribute__((address_space(1))) uint8_t *gptr;
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-enum { TAILK_NONE = 0, TAILK_PQ_LUT = 1, TAILK_ALU = 2, TAILK_HLG = 3 };
-// source specialisation: GENERIC reads planes / bytes / siting at run time; P01X = bi-planar 16-bit (P010/P016), NV12 =
-// bi-planar 8-bit, both with MPEG-2 or co-sited chroma (not horizontally centred)
-enum { SRC_GENERIC = 0, SRC_P01X = 1, SRC_NV12 = 2 };
-// epilogue specialisation: DITHER8 = B8G8R8A8 target behind a final pass (integer form); DIRECT8 = B8G8R8A8 target written
-// straight from the Y pass (8-bit sources: no post-scale step); both require 16-byte aligned rows and off_x % 4 == 0
-enum { EPI_GENERIC = 0, EPI_DITHER8 = 1, EPI_DIRECT8 = 2 };
-
-
-// everything the kernel needs, flattened (kernel argument => SGPRs)
-struct FusedArgs {
-    uint32_t off_u, off_v;         // byte offsets of the chroma plane(s) inside a sample (u = interleaved UV when biplanar)
-    int pitch_y, pitch_c;
-    int tex_w, cw, ch;             // luma width, chroma size
-    int rect_l, rect_t, W, H;      // source rect origin and size (== convert-output size)
-    int bytes, planes;
-    int center_h;                  // MPEG-1 siting: chroma sample centred between luma columns
-    int v_off4;                    // vertical chroma offset in quarter chroma rows: 1 for co-sited (+0.25), else 0
-    float m[9], c[3];              // colour matrix with the UNORM scale (and CopyPlane10to16 shift) folded in
-    int tail; float gamma, lum_scale;
-    float gamut[9];
-    const float *lut;              // LUT_N floats (device) for TAILK_PQ_LUT
-    float maxv, inv_maxv;          // internal UNORM format
-    float q_over_maxv;             // ps_final_pass QUANTIZATION / maxv
-    uint32_t epi_mul;              // FASTEPI: ceil(QUANTIZATION * 2^24 / maxv), see the final-pass epilogue
-    float we[6], wo[6];            // phase weights (even/odd outputs); Q1-folded by the launcher
-    int dst_pitch, off_x, off_y;
-    int final_pass, out10;
-    float quant;
-    const uint16_t *dither;
-    int seg_rows;
-};
-
-template <int SRC> __device__ __forceinline__ bool src_wide(const FusedArgs &P) { return SRC == SRC_P01X ? true : SRC == SRC_NV12 ? false : P.bytes == 2; }
-template <int SRC> __device__ __forceinline__ bool src_biplanar(const FusedArgs &P) { return SRC != SRC_GENERIC ? true : P.planes == 2; }
-template <int SRC> __device__ __forceinline__ bool src_center(const FusedArgs &P) { return SRC != SRC_GENERIC ? false : P.center_h != 0; }
-
-// tap offsets relative to `base` (ps_interpolation_*.hlsl).  NT = 5 is the D3D11 Lanczos3 as written (quirk Q1,
-// ps_interpolation_lanczos3.hlsl:33-34: the second tap re-reads the first tap's texel): taps {-2, 0, 1, 2, 3}
-// with the first weight = w0 + w1 (folded by the launcher).
-template <int NT>
-__host__ __device__ constexpr int tap_off(int t) { return NT == 4 ? (t - 1) : NT == 6 ? (t - 2) : (t == 0 ? -2 : t - 1); }
-
-__device__ __forceinline__ f2 splat(float x) { return f2{x, x}; }
-__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-// UNORM store rounding floor(x*maxv + 0.5) for x in [0,1] without v_floor (which has no packed form):
-// x*maxv + 2^23 rounds to an integer in the FMA itself (nearest-even; x*maxv can only tie at x = 0.5, where both
-// conventions give (maxv+1)/2), then 2^23 comes off again — two packed instructions for two values.
-// `big` = splat(2^23) held in a VGPR pair for the whole kernel (the other two operands are VGPR + SGPR; a third
-// constant would be re-materialised with v_mov_b64 at every use).
-__device__ __forceinline__ f2 unorm_round2(f2 x, f2 maxv2, f2 big)
-{
-    return pk_fma(x, maxv2, big) - big;
-}
-// fp32 -> fp16 (RNE) -> fp32 for a pair: v_cvt_pk_f16_f32 + two v_cvt_f32_f16
-typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 half_round2(f2 v) { return __builtin_convertvector(__builtin_convertvector(v, h2v), f2); }
-
-// Wave-uniform coefficients live two to an SGPR pair; VOP3P op_sel broadcasts either half to both lanes, so a
-// coefficient costs one SGPR instead of a splatted pair (the kernel is SGPR-bound otherwise: spills cost v_readlane).
-//   r = w.{x|y} * b + c   [saturated to 0..1 when CLAMP]
-template <int HALF, bool CLAMP>
-__device__ __forceinline__ f2 pk_fma_w(f2 w, f2 b, f2 c)
-{
-    f2 r;
-    if (HALF == 0) {
-        if (CLAMP) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] clamp" : "=v"(r) : "s"(w), "v"(b), "v"(c));
-        else       asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "s"(w), "v"(b), "v"(c));
-    } else {
-        if (CLAMP) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] clamp" : "=v"(r) : "s"(w), "v"(b), "v"(c));
-        else       asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "s"(w), "v"(b), "v"(c));
-    }
-    return r;
-}
-template <int HALF>
-__device__ __forceinline__ f2 pk_mul_w(f2 w, f2 b)
-{
-    f2 r;
-    if (HALF == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "s"(w), "v"(b));
-    else           asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "s"(w), "v"(b));
-    return r;
-}
-// tap chain: sum_t w[t] * x[t] with the weights in pairs; the last tap saturates when CLAMP
-template <int NT, bool CLAMP, typename F>
-__device__ __forceinline__ f2 taps(const f2 (&wp)[3], F x)
-{
-    f2 acc = pk_mul_w<0>(wp[0], x(0));
-    acc = pk_fma_w<1, false>(wp[0], x(1), acc);
-    acc = pk_fma_w<0, false>(wp[1], x(2), acc);
-    if (NT == 4) return pk_fma_w<1, CLAMP>(wp[1], x(3), acc);
-    acc = pk_fma_w<1, false>(wp[1], x(3), acc);
-    if (NT == 5) return pk_fma_w<0, CLAMP>(wp[2], x(4), acc);
-    acc = pk_fma_w<0, false>(wp[2], x(4), acc);
-    return pk_fma_w<1, CLAMP>(wp[2], x(5), acc);
-}
-
-// two independent outputs in lockstep: back-to-back dependent v_pk_fma_f32 cost a wait state each (s_nop)
-template <int NT, bool CLAMP, typename FA, typename FB>
-__device__ __forceinline__ void taps2(const f2 (&wp)[3], FA xa, FB xb, f2 &ra, f2 &rb)
-{
-    f2 a = pk_mul_w<0>(wp[0], xa(0)), b = pk_mul_w<0>(wp[0], xb(0));
-    a = pk_fma_w<1, false>(wp[0], xa(1), a); b = pk_fma_w<1, false>(wp[0], xb(1), b);
-    a = pk_fma_w<0, false>(wp[1], xa(2), a); b = pk_fma_w<0, false>(wp[1], xb(2), b);
-    if (NT == 4) { ra = pk_fma_w<1, CLAMP>(wp[1], xa(3), a); rb = pk_fma_w<1, CLAMP>(wp[1], xb(3), b); return; }
-    a = pk_fma_w<1, false>(wp[1], xa(3), a); b = pk_fma_w<1, false>(wp[1], xb(3), b);
-    if (NT == 5) { ra = pk_fma_w<0, CLAMP>(wp[2], xa(4), a); rb = pk_fma_w<0, CLAMP>(wp[2], xb(4), b); return; }
-    a = pk_fma_w<0, false>(wp[2], xa(4), a); b = pk_fma_w<0, false>(wp[2], xb(4), b);
-    ra = pk_fma_w<1, CLAMP>(wp[2], xa(5), a); rb = pk_fma_w<1, CLAMP>(wp[2], xb(5), b);
-}
-
-// coefficient i of a table packed two to an SGPR pair (i is a constant after unrolling)
-template <bool CLAMP>
-__device__ __forceinline__ f2 fma_k(const f2 *K, int i, f2 b, f2 c)
-{
-    return (i & 1) ? pk_fma_w<1, CLAMP>(K[i >> 1], b, c) : pk_fma_w<0, CLAMP>(K[i >> 1], b, c);
-}
-__device__ __forceinline__ f2 mul_k(const f2 *K, int i, f2 b) { return (i & 1) ? pk_mul_w<1>(K[i >> 1], b) : pk_mul_w<0>(K[i >> 1], b); }
-
-// raw codes of one 2x2 block (cols Xg, Xg+1; two source rows), prefetched one iteration ahead
-struct Raw {
-    uint32_t y[2];           // luma of the two rows: 2 px each (16-bit: one dword; 8-bit: low 16 bits)
-    uint32_t c[2][3];        // [chroma row n, n+1][cols c0-1, c0, c0+1]: packed (U | V<<16) codes, shared by both luma rows
-};
-
-__device__ __forceinline__ uint32_t ld_u8(gcptr p) { return *p; }
-__device__ __forceinline__ uint32_t ld_u16(gcptr p) { return *(const __attribute__((address_space(1))) uint16_t *)p; }
-__device__ __forceinline__ uint32_t ld_u32(gcptr p) { return *(const __attribute__((address_space(1))) uint32_t *)p; }
-
-// Addressing: every access is (wave-uniform row base, SGPR pair) + (per-lane 32-bit byte offset that does not change
-// over the rows), so the loads/stores take the saddr form and the loop spends no VALU on 64-bit pointer arithmetic.
-// Row offsets are 32-bit products (the launcher refuses surfaces of 4 GiB and more).
-// `opaque` hides a loop-invariant 32-bit lane offset from LICM: the zero-extension then stays next to the access and
-// instruction selection folds (uniform base + zext(offset)) into the saddr form instead of a 64-bit VALU add per access.
-__device__ __forceinline__ uint32_t opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
-
-struct RawAddr {
-    uint32_t yoff;            // luma: byte offset of column Xg inside a row
-    uint32_t coff[3];         // chroma columns c0-1, c0, c0+1 (clamp addressing), byte offset inside a chroma row
-};
-
-template <int SRC>
-__device__ __forceinline__ void make_raw_addr(const FusedArgs &P, int Xg, RawAddr &ra)
-{
-    const int sx0 = P.rect_l + Xg, c0 = sx0 >> 1;
-    const int yb = src_wide<SRC>(P) ? 2 : 1;
-    const int cb = src_biplanar<SRC>(P) ? 2 * yb : yb;
-    ra.yoff = (uint32_t)(yb * sx0);
-#pragma unroll
-    for (int i = 0; i < 3; i++) ra.coff[i] = (uint32_t)(cb * clampi(c0 - 1 + i, 0, P.cw - 1));
-}
-
-// chroma texel as U | V << 16 (raw codes); pu/pv = row bases
-template <int SRC>
-__device__ __forceinline__ uint32_t ld_uv(const FusedArgs &P, gcptr pu, gcptr pv, uint32_t off)
-{
-    if (src_biplanar<SRC>(P)) {
-        if (src_wide<SRC>(P)) return ld_u32(pu + off);
-        const uint32_t d = ld_u16(pu + off);
-        return (d & 0xffu) | ((d >> 8) << 16);
-    }
-    if (P.bytes == 2) return ld_u16(pu + off) | (ld_u16(pv + off) << 16);
-    return ld_u8(pu + off) | (ld_u8(pv + off) << 16);
-}
-
-// vertical chroma position of source row sy (Shaders.cpp:118-138): v' = (sy+0.5)/2 [+0.25 co-sited] - 0.5, kept in
-// QUARTER chroma rows as an integer (4v' = 2sy - 1 [+1]) so that the whole siting computation stays on the scalar unit
-__device__ __forceinline__ int chroma_v4(const FusedArgs &P, int sy) { return 2 * sy - 1 + P.v_off4; }
-// fr/4 for fr = 0..4 as a float built from integer selects (wave-uniform => SGPR; no v_cvt/v_mul per iteration)
-__device__ __forceinline__ float quarter(int fr)
-{
-    // float bits of fr/4 = (one byte of a 40-bit table) << 22: 0.25 = 0xFA<<22, 0.5 = 0xFC<<22, 0.75 = 0xFD<<22, 1 = 0xFE<<22
-    const uint64_t table = 0xFEFDFCFA00ull;
-    return __builtin_bit_cast(float, (uint32_t)((table >> (8 * fr)) & 0xffu) << 22);
-}
-
-// y0,y1: the two (clamped) rect rows of the block.
-// The two luma rows of an iteration are (odd, odd+1) source rows — or the same row twice where the rect clamps —
-// (rect top and segment starts are even, host-checked), so for every siting both take their chroma from the same
-// two chroma rows n = floor(v'(row 0)) and n+1.
-template <int SRC>
-__device__ __forceinline__ void load_raw(const FusedArgs &P, gcptr py, const RawAddr &ra, int y0, int y1, Raw &r)
-{
-    const int sy0 = P.rect_t + y0, sy1 = P.rect_t + y1;
-    const gcptr ry0 = py + (uint32_t)sy0 * (uint32_t)P.pitch_y, ry1 = py + (uint32_t)sy1 * (uint32_t)P.pitch_y;
-    r.y[0] = src_wide<SRC>(P) ? ld_u32(ry0 + opaque(ra.yoff)) : ld_u16(ry0 + opaque(ra.yoff));
-    r.y[1] = src_wide<SRC>(P) ? ld_u32(ry1 + opaque(ra.yoff)) : ld_u16(ry1 + opaque(ra.yoff));
-    const int n = chroma_v4(P, sy0) >> 2;
-    const uint32_t oA = (uint32_t)clampi(n, 0, P.ch - 1) * (uint32_t)P.pitch_c, oB = (uint32_t)clampi(n + 1, 0, P.ch - 1) * (uint32_t)P.pitch_c;
-    const gcptr pu = py + P.off_u, pv = src_biplanar<SRC>(P) ? pu : py + P.off_v;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        if (i == 0 && !src_center<SRC>(P)) { r.c[0][0] = r.c[1][0] = 0; continue; }
-        r.c[0][i] = ld_uv<SRC>(P, pu + oA, pv + oA, opaque(ra.coff[i]));
-        r.c[1][i] = ld_uv<SRC>(P, pu + oB, pv + oB, opaque(ra.coff[i]));
-    }
-}
-
-// The 2x2 block: 4:2:0 bilinear chroma + matrix (+ tail) for (even, odd column) x (row 0, row 1).
-// ShaderGetPixels' CHROMA_Bilinear branch (Shaders.cpp:265-270,319-325): same sample positions and weights,
-// evaluated in code units (vertical lerp first), UNORM scale folded into the matrix.  out[column][ch] = the channel as
-// a (row 0, row 1) pair — the layout LDS slice A wants — saturated (every continuation, tail or UNORM store,
-// saturates first).
-template <int TAIL, int SRC>
-__device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], const Raw &r, int sy0, int sy1, const f2 *T, f2 out[2][3])
-{
-    // vertical weights of chroma rows n (w0) and n+1 (w1) for (row 0, row 1): wave-uniform, one SGPR pair each
-    const int n4 = chroma_v4(P, sy0) & ~3;                 // 4 * floor(v'(row 0))
-    const int fr0 = chroma_v4(P, sy0) - n4, fr1 = chroma_v4(P, sy1) - n4;     // 0..4 quarters
-    const f2 w1 = f2{quarter(fr0), quarter(fr1)}, w0 = f2{quarter(4 - fr0), quarter(4 - fr1)};
-    f2 Uc[3], Vc[3];                              // U, V at chroma columns c0-1, c0, c0+1 as (row 0, row 1) pairs
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const float tu = (float)(r.c[0][i] & 0xffffu), tv = (float)(r.c[0][i] >> 16);
-        const float bu = (float)(r.c[1][i] & 0xffffu), bv = (float)(r.c[1][i] >> 16);
-        Uc[i] = pk_fma(splat(bu), w1, splat(tu) * w0);
-        Vc[i] = pk_fma(splat(bv), w1, splat(tv) * w0);
-    }
-    f2 Ycol[2], Ucol[2], Vcol[2];                 // even and odd luma column
-    if (src_wide<SRC>(P)) {
-        Ycol[0] = f2{(float)(r.y[0] & 0xffffu), (float)(r.y[1] & 0xffffu)};
-        Ycol[1] = f2{(float)(r.y[0] >> 16), (float)(r.y[1] >> 16)};
-    } else {
-        Ycol[0] = f2{(float)(r.y[0] & 0xffu), (float)(r.y[1] & 0xffu)};
-        Ycol[1] = f2{(float)((r.y[0] >> 8) & 0xffu), (float)((r.y[1] >> 8) & 0xffu)};
-    }
-    if (src_center<SRC>(P)) {                     // u' = sx/2 - 0.25 (MPEG-1 siting runs through the generic variant)
-        Ucol[0] = pk_fma(Uc[1], splat(0.75f), Uc[0] * splat(0.25f)); Vcol[0] = pk_fma(Vc[1], splat(0.75f), Vc[0] * splat(0.25f));
-        Ucol[1] = pk_fma(Uc[2], splat(0.25f), Uc[1] * splat(0.75f)); Vcol[1] = pk_fma(Vc[2], splat(0.25f), Vc[1] * splat(0.75f));
-    } else {                                      // u' = sx/2
-        Ucol[0] = Uc[1]; Vcol[0] = Vc[1];
-        Ucol[1] = pk_fma(Uc[2], splat(0.5f), Uc[1] * splat(0.5f)); Vcol[1] = pk_fma(Vc[2], splat(0.5f), Vc[1] * splat(0.5f));
-    }
-    f2 rgbc[2][3];
-#pragma unroll
-    for (int rr = 0; rr < 2; rr++)                // rr = luma column of the block
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++)
-            rgbc[rr][ch] = fma_k<true>(MM, 3 * ch, Ycol[rr], fma_k<false>(MM, 3 * ch + 1, Ucol[rr], fma_k<false>(MM, 3 * ch + 2, Vcol[rr], CC[ch])));
-    // PQ: all twelve table reads of the block are issued together (their addresses depend only on the matrix results),
-    // so the wave pays one LDS round trip per iteration instead of six
-    f2 linc[2][3];
-    if (TAIL == TAILK_PQ_LUT) {
-        f2 ent[2][3][2]; float frc[2][3][2];
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++)
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++)
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const float t = rgbc[rr][ch][e] * (float)(LUT_N - 1);
-                    frc[rr][ch][e] = __builtin_amdgcn_fractf(t);
-                    ent[rr][ch][e] = T[(int)t];
-                }
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++)
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++)
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    float r;   // {value, slope} entry: plain v_fma_f32 — a packed pair would need three v_mov to line its operands
-                               // up, and packing only pays when it is free (tools/ubench/op_rate.hip)
-                    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(ent[rr][ch][e].y), "v"(frc[rr][ch][e]), "v"(ent[rr][ch][e].x));
-                    linc[rr][ch][e] = r;
-                }
-    }
-#pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-        const f2 *rgb = rgbc[rr];
-        if (TAIL == TAILK_PQ_LUT) {
-            // Shaders.cpp:870-923: per-channel saturate -> ST2084ToLinear*scale -> Hable/hable(4.8) from the LDS table,
-            // then the 2020->709 matrix, saturate and pow 1/2.2 in ALU
-            const f2 *lin = linc[rr];
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const f2 g = fma_k<true>(GG, 3 * ch, lin[0], fma_k<false>(GG, 3 * ch + 1, lin[1], mul_k(GG, 3 * ch + 2, lin[2])));
-                out[rr][ch] = f2{hlsl_pow(g.x, 1.0f / 2.2f), hlsl_pow(g.y, 1.0f / 2.2f)};
-            }
-        } else if (TAIL == TAILK_HLG) {
-            // Shaders.cpp:862-923 for HLG: saturate -> HLGtoLinear (hlg.hlsl:1-20) -> LinearToST2084(., 1000) -> saturate ->
-            // ST2084ToLinear(., scale) -> Hable -> 2020->709 -> saturate -> pow 1/2.2.  The PQ encode/decode round trip
-            // (quirk Q7) is the identity x -> x*scale/1000 on the whole reachable range (x/1000 <= 0.09, never
-            // saturated); it is elided here.  The literal chain — kept in the pass-per-kernel path and the oracle —
-            // differs from the identity by ~1e-5 relative, the rounding noise of its own four pow() calls.
-            f2 lin[3];
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const f2 v = rgb[ch];
-                lin[ch] = f2{v.x <= 0.5f ? v.x * v.x * 4.0f : __expf((v.x - 0.55991073f) * (1.0f / 0.17883277f)) + 0.28466892f,
-                             v.y <= 0.5f ? v.y * v.y * 4.0f : __expf((v.y - 0.55991073f) * (1.0f / 0.17883277f)) + 0.28466892f};
-            }
-            const f2 ys = splat(2000.0f) * pk_fma(splat(0.2627f), lin[0], pk_fma(splat(0.6780f), lin[1], splat(0.0593f) * lin[2]));
-            const float ks = P.lum_scale * (1.0f / 1000.0f);
-            const f2 gain = f2{hlsl_pow(ys.x, 0.2f) * ks, hlsl_pow(ys.y, 0.2f) * ks};
-            const float A_ = 0.15f, B_ = 0.50f, CB = 0.10f * 0.50f, DE = 0.20f * 0.02f, DF = 0.20f * 0.30f, EF = 0.02f / 0.30f;
-            const float inv_div = 1.0f / (((4.8f * (A_ * 4.8f + CB) + DE) / (4.8f * (A_ * 4.8f + B_) + DF)) - EF);
-            f2 tm[3];
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const f2 x = lin[ch] * gain;
-                const f2 num = pk_fma(x, pk_fma(splat(A_), x, splat(CB)), splat(DE));
-                const f2 den = pk_fma(x, pk_fma(splat(A_), x, splat(B_)), splat(DF));
-                const f2 q = f2{num.x * __builtin_amdgcn_rcpf(den.x), num.y * __builtin_amdgcn_rcpf(den.y)};
-                tm[ch] = (q - splat(EF)) * splat(inv_div);
-            }
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const f2 g = fma_k<true>(GG, 3 * ch, tm[0], fma_k<false>(GG, 3 * ch + 1, tm[1], mul_k(GG, 3 * ch + 2, tm[2])));
-                out[rr][ch] = f2{hlsl_pow(g.x, 1.0f / 2.2f), hlsl_pow(g.y, 1.0f / 2.2f)};
-            }
-        } else if (TAIL == TAILK_ALU) {
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                f3 v = {rgb[0][e], rgb[1][e], rgb[2][e]};
-                v = hdr_tail(v, P.tail, P.gamma, P.lum_scale, make_mat3(P.gamut));
-                out[rr][0][e] = saturate(v.x); out[rr][1][e] = saturate(v.y); out[rr][2][e] = saturate(v.z);
-            }
-        } else {
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) out[rr][ch] = rgb[ch];
-        }
-    }
-}
 
 template <int NT, int TAIL, int SRC, int EPI>
 __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single)
@@ -850,12 +504,6 @@ __global__ __launch_bounds__(256) void k_convert_blocks_wide(FusedArgs P, const 
     }
 }
 
-int EnvInt(const char *name, int def)
-{
-    const char *v = std::getenv(name);
-    return (v && *v) ? std::atoi(v) : def;
-}
-
 }  // namespace
 
 bool FusedUp2xSupported(const FusedParams &P)
@@ -877,7 +525,7 @@ bool FusedUp2xSupported(const FusedParams &P)
 }
 
 // the convert-side and store-side constants both kernels of this file take
-static void FillFusedArgs(const FusedParams &P, FusedArgs &a)
+void FillFusedArgs(const FusedParams &P, FusedArgs &a)
 {
     const ConvertParams &c = P.conv;
     std::memset(&a, 0, sizeof(a));
@@ -912,14 +560,14 @@ static void FillFusedArgs(const FusedParams &P, FusedArgs &a)
     a.dither = P.store.dither;
 }
 
-static int TailKind(const FusedParams &P)
+int FusedTailKind(const FusedParams &P)
 {
     const ConvertParams &c = P.conv;
     // P.pq_lut is null when MPCVR_FLAG_NO_LUT asks for the literal ALU chains (A/B testing)
     return c.tail == TAIL_NONE ? TAILK_NONE : (c.tail == TAIL_PQ_TO_SDR && P.pq_lut) ? TAILK_PQ_LUT
          : (c.tail == TAIL_HLG_TO_SDR && !P.literal_tail) ? TAILK_HLG : TAILK_ALU;
 }
-static int SourceKind(const FusedParams &P)
+int FusedSourceKind(const FusedParams &P)
 {
     // source specialisations: bi-planar 16-bit (P010/P016) and bi-planar 8-bit (NV12) with MPEG-2 / co-sited chroma;
     // everything else (planar, MPEG-1 siting) runs through the variant that reads these properties at run time
@@ -967,7 +615,7 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
     FillFusedArgs(P, a);
     const ConvertParams &c = P.conv;
     const bool fin = P.store.mode == ST_FINAL;
-    const int tailk = TailKind(P), srck = SourceKind(P);
+    const int tailk = FusedTailKind(P), srck = FusedSourceKind(P);
     // four blocks per lane (8- / 16-byte loads, 16-byte stores) where every row allows it
     static const int no_wide = EnvInt("MPCVR_NO_WIDE_CONVERT", 0);
     const int lb = srck == SRC_P01X ? 16 : 8;                   // bytes of a lane's luma / chroma load
@@ -1029,12 +677,16 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     if (seg > c.out_h) seg = c.out_h;
     a.seg_rows = seg;
 
+    // the taps on the matrix cores (vp_fused_mx.hip) unless MPCVR_FUSED_MX=0 asks for the packed-fp32 kernel
+    static const int mx_default = EnvInt("MPCVR_FUSED_MX", 0);
+    if (P.taps_mfma >= 0 ? P.taps_mfma != 0 : mx_default != 0) return LaunchFusedUp2xMx(P, a, knt, frames_dev, single, n_frames, s);
+
     const dim3 grid((strips + WAVES - 1) / WAVES, (c.out_h + seg - 1) / seg, n_frames);
     const dim3 block(256, 1, 1);
-    const int tailk = TailKind(P);
+    const int tailk = FusedTailKind(P);
     static const int lds_pad = EnvInt("MPCVR_FUSED_LDS_PAD", 0);   // experiments: lower the occupancy by claiming more LDS
     const size_t lds = LDS_A + LDS_D + LDS_DB + (tailk == TAILK_PQ_LUT ? LDS_T : 0) + (size_t)lds_pad;
-    const int srck = SourceKind(P);
+    const int srck = FusedSourceKind(P);
     // the specialised epilogues use 16-byte stores / dither reads: off_x % 4 == 0 and 16-byte aligned rows; the integer
     // final pass additionally needs k*M + (j << 14) < 2^32 and M < 2^24 (true for 10-bit internal -> 8-bit target)
     const bool aligned = P.dst_aligned16 && (a.off_x & 3) == 0 && (a.dst_pitch & 15) == 0;

@@ -55,6 +55,7 @@ struct FusedParams {
     int dst_aligned16;        // every render target of the launch starts on a 16-byte boundary
     int src_aligned16;        // every sample of the launch starts on a 16-byte boundary (wide block convert)
     int literal_tail;         // MPCVR_FLAG_NO_LUT: evaluate the HDR tails literally in ALU (no LUT, no algebraic shortcut)
+    int taps_mfma;            // fused 2x kernel: 1 = resize taps on the matrix cores, 0 = packed-fp32 VALU chains, -1 = library default
 };
 bool FusedUp2xSupported(const FusedParams &P);
 // the fused kernel's convert stage as a kernel of its own: 2x2 blocks, shared chroma fetch, table tone map.  P.store describes
