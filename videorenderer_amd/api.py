@@ -8,6 +8,7 @@ GPU raises.  PyTorch only supplies device memory and streams.
 """
 import ctypes as C
 import os
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmpcvr.so")
@@ -168,6 +169,17 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run `python -m videorenderer_amd.build` "
                            "(or __graft_entry__.build()); there is no CPU fallback")
+    # In a process that also uses torch, torch's bundled HIP runtime must be the one both share: libmpcvr.so resolves
+    # libamdhip64 through the dynamic loader, and a second copy of the runtime (loaded first from /opt/rocm) sees no device once
+    # torch has initialised its own.  Importing torch first — only if it is installed; the library itself does not need it —
+    # makes the load order irrelevant.
+    if "torch" not in sys.modules:
+        try:
+            import importlib.util
+            if importlib.util.find_spec("torch") is not None:
+                import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, i32, u32, f = C.c_void_p, C.c_int32, C.c_uint32, C.c_float
     P = C.POINTER

@@ -106,16 +106,20 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
 
     // iteration t adds virtual rows a, a+1 with a = s0 - 3 + 2t; from t = 3 on it emits output rows of k = a-3, a-2
     const int n_iter = (s1 - s0 + 1) / 2 + 3;
-    Raw raw;
+    // raw codes are prefetched TWO iterations ahead, in two buffers used alternately: vmcnt counts loads and stores in issue
+    // order, so a load only reports back once the output stores issued before it have been acknowledged — with one iteration
+    // of distance every iteration waited for the previous iteration's stores
+    Raw raw2[2];
     RawAddr ra;
     make_raw_addr<SRC>(P, Xg, ra);
-    load_raw<SRC>(P, py, ra, clampi(s0 - 3, 0, H - 1), clampi(s0 - 2, 0, H - 1), raw);
+    load_raw<SRC>(P, py, ra, clampi(s0 - 3, 0, H - 1), clampi(s0 - 2, 0, H - 1), raw2[0]);
+    load_raw<SRC>(P, py, ra, clampi(s0 - 1, 0, H - 1), clampi(s0, 0, H - 1), raw2[1]);
 
-    // stage C for virtual rows ar, ar+1 (whose raw codes were prefetched): convert, write A, prefetch the next pair
-    auto stage_c = [&](int ar) {
+    // stage C for virtual rows ar, ar+1 (whose raw codes were prefetched into buffer b): convert, write A, prefetch rows ar+4, ar+5
+    auto stage_c = [&](int ar, int b) {
         f2 rc[2][3];
-        convert_block<TAIL, SRC>(P, MM, GG, CC, raw, P.rect_t + clampi(ar, 0, H - 1), P.rect_t + clampi(ar + 1, 0, H - 1), T, rc);
-        load_raw<SRC>(P, py, ra, clampi(ar + 2, 0, H - 1), clampi(ar + 3, 0, H - 1), raw);
+        convert_block<TAIL, SRC>(P, MM, GG, CC, raw2[b], P.rect_t + clampi(ar, 0, H - 1), P.rect_t + clampi(ar + 1, 0, H - 1), T, rc);
+        load_raw<SRC>(P, py, ra, clampi(ar + 4, 0, H - 1), clampi(ar + 5, 0, H - 1), raw2[b]);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             // store to m_TexConvertOutput (UNORM: floor(sat(x)*maxv + 0.5)) and read back (q/maxv to 1 ulp)
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
     // global prefetch behind it) is covered by the Y stage instead of stalling the wave.  A is exchanged between
     // lanes of this wave only: LDS operations of one wave execute in order; the fences keep the compiler from
     // reordering the A reads and writes (which look unrelated thread by thread).
-    stage_c(s0 - 3);
+    stage_c(s0 - 3, 0);
 
     for (int tb = 0; tb < n_iter; tb += 4) {
 #pragma unroll
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
             // ---------------- stage C of the NEXT iteration ----------------
-            if (t + 1 < n_iter) stage_c(a + 2);
+            if (t + 1 < n_iter) stage_c(a + 2, (u + 1) & 1);
 
             // ---------------- stage Y + final pass ----------------
             // window slot of virtual row r is (r - (s0-3)) & 7; rows a-6 .. a+1 are live: slot(a-6+i) = (2u+2+i) & 7

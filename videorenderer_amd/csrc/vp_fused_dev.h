@@ -36,6 +36,7 @@ struct FusedArgs {
     float quant;
     const uint16_t *dither;
     int seg_rows;
+    int dbg;                       // ablation switches of the matrix-core kernel (MPCVR_MX_DBG; 0 in normal use)
 };
 
 namespace {

@@ -82,14 +82,16 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x_mx(FusedArgs P, const Fus
         // window is a ring of four row PAIRS and iteration u (mod 4) has pair p in slot (u + 1 + p) & 3, so the weights rotate
         // with u: one fragment per u, built by wave u
         const int u = wave, kk = q >> 1, par = q & 1;
+        float wsel[NT];                                  // this row's phase weights: selects between kernel arguments (SGPRs)
+#pragma unroll
+        for (int tt = 0; tt < NT; tt++) { const float a0 = P.we[tt], a1 = P.wo[tt]; wsel[tt] = par ? a1 : a0; }
         float w[8];
 #pragma unroll
         for (int t = 0; t < 8; t++) {
             const int rho = 2 * (((t >> 1) - u - 1) & 3) + (t & 1);
             float s = 0.0f;
 #pragma unroll
-            for (int tt = 0; tt < NT; tt++)
-                if (2 + kk + par + tap_off<NT>(tt) == rho) s += par ? P.wo[tt] : P.we[tt];
+            for (int tt = 0; tt < NT; tt++) s += (2 + kk + par + tap_off<NT>(tt) == rho) ? wsel[tt] : 0.0f;
             w[t] = diag ? s * SY : 0.0f;
         }
         h8 hi, lo;
@@ -110,13 +112,15 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x_mx(FusedArgs P, const Fus
     h8 axh, axl;
     {
         const int ko = q >> 1, odd = q & 1;
+        float wsel[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; tt++) { const float a0 = P.we[tt], a1 = P.wo[tt]; wsel[tt] = odd ? a1 : a0; }
         float w[8];
 #pragma unroll
         for (int t = 0; t < 8; t++) {
             float s = 0.0f;
 #pragma unroll
-            for (int tt = 0; tt < NT; tt++)
-                if (3 + ko - (odd ? 0 : 1) + tap_off<NT>(tt) == t) s += odd ? P.wo[tt] : P.we[tt];
+            for (int tt = 0; tt < NT; tt++) s += (3 + ko - (odd ? 0 : 1) + tap_off<NT>(tt) == t) ? wsel[tt] : 0.0f;
             w[t] = diag ? s * (SX * 1024.0f * P.inv_maxv) : 0.0f;
         }
         split8(w, axh, axl);
@@ -172,7 +176,8 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x_mx(FusedArgs P, const Fus
 
     auto stage_c = [&](int ar) {
         f2 rc[2][3];
-        convert_block<TAIL, SRC>(P, MM, GG, CC, raw, P.rect_t + clampi(ar, 0, H - 1), P.rect_t + clampi(ar + 1, 0, H - 1), T, rc);
+        if (!(P.dbg & 8)) convert_block<TAIL, SRC>(P, MM, GG, CC, raw, P.rect_t + clampi(ar, 0, H - 1), P.rect_t + clampi(ar + 1, 0, H - 1), T, rc);
+        else { for (int i = 0; i < 2; i++) for (int c = 0; c < 3; c++) rc[i][c] = f2{__uint_as_float(raw.y[0] & 0x3f000000u), __uint_as_float(raw.c[0][1] & 0x3f000000u)}; }
         load_raw<SRC>(P, py, ra, clampi(ar + 2, 0, H - 1), clampi(ar + 3, 0, H - 1), raw);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -183,7 +188,10 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x_mx(FusedArgs P, const Fus
                 else if (X > W - 2) qe = qo;
             }
             const h2v r0 = __builtin_convertvector(f2{qe.x, qo.x}, h2v), r1 = __builtin_convertvector(f2{qe.y, qo.y}, h2v);
-            _Float16 *p0 = AH + (c * 2 + 0) * HW + 2 * lane + 1, *p1 = AH + (c * 2 + 1) * HW + 2 * lane + 1;
+            // four 2-byte stores: the pair (index 2l+1, 2l+2) straddles a dword, and a dword store off its natural alignment is
+            // replayed by the LDS (measured: SQ_WAIT_INST_LDS 43 % of the wave cycles when the compiler merged them)
+            typedef volatile __attribute__((address_space(3))) _Float16 *lds_h;
+            lds_h p0 = (lds_h)(AH + (c * 2 + 0) * HW + 2 * lane + 1), p1 = (lds_h)(AH + (c * 2 + 1) * HW + 2 * lane + 1);
             p0[0] = r0.x; p0[1] = r0.y;
             p1[0] = r1.x; p1[1] = r1.y;
         }
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x_mx(FusedArgs P, const Fus
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
             // ---------------- stage X: 6 (row, channel) operands, two MFMAs each ----------------
-            {
+            if (!(P.dbg & 1)) {
                 h8 bx[2][3];
 #pragma unroll
                 for (int c = 0; c < 3; c++)
@@ -234,7 +242,9 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x_mx(FusedArgs P, const Fus
             if (t + 1 < n_iter) stage_c(a + 2);
 
             // ---------------- stage Y + final pass: output rows 2(a-3) .. 2(a-3)+3 ----------------
-            if (t >= 3 && store_ok) {
+            // The MFMAs run for the WHOLE wave, outside any lane-divergent branch: a lane's results use the weight fragment held by
+            // another lane (rows 4g+q of A live in lane 4g+q+16g), so no lane may skip the fragment load or the instruction.
+            if (t >= 3) {
                 const h8 ayh = WY[(u * 2 + 0) * 64 + lane], ayl = WY[(u * 2 + 1) * 64 + lane];
                 const int wy0 = P.off_y + 2 * (a - 3);
                 u32x4 djr[4];
@@ -244,79 +254,100 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x_mx(FusedArgs P, const Fus
                 }
                 uint32_t pk[4][4];                                    // [row][pixel]
 #pragma unroll
-                for (int o = 0; o < 4; o++) {
-                    f4v dy[3];
+              for (int hp = 0; hp < 4; hp++) {                        // one output column at a time: 3 accumulators live
+                f4v dy[4][3];
+                if (P.dbg & 2) { for (int c = 0; c < 3; c++) dy[hp][c] = f4v{(float)win[hp][c][0], (float)win[hp][c][1], (float)win[hp][c][2], (float)win[hp][c][3]}; } else {
+#pragma unroll
+                for (int o = hp; o < hp + 1; o++)
 #pragma unroll
                     for (int c = 0; c < 3; c++)
-                        dy[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ayh, __builtin_bit_cast(h8, u32x4{win[o][c][0], win[o][c][1], win[o][c][2], win[o][c][3]}),
-                                                                      f4v{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+                        dy[o][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ayh, __builtin_bit_cast(h8, u32x4{win[o][c][0], win[o][c][1], win[o][c][2], win[o][c][3]}),
+                                                                         f4v{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+#pragma unroll
+                for (int o = hp; o < hp + 1; o++)
 #pragma unroll
                     for (int c = 0; c < 3; c++)
-                        dy[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ayl, __builtin_bit_cast(h8, u32x4{win[o][c][0], win[o][c][1], win[o][c][2], win[o][c][3]}),
-                                                                      dy[c], 0, 0, 0);
-                    if (FASTEPI || EPI == EPI_DIRECT8) {
-                        // saturate (the shader's output lands in a UNORM texture), then x*maxv + 2^23 leaves the code in the
-                        // low mantissa bits; integer final pass as in k_fused_up2x
-                        f2 uq[3][2];
+                        dy[o][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ayl, __builtin_bit_cast(h8, u32x4{win[o][c][0], win[o][c][1], win[o][c][2], win[o][c][3]}),
+                                                                         dy[o][c], 0, 0, 0);
+                // the epilogue's first readers are inline asm, for which hipcc pads no MFMA -> VALU wait states: 8 of them here,
+                // tied to the accumulators so that the statement stays between the MFMAs and their readers
+                asm volatile("s_nop 7" : "+v"(dy[hp][0]), "+v"(dy[hp][1]), "+v"(dy[hp][2]));
+                }
+                if (store_ok && !(P.dbg & 4)) {
 #pragma unroll
-                        for (int c = 0; c < 3; c++)
+                    for (int o = hp; o < hp + 1; o++) {
+                        if (P.dbg & 32) { for (int m = 0; m < 4; m++) pk[m][o] = __float_as_uint(dy[o][m & 1][m]); }
+                        else if (FASTEPI || EPI == EPI_DIRECT8) {
+                            // saturate (the shader's output lands in a UNORM texture), then x*maxv + 2^23 leaves the code in the
+                            // low mantissa bits; integer final pass as in k_fused_up2x
+                            f2 uq[3][2];
 #pragma unroll
-                            for (int h = 0; h < 2; h++)
-                                uq[c][h] = pk_fma(pk_mul_clamp(f2{dy[c][2 * h], dy[c][2 * h + 1]}, sdn2), maxv2, big2);
+                            for (int c = 0; c < 3; c++)
 #pragma unroll
-                        for (int m = 0; m < 4; m++) {
-                            const uint32_t ur = __float_as_uint(uq[0][m >> 1][m & 1]), ug = __float_as_uint(uq[1][m >> 1][m & 1]),
-                                           ub = __float_as_uint(uq[2][m >> 1][m & 1]);
-                            if (FASTEPI) {
-                                const uint32_t dj = djr[m][o];
-                                const uint32_t ib = __umul24(ub, P.epi_mul) + dj, ig = __umul24(ug, P.epi_mul) + dj, ir = __umul24(ur, P.epi_mul) + dj;
-                                const uint32_t bg = __builtin_amdgcn_perm(ig, ib, 0x0c0c0703u);    // [B, G, 0, 0]
-                                pk[m][o] = __builtin_amdgcn_perm(ir, bg, 0x0d070100u);             // [B, G, R, 0xff]
-                            } else {
-                                const uint32_t bg = __builtin_amdgcn_perm(ug, ub, 0x0c0c0400u);
-                                pk[m][o] = __builtin_amdgcn_perm(ur, bg, 0x0d040100u);
-                            }
-                        }
-                    } else {
-                        // generic epilogue: no final pass (straight UNORM store into the RT) and/or R10G10B10A2 target
+                                for (int h = 0; h < 2; h++)
+                                    uq[c][h] = pk_fma(pk_mul_clamp(f2{dy[o][c][2 * h], dy[o][c][2 * h + 1]}, sdn2), maxv2, big2);
 #pragma unroll
-                        for (int m = 0; m < 4; m++) {
-                            const int wy = wy0 + m;
-                            float c3[3];
-#pragma unroll
-                            for (int c = 0; c < 3; c++) {
-                                const float x = saturate(dy[c][m] * (1.0f / (SX * SY)));
-                                const float qv = floorf(fmaf(x, P.final_pass ? P.maxv : P.quant, 0.5f));
-                                float v = qv;
-                                if (P.final_pass) {
-                                    const float d = __half2float(__ushort_as_half(D[(wy & 31) * 32 + ((wx0 + o) & 31)]));
-                                    v = fminf(fmaxf(floorf(fmaf(qv, P.q_over_maxv, d)), 0.0f), P.quant);
+                            for (int m = 0; m < 4; m++) {
+                                const uint32_t ur = __float_as_uint(uq[0][m >> 1][m & 1]), ug = __float_as_uint(uq[1][m >> 1][m & 1]),
+                                               ub = __float_as_uint(uq[2][m >> 1][m & 1]);
+                                if (FASTEPI) {
+                                    const uint32_t dj = djr[m][o];
+                                    const uint32_t ib = __umul24(ub, P.epi_mul) + dj, ig = __umul24(ug, P.epi_mul) + dj, ir = __umul24(ur, P.epi_mul) + dj;
+                                    const uint32_t bg = __builtin_amdgcn_perm(ig, ib, 0x0c0c0703u);    // [B, G, 0, 0]
+                                    pk[m][o] = __builtin_amdgcn_perm(ir, bg, 0x0d070100u);             // [B, G, R, 0xff]
+                                } else {
+                                    const uint32_t bg = __builtin_amdgcn_perm(ug, ub, 0x0c0c0400u);
+                                    pk[m][o] = __builtin_amdgcn_perm(ur, bg, 0x0d040100u);
                                 }
-                                c3[c] = v;
                             }
-                            pk[m][o] = P.out10 ? pack_rgb10a2(c3[0], c3[1], c3[2]) : pack_bgra8(c3[0], c3[1], c3[2]);
+                        } else {
+                            // generic epilogue: no final pass (straight UNORM store into the RT) and/or R10G10B10A2 target
+#pragma unroll
+                            for (int m = 0; m < 4; m++) {
+                                const int wy = wy0 + m;
+                                float c3[3];
+#pragma unroll
+                                for (int c = 0; c < 3; c++) {
+                                    const float x = saturate(dy[o][c][m] * (1.0f / (SX * SY)));
+                                    const float qv = floorf(fmaf(x, P.final_pass ? P.maxv : P.quant, 0.5f));
+                                    float v = qv;
+                                    if (P.final_pass) {
+                                        const float d = __half2float(__ushort_as_half(D[(wy & 31) * 32 + ((wx0 + o) & 31)]));
+                                        v = fminf(fmaxf(floorf(fmaf(qv, P.q_over_maxv, d)), 0.0f), P.quant);
+                                    }
+                                    c3[c] = v;
+                                }
+                                pk[m][o] = P.out10 ? pack_rgb10a2(c3[0], c3[1], c3[2]) : pack_bgra8(c3[0], c3[1], c3[2]);
+                            }
                         }
                     }
                 }
+              }   // hp
+                if (P.dbg & 16) { uint32_t acc = 0; for (int m = 0; m < 4; m++) for (int o = 0; o < 4; o++) acc ^= pk[m][o]; if (acc == 0x9e3779b9u && store_ok) *(__attribute__((address_space(1))) uint32_t *)(pdst) = acc; }
+                else if (store_ok && !(P.dbg & 4)) {
 #pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    const gptr rowp = pdst + (uint32_t)(wy0 + m) * (uint32_t)P.dst_pitch;
-                    if (EPI != EPI_GENERIC || st_aligned) {
-                        *(__attribute__((address_space(1))) u32x4 *)(rowp + opaque(lane_off)) = u32x4{pk[m][0], pk[m][1], pk[m][2], pk[m][3]};
-                    } else {
-                        __attribute__((address_space(1))) uint32_t *dst = (__attribute__((address_space(1))) uint32_t *)(rowp + lane_off);
-                        dst[0] = pk[m][0]; dst[1] = pk[m][1]; dst[2] = pk[m][2]; dst[3] = pk[m][3];
+                    for (int m = 0; m < 4; m++) {
+                        const gptr rowp = pdst + (uint32_t)(wy0 + m) * (uint32_t)P.dst_pitch;
+                        if (EPI != EPI_GENERIC || st_aligned) {
+                            *(__attribute__((address_space(1))) u32x4 *)(rowp + opaque(lane_off)) = u32x4{pk[m][0], pk[m][1], pk[m][2], pk[m][3]};
+                        } else {
+                            __attribute__((address_space(1))) uint32_t *dst = (__attribute__((address_space(1))) uint32_t *)(rowp + lane_off);
+                            dst[0] = pk[m][0]; dst[1] = pk[m][1]; dst[2] = pk[m][2]; dst[3] = pk[m][3];
+                        }
                     }
                 }
-            }
-        }
-    }
+            }   // t >= 3
+        }   // u
+    }   // tb
 }
 
 }  // namespace
 
-hipError_t LaunchFusedUp2xMx(const FusedParams &P, const FusedArgs &a, int knt, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s)
+hipError_t LaunchFusedUp2xMx(const FusedParams &P, const FusedArgs &a_in, int knt, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s)
 {
+    FusedArgs a = a_in;
+    static const int dbg = EnvInt("MPCVR_MX_DBG", 0);       // ablation experiments (tools/prof_headline.sh): 1 no X stage, 2 no Y MFMAs,
+    a.dbg = dbg;                                             // 4 no epilogue / stores, 8 no convert arithmetic
     const ConvertParams &c = P.conv;
     const int strips = (c.out_w + S - 1) / S;
     const int seg = a.seg_rows;
