@@ -55,6 +55,18 @@ WORKLOADS = {
 }
 
 
+def csrc_digest():
+    """sha256 over the kernel / host sources: ties profiles/hbm_traffic.json to the code it was measured on."""
+    import hashlib
+    d = os.path.join(ROOT, "videorenderer_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp", ".inc")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
 def noise_frame_gpu(torch, wl, nbytes, pitch, gen):
     """Legal-range noise directly on the GPU (incompressible; throughput only — parity uses synth.py)."""
     w, h = wl["w"], wl["h"]
@@ -76,34 +88,105 @@ def noise_frame_gpu(torch, wl, nbytes, pitch, gen):
     return buf.contiguous()
 
 
-def cpu_baseline(wl, extfmt, seconds_budget=20.0):
-    """The oracle (our literal C restatement of the reference HLSL; SURVEY.md F1: the reference has NO CPU
-    pixel path) timed on this box's host cores on a bounded sample of the same workload."""
+def _oracle_cdll(O, native=False):
+    """The oracle library; native=True: the same source rebuilt HERE with -march=native (the box that runs the bench decides the ISA)."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+    if not native:
+        return O.lib()
+    out = os.path.join(tempfile.gettempdir(), f"libmpcvr_oracle_native_{os.getpid()}.so")
+    subprocess.check_call(["gcc", "-O3", "-march=native", "-std=c11", "-ffp-contract=off", "-fno-math-errno", "-fPIC", "-fopenmp",
+                           "-shared", "-o", out, os.path.join(ROOT, "oracle", "mpcvr_oracle.c"), "-lm"])
+    L = C.CDLL(out)
+    L.orc_process.restype = C.c_int
+    L.orc_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_set_num_threads.argtypes = [C.c_int]
+    L.orc_num_threads.restype = C.c_int
+    return L
+
+
+def cpu_baseline(wl, extfmt, seconds_budget=10.0):
+    """The oracle (our literal C restatement of the reference HLSL; SURVEY.md F1: the reference has NO CPU pixel path) timed on
+    this box's host cores on bounded samples of the same workload — SURVEY.md 8d's rows: -O3 -msse2 on all cores (the headline
+    row), one thread, -march=native, and the reference's only real per-frame CPU work, the upload repack
+    (CopyPlaneAsIs / CopyPlane10to16, Helper.cpp:414-428,789-803).  A failure is printed, never swallowed."""
+    import traceback
+    rows = {}
     try:
-        from oracle import oracle as O
+        import ctypes as C
         import numpy as np
+        from oracle import oracle as O
         from videorenderer_amd import synth
-        O.lib()
         w, h, s = wl["w"], wl["h"], wl["scale"]
         dw, dh = wl.get("dst", (w * s, h * s))
         frame, pitch = synth.make_frame(wl["cformat"], w, h, "noise", seed=1)
-        p = O.default_params(cformat=wl["cformat"], width=w, height=h, exfmt=extfmt, iUpscaling=wl["iUpscaling"],
-                             iDownscaling=wl.get("iDownscaling", 2), window_w=dw, window_h=dh, video_rect=(0, 0, dw, dh))
-        dst = np.zeros((dh, dw, 4), dtype=np.uint8)
-        threads = O.lib().orc_num_threads()
-        t0 = time.perf_counter()
-        O.process(p, frame, pitch, dst=dst)                  # warm-up + first estimate
-        first = time.perf_counter() - t0
-        n = max(1, min(8, int(seconds_budget / max(first, 1e-3))))
-        t0 = time.perf_counter()
-        for _ in range(n):
-            O.process(p, frame, pitch, dst=dst)
-        dt = (time.perf_counter() - t0) / n
-        return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": int(threads), "kind": "port",
-                "sample": f"{n} full {w}x{h}->{dw}x{dh} frames of the same workload, oracle C (-O3 -msse2 -fopenmp), "
-                          f"{threads} threads, {dt*1e3:.0f} ms/frame"}
-    except Exception as e:      # the baseline is a reported side figure: never fail the bench for it
-        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        frame = np.ascontiguousarray(frame).view(np.uint8).ravel()
+        dither = O.dither_table()
+
+        def time_frames(L, p, dst, budget):
+            run = lambda: L.orc_process(C.byref(p), frame.ctypes.data, pitch, dither.ctypes.data, dst.ctypes.data, p.window_w * 4)
+            t0 = time.perf_counter()
+            assert run() == 0
+            first = time.perf_counter() - t0
+            n = max(1, min(8, int(budget / max(first, 1e-3))))
+            t0 = time.perf_counter()
+            for _ in range(n):
+                run()
+            return (time.perf_counter() - t0) / n, n
+
+        def params(rect=None):
+            pw, ph = (dw, dh) if rect is None else ((rect[2] - rect[0]) * dw // w, (rect[3] - rect[1]) * dh // h)
+            p = O.default_params(cformat=wl["cformat"], width=w, height=h, exfmt=extfmt, iUpscaling=wl["iUpscaling"],
+                                 iDownscaling=wl.get("iDownscaling", 2), window_w=pw, window_h=ph, video_rect=(0, 0, pw, ph))
+            if rect is not None:
+                O.set_params(p, src_rect=rect)
+            return p, np.zeros((ph, pw, 4), dtype=np.uint8)
+
+        L = _oracle_cdll(O)
+        threads = L.orc_num_threads()
+        p, dst = params()
+        dt, n = time_frames(L, p, dst, seconds_budget)
+        rows["sse2_all_threads"] = {"frames_per_s": round(1.0 / dt, 4), "threads": int(threads), "flags": "-O3 -msse2 -fopenmp",
+                                    "sample": f"{n} full {w}x{h}->{dw}x{dh} frames, {dt*1e3:.0f} ms/frame"}
+        # one thread: a 1/16-height band of the same frame (full width), scaled to whole frames
+        band = max(16, (h // 16) & ~1)
+        L.orc_set_num_threads(1)
+        p1, d1 = params((0, 0, w, band))
+        dt1, n1 = time_frames(L, p1, d1, seconds_budget / 2)
+        L.orc_set_num_threads(0)
+        rows["sse2_one_thread"] = {"frames_per_s": round(band / h / dt1, 5), "threads": 1, "flags": "-O3 -msse2",
+                                   "sample": f"{n1} bands of {w}x{band} source rows ({band}/{h} of a frame), {dt1*1e3:.0f} ms/band"}
+        try:
+            Ln = _oracle_cdll(O, native=True)
+            dtn, nn = time_frames(Ln, p, dst, seconds_budget / 2)
+            rows["native_all_threads"] = {"frames_per_s": round(1.0 / dtn, 4), "threads": int(Ln.orc_num_threads()),
+                                          "flags": "-O3 -march=native -fopenmp", "sample": f"{nn} full frames, {dtn*1e3:.0f} ms/frame"}
+        except Exception:
+            traceback.print_exc(file=sys.stderr)
+            rows["native_all_threads"] = {"frames_per_s": None, "sample": "failed, see stderr"}
+        # the upload repack of one sample: plane-wise CopyPlaneAsIs (P010 / NV12: the bytes as they are) and CopyPlane10to16
+        # (planar 10-bit: << 6) into a "mapped texture" with a 256-byte aligned pitch, one thread as in the reference
+        tp = (pitch + 255) & ~255
+        lines = frame.size // pitch
+        tex = np.zeros(tp * lines, np.uint8)
+        L.orc_copy_plane_as_is.argtypes = [C.c_uint, C.c_void_p, C.c_uint, C.c_void_p, C.c_int]
+        L.orc_copy_plane_10to16.argtypes = [C.c_uint, C.c_void_p, C.c_uint, C.c_void_p, C.c_int]
+        rep = {}
+        for nm, fn in (("CopyPlaneAsIs", L.orc_copy_plane_as_is), ("CopyPlane10to16", L.orc_copy_plane_10to16)):
+            fn(lines, tex.ctypes.data, tp, frame.ctypes.data, pitch)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                fn(lines, tex.ctypes.data, tp, frame.ctypes.data, pitch)
+            d = (time.perf_counter() - t0) / 20
+            rep[nm] = {"frames_per_s": round(1.0 / d, 1), "GBps": round(frame.size / d / 1e9, 2)}
+        rows["upload_repack_one_thread"] = dict(rep, sample=f"20 x one {frame.size}-byte sample ({w}x{h}, pitch {pitch} -> {tp}), Helper.cpp:414-428 / 789-803 restated in C")
+        main = rows["sse2_all_threads"]
+        return {"value": main["frames_per_s"], "unit": "frames/s", "cores": main["threads"], "kind": "port",
+                "sample": main["sample"] + ", oracle C (" + main["flags"] + ")", "rows": rows}
+    except Exception as e:      # reported side figure: the bench line still goes out, but the failure is loud
+        traceback.print_exc(file=sys.stderr)
+        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"FAILED: {type(e).__name__}: {e} (traceback on stderr)", "rows": rows}
 
 
 def main():
@@ -243,15 +326,22 @@ def main():
         frames = world * args.batch * args.steps
         fps = frames / elapsed
         achieved = algo_bytes * args.batch / (launch_ms * 1e-3) / 1e9          # GB/s, algorithmic bytes per launch
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")                  # filled from the rocprofv3 --pmc passes
+        # HBM traffic from the PMC counters is NOT measured by this run: it comes from the committed rocprofv3 --pmc passes
+        # (profiles/hbm_traffic.json), and only when the kernels have not changed since (sha256 over videorenderer_amd/csrc)
+        traffic, traffic_source = None, None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tf):
             try:
-                t = json.load(open(tf)).get(args.workload)
+                doc = json.load(open(tf))
+                t = doc.get(args.workload)
                 if t and t.get("batch") == args.batch:
-                    traffic = t["bytes_per_launch"]
-            except Exception:
-                traffic = None
+                    if t.get("csrc_sha256") == csrc_digest():
+                        traffic = t["bytes_per_launch"]
+                        traffic_source = f"profiles/hbm_traffic.json [{t.get('profile', '?')}]: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes"
+                    else:
+                        traffic_source = f"omitted: kernels changed since profile {t.get('profile', '?')} (csrc hash differs)"
+            except Exception as e:
+                traffic_source = f"unreadable profiles/hbm_traffic.json: {e}"
         res = {
             # BASELINE.json's metric names the default workload; other --workload values are side measurements
             "metric": ("4K frames/sec/GPU (P010->Lanczos3 2x->PQ-SDR->dither); % HBM roofline" if args.workload == "c3hdr"
@@ -263,7 +353,7 @@ def main():
                        "input_ring_frames": ring, "path": path, "sharding": "frames by index, no data-path collective",
                        "fps_per_gpu": round(fps / world, 2), "algorithmic_bytes_per_frame": algo_bytes},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms_per_launch": round(launch_ms, 4), "bytes_per_launch": algo_bytes * args.batch,
                          "empirical_copy_peak_GBps": round(copy_gbps, 1) if copy_gbps else None,
                          "frac_of_empirical_copy_peak": round(achieved / copy_gbps, 4) if copy_gbps else None},

@@ -1743,6 +1743,28 @@ int orc_correction_pass(int kind, const uint8_t *src, int src_pitch, int src_fmt
     return 0;
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* upload repack: the reference's only per-frame CPU work (MemCopyToTexSrcVideo :1213-1252)    */
+/* ------------------------------------------------------------------------------------------ */
+/* CopyPlaneAsIs — Helper.cpp:414-428 */
+void orc_copy_plane_as_is(unsigned lines, uint8_t *dst, unsigned dst_pitch, const uint8_t *src, int src_pitch)
+{
+    if ((int)dst_pitch == src_pitch) { memcpy(dst, src, (size_t)dst_pitch * lines); return; }
+    const unsigned a = (unsigned)(src_pitch < 0 ? -src_pitch : src_pitch), linesize = a < dst_pitch ? a : dst_pitch;
+    for (unsigned y = 0; y < lines; ++y) { memcpy(dst, src, linesize); src += src_pitch; dst += dst_pitch; }
+}
+/* CopyPlane10to16 — Helper.cpp:789-803 */
+void orc_copy_plane_10to16(unsigned lines, uint8_t *dst, unsigned dst_pitch, const uint8_t *src, int src_pitch)
+{
+    const unsigned line_pixels = (unsigned)src_pitch / 2;
+    for (unsigned y = 0; y < lines; ++y) {
+        const uint16_t *s16 = (const uint16_t *)src; uint16_t *d16 = (uint16_t *)dst;
+        for (unsigned i = 0; i < line_pixels; i++) d16[i] = (uint16_t)(s16[i] << 6);
+        src += src_pitch; dst += dst_pitch;
+    }
+}
+
 void orc_params_default(orc_params *p)
 {   /* Settings_t::SetDefault — IVideoRenderer.h:140-185 */
     memset(p, 0, sizeof(*p));

@@ -202,6 +202,10 @@ int orc_check_unorm_div(int maxv);   /* mismatches of the product's reciprocal +
  * format table: 0 as-is, 1 RGB24, 2 r210, 3 RGB48, 4 BGR48, 5 BGRA64, 6 b64a; src_pitch < 0 = bottom-up */
 void orc_repack_rgb(int kind, int lines, uint8_t *dst, int dst_pitch, const uint8_t *src, int src_pitch);
 
+/* the upload repackers the reference runs on the CPU for every frame: CopyPlaneAsIs (Helper.cpp:414-428), CopyPlane10to16 (:789-803) */
+void orc_copy_plane_as_is(unsigned lines, uint8_t *dst, unsigned dst_pitch, const uint8_t *src, int src_pitch);
+void orc_copy_plane_10to16(unsigned lines, uint8_t *dst, unsigned dst_pitch, const uint8_t *src, int src_pitch);
+
 /* Whole Process() on the shader path — DX11VideoProcessor.cpp:3285-3424.
  * src: the media-sample bytes (planes back to back, MemCopyToTexSrcVideo layout :1213-1252), src_pitch >0.
  * dither_f16: the 32x32 fp16 threshold table (Source/res/dither32x32float16.bin).

@@ -334,12 +334,12 @@ def test_correction_matrices(mpcvr, oracle):
 
 
 # ---------------------------------------------------------------- the C-ABI from plain C
-def build_c_demo(tmpdir):
+def build_c_demo(tmpdir, name="c_abi_demo"):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(str(tmpdir), "c_abi_demo")
+    exe = os.path.join(str(tmpdir), name)
     subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-std=c99", "-I" + os.path.join(root, "include"),
-                           os.path.join(root, "examples", "c_abi_demo.c"), "-o", exe,
+                           os.path.join(root, "examples", name + ".c"), "-o", exe,
                            "-L" + os.path.join(root, "videorenderer_amd"), "-lmpcvr",
                            "-Wl,-rpath," + os.path.join(root, "videorenderer_amd")])
     return exe
@@ -350,4 +350,5 @@ def test_c_abi_links_from_plain_c(mpcvr, tmp_path):
     with gcc -std=c99 -Werror against them (it runs in the GPU suite)."""
     exe = build_c_demo(tmp_path)
     assert os.path.exists(exe)
+    assert os.path.exists(build_c_demo(tmp_path, "c_multi_gpu"))      # one context per device, parameter blob shared, frames by index
 

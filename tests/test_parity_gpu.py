@@ -936,6 +936,18 @@ def _rank_worker(rank, world, port, q):
     vp.close()
 
 
+def test_c_multi_gpu_example_degrades_to_one_device(mpcvr, torch_cuda, tmp_path):
+    """examples/c_multi_gpu.c: a context per device 0..N-1 in one plain-C process, rank 0's parameter blob given to the others,
+    frames dealt by index.  Here N is whatever the box has (1): every frame must come out identical."""
+    import subprocess
+    from tests.test_host_logic import build_c_demo
+    out = subprocess.run([build_c_demo(tmp_path, "c_multi_gpu"), "8", "6"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    last = out.stdout.strip().splitlines()[-1]
+    assert "identical=yes" in last and "frames=6" in last, out.stdout
+    assert int(last.split("devices=")[1].split()[0]) == torch_cuda.cuda.device_count()
+
+
 def test_two_ranks_share_rank0_parameters(mpcvr, torch_cuda):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")

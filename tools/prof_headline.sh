@@ -26,7 +26,7 @@ for f in glob.glob(out + "/kt/**/*kernel_stats.csv", recursive=True):
 acc = collections.defaultdict(list); meta = {}
 for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_fused_up2x" in r["Kernel_Name"]:
+        if os.environ.get("KFILTER", "k_fused_up2x") in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta = {k: r.get(k) for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size")}
 avg = {k: sum(v) / len(v) for k, v in acc.items()}

@@ -39,7 +39,7 @@ __global__ void k_owncol(const float *data, const float *wrow, float *out, int s
 
 // KIND: 0 = every wave issues NM mfma + NV pk_fma per iteration; 1 = wave 0 of each SIMD's group issues the MFMAs of all, the
 // others the VALU of all (same totals per workgroup); NM or NV may be 0
-template <int NM, int NV, int MUL>
+template <int NM, int NV, int MUL, int PLAIN>
 __global__ __launch_bounds__(256) void k_mix(float *out, int iters, float s, int split_roles)
 {
     const int l = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -62,7 +62,10 @@ __global__ __launch_bounds__(256) void k_mix(float *out, int iters, float s, int
         }
         if (do_v) {
 #pragma unroll
-            for (int j = 0; j < NV * MUL; j++) { p[j & 15] = __builtin_elementwise_fma(p[j & 15], s2, s2); }
+            for (int j = 0; j < NV * MUL; j++) {
+                if (PLAIN) { asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(p[j & 15].x) : "v"(p[(j + 1) & 15].y), "v"(p[(j + 2) & 15].y)); asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(p[j & 15].y) : "v"(p[(j + 1) & 15].x), "v"(p[(j + 2) & 15].x)); }
+                else p[j & 15] = __builtin_elementwise_fma(p[j & 15], s2, s2);
+            }
         }
     }
     float r = 0;
@@ -71,17 +74,17 @@ __global__ __launch_bounds__(256) void k_mix(float *out, int iters, float s, int
     out[blockIdx.x * blockDim.x + threadIdx.x] = r + wave;
 }
 
-template <int NM, int NV>
+template <int NM, int NV, int PLAIN = 0>
 static double run_mix(const char *name, float *d_out, int blocks, int split)
 {
     const int iters = 4000;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    if (split) hipLaunchKernelGGL((k_mix<NM, NV, 2>), dim3(blocks), dim3(256), 0, 0, d_out, 10, 0.999f, split);
-    else hipLaunchKernelGGL((k_mix<NM, NV, 1>), dim3(blocks), dim3(256), 0, 0, d_out, 10, 0.999f, split);
+    if (split) hipLaunchKernelGGL((k_mix<NM, NV, 2, PLAIN>), dim3(blocks), dim3(256), 0, 0, d_out, 10, 0.999f, split);
+    else hipLaunchKernelGGL((k_mix<NM, NV, 1, PLAIN>), dim3(blocks), dim3(256), 0, 0, d_out, 10, 0.999f, split);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    if (split) hipLaunchKernelGGL((k_mix<NM, NV, 2>), dim3(blocks), dim3(256), 0, 0, d_out, iters, 0.999f, split);
-    else hipLaunchKernelGGL((k_mix<NM, NV, 1>), dim3(blocks), dim3(256), 0, 0, d_out, iters, 0.999f, split);
+    if (split) hipLaunchKernelGGL((k_mix<NM, NV, 2, PLAIN>), dim3(blocks), dim3(256), 0, 0, d_out, iters, 0.999f, split);
+    else hipLaunchKernelGGL((k_mix<NM, NV, 1, PLAIN>), dim3(blocks), dim3(256), 0, 0, d_out, iters, 0.999f, split);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double wps = blocks / 256.0;                         // waves per SIMD
@@ -164,6 +167,19 @@ int main()
         const double v = run_mix<0, 90>("90 pk_fma alone", d_out, blocks, 0);
         const double b = run_mix<36, 90>("36 mfma + 90 pk_fma, same wave", d_out, blocks, 0);
         printf("     -> same wave: %.2f vs sum %.2f vs max %.2f\n", b, m + v, fmax(m, v));
+    }
+    printf("   plain v_fmac_f32 (VOP2, VGPR operands; 2 per packed FMA) instead of v_pk_fma_f32\n");
+    for (int blocks : {512, 768}) {
+        const double m = run_mix<36, 0, 1>("36 mfma alone", d_out, blocks, 0);
+        const double v = run_mix<0, 90, 1>("180 v_fmac alone", d_out, blocks, 0);
+        const double b = run_mix<36, 90, 1>("36 mfma + 180 v_fmac, same wave", d_out, blocks, 0);
+        printf("     -> same wave: %.2f vs sum %.2f vs max %.2f\n", b, m + v, fmax(m, v));
+    }
+    {
+        const double m = run_mix<36, 0, 1>("72 mfma per MFMA wave, alone (split, role bit 2)", d_out, 512, 2);
+        const double v = run_mix<0, 90, 1>("360 v_fmac per VALU wave, alone (split)", d_out, 512, 2);
+        const double b = run_mix<36, 90, 1>("MFMA waves beside plain-VALU waves", d_out, 512, 2);
+        printf("     -> separate waves, plain VALU: %.2f vs sum %.2f vs max %.2f\n", b, m + v, fmax(m, v));
     }
     for (int roles = 1; roles <= 3; roles++) {   // different waves: 512 blocks = 2 workgroups per CU, half MFMA-only (2x the MFMAs), half VALU-only (2x)
         printf("   role bit %d\n", roles);

@@ -167,12 +167,11 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
                     f2 av[10];
 #pragma unroll
                     for (int i = 0; i < 5; i++) { const f4 p4 = abuf[c & 1][i]; av[2 * i] = f2{p4.x, p4.y}; av[2 * i + 1] = f2{p4.z, p4.w}; }
-                    f2 o[4];                                  // 4 output columns x (row a, row a+1)
-#pragma unroll
-                    for (int odd = 0; odd < 2; odd++)         // even output 2k: base = k-1; odd output 2k+1: base = k
-                        taps2<NT, false>(WT[odd],             // source k = 2l + kk (kk = 0, 1) -> av index of k is kk + 4
-                                         [&](int tt) { return av[4 + (odd ? 0 : -1) + tap_off<NT>(tt)]; },
-                                         [&](int tt) { return av[5 + (odd ? 0 : -1) + tap_off<NT>(tt)]; }, o[odd], o[2 + odd]);
+                    f2 o[4];                                  // 4 output columns x (row a, row a+1), four chains in lockstep
+                    // output column i = 2*kk + odd: even output 2k: base = k-1; odd output 2k+1: base = k;
+                    // source k = 2l + kk (kk = 0, 1) -> av index of k is kk + 4
+                    tapsN<NT, false, 4>([&](int i) -> const f2 (&)[3] { return WT[i & 1]; },
+                                        [&](int i, int tt) { return av[4 + (i >> 1) + ((i & 1) ? 0 : -1) + tap_off<NT>(tt)]; }, o);
                     // m_TexResize is R16G16B16A16_FLOAT (:3155): round to fp16 (RNE), keep the rounded value as fp32
                     const int sa = (2 * u) & 7, sb = (2 * u + 1) & 7;
                     const f2 h0 = half_round2(o[0]), h1 = half_round2(o[1]), h2 = half_round2(o[2]), h3 = half_round2(o[3]);
@@ -208,13 +207,12 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
                             const u32x4 dd = *(const u32x4 *)(Di + (wy & 31) * 32 + (wx0 & 31));
                             dj[0] = dd.x; dj[1] = dd.y; dj[2] = dd.z; dj[3] = dd.w;
                         }
-                        f2 res[3][2];                             // [channel][pixel pair], saturated
+                        f2 res6[6];                               // [channel * 2 + pixel pair], saturated: six chains in lockstep
+                        tapsN<NT, true, 6>([&](int) -> const f2 (&)[3] { return WT[par]; },
+                                           [&](int i, int tt) { return win[(2 * u + 2 + kk + 2 + par + tap_off<NT>(tt)) & 7][i >> 1][i & 1]; }, res6);
+                        f2 res[3][2];
 #pragma unroll
-                        for (int c = 0; c < 3; c++) {
-                            taps2<NT, true>(WT[par],
-                                            [&](int tt) { return win[(2 * u + 2 + kk + 2 + par + tap_off<NT>(tt)) & 7][c][0]; },
-                                            [&](int tt) { return win[(2 * u + 2 + kk + 2 + par + tap_off<NT>(tt)) & 7][c][1]; }, res[c][0], res[c][1]);
-                        }
+                        for (int c = 0; c < 3; c++) { res[c][0] = res6[2 * c]; res[c][1] = res6[2 * c + 1]; }
                         uint32_t pk[4];
                         if (FASTEPI) {
                             // m_TexsPostScale store/load: k = floor(x*maxv + 0.5), p = k/maxv; ps_final_pass.hlsl:29:

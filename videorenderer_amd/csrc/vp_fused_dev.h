@@ -142,6 +142,23 @@ __device__ __forceinline__ void taps2(const f2 (&wp)[3], FA xa, FB xb, f2 &ra, f
     ra = pk_fma_w<1, CLAMP>(wp[2], xa(5), a); rb = pk_fma_w<1, CLAMP>(wp[2], xb(5), b);
 }
 
+
+// N independent tap chains in lockstep (tap by tap across the chains): a dependent v_pk_fma_f32 right behind its producer costs
+// wait states, N >= 4 chains in between cost none.  w(i) = the weight pairs of chain i (SGPR pairs), x(i, t) = tap t's operand.
+template <int TT, int NT, bool CLAMP, int N, typename WF, typename XF>
+__device__ __forceinline__ void taps_step(WF w, XF x, f2 (&acc)[N])
+{
+    constexpr bool last = TT == NT - 1;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        if (TT == 0) acc[i] = pk_mul_w<0>(w(i)[0], x(i, 0));
+        else acc[i] = pk_fma_w<TT & 1, CLAMP && last>(w(i)[TT >> 1], x(i, TT), acc[i]);
+    }
+    if constexpr (!last) taps_step<TT + 1, NT, CLAMP, N>(w, x, acc);
+}
+template <int NT, bool CLAMP, int N, typename WF, typename XF>
+__device__ __forceinline__ void tapsN(WF w, XF x, f2 (&acc)[N]) { taps_step<0, NT, CLAMP, N>(w, x, acc); }
+
 // coefficient i of a table packed two to an SGPR pair (i is a constant after unrolling)
 template <bool CLAMP>
 __device__ __forceinline__ f2 fma_k(const f2 *K, int i, f2 b, f2 c)
