@@ -78,6 +78,8 @@ enum { MPCVR_OUT_BGRA8 = 0, MPCVR_OUT_RGB10A2 = 1 };
 #define MPCVR_FLAG_FUSED_VALU       0x10u /* fused 2x kernel with its resize taps as packed-fp32 VALU chains (k_fused_up2x) */
 #define MPCVR_FLAG_FUSED_MFMA       0x20u /* fused 2x kernel with its resize taps on the matrix cores (k_fused_up2x_mx); neither flag:
                                              the library's default (environment MPCVR_FUSED_MX=0/1 overrides it) */
+#define MPCVR_FLAG_NO_STRIP         0x40u /* arbitrary-ratio resizes of 4:2:0 sources stay on the block convert + tiled two-draw
+                                             kernels instead of the one-kernel strip path (k_fused_strip; debug / A-B) */
 
 /* Subset of Settings_t (IVideoRenderer.h:104-135) that reaches the shader path; same field names. */
 typedef struct mpcvr_settings {

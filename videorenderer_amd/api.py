@@ -40,7 +40,7 @@ CHROMA_Nearest, CHROMA_Bilinear, CHROMA_CatmullRom = 0, 1, 2
 UPSCALE_Nearest, UPSCALE_Mitchell, UPSCALE_CatmullRom, UPSCALE_Lanczos2, UPSCALE_Lanczos3, UPSCALE_Jinc2 = range(6)
 DOWNSCALE_Box, DOWNSCALE_Bilinear, DOWNSCALE_Hamming, DOWNSCALE_Bicubic, DOWNSCALE_BicubicSharp, DOWNSCALE_Lanczos = range(6)
 OUT_BGRA8, OUT_RGB10A2 = 0, 1
-FLAG_LANCZOS3_FIXED, FLAG_NO_FUSED, FLAG_NO_LUT, FLAG_NO_FAST_CONVERT, FLAG_FUSED_VALU, FLAG_FUSED_MFMA = 1, 2, 4, 8, 16, 32
+FLAG_LANCZOS3_FIXED, FLAG_NO_FUSED, FLAG_NO_LUT, FLAG_NO_FAST_CONVERT, FLAG_FUSED_VALU, FLAG_FUSED_MFMA, FLAG_NO_STRIP = 1, 2, 4, 8, 16, 32, 64
 MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2
 PROCAMP_BRIGHTNESS, PROCAMP_CONTRAST, PROCAMP_HUE, PROCAMP_SATURATION = 1, 2, 4, 8
 

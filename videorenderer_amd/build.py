@@ -26,6 +26,7 @@ SOURCES = [
     ("vp_kernels.hip", ["-ffp-contract=off", "-DMPCVR_EXACT_FP"]),
     ("vp_fused.hip", []),
     ("vp_fused_mx.hip", []),
+    ("vp_fused_strip.hip", []),
 ]
 
 

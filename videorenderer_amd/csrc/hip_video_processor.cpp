@@ -582,6 +582,21 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         }
     }
 
+    // the arbitrary-ratio fused kernel takes an unrotated two-pass resize of a 4:2:0 source whose tables fit it
+    m_strip = false;
+    if (m_plan.two_pass && !m_firstJinc && !m_secondJinc && m_firstAxis == 0 && !m_firstSwap && m_plan.rotation == 0 &&
+        !m_plan.flip && m_plan.convert && !m_doviValid && m_plan.internal_fmt != SF_RGBA16F &&
+        !(m_cfg.flags & (MPCVR_FLAG_NO_FUSED | MPCVR_FLAG_NO_FAST_CONVERT | MPCVR_FLAG_NO_STRIP)) &&
+        PlanFusedStrip(hx, hy, w2, h2, w1, h1, &m_stripPlan)) {
+        const size_t ny = m_stripPlan.yrange.size(), nx = m_stripPlan.xstrip.size();
+        std::vector<int32_t> pack(ny + nx);
+        std::copy(m_stripPlan.yrange.begin(), m_stripPlan.yrange.end(), pack.begin());
+        std::copy(m_stripPlan.xstrip.begin(), m_stripPlan.xstrip.end(), pack.begin() + ny);
+        if ((hr = CheckHip(m_stripTab.CheckCreate(pack.size() * sizeof(int32_t)), "strip tables"))) return hr;
+        if ((hr = CheckHip(hipMemcpy(m_stripTab.ptr, pack.data(), pack.size() * sizeof(int32_t), hipMemcpyHostToDevice), "strip tables upload"))) return hr;
+        m_strip = true;
+    }
+
     // PQ -> SDR table: the fused kernel's tone-map stage and the folded convert kernel's
     if (m_tail == TAIL_PQ_TO_SDR) {
         if (!m_blobOverride) BuildPqSdrLut(m_lumScale, m_pqLutHost);
@@ -605,6 +620,10 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         FusedParams fp{};
         FillFusedParams(nullptr, nullptr, 0, &fp);
         m_plan.fused_up2x = FusedUp2xSupported(fp);
+    }
+    if (m_strip) {      // the launch-time conditions that do not depend on the frame pointers
+        FusedStripParams sp{};
+        m_strip = FillStripParams(nullptr, nullptr, m_windowRect.Width() * 4, MakeStore(nullptr, m_windowRect.Width() * 4, m_plan.swap_fmt, true), &sp);
     }
     m_planDirty = false;
     UseLane(0);
@@ -892,6 +911,19 @@ HRESULT CHipVideoProcessor::ResizeShaderPass(void *rt, int rtPitch, const uint8_
     return CheckHip(LaunchHdr10ToneMap(drawn ? post : conv, m_hdrTm, w2, h2, final, m_run), "k_hdr10_tonemap");
 }
 
+// parameters of the arbitrary-ratio fused kernel for one launch; false: this launch cannot take it (alignment, sizes)
+bool CHipVideoProcessor::FillStripParams(const uint8_t *sample, void *dst, int dstPitch, const StoreParams &store, FusedStripParams *sp) const
+{
+    FillFusedParams(sample, dst, dstPitch, &sp->fp);
+    sp->fp.store = store;
+    sp->tx = m_tapsX; sp->ty = m_tapsY;
+    sp->yrange = m_stripTab.ptr;
+    sp->xstrip = (const int32_t *)m_stripTab.ptr + m_stripPlan.yrange.size();
+    sp->out_w = m_videoRect.Width(); sp->out_h = m_videoRect.Height();
+    sp->pxl = m_stripPlan.pxl; sp->strip_w = m_stripPlan.strip_w; sp->ring = m_stripPlan.ring; sp->acols = m_stripPlan.acols;
+    return FusedStripSupported(*sp) && FusedStripLdsBytes(*sp) <= 160 * 1024;
+}
+
 HRESULT CHipVideoProcessor::ProcessOne(const uint8_t *sample, void *rt, int rtPitch)
 {
     HRESULT hr;
@@ -900,6 +932,19 @@ HRESULT CHipVideoProcessor::ProcessOne(const uint8_t *sample, void *rt, int rtPi
         FillFusedParams(sample, rt, rtPitch, &fp);
         const FusedFrame fr{sample, rt};        // a single frame travels by value in the kernel arguments
         return CheckHip(LaunchFusedUp2x(fp, nullptr, fr, 1, m_run), "k_fused_up2x");
+    }
+    if (m_strip) {
+        // with the HDR10 tone-mapping step the resize draws into the post-scale texture and the step writes the target (:3359-3367)
+        const int w2 = m_videoRect.Width(), h2 = m_videoRect.Height();
+        Surface post{m_runPost, (int)(w2 * SurfBytesPerPixel(m_plan.internal_fmt)), w2, h2, m_plan.internal_fmt};
+        const StoreParams final = MakeStore(rt, rtPitch, m_plan.swap_fmt, true);
+        const StoreParams last = m_plan.hdr_tonemap ? MakeStore(post.ptr, post.pitch, m_plan.internal_fmt, false) : final;
+        FusedStripParams sp{};
+        if (FillStripParams(sample, last.dst, last.dst_pitch, last, &sp)) {
+            if ((hr = CheckHip(LaunchFusedStrip(sp, nullptr, FusedFrame{sample, last.dst}, 1, m_run), "k_fused_strip"))) return hr;
+            if (!m_plan.hdr_tonemap) return MPCVR_S_OK;
+            return CheckHip(LaunchHdr10ToneMap(post, m_hdrTm, w2, h2, final, m_run), "k_hdr10_tonemap");
+        }
     }
     if (m_plan.direct_convert) {
         FusedParams fp{};
@@ -954,8 +999,12 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
         if (((uintptr_t)dsts[i] & 15) != 0) aligned = false;
     }
     // pass-per-kernel path, whole batch per launch: possible when every stage has a kernel with a frame dimension
+    // the arbitrary-ratio fused kernel takes the whole batch in one launch, like the 2x kernel
+    FusedStripParams strip_sp{};
+    const bool strip = m_strip && !m_plan.fused_up2x && !m_plan.hdr_tonemap && src4 &&
+                       FillStripParams((const uint8_t *)srcs[0], dsts[0], rtPitch, MakeStore(dsts[0], rtPitch, m_plan.swap_fmt, true), &strip_sp);
     bool batchable = false;
-    if (!m_plan.fused_up2x && n > 1 && src4 && !(m_cfg.flags & (MPCVR_FLAG_NO_FUSED | MPCVR_FLAG_NO_FAST_CONVERT))) {
+    if (!m_plan.fused_up2x && !strip && n > 1 && src4 && !(m_cfg.flags & (MPCVR_FLAG_NO_FUSED | MPCVR_FLAG_NO_FAST_CONVERT))) {
         FusedParams a{}, b{};
         batchable = BatchPlan((const uint8_t *)srcs[0], dsts[0], rtPitch, aligned, &a, &b);
     }
@@ -971,7 +1020,7 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
         m_timed = true;
         return hr;
     }
-    if ((!m_plan.fused_up2x && !batchable) || !src4) {
+    if ((!m_plan.fused_up2x && !strip && !batchable) || !src4) {
         // samples that are repacked (or, not starting on a dword, copied) first share m_TexSrcVideo: those batches stay on the
         // context stream, frame by frame
         const bool repack = m_srcParams->cformat == MPCVR_CF_V210 || m_srcParams->layout == LAY_RGB || !src4;
@@ -1024,6 +1073,19 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
     if (batchable) {
         (void)hipEventRecord(m_evStart, m_stream);
         hr = ProcessBatchLaunches(n, (const FusedFrame *)slot.dev.ptr, (const uint8_t *)srcs[0], dsts[0], rtPitch, aligned);
+        (void)hipEventRecord(m_evStop, m_stream);
+        (void)hipEventRecord(slot.done, m_stream);
+        slot.used = true;
+        m_timed = true;
+        return hr;
+    }
+    if (strip) {
+        bool aligned8 = true;
+        for (int i = 0; i < n; i++)
+            if (((uintptr_t)dsts[i] & 7) != 0) aligned8 = false;
+        strip_sp.fp.dst_aligned16 = aligned8 ? 1 : 0;
+        (void)hipEventRecord(m_evStart, m_stream);
+        hr = CheckHip(LaunchFusedStrip(strip_sp, (const FusedFrame *)slot.dev.ptr, FusedFrame{nullptr, nullptr}, n, m_stream), "k_fused_strip");
         (void)hipEventRecord(m_evStop, m_stream);
         (void)hipEventRecord(slot.done, m_stream);
         slot.used = true;
@@ -1273,7 +1335,7 @@ std::string CHipVideoProcessor::GetPathInfo()
 {
     if (!m_srcParams) return "uninitialised";
     if (m_planDirty && UpdatePlan() != MPCVR_S_OK) return "error: " + m_lastError;
-    return m_plan.describe();
+    return m_plan.describe() + (m_strip && !m_plan.fused_up2x ? ";kernel=fused_strip" : "");
 }
 
 HRESULT CHipVideoProcessor::GetLastProcessMs(float *ms)

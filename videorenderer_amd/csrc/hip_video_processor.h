@@ -206,6 +206,11 @@ private:
     DevBuffer m_jincFirst, m_jincSecond;
     const void *m_jincFirstTab = nullptr, *m_jincSecondTab = nullptr;
     HRESULT UploadJincPhases(const DrawCoords &dc, DevBuffer &buf, const void **tab);
+    // arbitrary-ratio fused kernel (vp_fused_strip.hip): geometry planned with the tap tables (UpdatePlan)
+    bool m_strip = false;
+    StripPlan m_stripPlan;
+    DevBuffer m_stripTab;          // yrange (int2 per output row) followed by xstrip (int2 per strip)
+    bool FillStripParams(const uint8_t *sample, void *dst, int dstPitch, const StoreParams &store, FusedStripParams *sp) const;
     bool BatchPlan(const uint8_t *sample0, void *rt0, int rtPitch, bool aligned, FusedParams *conv, FusedParams *direct) const;
     HRESULT ProcessBatchLaunches(int n, const FusedFrame *table, const uint8_t *sample0, void *rt0, int rtPitch, bool aligned);
     HRESULT PrepareLanes(int lanes);

@@ -1,0 +1,387 @@
+// vp_fused_strip.hip — the fused path for ARBITRARY resize ratios: convert -> X draw -> Y draw -> final pass in ONE kernel.
+//
+// The reference runs every geometry through the same draws (ConvertColorPass -> m_TexConvertOutput, TextureResizeShader X ->
+// fp16 m_TexResize, TextureResizeShader Y -> m_TexsPostScale, FinalPass; DX11VideoProcessor.cpp:3103-3187,3285-3424).  The
+// exact-2x kernel (vp_fused.hip) lives on its two fixed phases; here the per-output tap tables of BuildAxisTaps drive the
+// same wave-autonomous strip design for any ratio, up or down, with every intermediate rounding of the reference kept:
+//   convert output -> UNORM8/10, X draw -> fp16 (RNE), Y draw -> UNORM8/10 (m_TexsPostScale), final pass floor(p*Q + d).
+//
+// One wavefront owns a strip of `strip_w` output columns (PXL adjacent pixels per lane) and a segment of output rows, and
+// marches down the SOURCE rows two at a time (a 4:2:0 row pair shares its two chroma rows), no workgroup barrier in the loop:
+//   stage C  lane j converts the 2x2 blocks {cols c0+2j(+128..), +1} x {rows 2p-1, 2p} of the strip's source window from raw
+//            codes (prefetched one pair ahead), rounds them to the internal UNORM format and parks the CODES in this wave's
+//            LDS slice A as fp16 bit patterns: an integer k < 1024 IS the fp16 subnormal k * 2^-24, which v_fma_mix_f32
+//            reads exactly (tools/ubench/strip_probe.hip) — no int->float conversion anywhere, 8 bytes per texel
+//   stage X  lane l filters its PXL output columns of both rows: per tap one ds_read_b64 at the lane's own (tap-table)
+//            offset + three v_fma_mix_f32 (fp16 operand x fp32 weight, the 2^24/maxv scale folded into the weight);
+//            the fp16-rounded results (m_TexResize) enter an LDS ring window ring[row & mask][lane] — private to the lane,
+//            so no barrier; LDS as a register file with a run-time (wave-uniform) row index
+//   stage Y  for every output row whose source rows are in the ring: taps and weights are wave-uniform (scalar loads from
+//            the row-major table), per tap one LDS read for the lane's PXL pixels + v_fma_mix_f32 with an SGPR weight;
+//            then m_TexsPostScale rounding + ps_final_pass in integers (vp_fused.hip's epilogue) or the generic epilogue
+//            (store_epilogue: any target format, window clipping, post-scale textures)
+// HBM traffic = the source window once (+ halo rows per segment) + the render target once: nothing in between.
+#include "vp_fused_dev.h"
+
+namespace mpcvr {
+
+namespace {
+
+struct StripArgs {
+    const int32_t *xi_t; const float *xw_t; const float *xwsum;     // X tap tables, tap-major [k][out_w]
+    const int32_t *yi; const float *yw; const float *ywsum;         // Y tap tables, row-major [y][nty]
+    const int2 *yrange;          // [out_h] {smallest, largest} source row any tap of output row y reads
+    const int2 *xstrip;          // [n_strips] {smallest, largest} source column any tap of the strip reads
+    int ntx, nty, x_norm, y_norm;
+    int out_w, out_h;
+    int n_strips, strip_w;       // output columns per strip (<= 64 * PXL, a multiple of PXL)
+    int ring_mask;               // ring rows - 1 (8 or 16 rows)
+    int seg_rows;                // output rows per segment
+    int acols;                   // columns of an A row (even)
+    float a_scale;               // 2^24 / maxv: A holds integer codes as fp16 subnormals
+};
+
+// v_fma_mix_f32: fp16 operand (lo / hi half of a dword) x fp32 weight + fp32 accumulator
+template <bool HI, bool SW>
+__device__ __forceinline__ float fmix(uint32_t h, float w, float acc)
+{
+    float r;
+    if (SW) {
+        if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "s"(w), "v"(acc));
+        else    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "s"(w), "v"(acc));
+    } else {
+        if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(w), "v"(acc));
+        else    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(w), "v"(acc));
+    }
+    return r;
+}
+template <bool HI, bool SW>
+__device__ __forceinline__ float fmix0(uint32_t h, float w)
+{
+    float r;
+    if (SW) {
+        if (HI) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "s"(w));
+        else    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "s"(w));
+    } else {
+        if (HI) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(w));
+        else    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(w));
+    }
+    return r;
+}
+// one texel {r | g << 16, b | x << 16} (fp16 bit patterns) times weight w into acc[3]
+template <bool SW, bool FIRST>
+__device__ __forceinline__ void tap3(uint32_t rg, uint32_t bx, float w, float (&acc)[3])
+{
+    if (FIRST) { acc[0] = fmix0<false, SW>(rg, w); acc[1] = fmix0<true, SW>(rg, w); acc[2] = fmix0<false, SW>(bx, w); }
+    else { acc[0] = fmix<false, SW>(rg, w, acc[0]); acc[1] = fmix<true, SW>(rg, w, acc[1]); acc[2] = fmix<false, SW>(bx, w, acc[2]); }
+}
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// NT: taps per axis held in registers (4, 6: exactly that many on both axes; 8: up to 8, run-time counts, zero-padded)
+template <int NT, int PXL, int TAIL, int SRC, int EPI>
+__global__ __launch_bounds__(256) void k_fused_strip(FusedArgs P, StripArgs Q, StoreParams st, const FusedFrame *__restrict__ frames, FusedFrame single)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool FASTEPI = EPI == EPI_DITHER8;
+    uint32_t *Di = (uint32_t *)smem;                                   // dither as j << 14 (FASTEPI)
+    f2 *T = (f2 *)(smem + (FASTEPI ? LDS_DB : 0));
+    unsigned char *wbase = smem + (FASTEPI ? LDS_DB : 0) + (TAIL == TAILK_PQ_LUT ? LDS_T : 0);
+    if (FASTEPI)
+        for (int i = threadIdx.x; i < 1024; i += 256)
+            Di[i] = (uint32_t)(__half2float(__ushort_as_half(P.dither[i])) * 1024.0f + 0.5f) << 14;
+    if (TAIL == TAILK_PQ_LUT)
+        for (int i = threadIdx.x; i < LUT_N; i += 256) {
+            const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
+            T[i] = f2{v, n - v};
+        }
+    if (FASTEPI || TAIL == TAILK_PQ_LUT) __syncthreads();             // the only workgroup barrier: tables visible
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int strip = blockIdx.x * WAVES + wave;
+    const int y0 = blockIdx.y * Q.seg_rows;
+    if (strip >= Q.n_strips || y0 >= Q.out_h) return;
+    const int y1 = min(y0 + Q.seg_rows, Q.out_h);
+    const int W = P.W, H = P.H;
+    const int ring_rows = Q.ring_mask + 1;
+    const int a_row = Q.acols * 8, ring_row = 64 * PXL * 8;
+    unsigned char *const Aw = wbase + wave * (2 * a_row + ring_rows * ring_row);
+    unsigned char *const ringl = Aw + 2 * a_row + lane * (PXL * 8);
+
+    const FusedFrame frame = frames ? frames[blockIdx.z] : single;
+    auto uniform_ptr = [](const void *q) {
+        const uint64_t v = (uint64_t)q;
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    };
+    const gcptr py = (gcptr)uniform_ptr(frame.src);
+    const uint64_t dst_u = uniform_ptr(frame.dst);
+    const gptr pdst = (gptr)dst_u;
+    st.dst = (void *)dst_u;
+
+    // the strip's source window: columns c0 .. hi as 2x2 blocks, 64 per pass
+    const int2 xr = Q.xstrip[strip];
+    const int c0 = xr.x & ~1;
+    const int nb = ((xr.y - c0) >> 1) + 1, npass = (nb + 63) >> 6;
+
+    // stage X / Y role: output columns xs + PXL*lane + q
+    const int xs = strip * Q.strip_w;
+    const int x_first = xs + PXL * lane;
+    const bool xy_active = PXL * lane < Q.strip_w && x_first < Q.out_w;
+    uint32_t xo[PXL][NT]; float xw[PXL][NT];
+#pragma unroll
+    for (int q = 0; q < PXL; q++) {
+        const int xc = min(x_first + q, Q.out_w - 1);
+        const float nrm = Q.x_norm ? 1.0f / Q.xwsum[xc] : 1.0f;
+        const int i0 = Q.xi_t[xc];
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            const bool on = NT != 8 || k < Q.ntx;
+            const int idx = on ? Q.xi_t[xc + (size_t)k * Q.out_w] : i0;
+            const float w = on ? Q.xw_t[xc + (size_t)k * Q.out_w] : 0.0f;
+            xo[q][k] = (uint32_t)(idx - c0) * 8u;
+            xw[q][k] = w * nrm * Q.a_scale;
+        }
+    }
+
+    const f2 MM[5] = {f2{P.m[0], P.m[1]}, f2{P.m[2], P.m[3]}, f2{P.m[4], P.m[5]}, f2{P.m[6], P.m[7]}, f2{P.m[8], 0.0f}};
+    const f2 GG[5] = {f2{P.gamut[0], P.gamut[1]}, f2{P.gamut[2], P.gamut[3]}, f2{P.gamut[4], P.gamut[5]}, f2{P.gamut[6], P.gamut[7]}, f2{P.gamut[8], 0.0f}};
+    const f2 cmax2 = splat(P.maxv);
+    f2 big2 = splat(8388608.0f);                     // 2^23, pinned in VGPRs (see unorm_round2)
+    asm volatile("" : "+v"(big2));
+    f2 CC[3] = {splat(P.c[0]), splat(P.c[1]), splat(P.c[2])};
+    asm volatile("" : "+v"(CC[0]), "+v"(CC[1]), "+v"(CC[2]));
+
+    // raw codes of pass 0 are prefetched one row pair ahead
+    RawAddr ra0;
+    make_raw_addr<SRC>(P, min(c0 + 2 * lane, W - 2), ra0);
+    Raw rawn;
+    auto fetch = [&](int pp, const RawAddr &ra, Raw &r) {
+        load_raw<SRC>(P, py, ra, clampi(2 * pp - 1, 0, H - 1), clampi(2 * pp, 0, H - 1), r);
+    };
+
+    // pair pp = source rows 2pp-1, 2pp (rect-relative; the first and the last pair of a frame hold one useful row)
+    auto produce = [&](int pp) {
+        const int r0 = 2 * pp - 1;
+        const int sy0 = P.rect_t + clampi(r0, 0, H - 1), sy1 = P.rect_t + clampi(r0 + 1, 0, H - 1);
+        for (int pass = 0; pass < npass; pass++) {
+            const int b = pass * 64 + lane;
+            f2 rc[2][3];
+            if (pass == 0) {
+                convert_block<TAIL, SRC>(P, MM, GG, CC, rawn, sy0, sy1, T, rc);
+                fetch(pp + 1, ra0, rawn);
+            } else {
+                RawAddr ra; Raw rw;
+                make_raw_addr<SRC>(P, min(c0 + 2 * b, W - 2), ra);
+                fetch(pp, ra, rw);
+                convert_block<TAIL, SRC>(P, MM, GG, CC, rw, sy0, sy1, T, rc);
+            }
+            // store to m_TexConvertOutput (UNORM: floor(sat(x)*maxv + 0.5)): x*maxv + 2^23 leaves the code in the low
+            // mantissa bits — as an fp16 bit pattern that code is the subnormal k * 2^-24
+            uint32_t rg[2][2], bb[2][2];                // [column][row]
+#pragma unroll
+            for (int col = 0; col < 2; col++) {
+                const f2 qr = pk_fma(rc[col][0], cmax2, big2), qg = pk_fma(rc[col][1], cmax2, big2), qb = pk_fma(rc[col][2], cmax2, big2);
+                rg[col][0] = __builtin_amdgcn_perm(__float_as_uint(qg.x), __float_as_uint(qr.x), 0x05040100u);
+                rg[col][1] = __builtin_amdgcn_perm(__float_as_uint(qg.y), __float_as_uint(qr.y), 0x05040100u);
+                bb[col][0] = __float_as_uint(qb.x) & 0xffffu; bb[col][1] = __float_as_uint(qb.y) & 0xffffu;
+            }
+            if (b < nb) {
+                *(u32x4 *)(Aw + 16 * b) = u32x4{rg[0][0], bb[0][0], rg[1][0], bb[1][0]};
+                *(u32x4 *)(Aw + a_row + 16 * b) = u32x4{rg[0][1], bb[0][1], rg[1][1], bb[1][1]};
+            }
+        }
+        wave_sync();
+        // ---------------- stage X ----------------
+        if (xy_active) {
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int row = r0 + r;
+                if (row < 0 || row >= H) continue;               // wave-uniform
+                const unsigned char *Ar = Aw + r * a_row;
+                uint32_t o[PXL][2];
+#pragma unroll
+                for (int q = 0; q < PXL; q++) {
+                    float acc[3];
+                    u32x2 t[NT];
+#pragma unroll
+                    for (int k = 0; k < NT; k++) t[k] = *(const u32x2 *)(Ar + xo[q][k]);
+                    tap3<false, true>(t[0].x, t[0].y, xw[q][0], acc);
+#pragma unroll
+                    for (int k = 1; k < NT; k++) tap3<false, false>(t[k].x, t[k].y, xw[q][k], acc);
+                    // m_TexResize is R16G16B16A16_FLOAT (:3155): round to fp16 (RNE)
+                    const h2v h01 = __builtin_convertvector(f2{acc[0], acc[1]}, h2v), h2x = __builtin_convertvector(f2{acc[2], 0.0f}, h2v);
+                    o[q][0] = __builtin_bit_cast(uint32_t, h01); o[q][1] = __builtin_bit_cast(uint32_t, h2x);
+                }
+                unsigned char *dstp = ringl + (row & Q.ring_mask) * ring_row;
+                if (PXL == 2) *(u32x4 *)dstp = u32x4{o[0][0], o[0][1], o[PXL - 1][0], o[PXL - 1][1]};
+                else *(u32x2 *)dstp = u32x2{o[0][0], o[0][1]};
+            }
+        }
+        wave_sync();
+    };
+
+    // ---------------- the march ----------------
+    int p = (Q.yrange[y0].x + 1) >> 1;
+    int have = 2 * p - 2;                                // largest source row in the ring
+    fetch(p, ra0, rawn);
+    const uint32_t lane_off = (uint32_t)(P.off_x + x_first) * 4u;
+    const bool st8 = PXL == 2 && ((P.off_x + xs) & 1) == 0 && (((uintptr_t)dst_u | (uintptr_t)P.dst_pitch) & 7) == 0;
+    const float maxv = P.maxv;
+    for (int y = y0; y < y1; y++) {
+        const int hi = Q.yrange[y].y;
+        while (have < hi) { produce(p); have = 2 * p; p++; }
+        if (!xy_active) continue;
+        // ---------------- stage Y + final pass ----------------
+        const int32_t *yi = Q.yi + (size_t)y * Q.nty;
+        const float *yw = Q.yw + (size_t)y * Q.nty;
+        float acc[PXL][3];
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            if (NT == 8 && k >= Q.nty) break;
+            const int slot = yi[k] & Q.ring_mask;
+            const float w = yw[k];
+            const unsigned char *src = ringl + slot * ring_row;
+            if (PXL == 2) {
+                const u32x4 t = *(const u32x4 *)src;
+                if (k == 0) { tap3<true, true>(t.x, t.y, w, acc[0]); tap3<true, true>(t.z, t.w, w, acc[PXL - 1]); }
+                else { tap3<true, false>(t.x, t.y, w, acc[0]); tap3<true, false>(t.z, t.w, w, acc[PXL - 1]); }
+            } else {
+                const u32x2 t = *(const u32x2 *)src;
+                if (k == 0) tap3<true, true>(t.x, t.y, w, acc[0]);
+                else tap3<true, false>(t.x, t.y, w, acc[0]);
+            }
+        }
+        if (Q.y_norm) {
+            const float inv = 1.0f / Q.ywsum[y];
+#pragma unroll
+            for (int q = 0; q < PXL; q++) { acc[q][0] *= inv; acc[q][1] *= inv; acc[q][2] *= inv; }
+        }
+        if (FASTEPI) {
+            // m_TexsPostScale store/load + ps_final_pass.hlsl:29 in integers, see vp_fused.hip
+            const int wy = P.off_y + y;
+            uint32_t pk[PXL];
+#pragma unroll
+            for (int q = 0; q < PXL; q++) {
+                const uint32_t dj = Di[(wy & 31) * 32 + ((P.off_x + x_first + q) & 31)];
+                uint32_t code[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                    code[c] = __float_as_uint(fmaf(__builtin_amdgcn_fmed3f(acc[q][c], 0.0f, 1.0f), maxv, 8388608.0f));
+                const uint32_t ib = __umul24(code[2], P.epi_mul) + dj, ig = __umul24(code[1], P.epi_mul) + dj, ir = __umul24(code[0], P.epi_mul) + dj;
+                const uint32_t bg = __builtin_amdgcn_perm(ig, ib, 0x0c0c0703u);    // [B, G, 0, 0]
+                pk[q] = __builtin_amdgcn_perm(ir, bg, 0x0d070100u);               // [B, G, R, 0xff]
+            }
+            const gptr rowp = pdst + (uint32_t)wy * (uint32_t)P.dst_pitch;
+            if (PXL == 2 && st8 && x_first + 1 < Q.out_w) {
+                *(__attribute__((address_space(1))) u32x2 *)(rowp + opaque(lane_off)) = u32x2{pk[0], pk[PXL - 1]};
+            } else {
+#pragma unroll
+                for (int q = 0; q < PXL; q++)
+                    if (x_first + q < Q.out_w) *(__attribute__((address_space(1))) uint32_t *)(rowp + lane_off + 4 * q) = pk[q];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PXL; q++)
+                if (x_first + q < Q.out_w) store_epilogue(st, x_first + q, y, f3{acc[q][0], acc[q][1], acc[q][2]});
+        }
+    }
+}
+
+}  // namespace
+
+// host side -------------------------------------------------------------------------------------------------------------
+
+bool FusedStripSupported(const FusedStripParams &S)
+{
+    const FusedParams &P = S.fp;
+    const ConvertParams &c = P.conv;
+    if (c.out_fmt != SF_BGRA8 && c.out_fmt != SF_RGB10A2) return false;
+    if (c.fmt.layout != LAY_PLANAR || c.fmt.subsampling != 420 || c.chroma_scaling != 1 || c.blend_deint || c.dovi) return false;
+    if (c.out_w < 8 || c.out_h < 2 || (c.out_w & 1) || (c.out_h & 1)) return false;
+    if (!P.fast_convert) return false;
+    if ((uint64_t)c.pitch[0] * (uint64_t)(c.rect_t + c.out_h + 2) >= (1ull << 32)) return false;
+    if ((uint64_t)P.plane_off[1] >= (1ull << 31) || (uint64_t)P.plane_off[2] >= (1ull << 31)) return false;
+    if (P.store.off_x + S.out_w > 0 && (uint64_t)P.store.dst_pitch * (uint64_t)(std::max(P.store.off_y, 0) + S.out_h) >= (1ull << 32)) return false;
+    if (S.tx.ntaps < 1 || S.tx.ntaps > 8 || S.ty.ntaps < 1 || S.ty.ntaps > 8) return false;
+    if (!S.tx.idx_t || !S.tx.w_t || !S.ty.idx || !S.ty.w || !S.yrange || !S.xstrip) return false;
+    if (S.ring != 8 && S.ring != 16) return false;
+    if (S.pxl != 1 && S.pxl != 2) return false;
+    if (S.strip_w < S.pxl || S.strip_w > 64 * S.pxl || (S.strip_w % S.pxl)) return false;
+    return true;
+}
+
+// LDS per workgroup of a configuration
+static size_t StripLds(const FusedStripParams &S, bool fastepi, bool lut)
+{
+    return (fastepi ? LDS_DB : 0) + (lut ? LDS_T : 0) + (size_t)WAVES * (2 * (size_t)S.acols * 8 + (size_t)S.ring * 64 * S.pxl * 8);
+}
+
+hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s)
+{
+    if (!frames_dev && n_frames != 1) return hipErrorInvalidValue;
+    const FusedParams &P = S.fp;
+    FusedArgs a;
+    FillFusedArgs(P, a);
+    StripArgs q{};
+    q.xi_t = S.tx.idx_t; q.xw_t = S.tx.w_t; q.xwsum = S.tx.wsum;
+    q.yi = S.ty.idx; q.yw = S.ty.w; q.ywsum = S.ty.wsum;
+    q.yrange = (const int2 *)S.yrange; q.xstrip = (const int2 *)S.xstrip;
+    q.ntx = S.tx.ntaps; q.nty = S.ty.ntaps; q.x_norm = S.tx.normalise; q.y_norm = S.ty.normalise;
+    q.out_w = S.out_w; q.out_h = S.out_h;
+    q.strip_w = S.strip_w; q.n_strips = (S.out_w + S.strip_w - 1) / S.strip_w;
+    q.ring_mask = S.ring - 1;
+    q.acols = S.acols;
+    q.a_scale = 16777216.0f / a.maxv;
+    // segment height: long segments recompute less (the taps' span of source rows each), short ones fill the chip
+    static const int seg_env = EnvInt("MPCVR_STRIP_SEG", 0);
+    int seg = seg_env;
+    if (seg <= 0) {
+        seg = 16;
+        for (int cand : {192, 128, 96, 64, 48, 32, 24, 16})
+            if ((long)q.n_strips * ((S.out_h + cand - 1) / cand) * n_frames >= 8192 || cand == 16) { seg = cand; break; }
+    }
+    q.seg_rows = std::min(seg, S.out_h);
+
+    const StoreParams &st = P.store;
+    const bool inside = st.off_x >= 0 && st.off_y >= 0 && (st.clip_w <= 0 || (st.off_x + S.out_w <= st.clip_w && st.off_y + S.out_h <= st.clip_h));
+    const bool fastepi = inside && st.mode == ST_FINAL && st.dst_fmt == SF_BGRA8 && st.quant == 255 && a.epi_mul != 0 &&
+                         P.conv.out_fmt == SF_RGB10A2 && st.mid_fmt == SF_RGB10A2 && (st.dst_pitch & 3) == 0;
+    const int tailk = FusedTailKind(P), srck = FusedSourceKind(P);
+    const size_t lds = StripLds(S, fastepi, tailk == TAILK_PQ_LUT);
+    const dim3 grid((q.n_strips + WAVES - 1) / WAVES, (S.out_h + q.seg_rows - 1) / q.seg_rows, n_frames), block(256, 1, 1);
+    const int ntk = (S.pxl == 2 && S.tx.ntaps == S.ty.ntaps && !S.tx.normalise && !S.ty.normalise && (S.tx.ntaps == 4 || S.tx.ntaps == 6)) ? S.tx.ntaps : 8;
+    if (ntk == 8 && S.pxl != 1) return hipErrorNotSupported;
+#define MPCVR_ST5(NT, PX, TK, SK, EK) do { \
+        auto kern = k_fused_strip<NT, PX, TK, SK, EK>; \
+        if (lds > 48 * 1024) { \
+            const hipError_t ea = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (ea != hipSuccess) return ea; \
+        } \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, a, q, st, frames_dev, single); } while (0)
+#define MPCVR_ST4(NT, PX, TK, SK) do { if (fastepi) MPCVR_ST5(NT, PX, TK, SK, EPI_DITHER8); else MPCVR_ST5(NT, PX, TK, SK, EPI_GENERIC); } while (0)
+#define MPCVR_ST3(NT, PX, TK) do { if (srck == SRC_P01X) MPCVR_ST4(NT, PX, TK, SRC_P01X); else if (srck == SRC_NV12) MPCVR_ST4(NT, PX, TK, SRC_NV12); \
+                                   else MPCVR_ST4(NT, PX, TK, SRC_GENERIC); } while (0)
+#define MPCVR_ST2(NT, PX) do { if (tailk == TAILK_NONE) MPCVR_ST3(NT, PX, TAILK_NONE); else if (tailk == TAILK_PQ_LUT) MPCVR_ST3(NT, PX, TAILK_PQ_LUT); \
+                               else if (tailk == TAILK_HLG) MPCVR_ST3(NT, PX, TAILK_HLG); else MPCVR_ST3(NT, PX, TAILK_ALU); } while (0)
+    if (ntk == 4) MPCVR_ST2(4, 2);
+    else if (ntk == 6) MPCVR_ST2(6, 2);
+    else MPCVR_ST2(8, 1);
+#undef MPCVR_ST2
+#undef MPCVR_ST3
+#undef MPCVR_ST4
+#undef MPCVR_ST5
+    return hipGetLastError();
+}
+
+size_t FusedStripLdsBytes(const FusedStripParams &S) { return StripLds(S, true, true); }
+
+}  // namespace mpcvr

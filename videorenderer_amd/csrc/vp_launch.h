@@ -70,4 +70,18 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
 // frames_dev == nullptr: n_frames must be 1 and `single` is used (no device-side table needed)
 hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
 
+// arbitrary-ratio fused path (vp_fused_strip.hip): block convert + both draws of an unrotated two-pass resize + final pass in one
+// kernel, driven by the tap tables of BuildAxisTaps; wave-autonomous strips like the 2x kernel, the vertical window in LDS.
+struct FusedStripParams {
+    FusedParams fp;            // conv / plane_off / store / pq_lut / alignment flags (wx, wy, out_w, out_h of fp are not used)
+    AxisTaps tx, ty;           // device tap tables of the two draws (tx: idx_t / w_t tap-major; ty: idx / w row-major)
+    const void *yrange;        // device int2[out_h]: {smallest, largest} source row of every output row's taps
+    const void *xstrip;        // device int2[n_strips]: {smallest, largest} source column of every strip's taps
+    int out_w, out_h;
+    int pxl, strip_w, ring, acols;   // PlanFusedStrip's choices
+};
+bool FusedStripSupported(const FusedStripParams &S);
+hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
+size_t FusedStripLdsBytes(const FusedStripParams &S);
+
 }  // namespace mpcvr

@@ -2,6 +2,7 @@
 // fp32/fp64 expression shapes below round exactly like the reference's MSVC build.
 #include "vp_plan.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -512,6 +513,60 @@ void BuildPointIndex(int src_l, int src_len, int n_out, int tex_len, std::vector
     out->resize(n_out);
     for (int i = 0; i < n_out; i++)
         (*out)[i] = ClampI((int)std::floor(AxisCenterDir(src_l, src_len, i, scale, reversed)), 0, tex_len - 1);
+}
+
+// Strip geometry of the arbitrary-ratio fused kernel.  The kernel converts a strip's source window in passes of 64 2x2 blocks
+// per source row pair and filters 64 * pxl output columns from it, so the width of a strip trades idle convert lanes against
+// idle filter lanes; the choice below minimises an instruction-count model of one output pixel (convert ~250 VALU per block
+// pass, 3 per tap and channel set in the X / Y stages), which is what the kernel is bound by.
+bool PlanFusedStrip(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x, int n_out_y, int src_w, int src_h, StripPlan *sp)
+{
+    if (hx.ntaps < 1 || hx.ntaps > 8 || hy.ntaps < 1 || hy.ntaps > 8 || n_out_x < 1 || n_out_y < 1) return false;
+    if (hx.idx.size() != (size_t)n_out_x * hx.ntaps || hy.idx.size() != (size_t)n_out_y * hy.ntaps) return false;
+    sp->yrange.resize(2 * (size_t)n_out_y);
+    int span = 0, plo = 0, phi = 0;
+    for (int y = 0; y < n_out_y; y++) {
+        const auto mm = std::minmax_element(hy.idx.begin() + (size_t)y * hy.ntaps, hy.idx.begin() + (size_t)(y + 1) * hy.ntaps);
+        const int lo = *mm.first, hi = *mm.second;
+        if (lo < 0 || hi >= src_h || (y > 0 && (lo < plo || hi < phi))) return false;      // the march needs monotonic windows
+        sp->yrange[2 * y] = lo; sp->yrange[2 * y + 1] = hi;
+        span = std::max(span, hi - lo + 1);
+        plo = lo; phi = hi;
+    }
+    sp->ring = span + 1 <= 8 ? 8 : span + 1 <= 16 ? 16 : 0;
+    if (!sp->ring) return false;
+    std::vector<int> clo(n_out_x), chi(n_out_x);
+    for (int x = 0; x < n_out_x; x++) {
+        const auto mm = std::minmax_element(hx.idx.begin() + (size_t)x * hx.ntaps, hx.idx.begin() + (size_t)(x + 1) * hx.ntaps);
+        clo[x] = *mm.first; chi[x] = *mm.second;
+        if (clo[x] < 0 || chi[x] >= src_w) return false;
+    }
+    const bool reg_taps = hx.ntaps == hy.ntaps && (hx.ntaps == 4 || hx.ntaps == 6) && !hx.normalise && !hy.normalise;
+    sp->pxl = (reg_taps && src_w <= n_out_x) ? 2 : 1;
+    const double pairs_per_row = 0.5 * (double)src_h / (double)n_out_y;
+    double best = 0;
+    int best_w = 0, best_cols = 0;
+    for (int lanes : {64, 56, 48, 40, 32, 24, 16}) {
+        const int sw = lanes * sp->pxl;
+        int max_nb = 0;
+        for (int x0 = 0; x0 < n_out_x; x0 += sw) {
+            const int x1 = std::min(n_out_x, x0 + sw);
+            const int lo = *std::min_element(clo.begin() + x0, clo.begin() + x1), hi = *std::max_element(chi.begin() + x0, chi.begin() + x1);
+            max_nb = std::max(max_nb, ((hi - (lo & ~1)) >> 1) + 1);
+        }
+        const int passes = (max_nb + 63) / 64;
+        const double cost = (pairs_per_row * (passes * 250.0 + 2.0 * sp->pxl * (3.0 * hx.ntaps + 4.0)) + sp->pxl * (3.0 * hy.ntaps + 14.0)) / (double)sw;
+        if (!best_w || cost < best) { best = cost; best_w = sw; best_cols = 2 * max_nb; }
+    }
+    sp->strip_w = best_w; sp->acols = best_cols;
+    const int n_strips = (n_out_x + best_w - 1) / best_w;
+    sp->xstrip.resize(2 * (size_t)n_strips);
+    for (int s = 0; s < n_strips; s++) {
+        const int x0 = s * best_w, x1 = std::min(n_out_x, x0 + best_w);
+        sp->xstrip[2 * s] = *std::min_element(clo.begin() + x0, clo.begin() + x1);
+        sp->xstrip[2 * s + 1] = *std::max_element(chi.begin() + x0, chi.begin() + x1);
+    }
+    return true;
 }
 
 bool DecidePlan(int iTexFormat, int iChromaScaling, int iUpscaling, int iDownscaling, int bInterpolateAt50pct,

@@ -111,6 +111,18 @@ bool BuildAxisTaps(Resizer rs, int src_l, int src_len, int n_out, int tex_len, u
 // nearest / identity index map of the unfiltered axis of a draw
 void BuildPointIndex(int src_l, int src_len, int n_out, int tex_len, std::vector<int32_t> *out, bool reversed = false);
 
+// ---- arbitrary-ratio fused kernel (vp_fused_strip.hip): strip geometry from the two tap tables ----
+struct StripPlan {
+    int pxl = 1;                 // output pixels per lane (2 for 4- / 6-tap upscales)
+    int strip_w = 64;            // output columns per wavefront
+    int ring = 8;                // rows of the vertical LDS window (8 or 16)
+    int acols = 0;               // columns of a converted source row the widest strip needs (even)
+    std::vector<int32_t> yrange; // [2 * n_out_y] {lo, hi} source row per output row
+    std::vector<int32_t> xstrip; // [2 * n_strips] {lo, hi} source column per strip
+};
+// false: the tables do not fit the kernel (more than 8 taps, a vertical span above 15 rows, non-monotonic tables)
+bool PlanFusedStrip(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x, int n_out_y, int src_w, int src_h, StripPlan *sp);
+
 // ---- the pass plan of one Process() (DX11VideoProcessor.cpp:3285-3424, shader path) ----
 struct PassPlan {
     int internal_fmt = SF_BGRA8;     // UpdateTexParams :1143-1155
