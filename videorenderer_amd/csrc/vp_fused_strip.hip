@@ -42,11 +42,14 @@ struct StripArgs {
 };
 
 // v_fma_mix_f32: fp16 operand (lo / hi half of a dword) x fp32 weight + fp32 accumulator
-template <bool HI, bool SW>
+template <bool HI, bool SW, bool CLAMP = false>
 __device__ __forceinline__ float fmix(uint32_t h, float w, float acc)
 {
     float r;
-    if (SW) {
+    if (CLAMP) {        // the last tap of the Y draw saturates (UNORM store of m_TexsPostScale): SGPR weight
+        if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(r) : "v"(h), "s"(w), "v"(acc));
+        else    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(r) : "v"(h), "s"(w), "v"(acc));
+    } else if (SW) {
         if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "s"(w), "v"(acc));
         else    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "s"(w), "v"(acc));
     } else {
@@ -68,12 +71,12 @@ __device__ __forceinline__ float fmix0(uint32_t h, float w)
     }
     return r;
 }
-// one texel {r | g << 16, b | x << 16} (fp16 bit patterns) times weight w into acc[3]
-template <bool SW, bool FIRST>
+// one texel {r | g << 16, b in the lo (or, BHI, hi) half of bx} (fp16 bit patterns) times weight w into acc[3]
+template <bool SW, bool FIRST, bool BHI = false, bool CLAMP = false>
 __device__ __forceinline__ void tap3(uint32_t rg, uint32_t bx, float w, float (&acc)[3])
 {
-    if (FIRST) { acc[0] = fmix0<false, SW>(rg, w); acc[1] = fmix0<true, SW>(rg, w); acc[2] = fmix0<false, SW>(bx, w); }
-    else { acc[0] = fmix<false, SW>(rg, w, acc[0]); acc[1] = fmix<true, SW>(rg, w, acc[1]); acc[2] = fmix<false, SW>(bx, w, acc[2]); }
+    if (FIRST) { acc[0] = fmix0<false, SW>(rg, w); acc[1] = fmix0<true, SW>(rg, w); acc[2] = fmix0<BHI, SW>(bx, w); }
+    else { acc[0] = fmix<false, SW, CLAMP>(rg, w, acc[0]); acc[1] = fmix<true, SW, CLAMP>(rg, w, acc[1]); acc[2] = fmix<BHI, SW, CLAMP>(bx, w, acc[2]); }
 }
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -88,7 +91,7 @@ __device__ __forceinline__ void wave_sync()
 
 // NT: taps per axis held in registers (4, 6: exactly that many on both axes; 8: up to 8, run-time counts, zero-padded)
 template <int NT, int PXL, int TAIL, int SRC, int EPI>
-__global__ __launch_bounds__(256) void k_fused_strip(FusedArgs P, StripArgs Q, StoreParams st, const FusedFrame *__restrict__ frames, FusedFrame single)
+__global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, StoreParams st, const FusedFrame *__restrict__ frames, FusedFrame single)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool FASTEPI = EPI == EPI_DITHER8;
@@ -96,10 +99,10 @@ __global__ __launch_bounds__(256) void k_fused_strip(FusedArgs P, StripArgs Q, S
     f2 *T = (f2 *)(smem + (FASTEPI ? LDS_DB : 0));
     unsigned char *wbase = smem + (FASTEPI ? LDS_DB : 0) + (TAIL == TAILK_PQ_LUT ? LDS_T : 0);
     if (FASTEPI)
-        for (int i = threadIdx.x; i < 1024; i += 256)
+        for (int i = threadIdx.x; i < 1024; i += blockDim.x)
             Di[i] = (uint32_t)(__half2float(__ushort_as_half(P.dither[i])) * 1024.0f + 0.5f) << 14;
     if (TAIL == TAILK_PQ_LUT)
-        for (int i = threadIdx.x; i < LUT_N; i += 256) {
+        for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) {
             const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
             T[i] = f2{v, n - v};
         }
@@ -107,15 +110,20 @@ __global__ __launch_bounds__(256) void k_fused_strip(FusedArgs P, StripArgs Q, S
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int strip = blockIdx.x * WAVES + wave;
-    const int y0 = blockIdx.y * Q.seg_rows;
-    if (strip >= Q.n_strips || y0 >= Q.out_h) return;
+    // work items (strip, segment) are dealt to the waves of the grid in one sequence, neighbouring waves = neighbouring strips of one segment
+    const int item = blockIdx.x * (int)(blockDim.x >> 6) + wave;
+    const int seg_i = item / Q.n_strips, strip = item - seg_i * Q.n_strips;
+    const int y0 = seg_i * Q.seg_rows;
+    if (y0 >= Q.out_h) return;
     const int y1 = min(y0 + Q.seg_rows, Q.out_h);
     const int W = P.W, H = P.H;
     const int ring_rows = Q.ring_mask + 1;
-    const int a_row = Q.acols * 8, ring_row = 64 * PXL * 8;
+    // ring row: PXL = 1: {r|g, b|-} per lane (8 B); PXL = 2: {r0|g0, r1|g1} per lane (8 B) followed by {b0|b1} per lane (4 B)
+    constexpr int ring_row = PXL == 2 ? 64 * 12 : 64 * 8;
+    const int a_row = Q.acols * 8;
     unsigned char *const Aw = wbase + wave * (2 * a_row + ring_rows * ring_row);
-    unsigned char *const ringl = Aw + 2 * a_row + lane * (PXL * 8);
+    unsigned char *const ringl = Aw + 2 * a_row + lane * 8;
+    unsigned char *const ringb = Aw + 2 * a_row + 512 + lane * 4;          // PXL = 2: the b pairs of a row
 
     const FusedFrame frame = frames ? frames[blockIdx.z] : single;
     auto uniform_ptr = [](const void *q) {
@@ -207,23 +215,27 @@ __global__ __launch_bounds__(256) void k_fused_strip(FusedArgs P, StripArgs Q, S
                 const int row = r0 + r;
                 if (row < 0 || row >= H) continue;               // wave-uniform
                 const unsigned char *Ar = Aw + r * a_row;
-                uint32_t o[PXL][2];
+                float acc[PXL][3];
 #pragma unroll
                 for (int q = 0; q < PXL; q++) {
-                    float acc[3];
                     u32x2 t[NT];
 #pragma unroll
                     for (int k = 0; k < NT; k++) t[k] = *(const u32x2 *)(Ar + xo[q][k]);
-                    tap3<false, true>(t[0].x, t[0].y, xw[q][0], acc);
+                    tap3<false, true>(t[0].x, t[0].y, xw[q][0], acc[q]);
 #pragma unroll
-                    for (int k = 1; k < NT; k++) tap3<false, false>(t[k].x, t[k].y, xw[q][k], acc);
-                    // m_TexResize is R16G16B16A16_FLOAT (:3155): round to fp16 (RNE)
-                    const h2v h01 = __builtin_convertvector(f2{acc[0], acc[1]}, h2v), h2x = __builtin_convertvector(f2{acc[2], 0.0f}, h2v);
-                    o[q][0] = __builtin_bit_cast(uint32_t, h01); o[q][1] = __builtin_bit_cast(uint32_t, h2x);
+                    for (int k = 1; k < NT; k++) tap3<false, false>(t[k].x, t[k].y, xw[q][k], acc[q]);
                 }
-                unsigned char *dstp = ringl + (row & Q.ring_mask) * ring_row;
-                if (PXL == 2) *(u32x4 *)dstp = u32x4{o[0][0], o[0][1], o[PXL - 1][0], o[PXL - 1][1]};
-                else *(u32x2 *)dstp = u32x2{o[0][0], o[0][1]};
+                // m_TexResize is R16G16B16A16_FLOAT (:3155): round to fp16 (RNE)
+                const int slot_off = (row & Q.ring_mask) * ring_row;
+                const h2v h0 = __builtin_convertvector(f2{acc[0][0], acc[0][1]}, h2v);
+                if (PXL == 2) {
+                    const h2v h1 = __builtin_convertvector(f2{acc[PXL - 1][0], acc[PXL - 1][1]}, h2v), hb = __builtin_convertvector(f2{acc[0][2], acc[PXL - 1][2]}, h2v);
+                    *(u32x2 *)(ringl + slot_off) = u32x2{__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1)};
+                    *(uint32_t *)(ringb + slot_off) = __builtin_bit_cast(uint32_t, hb);
+                } else {
+                    const h2v hb = __builtin_convertvector(f2{acc[0][2], 0.0f}, h2v);
+                    *(u32x2 *)(ringl + slot_off) = u32x2{__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, hb)};
+                }
             }
         }
         wave_sync();
@@ -235,6 +247,7 @@ __global__ __launch_bounds__(256) void k_fused_strip(FusedArgs P, StripArgs Q, S
     fetch(p, ra0, rawn);
     const uint32_t lane_off = (uint32_t)(P.off_x + x_first) * 4u;
     const bool st8 = PXL == 2 && ((P.off_x + xs) & 1) == 0 && (((uintptr_t)dst_u | (uintptr_t)P.dst_pitch) & 7) == 0;
+    const bool dpair = PXL == 2 && ((P.off_x + xs) & 1) == 0;            // the lane's two dither texels are one aligned 8-byte read
     const float maxv = P.maxv;
     for (int y = y0; y < y1; y++) {
         const int hi = Q.yrange[y].y;
@@ -244,23 +257,37 @@ __global__ __launch_bounds__(256) void k_fused_strip(FusedArgs P, StripArgs Q, S
         const int32_t *yi = Q.yi + (size_t)y * Q.nty;
         const float *yw = Q.yw + (size_t)y * Q.nty;
         float acc[PXL][3];
+        // with the tap count known at compile time (and nothing to normalise) the last tap saturates in the FMA itself
+        constexpr bool CLAMPED = NT != 8;
+        uint32_t dj[PXL];
+        if (FASTEPI) {          // dither texels first: the LDS round trip hides behind the taps
+            const uint32_t *drow = Di + ((P.off_y + y) & 31) * 32;
+            if (PXL == 2 && dpair) {
+                const u32x2 dd = *(const u32x2 *)(drow + ((P.off_x + x_first) & 31));
+                dj[0] = dd.x; dj[PXL - 1] = dd.y;
+            } else {
+#pragma unroll
+                for (int q = 0; q < PXL; q++) dj[q] = drow[(P.off_x + x_first + q) & 31];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < NT; k++) {
             if (NT == 8 && k >= Q.nty) break;
-            const int slot = yi[k] & Q.ring_mask;
+            const int slot_off = (yi[k] & Q.ring_mask) * ring_row;
             const float w = yw[k];
-            const unsigned char *src = ringl + slot * ring_row;
+            const u32x2 t = *(const u32x2 *)(ringl + slot_off);
             if (PXL == 2) {
-                const u32x4 t = *(const u32x4 *)src;
-                if (k == 0) { tap3<true, true>(t.x, t.y, w, acc[0]); tap3<true, true>(t.z, t.w, w, acc[PXL - 1]); }
-                else { tap3<true, false>(t.x, t.y, w, acc[0]); tap3<true, false>(t.z, t.w, w, acc[PXL - 1]); }
+                const uint32_t tb = *(const uint32_t *)(ringb + slot_off);
+                if (k == 0) { tap3<true, true, false>(t.x, tb, w, acc[0]); tap3<true, true, true>(t.y, tb, w, acc[PXL - 1]); }
+                else if (CLAMPED && k == NT - 1) { tap3<true, false, false, true>(t.x, tb, w, acc[0]); tap3<true, false, true, true>(t.y, tb, w, acc[PXL - 1]); }
+                else { tap3<true, false, false>(t.x, tb, w, acc[0]); tap3<true, false, true>(t.y, tb, w, acc[PXL - 1]); }
             } else {
-                const u32x2 t = *(const u32x2 *)src;
                 if (k == 0) tap3<true, true>(t.x, t.y, w, acc[0]);
+                else if (CLAMPED && k == NT - 1) tap3<true, false, false, true>(t.x, t.y, w, acc[0]);
                 else tap3<true, false>(t.x, t.y, w, acc[0]);
             }
         }
-        if (Q.y_norm) {
+        if (!CLAMPED && Q.y_norm) {
             const float inv = 1.0f / Q.ywsum[y];
 #pragma unroll
             for (int q = 0; q < PXL; q++) { acc[q][0] *= inv; acc[q][1] *= inv; acc[q][2] *= inv; }
@@ -269,14 +296,27 @@ __global__ __launch_bounds__(256) void k_fused_strip(FusedArgs P, StripArgs Q, S
             // m_TexsPostScale store/load + ps_final_pass.hlsl:29 in integers, see vp_fused.hip
             const int wy = P.off_y + y;
             uint32_t pk[PXL];
+            uint32_t codes[PXL][3];
+            if (PXL == 2) {         // x*maxv + 2^23 for the pixel pair of a channel in one packed FMA
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    f2 v = f2{acc[0][c], acc[PXL - 1][c]};
+                    if (!CLAMPED) v = f2{__builtin_amdgcn_fmed3f(v.x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(v.y, 0.0f, 1.0f)};
+                    const f2 u = pk_fma(v, cmax2, big2);
+                    codes[0][c] = __float_as_uint(u.x); codes[PXL - 1][c] = __float_as_uint(u.y);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float v = CLAMPED ? acc[0][c] : __builtin_amdgcn_fmed3f(acc[0][c], 0.0f, 1.0f);
+                    codes[0][c] = __float_as_uint(fmaf(v, maxv, 8388608.0f));
+                }
+            }
 #pragma unroll
             for (int q = 0; q < PXL; q++) {
-                const uint32_t dj = Di[(wy & 31) * 32 + ((P.off_x + x_first + q) & 31)];
-                uint32_t code[3];
-#pragma unroll
-                for (int c = 0; c < 3; c++)
-                    code[c] = __float_as_uint(fmaf(__builtin_amdgcn_fmed3f(acc[q][c], 0.0f, 1.0f), maxv, 8388608.0f));
-                const uint32_t ib = __umul24(code[2], P.epi_mul) + dj, ig = __umul24(code[1], P.epi_mul) + dj, ir = __umul24(code[0], P.epi_mul) + dj;
+                const uint32_t *code = codes[q];
+                const uint32_t djq = dj[q];
+                const uint32_t ib = __umul24(code[2], P.epi_mul) + djq, ig = __umul24(code[1], P.epi_mul) + djq, ir = __umul24(code[0], P.epi_mul) + djq;
                 const uint32_t bg = __builtin_amdgcn_perm(ig, ib, 0x0c0c0703u);    // [B, G, 0, 0]
                 pk[q] = __builtin_amdgcn_perm(ir, bg, 0x0d070100u);               // [B, G, R, 0xff]
             }
@@ -319,10 +359,25 @@ bool FusedStripSupported(const FusedStripParams &S)
     return true;
 }
 
-// LDS per workgroup of a configuration
-static size_t StripLds(const FusedStripParams &S, bool fastepi, bool lut)
+// LDS per workgroup of a configuration with `waves` strips per workgroup
+static size_t StripLds(const FusedStripParams &S, bool fastepi, bool lut, int waves)
 {
-    return (fastepi ? LDS_DB : 0) + (lut ? LDS_T : 0) + (size_t)WAVES * (2 * (size_t)S.acols * 8 + (size_t)S.ring * 64 * S.pxl * 8);
+    return (fastepi ? LDS_DB : 0) + (lut ? LDS_T : 0) + (size_t)waves * (2 * (size_t)S.acols * 8 + (size_t)S.ring * 64 * (S.pxl == 2 ? 12 : 8));
+}
+// The tables (dither, tone-map LUT) exist once per workgroup, the A slice and the ring once per wave: the more waves share a
+// workgroup the more of them a CU's 160 KiB hold — occupancy is what hides this kernel's LDS and memory round trips.
+static int StripWaves(const FusedStripParams &S, bool fastepi, bool lut)
+{
+    static const int env = EnvInt("MPCVR_STRIP_WAVES", 0);
+    if (env >= 1 && env <= 16 && StripLds(S, fastepi, lut, env) <= 160 * 1024) return env;
+    int best = 1, best_per_cu = 0;
+    for (int w : {4, 6, 8, 10, 12, 14, 16}) {
+        const size_t lds = StripLds(S, fastepi, lut, w);
+        if (lds > 160 * 1024) break;
+        const int per_cu = std::min((int)((160 * 1024) / lds) * w, 32);
+        if (per_cu > best_per_cu) { best_per_cu = per_cu; best = w; }
+    }
+    return best;
 }
 
 hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s)
@@ -347,7 +402,7 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
     if (seg <= 0) {
         seg = 16;
         for (int cand : {192, 128, 96, 64, 48, 32, 24, 16})
-            if ((long)q.n_strips * ((S.out_h + cand - 1) / cand) * n_frames >= 8192 || cand == 16) { seg = cand; break; }
+            if ((long)q.n_strips * ((S.out_h + cand - 1) / cand) * n_frames >= 12288 || cand == 16) { seg = cand; break; }
     }
     q.seg_rows = std::min(seg, S.out_h);
 
@@ -356,8 +411,10 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
     const bool fastepi = inside && st.mode == ST_FINAL && st.dst_fmt == SF_BGRA8 && st.quant == 255 && a.epi_mul != 0 &&
                          P.conv.out_fmt == SF_RGB10A2 && st.mid_fmt == SF_RGB10A2 && (st.dst_pitch & 3) == 0;
     const int tailk = FusedTailKind(P), srck = FusedSourceKind(P);
-    const size_t lds = StripLds(S, fastepi, tailk == TAILK_PQ_LUT);
-    const dim3 grid((q.n_strips + WAVES - 1) / WAVES, (S.out_h + q.seg_rows - 1) / q.seg_rows, n_frames), block(256, 1, 1);
+    const int waves = StripWaves(S, fastepi, tailk == TAILK_PQ_LUT);
+    const size_t lds = StripLds(S, fastepi, tailk == TAILK_PQ_LUT, waves);
+    const int n_segs = (S.out_h + q.seg_rows - 1) / q.seg_rows;
+    const dim3 grid((q.n_strips * n_segs + waves - 1) / waves, 1, n_frames), block(64 * waves, 1, 1);
     const int ntk = (S.pxl == 2 && S.tx.ntaps == S.ty.ntaps && !S.tx.normalise && !S.ty.normalise && (S.tx.ntaps == 4 || S.tx.ntaps == 6)) ? S.tx.ntaps : 8;
     if (ntk == 8 && S.pxl != 1) return hipErrorNotSupported;
 #define MPCVR_ST5(NT, PX, TK, SK, EK) do { \
@@ -382,6 +439,6 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
     return hipGetLastError();
 }
 
-size_t FusedStripLdsBytes(const FusedStripParams &S) { return StripLds(S, true, true); }
+size_t FusedStripLdsBytes(const FusedStripParams &S) { return StripLds(S, true, true, 1); }
 
 }  // namespace mpcvr
