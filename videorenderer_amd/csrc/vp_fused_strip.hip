@@ -30,8 +30,8 @@ namespace {
 struct StripArgs {
     const int32_t *xi_t; const float *xw_t; const float *xwsum;     // X tap tables, tap-major [k][out_w]
     const int32_t *yi; const float *yw; const float *ywsum;         // Y tap tables, row-major [y][nty]
-    const int2 *yrange;          // [out_h] {smallest, largest} source row any tap of output row y reads
-    const int2 *xstrip;          // [n_strips] {smallest, largest} source column any tap of the strip reads
+    const int32_t *yrange;       // [out_h][2] {smallest, largest} source row any tap of output row y reads
+    const int32_t *xstrip;       // [n_strips][2] {smallest, largest} source column any tap of the strip reads
     int ntx, nty, x_norm, y_norm;
     int out_w, out_h;
     int n_strips, strip_w;       // output columns per strip (<= 64 * PXL, a multiple of PXL)
@@ -81,6 +81,12 @@ __device__ __forceinline__ void tap3(uint32_t rg, uint32_t bx, float w, float (&
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// The tap tables are read-only for the whole launch and read at wave-uniform addresses: through the constant address space
+// the loads become s_load (SGPR results, scalar cache).  Left as plain global pointers the compiler must assume the kernel's
+// own stores could alias them and issues per-lane vector loads — the row's taps and weights then arrive in VGPRs and every
+// ring address costs a v_mul_lo_u32.
+template <typename T> using cptr = const __attribute__((address_space(4))) T *;
+template <typename T> __device__ __forceinline__ cptr<T> as_const(const T *p) { return (cptr<T>)(uintptr_t)p; }
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -118,12 +124,14 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
     const int y1 = min(y0 + Q.seg_rows, Q.out_h);
     const int W = P.W, H = P.H;
     const int ring_rows = Q.ring_mask + 1;
-    // ring row: PXL = 1: {r|g, b|-} per lane (8 B); PXL = 2: {r0|g0, r1|g1} per lane (8 B) followed by {b0|b1} per lane (4 B)
+    // ring row: per lane {r|g, b|-} (PXL = 1, 8 B) or {r0|g0, r1|g1, b0|b1} (PXL = 2, 12 B): one address per tap
     constexpr int ring_row = PXL == 2 ? 64 * 12 : 64 * 8;
     const int a_row = Q.acols * 8;
     unsigned char *const Aw = wbase + wave * (2 * a_row + ring_rows * ring_row);
-    unsigned char *const ringl = Aw + 2 * a_row + lane * 8;
-    unsigned char *const ringb = Aw + 2 * a_row + 512 + lane * 4;          // PXL = 2: the b pairs of a row
+    // the lane's ring address as an integer the compiler cannot split into "register + large constant": ds_read2_b32 has no room
+    // for a large immediate, and a second v_add per tap to add the constant part is what it would cost
+    typedef __attribute__((address_space(3))) uint32_t *lds_u32;
+    const uint32_t ring_addr = opaque((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(Aw + 2 * a_row + lane * (PXL == 2 ? 12 : 8)));
 
     const FusedFrame frame = frames ? frames[blockIdx.z] : single;
     auto uniform_ptr = [](const void *q) {
@@ -136,9 +144,8 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
     st.dst = (void *)dst_u;
 
     // the strip's source window: columns c0 .. hi as 2x2 blocks, 64 per pass
-    const int2 xr = Q.xstrip[strip];
-    const int c0 = xr.x & ~1;
-    const int nb = ((xr.y - c0) >> 1) + 1, npass = (nb + 63) >> 6;
+    const int c0 = as_const(Q.xstrip)[2 * strip] & ~1;
+    const int nb = ((as_const(Q.xstrip)[2 * strip + 1] - c0) >> 1) + 1, npass = (nb + 63) >> 6;
 
     // stage X / Y role: output columns xs + PXL*lane + q
     const int xs = strip * Q.strip_w;
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
             const bool on = NT != 8 || k < Q.ntx;
             const int idx = on ? Q.xi_t[xc + (size_t)k * Q.out_w] : i0;
             const float w = on ? Q.xw_t[xc + (size_t)k * Q.out_w] : 0.0f;
-            xo[q][k] = (uint32_t)(idx - c0) * 8u;
+            xo[q][k] = (uint32_t)(idx - c0) * 16u;
             xw[q][k] = w * nrm * Q.a_scale;
         }
     }
@@ -202,39 +209,42 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
                 rg[col][1] = __builtin_amdgcn_perm(__float_as_uint(qg.y), __float_as_uint(qr.y), 0x05040100u);
                 bb[col][0] = __float_as_uint(qb.x) & 0xffffu; bb[col][1] = __float_as_uint(qb.y) & 0xffffu;
             }
-            if (b < nb) {
-                *(u32x4 *)(Aw + 16 * b) = u32x4{rg[0][0], bb[0][0], rg[1][0], bb[1][0]};
-                *(u32x4 *)(Aw + a_row + 16 * b) = u32x4{rg[0][1], bb[0][1], rg[1][1], bb[1][1]};
+            if (b < nb) {           // A[column] = {row 0 texel, row 1 texel}: a tap of stage X is one 16-byte read for both rows
+                *(u32x4 *)(Aw + 32 * b) = u32x4{rg[0][0], bb[0][0], rg[0][1], bb[0][1]};
+                *(u32x4 *)(Aw + 32 * b + 16) = u32x4{rg[1][0], bb[1][0], rg[1][1], bb[1][1]};
             }
         }
         wave_sync();
         // ---------------- stage X ----------------
         if (xy_active) {
+            float acc[2][PXL][3];                                // [row][pixel][channel]
+#pragma unroll
+            for (int q = 0; q < PXL; q++) {
+                u32x4 t[NT];
+#pragma unroll
+                for (int k = 0; k < NT; k++) t[k] = *(const u32x4 *)(Aw + xo[q][k]);
+                tap3<false, true>(t[0].x, t[0].y, xw[q][0], acc[0][q]);
+                tap3<false, true>(t[0].z, t[0].w, xw[q][0], acc[1][q]);
+#pragma unroll
+                for (int k = 1; k < NT; k++) {
+                    tap3<false, false>(t[k].x, t[k].y, xw[q][k], acc[0][q]);
+                    tap3<false, false>(t[k].z, t[k].w, xw[q][k], acc[1][q]);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 const int row = r0 + r;
                 if (row < 0 || row >= H) continue;               // wave-uniform
-                const unsigned char *Ar = Aw + r * a_row;
-                float acc[PXL][3];
-#pragma unroll
-                for (int q = 0; q < PXL; q++) {
-                    u32x2 t[NT];
-#pragma unroll
-                    for (int k = 0; k < NT; k++) t[k] = *(const u32x2 *)(Ar + xo[q][k]);
-                    tap3<false, true>(t[0].x, t[0].y, xw[q][0], acc[q]);
-#pragma unroll
-                    for (int k = 1; k < NT; k++) tap3<false, false>(t[k].x, t[k].y, xw[q][k], acc[q]);
-                }
                 // m_TexResize is R16G16B16A16_FLOAT (:3155): round to fp16 (RNE)
-                const int slot_off = (row & Q.ring_mask) * ring_row;
-                const h2v h0 = __builtin_convertvector(f2{acc[0][0], acc[0][1]}, h2v);
+                const lds_u32 dstp = (lds_u32)(ring_addr + (uint32_t)((row & Q.ring_mask) * ring_row));
+                const h2v h0 = __builtin_convertvector(f2{acc[r][0][0], acc[r][0][1]}, h2v);
+                dstp[0] = __builtin_bit_cast(uint32_t, h0);
                 if (PXL == 2) {
-                    const h2v h1 = __builtin_convertvector(f2{acc[PXL - 1][0], acc[PXL - 1][1]}, h2v), hb = __builtin_convertvector(f2{acc[0][2], acc[PXL - 1][2]}, h2v);
-                    *(u32x2 *)(ringl + slot_off) = u32x2{__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1)};
-                    *(uint32_t *)(ringb + slot_off) = __builtin_bit_cast(uint32_t, hb);
+                    const h2v h1 = __builtin_convertvector(f2{acc[r][PXL - 1][0], acc[r][PXL - 1][1]}, h2v), hb = __builtin_convertvector(f2{acc[r][0][2], acc[r][PXL - 1][2]}, h2v);
+                    dstp[1] = __builtin_bit_cast(uint32_t, h1); dstp[2] = __builtin_bit_cast(uint32_t, hb);
                 } else {
-                    const h2v hb = __builtin_convertvector(f2{acc[0][2], 0.0f}, h2v);
-                    *(u32x2 *)(ringl + slot_off) = u32x2{__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, hb)};
+                    const h2v hb = __builtin_convertvector(f2{acc[r][0][2], 0.0f}, h2v);
+                    dstp[1] = __builtin_bit_cast(uint32_t, hb);
                 }
             }
         }
@@ -242,7 +252,8 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
     };
 
     // ---------------- the march ----------------
-    int p = (Q.yrange[y0].x + 1) >> 1;
+    const cptr<int32_t> yrange = as_const(Q.yrange);
+    int p = (yrange[2 * y0] + 1) >> 1;
     int have = 2 * p - 2;                                // largest source row in the ring
     fetch(p, ra0, rawn);
     const uint32_t lane_off = (uint32_t)(P.off_x + x_first) * 4u;
@@ -250,12 +261,12 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
     const bool dpair = PXL == 2 && ((P.off_x + xs) & 1) == 0;            // the lane's two dither texels are one aligned 8-byte read
     const float maxv = P.maxv;
     for (int y = y0; y < y1; y++) {
-        const int hi = Q.yrange[y].y;
+        const int hi = yrange[2 * y + 1];
         while (have < hi) { produce(p); have = 2 * p; p++; }
         if (!xy_active) continue;
         // ---------------- stage Y + final pass ----------------
-        const int32_t *yi = Q.yi + (size_t)y * Q.nty;
-        const float *yw = Q.yw + (size_t)y * Q.nty;
+        const cptr<int32_t> yi = as_const(Q.yi) + (size_t)y * Q.nty;
+        const cptr<float> yw = as_const(Q.yw) + (size_t)y * Q.nty;
         float acc[PXL][3];
         // with the tap count known at compile time (and nothing to normalise) the last tap saturates in the FMA itself
         constexpr bool CLAMPED = NT != 8;
@@ -275,20 +286,21 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
             if (NT == 8 && k >= Q.nty) break;
             const int slot_off = (yi[k] & Q.ring_mask) * ring_row;
             const float w = yw[k];
-            const u32x2 t = *(const u32x2 *)(ringl + slot_off);
+            const lds_u32 tp = (lds_u32)(ring_addr + (uint32_t)slot_off);
+            const uint32_t t0 = tp[0], t1 = tp[1];
             if (PXL == 2) {
-                const uint32_t tb = *(const uint32_t *)(ringb + slot_off);
-                if (k == 0) { tap3<true, true, false>(t.x, tb, w, acc[0]); tap3<true, true, true>(t.y, tb, w, acc[PXL - 1]); }
-                else if (CLAMPED && k == NT - 1) { tap3<true, false, false, true>(t.x, tb, w, acc[0]); tap3<true, false, true, true>(t.y, tb, w, acc[PXL - 1]); }
-                else { tap3<true, false, false>(t.x, tb, w, acc[0]); tap3<true, false, true>(t.y, tb, w, acc[PXL - 1]); }
+                const uint32_t tb = tp[PXL];
+                if (k == 0) { tap3<true, true, false>(t0, tb, w, acc[0]); tap3<true, true, true>(t1, tb, w, acc[PXL - 1]); }
+                else if (CLAMPED && k == NT - 1) { tap3<true, false, false, true>(t0, tb, w, acc[0]); tap3<true, false, true, true>(t1, tb, w, acc[PXL - 1]); }
+                else { tap3<true, false, false>(t0, tb, w, acc[0]); tap3<true, false, true>(t1, tb, w, acc[PXL - 1]); }
             } else {
-                if (k == 0) tap3<true, true>(t.x, t.y, w, acc[0]);
-                else if (CLAMPED && k == NT - 1) tap3<true, false, false, true>(t.x, t.y, w, acc[0]);
-                else tap3<true, false>(t.x, t.y, w, acc[0]);
+                if (k == 0) tap3<true, true>(t0, t1, w, acc[0]);
+                else if (CLAMPED && k == NT - 1) tap3<true, false, false, true>(t0, t1, w, acc[0]);
+                else tap3<true, false>(t0, t1, w, acc[0]);
             }
         }
         if (!CLAMPED && Q.y_norm) {
-            const float inv = 1.0f / Q.ywsum[y];
+            const float inv = 1.0f / as_const(Q.ywsum)[y];
 #pragma unroll
             for (int q = 0; q < PXL; q++) { acc[q][0] *= inv; acc[q][1] *= inv; acc[q][2] *= inv; }
         }
@@ -389,7 +401,7 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
     StripArgs q{};
     q.xi_t = S.tx.idx_t; q.xw_t = S.tx.w_t; q.xwsum = S.tx.wsum;
     q.yi = S.ty.idx; q.yw = S.ty.w; q.ywsum = S.ty.wsum;
-    q.yrange = (const int2 *)S.yrange; q.xstrip = (const int2 *)S.xstrip;
+    q.yrange = (const int32_t *)S.yrange; q.xstrip = (const int32_t *)S.xstrip;
     q.ntx = S.tx.ntaps; q.nty = S.ty.ntaps; q.x_norm = S.tx.normalise; q.y_norm = S.ty.normalise;
     q.out_w = S.out_w; q.out_h = S.out_h;
     q.strip_w = S.strip_w; q.n_strips = (S.out_w + S.strip_w - 1) / S.strip_w;
