@@ -584,14 +584,26 @@ HRESULT CHipVideoProcessor::UpdatePlan()
 
     // the arbitrary-ratio fused kernel takes an unrotated two-pass resize of a 4:2:0 source whose tables fit it
     m_strip = false;
-    if (m_plan.two_pass && !m_firstJinc && !m_secondJinc && m_firstAxis == 0 && !m_firstSwap && m_plan.rotation == 0 &&
+    static const bool no_strip_env = [] { const char *e = std::getenv("MPCVR_NO_STRIP"); return e && *e && *e != '0'; }();
+    if (!no_strip_env && m_plan.two_pass && !m_firstJinc && !m_secondJinc && m_firstAxis == 0 && !m_firstSwap && m_plan.rotation == 0 &&
         !m_plan.flip && m_plan.convert && !m_doviValid && m_plan.internal_fmt != SF_RGBA16F &&
         !(m_cfg.flags & (MPCVR_FLAG_NO_FUSED | MPCVR_FLAG_NO_FAST_CONVERT | MPCVR_FLAG_NO_STRIP)) &&
         PlanFusedStrip(hx, hy, w2, h2, w1, h1, &m_stripPlan)) {
-        const size_t ny = m_stripPlan.yrange.size(), nx = m_stripPlan.xstrip.size();
-        std::vector<int32_t> pack(ny + nx);
-        std::copy(m_stripPlan.yrange.begin(), m_stripPlan.yrange.end(), pack.begin());
-        std::copy(m_stripPlan.xstrip.begin(), m_stripPlan.xstrip.end(), pack.begin() + ny);
+        // one buffer: yrange | xstrip | xi_t | xw_t | yi | yw  (all 4-byte words)
+        const StripPlan &sp = m_stripPlan;
+        std::vector<int32_t> pack;
+        auto put = [&pack](const void *src, size_t words) {
+            const size_t at = pack.size();
+            pack.resize(at + words);
+            std::memcpy(pack.data() + at, src, words * 4);
+            return at;
+        };
+        m_stripOff[0] = put(sp.yrange.data(), sp.yrange.size());
+        m_stripOff[1] = put(sp.xstrip.data(), sp.xstrip.size());
+        m_stripOff[2] = put(sp.xi_t.data(), sp.xi_t.size());
+        m_stripOff[3] = put(sp.xw_t.data(), sp.xw_t.size());
+        m_stripOff[4] = put(sp.yi.data(), sp.yi.size());
+        m_stripOff[5] = put(sp.yw.data(), sp.yw.size());
         if ((hr = CheckHip(m_stripTab.CheckCreate(pack.size() * sizeof(int32_t)), "strip tables"))) return hr;
         if ((hr = CheckHip(hipMemcpy(m_stripTab.ptr, pack.data(), pack.size() * sizeof(int32_t), hipMemcpyHostToDevice), "strip tables upload"))) return hr;
         m_strip = true;
@@ -882,7 +894,7 @@ HRESULT CHipVideoProcessor::ResizeShaderPass(void *rt, int rtPitch, const uint8_
     if (m_plan.two_pass && !plain && !m_firstJinc && !m_secondJinc && m_firstAxis == 0 && !m_firstSwap &&
         Resize2DSupported(conv, m_tapsX, m_tapsY, last)) {
         // both draws in one LDS-tiled kernel: m_TexResize stays on chip
-        hr = CheckHip(LaunchResize2D(conv, m_tapsX, m_tapsY, (const int32_t *)m_otherX.ptr, w2, h2, last, m_run), "k_resize_2d");
+        hr = CheckHip(LaunchResize2D(conv, m_tapsX, m_tapsY, (const int32_t *)m_otherX.ptr, m_plan.mid_h, w2, h2, last, m_run), "k_resize_2d");
     } else if (m_plan.two_pass) {
         Surface mid{m_runMid, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
         StoreParams st = MakeStore(mid.ptr, mid.pitch, SF_RGBA16F, false);
@@ -916,11 +928,12 @@ bool CHipVideoProcessor::FillStripParams(const uint8_t *sample, void *dst, int d
 {
     FillFusedParams(sample, dst, dstPitch, &sp->fp);
     sp->fp.store = store;
-    sp->tx = m_tapsX; sp->ty = m_tapsY;
-    sp->yrange = m_stripTab.ptr;
-    sp->xstrip = (const int32_t *)m_stripTab.ptr + m_stripPlan.yrange.size();
+    const int32_t *tab = (const int32_t *)m_stripTab.ptr;
+    sp->yrange = tab + m_stripOff[0]; sp->xstrip = tab + m_stripOff[1];
+    sp->xi_t = tab + m_stripOff[2]; sp->xw_t = tab + m_stripOff[3];
+    sp->yi = tab + m_stripOff[4]; sp->yw = tab + m_stripOff[5];
     sp->out_w = m_videoRect.Width(); sp->out_h = m_videoRect.Height();
-    sp->pxl = m_stripPlan.pxl; sp->strip_w = m_stripPlan.strip_w; sp->ring = m_stripPlan.ring; sp->acols = m_stripPlan.acols;
+    sp->nt = m_stripPlan.nt; sp->pxl = m_stripPlan.pxl; sp->strip_w = m_stripPlan.strip_w; sp->ring = m_stripPlan.ring; sp->acols = m_stripPlan.acols;
     return FusedStripSupported(*sp) && FusedStripLdsBytes(*sp) <= 160 * 1024;
 }
 
@@ -1163,7 +1176,7 @@ HRESULT CHipVideoProcessor::ProcessBatchLaunches(int n, const FusedFrame *table,
         ResizeBatch b1; b1.n = m; b1.in_stride = m_convBytes;
         if (m_plan.two_pass && m_firstAxis == 0 && !m_firstSwap && Resize2DSupported(cs, m_tapsX, m_tapsY, final)) {
             b1.frames = tab;
-            if ((hr = CheckHip(LaunchResize2D(cs, m_tapsX, m_tapsY, (const int32_t *)m_otherX.ptr, w2, h2, final, m_stream, &b1), "k_resize_2d"))) return hr;
+            if ((hr = CheckHip(LaunchResize2D(cs, m_tapsX, m_tapsY, (const int32_t *)m_otherX.ptr, m_plan.mid_h, w2, h2, final, m_stream, &b1), "k_resize_2d"))) return hr;
         } else if (m_plan.two_pass) {
             const Surface mid{m_batchMid.ptr, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
             b1.dst_stride = m_midBytes;
@@ -1335,7 +1348,9 @@ std::string CHipVideoProcessor::GetPathInfo()
 {
     if (!m_srcParams) return "uninitialised";
     if (m_planDirty && UpdatePlan() != MPCVR_S_OK) return "error: " + m_lastError;
-    return m_plan.describe() + (m_strip && !m_plan.fused_up2x ? ";kernel=fused_strip" : "");
+    if (!m_strip || m_plan.fused_up2x) return m_plan.describe();
+    return m_plan.describe() + ";kernel=fused_strip(taps=" + std::to_string(m_stripPlan.nt) + ",px_per_lane=" + std::to_string(m_stripPlan.pxl) +
+           ",strip=" + std::to_string(m_stripPlan.strip_w) + ",ring=" + std::to_string(m_stripPlan.ring) + ")";
 }
 
 HRESULT CHipVideoProcessor::GetLastProcessMs(float *ms)

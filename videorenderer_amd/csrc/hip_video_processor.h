@@ -209,7 +209,8 @@ private:
     // arbitrary-ratio fused kernel (vp_fused_strip.hip): geometry planned with the tap tables (UpdatePlan)
     bool m_strip = false;
     StripPlan m_stripPlan;
-    DevBuffer m_stripTab;          // yrange (int2 per output row) followed by xstrip (int2 per strip)
+    DevBuffer m_stripTab;          // yrange | xstrip | xi_t | xw_t | yi | yw, word offsets in m_stripOff
+    size_t m_stripOff[6] = {0, 0, 0, 0, 0, 0};
     bool FillStripParams(const uint8_t *sample, void *dst, int dstPitch, const StoreParams &store, FusedStripParams *sp) const;
     bool BatchPlan(const uint8_t *sample0, void *rt0, int rtPitch, bool aligned, FusedParams *conv, FusedParams *direct) const;
     HRESULT ProcessBatchLaunches(int n, const FusedFrame *table, const uint8_t *sample0, void *rt0, int rtPitch, bool aligned);

@@ -28,11 +28,12 @@ namespace mpcvr {
 namespace {
 
 struct StripArgs {
-    const int32_t *xi_t; const float *xw_t; const float *xwsum;     // X tap tables, tap-major [k][out_w]
-    const int32_t *yi; const float *yw; const float *ywsum;         // Y tap tables, row-major [y][nty]
+    // PlanFusedStrip's copies of the two tap tables: NT taps per output (zero-weight padding), ps_convolution's
+    // normalisation folded into the weights
+    const int32_t *xi_t; const float *xw_t;     // X taps, tap-major [NT][out_w]
+    const int32_t *yi; const float *yw;         // Y taps, row-major [out_h][NT]
     const int32_t *yrange;       // [out_h][2] {smallest, largest} source row any tap of output row y reads
     const int32_t *xstrip;       // [n_strips][2] {smallest, largest} source column any tap of the strip reads
-    int ntx, nty, x_norm, y_norm;
     int out_w, out_h;
     int n_strips, strip_w;       // output columns per strip (<= 64 * PXL, a multiple of PXL)
     int ring_mask;               // ring rows - 1 (8 or 16 rows)
@@ -95,7 +96,7 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// NT: taps per axis held in registers (4, 6: exactly that many on both axes; 8: up to 8, run-time counts, zero-padded)
+// NT: taps per output on both axes (4, 6 or 8; the host pads shorter tables with zero weights)
 template <int NT, int PXL, int TAIL, int SRC, int EPI>
 __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, StoreParams st, const FusedFrame *__restrict__ frames, FusedFrame single)
 {
@@ -155,15 +156,10 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
 #pragma unroll
     for (int q = 0; q < PXL; q++) {
         const int xc = min(x_first + q, Q.out_w - 1);
-        const float nrm = Q.x_norm ? 1.0f / Q.xwsum[xc] : 1.0f;
-        const int i0 = Q.xi_t[xc];
 #pragma unroll
         for (int k = 0; k < NT; k++) {
-            const bool on = NT != 8 || k < Q.ntx;
-            const int idx = on ? Q.xi_t[xc + (size_t)k * Q.out_w] : i0;
-            const float w = on ? Q.xw_t[xc + (size_t)k * Q.out_w] : 0.0f;
-            xo[q][k] = (uint32_t)(idx - c0) * 16u;
-            xw[q][k] = w * nrm * Q.a_scale;
+            xo[q][k] = (uint32_t)(Q.xi_t[xc + (size_t)k * Q.out_w] - c0) * 16u;
+            xw[q][k] = Q.xw_t[xc + (size_t)k * Q.out_w] * Q.a_scale;
         }
     }
 
@@ -265,11 +261,11 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
         while (have < hi) { produce(p); have = 2 * p; p++; }
         if (!xy_active) continue;
         // ---------------- stage Y + final pass ----------------
-        const cptr<int32_t> yi = as_const(Q.yi) + (size_t)y * Q.nty;
-        const cptr<float> yw = as_const(Q.yw) + (size_t)y * Q.nty;
+        const cptr<int32_t> yi = as_const(Q.yi) + (size_t)y * NT;
+        const cptr<float> yw = as_const(Q.yw) + (size_t)y * NT;
         float acc[PXL][3];
-        // with the tap count known at compile time (and nothing to normalise) the last tap saturates in the FMA itself
-        constexpr bool CLAMPED = NT != 8;
+        // the last tap saturates in the FMA itself (a zero-weight padding tap saturates just the same)
+        constexpr bool CLAMPED = true;
         uint32_t dj[PXL];
         if (FASTEPI) {          // dither texels first: the LDS round trip hides behind the taps
             const uint32_t *drow = Di + ((P.off_y + y) & 31) * 32;
@@ -283,7 +279,6 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
         }
 #pragma unroll
         for (int k = 0; k < NT; k++) {
-            if (NT == 8 && k >= Q.nty) break;
             const int slot_off = (yi[k] & Q.ring_mask) * ring_row;
             const float w = yw[k];
             const lds_u32 tp = (lds_u32)(ring_addr + (uint32_t)slot_off);
@@ -298,11 +293,6 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
                 else if (CLAMPED && k == NT - 1) tap3<true, false, false, true>(t0, t1, w, acc[0]);
                 else tap3<true, false>(t0, t1, w, acc[0]);
             }
-        }
-        if (!CLAMPED && Q.y_norm) {
-            const float inv = 1.0f / as_const(Q.ywsum)[y];
-#pragma unroll
-            for (int q = 0; q < PXL; q++) { acc[q][0] *= inv; acc[q][1] *= inv; acc[q][2] *= inv; }
         }
         if (FASTEPI) {
             // m_TexsPostScale store/load + ps_final_pass.hlsl:29 in integers, see vp_fused.hip
@@ -363,8 +353,8 @@ bool FusedStripSupported(const FusedStripParams &S)
     if ((uint64_t)c.pitch[0] * (uint64_t)(c.rect_t + c.out_h + 2) >= (1ull << 32)) return false;
     if ((uint64_t)P.plane_off[1] >= (1ull << 31) || (uint64_t)P.plane_off[2] >= (1ull << 31)) return false;
     if (P.store.off_x + S.out_w > 0 && (uint64_t)P.store.dst_pitch * (uint64_t)(std::max(P.store.off_y, 0) + S.out_h) >= (1ull << 32)) return false;
-    if (S.tx.ntaps < 1 || S.tx.ntaps > 8 || S.ty.ntaps < 1 || S.ty.ntaps > 8) return false;
-    if (!S.tx.idx_t || !S.tx.w_t || !S.ty.idx || !S.ty.w || !S.yrange || !S.xstrip) return false;
+    if (S.nt != 4 && S.nt != 6 && S.nt != 8) return false;
+    if (!S.xi_t || !S.xw_t || !S.yi || !S.yw || !S.yrange || !S.xstrip) return false;
     if (S.ring != 8 && S.ring != 16) return false;
     if (S.pxl != 1 && S.pxl != 2) return false;
     if (S.strip_w < S.pxl || S.strip_w > 64 * S.pxl || (S.strip_w % S.pxl)) return false;
@@ -399,10 +389,9 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
     FusedArgs a;
     FillFusedArgs(P, a);
     StripArgs q{};
-    q.xi_t = S.tx.idx_t; q.xw_t = S.tx.w_t; q.xwsum = S.tx.wsum;
-    q.yi = S.ty.idx; q.yw = S.ty.w; q.ywsum = S.ty.wsum;
+    q.xi_t = (const int32_t *)S.xi_t; q.xw_t = (const float *)S.xw_t;
+    q.yi = (const int32_t *)S.yi; q.yw = (const float *)S.yw;
     q.yrange = (const int32_t *)S.yrange; q.xstrip = (const int32_t *)S.xstrip;
-    q.ntx = S.tx.ntaps; q.nty = S.ty.ntaps; q.x_norm = S.tx.normalise; q.y_norm = S.ty.normalise;
     q.out_w = S.out_w; q.out_h = S.out_h;
     q.strip_w = S.strip_w; q.n_strips = (S.out_w + S.strip_w - 1) / S.strip_w;
     q.ring_mask = S.ring - 1;
@@ -427,8 +416,7 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
     const size_t lds = StripLds(S, fastepi, tailk == TAILK_PQ_LUT, waves);
     const int n_segs = (S.out_h + q.seg_rows - 1) / q.seg_rows;
     const dim3 grid((q.n_strips * n_segs + waves - 1) / waves, 1, n_frames), block(64 * waves, 1, 1);
-    const int ntk = (S.pxl == 2 && S.tx.ntaps == S.ty.ntaps && !S.tx.normalise && !S.ty.normalise && (S.tx.ntaps == 4 || S.tx.ntaps == 6)) ? S.tx.ntaps : 8;
-    if (ntk == 8 && S.pxl != 1) return hipErrorNotSupported;
+    const int ntk = S.nt;
 #define MPCVR_ST5(NT, PX, TK, SK, EK) do { \
         auto kern = k_fused_strip<NT, PX, TK, SK, EK>; \
         if (lds > 48 * 1024) { \
@@ -441,8 +429,11 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
                                    else MPCVR_ST4(NT, PX, TK, SRC_GENERIC); } while (0)
 #define MPCVR_ST2(NT, PX) do { if (tailk == TAILK_NONE) MPCVR_ST3(NT, PX, TAILK_NONE); else if (tailk == TAILK_PQ_LUT) MPCVR_ST3(NT, PX, TAILK_PQ_LUT); \
                                else if (tailk == TAILK_HLG) MPCVR_ST3(NT, PX, TAILK_HLG); else MPCVR_ST3(NT, PX, TAILK_ALU); } while (0)
-    if (ntk == 4) MPCVR_ST2(4, 2);
-    else if (ntk == 6) MPCVR_ST2(6, 2);
+    if (ntk == 4 && S.pxl == 2) MPCVR_ST2(4, 2);
+    else if (ntk == 6 && S.pxl == 2) MPCVR_ST2(6, 2);
+    else if (ntk == 8 && S.pxl == 2) MPCVR_ST2(8, 2);
+    else if (ntk == 4) MPCVR_ST2(4, 1);
+    else if (ntk == 6) MPCVR_ST2(6, 1);
     else MPCVR_ST2(8, 1);
 #undef MPCVR_ST2
 #undef MPCVR_ST3

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void k_resize_cols(Surface in, AxisTaps taps, 
 // straight into the final pass.  m_TexResize never exists in memory, and the Y draw's taps — the L2 reads the row kernel
 // spends most of its time on — become LDS reads.  Same tap order, same roundings as the two kernels above.
 template <int NT, int INFMT, int EPI>
-__global__ __launch_bounds__(256) void k_resize_2d(Surface in, AxisTaps tx, AxisTaps ty, const int32_t *__restrict__ other,
+__global__ __launch_bounds__(256) void k_resize_2d(Surface in, AxisTaps tx, AxisTaps ty, const int32_t *__restrict__ other, int mid_h,
                                                   int out_w, int out_h, int tiles_x, int tiles_y, StoreParams st, ResizeBatch bt)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char resize_smem[];
@@ -402,7 +402,9 @@ __global__ __launch_bounds__(256) void k_resize_2d(Surface in, AxisTaps tx, Axis
     const int x = txi * 64 + lane, xc = min(x, out_w - 1);
     const int ntx = NT ? NT : tx.ntaps, nty = NT ? NT : ty.ntaps;
     const int loX = tx.blk_lo[txi], nX = min(tx.blk_span, in.w - loX);
-    const int loY = ty.blk32_lo[tyi], nY = min(spanY, in.h - loY);
+    // rows of the X draw's result (m_TexResize) = entries of `other`: mid_h, which is the source RECT's height — not in.h when the
+    // draw reads the source texture itself (interleaved RGB without a convert draw)
+    const int loY = ty.blk32_lo[tyi], nY = min(spanY, mid_h - loY);
     constexpr int NTC = NT ? NT : 1;
     // the X taps of this lane's column, once (tap-major tables)
     int ix[NTC]; float wx[NTC];
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(256) void k_resize_2d(Surface in, AxisTaps tx, Axis
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int rr = wave + 4 * h;
-                const int o = other[min(loY + c0 + rr, in.h - 1)];
+                const int o = other[min(loY + c0 + rr, mid_h - 1)];
 #pragma unroll
                 for (int it = 0; it < IT; it++) {
                     const int p = lane + 64 * it;
@@ -869,13 +871,13 @@ static bool LaunchResizeFastN(int epi, bool rows, const Surface &in, const AxisT
 }
 
 template <int NT, int INFMT>
-static bool LaunchResize2DE(int epi, const Surface &in, const AxisTaps &tx, const AxisTaps &ty, const int32_t *other, int out_w, int out_h,
+static bool LaunchResize2DE(int epi, const Surface &in, const AxisTaps &tx, const AxisTaps &ty, const int32_t *other, int mid_h, int out_w, int out_h,
                             const StoreParams &st, hipStream_t s, const ResizeBatch &bt)
 {
     const int tiles_x = (out_w + 63) / 64, tiles_y = (out_h + 31) / 32;
     const dim3 grid((tiles_x * tiles_y * bt.n + 7) / 8 * 8, 1, 1), block(256, 1, 1);
     const size_t lds = (size_t)8 * ((tx.blk_span + 3) & ~3) * sizeof(float4) + (size_t)ty.blk32_span * 64 * sizeof(uint2);
-#define MPCVR_R2D(E) hipLaunchKernelGGL((k_resize_2d<NT, INFMT, E>), grid, block, lds, s, in, tx, ty, other, out_w, out_h, tiles_x, tiles_y, st, bt)
+#define MPCVR_R2D(E) hipLaunchKernelGGL((k_resize_2d<NT, INFMT, E>), grid, block, lds, s, in, tx, ty, other, mid_h, out_w, out_h, tiles_x, tiles_y, st, bt)
     switch (epi) {
     case EPI_FINAL_10_TO_8: MPCVR_R2D(EPI_FINAL_10_TO_8); return true;
     case EPI_FINAL_16F_TO_8: MPCVR_R2D(EPI_FINAL_16F_TO_8); return true;
@@ -899,7 +901,7 @@ bool Resize2DSupported(const Surface &in, const AxisTaps &tx, const AxisTaps &ty
     return true;          // equal tap counts of 4 or 6 get the unrolled instantiation, anything else the run-time loops
 }
 
-hipError_t LaunchResize2D(const Surface &in, const AxisTaps &tx, const AxisTaps &ty, const int32_t *other, int out_w, int out_h,
+hipError_t LaunchResize2D(const Surface &in, const AxisTaps &tx, const AxisTaps &ty, const int32_t *other, int mid_h, int out_w, int out_h,
                           const StoreParams &st, hipStream_t s, const ResizeBatch *batch)
 {
     if (!Resize2DSupported(in, tx, ty, st)) return hipErrorNotSupported;
@@ -907,9 +909,9 @@ hipError_t LaunchResize2D(const Surface &in, const AxisTaps &tx, const AxisTaps 
     const int epi = EpiOf(st);
     const int nt = (tx.ntaps == ty.ntaps && (tx.ntaps == 4 || tx.ntaps == 6)) ? tx.ntaps : 0;
     bool done = false;
-#define MPCVR_R2D_F(F) (nt == 4 ? LaunchResize2DE<4, F>(epi, in, tx, ty, other, out_w, out_h, st, s, bt) \
-                       : nt == 6 ? LaunchResize2DE<6, F>(epi, in, tx, ty, other, out_w, out_h, st, s, bt) \
-                                 : LaunchResize2DE<0, F>(epi, in, tx, ty, other, out_w, out_h, st, s, bt))
+#define MPCVR_R2D_F(F) (nt == 4 ? LaunchResize2DE<4, F>(epi, in, tx, ty, other, mid_h, out_w, out_h, st, s, bt) \
+                       : nt == 6 ? LaunchResize2DE<6, F>(epi, in, tx, ty, other, mid_h, out_w, out_h, st, s, bt) \
+                                 : LaunchResize2DE<0, F>(epi, in, tx, ty, other, mid_h, out_w, out_h, st, s, bt))
     if (in.fmt == SF_BGRA8) done = MPCVR_R2D_F(SF_BGRA8);
     else if (in.fmt == SF_RGB10A2) done = MPCVR_R2D_F(SF_RGB10A2);
     else done = MPCVR_R2D_F(SF_RGBA16F);

@@ -25,7 +25,8 @@ hipError_t LaunchResize(int axis, bool swap, const Surface &in, const AxisTaps &
 bool ResizeHasFoldedKernel(int axis, bool swap, const Surface &in, const AxisTaps &taps, const StoreParams &st);
 // both draws of an unrotated two-pass resize in one LDS-tiled kernel (no m_TexResize in memory); st = the second draw's epilogue
 bool Resize2DSupported(const Surface &in, const AxisTaps &tx, const AxisTaps &ty, const StoreParams &st);
-hipError_t LaunchResize2D(const Surface &in, const AxisTaps &tx, const AxisTaps &ty, const int32_t *other, int out_w, int out_h,
+// mid_h = rows of the first draw's result (entries of `other`): the source rect's extent along screen y
+hipError_t LaunchResize2D(const Surface &in, const AxisTaps &tx, const AxisTaps &ty, const int32_t *other, int mid_h, int out_w, int out_h,
                           const StoreParams &st, hipStream_t s, const ResizeBatch *batch = nullptr);
 hipError_t LaunchCopy(const Surface &in, int out_w, int out_h, const StoreParams &st, hipStream_t s);
 // m_pPSCorrection shaders as a same-size pass (kind = MPCVR_CORR_*); fix16 = the kind's 4x4 fix-up matrix (unused for 5, 6)
@@ -74,11 +75,13 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
 // kernel, driven by the tap tables of BuildAxisTaps; wave-autonomous strips like the 2x kernel, the vertical window in LDS.
 struct FusedStripParams {
     FusedParams fp;            // conv / plane_off / store / pq_lut / alignment flags (wx, wy, out_w, out_h of fp are not used)
-    AxisTaps tx, ty;           // device tap tables of the two draws (tx: idx_t / w_t tap-major; ty: idx / w row-major)
-    const void *yrange;        // device int2[out_h]: {smallest, largest} source row of every output row's taps
-    const void *xstrip;        // device int2[n_strips]: {smallest, largest} source column of every strip's taps
+    // device copies of PlanFusedStrip's tables: nt taps per output, zero-weight padding, normalisation folded in
+    const void *xi_t, *xw_t;   // X taps, tap-major: int32 / float [nt][out_w]
+    const void *yi, *yw;       // Y taps, row-major: int32 / float [out_h][nt]
+    const void *yrange;        // int32[out_h][2]: {smallest, largest} source row of every output row's taps
+    const void *xstrip;        // int32[n_strips][2]: {smallest, largest} source column of every strip's taps
     int out_w, out_h;
-    int pxl, strip_w, ring, acols;   // PlanFusedStrip's choices
+    int nt, pxl, strip_w, ring, acols;   // PlanFusedStrip's choices
 };
 bool FusedStripSupported(const FusedStripParams &S);
 hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);

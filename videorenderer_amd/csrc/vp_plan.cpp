@@ -541,23 +541,27 @@ bool PlanFusedStrip(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x,
         clo[x] = *mm.first; chi[x] = *mm.second;
         if (clo[x] < 0 || chi[x] >= src_w) return false;
     }
-    const bool reg_taps = hx.ntaps == hy.ntaps && (hx.ntaps == 4 || hx.ntaps == 6) && !hx.normalise && !hy.normalise;
-    sp->pxl = (reg_taps && src_w <= n_out_x) ? 2 : 1;
+    const int mt = std::max(hx.ntaps, hy.ntaps);
+    sp->nt = mt <= 4 ? 4 : mt <= 6 ? 6 : 8;
     const double pairs_per_row = 0.5 * (double)src_h / (double)n_out_y;
     double best = 0;
-    int best_w = 0, best_cols = 0;
-    for (int lanes : {64, 56, 48, 40, 32, 24, 16}) {
-        const int sw = lanes * sp->pxl;
-        int max_nb = 0;
-        for (int x0 = 0; x0 < n_out_x; x0 += sw) {
-            const int x1 = std::min(n_out_x, x0 + sw);
-            const int lo = *std::min_element(clo.begin() + x0, clo.begin() + x1), hi = *std::max_element(chi.begin() + x0, chi.begin() + x1);
-            max_nb = std::max(max_nb, ((hi - (lo & ~1)) >> 1) + 1);
+    int best_w = 0, best_cols = 0, best_pxl = 1;
+    for (int pxl : {1, 2})
+        for (int lanes : {64, 56, 48, 40, 32, 24, 16}) {
+            const int sw = lanes * pxl;
+            int max_nb = 0;
+            for (int x0 = 0; x0 < n_out_x; x0 += sw) {
+                const int x1 = std::min(n_out_x, x0 + sw);
+                const int lo = *std::min_element(clo.begin() + x0, clo.begin() + x1), hi = *std::max_element(chi.begin() + x0, chi.begin() + x1);
+                max_nb = std::max(max_nb, ((hi - (lo & ~1)) >> 1) + 1);
+            }
+            const int passes = (max_nb + 63) / 64;
+            // VALU instructions of a lane (counted in the ISA): convert pass 175, X stage pxl * (6 nt + 3) + 6 per row pair,
+            // Y stage pxl * (3 nt + 7) + nt + 6 per output row
+            const double cost = (pairs_per_row * (passes * 175.0 + pxl * (6.0 * sp->nt + 3.0) + 6.0) + pxl * (3.0 * sp->nt + 7.0) + sp->nt + 6.0) / (double)sw;
+            if (!best_w || cost < best) { best = cost; best_w = sw; best_cols = 2 * max_nb; best_pxl = pxl; }
         }
-        const int passes = (max_nb + 63) / 64;
-        const double cost = (pairs_per_row * (passes * 250.0 + 2.0 * sp->pxl * (3.0 * hx.ntaps + 4.0)) + sp->pxl * (3.0 * hy.ntaps + 14.0)) / (double)sw;
-        if (!best_w || cost < best) { best = cost; best_w = sw; best_cols = 2 * max_nb; }
-    }
+    sp->pxl = best_pxl;
     sp->strip_w = best_w; sp->acols = best_cols;
     const int n_strips = (n_out_x + best_w - 1) / best_w;
     sp->xstrip.resize(2 * (size_t)n_strips);
@@ -565,6 +569,26 @@ bool PlanFusedStrip(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x,
         const int x0 = s * best_w, x1 = std::min(n_out_x, x0 + best_w);
         sp->xstrip[2 * s] = *std::min_element(clo.begin() + x0, clo.begin() + x1);
         sp->xstrip[2 * s + 1] = *std::max_element(chi.begin() + x0, chi.begin() + x1);
+    }
+    // the tables as the kernel reads them
+    const int nt = sp->nt;
+    sp->xi_t.assign((size_t)nt * n_out_x, 0); sp->xw_t.assign((size_t)nt * n_out_x, 0.0f);
+    for (int x = 0; x < n_out_x; x++) {
+        const float ww = hx.normalise ? hx.wsum[x] : 1.0f;
+        for (int k = 0; k < nt; k++) {
+            const bool on = k < hx.ntaps;
+            sp->xi_t[(size_t)k * n_out_x + x] = hx.idx[(size_t)x * hx.ntaps + (on ? k : 0)];
+            sp->xw_t[(size_t)k * n_out_x + x] = on ? (hx.normalise ? hx.w[(size_t)x * hx.ntaps + k] / ww : hx.w[(size_t)x * hx.ntaps + k]) : 0.0f;
+        }
+    }
+    sp->yi.assign((size_t)nt * n_out_y, 0); sp->yw.assign((size_t)nt * n_out_y, 0.0f);
+    for (int y = 0; y < n_out_y; y++) {
+        const float ww = hy.normalise ? hy.wsum[y] : 1.0f;
+        for (int k = 0; k < nt; k++) {
+            const bool on = k < hy.ntaps;
+            sp->yi[(size_t)y * nt + k] = hy.idx[(size_t)y * hy.ntaps + (on ? k : 0)];
+            sp->yw[(size_t)y * nt + k] = on ? (hy.normalise ? hy.w[(size_t)y * hy.ntaps + k] / ww : hy.w[(size_t)y * hy.ntaps + k]) : 0.0f;
+        }
     }
     return true;
 }

@@ -113,12 +113,17 @@ void BuildPointIndex(int src_l, int src_len, int n_out, int tex_len, std::vector
 
 // ---- arbitrary-ratio fused kernel (vp_fused_strip.hip): strip geometry from the two tap tables ----
 struct StripPlan {
-    int pxl = 1;                 // output pixels per lane (2 for 4- / 6-tap upscales)
+    int nt = 4;                  // taps per output the kernel runs on both axes (4, 6 or 8; shorter tables are zero-padded)
+    int pxl = 1;                 // output pixels per lane
     int strip_w = 64;            // output columns per wavefront
     int ring = 8;                // rows of the vertical LDS window (8 or 16)
     int acols = 0;               // columns of a converted source row the widest strip needs (even)
     std::vector<int32_t> yrange; // [2 * n_out_y] {lo, hi} source row per output row
     std::vector<int32_t> xstrip; // [2 * n_strips] {lo, hi} source column per strip
+    // the tap tables as the kernel reads them: nt taps per output (padding: weight 0 on the first tap's texel), weights
+    // divided by ps_convolution's weight sum where the draw normalises
+    std::vector<int32_t> xi_t, yi;   // [nt][n_out_x] tap-major, [n_out_y][nt] row-major
+    std::vector<float> xw_t, yw;
 };
 // false: the tables do not fit the kernel (more than 8 taps, a vertical span above 15 rows, non-monotonic tables)
 bool PlanFusedStrip(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x, int n_out_y, int src_w, int src_h, StripPlan *sp);
