@@ -295,7 +295,8 @@ def test_process_batch_equals_single(mpcvr, torch_cuda):
     # same-size direct, 8-bit and 10-bit sources, a source rect, a letterboxed window)
     for name, flags in (("noise_p010_pq_lanczos3_2x", 0), ("noise_p010_pq_lanczos3_2x", 2), ("down_lanczos_2p5x", 0),
                         ("up_1p5x_lanczos3", 0), ("x_only_resize", 0), ("y_only_resize", 0), ("c1_nv12_bt709_passthrough", 0),
-                        ("mild_down_uses_upscaler", 0), ("crop_offset_letterbox", 0), ("down_hamming_3x", 0), ("c5_p010_hlg_lanczos3_2x", 8)):
+                        ("mild_down_uses_upscaler", 0), ("crop_offset_letterbox", 0), ("down_hamming_3x", 0), ("c5_p010_hlg_lanczos3_2x", 8),
+                        ("up_1p5x_lanczos3", 64), ("down_lanczos_2p5x", 64)):      # 64 = NO_STRIP: block convert + tiled two-draw kernel
         c = GOLDEN_CASES[name]
         vp, (ww, wh) = make_vp(mpcvr, c, flags)
         c = dict(c, kind="noise")        # distinct frames whatever the case's own content
@@ -512,6 +513,46 @@ def test_full_size_4k_to_8k(mpcvr, oracle, torch_cuda, label, exfmt, up):
         assert bool((got[..., 3] == 255).all())
         same = compare(got, want, f"{label} flags={flags}", exact=(min_same == 1.0), min_same=min_same)
         print(f"{label} flags={flags}: identical channels {same:.6f}")
+
+
+STRIP_FULL = [
+    ("p010_pq_1080p_to_1440p_lanczos3", dict(cformat=2, w=1920, h=1080, kind="noise", seed=311, dst=(2560, 1440), iUpscaling=4,
+                                             exfmt=GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"])),
+    ("p010_pq_4k_to_1440p_hamming", dict(cformat=2, w=3840, h=2160, kind="noise", seed=312, dst=(2560, 1440), iDownscaling=2,
+                                         exfmt=GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"])),
+    ("nv12_720p_to_1080p_catmull_odd_window", dict(cformat=1, w=1280, h=720, kind="noise", seed=313, dst=(1919, 1079), iUpscaling=2,
+                                                   window=(1931, 1090), offset=(5, 3),
+                                                   exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
+    ("yuv420p10_up_x_down_y", dict(cformat=20, w=1280, h=1440, kind="noise", seed=314, dst=(1920, 800), iUpscaling=3, iDownscaling=5,
+                                   exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
+    ("nv12_1080p_down_2p6x_hamming", dict(cformat=1, w=1920, h=1080, kind="noise", seed=316, dst=(738, 416), iDownscaling=2, bInterpolateAt50pct=0,
+                                          exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
+    ("p010_1080p_down_1p2x_bicubic_no_interp", dict(cformat=2, w=1920, h=1080, kind="noise", seed=317, dst=(1600, 900), iDownscaling=3, bInterpolateAt50pct=0,
+                                                    exfmt=GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"])),
+    ("p010_hlg_4k_to_1080p_interp50", dict(cformat=2, w=3840, h=2160, kind="noise", seed=315, dst=(1920, 1080), iUpscaling=1,
+                                           exfmt=GOLDEN_CASES["c5_p010_hlg_lanczos3_2x"]["exfmt"])),
+]
+
+
+@pytest.mark.parametrize("label,c", STRIP_FULL)
+def test_strip_kernel_whole_frame_vs_oracle(mpcvr, oracle, torch_cuda, label, c):
+    """The arbitrary-ratio fused kernel (k_fused_strip) at real sizes, every output pixel against the oracle: 1.33x Lanczos3 and
+    1.5x Hamming down of HDR10 P010 (the up1440 / down1440 bench workloads), an odd-sized letterboxed NV12 upscale (8-bit
+    internal format, no final pass, generic epilogue), up along x / down along y in one frame (8-tap variant), and the 2x
+    downscale the interpolation shader takes at 50 %.  <= 1 LSB, >= 99 % of the channels identical; MPCVR_FLAG_NO_STRIP must
+    take the kernel out again (block convert + tiled two-draw kernel) under the same bar."""
+    torch = torch_cuda
+    from videorenderer_amd import api
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+    got, info = run_product(mpcvr, torch, c)
+    assert "kernel=fused_strip" in info, info
+    same = compare(got, want, f"{label} [{info}]", min_same=0.99)
+    alt, info_alt = run_product(mpcvr, torch, c, extra_flags=api.FLAG_NO_STRIP)
+    assert "kernel=fused_strip" not in info_alt and info_alt.startswith("passes:convert,resizeX,resizeY"), info_alt
+    same_alt = compare(alt, want, f"{label} [{info_alt}]", min_same=0.99)
+    print(f"{label}: identical channels strip {same:.6f}, tiled {same_alt:.6f}  [{info}]")
 
 
 def test_full_size_flat_frame_and_dither_period(mpcvr, torch_cuda):
