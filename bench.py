@@ -55,15 +55,16 @@ WORKLOADS = {
 }
 
 
-def csrc_digest():
-    """sha256 over the kernel / host sources: ties profiles/hbm_traffic.json to the code it was measured on."""
+def csrc_digest(sources=None):
+    """sha256 over kernel sources: ties an entry of profiles/hbm_traffic.json to the code it was measured on.  `sources` = the
+    files (under videorenderer_amd/csrc) the workload's kernel is built from, as recorded with the profile; None = all of them."""
     import hashlib
     d = os.path.join(ROOT, "videorenderer_amd", "csrc")
     h = hashlib.sha256()
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h", ".cpp", ".inc")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    names = sorted(sources) if sources else sorted(f for f in os.listdir(d) if f.endswith((".hip", ".h", ".cpp", ".inc")))
+    for f in names:
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()
 
 
@@ -335,7 +336,7 @@ def main():
                 doc = json.load(open(tf))
                 t = doc.get(args.workload)
                 if t and t.get("batch") == args.batch:
-                    if t.get("csrc_sha256") == csrc_digest():
+                    if t.get("csrc_sha256") == csrc_digest(t.get("sources")):
                         traffic = t["bytes_per_launch"]
                         traffic_source = f"profiles/hbm_traffic.json [{t.get('profile', '?')}]: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes"
                     else:

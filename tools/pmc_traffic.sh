@@ -19,6 +19,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 s += float(r["Counter_Value"]); n += 1
     tot[c] = (s, n)
 launches = steps + warm
-print(json.dumps({"workload": w, "steps_profiled": launches, "fetch_kb_per_step": tot["FETCH_SIZE"][0] / launches,
-                  "write_kb_per_step": tot["WRITE_SIZE"][0] / launches, "dispatches": tot["FETCH_SIZE"][1]}))
+line = json.dumps({"workload": w, "steps_profiled": launches, "fetch_kb_per_step": tot["FETCH_SIZE"][0] / launches,
+                   "write_kb_per_step": tot["WRITE_SIZE"][0] / launches, "dispatches": tot["FETCH_SIZE"][1]})
+print(line)
+open(f"gpurun_out/traffic_{w}.json", "w").write(line + "\n")      # tools/update_traffic.py folds it into profiles/hbm_traffic.json
 PY

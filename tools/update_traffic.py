@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""tools/update_traffic.py <workload> <batch> <profile-tag> — fold the output of tools/pmc_traffic.sh (gpurun_out/traffic_<w>.json,
+one JSON line: fetch_kb_per_step / write_kb_per_step) into profiles/hbm_traffic.json, together with the sha256 of the kernel
+sources the workload runs on, so that bench.py reports the figure only while those sources are unchanged."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+
+KERNEL_SOURCES = {
+    "c3hdr": ["vp_fused.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
+    "c1": ["vp_fused.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
+    "hdr4k": ["vp_fused.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
+    "up1440": ["vp_fused_strip.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
+    "down1440": ["vp_fused_strip.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
+}
+ALGO = {"c3hdr": 157593600, "c1": 11404800, "hdr4k": 58060800, "up1440": 20966400, "down1440": 39628800}
+
+w, batch, tag = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+m = json.loads([l for l in open(os.path.join(ROOT, "gpurun_out", f"traffic_{w}.json")) if l.startswith("{")][-1])
+doc_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+doc = json.load(open(doc_path))
+fetch, write = m["fetch_kb_per_step"], m["write_kb_per_step"]
+doc[w] = {"batch": batch, "fetch_kb": round(fetch), "write_kb": round(write),
+          "bytes_per_launch": int((2 * fetch + write) * 1024), "algorithmic_bytes_per_launch": ALGO[w] * batch,
+          "profile": tag, "sources": KERNEL_SOURCES[w], "csrc_sha256": bench.csrc_digest(KERNEL_SOURCES[w]),
+          "note": f"tools/pmc_traffic.sh {w}: FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate rocprofv3 --pmc passes, per {batch}-frame step"}
+json.dump(doc, open(doc_path, "w"), indent=1)
+print(w, "traffic / algorithmic =", round(doc[w]["bytes_per_launch"] / doc[w]["algorithmic_bytes_per_launch"], 3))
