@@ -50,6 +50,13 @@ WORKLOADS = {
                    iUpscaling=4, desc="1080p P010 BT.2020/PQ -> Lanczos3 1.33x -> PQ->SDR -> ordered dither -> 1440p BGRA8"),
     "down1440": dict(cformat=2, w=3840, h=2160, scale=1, dst=(2560, 1440), ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
                      iUpscaling=4, iDownscaling=2, desc="4K P010 BT.2020/PQ -> Hamming 1.5x down -> PQ->SDR -> ordered dither -> 1440p BGRA8"),
+    # the everyday SDR case (8-bit source, 8-bit internal format, no final pass) and HDR passthrough to a 10-bit swap chain
+    "up1440_nv12": dict(cformat=1, w=1920, h=1080, scale=1, dst=(2560, 1440), ext=dict(chroma=5, nominal_range=2, matrix=1, primaries=2, transfer=5),
+                        iUpscaling=2, desc="1080p NV12 BT.709 -> Catmull-Rom 1.33x -> 1440p BGRA8 (8-bit internal format, no dither)"),
+    "hdrpass_2x": dict(cformat=2, w=3840, h=2160, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
+                       iUpscaling=4, hdr_output=1, output_format=1, desc="4K P010 BT.2020/PQ -> Lanczos3 2x -> HDR10 passthrough -> 8K R10G10B10A2"),
+    "hdrpass_1440": dict(cformat=2, w=1920, h=1080, scale=1, dst=(2560, 1440), ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
+                         iUpscaling=4, hdr_output=1, output_format=1, desc="1080p P010 BT.2020/PQ -> Lanczos3 1.33x -> HDR10 passthrough -> 1440p R10G10B10A2"),
     "c3hdr_1080p": dict(cformat=2, w=1920, h=1080, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
                         iUpscaling=4, desc="1080p P010 BT.2020/PQ -> Lanczos3 2x -> PQ->SDR -> dither -> 4K BGRA8 (alternative reading)"),
 }
@@ -227,7 +234,8 @@ def main():
     if args.src or args.scale:
         dw, dh = w * s, h * s
     extfmt = api.make_extfmt(**wl["ext"])
-    settings = api.default_settings(iUpscaling=wl["iUpscaling"], iDownscaling=wl.get("iDownscaling", 2), flags=args.flags)
+    settings = api.default_settings(iUpscaling=wl["iUpscaling"], iDownscaling=wl.get("iDownscaling", 2), flags=args.flags,
+                                    output_format=wl.get("output_format", 0))
     # One explicit (non-default) HIP stream shared by torch and the context: the kernels are launched on it and the
     # torch.cuda.Event pairs below are recorded on it, so they bracket exactly the launches of a step.
     stream = torch.cuda.Stream()
@@ -235,6 +243,8 @@ def main():
     vp = api.VideoProcessor(settings, device=dev)          # picks up torch's current stream (mpcvr_set_stream)
     assert stream.cuda_stream != 0
     vp.InitMediaType(wl["cformat"], w, h, extfmt=extfmt)
+    if wl.get("hdr_output"):
+        vp.SetHdrOutput(True)
     vp.SetWindowRect((0, 0, dw, dh))
     vp.SetVideoRect((0, 0, dw, dh))
     vdist.sync_params(vp)                                  # RCCL broadcast of rank 0's parameter blob (few KiB)

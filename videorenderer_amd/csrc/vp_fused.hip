@@ -245,8 +245,14 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
                                 for (int pp = 0; pp < 2; pp++) uq[c][pp] = pk_fma(res[c][pp], maxv2, big2);
 #pragma unroll
                             for (int px = 0; px < 4; px++) {
-                                const uint32_t bg = __builtin_amdgcn_perm(__float_as_uint(uq[1][px >> 1][px & 1]), __float_as_uint(uq[2][px >> 1][px & 1]), 0x0c0c0400u);
-                                pk[px] = __builtin_amdgcn_perm(__float_as_uint(uq[0][px >> 1][px & 1]), bg, 0x0d040100u);
+                                const uint32_t cr = __float_as_uint(uq[0][px >> 1][px & 1]), cg = __float_as_uint(uq[1][px >> 1][px & 1]), cb = __float_as_uint(uq[2][px >> 1][px & 1]);
+                                if (P.out10) {      // R10G10B10A2 target (HDR passthrough): the codes are 0x4B000000 | k — shifted left by 10 / 20
+                                                    // only k remains, and + 0x75000000 turns the red code into k | 3 << 30
+                                    pk[px] = (cb << 20) | ((cg << 10) | (cr + 0x75000000u));
+                                } else {
+                                    const uint32_t bg = __builtin_amdgcn_perm(cg, cb, 0x0c0c0400u);
+                                    pk[px] = __builtin_amdgcn_perm(cr, bg, 0x0d040100u);
+                                }
                             }
                         } else {
                             // generic epilogue: no final pass (straight UNORM store into the RT) and/or R10G10B10A2 target
@@ -692,13 +698,15 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     // the specialised epilogues use 16-byte stores / dither reads: off_x % 4 == 0 and 16-byte aligned rows; the integer
     // final pass additionally needs k*M + (j << 14) < 2^32 and M < 2^24 (true for 10-bit internal -> 8-bit target)
     const bool aligned = P.dst_aligned16 && (a.off_x & 3) == 0 && (a.dst_pitch & 15) == 0;
-    const int epik = !aligned || a.out10 ? EPI_GENERIC
-                   : (a.final_pass && a.epi_mul != 0) ? EPI_DITHER8
-                   : (!a.final_pass && P.store.dst_fmt == SF_BGRA8 && P.store.quant == 255) ? EPI_DIRECT8 : EPI_GENERIC;
+    const int epik = !aligned ? EPI_GENERIC
+                   : (!a.out10 && a.final_pass && a.epi_mul != 0) ? EPI_DITHER8
+                   : (!a.final_pass && P.store.dst_fmt == SF_BGRA8 && P.store.quant == 255) ? EPI_DIRECT8
+                   : (!a.final_pass && P.store.dst_fmt == SF_RGB10A2 && P.store.quant == 1023) ? EPI_DIRECT8 : EPI_GENERIC;
     // instantiated (source, epilogue) pairs: each source with the epilogue it normally meets + the generic one
 #define MPCVR_LAUNCH3(NT, TK, SK, EK) hipLaunchKernelGGL((k_fused_up2x<NT, TK, SK, EK>), grid, block, lds, s, a, frames_dev, single)
 #define MPCVR_LAUNCH(NT, TK) do { \
         if (srck == SRC_P01X && epik == EPI_DITHER8) MPCVR_LAUNCH3(NT, TK, SRC_P01X, EPI_DITHER8); \
+        else if (srck == SRC_P01X && epik == EPI_DIRECT8) MPCVR_LAUNCH3(NT, TK, SRC_P01X, EPI_DIRECT8); \
         else if (srck == SRC_P01X) MPCVR_LAUNCH3(NT, TK, SRC_P01X, EPI_GENERIC); \
         else if (srck == SRC_NV12 && epik == EPI_DIRECT8) MPCVR_LAUNCH3(NT, TK, SRC_NV12, EPI_DIRECT8); \
         else if (srck == SRC_NV12) MPCVR_LAUNCH3(NT, TK, SRC_NV12, EPI_GENERIC); \

@@ -60,8 +60,8 @@ enum { TAILK_NONE = 0, TAILK_PQ_LUT = 1, TAILK_ALU = 2, TAILK_HLG = 3 };
 // source specialisation: GENERIC reads planes / bytes / siting at run time; P01X = bi-planar 16-bit (P010/P016), NV12 =
 // bi-planar 8-bit, both with MPEG-2 or co-sited chroma (not horizontally centred)
 enum { SRC_GENERIC = 0, SRC_P01X = 1, SRC_NV12 = 2 };
-// epilogue specialisation: DITHER8 = B8G8R8A8 target behind a final pass (integer form); DIRECT8 = B8G8R8A8 target written
-// straight from the Y pass (8-bit sources: no post-scale step); both require 16-byte aligned rows and off_x % 4 == 0
+// epilogue specialisation: DITHER8 = B8G8R8A8 target behind a final pass (integer form); DIRECT8 = B8G8R8A8 or R10G10B10A2 target written
+// straight from the Y pass (no post-scale step: 8-bit sources, HDR passthrough to a 10-bit swap chain); both require 16-byte aligned rows and off_x % 4 == 0
 enum { EPI_GENERIC = 0, EPI_DITHER8 = 1, EPI_DIRECT8 = 2 };
 
 

@@ -294,7 +294,43 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
                 else tap3<true, false>(t0, t1, w, acc[0]);
             }
         }
-        if (FASTEPI) {
+        if (EPI == EPI_DIRECT8) {
+            // no post-scale step: the Y result is stored straight into the target's UNORM format (B8G8R8A8 or R10G10B10A2),
+            // floor(x*q + 0.5).  x*q + 2^23 leaves the code in the low mantissa bits
+            const int wy = P.off_y + y;
+            const float qd = P.out10 ? 1023.0f : 255.0f;
+            const f2 q2 = splat(qd);
+            uint32_t pk[PXL];
+            uint32_t codes[PXL][3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                if (PXL == 2) {
+                    const f2 u = pk_fma(f2{acc[0][c], acc[PXL - 1][c]}, q2, big2);
+                    codes[0][c] = __float_as_uint(u.x); codes[PXL - 1][c] = __float_as_uint(u.y);
+                } else {
+                    codes[0][c] = __float_as_uint(fmaf(acc[0][c], qd, 8388608.0f));
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < PXL; q++) {
+                if (P.out10) {      // 0x4B000000 | k: shifted left by 10 or 20 only k remains; + 0x75000000 turns the red code into k | 3 << 30
+                    uint32_t t = codes[q][0] + 0x75000000u;
+                    t = (codes[q][1] << 10) | t;
+                    pk[q] = (codes[q][2] << 20) | t;
+                } else {
+                    const uint32_t bg = __builtin_amdgcn_perm(codes[q][1], codes[q][2], 0x0c0c0400u);     // [B, G, 0, 0]
+                    pk[q] = __builtin_amdgcn_perm(codes[q][0], bg, 0x0d040100u);                         // [B, G, R, 0xff]
+                }
+            }
+            const gptr rowp = pdst + (uint32_t)wy * (uint32_t)P.dst_pitch;
+            if (PXL == 2 && st8 && x_first + 1 < Q.out_w) {
+                *(__attribute__((address_space(1))) u32x2 *)(rowp + opaque(lane_off)) = u32x2{pk[0], pk[PXL - 1]};
+            } else {
+#pragma unroll
+                for (int q = 0; q < PXL; q++)
+                    if (x_first + q < Q.out_w) *(__attribute__((address_space(1))) uint32_t *)(rowp + lane_off + 4 * q) = pk[q];
+            }
+        } else if (FASTEPI) {
             // m_TexsPostScale store/load + ps_final_pass.hlsl:29 in integers, see vp_fused.hip
             const int wy = P.off_y + y;
             uint32_t pk[PXL];
@@ -411,6 +447,8 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
     const bool inside = st.off_x >= 0 && st.off_y >= 0 && (st.clip_w <= 0 || (st.off_x + S.out_w <= st.clip_w && st.off_y + S.out_h <= st.clip_h));
     const bool fastepi = inside && st.mode == ST_FINAL && st.dst_fmt == SF_BGRA8 && st.quant == 255 && a.epi_mul != 0 &&
                          P.conv.out_fmt == SF_RGB10A2 && st.mid_fmt == SF_RGB10A2 && (st.dst_pitch & 3) == 0;
+    // straight UNORM store of the Y result (no final pass) into a B8G8R8A8 / R10G10B10A2 target or post-scale texture
+    const bool direct = !fastepi && inside && st.mode == ST_SURFACE && (st.dst_fmt == SF_BGRA8 || st.dst_fmt == SF_RGB10A2) && (st.dst_pitch & 3) == 0;
     const int tailk = FusedTailKind(P), srck = FusedSourceKind(P);
     const int waves = StripWaves(S, fastepi, tailk == TAILK_PQ_LUT);
     const size_t lds = StripLds(S, fastepi, tailk == TAILK_PQ_LUT, waves);
@@ -424,7 +462,8 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
             if (ea != hipSuccess) return ea; \
         } \
         hipLaunchKernelGGL(kern, grid, block, lds, s, a, q, st, frames_dev, single); } while (0)
-#define MPCVR_ST4(NT, PX, TK, SK) do { if (fastepi) MPCVR_ST5(NT, PX, TK, SK, EPI_DITHER8); else MPCVR_ST5(NT, PX, TK, SK, EPI_GENERIC); } while (0)
+#define MPCVR_ST4(NT, PX, TK, SK) do { if (fastepi) MPCVR_ST5(NT, PX, TK, SK, EPI_DITHER8); else if (direct) MPCVR_ST5(NT, PX, TK, SK, EPI_DIRECT8); \
+                                       else MPCVR_ST5(NT, PX, TK, SK, EPI_GENERIC); } while (0)
 #define MPCVR_ST3(NT, PX, TK) do { if (srck == SRC_P01X) MPCVR_ST4(NT, PX, TK, SRC_P01X); else if (srck == SRC_NV12) MPCVR_ST4(NT, PX, TK, SRC_NV12); \
                                    else MPCVR_ST4(NT, PX, TK, SRC_GENERIC); } while (0)
 #define MPCVR_ST2(NT, PX) do { if (tailk == TAILK_NONE) MPCVR_ST3(NT, PX, TAILK_NONE); else if (tailk == TAILK_PQ_LUT) MPCVR_ST3(NT, PX, TAILK_PQ_LUT); \
