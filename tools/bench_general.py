@@ -12,6 +12,10 @@ CASES = [("C1 1080p NV12 BT.709 -> 1080p BGRA8 (no resize)", 1920, 1080, 1920, 1
          ("4K P010 PQ -> 4K, pass-per-kernel (convert, final)", 3840, 2160, 3840, 2160, dict(flags=api.FLAG_NO_FUSED)),
          ("4K P010 Dolby Vision (MMR + L2 trims) -> 4K SDR + dither (no resize)", 3840, 2160, 3840, 2160, dict(), 2, dict(chroma=5, nominal_range=2), "mmr"),
          ("4K P010 Dolby Vision, plain kernels", 3840, 2160, 3840, 2160, dict(flags=api.FLAG_NO_FUSED), 2, dict(chroma=5, nominal_range=2), "mmr"),
+         ("4K P010 Dolby Vision (polynomial curves, no L2) -> 4K SDR + dither (no resize)", 3840, 2160, 3840, 2160, dict(), 2, dict(chroma=5, nominal_range=2), "poly", ()),
+         ("4K P010 Dolby Vision (MMR chroma, no L2) -> 4K SDR + dither (no resize)", 3840, 2160, 3840, 2160, dict(), 2, dict(chroma=5, nominal_range=2), "mmr", ()),
+         ("4K P010 Dolby Vision (polynomial, no L2), per-pixel kernel", 3840, 2160, 3840, 2160, dict(flags=api.FLAG_NO_FAST_CONVERT), 2, dict(chroma=5, nominal_range=2), "poly", ()),
+         ("1080p P010 Dolby Vision (polynomial, no L2) -> 1440p Lanczos3 -> SDR", 1920, 1080, 2560, 1440, dict(iUpscaling=4), 2, dict(chroma=5, nominal_range=2), "poly", ()),
          ("4K P010 PQ -> 1440p (Hamming down) -> SDR", 3840, 2160, 2560, 1440, dict(iDownscaling=2)),
          ("4K P010 PQ -> 1080p (Hamming down 2x) -> SDR", 3840, 2160, 1920, 1080, dict(iDownscaling=2)),
          ("4K NV12 BT.709 -> 1080p (Bicubic down 2x)", 3840, 2160, 1920, 1080, dict(iDownscaling=3), 1, dict(chroma=5, nominal_range=2, matrix=1)),
@@ -35,7 +39,7 @@ for case in CASES:
     vp.InitMediaType(cf, w, h, extfmt=ex); vp.SetWindowRect((0, 0, dw, dh)); vp.SetVideoRect((0, 0, dw, dh))
     if len(case) > 8:
         from videorenderer_amd import synth
-        vp.SetDoviMetadata(synth.dovi_metadata(case[8], l2=(100, 600, 1000)))
+        vp.SetDoviMetadata(synth.dovi_metadata(case[8], l2=case[9] if len(case) > 9 else (100, 600, 1000)))
     nb, pitch = vp.GetFrameBytes()
     # ring of DISTINCT samples and targets whose footprint exceeds the 256 MiB Infinity Cache several times over (>= 1.2 GB):
     # with 8 samples + 16 targets a 1080p case (158 MB) stayed cache-resident and read 25-30 % high (C1: 323 k vs bench.py's 253 k)

@@ -57,7 +57,7 @@ CHipVideoProcessor::~CHipVideoProcessor()
     (void)hipSetDevice(m_device);
     if (m_stream) (void)hipStreamSynchronize(m_stream);
     for (DevBuffer *b : {&m_batchConv, &m_batchMid, &m_jincFirst, &m_jincSecond, &m_TexSrcVideo, &m_TexRaw, &m_TexPost, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
-                         &m_pqLut, &m_tapsXi, &m_tapsXw, &m_tapsXs, &m_tapsYi, &m_tapsYw, &m_tapsYs, &m_otherX, &m_otherY, &m_tapsXb, &m_tapsYb})
+                         &m_pqLut, &m_eotfLut, &m_stripTab, &m_tapsXi, &m_tapsXw, &m_tapsXs, &m_tapsYi, &m_tapsYw, &m_tapsYs, &m_otherX, &m_otherY, &m_tapsXb, &m_tapsYb})
         b->Release();
     for (UploadSlot &u : m_up) {
         u.dev.Release();
@@ -343,6 +343,12 @@ HRESULT CHipVideoProcessor::UploadDoviParams()
     (void)hipSetDevice(m_device);
     HRESULT hr;
     if ((hr = CheckHip(m_doviDev.CheckCreate(sizeof(DoviParams)), "dovi constants"))) return hr;
+    if (!m_eotfLut.ptr) {           // the PQ EOTF table of the block convert's Dolby Vision variants: a constant of the transfer function
+        std::vector<float> lut(kPqLutSize);
+        BuildPqEotfLut(lut.data());
+        if ((hr = CheckHip(m_eotfLut.CheckCreate(lut.size() * sizeof(float)), "pq eotf lut"))) return hr;
+        if ((hr = CheckHip(hipMemcpy(m_eotfLut.ptr, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice), "pq eotf lut upload"))) return hr;
+    }
     DoviSlot &slot = m_doviSlots[m_doviSlotNext++ % 4];
     if (!slot.pinned) {
         if ((hr = CheckHip(hipHostMalloc((void **)&slot.pinned, sizeof(DoviParams), hipHostMallocDefault), "dovi staging"))) return hr;
@@ -794,6 +800,8 @@ void CHipVideoProcessor::FillFusedParams(const uint8_t *sample, void *rt, int rt
     const bool no_lut = (m_cfg.flags & MPCVR_FLAG_NO_LUT) != 0;
     fp->pq_lut = (m_pqLutValid && !no_lut) ? (const float *)m_pqLut.ptr : nullptr;
     fp->literal_tail = no_lut ? 1 : 0;
+    fp->eotf_lut = (m_doviValid && !no_lut) ? (const float *)m_eotfLut.ptr : nullptr;
+    fp->dovi_l2 = (m_doviValid && m_doviHost.l2_enabled) ? 1 : 0;
     fp->taps_mfma = (m_cfg.flags & MPCVR_FLAG_FUSED_MFMA) ? 1 : (m_cfg.flags & MPCVR_FLAG_FUSED_VALU) ? 0 : -1;
     fp->dst_aligned16 = (((uintptr_t)rt) & 15) == 0;        // batches: ProcessBatch checks every target
     fp->src_aligned16 = (((uintptr_t)sample) & 15) == 0;

@@ -177,6 +177,7 @@ private:
     DevBuffer m_TexConvertOutput, m_TexResize, m_BackBuffer, m_Snapshot;
     DevBuffer m_dither;
     DevBuffer m_pqLut;             // kPqLutSize floats (fused path tone-map table)
+    DevBuffer m_eotfLut;           // kPqLutSize floats: PQ EOTF (Dolby Vision block convert), uploaded with the first RPU
     float m_pqLutHost[kPqLutSize];
     bool m_pqLutValid = false;
     DevBuffer m_tapsXi, m_tapsXw, m_tapsXs, m_tapsYi, m_tapsYw, m_tapsYs, m_otherX, m_otherY, m_tapsXb, m_tapsYb;

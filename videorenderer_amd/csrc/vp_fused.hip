@@ -296,22 +296,39 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
 // FINAL = false: the block is stored as texels of the internal UNORM format (m_TexConvertOutput, or the render target when
 // nothing follows); FINAL = true: 10-bit internal -> ps_final_pass in integers -> B8G8R8A8 (see the fused epilogue).
 // ------------------------------------------------------------------------------------------------
-template <int TAIL, int SRC, bool FINAL>
+// DV != DV_NONE: the Dolby Vision variant (TAIL is then TAILK_ALU: the tone-map table is not used) — LDS holds the PQ EOTF table
+// and a copy of the frame's DoviParams instead.
+template <int TAIL, int SRC, bool FINAL, int DV = DV_NONE>
 __global__ __launch_bounds__(256) void k_convert_blocks(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single, int pairs,
                                                        uint8_t *batch_dst, size_t batch_stride, FrameTable32 tab)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *Di = (uint32_t *)smem;                                   // dither as j << 14 (FINAL)
     f2 *T = (f2 *)(smem + (FINAL ? 4096 : 0));
+    f2 *TE = T;                                                        // DV: the EOTF table takes the tone-map table's place ...
+    DoviParams *DL = (DoviParams *)(smem + (FINAL ? 4096 : 0) + LDS_E);
+    if (DV == DV_SDR_L2) T = (f2 *)(smem + (FINAL ? 4096 : 0) + LDS_E + LDS_V);     // ... and the tone-map table follows the curves
     if (FINAL)
         for (int i = threadIdx.x; i < 1024; i += 256)
             Di[i] = (uint32_t)(__half2float(__ushort_as_half(P.dither[i])) * 1024.0f + 0.5f) << 14;
-    if (TAIL == TAILK_PQ_LUT)
+    if (DV != DV_NONE) {
+        if (DV == DV_SDR || DV == DV_SDR_L2)
+            for (int i = threadIdx.x; i < LUT_N; i += 256) {
+                const float v = P.eotf_lut[i], n = P.eotf_lut[min(i + 1, LUT_N - 1)];
+                TE[i] = f2{v, n - v};
+            }
+        if (DV == DV_SDR_L2)
+            for (int i = threadIdx.x; i < LUT_N; i += 256) {
+                const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
+                T[i] = f2{v, n - v};
+            }
+        for (int i = threadIdx.x; i < (int)(sizeof(DoviParams) / 4); i += 256) ((uint32_t *)DL)[i] = ((const uint32_t *)P.dovi)[i];
+    } else if (TAIL == TAILK_PQ_LUT)
         for (int i = threadIdx.x; i < LUT_N; i += 256) {
             const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
             T[i] = f2{v, n - v};
         }
-    if (FINAL || TAIL == TAILK_PQ_LUT) __syncthreads();
+    if (FINAL || TAIL == TAILK_PQ_LUT || DV != DV_NONE) __syncthreads();
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int W = P.W, H = P.H;
@@ -335,6 +352,8 @@ __global__ __launch_bounds__(256) void k_convert_blocks(FusedArgs P, const Fused
     f2 CC[3] = {splat(P.c[0]), splat(P.c[1]), splat(P.c[2])};
     asm volatile("" : "+v"(CC[0]), "+v"(CC[1]), "+v"(CC[2]));
 
+    DoviRegs DRG;
+    if (DV != DV_NONE) load_dovi_regs(P.dovi, DRG);
     RawAddr ra;
     make_raw_addr<SRC>(P, X, ra);
     const uint32_t lane_off = (uint32_t)(P.off_x + X) * 4u;
@@ -347,7 +366,7 @@ __global__ __launch_bounds__(256) void k_convert_blocks(FusedArgs P, const Fused
         const int a = 2 * (pair0 + p) - 1;                             // rows a, a+1
         if (a >= H) break;
         f2 rc[2][3];
-        convert_block<TAIL, SRC>(P, MM, GG, CC, raw, P.rect_t + clampi(a, 0, H - 1), P.rect_t + clampi(a + 1, 0, H - 1), T, rc);
+        convert_block<TAIL, SRC, DV>(P, MM, GG, CC, raw, P.rect_t + clampi(a, 0, H - 1), P.rect_t + clampi(a + 1, 0, H - 1), T, rc, DL, TE, &DRG);
         if (p + 1 < pairs && a + 2 < H)
             load_raw<SRC>(P, py, ra, clampi(a + 2, 0, H - 1), clampi(a + 3, 0, H - 1), raw);
         // UNORM store of m_TexConvertOutput: floor(sat(x)*maxv + 0.5); x*maxv + 2^23 leaves the code in the low mantissa bits
@@ -549,12 +568,14 @@ void FillFusedArgs(const FusedParams &P, FusedArgs &a)
     // UNORM scale: v/255, or (v << shift)/65535 for planar data; interleaved UV planes carry no shift
     const float sy = c.fmt.bytes == 1 ? 1.0f / 255.0f : (float)(1 << c.fmt.shift) / 65535.0f;
     const float sc = c.fmt.bytes == 1 ? 1.0f / 255.0f : (float)(1 << (c.fmt.planes == 2 ? 0 : c.fmt.shift)) / 65535.0f;
+    const bool dv = c.dovi != nullptr;       // Dolby Vision: the reshaping curves sit between the texel and the matrix, so the scale stays outside
     for (int i = 0; i < 3; i++) {
-        a.m[3 * i + 0] = c.cm[3 * i + 0] * sy;
-        a.m[3 * i + 1] = c.cm[3 * i + 1] * sc;
-        a.m[3 * i + 2] = c.cm[3 * i + 2] * sc;
+        a.m[3 * i + 0] = c.cm[3 * i + 0] * (dv ? 1.0f : sy);
+        a.m[3 * i + 1] = c.cm[3 * i + 1] * (dv ? 1.0f : sc);
+        a.m[3 * i + 2] = c.cm[3 * i + 2] * (dv ? 1.0f : sc);
         a.c[i] = c.cm[9 + i];
     }
+    a.dovi = c.dovi; a.eotf_lut = P.eotf_lut; a.sy = sy; a.sc = sc;
     a.tail = c.tail; a.gamma = c.gamma; a.lum_scale = c.lum_scale;
     std::memcpy(a.gamut, c.gamut, sizeof(a.gamut));
     a.lut = P.pq_lut;
@@ -575,6 +596,12 @@ int FusedTailKind(const FusedParams &P)
     return c.tail == TAIL_NONE ? TAILK_NONE : (c.tail == TAIL_PQ_TO_SDR && P.pq_lut) ? TAILK_PQ_LUT
          : (c.tail == TAIL_HLG_TO_SDR && !P.literal_tail) ? TAILK_HLG : TAILK_ALU;
 }
+int FusedDoviKind(const FusedParams &P)
+{
+    if (!P.conv.dovi) return DV_NONE;
+    if (P.conv.tail != TAIL_PQ_TO_SDR || P.literal_tail) return DV_GENERAL;
+    return !P.dovi_l2 ? DV_SDR : P.pq_lut ? DV_SDR_L2 : DV_GENERAL;
+}
 int FusedSourceKind(const FusedParams &P)
 {
     // source specialisations: bi-planar 16-bit (P010/P016) and bi-planar 8-bit (NV12) with MPEG-2 / co-sited chroma;
@@ -588,7 +615,8 @@ bool ConvertBlocksSupported(const FusedParams &P, bool to_rt)
 {
     const ConvertParams &c = P.conv;
     if (c.out_fmt != SF_BGRA8 && c.out_fmt != SF_RGB10A2) return false;
-    if (c.fmt.layout != LAY_PLANAR || c.fmt.subsampling != 420 || c.chroma_scaling != 1 || c.blend_deint || c.dovi) return false;
+    if (c.fmt.layout != LAY_PLANAR || c.fmt.subsampling != 420 || c.chroma_scaling != 1 || c.blend_deint) return false;
+    if (c.dovi && !P.eotf_lut) return false;       // the Dolby Vision variant decodes PQ from a table (MPCVR_FLAG_NO_LUT: per-pixel kernel)
     if (c.out_w < 8 || c.out_h < 2 || (c.out_w & 1) || (c.out_h & 1)) return false;
     if (!P.fast_convert) return false;
     if ((uint64_t)c.pitch[0] * (uint64_t)(c.rect_t + c.out_h + 2) >= (1ull << 32)) return false;
@@ -627,7 +655,8 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
     // four blocks per lane (8- / 16-byte loads, 16-byte stores) where every row allows it
     static const int no_wide = EnvInt("MPCVR_NO_WIDE_CONVERT", 0);
     const int lb = srck == SRC_P01X ? 16 : 8;                   // bytes of a lane's luma / chroma load
-    const bool wide = !no_wide && srck != SRC_GENERIC && (c.out_w & 7) == 0 && (c.rect_l & 7) == 0 && (c.pitch[0] % lb) == 0 &&
+    const int dvk = FusedDoviKind(P);
+    const bool wide = !no_wide && dvk == DV_NONE && srck != SRC_GENERIC && (c.out_w & 7) == 0 && (c.rect_l & 7) == 0 && (c.pitch[0] % lb) == 0 &&
                       (c.pitch[1] % lb) == 0 && (P.plane_off[1] % lb) == 0 && P.dst_aligned16 && (P.store.off_x & 3) == 0 &&
                       (P.store.dst_pitch & 15) == 0 && P.src_aligned16;
     const int strip_w = wide ? 512 : 128;
@@ -636,7 +665,17 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
     int pairs = 16;
     while (pairs > 2 && (long)strips * ((npairs + pairs - 1) / pairs) * n_frames < (wide ? 4096 : 8192)) pairs >>= 1;
     const dim3 grid(strips, (npairs + 4 * pairs - 1) / (4 * pairs), n_frames), block(256, 1, 1);
-    const size_t lds = (fin ? 4096 : 0) + (tailk == TAILK_PQ_LUT ? LDS_T : 0);
+    const size_t lds = (fin ? 4096 : 0) + (dvk != DV_NONE ? LDS_E + LDS_V + (dvk == DV_SDR_L2 ? LDS_T : 0) : tailk == TAILK_PQ_LUT ? LDS_T : 0);
+    if (dvk != DV_NONE) {       // Dolby Vision: 16-bit bi-planar (P010 / P016) or whatever the generic source variant reads
+#define MPCVR_CBD(SK, FN, DK) hipLaunchKernelGGL((k_convert_blocks<TAILK_ALU, SK, FN, DK>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab)
+#define MPCVR_CBD2(SK, FN) do { if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_convert_blocks<TAILK_ALU, SK, FN, DV_SDR_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                                if (dvk == DV_SDR) MPCVR_CBD(SK, FN, DV_SDR); else if (dvk == DV_SDR_L2) MPCVR_CBD(SK, FN, DV_SDR_L2); else MPCVR_CBD(SK, FN, DV_GENERAL); } while (0)
+        if (srck == SRC_P01X) { if (fin) MPCVR_CBD2(SRC_P01X, true); else MPCVR_CBD2(SRC_P01X, false); }
+        else { if (fin) MPCVR_CBD2(SRC_GENERIC, true); else MPCVR_CBD2(SRC_GENERIC, false); }
+#undef MPCVR_CBD2
+#undef MPCVR_CBD
+        return hipGetLastError();
+    }
 #define MPCVR_CB3(TK, SK, FN) hipLaunchKernelGGL((k_convert_blocks<TK, SK, FN>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab)
 #define MPCVR_CBW(TK, SK, FN) hipLaunchKernelGGL((k_convert_blocks_wide<TK, SK, FN>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab)
 #define MPCVR_CB2(TK, SK) do { if (fin) MPCVR_CB3(TK, SK, true); else MPCVR_CB3(TK, SK, false); } while (0)

@@ -37,6 +37,11 @@ struct FusedArgs {
     const uint16_t *dither;
     int seg_rows;
     int dbg;                       // ablation switches of the matrix-core kernel (MPCVR_MX_DBG; 0 in normal use)
+    // Dolby Vision (DV template argument of convert_block): reshaping curves / LMS matrix / L2 trims (device DoviParams, copied
+    // into LDS by the kernel), the PQ EOTF table, and the UNORM scales the matrix does NOT carry then (the curves want 0..1 values)
+    const DoviParams *dovi;
+    const float *eotf_lut;         // LUT_N floats (device): log2 ST2084ToLinear((i / (LUT_N - 1))^2, 1)
+    float sy, sc;
 };
 
 namespace {
@@ -57,6 +62,12 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 enum { TAILK_NONE = 0, TAILK_PQ_LUT = 1, TAILK_ALU = 2, TAILK_HLG = 3 };
+// Dolby Vision variants of convert_block: DV_SDR = PQ -> SDR tail without level-2 trims (the LMS step's PQ encode and the tail's PQ
+// decode cancel and are elided, Hable in ALU); DV_SDR_L2 = PQ -> SDR with level-2 trims (PQ decode from the table, encode and trims
+// in ALU, tone map from the HDR10 path's table); DV_GENERAL = everything else (HDR output, no tone mapping): literal chain
+enum { DV_NONE = 0, DV_SDR = 1, DV_GENERAL = 2, DV_SDR_L2 = 3 };
+constexpr int LDS_E = LUT_N * 8;   // PQ EOTF table, {value, delta-to-next} pairs
+constexpr int LDS_V = (sizeof(DoviParams) + 15) & ~15;
 // source specialisation: GENERIC reads planes / bytes / siting at run time; P01X = bi-planar 16-bit (P010/P016), NV12 =
 // bi-planar 8-bit, both with MPEG-2 or co-sited chroma (not horizontally centred)
 enum { SRC_GENERIC = 0, SRC_P01X = 1, SRC_NV12 = 2 };
@@ -246,13 +257,79 @@ __device__ __forceinline__ void load_raw(const FusedArgs &P, gcptr py, const Raw
     }
 }
 
+
+// ---- Dolby Vision reshaping for a 2x2 block (ShaderDoviReshape / ShaderDoviReshapePoly, Shaders.cpp:531-589) ----
+// dovi_reshape (vp_device.h) serves one pixel and reads every field of the curves where it needs it; run four times per block
+// out of the LDS copy that is ~30 dependent LDS round trips per pixel.  Here the wave-uniform parts (pivots, method flags) are
+// loaded ONCE per wave by scalar loads, the piece search of the 12 (pixel, component) values runs on SGPR pivots, and the 12
+// coefficient reads are issued together.  Same arithmetic: pieces by `s < pivot`, (c2*s + c1)*s + c0, reshape_mmr for MMR pieces.
+struct DoviRegs {
+    float pv[3][7];
+    uint32_t methods[3], mmr_single[3], min_order[3], max_order[3];
+    int has_mmr;
+};
+template <typename T> using dv_cptr = const __attribute__((address_space(4))) T *;
+__device__ __forceinline__ void load_dovi_regs(const DoviParams *g, DoviRegs &R)
+{
+    const dv_cptr<DoviParams> c = (dv_cptr<DoviParams>)(uintptr_t)g;       // read-only for the launch: scalar loads
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) R.pv[k][i] = c->curves[k].pivots[i];
+        R.methods[k] = c->curves[k].methods; R.mmr_single[k] = c->curves[k].mmr_single;
+        R.min_order[k] = c->curves[k].min_order; R.max_order[k] = c->curves[k].max_order;
+    }
+    R.has_mmr = c->has_mmr;
+}
+// Y, U, V: [column] as (row 0, row 1) pairs of 0..1 values; reshaped in place.  DL = the LDS copy (coefficients, MMR weights)
+__device__ __forceinline__ void dovi_reshape_block(const DoviRegs &R, const DoviParams *DL, f2 (&Y)[2], f2 (&U)[2], f2 (&V)[2])
+{
+    float s[3][4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) { s[0][p] = Y[p >> 1][p & 1]; s[1][p] = U[p >> 1][p & 1]; s[2][p] = V[p >> 1][p & 1]; }
+    float4 co[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int piece[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            if (R.pv[k][i] > 2.0f) break;              // unused pivots are 1e9 (PackDoviCurves): wave-uniform exit
+#pragma unroll
+            for (int p = 0; p < 4; p++) piece[p] += (s[k][p] >= R.pv[k][i]) ? 1 : 0;      // == the nested `s < pivot` search on sorted pivots
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) co[k][p] = *reinterpret_cast<const float4 *>(DL->curves[k].coeffs[piece[p]]);
+    }
+    float out[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const bool any_mmr = R.has_mmr && (R.methods[k] & DOVI_RESHAPE_MMR);       // wave-uniform
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const float x = s[k][p];
+            float r = (co[k][p].z * x + co[k][p].y) * x + co[k][p].x;
+            if (any_mmr) {
+                const bool poly = R.methods[k] == DOVI_RESHAPE_POLY + DOVI_RESHAPE_MMR && co[k][p].w == 0.0f;
+                if (!poly) {
+                    const float c4[4] = {co[k][p].x, co[k][p].y, co[k][p].z, co[k][p].w};
+                    r = dovi_reshape_mmr(DL->curves[k], c4, f3{s[0][p], s[1][p], s[2][p]});
+                }
+            }
+            out[k][p] = saturate(r);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; p++) { Y[p >> 1][p & 1] = out[0][p]; U[p >> 1][p & 1] = out[1][p]; V[p >> 1][p & 1] = out[2][p]; }
+}
+
 // The 2x2 block: 4:2:0 bilinear chroma + matrix (+ tail) for (even, odd column) x (row 0, row 1).
 // ShaderGetPixels' CHROMA_Bilinear branch (Shaders.cpp:265-270,319-325): same sample positions and weights,
 // evaluated in code units (vertical lerp first), UNORM scale folded into the matrix.  out[column][ch] = the channel as
 // a (row 0, row 1) pair — the layout LDS slice A wants — saturated (every continuation, tail or UNORM store,
 // saturates first).
-template <int TAIL, int SRC>
-__device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], const Raw &r, int sy0, int sy1, const f2 *T, f2 out[2][3])
+template <int TAIL, int SRC, int DV = DV_NONE>
+__device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], const Raw &r, int sy0, int sy1, const f2 *T, f2 out[2][3],
+                                              const DoviParams *DL = nullptr, const f2 *TE = nullptr, const DoviRegs *DR = nullptr)
 {
     // vertical weights of chroma rows n (w0) and n+1 (w1) for (row 0, row 1): wave-uniform, one SGPR pair each
     const int n4 = chroma_v4(P, sy0) & ~3;                 // 4 * floor(v'(row 0))
@@ -281,12 +358,132 @@ __device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)
         Ucol[0] = Uc[1]; Vcol[0] = Vc[1];
         Ucol[1] = pk_fma(Uc[2], splat(0.5f), Uc[1] * splat(0.5f)); Vcol[1] = pk_fma(Vc[2], splat(0.5f), Vc[1] * splat(0.5f));
     }
+    if (DV != DV_NONE) {
+        // ShaderDoviReshape[Poly] (Shaders.cpp:531-589,786-792) on the sampled (Y, U, V) of every pixel, as 0..1 values; the
+        // matrix behind it (ycc_to_rgb, DoviColorMatrix) then carries no UNORM scale.  Curves are read from the LDS copy.
+        const f2 sy2 = splat(P.sy), sc2 = splat(P.sc);
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) { Ycol[rr] = Ycol[rr] * sy2; Ucol[rr] = Ucol[rr] * sc2; Vcol[rr] = Vcol[rr] * sc2; }
+        dovi_reshape_block(*DR, DL, Ycol, Ucol, Vcol);
+    }
     f2 rgbc[2][3];
 #pragma unroll
     for (int rr = 0; rr < 2; rr++)                // rr = luma column of the block
 #pragma unroll
         for (int ch = 0; ch < 3; ch++)
-            rgbc[rr][ch] = fma_k<true>(MM, 3 * ch, Ycol[rr], fma_k<false>(MM, 3 * ch + 1, Ucol[rr], fma_k<false>(MM, 3 * ch + 2, Vcol[rr], CC[ch])));
+            rgbc[rr][ch] = fma_k<DV == DV_NONE>(MM, 3 * ch, Ycol[rr], fma_k<false>(MM, 3 * ch + 1, Ucol[rr], fma_k<false>(MM, 3 * ch + 2, Vcol[rr], CC[ch])));
+    if (DV != DV_NONE) {
+        // PQ EOTF -> LMS matrix -> PQ OETF (Shaders.cpp:844-859).  EOTF from the LDS table on [0, 1]; the reference clamps at 0
+        // only, so a code above 1.0 (possible behind ycc_to_rgb) is decoded literally — a branch no wave takes on ordinary content.
+        // DV_SDR (8-bit tone-mapped target) reads the EOTF from the LDS table; DV_GENERAL (HDR output: 10-bit PQ codes leave the
+        // kernel, and the reference's own fp32 pow chain is what they are compared with code for code) evaluates it literally —
+        // a smooth table cannot follow the rounding noise of exp2(y * log2 x) closer than 1 % of the 10-bit codes.
+        f2 ent[2][3][2]; float frc[2][3][2];
+        float over = 1.0f;
+        if (DV == DV_SDR || DV == DV_SDR_L2) {
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        over = fmaxf(over, rgbc[rr][ch][e]);
+                        // the table holds log2 of the EOTF, sampled at x = (i / (N-1))^2: the EOTF itself is a ~x^3 power law at the
+                        // dark end, where linear interpolation on a uniform grid is 1e-3 relative; its logarithm over sqrt(x)
+                        // interpolates to < 5e-6 everywhere
+                        const float t = __builtin_amdgcn_sqrtf(__builtin_amdgcn_fmed3f(rgbc[rr][ch][e], 0.0f, 1.0f)) * (float)(LUT_N - 1);
+                        frc[rr][ch][e] = __builtin_amdgcn_fractf(t);
+                        ent[rr][ch][e] = TE[(int)t];
+                    }
+        }
+        float L[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) L[i] = DL->lms[i];
+        const float A_ = 0.15f, B_ = 0.50f, CB = 0.10f * 0.50f, DE = 0.20f * 0.02f, DF = 0.20f * 0.30f, EF = 0.02f / 0.30f;
+        const float inv_div = 1.0f / (((4.8f * (A_ * 4.8f + CB) + DE) / (4.8f * (A_ * 4.8f + B_) + DF)) - EF);
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            f2 lin[3], lms[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                if (DV == DV_SDR || DV == DV_SDR_L2)
+                    lin[ch] = f2{__builtin_amdgcn_exp2f(__builtin_fmaf(ent[rr][ch][0].y, frc[rr][ch][0], ent[rr][ch][0].x)),
+                                 __builtin_amdgcn_exp2f(__builtin_fmaf(ent[rr][ch][1].y, frc[rr][ch][1], ent[rr][ch][1].x))};
+                else
+                    lin[ch] = f2{st2084_to_linear(fmaxf(rgbc[rr][ch][0], 0.0f), 1.0f), st2084_to_linear(fmaxf(rgbc[rr][ch][1], 0.0f), 1.0f)};
+            }
+            if ((DV == DV_SDR || DV == DV_SDR_L2) && over > 1.0f) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+                    for (int e = 0; e < 2; e++)
+                        if (rgbc[rr][ch][e] > 1.0f) lin[ch][e] = st2084_to_linear(rgbc[rr][ch][e], 1.0f);
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const f2 v = pk_fma(splat(L[3 * ch]), lin[0], pk_fma(splat(L[3 * ch + 1]), lin[1], splat(L[3 * ch + 2]) * lin[2]));
+                lms[ch] = f2{fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f)};
+            }
+            if (DV == DV_SDR) {
+                // LinearToST2084 -> saturate -> ST2084ToLinear(., scale) is x -> min(x, 1) * scale: elided (like the HLG tail's
+                // round trip); Hable / hable(4.8), 2020 -> 709, saturate, pow 1/2.2 in ALU
+                f2 tm[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const f2 x = f2{fminf(lms[ch].x, 1.0f), fminf(lms[ch].y, 1.0f)} * splat(P.lum_scale);
+                    const f2 num = pk_fma(x, pk_fma(splat(A_), x, splat(CB)), splat(DE));
+                    const f2 den = pk_fma(x, pk_fma(splat(A_), x, splat(B_)), splat(DF));
+                    const f2 q = f2{num.x * __builtin_amdgcn_rcpf(den.x), num.y * __builtin_amdgcn_rcpf(den.y)};
+                    tm[ch] = (q - splat(EF)) * splat(inv_div);
+                }
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const f2 g = fma_k<true>(GG, 3 * ch, tm[0], fma_k<false>(GG, 3 * ch + 1, tm[1], mul_k(GG, 3 * ch + 2, tm[2])));
+                    out[rr][ch] = f2{hlsl_pow(g.x, 1.0f / 2.2f), hlsl_pow(g.y, 1.0f / 2.2f)};
+                }
+            } else if (DV == DV_SDR_L2) {
+                // LinearToST2084, saturate, DolbyVisionTrims (Shaders.cpp:766-773,873-877) in ALU; then the HDR10 path's table for
+                // saturate -> ST2084ToLinear * scale -> Hable / hable(4.8); 2020 -> 709, saturate, pow 1/2.2
+                float k5[5];
+#pragma unroll
+                for (int i = 0; i < 5; i++) k5[i] = DL->l2k[i];
+                f2 tm[3];
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    // the divisions as multiplications by v_rcp_f32 (1 ulp): the result is an 8-bit code behind a tone map and a dither
+                    float c3[3];
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        const float z = hlsl_pow(lms[ch][e], MPCVR_ST2084_m1);
+                        const float q = (MPCVR_ST2084_c1 + MPCVR_ST2084_c2 * z) * __builtin_amdgcn_rcpf(1.0f + MPCVR_ST2084_c3 * z);
+                        c3[ch] = hlsl_pow(saturate(hlsl_pow(q, MPCVR_ST2084_m2)) * k5[2] + k5[3], k5[4]);
+                    }
+                    const float ky = (1.0f + k5[0]) * __builtin_amdgcn_rcpf(0.2627f * c3[0] + 0.6780f * c3[1] + 0.0593f * c3[2]);
+                    const float v3[3] = {c3[0] * hlsl_pow(ky * c3[0], k5[1]), c3[1] * hlsl_pow(ky * c3[1], k5[1]), c3[2] * hlsl_pow(ky * c3[2], k5[1])};
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        const float t = __builtin_amdgcn_fmed3f(v3[ch], 0.0f, 1.0f) * (float)(LUT_N - 1);
+                        const f2 en = T[(int)t];
+                        tm[ch][e] = __builtin_fmaf(en.y, __builtin_amdgcn_fractf(t), en.x);
+                    }
+                }
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const f2 g = fma_k<true>(GG, 3 * ch, tm[0], fma_k<false>(GG, 3 * ch + 1, tm[1], mul_k(GG, 3 * ch + 2, tm[2])));
+                    out[rr][ch] = f2{hlsl_pow(g.x, 1.0f / 2.2f), hlsl_pow(g.y, 1.0f / 2.2f)};
+                }
+            } else {
+                const float *l2k = DL->l2_enabled ? DL->l2k : nullptr;
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    f3 c = {linear_to_st2084(lms[0][e], 1.0f), linear_to_st2084(lms[1][e], 1.0f), linear_to_st2084(lms[2][e], 1.0f)};
+                    c = hdr_tail(c, P.tail, P.gamma, P.lum_scale, make_mat3(P.gamut), l2k, nullptr);
+                    out[rr][0][e] = saturate(c.x); out[rr][1][e] = saturate(c.y); out[rr][2][e] = saturate(c.z);
+                }
+            }
+        }
+        return;
+    }
     // PQ: all twelve table reads of the block are issued together (their addresses depend only on the matrix results),
     // so the wave pays one LDS round trip per iteration instead of six
     f2 linc[2][3];
@@ -385,6 +582,7 @@ inline int EnvInt(const char *name, int def)
 void FillFusedArgs(const FusedParams &P, FusedArgs &a);
 int FusedTailKind(const FusedParams &P);
 int FusedSourceKind(const FusedParams &P);
+int FusedDoviKind(const FusedParams &P);          // DV_* for the launch
 // vp_fused_mx.hip: the same launch as LaunchFusedUp2x with the resize taps on the matrix cores; hipErrorNotSupported when the
 // variant does not cover the configuration (the caller then launches the packed-fp32 kernel)
 hipError_t LaunchFusedUp2xMx(const FusedParams &P, const FusedArgs &a, int knt, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);

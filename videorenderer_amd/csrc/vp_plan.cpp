@@ -329,6 +329,20 @@ void BuildPqSdrLut(float lum_scale, float out[kPqLutSize])
     }
 }
 
+void BuildPqEotfLut(float out[kPqLutSize])
+{
+    const float m1 = 2610.0f / (4096.0f * 4.0f), m2 = (2523.0f / 4096.0f) * 128.0f;
+    const float c1 = 3424.0f / 4096.0f, c2 = (2413.0f / 4096.0f) * 32.0f, c3 = (2392.0f / 4096.0f) * 32.0f;
+    for (int i = 0; i < kPqLutSize; i++) {
+        const float t = (float)i / (float)(kPqLutSize - 1);
+        float x = t * t;                                   // sampled uniformly in sqrt(x): see convert_block's Dolby Vision stage
+        x = std::exp2(std::log2(x) * (1.0f / m2));
+        x = std::fmax(x - c1, 0.0f) / (c2 - c3 * x);
+        const float l = std::log2(x) * (1.0f / m1);       // log2 of the EOTF; codes below 7.3e-7 decode to exactly 0
+        out[i] = l > -150.0f ? l : -150.0f;                // exp2(-150) == 0 in fp32; a finite floor keeps the interpolation NaN-free
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // resize weights
 // ------------------------------------------------------------------------------------------------
