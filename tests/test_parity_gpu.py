@@ -446,6 +446,48 @@ def test_dovi_metadata_lifecycle(mpcvr, oracle, torch_cuda):
     vp.close()
 
 
+DOVI_FULL = [
+    ("poly_sdr", dict(dovi=dict(kind="poly")), "direct:convert+final"),
+    ("mmr_sdr", dict(dovi=dict(kind="mmr")), "direct:convert+final"),
+    ("mixed_l2_sdr", dict(dovi=dict(kind="mixed", l2=(100, 600, 1000))), "direct:convert+final"),
+    ("mmr_hdr_passthrough", dict(dovi=dict(kind="mmr"), hdr_output=1, output_format=1), "direct:convert+copy"),
+    ("poly_sdr_720p_to_1080p", dict(dovi=dict(kind="poly"), w=1280, h=720, dst=(1920, 1080), iUpscaling=4), "passes:convert,resizeX,resizeY+final"),
+]
+
+
+@pytest.mark.parametrize("label,extra,path", DOVI_FULL)
+def test_dovi_block_convert_whole_frame(mpcvr, oracle, torch_cuda, label, extra, path):
+    """Dolby Vision through the 2x2-block convert (round 2) at 1080p, every pixel against the oracle: polynomial and MMR curves
+    behind the elided PQ round trip (no level-2 trims), mixed curves with level-2 trims (PQ decode and tone map from tables,
+    encode and trims in ALU), the literal chain into a 10-bit HDR target, and the block convert feeding the tiled resize.
+    >= 99.8 % identical; see the note on the ill-conditioned pixels at the end (10-bit target: <= 2 codes behind the tail)."""
+    torch = torch_cuda
+    from videorenderer_amd import api
+    c = dict(cformat=2, w=1920, h=1080, kind="hdr", seed=401, dst=(1920, 1080), exfmt=GOLDEN_CASES["dovi_poly_sdr"]["exfmt"])
+    c.update(extra)
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+    stats = {}
+    for flags in (api.FLAG_NO_FUSED, api.FLAG_NO_FAST_CONVERT, 0):
+        got, info = run_product(mpcvr, torch, c, extra_flags=flags)
+        assert info.startswith(path) or flags == api.FLAG_NO_FUSED, info
+        if c.get("output_format", 0) == 1:
+            compare_rgb10(got, want, f"{label} flags={flags}", tail=True)
+            continue
+        d = np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
+        stats[flags] = (float((d == 0).mean()), int((d > 1).sum()), int(d.max()))
+        print(f"dovi {label} flags={flags} [{info}]: identical {stats[flags][0]:.6f}, channels beyond 1 LSB {stats[flags][1]} of {d.size}, max {stats[flags][2]}")
+    # Behind the 2020 -> 709 matrix a saturated dark colour cancels to ~1e-7 and pow(x, 1/2.2) has a slope of thousands there: the
+    # GPU's v_log / v_exp (1 ulp) and the oracle's libm already disagree by several codes on a handful of such pixels — on EVERY
+    # tier, the literal per-pixel kernels included.  The block convert is held to the same handful (a few ppm of the channels),
+    # not to a bar the literal chain does not meet either.
+    for flags, (same, beyond, mx) in stats.items():
+        assert same >= 0.998, (label, flags, same)
+        assert beyond <= max(32, 4 * stats[api.FLAG_NO_FUSED][1] + 16) and beyond <= 1e-5 * d.size, (label, flags, beyond)
+        assert mx <= 8, (label, flags, mx)
+
+
 def test_error_behaviour(mpcvr, torch_cuda):
     torch = torch_cuda
     from videorenderer_amd import api
