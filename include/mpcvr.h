@@ -311,6 +311,17 @@ int32_t mpcvr_plan_upscale_weights(int32_t iUpscaling, float t, float w6[6]);
 int32_t mpcvr_plan_axis_taps(int32_t kind, int32_t method, int32_t src_l, int32_t src_len, int32_t n_out,
                              int32_t tex_len, uint32_t flags, int32_t cap_taps, int32_t *idx, float *w,
                              float *wsum, int32_t *ntaps, int32_t *normalise);
+/* Geometry of the arbitrary-ratio fused kernel (k_fused_strip) for an unrotated two-pass resize src_w x src_h -> out_w x out_h
+ * with the given per-axis draws (kind / method as in mpcvr_plan_axis_taps): out8 = {taps per output the kernel runs (4/6/8),
+ * pixels per lane, output columns per strip, rows of the LDS window, columns of a converted source row, strips, LDS bytes per
+ * wavefront, 0}.  yrange: [out_h][2] {smallest, largest} source row per output row; xstrip: [strips][2] likewise per strip;
+ * xi_t / xw_t: [taps][out_w] and yi / yw: [out_h][taps], the zero-padded, pre-normalised tables the kernel reads.  Any table
+ * pointer may be NULL.  MPCVR_E_NOTIMPL: the tables do not fit the kernel (more than 8 taps, window above 15 rows). */
+int32_t mpcvr_plan_strip(int32_t kind_x, int32_t method_x, int32_t kind_y, int32_t method_y, int32_t src_w, int32_t src_h,
+                         int32_t out_w, int32_t out_h, uint32_t flags, int32_t out8[8], int32_t *yrange, int32_t *xstrip,
+                         int32_t *xi_t, float *xw_t, int32_t *yi, float *yw);
+/* log2 of ST2084ToLinear(x, 1) at x = (i/4095)^2: the PQ EOTF table of the Dolby Vision block convert */
+int32_t mpcvr_plan_pq_eotf_lut(float out4096[4096]);
 /* which draws Process() would issue (UpdateTexParams :1143, UpdatePostScaleTexures :2894, ResizeShaderPass :3103) */
 int32_t mpcvr_plan_describe(const mpcvr_settings *s, int32_t cformat, int32_t rect_w, int32_t rect_h,
                             const mpcvr_rect *video_rect, int32_t window_w, int32_t window_h,

@@ -352,3 +352,85 @@ def test_c_abi_links_from_plain_c(mpcvr, tmp_path):
     assert os.path.exists(exe)
     assert os.path.exists(build_c_demo(tmp_path, "c_multi_gpu"))      # one context per device, parameter blob shared, frames by index
 
+
+
+@pytest.mark.parametrize("kx,mx,ky,my,sw,sh,dw,dh", [
+    (1, 4, 1, 4, 1920, 1080, 2560, 1440),        # up1440: Lanczos3 1.33x
+    (2, 2, 2, 2, 3840, 2160, 2560, 1440),        # down1440: Hamming 1.5x
+    (1, 2, 1, 2, 1280, 720, 1919, 1079),         # odd output size, Catmull-Rom
+    (1, 3, 1, 3, 1280, 1440, 1920, 800),         # up along x, down along y through the interpolation shader (50 % rule)
+    (2, 2, 2, 2, 1920, 1080, 738, 416),          # 2.6x Hamming: 8 taps
+    (1, 1, 1, 1, 3840, 2160, 1920, 1080),        # the interpolation shader at 50 %
+    (1, 4, 1, 4, 64, 48, 100, 70),               # small frame: one strip
+])
+def test_strip_plan_tables(mpcvr, kx, mx, ky, my, sw, sh, dw, dh):
+    """PlanFusedStrip (host side of the arbitrary-ratio fused kernel), without a device: the kernel's copies of the tap tables equal
+    the draws' own tables (normalisation folded in, zero-weight padding), every tap lies inside the windows the kernel stages
+    (per-strip source columns, per-row source rows), the row windows are monotonic and fit the LDS ring, and a CU's LDS holds at
+    least four waves."""
+    from videorenderer_amd import api
+    import numpy as np
+    sp = api.plan_strip(kx, mx, ky, my, sw, sh, dw, dh)
+    assert sp is not None
+    nt, pxl, strip_w = sp["taps"], sp["px_per_lane"], sp["strip_w"]
+    assert nt in (4, 6, 8) and pxl in (1, 2) and sp["ring"] in (8, 16)
+    assert strip_w % pxl == 0 and pxl <= strip_w <= 64 * pxl and sp["strips"] == -(-dw // strip_w)
+    for axis, (kind, method, src, n_out) in enumerate(((kx, mx, sw, dw), (ky, my, sh, dh))):
+        I, W, WS = api.plan_axis_taps(kind, method, 0, src, n_out, src)
+        I, W = np.array(I, np.int32), np.array(W, np.float32)
+        n = I.shape[1]
+        assert n <= nt
+        ti = sp["xi_t"].T if axis == 0 else sp["yi"]
+        tw = sp["xw_t"].T if axis == 0 else sp["yw"]
+        assert np.array_equal(ti[:, :n], I)
+        assert np.array_equal(ti[:, n:], np.repeat(I[:, :1], nt - n, axis=1))           # padding taps re-read the first texel ...
+        assert not tw[:, n:].any()                                                       # ... with weight 0
+        want = W / np.array(WS, np.float32)[:, None] if WS is not None else W
+        assert np.array_equal(tw[:, :n], want.astype(np.float32))
+        if WS is not None:
+            assert np.allclose(tw.sum(axis=1), 1.0, atol=2e-6)
+    # per-row windows: exact min / max of the row's taps, monotonic, and narrow enough for the ring (rows arrive in pairs)
+    yi = sp["yi"]
+    nty = len(api.plan_axis_taps(ky, my, 0, sh, dh, sh)[0][0])
+    assert np.array_equal(sp["yrange"][:, 0], yi[:, :nty].min(axis=1)) and np.array_equal(sp["yrange"][:, 1], yi[:, :nty].max(axis=1))
+    assert (np.diff(sp["yrange"][:, 0]) >= 0).all() and (np.diff(sp["yrange"][:, 1]) >= 0).all()
+    assert int((sp["yrange"][:, 1] - sp["yrange"][:, 0]).max()) + 2 <= sp["ring"]
+    # per-strip windows cover every tap of the strip and fit the converted-row slice
+    xi = sp["xi_t"]
+    for s_ in range(sp["strips"]):
+        cols = xi[:, s_ * strip_w:(s_ + 1) * strip_w]
+        lo, hi = sp["xstrip"][s_]
+        assert lo == cols.min() and hi == cols.max()
+        assert hi - (lo & ~1) + 1 <= sp["acols"]
+    assert 4 * sp["lds_per_wave"] + 4096 + 32768 <= 160 * 1024
+
+
+def test_strip_plan_refuses_what_the_kernel_cannot_run(mpcvr):
+    from videorenderer_amd import api
+    assert api.plan_strip(2, 5, 2, 5, 3840, 2160, 1280, 720) is None          # Lanczos 3x down: 18 taps
+    assert api.plan_strip(2, 3, 2, 3, 1920, 1080, 834, 470) is None           # bicubic 2.3x down: 10 taps
+    assert api.plan_strip(1, 4, 1, 4, 1920, 1080, 3840, 2160) is not None     # exact 2x fits too (the 2x kernel is preferred)
+
+
+def test_pq_eotf_table(mpcvr):
+    """The Dolby Vision block convert's PQ EOTF table: log2 of ST2084ToLinear at x = (i/4095)^2, floored at -150 where the
+    EOTF is exactly 0."""
+    from videorenderer_amd import api
+    import numpy as np
+    t = api.plan_pq_eotf_lut().astype(np.float64)
+    x = (np.arange(4096) / 4095.0) ** 2
+    m1, m2, c1, c2, c3 = 2610 / 16384, 2523 / 4096 * 128, 3424 / 4096, 2413 / 4096 * 32, 2392 / 4096 * 32
+    z = x ** (1 / m2)
+    lin = (np.maximum(z - c1, 0) / (c2 - c3 * z)) ** (1 / m1)
+    live = lin > 1e-30
+    assert np.allclose(t[live], np.log2(lin[live]), rtol=0, atol=2e-3)           # fp32 pow chain: a few 1e-4 in log2
+    assert (t[~live] == -150.0).all() and t[-1] == 0.0 and (np.diff(t) >= 0).all()
+    # linear interpolation of the table in sqrt(x) (midpoints): within 1e-4 relative wherever the EOTF exceeds 1e-7 (0.001 nits),
+    # and within 1e-9 absolute (1e-5 nits) below that, where the power law is steep but nothing visible depends on it
+    xm = ((np.arange(8, 4095) + 0.5) / 4095.0) ** 2
+    zm = xm ** (1 / m2)
+    lm = (np.maximum(zm - c1, 0) / (c2 - c3 * zm)) ** (1 / m1)
+    got = 2.0 ** (0.5 * (t[8:4095] + t[9:4096]))
+    vis = lm > 1e-7
+    assert np.abs(got[vis] / lm[vis] - 1).max() < 1e-4
+    assert np.abs(got[~vis] - lm[~vis]).max() < 1e-9

@@ -156,6 +156,7 @@ EXPORTS = [
     "mpcvr_get_last_process_ms",
     "mpcvr_plan_frame_layout", "mpcvr_plan_color_matrix", "mpcvr_plan_gamut_2020_to_709", "mpcvr_plan_pq_lut",
     "mpcvr_plan_upscale_weights", "mpcvr_plan_axis_taps", "mpcvr_plan_describe", "mpcvr_plan_final_pass_multiplier",
+    "mpcvr_plan_strip", "mpcvr_plan_pq_eotf_lut",
 ]
 
 _lib = None
@@ -225,6 +226,8 @@ def load_library():
         "mpcvr_plan_final_pass_multiplier": [i32, i32, P(u32)],
         "mpcvr_plan_upscale_weights": [i32, f, P(f)],
         "mpcvr_plan_axis_taps": [i32, i32, i32, i32, i32, i32, u32, i32, P(i32), P(f), P(f), P(i32), P(i32)],
+        "mpcvr_plan_strip": [i32, i32, i32, i32, i32, i32, i32, i32, u32, P(i32), P(i32), P(i32), P(i32), P(f), P(i32), P(f)],
+        "mpcvr_plan_pq_eotf_lut": [P(f)],
         "mpcvr_plan_describe": [P(Settings), i32, i32, i32, P(Rect), i32, i32, C.c_char_p, C.c_size_t],
     }
     for name, args in sig.items():
@@ -325,6 +328,37 @@ def plan_upscale_weights(method, t):
     w = (C.c_float * 6)()
     n = load_library().mpcvr_plan_upscale_weights(method, t, w)
     return list(w)[:n]
+
+
+def plan_strip(kind_x, method_x, kind_y, method_y, src_w, src_h, out_w, out_h, flags=0):
+    """PlanFusedStrip through the C-ABI (no device): dict with the kernel's geometry and its tables as numpy arrays, or None when
+    the resize does not fit the arbitrary-ratio fused kernel."""
+    import numpy as np
+    L = load_library()
+    out8 = (C.c_int32 * 8)()
+    hr = L.mpcvr_plan_strip(kind_x, method_x, kind_y, method_y, src_w, src_h, out_w, out_h, flags, out8, None, None, None, None, None, None)
+    if hr == E_NOTIMPL:
+        return None
+    if hr != 0:
+        raise MpcvrError(hr, "mpcvr_plan_strip")
+    nt, pxl, strip_w, ring, acols, strips, lds_wave, _ = list(out8)
+    yr = np.zeros((out_h, 2), np.int32); xs = np.zeros((strips, 2), np.int32)
+    xi = np.zeros((nt, out_w), np.int32); xw = np.zeros((nt, out_w), np.float32)
+    yi = np.zeros((out_h, nt), np.int32); yw = np.zeros((out_h, nt), np.float32)
+    as_p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    hr = L.mpcvr_plan_strip(kind_x, method_x, kind_y, method_y, src_w, src_h, out_w, out_h, flags, out8, as_p(yr, C.c_int32), as_p(xs, C.c_int32),
+                            as_p(xi, C.c_int32), as_p(xw, C.c_float), as_p(yi, C.c_int32), as_p(yw, C.c_float))
+    if hr != 0:
+        raise MpcvrError(hr, "mpcvr_plan_strip")
+    return dict(taps=nt, px_per_lane=pxl, strip_w=strip_w, ring=ring, acols=acols, strips=strips, lds_per_wave=lds_wave,
+                yrange=yr, xstrip=xs, xi_t=xi, xw_t=xw, yi=yi, yw=yw)
+
+
+def plan_pq_eotf_lut():
+    import numpy as np
+    out = np.zeros(4096, np.float32)
+    load_library().mpcvr_plan_pq_eotf_lut(out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
 
 
 def plan_axis_taps(kind, method, src_l, src_len, n_out, tex_len, flags=0, cap_taps=160):

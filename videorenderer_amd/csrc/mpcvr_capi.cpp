@@ -290,6 +290,38 @@ int32_t mpcvr_plan_axis_taps(int32_t kind, int32_t method, int32_t src_l, int32_
     return MPCVR_S_OK;
 }
 
+int32_t mpcvr_plan_strip(int32_t kind_x, int32_t method_x, int32_t kind_y, int32_t method_y, int32_t src_w, int32_t src_h,
+                         int32_t out_w, int32_t out_h, uint32_t flags, int32_t out8[8], int32_t *yrange, int32_t *xstrip,
+                         int32_t *xi_t, float *xw_t, int32_t *yi, float *yw)
+{
+    if (!out8) return MPCVR_E_POINTER;
+    if (src_w <= 0 || src_h <= 0 || out_w <= 0 || out_h <= 0) return MPCVR_E_INVALIDARG;
+    mpcvr::HostAxisTaps hx, hy;
+    // the draws as UpdatePlan builds them: X from the convert output (rect at the origin), Y from m_TexResize (src_h rows)
+    if (!mpcvr::BuildAxisTaps(mpcvr::Resizer{kind_x, method_x}, 0, src_w, out_w, src_w, flags, &hx)) return MPCVR_E_NOTIMPL;
+    if (!mpcvr::BuildAxisTaps(mpcvr::Resizer{kind_y, method_y}, 0, src_h, out_h, src_h, flags, &hy)) return MPCVR_E_NOTIMPL;
+    mpcvr::StripPlan sp;
+    if (!mpcvr::PlanFusedStrip(hx, hy, out_w, out_h, src_w, src_h, &sp)) return MPCVR_E_NOTIMPL;
+    const int strips = (out_w + sp.strip_w - 1) / sp.strip_w;
+    const int per_wave = 2 * sp.acols * 8 + sp.ring * 64 * (sp.pxl == 2 ? 12 : 8);
+    const int32_t o[8] = {sp.nt, sp.pxl, sp.strip_w, sp.ring, sp.acols, strips, per_wave, 0};
+    std::memcpy(out8, o, sizeof(o));
+    if (yrange) std::memcpy(yrange, sp.yrange.data(), sp.yrange.size() * sizeof(int32_t));
+    if (xstrip) std::memcpy(xstrip, sp.xstrip.data(), sp.xstrip.size() * sizeof(int32_t));
+    if (xi_t) std::memcpy(xi_t, sp.xi_t.data(), sp.xi_t.size() * sizeof(int32_t));
+    if (xw_t) std::memcpy(xw_t, sp.xw_t.data(), sp.xw_t.size() * sizeof(float));
+    if (yi) std::memcpy(yi, sp.yi.data(), sp.yi.size() * sizeof(int32_t));
+    if (yw) std::memcpy(yw, sp.yw.data(), sp.yw.size() * sizeof(float));
+    return MPCVR_S_OK;
+}
+
+int32_t mpcvr_plan_pq_eotf_lut(float out4096[4096])
+{
+    if (!out4096) return MPCVR_E_POINTER;
+    mpcvr::BuildPqEotfLut(out4096);
+    return MPCVR_S_OK;
+}
+
 int32_t mpcvr_plan_describe(const mpcvr_settings *s, int32_t cformat, int32_t rect_w, int32_t rect_h,
                             const mpcvr_rect *video_rect, int32_t window_w, int32_t window_h,
                             char *buf, size_t buf_size)
