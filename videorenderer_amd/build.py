@@ -27,6 +27,7 @@ SOURCES = [
     ("vp_fused.hip", []),
     ("vp_fused_mx.hip", []),
     ("vp_fused_strip.hip", []),
+    ("vp_jinc.hip", []),
 ]
 
 

@@ -899,6 +899,7 @@ HRESULT CHipVideoProcessor::ResizeShaderPass(void *rt, int rtPitch, const uint8_
     HRESULT hr = MPCVR_S_OK;
     bool drawn = true;
     const bool plain = (m_cfg.flags & MPCVR_FLAG_NO_FUSED) != 0;      // keep the whole path on the one-kernel-fits-all versions
+    const bool jfast = !(m_cfg.flags & (MPCVR_FLAG_NO_FUSED | MPCVR_FLAG_NO_FAST_CONVERT));       // Jinc2m quad kernel: default tier only
     if (m_plan.two_pass && !plain && !m_firstJinc && !m_secondJinc && m_firstAxis == 0 && !m_firstSwap &&
         Resize2DSupported(conv, m_tapsX, m_tapsY, last)) {
         // both draws in one LDS-tiled kernel: m_TexResize stays on chip
@@ -906,13 +907,13 @@ HRESULT CHipVideoProcessor::ResizeShaderPass(void *rt, int rtPitch, const uint8_
     } else if (m_plan.two_pass) {
         Surface mid{m_runMid, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
         StoreParams st = MakeStore(mid.ptr, mid.pitch, SF_RGBA16F, false);
-        if (m_firstJinc) hr = CheckHip(LaunchJinc2(conv, m_firstCoords, w2, m_plan.mid_h, st, m_run, m_jincFirstTab), "k_jinc2");
+        if (m_firstJinc) hr = CheckHip(LaunchJinc2(conv, m_firstCoords, w2, m_plan.mid_h, st, m_run, m_jincFirstTab, jfast), "k_jinc2");
         else hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, m_plan.mid_h, st, m_run, plain), "k_resize<first>");
         if (hr) return hr;
-        if (m_secondJinc) hr = CheckHip(LaunchJinc2(mid, m_secondCoords, w2, h2, last, m_run, m_jincSecondTab), "k_jinc2");
+        if (m_secondJinc) hr = CheckHip(LaunchJinc2(mid, m_secondCoords, w2, h2, last, m_run, m_jincSecondTab, jfast), "k_jinc2");
         else hr = CheckHip(LaunchResize(1, false, mid, m_tapsY, (const int32_t *)m_otherY.ptr, w2, h2, last, m_run, plain), "k_resize<Y>");
     } else if (m_plan.one_pass) {
-        if (m_firstJinc) hr = CheckHip(LaunchJinc2(conv, m_firstCoords, w2, h2, last, m_run, m_jincFirstTab), "k_jinc2");
+        if (m_firstJinc) hr = CheckHip(LaunchJinc2(conv, m_firstCoords, w2, h2, last, m_run, m_jincFirstTab, jfast), "k_jinc2");
         else hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, h2, last, m_run, plain), "k_resize<one>");
     } else {
         drawn = false;
@@ -1129,7 +1130,8 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
 // convert straight into the render targets (same-size frames).  Exactly one of them is used.
 bool CHipVideoProcessor::BatchPlan(const uint8_t *sample0, void *rt0, int rtPitch, bool aligned, FusedParams *conv, FusedParams *direct) const
 {
-    if (m_plan.hdr_tonemap || m_plan.rotation || m_plan.flip || m_firstJinc || m_secondJinc || !m_plan.convert) return false;
+    if (m_plan.hdr_tonemap || m_plan.rotation || m_plan.flip || m_secondJinc || !m_plan.convert) return false;
+    if (m_firstJinc && !(m_plan.one_pass && m_jincFirstTab)) return false;      // Jinc2m batches: the one-draw quad kernel only
     if (m_srcParams->cformat == MPCVR_CF_V210 || m_srcParams->layout == LAY_RGB) return false;
     const int w1 = m_srcRectWidth, h1 = m_srcRectHeight, w2 = m_videoRect.Width();
     if (m_plan.direct_convert) {
@@ -1153,6 +1155,7 @@ bool CHipVideoProcessor::BatchPlan(const uint8_t *sample0, void *rt0, int rtPitc
         return ResizeHasFoldedKernel(m_firstAxis, m_firstSwap, cs, m_tapsX, MakeStore(nullptr, mid.pitch, SF_RGBA16F, false)) &&
                ResizeHasFoldedKernel(1, false, mid, m_tapsY, final);
     }
+    if (m_firstJinc) return Jinc2QuadSupported(cs, m_firstCoords, m_videoRect.Width(), m_videoRect.Height(), final);
     return ResizeHasFoldedKernel(m_firstAxis, m_firstSwap, cs, m_tapsX, final);
 }
 
@@ -1192,6 +1195,9 @@ HRESULT CHipVideoProcessor::ProcessBatchLaunches(int n, const FusedFrame *table,
                                             MakeStore(mid.ptr, mid.pitch, SF_RGBA16F, false), m_stream, false, &b1), "k_resize<first>"))) return hr;
             ResizeBatch b2; b2.n = m; b2.in_stride = m_midBytes; b2.frames = tab;
             if ((hr = CheckHip(LaunchResize(1, false, mid, m_tapsY, (const int32_t *)m_otherY.ptr, w2, h2, final, m_stream, false, &b2), "k_resize<Y>"))) return hr;
+        } else if (m_firstJinc) {
+            b1.frames = tab; b1.dst_aligned8 = aligned ? 1 : 0;
+            if ((hr = CheckHip(LaunchJinc2Quad(cs, m_firstCoords, w2, h2, final, m_stream, m_jincFirstTab, &b1), "k_jinc2_quad"))) return hr;
         } else {
             b1.frames = tab;
             if ((hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, cs, m_tapsX, (const int32_t *)m_otherX.ptr, w2, h2, final, m_stream, false, &b1), "k_resize<one>"))) return hr;

@@ -578,7 +578,6 @@ __global__ __launch_bounds__(256) void k_copy(Surface in, int out_w, int out_h, 
 // the weights depend on — takes 1/step values per axis, exactly (every term of the shader's expression is exact in fp32
 // there), so the 16 weights and their sum come from a <= 4 x 4 phase table built on the host with the shader's own
 // expressions instead of 16 x (sqrt, 2 sin, divide) per pixel.  The accumulation is k_jinc2's, in the same order.
-struct JincPhases { float w[4][4][16]; float wsum[4][4]; int px, py; };     // [phase y][phase x][j * 4 + i]
 __global__ __launch_bounds__(256) void k_jinc2_phases(Surface in, DrawCoords dc, const JincPhases *__restrict__ tab, int out_w, int out_h, StoreParams st)
 {
     // the 64 x 4 outputs of the workgroup read at most (64 + 4) x (4 + 4) source texels (step <= 1): decoded once into LDS
@@ -990,8 +989,10 @@ bool BuildJincPhases(const DrawCoords &dc, void *out_table)
 }
 size_t JincPhasesBytes() { return sizeof(JincPhases); }
 
-hipError_t LaunchJinc2(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st, hipStream_t s, const void *phases_dev)
+hipError_t LaunchJinc2(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st, hipStream_t s, const void *phases_dev, bool fast)
 {
+    // exact 2x on both axes, default tier: a 2x2 output quad per lane (vp_jinc.hip)
+    if (fast && phases_dev && Jinc2QuadSupported(in, dc, out_w, out_h, st)) return LaunchJinc2Quad(in, dc, out_w, out_h, st, s, phases_dev);
     if (phases_dev) {
         hipLaunchKernelGGL(k_jinc2_phases, grid2d(out_w, out_h), dim3(64, 4, 1), 0, s, in, dc, (const JincPhases *)phases_dev, out_w, out_h, st);
         return hipGetLastError();

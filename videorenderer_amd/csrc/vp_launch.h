@@ -18,7 +18,7 @@ hipError_t LaunchRepackV210(const uint8_t *src, int src_pitch, uint8_t *dst, int
 // batch: n frames per launch (folded kernels only) — frame z reads in.ptr + z * in_stride and writes frames[z].dst when a
 // frame table is given, else st.dst + z * dst_stride.  Returns hipErrorNotSupported when the draw has no folded kernel.
 struct FusedFrame;
-struct ResizeBatch { int n = 1; size_t in_stride = 0, dst_stride = 0; const FusedFrame *frames = nullptr; };
+struct ResizeBatch { int n = 1; size_t in_stride = 0, dst_stride = 0; const FusedFrame *frames = nullptr; int dst_aligned8 = 1; /* every frames[z].dst on an 8-byte boundary */ };
 hipError_t LaunchResize(int axis, bool swap, const Surface &in, const AxisTaps &taps, const int32_t *other,
                         int out_w, int out_h, const StoreParams &st, hipStream_t s, bool generic = false,
                         const ResizeBatch *batch = nullptr);
@@ -35,8 +35,13 @@ hipError_t LaunchCorrection(int kind, const Surface &in, const Surface &out, con
 hipError_t LaunchHdr10ToneMap(const Surface &in, const HdrToneMapParams &tm, int out_w, int out_h, const StoreParams &st, hipStream_t s);
 // ps_resize_onepass_jinc2.hlsl: the 2-D Jinc2m draw
 // phases_dev: device copy of the table BuildJincPhases filled (dyadic, unrotated draws: weights per phase instead of per pixel)
+// fast: the default tier may take the quad kernel (exact 2x; FMA contraction) instead of the phase-table kernel
 hipError_t LaunchJinc2(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st, hipStream_t s,
-                       const void *phases_dev = nullptr);
+                       const void *phases_dev = nullptr, bool fast = false);
+// vp_jinc.hip: Jinc2m at exactly 2x on both axes, one 2x2 output quad per lane (25 LDS texel reads for 4 pixels instead of 64)
+bool Jinc2QuadSupported(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st);
+hipError_t LaunchJinc2Quad(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st, hipStream_t s, const void *phases_dev,
+                           const ResizeBatch *batch = nullptr);
 bool BuildJincPhases(const DrawCoords &dc, void *out_table);      // out_table: JincPhasesBytes() bytes of host memory
 size_t JincPhasesBytes();
 

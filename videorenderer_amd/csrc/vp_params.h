@@ -130,6 +130,9 @@ struct DrawCoords {
     int swap;                                  // rotation 90/270: screen x runs along texture Y
 };
 
+// Jinc2m at dyadic ratios: the 16 weights of an output pixel per phase (BuildJincPhases, vp_kernels.hip)
+struct JincPhases { float w[4][4][16]; float wsum[4][4]; int px, py; };     // [phase y][phase x][j * 4 + i]
+
 // per-output-index tap tables for one axis (built on the host, vp_plan.cpp)
 struct AxisTaps {
     const int32_t *idx;   // [n_out * ntaps] clamped source indices
