@@ -607,8 +607,9 @@ int FusedSourceKind(const FusedParams &P)
     // source specialisations: bi-planar 16-bit (P010/P016) and bi-planar 8-bit (NV12) with MPEG-2 / co-sited chroma;
     // everything else (planar, MPEG-1 siting) runs through the variant that reads these properties at run time
     const ConvertParams &c = P.conv;
-    const bool biplanar_fast = c.fmt.planes == 2 && c.chroma_loc != CLOC_MPEG1;
-    return (biplanar_fast && c.fmt.bytes == 2) ? SRC_P01X : (biplanar_fast && c.fmt.bytes == 1) ? SRC_NV12 : SRC_GENERIC;
+    const bool biplanar_fast = c.fmt.planes == 2 && c.chroma_loc != CLOC_MPEG1, planar_fast = c.fmt.planes == 3 && c.chroma_loc != CLOC_MPEG1;
+    return (biplanar_fast && c.fmt.bytes == 2) ? SRC_P01X : (biplanar_fast && c.fmt.bytes == 1) ? SRC_NV12
+         : (planar_fast && c.fmt.bytes == 2) ? SRC_PLANAR16 : (planar_fast && c.fmt.bytes == 1) ? SRC_PLANAR8 : SRC_GENERIC;
 }
 
 bool ConvertBlocksSupported(const FusedParams &P, bool to_rt)
@@ -656,7 +657,7 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
     static const int no_wide = EnvInt("MPCVR_NO_WIDE_CONVERT", 0);
     const int lb = srck == SRC_P01X ? 16 : 8;                   // bytes of a lane's luma / chroma load
     const int dvk = FusedDoviKind(P);
-    const bool wide = !no_wide && dvk == DV_NONE && srck != SRC_GENERIC && (c.out_w & 7) == 0 && (c.rect_l & 7) == 0 && (c.pitch[0] % lb) == 0 &&
+    const bool wide = !no_wide && dvk == DV_NONE && (srck == SRC_P01X || srck == SRC_NV12) && (c.out_w & 7) == 0 && (c.rect_l & 7) == 0 && (c.pitch[0] % lb) == 0 &&
                       (c.pitch[1] % lb) == 0 && (P.plane_off[1] % lb) == 0 && P.dst_aligned16 && (P.store.off_x & 3) == 0 &&
                       (P.store.dst_pitch & 15) == 0 && P.src_aligned16;
     const int strip_w = wide ? 512 : 128;
@@ -681,7 +682,8 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
 #define MPCVR_CB2(TK, SK) do { if (fin) MPCVR_CB3(TK, SK, true); else MPCVR_CB3(TK, SK, false); } while (0)
 #define MPCVR_CBW2(TK, SK) do { if (fin) MPCVR_CBW(TK, SK, true); else MPCVR_CBW(TK, SK, false); } while (0)
 #define MPCVR_CB(TK) do { if (wide && srck == SRC_P01X) MPCVR_CBW2(TK, SRC_P01X); else if (wide) MPCVR_CBW2(TK, SRC_NV12); \
-                          else if (srck == SRC_P01X) MPCVR_CB2(TK, SRC_P01X); else if (srck == SRC_NV12) MPCVR_CB2(TK, SRC_NV12); else MPCVR_CB2(TK, SRC_GENERIC); } while (0)
+                          else if (srck == SRC_P01X) MPCVR_CB2(TK, SRC_P01X); else if (srck == SRC_NV12) MPCVR_CB2(TK, SRC_NV12); \
+                          else if (srck == SRC_PLANAR16) MPCVR_CB2(TK, SRC_PLANAR16); else if (srck == SRC_PLANAR8) MPCVR_CB2(TK, SRC_PLANAR8); else MPCVR_CB2(TK, SRC_GENERIC); } while (0)
     if (tailk == TAILK_NONE) MPCVR_CB(TAILK_NONE);
     else if (tailk == TAILK_PQ_LUT) MPCVR_CB(TAILK_PQ_LUT);
     else if (tailk == TAILK_HLG) MPCVR_CB(TAILK_HLG);
@@ -749,6 +751,8 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
         else if (srck == SRC_P01X) MPCVR_LAUNCH3(NT, TK, SRC_P01X, EPI_GENERIC); \
         else if (srck == SRC_NV12 && epik == EPI_DIRECT8) MPCVR_LAUNCH3(NT, TK, SRC_NV12, EPI_DIRECT8); \
         else if (srck == SRC_NV12) MPCVR_LAUNCH3(NT, TK, SRC_NV12, EPI_GENERIC); \
+        else if (srck == SRC_PLANAR16 && epik == EPI_DITHER8) MPCVR_LAUNCH3(NT, TK, SRC_PLANAR16, EPI_DITHER8); \
+        else if (srck == SRC_PLANAR8 && epik == EPI_DIRECT8) MPCVR_LAUNCH3(NT, TK, SRC_PLANAR8, EPI_DIRECT8); \
         else if (epik == EPI_DITHER8) MPCVR_LAUNCH3(NT, TK, SRC_GENERIC, EPI_DITHER8); \
         else MPCVR_LAUNCH3(NT, TK, SRC_GENERIC, EPI_GENERIC); } while (0)
 #define MPCVR_LAUNCH_NT(NT) \

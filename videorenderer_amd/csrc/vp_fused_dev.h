@@ -69,15 +69,16 @@ enum { DV_NONE = 0, DV_SDR = 1, DV_GENERAL = 2, DV_SDR_L2 = 3 };
 constexpr int LDS_E = LUT_N * 8;   // PQ EOTF table, {value, delta-to-next} pairs
 constexpr int LDS_V = (sizeof(DoviParams) + 15) & ~15;
 // source specialisation: GENERIC reads planes / bytes / siting at run time; P01X = bi-planar 16-bit (P010/P016), NV12 =
-// bi-planar 8-bit, both with MPEG-2 or co-sited chroma (not horizontally centred)
-enum { SRC_GENERIC = 0, SRC_P01X = 1, SRC_NV12 = 2 };
+// bi-planar 8-bit, PLANAR16 / PLANAR8 = three planes of 16- / 8-bit samples (YUV420P10/16, YV12 / I420: what software decoders
+// hand over), all with MPEG-2 or co-sited chroma (not horizontally centred)
+enum { SRC_GENERIC = 0, SRC_P01X = 1, SRC_NV12 = 2, SRC_PLANAR16 = 3, SRC_PLANAR8 = 4 };
 // epilogue specialisation: DITHER8 = B8G8R8A8 target behind a final pass (integer form); DIRECT8 = B8G8R8A8 or R10G10B10A2 target written
 // straight from the Y pass (no post-scale step: 8-bit sources, HDR passthrough to a 10-bit swap chain); both require 16-byte aligned rows and off_x % 4 == 0
 enum { EPI_GENERIC = 0, EPI_DITHER8 = 1, EPI_DIRECT8 = 2 };
 
 
-template <int SRC> __device__ __forceinline__ bool src_wide(const FusedArgs &P) { return SRC == SRC_P01X ? true : SRC == SRC_NV12 ? false : P.bytes == 2; }
-template <int SRC> __device__ __forceinline__ bool src_biplanar(const FusedArgs &P) { return SRC != SRC_GENERIC ? true : P.planes == 2; }
+template <int SRC> __device__ __forceinline__ bool src_wide(const FusedArgs &P) { return (SRC == SRC_P01X || SRC == SRC_PLANAR16) ? true : (SRC == SRC_NV12 || SRC == SRC_PLANAR8) ? false : P.bytes == 2; }
+template <int SRC> __device__ __forceinline__ bool src_biplanar(const FusedArgs &P) { return (SRC == SRC_P01X || SRC == SRC_NV12) ? true : SRC != SRC_GENERIC ? false : P.planes == 2; }
 template <int SRC> __device__ __forceinline__ bool src_center(const FusedArgs &P) { return SRC != SRC_GENERIC ? false : P.center_h != 0; }
 
 // tap offsets relative to `base` (ps_interpolation_*.hlsl).  NT = 5 is the D3D11 Lanczos3 as written (quirk Q1,
@@ -220,7 +221,7 @@ __device__ __forceinline__ uint32_t ld_uv(const FusedArgs &P, gcptr pu, gcptr pv
         const uint32_t d = ld_u16(pu + off);
         return (d & 0xffu) | ((d >> 8) << 16);
     }
-    if (P.bytes == 2) return ld_u16(pu + off) | (ld_u16(pv + off) << 16);
+    if (src_wide<SRC>(P)) return ld_u16(pu + off) | (ld_u16(pv + off) << 16);
     return ld_u8(pu + off) | (ld_u8(pv + off) << 16);
 }
 

@@ -465,6 +465,7 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
 #define MPCVR_ST4(NT, PX, TK, SK) do { if (fastepi) MPCVR_ST5(NT, PX, TK, SK, EPI_DITHER8); else if (direct) MPCVR_ST5(NT, PX, TK, SK, EPI_DIRECT8); \
                                        else MPCVR_ST5(NT, PX, TK, SK, EPI_GENERIC); } while (0)
 #define MPCVR_ST3(NT, PX, TK) do { if (srck == SRC_P01X) MPCVR_ST4(NT, PX, TK, SRC_P01X); else if (srck == SRC_NV12) MPCVR_ST4(NT, PX, TK, SRC_NV12); \
+                                   else if (srck == SRC_PLANAR16) MPCVR_ST4(NT, PX, TK, SRC_PLANAR16); else if (srck == SRC_PLANAR8) MPCVR_ST4(NT, PX, TK, SRC_PLANAR8); \
                                    else MPCVR_ST4(NT, PX, TK, SRC_GENERIC); } while (0)
 #define MPCVR_ST2(NT, PX) do { if (tailk == TAILK_NONE) MPCVR_ST3(NT, PX, TAILK_NONE); else if (tailk == TAILK_PQ_LUT) MPCVR_ST3(NT, PX, TAILK_PQ_LUT); \
                                else if (tailk == TAILK_HLG) MPCVR_ST3(NT, PX, TAILK_HLG); else MPCVR_ST3(NT, PX, TAILK_ALU); } while (0)
