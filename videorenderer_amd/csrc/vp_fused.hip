@@ -664,7 +664,13 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
     const int strips = (c.out_w + strip_w - 1) / strip_w, npairs = c.out_h / 2 + 1;
     // row pairs per wave: enough waves to fill the chip a few times over, few enough to amortise the table staging
     int pairs = 16;
-    while (pairs > 2 && (long)strips * ((npairs + pairs - 1) / pairs) * n_frames < (wide ? 4096 : 8192)) pairs >>= 1;
+    static const int pairs_waves = EnvInt("MPCVR_CB_WAVES", 0);
+    // kernels that stage tables in LDS (dither, tone map) amortise that over long waves; without tables short waves win: a wave
+    // keeps one row pair of loads in flight, so the number of resident waves is the memory-level parallelism (C1: 244 k frames/s
+    // with 4 k waves per launch, 284 k with 64 k)
+    const bool tables = fin || tailk == TAILK_PQ_LUT || dvk != DV_NONE;
+    const long want_waves = pairs_waves > 0 ? pairs_waves : tables ? (wide ? 4096 : 8192) : 65536;
+    while (pairs > 2 && (long)strips * ((npairs + pairs - 1) / pairs) * n_frames < want_waves) pairs >>= 1;
     const dim3 grid(strips, (npairs + 4 * pairs - 1) / (4 * pairs), n_frames), block(256, 1, 1);
     const size_t lds = (fin ? 4096 : 0) + (dvk != DV_NONE ? LDS_E + LDS_V + (dvk == DV_SDR_L2 ? LDS_T : 0) : tailk == TAILK_PQ_LUT ? LDS_T : 0);
     if (dvk != DV_NONE) {       // Dolby Vision: 16-bit bi-planar (P010 / P016) or whatever the generic source variant reads
