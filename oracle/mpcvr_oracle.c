@@ -1205,6 +1205,12 @@ static void fetch_pixel(const src_tex *s, int chroma_loc, int chroma_scaling, in
 }
 
 /* CopyFrameV210 — Helper.cpp:709-748: v210 dwords -> Y210 words (10 bits in the MSBs), two dwords at a time */
+/* The copy loops below restate the reference's (Helper.cpp), which read and write rows through uint32_t / uint64_t pointers
+ * whatever the row's alignment (fine on x86, undefined in ISO C).  Same loops, through alignment-1 may-alias types: UBSan-clean
+ * (`make sanitize`). */
+typedef uint64_t __attribute__((aligned(1), may_alias)) u64u;
+typedef uint32_t __attribute__((aligned(1), may_alias)) u32u;
+typedef uint16_t __attribute__((aligned(1), may_alias)) u16u;
 void orc_repack_v210(int lines, uint8_t *dst, int dst_pitch, const uint8_t *src, int src_pitch)
 {
     const int dq = dst_pitch / 12, dr = dst_pitch % 12, sq = src_pitch / 8, sr = src_pitch % 8;
@@ -1239,7 +1245,7 @@ void orc_repack_rgb(int kind, int lines, uint8_t *dst, int dst_pitch, const uint
             memcpy(dst, src, (size_t)(ap < dst_pitch ? ap : dst_pitch));
         } else if (kind == RPK_RGB24) {
             const unsigned line_pixels = (unsigned)ap / 3, line_pixels4 = line_pixels & ~3u;
-            const uint32_t *src32 = (const uint32_t *)src; uint32_t *dst32 = (uint32_t *)dst;
+            const u32u *src32 = (const u32u *)src; u32u *dst32 = (u32u *)dst;
             unsigned i = 0;
             for (; i < line_pixels4; i += 4) {
                 uint32_t sa = *src32++, sb = *src32++, sc = *src32++;
@@ -1251,7 +1257,7 @@ void orc_repack_rgb(int kind, int lines, uint8_t *dst, int dst_pitch, const uint
             }
         } else if (kind == RPK_R210) {
             const unsigned line_pixels = (unsigned)ap / 4;
-            const uint32_t *src32 = (const uint32_t *)src; uint32_t *dst32 = (uint32_t *)dst;
+            const u32u *src32 = (const u32u *)src; u32u *dst32 = (u32u *)dst;
             for (unsigned i = 0; i < line_pixels; i++) {
                 const uint32_t t = src32[i];
                 uint32_t r = ((t & 0x0000003f) << 4) | ((t & 0x0000f000) >> 12);
@@ -1261,7 +1267,7 @@ void orc_repack_rgb(int kind, int lines, uint8_t *dst, int dst_pitch, const uint
             }
         } else if (kind == RPK_RGB48) {
             const unsigned line_pixels = (unsigned)ap / 6, line_pixels4 = line_pixels & ~3u;
-            const uint64_t *src64 = (const uint64_t *)src; uint64_t *dst64 = (uint64_t *)dst;
+            const u64u *src64 = (const u64u *)src; u64u *dst64 = (u64u *)dst;
             for (unsigned i = 0; i < line_pixels4; i += 4) {      /* no remainder handling, as written (:552-563) */
                 uint64_t sa = src64[0], sb = src64[1], sc = src64[2];
                 dst64[i + 0] = sa; dst64[i + 1] = (sa >> 48) | (sb << 16); dst64[i + 2] = (sb >> 32) | (sc << 32); dst64[i + 3] = sc >> 16;
@@ -1269,7 +1275,7 @@ void orc_repack_rgb(int kind, int lines, uint8_t *dst, int dst_pitch, const uint
             }
         } else if (kind == RPK_BGR48) {
             const unsigned line_pixels = (unsigned)ap / 6, line_pixels4 = line_pixels & ~3u;
-            const uint64_t *src64 = (const uint64_t *)src; uint64_t *dst64 = (uint64_t *)dst;
+            const u64u *src64 = (const u64u *)src; u64u *dst64 = (u64u *)dst;
             unsigned i = 0;
             for (; i < line_pixels4; i += 4) {
                 uint64_t sa = *src64++, sb = *src64++, sc = *src64++;
@@ -1283,23 +1289,23 @@ void orc_repack_rgb(int kind, int lines, uint8_t *dst, int dst_pitch, const uint
                 uint64_t sa = *src64++;
                 *dst64++ = ((sa & 0xffff) << 32) | (sa & 0xffff0000) | ((sa & 0xffff00000000) >> 32);
                 if (remainder == 2) {
-                    uint64_t sb = *(const uint32_t *)src64;
+                    uint64_t sb = *(const u32u *)src64;
                     *dst64 = ((sa & 0xffff000000000000) >> 16) | ((sb & 0xffff) << 16) | ((sb & 0xffff0000) >> 16);
                 } else if (remainder == 3) {
                     uint64_t sb = *src64++;
-                    uint64_t sc = *(const uint32_t *)src64;
+                    uint64_t sc = *(const u32u *)src64;
                     *dst64++ = ((sa & 0xffff000000000000) >> 16) | ((sb & 0xffff) << 16) | ((sb & 0xffff0000) >> 16);
                     *dst64 = (sb & 0xffff00000000) | ((sb & 0xffff000000000000) >> 32) | (sc & 0xffff);
                 }
             }
         } else if (kind == RPK_BGRA64) {
             const unsigned line_pixels = (unsigned)ap / 8;
-            const uint64_t *src64 = (const uint64_t *)src; uint64_t *dst64 = (uint64_t *)dst;
+            const u64u *src64 = (const u64u *)src; u64u *dst64 = (u64u *)dst;
             for (unsigned i = 0; i < line_pixels; i++)
                 dst64[i] = ((src64[i] & 0x000000000000ffffULL) << 32) | ((src64[i] & 0x0000ffff00000000ULL) >> 32) | (src64[i] & 0xffff0000ffff0000ULL);
         } else if (kind == RPK_B64A) {
             const unsigned line_pixels = (unsigned)ap / 8;
-            const uint64_t *src64 = (const uint64_t *)src; uint64_t *dst64 = (uint64_t *)dst;
+            const u64u *src64 = (const u64u *)src; u64u *dst64 = (u64u *)dst;
             for (unsigned i = 0; i < line_pixels; i++)
                 dst64[i] = ((src64[i] & 0xFF00FF00FF000000ULL) >> 24) + ((src64[i] & 0x00FF00FF00FF0000ULL) >> 8) +
                            ((src64[i] & 0x000000000000FF00ULL) << 40) + ((src64[i] & 0x00000000000000FFULL) << 56);

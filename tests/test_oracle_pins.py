@@ -582,3 +582,16 @@ def test_dovi_l1_nits_and_trims_known_answers(oracle):
     od = oracle.fill_dovi(oracle.OrcDovi(), md)
     assert oracle.lib().orc_dovi_l1_nits(C.byref(od), out) == 1
     assert 3950 <= out[1] <= 4050 and 98 <= out[2] <= 102        # 3696/4095 ~ 4000 nits
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """`make -C oracle sanitize`: the restatement compiled with -fsanitize=address,undefined (no OpenMP) and run over whole frames
+    of awkward shapes — all 39 ColorFormat_t values, odd sizes, source rects, clipped windows, rotations, HDR tails.  Any
+    report (the recipe compiles with -fno-sanitize-recover) fails the target."""
+    import os, shutil, subprocess
+    if not shutil.which("gcc") and not shutil.which("cc"):
+        pytest.skip("no C compiler")
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    out = subprocess.run(["make", "-C", here, "sanitize"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "no sanitizer report" in out.stdout

@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 
 namespace mpcvr {
@@ -88,9 +89,18 @@ CHipVideoProcessor::~CHipVideoProcessor()
     if (m_ownStream && m_stream) (void)hipStreamDestroy(m_stream);
 }
 
+// MPCVR_LOG=1: failures (and, =2, every plan the context settles on) go to stderr as well — the stand-in for the reference's
+// DLog() lines (Utils/Util.h); mpcvr_last_error carries the same text to the caller either way.
+static int LogLevel()
+{
+    static const int lvl = [] { const char *e = std::getenv("MPCVR_LOG"); return e && *e ? std::atoi(e) : 0; }();
+    return lvl;
+}
+
 HRESULT CHipVideoProcessor::Fail(HRESULT hr, const std::string &msg)
 {
     m_lastError = msg;
+    if (LogLevel() >= 1) std::fprintf(stderr, "mpcvr[%p]: error 0x%08x: %s\n", (void *)this, (unsigned)hr, msg.c_str());
     return hr;
 }
 
@@ -645,6 +655,9 @@ HRESULT CHipVideoProcessor::UpdatePlan()
     }
     m_planDirty = false;
     UseLane(0);
+    if (LogLevel() >= 2)
+        std::fprintf(stderr, "mpcvr[%p]: plan %s (%dx%d -> %dx%d in %dx%d)\n", (void *)this, GetPathInfo().c_str(), m_srcRectWidth, m_srcRectHeight,
+                     m_videoRect.Width(), m_videoRect.Height(), m_windowRect.Width(), m_windowRect.Height());
     return MPCVR_S_OK;
 }
 
