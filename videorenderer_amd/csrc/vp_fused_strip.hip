@@ -23,6 +23,9 @@
 // HBM traffic = the source window once (+ halo rows per segment) + the render target once: nothing in between.
 #include "vp_fused_dev.h"
 
+#include <map>
+#include <mutex>
+
 namespace mpcvr {
 
 namespace {
@@ -418,6 +421,21 @@ static int StripWaves(const FusedStripParams &S, bool fastepi, bool lut)
     return best;
 }
 
+// dynamic LDS above the default limit needs the function attribute once per kernel (and device); remembered per (kernel, device)
+static hipError_t AllowLargeLds(const void *kern, size_t lds)
+{
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> granted;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &g = granted[{kern, dev}];
+    if (g >= lds) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) g = lds;
+    return e;
+}
+
 hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s)
 {
     if (!frames_dev && n_frames != 1) return hipErrorInvalidValue;
@@ -458,7 +476,7 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
 #define MPCVR_ST5(NT, PX, TK, SK, EK) do { \
         auto kern = k_fused_strip<NT, PX, TK, SK, EK>; \
         if (lds > 48 * 1024) { \
-            const hipError_t ea = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            const hipError_t ea = AllowLargeLds((const void *)kern, lds); \
             if (ea != hipSuccess) return ea; \
         } \
         hipLaunchKernelGGL(kern, grid, block, lds, s, a, q, st, frames_dev, single); } while (0)
