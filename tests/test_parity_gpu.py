@@ -597,6 +597,39 @@ def test_strip_kernel_whole_frame_vs_oracle(mpcvr, oracle, torch_cuda, label, c)
     print(f"{label}: identical channels strip {same:.6f}, tiled {same_alt:.6f}  [{info}]")
 
 
+SURFACE_STRIP = [
+    ("p210_1080p_to_1440p", dict(cformat=6, w=1920, h=1080, kind="noise", seed=331, dst=(2560, 1440), iUpscaling=4,
+                                 exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
+    ("y410_720p_to_1080p_hamming_down_y", dict(cformat=9, w=1280, h=1440, kind="noise", seed=332, dst=(1920, 1080), iUpscaling=2, iDownscaling=2,
+                                                exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
+    ("rgb32_crop_1080p_to_1440p", dict(cformat=30, w=1920, h=1080, kind="noise", seed=333, src_rect=(16, 8, 1904, 1072), dst=(2511, 1419), iUpscaling=4,
+                                       window=(2560, 1440), offset=(21, 11))),
+    ("nv12_catmull_chroma_1080p_to_1440p_fp16", dict(cformat=1, w=1920, h=1080, kind="noise", seed=334, dst=(2560, 1440), iUpscaling=3, iChromaScaling=2,
+                                                     iTexFormat=16, exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
+]
+
+
+@pytest.mark.parametrize("label,c", SURFACE_STRIP)
+def test_strip_kernel_from_a_surface_whole_frame(mpcvr, oracle, torch_cuda, label, c):
+    """The arbitrary-ratio fused kernel WITHOUT its convert stage: sources the block convert does not take (4:2:2, packed 4:4:4,
+    Catmull-Rom chroma, fp16 internal format) go through their convert kernel into m_TexConvertOutput and from there through
+    k_fused_strip<SRC_SURFACE>; an interleaved RGB sample (no convert draw at all, a source rect => the draw's row map) is
+    sampled in place.  Whole frames against the oracle, and against the tiled two-draw kernel it replaces (bit-exact with the
+    plain kernels on this SDR content): <= 1 LSB, >= 99 % identical."""
+    torch = torch_cuda
+    from videorenderer_amd import api
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+    got, info = run_product(mpcvr, torch, c)
+    assert "kernel=fused_strip:surface" in info, info
+    same = compare(got, want, f"{label} [{info}]", min_same=0.99)
+    alt, info_alt = run_product(mpcvr, torch, c, extra_flags=api.FLAG_NO_STRIP)
+    assert "kernel=" not in info_alt, info_alt
+    compare(alt, want, f"{label} [{info_alt}]", exact=True)
+    print(f"{label}: identical channels {same:.6f}  [{info}]")
+
+
 def test_full_size_flat_frame_and_dither_period(mpcvr, torch_cuda):
     """Constant input at 4K: every pass keeps it constant; the only variation is the 32x32 dither tile."""
     torch = torch_cuda

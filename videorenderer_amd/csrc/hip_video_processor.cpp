@@ -420,6 +420,7 @@ HRESULT CHipVideoProcessor::SetProcAmpValues(uint32_t flags, float b, float c, f
 }
 
 static size_t SurfBytesPerPixel(int fmt) { return fmt == SF_RGBA16F ? 8 : 4; }
+static int RgbTexFmt(const FmtConvParams &f);
 
 HRESULT CHipVideoProcessor::UploadTaps(const HostAxisTaps &h, DevBuffer &bi, DevBuffer &bw, DevBuffer &bs, DevBuffer &bb,
                                        const std::vector<int32_t> &other, AxisTaps *out)
@@ -598,13 +599,13 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         }
     }
 
-    // the arbitrary-ratio fused kernel takes an unrotated two-pass resize of a 4:2:0 source whose tables fit it
-    m_strip = false;
+    // the arbitrary-ratio fused kernel takes an unrotated two-pass resize whose tables fit it: straight from the raw sample for
+    // 4:2:0 sources (m_strip, decided below), else from the convert kernel's output / the RGB source texture (m_stripSurf)
+    m_strip = m_stripSurf = m_stripPlanned = false;
     static const bool no_strip_env = [] { const char *e = std::getenv("MPCVR_NO_STRIP"); return e && *e && *e != '0'; }();
     if (!no_strip_env && m_plan.two_pass && !m_firstJinc && !m_secondJinc && m_firstAxis == 0 && !m_firstSwap && m_plan.rotation == 0 &&
-        !m_plan.flip && m_plan.convert && !m_doviValid && m_plan.internal_fmt != SF_RGBA16F &&
-        !(m_cfg.flags & (MPCVR_FLAG_NO_FUSED | MPCVR_FLAG_NO_FAST_CONVERT | MPCVR_FLAG_NO_STRIP)) &&
-        PlanFusedStrip(hx, hy, w2, h2, w1, h1, &m_stripPlan)) {
+        !m_plan.flip && !(m_cfg.flags & (MPCVR_FLAG_NO_FUSED | MPCVR_FLAG_NO_FAST_CONVERT | MPCVR_FLAG_NO_STRIP)) &&
+        PlanFusedStrip(hx, hy, w2, h2, m_plan.convert ? w1 : m_srcWidth, m_plan.mid_h, &m_stripPlan)) {
         // one buffer: yrange | xstrip | xi_t | xw_t | yi | yw  (all 4-byte words)
         const StripPlan &sp = m_stripPlan;
         std::vector<int32_t> pack;
@@ -622,7 +623,8 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         m_stripOff[5] = put(sp.yw.data(), sp.yw.size());
         if ((hr = CheckHip(m_stripTab.CheckCreate(pack.size() * sizeof(int32_t)), "strip tables"))) return hr;
         if ((hr = CheckHip(hipMemcpy(m_stripTab.ptr, pack.data(), pack.size() * sizeof(int32_t), hipMemcpyHostToDevice), "strip tables upload"))) return hr;
-        m_strip = true;
+        m_stripPlanned = true;
+        m_strip = m_plan.convert && !m_doviValid && m_plan.internal_fmt != SF_RGBA16F;
     }
 
     // PQ -> SDR table: the fused kernel's tone-map stage and the folded convert kernel's
@@ -652,6 +654,12 @@ HRESULT CHipVideoProcessor::UpdatePlan()
     if (m_strip) {      // the launch-time conditions that do not depend on the frame pointers
         FusedStripParams sp{};
         m_strip = FillStripParams(nullptr, nullptr, m_windowRect.Width() * 4, MakeStore(nullptr, m_windowRect.Width() * 4, m_plan.swap_fmt, true), &sp);
+    }
+    if (m_stripPlanned && !m_strip) {
+        FusedStripParams sp{};
+        const Surface probe = m_plan.convert ? Surface{nullptr, (int)(w1 * SurfBytesPerPixel(m_plan.internal_fmt)), w1, h1, m_plan.internal_fmt}
+                                             : Surface{nullptr, TexPitch(), m_srcWidth, m_srcHeight, RgbTexFmt(*m_srcParams)};
+        m_stripSurf = FillStripSurfParams(probe, MakeStore(nullptr, m_windowRect.Width() * 4, m_plan.swap_fmt, true), &sp);
     }
     m_planDirty = false;
     UseLane(0);
@@ -913,7 +921,11 @@ HRESULT CHipVideoProcessor::ResizeShaderPass(void *rt, int rtPitch, const uint8_
     bool drawn = true;
     const bool plain = (m_cfg.flags & MPCVR_FLAG_NO_FUSED) != 0;      // keep the whole path on the one-kernel-fits-all versions
     const bool jfast = !(m_cfg.flags & (MPCVR_FLAG_NO_FUSED | MPCVR_FLAG_NO_FAST_CONVERT));       // Jinc2m quad kernel: default tier only
-    if (m_plan.two_pass && !plain && !m_firstJinc && !m_secondJinc && m_firstAxis == 0 && !m_firstSwap &&
+    FusedStripParams ssp{};
+    if (m_stripSurf && FillStripSurfParams(conv, last, &ssp)) {
+        // convert output (or RGB source texture) -> both draws -> final pass in the arbitrary-ratio fused kernel, no convert stage
+        hr = CheckHip(LaunchFusedStrip(ssp, nullptr, FusedFrame{(const uint8_t *)conv.ptr, last.dst}, 1, m_run), "k_fused_strip<surface>");
+    } else if (m_plan.two_pass && !plain && !m_firstJinc && !m_secondJinc && m_firstAxis == 0 && !m_firstSwap &&
         Resize2DSupported(conv, m_tapsX, m_tapsY, last)) {
         // both draws in one LDS-tiled kernel: m_TexResize stays on chip
         hr = CheckHip(LaunchResize2D(conv, m_tapsX, m_tapsY, (const int32_t *)m_otherX.ptr, m_plan.mid_h, w2, h2, last, m_run), "k_resize_2d");
@@ -956,6 +968,25 @@ bool CHipVideoProcessor::FillStripParams(const uint8_t *sample, void *dst, int d
     sp->yi = tab + m_stripOff[4]; sp->yw = tab + m_stripOff[5];
     sp->out_w = m_videoRect.Width(); sp->out_h = m_videoRect.Height();
     sp->nt = m_stripPlan.nt; sp->pxl = m_stripPlan.pxl; sp->strip_w = m_stripPlan.strip_w; sp->ring = m_stripPlan.ring; sp->acols = m_stripPlan.acols;
+    return FusedStripSupported(*sp) && FusedStripLdsBytes(*sp) <= 160 * 1024;
+}
+
+// the same kernel without its convert stage: `src` = m_TexConvertOutput (any convert kernel wrote it) or the RGB source texture
+bool CHipVideoProcessor::FillStripSurfParams(const Surface &src, const StoreParams &store, FusedStripParams *sp) const
+{
+    *sp = FusedStripParams{};
+    sp->fp.store = store;
+    const int32_t *tab = (const int32_t *)m_stripTab.ptr;
+    sp->yrange = tab + m_stripOff[0]; sp->xstrip = tab + m_stripOff[1];
+    sp->xi_t = tab + m_stripOff[2]; sp->xw_t = tab + m_stripOff[3];
+    sp->yi = tab + m_stripOff[4]; sp->yw = tab + m_stripOff[5];
+    sp->out_w = m_videoRect.Width(); sp->out_h = m_videoRect.Height();
+    sp->nt = m_stripPlan.nt; sp->pxl = m_stripPlan.pxl;
+    sp->strip_w = m_stripPlan.strip_w; sp->ring = m_stripPlan.ring; sp->acols = m_stripPlan.acols;
+    sp->surface_mode = 1;
+    sp->surf = src;
+    sp->other = m_otherX.ptr && !m_tapsX.other_identity ? (const int32_t *)m_otherX.ptr : nullptr;
+    sp->mid_h = m_plan.mid_h;
     return FusedStripSupported(*sp) && FusedStripLdsBytes(*sp) <= 160 * 1024;
 }
 
@@ -1163,6 +1194,7 @@ bool CHipVideoProcessor::BatchPlan(const uint8_t *sample0, void *rt0, int rtPitc
     const Surface cs{nullptr, convPitch, w1, h1, m_plan.internal_fmt};
     const StoreParams final = MakeStore(rt0, rtPitch, m_plan.swap_fmt, true);
     if (m_plan.two_pass) {
+        if (m_stripSurf) return true;
         if (m_firstAxis == 0 && !m_firstSwap && Resize2DSupported(cs, m_tapsX, m_tapsY, final)) return true;
         const Surface mid{nullptr, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
         return ResizeHasFoldedKernel(m_firstAxis, m_firstSwap, cs, m_tapsX, MakeStore(nullptr, mid.pitch, SF_RGBA16F, false)) &&
@@ -1198,7 +1230,11 @@ HRESULT CHipVideoProcessor::ProcessBatchLaunches(int n, const FusedFrame *table,
         conv.store.dst = m_batchConv.ptr;
         if ((hr = CheckHip(LaunchConvertBlocks(conv, tab, FusedFrame{nullptr, nullptr}, m, m_stream, m_convBytes), "k_convert_blocks"))) return hr;
         ResizeBatch b1; b1.n = m; b1.in_stride = m_convBytes;
-        if (m_plan.two_pass && m_firstAxis == 0 && !m_firstSwap && Resize2DSupported(cs, m_tapsX, m_tapsY, final)) {
+        FusedStripParams ssp{};
+        if (m_stripSurf && FillStripSurfParams(cs, final, &ssp)) {
+            ssp.surf_stride = m_convBytes;
+            if ((hr = CheckHip(LaunchFusedStrip(ssp, tab, FusedFrame{nullptr, nullptr}, m, m_stream), "k_fused_strip<surface>"))) return hr;
+        } else if (m_plan.two_pass && m_firstAxis == 0 && !m_firstSwap && Resize2DSupported(cs, m_tapsX, m_tapsY, final)) {
             b1.frames = tab;
             if ((hr = CheckHip(LaunchResize2D(cs, m_tapsX, m_tapsY, (const int32_t *)m_otherX.ptr, m_plan.mid_h, w2, h2, final, m_stream, &b1), "k_resize_2d"))) return hr;
         } else if (m_plan.two_pass) {
@@ -1375,8 +1411,8 @@ std::string CHipVideoProcessor::GetPathInfo()
 {
     if (!m_srcParams) return "uninitialised";
     if (m_planDirty && UpdatePlan() != MPCVR_S_OK) return "error: " + m_lastError;
-    if (!m_strip || m_plan.fused_up2x) return m_plan.describe();
-    return m_plan.describe() + ";kernel=fused_strip(taps=" + std::to_string(m_stripPlan.nt) + ",px_per_lane=" + std::to_string(m_stripPlan.pxl) +
+    if ((!m_strip && !m_stripSurf) || m_plan.fused_up2x) return m_plan.describe();
+    return m_plan.describe() + (m_strip ? ";kernel=fused_strip(taps=" : ";kernel=fused_strip:surface(taps=") + std::to_string(m_stripPlan.nt) + ",px_per_lane=" + std::to_string(m_stripPlan.pxl) +
            ",strip=" + std::to_string(m_stripPlan.strip_w) + ",ring=" + std::to_string(m_stripPlan.ring) + ")";
 }
 

@@ -208,7 +208,10 @@ private:
     const void *m_jincFirstTab = nullptr, *m_jincSecondTab = nullptr;
     HRESULT UploadJincPhases(const DrawCoords &dc, DevBuffer &buf, const void **tab);
     // arbitrary-ratio fused kernel (vp_fused_strip.hip): geometry planned with the tap tables (UpdatePlan)
-    bool m_strip = false;
+    bool m_strip = false;          // raw 4:2:0 sample -> render target in one kernel
+    bool m_stripSurf = false;      // any other source: the convert kernel's output (or the RGB source texture) -> render target through the same kernel, no convert stage
+    bool m_stripPlanned = false;
+    bool FillStripSurfParams(const Surface &src, const StoreParams &store, FusedStripParams *sp) const;
     StripPlan m_stripPlan;
     DevBuffer m_stripTab;          // yrange | xstrip | xi_t | xw_t | yi | yw, word offsets in m_stripOff
     size_t m_stripOff[6] = {0, 0, 0, 0, 0, 0};

@@ -71,7 +71,8 @@ constexpr int LDS_V = (sizeof(DoviParams) + 15) & ~15;
 // source specialisation: GENERIC reads planes / bytes / siting at run time; P01X = bi-planar 16-bit (P010/P016), NV12 =
 // bi-planar 8-bit, PLANAR16 / PLANAR8 = three planes of 16- / 8-bit samples (YUV420P10/16, YV12 / I420: what software decoders
 // hand over), all with MPEG-2 or co-sited chroma (not horizontally centred)
-enum { SRC_GENERIC = 0, SRC_P01X = 1, SRC_NV12 = 2, SRC_PLANAR16 = 3, SRC_PLANAR8 = 4 };
+enum { SRC_GENERIC = 0, SRC_P01X = 1, SRC_NV12 = 2, SRC_PLANAR16 = 3, SRC_PLANAR8 = 4,
+       SRC_SURFACE = 5 };      // k_fused_strip only: no convert stage, the source is a B8G8R8A8 / R10G10B10A2 / fp16 surface
 // epilogue specialisation: DITHER8 = B8G8R8A8 target behind a final pass (integer form); DIRECT8 = B8G8R8A8 or R10G10B10A2 target written
 // straight from the Y pass (no post-scale step: 8-bit sources, HDR passthrough to a 10-bit swap chain); both require 16-byte aligned rows and off_x % 4 == 0
 enum { EPI_GENERIC = 0, EPI_DITHER8 = 1, EPI_DIRECT8 = 2 };

@@ -42,7 +42,13 @@ struct StripArgs {
     int ring_mask;               // ring rows - 1 (8 or 16 rows)
     int seg_rows;                // output rows per segment
     int acols;                   // columns of an A row (even)
-    float a_scale;               // 2^24 / maxv: A holds integer codes as fp16 subnormals
+    float a_scale;               // 2^24 / maxv: A holds integer codes as fp16 subnormals (1 for an fp16 surface: real halfs)
+    // SRC_SURFACE: the X draw samples a surface (m_TexConvertOutput of any convert kernel, or the source texture of an
+    // interleaved RGB sample) instead of converting raw YUV: its format, pitch, width (clamp), the row map of the draw
+    // (row of m_TexResize -> surface row; null = identity) and the distance between the frames of a batch
+    const uint8_t *surf; const int32_t *other;
+    int surf_fmt, surf_pitch, surf_w;
+    size_t surf_stride;
 };
 
 // v_fma_mix_f32: fp16 operand (lo / hi half of a dword) x fp32 weight + fp32 accumulator
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
         const uint64_t v = (uint64_t)q;
         return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
     };
-    const gcptr py = (gcptr)uniform_ptr(frame.src);
+    const gcptr py = (gcptr)uniform_ptr(SRC == SRC_SURFACE && Q.surf ? (const void *)(Q.surf + (size_t)blockIdx.z * Q.surf_stride) : (const void *)frame.src);
     const uint64_t dst_u = uniform_ptr(frame.dst);
     const gptr pdst = (gptr)dst_u;
     st.dst = (void *)dst_u;
@@ -175,11 +181,34 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
     asm volatile("" : "+v"(CC[0]), "+v"(CC[1]), "+v"(CC[2]));
 
     // raw codes of pass 0 are prefetched one row pair ahead
+    constexpr int YSRC = SRC == SRC_SURFACE ? SRC_GENERIC : SRC;      // (the YUV helpers are not instantiated for a surface)
     RawAddr ra0;
-    make_raw_addr<SRC>(P, min(c0 + 2 * lane, W - 2), ra0);
+    if (SRC != SRC_SURFACE) make_raw_addr<YSRC>(P, min(c0 + 2 * lane, W - 2), ra0);
     Raw rawn;
     auto fetch = [&](int pp, const RawAddr &ra, Raw &r) {
-        load_raw<SRC>(P, py, ra, clampi(2 * pp - 1, 0, H - 1), clampi(2 * pp, 0, H - 1), r);
+        load_raw<YSRC>(P, py, ra, clampi(2 * pp - 1, 0, H - 1), clampi(2 * pp, 0, H - 1), r);
+    };
+    // SRC_SURFACE: the 2x2 texels of block b of pair pp, [row][column], as stored (one dword; two for fp16)
+    u32x2 sraw[2][2];
+    auto fetch_s = [&](int pp, int b, u32x2 (&t)[2][2]) {
+        const cptr<int32_t> other = as_const(Q.other);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int row = clampi(2 * pp - 1 + r, 0, H - 1);
+            const gcptr rowp = py + (uint32_t)(Q.other ? other[row] : row) * (uint32_t)Q.surf_pitch;
+#pragma unroll
+            for (int col = 0; col < 2; col++) {
+                const uint32_t x = (uint32_t)min(c0 + 2 * b + col, Q.surf_w - 1);
+                if (Q.surf_fmt == SF_RGBA16F) t[r][col] = *(const __attribute__((address_space(1))) u32x2 *)(rowp + x * 8u);
+                else t[r][col] = u32x2{ld_u32(rowp + x * 4u), 0u};
+            }
+        }
+    };
+    // texel -> {r | g << 16, b}: UNORM codes (fp16 subnormals for stage X) or the halfs of an fp16 texel
+    auto unpack_s = [&](u32x2 t, uint32_t &rg, uint32_t &bb) {
+        if (Q.surf_fmt == SF_RGBA16F) { rg = t.x; bb = t.y & 0xffffu; }
+        else if (Q.surf_fmt == SF_RGB10A2) { rg = (t.x & 0x3ffu) | ((t.x << 6) & 0x03ff0000u); bb = (t.x >> 20) & 0x3ffu; }
+        else { rg = __builtin_amdgcn_perm(0u, t.x, 0x0c010c02u); bb = t.x & 0xffu; }       // B8G8R8A8: r = byte 2, g = byte 1
     };
 
     // pair pp = source rows 2pp-1, 2pp (rect-relative; the first and the last pair of a frame hold one useful row)
@@ -188,15 +217,33 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
         const int sy0 = P.rect_t + clampi(r0, 0, H - 1), sy1 = P.rect_t + clampi(r0 + 1, 0, H - 1);
         for (int pass = 0; pass < npass; pass++) {
             const int b = pass * 64 + lane;
+            if (SRC == SRC_SURFACE) {       // no convert stage: the texels are m_TexConvertOutput's (or the source texture's) own codes
+                u32x2 t[2][2];
+                if (pass == 0) {
+#pragma unroll
+                    for (int r = 0; r < 2; r++) { t[r][0] = sraw[r][0]; t[r][1] = sraw[r][1]; }
+                    fetch_s(pp + 1, lane, sraw);
+                } else fetch_s(pp, b, t);
+                uint32_t rg[2][2], bb[2][2];            // [column][row]
+#pragma unroll
+                for (int col = 0; col < 2; col++)
+#pragma unroll
+                    for (int r = 0; r < 2; r++) unpack_s(t[r][col], rg[col][r], bb[col][r]);
+                if (b < nb) {
+                    *(u32x4 *)(Aw + 32 * b) = u32x4{rg[0][0], bb[0][0], rg[0][1], bb[0][1]};
+                    *(u32x4 *)(Aw + 32 * b + 16) = u32x4{rg[1][0], bb[1][0], rg[1][1], bb[1][1]};
+                }
+                continue;
+            }
             f2 rc[2][3];
             if (pass == 0) {
-                convert_block<TAIL, SRC>(P, MM, GG, CC, rawn, sy0, sy1, T, rc);
+                convert_block<TAIL, YSRC>(P, MM, GG, CC, rawn, sy0, sy1, T, rc);
                 fetch(pp + 1, ra0, rawn);
             } else {
                 RawAddr ra; Raw rw;
-                make_raw_addr<SRC>(P, min(c0 + 2 * b, W - 2), ra);
+                make_raw_addr<YSRC>(P, min(c0 + 2 * b, W - 2), ra);
                 fetch(pp, ra, rw);
-                convert_block<TAIL, SRC>(P, MM, GG, CC, rw, sy0, sy1, T, rc);
+                convert_block<TAIL, YSRC>(P, MM, GG, CC, rw, sy0, sy1, T, rc);
             }
             // store to m_TexConvertOutput (UNORM: floor(sat(x)*maxv + 0.5)): x*maxv + 2^23 leaves the code in the low
             // mantissa bits — as an fp16 bit pattern that code is the subnormal k * 2^-24
@@ -235,7 +282,7 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
                 const int row = r0 + r;
                 if (row < 0 || row >= H) continue;               // wave-uniform
                 // m_TexResize is R16G16B16A16_FLOAT (:3155): round to fp16 (RNE)
-                const lds_u32 dstp = (lds_u32)(ring_addr + (uint32_t)((row & Q.ring_mask) * ring_row));
+                const lds_u32 dstp = (lds_u32)(uintptr_t)(ring_addr + (uint32_t)((row & Q.ring_mask) * ring_row));
                 const h2v h0 = __builtin_convertvector(f2{acc[r][0][0], acc[r][0][1]}, h2v);
                 dstp[0] = __builtin_bit_cast(uint32_t, h0);
                 if (PXL == 2) {
@@ -254,7 +301,7 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
     const cptr<int32_t> yrange = as_const(Q.yrange);
     int p = (yrange[2 * y0] + 1) >> 1;
     int have = 2 * p - 2;                                // largest source row in the ring
-    fetch(p, ra0, rawn);
+    if (SRC == SRC_SURFACE) fetch_s(p, lane, sraw); else fetch(p, ra0, rawn);
     const uint32_t lane_off = (uint32_t)(P.off_x + x_first) * 4u;
     const bool st8 = PXL == 2 && ((P.off_x + xs) & 1) == 0 && (((uintptr_t)dst_u | (uintptr_t)P.dst_pitch) & 7) == 0;
     const bool dpair = PXL == 2 && ((P.off_x + xs) & 1) == 0;            // the lane's two dither texels are one aligned 8-byte read
@@ -284,7 +331,7 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
         for (int k = 0; k < NT; k++) {
             const int slot_off = (yi[k] & Q.ring_mask) * ring_row;
             const float w = yw[k];
-            const lds_u32 tp = (lds_u32)(ring_addr + (uint32_t)slot_off);
+            const lds_u32 tp = (lds_u32)(uintptr_t)(ring_addr + (uint32_t)slot_off);
             const uint32_t t0 = tp[0], t1 = tp[1];
             if (PXL == 2) {
                 const uint32_t tb = tp[PXL];
@@ -385,6 +432,16 @@ bool FusedStripSupported(const FusedStripParams &S)
 {
     const FusedParams &P = S.fp;
     const ConvertParams &c = P.conv;
+    if (S.surface_mode) {
+        if (S.surf.fmt != SF_BGRA8 && S.surf.fmt != SF_RGB10A2 && S.surf.fmt != SF_RGBA16F) return false;
+        if (S.mid_h < 1 || S.surf.w < 1 || S.surf.pitch <= 0 || (S.surf.pitch & 3)) return false;
+        if ((uint64_t)S.surf.pitch * (uint64_t)S.surf.h >= (1ull << 32)) return false;
+        if (P.store.off_x + S.out_w > 0 && (uint64_t)P.store.dst_pitch * (uint64_t)(std::max(P.store.off_y, 0) + S.out_h) >= (1ull << 32)) return false;
+        if (S.nt != 4 && S.nt != 6 && S.nt != 8) return false;
+        if (!S.xi_t || !S.xw_t || !S.yi || !S.yw || !S.yrange || !S.xstrip) return false;
+        if ((S.ring != 8 && S.ring != 16) || (S.pxl != 1 && S.pxl != 2)) return false;
+        return S.strip_w >= S.pxl && S.strip_w <= 64 * S.pxl && (S.strip_w % S.pxl) == 0;
+    }
     if (c.out_fmt != SF_BGRA8 && c.out_fmt != SF_RGB10A2) return false;
     if (c.fmt.layout != LAY_PLANAR || c.fmt.subsampling != 420 || c.chroma_scaling != 1 || c.blend_deint || c.dovi) return false;
     if (c.out_w < 8 || c.out_h < 2 || (c.out_w & 1) || (c.out_h & 1)) return false;
@@ -441,7 +498,19 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
     if (!frames_dev && n_frames != 1) return hipErrorInvalidValue;
     const FusedParams &P = S.fp;
     FusedArgs a;
-    FillFusedArgs(P, a);
+    if (S.surface_mode) {       // store-side constants only: there is no convert stage
+        std::memset(&a, 0, sizeof(a));
+        a.maxv = S.surf.fmt == SF_RGB10A2 ? 1023.0f : 255.0f;       // format of m_TexsPostScale = the internal format
+        if (P.store.mode == ST_FINAL) a.maxv = P.store.mid_fmt == SF_RGB10A2 ? 1023.0f : 255.0f;
+        a.inv_maxv = 1.0f / a.maxv;
+        a.q_over_maxv = (float)P.store.quant / a.maxv;
+        a.epi_mul = FinalPassMultiplier(P.store.quant, (int)a.maxv);
+        a.dst_pitch = P.store.dst_pitch; a.off_x = P.store.off_x; a.off_y = P.store.off_y;
+        a.final_pass = P.store.mode == ST_FINAL; a.out10 = P.store.dst_fmt == SF_RGB10A2;
+        a.quant = (float)P.store.quant;
+        a.dither = P.store.dither;
+        a.H = S.mid_h; a.W = S.surf.w;
+    } else FillFusedArgs(P, a);
     StripArgs q{};
     q.xi_t = (const int32_t *)S.xi_t; q.xw_t = (const float *)S.xw_t;
     q.yi = (const int32_t *)S.yi; q.yw = (const float *)S.yw;
@@ -451,6 +520,11 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
     q.ring_mask = S.ring - 1;
     q.acols = S.acols;
     q.a_scale = 16777216.0f / a.maxv;
+    if (S.surface_mode) {
+        q.surf = n_frames > 1 || !single.src ? (const uint8_t *)S.surf.ptr : nullptr;      // a batch reads surf + z * stride; one frame: single.src
+        q.other = S.other; q.surf_fmt = S.surf.fmt; q.surf_pitch = S.surf.pitch; q.surf_w = S.surf.w; q.surf_stride = S.surf_stride;
+        q.a_scale = S.surf.fmt == SF_RGBA16F ? 1.0f : 16777216.0f / (S.surf.fmt == SF_RGB10A2 ? 1023.0f : 255.0f);
+    }
     // segment height: long segments recompute less (the taps' span of source rows each), short ones fill the chip
     static const int seg_env = EnvInt("MPCVR_STRIP_SEG", 0);
     int seg = seg_env;
@@ -464,10 +538,10 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
     const StoreParams &st = P.store;
     const bool inside = st.off_x >= 0 && st.off_y >= 0 && (st.clip_w <= 0 || (st.off_x + S.out_w <= st.clip_w && st.off_y + S.out_h <= st.clip_h));
     const bool fastepi = inside && st.mode == ST_FINAL && st.dst_fmt == SF_BGRA8 && st.quant == 255 && a.epi_mul != 0 &&
-                         P.conv.out_fmt == SF_RGB10A2 && st.mid_fmt == SF_RGB10A2 && (st.dst_pitch & 3) == 0;
+                         (S.surface_mode || P.conv.out_fmt == SF_RGB10A2) && st.mid_fmt == SF_RGB10A2 && (st.dst_pitch & 3) == 0;
     // straight UNORM store of the Y result (no final pass) into a B8G8R8A8 / R10G10B10A2 target or post-scale texture
     const bool direct = !fastepi && inside && st.mode == ST_SURFACE && (st.dst_fmt == SF_BGRA8 || st.dst_fmt == SF_RGB10A2) && (st.dst_pitch & 3) == 0;
-    const int tailk = FusedTailKind(P), srck = FusedSourceKind(P);
+    const int tailk = S.surface_mode ? TAILK_NONE : FusedTailKind(P), srck = S.surface_mode ? SRC_SURFACE : FusedSourceKind(P);
     const int waves = StripWaves(S, fastepi, tailk == TAILK_PQ_LUT);
     const size_t lds = StripLds(S, fastepi, tailk == TAILK_PQ_LUT, waves);
     const int n_segs = (S.out_h + q.seg_rows - 1) / q.seg_rows;
@@ -487,6 +561,15 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
                                    else MPCVR_ST4(NT, PX, TK, SRC_GENERIC); } while (0)
 #define MPCVR_ST2(NT, PX) do { if (tailk == TAILK_NONE) MPCVR_ST3(NT, PX, TAILK_NONE); else if (tailk == TAILK_PQ_LUT) MPCVR_ST3(NT, PX, TAILK_PQ_LUT); \
                                else if (tailk == TAILK_HLG) MPCVR_ST3(NT, PX, TAILK_HLG); else MPCVR_ST3(NT, PX, TAILK_ALU); } while (0)
+    if (S.surface_mode) {
+        if (ntk == 4 && S.pxl == 2) MPCVR_ST4(4, 2, TAILK_NONE, SRC_SURFACE);
+        else if (ntk == 6 && S.pxl == 2) MPCVR_ST4(6, 2, TAILK_NONE, SRC_SURFACE);
+        else if (ntk == 8 && S.pxl == 2) MPCVR_ST4(8, 2, TAILK_NONE, SRC_SURFACE);
+        else if (ntk == 4) MPCVR_ST4(4, 1, TAILK_NONE, SRC_SURFACE);
+        else if (ntk == 6) MPCVR_ST4(6, 1, TAILK_NONE, SRC_SURFACE);
+        else MPCVR_ST4(8, 1, TAILK_NONE, SRC_SURFACE);
+        return hipGetLastError();
+    }
     if (ntk == 4 && S.pxl == 2) MPCVR_ST2(4, 2);
     else if (ntk == 6 && S.pxl == 2) MPCVR_ST2(6, 2);
     else if (ntk == 8 && S.pxl == 2) MPCVR_ST2(8, 2);

@@ -89,6 +89,15 @@ struct FusedStripParams {
     const void *xstrip;        // int32[n_strips][2]: {smallest, largest} source column of every strip's taps
     int out_w, out_h;
     int nt, pxl, strip_w, ring, acols;   // PlanFusedStrip's choices
+    // surface mode (surf.ptr != nullptr or surf_batch): no convert stage — the X draw samples `surf` (m_TexConvertOutput of any
+    // convert kernel, or the source texture of an interleaved RGB sample); fp.store is the epilogue, fp.conv is not used.
+    // other: the draw's row map (device; null = identity); mid_h: rows of the X draw's result; surf_stride: bytes between the
+    // frames of a batch (frame z reads surf.ptr + z * surf_stride)
+    Surface surf;
+    const int32_t *other;
+    int mid_h;
+    size_t surf_stride;
+    int surface_mode;
 };
 bool FusedStripSupported(const FusedStripParams &S);
 hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
