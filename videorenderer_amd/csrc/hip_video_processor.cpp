@@ -1086,7 +1086,8 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
         m_timed = true;
         return hr;
     }
-    if ((!m_plan.fused_up2x && !strip && !batchable) || !src4) {
+    // (a batch of one needs no frame table: the frame travels in the kernel arguments, like mpcvr_process)
+    if ((!m_plan.fused_up2x && !strip && !batchable) || !src4 || n == 1) {
         // samples that are repacked (or, not starting on a dword, copied) first share m_TexSrcVideo: those batches stay on the
         // context stream, frame by frame
         const bool repack = m_srcParams->cformat == MPCVR_CF_V210 || m_srcParams->layout == LAY_RGB || !src4;

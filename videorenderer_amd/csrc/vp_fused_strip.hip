@@ -542,9 +542,13 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
     // straight UNORM store of the Y result (no final pass) into a B8G8R8A8 / R10G10B10A2 target or post-scale texture
     const bool direct = !fastepi && inside && st.mode == ST_SURFACE && (st.dst_fmt == SF_BGRA8 || st.dst_fmt == SF_RGB10A2) && (st.dst_pitch & 3) == 0;
     const int tailk = S.surface_mode ? TAILK_NONE : FusedTailKind(P), srck = S.surface_mode ? SRC_SURFACE : FusedSourceKind(P);
-    const int waves = StripWaves(S, fastepi, tailk == TAILK_PQ_LUT);
-    const size_t lds = StripLds(S, fastepi, tailk == TAILK_PQ_LUT, waves);
     const int n_segs = (S.out_h + q.seg_rows - 1) / q.seg_rows;
+    // waves per workgroup: as many as LDS allows for a launch that fills the chip several times over; a small launch (one frame) is
+    // spread over all CUs instead — 1,800 work items in 16-wave workgroups occupy 113 of 256 CUs, four waves deep
+    int waves = StripWaves(S, fastepi, tailk == TAILK_PQ_LUT);
+    const long items = (long)q.n_strips * n_segs * n_frames;
+    if (items < 512L * waves) waves = (int)std::max<long>(1, std::min<long>(waves, items / 512));
+    const size_t lds = StripLds(S, fastepi, tailk == TAILK_PQ_LUT, waves);
     const dim3 grid((q.n_strips * n_segs + waves - 1) / waves, 1, n_frames), block(64 * waves, 1, 1);
     const int ntk = S.nt;
 #define MPCVR_ST5(NT, PX, TK, SK, EK) do { \
