@@ -630,6 +630,44 @@ def test_strip_kernel_from_a_surface_whole_frame(mpcvr, oracle, torch_cuda, labe
     print(f"{label}: identical channels {same:.6f}  [{info}]")
 
 
+def _cr_cases():
+    from tests.golden.cases import ext, MPEG1, MPEG2, COSITED, TV, FULL, M709, M2020, P2020, TPQ
+    return [
+        ("nv12_mpeg2_same_size", dict(cformat=1, w=1920, h=1080, kind="noise", seed=341, dst=(1920, 1080), exfmt=ext(MPEG2, TV, M709))),
+        ("p010_cosited_pq_same_size", dict(cformat=2, w=1920, h=1080, kind="noise", seed=342, dst=(1920, 1080), exfmt=ext(COSITED, TV, M2020, P2020, TPQ))),
+        ("yuv420p10_mpeg1_to_1440p", dict(cformat=20, w=1920, h=1080, kind="noise", seed=343, dst=(2560, 1440), iUpscaling=4, exfmt=ext(MPEG1, FULL, M709))),
+        ("yv12_mpeg2_rect_down", dict(cformat=14, w=1920, h=1080, kind="noise", seed=344, src_rect=(8, 4, 1912, 1076), dst=(1270, 716), iDownscaling=2,
+                                      exfmt=ext(MPEG2, TV, M709))),
+    ]
+
+
+@pytest.mark.parametrize("label,c", _cr_cases())
+def test_catmull_rom_chroma_block_convert_whole_frame(mpcvr, oracle, torch_cuda, label, c):
+    """CHROMA_CatmullRom on the 2x2-block convert (round 2: a block's four pixels share one 4-column x 5-row chroma
+    neighbourhood; weights per column / row parity and siting from the shader's own expressions): bi-planar and three-plane
+    sources, all three sitings, same size (one kernel) and in front of a resize (block convert -> k_fused_strip:surface), whole
+    1080p frames against the oracle — and against the per-pixel kernel it replaces (MPCVR_FLAG_NO_FAST_CONVERT)."""
+    torch = torch_cuda
+    from videorenderer_amd import api
+    c = dict(c, iChromaScaling=2)
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+    got, info = run_product(mpcvr, torch, c)
+    ref, info_ref = run_product(mpcvr, torch, c, extra_flags=api.FLAG_NO_FAST_CONVERT)
+    if not has_tail(c):
+        same = compare(got, want, f"{label} [{info}]", min_same=0.99)
+        compare(ref, want, f"{label} [{info_ref}]", exact=True)
+    else:
+        # behind the PQ tail: the ill-conditioned handful (see test_dovi_block_convert_whole_frame) is counted, not fatal
+        for out, tag in ((got, info), (ref, info_ref)):
+            d = np.abs(out[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
+            same = float((d == 0).mean())
+            assert same >= 0.99 and int((d > 1).sum()) <= 1e-5 * d.size and d.max() <= 8, (label, tag, same, int((d > 1).sum()), int(d.max()))
+        same = float((np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16)) == 0).mean())
+    print(f"{label}: identical channels {same:.6f}  [{info}]")
+
+
 def test_full_size_flat_frame_and_dither_period(mpcvr, torch_cuda):
     """Constant input at 4K: every pass keeps it constant; the only variation is the 32x32 dither tile."""
     torch = torch_cuda

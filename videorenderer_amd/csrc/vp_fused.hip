@@ -298,7 +298,8 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
 // ------------------------------------------------------------------------------------------------
 // DV != DV_NONE: the Dolby Vision variant (TAIL is then TAILK_ALU: the tone-map table is not used) — LDS holds the PQ EOTF table
 // and a copy of the frame's DoviParams instead.
-template <int TAIL, int SRC, bool FINAL, int DV = DV_NONE>
+// CHR = 1: CHROMA_CatmullRom instead of CHROMA_Bilinear (4 x 5 chroma texels per block, convert_block_cr).
+template <int TAIL, int SRC, bool FINAL, int DV = DV_NONE, int CHR = 0>
 __global__ __launch_bounds__(256) void k_convert_blocks(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single, int pairs,
                                                        uint8_t *batch_dst, size_t batch_stride, FrameTable32 tab)
 {
@@ -355,20 +356,26 @@ __global__ __launch_bounds__(256) void k_convert_blocks(FusedArgs P, const Fused
     DoviRegs DRG;
     if (DV != DV_NONE) load_dovi_regs(P.dovi, DRG);
     RawAddr ra;
-    make_raw_addr<SRC>(P, X, ra);
+    RawAddrCR rac;
+    if (CHR) make_raw_addr_cr<SRC>(P, X, rac); else make_raw_addr<SRC>(P, X, ra);
     const uint32_t lane_off = (uint32_t)(P.off_x + X) * 4u;
     Raw raw;
+    RawCR rawc;
     {
         const int a = 2 * pair0 - 1;
-        load_raw<SRC>(P, py, ra, clampi(a, 0, H - 1), clampi(a + 1, 0, H - 1), raw);
+        if (CHR) load_raw_cr<SRC>(P, py, rac, clampi(a, 0, H - 1), clampi(a + 1, 0, H - 1), rawc);
+        else load_raw<SRC>(P, py, ra, clampi(a, 0, H - 1), clampi(a + 1, 0, H - 1), raw);
     }
     for (int p = 0; p < pairs; p++) {
         const int a = 2 * (pair0 + p) - 1;                             // rows a, a+1
         if (a >= H) break;
         f2 rc[2][3];
-        convert_block<TAIL, SRC, DV>(P, MM, GG, CC, raw, P.rect_t + clampi(a, 0, H - 1), P.rect_t + clampi(a + 1, 0, H - 1), T, rc, DL, TE, &DRG);
-        if (p + 1 < pairs && a + 2 < H)
-            load_raw<SRC>(P, py, ra, clampi(a + 2, 0, H - 1), clampi(a + 3, 0, H - 1), raw);
+        if (CHR) convert_block_cr<TAIL, SRC, DV>(P, MM, GG, CC, rawc, P.rect_t + clampi(a, 0, H - 1), P.rect_t + clampi(a + 1, 0, H - 1), T, rc, DL, TE, &DRG);
+        else convert_block<TAIL, SRC, DV>(P, MM, GG, CC, raw, P.rect_t + clampi(a, 0, H - 1), P.rect_t + clampi(a + 1, 0, H - 1), T, rc, DL, TE, &DRG);
+        if (p + 1 < pairs && a + 2 < H) {
+            if (CHR) load_raw_cr<SRC>(P, py, rac, clampi(a + 2, 0, H - 1), clampi(a + 3, 0, H - 1), rawc);
+            else load_raw<SRC>(P, py, ra, clampi(a + 2, 0, H - 1), clampi(a + 3, 0, H - 1), raw);
+        }
         // UNORM store of m_TexConvertOutput: floor(sat(x)*maxv + 0.5); x*maxv + 2^23 leaves the code in the low mantissa bits
         uint32_t code[2][3][2];                                        // [column][channel][row]
 #pragma unroll
@@ -551,6 +558,27 @@ bool FusedUp2xSupported(const FusedParams &P)
     return true;
 }
 
+// CHROMA_CatmullRom for 4:2:0 (Shaders.cpp:66-72,242-251): the phase t of even / odd luma columns and rows for a chroma siting, and
+// catmull_weights(t) with the shader's own expressions in fp32
+void ChromaCatmullWeights(int chroma_loc, float wx[2][4], float wy[2][4])
+{
+    for (int par = 0; par < 2; par++) {
+        float tx = par ? 0.75f : 0.25f, ty = par ? 0.75f : 0.25f;
+        if (chroma_loc == CLOC_COSITED) { tx += -0.25f; ty += -0.25f; }
+        else if (chroma_loc == CLOC_MPEG1) { tx += -0.5f; ty += -0.5f; }
+        else { tx += -0.25f; ty += -0.5f; }
+        for (int axis = 0; axis < 2; axis++) {
+            const float t = axis ? ty : tx;
+            float *w = axis ? wy[par] : wx[par];
+            const float t2 = t * t, t3 = t * t2;
+            w[0] = t2 - (t3 + t) / 2;
+            w[1] = t3 * 1.5f + 1 - t2 * 2.5f;
+            w[2] = t2 * 2 + t / 2 - t3 * 1.5f;
+            w[3] = (t3 - t2) / 2;
+        }
+    }
+}
+
 // the convert-side and store-side constants both kernels of this file take
 void FillFusedArgs(const FusedParams &P, FusedArgs &a)
 {
@@ -576,6 +604,7 @@ void FillFusedArgs(const FusedParams &P, FusedArgs &a)
         a.c[i] = c.cm[9 + i];
     }
     a.dovi = c.dovi; a.eotf_lut = P.eotf_lut; a.sy = sy; a.sc = sc;
+    ChromaCatmullWeights(c.chroma_loc, a.crx, a.cry);
     a.tail = c.tail; a.gamma = c.gamma; a.lum_scale = c.lum_scale;
     std::memcpy(a.gamut, c.gamut, sizeof(a.gamut));
     a.lut = P.pq_lut;
@@ -616,8 +645,9 @@ bool ConvertBlocksSupported(const FusedParams &P, bool to_rt)
 {
     const ConvertParams &c = P.conv;
     if (c.out_fmt != SF_BGRA8 && c.out_fmt != SF_RGB10A2) return false;
-    if (c.fmt.layout != LAY_PLANAR || c.fmt.subsampling != 420 || c.chroma_scaling != 1 || c.blend_deint) return false;
+    if (c.fmt.layout != LAY_PLANAR || c.fmt.subsampling != 420 || (c.chroma_scaling != 1 && c.chroma_scaling != 2) || c.blend_deint) return false;
     if (c.dovi && !P.eotf_lut) return false;       // the Dolby Vision variant decodes PQ from a table (MPCVR_FLAG_NO_LUT: per-pixel kernel)
+    if (c.chroma_scaling == 2 && c.dovi) return false;     // Catmull-Rom chroma: no Dolby Vision variant instantiated
     if (c.out_w < 8 || c.out_h < 2 || (c.out_w & 1) || (c.out_h & 1)) return false;
     if (!P.fast_convert) return false;
     if ((uint64_t)c.pitch[0] * (uint64_t)(c.rect_t + c.out_h + 2) >= (1ull << 32)) return false;
@@ -657,7 +687,8 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
     static const int no_wide = EnvInt("MPCVR_NO_WIDE_CONVERT", 0);
     const int lb = srck == SRC_P01X ? 16 : 8;                   // bytes of a lane's luma / chroma load
     const int dvk = FusedDoviKind(P);
-    const bool wide = !no_wide && dvk == DV_NONE && (srck == SRC_P01X || srck == SRC_NV12) && (c.out_w & 7) == 0 && (c.rect_l & 7) == 0 && (c.pitch[0] % lb) == 0 &&
+    const bool catmull = c.chroma_scaling == 2;
+    const bool wide = !no_wide && !catmull && dvk == DV_NONE && (srck == SRC_P01X || srck == SRC_NV12) && (c.out_w & 7) == 0 && (c.rect_l & 7) == 0 && (c.pitch[0] % lb) == 0 &&
                       (c.pitch[1] % lb) == 0 && (P.plane_off[1] % lb) == 0 && P.dst_aligned16 && (P.store.off_x & 3) == 0 &&
                       (P.store.dst_pitch & 15) == 0 && P.src_aligned16;
     const int strip_w = wide ? 512 : 128;
@@ -683,7 +714,8 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
 #undef MPCVR_CBD
         return hipGetLastError();
     }
-#define MPCVR_CB3(TK, SK, FN) hipLaunchKernelGGL((k_convert_blocks<TK, SK, FN>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab)
+#define MPCVR_CB3(TK, SK, FN) do { if (catmull) hipLaunchKernelGGL((k_convert_blocks<TK, SK, FN, DV_NONE, 1>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab); \
+                                   else hipLaunchKernelGGL((k_convert_blocks<TK, SK, FN>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab); } while (0)
 #define MPCVR_CBW(TK, SK, FN) hipLaunchKernelGGL((k_convert_blocks_wide<TK, SK, FN>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab)
 #define MPCVR_CB2(TK, SK) do { if (fin) MPCVR_CB3(TK, SK, true); else MPCVR_CB3(TK, SK, false); } while (0)
 #define MPCVR_CBW2(TK, SK) do { if (fin) MPCVR_CBW(TK, SK, true); else MPCVR_CBW(TK, SK, false); } while (0)

@@ -39,6 +39,8 @@ struct FusedArgs {
     int dbg;                       // ablation switches of the matrix-core kernel (MPCVR_MX_DBG; 0 in normal use)
     // Dolby Vision (DV template argument of convert_block): reshaping curves / LMS matrix / L2 trims (device DoviParams, copied
     // into LDS by the kernel), the PQ EOTF table, and the UNORM scales the matrix does NOT carry then (the curves want 0..1 values)
+    // CHROMA_CatmullRom (4:2:0): catmull_weights(t) of even / odd luma columns and rows for the stream's chroma siting
+    float crx[2][4], cry[2][4];
     const DoviParams *dovi;
     const float *eotf_lut;         // LUT_N floats (device): log2 ST2084ToLinear((i / (LUT_N - 1))^2, 1)
     float sy, sc;
@@ -329,6 +331,10 @@ __device__ __forceinline__ void dovi_reshape_block(const DoviRegs &R, const Dovi
 // evaluated in code units (vertical lerp first), UNORM scale folded into the matrix.  out[column][ch] = the channel as
 // a (row 0, row 1) pair — the layout LDS slice A wants — saturated (every continuation, tail or UNORM store,
 // saturates first).
+template <int TAIL, int SRC, int DV>
+__device__ __forceinline__ void convert_block_yuv(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], f2 (&Ycol)[2], f2 (&Ucol)[2], f2 (&Vcol)[2],
+                                                  const f2 *T, f2 out[2][3], const DoviParams *DL, const f2 *TE, const DoviRegs *DR);
+
 template <int TAIL, int SRC, int DV = DV_NONE>
 __device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], const Raw &r, int sy0, int sy1, const f2 *T, f2 out[2][3],
                                               const DoviParams *DL = nullptr, const f2 *TE = nullptr, const DoviRegs *DR = nullptr)
@@ -360,6 +366,15 @@ __device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)
         Ucol[0] = Uc[1]; Vcol[0] = Vc[1];
         Ucol[1] = pk_fma(Uc[2], splat(0.5f), Uc[1] * splat(0.5f)); Vcol[1] = pk_fma(Vc[2], splat(0.5f), Vc[1] * splat(0.5f));
     }
+    convert_block_yuv<TAIL, SRC, DV>(P, MM, GG, CC, Ycol, Ucol, Vcol, T, out, DL, TE, DR);
+}
+
+// everything behind ShaderGetPixels: (Dolby Vision reshaping,) colour matrix, HDR tail — for the (Y, U, V) of the block's four pixels in
+// code units, [column] as (row 0, row 1) pairs, whichever chroma filter produced them
+template <int TAIL, int SRC, int DV>
+__device__ __forceinline__ void convert_block_yuv(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], f2 (&Ycol)[2], f2 (&Ucol)[2], f2 (&Vcol)[2],
+                                                  const f2 *T, f2 out[2][3], const DoviParams *DL, const f2 *TE, const DoviRegs *DR)
+{
     if (DV != DV_NONE) {
         // ShaderDoviReshape[Poly] (Shaders.cpp:531-589,786-792) on the sampled (Y, U, V) of every pixel, as 0..1 values; the
         // matrix behind it (ycc_to_rgb, DoviColorMatrix) then carries no UNORM scale.  Curves are read from the LDS copy.
@@ -572,6 +587,87 @@ __device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)
 }
 
 
+// ---- CHROMA_CatmullRom for 4:2:0 (Shaders.cpp:66-72,242-251,288-299): the 2x2 block's four pixels weigh the same 4 chroma columns
+// bx-1 .. bx+2 (two weight sets, by column parity) and — rows (odd, odd+1) straddling two chroma rows — 5 chroma rows base .. base+4
+// (base = (sy0 >> 1) - 1; row r uses base + o_r .. + 3 with the weight set of its parity).  P.crx / P.cry hold catmull_weights(t) for
+// t(parity) as the shader computes it for the stream's siting, built on the host with the shader's own expressions. ----
+struct RawCR {
+    uint32_t y[2];
+    uint32_t c[5][4];        // [chroma row base + j][column bx - 1 + i]: U | V << 16 raw codes
+};
+struct RawAddrCR { uint32_t yoff; uint32_t coff[4]; };
+
+template <int SRC>
+__device__ __forceinline__ void make_raw_addr_cr(const FusedArgs &P, int Xg, RawAddrCR &ra)
+{
+    const int sx0 = P.rect_l + Xg, bx = sx0 >> 1;
+    const int yb = src_wide<SRC>(P) ? 2 : 1;
+    const int cb = src_biplanar<SRC>(P) ? 2 * yb : yb;
+    ra.yoff = (uint32_t)(yb * sx0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) ra.coff[i] = (uint32_t)(cb * clampi(bx - 1 + i, 0, P.cw - 1));
+}
+template <int SRC>
+__device__ __forceinline__ void load_raw_cr(const FusedArgs &P, gcptr py, const RawAddrCR &ra, int y0, int y1, RawCR &r)
+{
+    const int sy0 = P.rect_t + y0, sy1 = P.rect_t + y1;
+    const gcptr ry0 = py + (uint32_t)sy0 * (uint32_t)P.pitch_y, ry1 = py + (uint32_t)sy1 * (uint32_t)P.pitch_y;
+    r.y[0] = src_wide<SRC>(P) ? ld_u32(ry0 + opaque(ra.yoff)) : ld_u16(ry0 + opaque(ra.yoff));
+    r.y[1] = src_wide<SRC>(P) ? ld_u32(ry1 + opaque(ra.yoff)) : ld_u16(ry1 + opaque(ra.yoff));
+    const int base = (sy0 >> 1) - 1;
+    const gcptr pu = py + P.off_u, pv = src_biplanar<SRC>(P) ? pu : py + P.off_v;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const uint32_t o = (uint32_t)clampi(base + j, 0, P.ch - 1) * (uint32_t)P.pitch_c;
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.c[j][i] = ld_uv<SRC>(P, pu + o, pv + o, opaque(ra.coff[i]));
+    }
+}
+template <int TAIL, int SRC, int DV = DV_NONE>
+__device__ __forceinline__ void convert_block_cr(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], const RawCR &r, int sy0, int sy1, const f2 *T, f2 out[2][3],
+                                                 const DoviParams *DL = nullptr, const f2 *TE = nullptr, const DoviRegs *DR = nullptr)
+{
+    // horizontal pass: Q[row j][column parity] = sum_i wx[parity][i] * texel[j][i], as (U, V) pairs
+    f2 Q[5][2];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        f2 t[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] = f2{(float)(r.c[j][i] & 0xffffu), (float)(r.c[j][i] >> 16)};
+#pragma unroll
+        for (int par = 0; par < 2; par++) {
+            const float *w = P.crx[par];
+            Q[j][par] = pk_fma(splat(w[3]), t[3], pk_fma(splat(w[2]), t[2], pk_fma(splat(w[1]), t[1], splat(w[0]) * t[0])));
+        }
+    }
+    // vertical pass per luma row: its 4 chroma rows start at o_r = (sy_r >> 1) - 1 - base, its weights follow its parity
+    const int base = (sy0 >> 1) - 1;
+    f2 uv[2][2];                                  // [column][row] = (U, V)
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int sy = rr ? sy1 : sy0;
+        const int o = (sy >> 1) - 1 - base;       // 0 or 1, wave-uniform
+        const float *w = P.cry[sy & 1];
+#pragma unroll
+        for (int col = 0; col < 2; col++) {
+            const f2 q0 = o ? Q[1][col] : Q[0][col], q1 = o ? Q[2][col] : Q[1][col], q2 = o ? Q[3][col] : Q[2][col], q3 = o ? Q[4][col] : Q[3][col];
+            uv[col][rr] = pk_fma(splat(w[3]), q3, pk_fma(splat(w[2]), q2, pk_fma(splat(w[1]), q1, splat(w[0]) * q0)));
+        }
+    }
+    f2 Ycol[2], Ucol[2], Vcol[2];
+    if (src_wide<SRC>(P)) {
+        Ycol[0] = f2{(float)(r.y[0] & 0xffffu), (float)(r.y[1] & 0xffffu)};
+        Ycol[1] = f2{(float)(r.y[0] >> 16), (float)(r.y[1] >> 16)};
+    } else {
+        Ycol[0] = f2{(float)(r.y[0] & 0xffu), (float)(r.y[1] & 0xffu)};
+        Ycol[1] = f2{(float)((r.y[0] >> 8) & 0xffu), (float)((r.y[1] >> 8) & 0xffu)};
+    }
+#pragma unroll
+    for (int col = 0; col < 2; col++) { Ucol[col] = f2{uv[col][0].x, uv[col][1].x}; Vcol[col] = f2{uv[col][0].y, uv[col][1].y}; }
+    convert_block_yuv<TAIL, SRC, DV>(P, MM, GG, CC, Ycol, Ucol, Vcol, T, out, DL, TE, DR);
+}
+
+
 inline int EnvInt(const char *name, int def)
 {
     const char *v = std::getenv(name);
@@ -582,6 +678,7 @@ inline int EnvInt(const char *name, int def)
 
 // host side, vp_fused.hip
 void FillFusedArgs(const FusedParams &P, FusedArgs &a);
+void ChromaCatmullWeights(int chroma_loc, float wx[2][4], float wy[2][4]);
 int FusedTailKind(const FusedParams &P);
 int FusedSourceKind(const FusedParams &P);
 int FusedDoviKind(const FusedParams &P);          // DV_* for the launch
