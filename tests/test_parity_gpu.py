@@ -194,7 +194,12 @@ def test_direct_convert_vs_oracle(mpcvr, oracle, torch_cuda, name):
         assert info.startswith("passes:source") or c.get("flip"), info
     else:
         assert info.startswith("direct:convert"), info
-    blocks = c["cformat"] in (1, 2, 3, 14, 17, 20, 21) and c.get("iChromaScaling", 1) == 1      # 4:2:0, bilinear chroma
+    chroma = c.get("iChromaScaling", 1)
+    # what the 2x2-block convert takes (FMA contraction, scale folded into the matrix => <= 1 LSB instead of bit-exact): 4:2:0 with
+    # bilinear or Catmull-Rom chroma, planar / bi-planar 4:2:2 with bilinear chroma, planar 4:4:4 YUV
+    blocks = ((c["cformat"] in (1, 2, 3, 14, 17, 20, 21) and chroma in (1, 2) and not c.get("dovi") or
+               c["cformat"] in (1, 2, 3, 14, 17, 20, 21) and chroma == 1) or
+              (c["cformat"] in (6, 7, 15, 18, 22, 23) and chroma == 1) or c["cformat"] in (16, 19, 24, 25))
     if c.get("output_format", 0) == 1:
         compare_rgb10(got, want, name, exact=not has_tail(c) and not blocks)
     elif has_tail(c) or blocks:
@@ -598,9 +603,9 @@ def test_strip_kernel_whole_frame_vs_oracle(mpcvr, oracle, torch_cuda, label, c)
 
 
 SURFACE_STRIP = [
-    ("p210_1080p_to_1440p", dict(cformat=6, w=1920, h=1080, kind="noise", seed=331, dst=(2560, 1440), iUpscaling=4,
+    ("y210_1080p_to_1440p", dict(cformat=8, w=1920, h=1080, kind="noise", seed=331, dst=(2560, 1440), iUpscaling=4,
                                  exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
-    ("y410_720p_to_1080p_hamming_down_y", dict(cformat=9, w=1280, h=1440, kind="noise", seed=332, dst=(1920, 1080), iUpscaling=2, iDownscaling=2,
+    ("y216_720p_to_1080p_hamming_down_y", dict(cformat=9, w=1280, h=1440, kind="noise", seed=332, dst=(1920, 1080), iUpscaling=2, iDownscaling=2,
                                                 exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
     ("rgb32_crop_1080p_to_1440p", dict(cformat=30, w=1920, h=1080, kind="noise", seed=333, src_rect=(16, 8, 1904, 1072), dst=(2511, 1419), iUpscaling=4,
                                        window=(2560, 1440), offset=(21, 11))),
@@ -665,6 +670,43 @@ def test_catmull_rom_chroma_block_convert_whole_frame(mpcvr, oracle, torch_cuda,
             same = float((d == 0).mean())
             assert same >= 0.99 and int((d > 1).sum()) <= 1e-5 * d.size and d.max() <= 8, (label, tag, same, int((d > 1).sum()), int(d.max()))
         same = float((np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16)) == 0).mean())
+    print(f"{label}: identical channels {same:.6f}  [{info}]")
+
+
+@pytest.mark.parametrize("label,c,path", [
+    ("p210_pq_1080p_to_4k", dict(cformat=6, w=1920, h=1080, kind="noise", seed=351, dst=(3840, 2160), iUpscaling=4,
+                                 exfmt=GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"]), "fused_up2x"),
+    ("yuv422p10_same_size", dict(cformat=22, w=1920, h=1080, kind="noise", seed=352, dst=(1920, 1080),
+                                 exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]), "direct:convert+final"),
+    ("yv16_1080p_to_1440p", dict(cformat=15, w=1920, h=1080, kind="noise", seed=353, dst=(2560, 1440), iUpscaling=2,
+                                 exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]), "passes:convert,resizeX,resizeY;kernel=fused_strip("),
+    ("yv24_720p_to_1440p", dict(cformat=16, w=1280, h=720, kind="noise", seed=355, dst=(2560, 1440), iUpscaling=4,
+                                exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]), "fused_up2x"),
+    ("yuv444p10_pq_1080p_to_1440p", dict(cformat=24, w=1920, h=1080, kind="noise", seed=356, dst=(2560, 1440), iUpscaling=4, iChromaScaling=2,
+                                         exfmt=GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"]), "passes:convert,resizeX,resizeY+final;kernel=fused_strip("),
+    ("yuv444p16_same_size", dict(cformat=25, w=1920, h=1080, kind="noise", seed=357, dst=(1920, 1080), iChromaScaling=0,
+                                 exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]), "direct:convert+final"),
+    ("gbrp10_stays_on_the_per_draw_path", dict(cformat=27, w=640, h=360, kind="noise", seed=358, dst=(960, 540), iUpscaling=2), "passes:convert,resizeX,resizeY+final;kernel=fused_strip:surface("),
+    ("p216_rect_down_1p5x", dict(cformat=7, w=1920, h=1080, kind="noise", seed=354, src_rect=(8, 4, 1912, 1076), dst=(1270, 714), iDownscaling=2,
+                                 exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]), "passes:convert,resizeX,resizeY+final;kernel=fused_strip("),
+])
+def test_planar_422_and_444_on_the_fused_paths(mpcvr, oracle, torch_cuda, label, c, path):
+    """Planar / bi-planar 4:2:2 (P210, P216, YV16, YUV422P10) on the 2x2-block convert (round 2): chroma rows are luma rows, so a
+    row pair takes row 0 from chroma row sy and row 1 from sy + 1 with weight 1 — the 4:2:0 block code with a different row
+    rule; planar 4:4:4 (YV24, YUV444P8/10/16) likewise with a chroma sample per pixel and no filter.  The exact-2x kernel, the strip
+    kernel and the same-size convert take these formats now; three-plane RGB (GBRP) does not.  Whole frames against the oracle."""
+    torch = torch_cuda
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+    got, info = run_product(mpcvr, torch, c)
+    assert info.startswith(path), info
+    if has_tail(c):
+        d = np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
+        same = float((d == 0).mean())
+        assert same >= 0.99 and int((d > 1).sum()) <= 1e-5 * d.size and d.max() <= 8, (label, same, int((d > 1).sum()), int(d.max()))
+    else:
+        same = compare(got, want, f"{label} [{info}]", min_same=0.99)
     print(f"{label}: identical channels {same:.6f}  [{info}]")
 
 

@@ -548,7 +548,9 @@ bool FusedUp2xSupported(const FusedParams &P)
     if (P.wy.ntaps != P.wx.ntaps || P.wy.q1_quirk != P.wx.q1_quirk) return false;
     if (std::memcmp(P.wx.w_even, P.wy.w_even, sizeof(P.wx.w_even)) || std::memcmp(P.wx.w_odd, P.wy.w_odd, sizeof(P.wx.w_odd))) return false;
     if (c.out_fmt != SF_BGRA8 && c.out_fmt != SF_RGB10A2) return false;
-    if (c.fmt.subsampling != 420 || c.chroma_scaling != 1 || c.blend_deint) return false;
+    const bool planar_yuv = c.fmt.layout == LAY_PLANAR && c.fmt.planes == 3 && !P.planar_rgb;
+    if (c.fmt.subsampling != 420 && !(c.fmt.subsampling == 422 && c.fmt.layout == LAY_PLANAR) && !(c.fmt.subsampling == 444 && planar_yuv)) return false;
+    if ((c.chroma_scaling != 1 && c.fmt.subsampling != 444) || c.chroma_scaling == 2 || c.blend_deint) return false;
     if (c.out_w < 8 || c.out_h < 8 || (c.out_w & 1) || (c.out_h & 1)) return false;
     if (!P.fast_convert) return false;            // dword loads need aligned rows / rect (host-checked)
     // 32-bit row offsets inside the kernel
@@ -591,8 +593,11 @@ void FillFusedArgs(const FusedParams &P, FusedArgs &a)
     a.tex_w = c.tex_w; a.cw = c.cw; a.ch = c.ch;
     a.rect_l = c.rect_l; a.rect_t = c.rect_t; a.W = c.out_w; a.H = c.out_h;
     a.bytes = c.fmt.bytes; a.planes = c.fmt.planes;
-    a.center_h = c.chroma_loc == CLOC_MPEG1;
-    a.v_off4 = c.chroma_loc == CLOC_COSITED ? 1 : 0;
+    // 4:2:2 has one siting (Shaders.cpp:319-325: u' = sx/2 + 0.25, v' = sy): the 4:2:0 switches stay off
+    a.sub422 = c.fmt.subsampling == 422;
+    a.sub444 = c.fmt.subsampling == 444;
+    a.center_h = c.fmt.subsampling == 420 && c.chroma_loc == CLOC_MPEG1;
+    a.v_off4 = (c.fmt.subsampling == 420 && c.chroma_loc == CLOC_COSITED) ? 1 : 0;
     // UNORM scale: v/255, or (v << shift)/65535 for planar data; interleaved UV planes carry no shift
     const float sy = c.fmt.bytes == 1 ? 1.0f / 255.0f : (float)(1 << c.fmt.shift) / 65535.0f;
     const float sc = c.fmt.bytes == 1 ? 1.0f / 255.0f : (float)(1 << (c.fmt.planes == 2 ? 0 : c.fmt.shift)) / 65535.0f;
@@ -636,7 +641,8 @@ int FusedSourceKind(const FusedParams &P)
     // source specialisations: bi-planar 16-bit (P010/P016) and bi-planar 8-bit (NV12) with MPEG-2 / co-sited chroma;
     // everything else (planar, MPEG-1 siting) runs through the variant that reads these properties at run time
     const ConvertParams &c = P.conv;
-    const bool biplanar_fast = c.fmt.planes == 2 && c.chroma_loc != CLOC_MPEG1, planar_fast = c.fmt.planes == 3 && c.chroma_loc != CLOC_MPEG1;
+    const bool centred = c.fmt.subsampling == 420 && c.chroma_loc == CLOC_MPEG1;
+    const bool biplanar_fast = c.fmt.planes == 2 && !centred, planar_fast = c.fmt.planes == 3 && !centred;
     return (biplanar_fast && c.fmt.bytes == 2) ? SRC_P01X : (biplanar_fast && c.fmt.bytes == 1) ? SRC_NV12
          : (planar_fast && c.fmt.bytes == 2) ? SRC_PLANAR16 : (planar_fast && c.fmt.bytes == 1) ? SRC_PLANAR8 : SRC_GENERIC;
 }
@@ -645,7 +651,11 @@ bool ConvertBlocksSupported(const FusedParams &P, bool to_rt)
 {
     const ConvertParams &c = P.conv;
     if (c.out_fmt != SF_BGRA8 && c.out_fmt != SF_RGB10A2) return false;
-    if (c.fmt.layout != LAY_PLANAR || c.fmt.subsampling != 420 || (c.chroma_scaling != 1 && c.chroma_scaling != 2) || c.blend_deint) return false;
+    if (c.fmt.layout != LAY_PLANAR || c.blend_deint) return false;
+    if (c.fmt.subsampling == 444) { if (c.fmt.planes != 3 || P.planar_rgb) return false; }          // 4:4:4 planar YUV: no chroma filter at all
+    else if (c.fmt.subsampling == 422) { if (c.chroma_scaling != 1) return false; }                   // 4:2:2: the bilinear variant only
+    else if (c.fmt.subsampling != 420 || (c.chroma_scaling != 1 && c.chroma_scaling != 2)) return false;
+    if (c.fmt.subsampling == 444 && c.chroma_scaling == 2) {}                                         // (Catmull-Rom is a no-op at 4:4:4)
     if (c.dovi && !P.eotf_lut) return false;       // the Dolby Vision variant decodes PQ from a table (MPCVR_FLAG_NO_LUT: per-pixel kernel)
     if (c.chroma_scaling == 2 && c.dovi) return false;     // Catmull-Rom chroma: no Dolby Vision variant instantiated
     if (c.out_w < 8 || c.out_h < 2 || (c.out_w & 1) || (c.out_h & 1)) return false;
@@ -687,7 +697,7 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
     static const int no_wide = EnvInt("MPCVR_NO_WIDE_CONVERT", 0);
     const int lb = srck == SRC_P01X ? 16 : 8;                   // bytes of a lane's luma / chroma load
     const int dvk = FusedDoviKind(P);
-    const bool catmull = c.chroma_scaling == 2;
+    const bool catmull = c.chroma_scaling == 2 && c.fmt.subsampling == 420;
     const bool wide = !no_wide && !catmull && dvk == DV_NONE && (srck == SRC_P01X || srck == SRC_NV12) && (c.out_w & 7) == 0 && (c.rect_l & 7) == 0 && (c.pitch[0] % lb) == 0 &&
                       (c.pitch[1] % lb) == 0 && (P.plane_off[1] % lb) == 0 && P.dst_aligned16 && (P.store.off_x & 3) == 0 &&
                       (P.store.dst_pitch & 15) == 0 && P.src_aligned16;

@@ -23,6 +23,8 @@ struct FusedArgs {
     int bytes, planes;
     int center_h;                  // MPEG-1 siting: chroma sample centred between luma columns
     int v_off4;                    // vertical chroma offset in quarter chroma rows: 1 for co-sited (+0.25), else 0
+    int sub422;                    // 4:2:2 planar / bi-planar (P210, P216, YV16, YUV422P10...): chroma subsampled horizontally only
+    int sub444;                    // 4:4:4 planar (YV24, YUV444P8/10/16): a chroma sample per pixel, no interpolation at all
     float m[9], c[3];              // colour matrix with the UNORM scale (and CopyPlane10to16 shift) folded in
     int tail; float gamma, lum_scale;
     float gamut[9];
@@ -207,7 +209,7 @@ struct RawAddr {
 template <int SRC>
 __device__ __forceinline__ void make_raw_addr(const FusedArgs &P, int Xg, RawAddr &ra)
 {
-    const int sx0 = P.rect_l + Xg, c0 = sx0 >> 1;
+    const int sx0 = P.rect_l + Xg, c0 = P.sub444 ? sx0 : sx0 >> 1;        // 4:4:4: texels c0, c0+1 are the block's own two columns
     const int yb = src_wide<SRC>(P) ? 2 : 1;
     const int cb = src_biplanar<SRC>(P) ? 2 * yb : yb;
     ra.yoff = (uint32_t)(yb * sx0);
@@ -230,7 +232,8 @@ __device__ __forceinline__ uint32_t ld_uv(const FusedArgs &P, gcptr pu, gcptr pv
 
 // vertical chroma position of source row sy (Shaders.cpp:118-138): v' = (sy+0.5)/2 [+0.25 co-sited] - 0.5, kept in
 // QUARTER chroma rows as an integer (4v' = 2sy - 1 [+1]) so that the whole siting computation stays on the scalar unit
-__device__ __forceinline__ int chroma_v4(const FusedArgs &P, int sy) { return 2 * sy - 1 + P.v_off4; }
+// (4:2:2: chroma rows are luma rows — v' = sy exactly, so a row pair takes row 0 from chroma row sy0 and row 1 from sy0 + 1)
+__device__ __forceinline__ int chroma_v4(const FusedArgs &P, int sy) { return (P.sub422 | P.sub444) ? 4 * sy : 2 * sy - 1 + P.v_off4; }
 // fr/4 for fr = 0..4 as a float built from integer selects (wave-uniform => SGPR; no v_cvt/v_mul per iteration)
 __device__ __forceinline__ float quarter(int fr)
 {
@@ -362,9 +365,10 @@ __device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)
     if (src_center<SRC>(P)) {                     // u' = sx/2 - 0.25 (MPEG-1 siting runs through the generic variant)
         Ucol[0] = pk_fma(Uc[1], splat(0.75f), Uc[0] * splat(0.25f)); Vcol[0] = pk_fma(Vc[1], splat(0.75f), Vc[0] * splat(0.25f));
         Ucol[1] = pk_fma(Uc[2], splat(0.25f), Uc[1] * splat(0.75f)); Vcol[1] = pk_fma(Vc[2], splat(0.25f), Vc[1] * splat(0.75f));
-    } else {                                      // u' = sx/2
+    } else {                                      // u' = sx/2; 4:4:4: the odd column has its own sample
         Ucol[0] = Uc[1]; Vcol[0] = Vc[1];
-        Ucol[1] = pk_fma(Uc[2], splat(0.5f), Uc[1] * splat(0.5f)); Vcol[1] = pk_fma(Vc[2], splat(0.5f), Vc[1] * splat(0.5f));
+        Ucol[1] = P.sub444 ? Uc[2] : pk_fma(Uc[2], splat(0.5f), Uc[1] * splat(0.5f));
+        Vcol[1] = P.sub444 ? Vc[2] : pk_fma(Vc[2], splat(0.5f), Vc[1] * splat(0.5f));
     }
     convert_block_yuv<TAIL, SRC, DV>(P, MM, GG, CC, Ycol, Ucol, Vcol, T, out, DL, TE, DR);
 }
