@@ -603,9 +603,9 @@ def test_strip_kernel_whole_frame_vs_oracle(mpcvr, oracle, torch_cuda, label, c)
 
 
 SURFACE_STRIP = [
-    ("y210_1080p_to_1440p", dict(cformat=8, w=1920, h=1080, kind="noise", seed=331, dst=(2560, 1440), iUpscaling=4,
+    ("y410_1080p_to_1440p", dict(cformat=12, w=1920, h=1080, kind="noise", seed=331, dst=(2560, 1440), iUpscaling=4,
                                  exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
-    ("y216_720p_to_1080p_hamming_down_y", dict(cformat=9, w=1280, h=1440, kind="noise", seed=332, dst=(1920, 1080), iUpscaling=2, iDownscaling=2,
+    ("y416_720p_to_1080p_hamming_down_y", dict(cformat=13, w=1280, h=1440, kind="noise", seed=332, dst=(1920, 1080), iUpscaling=2, iDownscaling=2,
                                                 exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
     ("rgb32_crop_1080p_to_1440p", dict(cformat=30, w=1920, h=1080, kind="noise", seed=333, src_rect=(16, 8, 1904, 1072), dst=(2511, 1419), iUpscaling=4,
                                        window=(2560, 1440), offset=(21, 11))),
@@ -695,6 +695,41 @@ def test_planar_422_and_444_on_the_fused_paths(mpcvr, oracle, torch_cuda, label,
     row pair takes row 0 from chroma row sy and row 1 from sy + 1 with weight 1 — the 4:2:0 block code with a different row
     rule; planar 4:4:4 (YV24, YUV444P8/10/16) likewise with a chroma sample per pixel and no filter.  The exact-2x kernel, the strip
     kernel and the same-size convert take these formats now; three-plane RGB (GBRP) does not.  Whole frames against the oracle."""
+    torch = torch_cuda
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+    got, info = run_product(mpcvr, torch, c)
+    assert info.startswith(path), info
+    if has_tail(c):
+        d = np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
+        same = float((d == 0).mean())
+        assert same >= 0.99 and int((d > 1).sum()) <= 1e-5 * d.size and d.max() <= 8, (label, same, int((d > 1).sum()), int(d.max()))
+    else:
+        same = compare(got, want, f"{label} [{info}]", min_same=0.99)
+    print(f"{label}: identical channels {same:.6f}  [{info}]")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("label,c,path", [
+    ("yuy2_same_size_nearest_is_bilinear", dict(cformat=4, w=1920, h=1080, kind="noise", seed=361, dst=(1920, 1080), iChromaScaling=0,
+                                                exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]), "direct:convert"),
+    ("uyvy_720p_to_1440p", dict(cformat=5, w=1280, h=720, kind="noise", seed=362, dst=(2560, 1440), iUpscaling=4,
+                                exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]), "fused_up2x"),
+    ("y210_pq_1080p_to_1440p", dict(cformat=8, w=1920, h=1080, kind="noise", seed=363, dst=(2560, 1440), iUpscaling=4,
+                                    exfmt=GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"]), "passes:convert,resizeX,resizeY+final;kernel=fused_strip("),
+    ("y216_rect_down_1p5x", dict(cformat=9, w=1920, h=1080, kind="noise", seed=364, src_rect=(8, 4, 1912, 1076), dst=(1270, 714), iDownscaling=2,
+                                 exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]), "passes:convert,resizeX,resizeY+final;kernel=fused_strip("),
+    ("v210_1080p_to_4k", dict(cformat=10, w=1920, h=1080, kind="noise", seed=365, dst=(3840, 2160), iUpscaling=2,
+                              exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]), "fused_up2x"),
+    ("yuy2_catmull_chroma_stays_per_pixel", dict(cformat=4, w=640, h=360, kind="noise", seed=366, dst=(960, 540), iUpscaling=2, iChromaScaling=2),
+     "passes:convert,resizeX,resizeY;kernel=fused_strip:surface("),
+])
+def test_packed_422_on_the_fused_paths(mpcvr, oracle, torch_cuda, label, c, path):
+    """Packed 4:2:2 (YUY2, UYVY, Y210, Y216, and v210 behind its unpack) on the 2x2-block convert: one texel holds the block's two
+    luma samples and its own chroma, the next texel the neighbour's (Shaders.cpp:195-229: even pixel = own chroma, odd pixel = the
+    mean with the next texel; CHROMA_Nearest is not distinguished) — the planar 4:2:2 block code behind a whole-texel loader.
+    CATMULLROM_05 chroma stays on the per-pixel convert.  Whole frames against the oracle."""
     torch = torch_cuda
     frame, pitch = case_frame(c)
     p = oracle_params(oracle, c)

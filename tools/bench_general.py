@@ -18,6 +18,8 @@ CASES = [("C1 1080p NV12 BT.709 -> 1080p BGRA8 (no resize)", 1920, 1080, 1920, 1
          ("1080p P010 Dolby Vision (polynomial, no L2) -> 1440p Lanczos3 -> SDR", 1920, 1080, 2560, 1440, dict(iUpscaling=4), 2, dict(chroma=5, nominal_range=2), "poly", ()),
          ("1080p RGB32 -> 1440p (Lanczos3), no convert draw", 1920, 1080, 2560, 1440, dict(iUpscaling=4), 30, dict()),
          ("1080p P210 (4:2:2 10-bit) BT.709 -> 1440p (Lanczos3)", 1920, 1080, 2560, 1440, dict(iUpscaling=4), 6, dict(chroma=5, nominal_range=2, matrix=1)),
+         ("1080p YUY2 (packed 4:2:2 8-bit) BT.709 -> 1440p (Lanczos3)", 1920, 1080, 2560, 1440, dict(iUpscaling=4), 4, dict(chroma=5, nominal_range=2, matrix=1)),
+         ("1080p Y210 (packed 4:2:2 10-bit) BT.709 -> 4K (Lanczos3 2x)", 1920, 1080, 3840, 2160, dict(iUpscaling=4), 8, dict(chroma=5, nominal_range=2, matrix=1)),
          ("1080p NV12 BT.709, Catmull-Rom chroma -> 1440p (Lanczos3)", 1920, 1080, 2560, 1440, dict(iUpscaling=4, iChromaScaling=2), 1, dict(chroma=5, nominal_range=2, matrix=1)),
          ("4K P010 PQ -> 1440p (Hamming down) -> SDR", 3840, 2160, 2560, 1440, dict(iDownscaling=2)),
          ("4K P010 PQ -> 1080p (Hamming down 2x) -> SDR", 3840, 2160, 1920, 1080, dict(iDownscaling=2)),
@@ -54,7 +56,7 @@ for case in CASES:
             return (torch.randint(64, 941, (nb // 2,), device="cuda", dtype=torch.int32) << 6).to(torch.int16).view(torch.uint8)
         if cf == 20:
             return torch.randint(64, 941, (nb // 2,), device="cuda", dtype=torch.int32).to(torch.int16).view(torch.uint8)
-        if cf == 6:
+        if cf in (6, 8):
             return (torch.randint(64, 941, (nb // 2,), device="cuda", dtype=torch.int32) << 6).to(torch.int16).view(torch.uint8)
         return torch.randint(16, 236, (nb,), device="cuda", dtype=torch.int32).to(torch.uint8)
     base = [sample() for _ in range(8)]

@@ -540,6 +540,13 @@ __global__ __launch_bounds__(256) void k_convert_blocks_wide(FusedArgs P, const 
 
 }  // namespace
 
+// packed 4:2:2 texels are read whole: one dword (8-bit) or two (16-bit)
+bool Packed422Loadable(const FusedParams &P)
+{
+    const ConvertParams &c = P.conv;
+    return !c.fmt.bits10 && !(c.tex_w & 1) && (c.pitch[0] & 3) == 0;
+}
+
 bool FusedUp2xSupported(const FusedParams &P)
 {
     const ConvertParams &c = P.conv;
@@ -549,8 +556,11 @@ bool FusedUp2xSupported(const FusedParams &P)
     if (std::memcmp(P.wx.w_even, P.wy.w_even, sizeof(P.wx.w_even)) || std::memcmp(P.wx.w_odd, P.wy.w_odd, sizeof(P.wx.w_odd))) return false;
     if (c.out_fmt != SF_BGRA8 && c.out_fmt != SF_RGB10A2) return false;
     const bool planar_yuv = c.fmt.layout == LAY_PLANAR && c.fmt.planes == 3 && !P.planar_rgb;
-    if (c.fmt.subsampling != 420 && !(c.fmt.subsampling == 422 && c.fmt.layout == LAY_PLANAR) && !(c.fmt.subsampling == 444 && planar_yuv)) return false;
-    if ((c.chroma_scaling != 1 && c.fmt.subsampling != 444) || c.chroma_scaling == 2 || c.blend_deint) return false;
+    const bool packed422 = c.fmt.layout == LAY_PACKED422;
+    if (packed422 && !Packed422Loadable(P)) return false;
+    if (c.fmt.subsampling != 420 && !(c.fmt.subsampling == 422 && (c.fmt.layout == LAY_PLANAR || packed422)) && !(c.fmt.subsampling == 444 && planar_yuv)) return false;
+    // (packed 4:2:2 has one linear filter: CHROMA_Nearest is not distinguished from Bilinear, Shaders.cpp:195-229)
+    if ((c.chroma_scaling != 1 && c.fmt.subsampling != 444 && !packed422) || c.chroma_scaling == 2 || c.blend_deint) return false;
     if (c.out_w < 8 || c.out_h < 8 || (c.out_w & 1) || (c.out_h & 1)) return false;
     if (!P.fast_convert) return false;            // dword loads need aligned rows / rect (host-checked)
     // 32-bit row offsets inside the kernel
@@ -596,6 +606,8 @@ void FillFusedArgs(const FusedParams &P, FusedArgs &a)
     // 4:2:2 has one siting (Shaders.cpp:319-325: u' = sx/2 + 0.25, v' = sy): the 4:2:0 switches stay off
     a.sub422 = c.fmt.subsampling == 422;
     a.sub444 = c.fmt.subsampling == 444;
+    a.packed422 = c.fmt.layout == LAY_PACKED422;
+    for (int i = 0; i < 4; i++) a.ci[i] = c.fmt.ci[i];
     a.center_h = c.fmt.subsampling == 420 && c.chroma_loc == CLOC_MPEG1;
     a.v_off4 = (c.fmt.subsampling == 420 && c.chroma_loc == CLOC_COSITED) ? 1 : 0;
     // UNORM scale: v/255, or (v << shift)/65535 for planar data; interleaved UV planes carry no shift
@@ -651,8 +663,10 @@ bool ConvertBlocksSupported(const FusedParams &P, bool to_rt)
 {
     const ConvertParams &c = P.conv;
     if (c.out_fmt != SF_BGRA8 && c.out_fmt != SF_RGB10A2) return false;
-    if (c.fmt.layout != LAY_PLANAR || c.blend_deint) return false;
-    if (c.fmt.subsampling == 444) { if (c.fmt.planes != 3 || P.planar_rgb) return false; }          // 4:4:4 planar YUV: no chroma filter at all
+    const bool packed422 = c.fmt.layout == LAY_PACKED422;
+    if ((c.fmt.layout != LAY_PLANAR && !packed422) || c.blend_deint) return false;
+    if (packed422) { if (c.chroma_scaling == 2 || !Packed422Loadable(P)) return false; }               // packed 4:2:2: Nearest == Bilinear
+    else if (c.fmt.subsampling == 444) { if (c.fmt.planes != 3 || P.planar_rgb) return false; }     // 4:4:4 planar YUV: no chroma filter at all
     else if (c.fmt.subsampling == 422) { if (c.chroma_scaling != 1) return false; }                   // 4:2:2: the bilinear variant only
     else if (c.fmt.subsampling != 420 || (c.chroma_scaling != 1 && c.chroma_scaling != 2)) return false;
     if (c.fmt.subsampling == 444 && c.chroma_scaling == 2) {}                                         // (Catmull-Rom is a no-op at 4:4:4)

@@ -25,6 +25,8 @@ struct FusedArgs {
     int v_off4;                    // vertical chroma offset in quarter chroma rows: 1 for co-sited (+0.25), else 0
     int sub422;                    // 4:2:2 planar / bi-planar (P210, P216, YV16, YUV422P10...): chroma subsampled horizontally only
     int sub444;                    // 4:4:4 planar (YV24, YUV444P8/10/16): a chroma sample per pixel, no interpolation at all
+    int packed422;                 // one plane of (Y0,U,Y1,V) texels (YUY2, UYVY, Y210, Y216, v210 after the unpack): implies sub422
+    int ci[4];                     // packed422: position of Y0, U, Y1, V inside a texel
     float m[9], c[3];              // colour matrix with the UNORM scale (and CopyPlane10to16 shift) folded in
     int tail; float gamma, lum_scale;
     float gamut[9];
@@ -210,6 +212,11 @@ template <int SRC>
 __device__ __forceinline__ void make_raw_addr(const FusedArgs &P, int Xg, RawAddr &ra)
 {
     const int sx0 = P.rect_l + Xg, c0 = P.sub444 ? sx0 : sx0 >> 1;        // 4:4:4: texels c0, c0+1 are the block's own two columns
+    if (SRC == SRC_GENERIC && P.packed422) {       // texel c0 carries the block's two luma samples and its own chroma; c0+1 the neighbour's chroma
+        const int tb = P.bytes == 2 ? 8 : 4;
+        ra.yoff = (uint32_t)(tb * c0); ra.coff[0] = 0; ra.coff[1] = ra.yoff; ra.coff[2] = (uint32_t)(tb * clampi(c0 + 1, 0, P.cw - 1));
+        return;
+    }
     const int yb = src_wide<SRC>(P) ? 2 : 1;
     const int cb = src_biplanar<SRC>(P) ? 2 * yb : yb;
     ra.yoff = (uint32_t)(yb * sx0);
@@ -251,6 +258,33 @@ __device__ __forceinline__ void load_raw(const FusedArgs &P, gcptr py, const Raw
 {
     const int sy0 = P.rect_t + y0, sy1 = P.rect_t + y1;
     const gcptr ry0 = py + (uint32_t)sy0 * (uint32_t)P.pitch_y, ry1 = py + (uint32_t)sy1 * (uint32_t)P.pitch_y;
+    if (SRC == SRC_GENERIC && P.packed422) {
+        // packed 4:2:2 (Shaders.cpp:195-229): the even pixel takes the texel's own chroma, the odd pixel the mean with the next
+        // texel's (clamp addressing) — convert_block's 4:2:2 rule with c[.][1] = own, c[.][2] = next; chroma rows = luma rows
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const gcptr row = rr ? ry1 : ry0;
+            uint32_t own[4], nxt[4];
+            if (P.bytes == 2) {
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));      // rows and samples are dword aligned, no more is promised
+                const u32x2 t = *(const __attribute__((address_space(1))) u32x2 *)(row + opaque(ra.yoff));
+                const u32x2 n = *(const __attribute__((address_space(1))) u32x2 *)(row + opaque(ra.coff[2]));
+                own[0] = t.x & 0xffffu; own[1] = t.x >> 16; own[2] = t.y & 0xffffu; own[3] = t.y >> 16;
+                nxt[0] = n.x & 0xffffu; nxt[1] = n.x >> 16; nxt[2] = n.y & 0xffffu; nxt[3] = n.y >> 16;
+            } else {
+                const uint32_t t = ld_u32(row + opaque(ra.yoff)), n = ld_u32(row + opaque(ra.coff[2]));
+#pragma unroll
+                for (int k = 0; k < 4; k++) { own[k] = (t >> (8 * k)) & 0xffu; nxt[k] = (n >> (8 * k)) & 0xffu; }
+            }
+            // wave-uniform component positions: selects, not indexed registers
+            auto pick = [](const uint32_t (&v)[4], int k) { return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : v[3]; };
+            r.y[rr] = pick(own, P.ci[0]) | (pick(own, P.ci[2]) << (P.bytes == 2 ? 16 : 8));
+            r.c[rr][0] = 0;
+            r.c[rr][1] = pick(own, P.ci[1]) | (pick(own, P.ci[3]) << 16);
+            r.c[rr][2] = pick(nxt, P.ci[1]) | (pick(nxt, P.ci[3]) << 16);
+        }
+        return;
+    }
     r.y[0] = src_wide<SRC>(P) ? ld_u32(ry0 + opaque(ra.yoff)) : ld_u16(ry0 + opaque(ra.yoff));
     r.y[1] = src_wide<SRC>(P) ? ld_u32(ry1 + opaque(ra.yoff)) : ld_u16(ry1 + opaque(ra.yoff));
     const int n = chroma_v4(P, sy0) >> 2;
@@ -616,6 +650,33 @@ __device__ __forceinline__ void load_raw_cr(const FusedArgs &P, gcptr py, const 
 {
     const int sy0 = P.rect_t + y0, sy1 = P.rect_t + y1;
     const gcptr ry0 = py + (uint32_t)sy0 * (uint32_t)P.pitch_y, ry1 = py + (uint32_t)sy1 * (uint32_t)P.pitch_y;
+    if (SRC == SRC_GENERIC && P.packed422) {
+        // packed 4:2:2 (Shaders.cpp:195-229): the even pixel takes the texel's own chroma, the odd pixel the mean with the next
+        // texel's (clamp addressing) — convert_block's 4:2:2 rule with c[.][1] = own, c[.][2] = next; chroma rows = luma rows
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const gcptr row = rr ? ry1 : ry0;
+            uint32_t own[4], nxt[4];
+            if (P.bytes == 2) {
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));      // rows and samples are dword aligned, no more is promised
+                const u32x2 t = *(const __attribute__((address_space(1))) u32x2 *)(row + opaque(ra.yoff));
+                const u32x2 n = *(const __attribute__((address_space(1))) u32x2 *)(row + opaque(ra.coff[2]));
+                own[0] = t.x & 0xffffu; own[1] = t.x >> 16; own[2] = t.y & 0xffffu; own[3] = t.y >> 16;
+                nxt[0] = n.x & 0xffffu; nxt[1] = n.x >> 16; nxt[2] = n.y & 0xffffu; nxt[3] = n.y >> 16;
+            } else {
+                const uint32_t t = ld_u32(row + opaque(ra.yoff)), n = ld_u32(row + opaque(ra.coff[2]));
+#pragma unroll
+                for (int k = 0; k < 4; k++) { own[k] = (t >> (8 * k)) & 0xffu; nxt[k] = (n >> (8 * k)) & 0xffu; }
+            }
+            // wave-uniform component positions: selects, not indexed registers
+            auto pick = [](const uint32_t (&v)[4], int k) { return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : v[3]; };
+            r.y[rr] = pick(own, P.ci[0]) | (pick(own, P.ci[2]) << (P.bytes == 2 ? 16 : 8));
+            r.c[rr][0] = 0;
+            r.c[rr][1] = pick(own, P.ci[1]) | (pick(own, P.ci[3]) << 16);
+            r.c[rr][2] = pick(nxt, P.ci[1]) | (pick(nxt, P.ci[3]) << 16);
+        }
+        return;
+    }
     r.y[0] = src_wide<SRC>(P) ? ld_u32(ry0 + opaque(ra.yoff)) : ld_u16(ry0 + opaque(ra.yoff));
     r.y[1] = src_wide<SRC>(P) ? ld_u32(ry1 + opaque(ra.yoff)) : ld_u16(ry1 + opaque(ra.yoff));
     const int base = (sy0 >> 1) - 1;

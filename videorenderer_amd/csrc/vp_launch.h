@@ -67,6 +67,7 @@ struct FusedParams {
     int taps_mfma;            // fused 2x kernel: 1 = resize taps on the matrix cores, 0 = packed-fp32 VALU chains, -1 = library default
 };
 bool FusedUp2xSupported(const FusedParams &P);
+bool Packed422Loadable(const FusedParams &P);            // packed 4:2:2 texels readable by whole-texel loads
 // the fused kernel's convert stage as a kernel of its own: 2x2 blocks, shared chroma fetch, table tone map.  P.store describes
 // the destination: texels of the internal format (m_TexConvertOutput, or the render target when nothing follows: to_rt), or
 // the final pass into a B8G8R8A8 render target (store.mode == ST_FINAL).  out_w / out_h / wx / wy of P are not used.
