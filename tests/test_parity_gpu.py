@@ -603,9 +603,9 @@ def test_strip_kernel_whole_frame_vs_oracle(mpcvr, oracle, torch_cuda, label, c)
 
 
 SURFACE_STRIP = [
-    ("y410_1080p_to_1440p", dict(cformat=12, w=1920, h=1080, kind="noise", seed=331, dst=(2560, 1440), iUpscaling=4,
-                                 exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
-    ("y416_720p_to_1080p_hamming_down_y", dict(cformat=13, w=1280, h=1440, kind="noise", seed=332, dst=(1920, 1080), iUpscaling=2, iDownscaling=2,
+    ("p010_nearest_chroma_1080p_to_1440p", dict(cformat=2, w=1920, h=1080, kind="noise", seed=331, dst=(2560, 1440), iUpscaling=4, iChromaScaling=0,
+                                                exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
+    ("y216_catmull_chroma_720p_to_1080p_hamming_down_y", dict(cformat=9, iChromaScaling=2, w=1280, h=1440, kind="noise", seed=332, dst=(1920, 1080), iUpscaling=2, iDownscaling=2,
                                                 exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
     ("rgb32_crop_1080p_to_1440p", dict(cformat=30, w=1920, h=1080, kind="noise", seed=333, src_rect=(16, 8, 1904, 1072), dst=(2511, 1419), iUpscaling=4,
                                        window=(2560, 1440), offset=(21, 11))),
@@ -686,7 +686,7 @@ def test_catmull_rom_chroma_block_convert_whole_frame(mpcvr, oracle, torch_cuda,
                                          exfmt=GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"]), "passes:convert,resizeX,resizeY+final;kernel=fused_strip("),
     ("yuv444p16_same_size", dict(cformat=25, w=1920, h=1080, kind="noise", seed=357, dst=(1920, 1080), iChromaScaling=0,
                                  exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]), "direct:convert+final"),
-    ("gbrp10_stays_on_the_per_draw_path", dict(cformat=27, w=640, h=360, kind="noise", seed=358, dst=(960, 540), iUpscaling=2), "passes:convert,resizeX,resizeY+final;kernel=fused_strip:surface("),
+    ("gbrp10_360p_to_540p", dict(cformat=27, w=640, h=360, kind="noise", seed=358, dst=(960, 540), iUpscaling=2), "passes:convert,resizeX,resizeY+final;kernel=fused_strip("),
     ("p216_rect_down_1p5x", dict(cformat=7, w=1920, h=1080, kind="noise", seed=354, src_rect=(8, 4, 1912, 1076), dst=(1270, 714), iDownscaling=2,
                                  exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]), "passes:convert,resizeX,resizeY+final;kernel=fused_strip("),
 ])
@@ -694,7 +694,8 @@ def test_planar_422_and_444_on_the_fused_paths(mpcvr, oracle, torch_cuda, label,
     """Planar / bi-planar 4:2:2 (P210, P216, YV16, YUV422P10) on the 2x2-block convert (round 2): chroma rows are luma rows, so a
     row pair takes row 0 from chroma row sy and row 1 from sy + 1 with weight 1 — the 4:2:0 block code with a different row
     rule; planar 4:4:4 (YV24, YUV444P8/10/16) likewise with a chroma sample per pixel and no filter.  The exact-2x kernel, the strip
-    kernel and the same-size convert take these formats now; three-plane RGB (GBRP) does not.  Whole frames against the oracle."""
+    kernel and the same-size convert take these formats now, three-plane RGB (GBRP: the same loads behind a rotated matrix) too.
+    Whole frames against the oracle."""
     torch = torch_cuda
     frame, pitch = case_frame(c)
     p = oracle_params(oracle, c)
@@ -730,6 +731,41 @@ def test_packed_422_on_the_fused_paths(mpcvr, oracle, torch_cuda, label, c, path
     luma samples and its own chroma, the next texel the neighbour's (Shaders.cpp:195-229: even pixel = own chroma, odd pixel = the
     mean with the next texel; CHROMA_Nearest is not distinguished) — the planar 4:2:2 block code behind a whole-texel loader.
     CATMULLROM_05 chroma stays on the per-pixel convert.  Whole frames against the oracle."""
+    torch = torch_cuda
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+    got, info = run_product(mpcvr, torch, c)
+    assert info.startswith(path), info
+    if has_tail(c):
+        d = np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
+        same = float((d == 0).mean())
+        assert same >= 0.99 and int((d > 1).sum()) <= 1e-5 * d.size and d.max() <= 8, (label, same, int((d > 1).sum()), int(d.max()))
+    else:
+        same = compare(got, want, f"{label} [{info}]", min_same=0.99)
+    print(f"{label}: identical channels {same:.6f}  [{info}]")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("label,c,path", [
+    ("ayuv_same_size", dict(cformat=11, w=1920, h=1080, kind="noise", seed=371, dst=(1920, 1080),
+                            exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]), "direct:convert"),
+    ("y410_pq_1080p_to_4k", dict(cformat=12, w=1920, h=1080, kind="noise", seed=372, dst=(3840, 2160), iUpscaling=4,
+                                 exfmt=GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"]), "fused_up2x"),
+    ("y416_catmull_setting_1080p_to_1440p", dict(cformat=13, w=1920, h=1080, kind="noise", seed=373, dst=(2560, 1440), iUpscaling=4, iChromaScaling=2,
+                                                 exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]), "passes:convert,resizeX,resizeY+final;kernel=fused_strip("),
+    ("y8_gray_rect_720p_down", dict(cformat=37, w=1280, h=720, kind="noise", seed=374, src_rect=(8, 4, 1272, 716), dst=(846, 476), iDownscaling=2),
+     "passes:convert,resizeX,resizeY;kernel=fused_strip("),
+    ("y10_gray_2x", dict(cformat=38, w=640, h=360, kind="noise", seed=375, dst=(1280, 720), iUpscaling=2, exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]), "fused_up2x"),
+    ("y16_gray_same_size", dict(cformat=39, w=1280, h=720, kind="noise", seed=376, dst=(1280, 720)), "direct:convert"),
+    ("gbrp8_2x", dict(cformat=26, w=1280, h=720, kind="noise", seed=377, dst=(2560, 1440), iUpscaling=4), "fused_up2x"),
+    ("gbrp16_same_size_procamp", dict(cformat=28, w=1280, h=720, kind="noise", seed=378, dst=(1280, 720), procamp=(8.0, 1.1, 0.0, 1.0)), "direct:convert"),
+])
+def test_packed_444_gray_and_gbrp_on_the_fused_paths(mpcvr, oracle, torch_cuda, label, c, path):
+    """The remaining one-sample-per-pixel layouts on the 2x2-block convert: packed 4:4:4 (AYUV / Y410 / Y416: two consecutive texels
+    are the block's two columns, components by the format's swizzle, Shaders.cpp:186-193), gray (Y8 / Y10 / Y16: luma only, U = V = 0,
+    :184 and the cbuffer fix-up :863-873) and three-plane RGB (GBRP8/10/16: the planar 4:4:4 loads behind the rotated matrix).  No chroma
+    filter exists for any of them, so every chroma setting is accepted.  Whole frames against the oracle."""
     torch = torch_cuda
     frame, pitch = case_frame(c)
     p = oracle_params(oracle, c)

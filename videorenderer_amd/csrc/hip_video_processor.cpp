@@ -823,7 +823,6 @@ void CHipVideoProcessor::FillFusedParams(const uint8_t *sample, void *rt, int rt
     fp->literal_tail = no_lut ? 1 : 0;
     fp->eotf_lut = (m_doviValid && !no_lut) ? (const float *)m_eotfLut.ptr : nullptr;
     fp->dovi_l2 = (m_doviValid && m_doviHost.l2_enabled) ? 1 : 0;
-    fp->planar_rgb = m_srcParams->CSType == CST_RGB ? 1 : 0;
     fp->taps_mfma = (m_cfg.flags & MPCVR_FLAG_FUSED_MFMA) ? 1 : (m_cfg.flags & MPCVR_FLAG_FUSED_VALU) ? 0 : -1;
     fp->dst_aligned16 = (((uintptr_t)rt) & 15) == 0;        // batches: ProcessBatch checks every target
     fp->src_aligned16 = (((uintptr_t)sample) & 15) == 0;

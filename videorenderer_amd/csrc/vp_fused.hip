@@ -540,11 +540,24 @@ __global__ __launch_bounds__(256) void k_convert_blocks_wide(FusedArgs P, const 
 
 }  // namespace
 
-// packed 4:2:2 texels are read whole: one dword (8-bit) or two (16-bit)
-bool Packed422Loadable(const FusedParams &P)
+// Source layouts and chroma filters convert_block has a loader and a rule for (vp_fused_dev.h):
+//   planar / bi-planar 4:2:0 — bilinear (and Catmull-Rom where `catmull_420`: the block convert kernel only);
+//   planar / bi-planar 4:2:2 — bilinear;  packed 4:2:2 — its one linear filter (Nearest == Bilinear, Shaders.cpp:195-229);
+//   everything with a chroma sample per pixel, where no chroma setting applies — planar 4:4:4 (YUV and G,B,R planes), packed 4:4:4,
+//   gray.  Interleaved RGB has no convert stage of this kind.
+bool BlockConvertLayout(const FusedParams &P, bool catmull_420)
 {
     const ConvertParams &c = P.conv;
-    return !c.fmt.bits10 && !(c.tex_w & 1) && (c.pitch[0] & 3) == 0;
+    switch (c.fmt.layout) {
+    case LAY_PLANAR:
+        if (c.fmt.subsampling == 444) return c.fmt.planes == 3;
+        if (c.fmt.subsampling == 422) return c.chroma_scaling == 1;
+        return c.fmt.subsampling == 420 && (c.chroma_scaling == 1 || (catmull_420 && c.chroma_scaling == 2));
+    case LAY_PACKED422: return c.chroma_scaling != 2 && !(c.tex_w & 1) && (c.pitch[0] & 3) == 0;    // whole-texel loads: a dword (8-bit) or two
+    case LAY_PACKED444: return (c.pitch[0] & 3) == 0;
+    case LAY_GRAY: return true;
+    default: return false;
+    }
 }
 
 bool FusedUp2xSupported(const FusedParams &P)
@@ -555,12 +568,7 @@ bool FusedUp2xSupported(const FusedParams &P)
     if (P.wy.ntaps != P.wx.ntaps || P.wy.q1_quirk != P.wx.q1_quirk) return false;
     if (std::memcmp(P.wx.w_even, P.wy.w_even, sizeof(P.wx.w_even)) || std::memcmp(P.wx.w_odd, P.wy.w_odd, sizeof(P.wx.w_odd))) return false;
     if (c.out_fmt != SF_BGRA8 && c.out_fmt != SF_RGB10A2) return false;
-    const bool planar_yuv = c.fmt.layout == LAY_PLANAR && c.fmt.planes == 3 && !P.planar_rgb;
-    const bool packed422 = c.fmt.layout == LAY_PACKED422;
-    if (packed422 && !Packed422Loadable(P)) return false;
-    if (c.fmt.subsampling != 420 && !(c.fmt.subsampling == 422 && (c.fmt.layout == LAY_PLANAR || packed422)) && !(c.fmt.subsampling == 444 && planar_yuv)) return false;
-    // (packed 4:2:2 has one linear filter: CHROMA_Nearest is not distinguished from Bilinear, Shaders.cpp:195-229)
-    if ((c.chroma_scaling != 1 && c.fmt.subsampling != 444 && !packed422) || c.chroma_scaling == 2 || c.blend_deint) return false;
+    if (!BlockConvertLayout(P, false) || c.blend_deint) return false;
     if (c.out_w < 8 || c.out_h < 8 || (c.out_w & 1) || (c.out_h & 1)) return false;
     if (!P.fast_convert) return false;            // dword loads need aligned rows / rect (host-checked)
     // 32-bit row offsets inside the kernel
@@ -605,14 +613,17 @@ void FillFusedArgs(const FusedParams &P, FusedArgs &a)
     a.bytes = c.fmt.bytes; a.planes = c.fmt.planes;
     // 4:2:2 has one siting (Shaders.cpp:319-325: u' = sx/2 + 0.25, v' = sy): the 4:2:0 switches stay off
     a.sub422 = c.fmt.subsampling == 422;
-    a.sub444 = c.fmt.subsampling == 444;
+    a.sub444 = c.fmt.subsampling == 444 || c.fmt.layout == LAY_GRAY;
     a.packed422 = c.fmt.layout == LAY_PACKED422;
+    a.packed444 = c.fmt.layout != LAY_PACKED444 ? 0 : c.fmt.bits10 ? 2 : c.fmt.bytes == 1 ? 1 : 3;
+    a.gray = c.fmt.layout == LAY_GRAY;
+    if (a.packed444) a.bytes = a.packed444 == 1 ? 1 : 2;     // (width of the fields the loader packs the luma pair into)
     for (int i = 0; i < 4; i++) a.ci[i] = c.fmt.ci[i];
     a.center_h = c.fmt.subsampling == 420 && c.chroma_loc == CLOC_MPEG1;
     a.v_off4 = (c.fmt.subsampling == 420 && c.chroma_loc == CLOC_COSITED) ? 1 : 0;
     // UNORM scale: v/255, or (v << shift)/65535 for planar data; interleaved UV planes carry no shift
-    const float sy = c.fmt.bytes == 1 ? 1.0f / 255.0f : (float)(1 << c.fmt.shift) / 65535.0f;
-    const float sc = c.fmt.bytes == 1 ? 1.0f / 255.0f : (float)(1 << (c.fmt.planes == 2 ? 0 : c.fmt.shift)) / 65535.0f;
+    const float sy = c.fmt.bits10 ? 1.0f / 1023.0f : c.fmt.bytes == 1 ? 1.0f / 255.0f : (float)(1 << c.fmt.shift) / 65535.0f;
+    const float sc = c.fmt.bits10 ? 1.0f / 1023.0f : c.fmt.bytes == 1 ? 1.0f / 255.0f : (float)(1 << (c.fmt.planes == 2 ? 0 : c.fmt.shift)) / 65535.0f;
     const bool dv = c.dovi != nullptr;       // Dolby Vision: the reshaping curves sit between the texel and the matrix, so the scale stays outside
     for (int i = 0; i < 3; i++) {
         a.m[3 * i + 0] = c.cm[3 * i + 0] * (dv ? 1.0f : sy);
@@ -663,13 +674,7 @@ bool ConvertBlocksSupported(const FusedParams &P, bool to_rt)
 {
     const ConvertParams &c = P.conv;
     if (c.out_fmt != SF_BGRA8 && c.out_fmt != SF_RGB10A2) return false;
-    const bool packed422 = c.fmt.layout == LAY_PACKED422;
-    if ((c.fmt.layout != LAY_PLANAR && !packed422) || c.blend_deint) return false;
-    if (packed422) { if (c.chroma_scaling == 2 || !Packed422Loadable(P)) return false; }               // packed 4:2:2: Nearest == Bilinear
-    else if (c.fmt.subsampling == 444) { if (c.fmt.planes != 3 || P.planar_rgb) return false; }     // 4:4:4 planar YUV: no chroma filter at all
-    else if (c.fmt.subsampling == 422) { if (c.chroma_scaling != 1) return false; }                   // 4:2:2: the bilinear variant only
-    else if (c.fmt.subsampling != 420 || (c.chroma_scaling != 1 && c.chroma_scaling != 2)) return false;
-    if (c.fmt.subsampling == 444 && c.chroma_scaling == 2) {}                                         // (Catmull-Rom is a no-op at 4:4:4)
+    if (!BlockConvertLayout(P, true) || c.blend_deint) return false;
     if (c.dovi && !P.eotf_lut) return false;       // the Dolby Vision variant decodes PQ from a table (MPCVR_FLAG_NO_LUT: per-pixel kernel)
     if (c.chroma_scaling == 2 && c.dovi) return false;     // Catmull-Rom chroma: no Dolby Vision variant instantiated
     if (c.out_w < 8 || c.out_h < 2 || (c.out_w & 1) || (c.out_h & 1)) return false;

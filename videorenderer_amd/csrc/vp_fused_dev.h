@@ -26,7 +26,9 @@ struct FusedArgs {
     int sub422;                    // 4:2:2 planar / bi-planar (P210, P216, YV16, YUV422P10...): chroma subsampled horizontally only
     int sub444;                    // 4:4:4 planar (YV24, YUV444P8/10/16): a chroma sample per pixel, no interpolation at all
     int packed422;                 // one plane of (Y0,U,Y1,V) texels (YUY2, UYVY, Y210, Y216, v210 after the unpack): implies sub422
-    int ci[4];                     // packed422: position of Y0, U, Y1, V inside a texel
+    int ci[4];                     // packed422: position of Y0, U, Y1, V inside a texel; packed444: of Y, U, V
+    int packed444;                 // one texel per pixel: 1 = four bytes (AYUV), 2 = 10:10:10:2 (Y410), 3 = four words (Y416); implies sub444
+    int gray;                      // one plane, no chroma (Y8, Y10, Y16): U = V = 0; implies sub444
     float m[9], c[3];              // colour matrix with the UNORM scale (and CopyPlane10to16 shift) folded in
     int tail; float gamma, lum_scale;
     float gamut[9];
@@ -217,6 +219,10 @@ __device__ __forceinline__ void make_raw_addr(const FusedArgs &P, int Xg, RawAdd
         ra.yoff = (uint32_t)(tb * c0); ra.coff[0] = 0; ra.coff[1] = ra.yoff; ra.coff[2] = (uint32_t)(tb * clampi(c0 + 1, 0, P.cw - 1));
         return;
     }
+    if (SRC == SRC_GENERIC && P.packed444) {       // the block's two columns are two consecutive texels
+        ra.yoff = (uint32_t)((P.packed444 == 3 ? 8 : 4) * sx0); ra.coff[0] = ra.coff[1] = ra.coff[2] = 0;
+        return;
+    }
     const int yb = src_wide<SRC>(P) ? 2 : 1;
     const int cb = src_biplanar<SRC>(P) ? 2 * yb : yb;
     ra.yoff = (uint32_t)(yb * sx0);
@@ -285,8 +291,40 @@ __device__ __forceinline__ void load_raw(const FusedArgs &P, gcptr py, const Raw
         }
         return;
     }
+    if (SRC == SRC_GENERIC && P.packed444) {
+        // packed 4:4:4 (Shaders.cpp:186-193: color.zyxw for AYUV, .yxzw for Y410 / Y416): a texel per pixel, no chroma filter
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const gcptr row = rr ? ry1 : ry0;
+            uint32_t t[2][4];
+            if (P.packed444 == 3) {
+                const u32x4 q = *(const __attribute__((address_space(1))) u32x4 *)(row + opaque(ra.yoff));
+                t[0][0] = q.x & 0xffffu; t[0][1] = q.x >> 16; t[0][2] = q.y & 0xffffu; t[0][3] = q.y >> 16;
+                t[1][0] = q.z & 0xffffu; t[1][1] = q.z >> 16; t[1][2] = q.w & 0xffffu; t[1][3] = q.w >> 16;
+            } else {
+                const u32x2 q = *(const __attribute__((address_space(1))) u32x2 *)(row + opaque(ra.yoff));
+                const int bits = P.packed444 == 2 ? 10 : 8;
+                const uint32_t mask = (1u << bits) - 1u;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { t[0][k] = (q.x >> (bits * k)) & mask; t[1][k] = (q.y >> (bits * k)) & mask; }
+            }
+            auto pick = [](const uint32_t (&v)[4], int k) { return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : v[3]; };
+            r.y[rr] = pick(t[0], P.ci[0]) | (pick(t[1], P.ci[0]) << (P.bytes == 2 ? 16 : 8));
+            r.c[rr][0] = 0;
+            r.c[rr][1] = pick(t[0], P.ci[1]) | (pick(t[0], P.ci[2]) << 16);
+            r.c[rr][2] = pick(t[1], P.ci[1]) | (pick(t[1], P.ci[2]) << 16);
+        }
+        return;
+    }
     r.y[0] = src_wide<SRC>(P) ? ld_u32(ry0 + opaque(ra.yoff)) : ld_u16(ry0 + opaque(ra.yoff));
     r.y[1] = src_wide<SRC>(P) ? ld_u32(ry1 + opaque(ra.yoff)) : ld_u16(ry1 + opaque(ra.yoff));
+    if (SRC == SRC_GENERIC && P.gray) {            // float4 color = tex.Sample of an R8 / R16 texture (Shaders.cpp:184): no chroma
+#pragma unroll
+        for (int i = 0; i < 3; i++) r.c[0][i] = r.c[1][i] = 0;
+        return;
+    }
     const int n = chroma_v4(P, sy0) >> 2;
     const uint32_t oA = (uint32_t)clampi(n, 0, P.ch - 1) * (uint32_t)P.pitch_c, oB = (uint32_t)clampi(n + 1, 0, P.ch - 1) * (uint32_t)P.pitch_c;
     const gcptr pu = py + P.off_u, pv = src_biplanar<SRC>(P) ? pu : py + P.off_v;
@@ -674,6 +712,33 @@ __device__ __forceinline__ void load_raw_cr(const FusedArgs &P, gcptr py, const 
             r.c[rr][0] = 0;
             r.c[rr][1] = pick(own, P.ci[1]) | (pick(own, P.ci[3]) << 16);
             r.c[rr][2] = pick(nxt, P.ci[1]) | (pick(nxt, P.ci[3]) << 16);
+        }
+        return;
+    }
+    if (SRC == SRC_GENERIC && P.packed444) {
+        // packed 4:4:4 (Shaders.cpp:186-193: color.zyxw for AYUV, .yxzw for Y410 / Y416): a texel per pixel, no chroma filter
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const gcptr row = rr ? ry1 : ry0;
+            uint32_t t[2][4];
+            if (P.packed444 == 3) {
+                const u32x4 q = *(const __attribute__((address_space(1))) u32x4 *)(row + opaque(ra.yoff));
+                t[0][0] = q.x & 0xffffu; t[0][1] = q.x >> 16; t[0][2] = q.y & 0xffffu; t[0][3] = q.y >> 16;
+                t[1][0] = q.z & 0xffffu; t[1][1] = q.z >> 16; t[1][2] = q.w & 0xffffu; t[1][3] = q.w >> 16;
+            } else {
+                const u32x2 q = *(const __attribute__((address_space(1))) u32x2 *)(row + opaque(ra.yoff));
+                const int bits = P.packed444 == 2 ? 10 : 8;
+                const uint32_t mask = (1u << bits) - 1u;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { t[0][k] = (q.x >> (bits * k)) & mask; t[1][k] = (q.y >> (bits * k)) & mask; }
+            }
+            auto pick = [](const uint32_t (&v)[4], int k) { return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : v[3]; };
+            r.y[rr] = pick(t[0], P.ci[0]) | (pick(t[1], P.ci[0]) << (P.bytes == 2 ? 16 : 8));
+            r.c[rr][0] = 0;
+            r.c[rr][1] = pick(t[0], P.ci[1]) | (pick(t[0], P.ci[2]) << 16);
+            r.c[rr][2] = pick(t[1], P.ci[1]) | (pick(t[1], P.ci[2]) << 16);
         }
         return;
     }

@@ -443,11 +443,7 @@ bool FusedStripSupported(const FusedStripParams &S)
         return S.strip_w >= S.pxl && S.strip_w <= 64 * S.pxl && (S.strip_w % S.pxl) == 0;
     }
     if (c.out_fmt != SF_BGRA8 && c.out_fmt != SF_RGB10A2) return false;
-    const bool packed422 = c.fmt.layout == LAY_PACKED422;
-    if ((c.fmt.layout != LAY_PLANAR && !packed422) || c.blend_deint || c.dovi) return false;
-    if (packed422) { if (c.chroma_scaling == 2 || !Packed422Loadable(P)) return false; }
-    else if (c.fmt.subsampling == 444) { if (c.fmt.planes != 3 || P.planar_rgb) return false; }
-    else if ((c.fmt.subsampling != 420 && c.fmt.subsampling != 422) || c.chroma_scaling != 1) return false;
+    if (!BlockConvertLayout(P, false) || c.blend_deint || c.dovi) return false;
     if (c.out_w < 8 || c.out_h < 2 || (c.out_w & 1) || (c.out_h & 1)) return false;
     if (!P.fast_convert) return false;
     if ((uint64_t)c.pitch[0] * (uint64_t)(c.rect_t + c.out_h + 2) >= (1ull << 32)) return false;

@@ -62,12 +62,11 @@ struct FusedParams {
     int src_aligned16;        // every sample of the launch starts on a 16-byte boundary (wide block convert)
     int literal_tail;         // MPCVR_FLAG_NO_LUT: evaluate the HDR tails literally in ALU (no LUT, no algebraic shortcut)
     const float *eotf_lut;    // device, kPqLutSize floats: log2 ST2084ToLinear(x, 1) at x = (i/(N-1))^2 — the Dolby Vision variants of the block convert decode PQ from it
-    int planar_rgb;           // three-plane RGB (GBRP): not a YUV source — the block convert does not take it
     int dovi_l2;              // the frame's Dolby Vision metadata carries level-2 trims for this display (DoviParams::l2_enabled)
     int taps_mfma;            // fused 2x kernel: 1 = resize taps on the matrix cores, 0 = packed-fp32 VALU chains, -1 = library default
 };
 bool FusedUp2xSupported(const FusedParams &P);
-bool Packed422Loadable(const FusedParams &P);            // packed 4:2:2 texels readable by whole-texel loads
+bool BlockConvertLayout(const FusedParams &P, bool catmull_420);       // source layout + chroma filter convert_block serves
 // the fused kernel's convert stage as a kernel of its own: 2x2 blocks, shared chroma fetch, table tone map.  P.store describes
 // the destination: texels of the internal format (m_TexConvertOutput, or the render target when nothing follows: to_rt), or
 // the final pass into a B8G8R8A8 render target (store.mode == ST_FINAL).  out_w / out_h / wx / wy of P are not used.

@@ -657,11 +657,14 @@ bool DecidePlan(int iTexFormat, int iChromaScaling, int iUpscaling, int iDownsca
         p.one_pass_axis = (p.rx.kind != RS_NONE || p.ry.kind == RS_NONE) ? 0 : 1;       // screen axis carrying the taps
     }
     p.copy_only = !p.two_pass && !p.one_pass;
+    // layouts / chroma filters the block convert inside the fused kernels serves (BlockConvertLayout, vp_fused.hip)
+    const bool fused_layout = f.layout == LAY_PLANAR ? (f.Subsampling == 444 ? f.planes == 3 : (f.Subsampling == 420 || f.Subsampling == 422) && iChromaScaling == MPCVR_CHROMA_Bilinear)
+                            : f.layout == LAY_PACKED422 ? iChromaScaling != MPCVR_CHROMA_CatmullRom
+                            : (f.layout == LAY_PACKED444 || f.layout == LAY_GRAY);
     // fused 2x candidate: exact 2x on both axes with an interpolation shader, bilinear 4:2:0 chroma,
     // UNORM internal format, destination fully inside the window
     p.fused_up2x = !(flags & MPCVR_FLAG_NO_FUSED) && !g.dovi && g.rotation == 0 && !p.flip && !p.hdr_tonemap && p.two_pass && w2 == 2 * w1 && h2 == 2 * h1 &&
-                   p.rx.kind == RS_UP && p.ry.kind == RS_UP && (f.Subsampling == 420 || (f.Subsampling == 422 && (f.layout == LAY_PLANAR || f.layout == LAY_PACKED422)) || (f.Subsampling == 444 && f.layout == LAY_PLANAR && f.planes == 3 && f.CSType == CST_YUV)) &&
-                   (iChromaScaling == MPCVR_CHROMA_Bilinear || ((f.Subsampling == 444 || f.layout == LAY_PACKED422) && iChromaScaling != MPCVR_CHROMA_CatmullRom)) && p.internal_fmt != SF_RGBA16F &&
+                   p.rx.kind == RS_UP && p.ry.kind == RS_UP && fused_layout && p.internal_fmt != SF_RGBA16F &&
                    g.vl >= 0 && g.vt >= 0 && g.vr <= g.ww && g.vb <= g.wh && w1 >= 8 && h1 >= 8 && !(w1 & 1);
     p.direct_convert = !(flags & MPCVR_FLAG_NO_FUSED) && p.copy_only && p.convert && !p.hdr_tonemap;
     *plan = p;
