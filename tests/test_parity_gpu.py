@@ -603,8 +603,7 @@ def test_strip_kernel_whole_frame_vs_oracle(mpcvr, oracle, torch_cuda, label, c)
 
 
 SURFACE_STRIP = [
-    ("p010_nearest_chroma_1080p_to_1440p", dict(cformat=2, w=1920, h=1080, kind="noise", seed=331, dst=(2560, 1440), iUpscaling=4, iChromaScaling=0,
-                                                exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
+    ("r210_1080p_to_1440p", dict(cformat=32, w=1920, h=1080, kind="noise", seed=331, dst=(2560, 1440), iUpscaling=4)),
     ("y216_catmull_chroma_720p_to_1080p_hamming_down_y", dict(cformat=9, iChromaScaling=2, w=1280, h=1440, kind="noise", seed=332, dst=(1920, 1080), iUpscaling=2, iDownscaling=2,
                                                 exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
     ("rgb32_crop_1080p_to_1440p", dict(cformat=30, w=1920, h=1080, kind="noise", seed=333, src_rect=(16, 8, 1904, 1072), dst=(2511, 1419), iUpscaling=4,
@@ -616,8 +615,8 @@ SURFACE_STRIP = [
 
 @pytest.mark.parametrize("label,c", SURFACE_STRIP)
 def test_strip_kernel_from_a_surface_whole_frame(mpcvr, oracle, torch_cuda, label, c):
-    """The arbitrary-ratio fused kernel WITHOUT its convert stage: sources the block convert does not take (4:2:2, packed 4:4:4,
-    Catmull-Rom chroma, fp16 internal format) go through their convert kernel into m_TexConvertOutput and from there through
+    """The arbitrary-ratio fused kernel WITHOUT its convert stage: what the block convert inside the strip kernel does not take
+    (Catmull-Rom chroma, an fp16 internal format) goes through its convert kernel into m_TexConvertOutput and from there through
     k_fused_strip<SRC_SURFACE>; an interleaved RGB sample (no convert draw at all, a source rect => the draw's row map) is
     sampled in place.  Whole frames against the oracle, and against the tiled two-draw kernel it replaces (bit-exact with the
     plain kernels on this SDR content): <= 1 LSB, >= 99 % identical."""
@@ -731,6 +730,41 @@ def test_packed_422_on_the_fused_paths(mpcvr, oracle, torch_cuda, label, c, path
     luma samples and its own chroma, the next texel the neighbour's (Shaders.cpp:195-229: even pixel = own chroma, odd pixel = the
     mean with the next texel; CHROMA_Nearest is not distinguished) — the planar 4:2:2 block code behind a whole-texel loader.
     CATMULLROM_05 chroma stays on the per-pixel convert.  Whole frames against the oracle."""
+    torch = torch_cuda
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+    got, info = run_product(mpcvr, torch, c)
+    assert info.startswith(path), info
+    if has_tail(c):
+        d = np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
+        same = float((d == 0).mean())
+        assert same >= 0.99 and int((d > 1).sum()) <= 1e-5 * d.size and d.max() <= 8, (label, same, int((d > 1).sum()), int(d.max()))
+    else:
+        same = compare(got, want, f"{label} [{info}]", min_same=0.99)
+    print(f"{label}: identical channels {same:.6f}  [{info}]")
+
+
+NEAREST_CHROMA = [
+    ("nv12_same_size", dict(cformat=1, w=1920, h=1080, kind="noise", seed=381, dst=(1920, 1080), iChromaScaling=0,
+                            exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]), "direct:convert"),
+    ("p010_pq_mpeg1_siting_ignored_2x", dict(cformat=2, w=1920, h=1080, kind="noise", seed=382, dst=(3840, 2160), iUpscaling=4, iChromaScaling=0,
+                                             exfmt=(GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"] & ~0xF00) | (1 << 8)), "fused_up2x"),
+    ("yv12_rect_1080p_to_1440p", dict(cformat=14, w=1920, h=1080, kind="noise", seed=383, src_rect=(8, 6, 1912, 1074), dst=(2540, 1424), iUpscaling=2, iChromaScaling=0,
+                                      exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]), "passes:convert,resizeX,resizeY;kernel=fused_strip("),
+    ("p210_4k_down_to_1080p", dict(cformat=6, w=3840, h=2160, kind="noise", seed=384, dst=(1920, 1080), iDownscaling=3, iChromaScaling=0,
+                                   exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]), "passes:convert,resizeX,resizeY+final;kernel=fused_strip("),
+    ("yuv420p10_cosited_odd_height_pairs", dict(cformat=20, w=1280, h=722, kind="noise", seed=385, dst=(1280, 722), iChromaScaling=0,
+                                                exfmt=(GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"] & ~0xF00) | (7 << 8)), "direct:convert"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("label,c,path", NEAREST_CHROMA)
+def test_nearest_chroma_on_the_fused_paths(mpcvr, oracle, torch_cuda, label, c, path):
+    """CHROMA_Nearest on 4:2:0 and planar 4:2:2 (Shaders.cpp:239-241: the chroma texel under the pixel, (sx / div_w, sy / div_h), whatever
+    the stream's siting says): the block code with one texel per block column pair and whole-row vertical weights.  No arithmetic is
+    left between texel and matrix, so SDR cases must be as close to the oracle as the bilinear ones.  Whole frames."""
     torch = torch_cuda
     frame, pitch = case_frame(c)
     p = oracle_params(oracle, c)

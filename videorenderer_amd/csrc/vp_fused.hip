@@ -541,8 +541,8 @@ __global__ __launch_bounds__(256) void k_convert_blocks_wide(FusedArgs P, const 
 }  // namespace
 
 // Source layouts and chroma filters convert_block has a loader and a rule for (vp_fused_dev.h):
-//   planar / bi-planar 4:2:0 — bilinear (and Catmull-Rom where `catmull_420`: the block convert kernel only);
-//   planar / bi-planar 4:2:2 — bilinear;  packed 4:2:2 — its one linear filter (Nearest == Bilinear, Shaders.cpp:195-229);
+//   planar / bi-planar 4:2:0 — nearest, bilinear (and Catmull-Rom where `catmull_420`: the block convert kernel only);
+//   planar / bi-planar 4:2:2 — nearest, bilinear;  packed 4:2:2 — its one linear filter (Nearest == Bilinear, Shaders.cpp:195-229);
 //   everything with a chroma sample per pixel, where no chroma setting applies — planar 4:4:4 (YUV and G,B,R planes), packed 4:4:4,
 //   gray.  Interleaved RGB has no convert stage of this kind.
 bool BlockConvertLayout(const FusedParams &P, bool catmull_420)
@@ -551,8 +551,8 @@ bool BlockConvertLayout(const FusedParams &P, bool catmull_420)
     switch (c.fmt.layout) {
     case LAY_PLANAR:
         if (c.fmt.subsampling == 444) return c.fmt.planes == 3;
-        if (c.fmt.subsampling == 422) return c.chroma_scaling == 1;
-        return c.fmt.subsampling == 420 && (c.chroma_scaling == 1 || (catmull_420 && c.chroma_scaling == 2));
+        if (c.fmt.subsampling == 422) return c.chroma_scaling != 2;
+        return c.fmt.subsampling == 420 && (c.chroma_scaling != 2 || catmull_420);
     case LAY_PACKED422: return c.chroma_scaling != 2 && !(c.tex_w & 1) && (c.pitch[0] & 3) == 0;    // whole-texel loads: a dword (8-bit) or two
     case LAY_PACKED444: return (c.pitch[0] & 3) == 0;
     case LAY_GRAY: return true;
@@ -619,8 +619,9 @@ void FillFusedArgs(const FusedParams &P, FusedArgs &a)
     a.gray = c.fmt.layout == LAY_GRAY;
     if (a.packed444) a.bytes = a.packed444 == 1 ? 1 : 2;     // (width of the fields the loader packs the luma pair into)
     for (int i = 0; i < 4; i++) a.ci[i] = c.fmt.ci[i];
-    a.center_h = c.fmt.subsampling == 420 && c.chroma_loc == CLOC_MPEG1;
-    a.v_off4 = (c.fmt.subsampling == 420 && c.chroma_loc == CLOC_COSITED) ? 1 : 0;
+    a.nearest = c.chroma_scaling == 0 && c.fmt.layout == LAY_PLANAR && (c.fmt.subsampling == 420 || c.fmt.subsampling == 422);
+    a.center_h = c.fmt.subsampling == 420 && c.chroma_loc == CLOC_MPEG1 && !a.nearest;      // (no siting without a filter)
+    a.v_off4 = (c.fmt.subsampling == 420 && c.chroma_loc == CLOC_COSITED && !a.nearest) ? 1 : 0;
     // UNORM scale: v/255, or (v << shift)/65535 for planar data; interleaved UV planes carry no shift
     const float sy = c.fmt.bits10 ? 1.0f / 1023.0f : c.fmt.bytes == 1 ? 1.0f / 255.0f : (float)(1 << c.fmt.shift) / 65535.0f;
     const float sc = c.fmt.bits10 ? 1.0f / 1023.0f : c.fmt.bytes == 1 ? 1.0f / 255.0f : (float)(1 << (c.fmt.planes == 2 ? 0 : c.fmt.shift)) / 65535.0f;
@@ -664,7 +665,7 @@ int FusedSourceKind(const FusedParams &P)
     // source specialisations: bi-planar 16-bit (P010/P016) and bi-planar 8-bit (NV12) with MPEG-2 / co-sited chroma;
     // everything else (planar, MPEG-1 siting) runs through the variant that reads these properties at run time
     const ConvertParams &c = P.conv;
-    const bool centred = c.fmt.subsampling == 420 && c.chroma_loc == CLOC_MPEG1;
+    const bool centred = c.fmt.subsampling == 420 && c.chroma_loc == CLOC_MPEG1 && c.chroma_scaling != 0;
     const bool biplanar_fast = c.fmt.planes == 2 && !centred, planar_fast = c.fmt.planes == 3 && !centred;
     return (biplanar_fast && c.fmt.bytes == 2) ? SRC_P01X : (biplanar_fast && c.fmt.bytes == 1) ? SRC_NV12
          : (planar_fast && c.fmt.bytes == 2) ? SRC_PLANAR16 : (planar_fast && c.fmt.bytes == 1) ? SRC_PLANAR8 : SRC_GENERIC;

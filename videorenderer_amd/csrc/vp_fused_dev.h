@@ -29,6 +29,7 @@ struct FusedArgs {
     int ci[4];                     // packed422: position of Y0, U, Y1, V inside a texel; packed444: of Y, U, V
     int packed444;                 // one texel per pixel: 1 = four bytes (AYUV), 2 = 10:10:10:2 (Y410), 3 = four words (Y416); implies sub444
     int gray;                      // one plane, no chroma (Y8, Y10, Y16): U = V = 0; implies sub444
+    int nearest;                   // CHROMA_Nearest on 4:2:0 / planar 4:2:2: chroma texel (sx / div_w, sy / div_h), no filter (Shaders.cpp:239-241)
     float m[9], c[3];              // colour matrix with the UNORM scale (and CopyPlane10to16 shift) folded in
     int tail; float gamma, lum_scale;
     float gamut[9];
@@ -246,7 +247,8 @@ __device__ __forceinline__ uint32_t ld_uv(const FusedArgs &P, gcptr pu, gcptr pv
 // vertical chroma position of source row sy (Shaders.cpp:118-138): v' = (sy+0.5)/2 [+0.25 co-sited] - 0.5, kept in
 // QUARTER chroma rows as an integer (4v' = 2sy - 1 [+1]) so that the whole siting computation stays on the scalar unit
 // (4:2:2: chroma rows are luma rows — v' = sy exactly, so a row pair takes row 0 from chroma row sy0 and row 1 from sy0 + 1)
-__device__ __forceinline__ int chroma_v4(const FusedArgs &P, int sy) { return (P.sub422 | P.sub444) ? 4 * sy : 2 * sy - 1 + P.v_off4; }
+// (CHROMA_Nearest at 4:2:0: row sy reads chroma row sy >> 1 whole — v' = sy >> 1, so of an (odd, odd + 1) pair row 0 takes row n, row 1 row n + 1)
+__device__ __forceinline__ int chroma_v4(const FusedArgs &P, int sy) { return (P.sub422 | P.sub444) ? 4 * sy : P.nearest ? 4 * (sy >> 1) : 2 * sy - 1 + P.v_off4; }
 // fr/4 for fr = 0..4 as a float built from integer selects (wave-uniform => SGPR; no v_cvt/v_mul per iteration)
 __device__ __forceinline__ float quarter(int fr)
 {
@@ -437,10 +439,10 @@ __device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)
     if (src_center<SRC>(P)) {                     // u' = sx/2 - 0.25 (MPEG-1 siting runs through the generic variant)
         Ucol[0] = pk_fma(Uc[1], splat(0.75f), Uc[0] * splat(0.25f)); Vcol[0] = pk_fma(Vc[1], splat(0.75f), Vc[0] * splat(0.25f));
         Ucol[1] = pk_fma(Uc[2], splat(0.25f), Uc[1] * splat(0.75f)); Vcol[1] = pk_fma(Vc[2], splat(0.25f), Vc[1] * splat(0.75f));
-    } else {                                      // u' = sx/2; 4:4:4: the odd column has its own sample
+    } else {                                      // u' = sx/2; 4:4:4: the odd column has its own sample; nearest: the block's one texel
         Ucol[0] = Uc[1]; Vcol[0] = Vc[1];
-        Ucol[1] = P.sub444 ? Uc[2] : pk_fma(Uc[2], splat(0.5f), Uc[1] * splat(0.5f));
-        Vcol[1] = P.sub444 ? Vc[2] : pk_fma(Vc[2], splat(0.5f), Vc[1] * splat(0.5f));
+        Ucol[1] = P.sub444 ? Uc[2] : P.nearest ? Uc[1] : pk_fma(Uc[2], splat(0.5f), Uc[1] * splat(0.5f));
+        Vcol[1] = P.sub444 ? Vc[2] : P.nearest ? Vc[1] : pk_fma(Vc[2], splat(0.5f), Vc[1] * splat(0.5f));
     }
     convert_block_yuv<TAIL, SRC, DV>(P, MM, GG, CC, Ycol, Ucol, Vcol, T, out, DL, TE, DR);
 }

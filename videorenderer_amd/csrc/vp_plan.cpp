@@ -658,7 +658,7 @@ bool DecidePlan(int iTexFormat, int iChromaScaling, int iUpscaling, int iDownsca
     }
     p.copy_only = !p.two_pass && !p.one_pass;
     // layouts / chroma filters the block convert inside the fused kernels serves (BlockConvertLayout, vp_fused.hip)
-    const bool fused_layout = f.layout == LAY_PLANAR ? (f.Subsampling == 444 ? f.planes == 3 : (f.Subsampling == 420 || f.Subsampling == 422) && iChromaScaling == MPCVR_CHROMA_Bilinear)
+    const bool fused_layout = f.layout == LAY_PLANAR ? (f.Subsampling == 444 ? f.planes == 3 : (f.Subsampling == 420 || f.Subsampling == 422) && iChromaScaling != MPCVR_CHROMA_CatmullRom)
                             : f.layout == LAY_PACKED422 ? iChromaScaling != MPCVR_CHROMA_CatmullRom
                             : (f.layout == LAY_PACKED444 || f.layout == LAY_GRAY);
     // fused 2x candidate: exact 2x on both axes with an interpolation shader, bilinear 4:2:0 chroma,
