@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""tools/fuzz_strip.py [n] [seed] — a wider net than the test suite's 240 geometries for the arbitrary-ratio fused kernel: n random
-(format, size, source rect, ratio per axis, scaler, window offset / clipping, internal format, output format, HDR tagging)
+"""tools/fuzz_strip.py [n] [seed] — a wider net than the test suite's geometries for the fused kernels (arbitrary-ratio strip kernel,
+exact-2x kernel, one-kernel same-size convert): n random (source format out of all layouts, chroma setting, size, source rect, ratio
+per axis, scaler, window offset / clipping, internal format, output format, HDR tagging)
 combinations, default planner against the plain kernels (MPCVR_FLAG_NO_FUSED): every channel within 1 LSB (8-bit targets) /
 the 10-bit bars of tests/test_parity_gpu.py.  Prints which kernels the cases went through."""
 import sys, os, collections
@@ -15,21 +16,31 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20260925)
 sdr = GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]
 paths = collections.Counter(); worst = 0.0; refused = 0; outliers = 0
 for i in range(n):
-    cf = int(rng.choice([1, 2, 20, 17, 14, 21, 6, 4, 9, 30, 22], p=[.2, .25, .1, .08, .07, .05, .08, .05, .04, .04, .04]))
+    # every source layout: 4:2:0 weighted up, then planar / packed 4:2:2 and 4:4:4, gray, GBRP, one interleaved RGB
+    if rng.random() < 0.55:
+        cf = int(rng.choice([1, 2, 20, 17, 14, 21, 3]))
+    else:
+        cf = int(rng.choice([4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 18, 19, 22, 23, 24, 25, 26, 27, 28, 30, 37, 38, 39]))
     w, h = int(rng.integers(12, 330)) * 2, int(rng.integers(10, 230)) * 2
     c = dict(cformat=cf, w=w, h=h, kind="noise", seed=int(rng.integers(1, 1 << 30)),
-             exfmt=int(rng.choice([sdr, sdr, HDR10, HLG])) if cf in (2, 20, 21, 6, 9) else sdr,
+             exfmt=int(rng.choice([sdr, sdr, HDR10, HLG])) if cf in (2, 3, 20, 21, 6, 7, 8, 9, 10, 12, 13, 22, 23, 24, 25) else sdr,
+             iChromaScaling=int(rng.choice([0, 1, 1, 1, 2])),
              iUpscaling=int(rng.choice([1, 2, 3, 4])), iDownscaling=int(rng.integers(0, 6)), bInterpolateAt50pct=int(rng.integers(0, 2)))
     rw, rh = w, h
+    if cf in (27, 28, 26, 30): c.pop("exfmt")
     if rng.random() < 0.4 and cf not in (30,):
         l = int(rng.integers(0, w // 8)) * 4; t = int(rng.integers(0, h // 8)) * 2
         r = min(w, l + max(16, int(rng.integers(w // 2, w)) // 2 * 2)); b = min(h, t + max(16, int(rng.integers(h // 2, h)) // 2 * 2))
         c["src_rect"] = (l, t, r, b); rw, rh = r - l, b - t
     fx, fy = float(rng.uniform(0.4, 2.7)), float(rng.uniform(0.4, 2.7))
     if rng.random() < 0.2: fy = fx
+    mode = rng.random()              # 12 % same size (block convert), 12 % exactly 2x (fused_up2x), else any ratio (strip kernel)
+    if mode < 0.12: fx = fy = 1.0
+    elif mode < 0.24: fx = fy = 2.0
     dw, dh = max(8, int(round(rw * fx))), max(8, int(round(rh * fy)))
-    if dw == rw: dw += 1
-    if dh == rh: dh += 1
+    if mode >= 0.24:
+        if dw == rw: dw += 1
+        if dh == rh: dh += 1
     c["dst"] = (dw, dh)
     if rng.random() < 0.35:
         c["window"] = (max(8, dw + int(rng.integers(-20, 40))), max(8, dh + int(rng.integers(-20, 40)))); c["offset"] = (int(rng.integers(-15, 25)), int(rng.integers(-15, 25)))
@@ -41,7 +52,7 @@ for i in range(n):
         got, info = run_product(api, torch, c)
     except api.MpcvrError:
         refused += 1; continue
-    paths[info.split(";")[1].split("(")[0] if ";" in info else info.split(";")[0]] += 1
+    paths[info.split(";")[1].split("(")[0] if ";" in info else info.split(";")[0].split("+")[0]] += 1
     name = f"fuzz {i} [{info}] {c}"
     # own statistics instead of the tests' asserts: behind a PQ / HLG / gamma tail a saturated dark colour can sit where
     # pow(x, 1/2.2) has a slope of thousands (Dolby Vision parity note); such a channel is counted, not fatal
