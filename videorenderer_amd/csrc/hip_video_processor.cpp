@@ -650,6 +650,9 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         FusedParams fp{};
         FillFusedParams(nullptr, nullptr, 0, &fp);
         m_plan.fused_up2x = FusedUp2xSupported(fp);
+        // experiment knob: exact 2x through the arbitrary-ratio kernel instead (DESIGN.md §4.3 compares the two)
+        static const bool no_up2x_env = [] { const char *e = std::getenv("MPCVR_NO_UP2X"); return e && *e && *e != '0'; }();
+        if (no_up2x_env && m_strip) m_plan.fused_up2x = false;
     }
     if (m_strip) {      // the launch-time conditions that do not depend on the frame pointers
         FusedStripParams sp{};

@@ -362,42 +362,136 @@ __device__ __forceinline__ void load_dovi_regs(const DoviParams *g, DoviRegs &R)
     }
     R.has_mmr = c->has_mmr;
 }
+// reshape_mmr (Shaders.cpp:734-762) for a component whose MMR pieces all share ONE weight set of ONE order (mmr_single, min_order ==
+// max_order: what a chroma curve with a single MMR piece — the usual profile 5 / 8 stream — packs to).  The weights are wave-uniform:
+// broadcast reads of the LDS copy, a float4 row at a time, either half of a register pair broadcast to both pixels by op_sel; the
+// pixels go two to a packed FMA as the block's (row 0, row 1) pairs, one block column at a time.  Only the seven base monomials
+// {x, y, z, xy, xz, yz, xyz} of one column are kept — squares and cubes are formed where they are summed — instead of 2 x 21 terms
+// (which cost the kernel half its occupancy when tried; SGPR-held weights from scalar loads were tried too: the kernel has no SGPRs to
+// spare and the loads' latency stayed exposed).  Same terms and weights as the shader;
+// the summation order differs (rounding noise only).
+// r = w.{x|y} * b + c with the weight pair in VGPRs (a broadcast LDS read), either half broadcast to both pixels by op_sel
+template <int HALF>
+__device__ __forceinline__ f2 pk_fma_wv(f2 w, f2 b, f2 c)
+{
+    f2 r;
+    if (HALF == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(w), "v"(b), "v"(c));
+    else           asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(w), "v"(b), "v"(c));
+    return r;
+}
+// (x, y, z) = the block column's (Y, U, V) pairs; acc starts as the pieces' constant coefficient.  Weight rows (one float4 each, read
+// where they are used — all lanes the same LDS address — so that only a row or two is live): [0] 3 linear, [1] 4 cross, [2] 3 squares,
+// [3] 4 squared cross, [4] 3 cubes, [5] 4 cubed cross
+template <int LV>
+__device__ __forceinline__ f2 mmr_level(const DoviParams *DL, int k, const f2 (&b)[7], f2 acc)
+{
+    const float4 w3 = *reinterpret_cast<const float4 *>(DL->curves[k].mmr[2 * LV]), w4 = *reinterpret_cast<const float4 *>(DL->curves[k].mmr[2 * LV + 1]);
+    const f2 W[4] = {f2{w3.x, w3.y}, f2{w3.z, w3.w}, f2{w4.x, w4.y}, f2{w4.z, w4.w}};
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const f2 p = LV == 0 ? b[i] : LV == 1 ? b[i] * b[i] : (b[i] * b[i]) * b[i];
+        const int j = i < 3 ? i : i + 1;             // position in the two rows laid end to end (w3.w is padding)
+        acc = (j & 1) ? pk_fma_wv<1>(W[j >> 1], p, acc) : pk_fma_wv<0>(W[j >> 1], p, acc);    // (two chains were no faster)
+    }
+    return acc;
+}
+__device__ __forceinline__ f2 mmr_component(const DoviParams *DL, int k, uint32_t order, f2 x, f2 y, f2 z, f2 acc)
+{
+    const f2 xy = x * y;
+    const f2 b[7] = {x, y, z, xy, x * z, y * z, xy * z};
+    if (order == 3)         // the usual order: one basic block, so that the weight reads of all three levels can be issued ahead of the sums
+        return mmr_level<2>(DL, k, b, mmr_level<1>(DL, k, b, mmr_level<0>(DL, k, b, acc)));
+    acc = mmr_level<0>(DL, k, b, acc);
+    if (order >= 2) acc = mmr_level<1>(DL, k, b, acc);
+    return acc;
+}
+
 // Y, U, V: [column] as (row 0, row 1) pairs of 0..1 values; reshaped in place.  DL = the LDS copy (coefficients, MMR weights)
 __device__ __forceinline__ void dovi_reshape_block(const DoviRegs &R, const DoviParams *DL, f2 (&Y)[2], f2 (&U)[2], f2 (&V)[2])
 {
     float s[3][4];
 #pragma unroll
     for (int p = 0; p < 4; p++) { s[0][p] = Y[p >> 1][p & 1]; s[1][p] = U[p >> 1][p & 1]; s[2][p] = V[p >> 1][p & 1]; }
-    float4 co[3][4];
+    // the shared-weight MMR components (see mmr_component): wave-uniform conditions
+    bool fast_mmr[3], any_fast = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        fast_mmr[k] = R.has_mmr && (R.methods[k] & DOVI_RESHAPE_MMR) && R.mmr_single[k] && R.min_order[k] == R.max_order[k] &&
+                      R.max_order[k] >= 1 && R.max_order[k] <= 3;
+        any_fast = any_fast || fast_mmr[k];
+    }
+    if (!any_fast) {
+        // polynomial curves (and MMR pieces with weight sets of their own): the 12 coefficient reads are issued together
+        float4 co[3][4];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            int piece[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                if (R.pv[k][i] > 2.0f) break;              // unused pivots are 1e9 (PackDoviCurves): wave-uniform exit
+#pragma unroll
+                for (int p = 0; p < 4; p++) piece[p] += (s[k][p] >= R.pv[k][i]) ? 1 : 0;      // == the nested `s < pivot` search on sorted pivots
+            }
+#pragma unroll
+            for (int p = 0; p < 4; p++) co[k][p] = *reinterpret_cast<const float4 *>(DL->curves[k].coeffs[piece[p]]);
+        }
+        float out[3][4];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const bool any_mmr = R.has_mmr && (R.methods[k] & DOVI_RESHAPE_MMR);       // wave-uniform
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const float x = s[k][p];
+                float r = (co[k][p].z * x + co[k][p].y) * x + co[k][p].x;
+                if (any_mmr) {
+                    const bool poly = R.methods[k] == DOVI_RESHAPE_POLY + DOVI_RESHAPE_MMR && co[k][p].w == 0.0f;
+                    if (!poly) {
+                        const float c4[4] = {co[k][p].x, co[k][p].y, co[k][p].z, co[k][p].w};
+                        r = dovi_reshape_mmr(DL->curves[k], c4, f3{s[0][p], s[1][p], s[2][p]});
+                    }
+                }
+                out[k][p] = saturate(r);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) { Y[p >> 1][p & 1] = out[0][p]; U[p >> 1][p & 1] = out[1][p]; V[p >> 1][p & 1] = out[2][p]; }
+        return;
+    }
+    // at least one shared-weight MMR component: one component at a time (its four coefficient sets are the only ones in registers)
+    float out[3][4];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         int piece[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 7; i++) {
-            if (R.pv[k][i] > 2.0f) break;              // unused pivots are 1e9 (PackDoviCurves): wave-uniform exit
+            if (R.pv[k][i] > 2.0f) break;
 #pragma unroll
-            for (int p = 0; p < 4; p++) piece[p] += (s[k][p] >= R.pv[k][i]) ? 1 : 0;      // == the nested `s < pivot` search on sorted pivots
+            for (int p = 0; p < 4; p++) piece[p] += (s[k][p] >= R.pv[k][i]) ? 1 : 0;
         }
+        float4 co[4];
 #pragma unroll
-        for (int p = 0; p < 4; p++) co[k][p] = *reinterpret_cast<const float4 *>(DL->curves[k].coeffs[piece[p]]);
-    }
-    float out[3][4];
+        for (int p = 0; p < 4; p++) co[p] = *reinterpret_cast<const float4 *>(DL->curves[k].coeffs[piece[p]]);
+        const bool any_mmr = R.has_mmr && (R.methods[k] & DOVI_RESHAPE_MMR);
+        f2 fast[2];
+        if (fast_mmr[k]) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const bool any_mmr = R.has_mmr && (R.methods[k] & DOVI_RESHAPE_MMR);       // wave-uniform
+            for (int col = 0; col < 2; col++)
+                fast[col] = mmr_component(DL, k, R.max_order[k], f2{s[0][2 * col], s[0][2 * col + 1]}, f2{s[1][2 * col], s[1][2 * col + 1]},
+                                          f2{s[2][2 * col], s[2][2 * col + 1]}, f2{co[2 * col].x, co[2 * col + 1].x});
+        }
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             const float x = s[k][p];
-            float r = (co[k][p].z * x + co[k][p].y) * x + co[k][p].x;
-            if (any_mmr) {
-                const bool poly = R.methods[k] == DOVI_RESHAPE_POLY + DOVI_RESHAPE_MMR && co[k][p].w == 0.0f;
-                if (!poly) {
-                    const float c4[4] = {co[k][p].x, co[k][p].y, co[k][p].z, co[k][p].w};
-                    r = dovi_reshape_mmr(DL->curves[k], c4, f3{s[0][p], s[1][p], s[2][p]});
-                }
+            float r = (co[p].z * x + co[p].y) * x + co[p].x;
+            const bool poly = !any_mmr || (R.methods[k] == DOVI_RESHAPE_POLY + DOVI_RESHAPE_MMR && co[p].w == 0.0f);
+            if (fast_mmr[k]) r = poly ? r : fast[p >> 1][p & 1];
+            else if (!poly) {
+                const float c4[4] = {co[p].x, co[p].y, co[p].z, co[p].w};
+                r = dovi_reshape_mmr(DL->curves[k], c4, f3{s[0][p], s[1][p], s[2][p]});
             }
             out[k][p] = saturate(r);
         }
+        __builtin_amdgcn_sched_barrier(0);          // keep the next component's coefficient reads behind this one's arithmetic
     }
 #pragma unroll
     for (int p = 0; p < 4; p++) { Y[p >> 1][p & 1] = out[0][p]; U[p >> 1][p & 1] = out[1][p]; V[p >> 1][p & 1] = out[2][p]; }
@@ -690,60 +784,6 @@ __device__ __forceinline__ void load_raw_cr(const FusedArgs &P, gcptr py, const 
 {
     const int sy0 = P.rect_t + y0, sy1 = P.rect_t + y1;
     const gcptr ry0 = py + (uint32_t)sy0 * (uint32_t)P.pitch_y, ry1 = py + (uint32_t)sy1 * (uint32_t)P.pitch_y;
-    if (SRC == SRC_GENERIC && P.packed422) {
-        // packed 4:2:2 (Shaders.cpp:195-229): the even pixel takes the texel's own chroma, the odd pixel the mean with the next
-        // texel's (clamp addressing) — convert_block's 4:2:2 rule with c[.][1] = own, c[.][2] = next; chroma rows = luma rows
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            const gcptr row = rr ? ry1 : ry0;
-            uint32_t own[4], nxt[4];
-            if (P.bytes == 2) {
-                typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));      // rows and samples are dword aligned, no more is promised
-                const u32x2 t = *(const __attribute__((address_space(1))) u32x2 *)(row + opaque(ra.yoff));
-                const u32x2 n = *(const __attribute__((address_space(1))) u32x2 *)(row + opaque(ra.coff[2]));
-                own[0] = t.x & 0xffffu; own[1] = t.x >> 16; own[2] = t.y & 0xffffu; own[3] = t.y >> 16;
-                nxt[0] = n.x & 0xffffu; nxt[1] = n.x >> 16; nxt[2] = n.y & 0xffffu; nxt[3] = n.y >> 16;
-            } else {
-                const uint32_t t = ld_u32(row + opaque(ra.yoff)), n = ld_u32(row + opaque(ra.coff[2]));
-#pragma unroll
-                for (int k = 0; k < 4; k++) { own[k] = (t >> (8 * k)) & 0xffu; nxt[k] = (n >> (8 * k)) & 0xffu; }
-            }
-            // wave-uniform component positions: selects, not indexed registers
-            auto pick = [](const uint32_t (&v)[4], int k) { return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : v[3]; };
-            r.y[rr] = pick(own, P.ci[0]) | (pick(own, P.ci[2]) << (P.bytes == 2 ? 16 : 8));
-            r.c[rr][0] = 0;
-            r.c[rr][1] = pick(own, P.ci[1]) | (pick(own, P.ci[3]) << 16);
-            r.c[rr][2] = pick(nxt, P.ci[1]) | (pick(nxt, P.ci[3]) << 16);
-        }
-        return;
-    }
-    if (SRC == SRC_GENERIC && P.packed444) {
-        // packed 4:4:4 (Shaders.cpp:186-193: color.zyxw for AYUV, .yxzw for Y410 / Y416): a texel per pixel, no chroma filter
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            const gcptr row = rr ? ry1 : ry0;
-            uint32_t t[2][4];
-            if (P.packed444 == 3) {
-                const u32x4 q = *(const __attribute__((address_space(1))) u32x4 *)(row + opaque(ra.yoff));
-                t[0][0] = q.x & 0xffffu; t[0][1] = q.x >> 16; t[0][2] = q.y & 0xffffu; t[0][3] = q.y >> 16;
-                t[1][0] = q.z & 0xffffu; t[1][1] = q.z >> 16; t[1][2] = q.w & 0xffffu; t[1][3] = q.w >> 16;
-            } else {
-                const u32x2 q = *(const __attribute__((address_space(1))) u32x2 *)(row + opaque(ra.yoff));
-                const int bits = P.packed444 == 2 ? 10 : 8;
-                const uint32_t mask = (1u << bits) - 1u;
-#pragma unroll
-                for (int k = 0; k < 4; k++) { t[0][k] = (q.x >> (bits * k)) & mask; t[1][k] = (q.y >> (bits * k)) & mask; }
-            }
-            auto pick = [](const uint32_t (&v)[4], int k) { return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : v[3]; };
-            r.y[rr] = pick(t[0], P.ci[0]) | (pick(t[1], P.ci[0]) << (P.bytes == 2 ? 16 : 8));
-            r.c[rr][0] = 0;
-            r.c[rr][1] = pick(t[0], P.ci[1]) | (pick(t[0], P.ci[2]) << 16);
-            r.c[rr][2] = pick(t[1], P.ci[1]) | (pick(t[1], P.ci[2]) << 16);
-        }
-        return;
-    }
     r.y[0] = src_wide<SRC>(P) ? ld_u32(ry0 + opaque(ra.yoff)) : ld_u16(ry0 + opaque(ra.yoff));
     r.y[1] = src_wide<SRC>(P) ? ld_u32(ry1 + opaque(ra.yoff)) : ld_u16(ry1 + opaque(ra.yoff));
     const int base = (sy0 >> 1) - 1;
