@@ -300,9 +300,12 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
 // and a copy of the frame's DoviParams instead.
 // CHR = 1: CHROMA_CatmullRom instead of CHROMA_Bilinear (4 x 5 chroma texels per block, convert_block_cr).
 template <int TAIL, int SRC, bool FINAL, int DV = DV_NONE, int CHR = 0>
-__global__ __launch_bounds__(256) void k_convert_blocks(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single, int pairs,
+__global__ __launch_bounds__(DV == DV_SDR_L2 ? 512 : 256) void k_convert_blocks(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single, int pairs,
                                                        uint8_t *batch_dst, size_t batch_stride, FrameTable32 tab)
 {
+    // waves per workgroup: the tables are per workgroup, so the variant with two of them (67 KiB) shares them among 8 waves —
+    // two workgroups per CU are then 4 waves per SIMD instead of 2
+    constexpr int NTH = DV == DV_SDR_L2 ? 512 : 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *Di = (uint32_t *)smem;                                   // dither as j << 14 (FINAL)
     f2 *T = (f2 *)(smem + (FINAL ? 4096 : 0));
@@ -310,22 +313,22 @@ __global__ __launch_bounds__(256) void k_convert_blocks(FusedArgs P, const Fused
     DoviParams *DL = (DoviParams *)(smem + (FINAL ? 4096 : 0) + LDS_E);
     if (DV == DV_SDR_L2) T = (f2 *)(smem + (FINAL ? 4096 : 0) + LDS_E + LDS_V);     // ... and the tone-map table follows the curves
     if (FINAL)
-        for (int i = threadIdx.x; i < 1024; i += 256)
+        for (int i = threadIdx.x; i < 1024; i += NTH)
             Di[i] = (uint32_t)(__half2float(__ushort_as_half(P.dither[i])) * 1024.0f + 0.5f) << 14;
     if (DV != DV_NONE) {
         if (DV == DV_SDR || DV == DV_SDR_L2)
-            for (int i = threadIdx.x; i < LUT_N; i += 256) {
+            for (int i = threadIdx.x; i < LUT_N; i += NTH) {
                 const float v = P.eotf_lut[i], n = P.eotf_lut[min(i + 1, LUT_N - 1)];
                 TE[i] = f2{v, n - v};
             }
         if (DV == DV_SDR_L2)
-            for (int i = threadIdx.x; i < LUT_N; i += 256) {
+            for (int i = threadIdx.x; i < LUT_N; i += NTH) {
                 const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
                 T[i] = f2{v, n - v};
             }
-        for (int i = threadIdx.x; i < (int)(sizeof(DoviParams) / 4); i += 256) ((uint32_t *)DL)[i] = ((const uint32_t *)P.dovi)[i];
+        for (int i = threadIdx.x; i < (int)(sizeof(DoviParams) / 4); i += NTH) ((uint32_t *)DL)[i] = ((const uint32_t *)P.dovi)[i];
     } else if (TAIL == TAILK_PQ_LUT)
-        for (int i = threadIdx.x; i < LUT_N; i += 256) {
+        for (int i = threadIdx.x; i < LUT_N; i += NTH) {
             const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
             T[i] = f2{v, n - v};
         }
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(256) void k_convert_blocks(FusedArgs P, const Fused
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int W = P.W, H = P.H;
     const int X = blockIdx.x * 128 + 2 * lane;                         // rect columns X, X+1
-    const int pair0 = (blockIdx.y * 4 + wave) * pairs;                 // pair p covers rect rows 2p-1, 2p
+    const int pair0 = (blockIdx.y * (NTH / 64) + wave) * pairs;                 // pair p covers rect rows 2p-1, 2p
     if (X >= W || 2 * pair0 - 1 >= H) return;
     const FusedFrame frame = tab.n ? tab.f[blockIdx.z] : frames ? frames[blockIdx.z] : single;     // tab: the table in the kernel arguments
     auto uniform_ptr = [](const void *q) {
@@ -732,7 +735,8 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
     const bool tables = fin || tailk == TAILK_PQ_LUT || dvk != DV_NONE;
     const long want_waves = pairs_waves > 0 ? pairs_waves : tables ? (wide ? 4096 : 8192) : 65536;
     while (pairs > 2 && (long)strips * ((npairs + pairs - 1) / pairs) * n_frames < want_waves) pairs >>= 1;
-    const dim3 grid(strips, (npairs + 4 * pairs - 1) / (4 * pairs), n_frames), block(256, 1, 1);
+    const int wg_waves = dvk == DV_SDR_L2 ? 8 : 4;         // (k_convert_blocks: NTH)
+    const dim3 grid(strips, (npairs + wg_waves * pairs - 1) / (wg_waves * pairs), n_frames), block(64 * wg_waves, 1, 1);
     const size_t lds = (fin ? 4096 : 0) + (dvk != DV_NONE ? LDS_E + LDS_V + (dvk == DV_SDR_L2 ? LDS_T : 0) : tailk == TAILK_PQ_LUT ? LDS_T : 0);
     if (dvk != DV_NONE) {       // Dolby Vision: 16-bit bi-planar (P010 / P016) or whatever the generic source variant reads
 #define MPCVR_CBD(SK, FN, DK) hipLaunchKernelGGL((k_convert_blocks<TAILK_ALU, SK, FN, DK>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab)
