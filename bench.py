@@ -369,6 +369,13 @@ def main():
                          "empirical_copy_peak_GBps": round(copy_gbps, 1) if copy_gbps else None,
                          "frac_of_empirical_copy_peak": round(achieved / copy_gbps, 4) if copy_gbps else None},
         }
+        if args.workload == "c3hdr":
+            # the path is co-limited: the as-written arithmetic of one frame is ~4.3 GFLOP = 27 FLOP per algorithmic byte
+            # against a machine balance of ~20 (157.3 TFLOP/s packed fp32 / 8 TB/s).  Reported beside the HBM fraction, not instead of it.
+            flop = 4.3e9
+            res["roofline"]["co_limit"] = {"bound": "valu_fp32", "model_flop_per_frame": flop, "achieved_TFLOPs": round(flop * args.batch / (launch_ms * 1e-3) / 1e12, 1),
+                                           "peak_TFLOPs": 157.3, "frac": round(flop * args.batch / (launch_ms * 1e-3) / 157.3e12, 4),
+                                           "note": "SURVEY.md 8d FLOP model (taps, roundings, dither, matrix, HDR tail; transcendentals counted once)"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wl, extfmt)
         if host_path:
