@@ -636,6 +636,12 @@ HRESULT CHipVideoProcessor::UpdatePlan()
     } else {
         m_pqLutValid = false;
     }
+    if (m_tail == TAIL_HLG_TO_SDR && !m_hlgLut.ptr) {          // constants only: built once per context
+        std::vector<float> t(kPqLutSize);
+        BuildHlgInverseLut(t.data());
+        if ((hr = CheckHip(m_hlgLut.CheckCreate(t.size() * sizeof(float)), "hlg lut"))) return hr;
+        if ((hr = CheckHip(hipMemcpy(m_hlgLut.ptr, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice), "hlg lut upload"))) return hr;
+    }
     if (m_plan.fused_up2x) {
         if (!m_blobOverride || m_upX.ntaps == 0) {
             float w[6];
@@ -824,6 +830,7 @@ void CHipVideoProcessor::FillFusedParams(const uint8_t *sample, void *rt, int rt
     const bool no_lut = (m_cfg.flags & MPCVR_FLAG_NO_LUT) != 0;
     fp->pq_lut = (m_pqLutValid && !no_lut) ? (const float *)m_pqLut.ptr : nullptr;
     fp->literal_tail = no_lut ? 1 : 0;
+    fp->hlg_lut = (m_tail == TAIL_HLG_TO_SDR && !no_lut) ? (const float *)m_hlgLut.ptr : nullptr;
     fp->eotf_lut = (m_doviValid && !no_lut) ? (const float *)m_eotfLut.ptr : nullptr;
     fp->dovi_l2 = (m_doviValid && m_doviHost.l2_enabled) ? 1 : 0;
     fp->taps_mfma = (m_cfg.flags & MPCVR_FLAG_FUSED_MFMA) ? 1 : (m_cfg.flags & MPCVR_FLAG_FUSED_VALU) ? 0 : -1;

@@ -177,6 +177,7 @@ private:
     DevBuffer m_TexConvertOutput, m_TexResize, m_BackBuffer, m_Snapshot;
     DevBuffer m_dither;
     DevBuffer m_pqLut;             // kPqLutSize floats (fused path tone-map table)
+    DevBuffer m_hlgLut;            // kPqLutSize floats: per-channel inverse HLG OETF (fused kernels' HLG -> SDR tail)
     DevBuffer m_eotfLut;           // kPqLutSize floats: PQ EOTF (Dolby Vision block convert), uploaded with the first RPU
     float m_pqLutHost[kPqLutSize];
     bool m_pqLutValid = false;

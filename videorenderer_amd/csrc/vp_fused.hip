@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
         D[i] = d;
         Di[i] = (uint32_t)(__half2float(__ushort_as_half(d)) * 1024.0f + 0.5f) << 14;     // d = j/1024 exactly (dither32x32float16.bin)
     }
-    if (TAIL == TAILK_PQ_LUT)
+    if (tail_has_table(TAIL))
         for (int i = threadIdx.x; i < LUT_N; i += 256) {
             const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
             T[i] = f2{v, n - v};
@@ -327,12 +327,12 @@ __global__ __launch_bounds__(DV == DV_SDR_L2 ? 512 : 256) void k_convert_blocks(
                 T[i] = f2{v, n - v};
             }
         for (int i = threadIdx.x; i < (int)(sizeof(DoviParams) / 4); i += NTH) ((uint32_t *)DL)[i] = ((const uint32_t *)P.dovi)[i];
-    } else if (TAIL == TAILK_PQ_LUT)
+    } else if (tail_has_table(TAIL))
         for (int i = threadIdx.x; i < LUT_N; i += NTH) {
             const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
             T[i] = f2{v, n - v};
         }
-    if (FINAL || TAIL == TAILK_PQ_LUT || DV != DV_NONE) __syncthreads();
+    if (FINAL || tail_has_table(TAIL) || DV != DV_NONE) __syncthreads();
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int W = P.W, H = P.H;
@@ -428,12 +428,12 @@ __global__ __launch_bounds__(256) void k_convert_blocks_wide(FusedArgs P, const 
     if (FINAL)
         for (int i = threadIdx.x; i < 1024; i += 256)
             Di[i] = (uint32_t)(__half2float(__ushort_as_half(P.dither[i])) * 1024.0f + 0.5f) << 14;
-    if (TAIL == TAILK_PQ_LUT)
+    if (tail_has_table(TAIL))
         for (int i = threadIdx.x; i < LUT_N; i += 256) {
             const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
             T[i] = f2{v, n - v};
         }
-    if (FINAL || TAIL == TAILK_PQ_LUT) __syncthreads();
+    if (FINAL || tail_has_table(TAIL)) __syncthreads();
 
     constexpr bool WIDE16 = SRC == SRC_P01X;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -639,7 +639,7 @@ void FillFusedArgs(const FusedParams &P, FusedArgs &a)
     ChromaCatmullWeights(c.chroma_loc, a.crx, a.cry);
     a.tail = c.tail; a.gamma = c.gamma; a.lum_scale = c.lum_scale;
     std::memcpy(a.gamut, c.gamut, sizeof(a.gamut));
-    a.lut = P.pq_lut;
+    a.lut = c.tail == TAIL_HLG_TO_SDR ? P.hlg_lut : P.pq_lut;
     a.maxv = c.out_fmt == SF_RGB10A2 ? 1023.0f : 255.0f;
     a.inv_maxv = 1.0f / a.maxv;
     a.q_over_maxv = (float)P.store.quant / a.maxv;
@@ -655,7 +655,7 @@ int FusedTailKind(const FusedParams &P)
     const ConvertParams &c = P.conv;
     // P.pq_lut is null when MPCVR_FLAG_NO_LUT asks for the literal ALU chains (A/B testing)
     return c.tail == TAIL_NONE ? TAILK_NONE : (c.tail == TAIL_PQ_TO_SDR && P.pq_lut) ? TAILK_PQ_LUT
-         : (c.tail == TAIL_HLG_TO_SDR && !P.literal_tail) ? TAILK_HLG : TAILK_ALU;
+         : (c.tail == TAIL_HLG_TO_SDR && !P.literal_tail && P.hlg_lut) ? TAILK_HLG : TAILK_ALU;
 }
 int FusedDoviKind(const FusedParams &P)
 {
@@ -732,12 +732,12 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
     // kernels that stage tables in LDS (dither, tone map) amortise that over long waves; without tables short waves win: a wave
     // keeps one row pair of loads in flight, so the number of resident waves is the memory-level parallelism (C1: 244 k frames/s
     // with 4 k waves per launch, 284 k with 64 k)
-    const bool tables = fin || tailk == TAILK_PQ_LUT || dvk != DV_NONE;
+    const bool tables = fin || tail_has_table(tailk) || dvk != DV_NONE;
     const long want_waves = pairs_waves > 0 ? pairs_waves : tables ? (wide ? 4096 : 8192) : 65536;
     while (pairs > 2 && (long)strips * ((npairs + pairs - 1) / pairs) * n_frames < want_waves) pairs >>= 1;
     const int wg_waves = dvk == DV_SDR_L2 ? 8 : 4;         // (k_convert_blocks: NTH)
     const dim3 grid(strips, (npairs + wg_waves * pairs - 1) / (wg_waves * pairs), n_frames), block(64 * wg_waves, 1, 1);
-    const size_t lds = (fin ? 4096 : 0) + (dvk != DV_NONE ? LDS_E + LDS_V + (dvk == DV_SDR_L2 ? LDS_T : 0) : tailk == TAILK_PQ_LUT ? LDS_T : 0);
+    const size_t lds = (fin ? 4096 : 0) + (dvk != DV_NONE ? LDS_E + LDS_V + (dvk == DV_SDR_L2 ? LDS_T : 0) : tail_has_table(tailk) ? LDS_T : 0);
     if (dvk != DV_NONE) {       // Dolby Vision: 16-bit bi-planar (P010 / P016) or whatever the generic source variant reads
 #define MPCVR_CBD(SK, FN, DK) hipLaunchKernelGGL((k_convert_blocks<TAILK_ALU, SK, FN, DK>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab)
 #define MPCVR_CBD2(SK, FN) do { if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_convert_blocks<TAILK_ALU, SK, FN, DV_SDR_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -806,7 +806,7 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     const dim3 block(256, 1, 1);
     const int tailk = FusedTailKind(P);
     static const int lds_pad = EnvInt("MPCVR_FUSED_LDS_PAD", 0);   // experiments: lower the occupancy by claiming more LDS
-    const size_t lds = LDS_A + LDS_D + LDS_DB + (tailk == TAILK_PQ_LUT ? LDS_T : 0) + (size_t)lds_pad;
+    const size_t lds = LDS_A + LDS_D + LDS_DB + (tail_has_table(tailk) ? LDS_T : 0) + (size_t)lds_pad;
     const int srck = FusedSourceKind(P);
     // the specialised epilogues use 16-byte stores / dither reads: off_x % 4 == 0 and 16-byte aligned rows; the integer
     // final pass additionally needs k*M + (j << 14) < 2^32 and M < 2^24 (true for 10-bit internal -> 8-bit target)

@@ -71,6 +71,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 enum { TAILK_NONE = 0, TAILK_PQ_LUT = 1, TAILK_ALU = 2, TAILK_HLG = 3 };
+// tails that read a 4096-entry {value, slope} table out of LDS (P.lut): PQ -> SDR = hable(ST2084ToLinear(x) * scale) / hable(4.8);
+// HLG -> SDR = the per-channel part of HLGtoLinear (inverse_HLG, hlg.hlsl:1-9)
+__host__ __device__ constexpr bool tail_has_table(int t) { return t == TAILK_PQ_LUT || t == TAILK_HLG; }
 // Dolby Vision variants of convert_block: DV_SDR = PQ -> SDR tail without level-2 trims (the LMS step's PQ encode and the tail's PQ
 // decode cancel and are elided, Hable in ALU); DV_SDR_L2 = PQ -> SDR with level-2 trims (PQ decode from the table, encode and trims
 // in ALU, tone map from the HDR10 path's table); DV_GENERAL = everything else (HDR output, no tone mapping): literal chain
@@ -676,7 +679,7 @@ __device__ __forceinline__ void convert_block_yuv(const FusedArgs &P, const f2 (
     // PQ: all twelve table reads of the block are issued together (their addresses depend only on the matrix results),
     // so the wave pays one LDS round trip per iteration instead of six
     f2 linc[2][3];
-    if (TAIL == TAILK_PQ_LUT) {
+    if (tail_has_table(TAIL)) {
         f2 ent[2][3][2]; float frc[2][3][2];
 #pragma unroll
         for (int rr = 0; rr < 2; rr++)
@@ -718,13 +721,8 @@ __device__ __forceinline__ void convert_block_yuv(const FusedArgs &P, const f2 (
             // (quirk Q7) is the identity x -> x*scale/1000 on the whole reachable range (x/1000 <= 0.09, never
             // saturated); it is elided here.  The literal chain — kept in the pass-per-kernel path and the oracle —
             // differs from the identity by ~1e-5 relative, the rounding noise of its own four pow() calls.
-            f2 lin[3];
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const f2 v = rgb[ch];
-                lin[ch] = f2{v.x <= 0.5f ? v.x * v.x * 4.0f : __expf((v.x - 0.55991073f) * (1.0f / 0.17883277f)) + 0.28466892f,
-                             v.y <= 0.5f ? v.y * v.y * 4.0f : __expf((v.y - 0.55991073f) * (1.0f / 0.17883277f)) + 0.28466892f};
-            }
+            // inverse_HLG per channel (x <= 0.5 ? 4x^2 : exp((x - c) / a) + b) from the LDS table, read with the block's other lookups
+            const f2 *lin = linc[rr];
             const f2 ys = splat(2000.0f) * pk_fma(splat(0.2627f), lin[0], pk_fma(splat(0.6780f), lin[1], splat(0.0593f) * lin[2]));
             const float ks = P.lum_scale * (1.0f / 1000.0f);
             const f2 gain = f2{hlsl_pow(ys.x, 0.2f) * ks, hlsl_pow(ys.y, 0.2f) * ks};

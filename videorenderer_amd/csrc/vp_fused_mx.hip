@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x_mx(FusedArgs P, const Fus
         D[i] = d;
         Di[i] = (uint32_t)(__half2float(__ushort_as_half(d)) * 1024.0f + 0.5f) << 14;
     }
-    if (TAIL == TAILK_PQ_LUT)
+    if (tail_has_table(TAIL))
         for (int i = threadIdx.x; i < LUT_N; i += 256) {
             const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
             T[i] = f2{v, n - v};
@@ -355,7 +355,7 @@ hipError_t LaunchFusedUp2xMx(const FusedParams &P, const FusedArgs &a_in, int kn
     const dim3 block(256, 1, 1);
     const int tailk = FusedTailKind(P), srck = FusedSourceKind(P);
     static const int lds_pad = EnvInt("MPCVR_FUSED_LDS_PAD", 0);
-    const size_t lds = MX_LDS_A + MX_LDS_WY + LDS_D + LDS_DB + (tailk == TAILK_PQ_LUT ? LDS_T : 0) + (size_t)lds_pad;
+    const size_t lds = MX_LDS_A + MX_LDS_WY + LDS_D + LDS_DB + (tail_has_table(tailk) ? LDS_T : 0) + (size_t)lds_pad;
     const bool aligned = P.dst_aligned16 && (a.off_x & 3) == 0 && (a.dst_pitch & 15) == 0;
     const int epik = !aligned || a.out10 ? EPI_GENERIC
                    : (a.final_pass && a.epi_mul != 0) ? EPI_DITHER8

@@ -113,16 +113,16 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
     constexpr bool FASTEPI = EPI == EPI_DITHER8;
     uint32_t *Di = (uint32_t *)smem;                                   // dither as j << 14 (FASTEPI)
     f2 *T = (f2 *)(smem + (FASTEPI ? LDS_DB : 0));
-    unsigned char *wbase = smem + (FASTEPI ? LDS_DB : 0) + (TAIL == TAILK_PQ_LUT ? LDS_T : 0);
+    unsigned char *wbase = smem + (FASTEPI ? LDS_DB : 0) + (tail_has_table(TAIL) ? LDS_T : 0);
     if (FASTEPI)
         for (int i = threadIdx.x; i < 1024; i += blockDim.x)
             Di[i] = (uint32_t)(__half2float(__ushort_as_half(P.dither[i])) * 1024.0f + 0.5f) << 14;
-    if (TAIL == TAILK_PQ_LUT)
+    if (tail_has_table(TAIL))
         for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) {
             const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
             T[i] = f2{v, n - v};
         }
-    if (FASTEPI || TAIL == TAILK_PQ_LUT) __syncthreads();             // the only workgroup barrier: tables visible
+    if (FASTEPI || tail_has_table(TAIL)) __syncthreads();             // the only workgroup barrier: tables visible
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -545,10 +545,10 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
     const int n_segs = (S.out_h + q.seg_rows - 1) / q.seg_rows;
     // waves per workgroup: as many as LDS allows for a launch that fills the chip several times over; a small launch (one frame) is
     // spread over all CUs instead — 1,800 work items in 16-wave workgroups occupy 113 of 256 CUs, four waves deep
-    int waves = StripWaves(S, fastepi, tailk == TAILK_PQ_LUT);
+    int waves = StripWaves(S, fastepi, tail_has_table(tailk));
     const long items = (long)q.n_strips * n_segs * n_frames;
     if (items < 512L * waves) waves = (int)std::max<long>(1, std::min<long>(waves, items / 512));
-    const size_t lds = StripLds(S, fastepi, tailk == TAILK_PQ_LUT, waves);
+    const size_t lds = StripLds(S, fastepi, tail_has_table(tailk), waves);
     const dim3 grid((q.n_strips * n_segs + waves - 1) / waves, 1, n_frames), block(64 * waves, 1, 1);
     const int ntk = S.nt;
 #define MPCVR_ST5(NT, PX, TK, SK, EK) do { \

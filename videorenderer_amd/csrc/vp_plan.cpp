@@ -329,6 +329,16 @@ void BuildPqSdrLut(float lum_scale, float out[kPqLutSize])
     }
 }
 
+// inverse_HLG (Shaders/convert/hlg.hlsl:1-9) per channel at x = i / (N - 1): the HLG -> SDR tail of the fused kernels reads it from LDS
+void BuildHlgInverseLut(float out[kPqLutSize])
+{
+    const float a = 0.17883277f, b = 0.28466892f, c = 0.55991073f;
+    for (int i = 0; i < kPqLutSize; i++) {
+        const float x = (float)i / (float)(kPqLutSize - 1);
+        out[i] = x <= 0.5f ? x * x * 4.0f : std::exp((x - c) / a) + b;
+    }
+}
+
 void BuildPqEotfLut(float out[kPqLutSize])
 {
     const float m1 = 2610.0f / (4096.0f * 4.0f), m2 = (2523.0f / 4096.0f) * 128.0f;

@@ -81,6 +81,7 @@ void SelectTail(const ExtFmt &ex, bool convert_to_sdr, int *tail, float *gamma, 
 // per-channel PQ->SDR chain saturate -> ST2084ToLinear*LuminanceScale -> Hable/hable(4.8) sampled at
 // i/(kPqLutSize-1) (st2084.hlsl:9-16, hdr_tone_mapping.hlsl:1-13): the optional tone-map LUT of the fused path
 void BuildPqSdrLut(float lum_scale, float out[kPqLutSize]);
+void BuildHlgInverseLut(float out[kPqLutSize]);        // per-channel inverse_HLG for the fused kernels' HLG -> SDR tail
 // log2 ST2084ToLinear((i / (kPqLutSize - 1))^2, 1) (st2084.hlsl:9-16): the PQ EOTF table of the Dolby Vision block convert, sampled uniformly in sqrt(x)
 void BuildPqEotfLut(float out[kPqLutSize]);
 // ps_final_pass.hlsl:29 in integers (fused kernel): floor(k*quant/maxv + j/1024) == (k*M + (j << 14)) >> 24 for all
