@@ -58,7 +58,7 @@ CHipVideoProcessor::~CHipVideoProcessor()
     (void)hipSetDevice(m_device);
     if (m_stream) (void)hipStreamSynchronize(m_stream);
     for (DevBuffer *b : {&m_batchConv, &m_batchMid, &m_jincFirst, &m_jincSecond, &m_TexSrcVideo, &m_TexRaw, &m_TexPost, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
-                         &m_pqLut, &m_eotfLut, &m_stripTab, &m_tapsXi, &m_tapsXw, &m_tapsXs, &m_tapsYi, &m_tapsYw, &m_tapsYs, &m_otherX, &m_otherY, &m_tapsXb, &m_tapsYb})
+                         &m_pqLut, &m_hlgLut, &m_eotfLut, &m_stripTab, &m_tapsXi, &m_tapsXw, &m_tapsXs, &m_tapsYi, &m_tapsYw, &m_tapsYs, &m_otherX, &m_otherY, &m_tapsXb, &m_tapsYb})
         b->Release();
     for (UploadSlot &u : m_up) {
         u.dev.Release();
