@@ -409,6 +409,33 @@ __device__ __forceinline__ f2 mmr_component(const DoviParams *DL, int k, uint32_
     return acc;
 }
 
+// U and V together — the usual stream: each chroma curve is ONE order-N MMR piece over the whole range (no pivots to search, no
+// polynomial pieces, the constant term wave-uniform).  Every monomial is formed once and goes straight into both sums (two independent
+// FMA chains, nothing stored): 4 + 14 multiplies + 2 x 21 FMAs per block column instead of 2 x (4 + 14 + 21).
+template <int LV>
+__device__ __forceinline__ void mmr_level_uv(const DoviParams *DL, const f2 (&b)[7], f2 &au, f2 &av)
+{
+    const float4 u3 = *reinterpret_cast<const float4 *>(DL->curves[1].mmr[2 * LV]), u4 = *reinterpret_cast<const float4 *>(DL->curves[1].mmr[2 * LV + 1]);
+    const float4 v3 = *reinterpret_cast<const float4 *>(DL->curves[2].mmr[2 * LV]), v4 = *reinterpret_cast<const float4 *>(DL->curves[2].mmr[2 * LV + 1]);
+    const f2 WU[4] = {f2{u3.x, u3.y}, f2{u3.z, u3.w}, f2{u4.x, u4.y}, f2{u4.z, u4.w}};
+    const f2 WV[4] = {f2{v3.x, v3.y}, f2{v3.z, v3.w}, f2{v4.x, v4.y}, f2{v4.z, v4.w}};
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const f2 p = LV == 0 ? b[i] : LV == 1 ? b[i] * b[i] : (b[i] * b[i]) * b[i];
+        const int j = i < 3 ? i : i + 1;
+        au = (j & 1) ? pk_fma_wv<1>(WU[j >> 1], p, au) : pk_fma_wv<0>(WU[j >> 1], p, au);
+        av = (j & 1) ? pk_fma_wv<1>(WV[j >> 1], p, av) : pk_fma_wv<0>(WV[j >> 1], p, av);
+    }
+}
+__device__ __forceinline__ void mmr_pair(const DoviParams *DL, uint32_t order, f2 x, f2 y, f2 z, f2 &au, f2 &av)
+{
+    const f2 xy = x * y;
+    const f2 b[7] = {x, y, z, xy, x * z, y * z, xy * z};
+    if (order == 3) { mmr_level_uv<0>(DL, b, au, av); mmr_level_uv<1>(DL, b, au, av); mmr_level_uv<2>(DL, b, au, av); return; }
+    mmr_level_uv<0>(DL, b, au, av);
+    if (order >= 2) mmr_level_uv<1>(DL, b, au, av);
+}
+
 // Y, U, V: [column] as (row 0, row 1) pairs of 0..1 values; reshaped in place.  DL = the LDS copy (coefficients, MMR weights)
 __device__ __forceinline__ void dovi_reshape_block(const DoviRegs &R, const DoviParams *DL, f2 (&Y)[2], f2 (&U)[2], f2 (&V)[2])
 {
@@ -462,8 +489,23 @@ __device__ __forceinline__ void dovi_reshape_block(const DoviRegs &R, const Dovi
     }
     // at least one shared-weight MMR component: one component at a time (its four coefficient sets are the only ones in registers)
     float out[3][4];
+    // both chroma curves a single MMR piece of the same order and nothing else: U and V in one pass over the monomials
+    const bool uv_pair = fast_mmr[1] && fast_mmr[2] && R.methods[1] == DOVI_RESHAPE_MMR && R.methods[2] == DOVI_RESHAPE_MMR &&
+                         R.pv[1][0] > 2.0f && R.pv[2][0] > 2.0f && R.max_order[1] == R.max_order[2];
+    if (uv_pair) {
+        const float cu = DL->curves[1].coeffs[0][0], cv = DL->curves[2].coeffs[0][0];
+#pragma unroll
+        for (int col = 0; col < 2; col++) {
+            f2 au = splat(cu), av = splat(cv);
+            mmr_pair(DL, R.max_order[1], f2{s[0][2 * col], s[0][2 * col + 1]}, f2{s[1][2 * col], s[1][2 * col + 1]}, f2{s[2][2 * col], s[2][2 * col + 1]}, au, av);
+            out[1][2 * col] = saturate(au.x); out[1][2 * col + 1] = saturate(au.y);
+            out[2][2 * col] = saturate(av.x); out[2][2 * col + 1] = saturate(av.y);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
+        if (uv_pair && k > 0) break;
         int piece[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 7; i++) {
