@@ -172,6 +172,24 @@ def test_pass_plan_matches_reference_rules(mpcvr):
     assert d(2, 64, 64, (0, 0, 128, 20), 128, 20, s.copy(iUpscaling=5)).startswith("passes:convert,resizeX,resizeY+final")
 
 
+def test_exact_2x_candidates_by_source_layout(mpcvr):
+    """DecidePlan's fused-2x candidate rule = the layouts and chroma settings the block convert inside the fused kernels serves
+    (BlockConvertLayout): every YUV / gray / three-plane RGB layout, nearest or bilinear chroma where the layout has a filter at all;
+    Catmull-Rom chroma and interleaved RGB (no convert draw to fuse) stay on the per-draw plan."""
+    from videorenderer_amd import api
+    s = api.default_settings(iUpscaling=4)
+    up2x = lambda cf, **kw: api.plan_describe(s.copy(**kw), cf, 640, 360, (0, 0, 1280, 720), 1280, 720).startswith("fused_up2x")
+    yuv_gray_gbrp = [cf for cf in range(1, 40) if cf not in range(29, 37)]
+    for cf in yuv_gray_gbrp:
+        assert up2x(cf), cf
+        assert up2x(cf, iChromaScaling=0), cf                      # nearest: a rule of the block code, or no chroma filter to choose
+    for cf in range(29, 37):                                       # RGB24 ... b64a
+        assert not up2x(cf), cf
+    subsampled = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 14, 15, 17, 18, 20, 21, 22, 23)       # 4:2:0 and 4:2:2, planar and packed
+    for cf in yuv_gray_gbrp:
+        assert up2x(cf, iChromaScaling=2) == (cf not in subsampled), cf              # Catmull-Rom only matters where chroma is subsampled
+
+
 def test_settings_default_matches_reference(mpcvr):
     from videorenderer_amd import api
     s = api.default_settings()
