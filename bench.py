@@ -36,6 +36,9 @@ WORKLOADS = {
                iUpscaling=4, desc="4K P010 BT.709 SDR -> Lanczos3 2x -> ordered dither -> 8K BGRA8"),
     "c4": dict(cformat=2, w=3840, h=2160, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
                iUpscaling=1, desc="4K P010 HDR10 -> Mitchell 2x -> PQ->SDR -> ordered dither -> 8K BGRA8"),
+    # config 4's optional extension run (the reference has no Spline36: IVideoRenderer.h:54-62; unpinned, reported separately)
+    "c4ext": dict(cformat=2, w=3840, h=2160, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
+                  iUpscaling=6, desc="4K P010 HDR10 -> Spline36 (extension) 2x -> PQ->SDR -> ordered dither -> 8K BGRA8"),
     "c5": dict(cformat=2, w=3840, h=2160, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=16),
                iUpscaling=4, desc="4K P010 HLG -> Lanczos3 2x -> HLG->SDR -> ordered dither -> 8K BGRA8"),
     "c2": dict(cformat=20, w=1920, h=1080, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=1, primaries=2, transfer=5),

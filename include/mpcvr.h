@@ -59,7 +59,10 @@ enum mpcvr_cformat {
 enum { MPCVR_TEXFMT_AUTOINT = 0, MPCVR_TEXFMT_8INT = 8, MPCVR_TEXFMT_10INT = 10, MPCVR_TEXFMT_16FLOAT = 16 };
 enum { MPCVR_CHROMA_Nearest = 0, MPCVR_CHROMA_Bilinear = 1, MPCVR_CHROMA_CatmullRom = 2 };
 enum { MPCVR_UPSCALE_Nearest = 0, MPCVR_UPSCALE_Mitchell = 1, MPCVR_UPSCALE_CatmullRom = 2,
-       MPCVR_UPSCALE_Lanczos2 = 3, MPCVR_UPSCALE_Lanczos3 = 4, MPCVR_UPSCALE_Jinc2 = 5 };
+       MPCVR_UPSCALE_Lanczos2 = 3, MPCVR_UPSCALE_Lanczos3 = 4, MPCVR_UPSCALE_Jinc2 = 5,
+       /* EXTENSION — not a reference setting (IVideoRenderer.h:54-62 ends at Jinc2): the 6-tap Spline36 kernel, BASELINE.json
+        * config 4's optional run.  Same draws, tap positions and intermediate formats as the other interpolation shaders. */
+       MPCVR_UPSCALE_Spline36_EXT = 6 };
 enum { MPCVR_DOWNSCALE_Box = 0, MPCVR_DOWNSCALE_Bilinear = 1, MPCVR_DOWNSCALE_Hamming = 2,
        MPCVR_DOWNSCALE_Bicubic = 3, MPCVR_DOWNSCALE_BicubicSharp = 4, MPCVR_DOWNSCALE_Lanczos = 5 };
 

@@ -934,6 +934,23 @@ int orc_upscale_weights(int method, float t, float w[6])
         w[0] = w0[0]; w[1] = w0[1]; w[2] = w0[2]; w[3] = w1[0]; w[4] = w1[1]; w[5] = w1[2];
         return 6;
     }
+    case ORC_UP_SPLINE36_EXT: {
+        /* EXTENSION, no reference counterpart (the reference's "spline" is Mitchell): the classic three-piece cubic Spline36 kernel
+         * over taps base-2 .. base+3 (distances 2+t, 1+t, t, 1-t, 2-t, 3-t), weights divided by their sum; t == 0 returns the
+         * centre tap like the Lanczos shaders do */
+        if (t == 0.0f) { w[0] = w[1] = 0; w[2] = 1; w[3] = w[4] = w[5] = 0; return 6; }
+        const float d[6] = {2.f + t, 1.f + t, t, 1.f - t, 2.f - t, 3.f - t};
+        float s = 0;
+        for (int i = 0; i < 6; i++) {
+            float x = d[i];
+            if (x < 1.f) w[i] = ((13.f / 11.f * x - 453.f / 209.f) * x - 3.f / 209.f) * x + 1.f;
+            else if (x < 2.f) { x -= 1.f; w[i] = ((-6.f / 11.f * x + 270.f / 209.f) * x - 156.f / 209.f) * x; }
+            else { x -= 2.f; w[i] = ((1.f / 11.f * x - 45.f / 209.f) * x + 26.f / 209.f) * x; }
+            s += w[i];
+        }
+        for (int i = 0; i < 6; i++) w[i] /= s;
+        return 6;
+    }
     default: return 0;
     }
 }
@@ -1456,7 +1473,7 @@ static int build_taps_at(resizer_t rs, float center, float scale, int tex_len, u
             /* D3D11 ps_interpolation_lanczos3.hlsl:33-34,42-43 samples Q1 at pos-1.5 (same texel as Q0);
              * the D3D9 twin uses pos-0.5 (Shaders/d3d9/interpolation_lanczos3.hlsl:28-29). */
             static const int off11[6] = {-2, -2, 0, 1, 2, 3}, off9[6] = {-2, -1, 0, 1, 2, 3};
-            const int *off = (flags & ORC_FLAG_LANCZOS3_FIXED) ? off9 : off11;
+            const int *off = ((flags & ORC_FLAG_LANCZOS3_FIXED) || rs.method != ORC_UP_LANCZOS3) ? off9 : off11;   /* the quirk is the Lanczos3 shader's */
             t->n = 6;
             for (int k = 0; k < 6; k++) { t->idx[k] = clampi(base + off[k], 0, tex_len - 1); t->w[k] = w[k]; }
         } else return -1;

@@ -52,7 +52,8 @@ enum {
 enum { ORC_TEXFMT_AUTOINT = 0, ORC_TEXFMT_8INT = 8, ORC_TEXFMT_10INT = 10, ORC_TEXFMT_16FLOAT = 16 };
 enum { ORC_CHROMA_NEAREST = 0, ORC_CHROMA_BILINEAR = 1, ORC_CHROMA_CATMULLROM = 2 };
 enum { ORC_UP_NEAREST = 0, ORC_UP_MITCHELL = 1, ORC_UP_CATMULLROM = 2, ORC_UP_LANCZOS2 = 3,
-       ORC_UP_LANCZOS3 = 4, ORC_UP_JINC2 = 5 };
+       ORC_UP_LANCZOS3 = 4, ORC_UP_JINC2 = 5,
+       ORC_UP_SPLINE36_EXT = 6 };   /* extension (BASELINE config 4's optional run): NOT in the reference (IVideoRenderer.h:54-62) */
 enum { ORC_DOWN_BOX = 0, ORC_DOWN_BILINEAR = 1, ORC_DOWN_HAMMING = 2, ORC_DOWN_BICUBIC = 3,
        ORC_DOWN_BICUBIC_SHARP = 4, ORC_DOWN_LANCZOS = 5 };
 

@@ -190,6 +190,28 @@ def test_exact_2x_candidates_by_source_layout(mpcvr):
         assert up2x(cf, iChromaScaling=2) == (cf not in subsampled), cf              # Catmull-Rom only matters where chroma is subsampled
 
 
+def test_spline36_extension_weights(mpcvr, oracle):
+    """MPCVR_UPSCALE_Spline36_EXT (not a reference setting; BASELINE config 4's optional run): six taps, normalised, mirror
+    symmetric in t, the centre tap alone at t = 0 — and the planner's table equals the oracle's bit for bit.  Its taps sit at
+    base-2 .. base+3 without Lanczos3's Q1 quirk (that is a property of that shader's text)."""
+    import ctypes as C
+    from videorenderer_amd import api
+    L = oracle.lib()
+    for t in (0.0, 0.25, 0.5, 0.75, 0.1234, 0.999):
+        w = np.array(api.plan_upscale_weights(api.UPSCALE_Spline36_EXT, t), dtype=np.float32)
+        wo = (C.c_float * 6)()
+        assert L.orc_upscale_weights(6, C.c_float(t), wo) == 6
+        assert np.array_equal(w, np.array(list(wo), dtype=np.float32)), t
+        assert abs(float(w.astype(np.float64).sum()) - 1.0) < 3e-7
+        if t:
+            m = np.array(api.plan_upscale_weights(api.UPSCALE_Spline36_EXT, 1.0 - t), dtype=np.float32)
+            assert np.allclose(w, m[::-1], atol=2e-7)
+    assert list(api.plan_upscale_weights(api.UPSCALE_Spline36_EXT, 0.0)) == [0, 0, 1, 0, 0, 0]
+    s = api.default_settings(iUpscaling=api.UPSCALE_Spline36_EXT)
+    assert api.plan_describe(s, 2, 1920, 1080, (0, 0, 3840, 2160), 3840, 2160).startswith("fused_up2x")
+    assert api.plan_describe(s, 2, 1920, 1080, (0, 0, 2560, 1440), 2560, 1440).startswith("passes:convert,resizeX,resizeY+final")
+
+
 def test_settings_default_matches_reference(mpcvr):
     from videorenderer_amd import api
     s = api.default_settings()

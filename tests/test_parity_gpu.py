@@ -815,6 +815,39 @@ def test_packed_444_gray_and_gbrp_on_the_fused_paths(mpcvr, oracle, torch_cuda, 
     print(f"{label}: identical channels {same:.6f}  [{info}]")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("label,c,path", [
+    ("p010_pq_1080p_to_4k", dict(cformat=2, w=1920, h=1080, kind="noise", seed=391, dst=(3840, 2160), iUpscaling=6,
+                                 exfmt=GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"]), "fused_up2x"),
+    ("nv12_720p_to_1080p", dict(cformat=1, w=1280, h=720, kind="structure", seed=392, dst=(1920, 1080), iUpscaling=6,
+                                exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]), "passes:convert,resizeX,resizeY;kernel=fused_strip("),
+    ("yuv420p10_rect_odd_ratio", dict(cformat=20, w=640, h=360, kind="noise", seed=393, src_rect=(8, 4, 632, 356), dst=(1501, 777), iUpscaling=6,
+                                      window=(1520, 800), offset=(9, 11)), "passes:convert,resizeX,resizeY+final;kernel=fused_strip("),
+    ("rgb32_rot90", dict(cformat=30, w=320, h=200, kind="structure", seed=394, dst=(300, 480), iUpscaling=6, rotation=90), "passes:"),
+])
+def test_spline36_extension_vs_oracle(mpcvr, oracle, torch_cuda, label, c, path):
+    """The Spline36 extension (no reference shader: unpinned by construction — the oracle states the kernel, the product must agree with
+    it like with every reference scaler): exact 2x through the fused kernel's plain six-tap variant, other ratios through the strip
+    kernel, a rotated RGB frame through the per-draw kernels; and the plain tier bit-exact on SDR content."""
+    torch = torch_cuda
+    from videorenderer_amd import api
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+    got, info = run_product(mpcvr, torch, c)
+    assert info.startswith(path), info
+    plain, info_plain = run_product(mpcvr, torch, c, extra_flags=api.FLAG_NO_FUSED)
+    if has_tail(c):
+        for out, tag in ((got, info), (plain, info_plain)):
+            d = np.abs(out[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
+            same = float((d == 0).mean())
+            assert same >= 0.99 and int((d > 1).sum()) <= 1e-5 * d.size and d.max() <= 8, (label, tag, same, int((d > 1).sum()), int(d.max()))
+    else:
+        same = compare(got, want, f"{label} [{info}]", min_same=0.99)
+        compare(plain, want, f"{label} [{info_plain}]", exact=True)
+    print(f"{label}: identical channels {same:.6f}  [{info}]")
+
+
 def test_full_size_flat_frame_and_dither_period(mpcvr, torch_cuda):
     """Constant input at 4K: every pass keeps it constant; the only variation is the 32x32 dither tile."""
     torch = torch_cuda

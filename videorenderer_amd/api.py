@@ -38,6 +38,7 @@ CF_YUV420P10, CF_YUV420P16, CF_YUV422P10, CF_YUV422P16, CF_YUV444P10, CF_YUV444P
 TEXFMT_AUTOINT, TEXFMT_8INT, TEXFMT_10INT, TEXFMT_16FLOAT = 0, 8, 10, 16
 CHROMA_Nearest, CHROMA_Bilinear, CHROMA_CatmullRom = 0, 1, 2
 UPSCALE_Nearest, UPSCALE_Mitchell, UPSCALE_CatmullRom, UPSCALE_Lanczos2, UPSCALE_Lanczos3, UPSCALE_Jinc2 = range(6)
+UPSCALE_Spline36_EXT = 6          # extension: not a reference setting (IVideoRenderer.h:54-62)
 DOWNSCALE_Box, DOWNSCALE_Bilinear, DOWNSCALE_Hamming, DOWNSCALE_Bicubic, DOWNSCALE_BicubicSharp, DOWNSCALE_Lanczos = range(6)
 OUT_BGRA8, OUT_RGB10A2 = 0, 1
 FLAG_LANCZOS3_FIXED, FLAG_NO_FUSED, FLAG_NO_LUT, FLAG_NO_FAST_CONVERT, FLAG_FUSED_VALU, FLAG_FUSED_MFMA, FLAG_NO_STRIP = 1, 2, 4, 8, 16, 32, 64

@@ -117,7 +117,7 @@ static bool ValidSettings(const mpcvr_settings &s, std::string *why)
     if (s.iTexFormat != MPCVR_TEXFMT_AUTOINT && s.iTexFormat != MPCVR_TEXFMT_8INT &&
         s.iTexFormat != MPCVR_TEXFMT_10INT && s.iTexFormat != MPCVR_TEXFMT_16FLOAT) return bad("iTexFormat");
     if (s.iChromaScaling < 0 || s.iChromaScaling > MPCVR_CHROMA_CatmullRom) return bad("iChromaScaling");
-    if (s.iUpscaling < 0 || s.iUpscaling > MPCVR_UPSCALE_Jinc2) return bad("iUpscaling");
+    if (s.iUpscaling < 0 || s.iUpscaling > MPCVR_UPSCALE_Spline36_EXT) return bad("iUpscaling");
     if (s.iDownscaling < 0 || s.iDownscaling > MPCVR_DOWNSCALE_Lanczos) return bad("iDownscaling");
     if (s.iSDRDisplayNits < 25 || s.iSDRDisplayNits > 400) return bad("iSDRDisplayNits");   // IVideoRenderer.h:87-90
     if (s.output_format != MPCVR_OUT_BGRA8 && s.output_format != MPCVR_OUT_RGB10A2) return bad("output_format");
@@ -650,7 +650,7 @@ HRESULT CHipVideoProcessor::UpdatePlan()
             std::memcpy(m_upX.w_even, w, sizeof(float) * n);
             UpscaleWeights(m_cfg.iUpscaling, 0.25f, w);
             std::memcpy(m_upX.w_odd, w, sizeof(float) * n);
-            m_upX.q1_quirk = (n == 6 && !(m_cfg.flags & MPCVR_FLAG_LANCZOS3_FIXED)) ? 1 : 0;
+            m_upX.q1_quirk = (m_cfg.iUpscaling == MPCVR_UPSCALE_Lanczos3 && !(m_cfg.flags & MPCVR_FLAG_LANCZOS3_FIXED)) ? 1 : 0;
             m_upY = m_upX;
         }
         FusedParams fp{};

@@ -405,6 +405,20 @@ int UpscaleWeights(int method, float t, float w[6])
         w[0] = lo[0]; w[1] = lo[1]; w[2] = lo[2]; w[3] = hi[0]; w[4] = hi[1]; w[5] = hi[2];
         return 6;
     }
+    case MPCVR_UPSCALE_Spline36_EXT: {   // extension, no reference shader: three-piece cubic over taps base-2 .. base+3, normalised
+        if (t == 0.0f) { w[0] = w[1] = 0; w[2] = 1; w[3] = w[4] = w[5] = 0; return 6; }
+        const float d[6] = {2.f + t, 1.f + t, t, 1.f - t, 2.f - t, 3.f - t};
+        float s = 0;
+        for (int i = 0; i < 6; i++) {
+            float x = d[i];
+            if (x < 1.f) w[i] = ((13.f / 11.f * x - 453.f / 209.f) * x - 3.f / 209.f) * x + 1.f;
+            else if (x < 2.f) { x -= 1.f; w[i] = ((-6.f / 11.f * x + 270.f / 209.f) * x - 156.f / 209.f) * x; }
+            else { x -= 2.f; w[i] = ((1.f / 11.f * x - 45.f / 209.f) * x + 26.f / 209.f) * x; }
+            s += w[i];
+        }
+        for (int i = 0; i < 6; i++) w[i] /= s;
+        return 6;
+    }
     default: return 0;
     }
 }
@@ -483,7 +497,7 @@ bool BuildAxisTaps(Resizer rs, int src_l, int src_len, int n_out, int tex_len, u
         static const int off4[4] = {-1, 0, 1, 2};
         static const int off6_d3d11[6] = {-2, -2, 0, 1, 2, 3};
         static const int off6_fixed[6] = {-2, -1, 0, 1, 2, 3};
-        const int *off = n == 4 ? off4 : ((flags & MPCVR_FLAG_LANCZOS3_FIXED) ? off6_fixed : off6_d3d11);
+        const int *off = n == 4 ? off4 : ((flags & MPCVR_FLAG_LANCZOS3_FIXED) || rs.method != MPCVR_UPSCALE_Lanczos3) ? off6_fixed : off6_d3d11;
         for (int i = 0; i < n_out; i++) {
             float pos = AxisCenter(src_l, i, scale) - 0.5f;
             const float t = pos - std::floor(pos);
