@@ -301,7 +301,10 @@ def test_process_batch_equals_single(mpcvr, torch_cuda):
     for name, flags in (("noise_p010_pq_lanczos3_2x", 0), ("noise_p010_pq_lanczos3_2x", 2), ("down_lanczos_2p5x", 0),
                         ("up_1p5x_lanczos3", 0), ("x_only_resize", 0), ("y_only_resize", 0), ("c1_nv12_bt709_passthrough", 0),
                         ("mild_down_uses_upscaler", 0), ("crop_offset_letterbox", 0), ("down_hamming_3x", 0), ("c5_p010_hlg_lanczos3_2x", 8),
-                        ("up_1p5x_lanczos3", 64), ("down_lanczos_2p5x", 64), ("jinc2_p010_2x_dither", 0), ("jinc2_nv12_noise_1p5x", 0)):      # 64 = NO_STRIP: block convert + tiled two-draw kernel
+                        ("up_1p5x_lanczos3", 64), ("down_lanczos_2p5x", 64), ("jinc2_p010_2x_dither", 0), ("jinc2_nv12_noise_1p5x", 0),      # 64 = NO_STRIP: block convert + tiled two-draw kernel
+                        # the layouts that joined the fused kernels in round 2: packed 4:2:2 / 4:4:4, gray, three-plane RGB (v210 batches frame by frame)
+                        ("yuy2_bilinear_2x", 0), ("y210_lanczos3_2x", 0), ("yuy2_noise_same_size", 0), ("v210_2x", 0), ("ayuv_same_size", 0),
+                        ("y410_pq_2x", 0), ("y416_fullrange", 0), ("gbrp8_2x", 0), ("gbrp16_down", 0), ("y8_gray_2x", 0), ("y16_gray_crop", 0)):
         c = GOLDEN_CASES[name]
         vp, (ww, wh) = make_vp(mpcvr, c, flags)
         c = dict(c, kind="noise")        # distinct frames whatever the case's own content

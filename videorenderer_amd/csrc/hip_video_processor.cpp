@@ -1074,6 +1074,10 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
         if (((uintptr_t)srcs[i] & 3) != 0) src4 = false;
         if (((uintptr_t)dsts[i] & 15) != 0) aligned = false;
     }
+    // samples that are repacked into m_TexSrcVideo first (v210, interleaved RGB) cannot be read in place by a whole-batch launch:
+    // they take the frame-by-frame branch below like samples that do not start on a dword (v210 became a fused-2x / strip
+    // candidate when packed 4:2:2 joined the block convert)
+    if (m_srcParams->cformat == MPCVR_CF_V210 || m_srcParams->layout == LAY_RGB) src4 = false;
     // pass-per-kernel path, whole batch per launch: possible when every stage has a kernel with a frame dimension
     // the arbitrary-ratio fused kernel takes the whole batch in one launch, like the 2x kernel
     FusedStripParams strip_sp{};
