@@ -9,12 +9,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from videorenderer_amd import api
 from tests.golden.cases import GOLDEN_CASES, case_frame, HDR10, HLG
-from tests.test_parity_gpu import run_product, compare, compare_rgb10, internal_is_8bit, has_tail
+from tests.test_parity_gpu import run_product, compare, compare_rgb10, internal_is_8bit, has_tail, make_vp
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20260925)
 sdr = GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]
-paths = collections.Counter(); worst = 0.0; refused = 0; outliers = 0
+paths = collections.Counter(); worst = 0.0; refused = 0; outliers = 0; batches = 0
 for i in range(n):
     # every source layout: 4:2:0 weighted up, then planar / packed 4:2:2 and 4:4:4, gray, GBRP, one interleaved RGB
     if rng.random() < 0.55:
@@ -53,6 +53,19 @@ for i in range(n):
     except api.MpcvrError:
         refused += 1; continue
     paths[info.split(";")[1].split("(")[0] if ";" in info else info.split(";")[0].split("+")[0]] += 1
+    if i % 4 == 0:      # every fourth case also as a batch: mpcvr_process_batch of three distinct frames == three mpcvr_process calls, bit for bit
+        vp, (ww, wh) = make_vp(api, c)
+        frames = [torch.from_numpy(case_frame(dict(c, seed=c["seed"] + 7 * k))[0]).cuda() for k in range(3)]
+        pitch = vp.GetFrameBytes()[1]
+        singles = []
+        for f in frames:
+            dst = torch.full((wh, ww, 4), 77, dtype=torch.uint8, device="cuda")
+            vp.CopySample(f, pitch); vp.Process(dst, ww * 4); singles.append(dst)
+        dsts = [torch.full((wh, ww, 4), 77, dtype=torch.uint8, device="cuda") for _ in frames]
+        vp.ProcessBatch(frames, dsts, ww * 4); vp.Synchronize()
+        for k in range(3):
+            assert torch.equal(singles[k], dsts[k]), f"batch != single, frame {k}: fuzz {i} [{info}] {c}"
+        vp.close(); batches += 1
     name = f"fuzz {i} [{info}] {c}"
     # own statistics instead of the tests' asserts: behind a PQ / HLG / gamma tail a saturated dark colour can sit where
     # pow(x, 1/2.2) has a slope of thousands (Dolby Vision parity note); such a channel is counted, not fatal
@@ -71,4 +84,4 @@ for i in range(n):
     # (without a tail: a block-convert texel one code off its plain-kernel value can come out of a Lanczos tap sum 1.2 codes off,
     # i.e. two 10-bit codes after both roundings — seen once per ~1e6 channels; never beyond lim + 1)
     assert beyond == 0 or (beyond <= max(4, 2e-5 * d.size) and d.max() <= (8 if has_tail(c) else lim + 1)), name
-print("cases", n, "refused", refused, "kernels", dict(paths), "largest differing fraction", round(worst, 5), "cases with an ill-conditioned channel", outliers)
+print("cases", n, "of which also as 3-frame batches", batches, "refused", refused, "kernels", dict(paths), "largest differing fraction", round(worst, 5), "cases with an ill-conditioned channel", outliers)
