@@ -47,6 +47,19 @@ for i in range(n):
     if rng.random() < 0.2: c["output_format"] = 1
     if rng.random() < 0.2: c["iTexFormat"] = int(rng.choice([8, 10, 16]))
     if rng.random() < 0.1: c["bUseDither"] = 0
+    # the rarer switches of the sequencer: rotation / flip (first draw), ProcAmp, blend deinterlace, HDR output modes, Dolby Vision
+    if rng.random() < 0.08: c["rotation"] = int(rng.choice([90, 180, 270]))
+    if rng.random() < 0.05: c["flip"] = 1
+    if rng.random() < 0.08: c["procamp"] = (float(rng.uniform(-20, 20)), float(rng.uniform(0.8, 1.2)), float(rng.uniform(-30, 30)), float(rng.uniform(0.5, 1.5)))
+    if rng.random() < 0.05: c["bDeintBlend"] = 1; c["sample_format"] = int(rng.choice([1, 2]))
+    hdr_src = c.get("exfmt") in (HDR10, HLG)
+    if hdr_src and rng.random() < 0.2:
+        c["hdr_output"] = 1; c["output_format"] = 1; c["hdr_tonemap"] = int(rng.integers(0, 7)); c["hdr_display"] = float(rng.choice([400.0, 1000.0]))
+    if cf in (2, 3) and c.get("exfmt") == HDR10 and "hdr_output" not in c and rng.random() < 0.25:
+        c["dovi"] = dict(kind=str(rng.choice(["poly", "mmr", "mixed"])), l2=(100, 600, 1000) if rng.random() < 0.5 else ())
+    if c.get("rotation") in (90, 270):
+        c["dst"] = (c["dst"][1], c["dst"][0])       # (keeps the ratios of the two axes in the range drawn above)
+        c.pop("window", None); c.pop("offset", None)
     try:
         plain, _ = run_product(api, torch, c, extra_flags=api.FLAG_NO_FUSED)
         got, info = run_product(api, torch, c)
@@ -72,7 +85,9 @@ for i in range(n):
     if c.get("output_format", 0) == 1:
         g, p_ = got.view(np.uint32)[..., 0], plain.view(np.uint32)[..., 0]
         d = np.stack([np.abs(((g >> sh) & 1023).astype(np.int32) - ((p_ >> sh) & 1023).astype(np.int32)) for sh in (0, 10, 20)], -1)
-        lim = 5 if internal_is_8bit(c) else 2 if has_tail(c) else 1
+        # (Dolby Vision on a 10-bit target: the block convert decodes PQ from a table where the plain kernel runs the literal pow chain —
+        # one 8-bit code = 4 ten-bit codes is the bar the whole-frame DoVi test holds it to)
+        lim = 5 if internal_is_8bit(c) else 4 if "dovi" in c else 2 if has_tail(c) else 1
     else:
         d = np.abs(got[..., :3].astype(np.int32) - plain[..., :3].astype(np.int32)); lim = 1
     beyond = int((d > lim).sum()); same = float((d == 0).mean())
@@ -83,5 +98,6 @@ for i in range(n):
     assert same >= 0.97, name
     # (without a tail: a block-convert texel one code off its plain-kernel value can come out of a Lanczos tap sum 1.2 codes off,
     # i.e. two 10-bit codes after both roundings — seen once per ~1e6 channels; never beyond lim + 1)
-    assert beyond == 0 or (beyond <= max(4, 2e-5 * d.size) and d.max() <= (8 if has_tail(c) else lim + 1)), name
+    worst_ok = (8 * (4 if c.get("output_format", 0) == 1 else 1)) if has_tail(c) else lim + 1      # ill-conditioned channels: 8 eight-bit codes
+    assert beyond == 0 or (beyond <= max(4, 2e-5 * d.size) and d.max() <= worst_ok), name
 print("cases", n, "of which also as 3-frame batches", batches, "refused", refused, "kernels", dict(paths), "largest differing fraction", round(worst, 5), "cases with an ill-conditioned channel", outliers)
