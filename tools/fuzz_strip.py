@@ -8,13 +8,15 @@ import sys, os, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from videorenderer_amd import api
-from tests.golden.cases import GOLDEN_CASES, case_frame, HDR10, HLG
+from tests.golden.cases import GOLDEN_CASES, case_frame, oracle_params, HDR10, HLG
+from tests.test_parity_gpu import BG
+from oracle import oracle
 from tests.test_parity_gpu import run_product, compare, compare_rgb10, internal_is_8bit, has_tail, make_vp
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20260925)
 sdr = GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]
-paths = collections.Counter(); worst = 0.0; refused = 0; outliers = 0; batches = 0
+paths = collections.Counter(); worst = 0.0; refused = 0; outliers = 0; batches = 0; oracle_cases = 0
 for i in range(n):
     # every source layout: 4:2:0 weighted up, then planar / packed 4:2:2 and 4:4:4, gray, GBRP, one interleaved RGB
     if rng.random() < 0.55:
@@ -55,6 +57,10 @@ for i in range(n):
     hdr_src = c.get("exfmt") in (HDR10, HLG)
     if hdr_src and rng.random() < 0.2:
         c["hdr_output"] = 1; c["output_format"] = 1; c["hdr_tonemap"] = int(rng.integers(0, 7)); c["hdr_display"] = float(rng.choice([400.0, 1000.0]))
+        # (the tone-mapping step exists only with valid HDR10 metadata — SourceIsHDR() / m_lastHdr10.bValid; the oracle is told the type
+        # directly, so a case that asks for an operator always carries the metadata)
+        if c["hdr_tonemap"] or rng.random() < 0.5:
+            c["hdr_meta"] = (0.005, float(rng.choice([1000.0, 4000.0])), float(rng.choice([0.0, 800.0, 2000.0])), float(rng.choice([0.0, 200.0])))
     if cf in (2, 3) and c.get("exfmt") == HDR10 and "hdr_output" not in c and rng.random() < 0.25:
         c["dovi"] = dict(kind=str(rng.choice(["poly", "mmr", "mixed"])), l2=(100, 600, 1000) if rng.random() < 0.5 else ())
     if c.get("rotation") in (90, 270):
@@ -87,9 +93,27 @@ for i in range(n):
         d = np.stack([np.abs(((g >> sh) & 1023).astype(np.int32) - ((p_ >> sh) & 1023).astype(np.int32)) for sh in (0, 10, 20)], -1)
         # (Dolby Vision on a 10-bit target: the block convert decodes PQ from a table where the plain kernel runs the literal pow chain —
         # one 8-bit code = 4 ten-bit codes is the bar the whole-frame DoVi test holds it to)
-        lim = 5 if internal_is_8bit(c) else 4 if "dovi" in c else 2 if has_tail(c) else 1
+        # (an 8-bit internal format in front of an HDR10 tone-mapping operator: one 8-bit code of the intermediate goes through a curve of
+        # slope > 1 before it is rounded to ten bits)
+        lim = (12 if c.get("hdr_tonemap") else 5) if internal_is_8bit(c) else 4 if "dovi" in c else 2 if has_tail(c) else 1
     else:
         d = np.abs(got[..., :3].astype(np.int32) - plain[..., :3].astype(np.int32)); lim = 1
+    if i % 5 == 0:      # every fifth case against the CPU oracle as well: the plain tier bit-exact without a transcendental tail,
+        # within one code of the target format behind one; the default planner's distance to the oracle at the fused tiers' bar
+        want = oracle.process(oracle_params(oracle, c), *case_frame(c), dst=np.full((got.shape[0], got.shape[1], 4), BG, dtype=np.uint8))
+        def dist(a, b):
+            if c.get("output_format", 0) == 1:
+                a32, b32 = a.view(np.uint32)[..., 0], b.view(np.uint32)[..., 0]
+                return np.stack([np.abs(((a32 >> sh) & 1023).astype(np.int32) - ((b32 >> sh) & 1023).astype(np.int32)) for sh in (0, 10, 20)], -1)
+            return np.abs(a[..., :3].astype(np.int32) - b[..., :3].astype(np.int32))
+        dp, dg = dist(plain, want), dist(got, want)
+        oracle_cases += 1
+        if not has_tail(c):
+            assert dp.max() == 0, f"plain tier vs oracle: max {int(dp.max())}, {int((dp > 0).sum())} channels: {name}"
+            assert dg.max() <= lim and float((dg == 0).mean()) >= 0.97, f"default planner vs oracle: {name}"
+        else:
+            assert float((dp == 0).mean()) >= 0.97 and int((dp > lim).sum()) <= max(4, 2e-5 * dp.size), f"plain tier vs oracle (tail): same {float((dp == 0).mean()):.4f} beyond {int((dp > lim).sum())} max {int(dp.max())} lim {lim}: {name}"
+            assert float((dg == 0).mean()) >= 0.97 and int((dg > lim).sum()) <= max(4, 4e-5 * dg.size), f"default planner vs oracle (tail): same {float((dg == 0).mean()):.4f} beyond {int((dg > lim).sum())} max {int(dg.max())} lim {lim}: {name}"
     beyond = int((d > lim).sum()); same = float((d == 0).mean())
     worst = max(worst, 1.0 - same)
     if beyond:
@@ -100,4 +124,4 @@ for i in range(n):
     # i.e. two 10-bit codes after both roundings — seen once per ~1e6 channels; never beyond lim + 1)
     worst_ok = (8 * (4 if c.get("output_format", 0) == 1 else 1)) if has_tail(c) else lim + 1      # ill-conditioned channels: 8 eight-bit codes
     assert beyond == 0 or (beyond <= max(4, 2e-5 * d.size) and d.max() <= worst_ok), name
-print("cases", n, "of which also as 3-frame batches", batches, "refused", refused, "kernels", dict(paths), "largest differing fraction", round(worst, 5), "cases with an ill-conditioned channel", outliers)
+print("cases", n, "of which also as 3-frame batches", batches, "against the CPU oracle", oracle_cases, "refused", refused, "kernels", dict(paths), "largest differing fraction", round(worst, 5), "cases with an ill-conditioned channel", outliers)
