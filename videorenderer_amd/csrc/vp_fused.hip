@@ -623,6 +623,8 @@ void FillFusedArgs(const FusedParams &P, FusedArgs &a)
     if (a.packed444) a.bytes = a.packed444 == 1 ? 1 : 2;     // (width of the fields the loader packs the luma pair into)
     for (int i = 0; i < 4; i++) a.ci[i] = c.fmt.ci[i];
     a.nearest = c.chroma_scaling == 0 && c.fmt.layout == LAY_PLANAR && (c.fmt.subsampling == 420 || c.fmt.subsampling == 422);
+    a.cw_own = a.sub444 ? 0.0f : a.nearest ? 1.0f : 0.5f;
+    a.cw_next = a.sub444 ? 1.0f : a.nearest ? 0.0f : 0.5f;
     a.center_h = c.fmt.subsampling == 420 && c.chroma_loc == CLOC_MPEG1 && !a.nearest;      // (no siting without a filter)
     a.v_off4 = (c.fmt.subsampling == 420 && c.chroma_loc == CLOC_COSITED && !a.nearest) ? 1 : 0;
     // UNORM scale: v/255, or (v << shift)/65535 for planar data; interleaved UV planes carry no shift

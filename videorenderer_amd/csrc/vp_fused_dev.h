@@ -30,6 +30,7 @@ struct FusedArgs {
     int packed444;                 // one texel per pixel: 1 = four bytes (AYUV), 2 = 10:10:10:2 (Y410), 3 = four words (Y416); implies sub444
     int gray;                      // one plane, no chroma (Y8, Y10, Y16): U = V = 0; implies sub444
     int nearest;                   // CHROMA_Nearest on 4:2:0 / planar 4:2:2: chroma texel (sx / div_w, sy / div_h), no filter (Shaders.cpp:239-241)
+    float cw_own, cw_next;         // the odd luma column's chroma = cw_own * texel c0 + cw_next * texel c0 + 1: {.5, .5}; {0, 1} at 4:4:4; {1, 0} nearest
     float m[9], c[3];              // colour matrix with the UNORM scale (and CopyPlane10to16 shift) folded in
     int tail; float gamma, lum_scale;
     float gamut[9];
@@ -580,8 +581,11 @@ __device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)
         Ucol[1] = pk_fma(Uc[2], splat(0.25f), Uc[1] * splat(0.75f)); Vcol[1] = pk_fma(Vc[2], splat(0.25f), Vc[1] * splat(0.75f));
     } else {                                      // u' = sx/2; 4:4:4: the odd column has its own sample; nearest: the block's one texel
         Ucol[0] = Uc[1]; Vcol[0] = Vc[1];
-        Ucol[1] = P.sub444 ? Uc[2] : P.nearest ? Uc[1] : pk_fma(Uc[2], splat(0.5f), Uc[1] * splat(0.5f));
-        Vcol[1] = P.sub444 ? Vc[2] : P.nearest ? Vc[1] : pk_fma(Vc[2], splat(0.5f), Vc[1] * splat(0.5f));
+        // odd column: (c0 + c1) / 2 — or c1 alone (4:4:4) or c0 alone (nearest): wave-uniform weights {0.5, 0.5} / {0, 1} / {1, 0}
+        // instead of selects on the kernel arguments (eight v_cndmask per block in every variant when tried); exact in all three cases
+        const f2 cwa = splat(P.cw_own), cwb = splat(P.cw_next);
+        Ucol[1] = pk_fma(Uc[2], cwb, Uc[1] * cwa);
+        Vcol[1] = pk_fma(Vc[2], cwb, Vc[1] * cwa);
     }
     convert_block_yuv<TAIL, SRC, DV>(P, MM, GG, CC, Ycol, Ucol, Vcol, T, out, DL, TE, DR);
 }
