@@ -386,7 +386,7 @@ __global__ __launch_bounds__(DV == DV_SDR_L2 ? 512 : 256) void k_convert_blocks(
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 const f2 q = pk_fma(rc[col][c], cmax2, big2);
-                code[col][c][0] = __float_as_uint(q.x) & 0xffffu; code[col][c][1] = __float_as_uint(q.y) & 0xffffu;
+                code[col][c][0] = __float_as_uint(q.x); code[col][c][1] = __float_as_uint(q.y);      // 0x4B000000 | k: every use below drops the high byte for free
             }
 #pragma unroll
         for (int r = 0; r < 2; r++) {
@@ -402,10 +402,11 @@ __global__ __launch_bounds__(DV == DV_SDR_L2 ? 512 : 256) void k_convert_blocks(
                     const uint32_t ib = __umul24(cb, P.epi_mul) + dj, ig = __umul24(cg, P.epi_mul) + dj, ir = __umul24(cr, P.epi_mul) + dj;
                     const uint32_t bg = __builtin_amdgcn_perm(ig, ib, 0x0c0c0703u);
                     px[col] = __builtin_amdgcn_perm(ir, bg, 0x0d070100u);
-                } else if (P.out10) {
-                    px[col] = cr | (cg << 10) | (cb << 20) | 0xc0000000u;
+                } else if (P.out10) {       // the shifts push 0x4B out of the word; 0x4B + 0x75 = 0xC0 = the two alpha bits
+                    px[col] = (cr + 0x75000000u) | (cg << 10) | (cb << 20);
                 } else {
-                    px[col] = cb | (cg << 8) | (cr << 16) | 0xff000000u;
+                    const uint32_t bg = __builtin_amdgcn_perm(cg, cb, 0x0c0c0400u);     // [B, G, 0, 0]
+                    px[col] = __builtin_amdgcn_perm(cr, bg, 0x0d040100u);               // [B, G, R, 0xff]
                 }
             }
             const gptr rowp = pdst + (uint32_t)wy * (uint32_t)P.dst_pitch;
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(256) void k_convert_blocks_wide(FusedArgs P, const 
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     const f2 q = pk_fma(rc[col][c], cmax2, big2);
-                    code[c][0] = __float_as_uint(q.x) & 0xffffu; code[c][1] = __float_as_uint(q.y) & 0xffffu;
+                    code[c][0] = __float_as_uint(q.x); code[c][1] = __float_as_uint(q.y);          // 0x4B000000 | k, see k_convert_blocks
                 }
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
@@ -522,9 +523,10 @@ __global__ __launch_bounds__(256) void k_convert_blocks_wide(FusedArgs P, const 
                         const uint32_t bg = __builtin_amdgcn_perm(ig, ib, 0x0c0c0703u);
                         px[r][2 * b + col] = __builtin_amdgcn_perm(ir, bg, 0x0d070100u);
                     } else if (P.out10) {
-                        px[r][2 * b + col] = cr | (cg << 10) | (cb << 20) | 0xc0000000u;
+                        px[r][2 * b + col] = (cr + 0x75000000u) | (cg << 10) | (cb << 20);
                     } else {
-                        px[r][2 * b + col] = cb | (cg << 8) | (cr << 16) | 0xff000000u;
+                        const uint32_t bg = __builtin_amdgcn_perm(cg, cb, 0x0c0c0400u);     // [B, G, 0, 0]
+                        px[r][2 * b + col] = __builtin_amdgcn_perm(cr, bg, 0x0d040100u);    // [B, G, R, 0xff]
                     }
                 }
             }
