@@ -209,6 +209,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="frames per step (per GPU) = frames per fused launch")
     ap.add_argument("--ring", type=int, default=48, help="distinct input/output frame buffers cycled (>= batch)")
     ap.add_argument("--flags", type=int, default=0, help="mpcvr_settings.flags (2 = pass-per-kernel path)")
+    ap.add_argument("--settle", type=float, default=1.0,
+                    help="seconds of untimed launches BEFORE the counted warm-up (clock ramp: a cold part reads ~5 %% low over a 40 ms run); stated in config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive (host sample) measurement")
     ap.add_argument("--src", default=None, help="WxH: override the workload's source size (secondary rows, e.g. 1920x1080)")
@@ -271,6 +273,15 @@ def main():
             b = prepared[k] = vp.PrepareBatch([srcs[j] for j in idx], [dsts[j] for j in idx])
         vp.ProcessBatch(b, None, dw * 4)
 
+    # settle: a fixed DURATION of the same launches, untimed, so a fresh box has ramped its clocks before the counted warm-up
+    # (the driver's 20-step run is 30 ms of GPU work; profiles/r02: short runs read a few % under long ones)
+    settle_steps = 0
+    t_settle = time.perf_counter()
+    while args.settle > 0 and time.perf_counter() - t_settle < args.settle:
+        for _ in range(4):
+            step(settle_steps)
+            settle_steps += 1
+        torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -284,14 +295,24 @@ def main():
         step(args.warmup + i)
         ev[i][1].record()
     torch.cuda.synchronize()
+    my_elapsed = time.perf_counter() - t0                  # this rank's own K steps (before the closing barrier)
     if world > 1:
         torch.distributed.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     elapsed = vdist.max_over_ranks(elapsed)
     launch_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps       # per step == per launch on the fused path
+    my_launch_ms = launch_ms
     launch_ms = vdist.max_over_ranks(launch_ms)
     path = vp.GetVPInfo()
+    # every rank describes itself (device identity, its own rate): rank 0 checks that no two ranks shared a GPU and puts the
+    # spread into the line, so an N > 1 result proves its own shape
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "local_rank": local, "device_index": int(dev), "device": props.name,
+          "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")),
+          "visible": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES"),
+          "fps": args.batch * args.steps / my_elapsed, "kernel_ms_per_launch": my_launch_ms, "path": path}
+    ranks = vdist.gather_objects(me)
 
     # empirical HBM ceiling beside the 8 TB/s vendor figure: a large device-to-device copy, read + write bytes
     copy_gbps = None
@@ -337,6 +358,11 @@ def main():
                              "presents it); single-frame launches, 3-slot upload ring on a copy stream"}
 
     if rank == 0:
+        # one process per GPU means one GPU per process: two ranks on one device would double-count its throughput.
+        # (MPCVR_DIST_BACKEND=gloo is the single-GPU rehearsal of the N > 1 flow and shares the device on purpose.)
+        ids = [(r["visible"], r["device_index"], r["pci_bus_id"]) for r in ranks]
+        if len(set(ids)) != len(ids) and os.environ.get("MPCVR_DIST_BACKEND") != "gloo":
+            raise SystemExit(f"bench.py: ranks share a GPU: {ids}")
         frames = world * args.batch * args.steps
         fps = frames / elapsed
         achieved = algo_bytes * args.batch / (launch_ms * 1e-3) / 1e9          # GB/s, algorithmic bytes per launch
@@ -365,7 +391,12 @@ def main():
             "vs_baseline": None, "dtype": "f32 (u16 in, u8 out)", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}", "frames_per_step_per_gpu": args.batch,
                        "input_ring_frames": ring, "path": path, "sharding": "frames by index, no data-path collective",
-                       "fps_per_gpu": round(fps / world, 2), "algorithmic_bytes_per_frame": algo_bytes},
+                       "fps_per_gpu": round(fps / world, 2), "algorithmic_bytes_per_frame": algo_bytes,
+                       "settle_s": args.settle, "settle_steps": settle_steps,
+                       "distributed": dict(vdist.describe_backend(), collective="one broadcast of rank 0's parameter blob at set-up",
+                                           per_rank_fps_min=round(min(r["fps"] for r in ranks), 2), per_rank_fps_max=round(max(r["fps"] for r in ranks), 2),
+                                           devices=[{k: r[k] for k in ("rank", "device_index", "device", "pci_bus_id", "visible")} for r in ranks],
+                                           paths=sorted(set(r["path"] for r in ranks)))},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms_per_launch": round(launch_ms, 4), "bytes_per_launch": algo_bytes * args.batch,

@@ -1451,8 +1451,25 @@ typedef struct { int kind; int method; } resizer_t;
 #define ORC_MAX_TAPS 128
 typedef struct { int n; int idx[ORC_MAX_TAPS]; float w[ORC_MAX_TAPS]; float wsum; int normalise; } taps_t;
 
-/* Tex[AXIS]*wh[AXIS] for output i: interpolated texcoord (src_l + (i+.5)*srcLen/dstLen)/texLen times texLen */
-static inline float axis_center(int src_l, int i, float scale) { return (float)src_l + ((float)i + 0.5f) * scale; }
+/* Tex[AXIS]*wh[AXIS] for output i of n_out, as the shaders see it.  FillVertices (DX11VideoProcessor.cpp:133-138) puts
+ * fp32 texture coordinates on the quad's corners: src_dx = 1.0f / texLen, src_l = src_dx * rect.left, src_r = src_dx *
+ * rect.right — three fp32 roundings that are the reference's own.  The rasteriser interpolates TEXCOORD linearly to the
+ * pixel centre (i + .5) / n_out of the viewport (modelled as exact, rounded ONCE to fp32: the Direct3D functional spec
+ * leaves the interpolator's precision to the hardware) and the shader multiplies by its constant wh[AXIS] = (float)texLen
+ * in fp32 (ps_interpolation_*.hlsl:25, ps_convolution.hlsl:30).  `rev`: the coordinate runs from the far edge of the
+ * source range to the near one (rotation / flip permute the corners, :140-169).
+ * Until round 3 this was `src_l + (i + .5f) * srcLen / dstLen` in fp32 — the same number in real arithmetic, without the
+ * roundings above; at 3840 -> 7680 the two differ by up to 2^-13 texels, which moved 0.05 % of the 8-bit channels by one
+ * code against the reference shader text. */
+static inline float axis_center(int src_l, int src_len, int tex_len, int i, int n_out, int rev)
+{
+    const float src_d = 1.0f / (float)tex_len;
+    const float c_lo = src_d * (float)src_l, c_hi = src_d * (float)(src_l + src_len);
+    const double ua = rev ? c_hi : c_lo, ub = rev ? c_lo : c_hi;
+    const double a = ((double)i + 0.5) / (double)n_out;
+    const float tex = (float)(ua + (ub - ua) * a);
+    return tex * (float)tex_len;
+}
 
 /* taps of one output texel whose interpolated coordinate on the filtered axis is `center` (= Tex[AXIS]*wh[AXIS]);
  * `scale` = the shader constant scale[AXIS] (only ps_convolution reads it) */
@@ -1500,9 +1517,9 @@ static int build_taps_at(resizer_t rs, float center, float scale, int tex_len, u
     t->n = 1; t->idx[0] = clampi((int)floorf(center), 0, tex_len - 1); t->w[0] = 1.0f;
     return 0;
 }
-static int build_taps(resizer_t rs, int src_l, int i, float scale, int tex_len, uint32_t flags, taps_t *t)
+static int build_taps(resizer_t rs, int src_l, int src_len, int n_out, int i, float scale, int tex_len, uint32_t flags, taps_t *t)
 {
-    return build_taps_at(rs, axis_center(src_l, i, scale), scale, tex_len, flags, t);
+    return build_taps_at(rs, axis_center(src_l, src_len, tex_len, i, n_out, 0), scale, tex_len, flags, t);
 }
 
 int orc_axis_taps(int kind, int method, int src_l, int src_len, int n_out, int tex_len, uint32_t flags,
@@ -1511,7 +1528,7 @@ int orc_axis_taps(int kind, int method, int src_l, int src_len, int n_out, int t
     taps_t t;
     resizer_t rs = {kind, method};
     float scale = (float)src_len / (float)n_out;
-    if (build_taps(rs, src_l, i, scale, tex_len, flags, &t)) return -1;
+    if (build_taps(rs, src_l, src_len, n_out, i, scale, tex_len, flags, &t)) return -1;
     for (int k = 0; k < t.n; k++) { idx[k] = t.idx[k]; w[k] = t.w[k]; }
     if (wsum) *wsum = t.wsum;
     return t.n;
@@ -1542,7 +1559,6 @@ static int resize_draw(const img_t *in, const int rect[4], img_t *out, int tex_a
     const int len_x = tax == 0 ? rw : rh, len_y = tay == 0 ? rw : rh;               /* srcRect extent run through by x / y */
     const int org_x = tax == 0 ? rect[0] : rect[1], org_y = tay == 0 ? rect[0] : rect[1];
     const int tex_x = tax == 0 ? in->w : in->h, tex_y = tay == 0 ? in->w : in->h;   /* clamp range = whole texture */
-    const float step_x = (float)len_x / (float)out->w, step_y = (float)len_y / (float)out->h;
     const float cscale = tex_axis == 0 ? (float)rw / (float)out->w : (float)rh / (float)out->h;   /* scale[AXIS] */
     const resizer_t none = {RS_NONE, 0};
 
@@ -1554,8 +1570,8 @@ static int resize_draw(const img_t *in, const int rect[4], img_t *out, int tex_a
         ORC_PAR_FOR
         for (int y = 0; y < out->h; y++) {
             for (int x = 0; x < out->w; x++) {
-                const float cx = rev_x ? (float)(org_x + len_x) - ((float)x + 0.5f) * step_x : axis_center(org_x, x, step_x);
-                const float cy = rev_y ? (float)(org_y + len_y) - ((float)y + 0.5f) * step_y : axis_center(org_y, y, step_y);
+                const float cx = axis_center(org_x, len_x, tex_x, x, out->w, rev_x);
+                const float cy = axis_center(org_y, len_y, tex_y, y, out->h, rev_y);
                 const float pcx = tax == 0 ? cx : cy, pcy = tax == 0 ? cy : cx;        /* pc = Tex * wh */
                 const float tcx = floorf(pcx - 0.5f) + 0.5f, tcy = floorf(pcy - 0.5f) + 0.5f;
                 float w[4][4], wsum = 0.0f;
@@ -1596,11 +1612,11 @@ static int resize_draw(const img_t *in, const int rect[4], img_t *out, int tex_a
     taps_t *ty = (taps_t *)malloc(sizeof(taps_t) * (size_t)out->h);
     if (!tx || !ty) { free(tx); free(ty); return -1; }
     for (int i = 0; i < out->w; i++) {
-        const float c = rev_x ? (float)(org_x + len_x) - ((float)i + 0.5f) * step_x : axis_center(org_x, i, step_x);
+        const float c = axis_center(org_x, len_x, tex_x, i, out->w, rev_x);
         if (build_taps_at(tax == tex_axis ? rs : none, c, cscale, tex_x, flags, &tx[i])) { free(tx); free(ty); return -2; }
     }
     for (int i = 0; i < out->h; i++) {
-        const float c = rev_y ? (float)(org_y + len_y) - ((float)i + 0.5f) * step_y : axis_center(org_y, i, step_y);
+        const float c = axis_center(org_y, len_y, tex_y, i, out->h, rev_y);
         if (build_taps_at(tay == tex_axis ? rs : none, c, cscale, tex_y, flags, &ty[i])) { free(tx); free(ty); return -2; }
     }
     const int filt_x = (tax == tex_axis);      /* taps run along screen x; otherwise along screen y (or nowhere) */

@@ -362,6 +362,8 @@ def build_all(extra_params=()):
                          (20, 1920, 1080, cases.ext(matrix=cases.M709)), (1, 1920, 1080, cases.ext(matrix=cases.M709)),
                          (2, 1920, 1080, cases.HDR10), (2, 256, 144, cases.HDR10)):
         args.append(convert_args(O.default_params(cformat=cf, width=w, height=h, exfmt=ex, window_w=w, window_h=h, video_rect=(0, 0, w, h))))
+    for c in cases.FULL_SIZE_CASES.values():
+        args.append(convert_args(cases.oracle_params(O, c)))
     for p in extra_params:
         args.append(convert_args(p))
     return R.build(args)

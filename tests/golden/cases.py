@@ -206,6 +206,23 @@ for _i, (_cf, _ex) in enumerate(((2, HDR10), (2, HLG), (20, ext(COSITED, TV, M70
         PINNING_CASES["pin_convert_%d_chroma%d" % (_i, _cs)] = dict(cformat=_cf, w=64, h=32, kind="noise", seed=360 + 3 * _i + _cs, dst=(64, 32),
                                                                       exfmt=_ex, iChromaScaling=_cs, full_range=(_i in (3, 6)))
 
+# ---- full-size cases: the BASELINE.json configurations (and the two everyday non-2x bench workloads) at their REAL sizes.
+# tests/golden/make_full_size_pins.py runs the reference's own shader text over them (oracle/ref_hlsl) and records the sha256 of
+# its render target; tests/test_ref_hlsl.py holds the oracle to those hashes, tests/test_parity_gpu.py holds every GPU tier to
+# the reference-text output directly (live on the GPU box, where libref_hlsl.so travels).
+FULL_SIZE_CASES = {
+    "c3hdr": dict(cformat=2, w=3840, h=2160, kind="noise", seed=77, dst=(7680, 4320), exfmt=HDR10, iUpscaling=4),
+    "c3_sdr": dict(cformat=2, w=3840, h=2160, kind="noise", seed=77, dst=(7680, 4320), exfmt=ext(matrix=M709), iUpscaling=4),
+    "c5_hlg": dict(cformat=2, w=3840, h=2160, kind="noise", seed=77, dst=(7680, 4320), exfmt=HLG, iUpscaling=4),
+    "c4_mitchell": dict(cformat=2, w=3840, h=2160, kind="noise", seed=77, dst=(7680, 4320), exfmt=HDR10, iUpscaling=1),
+    "C1": dict(cformat=1, w=1920, h=1080, kind="structure", seed=201, dst=(1920, 1080), exfmt=ext(matrix=M709)),
+    "C2": dict(cformat=20, w=1920, h=1080, kind="noise", seed=202, dst=(3840, 2160), exfmt=ext(matrix=M709), iUpscaling=2),
+    "up1440": dict(cformat=2, w=1920, h=1080, kind="noise", seed=311, dst=(2560, 1440), exfmt=HDR10, iUpscaling=4),
+    "down1440": dict(cformat=2, w=3840, h=2160, kind="noise", seed=312, dst=(2560, 1440), exfmt=HDR10, iDownscaling=2),
+    "up1080_from_720_nv12": dict(cformat=1, w=1280, h=720, kind="noise", seed=318, dst=(1920, 1080), exfmt=ext(matrix=M709), iUpscaling=2),
+    "down1080_from_4k_hlg": dict(cformat=2, w=3840, h=2160, kind="noise", seed=315, dst=(1920, 1080), exfmt=HLG, iUpscaling=1),
+}
+
 SETTING_KEYS = ("iTexFormat", "iChromaScaling", "iUpscaling", "iDownscaling", "bInterpolateAt50pct",
                 "bUseDither", "bConvertToSdr", "iSDRDisplayNits", "output_format", "flags")
 
@@ -251,7 +268,7 @@ def oracle_params(oracle, c):
 
 def run_case(oracle, name, background=0):
     """Oracle output for a named case: (window_h, window_w, 4) uint8; untouched pixels = background."""
-    c = GOLDEN_CASES[name] if name in GOLDEN_CASES else PINNING_CASES[name]
+    c = GOLDEN_CASES[name] if name in GOLDEN_CASES else PINNING_CASES[name] if name in PINNING_CASES else FULL_SIZE_CASES[name]
     frame, pitch = case_frame(c)
     p = oracle_params(oracle, c)
     dst = np.full((p.window_h, p.window_w, 4), background, dtype=np.uint8)

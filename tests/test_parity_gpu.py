@@ -90,6 +90,11 @@ def compare(got, want, name, exact=False, min_same=0.99):
     same = float((d == 0).mean())
     assert d.max() <= (0 if exact else 1), f"{name}: max |delta| = {d.max()} ({(d > 1).sum()} channels > 1 LSB, same={same:.5f})"
     assert same >= min_same, f"{name}: only {same:.5f} of channels identical"
+    if os.environ.get("MPCVR_PARITY_LOG"):      # evidence: measured share of identical channels per comparison (profiles/rNN/parity_*.jsonl)
+        import json
+        with open(os.environ["MPCVR_PARITY_LOG"], "a") as f:
+            f.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], "what": name, "pixels": int(d.size // d.shape[-1]),
+                                "identical": same, "max_delta": int(d.max()), "floor": 0.0 if exact else min_same, "exact_required": bool(exact)}) + "\n")
     return same
 
 
@@ -532,37 +537,113 @@ def test_error_behaviour(mpcvr, torch_cuda):
 # ------------------------------------------------------------------------------------------------
 # BASELINE.json full sizes: size-independent properties + oracle on sampled regions
 # ------------------------------------------------------------------------------------------------
-def _full_size_case(exfmt, iUpscaling, seed):
-    return dict(cformat=2, w=3840, h=2160, kind="noise", seed=seed, dst=(7680, 4320), exfmt=exfmt, iUpscaling=iUpscaling)
+def reference_text_output(oracle, name):
+    """B8G8R8A8 render target of the REFERENCE's own shader text for a tests/golden/cases.py FULL_SIZE_CASES entry.
+    Where oracle/_ref/libref_hlsl.so exists (this container, and the GPU box: built .so files travel with the snapshot) the text is
+    EXECUTED here (oracle/ref_hlsl/ref_pipeline.py: the real Shaders/*.hlsl + the convert shader the real Source/Shaders.cpp emits)
+    and its hash checked against tests/golden/full_size_pins.json; where it does not, the oracle's output stands in — after ITS hash
+    matched the recorded reference-text hash, so either way the array returned is the reference text's result bit for bit (alpha set
+    opaque: the reference leaves the shader's A in the target and the swap chain ignores it)."""
+    import hashlib
+    import json
+    import sys
+    from tests.golden.cases import FULL_SIZE_CASES
+    from tests.golden.make_ref_hlsl_golden import rgb_channels
+    with open(os.path.join(HERE, "golden", "full_size_pins.json")) as f:
+        pin = json.load(f)["cases"][name]
+    c = FULL_SIZE_CASES[name]
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle", "ref_hlsl"))
+    import ref_hlsl
+    live = ref_hlsl.available()
+    if live:
+        import ref_pipeline
+        try:
+            out = ref_pipeline.process(p, frame, pitch)
+        except RuntimeError:            # this convert shader is not in the prebuilt library and /root/reference is not mounted
+            live = False
+    if not live:
+        out = oracle.process(p, frame, pitch)
+    assert hashlib.sha256(rgb_channels(out).astype(np.uint16).tobytes()).hexdigest() == pin["rgb_sha256"], \
+        f"{name}: {'reference text' if live else 'oracle'} output does not hash to the recorded reference-text result"
+    out = out.copy()
+    out[..., 3] = 255
+    return out, live
 
 
-@pytest.mark.parametrize("label,exfmt,up", [("c3hdr", GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"], 4),
-                                            ("c3_sdr", GOLDEN_CASES["c3_p010_lanczos3_2x"]["exfmt"], 4),
-                                            ("c5_hlg", GOLDEN_CASES["c5_p010_hlg_lanczos3_2x"]["exfmt"], 4),
-                                            ("c4_mitchell", GOLDEN_CASES["c4_p010_pq_mitchell_2x"]["exfmt"], 1)])
-def test_full_size_4k_to_8k(mpcvr, oracle, torch_cuda, label, exfmt, up):
-    """BASELINE.json configs 3 / 4 / 5 at their real size, 4K P010 -> 8K: EVERY one of the 33 M output pixels of the fused kernel
-    (both tap engines) and of the pass-per-kernel path against the oracle (which is pinned to the reference's own HLSL,
-    tests/test_ref_hlsl.py).  <= 1 LSB each; the two GPU paths are not compared with each other."""
+# measured share of identical channels per (case, tier) on MI355X, round 3 (max |delta| = 1 everywhere); the asserted floor is
+# 1 - 2 x (1 - measured): a rounding regression twice as bad as today's fails
+FULL_SIZE_TIERS = {
+    # name: ((flags attr or 0, expected GetVPInfo prefix, floor), ...)
+    "c3hdr": (("FLAG_FUSED_VALU", "fused_up2x", 0.99856), ("FLAG_FUSED_MFMA", "fused_up2x", 0.99854), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 0.99992)),        # 0.999280 0.999272 0.999962
+    "c3_sdr": (("FLAG_FUSED_VALU", "fused_up2x", 0.99925), ("FLAG_FUSED_MFMA", "fused_up2x", 0.99923), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 1.0)),                  # 0.999625 0.999616 1.0
+    "c5_hlg": (("FLAG_FUSED_VALU", "fused_up2x", 0.9979), ("FLAG_FUSED_MFMA", "fused_up2x", 0.99787), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 0.9993)),          # 0.998948 0.998939 0.999648
+    "c4_mitchell": (("FLAG_FUSED_VALU", "fused_up2x", 0.9988), ("FLAG_FUSED_MFMA", "fused_up2x", 0.99879), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 0.99993)),    # 0.999401 0.999397 0.999969
+    "C1": ((0, "direct:convert+copy", 0.99999),          # 0.999996 1.0 1.0
+            ("FLAG_NO_FAST_CONVERT", "direct:convert+copy", 1.0), ("FLAG_NO_FUSED", "passes:convert,copy", 1.0)),
+    "C2": ((0, "fused_up2x", 0.9996),        # 0.999804 1.0
+            ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 1.0)),
+    "up1440": ((0, "fused", 0.99938), ("FLAG_NO_STRIP", "passes:convert,resizeX,resizeY", 0.99939), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 0.99992)),            # 0.999691 0.999698 0.999963
+    "down1440": ((0, "fused", 0.99938), ("FLAG_NO_STRIP", "passes:convert,resizeX,resizeY", 0.99939), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 0.99993)),          # 0.999692 0.999697 0.999965
+    "up1080_from_720_nv12": ((0, "fused", 0.99996), ("FLAG_NO_STRIP", "passes:convert,resizeX,resizeY", 0.99998),      # 0.999981 0.999991 1.0
+                             ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY", 1.0)),
+    "down1080_from_4k_hlg": ((0, "fused", 0.99877), ("FLAG_NO_STRIP", "passes:convert,resizeX,resizeY", 0.9988), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 0.99939)),   # 0.999386 0.999401 0.999695
+}
+
+
+@pytest.mark.parametrize("name", sorted(FULL_SIZE_TIERS))
+def test_full_size_hip_vs_reference_shader_text(mpcvr, oracle, torch_cuda, name):
+    """The parity triangle closed at the BASELINE sizes: EVERY output pixel of every GPU tier — the fused kernels (both tap engines of
+    the exact-2x kernel; the periodic / strip kernels for the other ratios), the tiled kernels, the pass-per-kernel path — against
+    what the REFERENCE's own shader text produces for the same frame (reference_text_output: executed live on this box).
+    BASELINE.json's bar: |delta| <= 1 LSB per 8-bit channel.  Tiers whose floor is 1.0 must be bit-identical to the reference text
+    (no transcendental on the path, -ffp-contract=off, and the tap tables restate FillVertices' fp32 corner coordinates)."""
     torch = torch_cuda
     from videorenderer_amd import api
-    c = _full_size_case(exfmt, up, seed=77)
-    frame, pitch = case_frame(c)
-    want = oracle.process(oracle_params(oracle, c), frame, pitch)
-    dev = torch.from_numpy(frame).cuda()
-    for flags, path, min_same in ((api.FLAG_FUSED_VALU, "fused_up2x", 0.99), (api.FLAG_FUSED_MFMA, "fused_up2x", 0.99),
-                                  (api.FLAG_NO_FUSED, "passes:convert,resizeX,resizeY+final", 0.995 if label != "c3_sdr" else 1.0)):
-        vp, (ww, wh) = make_vp(mpcvr, c, flags)
-        dst = torch.empty((wh, ww, 4), dtype=torch.uint8, device="cuda")
-        vp.CopySample(dev, pitch)
-        vp.Process(dst, ww * 4)
-        vp.Synchronize()
-        assert vp.GetVPInfo() == path
-        vp.close()
-        got = dst.cpu().numpy()
+    from tests.golden.cases import FULL_SIZE_CASES
+    c = FULL_SIZE_CASES[name]
+    want, live = reference_text_output(oracle, name)
+    for flag, path, floor in FULL_SIZE_TIERS[name]:
+        flags = getattr(api, flag) if flag else 0
+        got, info = run_product(mpcvr, torch, c, extra_flags=flags)
+        assert info.startswith(path) or (path == "fused" and "kernel=fused_" in info), (name, flag, info)
         assert bool((got[..., 3] == 255).all())
-        same = compare(got, want, f"{label} flags={flags}", exact=(min_same == 1.0), min_same=min_same)
-        print(f"{label} flags={flags}: identical channels {same:.6f}")
+        same = compare(got, want, f"{name} flags={flag} [{info}]", exact=(floor == 1.0), min_same=floor)
+        print(f"FULLSIZE {name} {flag or 'default'} [{info}] vs reference text ({'live' if live else 'recorded hash'}): identical channels {same:.6f}")
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN_CASES))
+def test_default_planner_vs_live_reference_shader_text(mpcvr, oracle, torch_cuda, name):
+    """Every comparable golden case: the default planner's output against the reference's shader text EXECUTED ON THIS BOX
+    (oracle/_ref/libref_hlsl.so travels with the snapshot) — the GPU suite's own contact with reference-derived output, no oracle in
+    between.  Bars as for the oracle comparisons: <= 1 LSB (8-bit) / the 10-bit bars of compare_rgb10."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle", "ref_hlsl"))
+    import ref_hlsl
+    from tests.golden.make_ref_hlsl_golden import comparable
+    c = GOLDEN_CASES[name]
+    if not comparable(c):
+        pytest.skip("interleaved RGB sample / our own Lanczos3 tap fix: no reference-text counterpart")
+    if not ref_hlsl.available():
+        pytest.skip("oracle/_ref/libref_hlsl.so not built")
+    import ref_pipeline
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    try:
+        ref = ref_pipeline.process(p, frame, pitch, background=BG)
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    got, info = run_product(mpcvr, torch_cuda, c)
+    if c.get("output_format", 0) == 1:
+        g, r = got.view(np.uint32)[..., 0], ref                # untouched pixels carry BG in both
+        lim = 5 if internal_is_8bit(c) else 2 if has_tail(c) else 1
+        for sh in (0, 10, 20):
+            d = np.abs(((g >> sh) & 1023).astype(np.int32) - ((r >> sh) & 1023).astype(np.int32))
+            assert d.max() <= lim, f"{name} [{info}]: 10-bit delta {d.max()} vs the reference text"
+    else:
+        d = np.abs(got[..., :3].astype(np.int16) - ref[..., :3].astype(np.int16))
+        assert d.max() <= 1, f"{name} [{info}]: max |delta| = {d.max()} vs the reference text"
 
 
 STRIP_FULL = [

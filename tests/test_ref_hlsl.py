@@ -4,12 +4,15 @@ The reference has no tests and its arithmetic is HLSL.  oracl
 of /root/reference/Shaders and the convert shader the real Source/Shaders.cpp generates — for the CPU behind a small execution
 model of Direct3D (hlsl_shim.h) and runs the whole Process() with it (ref_pipeline.py).  These tests hold the oracle to it:
 
-  * every comparable golden / pinning case: B, G, R of the oracle's render target against the reference-text result — recorded in
-    tests/golden/ref_hlsl_pins.json (+ the full reference output where the two are not bit-identical), so the check runs without
-    /root/reference; and live whenever oracle/_ref/libref_hlsl.so is built (here, and on the GPU box where it travels);
-  * bar: bit-identical wherever the texture coordinates are exactly representable (all power-of-two "pin_*" cases, every 2x case);
-    <= 1 code otherwise (Tex * wh carries an ulp of slack once (i + .5) * src / dst has a long mantissa; the rasteriser's own
-    interpolation error is of the same size, so no fp32 model can claim more); the one exception is stated below;
+  * every comparable golden / pinning case (172) AND the BASELINE configurations at their real sizes (4K -> 8K, 1080p -> 4K,
+    1080p, 1080p -> 1440p, 4K -> 1440p ...: tests/golden/cases.py FULL_SIZE_CASES): B, G, R of the oracle's render target against
+    the reference-text result — recorded as sha256 in tests/golden/ref_hlsl_pins.json / full_size_pins.json, so the check runs
+    without /root/reference; and live whenever oracle/_ref/libref_hlsl.so is built (here, and on the GPU box where it travels);
+  * bar: BIT-IDENTICAL, every case (round 3).  Until round 2 nine cases sat at <= 1 code and ps_convolution's box filter at a
+    2.4x ratio differed by whole taps: the oracle computed Tex * wh as `src_l + (i + .5) * src / dst` where the reference rounds
+    the quad's corner coordinates to fp32 first (FillVertices, DX11VideoProcessor.cpp:133-138: src_dx = 1.0f / texW; src_l =
+    src_dx * rect.left ...).  With those three roundings restated (oracle axis_center, product TexCenter) every tap decision —
+    the box filter's `x < 0.5` edge included — falls the way the shader text's does, at every size;
   * alpha is not compared: the reference leaves the shader's A there (not 1 after the float4-wide HLG / Dolby Vision tails) and the
     swap chain ignores it; the oracle and the product write opaque alpha.
 """
@@ -33,10 +36,8 @@ with open(os.path.join(HERE, "golden", "ref_hlsl_pins.json")) as _f:
 OUTS = np.load(os.path.join(HERE, "golden", "ref_hlsl_outputs.npz"))
 CASES = {k: v for k, v in all_cases().items() if comparable(v)}
 
-# ps_convolution's box filter tests `x >= -0.5 && x < 0.5` (convolution_filters.hlsl:11-16); at a 2.4x ratio several taps sit on
-# that edge EXACTLY in real arithmetic, so which side they fall on is decided by the last ulp of the interpolated texcoord —
-# different on every GPU.  The whole-tap flips are large; the case is kept to show that, not held to 1 LSB.
-ILL_CONDITIONED = {"down_box_bilinear_mix"}
+with open(os.path.join(HERE, "golden", "full_size_pins.json")) as _f:
+    FULL_PINS = json.load(_f)["cases"]
 
 
 def oracle_rgb(oracle, name):
@@ -54,25 +55,25 @@ def sha(ch):
 def test_every_comparable_case_is_pinned():
     assert set(PINS) == set(CASES)
     assert len(PINS) >= 170
-    exact = [n for n, p in PINS.items() if p["oracle_max"] == 0]
-    assert len(exact) >= 160
-    assert all(PINS[n]["oracle_max"] == 0 for n in cases.PINNING_CASES)          # power-of-two geometry: one fp32 evaluation
     for n, p in PINS.items():
-        if n not in ILL_CONDITIONED:
-            assert p["oracle_max"] <= 1 and p["oracle_differing"] < 1e-3, (n, p)
+        assert p["oracle_max"] == 0 and p["oracle_differing"] == 0.0, (n, p)       # bit-identical to the reference shader text
+    assert len(OUTS.files) == 0                                                     # ... so no reference output needs storing
+    assert set(FULL_PINS) == set(cases.FULL_SIZE_CASES)
+    for n, p in FULL_PINS.items():
+        assert p["oracle_max"] == 0, (n, p)
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_oracle_against_recorded_reference_hlsl(oracle, name):
-    pin = PINS[name]
-    got = oracle_rgb(oracle, name)
-    if pin["oracle_max"] == 0:
-        assert sha(got) == pin["rgb_sha256"], "oracle no longer bit-identical to the reference shader text"
-        return
-    ref = rgb_channels(OUTS[name])
-    assert sha(ref) == pin["rgb_sha256"]
-    d = np.abs(got - ref)
-    assert int(d.max()) == pin["oracle_max"] and abs(float((d > 0).mean()) - pin["oracle_differing"]) < 1e-12
+    assert sha(oracle_rgb(oracle, name)) == PINS[name]["rgb_sha256"], "oracle no longer bit-identical to the reference shader text"
+
+
+@pytest.mark.parametrize("name", sorted(cases.FULL_SIZE_CASES))
+def test_oracle_full_size_against_recorded_reference_hlsl(oracle, name):
+    """BASELINE configurations at their real sizes (33 M output pixels at 4K -> 8K): the oracle's render target hashes to what the
+    reference's shader text produced (tests/golden/make_full_size_pins.py)."""
+    got = rgb_channels(cases.run_case(oracle, name))
+    assert sha(got) == FULL_PINS[name]["rgb_sha256"], "oracle no longer bit-identical to the reference shader text at full size"
 
 
 def _live():
@@ -96,7 +97,23 @@ def test_oracle_against_live_reference_hlsl(oracle, name):
     ref = rgb_channels(ref)
     assert sha(ref) == PINS[name]["rgb_sha256"], "reference-text result changed: regenerate tests/golden/ref_hlsl_pins.json"
     d = np.abs(oracle_rgb(oracle, name) - ref)
-    assert int(d.max()) == PINS[name]["oracle_max"]
+    assert int(d.max()) == 0
+
+
+@pytest.mark.parametrize("name", sorted(cases.FULL_SIZE_CASES))
+def test_oracle_full_size_against_live_reference_hlsl(oracle, name):
+    """The same at full size, live: the reference shader text is executed here (5 - 15 s per 8K frame on 8 threads)."""
+    RP = _live()
+    c = cases.FULL_SIZE_CASES[name]
+    frame, pitch = cases.case_frame(c)
+    p = cases.oracle_params(oracle, c)
+    try:
+        ref = rgb_channels(RP.process(p, frame, pitch))
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    assert sha(ref) == FULL_PINS[name]["rgb_sha256"], "reference-text result changed: regenerate tests/golden/full_size_pins.json"
+    got = rgb_channels(oracle.process(p, frame, pitch))
+    assert np.array_equal(got, ref)
 
 
 def test_headline_convert_shader_is_the_generators_text():

@@ -25,6 +25,9 @@ SOURCES = [
     ("mpcvr_capi.cpp", []),
     ("vp_kernels.hip", ["-ffp-contract=off", "-DMPCVR_EXACT_FP"]),
     ("vp_fused.hip", []),
+    ("vp_fused_up2x_nt4.hip", []),
+    ("vp_fused_up2x_nt5.hip", []),
+    ("vp_fused_up2x_nt6.hip", []),
     ("vp_fused_mx.hip", []),
     ("vp_fused_strip.hip", []),
     ("vp_jinc.hip", []),

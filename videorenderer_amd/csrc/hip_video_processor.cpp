@@ -559,7 +559,7 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         const Resizer rs = a < 0 ? Resizer{RS_NONE, 0} : m_plan.first_rs;
         m_firstJinc = rs.kind == RS_UP && rs.method == MPCVR_UPSCALE_Jinc2;
         m_firstCoords = DrawCoords{org_x, len_x, rev_x ? 1 : 0, (float)len_x / (float)outW,
-                                   org_y, len_y, rev_y ? 1 : 0, (float)len_y / (float)outH, swap ? 1 : 0};
+                                   org_y, len_y, rev_y ? 1 : 0, (float)len_y / (float)outH, swap ? 1 : 0, tex_x, tex_y, outW, outH};
         bool ok = true;
         if (m_firstJinc) {
             // the 2-D shader needs no tables
@@ -587,7 +587,7 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         if ((hr = CheckHip(m_TexResize.CheckCreate((size_t)w2 * 8 * mh), "m_TexResize"))) return hr;
         m_midBytes = (size_t)w2 * 8 * mh;
         m_secondJinc = m_plan.ry.kind == RS_UP && m_plan.ry.method == MPCVR_UPSCALE_Jinc2;
-        m_secondCoords = DrawCoords{0, w2, 0, 1.0f, 0, mh, 0, (float)mh / (float)h2, 0};
+        m_secondCoords = DrawCoords{0, w2, 0, 1.0f, 0, mh, 0, (float)mh / (float)h2, 0, w2, mh, w2, h2};
         m_jincSecondTab = nullptr;
         if (m_secondJinc && (hr = UploadJincPhases(m_secondCoords, m_jincSecond, &m_jincSecondTab))) return hr;
         if (!m_secondJinc) {

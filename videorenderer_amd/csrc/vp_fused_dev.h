@@ -901,5 +901,8 @@ int FusedDoviKind(const FusedParams &P);          // DV_* for the launch
 // vp_fused_mx.hip: the same launch as LaunchFusedUp2x with the resize taps on the matrix cores; hipErrorNotSupported when the
 // variant does not cover the configuration (the caller then launches the packed-fp32 kernel)
 hipError_t LaunchFusedUp2xMx(const FusedParams &P, const FusedArgs &a, int knt, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
+// vp_fused_up2x.h, instantiated by vp_fused_up2x_nt{4,5,6}.hip: the packed-fp32 kernel for one tap count
+template <int NT>
+hipError_t LaunchFusedUp2xNT(const FusedParams &P, const FusedArgs &a, int strips, int seg, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
 
 }  // namespace mpcvr

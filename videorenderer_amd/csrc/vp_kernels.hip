@@ -520,8 +520,8 @@ __global__ __launch_bounds__(256) void k_jinc2(Surface in, DrawCoords dc, int ou
     if (x >= out_w || y >= out_h) return;
     const float pi = 3.14159274101257324f;                 // acos(-1) folded to fp32
     const float wa = 0.416f * pi, wb = 0.985f * pi;
-    const float cx = dc.rev_x ? (float)(dc.org_x + dc.len_x) - ((float)x + 0.5f) * dc.step_x : (float)dc.org_x + ((float)x + 0.5f) * dc.step_x;
-    const float cy = dc.rev_y ? (float)(dc.org_y + dc.len_y) - ((float)y + 0.5f) * dc.step_y : (float)dc.org_y + ((float)y + 0.5f) * dc.step_y;
+    const float cx = TexCenter(dc.org_x, dc.len_x, dc.tex_x, x, dc.n_x, dc.rev_x);
+    const float cy = TexCenter(dc.org_y, dc.len_y, dc.tex_y, y, dc.n_y, dc.rev_y);
     const float pcx = dc.swap ? cy : cx, pcy = dc.swap ? cx : cy;      // pc = Tex * wh
     const float tcx = floorf(pcx - 0.5f) + 0.5f, tcy = floorf(pcy - 0.5f) + 0.5f;
     const int bx = (int)floorf(tcx), by = (int)floorf(tcy);

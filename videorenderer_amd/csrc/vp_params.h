@@ -122,12 +122,32 @@ struct StoreParams {
     const uint16_t *dither;  // 32x32 fp16 table (device)
 };
 
-// texture coordinate of an output pixel of a (possibly rotated / flipped) draw, per screen axis:
-// c(i) = rev ? (org + len) - (i + .5) * step : org + (i + .5) * step      (FillVertices :130-179)
+// Tex[AXIS] * wh[AXIS] of output i of n_out, as the reference's shaders see it.  FillVertices (DX11VideoProcessor.cpp:133-138)
+// puts fp32 texture coordinates on the quad's corners (src_dx = 1.0f / texLen; src_l = src_dx * rect.left; src_r = src_dx *
+// rect.right), the rasteriser interpolates them to the pixel centre (i + .5) / n_out (taken as exact, rounded once to fp32) and the
+// shader multiplies by wh[AXIS] = (float)texLen (ps_interpolation_*.hlsl:25, ps_convolution.hlsl:30).  `rev`: the coordinate
+// starts at the far edge of the source range (rotation / flip, FillVertices :140-169).  Every tap table and the plain Jinc kernel
+// go through this one function; the oracle restates it the same way (oracle/mpcvr_oracle.c axis_center) and is bit-identical to
+// the reference's shader text with it — the fp32 roundings of the corner values move t = frac(Tex * wh - .5) by up to 2^-13 at
+// 3840 -> 7680, enough to move one 8-bit channel in 2,000 by one code.
+__host__ __device__ inline float TexCenter(int org, int len, int tex_len, int i, int n_out, int rev)
+{
+    const float src_d = 1.0f / (float)tex_len;
+    const float c_lo = src_d * (float)org, c_hi = src_d * (float)(org + len);
+    const double ua = rev ? c_hi : c_lo, ub = rev ? c_lo : c_hi;
+    const double a = ((double)i + 0.5) / (double)n_out;
+    const float tex = (float)(ua + (ub - ua) * a);
+    return tex * (float)tex_len;
+}
+
+// texture coordinate of an output pixel of a (possibly rotated / flipped) draw, per screen axis: TexCenter(org, len, tex, i, n, rev);
+// step = len / n serves the phase-table kernels (dyadic ratios), whose tap bases do not depend on the last ulp
 struct DrawCoords {
     int org_x, len_x, rev_x; float step_x;     // run through by screen x
     int org_y, len_y, rev_y; float step_y;     // run through by screen y
     int swap;                                  // rotation 90/270: screen x runs along texture Y
+    int tex_x, tex_y;                          // texture extent along the axis screen x / y runs through (wh[AXIS])
+    int n_x, n_y;                              // outputs along screen x / y (the viewport)
 };
 
 // Jinc2m at dyadic ratios: the 16 weights of an output pixel per phase (BuildJincPhases, vp_kernels.hip)

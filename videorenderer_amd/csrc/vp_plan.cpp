@@ -464,20 +464,12 @@ float DownscaleFilter(int method, float x, float *support)
 
 static inline int ClampI(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// Tex[AXIS]*wh[AXIS] of output i: src_l + (i + 0.5) * srcLen/dstLen, scale as in the cbuffer (:353)
-// Tex[AXIS]*wh[AXIS] of output i: the rasteriser's interpolation of the quad's texture coordinates; `rev` = the
-// coordinate starts at the far edge of the source range (rotation / flip, FillVertices :130-179)
-static inline float AxisCenterDir(int src_l, int src_len, int i, float step, bool rev)
-{
-    return rev ? (float)(src_l + src_len) - ((float)i + 0.5f) * step : (float)src_l + ((float)i + 0.5f) * step;
-}
-
 bool BuildAxisTaps(Resizer rs, int src_l, int src_len, int n_out, int tex_len, uint32_t flags, HostAxisTaps *out,
                    bool reversed, float shader_scale)
 {
     const float step = (float)src_len / (float)n_out;
     const float scale = shader_scale > 0.0f ? shader_scale : step;     // scale[AXIS] of ps_convolution
-    auto AxisCenter = [&](int l, int i, float) { return AxisCenterDir(l, src_len, i, step, reversed); };
+    auto AxisCenter = [&](int l, int i, float) { return TexCenter(l, src_len, tex_len, i, n_out, reversed ? 1 : 0); };
     out->idx.clear(); out->w.clear(); out->wsum.clear();
     out->normalise = 0;
     if (rs.kind == RS_NONE) {
@@ -547,10 +539,9 @@ bool BuildAxisTaps(Resizer rs, int src_l, int src_len, int n_out, int tex_len, u
 
 void BuildPointIndex(int src_l, int src_len, int n_out, int tex_len, std::vector<int32_t> *out, bool reversed)
 {
-    const float scale = (float)src_len / (float)n_out;
     out->resize(n_out);
     for (int i = 0; i < n_out; i++)
-        (*out)[i] = ClampI((int)std::floor(AxisCenterDir(src_l, src_len, i, scale, reversed)), 0, tex_len - 1);
+        (*out)[i] = ClampI((int)std::floor(TexCenter(src_l, src_len, tex_len, i, n_out, reversed ? 1 : 0)), 0, tex_len - 1);
 }
 
 // Strip geometry of the arbitrary-ratio fused kernel.  The kernel converts a strip's source window in passes of 64 2x2 blocks

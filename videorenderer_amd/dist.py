@@ -79,3 +79,25 @@ def sum_over_ranks(value, device=None):
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def gather_objects(obj):
+    """Every rank's `obj` (picklable) as a list on every rank, rank order; [obj] in a single process."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def describe_backend():
+    """Backend name and, for nccl (= RCCL on ROCm), the library version — for the bench line's self-description."""
+    if not dist.is_initialized():
+        return {"backend": None, "world_size": 1}
+    d = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+    if d["backend"] == "nccl":
+        try:
+            d["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:       # noqa: BLE001 — a description only
+            d["rccl_version"] = f"unavailable: {e}"
+    return d
