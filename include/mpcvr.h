@@ -83,6 +83,8 @@ enum { MPCVR_OUT_BGRA8 = 0, MPCVR_OUT_RGB10A2 = 1 };
                                              the library's default (environment MPCVR_FUSED_MX=0/1 overrides it) */
 #define MPCVR_FLAG_NO_STRIP         0x40u /* arbitrary-ratio resizes of 4:2:0 sources stay on the block convert + tiled two-draw
                                              kernels instead of the one-kernel strip path (k_fused_strip; debug / A-B) */
+#define MPCVR_FLAG_NO_PERIOD        0x80u /* rational vertical ratios (4:3, 3:2, 2:3, 1:2) through k_fused_strip's run-time tap tables instead
+                                             of the periodic-phase kernel with its register window (k_fused_period; debug / A-B) */
 
 /* Subset of Settings_t (IVideoRenderer.h:104-135) that reaches the shader path; same field names. */
 typedef struct mpcvr_settings {
@@ -323,6 +325,18 @@ int32_t mpcvr_plan_axis_taps(int32_t kind, int32_t method, int32_t src_l, int32_
 int32_t mpcvr_plan_strip(int32_t kind_x, int32_t method_x, int32_t kind_y, int32_t method_y, int32_t src_w, int32_t src_h,
                          int32_t out_w, int32_t out_h, uint32_t flags, int32_t out8[8], int32_t *yrange, int32_t *xstrip,
                          int32_t *xi_t, float *xw_t, int32_t *yi, float *yw);
+/* Geometry of the periodic-phase fused kernel (k_fused_period) for an unrotated two-pass UPSCALE-shader resize (`method` =
+ * MPCVR_UPSCALE_*; also what a downscale of at most 2x takes with bInterpolateAt50pct, DX11VideoProcessor.cpp:3108):
+ * out6 = {P, Q (output : source rows), taps per output as the kernel runs them (4 / 5 = Lanczos3 with its shared texel folded /
+ * 6), strips of 128 output columns, columns of a converted source row, output rows per body of six source rows}.
+ * xi_t / xw_t: [taps][out_w]; yw: [out_h][8]; xstrip: [strips][2]; any may be NULL.  MPCVR_E_NOTIMPL: the vertical ratio is not
+ * 4:3 / 3:2 / 2:3 / 1:2 or the table's tap rows are not the periodic pattern the kernel hard-codes. */
+int32_t mpcvr_plan_period(int32_t method, int32_t src_w, int32_t src_h, int32_t out_w, int32_t out_h, uint32_t flags,
+                          int32_t out6[6], int32_t *xi_t, float *xw_t, float *yw, int32_t *xstrip);
+/* HDRParamsConstantBuffer_t as SetHDR10ShaderParams fills it (DX11VideoProcessor.cpp:907-923: defaults and clamps of the HDR10
+ * metadata, the display's peak and the tone-mapping operator): five floats + the selection as words */
+int32_t mpcvr_plan_hdr10_params(float min_mastering, float max_mastering, float max_cll, float max_fall, float display_max,
+                                int32_t selection, uint32_t out6[6]);
 /* log2 of ST2084ToLinear(x, 1) at x = (i/4095)^2: the PQ EOTF table of the Dolby Vision block convert */
 int32_t mpcvr_plan_pq_eotf_lut(float out4096[4096]);
 /* which draws Process() would issue (UpdateTexParams :1143, UpdatePostScaleTexures :2894, ResizeShaderPass :3103) */

@@ -768,6 +768,16 @@ int orc_check_unorm_div(int maxv)
 /* ------------------------------------------------------------------------------------------ */
 typedef struct { float min_m, max_m, max_cll, max_fall, display_max; int selection; } hdr_tm_t;
 
+/* SetHDR10ShaderParams (DX11VideoProcessor.cpp:911-916): defaults and clamps in front of the cbuffer */
+static void hdr_tm_sanitise(hdr_tm_t *t)
+{
+    if (t->min_m <= 0.f) t->min_m = 0.f;
+    if (t->max_m <= 10.f) t->max_m = 1000.f;
+    if (t->max_cll <= 10.f) t->max_cll = t->max_m;
+    if (t->max_fall <= 1.f) t->max_fall = t->max_cll;
+    if (t->display_max < 100.f || t->display_max > 10000.f) t->display_max = 1000.f;
+    if (t->selection < 1 || t->selection > 6) t->selection = 1;
+}
 static hdr_tm_t hdr_tm_params(const orc_params *p)
 {
     hdr_tm_t t = {p->hdr_min_mastering, p->hdr_max_mastering, p->hdr_max_cll, p->hdr_max_fall, p->hdr_display_max_nits, p->hdr_tonemap_type};
@@ -776,13 +786,15 @@ static hdr_tm_t hdr_tm_params(const orc_params *p)
         t.min_m = (float)l1[0]; t.max_m = (float)l1[1]; t.max_cll = (float)l1[1]; t.max_fall = (float)l1[2];
         if (t.selection == 5) t.selection = 6;
     }
-    if (t.min_m <= 0.f) t.min_m = 0.f;
-    if (t.max_m <= 10.f) t.max_m = 1000.f;
-    if (t.max_cll <= 10.f) t.max_cll = t.max_m;
-    if (t.max_fall <= 1.f) t.max_fall = t.max_cll;
-    if (t.display_max < 100.f || t.display_max > 10000.f) t.display_max = 1000.f;
-    if (t.selection < 1 || t.selection > 6) t.selection = 1;
+    hdr_tm_sanitise(&t);
     return t;
+}
+void orc_hdr10_params(float min_m, float max_m, float max_cll, float max_fall, float display_max, int selection, uint32_t out6[6])
+{
+    hdr_tm_t t = {min_m, max_m, max_cll, max_fall, display_max, selection};
+    hdr_tm_sanitise(&t);
+    memcpy(out6, &t, 20);
+    out6[5] = (uint32_t)t.selection;
 }
 
 static inline float lerpf(float a, float b, float t) { return a + t * (b - a); }

@@ -151,6 +151,8 @@ void orc_dovi_lms_matrix(const orc_dovi *d, float m[9]);
  * SetDolbyVisionDynamicParams uploads (:954-960): k = {ChromaWeight, SaturationGain, TrimSlope, TrimOffset, TrimPower};
  * returns L2Enabled */
 int  orc_dovi_l2_constants(const orc_dovi *d, int display_nits, float k[5]);
+/* HDRParamsConstantBuffer_t as SetHDR10ShaderParams fills it (DX11VideoProcessor.cpp:907-923): five floats + the selection */
+void orc_hdr10_params(float min_m, float max_m, float max_cll, float max_fall, float display_max, int selection, uint32_t out6[6]);
 /* level 1 (+3) -> nits as CopySample stores them (:2347-2372): out = {min, max, avg}; returns L1.present */
 int  orc_dovi_l1_nits(const orc_dovi *d, uint32_t out[3]);
 

@@ -176,6 +176,9 @@ def lib():
         L.orc_dovi_l2_constants.argtypes = [C.POINTER(OrcDovi), C.c_int, fp]
         L.orc_dovi_l1_nits.restype = C.c_int
         L.orc_dovi_l1_nits.argtypes = [C.POINTER(OrcDovi), C.POINTER(C.c_uint32)]
+        L.orc_hdr10_params.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_uint32)]
+        L.orc_specify_extfmt.restype = C.c_uint32
+        L.orc_specify_extfmt.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int]
         L.orc_correction_pass.restype = C.c_int
         L.orc_correction_pass.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_correction_matrices.argtypes = [fp, fp, fp]

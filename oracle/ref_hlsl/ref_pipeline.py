@@ -19,6 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import ref_hlsl as R  # noqa: E402
+import ref_hostmath as RH  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 F32 = np.float32
@@ -48,6 +49,43 @@ V_FIRST = (14, 15, 16)                         # YV12 / YV16 / YV24: texV is t1 
 
 def supported(cformat):
     return cformat in _FMT
+
+
+# ---- host-side constants: the reference's OWN functions (libref_hostmath.so: SpecifyExtendedFormat, CopyFrameV210,
+# SetShaderDoviCurves[Poly], the level 1 / 3 / 2 block of CopySample, SetHDR10ShaderParams).  The oracle supplies the colour matrix
+# only (pinned bit for bit to the real csputils.cpp) and plain data (the Dolby Vision RPU struct, the v210 texture's pitch). ----
+def _H():
+    L = RH.lib()
+    if L is None:
+        raise RuntimeError("oracle/_ref/libref_hostmath.so is not built (and /root/reference is not mounted)")
+    return L
+
+
+def specify_extfmt(exfmt, cformat, w, h):
+    """SpecifyExtendedFormat (Helper.cpp:1169-1211) with the format's CSType / Subsampling (s_FmtConvMapping)."""
+    cstype = {"yuv": 0, "rgb": 1, "gray": 2}[_FMT[cformat][5]]
+    return int(_H().ref_specify_extfmt(int(exfmt) & 0xffffffff, cstype, _FMT[cformat][3], int(w), int(h)))
+
+
+def dovi_curves(dovi_ptr):
+    """SetShaderDoviCurves / SetShaderDoviCurvesPoly (:990-1141) chosen as :2305-2318 does (any MMR piece -> the full cbuffer):
+    (cbuffer words, has_mmr)."""
+    has_mmr = any(dovi_ptr.contents.curves[c].mapping_idc[i] == 1 for c in range(3) for i in range(max(0, dovi_ptr.contents.curves[c].num_pivots - 1)))
+    buf = (C.c_uint8 * 3072)()
+    n = _H().ref_dovi_curves(dovi_ptr, 0 if has_mmr else 1, buf)
+    raw = np.frombuffer(bytes(buf)[:n], dtype=np.uint32).reshape(3, -1)
+    # The host struct spends a float4 on every pivot because that is how HLSL lays out `float pivots_data[7]` in a cbuffer (one
+    # register per array element, Shaders.cpp:718 "sizeof(float) == sizeof(float4)"); hlsl_shim.h's cbuffers are plain word streams
+    # in declaration order, so the seven .x words are handed over back to back — Direct3D's packing rule, applied here.
+    stream = np.concatenate([np.concatenate([r[0:28:4], r[28:]]) for r in raw])
+    return stream.astype(np.uint32), has_mmr
+
+
+def dovi_levels(dovi_ptr, display_nits):
+    """the level 1 / 3 / 2 block of CopySample + SetDolbyVisionDynamicParams: (k5 floats, enabled, l1 nits, l1 present)."""
+    k5 = (C.c_float * 5)(); en = C.c_int(0); l1 = (C.c_uint * 3)()
+    present = _H().ref_dovi_levels(dovi_ptr, int(display_nits), k5, C.byref(en), l1)
+    return np.array(k5, F32), int(en.value), [int(x) for x in l1], bool(present)
 
 
 def _rgba(h, w, *ch):
@@ -100,11 +138,11 @@ def source_textures(p, frame, pitch):
             b = (b.astype(np.uint32) << shift).astype(np.uint16)
         # planes are bound in storage order to t1, t2; for YV12 the first chroma plane is V and the shader names t1 texV
         return [t0, _rgba(ch, cw, _unorm(a, maxv)), _rgba(ch, cw, _unorm(b, maxv))]
-    if p.cformat == 10:                                                # v210 -> Y210 words (oracle's CopyFrameV210 restatement)
-        tp = O.lib().orc_v210_tex_pitch(w)
+    if p.cformat == 10:                                                # v210 -> Y210 words: the reference's own CopyFrameV210 (Helper.cpp:709-748)
+        tp = O.lib().orc_v210_tex_pitch(w)                             # (the mapped texture's row pitch: a property of the resource, not arithmetic)
         dst = np.zeros(tp * h + 16, np.uint8)
         buf = np.ascontiguousarray(buf)
-        O.lib().orc_repack_v210(C.c_int(h), C.c_void_p(dst.ctypes.data), C.c_int(tp), C.c_void_p(buf.ctypes.data), C.c_int(pitch))
+        _H().ref_copy_frame_v210(h, dst.ctypes.data, tp, buf.ctypes.data, pitch)
         buf, pitch = dst, tp
     if lay == "K422":
         tw = w // 2
@@ -128,17 +166,14 @@ def convert_args(p):
     rect = list(p.src_rect)
     if not any(rect):
         rect = [0, 0, p.width, p.height]
-    exfmt = O.lib().orc_specify_extfmt(p.exfmt, p.cformat, rect[2] - rect[0], rect[3] - rect[1])
+    exfmt = specify_extfmt(p.exfmt, p.cformat, rect[2] - rect[0], rect[3] - rect[1])
     trc = (exfmt >> 27) & 0x1f
     hdr_out = bool(p.hdr_output)
     convert_type = 1 if (p.bConvertToSdr and not hdr_out) else (2 if (hdr_out and trc == 16) else 0)    # :2948-2950
     texw = p.width // 2 if lay == "K422" else p.width
     dv_kind, lms = 0, None
     if p.dovi:
-        cb3 = (O.OrcDoviCb * 3)()
-        has_mmr = C.c_int(0)
-        O.lib().orc_dovi_pack_curves(p.dovi, cb3, C.byref(has_mmr))
-        dv_kind = 2 if has_mmr.value else 1
+        dv_kind = 2 if dovi_curves(p.dovi)[1] else 1
         lms = tuple(p.dovi.contents.rgb_to_lms_matrix)
     blend = bool(p.blend_deint) and sub == 420 and lay == "P"
     return (p.cformat, planes if lay == "P" else 1, sub, p.width, texw, p.height, exfmt, p.iChromaScaling, convert_type, blend, dv_kind, lms)
@@ -189,7 +224,7 @@ def process(p, frame, pitch, dither=None, background=0, stages=None):
     if not any(rect):
         rect = [0, 0, p.width, p.height]
     rw, rh = rect[2] - rect[0], rect[3] - rect[1]
-    exfmt = L.orc_specify_extfmt(p.exfmt, p.cformat, rw, rh)
+    exfmt = specify_extfmt(p.exfmt, p.cformat, rw, rh)
     trc, prim = (exfmt >> 27) & 0x1f, (exfmt >> 22) & 0x1f
     hdr_out = bool(p.hdr_output)
     dovi = p.dovi.contents if p.dovi else None
@@ -208,15 +243,10 @@ def process(p, frame, pitch, dither=None, background=0, stages=None):
     cm = O.color_matrix(p)                                              # cm_r, cm_g, cm_b, cm_c (pinned to the real csputils.cpp)
     cbs[0] = R.words(np.asarray(cm, F32))
     cbs[1] = R.words(F32(10000.0) / F32(p.iSDRDisplayNits), F32(0.0))   # SetShaderLuminanceParams :889-905
-    if dovi is not None:                                                # cbuffers b2 / b3 (:1055-1141, :954-960), oracle's packing
-        cb3 = (O.OrcDoviCb * 3)()
-        has_mmr = C.c_int(0)
-        L.orc_dovi_pack_curves(p.dovi, cb3, C.byref(has_mmr))
-        raw = np.frombuffer(bytes(cb3), dtype=np.uint32).reshape(3, -1)
-        cbs[2] = raw.ravel() if has_mmr.value else np.ascontiguousarray(raw[:, :7 + 32]).ravel()
-        k5 = (C.c_float * 5)()
-        l2 = L.orc_dovi_l2_constants(p.dovi, int(p.hdr_display_max_nits), k5)
-        cbs[3] = R.words(np.array(k5, F32), np.uint32(l2), F32(0), F32(0))
+    if dovi is not None:                                                # cbuffers b2 / b3 as the reference's own code fills them (:990-1141, :953-960)
+        cbs[2], _ = dovi_curves(p.dovi)
+        k5, l2, _, _ = dovi_levels(p.dovi, int(p.hdr_display_max_nits))
+        cbs[3] = R.words(k5, np.uint32(l2), F32(0), F32(0))
     fn, text = R.convert_fn(*convert_args(p))
     if fn is None:
         raise RuntimeError("convert shader for this configuration is not built (and /root/reference is not mounted)")
@@ -310,27 +340,18 @@ def process(p, frame, pitch, dither=None, background=0, stages=None):
 
 
 def _hdr_tm_constants(p, L):
-    """SetHDR10ShaderParams (:907-917); with Dolby Vision level-1 data the caller passes L1 nits and type 5 -> 6 (:2716-2720)."""
+    """HDRParamsConstantBuffer_t from the reference's own SetHDR10ShaderParams (:907-923); with Dolby Vision level-1 data the caller
+    passes the L1 nits and turns type 5 into 6 (Render :2716-2720)."""
     mn, mx, cll, fall, disp, sel = p.hdr_min_mastering, p.hdr_max_mastering, p.hdr_max_cll, p.hdr_max_fall, p.hdr_display_max_nits, p.hdr_tonemap_type
     if p.dovi:
-        l1 = (C.c_uint32 * 3)()
-        if L.orc_dovi_l1_nits(p.dovi, l1):
+        _, _, l1, present = dovi_levels(p.dovi, int(p.hdr_display_max_nits))
+        if present:
             mn, mx, cll, fall = float(l1[0]), float(l1[1]), float(l1[1]), float(l1[2])
             if sel == 5:
                 sel = 6
-    if mn <= 0:
-        mn = 0.0
-    if mx <= 10:
-        mx = 1000.0
-    if cll <= 10:
-        cll = mx
-    if fall <= 1:
-        fall = cll
-    if disp < 100 or disp > 10000:
-        disp = 1000.0
-    if sel < 1 or sel > 6:
-        sel = 1
-    return R.words(F32(mn), F32(mx), F32(cll), F32(fall), F32(disp), np.uint32(sel), F32(0), F32(0))
+    out = (C.c_uint32 * 6)()
+    _H().ref_hdr10_params(mn, mx, cll, fall, disp, int(sel), out)
+    return np.concatenate([np.array(out, np.uint32), R.words(F32(0), F32(0))])
 
 
 def pack_output(rt, swap, background=0):

@@ -474,3 +474,55 @@ def test_pq_eotf_table(mpcvr):
     vis = lm > 1e-7
     assert np.abs(got[vis] / lm[vis] - 1).max() < 1e-4
     assert np.abs(got[~vis] - lm[~vis]).max() < 1e-9
+
+
+# ---- periodic-phase fused kernel (vp_fused_period.h): the planner's side of its compile-time tap rows ----
+def _period_base(P, Q, r):
+    return ((2 * r + 1) * Q - P) // (2 * P)            # floor: pos = (r + .5) Q / P - .5
+
+
+@pytest.mark.parametrize("method,sw,sh,dw,dh,want", [
+    (4, 1920, 1080, 2560, 1440, (4, 3, 5)),       # up1440: Lanczos3 as Direct3D 11 draws it -> 5 taps
+    (2, 1280, 720, 1920, 1080, (3, 2, 4)),        # 720p -> 1080p Catmull-Rom
+    (4, 3840, 2160, 2560, 1440, (2, 3, 5)),       # down1440: the interpolation shader below 2x
+    (1, 3840, 2160, 1920, 1080, (1, 2, 4)),       # 4K -> 1080p Mitchell at exactly 50 %
+    (3, 2560, 1440, 3840, 2160, (3, 2, 4)),       # 1440p -> 4K Lanczos2
+    (6, 1920, 1080, 2560, 1440, (4, 3, 6)),       # Spline36 extension: six distinct texels
+    (2, 1919, 1080, 2559, 1440, (4, 3, 4)),       # the rows decide: any width rides along
+])
+def test_period_plan_matches_the_tap_tables(mpcvr, method, sw, sh, dw, dh, want):
+    """PlanFusedPeriod: (P, Q, taps) per geometry, and its tables against BuildAxisTaps' — every tap row the kernel hard-codes
+    (6m + base(r) + offset, clamped) is the row the reference's shader arithmetic picks, and the weights are the table's own."""
+    from videorenderer_amd import api
+    pp = api.plan_period(method, sw, sh, dw, dh)
+    assert pp is not None and (pp["P"], pp["Q"], pp["taps"]) == want
+    P, Q, nt = want
+    PB = 6 * P // Q
+    assert pp["rows_per_body"] == PB
+    I, W, _ = api.plan_axis_taps(1, method, 0, sh, dh, sh)
+    n = len(I[0])
+    off = {4: [-1, 0, 1, 2], 5: [-2, -2, 0, 1, 2, 3], 6: [-2, -1, 0, 1, 2, 3]}[nt]
+    for y in range(dh):
+        base = 6 * (y // PB) + _period_base(P, Q, y % PB)
+        assert [min(max(base + o, 0), sh - 1) for o in off] == list(I[y])
+        w = list(W[y])
+        folded = [np.float32(w[0]) + np.float32(w[1])] + w[2:] if nt == 5 else w
+        assert np.array_equal(np.asarray(folded, np.float32), pp["yw"][y, :nt]) and not pp["yw"][y, nt:].any()
+    IX, WX, _ = api.plan_axis_taps(1, method, 0, sw, dw, sw)
+    for x in (0, 1, dw // 2, dw - 1):
+        ix = list(IX[x]); wx = list(WX[x])
+        if nt == 5:
+            ix = [ix[0]] + ix[2:]; wx = [np.float32(wx[0]) + np.float32(wx[1])] + wx[2:]
+        assert ix == list(pp["xi_t"][:, x]) and np.array_equal(np.asarray(wx, np.float32), pp["xw_t"][:, x])
+    for s_ in range(pp["strips"]):
+        cols = IX[128 * s_: 128 * (s_ + 1)]
+        assert pp["xstrip"][s_, 0] == min(min(c) for c in cols) and pp["xstrip"][s_, 1] == max(max(c) for c in cols)
+    assert pp["acols"] % 2 == 0 and pp["acols"] >= max(pp["xstrip"][:, 1] - (pp["xstrip"][:, 0] & ~1)) + 1
+
+
+def test_period_plan_refuses_other_ratios(mpcvr):
+    from videorenderer_amd import api
+    assert api.plan_period(4, 1920, 1080, 3840, 2160) is None        # exact 2x: the 2x kernel's
+    assert api.plan_period(4, 1920, 1080, 2400, 1350) is None        # 5:4
+    assert api.plan_period(2, 1920, 1080, 2560, 1439) is None        # not exactly 4:3 down the rows
+    assert api.plan_period(4, 1920, 1080, 2560, 1440, flags=api.FLAG_LANCZOS3_FIXED)["taps"] == 6

@@ -595,3 +595,130 @@ def test_oracle_under_address_and_ub_sanitizers():
     out = subprocess.run(["make", "-C", here, "sanitize"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "no sanitizer report" in out.stdout
+
+
+# ---- host-side parameter maths pinned to the REFERENCE's own code (oracle/ref_hlsl/ref_hostmath.py -> tests/golden/hostmath_ref.json) ----
+# SetShaderDoviCurves / SetShaderDoviCurvesPoly (DX11VideoProcessor.cpp:990-1141), SetHDR10ShaderParams (:907-923), the level 1 / 3 / 2
+# block of CopySample + SetDolbyVisionDynamicParams (:2326-2469, :953-960), SpecifyExtendedFormat (Helper.cpp:1169-1211) and
+# CopyFrameV210 (:709-748), extracted mechanically from the reference tree and compiled; their outputs are recorded so that the
+# oracle's restatements AND the product's host code are held to them everywhere, and live wherever the library exists.
+with open(os.path.join(HERE, "golden", "hostmath_ref.json")) as _f:
+    HOSTMATH = json.load(_f)
+
+
+def _orc_curve_words(oracle, st):
+    """orc_dovi_pack_curves' result laid out as the reference's PS_DOVI_CURVE[3] (pivots_data[7] as float4.x, coeffs_data[8],
+    mmr_data[48], params) and as PS_DOVI_POLY_CURVE[3] (pivots + coefficients, MMR pieces replaced by the identity {0, 1, 0, 0})."""
+    cb3 = (oracle.OrcDoviCb * 3)()
+    has_mmr = C.c_int(0)
+    oracle.lib().orc_dovi_pack_curves(C.byref(st), cb3, C.byref(has_mmr))
+    full, poly = [], []
+    for c in range(3):
+        cb = cb3[c]
+        piv = np.zeros((7, 4), np.float32); piv[:, 0] = np.array(cb.pivots, np.float32)
+        co = np.array(cb.coeffs, np.float32).reshape(8, 4)
+        mm = np.array(cb.mmr, np.float32).reshape(48, 4)
+        par = np.array([cb.methods, cb.mmr_single, cb.min_order, cb.max_order], np.uint32)
+        full.append(np.concatenate([piv.view(np.uint32).ravel(), co.view(np.uint32).ravel(), mm.view(np.uint32).ravel(), par]))
+        cop = co.copy()
+        for i in range(8):
+            if cop[i, 3] != 0:                      # an MMR piece: "not supported, leave as is" (:1019-1025)
+                cop[i] = (0.0, 1.0, 0.0, 0.0)
+        poly.append(np.concatenate([piv.view(np.uint32).ravel(), cop.view(np.uint32).ravel()]))
+    return np.concatenate(full), np.concatenate(poly), has_mmr.value
+
+
+@pytest.mark.parametrize("name", sorted(HOSTMATH["dovi"]))
+def test_dovi_host_maths_against_reference_code(oracle, mpcvr, name):
+    """Curve packing, level-2 trim selection / interpolation, level-1 (+3) nits: oracle restatement and product (vp_dovi.cpp through
+    mpcvr_plan_dovi) against what the reference's own functions return for the same metadata — bit for bit."""
+    from videorenderer_amd import api, synth
+    rec = HOSTMATH["dovi"][name]
+    md = synth.dovi_metadata(**rec["kw"])
+    st = oracle.fill_dovi(oracle.OrcDovi(), md)
+    full, poly, has_mmr = _orc_curve_words(oracle, st)
+    want_full, want_poly = np.array(rec["curves_words"], np.uint32), np.array(rec["curves_poly_words"], np.uint32)
+    # coefficient slots behind the curve's last piece are never read (the pivots stop the search): compare what the shader can reach
+    assert full.shape == want_full.shape and poly.shape == want_poly.shape
+    assert np.array_equal(full, want_full), f"{name}: orc_dovi_pack_curves differs from SetShaderDoviCurves in {int((full != want_full).sum())} words"
+    assert np.array_equal(poly, want_poly), f"{name}: polynomial packing differs from SetShaderDoviCurvesPoly"
+    for disp, lv in rec["levels"].items():
+        k5 = (C.c_float * 5)()
+        en = oracle.lib().orc_dovi_l2_constants(C.byref(st), int(disp), k5)
+        l1 = (C.c_uint32 * 3)()
+        l1p = oracle.lib().orc_dovi_l1_nits(C.byref(st), l1)
+        assert en == lv["enabled"] and l1p == lv["l1_present"], (name, disp)
+        if en:
+            assert [int(np.float32(x).view(np.uint32)) for x in k5] == lv["k5_bits"], (name, disp, list(k5), lv["k5"])
+        if l1p:
+            assert [int(x) for x in l1] == lv["l1"], (name, disp)
+        pd = api.plan_dovi(md, int(disp))
+        assert pd["l2_enabled"] == lv["enabled"] and pd["l1_present"] == lv["l1_present"]
+        if lv["enabled"]:
+            assert [int(x) for x in pd["l2k"].view(np.uint32)] == lv["k5_bits"], (name, disp, "product")
+        if lv["l1_present"]:
+            assert [int(x) for x in pd["l1_nits"]] == lv["l1"], (name, disp, "product")
+    # the product's cbuffer: 3 x (pivots[7], coeffs[8][4], mmr[48][4], params as floats)
+    pd = api.plan_dovi(md, 1000)
+    for c in range(3):
+        row = pd["cb"][c]
+        ref = want_full[c * 256:(c + 1) * 256]
+        assert np.array_equal(row[:7].view(np.uint32), ref[0:28:4])
+        assert np.array_equal(row[7:39].view(np.uint32), ref[28:60]) and np.array_equal(row[39:231].view(np.uint32), ref[60:252])
+        assert [int(v) for v in row[231:235]] == [int(v) for v in ref[252:256]]
+
+
+def test_hdr10_params_against_reference_code(oracle, mpcvr):
+    from videorenderer_amd import api
+    for rec in HOSTMATH["hdr10"]:
+        a = rec["args"]
+        out = (C.c_uint32 * 6)()
+        oracle.lib().orc_hdr10_params(*a[:5], int(a[5]), out)
+        assert list(out) == rec["words"], (a, list(out))
+        out2 = (C.c_uint32 * 6)()
+        assert api.load_library().mpcvr_plan_hdr10_params(*a[:5], int(a[5]), out2) == 0
+        assert list(out2) == rec["words"], (a, "product")
+
+
+def test_specify_extended_format_against_reference_code(oracle, mpcvr):
+    from videorenderer_amd import api
+    for rec in HOSTMATH["extfmt"]:
+        got = oracle.lib().orc_specify_extfmt(rec["exfmt"], rec["cformat"], rec["w"], rec["h"])
+        assert got == rec["out"], (rec, hex(got))
+        _, ex = api.plan_color_matrix(rec["cformat"], rec["w"], rec["h"], extfmt=rec["exfmt"])
+        assert ex == rec["out"], (rec, hex(ex), "product")
+
+
+def test_copy_frame_v210_against_reference_code(oracle):
+    import hashlib
+    from tests.golden.make_hostmath_golden import v210_sample
+    for rec in HOSTMATH["v210"]:
+        src, pitch = v210_sample(rec["width"], rec["lines"])
+        assert pitch == rec["pitch"]
+        tp = oracle.lib().orc_v210_tex_pitch(rec["width"])
+        assert tp == rec["tex_pitch"]
+        dst = np.zeros(tp * rec["lines"] + 16, np.uint8)
+        oracle.lib().orc_repack_v210(C.c_int(rec["lines"]), C.c_void_p(dst.ctypes.data), C.c_int(tp), C.c_void_p(src.ctypes.data), C.c_int(pitch))
+        assert hashlib.sha256(dst[:tp * rec["lines"]].tobytes()).hexdigest() == rec["sha256"], rec
+
+
+def test_hostmath_fixture_is_what_the_reference_code_returns_live():
+    """Where oracle/_ref/libref_hostmath.so exists (or can be built from the mounted reference): the recorded fixture is regenerated
+    in memory and must be identical — so the pins above are the reference code's, not a stale file."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle", "ref_hlsl"))
+    import ref_hostmath
+    if ref_hostmath.lib() is None:
+        pytest.skip("oracle/_ref/libref_hostmath.so not built (no /root/reference here)")
+    from tests.golden import make_hostmath_golden as G
+    L = ref_hostmath.lib()
+    for name, kw in G.DOVI_CASES.items():
+        st = G.dovi_struct(kw)
+        assert [int(x) for x in G.ref_curves(L, st, False)] == HOSTMATH["dovi"][name]["curves_words"]
+        assert [int(x) for x in G.ref_curves(L, st, True)] == HOSTMATH["dovi"][name]["curves_poly_words"]
+        for d in G.DISPLAYS:
+            assert G.ref_levels(L, st, d) == HOSTMATH["dovi"][name]["levels"][str(d)]
+    for rec in HOSTMATH["hdr10"]:
+        out = (C.c_uint32 * 6)()
+        L.ref_hdr10_params(*rec["args"][:5], int(rec["args"][5]), out)
+        assert list(out) == rec["words"]

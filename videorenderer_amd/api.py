@@ -42,6 +42,7 @@ UPSCALE_Spline36_EXT = 6          # extension: not a reference setting (IVideoRe
 DOWNSCALE_Box, DOWNSCALE_Bilinear, DOWNSCALE_Hamming, DOWNSCALE_Bicubic, DOWNSCALE_BicubicSharp, DOWNSCALE_Lanczos = range(6)
 OUT_BGRA8, OUT_RGB10A2 = 0, 1
 FLAG_LANCZOS3_FIXED, FLAG_NO_FUSED, FLAG_NO_LUT, FLAG_NO_FAST_CONVERT, FLAG_FUSED_VALU, FLAG_FUSED_MFMA, FLAG_NO_STRIP = 1, 2, 4, 8, 16, 32, 64
+FLAG_NO_PERIOD = 128
 MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2
 PROCAMP_BRIGHTNESS, PROCAMP_CONTRAST, PROCAMP_HUE, PROCAMP_SATURATION = 1, 2, 4, 8
 
@@ -157,7 +158,7 @@ EXPORTS = [
     "mpcvr_get_last_process_ms",
     "mpcvr_plan_frame_layout", "mpcvr_plan_color_matrix", "mpcvr_plan_gamut_2020_to_709", "mpcvr_plan_pq_lut",
     "mpcvr_plan_upscale_weights", "mpcvr_plan_axis_taps", "mpcvr_plan_describe", "mpcvr_plan_final_pass_multiplier",
-    "mpcvr_plan_strip", "mpcvr_plan_pq_eotf_lut",
+    "mpcvr_plan_strip", "mpcvr_plan_pq_eotf_lut", "mpcvr_plan_period", "mpcvr_plan_hdr10_params",
 ]
 
 _lib = None
@@ -228,6 +229,8 @@ def load_library():
         "mpcvr_plan_upscale_weights": [i32, f, P(f)],
         "mpcvr_plan_axis_taps": [i32, i32, i32, i32, i32, i32, u32, i32, P(i32), P(f), P(f), P(i32), P(i32)],
         "mpcvr_plan_strip": [i32, i32, i32, i32, i32, i32, i32, i32, u32, P(i32), P(i32), P(i32), P(i32), P(f), P(i32), P(f)],
+        "mpcvr_plan_hdr10_params": [f, f, f, f, f, i32, P(u32)],
+        "mpcvr_plan_period": [i32, i32, i32, i32, i32, u32, P(i32), P(i32), P(f), P(f), P(i32)],
         "mpcvr_plan_pq_eotf_lut": [P(f)],
         "mpcvr_plan_describe": [P(Settings), i32, i32, i32, P(Rect), i32, i32, C.c_char_p, C.c_size_t],
     }
@@ -353,6 +356,27 @@ def plan_strip(kind_x, method_x, kind_y, method_y, src_w, src_h, out_w, out_h, f
         raise MpcvrError(hr, "mpcvr_plan_strip")
     return dict(taps=nt, px_per_lane=pxl, strip_w=strip_w, ring=ring, acols=acols, strips=strips, lds_per_wave=lds_wave,
                 yrange=yr, xstrip=xs, xi_t=xi, xw_t=xw, yi=yi, yw=yw)
+
+
+def plan_period(method, src_w, src_h, out_w, out_h, flags=0):
+    """PlanFusedPeriod through the C-ABI (no device): the periodic-phase kernel's geometry and tables, or None when the vertical
+    ratio is not one of 4:3 / 3:2 / 2:3 / 1:2 (or the tap rows are not the pattern the kernel hard-codes)."""
+    import numpy as np
+    L = load_library()
+    out6 = (C.c_int32 * 6)()
+    hr = L.mpcvr_plan_period(method, src_w, src_h, out_w, out_h, flags, out6, None, None, None, None)
+    if hr == E_NOTIMPL:
+        return None
+    if hr != 0:
+        raise MpcvrError(hr, "mpcvr_plan_period")
+    Pn, Qn, nt, strips, acols, pb = list(out6)
+    xi = np.zeros((nt, out_w), np.int32); xw = np.zeros((nt, out_w), np.float32)
+    yw = np.zeros((out_h, 8), np.float32); xs = np.zeros((strips, 2), np.int32)
+    as_p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    hr = L.mpcvr_plan_period(method, src_w, src_h, out_w, out_h, flags, out6, as_p(xi, C.c_int32), as_p(xw, C.c_float), as_p(yw, C.c_float), as_p(xs, C.c_int32))
+    if hr != 0:
+        raise MpcvrError(hr, "mpcvr_plan_period")
+    return dict(P=Pn, Q=Qn, taps=nt, strips=strips, acols=acols, rows_per_body=pb, xi_t=xi, xw_t=xw, yw=yw, xstrip=xs)
 
 
 def plan_pq_eotf_lut():

@@ -298,12 +298,7 @@ void CHipVideoProcessor::UpdateHdrToneMapParams()
     }
     k.l2_enabled = (m_doviValid && m_doviL2Present) ? 1 : 0;      // m_pDoViDynamicConstants at b1 (:3362-3364)
     std::memcpy(k.l2k, m_doviL2Raw, sizeof(k.l2k));
-    if (k.min_mastering <= 0.f) k.min_mastering = 0.f;
-    if (k.max_mastering <= 10.f) k.max_mastering = 1000.f;
-    if (k.max_cll <= 10.f) k.max_cll = k.max_mastering;
-    if (k.max_fall <= 1.f) k.max_fall = k.max_cll;
-    if (k.display_max < 100.f || k.display_max > 10000.f) k.display_max = 1000.f;
-    if (k.selection < 1 || k.selection > 6) k.selection = 1;
+    SanitiseHdr10Params(&k);
     m_hdrTm = k;
 }
 
@@ -602,6 +597,7 @@ HRESULT CHipVideoProcessor::UpdatePlan()
     // the arbitrary-ratio fused kernel takes an unrotated two-pass resize whose tables fit it: straight from the raw sample for
     // 4:2:0 sources (m_strip, decided below), else from the convert kernel's output / the RGB source texture (m_stripSurf)
     m_strip = m_stripSurf = m_stripPlanned = false;
+    m_periodPlan.P = 0;
     static const bool no_strip_env = [] { const char *e = std::getenv("MPCVR_NO_STRIP"); return e && *e && *e != '0'; }();
     if (!no_strip_env && m_plan.two_pass && !m_firstJinc && !m_secondJinc && m_firstAxis == 0 && !m_firstSwap && m_plan.rotation == 0 &&
         !m_plan.flip && !(m_cfg.flags & (MPCVR_FLAG_NO_FUSED | MPCVR_FLAG_NO_FAST_CONVERT | MPCVR_FLAG_NO_STRIP)) &&
@@ -621,6 +617,18 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         m_stripOff[3] = put(sp.xw_t.data(), sp.xw_t.size());
         m_stripOff[4] = put(sp.yi.data(), sp.yi.size());
         m_stripOff[5] = put(sp.yw.data(), sp.yw.size());
+        // periodic vertical ratio (1080p -> 1440p, 720p -> 1080p, 4K -> 1440p, 4K -> 1080p ...): the register-window kernel's tables
+        m_periodPlan.P = 0;
+        const bool q1 = m_plan.rx.kind == RS_UP && m_plan.ry.kind == RS_UP && m_cfg.iUpscaling == MPCVR_UPSCALE_Lanczos3 && !(m_cfg.flags & MPCVR_FLAG_LANCZOS3_FIXED);
+        if (m_plan.convert && m_plan.rx.kind == RS_UP && m_plan.ry.kind == RS_UP &&
+            PlanFusedPeriod(hx, hy, w2, h2, w1, m_plan.mid_h, q1, &m_periodPlan)) {
+            const PeriodPlan &pp = m_periodPlan;
+            m_periodOff[0] = put(pp.xi_t.data(), pp.xi_t.size());
+            m_periodOff[1] = put(pp.xw_t.data(), pp.xw_t.size());
+            while (pack.size() & 7) pack.push_back(0);                      // the weight rows (32 bytes each) are read with scalar multi-dword loads
+            m_periodOff[2] = put(pp.yw.data(), pp.yw.size());
+            m_periodOff[3] = put(pp.xstrip.data(), pp.xstrip.size());
+        }
         if ((hr = CheckHip(m_stripTab.CheckCreate(pack.size() * sizeof(int32_t)), "strip tables"))) return hr;
         if ((hr = CheckHip(hipMemcpy(m_stripTab.ptr, pack.data(), pack.size() * sizeof(int32_t), hipMemcpyHostToDevice), "strip tables upload"))) return hr;
         m_stripPlanned = true;
@@ -660,9 +668,11 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         static const bool no_up2x_env = [] { const char *e = std::getenv("MPCVR_NO_UP2X"); return e && *e && *e != '0'; }();
         if (no_up2x_env && m_strip) m_plan.fused_up2x = false;
     }
+    m_period = false;
     if (m_strip) {      // the launch-time conditions that do not depend on the frame pointers
         FusedStripParams sp{};
         m_strip = FillStripParams(nullptr, nullptr, m_windowRect.Width() * 4, MakeStore(nullptr, m_windowRect.Width() * 4, m_plan.swap_fmt, true), &sp);
+        m_period = m_strip && FusedPeriodTakes(sp);
     }
     if (m_stripPlanned && !m_strip) {
         FusedStripParams sp{};
@@ -978,6 +988,11 @@ bool CHipVideoProcessor::FillStripParams(const uint8_t *sample, void *dst, int d
     sp->yi = tab + m_stripOff[4]; sp->yw = tab + m_stripOff[5];
     sp->out_w = m_videoRect.Width(); sp->out_h = m_videoRect.Height();
     sp->nt = m_stripPlan.nt; sp->pxl = m_stripPlan.pxl; sp->strip_w = m_stripPlan.strip_w; sp->ring = m_stripPlan.ring; sp->acols = m_stripPlan.acols;
+    sp->per_P = 0;
+    if (m_periodPlan.P && !(m_cfg.flags & MPCVR_FLAG_NO_PERIOD)) {
+        sp->per_P = m_periodPlan.P; sp->per_Q = m_periodPlan.Q; sp->per_nt = m_periodPlan.nt; sp->per_acols = m_periodPlan.acols;
+        sp->per_xi_t = tab + m_periodOff[0]; sp->per_xw_t = tab + m_periodOff[1]; sp->per_yw = tab + m_periodOff[2]; sp->per_xstrip = tab + m_periodOff[3];
+    }
     return FusedStripSupported(*sp) && FusedStripLdsBytes(*sp) <= 160 * 1024;
 }
 
@@ -1427,6 +1442,8 @@ std::string CHipVideoProcessor::GetPathInfo()
     if (!m_srcParams) return "uninitialised";
     if (m_planDirty && UpdatePlan() != MPCVR_S_OK) return "error: " + m_lastError;
     if ((!m_strip && !m_stripSurf) || m_plan.fused_up2x) return m_plan.describe();
+    if (m_strip && m_period)
+        return m_plan.describe() + ";kernel=fused_period(rows=" + std::to_string(m_periodPlan.P) + ":" + std::to_string(m_periodPlan.Q) + ",taps=" + std::to_string(m_periodPlan.nt) + ",px_per_lane=2,strip=128,window=6 rows in registers)";
     return m_plan.describe() + (m_strip ? ";kernel=fused_strip(taps=" : ";kernel=fused_strip:surface(taps=") + std::to_string(m_stripPlan.nt) + ",px_per_lane=" + std::to_string(m_stripPlan.pxl) +
            ",strip=" + std::to_string(m_stripPlan.strip_w) + ",ring=" + std::to_string(m_stripPlan.ring) + ")";
 }

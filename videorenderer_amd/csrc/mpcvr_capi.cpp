@@ -315,6 +315,37 @@ int32_t mpcvr_plan_strip(int32_t kind_x, int32_t method_x, int32_t kind_y, int32
     return MPCVR_S_OK;
 }
 
+int32_t mpcvr_plan_period(int32_t method, int32_t src_w, int32_t src_h, int32_t out_w, int32_t out_h, uint32_t flags,
+                          int32_t out6[6], int32_t *xi_t, float *xw_t, float *yw, int32_t *xstrip)
+{
+    if (!out6) return MPCVR_E_POINTER;
+    if (src_w <= 0 || src_h <= 0 || out_w <= 0 || out_h <= 0) return MPCVR_E_INVALIDARG;
+    mpcvr::HostAxisTaps hx, hy;
+    if (!mpcvr::BuildAxisTaps(mpcvr::Resizer{mpcvr::RS_UP, method}, 0, src_w, out_w, src_w, flags, &hx)) return MPCVR_E_NOTIMPL;
+    if (!mpcvr::BuildAxisTaps(mpcvr::Resizer{mpcvr::RS_UP, method}, 0, src_h, out_h, src_h, flags, &hy)) return MPCVR_E_NOTIMPL;
+    const bool q1 = method == MPCVR_UPSCALE_Lanczos3 && !(flags & MPCVR_FLAG_LANCZOS3_FIXED);
+    mpcvr::PeriodPlan pp;
+    if (!mpcvr::PlanFusedPeriod(hx, hy, out_w, out_h, src_w, src_h, q1, &pp)) return MPCVR_E_NOTIMPL;
+    const int32_t o[6] = {pp.P, pp.Q, pp.nt, (out_w + 127) / 128, pp.acols, 6 * pp.P / pp.Q};
+    std::memcpy(out6, o, sizeof(o));
+    if (xi_t) std::memcpy(xi_t, pp.xi_t.data(), pp.xi_t.size() * sizeof(int32_t));
+    if (xw_t) std::memcpy(xw_t, pp.xw_t.data(), pp.xw_t.size() * sizeof(float));
+    if (yw) std::memcpy(yw, pp.yw.data(), pp.yw.size() * sizeof(float));
+    if (xstrip) std::memcpy(xstrip, pp.xstrip.data(), pp.xstrip.size() * sizeof(int32_t));
+    return MPCVR_S_OK;
+}
+
+int32_t mpcvr_plan_hdr10_params(float min_mastering, float max_mastering, float max_cll, float max_fall, float display_max,
+                                int32_t selection, uint32_t out6[6])
+{
+    if (!out6) return MPCVR_E_POINTER;
+    mpcvr::HdrToneMapParams k{min_mastering, max_mastering, max_cll, max_fall, display_max, selection};
+    mpcvr::SanitiseHdr10Params(&k);
+    std::memcpy(out6, &k, 20);
+    out6[5] = (uint32_t)k.selection;
+    return MPCVR_S_OK;
+}
+
 int32_t mpcvr_plan_pq_eotf_lut(float out4096[4096])
 {
     if (!out4096) return MPCVR_E_POINTER;

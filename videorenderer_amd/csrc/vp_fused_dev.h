@@ -901,6 +901,10 @@ int FusedDoviKind(const FusedParams &P);          // DV_* for the launch
 // vp_fused_mx.hip: the same launch as LaunchFusedUp2x with the resize taps on the matrix cores; hipErrorNotSupported when the
 // variant does not cover the configuration (the caller then launches the packed-fp32 kernel)
 hipError_t LaunchFusedUp2xMx(const FusedParams &P, const FusedArgs &a, int knt, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
+// dynamic LDS above the default limit needs the function attribute once per kernel (and device); remembered per (kernel, device) (vp_fused_strip.hip)
+hipError_t AllowLargeLds(const void *kern, size_t lds);
+// vp_fused_period.hip: the periodic-phase kernel for this strip launch, or hipErrorNotSupported (LaunchFusedStrip then runs k_fused_strip)
+hipError_t LaunchFusedPeriod(const FusedStripParams &S, const FusedArgs &a, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
 // vp_fused_up2x.h, instantiated by vp_fused_up2x_nt{4,5,6}.hip: the packed-fp32 kernel for one tap count
 template <int NT>
 hipError_t LaunchFusedUp2xNT(const FusedParams &P, const FusedArgs &a, int strips, int seg, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);

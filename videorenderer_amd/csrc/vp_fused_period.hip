@@ -1,0 +1,92 @@
+// vp_fused_period.hip — host side of the periodic-phase fused kernel (vp_fused_period.h): preconditions, work decomposition,
+// dispatch to the per-ratio translation units (vp_fused_period_{4_3,3_2,2_3,1_2}.hip hold the kernels).
+#include "vp_fused_period.h"
+
+namespace mpcvr {
+
+extern template hipError_t LaunchFusedPeriodPQ<4, 3>(const FusedArgs &, const PeriodArgs &, int, int, int, int, dim3, dim3, size_t, const FusedFrame *, FusedFrame, hipStream_t);
+extern template hipError_t LaunchFusedPeriodPQ<3, 2>(const FusedArgs &, const PeriodArgs &, int, int, int, int, dim3, dim3, size_t, const FusedFrame *, FusedFrame, hipStream_t);
+extern template hipError_t LaunchFusedPeriodPQ<2, 3>(const FusedArgs &, const PeriodArgs &, int, int, int, int, dim3, dim3, size_t, const FusedFrame *, FusedFrame, hipStream_t);
+extern template hipError_t LaunchFusedPeriodPQ<1, 2>(const FusedArgs &, const PeriodArgs &, int, int, int, int, dim3, dim3, size_t, const FusedFrame *, FusedFrame, hipStream_t);
+
+namespace {
+
+// which epilogue the launch would run: EPI_DITHER8 (10-bit internal -> final pass -> B8G8R8A8), EPI_DIRECT8 (straight UNORM store), or
+// -1 (window clipping, odd alignment, RGB10A2 behind a final pass ...: k_fused_strip's generic epilogue serves those)
+int PeriodEpilogue(const FusedStripParams &S, uint32_t epi_mul)
+{
+    const FusedParams &P = S.fp;
+    const StoreParams &st = P.store;
+    const bool inside = st.off_x >= 0 && st.off_y >= 0 && (st.clip_w <= 0 || (st.off_x + S.out_w <= st.clip_w && st.off_y + S.out_h <= st.clip_h));
+    // one 8-byte store and one 8-byte dither read per lane and row: even window column, 8-byte aligned rows and targets
+    if (!inside || (st.off_x & 1) || (st.dst_pitch & 7) || !P.dst_aligned16) return -1;
+    if (st.mode == ST_FINAL && st.dst_fmt == SF_BGRA8 && st.quant == 255 && epi_mul != 0 && P.conv.out_fmt == SF_RGB10A2 && st.mid_fmt == SF_RGB10A2) return EPI_DITHER8;
+    if (st.mode == ST_SURFACE && (st.dst_fmt == SF_BGRA8 || st.dst_fmt == SF_RGB10A2) && st.dst_fmt == P.conv.out_fmt) return EPI_DIRECT8;
+    return -1;
+}
+
+size_t PeriodLds(const FusedStripParams &S, bool fastepi, bool lut, int waves)
+{
+    return (fastepi ? LDS_DB : 0) + (lut ? LDS_T : 0) + (size_t)waves * (size_t)S.per_acols * 24;
+}
+
+}  // namespace
+
+bool FusedPeriodTakes(const FusedStripParams &S)
+{
+    if (!S.per_P || S.surface_mode || !S.per_xi_t || !S.per_xw_t || !S.per_yw || !S.per_xstrip) return false;
+    static const int off = EnvInt("MPCVR_NO_PERIOD", 0);
+    if (off) return false;
+    const FusedParams &P = S.fp;
+    const int tailk = FusedTailKind(P);
+    if (tailk == TAILK_ALU) return false;                         // the literal tails stay with k_fused_strip
+    if (S.per_nt < 4 || S.per_nt > 6 || S.per_acols < 2 || (S.per_acols & 1)) return false;
+    const uint32_t epi_mul = FinalPassMultiplier(P.store.quant, P.conv.out_fmt == SF_RGB10A2 ? 1023 : 255);
+    const int epik = PeriodEpilogue(S, epi_mul);
+    if (epik < 0) return false;
+    return PeriodLds(S, epik == EPI_DITHER8, tail_has_table(tailk), 1) <= 160 * 1024;
+}
+
+// the same launch contract as LaunchFusedStrip (which calls this first); hipErrorNotSupported = not this kernel's case
+hipError_t LaunchFusedPeriod(const FusedStripParams &S, const FusedArgs &a, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s)
+{
+    if (!FusedPeriodTakes(S)) return hipErrorNotSupported;
+    const FusedParams &P = S.fp;
+    const int tailk = FusedTailKind(P), srck0 = FusedSourceKind(P);
+    const int epik = PeriodEpilogue(S, a.epi_mul);
+    // built source specialisations: P01x and NV12; everything else reads its layout at run time
+    const int srck = (srck0 == SRC_P01X || (srck0 == SRC_NV12 && epik == EPI_DIRECT8)) ? srck0 : SRC_GENERIC;
+    const int PB = 6 * S.per_P / S.per_Q;
+    PeriodArgs q{};
+    q.xi_t = (const int32_t *)S.per_xi_t; q.xw_t = (const float *)S.per_xw_t; q.yw = (const float *)S.per_yw; q.xstrip = (const int32_t *)S.per_xstrip;
+    q.out_w = S.out_w; q.out_h = S.out_h;
+    q.n_strips = (S.out_w + kPeriodStripW - 1) / kPeriodStripW;
+    q.acols = S.per_acols;
+    // segment height (a multiple of the body's PB output rows): long segments recompute less (the taps' span each), short ones fill the chip
+    static const int seg_env = EnvInt("MPCVR_PERIOD_SEG", 0);
+    int seg = seg_env;
+    if (seg <= 0) {
+        seg = 2 * PB;
+        for (int cand : {24, 16, 12, 8, 6, 4, 3, 2})
+            if ((long)q.n_strips * ((S.out_h + cand * PB - 1) / (cand * PB)) * n_frames >= 12288 || cand == 2) { seg = cand * PB; break; }
+    }
+    seg = std::max(PB, (seg / PB) * PB);
+    q.seg_rows = seg;
+    const int n_segs = (S.out_h + seg - 1) / seg;
+    const bool fastepi = epik == EPI_DITHER8, lut = tail_has_table(tailk);
+    static const int waves_env = EnvInt("MPCVR_PERIOD_WAVES", 0);
+    int waves = kPeriodMaxThreads / 64;
+    if (waves_env >= 1 && waves_env <= kPeriodMaxThreads / 64) waves = waves_env;
+    while (waves > 1 && PeriodLds(S, fastepi, lut, waves) > 160 * 1024) waves--;
+    const long items = (long)q.n_strips * n_segs * n_frames;
+    if (items < 512L * waves) waves = (int)std::max<long>(1, std::min<long>(waves, items / 512));
+    const size_t lds = PeriodLds(S, fastepi, lut, waves);
+    const dim3 grid((q.n_strips * n_segs + waves - 1) / waves, 1, n_frames), block(64 * waves, 1, 1);
+    if (S.per_P == 4 && S.per_Q == 3) return LaunchFusedPeriodPQ<4, 3>(a, q, S.per_nt, tailk, srck, epik, grid, block, lds, frames_dev, single, s);
+    if (S.per_P == 3 && S.per_Q == 2) return LaunchFusedPeriodPQ<3, 2>(a, q, S.per_nt, tailk, srck, epik, grid, block, lds, frames_dev, single, s);
+    if (S.per_P == 2 && S.per_Q == 3) return LaunchFusedPeriodPQ<2, 3>(a, q, S.per_nt, tailk, srck, epik, grid, block, lds, frames_dev, single, s);
+    if (S.per_P == 1 && S.per_Q == 2) return LaunchFusedPeriodPQ<1, 2>(a, q, S.per_nt, tailk, srck, epik, grid, block, lds, frames_dev, single, s);
+    return hipErrorNotSupported;
+}
+
+}  // namespace mpcvr

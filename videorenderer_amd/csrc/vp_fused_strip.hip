@@ -479,7 +479,7 @@ static int StripWaves(const FusedStripParams &S, bool fastepi, bool lut)
 }
 
 // dynamic LDS above the default limit needs the function attribute once per kernel (and device); remembered per (kernel, device)
-static hipError_t AllowLargeLds(const void *kern, size_t lds)
+hipError_t AllowLargeLds(const void *kern, size_t lds)
 {
     static std::mutex mu;
     static std::map<std::pair<const void *, int>, size_t> granted;
@@ -511,6 +511,10 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
         a.dither = P.store.dither;
         a.H = S.mid_h; a.W = S.surf.w;
     } else FillFusedArgs(P, a);
+    if (S.per_P && !S.surface_mode) {       // a periodic vertical ratio: the register-window kernel when the launch meets its preconditions
+        const hipError_t ep = LaunchFusedPeriod(S, a, frames_dev, single, n_frames, s);
+        if (ep != hipErrorNotSupported) return ep;
+    }
     StripArgs q{};
     q.xi_t = (const int32_t *)S.xi_t; q.xw_t = (const float *)S.xw_t;
     q.yi = (const int32_t *)S.yi; q.yw = (const float *)S.yw;

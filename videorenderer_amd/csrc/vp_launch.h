@@ -100,9 +100,15 @@ struct FusedStripParams {
     int mid_h;
     size_t surf_stride;
     int surface_mode;
+    // periodic-phase variant (vp_fused_period.h; per_P != 0): device copies of PlanFusedPeriod's tables.  LaunchFusedStrip takes it
+    // whenever the launch meets its preconditions (fast epilogue, 8-byte aligned rows) and falls back to k_fused_strip otherwise.
+    int per_P, per_Q, per_nt, per_acols;
+    const void *per_xi_t, *per_xw_t, *per_yw, *per_xstrip;
 };
 bool FusedStripSupported(const FusedStripParams &S);
 hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
 size_t FusedStripLdsBytes(const FusedStripParams &S);
+// true when LaunchFusedStrip would run the periodic-phase kernel for this launch (GetVPInfo reports it)
+bool FusedPeriodTakes(const FusedStripParams &S);
 
 }  // namespace mpcvr

@@ -302,6 +302,16 @@ void SelectTail(const ExtFmt &ex, bool convert_to_sdr, int *tail, float *gamma, 
 // ------------------------------------------------------------------------------------------------
 // PQ -> SDR per-channel table (Shaders/convert/st2084.hlsl:1-16, hdr_tone_mapping.hlsl:1-13)
 // ------------------------------------------------------------------------------------------------
+void SanitiseHdr10Params(HdrToneMapParams *k)
+{
+    if (k->min_mastering <= 0.f) k->min_mastering = 0.f;
+    if (k->max_mastering <= 10.f) k->max_mastering = 1000.f;
+    if (k->max_cll <= 10.f) k->max_cll = k->max_mastering;
+    if (k->max_fall <= 1.f) k->max_fall = k->max_cll;
+    if (k->display_max < 100.f || k->display_max > 10000.f) k->display_max = 1000.f;
+    if (k->selection < 1 || k->selection > 6) k->selection = 1;
+}
+
 uint32_t FinalPassMultiplier(int quant, int maxv)
 {
     if (quant <= 0 || maxv <= 0) return 0;
@@ -619,6 +629,77 @@ bool PlanFusedStrip(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x,
             sp->yw[(size_t)y * nt + k] = on ? (hy.normalise ? hy.w[(size_t)y * hy.ntaps + k] / ww : hy.w[(size_t)y * hy.ntaps + k]) : 0.0f;
         }
     }
+    return true;
+}
+
+// Vertical phase pattern of the periodic-phase kernel: output row y = PB*m + r reads source rows 6m + base(r) + off(t), PB = 6P/Q
+// (the same integer arithmetic as vp_fused_period.h's period_base; checked against the real table below, so a disagreement can
+// only cost the fast path, never a wrong pixel)
+static int PeriodBase(int P, int Q, int r)
+{
+    const int num = (2 * r + 1) * Q - P, den = 2 * P;
+    return num >= 0 ? num / den : -((-num + den - 1) / den);
+}
+
+bool PlanFusedPeriod(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x, int n_out_y, int src_w, int src_h, bool fold_q1, PeriodPlan *pp)
+{
+    pp->P = pp->Q = 0;
+    if (hx.normalise || hy.normalise) return false;                       // interpolation shaders only (ps_convolution normalises)
+    if ((hy.ntaps != 4 && hy.ntaps != 6) || hx.ntaps != hy.ntaps) return false;
+    if (n_out_x < 2 || n_out_y < 1 || hx.idx.size() != (size_t)n_out_x * hx.ntaps || hy.idx.size() != (size_t)n_out_y * hy.ntaps) return false;
+    static const int ratios[][2] = {{4, 3}, {3, 2}, {2, 3}, {1, 2}};
+    int P = 0, Q = 0;
+    for (const auto &r : ratios)
+        if ((long)n_out_y * r[1] == (long)src_h * r[0]) { P = r[0]; Q = r[1]; }
+    if (!P) return false;
+    const int nth = hy.ntaps;
+    if (fold_q1 && nth != 6) return false;
+    // tap offsets of the table's columns relative to base: {-1..2}, {-2..3}, or Direct3D 11 Lanczos3's {-2, -2, 0, 1, 2, 3}
+    static const int off4[4] = {-1, 0, 1, 2}, off6[6] = {-2, -1, 0, 1, 2, 3}, off6q[6] = {-2, -2, 0, 1, 2, 3};
+    const int *off = nth == 4 ? off4 : fold_q1 ? off6q : off6;
+    const int PB = 6 * P / Q;
+    for (int y = 0; y < n_out_y; y++) {
+        const int m = y / PB, r = y % PB, base = 6 * m + PeriodBase(P, Q, r);
+        for (int k = 0; k < nth; k++)
+            if (hy.idx[(size_t)y * nth + k] != ClampI(base + off[k], 0, src_h - 1)) return false;
+    }
+    if (fold_q1)
+        for (int x = 0; x < n_out_x; x++)
+            if (hx.idx[(size_t)x * 6] != hx.idx[(size_t)x * 6 + 1]) return false;
+    const int nt = fold_q1 ? 5 : nth;
+    pp->nt = nt;
+    // the tables as the kernel reads them
+    pp->xi_t.assign((size_t)nt * n_out_x, 0); pp->xw_t.assign((size_t)nt * n_out_x, 0.0f);
+    for (int x = 0; x < n_out_x; x++)
+        for (int k = 0; k < nt; k++) {
+            const int ks = fold_q1 && k > 0 ? k + 1 : k;
+            pp->xi_t[(size_t)k * n_out_x + x] = hx.idx[(size_t)x * nth + ks];
+            pp->xw_t[(size_t)k * n_out_x + x] = (fold_q1 && k == 0) ? hx.w[(size_t)x * nth] + hx.w[(size_t)x * nth + 1] : hx.w[(size_t)x * nth + ks];
+        }
+    pp->yw.assign((size_t)n_out_y * 8, 0.0f);
+    for (int y = 0; y < n_out_y; y++)
+        for (int k = 0; k < nt; k++) {
+            const int ks = fold_q1 && k > 0 ? k + 1 : k;
+            pp->yw[(size_t)y * 8 + k] = (fold_q1 && k == 0) ? hy.w[(size_t)y * nth] + hy.w[(size_t)y * nth + 1] : hy.w[(size_t)y * nth + ks];
+        }
+    const int sw = 128;
+    const int n_strips = (n_out_x + sw - 1) / sw;
+    pp->xstrip.resize(2 * (size_t)n_strips);
+    int max_cols = 0;
+    for (int s = 0; s < n_strips; s++) {
+        const int x0 = s * sw, x1 = std::min(n_out_x, x0 + sw);
+        int lo = src_w, hi = -1;
+        for (int x = x0; x < x1; x++)
+            for (int k = 0; k < nth; k++) {
+                const int i = hx.idx[(size_t)x * nth + k];
+                if (i < 0 || i >= src_w) return false;
+                lo = std::min(lo, i); hi = std::max(hi, i);
+            }
+        pp->xstrip[2 * s] = lo; pp->xstrip[2 * s + 1] = hi;
+        max_cols = std::max(max_cols, (((hi - (lo & ~1)) >> 1) + 1) * 2);
+    }
+    pp->acols = max_cols;
+    pp->P = P; pp->Q = Q;
     return true;
 }
 

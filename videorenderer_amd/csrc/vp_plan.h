@@ -88,6 +88,8 @@ void BuildPqEotfLut(float out[kPqLutSize]);
 // k in [0,maxv], j in [0,1023] with M = ceil(quant * 2^24 / maxv).  Returns M, or 0 when the 32-bit evaluation could
 // overflow / M does not fit 24 bits (then the kernel keeps the float epilogue).
 uint32_t FinalPassMultiplier(int quant, int maxv);
+// SetHDR10ShaderParams (DX11VideoProcessor.cpp:911-916): the defaults and clamps in front of HDRParamsConstantBuffer_t
+void SanitiseHdr10Params(HdrToneMapParams *k);
 
 // ---- resize ----
 enum ResizerKind { RS_NONE = 0, RS_UP = 1, RS_DOWN = 2 };
@@ -130,6 +132,21 @@ struct StripPlan {
 };
 // false: the tables do not fit the kernel (more than 8 taps, a vertical span above 15 rows, non-monotonic tables)
 bool PlanFusedStrip(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x, int n_out_y, int src_w, int src_h, StripPlan *sp);
+
+// ---- periodic-phase fused kernel (vp_fused_period.h): vertical ratio out : in = P : Q with compile-time tap rows ----
+struct PeriodPlan {
+    int P = 0, Q = 0;            // output rows : source rows (4:3, 3:2, 2:3, 1:2); 0 = the tables do not fit the kernel
+    int nt = 0;                  // taps per output on both axes as the kernel runs them: 4, 5 (Lanczos3's shared texel folded) or 6
+    int acols = 0;               // columns of a converted source row the widest strip needs (even)
+    std::vector<int32_t> xstrip; // [2 * n_strips] {lo, hi} source column per strip of 128 output columns
+    std::vector<int32_t> xi_t;   // [nt][n_out_x] tap-major
+    std::vector<float> xw_t;
+    std::vector<float> yw;       // [n_out_y][8]: nt weights, zero padding
+};
+// The kernel's tap ROWS are compile-time (base(r) + 6m, vp_fused_period.h): the plan succeeds only when hy's index table is exactly that
+// pattern (clamped to the texture) for one of the supported ratios; hx may be any 4- or 6-tap table.  fold_q1: both tables are
+// Direct3D 11 Lanczos3 tables whose taps 0 and 1 read the same texel (ps_interpolation_lanczos3.hlsl:33-34) — folded to 5 taps.
+bool PlanFusedPeriod(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x, int n_out_y, int src_w, int src_h, bool fold_q1, PeriodPlan *pp);
 
 // ---- the pass plan of one Process() (DX11VideoProcessor.cpp:3285-3424, shader path) ----
 struct PassPlan {
