@@ -355,7 +355,9 @@ def main():
                 vp.Process(dsts[i % ring], dw * 4)
             vp.Synchronize()
             res_h[label] = nf / (time.perf_counter() - th)
+            res_h[label + "_timings"] = {k: round(v, 4) for k, v in vp.GetLastTimings().items()}
         host_path = {"frames_per_s_pinned_host_sample": round(res_h["pinned"], 1),
+                     "last_frame_timings_ms_pinned": res_h["pinned_timings"], "last_frame_timings_ms_pageable": res_h["pageable_timings"],
                      "frames_per_s_pageable_host_sample": round(res_h["pageable"], 1),
                      "upload_GBps_pinned": round(res_h["pinned"] * nbytes / 1e9, 2),
                      "note": "mpcvr_copy_sample(host) + mpcvr_process per frame; the output stays in HBM (the reference "

@@ -80,9 +80,11 @@ enum { MPCVR_OUT_BGRA8 = 0, MPCVR_OUT_RGB10A2 = 1 };
 
 #define MPCVR_FLAG_FUSED_VALU       0x10u /* fused 2x kernel with its resize taps as packed-fp32 VALU chains (k_fused_up2x) */
 #define MPCVR_FLAG_FUSED_MFMA       0x20u /* fused 2x kernel with its resize taps on the matrix cores (k_fused_up2x_mx); neither flag:
-                                             the library's default (environment MPCVR_FUSED_MX=0/1 overrides it) */
+                                             the packed-fp32 VALU kernel, unless the environment says MPCVR_FUSED_MX=1 */
 #define MPCVR_FLAG_NO_STRIP         0x40u /* arbitrary-ratio resizes of 4:2:0 sources stay on the block convert + tiled two-draw
                                              kernels instead of the one-kernel strip path (k_fused_strip; debug / A-B) */
+#define MPCVR_FLAG_FORCE_PERIOD     0x100u /* take k_fused_period wherever it is built, also where the planner prefers k_fused_strip (SDR content with a
+                                              4-tap filter: measured a few % faster there; debug / A-B, and how the suite reaches those instantiations) */
 #define MPCVR_FLAG_NO_PERIOD        0x80u /* rational vertical ratios (4:3, 3:2, 2:3, 1:2) through k_fused_strip's run-time tap tables instead
                                              of the periodic-phase kernel with its register window (k_fused_period; debug / A-B) */
 
@@ -284,6 +286,11 @@ const char *mpcvr_version(void);
 /* Timing of the last process/render on the context stream (hipEvent pair), milliseconds.
  * Mirrors m_RenderStats.paintticks (DX11VideoProcessor.cpp:2790).  Synchronises the stream. */
 int32_t mpcvr_get_last_process_ms(mpcvr_ctx *ctx, float *ms);
+/* The renderer's other per-frame timers (FrameStats.h:145-173): copy_host_ms = wall time the last mpcvr_copy_sample spent on the host
+ * (copyticks, DX11VideoProcessor.cpp:2594), upload_ms = its host-to-device transfer on the copy stream (hipEvent pair; absent for
+ * device samples), process_ms = mpcvr_get_last_process_ms, readback_ms = the device-to-host copy of the last mpcvr_get_current_image.
+ * -1 where nothing of the kind has been timed yet; any pointer may be NULL.  Synchronises the events it reads. */
+int32_t mpcvr_get_last_timings(mpcvr_ctx *ctx, float *copy_host_ms, float *upload_ms, float *process_ms, float *readback_ms);
 
 /* ---- host-side parameter maths, usable without a context or a GPU --------------------------------
  * The CPU work the reference does before touching the device.  Each mirrors a reference host function. */
@@ -328,11 +335,11 @@ int32_t mpcvr_plan_strip(int32_t kind_x, int32_t method_x, int32_t kind_y, int32
 /* Geometry of the periodic-phase fused kernel (k_fused_period) for an unrotated two-pass UPSCALE-shader resize (`method` =
  * MPCVR_UPSCALE_*; also what a downscale of at most 2x takes with bInterpolateAt50pct, DX11VideoProcessor.cpp:3108):
  * out6 = {P, Q (output : source rows), taps per output as the kernel runs them (4 / 5 = Lanczos3 with its shared texel folded /
- * 6), strips of 128 output columns, columns of a converted source row, output rows per body of six source rows}.
+ * 6), strips of *strip_w output columns (the width that fills the convert passes best, <= 128), columns of a converted source row, output rows per body of six source rows}.
  * xi_t / xw_t: [taps][out_w]; yw: [out_h][8]; xstrip: [strips][2]; any may be NULL.  MPCVR_E_NOTIMPL: the vertical ratio is not
  * 4:3 / 3:2 / 2:3 / 1:2 or the table's tap rows are not the periodic pattern the kernel hard-codes. */
 int32_t mpcvr_plan_period(int32_t method, int32_t src_w, int32_t src_h, int32_t out_w, int32_t out_h, uint32_t flags,
-                          int32_t out6[6], int32_t *xi_t, float *xw_t, float *yw, int32_t *xstrip);
+                          int32_t out6[6], int32_t *xi_t, float *xw_t, float *yw, int32_t *xstrip, int32_t *strip_w);
 /* HDRParamsConstantBuffer_t as SetHDR10ShaderParams fills it (DX11VideoProcessor.cpp:907-923: defaults and clamps of the HDR10
  * metadata, the display's peak and the tone-mapping operator): five floats + the selection as words */
 int32_t mpcvr_plan_hdr10_params(float min_mastering, float max_mastering, float max_cll, float max_fall, float display_max,

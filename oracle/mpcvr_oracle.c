@@ -28,7 +28,33 @@
 static inline int   clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 static inline float saturatef(float x) { return (x != x) ? 0.0f : (x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x)); }
 /* HLSL pow: exp2(y*log2(x)) (d3dcompiler lowers pow to log/mul/exp). */
-static inline float hlsl_pow(float x, float y) { return exp2f(y * log2f(x)); }
+/* Sensitivity probe (tests only, orc_set_pow_ulp_bias): every pow() of the chain answers `bias` units in the last place off.
+ * Direct3D's pow is exp2(y * log2(x)) with approximate log2 / exp2 — with 1-ulp building blocks the result is off by up to
+ * ~0.35 |y log2 x| + 1.5 ulp (4 ulp at x = 1e-4, y = 1/2.2), so an output that moves by several codes under +-4 ulp is one the
+ * reference itself does not define: the tests use this to tell ill-conditioned channels from wrong ones. */
+static int g_pow_ulp_bias = 0;
+static uint32_t g_pow_ulp_seed = 0;
+void orc_set_pow_ulp_bias(int bias) { g_pow_ulp_bias = bias; g_pow_ulp_seed = 0; }
+/* seed != 0: every call errs by its own amount in [-amplitude, +amplitude], a hash of (x, y, seed) — independent errors per channel
+ * and per pow of the chain, as a real approximate pow has them (a uniform bias cancels in the gamut matrix, whose rows sum to 1) */
+void orc_set_pow_ulp_noise(int amplitude, uint32_t seed) { g_pow_ulp_bias = amplitude; g_pow_ulp_seed = seed; }
+static inline float hlsl_pow(float x, float y)
+{
+    float r = exp2f(y * log2f(x));
+    if (g_pow_ulp_bias && r > 0.0f && r < 3.0e38f) {
+        uint32_t u; memcpy(&u, &r, 4);
+        int bias = g_pow_ulp_bias;
+        if (g_pow_ulp_seed) {
+            uint32_t a, b2; memcpy(&a, &x, 4); memcpy(&b2, &y, 4);
+            uint32_t h = (a ^ (b2 * 0x9E3779B9u) ^ g_pow_ulp_seed) * 0x85EBCA6Bu;
+            h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+            bias = (int)(h % (uint32_t)(2 * g_pow_ulp_bias + 1)) - g_pow_ulp_bias;
+        }
+        u = (uint32_t)((int32_t)u + bias);
+        memcpy(&r, &u, 4);
+    }
+    return r;
+}
 
 static int g_threads = 0;
 int orc_num_threads(void)

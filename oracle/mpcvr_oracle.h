@@ -121,6 +121,10 @@ typedef struct orc_params {
 } orc_params;
 
 void orc_params_default(orc_params *p);
+/* sensitivity probe for the parity tests: every pow() of the HDR / Dolby Vision chains answers `bias` ulps off (0 = exact libm) */
+void orc_set_pow_ulp_bias(int bias);
+/* ... or by its own amount in [-amplitude, +amplitude] per call (a hash of the operands and `seed`; seed 0 = the uniform bias) */
+void orc_set_pow_ulp_noise(int amplitude, uint32_t seed);
 void orc_hdr_tail_ex(float rgb[3], int trc, int prim, int convert_to_sdr, float lum_scale, int hdr_output);
 void orc_hdr10_tonemap(float rgb[3], const orc_params *p);
 /* ---- correction passes: the RGB -> RGB shaders of m_pPSCorrection (DX11VideoProcessor.cpp:1893-1930, run by Process at

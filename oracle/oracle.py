@@ -176,6 +176,8 @@ def lib():
         L.orc_dovi_l2_constants.argtypes = [C.POINTER(OrcDovi), C.c_int, fp]
         L.orc_dovi_l1_nits.restype = C.c_int
         L.orc_dovi_l1_nits.argtypes = [C.POINTER(OrcDovi), C.POINTER(C.c_uint32)]
+        L.orc_set_pow_ulp_bias.argtypes = [C.c_int]
+        L.orc_set_pow_ulp_noise.argtypes = [C.c_int, C.c_uint32]
         L.orc_hdr10_params.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_uint32)]
         L.orc_specify_extfmt.restype = C.c_uint32
         L.orc_specify_extfmt.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int]
@@ -270,6 +272,19 @@ def process(p, frame, pitch, dither=None, dst=None):
     if rc != 0:
         raise RuntimeError(f"orc_process failed: {rc}")
     return dst
+
+
+def process_with_pow_bias(p, frame, pitch, bias, dst=None, seed=0):
+    """process() with every pow() of the HDR / Dolby Vision chains answering `bias` ulps off (the sensitivity probe); seed != 0: each
+    call by its own hash-drawn amount in [-bias, +bias] instead."""
+    if seed:
+        lib().orc_set_pow_ulp_noise(int(abs(bias)), int(seed))
+    else:
+        lib().orc_set_pow_ulp_bias(int(bias))
+    try:
+        return process(p, frame, pitch, dst=dst)
+    finally:
+        lib().orc_set_pow_ulp_bias(0)
 
 
 def convert_only(p, frame, pitch):

@@ -515,8 +515,9 @@ def test_period_plan_matches_the_tap_tables(mpcvr, method, sw, sh, dw, dh, want)
             ix = [ix[0]] + ix[2:]; wx = [np.float32(wx[0]) + np.float32(wx[1])] + wx[2:]
         assert ix == list(pp["xi_t"][:, x]) and np.array_equal(np.asarray(wx, np.float32), pp["xw_t"][:, x])
     for s_ in range(pp["strips"]):
-        cols = IX[128 * s_: 128 * (s_ + 1)]
+        cols = IX[pp["strip_w"] * s_: pp["strip_w"] * (s_ + 1)]
         assert pp["xstrip"][s_, 0] == min(min(c) for c in cols) and pp["xstrip"][s_, 1] == max(max(c) for c in cols)
+    assert pp["strip_w"] % 2 == 0 and 48 <= pp["strip_w"] <= 128 and pp["strips"] == -(-dw // pp["strip_w"])
     assert pp["acols"] % 2 == 0 and pp["acols"] >= max(pp["xstrip"][:, 1] - (pp["xstrip"][:, 0] & ~1)) + 1
 
 

@@ -84,6 +84,48 @@ def run_product(mpcvr, torch, c, extra_flags=0, host_upload=False):
     return out, info
 
 
+POW_ULPS = 4      # Direct3D's pow is exp2(y * log2 x): with 1-ulp log2 / exp2 the result is off by up to ~0.35 |y log2 x| + 1.5 ulp (4 at x = 1e-4, y = 1/2.2)
+
+
+def compare_behind_tail(oracle, p, frame, pitch, got, want, name, min_same=0.99):
+    """Frames behind a PQ / HLG / Dolby Vision tail: |delta| <= 1 like everywhere else, EXCEPT on channels where the oracle's own
+    answer is not defined to one code — shown per channel, not assumed: the oracle is run again with every pow() of the chain POW_ULPS
+    ulps low, POW_ULPS ulps high, and eight times with each call off by its own hash-drawn amount within +-POW_ULPS
+    (oracle.process_with_pow_bias; D3D's pow = exp2(y log2 x) is allowed that slack and more), and a channel beyond 1 LSB passes only
+    if the product's code lies inside the interval those oracle runs span (+- 1).  Where that happens (measured: the oracle's own
+    answer spans 0..13 codes on such a channel):
+    a bright saturated colour whose third channel cancels to ~1e-4 behind the 2020 -> 709 matrix — the PQ EOTF's (c2 - c3 v) term
+    amplifies an ulp of pow(x, 1/m2) ~100x, pow(., 1/m1) 6x more, and pow(x, 1/2.2) has a slope of ~70 down there.
+    Returns (share of identical channels, number of such channels)."""
+    d = np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
+    same = float((d == 0).mean())
+    assert same >= min_same, f"{name}: only {same:.5f} of channels identical"
+    bad = d > 1
+    n_bad = int(bad.sum())
+    if n_bad:
+        bg = np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8)
+        w3 = want[..., :3].astype(np.int16)
+        lo, hi = w3.copy(), w3.copy()
+        # all pow() calls low, all high, and eight draws of independent per-call errors (a uniform bias cancels in the gamut matrix,
+        # whose rows sum to 1: the channels of a real approximate pow err independently)
+        for bias, seed in [(-POW_ULPS, 0), (POW_ULPS, 0)] + [(POW_ULPS, k) for k in range(1, 9)]:
+            run = oracle.process_with_pow_bias(p, frame, pitch, bias, dst=bg.copy(), seed=seed)[..., :3].astype(np.int16)
+            lo = np.minimum(lo, run); hi = np.maximum(hi, run)
+        lo -= 1; hi += 1
+        g3 = got[..., :3].astype(np.int16)
+        inside = (g3 >= lo) & (g3 <= hi)
+        worst = np.argwhere(bad & ~inside)
+        assert worst.size == 0, (f"{name}: {len(worst)} of {n_bad} channels beyond 1 LSB are NOT explained by +-{POW_ULPS} ulp of pow(): "
+                                 f"e.g. (y, x, ch) = {tuple(worst[0])}: got {g3[tuple(worst[0])]}, oracle {w3[tuple(worst[0])]}, interval [{lo[tuple(worst[0])] + 1}, {hi[tuple(worst[0])] - 1}]")
+        assert n_bad <= 1e-4 * d.size, f"{name}: {n_bad} ill-conditioned channels is more than a handful"
+    if os.environ.get("MPCVR_PARITY_LOG"):
+        import json
+        with open(os.environ["MPCVR_PARITY_LOG"], "a") as f:
+            f.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], "what": name, "pixels": int(d.size // 3), "identical": same,
+                                "max_delta": int(d.max()), "beyond_1lsb_all_inside_pow_ulp_interval": n_bad, "floor": min_same}) + "\n")
+    return same, n_bad
+
+
 def path_ok(info, path):
     """GetVPInfo against an expected prefix; where the prefix names k_fused_strip the periodic-phase kernel (the same launch with the
     vertical window in registers, taken at 4:3 / 3:2 / 2:3 / 1:2) is the planner's choice and counts as well."""
@@ -479,7 +521,8 @@ def test_dovi_block_convert_whole_frame(mpcvr, oracle, torch_cuda, label, extra,
     """Dolby Vision through the 2x2-block convert (round 2) at 1080p, every pixel against the oracle: polynomial and MMR curves
     behind the elided PQ round trip (no level-2 trims), mixed curves with level-2 trims (PQ decode and tone map from tables,
     encode and trims in ALU), the literal chain into a 10-bit HDR target, and the block convert feeding the tiled resize.
-    >= 99.8 % identical; see the note on the ill-conditioned pixels at the end (10-bit target: <= 2 codes behind the tail)."""
+    >= 99.8 % identical, |delta| <= 1 except on channels the oracle itself does not define to one code (compare_behind_tail: per-channel
+    witness, no blanket allowance; 10-bit target: <= 2 codes behind the tail)."""
     torch = torch_cuda
     from videorenderer_amd import api
     c = dict(cformat=2, w=1920, h=1080, kind="hdr", seed=401, dst=(1920, 1080), exfmt=GOLDEN_CASES["dovi_poly_sdr"]["exfmt"])
@@ -487,24 +530,39 @@ def test_dovi_block_convert_whole_frame(mpcvr, oracle, torch_cuda, label, extra,
     frame, pitch = case_frame(c)
     p = oracle_params(oracle, c)
     want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
-    stats = {}
     for flags in (api.FLAG_NO_FUSED, api.FLAG_NO_FAST_CONVERT, 0):
         got, info = run_product(mpcvr, torch, c, extra_flags=flags)
         assert info.startswith(path) or flags == api.FLAG_NO_FUSED, info
         if c.get("output_format", 0) == 1:
             compare_rgb10(got, want, f"{label} flags={flags}", tail=True)
             continue
-        d = np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
-        stats[flags] = (float((d == 0).mean()), int((d > 1).sum()), int(d.max()))
-        print(f"dovi {label} flags={flags} [{info}]: identical {stats[flags][0]:.6f}, channels beyond 1 LSB {stats[flags][1]} of {d.size}, max {stats[flags][2]}")
-    # Behind the 2020 -> 709 matrix a saturated dark colour cancels to ~1e-7 and pow(x, 1/2.2) has a slope of thousands there: the
-    # GPU's v_log / v_exp (1 ulp) and the oracle's libm already disagree by several codes on a handful of such pixels — on EVERY
-    # tier, the literal per-pixel kernels included.  The block convert is held to the same handful (a few ppm of the channels),
-    # not to a bar the literal chain does not meet either.
-    for flags, (same, beyond, mx) in stats.items():
-        assert same >= 0.998, (label, flags, same)
-        assert beyond <= max(32, 4 * stats[api.FLAG_NO_FUSED][1] + 16) and beyond <= 1e-5 * d.size, (label, flags, beyond)
-        assert mx <= 8, (label, flags, mx)
+        same, n_bad = compare_behind_tail(oracle, p, frame, pitch, got, want, f"dovi {label} flags={flags} [{info}]", min_same=0.998)
+        print(f"dovi {label} flags={flags} [{info}]: identical {same:.6f}, channels beyond 1 LSB (all inside the oracle's own +-{POW_ULPS} ulp pow() interval) {n_bad}")
+
+
+def test_frame_timers(mpcvr, torch_cuda):
+    """mpcvr_get_last_timings (FrameStats.h:145-173: copyticks, paintticks + the snapshot's read-back): nothing timed -> -1; a host
+    sample times its upload, a device sample does not touch the upload timer, a snapshot times its read-back."""
+    torch = torch_cuda
+    from videorenderer_amd import api
+    c = GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]
+    vp, (ww, wh) = make_vp(mpcvr, c)
+    t = vp.GetLastTimings()
+    assert t == dict(copy_host_ms=-1.0, upload_ms=-1.0, process_ms=-1.0, readback_ms=-1.0)
+    frame, pitch = case_frame(c)
+    dst = torch.zeros((wh, ww, 4), dtype=torch.uint8, device="cuda")
+    vp.CopySample(torch.from_numpy(frame).cuda(), pitch)
+    vp.Process(dst, ww * 4)
+    t = vp.GetLastTimings()
+    assert t["copy_host_ms"] >= 0 and t["upload_ms"] == -1.0 and t["process_ms"] > 0 and t["readback_ms"] == -1.0
+    assert abs(t["process_ms"] - vp.GetLastProcessMs()) < 1e-6
+    vp.CopySample(frame, pitch)                      # pageable host memory: staged and uploaded on the copy stream
+    vp.Process(dst, ww * 4)
+    t = vp.GetLastTimings()
+    assert t["upload_ms"] > 0 and t["copy_host_ms"] > 0
+    vp.GetCurentImage()
+    assert vp.GetLastTimings()["readback_ms"] > 0
+    vp.close()
 
 
 def test_error_behaviour(mpcvr, torch_cuda):
@@ -592,7 +650,7 @@ FULL_SIZE_TIERS = {
             ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 1.0)),
     "up1440": ((0, "period", 0.99938), ("FLAG_NO_PERIOD", "strip", 0.99938), ("FLAG_NO_STRIP", "passes:convert,resizeX,resizeY", 0.99939), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 0.99992)),            # 0.999691 0.999698 0.999963
     "down1440": ((0, "period", 0.99938), ("FLAG_NO_PERIOD", "strip", 0.99938), ("FLAG_NO_STRIP", "passes:convert,resizeX,resizeY", 0.99939), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 0.99993)),          # 0.999692 0.999697 0.999965
-    "up1080_from_720_nv12": ((0, "period", 0.99996), ("FLAG_NO_PERIOD", "strip", 0.99996), ("FLAG_NO_STRIP", "passes:convert,resizeX,resizeY", 0.99998),      # 0.999981 0.999991 1.0
+    "up1080_from_720_nv12": (("FLAG_FORCE_PERIOD", "period", 0.99996), (0, "strip", 0.99996), ("FLAG_NO_STRIP", "passes:convert,resizeX,resizeY", 0.99998),      # 0.999981 0.999991 1.0
                              ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY", 1.0)),
     "down1080_from_4k_hlg": ((0, "period", 0.99877), ("FLAG_NO_PERIOD", "strip", 0.99877), ("FLAG_NO_STRIP", "passes:convert,resizeX,resizeY", 0.9988), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 0.99939)),   # 0.999386 0.999401 0.999695
 }
@@ -726,7 +784,7 @@ def test_period_kernel_vs_oracle_and_strip_kernel(mpcvr, oracle, torch_cuda, lab
     frame, pitch = case_frame(c)
     p = oracle_params(oracle, c)
     want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
-    got, info = run_product(mpcvr, torch, c)
+    got, info = run_product(mpcvr, torch, c, extra_flags=api.FLAG_FORCE_PERIOD)       # (SDR + 4 taps: the planner's own choice is k_fused_strip)
     P, Q, nt = pqn
     assert f"kernel=fused_period(rows={P}:{Q},taps={nt}," in info, info
     alt, info_alt = run_product(mpcvr, torch, c, extra_flags=api.FLAG_NO_PERIOD)
@@ -827,12 +885,9 @@ def test_catmull_rom_chroma_block_convert_whole_frame(mpcvr, oracle, torch_cuda,
         same = compare(got, want, f"{label} [{info}]", min_same=0.99)
         compare(ref, want, f"{label} [{info_ref}]", exact=True)
     else:
-        # behind the PQ tail: the ill-conditioned handful (see test_dovi_block_convert_whole_frame) is counted, not fatal
-        for out, tag in ((got, info), (ref, info_ref)):
-            d = np.abs(out[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
-            same = float((d == 0).mean())
-            assert same >= 0.99 and int((d > 1).sum()) <= 1e-5 * d.size and d.max() <= 8, (label, tag, same, int((d > 1).sum()), int(d.max()))
-        same = float((np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16)) == 0).mean())
+        # behind the PQ tail: a channel beyond 1 LSB must be one the oracle itself does not define to a code (compare_behind_tail)
+        compare_behind_tail(oracle, p, frame, pitch, ref, want, f"{label} [{info_ref}]")
+        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]")
     print(f"{label}: identical channels {same:.6f}  [{info}]")
 
 
@@ -866,9 +921,7 @@ def test_planar_422_and_444_on_the_fused_paths(mpcvr, oracle, torch_cuda, label,
     got, info = run_product(mpcvr, torch, c)
     assert path_ok(info, path), info
     if has_tail(c):
-        d = np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
-        same = float((d == 0).mean())
-        assert same >= 0.99 and int((d > 1).sum()) <= 1e-5 * d.size and d.max() <= 8, (label, same, int((d > 1).sum()), int(d.max()))
+        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]")
     else:
         same = compare(got, want, f"{label} [{info}]", min_same=0.99)
     print(f"{label}: identical channels {same:.6f}  [{info}]")
@@ -901,9 +954,7 @@ def test_packed_422_on_the_fused_paths(mpcvr, oracle, torch_cuda, label, c, path
     got, info = run_product(mpcvr, torch, c)
     assert path_ok(info, path), info
     if has_tail(c):
-        d = np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
-        same = float((d == 0).mean())
-        assert same >= 0.99 and int((d > 1).sum()) <= 1e-5 * d.size and d.max() <= 8, (label, same, int((d > 1).sum()), int(d.max()))
+        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]")
     else:
         same = compare(got, want, f"{label} [{info}]", min_same=0.99)
     print(f"{label}: identical channels {same:.6f}  [{info}]")
@@ -936,9 +987,7 @@ def test_nearest_chroma_on_the_fused_paths(mpcvr, oracle, torch_cuda, label, c, 
     got, info = run_product(mpcvr, torch, c)
     assert path_ok(info, path), info
     if has_tail(c):
-        d = np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
-        same = float((d == 0).mean())
-        assert same >= 0.99 and int((d > 1).sum()) <= 1e-5 * d.size and d.max() <= 8, (label, same, int((d > 1).sum()), int(d.max()))
+        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]")
     else:
         same = compare(got, want, f"{label} [{info}]", min_same=0.99)
     print(f"{label}: identical channels {same:.6f}  [{info}]")
@@ -971,9 +1020,7 @@ def test_packed_444_gray_and_gbrp_on_the_fused_paths(mpcvr, oracle, torch_cuda, 
     got, info = run_product(mpcvr, torch, c)
     assert path_ok(info, path), info
     if has_tail(c):
-        d = np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
-        same = float((d == 0).mean())
-        assert same >= 0.99 and int((d > 1).sum()) <= 1e-5 * d.size and d.max() <= 8, (label, same, int((d > 1).sum()), int(d.max()))
+        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]")
     else:
         same = compare(got, want, f"{label} [{info}]", min_same=0.99)
     print(f"{label}: identical channels {same:.6f}  [{info}]")
@@ -1002,10 +1049,8 @@ def test_spline36_extension_vs_oracle(mpcvr, oracle, torch_cuda, label, c, path)
     assert path_ok(info, path), info
     plain, info_plain = run_product(mpcvr, torch, c, extra_flags=api.FLAG_NO_FUSED)
     if has_tail(c):
-        for out, tag in ((got, info), (plain, info_plain)):
-            d = np.abs(out[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
-            same = float((d == 0).mean())
-            assert same >= 0.99 and int((d > 1).sum()) <= 1e-5 * d.size and d.max() <= 8, (label, tag, same, int((d > 1).sum()), int(d.max()))
+        compare_behind_tail(oracle, p, frame, pitch, plain, want, f"{label} [{info_plain}]")
+        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]")
     else:
         same = compare(got, want, f"{label} [{info}]", min_same=0.99)
         compare(plain, want, f"{label} [{info_plain}]", exact=True)

@@ -111,9 +111,15 @@ for i in range(n):
         if not has_tail(c):
             assert dp.max() == 0, f"plain tier vs oracle: max {int(dp.max())}, {int((dp > 0).sum())} channels: {name}"
             assert dg.max() <= lim and float((dg == 0).mean()) >= 0.97, f"default planner vs oracle: {name}"
-        else:
-            assert float((dp == 0).mean()) >= 0.97 and int((dp > lim).sum()) <= max(4, 2e-5 * dp.size), f"plain tier vs oracle (tail): same {float((dp == 0).mean()):.4f} beyond {int((dp > lim).sum())} max {int(dp.max())} lim {lim}: {name}"
-            assert float((dg == 0).mean()) >= 0.97 and int((dg > lim).sum()) <= max(4, 4e-5 * dg.size), f"default planner vs oracle (tail): same {float((dg == 0).mean()):.4f} beyond {int((dg > lim).sum())} max {int(dg.max())} lim {lim}: {name}"
+        elif c.get("output_format", 0) == 1:        # 10-bit targets behind a tail: the suite's compare_rgb10 bar (<= 2 ten-bit codes, 5 with 8-bit intermediates)
+            assert float((dp == 0).mean()) >= 0.97 and dp.max() <= lim, f"plain tier vs oracle (tail, 10-bit): max {int(dp.max())} lim {lim}: {name}"
+            assert float((dg == 0).mean()) >= 0.97 and dg.max() <= lim, f"default planner vs oracle (tail, 10-bit): max {int(dg.max())} lim {lim}: {name}"
+        else:                                       # 8-bit targets: <= 1 LSB, or the per-channel witness (the oracle's own +-4 ulp pow() interval)
+            from tests.test_parity_gpu import compare_behind_tail
+            po = oracle_params(oracle, c)
+            fr, pit = case_frame(c)
+            compare_behind_tail(oracle, po, fr, pit, plain, want, f"plain tier vs oracle (tail): {name}", min_same=0.97)
+            compare_behind_tail(oracle, po, fr, pit, got, want, f"default planner vs oracle (tail): {name}", min_same=0.97)
     beyond = int((d > lim).sum()); same = float((d == 0).mean())
     worst = max(worst, 1.0 - same)
     if beyond:

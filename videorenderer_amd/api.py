@@ -43,6 +43,7 @@ DOWNSCALE_Box, DOWNSCALE_Bilinear, DOWNSCALE_Hamming, DOWNSCALE_Bicubic, DOWNSCA
 OUT_BGRA8, OUT_RGB10A2 = 0, 1
 FLAG_LANCZOS3_FIXED, FLAG_NO_FUSED, FLAG_NO_LUT, FLAG_NO_FAST_CONVERT, FLAG_FUSED_VALU, FLAG_FUSED_MFMA, FLAG_NO_STRIP = 1, 2, 4, 8, 16, 32, 64
 FLAG_NO_PERIOD = 128
+FLAG_FORCE_PERIOD = 256
 MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2
 PROCAMP_BRIGHTNESS, PROCAMP_CONTRAST, PROCAMP_HUE, PROCAMP_SATURATION = 1, 2, 4, 8
 
@@ -155,7 +156,7 @@ EXPORTS = [
     "mpcvr_get_backbuffer", "mpcvr_get_current_image", "mpcvr_flush", "mpcvr_reset", "mpcvr_process_batch",
     "mpcvr_get_param_blob", "mpcvr_set_param_blob", "mpcvr_get_color_matrix", "mpcvr_get_extfmt",
     "mpcvr_get_frame_bytes", "mpcvr_get_path_info", "mpcvr_last_error", "mpcvr_version",
-    "mpcvr_get_last_process_ms",
+    "mpcvr_get_last_process_ms", "mpcvr_get_last_timings",
     "mpcvr_plan_frame_layout", "mpcvr_plan_color_matrix", "mpcvr_plan_gamut_2020_to_709", "mpcvr_plan_pq_lut",
     "mpcvr_plan_upscale_weights", "mpcvr_plan_axis_taps", "mpcvr_plan_describe", "mpcvr_plan_final_pass_multiplier",
     "mpcvr_plan_strip", "mpcvr_plan_pq_eotf_lut", "mpcvr_plan_period", "mpcvr_plan_hdr10_params",
@@ -165,7 +166,8 @@ _lib = None
 
 
 def load_library():
-    """dlopen libmpcvr.so.  Raises (never falls back) when it has not been built."""
+    """dlopen libmpcvr.so.  Raises (never falls back) when it has not been built.
+    Side effect: imports torch first when it is installed (one HIP runtime for both, see below) unless MPCVR_NO_TORCH_IMPORT=1."""
     global _lib
     if _lib is not None:
         return _lib
@@ -175,8 +177,8 @@ def load_library():
     # In a process that also uses torch, torch's bundled HIP runtime must be the one both share: libmpcvr.so resolves
     # libamdhip64 through the dynamic loader, and a second copy of the runtime (loaded first from /opt/rocm) sees no device once
     # torch has initialised its own.  Importing torch first — only if it is installed; the library itself does not need it —
-    # makes the load order irrelevant.
-    if "torch" not in sys.modules:
+    # makes the load order irrelevant.  A host that never touches torch can skip the (slow) import with MPCVR_NO_TORCH_IMPORT=1.
+    if "torch" not in sys.modules and not os.environ.get("MPCVR_NO_TORCH_IMPORT"):
         try:
             import importlib.util
             if importlib.util.find_spec("torch") is not None:
@@ -221,6 +223,7 @@ def load_library():
         "mpcvr_get_frame_bytes": [vp, P(C.c_size_t), P(i32)],
         "mpcvr_get_path_info": [vp, C.c_char_p, C.c_size_t],
         "mpcvr_get_last_process_ms": [vp, P(f)],
+        "mpcvr_get_last_timings": [vp, P(f), P(f), P(f), P(f)],
         "mpcvr_plan_frame_layout": [i32, i32, i32, P(i32), P(C.c_size_t)],
         "mpcvr_plan_color_matrix": [i32, i32, i32, u32, f, f, f, f, P(f), P(u32)],
         "mpcvr_plan_gamut_2020_to_709": [P(f)],
@@ -230,7 +233,7 @@ def load_library():
         "mpcvr_plan_axis_taps": [i32, i32, i32, i32, i32, i32, u32, i32, P(i32), P(f), P(f), P(i32), P(i32)],
         "mpcvr_plan_strip": [i32, i32, i32, i32, i32, i32, i32, i32, u32, P(i32), P(i32), P(i32), P(i32), P(f), P(i32), P(f)],
         "mpcvr_plan_hdr10_params": [f, f, f, f, f, i32, P(u32)],
-        "mpcvr_plan_period": [i32, i32, i32, i32, i32, u32, P(i32), P(i32), P(f), P(f), P(i32)],
+        "mpcvr_plan_period": [i32, i32, i32, i32, i32, u32, P(i32), P(i32), P(f), P(f), P(i32), P(i32)],
         "mpcvr_plan_pq_eotf_lut": [P(f)],
         "mpcvr_plan_describe": [P(Settings), i32, i32, i32, P(Rect), i32, i32, C.c_char_p, C.c_size_t],
     }
@@ -364,7 +367,8 @@ def plan_period(method, src_w, src_h, out_w, out_h, flags=0):
     import numpy as np
     L = load_library()
     out6 = (C.c_int32 * 6)()
-    hr = L.mpcvr_plan_period(method, src_w, src_h, out_w, out_h, flags, out6, None, None, None, None)
+    sw = C.c_int32(0)
+    hr = L.mpcvr_plan_period(method, src_w, src_h, out_w, out_h, flags, out6, None, None, None, None, C.byref(sw))
     if hr == E_NOTIMPL:
         return None
     if hr != 0:
@@ -373,10 +377,10 @@ def plan_period(method, src_w, src_h, out_w, out_h, flags=0):
     xi = np.zeros((nt, out_w), np.int32); xw = np.zeros((nt, out_w), np.float32)
     yw = np.zeros((out_h, 8), np.float32); xs = np.zeros((strips, 2), np.int32)
     as_p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
-    hr = L.mpcvr_plan_period(method, src_w, src_h, out_w, out_h, flags, out6, as_p(xi, C.c_int32), as_p(xw, C.c_float), as_p(yw, C.c_float), as_p(xs, C.c_int32))
+    hr = L.mpcvr_plan_period(method, src_w, src_h, out_w, out_h, flags, out6, as_p(xi, C.c_int32), as_p(xw, C.c_float), as_p(yw, C.c_float), as_p(xs, C.c_int32), C.byref(sw))
     if hr != 0:
         raise MpcvrError(hr, "mpcvr_plan_period")
-    return dict(P=Pn, Q=Qn, taps=nt, strips=strips, acols=acols, rows_per_body=pb, xi_t=xi, xw_t=xw, yw=yw, xstrip=xs)
+    return dict(strip_w=sw.value, P=Pn, Q=Qn, taps=nt, strips=strips, acols=acols, rows_per_body=pb, xi_t=xi, xw_t=xw, yw=yw, xstrip=xs)
 
 
 def plan_pq_eotf_lut():
@@ -613,3 +617,9 @@ class VideoProcessor:
         ms = C.c_float()
         self._check(self._L.mpcvr_get_last_process_ms(self._ctx, C.byref(ms)))
         return ms.value
+
+    def GetLastTimings(self):
+        """{copy_host_ms, upload_ms, process_ms, readback_ms} (FrameStats.h:145-173); -1 = not timed yet."""
+        v = [C.c_float(-1.0) for _ in range(4)]
+        self._check(self._L.mpcvr_get_last_timings(self._ctx, *(C.byref(x) for x in v)))
+        return dict(zip(("copy_host_ms", "upload_ms", "process_ms", "readback_ms"), (x.value for x in v)))

@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 
@@ -86,6 +87,7 @@ CHipVideoProcessor::~CHipVideoProcessor()
     }
     if (m_evStart) (void)hipEventDestroy(m_evStart);
     if (m_evStop) (void)hipEventDestroy(m_evStop);
+    for (hipEvent_t *e : {&m_evUp0, &m_evUp1, &m_evRb0, &m_evRb1}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
     if (m_ownStream && m_stream) (void)hipStreamDestroy(m_stream);
 }
 
@@ -621,7 +623,7 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         m_periodPlan.P = 0;
         const bool q1 = m_plan.rx.kind == RS_UP && m_plan.ry.kind == RS_UP && m_cfg.iUpscaling == MPCVR_UPSCALE_Lanczos3 && !(m_cfg.flags & MPCVR_FLAG_LANCZOS3_FIXED);
         if (m_plan.convert && m_plan.rx.kind == RS_UP && m_plan.ry.kind == RS_UP &&
-            PlanFusedPeriod(hx, hy, w2, h2, w1, m_plan.mid_h, q1, &m_periodPlan)) {
+            PlanFusedPeriod(hx, hy, w2, h2, w1, m_plan.mid_h, q1, &m_periodPlan, m_tail == TAIL_PQ_TO_SDR || m_tail == TAIL_HLG_TO_SDR)) {
             const PeriodPlan &pp = m_periodPlan;
             m_periodOff[0] = put(pp.xi_t.data(), pp.xi_t.size());
             m_periodOff[1] = put(pp.xw_t.data(), pp.xw_t.size());
@@ -863,6 +865,9 @@ HRESULT CHipVideoProcessor::CopySample(const void *data, int pitch, int memKind)
     (void)hipSetDevice(m_device);
     const size_t bytes = (size_t)m_srcPitch * m_srcLines;
     HRESULT hr;
+    const auto t_host0 = std::chrono::steady_clock::now();
+    struct HostTimer { CHipVideoProcessor *self; std::chrono::steady_clock::time_point t0;
+                       ~HostTimer() { self->m_copyHostMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } host_timer{this, t_host0};
     MarkConsumed();                                  // the previous sample is done with as far as the host is concerned
     m_curSlot = -1;
     if (memKind == MPCVR_MEM_DEVICE) {               // zero-copy, cf. the IMediaSampleD3D11 branch :2528-2569
@@ -892,7 +897,11 @@ HRESULT CHipVideoProcessor::CopySample(const void *data, int pitch, int memKind)
         from = u.pinned;                             // <<6 / v210 / RGB repacks happen on the device (PrepareSample)
     }
     // the new data must not overtake work of the main stream that still reads this device buffer
+    if (!m_evUp0 && ((hr = CheckHip(hipEventCreate(&m_evUp0), "upload timer")) || (hr = CheckHip(hipEventCreate(&m_evUp1), "upload timer")))) return hr;
+    (void)hipEventRecord(m_evUp0, m_copyStream);
     if ((hr = CheckHip(hipMemcpyAsync(u.dev.ptr, from, bytes, hipMemcpyHostToDevice, m_copyStream), "upload"))) return hr;
+    (void)hipEventRecord(m_evUp1, m_copyStream);
+    m_upTimed = true;
     if ((hr = CheckHip(hipEventRecord(u.uploaded, m_copyStream), "upload event"))) return hr;
     if ((hr = CheckHip(hipStreamWaitEvent(m_stream, u.uploaded, 0), "stream wait"))) return hr;
     u.inFlight = true; u.consumedRecorded = false;
@@ -990,10 +999,10 @@ bool CHipVideoProcessor::FillStripParams(const uint8_t *sample, void *dst, int d
     sp->nt = m_stripPlan.nt; sp->pxl = m_stripPlan.pxl; sp->strip_w = m_stripPlan.strip_w; sp->ring = m_stripPlan.ring; sp->acols = m_stripPlan.acols;
     sp->per_P = 0;
     if (m_periodPlan.P && !(m_cfg.flags & MPCVR_FLAG_NO_PERIOD)) {
-        sp->per_P = m_periodPlan.P; sp->per_Q = m_periodPlan.Q; sp->per_nt = m_periodPlan.nt; sp->per_acols = m_periodPlan.acols;
+        sp->per_P = m_periodPlan.P; sp->per_Q = m_periodPlan.Q; sp->per_nt = m_periodPlan.nt; sp->per_acols = m_periodPlan.acols; sp->per_strip_w = m_periodPlan.strip_w; sp->per_force = (m_cfg.flags & MPCVR_FLAG_FORCE_PERIOD) ? 1 : 0;
         sp->per_xi_t = tab + m_periodOff[0]; sp->per_xw_t = tab + m_periodOff[1]; sp->per_yw = tab + m_periodOff[2]; sp->per_xstrip = tab + m_periodOff[3];
     }
-    return FusedStripSupported(*sp) && FusedStripLdsBytes(*sp) <= 160 * 1024;
+    return FusedStripSupported(*sp) && FusedStripLdsBytes(*sp) <= DeviceLdsLimit();
 }
 
 // the same kernel without its convert stage: `src` = m_TexConvertOutput (any convert kernel wrote it) or the RGB source texture
@@ -1012,7 +1021,7 @@ bool CHipVideoProcessor::FillStripSurfParams(const Surface &src, const StorePara
     sp->surf = src;
     sp->other = m_otherX.ptr && !m_tapsX.other_identity ? (const int32_t *)m_otherX.ptr : nullptr;
     sp->mid_h = m_plan.mid_h;
-    return FusedStripSupported(*sp) && FusedStripLdsBytes(*sp) <= 160 * 1024;
+    return FusedStripSupported(*sp) && FusedStripLdsBytes(*sp) <= DeviceLdsLimit();
 }
 
 HRESULT CHipVideoProcessor::ProcessOne(const uint8_t *sample, void *rt, int rtPitch)
@@ -1224,7 +1233,10 @@ bool CHipVideoProcessor::BatchPlan(const uint8_t *sample0, void *rt0, int rtPitc
     const Surface cs{nullptr, convPitch, w1, h1, m_plan.internal_fmt};
     const StoreParams final = MakeStore(rt0, rtPitch, m_plan.swap_fmt, true);
     if (m_plan.two_pass) {
-        if (m_stripSurf) return true;
+        // m_stripSurf was probed with a null target and a window-width pitch (UpdatePlan): re-check with THIS batch's target, and fall
+        // through to the tiled / folded kernels' own checks when the strip kernel does not take it
+        FusedStripParams ssp{};
+        if (m_stripSurf && FillStripSurfParams(cs, final, &ssp)) return true;
         if (m_firstAxis == 0 && !m_firstSwap && Resize2DSupported(cs, m_tapsX, m_tapsY, final)) return true;
         const Surface mid{nullptr, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
         return ResizeHasFoldedKernel(m_firstAxis, m_firstSwap, cs, m_tapsX, MakeStore(nullptr, mid.pitch, SF_RGBA16F, false)) &&
@@ -1333,15 +1345,39 @@ HRESULT CHipVideoProcessor::GetCurentImage(void *hostBGRA, size_t *size)
     // the convert shader rebuilt with the PQ / HLG -> SDR tail (:3530-3545, restored :3562-3580)
     const bool backupHdr = m_hdrOutput;
     const bool backupOverride = m_blobOverride;
+    // a context running on rank 0's broadcast parameter blob keeps it: the whole block is saved and put back verbatim (recomputing
+    // the parameters locally and then claiming "overridden" again would silently drop the blob's matrices, tail and tables)
+    struct { float cm[12]; float lum; float gamut[9]; int tail; float gamma; Up2xWeights ux, uy; } keep{};
+    std::vector<uint16_t> keepDither;
+    std::vector<float> keepLut;
+    if (m_hdrOutput && backupOverride) {
+        std::memcpy(keep.cm, m_cm, sizeof(m_cm)); keep.lum = m_lumScale; std::memcpy(keep.gamut, m_gamut, sizeof(m_gamut));
+        keep.tail = m_tail; keep.gamma = m_gamma; keep.ux = m_upX; keep.uy = m_upY;
+        keepDither.assign(m_ditherHost, m_ditherHost + sizeof(m_ditherHost) / sizeof(m_ditherHost[0]));
+        keepLut.assign(m_pqLutHost, m_pqLutHost + sizeof(m_pqLutHost) / sizeof(m_pqLutHost[0]));
+    }
     if (m_hdrOutput) { m_hdrOutput = false; m_blobOverride = false; SetShaderConvertColorParams(); UpdateHdrToneMapParams(); }
     m_videoRect = CRect(0, 0, w, h); m_windowRect = m_videoRect; m_cfg.output_format = MPCVR_OUT_BGRA8;
     m_planDirty = true;
     hr = Process(m_Snapshot.ptr, w * 4, nullptr, nullptr, false);
     m_videoRect = backupVid; m_windowRect = backupWnd; m_cfg.output_format = backupOut;
-    if (backupHdr) { m_hdrOutput = true; SetShaderConvertColorParams(); UpdateHdrToneMapParams(); m_blobOverride = backupOverride; }
+    if (backupHdr) {
+        m_hdrOutput = true; SetShaderConvertColorParams(); UpdateHdrToneMapParams();
+        if (backupOverride) {
+            std::memcpy(m_cm, keep.cm, sizeof(m_cm)); m_lumScale = keep.lum; std::memcpy(m_gamut, keep.gamut, sizeof(m_gamut));
+            m_tail = keep.tail; m_gamma = keep.gamma; m_upX = keep.ux; m_upY = keep.uy;
+            std::memcpy(m_ditherHost, keepDither.data(), sizeof(m_ditherHost));
+            std::memcpy(m_pqLutHost, keepLut.data(), sizeof(m_pqLutHost));
+            m_blobOverride = true;
+        }
+    }
     m_planDirty = true;
     if (hr) return hr;
+    if (!m_evRb0 && ((hr = CheckHip(hipEventCreate(&m_evRb0), "read-back timer")) || (hr = CheckHip(hipEventCreate(&m_evRb1), "read-back timer")))) return hr;
+    (void)hipEventRecord(m_evRb0, m_stream);
     if ((hr = CheckHip(hipMemcpyAsync(hostBGRA, m_Snapshot.ptr, need, hipMemcpyDeviceToHost, m_stream), "readback"))) return hr;
+    (void)hipEventRecord(m_evRb1, m_stream);
+    m_rbTimed = true;
     if ((hr = CheckHip(hipStreamSynchronize(m_stream), "readback sync"))) return hr;
     *size = need;
     return MPCVR_S_OK;
@@ -1443,9 +1479,25 @@ std::string CHipVideoProcessor::GetPathInfo()
     if (m_planDirty && UpdatePlan() != MPCVR_S_OK) return "error: " + m_lastError;
     if ((!m_strip && !m_stripSurf) || m_plan.fused_up2x) return m_plan.describe();
     if (m_strip && m_period)
-        return m_plan.describe() + ";kernel=fused_period(rows=" + std::to_string(m_periodPlan.P) + ":" + std::to_string(m_periodPlan.Q) + ",taps=" + std::to_string(m_periodPlan.nt) + ",px_per_lane=2,strip=128,window=6 rows in registers)";
+        return m_plan.describe() + ";kernel=fused_period(rows=" + std::to_string(m_periodPlan.P) + ":" + std::to_string(m_periodPlan.Q) + ",taps=" + std::to_string(m_periodPlan.nt) + ",px_per_lane=2,strip=" + std::to_string(m_periodPlan.strip_w) + ",window=6 rows in registers)";
     return m_plan.describe() + (m_strip ? ";kernel=fused_strip(taps=" : ";kernel=fused_strip:surface(taps=") + std::to_string(m_stripPlan.nt) + ",px_per_lane=" + std::to_string(m_stripPlan.pxl) +
            ",strip=" + std::to_string(m_stripPlan.strip_w) + ",ring=" + std::to_string(m_stripPlan.ring) + ")";
+}
+
+// FrameStats.h:145-173: copyticks (:2594), paintticks (:2790) and the snapshot's read-back; -1 = not timed yet
+HRESULT CHipVideoProcessor::GetLastTimings(float *copy_host_ms, float *upload_ms, float *process_ms, float *readback_ms)
+{
+    (void)hipSetDevice(m_device);
+    auto elapsed = [](bool on, hipEvent_t a, hipEvent_t b) {
+        float ms = -1.0f;
+        if (on && hipEventSynchronize(b) == hipSuccess && hipEventElapsedTime(&ms, a, b) != hipSuccess) ms = -1.0f;
+        return ms;
+    };
+    if (copy_host_ms) *copy_host_ms = m_copyHostMs;
+    if (upload_ms) *upload_ms = elapsed(m_upTimed, m_evUp0, m_evUp1);
+    if (process_ms) *process_ms = elapsed(m_timed, m_evStart, m_evStop);
+    if (readback_ms) *readback_ms = elapsed(m_rbTimed, m_evRb0, m_evRb1);
+    return MPCVR_S_OK;
 }
 
 HRESULT CHipVideoProcessor::GetLastProcessMs(float *ms)

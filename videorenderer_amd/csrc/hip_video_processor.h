@@ -73,6 +73,7 @@ public:
     HRESULT GetFrameBytes(size_t *bytes, int *pitch);
     std::string GetPathInfo();
     HRESULT GetLastProcessMs(float *ms);
+    HRESULT GetLastTimings(float *copy_host_ms, float *upload_ms, float *process_ms, float *readback_ms);
     const char *LastError() const { return m_lastError.c_str(); }
 
 private:
@@ -102,6 +103,11 @@ private:
     bool m_ownStream = false;
     hipEvent_t m_evStart = nullptr, m_evStop = nullptr;
     bool m_timed = false;
+    // FrameStats.h:145-173 beside paintticks: the last CopySample (host wall time = copyticks :2594, and its H2D transfer on the copy
+    // stream) and the last GetCurentImage read-back
+    hipEvent_t m_evUp0 = nullptr, m_evUp1 = nullptr, m_evRb0 = nullptr, m_evRb1 = nullptr;
+    bool m_upTimed = false, m_rbTimed = false;
+    float m_copyHostMs = -1.0f;
     std::string m_lastError;
 
     // settings (Settings_t mirror)

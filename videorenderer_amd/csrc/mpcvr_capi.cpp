@@ -151,6 +151,11 @@ const char *mpcvr_last_error(mpcvr_ctx *ctx) { return ctx ? ctx->vp.LastError() 
 const char *mpcvr_version(void) { return "mpcvr-mi355x 0.1 (gfx950)"; }
 
 int32_t mpcvr_get_last_process_ms(mpcvr_ctx *ctx, float *ms) { CTX_OR_FAIL(); return ctx->vp.GetLastProcessMs(ms); }
+int32_t mpcvr_get_last_timings(mpcvr_ctx *ctx, float *copy_host_ms, float *upload_ms, float *process_ms, float *readback_ms)
+{
+    CTX_OR_FAIL();
+    return ctx->vp.GetLastTimings(copy_host_ms, upload_ms, process_ms, readback_ms);
+}
 
 }  // extern "C"
 
@@ -316,7 +321,7 @@ int32_t mpcvr_plan_strip(int32_t kind_x, int32_t method_x, int32_t kind_y, int32
 }
 
 int32_t mpcvr_plan_period(int32_t method, int32_t src_w, int32_t src_h, int32_t out_w, int32_t out_h, uint32_t flags,
-                          int32_t out6[6], int32_t *xi_t, float *xw_t, float *yw, int32_t *xstrip)
+                          int32_t out6[6], int32_t *xi_t, float *xw_t, float *yw, int32_t *xstrip, int32_t *strip_w)
 {
     if (!out6) return MPCVR_E_POINTER;
     if (src_w <= 0 || src_h <= 0 || out_w <= 0 || out_h <= 0) return MPCVR_E_INVALIDARG;
@@ -326,7 +331,8 @@ int32_t mpcvr_plan_period(int32_t method, int32_t src_w, int32_t src_h, int32_t 
     const bool q1 = method == MPCVR_UPSCALE_Lanczos3 && !(flags & MPCVR_FLAG_LANCZOS3_FIXED);
     mpcvr::PeriodPlan pp;
     if (!mpcvr::PlanFusedPeriod(hx, hy, out_w, out_h, src_w, src_h, q1, &pp)) return MPCVR_E_NOTIMPL;
-    const int32_t o[6] = {pp.P, pp.Q, pp.nt, (out_w + 127) / 128, pp.acols, 6 * pp.P / pp.Q};
+    const int32_t o[6] = {pp.P, pp.Q, pp.nt, (out_w + pp.strip_w - 1) / pp.strip_w, pp.acols, 6 * pp.P / pp.Q};
+    if (strip_w) *strip_w = pp.strip_w;
     std::memcpy(out6, o, sizeof(o));
     if (xi_t) std::memcpy(xi_t, pp.xi_t.data(), pp.xi_t.size() * sizeof(int32_t));
     if (xw_t) std::memcpy(xw_t, pp.xw_t.data(), pp.xw_t.size() * sizeof(float));

@@ -546,7 +546,8 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     if (seg > c.out_h) seg = c.out_h;
     a.seg_rows = seg;
 
-    // the taps on the matrix cores (vp_fused_mx.hip) unless MPCVR_FUSED_MX=0 asks for the packed-fp32 kernel
+    // default: the packed-fp32 VALU kernel (vp_fused_up2x.h).  The matrix-core variant (vp_fused_mx.hip) runs when MPCVR_FLAG_FUSED_MFMA
+    // is set, or — with neither flag — when the environment says MPCVR_FUSED_MX=1; it is parity-green but not faster
     static const int mx_default = EnvInt("MPCVR_FUSED_MX", 0);
     if (P.taps_mfma >= 0 ? P.taps_mfma != 0 : mx_default != 0) return LaunchFusedUp2xMx(P, a, knt, frames_dev, single, n_frames, s);
 

@@ -903,6 +903,9 @@ int FusedDoviKind(const FusedParams &P);          // DV_* for the launch
 hipError_t LaunchFusedUp2xMx(const FusedParams &P, const FusedArgs &a, int knt, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
 // dynamic LDS above the default limit needs the function attribute once per kernel (and device); remembered per (kernel, device) (vp_fused_strip.hip)
 hipError_t AllowLargeLds(const void *kern, size_t lds);
+// LDS a workgroup of the current device may claim with that attribute (gfx950: 160 KiB): queried once per device, so a part or
+// partition with less makes the planners fall back at plan time instead of failing at launch; 160 KiB where no device answers
+size_t DeviceLdsLimit();
 // vp_fused_period.hip: the periodic-phase kernel for this strip launch, or hipErrorNotSupported (LaunchFusedStrip then runs k_fused_strip)
 hipError_t LaunchFusedPeriod(const FusedStripParams &S, const FusedArgs &a, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
 // vp_fused_up2x.h, instantiated by vp_fused_up2x_nt{4,5,6}.hip: the packed-fp32 kernel for one tap count

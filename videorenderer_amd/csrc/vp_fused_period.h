@@ -12,7 +12,7 @@
 // X draw -> fp16, Y draw -> UNORM, final pass in integers), and so are the reference's own per-column / per-row WEIGHTS: they come
 // from BuildAxisTaps' tables (FillVertices' fp32 texture coordinates and all), only the tap INDICES are compile-time.
 //
-// One wavefront = one strip of 128 output columns (2 adjacent pixels per lane: one 8-byte store per lane and output row) x one
+// One wavefront = one strip of up to 128 output columns (2 adjacent pixels per lane: one 8-byte store per lane and output row) x one
 // segment of output rows, marching down the source rows two at a time, no workgroup barrier in the loop:
 //   stage C  as in k_fused_strip: lane j converts the 2x2 blocks of the strip's source window, 64 per pass, raw codes of pass 0
 //            prefetched one row pair ahead; the UNORM-rounded values go to this wave's LDS slice A as (row 0, row 1) fp32 pairs,
@@ -38,11 +38,12 @@ struct PeriodArgs {
     const float *yw;                            // Y weights, [out_h][8] (NT used, zero padding), same folding
     const int32_t *xstrip;                      // [n_strips][2] {smallest, largest} source column any tap of the strip reads
     int out_w, out_h, n_strips, seg_rows, acols;
+    int strip_w;                                // output columns per wavefront (even, <= 128): 2 per lane
 };
 
 namespace {
 
-constexpr int kPeriodStripW = 128;              // output columns per wavefront: 2 per lane
+constexpr int kPeriodStripMax = 128;            // output columns per wavefront at most: 2 per lane
 #ifndef MPCVR_PERIOD_THREADS
 #define MPCVR_PERIOD_THREADS 1024
 #endif
@@ -136,9 +137,11 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
     const int nb = ((p_const(Q.xstrip)[2 * strip + 1] - c0) >> 1) + 1, npass = (nb + 63) >> 6;
 
     // stage X / Y role: output columns x_first, x_first + 1
-    const int xs = strip * kPeriodStripW;
+    const int xs = strip * Q.strip_w;
     const int x_first = xs + 2 * lane;
-    const bool xy_active = x_first < Q.out_w;
+    const bool xy_active = 2 * lane < Q.strip_w && x_first < Q.out_w;
+    typedef __attribute__((address_space(3))) const f2 *lds_f2;
+    const uint32_t aw_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)Aw;
     uint32_t xo[2][NT]; f2 xwp[2][NP];
 #pragma unroll
     for (int q = 0; q < 2; q++) {
@@ -148,8 +151,8 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
         for (int k = 0; k < 2 * NP; k++) wq[k] = 0.0f;
 #pragma unroll
         for (int k = 0; k < NT; k++) {
-            xo[q][k] = (uint32_t)(Q.xi_t[xc + (size_t)k * Q.out_w] - c0) * 24u;
-            wq[k] = Q.xw_t[xc + (size_t)k * Q.out_w];
+            xo[q][k] = aw_lds + (uint32_t)(Q.xi_t[xc + (size_t)k * Q.out_w] - c0) * 24u;    // absolute LDS address: one VGPR per tap, the channel as an immediate
+            wq[k] = Q.xw_t[xc + (size_t)k * Q.out_w] * P.inv_maxv;       // A holds UNORM CODES: the 1 / maxv of the texel read is folded into the weight
         }
 #pragma unroll
         for (int k = 0; k < NP; k++) xwp[q][k] = f2{wq[2 * k], wq[2 * k + 1]};
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
 
     const f2 MM[5] = {f2{P.m[0], P.m[1]}, f2{P.m[2], P.m[3]}, f2{P.m[4], P.m[5]}, f2{P.m[6], P.m[7]}, f2{P.m[8], 0.0f}};
     const f2 GG[5] = {f2{P.gamut[0], P.gamut[1]}, f2{P.gamut[2], P.gamut[3]}, f2{P.gamut[4], P.gamut[5]}, f2{P.gamut[6], P.gamut[7]}, f2{P.gamut[8], 0.0f}};
-    const f2 cmax2 = splat(P.maxv), cinv2 = splat(P.inv_maxv);
+    const f2 cmax2 = splat(P.maxv);
     const f2 qmax2 = splat(FASTEPI ? P.maxv : P.quant);          // Y result -> m_TexsPostScale codes (final pass) or the target's own codes
     f2 big2 = splat(8388608.0f);                     // 2^23, pinned in VGPRs (see unorm_round2)
     asm volatile("" : "+v"(big2));
@@ -188,12 +191,12 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
                 fetch(pp, ra, rw);
                 convert_block<TAIL, SRC>(P, MM, GG, CC, rw, sy0, sy1, T, rc);
             }
-            // store to m_TexConvertOutput (UNORM: floor(sat(x)*maxv + 0.5)) and read back (q/maxv to 1 ulp), as (row 0, row 1) pairs
+            // store to m_TexConvertOutput (UNORM: floor(sat(x)*maxv + 0.5)): the integer codes as floats, (row 0, row 1) pairs
             f2 q[2][3];
 #pragma unroll
             for (int col = 0; col < 2; col++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) q[col][c] = unorm_round2(rc[col][c], cmax2, big2) * cinv2;
+                for (int c = 0; c < 3; c++) q[col][c] = unorm_round2(rc[col][c], cmax2, big2);
             if (b < nb) {           // A[column][channel]: the block's two columns are 48 contiguous bytes
                 f4 *dst = (f4 *)(Aw + 48 * b);
                 dst[0] = f4{q[0][0].x, q[0][0].y, q[0][1].x, q[0][1].y};
@@ -205,7 +208,6 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
     // stage X: the X draw's result of the pair in A for the lane's two pixels, rounded through fp16: rowA = row 2pp-1, rowB = row 2pp,
     // [channel] = (px 0, px 1)
     auto stage_x = [&](f2 (&rowA)[3], f2 (&rowB)[3]) __attribute__((always_inline)) {
-        if (!xy_active) return;
         f2 acc[2][3];                                        // [pixel][channel] = (row 0, row 1)
 #pragma unroll
         for (int q = 0; q < 2; q++) {
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
 #pragma unroll
             for (int k = 0; k < NT; k++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) t[k][c] = *(const f2 *)(Aw + xo[q][k] + 8 * c);
+                for (int c = 0; c < 3; c++) t[k][c] = ((lds_f2)(uintptr_t)xo[q][k])[c];
 #pragma unroll
             for (int k = 0; k < NT; k++)
 #pragma unroll
@@ -239,7 +241,8 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
         for (int c = 0; c < 3; c++) win[i][c] = splat(0.0f);
 
     const uint32_t lane_off = (uint32_t)(P.off_x + x_first) * 4u;
-    const bool pair_ok = x_first + 1 < Q.out_w;              // both pixels of the lane exist (odd widths: the last lane stores one)
+    const bool pair_ok = xy_active && x_first + 1 < Q.out_w;              // both pixels of the lane exist (odd widths: the last lane stores one)
+    const bool wave_full = Q.strip_w == kPeriodStripMax && xs + kPeriodStripMax <= Q.out_w;    // (lanes outside the frame filter clamped columns and store nothing)
     const pcptr<f2> ywp = (pcptr<f2>)(uintptr_t)Q.yw;
 
     // output row y = PB*m + r (r static): taps from the window, epilogue, one 8-byte store
@@ -278,13 +281,17 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
             }
         }
         const gptr rowp = pdst + (uint32_t)wy * (uint32_t)P.dst_pitch;
-        if (pair_ok) *(__attribute__((address_space(1))) u32x2 *)(rowp + opaque(lane_off)) = u32x2{pk[0], pk[1]};
-        else *(__attribute__((address_space(1))) uint32_t *)(rowp + lane_off) = pk[0];
+        if (wave_full) {                // wave-uniform: every lane of the strip owns two pixels inside the frame
+            *(__attribute__((address_space(1))) u32x2 *)(rowp + opaque(lane_off)) = u32x2{pk[0], pk[1]};
+        } else if (pair_ok) {           // the frame's last strip: lanes beyond the right edge store nothing, an odd width ends in one pixel
+            *(__attribute__((address_space(1))) u32x2 *)(rowp + lane_off) = u32x2{pk[0], pk[1]};
+        } else if (xy_active) {
+            *(__attribute__((address_space(1))) uint32_t *)(rowp + lane_off) = pk[0];
+        }
     };
     // after source row 6j - 1 + RHO went into slot RHO: every output phase whose last tap it is
     auto emit_after = [&](auto RHOC, int j) __attribute__((always_inline)) {
         constexpr int RHO = decltype(RHOC)::value;
-        if (!xy_active) return;
         auto one = [&](auto RC) __attribute__((always_inline)) {
             constexpr int r = decltype(RC)::value;
             if constexpr (period_rho<NT>(PP, QQ, r) == RHO) emit_row(RC, j + period_delta<NT>(PP, QQ, r));

@@ -41,10 +41,14 @@ bool FusedPeriodTakes(const FusedStripParams &S)
     const int tailk = FusedTailKind(P);
     if (tailk == TAILK_ALU) return false;                         // the literal tails stay with k_fused_strip
     if (S.per_nt < 4 || S.per_nt > 6 || S.per_acols < 2 || (S.per_acols & 1)) return false;
+    if (S.per_strip_w < 2 || S.per_strip_w > kPeriodStripMax || (S.per_strip_w & 1)) return false;
+    // measured (profiles/r03): without a table tail the 4-tap filters run as fast or faster through k_fused_strip (SDR 1080p -> 1440p
+    // Catmull-Rom 120.6 k against 115.4 k frames/s: the convert is light, and that is where the register window pays)
+    if (tailk == TAILK_NONE && S.per_nt == 4 && !S.per_force) return false;
     const uint32_t epi_mul = FinalPassMultiplier(P.store.quant, P.conv.out_fmt == SF_RGB10A2 ? 1023 : 255);
     const int epik = PeriodEpilogue(S, epi_mul);
     if (epik < 0) return false;
-    return PeriodLds(S, epik == EPI_DITHER8, tail_has_table(tailk), 1) <= 160 * 1024;
+    return PeriodLds(S, epik == EPI_DITHER8, tail_has_table(tailk), 1) <= DeviceLdsLimit();
 }
 
 // the same launch contract as LaunchFusedStrip (which calls this first); hipErrorNotSupported = not this kernel's case
@@ -60,7 +64,8 @@ hipError_t LaunchFusedPeriod(const FusedStripParams &S, const FusedArgs &a, cons
     PeriodArgs q{};
     q.xi_t = (const int32_t *)S.per_xi_t; q.xw_t = (const float *)S.per_xw_t; q.yw = (const float *)S.per_yw; q.xstrip = (const int32_t *)S.per_xstrip;
     q.out_w = S.out_w; q.out_h = S.out_h;
-    q.n_strips = (S.out_w + kPeriodStripW - 1) / kPeriodStripW;
+    q.strip_w = S.per_strip_w;
+    q.n_strips = (S.out_w + q.strip_w - 1) / q.strip_w;
     q.acols = S.per_acols;
     // segment height (a multiple of the body's PB output rows): long segments recompute less (the taps' span each), short ones fill the chip
     static const int seg_env = EnvInt("MPCVR_PERIOD_SEG", 0);
@@ -74,10 +79,22 @@ hipError_t LaunchFusedPeriod(const FusedStripParams &S, const FusedArgs &a, cons
     q.seg_rows = seg;
     const int n_segs = (S.out_h + seg - 1) / seg;
     const bool fastepi = epik == EPI_DITHER8, lut = tail_has_table(tailk);
+    // waves per workgroup: the tables exist once per workgroup, the A slice once per wave.  8 measured best where LDS leaves the choice
+    // (up1440: 84.9 k frames/s against 83.2 k at 12 and 78.6 k at 16 — a workgroup's slot frees only when its slowest wave is done, and two
+    // 8-wave workgroups fill a CU's SIMDs like one 16-wave workgroup); wide source windows (downscales) take what puts most waves on a CU
     static const int waves_env = EnvInt("MPCVR_PERIOD_WAVES", 0);
-    int waves = kPeriodMaxThreads / 64;
+    int waves = 8;
     if (waves_env >= 1 && waves_env <= kPeriodMaxThreads / 64) waves = waves_env;
-    while (waves > 1 && PeriodLds(S, fastepi, lut, waves) > 160 * 1024) waves--;
+    else {
+        int best_per_cu = 0;
+        for (int w : {8, 7, 6, 5, 4}) {
+            const size_t l = PeriodLds(S, fastepi, lut, w);
+            if (l > DeviceLdsLimit()) continue;
+            const int per_cu = std::min((int)(DeviceLdsLimit() / l) * w, 16);
+            if (per_cu > best_per_cu) { best_per_cu = per_cu; waves = w; }
+        }
+    }
+    while (waves > 1 && PeriodLds(S, fastepi, lut, waves) > DeviceLdsLimit()) waves--;
     const long items = (long)q.n_strips * n_segs * n_frames;
     if (items < 512L * waves) waves = (int)std::max<long>(1, std::min<long>(waves, items / 512));
     const size_t lds = PeriodLds(S, fastepi, lut, waves);

@@ -23,6 +23,7 @@
 // HBM traffic = the source window once (+ halo rows per segment) + the render target once: nothing in between.
 #include "vp_fused_dev.h"
 
+#include <cstdio>
 #include <map>
 #include <mutex>
 
@@ -432,6 +433,10 @@ bool FusedStripSupported(const FusedStripParams &S)
 {
     const FusedParams &P = S.fp;
     const ConvertParams &c = P.conv;
+    // the last tap of the Y draw saturates to [0, 1] (UNORM targets store that way anyway): an fp16 destination — m_TexsPostScale in front
+    // of the HDR10 tone-mapping step with iTexFormat = 16FLOAT — keeps the filter's over- and undershoot in the reference, so it is not
+    // this kernel's case (k_resize* store fp16 unclamped)
+    if (P.store.mode == ST_SURFACE && P.store.dst_fmt == SF_RGBA16F) return false;
     if (S.surface_mode) {
         if (S.surf.fmt != SF_BGRA8 && S.surf.fmt != SF_RGB10A2 && S.surf.fmt != SF_RGBA16F) return false;
         if (S.mid_h < 1 || S.surf.w < 1 || S.surf.pitch <= 0 || (S.surf.pitch & 3)) return false;
@@ -467,18 +472,36 @@ static size_t StripLds(const FusedStripParams &S, bool fastepi, bool lut, int wa
 static int StripWaves(const FusedStripParams &S, bool fastepi, bool lut)
 {
     static const int env = EnvInt("MPCVR_STRIP_WAVES", 0);
-    if (env >= 1 && env <= 16 && StripLds(S, fastepi, lut, env) <= 160 * 1024) return env;
+    if (env >= 1 && env <= 16 && StripLds(S, fastepi, lut, env) <= DeviceLdsLimit()) return env;
     int best = 1, best_per_cu = 0;
     for (int w : {4, 6, 8, 10, 12, 14, 16}) {
         const size_t lds = StripLds(S, fastepi, lut, w);
-        if (lds > 160 * 1024) break;
-        const int per_cu = std::min((int)((160 * 1024) / lds) * w, 32);
+        if (lds > DeviceLdsLimit()) break;
+        const int per_cu = std::min((int)(DeviceLdsLimit() / lds) * w, 32);
         if (per_cu > best_per_cu) { best_per_cu = per_cu; best = w; }
     }
     return best;
 }
 
 // dynamic LDS above the default limit needs the function attribute once per kernel (and device); remembered per (kernel, device)
+size_t DeviceLdsLimit()
+{
+    static std::mutex mu;
+    static std::map<int, size_t> limit;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 160 * 1024;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = limit.find(dev);
+    if (it != limit.end()) return it->second;
+    int optin = 0, plain = 0;
+    (void)hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, dev);
+    (void)hipDeviceGetAttribute(&plain, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+    const size_t v = (size_t)std::max(std::max(optin, plain), 0);
+    if (EnvInt("MPCVR_LOG", 0) >= 2)
+        std::fprintf(stderr, "mpcvr: device %d LDS per workgroup: opt-in %d B, default %d B\n", dev, optin, plain);
+    return limit[dev] = v >= 32 * 1024 ? v : 160 * 1024;
+}
+
 hipError_t AllowLargeLds(const void *kern, size_t lds)
 {
     static std::mutex mu;

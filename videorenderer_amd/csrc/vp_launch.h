@@ -102,12 +102,14 @@ struct FusedStripParams {
     int surface_mode;
     // periodic-phase variant (vp_fused_period.h; per_P != 0): device copies of PlanFusedPeriod's tables.  LaunchFusedStrip takes it
     // whenever the launch meets its preconditions (fast epilogue, 8-byte aligned rows) and falls back to k_fused_strip otherwise.
-    int per_P, per_Q, per_nt, per_acols;
+    int per_P, per_Q, per_nt, per_acols, per_strip_w;
+    int per_force;             // MPCVR_FLAG_FORCE_PERIOD: also where the planner would prefer k_fused_strip
     const void *per_xi_t, *per_xw_t, *per_yw, *per_xstrip;
 };
 bool FusedStripSupported(const FusedStripParams &S);
 hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
 size_t FusedStripLdsBytes(const FusedStripParams &S);
+size_t DeviceLdsLimit();       // LDS bytes one workgroup may claim on the current device (queried, not assumed)
 // true when LaunchFusedStrip would run the periodic-phase kernel for this launch (GetVPInfo reports it)
 bool FusedPeriodTakes(const FusedStripParams &S);
 

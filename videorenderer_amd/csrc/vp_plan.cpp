@@ -641,7 +641,7 @@ static int PeriodBase(int P, int Q, int r)
     return num >= 0 ? num / den : -((-num + den - 1) / den);
 }
 
-bool PlanFusedPeriod(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x, int n_out_y, int src_w, int src_h, bool fold_q1, PeriodPlan *pp)
+bool PlanFusedPeriod(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x, int n_out_y, int src_w, int src_h, bool fold_q1, PeriodPlan *pp, bool heavy_convert)
 {
     pp->P = pp->Q = 0;
     if (hx.normalise || hy.normalise) return false;                       // interpolation shaders only (ps_convolution normalises)
@@ -682,19 +682,42 @@ bool PlanFusedPeriod(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x
             const int ks = fold_q1 && k > 0 ? k + 1 : k;
             pp->yw[(size_t)y * 8 + k] = (fold_q1 && k == 0) ? hy.w[(size_t)y * nth] + hy.w[(size_t)y * nth + 1] : hy.w[(size_t)y * nth + ks];
         }
-    const int sw = 128;
+    // strip width: a convert pass costs the same whether 33 or 64 of its lanes hold a block, so the width is chosen to fill the passes —
+    // an instruction-count model of one body (three source row pairs): passes x convert + X stage per pair, Y stage + epilogue per row
+    // (counted in the ISA: convert ~230 with a table tail, ~70 without; X ~50 per pair; Y + final pass ~30 per row), per output pixel
+    std::vector<int> clo(n_out_x), chi(n_out_x);
+    for (int x = 0; x < n_out_x; x++) {
+        const auto mm = std::minmax_element(hx.idx.begin() + (size_t)x * nth, hx.idx.begin() + (size_t)(x + 1) * nth);
+        clo[x] = *mm.first; chi[x] = *mm.second;
+        if (clo[x] < 0 || chi[x] >= src_w) return false;
+    }
+    auto blocks_of = [&](int sw) {
+        int max_nb = 0;
+        for (int x0 = 0; x0 < n_out_x; x0 += sw) {
+            const int x1 = std::min(n_out_x, x0 + sw);
+            const int lo = *std::min_element(clo.begin() + x0, clo.begin() + x1), hi = *std::max_element(chi.begin() + x0, chi.begin() + x1);
+            max_nb = std::max(max_nb, ((hi - (lo & ~1)) >> 1) + 1);
+        }
+        return max_nb;
+    };
+    int sw = 128;
+    {
+        double best = 0;
+        const double conv = heavy_convert ? 230.0 : 70.0;
+        for (int lanes = 64; lanes >= 24; lanes--) {
+            const int w = 2 * lanes;
+            const int passes = (blocks_of(w) + 63) / 64;
+            const double cost = (3.0 * (passes * conv + 50.0) + PB * 30.0) / ((double)PB * w);
+            if (best == 0 || cost < best * 0.985) { best = cost; sw = w; }       // a narrower strip must pay for its idle filter lanes by >= 1.5 %
+        }
+    }
+    pp->strip_w = sw;
     const int n_strips = (n_out_x + sw - 1) / sw;
     pp->xstrip.resize(2 * (size_t)n_strips);
     int max_cols = 0;
     for (int s = 0; s < n_strips; s++) {
         const int x0 = s * sw, x1 = std::min(n_out_x, x0 + sw);
-        int lo = src_w, hi = -1;
-        for (int x = x0; x < x1; x++)
-            for (int k = 0; k < nth; k++) {
-                const int i = hx.idx[(size_t)x * nth + k];
-                if (i < 0 || i >= src_w) return false;
-                lo = std::min(lo, i); hi = std::max(hi, i);
-            }
+        const int lo = *std::min_element(clo.begin() + x0, clo.begin() + x1), hi = *std::max_element(chi.begin() + x0, chi.begin() + x1);
         pp->xstrip[2 * s] = lo; pp->xstrip[2 * s + 1] = hi;
         max_cols = std::max(max_cols, (((hi - (lo & ~1)) >> 1) + 1) * 2);
     }

@@ -138,7 +138,8 @@ struct PeriodPlan {
     int P = 0, Q = 0;            // output rows : source rows (4:3, 3:2, 2:3, 1:2); 0 = the tables do not fit the kernel
     int nt = 0;                  // taps per output on both axes as the kernel runs them: 4, 5 (Lanczos3's shared texel folded) or 6
     int acols = 0;               // columns of a converted source row the widest strip needs (even)
-    std::vector<int32_t> xstrip; // [2 * n_strips] {lo, hi} source column per strip of 128 output columns
+    int strip_w = 128;           // output columns per wavefront (even, <= 128): the width whose convert passes are best filled
+    std::vector<int32_t> xstrip; // [2 * n_strips] {lo, hi} source column per strip
     std::vector<int32_t> xi_t;   // [nt][n_out_x] tap-major
     std::vector<float> xw_t;
     std::vector<float> yw;       // [n_out_y][8]: nt weights, zero padding
@@ -146,7 +147,8 @@ struct PeriodPlan {
 // The kernel's tap ROWS are compile-time (base(r) + 6m, vp_fused_period.h): the plan succeeds only when hy's index table is exactly that
 // pattern (clamped to the texture) for one of the supported ratios; hx may be any 4- or 6-tap table.  fold_q1: both tables are
 // Direct3D 11 Lanczos3 tables whose taps 0 and 1 read the same texel (ps_interpolation_lanczos3.hlsl:33-34) — folded to 5 taps.
-bool PlanFusedPeriod(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x, int n_out_y, int src_w, int src_h, bool fold_q1, PeriodPlan *pp);
+// heavy_convert: the convert stage carries a table tail (PQ / HLG -> SDR): its passes weigh ~4x what they do on SDR content
+bool PlanFusedPeriod(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x, int n_out_y, int src_w, int src_h, bool fold_q1, PeriodPlan *pp, bool heavy_convert = true);
 
 // ---- the pass plan of one Process() (DX11VideoProcessor.cpp:3285-3424, shader path) ----
 struct PassPlan {
