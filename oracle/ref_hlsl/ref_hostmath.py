@@ -8,6 +8,7 @@ oracle/_ref/libref_hostmath.so holds, compiled from the text of /root/reference 
   SetDolbyVisionDynamicParams                     DX11VideoProcessor.cpp:953-960    DoViDynamicConstantsBuffer_t
   SpecifyExtendedFormat                           Helper.cpp:1169-1211
   CopyFrameV210                                   Helper.cpp:709-748
+  CopyPlaneAsIs, CopyFrameRGB24 / R210 / RGB48 / BGR48 / BGRA64 / B64A   Helper.cpp:414-483,541-566,600-677,769-787 (interleaved RGB uploads)
 
 The extraction is MECHANICAL, like hlsl2cpp.py's: this file knows where a region starts and ends (an anchor line each) and what
 class members it mentions, not what it computes.  Member functions of CDX11VideoProcessor are cut at the point where the Direct3D
@@ -73,6 +74,14 @@ def generate():
     free_fns = "\n".join([
         _braces(hp, "void CopyFrameV210("),
         _braces(hp, "DXVA2_ExtendedFormat SpecifyExtendedFormat("),
+        # the upload repacks of the interleaved RGB formats (GetCopyPlaneFunction, Helper.cpp:377-412; the plain C versions)
+        _braces(hp, "void CopyPlaneAsIs("),
+        _braces(hp, "void CopyFrameRGB24("),
+        _braces(hp, "void CopyFrameRGB48("),
+        _braces(hp, "void CopyFrameBGR48("),
+        _braces(hp, "void CopyFrameBGRA64("),
+        _braces(hp, "void CopyFrameB64A("),
+        _braces(hp, "void CopyFrameR210("),
     ])
     # member functions, cut where the D3D buffer plumbing starts
     poly = _cut(vp, "PS_DOVI_POLY_CURVE polyCurves[3] = {};", "HRESULT hr;", after=vp.index("CDX11VideoProcessor::SetShaderDoviCurvesPoly()"))
@@ -202,6 +211,20 @@ void ref_copy_frame_v210(unsigned lines, unsigned char* dst, unsigned dst_pitch,
 {{
     CopyFrameV210(lines, dst, dst_pitch, src, src_pitch);
 }}
+// kind: 0 CopyPlaneAsIs, 1 CopyFrameRGB24, 2 CopyFrameR210, 3 CopyFrameRGB48, 4 CopyFrameBGR48, 5 CopyFrameBGRA64, 6 CopyFrameB64A
+// (the order of the oracle's RPK_* codes)
+void ref_copy_frame_rgb(int kind, unsigned lines, unsigned char* dst, unsigned dst_pitch, const unsigned char* src, int src_pitch)
+{{
+    switch (kind) {{
+    case 0: CopyPlaneAsIs(lines, dst, dst_pitch, src, src_pitch); break;
+    case 1: CopyFrameRGB24(lines, dst, dst_pitch, src, src_pitch); break;
+    case 2: CopyFrameR210(lines, dst, dst_pitch, src, src_pitch); break;
+    case 3: CopyFrameRGB48(lines, dst, dst_pitch, src, src_pitch); break;
+    case 4: CopyFrameBGR48(lines, dst, dst_pitch, src, src_pitch); break;
+    case 5: CopyFrameBGRA64(lines, dst, dst_pitch, src, src_pitch); break;
+    case 6: CopyFrameB64A(lines, dst, dst_pitch, src, src_pitch); break;
+    }}
+}}
 }}
 """
     os.makedirs(GEN_DIR, exist_ok=True)
@@ -240,6 +263,7 @@ def lib():
         L.ref_specify_extfmt.restype = C.c_uint
         L.ref_specify_extfmt.argtypes = [C.c_uint, C.c_int, C.c_int, C.c_uint, C.c_uint]
         L.ref_copy_frame_v210.argtypes = [C.c_uint, C.c_void_p, C.c_uint, C.c_void_p, C.c_int]
+        L.ref_copy_frame_rgb.argtypes = [C.c_int, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 

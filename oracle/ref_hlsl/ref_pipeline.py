@@ -5,9 +5,9 @@ what the C++ host and the Direct3D runtime do around the shaders: decode the sam
 constants (DX11VideoProcessor.cpp:3285-3424, :3103-3187, :332-377, :3189-3233, :3048-3101), set viewports and vertex texcoords
 (FillVertices :130-179).  It takes the same orc_params the oracle takes, so a test can run both on one input.
 
-Covered: planar / bi-planar YUV, planar RGB, gray, packed 4:2:2 / 4:4:4 YUV; all chroma modes, HDR tails, Dolby Vision reshaping,
-every scaler incl. Jinc2, rotation / flip, post-scale tone mapping, final pass.  Interleaved RGB samples are not (their only
-arithmetic is the resize, which the other formats exercise).
+Covered: every ColorFormat_t — planar / bi-planar YUV, planar RGB, gray, packed 4:2:2 / 4:4:4 YUV, interleaved RGB (uploaded by the
+reference's own CopyFrame* functions, with and without the convert draw); all chroma modes, HDR tails, Dolby Vision reshaping, every
+scaler incl. Jinc2, rotation / flip, post-scale tone mapping, final pass.
 """
 import ctypes as C
 import os
@@ -44,6 +44,12 @@ _FMT[10] = ("K422", 1, 2, 422, 10, "yuv")     # v210 (CopyFrameV210 -> Y210 text
 _FMT[11] = ("K444", 1, 1, 444, 8, "yuv")      # AYUV  -> R8G8B8A8
 _FMT[12] = ("K444", 1, 4, 444, 10, "yuv")     # Y410  -> R10G10B10A2
 _FMT[13] = ("K444", 1, 2, 444, 16, "yuv")     # Y416  -> R16G16B16A16
+# interleaved RGB (Helper.cpp:344-354): cformat -> (oracle RPK_* = ref_copy_frame_rgb kind, sample bytes per pixel, texture format, CDepth);
+# texture formats: "bgrx8" DXGI_FORMAT_B8G8R8X8/A8_UNORM, "rgb10a2" R10G10B10A2_UNORM, "rgba16" R16G16B16A16_UNORM
+_RGB = {29: (1, 3, "bgrx8", 8), 30: (0, 4, "bgrx8", 8), 31: (0, 4, "bgrx8", 8), 32: (2, 4, "rgb10a2", 10),
+        33: (3, 6, "rgba16", 16), 34: (4, 6, "rgba16", 16), 35: (5, 8, "rgba16", 16), 36: (6, 8, "rgba16", 16)}
+for cf, (_k, _pk, _tf, cd) in _RGB.items():
+    _FMT[cf] = ("RGB", 1, 1, 444, cd, "rgb")
 V_FIRST = (14, 15, 16)                         # YV12 / YV16 / YV24: texV is t1 (Shaders.cpp:159-162), and V is stored first
 
 
@@ -113,6 +119,37 @@ def source_textures(p, frame, pitch):
         a = np.lib.stride_tricks.as_strided(buf[off:], shape=(rows, pit), strides=(pit, 1))[:, :cols * comps * by]
         return np.ascontiguousarray(a).view(dt).reshape(rows, cols, comps) if comps > 1 else np.ascontiguousarray(a).view(dt).reshape(rows, cols)
 
+    if lay == "RGB":
+        # MemCopyToTexSrcVideo (:1213-1252) with the format's upload function (GetCopyPlaneFunction, Helper.cpp:377-412) — the
+        # reference's own CopyFrame* code (libref_hostmath.so) — into a mapped texture row; a bottom-up DIB (negative pitch) is walked
+        # from its last row (:1243-1248).  The row is `width` texels, widened when the sample's pitch makes the reference's loops copy
+        # more pixels than that (they land in the padding of the mapped row).
+        kind, pack, tfmt, _cd = _RGB[p.cformat]
+        tbpp = 8 if tfmt == "rgba16" else 4
+        ap = abs(pitch)
+        row_px = max(w, ap // pack + 1)
+        tp = row_px * tbpp
+        dst = np.zeros(tp * h + 16, np.uint8)
+        src = np.ascontiguousarray(buf)
+        s0 = src.ctypes.data + (pitch * (1 - h) if pitch < 0 else 0)
+        _H().ref_copy_frame_rgb(kind, h, dst.ctypes.data, tp, s0, pitch)
+        rows = np.lib.stride_tricks.as_strided(dst, shape=(h, tp), strides=(tp, 1))[:, :w * tbpp]
+        rows = np.ascontiguousarray(rows)
+        t = np.zeros((h, w, 4), F32)
+        if tfmt == "bgrx8":
+            px = rows.reshape(h, w, 4)
+            t[..., 0] = _unorm(px[..., 2], 255); t[..., 1] = _unorm(px[..., 1], 255); t[..., 2] = _unorm(px[..., 0], 255)
+            t[..., 3] = _unorm(px[..., 3], 255) if p.cformat == 31 else 1.0
+        elif tfmt == "rgb10a2":
+            d = rows.view(np.uint32).reshape(h, w)
+            for k in range(3):
+                t[..., k] = _unorm((d >> (10 * k)) & 0x3ff, 1023)
+            t[..., 3] = _unorm(d >> 30, 3)
+        else:
+            px = rows.view(np.uint16).reshape(h, w, 4)
+            for k in range(4):
+                t[..., k] = _unorm(px[..., k], 65535)
+        return [t, None, None]
     if lay in ("P", "G"):
         shift = 6 if (cdepth == 10 and planes != 2) else 0            # CopyPlane10to16 (Helper.cpp:789-803); P010 is MSB-aligned already
         y = plane(0, h, w, pitch)
@@ -247,15 +284,22 @@ def process(p, frame, pitch, dither=None, background=0, stages=None):
         cbs[2], _ = dovi_curves(p.dovi)
         k5, l2, _, _ = dovi_levels(p.dovi, int(p.hdr_display_max_nits))
         cbs[3] = R.words(k5, np.uint32(l2), F32(0), F32(0))
-    fn, text = R.convert_fn(*convert_args(p))
-    if fn is None:
-        raise RuntimeError("convert shader for this configuration is not built (and /root/reference is not mounted)")
-    conv = _rgba(rh, rw)
-    uv = fill_vertices(p.width, p.height, rect, 0, False)               # CreateVertexBuffer(m_srcWidth, m_srcHeight, m_srcRect) :2042
-    R.draw(fn, texs, conv, _FMT_RT[internal], (0, 0, rw, rh), uv, samplers=[(0, 0), (1, 0)], cbs=cbs)
-    if stages is not None:
-        stages["convert"] = conv.copy()
-        stages["convert_text"] = text
+    # m_PSConvColorData.bEnable (:849-853): interleaved RGB with default brightness / contrast has no convert draw — the source
+    # texture itself feeds the resize / final pass with rSrc = m_srcRect (:3321-3323)
+    enable = (cstype in ("yuv", "gray") or (cstype == "rgb" and lay == "P") or
+              abs(F32(p.brightness) / F32(255)) > F32(1e-4) or abs(F32(p.contrast) - F32(1)) > F32(1e-4))
+    if enable:
+        fn, text = R.convert_fn(*convert_args(p))
+        if fn is None:
+            raise RuntimeError("convert shader for this configuration is not built (and /root/reference is not mounted)")
+        conv = _rgba(rh, rw)
+        uv = fill_vertices(p.width, p.height, rect, 0, False)           # CreateVertexBuffer(m_srcWidth, m_srcHeight, m_srcRect) :2042
+        R.draw(fn, texs, conv, _FMT_RT[internal], (0, 0, rw, rh), uv, samplers=[(0, 0), (1, 0)], cbs=cbs)
+        if stages is not None:
+            stages["convert"] = conv.copy()
+            stages["convert_text"] = text
+    else:
+        conv = texs[0]
 
     # ---- Process :3285-3424 ----
     ww, wh = p.window_w, p.window_h
@@ -263,7 +307,7 @@ def process(p, frame, pitch, dither=None, background=0, stages=None):
     w2, h2 = dst[2] - dst[0], dst[3] - dst[1]
     rt_final = np.zeros((wh, ww, 4), F32)
     rt_final[...] = np.nan                                              # untouched pixels are reported as `background`
-    rsrc = [0, 0, rw, rh]
+    rsrc = [0, 0, rw, rh] if enable else list(rect)
     rot, flip = p.rotation, bool(p.flip)
     k = 2 if p.bInterpolateAt50pct else 1
 

@@ -223,6 +223,10 @@ FULL_SIZE_CASES = {
     "down1080_from_4k_hlg": dict(cformat=2, w=3840, h=2160, kind="noise", seed=315, dst=(1920, 1080), exfmt=HLG, iUpscaling=1),
 }
 
+# the two ColorFormat_t values no other case carries (P216, YUV422P16): with them the reference-text comparison covers all 39 formats
+PINNING_CASES["pin_format_p216_2x"] = dict(cformat=7, w=64, h=32, kind="noise", seed=390, dst=(128, 64), iUpscaling=2, exfmt=ext(matrix=M709))
+PINNING_CASES["pin_format_yuv422p16_down"] = dict(cformat=23, w=128, h=64, kind="noise", seed=391, dst=(48, 24), iDownscaling=2, exfmt=HDR10)
+
 SETTING_KEYS = ("iTexFormat", "iChromaScaling", "iUpscaling", "iDownscaling", "bInterpolateAt50pct",
                 "bUseDither", "bConvertToSdr", "iSDRDisplayNits", "output_format", "flags")
 

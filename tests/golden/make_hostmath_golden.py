@@ -37,6 +37,10 @@ HDR10_CASES = [(0.0, 0.0, 0.0, 0.0, 0.0, 0), (0.005, 1000.0, 800.0, 400.0, 600.0
                (0.01, 4000.0, 0.0, 0.0, 10000.0, 6), (0.5, 11.0, 11.0, 2.0, 10001.0, 1), (50.0, 1200.0, 1100.0, 0.5, 100.0, 5)]
 EXTFMT_CASES = [(ex, cf, w, h) for ex in (0, 0x0288ca500 & 0xffffffff, (5 << 8) | (1 << 12), (4 << 15) | (9 << 22) | (15 << 27), (7 << 8) | (2 << 12) | (2 << 15))
                 for cf, w, h in ((1, 1920, 1080), (2, 720, 576), (2, 1024, 576), (6, 1280, 720), (16, 640, 360), (30, 1920, 1080), (37, 1920, 1080), (20, 1025, 576))]
+# (ref_copy_frame_rgb kind = the oracle's RPK_* code, sample bytes per pixel, texture bytes per pixel, width, lines, bottom-up)
+RGB_COPY_CASES = [(1, 3, 4, 46, 5, 0), (1, 3, 4, 47, 4, 0), (1, 3, 4, 48, 3, 1), (0, 4, 4, 33, 4, 0), (0, 4, 4, 32, 4, 1), (2, 4, 4, 31, 3, 0),
+                  (3, 6, 8, 48, 3, 0), (3, 6, 8, 46, 3, 0), (4, 6, 8, 45, 3, 0), (4, 6, 8, 46, 3, 1), (4, 6, 8, 47, 2, 0), (4, 6, 8, 48, 2, 0),
+                  (5, 8, 8, 19, 3, 0), (6, 8, 8, 20, 3, 1)]
 V210_CASES = [(48, 4), (46, 3), (6, 1), (1280, 2), (1921, 2)]          # (width, lines)
 
 
@@ -73,6 +77,25 @@ def v210_sample(width, lines):
     return rng.integers(0, 2 ** 32, size=pitch * lines // 4, dtype=np.uint32).view(np.uint8), pitch
 
 
+def rgb_sample(kind, pack, width, lines):
+    pitch = (width * pack + 3) & ~3
+    rng = np.random.default_rng(kind * 1009 + width * 31 + lines)
+    return rng.integers(0, 256, size=pitch * lines + 16, dtype=np.uint8), pitch
+
+
+def rgb_copy(fn, kind, pack, tbpp, width, lines, bottom_up):
+    """The upload as MemCopyToTexSrcVideo drives it (:1243-1248): a bottom-up DIB is walked from its last row with a negative pitch;
+    the texture row is wide enough for every pixel the copy loop writes (the oracle's rule, mpcvr_oracle.c setup_convert)."""
+    src, pitch = rgb_sample(kind, pack, width, lines)
+    row_px = max(width, pitch // pack + 1)
+    tp = row_px * tbpp
+    dst = np.zeros(tp * lines + 16, np.uint8)
+    base = src.ctypes.data + (pitch * (lines - 1) if bottom_up else 0)
+    fn(kind, lines, dst.ctypes.data, tp, base, -pitch if bottom_up else pitch)
+    rows = np.lib.stride_tricks.as_strided(dst, shape=(lines, tp), strides=(tp, 1))[:, :width * tbpp]
+    return hashlib.sha256(np.ascontiguousarray(rows).tobytes()).hexdigest()
+
+
 def main():
     L = RH.lib()
     assert L is not None, "the reference tree is not mounted"
@@ -96,6 +119,11 @@ def main():
         dst = np.zeros(tp * lines + 16, np.uint8)
         L.ref_copy_frame_v210(lines, dst.ctypes.data, tp, src.ctypes.data, pitch)
         doc["v210"].append(dict(width=width, lines=lines, pitch=pitch, tex_pitch=int(tp), sha256=hashlib.sha256(dst[:tp * lines].tobytes()).hexdigest()))
+    doc["rgbcopy"] = []
+    for kind, pack, tbpp, width, lines, bu in RGB_COPY_CASES:
+        ref_fn = lambda k, n, d, dp, s_, sp: L.ref_copy_frame_rgb(k, n, d, dp, s_, sp)
+        doc["rgbcopy"].append(dict(kind=kind, pack=pack, tbpp=tbpp, width=width, lines=lines, bottom_up=bu,
+                                   sha256=rgb_copy(ref_fn, kind, pack, tbpp, width, lines, bu)))
     with open(os.path.join(HERE, "hostmath_ref.json"), "w") as f:
         json.dump(doc, f, indent=0, sort_keys=True)
     print("recorded", {k: len(v) for k, v in doc.items() if k != "source"})

@@ -702,6 +702,19 @@ def test_copy_frame_v210_against_reference_code(oracle):
         assert hashlib.sha256(dst[:tp * rec["lines"]].tobytes()).hexdigest() == rec["sha256"], rec
 
 
+def test_rgb_upload_copies_against_reference_code(oracle):
+    """CopyPlaneAsIs / CopyFrameRGB24 / R210 / RGB48 / BGR48 / BGRA64 / B64A (Helper.cpp:414-787, the uploads of the interleaved RGB
+    formats): the oracle's orc_repack_rgb against the reference functions' recorded output — ragged widths (the 4-pixel loops'
+    remainders), bottom-up DIBs."""
+    from tests.golden.make_hostmath_golden import rgb_copy
+    L = oracle.lib()
+    L.orc_repack_rgb.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    fn = lambda k, n, d, dp, s_, sp: L.orc_repack_rgb(k, n, d, dp, s_, sp)
+    for rec in HOSTMATH["rgbcopy"]:
+        got = rgb_copy(fn, rec["kind"], rec["pack"], rec["tbpp"], rec["width"], rec["lines"], rec["bottom_up"])
+        assert got == rec["sha256"], rec
+
+
 def test_hostmath_fixture_is_what_the_reference_code_returns_live():
     """Where oracle/_ref/libref_hostmath.so exists (or can be built from the mounted reference): the recorded fixture is regenerated
     in memory and must be identical — so the pins above are the reference code's, not a stale file."""
@@ -722,3 +735,6 @@ def test_hostmath_fixture_is_what_the_reference_code_returns_live():
         out = (C.c_uint32 * 6)()
         L.ref_hdr10_params(*rec["args"][:5], int(rec["args"][5]), out)
         assert list(out) == rec["words"]
+    ref_fn = lambda k, n, d, dp, s_, sp: L.ref_copy_frame_rgb(k, n, d, dp, s_, sp)
+    for rec in HOSTMATH["rgbcopy"]:
+        assert G.rgb_copy(ref_fn, rec["kind"], rec["pack"], rec["tbpp"], rec["width"], rec["lines"], rec["bottom_up"]) == rec["sha256"]

@@ -84,6 +84,9 @@ def run_product(mpcvr, torch, c, extra_flags=0, host_upload=False):
     return out, info
 
 
+# whole frames (>= 0.4 M pixels): the smallest share of identical channels measured over every such comparison of the suite is 0.99922
+# (profiles/r03/parity_identical_channels.jsonl, MPCVR_PARITY_LOG); the floor is 1 - 2 x (1 - that): twice today's worst fails
+WHOLE_FRAME_FLOOR = 0.9984
 POW_ULPS = 4      # Direct3D's pow is exp2(y * log2 x): with 1-ulp log2 / exp2 the result is off by up to ~0.35 |y log2 x| + 1.5 ulp (4 at x = 1e-4, y = 1/2.2)
 
 
@@ -743,10 +746,10 @@ def test_strip_kernel_whole_frame_vs_oracle(mpcvr, oracle, torch_cuda, label, c)
     want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
     got, info = run_product(mpcvr, torch, c, extra_flags=api.FLAG_NO_PERIOD)
     assert "kernel=fused_strip" in info, info
-    same = compare(got, want, f"{label} [{info}]", min_same=0.99)
+    same = compare(got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
     alt, info_alt = run_product(mpcvr, torch, c, extra_flags=api.FLAG_NO_STRIP)
     assert "kernel=fused_" not in info_alt and info_alt.startswith("passes:convert,resizeX,resizeY"), info_alt
-    same_alt = compare(alt, want, f"{label} [{info_alt}]", min_same=0.99)
+    same_alt = compare(alt, want, f"{label} [{info_alt}]", min_same=WHOLE_FRAME_FLOOR)
     print(f"{label}: identical channels strip {same:.6f}, tiled {same_alt:.6f}  [{info}]")
 
 
@@ -849,7 +852,7 @@ def test_strip_kernel_from_a_surface_whole_frame(mpcvr, oracle, torch_cuda, labe
     want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
     got, info = run_product(mpcvr, torch, c)
     assert "kernel=fused_strip:surface" in info, info
-    same = compare(got, want, f"{label} [{info}]", min_same=0.99)
+    same = compare(got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
     alt, info_alt = run_product(mpcvr, torch, c, extra_flags=api.FLAG_NO_STRIP)
     assert "kernel=" not in info_alt, info_alt
     compare(alt, want, f"{label} [{info_alt}]", exact=True)
@@ -882,12 +885,12 @@ def test_catmull_rom_chroma_block_convert_whole_frame(mpcvr, oracle, torch_cuda,
     got, info = run_product(mpcvr, torch, c)
     ref, info_ref = run_product(mpcvr, torch, c, extra_flags=api.FLAG_NO_FAST_CONVERT)
     if not has_tail(c):
-        same = compare(got, want, f"{label} [{info}]", min_same=0.99)
+        same = compare(got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
         compare(ref, want, f"{label} [{info_ref}]", exact=True)
     else:
         # behind the PQ tail: a channel beyond 1 LSB must be one the oracle itself does not define to a code (compare_behind_tail)
-        compare_behind_tail(oracle, p, frame, pitch, ref, want, f"{label} [{info_ref}]")
-        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]")
+        compare_behind_tail(oracle, p, frame, pitch, ref, want, f"{label} [{info_ref}]", min_same=WHOLE_FRAME_FLOOR)
+        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
     print(f"{label}: identical channels {same:.6f}  [{info}]")
 
 
@@ -921,9 +924,9 @@ def test_planar_422_and_444_on_the_fused_paths(mpcvr, oracle, torch_cuda, label,
     got, info = run_product(mpcvr, torch, c)
     assert path_ok(info, path), info
     if has_tail(c):
-        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]")
+        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
     else:
-        same = compare(got, want, f"{label} [{info}]", min_same=0.99)
+        same = compare(got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
     print(f"{label}: identical channels {same:.6f}  [{info}]")
 
 
@@ -954,9 +957,9 @@ def test_packed_422_on_the_fused_paths(mpcvr, oracle, torch_cuda, label, c, path
     got, info = run_product(mpcvr, torch, c)
     assert path_ok(info, path), info
     if has_tail(c):
-        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]")
+        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
     else:
-        same = compare(got, want, f"{label} [{info}]", min_same=0.99)
+        same = compare(got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
     print(f"{label}: identical channels {same:.6f}  [{info}]")
 
 
@@ -987,9 +990,9 @@ def test_nearest_chroma_on_the_fused_paths(mpcvr, oracle, torch_cuda, label, c, 
     got, info = run_product(mpcvr, torch, c)
     assert path_ok(info, path), info
     if has_tail(c):
-        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]")
+        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
     else:
-        same = compare(got, want, f"{label} [{info}]", min_same=0.99)
+        same = compare(got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
     print(f"{label}: identical channels {same:.6f}  [{info}]")
 
 
@@ -1020,9 +1023,9 @@ def test_packed_444_gray_and_gbrp_on_the_fused_paths(mpcvr, oracle, torch_cuda, 
     got, info = run_product(mpcvr, torch, c)
     assert path_ok(info, path), info
     if has_tail(c):
-        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]")
+        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
     else:
-        same = compare(got, want, f"{label} [{info}]", min_same=0.99)
+        same = compare(got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
     print(f"{label}: identical channels {same:.6f}  [{info}]")
 
 
@@ -1049,10 +1052,10 @@ def test_spline36_extension_vs_oracle(mpcvr, oracle, torch_cuda, label, c, path)
     assert path_ok(info, path), info
     plain, info_plain = run_product(mpcvr, torch, c, extra_flags=api.FLAG_NO_FUSED)
     if has_tail(c):
-        compare_behind_tail(oracle, p, frame, pitch, plain, want, f"{label} [{info_plain}]")
-        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]")
+        compare_behind_tail(oracle, p, frame, pitch, plain, want, f"{label} [{info_plain}]", min_same=WHOLE_FRAME_FLOOR)
+        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
     else:
-        same = compare(got, want, f"{label} [{info}]", min_same=0.99)
+        same = compare(got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
         compare(plain, want, f"{label} [{info_plain}]", exact=True)
     print(f"{label}: identical channels {same:.6f}  [{info}]")
 
@@ -1092,13 +1095,13 @@ def test_full_size_baseline_configs_whole_frame(mpcvr, oracle, torch_cuda, label
     if label == "C1":
         from videorenderer_amd import api
         assert info.startswith("direct:convert+copy")
-        compare(got, want, label, min_same=0.99)              # block convert (FMA contraction): <= 1 LSB
+        compare(got, want, label, min_same=WHOLE_FRAME_FLOOR)              # block convert (FMA contraction): <= 1 LSB
         got, info = run_product(mpcvr, torch_cuda, c, extra_flags=api.FLAG_NO_FAST_CONVERT)
         assert info.startswith("direct:convert+copy")
         compare(got, want, label + " folded", exact=True)     # folded per-pixel kernel, SDR: bit-exact
     else:
         assert info == "fused_up2x"
-        compare(got, want, label, min_same=0.99)
+        compare(got, want, label, min_same=WHOLE_FRAME_FLOOR)
 
 
 @pytest.mark.parametrize("label,c", [
@@ -1123,7 +1126,7 @@ def test_full_size_general_ratio_tiers_agree(mpcvr, torch_cuda, label, c):
         compare(folded, plain, label + " phase table vs per-pixel weights", min_same=0.999)
     else:
         assert np.array_equal(plain, folded), f"{label}: folded kernels differ from the plain ones in {(plain != folded).sum()} bytes"
-    compare(default, plain, label + " default vs plain", min_same=0.99)
+    compare(default, plain, label + " default vs plain", min_same=WHOLE_FRAME_FLOOR)
 
 
 def _random_case(rng):

@@ -54,7 +54,8 @@ def sha(ch):
 
 def test_every_comparable_case_is_pinned():
     assert set(PINS) == set(CASES)
-    assert len(PINS) >= 170
+    assert len(PINS) >= 185
+    assert set(c["cformat"] for c in CASES.values()) == set(range(1, 40))          # every ColorFormat_t (Helper.h:86-127), interleaved RGB included
     for n, p in PINS.items():
         assert p["oracle_max"] == 0 and p["oracle_differing"] == 0.0, (n, p)       # bit-identical to the reference shader text
     assert len(OUTS.files) == 0                                                     # ... so no reference output needs storing
