@@ -827,6 +827,107 @@ def test_period_kernel_batches_equal_single_frames(mpcvr, torch_cuda):
         assert torch.equal(a, b)
 
 
+# ---- instantiation sweeps: every template instantiation of the two headline kernel families is launched by the suite ----
+# (tests/test_kernel_coverage.py checks it against the kernel trace of the suite: a planner typo cannot select a variant nothing ran)
+_SWEEP_TAILS = {"none": (_SDR, 0), "pq": (_PQ, 0), "hlg": (_HLG, 0), "alu": (_PQ, 4)}          # name -> (extfmt, extra flags: 4 = MPCVR_FLAG_NO_LUT)
+_SWEEP_TAPS = {4: dict(iUpscaling=2), 5: dict(iUpscaling=4), 6: dict(iUpscaling=4, flags=1)}   # Catmull-Rom, Lanczos3 (Q1 folded), Lanczos3 fixed
+# (source, epilogue) pairs the launchers instantiate: name -> (cformat, case overrides)
+_SWEEP_UP2X_SRC = {
+    "p01x_dither8": (2, {}), "p01x_direct10": (2, dict(output_format=1, hdr_output_if_tail=1)), "p01x_generic": (2, dict(misalign=1)),
+    "nv12_direct8": (1, {}), "nv12_generic": (1, dict(misalign=1)),
+    "planar16_dither8": (20, {}), "planar8_direct8": (14, {}),
+    "generic_dither8": (8, {}), "generic_generic": (8, dict(misalign=1)),          # Y210: packed 4:2:2 reads its layout at run time
+}
+_SWEEP_PERIOD_SRC = {"p01x_dither8": (2, {}), "p01x_direct10": (2, dict(output_format=1, hdr_output_if_tail=1)), "nv12_direct8": (1, {}),
+                     "generic_dither8": (20, {}), "generic_direct8": (14, {})}
+_SWEEP_PERIOD_GEO = {"4:3": ((48, 30), (64, 40)), "3:2": ((48, 32), (72, 48)), "2:3": ((96, 48), (64, 32)), "1:2": ((96, 48), (48, 24))}
+
+
+def _sweep_case(cformat, over, tail, taps, src_wh, dst_wh, seed):
+    ex, tflags = _SWEEP_TAILS[tail]
+    c = dict(cformat=cformat, w=src_wh[0], h=src_wh[1], kind="noise", seed=seed, dst=dst_wh, exfmt=ex)
+    c.update(_SWEEP_TAPS[taps])
+    c["flags"] = c.get("flags", 0) | tflags
+    if over.get("output_format"):
+        c["output_format"] = 1          # R10G10B10A2 target, no final pass: the straight 10-bit store
+    if over.get("misalign"):            # a window column that is not a multiple of 4: the generic epilogue
+        c["window"] = (dst_wh[0] + 8, dst_wh[1] + 4); c["offset"] = (2, 1)
+    return c
+
+
+def _tiers_agree(mpcvr, torch, c, fast_flags, expect):
+    from videorenderer_amd import api
+    got, info = run_product(mpcvr, torch, c, extra_flags=fast_flags)
+    assert expect in info, (c, info)
+    ref, info_ref = run_product(mpcvr, torch, c, extra_flags=api.FLAG_NO_FUSED)
+    assert info_ref.startswith("passes:"), info_ref
+    if c.get("output_format", 0) == 1:
+        g, r = got.view(np.uint32)[..., 0], ref.view(np.uint32)[..., 0]
+        lim = 5 if internal_is_8bit(c) else 2 if has_tail(c) else 1
+        for sh in (0, 10, 20):
+            d = np.abs(((g >> sh) & 1023).astype(np.int32) - ((r >> sh) & 1023).astype(np.int32))
+            assert d.max() <= lim, (c, info, int(d.max()))
+    else:
+        d = np.abs(got[..., :3].astype(np.int16) - ref[..., :3].astype(np.int16))
+        assert d.max() <= 1, (c, info, int(d.max()), int((d > 1).sum()))        # two GPU tiers of one frame
+        assert np.array_equal(got[..., 3], ref[..., 3])
+
+
+@pytest.mark.parametrize("taps", sorted(_SWEEP_TAPS))
+@pytest.mark.parametrize("tail", sorted(_SWEEP_TAILS))
+def test_sweep_every_fused_up2x_instantiation(mpcvr, torch_cuda, tail, taps):
+    """k_fused_up2x<taps, tail, source, epilogue>: all nine (source, epilogue) pairs the launcher instantiates, per tap count and tail
+    kind, on small frames against the plain kernels of the same frame."""
+    for i, (name, (cf, over)) in enumerate(sorted(_SWEEP_UP2X_SRC.items())):
+        c = _sweep_case(cf, over, tail, taps, (64, 40), (128, 80), 500 + 17 * i + taps)
+        _tiers_agree(mpcvr, torch_cuda, c, 0, "fused_up2x")
+
+
+@pytest.mark.parametrize("taps", sorted(_SWEEP_TAPS))
+@pytest.mark.parametrize("tail", ["none", "pq", "hlg"])
+@pytest.mark.parametrize("ratio", sorted(_SWEEP_PERIOD_GEO))
+def test_sweep_every_fused_period_instantiation(mpcvr, torch_cuda, ratio, tail, taps):
+    """k_fused_period<P, Q, taps, tail, source, epilogue>: the five (source, epilogue) pairs per ratio, tap count and table tail
+    (MPCVR_FLAG_FORCE_PERIOD: the planner's own choice for SDR content with 4 taps is k_fused_strip)."""
+    from videorenderer_amd import api
+    src_wh, dst_wh = _SWEEP_PERIOD_GEO[ratio]
+    for i, (name, (cf, over)) in enumerate(sorted(_SWEEP_PERIOD_SRC.items())):
+        c = _sweep_case(cf, over, tail, taps, src_wh, dst_wh, 700 + 13 * i + taps)
+        _tiers_agree(mpcvr, torch_cuda, c, api.FLAG_FORCE_PERIOD, "kernel=fused_period(rows=" + ratio)
+
+
+_SWEEP_STRIP_SRC = dict(_SWEEP_UP2X_SRC, planar16_generic=(20, dict(misalign=1)), planar8_generic=(14, dict(misalign=1)), p01x_direct10=(2, dict(output_format=1)))
+_SWEEP_STRIP_GEO = {4: ((64, 40), (100, 62), dict(iUpscaling=2)), 6: ((64, 40), (100, 62), dict(iUpscaling=4)),
+                    8: ((208, 104), (80, 40), dict(iDownscaling=2))}          # Hamming 2.6x down: 7 taps -> the 8-tap variant
+
+
+@pytest.mark.parametrize("taps", sorted(_SWEEP_STRIP_GEO))
+@pytest.mark.parametrize("tail", sorted(_SWEEP_TAILS))
+def test_sweep_fused_strip_instantiations(mpcvr, torch_cuda, tail, taps):
+    """k_fused_strip<taps, px per lane, tail, source, epilogue> at a ratio that is no period (1.5625 / 2.6x): every source specialisation
+    with every epilogue it can meet (integer final pass, straight 8- / 10-bit store, the generic store behind a misaligned window
+    column), per tap count and tail kind, against the plain kernels of the same frame."""
+    src_wh, dst_wh, scaler = _SWEEP_STRIP_GEO[taps]
+    for i, (name, (cf, over)) in enumerate(sorted(_SWEEP_STRIP_SRC.items())):
+        ex, tflags = _SWEEP_TAILS[tail]
+        c = dict(cformat=cf, w=src_wh[0], h=src_wh[1], kind="noise", seed=900 + 11 * i + taps, dst=dst_wh, exfmt=ex, flags=tflags, **scaler)
+        if over.get("output_format"):
+            c["output_format"] = 1
+        if over.get("misalign"):
+            c["window"] = (dst_wh[0] + 8, dst_wh[1] + 4); c["offset"] = (3, 1)
+        _tiers_agree(mpcvr, torch_cuda, c, 0, "kernel=fused_strip(")
+
+
+@pytest.mark.parametrize("tail", sorted(_SWEEP_TAILS))
+def test_sweep_wide_block_convert_instantiations(mpcvr, torch_cuda, tail):
+    """k_convert_blocks_wide<tail, source, final> (same-size frames, four 2x2 blocks per lane): P01x and NV12, each into a final pass
+    (10-bit internal format — forced for NV12 — and an 8-bit target) and into a straight store."""
+    ex, tflags = _SWEEP_TAILS[tail]
+    for i, (cf, over) in enumerate(((2, {}), (2, dict(output_format=1)), (1, {}), (1, dict(iTexFormat=10)))):
+        c = dict(cformat=cf, w=256, h=64, kind="noise", seed=960 + i, dst=(256, 64), exfmt=ex, flags=tflags, **over)
+        _tiers_agree(mpcvr, torch_cuda, c, 0, "direct:convert")
+
+
 SURFACE_STRIP = [
     ("r210_1080p_to_1440p", dict(cformat=32, w=1920, h=1080, kind="noise", seed=331, dst=(2560, 1440), iUpscaling=4)),
     ("y216_catmull_chroma_720p_to_1080p_hamming_down_y", dict(cformat=9, iChromaScaling=2, w=1280, h=1440, kind="noise", seed=332, dst=(1920, 1080), iUpscaling=2, iDownscaling=2,

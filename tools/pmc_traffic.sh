@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 W=${1:-c1}; STEPS=${2:-6}; WARM=2
 OUT=gpurun_out/traffic_$W; rm -rf $OUT; mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 5 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o p -- python bench.py --workload $W --steps $STEPS --warmup $WARM --no-cpu-baseline --no-host-path > $OUT/log_$c 2>&1 || tail -2 $OUT/log_$c
+  timeout -k 5 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o p -- python bench.py --workload $W --steps $STEPS --warmup $WARM --settle 0 --no-cpu-baseline --no-host-path > $OUT/log_$c 2>&1 || tail -2 $OUT/log_$c
 done
 python - "$W" "$STEPS" "$WARM" <<'PY'
 import csv, glob, sys, json

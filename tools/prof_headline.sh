@@ -9,7 +9,7 @@ OUT=gpurun_out/$TAG; rm -rf $OUT; mkdir -p $OUT
 # table is then directly comparable with the bench line's kernel_ms_per_launch; a 12-step run reads ~7 % slower, the clocks are still
 # ramping); the counter passes below only need a few dispatches
 FULL="python bench.py --no-cpu-baseline --no-host-path $*"
-BENCH="python bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-host-path $*"
+BENCH="python bench.py --steps 12 --warmup 4 --settle 0 --no-cpu-baseline --no-host-path $*"
 $FULL > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $FULL > $OUT/bench_under_kernel_trace.json 2> $OUT/kt.err
 i=0

@@ -8,11 +8,11 @@ sys.path.insert(0, ROOT)
 import bench
 
 KERNEL_SOURCES = {
-    "c3hdr": ["vp_fused.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
+    "c3hdr": ["vp_fused_up2x.h", "vp_fused.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
     "c1": ["vp_fused.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
     "hdr4k": ["vp_fused.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
-    "up1440": ["vp_fused_strip.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
-    "down1440": ["vp_fused_strip.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
+    "up1440": ["vp_fused_period.h", "vp_fused_period.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
+    "down1440": ["vp_fused_period.h", "vp_fused_period.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
 }
 ALGO = {"c3hdr": 157593600, "c1": 11404800, "hdr4k": 58060800, "up1440": 20966400, "down1440": 39628800}
 
