@@ -132,7 +132,8 @@ def compare_behind_tail(oracle, p, frame, pitch, got, want, name, min_same=0.99)
 def path_ok(info, path):
     """GetVPInfo against an expected prefix; where the prefix names k_fused_strip the periodic-phase kernel (the same launch with the
     vertical window in registers, taken at 4:3 / 3:2 / 2:3 / 1:2) is the planner's choice and counts as well."""
-    return info.startswith(path) or info.startswith(path.replace("kernel=fused_strip(", "kernel=fused_period("))
+    return (info.startswith(path) or info.startswith(path.replace("kernel=fused_strip(", "kernel=fused_period(")) or
+            info.startswith(path.replace("kernel=fused_strip:surface(", "kernel=fused_period:surface(")))
 
 
 def compare(got, want, name, exact=False, min_same=0.99):
@@ -803,6 +804,44 @@ def test_period_kernel_vs_oracle_and_strip_kernel(mpcvr, oracle, torch_cuda, lab
     print(f"PERIOD {label}: identical channels period {same:.6f}, strip {same_alt:.6f}  [{info}]")
 
 
+PERIOD_SURFACE_CASES = [
+    ("dovi_poly_540p_to_720p_lanczos3", dict(cformat=2, w=960, h=540, kind="hdr", seed=431, dst=(1280, 720), iUpscaling=4, exfmt=GOLDEN_CASES["dovi_poly_sdr"]["exfmt"], dovi=dict(kind="poly")), (4, 3, 5)),
+    ("dovi_mmr_l2_1080p_to_720p", dict(cformat=2, w=1920, h=1080, kind="hdr", seed=432, dst=(1280, 720), iUpscaling=2, exfmt=GOLDEN_CASES["dovi_poly_sdr"]["exfmt"],
+                                       dovi=dict(kind="mmr", l2=(100, 600, 1000))), (2, 3, 4)),
+    ("nv12_catmull_chroma_360p_to_540p", dict(cformat=1, w=640, h=360, kind="noise", seed=433, dst=(960, 540), iUpscaling=4, iChromaScaling=2, exfmt=_SDR), (3, 2, 5)),
+    ("p010_pq_catmull_chroma_1080p_to_540p", dict(cformat=2, w=1920, h=1080, kind="noise", seed=434, dst=(960, 540), iUpscaling=2, iChromaScaling=2, exfmt=_PQ), (1, 2, 4)),
+    ("uyvy_catmull_chroma_540p_to_720p_10bit_target", dict(cformat=5, w=960, h=540, kind="noise", seed=435, dst=(1280, 720), iUpscaling=3, iChromaScaling=2, iTexFormat=10, output_format=1, exfmt=_SDR), (4, 3, 4)),
+]
+
+
+@pytest.mark.parametrize("label,c,pqn", PERIOD_SURFACE_CASES)
+def test_period_kernel_from_a_surface(mpcvr, oracle, torch_cuda, label, c, pqn):
+    """k_fused_period<..., SRC_SURFACE>: what its own convert stage does not take — Dolby Vision reshaping, Catmull-Rom chroma, packed
+    4:2:2 with Catmull-Rom chroma — is converted by its own kernel into m_TexConvertOutput and the periodic-phase kernel runs both draws and
+    the final pass from that surface (B8G8R8A8 / R10G10B10A2 texels -> window codes).  Whole frames against the oracle, and against
+    k_fused_strip:surface on the same launch (MPCVR_FLAG_NO_PERIOD)."""
+    torch = torch_cuda
+    from videorenderer_amd import api
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+    got, info = run_product(mpcvr, torch, c)
+    P, Q, nt = pqn
+    assert f"kernel=fused_period:surface(rows={P}:{Q},taps={nt}," in info, info
+    alt, info_alt = run_product(mpcvr, torch, c, extra_flags=api.FLAG_NO_PERIOD)
+    assert "kernel=fused_strip:surface(" in info_alt, info_alt
+    if c.get("output_format", 0) == 1:
+        compare_rgb10(got, want, f"{label} [{info}]", tail=has_tail(c), min_same=0.99)
+        compare_rgb10(alt, want, f"{label} [{info_alt}]", tail=has_tail(c), min_same=0.99)
+        return
+    for out, tag in ((got, info), (alt, info_alt)):
+        if has_tail(c):
+            same, _ = compare_behind_tail(oracle, p, frame, pitch, out, want, f"{label} [{tag}]", min_same=WHOLE_FRAME_FLOOR)
+        else:
+            same = compare(out, want, f"{label} [{tag}]", min_same=WHOLE_FRAME_FLOOR)
+        print(f"PERIOD:SURFACE {label}: identical channels {same:.6f}  [{tag}]")
+
+
 def test_period_kernel_batches_equal_single_frames(mpcvr, torch_cuda):
     """mpcvr_process_batch through the periodic-phase kernel: every frame of a batch equals its single-frame result bit for bit."""
     torch = torch_cuda
@@ -894,6 +933,11 @@ def test_sweep_every_fused_period_instantiation(mpcvr, torch_cuda, ratio, tail, 
     for i, (name, (cf, over)) in enumerate(sorted(_SWEEP_PERIOD_SRC.items())):
         c = _sweep_case(cf, over, tail, taps, src_wh, dst_wh, 700 + 13 * i + taps)
         _tiers_agree(mpcvr, torch_cuda, c, api.FLAG_FORCE_PERIOD, "kernel=fused_period(rows=" + ratio)
+    if tail == "none":      # SRC_SURFACE (no tail of its own): Catmull-Rom chroma puts the convert into its own kernel; 8-bit surface -> straight store, 10-bit -> final pass
+        for i, cf in enumerate((1, 2)):
+            c = _sweep_case(cf, {}, "none", taps, src_wh, dst_wh, 800 + i + taps)
+            c["iChromaScaling"] = 2
+            _tiers_agree(mpcvr, torch_cuda, c, 0, "kernel=fused_period:surface(rows=" + ratio)
 
 
 _SWEEP_STRIP_SRC = dict(_SWEEP_UP2X_SRC, planar16_generic=(20, dict(misalign=1)), planar8_generic=(14, dict(misalign=1)), p01x_direct10=(2, dict(output_format=1)))

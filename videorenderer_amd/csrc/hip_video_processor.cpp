@@ -681,6 +681,7 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         const Surface probe = m_plan.convert ? Surface{nullptr, (int)(w1 * SurfBytesPerPixel(m_plan.internal_fmt)), w1, h1, m_plan.internal_fmt}
                                              : Surface{nullptr, TexPitch(), m_srcWidth, m_srcHeight, RgbTexFmt(*m_srcParams)};
         m_stripSurf = FillStripSurfParams(probe, MakeStore(nullptr, m_windowRect.Width() * 4, m_plan.swap_fmt, true), &sp);
+        m_period = m_stripSurf && FusedPeriodTakes(sp);
     }
     m_planDirty = false;
     UseLane(0);
@@ -1010,6 +1011,7 @@ bool CHipVideoProcessor::FillStripSurfParams(const Surface &src, const StorePara
 {
     *sp = FusedStripParams{};
     sp->fp.store = store;
+    sp->fp.dst_aligned16 = (((uintptr_t)store.dst) & 15) == 0;      // (batches: the caller knows every target of the table and overrides it)
     const int32_t *tab = (const int32_t *)m_stripTab.ptr;
     sp->yrange = tab + m_stripOff[0]; sp->xstrip = tab + m_stripOff[1];
     sp->xi_t = tab + m_stripOff[2]; sp->xw_t = tab + m_stripOff[3];
@@ -1021,6 +1023,11 @@ bool CHipVideoProcessor::FillStripSurfParams(const Surface &src, const StorePara
     sp->surf = src;
     sp->other = m_otherX.ptr && !m_tapsX.other_identity ? (const int32_t *)m_otherX.ptr : nullptr;
     sp->mid_h = m_plan.mid_h;
+    sp->per_P = 0;
+    if (m_periodPlan.P && !(m_cfg.flags & MPCVR_FLAG_NO_PERIOD)) {      // periodic vertical ratio: the register-window kernel reads the surface as well
+        sp->per_P = m_periodPlan.P; sp->per_Q = m_periodPlan.Q; sp->per_nt = m_periodPlan.nt; sp->per_acols = m_periodPlan.acols; sp->per_strip_w = m_periodPlan.strip_w; sp->per_force = 1;
+        sp->per_xi_t = tab + m_periodOff[0]; sp->per_xw_t = tab + m_periodOff[1]; sp->per_yw = tab + m_periodOff[2]; sp->per_xstrip = tab + m_periodOff[3];
+    }
     return FusedStripSupported(*sp) && FusedStripLdsBytes(*sp) <= DeviceLdsLimit();
 }
 
@@ -1275,6 +1282,7 @@ HRESULT CHipVideoProcessor::ProcessBatchLaunches(int n, const FusedFrame *table,
         FusedStripParams ssp{};
         if (m_stripSurf && FillStripSurfParams(cs, final, &ssp)) {
             ssp.surf_stride = m_convBytes;
+            ssp.fp.dst_aligned16 = aligned ? 1 : 0;
             if ((hr = CheckHip(LaunchFusedStrip(ssp, tab, FusedFrame{nullptr, nullptr}, m, m_stream), "k_fused_strip<surface>"))) return hr;
         } else if (m_plan.two_pass && m_firstAxis == 0 && !m_firstSwap && Resize2DSupported(cs, m_tapsX, m_tapsY, final)) {
             b1.frames = tab;
@@ -1478,8 +1486,8 @@ std::string CHipVideoProcessor::GetPathInfo()
     if (!m_srcParams) return "uninitialised";
     if (m_planDirty && UpdatePlan() != MPCVR_S_OK) return "error: " + m_lastError;
     if ((!m_strip && !m_stripSurf) || m_plan.fused_up2x) return m_plan.describe();
-    if (m_strip && m_period)
-        return m_plan.describe() + ";kernel=fused_period(rows=" + std::to_string(m_periodPlan.P) + ":" + std::to_string(m_periodPlan.Q) + ",taps=" + std::to_string(m_periodPlan.nt) + ",px_per_lane=2,strip=" + std::to_string(m_periodPlan.strip_w) + ",window=6 rows in registers)";
+    if ((m_strip || m_stripSurf) && m_period)
+        return m_plan.describe() + (m_strip ? ";kernel=fused_period(rows=" : ";kernel=fused_period:surface(rows=") + std::to_string(m_periodPlan.P) + ":" + std::to_string(m_periodPlan.Q) + ",taps=" + std::to_string(m_periodPlan.nt) + ",px_per_lane=2,strip=" + std::to_string(m_periodPlan.strip_w) + ",window=6 rows in registers)";
     return m_plan.describe() + (m_strip ? ";kernel=fused_strip(taps=" : ";kernel=fused_strip:surface(taps=") + std::to_string(m_stripPlan.nt) + ",px_per_lane=" + std::to_string(m_stripPlan.pxl) +
            ",strip=" + std::to_string(m_stripPlan.strip_w) + ",ring=" + std::to_string(m_stripPlan.ring) + ")";
 }

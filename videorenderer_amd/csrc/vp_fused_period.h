@@ -39,6 +39,9 @@ struct PeriodArgs {
     const int32_t *xstrip;                      // [n_strips][2] {smallest, largest} source column any tap of the strip reads
     int out_w, out_h, n_strips, seg_rows, acols;
     int strip_w;                                // output columns per wavefront (even, <= 128): 2 per lane
+    // SRC_SURFACE: no convert stage — the X draw samples m_TexConvertOutput as another convert kernel wrote it (Dolby Vision, Catmull-Rom
+    // chroma ...: B8G8R8A8 or R10G10B10A2 texels); frame z of a batch reads surf + z * surf_stride (null: FusedFrame::src)
+    const uint8_t *surf; int surf_fmt, surf_pitch, surf_w; size_t surf_stride;
 };
 
 namespace {
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
         const uint64_t v = (uint64_t)q;
         return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
     };
-    const gcptr py = (gcptr)uniform_ptr(frame.src);
+    const gcptr py = (gcptr)uniform_ptr(SRC == SRC_SURFACE && Q.surf ? (const void *)(Q.surf + (size_t)blockIdx.z * Q.surf_stride) : (const void *)frame.src);
     const uint64_t dst_u = uniform_ptr(frame.dst);
     const gptr pdst = (gptr)dst_u;
 
@@ -167,11 +170,27 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
     const f2 CC[3] = {splat(P.c[0]), splat(P.c[1]), splat(P.c[2])};        // (not pinned in VGPRs: the window needs the registers more than the convert stage six moves less)
 
     // raw codes of pass 0 are prefetched one row pair ahead
+    constexpr int YSRC = SRC == SRC_SURFACE ? SRC_GENERIC : SRC;      // (the YUV helpers are not instantiated for a surface)
     RawAddr ra0;
-    make_raw_addr<SRC>(P, min(c0 + 2 * lane, W - 2), ra0);
+    if (SRC != SRC_SURFACE) make_raw_addr<YSRC>(P, min(c0 + 2 * lane, W - 2), ra0);
     Raw rawn;
     auto fetch = [&](int pp, const RawAddr &ra, Raw &r) __attribute__((always_inline)) {
-        load_raw<SRC>(P, py, ra, clampi(2 * pp - 1, 0, H - 1), clampi(2 * pp, 0, H - 1), r);
+        if (SRC != SRC_SURFACE) load_raw<YSRC>(P, py, ra, clampi(2 * pp - 1, 0, H - 1), clampi(2 * pp, 0, H - 1), r);
+    };
+    // SRC_SURFACE: the 2x2 texels of block b of pair pp, [row][column], one dword each (clamp addressing of the draw)
+    uint32_t sraw[2][2];
+    auto fetch_s = [&](int pp, int b, uint32_t (&t)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const gcptr rowp = py + (uint32_t)clampi(2 * pp - 1 + r, 0, H - 1) * (uint32_t)Q.surf_pitch;
+#pragma unroll
+            for (int col = 0; col < 2; col++) t[r][col] = ld_u32(rowp + (uint32_t)min(c0 + 2 * b + col, Q.surf_w - 1) * 4u);
+        }
+    };
+    // texel -> (r, g, b) codes as floats: the integers the UNORM texel holds
+    auto unpack_s = [&](uint32_t t, float (&c3)[3]) __attribute__((always_inline)) {
+        if (Q.surf_fmt == SF_RGB10A2) { c3[0] = (float)(t & 0x3ffu); c3[1] = (float)((t >> 10) & 0x3ffu); c3[2] = (float)((t >> 20) & 0x3ffu); }
+        else { c3[0] = (float)((t >> 16) & 0xffu); c3[1] = (float)((t >> 8) & 0xffu); c3[2] = (float)(t & 0xffu); }      // B8G8R8A8: r = byte 2
     };
 
     // pair pp = source rows 2pp-1, 2pp (rect-relative, clamped to the rect: clamp-to-edge addressing of the draws = replicated rows).
@@ -181,15 +200,35 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
         const int sy0 = P.rect_t + clampi(r0, 0, H - 1), sy1 = P.rect_t + clampi(r0 + 1, 0, H - 1);
         for (int pass = 0; pass < npass; pass++) {
             const int b = pass * 64 + lane;
+            if constexpr (SRC == SRC_SURFACE) {     // no convert stage: the texels are m_TexConvertOutput's own codes
+                uint32_t t[2][2];
+                if (pass == 0) {
+#pragma unroll
+                    for (int r = 0; r < 2; r++) { t[r][0] = sraw[r][0]; t[r][1] = sraw[r][1]; }
+                    fetch_s(pp + 1, lane, sraw);
+                } else fetch_s(pp, b, t);
+                float k[2][2][3];                   // [row][column][channel]
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int col = 0; col < 2; col++) unpack_s(t[r][col], k[r][col]);
+                if (b < nb) {
+                    f4 *dst = (f4 *)(Aw + 48 * b);
+                    dst[0] = f4{k[0][0][0], k[1][0][0], k[0][0][1], k[1][0][1]};
+                    dst[1] = f4{k[0][0][2], k[1][0][2], k[0][1][0], k[1][1][0]};
+                    dst[2] = f4{k[0][1][1], k[1][1][1], k[0][1][2], k[1][1][2]};
+                }
+                continue;
+            }
             f2 rc[2][3];
             if (pass == 0) {
-                convert_block<TAIL, SRC>(P, MM, GG, CC, rawn, sy0, sy1, T, rc);
+                convert_block<TAIL, YSRC>(P, MM, GG, CC, rawn, sy0, sy1, T, rc);
                 fetch(pp + 1, ra0, rawn);
             } else {
                 RawAddr ra; Raw rw;
-                make_raw_addr<SRC>(P, min(c0 + 2 * b, W - 2), ra);
+                make_raw_addr<YSRC>(P, min(c0 + 2 * b, W - 2), ra);
                 fetch(pp, ra, rw);
-                convert_block<TAIL, SRC>(P, MM, GG, CC, rw, sy0, sy1, T, rc);
+                convert_block<TAIL, YSRC>(P, MM, GG, CC, rw, sy0, sy1, T, rc);
             }
             // store to m_TexConvertOutput (UNORM: floor(sat(x)*maxv + 0.5)): the integer codes as floats, (row 0, row 1) pairs
             f2 q[2][3];
@@ -309,7 +348,7 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
     // Software pipeline per pair: X(pp) -> C(pp + 1) -> the rows pair pp completes, so A's LDS write -> read round trip (and the global
     // prefetch behind it) hides behind the Y work.  A is exchanged between the lanes of this wave only: LDS operations of one wave
     // execute in order; the fences keep the compiler from reordering the reads and writes (unrelated, lane by lane).
-    fetch(pp_lo, ra0, rawn);
+    if (SRC == SRC_SURFACE) fetch_s(pp_lo, lane, sraw); else fetch(pp_lo, ra0, rawn);
     stage_c(pp_lo);
     for (int j = j_lo; j <= j_hi; j++) {
         auto pair_step = [&](auto IC) __attribute__((always_inline)) {
@@ -357,6 +396,12 @@ hipError_t LaunchFusedPeriodPQ(const FusedArgs &a, const PeriodArgs &q, int nt, 
         else MPCVR_PD5(NT, TK, SRC_GENERIC, EPI_DIRECT8); } while (0)
 #define MPCVR_PD2(NT) do { if (tailk == TAILK_NONE) MPCVR_PD3(NT, TAILK_NONE); else if (tailk == TAILK_PQ_LUT) MPCVR_PD3(NT, TAILK_PQ_LUT); \
                            else if (tailk == TAILK_HLG) MPCVR_PD3(NT, TAILK_HLG); else return hipErrorNotSupported; } while (0)
+    if (srck == SRC_SURFACE) {      // the convert output of another kernel: no tail, both epilogues
+#define MPCVR_PDS(NT) do { if (epik == EPI_DITHER8) MPCVR_PD5(NT, TAILK_NONE, SRC_SURFACE, EPI_DITHER8); else MPCVR_PD5(NT, TAILK_NONE, SRC_SURFACE, EPI_DIRECT8); } while (0)
+        if (nt == 4) MPCVR_PDS(4); else if (nt == 5) MPCVR_PDS(5); else if (nt == 6) MPCVR_PDS(6); else return hipErrorNotSupported;
+#undef MPCVR_PDS
+        return hipGetLastError();
+    }
 #ifdef MPCVR_PERIOD_DEV_ONLY
 #ifndef MPCVR_PERIOD_DEV_NT
 #define MPCVR_PERIOD_DEV_NT 5

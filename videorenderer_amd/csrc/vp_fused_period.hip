@@ -20,8 +20,9 @@ int PeriodEpilogue(const FusedStripParams &S, uint32_t epi_mul)
     const bool inside = st.off_x >= 0 && st.off_y >= 0 && (st.clip_w <= 0 || (st.off_x + S.out_w <= st.clip_w && st.off_y + S.out_h <= st.clip_h));
     // one 8-byte store and one 8-byte dither read per lane and row: even window column, 8-byte aligned rows and targets
     if (!inside || (st.off_x & 1) || (st.dst_pitch & 7) || !P.dst_aligned16) return -1;
-    if (st.mode == ST_FINAL && st.dst_fmt == SF_BGRA8 && st.quant == 255 && epi_mul != 0 && P.conv.out_fmt == SF_RGB10A2 && st.mid_fmt == SF_RGB10A2) return EPI_DITHER8;
-    if (st.mode == ST_SURFACE && (st.dst_fmt == SF_BGRA8 || st.dst_fmt == SF_RGB10A2) && st.dst_fmt == P.conv.out_fmt) return EPI_DIRECT8;
+    const int in_fmt = S.surface_mode ? S.surf.fmt : P.conv.out_fmt;        // format of m_TexConvertOutput (its UNORM scale is the window's)
+    if (st.mode == ST_FINAL && st.dst_fmt == SF_BGRA8 && st.quant == 255 && epi_mul != 0 && in_fmt == SF_RGB10A2 && st.mid_fmt == SF_RGB10A2) return EPI_DITHER8;
+    if (st.mode == ST_SURFACE && (st.dst_fmt == SF_BGRA8 || st.dst_fmt == SF_RGB10A2) && st.dst_fmt == in_fmt) return EPI_DIRECT8;
     return -1;
 }
 
@@ -34,18 +35,21 @@ size_t PeriodLds(const FusedStripParams &S, bool fastepi, bool lut, int waves)
 
 bool FusedPeriodTakes(const FusedStripParams &S)
 {
-    if (!S.per_P || S.surface_mode || !S.per_xi_t || !S.per_xw_t || !S.per_yw || !S.per_xstrip) return false;
+    if (!S.per_P || !S.per_xi_t || !S.per_xw_t || !S.per_yw || !S.per_xstrip) return false;
     static const int off = EnvInt("MPCVR_NO_PERIOD", 0);
     if (off) return false;
     const FusedParams &P = S.fp;
-    const int tailk = FusedTailKind(P);
+    // surface mode (the convert output of another kernel feeds the X draw): UNORM texels read row for row — an interleaved RGB sample
+    // with a source rect (row map) or an fp16 internal format stays with k_fused_strip
+    if (S.surface_mode && (S.other || (S.surf.fmt != SF_BGRA8 && S.surf.fmt != SF_RGB10A2) || (S.surf.pitch & 3))) return false;
+    const int tailk = S.surface_mode ? TAILK_NONE : FusedTailKind(P);
     if (tailk == TAILK_ALU) return false;                         // the literal tails stay with k_fused_strip
     if (S.per_nt < 4 || S.per_nt > 6 || S.per_acols < 2 || (S.per_acols & 1)) return false;
     if (S.per_strip_w < 2 || S.per_strip_w > kPeriodStripMax || (S.per_strip_w & 1)) return false;
     // measured (profiles/r03): without a table tail the 4-tap filters run as fast or faster through k_fused_strip (SDR 1080p -> 1440p
     // Catmull-Rom 120.6 k against 115.4 k frames/s: the convert is light, and that is where the register window pays)
-    if (tailk == TAILK_NONE && S.per_nt == 4 && !S.per_force) return false;
-    const uint32_t epi_mul = FinalPassMultiplier(P.store.quant, P.conv.out_fmt == SF_RGB10A2 ? 1023 : 255);
+    if (!S.surface_mode && tailk == TAILK_NONE && S.per_nt == 4 && !S.per_force) return false;
+    const uint32_t epi_mul = FinalPassMultiplier(P.store.quant, (S.surface_mode ? S.surf.fmt : P.conv.out_fmt) == SF_RGB10A2 ? 1023 : 255);
     const int epik = PeriodEpilogue(S, epi_mul);
     if (epik < 0) return false;
     return PeriodLds(S, epik == EPI_DITHER8, tail_has_table(tailk), 1) <= DeviceLdsLimit();
@@ -56,10 +60,10 @@ hipError_t LaunchFusedPeriod(const FusedStripParams &S, const FusedArgs &a, cons
 {
     if (!FusedPeriodTakes(S)) return hipErrorNotSupported;
     const FusedParams &P = S.fp;
-    const int tailk = FusedTailKind(P), srck0 = FusedSourceKind(P);
+    const int tailk = S.surface_mode ? TAILK_NONE : FusedTailKind(P), srck0 = S.surface_mode ? SRC_SURFACE : FusedSourceKind(P);
     const int epik = PeriodEpilogue(S, a.epi_mul);
-    // built source specialisations: P01x and NV12; everything else reads its layout at run time
-    const int srck = (srck0 == SRC_P01X || (srck0 == SRC_NV12 && epik == EPI_DIRECT8)) ? srck0 : SRC_GENERIC;
+    // built source specialisations: P01x and NV12 (and a surface); everything else reads its layout at run time
+    const int srck = (srck0 == SRC_SURFACE || srck0 == SRC_P01X || (srck0 == SRC_NV12 && epik == EPI_DIRECT8)) ? srck0 : SRC_GENERIC;
     const int PB = 6 * S.per_P / S.per_Q;
     PeriodArgs q{};
     q.xi_t = (const int32_t *)S.per_xi_t; q.xw_t = (const float *)S.per_xw_t; q.yw = (const float *)S.per_yw; q.xstrip = (const int32_t *)S.per_xstrip;
@@ -67,6 +71,10 @@ hipError_t LaunchFusedPeriod(const FusedStripParams &S, const FusedArgs &a, cons
     q.strip_w = S.per_strip_w;
     q.n_strips = (S.out_w + q.strip_w - 1) / q.strip_w;
     q.acols = S.per_acols;
+    if (S.surface_mode) {
+        q.surf = n_frames > 1 || !single.src ? (const uint8_t *)S.surf.ptr : nullptr;      // a batch reads surf + z * stride; one frame: single.src
+        q.surf_fmt = S.surf.fmt; q.surf_pitch = S.surf.pitch; q.surf_w = S.surf.w; q.surf_stride = S.surf_stride;
+    }
     // segment height (a multiple of the body's PB output rows): long segments recompute less (the taps' span each), short ones fill the chip
     static const int seg_env = EnvInt("MPCVR_PERIOD_SEG", 0);
     int seg = seg_env;

@@ -534,7 +534,7 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
         a.dither = P.store.dither;
         a.H = S.mid_h; a.W = S.surf.w;
     } else FillFusedArgs(P, a);
-    if (S.per_P && !S.surface_mode) {       // a periodic vertical ratio: the register-window kernel when the launch meets its preconditions
+    if (S.per_P) {       // a periodic vertical ratio: the register-window kernel when the launch meets its preconditions
         const hipError_t ep = LaunchFusedPeriod(S, a, frames_dev, single, n_frames, s);
         if (ep != hipErrorNotSupported) return ep;
     }
