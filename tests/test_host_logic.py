@@ -488,6 +488,9 @@ def _period_base(P, Q, r):
     (1, 3840, 2160, 1920, 1080, (1, 2, 4)),       # 4K -> 1080p Mitchell at exactly 50 %
     (3, 2560, 1440, 3840, 2160, (3, 2, 4)),       # 1440p -> 4K Lanczos2
     (6, 1920, 1080, 2560, 1440, (4, 3, 6)),       # Spline36 extension: six distinct texels
+    (4, 1280, 720, 3840, 2160, (3, 1, 5)),        # 720p -> 2160p: every third row exactly on a texel centre (period_centre)
+    (2, 640, 360, 1920, 1080, (3, 1, 4)),
+    (4, 640, 480, 1920, 1440, (3, 1, 5)),
     (2, 1919, 1080, 2559, 1440, (4, 3, 4)),       # the rows decide: any width rides along
 ])
 def test_period_plan_matches_the_tap_tables(mpcvr, method, sw, sh, dw, dh, want):
@@ -502,12 +505,21 @@ def test_period_plan_matches_the_tap_tables(mpcvr, method, sw, sh, dw, dh, want)
     I, W, _ = api.plan_axis_taps(1, method, 0, sh, dh, sh)
     n = len(I[0])
     off = {4: [-1, 0, 1, 2], 5: [-2, -2, 0, 1, 2, 3], 6: [-2, -1, 0, 1, 2, 3]}[nt]
+    below = pp["yw"][::PB, 7].copy().view(np.uint32)      # per body: bit r = row PB*m + r reads one source row lower (centre rows, 3:1)
+    n_below = 0
     for y in range(dh):
-        base = 6 * (y // PB) + _period_base(P, Q, y % PB)
+        r = y % PB
+        centre = ((2 * r + 1) * Q - P) % (2 * P) == 0
+        low = int(below[y // PB] >> r) & 1
+        assert centre or not low
+        n_below += low
+        base = 6 * (y // PB) + _period_base(P, Q, r) - low
         assert [min(max(base + o, 0), sh - 1) for o in off] == list(I[y])
         w = list(W[y])
         folded = [np.float32(w[0]) + np.float32(w[1])] + w[2:] if nt == 5 else w
-        assert np.array_equal(np.asarray(folded, np.float32), pp["yw"][y, :nt]) and not pp["yw"][y, nt:].any()
+        assert np.array_equal(np.asarray(folded, np.float32), pp["yw"][y, :nt]) and not pp["yw"][y, nt:7].any()
+        assert r == 0 or pp["yw"][y, 7] == 0
+    assert (P, Q) == (3, 1) or n_below == 0
     IX, WX, _ = api.plan_axis_taps(1, method, 0, sw, dw, sw)
     for x in (0, 1, dw // 2, dw - 1):
         ix = list(IX[x]); wx = list(WX[x])

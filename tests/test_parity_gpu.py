@@ -773,13 +773,18 @@ PERIOD_CASES = [
     ("p010_pq_spline36_ext_540p_to_720p", dict(cformat=2, w=960, h=540, kind="noise", seed=411, dst=(1280, 720), iUpscaling=6, exfmt=_PQ), (4, 3, 6)),
     ("p210_pq_360p_to_540p_lanczos3", dict(cformat=6, w=640, h=360, kind="noise", seed=412, dst=(960, 540), iUpscaling=4, exfmt=_PQ), (3, 2, 5)),
     ("tiny_p010_48x30_to_64x40", dict(cformat=2, w=48, h=30, kind="noise", seed=413, dst=(64, 40), iUpscaling=4, exfmt=_PQ), (4, 3, 5)),
+    # 3:1 — every third output row sits exactly on a texel centre and the fp32 texcoord picks its tap rows (period_centre)
+    ("p010_pq_360p_to_1080p_lanczos3", dict(cformat=2, w=640, h=360, kind="noise", seed=414, dst=(1920, 1080), iUpscaling=4, exfmt=_PQ), (3, 1, 5)),
+    ("nv12_240p_to_720p_catmull_direct8", dict(cformat=1, w=426, h=240, kind="noise", seed=415, dst=(1278, 720), iUpscaling=2, exfmt=_SDR), (3, 1, 4)),
+    ("p010_hlg_360p_to_1080p_lanczos3_fixed", dict(cformat=2, w=640, h=360, kind="noise", seed=416, dst=(1920, 1080), iUpscaling=4, flags=1, exfmt=_HLG), (3, 1, 6)),
+    ("p010_pq_720p_to_2160p_lanczos3", dict(cformat=2, w=1280, h=720, kind="noise", seed=417, dst=(3840, 2160), iUpscaling=4, exfmt=_PQ), (3, 1, 5)),
 ]
 
 
 @pytest.mark.parametrize("label,c,pqn", PERIOD_CASES)
 def test_period_kernel_vs_oracle_and_strip_kernel(mpcvr, oracle, torch_cuda, label, c, pqn):
     """The periodic-phase fused kernel (k_fused_period: the vertical window in registers, compile-time tap rows) at every ratio it is
-    built for (4:3, 3:2, 2:3, 1:2), 4 / 5 / 6 taps, the three table tails, both epilogues (integer final pass, straight UNORM store incl.
+    built for (4:3, 3:2, 2:3, 1:2, 3:1), 4 / 5 / 6 taps, the three table tails, both epilogues (integer final pass, straight UNORM store incl.
     R10G10B10A2), an odd width inside a larger window, a frame smaller than one strip: whole frames against the oracle (<= 1 LSB), and
     against k_fused_strip on the same launch (MPCVR_FLAG_NO_PERIOD), which reads the same tables at run time — the two may differ only
     where an FMA contracts differently, so their outputs are held to <= 1 LSB of each other too."""
@@ -879,7 +884,7 @@ _SWEEP_UP2X_SRC = {
 }
 _SWEEP_PERIOD_SRC = {"p01x_dither8": (2, {}), "p01x_direct10": (2, dict(output_format=1, hdr_output_if_tail=1)), "nv12_direct8": (1, {}),
                      "generic_dither8": (20, {}), "generic_direct8": (14, {})}
-_SWEEP_PERIOD_GEO = {"4:3": ((48, 30), (64, 40)), "3:2": ((48, 32), (72, 48)), "2:3": ((96, 48), (64, 32)), "1:2": ((96, 48), (48, 24))}
+_SWEEP_PERIOD_GEO = {"4:3": ((48, 30), (64, 40)), "3:2": ((48, 32), (72, 48)), "2:3": ((96, 48), (64, 32)), "1:2": ((96, 48), (48, 24)), "3:1": ((32, 16), (96, 48))}
 
 
 def _sweep_case(cformat, over, tail, taps, src_wh, dst_wh, seed):

@@ -25,6 +25,8 @@ CASES = [("C1 1080p NV12 BT.709 -> 1080p BGRA8 (no resize)", 1920, 1080, 1920, 1
          ("4K P010 PQ -> 1080p (Hamming down 2x) -> SDR", 3840, 2160, 1920, 1080, dict(iDownscaling=2)),
          ("4K NV12 BT.709 -> 1080p (Bicubic down 2x)", 3840, 2160, 1920, 1080, dict(iDownscaling=3), 1, dict(chroma=5, nominal_range=2, matrix=1)),
          ("1080p P010 PQ -> 1440p (Lanczos3 1.33x) -> SDR", 1920, 1080, 2560, 1440, dict(iUpscaling=4)),
+         ("720p P010 PQ -> 2160p (Lanczos3 3x) -> SDR", 1280, 720, 3840, 2160, dict(iUpscaling=4)),
+         ("720p NV12 BT.709 -> 2160p (Lanczos3 3x)", 1280, 720, 3840, 2160, dict(iUpscaling=4), 1, dict(chroma=5, nominal_range=2, matrix=1)),
          ("1080p P010 PQ -> 4K (Lanczos3 2x), pass-per-kernel", 1920, 1080, 3840, 2160, dict(iUpscaling=4, flags=api.FLAG_NO_FUSED)),
          ("1080p P010 PQ -> 4K (Lanczos3 2x), fused", 1920, 1080, 3840, 2160, dict(iUpscaling=4)),
          ("1080p P010 PQ -> 4K (Jinc2m)", 1920, 1080, 3840, 2160, dict(iUpscaling=5)),

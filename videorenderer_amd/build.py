@@ -35,6 +35,7 @@ SOURCES = [
     ("vp_fused_period_3_2.hip", []),
     ("vp_fused_period_2_3.hip", []),
     ("vp_fused_period_1_2.hip", []),
+    ("vp_fused_period_3_1.hip", []),
     ("vp_jinc.hip", []),
 ]
 

@@ -123,6 +123,12 @@ template <int HALF, bool CLAMP>
 __device__ __forceinline__ f2 pk_fma_w(f2 w, f2 b, f2 c)
 {
     f2 r;
+#ifdef MPCVR_NO_PK      // experiment (tools/build_nopk.sh): the same FMAs one at a time, so that nothing packed sits beside the MFMAs
+    const float ws = HALF == 0 ? w.x : w.y;
+    r = f2{__builtin_fmaf(ws, b.x, c.x), __builtin_fmaf(ws, b.y, c.y)};
+    if (CLAMP) r = f2{__builtin_amdgcn_fmed3f(r.x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(r.y, 0.0f, 1.0f)};
+    return r;
+#endif
     if (HALF == 0) {
         if (CLAMP) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] clamp" : "=v"(r) : "s"(w), "v"(b), "v"(c));
         else       asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "s"(w), "v"(b), "v"(c));
@@ -136,6 +142,9 @@ template <int HALF>
 __device__ __forceinline__ f2 pk_mul_w(f2 w, f2 b)
 {
     f2 r;
+#ifdef MPCVR_NO_PK
+    return f2{(HALF == 0 ? w.x : w.y) * b.x, (HALF == 0 ? w.x : w.y) * b.y};
+#endif
     if (HALF == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "s"(w), "v"(b));
     else           asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "s"(w), "v"(b));
     return r;
@@ -379,6 +388,9 @@ template <int HALF>
 __device__ __forceinline__ f2 pk_fma_wv(f2 w, f2 b, f2 c)
 {
     f2 r;
+#ifdef MPCVR_NO_PK
+    return f2{__builtin_fmaf(HALF == 0 ? w.x : w.y, b.x, c.x), __builtin_fmaf(HALF == 0 ? w.x : w.y, b.y, c.y)};
+#endif
     if (HALF == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(w), "v"(b), "v"(c));
     else           asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(w), "v"(b), "v"(c));
     return r;

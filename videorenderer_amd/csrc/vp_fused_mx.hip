@@ -37,6 +37,9 @@ constexpr float SX = 4096.0f, SY = 64.0f;
 __device__ __forceinline__ f2 pk_mul_clamp(f2 a, f2 b)
 {
     f2 r;
+#ifdef MPCVR_NO_PK
+    return f2{__builtin_amdgcn_fmed3f(a.x * b.x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(a.y * b.y, 0.0f, 1.0f)};
+#endif
     asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }

@@ -1,4 +1,4 @@
-// vp_fused_period.h — the fused path for the everyday RATIONAL ratios (4:3, 3:2, 2:3, 1:2 on the vertical axis; any ratio along
+// vp_fused_period.h — the fused path for the everyday RATIONAL ratios (4:3, 3:2, 2:3, 1:2, 3:1 on the vertical axis; any ratio along
 // the rows): convert -> X draw -> Y draw -> final pass in ONE kernel, the vertical window in REGISTERS.
 //
 // The reference runs every geometry through the same draws (ResizeShaderPass, DX11VideoProcessor.cpp:3103-3187); the exact-2x
@@ -35,7 +35,7 @@ namespace mpcvr {
 
 struct PeriodArgs {
     const int32_t *xi_t; const float *xw_t;     // X taps, tap-major [NT][out_w]; Lanczos3's shared texel (quirk Q1) folded: 5 taps
-    const float *yw;                            // Y weights, [out_h][8] (NT used, zero padding), same folding
+    const float *yw;                            // Y weights, [out_h][8] (NT used, zero padding), same folding; 3:1: slot 7 of a body's first row = its centre-row bits
     const int32_t *xstrip;                      // [n_strips][2] {smallest, largest} source column any tap of the strip reads
     int out_w, out_h, n_strips, seg_rows, acols;
     int strip_w;                                // output columns per wavefront (even, <= 128): 2 per lane
@@ -60,11 +60,27 @@ __host__ __device__ constexpr int period_base(int P, int Q, int r)
 }
 __host__ __device__ constexpr int mod6(int v) { return ((v % 6) + 6) % 6; }
 template <int NT> __host__ __device__ constexpr int tap_hi() { return NT == 4 ? 2 : 3; }
-// output phase r is emitted right after the source row in slot period_rho (its last tap) went in; it belongs to period j + delta
-template <int NT> __host__ __device__ constexpr int period_rho(int P, int Q, int r) { return mod6(1 + period_base(P, Q, r) + tap_hi<NT>()); }
-template <int NT> __host__ __device__ constexpr int period_delta(int P, int Q, int r)
+// output phase r is emitted right after the source row in slot period_rho (its last tap) went in; it belongs to period j + delta.
+// sh = 1: the same phase one source row lower (period_centre rows whose fp32 texcoord fell below the texel centre)
+template <int NT> __host__ __device__ constexpr int period_rho(int P, int Q, int r, int sh = 0) { return mod6(1 + period_base(P, Q, r) - sh + tap_hi<NT>()); }
+template <int NT> __host__ __device__ constexpr int period_delta(int P, int Q, int r, int sh = 0)
 {
-    return (period_rho<NT>(P, Q, r) - 1 - period_base(P, Q, r) - tap_hi<NT>()) / 6;      // exact: 0, -1 (or -2)
+    return (period_rho<NT>(P, Q, r, sh) - 1 - (period_base(P, Q, r) - sh) - tap_hi<NT>()) / 6;      // exact: 0, -1 (or -2)
+}
+// P and Q both odd (3:1): phase r sits EXACTLY on a texel centre n — pos = (r + .5) Q / P - .5 is an integer — and the reference's fp32
+// texcoord decides row by row whether the shader reads base n at t = 0 or base n - 1 at t = 1 - eps.  Both emissions are compiled in;
+// the planner's bit per row (PeriodArgs::yw, slot 7 of each body's first row) picks one
+__host__ __device__ constexpr bool period_centre(int P, int Q, int r) { return ((2 * r + 1) * Q - P) % (2 * P) == 0; }
+__host__ __device__ constexpr bool period_has_centres(int P, int Q) { return (P & 1) && (Q & 1); }
+// lowest base (relative to 6m) any phase of a body reads from, the lowered centre rows included
+__host__ __device__ constexpr int period_low_base(int P, int Q)
+{
+    int lo = period_base(P, Q, 0);
+    for (int r = 0; r < 6 * P / Q; r++) {
+        const int b = period_base(P, Q, r) - (period_centre(P, Q, r) ? 1 : 0);
+        lo = b < lo ? b : lo;
+    }
+    return lo;
 }
 
 template <typename T> using pcptr = const __attribute__((address_space(4))) T *;
@@ -96,6 +112,7 @@ template <int PP, int QQ, int NT, int TAIL, int SRC, int EPI>
 __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P, PeriodArgs Q, const FusedFrame *__restrict__ frames, FusedFrame single)
 {
     static_assert(6 % QQ == 0 && (6 * PP) % QQ == 0, "a body of six source rows must hold whole periods");
+    static_assert(6 * PP / QQ <= 32, "one word of centre-row bits per body");
     static_assert(EPI == EPI_DITHER8 || EPI == EPI_DIRECT8, "the generic epilogue stays with k_fused_strip");
     constexpr int PB = 6 * PP / QQ;                 // output rows per body
     constexpr int NP = (NT + 1) / 2;                // weight pairs
@@ -285,10 +302,12 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
     const pcptr<f2> ywp = (pcptr<f2>)(uintptr_t)Q.yw;
 
     // output row y = PB*m + r (r static): taps from the window, epilogue, one 8-byte store
-    auto emit_row = [&](auto RC, int m) __attribute__((always_inline)) {
-        constexpr int r = decltype(RC)::value;
+    auto emit_row = [&](auto RC, auto SHC, int m, uint32_t below) __attribute__((always_inline)) {
+        constexpr int r = decltype(RC)::value, SH = decltype(SHC)::value;
         const int y = PB * m + r;
         if (y < y0 || y >= y1) return;                                 // wave-uniform: rows of the neighbouring segments
+        if constexpr (period_centre(PP, QQ, r))                        // (wave-uniform) the other emission of this phase draws the row
+            if (((below >> r) & 1u) != (uint32_t)SH) return;
         const pcptr<f2> wr = ywp + (size_t)y * 4;
         const f2 WP[3] = {wr[0], wr[1], wr[2]};
         const int wy = P.off_y + y;
@@ -298,7 +317,7 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
             dj[0] = dd.x; dj[1] = dd.y;
         }
         f2 res[3];
-        constexpr int base = period_base(PP, QQ, r);
+        constexpr int base = period_base(PP, QQ, r) - SH;
         tapsN<NT, true, 3>([&](int) -> const f2 (&)[3] { return WP; },
                            [&](int c, int tt) { return win[mod6(base + tap_off<NT>(tt) + 1)][c]; }, res);
         f2 uq[3];
@@ -329,18 +348,33 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
         }
     };
     // after source row 6j - 1 + RHO went into slot RHO: every output phase whose last tap it is
+    // below_cur / below_prev: the centre-row bits of bodies j and j - 1 (period_has_centres ratios; 0 otherwise)
+    uint32_t below_cur = 0, below_prev = 0;
     auto emit_after = [&](auto RHOC, int j) __attribute__((always_inline)) {
         constexpr int RHO = decltype(RHOC)::value;
         auto one = [&](auto RC) __attribute__((always_inline)) {
             constexpr int r = decltype(RC)::value;
-            if constexpr (period_rho<NT>(PP, QQ, r) == RHO) emit_row(RC, j + period_delta<NT>(PP, QQ, r));
+            if constexpr (period_rho<NT>(PP, QQ, r) == RHO) {
+                constexpr int d = period_delta<NT>(PP, QQ, r);
+                static_assert(!period_centre(PP, QQ, r) || d == 0 || d == -1, "centre rows are drawn within two bodies");
+                emit_row(RC, std::integral_constant<int, 0>{}, j + d, d == 0 ? below_cur : below_prev);
+            }
+            if constexpr (period_centre(PP, QQ, r) && period_rho<NT>(PP, QQ, r, 1) == RHO) {
+                constexpr int d = period_delta<NT>(PP, QQ, r, 1);
+                static_assert(d == 0 || d == -1, "centre rows are drawn within two bodies");
+                emit_row(RC, std::integral_constant<int, 1>{}, j + d, d == 0 ? below_cur : below_prev);
+            }
         };
         period_static_for<0, PB>(one);
+    };
+    const int n_bodies = (Q.out_h + PB - 1) / PB;
+    auto body_bits = [&](int m) __attribute__((always_inline)) -> uint32_t {
+        return m >= 0 && m < n_bodies ? p_const((const uint32_t *)Q.yw)[(size_t)m * (PB * 8) + 7] : 0u;
     };
 
     // rows the segment's outputs read: [need_lo, need_hi] (virtual: outside 0..H-1 they replicate the edge rows)
     const int m_first = y0 / PB, m_last = (y1 - 1) / PB;
-    const int need_lo = 6 * m_first + period_base(PP, QQ, 0) + tap_off<NT>(0);
+    const int need_lo = 6 * m_first + period_low_base(PP, QQ) + tap_off<NT>(0);
     const int need_hi = 6 * m_last + period_base(PP, QQ, PB - 1) + tap_hi<NT>();
     // pairs pp_lo .. pp_hi cover them: pair pp = rows 2pp - 1, 2pp
     const int pp_lo = (need_lo + 1) >> 1, pp_hi = (need_hi + 1) >> 1;      // floor((row + 1) / 2), rows may be negative
@@ -350,7 +384,9 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
     // execute in order; the fences keep the compiler from reordering the reads and writes (unrelated, lane by lane).
     if (SRC == SRC_SURFACE) fetch_s(pp_lo, lane, sraw); else fetch(pp_lo, ra0, rawn);
     stage_c(pp_lo);
+    if constexpr (period_has_centres(PP, QQ)) below_cur = body_bits(j_lo - 1);
     for (int j = j_lo; j <= j_hi; j++) {
+        if constexpr (period_has_centres(PP, QQ)) { below_prev = below_cur; below_cur = body_bits(j); }
         auto pair_step = [&](auto IC) __attribute__((always_inline)) {
             constexpr int i = decltype(IC)::value;
             const int pp = 3 * j + i;

@@ -1,5 +1,5 @@
 // vp_fused_period.hip — host side of the periodic-phase fused kernel (vp_fused_period.h): preconditions, work decomposition,
-// dispatch to the per-ratio translation units (vp_fused_period_{4_3,3_2,2_3,1_2}.hip hold the kernels).
+// dispatch to the per-ratio translation units (vp_fused_period_{4_3,3_2,2_3,1_2,3_1}.hip hold the kernels).
 #include "vp_fused_period.h"
 
 namespace mpcvr {
@@ -8,6 +8,7 @@ extern template hipError_t LaunchFusedPeriodPQ<4, 3>(const FusedArgs &, const Pe
 extern template hipError_t LaunchFusedPeriodPQ<3, 2>(const FusedArgs &, const PeriodArgs &, int, int, int, int, dim3, dim3, size_t, const FusedFrame *, FusedFrame, hipStream_t);
 extern template hipError_t LaunchFusedPeriodPQ<2, 3>(const FusedArgs &, const PeriodArgs &, int, int, int, int, dim3, dim3, size_t, const FusedFrame *, FusedFrame, hipStream_t);
 extern template hipError_t LaunchFusedPeriodPQ<1, 2>(const FusedArgs &, const PeriodArgs &, int, int, int, int, dim3, dim3, size_t, const FusedFrame *, FusedFrame, hipStream_t);
+extern template hipError_t LaunchFusedPeriodPQ<3, 1>(const FusedArgs &, const PeriodArgs &, int, int, int, int, dim3, dim3, size_t, const FusedFrame *, FusedFrame, hipStream_t);
 
 namespace {
 
@@ -111,6 +112,7 @@ hipError_t LaunchFusedPeriod(const FusedStripParams &S, const FusedArgs &a, cons
     if (S.per_P == 3 && S.per_Q == 2) return LaunchFusedPeriodPQ<3, 2>(a, q, S.per_nt, tailk, srck, epik, grid, block, lds, frames_dev, single, s);
     if (S.per_P == 2 && S.per_Q == 3) return LaunchFusedPeriodPQ<2, 3>(a, q, S.per_nt, tailk, srck, epik, grid, block, lds, frames_dev, single, s);
     if (S.per_P == 1 && S.per_Q == 2) return LaunchFusedPeriodPQ<1, 2>(a, q, S.per_nt, tailk, srck, epik, grid, block, lds, frames_dev, single, s);
+    if (S.per_P == 3 && S.per_Q == 1) return LaunchFusedPeriodPQ<3, 1>(a, q, S.per_nt, tailk, srck, epik, grid, block, lds, frames_dev, single, s);
     return hipErrorNotSupported;
 }
 

@@ -647,7 +647,7 @@ bool PlanFusedPeriod(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x
     if (hx.normalise || hy.normalise) return false;                       // interpolation shaders only (ps_convolution normalises)
     if ((hy.ntaps != 4 && hy.ntaps != 6) || hx.ntaps != hy.ntaps) return false;
     if (n_out_x < 2 || n_out_y < 1 || hx.idx.size() != (size_t)n_out_x * hx.ntaps || hy.idx.size() != (size_t)n_out_y * hy.ntaps) return false;
-    static const int ratios[][2] = {{4, 3}, {3, 2}, {2, 3}, {1, 2}};
+    static const int ratios[][2] = {{4, 3}, {3, 2}, {2, 3}, {1, 2}, {3, 1}};
     int P = 0, Q = 0;
     for (const auto &r : ratios)
         if ((long)n_out_y * r[1] == (long)src_h * r[0]) { P = r[0]; Q = r[1]; }
@@ -658,10 +658,21 @@ bool PlanFusedPeriod(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x
     static const int off4[4] = {-1, 0, 1, 2}, off6[6] = {-2, -1, 0, 1, 2, 3}, off6q[6] = {-2, -2, 0, 1, 2, 3};
     const int *off = nth == 4 ? off4 : fold_q1 ? off6q : off6;
     const int PB = 6 * P / Q;
+    // P and Q both odd (3:1): output rows with ((2r + 1) Q - P) % 2P == 0 sit exactly on a texel centre n, where the reference's fp32
+    // texcoord lands on either side row by row: the table holds base n with t = 0, or base n - 1 with t = 1 - eps.  The kernel has both
+    // emissions compiled in for those rows and picks by a bit per row: `below`, one word per body, rides in the spare slot 7 of the
+    // body's first yw row
+    std::vector<uint32_t> below((n_out_y + PB - 1) / PB, 0u);
     for (int y = 0; y < n_out_y; y++) {
         const int m = y / PB, r = y % PB, base = 6 * m + PeriodBase(P, Q, r);
-        for (int k = 0; k < nth; k++)
-            if (hy.idx[(size_t)y * nth + k] != ClampI(base + off[k], 0, src_h - 1)) return false;
+        const bool centre = ((2 * r + 1) * Q - P) % (2 * P) == 0;
+        bool fits = false;
+        for (int sh = 0; sh <= (centre ? 1 : 0) && !fits; sh++) {
+            fits = true;
+            for (int k = 0; k < nth && fits; k++) fits = hy.idx[(size_t)y * nth + k] == ClampI(base - sh + off[k], 0, src_h - 1);
+            if (fits && sh) below[m] |= 1u << r;
+        }
+        if (!fits) return false;
     }
     if (fold_q1)
         for (int x = 0; x < n_out_x; x++)
@@ -682,6 +693,7 @@ bool PlanFusedPeriod(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x
             const int ks = fold_q1 && k > 0 ? k + 1 : k;
             pp->yw[(size_t)y * 8 + k] = (fold_q1 && k == 0) ? hy.w[(size_t)y * nth] + hy.w[(size_t)y * nth + 1] : hy.w[(size_t)y * nth + ks];
         }
+    for (size_t m = 0; m < below.size(); m++) std::memcpy(&pp->yw[m * PB * 8 + 7], &below[m], 4);
     // strip width: a convert pass costs the same whether 33 or 64 of its lanes hold a block, so the width is chosen to fill the passes —
     // an instruction-count model of one body (three source row pairs): passes x convert + X stage per pair, Y stage + epilogue per row
     // (counted in the ISA: convert ~230 with a table tail, ~70 without; X ~50 per pair; Y + final pass ~30 per row), per output pixel

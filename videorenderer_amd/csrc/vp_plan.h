@@ -135,14 +135,14 @@ bool PlanFusedStrip(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x,
 
 // ---- periodic-phase fused kernel (vp_fused_period.h): vertical ratio out : in = P : Q with compile-time tap rows ----
 struct PeriodPlan {
-    int P = 0, Q = 0;            // output rows : source rows (4:3, 3:2, 2:3, 1:2); 0 = the tables do not fit the kernel
+    int P = 0, Q = 0;            // output rows : source rows (4:3, 3:2, 2:3, 1:2, 3:1); 0 = the tables do not fit the kernel
     int nt = 0;                  // taps per output on both axes as the kernel runs them: 4, 5 (Lanczos3's shared texel folded) or 6
     int acols = 0;               // columns of a converted source row the widest strip needs (even)
     int strip_w = 128;           // output columns per wavefront (even, <= 128): the width whose convert passes are best filled
     std::vector<int32_t> xstrip; // [2 * n_strips] {lo, hi} source column per strip
     std::vector<int32_t> xi_t;   // [nt][n_out_x] tap-major
     std::vector<float> xw_t;
-    std::vector<float> yw;       // [n_out_y][8]: nt weights, zero padding
+    std::vector<float> yw;       // [n_out_y][8]: nt weights, zero padding; slot 7 of row PB * m: body m's centre-row bits (3:1, see PlanFusedPeriod)
 };
 // The kernel's tap ROWS are compile-time (base(r) + 6m, vp_fused_period.h): the plan succeeds only when hy's index table is exactly that
 // pattern (clamped to the texture) for one of the supported ratios; hx may be any 4- or 6-tap table.  fold_q1: both tables are
