@@ -48,7 +48,7 @@ WORKLOADS = {
                iUpscaling=2, desc="1080p NV12 BT.709 -> BGRA8, no resize (BASELINE configs[0])"),
     "hdr4k": dict(cformat=2, w=3840, h=2160, scale=1, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
                   iUpscaling=4, desc="4K P010 BT.2020/PQ -> PQ->SDR(Hable,125nits) -> ordered dither -> 4K BGRA8, no resize"),
-    # everyday non-integer geometries: one fused kernel per batch (k_fused_period at 4:3 / 3:2 / 2:3 / 1:2 down the rows, k_fused_strip otherwise; --flags 128 = MPCVR_FLAG_NO_PERIOD)
+    # everyday non-integer geometries: one fused kernel per batch (k_fused_period at 4:3 / 3:2 / 2:3 / 1:2 / 3:1 down the rows, k_fused_strip otherwise; --flags 128 = MPCVR_FLAG_NO_PERIOD)
     "up1440": dict(cformat=2, w=1920, h=1080, scale=1, dst=(2560, 1440), ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
                    iUpscaling=4, desc="1080p P010 BT.2020/PQ -> Lanczos3 1.33x -> PQ->SDR -> ordered dither -> 1440p BGRA8"),
     "down1440": dict(cformat=2, w=3840, h=2160, scale=1, dst=(2560, 1440), ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),

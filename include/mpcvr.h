@@ -85,7 +85,7 @@ enum { MPCVR_OUT_BGRA8 = 0, MPCVR_OUT_RGB10A2 = 1 };
                                              kernels instead of the one-kernel strip path (k_fused_strip; debug / A-B) */
 #define MPCVR_FLAG_FORCE_PERIOD     0x100u /* take k_fused_period wherever it is built, also where the planner prefers k_fused_strip (SDR content with a
                                               4-tap filter: measured a few % faster there; debug / A-B, and how the suite reaches those instantiations) */
-#define MPCVR_FLAG_NO_PERIOD        0x80u /* rational vertical ratios (4:3, 3:2, 2:3, 1:2) through k_fused_strip's run-time tap tables instead
+#define MPCVR_FLAG_NO_PERIOD        0x80u /* rational vertical ratios (4:3, 3:2, 2:3, 1:2, 3:1) through k_fused_strip's run-time tap tables instead
                                              of the periodic-phase kernel with its register window (k_fused_period; debug / A-B) */
 
 /* Subset of Settings_t (IVideoRenderer.h:104-135) that reaches the shader path; same field names. */
@@ -337,7 +337,7 @@ int32_t mpcvr_plan_strip(int32_t kind_x, int32_t method_x, int32_t kind_y, int32
  * out6 = {P, Q (output : source rows), taps per output as the kernel runs them (4 / 5 = Lanczos3 with its shared texel folded /
  * 6), strips of *strip_w output columns (the width that fills the convert passes best, <= 128), columns of a converted source row, output rows per body of six source rows}.
  * xi_t / xw_t: [taps][out_w]; yw: [out_h][8]; xstrip: [strips][2]; any may be NULL.  MPCVR_E_NOTIMPL: the vertical ratio is not
- * 4:3 / 3:2 / 2:3 / 1:2 or the table's tap rows are not the periodic pattern the kernel hard-codes. */
+ * 4:3 / 3:2 / 2:3 / 1:2 / 3:1 or the table's tap rows are not the periodic pattern the kernel hard-codes. */
 int32_t mpcvr_plan_period(int32_t method, int32_t src_w, int32_t src_h, int32_t out_w, int32_t out_h, uint32_t flags,
                           int32_t out6[6], int32_t *xi_t, float *xw_t, float *yw, int32_t *xstrip, int32_t *strip_w);
 /* HDRParamsConstantBuffer_t as SetHDR10ShaderParams fills it (DX11VideoProcessor.cpp:907-923: defaults and clamps of the HDR10

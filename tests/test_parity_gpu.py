@@ -131,7 +131,7 @@ def compare_behind_tail(oracle, p, frame, pitch, got, want, name, min_same=0.99)
 
 def path_ok(info, path):
     """GetVPInfo against an expected prefix; where the prefix names k_fused_strip the periodic-phase kernel (the same launch with the
-    vertical window in registers, taken at 4:3 / 3:2 / 2:3 / 1:2) is the planner's choice and counts as well."""
+    vertical window in registers, taken at 4:3 / 3:2 / 2:3 / 1:2 / 3:1) is the planner's choice and counts as well."""
     return (info.startswith(path) or info.startswith(path.replace("kernel=fused_strip(", "kernel=fused_period(")) or
             info.startswith(path.replace("kernel=fused_strip:surface(", "kernel=fused_period:surface(")))
 
@@ -730,6 +730,11 @@ STRIP_FULL = [
                                                     exfmt=GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"])),
     ("p010_hlg_4k_to_1080p_interp50", dict(cformat=2, w=3840, h=2160, kind="noise", seed=315, dst=(1920, 1080), iUpscaling=1,
                                            exfmt=GOLDEN_CASES["c5_p010_hlg_lanczos3_2x"]["exfmt"])),
+    # a horizontal flip is the X draw's table read from the other end (FillVertices swaps src_l / src_r): same kernel
+    ("p010_pq_flipped_1080p_to_1500p_lanczos3", dict(cformat=2, w=1920, h=1080, kind="noise", seed=318, dst=(2666, 1500), iUpscaling=4, flip=1,
+                                                     exfmt=GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"])),
+    ("nv12_flipped_letterboxed_2x_catmull", dict(cformat=1, w=640, h=360, kind="noise", seed=319, dst=(1280, 720), iUpscaling=2, flip=1,
+                                                 window=(1300, 740), offset=(9, 10), exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
 ]
 
 
@@ -778,6 +783,9 @@ PERIOD_CASES = [
     ("nv12_240p_to_720p_catmull_direct8", dict(cformat=1, w=426, h=240, kind="noise", seed=415, dst=(1278, 720), iUpscaling=2, exfmt=_SDR), (3, 1, 4)),
     ("p010_hlg_360p_to_1080p_lanczos3_fixed", dict(cformat=2, w=640, h=360, kind="noise", seed=416, dst=(1920, 1080), iUpscaling=4, flags=1, exfmt=_HLG), (3, 1, 6)),
     ("p010_pq_720p_to_2160p_lanczos3", dict(cformat=2, w=1280, h=720, kind="noise", seed=417, dst=(3840, 2160), iUpscaling=4, exfmt=_PQ), (3, 1, 5)),
+    ("p010_pq_flipped_540p_to_720p_lanczos3", dict(cformat=2, w=960, h=540, kind="noise", seed=418, dst=(1280, 720), iUpscaling=4, flip=1, exfmt=_PQ), (4, 3, 5)),
+    ("nv12_flipped_odd_width_1080p_to_720p_catmull", dict(cformat=1, w=1918, h=1080, kind="noise", seed=419, dst=(1279, 720), iUpscaling=2, flip=1, exfmt=_SDR,
+                                                          window=(1300, 736), offset=(10, 7)), (2, 3, 4)),
 ]
 
 
@@ -815,6 +823,7 @@ PERIOD_SURFACE_CASES = [
                                        dovi=dict(kind="mmr", l2=(100, 600, 1000))), (2, 3, 4)),
     ("nv12_catmull_chroma_360p_to_540p", dict(cformat=1, w=640, h=360, kind="noise", seed=433, dst=(960, 540), iUpscaling=4, iChromaScaling=2, exfmt=_SDR), (3, 2, 5)),
     ("p010_pq_catmull_chroma_1080p_to_540p", dict(cformat=2, w=1920, h=1080, kind="noise", seed=434, dst=(960, 540), iUpscaling=2, iChromaScaling=2, exfmt=_PQ), (1, 2, 4)),
+    ("dovi_poly_flipped_540p_to_720p_lanczos3", dict(cformat=2, w=960, h=540, kind="hdr", seed=436, dst=(1280, 720), iUpscaling=4, flip=1, exfmt=GOLDEN_CASES["dovi_poly_sdr"]["exfmt"], dovi=dict(kind="poly")), (4, 3, 5)),
     ("uyvy_catmull_chroma_540p_to_720p_10bit_target", dict(cformat=5, w=960, h=540, kind="noise", seed=435, dst=(1280, 720), iUpscaling=3, iChromaScaling=2, iTexFormat=10, output_format=1, exfmt=_SDR), (4, 3, 4)),
 ]
 
@@ -847,11 +856,18 @@ def test_period_kernel_from_a_surface(mpcvr, oracle, torch_cuda, label, c, pqn):
         print(f"PERIOD:SURFACE {label}: identical channels {same:.6f}  [{tag}]")
 
 
-def test_period_kernel_batches_equal_single_frames(mpcvr, torch_cuda):
-    """mpcvr_process_batch through the periodic-phase kernel: every frame of a batch equals its single-frame result bit for bit."""
+@pytest.mark.parametrize("over,kernel", [
+    (dict(), "kernel=fused_period("),
+    (dict(flip=1), "kernel=fused_period("),                                         # flipped: the X tables read from the other end, still one launch per batch
+    (dict(cformat=1, iChromaScaling=2, exfmt=_SDR, flip=1), "kernel=fused_period:surface("),      # convert kernel per batch + the surface variant per batch
+    (dict(cformat=1, iChromaScaling=2, exfmt=_SDR, dst=(1300, 700), flip=1), "kernel=fused_strip:surface("),
+])
+def test_period_kernel_batches_equal_single_frames(mpcvr, torch_cuda, over, kernel):
+    """mpcvr_process_batch through the periodic-phase kernel (and, flipped, through the strip kernel's surface variant): every frame of
+    a batch equals its single-frame result bit for bit."""
     torch = torch_cuda
     from videorenderer_amd import api
-    c = dict(cformat=2, w=960, h=540, kind="noise", seed=420, dst=(1280, 720), iUpscaling=4, exfmt=_PQ)
+    c = dict(dict(cformat=2, w=960, h=540, kind="noise", seed=420, dst=(1280, 720), iUpscaling=4, exfmt=_PQ), **over)
     vp, (ww, wh) = make_vp(mpcvr, c)
     frames = [torch.from_numpy(case_frame(dict(c, seed=420 + i))[0]).cuda() for i in range(5)]
     pitch = case_frame(c)[1]
@@ -862,7 +878,7 @@ def test_period_kernel_batches_equal_single_frames(mpcvr, torch_cuda):
         vp.Process(d, ww * 4)
         singles.append(d)
     vp.Synchronize()
-    assert "kernel=fused_period(" in vp.GetVPInfo()
+    assert kernel in vp.GetVPInfo(), vp.GetVPInfo()
     outs = [torch.zeros((wh, ww, 4), dtype=torch.uint8, device="cuda") for _ in frames]
     vp.ProcessBatch(frames, outs, ww * 4)
     vp.Synchronize()
@@ -985,6 +1001,7 @@ SURFACE_STRIP = [
                                        window=(2560, 1440), offset=(21, 11))),
     ("nv12_catmull_chroma_1080p_to_1440p_fp16", dict(cformat=1, w=1920, h=1080, kind="noise", seed=334, dst=(2560, 1440), iUpscaling=3, iChromaScaling=2,
                                                      iTexFormat=16, exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
+    ("rgb32_flipped_crop_720p_to_1000p", dict(cformat=30, w=1280, h=720, kind="noise", seed=335, src_rect=(10, 6, 1270, 714), dst=(1777, 1000), iUpscaling=4, flip=1)),
 ]
 
 

@@ -363,7 +363,7 @@ def plan_strip(kind_x, method_x, kind_y, method_y, src_w, src_h, out_w, out_h, f
 
 def plan_period(method, src_w, src_h, out_w, out_h, flags=0):
     """PlanFusedPeriod through the C-ABI (no device): the periodic-phase kernel's geometry and tables, or None when the vertical
-    ratio is not one of 4:3 / 3:2 / 2:3 / 1:2 (or the tap rows are not the pattern the kernel hard-codes)."""
+    ratio is not one of 4:3 / 3:2 / 2:3 / 1:2 / 3:1 (or the tap rows are not the pattern the kernel hard-codes)."""
     import numpy as np
     L = load_library()
     out6 = (C.c_int32 * 6)()

@@ -223,7 +223,7 @@ private:
     DevBuffer m_stripTab;          // yrange | xstrip | xi_t | xw_t | yi | yw, word offsets in m_stripOff
     size_t m_stripOff[6] = {0, 0, 0, 0, 0, 0};
     bool FillStripParams(const uint8_t *sample, void *dst, int dstPitch, const StoreParams &store, FusedStripParams *sp) const;
-    // periodic-phase variant of the same launch (vp_fused_period.h): vertical ratio 4:3 / 3:2 / 2:3 / 1:2, tables behind the strip kernel's in m_stripTab
+    // periodic-phase variant of the same launch (vp_fused_period.h): vertical ratio 4:3 / 3:2 / 2:3 / 1:2 / 3:1, tables behind the strip kernel's in m_stripTab
     PeriodPlan m_periodPlan;       // P == 0: not a periodic geometry
     size_t m_periodOff[4] = {0, 0, 0, 0};     // xi_t | xw_t | yw | xstrip
     bool m_period = false;         // the planned launch (window-sized target) takes the periodic kernel: what GetVPInfo reports
