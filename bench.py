@@ -57,6 +57,8 @@ WORKLOADS = {
                    iUpscaling=2, desc="720p NV12 BT.709 -> Catmull-Rom 1.5x -> 1080p BGRA8 (8-bit internal format, no dither)"),
     "down1080": dict(cformat=2, w=3840, h=2160, scale=1, dst=(1920, 1080), ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
                      iUpscaling=4, desc="4K P010 BT.2020/PQ -> Lanczos3 at exactly 50 % (interpolation shader) -> PQ->SDR -> ordered dither -> 1080p BGRA8"),
+    "up2160": dict(cformat=2, w=1280, h=720, scale=1, dst=(3840, 2160), ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
+                   iUpscaling=4, desc="720p P010 BT.2020/PQ -> Lanczos3 3x -> PQ->SDR -> ordered dither -> 2160p BGRA8"),
     # the everyday SDR case (8-bit source, 8-bit internal format, no final pass) and HDR passthrough to a 10-bit swap chain
     "up1440_nv12": dict(cformat=1, w=1920, h=1080, scale=1, dst=(2560, 1440), ext=dict(chroma=5, nominal_range=2, matrix=1, primaries=2, transfer=5),
                         iUpscaling=2, desc="1080p NV12 BT.709 -> Catmull-Rom 1.33x -> 1440p BGRA8 (8-bit internal format, no dither)"),

@@ -11,11 +11,11 @@ KFILTER=k_fused_period bash tools/prof_headline.sh period_up1440_final --workloa
 KFILTER=k_fused_period bash tools/prof_headline.sh period_down1440_final --workload down1440 > /dev/null 2>&1
 # which kernel instantiations the GPU suite launches (tests/test_kernel_coverage.py reads the stats table)
 ( cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; timeout -k 5 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/suite_kt -o suite -- python -m pytest tests -m gpu -x -q > gpurun_out/suite_under_kernel_trace.txt 2>&1 )
-for wl in c3hdr c3 c4 c4ext c5 c2 c1 hdr4k up1440 down1440 up1080 down1080 up1440_nv12 hdrpass_2x hdrpass_1440 c3hdr_1080p; do
+for wl in c3hdr c3 c4 c4ext c5 c2 c1 hdr4k up1440 down1440 up1080 down1080 up2160 up1440_nv12 hdrpass_2x hdrpass_1440 c3hdr_1080p; do
   python bench.py --workload $wl --no-host-path --steps 30 --warmup 5 $( [ $wl = c3hdr ] || echo --no-cpu-baseline ) 2>/dev/null | tail -n 1
 done > gpurun_out/bench_workloads.jsonl
 python tools/bench_general.py 2>/dev/null | grep "^{" > gpurun_out/bench_general.jsonl
-for wl in up1440 down1440 down1080 hdrpass_1440; do python bench.py --workload $wl --flags 128 --no-host-path --no-cpu-baseline --steps 30 --warmup 5 2>/dev/null | tail -n 1; done > gpurun_out/bench_workloads_strip_kernel.jsonl
+for wl in up1440 down1440 down1080 up2160 hdrpass_1440; do python bench.py --workload $wl --flags 128 --no-host-path --no-cpu-baseline --steps 30 --warmup 5 2>/dev/null | tail -n 1; done > gpurun_out/bench_workloads_strip_kernel.jsonl
 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_driver_shape.json 2> gpurun_out/bench_driver_shape.err
 # gpurun merges at most 64 MiB back: keep the tables anyone reads (summaries, stats, traffic, bench lines), drop the raw traces

@@ -599,12 +599,13 @@ HRESULT CHipVideoProcessor::UpdatePlan()
     // the arbitrary-ratio fused kernel takes an unrotated two-pass resize whose tables fit it: straight from the raw sample for
     // 4:2:0 sources (m_strip, decided below), else from the convert kernel's output / the RGB source texture (m_stripSurf).
     // A horizontal flip (FillVertices swaps src_l and src_r, DX11VideoProcessor.cpp:167-169) is the X draw's table read from the other end — per-column tap
-    // indices and weights are what these kernels read anyway — so a flipped frame stays on the fused path; rotations do not
-    // (90 / 270 turn the first draw into a Y shader, 180 also reverses the rows the march runs down)
+    // indices and weights are what these kernels read anyway — so a flipped frame stays on the fused path.  Rotation 180 also
+    // reverses the first draw's ROW map (m_otherX), which the surface variant reads row by row: a frame turned upside down goes
+    // convert kernel -> m_TexConvertOutput -> k_fused_strip:surface.  90 / 270 turn the first draw into a Y shader and stay per draw
     m_strip = m_stripSurf = m_stripPlanned = false;
     m_periodPlan.P = 0;
     static const bool no_strip_env = [] { const char *e = std::getenv("MPCVR_NO_STRIP"); return e && *e && *e != '0'; }();
-    if (!no_strip_env && m_plan.two_pass && !m_firstJinc && !m_secondJinc && m_firstAxis == 0 && !m_firstSwap && m_plan.rotation == 0 &&
+    if (!no_strip_env && m_plan.two_pass && !m_firstJinc && !m_secondJinc && m_firstAxis == 0 && !m_firstSwap && (m_plan.rotation == 0 || m_plan.rotation == 180) &&
         !(m_cfg.flags & (MPCVR_FLAG_NO_FUSED | MPCVR_FLAG_NO_FAST_CONVERT | MPCVR_FLAG_NO_STRIP)) &&
         PlanFusedStrip(hx, hy, w2, h2, m_plan.convert ? w1 : m_srcWidth, m_plan.mid_h, &m_stripPlan)) {
         // one buffer: yrange | xstrip | xi_t | xw_t | yi | yw  (all 4-byte words)
@@ -637,7 +638,7 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         if ((hr = CheckHip(m_stripTab.CheckCreate(pack.size() * sizeof(int32_t)), "strip tables"))) return hr;
         if ((hr = CheckHip(hipMemcpy(m_stripTab.ptr, pack.data(), pack.size() * sizeof(int32_t), hipMemcpyHostToDevice), "strip tables upload"))) return hr;
         m_stripPlanned = true;
-        m_strip = m_plan.convert && !m_doviValid && m_plan.internal_fmt != SF_RGBA16F;
+        m_strip = m_plan.convert && !m_doviValid && m_plan.internal_fmt != SF_RGBA16F && m_plan.rotation == 0;
     }
 
     // PQ -> SDR table: the fused kernel's tone-map stage and the folded convert kernel's
@@ -1223,8 +1224,9 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
 // convert straight into the render targets (same-size frames).  Exactly one of them is used.
 bool CHipVideoProcessor::BatchPlan(const uint8_t *sample0, void *rt0, int rtPitch, bool aligned, FusedParams *conv, FusedParams *direct) const
 {
-    // (a flipped frame batches only through the strip / periodic kernels' surface variant, whose X draw reads per-column tables)
-    if (m_plan.hdr_tonemap || m_plan.rotation || (m_plan.flip && !(m_plan.two_pass && m_stripSurf)) || m_secondJinc || !m_plan.convert) return false;
+    // (a flipped or upside-down frame batches only through the strip / periodic kernels' surface variant: per-column tables, a row map)
+    const bool turned = m_plan.flip || m_plan.rotation == 180;
+    if (m_plan.hdr_tonemap || (m_plan.rotation && m_plan.rotation != 180) || (turned && !(m_plan.two_pass && m_stripSurf)) || m_secondJinc || !m_plan.convert) return false;
     if (m_firstJinc && !(m_plan.one_pass && m_jincFirstTab)) return false;      // Jinc2m batches: the one-draw quad kernel only
     if (m_srcParams->cformat == MPCVR_CF_V210 || m_srcParams->layout == LAY_RGB) return false;
     const int w1 = m_srcRectWidth, h1 = m_srcRectHeight, w2 = m_videoRect.Width();
@@ -1248,7 +1250,7 @@ bool CHipVideoProcessor::BatchPlan(const uint8_t *sample0, void *rt0, int rtPitc
         // through to the tiled / folded kernels' own checks when the strip kernel does not take it
         FusedStripParams ssp{};
         if (m_stripSurf && FillStripSurfParams(cs, final, &ssp)) return true;
-        if (m_plan.flip) return false;
+        if (turned) return false;
         if (m_firstAxis == 0 && !m_firstSwap && Resize2DSupported(cs, m_tapsX, m_tapsY, final)) return true;
         const Surface mid{nullptr, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
         return ResizeHasFoldedKernel(m_firstAxis, m_firstSwap, cs, m_tapsX, MakeStore(nullptr, mid.pitch, SF_RGBA16F, false)) &&
