@@ -824,6 +824,9 @@ PERIOD_SURFACE_CASES = [
     ("nv12_catmull_chroma_360p_to_540p", dict(cformat=1, w=640, h=360, kind="noise", seed=433, dst=(960, 540), iUpscaling=4, iChromaScaling=2, exfmt=_SDR), (3, 2, 5)),
     ("p010_pq_catmull_chroma_1080p_to_540p", dict(cformat=2, w=1920, h=1080, kind="noise", seed=434, dst=(960, 540), iUpscaling=2, iChromaScaling=2, exfmt=_PQ), (1, 2, 4)),
     ("dovi_poly_flipped_540p_to_720p_lanczos3", dict(cformat=2, w=960, h=540, kind="hdr", seed=436, dst=(1280, 720), iUpscaling=4, flip=1, exfmt=GOLDEN_CASES["dovi_poly_sdr"]["exfmt"], dovi=dict(kind="poly")), (4, 3, 5)),
+    # interleaved RGB without a convert draw: the source texture itself is the surface
+    ("r210_540p_to_720p_lanczos3", dict(cformat=32, w=960, h=540, kind="noise", seed=437, dst=(1280, 720), iUpscaling=4), (4, 3, 5)),
+    ("rgb32_360p_to_540p_catmull_letterboxed", dict(cformat=30, w=640, h=360, kind="noise", seed=438, dst=(960, 540), iUpscaling=2, window=(980, 560), offset=(10, 9)), (3, 2, 4)),
     ("uyvy_catmull_chroma_540p_to_720p_10bit_target", dict(cformat=5, w=960, h=540, kind="noise", seed=435, dst=(1280, 720), iUpscaling=3, iChromaScaling=2, iTexFormat=10, output_format=1, exfmt=_SDR), (4, 3, 4)),
 ]
 
@@ -862,6 +865,10 @@ def test_period_kernel_from_a_surface(mpcvr, oracle, torch_cuda, label, c, pqn):
     (dict(cformat=1, iChromaScaling=2, exfmt=_SDR, flip=1), "kernel=fused_period:surface("),      # convert kernel per batch + the surface variant per batch
     (dict(cformat=1, iChromaScaling=2, exfmt=_SDR, dst=(1300, 700), flip=1), "kernel=fused_strip:surface("),
     (dict(rotation=180), "kernel=fused_strip:surface("),                                            # upside down: the row map of the surface variant
+    # interleaved RGB without a convert draw: a repack launch per frame into a batch texture, ONE resize launch per batch
+    (dict(cformat=30, exfmt=None), "kernel=fused_period:surface("),
+    (dict(cformat=32, exfmt=None, src_rect=(8, 4, 952, 536), dst=(1300, 733)), "kernel=fused_strip:surface("),
+    (dict(cformat=29, exfmt=None, dst=(1301, 733), window=(1320, 740), offset=(6, 3)), "kernel=fused_strip:surface("),
 ])
 def test_period_kernel_batches_equal_single_frames(mpcvr, torch_cuda, over, kernel):
     """mpcvr_process_batch through the periodic-phase kernel (and, flipped, through the strip kernel's surface variant): every frame of
@@ -869,6 +876,8 @@ def test_period_kernel_batches_equal_single_frames(mpcvr, torch_cuda, over, kern
     torch = torch_cuda
     from videorenderer_amd import api
     c = dict(dict(cformat=2, w=960, h=540, kind="noise", seed=420, dst=(1280, 720), iUpscaling=4, exfmt=_PQ), **over)
+    if c["exfmt"] is None:
+        del c["exfmt"]
     vp, (ww, wh) = make_vp(mpcvr, c)
     frames = [torch.from_numpy(case_frame(dict(c, seed=420 + i))[0]).cuda() for i in range(5)]
     pitch = case_frame(c)[1]
@@ -1025,7 +1034,7 @@ def test_strip_kernel_from_a_surface_whole_frame(mpcvr, oracle, torch_cuda, labe
     frame, pitch = case_frame(c)
     p = oracle_params(oracle, c)
     want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
-    got, info = run_product(mpcvr, torch, c)
+    got, info = run_product(mpcvr, torch, c, extra_flags=api.FLAG_NO_PERIOD)      # (4:3 and friends would go to k_fused_period:surface)
     assert "kernel=fused_strip:surface" in info, info
     same = compare(got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
     alt, info_alt = run_product(mpcvr, torch, c, extra_flags=api.FLAG_NO_STRIP)

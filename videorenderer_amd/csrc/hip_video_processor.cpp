@@ -58,7 +58,7 @@ CHipVideoProcessor::~CHipVideoProcessor()
     if (!m_bInit && !m_stream && !m_evStart && !m_evStop && !m_dither.ptr) return;
     (void)hipSetDevice(m_device);
     if (m_stream) (void)hipStreamSynchronize(m_stream);
-    for (DevBuffer *b : {&m_batchConv, &m_batchMid, &m_jincFirst, &m_jincSecond, &m_TexSrcVideo, &m_TexRaw, &m_TexPost, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
+    for (DevBuffer *b : {&m_batchConv, &m_batchMid, &m_batchTex, &m_jincFirst, &m_jincSecond, &m_TexSrcVideo, &m_TexRaw, &m_TexPost, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
                          &m_pqLut, &m_hlgLut, &m_eotfLut, &m_stripTab, &m_tapsXi, &m_tapsXw, &m_tapsXs, &m_tapsYi, &m_tapsYw, &m_tapsYs, &m_otherX, &m_otherY, &m_tapsXb, &m_tapsYb})
         b->Release();
     for (UploadSlot &u : m_up) {
@@ -626,8 +626,9 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         // periodic vertical ratio (1080p -> 1440p, 720p -> 1080p, 4K -> 1440p, 4K -> 1080p ...): the register-window kernel's tables
         m_periodPlan.P = 0;
         const bool q1 = m_plan.rx.kind == RS_UP && m_plan.ry.kind == RS_UP && m_cfg.iUpscaling == MPCVR_UPSCALE_Lanczos3 && !(m_cfg.flags & MPCVR_FLAG_LANCZOS3_FIXED);
-        if (m_plan.convert && m_plan.rx.kind == RS_UP && m_plan.ry.kind == RS_UP &&
-            PlanFusedPeriod(hx, hy, w2, h2, w1, m_plan.mid_h, q1, &m_periodPlan, m_tail == TAIL_PQ_TO_SDR || m_tail == TAIL_HLG_TO_SDR)) {
+        // (an interleaved RGB sample without a convert draw is read in place: the X tables then index the whole texture's columns)
+        if (m_plan.rx.kind == RS_UP && m_plan.ry.kind == RS_UP &&
+            PlanFusedPeriod(hx, hy, w2, h2, m_plan.convert ? w1 : m_srcWidth, m_plan.mid_h, q1, &m_periodPlan, m_tail == TAIL_PQ_TO_SDR || m_tail == TAIL_HLG_TO_SDR)) {
             const PeriodPlan &pp = m_periodPlan;
             m_periodOff[0] = put(pp.xi_t.data(), pp.xi_t.size());
             m_periodOff[1] = put(pp.xw_t.data(), pp.xw_t.size());
@@ -1134,6 +1135,56 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
         (void)hipEventRecord(m_evStop, m_stream);
         m_timed = true;
         return hr;
+    }
+    // Interleaved RGB without a convert draw (m_PSConvColorData.bEnable false, :849-853): every frame is repacked into its own slot of a
+    // batch texture (the reference's CopyFrame* upload, one launch per frame — the repack kernels have no frame dimension) and ONE
+    // k_fused_strip:surface launch resizes the whole chunk from there, instead of a repack + a resize launch per frame
+    if (m_srcParams->layout == LAY_RGB && !m_plan.convert && m_stripSurf && m_plan.two_pass && !m_plan.hdr_tonemap && n > 1 &&
+        !(m_cfg.flags & (MPCVR_FLAG_NO_FUSED | MPCVR_FLAG_NO_FAST_CONVERT | MPCVR_FLAG_NO_STRIP))) {
+        const int tp = TexPitch();
+        const size_t texBytes = (size_t)tp * m_srcHeight;
+        const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)1 << 30) / std::max<size_t>(texBytes, 1)));
+        const bool fresh = m_batchTex.size < texBytes * chunk || !m_batchTex.ptr;
+        if ((hr = CheckHip(m_batchTex.CheckCreate(texBytes * chunk), "batch source texture"))) return hr;
+        const Surface cs{m_batchTex.ptr, tp, m_srcWidth, m_srcHeight, RgbTexFmt(*m_srcParams)};
+        FusedStripParams ssp{};
+        if (FillStripSurfParams(cs, MakeStore(dsts[0], rtPitch, m_plan.swap_fmt, true), &ssp)) {
+            // texels the reference's copy loop never writes (RGB48 remainder) stay zero, as in PrepareSample
+            if (fresh && (hr = CheckHip(hipMemsetAsync(m_batchTex.ptr, 0, texBytes * chunk, m_stream), "clear batch texture"))) return hr;
+            FrameSlot &slot = m_slots[m_slotNext];
+            m_slotNext = (m_slotNext + 1) % kFrameSlots;
+            if (!slot.done && (hr = CheckHip(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming), "slot event"))) return hr;
+            if (slot.used && (hr = CheckHip(hipEventSynchronize(slot.done), "slot wait"))) return hr;
+            if ((size_t)n > slot.cap) {
+                if (slot.pinned) (void)hipHostFree(slot.pinned);
+                slot.pinned = nullptr; slot.cap = 0;
+                const size_t cap = n < 64 ? 64 : (size_t)n;
+                if ((hr = CheckHip(hipHostMalloc(&slot.pinned, sizeof(FusedFrame) * cap, hipHostMallocDefault), "frames pinned"))) return hr;
+                if ((hr = CheckHip(slot.dev.CheckCreate(sizeof(FusedFrame) * cap), "frames"))) return hr;
+                slot.cap = cap;
+            }
+            FusedFrame *fr = (FusedFrame *)slot.pinned;
+            for (int i = 0; i < n; i++) { fr[i].src = (const uint8_t *)srcs[i]; fr[i].dst = dsts[i]; }
+            if ((hr = CheckHip(hipMemcpyAsync(slot.dev.ptr, fr, sizeof(FusedFrame) * n, hipMemcpyHostToDevice, m_stream), "frame table"))) return hr;
+            bool aligned8 = true;
+            for (int i = 0; i < n; i++)
+                if (((uintptr_t)dsts[i] & 7) != 0) aligned8 = false;
+            ssp.surf_stride = texBytes;
+            ssp.fp.dst_aligned16 = aligned8 ? 1 : 0;
+            (void)hipEventRecord(m_evStart, m_stream);
+            for (int at = 0; at < n && !hr; at += chunk) {
+                const int m = std::min(chunk, n - at);
+                for (int z = 0; z < m && !hr; z++)
+                    hr = CheckHip(LaunchRepackRgb(m_srcParams->repack, (const uint8_t *)srcs[at + z], m_srcBottomUp ? -m_srcPitch : m_srcPitch,
+                                                  (uint8_t *)m_batchTex.ptr + (size_t)z * texBytes, tp, m_srcWidth, m_srcHeight, m_stream), "k_repack_rgb");
+                if (!hr) hr = CheckHip(LaunchFusedStrip(ssp, (const FusedFrame *)slot.dev.ptr + at, FusedFrame{nullptr, nullptr}, m, m_stream), "k_fused_strip<surface>");
+            }
+            (void)hipEventRecord(m_evStop, m_stream);
+            (void)hipEventRecord(slot.done, m_stream);
+            slot.used = true;
+            m_timed = true;
+            return hr;
+        }
     }
     // (a batch of one needs no frame table: the frame travels in the kernel arguments, like mpcvr_process)
     if ((!m_plan.fused_up2x && !strip && !batchable) || !src4 || n == 1) {
