@@ -90,7 +90,12 @@ WHOLE_FRAME_FLOOR = 0.9984
 POW_ULPS = 4      # Direct3D's pow is exp2(y * log2 x): with 1-ulp log2 / exp2 the result is off by up to ~0.35 |y log2 x| + 1.5 ulp (4 at x = 1e-4, y = 1/2.2)
 
 
-def compare_behind_tail(oracle, p, frame, pitch, got, want, name, min_same=0.99):
+def _codes10(a):
+    u = a.view(np.uint32)[..., 0]
+    return np.stack([(u >> sh) & 1023 for sh in (0, 10, 20)], -1).astype(np.int16)
+
+
+def compare_behind_tail(oracle, p, frame, pitch, got, want, name, min_same=0.99, ten_bit=False, lim=1):
     """Frames behind a PQ / HLG / Dolby Vision tail: |delta| <= 1 like everywhere else, EXCEPT on channels where the oracle's own
     answer is not defined to one code — shown per channel, not assumed: the oracle is run again with every pow() of the chain POW_ULPS
     ulps low, POW_ULPS ulps high, and eight times with each call off by its own hash-drawn amount within +-POW_ULPS
@@ -99,27 +104,28 @@ def compare_behind_tail(oracle, p, frame, pitch, got, want, name, min_same=0.99)
     answer spans 0..13 codes on such a channel):
     a bright saturated colour whose third channel cancels to ~1e-4 behind the 2020 -> 709 matrix — the PQ EOTF's (c2 - c3 v) term
     amplifies an ulp of pow(x, 1/m2) ~100x, pow(., 1/m1) 6x more, and pow(x, 1/2.2) has a slope of ~70 down there.
+    ten_bit: an R10G10B10A2 target, compared code for code with `lim` ten-bit codes in place of the one 8-bit code.
     Returns (share of identical channels, number of such channels)."""
-    d = np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
+    codes = _codes10 if ten_bit else (lambda a: a[..., :3].astype(np.int16))
+    g3, w3 = codes(got), codes(want)
+    d = np.abs(g3 - w3)
     same = float((d == 0).mean())
     assert same >= min_same, f"{name}: only {same:.5f} of channels identical"
-    bad = d > 1
+    bad = d > lim
     n_bad = int(bad.sum())
     if n_bad:
         bg = np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8)
-        w3 = want[..., :3].astype(np.int16)
         lo, hi = w3.copy(), w3.copy()
         # all pow() calls low, all high, and eight draws of independent per-call errors (a uniform bias cancels in the gamut matrix,
         # whose rows sum to 1: the channels of a real approximate pow err independently)
         for bias, seed in [(-POW_ULPS, 0), (POW_ULPS, 0)] + [(POW_ULPS, k) for k in range(1, 9)]:
-            run = oracle.process_with_pow_bias(p, frame, pitch, bias, dst=bg.copy(), seed=seed)[..., :3].astype(np.int16)
+            run = codes(oracle.process_with_pow_bias(p, frame, pitch, bias, dst=bg.copy(), seed=seed))
             lo = np.minimum(lo, run); hi = np.maximum(hi, run)
-        lo -= 1; hi += 1
-        g3 = got[..., :3].astype(np.int16)
+        lo -= lim; hi += lim
         inside = (g3 >= lo) & (g3 <= hi)
         worst = np.argwhere(bad & ~inside)
-        assert worst.size == 0, (f"{name}: {len(worst)} of {n_bad} channels beyond 1 LSB are NOT explained by +-{POW_ULPS} ulp of pow(): "
-                                 f"e.g. (y, x, ch) = {tuple(worst[0])}: got {g3[tuple(worst[0])]}, oracle {w3[tuple(worst[0])]}, interval [{lo[tuple(worst[0])] + 1}, {hi[tuple(worst[0])] - 1}]")
+        assert worst.size == 0, (f"{name}: {len(worst)} of {n_bad} channels beyond {lim} code(s) are NOT explained by +-{POW_ULPS} ulp of pow(): "
+                                 f"e.g. (y, x, ch) = {tuple(worst[0])}: got {g3[tuple(worst[0])]}, oracle {w3[tuple(worst[0])]}, interval [{lo[tuple(worst[0])] + lim}, {hi[tuple(worst[0])] - lim}]")
         assert n_bad <= 1e-4 * d.size, f"{name}: {n_bad} ill-conditioned channels is more than a handful"
     if os.environ.get("MPCVR_PARITY_LOG"):
         import json
