@@ -328,7 +328,7 @@ int32_t mpcvr_plan_axis_taps(int32_t kind, int32_t method, int32_t src_l, int32_
  * pixels per lane, output columns per strip, rows of the LDS window, columns of a converted source row, strips, LDS bytes per
  * wavefront, 0}.  yrange: [out_h][2] {smallest, largest} source row per output row; xstrip: [strips][2] likewise per strip;
  * xi_t / xw_t: [taps][out_w] and yi / yw: [out_h][taps], the zero-padded, pre-normalised tables the kernel reads.  Any table
- * pointer may be NULL.  MPCVR_E_NOTIMPL: the tables do not fit the kernel (more than 8 taps, window above 15 rows). */
+ * pointer may be NULL.  MPCVR_E_NOTIMPL: the tables do not fit the kernel (more than 16 taps, window above 31 rows). */
 int32_t mpcvr_plan_strip(int32_t kind_x, int32_t method_x, int32_t kind_y, int32_t method_y, int32_t src_w, int32_t src_h,
                          int32_t out_w, int32_t out_h, uint32_t flags, int32_t out8[8], int32_t *yrange, int32_t *xstrip,
                          int32_t *xi_t, float *xw_t, int32_t *yi, float *yw);

@@ -400,6 +400,9 @@ def test_c_abi_links_from_plain_c(mpcvr, tmp_path):
     (1, 2, 1, 2, 1280, 720, 1919, 1079),         # odd output size, Catmull-Rom
     (1, 3, 1, 3, 1280, 1440, 1920, 800),         # up along x, down along y through the interpolation shader (50 % rule)
     (2, 2, 2, 2, 1920, 1080, 738, 416),          # 2.6x Hamming: 8 taps
+    (2, 3, 2, 3, 1920, 1080, 834, 470),          # bicubic 2.3x down: 10 taps -> the 16-tap variant, a 32-row ring, one pixel per lane
+    (2, 5, 2, 5, 3840, 2160, 1920, 1080),        # Lanczos down at exactly 2x without the 50 % rule: 13 taps
+    (2, 3, 2, 3, 3840, 2160, 1280, 720),         # 4K -> 720p bicubic: 13 taps
     (1, 1, 1, 1, 3840, 2160, 1920, 1080),        # the interpolation shader at 50 %
     (1, 4, 1, 4, 64, 48, 100, 70),               # small frame: one strip
 ])
@@ -413,7 +416,8 @@ def test_strip_plan_tables(mpcvr, kx, mx, ky, my, sw, sh, dw, dh):
     sp = api.plan_strip(kx, mx, ky, my, sw, sh, dw, dh)
     assert sp is not None
     nt, pxl, strip_w = sp["taps"], sp["px_per_lane"], sp["strip_w"]
-    assert nt in (4, 6, 8) and pxl in (1, 2) and sp["ring"] in (8, 16)
+    assert nt in (4, 6, 8, 16) and pxl in (1, 2) and sp["ring"] in (8, 16, 32)
+    assert nt != 16 or pxl == 1
     assert strip_w % pxl == 0 and pxl <= strip_w <= 64 * pxl and sp["strips"] == -(-dw // strip_w)
     for axis, (kind, method, src, n_out) in enumerate(((kx, mx, sw, dw), (ky, my, sh, dh))):
         I, W, WS = api.plan_axis_taps(kind, method, 0, src, n_out, src)
@@ -442,13 +446,14 @@ def test_strip_plan_tables(mpcvr, kx, mx, ky, my, sw, sh, dw, dh):
         lo, hi = sp["xstrip"][s_]
         assert lo == cols.min() and hi == cols.max()
         assert hi - (lo & ~1) + 1 <= sp["acols"]
-    assert 4 * sp["lds_per_wave"] + 4096 + 32768 <= 160 * 1024
+    assert 4 * sp["lds_per_wave"] + 4096 + 32768 <= 160 * 1024          # at least four waves per CU beside the tables
 
 
 def test_strip_plan_refuses_what_the_kernel_cannot_run(mpcvr):
     from videorenderer_amd import api
-    assert api.plan_strip(2, 5, 2, 5, 3840, 2160, 1280, 720) is None          # Lanczos 3x down: 18 taps
-    assert api.plan_strip(2, 3, 2, 3, 1920, 1080, 834, 470) is None           # bicubic 2.3x down: 10 taps
+    assert api.plan_strip(2, 5, 2, 5, 3840, 2160, 1280, 720) is None          # Lanczos 3x down: 19 taps
+    assert api.plan_strip(2, 3, 2, 3, 3840, 2160, 900, 506) is None           # bicubic 4.3x down: 19 taps
+    assert api.plan_strip(2, 3, 2, 3, 1920, 1080, 834, 470)["taps"] == 16     # bicubic 2.3x down: 10 taps -> the 16-tap kernels
     assert api.plan_strip(1, 4, 1, 4, 1920, 1080, 3840, 2160) is not None     # exact 2x fits too (the 2x kernel is preferred)
 
 

@@ -736,6 +736,13 @@ STRIP_FULL = [
                                                     exfmt=GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"])),
     ("p010_hlg_4k_to_1080p_interp50", dict(cformat=2, w=3840, h=2160, kind="noise", seed=315, dst=(1920, 1080), iUpscaling=1,
                                            exfmt=GOLDEN_CASES["c5_p010_hlg_lanczos3_2x"]["exfmt"])),
+    # 9..16 taps (ps_convolution beyond ~2x with the wider kernels): the 16-tap variant, one pixel per lane, a 32-row ring
+    ("p010_pq_4k_to_1080p_lanczos_without_the_50pct_rule", dict(cformat=2, w=3840, h=2160, kind="noise", seed=320, dst=(1920, 1080), iDownscaling=5, bInterpolateAt50pct=0,
+                                                               exfmt=GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"])),
+    ("nv12_1080p_to_480p_bicubic", dict(cformat=1, w=1920, h=1080, kind="noise", seed=321, dst=(854, 480), iDownscaling=3,
+                                        exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])),
+    ("yuv420p10_hlg_1440p_to_540p_bicubic_sharp_letterboxed", dict(cformat=20, w=2560, h=1440, kind="noise", seed=322, dst=(960, 540), iDownscaling=4,
+                                                                   window=(1000, 560), offset=(20, 9), exfmt=GOLDEN_CASES["c5_p010_hlg_lanczos3_2x"]["exfmt"])),
     # a horizontal flip is the X draw's table read from the other end (FillVertices swaps src_l / src_r): same kernel
     ("p010_pq_flipped_1080p_to_1500p_lanczos3", dict(cformat=2, w=1920, h=1080, kind="noise", seed=318, dst=(2666, 1500), iUpscaling=4, flip=1,
                                                      exfmt=GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"])),
@@ -979,7 +986,8 @@ def test_sweep_every_fused_period_instantiation(mpcvr, torch_cuda, ratio, tail, 
 
 _SWEEP_STRIP_SRC = dict(_SWEEP_UP2X_SRC, planar16_generic=(20, dict(misalign=1)), planar8_generic=(14, dict(misalign=1)), p01x_direct10=(2, dict(output_format=1)))
 _SWEEP_STRIP_GEO = {4: ((64, 40), (100, 62), dict(iUpscaling=2)), 6: ((64, 40), (100, 62), dict(iUpscaling=4)),
-                    8: ((208, 104), (80, 40), dict(iDownscaling=2))}          # Hamming 2.6x down: 7 taps -> the 8-tap variant
+                    8: ((208, 104), (80, 40), dict(iDownscaling=2)),          # Hamming 2.6x down: 7 taps -> the 8-tap variant
+                    16: ((208, 104), (80, 40), dict(iDownscaling=3))}         # bicubic 2.6x down: 13 taps -> the 16-tap variant
 
 
 @pytest.mark.parametrize("taps", sorted(_SWEEP_STRIP_GEO))

@@ -23,6 +23,9 @@ CASES = [("C1 1080p NV12 BT.709 -> 1080p BGRA8 (no resize)", 1920, 1080, 1920, 1
          ("1080p NV12 BT.709, Catmull-Rom chroma -> 1440p (Lanczos3)", 1920, 1080, 2560, 1440, dict(iUpscaling=4, iChromaScaling=2), 1, dict(chroma=5, nominal_range=2, matrix=1)),
          ("4K P010 PQ -> 1440p (Hamming down) -> SDR", 3840, 2160, 2560, 1440, dict(iDownscaling=2)),
          ("4K P010 PQ -> 1080p (Hamming down 2x) -> SDR", 3840, 2160, 1920, 1080, dict(iDownscaling=2)),
+         ("4K P010 PQ -> 1080p (Lanczos ps_convolution 2x: 13 taps) -> SDR", 3840, 2160, 1920, 1080, dict(iDownscaling=5, bInterpolateAt50pct=0)),
+         ("4K P010 PQ -> 1080p (Lanczos ps_convolution 2x: 13 taps), block convert + tiled kernel", 3840, 2160, 1920, 1080, dict(iDownscaling=5, bInterpolateAt50pct=0, flags=api.FLAG_NO_STRIP)),
+         ("4K P010 PQ -> 720p (Bicubic down 3x: 13 taps) -> SDR", 3840, 2160, 1280, 720, dict(iDownscaling=3)),
          ("4K NV12 BT.709 -> 1080p (Bicubic down 2x)", 3840, 2160, 1920, 1080, dict(iDownscaling=3), 1, dict(chroma=5, nominal_range=2, matrix=1)),
          ("1080p P010 PQ -> 1440p (Lanczos3 1.33x) -> SDR", 1920, 1080, 2560, 1440, dict(iUpscaling=4)),
          ("720p P010 PQ -> 2160p (Lanczos3 3x) -> SDR", 1280, 720, 3840, 2160, dict(iUpscaling=4)),

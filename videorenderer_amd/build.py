@@ -30,6 +30,10 @@ SOURCES = [
     ("vp_fused_up2x_nt6.hip", []),
     ("vp_fused_mx.hip", []),
     ("vp_fused_strip.hip", []),
+    ("vp_fused_strip_nt4.hip", []),
+    ("vp_fused_strip_nt6.hip", []),
+    ("vp_fused_strip_nt8.hip", []),
+    ("vp_fused_strip_nt16.hip", []),
     ("vp_fused_period.hip", []),
     ("vp_fused_period_4_3.hip", []),
     ("vp_fused_period_3_2.hip", []),

@@ -560,7 +560,7 @@ void BuildPointIndex(int src_l, int src_len, int n_out, int tex_len, std::vector
 // pass, 3 per tap and channel set in the X / Y stages), which is what the kernel is bound by.
 bool PlanFusedStrip(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x, int n_out_y, int src_w, int src_h, StripPlan *sp)
 {
-    if (hx.ntaps < 1 || hx.ntaps > 8 || hy.ntaps < 1 || hy.ntaps > 8 || n_out_x < 1 || n_out_y < 1) return false;
+    if (hx.ntaps < 1 || hx.ntaps > 16 || hy.ntaps < 1 || hy.ntaps > 16 || n_out_x < 1 || n_out_y < 1) return false;
     if (hx.idx.size() != (size_t)n_out_x * hx.ntaps || hy.idx.size() != (size_t)n_out_y * hy.ntaps) return false;
     sp->yrange.resize(2 * (size_t)n_out_y);
     int span = 0, plo = 0, phi = 0;
@@ -572,7 +572,7 @@ bool PlanFusedStrip(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x,
         span = std::max(span, hi - lo + 1);
         plo = lo; phi = hi;
     }
-    sp->ring = span + 1 <= 8 ? 8 : span + 1 <= 16 ? 16 : 0;
+    sp->ring = span + 1 <= 8 ? 8 : span + 1 <= 16 ? 16 : span + 1 <= 32 ? 32 : 0;
     if (!sp->ring) return false;
     std::vector<int> clo(n_out_x), chi(n_out_x);
     for (int x = 0; x < n_out_x; x++) {
@@ -581,12 +581,14 @@ bool PlanFusedStrip(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x,
         if (clo[x] < 0 || chi[x] >= src_w) return false;
     }
     const int mt = std::max(hx.ntaps, hy.ntaps);
-    sp->nt = mt <= 4 ? 4 : mt <= 6 ? 6 : 8;
+    sp->nt = mt <= 4 ? 4 : mt <= 6 ? 6 : mt <= 8 ? 8 : 16;       // 9..16 taps (ps_convolution beyond ~2x with bicubic / Lanczos): one pixel per lane only
+    if (sp->ring == 32 && sp->nt != 16) return false;           // (a 32-row ring exists for the 16-tap kernels)
     const double pairs_per_row = 0.5 * (double)src_h / (double)n_out_y;
     double best = 0;
     int best_w = 0, best_cols = 0, best_pxl = 1;
     for (int pxl : {1, 2})
         for (int lanes : {64, 56, 48, 40, 32, 24, 16}) {
+            if (pxl == 2 && sp->nt == 16) continue;
             const int sw = lanes * pxl;
             int max_nb = 0;
             for (int x0 = 0; x0 < n_out_x; x0 += sw) {

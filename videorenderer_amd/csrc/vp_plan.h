@@ -130,7 +130,7 @@ struct StripPlan {
     std::vector<int32_t> xi_t, yi;   // [nt][n_out_x] tap-major, [n_out_y][nt] row-major
     std::vector<float> xw_t, yw;
 };
-// false: the tables do not fit the kernel (more than 8 taps, a vertical span above 15 rows, non-monotonic tables)
+// false: the tables do not fit the kernel (more than 16 taps, a vertical span above 31 rows, non-monotonic tables)
 bool PlanFusedStrip(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x, int n_out_y, int src_w, int src_h, StripPlan *sp);
 
 // ---- periodic-phase fused kernel (vp_fused_period.h): vertical ratio out : in = P : Q with compile-time tap rows ----
