@@ -840,6 +840,10 @@ PERIOD_SURFACE_CASES = [
     # interleaved RGB without a convert draw: the source texture itself is the surface
     ("r210_540p_to_720p_lanczos3", dict(cformat=32, w=960, h=540, kind="noise", seed=437, dst=(1280, 720), iUpscaling=4), (4, 3, 5)),
     ("rgb32_360p_to_540p_catmull_letterboxed", dict(cformat=30, w=640, h=360, kind="noise", seed=438, dst=(960, 540), iUpscaling=2, window=(980, 560), offset=(10, 9)), (3, 2, 4)),
+    # the draw's row map: a frame turned upside down, an RGB sample with a source rect
+    ("p010_pq_rot180_540p_to_720p_lanczos3", dict(cformat=2, w=960, h=540, kind="noise", seed=439, dst=(1280, 720), iUpscaling=4, rotation=180, exfmt=_PQ), (4, 3, 5)),
+    ("rgb32_source_rect_528_rows_to_704", dict(cformat=30, w=960, h=540, kind="noise", seed=440, src_rect=(16, 6, 944, 534), dst=(1237, 704), iUpscaling=4,
+                                               window=(1244, 710), offset=(2, 3)), (4, 3, 5)),
     ("uyvy_catmull_chroma_540p_to_720p_10bit_target", dict(cformat=5, w=960, h=540, kind="noise", seed=435, dst=(1280, 720), iUpscaling=3, iChromaScaling=2, iTexFormat=10, output_format=1, exfmt=_SDR), (4, 3, 4)),
 ]
 
@@ -877,7 +881,8 @@ def test_period_kernel_from_a_surface(mpcvr, oracle, torch_cuda, label, c, pqn):
     (dict(flip=1), "kernel=fused_period("),                                         # flipped: the X tables read from the other end, still one launch per batch
     (dict(cformat=1, iChromaScaling=2, exfmt=_SDR, flip=1), "kernel=fused_period:surface("),      # convert kernel per batch + the surface variant per batch
     (dict(cformat=1, iChromaScaling=2, exfmt=_SDR, dst=(1300, 700), flip=1), "kernel=fused_strip:surface("),
-    (dict(rotation=180), "kernel=fused_strip:surface("),                                            # upside down: the row map of the surface variant
+    (dict(rotation=180), "kernel=fused_period:surface("),                                           # upside down: the row map of the surface variant
+    (dict(rotation=180, flip=1, dst=(1300, 733)), "kernel=fused_strip:surface("),
     # interleaved RGB without a convert draw: a repack launch per frame into a batch texture, ONE resize launch per batch
     (dict(cformat=30, exfmt=None), "kernel=fused_period:surface("),
     (dict(cformat=32, exfmt=None, src_rect=(8, 4, 952, 536), dst=(1300, 733)), "kernel=fused_strip:surface("),

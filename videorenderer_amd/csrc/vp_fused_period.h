@@ -42,6 +42,7 @@ struct PeriodArgs {
     // SRC_SURFACE: no convert stage — the X draw samples m_TexConvertOutput as another convert kernel wrote it (Dolby Vision, Catmull-Rom
     // chroma ...: B8G8R8A8 or R10G10B10A2 texels); frame z of a batch reads surf + z * surf_stride (null: FusedFrame::src)
     const uint8_t *surf; int surf_fmt, surf_pitch, surf_w; size_t surf_stride;
+    const int32_t *other;                       // SRC_SURFACE: the X draw's row map (row of m_TexResize -> surface row: a source rect, rotation 180); null = identity
 };
 
 namespace {
@@ -199,7 +200,8 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
     auto fetch_s = [&](int pp, int b, uint32_t (&t)[2][2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 2; r++) {
-            const gcptr rowp = py + (uint32_t)clampi(2 * pp - 1 + r, 0, H - 1) * (uint32_t)Q.surf_pitch;
+            const int row = clampi(2 * pp - 1 + r, 0, H - 1);
+            const gcptr rowp = py + (uint32_t)(Q.other ? p_const(Q.other)[row] : row) * (uint32_t)Q.surf_pitch;
 #pragma unroll
             for (int col = 0; col < 2; col++) t[r][col] = ld_u32(rowp + (uint32_t)min(c0 + 2 * b + col, Q.surf_w - 1) * 4u);
         }

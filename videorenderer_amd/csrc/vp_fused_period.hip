@@ -40,9 +40,9 @@ bool FusedPeriodTakes(const FusedStripParams &S)
     static const int off = EnvInt("MPCVR_NO_PERIOD", 0);
     if (off) return false;
     const FusedParams &P = S.fp;
-    // surface mode (the convert output of another kernel feeds the X draw): UNORM texels read row for row — an interleaved RGB sample
-    // with a source rect (row map) or an fp16 internal format stays with k_fused_strip
-    if (S.surface_mode && (S.other || (S.surf.fmt != SF_BGRA8 && S.surf.fmt != SF_RGB10A2) || (S.surf.pitch & 3))) return false;
+    // surface mode (the convert output of another kernel, or an interleaved RGB source texture, feeds the X draw): UNORM texels read row
+    // for row, through the draw's row map where there is one (a source rect, rotation 180); an fp16 internal format stays with k_fused_strip
+    if (S.surface_mode && ((S.surf.fmt != SF_BGRA8 && S.surf.fmt != SF_RGB10A2) || (S.surf.pitch & 3))) return false;
     const int tailk = S.surface_mode ? TAILK_NONE : FusedTailKind(P);
     if (tailk == TAILK_ALU) return false;                         // the literal tails stay with k_fused_strip
     if (S.per_nt < 4 || S.per_nt > 6 || S.per_acols < 2 || (S.per_acols & 1)) return false;
@@ -74,7 +74,7 @@ hipError_t LaunchFusedPeriod(const FusedStripParams &S, const FusedArgs &a, cons
     q.acols = S.per_acols;
     if (S.surface_mode) {
         q.surf = n_frames > 1 || !single.src ? (const uint8_t *)S.surf.ptr : nullptr;      // a batch reads surf + z * stride; one frame: single.src
-        q.surf_fmt = S.surf.fmt; q.surf_pitch = S.surf.pitch; q.surf_w = S.surf.w; q.surf_stride = S.surf_stride;
+        q.surf_fmt = S.surf.fmt; q.surf_pitch = S.surf.pitch; q.surf_w = S.surf.w; q.surf_stride = S.surf_stride; q.other = S.other;
     }
     // segment height (a multiple of the body's PB output rows): long segments recompute less (the taps' span each), short ones fill the chip
     static const int seg_env = EnvInt("MPCVR_PERIOD_SEG", 0);
