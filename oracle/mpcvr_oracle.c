@@ -1041,13 +1041,45 @@ float orc_downscale_filter(int method, float x, float *support)
 /* ------------------------------------------------------------------------------------------ */
 typedef struct { int w, h; float *p; } img_t;   /* RGBA fp32, values as a later texture read returns them */
 
+/* The intermediates of one frame (m_TexConvertOutput, m_TexResize, m_TexsPostScale as fp32 RGBA: 1 GB at 4K -> 8K) come out of a small
+   pool instead of malloc / free per frame: glibc maps and unmaps anything above 32 MiB, and the page faults of a fresh gigabyte per
+   frame cost a 128-thread host a quarter of its frame time (bench.py's cpu_baseline: 2.0 -> 2.8 frames/s; the arithmetic is unchanged).
+   Every image is fully written by the pass that produces it before anything reads it, so a reused buffer needs no clearing. */
+#define ORC_POOL_N 8
+static struct { float *p; size_t bytes; int busy; } g_pool[ORC_POOL_N];
 static int img_alloc(img_t *im, int w, int h)
 {
-    im->w = w; im->h = h;
-    im->p = (float *)malloc((size_t)w * h * 4 * sizeof(float));
+    const size_t need = (size_t)w * h * 4 * sizeof(float);
+    int best = -1, idle = -1;
+    im->w = w; im->h = h; im->p = NULL;
+#pragma omp critical(orc_pool)
+    {
+        for (int i = 0; i < ORC_POOL_N; i++) {
+            if (g_pool[i].busy) continue;
+            if (g_pool[i].p && g_pool[i].bytes >= need && (best < 0 || g_pool[i].bytes < g_pool[best].bytes)) best = i;
+            if (idle < 0 || !g_pool[i].p || (g_pool[idle].p && g_pool[i].bytes < g_pool[idle].bytes)) idle = i;
+        }
+        if (best < 0 && idle >= 0) {            /* nothing fits: replace the smallest idle buffer (or fill an empty slot) */
+            free(g_pool[idle].p);
+            g_pool[idle].p = (float *)malloc(need);
+            g_pool[idle].bytes = g_pool[idle].p ? need : 0;
+            if (g_pool[idle].p) best = idle;
+        }
+        if (best >= 0) { g_pool[best].busy = 1; im->p = g_pool[best].p; }
+    }
+    if (!im->p) im->p = (float *)malloc(need);  /* every slot busy (concurrent callers): a plain allocation */
     return im->p ? 0 : -1;
 }
-static void img_free(img_t *im) { free(im->p); im->p = NULL; }
+static void img_free(img_t *im)
+{
+    int pooled = 0;
+    if (!im->p) return;
+#pragma omp critical(orc_pool)
+    for (int i = 0; i < ORC_POOL_N; i++)
+        if (g_pool[i].p == im->p) { g_pool[i].busy = 0; pooled = 1; }
+    if (!pooled) free(im->p);
+    im->p = NULL;
+}
 
 enum { FMT_BGRA8 = 8, FMT_RGB10A2 = 10, FMT_RGBA16F = 16 };
 
