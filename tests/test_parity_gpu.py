@@ -877,6 +877,37 @@ def test_period_kernel_from_a_surface(mpcvr, oracle, torch_cuda, label, c, pqn):
 
 
 @pytest.mark.parametrize("over,kernel", [
+    (dict(iTexFormat=8), "kernel=fused_period("),            # 8-bit m_TexsPostScale in front of a 10-bit swap chain: the straight store's scale is the texture's
+    (dict(iTexFormat=10), "kernel=fused_period("),
+    (dict(iTexFormat=8, iChromaScaling=2), "kernel=fused_period:surface("),
+    (dict(iTexFormat=8, dst=(1300, 733)), "kernel=fused_strip("),
+])
+def test_fused_resize_in_front_of_the_hdr10_tone_mapping_step(mpcvr, oracle, torch_cuda, over, kernel):
+    """With an HDR10 tone-mapping operator (DX11VideoProcessor.cpp:3359-3367) the resize draws go into m_TexsPostScale (internal format)
+    and the step writes the swap chain: the fused kernels then store straight into a texture whose format is NOT the swap chain's —
+    a fuzz case (8-bit internal format, 10-bit target, 3:1) found the periodic-phase kernel scaling that store with the swap chain's
+    quantiser.  Every fused tier against the plain kernels and the oracle."""
+    torch = torch_cuda
+    from videorenderer_amd import api
+    c = dict(dict(cformat=2, w=960, h=540, kind="noise", seed=450, dst=(1280, 720), iUpscaling=4, exfmt=_PQ, hdr_output=1, output_format=1,
+                  hdr_tonemap=6, hdr_display=400.0, hdr_meta=(0.005, 4000.0, 800.0, 0.0)), **over)
+    got, info = run_product(mpcvr, torch, c)
+    assert kernel in info and "hdr10tonemap" in info, info
+    plain, _ = run_product(mpcvr, torch, c, extra_flags=api.FLAG_NO_FUSED)
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+    # one code of the intermediate (the fused tiers' own bar) through an operator whose slope reaches ~3 at this display peak: 3 x 4 ten-bit
+    # codes behind an 8-bit intermediate, 3 (+ its own rounding) behind a 10-bit one — the fuzz's bars
+    lim = 12 if c["iTexFormat"] == 8 else 4
+    for name, out in (("fused", got), ("plain", plain)):
+        d = np.abs(_codes10(out) - _codes10(want))
+        assert d.max() <= lim and float((d == 0).mean()) >= 0.97, f"{name} [{info}]: max {int(d.max())}, identical {float((d == 0).mean()):.4f}"
+    d = np.abs(_codes10(got) - _codes10(plain))
+    assert d.max() <= lim and float((d == 0).mean()) >= 0.97, f"fused vs plain [{info}]: max {int(d.max())}, identical {float((d == 0).mean()):.4f}"
+
+
+@pytest.mark.parametrize("over,kernel", [
     (dict(), "kernel=fused_period("),
     (dict(flip=1), "kernel=fused_period("),                                         # flipped: the X tables read from the other end, still one launch per batch
     (dict(cformat=1, iChromaScaling=2, exfmt=_SDR, flip=1), "kernel=fused_period:surface("),      # convert kernel per batch + the surface variant per batch

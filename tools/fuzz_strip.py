@@ -103,7 +103,8 @@ for i in range(n):
         # one 8-bit code = 4 ten-bit codes is the bar the whole-frame DoVi test holds it to)
         # (an 8-bit internal format in front of an HDR10 tone-mapping operator: one 8-bit code of the intermediate goes through a curve of
         # slope > 1 before it is rounded to ten bits)
-        lim = (12 if c.get("hdr_tonemap") else 5) if internal_is_8bit(c) else 4 if "dovi" in c else 2 if has_tail(c) else 1
+        # (a 10-bit internal format in front of an operator: one code of the intermediate — the fused tiers' own bar — times a slope of ~3)
+        lim = (12 if c.get("hdr_tonemap") else 5) if internal_is_8bit(c) else 4 if ("dovi" in c or c.get("hdr_tonemap")) else 2 if has_tail(c) else 1
     else:
         d = np.abs(got[..., :3].astype(np.int32) - plain[..., :3].astype(np.int32)); lim = 1
     if i % 5 == 0:      # every fifth case against the CPU oracle as well: the plain tier bit-exact without a transcendental tail,

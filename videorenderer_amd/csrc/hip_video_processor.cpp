@@ -676,16 +676,19 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         if (no_up2x_env && m_strip) m_plan.fused_up2x = false;
     }
     m_period = false;
+    // the store the resize draws will meet: the render target, or m_TexsPostScale in front of the HDR10 tone-mapping step (:3359-3367)
+    const StoreParams probeStore = m_plan.hdr_tonemap ? MakeStore(nullptr, (int)(w2 * SurfBytesPerPixel(m_plan.internal_fmt)), m_plan.internal_fmt, false)
+                                                      : MakeStore(nullptr, m_windowRect.Width() * 4, m_plan.swap_fmt, true);
     if (m_strip) {      // the launch-time conditions that do not depend on the frame pointers
         FusedStripParams sp{};
-        m_strip = FillStripParams(nullptr, nullptr, m_windowRect.Width() * 4, MakeStore(nullptr, m_windowRect.Width() * 4, m_plan.swap_fmt, true), &sp);
+        m_strip = FillStripParams(nullptr, nullptr, probeStore.dst_pitch, probeStore, &sp);
         m_period = m_strip && FusedPeriodTakes(sp);
     }
     if (m_stripPlanned && !m_strip) {
         FusedStripParams sp{};
         const Surface probe = m_plan.convert ? Surface{nullptr, (int)(w1 * SurfBytesPerPixel(m_plan.internal_fmt)), w1, h1, m_plan.internal_fmt}
                                              : Surface{nullptr, TexPitch(), m_srcWidth, m_srcHeight, RgbTexFmt(*m_srcParams)};
-        m_stripSurf = FillStripSurfParams(probe, MakeStore(nullptr, m_windowRect.Width() * 4, m_plan.swap_fmt, true), &sp);
+        m_stripSurf = FillStripSurfParams(probe, probeStore, &sp);
         m_period = m_stripSurf && FusedPeriodTakes(sp);
     }
     m_planDirty = false;

@@ -57,12 +57,16 @@ bool FusedPeriodTakes(const FusedStripParams &S)
 }
 
 // the same launch contract as LaunchFusedStrip (which calls this first); hipErrorNotSupported = not this kernel's case
-hipError_t LaunchFusedPeriod(const FusedStripParams &S, const FusedArgs &a, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s)
+hipError_t LaunchFusedPeriod(const FusedStripParams &S, const FusedArgs &a_in, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s)
 {
     if (!FusedPeriodTakes(S)) return hipErrorNotSupported;
     const FusedParams &P = S.fp;
     const int tailk = S.surface_mode ? TAILK_NONE : FusedTailKind(P), srck0 = S.surface_mode ? SRC_SURFACE : FusedSourceKind(P);
-    const int epik = PeriodEpilogue(S, a.epi_mul);
+    const int epik = PeriodEpilogue(S, a_in.epi_mul);
+    // the straight store writes the TARGET's codes: StoreParams::quant is the swap chain's, which is not the target when the HDR10
+    // tone-mapping step follows (the draw then goes into m_TexsPostScale, internal format — 8-bit texels in front of a 10-bit swap chain)
+    FusedArgs a = a_in;
+    if (epik == EPI_DIRECT8) a.quant = a.out10 ? 1023.0f : 255.0f;
     // built source specialisations: P01x and NV12 (and a surface); everything else reads its layout at run time
     const int srck = (srck0 == SRC_SURFACE || srck0 == SRC_P01X || (srck0 == SRC_NV12 && epik == EPI_DIRECT8)) ? srck0 : SRC_GENERIC;
     const int PB = 6 * S.per_P / S.per_Q;
