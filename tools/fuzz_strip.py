@@ -40,8 +40,14 @@ for i in range(n):
     if mode < 0.12: fx = fy = 1.0
     elif mode < 0.24: fx = fy = 2.0
     dw, dh = max(8, int(round(rw * fx))), max(8, int(round(rh * fy)))
+    periodic_only = bool(os.environ.get("MPCVR_FUZZ_PERIODIC"))     # every case at a periodic row ratio (rows cropped to a multiple of Q)
+    if periodic_only: mode = 0.3
     if 0.24 <= mode < 0.44:          # k_fused_period: output rows : source rows exactly 4:3 / 3:2 / 2:3 / 1:2 / 3:1, any ratio along the rows
         P_, Q_ = [(4, 3), (3, 2), (2, 3), (1, 2), (3, 1)][int(rng.integers(0, 5))]
+        if periodic_only and rh % Q_ and rh - rh % (2 * Q_) >= 16:
+            rh -= rh % (2 * Q_)
+            l_, t_, r_, b_ = c.get("src_rect", (0, 0, w, h))
+            c["src_rect"] = (l_, t_, r_, t_ + rh)
         if rh % Q_ == 0:
             dh = rh * P_ // Q_
             if rng.random() < 0.7: dw = max(8, int(round(rw * P_ / Q_)))
