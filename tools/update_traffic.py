@@ -13,8 +13,9 @@ KERNEL_SOURCES = {
     "hdr4k": ["vp_fused.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
     "up1440": ["vp_fused_period.h", "vp_fused_period.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
     "down1440": ["vp_fused_period.h", "vp_fused_period.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
+    "up2160": ["vp_fused_period.h", "vp_fused_period.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
 }
-ALGO = {"c3hdr": 157593600, "c1": 11404800, "hdr4k": 58060800, "up1440": 20966400, "down1440": 39628800}
+ALGO = {"c3hdr": 157593600, "c1": 11404800, "hdr4k": 58060800, "up1440": 20966400, "down1440": 39628800, "up2160": 35942400}
 
 w, batch, tag = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 m = json.loads([l for l in open(os.path.join(ROOT, "gpurun_out", f"traffic_{w}.json")) if l.startswith("{")][-1])
