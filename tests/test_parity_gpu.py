@@ -918,6 +918,11 @@ def test_fused_resize_in_front_of_the_hdr10_tone_mapping_step(mpcvr, oracle, tor
     (dict(cformat=30, exfmt=None), "kernel=fused_period:surface("),
     (dict(cformat=32, exfmt=None, src_rect=(8, 4, 952, 536), dst=(1300, 733)), "kernel=fused_strip:surface("),
     (dict(cformat=29, exfmt=None, dst=(1301, 733), window=(1320, 740), offset=(6, 3)), "kernel=fused_strip:surface("),
+    # v210: a repack launch per frame into the batch texture (CopyFrameV210), then the whole-batch launches of any 4:2:2 sample
+    (dict(cformat=10), "kernel=fused_period("),
+    (dict(cformat=10, dst=(1920, 1080)), "fused_up2x"),
+    (dict(cformat=10, dst=(960, 540)), "direct:convert"),
+    (dict(cformat=10, dst=(1300, 733), iChromaScaling=2), "kernel=fused_strip:surface("),
 ])
 def test_period_kernel_batches_equal_single_frames(mpcvr, torch_cuda, over, kernel):
     """mpcvr_process_batch through the periodic-phase kernel (and, flipped, through the strip kernel's surface variant): every frame of

@@ -19,6 +19,7 @@ CASES = [("C1 1080p NV12 BT.709 -> 1080p BGRA8 (no resize)", 1920, 1080, 1920, 1
          ("1080p RGB32 -> 1440p (Lanczos3), no convert draw", 1920, 1080, 2560, 1440, dict(iUpscaling=4), 30, dict()),
          ("1080p P210 (4:2:2 10-bit) BT.709 -> 1440p (Lanczos3)", 1920, 1080, 2560, 1440, dict(iUpscaling=4), 6, dict(chroma=5, nominal_range=2, matrix=1)),
          ("1080p YUY2 (packed 4:2:2 8-bit) BT.709 -> 1440p (Lanczos3)", 1920, 1080, 2560, 1440, dict(iUpscaling=4), 4, dict(chroma=5, nominal_range=2, matrix=1)),
+         ("1080p v210 (packed 4:2:2 10-bit, 6 pixels in 16 bytes) BT.709 -> 1440p (Lanczos3)", 1920, 1080, 2560, 1440, dict(iUpscaling=4), 10, dict(chroma=5, nominal_range=2, matrix=1)),
          ("1080p Y210 (packed 4:2:2 10-bit) BT.709 -> 4K (Lanczos3 2x)", 1920, 1080, 3840, 2160, dict(iUpscaling=4), 8, dict(chroma=5, nominal_range=2, matrix=1)),
          ("1080p NV12 BT.709, Catmull-Rom chroma -> 1440p (Lanczos3)", 1920, 1080, 2560, 1440, dict(iUpscaling=4, iChromaScaling=2), 1, dict(chroma=5, nominal_range=2, matrix=1)),
          ("4K P010 PQ -> 1440p (Hamming down) -> SDR", 3840, 2160, 2560, 1440, dict(iDownscaling=2)),

@@ -55,12 +55,26 @@ def _newer(src, dst):
     return not os.path.exists(dst) or os.path.getmtime(src) > os.path.getmtime(dst)
 
 
+def _project_deps(path, seen=None):
+    """The project headers a file includes, transitively (#include "..." resolved beside the file): a translation unit is rebuilt
+    when one of ITS headers changed, not when any header did (a host-only header costs seconds, not the four-minute kernel build)."""
+    import re
+    seen = set() if seen is None else seen
+    try:
+        text = open(path, encoding="utf-8", errors="replace").read()
+    except OSError:
+        return seen
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, flags=re.M):
+        dep = os.path.normpath(os.path.join(os.path.dirname(path), inc))
+        if os.path.exists(dep) and dep not in seen:
+            seen.add(dep)
+            _project_deps(dep, seen)
+    return seen
+
+
 def build(force=False, verbose=False):
     hipcc = _hipcc()
     os.makedirs(BUILD, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
-    headers.append(os.path.join(os.path.dirname(HERE), "include", "mpcvr.h"))
-    hdr_mtime = max(os.path.getmtime(h) for h in headers)
     objs = []
     common = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
     jobs = []
@@ -68,7 +82,7 @@ def build(force=False, verbose=False):
         src = os.path.join(CSRC, name)
         obj = os.path.join(BUILD, name + ".o")
         objs.append(obj)
-        if force or _newer(src, obj) or os.path.getmtime(obj) < hdr_mtime:
+        if force or _newer(src, obj) or any(_newer(h, obj) for h in _project_deps(src)):
             # host files include hip_runtime.h for launch types: everything goes through -x hip
             cmd = [hipcc, "-x", "hip", "-c", src, "-o", obj] + common + extra
             if verbose:

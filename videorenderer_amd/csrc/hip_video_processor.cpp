@@ -1106,6 +1106,25 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
     if (m_planDirty && (hr = UpdatePlan())) return hr;
     for (int i = 0; i < n; i++)
         if (!srcs[i] || !dsts[i]) return Fail(MPCVR_E_POINTER, "null frame in batch");
+    // v210 samples are repacked into m_TexSrcVideo's layout first (CopyFrameV210, Helper.cpp:709-748): a batch gets one repack launch
+    // per frame into a slot of a batch texture, and the whole-batch launches below read the slots as if they were the samples
+    std::vector<const void *> slots;
+    m_batchRepacked = false;
+    if (m_srcParams->cformat == MPCVR_CF_V210 && n > 1 && !(m_cfg.flags & (MPCVR_FLAG_NO_FUSED | MPCVR_FLAG_NO_FAST_CONVERT))) {
+        const int tp = TexPitch();
+        const size_t texBytes = ((size_t)tp * m_srcHeight + 255) & ~(size_t)255;
+        if (texBytes * (size_t)n <= ((size_t)1 << 30)) {
+            if ((hr = CheckHip(m_batchTex.CheckCreate(texBytes * n), "batch source texture"))) return hr;
+            slots.resize(n);
+            for (int i = 0; i < n; i++) {
+                uint8_t *slot = (uint8_t *)m_batchTex.ptr + (size_t)i * texBytes;
+                if ((hr = CheckHip(LaunchRepackV210((const uint8_t *)srcs[i], m_srcPitch, slot, tp, m_srcHeight, m_stream), "k_repack_v210"))) return hr;
+                slots[i] = slot;
+            }
+            srcs = slots.data();
+            m_batchRepacked = true;
+        }
+    }
     bool aligned = true, src4 = true;
     m_batchSrc16 = true;
     for (int i = 0; i < n; i++) {
@@ -1116,7 +1135,7 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
     // samples that are repacked into m_TexSrcVideo first (v210, interleaved RGB) cannot be read in place by a whole-batch launch:
     // they take the frame-by-frame branch below like samples that do not start on a dword (v210 became a fused-2x / strip
     // candidate when packed 4:2:2 joined the block convert)
-    if (m_srcParams->cformat == MPCVR_CF_V210 || m_srcParams->layout == LAY_RGB) src4 = false;
+    if ((m_srcParams->cformat == MPCVR_CF_V210 && !m_batchRepacked) || m_srcParams->layout == LAY_RGB) src4 = false;
     // pass-per-kernel path, whole batch per launch: possible when every stage has a kernel with a frame dimension
     // the arbitrary-ratio fused kernel takes the whole batch in one launch, like the 2x kernel
     FusedStripParams strip_sp{};
@@ -1193,7 +1212,7 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
     if ((!m_plan.fused_up2x && !strip && !batchable) || !src4 || n == 1) {
         // samples that are repacked (or, not starting on a dword, copied) first share m_TexSrcVideo: those batches stay on the
         // context stream, frame by frame
-        const bool repack = m_srcParams->cformat == MPCVR_CF_V210 || m_srcParams->layout == LAY_RGB || !src4;
+        const bool repack = (m_srcParams->cformat == MPCVR_CF_V210 && !m_batchRepacked) || m_srcParams->layout == LAY_RGB || !src4;
         // MPCVR_BATCH_LANES=2..4 deals the frames to that many streams with private intermediates.  Measured on MI355X:
         // +5..10 % on the two-pass resize geometries, -15 % on 1080p same-size (fork/join events cost more than the
         // overlap returns), so one lane is the default.
@@ -1209,7 +1228,8 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
         for (int i = 0; i < n && !hr; i++) {
             const uint8_t *tex;
             UseLane(i % lanes);
-            if ((hr = PrepareSample((const uint8_t *)srcs[i], &tex))) break;
+            if (m_batchRepacked) tex = (const uint8_t *)srcs[i];           // (already in m_TexSrcVideo's layout: a slot of the batch texture)
+            else if ((hr = PrepareSample((const uint8_t *)srcs[i], &tex))) break;
             hr = ProcessOne(tex, dsts[i], rtPitch);
         }
         UseLane(0);
@@ -1282,7 +1302,7 @@ bool CHipVideoProcessor::BatchPlan(const uint8_t *sample0, void *rt0, int rtPitc
     const bool turned = m_plan.flip || m_plan.rotation == 180;
     if (m_plan.hdr_tonemap || (m_plan.rotation && m_plan.rotation != 180) || (turned && !(m_plan.two_pass && m_stripSurf)) || m_secondJinc || !m_plan.convert) return false;
     if (m_firstJinc && !(m_plan.one_pass && m_jincFirstTab)) return false;      // Jinc2m batches: the one-draw quad kernel only
-    if (m_srcParams->cformat == MPCVR_CF_V210 || m_srcParams->layout == LAY_RGB) return false;
+    if ((m_srcParams->cformat == MPCVR_CF_V210 && !m_batchRepacked) || m_srcParams->layout == LAY_RGB) return false;
     const int w1 = m_srcRectWidth, h1 = m_srcRectHeight, w2 = m_videoRect.Width();
     if (m_plan.direct_convert) {
         FillFusedParams(sample0, rt0, rtPitch, direct);

@@ -209,7 +209,8 @@ private:
     void UseLane(int lane);
     // whole-batch launches of the pass-per-kernel path (block convert + folded resize kernels with a frame dimension)
     DevBuffer m_batchConv, m_batchMid;
-    DevBuffer m_batchTex;          // interleaved RGB batches: the frames' m_TexSrcVideo copies side by side (ProcessBatch)
+    DevBuffer m_batchTex;          // interleaved RGB / v210 batches: the frames' m_TexSrcVideo copies side by side (ProcessBatch)
+    bool m_batchRepacked = false;  // the batch at hand reads v210 samples already repacked into m_batchTex
     bool m_batchSrc16 = false;     // every sample of the batch being planned starts on a 16-byte boundary
     // Jinc2m phase tables of the first / second draw (null: weights per pixel)
     DevBuffer m_jincFirst, m_jincSecond;
