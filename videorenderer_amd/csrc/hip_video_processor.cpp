@@ -1107,7 +1107,7 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
     for (int i = 0; i < n; i++)
         if (!srcs[i] || !dsts[i]) return Fail(MPCVR_E_POINTER, "null frame in batch");
     // v210 samples are repacked into m_TexSrcVideo's layout first (CopyFrameV210, Helper.cpp:709-748): a batch gets one repack launch
-    // per frame into a slot of a batch texture, and the whole-batch launches below read the slots as if they were the samples
+    // per 32 frames into the slots of a batch texture, and the whole-batch launches below read the slots as if they were the samples
     std::vector<const void *> slots;
     m_batchRepacked = false;
     if (m_srcParams->cformat == MPCVR_CF_V210 && n > 1 && !(m_cfg.flags & (MPCVR_FLAG_NO_FUSED | MPCVR_FLAG_NO_FAST_CONVERT))) {
@@ -1116,11 +1116,8 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
         if (texBytes * (size_t)n <= ((size_t)1 << 30)) {
             if ((hr = CheckHip(m_batchTex.CheckCreate(texBytes * n), "batch source texture"))) return hr;
             slots.resize(n);
-            for (int i = 0; i < n; i++) {
-                uint8_t *slot = (uint8_t *)m_batchTex.ptr + (size_t)i * texBytes;
-                if ((hr = CheckHip(LaunchRepackV210((const uint8_t *)srcs[i], m_srcPitch, slot, tp, m_srcHeight, m_stream), "k_repack_v210"))) return hr;
-                slots[i] = slot;
-            }
+            if ((hr = CheckHip(LaunchRepackV210(nullptr, m_srcPitch, (uint8_t *)m_batchTex.ptr, tp, m_srcHeight, m_stream, srcs, n, texBytes), "k_repack_v210"))) return hr;
+            for (int i = 0; i < n; i++) slots[i] = (uint8_t *)m_batchTex.ptr + (size_t)i * texBytes;
             srcs = slots.data();
             m_batchRepacked = true;
         }
@@ -1159,7 +1156,7 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
         return hr;
     }
     // Interleaved RGB without a convert draw (m_PSConvColorData.bEnable false, :849-853): every frame is repacked into its own slot of a
-    // batch texture (the reference's CopyFrame* upload, one launch per frame — the repack kernels have no frame dimension) and ONE
+    // batch texture (the reference's CopyFrame* upload: one repack launch per 32 frames, the sample pointers in its arguments) and ONE
     // k_fused_strip:surface launch resizes the whole chunk from there, instead of a repack + a resize launch per frame
     if (m_srcParams->layout == LAY_RGB && !m_plan.convert && m_stripSurf && m_plan.two_pass && !m_plan.hdr_tonemap && n > 1 &&
         !(m_cfg.flags & (MPCVR_FLAG_NO_FUSED | MPCVR_FLAG_NO_FAST_CONVERT | MPCVR_FLAG_NO_STRIP))) {
@@ -1196,9 +1193,8 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
             (void)hipEventRecord(m_evStart, m_stream);
             for (int at = 0; at < n && !hr; at += chunk) {
                 const int m = std::min(chunk, n - at);
-                for (int z = 0; z < m && !hr; z++)
-                    hr = CheckHip(LaunchRepackRgb(m_srcParams->repack, (const uint8_t *)srcs[at + z], m_srcBottomUp ? -m_srcPitch : m_srcPitch,
-                                                  (uint8_t *)m_batchTex.ptr + (size_t)z * texBytes, tp, m_srcWidth, m_srcHeight, m_stream), "k_repack_rgb");
+                hr = CheckHip(LaunchRepackRgb(m_srcParams->repack, nullptr, m_srcBottomUp ? -m_srcPitch : m_srcPitch, (uint8_t *)m_batchTex.ptr, tp,
+                                              m_srcWidth, m_srcHeight, m_stream, srcs + at, m, texBytes), "k_repack_rgb");
                 if (!hr) hr = CheckHip(LaunchFusedStrip(ssp, (const FusedFrame *)slot.dev.ptr + at, FusedFrame{nullptr, nullptr}, m, m_stream), "k_fused_strip<surface>");
             }
             (void)hipEventRecord(m_evStop, m_stream);

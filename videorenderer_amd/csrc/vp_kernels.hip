@@ -686,11 +686,13 @@ static inline dim3 grid2d(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4
 
 // CopyFrameV210 (Helper.cpp:709-748) on the device: v210 dwords -> Y210 words (10 bits in the MSBs), one thread per
 // pair of dwords (= 6 words), plus the reference's one-dword remainder at the end of a row
+// (srcs.n != 0: a batch — frame z = blockIdx.z reads srcs.f[z].src and writes dst + z * dst_stride)
 __global__ __launch_bounds__(256) void k_repack_v210(const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch,
-                                                      int lines, int line_blocks, int remainder)
+                                                      int lines, int line_blocks, int remainder, SrcTable32 srcs, size_t dst_stride)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (y >= lines || i > line_blocks) return;
+    if (srcs.n) { src = srcs.p[blockIdx.z]; dst += (size_t)blockIdx.z * dst_stride; }
     const uint32_t *src32 = (const uint32_t *)(src + (size_t)y * src_pitch) + 2 * i;
     uint16_t *dst16 = (uint16_t *)(dst + (size_t)y * dst_pitch) + 6 * i;
     if (i < line_blocks) {
@@ -712,10 +714,11 @@ __global__ __launch_bounds__(256) void k_repack_v210(const uint8_t *src, int src
 // 647-663 BGRA64, 665-683 b64a, 770-787 r210, 414-428 as-is) as one texel per thread.  `n_px` = pixels the reference loop
 // writes per row (RGB48: whole groups of four only, as written); bottom_up: negative source pitch (:1243-1248).
 __global__ __launch_bounds__(256) void k_repack_rgb(int kind, const uint8_t *src, int src_pitch_abs, int bottom_up,
-                                                     uint8_t *dst, int dst_pitch, int n_px, int lines)
+                                                     uint8_t *dst, int dst_pitch, int n_px, int lines, SrcTable32 srcs, size_t dst_stride)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (y >= lines || i >= n_px) return;
+    if (srcs.n) { src = srcs.p[blockIdx.z]; dst += (size_t)blockIdx.z * dst_stride; }
     const uint8_t *srow = src + (size_t)(bottom_up ? lines - 1 - y : y) * src_pitch_abs;
     uint8_t *drow = dst + (size_t)y * dst_pitch;
     if (kind == RPK_NONE) { ((uint32_t *)drow)[i] = ((const uint32_t *)srow)[i]; return; }
@@ -748,7 +751,17 @@ __global__ __launch_bounds__(256) void k_repack_rgb(int kind, const uint8_t *src
     d[0] = c0; d[1] = c1; d[2] = c2; d[3] = 0xffff;
 }
 
-hipError_t LaunchRepackRgb(int kind, const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int width, int lines, hipStream_t s)
+// batches: up to 32 source pointers travel in the kernel arguments per launch
+static SrcTable32 SrcTable(const void *const *srcs, int at, int n)
+{
+    SrcTable32 t;
+    t.n = n;
+    for (int i = 0; i < 32; i++) t.p[i] = i < n ? (const uint8_t *)srcs[at + i] : nullptr;
+    return t;
+}
+
+hipError_t LaunchRepackRgb(int kind, const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int width, int lines, hipStream_t s,
+                           const void *const *srcs, int n, size_t dst_stride)
 {
     const int ap = src_pitch < 0 ? -src_pitch : src_pitch;
     const int bpp = kind == RPK_RGB24 ? 3 : (kind == RPK_RGB48 || kind == RPK_BGR48) ? 6 : (kind == RPK_BGRA64 || kind == RPK_B64A) ? 8 : 4;
@@ -756,18 +769,35 @@ hipError_t LaunchRepackRgb(int kind, const uint8_t *src, int src_pitch, uint8_t 
     if (n_px > width) n_px = width;                        // the texture row holds `width` texels
     if (kind == RPK_RGB48) n_px &= ~3;                     // CopyFrameRGB48 has no remainder branch (:552-563)
     if (n_px <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_repack_rgb, dim3((n_px + 255) / 256, lines, 1), dim3(256, 1, 1), 0, s,
-                       kind, src, ap, src_pitch < 0 ? 1 : 0, dst, dst_pitch, n_px, lines);
+    if (!srcs) {
+        hipLaunchKernelGGL(k_repack_rgb, dim3((n_px + 255) / 256, lines, 1), dim3(256, 1, 1), 0, s,
+                           kind, src, ap, src_pitch < 0 ? 1 : 0, dst, dst_pitch, n_px, lines, SrcTable32{}, (size_t)0);
+        return hipGetLastError();
+    }
+    for (int at = 0; at < n; at += 32) {
+        const int m = n - at < 32 ? n - at : 32;
+        hipLaunchKernelGGL(k_repack_rgb, dim3((n_px + 255) / 256, lines, m), dim3(256, 1, 1), 0, s,
+                           kind, nullptr, ap, src_pitch < 0 ? 1 : 0, dst + (size_t)at * dst_stride, dst_pitch, n_px, lines, SrcTable(srcs, at, m), dst_stride);
+    }
     return hipGetLastError();
 }
 
-hipError_t LaunchRepackV210(const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int lines, hipStream_t s)
+hipError_t LaunchRepackV210(const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int lines, hipStream_t s,
+                            const void *const *srcs, int n, size_t dst_stride)
 {
     const int dq = dst_pitch / 12, dr = dst_pitch % 12, sq = src_pitch / 8, sr = src_pitch % 8;
     int line_blocks, remainder;
     if (dq <= sq) { line_blocks = dq; remainder = dr != 0; } else { line_blocks = sq; remainder = sr != 0; }
-    hipLaunchKernelGGL(k_repack_v210, dim3((line_blocks + 1 + 255) / 256, lines, 1), dim3(256, 1, 1), 0, s,
-                       src, src_pitch, dst, dst_pitch, lines, line_blocks, remainder);
+    if (!srcs) {
+        hipLaunchKernelGGL(k_repack_v210, dim3((line_blocks + 1 + 255) / 256, lines, 1), dim3(256, 1, 1), 0, s,
+                           src, src_pitch, dst, dst_pitch, lines, line_blocks, remainder, SrcTable32{}, (size_t)0);
+        return hipGetLastError();
+    }
+    for (int at = 0; at < n; at += 32) {
+        const int m = n - at < 32 ? n - at : 32;
+        hipLaunchKernelGGL(k_repack_v210, dim3((line_blocks + 1 + 255) / 256, lines, m), dim3(256, 1, 1), 0, s,
+                           nullptr, src_pitch, dst + (size_t)at * dst_stride, dst_pitch, lines, line_blocks, remainder, SrcTable(srcs, at, m), dst_stride);
+    }
     return hipGetLastError();
 }
 

@@ -11,9 +11,13 @@ namespace mpcvr {
 hipError_t LaunchConvert(const ConvertParams &P, const Surface &out, hipStream_t s, bool generic = false);
 hipError_t LaunchConvertDirect(const ConvertParams &P, const StoreParams &st, hipStream_t s);
 // CopyFrameRGB24 / R210 / RGB48 / BGR48 / BGRA64 / B64A / CopyPlaneAsIs: interleaved RGB sample -> its texture
-hipError_t LaunchRepackRgb(int kind, const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int width, int lines, hipStream_t s);
+// srcs != nullptr: a batch of n samples in one launch per 32 frames — frame z reads srcs[z] and writes dst + z * dst_stride (src unused)
+struct SrcTable32 { const uint8_t *p[32]; int n; };
+hipError_t LaunchRepackRgb(int kind, const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int width, int lines, hipStream_t s,
+                           const void *const *srcs = nullptr, int n = 1, size_t dst_stride = 0);
 // CopyFrameV210 (Helper.cpp:709-748): v210 sample -> Y210-layout texture
-hipError_t LaunchRepackV210(const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int lines, hipStream_t s);
+hipError_t LaunchRepackV210(const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int lines, hipStream_t s,
+                            const void *const *srcs = nullptr, int n = 1, size_t dst_stride = 0);
 // axis = screen axis the tap table runs along; swap = rotation 90/270 (taps address the other texture axis)
 // batch: n frames per launch (folded kernels only) — frame z reads in.ptr + z * in_stride and writes frames[z].dst when a
 // frame table is given, else st.dst + z * dst_stride.  Returns hipErrorNotSupported when the draw has no folded kernel.
