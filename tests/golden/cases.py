@@ -221,6 +221,14 @@ FULL_SIZE_CASES = {
     "down1440": dict(cformat=2, w=3840, h=2160, kind="noise", seed=312, dst=(2560, 1440), exfmt=HDR10, iDownscaling=2),
     "up1080_from_720_nv12": dict(cformat=1, w=1280, h=720, kind="noise", seed=318, dst=(1920, 1080), exfmt=ext(matrix=M709), iUpscaling=2),
     "down1080_from_4k_hlg": dict(cformat=2, w=3840, h=2160, kind="noise", seed=315, dst=(1920, 1080), exfmt=HLG, iUpscaling=1),
+    # round 3's new geometries: 3:1 (every third row and column exactly on a texel centre: the fp32 texcoord decides the tap rows),
+    # a flipped and an upside-down frame, a 13-tap ps_convolution downscale
+    "up2160_from_720": dict(cformat=2, w=1280, h=720, kind="noise", seed=417, dst=(3840, 2160), exfmt=HDR10, iUpscaling=4),
+    "up720_from_240_nv12_catmull": dict(cformat=1, w=426, h=240, kind="noise", seed=415, dst=(1278, 720), exfmt=ext(matrix=M709), iUpscaling=2),
+    "flipped_540_to_720_nv12": dict(cformat=1, w=960, h=540, kind="noise", seed=418, dst=(1280, 720), exfmt=ext(matrix=M709), iUpscaling=4, flip=1),
+    "rot180_540_to_720_pq": dict(cformat=2, w=960, h=540, kind="noise", seed=439, dst=(1280, 720), exfmt=HDR10, iUpscaling=4, rotation=180),
+    "down1080_from_4k_lanczos_convolution": dict(cformat=2, w=3840, h=2160, kind="noise", seed=320, dst=(1920, 1080), exfmt=HDR10, iDownscaling=5,
+                                                 bInterpolateAt50pct=0),
 }
 
 # the two ColorFormat_t values no other case carries (P216, YUV422P16): with them the reference-text comparison covers all 39 formats

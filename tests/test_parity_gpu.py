@@ -663,6 +663,13 @@ FULL_SIZE_TIERS = {
     "up1080_from_720_nv12": (("FLAG_FORCE_PERIOD", "period", 0.99996), (0, "strip", 0.99996), ("FLAG_NO_STRIP", "passes:convert,resizeX,resizeY", 0.99998),      # 0.999981 0.999991 1.0
                              ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY", 1.0)),
     "down1080_from_4k_hlg": ((0, "period", 0.99877), ("FLAG_NO_PERIOD", "strip", 0.99877), ("FLAG_NO_STRIP", "passes:convert,resizeX,resizeY", 0.9988), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 0.99939)),   # 0.999386 0.999401 0.999695
+    # round 3's new paths against the reference text
+    "up2160_from_720": ((0, "period", 0.99939), ("FLAG_NO_PERIOD", "strip", 0.99939), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 0.99992)),      # 0.999695 0.999695 0.999962
+    "up720_from_240_nv12_catmull": (("FLAG_FORCE_PERIOD", "period", 0.99997), (0, "strip", 0.99997), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY", 1.0)),  # 0.999988 0.999988 1.0
+    "flipped_540_to_720_nv12": ((0, "period", 0.99996), ("FLAG_NO_PERIOD", "strip", 0.99996), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY", 1.0)),          # 0.999984 0.999984 1.0
+    "rot180_540_to_720_pq": ((0, "period:surface", 0.99936), ("FLAG_NO_PERIOD", "strip:surface", 0.99936), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 0.99992)),   # 0.999683 0.999683 0.999960
+    "down1080_from_4k_lanczos_convolution": ((0, "strip", 0.99925), ("FLAG_NO_STRIP", "passes:convert,resizeX,resizeY", 0.99928),         # 0.999629 0.999644 0.999960
+                                             ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 0.99992)),
 }
 
 
@@ -681,7 +688,7 @@ def test_full_size_hip_vs_reference_shader_text(mpcvr, oracle, torch_cuda, name)
     for flag, path, floor in FULL_SIZE_TIERS[name]:
         flags = getattr(api, flag) if flag else 0
         got, info = run_product(mpcvr, torch, c, extra_flags=flags)
-        assert info.startswith(path) or (path in ("period", "strip") and f"kernel=fused_{path}(" in info), (name, flag, info)
+        assert info.startswith(path) or (path in ("period", "strip", "period:surface", "strip:surface") and f"kernel=fused_{path}(" in info), (name, flag, info)
         assert bool((got[..., 3] == 255).all())
         same = compare(got, want, f"{name} flags={flag} [{info}]", exact=(floor == 1.0), min_same=floor)
         print(f"FULLSIZE {name} {flag or 'default'} [{info}] vs reference text ({'live' if live else 'recorded hash'}): identical channels {same:.6f}")
