@@ -87,6 +87,9 @@ def run_product(mpcvr, torch, c, extra_flags=0, host_upload=False):
 # whole frames (>= 0.4 M pixels): the smallest share of identical channels measured over every such comparison of the suite is 0.99922
 # (profiles/r03/parity_identical_channels.jsonl, MPCVR_PARITY_LOG); the floor is 1 - 2 x (1 - that): twice today's worst fails
 WHOLE_FRAME_FLOOR = 0.9984
+# Dolby Vision frames through the fused resize kernels ("hdr" content: bright saturated colours behind the reshaping and both PQ chains)
+# measure 0.99846 .. 0.99854 on every tier, the plain kernels included: the same rule gives them their own floor
+DOVI_RESIZE_FLOOR = 0.9969
 POW_ULPS = 4      # Direct3D's pow is exp2(y * log2 x): with 1-ulp log2 / exp2 the result is off by up to ~0.35 |y log2 x| + 1.5 ulp (4 at x = 1e-4, y = 1/2.2)
 
 
@@ -877,7 +880,7 @@ def test_period_kernel_from_a_surface(mpcvr, oracle, torch_cuda, label, c, pqn):
         return
     for out, tag in ((got, info), (alt, info_alt)):
         if has_tail(c):
-            same, _ = compare_behind_tail(oracle, p, frame, pitch, out, want, f"{label} [{tag}]", min_same=WHOLE_FRAME_FLOOR)
+            same, _ = compare_behind_tail(oracle, p, frame, pitch, out, want, f"{label} [{tag}]", min_same=DOVI_RESIZE_FLOOR if c.get("dovi") else WHOLE_FRAME_FLOOR)
         else:
             same = compare(out, want, f"{label} [{tag}]", min_same=WHOLE_FRAME_FLOOR)
         print(f"PERIOD:SURFACE {label}: identical channels {same:.6f}  [{tag}]")
