@@ -161,7 +161,21 @@ def cpu_baseline(wl, extfmt, seconds_budget=10.0):
             return p, np.zeros((ph, pw, 4), dtype=np.uint8)
 
         L = _oracle_cdll(O)
-        threads = L.orc_num_threads()
+        # threads: what the host lets this process use — the affinity mask and the cgroup's CPU quota (a 256-CPU box may grant 16:
+        # OpenMP's default of one thread per logical CPU then spends its time being throttled)
+        avail = os.cpu_count() or 1
+        try:
+            avail = min(avail, len(os.sched_getaffinity(0)))
+        except Exception:
+            pass
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                avail = max(1, min(avail, -(-int(q) // int(per))))
+        except Exception:
+            pass
+        threads = max(1, min(int(L.orc_num_threads()), avail))
+        L.orc_set_num_threads(threads)
         p, dst = params()
         dt, n = time_frames(L, p, dst, seconds_budget)
         rows["sse2_all_threads"] = {"frames_per_s": round(1.0 / dt, 4), "threads": int(threads), "flags": "-O3 -msse2 -fopenmp",
@@ -171,11 +185,12 @@ def cpu_baseline(wl, extfmt, seconds_budget=10.0):
         L.orc_set_num_threads(1)
         p1, d1 = params((0, 0, w, band))
         dt1, n1 = time_frames(L, p1, d1, seconds_budget / 2)
-        L.orc_set_num_threads(0)
+        L.orc_set_num_threads(threads)
         rows["sse2_one_thread"] = {"frames_per_s": round(band / h / dt1, 5), "threads": 1, "flags": "-O3 -msse2",
                                    "sample": f"{n1} bands of {w}x{band} source rows ({band}/{h} of a frame), {dt1*1e3:.0f} ms/band"}
         try:
             Ln = _oracle_cdll(O, native=True)
+            Ln.orc_set_num_threads(threads)
             dtn, nn = time_frames(Ln, p, dst, seconds_budget / 2)
             rows["native_all_threads"] = {"frames_per_s": round(1.0 / dtn, 4), "threads": int(Ln.orc_num_threads()),
                                           "flags": "-O3 -march=native -fopenmp", "sample": f"{nn} full frames, {dtn*1e3:.0f} ms/frame"}
@@ -199,6 +214,20 @@ def cpu_baseline(wl, extfmt, seconds_budget=10.0):
             rep[nm] = {"frames_per_s": round(1.0 / d, 1), "GBps": round(frame.size / d / 1e9, 2)}
         rows["upload_repack_one_thread"] = dict(rep, sample=f"20 x one {frame.size}-byte sample ({w}x{h}, pitch {pitch} -> {tp}), Helper.cpp:414-428 / 789-803 restated in C")
         main = rows["sse2_all_threads"]
+        # what the threads could run on: the scheduler's affinity mask, the cgroup's CPU quota (cpu.max: "<quota> <period>" or "max"), the
+        # machine's logical CPUs — 128 OpenMP threads on a quota of a few cores is not a 128-core baseline
+        host = {"logical_cpus": os.cpu_count()}
+        try:
+            host["affinity_cpus"] = len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+        for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            try:
+                host["cgroup_" + os.path.basename(f)] = open(f).read().strip()
+                break
+            except OSError:
+                pass
+        rows["host"] = host
         return {"value": main["frames_per_s"], "unit": "frames/s", "cores": main["threads"], "kind": "port",
                 "sample": main["sample"] + ", oracle C (" + main["flags"] + ")", "rows": rows}
     except Exception as e:      # reported side figure: the bench line still goes out, but the failure is loud
