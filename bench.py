@@ -161,19 +161,8 @@ def cpu_baseline(wl, extfmt, seconds_budget=10.0):
             return p, np.zeros((ph, pw, 4), dtype=np.uint8)
 
         L = _oracle_cdll(O)
-        # threads: what the host lets this process use — the affinity mask and the cgroup's CPU quota (a 256-CPU box may grant 16:
-        # OpenMP's default of one thread per logical CPU then spends its time being throttled)
-        avail = os.cpu_count() or 1
-        try:
-            avail = min(avail, len(os.sched_getaffinity(0)))
-        except Exception:
-            pass
-        try:
-            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-            if q != "max":
-                avail = max(1, min(avail, -(-int(q) // int(per))))
-        except Exception:
-            pass
+        # threads: what the host lets this process use — the affinity mask and the cgroup's CPU quota (oracle.host_cpus)
+        avail = O.host_cpus()
         threads = max(1, min(int(L.orc_num_threads()), avail))
         L.orc_set_num_threads(threads)
         p, dst = params()

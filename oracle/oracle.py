@@ -10,6 +10,28 @@ import subprocess
 
 import numpy as np
 
+
+
+def host_cpus():
+    """CPUs this process may actually use: logical CPUs, capped by the affinity mask and the cgroup's CPU quota (a 256-CPU box may
+    grant 16; OpenMP's default of one thread per logical CPU is then throttled to a fraction of a core each)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, -(-int(q) // int(per))))
+    except Exception:
+        pass
+    return n
+
+
+# the oracle and the reference-text harness are OpenMP code: tell their runtime before it starts (the libraries are loaded later)
+os.environ.setdefault("OMP_NUM_THREADS", str(host_cpus()))
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_build", "libmpcvr_oracle.so")
 REF_PATH = os.path.join(HERE, "_ref", "libref_csputils.so")
@@ -186,6 +208,7 @@ def lib():
         L.orc_correction_matrices.argtypes = [fp, fp, fp]
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_set_num_threads(min(int(L.orc_num_threads()), host_cpus()))
         _lib = L
     return _lib
 
