@@ -1,8 +1,8 @@
 """ctypes loader for the CPU oracle (oracle/mpcvr_oracle.c) and, when built, the real-reference
 csputils library (oracle/_ref/libref_csputils.so).
 
-TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
-leg — never by the product package (videorenderer_amd/).
+TEST INFRASTRUCTURE ONLY: imported by tests/ (the suite and its checker scripts under tests/tools/: fuzz, diagnostics),
+__graft_entry__.smoke() and bench.py's cpu_baseline leg — never by the product package (videorenderer_amd/) or tools/.
 """
 import ctypes as C
 import os

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""tools/diag_case.py '<case dict>' — one case through the default planner, the plain kernels and the CPU oracle: where do they differ?"""
+"""tests/tools/diag_case.py '<case dict>' — one case through the default planner, the plain kernels and the CPU oracle: where do they differ?"""
 import sys, os, ast
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from videorenderer_amd import api
 from tests.golden.cases import case_frame, oracle_params

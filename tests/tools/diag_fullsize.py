@@ -1,6 +1,6 @@
 """GPU diagnostic: locate fused-vs-general mismatches > 1 LSB at full size and compare both to the oracle."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from videorenderer_amd import api
 from oracle import oracle as O

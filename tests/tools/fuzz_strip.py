@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""tools/fuzz_strip.py [n] [seed] — a wider net than the test suite's geometries for the fused kernels (arbitrary-ratio strip kernel,
+"""tests/tools/fuzz_strip.py [n] [seed] — a wider net than the test suite's geometries for the fused kernels (arbitrary-ratio strip kernel,
 exact-2x kernel, one-kernel same-size convert): n random (source format out of all layouts, chroma setting, size, source rect, ratio
 per axis, scaler, window offset / clipping, internal format, output format, HDR tagging)
 combinations, default planner against the plain kernels (MPCVR_FLAG_NO_FUSED): every channel within 1 LSB (8-bit targets) /
 the 10-bit bars of tests/test_parity_gpu.py.  Prints which kernels the cases went through."""
 import sys, os, collections
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from videorenderer_amd import api
 from tests.golden.cases import GOLDEN_CASES, case_frame, oracle_params, HDR10, HLG
