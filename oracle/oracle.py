@@ -20,12 +20,18 @@ def host_cpus():
         n = min(n, len(os.sched_getaffinity(0)))
     except Exception:
         pass
-    try:
+    try:                                            # cgroup v2
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
         if q != "max":
             n = max(1, min(n, -(-int(q) // int(per))))
     except Exception:
-        pass
+        try:                                        # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = max(1, min(n, -(-q // per)))
+        except Exception:
+            pass
     return n
 
 
