@@ -394,7 +394,7 @@ def main():
         achieved = algo_bytes * args.batch / (launch_ms * 1e-3) / 1e9          # GB/s, algorithmic bytes per launch
         # HBM traffic from the PMC counters is NOT measured by this run: it comes from the committed rocprofv3 --pmc passes
         # (profiles/hbm_traffic.json), and only when the kernels have not changed since (sha256 over videorenderer_amd/csrc)
-        traffic, traffic_source = None, None
+        traffic, traffic_source, valu_issue = None, None, None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tf):
             try:
@@ -404,6 +404,11 @@ def main():
                     if t.get("csrc_sha256") == csrc_digest(t.get("sources")):
                         traffic = t["bytes_per_launch"]
                         traffic_source = f"profiles/hbm_traffic.json [{t.get('profile', '?')}]: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes"
+                        if t.get("valu_issue_frac"):
+                            # the roof that binds the fused kernels: the share of the launch during which a SIMD's VALU pipe is issuing
+                            # (1.0 = no free issue slot left).  From the same committed PMC passes as `traffic`, tied to the same sources.
+                            valu_issue = {"bound": "valu_issue", "frac": t["valu_issue_frac"], "wait_inst_any_share": t.get("wait_inst_any_share"),
+                                          "source": f"profiles/hbm_traffic.json [{t.get('profile', '?')}]: SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs over SQ_BUSY_CYCLES / 32, rocprofv3 --pmc pass of tools/pmc_traffic.sh"}
                     else:
                         traffic_source = f"omitted: kernels changed since profile {t.get('profile', '?')} (csrc hash differs)"
             except Exception as e:
@@ -429,13 +434,11 @@ def main():
                          "empirical_copy_peak_GBps": round(copy_gbps, 1) if copy_gbps else None,
                          "frac_of_empirical_copy_peak": round(achieved / copy_gbps, 4) if copy_gbps else None},
         }
-        if args.workload == "c3hdr":
-            # the path is co-limited: the as-written arithmetic of one frame is ~4.3 GFLOP = 27 FLOP per algorithmic byte
-            # against a machine balance of ~20 (157.3 TFLOP/s packed fp32 / 8 TB/s).  Reported beside the HBM fraction, not instead of it.
-            flop = 4.3e9
-            res["roofline"]["co_limit"] = {"bound": "valu_fp32", "model_flop_per_frame": flop, "achieved_TFLOPs": round(flop * args.batch / (launch_ms * 1e-3) / 1e12, 1),
-                                           "peak_TFLOPs": 157.3, "frac": round(flop * args.batch / (launch_ms * 1e-3) / 157.3e12, 4),
-                                           "note": "SURVEY.md 8d FLOP model (taps, roundings, dither, matrix, HDR tail; transcendentals counted once)"}
+        # the fused kernels are bound by VALU issue slots, not by HBM (traffic is ~1.04x algorithmic): the measured occupancy of that
+        # roof rides beside the HBM fraction — frac_at_full_issue is what the HBM fraction would be with every issue slot used
+        if valu_issue:
+            valu_issue["hbm_frac_at_full_issue"] = round(achieved / HBM_PEAK_GBS / valu_issue["frac"], 4)
+            res["roofline"]["co_limit"] = valu_issue
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wl, extfmt)
         if host_path:

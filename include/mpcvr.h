@@ -274,6 +274,17 @@ int32_t mpcvr_process_batch(mpcvr_ctx *ctx, int32_t n, const void *const *srcs, 
  * Two-call size protocol. */
 int32_t mpcvr_get_param_blob(mpcvr_ctx *ctx, void *buf, size_t *size);
 int32_t mpcvr_set_param_blob(mpcvr_ctx *ctx, const void *buf, size_t size);
+/* The same exchange done by the library over RCCL ("one ncclBroadcast (RCCL, root 0) at context creation") for hosts
+ * without Python: `nccl_comm` is an ncclComm_t the host created (ncclCommInitRank in a process-per-GPU host, ncclCommInitAll when
+ * one process drives several devices), `rank` this context's rank in it.  The broadcast runs on the context's stream; the
+ * library resolves librccl at the first call (it is not a link-time dependency).
+ *   one process per GPU:       mpcvr_broadcast_param_blob(ctx, comm, 0, rank);
+ *   one process, N devices:    ncclGroupStart(); for d: mpcvr_broadcast_param_blob_begin(ctx[d], comm[d], 0, d); ncclGroupEnd();
+ *                              for d: mpcvr_broadcast_param_blob_end(ctx[d]);            (examples/c_multi_gpu_rccl.c)
+ * There is no reference line to cite: the reference is single-GPU (Source/DX11Helper.cpp:81-112). */
+int32_t mpcvr_broadcast_param_blob_begin(mpcvr_ctx *ctx, void *nccl_comm, int32_t root, int32_t rank);
+int32_t mpcvr_broadcast_param_blob_end(mpcvr_ctx *ctx);
+int32_t mpcvr_broadcast_param_blob(mpcvr_ctx *ctx, void *nccl_comm, int32_t root, int32_t rank);
 
 /* Introspection used by tests / stats (GetVPInfo analogue, DX11VideoProcessor.cpp:4100+). */
 int32_t mpcvr_get_color_matrix(mpcvr_ctx *ctx, float out12[12]);     /* cm_r, cm_g, cm_b, cm_c */

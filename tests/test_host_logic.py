@@ -374,14 +374,19 @@ def test_correction_matrices(mpcvr, oracle):
 
 
 # ---------------------------------------------------------------- the C-ABI from plain C
-def build_c_demo(tmpdir, name="c_abi_demo"):
+def build_c_demo(tmpdir, name="c_abi_demo", rccl=False):
+    """gcc -std=c99 on examples/<name>.c against include/mpcvr.h and libmpcvr.so; rccl: the host also talks to RCCL itself
+    (rccl.h pulls in the HIP runtime API header, which is not -Werror clean as C)."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(str(tmpdir), name)
-    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-std=c99", "-I" + os.path.join(root, "include"),
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    extra_c = ["-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include")] if rccl else ["-Werror"]
+    extra_l = ["-L" + os.path.join(rocm, "lib"), "-lrccl", "-lamdhip64", "-Wl,-rpath," + os.path.join(rocm, "lib")] if rccl else []
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-std=c99"] + extra_c + ["-I" + os.path.join(root, "include"),
                            os.path.join(root, "examples", name + ".c"), "-o", exe,
                            "-L" + os.path.join(root, "videorenderer_amd"), "-lmpcvr",
-                           "-Wl,-rpath," + os.path.join(root, "videorenderer_amd")])
+                           "-Wl,-rpath," + os.path.join(root, "videorenderer_amd")] + extra_l)
     return exe
 
 
@@ -391,6 +396,8 @@ def test_c_abi_links_from_plain_c(mpcvr, tmp_path):
     exe = build_c_demo(tmp_path)
     assert os.path.exists(exe)
     assert os.path.exists(build_c_demo(tmp_path, "c_multi_gpu"))      # one context per device, parameter blob shared, frames by index
+    # the same with the blob broadcast by the library over RCCL (mpcvr_broadcast_param_blob_begin / _end inside the host's nccl group)
+    assert os.path.exists(build_c_demo(tmp_path, "c_multi_gpu_rccl", rccl=True))
 
 
 

@@ -91,6 +91,17 @@ WHOLE_FRAME_FLOOR = 0.9984
 # measure 0.99846 .. 0.99854 on every tier, the plain kernels included: the same rule gives them their own floor
 DOVI_RESIZE_FLOOR = 0.9969
 POW_ULPS = 4      # Direct3D's pow is exp2(y * log2 x): with 1-ulp log2 / exp2 the result is off by up to ~0.35 |y log2 x| + 1.5 ulp (4 at x = 1e-4, y = 1/2.2)
+# How MANY channels may sit beyond 1 LSB behind their witness (compare_behind_tail), from what was measured, not from a blanket share:
+# Dolby Vision frames (reshaping + two PQ chains in front of the cancelling 2020 -> 709 row): at most 16 per 2.07 M-pixel frame over the
+# whole round-3 suite (profiles/r03/parity_identical_channels.jsonl: 1-16, 17 of 1,187 comparisons) = 7.7 per million pixels; the cap
+# is twice that.  Every other frame: none — except the cases named here, each with the count it was witnessed with.
+ILL_CONDITIONED_PER_MPX_DOVI = 16
+KNOWN_ILL_CONDITIONED = {
+    # one channel, 2 LSB, on the block-convert kernel only (the plain per-pixel kernel is within 1): a saturated BT.2020 colour whose
+    # blue cancels to 2e-4 of its terms behind the 2020 -> 709 row — the table's interpolated tone-map value (5e-7 off the literal chain)
+    # and the fused chain's roundings move pow(x, 1/2.2)'s argument by 2 % there; the oracle's own answer spans 3 codes under +-4 ulp of pow()
+    "p010_cosited_pq_same_size": 1,
+}
 
 
 def _codes10(a):
@@ -98,7 +109,7 @@ def _codes10(a):
     return np.stack([(u >> sh) & 1023 for sh in (0, 10, 20)], -1).astype(np.int16)
 
 
-def compare_behind_tail(oracle, p, frame, pitch, got, want, name, min_same=0.99, ten_bit=False, lim=1):
+def compare_behind_tail(oracle, p, frame, pitch, got, want, name, min_same=0.99, ten_bit=False, lim=1, dovi=False):
     """Frames behind a PQ / HLG / Dolby Vision tail: |delta| <= 1 like everywhere else, EXCEPT on channels where the oracle's own
     answer is not defined to one code — shown per channel, not assumed: the oracle is run again with every pow() of the chain POW_ULPS
     ulps low, POW_ULPS ulps high, and eight times with each call off by its own hash-drawn amount within +-POW_ULPS
@@ -129,7 +140,10 @@ def compare_behind_tail(oracle, p, frame, pitch, got, want, name, min_same=0.99,
         worst = np.argwhere(bad & ~inside)
         assert worst.size == 0, (f"{name}: {len(worst)} of {n_bad} channels beyond {lim} code(s) are NOT explained by +-{POW_ULPS} ulp of pow(): "
                                  f"e.g. (y, x, ch) = {tuple(worst[0])}: got {g3[tuple(worst[0])]}, oracle {w3[tuple(worst[0])]}, interval [{lo[tuple(worst[0])] + lim}, {hi[tuple(worst[0])] - lim}]")
-        assert n_bad <= 1e-4 * d.size, f"{name}: {n_bad} ill-conditioned channels is more than a handful"
+        mpx = d.size / 3 / 1e6
+        cap = int(np.ceil(ILL_CONDITIONED_PER_MPX_DOVI * mpx)) if dovi else KNOWN_ILL_CONDITIONED.get(name.split(" ")[0], 0)
+        assert n_bad <= cap, (f"{name}: {n_bad} channels beyond {lim} code(s) (each inside the oracle's own +-{POW_ULPS} ulp interval) — more than "
+                              f"the {cap} this kind of frame was measured with ({'Dolby Vision: 16 per M pixels' if dovi else 'named cases only'})")
     if os.environ.get("MPCVR_PARITY_LOG"):
         import json
         with open(os.environ["MPCVR_PARITY_LOG"], "a") as f:
@@ -549,7 +563,7 @@ def test_dovi_block_convert_whole_frame(mpcvr, oracle, torch_cuda, label, extra,
         if c.get("output_format", 0) == 1:
             compare_rgb10(got, want, f"{label} flags={flags}", tail=True)
             continue
-        same, n_bad = compare_behind_tail(oracle, p, frame, pitch, got, want, f"dovi {label} flags={flags} [{info}]", min_same=0.998)
+        same, n_bad = compare_behind_tail(oracle, p, frame, pitch, got, want, f"dovi {label} flags={flags} [{info}]", min_same=0.998, dovi=True)
         print(f"dovi {label} flags={flags} [{info}]: identical {same:.6f}, channels beyond 1 LSB (all inside the oracle's own +-{POW_ULPS} ulp pow() interval) {n_bad}")
 
 
@@ -880,7 +894,7 @@ def test_period_kernel_from_a_surface(mpcvr, oracle, torch_cuda, label, c, pqn):
         return
     for out, tag in ((got, info), (alt, info_alt)):
         if has_tail(c):
-            same, _ = compare_behind_tail(oracle, p, frame, pitch, out, want, f"{label} [{tag}]", min_same=DOVI_RESIZE_FLOOR if c.get("dovi") else WHOLE_FRAME_FLOOR)
+            same, _ = compare_behind_tail(oracle, p, frame, pitch, out, want, f"{label} [{tag}]", min_same=DOVI_RESIZE_FLOOR if c.get("dovi") else WHOLE_FRAME_FLOOR, dovi=bool(c.get("dovi")))
         else:
             same = compare(out, want, f"{label} [{tag}]", min_same=WHOLE_FRAME_FLOOR)
         print(f"PERIOD:SURFACE {label}: identical channels {same:.6f}  [{tag}]")
@@ -1142,8 +1156,8 @@ def test_catmull_rom_chroma_block_convert_whole_frame(mpcvr, oracle, torch_cuda,
         compare(ref, want, f"{label} [{info_ref}]", exact=True)
     else:
         # behind the PQ tail: a channel beyond 1 LSB must be one the oracle itself does not define to a code (compare_behind_tail)
-        compare_behind_tail(oracle, p, frame, pitch, ref, want, f"{label} [{info_ref}]", min_same=WHOLE_FRAME_FLOOR)
-        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
+        compare_behind_tail(oracle, p, frame, pitch, ref, want, f"{label} [{info_ref}]", min_same=WHOLE_FRAME_FLOOR, dovi=bool(c.get("dovi")))
+        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR, dovi=bool(c.get("dovi")))
     print(f"{label}: identical channels {same:.6f}  [{info}]")
 
 
@@ -1177,7 +1191,7 @@ def test_planar_422_and_444_on_the_fused_paths(mpcvr, oracle, torch_cuda, label,
     got, info = run_product(mpcvr, torch, c)
     assert path_ok(info, path), info
     if has_tail(c):
-        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
+        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR, dovi=bool(c.get("dovi")))
     else:
         same = compare(got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
     print(f"{label}: identical channels {same:.6f}  [{info}]")
@@ -1210,7 +1224,7 @@ def test_packed_422_on_the_fused_paths(mpcvr, oracle, torch_cuda, label, c, path
     got, info = run_product(mpcvr, torch, c)
     assert path_ok(info, path), info
     if has_tail(c):
-        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
+        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR, dovi=bool(c.get("dovi")))
     else:
         same = compare(got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
     print(f"{label}: identical channels {same:.6f}  [{info}]")
@@ -1243,7 +1257,7 @@ def test_nearest_chroma_on_the_fused_paths(mpcvr, oracle, torch_cuda, label, c, 
     got, info = run_product(mpcvr, torch, c)
     assert path_ok(info, path), info
     if has_tail(c):
-        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
+        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR, dovi=bool(c.get("dovi")))
     else:
         same = compare(got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
     print(f"{label}: identical channels {same:.6f}  [{info}]")
@@ -1276,7 +1290,7 @@ def test_packed_444_gray_and_gbrp_on_the_fused_paths(mpcvr, oracle, torch_cuda, 
     got, info = run_product(mpcvr, torch, c)
     assert path_ok(info, path), info
     if has_tail(c):
-        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
+        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR, dovi=bool(c.get("dovi")))
     else:
         same = compare(got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
     print(f"{label}: identical channels {same:.6f}  [{info}]")
@@ -1305,8 +1319,8 @@ def test_spline36_extension_vs_oracle(mpcvr, oracle, torch_cuda, label, c, path)
     assert path_ok(info, path), info
     plain, info_plain = run_product(mpcvr, torch, c, extra_flags=api.FLAG_NO_FUSED)
     if has_tail(c):
-        compare_behind_tail(oracle, p, frame, pitch, plain, want, f"{label} [{info_plain}]", min_same=WHOLE_FRAME_FLOOR)
-        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
+        compare_behind_tail(oracle, p, frame, pitch, plain, want, f"{label} [{info_plain}]", min_same=WHOLE_FRAME_FLOOR, dovi=bool(c.get("dovi")))
+        same, _ = compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR, dovi=bool(c.get("dovi")))
     else:
         same = compare(got, want, f"{label} [{info}]", min_same=WHOLE_FRAME_FLOOR)
         compare(plain, want, f"{label} [{info_plain}]", exact=True)
@@ -1745,6 +1759,20 @@ def test_c_multi_gpu_example_degrades_to_one_device(mpcvr, torch_cuda, tmp_path)
     last = out.stdout.strip().splitlines()[-1]
     assert "identical=yes" in last and "frames=6" in last, out.stdout
     assert int(last.split("devices=")[1].split()[0]) == torch_cuda.cuda.device_count()
+
+
+def test_c_multi_gpu_rccl_example(mpcvr, torch_cuda, tmp_path):
+    """examples/c_multi_gpu_rccl.c: SURVEY.md 8e without Python — ncclCommInitAll over the box's devices, ONE ncclBroadcast of rank 0's
+    parameter blob issued by the library (mpcvr_broadcast_param_blob_begin / _end, librccl resolved at run time), frames by index.  On
+    this box N = 1: the collective is degenerate, but RCCL is loaded, a communicator exists and ncclBroadcast runs on the context's stream."""
+    import subprocess
+    from tests.test_host_logic import build_c_demo
+    out = subprocess.run([build_c_demo(tmp_path, "c_multi_gpu_rccl", rccl=True), "8", "6"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[0].startswith("rccl=") and "broadcast=ok" in lines[0], out.stdout
+    assert int(lines[0].split("ranks=")[1].split()[0]) == torch_cuda.cuda.device_count()
+    assert "identical=yes" in lines[-1] and "frames=6" in lines[-1], out.stdout
 
 
 def test_two_ranks_share_rank0_parameters(mpcvr, torch_cuda):

@@ -1,11 +1,14 @@
 #!/bin/bash
 # tools/pmc_traffic.sh <workload> [steps] — HBM traffic of one bench.py workload: FETCH_SIZE and WRITE_SIZE in separate
-# rocprofv3 --pmc passes (kernel-trace only, hard timeouts), summed over the mpcvr kernels and divided by the number of steps
+# rocprofv3 --pmc passes (kernel-trace only, hard timeouts), summed over the mpcvr kernels and divided by the number of steps;
+# a third pass collects the issue-slot counters (SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES, SQ_WAVE_CYCLES, SQ_WAIT_INST_ANY): the
+# VALU pipe's busy share of the launch is the roof that binds the fused kernels (bench.py: roofline.valu_issue)
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 W=${1:-c1}; STEPS=${2:-6}; WARM=2
 OUT=gpurun_out/traffic_$W; rm -rf $OUT; mkdir -p $OUT
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 5 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o p -- python bench.py --workload $W --steps $STEPS --warmup $WARM --settle 0 --no-cpu-baseline --no-host-path > $OUT/log_$c 2>&1 || tail -2 $OUT/log_$c
+for c in FETCH_SIZE WRITE_SIZE "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
+  d=${c%% *}
+  timeout -k 5 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$d -o p -- python bench.py --workload $W --steps $STEPS --warmup $WARM --settle 0 --no-cpu-baseline --no-host-path > $OUT/log_$d 2>&1 || tail -2 $OUT/log_$d
 done
 python - "$W" "$STEPS" "$WARM" <<'PY'
 import csv, glob, sys, json
@@ -19,8 +22,18 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 s += float(r["Counter_Value"]); n += 1
     tot[c] = (s, n)
 launches = steps + warm
+sq = {}
+for f in glob.glob(f"gpurun_out/traffic_{w}/SQ_ACTIVE_INST_VALU/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "mpcvr" in r["Kernel_Name"]:
+            sq[r["Counter_Name"]] = sq.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+# SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs, SQ_BUSY_CYCLES cycles summed over the 32 shader engines' SQs
+# (MI355X_MICROARCH.md, rocprofv3 units): VALU-busy cycles per SIMD / cycles of the launch
+issue = (sq["SQ_ACTIVE_INST_VALU"] * 4 / 1024) / (sq["SQ_BUSY_CYCLES"] / 32) if sq.get("SQ_BUSY_CYCLES") else None
 line = json.dumps({"workload": w, "steps_profiled": launches, "fetch_kb_per_step": tot["FETCH_SIZE"][0] / launches,
-                   "write_kb_per_step": tot["WRITE_SIZE"][0] / launches, "dispatches": tot["FETCH_SIZE"][1]})
+                   "write_kb_per_step": tot["WRITE_SIZE"][0] / launches, "dispatches": tot["FETCH_SIZE"][1],
+                   "valu_issue_frac": issue, "sq": {k: v / launches for k, v in sq.items()},
+                   "wait_inst_any_share": (sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAVE_CYCLES") else None})
 print(line)
 open(f"gpurun_out/traffic_{w}.json", "w").write(line + "\n")      # tools/update_traffic.py folds it into profiles/hbm_traffic.json
 PY

@@ -154,7 +154,8 @@ EXPORTS = [
     "mpcvr_set_dovi_metadata", "mpcvr_plan_dovi", "mpcvr_correction_pass", "mpcvr_plan_correction_matrices",
     "mpcvr_configure", "mpcvr_set_procamp", "mpcvr_copy_sample", "mpcvr_process", "mpcvr_render",
     "mpcvr_get_backbuffer", "mpcvr_get_current_image", "mpcvr_flush", "mpcvr_reset", "mpcvr_process_batch",
-    "mpcvr_get_param_blob", "mpcvr_set_param_blob", "mpcvr_get_color_matrix", "mpcvr_get_extfmt",
+    "mpcvr_get_param_blob", "mpcvr_set_param_blob", "mpcvr_broadcast_param_blob_begin", "mpcvr_broadcast_param_blob_end",
+    "mpcvr_broadcast_param_blob", "mpcvr_get_color_matrix", "mpcvr_get_extfmt",
     "mpcvr_get_frame_bytes", "mpcvr_get_path_info", "mpcvr_last_error", "mpcvr_version",
     "mpcvr_get_last_process_ms", "mpcvr_get_last_timings",
     "mpcvr_plan_frame_layout", "mpcvr_plan_color_matrix", "mpcvr_plan_gamut_2020_to_709", "mpcvr_plan_pq_lut",
@@ -171,8 +172,11 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} is missing: run `python -m videorenderer_amd.build` "
+    # MPCVR_LIB=<path>: load another build of the library instead (same-box A/B runs of tools/ against an older libmpcvr.so; entry
+    # points that build lacks are skipped).  Never set in normal use.
+    lib_path = os.environ.get("MPCVR_LIB") or LIB_PATH
+    if not os.path.exists(lib_path):
+        raise RuntimeError(f"{lib_path} is missing: run `python -m videorenderer_amd.build` "
                            "(or __graft_entry__.build()); there is no CPU fallback")
     # In a process that also uses torch, torch's bundled HIP runtime must be the one both share: libmpcvr.so resolves
     # libamdhip64 through the dynamic loader, and a second copy of the runtime (loaded first from /opt/rocm) sees no device once
@@ -185,7 +189,7 @@ def load_library():
                 import torch  # noqa: F401
         except Exception:
             pass
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(lib_path)
     vp, i32, u32, f = C.c_void_p, C.c_int32, C.c_uint32, C.c_float
     P = C.POINTER
     sig = {
@@ -218,6 +222,9 @@ def load_library():
         "mpcvr_process_batch": [vp, i32, P(vp), P(vp), i32],
         "mpcvr_get_param_blob": [vp, vp, P(C.c_size_t)],
         "mpcvr_set_param_blob": [vp, vp, C.c_size_t],
+        "mpcvr_broadcast_param_blob_begin": [vp, vp, i32, i32],
+        "mpcvr_broadcast_param_blob_end": [vp],
+        "mpcvr_broadcast_param_blob": [vp, vp, i32, i32],
         "mpcvr_get_color_matrix": [vp, P(f)],
         "mpcvr_get_extfmt": [vp, P(u32)],
         "mpcvr_get_frame_bytes": [vp, P(C.c_size_t), P(i32)],
@@ -238,6 +245,8 @@ def load_library():
         "mpcvr_plan_describe": [P(Settings), i32, i32, i32, P(Rect), i32, i32, C.c_char_p, C.c_size_t],
     }
     for name, args in sig.items():
+        if lib_path != LIB_PATH and not hasattr(L, name):
+            continue
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = i32

@@ -6,6 +6,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -69,6 +71,7 @@ CHipVideoProcessor::~CHipVideoProcessor()
     }
     if (m_copyStream) (void)hipStreamDestroy(m_copyStream);
     m_doviDev.Release();
+    m_bcast.Release();
     for (DoviSlot &d : m_doviSlots) {
         if (d.pinned) (void)hipHostFree(d.pinned);
         if (d.copied) (void)hipEventDestroy(d.copied);
@@ -1008,7 +1011,7 @@ bool CHipVideoProcessor::FillStripParams(const uint8_t *sample, void *dst, int d
     sp->nt = m_stripPlan.nt; sp->pxl = m_stripPlan.pxl; sp->strip_w = m_stripPlan.strip_w; sp->ring = m_stripPlan.ring; sp->acols = m_stripPlan.acols;
     sp->per_P = 0;
     if (m_periodPlan.P && !(m_cfg.flags & MPCVR_FLAG_NO_PERIOD)) {
-        sp->per_P = m_periodPlan.P; sp->per_Q = m_periodPlan.Q; sp->per_nt = m_periodPlan.nt; sp->per_acols = m_periodPlan.acols; sp->per_strip_w = m_periodPlan.strip_w; sp->per_force = (m_cfg.flags & MPCVR_FLAG_FORCE_PERIOD) ? 1 : 0;
+        sp->per_P = m_periodPlan.P; sp->per_Q = m_periodPlan.Q; sp->per_nt = m_periodPlan.nt; sp->per_acols = m_periodPlan.acols; sp->per_strip_w = m_periodPlan.strip_w; sp->per_own = m_periodPlan.own; sp->per_force = (m_cfg.flags & MPCVR_FLAG_FORCE_PERIOD) ? 1 : 0;
         sp->per_xi_t = tab + m_periodOff[0]; sp->per_xw_t = tab + m_periodOff[1]; sp->per_yw = tab + m_periodOff[2]; sp->per_xstrip = tab + m_periodOff[3];
     }
     return FusedStripSupported(*sp) && FusedStripLdsBytes(*sp) <= DeviceLdsLimit();
@@ -1033,7 +1036,7 @@ bool CHipVideoProcessor::FillStripSurfParams(const Surface &src, const StorePara
     sp->mid_h = m_plan.mid_h;
     sp->per_P = 0;
     if (m_periodPlan.P && !(m_cfg.flags & MPCVR_FLAG_NO_PERIOD)) {      // periodic vertical ratio: the register-window kernel reads the surface as well
-        sp->per_P = m_periodPlan.P; sp->per_Q = m_periodPlan.Q; sp->per_nt = m_periodPlan.nt; sp->per_acols = m_periodPlan.acols; sp->per_strip_w = m_periodPlan.strip_w; sp->per_force = 1;
+        sp->per_P = m_periodPlan.P; sp->per_Q = m_periodPlan.Q; sp->per_nt = m_periodPlan.nt; sp->per_acols = m_periodPlan.acols; sp->per_strip_w = m_periodPlan.strip_w; sp->per_own = m_periodPlan.own; sp->per_force = 1;
         sp->per_xi_t = tab + m_periodOff[0]; sp->per_xw_t = tab + m_periodOff[1]; sp->per_yw = tab + m_periodOff[2]; sp->per_xstrip = tab + m_periodOff[3];
     }
     return FusedStripSupported(*sp) && FusedStripLdsBytes(*sp) <= DeviceLdsLimit();
@@ -1534,6 +1537,71 @@ HRESULT CHipVideoProcessor::SetParamBlob(const void *buf, size_t size)
     m_blobOverride = true;
     m_planDirty = true;
     return MPCVR_S_OK;
+}
+
+// ---- RCCL ----
+// The library does not link librccl: a host that never broadcasts never loads it.  The communicator comes from the host, so the
+// host's RCCL is already mapped when these entry points are called; it is looked up (RTLD_NOLOAD first: torch ships its own copy)
+// and only loaded from the default search path when the process has none yet.  Prototypes as in rccl.h (ncclResult_t = int, ncclChar = 0).
+namespace {
+struct RcclApi {
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+const RcclApi &Rccl()
+{
+    static const RcclApi api = [] {
+        RcclApi a;
+        void *h = nullptr;
+        for (const char *name : {"librccl.so.1", "librccl.so"})
+            if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return a;
+        a.Broadcast = (decltype(a.Broadcast))dlsym(h, "ncclBroadcast");
+        a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+        a.ok = a.Broadcast != nullptr;
+        return a;
+    }();
+    return api;
+}
+}  // namespace
+
+HRESULT CHipVideoProcessor::BroadcastParamBlobBegin(void *ncclComm, int root, int rank)
+{
+    if (!m_bInit || !m_srcParams) return Fail(MPCVR_E_NOT_VALID_STATE, "InitMediaType has not been called");
+    if (!ncclComm) return Fail(MPCVR_E_POINTER, "null RCCL communicator");
+    if (m_bcastPending) return Fail(MPCVR_E_NOT_VALID_STATE, "a parameter-blob broadcast is already in flight");
+    const RcclApi &R = Rccl();
+    if (!R.ok) return Fail(MPCVR_E_FAIL, std::string("librccl.so could not be loaded: ") + (dlerror() ? dlerror() : "ncclBroadcast not found"));
+    (void)hipSetDevice(m_device);
+    HRESULT hr;
+    if ((hr = CheckHip(m_bcast.CheckCreate(sizeof(ParamBlob)), "broadcast buffer"))) return hr;
+    m_bcastIsRoot = rank == root;
+    if (m_bcastIsRoot) {
+        m_bcastHost.resize(sizeof(ParamBlob));
+        size_t size = m_bcastHost.size();
+        if ((hr = GetParamBlob(m_bcastHost.data(), &size))) return hr;
+        if ((hr = CheckHip(hipMemcpyAsync(m_bcast.ptr, m_bcastHost.data(), sizeof(ParamBlob), hipMemcpyHostToDevice, m_stream), "blob upload"))) return hr;
+    }
+    const int rc = R.Broadcast(m_bcast.ptr, m_bcast.ptr, sizeof(ParamBlob), /* ncclChar */ 0, root, ncclComm, m_stream);
+    if (rc != 0) return Fail(MPCVR_E_FAIL, std::string("ncclBroadcast: ") + (R.GetErrorString ? R.GetErrorString(rc) : "error"));
+    m_bcastPending = true;
+    return MPCVR_S_OK;
+}
+
+HRESULT CHipVideoProcessor::BroadcastParamBlobEnd()
+{
+    if (!m_bcastPending) return Fail(MPCVR_E_NOT_VALID_STATE, "no parameter-blob broadcast in flight");
+    (void)hipSetDevice(m_device);
+    m_bcastPending = false;
+    HRESULT hr;
+    if (m_bcastIsRoot) return CheckHip(hipStreamSynchronize(m_stream), "broadcast sync");
+    m_bcastHost.resize(sizeof(ParamBlob));
+    if ((hr = CheckHip(hipMemcpyAsync(m_bcastHost.data(), m_bcast.ptr, sizeof(ParamBlob), hipMemcpyDeviceToHost, m_stream), "blob download"))) return hr;
+    if ((hr = CheckHip(hipStreamSynchronize(m_stream), "broadcast sync"))) return hr;
+    return SetParamBlob(m_bcastHost.data(), m_bcastHost.size());
 }
 
 HRESULT CHipVideoProcessor::GetColorMatrix(float out[12])

@@ -68,6 +68,11 @@ public:
 
     HRESULT GetParamBlob(void *buf, size_t *size);
     HRESULT SetParamBlob(const void *buf, size_t size);
+    // the one collective of the path — rank `root`'s parameter blob to every rank of an RCCL communicator the host created
+    // (ncclCommInitRank / ncclCommInitAll), on the context's stream.  Begin queues the broadcast (inside the host's ncclGroupStart /
+    // ncclGroupEnd when one process drives several devices), End waits for it and adopts the blob on the other ranks.
+    HRESULT BroadcastParamBlobBegin(void *ncclComm, int root, int rank);
+    HRESULT BroadcastParamBlobEnd();
     HRESULT GetColorMatrix(float out[12]);
     HRESULT GetExtFmt(uint32_t *v);
     HRESULT GetFrameBytes(size_t *bytes, int *pitch);
@@ -155,6 +160,9 @@ private:
     int m_tail = TAIL_NONE;
     float m_gamma = 1.0f;
     bool m_blobOverride = false;
+    DevBuffer m_bcast;             // the blob in device memory while an RCCL broadcast is in flight
+    bool m_bcastPending = false, m_bcastIsRoot = false;
+    std::vector<unsigned char> m_bcastHost;      // host side of that copy: alive until BroadcastParamBlobEnd
 
     // plan
     bool m_planDirty = true;

@@ -133,6 +133,14 @@ int32_t mpcvr_process_batch(mpcvr_ctx *ctx, int32_t n, const void *const *srcs, 
 
 int32_t mpcvr_get_param_blob(mpcvr_ctx *ctx, void *buf, size_t *size) { CTX_OR_FAIL(); return ctx->vp.GetParamBlob(buf, size); }
 int32_t mpcvr_set_param_blob(mpcvr_ctx *ctx, const void *buf, size_t size) { CTX_OR_FAIL(); return ctx->vp.SetParamBlob(buf, size); }
+int32_t mpcvr_broadcast_param_blob_begin(mpcvr_ctx *ctx, void *nccl_comm, int32_t root, int32_t rank) { CTX_OR_FAIL(); return ctx->vp.BroadcastParamBlobBegin(nccl_comm, root, rank); }
+int32_t mpcvr_broadcast_param_blob_end(mpcvr_ctx *ctx) { CTX_OR_FAIL(); return ctx->vp.BroadcastParamBlobEnd(); }
+int32_t mpcvr_broadcast_param_blob(mpcvr_ctx *ctx, void *nccl_comm, int32_t root, int32_t rank)
+{
+    CTX_OR_FAIL();
+    const int32_t hr = ctx->vp.BroadcastParamBlobBegin(nccl_comm, root, rank);
+    return hr < 0 ? hr : ctx->vp.BroadcastParamBlobEnd();
+}
 
 int32_t mpcvr_get_color_matrix(mpcvr_ctx *ctx, float out12[12]) { CTX_OR_FAIL(); if (!out12) return MPCVR_E_POINTER; return ctx->vp.GetColorMatrix(out12); }
 int32_t mpcvr_get_extfmt(mpcvr_ctx *ctx, uint32_t *extfmt) { CTX_OR_FAIL(); if (!extfmt) return MPCVR_E_POINTER; return ctx->vp.GetExtFmt(extfmt); }

@@ -28,6 +28,10 @@
 //   Recomputed: the horizontal halo (8 of 128 columns) and 6 rows per segment.
 #include "vp_fused_dev.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace mpcvr {
 
 namespace {
@@ -287,6 +291,197 @@ __global__ __launch_bounds__(256) void k_convert_blocks_wide(FusedArgs P, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Same-size frames as a STREAM (round 4): BASELINE configs[0] (1080p NV12 -> BGRA8) is 11.4 MB per frame — a 32-frame launch
+// of k_convert_blocks_wide lasts ~100 us, its waves live for two row pairs (prologue, one exposed load round trip, two
+// half-line stores per lane and row) and the launch ramps up and drains for a tenth of that.  Here the launch holds exactly the
+// waves the chip keeps resident and each of them walks a long run of row pairs:
+//   * one strip of 256 rect columns per wave (4 px per lane: ONE 16-byte store per lane and row, 1 KiB contiguous per
+//     wavefront) — the strip never changes, so every per-lane byte offset is loop-invariant;
+//   * the launch's row pairs — all frames of the batch laid end to end, G = frames x (H/2 + 1) per strip — are dealt to the
+//     strip's waves as contiguous runs [g0, g1) that differ by at most one pair: no tail, no quantisation, whatever the
+//     frame size; a run crosses frame boundaries (the frame table entry is re-read by scalar loads when it does);
+//   * raw codes travel TWO row pairs ahead of the arithmetic (two buffers, used alternately), across frame boundaries too:
+//     a wave has 6-12 loads in flight whenever it computes.
+// Arithmetic: convert_block (vp_fused_dev.h) on the lane's two 2x2 blocks — the same code, the same results as
+// k_convert_blocks[_wide].  SRC is SRC_NV12 or SRC_P01X; FINAL as in k_convert_blocks.
+// ------------------------------------------------------------------------------------------------
+struct StreamArgs {
+    int n_strips;              // strips of 256 columns per frame row
+    int n_slots;               // waves per strip
+    int npairs;                // row pairs per frame: H / 2 + 1 (pair p = rows 2p - 1, 2p)
+    int total;                 // n_frames * npairs
+    int n_frames;
+    uint8_t *batch_dst; size_t batch_stride;
+};
+
+template <int TAIL, int SRC, bool FINAL>
+__global__ __launch_bounds__(512) void k_convert_stream(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single, StreamArgs Q, FrameTable32 tab)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *Di = (uint32_t *)smem;
+    f2 *T = (f2 *)(smem + (FINAL ? 4096 : 0));
+    if (FINAL)
+        for (int i = threadIdx.x; i < 1024; i += blockDim.x)
+            Di[i] = (uint32_t)(__half2float(__ushort_as_half(P.dither[i])) * 1024.0f + 0.5f) << 14;
+    if (tail_has_table(TAIL))
+        for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) {
+            const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
+            T[i] = f2{v, n - v};
+        }
+    if (FINAL || tail_has_table(TAIL)) __syncthreads();
+
+    constexpr bool WIDE16 = SRC == SRC_P01X;
+    constexpr int LW = WIDE16 ? 2 : 1;                                 // dwords of a lane's 4 luma samples / 2 chroma texels
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int w = blockIdx.x * (int)(blockDim.x >> 6) + wave;
+    const int slot = w / Q.n_strips, strip = w - slot * Q.n_strips;
+    if (slot >= Q.n_slots) return;
+    // the strip's run of global pairs: [g0, g1), sizes differ by at most one
+    const int g0 = (int)(((long)Q.total * slot) / Q.n_slots), g1 = (int)(((long)Q.total * (slot + 1)) / Q.n_slots);
+    if (g0 >= g1) return;
+    const int W = P.W, H = P.H;
+    const int X = strip * 256 + 4 * lane;                              // rect columns X .. X+3
+    const bool active = X < W;                                         // (W is a multiple of 4: launcher)
+    const int Xc = active ? X : W - 4;                                 // lanes beyond the right edge load what the last lane loads and store nothing
+
+    const f2 MM[5] = {f2{P.m[0], P.m[1]}, f2{P.m[2], P.m[3]}, f2{P.m[4], P.m[5]}, f2{P.m[6], P.m[7]}, f2{P.m[8], 0.0f}};
+    const f2 GG[5] = {f2{P.gamut[0], P.gamut[1]}, f2{P.gamut[2], P.gamut[3]}, f2{P.gamut[4], P.gamut[5]}, f2{P.gamut[6], P.gamut[7]}, f2{P.gamut[8], 0.0f}};
+    const f2 cmax2 = splat(P.maxv);
+    f2 big2 = splat(8388608.0f);
+    asm volatile("" : "+v"(big2));
+    f2 CC[3] = {splat(P.c[0]), splat(P.c[1]), splat(P.c[2])};
+    asm volatile("" : "+v"(CC[0]), "+v"(CC[1]), "+v"(CC[2]));
+
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int sx0 = P.rect_l + Xc, c0 = sx0 >> 1;
+    const uint32_t yoff = (uint32_t)(WIDE16 ? 2 * sx0 : sx0);           // luma bytes of the lane's 4 px; its 2 chroma texels start at the same byte offset of a UV row
+    const uint32_t xoff = (uint32_t)((WIDE16 ? 4 : 2) * clampi(c0 + 2, 0, P.cw - 1));     // the chroma texel right of the lane's two
+    const uint32_t lane_off = (uint32_t)(P.off_x + Xc) * 4u;
+    const uint32_t dix = (uint32_t)((P.off_x + Xc) & 31);              // dither texels of the 4 px: one aligned 16-byte LDS read (off_x % 4 == 0: launcher)
+
+    auto uniform_ptr = [](const void *q) {
+        const uint64_t v = (uint64_t)q;
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    };
+    auto frame_src = [&](int z) -> gcptr {
+        const FusedFrame f = tab.n ? tab.f[z] : frames ? frames[z] : single;
+        return (gcptr)uniform_ptr(f.src);
+    };
+    auto frame_dst = [&](int z) -> gptr {
+        const FusedFrame f = tab.n ? tab.f[z] : frames ? frames[z] : single;
+        return (gptr)uniform_ptr(Q.batch_dst ? (void *)(Q.batch_dst + (size_t)z * Q.batch_stride) : f.dst);
+    };
+
+    // raw codes of one row pair: luma rows a, a+1 and chroma rows n, n+1 (the lane's two texels + the one to their right)
+    struct RawPair { uint32_t l[2][LW], c[2][LW], x[2]; };
+    auto load_pair = [&](gcptr py, int p, RawPair &r) __attribute__((always_inline)) {
+        const int a = 2 * p - 1;
+        const int sy0 = P.rect_t + clampi(a, 0, H - 1), sy1 = P.rect_t + clampi(a + 1, 0, H - 1);
+        const int n = chroma_v4(P, sy0) >> 2;
+        const gcptr pu = py + P.off_u;
+        const gcptr ry[2] = {py + (uint32_t)sy0 * (uint32_t)P.pitch_y, py + (uint32_t)sy1 * (uint32_t)P.pitch_y};
+        const gcptr rc[2] = {pu + (uint32_t)clampi(n, 0, P.ch - 1) * (uint32_t)P.pitch_c, pu + (uint32_t)clampi(n + 1, 0, P.ch - 1) * (uint32_t)P.pitch_c};
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if constexpr (WIDE16) {
+                const u32x2 l = *(const __attribute__((address_space(1))) u32x2 *)(ry[k] + opaque(yoff));
+                const u32x2 c = *(const __attribute__((address_space(1))) u32x2 *)(rc[k] + opaque(yoff));
+                r.l[k][0] = l.x; r.l[k][1] = l.y; r.c[k][0] = c.x; r.c[k][1] = c.y;
+                r.x[k] = ld_u32(rc[k] + opaque(xoff));
+            } else {
+                r.l[k][0] = ld_u32(ry[k] + opaque(yoff));
+                r.c[k][0] = ld_u32(rc[k] + opaque(yoff));
+                r.x[k] = ld_u16(rc[k] + opaque(xoff));
+            }
+        }
+    };
+
+    // consumer cursor (z, p) and producer cursor (zp, pp), two pairs ahead
+    int z = g0 / Q.npairs, p = g0 - z * Q.npairs;
+    int zp = z, pp = p;
+    gptr pdst = frame_dst(z);
+    gcptr py_p = frame_src(z);
+    auto advance_producer = [&]() __attribute__((always_inline)) {
+        if (++pp == Q.npairs) { pp = 0; zp = min(zp + 1, Q.n_frames - 1); py_p = frame_src(zp); }
+    };
+    RawPair buf[2];
+    load_pair(py_p, pp, buf[0]);
+    advance_producer();
+    load_pair(py_p, pp, buf[1]);           // (at most two pairs past the run: valid pairs of the batch, read and dropped)
+    advance_producer();
+
+    // one row pair: convert the lane's two blocks out of `r`, send the loads of the pair after next into `r`, store both rows
+    auto step = [&](RawPair &r) __attribute__((always_inline)) {
+        const int a = 2 * p - 1;
+        uint32_t code[4][3][2];                                        // [column][channel][row]: 0x4B000000 | UNORM code, see k_convert_blocks
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            Raw raw;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                raw.c[k][0] = 0;
+                if constexpr (WIDE16) {
+                    raw.y[k] = r.l[k][b];
+                    raw.c[k][1] = r.c[k][b];
+                    raw.c[k][2] = b == 0 ? r.c[k][1] : r.x[k];
+                } else {
+                    raw.y[k] = b == 0 ? (r.l[k][0] & 0xffffu) : (r.l[k][0] >> 16);
+                    const uint32_t e0 = b == 0 ? (r.c[k][0] & 0xffffu) : (r.c[k][0] >> 16), e1 = b == 0 ? (r.c[k][0] >> 16) : r.x[k];
+                    raw.c[k][1] = (e0 & 0xffu) | ((e0 >> 8) << 16);    // U | V << 16
+                    raw.c[k][2] = (e1 & 0xffu) | ((e1 >> 8) << 16);
+                }
+            }
+            f2 rc[2][3];
+            convert_block<TAIL, SRC>(P, MM, GG, CC, raw, P.rect_t + clampi(a, 0, H - 1), P.rect_t + clampi(a + 1, 0, H - 1), T, rc);
+#pragma unroll
+            for (int col = 0; col < 2; col++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const f2 q = pk_fma(rc[col][c], cmax2, big2);
+                    code[2 * b + col][c][0] = __float_as_uint(q.x); code[2 * b + col][c][1] = __float_as_uint(q.y);
+                }
+        }
+        load_pair(py_p, pp, r);
+        advance_producer();
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int y = a + k;
+            if (y < 0 || y >= H) continue;                             // wave-uniform: the half pairs at a frame's top and bottom
+            const int wy = P.off_y + y;
+            uint32_t dj[4] = {0, 0, 0, 0};
+            if (FINAL) {
+                const u32x4 dd = *(const u32x4 *)(Di + (wy & 31) * 32 + dix);
+                dj[0] = dd.x; dj[1] = dd.y; dj[2] = dd.z; dj[3] = dd.w;
+            }
+            uint32_t px[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t cr = code[i][0][k], cg = code[i][1][k], cb = code[i][2][k];
+                if (FINAL) {
+                    const uint32_t ib = __umul24(cb, P.epi_mul) + dj[i], ig = __umul24(cg, P.epi_mul) + dj[i], ir = __umul24(cr, P.epi_mul) + dj[i];
+                    const uint32_t bg = __builtin_amdgcn_perm(ig, ib, 0x0c0c0703u);
+                    px[i] = __builtin_amdgcn_perm(ir, bg, 0x0d070100u);
+                } else if (P.out10) {
+                    px[i] = (cr + 0x75000000u) | (cg << 10) | (cb << 20);
+                } else {
+                    const uint32_t bg = __builtin_amdgcn_perm(cg, cb, 0x0c0c0400u);     // [B, G, 0, 0]
+                    px[i] = __builtin_amdgcn_perm(cr, bg, 0x0d040100u);                 // [B, G, R, 0xff]
+                }
+            }
+            const gptr rowp = pdst + (uint32_t)wy * (uint32_t)P.dst_pitch;
+            if (active) *(__attribute__((address_space(1))) u32x4 *)(rowp + opaque(lane_off)) = u32x4{px[0], px[1], px[2], px[3]};
+        }
+        if (++p == Q.npairs) { p = 0; z = min(z + 1, Q.n_frames - 1); pdst = frame_dst(z); }
+    };
+    for (int g = g0; g < g1; g += 2) {
+        step(buf[0]);
+        if (g + 1 < g1) step(buf[1]);
+    }
+}
+
 }  // namespace
 
 // Source layouts and chroma filters convert_block has a loader and a rule for (vp_fused_dev.h):
@@ -373,6 +568,10 @@ void FillFusedArgs(const FusedParams &P, FusedArgs &a)
     a.cw_next = a.sub444 ? 1.0f : a.nearest ? 0.0f : 0.5f;
     a.center_h = c.fmt.subsampling == 420 && c.chroma_loc == CLOC_MPEG1 && !a.nearest;      // (no siting without a filter)
     a.v_off4 = (c.fmt.subsampling == 420 && c.chroma_loc == CLOC_COSITED && !a.nearest) ? 1 : 0;
+    // chroma_v4 (vp_fused_dev.h): 4 sy (4:2:2 / 4:4:4), 4 (sy >> 1) (nearest), 2 sy - 1 + v_off4 (4:2:0 filtered)
+    a.vk1 = (a.sub422 | a.sub444) ? 4 : a.nearest ? 0 : 2;
+    a.vk2 = (a.sub422 | a.sub444) ? 0 : a.nearest ? 2 : 0;
+    a.vk3 = (a.sub422 | a.sub444 | a.nearest) ? 0 : a.v_off4 - 1;
     // UNORM scale: v/255, or (v << shift)/65535 for planar data; interleaved UV planes carry no shift
     const float sy = c.fmt.bits10 ? 1.0f / 1023.0f : c.fmt.bytes == 1 ? 1.0f / 255.0f : (float)(1 << c.fmt.shift) / 65535.0f;
     const float sc = c.fmt.bits10 ? 1.0f / 1023.0f : c.fmt.bytes == 1 ? 1.0f / 255.0f : (float)(1 << (c.fmt.planes == 2 ? 0 : c.fmt.shift)) / 65535.0f;
@@ -447,6 +646,36 @@ bool ConvertBlocksSupported(const FusedParams &P, bool to_rt)
     return st.dst_fmt == c.out_fmt && st.mode == ST_SURFACE;
 }
 
+// compute units of the current device, and the workgroups of a kernel one of them keeps resident (queried once per kernel, block
+// size, LDS size and device): k_convert_stream launches exactly that many
+static int DeviceCuCount()
+{
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cus.find(dev);
+    if (it != cus.end()) return it->second;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return cus[dev] = n;
+}
+static int ResidentWorkgroups(const void *kern, int threads, size_t lds)
+{
+    static std::mutex mu;
+    static std::map<std::pair<std::pair<const void *, int>, std::pair<int, size_t>>, int> memo;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const auto key = std::make_pair(std::make_pair(kern, dev), std::make_pair(threads, lds));
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = memo.find(key);
+    if (it != memo.end()) return it->second;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, threads, lds) != hipSuccess || n <= 0) n = 2;
+    return memo[key] = n;
+}
+
 hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s,
                                size_t batch_stride, const FusedFrame *frames_host)
 {
@@ -472,6 +701,47 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
     const bool wide = !no_wide && !catmull && dvk == DV_NONE && (srck == SRC_P01X || srck == SRC_NV12) && (c.out_w & 7) == 0 && (c.rect_l & 7) == 0 && (c.pitch[0] % lb) == 0 &&
                       (c.pitch[1] % lb) == 0 && (P.plane_off[1] % lb) == 0 && P.dst_aligned16 && (P.store.off_x & 3) == 0 &&
                       (P.store.dst_pitch & 15) == 0 && P.src_aligned16;
+    // the streaming kernel (k_convert_stream): bi-planar 4:2:0 / 4:2:2 samples whose rows take the lane's 4- / 8-byte loads and 16-byte stores
+    static const int no_stream = EnvInt("MPCVR_NO_STREAM_CONVERT", 0);
+    const int lbs = srck == SRC_P01X ? 8 : 4;
+    const bool stream = !no_stream && !catmull && dvk == DV_NONE && (srck == SRC_P01X || srck == SRC_NV12) && c.out_w >= 8 && (c.out_w & 3) == 0 && (c.rect_l & 3) == 0 &&
+                        (c.pitch[0] % lbs) == 0 && (c.pitch[1] % lbs) == 0 && (P.plane_off[1] % lbs) == 0 && P.dst_aligned16 && (P.store.off_x & 3) == 0 &&
+                        (P.store.dst_pitch & 15) == 0 && P.src_aligned16 && (frames_dev || tab.n || n_frames == 1);
+    if (stream) {
+        const bool tables = fin || tail_has_table(tailk);
+        const size_t lds = (fin ? 4096 : 0) + (tail_has_table(tailk) ? LDS_T : 0);
+        StreamArgs q{};
+        q.n_strips = (c.out_w + 255) / 256;
+        q.npairs = c.out_h / 2 + 1;
+        q.n_frames = n_frames;
+        q.total = n_frames * q.npairs;
+        q.batch_dst = batch_dst; q.batch_stride = batch_stride;
+        // workgroups of 8 waves where tables are staged (once per workgroup), of 4 otherwise; exactly the waves the chip keeps resident
+        static const int wg_env = EnvInt("MPCVR_STREAM_WG_WAVES", 0), occ_env = EnvInt("MPCVR_STREAM_WG_PER_CU", 0), min_pairs_env = EnvInt("MPCVR_STREAM_MIN_PAIRS", 0);
+        const int wgw = wg_env >= 1 && wg_env <= 8 ? wg_env : tables ? 8 : 4;
+        const dim3 block(64 * wgw, 1, 1);
+        hipError_t err = hipSuccess;
+        auto launch = [&](auto kern) {
+            const int per_cu = occ_env > 0 ? occ_env : ResidentWorkgroups((const void *)kern, 64 * wgw, lds);
+            const long n_waves = (long)std::max(per_cu, 1) * DeviceCuCount() * wgw;
+            const int min_pairs = min_pairs_env > 0 ? min_pairs_env : 4;            // a wave's run: at least this many row pairs (a short launch spreads thinner, not shorter)
+            q.n_slots = (int)std::max<long>(1, std::min<long>(n_waves / q.n_strips, std::max(1, q.total / min_pairs)));
+            const dim3 grid((unsigned)(((long)q.n_slots * q.n_strips + wgw - 1) / wgw), 1, 1);
+            hipLaunchKernelGGL(kern, grid, block, lds, s, a, frames_dev, single, q, tab);
+            err = hipGetLastError();
+        };
+#define MPCVR_ST3(TK, SK, FN) launch(k_convert_stream<TK, SK, FN>)
+#define MPCVR_ST2(TK, SK) do { if (fin) MPCVR_ST3(TK, SK, true); else MPCVR_ST3(TK, SK, false); } while (0)
+#define MPCVR_ST(TK) do { if (srck == SRC_P01X) MPCVR_ST2(TK, SRC_P01X); else MPCVR_ST2(TK, SRC_NV12); } while (0)
+        if (tailk == TAILK_NONE) MPCVR_ST(TAILK_NONE);
+        else if (tailk == TAILK_PQ_LUT) MPCVR_ST(TAILK_PQ_LUT);
+        else if (tailk == TAILK_HLG) MPCVR_ST(TAILK_HLG);
+        else MPCVR_ST(TAILK_ALU);
+#undef MPCVR_ST
+#undef MPCVR_ST2
+#undef MPCVR_ST3
+        return err;
+    }
     const int strip_w = wide ? 512 : 128;
     const int strips = (c.out_w + strip_w - 1) / strip_w, npairs = c.out_h / 2 + 1;
     // row pairs per wave: enough waves to fill the chip a few times over, few enough to amortise the table staging

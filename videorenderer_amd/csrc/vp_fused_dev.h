@@ -23,6 +23,7 @@ struct FusedArgs {
     int bytes, planes;
     int center_h;                  // MPEG-1 siting: chroma sample centred between luma columns
     int v_off4;                    // vertical chroma offset in quarter chroma rows: 1 for co-sited (+0.25), else 0
+    int vk1, vk2, vk3;             // chroma_v4(sy) = vk1 * sy + vk2 * (sy & ~1) + vk3: the three siting rules as one branch-free scalar expression
     int sub422;                    // 4:2:2 planar / bi-planar (P210, P216, YV16, YUV422P10...): chroma subsampled horizontally only
     int sub444;                    // 4:4:4 planar (YV24, YUV444P8/10/16): a chroma sample per pixel, no interpolation at all
     int packed422;                 // one plane of (Y0,U,Y1,V) texels (YUY2, UYVY, Y210, Y216, v210 after the unpack): implies sub422
@@ -201,6 +202,23 @@ __device__ __forceinline__ f2 fma_k(const f2 *K, int i, f2 b, f2 c)
     return (i & 1) ? pk_fma_w<1, CLAMP>(K[i >> 1], b, c) : pk_fma_w<0, CLAMP>(K[i >> 1], b, c);
 }
 __device__ __forceinline__ f2 mul_k(const f2 *K, int i, f2 b) { return (i & 1) ? pk_mul_w<1>(K[i >> 1], b) : pk_mul_w<0>(K[i >> 1], b); }
+// One matrix row as the shader's mul() is restated everywhere else (mat3_mul, vp_device.h; the oracle): products summed left to right,
+// every product and sum rounded — NO contraction.  The Dolby Vision variants use it for their three matrices: behind ycc_to_rgb, the LMS
+// step and 2020 -> 709 a bright saturated colour leaves a channel that cancels to ~1e-4 of its terms, where the different rounding of a
+// fused chain is amplified a thousandfold (round 3 counted 3-4x the ill-conditioned channels of the plain kernels on the same frame).
+__device__ __forceinline__ f2 row3_unfused(float m0, float m1, float m2, f2 x, f2 y, f2 z)
+{
+#pragma clang fp contract(off)
+    f2 r = splat(m0) * x;
+    r = r + splat(m1) * y;
+    r = r + splat(m2) * z;
+    return r;
+}
+__device__ __forceinline__ f2 add_unfused(f2 a, f2 b)
+{
+#pragma clang fp contract(off)
+    return a + b;
+}
 
 // raw codes of one 2x2 block (cols Xg, Xg+1; two source rows), prefetched one iteration ahead
 struct Raw {
@@ -261,7 +279,9 @@ __device__ __forceinline__ uint32_t ld_uv(const FusedArgs &P, gcptr pu, gcptr pv
 // QUARTER chroma rows as an integer (4v' = 2sy - 1 [+1]) so that the whole siting computation stays on the scalar unit
 // (4:2:2: chroma rows are luma rows — v' = sy exactly, so a row pair takes row 0 from chroma row sy0 and row 1 from sy0 + 1)
 // (CHROMA_Nearest at 4:2:0: row sy reads chroma row sy >> 1 whole — v' = sy >> 1, so of an (odd, odd + 1) pair row 0 takes row n, row 1 row n + 1)
-__device__ __forceinline__ int chroma_v4(const FusedArgs &P, int sy) { return (P.sub422 | P.sub444) ? 4 * sy : P.nearest ? 4 * (sy >> 1) : 2 * sy - 1 + P.v_off4; }
+// (FillFusedArgs folds the three cases into coefficients: {4, 0, 0}, {0, 2, 0}, {2, 0, v_off4 - 1} — the nested selects on kernel
+// arguments compiled to a chain of scalar branches, four times per iteration of every fused kernel)
+__device__ __forceinline__ int chroma_v4(const FusedArgs &P, int sy) { return P.vk1 * sy + P.vk2 * (sy & ~1) + P.vk3; }
 // fr/4 for fr = 0..4 as a float built from integer selects (wave-uniform => SGPR; no v_cvt/v_mul per iteration)
 __device__ __forceinline__ float quarter(int fr)
 {
@@ -620,8 +640,12 @@ __device__ __forceinline__ void convert_block_yuv(const FusedArgs &P, const f2 (
 #pragma unroll
     for (int rr = 0; rr < 2; rr++)                // rr = luma column of the block
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++)
-            rgbc[rr][ch] = fma_k<DV == DV_NONE>(MM, 3 * ch, Ycol[rr], fma_k<false>(MM, 3 * ch + 1, Ucol[rr], fma_k<false>(MM, 3 * ch + 2, Vcol[rr], CC[ch])));
+        for (int ch = 0; ch < 3; ch++) {
+            if (DV != DV_NONE)      // (cm0 y + cm1 u + cm2 v) + c as convert_pixel writes it (vp_convert.h), unfused
+                rgbc[rr][ch] = add_unfused(row3_unfused(P.m[3 * ch], P.m[3 * ch + 1], P.m[3 * ch + 2], Ycol[rr], Ucol[rr], Vcol[rr]), CC[ch]);
+            else
+                rgbc[rr][ch] = fma_k<true>(MM, 3 * ch, Ycol[rr], fma_k<false>(MM, 3 * ch + 1, Ucol[rr], fma_k<false>(MM, 3 * ch + 2, Vcol[rr], CC[ch])));
+        }
     if (DV != DV_NONE) {
         // PQ EOTF -> LMS matrix -> PQ OETF (Shaders.cpp:844-859).  EOTF from the LDS table on [0, 1]; the reference clamps at 0
         // only, so a code above 1.0 (possible behind ycc_to_rgb) is decoded literally — a branch no wave takes on ordinary content.
@@ -671,7 +695,7 @@ __device__ __forceinline__ void convert_block_yuv(const FusedArgs &P, const f2 (
             }
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
-                const f2 v = pk_fma(splat(L[3 * ch]), lin[0], pk_fma(splat(L[3 * ch + 1]), lin[1], splat(L[3 * ch + 2]) * lin[2]));
+                const f2 v = row3_unfused(L[3 * ch], L[3 * ch + 1], L[3 * ch + 2], lin[0], lin[1], lin[2]);        // dovi_lms_step's order
                 lms[ch] = f2{fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f)};
             }
             if (DV == DV_SDR) {
@@ -688,7 +712,8 @@ __device__ __forceinline__ void convert_block_yuv(const FusedArgs &P, const f2 (
                 }
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
-                    const f2 g = fma_k<true>(GG, 3 * ch, tm[0], fma_k<false>(GG, 3 * ch + 1, tm[1], mul_k(GG, 3 * ch + 2, tm[2])));
+                    const f2 gu = row3_unfused(P.gamut[3 * ch], P.gamut[3 * ch + 1], P.gamut[3 * ch + 2], tm[0], tm[1], tm[2]);     // mat3_mul's order
+                    const f2 g = f2{__builtin_amdgcn_fmed3f(gu.x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(gu.y, 0.0f, 1.0f)};
                     out[rr][ch] = f2{hlsl_pow(g.x, 1.0f / 2.2f), hlsl_pow(g.y, 1.0f / 2.2f)};
                 }
             } else if (DV == DV_SDR_L2) {
@@ -719,7 +744,8 @@ __device__ __forceinline__ void convert_block_yuv(const FusedArgs &P, const f2 (
                 }
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
-                    const f2 g = fma_k<true>(GG, 3 * ch, tm[0], fma_k<false>(GG, 3 * ch + 1, tm[1], mul_k(GG, 3 * ch + 2, tm[2])));
+                    const f2 gu = row3_unfused(P.gamut[3 * ch], P.gamut[3 * ch + 1], P.gamut[3 * ch + 2], tm[0], tm[1], tm[2]);     // mat3_mul's order
+                    const f2 g = f2{__builtin_amdgcn_fmed3f(gu.x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(gu.y, 0.0f, 1.0f)};
                     out[rr][ch] = f2{hlsl_pow(g.x, 1.0f / 2.2f), hlsl_pow(g.y, 1.0f / 2.2f)};
                 }
             } else {

@@ -39,6 +39,10 @@ struct PeriodArgs {
     const int32_t *xstrip;                      // [n_strips][2] {smallest, largest} source column any tap of the strip reads
     int out_w, out_h, n_strips, seg_rows, acols;
     int strip_w;                                // output columns per wavefront (even, <= 128): 2 per lane
+    int own;                                    // which two columns a lane owns (PeriodLaneColumn, vp_plan.h): 1 = (lane, 64 + lane), 2 = (2 (lane & 31) +
+                                                // (lane >> 5), 64 + the same) — the planner picks the one whose X-stage reads meet no LDS bank twice; each
+                                                // row leaves as two dword stores of 256 contiguous bytes per wavefront.  0 = the adjacent pair (2 lane,
+                                                // 2 lane + 1) of rounds 2-3, kept for A/B runs (MPCVR_PERIOD_OWN): every ds_read_b64 of a 4:3 frame a 2-way conflict
     // SRC_SURFACE: no convert stage — the X draw samples m_TexConvertOutput as another convert kernel wrote it (Dolby Vision, Catmull-Rom
     // chroma ...: B8G8R8A8 or R10G10B10A2 texels); frame z of a batch reads surf + z * surf_stride (null: FusedFrame::src)
     const uint8_t *surf; int surf_fmt, surf_pitch, surf_w; size_t surf_stride;
@@ -157,16 +161,22 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
     const int c0 = p_const(Q.xstrip)[2 * strip] & ~1;
     const int nb = ((p_const(Q.xstrip)[2 * strip + 1] - c0) >> 1) + 1, npass = (nb + 63) >> 6;
 
-    // stage X / Y role: output columns x_first, x_first + 1
+    // stage X / Y role: output columns xq[0], xq[1] (PeriodLaneColumn: adjacent, or 64 apart so that a 32-lane group's reads stay inside
+    // 32 source columns = the 64 banks a ds_read_b64 group has)
     const int xs = strip * Q.strip_w;
-    const int x_first = xs + 2 * lane;
-    const bool xy_active = 2 * lane < Q.strip_w && x_first < Q.out_w;
+    const int own = Q.own;
+    const int lcol = own == 0 ? 2 * lane : own == 1 ? lane : 2 * (lane & 31) + (lane >> 5);
+    const int xq[2] = {xs + lcol, xs + lcol + (own == 0 ? 1 : 64)};
+    const int x_first = xq[0];
+    const int x_end = min(xs + Q.strip_w, Q.out_w);                   // the strip's columns inside the frame
+    const bool act[2] = {xq[0] < x_end, xq[1] < x_end};
+    const bool xy_active = act[0];
     typedef __attribute__((address_space(3))) const f2 *lds_f2;
     const uint32_t aw_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)Aw;
     uint32_t xo[2][NT]; f2 xwp[2][NP];
 #pragma unroll
     for (int q = 0; q < 2; q++) {
-        const int xc = min(x_first + q, Q.out_w - 1);
+        const int xc = min(xq[q], x_end - 1);
         float wq[2 * NP];
 #pragma unroll
         for (int k = 0; k < 2 * NP; k++) wq[k] = 0.0f;
@@ -299,7 +309,9 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
         for (int c = 0; c < 3; c++) win[i][c] = splat(0.0f);
 
     const uint32_t lane_off = (uint32_t)(P.off_x + x_first) * 4u;
-    const bool pair_ok = xy_active && x_first + 1 < Q.out_w;              // both pixels of the lane exist (odd widths: the last lane stores one)
+    const uint32_t px1_off = own == 0 ? 4u : 256u;                        // wave-uniform: byte distance of the lane's second pixel
+    // dither texels of the lane's two columns (32-periodic table: columns 64 apart meet the same one)
+    const uint32_t dix[2] = {(uint32_t)((P.off_x + xq[0]) & 31), (uint32_t)((P.off_x + xq[1]) & 31)};
     const bool wave_full = Q.strip_w == kPeriodStripMax && xs + kPeriodStripMax <= Q.out_w;    // (lanes outside the frame filter clamped columns and store nothing)
     const pcptr<f2> ywp = (pcptr<f2>)(uintptr_t)Q.yw;
 
@@ -315,8 +327,8 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
         const int wy = P.off_y + y;
         uint32_t dj[2] = {0, 0};
         if (FASTEPI) {          // dither texels first: the LDS round trip hides behind the taps; off_x + xs is even (launcher)
-            const u32x2 dd = *(const u32x2 *)(Di + (wy & 31) * 32 + ((P.off_x + x_first) & 31));
-            dj[0] = dd.x; dj[1] = dd.y;
+            const uint32_t *drow = Di + (wy & 31) * 32;
+            dj[0] = drow[dix[0]]; dj[1] = drow[dix[1]];
         }
         f2 res[3];
         constexpr int base = period_base(PP, QQ, r) - SH;
@@ -341,12 +353,14 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
             }
         }
         const gptr rowp = pdst + (uint32_t)wy * (uint32_t)P.dst_pitch;
+        // two dword stores per row: the lane's columns are 64 apart, so each store is 256 contiguous bytes per wavefront
+        const gptr rowq = rowp + px1_off;
         if (wave_full) {                // wave-uniform: every lane of the strip owns two pixels inside the frame
-            *(__attribute__((address_space(1))) u32x2 *)(rowp + opaque(lane_off)) = u32x2{pk[0], pk[1]};
-        } else if (pair_ok) {           // the frame's last strip: lanes beyond the right edge store nothing, an odd width ends in one pixel
-            *(__attribute__((address_space(1))) u32x2 *)(rowp + lane_off) = u32x2{pk[0], pk[1]};
-        } else if (xy_active) {
-            *(__attribute__((address_space(1))) uint32_t *)(rowp + lane_off) = pk[0];
+            *(__attribute__((address_space(1))) uint32_t *)(rowp + opaque(lane_off)) = pk[0];
+            *(__attribute__((address_space(1))) uint32_t *)(rowq + opaque(lane_off)) = pk[1];
+        } else {                        // the frame's last strip / a narrow strip: lanes beyond its right edge store nothing
+            if (act[0]) *(__attribute__((address_space(1))) uint32_t *)(rowp + lane_off) = pk[0];
+            if (act[1]) *(__attribute__((address_space(1))) uint32_t *)(rowq + lane_off) = pk[1];
         }
     };
     // after source row 6j - 1 + RHO went into slot RHO: every output phase whose last tap it is

@@ -74,6 +74,8 @@ hipError_t LaunchFusedPeriod(const FusedStripParams &S, const FusedArgs &a_in, c
     q.xi_t = (const int32_t *)S.per_xi_t; q.xw_t = (const float *)S.per_xw_t; q.yw = (const float *)S.per_yw; q.xstrip = (const int32_t *)S.per_xstrip;
     q.out_w = S.out_w; q.out_h = S.out_h;
     q.strip_w = S.per_strip_w;
+    static const int own_env = EnvInt("MPCVR_PERIOD_OWN", -1);       // A/B knob: force the lane -> column ownership (0, 1, 2)
+    q.own = own_env >= 0 && own_env <= 2 ? own_env : S.per_own;
     q.n_strips = (S.out_w + q.strip_w - 1) / q.strip_w;
     q.acols = S.per_acols;
     if (S.surface_mode) {

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
         }
     __syncthreads();                                   // the only workgroup barrier: tables visible
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;      // (wave-uniform, and the compiler should know)
     const int W = P.W, H = P.H;
     const int x0 = (blockIdx.x * WAVES + wave) * S;
     const int s0 = blockIdx.y * P.seg_rows;

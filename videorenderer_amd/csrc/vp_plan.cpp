@@ -736,6 +736,33 @@ bool PlanFusedPeriod(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x
         max_cols = std::max(max_cols, (((hi - (lo & ~1)) >> 1) + 1) * 2);
     }
     pp->acols = max_cols;
+    // lane -> output column ownership: the one whose X-stage reads (one ds_read_b64 per tap, pixel and channel at A + 24 * column) cost the
+    // fewest LDS cycles, counted exactly on a strip in the middle of the frame: per 32-lane group one cycle + one per extra distinct
+    // column on the busiest 8-byte slot (slot = 3 * column mod 32).  The adjacent pair (0) is not a candidate: its two dword stores
+    // would interleave inside every cache line.
+    {
+        const int s = n_strips / 2, x0 = s * sw, lo = pp->xstrip[2 * s] & ~1;
+        long best = -1;
+        for (int own = 1; own < 3; own++) {
+            long cycles = 0;
+            for (int q = 0; q < 2; q++)
+                for (int k = 0; k < nt; k++)
+                    for (int g = 0; g < 2; g++) {
+                        int cols[32], n = 0;
+                        for (int i = 0; i < 32; i++) {
+                            const int x = std::min(x0 + PeriodLaneColumn(own, 32 * g + i, q), n_out_x - 1);
+                            const int c = pp->xi_t[(size_t)k * n_out_x + x] - lo;
+                            bool dup = false;
+                            for (int j = 0; j < n && !dup; j++) dup = cols[j] == c;
+                            if (!dup) cols[n++] = c;
+                        }
+                        int slot[32] = {0}, worst = 1;
+                        for (int j = 0; j < n; j++) worst = std::max(worst, ++slot[(3 * cols[j]) & 31]);
+                        cycles += worst;
+                    }
+            if (best < 0 || cycles < best) { best = cycles; pp->own = own; }
+        }
+    }
     pp->P = P; pp->Q = Q;
     return true;
 }

@@ -139,6 +139,7 @@ struct PeriodPlan {
     int nt = 0;                  // taps per output on both axes as the kernel runs them: 4, 5 (Lanczos3's shared texel folded) or 6
     int acols = 0;               // columns of a converted source row the widest strip needs (even)
     int strip_w = 128;           // output columns per wavefront (even, <= 128): the width whose convert passes are best filled
+    int own = 0;                 // which two output columns a lane owns (PeriodLaneColumn): chosen so that the X stage's ds_read_b64 meet no bank twice
     std::vector<int32_t> xstrip; // [2 * n_strips] {lo, hi} source column per strip
     std::vector<int32_t> xi_t;   // [nt][n_out_x] tap-major
     std::vector<float> xw_t;
@@ -148,6 +149,16 @@ struct PeriodPlan {
 // pattern (clamped to the texture) for one of the supported ratios; hx may be any 4- or 6-tap table.  fold_q1: both tables are
 // Direct3D 11 Lanczos3 tables whose taps 0 and 1 read the same texel (ps_interpolation_lanczos3.hlsl:33-34) — folded to 5 taps.
 // heavy_convert: the convert stage carries a table tail (PQ / HLG -> SDR): its passes weigh ~4x what they do on SDR content
+// Output column (relative to the strip) of lane `lane`'s pixel q under ownership `own`:
+//   0: (2 lane, 2 lane + 1) — adjacent pair, one 8-byte store per row;  1: (lane, 64 + lane);  2: (2 (lane & 31) + (lane >> 5), 64 + the same)
+// A ds_read_b64 serves lanes 0-31 and 32-63 as two groups over 64 four-byte banks (MI355X_MICROARCH.md, LDS): two bytes-apart columns of
+// A's 24-byte column stride collide when they are 32 columns apart.  With `own` = 0 one group's 32 reads cover 64 output columns — 48 source
+// columns at 4:3, every read a 2-way conflict (r03: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50); 1 makes them 32 consecutive output
+// columns (<= 32 source columns when upscaling), 2 every other output column (source stride 3 at 2:3: a permutation of the banks).
+inline int PeriodLaneColumn(int own, int lane, int q)
+{
+    return own == 0 ? 2 * lane + q : own == 1 ? lane + 64 * q : 2 * (lane & 31) + (lane >> 5) + 64 * q;
+}
 bool PlanFusedPeriod(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x, int n_out_y, int src_w, int src_h, bool fold_q1, PeriodPlan *pp, bool heavy_convert = true);
 
 // ---- the pass plan of one Process() (DX11VideoProcessor.cpp:3285-3424, shader path) ----
