@@ -45,7 +45,7 @@ WORKLOADS = {
                iUpscaling=2, desc="1080p YUV420P10 BT.709 -> Catmull-Rom 2x -> ordered dither -> 4K BGRA8"),
     # BASELINE.json configs[0] and the native-resolution HDR case: no resize, one block-convert launch per batch
     "c1": dict(cformat=1, w=1920, h=1080, scale=1, ext=dict(chroma=5, nominal_range=2, matrix=1, primaries=2, transfer=5),
-               iUpscaling=2, desc="1080p NV12 BT.709 -> BGRA8, no resize (BASELINE configs[0])"),
+               iUpscaling=2, batch=128, desc="1080p NV12 BT.709 -> BGRA8, no resize (BASELINE configs[0])"),
     "hdr4k": dict(cformat=2, w=3840, h=2160, scale=1, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
                   iUpscaling=4, desc="4K P010 BT.2020/PQ -> PQ->SDR(Hable,125nits) -> ordered dither -> 4K BGRA8, no resize"),
     # everyday non-integer geometries: one fused kernel per batch (k_fused_period at 4:3 / 3:2 / 2:3 / 1:2 / 3:1 down the rows, k_fused_strip otherwise; --flags 128 = MPCVR_FLAG_NO_PERIOD)
@@ -230,8 +230,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3hdr", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=32, help="frames per step (per GPU) = frames per fused launch")
-    ap.add_argument("--ring", type=int, default=48, help="distinct input/output frame buffers cycled (>= batch)")
+    ap.add_argument("--batch", type=int, default=None, help="frames per step (per GPU) = frames per fused launch; default 32 (c1: 128 — a 1080p NV12 frame is 11 MB, "
+                    "32 of them are an 80 us launch whose ramp-up, drain and the gap to the next launch cost a sixth of the step)")
+    ap.add_argument("--ring", type=int, default=None, help="distinct input/output frame buffers cycled (>= batch); default batch + 16")
     ap.add_argument("--flags", type=int, default=0, help="mpcvr_settings.flags (2 = pass-per-kernel path)")
     ap.add_argument("--settle", type=float, default=1.0,
                     help="seconds of untimed launches BEFORE the counted warm-up (clock ramp: a cold part reads ~5 %% low over a 40 ms run); stated in config")
@@ -253,6 +254,10 @@ def main():
     dev = torch.cuda.current_device()
 
     wl = dict(WORKLOADS[args.workload])
+    if args.batch is None:
+        args.batch = wl.get("batch", 32)
+    if args.ring is None:
+        args.ring = args.batch + 16
     if args.src:
         wl["w"], wl["h"] = (int(v) for v in args.src.lower().split("x"))
         wl["desc"] += f" [source overridden to {wl['w']}x{wl['h']}]"
@@ -383,6 +388,47 @@ def main():
                      "note": "mpcvr_copy_sample(host) + mpcvr_process per frame; the output stays in HBM (the reference "
                              "presents it); single-frame launches, 3-slot upload ring on a copy stream"}
 
+    # The reference's own call pattern (Render -> Process per frame, DX11VideoProcessor.cpp:2730): mpcvr_copy_sample (device sample, used in
+    # place) + mpcvr_process, one frame per call, on a context that owns its stream like a C / C++ host's — reported beside `value`, which
+    # is the mpcvr_process_batch rate.  Two figures: frames dealt to the context's two frame lanes (default) and strictly one after the other.
+    per_frame = None
+    if rank == 0 and world == 1 and not args.no_host_path:
+        import ctypes as C
+        L = api.load_library()
+        sp = [C.c_void_p(t.data_ptr()) for t in srcs]
+        dp = [C.c_void_p(t.data_ptr()) for t in dsts]
+        res_pf = {}
+        for label, extra in (("frame_lanes", 0), ("one_after_the_other", api.FLAG_NO_FRAME_LANES)):
+            st2 = api.default_settings(iUpscaling=wl["iUpscaling"], iDownscaling=wl.get("iDownscaling", 2), flags=args.flags | extra,
+                                       output_format=wl.get("output_format", 0))
+            vp2 = api.VideoProcessor(st2, device=dev, use_torch_stream=False)
+            vp2.InitMediaType(wl["cformat"], w, h, extfmt=extfmt)
+            if wl.get("hdr_output"):
+                vp2.SetHdrOutput(True)
+            vp2.SetWindowRect((0, 0, dw, dh))
+            vp2.SetVideoRect((0, 0, dw, dh))
+            ctx = vp2._ctx
+            nf = max(256, 8 * ring)
+
+            def frames(n, i0=0):
+                for i in range(i0, i0 + n):
+                    k = i % ring
+                    if L.mpcvr_copy_sample(ctx, sp[k], pitch, api.MEM_DEVICE) < 0 or L.mpcvr_process(ctx, dp[k], dw * 4, None, None, 0) < 0:
+                        raise SystemExit("per-frame path: " + L.mpcvr_last_error(ctx).decode())
+            frames(2 * ring)
+            vp2.Synchronize()
+            tp = time.perf_counter()
+            frames(nf)
+            vp2.Synchronize()
+            res_pf[label] = nf / (time.perf_counter() - tp)
+            res_pf[label + "_last_process_ms"] = round(vp2.GetLastTimings()["process_ms"], 4)
+            vp2.close()
+        per_frame = {"frames_per_s": round(res_pf["frame_lanes"], 1), "frames_per_s_one_after_the_other": round(res_pf["one_after_the_other"], 1),
+                     "last_process_ms": res_pf["frame_lanes_last_process_ms"], "last_process_ms_one_after_the_other": res_pf["one_after_the_other_last_process_ms"],
+                     "hbm_frac": round(res_pf["frame_lanes"] * algo_bytes / 1e9 / HBM_PEAK_GBS, 4),
+                     "note": "mpcvr_copy_sample(device) + mpcvr_process per frame, wall clock over frames queued back to back, one mpcvr_synchronize at the end; "
+                             "the context owns its stream (no mpcvr_set_stream), so consecutive frames overlap on its two frame lanes (MPCVR_FLAG_NO_FRAME_LANES: off)"}
+
     if rank == 0:
         # one process per GPU means one GPU per process: two ranks on one device would double-count its throughput.
         # (MPCVR_DIST_BACKEND=gloo is the single-GPU rehearsal of the N > 1 flow and shares the device on purpose.)
@@ -443,6 +489,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline(wl, extfmt)
         if host_path:
             res["host_sample_path"] = host_path
+        if per_frame:
+            res["process_per_frame"] = per_frame
         print(json.dumps(res), flush=True)
     vp.close()
     if world > 1:

@@ -85,6 +85,12 @@ enum { MPCVR_OUT_BGRA8 = 0, MPCVR_OUT_RGB10A2 = 1 };
                                              kernels instead of the one-kernel strip path (k_fused_strip; debug / A-B) */
 #define MPCVR_FLAG_FORCE_PERIOD     0x100u /* take k_fused_period wherever it is built, also where the planner prefers k_fused_strip (SDR content with a
                                               4-tap filter: measured a few % faster there; debug / A-B, and how the suite reaches those instantiations) */
+#define MPCVR_FLAG_NO_FRAME_LANES   0x200u /* mpcvr_process strictly one frame after the other.  Default: a context that owns its stream (no
+                                              mpcvr_set_stream) deals consecutive single frames to two internal streams so that one frame's drain
+                                              overlaps the next one's ramp-up — frames are independent, as the reference's draws into different
+                                              render targets are for the D3D11 driver (Render -> Process, DX11VideoProcessor.cpp:2730).  Results are
+                                              complete after mpcvr_synchronize (or any call that reads them back); frames into the SAME target
+                                              stay in order.  (debug / A-B) */
 #define MPCVR_FLAG_NO_PERIOD        0x80u /* rational vertical ratios (4:3, 3:2, 2:3, 1:2, 3:1) through k_fused_strip's run-time tap tables instead
                                              of the periodic-phase kernel with its register window (k_fused_period; debug / A-B) */
 

@@ -7,7 +7,7 @@ table is committed (profiles/<round>/gpu_suite_kernel_stats.csv).  This CPU test
 
   * every kernel FAMILY of the library is launched by the suite;
   * every instantiation of the families the BASELINE configurations and the bench workloads run on by default (the exact-2x kernel,
-    the periodic-phase kernel, the wide block convert) is launched — or named in tests/golden/kernels_not_launched.json with a reason;
+    the periodic-phase kernel, the streaming same-size convert) is launched — or named in tests/golden/kernels_not_launched.json with a reason;
   * for the table-driven families (k_fused_strip, k_convert_420, k_resize_*) the share of launched instantiations is reported and held
     to the recorded figure, so coverage cannot silently fall; the unlaunched ones are listed in the assertion message.
 A kernel that exists in the build but not in the profile's era (added since) fails the second rule until the profile is refreshed.
@@ -24,7 +24,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(ROOT, "videorenderer_amd", "libmpcvr.so")
-STRICT_FAMILIES = ("k_fused_up2x", "k_fused_period", "k_convert_blocks_wide")
+STRICT_FAMILIES = ("k_fused_up2x", "k_fused_period", "k_convert_stream")
 # share of a family's instantiations the suite launched when the profile was taken (round 3: k_fused_strip 97 / 378, k_convert_blocks 30 / 92,
 # k_convert_420 30 / 160, k_resize_2d 17 / 45, k_resize_rows 22 / 54, k_resize_cols 16 / 54, k_fused_up2x_mx 16 / 72, k_jinc2_quad 1 / 9): the
 # floors sit just under those figures — coverage of the table-driven families is partial and must not fall; the strict families are complete

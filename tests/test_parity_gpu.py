@@ -1761,6 +1761,54 @@ def test_c_multi_gpu_example_degrades_to_one_device(mpcvr, torch_cuda, tmp_path)
     assert int(last.split("devices=")[1].split()[0]) == torch_cuda.cuda.device_count()
 
 
+@pytest.mark.parametrize("name", ["c3hdr_p010_pq_lanczos3_2x", "up_1p5x_lanczos3", "c1_nv12_bt709_passthrough", "c3hdr_p010_pq_lanczos3_2x@1080p"])
+def test_frame_lanes_equal_one_after_the_other(mpcvr, torch_cuda, name):
+    """mpcvr_process frame after frame (Render -> Process per frame, DX11VideoProcessor.cpp:2730) on a context that owns its stream: the
+    frames overlap on its two frame lanes — same bytes as strictly one after the other (MPCVR_FLAG_NO_FRAME_LANES), also when later
+    frames reuse a render target (frames into the same target keep their order), and nothing is read before mpcvr_synchronize."""
+    from videorenderer_amd import api, synth
+    torch = torch_cuda
+    c = dict(GOLDEN_CASES[name.split("@")[0]])
+    if name.endswith("@1080p"):                    # kernels long enough (~15 us) that consecutive frames really overlap
+        c.update(w=1920, h=1080, dst=(3840, 2160))
+    (ww, wh), vr = case_geometry(c)
+    n_frames, n_targets = 9, 4                     # frame i -> target i % 4: frames 4..8 overwrite what 0..4 wrote
+    frames = []
+    for i in range(n_frames):
+        f, pitch = synth.make_frame(c["cformat"], c["w"], c["h"], "noise", seed=900 + i)
+        frames.append(torch.from_numpy(np.ascontiguousarray(f)).cuda())
+    torch.cuda.synchronize()
+    outs = {}
+    for label, extra in (("lanes", 0), ("serial", api.FLAG_NO_FRAME_LANES)):
+        kw = {k: c[k] for k in SETTING_KEYS if k in c}
+        kw["flags"] = kw.get("flags", 0) | extra
+        vp = api.VideoProcessor(api.default_settings(**kw), use_torch_stream=False)       # the context's own stream, as in a C host
+        vp.InitMediaType(c["cformat"], c["w"], c["h"], extfmt=c.get("exfmt", 0))
+        vp.SetWindowRect((0, 0, ww, wh))
+        vp.SetVideoRect(vr)
+        dsts = [torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda") for _ in range(n_targets)]
+        torch.cuda.synchronize()
+        for i in range(n_frames):
+            vp.CopySample(frames[i], pitch)
+            vp.Process(dsts[i % n_targets], ww * 4)
+        vp.Synchronize()
+        outs[label] = [d.cpu().numpy() for d in dsts]
+        info = vp.GetVPInfo()
+        vp.close()
+    for t in range(n_targets):
+        assert np.array_equal(outs["lanes"][t], outs["serial"][t]), f"{name} [{info}]: target {t} differs between the frame lanes and strict order"
+    # and the last frame written to each target is the one that is there: compare with that frame processed alone
+    vp, _ = make_vp(mpcvr, c)
+    for t in range(n_targets):
+        last = max(i for i in range(n_frames) if i % n_targets == t)
+        d = torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda")
+        vp.CopySample(frames[last], pitch)
+        vp.Process(d, ww * 4)
+        vp.Synchronize()
+        assert np.array_equal(d.cpu().numpy(), outs["lanes"][t]), f"{name}: target {t} does not hold frame {last}"
+    vp.close()
+
+
 def test_c_multi_gpu_rccl_example(mpcvr, torch_cuda, tmp_path):
     """examples/c_multi_gpu_rccl.c: SURVEY.md 8e without Python — ncclCommInitAll over the box's devices, ONE ncclBroadcast of rank 0's
     parameter blob issued by the library (mpcvr_broadcast_param_blob_begin / _end, librccl resolved at run time), frames by index.  On
@@ -1770,8 +1818,9 @@ def test_c_multi_gpu_rccl_example(mpcvr, torch_cuda, tmp_path):
     out = subprocess.run([build_c_demo(tmp_path, "c_multi_gpu_rccl", rccl=True), "8", "6"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = out.stdout.strip().splitlines()
-    assert lines[0].startswith("rccl=") and "broadcast=ok" in lines[0], out.stdout
-    assert int(lines[0].split("ranks=")[1].split()[0]) == torch_cuda.cuda.device_count()
+    head = [l for l in lines if l.startswith("rccl=")]             # (RCCL prints its own banner first)
+    assert len(head) == 1 and "broadcast=ok" in head[0], out.stdout
+    assert int(head[0].split("ranks=")[1].split()[0]) == torch_cuda.cuda.device_count()
     assert "identical=yes" in lines[-1] and "frames=6" in lines[-1], out.stdout
 
 

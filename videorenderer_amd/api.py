@@ -44,6 +44,7 @@ OUT_BGRA8, OUT_RGB10A2 = 0, 1
 FLAG_LANCZOS3_FIXED, FLAG_NO_FUSED, FLAG_NO_LUT, FLAG_NO_FAST_CONVERT, FLAG_FUSED_VALU, FLAG_FUSED_MFMA, FLAG_NO_STRIP = 1, 2, 4, 8, 16, 32, 64
 FLAG_NO_PERIOD = 128
 FLAG_FORCE_PERIOD = 256
+FLAG_NO_FRAME_LANES = 512     # mpcvr_process strictly frame after frame (default: two overlapping lanes when the context owns its stream)
 MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2
 PROCAMP_BRIGHTNESS, PROCAMP_CONTRAST, PROCAMP_HUE, PROCAMP_SATURATION = 1, 2, 4, 8
 

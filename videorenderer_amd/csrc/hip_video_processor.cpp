@@ -83,6 +83,10 @@ CHipVideoProcessor::~CHipVideoProcessor()
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     if (m_fork) (void)hipEventDestroy(m_fork);
+    for (FrameLane &fl : m_flanes) {
+        if (fl.stream) { (void)hipStreamSynchronize(fl.stream); (void)hipStreamDestroy(fl.stream); }
+        if (fl.done) (void)hipEventDestroy(fl.done);
+    }
     for (FrameSlot &fs : m_slots) {
         fs.dev.Release();
         if (fs.pinned) (void)hipHostFree(fs.pinned);
@@ -159,6 +163,7 @@ HRESULT CHipVideoProcessor::SetStream(hipStream_t s)
 {
     if (!m_bInit) return Fail(MPCVR_E_NOT_VALID_STATE, "not initialised");
     (void)hipSetDevice(m_device);
+    (void)JoinFrameLanes(true);
     if (m_stream) (void)hipStreamSynchronize(m_stream);
     if (m_ownStream && m_stream) (void)hipStreamDestroy(m_stream);
     m_ownStream = false;
@@ -176,7 +181,57 @@ HRESULT CHipVideoProcessor::Synchronize()
 {
     if (!m_bInit) return Fail(MPCVR_E_NOT_VALID_STATE, "not initialised");
     (void)hipSetDevice(m_device);
+    HRESULT hr = JoinFrameLanes(true);
+    if (hr) return hr;
     return CheckHip(hipStreamSynchronize(m_stream), "hipStreamSynchronize");
+}
+
+// ---- frame lanes (see hip_video_processor.h) ----
+// A frame may run beside its predecessor when nothing it touches is shared with it: the context owns its stream (a caller's stream
+// promises stream order), the sample is read in place (no repack / copy into m_TexSrcVideo), no per-frame constants are uploaded on
+// the context stream (Dolby Vision), and the plan has no intermediate surface (one fused kernel per frame: exact 2x, the strip /
+// periodic kernel without the HDR10 tone-mapping step, the same-size block convert).
+bool CHipVideoProcessor::FrameLanesUsable() const
+{
+    static const bool off = [] { const char *e = std::getenv("MPCVR_NO_FRAME_LANES"); return e && *e && *e != '0'; }();
+    if (off || !m_ownStream || (m_cfg.flags & MPCVR_FLAG_NO_FRAME_LANES) || m_doviValid || !m_srcParams) return false;
+    if (m_srcParams->cformat == MPCVR_CF_V210 || m_srcParams->layout == LAY_RGB || ((uintptr_t)m_curSample & 3) != 0) return false;
+    if (m_plan.fused_up2x) return true;
+    if (m_strip && !m_plan.hdr_tonemap) return true;
+    if (m_plan.direct_convert) return true;
+    return false;
+}
+
+// the lane of the frame about to be queued: the one still writing the same render target if there is one (stream order then
+// keeps the two writes apart), else the next in turn
+CHipVideoProcessor::FrameLane *CHipVideoProcessor::PickFrameLane(const void *rt)
+{
+    FrameLane *pick = nullptr;
+    for (FrameLane &fl : m_flanes)
+        if (fl.busy && fl.rt == rt) {
+            if (hipEventQuery(fl.done) == hipSuccess) fl.busy = false;          // finished long ago: no constraint
+            else if (!pick) pick = &fl;
+            else { (void)hipStreamWaitEvent(pick->stream, fl.done, 0); }         // (both lanes wrote it: order behind both)
+        }
+    if (!pick) { pick = &m_flanes[m_flaneNext]; m_flaneNext = (m_flaneNext + 1) % kFrameLanes; }
+    if (!pick->stream) {
+        if (hipStreamCreateWithFlags(&pick->stream, hipStreamDefault) != hipSuccess) { pick->stream = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&pick->done, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    return pick;
+}
+
+// host_wait: block until the lanes are idle; otherwise the context stream waits for them (work queued on it afterwards runs behind
+// every frame in flight)
+HRESULT CHipVideoProcessor::JoinFrameLanes(bool host_wait)
+{
+    HRESULT hr = MPCVR_S_OK;
+    for (FrameLane &fl : m_flanes) {
+        if (!fl.stream || !fl.busy) continue;
+        if (host_wait) { HRESULT h = CheckHip(hipStreamSynchronize(fl.stream), "frame lane sync"); if (h) hr = h; fl.busy = false; }
+        else if (m_stream) (void)hipStreamWaitEvent(m_stream, fl.done, 0);
+    }
+    return hr;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -504,6 +559,7 @@ HRESULT CHipVideoProcessor::UpdatePlan()
 {
     if (!m_srcParams) return Fail(MPCVR_E_NOT_VALID_STATE, "InitMediaType has not been called");
     (void)hipSetDevice(m_device);
+    (void)JoinFrameLanes(true);
     (void)hipStreamSynchronize(m_stream);    // resources below may still be in use
     const int w1 = m_srcRectWidth, h1 = m_srcRectHeight;
     const int w2 = m_videoRect.Width(), h2 = m_videoRect.Height();
@@ -882,6 +938,7 @@ HRESULT CHipVideoProcessor::CopySample(const void *data, int pitch, int memKind)
                        ~HostTimer() { self->m_copyHostMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } host_timer{this, t_host0};
     MarkConsumed();                                  // the previous sample is done with as far as the host is concerned
     m_curSlot = -1;
+    m_lastRun = nullptr;
     if (memKind == MPCVR_MEM_DEVICE) {               // zero-copy, cf. the IMediaSampleD3D11 branch :2528-2569
         return PrepareSample((const uint8_t *)data, &m_curSample);
     }
@@ -926,7 +983,7 @@ void CHipVideoProcessor::MarkConsumed()
 {
     if (m_curSlot < 0) return;
     UploadSlot &u = m_up[m_curSlot];
-    if (u.consumed && hipEventRecord(u.consumed, m_stream) == hipSuccess) u.consumedRecorded = true;
+    if (u.consumed && hipEventRecord(u.consumed, m_lastRun ? m_lastRun : m_stream) == hipSuccess) u.consumedRecorded = true;
 }
 
 HRESULT CHipVideoProcessor::ConvertColorPass(const uint8_t *sample)
@@ -1091,10 +1148,25 @@ HRESULT CHipVideoProcessor::Process(void *pRenderTarget, int rtPitch, const CRec
     if (rtPitch < m_windowRect.Width() * 4) return Fail(MPCVR_E_INVALIDARG, "render-target pitch smaller than a row");
     if (m_planDirty && (hr = UpdatePlan())) return hr;
     UseLane(0);
-    (void)hipEventRecord(m_evStart, m_stream);
+    FrameLane *fl = (m_noLanesOnce || !FrameLanesUsable()) ? nullptr : PickFrameLane(pRenderTarget);
+    if (fl) {
+        m_run = fl->stream;
+        // the sample's upload (copy stream) was ordered in front of the context stream by CopySample: the lane needs the same edge
+        if (m_curSlot >= 0 && m_up[m_curSlot].uploaded) (void)hipStreamWaitEvent(fl->stream, m_up[m_curSlot].uploaded, 0);
+        if (m_clearOnRun) (void)hipMemsetAsync(m_BackBuffer.ptr, 0, m_clearOnRun, fl->stream);
+    } else {
+        // strictly in stream order behind whatever the lanes still hold (a plan that left the lanes, a caller's stream, the snapshot)
+        (void)JoinFrameLanes(false);
+        if (m_clearOnRun) (void)hipMemsetAsync(m_BackBuffer.ptr, 0, m_clearOnRun, m_stream);
+    }
+    m_clearOnRun = 0;
+    (void)hipEventRecord(m_evStart, m_run);
     hr = ProcessOne(m_curSample, pRenderTarget, rtPitch);
-    (void)hipEventRecord(m_evStop, m_stream);
+    (void)hipEventRecord(m_evStop, m_run);
+    m_lastRun = m_run;
     MarkConsumed();
+    if (fl) { fl->rt = pRenderTarget; fl->busy = true; (void)hipEventRecord(fl->done, fl->stream); }
+    UseLane(0);
     m_timed = true;
     return hr;
 }
@@ -1107,6 +1179,7 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
     (void)hipSetDevice(m_device);
     HRESULT hr;
     if (m_planDirty && (hr = UpdatePlan())) return hr;
+    (void)JoinFrameLanes(false);             // a batch runs on the context stream, behind every single frame still in flight
     for (int i = 0; i < n; i++)
         if (!srcs[i] || !dsts[i]) return Fail(MPCVR_E_POINTER, "null frame in batch");
     // v210 samples are repacked into m_TexSrcVideo's layout first (CopyFrameV210, Helper.cpp:709-748): a batch gets one repack launch
@@ -1397,9 +1470,10 @@ HRESULT CHipVideoProcessor::Render(int /*field*/)
     const bool fresh = m_BackBuffer.size < bytes || !m_BackBuffer.ptr;
     if ((hr = CheckHip(m_BackBuffer.CheckCreate(bytes), "back buffer"))) return hr;
     // ClearRenderTargetView to black (:2622) — only the letterbox area survives Process
-    if (fresh || m_videoRect != CRect(0, 0, w, h))
-        if ((hr = CheckHip(hipMemsetAsync(m_BackBuffer.ptr, 0, bytes, m_stream), "clear"))) return hr;
-    return Process(m_BackBuffer.ptr, w * 4, nullptr, nullptr, false);
+    m_clearOnRun = (fresh || m_videoRect != CRect(0, 0, w, h)) ? bytes : 0;     // queued by Process on the stream the frame runs on
+    hr = Process(m_BackBuffer.ptr, w * 4, nullptr, nullptr, false);
+    m_clearOnRun = 0;
+    return hr;
 }
 
 HRESULT CHipVideoProcessor::GetBackBuffer(void **ptr, int *pitch, int *w, int *h)
@@ -1447,7 +1521,9 @@ HRESULT CHipVideoProcessor::GetCurentImage(void *hostBGRA, size_t *size)
     if (m_hdrOutput) { m_hdrOutput = false; m_blobOverride = false; SetShaderConvertColorParams(); UpdateHdrToneMapParams(); }
     m_videoRect = CRect(0, 0, w, h); m_windowRect = m_videoRect; m_cfg.output_format = MPCVR_OUT_BGRA8;
     m_planDirty = true;
+    m_noLanesOnce = true;                    // the read-back below follows on the context stream
     hr = Process(m_Snapshot.ptr, w * 4, nullptr, nullptr, false);
+    m_noLanesOnce = false;
     m_videoRect = backupVid; m_windowRect = backupWnd; m_cfg.output_format = backupOut;
     if (backupHdr) {
         m_hdrOutput = true; SetShaderConvertColorParams(); UpdateHdrToneMapParams();
@@ -1473,7 +1549,7 @@ HRESULT CHipVideoProcessor::GetCurentImage(void *hostBGRA, size_t *size)
 
 void CHipVideoProcessor::Flush()
 {
-    if (m_bInit) { (void)hipSetDevice(m_device); (void)hipStreamSynchronize(m_stream); }
+    if (m_bInit) { (void)hipSetDevice(m_device); (void)JoinFrameLanes(true); (void)hipStreamSynchronize(m_stream); }
     m_curSample = nullptr;
     // m_DoviExtensionMetadata = {} (:4082): L1 / L2 are forgotten; the uploaded constants change with the next RPU
     m_doviL1Present = m_doviL2Present = false;

@@ -164,138 +164,12 @@ __global__ __launch_bounds__(DV == DV_SDR_L2 ? 512 : 256) void k_convert_blocks(
     }
 }
 
-// The same, four blocks (8 columns x 2 rows) per lane for bi-planar sources whose rows allow it: one 8- / 16-byte load per
-// luma row and chroma row instead of four 2- / 4-byte ones, two 16-byte stores per output row.  Same convert_block, same
-// results; it only changes how the bytes travel.  SRC is SRC_NV12 or SRC_P01X.
-template <int TAIL, int SRC, bool FINAL>
-__global__ __launch_bounds__(256) void k_convert_blocks_wide(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single, int pairs,
-                                                            uint8_t *batch_dst, size_t batch_stride, FrameTable32 tab)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *Di = (uint32_t *)smem;
-    f2 *T = (f2 *)(smem + (FINAL ? 4096 : 0));
-    if (FINAL)
-        for (int i = threadIdx.x; i < 1024; i += 256)
-            Di[i] = (uint32_t)(__half2float(__ushort_as_half(P.dither[i])) * 1024.0f + 0.5f) << 14;
-    if (tail_has_table(TAIL))
-        for (int i = threadIdx.x; i < LUT_N; i += 256) {
-            const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
-            T[i] = f2{v, n - v};
-        }
-    if (FINAL || tail_has_table(TAIL)) __syncthreads();
-
-    constexpr bool WIDE16 = SRC == SRC_P01X;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int W = P.W, H = P.H;
-    const int X = blockIdx.x * 512 + 8 * lane;                         // rect columns X .. X+7
-    const int pair0 = (blockIdx.y * 4 + wave) * pairs;
-    if (X >= W || 2 * pair0 - 1 >= H) return;
-    const FusedFrame frame = tab.n ? tab.f[blockIdx.z] : frames ? frames[blockIdx.z] : single;
-    auto uniform_ptr = [](const void *q) {
-        const uint64_t v = (uint64_t)q;
-        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-    };
-    const gcptr py = (gcptr)uniform_ptr(frame.src);
-    const gptr pdst = (gptr)uniform_ptr(batch_dst ? (void *)(batch_dst + (size_t)blockIdx.z * batch_stride) : frame.dst);
-
-    const f2 MM[5] = {f2{P.m[0], P.m[1]}, f2{P.m[2], P.m[3]}, f2{P.m[4], P.m[5]}, f2{P.m[6], P.m[7]}, f2{P.m[8], 0.0f}};
-    const f2 GG[5] = {f2{P.gamut[0], P.gamut[1]}, f2{P.gamut[2], P.gamut[3]}, f2{P.gamut[4], P.gamut[5]}, f2{P.gamut[6], P.gamut[7]}, f2{P.gamut[8], 0.0f}};
-    const f2 cmax2 = splat(P.maxv);
-    f2 big2 = splat(8388608.0f);
-    asm volatile("" : "+v"(big2));
-    f2 CC[3] = {splat(P.c[0]), splat(P.c[1]), splat(P.c[2])};
-    asm volatile("" : "+v"(CC[0]), "+v"(CC[1]), "+v"(CC[2]));
-
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const int sx0 = P.rect_l + X, c0 = sx0 >> 1;
-    const uint32_t yoff = (uint32_t)(WIDE16 ? 2 * sx0 : sx0);           // luma bytes; the UV row starts at the same byte offset
-    const uint32_t xoff = (uint32_t)((WIDE16 ? 4 : 2) * clampi(c0 + 4, 0, P.cw - 1));     // the chroma texel right of the lane's four
-    const uint32_t lane_off = (uint32_t)(P.off_x + X) * 4u;
-    const gcptr pu = py + P.off_u;
-    // luma rows a, a+1 and chroma rows n, n+1 of a pair: 4 wide loads + 2 for the neighbour texel
-    uint32_t L[2][4], Cc[2][5];
-    auto load_pair = [&](int a) {
-        const int sy0 = P.rect_t + clampi(a, 0, H - 1), sy1 = P.rect_t + clampi(a + 1, 0, H - 1);
-        const int n = chroma_v4(P, sy0) >> 2;
-        const gcptr ry[2] = {py + (uint32_t)sy0 * (uint32_t)P.pitch_y, py + (uint32_t)sy1 * (uint32_t)P.pitch_y};
-        const gcptr rc[2] = {pu + (uint32_t)clampi(n, 0, P.ch - 1) * (uint32_t)P.pitch_c, pu + (uint32_t)clampi(n + 1, 0, P.ch - 1) * (uint32_t)P.pitch_c};
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            if (WIDE16) {
-                const u32x4 l = *(const __attribute__((address_space(1))) u32x4 *)(ry[r] + opaque(yoff));
-                const u32x4 c = *(const __attribute__((address_space(1))) u32x4 *)(rc[r] + opaque(yoff));
-                L[r][0] = l.x; L[r][1] = l.y; L[r][2] = l.z; L[r][3] = l.w;
-                Cc[r][0] = c.x; Cc[r][1] = c.y; Cc[r][2] = c.z; Cc[r][3] = c.w;
-                Cc[r][4] = ld_u32(rc[r] + opaque(xoff));
-            } else {
-                const u32x2 l = *(const __attribute__((address_space(1))) u32x2 *)(ry[r] + opaque(yoff));
-                const u32x2 c = *(const __attribute__((address_space(1))) u32x2 *)(rc[r] + opaque(yoff));
-                L[r][0] = l.x & 0xffffu; L[r][1] = l.x >> 16; L[r][2] = l.y & 0xffffu; L[r][3] = l.y >> 16;
-                const uint32_t e = ld_u16(rc[r] + opaque(xoff));
-                const uint32_t pr[5] = {c.x & 0xffffu, c.x >> 16, c.y & 0xffffu, c.y >> 16, e};
-#pragma unroll
-                for (int i = 0; i < 5; i++) Cc[r][i] = (pr[i] & 0xffu) | ((pr[i] >> 8) << 16);       // U | V << 16
-            }
-        }
-    };
-    load_pair(2 * pair0 - 1);
-    for (int p = 0; p < pairs; p++) {
-        const int a = 2 * (pair0 + p) - 1;
-        if (a >= H) break;
-        uint32_t px[2][8];                                             // [row][column]
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            Raw raw;
-            raw.y[0] = L[0][b]; raw.y[1] = L[1][b];
-            raw.c[0][0] = raw.c[1][0] = 0;
-            raw.c[0][1] = Cc[0][b]; raw.c[0][2] = Cc[0][b + 1];
-            raw.c[1][1] = Cc[1][b]; raw.c[1][2] = Cc[1][b + 1];
-            f2 rc[2][3];
-            convert_block<TAIL, SRC>(P, MM, GG, CC, raw, P.rect_t + clampi(a, 0, H - 1), P.rect_t + clampi(a + 1, 0, H - 1), T, rc);
-#pragma unroll
-            for (int col = 0; col < 2; col++) {
-                uint32_t code[3][2];
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const f2 q = pk_fma(rc[col][c], cmax2, big2);
-                    code[c][0] = __float_as_uint(q.x); code[c][1] = __float_as_uint(q.y);          // 0x4B000000 | k, see k_convert_blocks
-                }
-#pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    const uint32_t cr = code[0][r], cg = code[1][r], cb = code[2][r];
-                    if (FINAL) {
-                        const int wy = P.off_y + a + r;
-                        const uint32_t dj = Di[(wy & 31) * 32 + ((P.off_x + X + 2 * b + col) & 31)];
-                        const uint32_t ib = __umul24(cb, P.epi_mul) + dj, ig = __umul24(cg, P.epi_mul) + dj, ir = __umul24(cr, P.epi_mul) + dj;
-                        const uint32_t bg = __builtin_amdgcn_perm(ig, ib, 0x0c0c0703u);
-                        px[r][2 * b + col] = __builtin_amdgcn_perm(ir, bg, 0x0d070100u);
-                    } else if (P.out10) {
-                        px[r][2 * b + col] = (cr + 0x75000000u) | (cg << 10) | (cb << 20);
-                    } else {
-                        const uint32_t bg = __builtin_amdgcn_perm(cg, cb, 0x0c0c0400u);     // [B, G, 0, 0]
-                        px[r][2 * b + col] = __builtin_amdgcn_perm(cr, bg, 0x0d040100u);    // [B, G, R, 0xff]
-                    }
-                }
-            }
-        }
-        if (p + 1 < pairs && a + 2 < H) load_pair(a + 2);
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const int y = a + r;
-            if (y < 0 || y >= H) continue;
-            const gptr rowp = pdst + (uint32_t)(P.off_y + y) * (uint32_t)P.dst_pitch;
-            *(__attribute__((address_space(1))) u32x4 *)(rowp + opaque(lane_off)) = u32x4{px[r][0], px[r][1], px[r][2], px[r][3]};
-            *(__attribute__((address_space(1))) u32x4 *)(rowp + opaque(lane_off) + 16) = u32x4{px[r][4], px[r][5], px[r][6], px[r][7]};
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Same-size frames as a STREAM (round 4): BASELINE configs[0] (1080p NV12 -> BGRA8) is 11.4 MB per frame — a 32-frame launch
-// of k_convert_blocks_wide lasts ~100 us, its waves live for two row pairs (prologue, one exposed load round trip, two
-// half-line stores per lane and row) and the launch ramps up and drains for a tenth of that.  Here the launch holds exactly the
-// waves the chip keeps resident and each of them walks a long run of row pairs:
+// of round 3's 8-columns-per-lane variant of k_convert_blocks lasted ~100 us, its waves lived for two row pairs (prologue, one
+// exposed load round trip, two half-line stores per lane and row) and the launch ramped up and drained for a tenth of that
+// (same box, profiles/r04/ab_call1_same_box.jsonl: c1 291 k -> 322 k frames/s, 4K P010 PQ -> SDR 54 k -> 67 k).  Here the launch
+// holds exactly the waves the chip keeps resident and each of them walks a long run of row pairs:
 //   * one strip of 256 rect columns per wave (4 px per lane: ONE 16-byte store per lane and row, 1 KiB contiguous per
 //     wavefront) — the strip never changes, so every per-lane byte offset is loop-invariant;
 //   * the launch's row pairs — all frames of the batch laid end to end, G = frames x (H/2 + 1) per strip — are dealt to the
@@ -304,7 +178,7 @@ __global__ __launch_bounds__(256) void k_convert_blocks_wide(FusedArgs P, const 
 //   * raw codes travel TWO row pairs ahead of the arithmetic (two buffers, used alternately), across frame boundaries too:
 //     a wave has 6-12 loads in flight whenever it computes.
 // Arithmetic: convert_block (vp_fused_dev.h) on the lane's two 2x2 blocks — the same code, the same results as
-// k_convert_blocks[_wide].  SRC is SRC_NV12 or SRC_P01X; FINAL as in k_convert_blocks.
+// k_convert_blocks.  SRC is SRC_NV12 or SRC_P01X; FINAL as in k_convert_blocks.
 // ------------------------------------------------------------------------------------------------
 struct StreamArgs {
     int n_strips;              // strips of 256 columns per frame row
@@ -693,14 +567,8 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
     const ConvertParams &c = P.conv;
     const bool fin = P.store.mode == ST_FINAL;
     const int tailk = FusedTailKind(P), srck = FusedSourceKind(P);
-    // four blocks per lane (8- / 16-byte loads, 16-byte stores) where every row allows it
-    static const int no_wide = EnvInt("MPCVR_NO_WIDE_CONVERT", 0);
-    const int lb = srck == SRC_P01X ? 16 : 8;                   // bytes of a lane's luma / chroma load
     const int dvk = FusedDoviKind(P);
     const bool catmull = c.chroma_scaling == 2 && c.fmt.subsampling == 420;
-    const bool wide = !no_wide && !catmull && dvk == DV_NONE && (srck == SRC_P01X || srck == SRC_NV12) && (c.out_w & 7) == 0 && (c.rect_l & 7) == 0 && (c.pitch[0] % lb) == 0 &&
-                      (c.pitch[1] % lb) == 0 && (P.plane_off[1] % lb) == 0 && P.dst_aligned16 && (P.store.off_x & 3) == 0 &&
-                      (P.store.dst_pitch & 15) == 0 && P.src_aligned16;
     // the streaming kernel (k_convert_stream): bi-planar 4:2:0 / 4:2:2 samples whose rows take the lane's 4- / 8-byte loads and 16-byte stores
     static const int no_stream = EnvInt("MPCVR_NO_STREAM_CONVERT", 0);
     const int lbs = srck == SRC_P01X ? 8 : 4;
@@ -742,8 +610,7 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
 #undef MPCVR_ST3
         return err;
     }
-    const int strip_w = wide ? 512 : 128;
-    const int strips = (c.out_w + strip_w - 1) / strip_w, npairs = c.out_h / 2 + 1;
+    const int strips = (c.out_w + 127) / 128, npairs = c.out_h / 2 + 1;
     // row pairs per wave: enough waves to fill the chip a few times over, few enough to amortise the table staging
     int pairs = 16;
     static const int pairs_waves = EnvInt("MPCVR_CB_WAVES", 0);
@@ -751,7 +618,7 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
     // keeps one row pair of loads in flight, so the number of resident waves is the memory-level parallelism (C1: 244 k frames/s
     // with 4 k waves per launch, 284 k with 64 k)
     const bool tables = fin || tail_has_table(tailk) || dvk != DV_NONE;
-    const long want_waves = pairs_waves > 0 ? pairs_waves : tables ? (wide ? 4096 : 8192) : 65536;
+    const long want_waves = pairs_waves > 0 ? pairs_waves : tables ? 8192 : 65536;
     while (pairs > 2 && (long)strips * ((npairs + pairs - 1) / pairs) * n_frames < want_waves) pairs >>= 1;
     const int wg_waves = dvk == DV_SDR_L2 ? 8 : 4;         // (k_convert_blocks: NTH)
     const dim3 grid(strips, (npairs + wg_waves * pairs - 1) / (wg_waves * pairs), n_frames), block(64 * wg_waves, 1, 1);
@@ -768,20 +635,15 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
     }
 #define MPCVR_CB3(TK, SK, FN) do { if (catmull) hipLaunchKernelGGL((k_convert_blocks<TK, SK, FN, DV_NONE, 1>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab); \
                                    else hipLaunchKernelGGL((k_convert_blocks<TK, SK, FN>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab); } while (0)
-#define MPCVR_CBW(TK, SK, FN) hipLaunchKernelGGL((k_convert_blocks_wide<TK, SK, FN>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab)
 #define MPCVR_CB2(TK, SK) do { if (fin) MPCVR_CB3(TK, SK, true); else MPCVR_CB3(TK, SK, false); } while (0)
-#define MPCVR_CBW2(TK, SK) do { if (fin) MPCVR_CBW(TK, SK, true); else MPCVR_CBW(TK, SK, false); } while (0)
-#define MPCVR_CB(TK) do { if (wide && srck == SRC_P01X) MPCVR_CBW2(TK, SRC_P01X); else if (wide) MPCVR_CBW2(TK, SRC_NV12); \
-                          else if (srck == SRC_P01X) MPCVR_CB2(TK, SRC_P01X); else if (srck == SRC_NV12) MPCVR_CB2(TK, SRC_NV12); \
+#define MPCVR_CB(TK) do { if (srck == SRC_P01X) MPCVR_CB2(TK, SRC_P01X); else if (srck == SRC_NV12) MPCVR_CB2(TK, SRC_NV12); \
                           else if (srck == SRC_PLANAR16) MPCVR_CB2(TK, SRC_PLANAR16); else if (srck == SRC_PLANAR8) MPCVR_CB2(TK, SRC_PLANAR8); else MPCVR_CB2(TK, SRC_GENERIC); } while (0)
     if (tailk == TAILK_NONE) MPCVR_CB(TAILK_NONE);
     else if (tailk == TAILK_PQ_LUT) MPCVR_CB(TAILK_PQ_LUT);
     else if (tailk == TAILK_HLG) MPCVR_CB(TAILK_HLG);
     else MPCVR_CB(TAILK_ALU);
 #undef MPCVR_CB
-#undef MPCVR_CBW2
 #undef MPCVR_CB2
-#undef MPCVR_CBW
 #undef MPCVR_CB3
     return hipGetLastError();
 }
