@@ -390,7 +390,7 @@ def main():
 
     # The reference's own call pattern (Render -> Process per frame, DX11VideoProcessor.cpp:2730): mpcvr_copy_sample (device sample, used in
     # place) + mpcvr_process, one frame per call, on a context that owns its stream like a C / C++ host's — reported beside `value`, which
-    # is the mpcvr_process_batch rate.  Two figures: frames dealt to the context's two frame lanes (default) and strictly one after the other.
+    # is the mpcvr_process_batch rate.  Two figures: frames dealt to the context's frame lanes (default) and strictly one after the other.
     per_frame = None
     if rank == 0 and world == 1 and not args.no_host_path:
         import ctypes as C
@@ -427,7 +427,7 @@ def main():
                      "last_process_ms": res_pf["frame_lanes_last_process_ms"], "last_process_ms_one_after_the_other": res_pf["one_after_the_other_last_process_ms"],
                      "hbm_frac": round(res_pf["frame_lanes"] * algo_bytes / 1e9 / HBM_PEAK_GBS, 4),
                      "note": "mpcvr_copy_sample(device) + mpcvr_process per frame, wall clock over frames queued back to back, one mpcvr_synchronize at the end; "
-                             "the context owns its stream (no mpcvr_set_stream), so consecutive frames overlap on its two frame lanes (MPCVR_FLAG_NO_FRAME_LANES: off)"}
+                             "the context owns its stream (no mpcvr_set_stream), so consecutive frames overlap on its frame lanes (MPCVR_FLAG_NO_FRAME_LANES: off)"}
 
     if rank == 0:
         # one process per GPU means one GPU per process: two ranks on one device would double-count its throughput.

@@ -86,7 +86,7 @@ enum { MPCVR_OUT_BGRA8 = 0, MPCVR_OUT_RGB10A2 = 1 };
 #define MPCVR_FLAG_FORCE_PERIOD     0x100u /* take k_fused_period wherever it is built, also where the planner prefers k_fused_strip (SDR content with a
                                               4-tap filter: measured a few % faster there; debug / A-B, and how the suite reaches those instantiations) */
 #define MPCVR_FLAG_NO_FRAME_LANES   0x200u /* mpcvr_process strictly one frame after the other.  Default: a context that owns its stream (no
-                                              mpcvr_set_stream) deals consecutive single frames to two internal streams so that one frame's drain
+                                              mpcvr_set_stream) deals consecutive single frames to four internal streams so that one frame's drain
                                               overlaps the next one's ramp-up — frames are independent, as the reference's draws into different
                                               render targets are for the D3D11 driver (Render -> Process, DX11VideoProcessor.cpp:2730).  Results are
                                               complete after mpcvr_synchronize (or any call that reads them back); frames into the SAME target

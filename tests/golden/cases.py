@@ -32,6 +32,11 @@ GOLDEN_CASES = {
     "c3hdr_p010_pq_lanczos3_2x": dict(cformat=2, w=128, h=72, kind="hdr", seed=4, dst=(256, 144), exfmt=HDR10, iUpscaling=4),
     "c4_p010_pq_mitchell_2x": dict(cformat=2, w=128, h=72, kind="hdr", seed=5, dst=(256, 144), exfmt=HDR10, iUpscaling=1),
     "c5_p010_hlg_lanczos3_2x": dict(cformat=2, w=128, h=72, kind="hdr", seed=6, dst=(256, 144), exfmt=HLG, iUpscaling=4),
+    # exact 2x with the combinations no BASELINE configuration hits (both tap engines run every exact-2x case): a window offset that is
+    # not a multiple of 4 (the generic epilogue behind a PQ table tail), HLG behind a 4-tap filter, the literal PQ chain (MPCVR_FLAG_NO_LUT)
+    "x2_p010_pq_mitchell_offset": dict(cformat=2, w=64, h=40, kind="hdr", seed=501, dst=(128, 80), exfmt=HDR10, iUpscaling=1, window=(140, 88), offset=(3, 4)),
+    "x2_p010_hlg_mitchell": dict(cformat=2, w=64, h=40, kind="hdr", seed=502, dst=(128, 80), exfmt=HLG, iUpscaling=1),
+    "x2_p010_pq_lanczos3_literal_tail": dict(cformat=2, w=64, h=40, kind="hdr", seed=503, dst=(128, 80), exfmt=HDR10, iUpscaling=4, flags=4),
     # ---- noise through the headline pipeline (worst case for rounding) ----
     "noise_p010_pq_lanczos3_2x": dict(cformat=2, w=248, h=40, kind="noise", seed=7, dst=(496, 80), exfmt=HDR10, iUpscaling=4),
     "noise_p010_sdr_lanczos2_2x": dict(cformat=2, w=136, h=24, kind="noise", seed=8, dst=(272, 48), exfmt=ext(matrix=M709), iUpscaling=3),

@@ -1764,7 +1764,7 @@ def test_c_multi_gpu_example_degrades_to_one_device(mpcvr, torch_cuda, tmp_path)
 @pytest.mark.parametrize("name", ["c3hdr_p010_pq_lanczos3_2x", "up_1p5x_lanczos3", "c1_nv12_bt709_passthrough", "c3hdr_p010_pq_lanczos3_2x@1080p"])
 def test_frame_lanes_equal_one_after_the_other(mpcvr, torch_cuda, name):
     """mpcvr_process frame after frame (Render -> Process per frame, DX11VideoProcessor.cpp:2730) on a context that owns its stream: the
-    frames overlap on its two frame lanes — same bytes as strictly one after the other (MPCVR_FLAG_NO_FRAME_LANES), also when later
+    frames overlap on its frame lanes — same bytes as strictly one after the other (MPCVR_FLAG_NO_FRAME_LANES), also when later
     frames reuse a render target (frames into the same target keep their order), and nothing is read before mpcvr_synchronize."""
     from videorenderer_amd import api, synth
     torch = torch_cuda
@@ -1772,7 +1772,7 @@ def test_frame_lanes_equal_one_after_the_other(mpcvr, torch_cuda, name):
     if name.endswith("@1080p"):                    # kernels long enough (~15 us) that consecutive frames really overlap
         c.update(w=1920, h=1080, dst=(3840, 2160))
     (ww, wh), vr = case_geometry(c)
-    n_frames, n_targets = 9, 4                     # frame i -> target i % 4: frames 4..8 overwrite what 0..4 wrote
+    n_frames, n_targets = 13, 5                     # frame i -> target i % 5: later frames overwrite what earlier ones wrote (4 lanes, 5 targets: the writers of a target sit on different lanes)
     frames = []
     for i in range(n_frames):
         f, pitch = synth.make_frame(c["cformat"], c["w"], c["h"], "noise", seed=900 + i)

@@ -85,7 +85,7 @@ CHipVideoProcessor::~CHipVideoProcessor()
     if (m_fork) (void)hipEventDestroy(m_fork);
     for (FrameLane &fl : m_flanes) {
         if (fl.stream) { (void)hipStreamSynchronize(fl.stream); (void)hipStreamDestroy(fl.stream); }
-        if (fl.done) (void)hipEventDestroy(fl.done);
+        for (LaneFrame &f : fl.ring) if (f.done) (void)hipEventDestroy(f.done);
     }
     for (FrameSlot &fs : m_slots) {
         fs.dev.Release();
@@ -202,23 +202,40 @@ bool CHipVideoProcessor::FrameLanesUsable() const
     return false;
 }
 
-// the lane of the frame about to be queued: the one still writing the same render target if there is one (stream order then
-// keeps the two writes apart), else the next in turn
+// the lane of the frame about to be queued: one that still holds a frame into the same render target if there is one (stream order
+// then keeps the two writes apart; further lanes holding such a frame are waited for), else the next in turn
 CHipVideoProcessor::FrameLane *CHipVideoProcessor::PickFrameLane(const void *rt)
 {
     FrameLane *pick = nullptr;
-    for (FrameLane &fl : m_flanes)
-        if (fl.busy && fl.rt == rt) {
-            if (hipEventQuery(fl.done) == hipSuccess) fl.busy = false;          // finished long ago: no constraint
-            else if (!pick) pick = &fl;
-            else { (void)hipStreamWaitEvent(pick->stream, fl.done, 0); }         // (both lanes wrote it: order behind both)
+    hipEvent_t also[kFrameLanes];
+    int n_also = 0;
+    for (FrameLane &fl : m_flanes) {
+        hipEvent_t latest = nullptr;                 // the lane's most recent unfinished frame into rt (the ring is walked oldest first)
+        for (int i = 0; i < kLaneDepth; i++) {
+            LaneFrame &f = fl.ring[(fl.head + i) % kLaneDepth];
+            if (!f.pending) continue;
+            if (hipEventQuery(f.done) == hipSuccess) { f.pending = false; continue; }
+            if (f.rt == rt) latest = f.done;
         }
-    if (!pick) { pick = &m_flanes[m_flaneNext]; m_flaneNext = (m_flaneNext + 1) % kFrameLanes; }
-    if (!pick->stream) {
-        if (hipStreamCreateWithFlags(&pick->stream, hipStreamDefault) != hipSuccess) { pick->stream = nullptr; return nullptr; }
-        if (hipEventCreateWithFlags(&pick->done, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (!latest) continue;
+        if (!pick) pick = &fl; else also[n_also++] = latest;
     }
+    if (!pick) { pick = &m_flanes[m_flaneNext]; m_flaneNext = (m_flaneNext + 1) % kFrameLanes; }
+    if (!pick->stream && hipStreamCreateWithFlags(&pick->stream, hipStreamDefault) != hipSuccess) { pick->stream = nullptr; return nullptr; }
+    for (int i = 0; i < n_also; i++) (void)hipStreamWaitEvent(pick->stream, also[i], 0);
     return pick;
+}
+
+// the frame just queued on `fl` writes `rt`: its completion event takes the ring's oldest slot (whose frame must have completed)
+void CHipVideoProcessor::NoteLaneFrame(FrameLane *fl, const void *rt)
+{
+    LaneFrame &f = fl->ring[fl->head];
+    fl->head = (fl->head + 1) % kLaneDepth;
+    if (!f.done && hipEventCreateWithFlags(&f.done, hipEventDisableTiming) != hipSuccess) { f.done = nullptr; (void)hipStreamSynchronize(fl->stream); return; }
+    if (f.pending) (void)hipEventSynchronize(f.done);
+    f.rt = rt; f.pending = true;
+    (void)hipEventRecord(f.done, fl->stream);
+    fl->last = f.done;
 }
 
 // host_wait: block until the lanes are idle; otherwise the context stream waits for them (work queued on it afterwards runs behind
@@ -227,9 +244,13 @@ HRESULT CHipVideoProcessor::JoinFrameLanes(bool host_wait)
 {
     HRESULT hr = MPCVR_S_OK;
     for (FrameLane &fl : m_flanes) {
-        if (!fl.stream || !fl.busy) continue;
-        if (host_wait) { HRESULT h = CheckHip(hipStreamSynchronize(fl.stream), "frame lane sync"); if (h) hr = h; fl.busy = false; }
-        else if (m_stream) (void)hipStreamWaitEvent(m_stream, fl.done, 0);
+        if (!fl.stream || !fl.last) continue;
+        if (host_wait) {
+            HRESULT h = CheckHip(hipStreamSynchronize(fl.stream), "frame lane sync");
+            if (h) hr = h;
+            for (LaneFrame &f : fl.ring) f.pending = false;
+            fl.last = nullptr;
+        } else if (m_stream) (void)hipStreamWaitEvent(m_stream, fl.last, 0);
     }
     return hr;
 }
@@ -914,6 +935,7 @@ void CHipVideoProcessor::FillFusedParams(const uint8_t *sample, void *rt, int rt
     fp->eotf_lut = (m_doviValid && !no_lut) ? (const float *)m_eotfLut.ptr : nullptr;
     fp->dovi_l2 = (m_doviValid && m_doviHost.l2_enabled) ? 1 : 0;
     fp->taps_mfma = (m_cfg.flags & MPCVR_FLAG_FUSED_MFMA) ? 1 : (m_cfg.flags & MPCVR_FLAG_FUSED_VALU) ? 0 : -1;
+    fp->inflight = m_inflight;
     fp->dst_aligned16 = (((uintptr_t)rt) & 15) == 0;        // batches: ProcessBatch checks every target
     fp->src_aligned16 = (((uintptr_t)sample) & 15) == 0;
     // vectorised convert: dword loads need 4-byte aligned rows and a source rect starting on a 4-px boundary
@@ -1149,6 +1171,7 @@ HRESULT CHipVideoProcessor::Process(void *pRenderTarget, int rtPitch, const CRec
     if (m_planDirty && (hr = UpdatePlan())) return hr;
     UseLane(0);
     FrameLane *fl = (m_noLanesOnce || !FrameLanesUsable()) ? nullptr : PickFrameLane(pRenderTarget);
+    m_inflight = fl ? kFrameLanes : 1;           // the kernels size their segments for that many frames side by side
     if (fl) {
         m_run = fl->stream;
         // the sample's upload (copy stream) was ordered in front of the context stream by CopySample: the lane needs the same edge
@@ -1165,7 +1188,8 @@ HRESULT CHipVideoProcessor::Process(void *pRenderTarget, int rtPitch, const CRec
     (void)hipEventRecord(m_evStop, m_run);
     m_lastRun = m_run;
     MarkConsumed();
-    if (fl) { fl->rt = pRenderTarget; fl->busy = true; (void)hipEventRecord(fl->done, fl->stream); }
+    if (fl) NoteLaneFrame(fl, pRenderTarget);
+    m_inflight = 1;
     UseLane(0);
     m_timed = true;
     return hr;

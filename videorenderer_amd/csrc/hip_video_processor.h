@@ -213,19 +213,25 @@ private:
     // mpcvr_process frame after frame (the reference's own call pattern, Render -> Process, DX11VideoProcessor.cpp:2730): a single 4K
     // frame is one round of waves on this part, so a kernel's ramp-up and drain cost a third of its time when frames run strictly one
     // after the other.  Frames are independent (a D3D11 driver overlaps draws into different render targets as well): a context that
-    // owns its stream deals consecutive frames to two lanes whose kernels overlap; everything that can observe a result
+    // owns its stream deals consecutive frames to four lanes whose kernels overlap; everything that can observe a result
     // (mpcvr_synchronize, the snapshot, a batch, a plan change, a new stream) joins them first.  The lane streams are BLOCKING streams
     // like the context's own (Init), so work on the legacy default stream stays ordered against them.
-    static constexpr int kFrameLanes = 2;
-    struct FrameLane { hipStream_t stream = nullptr; hipEvent_t done = nullptr; const void *rt = nullptr; bool busy = false; };
+    static constexpr int kFrameLanes = 4;
+    // every frame queued on a lane leaves (render target, completion event) in the lane's ring; a slot is reused only after its frame has
+    // completed, which also bounds how far the host runs ahead (kFrameLanes x kLaneDepth frames)
+    static constexpr int kLaneDepth = 8;
+    struct LaneFrame { const void *rt = nullptr; hipEvent_t done = nullptr; bool pending = false; };
+    struct FrameLane { hipStream_t stream = nullptr; LaneFrame ring[kLaneDepth]; int head = 0; hipEvent_t last = nullptr; };
     FrameLane m_flanes[kFrameLanes];
     int m_flaneNext = 0;
+    int m_inflight = 1;                       // FusedParams::inflight of the frame being queued
     size_t m_clearOnRun = 0;                  // Render: bytes of the back buffer to clear in front of the frame, on whatever stream it runs
     bool m_noLanesOnce = false;               // the snapshot's Process stays on the context stream
     hipStream_t m_lastRun = nullptr;          // the stream the current sample's last Process ran on (MarkConsumed records there)
     bool FrameLanesUsable() const;
     FrameLane *PickFrameLane(const void *rt);
     HRESULT JoinFrameLanes(bool host_wait);
+    void NoteLaneFrame(FrameLane *fl, const void *rt);
     size_t m_convBytes = 0, m_midBytes = 0, m_postBytes = 0;
     // resources of the frame being processed (lane 0 outside ProcessBatch)
     hipStream_t m_run = nullptr;

@@ -671,8 +671,12 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     int seg = seg_env;
     if (seg <= 0) {
         seg = 72;
+        // frames that run side by side (a batch, or single frames on the context's lanes) share the chip: a batch aims at >= 4 rounds of
+        // the ~3072 resident waves, overlapping single frames at one round between them — the fewest, longest segments that still fill it
+        const long side = (long)n_frames * (P.inflight > 1 ? P.inflight : 1);
+        const long want = n_frames > 1 ? 12288 : 3072;
         for (int cand : {180, 144, 120, 108, 90, 72, 60, 48, 36, 24})
-            if ((long)strips * ((c.out_h + cand - 1) / cand) * n_frames >= 12288 || cand == 24) { seg = cand; break; }
+            if ((long)strips * ((c.out_h + cand - 1) / cand) * side >= want || cand == 24) { seg = cand; break; }
     }
     seg = (seg + 1) & ~1;
     if (seg > c.out_h) seg = c.out_h;
@@ -681,7 +685,10 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     // default: the packed-fp32 VALU kernel (vp_fused_up2x.h).  The matrix-core variant (vp_fused_mx.hip) runs when MPCVR_FLAG_FUSED_MFMA
     // is set, or — with neither flag — when the environment says MPCVR_FUSED_MX=1; it is parity-green but not faster
     static const int mx_default = EnvInt("MPCVR_FUSED_MX", 0);
-    if (P.taps_mfma >= 0 ? P.taps_mfma != 0 : mx_default != 0) return LaunchFusedUp2xMx(P, a, knt, frames_dev, single, n_frames, s);
+    if (P.taps_mfma >= 0 ? P.taps_mfma != 0 : mx_default != 0) {
+        const hipError_t e = LaunchFusedUp2xMx(P, a, knt, frames_dev, single, n_frames, s);
+        if (e != hipErrorNotSupported) return e;            // (a combination the experiment kernel is not built for: the default kernel below)
+    }
 
     if (knt == 4) return LaunchFusedUp2xNT<4>(P, a, strips, seg, frames_dev, single, n_frames, s);
     if (knt == 5) return LaunchFusedUp2xNT<5>(P, a, strips, seg, frames_dev, single, n_frames, s);

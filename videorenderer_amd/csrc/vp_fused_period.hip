@@ -87,8 +87,10 @@ hipError_t LaunchFusedPeriod(const FusedStripParams &S, const FusedArgs &a_in, c
     int seg = seg_env;
     if (seg <= 0) {
         seg = 2 * PB;
+        const long side = (long)n_frames * (P.inflight > 1 ? P.inflight : 1);       // frames sharing the chip: a batch, or single frames on the context's lanes
+        const long want = n_frames > 1 ? 12288 : 4096;
         for (int cand : {24, 16, 12, 8, 6, 4, 3, 2})
-            if ((long)q.n_strips * ((S.out_h + cand * PB - 1) / (cand * PB)) * n_frames >= 12288 || cand == 2) { seg = cand * PB; break; }
+            if ((long)q.n_strips * ((S.out_h + cand * PB - 1) / (cand * PB)) * side >= want || cand == 2) { seg = cand * PB; break; }
     }
     seg = std::max(PB, (seg / PB) * PB);
     q.seg_rows = seg;

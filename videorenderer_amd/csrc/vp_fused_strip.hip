@@ -143,8 +143,10 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
     int seg = seg_env;
     if (seg <= 0) {
         seg = 16;
+        const long side = (long)n_frames * (P.inflight > 1 ? P.inflight : 1);       // frames sharing the chip: a batch, or single frames on the context's lanes
+        const long want = n_frames > 1 ? 12288 : 4096;
         for (int cand : {192, 128, 96, 64, 48, 32, 24, 16})
-            if ((long)q.n_strips * ((S.out_h + cand - 1) / cand) * n_frames >= 12288 || cand == 16) { seg = cand; break; }
+            if ((long)q.n_strips * ((S.out_h + cand - 1) / cand) * side >= want || cand == 16) { seg = cand; break; }
     }
     q.seg_rows = std::min(seg, S.out_h);
 

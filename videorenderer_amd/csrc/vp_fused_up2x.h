@@ -35,7 +35,7 @@ namespace mpcvr {
 
 namespace {
 
-template <int NT, int TAIL, int SRC, int EPI, int STOREPOL = 0>
+template <int NT, int TAIL, int SRC, int EPI>
 __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -281,11 +281,9 @@ __global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedF
                             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                             u32x4 v4 = {pk[0], pk[1], pk[2], pk[3]};
                             __attribute__((address_space(1))) u32x4 *sp = (__attribute__((address_space(1))) u32x4 *)(rowp + opaque(lane_off));
-                            // store policy (MPCVR_UP2X_STORE, A/B measured in round 3): 1 = non-temporal (global_store_dwordx4 ... nt:
-                            // the render target is written once and never read back by this launch), 2 = raised wave priority around the store
-                            if (STOREPOL == 1) __builtin_nontemporal_store(v4, sp);
-                            else if (STOREPOL == 2) { __builtin_amdgcn_s_setprio(3); *sp = v4; __builtin_amdgcn_s_setprio(0); }
-                            else *sp = v4;
+                            // (plain stores: non-temporal ones and a raised wave priority around the store were A/B-measured in round 3 — both
+                            // inside the run-to-run spread; the template argument that carried them is gone)
+                            *sp = v4;
                         } else {
                             __attribute__((address_space(1))) uint32_t *dst = (__attribute__((address_space(1))) uint32_t *)(rowp + lane_off);
                             dst[0] = pk[0]; dst[1] = pk[1]; dst[2] = pk[2]; dst[3] = pk[3];
@@ -308,7 +306,6 @@ hipError_t LaunchFusedUp2xNT(const FusedParams &P, const FusedArgs &a_in, int st
     const dim3 block(256, 1, 1);
     const int tailk = FusedTailKind(P);
     static const int lds_pad = EnvInt("MPCVR_FUSED_LDS_PAD", 0);   // experiments: lower the occupancy by claiming more LDS
-    static const int store_policy = EnvInt("MPCVR_UP2X_STORE", 0);
     const FusedArgs &a = a_in;
     const size_t lds = LDS_A + LDS_D + LDS_DB + (tail_has_table(tailk) ? LDS_T : 0) + (size_t)lds_pad;
     const int srck = FusedSourceKind(P);
@@ -337,14 +334,6 @@ hipError_t LaunchFusedUp2xNT(const FusedParams &P, const FusedArgs &a_in, int st
 #ifdef MPCVR_UP2X_HEADLINE_ONLY
     MPCVR_LAUNCH3(NT, TAILK_PQ_LUT, SRC_P01X, EPI_DITHER8);
 #else
-    // store-policy A/B of the headline instantiation only (MPCVR_UP2X_STORE = 1 non-temporal, 2 raised priority): see DESIGN.md 4.2
-    if constexpr (NT == 5) {
-        if (store_policy && tailk == TAILK_PQ_LUT && srck == SRC_P01X && epik == EPI_DITHER8) {
-            if (store_policy == 1) hipLaunchKernelGGL((k_fused_up2x<5, TAILK_PQ_LUT, SRC_P01X, EPI_DITHER8, 1>), grid, block, lds, s, a, frames_dev, single);
-            else hipLaunchKernelGGL((k_fused_up2x<5, TAILK_PQ_LUT, SRC_P01X, EPI_DITHER8, 2>), grid, block, lds, s, a, frames_dev, single);
-            return hipGetLastError();
-        }
-    }
     MPCVR_LAUNCH_NT(NT);
 #endif
 #undef MPCVR_LAUNCH_NT

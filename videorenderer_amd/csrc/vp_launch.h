@@ -69,6 +69,8 @@ struct FusedParams {
     const float *eotf_lut;    // device, kPqLutSize floats: log2 ST2084ToLinear(x, 1) at x = (i/(N-1))^2 — the Dolby Vision variants of the block convert decode PQ from it
     int dovi_l2;              // the frame's Dolby Vision metadata carries level-2 trims for this display (DoviParams::l2_enabled)
     int taps_mfma;            // fused 2x kernel: 1 = resize taps on the matrix cores, 0 = packed-fp32 VALU chains, -1 = library default
+    int inflight;             // single-frame launches: frames the host keeps running side by side (the context's frame lanes), 0 / 1 = none.  The
+                              // segment rules count them like frames of a batch: four overlapping 4K frames fill the chip with long segments
 };
 bool FusedUp2xSupported(const FusedParams &P);
 bool BlockConvertLayout(const FusedParams &P, bool catmull_420);       // source layout + chroma filter convert_block serves
