@@ -202,6 +202,14 @@ bool CHipVideoProcessor::FrameLanesUsable() const
     return false;
 }
 
+// Four lanes: measured on MI355X with 4K P010 -> 8K frames (bench.py process_per_frame) — one lane 14.4 k frames/s, two 18.2 k, four
+// 19.3 k; the kernels size their segments for that many frames side by side (FusedParams::inflight).
+int CHipVideoProcessor::FrameLaneCount()
+{
+    static const int n = [] { const char *e = std::getenv("MPCVR_FRAME_LANES"); const int v = e && *e ? std::atoi(e) : 4; return v < 1 ? 1 : v > kFrameLanes ? kFrameLanes : v; }();
+    return n;
+}
+
 // the lane of the frame about to be queued: one that still holds a frame into the same render target if there is one (stream order
 // then keeps the two writes apart; further lanes holding such a frame are waited for), else the next in turn
 CHipVideoProcessor::FrameLane *CHipVideoProcessor::PickFrameLane(const void *rt)
@@ -209,18 +217,19 @@ CHipVideoProcessor::FrameLane *CHipVideoProcessor::PickFrameLane(const void *rt)
     FrameLane *pick = nullptr;
     hipEvent_t also[kFrameLanes];
     int n_also = 0;
-    for (FrameLane &fl : m_flanes) {
+    for (int li = 0; li < FrameLaneCount(); li++) {
+        FrameLane &fl = m_flanes[li];
         hipEvent_t latest = nullptr;                 // the lane's most recent unfinished frame into rt (the ring is walked oldest first)
         for (int i = 0; i < kLaneDepth; i++) {
             LaneFrame &f = fl.ring[(fl.head + i) % kLaneDepth];
-            if (!f.pending) continue;
+            if (!f.pending || f.rt != rt) continue;          // (only a frame into the same target is worth a driver call)
             if (hipEventQuery(f.done) == hipSuccess) { f.pending = false; continue; }
-            if (f.rt == rt) latest = f.done;
+            latest = f.done;
         }
         if (!latest) continue;
         if (!pick) pick = &fl; else also[n_also++] = latest;
     }
-    if (!pick) { pick = &m_flanes[m_flaneNext]; m_flaneNext = (m_flaneNext + 1) % kFrameLanes; }
+    if (!pick) { pick = &m_flanes[m_flaneNext]; m_flaneNext = (m_flaneNext + 1) % FrameLaneCount(); }
     if (!pick->stream && hipStreamCreateWithFlags(&pick->stream, hipStreamDefault) != hipSuccess) { pick->stream = nullptr; return nullptr; }
     for (int i = 0; i < n_also; i++) (void)hipStreamWaitEvent(pick->stream, also[i], 0);
     return pick;
@@ -1171,7 +1180,7 @@ HRESULT CHipVideoProcessor::Process(void *pRenderTarget, int rtPitch, const CRec
     if (m_planDirty && (hr = UpdatePlan())) return hr;
     UseLane(0);
     FrameLane *fl = (m_noLanesOnce || !FrameLanesUsable()) ? nullptr : PickFrameLane(pRenderTarget);
-    m_inflight = fl ? kFrameLanes : 1;           // the kernels size their segments for that many frames side by side
+    m_inflight = fl ? FrameLaneCount() : 1;           // the kernels size their segments for that many frames side by side
     if (fl) {
         m_run = fl->stream;
         // the sample's upload (copy stream) was ordered in front of the context stream by CopySample: the lane needs the same edge

@@ -216,7 +216,8 @@ private:
     // owns its stream deals consecutive frames to four lanes whose kernels overlap; everything that can observe a result
     // (mpcvr_synchronize, the snapshot, a batch, a plan change, a new stream) joins them first.  The lane streams are BLOCKING streams
     // like the context's own (Init), so work on the legacy default stream stays ordered against them.
-    static constexpr int kFrameLanes = 4;
+    static constexpr int kFrameLanes = 8;         // built; FrameLaneCount() of them are used (4 unless MPCVR_FRAME_LANES says otherwise)
+    static int FrameLaneCount();
     // every frame queued on a lane leaves (render target, completion event) in the lane's ring; a slot is reused only after its frame has
     // completed, which also bounds how far the host runs ahead (kFrameLanes x kLaneDepth frames)
     static constexpr int kLaneDepth = 8;

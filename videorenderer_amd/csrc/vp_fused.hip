@@ -189,8 +189,13 @@ struct StreamArgs {
     uint8_t *batch_dst; size_t batch_stride;
 };
 
+#ifdef MPCVR_STREAM_WAVES_PER_EU      // experiment builds only (tools/build_variant.sh): cap the registers for that many waves per SIMD
+#define MPCVR_STREAM_OCC __attribute__((amdgpu_waves_per_eu(MPCVR_STREAM_WAVES_PER_EU, MPCVR_STREAM_WAVES_PER_EU)))
+#else
+#define MPCVR_STREAM_OCC
+#endif
 template <int TAIL, int SRC, bool FINAL>
-__global__ __launch_bounds__(512) void k_convert_stream(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single, StreamArgs Q, FrameTable32 tab)
+__global__ __launch_bounds__(512) MPCVR_STREAM_OCC void k_convert_stream(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single, StreamArgs Q, FrameTable32 tab)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *Di = (uint32_t *)smem;

@@ -680,7 +680,10 @@ __device__ __forceinline__ void convert_block_yuv(const FusedArgs &P, const f2 (
             f2 lin[3], lms[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
-                if (DV == DV_SDR || DV == DV_SDR_L2)
+#ifndef MPCVR_DV_EXP
+#define MPCVR_DV_EXP 0      // experiment builds only (tools/build_variant.sh): 1 = the PQ EOTF of the Dolby Vision block convert literally instead of from
+#endif                      // its table, 2 = Hable's quotient by a true division instead of v_rcp_f32 (round 4: which of them moves the cancelling channels)
+                if ((DV == DV_SDR || DV == DV_SDR_L2) && !(MPCVR_DV_EXP & 1))
                     lin[ch] = f2{__builtin_amdgcn_exp2f(__builtin_fmaf(ent[rr][ch][0].y, frc[rr][ch][0], ent[rr][ch][0].x)),
                                  __builtin_amdgcn_exp2f(__builtin_fmaf(ent[rr][ch][1].y, frc[rr][ch][1], ent[rr][ch][1].x))};
                 else
@@ -707,7 +710,7 @@ __device__ __forceinline__ void convert_block_yuv(const FusedArgs &P, const f2 (
                     const f2 x = f2{fminf(lms[ch].x, 1.0f), fminf(lms[ch].y, 1.0f)} * splat(P.lum_scale);
                     const f2 num = pk_fma(x, pk_fma(splat(A_), x, splat(CB)), splat(DE));
                     const f2 den = pk_fma(x, pk_fma(splat(A_), x, splat(B_)), splat(DF));
-                    const f2 q = f2{num.x * __builtin_amdgcn_rcpf(den.x), num.y * __builtin_amdgcn_rcpf(den.y)};
+                    const f2 q = (MPCVR_DV_EXP & 2) ? f2{num.x / den.x, num.y / den.y} : f2{num.x * __builtin_amdgcn_rcpf(den.x), num.y * __builtin_amdgcn_rcpf(den.y)};
                     tm[ch] = (q - splat(EF)) * splat(inv_div);
                 }
 #pragma unroll
