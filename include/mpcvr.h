@@ -361,8 +361,8 @@ int32_t mpcvr_plan_period(int32_t method, int32_t src_w, int32_t src_h, int32_t 
  * metadata, the display's peak and the tone-mapping operator): five floats + the selection as words */
 int32_t mpcvr_plan_hdr10_params(float min_mastering, float max_mastering, float max_cll, float max_fall, float display_max,
                                 int32_t selection, uint32_t out6[6]);
-/* log2 of ST2084ToLinear(x, 1) at x = (i/4095)^2: the PQ EOTF table of the Dolby Vision block convert */
-int32_t mpcvr_plan_pq_eotf_lut(float out4096[4096]);
+/* log2 of ST2084ToLinear(x, 1) at x = (i/8192)^2, i = 0 .. 8192: the PQ EOTF table of the Dolby Vision block convert */
+int32_t mpcvr_plan_pq_eotf_lut(float out8193[8193]);
 /* which draws Process() would issue (UpdateTexParams :1143, UpdatePostScaleTexures :2894, ResizeShaderPass :3103) */
 int32_t mpcvr_plan_describe(const mpcvr_settings *s, int32_t cformat, int32_t rect_w, int32_t rect_h,
                             const mpcvr_rect *video_rect, int32_t window_w, int32_t window_h,

@@ -395,7 +395,7 @@ def plan_period(method, src_w, src_h, out_w, out_h, flags=0):
 
 def plan_pq_eotf_lut():
     import numpy as np
-    out = np.zeros(4096, np.float32)
+    out = np.zeros(8193, np.float32)
     load_library().mpcvr_plan_pq_eotf_lut(out.ctypes.data_as(C.POINTER(C.c_float)))
     return out
 

@@ -192,7 +192,7 @@ private:
     DevBuffer m_dither;
     DevBuffer m_pqLut;             // kPqLutSize floats (fused path tone-map table)
     DevBuffer m_hlgLut;            // kPqLutSize floats: per-channel inverse HLG OETF (fused kernels' HLG -> SDR tail)
-    DevBuffer m_eotfLut;           // kPqLutSize floats: PQ EOTF (Dolby Vision block convert), uploaded with the first RPU
+    DevBuffer m_eotfLut;           // kEotfLutSize + 1 floats: PQ EOTF (Dolby Vision block convert), uploaded with the first RPU
     float m_pqLutHost[kPqLutSize];
     bool m_pqLutValid = false;
     DevBuffer m_tapsXi, m_tapsXw, m_tapsXs, m_tapsYi, m_tapsYw, m_tapsYs, m_otherX, m_otherY, m_tapsXb, m_tapsYb;

@@ -360,10 +360,11 @@ int32_t mpcvr_plan_hdr10_params(float min_mastering, float max_mastering, float 
     return MPCVR_S_OK;
 }
 
-int32_t mpcvr_plan_pq_eotf_lut(float out4096[4096])
+int32_t mpcvr_plan_pq_eotf_lut(float out8193[8193])
 {
-    if (!out4096) return MPCVR_E_POINTER;
-    mpcvr::BuildPqEotfLut(out4096);
+    static_assert(mpcvr::kEotfLutSize + 1 == 8193, "header and table size");
+    if (!out8193) return MPCVR_E_POINTER;
+    mpcvr::BuildPqEotfLut(out8193);
     return MPCVR_S_OK;
 }
 

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(DV == DV_SDR_L2 ? 512 : 256) void k_convert_blocks(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *Di = (uint32_t *)smem;                                   // dither as j << 14 (FINAL)
     f2 *T = (f2 *)(smem + (FINAL ? 4096 : 0));
-    f2 *TE = T;                                                        // DV: the EOTF table takes the tone-map table's place ...
+    float *TE = (float *)T;                                            // DV: the EOTF table takes the tone-map table's place ...
     DoviParams *DL = (DoviParams *)(smem + (FINAL ? 4096 : 0) + LDS_E);
     if (DV == DV_SDR_L2) T = (f2 *)(smem + (FINAL ? 4096 : 0) + LDS_E + LDS_V);     // ... and the tone-map table follows the curves
     if (FINAL)
@@ -65,10 +65,7 @@ __global__ __launch_bounds__(DV == DV_SDR_L2 ? 512 : 256) void k_convert_blocks(
             Di[i] = (uint32_t)(__half2float(__ushort_as_half(P.dither[i])) * 1024.0f + 0.5f) << 14;
     if (DV != DV_NONE) {
         if (DV == DV_SDR || DV == DV_SDR_L2)
-            for (int i = threadIdx.x; i < LUT_N; i += NTH) {
-                const float v = P.eotf_lut[i], n = P.eotf_lut[min(i + 1, LUT_N - 1)];
-                TE[i] = f2{v, n - v};
-            }
+            for (int i = threadIdx.x; i < EOTF_N + 2; i += NTH) TE[i] = P.eotf_lut[min(i, EOTF_N)];       // (one pad entry: t = N reads N, N + 1)
         if (DV == DV_SDR_L2)
             for (int i = threadIdx.x; i < LUT_N; i += NTH) {
                 const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
@@ -189,11 +186,12 @@ struct StreamArgs {
     uint8_t *batch_dst; size_t batch_stride;
 };
 
-#ifdef MPCVR_STREAM_WAVES_PER_EU      // experiment builds only (tools/build_variant.sh): cap the registers for that many waves per SIMD
-#define MPCVR_STREAM_OCC __attribute__((amdgpu_waves_per_eu(MPCVR_STREAM_WAVES_PER_EU, MPCVR_STREAM_WAVES_PER_EU)))
-#else
-#define MPCVR_STREAM_OCC
+// at least six waves per SIMD (<= 80 VGPRs): the PQ-table variants would take 105 for four — measured on one box with experiment builds
+// (tools/build_variant.sh, profiles/r04/ab_call4_same_box.jsonl): 4K P010 PQ -> SDR 65.9 k frames/s unconstrained, 66.2 k at five, 67.2 k at six
+#ifndef MPCVR_STREAM_WAVES_PER_EU
+#define MPCVR_STREAM_WAVES_PER_EU 6
 #endif
+#define MPCVR_STREAM_OCC __attribute__((amdgpu_waves_per_eu(MPCVR_STREAM_WAVES_PER_EU)))
 template <int TAIL, int SRC, bool FINAL>
 __global__ __launch_bounds__(512) MPCVR_STREAM_OCC void k_convert_stream(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single, StreamArgs Q, FrameTable32 tab)
 {

@@ -51,7 +51,7 @@ struct FusedArgs {
     // CHROMA_CatmullRom (4:2:0): catmull_weights(t) of even / odd luma columns and rows for the stream's chroma siting
     float crx[2][4], cry[2][4];
     const DoviParams *dovi;
-    const float *eotf_lut;         // LUT_N floats (device): log2 ST2084ToLinear((i / (LUT_N - 1))^2, 1)
+    const float *eotf_lut;         // kEotfLutSize + 1 floats (device): log2 ST2084ToLinear((i / kEotfLutSize)^2, 1)
     float sy, sc;
 };
 
@@ -80,7 +80,8 @@ __host__ __device__ constexpr bool tail_has_table(int t) { return t == TAILK_PQ_
 // decode cancel and are elided, Hable in ALU); DV_SDR_L2 = PQ -> SDR with level-2 trims (PQ decode from the table, encode and trims
 // in ALU, tone map from the HDR10 path's table); DV_GENERAL = everything else (HDR output, no tone mapping): literal chain
 enum { DV_NONE = 0, DV_SDR = 1, DV_GENERAL = 2, DV_SDR_L2 = 3 };
-constexpr int LDS_E = LUT_N * 8;   // PQ EOTF table, {value, delta-to-next} pairs
+constexpr int EOTF_N = kEotfLutSize;
+constexpr int LDS_E = (EOTF_N + 1 + 3) / 4 * 16;   // PQ EOTF table: EOTF_N + 1 values, adjacent pairs read with one ds_read2_b32
 constexpr int LDS_V = (sizeof(DoviParams) + 15) & ~15;
 // source specialisation: GENERIC reads planes / bytes / siting at run time; P01X = bi-planar 16-bit (P010/P016), NV12 =
 // bi-planar 8-bit, PLANAR16 / PLANAR8 = three planes of 16- / 8-bit samples (YUV420P10/16, YV12 / I420: what software decoders
@@ -582,11 +583,11 @@ __device__ __forceinline__ void dovi_reshape_block(const DoviRegs &R, const Dovi
 // saturates first).
 template <int TAIL, int SRC, int DV>
 __device__ __forceinline__ void convert_block_yuv(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], f2 (&Ycol)[2], f2 (&Ucol)[2], f2 (&Vcol)[2],
-                                                  const f2 *T, f2 out[2][3], const DoviParams *DL, const f2 *TE, const DoviRegs *DR);
+                                                  const f2 *T, f2 out[2][3], const DoviParams *DL, const float *TE, const DoviRegs *DR);
 
 template <int TAIL, int SRC, int DV = DV_NONE>
 __device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], const Raw &r, int sy0, int sy1, const f2 *T, f2 out[2][3],
-                                              const DoviParams *DL = nullptr, const f2 *TE = nullptr, const DoviRegs *DR = nullptr)
+                                              const DoviParams *DL = nullptr, const float *TE = nullptr, const DoviRegs *DR = nullptr)
 {
     // vertical weights of chroma rows n (w0) and n+1 (w1) for (row 0, row 1): wave-uniform, one SGPR pair each
     const int n4 = chroma_v4(P, sy0) & ~3;                 // 4 * floor(v'(row 0))
@@ -626,7 +627,7 @@ __device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)
 // code units, [column] as (row 0, row 1) pairs, whichever chroma filter produced them
 template <int TAIL, int SRC, int DV>
 __device__ __forceinline__ void convert_block_yuv(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], f2 (&Ycol)[2], f2 (&Ucol)[2], f2 (&Vcol)[2],
-                                                  const f2 *T, f2 out[2][3], const DoviParams *DL, const f2 *TE, const DoviRegs *DR)
+                                                  const f2 *T, f2 out[2][3], const DoviParams *DL, const float *TE, const DoviRegs *DR)
 {
     if (DV != DV_NONE) {
         // ShaderDoviReshape[Poly] (Shaders.cpp:531-589,786-792) on the sampled (Y, U, V) of every pixel, as 0..1 values; the
@@ -662,12 +663,14 @@ __device__ __forceinline__ void convert_block_yuv(const FusedArgs &P, const f2 (
 #pragma unroll
                     for (int e = 0; e < 2; e++) {
                         over = fmaxf(over, rgbc[rr][ch][e]);
-                        // the table holds log2 of the EOTF, sampled at x = (i / (N-1))^2: the EOTF itself is a ~x^3 power law at the
+                        // the table holds log2 of the EOTF, sampled at x = (i / N)^2: the EOTF itself is a ~x^3 power law at the
                         // dark end, where linear interpolation on a uniform grid is 1e-3 relative; its logarithm over sqrt(x)
-                        // interpolates to < 5e-6 everywhere
-                        const float t = __builtin_amdgcn_sqrtf(__builtin_amdgcn_fmed3f(rgbc[rr][ch][e], 0.0f, 1.0f)) * (float)(LUT_N - 1);
+                        // interpolates to 1.2e-6 with N = 8192 (adjacent entries: one ds_read2_b32, the slope is their difference)
+                        typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+                        const float t = __builtin_amdgcn_sqrtf(__builtin_amdgcn_fmed3f(rgbc[rr][ch][e], 0.0f, 1.0f)) * (float)EOTF_N;
                         frc[rr][ch][e] = __builtin_amdgcn_fractf(t);
-                        ent[rr][ch][e] = TE[(int)t];
+                        const f2u pe = *(const f2u *)(TE + (int)t);            // (int)t <= N: the table has N + 1 values and a pad
+                        ent[rr][ch][e] = f2{pe.x, pe.y - pe.x};
                     }
         }
         float L[9];
@@ -882,7 +885,7 @@ __device__ __forceinline__ void load_raw_cr(const FusedArgs &P, gcptr py, const 
 }
 template <int TAIL, int SRC, int DV = DV_NONE>
 __device__ __forceinline__ void convert_block_cr(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], const RawCR &r, int sy0, int sy1, const f2 *T, f2 out[2][3],
-                                                 const DoviParams *DL = nullptr, const f2 *TE = nullptr, const DoviRegs *DR = nullptr)
+                                                 const DoviParams *DL = nullptr, const float *TE = nullptr, const DoviRegs *DR = nullptr)
 {
     // horizontal pass: Q[row j][column parity] = sum_i wx[parity][i] * texel[j][i], as (U, V) pairs
     f2 Q[5][2];

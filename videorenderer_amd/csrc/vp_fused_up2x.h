@@ -35,8 +35,11 @@ namespace mpcvr {
 
 namespace {
 
+#ifndef MPCVR_UP2X_WAVES
+#define MPCVR_UP2X_WAVES 3     // waves per SIMD the register allocation aims at (experiment builds: tools/build_variant.sh)
+#endif
 template <int NT, int TAIL, int SRC, int EPI>
-__global__ __launch_bounds__(256, 3) void k_fused_up2x(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single)
+__global__ __launch_bounds__(256, MPCVR_UP2X_WAVES) void k_fused_up2x(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *Aall = (float *)smem;

@@ -66,7 +66,7 @@ struct FusedParams {
     int src_aligned16;        // every sample of the launch starts on a 16-byte boundary (wide block convert)
     int literal_tail;         // MPCVR_FLAG_NO_LUT: evaluate the HDR tails literally in ALU (no LUT, no algebraic shortcut)
     const float *hlg_lut;     // device, kPqLutSize floats (BuildHlgInverseLut): HLG -> SDR tail of the fused kernels; null => literal chain
-    const float *eotf_lut;    // device, kPqLutSize floats: log2 ST2084ToLinear(x, 1) at x = (i/(N-1))^2 — the Dolby Vision variants of the block convert decode PQ from it
+    const float *eotf_lut;    // device, kEotfLutSize + 1 floats: log2 ST2084ToLinear(x, 1) at x = (i/N)^2 — the Dolby Vision variants of the block convert decode PQ from it
     int dovi_l2;              // the frame's Dolby Vision metadata carries level-2 trims for this display (DoviParams::l2_enabled)
     int taps_mfma;            // fused 2x kernel: 1 = resize taps on the matrix cores, 0 = packed-fp32 VALU chains, -1 = library default
     int inflight;             // single-frame launches: frames the host keeps running side by side (the context's frame lanes), 0 / 1 = none.  The

@@ -8,6 +8,10 @@ namespace mpcvr {
 // entries of the fused path's PQ->SDR per-channel table (linear interpolation; worst case 0.17 LSB of the
 // 10-bit convert output on saturated colours, where the gamut matrix cancels to near zero)
 constexpr int kPqLutSize = 4096;
+// PQ EOTF table of the Dolby Vision block convert: log2 of the EOTF sampled in sqrt(x), read as adjacent entries (ds_read2_b32). 8192
+// intervals in the 32 KiB the {value, slope} table of 4096 took: interpolation error 1.2e-6 instead of 5e-6 — round 4 found the coarser
+// table (built through an fp32 pow chain on top) behind three quarters of the channels beyond 1 LSB on Dolby Vision frames
+constexpr int kEotfLutSize = 8192;          // intervals; the table holds kEotfLutSize + 1 values
 
 // surface formats of the intermediate / output textures
 // (m_InternalTexFmt — DX11VideoProcessor.cpp:1143-1155; m_TexResize is always fp16 — :3155)

@@ -349,17 +349,19 @@ void BuildHlgInverseLut(float out[kPqLutSize])
     }
 }
 
-void BuildPqEotfLut(float out[kPqLutSize])
+void BuildPqEotfLut(float out[kEotfLutSize + 1])
 {
-    const float m1 = 2610.0f / (4096.0f * 4.0f), m2 = (2523.0f / 4096.0f) * 128.0f;
-    const float c1 = 3424.0f / 4096.0f, c2 = (2413.0f / 4096.0f) * 32.0f, c3 = (2392.0f / 4096.0f) * 32.0f;
-    for (int i = 0; i < kPqLutSize; i++) {
-        const float t = (float)i / (float)(kPqLutSize - 1);
-        float x = t * t;                                   // sampled uniformly in sqrt(x): see convert_block's Dolby Vision stage
-        x = std::exp2(std::log2(x) * (1.0f / m2));
-        x = std::fmax(x - c1, 0.0f) / (c2 - c3 * x);
-        const float l = std::log2(x) * (1.0f / m1);       // log2 of the EOTF; codes below 7.3e-7 decode to exactly 0
-        out[i] = l > -150.0f ? l : -150.0f;                // exp2(-150) == 0 in fp32; a finite floor keeps the interpolation NaN-free
+    // evaluated in double and rounded once: the table is as exact as an fp32 log2 value can be (1e-6 relative on the decoded value);
+    // until round 4 it went through the shader's own fp32 exp2(y log2 x) chain, whose 1e-4 error in log2 rode on every entry
+    const double m1 = 2610.0 / (4096.0 * 4.0), m2 = (2523.0 / 4096.0) * 128.0;
+    const double c1 = 3424.0 / 4096.0, c2 = (2413.0 / 4096.0) * 32.0, c3 = (2392.0 / 4096.0) * 32.0;
+    for (int i = 0; i <= kEotfLutSize; i++) {
+        const double t = (double)i / (double)kEotfLutSize;
+        double x = t * t;                                  // sampled uniformly in sqrt(x): see convert_block's Dolby Vision stage
+        x = std::pow(x, 1.0 / m2);
+        x = std::fmax(x - c1, 0.0) / (c2 - c3 * x);
+        const double l = x > 0.0 ? std::log2(x) / m1 : -1e9;       // log2 of the EOTF; codes below 7.3e-7 decode to exactly 0
+        out[i] = l > -150.0 ? (float)l : -150.0f;          // exp2(-150) == 0 in fp32; a finite floor keeps the interpolation NaN-free
     }
 }
 
