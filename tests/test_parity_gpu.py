@@ -384,7 +384,14 @@ def test_process_batch_equals_single(mpcvr, torch_cuda):
                         ("up_1p5x_lanczos3", 64), ("down_lanczos_2p5x", 64), ("jinc2_p010_2x_dither", 0), ("jinc2_nv12_noise_1p5x", 0),      # 64 = NO_STRIP: block convert + tiled two-draw kernel
                         # the layouts that joined the fused kernels in round 2: packed 4:2:2 / 4:4:4, gray, three-plane RGB (v210 batches frame by frame)
                         ("yuy2_bilinear_2x", 0), ("y210_lanczos3_2x", 0), ("yuy2_noise_same_size", 0), ("v210_2x", 0), ("ayuv_same_size", 0),
-                        ("y410_pq_2x", 0), ("y416_fullrange", 0), ("gbrp8_2x", 0), ("gbrp16_down", 0), ("y8_gray_2x", 0), ("y16_gray_crop", 0)):
+                        ("y410_pq_2x", 0), ("y416_fullrange", 0), ("gbrp8_2x", 0), ("gbrp16_down", 0), ("y8_gray_2x", 0), ("y16_gray_crop", 0),
+                        # round 4: the HDR10 tone-mapping step as one launch per batch behind batched post-scale textures (2x, 1.5x, same size, an
+                        # 8-bit target with the final pass behind it, the fp16 internal format), Dolby Vision through the block convert's frame
+                        # dimension (same-size, resized, HDR output with the tone-mapping step), quarter turns (frame by frame: still equal)
+                        ("hdrout_tm1_aces_2x", 0), ("hdrout_tm2_reinhard", 0), ("hdrout_tm3_habel_same_size", 0), ("hdrout_tm4_moebius_bgra8_dither", 0),
+                        ("hdrout_tm5_bt2390", 0), ("hdrout_tm6_st2094_hlg_fp16", 0), ("hdrout_tm2_reinhard", 64),
+                        ("dovi_poly_sdr", 0), ("dovi_poly_sdr_l2_between_2x", 0), ("dovi_mmr_sdr_l2_brighter", 0), ("dovi_hdrout_tm5_l1_l3_l2", 0),
+                        ("rot90_same_shader_single_draw", 0), ("rot270_down_hamming", 0)):
         c = GOLDEN_CASES[name]
         vp, (ww, wh) = make_vp(mpcvr, c, flags)
         c = dict(c, kind="noise")        # distinct frames whatever the case's own content

@@ -60,7 +60,7 @@ CHipVideoProcessor::~CHipVideoProcessor()
     if (!m_bInit && !m_stream && !m_evStart && !m_evStop && !m_dither.ptr) return;
     (void)hipSetDevice(m_device);
     if (m_stream) (void)hipStreamSynchronize(m_stream);
-    for (DevBuffer *b : {&m_batchConv, &m_batchMid, &m_batchTex, &m_jincFirst, &m_jincSecond, &m_TexSrcVideo, &m_TexRaw, &m_TexPost, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
+    for (DevBuffer *b : {&m_batchConv, &m_batchMid, &m_batchPost, &m_batchTex, &m_jincFirst, &m_jincSecond, &m_TexSrcVideo, &m_TexRaw, &m_TexPost, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
                          &m_pqLut, &m_hlgLut, &m_eotfLut, &m_stripTab, &m_tapsXi, &m_tapsXw, &m_tapsXs, &m_tapsYi, &m_tapsYw, &m_tapsYs, &m_otherX, &m_otherY, &m_tapsXb, &m_tapsYb})
         b->Release();
     for (UploadSlot &u : m_up) {
@@ -1399,13 +1399,37 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
     return hr;
 }
 
+HRESULT CHipVideoProcessor::UploadFrameTable(int n, const void *const *srcs, void *const *dsts, uint8_t *dst_base, size_t dst_stride, const FusedFrame **dev, hipEvent_t *done)
+{
+    HRESULT hr;
+    FrameSlot &slot = m_slots[m_slotNext];
+    m_slotNext = (m_slotNext + 1) % kFrameSlots;
+    if (!slot.done && (hr = CheckHip(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming), "slot event"))) return hr;
+    if (slot.used && (hr = CheckHip(hipEventSynchronize(slot.done), "slot wait"))) return hr;
+    if ((size_t)n > slot.cap) {
+        if (slot.pinned) (void)hipHostFree(slot.pinned);
+        slot.pinned = nullptr; slot.cap = 0;
+        const size_t cap = n < 64 ? 64 : (size_t)n;
+        if ((hr = CheckHip(hipHostMalloc(&slot.pinned, sizeof(FusedFrame) * cap, hipHostMallocDefault), "frames pinned"))) return hr;
+        if ((hr = CheckHip(slot.dev.CheckCreate(sizeof(FusedFrame) * cap), "frames"))) return hr;
+        slot.cap = cap;
+    }
+    FusedFrame *fr = (FusedFrame *)slot.pinned;
+    for (int i = 0; i < n; i++) { fr[i].src = srcs ? (const uint8_t *)srcs[i] : nullptr; fr[i].dst = dsts ? dsts[i] : (void *)(dst_base + (size_t)i * dst_stride); }
+    if ((hr = CheckHip(hipMemcpyAsync(slot.dev.ptr, fr, sizeof(FusedFrame) * n, hipMemcpyHostToDevice, m_stream), "frame table"))) return hr;
+    slot.used = true;        // the caller records *done behind the last launch that reads the table
+    *dev = (const FusedFrame *)slot.dev.ptr;
+    *done = slot.done;
+    return MPCVR_S_OK;
+}
+
 // Can this plan run as whole-batch launches?  *conv: the block convert into the (batched) convert output; *direct: the block
 // convert straight into the render targets (same-size frames).  Exactly one of them is used.
 bool CHipVideoProcessor::BatchPlan(const uint8_t *sample0, void *rt0, int rtPitch, bool aligned, FusedParams *conv, FusedParams *direct) const
 {
     // (a flipped or upside-down frame batches only through the strip / periodic kernels' surface variant: per-column tables, a row map)
     const bool turned = m_plan.flip || m_plan.rotation == 180;
-    if (m_plan.hdr_tonemap || (m_plan.rotation && m_plan.rotation != 180) || (turned && !(m_plan.two_pass && m_stripSurf)) || m_secondJinc || !m_plan.convert) return false;
+    if ((m_plan.rotation && m_plan.rotation != 180) || (turned && !(m_plan.two_pass && m_stripSurf)) || m_secondJinc || !m_plan.convert) return false;
     if (m_firstJinc && !(m_plan.one_pass && m_jincFirstTab)) return false;      // Jinc2m batches: the one-draw quad kernel only
     if ((m_srcParams->cformat == MPCVR_CF_V210 && !m_batchRepacked) || m_srcParams->layout == LAY_RGB) return false;
     const int w1 = m_srcRectWidth, h1 = m_srcRectHeight, w2 = m_videoRect.Width();
@@ -1415,7 +1439,10 @@ bool CHipVideoProcessor::BatchPlan(const uint8_t *sample0, void *rt0, int rtPitc
         direct->src_aligned16 = m_batchSrc16 ? 1 : 0;
         return ConvertBlocksSupported(*direct, true);
     }
-    if (!m_plan.two_pass && !m_plan.one_pass) return false;
+    // with the HDR10 tone-mapping step (:3359-3367) the draws go into the frames' post-scale textures (m_batchPost, internal format)
+    // and one tone-mapping launch writes the render targets; without a resize the step reads the convert outputs
+    const bool hdr = m_plan.hdr_tonemap;
+    if (!m_plan.two_pass && !m_plan.one_pass && !hdr) return false;
     const int convPitch = (int)(w1 * SurfBytesPerPixel(m_plan.internal_fmt));
     FillFusedParams(sample0, m_batchConv.ptr, convPitch, conv);
     conv->store = MakeStore(m_batchConv.ptr, convPitch, m_plan.internal_fmt, false);
@@ -1423,7 +1450,9 @@ bool CHipVideoProcessor::BatchPlan(const uint8_t *sample0, void *rt0, int rtPitc
     conv->src_aligned16 = m_batchSrc16 ? 1 : 0;
     if (!ConvertBlocksSupported(*conv, false)) return false;
     const Surface cs{nullptr, convPitch, w1, h1, m_plan.internal_fmt};
-    const StoreParams final = MakeStore(rt0, rtPitch, m_plan.swap_fmt, true);
+    const StoreParams final = hdr ? MakeStore((void *)(uintptr_t)4096, (int)(w2 * SurfBytesPerPixel(m_plan.internal_fmt)), m_plan.internal_fmt, false)
+                                  : MakeStore(rt0, rtPitch, m_plan.swap_fmt, true);
+    if (!m_plan.two_pass && !m_plan.one_pass) return true;          // convert -> tone mapping
     if (m_plan.two_pass) {
         // m_stripSurf was probed with a null target and a window-width pitch (UpdatePlan): re-check with THIS batch's target, and fall
         // through to the tiled / folded kernels' own checks when the strip kernel does not take it
@@ -1450,20 +1479,34 @@ HRESULT CHipVideoProcessor::ProcessBatchLaunches(int n, const FusedFrame *table,
         return CheckHip(LaunchConvertBlocks(direct, table, FusedFrame{nullptr, nullptr}, n, m_stream), "k_convert_blocks");
     }
     // intermediates for up to `chunk` frames (at most ~4 GiB)
-    const size_t per = m_convBytes + m_midBytes;
+    const bool hdr = m_plan.hdr_tonemap;
+    const size_t postStride = hdr ? PostStride() : 0;
+    const size_t per = m_convBytes + m_midBytes + postStride;
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)4 << 30) / std::max<size_t>(per, 1)));
     if ((hr = CheckHip(m_batchConv.CheckCreate(m_convBytes * chunk), "batch convert output"))) return hr;
     if (m_midBytes && (hr = CheckHip(m_batchMid.CheckCreate(m_midBytes * chunk), "batch resize texture"))) return hr;
+    if (hdr && (hr = CheckHip(m_batchPost.CheckCreate(postStride * chunk), "batch post-scale textures"))) return hr;
     if (!BatchPlan(sample0, rt0, rtPitch, aligned, &conv, &direct)) return Fail(MPCVR_E_UNEXPECTED, "batch plan changed");
     const int convPitch = (int)(w1 * SurfBytesPerPixel(m_plan.internal_fmt));
     const Surface cs{m_batchConv.ptr, convPitch, w1, h1, m_plan.internal_fmt};
-    const StoreParams final = MakeStore(rt0, rtPitch, m_plan.swap_fmt, true);
+    const StoreParams target = MakeStore(rt0, rtPitch, m_plan.swap_fmt, true);
+    // HDR10 tone-mapping step: the draws write frame z's post-scale texture (a second frame table whose targets are the slots of
+    // m_batchPost), then ONE k_hdr10_tonemap launch per chunk writes the render targets (:3359-3367)
+    const Surface post{m_batchPost.ptr, (int)(w2 * SurfBytesPerPixel(m_plan.internal_fmt)), w2, h2, m_plan.internal_fmt};
+    const StoreParams final = hdr ? MakeStore(post.ptr, post.pitch, m_plan.internal_fmt, false) : target;
+    const FusedFrame *postTab = nullptr;
+    hipEvent_t postDone = nullptr;
+    if (hdr) {
+        if ((hr = UploadFrameTable(chunk, nullptr, nullptr, (uint8_t *)m_batchPost.ptr, postStride, &postTab, &postDone))) return hr;
+        aligned = true;             // the slots of m_batchPost start on 256-byte boundaries
+    }
+    const bool drawn = m_plan.two_pass || m_plan.one_pass;
     for (int at = 0; at < n; at += chunk) {
         const int m = std::min(chunk, n - at);
-        const FusedFrame *tab = table + at;
+        const FusedFrame *tab = hdr ? postTab : table + at;
         // frame z of the chunk: sample from the table, output at m_batchConv + z * m_convBytes
         conv.store.dst = m_batchConv.ptr;
-        if ((hr = CheckHip(LaunchConvertBlocks(conv, tab, FusedFrame{nullptr, nullptr}, m, m_stream, m_convBytes), "k_convert_blocks"))) return hr;
+        if ((hr = CheckHip(LaunchConvertBlocks(conv, table + at, FusedFrame{nullptr, nullptr}, m, m_stream, m_convBytes), "k_convert_blocks"))) return hr;
         ResizeBatch b1; b1.n = m; b1.in_stride = m_convBytes;
         FusedStripParams ssp{};
         if (m_stripSurf && FillStripSurfParams(cs, final, &ssp)) {
@@ -1483,11 +1526,16 @@ HRESULT CHipVideoProcessor::ProcessBatchLaunches(int n, const FusedFrame *table,
         } else if (m_firstJinc) {
             b1.frames = tab; b1.dst_aligned8 = aligned ? 1 : 0;
             if ((hr = CheckHip(LaunchJinc2Quad(cs, m_firstCoords, w2, h2, final, m_stream, m_jincFirstTab, &b1), "k_jinc2_quad"))) return hr;
-        } else {
+        } else if (drawn) {
             b1.frames = tab;
             if ((hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, cs, m_tapsX, (const int32_t *)m_otherX.ptr, w2, h2, final, m_stream, false, &b1), "k_resize<one>"))) return hr;
         }
+        if (hdr) {
+            ResizeBatch tb; tb.n = m; tb.in_stride = drawn ? postStride : m_convBytes; tb.frames = table + at;
+            if ((hr = CheckHip(LaunchHdr10ToneMap(drawn ? post : cs, m_hdrTm, w2, h2, target, m_stream, &tb), "k_hdr10_tonemap"))) return hr;
+        }
     }
+    if (postDone) (void)hipEventRecord(postDone, m_stream);
     return MPCVR_S_OK;
 }
 

@@ -240,6 +240,10 @@ private:
     void UseLane(int lane);
     // whole-batch launches of the pass-per-kernel path (block convert + folded resize kernels with a frame dimension)
     DevBuffer m_batchConv, m_batchMid;
+    DevBuffer m_batchPost;         // HDR10 tone-mapping step of a batch: the frames' m_TexsPostScale copies side by side
+    size_t PostStride() const { return (m_postBytes + 255) & ~(size_t)255; }
+    // a frame table in a slot of the ring (pinned copy + device copy): frame i = {srcs ? srcs[i] : null, dsts ? dsts[i] : dst_base + i * dst_stride}
+    HRESULT UploadFrameTable(int n, const void *const *srcs, void *const *dsts, uint8_t *dst_base, size_t dst_stride, const FusedFrame **dev, hipEvent_t *done);
     DevBuffer m_batchTex;          // interleaved RGB / v210 batches: the frames' m_TexSrcVideo copies side by side (ProcessBatch)
     bool m_batchRepacked = false;  // the batch at hand reads v210 samples already repacked into m_batchTex
     bool m_batchSrc16 = false;     // every sample of the batch being planned starts on a 16-byte boundary

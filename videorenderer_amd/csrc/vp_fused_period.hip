@@ -88,7 +88,9 @@ hipError_t LaunchFusedPeriod(const FusedStripParams &S, const FusedArgs &a_in, c
     if (seg <= 0) {
         seg = 2 * PB;
         const long side = (long)n_frames * (P.inflight > 1 ? P.inflight : 1);       // frames sharing the chip: a batch, or single frames on the context's lanes
-        const long want = n_frames > 1 ? 12288 : 4096;
+        // two rounds of the 4096 resident waves are enough: longer segments recompute less than a third round balances (round 4, same box:
+        // 1080p -> 1440p 93.3 k frames/s at 64 rows (14,720 waves), 99.2 k at 96 (9,600), 85.3 k at 192 (5,120); 4K -> 1440p flat from 48 to 192)
+        const long want = n_frames > 1 ? 8192 : 4096;
         for (int cand : {24, 16, 12, 8, 6, 4, 3, 2})
             if ((long)q.n_strips * ((S.out_h + cand * PB - 1) / (cand * PB)) * side >= want || cand == 2) { seg = cand * PB; break; }
     }

@@ -559,10 +559,13 @@ __global__ __launch_bounds__(256) void k_jinc2(Surface in, DrawCoords dc, int ou
 }
 
 // TextureCopyRect(..., m_pPSHDR10ToneMapping, ...) — the HDR10 local tone-mapping post-scale step (:3359-3367)
-__global__ __launch_bounds__(256) void k_hdr10_tonemap(Surface in, HdrToneMapParams tm, int out_w, int out_h, StoreParams st)
+// (a batch: frame blockIdx.z reads in + z * in_stride and writes its own render target)
+__global__ __launch_bounds__(256) void k_hdr10_tonemap(Surface in, HdrToneMapParams tm, int out_w, int out_h, StoreParams st, ResizeBatch bt)
 {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= out_w || y >= out_h) return;
+    in.ptr = (uint8_t *)in.ptr + (size_t)blockIdx.z * bt.in_stride;
+    st.dst = bt.frames ? bt.frames[blockIdx.z].dst : (void *)((uint8_t *)st.dst + (size_t)blockIdx.z * bt.dst_stride);
     store_epilogue(st, x, y, hdr10_tonemap(load_surface(in, x, y), tm));
 }
 
@@ -982,9 +985,12 @@ hipError_t LaunchResize(int axis, bool swap, const Surface &in, const AxisTaps &
     return hipGetLastError();
 }
 
-hipError_t LaunchHdr10ToneMap(const Surface &in, const HdrToneMapParams &tm, int out_w, int out_h, const StoreParams &st, hipStream_t s)
+hipError_t LaunchHdr10ToneMap(const Surface &in, const HdrToneMapParams &tm, int out_w, int out_h, const StoreParams &st, hipStream_t s, const ResizeBatch *batch)
 {
-    hipLaunchKernelGGL(k_hdr10_tonemap, grid2d(out_w, out_h), dim3(64, 4, 1), 0, s, in, tm, out_w, out_h, st);
+    const ResizeBatch bt = batch ? *batch : ResizeBatch{};
+    dim3 g = grid2d(out_w, out_h);
+    g.z = (unsigned)bt.n;
+    hipLaunchKernelGGL(k_hdr10_tonemap, g, dim3(64, 4, 1), 0, s, in, tm, out_w, out_h, st, bt);
     return hipGetLastError();
 }
 

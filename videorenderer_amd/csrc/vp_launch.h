@@ -36,7 +36,8 @@ hipError_t LaunchCopy(const Surface &in, int out_w, int out_h, const StoreParams
 // m_pPSCorrection shaders as a same-size pass (kind = MPCVR_CORR_*); fix16 = the kind's 4x4 fix-up matrix (unused for 5, 6)
 hipError_t LaunchCorrection(int kind, const Surface &in, const Surface &out, const float fix16[16], const float gamut9[9], float lum_scale, hipStream_t s);
 // ps_hdr10_tonemap.hlsl: HDR10 local tone mapping as a post-scale step
-hipError_t LaunchHdr10ToneMap(const Surface &in, const HdrToneMapParams &tm, int out_w, int out_h, const StoreParams &st, hipStream_t s);
+hipError_t LaunchHdr10ToneMap(const Surface &in, const HdrToneMapParams &tm, int out_w, int out_h, const StoreParams &st, hipStream_t s,
+                              const ResizeBatch *batch = nullptr);
 // ps_resize_onepass_jinc2.hlsl: the 2-D Jinc2m draw
 // phases_dev: device copy of the table BuildJincPhases filled (dyadic, unrotated draws: weights per phase instead of per pixel)
 // fast: the default tier may take the quad kernel (exact 2x; FMA contraction) instead of the phase-table kernel
