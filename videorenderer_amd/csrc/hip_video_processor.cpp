@@ -1313,6 +1313,37 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
             return hr;
         }
     }
+    // HDR10 tone-mapping step behind the one-kernel strip path (what a single frame of this plan runs, ProcessOne): the strip kernel draws
+    // every frame of a chunk into its slot of m_batchPost (a second frame table: same samples, the slots as targets) and ONE
+    // k_hdr10_tonemap launch writes the render targets (:3359-3367)
+    if (m_plan.hdr_tonemap && m_strip && !m_plan.fused_up2x && src4 && n > 1 && !(m_cfg.flags & (MPCVR_FLAG_NO_FUSED | MPCVR_FLAG_NO_FAST_CONVERT | MPCVR_FLAG_NO_STRIP))) {
+        const int w2 = m_videoRect.Width(), h2 = m_videoRect.Height();
+        const size_t postStride = PostStride();
+        const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)4 << 30) / std::max<size_t>(postStride, 1)));
+        if ((hr = CheckHip(m_batchPost.CheckCreate(postStride * chunk), "batch post-scale textures"))) return hr;
+        const Surface post{m_batchPost.ptr, (int)(w2 * SurfBytesPerPixel(m_plan.internal_fmt)), w2, h2, m_plan.internal_fmt};
+        const StoreParams last = MakeStore(post.ptr, post.pitch, m_plan.internal_fmt, false);
+        FusedStripParams sp{};
+        if (FillStripParams((const uint8_t *)srcs[0], post.ptr, post.pitch, last, &sp)) {
+            sp.fp.dst_aligned16 = 1;                         // the slots start on 256-byte boundaries
+            (void)hipEventRecord(m_evStart, m_stream);
+            for (int at = 0; at < n; at += chunk) {
+                const int m = std::min(chunk, n - at);
+                const FusedFrame *drawTab = nullptr, *realTab = nullptr;
+                hipEvent_t d1 = nullptr, d2 = nullptr;
+                if ((hr = UploadFrameTable(m, srcs + at, nullptr, (uint8_t *)m_batchPost.ptr, postStride, &drawTab, &d1))) return hr;
+                if ((hr = UploadFrameTable(m, srcs + at, dsts + at, nullptr, 0, &realTab, &d2))) return hr;
+                if ((hr = CheckHip(LaunchFusedStrip(sp, drawTab, FusedFrame{nullptr, nullptr}, m, m_stream), "k_fused_strip"))) return hr;
+                ResizeBatch tb; tb.n = m; tb.in_stride = postStride; tb.frames = realTab;
+                if ((hr = CheckHip(LaunchHdr10ToneMap(post, m_hdrTm, w2, h2, MakeStore(dsts[at], rtPitch, m_plan.swap_fmt, true), m_stream, &tb), "k_hdr10_tonemap"))) return hr;
+                (void)hipEventRecord(d1, m_stream);
+                (void)hipEventRecord(d2, m_stream);
+            }
+            (void)hipEventRecord(m_evStop, m_stream);
+            m_timed = true;
+            return MPCVR_S_OK;
+        }
+    }
     // (a batch of one needs no frame table: the frame travels in the kernel arguments, like mpcvr_process)
     if ((!m_plan.fused_up2x && !strip && !batchable) || !src4 || n == 1) {
         // samples that are repacked (or, not starting on a dword, copied) first share m_TexSrcVideo: those batches stay on the

@@ -203,23 +203,10 @@ __device__ __forceinline__ f2 fma_k(const f2 *K, int i, f2 b, f2 c)
     return (i & 1) ? pk_fma_w<1, CLAMP>(K[i >> 1], b, c) : pk_fma_w<0, CLAMP>(K[i >> 1], b, c);
 }
 __device__ __forceinline__ f2 mul_k(const f2 *K, int i, f2 b) { return (i & 1) ? pk_mul_w<1>(K[i >> 1], b) : pk_mul_w<0>(K[i >> 1], b); }
-// One matrix row as the shader's mul() is restated everywhere else (mat3_mul, vp_device.h; the oracle): products summed left to right,
-// every product and sum rounded — NO contraction.  The Dolby Vision variants use it for their three matrices: behind ycc_to_rgb, the LMS
-// step and 2020 -> 709 a bright saturated colour leaves a channel that cancels to ~1e-4 of its terms, where the different rounding of a
-// fused chain is amplified a thousandfold (round 3 counted 3-4x the ill-conditioned channels of the plain kernels on the same frame).
-__device__ __forceinline__ f2 row3_unfused(float m0, float m1, float m2, f2 x, f2 y, f2 z)
-{
-#pragma clang fp contract(off)
-    f2 r = splat(m0) * x;
-    r = r + splat(m1) * y;
-    r = r + splat(m2) * z;
-    return r;
-}
-__device__ __forceinline__ f2 add_unfused(f2 a, f2 b)
-{
-#pragma clang fp contract(off)
-    return a + b;
-}
+// (Round 4 tried the Dolby Vision variants' three matrices — ycc_to_rgb, the LMS step, 2020 -> 709 — as uncontracted products summed
+// left to right, the way mat3_mul and the oracle write them: the count of channels beyond 1 LSB on the whole-frame cases did not move
+// (16 / 12 / 10 per 2 M pixels, profiles/r04/parity_identical_channels.jsonl of call 1), and the kernels lost 10-15 %.  What moved it was the
+// PQ EOTF table — see EOTF_N.  The fused chains stay.)
 
 // raw codes of one 2x2 block (cols Xg, Xg+1; two source rows), prefetched one iteration ahead
 struct Raw {
@@ -642,8 +629,8 @@ __device__ __forceinline__ void convert_block_yuv(const FusedArgs &P, const f2 (
     for (int rr = 0; rr < 2; rr++)                // rr = luma column of the block
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            if (DV != DV_NONE)      // (cm0 y + cm1 u + cm2 v) + c as convert_pixel writes it (vp_convert.h), unfused
-                rgbc[rr][ch] = add_unfused(row3_unfused(P.m[3 * ch], P.m[3 * ch + 1], P.m[3 * ch + 2], Ycol[rr], Ucol[rr], Vcol[rr]), CC[ch]);
+            if (DV != DV_NONE)
+                rgbc[rr][ch] = fma_k<false>(MM, 3 * ch, Ycol[rr], fma_k<false>(MM, 3 * ch + 1, Ucol[rr], fma_k<false>(MM, 3 * ch + 2, Vcol[rr], CC[ch])));
             else
                 rgbc[rr][ch] = fma_k<true>(MM, 3 * ch, Ycol[rr], fma_k<false>(MM, 3 * ch + 1, Ucol[rr], fma_k<false>(MM, 3 * ch + 2, Vcol[rr], CC[ch])));
         }
@@ -701,7 +688,7 @@ __device__ __forceinline__ void convert_block_yuv(const FusedArgs &P, const f2 (
             }
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
-                const f2 v = row3_unfused(L[3 * ch], L[3 * ch + 1], L[3 * ch + 2], lin[0], lin[1], lin[2]);        // dovi_lms_step's order
+                const f2 v = pk_fma(splat(L[3 * ch]), lin[0], pk_fma(splat(L[3 * ch + 1]), lin[1], splat(L[3 * ch + 2]) * lin[2]));
                 lms[ch] = f2{fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f)};
             }
             if (DV == DV_SDR) {
@@ -718,8 +705,7 @@ __device__ __forceinline__ void convert_block_yuv(const FusedArgs &P, const f2 (
                 }
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
-                    const f2 gu = row3_unfused(P.gamut[3 * ch], P.gamut[3 * ch + 1], P.gamut[3 * ch + 2], tm[0], tm[1], tm[2]);     // mat3_mul's order
-                    const f2 g = f2{__builtin_amdgcn_fmed3f(gu.x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(gu.y, 0.0f, 1.0f)};
+                    const f2 g = fma_k<true>(GG, 3 * ch, tm[0], fma_k<false>(GG, 3 * ch + 1, tm[1], mul_k(GG, 3 * ch + 2, tm[2])));
                     out[rr][ch] = f2{hlsl_pow(g.x, 1.0f / 2.2f), hlsl_pow(g.y, 1.0f / 2.2f)};
                 }
             } else if (DV == DV_SDR_L2) {
@@ -750,8 +736,7 @@ __device__ __forceinline__ void convert_block_yuv(const FusedArgs &P, const f2 (
                 }
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
-                    const f2 gu = row3_unfused(P.gamut[3 * ch], P.gamut[3 * ch + 1], P.gamut[3 * ch + 2], tm[0], tm[1], tm[2]);     // mat3_mul's order
-                    const f2 g = f2{__builtin_amdgcn_fmed3f(gu.x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(gu.y, 0.0f, 1.0f)};
+                    const f2 g = fma_k<true>(GG, 3 * ch, tm[0], fma_k<false>(GG, 3 * ch + 1, tm[1], mul_k(GG, 3 * ch + 2, tm[2])));
                     out[rr][ch] = f2{hlsl_pow(g.x, 1.0f / 2.2f), hlsl_pow(g.y, 1.0f / 2.2f)};
                 }
             } else {
