@@ -202,7 +202,10 @@ typedef struct mpcvr_dovi_metadata {
  * the tone-mapping step (HDR output); level 1 (+3) replaces the HDR10 metadata of that step (:2716-2720).
  * md == NULL ends Dolby Vision mode (m_Dovi = {}).  E_INVALIDARG for what CheckDoviMetadata rejects in the curves
  * (VideoProcessor.cpp:283-292); the profile checks on the RPU header (:275-281) stay with the adapter.
- * The fused 2x kernel does not carry this path; Dolby Vision frames take the pass-per-kernel path. */
+ * Kernels: the reshaping, the LMS step and the tail run in the 2x2-block convert (k_convert_blocks<..., DV_*>: same-size frames in
+ * one kernel, straight into the render target; in front of k_fused_strip:surface / k_fused_period:surface when the frame is
+ * resized); the exact-2x and the raw-sample strip kernels have no reshaping stage.  The metadata is per context: every frame of an
+ * mpcvr_process_batch call runs on the RPU last set. */
 int32_t mpcvr_set_dovi_metadata(mpcvr_ctx *ctx, const mpcvr_dovi_metadata *md);
 
 /* The correction shaders (m_pPSCorrection, DX11VideoProcessor.cpp:1893-1930): same-size RGB -> RGB passes the reference runs
@@ -268,10 +271,11 @@ int32_t mpcvr_reset(mpcvr_ctx *ctx);
  * regime.  srcs[i]: DEVICE sample pointers (layout/pitch as declared by mpcvr_set_input);
  * dsts[i]: DEVICE render targets (dst_pitch each).
  * The frames of a batch are independent of each other: on every path that can, the whole batch runs as one launch per
- * draw (fused 2x kernel: one launch; pass-per-kernel path with a 4:2:0 source: block convert / X draw / Y draw with a
- * frame dimension and batched intermediates, <= 4 GiB), otherwise frame by frame.  The targets must therefore be distinct
- * buffers; completion is in stream order for the batch as a whole.  Dolby Vision metadata, rotation, Jinc2 and the HDR10
- * tone-mapping step keep the frame-by-frame loop. */
+ * draw (fused 2x / strip / periodic kernel: one launch; same-size frames: one k_convert_stream launch; pass-per-kernel path:
+ * block convert / X draw / Y draw with a frame dimension and batched intermediates, <= 4 GiB; Dolby Vision: the block convert's
+ * frame dimension, one RPU per call; the HDR10 tone-mapping step: one launch behind batched post-scale textures; Jinc2m: the
+ * one-draw quad kernel), otherwise frame by frame (quarter turns, the two-draw Jinc2m, samples that need a repack of their
+ * own).  The targets must therefore be distinct buffers; completion is in stream order for the batch as a whole. */
 int32_t mpcvr_process_batch(mpcvr_ctx *ctx, int32_t n, const void *const *srcs, void *const *dsts,
                             int32_t dst_pitch);
 

@@ -255,6 +255,49 @@ def test_folded_kernels_vs_oracle(mpcvr, oracle, torch_cuda, name):
         compare(got, want, f"{name} [{info}]", exact=True)
 
 
+# ---- round 4: the table-driven kernel families swept through their template-argument space -----------------------------------------
+# k_resize_rows / k_resize_cols / k_resize_2d are instantiated per (tap count: 4, 6, run-time) x (format of the texture they read: 8-bit,
+# 10-bit, fp16) x (epilogue: surface store / final pass into either swap chain format); k_convert_420 per (planes, bytes, tail, output
+# format, destination).  The golden cases reach a third of them; this sweep walks the settings that select the rest — internal
+# format x filter x swap chain x dither x source layout — through the tiers that use those kernels (MPCVR_FLAG_NO_STRIP: block convert +
+# tiled two-draw kernel; MPCVR_FLAG_NO_FAST_CONVERT: folded per-pixel convert + folded row / column kernels), each against the oracle.
+def _sweep_cases():
+    out = []
+    k = 0
+    for cf, ex in ((2, "HDR10"), (1, "SDR"), (20, "SDR"), (3, "SDR")):              # P010 (PQ tail), NV12, YUV420P10, YV12
+        for itex in (8, 10, 16):
+            for (up, down, dst) in ((1, 2, (90, 66)), (4, 2, (90, 66)), (2, 2, (24, 18)), (2, 5, (30, 22))):   # Mitchell, Lanczos3, Hamming 2.7x, Lanczos 2.1x
+                for outfmt in (0, 1):
+                    for dither in (1, 0):
+                        k += 1
+                        if (k * 7 + cf) % 3 and cf != 2:                             # every combination for P010, a third for the others
+                            continue
+                        out.append((f"cf{cf}_tex{itex}_up{up}_down{down}_{dst[0]}x{dst[1]}_out{outfmt}_d{dither}",
+                                    dict(cformat=cf, w=64, h=48, kind="noise", seed=7000 + k, dst=dst, exfmt_name=ex, iTexFormat=itex, iUpscaling=up,
+                                         iDownscaling=down, output_format=outfmt, bUseDither=dither)))
+    return out
+
+
+SWEEP = _sweep_cases()
+
+
+@pytest.mark.parametrize("tier", ["FLAG_NO_STRIP", "FLAG_NO_FAST_CONVERT"])
+@pytest.mark.parametrize("label", [n for n, _ in SWEEP])
+def test_kernel_family_sweep_vs_oracle(mpcvr, oracle, torch_cuda, label, tier):
+    from videorenderer_amd import api
+    from tests.golden import cases as G
+    c = dict(dict(SWEEP)[label])
+    c["exfmt"] = G.HDR10 if c.pop("exfmt_name") == "HDR10" else G.ext(matrix=G.M709)
+    p = oracle_params(oracle, c)
+    frame, pitch = case_frame(c)
+    want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+    got, info = run_product(mpcvr, torch_cuda, c, extra_flags=getattr(api, tier))
+    if c["output_format"] == 1:
+        compare_rgb10(got, want, f"{label} [{info}]", tail=has_tail(c), internal8=internal_is_8bit(c))
+    else:
+        compare(got, want, f"{label} [{info}]", min_same=0.99)
+
+
 def _is_same_size(c):
     r = c.get("src_rect", (0, 0, c["w"], c["h"]))
     return c["dst"] == (r[2] - r[0], r[3] - r[1]) and not c.get("rotation", 0) and not c.get("hdr_tonemap", 0)

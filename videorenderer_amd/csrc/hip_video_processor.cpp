@@ -309,6 +309,7 @@ HRESULT CHipVideoProcessor::InitMediaType(int cformat, int width, int height, in
     SetShaderLuminanceParams();
     m_curSample = nullptr;
     m_planDirty = true;
+    m_texSrcZeroed = m_batchTexZeroed = false;      // another format / size: the RGB48 remainder texels must be cleared again
     return MPCVR_S_OK;
 }
 
@@ -692,6 +693,7 @@ HRESULT CHipVideoProcessor::UpdatePlan()
     // reverses the first draw's ROW map (m_otherX), which the surface variant reads row by row: a frame turned upside down goes
     // convert kernel -> m_TexConvertOutput -> k_fused_strip:surface.  90 / 270 turn the first draw into a Y shader and stay per draw
     m_strip = m_stripSurf = m_stripPlanned = false;
+    m_stripRan = -1;
     m_periodPlan.P = 0;
     static const bool no_strip_env = [] { const char *e = std::getenv("MPCVR_NO_STRIP"); return e && *e && *e != '0'; }();
     if (!no_strip_env && m_plan.two_pass && !m_firstJinc && !m_secondJinc && m_firstAxis == 0 && !m_firstSwap && (m_plan.rotation == 0 || m_plan.rotation == 180) &&
@@ -857,21 +859,24 @@ HRESULT CHipVideoProcessor::PrepareSample(const uint8_t *dev_sample, const uint8
         // DX11VideoProcessor.cpp:2563-2569)
         const size_t bytes = (size_t)m_srcPitch * m_srcLines;
         if ((hr = CheckHip(m_TexSrcVideo.CheckCreate(bytes), "m_TexSrcVideo"))) return hr;
+        m_texSrcZeroed = false;
         if ((hr = CheckHip(hipMemcpyAsync(m_TexSrcVideo.ptr, dev_sample, bytes, hipMemcpyDeviceToDevice, m_stream), "sample copy"))) return hr;
         *tex = (const uint8_t *)m_TexSrcVideo.ptr;
         return MPCVR_S_OK;
     }
     const int tp = TexPitch();
-    const bool fresh = m_TexSrcVideo.size < (size_t)tp * m_srcHeight || !m_TexSrcVideo.ptr;
+    const bool fresh = m_TexSrcVideo.size < (size_t)tp * m_srcHeight || !m_TexSrcVideo.ptr || !m_texSrcZeroed;
     if ((hr = CheckHip(m_TexSrcVideo.CheckCreate((size_t)tp * m_srcHeight), "m_TexSrcVideo"))) return hr;
     if (m_srcParams->layout == LAY_RGB) {
         // texels the reference's copy loop never writes (RGB48 remainder) stay zero
         if (fresh && (hr = CheckHip(hipMemsetAsync(m_TexSrcVideo.ptr, 0, (size_t)tp * m_srcHeight, m_stream), "clear texture"))) return hr;
+        m_texSrcZeroed = true;
         if ((hr = CheckHip(LaunchRepackRgb(m_srcParams->repack, dev_sample, m_srcBottomUp ? -m_srcPitch : m_srcPitch,
                                            (uint8_t *)m_TexSrcVideo.ptr, tp, m_srcWidth, m_srcHeight, m_stream), "k_repack_rgb"))) return hr;
         *tex = (const uint8_t *)m_TexSrcVideo.ptr;
         return MPCVR_S_OK;
     }
+    m_texSrcZeroed = false;
     if ((hr = CheckHip(LaunchRepackV210(dev_sample, m_srcPitch, (uint8_t *)m_TexSrcVideo.ptr, tp, m_srcHeight, m_stream), "k_repack_v210"))) return hr;
     *tex = (const uint8_t *)m_TexSrcVideo.ptr;
     return MPCVR_S_OK;
@@ -1091,6 +1096,7 @@ bool CHipVideoProcessor::FillStripParams(const uint8_t *sample, void *dst, int d
 {
     FillFusedParams(sample, dst, dstPitch, &sp->fp);
     sp->fp.store = store;
+    sp->ran_period = &m_stripRan;
     const int32_t *tab = (const int32_t *)m_stripTab.ptr;
     sp->yrange = tab + m_stripOff[0]; sp->xstrip = tab + m_stripOff[1];
     sp->xi_t = tab + m_stripOff[2]; sp->xw_t = tab + m_stripOff[3];
@@ -1110,6 +1116,7 @@ bool CHipVideoProcessor::FillStripSurfParams(const Surface &src, const StorePara
 {
     *sp = FusedStripParams{};
     sp->fp.store = store;
+    sp->ran_period = &m_stripRan;
     sp->fp.dst_aligned16 = (((uintptr_t)store.dst) & 15) == 0;      // (batches: the caller knows every target of the table and overrides it)
     const int32_t *tab = (const int32_t *)m_stripTab.ptr;
     sp->yrange = tab + m_stripOff[0]; sp->xstrip = tab + m_stripOff[1];
@@ -1211,6 +1218,7 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
     if (rtPitch < m_windowRect.Width() * 4) return Fail(MPCVR_E_INVALIDARG, "render-target pitch smaller than a row");
     (void)hipSetDevice(m_device);
     HRESULT hr;
+    m_startRecorded = false;
     if (m_planDirty && (hr = UpdatePlan())) return hr;
     (void)JoinFrameLanes(false);             // a batch runs on the context stream, behind every single frame still in flight
     for (int i = 0; i < n; i++)
@@ -1225,7 +1233,10 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
         if (texBytes * (size_t)n <= ((size_t)1 << 30)) {
             if ((hr = CheckHip(m_batchTex.CheckCreate(texBytes * n), "batch source texture"))) return hr;
             slots.resize(n);
+            (void)hipEventRecord(m_evStart, m_stream);      // the repack is part of the batch's process time, as on the other branches
+            m_startRecorded = true;
             if ((hr = CheckHip(LaunchRepackV210(nullptr, m_srcPitch, (uint8_t *)m_batchTex.ptr, tp, m_srcHeight, m_stream, srcs, n, texBytes), "k_repack_v210"))) return hr;
+            m_batchTexZeroed = false;                       // (the RGB batches' zeroed remainder columns are gone)
             for (int i = 0; i < n; i++) slots[i] = (uint8_t *)m_batchTex.ptr + (size_t)i * texBytes;
             srcs = slots.data();
             m_batchRepacked = true;
@@ -1258,7 +1269,7 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
         if (!BatchPlan((const uint8_t *)srcs[0], dsts[0], rtPitch, aligned, &conv, &direct)) return Fail(MPCVR_E_UNEXPECTED, "batch plan changed");
         FusedFrame tab[32];
         for (int i = 0; i < n; i++) tab[i] = FusedFrame{(const uint8_t *)srcs[i], dsts[i]};
-        (void)hipEventRecord(m_evStart, m_stream);
+        if (!m_startRecorded) (void)hipEventRecord(m_evStart, m_stream);
         hr = CheckHip(LaunchConvertBlocks(direct, nullptr, FusedFrame{nullptr, nullptr}, n, m_stream, 0, tab), "k_convert_blocks");
         (void)hipEventRecord(m_evStop, m_stream);
         m_timed = true;
@@ -1272,13 +1283,14 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
         const int tp = TexPitch();
         const size_t texBytes = (size_t)tp * m_srcHeight;
         const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)1 << 30) / std::max<size_t>(texBytes, 1)));
-        const bool fresh = m_batchTex.size < texBytes * chunk || !m_batchTex.ptr;
+        const bool fresh = m_batchTex.size < texBytes * chunk || !m_batchTex.ptr || !m_batchTexZeroed;     // (not by size alone: a v210 batch or another media type may have used it since)
         if ((hr = CheckHip(m_batchTex.CheckCreate(texBytes * chunk), "batch source texture"))) return hr;
         const Surface cs{m_batchTex.ptr, tp, m_srcWidth, m_srcHeight, RgbTexFmt(*m_srcParams)};
         FusedStripParams ssp{};
         if (FillStripSurfParams(cs, MakeStore(dsts[0], rtPitch, m_plan.swap_fmt, true), &ssp)) {
             // texels the reference's copy loop never writes (RGB48 remainder) stay zero, as in PrepareSample
             if (fresh && (hr = CheckHip(hipMemsetAsync(m_batchTex.ptr, 0, texBytes * chunk, m_stream), "clear batch texture"))) return hr;
+            m_batchTexZeroed = true;
             FrameSlot &slot = m_slots[m_slotNext];
             m_slotNext = (m_slotNext + 1) % kFrameSlots;
             if (!slot.done && (hr = CheckHip(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming), "slot event"))) return hr;
@@ -1299,7 +1311,7 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
                 if (((uintptr_t)dsts[i] & 7) != 0) aligned8 = false;
             ssp.surf_stride = texBytes;
             ssp.fp.dst_aligned16 = aligned8 ? 1 : 0;
-            (void)hipEventRecord(m_evStart, m_stream);
+            if (!m_startRecorded) (void)hipEventRecord(m_evStart, m_stream);
             for (int at = 0; at < n && !hr; at += chunk) {
                 const int m = std::min(chunk, n - at);
                 hr = CheckHip(LaunchRepackRgb(m_srcParams->repack, nullptr, m_srcBottomUp ? -m_srcPitch : m_srcPitch, (uint8_t *)m_batchTex.ptr, tp,
@@ -1326,7 +1338,7 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
         FusedStripParams sp{};
         if (FillStripParams((const uint8_t *)srcs[0], post.ptr, post.pitch, last, &sp)) {
             sp.fp.dst_aligned16 = 1;                         // the slots start on 256-byte boundaries
-            (void)hipEventRecord(m_evStart, m_stream);
+            if (!m_startRecorded) (void)hipEventRecord(m_evStart, m_stream);
             for (int at = 0; at < n; at += chunk) {
                 const int m = std::min(chunk, n - at);
                 const FusedFrame *drawTab = nullptr, *realTab = nullptr;
@@ -1355,7 +1367,7 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
         static const int want = [] { const char *e = std::getenv("MPCVR_BATCH_LANES"); return e ? std::atoi(e) : 1; }();
         const int lanes = (repack || n < 2 || want < 2) ? 1 : std::min(std::min(n, want), (int)kLanes);
         if (lanes > 1 && (hr = PrepareLanes(lanes))) return hr;
-        (void)hipEventRecord(m_evStart, m_stream);
+        if (!m_startRecorded) (void)hipEventRecord(m_evStart, m_stream);
         if (lanes > 1) {
             if ((hr = CheckHip(hipEventRecord(m_fork, m_stream), "fork"))) return hr;
             for (int l = 1; l < lanes; l++)
@@ -1397,7 +1409,7 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
     for (int i = 0; i < n; i++) { fr[i].src = (const uint8_t *)srcs[i]; fr[i].dst = dsts[i]; }
     if ((hr = CheckHip(hipMemcpyAsync(slot.dev.ptr, fr, sizeof(FusedFrame) * n, hipMemcpyHostToDevice, m_stream), "frame table"))) return hr;
     if (batchable) {
-        (void)hipEventRecord(m_evStart, m_stream);
+        if (!m_startRecorded) (void)hipEventRecord(m_evStart, m_stream);
         hr = ProcessBatchLaunches(n, (const FusedFrame *)slot.dev.ptr, (const uint8_t *)srcs[0], dsts[0], rtPitch, aligned);
         (void)hipEventRecord(m_evStop, m_stream);
         (void)hipEventRecord(slot.done, m_stream);
@@ -1410,7 +1422,7 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
         for (int i = 0; i < n; i++)
             if (((uintptr_t)dsts[i] & 7) != 0) aligned8 = false;
         strip_sp.fp.dst_aligned16 = aligned8 ? 1 : 0;
-        (void)hipEventRecord(m_evStart, m_stream);
+        if (!m_startRecorded) (void)hipEventRecord(m_evStart, m_stream);
         hr = CheckHip(LaunchFusedStrip(strip_sp, (const FusedFrame *)slot.dev.ptr, FusedFrame{nullptr, nullptr}, n, m_stream), "k_fused_strip");
         (void)hipEventRecord(m_evStop, m_stream);
         (void)hipEventRecord(slot.done, m_stream);
@@ -1421,7 +1433,7 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
     FusedParams fp{};
     FillFusedParams((const uint8_t *)srcs[0], nullptr, rtPitch, &fp);
     fp.dst_aligned16 = aligned ? 1 : 0;
-    (void)hipEventRecord(m_evStart, m_stream);
+    if (!m_startRecorded) (void)hipEventRecord(m_evStart, m_stream);
     hr = CheckHip(LaunchFusedUp2x(fp, (const FusedFrame *)slot.dev.ptr, FusedFrame{nullptr, nullptr}, n, m_stream), "k_fused_up2x");
     (void)hipEventRecord(m_evStop, m_stream);
     (void)hipEventRecord(slot.done, m_stream);
@@ -1819,7 +1831,7 @@ std::string CHipVideoProcessor::GetPathInfo()
     if (!m_srcParams) return "uninitialised";
     if (m_planDirty && UpdatePlan() != MPCVR_S_OK) return "error: " + m_lastError;
     if ((!m_strip && !m_stripSurf) || m_plan.fused_up2x) return m_plan.describe();
-    if ((m_strip || m_stripSurf) && m_period)
+    if ((m_strip || m_stripSurf) && (m_stripRan >= 0 ? m_stripRan == 1 : m_period))
         return m_plan.describe() + (m_strip ? ";kernel=fused_period(rows=" : ";kernel=fused_period:surface(rows=") + std::to_string(m_periodPlan.P) + ":" + std::to_string(m_periodPlan.Q) + ",taps=" + std::to_string(m_periodPlan.nt) + ",px_per_lane=2,strip=" + std::to_string(m_periodPlan.strip_w) + ",window=6 rows in registers)";
     return m_plan.describe() + (m_strip ? ";kernel=fused_strip(taps=" : ";kernel=fused_strip:surface(taps=") + std::to_string(m_stripPlan.nt) + ",px_per_lane=" + std::to_string(m_stripPlan.pxl) +
            ",strip=" + std::to_string(m_stripPlan.strip_w) + ",ring=" + std::to_string(m_stripPlan.ring) + ")";

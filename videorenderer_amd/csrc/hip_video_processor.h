@@ -245,6 +245,8 @@ private:
     // a frame table in a slot of the ring (pinned copy + device copy): frame i = {srcs ? srcs[i] : null, dsts ? dsts[i] : dst_base + i * dst_stride}
     HRESULT UploadFrameTable(int n, const void *const *srcs, void *const *dsts, uint8_t *dst_base, size_t dst_stride, const FusedFrame **dev, hipEvent_t *done);
     DevBuffer m_batchTex;          // interleaved RGB / v210 batches: the frames' m_TexSrcVideo copies side by side (ProcessBatch)
+    bool m_texSrcZeroed = false, m_batchTexZeroed = false;     // the texels the RGB copy loops never write have been cleared for the current media type
+    bool m_startRecorded = false;  // ProcessBatch: m_evStart already sits in front of a repack launch
     bool m_batchRepacked = false;  // the batch at hand reads v210 samples already repacked into m_batchTex
     bool m_batchSrc16 = false;     // every sample of the batch being planned starts on a 16-byte boundary
     // Jinc2m phase tables of the first / second draw (null: weights per pixel)
@@ -262,6 +264,8 @@ private:
     bool FillStripParams(const uint8_t *sample, void *dst, int dstPitch, const StoreParams &store, FusedStripParams *sp) const;
     // periodic-phase variant of the same launch (vp_fused_period.h): vertical ratio 4:3 / 3:2 / 2:3 / 1:2 / 3:1, tables behind the strip kernel's in m_stripTab
     PeriodPlan m_periodPlan;       // P == 0: not a periodic geometry
+    mutable int m_stripRan = -1;   // which kernel the last strip launch of this plan really ran (1 = k_fused_period, 0 = k_fused_strip, -1 = none yet): the plan-time
+                                   // probe uses a null, aligned target — a real target with an odd pitch or offset sends the launch to k_fused_strip (GetPathInfo reports what ran)
     size_t m_periodOff[4] = {0, 0, 0, 0};     // xi_t | xw_t | yw | xstrip
     bool m_period = false;         // the planned launch (window-sized target) takes the periodic kernel: what GetVPInfo reports
     bool BatchPlan(const uint8_t *sample0, void *rt0, int rtPitch, bool aligned, FusedParams *conv, FusedParams *direct) const;

@@ -122,8 +122,9 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
     } else FillFusedArgs(P, a);
     if (S.per_P) {       // a periodic vertical ratio: the register-window kernel when the launch meets its preconditions
         const hipError_t ep = LaunchFusedPeriod(S, a, frames_dev, single, n_frames, s);
-        if (ep != hipErrorNotSupported) return ep;
+        if (ep != hipErrorNotSupported) { if (S.ran_period) *S.ran_period = 1; return ep; }
     }
+    if (S.ran_period) *S.ran_period = 0;
     StripArgs q{};
     q.xi_t = (const int32_t *)S.xi_t; q.xw_t = (const float *)S.xw_t;
     q.yi = (const int32_t *)S.yi; q.yw = (const float *)S.yw;

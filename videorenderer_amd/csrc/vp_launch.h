@@ -110,6 +110,7 @@ struct FusedStripParams {
     // periodic-phase variant (vp_fused_period.h; per_P != 0): device copies of PlanFusedPeriod's tables.  LaunchFusedStrip takes it
     // whenever the launch meets its preconditions (fast epilogue, 8-byte aligned rows) and falls back to k_fused_strip otherwise.
     int per_P, per_Q, per_nt, per_acols, per_strip_w, per_own;
+    int *ran_period;           // host, may be null: LaunchFusedStrip notes which kernel it launched (1 = k_fused_period, 0 = k_fused_strip)
     int per_force;             // MPCVR_FLAG_FORCE_PERIOD: also where the planner would prefer k_fused_strip
     const void *per_xi_t, *per_xw_t, *per_yw, *per_xstrip;
 };
