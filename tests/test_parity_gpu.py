@@ -266,18 +266,18 @@ def _sweep_cases():
     4 / 6 / 8 / 16 taps x two-pass, one-axis and same-size geometries x both swap chain formats x dither x aligned / odd window offsets,
     thinned deterministically to a few hundred cases (every value of every dimension appears many times; P010 runs the full product of
     the dimensions the resize kernels are instantiated over)."""
-    fmts = ((2, "p010"), (1, "nv12"), (20, "yuv420p10"), (3, "yv12"), (4, "yuy2"), (30, "rgb32"))
+    fmts = ((2, "p010"), (1, "nv12"), (20, "yuv420p10"), (3, "yv12"), (4, "yuy2"), (30, "rgb32"), (32, "r210"))
     tails = ("HDR10", "SDR", "HLG", "BT2020SDR")
     geos = (("up_mitchell", dict(iUpscaling=1, dst=(90, 66))), ("up_lanczos3", dict(iUpscaling=4, dst=(90, 66))),
             ("down_hamming8", dict(iDownscaling=2, dst=(24, 18))), ("down_bicubic16", dict(iDownscaling=3, dst=(28, 20))),
             ("x_only", dict(iUpscaling=4, dst=(90, 48))), ("y_only", dict(iUpscaling=1, dst=(64, 66))), ("y_only_down", dict(iDownscaling=2, dst=(64, 18))),
-            ("same_size", dict(dst=(64, 48))))
+            ("same_size", dict(dst=(64, 48))), ("jinc_2x", dict(iUpscaling=5, dst=(128, 96))))
     tiers = ("DEFAULT", "FLAG_NO_LUT", "FLAG_NO_STRIP", "FLAG_NO_FAST_CONVERT", "NO_STRIP_NO_FAST_CONVERT")
     out = []
     k = 0
     for cf, fname in fmts:
         for tail in tails:
-            if cf in (1, 3, 4, 30) and tail != "SDR" and not (cf == 1 and tail == "HDR10"):      # 8-bit sources: SDR (and one 8-bit PQ stream)
+            if cf in (1, 3, 4, 30, 32) and tail != "SDR" and not (cf == 1 and tail == "HDR10"):      # 8-bit / RGB sources: SDR (and one 8-bit PQ stream)
                 continue
             for itex in (8, 10, 16):
                 for gname, g in geos:
@@ -287,6 +287,11 @@ def _sweep_cases():
                                 for tier in tiers:
                                     k += 1
                                     full = cf == 2 and tail == "HDR10" and off == (0, 0) and tier in ("FLAG_NO_STRIP", "NO_STRIP_NO_FAST_CONVERT")
+                                    # interleaved RGB feeds the resize kernels its own texture format whatever the internal format is: the
+                                    # (texture format, epilogue) pairs no YUV source produces
+                                    full = full or (cf in (30, 32) and off == (0, 0) and tier == "FLAG_NO_STRIP" and gname != "jinc_2x")
+                                    # the one-draw Jinc2m quad kernel: internal format x epilogue (integer final pass, straight store, generic)
+                                    full = full or (gname == "jinc_2x" and tier == "DEFAULT" and ((cf == 2 and tail == "HDR10") or (cf == 1 and tail == "SDR")))
                                     if not full and (k * 2654435761 >> 7) % 23:
                                         continue
                                     c = dict(cformat=cf, w=64, h=48, kind="noise", seed=7000 + k % 997, exfmt_name=tail, iTexFormat=itex, output_format=outfmt,
@@ -307,7 +312,7 @@ def test_kernel_family_sweep_vs_oracle(mpcvr, oracle, torch_cuda, label):
     c, tier = next((dict(c), t) for n, c, t in SWEEP if n == label)
     ex = c.pop("exfmt_name")
     c["exfmt"] = {"HDR10": G.HDR10, "HLG": G.HLG, "SDR": G.ext(matrix=G.M709), "BT2020SDR": G.ext(G.MPEG2, G.TV, G.M2020, G.P2020, G.T709)}[ex]
-    if c["cformat"] == 30:
+    if c["cformat"] in (30, 32):
         c["exfmt"] = 0
     flags = {"DEFAULT": 0, "NO_STRIP_NO_FAST_CONVERT": api.FLAG_NO_STRIP | api.FLAG_NO_FAST_CONVERT}.get(tier)
     if flags is None:
