@@ -13,6 +13,10 @@ model of Direct3D (hlsl_shim.h) and runs the whole Process() with it (ref_pipeli
     the quad's corner coordinates to fp32 first (FillVertices, DX11VideoProcessor.cpp:133-138: src_dx = 1.0f / texW; src_l =
     src_dx * rect.left ...).  With those three roundings restated (oracle axis_center, product TexCenter) every tap decision —
     the box filter's `x < 0.5` edge included — falls the way the shader text's does, at every size;
+  * "bit-identical" is UNDER THE MODELLED INTERPOLATOR: the shader text is the reference's, the rasteriser that hands it texture
+    coordinates is oracle/ref_hlsl/ref_draw.h's model (interpolation in double, one rounding to fp32) — the same model TexCenter and
+    axis_center restate.  Channels that hang on the last ulp of a coordinate (exact texel centres at 3:1, the box filter's x < 0.5 edge)
+    are decided by that model on both sides; real hardware's fixed-point interpolators are not claimed to agree there;
   * alpha is not compared: the reference leaves the shader's A there (not 1 after the float4-wide HLG / Dolby Vision tails) and the
     swap chain ignores it; the oracle and the product write opaque alpha.
 """
