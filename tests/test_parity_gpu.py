@@ -109,7 +109,7 @@ def _codes10(a):
     return np.stack([(u >> sh) & 1023 for sh in (0, 10, 20)], -1).astype(np.int16)
 
 
-def compare_behind_tail(oracle, p, frame, pitch, got, want, name, min_same=0.99, ten_bit=False, lim=1, dovi=False):
+def compare_behind_tail(oracle, p, frame, pitch, got, want, name, min_same=0.99, ten_bit=False, lim=1, dovi=False, cap=None):
     """Frames behind a PQ / HLG / Dolby Vision tail: |delta| <= 1 like everywhere else, EXCEPT on channels where the oracle's own
     answer is not defined to one code — shown per channel, not assumed: the oracle is run again with every pow() of the chain POW_ULPS
     ulps low, POW_ULPS ulps high, and eight times with each call off by its own hash-drawn amount within +-POW_ULPS
@@ -141,7 +141,8 @@ def compare_behind_tail(oracle, p, frame, pitch, got, want, name, min_same=0.99,
         assert worst.size == 0, (f"{name}: {len(worst)} of {n_bad} channels beyond {lim} code(s) are NOT explained by +-{POW_ULPS} ulp of pow(): "
                                  f"e.g. (y, x, ch) = {tuple(worst[0])}: got {g3[tuple(worst[0])]}, oracle {w3[tuple(worst[0])]}, interval [{lo[tuple(worst[0])] + lim}, {hi[tuple(worst[0])] - lim}]")
         mpx = d.size / 3 / 1e6
-        cap = int(np.ceil(ILL_CONDITIONED_PER_MPX_DOVI * mpx)) if dovi else KNOWN_ILL_CONDITIONED.get(name.split(" ")[0], 0)
+        if cap is None:
+            cap = int(np.ceil(ILL_CONDITIONED_PER_MPX_DOVI * mpx)) if dovi else KNOWN_ILL_CONDITIONED.get(name.split(" ")[0], 0)
         assert n_bad <= cap, (f"{name}: {n_bad} channels beyond {lim} code(s) (each inside the oracle's own +-{POW_ULPS} ulp interval) — more than "
                               f"the {cap} this kind of frame was measured with ({'Dolby Vision: 16 per M pixels' if dovi else 'named cases only'})")
     if os.environ.get("MPCVR_PARITY_LOG"):
@@ -332,11 +333,19 @@ def test_kernel_family_sweep_vs_oracle(mpcvr, oracle, torch_cuda, label):
     frame, pitch = case_frame(c)
     want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
     got, info = run_product(mpcvr, torch_cuda, c, extra_flags=flags)
-    if c["output_format"] == 1:
+    # noise frames of a few thousand pixels: with an 8-bit internal format one code of the texture is four ten-bit codes of the target,
+    # so the share of identical channels is held at 0.97 there (0.99 elsewhere); behind a PQ / HLG tail a channel beyond the bar needs
+    # its witness (compare_behind_tail: inside the oracle's own +-4 ulp pow() interval), at most two per frame
+    same_floor = 0.97 if internal_is_8bit(c) else 0.99
+    if has_tail(c):
+        ten = c["output_format"] == 1
+        compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]", min_same=same_floor, ten_bit=ten,
+                            lim=(5 if internal_is_8bit(c) else 2) if ten else 1, cap=2)
+    elif c["output_format"] == 1:
         # (Jinc2m: a one-code difference of the block convert in the 10-bit texture may come out as two ten-bit codes = half an 8-bit code)
-        compare_rgb10(got, want, f"{label} [{info}]", tail=has_tail(c) or c.get("iUpscaling") == 5, internal8=internal_is_8bit(c))
+        compare_rgb10(got, want, f"{label} [{info}]", tail=c.get("iUpscaling") == 5, internal8=internal_is_8bit(c), min_same=same_floor)
     else:
-        compare(got, want, f"{label} [{info}]", min_same=0.99)
+        compare(got, want, f"{label} [{info}]", min_same=same_floor)
 
 
 def _is_same_size(c):
