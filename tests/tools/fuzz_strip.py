@@ -16,6 +16,10 @@ from tests.test_parity_gpu import run_product, compare, compare_rgb10, internal_
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20260925)
 sdr = GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]
+# channels beyond the bar behind a PQ / HLG / Dolby Vision tail: each needs its witness (compare_behind_tail); uniform noise in Y, U, V is
+# mostly out-of-gamut saturated colour — the worst case for the cancelling 2020 -> 709 row — so the count allowed per frame is the
+# suite's Dolby Vision rate (16 per M pixels, twice what round 3 measured on its hardest frames), at least 3
+FUZZ_CAP = lambda img: max(3, int(np.ceil(16 * img.shape[0] * img.shape[1] / 1e6)))
 paths = collections.Counter(); worst = 0.0; refused = 0; outliers = 0; batches = 0; oracle_cases = 0
 for i in range(n):
     # every source layout: 4:2:0 weighted up, then planar / packed 4:2:2 and 4:4:4, gray, GBRP, one interleaved RGB
@@ -131,14 +135,14 @@ for i in range(n):
             from tests.test_parity_gpu import compare_behind_tail
             po = oracle_params(oracle, c)
             fr, pit = case_frame(c)
-            compare_behind_tail(oracle, po, fr, pit, plain, want, f"plain tier vs oracle (tail, 10-bit): {name}", min_same=0.97, ten_bit=True, lim=lim)
-            compare_behind_tail(oracle, po, fr, pit, got, want, f"default planner vs oracle (tail, 10-bit): {name}", min_same=0.97, ten_bit=True, lim=lim)
+            compare_behind_tail(oracle, po, fr, pit, plain, want, f"plain tier vs oracle (tail, 10-bit): {name}", min_same=0.97, ten_bit=True, lim=lim, cap=FUZZ_CAP(want))
+            compare_behind_tail(oracle, po, fr, pit, got, want, f"default planner vs oracle (tail, 10-bit): {name}", min_same=0.97, ten_bit=True, lim=lim, cap=FUZZ_CAP(want))
         else:                                       # 8-bit targets: <= 1 LSB, or the per-channel witness (the oracle's own +-4 ulp pow() interval)
             from tests.test_parity_gpu import compare_behind_tail
             po = oracle_params(oracle, c)
             fr, pit = case_frame(c)
-            compare_behind_tail(oracle, po, fr, pit, plain, want, f"plain tier vs oracle (tail): {name}", min_same=0.97)
-            compare_behind_tail(oracle, po, fr, pit, got, want, f"default planner vs oracle (tail): {name}", min_same=0.97)
+            compare_behind_tail(oracle, po, fr, pit, plain, want, f"plain tier vs oracle (tail): {name}", min_same=0.97, cap=FUZZ_CAP(want))
+            compare_behind_tail(oracle, po, fr, pit, got, want, f"default planner vs oracle (tail): {name}", min_same=0.97, cap=FUZZ_CAP(want))
     beyond = int((d > lim).sum()); same = float((d == 0).mean())
     worst = max(worst, 1.0 - same)
     if beyond:
