@@ -173,7 +173,6 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
     const int x_first = xq[0];
     const int x_end = min(xs + Q.strip_w, Q.out_w);                   // the strip's columns inside the frame
     const bool act[2] = {xq[0] < x_end, xq[1] < x_end};
-    const bool xy_active = act[0];
     typedef __attribute__((address_space(3))) const f2 *lds_f2;
     const uint32_t aw_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)Aw;
     uint32_t xo[2][NT]; f2 xwp[2][NP];
