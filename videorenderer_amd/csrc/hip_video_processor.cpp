@@ -1263,17 +1263,21 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
         FusedParams a{}, b{};
         batchable = BatchPlan((const uint8_t *)srcs[0], dsts[0], rtPitch, aligned, &a, &b);
     }
-    if (batchable && m_plan.direct_convert && n <= 32) {
-        // same-size frames, small batch: one block-convert launch with the frame table in its kernel arguments
+    if (batchable && m_plan.direct_convert && n <= kHostTableMax) {
+        // same-size frames: one convert launch with the frame table in its kernel arguments (32 frames for the block convert, 128 where the
+        // streaming kernel takes the launch — it answers hipErrorInvalidValue otherwise and the table is uploaded below)
         FusedParams conv{}, direct{};
         if (!BatchPlan((const uint8_t *)srcs[0], dsts[0], rtPitch, aligned, &conv, &direct)) return Fail(MPCVR_E_UNEXPECTED, "batch plan changed");
-        FusedFrame tab[32];
+        FusedFrame tab[kHostTableMax];
         for (int i = 0; i < n; i++) tab[i] = FusedFrame{(const uint8_t *)srcs[i], dsts[i]};
-        if (!m_startRecorded) (void)hipEventRecord(m_evStart, m_stream);
-        hr = CheckHip(LaunchConvertBlocks(direct, nullptr, FusedFrame{nullptr, nullptr}, n, m_stream, 0, tab), "k_convert_blocks");
-        (void)hipEventRecord(m_evStop, m_stream);
-        m_timed = true;
-        return hr;
+        if (!m_startRecorded) { (void)hipEventRecord(m_evStart, m_stream); m_startRecorded = true; }
+        const hipError_t e = LaunchConvertBlocks(direct, nullptr, FusedFrame{nullptr, nullptr}, n, m_stream, 0, tab);
+        if (e != hipErrorInvalidValue || n <= 32) {
+            hr = CheckHip(e, "k_convert_blocks");
+            (void)hipEventRecord(m_evStop, m_stream);
+            m_timed = true;
+            return hr;
+        }
     }
     // Interleaved RGB without a convert draw (m_PSConvColorData.bEnable false, :849-853): every frame is repacked into its own slot of a
     // batch texture (the reference's CopyFrame* upload: one repack launch per 32 frames, the sample pointers in its arguments) and ONE

@@ -193,7 +193,7 @@ struct StreamArgs {
 #endif
 #define MPCVR_STREAM_OCC __attribute__((amdgpu_waves_per_eu(MPCVR_STREAM_WAVES_PER_EU)))
 template <int TAIL, int SRC, bool FINAL>
-__global__ __launch_bounds__(512) MPCVR_STREAM_OCC void k_convert_stream(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single, StreamArgs Q, FrameTable32 tab)
+__global__ __launch_bounds__(512) MPCVR_STREAM_OCC void k_convert_stream(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single, StreamArgs Q, FrameTable128 tab)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *Di = (uint32_t *)smem;
@@ -564,7 +564,7 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
         tab.n = n_frames;
         for (int i = 0; i < n_frames; i++) tab.f[i] = frames_host[i];
         for (int i = n_frames; i < 32; i++) tab.f[i] = FusedFrame{nullptr, nullptr};
-    } else if (!frames_dev && n_frames != 1) return hipErrorInvalidValue;
+    } else if (!frames_dev && n_frames != 1 && !(frames_host && n_frames <= kHostTableMax)) return hipErrorInvalidValue;
     FusedArgs a;
     FillFusedArgs(P, a);
     const ConvertParams &c = P.conv;
@@ -577,8 +577,16 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
     const int lbs = srck == SRC_P01X ? 8 : 4;
     const bool stream = !no_stream && !catmull && dvk == DV_NONE && (srck == SRC_P01X || srck == SRC_NV12) && c.out_w >= 8 && (c.out_w & 3) == 0 && (c.rect_l & 3) == 0 &&
                         (c.pitch[0] % lbs) == 0 && (c.pitch[1] % lbs) == 0 && (P.plane_off[1] % lbs) == 0 && P.dst_aligned16 && (P.store.off_x & 3) == 0 &&
-                        (P.store.dst_pitch & 15) == 0 && P.src_aligned16 && (frames_dev || tab.n || n_frames == 1);
+                        (P.store.dst_pitch & 15) == 0 && P.src_aligned16 && (frames_dev || frames_host || n_frames == 1);
+    if (!stream && !frames_dev && n_frames != 1 && !tab.n) return hipErrorInvalidValue;     // (a host table of more than 32 frames serves the streaming kernel only)
     if (stream) {
+        FrameTable128 tab128;
+        tab128.n = 0;
+        if (frames_host && n_frames <= kHostTableMax) {
+            tab128.n = n_frames;
+            for (int i = 0; i < n_frames; i++) tab128.f[i] = frames_host[i];
+            for (int i = n_frames; i < kHostTableMax; i++) tab128.f[i] = FusedFrame{nullptr, nullptr};
+        }
         const bool tables = fin || tail_has_table(tailk);
         const size_t lds = (fin ? 4096 : 0) + (tail_has_table(tailk) ? LDS_T : 0);
         StreamArgs q{};
@@ -598,7 +606,7 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
             const int min_pairs = min_pairs_env > 0 ? min_pairs_env : 4;            // a wave's run: at least this many row pairs (a short launch spreads thinner, not shorter)
             q.n_slots = (int)std::max<long>(1, std::min<long>(n_waves / q.n_strips, std::max(1, q.total / min_pairs)));
             const dim3 grid((unsigned)(((long)q.n_slots * q.n_strips + wgw - 1) / wgw), 1, 1);
-            hipLaunchKernelGGL(kern, grid, block, lds, s, a, frames_dev, single, q, tab);
+            hipLaunchKernelGGL(kern, grid, block, lds, s, a, frames_dev, single, q, tab128);
             err = hipGetLastError();
         };
 #define MPCVR_ST3(TK, SK, FN) launch(k_convert_stream<TK, SK, FN>)

@@ -80,8 +80,12 @@ bool BlockConvertLayout(const FusedParams &P, bool catmull_420);       // source
 // the final pass into a B8G8R8A8 render target (store.mode == ST_FINAL).  out_w / out_h / wx / wy of P are not used.
 bool ConvertBlocksSupported(const FusedParams &P, bool to_rt);
 // batch_stride != 0: frame z is stored at P.store.dst + z * batch_stride (a batched intermediate) instead of frames[z].dst
-// frames_host != nullptr and n_frames <= 32: the frame table travels by value in the kernel arguments (frames_dev is not read)
+// frames_host != nullptr and n_frames <= 32 (<= kHostTableMax where the streaming kernel takes the launch; hipErrorInvalidValue otherwise: the
+// caller then uploads the table): the frame table travels by value in the kernel arguments (frames_dev is not read)
 struct FrameTable32 { FusedFrame f[32]; int n; };
+// k_convert_stream: up to 128 frames (a step of 1080p frames is 128 of them: no table upload in front of an 80-300 us launch)
+struct FrameTable128 { FusedFrame f[128]; int n; };
+enum { kHostTableMax = 128 };
 hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s,
                                size_t batch_stride = 0, const FusedFrame *frames_host = nullptr);
 // frames_dev == nullptr: n_frames must be 1 and `single` is used (no device-side table needed)
