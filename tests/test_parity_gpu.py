@@ -311,6 +311,33 @@ def _sweep_cases():
                                     if off != (0, 0):
                                         c.update(window=(c["dst"][0] + 8, c["dst"][1] + 4), offset=off)
                                     out.append((f"{fname}_{tail}_tex{itex}_{gname}_out{outfmt}_d{dither}_off{off[0]}_{tier}", c, tier))
+    # the strip kernel family in full: source loader x tail x tap count x epilogue (k_fused_strip<NT, PXL, TAIL, SRC, EPI>; PXL is the
+    # planner's choice, steered here by the ratio: a 1.7x interpolated downscale and the 16-tap filters run one pixel per lane)
+    strip_geos = (("s_up_mitchell", dict(iUpscaling=1, dst=(90, 66))), ("s_up_lanczos3fix", dict(iUpscaling=4, flags=1, dst=(90, 66))),
+                  ("s_down17_mitchell", dict(iUpscaling=1, bInterpolateAt50pct=1, dst=(38, 28))), ("s_down17_lanczos3fix", dict(iUpscaling=4, flags=1, bInterpolateAt50pct=1, dst=(38, 28))),
+                  ("s_down_hamming8", dict(iDownscaling=2, dst=(24, 18))), ("s_down_bicubic16", dict(iDownscaling=3, dst=(28, 20))))
+    epis = (("dither8", dict(iTexFormat=10, output_format=0, bUseDither=1)), ("direct", dict(iTexFormat=0, bUseDither=0)),
+            ("generic", dict(iTexFormat=10, output_format=0, bUseDither=1, offset=(3, 1))))
+    for cf, fname in fmts:
+        for tail in tails:
+            if cf in (30, 32) and tail != "SDR":
+                continue
+            for gname, g in strip_geos:
+                for ename, e in epis:
+                    for tier in ("DEFAULT", "FLAG_NO_LUT"):
+                        if tier == "FLAG_NO_LUT" and tail in ("SDR", "BT2020SDR"):
+                            continue
+                        k += 1
+                        c = dict(dict(cformat=cf, w=64, h=48, kind="noise", seed=9000 + k % 997, exfmt_name=tail, output_format=1 if (ename == "direct" and cf in (2, 20, 32)) else 0), **g)
+                        c.update(e)
+                        if ename == "direct" and cf in (2, 20, 32):
+                            c["output_format"] = 1           # a 10-bit source into a 10-bit swap chain: the straight R10G10B10A2 store
+                        if "offset" in c:
+                            c["window"] = (c["dst"][0] + 8, c["dst"][1] + 4)
+                        flags = c.pop("flags", 0)
+                        if flags:
+                            c["flags"] = flags
+                        out.append((f"strip_{fname}_{tail}_{gname}_{ename}_{tier}", c, tier))
     return out
 
 
