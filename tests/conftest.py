@@ -32,3 +32,27 @@ def mpcvr():
         build()
     api.load_library()
     return V
+
+
+@pytest.fixture(autouse=True)
+def _test_times(request):
+    """MPCVR_TEST_TIMES=<file>: one JSON line per test with its start / end on the clocks a rocprofv3 kernel trace may be stamped in —
+    tests/tools/kernel_witnesses.py joins the two into 'which test launched which kernel instantiation' (profiles/<round>/kernels_by_test.json)."""
+    path = os.environ.get("MPCVR_TEST_TIMES")
+    if not path:
+        yield
+        return
+    import json
+    import time
+    clocks = {"mono": time.CLOCK_MONOTONIC, "boot": getattr(time, "CLOCK_BOOTTIME", time.CLOCK_MONOTONIC), "real": time.CLOCK_REALTIME}
+    t0 = {k: time.clock_gettime_ns(v) for k, v in clocks.items()}
+    yield
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
+    t1 = {k: time.clock_gettime_ns(v) for k, v in clocks.items()}
+    with open(path, "a") as f:
+        f.write(json.dumps({"test": request.node.nodeid, "t0": t0, "t1": t1}) + "\n")

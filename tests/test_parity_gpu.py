@@ -267,7 +267,7 @@ def _sweep_cases():
     4 / 6 / 8 / 16 taps x two-pass, one-axis and same-size geometries x both swap chain formats x dither x aligned / odd window offsets,
     thinned deterministically to a few hundred cases (every value of every dimension appears many times; P010 runs the full product of
     the dimensions the resize kernels are instantiated over)."""
-    fmts = ((2, "p010"), (1, "nv12"), (20, "yuv420p10"), (3, "yv12"), (4, "yuy2"), (30, "rgb32"), (32, "r210"))
+    fmts = ((2, "p010"), (1, "nv12"), (20, "yuv420p10"), (14, "yv12"), (4, "yuy2"), (30, "rgb32"), (32, "r210"))
     tails = ("HDR10", "SDR", "HLG", "BT2020SDR")
     geos = (("up_mitchell", dict(iUpscaling=1, dst=(90, 66))), ("up_lanczos3", dict(iUpscaling=4, dst=(90, 66))),
             ("down_hamming8", dict(iDownscaling=2, dst=(24, 18))), ("down_bicubic16", dict(iDownscaling=3, dst=(28, 20))),
@@ -283,7 +283,7 @@ def _sweep_cases():
     k = 0
     for cf, fname in fmts:
         for tail in tails:
-            if cf in (1, 3, 4, 30, 32) and tail != "SDR" and not (cf == 1 and tail == "HDR10"):      # 8-bit / RGB sources: SDR (and one 8-bit PQ stream)
+            if cf in (1, 14, 4, 30, 32) and tail != "SDR" and not (cf == 1 and tail == "HDR10"):      # 8-bit / RGB sources: SDR (and one 8-bit PQ stream)
                 continue
             for itex in (8, 10, 16):
                 for gname, g in geos:
@@ -317,7 +317,9 @@ def _sweep_cases():
                   ("s_down17_mitchell", dict(iUpscaling=1, bInterpolateAt50pct=1, dst=(38, 28))), ("s_down17_lanczos3fix", dict(iUpscaling=4, flags=1, bInterpolateAt50pct=1, dst=(38, 28))),
                   ("s_down_hamming8", dict(iDownscaling=2, dst=(24, 18))), ("s_down_bicubic16", dict(iDownscaling=3, dst=(28, 20))))
     epis = (("dither8", dict(iTexFormat=10, output_format=0, bUseDither=1)), ("direct", dict(iTexFormat=0, bUseDither=0)),
-            ("generic", dict(iTexFormat=10, output_format=0, bUseDither=1, offset=(3, 1))))
+            ("generic", dict(iTexFormat=10, output_format=0, bUseDither=1, offset=(3, 1))),
+            # a video rectangle the window clips on every side: the per-pixel store_epilogue variant of every loader x tail x tap count
+            ("clipped", dict(iTexFormat=10, output_format=0, bUseDither=1, clip=1)))
     for cf, fname in fmts:
         for tail in tails:
             if cf in (30, 32) and tail != "SDR":
@@ -332,12 +334,78 @@ def _sweep_cases():
                         c.update(e)
                         if ename == "direct" and cf in (2, 20, 32):
                             c["output_format"] = 1           # a 10-bit source into a 10-bit swap chain: the straight R10G10B10A2 store
-                        if "offset" in c:
+                        if c.pop("clip", 0):
+                            c.update(window=(c["dst"][0] - 10, c["dst"][1] - 6), offset=(-4, -2))
+                        elif "offset" in c:
                             c["window"] = (c["dst"][0] + 8, c["dst"][1] + 4)
                         flags = c.pop("flags", 0)
                         if flags:
                             c["flags"] = flags
                         out.append((f"strip_{fname}_{tail}_{gname}_{ename}_{tier}", c, tier))
+    # the convert kernels in full.  Same-size frames, bi-planar ones 66 columns wide (not a multiple of 4: the streaming kernel declines, the
+    # 2x2-block kernel k_convert_blocks<TAIL, SRC, FINAL, DV, CHR> runs; three planes need 4-byte aligned chroma rows: 72): loader (P010 with centred chroma = the run-time variant) x tail x
+    # bilinear / Catmull-Rom chroma x with / without the final pass; Dolby Vision: the three variants x both loaders x final pass
+    conv_fmts = ((2, "p010", {}), (1, "nv12", {}), (20, "yuv420p10", dict(w=72, dst=(72, 48))), (14, "yv12", dict(w=72, dst=(72, 48))), (2, "p010centred", dict(chroma_loc=1)))
+    for cf, fname, extra in conv_fmts:
+        for tail in tails:
+            if cf in (1, 14) and tail != "SDR" and not (cf == 1 and tail == "HDR10"):
+                continue
+            for chroma in (1, 2):
+                for fin in (1, 0):
+                    k += 1
+                    c = dict(dict(cformat=cf, w=66, h=48, kind="noise", seed=11000 + k % 997, exfmt_name=tail, dst=(66, 48), iChromaScaling=chroma,
+                                  iTexFormat=10 if fin else 0, output_format=0 if fin or cf in (1, 14) else 1, bUseDither=fin), **extra)
+                    out.append((f"blocks_{fname}_{tail}_chroma{chroma}_final{fin}_DEFAULT", c, "DEFAULT"))
+    dv_kinds = (("sdr", dict(dovi=dict(kind="poly"))), ("sdr_l2", dict(dovi=dict(kind="mixed", l2=(100, 600, 1000)), hdr_display=400.0)),
+                ("hlg_tagged", dict(dovi=dict(kind="identity"), exfmt_name="HLG")), ("hdr_out", dict(dovi=dict(kind="mmr"), hdr_output=1)),
+                ("no_sdr_convert", dict(dovi=dict(kind="poly"), bConvertToSdr=0)))
+    for cf, fname in ((2, "p010"), (20, "yuv420p10")):
+        for dname, dv in dv_kinds:
+            for fin in (1, 0):
+                k += 1
+                ho = dv.get("hdr_output", 0)
+                wd = 66 if cf == 2 else 72
+                c = dict(dict(cformat=cf, w=wd, h=48, kind="hdr", seed=12000 + k % 997, exfmt_name="TVONLY", dst=(wd, 48), iTexFormat=(16 if ho else 10) if fin else 0,
+                              output_format=1 if ho else (0 if fin else 1), bUseDither=fin), **dv)
+                out.append((f"blocks_dovi_{fname}_{dname}_final{fin}_DEFAULT", c, "DEFAULT"))
+    # the folded per-pixel convert k_convert_420<PLANES, BYTES, TAIL, OFMT, DMODE, DFMT, DV> (MPCVR_FLAG_NO_FAST_CONVERT): loader x tail x
+    # internal format x {a resize behind it, the final pass folded in, a straight copy folded in}
+    folded = (("resize", dict(iUpscaling=1, dst=(90, 66))), ("final8", dict(dst=(64, 48), output_format=0, bUseDither=1)),
+              ("copy8", dict(dst=(64, 48), output_format=0, bUseDither=0)), ("out10", dict(dst=(64, 48), output_format=1, bUseDither=1)))
+    for cf, fname in fmts[:4]:
+        for tail in tails:
+            if cf in (1, 14) and tail != "SDR":
+                continue
+            for itex in (8, 10, 16):
+                for gname, g in folded:
+                    k += 1
+                    c = dict(dict(cformat=cf, w=64, h=48, kind="noise", seed=13000 + k % 997, exfmt_name=tail, iTexFormat=itex, output_format=0, bUseDither=1), **g)
+                    out.append((f"folded_{fname}_{tail}_tex{itex}_{gname}_NO_STRIP_NO_FAST_CONVERT", c, "NO_STRIP_NO_FAST_CONVERT"))
+    for cf, fname in ((2, "p010"), (20, "yuv420p10")):
+        for dname, dv in (dv_kinds[0], dv_kinds[3], dv_kinds[4]):
+            for itex in (8, 10, 16):
+                for gname, g in folded:
+                    if dv.get("hdr_output") and g.get("output_format", 0) == 0 and gname != "resize":
+                        continue                # (an HDR passthrough goes to a 10-bit swap chain)
+                    k += 1
+                    c = dict(dict(cformat=cf, w=64, h=48, kind="hdr", seed=14000 + k % 997, exfmt_name="TVONLY", iTexFormat=itex, output_format=0, bUseDither=1), **g)
+                    c.update(dv)
+                    if dv.get("hdr_output"):
+                        c["output_format"] = 1
+                    out.append((f"folded_dovi_{fname}_{dname}_tex{itex}_{gname}_NO_STRIP_NO_FAST_CONVERT", c, "NO_STRIP_NO_FAST_CONVERT"))
+    # the folded column kernel as the FIRST of two draws (it fills m_TexResize) from every texture format: 32 output rows of a 6x downscale
+    # along Y read more source rows than the tiled two-draw kernel keeps (kResizeTileRowsMax); and the one-draw Jinc2m from an 8-bit RGB texture into a 10-bit post-scale one
+    for gname, g in (("x_up_mitchell_y_down6", dict(h=192, iUpscaling=1, iDownscaling=2, dst=(90, 32))), ("x_up_lanczos3_y_down6", dict(h=192, iUpscaling=4, iDownscaling=2, dst=(90, 32))),
+                     ("x_down2p5_y_down6", dict(w=500, h=192, iDownscaling=2, dst=(200, 32)))):
+        for cf, fname, tail in ((2, "p010", "HDR10"), (30, "rgb32", "SDR")):
+            for itex in (8, 10, 16):
+                k += 1
+                c = dict(dict(cformat=cf, w=64, h=48, kind="noise", seed=15000 + k % 997, exfmt_name=tail, iTexFormat=itex, output_format=0, bUseDither=1), **g)
+                out.append((f"cols_{fname}_{tail}_tex{itex}_{gname}_FLAG_NO_STRIP", c, "FLAG_NO_STRIP"))
+    for cf, fname in ((30, "rgb32"), (32, "r210")):
+        k += 1
+        out.append((f"jinc_{fname}_tex10_final_DEFAULT", dict(cformat=cf, w=64, h=48, kind="noise", seed=16000 + k, exfmt_name="SDR", iTexFormat=10, output_format=0,
+                                                          bUseDither=1, iUpscaling=5, dst=(128, 96)), "DEFAULT"))
     return out
 
 
@@ -350,7 +418,10 @@ def test_kernel_family_sweep_vs_oracle(mpcvr, oracle, torch_cuda, label):
     from tests.golden import cases as G
     c, tier = next((dict(c), t) for n, c, t in SWEEP if n == label)
     ex = c.pop("exfmt_name")
-    c["exfmt"] = {"HDR10": G.HDR10, "HLG": G.HLG, "SDR": G.ext(matrix=G.M709), "BT2020SDR": G.ext(G.MPEG2, G.TV, G.M2020, G.P2020, G.T709)}[ex]
+    c["exfmt"] = {"HDR10": G.HDR10, "HLG": G.HLG, "SDR": G.ext(matrix=G.M709), "BT2020SDR": G.ext(G.MPEG2, G.TV, G.M2020, G.P2020, G.T709),
+                  "TVONLY": G.ext(G.MPEG2, G.TV)}[ex]
+    if "chroma_loc" in c:           # (the chroma siting field of DXVA2_ExtendedFormat: bits 8..11)
+        c["exfmt"] = (c["exfmt"] & ~(0xf << 8)) | (c.pop("chroma_loc") << 8)
     if c["cformat"] in (30, 32):
         c["exfmt"] = 0
     flags = {"DEFAULT": 0, "NO_STRIP_NO_FAST_CONVERT": api.FLAG_NO_STRIP | api.FLAG_NO_FAST_CONVERT}.get(tier)

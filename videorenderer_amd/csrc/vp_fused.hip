@@ -493,6 +493,9 @@ int FusedSourceKind(const FusedParams &P)
     // everything else (planar, MPEG-1 siting) runs through the variant that reads these properties at run time
     const ConvertParams &c = P.conv;
     const bool centred = c.fmt.subsampling == 420 && c.chroma_loc == CLOC_MPEG1 && c.chroma_scaling != 0;
+    // 8-bit samples behind a PQ / HLG / BT.2020 tail (streams that hardly exist) read through the run-time variant as well: the
+    // (8-bit loader, tail) products of every fused family are not built
+    if (c.fmt.bytes == 1 && c.tail != TAIL_NONE) return SRC_GENERIC;
     const bool biplanar_fast = c.fmt.planes == 2 && !centred, planar_fast = c.fmt.planes == 3 && !centred;
     return (biplanar_fast && c.fmt.bytes == 2) ? SRC_P01X : (biplanar_fast && c.fmt.bytes == 1) ? SRC_NV12
          : (planar_fast && c.fmt.bytes == 2) ? SRC_PLANAR16 : (planar_fast && c.fmt.bytes == 1) ? SRC_PLANAR8 : SRC_GENERIC;
@@ -611,12 +614,12 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
         };
 #define MPCVR_ST3(TK, SK, FN) launch(k_convert_stream<TK, SK, FN>)
 #define MPCVR_ST2(TK, SK) do { if (fin) MPCVR_ST3(TK, SK, true); else MPCVR_ST3(TK, SK, false); } while (0)
-#define MPCVR_ST(TK) do { if (srck == SRC_P01X) MPCVR_ST2(TK, SRC_P01X); else MPCVR_ST2(TK, SRC_NV12); } while (0)
-        if (tailk == TAILK_NONE) MPCVR_ST(TAILK_NONE);
-        else if (tailk == TAILK_PQ_LUT) MPCVR_ST(TAILK_PQ_LUT);
-        else if (tailk == TAILK_HLG) MPCVR_ST(TAILK_HLG);
-        else MPCVR_ST(TAILK_ALU);
-#undef MPCVR_ST
+        // (NV12 reaches this point without a tail only — FusedSourceKind — so the tails exist for the 16-bit loader)
+        if (srck == SRC_NV12) MPCVR_ST2(TAILK_NONE, SRC_NV12);
+        else if (tailk == TAILK_NONE) MPCVR_ST2(TAILK_NONE, SRC_P01X);
+        else if (tailk == TAILK_PQ_LUT) MPCVR_ST2(TAILK_PQ_LUT, SRC_P01X);
+        else if (tailk == TAILK_HLG) MPCVR_ST2(TAILK_HLG, SRC_P01X);
+        else MPCVR_ST2(TAILK_ALU, SRC_P01X);
 #undef MPCVR_ST2
 #undef MPCVR_ST3
         return err;
@@ -647,9 +650,10 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
 #define MPCVR_CB3(TK, SK, FN) do { if (catmull) hipLaunchKernelGGL((k_convert_blocks<TK, SK, FN, DV_NONE, 1>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab); \
                                    else hipLaunchKernelGGL((k_convert_blocks<TK, SK, FN>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab); } while (0)
 #define MPCVR_CB2(TK, SK) do { if (fin) MPCVR_CB3(TK, SK, true); else MPCVR_CB3(TK, SK, false); } while (0)
-#define MPCVR_CB(TK) do { if (srck == SRC_P01X) MPCVR_CB2(TK, SRC_P01X); else if (srck == SRC_NV12) MPCVR_CB2(TK, SRC_NV12); \
-                          else if (srck == SRC_PLANAR16) MPCVR_CB2(TK, SRC_PLANAR16); else if (srck == SRC_PLANAR8) MPCVR_CB2(TK, SRC_PLANAR8); else MPCVR_CB2(TK, SRC_GENERIC); } while (0)
-    if (tailk == TAILK_NONE) MPCVR_CB(TAILK_NONE);
+#define MPCVR_CB(TK) do { if (srck == SRC_P01X) MPCVR_CB2(TK, SRC_P01X); else if (srck == SRC_PLANAR16) MPCVR_CB2(TK, SRC_PLANAR16); else MPCVR_CB2(TK, SRC_GENERIC); } while (0)
+    if (tailk == TAILK_NONE) {          // (the 8-bit loaders exist without a tail only: FusedSourceKind)
+        if (srck == SRC_NV12) MPCVR_CB2(TAILK_NONE, SRC_NV12); else if (srck == SRC_PLANAR8) MPCVR_CB2(TAILK_NONE, SRC_PLANAR8); else MPCVR_CB(TAILK_NONE);
+    }
     else if (tailk == TAILK_PQ_LUT) MPCVR_CB(TAILK_PQ_LUT);
     else if (tailk == TAILK_HLG) MPCVR_CB(TAILK_HLG);
     else MPCVR_CB(TAILK_ALU);

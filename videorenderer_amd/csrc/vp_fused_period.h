@@ -454,10 +454,11 @@ hipError_t LaunchFusedPeriodPQ(const FusedArgs &a, const PeriodArgs &q, int nt, 
 #define MPCVR_PD3(NT, TK) do { \
         if (srck == SRC_P01X && epik == EPI_DITHER8) MPCVR_PD5(NT, TK, SRC_P01X, EPI_DITHER8); \
         else if (srck == SRC_P01X) MPCVR_PD5(NT, TK, SRC_P01X, EPI_DIRECT8); \
-        else if (srck == SRC_NV12 && epik == EPI_DIRECT8) MPCVR_PD5(NT, TK, SRC_NV12, EPI_DIRECT8); \
         else if (epik == EPI_DITHER8) MPCVR_PD5(NT, TK, SRC_GENERIC, EPI_DITHER8); \
         else MPCVR_PD5(NT, TK, SRC_GENERIC, EPI_DIRECT8); } while (0)
-#define MPCVR_PD2(NT) do { if (tailk == TAILK_NONE) MPCVR_PD3(NT, TAILK_NONE); else if (tailk == TAILK_PQ_LUT) MPCVR_PD3(NT, TAILK_PQ_LUT); \
+    // (the NV12 loader exists without a tail only: FusedSourceKind)
+#define MPCVR_PD2(NT) do { if (tailk == TAILK_NONE && srck == SRC_NV12 && epik == EPI_DIRECT8) MPCVR_PD5(NT, TAILK_NONE, SRC_NV12, EPI_DIRECT8); \
+                           else if (tailk == TAILK_NONE) MPCVR_PD3(NT, TAILK_NONE); else if (tailk == TAILK_PQ_LUT) MPCVR_PD3(NT, TAILK_PQ_LUT); \
                            else if (tailk == TAILK_HLG) MPCVR_PD3(NT, TAILK_HLG); else return hipErrorNotSupported; } while (0)
     if (srck == SRC_SURFACE) {      // the convert output of another kernel: no tail, both epilogues
 #define MPCVR_PDS(NT) do { if (epik == EPI_DITHER8) MPCVR_PD5(NT, TAILK_NONE, SRC_SURFACE, EPI_DITHER8); else MPCVR_PD5(NT, TAILK_NONE, SRC_SURFACE, EPI_DIRECT8); } while (0)

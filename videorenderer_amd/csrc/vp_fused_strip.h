@@ -429,7 +429,9 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
 enum { STRIP_EPI_FAST = 0, STRIP_EPI_DIRECT = 1, STRIP_EPI_GENERIC = 2 };
 
 // per-tap-count launcher, instantiated by vp_fused_strip_nt*.hip: every (pixels per lane, tail, source, epilogue) combination the planner
-// can pick for NT taps.  NT = 16 (9..16-tap downscales: ps_convolution beyond ~2x with bicubic / Lanczos) exists with one pixel per lane only.
+// can pick for NT taps: two pixels per lane up to 8 taps, one for NT = 16 (9..16-tap downscales: ps_convolution beyond ~2x with bicubic /
+// Lanczos).  PlanFusedStrip's cost model never chose a one-pixel strip below 9 taps (its X / Y stages cost the same per lane and the
+// convert pass is shared by half as many outputs), so those 189 kernels are not built; a plan that asks for one is refused, not skipped.
 template <int NT>
 hipError_t LaunchFusedStripNT(const FusedArgs &a, const StripArgs &q, const StoreParams &st, int pxl, int tailk, int srck, int epi, bool surface_mode,
                               dim3 grid, dim3 block, size_t lds, const FusedFrame *frames_dev, FusedFrame single, hipStream_t s)
@@ -443,15 +445,21 @@ hipError_t LaunchFusedStripNT(const FusedArgs &a, const StripArgs &q, const Stor
         hipLaunchKernelGGL(kern, grid, block, lds, s, a, q, st, frames_dev, single); } while (0)
 #define MPCVR_ST4(PX, TK, SK) do { if (epi == STRIP_EPI_FAST) MPCVR_ST5(PX, TK, SK, EPI_DITHER8); else if (epi == STRIP_EPI_DIRECT) MPCVR_ST5(PX, TK, SK, EPI_DIRECT8); \
                                    else MPCVR_ST5(PX, TK, SK, EPI_GENERIC); } while (0)
-#define MPCVR_ST3(PX, TK) do { if (srck == SRC_P01X) MPCVR_ST4(PX, TK, SRC_P01X); else if (srck == SRC_NV12) MPCVR_ST4(PX, TK, SRC_NV12); \
-                               else if (srck == SRC_PLANAR16) MPCVR_ST4(PX, TK, SRC_PLANAR16); else if (srck == SRC_PLANAR8) MPCVR_ST4(PX, TK, SRC_PLANAR8); \
+#define MPCVR_ST3(PX, TK) do { if (srck == SRC_P01X) MPCVR_ST4(PX, TK, SRC_P01X); else if (srck == SRC_PLANAR16) MPCVR_ST4(PX, TK, SRC_PLANAR16); \
                                else MPCVR_ST4(PX, TK, SRC_GENERIC); } while (0)
+    // (the 8-bit loaders exist without a tail only: FusedSourceKind)
 #define MPCVR_ST2(PX) do { if (surface_mode) MPCVR_ST4(PX, TAILK_NONE, SRC_SURFACE); \
+                           else if (tailk == TAILK_NONE && srck == SRC_NV12) MPCVR_ST4(PX, TAILK_NONE, SRC_NV12); \
+                           else if (tailk == TAILK_NONE && srck == SRC_PLANAR8) MPCVR_ST4(PX, TAILK_NONE, SRC_PLANAR8); \
                            else if (tailk == TAILK_NONE) MPCVR_ST3(PX, TAILK_NONE); else if (tailk == TAILK_PQ_LUT) MPCVR_ST3(PX, TAILK_PQ_LUT); \
                            else if (tailk == TAILK_HLG) MPCVR_ST3(PX, TAILK_HLG); else MPCVR_ST3(PX, TAILK_ALU); } while (0)
-    if constexpr (NT <= 8) { if (pxl == 2) { MPCVR_ST2(2); return hipGetLastError(); } }
-    if (pxl != 1) return hipErrorNotSupported;
-    MPCVR_ST2(1);
+    if constexpr (NT <= 8) {
+        if (pxl != 2) return hipErrorNotSupported;
+        MPCVR_ST2(2);
+    } else {
+        if (pxl != 1) return hipErrorNotSupported;
+        MPCVR_ST2(1);
+    }
 #undef MPCVR_ST2
 #undef MPCVR_ST3
 #undef MPCVR_ST4

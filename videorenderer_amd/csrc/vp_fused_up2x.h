@@ -325,14 +325,17 @@ hipError_t LaunchFusedUp2xNT(const FusedParams &P, const FusedArgs &a_in, int st
         if (srck == SRC_P01X && epik == EPI_DITHER8) MPCVR_LAUNCH3(NT, TK, SRC_P01X, EPI_DITHER8); \
         else if (srck == SRC_P01X && epik == EPI_DIRECT8) MPCVR_LAUNCH3(NT, TK, SRC_P01X, EPI_DIRECT8); \
         else if (srck == SRC_P01X) MPCVR_LAUNCH3(NT, TK, SRC_P01X, EPI_GENERIC); \
-        else if (srck == SRC_NV12 && epik == EPI_DIRECT8) MPCVR_LAUNCH3(NT, TK, SRC_NV12, EPI_DIRECT8); \
-        else if (srck == SRC_NV12) MPCVR_LAUNCH3(NT, TK, SRC_NV12, EPI_GENERIC); \
         else if (srck == SRC_PLANAR16 && epik == EPI_DITHER8) MPCVR_LAUNCH3(NT, TK, SRC_PLANAR16, EPI_DITHER8); \
-        else if (srck == SRC_PLANAR8 && epik == EPI_DIRECT8) MPCVR_LAUNCH3(NT, TK, SRC_PLANAR8, EPI_DIRECT8); \
         else if (epik == EPI_DITHER8) MPCVR_LAUNCH3(NT, TK, SRC_GENERIC, EPI_DITHER8); \
         else MPCVR_LAUNCH3(NT, TK, SRC_GENERIC, EPI_GENERIC); } while (0)
+    // the 8-bit loaders exist without a tail only (FusedSourceKind sends 8-bit samples behind a tail through the run-time variant)
+#define MPCVR_LAUNCH_8(NT) do { \
+        if (srck == SRC_NV12 && epik == EPI_DIRECT8) MPCVR_LAUNCH3(NT, TAILK_NONE, SRC_NV12, EPI_DIRECT8); \
+        else if (srck == SRC_NV12) MPCVR_LAUNCH3(NT, TAILK_NONE, SRC_NV12, EPI_GENERIC); \
+        else if (srck == SRC_PLANAR8 && epik == EPI_DIRECT8) MPCVR_LAUNCH3(NT, TAILK_NONE, SRC_PLANAR8, EPI_DIRECT8); \
+        else MPCVR_LAUNCH(NT, TAILK_NONE); } while (0)
 #define MPCVR_LAUNCH_NT(NT) \
-    do { if (tailk == TAILK_NONE) MPCVR_LAUNCH(NT, TAILK_NONE); else if (tailk == TAILK_PQ_LUT) MPCVR_LAUNCH(NT, TAILK_PQ_LUT); \
+    do { if (tailk == TAILK_NONE) MPCVR_LAUNCH_8(NT); else if (tailk == TAILK_PQ_LUT) MPCVR_LAUNCH(NT, TAILK_PQ_LUT); \
          else if (tailk == TAILK_HLG) MPCVR_LAUNCH(NT, TAILK_HLG); else MPCVR_LAUNCH(NT, TAILK_ALU); } while (0)
 #ifdef MPCVR_UP2X_HEADLINE_ONLY
     MPCVR_LAUNCH3(NT, TAILK_PQ_LUT, SRC_P01X, EPI_DITHER8);
@@ -340,6 +343,7 @@ hipError_t LaunchFusedUp2xNT(const FusedParams &P, const FusedArgs &a_in, int st
     MPCVR_LAUNCH_NT(NT);
 #endif
 #undef MPCVR_LAUNCH_NT
+#undef MPCVR_LAUNCH_8
 #undef MPCVR_LAUNCH
 #undef MPCVR_LAUNCH3
     return hipGetLastError();

@@ -164,7 +164,11 @@ hipError_t LaunchJinc2Quad(const Surface &in, const DrawCoords &dc, int out_w, i
                          else hipLaunchKernelGGL((k_jinc2_quad<F, 0>), grid, block, 0, s, in, dc, tab, out_w, out_h, st, e, bt); } while (0)
     if (in.fmt == SF_BGRA8) MPCVR_JQ(SF_BGRA8);
     else if (in.fmt == SF_RGB10A2) MPCVR_JQ(SF_RGB10A2);
-    else MPCVR_JQ(SF_RGBA16F);
+    else {      // an fp16 texture is the fp16 internal format's convert output (no source arrives as fp16): its final pass is never the 10 -> 8 one
+        if (epi == 1) return hipErrorNotSupported;
+        if (epi == 2) hipLaunchKernelGGL((k_jinc2_quad<SF_RGBA16F, 2>), grid, block, 0, s, in, dc, tab, out_w, out_h, st, e, bt);
+        else hipLaunchKernelGGL((k_jinc2_quad<SF_RGBA16F, 0>), grid, block, 0, s, in, dc, tab, out_w, out_h, st, e, bt);
+    }
 #undef MPCVR_JQ
     return hipGetLastError();
 }

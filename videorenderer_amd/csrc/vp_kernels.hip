@@ -820,8 +820,9 @@ static void LaunchConvert420T(const ConvertParams &P, const Surface &out, const 
 #undef MPCVR_C420_DV
         return;
     }
-    if (P.fmt.planes == 2) { if (P.fmt.bytes == 1) { MPCVR_C420_T(2, 1) } else { MPCVR_C420_T(2, 2) } }
-    else                   { if (P.fmt.bytes == 1) { MPCVR_C420_T(3, 1) } else { MPCVR_C420_T(3, 2) } }
+    // (8-bit samples: without a tail only — Convert420Eligible)
+    if (P.fmt.planes == 2) { if (P.fmt.bytes == 1) MPCVR_C420(2, 1, TAIL_NONE); else { MPCVR_C420_T(2, 2) } }
+    else                   { if (P.fmt.bytes == 1) MPCVR_C420(3, 1, TAIL_NONE); else { MPCVR_C420_T(3, 2) } }
 #undef MPCVR_C420_T
 #undef MPCVR_C420
 }
@@ -830,7 +831,7 @@ static bool Convert420Eligible(const ConvertParams &P)
 {
     return P.fmt.layout == LAY_PLANAR && P.fmt.subsampling == 420 && P.fmt.div_w == 2 && P.fmt.div_h == 2 && P.chroma_scaling == 1 &&
            !P.blend_deint && (P.fmt.planes == 2 || P.fmt.planes == 3) && (P.fmt.bytes == 1 || P.fmt.bytes == 2) &&
-           P.tail >= TAIL_NONE && P.tail <= TAIL_GAMMA_GAMUT &&
+           P.tail >= TAIL_NONE && P.tail <= TAIL_GAMMA_GAMUT && (P.fmt.bytes == 2 || P.tail == TAIL_NONE) &&    // (8-bit PQ / HLG / BT.2020: the generic kernel)
            (!P.dovi || (P.fmt.bytes == 2 && (P.tail == TAIL_NONE || P.tail == TAIL_PQ_TO_SDR)));
 }
 

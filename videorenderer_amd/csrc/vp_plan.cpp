@@ -590,7 +590,7 @@ bool PlanFusedStrip(const HostAxisTaps &hx, const HostAxisTaps &hy, int n_out_x,
     int best_w = 0, best_cols = 0, best_pxl = 1;
     for (int pxl : {1, 2})
         for (int lanes : {64, 56, 48, 40, 32, 24, 16}) {
-            if (pxl == 2 && sp->nt == 16) continue;
+            if ((pxl == 2) == (sp->nt == 16)) continue;     // built as: two pixels per lane up to 8 taps, one for 16 (a one-pixel strip never won the model below 9 taps)
             const int sw = lanes * pxl;
             int max_nb = 0;
             for (int x0 = 0; x0 < n_out_x; x0 += sw) {
