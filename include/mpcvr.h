@@ -205,7 +205,7 @@ typedef struct mpcvr_dovi_metadata {
  * Kernels: the reshaping, the LMS step and the tail run in the 2x2-block convert (k_convert_blocks<..., DV_*>: same-size frames in
  * one kernel, straight into the render target; in front of k_fused_strip:surface / k_fused_period:surface when the frame is
  * resized); the exact-2x and the raw-sample strip kernels have no reshaping stage.  The metadata is per context: every frame of an
- * mpcvr_process_batch call runs on the RPU last set. */
+ * mpcvr_process_batch call runs on the RPU last set (mpcvr_process_batch_dovi takes one RPU per frame). */
 int32_t mpcvr_set_dovi_metadata(mpcvr_ctx *ctx, const mpcvr_dovi_metadata *md);
 
 /* The correction shaders (m_pPSCorrection, DX11VideoProcessor.cpp:1893-1930): same-size RGB -> RGB passes the reference runs
@@ -273,11 +273,22 @@ int32_t mpcvr_reset(mpcvr_ctx *ctx);
  * The frames of a batch are independent of each other: on every path that can, the whole batch runs as one launch per
  * draw (fused 2x / strip / periodic kernel: one launch; same-size frames: one k_convert_stream launch; pass-per-kernel path:
  * block convert / X draw / Y draw with a frame dimension and batched intermediates, <= 4 GiB; Dolby Vision: the block convert's
- * frame dimension, one RPU per call; the HDR10 tone-mapping step: one launch behind batched post-scale textures; Jinc2m: the
+ * frame dimension, one RPU per call here, one per frame in mpcvr_process_batch_dovi; the HDR10 tone-mapping step: one launch behind batched post-scale textures; Jinc2m: the
  * one-draw quad kernel), otherwise frame by frame (quarter turns, the two-draw Jinc2m, samples that need a repack of their
  * own).  The targets must therefore be distinct buffers; completion is in stream order for the batch as a whole. */
 int32_t mpcvr_process_batch(mpcvr_ctx *ctx, int32_t n, const void *const *srcs, void *const *dsts,
                             int32_t dst_pitch);
+/* mpcvr_process_batch for a Dolby Vision stream: rpus[i] is the RPU of frame i — the reference reads it from every sample in
+ * CopySample (IID_MediaSideDataDOVIMetadataV2, DX11VideoProcessor.cpp:2270-2520).  The result is what n rounds of
+ * mpcvr_set_dovi_metadata(&rpus[i]) + mpcvr_process(srcs[i] -> dsts[i]) produce, level-1 / level-2 blocks staying as last seen
+ * like there, and the context ends up holding the last frame's RPU.  Frames are cut into runs that share a plan and a kernel variant
+ * (level-2 trims for this display present or not); a run is ONE launch per stage where the block convert's Dolby Vision variants
+ * run (same-size frames; convert + resize kernels): they read frame z's curves, LMS matrix, trims and ycc_to_rgb matrix from
+ * device tables indexed by the frame.  A run behind the HDR10 tone-mapping step (its level-1 constants travel by value), and
+ * whatever the per-pixel convert serves, goes frame by frame with each RPU's constants uploaded in stream order.
+ * E_INVALIDARG, and nothing drawn, when any RPU of the batch fails the checks of mpcvr_set_dovi_metadata. */
+int32_t mpcvr_process_batch_dovi(mpcvr_ctx *ctx, int32_t n, const void *const *srcs, void *const *dsts,
+                                 int32_t dst_pitch, const mpcvr_dovi_metadata *rpus);
 
 /* Multi-GPU: the parameter blob (colour matrix, luminance scale, gamut matrix, resize phase weights,
  * dither table) a rank-0 context computes and every other rank adopts after an RCCL broadcast.

@@ -1,18 +1,17 @@
-"""Which kernel instantiations does the GPU suite actually launch?
+"""Which kernel instantiations does the GPU suite actually launch?  All of them.
 
-libmpcvr.so holds ~1,200 kernel instantiations (template arguments = taps x tail x source layout x epilogue x ...); a planner typo can
-select one no test ever ran.  tools/final_profiles.sh runs the whole GPU suite under `rocprofv3 --kernel-trace --stats` and the stats
-table is committed (profiles/<round>/gpu_suite_kernel_stats.csv).  This CPU test compares it with the kernels of the CURRENT build
-(the host-side __device_stub__ symbols of the library):
+libmpcvr.so holds ~860 kernel instantiations (template arguments = taps x tail x source layout x epilogue x ...); a planner typo can
+select one no test ever ran.  The GPU suite runs under `rocprofv3 --kernel-trace --stats` (tools/final_profiles.sh) with every test's
+start / end logged (MPCVR_TEST_TIMES, tests/conftest.py); the stats table and the join of the two — which test launched which
+instantiation, tests/tools/kernel_witnesses.py — are committed (profiles/<round>/gpu_suite_kernel_stats.csv, kernels_by_test.json).
+This CPU test compares them with the kernels of the CURRENT build (the host-side __device_stub__ symbols of the library):
 
-  * every kernel FAMILY of the library is launched by the suite;
-  * every instantiation of the families the BASELINE configurations and the bench workloads run on by default (the exact-2x kernel and
-    its matrix-core twin, the periodic-phase kernel, the streaming same-size convert) and of the folded row / tiled two-draw resize
-    kernels is launched — or named in tests/golden/kernels_not_launched.json with a reason;
-  * for the remaining table-driven families (k_fused_strip, k_convert_420, k_convert_blocks, k_resize_cols, k_jinc2_quad) the share of
-    launched instantiations is reported and held to the recorded figure, so coverage cannot silently fall; the unlaunched ones are
-    listed in the assertion message.
-A kernel that exists in the build but not in the profile's era (added since) fails the second rule until the profile is refreshed.
+  * every instantiation in the library was launched by the suite (round 4: what no plan can select was pruned — one-pixel strips
+    below 9 taps, the 8-bit loaders behind a PQ / HLG / BT.2020 tail, resize (texture, epilogue) pairs no plan produces — and the
+    kernel-family sweep of tests/test_parity_gpu.py drives the rest, each case against the oracle), or is named in
+    tests/golden/kernels_not_launched.json with a reason (empty since round 4);
+  * every instantiation has a witness: a test id in kernels_by_test.json whose interval held one of its dispatches.
+A kernel that exists in the build but not in the profile's era (added since) fails until the profile is refreshed.
 """
 import csv
 import glob
@@ -26,14 +25,6 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(ROOT, "videorenderer_amd", "libmpcvr.so")
-STRICT_FAMILIES = ("k_fused_up2x", "k_fused_period", "k_convert_stream", "k_fused_up2x_mx", "k_resize_rows", "k_resize_2d")
-# share of a family's instantiations the suite launched when the profile was taken (round 4, after the kernel-family sweep of
-# tests/test_parity_gpu.py and the pruning of combinations no plan can produce: k_resize_cols 46 / 51, k_jinc2_quad 7 / 9, k_convert_420 71 / 160,
-# k_fused_strip 137 / 441, k_convert_blocks 34 / 92; round 3: 16 / 54, 1 / 9, 30 / 160, 97 / 378, 30 / 92): the floors sit just under those
-# figures — coverage of the table-driven families is partial and must not fall; the strict families are complete
-FLOORS = {"k_fused_strip": 0.30, "k_convert_blocks": 0.36, "k_convert_420": 0.43, "k_resize_cols": 0.88, "k_jinc2_quad": 0.75}
-
-
 def norm(name):
     """'void mpcvr::(anonymous namespace)::k_x<5, 1, (int)1>(args)' / '...__device_stub__k_x<5, 1, 1>(args)' -> 'k_x<5,1,1>'"""
     m = re.search(r"(k_[a-z0-9_]+)(<[^(]*>)?\s*\(", name)
@@ -86,12 +77,16 @@ def test_gpu_suite_launches_every_kernel_family_and_every_headline_instantiation
         b = sorted(k for k in built if family(k) == fam)
         got = [k for k in b if k in launched]
         miss = [k for k in b if k not in launched and k not in excused]
-        share = len(got) / len(b)
         report.append(f"{fam}: {len(got)}/{len(b)}")
-        if fam in STRICT_FAMILIES:
-            assert not miss, f"{fam}: {len(miss)} instantiations are never launched by the GPU suite and carry no reason in kernels_not_launched.json: {miss[:12]}"
-        elif fam in FLOORS:
-            assert share >= FLOORS[fam], f"{fam}: only {len(got)} of {len(b)} instantiations launched (floor {FLOORS[fam]}); unlaunched e.g. {miss[:8]}"
+        assert not miss, f"{fam}: {len(miss)} instantiations are never launched by the GPU suite and carry no reason in kernels_not_launched.json: {miss[:12]}"
     print("kernel coverage of the GPU suite:", "; ".join(report))
+    # the witness table: a test for every instantiation
+    wfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "kernels_by_test.json")))
+    assert wfiles, "no profiles/*/kernels_by_test.json (tests/tools/kernel_witnesses.py on the GPU box)"
+    with open(wfiles[-1]) as f:
+        wit = json.load(f)
+    assert wit["attributed"] >= 0.99 * wit["dispatches"], f"{wfiles[-1]}: only {wit['attributed']} of {wit['dispatches']} dispatches fall inside a test interval"
+    nowit = sorted(k for k in built if k not in excused and not wit["kernels"].get(k, {}).get("tests"))
+    assert not nowit, f"{len(nowit)} instantiations without a witness test in {wfiles[-1]}: {nowit[:12]}"
     stale = sorted(k for k in excused if k not in built)
     assert not stale, f"kernels_not_launched.json names kernels that are not in the build any more: {stale[:8]}"

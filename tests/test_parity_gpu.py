@@ -396,7 +396,8 @@ def _sweep_cases():
     # the folded column kernel as the FIRST of two draws (it fills m_TexResize) from every texture format: 32 output rows of a 6x downscale
     # along Y read more source rows than the tiled two-draw kernel keeps (kResizeTileRowsMax); and the one-draw Jinc2m from an 8-bit RGB texture into a 10-bit post-scale one
     for gname, g in (("x_up_mitchell_y_down6", dict(h=192, iUpscaling=1, iDownscaling=2, dst=(90, 32))), ("x_up_lanczos3_y_down6", dict(h=192, iUpscaling=4, iDownscaling=2, dst=(90, 32))),
-                     ("x_down2p5_y_down6", dict(w=500, h=192, iDownscaling=2, dst=(200, 32)))):
+                     ("x_down2p5_y_down6", dict(w=500, h=192, iDownscaling=2, dst=(200, 32))),
+                     ("x_down2p5_lanczos15_y_down6", dict(w=500, h=192, iDownscaling=5, dst=(200, 32)))):
         for cf, fname, tail in ((2, "p010", "HDR10"), (30, "rgb32", "SDR")):
             for itex in (8, 10, 16):
                 k += 1
@@ -608,6 +609,117 @@ def test_process_batch_equals_single(mpcvr, torch_cuda):
         for i in range(3):
             assert torch.equal(singles[2 + i], dsts[i]), (name, flags, "second batch", i)
         vp.close()
+
+
+DOVI_BATCH_CASES = (
+    # (label, case, expected GetVPInfo suffix): a stream whose RPU changes with every frame — curves (poly / MMR / mixed / identity), the
+    # ycc_to_rgb matrix, level-2 trims appearing (a new kernel variant: a new run) and staying as last seen afterwards
+    ("same_size_sdr", dict(cformat=2, w=128, h=64, kind="hdr", seed=700, dst=(128, 64), exfmt_name="TVONLY"), "dovi_batch=3:tables,4:tables"),
+    ("resized_sdr", dict(cformat=2, w=128, h=64, kind="hdr", seed=701, dst=(192, 96), iUpscaling=4, exfmt_name="TVONLY"), "dovi_batch=3:tables,4:tables"),
+    ("planar_2x_sdr", dict(cformat=20, w=128, h=64, kind="hdr", seed=702, dst=(256, 128), iUpscaling=2, exfmt_name="TVONLY"), "dovi_batch=3:tables,4:tables"),
+    ("hdr_passthrough", dict(cformat=2, w=128, h=64, kind="hdr", seed=703, dst=(128, 64), output_format=1, hdr_output=1, exfmt_name="TVONLY"), "dovi_batch=3:tables,4:tables"),
+    # the per-pixel convert (a source rect the 2x2-block kernel does not take) and the HDR10 tone-mapping step (level-1 constants by value): frame by frame
+    ("odd_rect_per_pixel_convert", dict(cformat=2, w=128, h=64, kind="hdr", seed=704, src_rect=(3, 1, 125, 63), dst=(122, 62), exfmt_name="TVONLY"), "dovi_batch=3:frames,4:frames"),
+    ("hdr_tonemap_l1", dict(cformat=2, w=128, h=64, kind="hdr", seed=705, dst=(192, 96), iUpscaling=2, output_format=1, hdr_output=1, hdr_tonemap=5, hdr_display=1000.0,
+                            exfmt_name="TVONLY"), None),
+)
+
+
+@pytest.mark.parametrize("label", [c[0] for c in DOVI_BATCH_CASES])
+def test_process_batch_dovi_one_rpu_per_frame(mpcvr, oracle, torch_cuda, label):
+    """mpcvr_process_batch_dovi: frame i of the batch runs on rpus[i].  Must equal, bit for bit, the reference's own pattern — the RPU read
+    from every sample: SetDoviMetadata + CopySample + Process frame after frame on a second context — and the oracle run with frame i's
+    RPU; the whole-batch routes must really be taken (GetVPInfo names the runs), and the context must end up on the last RPU."""
+    torch = torch_cuda
+    from videorenderer_amd import api, synth
+    from tests.golden import cases as G
+    _, c, want_info = next(x for x in DOVI_BATCH_CASES if x[0] == label)
+    c = dict(c)
+    c.pop("exfmt_name")
+    c["exfmt"] = G.ext(G.MPEG2, G.TV)
+    kinds = [dict(kind="poly"), dict(kind="mmr"), dict(kind="mixed"), dict(kind="mmr", l2=(100, 600, 1000)), dict(kind="poly"),
+             dict(kind="identity", l2=(600,)), dict(kind="mixed")]
+    if c.get("hdr_tonemap"):
+        kinds[2] = dict(kind="mixed", l1=True)          # level-1 data appear on frame 2: the tone-mapping step switches on (a new plan, a new run)
+    rpus = []
+    for i, k in enumerate(kinds):
+        md = api.DoviMetadata.from_dict(synth.dovi_metadata(**k))
+        md.ycc_to_rgb_matrix[0] *= 1.0 - 0.01 * i       # every frame its own colour matrix
+        md.ycc_to_rgb_matrix[5] += 0.004 * i
+        md.ycc_to_rgb_offset[1] += 0.001 * i
+        rpus.append(md)
+    n = len(rpus)
+    frames = [torch.from_numpy(case_frame(dict(c, seed=c["seed"] + 31 * i))[0]).cuda() for i in range(n)]
+    # frame after frame
+    one, (ww, wh) = make_vp(mpcvr, c)
+    pitch = one.GetFrameBytes()[1]
+    singles = []
+    for f, md in zip(frames, rpus):
+        dst = torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda")
+        one.SetDoviMetadata(md)
+        one.CopySample(f, pitch)
+        one.Process(dst, ww * 4)
+        singles.append(dst)
+    one.Synchronize()
+    # the batch
+    vp, _ = make_vp(mpcvr, c)
+    dsts = [torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda") for _ in frames]
+    vp.ProcessBatchDovi(frames, dsts, ww * 4, rpus)
+    vp.Synchronize()
+    info = vp.GetVPInfo()
+    for i in range(n):
+        assert torch.equal(singles[i], dsts[i]), (label, i, info)
+    assert not torch.equal(dsts[0], dsts[1])
+    if want_info:
+        assert info.endswith(want_info), info
+    else:           # (level-1 data from frame 2 on: the runs behind the tone-mapping step go frame by frame)
+        assert "dovi_batch=" in info and ":frames" in info.split("dovi_batch=")[1], info
+    # the context holds the last frame's RPU (and the level-2 block frame 5 brought): a plain Process repeats the batch's last frame
+    again = torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda")
+    vp.CopySample(frames[-1], pitch)
+    vp.Process(again, ww * 4)
+    vp.Synchronize()
+    assert torch.equal(again, dsts[-1]), label
+    # a second batch through the same context: the table slots are reused; starts on the sticky level-2 state like the loop would
+    dsts2 = [torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda") for _ in range(3)]
+    vp.ProcessBatchDovi(frames[:3], dsts2, ww * 4, rpus[:3])
+    singles2 = []
+    for f, md in zip(frames[:3], rpus[:3]):
+        dst = torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda")
+        one.SetDoviMetadata(md)
+        one.CopySample(f, pitch)
+        one.Process(dst, ww * 4)
+        singles2.append(dst)
+    vp.Synchronize(); one.Synchronize()
+    for i in range(3):
+        assert torch.equal(singles2[i], dsts2[i]), (label, "second batch", i)
+    # a malformed RPU anywhere in the batch: E_INVALIDARG and nothing drawn
+    bad = api.DoviMetadata.from_dict(synth.dovi_metadata("poly"))
+    bad.curves[1].num_pivots = 11
+    untouched = [torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    with pytest.raises(api.MpcvrError):
+        vp.ProcessBatchDovi(frames[:2], untouched, ww * 4, [rpus[0], bad])
+    vp.Synchronize()
+    assert all(bool((u == BG).all()) for u in untouched)
+    vp.close(); one.close()
+    if c.get("hdr_tonemap"):
+        return          # (level-1 data stay as last seen: the loop above is the statement of that; the tone-mapping step has its own oracle tests)
+    # frames 1 (MMR) and 3 (MMR + level-2 trims) against the oracle on their own RPUs
+    for i in (1, 3):
+        k = dict(kinds[i])
+        p = oracle_params(oracle, dict(c, dovi=k))
+        mdd = synth.dovi_metadata(**k)
+        mdd["ycc_to_rgb_matrix"] = list(rpus[i].ycc_to_rgb_matrix)
+        mdd["ycc_to_rgb_offset"] = list(rpus[i].ycc_to_rgb_offset)
+        # (level-2 / level-1 blocks stay as last seen: frame 3 brings its own trims; nothing earlier in this stream carries any)
+        oracle.set_params(p, dovi=mdd)
+        frame = frames[i].cpu().numpy()
+        want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+        got = dsts[i].cpu().numpy()
+        if c.get("output_format", 0) == 1:
+            compare_rgb10(got, want, f"{label} frame {i}", tail=True)
+        else:
+            compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} frame {i} [{info}]", min_same=0.99, dovi=True, cap=2)
 
 
 def test_process_batch_lanes(torch_cuda):

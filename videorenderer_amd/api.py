@@ -154,7 +154,7 @@ EXPORTS = [
     "mpcvr_set_input", "mpcvr_set_video_rect", "mpcvr_set_window_rect", "mpcvr_set_rotation", "mpcvr_set_flip", "mpcvr_set_sample_format", "mpcvr_set_hdr_output", "mpcvr_set_hdr_metadata",
     "mpcvr_set_dovi_metadata", "mpcvr_plan_dovi", "mpcvr_correction_pass", "mpcvr_plan_correction_matrices",
     "mpcvr_configure", "mpcvr_set_procamp", "mpcvr_copy_sample", "mpcvr_process", "mpcvr_render",
-    "mpcvr_get_backbuffer", "mpcvr_get_current_image", "mpcvr_flush", "mpcvr_reset", "mpcvr_process_batch",
+    "mpcvr_get_backbuffer", "mpcvr_get_current_image", "mpcvr_flush", "mpcvr_reset", "mpcvr_process_batch", "mpcvr_process_batch_dovi",
     "mpcvr_get_param_blob", "mpcvr_set_param_blob", "mpcvr_broadcast_param_blob_begin", "mpcvr_broadcast_param_blob_end",
     "mpcvr_broadcast_param_blob", "mpcvr_get_color_matrix", "mpcvr_get_extfmt",
     "mpcvr_get_frame_bytes", "mpcvr_get_path_info", "mpcvr_last_error", "mpcvr_version",
@@ -221,6 +221,7 @@ def load_library():
         "mpcvr_flush": [vp],
         "mpcvr_reset": [vp],
         "mpcvr_process_batch": [vp, i32, P(vp), P(vp), i32],
+        "mpcvr_process_batch_dovi": [vp, i32, P(vp), P(vp), i32, P(DoviMetadata)],
         "mpcvr_get_param_blob": [vp, vp, P(C.c_size_t)],
         "mpcvr_set_param_blob": [vp, vp, C.c_size_t],
         "mpcvr_broadcast_param_blob_begin": [vp, vp, i32, i32],
@@ -576,6 +577,15 @@ class VideoProcessor:
         b = self.PrepareBatch(srcs, dsts)
         self._keep = b
         return self._check(self._L.mpcvr_process_batch(self._ctx, b.n, b.sa, b.da, rt_pitch))
+
+    def ProcessBatchDovi(self, srcs, dsts, rt_pitch, rpus):
+        """ProcessBatch with one Dolby Vision RPU per frame (mpcvr_process_batch_dovi): rpus[i] is a DoviMetadata or the dict
+        DoviMetadata.from_dict takes."""
+        b = srcs if isinstance(srcs, PreparedBatch) else self.PrepareBatch(srcs, dsts)
+        self._keep = b
+        assert len(rpus) == b.n
+        arr = (DoviMetadata * b.n)(*[m if isinstance(m, DoviMetadata) else DoviMetadata.from_dict(m) for m in rpus])
+        return self._check(self._L.mpcvr_process_batch_dovi(self._ctx, b.n, b.sa, b.da, rt_pitch, arr))
 
     @staticmethod
     def PrepareBatch(srcs, dsts):

@@ -76,6 +76,11 @@ CHipVideoProcessor::~CHipVideoProcessor()
         if (d.pinned) (void)hipHostFree(d.pinned);
         if (d.copied) (void)hipEventDestroy(d.copied);
     }
+    for (DoviTableSlot &d : m_dvSlots) {
+        d.dev.Release();
+        if (d.pinned) (void)hipHostFree(d.pinned);
+        if (d.done) (void)hipEventDestroy(d.done);
+    }
     for (int i = 1; i < kLanes; i++) {
         Lane &l = m_lanes[i];
         l.conv.Release(); l.mid.Release(); l.post.Release();
@@ -404,6 +409,13 @@ bool CHipVideoProcessor::ToneMapActive() const
 // CopySample, IID_MediaSideDataDOVIMetadataV2 branch — DX11VideoProcessor.cpp:2270-2520
 HRESULT CHipVideoProcessor::SetDoviMetadata(const mpcvr_dovi_metadata *md)
 {
+    const HRESULT hr = ApplyDoviMetadata(md);
+    return (hr || !md) ? hr : UploadDoviParams();
+}
+
+// the host side of an RPU: curves, matrices, trims, what the plan depends on — everything but the copy to the device
+HRESULT CHipVideoProcessor::ApplyDoviMetadata(const mpcvr_dovi_metadata *md)
+{
     if (!m_bInit) return Fail(MPCVR_E_NOT_VALID_STATE, "not initialised");
     if (!md) {
         if (m_doviValid) { m_doviValid = false; m_planDirty = true; }
@@ -430,7 +442,7 @@ HRESULT CHipVideoProcessor::SetDoviMetadata(const mpcvr_dovi_metadata *md)
     SetShaderConvertColorParams();
     UpdateHdrToneMapParams();
     if (!wasValid || (m_srcParams && hadToneMap != ToneMapActive())) m_planDirty = true;
-    return UploadDoviParams();
+    return MPCVR_S_OK;
 }
 
 // the curve / trim constant buffers travel through a small pinned ring so per-frame RPUs never stall the stream
@@ -915,7 +927,7 @@ void CHipVideoProcessor::FillConvertParams(const uint8_t *sample, ConvertParams 
     P->lum_scale = m_lumScale;
     std::memcpy(P->gamut, m_gamut, sizeof(m_gamut));
     P->out_fmt = m_plan.internal_fmt;
-    P->dovi = m_doviValid ? (const DoviParams *)m_doviDev.ptr : nullptr;
+    P->dovi = !m_doviValid ? nullptr : m_dvTabDev ? m_dvTabDev : (const DoviParams *)m_doviDev.ptr;     // (m_dvTabDev: one RPU per frame, ProcessBatchDovi)
     P->pq_lut = (m_pqLutValid && !(m_cfg.flags & (MPCVR_FLAG_NO_LUT | MPCVR_FLAG_NO_FUSED))) ? (const float *)m_pqLut.ptr : nullptr;
 }
 
@@ -948,6 +960,7 @@ void CHipVideoProcessor::FillFusedParams(const uint8_t *sample, void *rt, int rt
     fp->hlg_lut = (m_tail == TAIL_HLG_TO_SDR && !no_lut) ? (const float *)m_hlgLut.ptr : nullptr;
     fp->eotf_lut = (m_doviValid && !no_lut) ? (const float *)m_eotfLut.ptr : nullptr;
     fp->dovi_l2 = (m_doviValid && m_doviHost.l2_enabled) ? 1 : 0;
+    fp->dovi_cm = (m_doviValid && m_dvTabDev) ? m_dvCmDev : nullptr;
     fp->taps_mfma = (m_cfg.flags & MPCVR_FLAG_FUSED_MFMA) ? 1 : (m_cfg.flags & MPCVR_FLAG_FUSED_VALU) ? 0 : -1;
     fp->inflight = m_inflight;
     fp->dst_aligned16 = (((uintptr_t)rt) & 15) == 0;        // batches: ProcessBatch checks every target
@@ -1256,12 +1269,16 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
     // pass-per-kernel path, whole batch per launch: possible when every stage has a kernel with a frame dimension
     // the arbitrary-ratio fused kernel takes the whole batch in one launch, like the 2x kernel
     FusedStripParams strip_sp{};
-    const bool strip = m_strip && !m_plan.fused_up2x && !m_plan.hdr_tonemap && src4 &&
+    const bool strip = m_strip && !m_plan.fused_up2x && !m_plan.hdr_tonemap && src4 && !m_dvFrames &&
                        FillStripParams((const uint8_t *)srcs[0], dsts[0], rtPitch, MakeStore(dsts[0], rtPitch, m_plan.swap_fmt, true), &strip_sp);
     bool batchable = false;
     if (!m_plan.fused_up2x && !strip && n > 1 && src4 && !(m_cfg.flags & (MPCVR_FLAG_NO_FUSED | MPCVR_FLAG_NO_FAST_CONVERT))) {
         FusedParams a{}, b{};
         batchable = BatchPlan((const uint8_t *)srcs[0], dsts[0], rtPitch, aligned, &a, &b);
+        // one RPU per frame (ProcessBatchDovi): the block convert's Dolby Vision variants index the run's tables by the frame; the HDR10
+        // tone-mapping step takes its level-1 constants by value, so such a run goes frame by frame
+        if (m_dvFrames && (!m_dvTabReady || m_plan.hdr_tonemap)) batchable = false;
+        if (batchable && m_dvFrames) { m_dvTabDev = m_dvTabReady; m_dvCmDev = m_dvCmReady; }
     }
     if (batchable && m_plan.direct_convert && n <= kHostTableMax) {
         // same-size frames: one convert launch with the frame table in its kernel arguments (32 frames for the block convert, 128 where the
@@ -1369,7 +1386,7 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
         // +5..10 % on the two-pass resize geometries, -15 % on 1080p same-size (fork/join events cost more than the
         // overlap returns), so one lane is the default.
         static const int want = [] { const char *e = std::getenv("MPCVR_BATCH_LANES"); return e ? std::atoi(e) : 1; }();
-        const int lanes = (repack || n < 2 || want < 2) ? 1 : std::min(std::min(n, want), (int)kLanes);
+        const int lanes = (repack || n < 2 || want < 2 || m_dvFrames) ? 1 : std::min(std::min(n, want), (int)kLanes);
         if (lanes > 1 && (hr = PrepareLanes(lanes))) return hr;
         if (!m_startRecorded) (void)hipEventRecord(m_evStart, m_stream);
         if (lanes > 1) {
@@ -1382,6 +1399,7 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
             UseLane(i % lanes);
             if (m_batchRepacked) tex = (const uint8_t *)srcs[i];           // (already in m_TexSrcVideo's layout: a slot of the batch texture)
             else if ((hr = PrepareSample((const uint8_t *)srcs[i], &tex))) break;
+            if (m_dvFrames && (hr = ApplyDoviFrame(m_dvFrames[i]))) break;          // this frame's RPU: constants, matrix, tone-mapping metadata
             hr = ProcessOne(tex, dsts[i], rtPitch);
         }
         UseLane(0);
@@ -1553,6 +1571,7 @@ HRESULT CHipVideoProcessor::ProcessBatchLaunches(int n, const FusedFrame *table,
         const FusedFrame *tab = hdr ? postTab : table + at;
         // frame z of the chunk: sample from the table, output at m_batchConv + z * m_convBytes
         conv.store.dst = m_batchConv.ptr;
+        if (m_dvTabDev) { conv.conv.dovi = m_dvTabDev + at; conv.dovi_cm = m_dvCmDev + (size_t)12 * at; }       // (the chunk's slice of the per-frame RPU tables)
         if ((hr = CheckHip(LaunchConvertBlocks(conv, table + at, FusedFrame{nullptr, nullptr}, m, m_stream, m_convBytes), "k_convert_blocks"))) return hr;
         ResizeBatch b1; b1.n = m; b1.in_stride = m_convBytes;
         FusedStripParams ssp{};
@@ -1584,6 +1603,111 @@ HRESULT CHipVideoProcessor::ProcessBatchLaunches(int n, const FusedFrame *table,
     }
     if (postDone) (void)hipEventRecord(postDone, m_stream);
     return MPCVR_S_OK;
+}
+
+// ---- a batch with one Dolby Vision RPU per frame -------------------------------------------------------------------------------
+// The reference reads the RPU of every sample in CopySample (IID_MediaSideDataDOVIMetadataV2, :2270-2520) and rebuilds the constant
+// buffers when it differs from the previous one.  Here: rpus[i] is applied in front of frame i exactly as SetDoviMetadata would
+// (level-1 / level-2 blocks stay as last seen until Flush), the frames are cut into runs that share a plan and a kernel variant
+// (level-2 trims present or not), and a run goes through ProcessBatch — ONE launch per stage where the block convert's Dolby Vision
+// variants take it (they index a table of DoviParams and colour matrices by the frame), frame by frame with the RPU's constants
+// uploaded in stream order otherwise.  The context is left as after the last frame's SetDoviMetadata.
+void CHipVideoProcessor::SaveDoviWalk(DoviWalkState *s) const
+{
+    s->valid = m_doviValid; s->l1Present = m_doviL1Present; s->l2Present = m_doviL2Present; s->blobOverride = m_blobOverride; s->planDirty = m_planDirty;
+    s->md = m_doviMd; s->host = m_doviHost;
+    std::memcpy(s->l1, m_doviL1, sizeof(m_doviL1)); std::memcpy(s->l2raw, m_doviL2Raw, sizeof(m_doviL2Raw)); std::memcpy(s->cm, m_cm, sizeof(m_cm));
+    s->tail = m_tail; s->gamma = m_gamma; s->tm = m_hdrTm;
+}
+void CHipVideoProcessor::RestoreDoviWalk(const DoviWalkState &s)
+{
+    m_doviValid = s.valid; m_doviL1Present = s.l1Present; m_doviL2Present = s.l2Present; m_blobOverride = s.blobOverride; m_planDirty = s.planDirty;
+    m_doviMd = s.md; m_doviHost = s.host;
+    std::memcpy(m_doviL1, s.l1, sizeof(m_doviL1)); std::memcpy(m_doviL2Raw, s.l2raw, sizeof(m_doviL2Raw)); std::memcpy(m_cm, s.cm, sizeof(m_cm));
+    m_tail = s.tail; m_gamma = s.gamma; m_hdrTm = s.tm;
+}
+
+HRESULT CHipVideoProcessor::ApplyDoviFrame(const DoviFrameState &f)
+{
+    m_doviHost = f.p;
+    std::memcpy(m_cm, f.cm, sizeof(m_cm));
+    m_hdrTm = f.tm;
+    return UploadDoviParams();          // through the pinned ring, in stream order: the frames before this one read their own copy
+}
+
+// DoviParams[n] followed by cm[12 n], staged through one of two pinned / device slots (a slot is rewritten only after the launches
+// that read it have completed: `done`, recorded by ProcessBatchDovi behind the run)
+HRESULT CHipVideoProcessor::UploadDoviTables(int n, hipEvent_t *done)
+{
+    HRESULT hr;
+    DoviTableSlot &slot = m_dvSlots[m_dvSlotNext++ % 2];
+    if (!slot.done && (hr = CheckHip(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming), "dovi table event"))) return hr;
+    if (slot.used && (hr = CheckHip(hipEventSynchronize(slot.done), "dovi table wait"))) return hr;
+    const size_t need = (size_t)n * (sizeof(DoviParams) + 12 * sizeof(float));
+    if (need > slot.cap) {
+        if (slot.pinned) (void)hipHostFree(slot.pinned);
+        slot.pinned = nullptr; slot.cap = 0;
+        const size_t cap = std::max<size_t>(need, 64 * (sizeof(DoviParams) + 12 * sizeof(float)));
+        if ((hr = CheckHip(hipHostMalloc(&slot.pinned, cap, hipHostMallocDefault), "dovi tables pinned"))) return hr;
+        if ((hr = CheckHip(slot.dev.CheckCreate(cap), "dovi tables"))) return hr;
+        slot.cap = cap;
+    }
+    DoviParams *tp = (DoviParams *)slot.pinned;
+    float *tc = (float *)(tp + n);
+    for (int i = 0; i < n; i++) {
+        tp[i] = m_dvFrames[i].p;
+        std::memcpy(tc + (size_t)12 * i, m_dvFrames[i].cm, 12 * sizeof(float));
+    }
+    if ((hr = CheckHip(hipMemcpyAsync(slot.dev.ptr, slot.pinned, need, hipMemcpyHostToDevice, m_stream), "dovi tables upload"))) return hr;
+    m_dvTabReady = (const DoviParams *)slot.dev.ptr;
+    m_dvCmReady = (const float *)((const DoviParams *)slot.dev.ptr + n);
+    slot.used = true;
+    *done = slot.done;
+    return MPCVR_S_OK;
+}
+
+HRESULT CHipVideoProcessor::ProcessBatchDovi(int n, const void *const *srcs, void *const *dsts, int rtPitch, const mpcvr_dovi_metadata *rpus)
+{
+    if (!m_bInit || !m_srcParams) return Fail(MPCVR_E_NOT_VALID_STATE, "InitMediaType has not been called");
+    if (n <= 0 || !srcs || !dsts || !rpus) return Fail(MPCVR_E_INVALIDARG, "empty batch");
+    for (int i = 0; i < n; i++)         // all or nothing: no frame is drawn when one RPU of the batch is malformed
+        if (!CheckDoviCurves(rpus[i])) return Fail(MPCVR_E_INVALIDARG, "Dolby Vision curves: num_pivots outside [2,9], mapping_idc > 1 or more than 32 level-2 blocks");
+    (void)hipSetDevice(m_device);
+    HRESULT hr = MPCVR_S_OK;
+    std::vector<DoviFrameState> fs((size_t)n);
+    m_dvLastInfo.clear();
+    auto collect = [&](int i) { fs[i].p = m_doviHost; std::memcpy(fs[i].cm, m_cm, sizeof(m_cm)); fs[i].tm = m_hdrTm; };
+    DoviWalkState back;
+    for (int i = 0; i < n && !hr;) {
+        // frame i opens a run: its RPU may change the plan (the first RPU of a stream, level-1 data switching the tone mapping on)
+        if ((hr = ApplyDoviMetadata(&rpus[i]))) break;
+        if (m_planDirty && (hr = UpdatePlan())) break;
+        collect(i);
+        if ((hr = UploadDoviParams())) break;           // (the context's own copy and, at the first RPU of a stream, the PQ EOTF table exist from here on)
+        int j = i + 1;
+        for (; j < n; j++) {
+            SaveDoviWalk(&back);
+            if ((hr = ApplyDoviMetadata(&rpus[j]))) break;
+            if (m_planDirty || m_doviHost.l2_enabled != fs[i].p.l2_enabled) { RestoreDoviWalk(back); break; }      // frame j opens the next run
+            collect(j);
+        }
+        if (hr) break;
+        const int len = j - i;
+        m_dvFrames = fs.data() + i; m_dvCount = len;
+        m_dvTabReady = nullptr; m_dvCmReady = nullptr; m_dvTabDev = nullptr; m_dvCmDev = nullptr;
+        hipEvent_t done = nullptr;
+        if (len > 1 && !m_plan.hdr_tonemap) hr = UploadDoviTables(len, &done);
+        if (!hr) hr = ProcessBatch(len, srcs + i, dsts + i, rtPitch);
+        const bool tables = m_dvTabDev != nullptr;
+        m_dvLastInfo += (m_dvLastInfo.empty() ? "" : ",") + std::to_string(len) + (tables ? ":tables" : ":frames");
+        m_dvFrames = nullptr; m_dvCount = 0;
+        m_dvTabReady = nullptr; m_dvCmReady = nullptr; m_dvTabDev = nullptr; m_dvCmDev = nullptr;
+        if (done) (void)hipEventRecord(done, m_stream);
+        // the context's own copy of the constants: the run's last frame (a whole-batch route did not touch it)
+        if (!hr && tables) hr = UploadDoviParams();
+        i = j;
+    }
+    return hr;
 }
 
 // Render minus Present — DX11VideoProcessor.cpp:2599-2813
@@ -1831,6 +1955,12 @@ HRESULT CHipVideoProcessor::GetFrameBytes(size_t *bytes, int *pitch)
 }
 
 std::string CHipVideoProcessor::GetPathInfo()
+{
+    std::string s = PathInfoCore();
+    if (!m_dvLastInfo.empty()) s += ";dovi_batch=" + m_dvLastInfo;       // the last call was mpcvr_process_batch_dovi: its runs, "frames:route"
+    return s;
+}
+std::string CHipVideoProcessor::PathInfoCore()
 {
     if (!m_srcParams) return "uninitialised";
     if (m_planDirty && UpdatePlan() != MPCVR_S_OK) return "error: " + m_lastError;

@@ -63,6 +63,7 @@ public:
     HRESULT GetBackBuffer(void **ptr, int *pitch, int *w, int *h);
     HRESULT GetCurentImage(void *hostBGRA, size_t *size);                     // :3493
     HRESULT ProcessBatch(int n, const void *const *srcs, void *const *dsts, int rtPitch);
+    HRESULT ProcessBatchDovi(int n, const void *const *srcs, void *const *dsts, int rtPitch, const mpcvr_dovi_metadata *rpus);
     void Flush();                                                             // :4074
     HRESULT Reset();                                                          // :3453
 
@@ -138,6 +139,29 @@ private:
     DoviSlot m_doviSlots[4];
     unsigned m_doviSlotNext = 0;
     HRESULT UploadDoviParams();
+    HRESULT ApplyDoviMetadata(const mpcvr_dovi_metadata *md);       // SetDoviMetadata without the upload
+    // ProcessBatchDovi: one RPU per frame of a batch.  What the kernels of frame k read that its RPU decides ...
+    struct DoviFrameState { DoviParams p; float cm[12]; HdrToneMapParams tm; };
+    // ... and everything an RPU changes in the context (to take a step back when frame j turns out to open the next run)
+    struct DoviWalkState {
+        bool valid, l1Present, l2Present, blobOverride, planDirty;
+        mpcvr_dovi_metadata md; DoviParams host; uint32_t l1[3]; float l2raw[5]; float cm[12]; int tail; float gamma; HdrToneMapParams tm;
+    };
+    void SaveDoviWalk(DoviWalkState *s) const;
+    void RestoreDoviWalk(const DoviWalkState &s);
+    const DoviFrameState *m_dvFrames = nullptr;       // set around ProcessBatch by ProcessBatchDovi: the frames of the run in flight
+    int m_dvCount = 0;
+    const DoviParams *m_dvTabReady = nullptr;         // device tables of the run, uploaded: DoviParams[n], then cm[12 n] ...
+    const float *m_dvCmReady = nullptr;
+    const DoviParams *m_dvTabDev = nullptr;           // ... and in use: ProcessBatch took a whole-batch route (FillConvertParams / FillFusedParams point the kernels at them)
+    const float *m_dvCmDev = nullptr;
+    struct DoviTableSlot { void *pinned = nullptr; size_t cap = 0; DevBuffer dev; hipEvent_t done = nullptr; bool used = false; };
+    DoviTableSlot m_dvSlots[2];
+    unsigned m_dvSlotNext = 0;
+    HRESULT UploadDoviTables(int n, hipEvent_t *done);
+    HRESULT ApplyDoviFrame(const DoviFrameState &f);
+    std::string m_dvLastInfo;                         // the runs of the last ProcessBatchDovi call (GetPathInfo: ";dovi_batch=3:tables,1:frames")
+    std::string PathInfoCore();
     bool ToneMapActive() const;
     int m_firstAxis = 0;           // screen axis the first draw's tap table runs along
     bool m_firstSwap = false;      // rotation 90/270: taps address the other texture axis

@@ -131,6 +131,12 @@ int32_t mpcvr_process_batch(mpcvr_ctx *ctx, int32_t n, const void *const *srcs, 
     return ctx->vp.ProcessBatch(n, srcs, dsts, dst_pitch);
 }
 
+int32_t mpcvr_process_batch_dovi(mpcvr_ctx *ctx, int32_t n, const void *const *srcs, void *const *dsts, int32_t dst_pitch, const mpcvr_dovi_metadata *rpus)
+{
+    CTX_OR_FAIL();
+    return ctx->vp.ProcessBatchDovi(n, srcs, dsts, dst_pitch, rpus);
+}
+
 int32_t mpcvr_get_param_blob(mpcvr_ctx *ctx, void *buf, size_t *size) { CTX_OR_FAIL(); return ctx->vp.GetParamBlob(buf, size); }
 int32_t mpcvr_set_param_blob(mpcvr_ctx *ctx, const void *buf, size_t size) { CTX_OR_FAIL(); return ctx->vp.SetParamBlob(buf, size); }
 int32_t mpcvr_broadcast_param_blob_begin(mpcvr_ctx *ctx, void *nccl_comm, int32_t root, int32_t rank) { CTX_OR_FAIL(); return ctx->vp.BroadcastParamBlobBegin(nccl_comm, root, rank); }

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(DV == DV_SDR_L2 ? 512 : 256) void k_convert_blocks(
                 const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
                 T[i] = f2{v, n - v};
             }
-        for (int i = threadIdx.x; i < (int)(sizeof(DoviParams) / 4); i += NTH) ((uint32_t *)DL)[i] = ((const uint32_t *)P.dovi)[i];
+        const DoviParams *dvp = P.dovi + (P.dovi_per_frame ? blockIdx.z : 0u);          // (one RPU per frame of the batch, or one for the launch)
+        for (int i = threadIdx.x; i < (int)(sizeof(DoviParams) / 4); i += NTH) ((uint32_t *)DL)[i] = ((const uint32_t *)dvp)[i];
     } else if (tail_has_table(TAIL))
         for (int i = threadIdx.x; i < LUT_N; i += NTH) {
             const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
@@ -93,16 +94,23 @@ __global__ __launch_bounds__(DV == DV_SDR_L2 ? 512 : 256) void k_convert_blocks(
     // batch_dst: frame z of the launch goes into an intermediate (batch_dst + z * batch_stride) instead of the table's target
     const gptr pdst = (gptr)uniform_ptr(batch_dst ? (void *)(batch_dst + (size_t)blockIdx.z * batch_stride) : frame.dst);
 
-    const f2 MM[5] = {f2{P.m[0], P.m[1]}, f2{P.m[2], P.m[3]}, f2{P.m[4], P.m[5]}, f2{P.m[6], P.m[7]}, f2{P.m[8], 0.0f}};
+    // colour matrix: the launch's, or (Dolby Vision, one RPU per frame) frame z's own — a wave-uniform read
+    float m9[9] = {P.m[0], P.m[1], P.m[2], P.m[3], P.m[4], P.m[5], P.m[6], P.m[7], P.m[8]}, c3[3] = {P.c[0], P.c[1], P.c[2]};
+    if (DV != DV_NONE && P.dovi_per_frame) {
+        const dv_cptr<float> t = (dv_cptr<float>)(uintptr_t)(P.dovi_cm + 12u * blockIdx.z);       // (read-only for the launch: scalar loads)
+        for (int i = 0; i < 9; i++) m9[i] = t[i];
+        for (int i = 0; i < 3; i++) c3[i] = t[9 + i];
+    }
+    const f2 MM[5] = {f2{m9[0], m9[1]}, f2{m9[2], m9[3]}, f2{m9[4], m9[5]}, f2{m9[6], m9[7]}, f2{m9[8], 0.0f}};
     const f2 GG[5] = {f2{P.gamut[0], P.gamut[1]}, f2{P.gamut[2], P.gamut[3]}, f2{P.gamut[4], P.gamut[5]}, f2{P.gamut[6], P.gamut[7]}, f2{P.gamut[8], 0.0f}};
     const f2 cmax2 = splat(P.maxv);
     f2 big2 = splat(8388608.0f);
     asm volatile("" : "+v"(big2));
-    f2 CC[3] = {splat(P.c[0]), splat(P.c[1]), splat(P.c[2])};
+    f2 CC[3] = {splat(c3[0]), splat(c3[1]), splat(c3[2])};
     asm volatile("" : "+v"(CC[0]), "+v"(CC[1]), "+v"(CC[2]));
 
     DoviRegs DRG;
-    if (DV != DV_NONE) load_dovi_regs(P.dovi, DRG);
+    if (DV != DV_NONE) load_dovi_regs(P.dovi + (P.dovi_per_frame ? blockIdx.z : 0u), DRG);
     RawAddr ra;
     RawAddrCR rac;
     if (CHR) make_raw_addr_cr<SRC>(P, X, rac); else make_raw_addr<SRC>(P, X, ra);
@@ -460,6 +468,7 @@ void FillFusedArgs(const FusedParams &P, FusedArgs &a)
         a.c[i] = c.cm[9 + i];
     }
     a.dovi = c.dovi; a.eotf_lut = P.eotf_lut; a.sy = sy; a.sc = sc;
+    a.dovi_cm = dv ? P.dovi_cm : nullptr; a.dovi_per_frame = a.dovi_cm ? 1 : 0;
     ChromaCatmullWeights(c.chroma_loc, a.crx, a.cry);
     a.tail = c.tail; a.gamma = c.gamma; a.lum_scale = c.lum_scale;
     std::memcpy(a.gamut, c.gamut, sizeof(a.gamut));

@@ -53,6 +53,10 @@ struct FusedArgs {
     const DoviParams *dovi;
     const float *eotf_lut;         // kEotfLutSize + 1 floats (device): log2 ST2084ToLinear((i / kEotfLutSize)^2, 1)
     float sy, sc;
+    // one RPU per frame of a batch (mpcvr_process_batch_dovi): frame z reads dovi[z] and the colour matrix dovi_cm[12 z .. 12 z + 11]
+    // (ycc_to_rgb_matrix / offset of ITS RPU, rows then constants, as ConvertParams::cm) instead of dovi[0] and m / c above
+    const float *dovi_cm;
+    int dovi_per_frame;
 };
 
 namespace {

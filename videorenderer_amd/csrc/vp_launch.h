@@ -69,6 +69,9 @@ struct FusedParams {
     const float *hlg_lut;     // device, kPqLutSize floats (BuildHlgInverseLut): HLG -> SDR tail of the fused kernels; null => literal chain
     const float *eotf_lut;    // device, kEotfLutSize + 1 floats: log2 ST2084ToLinear(x, 1) at x = (i/N)^2 — the Dolby Vision variants of the block convert decode PQ from it
     int dovi_l2;              // the frame's Dolby Vision metadata carries level-2 trims for this display (DoviParams::l2_enabled)
+    // a batch with one RPU per frame: conv.dovi points at n DoviParams and dovi_cm at n colour matrices (12 floats each, the layout of
+    // ConvertParams::cm); the block convert's Dolby Vision variants index both by the frame.  Null: one RPU for the launch (conv.dovi, conv.cm)
+    const float *dovi_cm;
     int taps_mfma;            // fused 2x kernel: 1 = resize taps on the matrix cores, 0 = packed-fp32 VALU chains, -1 = library default
     int inflight;             // single-frame launches: frames the host keeps running side by side (the context's frame lanes), 0 / 1 = none.  The
                               // segment rules count them like frames of a batch: four overlapping 4K frames fill the chip with long segments
