@@ -566,10 +566,16 @@ def test_get_current_image_and_render(mpcvr, oracle, torch_cuda):
     vp.close()
 
 
+# batches that go frame by frame by design (everything else in test_process_batch_equals_single must take a whole-batch route)
+# — the fp16 internal format (a user-forced setting): its convert is the per-pixel kernel, which has no frame dimension
+BATCH_FRAME_BY_FRAME = ("hdrout_tm6_st2094_hlg_fp16",)
+
+
 def test_process_batch_equals_single(mpcvr, torch_cuda):
     torch = torch_cuda
     # fused launch, plain per-frame loop, and the whole-batch launches of the pass-per-kernel path (two-pass, one-pass,
     # same-size direct, 8-bit and 10-bit sources, a source rect, a letterboxed window)
+    by_frame = []
     for name, flags in (("noise_p010_pq_lanczos3_2x", 0), ("noise_p010_pq_lanczos3_2x", 2), ("down_lanczos_2p5x", 0),
                         ("up_1p5x_lanczos3", 0), ("x_only_resize", 0), ("y_only_resize", 0), ("c1_nv12_bt709_passthrough", 0),
                         ("mild_down_uses_upscaler", 0), ("crop_offset_letterbox", 0), ("down_hamming_3x", 0), ("c5_p010_hlg_lanczos3_2x", 8),
@@ -583,7 +589,13 @@ def test_process_batch_equals_single(mpcvr, torch_cuda):
                         ("hdrout_tm1_aces_2x", 0), ("hdrout_tm2_reinhard", 0), ("hdrout_tm3_habel_same_size", 0), ("hdrout_tm4_moebius_bgra8_dither", 0),
                         ("hdrout_tm5_bt2390", 0), ("hdrout_tm6_st2094_hlg_fp16", 0), ("hdrout_tm2_reinhard", 64),
                         ("dovi_poly_sdr", 0), ("dovi_poly_sdr_l2_between_2x", 0), ("dovi_mmr_sdr_l2_brighter", 0), ("dovi_hdrout_tm5_l1_l3_l2", 0),
-                        ("rot90_same_shader_single_draw", 0), ("rot270_down_hamming", 0)):
+                        ("rot90_same_shader_single_draw", 0), ("rot270_down_hamming", 0),
+                        # round 4, second half: the one-kernel-fits-all draws have a frame dimension too — quarter turns (one draw, two draws, with
+                        # a flip, a rotated Jinc2m), flips / half turns where the strip kernels' surface variant is switched off (64), the two-draw
+                        # Jinc2m (one axis Jinc, the other the downscaler) and Jinc2m at a non-dyadic ratio
+                        ("rot90_two_pass_down_up", 0), ("rot270_one_axis_only", 0), ("rot90_flip_mitchell", 0), ("rot90_copy_nv12", 0), ("jinc2_rot90_pq", 0),
+                        ("flip_catmull_1p5x", 64), ("rot180_lanczos3_2x_dither", 64), ("flip_offset_rect_final_pass", 0),
+                        ("jinc2_x_with_hamming_down_y", 0), ("jinc2_y_only", 0), ("jinc2_nv12_noise_1p5x", 64)):
         c = GOLDEN_CASES[name]
         vp, (ww, wh) = make_vp(mpcvr, c, flags)
         c = dict(c, kind="noise")        # distinct frames whatever the case's own content
@@ -601,6 +613,13 @@ def test_process_batch_equals_single(mpcvr, torch_cuda):
         for i in range(5):
             assert torch.equal(singles[i], dsts[i]), (name, flags, i)
         assert c["kind"] != "noise" or not torch.equal(dsts[0], dsts[1])       # (structure frames ignore the seed)
+        # the whole-batch routes really run: one launch per stage (convert, up to two draws, the tone-mapping step), not one per frame.
+        # Frame by frame by design: samples that are repacked one by one (v210 would be batched; interleaved RGB is not in this list),
+        # MPCVR_FLAG_NO_FUSED (2) and the literal-tail tier (8) on the pass-per-kernel path
+        route = vp.GetLastBatchInfo()
+        assert route["frames"] == 5
+        if flags in (0, 64) and route["launches"] > 4:
+            by_frame.append((name, flags, route["launches"], vp.GetVPInfo()))
         assert vp.GetLastProcessMs() > 0
         # a second batch through the same context (frame-table slots, batched intermediates reused), odd frame count
         dsts = [torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda") for _ in range(3)]
@@ -609,6 +628,7 @@ def test_process_batch_equals_single(mpcvr, torch_cuda):
         for i in range(3):
             assert torch.equal(singles[2 + i], dsts[i]), (name, flags, "second batch", i)
         vp.close()
+    assert sorted(n for n, _, _, _ in by_frame) == sorted(BATCH_FRAME_BY_FRAME), by_frame
 
 
 DOVI_BATCH_CASES = (
@@ -667,13 +687,19 @@ def test_process_batch_dovi_one_rpu_per_frame(mpcvr, oracle, torch_cuda, label):
     vp.ProcessBatchDovi(frames, dsts, ww * 4, rpus)
     vp.Synchronize()
     info = vp.GetVPInfo()
+    route = vp.GetLastBatchInfo()
     for i in range(n):
-        assert torch.equal(singles[i], dsts[i]), (label, i, info)
+        assert torch.equal(singles[i], dsts[i]), (label, i, info, route)
     assert not torch.equal(dsts[0], dsts[1])
+    assert route["frames"] == n
     if want_info:
-        assert info.endswith(want_info), info
+        assert route["dovi_runs"] == want_info.split("=")[1], route
+        if "tables" in want_info:       # two runs, a convert launch each (+ the draws behind it): fewer launches than frames
+            assert route["launches"] <= 4, route
+        else:
+            assert route["launches"] >= n, route
     else:           # (level-1 data from frame 2 on: the runs behind the tone-mapping step go frame by frame)
-        assert "dovi_batch=" in info and ":frames" in info.split("dovi_batch=")[1], info
+        assert ":frames" in route["dovi_runs"], route
     # the context holds the last frame's RPU (and the level-2 block frame 5 brought): a plain Process repeats the batch's last frame
     again = torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda")
     vp.CopySample(frames[-1], pitch)

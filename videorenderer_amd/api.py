@@ -157,7 +157,7 @@ EXPORTS = [
     "mpcvr_get_backbuffer", "mpcvr_get_current_image", "mpcvr_flush", "mpcvr_reset", "mpcvr_process_batch", "mpcvr_process_batch_dovi",
     "mpcvr_get_param_blob", "mpcvr_set_param_blob", "mpcvr_broadcast_param_blob_begin", "mpcvr_broadcast_param_blob_end",
     "mpcvr_broadcast_param_blob", "mpcvr_get_color_matrix", "mpcvr_get_extfmt",
-    "mpcvr_get_frame_bytes", "mpcvr_get_path_info", "mpcvr_last_error", "mpcvr_version",
+    "mpcvr_get_frame_bytes", "mpcvr_get_path_info", "mpcvr_get_last_batch_info", "mpcvr_last_error", "mpcvr_version",
     "mpcvr_get_last_process_ms", "mpcvr_get_last_timings",
     "mpcvr_plan_frame_layout", "mpcvr_plan_color_matrix", "mpcvr_plan_gamut_2020_to_709", "mpcvr_plan_pq_lut",
     "mpcvr_plan_upscale_weights", "mpcvr_plan_axis_taps", "mpcvr_plan_describe", "mpcvr_plan_final_pass_multiplier",
@@ -231,6 +231,7 @@ def load_library():
         "mpcvr_get_extfmt": [vp, P(u32)],
         "mpcvr_get_frame_bytes": [vp, P(C.c_size_t), P(i32)],
         "mpcvr_get_path_info": [vp, C.c_char_p, C.c_size_t],
+        "mpcvr_get_last_batch_info": [vp, C.c_char_p, C.c_size_t],
         "mpcvr_get_last_process_ms": [vp, P(f)],
         "mpcvr_get_last_timings": [vp, P(f), P(f), P(f), P(f)],
         "mpcvr_plan_frame_layout": [i32, i32, i32, P(i32), P(C.c_size_t)],
@@ -632,6 +633,13 @@ class VideoProcessor:
         buf = C.create_string_buffer(256)
         self._check(self._L.mpcvr_get_path_info(self._ctx, buf, 256))
         return buf.value.decode()
+
+    def GetLastBatchInfo(self):
+        """'frames=<n>;launches=<kernel launches>[;dovi_runs=...]' of the last ProcessBatch / ProcessBatchDovi call, as a dict."""
+        buf = C.create_string_buffer(512)
+        self._check(self._L.mpcvr_get_last_batch_info(self._ctx, buf, 512))
+        d = dict(kv.split("=", 1) for kv in buf.value.decode().split(";"))
+        return dict(frames=int(d["frames"]), launches=int(d["launches"]), dovi_runs=d.get("dovi_runs", ""))
 
     def GetLastProcessMs(self):
         ms = C.c_float()

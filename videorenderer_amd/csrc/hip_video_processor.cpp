@@ -120,6 +120,7 @@ HRESULT CHipVideoProcessor::Fail(HRESULT hr, const std::string &msg)
 
 HRESULT CHipVideoProcessor::CheckHip(hipError_t e, const char *what)
 {
+    if (what[0] == 'k' && what[1] == '_') m_launches++;        // (kernel launches are checked under their kernel's name: GetLastBatchInfo counts them)
     if (e == hipSuccess) return MPCVR_S_OK;
     return Fail(e == hipErrorOutOfMemory ? MPCVR_E_OUTOFMEMORY : MPCVR_E_FAIL,
                 std::string(what) + ": " + hipGetErrorString(e));
@@ -1226,6 +1227,14 @@ HRESULT CHipVideoProcessor::Process(void *pRenderTarget, int rtPitch, const CRec
 
 HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *const *dsts, int rtPitch)
 {
+    const unsigned before = m_launches;
+    const HRESULT hr = ProcessBatchRoutes(n, srcs, dsts, rtPitch);
+    m_lastBatchFrames = n; m_lastBatchLaunches = (int)(m_launches - before);
+    return hr;
+}
+
+HRESULT CHipVideoProcessor::ProcessBatchRoutes(int n, const void *const *srcs, void *const *dsts, int rtPitch)
+{
     if (!m_bInit || !m_srcParams) return Fail(MPCVR_E_NOT_VALID_STATE, "InitMediaType has not been called");
     if (n <= 0 || !srcs || !dsts) return Fail(MPCVR_E_INVALIDARG, "empty batch");
     if (rtPitch < m_windowRect.Width() * 4) return Fail(MPCVR_E_INVALIDARG, "render-target pitch smaller than a row");
@@ -1492,10 +1501,9 @@ HRESULT CHipVideoProcessor::UploadFrameTable(int n, const void *const *srcs, voi
 // convert straight into the render targets (same-size frames).  Exactly one of them is used.
 bool CHipVideoProcessor::BatchPlan(const uint8_t *sample0, void *rt0, int rtPitch, bool aligned, FusedParams *conv, FusedParams *direct) const
 {
-    // (a flipped or upside-down frame batches only through the strip / periodic kernels' surface variant: per-column tables, a row map)
-    const bool turned = m_plan.flip || m_plan.rotation == 180;
-    if ((m_plan.rotation && m_plan.rotation != 180) || (turned && !(m_plan.two_pass && m_stripSurf)) || m_secondJinc || !m_plan.convert) return false;
-    if (m_firstJinc && !(m_plan.one_pass && m_jincFirstTab)) return false;      // Jinc2m batches: the one-draw quad kernel only
+    // every draw kernel has a frame dimension (round 4: the one-kernel-fits-all k_resize / k_jinc2 too — quarter turns, flips outside the
+    // strip kernels' reach, the two-draw Jinc2m), so what decides is the convert stage: the 2x2-block kernel must take the sample
+    if (!m_plan.convert) return false;
     if ((m_srcParams->cformat == MPCVR_CF_V210 && !m_batchRepacked) || m_srcParams->layout == LAY_RGB) return false;
     const int w1 = m_srcRectWidth, h1 = m_srcRectHeight, w2 = m_videoRect.Width();
     if (m_plan.direct_convert) {
@@ -1517,20 +1525,8 @@ bool CHipVideoProcessor::BatchPlan(const uint8_t *sample0, void *rt0, int rtPitc
     const Surface cs{nullptr, convPitch, w1, h1, m_plan.internal_fmt};
     const StoreParams final = hdr ? MakeStore((void *)(uintptr_t)4096, (int)(w2 * SurfBytesPerPixel(m_plan.internal_fmt)), m_plan.internal_fmt, false)
                                   : MakeStore(rt0, rtPitch, m_plan.swap_fmt, true);
-    if (!m_plan.two_pass && !m_plan.one_pass) return true;          // convert -> tone mapping
-    if (m_plan.two_pass) {
-        // m_stripSurf was probed with a null target and a window-width pitch (UpdatePlan): re-check with THIS batch's target, and fall
-        // through to the tiled / folded kernels' own checks when the strip kernel does not take it
-        FusedStripParams ssp{};
-        if (m_stripSurf && FillStripSurfParams(cs, final, &ssp)) return true;
-        if (turned) return false;
-        if (m_firstAxis == 0 && !m_firstSwap && Resize2DSupported(cs, m_tapsX, m_tapsY, final)) return true;
-        const Surface mid{nullptr, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
-        return ResizeHasFoldedKernel(m_firstAxis, m_firstSwap, cs, m_tapsX, MakeStore(nullptr, mid.pitch, SF_RGBA16F, false)) &&
-               ResizeHasFoldedKernel(1, false, mid, m_tapsY, final);
-    }
-    if (m_firstJinc) return Jinc2QuadSupported(cs, m_firstCoords, m_videoRect.Width(), m_videoRect.Height(), final);
-    return ResizeHasFoldedKernel(m_firstAxis, m_firstSwap, cs, m_tapsX, final);
+    (void)cs; (void)final; (void)w2;
+    return true;            // the draws: ProcessBatchLaunches picks the kernel per chunk exactly as ResizeShaderPass does per frame
 }
 
 // convert all -> first draw all -> second draw all, a frame dimension in every grid; the intermediates hold `chunk` frames
@@ -1573,25 +1569,30 @@ HRESULT CHipVideoProcessor::ProcessBatchLaunches(int n, const FusedFrame *table,
         conv.store.dst = m_batchConv.ptr;
         if (m_dvTabDev) { conv.conv.dovi = m_dvTabDev + at; conv.dovi_cm = m_dvCmDev + (size_t)12 * at; }       // (the chunk's slice of the per-frame RPU tables)
         if ((hr = CheckHip(LaunchConvertBlocks(conv, table + at, FusedFrame{nullptr, nullptr}, m, m_stream, m_convBytes), "k_convert_blocks"))) return hr;
+        // the draws, kernel by kernel as ResizeShaderPass picks them for one frame (default tier), each with the chunk as its frame dimension
         ResizeBatch b1; b1.n = m; b1.in_stride = m_convBytes;
         FusedStripParams ssp{};
         if (m_stripSurf && FillStripSurfParams(cs, final, &ssp)) {
             ssp.surf_stride = m_convBytes;
             ssp.fp.dst_aligned16 = aligned ? 1 : 0;
             if ((hr = CheckHip(LaunchFusedStrip(ssp, tab, FusedFrame{nullptr, nullptr}, m, m_stream), "k_fused_strip<surface>"))) return hr;
-        } else if (m_plan.two_pass && m_firstAxis == 0 && !m_firstSwap && Resize2DSupported(cs, m_tapsX, m_tapsY, final)) {
+        } else if (m_plan.two_pass && !m_firstJinc && !m_secondJinc && m_firstAxis == 0 && !m_firstSwap && Resize2DSupported(cs, m_tapsX, m_tapsY, final)) {
             b1.frames = tab;
             if ((hr = CheckHip(LaunchResize2D(cs, m_tapsX, m_tapsY, (const int32_t *)m_otherX.ptr, m_plan.mid_h, w2, h2, final, m_stream, &b1), "k_resize_2d"))) return hr;
         } else if (m_plan.two_pass) {
             const Surface mid{m_batchMid.ptr, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
             b1.dst_stride = m_midBytes;
-            if ((hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, cs, m_tapsX, (const int32_t *)m_otherX.ptr, w2, m_plan.mid_h,
-                                            MakeStore(mid.ptr, mid.pitch, SF_RGBA16F, false), m_stream, false, &b1), "k_resize<first>"))) return hr;
-            ResizeBatch b2; b2.n = m; b2.in_stride = m_midBytes; b2.frames = tab;
-            if ((hr = CheckHip(LaunchResize(1, false, mid, m_tapsY, (const int32_t *)m_otherY.ptr, w2, h2, final, m_stream, false, &b2), "k_resize<Y>"))) return hr;
+            const StoreParams st = MakeStore(mid.ptr, mid.pitch, SF_RGBA16F, false);
+            if (m_firstJinc) hr = CheckHip(LaunchJinc2(cs, m_firstCoords, w2, m_plan.mid_h, st, m_stream, m_jincFirstTab, true, &b1), "k_jinc2");
+            else hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, cs, m_tapsX, (const int32_t *)m_otherX.ptr, w2, m_plan.mid_h, st, m_stream, false, &b1), "k_resize<first>");
+            if (hr) return hr;
+            ResizeBatch b2; b2.n = m; b2.in_stride = m_midBytes; b2.frames = tab; b2.dst_aligned8 = aligned ? 1 : 0;
+            if (m_secondJinc) hr = CheckHip(LaunchJinc2(mid, m_secondCoords, w2, h2, final, m_stream, m_jincSecondTab, true, &b2), "k_jinc2");
+            else hr = CheckHip(LaunchResize(1, false, mid, m_tapsY, (const int32_t *)m_otherY.ptr, w2, h2, final, m_stream, false, &b2), "k_resize<Y>");
+            if (hr) return hr;
         } else if (m_firstJinc) {
             b1.frames = tab; b1.dst_aligned8 = aligned ? 1 : 0;
-            if ((hr = CheckHip(LaunchJinc2Quad(cs, m_firstCoords, w2, h2, final, m_stream, m_jincFirstTab, &b1), "k_jinc2_quad"))) return hr;
+            if ((hr = CheckHip(LaunchJinc2(cs, m_firstCoords, w2, h2, final, m_stream, m_jincFirstTab, true, &b1), "k_jinc2"))) return hr;
         } else if (drawn) {
             b1.frames = tab;
             if ((hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, cs, m_tapsX, (const int32_t *)m_otherX.ptr, w2, h2, final, m_stream, false, &b1), "k_resize<one>"))) return hr;
@@ -1676,6 +1677,7 @@ HRESULT CHipVideoProcessor::ProcessBatchDovi(int n, const void *const *srcs, voi
     HRESULT hr = MPCVR_S_OK;
     std::vector<DoviFrameState> fs((size_t)n);
     m_dvLastInfo.clear();
+    int launches = 0;
     auto collect = [&](int i) { fs[i].p = m_doviHost; std::memcpy(fs[i].cm, m_cm, sizeof(m_cm)); fs[i].tm = m_hdrTm; };
     DoviWalkState back;
     for (int i = 0; i < n && !hr;) {
@@ -1699,6 +1701,7 @@ HRESULT CHipVideoProcessor::ProcessBatchDovi(int n, const void *const *srcs, voi
         if (len > 1 && !m_plan.hdr_tonemap) hr = UploadDoviTables(len, &done);
         if (!hr) hr = ProcessBatch(len, srcs + i, dsts + i, rtPitch);
         const bool tables = m_dvTabDev != nullptr;
+        launches += m_lastBatchLaunches;
         m_dvLastInfo += (m_dvLastInfo.empty() ? "" : ",") + std::to_string(len) + (tables ? ":tables" : ":frames");
         m_dvFrames = nullptr; m_dvCount = 0;
         m_dvTabReady = nullptr; m_dvCmReady = nullptr; m_dvTabDev = nullptr; m_dvCmDev = nullptr;
@@ -1707,7 +1710,17 @@ HRESULT CHipVideoProcessor::ProcessBatchDovi(int n, const void *const *srcs, voi
         if (!hr && tables) hr = UploadDoviParams();
         i = j;
     }
+    m_lastBatchFrames = n; m_lastBatchLaunches = launches;
     return hr;
+}
+
+// how the last mpcvr_process_batch[_dovi] call ran: "frames=<n>;launches=<kernel launches>[;dovi_runs=<frames>:<tables|frames>,...]" —
+// a batch on a whole-batch route launches a handful of kernels whatever n is, a frame-by-frame one at least n
+std::string CHipVideoProcessor::GetLastBatchInfo() const
+{
+    std::string s = "frames=" + std::to_string(m_lastBatchFrames) + ";launches=" + std::to_string(m_lastBatchLaunches);
+    if (!m_dvLastInfo.empty()) s += ";dovi_runs=" + m_dvLastInfo;
+    return s;
 }
 
 // Render minus Present — DX11VideoProcessor.cpp:2599-2813
@@ -1955,12 +1968,6 @@ HRESULT CHipVideoProcessor::GetFrameBytes(size_t *bytes, int *pitch)
 }
 
 std::string CHipVideoProcessor::GetPathInfo()
-{
-    std::string s = PathInfoCore();
-    if (!m_dvLastInfo.empty()) s += ";dovi_batch=" + m_dvLastInfo;       // the last call was mpcvr_process_batch_dovi: its runs, "frames:route"
-    return s;
-}
-std::string CHipVideoProcessor::PathInfoCore()
 {
     if (!m_srcParams) return "uninitialised";
     if (m_planDirty && UpdatePlan() != MPCVR_S_OK) return "error: " + m_lastError;

@@ -63,6 +63,7 @@ public:
     HRESULT GetBackBuffer(void **ptr, int *pitch, int *w, int *h);
     HRESULT GetCurentImage(void *hostBGRA, size_t *size);                     // :3493
     HRESULT ProcessBatch(int n, const void *const *srcs, void *const *dsts, int rtPitch);
+    std::string GetLastBatchInfo() const;
     HRESULT ProcessBatchDovi(int n, const void *const *srcs, void *const *dsts, int rtPitch, const mpcvr_dovi_metadata *rpus);
     void Flush();                                                             // :4074
     HRESULT Reset();                                                          // :3453
@@ -160,8 +161,10 @@ private:
     unsigned m_dvSlotNext = 0;
     HRESULT UploadDoviTables(int n, hipEvent_t *done);
     HRESULT ApplyDoviFrame(const DoviFrameState &f);
-    std::string m_dvLastInfo;                         // the runs of the last ProcessBatchDovi call (GetPathInfo: ";dovi_batch=3:tables,1:frames")
-    std::string PathInfoCore();
+    std::string m_dvLastInfo;                         // the runs of the last ProcessBatchDovi call (GetLastBatchInfo: ";dovi_runs=3:tables,1:frames")
+    unsigned m_launches = 0;                          // kernel launches so far (CheckHip) ...
+    int m_lastBatchFrames = 0, m_lastBatchLaunches = 0;      // ... and what the last batch call used
+    HRESULT ProcessBatchRoutes(int n, const void *const *srcs, void *const *dsts, int rtPitch);
     bool ToneMapActive() const;
     int m_firstAxis = 0;           // screen axis the first draw's tap table runs along
     bool m_firstSwap = false;      // rotation 90/270: taps address the other texture axis

@@ -161,6 +161,14 @@ int32_t mpcvr_get_path_info(mpcvr_ctx *ctx, char *buf, size_t buf_size)
     return MPCVR_S_OK;
 }
 
+int32_t mpcvr_get_last_batch_info(mpcvr_ctx *ctx, char *buf, size_t buf_size)
+{
+    CTX_OR_FAIL();
+    if (!buf || !buf_size) return MPCVR_E_POINTER;
+    std::snprintf(buf, buf_size, "%s", ctx->vp.GetLastBatchInfo().c_str());
+    return MPCVR_S_OK;
+}
+
 const char *mpcvr_last_error(mpcvr_ctx *ctx) { return ctx ? ctx->vp.LastError() : "null context"; }
 const char *mpcvr_version(void) { return "mpcvr-mi355x 0.1 (gfx950)"; }
 

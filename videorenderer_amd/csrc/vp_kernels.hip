@@ -64,10 +64,12 @@ __global__ __launch_bounds__(256) void k_convert_420(ConvertParams P, Surface ou
 // rows when they run along screen x (and columns along screen y).
 template <int AXIS, bool SWAP>
 __global__ __launch_bounds__(256) void k_resize(Surface in, AxisTaps taps, const int32_t *__restrict__ other,
-                                               int out_w, int out_h, StoreParams st)
+                                               int out_w, int out_h, StoreParams st, ResizeBatch bt)
 {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= out_w || y >= out_h) return;
+    in.ptr = (uint8_t *)in.ptr + (size_t)blockIdx.z * bt.in_stride;        // a batch: frame z's texture and target (vp_launch.h)
+    st.dst = bt.frames ? bt.frames[blockIdx.z].dst : (void *)((uint8_t *)st.dst + (size_t)blockIdx.z * bt.dst_stride);
     const int f = AXIS == 0 ? x : y;
     const int o = other[AXIS == 0 ? y : x];
     const int32_t *idx = taps.idx + (size_t)f * taps.ntaps;
@@ -514,10 +516,12 @@ __global__ __launch_bounds__(256) void k_resize_2d(Surface in, AxisTaps tx, Axis
 
 // ps_resize_onepass_jinc2.hlsl:44-101 ("Jinc2m"): one 2-D draw — 4x4 texels around the sample position weighted by the
 // windowed jinc of their distance, normalised, then anti-ringing towards the min/max of the inner 2x2 (strength 0.8)
-__global__ __launch_bounds__(256) void k_jinc2(Surface in, DrawCoords dc, int out_w, int out_h, StoreParams st)
+__global__ __launch_bounds__(256) void k_jinc2(Surface in, DrawCoords dc, int out_w, int out_h, StoreParams st, ResizeBatch bt)
 {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= out_w || y >= out_h) return;
+    in.ptr = (uint8_t *)in.ptr + (size_t)blockIdx.z * bt.in_stride;        // a batch: frame z's texture and target (vp_launch.h)
+    st.dst = bt.frames ? bt.frames[blockIdx.z].dst : (void *)((uint8_t *)st.dst + (size_t)blockIdx.z * bt.dst_stride);
     const float pi = 3.14159274101257324f;                 // acos(-1) folded to fp32
     const float wa = 0.416f * pi, wb = 0.985f * pi;
     const float cx = TexCenter(dc.org_x, dc.len_x, dc.tex_x, x, dc.n_x, dc.rev_x);
@@ -581,8 +585,10 @@ __global__ __launch_bounds__(256) void k_copy(Surface in, int out_w, int out_h, 
 // the weights depend on — takes 1/step values per axis, exactly (every term of the shader's expression is exact in fp32
 // there), so the 16 weights and their sum come from a <= 4 x 4 phase table built on the host with the shader's own
 // expressions instead of 16 x (sqrt, 2 sin, divide) per pixel.  The accumulation is k_jinc2's, in the same order.
-__global__ __launch_bounds__(256) void k_jinc2_phases(Surface in, DrawCoords dc, const JincPhases *__restrict__ tab, int out_w, int out_h, StoreParams st)
+__global__ __launch_bounds__(256) void k_jinc2_phases(Surface in, DrawCoords dc, const JincPhases *__restrict__ tab, int out_w, int out_h, StoreParams st, ResizeBatch bt)
 {
+    in.ptr = (uint8_t *)in.ptr + (size_t)blockIdx.z * bt.in_stride;        // a batch: frame z's texture and target (vp_launch.h)
+    st.dst = bt.frames ? bt.frames[blockIdx.z].dst : (void *)((uint8_t *)st.dst + (size_t)blockIdx.z * bt.dst_stride);
     // the 64 x 4 outputs of the workgroup read at most (64 + 4) x (4 + 4) source texels (step <= 1): decoded once into LDS
     // (with the clamp addressing applied there), the 16 taps of a pixel are LDS reads
     constexpr int TW = 68, THh = 8;
@@ -986,12 +992,15 @@ hipError_t LaunchResize(int axis, bool swap, const Surface &in, const AxisTaps &
         else if (in.fmt == SF_RGBA16F) done = LaunchResizeFastN<SF_RGBA16F>(epi, rows, in, taps, other, out_w, out_h, st, s, bt);
         if (done) return hipGetLastError();
     }
-    if (batch && batch->n != 1) return hipErrorNotSupported;
-    const dim3 g = grid2d(out_w, out_h), b(64, 4, 1);
-    if (axis == 0 && !swap) hipLaunchKernelGGL((k_resize<0, false>), g, b, 0, s, in, taps, other, out_w, out_h, st);
-    else if (axis == 0)     hipLaunchKernelGGL((k_resize<0, true>), g, b, 0, s, in, taps, other, out_w, out_h, st);
-    else if (!swap)         hipLaunchKernelGGL((k_resize<1, false>), g, b, 0, s, in, taps, other, out_w, out_h, st);
-    else                    hipLaunchKernelGGL((k_resize<1, true>), g, b, 0, s, in, taps, other, out_w, out_h, st);
+    // the one-kernel-fits-all version (quarter turns, tap tables without a block structure): a frame dimension like the folded ones
+    const ResizeBatch one{}, &gb = batch ? *batch : one;
+    dim3 g = grid2d(out_w, out_h);
+    g.z = (unsigned)gb.n;
+    const dim3 b(64, 4, 1);
+    if (axis == 0 && !swap) hipLaunchKernelGGL((k_resize<0, false>), g, b, 0, s, in, taps, other, out_w, out_h, st, gb);
+    else if (axis == 0)     hipLaunchKernelGGL((k_resize<0, true>), g, b, 0, s, in, taps, other, out_w, out_h, st, gb);
+    else if (!swap)         hipLaunchKernelGGL((k_resize<1, false>), g, b, 0, s, in, taps, other, out_w, out_h, st, gb);
+    else                    hipLaunchKernelGGL((k_resize<1, true>), g, b, 0, s, in, taps, other, out_w, out_h, st, gb);
     return hipGetLastError();
 }
 
@@ -1035,15 +1044,19 @@ bool BuildJincPhases(const DrawCoords &dc, void *out_table)
 }
 size_t JincPhasesBytes() { return sizeof(JincPhases); }
 
-hipError_t LaunchJinc2(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st, hipStream_t s, const void *phases_dev, bool fast)
+hipError_t LaunchJinc2(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st, hipStream_t s, const void *phases_dev, bool fast,
+                       const ResizeBatch *batch)
 {
     // exact 2x on both axes, default tier: a 2x2 output quad per lane (vp_jinc.hip)
-    if (fast && phases_dev && Jinc2QuadSupported(in, dc, out_w, out_h, st)) return LaunchJinc2Quad(in, dc, out_w, out_h, st, s, phases_dev);
+    if (fast && phases_dev && Jinc2QuadSupported(in, dc, out_w, out_h, st)) return LaunchJinc2Quad(in, dc, out_w, out_h, st, s, phases_dev, batch);
+    const ResizeBatch one{}, &gb = batch ? *batch : one;
+    dim3 g = grid2d(out_w, out_h);
+    g.z = (unsigned)gb.n;
     if (phases_dev) {
-        hipLaunchKernelGGL(k_jinc2_phases, grid2d(out_w, out_h), dim3(64, 4, 1), 0, s, in, dc, (const JincPhases *)phases_dev, out_w, out_h, st);
+        hipLaunchKernelGGL(k_jinc2_phases, g, dim3(64, 4, 1), 0, s, in, dc, (const JincPhases *)phases_dev, out_w, out_h, st, gb);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_jinc2, grid2d(out_w, out_h), dim3(64, 4, 1), 0, s, in, dc, out_w, out_h, st);
+    hipLaunchKernelGGL(k_jinc2, g, dim3(64, 4, 1), 0, s, in, dc, out_w, out_h, st, gb);
     return hipGetLastError();
 }
 

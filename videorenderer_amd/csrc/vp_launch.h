@@ -19,8 +19,8 @@ hipError_t LaunchRepackRgb(int kind, const uint8_t *src, int src_pitch, uint8_t 
 hipError_t LaunchRepackV210(const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int lines, hipStream_t s,
                             const void *const *srcs = nullptr, int n = 1, size_t dst_stride = 0);
 // axis = screen axis the tap table runs along; swap = rotation 90/270 (taps address the other texture axis)
-// batch: n frames per launch (folded kernels only) — frame z reads in.ptr + z * in_stride and writes frames[z].dst when a
-// frame table is given, else st.dst + z * dst_stride.  Returns hipErrorNotSupported when the draw has no folded kernel.
+// batch: n frames per launch — frame z reads in.ptr + z * in_stride and writes frames[z].dst when a
+// frame table is given, else st.dst + z * dst_stride (the folded kernels and the one-kernel-fits-all versions alike).
 struct FusedFrame;
 struct ResizeBatch { int n = 1; size_t in_stride = 0, dst_stride = 0; const FusedFrame *frames = nullptr; int dst_aligned8 = 1; /* every frames[z].dst on an 8-byte boundary */ };
 hipError_t LaunchResize(int axis, bool swap, const Surface &in, const AxisTaps &taps, const int32_t *other,
@@ -42,7 +42,7 @@ hipError_t LaunchHdr10ToneMap(const Surface &in, const HdrToneMapParams &tm, int
 // phases_dev: device copy of the table BuildJincPhases filled (dyadic, unrotated draws: weights per phase instead of per pixel)
 // fast: the default tier may take the quad kernel (exact 2x; FMA contraction) instead of the phase-table kernel
 hipError_t LaunchJinc2(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st, hipStream_t s,
-                       const void *phases_dev = nullptr, bool fast = false);
+                       const void *phases_dev = nullptr, bool fast = false, const ResizeBatch *batch = nullptr);
 // vp_jinc.hip: Jinc2m at exactly 2x on both axes, one 2x2 output quad per lane (25 LDS texel reads for 4 pixels instead of 64)
 bool Jinc2QuadSupported(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st);
 hipError_t LaunchJinc2Quad(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st, hipStream_t s, const void *phases_dev,
