@@ -374,6 +374,21 @@ struct DoviRegs {
     uint32_t methods[3], mmr_single[3], min_order[3], max_order[3];
     int has_mmr;
 };
+// Workgroups are dealt round-robin to the 8 XCDs in launch order (x fastest, then z here: the grids are (items, 1, frames)), and each
+// XCD has its own L2.  The waves of neighbouring strips read the same 128-byte lines at their seams and neighbouring segments the same
+// source rows: give XCD k the k-th contiguous range of the launch's (frame, item) sequence instead of every 8th workgroup of it, so a
+// seam is fetched once (round 4: the periodic kernel's FETCH_SIZE was 1.11x the algorithmic bytes with the plain mapping).
+// A bijection on [0, gridDim.x * gridDim.z) for any size; wave-uniform scalar arithmetic.
+__device__ __forceinline__ void xcd_contiguous_block(int &bx, int &bz)
+{
+    const int gx = (int)gridDim.x, total = gx * (int)gridDim.z;
+    const int g = (int)blockIdx.x + gx * (int)blockIdx.z;
+    const int per = total >> 3, rem = total & 7, xcd = g & 7, idx = g >> 3;
+    const int gp = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
+    bz = gp / gx;
+    bx = gp - bz * gx;
+}
+
 template <typename T> using dv_cptr = const __attribute__((address_space(4))) T *;
 __device__ __forceinline__ void load_dovi_regs(const DoviParams *g, DoviRegs &R)
 {

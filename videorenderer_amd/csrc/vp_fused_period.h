@@ -140,7 +140,9 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int item = blockIdx.x * (int)(blockDim.x >> 6) + wave;
+    int bx, bz;
+    xcd_contiguous_block(bx, bz);                                     // (workgroup -> (item group, frame): an XCD works on neighbours, vp_fused_dev.h)
+    const int item = bx * (int)(blockDim.x >> 6) + wave;
     const int seg_i = item / Q.n_strips, strip = item - seg_i * Q.n_strips;
     const int y0 = seg_i * Q.seg_rows;                                  // a multiple of PB (launcher)
     if (y0 >= Q.out_h) return;
@@ -148,12 +150,12 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
     const int W = P.W, H = P.H;
     unsigned char *const Aw = wbase + wave * (Q.acols * 24);
 
-    const FusedFrame frame = frames ? frames[blockIdx.z] : single;
+    const FusedFrame frame = frames ? frames[bz] : single;
     auto uniform_ptr = [](const void *q) {
         const uint64_t v = (uint64_t)q;
         return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
     };
-    const gcptr py = (gcptr)uniform_ptr(SRC == SRC_SURFACE && Q.surf ? (const void *)(Q.surf + (size_t)blockIdx.z * Q.surf_stride) : (const void *)frame.src);
+    const gcptr py = (gcptr)uniform_ptr(SRC == SRC_SURFACE && Q.surf ? (const void *)(Q.surf + (size_t)bz * Q.surf_stride) : (const void *)frame.src);
     const uint64_t dst_u = uniform_ptr(frame.dst);
     const gptr pdst = (gptr)dst_u;
 
