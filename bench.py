@@ -39,6 +39,10 @@ WORKLOADS = {
     # config 4's optional extension run (the reference has no Spline36: IVideoRenderer.h:54-62; unpinned, reported separately)
     "c4ext": dict(cformat=2, w=3840, h=2160, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
                   iUpscaling=6, desc="4K P010 HDR10 -> Spline36 (extension) 2x -> PQ->SDR -> ordered dither -> 8K BGRA8"),
+    # config 4 as BASELINE.json words it: Spline36 (extension) + error-diffusion dither (extension, bUseDither = 2: no reference counterpart, parity unpinned) —
+    # the 10-bit plan's fused launch per batch + ONE k_error_diffusion launch (a serial chain of W + 2H steps per frame: VALU-issue and depth bound, not HBM)
+    "c4ed": dict(cformat=2, w=3840, h=2160, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
+                 iUpscaling=6, bUseDither=2, desc="4K P010 HDR10 -> Spline36 (extension) 2x -> PQ->SDR -> error-diffusion dither (extension) -> 8K BGRA8"),
     "c5": dict(cformat=2, w=3840, h=2160, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=16),
                iUpscaling=4, desc="4K P010 HLG -> Lanczos3 2x -> HLG->SDR -> ordered dither -> 8K BGRA8"),
     "c2": dict(cformat=20, w=1920, h=1080, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=1, primaries=2, transfer=5),
@@ -269,7 +273,7 @@ def main():
         dw, dh = w * s, h * s
     extfmt = api.make_extfmt(**wl["ext"])
     settings = api.default_settings(iUpscaling=wl["iUpscaling"], iDownscaling=wl.get("iDownscaling", 2), flags=args.flags,
-                                    output_format=wl.get("output_format", 0))
+                                    output_format=wl.get("output_format", 0), bUseDither=wl.get("bUseDither", 1))
     # One explicit (non-default) HIP stream shared by torch and the context: the kernels are launched on it and the
     # torch.cuda.Event pairs below are recorded on it, so they bracket exactly the launches of a step.
     stream = torch.cuda.Stream()
@@ -400,7 +404,7 @@ def main():
         res_pf = {}
         for label, extra in (("frame_lanes", 0), ("one_after_the_other", api.FLAG_NO_FRAME_LANES)):
             st2 = api.default_settings(iUpscaling=wl["iUpscaling"], iDownscaling=wl.get("iDownscaling", 2), flags=args.flags | extra,
-                                       output_format=wl.get("output_format", 0))
+                                       output_format=wl.get("output_format", 0), bUseDither=wl.get("bUseDither", 1))
             vp2 = api.VideoProcessor(st2, device=dev, use_torch_stream=False)
             vp2.InitMediaType(wl["cformat"], w, h, extfmt=extfmt)
             if wl.get("hdr_output"):

@@ -66,6 +66,14 @@ enum { MPCVR_UPSCALE_Nearest = 0, MPCVR_UPSCALE_Mitchell = 1, MPCVR_UPSCALE_Catm
 enum { MPCVR_DOWNSCALE_Box = 0, MPCVR_DOWNSCALE_Bilinear = 1, MPCVR_DOWNSCALE_Hamming = 2,
        MPCVR_DOWNSCALE_Bicubic = 3, MPCVR_DOWNSCALE_BicubicSharp = 4, MPCVR_DOWNSCALE_Lanczos = 5 };
 
+/* mpcvr_settings.bUseDither: 0 / 1 as the reference's bool (Settings_t::bUseDither, IVideoRenderer.h:117: the ordered dither of
+ * ps_final_pass.hlsl).  EXTENSION — 2 is not a reference setting (the reference has no error diffusion at all): BASELINE.json config 4's
+ * "error-diffusion dither".  Where the reference would run its final pass into an 8-bit target (internal format above 8 bits), the
+ * frame is rendered as for a 10-bit swap chain (R10G10B10A2, no final pass) and Floyd-Steinberg error diffusion in integers takes it
+ * to B8G8R8A8 inside video rect ∩ window (definition: csrc/vp_errdiff_core.h; the serial model in oracle/ is its only check).  On a
+ * 10-bit target or with the 8-bit internal format it changes nothing, like bUseDither = 1 there.  Regions up to ~13,400 columns. */
+enum { MPCVR_DITHER_None = 0, MPCVR_DITHER_Ordered = 1, MPCVR_DITHER_ErrorDiffusion_EXT = 2 };
+
 /* Render-target format: stands in for the display-driven m_SwapChainFmt decision
  * (DX11VideoProcessor.cpp:1476-1478, Preferred10BitOutput DX11VideoProcessor.h:290-292). */
 enum { MPCVR_OUT_BGRA8 = 0, MPCVR_OUT_RGB10A2 = 1 };
@@ -101,7 +109,7 @@ typedef struct mpcvr_settings {
     int32_t  iUpscaling;          /* MPCVR_UPSCALE_*           default CatmullRom*/
     int32_t  iDownscaling;        /* MPCVR_DOWNSCALE_*         default Hamming   */
     int32_t  bInterpolateAt50pct; /*                           default 1         */
-    int32_t  bUseDither;          /*                           default 1         */
+    int32_t  bUseDither;          /* MPCVR_DITHER_*            default 1 (Ordered) */
     int32_t  bDeintBlend;         /* blend-deinterlace 4:2:0 samples flagged interlaced (mpcvr_set_sample_format) */
     int32_t  bConvertToSdr;       /*                           default 1         */
     int32_t  iSDRDisplayNits;     /* 25..400                   default 125       */

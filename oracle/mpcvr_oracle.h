@@ -213,6 +213,9 @@ void orc_repack_rgb(int kind, int lines, uint8_t *dst, int dst_pitch, const uint
 void orc_copy_plane_as_is(unsigned lines, uint8_t *dst, unsigned dst_pitch, const uint8_t *src, int src_pitch);
 void orc_copy_plane_10to16(unsigned lines, uint8_t *dst, unsigned dst_pitch, const uint8_t *src, int src_pitch);
 
+/* sensitivity probe: the interpolated texture coordinate of every draw arrives `bias` ulps off the modelled rasteriser's (0 = the model) */
+void orc_set_tex_ulp_bias(int bias);
+
 /* Whole Process() on the shader path — DX11VideoProcessor.cpp:3285-3424.
  * src: the media-sample bytes (planes back to back, MemCopyToTexSrcVideo layout :1213-1252), src_pitch >0.
  * dither_f16: the 32x32 fp16 threshold table (Source/res/dither32x32float16.bin).
@@ -225,6 +228,10 @@ int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
 /* Convert pass only: writes the m_TexConvertOutput contents as float RGBA (already quantised to the
  * internal format), rect_w*rect_h*4 floats.  Returns internal format (8,10,16) or <0. */
 int orc_convert_only(const orc_params *p, const uint8_t *src, int src_pitch, float *rgba_out);
+
+/* EXTENSION (no reference counterpart, parity unpinned): the error-diffusion final pass, bUseDither = 2 — Floyd-Steinberg in integers
+ * over [x0, x1) x [y0, y1) of an R10G10B10A2 window image into a B8G8R8A8 one; definition at the function (mpcvr_oracle.c). */
+int orc_error_diffusion(const uint32_t *src10, int src_pitch, uint8_t *dst, int dst_pitch, int x0, int y0, int x1, int y1);
 
 /* number of OpenMP threads the oracle will use (1 if built without OpenMP) */
 int orc_num_threads(void);

@@ -206,12 +206,15 @@ def lib():
         L.orc_dovi_l1_nits.argtypes = [C.POINTER(OrcDovi), C.POINTER(C.c_uint32)]
         L.orc_set_pow_ulp_bias.argtypes = [C.c_int]
         L.orc_set_pow_ulp_noise.argtypes = [C.c_int, C.c_uint32]
+        L.orc_set_tex_ulp_bias.argtypes = [C.c_int]
         L.orc_hdr10_params.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_uint32)]
         L.orc_specify_extfmt.restype = C.c_uint32
         L.orc_specify_extfmt.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int]
         L.orc_correction_pass.restype = C.c_int
         L.orc_correction_pass.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_correction_matrices.argtypes = [fp, fp, fp]
+        L.orc_error_diffusion.restype = C.c_int
+        L.orc_error_diffusion.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_num_threads(min(int(L.orc_num_threads()), host_cpus()))
@@ -303,6 +306,35 @@ def process(p, frame, pitch, dither=None, dst=None):
     return dst
 
 
+def error_diffusion(img10, rect=None, dst=None):
+    """EXTENSION (bUseDither = 2; no reference counterpart): the serial error-diffusion model over rect = (x0, y0, x1, y1) of an
+    (h, w) uint32 R10G10B10A2 image; returns (h, w, 4) uint8 B8G8R8A8, untouched (zero) outside the rect."""
+    img10 = np.ascontiguousarray(img10, dtype=np.uint32)
+    h, w = img10.shape
+    x0, y0, x1, y1 = rect if rect is not None else (0, 0, w, h)
+    if dst is None:
+        dst = np.zeros((h, w, 4), dtype=np.uint8)
+    rc = lib().orc_error_diffusion(img10.ctypes.data, w * 4, dst.ctypes.data, w * 4, int(x0), int(y0), int(x1), int(y1))
+    if rc != 0:
+        raise RuntimeError(f"orc_error_diffusion failed: {rc}")
+    return dst
+
+
+def process_errdiff(p, frame, pitch):
+    """bUseDither = 2 as the product defines it: the frame as a 10-bit swap chain would receive it (no final pass), then the serial
+    error diffusion inside video rect ∩ window."""
+    import copy
+    keep = (p.output_format,)
+    p.output_format = 1             # ORC_OUT_RGB10A2
+    try:
+        img10 = process(p, frame, pitch).view(np.uint32)[:, :, 0]
+    finally:
+        p.output_format = keep[0]
+    x0, y0 = max(p.video_rect[0], 0), max(p.video_rect[1], 0)
+    x1, y1 = min(p.video_rect[2], p.window_w), min(p.video_rect[3], p.window_h)
+    return error_diffusion(img10, (x0, y0, x1, y1))
+
+
 def process_with_pow_bias(p, frame, pitch, bias, dst=None, seed=0):
     """process() with every pow() of the HDR / Dolby Vision chains answering `bias` ulps off (the sensitivity probe); seed != 0: each
     call by its own hash-drawn amount in [-bias, +bias] instead."""
@@ -314,6 +346,15 @@ def process_with_pow_bias(p, frame, pitch, bias, dst=None, seed=0):
         return process(p, frame, pitch, dst=dst)
     finally:
         lib().orc_set_pow_ulp_bias(0)
+
+
+def process_with_tex_bias(p, frame, pitch, bias):
+    """process() with every draw's interpolated texture coordinate `bias` ulps off the modelled rasteriser's (sensitivity probe)."""
+    lib().orc_set_tex_ulp_bias(int(bias))
+    try:
+        return process(p, frame, pitch)
+    finally:
+        lib().orc_set_tex_ulp_bias(0)
 
 
 def convert_only(p, frame, pitch):

@@ -70,7 +70,7 @@ def test_gpu_suite_launches_every_kernel_family_and_every_headline_instantiation
     with open(os.path.join(HERE, "golden", "kernels_not_launched.json")) as f:
         excused = json.load(f)
     fams = sorted({family(k) for k in built})
-    missing_fam = [f for f in fams if not any(family(k) == f for k in launched)]
+    missing_fam = [f for f in fams if not any(family(k) == f for k in launched) and not all(k in excused for k in built if family(k) == f)]
     assert not missing_fam, f"kernel families the GPU suite never launches ({src}): {missing_fam}"
     report = []
     for fam in fams:

@@ -41,6 +41,7 @@ UPSCALE_Nearest, UPSCALE_Mitchell, UPSCALE_CatmullRom, UPSCALE_Lanczos2, UPSCALE
 UPSCALE_Spline36_EXT = 6          # extension: not a reference setting (IVideoRenderer.h:54-62)
 DOWNSCALE_Box, DOWNSCALE_Bilinear, DOWNSCALE_Hamming, DOWNSCALE_Bicubic, DOWNSCALE_BicubicSharp, DOWNSCALE_Lanczos = range(6)
 OUT_BGRA8, OUT_RGB10A2 = 0, 1
+DITHER_None, DITHER_Ordered, DITHER_ErrorDiffusion_EXT = 0, 1, 2     # bUseDither; 2 is an extension (error diffusion, include/mpcvr.h)
 FLAG_LANCZOS3_FIXED, FLAG_NO_FUSED, FLAG_NO_LUT, FLAG_NO_FAST_CONVERT, FLAG_FUSED_VALU, FLAG_FUSED_MFMA, FLAG_NO_STRIP = 1, 2, 4, 8, 16, 32, 64
 FLAG_NO_PERIOD = 128
 FLAG_FORCE_PERIOD = 256

@@ -60,7 +60,7 @@ CHipVideoProcessor::~CHipVideoProcessor()
     if (!m_bInit && !m_stream && !m_evStart && !m_evStop && !m_dither.ptr) return;
     (void)hipSetDevice(m_device);
     if (m_stream) (void)hipStreamSynchronize(m_stream);
-    for (DevBuffer *b : {&m_batchConv, &m_batchMid, &m_batchPost, &m_batchTex, &m_jincFirst, &m_jincSecond, &m_TexSrcVideo, &m_TexRaw, &m_TexPost, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
+    for (DevBuffer *b : {&m_batchConv, &m_batchMid, &m_batchPost, &m_edPost, &m_batchTex, &m_jincFirst, &m_jincSecond, &m_TexSrcVideo, &m_TexRaw, &m_TexPost, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
                          &m_pqLut, &m_hlgLut, &m_eotfLut, &m_stripTab, &m_tapsXi, &m_tapsXw, &m_tapsXs, &m_tapsYi, &m_tapsYw, &m_tapsYs, &m_otherX, &m_otherY, &m_tapsXb, &m_tapsYb})
         b->Release();
     for (UploadSlot &u : m_up) {
@@ -136,6 +136,7 @@ static bool ValidSettings(const mpcvr_settings &s, std::string *why)
     if (s.iDownscaling < 0 || s.iDownscaling > MPCVR_DOWNSCALE_Lanczos) return bad("iDownscaling");
     if (s.iSDRDisplayNits < 25 || s.iSDRDisplayNits > 400) return bad("iSDRDisplayNits");   // IVideoRenderer.h:87-90
     if (s.output_format != MPCVR_OUT_BGRA8 && s.output_format != MPCVR_OUT_RGB10A2) return bad("output_format");
+    if (s.bUseDither < 0 || s.bUseDither > MPCVR_DITHER_ErrorDiffusion_EXT) return bad("bUseDither");
     return true;
 }
 
@@ -202,6 +203,7 @@ bool CHipVideoProcessor::FrameLanesUsable() const
     static const bool off = [] { const char *e = std::getenv("MPCVR_NO_FRAME_LANES"); return e && *e && *e != '0'; }();
     if (off || !m_ownStream || (m_cfg.flags & MPCVR_FLAG_NO_FRAME_LANES) || m_doviValid || !m_srcParams) return false;
     if (m_srcParams->cformat == MPCVR_CF_V210 || m_srcParams->layout == LAY_RGB || ((uintptr_t)m_curSample & 3) != 0) return false;
+    if (m_plan.errdiff) return false;                 // (the error-diffusion pass reads the context's one intermediate)
     if (m_plan.fused_up2x) return true;
     if (m_strip && !m_plan.hdr_tonemap) return true;
     if (m_plan.direct_convert) return true;
@@ -678,8 +680,8 @@ HRESULT CHipVideoProcessor::UpdatePlan()
             if ((hr = UploadTaps(hx, m_tapsXi, m_tapsXw, m_tapsXs, m_tapsXb, ox, &m_tapsX))) return hr;
             if ((hr = UploadIndex(ox, m_otherX))) return hr;
         }
-        m_jincFirstTab = nullptr;
-        if (m_firstJinc && (hr = UploadJincPhases(m_firstCoords, m_jincFirst, &m_jincFirstTab))) return hr;
+        m_jincFirstTab = nullptr; m_jincFirstCtr = nullptr;
+        if (m_firstJinc && (hr = UploadJincPhases(m_firstCoords, m_jincFirst, &m_jincFirstTab, &m_jincFirstCtr))) return hr;
     }
     if (m_plan.two_pass) {
         // m_TexResize: fp16, dst width x (source extent along screen y) (:3143-3160); the second draw is unrotated
@@ -688,8 +690,8 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         m_midBytes = (size_t)w2 * 8 * mh;
         m_secondJinc = m_plan.ry.kind == RS_UP && m_plan.ry.method == MPCVR_UPSCALE_Jinc2;
         m_secondCoords = DrawCoords{0, w2, 0, 1.0f, 0, mh, 0, (float)mh / (float)h2, 0, w2, mh, w2, h2};
-        m_jincSecondTab = nullptr;
-        if (m_secondJinc && (hr = UploadJincPhases(m_secondCoords, m_jincSecond, &m_jincSecondTab))) return hr;
+        m_jincSecondTab = nullptr; m_jincSecondCtr = nullptr;
+        if (m_secondJinc && (hr = UploadJincPhases(m_secondCoords, m_jincSecond, &m_jincSecondTab, &m_jincSecondCtr))) return hr;
         if (!m_secondJinc) {
             if (!BuildAxisTaps(m_plan.ry, 0, mh, h2, mh, m_cfg.flags, &hy))
                 return Fail(MPCVR_E_NOTIMPL, "resize ratio outside the supported range");
@@ -804,13 +806,20 @@ HRESULT CHipVideoProcessor::UpdatePlan()
 }
 
 // dyadic, unrotated Jinc2m draws take their 16 weights from a phase table (vp_kernels.hip: k_jinc2_phases)
-HRESULT CHipVideoProcessor::UploadJincPhases(const DrawCoords &dc, DevBuffer &buf, const void **tab)
+HRESULT CHipVideoProcessor::UploadJincPhases(const DrawCoords &dc, DevBuffer &buf, const void **tab, const float **ctr)
 {
-    *tab = nullptr;
-    if (m_cfg.flags & MPCVR_FLAG_NO_FUSED) return MPCVR_S_OK;
-    std::vector<unsigned char> host(JincPhasesBytes());
-    if (!BuildJincPhases(dc, host.data())) return MPCVR_S_OK;
+    *tab = nullptr; *ctr = nullptr;
     HRESULT hr;
+    std::vector<unsigned char> host(JincPhasesBytes());
+    if ((m_cfg.flags & MPCVR_FLAG_NO_FUSED) || !BuildJincPhases(dc, host.data())) {
+        // the plain kernel: its per-column / per-row texture coordinates as a table (FillVertices' corner values interpolated in fp64, once per index)
+        std::vector<float> c((size_t)dc.n_x + dc.n_y);
+        BuildDrawCentres(dc, c.data());
+        if ((hr = CheckHip(buf.CheckCreate(c.size() * sizeof(float)), "jinc centres"))) return hr;
+        if ((hr = CheckHip(hipMemcpy(buf.ptr, c.data(), c.size() * sizeof(float), hipMemcpyHostToDevice), "jinc centres upload"))) return hr;
+        *ctr = (const float *)buf.ptr;
+        return MPCVR_S_OK;
+    }
     if ((hr = CheckHip(buf.CheckCreate(host.size()), "jinc phases"))) return hr;
     if ((hr = CheckHip(hipMemcpy(buf.ptr, host.data(), host.size(), hipMemcpyHostToDevice), "jinc phases upload"))) return hr;
     *tab = buf.ptr;
@@ -1080,13 +1089,13 @@ HRESULT CHipVideoProcessor::ResizeShaderPass(void *rt, int rtPitch, const uint8_
     } else if (m_plan.two_pass) {
         Surface mid{m_runMid, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
         StoreParams st = MakeStore(mid.ptr, mid.pitch, SF_RGBA16F, false);
-        if (m_firstJinc) hr = CheckHip(LaunchJinc2(conv, m_firstCoords, w2, m_plan.mid_h, st, m_run, m_jincFirstTab, jfast), "k_jinc2");
+        if (m_firstJinc) hr = CheckHip(LaunchJinc2(conv, m_firstCoords, w2, m_plan.mid_h, st, m_run, m_jincFirstTab, jfast, nullptr, m_jincFirstCtr), "k_jinc2");
         else hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, m_plan.mid_h, st, m_run, plain), "k_resize<first>");
         if (hr) return hr;
-        if (m_secondJinc) hr = CheckHip(LaunchJinc2(mid, m_secondCoords, w2, h2, last, m_run, m_jincSecondTab, jfast), "k_jinc2");
+        if (m_secondJinc) hr = CheckHip(LaunchJinc2(mid, m_secondCoords, w2, h2, last, m_run, m_jincSecondTab, jfast, nullptr, m_jincSecondCtr), "k_jinc2");
         else hr = CheckHip(LaunchResize(1, false, mid, m_tapsY, (const int32_t *)m_otherY.ptr, w2, h2, last, m_run, plain), "k_resize<Y>");
     } else if (m_plan.one_pass) {
-        if (m_firstJinc) hr = CheckHip(LaunchJinc2(conv, m_firstCoords, w2, h2, last, m_run, m_jincFirstTab, jfast), "k_jinc2");
+        if (m_firstJinc) hr = CheckHip(LaunchJinc2(conv, m_firstCoords, w2, h2, last, m_run, m_jincFirstTab, jfast, nullptr, m_jincFirstCtr), "k_jinc2");
         else hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, conv, m_tapsX, (const int32_t *)m_otherX.ptr, w2, h2, last, m_run, plain), "k_resize<one>");
     } else {
         drawn = false;
@@ -1214,7 +1223,13 @@ HRESULT CHipVideoProcessor::Process(void *pRenderTarget, int rtPitch, const CRec
     }
     m_clearOnRun = 0;
     (void)hipEventRecord(m_evStart, m_run);
-    hr = ProcessOne(m_curSample, pRenderTarget, rtPitch);
+    if (m_plan.errdiff) {
+        // EXTENSION (bUseDither = 2): the draws render into the window-sized R10G10B10A2 intermediate, as for a 10-bit swap chain; the
+        // error-diffusion pass takes it to the render target
+        if (!(hr = PrepareErrDiff(1)) && !(hr = ProcessOne(m_curSample, m_edPost.ptr, m_edPitch)))
+            hr = ErrDiffPass(1, nullptr, FusedFrame{(const uint8_t *)m_edPost.ptr, pRenderTarget}, &pRenderTarget, rtPitch, m_run);
+    } else
+        hr = ProcessOne(m_curSample, pRenderTarget, rtPitch);
     (void)hipEventRecord(m_evStop, m_run);
     m_lastRun = m_run;
     MarkConsumed();
@@ -1228,7 +1243,10 @@ HRESULT CHipVideoProcessor::Process(void *pRenderTarget, int rtPitch, const CRec
 HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *const *dsts, int rtPitch)
 {
     const unsigned before = m_launches;
-    const HRESULT hr = ProcessBatchRoutes(n, srcs, dsts, rtPitch);
+    HRESULT hr = MPCVR_S_OK;
+    if (m_cfg.bUseDither == MPCVR_DITHER_ErrorDiffusion_EXT && m_bInit && m_srcParams && n > 0 && srcs && dsts && m_planDirty) hr = UpdatePlan();
+    if (!hr) hr = (m_bInit && m_srcParams && n > 0 && srcs && dsts && !m_planDirty && m_plan.errdiff) ? ProcessBatchErrDiff(n, srcs, dsts, rtPitch)
+                                                                                                     : ProcessBatchRoutes(n, srcs, dsts, rtPitch);
     m_lastBatchFrames = n; m_lastBatchLaunches = (int)(m_launches - before);
     return hr;
 }
@@ -1473,6 +1491,62 @@ HRESULT CHipVideoProcessor::ProcessBatchRoutes(int n, const void *const *srcs, v
     return hr;
 }
 
+// ---- EXTENSION: error-diffusion final pass (bUseDither = 2; no reference counterpart, include/mpcvr.h) -----------------------------
+// The plan of such a context is the 10-bit swap chain's (DecidePlan: swap_fmt = SF_RGB10A2, no final pass for UNORM internal formats),
+// so every kernel of the library — fused, batched, Dolby Vision — runs as it does for a 10-bit target; only the target differs: a
+// window-sized intermediate per frame, from which k_error_diffusion writes the B8G8R8A8 render target inside video rect ∩ window.
+HRESULT CHipVideoProcessor::PrepareErrDiff(int frames)
+{
+    m_edPitch = (m_windowRect.Width() * 4 + 255) & ~255;
+    m_edStride = (size_t)m_edPitch * (size_t)m_windowRect.Height();
+    // (+ 256: the pass reads pixel pairs, the last one may end one pixel behind the last row)
+    return CheckHip(m_edPost.CheckCreate(m_edStride * (size_t)frames + 256), "error-diffusion intermediates");
+}
+
+HRESULT CHipVideoProcessor::ErrDiffPass(int n, const FusedFrame *table, FusedFrame single, void *const *dsts, int rtPitch, hipStream_t s)
+{
+    ErrDiffParams P{};
+    P.x0 = std::max((int)m_videoRect.left, 0); P.y0 = std::max((int)m_videoRect.top, 0);
+    P.x1 = std::min((int)m_videoRect.right, m_windowRect.Width()); P.y1 = std::min((int)m_videoRect.bottom, m_windowRect.Height());
+    if (P.x1 <= P.x0 || P.y1 <= P.y0) return MPCVR_S_OK;          // the video rect lies outside the window: nothing is drawn
+    P.src_pitch = m_edPitch; P.dst_pitch = rtPitch;
+    P.pair_stores = (rtPitch & 7) == 0;
+    for (int i = 0; i < n; i++)
+        if (((uintptr_t)dsts[i] & 7) != 0) P.pair_stores = 0;
+    const char *shift = std::getenv("MPCVR_ERRDIFF_SHIFT");          // (read per call: the suite runs both variants in one process)
+    P.shift = shift && std::strcmp(shift, "bpermute") == 0 ? 1 : 0;
+    if (!ErrorDiffusionSupported(P)) return Fail(MPCVR_E_INVALIDARG, "error diffusion (bUseDither = 2): the region is wider than the pass's LDS row buffer holds (~13,400 columns)");
+    return CheckHip(LaunchErrorDiffusion(P, table, single, n, s), "k_error_diffusion");
+}
+
+HRESULT CHipVideoProcessor::ProcessBatchErrDiff(int n, const void *const *srcs, void *const *dsts, int rtPitch)
+{
+    if (rtPitch < m_windowRect.Width() * 4) return Fail(MPCVR_E_INVALIDARG, "render-target pitch smaller than a row");
+    for (int i = 0; i < n; i++)
+        if (!srcs[i] || !dsts[i]) return Fail(MPCVR_E_POINTER, "null frame in batch");
+    (void)hipSetDevice(m_device);
+    HRESULT hr;
+    const size_t one = ((size_t)((m_windowRect.Width() * 4 + 255) & ~255)) * (size_t)m_windowRect.Height();
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)4 << 30) / std::max<size_t>(one, 1)));
+    if ((hr = PrepareErrDiff(chunk))) return hr;
+    std::vector<void *> mids(chunk);
+    for (int i = 0; i < chunk; i++) mids[i] = (uint8_t *)m_edPost.ptr + (size_t)i * m_edStride;
+    for (int at = 0; at < n; at += chunk) {
+        const int m = std::min(chunk, n - at);
+        // the whole-batch routes of the 10-bit plan, into the intermediates (the previous chunk's pass reads them in stream order)
+        if ((hr = ProcessBatchRoutes(m, srcs + at, mids.data(), m_edPitch))) return hr;
+        const FusedFrame *tab = nullptr;
+        hipEvent_t done = nullptr;
+        if ((hr = UploadFrameTable(m, (const void *const *)mids.data(), dsts + at, nullptr, 0, &tab, &done))) return hr;
+        hr = ErrDiffPass(m, tab, FusedFrame{nullptr, nullptr}, dsts + at, rtPitch, m_stream);
+        (void)hipEventRecord(done, m_stream);
+        if (hr) return hr;
+    }
+    (void)hipEventRecord(m_evStop, m_stream);       // (the batch's process time includes the pass)
+    m_timed = true;
+    return MPCVR_S_OK;
+}
+
 HRESULT CHipVideoProcessor::UploadFrameTable(int n, const void *const *srcs, void *const *dsts, uint8_t *dst_base, size_t dst_stride, const FusedFrame **dev, hipEvent_t *done)
 {
     HRESULT hr;
@@ -1583,16 +1657,16 @@ HRESULT CHipVideoProcessor::ProcessBatchLaunches(int n, const FusedFrame *table,
             const Surface mid{m_batchMid.ptr, w2 * 8, w2, m_plan.mid_h, SF_RGBA16F};
             b1.dst_stride = m_midBytes;
             const StoreParams st = MakeStore(mid.ptr, mid.pitch, SF_RGBA16F, false);
-            if (m_firstJinc) hr = CheckHip(LaunchJinc2(cs, m_firstCoords, w2, m_plan.mid_h, st, m_stream, m_jincFirstTab, true, &b1), "k_jinc2");
+            if (m_firstJinc) hr = CheckHip(LaunchJinc2(cs, m_firstCoords, w2, m_plan.mid_h, st, m_stream, m_jincFirstTab, true, &b1, m_jincFirstCtr), "k_jinc2");
             else hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, cs, m_tapsX, (const int32_t *)m_otherX.ptr, w2, m_plan.mid_h, st, m_stream, false, &b1), "k_resize<first>");
             if (hr) return hr;
             ResizeBatch b2; b2.n = m; b2.in_stride = m_midBytes; b2.frames = tab; b2.dst_aligned8 = aligned ? 1 : 0;
-            if (m_secondJinc) hr = CheckHip(LaunchJinc2(mid, m_secondCoords, w2, h2, final, m_stream, m_jincSecondTab, true, &b2), "k_jinc2");
+            if (m_secondJinc) hr = CheckHip(LaunchJinc2(mid, m_secondCoords, w2, h2, final, m_stream, m_jincSecondTab, true, &b2, m_jincSecondCtr), "k_jinc2");
             else hr = CheckHip(LaunchResize(1, false, mid, m_tapsY, (const int32_t *)m_otherY.ptr, w2, h2, final, m_stream, false, &b2), "k_resize<Y>");
             if (hr) return hr;
         } else if (m_firstJinc) {
             b1.frames = tab; b1.dst_aligned8 = aligned ? 1 : 0;
-            if ((hr = CheckHip(LaunchJinc2(cs, m_firstCoords, w2, h2, final, m_stream, m_jincFirstTab, true, &b1), "k_jinc2"))) return hr;
+            if ((hr = CheckHip(LaunchJinc2(cs, m_firstCoords, w2, h2, final, m_stream, m_jincFirstTab, true, &b1, m_jincFirstCtr), "k_jinc2"))) return hr;
         } else if (drawn) {
             b1.frames = tab;
             if ((hr = CheckHip(LaunchResize(m_firstAxis, m_firstSwap, cs, m_tapsX, (const int32_t *)m_otherX.ptr, w2, h2, final, m_stream, false, &b1), "k_resize<one>"))) return hr;

@@ -268,6 +268,14 @@ private:
     // whole-batch launches of the pass-per-kernel path (block convert + folded resize kernels with a frame dimension)
     DevBuffer m_batchConv, m_batchMid;
     DevBuffer m_batchPost;         // HDR10 tone-mapping step of a batch: the frames' m_TexsPostScale copies side by side
+    // EXTENSION (bUseDither = 2, m_plan.errdiff): the frames as a 10-bit swap chain would receive them, window geometry, side by side;
+    // the error-diffusion pass (vp_errdiff.hip) reads them and writes the real render targets
+    DevBuffer m_edPost;
+    int m_edPitch = 0;             // bytes per row of an intermediate (a multiple of 256)
+    size_t m_edStride = 0;         // bytes per intermediate
+    HRESULT PrepareErrDiff(int frames);
+    HRESULT ErrDiffPass(int n, const FusedFrame *table, FusedFrame single, void *const *dsts, int rtPitch, hipStream_t s);
+    HRESULT ProcessBatchErrDiff(int n, const void *const *srcs, void *const *dsts, int rtPitch);
     size_t PostStride() const { return (m_postBytes + 255) & ~(size_t)255; }
     // a frame table in a slot of the ring (pinned copy + device copy): frame i = {srcs ? srcs[i] : null, dsts ? dsts[i] : dst_base + i * dst_stride}
     HRESULT UploadFrameTable(int n, const void *const *srcs, void *const *dsts, uint8_t *dst_base, size_t dst_stride, const FusedFrame **dev, hipEvent_t *done);
@@ -279,7 +287,8 @@ private:
     // Jinc2m phase tables of the first / second draw (null: weights per pixel)
     DevBuffer m_jincFirst, m_jincSecond;
     const void *m_jincFirstTab = nullptr, *m_jincSecondTab = nullptr;
-    HRESULT UploadJincPhases(const DrawCoords &dc, DevBuffer &buf, const void **tab);
+    const float *m_jincFirstCtr = nullptr, *m_jincSecondCtr = nullptr;     // the plain kernel's texcoord tables (no phase table: BuildDrawCentres), in the same buffers
+    HRESULT UploadJincPhases(const DrawCoords &dc, DevBuffer &buf, const void **tab, const float **ctr);
     // arbitrary-ratio fused kernel (vp_fused_strip.hip): geometry planned with the tap tables (UpdatePlan)
     bool m_strip = false;          // raw 4:2:0 sample -> render target in one kernel
     bool m_stripSurf = false;      // any other source: the convert kernel's output (or the RGB source texture) -> render target through the same kernel, no convert stage

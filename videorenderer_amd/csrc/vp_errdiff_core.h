@@ -1,0 +1,117 @@
+// vp_errdiff_core.h — the arithmetic and the wavefront schedule of the error-diffusion final pass (EXTENSION: bUseDither = 2,
+// MPCVR_DITHER_ErrorDiffusion_EXT).  The reference has no such pass (its final pass is the ordered dither of ps_final_pass.hlsl;
+// `grep -ri diffusion` over the reference is empty): BASELINE.json's config 4 names it, nothing pins it.  So the definition below IS
+// the specification, in integers so that a GPU schedule and a serial loop cannot differ by a rounding:
+//
+//   the frame is rendered as for a 10-bit swap chain (R10G10B10A2, no final pass); inside (video rect ∩ window), rows top to bottom,
+//   every row left to right, per channel, with U = 16 * 1023 error units per 8-bit code:
+//       T  = 4080 k + E(x, y)                        k = the UNORM10 code (k / 1023 * 255 codes = 4080 k units), E = errors received
+//       q  = clamp(floor((T + U / 2) / U), 0, 255)   the 8-bit code stored
+//       e  = T - q U
+//       right (7 e) >> 4, below-left (3 e) >> 4, below (5 e) >> 4 (arithmetic shifts = floor), below-right the remainder
+//   (Floyd-Steinberg weights; what falls outside the region is dropped; alpha = 0xFF).
+//
+// Schedule: pixel (x, y) needs (x-1, y), (x-1, y-1), (x, y-1), (x+1, y-1), so row y may run two columns behind row y-1.  A wavefront
+// owns a BAND of 64 rows, lane i = row i, at step t lane i works on column t - 2 i; what a row passes to the row below,
+//       D(x) = below-right(x-1) + below(x) + below-left(x+1),
+// is complete one step before the lane below needs it and travels there by one DPP wave shift per step.  The bottom row of a band
+// leaves its D in an LDS row buffer for the top row of the next band, which another wave of the workgroup runs two SLOTS (of 128
+// steps, one workgroup barrier each) later.  This header holds everything a host emulation of that schedule shares with the kernel
+// (tests/tools/errdiff_emulate.cpp: the schedule against the serial model, no GPU needed).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MPCVR_ED_HD __host__ __device__ __forceinline__
+#else
+#define MPCVR_ED_HD inline
+#endif
+
+namespace mpcvr {
+
+constexpr int kEdUnit = 16 * 1023;        // error units per 8-bit code
+constexpr int kEdCode = 16 * 255;         // one UNORM10 code in those units
+constexpr int kEdRows = 64;               // rows per band = lanes of a wavefront
+constexpr int kEdSkew = 2;                // columns a row runs behind the row above
+constexpr int kEdChunk = 128;             // steps per slot
+constexpr int kEdLag = 2;                 // slots a band starts behind the band above: (kEdLag - 1) * kEdChunk >= kEdSkew * (kEdRows - 1) + 1
+constexpr int kEdWaves = 16;              // waves per workgroup = bands in flight per frame
+static_assert((kEdLag - 1) * kEdChunk >= kEdSkew * (kEdRows - 1) + 1, "a band must find the row buffer filled one column ahead");
+
+// floor((T + U / 2) / U) clamped to a byte.  T + U/2 + 16 U is positive for every reachable T (|E| stays within a few U) and below
+// 2^23; n = that >> 4 is below 2^19, where floor(n / 1023) = mulhi(n, ceil(2^32 / 1023)) exactly (the excess 1019 n / (1023 * 2^32)
+// stays below 1 / 1023 up to n = 4.2 M) — tests/test_errdiff.py checks the whole range against the division
+constexpr uint32_t kEdMagic = 4198405u;   // ceil(2^32 / 1023)
+MPCVR_ED_HD int ed_quant(int32_t T)
+{
+    const uint32_t n = (uint32_t)(T + kEdUnit / 2 + 16 * kEdUnit) >> 4;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int q = (int)__umulhi(n, kEdMagic) - 16;
+#else
+    const int q = (int)(((uint64_t)n * kEdMagic) >> 32) - 16;
+#endif
+    return q < 0 ? 0 : q > 255 ? 255 : q;
+}
+
+// one channel of one row: what the lane carries from pixel to pixel
+struct EdChannel {
+    int32_t er;          // right share of the previous pixel
+    int32_t b1, br1;     // below / below-right shares of the previous pixel
+    int32_t br2;         // below-right share of the pixel before that
+};
+
+// One step of one channel.  live: the lane stands on a pixel of the region (k = its code, din = D of that column from the row above);
+// otherwise the step only flushes the shares still in flight (e = 0).  dout = D(x - 1) for the row below; returns the 8-bit code.
+MPCVR_ED_HD int ed_step(EdChannel &s, bool live, int k, int32_t din, int32_t &dout)
+{
+    int q = 0;
+    int32_t e = 0;
+    if (live) {
+        const int32_t T = k * kEdCode + s.er + din;
+        q = ed_quant(T);
+        e = T - q * kEdUnit;
+    }
+    const int32_t r = (7 * e) >> 4, bl = (3 * e) >> 4, b = (5 * e) >> 4, br = e - r - bl - b;
+    dout = s.br2 + s.b1 + bl;
+    s.er = r; s.br2 = s.br1; s.br1 = br; s.b1 = b;
+    return q;
+}
+
+// ---- the schedule ----
+// Region columns are counted from A0 = x0 & ~1 (xr = column - A0), so that xr and the step index have the same parity in every lane:
+// a pair of steps (even, odd) covers one 8-byte aligned pixel pair.  wl = x1 - A0 columns, the first x0 - A0 (0 or 1) of them outside.
+struct EdSchedule {
+    int wl;              // columns counted from A0
+    int lead;            // x0 - A0
+    int bands;           // ceil(rows / 64)
+    int slots_per_band;  // ceil((wl + 1 + kEdSkew * 63) / kEdChunk): lane 63 must reach the flush step at xr = wl
+    int round;           // slots between two bands of the same wave
+    int total_slots;     // workgroup barriers of the launch
+};
+MPCVR_ED_HD EdSchedule ed_schedule(int x0, int x1, int rows)
+{
+    EdSchedule s;
+    const int a0 = x0 & ~1;
+    s.wl = x1 - a0; s.lead = x0 - a0;
+    s.bands = (rows + kEdRows - 1) / kEdRows;
+    s.slots_per_band = (s.wl + 1 + kEdSkew * (kEdRows - 1) + kEdChunk - 1) / kEdChunk;
+    s.round = s.slots_per_band > kEdLag * kEdWaves ? s.slots_per_band : kEdLag * kEdWaves;
+    const int rounds = (s.bands + kEdWaves - 1) / kEdWaves;
+    const int last_wave = (s.bands - 1) % kEdWaves;        // the wave that runs the last band
+    s.total_slots = (rounds - 1) * s.round + kEdLag * last_wave + s.slots_per_band;
+    // (a wave of an earlier position in the last round ends earlier; waves beyond the last band idle through the barriers)
+    return s;
+}
+// which (band, chunk) wave w works on in slot `slot`; false: it only meets the barrier
+MPCVR_ED_HD bool ed_slot_work(const EdSchedule &s, int w, int slot, int *band, int *chunk)
+{
+    const int rel = slot - kEdLag * w;
+    if (rel < 0) return false;
+    const int k = rel / s.round, j = rel - k * s.round;
+    const int b = w + kEdWaves * k;
+    if (b >= s.bands || j >= s.slots_per_band) return false;
+    *band = b; *chunk = j;
+    return true;
+}
+
+}  // namespace mpcvr

@@ -516,7 +516,9 @@ __global__ __launch_bounds__(256) void k_resize_2d(Surface in, AxisTaps tx, Axis
 
 // ps_resize_onepass_jinc2.hlsl:44-101 ("Jinc2m"): one 2-D draw — 4x4 texels around the sample position weighted by the
 // windowed jinc of their distance, normalised, then anti-ringing towards the min/max of the inner 2x2 (strength 0.8)
-__global__ __launch_bounds__(256) void k_jinc2(Surface in, DrawCoords dc, int out_w, int out_h, StoreParams st, ResizeBatch bt)
+// ctr: Tex * wh of every output column, then of every output row (BuildDrawCentres: the host evaluates TexCenter once per column and row
+// — its fp64 interpolation and division — instead of every pixel twice on the device)
+__global__ __launch_bounds__(256) void k_jinc2(Surface in, DrawCoords dc, const float *__restrict__ ctr, int out_w, int out_h, StoreParams st, ResizeBatch bt)
 {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= out_w || y >= out_h) return;
@@ -524,8 +526,7 @@ __global__ __launch_bounds__(256) void k_jinc2(Surface in, DrawCoords dc, int ou
     st.dst = bt.frames ? bt.frames[blockIdx.z].dst : (void *)((uint8_t *)st.dst + (size_t)blockIdx.z * bt.dst_stride);
     const float pi = 3.14159274101257324f;                 // acos(-1) folded to fp32
     const float wa = 0.416f * pi, wb = 0.985f * pi;
-    const float cx = TexCenter(dc.org_x, dc.len_x, dc.tex_x, x, dc.n_x, dc.rev_x);
-    const float cy = TexCenter(dc.org_y, dc.len_y, dc.tex_y, y, dc.n_y, dc.rev_y);
+    const float cx = ctr[x], cy = ctr[dc.n_x + y];
     const float pcx = dc.swap ? cy : cx, pcy = dc.swap ? cx : cy;      // pc = Tex * wh
     const float tcx = floorf(pcx - 0.5f) + 0.5f, tcy = floorf(pcy - 0.5f) + 0.5f;
     const int bx = (int)floorf(tcx), by = (int)floorf(tcy);
@@ -1044,8 +1045,15 @@ bool BuildJincPhases(const DrawCoords &dc, void *out_table)
 }
 size_t JincPhasesBytes() { return sizeof(JincPhases); }
 
+// Tex * wh of the draw's output columns [0, n_x) and rows [n_x, n_x + n_y) for the plain Jinc2m kernel: TexCenter, once per index
+void BuildDrawCentres(const DrawCoords &dc, float *out)
+{
+    for (int x = 0; x < dc.n_x; x++) out[x] = TexCenter(dc.org_x, dc.len_x, dc.tex_x, x, dc.n_x, dc.rev_x);
+    for (int y = 0; y < dc.n_y; y++) out[dc.n_x + y] = TexCenter(dc.org_y, dc.len_y, dc.tex_y, y, dc.n_y, dc.rev_y);
+}
+
 hipError_t LaunchJinc2(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st, hipStream_t s, const void *phases_dev, bool fast,
-                       const ResizeBatch *batch)
+                       const ResizeBatch *batch, const float *centres_dev)
 {
     // exact 2x on both axes, default tier: a 2x2 output quad per lane (vp_jinc.hip)
     if (fast && phases_dev && Jinc2QuadSupported(in, dc, out_w, out_h, st)) return LaunchJinc2Quad(in, dc, out_w, out_h, st, s, phases_dev, batch);
@@ -1056,7 +1064,8 @@ hipError_t LaunchJinc2(const Surface &in, const DrawCoords &dc, int out_w, int o
         hipLaunchKernelGGL(k_jinc2_phases, g, dim3(64, 4, 1), 0, s, in, dc, (const JincPhases *)phases_dev, out_w, out_h, st, gb);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_jinc2, g, dim3(64, 4, 1), 0, s, in, dc, out_w, out_h, st, gb);
+    if (!centres_dev || out_w > dc.n_x || out_h > dc.n_y) return hipErrorInvalidValue;       // the plain kernel reads its texcoords from the table
+    hipLaunchKernelGGL(k_jinc2, g, dim3(64, 4, 1), 0, s, in, dc, centres_dev, out_w, out_h, st, gb);
     return hipGetLastError();
 }
 

@@ -41,8 +41,10 @@ hipError_t LaunchHdr10ToneMap(const Surface &in, const HdrToneMapParams &tm, int
 // ps_resize_onepass_jinc2.hlsl: the 2-D Jinc2m draw
 // phases_dev: device copy of the table BuildJincPhases filled (dyadic, unrotated draws: weights per phase instead of per pixel)
 // fast: the default tier may take the quad kernel (exact 2x; FMA contraction) instead of the phase-table kernel
+// centres_dev: device copy of BuildDrawCentres' table (n_x + n_y floats) — what the plain kernel (no phase table) reads its texcoords from
 hipError_t LaunchJinc2(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st, hipStream_t s,
-                       const void *phases_dev = nullptr, bool fast = false, const ResizeBatch *batch = nullptr);
+                       const void *phases_dev = nullptr, bool fast = false, const ResizeBatch *batch = nullptr, const float *centres_dev = nullptr);
+void BuildDrawCentres(const DrawCoords &dc, float *out);       // out: dc.n_x + dc.n_y floats of host memory
 // vp_jinc.hip: Jinc2m at exactly 2x on both axes, one 2x2 output quad per lane (25 LDS texel reads for 4 pixels instead of 64)
 bool Jinc2QuadSupported(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st);
 hipError_t LaunchJinc2Quad(const Surface &in, const DrawCoords &dc, int out_w, int out_h, const StoreParams &st, hipStream_t s, const void *phases_dev,
@@ -76,6 +78,17 @@ struct FusedParams {
     int inflight;             // single-frame launches: frames the host keeps running side by side (the context's frame lanes), 0 / 1 = none.  The
                               // segment rules count them like frames of a batch: four overlapping 4K frames fill the chip with long segments
 };
+// vp_errdiff.hip — the error-diffusion final pass (EXTENSION, bUseDither = 2; definition in vp_errdiff_core.h): frame z's R10G10B10A2 image
+// (frames[z].src, window geometry, src_pitch) -> its B8G8R8A8 render target (frames[z].dst, dst_pitch) inside [x0, x1) x [y0, y1)
+struct ErrDiffParams {
+    int x0, y0, x1, y1;        // video rect ∩ window, window coordinates
+    int src_pitch, dst_pitch;  // bytes; src rows are readable one pixel beyond x1 (the caller's intermediate has the slack)
+    int pair_stores;           // every target and dst_pitch on 8-byte boundaries: one 8-byte store per pixel pair
+    int shift;                 // 0: rows hand their errors down by a DPP wave shift; 1: by ds_bpermute (MPCVR_ERRDIFF_SHIFT=bpermute, A/B)
+};
+bool ErrorDiffusionSupported(const ErrDiffParams &P);       // the LDS row buffer fits (regions up to ~13,400 columns)
+size_t ErrorDiffusionLdsBytes(const ErrDiffParams &P);
+hipError_t LaunchErrorDiffusion(const ErrDiffParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
 bool FusedUp2xSupported(const FusedParams &P);
 bool BlockConvertLayout(const FusedParams &P, bool catmull_420);       // source layout + chroma filter convert_block serves
 // the fused kernel's convert stage as a kernel of its own: 2x2 blocks, shared chroma fetch, table tone map.  P.store describes

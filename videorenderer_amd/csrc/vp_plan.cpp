@@ -780,6 +780,10 @@ bool DecidePlan(int iTexFormat, int iChromaScaling, int iUpscaling, int iDownsca
     case MPCVR_TEXFMT_16FLOAT: p.internal_fmt = SF_RGBA16F; break;
     default: p.internal_fmt = f.CDepth > 8 ? SF_RGB10A2 : SF_BGRA8; break;
     }
+    // EXTENSION, bUseDither = 2 (no reference counterpart): where the reference's final pass would dither into an 8-bit target, render
+    // as for a 10-bit swap chain and let the error-diffusion pass quantise (include/mpcvr.h, vp_errdiff_core.h)
+    p.errdiff = bUseDither == MPCVR_DITHER_ErrorDiffusion_EXT && output_format != MPCVR_OUT_RGB10A2 && p.internal_fmt != SF_BGRA8;
+    if (p.errdiff) output_format = MPCVR_OUT_RGB10A2;
     p.swap_fmt = output_format == MPCVR_OUT_RGB10A2 ? SF_RGB10A2 : SF_BGRA8;
     const bool needDither = (p.swap_fmt == SF_BGRA8 && p.internal_fmt != SF_BGRA8) ||
                             (p.swap_fmt == SF_RGB10A2 && p.internal_fmt == SF_RGBA16F);   // :2896-2900
@@ -835,13 +839,14 @@ bool DecidePlan(int iTexFormat, int iChromaScaling, int iUpscaling, int iDownsca
 
 std::string PassPlan::describe() const
 {
-    if (fused_up2x) return "fused_up2x";
-    if (direct_convert) return final_pass ? "direct:convert+final" : "direct:convert+copy";
+    if (fused_up2x) return errdiff ? "fused_up2x,errdiff" : "fused_up2x";
+    if (direct_convert) return std::string(final_pass ? "direct:convert+final" : "direct:convert+copy") + (errdiff ? ",errdiff" : "");
     std::string s = convert ? "passes:convert" : "passes:source";
     if (two_pass) s += final_pass ? ",resizeX,resizeY+final" : ",resizeX,resizeY";
     else if (one_pass) s += std::string(one_pass_axis == 0 ? ",resizeX" : ",resizeY") + (final_pass ? "+final" : "");
     else s += final_pass ? ",final" : ",copy";
     if (hdr_tonemap) s += ",hdr10tonemap";
+    if (errdiff) s += ",errdiff";
     if (rotation) s += ";rot" + std::to_string(rotation);
     if (flip) s += ";flip";
     return s;

@@ -183,6 +183,8 @@ struct PassPlan {
     int mid_h = 0;                   // height of m_TexResize in the two-pass case (srcRect extent along screen y)
     bool hdr_tonemap = false;        // ps_hdr10_tonemap step between the resize and the final pass / render target
     bool convert = true;             // ConvertColorPass runs; false: the source texture feeds the resize directly (:3321-3323)
+    bool errdiff = false;            // EXTENSION (bUseDither = 2): the plan above is the 10-bit swap chain's (swap_fmt = SF_RGB10A2 into a window-sized
+                                     // intermediate), and the error-diffusion pass (vp_errdiff.hip) takes it to the B8G8R8A8 render target
     std::string describe() const;
 };
 
