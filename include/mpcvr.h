@@ -281,9 +281,12 @@ int32_t mpcvr_reset(mpcvr_ctx *ctx);
  * The frames of a batch are independent of each other: on every path that can, the whole batch runs as one launch per
  * draw (fused 2x / strip / periodic kernel: one launch; same-size frames: one k_convert_stream launch; pass-per-kernel path:
  * block convert / X draw / Y draw with a frame dimension and batched intermediates, <= 4 GiB; Dolby Vision: the block convert's
- * frame dimension, one RPU per call here, one per frame in mpcvr_process_batch_dovi; the HDR10 tone-mapping step: one launch behind batched post-scale textures; Jinc2m: the
- * one-draw quad kernel), otherwise frame by frame (quarter turns, the two-draw Jinc2m, samples that need a repack of their
- * own).  The targets must therefore be distinct buffers; completion is in stream order for the batch as a whole. */
+ * frame dimension, one RPU per call here, one per frame in mpcvr_process_batch_dovi; the HDR10 tone-mapping step: one launch behind
+ * batched post-scale textures; quarter turns, flips outside the strip kernels' reach and Jinc2m in its one- and two-draw forms: every
+ * draw kernel has a frame dimension; bUseDither = 2: ONE error-diffusion launch behind the batch's 10-bit frames), otherwise frame by
+ * frame (samples that do not start on a dword or need a repack of their own outside the v210 / interleaved-RGB batch textures).
+ * mpcvr_get_last_batch_info reports the kernel launches a batch took.  The targets must therefore be distinct buffers; completion is
+ * in stream order for the batch as a whole. */
 int32_t mpcvr_process_batch(mpcvr_ctx *ctx, int32_t n, const void *const *srcs, void *const *dsts,
                             int32_t dst_pitch);
 /* mpcvr_process_batch for a Dolby Vision stream: rpus[i] is the RPU of frame i — the reference reads it from every sample in
