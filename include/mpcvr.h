@@ -71,7 +71,7 @@ enum { MPCVR_DOWNSCALE_Box = 0, MPCVR_DOWNSCALE_Bilinear = 1, MPCVR_DOWNSCALE_Ha
  * "error-diffusion dither".  Where the reference would run its final pass into an 8-bit target (internal format above 8 bits), the
  * frame is rendered as for a 10-bit swap chain (R10G10B10A2, no final pass) and Floyd-Steinberg error diffusion in integers takes it
  * to B8G8R8A8 inside video rect ∩ window (definition: csrc/vp_errdiff_core.h; the serial model in oracle/ is its only check).  On a
- * 10-bit target or with the 8-bit internal format it changes nothing, like bUseDither = 1 there.  Regions up to ~13,400 columns. */
+ * 10-bit target or with the 8-bit internal format it changes nothing, like bUseDither = 1 there. */
 enum { MPCVR_DITHER_None = 0, MPCVR_DITHER_Ordered = 1, MPCVR_DITHER_ErrorDiffusion_EXT = 2 };
 
 /* Render-target format: stands in for the display-driven m_SwapChainFmt decision

@@ -3,8 +3,8 @@
 PARITY UNPINNED BY CONSTRUCTION: the reference has no error diffusion (its final pass is the ordered dither of ps_final_pass.hlsl and
 `grep -ri diffusion /root/reference` is empty), so there is nothing to pin against.  The definition is the serial integer model
 oracle/mpcvr_oracle.c:orc_error_diffusion, and what these tests establish is that the product equals THAT, bit for bit:
-  * CPU: the kernel's wavefront schedule (tests/tools/errdiff_emulate.cpp, built from the product's own vp_errdiff_core.h) against the
-    serial model; the quantiser's multiply-high division over its whole range; the planner's rule for when the pass runs;
+  * CPU: the kernel's schedule — free-running bands behind tagged hand-off words — (tests/tools/errdiff_emulate.cpp, built from the
+    product's own vp_errdiff_core.h) against the serial model; the quantiser's multiply-high division over its whole range; the planner's rule for when the pass runs;
   * GPU: k_error_diffusion against the serial model on the product's own 10-bit frames (every route: fused 2x, strip / periodic,
     same-size convert, plain kernels, batches, clipped and offset video rects, both ways of handing errors down), end to end against
     the oracle where the tier in front is bit-exact, and at BASELINE's 4K -> 8K size.
@@ -30,7 +30,7 @@ def emu(tmp_path_factory):
     subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-o", out, os.path.join(HERE, "tools", "errdiff_emulate.cpp")])
     L = C.CDLL(out)
     L.ed_emulate.restype = C.c_int
-    L.ed_emulate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 5
+    L.ed_emulate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 4 + [C.c_uint32]
     L.ed_quant_range.argtypes = [C.c_int32, C.c_int32, C.c_void_p]
     return L
 
@@ -63,16 +63,18 @@ def test_quantiser_division_is_exact_over_its_range(emu):
                                       (200, 37, None), (1100, 260, (5, 7, 255, 1090)), (70, 1, None), (1, 50, None), (2100, 150, (1, 1, 149, 2100)),
                                       (66, 700, (0, 0, 700, 66))])
 def test_wavefront_schedule_equals_the_serial_model(emu, oracle, h, w, rect):
-    """Bands of 64 rows, two columns of skew, the in-place row buffer, two slots of lag, 16 waves taking turns: every dependency of
-    the kernel's schedule, executed on the host with the waves of a slot in three different orders."""
+    """One free-running wavefront per band of 64 rows, two columns of skew from lane to lane, tagged hand-off words between bands: every
+    dependency of the kernel's schedule, executed on the host with the bands taking turns top-down, as-late-as-possible and at random —
+    no band may read a word before it is written, and none may wait for a word that is never written (the emulator returns -1)."""
     rect = rect or (0, 0, w, h)
     for kind in ("noise", "flat", "ramp", "dark"):
         img = synth10(kind, h, w, seed=h * 1000 + w)
         want = oracle.error_diffusion(img, rect)
-        for order in (0, 1, 2):
+        for seed in (0, 1, 7, 12345):
             got = np.zeros((h, w, 4), np.uint8)
-            emu.ed_emulate(img.ctypes.data, w * 4, got.ctypes.data, w * 4, *rect, order)
-            assert np.array_equal(got, want), (kind, order)
+            waits = emu.ed_emulate(img.ctypes.data, w * 4, got.ctypes.data, w * 4, *rect, seed)
+            assert waits >= 0, (kind, seed, "a band that can never proceed")
+            assert np.array_equal(got, want), (kind, seed)
 
 
 def test_serial_model_properties(oracle):
@@ -140,8 +142,8 @@ ED_CASES = {
     "fused_2x_window_offset": dict(GOLDEN_CASES["x2_p010_pq_mitchell_offset"]),                  # x0 = 3: an odd first column
     "strip_1p5x": dict(GOLDEN_CASES["up_1p5x_lanczos3"]),
     "same_size_pq": dict(cformat=2, w=192, h=80, kind="hdr", seed=901, dst=(192, 80), exfmt=GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"]),
-    "tall_1100_rows": dict(cformat=2, w=72, h=1100, kind="noise", seed=902, dst=(72, 1100)),          # 18 bands: the second round of the waves
-    "wide_700": dict(cformat=2, w=700, h=70, kind="structure", seed=903, dst=(700, 70)),               # six slots per band, two bands
+    "tall_1100_rows": dict(cformat=2, w=72, h=1100, kind="noise", seed=902, dst=(72, 1100)),          # 18 bands, each ~20 steps long: they wait for each other all the time
+    "wide_700": dict(cformat=2, w=700, h=70, kind="structure", seed=903, dst=(700, 70)),               # two bands, 104 groups each
     "clipped_left_top": dict(cformat=2, w=96, h=64, kind="structure", seed=904, dst=(144, 96), iUpscaling=2, window=(120, 80), offset=(-13, -9)),
     "clipped_right_bottom": dict(cformat=2, w=96, h=64, kind="noise", seed=905, dst=(144, 96), iUpscaling=2, window=(120, 80), offset=(31, 22)),
     "fp16_internal": dict(cformat=2, w=64, h=48, kind="structure", seed=906, dst=(96, 72), iUpscaling=4, iTexFormat=16),
@@ -215,7 +217,7 @@ def test_batch_equals_single_frames_and_is_one_pass_launch(mpcvr, oracle):
 @pytest.mark.gpu
 def test_full_size_4k_to_8k_equals_serial_model(mpcvr, oracle):
     """BASELINE config 4's shape at full size: 4K P010 PQ -> 2x -> PQ->SDR -> error diffusion into 8K B8G8R8A8 (Mitchell; the Spline36
-    extension rides the same kernel): 335 slots, 68 bands, five rounds of the 16 waves."""
+    extension rides the same kernel): 68 bands of 976 groups, one workgroup each."""
     import torch
     c = dict(FULL_SIZE_CASES["c4_mitchell"])
     ten, out, info10, info = product_10bit_and_diffused(mpcvr, torch, c)

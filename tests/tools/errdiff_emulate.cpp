@@ -1,9 +1,11 @@
-// tests/tools/errdiff_emulate.cpp — TEST TOOL (never linked into libmpcvr.so): the wavefront schedule of k_error_diffusion
-// (videorenderer_amd/csrc/vp_errdiff.hip) executed on the host, lane by lane and slot by slot, from the SAME header the kernel is
-// built from (vp_errdiff_core.h: ed_step, ed_quant, ed_schedule, ed_slot_work).  tests/test_errdiff.py compares it with the serial
-// model of the oracle: the dependency analysis of the schedule (skew, lag, the in-place row buffer) is checked without a GPU.
-// Waves of a slot run here one after the other in an order the caller picks (`order` = 0: ascending, 1: descending, 2: interleaved),
-// which is how a race between waves inside a slot would show.
+// tests/tools/errdiff_emulate.cpp — TEST TOOL (never linked into libmpcvr.so): the schedule of k_error_diffusion
+// (videorenderer_amd/csrc/vp_errdiff.hip) executed on the host from the SAME header the kernel is built from (vp_errdiff_core.h:
+// ed_step, ed_quant, ed_schedule, the tagged hand-off words).  Every band of 64 rows is a free-running wavefront that advances one
+// group of 8 steps at a time and may do so only when the hand-off words it needs from the band above are there; here the bands take
+// turns in an order drawn from `seed` (or strictly top-down / bottom-up first), which is how a missing dependency, a word read before
+// it is written or a band that can never proceed would show.  tests/test_errdiff.py compares the result with the serial model of the
+// oracle: the dependency analysis of the schedule is checked without a GPU.  Returns the number of (band, group) turns that had to
+// wait, or -1 when no band can proceed (deadlock).
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -15,55 +17,75 @@ using namespace mpcvr;
 extern "C" int ed_quant_host(int32_t T) { return ed_quant(T); }
 extern "C" void ed_quant_range(int32_t lo, int32_t hi, int32_t *out) { for (int32_t t = lo; t < hi; t++) out[t - lo] = ed_quant(t); }
 
-extern "C" int ed_emulate(const uint32_t *src10, int src_pitch, uint8_t *dst, int dst_pitch, int x0, int y0, int x1, int y1, int order)
+namespace {
+struct Band { EdChannel st[64][3]; int32_t dprev[64][3]; int g; };
+uint32_t lcg(uint32_t &s) { s = s * 1664525u + 1013904223u; return s >> 8; }
+}
+
+extern "C" int ed_emulate(const uint32_t *src10, int src_pitch, uint8_t *dst, int dst_pitch, int x0, int y0, int x1, int y1, uint32_t seed)
 {
     const EdSchedule S = ed_schedule(x0, x1, y1 - y0);
-    const int brw = S.slots_per_band * kEdChunk + 8;
-    std::vector<int32_t> rowbuf((size_t)3 * brw, 0);
+    std::vector<uint32_t> handoff((size_t)S.bands * S.stride, 0u);           // zero = not written yet (the launcher's memset)
     const int a0 = x0 & ~1, rows = y1 - y0;
-    struct Wave { EdChannel st[64][3]; int32_t dprev[64][3]; };
-    std::vector<Wave> waves(kEdWaves);
-    for (int slot = 0; slot < S.total_slots; slot++) {
-        // reads of the row buffer by lane 0 happen at group starts, writes by lane 63 per step: emulate in program order per wave
-        for (int wi = 0; wi < kEdWaves; wi++) {
-            const int w = order == 0 ? wi : order == 1 ? kEdWaves - 1 - wi : ((wi & 1) ? kEdWaves - 1 - wi / 2 : wi / 2);
-            int band, chunk;
-            if (!ed_slot_work(S, w, slot, &band, &chunk)) continue;
-            Wave &W = waves[w];
-            if (chunk == 0) std::memset(&W, 0, sizeof(W));
-            const int tbase = chunk * kEdChunk;
-            for (int g = 0; g < kEdChunk / 8; g++) {
-                const int t0 = tbase + 8 * g;
-                int32_t top[3][8];
-                for (int c = 0; c < 3; c++)
-                    for (int s = 0; s < 8; s++) top[c][s] = band > 0 ? rowbuf[(size_t)c * brw + t0 + s] : 0;
-                for (int s = 0; s < 8; s++) {
-                    int32_t shifted[64][3];
-                    for (int lane = 0; lane < 64; lane++)
-                        for (int c = 0; c < 3; c++) shifted[lane][c] = lane ? W.dprev[lane - 1][c] : 0;      // the DPP wave shift
-                    for (int lane = 0; lane < 64; lane++) {
-                        const int r = band * kEdRows + lane;
-                        const bool row_ok = r < rows;
-                        const int xr = t0 + s - kEdSkew * lane;
-                        const bool live = row_ok && xr >= S.lead && xr < S.wl;
-                        uint32_t code = 0;
-                        if (row_ok && xr >= 0 && xr < S.wl + 1 && a0 + xr < x1)        // (the kernel reads pairs; only live codes matter)
-                            code = *(const uint32_t *)((const uint8_t *)src10 + (size_t)(y0 + r) * src_pitch + (size_t)(a0 + xr) * 4);
-                        int q[3];
-                        for (int c = 0; c < 3; c++) {
-                            const int32_t din = lane == 0 ? top[c][s] : shifted[lane][c];
-                            q[c] = ed_step(W.st[lane][c], live, (int)((code >> (10 * c)) & 0x3ffu), din, W.dprev[lane][c]);
-                        }
-                        if (live) {
-                            uint8_t *px = dst + (size_t)(y0 + r) * dst_pitch + (size_t)(a0 + xr) * 4;
-                            px[0] = (uint8_t)q[2]; px[1] = (uint8_t)q[1]; px[2] = (uint8_t)q[0]; px[3] = 0xff;
-                        }
-                        if (lane == 63 && xr >= 1)
-                            for (int c = 0; c < 3; c++) rowbuf[(size_t)c * brw + (xr - 1)] = W.dprev[63][c];
-                    }
+    std::vector<Band> bands(S.bands);
+    for (Band &b : bands) std::memset(&b, 0, sizeof(b));
+    int waits = 0, idle = 0;
+    size_t left = (size_t)S.bands * S.groups;
+    uint32_t rs = seed;
+    // the kernel's wait: every word of a column inside the region must carry its tag
+    auto ready = [&](int b) {
+        if (b == 0) return true;
+        const uint32_t *above = &handoff[(size_t)(b - 1) * S.stride];
+        const int t0 = kEdGroup * bands[b].g;
+        for (int l = 0; l < 3 * kEdGroup; l++)
+            if (t0 + l / 3 < S.wl && !(above[3 * t0 + l] & 1u)) return false;
+        return true;
+    };
+    while (left) {
+        // whose turn: seed 0 = the lowest unfinished band (the serial order), 1 = the HIGHEST unfinished band that can move (every band runs as
+        // close behind the band above as the hand-off allows), else a random unfinished band, which waits when its words are not there
+        int b = -1;
+        if (seed == 0) { for (int i = 0; i < S.bands && b < 0; i++) if (bands[i].g < S.groups) b = i; }
+        else if (seed == 1) {
+            for (int i = S.bands - 1; i >= 0 && b < 0; i--)
+                if (bands[i].g < S.groups) { if (ready(i)) b = i; else waits++; }
+            if (b < 0) return -1;
+        } else { do b = (int)(lcg(rs) % (uint32_t)S.bands); while (bands[b].g >= S.groups); }
+        if (!ready(b)) {
+            waits++;
+            if (++idle > 64 * S.bands + 64) return -1;      // nobody moved for a long time: a band that can never proceed
+            continue;
+        }
+        Band &W = bands[b];
+        const int t0 = kEdGroup * W.g;
+        const uint32_t *above = b ? &handoff[(size_t)(b - 1) * S.stride] : nullptr;
+        uint32_t *mine = &handoff[(size_t)b * S.stride];
+        idle = 0;
+        for (int s = 0; s < kEdGroup; s++) {
+            int32_t shifted[64][3];
+            for (int lane = 0; lane < 64; lane++)
+                for (int c = 0; c < 3; c++) shifted[lane][c] = lane ? W.dprev[lane - 1][c] : 0;      // the DPP wave shift
+            for (int lane = 0; lane < 64; lane++) {
+                const int r = b * kEdRows + lane;
+                const bool row_ok = r < rows;
+                const int xr = t0 + s - kEdSkew * lane;
+                const bool live = row_ok && xr >= S.lead && xr < S.wl;
+                uint32_t code = 0;
+                if (live) code = *(const uint32_t *)((const uint8_t *)src10 + (size_t)(y0 + r) * src_pitch + (size_t)(a0 + xr) * 4);
+                int q[3];
+                for (int c = 0; c < 3; c++) {
+                    const int32_t din = lane == 0 ? (above ? ed_untag(above[3 * (t0 + s) + c]) : 0) : shifted[lane][c];
+                    q[c] = ed_step(W.st[lane][c], live, (int)((code >> (10 * c)) & 0x3ffu), din, W.dprev[lane][c]);
                 }
+                if (live) {
+                    uint8_t *px = dst + (size_t)(y0 + r) * dst_pitch + (size_t)(a0 + xr) * 4;
+                    px[0] = (uint8_t)q[2]; px[1] = (uint8_t)q[1]; px[2] = (uint8_t)q[0]; px[3] = 0xff;
+                }
+                if (lane == kEdRows - 1 && xr >= 1 && xr <= S.wl)
+                    for (int c = 0; c < 3; c++) mine[3 * (xr - 1) + c] = ed_tag(W.dprev[lane][c]);
             }
         }
+        W.g++; left--;
     }
-    return S.total_slots;
+    return waits;
 }

@@ -60,7 +60,7 @@ CHipVideoProcessor::~CHipVideoProcessor()
     if (!m_bInit && !m_stream && !m_evStart && !m_evStop && !m_dither.ptr) return;
     (void)hipSetDevice(m_device);
     if (m_stream) (void)hipStreamSynchronize(m_stream);
-    for (DevBuffer *b : {&m_batchConv, &m_batchMid, &m_batchPost, &m_edPost, &m_batchTex, &m_jincFirst, &m_jincSecond, &m_TexSrcVideo, &m_TexRaw, &m_TexPost, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
+    for (DevBuffer *b : {&m_batchConv, &m_batchMid, &m_batchPost, &m_edPost, &m_edHandoff, &m_batchTex, &m_jincFirst, &m_jincSecond, &m_TexSrcVideo, &m_TexRaw, &m_TexPost, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
                          &m_pqLut, &m_hlgLut, &m_eotfLut, &m_stripTab, &m_tapsXi, &m_tapsXw, &m_tapsXs, &m_tapsYi, &m_tapsYw, &m_tapsYs, &m_otherX, &m_otherY, &m_tapsXb, &m_tapsYb})
         b->Release();
     for (UploadSlot &u : m_up) {
@@ -69,6 +69,7 @@ CHipVideoProcessor::~CHipVideoProcessor()
         if (u.uploaded) (void)hipEventDestroy(u.uploaded);
         if (u.consumed) (void)hipEventDestroy(u.consumed);
     }
+    if (m_edStatus) (void)hipHostFree(m_edStatus);
     if (m_copyStream) (void)hipStreamDestroy(m_copyStream);
     m_doviDev.Release();
     m_bcast.Release();
@@ -190,7 +191,9 @@ HRESULT CHipVideoProcessor::Synchronize()
     (void)hipSetDevice(m_device);
     HRESULT hr = JoinFrameLanes(true);
     if (hr) return hr;
-    return CheckHip(hipStreamSynchronize(m_stream), "hipStreamSynchronize");
+    if ((hr = CheckHip(hipStreamSynchronize(m_stream), "hipStreamSynchronize"))) return hr;
+    if (m_edStatus && *m_edStatus) { *m_edStatus = 0; return Fail(MPCVR_E_FAIL, "error diffusion: a band gave up waiting for the band above"); }
+    return MPCVR_S_OK;
 }
 
 // ---- frame lanes (see hip_video_processor.h) ----
@@ -1515,7 +1518,16 @@ HRESULT CHipVideoProcessor::ErrDiffPass(int n, const FusedFrame *table, FusedFra
         if (((uintptr_t)dsts[i] & 7) != 0) P.pair_stores = 0;
     const char *shift = std::getenv("MPCVR_ERRDIFF_SHIFT");          // (read per call: the suite runs both variants in one process)
     P.shift = shift && std::strcmp(shift, "bpermute") == 0 ? 1 : 0;
-    if (!ErrorDiffusionSupported(P)) return Fail(MPCVR_E_INVALIDARG, "error diffusion (bUseDither = 2): the region is wider than the pass's LDS row buffer holds (~13,400 columns)");
+    HRESULT hr;
+    if (!m_edStatus) {
+        if ((hr = CheckHip(hipHostMalloc((void **)&m_edStatus, sizeof(int), hipHostMallocDefault), "error-diffusion status word"))) return hr;
+        *m_edStatus = 0;
+    }
+    if (*m_edStatus) { *m_edStatus = 0; return Fail(MPCVR_E_FAIL, "error diffusion: a band of an earlier pass gave up waiting for the band above"); }
+    // the hand-off rows are cleared and rewritten by every launch: launches of one context run in stream order on one buffer
+    if (s != m_stream) (void)hipStreamSynchronize(m_stream);
+    if ((hr = CheckHip(m_edHandoff.CheckCreate(ErrorDiffusionHandoffBytes(P, n)), "error-diffusion hand-off rows"))) return hr;
+    P.handoff = (uint32_t *)m_edHandoff.ptr; P.status = m_edStatus;
     return CheckHip(LaunchErrorDiffusion(P, table, single, n, s), "k_error_diffusion");
 }
 

@@ -271,6 +271,8 @@ private:
     // EXTENSION (bUseDither = 2, m_plan.errdiff): the frames as a 10-bit swap chain would receive them, window geometry, side by side;
     // the error-diffusion pass (vp_errdiff.hip) reads them and writes the real render targets
     DevBuffer m_edPost;
+    DevBuffer m_edHandoff;         // the pass's hand-off rows between bands of 64 rows (vp_errdiff.hip)
+    int *m_edStatus = nullptr;     // pinned host word the pass sets when a band gave up waiting (checked at the next pass and in Synchronize)
     int m_edPitch = 0;             // bytes per row of an intermediate (a multiple of 256)
     size_t m_edStride = 0;         // bytes per intermediate
     HRESULT PrepareErrDiff(int frames);

@@ -2,13 +2,17 @@
 // them -> B8G8R8A8 render targets, Floyd-Steinberg in integers.  Definition and schedule: vp_errdiff_core.h (no reference counterpart;
 // the serial model oracle/mpcvr_oracle.c orc_error_diffusion is its only check, and the kernel must equal it bit for bit).
 //
-// One workgroup per frame, 16 wavefronts, each running a band of 64 rows with a two-column skew from lane to lane:
-//   * what a row hands to the row below (D, three channels) moves by ONE DPP wave shift per step and channel — no LDS, no barrier;
-//   * the bottom row of a band parks its D in an LDS row buffer, read by lane 0 of the band below two slots (= two workgroup barriers)
-//     later; the buffer is rewritten in place, 127 columns behind its reader;
+// One wavefront per band of 64 rows, one workgroup per wavefront, (frames x bands) workgroups per launch, all free-running:
+//   * lane i = row i of the band, two columns behind lane i - 1; what a row hands to the row below (D, three channels) moves by ONE
+//     DPP wave shift per step and channel — no LDS, no barrier anywhere in the kernel;
+//   * the bottom row of a band publishes its D as tagged words in a device-memory hand-off row (relaxed agent-scope atomic stores: value
+//     and tag in one word, so there is nothing to order); lane 0 of the band below — another workgroup, usually on another XCD — fetches
+//     them one group of 8 columns ahead (lanes 0-23 load the 24 words of a group at once) and spins, politely and with a bound, only
+//     when the band above has not written them yet; the caller zeroes the hand-off rows in front of the launch;
 //   * a lane reads its row as 8-byte pixel pairs one group of 8 steps ahead and writes 8-byte pairs.
-// The pass is a chain of W + 2 H dependent steps per frame with ~30 integer instructions per channel and pixel: it is bound by VALU
-// issue and by its own serial depth, not by HBM (DESIGN.md §4.6 has the numbers); frames of a batch are what fills the chip.
+// Round 4's first version ran a frame in ONE workgroup (16 waves taking turns behind workgroup barriers, hand-off rows in LDS): 32 of
+// 256 CUs busy on a 32-frame batch, 630 frames/s at 4K -> 8K.  The pass is a chain of W + 2 H dependent steps per frame with ~30 integer
+// instructions per channel and pixel: bound by VALU issue and by its own serial depth, not by HBM.
 #include <hip/hip_runtime.h>
 
 #include "vp_errdiff_core.h"
@@ -16,17 +20,15 @@
 
 namespace mpcvr {
 
-hipError_t AllowLargeLds(const void *kern, size_t lds);      // vp_fused_strip.hip
-size_t DeviceLdsLimit();
-
 namespace {
 
 typedef uint32_t ed_u2 __attribute__((ext_vector_type(2)));
-typedef int32_t ed_i4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) uint8_t *ed_gcptr;
 typedef __attribute__((address_space(1))) uint8_t *ed_gptr;
 
-// the value of lane - 1 (lane 0: anything — it reads the row buffer instead)
+constexpr int kEdSpinLimit = 1 << 21;       // polls (~1 us each) a band grants the band above before it gives up and flags the launch
+
+// the value of lane - 1 (lane 0: anything — it reads the hand-off row instead)
 template <int SHIFT>
 __device__ __forceinline__ int32_t ed_from_lane_above(int32_t v, int lane)
 {
@@ -34,135 +36,118 @@ __device__ __forceinline__ int32_t ed_from_lane_above(int32_t v, int lane)
     return __builtin_amdgcn_ds_bpermute(((lane - 1) & 63) << 2, v);
 }
 
-// LDS: int32 rowbuf[3][brw], brw = slots_per_band * kEdChunk + 8 (every step of lane 0 has its own entry: no clamping in the loop)
-__host__ __device__ inline int ed_rowbuf_stride(const EdSchedule &S) { return S.slots_per_band * kEdChunk + 8; }
-
 template <int SHIFT>
-__global__ __launch_bounds__(kEdWaves * 64) void k_error_diffusion(ErrDiffParams P, const FusedFrame *__restrict__ frames, FusedFrame single)
+__global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const FusedFrame *__restrict__ frames, FusedFrame single)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t ed_rowbuf[];
     const EdSchedule S = ed_schedule(P.x0, P.x1, P.y1 - P.y0);
-    const int brw = ed_rowbuf_stride(S);
-    for (int i = threadIdx.x; i < 3 * brw; i += blockDim.x) ed_rowbuf[i] = 0;
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const FusedFrame fr = frames ? frames[blockIdx.x] : single;
+    const int lane = threadIdx.x;
+    const int z = (int)blockIdx.x / S.bands, band = (int)blockIdx.x - z * S.bands;       // a band's producer = the workgroup in front of it
+    const FusedFrame fr = frames ? frames[z] : single;
     const int a0 = P.x0 & ~1;
     const int rows = P.y1 - P.y0;
+    const int r = band * kEdRows + lane;
+    const bool row_ok = r < rows;
+    const int y = P.y0 + (row_ok ? r : rows - 1);
+    const ed_gcptr src_row = (ed_gcptr)fr.src + (size_t)y * (size_t)P.src_pitch + (size_t)a0 * 4u;
+    const ed_gptr dst_row = (ed_gptr)fr.dst + (size_t)y * (size_t)P.dst_pitch + (size_t)a0 * 4u;
+    uint32_t *const mine = P.handoff + ((size_t)z * S.bands + band) * (size_t)S.stride;
+    const uint32_t *const above = mine - S.stride;                                       // (read only when band > 0)
+    const bool has_above = band > 0;
 
     EdChannel st[3];
     int32_t dprev[3];
-    ed_gcptr src_row = nullptr;
-    ed_gptr dst_row = nullptr;
-    bool row_ok = false;
+#pragma unroll
+    for (int c = 0; c < 3; c++) { st[c] = EdChannel{0, 0, 0, 0}; dprev[c] = 0; }
 
-    for (int slot = 0; slot < S.total_slots; slot++) {
-        int band = 0, chunk = 0;
-        if (ed_slot_work(S, wave, slot, &band, &chunk)) {        // wave-uniform
-            if (chunk == 0) {
+    // pixel pairs of a group of 8 steps: xr = t - 2 lane is even on the even step of a pair in every lane
+    auto load_group = [&](int t0, ed_u2 (&v)[4]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int c = 0; c < 3; c++) { st[c] = EdChannel{0, 0, 0, 0}; dprev[c] = 0; }
-                const int r = band * kEdRows + lane;
-                row_ok = r < rows;
-                const int y = P.y0 + (row_ok ? r : rows - 1);
-                src_row = (ed_gcptr)fr.src + (size_t)y * (size_t)P.src_pitch + (size_t)a0 * 4u;
-                dst_row = (ed_gptr)fr.dst + (size_t)y * (size_t)P.dst_pitch + (size_t)a0 * 4u;
+        for (int p = 0; p < 4; p++) {
+            const int xr = t0 + 2 * p - kEdSkew * lane;
+            v[p] = ed_u2{0u, 0u};
+            if (row_ok && xr >= 0 && xr < S.wl) v[p] = *(const __attribute__((address_space(1))) ed_u2 *)(src_row + (size_t)xr * 4u);
+        }
+    };
+    // the 24 hand-off words of a group (columns t0 .. t0 + 7, word 3 column + channel): lane l < 24 fetches word l
+    auto fetch_above = [&](int t0) __attribute__((always_inline)) -> uint32_t {
+        if (!has_above || lane >= 3 * kEdGroup) return 1u;
+        return __hip_atomic_load(above + 3 * t0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+
+    ed_u2 cur[4], nxt[4];
+    load_group(0, cur);
+    uint32_t wnext = fetch_above(0);
+    for (int g = 0; g < S.groups; g++) {
+        const int t0 = kEdGroup * g;
+        if (g + 1 < S.groups) load_group(t0 + kEdGroup, nxt);
+        // D of the band above for the eight columns of this group: fetched a group ago; wait for what is not there yet
+        uint32_t w = wnext;
+        if (has_above) {
+            const bool need = lane < 3 * kEdGroup && t0 + lane / 3 < S.wl;          // (columns beyond the region are never written, nor used)
+            int spins = 0;
+            while (__ballot(need && !(w & 1u)) != 0) {                               // wave-uniform
+                if (++spins > kEdSpinLimit) { if (lane == 0) *P.status = 1; break; }
+                __builtin_amdgcn_s_sleep(16);
+                w = fetch_above(t0);
             }
-            const int tbase = chunk * kEdChunk;
-            const bool has_above = band > 0;
-            // pixel pairs of a group of 8 steps: xr = t - 2 lane is even on the even step of a pair in every lane
-            auto load_group = [&](int t0, ed_u2 (&v)[4]) __attribute__((always_inline)) {
+            wnext = fetch_above(t0 + kEdGroup);                                      // (the row has a spare group of entries behind the last one)
+        }
+        uint32_t even_px = 0;
+        bool even_live = false;
 #pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    const int xr = t0 + 2 * p - kEdSkew * lane;
-                    v[p] = ed_u2{0u, 0u};
-                    if (row_ok && xr >= 0 && xr < S.wl) v[p] = *(const __attribute__((address_space(1))) ed_u2 *)(src_row + (size_t)xr * 4u);
+        for (int s = 0; s < kEdGroup; s++) {
+            const int xr = t0 + s - kEdSkew * lane;
+            const bool live = row_ok && xr >= S.lead && xr < S.wl;
+            const uint32_t code = (s & 1) ? cur[s >> 1].y : cur[s >> 1].x;
+            int q[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                int32_t din = ed_from_lane_above<SHIFT>(dprev[c], lane);
+                const int32_t top = ed_untag((uint32_t)__builtin_amdgcn_readlane((int)w, 3 * s + c));     // (0 without a band above / outside the region)
+                if (lane == 0) din = has_above ? top : 0;
+                q[c] = ed_step(st[c], live, (int)((code >> (10 * c)) & 0x3ffu), din, dprev[c]);
+            }
+            const uint32_t px = 0xff000000u | ((uint32_t)q[0] << 16) | ((uint32_t)q[1] << 8) | (uint32_t)q[2];     // B8G8R8A8: R = byte 2
+            if ((s & 1) == 0) { even_px = px; even_live = live; }
+            else {
+                const ed_gptr at = dst_row + (size_t)(xr - 1) * 4u;
+                if (P.pair_stores && even_live && live) *(__attribute__((address_space(1))) ed_u2 *)at = ed_u2{even_px, px};
+                else {
+                    if (even_live) *(__attribute__((address_space(1))) uint32_t *)at = even_px;
+                    if (live) *(__attribute__((address_space(1))) uint32_t *)(at + 4) = px;
                 }
-            };
-            ed_u2 cur[4], nxt[4];
-            load_group(tbase, cur);
-            for (int g = 0; g < kEdChunk / 8; g++) {
-                const int t0 = tbase + 8 * g;
-                if (g + 1 < kEdChunk / 8) load_group(t0 + 8, nxt);
-                // lane 0: D of the band above for the eight columns of this group (the band above finished them a slot ago)
-                int32_t top[3][8];
+            }
+            // the band's bottom row: D(xr - 1) for the band below, value and tag in one word
+            if (lane == kEdRows - 1 && xr >= 1 && xr <= S.wl) {
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    ed_i4 a = ed_i4{0, 0, 0, 0}, b = ed_i4{0, 0, 0, 0};
-                    if (has_above && lane == 0) {
-                        const ed_i4 *q = (const ed_i4 *)(ed_rowbuf + c * brw + t0);      // t0 is a multiple of 8, brw of 8: 16-byte aligned
-                        a = q[0]; b = q[1];
-                    }
-                    top[c][0] = a.x; top[c][1] = a.y; top[c][2] = a.z; top[c][3] = a.w;
-                    top[c][4] = b.x; top[c][5] = b.y; top[c][6] = b.z; top[c][7] = b.w;
-                }
-                uint32_t even_px = 0;
-                bool even_live = false;
-#pragma unroll
-                for (int s = 0; s < 8; s++) {
-                    const int xr = t0 + s - kEdSkew * lane;
-                    const bool live = row_ok && xr >= S.lead && xr < S.wl;
-                    const uint32_t code = (s & 1) ? cur[s >> 1].y : cur[s >> 1].x;
-                    int q[3];
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        int32_t din = ed_from_lane_above<SHIFT>(dprev[c], lane);
-                        if (lane == 0) din = top[c][s];
-                        q[c] = ed_step(st[c], live, (int)((code >> (10 * c)) & 0x3ffu), din, dprev[c]);
-                    }
-                    const uint32_t px = 0xff000000u | ((uint32_t)q[0] << 16) | ((uint32_t)q[1] << 8) | (uint32_t)q[2];     // B8G8R8A8: R = byte 2
-                    if ((s & 1) == 0) { even_px = px; even_live = live; }
-                    else {
-                        const ed_gptr at = dst_row + (size_t)(xr - 1) * 4u;
-                        if (P.pair_stores && even_live && live) *(__attribute__((address_space(1))) ed_u2 *)at = ed_u2{even_px, px};
-                        else {
-                            if (even_live) *(__attribute__((address_space(1))) uint32_t *)at = even_px;
-                            if (live) *(__attribute__((address_space(1))) uint32_t *)(at + 4) = px;
-                        }
-                    }
-                    // the band's bottom row: D(xr - 1) for the band below
-                    if (lane == 63 && xr >= 1) {
-#pragma unroll
-                        for (int c = 0; c < 3; c++) ed_rowbuf[c * brw + (xr - 1)] = dprev[c];
-                    }
-                }
-#pragma unroll
-                for (int p = 0; p < 4; p++) cur[p] = nxt[p];
+                for (int c = 0; c < 3; c++) __hip_atomic_store(mine + 3 * (xr - 1) + c, ed_tag(dprev[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; p++) cur[p] = nxt[p];
     }
 }
 
 }  // namespace
 
-size_t ErrorDiffusionLdsBytes(const ErrDiffParams &P)
+size_t ErrorDiffusionHandoffBytes(const ErrDiffParams &P, int n_frames)
 {
     const EdSchedule S = ed_schedule(P.x0, P.x1, P.y1 - P.y0);
-    return (size_t)3 * ed_rowbuf_stride(S) * sizeof(int32_t);
-}
-
-bool ErrorDiffusionSupported(const ErrDiffParams &P)
-{
-    return P.x1 > P.x0 && P.y1 > P.y0 && ErrorDiffusionLdsBytes(P) <= DeviceLdsLimit();
+    return (size_t)n_frames * S.bands * S.stride * sizeof(uint32_t);
 }
 
 hipError_t LaunchErrorDiffusion(const ErrDiffParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s)
 {
     if (n_frames <= 0 || (!frames_dev && n_frames != 1)) return hipErrorInvalidValue;
-    if (!ErrorDiffusionSupported(P)) return hipErrorInvalidValue;
-    const size_t lds = ErrorDiffusionLdsBytes(P);
-    auto launch = [&](auto kern) -> hipError_t {
-        if (lds > 48 * 1024) {
-            const hipError_t e = AllowLargeLds((const void *)kern, lds);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(kern, dim3((unsigned)n_frames), dim3(kEdWaves * 64), lds, s, P, frames_dev, single);
-        return hipGetLastError();
-    };
-    return P.shift == 1 ? launch(k_error_diffusion<1>) : launch(k_error_diffusion<0>);
+    if (P.x1 <= P.x0 || P.y1 <= P.y0 || !P.handoff || !P.status) return hipErrorInvalidValue;
+    const EdSchedule S = ed_schedule(P.x0, P.x1, P.y1 - P.y0);
+    // zero = "not written yet": the hand-off rows are cleared in front of every launch (a few MB per frame, in stream order)
+    const hipError_t e = hipMemsetAsync(P.handoff, 0, ErrorDiffusionHandoffBytes(P, n_frames), s);
+    if (e != hipSuccess) return e;
+    const dim3 grid((unsigned)((size_t)n_frames * S.bands)), block(64);
+    if (P.shift == 1) hipLaunchKernelGGL(k_error_diffusion<1>, grid, block, 0, s, P, frames_dev, single);
+    else hipLaunchKernelGGL(k_error_diffusion<0>, grid, block, 0, s, P, frames_dev, single);
+    return hipGetLastError();
 }
 
 }  // namespace mpcvr

@@ -14,10 +14,14 @@
 // Schedule: pixel (x, y) needs (x-1, y), (x-1, y-1), (x, y-1), (x+1, y-1), so row y may run two columns behind row y-1.  A wavefront
 // owns a BAND of 64 rows, lane i = row i, at step t lane i works on column t - 2 i; what a row passes to the row below,
 //       D(x) = below-right(x-1) + below(x) + below-left(x+1),
-// is complete one step before the lane below needs it and travels there by one DPP wave shift per step.  The bottom row of a band
-// leaves its D in an LDS row buffer for the top row of the next band, which another wave of the workgroup runs two SLOTS (of 128
-// steps, one workgroup barrier each) later.  This header holds everything a host emulation of that schedule shares with the kernel
-// (tests/tools/errdiff_emulate.cpp: the schedule against the serial model, no GPU needed).
+// is complete one step before the lane below needs it and travels there by one DPP wave shift per step.  Every band is a workgroup
+// of ONE wavefront, free-running: its bottom row publishes D column by column as tagged words (value << 1 | 1, zero = not there yet)
+// in device memory — a relaxed agent-scope atomic store each, so value and tag arrive together and no fence is needed — and lane 0 of
+// the band below reads them eight columns ahead and waits only when the band above has not got there yet (in steady state it runs
+// ~130 columns behind).  A band depends on the band above alone = the workgroup with the next lower index: workgroups are started in
+// index order per XCD, so the lowest unfinished one always finds its producer finished or running — no deadlock, whatever is resident.
+// This header holds everything a host emulation of that schedule shares with the kernel (tests/tools/errdiff_emulate.cpp: bands taking
+// turns in random order against the serial model, no GPU needed).
 #pragma once
 #include <stdint.h>
 
@@ -33,10 +37,7 @@ constexpr int kEdUnit = 16 * 1023;        // error units per 8-bit code
 constexpr int kEdCode = 16 * 255;         // one UNORM10 code in those units
 constexpr int kEdRows = 64;               // rows per band = lanes of a wavefront
 constexpr int kEdSkew = 2;                // columns a row runs behind the row above
-constexpr int kEdChunk = 128;             // steps per slot
-constexpr int kEdLag = 2;                 // slots a band starts behind the band above: (kEdLag - 1) * kEdChunk >= kEdSkew * (kEdRows - 1) + 1
-constexpr int kEdWaves = 16;              // waves per workgroup = bands in flight per frame
-static_assert((kEdLag - 1) * kEdChunk >= kEdSkew * (kEdRows - 1) + 1, "a band must find the row buffer filled one column ahead");
+constexpr int kEdGroup = 8;               // steps between two looks at the band above (and two loads of pixel pairs)
 
 // floor((T + U / 2) / U) clamped to a byte.  T + U/2 + 16 U is positive for every reachable T (|E| stays within a few U) and below
 // 2^23; n = that >> 4 is below 2^19, where floor(n / 1023) = mulhi(n, ceil(2^32 / 1023)) exactly (the excess 1019 n / (1023 * 2^32)
@@ -84,9 +85,8 @@ struct EdSchedule {
     int wl;              // columns counted from A0
     int lead;            // x0 - A0
     int bands;           // ceil(rows / 64)
-    int slots_per_band;  // ceil((wl + 1 + kEdSkew * 63) / kEdChunk): lane 63 must reach the flush step at xr = wl
-    int round;           // slots between two bands of the same wave
-    int total_slots;     // workgroup barriers of the launch
+    int groups;          // groups of kEdGroup steps per band: lane 63 must reach the flush step at xr = wl
+    int stride;          // words of one band's hand-off row: 3 per column (R, G, B), every step of lane 0 has its entry
 };
 MPCVR_ED_HD EdSchedule ed_schedule(int x0, int x1, int rows)
 {
@@ -94,24 +94,12 @@ MPCVR_ED_HD EdSchedule ed_schedule(int x0, int x1, int rows)
     const int a0 = x0 & ~1;
     s.wl = x1 - a0; s.lead = x0 - a0;
     s.bands = (rows + kEdRows - 1) / kEdRows;
-    s.slots_per_band = (s.wl + 1 + kEdSkew * (kEdRows - 1) + kEdChunk - 1) / kEdChunk;
-    s.round = s.slots_per_band > kEdLag * kEdWaves ? s.slots_per_band : kEdLag * kEdWaves;
-    const int rounds = (s.bands + kEdWaves - 1) / kEdWaves;
-    const int last_wave = (s.bands - 1) % kEdWaves;        // the wave that runs the last band
-    s.total_slots = (rounds - 1) * s.round + kEdLag * last_wave + s.slots_per_band;
-    // (a wave of an earlier position in the last round ends earlier; waves beyond the last band idle through the barriers)
+    s.groups = (s.wl + 1 + kEdSkew * (kEdRows - 1) + kEdGroup - 1) / kEdGroup;
+    s.stride = 3 * kEdGroup * (s.groups + 1);
     return s;
 }
-// which (band, chunk) wave w works on in slot `slot`; false: it only meets the barrier
-MPCVR_ED_HD bool ed_slot_work(const EdSchedule &s, int w, int slot, int *band, int *chunk)
-{
-    const int rel = slot - kEdLag * w;
-    if (rel < 0) return false;
-    const int k = rel / s.round, j = rel - k * s.round;
-    const int b = w + kEdWaves * k;
-    if (b >= s.bands || j >= s.slots_per_band) return false;
-    *band = b; *chunk = j;
-    return true;
-}
+// hand-off words: D of column c, channel ch of a band's bottom row sits at word 3 c + ch; tagged so that zero means "not written yet"
+MPCVR_ED_HD uint32_t ed_tag(int32_t d) { return ((uint32_t)d << 1) | 1u; }
+MPCVR_ED_HD int32_t ed_untag(uint32_t w) { return (int32_t)w >> 1; }
 
 }  // namespace mpcvr

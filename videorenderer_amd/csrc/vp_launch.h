@@ -85,9 +85,10 @@ struct ErrDiffParams {
     int src_pitch, dst_pitch;  // bytes; src rows are readable one pixel beyond x1 (the caller's intermediate has the slack)
     int pair_stores;           // every target and dst_pitch on 8-byte boundaries: one 8-byte store per pixel pair
     int shift;                 // 0: rows hand their errors down by a DPP wave shift; 1: by ds_bpermute (MPCVR_ERRDIFF_SHIFT=bpermute, A/B)
+    uint32_t *handoff;         // device: ErrorDiffusionHandoffBytes(P, n_frames) — the bands' bottom rows for the bands below (the launcher clears it)
+    int *status;               // host memory the device can write: set to 1 when a band gave up waiting for the band above (never, unless a launch is broken)
 };
-bool ErrorDiffusionSupported(const ErrDiffParams &P);       // the LDS row buffer fits (regions up to ~13,400 columns)
-size_t ErrorDiffusionLdsBytes(const ErrDiffParams &P);
+size_t ErrorDiffusionHandoffBytes(const ErrDiffParams &P, int n_frames);
 hipError_t LaunchErrorDiffusion(const ErrDiffParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
 bool FusedUp2xSupported(const FusedParams &P);
 bool BlockConvertLayout(const FusedParams &P, bool catmull_420);       // source layout + chroma filter convert_block serves
