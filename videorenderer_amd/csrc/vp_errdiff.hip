@@ -6,10 +6,11 @@
 //   * lane i = row i of the band, two columns behind lane i - 1; what a row hands to the row below (D, three channels) moves by ONE
 //     DPP wave shift per step and channel — no LDS, no barrier anywhere in the kernel;
 //   * the bottom row of a band publishes its D as tagged words in a device-memory hand-off row (relaxed agent-scope atomic stores: value
-//     and tag in one word, so there is nothing to order); lane 0 of the band below — another workgroup, usually on another XCD — fetches
-//     them one group of 8 columns ahead (lanes 0-23 load the 24 words of a group at once) and spins, politely and with a bound, only
-//     when the band above has not written them yet; the caller zeroes the hand-off rows in front of the launch;
-//   * a lane reads its row as 8-byte pixel pairs one group of 8 steps ahead and writes 8-byte pairs.
+//     and tag in one word, so there is nothing to order), the 24 words of a group of 8 steps in ONE store of lanes 0-23; lane 0 of the band
+//     below — another workgroup, usually on another XCD — fetches them one group of 8 columns ahead (lanes 0-23 load a group at once) and
+//     spins, politely and with a bound, only when the band above has not written them yet; the launcher zeroes the rows first;
+//   * a lane reads its row as 8-byte pixel pairs one group of 8 steps ahead and writes 8-byte pairs; no memory instruction of the loop
+//     is predicated (clamped addresses, a dummy slot for lanes off the region), so the waits the compiler inserts are exact.
 // Round 4's first version ran a frame in ONE workgroup (16 waves taking turns behind workgroup barriers, hand-off rows in LDS): 32 of
 // 256 CUs busy on a 32-frame batch, 630 frames/s at 4K -> 8K.  The pass is a chain of W + 2 H dependent steps per frame with ~30 integer
 // instructions per channel and pixel: bound by VALU issue and by its own serial depth, not by HBM.
@@ -36,7 +37,12 @@ __device__ __forceinline__ int32_t ed_from_lane_above(int32_t v, int lane)
     return __builtin_amdgcn_ds_bpermute(((lane - 1) & 63) << 2, v);
 }
 
-template <int SHIFT>
+// PAIR: every pixel pair (even column, odd column) of the region is whole (x0 and x1 even) and every target row starts on an 8-byte
+// boundary: one 8-byte store per pair.  Every vector memory instruction of the loop is UNCONDITIONAL — lanes off the region read a
+// clamped address and write into a dummy slot — so that the compiler can count them: its s_waitcnt for the pixel pairs fetched a group
+// ago then leaves this group's stores and fetches in flight (with predicated accesses it must assume vmcnt(0) at every wait: the first
+// cut of this kernel waited for its own prefetch, 670 cycles per step)
+template <int SHIFT, bool PAIR>
 __global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const FusedFrame *__restrict__ frames, FusedFrame single)
 {
     const EdSchedule S = ed_schedule(P.x0, P.x1, P.y1 - P.y0);
@@ -51,35 +57,44 @@ __global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const F
     const ed_gcptr src_row = (ed_gcptr)fr.src + (size_t)y * (size_t)P.src_pitch + (size_t)a0 * 4u;
     const ed_gptr dst_row = (ed_gptr)fr.dst + (size_t)y * (size_t)P.dst_pitch + (size_t)a0 * 4u;
     uint32_t *const mine = P.handoff + ((size_t)z * S.bands + band) * (size_t)S.stride;
-    const uint32_t *const above = mine - S.stride;                                       // (read only when band > 0)
     const bool has_above = band > 0;
+    const uint32_t *const above = has_above ? mine - S.stride : mine;                    // (the first band reads its own row: zeros, ignored)
+    const ed_gptr dummy = (ed_gptr)P.dummy + (size_t)lane * 8u;                          // where lanes off the region store
+    const int wl_even = (S.wl - 1) & ~1;                                                 // last even column a pair load may start at
 
     EdChannel st[3];
     int32_t dprev[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) { st[c] = EdChannel{0, 0, 0, 0}; dprev[c] = 0; }
 
-    // pixel pairs of a group of 8 steps: xr = t - 2 lane is even on the even step of a pair in every lane
+    // pixel pairs of a group of 8 steps: xr = t - 2 lane is even on the even step of a pair in every lane (off the region: a clamped address)
     auto load_group = [&](int t0, ed_u2 (&v)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            const int xr = t0 + 2 * p - kEdSkew * lane;
-            v[p] = ed_u2{0u, 0u};
-            if (row_ok && xr >= 0 && xr < S.wl) v[p] = *(const __attribute__((address_space(1))) ed_u2 *)(src_row + (size_t)xr * 4u);
+            const int xr = min(max(t0 + 2 * p - kEdSkew * lane, 0), wl_even);
+            v[p] = *(const __attribute__((address_space(1))) ed_u2 *)(src_row + (size_t)xr * 4u);
         }
     };
-    // the 24 hand-off words of a group (columns t0 .. t0 + 7, word 3 column + channel): lane l < 24 fetches word l
+    // the 24 hand-off words of a group (columns t0 .. t0 + 7, word 3 column + channel): lane l < 24 fetches word l (the others: word 0)
+    const int wlane = lane < 3 * kEdGroup ? lane : 0;
     auto fetch_above = [&](int t0) __attribute__((always_inline)) -> uint32_t {
-        if (!has_above || lane >= 3 * kEdGroup) return 1u;
-        return __hip_atomic_load(above + 3 * t0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __hip_atomic_load(above + 3 * t0 + wlane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
     ed_u2 cur[4], nxt[4];
     load_group(0, cur);
     uint32_t wnext = fetch_above(0);
+    uint32_t outw = 0;              // lanes 0-23: the 24 hand-off words the previous group's steps produced
     for (int g = 0; g < S.groups; g++) {
         const int t0 = kEdGroup * g;
-        if (g + 1 < S.groups) load_group(t0 + kEdGroup, nxt);
+        // publish the previous group's words (lane 63's D of columns t0 - 135 .. t0 - 128): value and tag in one word, ONE store of lanes 0-23
+        {
+            const int col0 = t0 - kEdGroup - (kEdSkew * (kEdRows - 1) + 1);
+            const int col = col0 + lane / 3;
+            const bool pub = lane < 3 * kEdGroup && col >= 0 && col < S.wl;
+            uint32_t *at = pub ? mine + 3 * col0 + lane : (uint32_t *)(dummy + 4);
+            __hip_atomic_store(at, outw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         // D of the band above for the eight columns of this group: fetched a group ago; wait for what is not there yet
         uint32_t w = wnext;
         if (has_above) {
@@ -87,11 +102,12 @@ __global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const F
             int spins = 0;
             while (__ballot(need && !(w & 1u)) != 0) {                               // wave-uniform
                 if (++spins > kEdSpinLimit) { if (lane == 0) *P.status = 1; break; }
-                __builtin_amdgcn_s_sleep(16);
+                __builtin_amdgcn_s_sleep(4);
                 w = fetch_above(t0);
             }
-            wnext = fetch_above(t0 + kEdGroup);                                      // (the row has a spare group of entries behind the last one)
         }
+        load_group(t0 + kEdGroup, nxt);                                              // (clamped: the group behind the last one reads the row's end again)
+        wnext = fetch_above(t0 + kEdGroup);                                          // (the row has a spare group of entries behind the last one)
         uint32_t even_px = 0;
         bool even_live = false;
 #pragma unroll
@@ -103,7 +119,7 @@ __global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const F
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 int32_t din = ed_from_lane_above<SHIFT>(dprev[c], lane);
-                const int32_t top = ed_untag((uint32_t)__builtin_amdgcn_readlane((int)w, 3 * s + c));     // (0 without a band above / outside the region)
+                const int32_t top = ed_untag((uint32_t)__builtin_amdgcn_readlane((int)w, 3 * s + c));     // (scalar)
                 if (lane == 0) din = has_above ? top : 0;
                 q[c] = ed_step(st[c], live, (int)((code >> (10 * c)) & 0x3ffu), din, dprev[c]);
             }
@@ -111,20 +127,27 @@ __global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const F
             if ((s & 1) == 0) { even_px = px; even_live = live; }
             else {
                 const ed_gptr at = dst_row + (size_t)(xr - 1) * 4u;
-                if (P.pair_stores && even_live && live) *(__attribute__((address_space(1))) ed_u2 *)at = ed_u2{even_px, px};
+                if (PAIR) *(__attribute__((address_space(1))) ed_u2 *)(live ? at : dummy) = ed_u2{even_px, px};      // (whole pairs: live == even_live)
                 else {
-                    if (even_live) *(__attribute__((address_space(1))) uint32_t *)at = even_px;
-                    if (live) *(__attribute__((address_space(1))) uint32_t *)(at + 4) = px;
+                    *(__attribute__((address_space(1))) uint32_t *)(even_live ? at : dummy) = even_px;
+                    *(__attribute__((address_space(1))) uint32_t *)(live ? at + 4 : dummy + 4) = px;
                 }
             }
-            // the band's bottom row: D(xr - 1) for the band below, value and tag in one word
-            if (lane == kEdRows - 1 && xr >= 1 && xr <= S.wl) {
+            // the band's bottom row: D(xr - 1) for the band below — lane 63's value travels through a scalar into lane 3 s + c of outw
 #pragma unroll
-                for (int c = 0; c < 3; c++) __hip_atomic_store(mine + 3 * (xr - 1) + c, ed_tag(dprev[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int c = 0; c < 3; c++) {
+                const uint32_t word = ed_tag(__builtin_amdgcn_readlane(dprev[c], kEdRows - 1));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(outw) : "s"(word), "n"(3 * s + c));
             }
         }
 #pragma unroll
         for (int p = 0; p < 4; p++) cur[p] = nxt[p];
+    }
+    // the last group's words: columns up to groups * 8 - 128 >= wl - 1
+    {
+        const int col0 = kEdGroup * S.groups - kEdGroup - (kEdSkew * (kEdRows - 1) + 1);
+        const int col = col0 + lane / 3;
+        if (lane < 3 * kEdGroup && col >= 0 && col < S.wl) __hip_atomic_store(mine + 3 * col0 + lane, outw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -139,14 +162,20 @@ size_t ErrorDiffusionHandoffBytes(const ErrDiffParams &P, int n_frames)
 hipError_t LaunchErrorDiffusion(const ErrDiffParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s)
 {
     if (n_frames <= 0 || (!frames_dev && n_frames != 1)) return hipErrorInvalidValue;
-    if (P.x1 <= P.x0 || P.y1 <= P.y0 || !P.handoff || !P.status) return hipErrorInvalidValue;
+    if (P.x1 <= P.x0 || P.y1 <= P.y0 || !P.handoff || !P.dummy || !P.status) return hipErrorInvalidValue;
     const EdSchedule S = ed_schedule(P.x0, P.x1, P.y1 - P.y0);
     // zero = "not written yet": the hand-off rows are cleared in front of every launch (a few MB per frame, in stream order)
     const hipError_t e = hipMemsetAsync(P.handoff, 0, ErrorDiffusionHandoffBytes(P, n_frames), s);
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)((size_t)n_frames * S.bands)), block(64);
-    if (P.shift == 1) hipLaunchKernelGGL(k_error_diffusion<1>, grid, block, 0, s, P, frames_dev, single);
-    else hipLaunchKernelGGL(k_error_diffusion<0>, grid, block, 0, s, P, frames_dev, single);
+    const bool pair = P.pair_stores && !(P.x0 & 1) && !(P.x1 & 1);
+    if (P.shift == 1) {
+        if (pair) hipLaunchKernelGGL((k_error_diffusion<1, true>), grid, block, 0, s, P, frames_dev, single);
+        else hipLaunchKernelGGL((k_error_diffusion<1, false>), grid, block, 0, s, P, frames_dev, single);
+    } else {
+        if (pair) hipLaunchKernelGGL((k_error_diffusion<0, true>), grid, block, 0, s, P, frames_dev, single);
+        else hipLaunchKernelGGL((k_error_diffusion<0, false>), grid, block, 0, s, P, frames_dev, single);
+    }
     return hipGetLastError();
 }
 

@@ -65,13 +65,10 @@ struct EdChannel {
 // otherwise the step only flushes the shares still in flight (e = 0).  dout = D(x - 1) for the row below; returns the 8-bit code.
 MPCVR_ED_HD int ed_step(EdChannel &s, bool live, int k, int32_t din, int32_t &dout)
 {
-    int q = 0;
-    int32_t e = 0;
-    if (live) {
-        const int32_t T = k * kEdCode + s.er + din;
-        q = ed_quant(T);
-        e = T - q * kEdUnit;
-    }
+    // (branch-free: off the region T is whatever the shares in flight add up to, q is not used and e is forced to zero)
+    const int32_t T = k * kEdCode + s.er + din;
+    const int q = ed_quant(T);
+    const int32_t e = live ? T - q * kEdUnit : 0;
     const int32_t r = (7 * e) >> 4, bl = (3 * e) >> 4, b = (5 * e) >> 4, br = e - r - bl - b;
     dout = s.br2 + s.b1 + bl;
     s.er = r; s.br2 = s.br1; s.br1 = br; s.b1 = b;
