@@ -1526,9 +1526,8 @@ HRESULT CHipVideoProcessor::ErrDiffPass(int n, const FusedFrame *table, FusedFra
     if (*m_edStatus) { *m_edStatus = 0; return Fail(MPCVR_E_FAIL, "error diffusion: a band of an earlier pass gave up waiting for the band above"); }
     // the hand-off rows are cleared and rewritten by every launch: launches of one context run in stream order on one buffer
     if (s != m_stream) (void)hipStreamSynchronize(m_stream);
-    const size_t rowsBytes = (ErrorDiffusionHandoffBytes(P, n) + 255) & ~(size_t)255;
-    if ((hr = CheckHip(m_edHandoff.CheckCreate(rowsBytes + 1024), "error-diffusion hand-off rows"))) return hr;
-    P.handoff = (uint32_t *)m_edHandoff.ptr; P.dummy = (uint8_t *)m_edHandoff.ptr + rowsBytes; P.status = m_edStatus;
+    if ((hr = CheckHip(m_edHandoff.CheckCreate(ErrorDiffusionHandoffBytes(P, n)), "error-diffusion hand-off rows"))) return hr;
+    P.handoff = (uint32_t *)m_edHandoff.ptr; P.status = m_edStatus;
     return CheckHip(LaunchErrorDiffusion(P, table, single, n, s), "k_error_diffusion");
 }
 

@@ -59,7 +59,10 @@ __global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const F
     uint32_t *const mine = P.handoff + ((size_t)z * S.bands + band) * (size_t)S.stride;
     const bool has_above = band > 0;
     const uint32_t *const above = has_above ? mine - S.stride : mine;                    // (the first band reads its own row: zeros, ignored)
-    const ed_gptr dummy = (ed_gptr)P.dummy + (size_t)lane * 8u;                          // where lanes off the region store
+    // where lanes off the region store: slots of this band's own row (all bands writing one shared dummy meant every wavefront of the launch
+    // pushing write-through stores at the same 64 bytes: 32 frames took eight times as long as with predicated stores)
+    uint32_t *const spare = mine + 3 * kEdGroup * S.groups;                              // the spare group: 24 words nobody waits for
+    const ed_gptr dummy = (ed_gptr)(spare + 3 * kEdGroup) + (size_t)lane * 8u;
     const int wl_even = (S.wl - 1) & ~1;                                                 // last even column a pair load may start at
 
     EdChannel st[3];
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const F
             const int col0 = t0 - kEdGroup - (kEdSkew * (kEdRows - 1) + 1);
             const int col = col0 + lane / 3;
             const bool pub = lane < 3 * kEdGroup && col >= 0 && col < S.wl;
-            uint32_t *at = pub ? mine + 3 * col0 + lane : (uint32_t *)(dummy + 4);
+            uint32_t *at = pub ? mine + 3 * col0 + lane : spare + (lane & 15);
             __hip_atomic_store(at, outw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // D of the band above for the eight columns of this group: fetched a group ago; wait for what is not there yet
@@ -162,7 +165,7 @@ size_t ErrorDiffusionHandoffBytes(const ErrDiffParams &P, int n_frames)
 hipError_t LaunchErrorDiffusion(const ErrDiffParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s)
 {
     if (n_frames <= 0 || (!frames_dev && n_frames != 1)) return hipErrorInvalidValue;
-    if (P.x1 <= P.x0 || P.y1 <= P.y0 || !P.handoff || !P.dummy || !P.status) return hipErrorInvalidValue;
+    if (P.x1 <= P.x0 || P.y1 <= P.y0 || !P.handoff || !P.status) return hipErrorInvalidValue;
     const EdSchedule S = ed_schedule(P.x0, P.x1, P.y1 - P.y0);
     // zero = "not written yet": the hand-off rows are cleared in front of every launch (a few MB per frame, in stream order)
     const hipError_t e = hipMemsetAsync(P.handoff, 0, ErrorDiffusionHandoffBytes(P, n_frames), s);

@@ -38,6 +38,7 @@ constexpr int kEdCode = 16 * 255;         // one UNORM10 code in those units
 constexpr int kEdRows = 64;               // rows per band = lanes of a wavefront
 constexpr int kEdSkew = 2;                // columns a row runs behind the row above
 constexpr int kEdGroup = 8;               // steps between two looks at the band above (and two loads of pixel pairs)
+constexpr int kEdDummyWords = 128;       // 64 lanes x 8 bytes
 
 // floor((T + U / 2) / U) clamped to a byte.  T + U/2 + 16 U is positive for every reachable T (|E| stays within a few U) and below
 // 2^23; n = that >> 4 is below 2^19, where floor(n / 1023) = mulhi(n, ceil(2^32 / 1023)) exactly (the excess 1019 n / (1023 * 2^32)
@@ -83,7 +84,9 @@ struct EdSchedule {
     int lead;            // x0 - A0
     int bands;           // ceil(rows / 64)
     int groups;          // groups of kEdGroup steps per band: lane 63 must reach the flush step at xr = wl
-    int stride;          // words of one band's hand-off row: 3 per column (R, G, B), every step of lane 0 has its entry
+    int stride;          // words of one band's hand-off row: 3 per column (R, G, B), every step of lane 0 has its entry, a spare group
+                         // behind them (where the lanes of a group's store that have nothing to publish write), then kEdDummyWords of
+                         // dummy slots for this band's pixel stores off the region
 };
 MPCVR_ED_HD EdSchedule ed_schedule(int x0, int x1, int rows)
 {
@@ -92,7 +95,7 @@ MPCVR_ED_HD EdSchedule ed_schedule(int x0, int x1, int rows)
     s.wl = x1 - a0; s.lead = x0 - a0;
     s.bands = (rows + kEdRows - 1) / kEdRows;
     s.groups = (s.wl + 1 + kEdSkew * (kEdRows - 1) + kEdGroup - 1) / kEdGroup;
-    s.stride = 3 * kEdGroup * (s.groups + 1);
+    s.stride = 3 * kEdGroup * (s.groups + 1) + kEdDummyWords;
     return s;
 }
 // hand-off words: D of column c, channel ch of a band's bottom row sits at word 3 c + ch; tagged so that zero means "not written yet"

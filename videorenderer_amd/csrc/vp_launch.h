@@ -85,8 +85,7 @@ struct ErrDiffParams {
     int src_pitch, dst_pitch;  // bytes; src rows are readable one pixel beyond x1 (the caller's intermediate has the slack)
     int pair_stores;           // every target and dst_pitch on 8-byte boundaries: one 8-byte store per pixel pair
     int shift;                 // 0: rows hand their errors down by a DPP wave shift; 1: by ds_bpermute (MPCVR_ERRDIFF_SHIFT=bpermute, A/B)
-    uint32_t *handoff;         // device: ErrorDiffusionHandoffBytes(P, n_frames) — the bands' bottom rows for the bands below (the launcher clears it)
-    void *dummy;               // device, 1 KiB: where lanes off the region put their stores (every memory instruction of the pass is unconditional)
+    uint32_t *handoff;         // device: ErrorDiffusionHandoffBytes(P, n_frames) — the bands' bottom rows for the bands below + their dummy slots (the launcher clears it)
     int *status;               // host memory the device can write: set to 1 when a band gave up waiting for the band above (never, unless a launch is broken)
 };
 size_t ErrorDiffusionHandoffBytes(const ErrDiffParams &P, int n_frames);
