@@ -1229,8 +1229,8 @@ HRESULT CHipVideoProcessor::Process(void *pRenderTarget, int rtPitch, const CRec
     if (m_plan.errdiff) {
         // EXTENSION (bUseDither = 2): the draws render into the window-sized R10G10B10A2 intermediate, as for a 10-bit swap chain; the
         // error-diffusion pass takes it to the render target
-        if (!(hr = PrepareErrDiff(1)) && !(hr = ProcessOne(m_curSample, m_edPost.ptr, m_edPitch)))
-            hr = ErrDiffPass(1, nullptr, FusedFrame{(const uint8_t *)m_edPost.ptr, pRenderTarget}, &pRenderTarget, rtPitch, m_run);
+        if (!(hr = PrepareErrDiff(1)) && !(hr = ProcessOne(m_curSample, m_edBase, m_edPitch)))
+            hr = ErrDiffPass(1, nullptr, FusedFrame{m_edBase, pRenderTarget}, &pRenderTarget, rtPitch, m_run);
     } else
         hr = ProcessOne(m_curSample, pRenderTarget, rtPitch);
     (void)hipEventRecord(m_evStop, m_run);
@@ -1502,8 +1502,11 @@ HRESULT CHipVideoProcessor::PrepareErrDiff(int frames)
 {
     m_edPitch = (m_windowRect.Width() * 4 + 255) & ~255;
     m_edStride = (size_t)m_edPitch * (size_t)m_windowRect.Height();
-    // (+ 256: the pass reads pixel pairs, the last one may end one pixel behind the last row)
-    return CheckHip(m_edPost.CheckCreate(m_edStride * (size_t)frames + 256), "error-diffusion intermediates");
+    // (256 bytes in front and behind: the pass reads its rows in 16-byte pieces that may start two pixels in front of a row and end three
+    // behind it — inside the image that is the neighbouring row's padding, at its two ends it is this margin)
+    const HRESULT hr = CheckHip(m_edPost.CheckCreate(m_edStride * (size_t)frames + 512), "error-diffusion intermediates");
+    m_edBase = hr ? nullptr : (uint8_t *)m_edPost.ptr + 256;
+    return hr;
 }
 
 HRESULT CHipVideoProcessor::ErrDiffPass(int n, const FusedFrame *table, FusedFrame single, void *const *dsts, int rtPitch, hipStream_t s)
@@ -1542,7 +1545,7 @@ HRESULT CHipVideoProcessor::ProcessBatchErrDiff(int n, const void *const *srcs, 
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)4 << 30) / std::max<size_t>(one, 1)));
     if ((hr = PrepareErrDiff(chunk))) return hr;
     std::vector<void *> mids(chunk);
-    for (int i = 0; i < chunk; i++) mids[i] = (uint8_t *)m_edPost.ptr + (size_t)i * m_edStride;
+    for (int i = 0; i < chunk; i++) mids[i] = m_edBase + (size_t)i * m_edStride;
     for (int at = 0; at < n; at += chunk) {
         const int m = std::min(chunk, n - at);
         // the whole-batch routes of the 10-bit plan, into the intermediates (the previous chunk's pass reads them in stream order)

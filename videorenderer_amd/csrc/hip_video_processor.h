@@ -273,6 +273,7 @@ private:
     DevBuffer m_edPost;
     DevBuffer m_edHandoff;         // the pass's hand-off rows between bands of 64 rows (vp_errdiff.hip)
     int *m_edStatus = nullptr;     // pinned host word the pass sets when a band gave up waiting (checked at the next pass and in Synchronize)
+    uint8_t *m_edBase = nullptr;   // first intermediate (m_edPost.ptr + a margin)
     int m_edPitch = 0;             // bytes per row of an intermediate (a multiple of 256)
     size_t m_edStride = 0;         // bytes per intermediate
     HRESULT PrepareErrDiff(int frames);

@@ -9,8 +9,8 @@
 //     and tag in one word, so there is nothing to order), the 24 words of a group of 8 steps in ONE store of lanes 0-23; lane 0 of the band
 //     below — another workgroup, usually on another XCD — fetches them one group of 8 columns ahead (lanes 0-23 load a group at once) and
 //     spins, politely and with a bound, only when the band above has not written them yet; the launcher zeroes the rows first;
-//   * a lane reads its row as 8-byte pixel pairs one group of 8 steps ahead and writes 8-byte pairs; no memory instruction of the loop
-//     is predicated (clamped addresses, a dummy slot for lanes off the region), so the waits the compiler inserts are exact.
+//   * a lane reads its row 32 pixels (one cache line's worth, eight 16-byte loads) a block of 32 steps ahead and writes 8-byte pairs; no
+//     memory instruction of the loop is predicated (clamped addresses, a dummy slot for lanes off the region), so the waits the compiler inserts are exact.
 // Round 4's first version ran a frame in ONE workgroup (16 waves taking turns behind workgroup barriers, hand-off rows in LDS): 32 of
 // 256 CUs busy on a 32-frame batch, 630 frames/s at 4K -> 8K.  The pass is a chain of W + 2 H dependent steps per frame with ~30 integer
 // instructions per channel and pixel: bound by VALU issue and by its own serial depth, not by HBM.
@@ -24,6 +24,7 @@ namespace mpcvr {
 namespace {
 
 typedef uint32_t ed_u2 __attribute__((ext_vector_type(2)));
+typedef uint32_t ed_u4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) uint8_t *ed_gcptr;
 typedef __attribute__((address_space(1))) uint8_t *ed_gptr;
 
@@ -63,19 +64,26 @@ __global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const F
     // pushing write-through stores at the same 64 bytes: 32 frames took eight times as long as with predicated stores)
     uint32_t *const spare = mine + 3 * kEdGroup * S.groups;                              // the spare group: 24 words nobody waits for
     const ed_gptr dummy = (ed_gptr)(spare + 3 * kEdGroup) + (size_t)lane * 8u;
-    const int wl_even = (S.wl - 1) & ~1;                                                 // last even column a pair load may start at
+    const int xr_last = (S.wl - 1) & ~1;                                                 // last even column of the region
 
     EdChannel st[3];
     int32_t dprev[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) { st[c] = EdChannel{0, 0, 0, 0}; dprev[c] = 0; }
 
-    // pixel pairs of a group of 8 steps: xr = t - 2 lane is even on the even step of a pair in every lane (off the region: a clamped address)
-    auto load_group = [&](int t0, ed_u2 (&v)[4]) __attribute__((always_inline)) {
+    // A block = 32 steps = the next 32 pixels of the lane's row (one cache line's worth), fetched as eight 16-byte loads a block ahead:
+    // the eight loads of a lane hit one or two lines back to back.  (8-byte loads a group of 8 steps ahead, the first cut, had every
+    // load instruction of a wavefront touch 64 lines that the CU's other wavefronts had evicted since the last visit: 16x the useful bytes
+    // from L2, and a 32-frame batch ran at a third of the single-frame rate.)  The loads are dword-aligned (xr is even, not a multiple of
+    // four in odd lanes); off the region they read a clamped position: the caller's image has a margin of two pixels in front of every
+    // row it does not own and slack behind the last one.
+    constexpr int BLK = kEdGroup * kEdBlockGroups;
+    auto load_block = [&](int tb, ed_u4 (&v)[BLK / 4]) __attribute__((always_inline)) {
+        const int xs = tb - kEdSkew * lane;
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int xr = min(max(t0 + 2 * p - kEdSkew * lane, 0), wl_even);
-            v[p] = *(const __attribute__((address_space(1))) ed_u2 *)(src_row + (size_t)xr * 4u);
+        for (int p = 0; p < BLK / 4; p++) {
+            const int xr = min(max(xs + 4 * p, -2), xr_last);
+            v[p] = *(const __attribute__((address_space(1))) ed_u4 *)(src_row + (ptrdiff_t)xr * 4);
         }
     };
     // the 24 hand-off words of a group (columns t0 .. t0 + 7, word 3 column + channel): lane l < 24 fetches word l (the others: word 0)
@@ -84,67 +92,71 @@ __global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const F
         return __hip_atomic_load(above + 3 * t0 + wlane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
-    ed_u2 cur[4], nxt[4];
-    load_group(0, cur);
+    ed_u4 cur[BLK / 4], nxt[BLK / 4];
+    load_block(0, cur);
     uint32_t wnext = fetch_above(0);
     uint32_t outw = 0;              // lanes 0-23: the 24 hand-off words the previous group's steps produced
-    for (int g = 0; g < S.groups; g++) {
-        const int t0 = kEdGroup * g;
-        // publish the previous group's words (lane 63's D of columns t0 - 135 .. t0 - 128): value and tag in one word, ONE store of lanes 0-23
-        {
-            const int col0 = t0 - kEdGroup - (kEdSkew * (kEdRows - 1) + 1);
-            const int col = col0 + lane / 3;
-            const bool pub = lane < 3 * kEdGroup && col >= 0 && col < S.wl;
-            uint32_t *at = pub ? mine + 3 * col0 + lane : spare + (lane & 15);
-            __hip_atomic_store(at, outw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // D of the band above for the eight columns of this group: fetched a group ago; wait for what is not there yet
-        uint32_t w = wnext;
-        if (has_above) {
-            const bool need = lane < 3 * kEdGroup && t0 + lane / 3 < S.wl;          // (columns beyond the region are never written, nor used)
-            int spins = 0;
-            while (__ballot(need && !(w & 1u)) != 0) {                               // wave-uniform
-                if (++spins > kEdSpinLimit) { if (lane == 0) *P.status = 1; break; }
-                __builtin_amdgcn_s_sleep(4);
-                w = fetch_above(t0);
-            }
-        }
-        load_group(t0 + kEdGroup, nxt);                                              // (clamped: the group behind the last one reads the row's end again)
-        wnext = fetch_above(t0 + kEdGroup);                                          // (the row has a spare group of entries behind the last one)
-        uint32_t even_px = 0;
-        bool even_live = false;
+    for (int blk = 0; blk < S.groups / kEdBlockGroups; blk++) {
+        load_block(BLK * (blk + 1), nxt);                                            // (clamped: the block behind the last one reads the row's end again)
 #pragma unroll
-        for (int s = 0; s < kEdGroup; s++) {
-            const int xr = t0 + s - kEdSkew * lane;
-            const bool live = row_ok && xr >= S.lead && xr < S.wl;
-            const uint32_t code = (s & 1) ? cur[s >> 1].y : cur[s >> 1].x;
-            int q[3];
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                int32_t din = ed_from_lane_above<SHIFT>(dprev[c], lane);
-                const int32_t top = ed_untag((uint32_t)__builtin_amdgcn_readlane((int)w, 3 * s + c));     // (scalar)
-                if (lane == 0) din = has_above ? top : 0;
-                q[c] = ed_step(st[c], live, (int)((code >> (10 * c)) & 0x3ffu), din, dprev[c]);
+        for (int gi = 0; gi < kEdBlockGroups; gi++) {
+            const int t0 = BLK * blk + kEdGroup * gi;
+            // publish the previous group's words (lane 63's D of columns t0 - 135 .. t0 - 128): value and tag in one word, ONE store of lanes 0-23
+            {
+                const int col0 = t0 - kEdGroup - (kEdSkew * (kEdRows - 1) + 1);
+                const int col = col0 + lane / 3;
+                const bool pub = lane < 3 * kEdGroup && col >= 0 && col < S.wl;
+                uint32_t *at = pub ? mine + 3 * col0 + lane : spare + (lane & 15);
+                __hip_atomic_store(at, outw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            const uint32_t px = 0xff000000u | ((uint32_t)q[0] << 16) | ((uint32_t)q[1] << 8) | (uint32_t)q[2];     // B8G8R8A8: R = byte 2
-            if ((s & 1) == 0) { even_px = px; even_live = live; }
-            else {
-                const ed_gptr at = dst_row + (size_t)(xr - 1) * 4u;
-                if (PAIR) *(__attribute__((address_space(1))) ed_u2 *)(live ? at : dummy) = ed_u2{even_px, px};      // (whole pairs: live == even_live)
-                else {
-                    *(__attribute__((address_space(1))) uint32_t *)(even_live ? at : dummy) = even_px;
-                    *(__attribute__((address_space(1))) uint32_t *)(live ? at + 4 : dummy + 4) = px;
+            // D of the band above for the eight columns of this group: fetched a group ago; wait for what is not there yet
+            uint32_t w = wnext;
+            if (has_above) {
+                const bool need = lane < 3 * kEdGroup && t0 + lane / 3 < S.wl;      // (columns beyond the region are never written, nor used)
+                int spins = 0;
+                while (__ballot(need && !(w & 1u)) != 0) {                           // wave-uniform
+                    if (++spins > kEdSpinLimit) { if (lane == 0) *P.status = 1; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                    w = fetch_above(t0);
                 }
             }
-            // the band's bottom row: D(xr - 1) for the band below — lane 63's value travels through a scalar into lane 3 s + c of outw
+            wnext = fetch_above(t0 + kEdGroup);                                      // (the row has a spare group of entries behind the last one)
+            uint32_t even_px = 0;
+            bool even_live = false;
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const uint32_t word = ed_tag(__builtin_amdgcn_readlane(dprev[c], kEdRows - 1));
-                asm("v_writelane_b32 %0, %1, %2" : "+v"(outw) : "s"(word), "n"(3 * s + c));
+            for (int s = 0; s < kEdGroup; s++) {
+                const int sb = kEdGroup * gi + s;                                    // step inside the block
+                const int xr = t0 + s - kEdSkew * lane;
+                const bool live = row_ok && xr >= S.lead && xr < S.wl;
+                const uint32_t code = cur[sb >> 2][sb & 3];
+                int q[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    int32_t din = ed_from_lane_above<SHIFT>(dprev[c], lane);
+                    const int32_t top = ed_untag((uint32_t)__builtin_amdgcn_readlane((int)w, 3 * s + c));     // (scalar)
+                    if (lane == 0) din = has_above ? top : 0;
+                    q[c] = ed_step(st[c], live, (int)((code >> (10 * c)) & 0x3ffu), din, dprev[c]);
+                }
+                const uint32_t px = 0xff000000u | ((uint32_t)q[0] << 16) | ((uint32_t)q[1] << 8) | (uint32_t)q[2];     // B8G8R8A8: R = byte 2
+                if ((s & 1) == 0) { even_px = px; even_live = live; }
+                else {
+                    const ed_gptr at = dst_row + (ptrdiff_t)(xr - 1) * 4;
+                    if (PAIR) *(__attribute__((address_space(1))) ed_u2 *)(live ? at : dummy) = ed_u2{even_px, px};      // (whole pairs: live == even_live)
+                    else {
+                        *(__attribute__((address_space(1))) uint32_t *)(even_live ? at : dummy) = even_px;
+                        *(__attribute__((address_space(1))) uint32_t *)(live ? at + 4 : dummy + 4) = px;
+                    }
+                }
+                // the band's bottom row: D(xr - 1) for the band below — lane 63's value travels through a scalar into lane 3 s + c of outw
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const uint32_t word = ed_tag(__builtin_amdgcn_readlane(dprev[c], kEdRows - 1));
+                    asm("v_writelane_b32 %0, %1, %2" : "+v"(outw) : "s"(word), "n"(3 * s + c));
+                }
             }
         }
 #pragma unroll
-        for (int p = 0; p < 4; p++) cur[p] = nxt[p];
+        for (int p = 0; p < BLK / 4; p++) cur[p] = nxt[p];
     }
     // the last group's words: columns up to groups * 8 - 128 >= wl - 1
     {

@@ -39,6 +39,7 @@ constexpr int kEdRows = 64;               // rows per band = lanes of a wavefron
 constexpr int kEdSkew = 2;                // columns a row runs behind the row above
 constexpr int kEdGroup = 8;               // steps between two looks at the band above (and two loads of pixel pairs)
 constexpr int kEdDummyWords = 128;       // 64 lanes x 8 bytes
+constexpr int kEdBlockGroups = 4;        // groups per block of pixel loads: a lane fetches 32 pixels of its row (one cache line's worth) at a time
 
 // floor((T + U / 2) / U) clamped to a byte.  T + U/2 + 16 U is positive for every reachable T (|E| stays within a few U) and below
 // 2^23; n = that >> 4 is below 2^19, where floor(n / 1023) = mulhi(n, ceil(2^32 / 1023)) exactly (the excess 1019 n / (1023 * 2^32)
@@ -95,6 +96,7 @@ MPCVR_ED_HD EdSchedule ed_schedule(int x0, int x1, int rows)
     s.wl = x1 - a0; s.lead = x0 - a0;
     s.bands = (rows + kEdRows - 1) / kEdRows;
     s.groups = (s.wl + 1 + kEdSkew * (kEdRows - 1) + kEdGroup - 1) / kEdGroup;
+    s.groups = (s.groups + kEdBlockGroups - 1) / kEdBlockGroups * kEdBlockGroups;
     s.stride = 3 * kEdGroup * (s.groups + 1) + kEdDummyWords;
     return s;
 }

@@ -82,7 +82,7 @@ struct FusedParams {
 // (frames[z].src, window geometry, src_pitch) -> its B8G8R8A8 render target (frames[z].dst, dst_pitch) inside [x0, x1) x [y0, y1)
 struct ErrDiffParams {
     int x0, y0, x1, y1;        // video rect ∩ window, window coordinates
-    int src_pitch, dst_pitch;  // bytes; src rows are readable one pixel beyond x1 (the caller's intermediate has the slack)
+    int src_pitch, dst_pitch;  // bytes; src is readable from two pixels in front of a row of the region to three behind it (the caller's intermediates have the margins)
     int pair_stores;           // every target and dst_pitch on 8-byte boundaries: one 8-byte store per pixel pair
     int shift;                 // 0: rows hand their errors down by a DPP wave shift; 1: by ds_bpermute (MPCVR_ERRDIFF_SHIFT=bpermute, A/B)
     uint32_t *handoff;         // device: ErrorDiffusionHandoffBytes(P, n_frames) — the bands' bottom rows for the bands below + their dummy slots (the launcher clears it)
