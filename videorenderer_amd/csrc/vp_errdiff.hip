@@ -16,6 +16,8 @@
 // instructions per channel and pixel: bound by VALU issue and by its own serial depth, not by HBM.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "vp_errdiff_core.h"
 #include "vp_launch.h"
 
@@ -28,6 +30,7 @@ typedef uint32_t ed_u4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) uint8_t *ed_gcptr;
 typedef __attribute__((address_space(1))) uint8_t *ed_gptr;
 
+constexpr int kEdOccupancyLds = 0;             // dynamic LDS claimed per workgroup (never touched): 160 KiB / that = workgroups per CU
 constexpr int kEdSpinLimit = 1 << 21;       // polls (~1 us each) a band grants the band above before it gives up and flags the launch
 
 // the value of lane - 1 (lane 0: anything — it reads the hand-off row instead)
@@ -183,13 +186,17 @@ hipError_t LaunchErrorDiffusion(const ErrDiffParams &P, const FusedFrame *frames
     const hipError_t e = hipMemsetAsync(P.handoff, 0, ErrorDiffusionHandoffBytes(P, n_frames), s);
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)((size_t)n_frames * S.bands)), block(64);
+    // Bands in flight per SIMD.  A band is a chain of dependent steps and a frame is a chain of bands: a wavefront that shares its SIMD with
+    // three busy ones runs at a quarter of its speed and so does everything behind it, so the pass wants FEW resident wavefronts, each at
+    // full speed — the kernel claims LDS it never touches to hold the occupancy down (MPCVR_ERRDIFF_LDS overrides, bytes; A/B in DESIGN.md)
+    static const size_t lds = [] { const char *e = std::getenv("MPCVR_ERRDIFF_LDS"); return e ? (size_t)std::atol(e) : (size_t)kEdOccupancyLds; }();
     const bool pair = P.pair_stores && !(P.x0 & 1) && !(P.x1 & 1);
     if (P.shift == 1) {
-        if (pair) hipLaunchKernelGGL((k_error_diffusion<1, true>), grid, block, 0, s, P, frames_dev, single);
-        else hipLaunchKernelGGL((k_error_diffusion<1, false>), grid, block, 0, s, P, frames_dev, single);
+        if (pair) hipLaunchKernelGGL((k_error_diffusion<1, true>), grid, block, lds, s, P, frames_dev, single);
+        else hipLaunchKernelGGL((k_error_diffusion<1, false>), grid, block, lds, s, P, frames_dev, single);
     } else {
-        if (pair) hipLaunchKernelGGL((k_error_diffusion<0, true>), grid, block, 0, s, P, frames_dev, single);
-        else hipLaunchKernelGGL((k_error_diffusion<0, false>), grid, block, 0, s, P, frames_dev, single);
+        if (pair) hipLaunchKernelGGL((k_error_diffusion<0, true>), grid, block, lds, s, P, frames_dev, single);
+        else hipLaunchKernelGGL((k_error_diffusion<0, false>), grid, block, lds, s, P, frames_dev, single);
     }
     return hipGetLastError();
 }
