@@ -1521,6 +1521,9 @@ HRESULT CHipVideoProcessor::ErrDiffPass(int n, const FusedFrame *table, FusedFra
         if (((uintptr_t)dsts[i] & 7) != 0) P.pair_stores = 0;
     const char *shift = std::getenv("MPCVR_ERRDIFF_SHIFT");          // (read per call: the suite runs both variants in one process)
     P.shift = shift && std::strcmp(shift, "bpermute") == 0 ? 1 : 0;
+    // band-major workgroup order: same box, 32 frames 4K -> 8K: 3.85 k frames/s against 3.28 k frame-major (profiles/r04/ab_call24_errdiff_order.jsonl)
+    static const int order = [] { const char *e = std::getenv("MPCVR_ERRDIFF_ORDER"); return e ? std::atoi(e) : 1; }();
+    P.order = order;
     HRESULT hr;
     if (!m_edStatus) {
         if ((hr = CheckHip(hipHostMalloc((void **)&m_edStatus, sizeof(int), hipHostMallocDefault), "error-diffusion status word"))) return hr;
@@ -1542,7 +1545,11 @@ HRESULT CHipVideoProcessor::ProcessBatchErrDiff(int n, const void *const *srcs, 
     (void)hipSetDevice(m_device);
     HRESULT hr;
     const size_t one = ((size_t)((m_windowRect.Width() * 4 + 255) & ~255)) * (size_t)m_windowRect.Height();
-    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)4 << 30) / std::max<size_t>(one, 1)));
+    // intermediates for up to ~4 GiB of frames at a time, in chunks of equal size: the pass is a chain of dependent steps per frame and only
+    // many frames side by side fill the chip (a 33-frame batch as 32 + 1 took 13.8 ms where 32 take 8.5: the odd frame ran alone)
+    const int most = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)4 << 30) / std::max<size_t>(one, 1)));
+    const int chunks = (n + most - 1) / most;
+    const int chunk = (n + chunks - 1) / chunks;
     if ((hr = PrepareErrDiff(chunk))) return hr;
     std::vector<void *> mids(chunk);
     for (int i = 0; i < chunk; i++) mids[i] = m_edBase + (size_t)i * m_edStride;

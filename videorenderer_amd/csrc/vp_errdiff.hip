@@ -51,7 +51,11 @@ __global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const F
 {
     const EdSchedule S = ed_schedule(P.x0, P.x1, P.y1 - P.y0);
     const int lane = threadIdx.x;
-    const int z = (int)blockIdx.x / S.bands, band = (int)blockIdx.x - z * S.bands;       // a band's producer = the workgroup in front of it
+    // workgroup -> (frame, band); either way a band's producer has a lower index.  order 0: a frame's bands are neighbours (neighbouring
+    // workgroups = neighbouring phases of one frame); 1: a band of every frame, then the next band (neighbours = the same phase of all frames)
+    const int nfr = (int)gridDim.x / S.bands;
+    const int z = P.order ? (int)blockIdx.x % nfr : (int)blockIdx.x / S.bands;
+    const int band = P.order ? (int)blockIdx.x / nfr : (int)blockIdx.x - z * S.bands;
     const FusedFrame fr = frames ? frames[z] : single;
     const int a0 = P.x0 & ~1;
     const int rows = P.y1 - P.y0;

@@ -85,6 +85,7 @@ struct ErrDiffParams {
     int src_pitch, dst_pitch;  // bytes; src is readable from two pixels in front of a row of the region to three behind it (the caller's intermediates have the margins)
     int pair_stores;           // every target and dst_pitch on 8-byte boundaries: one 8-byte store per pixel pair
     int shift;                 // 0: rows hand their errors down by a DPP wave shift; 1: by ds_bpermute (MPCVR_ERRDIFF_SHIFT=bpermute, A/B)
+    int order;                 // workgroup order: 0 = frame-major, 1 = band-major (MPCVR_ERRDIFF_ORDER, A/B)
     uint32_t *handoff;         // device: ErrorDiffusionHandoffBytes(P, n_frames) — the bands' bottom rows for the bands below + their dummy slots (the launcher clears it)
     int *status;               // host memory the device can write: set to 1 when a band gave up waiting for the band above (never, unless a launch is broken)
 };
