@@ -149,6 +149,9 @@ ED_CASES = {
     "fp16_internal": dict(cformat=2, w=64, h=48, kind="structure", seed=906, dst=(96, 72), iUpscaling=4, iTexFormat=16),
     "down_hamming": dict(GOLDEN_CASES["down_hamming_3x"]),
     "rot90": dict(cformat=2, w=64, h=48, kind="structure", seed=907, dst=(72, 96), iUpscaling=2, rotation=90),
+    "dolby_vision_poly": dict(GOLDEN_CASES["dovi_poly_sdr"]),                                          # reshaping in the convert stage, the pass behind it
+    "rgb48_no_convert_draw": dict(cformat=33, w=70, h=44, kind="structure", seed=908, dst=(105, 66), iUpscaling=4),   # the source texture feeds the resize
+    "v210_repacked": dict(cformat=10, w=96, h=40, kind="structure", seed=909, dst=(144, 60), iUpscaling=2),
 }
 
 

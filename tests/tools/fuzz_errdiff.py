@@ -22,7 +22,9 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20260926)
 paths = collections.Counter()
 bad = 0; refused = 0
 for i in range(n):
-    cf = int(rng.choice([2, 2, 20, 21, 12, 24, 38]))                  # sources above 8 bits: the internal format is 10-bit, the pass runs
+    # sources above 8 bits (the internal format is 10-bit, the pass runs): bi-planar / planar 4:2:0, packed 4:4:4 and 4:2:2, gray, v210 (repacked
+    # first), interleaved r210 / RGB48 / BGRA64 (no convert draw: the source texture feeds the resize)
+    cf = int(rng.choice([2, 2, 20, 21, 12, 24, 38, 8, 10, 32, 33, 35, 27]))
     shape = rng.random()
     if shape < 0.15: w, h = int(rng.integers(4, 24)) * 2, int(rng.integers(300, 1300)) * 2        # narrow and tall: short bands, long chains
     elif shape < 0.3: w, h = int(rng.integers(300, 900)) * 2, int(rng.integers(4, 40)) * 2         # wide and flat: one or two bands
@@ -30,6 +32,12 @@ for i in range(n):
     c = dict(cformat=cf, w=w, h=h, kind=str(rng.choice(["noise", "structure", "hdr"])), seed=int(rng.integers(1, 1 << 30)),
              iUpscaling=int(rng.choice([1, 2, 3, 4, 6])), iDownscaling=int(rng.integers(0, 6)), bUseDither=2)
     if cf in (2, 20, 21) and rng.random() < 0.4: c["exfmt"] = HDR10
+    if cf == 20 and rng.random() < 0.3:          # Dolby Vision: reshaping in the convert stage, the pass behind it
+        c["kind"] = "hdr"; c["dovi"] = dict(kind=str(rng.choice(["poly", "mmr"])))
+        c.pop("exfmt", None)
+    if rng.random() < 0.15: c["rotation"] = int(rng.choice([90, 180, 270]))
+    if rng.random() < 0.15: c["flip"] = 1
+    if cf == 10: w = (w + 5) // 6 * 6; c["w"] = w          # v210: six pixels per 16-byte group
     mode = rng.random()
     fx = fy = 1.0 if mode < 0.25 else 2.0 if mode < 0.45 else float(rng.uniform(0.5, 2.2))
     if mode >= 0.45 and rng.random() < 0.6: fy = float(rng.uniform(0.5, 2.2))
