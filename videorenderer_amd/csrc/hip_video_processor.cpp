@@ -1225,7 +1225,12 @@ HRESULT CHipVideoProcessor::Process(void *pRenderTarget, int rtPitch, const CRec
         if (m_clearOnRun) (void)hipMemsetAsync(m_BackBuffer.ptr, 0, m_clearOnRun, m_stream);
     }
     m_clearOnRun = 0;
-    (void)hipEventRecord(m_evStart, m_run);
+    // the timing pair (m_RenderStats.paintticks' stand-in): every frame off the lanes; on the lanes one frame in eight — two timestamped
+    // events per frame are two more packets in front of and behind a 45 us kernel on each of four queues (same box, timed every frame /
+    // every 8th: 4K -> 8K 20.03 k -> 20.35 k frames/s, 1080p same size 111 k -> 121-162 k; profiles/r04/ab_call29_lane_timing.jsonl)
+    static const int every = [] { const char *e = std::getenv("MPCVR_LANE_TIMING_EVERY"); const int v = e && *e ? std::atoi(e) : 8; return v < 1 ? 1 : v; }();
+    const bool timeIt = !fl || every == 1 || (m_laneFrames++ % (unsigned)every) == 0 || !m_timed;
+    if (timeIt) (void)hipEventRecord(m_evStart, m_run);
     if (m_plan.errdiff) {
         // EXTENSION (bUseDither = 2): the draws render into the window-sized R10G10B10A2 intermediate, as for a 10-bit swap chain; the
         // error-diffusion pass takes it to the render target
@@ -1233,7 +1238,7 @@ HRESULT CHipVideoProcessor::Process(void *pRenderTarget, int rtPitch, const CRec
             hr = ErrDiffPass(1, nullptr, FusedFrame{m_edBase, pRenderTarget}, &pRenderTarget, rtPitch, m_run);
     } else
         hr = ProcessOne(m_curSample, pRenderTarget, rtPitch);
-    (void)hipEventRecord(m_evStop, m_run);
+    if (timeIt) (void)hipEventRecord(m_evStop, m_run);
     m_lastRun = m_run;
     MarkConsumed();
     if (fl) NoteLaneFrame(fl, pRenderTarget);

@@ -162,6 +162,7 @@ private:
     HRESULT UploadDoviTables(int n, hipEvent_t *done);
     HRESULT ApplyDoviFrame(const DoviFrameState &f);
     std::string m_dvLastInfo;                         // the runs of the last ProcessBatchDovi call (GetLastBatchInfo: ";dovi_runs=3:tables,1:frames")
+    unsigned m_laneFrames = 0;                        // frames queued on the frame lanes (the timing pair is recorded on every n-th)
     unsigned m_launches = 0;                          // kernel launches so far (CheckHip) ...
     int m_lastBatchFrames = 0, m_lastBatchLaunches = 0;      // ... and what the last batch call used
     HRESULT ProcessBatchRoutes(int n, const void *const *srcs, void *const *dsts, int rtPitch);
