@@ -229,3 +229,49 @@ def test_full_size_4k_to_8k_equals_serial_model(mpcvr, oracle):
     assert np.array_equal(out, want), f"{(out != want).any(axis=2).sum()} pixels differ [{info}]"
     k = ((ten >> 0) & 0x3ff).astype(np.float64).mean() * 255 / 1023
     assert abs(out[..., 2].astype(np.float64).mean() - k) < 0.01
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("label", ["same_size_sdr", "resized_sdr"])
+def test_dolby_vision_batch_with_one_rpu_per_frame_through_chunked_passes(mpcvr, oracle, label):
+    """mpcvr_process_batch_dovi in front of the pass: seven frames, seven RPUs, runs cut where the kernel variant changes, each run's
+    pass cut into chunks of two frames (MPCVR_ERRDIFF_CHUNK — set for the whole GPU session of this module by the subprocess below):
+    every chunk must see ITS frames' RPUs.  Equal, bit for bit, to SetDoviMetadata + Process frame after frame."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent(f"""
+        import sys, torch
+        sys.path.insert(0, {ROOT!r})
+        from tests.test_parity_gpu import DOVI_BATCH_CASES, make_vp, BG
+        from tests.golden.cases import case_frame
+        from tests.golden import cases as G
+        from videorenderer_amd import api, synth
+        _, c, _ = next(x for x in DOVI_BATCH_CASES if x[0] == {label!r})
+        c = dict(c); c.pop("exfmt_name"); c["exfmt"] = G.ext(G.MPEG2, G.TV); c["bUseDither"] = 2
+        kinds = [dict(kind="poly"), dict(kind="mmr"), dict(kind="mixed"), dict(kind="mmr", l2=(100, 600, 1000)), dict(kind="poly"),
+                 dict(kind="identity", l2=(600,)), dict(kind="mixed")]
+        rpus = []
+        for i, k in enumerate(kinds):
+            md = api.DoviMetadata.from_dict(synth.dovi_metadata(**k))
+            md.ycc_to_rgb_matrix[0] *= 1.0 - 0.01 * i
+            md.ycc_to_rgb_offset[1] += 0.001 * i
+            rpus.append(md)
+        frames = [torch.from_numpy(case_frame(dict(c, seed=c["seed"] + 31 * i))[0]).cuda() for i in range(len(rpus))]
+        one, (ww, wh) = make_vp(None, c)
+        pitch = one.GetFrameBytes()[1]
+        singles = []
+        for f, md in zip(frames, rpus):
+            d = torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda")
+            one.SetDoviMetadata(md); one.CopySample(f, pitch); one.Process(d, ww * 4); singles.append(d)
+        one.Synchronize()
+        assert "errdiff" in one.GetVPInfo(), one.GetVPInfo()
+        vp, _ = make_vp(None, c)
+        dsts = [torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda") for _ in frames]
+        vp.ProcessBatchDovi(frames, dsts, ww * 4, rpus); vp.Synchronize()
+        bad = [i for i in range(len(frames)) if not torch.equal(singles[i], dsts[i])]
+        assert not bad, (bad, vp.GetLastBatchInfo())
+        assert not torch.equal(dsts[0], dsts[1])
+        print("ok", vp.GetLastBatchInfo())
+    """)
+    env = dict(os.environ, MPCVR_ERRDIFF_CHUNK="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

@@ -1552,16 +1552,29 @@ HRESULT CHipVideoProcessor::ProcessBatchErrDiff(int n, const void *const *srcs, 
     const size_t one = ((size_t)((m_windowRect.Width() * 4 + 255) & ~255)) * (size_t)m_windowRect.Height();
     // intermediates for up to ~4 GiB of frames at a time, in chunks of equal size: the pass is a chain of dependent steps per frame and only
     // many frames side by side fill the chip (a 33-frame batch as 32 + 1 took 13.8 ms where 32 take 8.5: the odd frame ran alone)
-    const int most = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)4 << 30) / std::max<size_t>(one, 1)));
+    static const int cap = [] { const char *e = std::getenv("MPCVR_ERRDIFF_CHUNK"); return e ? std::atoi(e) : 0; }();      // (tests: chunks of a few small frames)
+    int most = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)4 << 30) / std::max<size_t>(one, 1)));
+    if (cap > 0) most = std::min(most, cap);
     const int chunks = (n + most - 1) / most;
     const int chunk = (n + chunks - 1) / chunks;
     if ((hr = PrepareErrDiff(chunk))) return hr;
+    bool usedTables = false;         // (ProcessBatchDovi reports per run whether the per-frame tables were read)
     std::vector<void *> mids(chunk);
     for (int i = 0; i < chunk; i++) mids[i] = m_edBase + (size_t)i * m_edStride;
     for (int at = 0; at < n; at += chunk) {
         const int m = std::min(chunk, n - at);
-        // the whole-batch routes of the 10-bit plan, into the intermediates (the previous chunk's pass reads them in stream order)
-        if ((hr = ProcessBatchRoutes(m, srcs + at, mids.data(), m_edPitch))) return hr;
+        // the whole-batch routes of the 10-bit plan, into the intermediates (the previous chunk's pass reads them in stream order); a run of
+        // ProcessBatchDovi hands its per-frame RPU state over by frame index: the chunk sees its own slice
+        const DoviFrameState *const dvFrames = m_dvFrames;
+        const DoviParams *const dvTab = m_dvTabReady;
+        const float *const dvCm = m_dvCmReady;
+        if (m_dvFrames) m_dvFrames += at;
+        if (m_dvTabReady) { m_dvTabReady += at; m_dvCmReady += (size_t)12 * at; }
+        if (m_dvFrames) { m_dvTabDev = nullptr; m_dvCmDev = nullptr; }      // (a chunk that goes frame by frame must not read the tables the chunk before it took)
+        hr = ProcessBatchRoutes(m, srcs + at, mids.data(), m_edPitch);
+        m_dvFrames = dvFrames; m_dvTabReady = dvTab; m_dvCmReady = dvCm;
+        if (hr) return hr;
+        usedTables = usedTables || m_dvTabDev != nullptr;
         const FusedFrame *tab = nullptr;
         hipEvent_t done = nullptr;
         if ((hr = UploadFrameTable(m, (const void *const *)mids.data(), dsts + at, nullptr, 0, &tab, &done))) return hr;
@@ -1569,6 +1582,7 @@ HRESULT CHipVideoProcessor::ProcessBatchErrDiff(int n, const void *const *srcs, 
         (void)hipEventRecord(done, m_stream);
         if (hr) return hr;
     }
+    if (m_dvFrames && usedTables && !m_dvTabDev) { m_dvTabDev = m_dvTabReady; m_dvCmDev = m_dvCmReady; }
     (void)hipEventRecord(m_evStop, m_stream);       // (the batch's process time includes the pass)
     m_timed = true;
     return MPCVR_S_OK;
