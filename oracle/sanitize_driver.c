@@ -1,7 +1,8 @@
 /* oracle/sanitize_driver.c — TEST INFRASTRUCTURE: the oracle under AddressSanitizer + UndefinedBehaviorSanitizer.
  * `make -C oracle sanitize` compiles mpcvr_oracle.c together with this driver (-fsanitize=address,undefined, no OpenMP) and runs
  * whole frames of awkward shapes through orc_process: every ColorFormat_t value, odd sizes, source rects, up / down / mixed
- * ratios, windows that clip the video rect, rotations, HDR tails.  A memory error or UB report makes it exit non-zero. */
+ * ratios, windows that clip the video rect, rotations, HDR tails; and the error-diffusion extension's serial model over regions of
+ * awkward shapes.  A memory error or UB report makes it exit non-zero. */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -51,6 +52,18 @@ int main(void)
             runs++;
             free(dst); free(src);
         }
-    printf("sanitize_driver: %d frames processed, %d refused combinations, no sanitizer report\n", runs, refused);
+    /* the error-diffusion extension's serial model: regions of awkward shapes inside larger images (one column, one row, odd edges) */
+    int ed_runs = 0;
+    for (int rep = 0; rep < 40; rep++) {
+        const int w = rnd(1, 90), h = rnd(1, 150);
+        const int x0 = rnd(0, w - 1), y0 = rnd(0, h - 1), x1 = rnd(x0 + 1, w), y1 = rnd(y0 + 1, h);
+        uint32_t *img = (uint32_t *)malloc((size_t)w * h * 4);
+        for (int i = 0; i < w * h; i++) img[i] = next32() & 0x3fffffffu;
+        uint8_t *out = (uint8_t *)calloc((size_t)w * h, 4);
+        if (orc_error_diffusion(img, w * 4, out, w * 4, x0, y0, x1, y1) != 0) refused++;
+        ed_runs++;
+        free(out); free(img);
+    }
+    printf("sanitize_driver: %d frames processed, %d error-diffusion regions, %d refused combinations, no sanitizer report\n", runs, ed_runs, refused);
     return 0;
 }
