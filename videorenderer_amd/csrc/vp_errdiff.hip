@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "vp_errdiff_core.h"
 #include "vp_launch.h"
@@ -33,12 +34,15 @@ typedef __attribute__((address_space(1))) uint8_t *ed_gptr;
 constexpr int kEdOccupancyLds = 0;             // dynamic LDS claimed per workgroup (never touched): 160 KiB / that = workgroups per CU
 constexpr int kEdSpinLimit = 1 << 21;       // polls (~1 us each) a band grants the band above before it gives up and flags the launch
 
-// the value of lane - 1 (lane 0: anything — it reads the hand-off row instead)
+// the value of lane - 1; lane 0 — the band's top row, which has no lane above — gets `top` (wave-uniform: the band above's D of this column).
+// DPP: `top` rides in as the instruction's old-value operand, which a lane without a source keeps (v_mov + v_mov_dpp; the select
+// behind a zero-initialised shift was four instructions per channel and step)
 template <int SHIFT>
-__device__ __forceinline__ int32_t ed_from_lane_above(int32_t v, int lane)
+__device__ __forceinline__ int32_t ed_from_lane_above(int32_t v, int32_t top, int lane)
 {
-    if (SHIFT == 0) return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-    return __builtin_amdgcn_ds_bpermute(((lane - 1) & 63) << 2, v);
+    if (SHIFT == 0) return __builtin_amdgcn_update_dpp(top, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    const int32_t d = __builtin_amdgcn_ds_bpermute(((lane - 1) & 63) << 2, v);
+    return lane == 0 ? top : d;
 }
 
 // PAIR: every pixel pair (even column, odd column) of the region is whole (x0 and x1 even) and every target row starts on an 8-byte
@@ -103,8 +107,11 @@ __global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const F
     load_block(0, cur);
     uint32_t wnext = fetch_above(0);
     uint32_t outw = 0;              // lanes 0-23: the 24 hand-off words the previous group's steps produced
-    for (int blk = 0; blk < S.groups / kEdBlockGroups; blk++) {
-        load_block(BLK * (blk + 1), nxt);                                            // (clamped: the block behind the last one reads the row's end again)
+    const bool full_band = (band + 1) * kEdRows <= rows;
+    // one block of 32 steps; ALL: every lane stands on a pixel of the region at every step of the block (wave-uniform, true for all but the
+    // first four and the last block or two of a full band) — no live test, no select of e, no dummy addresses
+    auto run_block = [&](auto ALLC, int blk) __attribute__((always_inline)) {
+        constexpr bool ALL = decltype(ALLC)::value;
 #pragma unroll
         for (int gi = 0; gi < kEdBlockGroups; gi++) {
             const int t0 = BLK * blk + kEdGroup * gi;
@@ -128,30 +135,31 @@ __global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const F
                 }
             }
             wnext = fetch_above(t0 + kEdGroup);                                      // (the row has a spare group of entries behind the last one)
+            if (!has_above) w = 0;                                                   // (the frame's first band: nothing comes down; untag(0) = 0)
             uint32_t even_px = 0;
             bool even_live = false;
 #pragma unroll
             for (int s = 0; s < kEdGroup; s++) {
                 const int sb = kEdGroup * gi + s;                                    // step inside the block
                 const int xr = t0 + s - kEdSkew * lane;
-                const bool live = row_ok && xr >= S.lead && xr < S.wl;
+                const bool live = ALL || (row_ok && xr >= S.lead && xr < S.wl);
                 const uint32_t code = cur[sb >> 2][sb & 3];
                 int q[3];
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    int32_t din = ed_from_lane_above<SHIFT>(dprev[c], lane);
-                    const int32_t top = ed_untag((uint32_t)__builtin_amdgcn_readlane((int)w, 3 * s + c));     // (scalar)
-                    if (lane == 0) din = has_above ? top : 0;
+                    const int32_t top = ed_untag((uint32_t)__builtin_amdgcn_readlane((int)w, 3 * s + c));      // (scalar)
+                    const int32_t din = ed_from_lane_above<SHIFT>(dprev[c], top, lane);
                     q[c] = ed_step(st[c], live, (int)((code >> (10 * c)) & 0x3ffu), din, dprev[c]);
                 }
-                const uint32_t px = 0xff000000u | ((uint32_t)q[0] << 16) | ((uint32_t)q[1] << 8) | (uint32_t)q[2];     // B8G8R8A8: R = byte 2
+                // B8G8R8A8: R = byte 2; ed_step answers q + 16: the three biases leave in one subtraction
+                const uint32_t px = (((uint32_t)q[0] << 16) | ((uint32_t)q[1] << 8) | (uint32_t)q[2]) + (0xff000000u - 0x00101010u);
                 if ((s & 1) == 0) { even_px = px; even_live = live; }
                 else {
                     const ed_gptr at = dst_row + (ptrdiff_t)(xr - 1) * 4;
-                    if (PAIR) *(__attribute__((address_space(1))) ed_u2 *)(live ? at : dummy) = ed_u2{even_px, px};      // (whole pairs: live == even_live)
+                    if (PAIR) *(__attribute__((address_space(1))) ed_u2 *)(ALL || live ? at : dummy) = ed_u2{even_px, px};      // (whole pairs: live == even_live)
                     else {
-                        *(__attribute__((address_space(1))) uint32_t *)(even_live ? at : dummy) = even_px;
-                        *(__attribute__((address_space(1))) uint32_t *)(live ? at + 4 : dummy + 4) = px;
+                        *(__attribute__((address_space(1))) uint32_t *)(ALL || even_live ? at : dummy) = even_px;
+                        *(__attribute__((address_space(1))) uint32_t *)(ALL || live ? at + 4 : dummy + 4) = px;
                     }
                 }
                 // the band's bottom row: D(xr - 1) for the band below — lane 63's value travels through a scalar into lane 3 s + c of outw
@@ -162,6 +170,12 @@ __global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const F
                 }
             }
         }
+    };
+    for (int blk = 0; blk < S.groups / kEdBlockGroups; blk++) {
+        load_block(BLK * (blk + 1), nxt);                                            // (clamped: the block behind the last one reads the row's end again)
+        const int tb = BLK * blk;
+        if (full_band && tb - kEdSkew * (kEdRows - 1) >= S.lead && tb + BLK - 1 < S.wl) run_block(std::true_type{}, blk);
+        else run_block(std::false_type{}, blk);
 #pragma unroll
         for (int p = 0; p < BLK / 4; p++) cur[p] = nxt[p];
     }

@@ -48,18 +48,21 @@ constexpr int kEdGroup = 8;               // steps between two looks at the band
 constexpr int kEdDummyWords = 128;       // 64 lanes x 8 bytes
 constexpr int kEdBlockGroups = 4;        // groups per block of pixel loads: a lane fetches 32 pixels of its row (one cache line's worth) at a time
 
-// floor((T + U / 2) / U) clamped to a byte.  T + U/2 + 16 U is positive for every reachable T (|E| stays within a few U) and below
-// 2^23; n = that >> 4 is below 2^19, where floor(n / 1023) = mulhi(n, ceil(2^32 / 1023)) exactly (the excess 1019 n / (1023 * 2^32)
-// stays below 1 / 1023 up to n = 4.2 M) — tests/test_errdiff.py checks the whole range against the division
+// floor((T + U / 2) / U) clamped to a byte, as a BIASED code q + 16 from the biased sum Tb = T + U/2 + 16 U: Tb is positive for every
+// reachable T (|E| stays within a few U) and below 2^23; n = Tb >> 4 is below 2^19, where floor(n / 1023) = mulhi(n, ceil(2^32 / 1023))
+// exactly (the excess 1019 n / (1023 * 2^32) stays below 1 / 1023 up to n = 4.2 M) — tests/test_errdiff.py checks the whole range against
+// the division.  The masks change no value (n < 2^19, the magic < 2^23) and let the compiler take the full-rate 24-bit multiply-high; the
+// bias saves the kernel an addition per channel (it subtracts 16 from the three codes of a pixel at once, in the packed word)
 constexpr uint32_t kEdMagic = 4198405u;   // ceil(2^32 / 1023)
-MPCVR_ED_HD int ed_quant(int32_t T)
+constexpr int32_t kEdBias = kEdUnit / 2 + 16 * kEdUnit;
+MPCVR_ED_HD int ed_quant_biased(int32_t Tb)
 {
-    // (the masks change no value — n < 2^19, the magic < 2^23 — and let the compiler take the full-rate 24-bit multiply-high; the 32-bit
-    // multiplies are quarter-rate on CDNA: with them a step cost 111 issue slots instead of 93)
-    const uint32_t n = ((uint32_t)(T + kEdUnit / 2 + 16 * kEdUnit) >> 4) & 0xffffffu;
-    const int q = (int)(uint32_t)(((uint64_t)n * (uint64_t)(kEdMagic & 0xffffffu)) >> 32) - 16;
-    return q < 0 ? 0 : q > 255 ? 255 : q;
+    const uint32_t n = ((uint32_t)Tb >> 4) & 0xffffffu;
+    const uint32_t qb = (uint32_t)(((uint64_t)n * (uint64_t)(kEdMagic & 0xffffffu)) >> 32);
+    const uint32_t lo = qb > 16u ? qb : 16u;             // (max, then min: one v_med3_u32)
+    return (int)(lo < 271u ? lo : 271u);
 }
+MPCVR_ED_HD int ed_quant(int32_t T) { return ed_quant_biased(T + kEdBias) - 16; }
 
 // one channel of one row: what the lane carries from pixel to pixel
 struct EdChannel {
@@ -69,17 +72,19 @@ struct EdChannel {
 };
 
 // One step of one channel.  live: the lane stands on a pixel of the region (k = its code, din = D of that column from the row above);
-// otherwise the step only flushes the shares still in flight (e = 0).  dout = D(x - 1) for the row below; returns the 8-bit code.
+// otherwise the step only flushes the shares still in flight (e = 0).  dout = D(x - 1) for the row below; returns the BIASED 8-bit code
+// q + 16 (meaningful on live pixels only).
 MPCVR_ED_HD int ed_step(EdChannel &s, bool live, int k, int32_t din, int32_t &dout)
 {
-    // (branch-free: off the region T is whatever the shares in flight add up to, q is not used and e is forced to zero)
-    const int32_t T = k * kEdCode + s.er + din;
-    const int q = ed_quant(T);
-    const int32_t e = live ? T - (int32_t)(((uint32_t)q & 0xffu) * (uint32_t)kEdUnit) : 0;        // (q is a byte: a 24-bit multiply)
+    // (branch-free: off the region Tb is whatever the shares in flight add up to, the code is not used and e is forced to zero)
+    const int32_t Tb = (k * kEdCode + s.er) + din + kEdBias;
+    const int qb = ed_quant_biased(Tb);
+    // T - q U = Tb - (q + 16) U - U/2; q + 16 < 2^9: a 24-bit multiply
+    const int32_t e = live ? Tb - (int32_t)(((uint32_t)qb & 0x1ffu) * (uint32_t)kEdUnit) - kEdUnit / 2 : 0;
     const int32_t r = MPCVR_ED_MUL24(e, 7) >> 4, bl = (3 * e) >> 4, b = (5 * e) >> 4, br = e - r - bl - b;      // (|e| stays far below 2^23)
     dout = s.br2 + s.b1 + bl;
     s.er = r; s.br2 = s.br1; s.br1 = br; s.b1 = b;
-    return q;
+    return qb;
 }
 
 // ---- the schedule ----
