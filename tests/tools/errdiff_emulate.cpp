@@ -77,9 +77,9 @@ extern "C" int ed_emulate(const uint32_t *src10, int src_pitch, uint8_t *dst, in
                     const int32_t din = lane == 0 ? (above ? ed_untag(above[3 * (t0 + s) + c]) : 0) : shifted[lane][c];
                     q[c] = ed_step(W.st[lane][c], live, (int)((code >> (10 * c)) & 0x3ffu), din, W.dprev[lane][c]);
                 }
-                if (live) {         // (ed_step answers the biased code q + 16)
-                    uint8_t *px = dst + (size_t)(y0 + r) * dst_pitch + (size_t)(a0 + xr) * 4;
-                    px[0] = (uint8_t)(q[2] - 16); px[1] = (uint8_t)(q[1] - 16); px[2] = (uint8_t)(q[0] - 16); px[3] = 0xff;
+                if (live) {         // (ed_step answers the biased code q + 16; the kernel's own packing)
+                    const uint32_t texel = ed_pack_bgra(q[0], q[1], q[2]);
+                    std::memcpy(dst + (size_t)(y0 + r) * dst_pitch + (size_t)(a0 + xr) * 4, &texel, 4);
                 }
                 if (lane == kEdRows - 1 && xr >= 1 && xr <= S.wl)
                     for (int c = 0; c < 3; c++) mine[3 * (xr - 1) + c] = ed_tag(W.dprev[lane][c]);

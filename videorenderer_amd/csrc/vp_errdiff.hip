@@ -151,9 +151,7 @@ __global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const F
                     const int32_t din = ed_from_lane_above<SHIFT>(dprev[c], top, lane);
                     q[c] = ed_step(st[c], live, (int)((code >> (10 * c)) & 0x3ffu), din, dprev[c]);
                 }
-                // B8G8R8A8: R = byte 2; ed_step answers q + 16: the three biases leave in one subtraction
-                // (sums, not ors: a biased code reaches 271 and carries into the field above it until the bias is taken out)
-                const uint32_t px = (((uint32_t)q[0] << 16) + ((uint32_t)q[1] << 8) + (uint32_t)q[2]) + (0xff000000u - 0x00101010u);
+                const uint32_t px = ed_pack_bgra(q[0], q[1], q[2]);                  // (ed_step answers q + 16: the three biases leave in one subtraction)
                 if ((s & 1) == 0) { even_px = px; even_live = live; }
                 else {
                     const ed_gptr at = dst_row + (ptrdiff_t)(xr - 1) * 4;

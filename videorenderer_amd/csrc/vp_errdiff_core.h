@@ -87,6 +87,14 @@ MPCVR_ED_HD int ed_step(EdChannel &s, bool live, int k, int32_t din, int32_t &do
     return qb;
 }
 
+// The B8G8R8A8 texel of three BIASED codes (ed_step's answers): R = byte 2, alpha 0xFF.  A sum, not an or: a biased code reaches 271 and
+// carries into the field above it until the three biases are taken out in one subtraction (shared with the host emulation: the first
+// cut or-ed the fields in the kernel only, and only the GPU tests could see it)
+MPCVR_ED_HD uint32_t ed_pack_bgra(int qr, int qg, int qb)
+{
+    return (((uint32_t)qr << 16) + ((uint32_t)qg << 8) + (uint32_t)qb) + (0xff000000u - 0x00101010u);
+}
+
 // ---- the schedule ----
 // Region columns are counted from A0 = x0 & ~1 (xr = column - A0), so that xr and the step index have the same parity in every lane:
 // a pair of steps (even, odd) covers one 8-byte aligned pixel pair.  wl = x1 - A0 columns, the first x0 - A0 (0 or 1) of them outside.
