@@ -2198,3 +2198,118 @@ def test_bench_two_ranks_one_gpu(mpcvr, torch_cuda):
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["scaling"] == "weak"
     assert r["value"] > 0 and r["config"]["path"] == "fused_up2x"
     assert abs(r["config"]["fps_per_gpu"] * 2 - r["value"]) < 1e-2 * r["value"]
+
+
+# ------------------------------------------------------------------------------------------------
+# 8-bit internal formats in front of a resize (round 5): the convert stage of the block / fused kernels takes its EXACT form there
+# (FusedArgs::exact_cv, convert_block_exact in csrc/vp_fused_dev.h): every texel of m_TexConvertOutput carries the oracle's code, so a
+# negative-lobe filter has no one-code-off texel to amplify to two codes.  Until round 4 the fuzz tool counted that class (1-3 channels
+# per 1e6 on NV12 / YV12 resizes) instead of failing on it.
+def _exact8_cases():
+    from tests.golden.cases import ext, MPEG1, MPEG2, COSITED, TV, FULL, M709, M601
+    sdr = GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]
+    out = []
+    # (label, cformat, extra): every source layout the block convert reads, every siting / chroma filter with an exact form of its own
+    for label, cf, extra in [
+            ("nv12", 1, {}), ("yv12", 14, {}), ("yuv420p8_mpeg1", 17, dict(exfmt=ext(MPEG1, TV, M601))), ("nv12_cosited_full", 1, dict(exfmt=ext(COSITED, FULL, M709))),
+            ("nv12_nearest", 1, dict(iChromaScaling=0)), ("yuv420p8_catmull", 17, dict(iChromaScaling=2)), ("nv12_catmull_mpeg1", 1, dict(iChromaScaling=2, exfmt=ext(MPEG1, TV, M709))),
+            ("yuy2", 4, {}), ("uyvy", 5, {}), ("ayuv", 11, {}), ("yv16", 15, {}), ("yuv422p8_nearest", 18, dict(iChromaScaling=0)), ("yv24", 16, {}), ("yuv444p8", 19, {}),
+            ("gbrp8", 26, dict(exfmt=0)), ("y8", 37, {}),
+            # deeper sources behind a forced 8-bit internal format: the 16-bit loaders, the CopyPlane10to16 shift, the 10:10:10:2 texel
+            ("p010_tex8", 2, dict(iTexFormat=8)), ("yuv420p10_tex8", 20, dict(iTexFormat=8)), ("yuv422p10_tex8", 22, dict(iTexFormat=8)),
+            ("y410_tex8", 12, dict(iTexFormat=8)), ("y416_tex8", 13, dict(iTexFormat=8)), ("y210_tex8", 8, dict(iTexFormat=8)), ("yuv444p10_tex8", 24, dict(iTexFormat=8))]:
+        c = dict(cformat=cf, w=320, h=200, kind="noise", seed=8800 + len(out), exfmt=sdr, iUpscaling=4, dst=(270, 430), rotation=90)
+        c.update(extra)
+        out.append((label, c))
+    return out
+
+
+@pytest.mark.parametrize("label,c", _exact8_cases())
+def test_exact_convert_stage_carries_the_oracles_codes(mpcvr, oracle, torch_cuda, label, c):
+    """A quarter turn keeps the draws on the plain kernels (bit-exact with the oracle on SDR content) while the convert draw is the 2x2-block
+    kernel: the whole frame is then identical to the oracle bit for bit exactly when every convert texel is (192,000 channels per case;
+    the fast form of the stage differs in ~1e-4 of them)."""
+    from videorenderer_amd import api
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+    got, info = run_product(mpcvr, torch_cuda, c)
+    assert info.startswith("passes:convert"), info
+    compare(got, want, f"{label} [{info}]", exact=True)
+
+
+FUZZ_8000_CASE_1250 = dict(cformat=17, w=544, h=98, kind="noise", seed=46112843, exfmt=32768, iChromaScaling=1, iUpscaling=2, iDownscaling=0,
+                           bInterpolateAt50pct=1, dst=(981, 133))
+
+
+def test_amplified_convert_code_replay_of_fuzz_8000_case_1250(mpcvr, oracle, torch_cuda):
+    """profiles/r04/fuzz_8000.txt case 1250 (YUV420P8 544x98 -> 981x133 Catmull-Rom through k_fused_strip): one channel came out two codes off
+    the oracle with the contracted convert stage."""
+    c = FUZZ_8000_CASE_1250
+    frame, pitch = case_frame(c)
+    want = oracle.process(oracle_params(oracle, c), frame, pitch)
+    got, info = run_product(mpcvr, torch_cuda, c)
+    assert "fused_strip" in info or "fused_period" in info, info
+    compare(got, want, f"fuzz_8000 case 1250 [{info}]", min_same=0.98)
+
+
+def _hunt_case(rng, i):
+    """8-bit internal format x negative-lobe filter x a ratio that is not 2x (a third of the cases exactly 2x: the other fused kernel)"""
+    sdr = GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]
+    cf = int(rng.choice([1, 1, 14, 17, 4, 5, 11, 15, 18, 16, 19, 2, 20]))
+    w, h = int(rng.integers(120, 330)) * 2, int(rng.integers(60, 150)) * 2
+    c = dict(cformat=cf, w=w, h=h, kind="noise", seed=int(rng.integers(1, 1 << 30)), exfmt=sdr, iChromaScaling=int(rng.choice([0, 1, 1, 1])),
+             iUpscaling=int(rng.choice([1, 2, 2, 3, 4, 4])), iDownscaling=int(rng.choice([3, 4, 5])), bInterpolateAt50pct=int(rng.integers(0, 2)))
+    if cf in (2, 20):
+        c["iTexFormat"] = 8
+    mode = rng.random()
+    if mode < 0.3:
+        fx = fy = 2.0
+    elif mode < 0.55:       # a periodic row ratio
+        P_, Q_ = [(4, 3), (3, 2), (2, 3), (1, 2), (3, 1)][int(rng.integers(0, 5))]
+        h -= h % (2 * Q_); c["h"] = h
+        fx = fy = P_ / Q_
+        c["bInterpolateAt50pct"] = 1
+    else:
+        fx, fy = float(rng.uniform(0.45, 2.6)), float(rng.uniform(0.45, 2.6))
+    dw, dh = max(8, int(round(w * fx))), max(8, int(round(h * fy)))
+    if mode >= 0.55:
+        dw += dw == w; dh += dh == h
+    c["dst"] = (dw, dh)
+    return c
+
+
+def test_hunt_8bit_internal_formats_behind_negative_lobe_filters(mpcvr, oracle, torch_cuda):
+    """300 seeded shapes where the amplified-convert-code class lived (8-bit internal format, Catmull-Rom / Lanczos / bicubic, any ratio):
+    the default planner within ONE code of the oracle on every channel — no count of exceptions."""
+    from videorenderer_amd import api
+    rng = np.random.default_rng(20260925)
+    kernels = {}
+    channels = 0
+    for i in range(300):
+        c = _hunt_case(rng, i)
+        frame, pitch = case_frame(c)
+        want = oracle.process(oracle_params(oracle, c), frame, pitch)
+        got, info = run_product(mpcvr, torch_cuda, c)
+        d = np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
+        assert d.max() <= 1, f"hunt {i}: {int((d > 1).sum())} channel(s) beyond one code (max {int(d.max())}) [{info}] {c}"
+        assert float((d == 0).mean()) >= 0.97, f"hunt {i} [{info}] {c}"
+        channels += d.size
+        k = [q for q in info.split(";") if q.startswith("kernel=")]
+        key = k[0].split("(")[0] if k else info.split(";")[0]
+        kernels[key] = kernels.get(key, 0) + 1
+    assert sum(v for k, v in kernels.items() if "fused" in k) >= 200, kernels
+    if os.environ.get("MPCVR_PARITY_LOG"):
+        import json
+        with open(os.environ["MPCVR_PARITY_LOG"], "a") as f:
+            f.write(json.dumps({"test": "hunt_8bit_internal", "cases": 300, "channels": int(channels), "kernels": kernels, "beyond_one_code": 0}) + "\n")
+
+
+def test_full_size_up1440_nv12_within_one_code(mpcvr, oracle, torch_cuda):
+    """bench.py's up1440_nv12 at its real size (1080p NV12 -> Catmull-Rom 4:3 -> 1440p, 8-bit internal format): all 11 M channels within one code."""
+    c = dict(cformat=1, w=1920, h=1080, kind="noise", seed=1440, dst=(2560, 1440), iUpscaling=2, exfmt=GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"])
+    frame, pitch = case_frame(c)
+    want = oracle.process(oracle_params(oracle, c), frame, pitch)
+    got, info = run_product(mpcvr, torch_cuda, c)
+    assert "fused_period" in info, info
+    compare(got, want, f"up1440_nv12 [{info}]", min_same=WHOLE_FRAME_FLOOR)

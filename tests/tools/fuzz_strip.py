@@ -129,13 +129,15 @@ for i in range(n):
         oracle_cases += 1
         if not has_tail(c):
             assert dp.max() == 0, f"plain tier vs oracle: max {int(dp.max())}, {int((dp > 0).sum())} channels: {name}"
-            # (default planner, no tail: a convert texel one code off the oracle's — the fused tiers contract a*b + c, the oracle does not: 1e-4 of the
-            # texels of an 8-bit internal format — can leave a Catmull-Rom / Lanczos tap sum (sum |w| = 1.3 - 1.6 over both axes) two codes off:
-            # measured 1 - 3 channels per ~1e6 on uniform noise, the same on the round-3 library; never more than lim + 1, never more than 4 per frame)
+            # (default planner, no tail: within the bar on every channel.  Until round 4 a convert texel one code off the oracle's — the fused tiers
+            # contracted a*b + c, 1e-4 of the texels of an 8-bit internal format — could leave a Catmull-Rom / Lanczos tap sum two codes off, 1 - 3
+            # channels per ~1e6, and this tool counted them; round 5 gave 8-bit internal formats the exact form of the convert stage
+            # (convert_block_exact).  A 10-bit target behind a 10-bit internal format keeps the fast form: lim there is in ten-bit codes.)
             n_over = int((dg > lim).sum())
-            assert dg.max() <= lim + 1 and n_over <= 4 and float((dg == 0).mean()) >= 0.97, f"default planner vs oracle: max {int(dg.max())}, {n_over} channels beyond {lim}: {name}"
+            over_ok = 0 if (c.get("output_format", 0) != 1 or internal_is_8bit(c)) else 4        # (10-bit codes of a 10-bit target: a quarter of the 8-bit bar each)
+            assert dg.max() <= lim + (1 if over_ok else 0) and n_over <= over_ok and float((dg == 0).mean()) >= 0.97, f"default planner vs oracle: max {int(dg.max())}, {n_over} channels beyond {lim}: {name}"
             if n_over:
-                print(f"  amplified convert code: {n_over} channel(s) at {int(dg.max())} vs the oracle in {name}")
+                print(f"  ten-bit target, 10-bit internal format: {n_over} channel(s) at {int(dg.max())} ten-bit codes vs the oracle in {name}")
         elif c.get("output_format", 0) == 1:        # 10-bit targets behind a tail: the suite's compare_rgb10 bar (<= 2 ten-bit codes, 5 with 8-bit
             # intermediates), or — per channel — inside the oracle's own +-4 ulp pow() interval
             from tests.test_parity_gpu import compare_behind_tail
@@ -158,5 +160,7 @@ for i in range(n):
     # (without a tail: a block-convert texel one code off its plain-kernel value can come out of a Lanczos tap sum 1.2 codes off,
     # i.e. two 10-bit codes after both roundings — seen once per ~1e6 channels; never beyond lim + 1)
     worst_ok = (8 * (4 if c.get("output_format", 0) == 1 else 1)) if has_tail(c) else lim + 1      # ill-conditioned channels: 8 eight-bit codes
+    if not has_tail(c) and (c.get("output_format", 0) != 1 or internal_is_8bit(c)):
+        assert beyond == 0, name          # (round 5: nothing beyond the bar where no transcendental decides the last code)
     assert beyond == 0 or (beyond <= max(4, 2e-5 * d.size) and d.max() <= worst_ok), name
 print("cases", n, "of which also as 3-frame batches", batches, "against the CPU oracle", oracle_cases, "refused", refused, "kernels", dict(paths), "largest differing fraction", round(worst, 5), "cases with an ill-conditioned channel", outliers)

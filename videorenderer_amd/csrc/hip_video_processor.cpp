@@ -1059,6 +1059,7 @@ HRESULT CHipVideoProcessor::ConvertColorPass(const uint8_t *sample)
         FillFusedParams(sample, out.ptr, out.pitch, &fp);
         fp.store = MakeStore(out.ptr, out.pitch, out.fmt, false);
         fp.dst_aligned16 = 1;
+        fp.exact_convert = 1;            // m_TexConvertOutput in front of a draw
         if (ConvertBlocksSupported(fp, false))
             return CheckHip(LaunchConvertBlocks(fp, nullptr, FusedFrame{sample, out.ptr}, 1, m_run), "k_convert_blocks");
     }
@@ -1636,6 +1637,7 @@ bool CHipVideoProcessor::BatchPlan(const uint8_t *sample0, void *rt0, int rtPitc
     conv->store = MakeStore(m_batchConv.ptr, convPitch, m_plan.internal_fmt, false);
     conv->dst_aligned16 = 1;
     conv->src_aligned16 = m_batchSrc16 ? 1 : 0;
+    conv->exact_convert = 1;
     if (!ConvertBlocksSupported(*conv, false)) return false;
     const Surface cs{nullptr, convPitch, w1, h1, m_plan.internal_fmt};
     const StoreParams final = hdr ? MakeStore((void *)(uintptr_t)4096, (int)(w2 * SurfBytesPerPixel(m_plan.internal_fmt)), m_plan.internal_fmt, false)

@@ -429,7 +429,7 @@ void ChromaCatmullWeights(int chroma_loc, float wx[2][4], float wy[2][4])
 }
 
 // the convert-side and store-side constants both kernels of this file take
-void FillFusedArgs(const FusedParams &P, FusedArgs &a)
+void FillFusedArgs(const FusedParams &P, FusedArgs &a, int resize_follows)
 {
     const ConvertParams &c = P.conv;
     std::memset(&a, 0, sizeof(a));
@@ -466,6 +466,20 @@ void FillFusedArgs(const FusedParams &P, FusedArgs &a)
         a.m[3 * i + 1] = c.cm[3 * i + 1] * (dv ? 1.0f : sc);
         a.m[3 * i + 2] = c.cm[3 * i + 2] * (dv ? 1.0f : sc);
         a.c[i] = c.cm[9 + i];
+    }
+    // the exact form of the convert stage (convert_block_exact): an 8-bit internal format in front of a resize — there a texel one code off
+    // the reference's comes out of a negative-lobe filter up to two codes off.  10-bit internal formats keep the fast form (the same effect
+    // is a quarter of an 8-bit code), and so do the tails (their own transcendentals decide the last code) and Dolby Vision.
+    static const int exact8 = EnvInt("MPCVR_EXACT8", 1);          // 0: the fast form everywhere (A/B)
+    a.exact_cv = (exact8 && (resize_follows >= 0 ? resize_follows : P.exact_convert) && c.out_fmt == SF_BGRA8 && c.tail == TAIL_NONE && !dv) ? 1 : 0;
+    for (int i = 0; i < 9; i++) a.xm[i] = c.cm[i];
+    for (int i = 0; i < 3; i++) a.xc[i] = c.cm[9 + i];
+    {
+        const float maxc = c.fmt.bits10 ? 1023.0f : c.fmt.bytes == 1 ? 255.0f : 65535.0f;
+        const float py = c.fmt.bytes == 2 && !c.fmt.bits10 ? (float)(1 << c.fmt.shift) : 1.0f;
+        const float pc = c.fmt.bytes == 2 && !c.fmt.bits10 && c.fmt.planes != 2 ? (float)(1 << c.fmt.shift) : 1.0f;
+        a.xdy = maxc / py; a.xry = (1.0f / maxc) * py;            // exact scalings by a power of two
+        a.xdc = maxc / pc; a.xrc = (1.0f / maxc) * pc;
     }
     a.dovi = c.dovi; a.eotf_lut = P.eotf_lut; a.sy = sy; a.sc = sc;
     a.dovi_cm = dv ? P.dovi_cm : nullptr; a.dovi_per_frame = a.dovi_cm ? 1 : 0;
@@ -678,7 +692,7 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     if (!frames_dev && n_frames != 1) return hipErrorInvalidValue;
     const ConvertParams &c = P.conv;
     FusedArgs a;
-    FillFusedArgs(P, a);
+    FillFusedArgs(P, a, 1);
     const int nt = P.wx.ntaps;
     for (int t = 0; t < 6; t++) { a.we[t] = P.wx.w_even[t]; a.wo[t] = P.wx.w_odd[t]; }
     int knt = nt;

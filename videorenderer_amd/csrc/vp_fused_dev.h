@@ -57,6 +57,13 @@ struct FusedArgs {
     // (ycc_to_rgb_matrix / offset of ITS RPU, rows then constants, as ConvertParams::cm) instead of dovi[0] and m / c above
     const float *dovi_cm;
     int dovi_per_frame;
+    // exact_cv (8-bit internal format in front of a resize, no tail, no Dolby Vision): the convert stage runs convert_block_exact — the
+    // reference's own expression shapes on 0..1 values, nothing contracted — so that every texel of m_TexConvertOutput carries the
+    // oracle's code (the fast form is one code off on 1e-4 of the texels; a negative-lobe filter behind it can make that two).
+    // xm / xc: the colour matrix WITHOUT the UNORM scale; code / maxv = unorm_div with (xd, xr) = (maxv / 2^shift, 2^shift / maxv) per plane kind
+    int exact_cv;
+    float xm[9], xc[3];
+    float xdy, xry, xdc, xrc;
 };
 
 namespace {
@@ -582,6 +589,75 @@ __device__ __forceinline__ void dovi_reshape_block(const DoviRegs &R, const Dovi
     for (int p = 0; p < 4; p++) { Y[p >> 1][p & 1] = out[0][p]; U[p >> 1][p & 1] = out[1][p]; V[p >> 1][p & 1] = out[2][p]; }
 }
 
+// ---- the exact form of the block convert (FusedArgs::exact_cv) ----
+// What the generated shader computes (Shaders.cpp:231-325 sampling, :819-820 matrix) and the store into m_TexConvertOutput does, in the
+// shader's own expression shapes: texels as 0..1 values (correctly rounded code / maxv), the bilinear chroma sample horizontally first and
+// then vertically with both products rounded, the matrix as three rounded products summed left to right plus the constant, the UNORM
+// store as floor(saturate(x) * maxv + 0.5).  Nothing may contract here: out[column][channel] is code / maxv of EXACTLY the code the
+// oracle stores, as (row 0, row 1) pairs, so a kernel's own `x * maxv + 2^23` reads the same code back.
+#pragma clang fp contract(off)
+__device__ __forceinline__ f2 xnorm2(f2 code, float d, float r)
+{
+    // unorm_div (vp_device.h) on a pair; (d, r) = (maxv / 2^shift, 2^shift / maxv) divides (code << shift) by maxv: the power of two
+    // scales every intermediate exactly
+    const f2 q = code * splat(r);
+    return pk_fma(pk_fma(-q, splat(d), code), splat(r), q);
+}
+// (Y, U, V) of the block as 0..1 values, [column] as (row 0, row 1) pairs -> out
+__device__ __forceinline__ void exact_matrix_store(const FusedArgs &P, const f2 (&Y)[2], const f2 (&U)[2], const f2 (&V)[2], f2 out[2][3])
+{
+    const f2 half2 = splat(0.5f), mx = splat(P.maxv), inv = splat(P.inv_maxv);
+#pragma unroll
+    for (int col = 0; col < 2; col++)
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            f2 s = splat(P.xm[3 * ch]) * Y[col] + splat(P.xm[3 * ch + 1]) * U[col];
+            s = s + splat(P.xm[3 * ch + 2]) * V[col];
+            s = s + splat(P.xc[ch]);
+            s = f2{__builtin_amdgcn_fmed3f(s.x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(s.y, 0.0f, 1.0f)};
+            const f2 t = s * mx + half2;
+            out[col][ch] = f2{__builtin_floorf(t.x), __builtin_floorf(t.y)} * inv;
+        }
+}
+template <int SRC>
+__device__ __forceinline__ void convert_block_exact(const FusedArgs &P, const Raw &r, int sy0, int sy1, f2 out[2][3])
+{
+    const int n4 = chroma_v4(P, sy0) & ~3;
+    const int fr0 = chroma_v4(P, sy0) - n4, fr1 = chroma_v4(P, sy1) - n4;
+    const f2 w1 = f2{quarter(fr0), quarter(fr1)}, w0 = f2{quarter(4 - fr0), quarter(4 - fr1)};    // wy and 1 - wy of (row 0, row 1): quarters, exact
+    f2 Un[3], Vn[3];                              // chroma columns c0-1, c0, c0+1 as (chroma row n, row n+1) pairs, 0..1
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if (i == 0 && !src_center<SRC>(P)) { Un[0] = Vn[0] = splat(0.0f); continue; }
+        Un[i] = xnorm2(f2{(float)(r.c[0][i] & 0xffffu), (float)(r.c[1][i] & 0xffffu)}, P.xdc, P.xrc);
+        Vn[i] = xnorm2(f2{(float)(r.c[0][i] >> 16), (float)(r.c[1][i] >> 16)}, P.xdc, P.xrc);
+    }
+    f2 Hu[2], Hv[2];                              // c00 * (1 - wx) + c10 * wx of the even / odd luma column, rows (n, n+1)
+    if (src_center<SRC>(P)) {                     // MPEG-1: wx = 0.75 (even column, texels c0-1, c0), 0.25 (odd column, texels c0, c0+1)
+        Hu[0] = Un[0] * splat(0.25f) + Un[1] * splat(0.75f); Hv[0] = Vn[0] * splat(0.25f) + Vn[1] * splat(0.75f);
+        Hu[1] = Un[1] * splat(0.75f) + Un[2] * splat(0.25f); Hv[1] = Vn[1] * splat(0.75f) + Vn[2] * splat(0.25f);
+    } else {                                      // wx = 0 (even column: c00 * 1 + c10 * 0 = c00), 0.5 (odd; {0, 1} at 4:4:4, {1, 0} nearest)
+        Hu[0] = Un[1]; Hv[0] = Vn[1];
+        Hu[1] = Un[1] * splat(P.cw_own) + Un[2] * splat(P.cw_next);
+        Hv[1] = Vn[1] * splat(P.cw_own) + Vn[2] * splat(P.cw_next);
+    }
+    f2 Y[2], U[2], V[2];
+#pragma unroll
+    for (int col = 0; col < 2; col++) {           // top * (1 - wy) + bot * wy for (row 0, row 1)
+        U[col] = splat(Hu[col].x) * w0 + splat(Hu[col].y) * w1;
+        V[col] = splat(Hv[col].x) * w0 + splat(Hv[col].y) * w1;
+    }
+    if (src_wide<SRC>(P)) {
+        Y[0] = xnorm2(f2{(float)(r.y[0] & 0xffffu), (float)(r.y[1] & 0xffffu)}, P.xdy, P.xry);
+        Y[1] = xnorm2(f2{(float)(r.y[0] >> 16), (float)(r.y[1] >> 16)}, P.xdy, P.xry);
+    } else {
+        Y[0] = xnorm2(f2{(float)(r.y[0] & 0xffu), (float)(r.y[1] & 0xffu)}, P.xdy, P.xry);
+        Y[1] = xnorm2(f2{(float)((r.y[0] >> 8) & 0xffu), (float)((r.y[1] >> 8) & 0xffu)}, P.xdy, P.xry);
+    }
+    exact_matrix_store(P, Y, U, V, out);
+}
+#pragma clang fp contract(fast)
+
 // The 2x2 block: 4:2:0 bilinear chroma + matrix (+ tail) for (even, odd column) x (row 0, row 1).
 // ShaderGetPixels' CHROMA_Bilinear branch (Shaders.cpp:265-270,319-325): same sample positions and weights,
 // evaluated in code units (vertical lerp first), UNORM scale folded into the matrix.  out[column][ch] = the channel as
@@ -595,6 +671,9 @@ template <int TAIL, int SRC, int DV = DV_NONE>
 __device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], const Raw &r, int sy0, int sy1, const f2 *T, f2 out[2][3],
                                               const DoviParams *DL = nullptr, const float *TE = nullptr, const DoviRegs *DR = nullptr)
 {
+    if constexpr (TAIL == TAILK_NONE && DV == DV_NONE) {
+        if (P.exact_cv) { convert_block_exact<SRC>(P, r, sy0, sy1, out); return; }        // wave-uniform (a kernel argument)
+    }
     // vertical weights of chroma rows n (w0) and n+1 (w1) for (row 0, row 1): wave-uniform, one SGPR pair each
     const int n4 = chroma_v4(P, sy0) & ~3;                 // 4 * floor(v'(row 0))
     const int fr0 = chroma_v4(P, sy0) - n4, fr1 = chroma_v4(P, sy1) - n4;     // 0..4 quarters
@@ -887,10 +966,61 @@ __device__ __forceinline__ void load_raw_cr(const FusedArgs &P, gcptr py, const 
         for (int i = 0; i < 4; i++) r.c[j][i] = ld_uv<SRC>(P, pu + o, pv + o, opaque(ra.coff[i]));
     }
 }
+// exact form (FusedArgs::exact_cv, see convert_block_exact): code_Bicubic_UV (Shaders.cpp:74-79) on 0..1 texels, the four products of a row
+// summed left to right, then the four rows the same way
+#pragma clang fp contract(off)
+template <int SRC>
+__device__ __forceinline__ void convert_block_cr_exact(const FusedArgs &P, const RawCR &r, int sy0, int sy1, f2 out[2][3])
+{
+    f2 Q[5][2];                                   // [chroma row base + j][column parity] = (U, V)
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        f2 t[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] = xnorm2(f2{(float)(r.c[j][i] & 0xffffu), (float)(r.c[j][i] >> 16)}, P.xdc, P.xrc);
+#pragma unroll
+        for (int par = 0; par < 2; par++) {
+            const float *w = P.crx[par];
+            f2 q = t[0] * splat(w[0]) + t[1] * splat(w[1]);
+            q = q + t[2] * splat(w[2]);
+            Q[j][par] = q + t[3] * splat(w[3]);
+        }
+    }
+    const int base = (sy0 >> 1) - 1;
+    f2 uv[2][2];                                  // [column][row] = (U, V)
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int sy = rr ? sy1 : sy0;
+        const int o = (sy >> 1) - 1 - base;       // 0 or 1, wave-uniform
+        const float *w = P.cry[sy & 1];
+#pragma unroll
+        for (int col = 0; col < 2; col++) {
+            const f2 q0 = o ? Q[1][col] : Q[0][col], q1 = o ? Q[2][col] : Q[1][col], q2 = o ? Q[3][col] : Q[2][col], q3 = o ? Q[4][col] : Q[3][col];
+            f2 v = q0 * splat(w[0]) + q1 * splat(w[1]);
+            v = v + q2 * splat(w[2]);
+            uv[col][rr] = v + q3 * splat(w[3]);
+        }
+    }
+    f2 Y[2], U[2], V[2];
+    if (src_wide<SRC>(P)) {
+        Y[0] = xnorm2(f2{(float)(r.y[0] & 0xffffu), (float)(r.y[1] & 0xffffu)}, P.xdy, P.xry);
+        Y[1] = xnorm2(f2{(float)(r.y[0] >> 16), (float)(r.y[1] >> 16)}, P.xdy, P.xry);
+    } else {
+        Y[0] = xnorm2(f2{(float)(r.y[0] & 0xffu), (float)(r.y[1] & 0xffu)}, P.xdy, P.xry);
+        Y[1] = xnorm2(f2{(float)((r.y[0] >> 8) & 0xffu), (float)((r.y[1] >> 8) & 0xffu)}, P.xdy, P.xry);
+    }
+#pragma unroll
+    for (int col = 0; col < 2; col++) { U[col] = f2{uv[col][0].x, uv[col][1].x}; V[col] = f2{uv[col][0].y, uv[col][1].y}; }
+    exact_matrix_store(P, Y, U, V, out);
+}
+#pragma clang fp contract(fast)
 template <int TAIL, int SRC, int DV = DV_NONE>
 __device__ __forceinline__ void convert_block_cr(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], const RawCR &r, int sy0, int sy1, const f2 *T, f2 out[2][3],
                                                  const DoviParams *DL = nullptr, const float *TE = nullptr, const DoviRegs *DR = nullptr)
 {
+    if constexpr (TAIL == TAILK_NONE && DV == DV_NONE) {
+        if (P.exact_cv) { convert_block_cr_exact<SRC>(P, r, sy0, sy1, out); return; }
+    }
     // horizontal pass: Q[row j][column parity] = sum_i wx[parity][i] * texel[j][i], as (U, V) pairs
     f2 Q[5][2];
 #pragma unroll
@@ -941,7 +1071,8 @@ inline int EnvInt(const char *name, int def)
 }  // namespace
 
 // host side, vp_fused.hip
-void FillFusedArgs(const FusedParams &P, FusedArgs &a);
+// resize_follows: 1 / 0 = a resize reads the convert output / nothing does; -1 = what P.exact_convert says (FusedArgs::exact_cv)
+void FillFusedArgs(const FusedParams &P, FusedArgs &a, int resize_follows = -1);
 void ChromaCatmullWeights(int chroma_loc, float wx[2][4], float wy[2][4]);
 int FusedTailKind(const FusedParams &P);
 int FusedSourceKind(const FusedParams &P);

@@ -119,7 +119,7 @@ hipError_t LaunchFusedStrip(const FusedStripParams &S, const FusedFrame *frames_
         a.quant = (float)P.store.quant;
         a.dither = P.store.dither;
         a.H = S.mid_h; a.W = S.surf.w;
-    } else FillFusedArgs(P, a);
+    } else FillFusedArgs(P, a, 1);
     if (S.per_P) {       // a periodic vertical ratio: the register-window kernel when the launch meets its preconditions
         const hipError_t ep = LaunchFusedPeriod(S, a, frames_dev, single, n_frames, s);
         if (ep != hipErrorNotSupported) { if (S.ran_period) *S.ran_period = 1; return ep; }

@@ -75,6 +75,8 @@ struct FusedParams {
     // ConvertParams::cm); the block convert's Dolby Vision variants index both by the frame.  Null: one RPU for the launch (conv.dovi, conv.cm)
     const float *dovi_cm;
     int taps_mfma;            // fused 2x kernel: 1 = resize taps on the matrix cores, 0 = packed-fp32 VALU chains, -1 = library default
+    int exact_convert;        // a resize reads this launch's convert output: 8-bit internal formats then take the exact form of the convert stage
+                              // (FusedArgs::exact_cv).  LaunchFusedUp2x / LaunchFusedStrip set it themselves; the block convert's callers say so.
     int inflight;             // single-frame launches: frames the host keeps running side by side (the context's frame lanes), 0 / 1 = none.  The
                               // segment rules count them like frames of a batch: four overlapping 4K frames fill the chip with long segments
 };
