@@ -69,8 +69,9 @@ enum { MPCVR_DOWNSCALE_Box = 0, MPCVR_DOWNSCALE_Bilinear = 1, MPCVR_DOWNSCALE_Ha
 /* mpcvr_settings.bUseDither: 0 / 1 as the reference's bool (Settings_t::bUseDither, IVideoRenderer.h:117: the ordered dither of
  * ps_final_pass.hlsl).  EXTENSION — 2 is not a reference setting (the reference has no error diffusion at all): BASELINE.json config 4's
  * "error-diffusion dither".  Where the reference would run its final pass into an 8-bit target (internal format above 8 bits), the
- * frame is rendered as for a 10-bit swap chain (R10G10B10A2, no final pass) and Floyd-Steinberg error diffusion in integers takes it
- * to B8G8R8A8 inside video rect ∩ window (definition: csrc/vp_errdiff_core.h; the serial model in oracle/ is its only check).  On a
+ * frame is rendered as for a 10-bit swap chain (R10G10B10A2: no final pass behind the 10-bit internal format; behind the fp16 internal
+ * format that chain's own final pass — the ordered dither from fp16 to 10 bits, as the reference runs it there — stays in front of the
+ * pass) and Floyd-Steinberg error diffusion in integers takes it to B8G8R8A8 inside video rect ∩ window (definition: csrc/vp_errdiff_core.h; the serial model in oracle/ is its only check).  On a
  * 10-bit target or with the 8-bit internal format it changes nothing, like bUseDither = 1 there. */
 enum { MPCVR_DITHER_None = 0, MPCVR_DITHER_Ordered = 1, MPCVR_DITHER_ErrorDiffusion_EXT = 2 };
 
@@ -395,8 +396,11 @@ int32_t mpcvr_plan_period(int32_t method, int32_t src_w, int32_t src_h, int32_t 
  * metadata, the display's peak and the tone-mapping operator): five floats + the selection as words */
 int32_t mpcvr_plan_hdr10_params(float min_mastering, float max_mastering, float max_cll, float max_fall, float display_max,
                                 int32_t selection, uint32_t out6[6]);
-/* log2 of ST2084ToLinear(x, 1) at x = (i/8192)^2, i = 0 .. 8192: the PQ EOTF table of the Dolby Vision block convert */
-int32_t mpcvr_plan_pq_eotf_lut(float out8193[8193]);
+/* log2 of ST2084ToLinear(x, 1) at x = (i/N)^2, i = 0 .. N: the PQ EOTF table of the Dolby Vision block convert (N = 8192 in this
+ * build).  Two calls: out = NULL stores the number of floats (N + 1) in *count; then `capacity` floats of room — MPCVR_E_INVALIDARG when
+ * that is fewer than the table has, nothing is written.  (Replaces mpcvr_plan_pq_eotf_lut(float[4096]) of round 3, whose table grew in
+ * place in round 4: a caller that sizes its buffer from an old header can no longer be overrun.) */
+int32_t mpcvr_plan_pq_eotf_table(float *out, int32_t capacity, int32_t *count);
 /* which draws Process() would issue (UpdateTexParams :1143, UpdatePostScaleTexures :2894, ResizeShaderPass :3103) */
 int32_t mpcvr_plan_describe(const mpcvr_settings *s, int32_t cformat, int32_t rect_w, int32_t rect_h,
                             const mpcvr_rect *video_rect, int32_t window_w, int32_t window_h,

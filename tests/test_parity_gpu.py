@@ -2313,3 +2313,48 @@ def test_full_size_up1440_nv12_within_one_code(mpcvr, oracle, torch_cuda):
     got, info = run_product(mpcvr, torch_cuda, c)
     assert "fused_period" in info, info
     compare(got, want, f"up1440_nv12 [{info}]", min_same=WHOLE_FRAME_FLOOR)
+
+
+def test_single_frames_queued_behind_a_batch_stay_behind_it(mpcvr, torch_cuda):
+    """mpcvr_process_batch into dst[0..n) followed IMMEDIATELY, without a sync, by mpcvr_process into dst[0] (and by one out of a misaligned device
+    sample, which is copied on the context stream first): the single frame runs on a frame lane and must neither overtake nor overlap the
+    batch still running on the context stream (include/mpcvr.h: frames into the same target stay in order).  The batch is ~0.4 ms of 4K -> 8K
+    frames, the single frame 45 us: without the context-stream -> lane edge the batch overwrites it."""
+    from videorenderer_amd import api, synth
+    torch = torch_cuda
+    c = dict(GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"])
+    c.update(w=3840, h=2160, dst=(7680, 4320))
+    (ww, wh), vr = case_geometry(c)
+    n = 6
+    frames = []
+    for i in range(n + 2):
+        f, pitch = synth.make_frame(c["cformat"], c["w"], c["h"], "noise", seed=700 + i)
+        frames.append(torch.from_numpy(np.ascontiguousarray(f)).cuda())
+    kw = {k: c[k] for k in SETTING_KEYS if k in c}
+    vp = api.VideoProcessor(api.default_settings(**kw), use_torch_stream=False)
+    vp.InitMediaType(c["cformat"], c["w"], c["h"], extfmt=c.get("exfmt", 0))
+    vp.SetWindowRect((0, 0, ww, wh))
+    vp.SetVideoRect(vr)
+    dsts = [torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda") for _ in range(n)]
+    # what frames n and n + 1 look like on their own
+    alone = []
+    for k in (n, n + 1):
+        d = torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda")
+        vp.CopySample(frames[k], pitch); vp.Process(d, ww * 4); vp.Synchronize()
+        alone.append(d.clone())
+    # the second single frame arrives as a device sample that does not start on a dword: PrepareSample copies it on the context stream
+    odd = torch.empty(frames[n + 1].numel() + 16, dtype=torch.uint8, device="cuda")
+    odd[2:2 + frames[n + 1].numel()] = frames[n + 1]
+    torch.cuda.synchronize()
+    for rep in range(4):
+        vp.ProcessBatch(frames[:n], dsts, ww * 4)
+        vp.CopySample(frames[n], pitch)
+        vp.Process(dsts[0], ww * 4)                  # a lane frame into the batch's first target
+        vp.CopySample(odd[2:2 + frames[n + 1].numel()], pitch)
+        vp.Process(dsts[1], ww * 4)                  # ... and one whose sample is still being copied
+        vp.Synchronize()
+        assert torch.equal(dsts[0], alone[0]), f"round {rep}: target 0 does not hold the frame queued behind the batch"
+        assert torch.equal(dsts[1], alone[1]), f"round {rep}: target 1 does not hold the frame queued behind the batch (misaligned sample)"
+    info = vp.GetVPInfo()
+    vp.close()
+    assert info.startswith("fused_up2x"), info

@@ -89,6 +89,7 @@ CHipVideoProcessor::~CHipVideoProcessor()
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     if (m_fork) (void)hipEventDestroy(m_fork);
+    if (m_evStreamMark) (void)hipEventDestroy(m_evStreamMark);
     for (FrameLane &fl : m_flanes) {
         if (fl.stream) { (void)hipStreamSynchronize(fl.stream); (void)hipStreamDestroy(fl.stream); }
         for (LaneFrame &f : fl.ring) if (f.done) (void)hipEventDestroy(f.done);
@@ -256,6 +257,23 @@ void CHipVideoProcessor::NoteLaneFrame(FrameLane *fl, const void *rt)
     f.rt = rt; f.pending = true;
     (void)hipEventRecord(f.done, fl->stream);
     fl->last = f.done;
+}
+
+// the context stream -> lane edge (see m_streamGen): one event record per generation of context-stream work, one wait per lane
+void CHipVideoProcessor::LaneWaitsForStream(FrameLane *fl)
+{
+    if (fl->seenGen == m_streamGen || !m_stream) return;
+    if (m_markGen != m_streamGen) {
+        if (!m_evStreamMark && hipEventCreateWithFlags(&m_evStreamMark, hipEventDisableTiming) != hipSuccess) m_evStreamMark = nullptr;
+        if (!m_evStreamMark || hipEventRecord(m_evStreamMark, m_stream) != hipSuccess) {       // no event: the host waits instead
+            (void)hipStreamSynchronize(m_stream);
+            for (FrameLane &l : m_flanes) l.seenGen = m_streamGen;
+            return;
+        }
+        m_markGen = m_streamGen;
+    }
+    (void)hipStreamWaitEvent(fl->stream, m_evStreamMark, 0);
+    fl->seenGen = m_streamGen;
 }
 
 // host_wait: block until the lanes are idle; otherwise the context stream waits for them (work queued on it afterwards runs behind
@@ -885,11 +903,16 @@ HRESULT CHipVideoProcessor::PrepareSample(const uint8_t *dev_sample, const uint8
         const size_t bytes = (size_t)m_srcPitch * m_srcLines;
         if ((hr = CheckHip(m_TexSrcVideo.CheckCreate(bytes), "m_TexSrcVideo"))) return hr;
         m_texSrcZeroed = false;
+        // the copy runs on the context stream: behind every lane frame that still reads the texture, and in front of the lane frames to come
+        (void)JoinFrameLanes(false);
+        NoteStreamWork();
         if ((hr = CheckHip(hipMemcpyAsync(m_TexSrcVideo.ptr, dev_sample, bytes, hipMemcpyDeviceToDevice, m_stream), "sample copy"))) return hr;
         *tex = (const uint8_t *)m_TexSrcVideo.ptr;
         return MPCVR_S_OK;
     }
     const int tp = TexPitch();
+    (void)JoinFrameLanes(false);
+    NoteStreamWork();                 // (the repacks below run on the context stream)
     const bool fresh = m_TexSrcVideo.size < (size_t)tp * m_srcHeight || !m_TexSrcVideo.ptr || !m_texSrcZeroed;
     if ((hr = CheckHip(m_TexSrcVideo.CheckCreate((size_t)tp * m_srcHeight), "m_TexSrcVideo"))) return hr;
     if (m_srcParams->layout == LAY_RGB) {
@@ -1217,12 +1240,14 @@ HRESULT CHipVideoProcessor::Process(void *pRenderTarget, int rtPitch, const CRec
     m_inflight = fl ? FrameLaneCount() : 1;           // the kernels size their segments for that many frames side by side
     if (fl) {
         m_run = fl->stream;
+        LaneWaitsForStream(fl);           // behind a batch / an off-lane frame / a sample copy still queued on the context stream
         // the sample's upload (copy stream) was ordered in front of the context stream by CopySample: the lane needs the same edge
         if (m_curSlot >= 0 && m_up[m_curSlot].uploaded) (void)hipStreamWaitEvent(fl->stream, m_up[m_curSlot].uploaded, 0);
         if (m_clearOnRun) (void)hipMemsetAsync(m_BackBuffer.ptr, 0, m_clearOnRun, fl->stream);
     } else {
         // strictly in stream order behind whatever the lanes still hold (a plan that left the lanes, a caller's stream, the snapshot)
         (void)JoinFrameLanes(false);
+        NoteStreamWork();
         if (m_clearOnRun) (void)hipMemsetAsync(m_BackBuffer.ptr, 0, m_clearOnRun, m_stream);
     }
     m_clearOnRun = 0;
@@ -1267,9 +1292,10 @@ HRESULT CHipVideoProcessor::ProcessBatchRoutes(int n, const void *const *srcs, v
     if (rtPitch < m_windowRect.Width() * 4) return Fail(MPCVR_E_INVALIDARG, "render-target pitch smaller than a row");
     (void)hipSetDevice(m_device);
     HRESULT hr;
-    m_startRecorded = false;
+    if (!m_keepStart) m_startRecorded = false;
     if (m_planDirty && (hr = UpdatePlan())) return hr;
     (void)JoinFrameLanes(false);             // a batch runs on the context stream, behind every single frame still in flight
+    NoteStreamWork();                        // ... and single frames queued after it run behind the batch (LaneWaitsForStream)
     for (int i = 0; i < n; i++)
         if (!srcs[i] || !dsts[i]) return Fail(MPCVR_E_POINTER, "null frame in batch");
     // v210 samples are repacked into m_TexSrcVideo's layout first (CopyFrameV210, Helper.cpp:709-748): a batch gets one repack launch
@@ -1282,7 +1308,7 @@ HRESULT CHipVideoProcessor::ProcessBatchRoutes(int n, const void *const *srcs, v
         if (texBytes * (size_t)n <= ((size_t)1 << 30)) {
             if ((hr = CheckHip(m_batchTex.CheckCreate(texBytes * n), "batch source texture"))) return hr;
             slots.resize(n);
-            (void)hipEventRecord(m_evStart, m_stream);      // the repack is part of the batch's process time, as on the other branches
+            if (!m_startRecorded) (void)hipEventRecord(m_evStart, m_stream);      // the repack is part of the batch's process time, as on the other branches
             m_startRecorded = true;
             if ((hr = CheckHip(LaunchRepackV210(nullptr, m_srcPitch, (uint8_t *)m_batchTex.ptr, tp, m_srcHeight, m_stream, srcs, n, texBytes), "k_repack_v210"))) return hr;
             m_batchTexZeroed = false;                       // (the RGB batches' zeroed remainder columns are gone)
@@ -1562,6 +1588,11 @@ HRESULT CHipVideoProcessor::ProcessBatchErrDiff(int n, const void *const *srcs, 
     bool usedTables = false;         // (ProcessBatchDovi reports per run whether the per-frame tables were read)
     std::vector<void *> mids(chunk);
     for (int i = 0; i < chunk; i++) mids[i] = m_edBase + (size_t)i * m_edStride;
+    // the batch's process time runs from in front of the first chunk to behind the last chunk's pass
+    (void)JoinFrameLanes(false);
+    (void)hipEventRecord(m_evStart, m_stream);
+    m_startRecorded = true; m_keepStart = true;
+    struct KeepStartGuard { bool &f; ~KeepStartGuard() { f = false; } } keepGuard{m_keepStart};
     for (int at = 0; at < n; at += chunk) {
         const int m = std::min(chunk, n - at);
         // the whole-batch routes of the 10-bit plan, into the intermediates (the previous chunk's pass reads them in stream order); a run of

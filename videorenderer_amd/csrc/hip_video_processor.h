@@ -250,7 +250,15 @@ private:
     // completed, which also bounds how far the host runs ahead (kFrameLanes x kLaneDepth frames)
     static constexpr int kLaneDepth = 8;
     struct LaneFrame { const void *rt = nullptr; hipEvent_t done = nullptr; bool pending = false; };
-    struct FrameLane { hipStream_t stream = nullptr; LaneFrame ring[kLaneDepth]; int head = 0; hipEvent_t last = nullptr; };
+    struct FrameLane { hipStream_t stream = nullptr; LaneFrame ring[kLaneDepth]; int head = 0; hipEvent_t last = nullptr; unsigned seenGen = 0; };
+    // work queued on the CONTEXT stream (a batch, a frame that ran off the lanes, a sample copy / repack, a read-back) since a lane last
+    // waited for it: every such call bumps m_streamGen; a lane whose seenGen is behind waits for an event recorded on the context stream
+    // (m_evStreamMark, recorded once per generation) before its next frame — a lane frame into the render target, or out of the sample, that
+    // the context stream is still writing or reading can then neither overtake nor overlap it (mpcvr.h: frames into the same target stay in order)
+    unsigned m_streamGen = 0, m_markGen = ~0u;
+    hipEvent_t m_evStreamMark = nullptr;
+    void NoteStreamWork() { m_streamGen++; }
+    void LaneWaitsForStream(FrameLane *fl);
     FrameLane m_flanes[kFrameLanes];
     int m_flaneNext = 0;
     int m_inflight = 1;                       // FusedParams::inflight of the frame being queued
@@ -286,6 +294,7 @@ private:
     DevBuffer m_batchTex;          // interleaved RGB / v210 batches: the frames' m_TexSrcVideo copies side by side (ProcessBatch)
     bool m_texSrcZeroed = false, m_batchTexZeroed = false;     // the texels the RGB copy loops never write have been cleared for the current media type
     bool m_startRecorded = false;  // ProcessBatch: m_evStart already sits in front of a repack launch
+    bool m_keepStart = false;      // ProcessBatchErrDiff: m_evStart sits in front of the FIRST chunk; the chunks' ProcessBatchRoutes calls leave it there
     bool m_batchRepacked = false;  // the batch at hand reads v210 samples already repacked into m_batchTex
     bool m_batchSrc16 = false;     // every sample of the batch being planned starts on a 16-byte boundary
     // Jinc2m phase tables of the first / second draw (null: weights per pixel)

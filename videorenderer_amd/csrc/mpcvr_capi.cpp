@@ -374,11 +374,13 @@ int32_t mpcvr_plan_hdr10_params(float min_mastering, float max_mastering, float 
     return MPCVR_S_OK;
 }
 
-int32_t mpcvr_plan_pq_eotf_lut(float out8193[8193])
+int32_t mpcvr_plan_pq_eotf_table(float *out, int32_t capacity, int32_t *count)
 {
-    static_assert(mpcvr::kEotfLutSize + 1 == 8193, "header and table size");
-    if (!out8193) return MPCVR_E_POINTER;
-    mpcvr::BuildPqEotfLut(out8193);
+    constexpr int32_t n = mpcvr::kEotfLutSize + 1;
+    if (count) *count = n;
+    if (!out) return count ? MPCVR_S_OK : MPCVR_E_POINTER;
+    if (capacity < n) return MPCVR_E_INVALIDARG;
+    mpcvr::BuildPqEotfLut(out);
     return MPCVR_S_OK;
 }
 
