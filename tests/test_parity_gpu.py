@@ -2281,7 +2281,9 @@ def _hunt_case(rng, i):
 
 def test_hunt_8bit_internal_formats_behind_negative_lobe_filters(mpcvr, oracle, torch_cuda):
     """300 seeded shapes where the amplified-convert-code class lived (8-bit internal format, Catmull-Rom / Lanczos / bicubic, any ratio):
-    the default planner within ONE code of the oracle on every channel — no count of exceptions."""
+    the default planner within ONE code of the oracle on every channel — no count of exceptions.  (A net, not the detector: the class was
+    one channel in ~1e8 on these shapes and the contracted convert stage passes this hunt too — profiles/r05/exact8_tests_with_fast_form_call1.txt;
+    what tells the two forms apart is test_exact_convert_stage_carries_the_oracles_codes and the replay below it.)"""
     from videorenderer_amd import api
     rng = np.random.default_rng(20260925)
     kernels = {}
@@ -2311,7 +2313,7 @@ def test_full_size_up1440_nv12_within_one_code(mpcvr, oracle, torch_cuda):
     frame, pitch = case_frame(c)
     want = oracle.process(oracle_params(oracle, c), frame, pitch)
     got, info = run_product(mpcvr, torch_cuda, c)
-    assert "fused_period" in info, info
+    assert "fused_strip" in info or "fused_period" in info, info
     compare(got, want, f"up1440_nv12 [{info}]", min_same=WHOLE_FRAME_FLOOR)
 
 

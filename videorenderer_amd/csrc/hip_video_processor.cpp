@@ -1548,14 +1548,14 @@ HRESULT CHipVideoProcessor::ErrDiffPass(int n, const FusedFrame *table, FusedFra
     P.x1 = std::min((int)m_videoRect.right, m_windowRect.Width()); P.y1 = std::min((int)m_videoRect.bottom, m_windowRect.Height());
     if (P.x1 <= P.x0 || P.y1 <= P.y0) return MPCVR_S_OK;          // the video rect lies outside the window: nothing is drawn
     P.src_pitch = m_edPitch; P.dst_pitch = rtPitch;
-    P.pair_stores = (rtPitch & 7) == 0;
-    for (int i = 0; i < n; i++)
-        if (((uintptr_t)dsts[i] & 7) != 0) P.pair_stores = 0;
-    const char *shift = std::getenv("MPCVR_ERRDIFF_SHIFT");          // (read per call: the suite runs both variants in one process)
-    P.shift = shift && std::strcmp(shift, "bpermute") == 0 ? 1 : 0;
-    // band-major workgroup order: same box, 32 frames 4K -> 8K: 3.85 k frames/s against 3.28 k frame-major (profiles/r04/ab_call24_errdiff_order.jsonl)
+    (void)dsts;
+    // band-major ticket order: same box, 32 frames 4K -> 8K: 3.85 k frames/s against 3.28 k frame-major (profiles/r04/ab_call24_errdiff_order.jsonl)
     static const int order = [] { const char *e = std::getenv("MPCVR_ERRDIFF_ORDER"); return e ? std::atoi(e) : 1; }();
     P.order = order;
+    // (tests: a band that never publishes and a short patience, read per call — the give-up path must end in an error, not in a hang)
+    const char *stall = std::getenv("MPCVR_ERRDIFF_TEST_STALL"), *spin = std::getenv("MPCVR_ERRDIFF_SPIN");
+    P.test_stall = stall && *stall && *stall != '0' ? 1 : 0;
+    P.spin_limit = spin && *spin ? std::atoi(spin) : 0;
     HRESULT hr;
     if (!m_edStatus) {
         if ((hr = CheckHip(hipHostMalloc((void **)&m_edStatus, sizeof(int), hipHostMallocDefault), "error-diffusion status word"))) return hr;
@@ -1564,8 +1564,15 @@ HRESULT CHipVideoProcessor::ErrDiffPass(int n, const FusedFrame *table, FusedFra
     if (*m_edStatus) { *m_edStatus = 0; return Fail(MPCVR_E_FAIL, "error diffusion: a band of an earlier pass gave up waiting for the band above"); }
     // the hand-off rows are cleared and rewritten by every launch: launches of one context run in stream order on one buffer
     if (s != m_stream) (void)hipStreamSynchronize(m_stream);
-    if ((hr = CheckHip(m_edHandoff.CheckCreate(ErrorDiffusionHandoffBytes(P, n)), "error-diffusion hand-off rows"))) return hr;
+    const size_t need = ErrorDiffusionHandoffBytes(P, n);
+    if ((hr = CheckHip(m_edHandoff.CheckCreate(need), "error-diffusion hand-off rows"))) return hr;
     P.handoff = (uint32_t *)m_edHandoff.ptr; P.status = m_edStatus;
+    // the hand-off words carry the launch's generation: rows of the same layout need no clearing from launch to launch (600 MB for a 32-frame
+    // batch of 8K frames); another layout, another buffer or a wrapped count: gen = 0 = the launcher clears them and starts at 1
+    const uint64_t key = ((uint64_t)(uint32_t)P.x0 << 48) ^ ((uint64_t)(uint32_t)P.x1 << 32) ^ ((uint64_t)(uint32_t)P.y0 << 16) ^ (uint64_t)(uint32_t)P.y1 ^
+                         ((uint64_t)(uint32_t)n * 0x9E3779B97F4A7C15ull) ^ (uint64_t)(uintptr_t)P.handoff;
+    if (key != m_edKey || m_edGen >= 4095 || m_edGen <= 0 || P.test_stall) { P.gen = 0; m_edGen = 1; m_edKey = P.test_stall ? 0 : key; }
+    else P.gen = ++m_edGen;
     return CheckHip(LaunchErrorDiffusion(P, table, single, n, s), "k_error_diffusion");
 }
 
@@ -1956,6 +1963,8 @@ HRESULT CHipVideoProcessor::GetCurentImage(void *hostBGRA, size_t *size)
     (void)hipEventRecord(m_evRb1, m_stream);
     m_rbTimed = true;
     if ((hr = CheckHip(hipStreamSynchronize(m_stream), "readback sync"))) return hr;
+    // (the error-diffusion pass's give-up flag: a snapshot is a result handed back, it must not carry a broken frame with S_OK)
+    if (m_edStatus && *m_edStatus) { *m_edStatus = 0; return Fail(MPCVR_E_FAIL, "error diffusion: a band gave up waiting for the band above"); }
     *size = need;
     return MPCVR_S_OK;
 }

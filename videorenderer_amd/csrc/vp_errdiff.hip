@@ -2,21 +2,28 @@
 // them -> B8G8R8A8 render targets, Floyd-Steinberg in integers.  Definition and schedule: vp_errdiff_core.h (no reference counterpart;
 // the serial model oracle/mpcvr_oracle.c orc_error_diffusion is its only check, and the kernel must equal it bit for bit).
 //
-// One wavefront per band of 64 rows, one workgroup per wavefront, (frames x bands) workgroups per launch, all free-running:
-//   * lane i = row i of the band, two columns behind lane i - 1; what a row hands to the row below (D, three channels) moves by ONE
-//     DPP wave shift per step and channel — no LDS, no barrier anywhere in the kernel;
-//   * the bottom row of a band publishes its D as tagged words in a device-memory hand-off row (relaxed agent-scope atomic stores: value
-//     and tag in one word, so there is nothing to order), the 24 words of a group of 8 steps in ONE store of lanes 0-23; lane 0 of the band
-//     below — another workgroup, usually on another XCD — fetches them one group of 8 columns ahead (lanes 0-23 load a group at once) and
-//     spins, politely and with a bound, only when the band above has not written them yet; the launcher zeroes the rows first;
-//   * a lane reads its row 32 pixels (one cache line's worth, eight 16-byte loads) a block of 32 steps ahead and writes 8-byte pairs; no
-//     memory instruction of the loop is predicated (clamped addresses, a dummy slot for lanes off the region), so the waits the compiler inserts are exact.
-// Round 4's first version ran a frame in ONE workgroup (16 waves taking turns behind workgroup barriers, hand-off rows in LDS): 32 of
-// 256 CUs busy on a 32-frame batch, 630 frames/s at 4K -> 8K.  The pass is a chain of W + 2 H dependent steps per frame with ~30 integer
-// instructions per channel and pixel: bound by VALU issue and by its own serial depth, not by HBM.
+// One wavefront per band of 21 rows, lane = 21 * channel + row (round 5: one channel per lane — until round 4 a lane carried the three
+// independent chains of its row one after the other), one wavefront per workgroup, bands taken by ticket:
+//   * the lanes of row i are two columns behind those of row i - 1; what a row hands to the row below (D) moves by ONE DPP wave shift
+//     per step (lanes 0, 21, 42 — a row 0 each — take the band above's value instead): no barrier anywhere in the kernel;
+//   * pixels travel through LDS: every block of 32 steps a row's next 32 pixels (128 bytes of it) are fetched as 16-byte pieces — each of
+//     the row's three lanes fetches a third, a block ahead — and laid into the wavefront's input tile; a step reads its pixel word from the
+//     tile (the row's three lanes read the same word) and writes its 8-bit code as ONE BYTE into the output tile, whose rows leave as
+//     16-byte pieces at the end of the block: three store instructions per 32 steps instead of sixteen, a row's 128 bytes within a few
+//     hundred cycles of each other;
+//   * the bottom row publishes its D as tagged words in a device-memory hand-off row (relaxed agent-scope atomic stores: value and tag
+//     in one word, nothing to order), the 24 words of a group of 8 steps gathered through LDS into ONE store of lanes 0-23; the band below —
+//     another wavefront, usually on another XCD — fetches them one group ahead and spins, politely and with a bound, only when the band
+//     above has not written them yet; the launcher zeroes the rows (and the ticket counter) first;
+//   * no global memory instruction of the all-live block body is predicated (a lane without a piece of its own repeats its neighbour's),
+//     so the waits the compiler inserts are exact counts.
+// Round 4's versions for the record: one workgroup per frame (630 frames/s at 4K -> 8K), one wavefront per band of 64 rows with three
+// channels per lane (4.0 k frames/s in 32-frame batches, 2.9 ms a frame, a third of the VALU issue slots busy).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <type_traits>
 
 #include "vp_errdiff_core.h"
@@ -26,163 +33,176 @@ namespace mpcvr {
 
 namespace {
 
-typedef uint32_t ed_u2 __attribute__((ext_vector_type(2)));
-typedef uint32_t ed_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t ed_u4 __attribute__((ext_vector_type(4), aligned(4)));          // (global pieces are dword aligned, no more is promised)
+typedef uint32_t ed_l4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) uint8_t *ed_gcptr;
 typedef __attribute__((address_space(1))) uint8_t *ed_gptr;
 
-constexpr int kEdOccupancyLds = 0;             // dynamic LDS claimed per workgroup (never touched): 160 KiB / that = workgroups per CU
-constexpr int kEdSpinLimit = 1 << 21;       // polls (~1 us each) a band grants the band above before it gives up and flags the launch
+constexpr int kEdTileRow = 144;                      // bytes of a tile row: 32 pixels + a pad that keeps the 21 rows off each other's banks, 16-byte aligned
+constexpr int kEdTile = kEdRows * kEdTileRow;        // 3024
+constexpr int kEdLdsIn = 0, kEdLdsOut = kEdTile, kEdLdsTop = 2 * kEdTile, kEdLdsHand = kEdLdsTop + 256, kEdLdsDummy = kEdLdsHand + 96;
+constexpr int kEdLds = kEdLdsDummy + 64 * 4 + 128;   // (a lane's dummy word + the largest immediate offset of a step's hand-off write)
 
-// the value of lane - 1; lane 0 — the band's top row, which has no lane above — gets `top` (wave-uniform: the band above's D of this column).
-// DPP: `top` rides in as the instruction's old-value operand, which a lane without a source keeps (v_mov + v_mov_dpp; the select
-// behind a zero-initialised shift was four instructions per channel and step)
-template <int SHIFT>
-__device__ __forceinline__ int32_t ed_from_lane_above(int32_t v, int32_t top, int lane)
+__device__ __forceinline__ void ed_wave_sync()
 {
-    if (SHIFT == 0) return __builtin_amdgcn_update_dpp(top, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-    const int32_t d = __builtin_amdgcn_ds_bpermute(((lane - 1) & 63) << 2, v);
-    return lane == 0 ? top : d;
+    // LDS instructions of one wavefront execute in order; the fences only keep the COMPILER from moving a lane's read in front of another
+    // lane's write (which look unrelated thread by thread)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// PAIR: every pixel pair (even column, odd column) of the region is whole (x0 and x1 even) and every target row starts on an 8-byte
-// boundary: one 8-byte store per pair.  Every vector memory instruction of the loop is UNCONDITIONAL — lanes off the region read a
-// clamped address and write into a dummy slot — so that the compiler can count them: its s_waitcnt for the pixel pairs fetched a group
-// ago then leaves this group's stores and fetches in flight (with predicated accesses it must assume vmcnt(0) at every wait: the first
-// cut of this kernel waited for its own prefetch, 670 cycles per step)
-template <int SHIFT, bool PAIR>
-__global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const FusedFrame *__restrict__ frames, FusedFrame single)
+__global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const FusedFrame *__restrict__ frames, FusedFrame single, int n_frames)
 {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kEdLds];
     const EdSchedule S = ed_schedule(P.x0, P.x1, P.y1 - P.y0);
     const int lane = threadIdx.x;
-    // workgroup -> (frame, band); either way a band's producer has a lower index.  order 0: a frame's bands are neighbours (neighbouring
-    // workgroups = neighbouring phases of one frame); 1: a band of every frame, then the next band (neighbours = the same phase of all frames)
-    const int nfr = (int)gridDim.x / S.bands;
-    const int z = P.order ? (int)blockIdx.x % nfr : (int)blockIdx.x / S.bands;
-    const int band = P.order ? (int)blockIdx.x / nfr : (int)blockIdx.x - z * S.bands;
-    const FusedFrame fr = frames ? frames[z] : single;
-    const int a0 = P.x0 & ~1;
+    const bool idle = lane == 63;                    // (computes along as a second copy of lane 42's row; its results go to dummy slots)
+    const int ch = idle ? 2 : lane / kEdRows, i = idle ? 0 : lane - ch * kEdRows;
     const int rows = P.y1 - P.y0;
-    const int r = band * kEdRows + lane;
-    const bool row_ok = r < rows;
-    const int y = P.y0 + (row_ok ? r : rows - 1);
-    const ed_gcptr src_row = (ed_gcptr)fr.src + (size_t)y * (size_t)P.src_pitch + (size_t)a0 * 4u;
-    const ed_gptr dst_row = (ed_gptr)fr.dst + (size_t)y * (size_t)P.dst_pitch + (size_t)a0 * 4u;
-    uint32_t *const mine = P.handoff + ((size_t)z * S.bands + band) * (size_t)S.stride;
-    const bool has_above = band > 0;
-    const uint32_t *const above = has_above ? mine - S.stride : mine;                    // (the first band reads its own row: zeros, ignored)
-    // where lanes off the region store: slots of this band's own row (all bands writing one shared dummy meant every wavefront of the launch
-    // pushing write-through stores at the same 64 bytes: 32 frames took eight times as long as with predicated stores)
-    uint32_t *const spare = mine + 3 * kEdGroup * S.groups;                              // the spare group: 24 words nobody waits for
-    const ed_gptr dummy = (ed_gptr)(spare + 3 * kEdGroup) + (size_t)lane * 8u;
-    const int xr_last = (S.wl - 1) & ~1;                                                 // last even column of the region
+    const int total = n_frames * S.bands;
+    uint32_t *const ticket = P.handoff + (size_t)total * (size_t)S.stride;
+    const uint32_t sh = 10u * (uint32_t)ch;
+    // lanes 0, 21, 42 are the band's top row of a channel: the band above's D instead of the shifted one
+    const bool row0 = i == 0 && !idle;
+    const bool bottom = i == kEdRows - 1;
+    const uint32_t gen = (uint32_t)P.gen;
 
-    EdChannel st[3];
-    int32_t dprev[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) { st[c] = EdChannel{0, 0, 0, 0}; dprev[c] = 0; }
+    unsigned char *const in_row = lds + kEdLdsIn + i * kEdTileRow;
+    unsigned char *const out_row = lds + kEdLdsOut + i * kEdTileRow;
+    unsigned char *const out_byte = idle ? lds + kEdLdsDummy + 4 * lane : out_row + (2 - ch);          // B8G8R8A8: R = byte 2
+    uint32_t *const top_word = (uint32_t *)(lds + kEdLdsTop) + ch;                                      // + 3 s: D of column t0 + s, this channel
+    uint32_t *const hand_word = bottom ? (uint32_t *)(lds + kEdLdsHand) + ch : (uint32_t *)(lds + kEdLdsDummy) + lane;      // + 3 s
+    // the alpha bytes of the output tile are written once: the steps touch bytes 0-2 only
+    for (int w = lane; w < kEdTile / 4; w += 64) ((uint32_t *)(lds + kEdLdsOut))[w] = 0xff000000u;
 
-    // A block = 32 steps = the next 32 pixels of the lane's row (one cache line's worth), fetched as eight 16-byte loads a block ahead:
-    // the eight loads of a lane hit one or two lines back to back.  (8-byte loads a group of 8 steps ahead, the first cut, had every
-    // load instruction of a wavefront touch 64 lines that the CU's other wavefronts had evicted since the last visit: 16x the useful bytes
-    // from L2, and a 32-frame batch ran at a third of the single-frame rate.)  The loads are dword-aligned (xr is even, not a multiple of
-    // four in odd lanes); off the region they read a clamped position: the caller's image has a margin of two pixels in front of every
-    // row it does not own and slack behind the last one.
-    constexpr int BLK = kEdGroup * kEdBlockGroups;
-    auto load_block = [&](int tb, ed_u4 (&v)[BLK / 4]) __attribute__((always_inline)) {
-        const int xs = tb - kEdSkew * lane;
+    // the three (or two) 16-byte pieces of its row's 128 bytes a lane fetches and stores: pieces ch, ch + 3, ch + 6 (a lane without a third
+    // piece repeats piece 7 — the same bytes at the same address as its neighbour)
+    int piece[3];
 #pragma unroll
-        for (int p = 0; p < BLK / 4; p++) {
-            const int xr = min(max(xs + 4 * p, -2), xr_last);
-            v[p] = *(const __attribute__((address_space(1))) ed_u4 *)(src_row + (ptrdiff_t)xr * 4);
-        }
-    };
-    // the 24 hand-off words of a group (columns t0 .. t0 + 7, word 3 column + channel): lane l < 24 fetches word l (the others: word 0)
-    const int wlane = lane < 3 * kEdGroup ? lane : 0;
-    auto fetch_above = [&](int t0) __attribute__((always_inline)) -> uint32_t {
-        return __hip_atomic_load(above + 3 * t0 + wlane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
+    for (int m = 0; m < 3; m++) piece[m] = min(ch + 3 * m, 7);
 
-    ed_u4 cur[BLK / 4], nxt[BLK / 4];
-    load_block(0, cur);
-    uint32_t wnext = fetch_above(0);
-    uint32_t outw = 0;              // lanes 0-23: the 24 hand-off words the previous group's steps produced
-    const bool full_band = (band + 1) * kEdRows <= rows;
-    // one block of 32 steps; ALL: every lane stands on a pixel of the region at every step of the block (wave-uniform, true for all but the
-    // first four and the last block or two of a full band) — no live test, no select of e, no dummy addresses
-    auto run_block = [&](auto ALLC, int blk) __attribute__((always_inline)) {
-        constexpr bool ALL = decltype(ALLC)::value;
+    for (;;) {
+        int tk = 0;
+        if (lane == 0) tk = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        if (tk >= total) break;
+        int z, band;
+        ed_ticket(tk, n_frames, S.bands, P.order, z, band);
+        const FusedFrame fr = frames ? frames[z] : single;
+        const int r = band * kEdRows + i;
+        const bool row_ok = r < rows && !idle;
+        const int y = P.y0 + min(r, rows - 1);
+        const ed_gcptr src_row = (ed_gcptr)fr.src + (size_t)y * (size_t)P.src_pitch + (size_t)P.x0 * 4u;
+        const ed_gptr dst_row = (ed_gptr)fr.dst + (size_t)y * (size_t)P.dst_pitch + (size_t)P.x0 * 4u;
+        uint32_t *const mine = P.handoff + ((size_t)z * S.bands + band) * (size_t)S.stride;
+        const bool has_above = band > 0;
+        const uint32_t *const above = has_above ? mine - S.stride : mine;                    // (the first band reads its own row: zeros, ignored)
+        uint32_t *const spare = mine + 3 * kEdGroup * S.groups;                              // the spare group: 24 words nobody waits for
+        const bool full_band = (band + 1) * kEdRows <= rows;
+        const bool stall = P.test_stall && band == 0 && z == 0;                              // (tests: this band never publishes, the one below gives up)
+
+        EdChannel st{0, 0, 0, 0};
+        int32_t dprev = 0;
+
+        // pieces of block tb: columns tb - 2 i + 4 j .. + 3 of the row; a piece that lies outside the region altogether reads a clamped
+        // position (the caller's image is readable from two pixels in front of a row of the region to three behind it)
+        auto load_block = [&](int tb, ed_u4 (&v)[3]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int gi = 0; gi < kEdBlockGroups; gi++) {
-            const int t0 = BLK * blk + kEdGroup * gi;
-            // publish the previous group's words (lane 63's D of columns t0 - 135 .. t0 - 128): value and tag in one word, ONE store of lanes 0-23
-            {
-                const int col0 = t0 - kEdGroup - (kEdSkew * (kEdRows - 1) + 1);
-                const int col = col0 + lane / 3;
-                const bool pub = lane < 3 * kEdGroup && col >= 0 && col < S.wl;
-                uint32_t *at = pub ? mine + 3 * col0 + lane : spare + (lane & 15);
-                __hip_atomic_store(at, outw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int m = 0; m < 3; m++) {
+                const int xr = min(max(tb - kEdSkew * i + 4 * piece[m], -2), S.wl - 1);
+                v[m] = *(const __attribute__((address_space(1))) ed_u4 *)(src_row + (ptrdiff_t)xr * 4);
             }
-            // D of the band above for the eight columns of this group: fetched a group ago; wait for what is not there yet
-            uint32_t w = wnext;
-            if (has_above) {
-                const bool need = lane < 3 * kEdGroup && t0 + lane / 3 < S.wl;      // (columns beyond the region are never written, nor used)
-                int spins = 0;
-                while (__ballot(need && !(w & 1u)) != 0) {                           // wave-uniform
-                    if (++spins > kEdSpinLimit) { if (lane == 0) *P.status = 1; break; }
-                    __builtin_amdgcn_s_sleep(4);
-                    w = fetch_above(t0);
-                }
-            }
-            wnext = fetch_above(t0 + kEdGroup);                                      // (the row has a spare group of entries behind the last one)
-            if (!has_above) w = 0;                                                   // (the frame's first band: nothing comes down; untag(0) = 0)
-            uint32_t even_px = 0;
-            bool even_live = false;
+        };
+        auto tile_block = [&](const ed_u4 (&v)[3]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int s = 0; s < kEdGroup; s++) {
-                const int sb = kEdGroup * gi + s;                                    // step inside the block
-                const int xr = t0 + s - kEdSkew * lane;
-                const bool live = ALL || (row_ok && xr >= S.lead && xr < S.wl);
-                const uint32_t code = cur[sb >> 2][sb & 3];
-                int q[3];
+            for (int m = 0; m < 3; m++) *(ed_l4 *)(in_row + 16 * piece[m]) = ed_l4{v[m].x, v[m].y, v[m].z, v[m].w};
+        };
+        const int wlane = lane < 3 * kEdGroup ? lane : 0;
+        auto fetch_above = [&](int t0) __attribute__((always_inline)) -> uint32_t {
+            return __hip_atomic_load(above + 3 * t0 + wlane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+
+        ed_u4 nxt[3];
+        load_block(0, nxt);
+        uint32_t wnext = fetch_above(0);
+        ed_wave_sync();                              // (the previous band's last reads of the tiles lie in front of these writes)
+        tile_block(nxt);
+        ed_wave_sync();
+
+        // one block of 32 steps; ALL: every row stands on a pixel of the region at every step of the block (wave-uniform, true for all but
+        // the first two and the last two blocks of a full band) — no live test, no select of e, 16-byte stores
+        auto run_block = [&](auto ALLC, int blk) __attribute__((always_inline)) {
+            constexpr bool ALL = decltype(ALLC)::value;
+            const int tb = kEdBlock * blk;
+            load_block(tb + kEdBlock, nxt);                                              // the next block's pieces, a block ahead
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const int32_t top = ed_untag((uint32_t)__builtin_amdgcn_readlane((int)w, 3 * s + c));      // (scalar)
-                    const int32_t din = ed_from_lane_above<SHIFT>(dprev[c], top, lane);
-                    q[c] = ed_step(st[c], live, (int)((code >> (10 * c)) & 0x3ffu), din, dprev[c]);
-                }
-                const uint32_t px = ed_pack_bgra(q[0], q[1], q[2]);                  // (ed_step answers q + 16: the three biases leave in one subtraction)
-                if ((s & 1) == 0) { even_px = px; even_live = live; }
-                else {
-                    const ed_gptr at = dst_row + (ptrdiff_t)(xr - 1) * 4;
-                    if (PAIR) *(__attribute__((address_space(1))) ed_u2 *)(ALL || live ? at : dummy) = ed_u2{even_px, px};      // (whole pairs: live == even_live)
-                    else {
-                        *(__attribute__((address_space(1))) uint32_t *)(ALL || even_live ? at : dummy) = even_px;
-                        *(__attribute__((address_space(1))) uint32_t *)(ALL || live ? at + 4 : dummy + 4) = px;
+            for (int gi = 0; gi < kEdBlockGroups; gi++) {
+                const int t0 = tb + kEdGroup * gi;
+                // D of the band above for the eight columns of this group: fetched a group ago; wait for what is not there yet
+                uint32_t w = wnext;
+                if (has_above) {
+                    const bool need = lane < 3 * kEdGroup && t0 + lane / 3 < S.wl;      // (columns beyond the region are never written, nor used)
+                    int spins = 0;
+                    while (__ballot(need && !ed_tagged(w, gen)) != 0) {                           // wave-uniform
+                        if (++spins > P.spin_limit) { if (lane == 0) *P.status = 1; break; }
+                        __builtin_amdgcn_s_sleep(4);
+                        w = fetch_above(t0);
                     }
                 }
-                // the band's bottom row: D(xr - 1) for the band below — lane 63's value travels through a scalar into lane 3 s + c of outw
+                wnext = fetch_above(t0 + kEdGroup);                                      // (the row has a spare group of entries behind the last one)
+                if (!has_above) w = 0;                                                   // (the frame's first band: nothing comes down; untag(0) = 0)
+                ((uint32_t *)(lds + kEdLdsTop))[lane] = (uint32_t)ed_untag(w);          // word 3 s + c of the group in lane 3 s + c
+                ed_wave_sync();
+                int32_t top[kEdGroup];
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const uint32_t word = ed_tag(__builtin_amdgcn_readlane(dprev[c], kEdRows - 1));
-                    asm("v_writelane_b32 %0, %1, %2" : "+v"(outw) : "s"(word), "n"(3 * s + c));
+                for (int s = 0; s < kEdGroup; s++) top[s] = (int32_t)top_word[3 * s];
+#pragma unroll
+                for (int s = 0; s < kEdGroup; s++) {
+                    const int sb = kEdGroup * gi + s;                                    // step inside the block = position inside the tile row
+                    const int xr = t0 + s - kEdSkew * i;
+                    const bool live = ALL ? !idle : (row_ok && xr >= 0 && xr < S.wl);
+                    const uint32_t code = *(const uint32_t *)(in_row + 4 * sb);
+                    const int32_t shifted = __builtin_amdgcn_update_dpp(top[s], dprev, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                    const int32_t din = row0 ? top[s] : shifted;
+                    const int qb = ed_step(st, ALL || live, (int)((code >> sh) & 0x3ffu), din, dprev);
+                    out_byte[4 * sb] = (unsigned char)(qb - 16);
+                    hand_word[3 * s] = ed_tag(dprev, gen);                                    // the bottom row: D(xr - 1) for the band below
+                }
+                ed_wave_sync();
+                // publish the group's 24 words (the bottom row's D of columns t0 - 41 .. t0 - 34): ONE store of lanes 0-23, value and tag in one word
+                {
+                    const uint32_t outw = ((const uint32_t *)(lds + kEdLdsHand))[wlane];
+                    const int col0 = t0 - kEdFlush;
+                    const int col = col0 + lane / 3;
+                    const bool pub = lane < 3 * kEdGroup && col >= 0 && col < S.wl && !stall;
+                    uint32_t *at = pub ? mine + 3 * col0 + lane : spare + (lane & 15);
+                    __hip_atomic_store(at, outw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-        }
-    };
-    for (int blk = 0; blk < S.groups / kEdBlockGroups; blk++) {
-        load_block(BLK * (blk + 1), nxt);                                            // (clamped: the block behind the last one reads the row's end again)
-        const int tb = BLK * blk;
-        if (full_band && tb - kEdSkew * (kEdRows - 1) >= S.lead && tb + BLK - 1 < S.wl) run_block(std::true_type{}, blk);
-        else run_block(std::false_type{}, blk);
+            // the block's 32 pixels of every row leave the output tile, the next block's enter the input tile
+            ed_l4 o[3];
 #pragma unroll
-        for (int p = 0; p < BLK / 4; p++) cur[p] = nxt[p];
-    }
-    // the last group's words: columns up to groups * 8 - 128 >= wl - 1
-    {
-        const int col0 = kEdGroup * S.groups - kEdGroup - (kEdSkew * (kEdRows - 1) + 1);
-        const int col = col0 + lane / 3;
-        if (lane < 3 * kEdGroup && col >= 0 && col < S.wl) __hip_atomic_store(mine + 3 * col0 + lane, outw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int m = 0; m < 3; m++) o[m] = *(const ed_l4 *)(out_row + 16 * piece[m]);
+            tile_block(nxt);
+            ed_wave_sync();
+#pragma unroll
+            for (int m = 0; m < 3; m++) {
+                const int xr = tb - kEdSkew * i + 4 * piece[m];
+                const ed_gptr at = dst_row + (ptrdiff_t)xr * 4;
+                if (ALL) *(__attribute__((address_space(1))) ed_u4 *)at = ed_u4{o[m].x, o[m].y, o[m].z, o[m].w};
+                else if (m < 2 || ch < 2) {
+#pragma unroll
+                    for (int p = 0; p < 4; p++)
+                        if (row_ok && xr + p >= 0 && xr + p < S.wl) *(__attribute__((address_space(1))) uint32_t *)(at + 4 * p) = o[m][p];
+                }
+            }
+        };
+        for (int blk = 0; blk < S.groups / kEdBlockGroups; blk++) {
+            const int tb = kEdBlock * blk;
+            if (full_band && tb - kEdSkew * (kEdRows - 1) >= 0 && tb + kEdBlock - 1 < S.wl) run_block(std::true_type{}, blk);
+            else run_block(std::false_type{}, blk);
+        }
     }
 }
 
@@ -191,30 +211,46 @@ __global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const F
 size_t ErrorDiffusionHandoffBytes(const ErrDiffParams &P, int n_frames)
 {
     const EdSchedule S = ed_schedule(P.x0, P.x1, P.y1 - P.y0);
-    return (size_t)n_frames * S.bands * S.stride * sizeof(uint32_t);
+    return ((size_t)n_frames * S.bands * S.stride + 16) * sizeof(uint32_t);          // the hand-off rows + the ticket counter
 }
 
-hipError_t LaunchErrorDiffusion(const ErrDiffParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s)
+// wavefronts of the pass the current device keeps resident (one per workgroup): queried once per device
+static int ErrDiffResidentWaves()
+{
+    static std::mutex mu;
+    static std::map<int, int> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256 * 16;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(dev);
+    if (it != cache.end()) return it->second;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_error_diffusion, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cache[dev] = per_cu * cus;
+}
+
+hipError_t LaunchErrorDiffusion(const ErrDiffParams &P_in, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s)
 {
     if (n_frames <= 0 || (!frames_dev && n_frames != 1)) return hipErrorInvalidValue;
-    if (P.x1 <= P.x0 || P.y1 <= P.y0 || !P.handoff || !P.status) return hipErrorInvalidValue;
+    if (P_in.x1 <= P_in.x0 || P_in.y1 <= P_in.y0 || !P_in.handoff || !P_in.status) return hipErrorInvalidValue;
+    ErrDiffParams P = P_in;
+    if (P.spin_limit <= 0) P.spin_limit = 1 << 21;           // polls (~1 us each) a band grants the band above before it gives up and flags the launch
     const EdSchedule S = ed_schedule(P.x0, P.x1, P.y1 - P.y0);
-    // zero = "not written yet": the hand-off rows are cleared in front of every launch (a few MB per frame, in stream order)
-    const hipError_t e = hipMemsetAsync(P.handoff, 0, ErrorDiffusionHandoffBytes(P, n_frames), s);
+    // the ticket counter starts at zero; the hand-off rows are cleared only when the caller does not vouch for them (gen = 0: no word of an
+    // earlier launch on this buffer may carry the generation this launch tags its words with — then it runs as generation 1 on cleared rows)
+    const size_t rows_bytes = ErrorDiffusionHandoffBytes(P, n_frames) - 16 * sizeof(uint32_t);
+    hipError_t e = hipSuccess;
+    if (P.gen <= 0 || P.gen > (int)kEdGenMask) { P.gen = 1; e = hipMemsetAsync(P.handoff, 0, rows_bytes + 16 * sizeof(uint32_t), s); }
+    else e = hipMemsetAsync((uint8_t *)P.handoff + rows_bytes, 0, 16 * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    const dim3 grid((unsigned)((size_t)n_frames * S.bands)), block(64);
-    // Bands in flight per SIMD.  A band is a chain of dependent steps and a frame is a chain of bands: a wavefront that shares its SIMD with
-    // three busy ones runs at a quarter of its speed and so does everything behind it, so the pass wants FEW resident wavefronts, each at
-    // full speed — the kernel claims LDS it never touches to hold the occupancy down (MPCVR_ERRDIFF_LDS overrides, bytes; A/B in DESIGN.md)
-    static const size_t lds = [] { const char *e = std::getenv("MPCVR_ERRDIFF_LDS"); return e ? (size_t)std::atol(e) : (size_t)kEdOccupancyLds; }();
-    const bool pair = P.pair_stores && !(P.x0 & 1) && !(P.x1 & 1);
-    if (P.shift == 1) {
-        if (pair) hipLaunchKernelGGL((k_error_diffusion<1, true>), grid, block, lds, s, P, frames_dev, single);
-        else hipLaunchKernelGGL((k_error_diffusion<1, false>), grid, block, lds, s, P, frames_dev, single);
-    } else {
-        if (pair) hipLaunchKernelGGL((k_error_diffusion<0, true>), grid, block, lds, s, P, frames_dev, single);
-        else hipLaunchKernelGGL((k_error_diffusion<0, false>), grid, block, lds, s, P, frames_dev, single);
-    }
+    // as many wavefronts as the chip keeps resident (or as there are bands); each takes bands by ticket until none is left.  MPCVR_ERRDIFF_WAVES
+    // overrides the number (A/B: fewer resident wavefronts = fewer bands sharing a SIMD)
+    static const int waves_env = [] { const char *v = std::getenv("MPCVR_ERRDIFF_WAVES"); return v ? std::atoi(v) : 0; }();
+    const long total = (long)n_frames * S.bands;
+    const long want = waves_env > 0 ? waves_env : ErrDiffResidentWaves();
+    const dim3 grid((unsigned)std::max<long>(1, std::min<long>(total, want))), block(64);
+    hipLaunchKernelGGL(k_error_diffusion, grid, block, 0, s, P, frames_dev, single, n_frames);
     return hipGetLastError();
 }
 

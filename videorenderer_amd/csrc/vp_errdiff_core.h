@@ -11,15 +11,20 @@
 //       right (7 e) >> 4, below-left (3 e) >> 4, below (5 e) >> 4 (arithmetic shifts = floor), below-right the remainder
 //   (Floyd-Steinberg weights; what falls outside the region is dropped; alpha = 0xFF).
 //
-// Schedule: pixel (x, y) needs (x-1, y), (x-1, y-1), (x, y-1), (x+1, y-1), so row y may run two columns behind row y-1.  A wavefront
-// owns a BAND of 64 rows, lane i = row i, at step t lane i works on column t - 2 i; what a row passes to the row below,
+// Schedule (round 5: ONE CHANNEL PER LANE).  Pixel (x, y) needs (x-1, y), (x-1, y-1), (x, y-1), (x+1, y-1), so row y may run two columns
+// behind row y-1; the three channels are independent chains.  A wavefront owns a BAND of 21 rows: lane = 21 * channel + row (lane 63 idles),
+// at step t the lanes of row i work on column t - 2 i; what a row passes to the row below,
 //       D(x) = below-right(x-1) + below(x) + below-left(x+1),
-// is complete one step before the lane below needs it and travels there by one DPP wave shift per step.  Every band is a workgroup
-// of ONE wavefront, free-running: its bottom row publishes D column by column as tagged words (value << 1 | 1, zero = not there yet)
-// in device memory — a relaxed agent-scope atomic store each, so value and tag arrive together and no fence is needed — and lane 0 of
-// the band below reads them eight columns ahead and waits only when the band above has not got there yet (in steady state it runs
-// ~130 columns behind).  A band depends on the band above alone = the workgroup with the next lower index: workgroups are started in
-// index order per XCD, so the lowest unfinished one always finds its producer finished or running — no deadlock, whatever is resident.
+// is complete one step before the lane below needs it and travels there by one DPP wave shift per step (the three lanes that are a row 0
+// take the band above's value instead).  Until round 4 a lane carried all three channels of its row (64 rows per band): three chains
+// serialised in one lane, 76 instructions per step, 2.9 ms per 8K frame and a third of the issue slots busy in a batch.  Now a step is a
+// third as long, a frame has three times as many bands running (206 instead of 68 for 4320 rows) and every SIMD holds bands of six phases.
+// A band's bottom row publishes D column by column as tagged words (value << 12 | the launch's generation) in device memory — a relaxed
+// agent-scope atomic store per group of 8 steps, value and tag in one word, so nothing needs a fence — and the band below reads them a
+// group ahead and waits only when the band above has not got there yet (in steady state it runs ~56 columns behind).
+// Bands are handed out by TICKET (an atomic counter, band-major over the frames of a launch): a band's producer always holds a lower
+// ticket, i.e. it was taken by a wavefront that is running or done — forward progress does not hang on the order in which the hardware
+// starts workgroups (round 4's version did: workgroup index = band), and a launch never needs more wavefronts resident than the chip holds.
 // This header holds everything a host emulation of that schedule shares with the kernel (tests/tools/errdiff_emulate.cpp: bands taking
 // turns in random order against the serial model, no GPU needed).
 #pragma once
@@ -42,17 +47,17 @@ namespace mpcvr {
 
 constexpr int kEdUnit = 16 * 1023;        // error units per 8-bit code
 constexpr int kEdCode = 16 * 255;         // one UNORM10 code in those units
-constexpr int kEdRows = 64;               // rows per band = lanes of a wavefront
+constexpr int kEdRows = 21;               // rows per band: 3 channels x 21 rows = 63 lanes of a wavefront
 constexpr int kEdSkew = 2;                // columns a row runs behind the row above
-constexpr int kEdGroup = 8;               // steps between two looks at the band above (and two loads of pixel pairs)
-constexpr int kEdDummyWords = 128;       // 64 lanes x 8 bytes
-constexpr int kEdBlockGroups = 4;        // groups per block of pixel loads: a lane fetches 32 pixels of its row (one cache line's worth) at a time
+constexpr int kEdGroup = 8;               // steps between two looks at the band above
+constexpr int kEdBlockGroups = 4;         // groups per block: the 32 pixels a row works on in a block are one 128-byte piece of it
+constexpr int kEdBlock = kEdGroup * kEdBlockGroups;
+constexpr int kEdFlush = kEdSkew * (kEdRows - 1) + 1;     // the bottom row hands D(c) down at step c + kEdFlush
 
 // floor((T + U / 2) / U) clamped to a byte, as a BIASED code q + 16 from the biased sum Tb = T + U/2 + 16 U: Tb is positive for every
 // reachable T (|E| stays within a few U) and below 2^23; n = Tb >> 4 is below 2^19, where floor(n / 1023) = mulhi(n, ceil(2^32 / 1023))
 // exactly (the excess 1019 n / (1023 * 2^32) stays below 1 / 1023 up to n = 4.2 M) — tests/test_errdiff.py checks the whole range against
-// the division.  The masks change no value (n < 2^19, the magic < 2^23) and let the compiler take the full-rate 24-bit multiply-high; the
-// bias saves the kernel an addition per channel (it subtracts 16 from the three codes of a pixel at once, in the packed word)
+// the division.  The masks change no value (n < 2^19, the magic < 2^23) and let the compiler take the full-rate 24-bit multiply-high.
 constexpr uint32_t kEdMagic = 4198405u;   // ceil(2^32 / 1023)
 constexpr int32_t kEdBias = kEdUnit / 2 + 16 * kEdUnit;
 MPCVR_ED_HD int ed_quant_biased(int32_t Tb)
@@ -87,39 +92,46 @@ MPCVR_ED_HD int ed_step(EdChannel &s, bool live, int k, int32_t din, int32_t &do
     return qb;
 }
 
-// The B8G8R8A8 texel of three BIASED codes (ed_step's answers): R = byte 2, alpha 0xFF.  A sum, not an or: a biased code reaches 271 and
-// carries into the field above it until the three biases are taken out in one subtraction (shared with the host emulation: the first
-// cut or-ed the fields in the kernel only, and only the GPU tests could see it)
+// The B8G8R8A8 texel of three BIASED codes (ed_step's answers): R = byte 2, alpha 0xFF.  (The kernel writes the three bytes from three
+// lanes; the host emulation packs them here.)
 MPCVR_ED_HD uint32_t ed_pack_bgra(int qr, int qg, int qb)
 {
     return (((uint32_t)qr << 16) + ((uint32_t)qg << 8) + (uint32_t)qb) + (0xff000000u - 0x00101010u);
 }
 
 // ---- the schedule ----
-// Region columns are counted from A0 = x0 & ~1 (xr = column - A0), so that xr and the step index have the same parity in every lane:
-// a pair of steps (even, odd) covers one 8-byte aligned pixel pair.  wl = x1 - A0 columns, the first x0 - A0 (0 or 1) of them outside.
+// Region columns are counted from x0 (xr = column - x0); wl = x1 - x0 of them.
 struct EdSchedule {
-    int wl;              // columns counted from A0
-    int lead;            // x0 - A0
-    int bands;           // ceil(rows / 64)
-    int groups;          // groups of kEdGroup steps per band: lane 63 must reach the flush step at xr = wl
-    int stride;          // words of one band's hand-off row: 3 per column (R, G, B), every step of lane 0 has its entry, a spare group
-                         // behind them (where the lanes of a group's store that have nothing to publish write), then kEdDummyWords of
-                         // dummy slots for this band's pixel stores off the region
+    int wl;              // columns of the region
+    int bands;           // ceil(rows / 21)
+    int groups;          // groups of kEdGroup steps per band: the bottom row must reach the flush step at xr = wl; a multiple of kEdBlockGroups
+    int stride;          // words of one band's hand-off row: 3 per column (R, G, B), every step of a row 0 has its entry, a spare group
+                         // behind them (where the lanes of a group's store that have nothing to publish write)
 };
 MPCVR_ED_HD EdSchedule ed_schedule(int x0, int x1, int rows)
 {
     EdSchedule s;
-    const int a0 = x0 & ~1;
-    s.wl = x1 - a0; s.lead = x0 - a0;
+    s.wl = x1 - x0;
     s.bands = (rows + kEdRows - 1) / kEdRows;
-    s.groups = (s.wl + 1 + kEdSkew * (kEdRows - 1) + kEdGroup - 1) / kEdGroup;
+    s.groups = (s.wl + kEdFlush + kEdGroup - 1) / kEdGroup;          // steps 0 .. wl + kEdFlush - 1
     s.groups = (s.groups + kEdBlockGroups - 1) / kEdBlockGroups * kEdBlockGroups;
-    s.stride = 3 * kEdGroup * (s.groups + 1) + kEdDummyWords;
+    s.stride = 3 * kEdGroup * (s.groups + 1);
     return s;
 }
-// hand-off words: D of column c, channel ch of a band's bottom row sits at word 3 c + ch; tagged so that zero means "not written yet"
-MPCVR_ED_HD uint32_t ed_tag(int32_t d) { return ((uint32_t)d << 1) | 1u; }
-MPCVR_ED_HD int32_t ed_untag(uint32_t w) { return (int32_t)w >> 1; }
+// hand-off words: D of column c, channel ch of a band's bottom row sits at word 3 c + ch, as D << 12 | gen: gen = the launch's generation
+// (1 .. 4095, counted by the owner of the rows), so that a word of an EARLIER launch reads as "not written yet" and the rows need no clearing
+// between launches of one geometry (they are cleared when the generation wraps or the layout changes; round 4 cleared them in front of every
+// launch — 600 MB for a 32-frame batch at 21 rows per band).  |D| stays below 2^18 (three shares of an error of a few U), 20 bits hold it.
+constexpr int kEdGenBits = 12;
+constexpr uint32_t kEdGenMask = (1u << kEdGenBits) - 1u;
+MPCVR_ED_HD uint32_t ed_tag(int32_t d, uint32_t gen) { return ((uint32_t)d << kEdGenBits) | gen; }
+MPCVR_ED_HD int32_t ed_untag(uint32_t w) { return (int32_t)w >> kEdGenBits; }
+MPCVR_ED_HD bool ed_tagged(uint32_t w, uint32_t gen) { return (w & kEdGenMask) == gen; }
+// ticket -> (frame, band): band-major (a band of every frame, then the next band) or frame-major; either way a band's producer has a lower ticket
+MPCVR_ED_HD void ed_ticket(int ticket, int n_frames, int bands, int order, int &z, int &band)
+{
+    if (order) { band = ticket / n_frames; z = ticket - band * n_frames; }
+    else { z = ticket / bands; band = ticket - z * bands; }
+}
 
 }  // namespace mpcvr

@@ -613,8 +613,9 @@ __device__ __forceinline__ void exact_matrix_store(const FusedArgs &P, const f2 
         for (int ch = 0; ch < 3; ch++) {
             f2 s = splat(P.xm[3 * ch]) * Y[col] + splat(P.xm[3 * ch + 1]) * U[col];
             s = s + splat(P.xm[3 * ch + 2]) * V[col];
-            s = s + splat(P.xc[ch]);
-            s = f2{__builtin_amdgcn_fmed3f(s.x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(s.y, 0.0f, 1.0f)};
+            // + cm_c and saturate: the packed add's clamp modifier (the compiler spends a v_max per value on it)
+            const f2 cc = splat(P.xc[ch]);
+            asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(s) : "v"(s), "v"(cc));
             const f2 t = s * mx + half2;
             out[col][ch] = f2{__builtin_floorf(t.x), __builtin_floorf(t.y)} * inv;
         }
@@ -638,8 +639,9 @@ __device__ __forceinline__ void convert_block_exact(const FusedArgs &P, const Ra
         Hu[1] = Un[1] * splat(0.75f) + Un[2] * splat(0.25f); Hv[1] = Vn[1] * splat(0.75f) + Vn[2] * splat(0.25f);
     } else {                                      // wx = 0 (even column: c00 * 1 + c10 * 0 = c00), 0.5 (odd; {0, 1} at 4:4:4, {1, 0} nearest)
         Hu[0] = Un[1]; Hv[0] = Vn[1];
-        Hu[1] = Un[1] * splat(P.cw_own) + Un[2] * splat(P.cw_next);
-        Hv[1] = Vn[1] * splat(P.cw_own) + Vn[2] * splat(P.cw_next);
+        // (the weights are 0, 0.5 or 1: both products are exact, so the FMA rounds once like the shader's add)
+        Hu[1] = pk_fma(Un[2], splat(P.cw_next), Un[1] * splat(P.cw_own));
+        Hv[1] = pk_fma(Vn[2], splat(P.cw_next), Vn[1] * splat(P.cw_own));
     }
     f2 Y[2], U[2], V[2];
 #pragma unroll

@@ -84,11 +84,14 @@ struct FusedParams {
 // (frames[z].src, window geometry, src_pitch) -> its B8G8R8A8 render target (frames[z].dst, dst_pitch) inside [x0, x1) x [y0, y1)
 struct ErrDiffParams {
     int x0, y0, x1, y1;        // video rect ∩ window, window coordinates
-    int src_pitch, dst_pitch;  // bytes; src is readable from two pixels in front of a row of the region to three behind it (the caller's intermediates have the margins)
-    int pair_stores;           // every target and dst_pitch on 8-byte boundaries: one 8-byte store per pixel pair
-    int shift;                 // 0: rows hand their errors down by a DPP wave shift; 1: by ds_bpermute (MPCVR_ERRDIFF_SHIFT=bpermute, A/B)
-    int order;                 // workgroup order: 0 = frame-major, 1 = band-major (MPCVR_ERRDIFF_ORDER, A/B)
-    uint32_t *handoff;         // device: ErrorDiffusionHandoffBytes(P, n_frames) — the bands' bottom rows for the bands below + their dummy slots (the launcher clears it)
+    int src_pitch, dst_pitch;  // bytes; src is readable from two pixels in front of a row of the region to three behind it (the caller's intermediates have the margins);
+                               // rows of both surfaces on dword boundaries (the kernel moves 16-byte pieces that need no more)
+    int order;                 // ticket order: 1 = band-major (a band of every frame, then the next band), 0 = frame-major (MPCVR_ERRDIFF_ORDER, A/B)
+    int gen;                   // generation the launch tags its hand-off words with, 1 .. 4095: no word of an earlier launch still in the rows may carry
+                               // it (the owner counts launches and passes 0 — "clear the rows first" — when the count wraps or the layout changed)
+    int spin_limit;            // polls a band grants the band above before it gives up and sets *status; 0 = the default (2^21, ~2 s)
+    int test_stall;            // tests only: frame 0's first band never publishes, so that the band below gives up
+    uint32_t *handoff;         // device: ErrorDiffusionHandoffBytes(P, n_frames) — the bands' bottom rows for the bands below and the ticket counter
     int *status;               // host memory the device can write: set to 1 when a band gave up waiting for the band above (never, unless a launch is broken)
 };
 size_t ErrorDiffusionHandoffBytes(const ErrDiffParams &P, int n_frames);
