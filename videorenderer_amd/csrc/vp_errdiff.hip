@@ -40,7 +40,7 @@ typedef __attribute__((address_space(1))) uint8_t *ed_gptr;
 
 constexpr int kEdTileRow = 144;                      // bytes of a tile row: 32 pixels + a pad that keeps the 21 rows off each other's banks, 16-byte aligned
 constexpr int kEdTile = kEdRows * kEdTileRow;        // 3024
-constexpr int kEdLdsIn = 0, kEdLdsOut = kEdTile, kEdLdsTop = 2 * kEdTile, kEdLdsHand = kEdLdsTop + 256, kEdLdsDummy = kEdLdsHand + 96;
+constexpr int kEdLdsIn = 0, kEdLdsOut = kEdTile, kEdLdsTop = 2 * kEdTile, kEdLdsHand = kEdLdsTop + 2 * 32 * 4, kEdLdsDummy = kEdLdsHand + 96;
 constexpr int kEdLds = kEdLdsDummy + 64 * 4 + 128;   // (a lane's dummy word + the largest immediate offset of a step's hand-off write)
 
 __device__ __forceinline__ void ed_wave_sync()
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const F
 
         EdChannel st{0, 0, 0, 0};
         int32_t dprev = 0;
+        uint32_t pend_w = 0; int pend_t0 = 0; bool have_pending = false;      // a group's hand-off words on their way from LDS to the band's row
 
         // pieces of block tb: columns tb - 2 i + 4 j .. + 3 of the row; a piece that lies outside the region altogether reads a clamped
         // position (the caller's image is readable from two pixels in front of a row of the region to three behind it)
@@ -119,16 +120,44 @@ __global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const F
             for (int m = 0; m < 3; m++) *(ed_l4 *)(in_row + 16 * piece[m]) = ed_l4{v[m].x, v[m].y, v[m].z, v[m].w};
         };
         const int wlane = lane < 3 * kEdGroup ? lane : 0;
-        auto fetch_above = [&](int t0) __attribute__((always_inline)) -> uint32_t {
-            return __hip_atomic_load(above + 3 * t0 + wlane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the band above's D, a group of 8 columns = 24 tagged words at a time (word l in lane l), fetched FOUR groups ahead into a ring of
+        // four registers: the load crosses to another XCD's memory (a microsecond or two), a group of 8 steps takes 0.7 us.  A group's words
+        // are looked at one group before its steps (the steps' LDS reads are issued a group ahead): the band runs as close behind the band
+        // above as its words allow, whatever the distance of the prefetch.
+        auto fetch_above = [&](int group) __attribute__((always_inline)) -> uint32_t {
+            return __hip_atomic_load(above + 3 * kEdGroup * group + wlane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        // words of `group` (in w, or fetched again until they carry the launch's tag) -> LDS slot group & 1, untagged.  The first look is
+        // straight-line code: a wait in a loop header makes the compiler drain EVERY outstanding memory instruction, the store of the group
+        // just published included — a full memory round trip per group.
+        auto stage_above = [&](int group, uint32_t w) __attribute__((always_inline)) {
+            if (has_above) {
+                const bool need = lane < 3 * kEdGroup && kEdGroup * group + lane / 3 < S.wl;      // (columns beyond the region are never written, nor used)
+                if (__ballot(need && !ed_tagged(w, gen)) != 0) {                                  // wave-uniform
+                    int spins = 0;
+                    do {
+                        if (++spins > P.spin_limit) { if (lane == 0) *P.status = 1; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        w = fetch_above(group);
+                    } while (__ballot(need && !ed_tagged(w, gen)) != 0);
+                }
+            } else w = 0;                                                                          // (the frame's first band: nothing comes down; untag(0) = 0)
+            if (lane < 32) ((uint32_t *)(lds + kEdLdsTop))[32 * (group & 1) + lane] = (uint32_t)ed_untag(w);      // (lanes 24-31: words nobody reads)
         };
 
         ed_u4 nxt[3];
         load_block(0, nxt);
-        uint32_t wnext = fetch_above(0);
+        uint32_t wq[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) wq[j] = fetch_above(j);
         ed_wave_sync();                              // (the previous band's last reads of the tiles lie in front of these writes)
         tile_block(nxt);
+        stage_above(0, wq[0]);
+        wq[0] = fetch_above(4);
         ed_wave_sync();
+        int32_t tops[kEdGroup];                      // the band above's D for the steps of the group at hand (this lane's channel)
+#pragma unroll
+        for (int s = 0; s < kEdGroup; s++) tops[s] = (int32_t)top_word[3 * s];
 
         // one block of 32 steps; ALL: every row stands on a pixel of the region at every step of the block (wave-uniform, true for all but
         // the first two and the last two blocks of a full band) — no live test, no select of e, 16-byte stores
@@ -136,49 +165,53 @@ __global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const F
             constexpr bool ALL = decltype(ALLC)::value;
             const int tb = kEdBlock * blk;
             load_block(tb + kEdBlock, nxt);                                              // the next block's pieces, a block ahead
+            // Every LDS read a step needs — its pixel word and the band above's D for row 0 — is issued a GROUP ahead into registers: a read
+            // right in front of its use makes the wavefront sit out an LDS round trip (behind its own two writes of the step before) at every
+            // step, which was 40 % of a lone band's time.  pxs / tops: this group's; pxn / topn: the next one's, in flight.
+            uint32_t pxs[kEdGroup], pxn[kEdGroup];
+            int32_t topn[kEdGroup];
+#pragma unroll
+            for (int s = 0; s < kEdGroup; s++) pxs[s] = *(const uint32_t *)(in_row + 4 * s);
 #pragma unroll
             for (int gi = 0; gi < kEdBlockGroups; gi++) {
                 const int t0 = tb + kEdGroup * gi;
-                // D of the band above for the eight columns of this group: fetched a group ago; wait for what is not there yet
-                uint32_t w = wnext;
-                if (has_above) {
-                    const bool need = lane < 3 * kEdGroup && t0 + lane / 3 < S.wl;      // (columns beyond the region are never written, nor used)
-                    int spins = 0;
-                    while (__ballot(need && !ed_tagged(w, gen)) != 0) {                           // wave-uniform
-                        if (++spins > P.spin_limit) { if (lane == 0) *P.status = 1; break; }
-                        __builtin_amdgcn_s_sleep(4);
-                        w = fetch_above(t0);
-                    }
-                }
-                wnext = fetch_above(t0 + kEdGroup);                                      // (the row has a spare group of entries behind the last one)
-                if (!has_above) w = 0;                                                   // (the frame's first band: nothing comes down; untag(0) = 0)
-                ((uint32_t *)(lds + kEdLdsTop))[lane] = (uint32_t)ed_untag(w);          // word 3 s + c of the group in lane 3 s + c
+                const int G = kEdBlockGroups * blk + gi;
+                // the NEXT group's words of the band above: fetched four groups ago -> LDS -> this lane's channel, in flight during this group's steps
+                stage_above(G + 1, wq[(gi + 1) & 3]);
+                wq[(gi + 1) & 3] = fetch_above(G + 5);                                   // (the row has spare entries behind the last group)
                 ed_wave_sync();
-                int32_t top[kEdGroup];
 #pragma unroll
-                for (int s = 0; s < kEdGroup; s++) top[s] = (int32_t)top_word[3 * s];
+                for (int s = 0; s < kEdGroup; s++) {
+                    topn[s] = (int32_t)top_word[32 * ((gi + 1) & 1) + 3 * s];
+                    if (gi + 1 < kEdBlockGroups) pxn[s] = *(const uint32_t *)(in_row + 4 * (kEdGroup * (gi + 1) + s));
+                }
 #pragma unroll
                 for (int s = 0; s < kEdGroup; s++) {
                     const int sb = kEdGroup * gi + s;                                    // step inside the block = position inside the tile row
                     const int xr = t0 + s - kEdSkew * i;
                     const bool live = ALL ? !idle : (row_ok && xr >= 0 && xr < S.wl);
-                    const uint32_t code = *(const uint32_t *)(in_row + 4 * sb);
-                    const int32_t shifted = __builtin_amdgcn_update_dpp(top[s], dprev, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-                    const int32_t din = row0 ? top[s] : shifted;
-                    const int qb = ed_step(st, ALL || live, (int)((code >> sh) & 0x3ffu), din, dprev);
+                    const int32_t shifted = __builtin_amdgcn_mov_dpp(dprev, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+                    const int32_t din = row0 ? tops[s] : shifted;
+                    const int qb = ed_step(st, ALL || live, (int)((pxs[s] >> sh) & 0x3ffu), din, dprev);
                     out_byte[4 * sb] = (unsigned char)(qb - 16);
-                    hand_word[3 * s] = ed_tag(dprev, gen);                                    // the bottom row: D(xr - 1) for the band below
+                    hand_word[3 * s] = ed_tag(dprev, gen);                               // the bottom row: D(xr - 1) for the band below
+                    if (s == 1 && have_pending) {
+                        // publish the PREVIOUS group's 24 words (its LDS read was issued at its end, two steps ago): ONE store of lanes 0-23,
+                        // value and tag in one word
+                        const int col0 = pend_t0 - kEdFlush;
+                        const int col = col0 + lane / 3;
+                        const bool pub = lane < 3 * kEdGroup && col >= 0 && col < S.wl && !stall;
+                        uint32_t *at = pub ? mine + 3 * col0 + lane : spare + (lane & 15);
+                        __hip_atomic_store(at, pend_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
                 ed_wave_sync();
-                // publish the group's 24 words (the bottom row's D of columns t0 - 41 .. t0 - 34): ONE store of lanes 0-23, value and tag in one word
-                {
-                    const uint32_t outw = ((const uint32_t *)(lds + kEdLdsHand))[wlane];
-                    const int col0 = t0 - kEdFlush;
-                    const int col = col0 + lane / 3;
-                    const bool pub = lane < 3 * kEdGroup && col >= 0 && col < S.wl && !stall;
-                    uint32_t *at = pub ? mine + 3 * col0 + lane : spare + (lane & 15);
-                    __hip_atomic_store(at, outw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                // this group's 24 words (the bottom row's D of columns t0 - 41 .. t0 - 34) gathered from the lanes that wrote them
+                pend_w = ((const uint32_t *)(lds + kEdLdsHand))[wlane];
+                pend_t0 = t0; have_pending = true;
+                ed_wave_sync();                                                          // (the next group's steps overwrite the words: the read above stays in front of them)
+#pragma unroll
+                for (int s = 0; s < kEdGroup; s++) { pxs[s] = pxn[s]; tops[s] = topn[s]; }
             }
             // the block's 32 pixels of every row leave the output tile, the next block's enter the input tile
             ed_l4 o[3];
@@ -202,6 +235,11 @@ __global__ __launch_bounds__(64) void k_error_diffusion(ErrDiffParams P, const F
             const int tb = kEdBlock * blk;
             if (full_band && tb - kEdSkew * (kEdRows - 1) >= 0 && tb + kEdBlock - 1 < S.wl) run_block(std::true_type{}, blk);
             else run_block(std::false_type{}, blk);
+        }
+        {   // the last group's words
+            const int col0 = pend_t0 - kEdFlush;
+            const int col = col0 + lane / 3;
+            if (have_pending && lane < 3 * kEdGroup && col >= 0 && col < S.wl && !stall) __hip_atomic_store(mine + 3 * col0 + lane, pend_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

@@ -105,8 +105,8 @@ struct EdSchedule {
     int wl;              // columns of the region
     int bands;           // ceil(rows / 21)
     int groups;          // groups of kEdGroup steps per band: the bottom row must reach the flush step at xr = wl; a multiple of kEdBlockGroups
-    int stride;          // words of one band's hand-off row: 3 per column (R, G, B), every step of a row 0 has its entry, a spare group
-                         // behind them (where the lanes of a group's store that have nothing to publish write)
+    int stride;          // words of one band's hand-off row: 3 per column (R, G, B), every step of a row 0 has its entry, spare groups
+                         // behind them (the band below fetches five groups ahead; the lanes of a group's store that have nothing to publish write there)
 };
 MPCVR_ED_HD EdSchedule ed_schedule(int x0, int x1, int rows)
 {
@@ -115,7 +115,7 @@ MPCVR_ED_HD EdSchedule ed_schedule(int x0, int x1, int rows)
     s.bands = (rows + kEdRows - 1) / kEdRows;
     s.groups = (s.wl + kEdFlush + kEdGroup - 1) / kEdGroup;          // steps 0 .. wl + kEdFlush - 1
     s.groups = (s.groups + kEdBlockGroups - 1) / kEdBlockGroups * kEdBlockGroups;
-    s.stride = 3 * kEdGroup * (s.groups + 1);
+    s.stride = 3 * kEdGroup * (s.groups + 6);
     return s;
 }
 // hand-off words: D of column c, channel ch of a band's bottom row sits at word 3 c + ch, as D << 12 | gen: gen = the launch's generation
