@@ -70,6 +70,11 @@ WORKLOADS = {
                        iUpscaling=4, hdr_output=1, output_format=1, desc="4K P010 BT.2020/PQ -> Lanczos3 2x -> HDR10 passthrough -> 8K R10G10B10A2"),
     "hdrpass_1440": dict(cformat=2, w=1920, h=1080, scale=1, dst=(2560, 1440), ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
                          iUpscaling=4, hdr_output=1, output_format=1, desc="1080p P010 BT.2020/PQ -> Lanczos3 1.33x -> HDR10 passthrough -> 1440p R10G10B10A2"),
+    # the two slowest reference-pinned rows (round-5 counter digests: profiles/r05/jinc1080_*, dovi4k_*)
+    "jinc1080": dict(cformat=2, w=1920, h=1080, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
+                     iUpscaling=5, desc="1080p P010 BT.2020/PQ -> Jinc2m 2x (ps_resize_onepass_jinc2) -> PQ->SDR -> ordered dither -> 4K BGRA8"),
+    "dovi4k": dict(cformat=2, w=3840, h=2160, scale=1, ext=dict(chroma=5, nominal_range=2), iUpscaling=4, dovi=("mmr", (100, 600, 1000)),
+                   desc="4K P010 Dolby Vision (MMR chroma curves, level-2 trims) -> SDR -> ordered dither -> 4K BGRA8, no resize"),
     "c3hdr_1080p": dict(cformat=2, w=1920, h=1080, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
                         iUpscaling=4, desc="1080p P010 BT.2020/PQ -> Lanczos3 2x -> PQ->SDR -> dither -> 4K BGRA8 (alternative reading)"),
 }
@@ -283,6 +288,9 @@ def main():
     vp.InitMediaType(wl["cformat"], w, h, extfmt=extfmt)
     if wl.get("hdr_output"):
         vp.SetHdrOutput(True)
+    if wl.get("dovi"):
+        from videorenderer_amd import synth
+        vp.SetDoviMetadata(synth.dovi_metadata(wl["dovi"][0], l2=wl["dovi"][1]))
     vp.SetWindowRect((0, 0, dw, dh))
     vp.SetVideoRect((0, 0, dw, dh))
     vdist.sync_params(vp)                                  # RCCL broadcast of rank 0's parameter blob (few KiB)
@@ -409,6 +417,9 @@ def main():
             vp2.InitMediaType(wl["cformat"], w, h, extfmt=extfmt)
             if wl.get("hdr_output"):
                 vp2.SetHdrOutput(True)
+            if wl.get("dovi"):
+                from videorenderer_amd import synth
+                vp2.SetDoviMetadata(synth.dovi_metadata(wl["dovi"][0], l2=wl["dovi"][1]))
             vp2.SetWindowRect((0, 0, dw, dh))
             vp2.SetVideoRect((0, 0, dw, dh))
             ctx = vp2._ctx
