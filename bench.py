@@ -371,6 +371,31 @@ def main():
         torch.cuda.synchronize()
         copy_gbps = 10 * 2 * n_el / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del a_, b_
+    # ... and the ceiling for THIS workload's traffic shape (the fused kernels write several times what they read; a copy reads as much as
+    # it writes and flatters them): the library's own probe kernel — each 16-byte word of a sample read once, fanned out to `fan` words of
+    # a target, no arithmetic — over the same ring of samples and targets as the timed steps
+    shape_gbps, shape_fan = None, None
+    if rank == 0:
+        import ctypes as C
+        Lp = api.load_library()
+        src16 = nbytes // 16 * 16
+        shape_fan = max(1, min(64, int(out_bytes // src16)))
+        n_probe = min(ring, 24)
+        def probe(i):
+            k = i % n_probe
+            hr = Lp.mpcvr_bandwidth_probe(C.c_void_p(srcs[k].data_ptr()), C.c_void_p(dsts[k].data_ptr()), C.c_size_t(src16), shape_fan, C.c_void_p(stream.cuda_stream))
+            if hr < 0:
+                raise SystemExit(f"mpcvr_bandwidth_probe failed: {hr:#x}")
+        for i in range(n_probe):
+            probe(i)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 4 * n_probe
+        e0.record()
+        for i in range(reps):
+            probe(i)
+        e1.record()
+        torch.cuda.synchronize()
+        shape_gbps = reps * src16 * (1 + shape_fan) / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
     # PCIe-inclusive rate of the reference's own calling pattern (CopySample from host memory, then Process), frame by
     # frame through the 3-slot upload ring: reported beside `value`, never as `value` (inputs-resident is the metric)
@@ -469,6 +494,8 @@ def main():
                             # the roof that binds the fused kernels: the share of the launch during which a SIMD's VALU pipe is issuing
                             # (1.0 = no free issue slot left).  From the same committed PMC passes as `traffic`, tied to the same sources.
                             valu_issue = {"bound": "valu_issue", "frac": t["valu_issue_frac"], "wait_inst_any_share": t.get("wait_inst_any_share"),
+                                          # the clock the kernel sustained in that pass (SQ_BUSY_CYCLES / 32 over the kernel's duration): issue slots x clock
+                                          "sustained_mhz": t.get("sustained_mhz"),
                                           "source": f"profiles/hbm_traffic.json [{t.get('profile', '?')}]: SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs over SQ_BUSY_CYCLES / 32, rocprofv3 --pmc pass of tools/pmc_traffic.sh"}
                     else:
                         traffic_source = f"omitted: kernels changed since profile {t.get('profile', '?')} (csrc hash differs)"
@@ -493,7 +520,11 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms_per_launch": round(launch_ms, 4), "bytes_per_launch": algo_bytes * args.batch,
                          "empirical_copy_peak_GBps": round(copy_gbps, 1) if copy_gbps else None,
-                         "frac_of_empirical_copy_peak": round(achieved / copy_gbps, 4) if copy_gbps else None},
+                         "frac_of_empirical_copy_peak": round(achieved / copy_gbps, 4) if copy_gbps else None,
+                         # the same box's rate for this workload's read : write shape with no arithmetic (mpcvr_bandwidth_probe, csrc/vp_probe.hip)
+                         "empirical_shape_peak_GBps": round(shape_gbps, 1) if shape_gbps else None,
+                         "empirical_shape": f"1 : {shape_fan} bytes read : written, 16-byte accesses, {min(ring, 24)}-frame ring" if shape_gbps else None,
+                         "frac_of_empirical_shape_peak": round(achieved / shape_gbps, 4) if shape_gbps else None},
         }
         # the fused kernels are bound by VALU issue slots, not by HBM (traffic is ~1.04x algorithmic): the measured occupancy of that
         # roof rides beside the HBM fraction — frac_at_full_issue is what the HBM fraction would be with every issue slot used

@@ -406,6 +406,11 @@ int32_t mpcvr_plan_describe(const mpcvr_settings *s, int32_t cformat, int32_t re
                             const mpcvr_rect *video_rect, int32_t window_w, int32_t window_h,
                             char *buf, size_t buf_size);
 
+/* A measurement aid (bench.py: roofline.empirical_shape_peak_GBps), not part of the video path: one launch that reads src_bytes (a multiple of
+ * 16, 16-byte aligned DEVICE buffers) once and writes fan * src_bytes — the fused kernels' traffic shape (a 4K P010 sample in, an 8K
+ * B8G8R8A8 target out is 1 : 5.33) with no arithmetic.  dst holds fan * src_bytes bytes; stream = a hipStream_t or NULL. */
+int32_t mpcvr_bandwidth_probe(const void *src_dev, void *dst_dev, size_t src_bytes, int32_t fan, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2360,3 +2360,26 @@ def test_single_frames_queued_behind_a_batch_stay_behind_it(mpcvr, torch_cuda):
     info = vp.GetVPInfo()
     vp.close()
     assert info.startswith("fused_up2x"), info
+
+
+def test_bench_through_rccl_in_a_world_of_one(mpcvr, torch_cuda):
+    """The `nccl` branch of videorenderer_amd/dist.py on hardware, as far as one GPU allows: bench.py under torchrun with ONE rank and
+    MPCVR_DIST_FORCE=1 — init_process_group("nccl"), the parameter-blob broadcast, the max-over-ranks all_reduce and all_gather_object all
+    execute over RCCL (a world of one), and the line says which RCCL it was.  No scaling curve comes out of this; that is the driver's run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MPCVR_DIST_FORCE="1")
+    env.pop("MPCVR_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--ring", "2", "--src", "256x144", "--no-cpu-baseline", "--no-host-path"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    d = r["config"]["distributed"]
+    assert d["backend"] == "nccl" and d["world_size"] == 1 and d.get("rccl_version") and "unavailable" not in d["rccl_version"], d
+    assert r["n_gpus"] == 1 and r["value"] > 0 and r["config"]["path"] == "fused_up2x"

@@ -30,9 +30,16 @@ for f in glob.glob(f"gpurun_out/traffic_{w}/SQ_ACTIVE_INST_VALU/*counter_collect
 # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs, SQ_BUSY_CYCLES cycles summed over the 32 shader engines' SQs
 # (MI355X_MICROARCH.md, rocprofv3 units): VALU-busy cycles per SIMD / cycles of the launch
 issue = (sq["SQ_ACTIVE_INST_VALU"] * 4 / 1024) / (sq["SQ_BUSY_CYCLES"] / 32) if sq.get("SQ_BUSY_CYCLES") else None
+# the clock the kernels sustained in that pass: busy cycles per SQ over the kernels' own duration (kernel trace of the same run)
+dur_ns = 0.0
+for f in glob.glob(f"gpurun_out/traffic_{w}/SQ_ACTIVE_INST_VALU/*kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        if "mpcvr" in r.get("Kernel_Name", ""):
+            dur_ns += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+mhz = (sq["SQ_BUSY_CYCLES"] / 32) / dur_ns * 1e3 if dur_ns and sq.get("SQ_BUSY_CYCLES") else None
 line = json.dumps({"workload": w, "steps_profiled": launches, "fetch_kb_per_step": tot["FETCH_SIZE"][0] / launches,
                    "write_kb_per_step": tot["WRITE_SIZE"][0] / launches, "dispatches": tot["FETCH_SIZE"][1],
-                   "valu_issue_frac": issue, "sq": {k: v / launches for k, v in sq.items()},
+                   "valu_issue_frac": issue, "sustained_mhz": mhz, "sq": {k: v / launches for k, v in sq.items()},
                    "wait_inst_any_share": (sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAVE_CYCLES") else None})
 print(line)
 open(f"gpurun_out/traffic_{w}.json", "w").write(line + "\n")      # tools/update_traffic.py folds it into profiles/hbm_traffic.json

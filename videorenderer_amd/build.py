@@ -42,6 +42,7 @@ SOURCES = [
     ("vp_fused_period_3_1.hip", []),
     ("vp_jinc.hip", []),
     ("vp_errdiff.hip", []),
+    ("vp_probe.hip", []),
 ]
 
 

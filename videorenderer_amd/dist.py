@@ -12,12 +12,23 @@ import torch
 import torch.distributed as dist
 
 
+def _forced():
+    """MPCVR_DIST_FORCE=1: run the collectives even in a world of ONE rank — a single-GPU box then executes the nccl (= RCCL) branch of every
+    function below for real (init_process_group("nccl"), broadcast, all_reduce, all_gather_object), which is all the multi-GPU code there is."""
+    v = os.environ.get("MPCVR_DIST_FORCE", "")
+    return bool(v) and v != "0"
+
+
+def _single():
+    return not dist.is_initialized() or (dist.get_world_size() == 1 and not _forced())
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _forced()) and not dist.is_initialized():
         if backend is None:      # MPCVR_DIST_BACKEND=gloo lets a single-GPU box exercise the multi-rank flow
             backend = os.environ.get("MPCVR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -34,7 +45,7 @@ def shard_frames(n_frames, rank, world):
 def broadcast_blob(blob, device=None, src=0):
     """Broadcast rank `src`'s parameter blob (bytes).  Non-source ranks pass None (or anything) and get bytes back.
     `device`: torch device holding the staging tensor — a CUDA device for RCCL, CPU for gloo."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return blob
     rank = dist.get_rank()
     if device is None:
@@ -52,7 +63,7 @@ def broadcast_blob(blob, device=None, src=0):
 
 def sync_params(vp, device=None, src=0):
     """Make every rank's processor use rank `src`'s parameter blob (mpcvr_get/set_param_blob)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return
     blob = vp.GetParamBlob() if dist.get_rank() == src else None
     blob = broadcast_blob(blob, device=device, src=src)
@@ -62,7 +73,7 @@ def sync_params(vp, device=None, src=0):
 
 def max_over_ranks(value, device=None):
     """MAX-reduce a python float (timing) over ranks."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return value
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
@@ -72,7 +83,7 @@ def max_over_ranks(value, device=None):
 
 
 def sum_over_ranks(value, device=None):
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return value
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
@@ -83,7 +94,7 @@ def sum_over_ranks(value, device=None):
 
 def gather_objects(obj):
     """Every rank's `obj` (picklable) as a list on every rank, rank order; [obj] in a single process."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return [obj]
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, obj)
