@@ -1176,7 +1176,10 @@ def test_period_kernel_vs_oracle_and_strip_kernel(mpcvr, oracle, torch_cuda, lab
     want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
     got, info = run_product(mpcvr, torch, c, extra_flags=api.FLAG_FORCE_PERIOD)       # (SDR + 4 taps: the planner's own choice is k_fused_strip)
     P, Q, nt = pqn
-    assert f"kernel=fused_period(rows={P}:{Q},taps={nt}," in info, info
+    if nt == 6:     # (round 5: six taps — MPCVR_FLAG_LANCZOS3_FIXED, the Spline36 extension — have no periodic variant any more; the strip kernel draws them)
+        assert "kernel=fused_strip(" in info, info
+    else:
+        assert f"kernel=fused_period(rows={P}:{Q},taps={nt}," in info, info
     alt, info_alt = run_product(mpcvr, torch, c, extra_flags=api.FLAG_NO_PERIOD)
     assert "kernel=fused_strip(" in info_alt, info_alt
     if c.get("output_format", 0) == 1:
@@ -1377,12 +1380,13 @@ def test_sweep_every_fused_period_instantiation(mpcvr, torch_cuda, ratio, tail, 
     src_wh, dst_wh = _SWEEP_PERIOD_GEO[ratio]
     for i, (name, (cf, over)) in enumerate(sorted(_SWEEP_PERIOD_SRC.items())):
         c = _sweep_case(cf, over, tail, taps, src_wh, dst_wh, 700 + 13 * i + taps)
-        _tiers_agree(mpcvr, torch_cuda, c, api.FLAG_FORCE_PERIOD, "kernel=fused_period(rows=" + ratio)
+        # (six taps — the as-intended Lanczos3 of MPCVR_FLAG_LANCZOS3_FIXED, Spline36 — have no periodic variant since round 5: the strip kernel draws them)
+        _tiers_agree(mpcvr, torch_cuda, c, api.FLAG_FORCE_PERIOD, ("kernel=fused_period(rows=" + ratio) if taps != 6 else "kernel=fused_strip(")
     if tail == "none":      # SRC_SURFACE (no tail of its own): Catmull-Rom chroma puts the convert into its own kernel; 8-bit surface -> straight store, 10-bit -> final pass
         for i, cf in enumerate((1, 2)):
             c = _sweep_case(cf, {}, "none", taps, src_wh, dst_wh, 800 + i + taps)
             c["iChromaScaling"] = 2
-            _tiers_agree(mpcvr, torch_cuda, c, 0, "kernel=fused_period:surface(rows=" + ratio)
+            _tiers_agree(mpcvr, torch_cuda, c, 0, ("kernel=fused_period:surface(rows=" + ratio) if taps != 6 else "kernel=fused_strip:surface(")
 
 
 _SWEEP_STRIP_SRC = dict(_SWEEP_UP2X_SRC, planar16_generic=(20, dict(misalign=1)), planar8_generic=(14, dict(misalign=1)), p01x_direct10=(2, dict(output_format=1)))
@@ -2383,3 +2387,22 @@ def test_bench_through_rccl_in_a_world_of_one(mpcvr, torch_cuda):
     d = r["config"]["distributed"]
     assert d["backend"] == "nccl" and d["world_size"] == 1 and d.get("rccl_version") and "unavailable" not in d["rccl_version"], d
     assert r["n_gpus"] == 1 and r["value"] > 0 and r["config"]["path"] == "fused_up2x"
+
+
+def test_bandwidth_probe_moves_what_it_says(mpcvr, torch_cuda):
+    """mpcvr_bandwidth_probe (csrc/vp_probe.hip, bench.py's traffic-shaped ceiling): every 16-byte word of the source read once, `fan` words written."""
+    import ctypes as C
+    from videorenderer_amd import api
+    torch = torch_cuda
+    L = api.load_library()
+    n, fan = 1 << 16, 5
+    src = torch.randint(0, 1 << 31, (n // 4,), dtype=torch.int32, device="cuda")
+    dst = torch.zeros((fan, n // 4), dtype=torch.int32, device="cuda")
+    assert L.mpcvr_bandwidth_probe(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n), fan, None) == 0
+    torch.cuda.synchronize()
+    s4 = src.view(-1, 4)
+    for k in range(fan):
+        d4 = dst[k].view(-1, 4)
+        assert torch.equal(d4[:, 1:], s4[:, 1:]) and torch.equal(d4[:, 0], s4[:, 0] + k)
+    assert L.mpcvr_bandwidth_probe(None, C.c_void_p(dst.data_ptr()), C.c_size_t(n), fan, None) < 0
+    assert L.mpcvr_bandwidth_probe(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n), 0, None) < 0

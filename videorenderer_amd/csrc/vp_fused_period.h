@@ -464,7 +464,7 @@ hipError_t LaunchFusedPeriodPQ(const FusedArgs &a, const PeriodArgs &q, int nt, 
                            else if (tailk == TAILK_HLG) MPCVR_PD3(NT, TAILK_HLG); else return hipErrorNotSupported; } while (0)
     if (srck == SRC_SURFACE) {      // the convert output of another kernel: no tail, both epilogues
 #define MPCVR_PDS(NT) do { if (epik == EPI_DITHER8) MPCVR_PD5(NT, TAILK_NONE, SRC_SURFACE, EPI_DITHER8); else MPCVR_PD5(NT, TAILK_NONE, SRC_SURFACE, EPI_DIRECT8); } while (0)
-        if (nt == 4) MPCVR_PDS(4); else if (nt == 5) MPCVR_PDS(5); else if (nt == 6) MPCVR_PDS(6); else return hipErrorNotSupported;
+        if (nt == 4) MPCVR_PDS(4); else if (nt == 5) MPCVR_PDS(5); else return hipErrorNotSupported;
 #undef MPCVR_PDS
         return hipGetLastError();
     }
@@ -474,9 +474,10 @@ hipError_t LaunchFusedPeriodPQ(const FusedArgs &a, const PeriodArgs &q, int nt, 
 #endif
     MPCVR_PD5(MPCVR_PERIOD_DEV_NT, TAILK_PQ_LUT, SRC_P01X, EPI_DITHER8);
 #else
+    // (round 5: the 6-tap variants — Spline36, the as-intended Lanczos3 of MPCVR_FLAG_LANCZOS3_FIXED — are no longer built: 75 instantiations, a
+    // fifth of the library's build time, for two settings no reference build offers; k_fused_strip draws those frames)
     if (nt == 4) MPCVR_PD2(4);
     else if (nt == 5) MPCVR_PD2(5);
-    else if (nt == 6) MPCVR_PD2(6);
     else return hipErrorNotSupported;
 #endif
 #undef MPCVR_PD2

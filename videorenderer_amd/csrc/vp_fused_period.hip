@@ -45,7 +45,7 @@ bool FusedPeriodTakes(const FusedStripParams &S)
     if (S.surface_mode && ((S.surf.fmt != SF_BGRA8 && S.surf.fmt != SF_RGB10A2) || (S.surf.pitch & 3))) return false;
     const int tailk = S.surface_mode ? TAILK_NONE : FusedTailKind(P);
     if (tailk == TAILK_ALU) return false;                         // the literal tails stay with k_fused_strip
-    if (S.per_nt < 4 || S.per_nt > 6 || S.per_acols < 2 || (S.per_acols & 1)) return false;
+    if (S.per_nt < 4 || S.per_nt > 5 || S.per_acols < 2 || (S.per_acols & 1)) return false;      // (4 taps, or Lanczos3 as Direct3D 11 draws it; six taps: k_fused_strip)
     if (S.per_strip_w < 2 || S.per_strip_w > kPeriodStripMax || (S.per_strip_w & 1)) return false;
     // measured (profiles/r03): without a table tail the 4-tap filters run as fast or faster through k_fused_strip (SDR 1080p -> 1440p
     // Catmull-Rom 120.6 k against 115.4 k frames/s: the convert is light, and that is where the register window pays)

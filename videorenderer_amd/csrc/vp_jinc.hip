@@ -54,10 +54,21 @@ __global__ __launch_bounds__(256) void k_jinc2_quad(Surface in, DrawCoords dc, c
     const int bx_hi = jinc_base(dc.org_x, min(2 * qx0 + 127, out_w - 1), dc.step_x) + 2;
     const int by_hi = jinc_base(dc.org_y, min(2 * qy0 + 7, out_h - 1), dc.step_y) + 2;
     const int ncols = min(bx_hi - bx_lo + 1, TW), nrows = min(by_hi - by_lo + 1, TH);
-    for (int t = tid; t < ncols * nrows; t += 256) {
-        const int r = t / ncols, c = t - r * ncols;
-        const f3 q = decode_texel<INFMT>(load_texel_raw<INFMT>(in, clampi(bx_lo + c, 0, in.w - 1), clampi(by_lo + r, 0, in.h - 1)));
-        tile[r * TW + c] = make_float4(q.x, q.y, q.z, 0.0f);
+    // (no division per texel: wavefront w takes rows w and w + 4, its lanes 64 columns; the last eight columns of all eight rows go to wavefront 0)
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int r = threadIdx.y + 4 * rr, c = threadIdx.x;
+        if (r < nrows && c < ncols) {
+            const f3 q = decode_texel<INFMT>(load_texel_raw<INFMT>(in, clampi(bx_lo + c, 0, in.w - 1), clampi(by_lo + r, 0, in.h - 1)));
+            tile[r * TW + c] = make_float4(q.x, q.y, q.z, 0.0f);
+        }
+    }
+    if (threadIdx.y == 0) {
+        const int r = threadIdx.x >> 3, c = 64 + (threadIdx.x & 7);
+        if (r < nrows && c < ncols) {
+            const f3 q = decode_texel<INFMT>(load_texel_raw<INFMT>(in, clampi(bx_lo + c, 0, in.w - 1), clampi(by_lo + r, 0, in.h - 1)));
+            tile[r * TW + c] = make_float4(q.x, q.y, q.z, 0.0f);
+        }
     }
     __syncthreads();
     const int x = 2 * (qx0 + threadIdx.x), y = 2 * (qy0 + threadIdx.y);
@@ -103,7 +114,8 @@ __global__ __launch_bounds__(256) void k_jinc2_quad(Surface in, DrawCoords dc, c
         const int ox = x + (p & 1), oy = y + (p >> 1);
         const float iw = INVW[p];
         f3 c = {col[p].x * iw, col[p].y * iw, col[p].z * iw};
-        const f3 cl = {fminf(fmaxf(c.x, mn[p].x), mx[p].x), fminf(fmaxf(c.y, mn[p].y), mx[p].y), fminf(fmaxf(c.z, mn[p].z), mx[p].z)};
+        // clamp(c, mn, mx) with mn <= mx is the median of the three: one v_med3_f32 per channel (min(max()) was two)
+        const f3 cl = {__builtin_amdgcn_fmed3f(c.x, mn[p].x, mx[p].x), __builtin_amdgcn_fmed3f(c.y, mn[p].y, mx[p].y), __builtin_amdgcn_fmed3f(c.z, mn[p].z, mx[p].z)};
         c.x = __builtin_fmaf(0.8f, cl.x - c.x, c.x); c.y = __builtin_fmaf(0.8f, cl.y - c.y, c.y); c.z = __builtin_fmaf(0.8f, cl.z - c.z, c.z);
         if (EPI == 0) {
             if (ox < out_w && oy < out_h) store_epilogue(st, ox, oy, c);
