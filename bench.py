@@ -380,6 +380,8 @@ def main():
         Lp = api.load_library()
         src16 = nbytes // 16 * 16
         shape_fan = max(1, min(64, int(out_bytes // src16)))
+        if shape_fan * src16 > out_bytes:           # a downscale writes less than it reads: the probe's shape is then a plain copy of a target's size
+            src16 = out_bytes // 16 * 16
         n_probe = min(ring, 24)
         def probe(i):
             k = i % n_probe
