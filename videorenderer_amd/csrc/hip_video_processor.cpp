@@ -476,8 +476,9 @@ HRESULT CHipVideoProcessor::UploadDoviParams()
     HRESULT hr;
     if ((hr = CheckHip(m_doviDev.CheckCreate(sizeof(DoviParams)), "dovi constants"))) return hr;
     if (!m_eotfLut.ptr) {           // the PQ EOTF table of the block convert's Dolby Vision variants: a constant of the transfer function
-        std::vector<float> lut(kEotfLutSize + 1);
+        std::vector<float> lut(kPqEncOffset + kPqEncSize + 1, 0.0f);      // the EOTF table, then (16-byte aligned) the PQ encode table of the level-2 variant
         BuildPqEotfLut(lut.data());
+        BuildPqEncodeLut(lut.data() + kPqEncOffset);
         if ((hr = CheckHip(m_eotfLut.CheckCreate(lut.size() * sizeof(float)), "pq eotf lut"))) return hr;
         if ((hr = CheckHip(hipMemcpy(m_eotfLut.ptr, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice), "pq eotf lut upload"))) return hr;
     }

@@ -66,11 +66,17 @@ __global__ __launch_bounds__(DV == DV_SDR_L2 ? 512 : 256) void k_convert_blocks(
     if (DV != DV_NONE) {
         if (DV == DV_SDR || DV == DV_SDR_L2)
             for (int i = threadIdx.x; i < EOTF_N + 2; i += NTH) TE[i] = P.eotf_lut[min(i, EOTF_N)];       // (one pad entry: t = N reads N, N + 1)
-        if (DV == DV_SDR_L2)
+        if (DV == DV_SDR_L2) {
             for (int i = threadIdx.x; i < LUT_N; i += NTH) {
                 const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
                 T[i] = f2{v, n - v};
             }
+            // the PQ encode table ({value, slope}) behind the tone-map table: convert_block finds it at T + LUT_N
+            for (int i = threadIdx.x; i < kPqEncSize; i += NTH) {
+                const float v = P.eotf_lut[kPqEncOffset + i], n = P.eotf_lut[kPqEncOffset + i + 1];
+                T[LUT_N + i] = f2{v, n - v};
+            }
+        }
         const DoviParams *dvp = P.dovi + (P.dovi_per_frame ? blockIdx.z : 0u);          // (one RPU per frame of the batch, or one for the launch)
         for (int i = threadIdx.x; i < (int)(sizeof(DoviParams) / 4); i += NTH) ((uint32_t *)DL)[i] = ((const uint32_t *)dvp)[i];
     } else if (tail_has_table(TAIL))
@@ -659,7 +665,7 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
     while (pairs > 2 && (long)strips * ((npairs + pairs - 1) / pairs) * n_frames < want_waves) pairs >>= 1;
     const int wg_waves = dvk == DV_SDR_L2 ? 8 : 4;         // (k_convert_blocks: NTH)
     const dim3 grid(strips, (npairs + wg_waves * pairs - 1) / (wg_waves * pairs), n_frames), block(64 * wg_waves, 1, 1);
-    const size_t lds = (fin ? 4096 : 0) + (dvk != DV_NONE ? LDS_E + LDS_V + (dvk == DV_SDR_L2 ? LDS_T : 0) : tail_has_table(tailk) ? LDS_T : 0);
+    const size_t lds = (fin ? 4096 : 0) + (dvk != DV_NONE ? LDS_E + LDS_V + (dvk == DV_SDR_L2 ? LDS_T + LDS_PE : 0) : tail_has_table(tailk) ? LDS_T : 0);
     if (dvk != DV_NONE) {       // Dolby Vision: 16-bit bi-planar (P010 / P016) or whatever the generic source variant reads
 #define MPCVR_CBD(SK, FN, DK) hipLaunchKernelGGL((k_convert_blocks<TAILK_ALU, SK, FN, DK>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab)
 #define MPCVR_CBD2(SK, FN) do { if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_convert_blocks<TAILK_ALU, SK, FN, DV_SDR_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

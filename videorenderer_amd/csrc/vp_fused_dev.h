@@ -94,6 +94,7 @@ enum { DV_NONE = 0, DV_SDR = 1, DV_GENERAL = 2, DV_SDR_L2 = 3 };
 constexpr int EOTF_N = kEotfLutSize;
 constexpr int LDS_E = (EOTF_N + 1 + 3) / 4 * 16;   // PQ EOTF table: EOTF_N + 1 values, adjacent pairs read with one ds_read2_b32
 constexpr int LDS_V = (sizeof(DoviParams) + 15) & ~15;
+constexpr int LDS_PE = kPqEncSize * 8;         // PQ encode table of DV_SDR_L2: {value, slope} pairs behind the tone-map table
 // source specialisation: GENERIC reads planes / bytes / siting at run time; P01X = bi-planar 16-bit (P010/P016), NV12 =
 // bi-planar 8-bit, PLANAR16 / PLANAR8 = three planes of 16- / 8-bit samples (YUV420P10/16, YV12 / I420: what software decoders
 // hand over), all with MPEG-2 or co-sited chroma (not horizontally centred)
@@ -821,9 +822,19 @@ __device__ __forceinline__ void convert_block_yuv(const FusedArgs &P, const f2 (
                     float c3[3];
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
+#ifndef MPCVR_DV_PQENC_ALU      // (experiment builds: the literal chain — two pow() and a division — instead of the table)
+                        // saturate(LinearToST2084(x, 1)) from the table over log2 x (vp_params.h kPqEncSize): x >= 1 reads the last entry's end (1.0),
+                        // x = 0 (log2 = -inf) the first entry
+                        const float u = __builtin_amdgcn_fmed3f(__builtin_fmaf(__builtin_amdgcn_logf(lms[ch][e]), (float)kPqEncSize / (float)kPqEncLog2Range, (float)kPqEncSize),
+                                                                0.0f, (float)kPqEncSize - 0.001f);
+                        const f2 pe = (T + LUT_N)[(int)u];
+                        const float pq = __builtin_fmaf(pe.y, __builtin_amdgcn_fractf(u), pe.x);
+                        c3[ch] = hlsl_pow(pq * k5[2] + k5[3], k5[4]);
+#else
                         const float z = hlsl_pow(lms[ch][e], MPCVR_ST2084_m1);
                         const float q = (MPCVR_ST2084_c1 + MPCVR_ST2084_c2 * z) * __builtin_amdgcn_rcpf(1.0f + MPCVR_ST2084_c3 * z);
                         c3[ch] = hlsl_pow(saturate(hlsl_pow(q, MPCVR_ST2084_m2)) * k5[2] + k5[3], k5[4]);
+#endif
                     }
                     const float ky = (1.0f + k5[0]) * __builtin_amdgcn_rcpf(0.2627f * c3[0] + 0.6780f * c3[1] + 0.0593f * c3[2]);
                     const float v3[3] = {c3[0] * hlsl_pow(ky * c3[0], k5[1]), c3[1] * hlsl_pow(ky * c3[1], k5[1]), c3[2] * hlsl_pow(ky * c3[2], k5[1])};

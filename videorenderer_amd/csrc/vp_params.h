@@ -12,6 +12,13 @@ constexpr int kPqLutSize = 4096;
 // intervals in the 32 KiB the {value, slope} table of 4096 took: interpolation error 1.2e-6 instead of 5e-6 — round 4 found the coarser
 // table (built through an fp32 pow chain on top) behind three quarters of the channels beyond 1 LSB on Dolby Vision frames
 constexpr int kEotfLutSize = 8192;          // intervals; the table holds kEotfLutSize + 1 values
+// PQ ENCODE table of the Dolby Vision level-2 variant (round 5): LinearToST2084(x, 1) over t = log2 x in [-kPqEncLog2Range, 0], kPqEncSize intervals
+// (the function is an S-curve of slope <= 0.06 per stop there: linear interpolation is good to 3e-6).  Replaces two pow() and a division per
+// channel in front of the trims — 15 of the 40 transcendentals a pixel of that variant costs.  It rides behind the EOTF table in the same
+// device buffer (kPqEncOffset floats in) and behind the tone-map table in LDS.
+constexpr int kPqEncSize = 1024;            // intervals; kPqEncSize + 1 values
+constexpr int kPqEncLog2Range = 48;
+constexpr int kPqEncOffset = (kEotfLutSize + 1 + 3) & ~3;
 
 // surface formats of the intermediate / output textures
 // (m_InternalTexFmt — DX11VideoProcessor.cpp:1143-1155; m_TexResize is always fp16 — :3155)

@@ -365,6 +365,18 @@ void BuildPqEotfLut(float out[kEotfLutSize + 1])
     }
 }
 
+void BuildPqEncodeLut(float out[kPqEncSize + 1])
+{
+    // LinearToST2084(2^t, 1) (st2084.hlsl:18-25) at t = -R + R i / N, in double, rounded once
+    const double m1 = 2610.0 / (4096.0 * 4.0), m2 = (2523.0 / 4096.0) * 128.0;
+    const double c1 = 3424.0 / 4096.0, c2 = (2413.0 / 4096.0) * 32.0, c3 = (2392.0 / 4096.0) * 32.0;
+    for (int i = 0; i <= kPqEncSize; i++) {
+        const double t = -(double)kPqEncLog2Range + (double)kPqEncLog2Range * (double)i / (double)kPqEncSize;
+        const double z = std::pow(std::exp2(t), m1);
+        out[i] = (float)std::pow((c1 + c2 * z) / (1.0 + c3 * z), m2);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // resize weights
 // ------------------------------------------------------------------------------------------------

@@ -84,6 +84,7 @@ void BuildPqSdrLut(float lum_scale, float out[kPqLutSize]);
 void BuildHlgInverseLut(float out[kPqLutSize]);        // per-channel inverse_HLG for the fused kernels' HLG -> SDR tail
 // log2 ST2084ToLinear((i / (kPqLutSize - 1))^2, 1) (st2084.hlsl:9-16): the PQ EOTF table of the Dolby Vision block convert, sampled uniformly in sqrt(x)
 void BuildPqEotfLut(float out[kEotfLutSize + 1]);
+void BuildPqEncodeLut(float out[kPqEncSize + 1]);      // vp_params.h kPqEncSize: the Dolby Vision level-2 variant's PQ encode over log2 x
 // ps_final_pass.hlsl:29 in integers (fused kernel): floor(k*quant/maxv + j/1024) == (k*M + (j << 14)) >> 24 for all
 // k in [0,maxv], j in [0,1023] with M = ceil(quant * 2^24 / maxv).  Returns M, or 0 when the 32-bit evaluation could
 // overflow / M does not fit 24 bits (then the kernel keeps the float epilogue).
