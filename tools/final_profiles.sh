@@ -9,20 +9,19 @@
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 O=gpurun_out; mkdir -p $O
-for w in c3hdr c1 hdr4k up1440 down1440 up2160 c5; do bash tools/pmc_traffic.sh $w > /dev/null 2>&1; done
+for w in c3hdr c1 hdr4k up1440 down1440 up2160 c5 c4ed jinc1080 dovi4k; do bash tools/pmc_traffic.sh $w > /dev/null 2>&1; done
 KFILTER=k_fused_up2x bash tools/prof_headline.sh headline_final > /dev/null 2>&1
-KFILTER=k_convert_stream bash tools/prof_headline.sh stream_c1_final --workload c1 > /dev/null 2>&1
-KFILTER=k_convert_stream bash tools/prof_headline.sh stream_hdr4k_final --workload hdr4k > /dev/null 2>&1
 KFILTER=k_fused_period bash tools/prof_headline.sh period_up1440_final --workload up1440 > /dev/null 2>&1
-KFILTER=k_fused_period bash tools/prof_headline.sh period_down1440_final --workload down1440 > /dev/null 2>&1
 KFILTER=k_error_diffusion bash tools/prof_headline.sh errdiff_c4ed_final --workload c4ed > /dev/null 2>&1
+KFILTER=k_jinc2_quad bash tools/prof_headline.sh jinc1080_final --workload jinc1080 > /dev/null 2>&1
+KFILTER=k_convert_blocks bash tools/prof_headline.sh dovi4k_final --workload dovi4k > /dev/null 2>&1
 # which kernel instantiations the GPU suite launches (tests/test_kernel_coverage.py reads the stats table) + the parity log
 rm -f /tmp/test_times.jsonl
 ( cd /tmp; cd "$GRAFT_REPO_ROOT"; MPCVR_TEST_TIMES=/tmp/test_times.jsonl MPCVR_PARITY_LOG=$GRAFT_REPO_ROOT/$O/parity_identical_channels.jsonl timeout -k 5 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/suite_kt -o suite -- python -m pytest tests -m gpu -q > $O/suite_under_kernel_trace.txt 2>&1 )
 f=$(find /tmp/suite_kt -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $O/gpu_suite_kernel_stats.csv
 t=$(find /tmp/suite_kt -name "*kernel_trace.csv" 2>/dev/null | head -1); [ -n "$t" ] && python tests/tools/kernel_witnesses.py "$t" /tmp/test_times.jsonl $O/kernels_by_test.json   # which test launched which instantiation
 grep -E "passed|failed" $O/suite_under_kernel_trace.txt | grep -v rocprofv3 | tail -2
-for wl in c3hdr c3 c4 c4ext c4ed c5 c2 c1 hdr4k up1440 down1440 up1080 down1080 up2160 up1440_nv12 hdrpass_2x hdrpass_1440 c3hdr_1080p; do
+for wl in c3hdr c3 c4 c4ext c4ed c5 c2 c1 hdr4k up1440 down1440 up1080 down1080 up2160 up1440_nv12 hdrpass_2x hdrpass_1440 c3hdr_1080p jinc1080 dovi4k; do
   python bench.py --workload $wl --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -n 1
 done > $O/bench_workloads.jsonl
 python tools/bench_general.py 2>/dev/null | grep "^{" > $O/bench_general.jsonl
@@ -31,5 +30,5 @@ python bench.py --steps 20 --warmup 5 > $O/bench_driver_shape.json 2> $O/bench_d
 # gpurun merges at most 64 MiB back: keep the tables anyone reads (summaries, stats, traffic, bench lines), drop the raw traces
 K=/tmp/keep_final; rm -rf $K; mkdir -p $K
 cp $O/*_summary.txt $O/traffic_*.json $O/bench_*.json* $O/suite_under_kernel_trace.txt $O/gpu_suite_kernel_stats.csv $O/kernels_by_test.json $O/parity_identical_channels.jsonl $K/ 2>/dev/null
-for d in headline_final stream_c1_final stream_hdr4k_final period_up1440_final period_down1440_final errdiff_c4ed_final; do f=$(find $O/$d/kt -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $K/${d}_kernel_stats.csv; done
+for d in headline_final stream_c1_final stream_hdr4k_final period_up1440_final period_down1440_final errdiff_c4ed_final jinc1080_final dovi4k_final; do f=$(find $O/$d/kt -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $K/${d}_kernel_stats.csv; done
 rm -rf $O/*; cp $K/* $O/; du -sh $O; ls $O

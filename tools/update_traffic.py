@@ -16,9 +16,11 @@ KERNEL_SOURCES = {
     "up1440": ["vp_fused_period.h", "vp_fused_period.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
     "down1440": ["vp_fused_period.h", "vp_fused_period.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
     "up2160": ["vp_fused_period.h", "vp_fused_period.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
+    "jinc1080": ["vp_jinc.hip", "vp_fused.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
+    "dovi4k": ["vp_fused.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
     "c4ed": ["vp_errdiff.hip", "vp_errdiff_core.h", "vp_fused_up2x.h", "vp_fused.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
 }
-ALGO = {"c3": 157593600, "c5": 157593600, "c3hdr": 157593600, "c1": 11404800, "hdr4k": 58060800, "up1440": 20966400, "down1440": 39628800, "up2160": 35942400, "c4ed": 157593600}
+ALGO = {"c3": 157593600, "c5": 157593600, "c3hdr": 157593600, "c1": 11404800, "hdr4k": 58060800, "up1440": 20966400, "down1440": 39628800, "up2160": 35942400, "c4ed": 157593600, "jinc1080": 39398400, "dovi4k": 58060800}
 
 w, batch, tag = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 m = json.loads([l for l in open(os.path.join(ROOT, "gpurun_out", f"traffic_{w}.json")) if l.startswith("{")][-1])
