@@ -72,7 +72,11 @@ enum { MPCVR_DOWNSCALE_Box = 0, MPCVR_DOWNSCALE_Bilinear = 1, MPCVR_DOWNSCALE_Ha
  * frame is rendered as for a 10-bit swap chain (R10G10B10A2: no final pass behind the 10-bit internal format; behind the fp16 internal
  * format that chain's own final pass — the ordered dither from fp16 to 10 bits, as the reference runs it there — stays in front of the
  * pass) and Floyd-Steinberg error diffusion in integers takes it to B8G8R8A8 inside video rect ∩ window (definition: csrc/vp_errdiff_core.h; the serial model in oracle/ is its only check).  On a
- * 10-bit target or with the 8-bit internal format it changes nothing, like bUseDither = 1 there. */
+ * 10-bit target or with the 8-bit internal format it changes nothing, like bUseDither = 1 there.
+ * The pass is a chain of bands that wait for each other through device memory; its forward progress does not depend on the order in which
+ * the hardware starts workgroups (bands are taken by ticket).  Should a band ever give up waiting (a bounded number of polls), the frame is
+ * wrong and the pass flags it: mpcvr_synchronize, mpcvr_get_current_image and the next error-diffusion pass answer MPCVR_E_FAIL — a caller
+ * that synchronises its OWN stream instead must call mpcvr_synchronize before it trusts such a frame. */
 enum { MPCVR_DITHER_None = 0, MPCVR_DITHER_Ordered = 1, MPCVR_DITHER_ErrorDiffusion_EXT = 2 };
 
 /* Render-target format: stands in for the display-driven m_SwapChainFmt decision

@@ -319,13 +319,17 @@ def _sweep_cases():
     epis = (("dither8", dict(iTexFormat=10, output_format=0, bUseDither=1)), ("direct", dict(iTexFormat=0, bUseDither=0)),
             ("generic", dict(iTexFormat=10, output_format=0, bUseDither=1, offset=(3, 1))),
             # a video rectangle the window clips on every side: the per-pixel store_epilogue variant of every loader x tail x tap count
-            ("clipped", dict(iTexFormat=10, output_format=0, bUseDither=1, clip=1)))
+            ("clipped", dict(iTexFormat=10, output_format=0, bUseDither=1, clip=1)),
+            # ... and behind an 8-bit internal format: the exact-form twins of the 8-bit and the run-time loader with that epilogue
+            ("clipped8", dict(iTexFormat=0, bUseDither=0, clip=1)))
     for cf, fname in fmts:
         for tail in tails:
             if cf in (30, 32) and tail != "SDR":
                 continue
             for gname, g in strip_geos:
                 for ename, e in epis:
+                    if ename == "clipped8" and not (cf in (1, 14, 4) and tail == "SDR"):
+                        continue
                     for tier in ("DEFAULT", "FLAG_NO_LUT"):
                         if tier == "FLAG_NO_LUT" and tail in ("SDR", "BT2020SDR"):
                             continue
@@ -493,6 +497,19 @@ def test_fused_kernel_both_tap_engines_vs_oracle(mpcvr, oracle, torch_cuda, name
         compare_rgb10(got, want, f"{name} [{info}/{engine}]", tail=has_tail(c), internal8=internal_is_8bit(c))
     else:
         compare(got, want, f"{name} [{info}/{engine}]", min_same=0.99)
+
+
+@pytest.mark.parametrize("taps", [4, 5])
+def test_matrix_core_kernel_tail_less_generic_epilogue(mpcvr, torch_cuda, taps):
+    """k_fused_up2x_mx<taps, no tail, P01x / run-time loader, generic epilogue>: a 10-bit target without a final pass.  (Frames with an
+    8-bit internal format — what used to witness these instantiations — are not this kernel's since round 5: the exact form of the convert
+    stage lives in the packed-fp32 kernels, and MPCVR_FLAG_FUSED_MFMA falls back to them there.)"""
+    from videorenderer_amd import api
+    for i, cf in enumerate((2, 20)):
+        c = _sweep_case(cf, dict(output_format=1), "none", taps, (64, 40), (128, 80), 560 + i + taps)
+        _tiers_agree(mpcvr, torch_cuda, c, api.FLAG_FUSED_MFMA, "fused_up2x")
+    c = _sweep_case(1, {}, "none", taps, (64, 40), (128, 80), 570 + taps)          # NV12, 8-bit internal format: drawn all the same, by the other kernel
+    _tiers_agree(mpcvr, torch_cuda, c, api.FLAG_FUSED_MFMA, "fused_up2x")
 
 
 def test_mfma_operand_layout_probe():
@@ -1325,6 +1342,18 @@ _SWEEP_UP2X_SRC = {
     "planar16_dither8": (20, {}), "planar8_direct8": (14, {}),
     "generic_dither8": (8, {}), "generic_generic": (8, dict(misalign=1)),          # Y210: packed 4:2:2 reads its layout at run time
 }
+# The exact-form twins (round 5: kernels that can meet an 8-bit internal format in front of a resize exist twice — k_*<..., XC_ALWAYS> where
+# FusedArgs::exact_cv asks for the convert stage that rounds like the reference's, <..., XC_NEVER> otherwise; tail-less only).  The pairs
+# above run the 8-bit loaders in their exact form (AUTO = an 8-bit internal format) and the run-time loader in the fast one (Y210: 10 bits);
+# these are the other halves: the 8-bit loaders behind a forced 10-bit internal format and a 10-bit target (no final pass: the straight and
+# the generic store), the run-time loader behind an 8-bit one (YUY2).
+_SWEEP_UP2X_TWINS = {
+    "nv12_direct10_fast": (1, dict(iTexFormat=10, output_format=1)), "nv12_generic10_fast": (1, dict(iTexFormat=10, output_format=1, misalign=1)),
+    "planar8_direct10_fast": (14, dict(iTexFormat=10, output_format=1)), "generic_generic8_exact": (4, dict(misalign=1)),
+}
+_SWEEP_PERIOD_TWINS = {"nv12_direct10_fast": (1, dict(iTexFormat=10, output_format=1)), "generic_direct10_fast": (14, dict(iTexFormat=10, output_format=1))}
+_SWEEP_STRIP_TWINS = dict(_SWEEP_UP2X_TWINS, planar8_generic10_fast=(14, dict(iTexFormat=10, output_format=1, misalign=1)),
+                          generic_direct10_fast=(8, dict(output_format=1)), generic_direct8_exact=(4, {}))
 _SWEEP_PERIOD_SRC = {"p01x_dither8": (2, {}), "p01x_direct10": (2, dict(output_format=1, hdr_output_if_tail=1)), "nv12_direct8": (1, {}),
                      "generic_dither8": (20, {}), "generic_direct8": (14, {})}
 _SWEEP_PERIOD_GEO = {"4:3": ((48, 30), (64, 40)), "3:2": ((48, 32), (72, 48)), "2:3": ((96, 48), (64, 32)), "1:2": ((96, 48), (48, 24)), "3:1": ((32, 16), (96, 48))}
@@ -1337,6 +1366,8 @@ def _sweep_case(cformat, over, tail, taps, src_wh, dst_wh, seed):
     c["flags"] = c.get("flags", 0) | tflags
     if over.get("output_format"):
         c["output_format"] = 1          # R10G10B10A2 target, no final pass: the straight 10-bit store
+    if over.get("iTexFormat"):
+        c["iTexFormat"] = over["iTexFormat"]
     if over.get("misalign"):            # a window column that is not a multiple of 4: the generic epilogue
         c["window"] = (dst_wh[0] + 8, dst_wh[1] + 4); c["offset"] = (2, 1)
     return c
@@ -1365,7 +1396,7 @@ def _tiers_agree(mpcvr, torch, c, fast_flags, expect):
 def test_sweep_every_fused_up2x_instantiation(mpcvr, torch_cuda, tail, taps):
     """k_fused_up2x<taps, tail, source, epilogue>: all nine (source, epilogue) pairs the launcher instantiates, per tap count and tail
     kind, on small frames against the plain kernels of the same frame."""
-    for i, (name, (cf, over)) in enumerate(sorted(_SWEEP_UP2X_SRC.items())):
+    for i, (name, (cf, over)) in enumerate(sorted(_SWEEP_UP2X_SRC.items()) + (sorted(_SWEEP_UP2X_TWINS.items()) if tail == "none" else [])):
         c = _sweep_case(cf, over, tail, taps, (64, 40), (128, 80), 500 + 17 * i + taps)
         _tiers_agree(mpcvr, torch_cuda, c, 0, "fused_up2x")
 
@@ -1378,7 +1409,7 @@ def test_sweep_every_fused_period_instantiation(mpcvr, torch_cuda, ratio, tail, 
     (MPCVR_FLAG_FORCE_PERIOD: the planner's own choice for SDR content with 4 taps is k_fused_strip)."""
     from videorenderer_amd import api
     src_wh, dst_wh = _SWEEP_PERIOD_GEO[ratio]
-    for i, (name, (cf, over)) in enumerate(sorted(_SWEEP_PERIOD_SRC.items())):
+    for i, (name, (cf, over)) in enumerate(sorted(_SWEEP_PERIOD_SRC.items()) + (sorted(_SWEEP_PERIOD_TWINS.items()) if tail == "none" else [])):
         c = _sweep_case(cf, over, tail, taps, src_wh, dst_wh, 700 + 13 * i + taps)
         # (six taps — the as-intended Lanczos3 of MPCVR_FLAG_LANCZOS3_FIXED, Spline36 — have no periodic variant since round 5: the strip kernel draws them)
         _tiers_agree(mpcvr, torch_cuda, c, api.FLAG_FORCE_PERIOD, ("kernel=fused_period(rows=" + ratio) if taps != 6 else "kernel=fused_strip(")
@@ -1402,14 +1433,35 @@ def test_sweep_fused_strip_instantiations(mpcvr, torch_cuda, tail, taps):
     with every epilogue it can meet (integer final pass, straight 8- / 10-bit store, the generic store behind a misaligned window
     column), per tap count and tail kind, against the plain kernels of the same frame."""
     src_wh, dst_wh, scaler = _SWEEP_STRIP_GEO[taps]
-    for i, (name, (cf, over)) in enumerate(sorted(_SWEEP_STRIP_SRC.items())):
+    for i, (name, (cf, over)) in enumerate(sorted(_SWEEP_STRIP_SRC.items()) + (sorted(_SWEEP_STRIP_TWINS.items()) if tail == "none" else [])):
         ex, tflags = _SWEEP_TAILS[tail]
         c = dict(cformat=cf, w=src_wh[0], h=src_wh[1], kind="noise", seed=900 + 11 * i + taps, dst=dst_wh, exfmt=ex, flags=tflags, **scaler)
         if over.get("output_format"):
             c["output_format"] = 1
+        if over.get("iTexFormat"):
+            c["iTexFormat"] = over["iTexFormat"]
         if over.get("misalign"):
             c["window"] = (dst_wh[0] + 8, dst_wh[1] + 4); c["offset"] = (3, 1)
         _tiers_agree(mpcvr, torch_cuda, c, 0, "kernel=fused_strip(")
+
+
+@pytest.mark.parametrize("label,cf,over", [
+    ("nv12_bilinear", 1, dict(w=66)), ("nv12_catmull", 1, dict(w=66, iChromaScaling=2)),
+    ("yv12_bilinear", 14, dict(w=72)), ("yv12_catmull", 14, dict(w=72, iChromaScaling=2)),
+    ("nv12_centred_bilinear", 1, dict(w=66, chroma_loc=1)), ("nv12_centred_catmull", 1, dict(w=66, chroma_loc=1, iChromaScaling=2)),
+    ("p010_tex8_catmull", 2, dict(w=66, iTexFormat=8, iChromaScaling=2)),
+])
+def test_sweep_exact_twins_of_the_block_convert_kernel(mpcvr, torch_cuda, label, cf, over):
+    """k_convert_blocks<TAILK_NONE, source, no final pass, no DV, chroma filter, XC_ALWAYS>: a convert draw of its own into an 8-bit internal
+    format with a resize behind it — Catmull-Rom chroma (no fused kernel takes it), or the fused kernels switched off — for the NV12, the
+    three-plane and the run-time loader (centred chroma; 16-bit samples behind a forced 8-bit format).  (The XC_NEVER halves are the
+    same-size cases of the kernel-family sweep: blocks_*_final0.)"""
+    from videorenderer_amd import api
+    c = dict(cformat=cf, h=48, kind="noise", seed=970 + len(label), dst=(100, 62), iUpscaling=2, exfmt=_SDR, **over)
+    if "chroma_loc" in c:           # (the chroma siting field of DXVA2_ExtendedFormat: bits 8..11)
+        c["exfmt"] = (c["exfmt"] & ~(0xf << 8)) | (c.pop("chroma_loc") << 8)
+    for fast_flags in (0, api.FLAG_NO_STRIP):
+        _tiers_agree(mpcvr, torch_cuda, c, fast_flags, "")
 
 
 @pytest.mark.parametrize("tail", sorted(_SWEEP_TAILS))

@@ -47,9 +47,9 @@ namespace {
 // DV != DV_NONE: the Dolby Vision variant (TAIL is then TAILK_ALU: the tone-map table is not used) — LDS holds the PQ EOTF table
 // and a copy of the frame's DoviParams instead.
 // CHR = 1: CHROMA_CatmullRom instead of CHROMA_Bilinear (4 x 5 chroma texels per block, convert_block_cr).
-template <int TAIL, int SRC, bool FINAL, int DV = DV_NONE, int CHR = 0>
-__global__ __launch_bounds__(DV == DV_SDR_L2 ? 512 : 256) void k_convert_blocks(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single, int pairs,
-                                                       uint8_t *batch_dst, size_t batch_stride, FrameTable32 tab)
+template <int TAIL, int SRC, bool FINAL, int DV, int CHR, int XC>
+__device__ __forceinline__ void convert_blocks_body(const FusedArgs &P, const FusedFrame *__restrict__ frames, const FusedFrame &single, int pairs,
+                                                    uint8_t *batch_dst, size_t batch_stride, const FrameTable32 &tab)
 {
     // waves per workgroup: the tables are per workgroup, so the variant with two of them (67 KiB) shares them among 8 waves —
     // two workgroups per CU are then 4 waves per SIMD instead of 2
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(DV == DV_SDR_L2 ? 512 : 256) void k_convert_blocks(
         const int a = 2 * (pair0 + p) - 1;                             // rows a, a+1
         if (a >= H) break;
         f2 rc[2][3];
-        if (CHR) convert_block_cr<TAIL, SRC, DV>(P, MM, GG, CC, rawc, P.rect_t + clampi(a, 0, H - 1), P.rect_t + clampi(a + 1, 0, H - 1), T, rc, DL, TE, &DRG);
-        else convert_block<TAIL, SRC, DV>(P, MM, GG, CC, raw, P.rect_t + clampi(a, 0, H - 1), P.rect_t + clampi(a + 1, 0, H - 1), T, rc, DL, TE, &DRG);
+        if (CHR) convert_block_cr<TAIL, SRC, DV, XC>(P, MM, GG, CC, rawc, P.rect_t + clampi(a, 0, H - 1), P.rect_t + clampi(a + 1, 0, H - 1), T, rc, DL, TE, &DRG);
+        else convert_block<TAIL, SRC, DV, XC>(P, MM, GG, CC, raw, P.rect_t + clampi(a, 0, H - 1), P.rect_t + clampi(a + 1, 0, H - 1), T, rc, DL, TE, &DRG);
         if (p + 1 < pairs && a + 2 < H) {
             if (CHR) load_raw_cr<SRC>(P, py, rac, clampi(a + 2, 0, H - 1), clampi(a + 3, 0, H - 1), rawc);
             else load_raw<SRC>(P, py, ra, clampi(a + 2, 0, H - 1), clampi(a + 3, 0, H - 1), raw);
@@ -173,6 +173,21 @@ __global__ __launch_bounds__(DV == DV_SDR_L2 ? 512 : 256) void k_convert_blocks(
             *(__attribute__((address_space(1))) u32x2 *)(rowp + opaque(lane_off)) = u32x2{px[0], px[1]};
         }
     }
+}
+
+template <int TAIL, int SRC, bool FINAL, int DV = DV_NONE, int CHR = 0, int XC = XC_NEVER>
+__global__ __launch_bounds__(DV == DV_SDR_L2 ? 512 : 256) void k_convert_blocks(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single, int pairs,
+                                                       uint8_t *batch_dst, size_t batch_stride, FrameTable32 tab)
+{
+    convert_blocks_body<TAIL, SRC, FINAL, DV, CHR, XC>(P, frames, single, pairs, batch_dst, batch_stride, tab);
+}
+// the kernel of an instantiation: its exact-form twin where one exists and the launch asks for it (exact_capable, vp_fused_dev.h;
+// FINAL = the 10 -> 8 final pass behind it: a 10-bit internal format, the fast form)
+template <int TAIL, int SRC, bool FINAL, int CHR>
+inline auto convert_blocks_kernel(bool exact) -> decltype(&k_convert_blocks<TAIL, SRC, FINAL, DV_NONE, CHR, XC_NEVER>)
+{
+    if constexpr (exact_capable<TAIL, SRC, FINAL>() == XC_RUNTIME) { if (exact) return k_convert_blocks<TAIL, SRC, FINAL, DV_NONE, CHR, XC_ALWAYS>; }
+    return k_convert_blocks<TAIL, SRC, FINAL, DV_NONE, CHR, XC_NEVER>;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -525,6 +540,9 @@ int FusedSourceKind(const FusedParams &P)
     // 8-bit samples behind a PQ / HLG / BT.2020 tail (streams that hardly exist) read through the run-time variant as well: the
     // (8-bit loader, tail) products of every fused family are not built
     if (c.fmt.bytes == 1 && c.tail != TAIL_NONE) return SRC_GENERIC;
+    // 16-bit samples behind a forced 8-bit internal format (TEXFMT_8INT on a P010 / YUV420P10 stream: hardly ever): the exact form of the convert
+    // stage lives in the 8-bit loaders and in the run-time variant only (exact_capable, vp_fused_dev.h) — the 16-bit loaders keep their registers
+    if (c.fmt.bytes == 2 && c.out_fmt == SF_BGRA8 && c.tail == TAIL_NONE && !c.dovi) return SRC_GENERIC;
     const bool biplanar_fast = c.fmt.planes == 2 && !centred, planar_fast = c.fmt.planes == 3 && !centred;
     return (biplanar_fast && c.fmt.bytes == 2) ? SRC_P01X : (biplanar_fast && c.fmt.bytes == 1) ? SRC_NV12
          : (planar_fast && c.fmt.bytes == 2) ? SRC_PLANAR16 : (planar_fast && c.fmt.bytes == 1) ? SRC_PLANAR8 : SRC_GENERIC;
@@ -607,7 +625,9 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
     // the streaming kernel (k_convert_stream): bi-planar 4:2:0 / 4:2:2 samples whose rows take the lane's 4- / 8-byte loads and 16-byte stores
     static const int no_stream = EnvInt("MPCVR_NO_STREAM_CONVERT", 0);
     const int lbs = srck == SRC_P01X ? 8 : 4;
-    const bool stream = !no_stream && !catmull && dvk == DV_NONE && (srck == SRC_P01X || srck == SRC_NV12) && c.out_w >= 8 && (c.out_w & 3) == 0 && (c.rect_l & 3) == 0 &&
+    // (the exact form of the convert stage — an 8-bit texture in front of an UNFUSED resize — is k_convert_blocks' alone: the streaming kernel is
+    // C1's, and the second form behind a branch cost it 8 registers and 15 % with the branch never taken)
+    const bool stream = !no_stream && !catmull && dvk == DV_NONE && !a.exact_cv && (srck == SRC_P01X || srck == SRC_NV12) && c.out_w >= 8 && (c.out_w & 3) == 0 && (c.rect_l & 3) == 0 &&
                         (c.pitch[0] % lbs) == 0 && (c.pitch[1] % lbs) == 0 && (P.plane_off[1] % lbs) == 0 && P.dst_aligned16 && (P.store.off_x & 3) == 0 &&
                         (P.store.dst_pitch & 15) == 0 && P.src_aligned16 && (frames_dev || frames_host || n_frames == 1);
     if (!stream && !frames_dev && n_frames != 1 && !tab.n) return hipErrorInvalidValue;     // (a host table of more than 32 frames serves the streaming kernel only)
@@ -676,8 +696,8 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
 #undef MPCVR_CBD
         return hipGetLastError();
     }
-#define MPCVR_CB3(TK, SK, FN) do { if (catmull) hipLaunchKernelGGL((k_convert_blocks<TK, SK, FN, DV_NONE, 1>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab); \
-                                   else hipLaunchKernelGGL((k_convert_blocks<TK, SK, FN>), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab); } while (0)
+#define MPCVR_CB3(TK, SK, FN) do { if (catmull) hipLaunchKernelGGL((convert_blocks_kernel<TK, SK, FN, 1>(a.exact_cv != 0)), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab); \
+                                   else hipLaunchKernelGGL((convert_blocks_kernel<TK, SK, FN, 0>(a.exact_cv != 0)), grid, block, lds, s, a, frames_dev, single, pairs, batch_dst, batch_stride, tab); } while (0)
 #define MPCVR_CB2(TK, SK) do { if (fin) MPCVR_CB3(TK, SK, true); else MPCVR_CB3(TK, SK, false); } while (0)
 #define MPCVR_CB(TK) do { if (srck == SRC_P01X) MPCVR_CB2(TK, SRC_P01X); else if (srck == SRC_PLANAR16) MPCVR_CB2(TK, SRC_PLANAR16); else MPCVR_CB2(TK, SRC_GENERIC); } while (0)
     if (tailk == TAILK_NONE) {          // (the 8-bit loaders exist without a tail only: FusedSourceKind)

@@ -100,6 +100,21 @@ constexpr int LDS_PE = kPqEncSize * 8;         // PQ encode table of DV_SDR_L2: 
 // hand over), all with MPEG-2 or co-sited chroma (not horizontally centred)
 enum { SRC_GENERIC = 0, SRC_P01X = 1, SRC_NV12 = 2, SRC_PLANAR16 = 3, SRC_PLANAR8 = 4,
        SRC_SURFACE = 5 };      // k_fused_strip only: no convert stage, the source is a B8G8R8A8 / R10G10B10A2 / fp16 surface
+// The exact form of the convert stage (convert_block_exact, asked for by FusedArgs::exact_cv) is a compile-time property of a KERNEL, its
+// last template argument: XC_NEVER = the fast form, XC_ALWAYS = the exact one.  An instantiation that can meet an 8-bit internal format in
+// front of a resize (exact_capable() == XC_RUNTIME: no tail, no Dolby Vision, no 10 -> 8 final pass behind it, an 8-bit loader or the
+// run-time one — FusedSourceKind sends 16-bit samples behind a forced 8-bit format there) is built TWICE and the launcher picks by
+// exact_cv (fused_*_kernel()); every other one exists in the fast form alone.  How it got there (round 5, 1080p NV12 -> 1440p, frames/s):
+//   123 k  round 4, the fast form alone (a class of frames two codes off the reference behind negative-lobe filters);
+//    90 k  a wave-uniform branch on exact_cv inside convert_block of EVERY tail-less instantiation: 70 -> 81 VGPRs in the strip kernels,
+//          61 -> 69 in the streaming convert — C1 lost 15 %, HDR passthrough 22 %, with the branch never taken there;
+//    90 k  the branch in the capable instantiations only (the others back to their registers and speed): still 81 - 85 VGPRs;
+//    88 k  two bodies behind one branch at the top of the kernel: 76 VGPRs but 72 spilled SGPRs (the arguments of both bodies are loaded in
+//          the entry block);
+//   106 k  two kernels.
+enum { XC_NEVER = 0, XC_RUNTIME = 1, XC_ALWAYS = 2 };
+template <int TAIL, int SRC, bool FINAL10>
+__host__ __device__ constexpr int exact_capable() { return (TAIL == 0 /* TAILK_NONE */ && !FINAL10 && (SRC == 0 /* GENERIC */ || SRC == 2 /* NV12 */ || SRC == 4 /* PLANAR8 */)) ? XC_RUNTIME : XC_NEVER; }
 // epilogue specialisation: DITHER8 = B8G8R8A8 target behind a final pass (integer form); DIRECT8 = B8G8R8A8 or R10G10B10A2 target written
 // straight from the Y pass (no post-scale step: 8-bit sources, HDR passthrough to a 10-bit swap chain); both require 16-byte aligned rows and off_x % 4 == 0
 enum { EPI_GENERIC = 0, EPI_DITHER8 = 1, EPI_DIRECT8 = 2 };
@@ -670,13 +685,11 @@ template <int TAIL, int SRC, int DV>
 __device__ __forceinline__ void convert_block_yuv(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], f2 (&Ycol)[2], f2 (&Ucol)[2], f2 (&Vcol)[2],
                                                   const f2 *T, f2 out[2][3], const DoviParams *DL, const float *TE, const DoviRegs *DR);
 
-template <int TAIL, int SRC, int DV = DV_NONE>
+template <int TAIL, int SRC, int DV = DV_NONE, int XC = XC_NEVER>
 __device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], const Raw &r, int sy0, int sy1, const f2 *T, f2 out[2][3],
                                               const DoviParams *DL = nullptr, const float *TE = nullptr, const DoviRegs *DR = nullptr)
 {
-    if constexpr (TAIL == TAILK_NONE && DV == DV_NONE) {
-        if (P.exact_cv) { convert_block_exact<SRC>(P, r, sy0, sy1, out); return; }        // wave-uniform (a kernel argument)
-    }
+    if constexpr (XC == XC_ALWAYS) { convert_block_exact<SRC>(P, r, sy0, sy1, out); return; }
     // vertical weights of chroma rows n (w0) and n+1 (w1) for (row 0, row 1): wave-uniform, one SGPR pair each
     const int n4 = chroma_v4(P, sy0) & ~3;                 // 4 * floor(v'(row 0))
     const int fr0 = chroma_v4(P, sy0) - n4, fr1 = chroma_v4(P, sy1) - n4;     // 0..4 quarters
@@ -1027,13 +1040,11 @@ __device__ __forceinline__ void convert_block_cr_exact(const FusedArgs &P, const
     exact_matrix_store(P, Y, U, V, out);
 }
 #pragma clang fp contract(fast)
-template <int TAIL, int SRC, int DV = DV_NONE>
+template <int TAIL, int SRC, int DV = DV_NONE, int XC = XC_NEVER>
 __device__ __forceinline__ void convert_block_cr(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], const RawCR &r, int sy0, int sy1, const f2 *T, f2 out[2][3],
                                                  const DoviParams *DL = nullptr, const float *TE = nullptr, const DoviRegs *DR = nullptr)
 {
-    if constexpr (TAIL == TAILK_NONE && DV == DV_NONE) {
-        if (P.exact_cv) { convert_block_cr_exact<SRC>(P, r, sy0, sy1, out); return; }
-    }
+    if constexpr (XC == XC_ALWAYS) { convert_block_cr_exact<SRC>(P, r, sy0, sy1, out); return; }
     // horizontal pass: Q[row j][column parity] = sum_i wx[parity][i] * texel[j][i], as (U, V) pairs
     f2 Q[5][2];
 #pragma unroll

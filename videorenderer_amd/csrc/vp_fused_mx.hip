@@ -369,6 +369,9 @@ hipError_t LaunchFusedUp2xMx(const FusedParams &P, const FusedArgs &a_in, int kn
     // R10G10B10A2 target, NV12's own loader — answers hipErrorNotSupported and runs on the packed-fp32 kernel (LaunchFusedUp2x).
     // (Round 3 built all 72 combinations of a kernel nobody selects by default; 56 of them were never launched by any test.)
     if (knt != 4 && knt != 5) return hipErrorNotSupported;
+    // the convert stage that rounds like the reference's (an 8-bit internal format, vp_fused_dev.h: exact_capable) exists in the packed-fp32
+    // kernels only: this one steps aside instead of drawing such a frame in the fast form
+    if (a.exact_cv) return hipErrorNotSupported;
     const int sk = srck == SRC_P01X ? SRC_P01X : SRC_GENERIC, ek = epik == EPI_DITHER8 ? EPI_DITHER8 : EPI_GENERIC;
     if (tailk != TAILK_NONE && sk != SRC_P01X) return hipErrorNotSupported;
     if ((tailk == TAILK_HLG || tailk == TAILK_ALU) && ek != EPI_DITHER8) return hipErrorNotSupported;

@@ -113,8 +113,8 @@ __device__ __forceinline__ f2 pk_mul_wv(f2 w, f2 b)
 }
 
 // PP : QQ = output rows : source rows; NT = taps per output (4: base-1..base+2; 5: Lanczos3 as Direct3D 11 draws it; 6: base-2..base+3)
-template <int PP, int QQ, int NT, int TAIL, int SRC, int EPI>
-__global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P, PeriodArgs Q, const FusedFrame *__restrict__ frames, FusedFrame single)
+template <int PP, int QQ, int NT, int TAIL, int SRC, int EPI, int XC>
+__device__ __forceinline__ void fused_period_body(const FusedArgs &P, const PeriodArgs &Q, const FusedFrame *__restrict__ frames, const FusedFrame &single)
 {
     static_assert(6 % QQ == 0 && (6 * PP) % QQ == 0, "a body of six source rows must hold whole periods");
     static_assert(6 * PP / QQ <= 32, "one word of centre-row bits per body");
@@ -255,13 +255,13 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
             }
             f2 rc[2][3];
             if (pass == 0) {
-                convert_block<TAIL, YSRC>(P, MM, GG, CC, rawn, sy0, sy1, T, rc);
+                convert_block<TAIL, YSRC, DV_NONE, XC>(P, MM, GG, CC, rawn, sy0, sy1, T, rc);
                 fetch(pp + 1, ra0, rawn);
             } else {
                 RawAddr ra; Raw rw;
                 make_raw_addr<YSRC>(P, min(c0 + 2 * b, W - 2), ra);
                 fetch(pp, ra, rw);
-                convert_block<TAIL, YSRC>(P, MM, GG, CC, rw, sy0, sy1, T, rc);
+                convert_block<TAIL, YSRC, DV_NONE, XC>(P, MM, GG, CC, rw, sy0, sy1, T, rc);
             }
             // store to m_TexConvertOutput (UNORM: floor(sat(x)*maxv + 0.5)): the integer codes as floats, (row 0, row 1) pairs
             f2 q[2][3];
@@ -438,6 +438,19 @@ __global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P,
     }
 }
 
+template <int PP, int QQ, int NT, int TAIL, int SRC, int EPI, int XC = XC_NEVER>
+__global__ __launch_bounds__(kPeriodMaxThreads) void k_fused_period(FusedArgs P, PeriodArgs Q, const FusedFrame *__restrict__ frames, FusedFrame single)
+{
+    fused_period_body<PP, QQ, NT, TAIL, SRC, EPI, XC>(P, Q, frames, single);
+}
+// the kernel of an instantiation: its exact-form twin where one exists and the launch asks for it (exact_capable, vp_fused_dev.h)
+template <int PP, int QQ, int NT, int TAIL, int SRC, int EPI>
+inline auto fused_period_kernel(bool exact) -> decltype(&k_fused_period<PP, QQ, NT, TAIL, SRC, EPI, XC_NEVER>)
+{
+    if constexpr (exact_capable<TAIL, SRC, EPI == EPI_DITHER8>() == XC_RUNTIME) { if (exact) return k_fused_period<PP, QQ, NT, TAIL, SRC, EPI, XC_ALWAYS>; }
+    return k_fused_period<PP, QQ, NT, TAIL, SRC, EPI, XC_NEVER>;
+}
+
 }  // namespace
 
 // per-(P, Q) launcher, instantiated by vp_fused_period_*.hip: every (taps, tail, source, epilogue) combination the planner can pick
@@ -446,7 +459,7 @@ hipError_t LaunchFusedPeriodPQ(const FusedArgs &a, const PeriodArgs &q, int nt, 
                                const FusedFrame *frames_dev, FusedFrame single, hipStream_t s)
 {
 #define MPCVR_PD5(NT, TK, SK, EK) do { \
-        auto kern = k_fused_period<PP, QQ, NT, TK, SK, EK>; \
+        auto kern = fused_period_kernel<PP, QQ, NT, TK, SK, EK>(a.exact_cv != 0); \
         if (lds > 48 * 1024) { \
             const hipError_t ea = AllowLargeLds((const void *)kern, lds); \
             if (ea != hipSuccess) return ea; \

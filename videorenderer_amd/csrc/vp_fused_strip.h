@@ -105,8 +105,8 @@ __device__ __forceinline__ void wave_sync()
 }
 
 // NT: taps per output on both axes (4, 6, 8 or 16; the host pads shorter tables with zero weights)
-template <int NT, int PXL, int TAIL, int SRC, int EPI>
-__global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, StoreParams st, const FusedFrame *__restrict__ frames, FusedFrame single)
+template <int NT, int PXL, int TAIL, int SRC, int EPI, int XC>
+__device__ __forceinline__ void fused_strip_body(const FusedArgs &P, const StripArgs &Q, StoreParams st, const FusedFrame *__restrict__ frames, const FusedFrame &single)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool FASTEPI = EPI == EPI_DITHER8;
@@ -238,13 +238,13 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
             }
             f2 rc[2][3];
             if (pass == 0) {
-                convert_block<TAIL, YSRC>(P, MM, GG, CC, rawn, sy0, sy1, T, rc);
+                convert_block<TAIL, YSRC, DV_NONE, XC>(P, MM, GG, CC, rawn, sy0, sy1, T, rc);
                 fetch(pp + 1, ra0, rawn);
             } else {
                 RawAddr ra; Raw rw;
                 make_raw_addr<YSRC>(P, min(c0 + 2 * b, W - 2), ra);
                 fetch(pp, ra, rw);
-                convert_block<TAIL, YSRC>(P, MM, GG, CC, rw, sy0, sy1, T, rc);
+                convert_block<TAIL, YSRC, DV_NONE, XC>(P, MM, GG, CC, rw, sy0, sy1, T, rc);
             }
             // store to m_TexConvertOutput (UNORM: floor(sat(x)*maxv + 0.5)): x*maxv + 2^23 leaves the code in the low
             // mantissa bits — as an fp16 bit pattern that code is the subnormal k * 2^-24
@@ -425,6 +425,20 @@ __global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, 
     }
 }
 
+template <int NT, int PXL, int TAIL, int SRC, int EPI, int XC = XC_NEVER>
+__global__ __launch_bounds__(1024) void k_fused_strip(FusedArgs P, StripArgs Q, StoreParams st, const FusedFrame *__restrict__ frames, FusedFrame single)
+{
+    fused_strip_body<NT, PXL, TAIL, SRC, EPI, XC>(P, Q, st, frames, single);
+}
+// the kernel of an instantiation: its exact-form twin where one exists and the launch asks for it (exact_capable, vp_fused_dev.h;
+// SRC_SURFACE has no convert stage and no twin)
+template <int NT, int PXL, int TAIL, int SRC, int EPI>
+inline auto fused_strip_kernel(bool exact) -> decltype(&k_fused_strip<NT, PXL, TAIL, SRC, EPI, XC_NEVER>)
+{
+    if constexpr (exact_capable<TAIL, SRC, EPI == EPI_DITHER8>() == XC_RUNTIME) { if (exact) return k_fused_strip<NT, PXL, TAIL, SRC, EPI, XC_ALWAYS>; }
+    return k_fused_strip<NT, PXL, TAIL, SRC, EPI, XC_NEVER>;
+}
+
 }  // namespace
 
 // which epilogue a launch runs (vp_fused_strip.hip decides): the integer final pass, the straight UNORM store, or store_epilogue
@@ -439,7 +453,7 @@ hipError_t LaunchFusedStripNT(const FusedArgs &a, const StripArgs &q, const Stor
                               dim3 grid, dim3 block, size_t lds, const FusedFrame *frames_dev, FusedFrame single, hipStream_t s)
 {
 #define MPCVR_ST5(PX, TK, SK, EK) do { \
-        auto kern = k_fused_strip<NT, PX, TK, SK, EK>; \
+        auto kern = fused_strip_kernel<NT, PX, TK, SK, EK>(a.exact_cv != 0); \
         if (lds > 48 * 1024) { \
             const hipError_t ea = AllowLargeLds((const void *)kern, lds); \
             if (ea != hipSuccess) return ea; \

@@ -38,8 +38,8 @@ namespace {
 #ifndef MPCVR_UP2X_WAVES
 #define MPCVR_UP2X_WAVES 3     // waves per SIMD the register allocation aims at (experiment builds: tools/build_variant.sh)
 #endif
-template <int NT, int TAIL, int SRC, int EPI>
-__global__ __launch_bounds__(256, MPCVR_UP2X_WAVES) void k_fused_up2x(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single)
+template <int NT, int TAIL, int SRC, int EPI, int XC>
+__device__ __forceinline__ void fused_up2x_body(const FusedArgs &P, const FusedFrame *__restrict__ frames, const FusedFrame &single)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *Aall = (float *)smem;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, MPCVR_UP2X_WAVES) void k_fused_up2x(FusedArgs 
     // stage C for virtual rows ar, ar+1 (whose raw codes were prefetched into buffer b): convert, write A, prefetch rows ar+4, ar+5
     auto stage_c = [&](int ar, int b) {
         f2 rc[2][3];
-        convert_block<TAIL, SRC>(P, MM, GG, CC, raw2[b], P.rect_t + clampi(ar, 0, H - 1), P.rect_t + clampi(ar + 1, 0, H - 1), T, rc);
+        convert_block<TAIL, SRC, DV_NONE, XC>(P, MM, GG, CC, raw2[b], P.rect_t + clampi(ar, 0, H - 1), P.rect_t + clampi(ar + 1, 0, H - 1), T, rc);
         load_raw<SRC>(P, py, ra, clampi(ar + 4, 0, H - 1), clampi(ar + 5, 0, H - 1), raw2[b]);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -298,6 +298,19 @@ __global__ __launch_bounds__(256, MPCVR_UP2X_WAVES) void k_fused_up2x(FusedArgs 
     }
 }
 
+template <int NT, int TAIL, int SRC, int EPI, int XC = XC_NEVER>
+__global__ __launch_bounds__(256, MPCVR_UP2X_WAVES) void k_fused_up2x(FusedArgs P, const FusedFrame *__restrict__ frames, FusedFrame single)
+{
+    fused_up2x_body<NT, TAIL, SRC, EPI, XC>(P, frames, single);
+}
+// the kernel of an instantiation: its exact-form twin where one exists and the launch asks for it (exact_capable, vp_fused_dev.h)
+template <int NT, int TAIL, int SRC, int EPI>
+inline auto fused_up2x_kernel(bool exact) -> decltype(&k_fused_up2x<NT, TAIL, SRC, EPI, XC_NEVER>)
+{
+    if constexpr (exact_capable<TAIL, SRC, EPI == EPI_DITHER8>() == XC_RUNTIME) { if (exact) return k_fused_up2x<NT, TAIL, SRC, EPI, XC_ALWAYS>; }
+    return k_fused_up2x<NT, TAIL, SRC, EPI, XC_NEVER>;
+}
+
 }  // namespace
 
 // grid / LDS / (source, epilogue, tail) dispatch of one tap count; `a` is complete (FillFusedArgs + weights + seg_rows)
@@ -320,7 +333,7 @@ hipError_t LaunchFusedUp2xNT(const FusedParams &P, const FusedArgs &a_in, int st
                    : (!a.final_pass && P.store.dst_fmt == SF_BGRA8 && P.store.quant == 255) ? EPI_DIRECT8
                    : (!a.final_pass && P.store.dst_fmt == SF_RGB10A2 && P.store.quant == 1023) ? EPI_DIRECT8 : EPI_GENERIC;
     // instantiated (source, epilogue) pairs: each source with the epilogue it normally meets + the generic one
-#define MPCVR_LAUNCH3(NTK, TK, SK, EK) hipLaunchKernelGGL((k_fused_up2x<NTK, TK, SK, EK>), grid, block, lds, s, a, frames_dev, single)
+#define MPCVR_LAUNCH3(NTK, TK, SK, EK) hipLaunchKernelGGL((fused_up2x_kernel<NTK, TK, SK, EK>(a.exact_cv != 0)), grid, block, lds, s, a, frames_dev, single)
 #define MPCVR_LAUNCH(NT, TK) do { \
         if (srck == SRC_P01X && epik == EPI_DITHER8) MPCVR_LAUNCH3(NT, TK, SRC_P01X, EPI_DITHER8); \
         else if (srck == SRC_P01X && epik == EPI_DIRECT8) MPCVR_LAUNCH3(NT, TK, SRC_P01X, EPI_DIRECT8); \

@@ -11,6 +11,7 @@
 
 #include "../../include/mpcvr.h"
 
+namespace mpcvr {
 namespace {
 typedef uint32_t pr_u4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_probe_shape(const pr_u4 *__restrict__ src, pr_u4 *__restrict__ dst, size_t n16_src, int fan)
@@ -21,11 +22,12 @@ __global__ __launch_bounds__(256) void k_probe_shape(const pr_u4 *__restrict__ s
     }
 }
 }  // namespace
+}  // namespace mpcvr
 
 extern "C" int32_t mpcvr_bandwidth_probe(const void *src_dev, void *dst_dev, size_t src_bytes, int32_t fan, void *stream)
 {
     if (!src_dev || !dst_dev) return MPCVR_E_POINTER;
     if (fan < 1 || fan > 64 || src_bytes < 16 || (((uintptr_t)src_dev | (uintptr_t)dst_dev) & 15)) return MPCVR_E_INVALIDARG;
-    hipLaunchKernelGGL(k_probe_shape, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const pr_u4 *)src_dev, (pr_u4 *)dst_dev, src_bytes / 16, (int)fan);
+    hipLaunchKernelGGL(mpcvr::k_probe_shape, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const mpcvr::pr_u4 *)src_dev, (mpcvr::pr_u4 *)dst_dev, src_bytes / 16, (int)fan);
     return hipGetLastError() == hipSuccess ? MPCVR_S_OK : MPCVR_E_FAIL;
 }
