@@ -555,3 +555,23 @@ def test_period_plan_refuses_other_ratios(mpcvr):
     assert api.plan_period(4, 1920, 1080, 2400, 1350) is None        # 5:4
     assert api.plan_period(2, 1920, 1080, 2560, 1439) is None        # not exactly 4:3 down the rows
     assert api.plan_period(4, 1920, 1080, 2560, 1440, flags=api.FLAG_LANCZOS3_FIXED)["taps"] == 6
+
+
+def test_two_step_quotient_of_8bit_codes():
+    """vp_fused_dev.h: xnorm2_u8 — code / 255 as fma(code, hi, fl(code * lo)) with hi + lo = 1/255 to 2^-56.  The exact form of the fused
+    convert stage reads 8-bit texels that way (two packed operations instead of unorm_div's three); it must be the correctly rounded
+    quotient — what a UNORM texture fetch returns — for every code."""
+    import re
+    from fractions import Fraction
+    import numpy as np
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "videorenderer_amd", "csrc", "vp_fused_dev.h")).read()
+    m = re.search(r"kInv255Hi = (\S+)f, kInv255Lo = (\S+)f;", src)
+    hi, lo = float.fromhex(m.group(1)), float.fromhex(m.group(2))
+    assert np.float32(hi) == hi and np.float32(lo) == lo          # both are floats
+    def rn32(fr):           # the float nearest to a rational
+        x = np.float32(float(fr))
+        return min((np.nextafter(x, np.float32(-1)), x, np.nextafter(x, np.float32(2))), key=lambda c: abs(Fraction(float(c)) - fr))
+    for code in range(256):
+        t = np.float32(code) * np.float32(lo)                                     # rounded product
+        got = rn32(Fraction(code) * Fraction(hi) + Fraction(float(t)))            # the FMA: one rounding of the exact sum
+        assert got == rn32(Fraction(code, 255)), code

@@ -132,8 +132,9 @@ __device__ __forceinline__ void convert_blocks_body(const FusedArgs &P, const Fu
         const int a = 2 * (pair0 + p) - 1;                             // rows a, a+1
         if (a >= H) break;
         f2 rc[2][3];
-        if (CHR) convert_block_cr<TAIL, SRC, DV, XC>(P, MM, GG, CC, rawc, P.rect_t + clampi(a, 0, H - 1), P.rect_t + clampi(a + 1, 0, H - 1), T, rc, DL, TE, &DRG);
-        else convert_block<TAIL, SRC, DV, XC>(P, MM, GG, CC, raw, P.rect_t + clampi(a, 0, H - 1), P.rect_t + clampi(a + 1, 0, H - 1), T, rc, DL, TE, &DRG);
+        constexpr int OUTK = XC == XC_ALWAYS ? OUT_CODE_I : OUT_NORM;
+        if (CHR) convert_block_cr<TAIL, SRC, DV, XC, OUTK>(P, MM, GG, CC, rawc, P.rect_t + clampi(a, 0, H - 1), P.rect_t + clampi(a + 1, 0, H - 1), T, rc, DL, TE, &DRG);
+        else convert_block<TAIL, SRC, DV, XC, OUTK>(P, MM, GG, CC, raw, P.rect_t + clampi(a, 0, H - 1), P.rect_t + clampi(a + 1, 0, H - 1), T, rc, DL, TE, &DRG);
         if (p + 1 < pairs && a + 2 < H) {
             if (CHR) load_raw_cr<SRC>(P, py, rac, clampi(a + 2, 0, H - 1), clampi(a + 3, 0, H - 1), rawc);
             else load_raw<SRC>(P, py, ra, clampi(a + 2, 0, H - 1), clampi(a + 3, 0, H - 1), raw);
@@ -144,7 +145,7 @@ __device__ __forceinline__ void convert_blocks_body(const FusedArgs &P, const Fu
         for (int col = 0; col < 2; col++)
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const f2 q = pk_fma(rc[col][c], cmax2, big2);
+                const f2 q = XC == XC_ALWAYS ? rc[col][c] : pk_fma(rc[col][c], cmax2, big2);              // (the exact form hands over the codes as integers)
                 code[col][c][0] = __float_as_uint(q.x); code[col][c][1] = __float_as_uint(q.y);      // 0x4B000000 | k: every use below drops the high byte for free
             }
 #pragma unroll
@@ -162,7 +163,7 @@ __device__ __forceinline__ void convert_blocks_body(const FusedArgs &P, const Fu
                     const uint32_t bg = __builtin_amdgcn_perm(ig, ib, 0x0c0c0703u);
                     px[col] = __builtin_amdgcn_perm(ir, bg, 0x0d070100u);
                 } else if (P.out10) {       // the shifts push 0x4B out of the word; 0x4B + 0x75 = 0xC0 = the two alpha bits
-                    px[col] = (cr + 0x75000000u) | (cg << 10) | (cb << 20);
+                    px[col] = (cr + (XC == XC_ALWAYS ? 0xC0000000u : 0x75000000u)) | (cg << 10) | (cb << 20);
                 } else {
                     const uint32_t bg = __builtin_amdgcn_perm(cg, cb, 0x0c0c0400u);     // [B, G, 0, 0]
                     px[col] = __builtin_amdgcn_perm(cr, bg, 0x0d040100u);               // [B, G, R, 0xff]

@@ -619,7 +619,22 @@ __device__ __forceinline__ f2 xnorm2(f2 code, float d, float r)
     const f2 q = code * splat(r);
     return pk_fma(pk_fma(-q, splat(d), code), splat(r), q);
 }
+// the same quotient for an 8-bit code in two operations: 1/255 as a float pair (hi + lo to 2^-56), code * hi + fl(code * lo) rounded once —
+// the correctly rounded code / 255 for every code 0 .. 255 (checked exhaustively: tests/test_host_logic.py::test_two_step_quotient_of_8bit_codes)
+constexpr float kInv255Hi = 0x1.010102p-8f, kInv255Lo = -0x1.fdfdfep-33f;
+__device__ __forceinline__ f2 xnorm2_u8(f2 code) { return pk_fma(code, splat(kInv255Hi), code * splat(kInv255Lo)); }
+template <int SRC>
+__device__ __forceinline__ f2 xnorm2_src(f2 code, float d, float r)
+{
+    if constexpr (SRC == SRC_NV12 || SRC == SRC_PLANAR8) return xnorm2_u8(code);
+    else return xnorm2(code, d, r);
+}
+// what convert_block leaves in out[][]: the 0..1 value, or — the exact form only, which rounds to the internal format's code itself — that
+// code as a float or as an integer's bits: a consumer that wants the code does not multiply it back (OUT_NORM: floor, * 1/maxv there and
+// * maxv + 2^23 here per value)
+enum { OUT_NORM = 0, OUT_CODE_F = 1, OUT_CODE_I = 2 };
 // (Y, U, V) of the block as 0..1 values, [column] as (row 0, row 1) pairs -> out
+template <int OUTK>
 __device__ __forceinline__ void exact_matrix_store(const FusedArgs &P, const f2 (&Y)[2], const f2 (&U)[2], const f2 (&V)[2], f2 out[2][3])
 {
     const f2 half2 = splat(0.5f), mx = splat(P.maxv), inv = splat(P.inv_maxv);
@@ -632,11 +647,13 @@ __device__ __forceinline__ void exact_matrix_store(const FusedArgs &P, const f2 
             // + cm_c and saturate: the packed add's clamp modifier (the compiler spends a v_max per value on it)
             const f2 cc = splat(P.xc[ch]);
             asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(s) : "v"(s), "v"(cc));
-            const f2 t = s * mx + half2;
-            out[col][ch] = f2{__builtin_floorf(t.x), __builtin_floorf(t.y)} * inv;
+            const f2 t = s * mx + half2;                       // (>= 0.5: the truncating conversion is the floor)
+            if constexpr (OUTK == OUT_CODE_I) out[col][ch] = f2{__uint_as_float((uint32_t)t.x), __uint_as_float((uint32_t)t.y)};
+            else if constexpr (OUTK == OUT_CODE_F) out[col][ch] = f2{__builtin_floorf(t.x), __builtin_floorf(t.y)};
+            else out[col][ch] = f2{__builtin_floorf(t.x), __builtin_floorf(t.y)} * inv;
         }
 }
-template <int SRC>
+template <int SRC, int OUTK>
 __device__ __forceinline__ void convert_block_exact(const FusedArgs &P, const Raw &r, int sy0, int sy1, f2 out[2][3])
 {
     const int n4 = chroma_v4(P, sy0) & ~3;
@@ -646,8 +663,8 @@ __device__ __forceinline__ void convert_block_exact(const FusedArgs &P, const Ra
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         if (i == 0 && !src_center<SRC>(P)) { Un[0] = Vn[0] = splat(0.0f); continue; }
-        Un[i] = xnorm2(f2{(float)(r.c[0][i] & 0xffffu), (float)(r.c[1][i] & 0xffffu)}, P.xdc, P.xrc);
-        Vn[i] = xnorm2(f2{(float)(r.c[0][i] >> 16), (float)(r.c[1][i] >> 16)}, P.xdc, P.xrc);
+        Un[i] = xnorm2_src<SRC>(f2{(float)(r.c[0][i] & 0xffffu), (float)(r.c[1][i] & 0xffffu)}, P.xdc, P.xrc);
+        Vn[i] = xnorm2_src<SRC>(f2{(float)(r.c[0][i] >> 16), (float)(r.c[1][i] >> 16)}, P.xdc, P.xrc);
     }
     f2 Hu[2], Hv[2];                              // c00 * (1 - wx) + c10 * wx of the even / odd luma column, rows (n, n+1)
     if (src_center<SRC>(P)) {                     // MPEG-1: wx = 0.75 (even column, texels c0-1, c0), 0.25 (odd column, texels c0, c0+1)
@@ -666,13 +683,13 @@ __device__ __forceinline__ void convert_block_exact(const FusedArgs &P, const Ra
         V[col] = splat(Hv[col].x) * w0 + splat(Hv[col].y) * w1;
     }
     if (src_wide<SRC>(P)) {
-        Y[0] = xnorm2(f2{(float)(r.y[0] & 0xffffu), (float)(r.y[1] & 0xffffu)}, P.xdy, P.xry);
-        Y[1] = xnorm2(f2{(float)(r.y[0] >> 16), (float)(r.y[1] >> 16)}, P.xdy, P.xry);
+        Y[0] = xnorm2_src<SRC>(f2{(float)(r.y[0] & 0xffffu), (float)(r.y[1] & 0xffffu)}, P.xdy, P.xry);
+        Y[1] = xnorm2_src<SRC>(f2{(float)(r.y[0] >> 16), (float)(r.y[1] >> 16)}, P.xdy, P.xry);
     } else {
-        Y[0] = xnorm2(f2{(float)(r.y[0] & 0xffu), (float)(r.y[1] & 0xffu)}, P.xdy, P.xry);
-        Y[1] = xnorm2(f2{(float)((r.y[0] >> 8) & 0xffu), (float)((r.y[1] >> 8) & 0xffu)}, P.xdy, P.xry);
+        Y[0] = xnorm2_src<SRC>(f2{(float)(r.y[0] & 0xffu), (float)(r.y[1] & 0xffu)}, P.xdy, P.xry);
+        Y[1] = xnorm2_src<SRC>(f2{(float)((r.y[0] >> 8) & 0xffu), (float)((r.y[1] >> 8) & 0xffu)}, P.xdy, P.xry);
     }
-    exact_matrix_store(P, Y, U, V, out);
+    exact_matrix_store<OUTK>(P, Y, U, V, out);
 }
 #pragma clang fp contract(fast)
 
@@ -685,11 +702,11 @@ template <int TAIL, int SRC, int DV>
 __device__ __forceinline__ void convert_block_yuv(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], f2 (&Ycol)[2], f2 (&Ucol)[2], f2 (&Vcol)[2],
                                                   const f2 *T, f2 out[2][3], const DoviParams *DL, const float *TE, const DoviRegs *DR);
 
-template <int TAIL, int SRC, int DV = DV_NONE, int XC = XC_NEVER>
+template <int TAIL, int SRC, int DV = DV_NONE, int XC = XC_NEVER, int OUTK = OUT_NORM>
 __device__ __forceinline__ void convert_block(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], const Raw &r, int sy0, int sy1, const f2 *T, f2 out[2][3],
                                               const DoviParams *DL = nullptr, const float *TE = nullptr, const DoviRegs *DR = nullptr)
 {
-    if constexpr (XC == XC_ALWAYS) { convert_block_exact<SRC>(P, r, sy0, sy1, out); return; }
+    if constexpr (XC == XC_ALWAYS) { convert_block_exact<SRC, OUTK>(P, r, sy0, sy1, out); return; }
     // vertical weights of chroma rows n (w0) and n+1 (w1) for (row 0, row 1): wave-uniform, one SGPR pair each
     const int n4 = chroma_v4(P, sy0) & ~3;                 // 4 * floor(v'(row 0))
     const int fr0 = chroma_v4(P, sy0) - n4, fr1 = chroma_v4(P, sy1) - n4;     // 0..4 quarters
@@ -995,7 +1012,7 @@ __device__ __forceinline__ void load_raw_cr(const FusedArgs &P, gcptr py, const 
 // exact form (FusedArgs::exact_cv, see convert_block_exact): code_Bicubic_UV (Shaders.cpp:74-79) on 0..1 texels, the four products of a row
 // summed left to right, then the four rows the same way
 #pragma clang fp contract(off)
-template <int SRC>
+template <int SRC, int OUTK>
 __device__ __forceinline__ void convert_block_cr_exact(const FusedArgs &P, const RawCR &r, int sy0, int sy1, f2 out[2][3])
 {
     f2 Q[5][2];                                   // [chroma row base + j][column parity] = (U, V)
@@ -1003,7 +1020,7 @@ __device__ __forceinline__ void convert_block_cr_exact(const FusedArgs &P, const
     for (int j = 0; j < 5; j++) {
         f2 t[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) t[i] = xnorm2(f2{(float)(r.c[j][i] & 0xffffu), (float)(r.c[j][i] >> 16)}, P.xdc, P.xrc);
+        for (int i = 0; i < 4; i++) t[i] = xnorm2_src<SRC>(f2{(float)(r.c[j][i] & 0xffffu), (float)(r.c[j][i] >> 16)}, P.xdc, P.xrc);
 #pragma unroll
         for (int par = 0; par < 2; par++) {
             const float *w = P.crx[par];
@@ -1029,22 +1046,22 @@ __device__ __forceinline__ void convert_block_cr_exact(const FusedArgs &P, const
     }
     f2 Y[2], U[2], V[2];
     if (src_wide<SRC>(P)) {
-        Y[0] = xnorm2(f2{(float)(r.y[0] & 0xffffu), (float)(r.y[1] & 0xffffu)}, P.xdy, P.xry);
-        Y[1] = xnorm2(f2{(float)(r.y[0] >> 16), (float)(r.y[1] >> 16)}, P.xdy, P.xry);
+        Y[0] = xnorm2_src<SRC>(f2{(float)(r.y[0] & 0xffffu), (float)(r.y[1] & 0xffffu)}, P.xdy, P.xry);
+        Y[1] = xnorm2_src<SRC>(f2{(float)(r.y[0] >> 16), (float)(r.y[1] >> 16)}, P.xdy, P.xry);
     } else {
-        Y[0] = xnorm2(f2{(float)(r.y[0] & 0xffu), (float)(r.y[1] & 0xffu)}, P.xdy, P.xry);
-        Y[1] = xnorm2(f2{(float)((r.y[0] >> 8) & 0xffu), (float)((r.y[1] >> 8) & 0xffu)}, P.xdy, P.xry);
+        Y[0] = xnorm2_src<SRC>(f2{(float)(r.y[0] & 0xffu), (float)(r.y[1] & 0xffu)}, P.xdy, P.xry);
+        Y[1] = xnorm2_src<SRC>(f2{(float)((r.y[0] >> 8) & 0xffu), (float)((r.y[1] >> 8) & 0xffu)}, P.xdy, P.xry);
     }
 #pragma unroll
     for (int col = 0; col < 2; col++) { U[col] = f2{uv[col][0].x, uv[col][1].x}; V[col] = f2{uv[col][0].y, uv[col][1].y}; }
-    exact_matrix_store(P, Y, U, V, out);
+    exact_matrix_store<OUTK>(P, Y, U, V, out);
 }
 #pragma clang fp contract(fast)
-template <int TAIL, int SRC, int DV = DV_NONE, int XC = XC_NEVER>
+template <int TAIL, int SRC, int DV = DV_NONE, int XC = XC_NEVER, int OUTK = OUT_NORM>
 __device__ __forceinline__ void convert_block_cr(const FusedArgs &P, const f2 (&MM)[5], const f2 (&GG)[5], const f2 (&CC)[3], const RawCR &r, int sy0, int sy1, const f2 *T, f2 out[2][3],
                                                  const DoviParams *DL = nullptr, const float *TE = nullptr, const DoviRegs *DR = nullptr)
 {
-    if constexpr (XC == XC_ALWAYS) { convert_block_cr_exact<SRC>(P, r, sy0, sy1, out); return; }
+    if constexpr (XC == XC_ALWAYS) { convert_block_cr_exact<SRC, OUTK>(P, r, sy0, sy1, out); return; }
     // horizontal pass: Q[row j][column parity] = sum_i wx[parity][i] * texel[j][i], as (U, V) pairs
     f2 Q[5][2];
 #pragma unroll

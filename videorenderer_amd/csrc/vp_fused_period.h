@@ -255,20 +255,20 @@ __device__ __forceinline__ void fused_period_body(const FusedArgs &P, const Peri
             }
             f2 rc[2][3];
             if (pass == 0) {
-                convert_block<TAIL, YSRC, DV_NONE, XC>(P, MM, GG, CC, rawn, sy0, sy1, T, rc);
+                convert_block<TAIL, YSRC, DV_NONE, XC, XC == XC_ALWAYS ? OUT_CODE_F : OUT_NORM>(P, MM, GG, CC, rawn, sy0, sy1, T, rc);
                 fetch(pp + 1, ra0, rawn);
             } else {
                 RawAddr ra; Raw rw;
                 make_raw_addr<YSRC>(P, min(c0 + 2 * b, W - 2), ra);
                 fetch(pp, ra, rw);
-                convert_block<TAIL, YSRC, DV_NONE, XC>(P, MM, GG, CC, rw, sy0, sy1, T, rc);
+                convert_block<TAIL, YSRC, DV_NONE, XC, XC == XC_ALWAYS ? OUT_CODE_F : OUT_NORM>(P, MM, GG, CC, rw, sy0, sy1, T, rc);
             }
             // store to m_TexConvertOutput (UNORM: floor(sat(x)*maxv + 0.5)): the integer codes as floats, (row 0, row 1) pairs
             f2 q[2][3];
 #pragma unroll
             for (int col = 0; col < 2; col++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) q[col][c] = unorm_round2(rc[col][c], cmax2, big2);
+                for (int c = 0; c < 3; c++) q[col][c] = XC == XC_ALWAYS ? rc[col][c] : unorm_round2(rc[col][c], cmax2, big2);      // (the exact form hands over the codes)
             if (b < nb) {           // A[column][channel]: the block's two columns are 48 contiguous bytes
                 f4 *dst = (f4 *)(Aw + 48 * b);
                 dst[0] = f4{q[0][0].x, q[0][0].y, q[0][1].x, q[0][1].y};

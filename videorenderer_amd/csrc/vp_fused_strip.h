@@ -238,20 +238,22 @@ __device__ __forceinline__ void fused_strip_body(const FusedArgs &P, const Strip
             }
             f2 rc[2][3];
             if (pass == 0) {
-                convert_block<TAIL, YSRC, DV_NONE, XC>(P, MM, GG, CC, rawn, sy0, sy1, T, rc);
+                convert_block<TAIL, YSRC, DV_NONE, XC, XC == XC_ALWAYS ? OUT_CODE_I : OUT_NORM>(P, MM, GG, CC, rawn, sy0, sy1, T, rc);
                 fetch(pp + 1, ra0, rawn);
             } else {
                 RawAddr ra; Raw rw;
                 make_raw_addr<YSRC>(P, min(c0 + 2 * b, W - 2), ra);
                 fetch(pp, ra, rw);
-                convert_block<TAIL, YSRC, DV_NONE, XC>(P, MM, GG, CC, rw, sy0, sy1, T, rc);
+                convert_block<TAIL, YSRC, DV_NONE, XC, XC == XC_ALWAYS ? OUT_CODE_I : OUT_NORM>(P, MM, GG, CC, rw, sy0, sy1, T, rc);
             }
             // store to m_TexConvertOutput (UNORM: floor(sat(x)*maxv + 0.5)): x*maxv + 2^23 leaves the code in the low
             // mantissa bits — as an fp16 bit pattern that code is the subnormal k * 2^-24
             uint32_t rg[2][2], bb[2][2];                // [column][row]
 #pragma unroll
             for (int col = 0; col < 2; col++) {
-                const f2 qr = pk_fma(rc[col][0], cmax2, big2), qg = pk_fma(rc[col][1], cmax2, big2), qb = pk_fma(rc[col][2], cmax2, big2);
+                // (the exact form hands over the codes as integers: the same low halves)
+                const f2 qr = XC == XC_ALWAYS ? rc[col][0] : pk_fma(rc[col][0], cmax2, big2), qg = XC == XC_ALWAYS ? rc[col][1] : pk_fma(rc[col][1], cmax2, big2),
+                         qb = XC == XC_ALWAYS ? rc[col][2] : pk_fma(rc[col][2], cmax2, big2);
                 rg[col][0] = __builtin_amdgcn_perm(__float_as_uint(qg.x), __float_as_uint(qr.x), 0x05040100u);
                 rg[col][1] = __builtin_amdgcn_perm(__float_as_uint(qg.y), __float_as_uint(qr.y), 0x05040100u);
                 bb[col][0] = __float_as_uint(qb.x) & 0xffffu; bb[col][1] = __float_as_uint(qb.y) & 0xffffu;

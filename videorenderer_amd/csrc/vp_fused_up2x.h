@@ -125,13 +125,14 @@ __device__ __forceinline__ void fused_up2x_body(const FusedArgs &P, const FusedF
     // stage C for virtual rows ar, ar+1 (whose raw codes were prefetched into buffer b): convert, write A, prefetch rows ar+4, ar+5
     auto stage_c = [&](int ar, int b) {
         f2 rc[2][3];
-        convert_block<TAIL, SRC, DV_NONE, XC>(P, MM, GG, CC, raw2[b], P.rect_t + clampi(ar, 0, H - 1), P.rect_t + clampi(ar + 1, 0, H - 1), T, rc);
+        convert_block<TAIL, SRC, DV_NONE, XC, XC == XC_ALWAYS ? OUT_CODE_F : OUT_NORM>(P, MM, GG, CC, raw2[b], P.rect_t + clampi(ar, 0, H - 1), P.rect_t + clampi(ar + 1, 0, H - 1), T, rc);
         load_raw<SRC>(P, py, ra, clampi(ar + 4, 0, H - 1), clampi(ar + 5, 0, H - 1), raw2[b]);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             // store to m_TexConvertOutput (UNORM: floor(sat(x)*maxv + 0.5)) and read back (q/maxv to 1 ulp)
-            f2 qe = unorm_round2(rc[0][c], cmax2, big2) * cinv2;             // even column, rows (a, a+1)
-            f2 qo = unorm_round2(rc[1][c], cmax2, big2) * cinv2;             // odd column
+            // (the exact form hands over the codes themselves)
+            f2 qe = (XC == XC_ALWAYS ? rc[0][c] : unorm_round2(rc[0][c], cmax2, big2)) * cinv2;             // even column, rows (a, a+1)
+            f2 qo = (XC == XC_ALWAYS ? rc[1][c] : unorm_round2(rc[1][c], cmax2, big2)) * cinv2;             // odd column
             // A[ch][col][row]: columns 2l, 2l+1 as (row a, row a+1) pairs = one 16-byte store
             *(f4 *)(A + (c * AW + 2 * lane) * 2) = f4{qe.x, qe.y, qo.x, qo.y};
             if (edge_wave) {       // clamp-to-edge of the convert texture: patch the column that hangs over (rare wave;
