@@ -168,7 +168,10 @@ def test_pass_plan_matches_reference_rules(mpcvr):
     assert d(2, 64, 64, (0, 0, 64, 64), 64, 64, s.copy(output_format=1, iTexFormat=16)).endswith("internal=16;swap=10;final=1")
     assert d(2, 64, 64, (0, 0, 64, 64), 64, 64, s.copy(bUseDither=0)).endswith("final=0")
     # Jinc2m: one 2-D shader for both axes => a single draw (m_pShaderUpscaleY = m_pShaderUpscaleX, :2921,3131-3137)
-    assert d(2, 64, 64, (0, 0, 128, 128), 128, 128, s.copy(iUpscaling=5)).startswith("passes:convert,resizeX+final")
+    # (at exactly 2x the fused Jinc2m kernel replaces convert + that draw + the final pass since round 5; the passes show with the fused tier off)
+    assert d(2, 64, 64, (0, 0, 128, 128), 128, 128, s.copy(iUpscaling=5)).startswith("fused_jinc2x")
+    assert d(2, 64, 64, (0, 0, 128, 128), 128, 128, s.copy(iUpscaling=5, flags=api.FLAG_NO_FUSED)).startswith("passes:convert,resizeX+final")
+    assert d(2, 64, 64, (0, 0, 192, 192), 192, 192, s.copy(iUpscaling=5)).startswith("passes:convert,resizeX+final")
     assert d(2, 64, 64, (0, 0, 128, 20), 128, 20, s.copy(iUpscaling=5)).startswith("passes:convert,resizeX,resizeY+final")
 
 

@@ -41,6 +41,7 @@ SOURCES = [
     ("vp_fused_period_1_2.hip", []),
     ("vp_fused_period_3_1.hip", []),
     ("vp_jinc.hip", []),
+    ("vp_fused_jinc.hip", []),
     ("vp_errdiff.hip", []),
     ("vp_probe.hip", []),
 ]

@@ -60,7 +60,7 @@ CHipVideoProcessor::~CHipVideoProcessor()
     if (!m_bInit && !m_stream && !m_evStart && !m_evStop && !m_dither.ptr) return;
     (void)hipSetDevice(m_device);
     if (m_stream) (void)hipStreamSynchronize(m_stream);
-    for (DevBuffer *b : {&m_batchConv, &m_batchMid, &m_batchPost, &m_edPost, &m_edHandoff, &m_batchTex, &m_jincFirst, &m_jincSecond, &m_TexSrcVideo, &m_TexRaw, &m_TexPost, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
+    for (DevBuffer *b : {&m_batchConv, &m_batchMid, &m_batchPost, &m_edPost, &m_edHandoff, &m_batchTex, &m_jincFirst, &m_jincSecond, &m_jincFused, &m_TexSrcVideo, &m_TexRaw, &m_TexPost, &m_TexConvertOutput, &m_TexResize, &m_BackBuffer, &m_Snapshot, &m_dither,
                          &m_pqLut, &m_hlgLut, &m_eotfLut, &m_stripTab, &m_tapsXi, &m_tapsXw, &m_tapsXs, &m_tapsYi, &m_tapsYw, &m_tapsYs, &m_otherX, &m_otherY, &m_tapsXb, &m_tapsYb})
         b->Release();
     for (UploadSlot &u : m_up) {
@@ -785,8 +785,28 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         if ((hr = CheckHip(m_hlgLut.CheckCreate(t.size() * sizeof(float)), "hlg lut"))) return hr;
         if ((hr = CheckHip(hipMemcpy(m_hlgLut.ptr, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice), "hlg lut upload"))) return hr;
     }
+    m_jincFusedTab = nullptr;
+    if (m_plan.fused_jinc) {
+        // the fused Jinc2m kernel's weights: the phase table of a 2x draw (integer origins drop out of it) in the kernel's reading order
+        DrawCoords dc{};
+        dc.step_x = dc.step_y = 0.5f;
+        std::vector<unsigned char> phases(JincPhasesBytes());
+        std::vector<float> tab(FusedJincTableBytes() / sizeof(float));
+        if (!BuildJincPhases(dc, phases.data())) m_plan.fused_up2x = m_plan.fused_jinc = false;
+        else {
+            if (const char *e = std::getenv("MPCVR_JINC_DBG")) {        // (debug: a one-tap filter — which texel does an output pixel read?)
+                JincPhases &jp = *(JincPhases *)phases.data();
+                const int tap = std::atoi(e);
+                for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) { for (int k = 0; k < 16; k++) jp.w[a][b][k] = k == tap ? 1.0f : 0.0f; jp.wsum[a][b] = 1.0f; }
+            }
+            BuildFusedJincTable(phases.data(), tab.data());
+            if ((hr = CheckHip(m_jincFused.CheckCreate(tab.size() * sizeof(float)), "fused jinc table"))) return hr;
+            if ((hr = CheckHip(hipMemcpy(m_jincFused.ptr, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice), "fused jinc table upload"))) return hr;
+            m_jincFusedTab = (const float *)m_jincFused.ptr;
+        }
+    }
     if (m_plan.fused_up2x) {
-        if (!m_blobOverride || m_upX.ntaps == 0) {
+        if (!m_plan.fused_jinc && (!m_blobOverride || m_upX.ntaps == 0)) {
             float w[6];
             const int n = UpscaleWeights(m_cfg.iUpscaling, 0.75f, w);
             m_upX.ntaps = n; std::memset(m_upX.w_even, 0, sizeof(m_upX.w_even)); std::memset(m_upX.w_odd, 0, sizeof(m_upX.w_odd));
@@ -799,6 +819,7 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         FusedParams fp{};
         FillFusedParams(nullptr, nullptr, 0, &fp);
         m_plan.fused_up2x = FusedUp2xSupported(fp);
+        if (!m_plan.fused_up2x) m_plan.fused_jinc = false;
         // experiment knob: exact 2x through the arbitrary-ratio kernel instead (DESIGN.md §4.3 compares the two)
         static const bool no_up2x_env = [] { const char *e = std::getenv("MPCVR_NO_UP2X"); return e && *e && *e != '0'; }();
         if (no_up2x_env && m_strip) m_plan.fused_up2x = false;
@@ -998,6 +1019,7 @@ void CHipVideoProcessor::FillFusedParams(const uint8_t *sample, void *rt, int rt
     fp->eotf_lut = (m_doviValid && !no_lut) ? (const float *)m_eotfLut.ptr : nullptr;
     fp->dovi_l2 = (m_doviValid && m_doviHost.l2_enabled) ? 1 : 0;
     fp->dovi_cm = (m_doviValid && m_dvTabDev) ? m_dvCmDev : nullptr;
+    fp->jinc_tab = m_plan.fused_jinc ? m_jincFusedTab : nullptr;
     fp->taps_mfma = (m_cfg.flags & MPCVR_FLAG_FUSED_MFMA) ? 1 : (m_cfg.flags & MPCVR_FLAG_FUSED_VALU) ? 0 : -1;
     fp->inflight = m_inflight;
     fp->dst_aligned16 = (((uintptr_t)rt) & 15) == 0;        // batches: ProcessBatch checks every target

@@ -299,7 +299,8 @@ private:
     bool m_batchRepacked = false;  // the batch at hand reads v210 samples already repacked into m_batchTex
     bool m_batchSrc16 = false;     // every sample of the batch being planned starts on a 16-byte boundary
     // Jinc2m phase tables of the first / second draw (null: weights per pixel)
-    DevBuffer m_jincFirst, m_jincSecond;
+    DevBuffer m_jincFirst, m_jincSecond, m_jincFused;
+    const float *m_jincFusedTab = nullptr;                                  // the fused Jinc2m kernel's weight table (BuildFusedJincTable), PassPlan::fused_jinc
     const void *m_jincFirstTab = nullptr, *m_jincSecondTab = nullptr;
     const float *m_jincFirstCtr = nullptr, *m_jincSecondCtr = nullptr;     // the plain kernel's texcoord tables (no phase table: BuildDrawCentres), in the same buffers
     HRESULT UploadJincPhases(const DrawCoords &dc, DevBuffer &buf, const void **tab, const float **ctr);

@@ -415,9 +415,11 @@ bool FusedUp2xSupported(const FusedParams &P)
 {
     const ConvertParams &c = P.conv;
     if (P.out_w != 2 * c.out_w || P.out_h != 2 * c.out_h) return false;
-    if (P.wx.ntaps != 4 && P.wx.ntaps != 6) return false;
-    if (P.wy.ntaps != P.wx.ntaps || P.wy.q1_quirk != P.wx.q1_quirk) return false;
-    if (std::memcmp(P.wx.w_even, P.wy.w_even, sizeof(P.wx.w_even)) || std::memcmp(P.wx.w_odd, P.wy.w_odd, sizeof(P.wx.w_odd))) return false;
+    if (!P.jinc_tab) {      // (the 2-D Jinc2m filter brings its own table)
+        if (P.wx.ntaps != 4 && P.wx.ntaps != 6) return false;
+        if (P.wy.ntaps != P.wx.ntaps || P.wy.q1_quirk != P.wx.q1_quirk) return false;
+        if (std::memcmp(P.wx.w_even, P.wy.w_even, sizeof(P.wx.w_even)) || std::memcmp(P.wx.w_odd, P.wy.w_odd, sizeof(P.wx.w_odd))) return false;
+    }
     if (c.out_fmt != SF_BGRA8 && c.out_fmt != SF_RGB10A2) return false;
     if (!BlockConvertLayout(P, false) || c.blend_deint) return false;
     if (c.out_w < 8 || c.out_h < 8 || (c.out_w & 1) || (c.out_h & 1)) return false;
@@ -720,6 +722,7 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     const ConvertParams &c = P.conv;
     FusedArgs a;
     FillFusedArgs(P, a, 1);
+    if (P.jinc_tab) return LaunchFusedJinc2x(P, a, P.jinc_tab, frames_dev, single, n_frames, s);
     const int nt = P.wx.ntaps;
     for (int t = 0; t < 6; t++) { a.we[t] = P.wx.w_even[t]; a.wo[t] = P.wx.w_odd[t]; }
     int knt = nt;

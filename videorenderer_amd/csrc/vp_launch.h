@@ -74,6 +74,7 @@ struct FusedParams {
     // a batch with one RPU per frame: conv.dovi points at n DoviParams and dovi_cm at n colour matrices (12 floats each, the layout of
     // ConvertParams::cm); the block convert's Dolby Vision variants index both by the frame.  Null: one RPU for the launch (conv.dovi, conv.cm)
     const float *dovi_cm;
+    const float *jinc_tab;    // fused 2x route with the 2-D Jinc2m filter (PassPlan::fused_jinc): the device copy of BuildFusedJincTable's table; null: separable taps (wx, wy)
     int taps_mfma;            // fused 2x kernel: 1 = resize taps on the matrix cores, 0 = packed-fp32 VALU chains, -1 = library default
     int exact_convert;        // a resize reads this launch's convert output: 8-bit internal formats then take the exact form of the convert stage
                               // (FusedArgs::exact_cv).  LaunchFusedUp2x / LaunchFusedStrip set it themselves; the block convert's callers say so.
@@ -97,6 +98,9 @@ struct ErrDiffParams {
 size_t ErrorDiffusionHandoffBytes(const ErrDiffParams &P, int n_frames);
 hipError_t LaunchErrorDiffusion(const ErrDiffParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
 bool FusedUp2xSupported(const FusedParams &P);
+// vp_fused_jinc.hip: the weight table of the fused Jinc2m kernel, from BuildJincPhases' table of a 2x draw
+size_t FusedJincTableBytes();
+void BuildFusedJincTable(const void *phases, float *out);
 bool BlockConvertLayout(const FusedParams &P, bool catmull_420);       // source layout + chroma filter convert_block serves
 // the fused kernel's convert stage as a kernel of its own: 2x2 blocks, shared chroma fetch, table tone map.  P.store describes
 // the destination: texels of the internal format (m_TexConvertOutput, or the render target when nothing follows: to_rt), or

@@ -841,9 +841,12 @@ bool DecidePlan(int iTexFormat, int iChromaScaling, int iUpscaling, int iDownsca
                             : (f.layout == LAY_PACKED444 || f.layout == LAY_GRAY);
     // fused 2x candidate: exact 2x on both axes with an interpolation shader, bilinear 4:2:0 chroma,
     // UNORM internal format, destination fully inside the window
-    p.fused_up2x = !(flags & MPCVR_FLAG_NO_FUSED) && !g.dovi && g.rotation == 0 && !p.flip && !p.hdr_tonemap && p.two_pass && w2 == 2 * w1 && h2 == 2 * h1 &&
+    // ... or the one 2-D draw of Jinc2m (same_shader above), which the fused kernel of vp_fused_jinc.hip replaces together with the convert draw
+    const bool jinc_draw = p.one_pass && !rotated && p.rx.kind == RS_UP && p.ry.kind == RS_UP && iUpscaling == MPCVR_UPSCALE_Jinc2;
+    p.fused_up2x = !(flags & MPCVR_FLAG_NO_FUSED) && !g.dovi && g.rotation == 0 && !p.flip && !p.hdr_tonemap && (p.two_pass || jinc_draw) && w2 == 2 * w1 && h2 == 2 * h1 &&
                    p.rx.kind == RS_UP && p.ry.kind == RS_UP && fused_layout && p.internal_fmt != SF_RGBA16F &&
                    g.vl >= 0 && g.vt >= 0 && g.vr <= g.ww && g.vb <= g.wh && w1 >= 8 && h1 >= 8 && !(w1 & 1);
+    p.fused_jinc = p.fused_up2x && jinc_draw;
     p.direct_convert = !(flags & MPCVR_FLAG_NO_FUSED) && p.copy_only && p.convert && !p.hdr_tonemap;
     *plan = p;
     return true;
@@ -851,7 +854,7 @@ bool DecidePlan(int iTexFormat, int iChromaScaling, int iUpscaling, int iDownsca
 
 std::string PassPlan::describe() const
 {
-    if (fused_up2x) return errdiff ? "fused_up2x,errdiff" : "fused_up2x";
+    if (fused_up2x) return std::string(fused_jinc ? "fused_jinc2x" : "fused_up2x") + (errdiff ? ",errdiff" : "");
     if (direct_convert) return std::string(final_pass ? "direct:convert+final" : "direct:convert+copy") + (errdiff ? ",errdiff" : "");
     std::string s = convert ? "passes:convert" : "passes:source";
     if (two_pass) s += final_pass ? ",resizeX,resizeY+final" : ",resizeX,resizeY";

@@ -174,6 +174,7 @@ struct PassPlan {
     int one_pass_axis = 0;
     bool copy_only = false;          // no size change: straight copy / final pass from the convert output
     bool fused_up2x = false;         // eligible for the fused 2x kernel
+    bool fused_jinc = false;         // ... with the one-draw 2-D Jinc2m filter in the place of the two separable draws (vp_fused_jinc.hip)
     bool direct_convert = false;     // no resize draw and no tone-map step: the convert kernel rounds like m_TexConvertOutput
                                      // and runs the copy / final pass in its own epilogue (one kernel, no intermediate)
     // rotation-carrying (first) draw — FillVertices :130-179, ResizeShaderPass :3112-3137
