@@ -578,7 +578,7 @@ bool ConvertBlocksSupported(const FusedParams &P, bool to_rt)
 
 // compute units of the current device, and the workgroups of a kernel one of them keeps resident (queried once per kernel, block
 // size, LDS size and device): k_convert_stream launches exactly that many
-static int DeviceCuCount()
+int DeviceCuCount()
 {
     static std::mutex mu;
     static std::map<int, int> cus;

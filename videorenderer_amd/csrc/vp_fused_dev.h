@@ -1123,6 +1123,7 @@ int FusedDoviKind(const FusedParams &P);          // DV_* for the launch
 hipError_t LaunchFusedUp2xMx(const FusedParams &P, const FusedArgs &a, int knt, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
 // dynamic LDS above the default limit needs the function attribute once per kernel (and device); remembered per (kernel, device) (vp_fused_strip.hip)
 hipError_t AllowLargeLds(const void *kern, size_t lds);
+int DeviceCuCount();        // vp_fused.hip: compute units of the current device (256)
 // vp_fused_jinc.hip: the fused 2x launch with the 2-D Jinc2m filter in the place of the two separable draws (`a` complete but for seg_rows)
 hipError_t LaunchFusedJinc2x(const FusedParams &P, const FusedArgs &a, const float *jtab_dev, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
 // LDS a workgroup of the current device may claim with that attribute (gfx950: 160 KiB): queried once per device, so a part or

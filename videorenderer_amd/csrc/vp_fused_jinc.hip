@@ -19,7 +19,8 @@
 //              saturates), UNORM round, dither in integers, one 16-byte store per lane and output row.
 //   Weights: 4 phases x 16, re-ordered on the host into the order stage J meets them (source row of the neighbourhood x output row parity
 //   x column parity x 4 taps) and read with scalar loads inside the loop: 16 SGPRs at a time instead of 64 for the whole table.
-//   LDS: 12 KiB of ring per wave, 8 waves per workgroup, + the dither tables and the tone-map table: 134 KiB -> 2 waves per SIMD.
+//   LDS: 9 KiB of ring per wave (three row pairs: stage C of the next pair runs BEHIND stage J), 12 waves per workgroup, + the dither tables
+//   and the tone-map table: 146 KiB -> 3 waves per SIMD.  The slot of a row pair is a run-time offset (t mod 3 has no power-of-two unroll).
 // Arithmetic identical to k_jinc2_quad's (same products, same order: row by row, left to right, FMAs) on the same converted texels.
 #include "vp_fused_dev.h"
 
@@ -27,9 +28,17 @@ namespace mpcvr {
 
 namespace {
 
-constexpr int JWAVES = 8;                          // strips per workgroup
-constexpr int JSLOTS = 4;                          // row pairs in the ring: three being read, one being written
-constexpr int JRING_FLOATS = JSLOTS * 3 * 2 * AW;  // [slot][channel][row][column]
+#ifndef MPCVR_JINC_WAVES
+#define MPCVR_JINC_WAVES 12
+#endif
+#ifndef MPCVR_JINC_SLOTS
+#define MPCVR_JINC_SLOTS 3
+#endif
+constexpr int JWAVES = MPCVR_JINC_WAVES;           // strips per workgroup
+constexpr int JSLOTS = MPCVR_JINC_SLOTS;           // row pairs in the ring: the three stage J reads (+ one being written meanwhile: 4 slots, 8 waves —
+                                                   // the first version, 2 waves per SIMD; 3 slots and stage C behind stage J: 12 waves, 3 per SIMD)
+constexpr int JSLOT_FLOATS = 3 * 2 * AW;           // [channel][row][column]
+constexpr int JRING_FLOATS = JSLOTS * JSLOT_FLOATS;
 constexpr int LDS_JRING = JWAVES * JRING_FLOATS * 4;
 // the host's weight table (FusedJincTable): [source row sr of the 5-row neighbourhood][output row parity rp][column parity cp][tap i] =
 // w[rp][cp][(sr - rp) * 4 + i], zero where sr - rp is no tap row; then 1 / wsum per phase [rp][cp]
@@ -37,6 +46,20 @@ constexpr int JTAB_W = 5 * 16, JTAB_FLOATS = JTAB_W + 4;
 
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));      // a pair at any float of a ring row
 typedef const __attribute__((address_space(4))) float *jcptr;           // the constant address space: scalar loads
+// min / max of four texel values: v_min3 + v_min spelt out — through fminf the compiler canonicalises every operand first (v_max x, x: the
+// values come out of LDS and could be signalling NaNs for all it knows), 4.5 instructions per output pixel for nothing
+__device__ __forceinline__ float jmin4(float a, float b, float c, float d)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3\n\tv_min_f32 %0, %0, %4" : "=&v"(r) : "v"(a), "v"(b), "v"(c), "v"(d));
+    return r;
+}
+__device__ __forceinline__ float jmax4(float a, float b, float c, float d)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(r) : "v"(a), "v"(b), "v"(c), "v"(d));
+    return r;
+}
 __device__ __forceinline__ void jinc_wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -67,9 +90,13 @@ __device__ __forceinline__ void fused_jinc2x_body(const FusedArgs &P, const floa
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int W = P.W, H = P.H;
-    const int x0 = (blockIdx.x * JWAVES + wave) * S;
-    const int s0 = blockIdx.y * P.seg_rows;
-    if (x0 >= W || s0 >= H) return;
+    // work items = (strip, segment) pairs, strips fastest, dealt to the waves of the workgroups in order: a frame's 16 strips need not be a
+    // multiple of the workgroup's waves (12 waves by whole rows of strips: the second workgroup of a row two thirds empty — 28.7 k instead of 37 k frames/s)
+    const int n_strips = (W + S - 1) / S;
+    const int item = blockIdx.x * JWAVES + wave;
+    const int x0 = (item % n_strips) * S;
+    const int s0 = (item / n_strips) * P.seg_rows;
+    if (s0 >= H) return;
     const int s1 = min(s0 + P.seg_rows, H);
     float *R = Rall + wave * JRING_FLOATS;
 
@@ -117,7 +144,7 @@ __device__ __forceinline__ void fused_jinc2x_body(const FusedArgs &P, const floa
     load_raw<SRC>(P, py, ra, clampi(s0 - 1, 0, H - 1), clampi(s0, 0, H - 1), raw2[1]);
 
     // stage C for virtual rows ar, ar+1 (raw codes in buffer b) into ring slot `slot`; prefetches rows ar+4, ar+5
-    auto stage_c = [&](int ar, int b, int slot) {
+    auto stage_c = [&](int ar, int b, int slot_off) {
         f2 rc[2][3];
         convert_block<TAIL, SRC, DV_NONE, XC, XC == XC_ALWAYS ? OUT_CODE_F : OUT_NORM>(P, MM, GG, CC, raw2[b], P.rect_t + clampi(ar, 0, H - 1), P.rect_t + clampi(ar + 1, 0, H - 1), T, rc);
         load_raw<SRC>(P, py, ra, clampi(ar + 4, 0, H - 1), clampi(ar + 5, 0, H - 1), raw2[b]);
@@ -126,7 +153,7 @@ __device__ __forceinline__ void fused_jinc2x_body(const FusedArgs &P, const floa
             // store to m_TexConvertOutput (UNORM: floor(sat(x)*maxv + 0.5)) and read back (q/maxv to 1 ulp); the exact form hands over the codes
             const f2 qe = (XC == XC_ALWAYS ? rc[0][c] : unorm_round2(rc[0][c], cmax2, big2)) * cinv2;             // even column, rows (a, a+1)
             const f2 qo = (XC == XC_ALWAYS ? rc[1][c] : unorm_round2(rc[1][c], cmax2, big2)) * cinv2;             // odd column
-            float *r0 = R + ((slot * 3 + c) * 2 + 0) * AW + 2 * lane, *r1 = r0 + AW;
+            float *r0 = R + slot_off + (c * 2 + 0) * AW + 2 * lane, *r1 = r0 + AW;
             *(f2 *)r0 = f2{qe.x, qo.x};
             *(f2 *)r1 = f2{qe.y, qo.y};
             if (edge_wave) {       // clamp-to-edge of the convert texture: patch the column that hangs over (rare wave)
@@ -136,20 +163,24 @@ __device__ __forceinline__ void fused_jinc2x_body(const FusedArgs &P, const floa
         }
     };
     stage_c(s0 - 3, 0, 0);
+    int slot_t = 0;                                   // t mod JSLOTS (wave-uniform)
+    auto slot_back = [&](int d) { const int v = slot_t - d; return (v < 0 ? v + JSLOTS : v) * JSLOT_FLOATS; };      // float offset of the pair of iteration t - d
 
     jcptr jtab = (jcptr)(uintptr_t)jtab_g;
-    for (int tb = 0; tb < n_iter; tb += 4) {
+    for (int tb = 0; tb < n_iter; tb += 2) {
         // (keeps the weight loads inside the loop: hoisted, the 84 values would sit in SGPRs — and spill into VGPR lanes — for its whole length)
         asm volatile("" : "+s"(jtab));
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < 2; u++) {
             const int t = tb + u;
             if (t >= n_iter) break;
             const int a = s0 - 3 + 2 * t;
             jinc_wave_sync();
-            // ---------------- stage C of the NEXT iteration (its slot is not among the three stage J reads) ----------------
-            if (t + 1 < n_iter) stage_c(a + 2, (u + 1) & 1, (u + 1) & 3);
-            if (t < 2 || !store_ok) continue;
+            const int next_off = (slot_t + 1 == JSLOTS ? 0 : slot_t + 1) * JSLOT_FLOATS;
+            // ---------------- stage C of the NEXT iteration: in front of stage J where its slot is not among the three stage J reads ----------------
+            if (JSLOTS >= 4 && t + 1 < n_iter) stage_c(a + 2, (u + 1) & 1, next_off);
+            const float *rb[3] = {R + slot_back(2) + 2 * lane + 2, R + slot_back(1) + 2 * lane + 2, R + slot_back(0) + 2 * lane + 2};      // ring column of source column 2l - 2
+            if (t >= 2 && store_ok) {
             // ---------------- stage J + final pass ----------------
 #pragma unroll
             for (int qr = 0; qr < 2; qr++) {
@@ -160,7 +191,6 @@ __device__ __forceinline__ void fused_jinc2x_body(const FusedArgs &P, const floa
 #pragma unroll
                 for (int sr = 0; sr < 5; sr++) {
                     const int ri = qr + sr;                     // row of the six this iteration's quads read: rows a-4 .. a+1
-                    const int slot = (u + 2 + (ri >> 1)) & 3;
                     // the 16 weights of this neighbourhood row: [rp][cp][i], two to an SGPR pair
                     f2 wq[8];
 #pragma unroll
@@ -168,7 +198,7 @@ __device__ __forceinline__ void fused_jinc2x_body(const FusedArgs &P, const floa
                     f2 pr[3][5];
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
-                        const float *row = R + ((slot * 3 + c) * 2 + (ri & 1)) * AW + 2 * lane + 2;       // ring column of source column 2l - 2
+                        const float *row = rb[ri >> 1] + (c * 2 + (ri & 1)) * AW;
                         pr[c][0] = *(const f2 *)(row); pr[c][2] = *(const f2 *)(row + 2); pr[c][4] = *(const f2 *)(row + 4);
                         pr[c][1] = *(const f2u *)(row + 1); pr[c][3] = *(const f2u *)(row + 3);
                     }
@@ -193,8 +223,8 @@ __device__ __forceinline__ void fused_jinc2x_body(const FusedArgs &P, const floa
 #pragma unroll
                                 for (int c = 0; c < 3; c++) {
                                     const f2 p1 = prv[c][cp + 1], p2 = prv[c][cp + 2], q1 = pr[c][cp + 1], q2 = pr[c][cp + 2];
-                                    mn[rp][cp][c] = f2{fminf(fminf(fminf(p1.x, p2.x), q1.x), q2.x), fminf(fminf(fminf(p1.y, p2.y), q1.y), q2.y)};
-                                    mx[rp][cp][c] = f2{fmaxf(fmaxf(fmaxf(p1.x, p2.x), q1.x), q2.x), fmaxf(fmaxf(fmaxf(p1.y, p2.y), q1.y), q2.y)};
+                                    mn[rp][cp][c] = f2{jmin4(p1.x, p2.x, q1.x, q2.x), jmin4(p1.y, p2.y, q1.y, q2.y)};
+                                    mx[rp][cp][c] = f2{jmax4(p1.x, p2.x, q1.x, q2.x), jmax4(p1.y, p2.y, q1.y, q2.y)};
                                 }
                         }
                         if (j != 3) continue;
@@ -280,6 +310,12 @@ __device__ __forceinline__ void fused_jinc2x_body(const FusedArgs &P, const floa
                         for (int m = 0; m < 5; m++) prv[c][m] = pr[c][m];
                 }
             }
+            }
+            if (JSLOTS < 4 && t + 1 < n_iter) {       // the oldest pair's slot is free now (the wave's LDS reads and writes execute in order)
+                jinc_wave_sync();
+                stage_c(a + 2, (u + 1) & 1, next_off);
+            }
+            slot_t = slot_t + 1 == JSLOTS ? 0 : slot_t + 1;
         }
     }
 }
@@ -324,17 +360,22 @@ hipError_t LaunchFusedJinc2x(const FusedParams &P, const FusedArgs &a_in, const 
     const int strips = (c.out_w + S - 1) / S;
     int seg = seg_env;
     if (seg <= 0) {
-        // long segments recompute less (4 rows each), short ones fill the chip: 2 waves per SIMD = 2,048 resident waves
-        seg = 72;
+        // One workgroup per CU (LDS), so a launch runs in rounds of CUs x 12 waves and a last round that is half empty costs a whole one
+        // (32 frames of 1080p: 90-row segments = 6,144 items = 2 rounds: 45.7 k frames/s; 120 rows = 1.5 rounds: 35.7 k; 72 rows = 2.5: 39.0 k).
+        // Cost of a candidate = rounds x rows an item walks (its segment + 7 rows of run-in); the longest segment among the cheapest.
         const long side = (long)n_frames * (P.inflight > 1 ? P.inflight : 1);
-        const long want = n_frames > 1 ? 8192 : 2560;
-        for (int cand : {180, 144, 120, 108, 90, 72, 60, 48, 36, 24})
-            if ((long)strips * ((c.out_h + cand - 1) / cand) * side >= want || cand == 24) { seg = cand; break; }
+        const long resident = (long)DeviceCuCount() * JWAVES;
+        long best = -1;
+        for (int cand : {180, 144, 120, 108, 90, 72, 60, 48, 36, 24}) {
+            const long items = (long)strips * ((c.out_h + cand - 1) / cand) * side;
+            const long cost = ((items + resident - 1) / resident) * (long)(std::min(cand, c.out_h) + 7);
+            if (best < 0 || cost < best) { best = cost; seg = cand; }
+        }
     }
     seg = (seg + 1) & ~1;
     if (seg > c.out_h) seg = c.out_h;
     a.seg_rows = seg;
-    const dim3 grid((strips + JWAVES - 1) / JWAVES, (c.out_h + seg - 1) / seg, n_frames), block(64 * JWAVES, 1, 1);
+    const dim3 grid((strips * ((c.out_h + seg - 1) / seg) + JWAVES - 1) / JWAVES, 1, n_frames), block(64 * JWAVES, 1, 1);
     const int tailk = FusedTailKind(P), srck = FusedSourceKind(P);
     const size_t lds = LDS_JRING + LDS_D + LDS_DB + (tail_has_table(tailk) ? LDS_T : 0);
     const bool aligned = P.dst_aligned16 && (a.off_x & 3) == 0 && (a.dst_pitch & 15) == 0;
