@@ -40,7 +40,10 @@ for i in range(n):
         c["src_rect"] = (l, t, r, b); rw, rh = r - l, b - t
     fx, fy = float(rng.uniform(0.4, 2.7)), float(rng.uniform(0.4, 2.7))
     if rng.random() < 0.2: fy = fx
+    if os.environ.get("MPCVR_FUZZ_JINC"):       # every case with the one-draw 2-D scaler, most of them at exactly 2x (the fused Jinc2m kernel)
+        c["iUpscaling"] = 5
     mode = rng.random()              # 12 % same size (block convert), 12 % exactly 2x (fused_up2x), 20 % a periodic row ratio, else any ratio (strip kernel)
+    if os.environ.get("MPCVR_FUZZ_JINC") and mode < 0.75: mode = 0.2
     if mode < 0.12: fx = fy = 1.0
     elif mode < 0.24: fx = fy = 2.0
     dw, dh = max(8, int(round(rw * fx))), max(8, int(round(rh * fy)))
@@ -64,6 +67,10 @@ for i in range(n):
         c["window"] = (max(8, dw + int(rng.integers(-20, 40))), max(8, dh + int(rng.integers(-20, 40)))); c["offset"] = (int(rng.integers(-15, 25)), int(rng.integers(-15, 25)))
     if rng.random() < 0.2: c["output_format"] = 1
     if rng.random() < 0.2: c["iTexFormat"] = int(rng.choice([8, 10, 16]))
+    # (Jinc2m behind a PQ / HLG tail with a FORCED 8-bit internal format — a setting AUTO never picks for such sources: the filter's weights sum
+    # to |w| = 1.9, so the one 8-bit code by which two tiers' pow() runs differ comes out as two on every tier, the oracle's own +-4 ulp runs
+    # included; tests/test_parity_gpu.py does not sweep that corner either)
+    if c.get("iUpscaling") == 5 and c.get("iTexFormat") == 8 and c.get("exfmt") in (HDR10, HLG): c["iTexFormat"] = 10
     if rng.random() < 0.1: c["bUseDither"] = 0
     # the rarer switches of the sequencer: rotation / flip (first draw), ProcAmp, blend deinterlace, HDR output modes, Dolby Vision
     if rng.random() < 0.10: c["rotation"] = int(rng.choice([90, 180, 180, 270]))
@@ -115,6 +122,7 @@ for i in range(n):
         # slope > 1 before it is rounded to ten bits)
         # (a 10-bit internal format in front of an operator: one code of the intermediate — the fused tiers' own bar — times a slope of ~3)
         lim = (12 if c.get("hdr_tonemap") else 5) if internal_is_8bit(c) else 4 if ("dovi" in c or c.get("hdr_tonemap")) else 2 if has_tail(c) else 1
+        if c.get("iUpscaling") == 5: lim = max(lim, 2)      # (Jinc2m's weights sum to |w| = 1.9: one code of the 10-bit texture comes out as up to two)
     else:
         d = np.abs(got[..., :3].astype(np.int32) - plain[..., :3].astype(np.int32)); lim = 1
     if i % 5 == 0:      # every fifth case against the CPU oracle as well: the plain tier bit-exact without a transcendental tail,
@@ -128,7 +136,8 @@ for i in range(n):
         dp, dg = dist(plain, want), dist(got, want)
         oracle_cases += 1
         if not has_tail(c):
-            assert dp.max() == 0, f"plain tier vs oracle: max {int(dp.max())}, {int((dp > 0).sum())} channels: {name}"
+            # (Jinc2m: the plain kernel evaluates the windowed jinc per pixel with the device's sinf, the oracle with the host's: last-ulp weights)
+            assert dp.max() <= (1 if c.get("iUpscaling") == 5 else 0), f"plain tier vs oracle: max {int(dp.max())}, {int((dp > 0).sum())} channels: {name}"
             # (default planner, no tail: within the bar on every channel.  Until round 4 a convert texel one code off the oracle's — the fused tiers
             # contracted a*b + c, 1e-4 of the texels of an 8-bit internal format — could leave a Catmull-Rom / Lanczos tap sum two codes off, 1 - 3
             # channels per ~1e6, and this tool counted them; round 5 gave 8-bit internal formats the exact form of the convert stage

@@ -13,7 +13,7 @@ for w in c3hdr c1 hdr4k up1440 down1440 up2160 c5 c4ed jinc1080 dovi4k; do bash 
 KFILTER=k_fused_up2x bash tools/prof_headline.sh headline_final > /dev/null 2>&1
 KFILTER=k_fused_period bash tools/prof_headline.sh period_up1440_final --workload up1440 > /dev/null 2>&1
 KFILTER=k_error_diffusion bash tools/prof_headline.sh errdiff_c4ed_final --workload c4ed > /dev/null 2>&1
-KFILTER=k_jinc2_quad bash tools/prof_headline.sh jinc1080_final --workload jinc1080 > /dev/null 2>&1
+KFILTER=k_fused_jinc2x bash tools/prof_headline.sh jinc1080_final --workload jinc1080 > /dev/null 2>&1
 KFILTER=k_convert_blocks bash tools/prof_headline.sh dovi4k_final --workload dovi4k > /dev/null 2>&1
 # which kernel instantiations the GPU suite launches (tests/test_kernel_coverage.py reads the stats table) + the parity log
 rm -f /tmp/test_times.jsonl
@@ -26,9 +26,15 @@ for wl in c3hdr c3 c4 c4ext c4ed c5 c2 c1 hdr4k up1440 down1440 up1080 down1080 
 done > $O/bench_workloads.jsonl
 python tools/bench_general.py 2>/dev/null | grep "^{" > $O/bench_general.jsonl
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+# the fuzz evidence on the final code: random fused-path cases against the oracle (the tool FAILS on a channel beyond the bar where no
+# transcendental decides the last code), the error-diffusion pass on random shapes against its serial model
+( time timeout 900 python tests/tools/fuzz_strip.py 8000 ) > $O/fuzz_8000.txt 2>&1; echo "rc=$?" >> $O/fuzz_8000.txt
+( time timeout 600 python tests/tools/fuzz_strip.py 3000 777 ) > $O/fuzz_3000_seed777.txt 2>&1; echo "rc=$?" >> $O/fuzz_3000_seed777.txt
+( time MPCVR_FUZZ_JINC=1 timeout 600 python tests/tools/fuzz_strip.py 2000 5 ) > $O/fuzz_2000_jinc.txt 2>&1; echo "rc=$?" >> $O/fuzz_2000_jinc.txt
+( timeout 400 python tests/tools/fuzz_errdiff.py 250 1 2>&1 | tail -8; timeout 400 python tests/tools/fuzz_errdiff.py 250 11 2>&1 | tail -8 ) > $O/fuzz_errdiff.txt
 python bench.py --steps 20 --warmup 5 > $O/bench_driver_shape.json 2> $O/bench_driver_shape.err
 # gpurun merges at most 64 MiB back: keep the tables anyone reads (summaries, stats, traffic, bench lines), drop the raw traces
 K=/tmp/keep_final; rm -rf $K; mkdir -p $K
-cp $O/*_summary.txt $O/traffic_*.json $O/bench_*.json* $O/suite_under_kernel_trace.txt $O/gpu_suite_kernel_stats.csv $O/kernels_by_test.json $O/parity_identical_channels.jsonl $K/ 2>/dev/null
+cp $O/*_summary.txt $O/traffic_*.json $O/bench_*.json* $O/fuzz_*.txt $O/suite_under_kernel_trace.txt $O/gpu_suite_kernel_stats.csv $O/kernels_by_test.json $O/parity_identical_channels.jsonl $K/ 2>/dev/null
 for d in headline_final stream_c1_final stream_hdr4k_final period_up1440_final period_down1440_final errdiff_c4ed_final jinc1080_final dovi4k_final; do f=$(find $O/$d/kt -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $K/${d}_kernel_stats.csv; done
 rm -rf $O/*; cp $K/* $O/; du -sh $O; ls $O

@@ -16,7 +16,7 @@ KERNEL_SOURCES = {
     "up1440": ["vp_fused_period.h", "vp_fused_period.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
     "down1440": ["vp_fused_period.h", "vp_fused_period.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
     "up2160": ["vp_fused_period.h", "vp_fused_period.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
-    "jinc1080": ["vp_jinc.hip", "vp_fused.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
+    "jinc1080": ["vp_fused_jinc.hip", "vp_fused.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
     "dovi4k": ["vp_fused.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
     "c4ed": ["vp_errdiff.hip", "vp_errdiff_core.h", "vp_fused_up2x.h", "vp_fused.hip", "vp_fused_dev.h", "vp_device.h", "vp_params.h"],
 }

@@ -715,6 +715,9 @@ hipError_t LaunchConvertBlocks(const FusedParams &P, const FusedFrame *frames_de
     return hipGetLastError();
 }
 
+#ifndef MPCVR_UP2X_WAVES_HOST
+#define MPCVR_UP2X_WAVES_HOST 3     // = MPCVR_UP2X_WAVES of vp_fused_up2x.h: waves per SIMD the fused 2x kernel is allocated for
+#endif
 hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s)
 {
     static const int seg_env = EnvInt("MPCVR_FUSED_SEG", 0);
@@ -746,6 +749,19 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
         const long want = n_frames > 1 ? 12288 : 3840;
         for (int cand : {180, 144, 120, 108, 90, 72, 60, 48, 36, 24})
             if ((long)strips * ((c.out_h + cand - 1) / cand) * side >= want || cand == 24) { seg = cand; break; }
+        if (n_frames > 1) {
+            // A batch starts together and runs in rounds of the resident waves (3 per SIMD): a half-empty last round costs a whole one, and every
+            // segment walks 6 rows of run-in.  Cost of a candidate = rounds x (rows + 6); the longest segment among the cheapest.  32 frames of
+            // 1080p: 180 rows = 3,072 items = ONE round, 96.2 k frames/s (C2) where the rule above took 36 rows (5 rounds, 17 % run-in): 87.9 k.
+            // (Single frames on the context's lanes do not start together: the measured table above stands for them.)
+            const long resident = (long)DeviceCuCount() * 4 * MPCVR_UP2X_WAVES_HOST;
+            long best = -1;
+            for (int cand : {180, 144, 120, 108, 90, 72, 60, 48, 36, 24}) {
+                const long items = (long)strips * ((c.out_h + cand - 1) / cand) * side;
+                const long cost = ((items + resident - 1) / resident) * (long)(std::min(cand, c.out_h) + 6);
+                if (best < 0 || cost < best) { best = cost; seg = cand; }
+            }
+        }
     }
     seg = (seg + 1) & ~1;
     if (seg > c.out_h) seg = c.out_h;
