@@ -13,19 +13,21 @@ done
 python - "$W" "$STEPS" "$WARM" <<'PY'
 import csv, glob, sys, json
 w, steps, warm = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+# the library's kernels of the step — not bench.py's own bandwidth probe (mpcvr::k_probe_shape: it moves several steps' worth of bytes)
+ours = lambda name: "mpcvr" in name and "k_probe_shape" not in name
 tot = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     s = 0.0; n = 0
     for f in glob.glob(f"gpurun_out/traffic_{w}/{c}/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            if "mpcvr" in r["Kernel_Name"] and r["Counter_Name"] == c:
+            if ours(r["Kernel_Name"]) and r["Counter_Name"] == c:
                 s += float(r["Counter_Value"]); n += 1
     tot[c] = (s, n)
 launches = steps + warm
 sq = {}
 for f in glob.glob(f"gpurun_out/traffic_{w}/SQ_ACTIVE_INST_VALU/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "mpcvr" in r["Kernel_Name"]:
+        if ours(r["Kernel_Name"]):
             sq[r["Counter_Name"]] = sq.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs, SQ_BUSY_CYCLES cycles summed over the 32 shader engines' SQs
 # (MI355X_MICROARCH.md, rocprofv3 units): VALU-busy cycles per SIMD / cycles of the launch
@@ -34,7 +36,7 @@ issue = (sq["SQ_ACTIVE_INST_VALU"] * 4 / 1024) / (sq["SQ_BUSY_CYCLES"] / 32) if 
 dur_ns = 0.0
 for f in glob.glob(f"gpurun_out/traffic_{w}/SQ_ACTIVE_INST_VALU/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
-        if "mpcvr" in r.get("Kernel_Name", ""):
+        if ours(r.get("Kernel_Name", "")):
             dur_ns += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
 mhz = (sq["SQ_BUSY_CYCLES"] / 32) / dur_ns * 1e3 if dur_ns and sq.get("SQ_BUSY_CYCLES") else None
 line = json.dumps({"workload": w, "steps_profiled": launches, "fetch_kb_per_step": tot["FETCH_SIZE"][0] / launches,
