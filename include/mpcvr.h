@@ -327,7 +327,7 @@ int32_t mpcvr_broadcast_param_blob(mpcvr_ctx *ctx, void *nccl_comm, int32_t root
 int32_t mpcvr_get_color_matrix(mpcvr_ctx *ctx, float out12[12]);     /* cm_r, cm_g, cm_b, cm_c */
 int32_t mpcvr_get_extfmt(mpcvr_ctx *ctx, uint32_t *extfmt);           /* after SpecifyExtendedFormat */
 int32_t mpcvr_get_frame_bytes(mpcvr_ctx *ctx, size_t *bytes, int32_t *pitch);
-int32_t mpcvr_get_path_info(mpcvr_ctx *ctx, char *buf, size_t buf_size); /* e.g. "fused_up2x" / "passes:convert,resizeX,resizeY+final" */
+int32_t mpcvr_get_path_info(mpcvr_ctx *ctx, char *buf, size_t buf_size); /* e.g. "fused_up2x" / "fused_jinc2x" / "passes:convert,resizeX,resizeY+final" */
 /* How the last mpcvr_process_batch / mpcvr_process_batch_dovi call ran: "frames=<n>;launches=<kernel launches>[;dovi_runs=<frames>:<tables|frames>,...]".
  * A batch on a whole-batch route launches a handful of kernels whatever n is (one per stage and <= 4 GiB chunk of intermediates); a
  * frame-by-frame one at least n.  dovi_runs: the runs mpcvr_process_batch_dovi cut the frames into and whether a run read its RPUs from the
