@@ -141,6 +141,7 @@ ED_CASES = {
     "fused_2x": dict(GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]),
     "fused_2x_window_offset": dict(GOLDEN_CASES["x2_p010_pq_mitchell_offset"]),                  # x0 = 3: an odd first column
     "strip_1p5x": dict(GOLDEN_CASES["up_1p5x_lanczos3"]),
+    "fused_jinc_2x": dict(GOLDEN_CASES["jinc2_p010_2x_dither"]),                                   # the fused Jinc2m kernel's 10-bit frame (generic epilogue) in front of the pass
     "same_size_pq": dict(cformat=2, w=192, h=80, kind="hdr", seed=901, dst=(192, 80), exfmt=GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]["exfmt"]),
     "tall_1100_rows": dict(cformat=2, w=72, h=1100, kind="noise", seed=902, dst=(72, 1100)),          # 18 bands, each ~20 steps long: they wait for each other all the time
     "wide_700": dict(cformat=2, w=700, h=70, kind="structure", seed=903, dst=(700, 70)),               # two bands, 104 groups each
