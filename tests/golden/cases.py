@@ -234,6 +234,9 @@ FULL_SIZE_CASES = {
     "rot180_540_to_720_pq": dict(cformat=2, w=960, h=540, kind="noise", seed=439, dst=(1280, 720), exfmt=HDR10, iUpscaling=4, rotation=180),
     "down1080_from_4k_lanczos_convolution": dict(cformat=2, w=3840, h=2160, kind="noise", seed=320, dst=(1920, 1080), exfmt=HDR10, iDownscaling=5,
                                                  bInterpolateAt50pct=0),
+    # round 5: the one-draw 2-D scaler at exactly 2x (the fused Jinc2m kernel; the 8-bit source runs the exact form of its convert stage)
+    "jinc_4k_from_1080_pq": dict(cformat=2, w=1920, h=1080, kind="noise", seed=521, dst=(3840, 2160), exfmt=HDR10, iUpscaling=5),
+    "jinc_1440_from_720_nv12": dict(cformat=1, w=1280, h=720, kind="noise", seed=522, dst=(2560, 1440), exfmt=ext(matrix=M709), iUpscaling=5),
 }
 
 # the two ColorFormat_t values no other case carries (P216, YUV422P16): with them the reference-text comparison covers all 39 formats

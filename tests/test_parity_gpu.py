@@ -1038,9 +1038,21 @@ FULL_SIZE_TIERS = {
     "up720_from_240_nv12_catmull": (("FLAG_FORCE_PERIOD", "period", 0.99997), (0, "strip", 0.99997), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY", 1.0)),  # 0.999988 0.999988 1.0
     "flipped_540_to_720_nv12": ((0, "period", 0.99996), ("FLAG_NO_PERIOD", "strip", 0.99996), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY", 1.0)),          # 0.999984 0.999984 1.0
     "rot180_540_to_720_pq": ((0, "period:surface", 0.99936), ("FLAG_NO_PERIOD", "strip:surface", 0.99936), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 0.99992)),   # 0.999683 0.999683 0.999960
+    # round 5: the fused Jinc2m kernel (10-bit internal format behind a PQ tail; 8-bit internal format = the exact form of the convert stage)
+    # (floors = 1 - 2 x (1 - measured), like the rows above; the plain tier evaluates the windowed jinc per pixel with the device's sinf: not bit-identical)
+    "jinc_4k_from_1080_pq": ((0, "fused_jinc2x", 0.99844), ("FLAG_NO_FAST_CONVERT", "passes:convert,resizeX+final", 0.99846),       # 0.999223 0.999230 0.999940
+                             ("FLAG_NO_FUSED", "passes:convert,resizeX+final", 0.99988)),
+    "jinc_1440_from_720_nv12": ((0, "fused_jinc2x", 0.99968), ("FLAG_NO_FAST_CONVERT", "passes:convert,resizeX", 0.9997),          # 0.999844 0.999850 0.999994
+                                ("FLAG_NO_FUSED", "passes:convert,resizeX", 0.99998)),
     "down1080_from_4k_lanczos_convolution": ((0, "strip", 0.99925), ("FLAG_NO_STRIP", "passes:convert,resizeX,resizeY", 0.99928),         # 0.999629 0.999644 0.999960
                                              ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 0.99992)),
 }
+
+
+# Jinc2m's weights sum to |w| = 1.9 (negative ring): behind a PQ tail, where dark saturated colours sit on pow()'s steep end, what the separable
+# filters keep inside one code comes out at two on a handful of channels per frame — each must be shown ill-conditioned (compare_behind_tail),
+# and their number is capped at twice what was measured (3 of 24.9 M channels on every tier)
+FULL_SIZE_BEHIND_A_TAIL = {"jinc_4k_from_1080_pq": 6}
 
 
 @pytest.mark.parametrize("name", sorted(FULL_SIZE_TIERS))
@@ -1060,7 +1072,13 @@ def test_full_size_hip_vs_reference_shader_text(mpcvr, oracle, torch_cuda, name)
         got, info = run_product(mpcvr, torch, c, extra_flags=flags)
         assert info.startswith(path) or (path in ("period", "strip", "period:surface", "strip:surface") and f"kernel=fused_{path}(" in info), (name, flag, info)
         assert bool((got[..., 3] == 255).all())
-        same = compare(got, want, f"{name} flags={flag} [{info}]", exact=(floor == 1.0), min_same=floor)
+        if name in FULL_SIZE_BEHIND_A_TAIL:     # channels beyond 1 LSB must each lie inside the oracle's own +-4 ulp pow() interval, and be few
+            frame, pitch = case_frame(c)
+            same, n_ill = compare_behind_tail(oracle, oracle_params(oracle, c), frame, pitch, got, want, f"{name} flags={flag} [{info}]", min_same=floor,
+                                              cap=FULL_SIZE_BEHIND_A_TAIL[name])
+            print(f"FULLSIZE {name} {flag or 'default'}: {n_ill} ill-conditioned channel(s)")
+        else:
+            same = compare(got, want, f"{name} flags={flag} [{info}]", exact=(floor == 1.0), min_same=floor)
         print(f"FULLSIZE {name} {flag or 'default'} [{info}] vs reference text ({'live' if live else 'recorded hash'}): identical channels {same:.6f}")
 
 
