@@ -1445,6 +1445,22 @@ def test_sweep_every_fused_jinc_instantiation(mpcvr, torch_cuda, tail):
         _tiers_agree(mpcvr, torch_cuda, c, 0, "fused_jinc2x")
 
 
+def test_two_draw_jinc_whose_one_to_one_axis_sits_on_the_floor_step(mpcvr, oracle, torch_cuda):
+    """fuzz_strip.py's Jinc2m mode, seed 9, case 3109: X downscaled by the convolution shader, Y exactly 2x by Jinc2m — the second draw runs 1:1
+    along x over an 88-texel-wide texture, where Tex * wh of four columns lands one ulp below k + 0.5 and the shader's 4 x 4 window sits one
+    texel further left.  The phase-table kernels took the tap base from org + (o + 0.5) * step (up to 53 codes off in those columns on every
+    tier but the plain one); BuildJincPhases now checks every output index against TexCenter and leaves such a draw to the per-pixel kernel."""
+    c = dict(cformat=15, w=438, h=68, kind="noise", seed=426369876, exfmt=_SDR, iChromaScaling=2, iUpscaling=5, iDownscaling=3, bInterpolateAt50pct=0,
+             src_rect=(40, 14, 258, 68), dst=(88, 108))
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+    from videorenderer_amd import api
+    for flags in (0, api.FLAG_NO_FAST_CONVERT, api.FLAG_NO_STRIP):
+        got, info = run_product(mpcvr, torch_cuda, c, extra_flags=flags)
+        compare(got, want, f"two-draw Jinc2m, 1:1 axis on the floor step [{info}] flags={flags}", min_same=0.99)
+
+
 def test_jinc_quad_kernel_behind_a_convert_kernel_of_its_own(mpcvr, torch_cuda):
     """k_jinc2_quad (vp_jinc.hip) still draws the exact-2x Jinc2m frames the fused kernel does not take: Catmull-Rom chroma (the convert is a
     kernel of its own; 8-bit texture, straight store and 10-bit texture, integer final pass) and interleaved RGB (no convert at all)."""

@@ -788,8 +788,12 @@ HRESULT CHipVideoProcessor::UpdatePlan()
     m_jincFusedTab = nullptr;
     if (m_plan.fused_jinc) {
         // the fused Jinc2m kernel's weights: the phase table of a 2x draw (integer origins drop out of it) in the kernel's reading order
+        // (the draw the kernel replaces: the whole m_TexConvertOutput, src-rect sized, onto the video rect; BuildJincPhases checks every
+        // output index's tap base against the shader's own texture coordinate)
         DrawCoords dc{};
         dc.step_x = dc.step_y = 0.5f;
+        dc.len_x = dc.tex_x = m_srcRectWidth; dc.len_y = dc.tex_y = m_srcRectHeight;
+        dc.n_x = m_videoRect.Width(); dc.n_y = m_videoRect.Height();
         std::vector<unsigned char> phases(JincPhasesBytes());
         std::vector<float> tab(FusedJincTableBytes() / sizeof(float));
         if (!BuildJincPhases(dc, phases.data())) m_plan.fused_up2x = m_plan.fused_jinc = false;

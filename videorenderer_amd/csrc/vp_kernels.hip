@@ -1021,6 +1021,19 @@ bool BuildJincPhases(const DrawCoords &dc, void *out_table)
     auto period = [](float step) { return step == 1.0f ? 1 : step == 0.5f ? 2 : step == 0.25f ? 4 : 0; };
     t.px = period(dc.step_x); t.py = period(dc.step_y);
     if (!t.px || !t.py || dc.swap || dc.rev_x || dc.rev_y) return false;
+    // The phase kernels take an output pixel's tap base from org + (o + 0.5) * step; the shader takes it from Tex * wh — the interpolated
+    // texture coordinate (TexCenter), which can sit one ulp beside that.  At 2x / 4x the positions k + 0.25 ... are far from the floor's
+    // step and the ulp changes nothing; on a 1:1 axis (the OTHER axis of a two-draw Jinc2m, always) the position is k + 0.5 — exactly ON the
+    // step: one ulp low and the shader's 4 x 4 window sits a texel further left (found by the Jinc2m mode of tests/tools/fuzz_strip.py: 4 columns
+    // of an 88-wide frame, up to 53 codes).  So: every output index is checked here, and a draw with one such index keeps the per-pixel kernel.
+    auto axis_ok = [](int org, int len, int tex, int n, int rev, float step) {
+        for (int i = 0; i < n; i++) {
+            const float pc = TexCenter(org, len, tex, i, n, rev), nominal = (float)org + ((float)i + 0.5f) * step;
+            if (floorf(pc - 0.5f) != floorf(nominal - 0.5f)) return false;
+        }
+        return true;
+    };
+    if (!axis_ok(dc.org_x, dc.len_x, dc.tex_x, dc.n_x, dc.rev_x, dc.step_x) || !axis_ok(dc.org_y, dc.len_y, dc.tex_y, dc.n_y, dc.rev_y, dc.step_y)) return false;
     const float pi = 3.14159274101257324f, wa = 0.416f * pi, wb = 0.985f * pi;
     for (int py = 0; py < 4; py++)
         for (int px = 0; px < 4; px++) {
