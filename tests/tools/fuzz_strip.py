@@ -40,6 +40,8 @@ for i in range(n):
         c["src_rect"] = (l, t, r, b); rw, rh = r - l, b - t
     fx, fy = float(rng.uniform(0.4, 2.7)), float(rng.uniform(0.4, 2.7))
     if rng.random() < 0.2: fy = fx
+    if os.environ.get("MPCVR_FUZZ_SCALERS"):    # the scalers the default mode leaves out: nearest (0), Jinc2m (5), the Spline36 extension (6)
+        c["iUpscaling"] = int(np.random.default_rng(c["seed"]).choice([0, 5, 6, 6]))
     if os.environ.get("MPCVR_FUZZ_JINC"):       # every case with the one-draw 2-D scaler, most of them at exactly 2x (the fused Jinc2m kernel)
         c["iUpscaling"] = 5
     mode = rng.random()              # 12 % same size (block convert), 12 % exactly 2x (fused_up2x), 20 % a periodic row ratio, else any ratio (strip kernel)
