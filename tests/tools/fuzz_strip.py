@@ -34,9 +34,13 @@ for i in range(n):
              iUpscaling=int(rng.choice([1, 2, 3, 4])), iDownscaling=int(rng.integers(0, 6)), bInterpolateAt50pct=int(rng.integers(0, 2)))
     rw, rh = w, h
     if cf in (27, 28, 26, 30, 32): c.pop("exfmt")
-    if rng.random() < 0.4 and cf not in (30, 32):
+    if rng.random() < (0.9 if os.environ.get("MPCVR_FUZZ_UNALIGNED") else 0.4) and cf not in (30, 32):
         l = int(rng.integers(0, w // 8)) * 4; t = int(rng.integers(0, h // 8)) * 2
         r = min(w, l + max(16, int(rng.integers(w // 2, w)) // 2 * 2)); b = min(h, t + max(16, int(rng.integers(h // 2, h)) // 2 * 2))
+        if os.environ.get("MPCVR_FUZZ_UNALIGNED"):      # source rects on ANY pixel (the default mode keeps them on the 4 x 2 grid the vectorised loaders want)
+            jr = np.random.default_rng(c["seed"] ^ 0x5a5a)
+            l = min(l + int(jr.integers(0, 4)), w - 18); t = min(t + int(jr.integers(0, 2)), h - 18)
+            r = max(l + 16, min(w, r - int(jr.integers(0, 4)))); b = max(t + 16, min(h, b - int(jr.integers(0, 2))))
         c["src_rect"] = (l, t, r, b); rw, rh = r - l, b - t
     fx, fy = float(rng.uniform(0.4, 2.7)), float(rng.uniform(0.4, 2.7))
     if rng.random() < 0.2: fy = fx
