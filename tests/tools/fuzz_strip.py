@@ -97,7 +97,7 @@ for i in range(n):
         c.pop("window", None); c.pop("offset", None)
     try:
         plain, _ = run_product(api, torch, c, extra_flags=api.FLAG_NO_FUSED)
-        got, info = run_product(api, torch, c)
+        got, info = run_product(api, torch, c, host_upload=bool(os.environ.get("MPCVR_FUZZ_HOST")))      # (MPCVR_FUZZ_HOST: the sample through mpcvr_copy_sample's host path — pinned ring, copy stream, device repacks)
     except api.MpcvrError:
         refused += 1; continue
     parts = info.split(";")
