@@ -73,6 +73,8 @@ WORKLOADS = {
     # the two slowest reference-pinned rows (round-5 counter digests: profiles/r05/jinc1080_*, dovi4k_*)
     "jinc1080": dict(cformat=2, w=1920, h=1080, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),
                      iUpscaling=5, desc="1080p P010 BT.2020/PQ -> Jinc2m 2x (ps_resize_onepass_jinc2) -> PQ->SDR -> ordered dither -> 4K BGRA8"),
+    "jinc1080_nv12": dict(cformat=1, w=1920, h=1080, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=1, primaries=2, transfer=5),
+                          iUpscaling=5, desc="1080p NV12 BT.709 -> Jinc2m 2x -> 4K BGRA8 (8-bit internal format: the exact form of the convert stage, no dither)"),
     "dovi4k": dict(cformat=2, w=3840, h=2160, scale=1, ext=dict(chroma=5, nominal_range=2), iUpscaling=4, dovi=("mmr", (100, 600, 1000)),
                    desc="4K P010 Dolby Vision (MMR chroma curves, level-2 trims) -> SDR -> ordered dither -> 4K BGRA8, no resize"),
     "c3hdr_1080p": dict(cformat=2, w=1920, h=1080, scale=2, ext=dict(chroma=5, nominal_range=2, matrix=4, primaries=9, transfer=15),

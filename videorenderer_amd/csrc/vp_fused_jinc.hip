@@ -39,7 +39,15 @@ constexpr int JSLOTS = MPCVR_JINC_SLOTS;           // row pairs in the ring: the
                                                    // the first version, 2 waves per SIMD; 3 slots and stage C behind stage J: 12 waves, 3 per SIMD)
 constexpr int JSLOT_FLOATS = 3 * 2 * AW;           // [channel][row][column]
 constexpr int JRING_FLOATS = JSLOTS * JSLOT_FLOATS;
-constexpr int LDS_JRING = JWAVES * JRING_FLOATS * 4;
+// waves per workgroup by tail kind.  Without a tail there is no tone-map table in LDS and (with the anti-ringing state kept as texel pairs) the
+// kernel fits 128 VGPRs: 16 waves = 4 per SIMD are possible — built and measured on one box (1080p NV12 -> 4K, bench.py --workload
+// jinc1080_nv12): 47.0 k frames/s against 47.9 k with 12 waves.  The kernel issues VALU instructions three quarters of the time with three
+// waves per SIMD; a fourth adds 16-wave workgroup granularity and nothing else.  The knob stays (-DMPCVR_JINC_WAVES_NOTAIL=16).
+#ifndef MPCVR_JINC_WAVES_NOTAIL
+#define MPCVR_JINC_WAVES_NOTAIL 12
+#endif
+__host__ __device__ constexpr int jinc_waves(int tail) { return tail == TAILK_NONE ? MPCVR_JINC_WAVES_NOTAIL : JWAVES; }
+__host__ __device__ constexpr int jinc_ring_bytes(int tail) { return jinc_waves(tail) * JRING_FLOATS * 4; }
 // the host's weight table (FusedJincTable): [source row sr of the 5-row neighbourhood][output row parity rp][column parity cp][tap i] =
 // w[rp][cp][(sr - rp) * 4 + i], zero where sr - rp is no tap row; then 1 / wsum per phase [rp][cp]
 constexpr int JTAB_W = 5 * 16, JTAB_FLOATS = JTAB_W + 4;
@@ -72,17 +80,18 @@ __device__ __forceinline__ void fused_jinc2x_body(const FusedArgs &P, const floa
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *Rall = (float *)smem;
+    constexpr int JW = jinc_waves(TAIL), LDS_JRING = jinc_ring_bytes(TAIL);
     unsigned short *D = (unsigned short *)(smem + LDS_JRING);
     uint32_t *Di = (uint32_t *)(smem + LDS_JRING + LDS_D);
     f2 *T = (f2 *)(smem + LDS_JRING + LDS_D + LDS_DB);
 
-    for (int i = threadIdx.x; i < 1024; i += 64 * JWAVES) {
+    for (int i = threadIdx.x; i < 1024; i += 64 * JW) {
         const unsigned short d = P.dither[i];
         D[i] = d;
         Di[i] = (uint32_t)(__half2float(__ushort_as_half(d)) * 1024.0f + 0.5f) << 14;     // d = j/1024 exactly (dither32x32float16.bin)
     }
     if (tail_has_table(TAIL))
-        for (int i = threadIdx.x; i < LUT_N; i += 64 * JWAVES) {
+        for (int i = threadIdx.x; i < LUT_N; i += 64 * JW) {
             const float v = P.lut[i], n = P.lut[min(i + 1, LUT_N - 1)];
             T[i] = f2{v, n - v};
         }
@@ -93,7 +102,7 @@ __device__ __forceinline__ void fused_jinc2x_body(const FusedArgs &P, const floa
     // work items = (strip, segment) pairs, strips fastest, dealt to the waves of the workgroups in order: a frame's 16 strips need not be a
     // multiple of the workgroup's waves (12 waves by whole rows of strips: the second workgroup of a row two thirds empty — 28.7 k instead of 37 k frames/s)
     const int n_strips = (W + S - 1) / S;
-    const int item = blockIdx.x * JWAVES + wave;
+    const int item = blockIdx.x * JW + wave;
     const int x0 = (item % n_strips) * S;
     const int s0 = (item / n_strips) * P.seg_rows;
     if (s0 >= H) return;
@@ -186,8 +195,10 @@ __device__ __forceinline__ void fused_jinc2x_body(const FusedArgs &P, const floa
             for (int qr = 0; qr < 2; qr++) {
                 const int k = a - 2 + qr;                       // source row -> output rows 2k, 2k+1
                 if (k < s0 || k >= s1) continue;                // (wave-uniform: the neighbouring segments' rows)
-                f2 acc[2][2][3], mn[2][2][3], mx[2][2][3];      // [row parity][column parity][channel] = (left quad, right quad)
-                f2 prv[3][5];                                   // the previous source row's pairs (anti-ringing reads two rows)
+                f2 acc[2][2][3];                                // [row parity][column parity][channel] = (left quad, right quad)
+                f2 in1[3][3], in2[3][3];                        // the inner pairs (m = 1 .. 3) of the previous source row and of the one before: what the
+                                                                // anti-ringing clamp of the row being finished reads (36 registers; its min / max are formed
+                                                                // where they are used — per pixel and held from tap row 2 on they were 48 + a full previous row)
 #pragma unroll
                 for (int sr = 0; sr < 5; sr++) {
                     const int ri = qr + sr;                     // row of the six this iteration's quads read: rows a-4 .. a+1
@@ -217,16 +228,6 @@ __device__ __forceinline__ void fused_jinc2x_body(const FusedArgs &P, const floa
                                     if (j == 0 && i == 0) acc[rp][cp][c] = (i & 1) ? pk_mul_w<1>(w, x) : pk_mul_w<0>(w, x);
                                     else acc[rp][cp][c] = (i & 1) ? pk_fma_w<1, false>(w, x, acc[rp][cp][c]) : pk_fma_w<0, false>(w, x, acc[rp][cp][c]);
                                 }
-                        if (j == 2) {           // inner 2x2 = tap rows 1, 2 x tap columns 1, 2
-#pragma unroll
-                            for (int cp = 0; cp < 2; cp++)
-#pragma unroll
-                                for (int c = 0; c < 3; c++) {
-                                    const f2 p1 = prv[c][cp + 1], p2 = prv[c][cp + 2], q1 = pr[c][cp + 1], q2 = pr[c][cp + 2];
-                                    mn[rp][cp][c] = f2{jmin4(p1.x, p2.x, q1.x, q2.x), jmin4(p1.y, p2.y, q1.y, q2.y)};
-                                    mx[rp][cp][c] = f2{jmax4(p1.x, p2.x, q1.x, q2.x), jmax4(p1.y, p2.y, q1.y, q2.y)};
-                                }
-                        }
                         if (j != 3) continue;
                         // ---- the output row 2k + rp is complete: normalise, anti-ringing, final pass, store ----
                         const f2 iw = f2{jtab[JTAB_W + 2 * rp], jtab[JTAB_W + 2 * rp + 1]};          // 1 / wsum of (rp, cp = 0), (rp, cp = 1)
@@ -237,7 +238,10 @@ __device__ __forceinline__ void fused_jinc2x_body(const FusedArgs &P, const floa
                             for (int cp = 0; cp < 2; cp++) {
                                 const f2 v = cp ? pk_mul_w<1>(iw, acc[rp][cp][c]) : pk_mul_w<0>(iw, acc[rp][cp][c]);
                                 // clamp(v, mn, mx) with mn <= mx is the median of the three
-                                const f2 cl = f2{__builtin_amdgcn_fmed3f(v.x, mn[rp][cp][c].x, mx[rp][cp][c].x), __builtin_amdgcn_fmed3f(v.y, mn[rp][cp][c].y, mx[rp][cp][c].y)};
+                                // inner 2x2 = tap rows 1, 2 (the two source rows in front of this one) x tap columns 1, 2 (pairs cp + 1, cp + 2)
+                                const f2 p1 = in2[c][cp], p2 = in2[c][cp + 1], q1 = in1[c][cp], q2 = in1[c][cp + 1];
+                                const f2 lo = f2{jmin4(p1.x, p2.x, q1.x, q2.x), jmin4(p1.y, p2.y, q1.y, q2.y)}, hi = f2{jmax4(p1.x, p2.x, q1.x, q2.x), jmax4(p1.y, p2.y, q1.y, q2.y)};
+                                const f2 cl = f2{__builtin_amdgcn_fmed3f(v.x, lo.x, hi.x), __builtin_amdgcn_fmed3f(v.y, lo.y, hi.y)};
                                 fin[c][cp] = pk_fma_w<0, true>(k08, cl - v, v);             // lerp(v, cl, 0.8), saturated (every store below clamps to 0..1)
                             }
                         const int wy = P.off_y + 2 * k + rp;
@@ -307,7 +311,7 @@ __device__ __forceinline__ void fused_jinc2x_body(const FusedArgs &P, const floa
 #pragma unroll
                     for (int c = 0; c < 3; c++)
 #pragma unroll
-                        for (int m = 0; m < 5; m++) prv[c][m] = pr[c][m];
+                        for (int m = 0; m < 3; m++) { in2[c][m] = in1[c][m]; in1[c][m] = pr[c][m + 1]; }
                 }
             }
             }
@@ -321,7 +325,7 @@ __device__ __forceinline__ void fused_jinc2x_body(const FusedArgs &P, const floa
 }
 
 template <int TAIL, int SRC, int EPI, int XC = XC_NEVER>
-__global__ __launch_bounds__(64 * JWAVES) void k_fused_jinc2x(FusedArgs P, const float *__restrict__ jtab, const FusedFrame *__restrict__ frames, FusedFrame single)
+__global__ __launch_bounds__(64 * jinc_waves(TAIL)) void k_fused_jinc2x(FusedArgs P, const float *__restrict__ jtab, const FusedFrame *__restrict__ frames, FusedFrame single)
 {
     fused_jinc2x_body<TAIL, SRC, EPI, XC>(P, jtab, frames, single);
 }
@@ -358,13 +362,14 @@ hipError_t LaunchFusedJinc2x(const FusedParams &P, const FusedArgs &a_in, const 
     const ConvertParams &c = P.conv;
     FusedArgs a = a_in;
     const int strips = (c.out_w + S - 1) / S;
+    const int tailk = FusedTailKind(P), srck = FusedSourceKind(P), jw = jinc_waves(tailk);
     int seg = seg_env;
     if (seg <= 0) {
         // One workgroup per CU (LDS), so a launch runs in rounds of CUs x 12 waves and a last round that is half empty costs a whole one
         // (32 frames of 1080p: 90-row segments = 6,144 items = 2 rounds: 45.7 k frames/s; 120 rows = 1.5 rounds: 35.7 k; 72 rows = 2.5: 39.0 k).
         // Cost of a candidate = rounds x rows an item walks (its segment + 7 rows of run-in); the longest segment among the cheapest.
         const long side = (long)n_frames * (P.inflight > 1 ? P.inflight : 1);
-        const long resident = (long)DeviceCuCount() * JWAVES;
+        const long resident = (long)DeviceCuCount() * jw;
         long best = -1;
         for (int cand : {180, 144, 120, 108, 90, 72, 60, 48, 36, 24}) {
             const long items = (long)strips * ((c.out_h + cand - 1) / cand) * side;
@@ -375,9 +380,8 @@ hipError_t LaunchFusedJinc2x(const FusedParams &P, const FusedArgs &a_in, const 
     seg = (seg + 1) & ~1;
     if (seg > c.out_h) seg = c.out_h;
     a.seg_rows = seg;
-    const dim3 grid((strips * ((c.out_h + seg - 1) / seg) + JWAVES - 1) / JWAVES, 1, n_frames), block(64 * JWAVES, 1, 1);
-    const int tailk = FusedTailKind(P), srck = FusedSourceKind(P);
-    const size_t lds = LDS_JRING + LDS_D + LDS_DB + (tail_has_table(tailk) ? LDS_T : 0);
+    const dim3 grid((strips * ((c.out_h + seg - 1) / seg) + jw - 1) / jw, 1, n_frames), block(64 * jw, 1, 1);
+    const size_t lds = jinc_ring_bytes(tailk) + LDS_D + LDS_DB + (tail_has_table(tailk) ? LDS_T : 0);
     const bool aligned = P.dst_aligned16 && (a.off_x & 3) == 0 && (a.dst_pitch & 15) == 0;
     const int epik = !aligned ? EPI_GENERIC
                    : (!a.out10 && a.final_pass && a.epi_mul != 0) ? EPI_DITHER8
