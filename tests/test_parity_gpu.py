@@ -1461,6 +1461,30 @@ def test_two_draw_jinc_whose_one_to_one_axis_sits_on_the_floor_step(mpcvr, oracl
         compare(got, want, f"two-draw Jinc2m, 1:1 axis on the floor step [{info}] flags={flags}", min_same=0.99)
 
 
+def test_block_convert_in_front_of_a_tone_mapping_operator_carries_the_exact_codes(mpcvr, torch_cuda):
+    """fuzz_strip.py with the tier flags on the product side, seed 208, case 600: HDR10 output through tone-mapping operator 5 — one code of the
+    10-bit intermediate by which the block convert (contracted FMAs) differed from the per-pixel convert came out of the operator's curve as
+    FIVE ten-bit codes.  Plans with an operator now take the exact form of the convert stage for 10-bit internal formats too
+    (FusedParams::exact_wide): the tier with the block convert and the tier with the per-pixel convert draw the same frame, bit for bit."""
+    from videorenderer_amd import api
+    c = dict(cformat=2, w=608, h=156, kind="noise", seed=173819605, exfmt=2051155200, iChromaScaling=2, iUpscaling=2, iDownscaling=5, bInterpolateAt50pct=0,
+             dst=(137, 332), rotation=90, hdr_output=1, output_format=1, hdr_tonemap=5, hdr_display=400.0, hdr_meta=(0.005, 4000.0, 0.0, 0.0))
+    block, info_b = run_product(mpcvr, torch_cuda, c)
+    pixel, info_p = run_product(mpcvr, torch_cuda, c, extra_flags=api.FLAG_NO_FAST_CONVERT)
+    assert "hdr10tonemap" in info_b and "hdr10tonemap" in info_p, (info_b, info_p)
+    assert np.array_equal(block, pixel), f"{(block != pixel).any(axis=2).sum()} pixels differ between the block convert and the per-pixel convert in front of the operator"
+    for cf, chroma in ((2, 1), (1, 1), (20, 2)):        # bilinear chroma, an 8-bit source, three planes: the other loaders' exact twins in front of an operator
+        c2 = dict(c, cformat=cf, iChromaScaling=chroma, rotation=0, dst=(760, 208), w=608, h=156)
+        if cf == 1:
+            c2["iTexFormat"] = 10
+        block, _ = run_product(mpcvr, torch_cuda, c2)
+        pixel, _ = run_product(mpcvr, torch_cuda, c2, extra_flags=api.FLAG_NO_FAST_CONVERT | api.FLAG_NO_STRIP)
+        ref, _ = run_product(mpcvr, torch_cuda, c2, extra_flags=api.FLAG_NO_FUSED)
+        g, r = block.view(np.uint32)[..., 0], ref.view(np.uint32)[..., 0]
+        d = max(int(np.abs(((g >> sh) & 1023).astype(np.int32) - ((r >> sh) & 1023).astype(np.int32)).max()) for sh in (0, 10, 20))
+        assert d <= 2, (cf, d)          # the fused resize tiers keep their own <= 1-code bar on the post-scale texture; the operator may double it
+
+
 def test_jinc_quad_kernel_behind_a_convert_kernel_of_its_own(mpcvr, torch_cuda):
     """k_jinc2_quad (vp_jinc.hip) still draws the exact-2x Jinc2m frames the fused kernel does not take: Catmull-Rom chroma (the convert is a
     kernel of its own; 8-bit texture, straight store and 10-bit texture, integer final pass) and interleaved RGB (no convert at all)."""

@@ -97,14 +97,14 @@ for i in range(n):
         c.pop("window", None); c.pop("offset", None)
     try:
         plain, _ = run_product(api, torch, c, extra_flags=api.FLAG_NO_FUSED)
-        got, info = run_product(api, torch, c, host_upload=bool(os.environ.get("MPCVR_FUZZ_HOST")))      # (MPCVR_FUZZ_HOST: the sample through mpcvr_copy_sample's host path — pinned ring, copy stream, device repacks)
+        got, info = run_product(api, torch, c, extra_flags=int(os.environ.get("MPCVR_FUZZ_FLAGS", "0")), host_upload=bool(os.environ.get("MPCVR_FUZZ_HOST")))      # (MPCVR_FUZZ_HOST: the sample through mpcvr_copy_sample's host path — pinned ring, copy stream, device repacks)
     except api.MpcvrError:
         refused += 1; continue
     parts = info.split(";")
     kern = [q for q in parts if q.startswith("kernel=")]
     paths[kern[0].split("(")[0] if kern else parts[0].split("+")[0] + "".join(";" + q for q in parts[1:] if q.startswith("rot"))] += 1
     if i % 4 == 0:      # every fourth case also as a batch: mpcvr_process_batch of three distinct frames == three mpcvr_process calls, bit for bit
-        vp, (ww, wh) = make_vp(api, c)
+        vp, (ww, wh) = make_vp(api, c, int(os.environ.get("MPCVR_FUZZ_FLAGS", "0")))
         frames = [torch.from_numpy(case_frame(dict(c, seed=c["seed"] + 7 * k))[0]).cuda() for k in range(3)]
         pitch = vp.GetFrameBytes()[1]
         singles = []

@@ -1024,6 +1024,7 @@ void CHipVideoProcessor::FillFusedParams(const uint8_t *sample, void *rt, int rt
     fp->dovi_l2 = (m_doviValid && m_doviHost.l2_enabled) ? 1 : 0;
     fp->dovi_cm = (m_doviValid && m_dvTabDev) ? m_dvCmDev : nullptr;
     fp->jinc_tab = m_plan.fused_jinc ? m_jincFusedTab : nullptr;
+    fp->exact_wide = m_plan.hdr_tonemap ? 1 : 0;
     fp->taps_mfma = (m_cfg.flags & MPCVR_FLAG_FUSED_MFMA) ? 1 : (m_cfg.flags & MPCVR_FLAG_FUSED_VALU) ? 0 : -1;
     fp->inflight = m_inflight;
     fp->dst_aligned16 = (((uintptr_t)rt) & 15) == 0;        // batches: ProcessBatch checks every target

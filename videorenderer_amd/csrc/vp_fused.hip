@@ -495,7 +495,10 @@ void FillFusedArgs(const FusedParams &P, FusedArgs &a, int resize_follows)
     // the reference's comes out of a negative-lobe filter up to two codes off.  10-bit internal formats keep the fast form (the same effect
     // is a quarter of an 8-bit code), and so do the tails (their own transcendentals decide the last code) and Dolby Vision.
     static const int exact8 = EnvInt("MPCVR_EXACT8", 1);          // 0: the fast form everywhere (A/B)
-    a.exact_cv = (exact8 && (resize_follows >= 0 ? resize_follows : P.exact_convert) && c.out_fmt == SF_BGRA8 && c.tail == TAIL_NONE && !dv) ? 1 : 0;
+    // ... and, round 5's last finding (the fuzz tool with the tier flags, seed 208, case 600): 10-bit internal formats too where an HDR10 tone-mapping
+    // operator follows — one code of the intermediate came out of operator 5 as five ten-bit codes
+    const bool exact_fmt = c.out_fmt == SF_BGRA8 || (P.exact_wide && c.out_fmt == SF_RGB10A2);
+    a.exact_cv = (exact8 && ((resize_follows >= 0 ? resize_follows : P.exact_convert) || P.exact_wide) && exact_fmt && c.tail == TAIL_NONE && !dv) ? 1 : 0;
     for (int i = 0; i < 9; i++) a.xm[i] = c.cm[i];
     for (int i = 0; i < 3; i++) a.xc[i] = c.cm[9 + i];
     {
@@ -545,7 +548,7 @@ int FusedSourceKind(const FusedParams &P)
     if (c.fmt.bytes == 1 && c.tail != TAIL_NONE) return SRC_GENERIC;
     // 16-bit samples behind a forced 8-bit internal format (TEXFMT_8INT on a P010 / YUV420P10 stream: hardly ever): the exact form of the convert
     // stage lives in the 8-bit loaders and in the run-time variant only (exact_capable, vp_fused_dev.h) — the 16-bit loaders keep their registers
-    if (c.fmt.bytes == 2 && c.out_fmt == SF_BGRA8 && c.tail == TAIL_NONE && !c.dovi) return SRC_GENERIC;
+    if (c.fmt.bytes == 2 && (c.out_fmt == SF_BGRA8 || (P.exact_wide && c.out_fmt == SF_RGB10A2)) && c.tail == TAIL_NONE && !c.dovi) return SRC_GENERIC;
     const bool biplanar_fast = c.fmt.planes == 2 && !centred, planar_fast = c.fmt.planes == 3 && !centred;
     return (biplanar_fast && c.fmt.bytes == 2) ? SRC_P01X : (biplanar_fast && c.fmt.bytes == 1) ? SRC_NV12
          : (planar_fast && c.fmt.bytes == 2) ? SRC_PLANAR16 : (planar_fast && c.fmt.bytes == 1) ? SRC_PLANAR8 : SRC_GENERIC;
