@@ -8,8 +8,9 @@
 // results (the 2-D filter is not separable: there is no X pass to park):
 //   one wavefront owns a strip of S = 120 source columns (4-column halo each side; the filter needs 2) and marches down a segment two
 //   source rows per iteration, no workgroup barrier in the loop:
-//     stage C  (= the fused 2x kernel's) lane j converts the 2x2 block {cols 2j, 2j+1} x {rows a, a+1}, rounds it to the internal UNORM
-//              format and writes it as 0..1 floats into slot t & 3 of the wave's ring: R[slot][channel][row][128 columns];
+//     stage C  (= the fused 2x kernel's) lane j converts the 2x2 block {cols 2j, 2j+1} x {rows a, a+1} (a odd: the two rows lie between the
+//              same two chroma rows), rounds it to the internal UNORM format and writes it as 0..1 floats into slot t mod 3 of the wave's
+//              ring: R[slot][channel][row][128 columns];
 //     stage J  lane l owns source columns 2l, 2l+1 and, this iteration, source rows k = a-2, a-1: four 2x2 output quads.  The two quads of
 //              a source row sit one column apart and see the SAME four phases, so a packed FMA serves both: its operand is the pair of
 //              horizontally adjacent texels (v[m], v[m+1]), m = 0..4 — the even pairs are aligned 8-byte reads of the ring row, the odd
@@ -142,7 +143,7 @@ __device__ __forceinline__ void fused_jinc2x_body(const FusedArgs &P, const floa
     asm volatile("" : "+v"(CC[0]), "+v"(CC[1]), "+v"(CC[2]));
     const f2 k08 = f2{0.8f, 0.0f};                    // the anti-ringing strength (ps_resize_onepass_jinc2.hlsl: AR_STRENGTH)
 
-    // iteration t converts virtual rows a, a+1 with a = s0 - 3 + 2t into slot t & 3 — an ODD row first: rows 2m-1, 2m lie between the same two
+    // iteration t converts virtual rows a, a+1 with a = s0 - 3 + 2t into slot t mod 3 — an ODD row first: rows 2m-1, 2m lie between the same two
     // chroma rows (load_raw fetches the pair's chroma once), rows 2m, 2m+1 do not — and from t = 2 on emits the output rows of k = a-2, a-1
     // (the first of them belongs to the segment above in the first emitting iteration, the second to the one below in the last)
     const int n_iter = (s1 - s0 + 1) / 2 + 3;
