@@ -12,8 +12,12 @@ ring of distinct noise frames (48 x 24.9 MB = 1.2 GB, far beyond the 256 MiB Inf
 re-reads cached input, and every frame is written to its own 132.7 MB output buffer.
 
     python bench.py                       # N=1, finishes in a few minutes incl. the CPU baseline
+    python bench.py --gpus 8 --steps 50 --warmup 5      # starts its own 8 ranks (one per GPU) under torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
-        bench.py --gpus 8 --steps 50 --warmup 5
+        bench.py --gpus 8 --steps 50 --warmup 5         # the driver's form: the ranks exist already, nothing is spawned
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes this file under torch.distributed.run with N
+ranks (refusing when fewer than N devices are visible); a rank whose WORLD_SIZE differs from --gpus FAILS.
 
 Prints ONE JSON line on rank 0.
 """
@@ -235,6 +239,64 @@ def cpu_baseline(wl, extfmt, seconds_budget=10.0):
         return {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"FAILED: {type(e).__name__}: {e} (traceback on stderr)", "rows": rows}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` from a plain shell: start the N ranks ourselves — one process per GPU under torch.distributed.run on
+    127.0.0.1, the same command line the driver uses — and hand back its exit code.  Refuses when fewer than N devices are visible
+    (MPCVR_DIST_BACKEND=gloo is the single-GPU rehearsal of the flow: there the ranks share what devices there are, on purpose,
+    and the line says so).  --rendezvous-only needs no device at all."""
+    import subprocess
+    rehearsal = os.environ.get("MPCVR_DIST_BACKEND") == "gloo"
+    if "--rendezvous-only" not in argv:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < 1:
+            raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+        if have < n and not rehearsal:
+            raise SystemExit(f"bench.py: --gpus {n} but only {have} device(s) visible: refusing to put two ranks on one GPU "
+                             f"(MPCVR_DIST_BACKEND=gloo rehearses the multi-rank flow on fewer devices)")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL between processes needs on this driver
+    env["MPCVR_BENCH_SPAWNED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def rendezvous_only(args, vdist):
+    """--rendezvous-only: everything of the N-rank flow that is not pixels — rendezvous, the parameter-blob broadcast (a stand-in blob),
+    MAX over ranks, every rank's self-description gathered on rank 0 — and a line of the same shape as the real one.  Runs without a
+    GPU (gloo), so the launcher and the rank bookkeeping are covered by the CPU suite."""
+    import torch
+    rank, world, local = vdist.init_from_env()
+    if world != max(1, args.gpus):
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}")
+    dev = torch.device("cuda", local % torch.cuda.device_count()) if torch.cuda.is_available() else torch.device("cpu")
+    blob = vdist.broadcast_blob(bytes(range(256)) * 28 if rank == 0 else None, device=dev if dev.type == "cuda" and vdist.describe_backend().get("backend") == "nccl" else torch.device("cpu"))
+    assert blob == bytes(range(256)) * 28, "rank %d holds a different parameter blob" % rank
+    frames = vdist.shard_frames(world * args.steps, rank, world)
+    elapsed = vdist.max_over_ranks(1.0 + 0.001 * rank, device=torch.device("cpu") if vdist.describe_backend().get("backend") != "nccl" else None)
+    ranks = vdist.gather_objects({"rank": rank, "local_rank": local, "device_index": dev.index, "device": str(dev), "pci_bus_id": None,
+                                  "visible": None, "frames": len(frames), "pid": os.getpid()})
+    if rank == 0:
+        print(json.dumps({"metric": "rendezvous only (no pixels)", "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "scaling": "weak", "max_over_ranks_check": elapsed,
+                          "config": {"workload": "none", "spawned_by_bench": bool(os.environ.get("MPCVR_BENCH_SPAWNED")),
+                                     "distributed": dict(vdist.describe_backend(), devices=ranks)}}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,16 +313,28 @@ def main():
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive (host sample) measurement")
     ap.add_argument("--src", default=None, help="WxH: override the workload's source size (secondary rows, e.g. 1920x1080)")
     ap.add_argument("--scale", type=int, default=None, help="integer upscale factor override (the fused kernel covers 2)")
+    ap.add_argument("--rendezvous-only", action="store_true", help="the N-rank flow without pixels (rendezvous, blob broadcast, reductions, the line's "
+                    "distributed block): runs without a GPU; the CPU suite's check of `--gpus N` starting its own ranks")
     args = ap.parse_args()
+
+    # `--gpus N` from a plain shell starts its own N ranks (round 6: it used to warn and measure ONE GPU)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    if args.rendezvous_only:
+        from videorenderer_amd import dist as vdist
+        return rendezvous_only(args, vdist)
 
     import torch
     from videorenderer_amd import api, dist as vdist
 
     rank, world, local = vdist.init_from_env()
-    if world != max(1, args.gpus) and rank == 0:
-        print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
+    if world != max(1, args.gpus):
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: the line would not describe the run that was asked for")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    if world > torch.cuda.device_count() and os.environ.get("MPCVR_DIST_BACKEND") != "gloo":
+        raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible device(s)")
     torch.cuda.set_device(local % torch.cuda.device_count())
     dev = torch.cuda.current_device()
 

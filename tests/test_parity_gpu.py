@@ -2349,6 +2349,34 @@ def test_bench_two_ranks_one_gpu(mpcvr, torch_cuda):
     assert abs(r["config"]["fps_per_gpu"] * 2 - r["value"]) < 1e-2 * r["value"]
 
 
+def test_bench_gpus_2_starts_its_own_ranks(mpcvr, torch_cuda):
+    """`python bench.py --gpus 2` from a plain shell (no torchrun, no WORLD_SIZE): the script starts its own two ranks (round 6: it used to
+    warn and measure one GPU) — here over gloo on this box's one device, the rehearsal mode — and the line describes a world of two."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MPCVR_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--ring", "2", "--src", "256x144", "--no-cpu-baseline", "--no-host-path"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    d = r["config"]["distributed"]
+    assert r["n_gpus"] == 2 and d["world_size"] == 2 and d["backend"] == "gloo" and len(d["devices"]) == 2
+    assert sorted(x["rank"] for x in d["devices"]) == [0, 1]
+    assert r["value"] > 0 and abs(r["config"]["fps_per_gpu"] * 2 - r["value"]) < 1e-2 * r["value"]
+    # without the rehearsal backend two ranks on ONE device are refused before anything is spawned (the box has one GPU)
+    if torch_cuda.cuda.device_count() < 2:
+        env.pop("MPCVR_DIST_BACKEND")
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert out.returncode != 0 and "refusing" in out.stderr, (out.returncode, out.stderr[-500:])
+        assert not [l for l in out.stdout.splitlines() if l.startswith("{")], "a refused run must not print a line"
+
+
 # ------------------------------------------------------------------------------------------------
 # 8-bit internal formats in front of a resize (round 5): the convert stage of the block / fused kernels takes its EXACT form there
 # (FusedArgs::exact_cv, convert_block_exact in csrc/vp_fused_dev.h): every texel of m_TexConvertOutput carries the oracle's code, so a
