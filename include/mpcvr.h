@@ -415,6 +415,15 @@ int32_t mpcvr_plan_describe(const mpcvr_settings *s, int32_t cformat, int32_t re
  * B8G8R8A8 target out is 1 : 5.33) with no arithmetic.  dst holds fan * src_bytes bytes; stream = a hipStream_t or NULL. */
 int32_t mpcvr_bandwidth_probe(const void *src_dev, void *dst_dev, size_t src_bytes, int32_t fan, void *stream);
 
+/* A verification aid, not part of the video path: the transcendentals of the pass-per-kernel tier (csrc/vp_crmath.h — HLSL's
+ * pow(x, y) = exp2(y * log2(x)) as d3dcompiler lowers it, Shaders/convert/st2084.hlsl:9-25, with every step the correctly rounded fp32
+ * function) evaluated on the device over n floats: fn = 0 log2f(x), 1 exp2f(x), 2 expf(x), 3 powf(x, y), 4 sinf(x), 5 cosf(x) (the last two:
+ * the windowed sinc / jinc weights of the resize shaders, ps_interpolation_lanczos3.hlsl:50-59, ps_resize_onepass_jinc2.hlsl:44-101); y_dev is read by fn = 3 only.
+ * The tests hold the result to a CPU evaluation of the same definition bit for bit.  DEVICE buffers; stream = a hipStream_t or NULL. */
+int32_t mpcvr_eval_transcendental(int32_t fn, const float *x_dev, const float *y_dev, float *out_dev, size_t n, void *stream);
+/* ... and the same functions compiled for the host, over HOST buffers (no GPU needed: the CPU suite's check of the definition) */
+int32_t mpcvr_eval_transcendental_host(int32_t fn, const float *x, const float *y, float *out, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,7 @@
  *   saturate;  frac;  pow(x,y)=exp2(y*log2(x)).
  */
 #include "mpcvr_oracle.h"
+#include "crmath.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -40,7 +41,7 @@ void orc_set_pow_ulp_bias(int bias) { g_pow_ulp_bias = bias; g_pow_ulp_seed = 0;
 void orc_set_pow_ulp_noise(int amplitude, uint32_t seed) { g_pow_ulp_bias = amplitude; g_pow_ulp_seed = seed; }
 static inline float hlsl_pow(float x, float y)
 {
-    float r = exp2f(y * log2f(x));
+    float r = crm_powf(x, y);          /* exp2(y * log2 x), each step the correctly rounded fp32 function (crmath.h) */
     if (g_pow_ulp_bias && r > 0.0f && r < 3.0e38f) {
         uint32_t u; memcpy(&u, &r, 4);
         int bias = g_pow_ulp_bias;
@@ -54,6 +55,13 @@ static inline float hlsl_pow(float x, float y)
         memcpy(&r, &u, 4);
     }
     return r;
+}
+
+/* the defined transcendentals over an array (tests: the product's device evaluation must equal this bit for bit) */
+void orc_eval_transcendental(int fn, const float *x, const float *y, float *out, size_t n)
+{
+    for (size_t i = 0; i < n; i++)
+        out[i] = fn == 0 ? crm_log2f(x[i]) : fn == 1 ? crm_exp2f(x[i]) : fn == 2 ? crm_expf(x[i]) : fn == 3 ? crm_powf(x[i], y[i]) : fn == 4 ? crm_sinf(x[i]) : crm_cosf(x[i]);
 }
 
 static int g_threads = 0;
@@ -445,7 +453,7 @@ void orc_hlg_to_linear(float rgb[3])                    /* hlg.hlsl:1-20 */
 {
     const float B67_a = 0.17883277f, B67_b = 0.28466892f, B67_c = 0.55991073f, B67_inv_r2 = 4.0f;
     for (int i = 0; i < 3; i++)
-        rgb[i] = (rgb[i] <= 0.5f) ? rgb[i] * rgb[i] * B67_inv_r2 : expf((rgb[i] - B67_c) / B67_a) + B67_b;
+        rgb[i] = (rgb[i] <= 0.5f) ? rgb[i] * rgb[i] * B67_inv_r2 : crm_expf((rgb[i] - B67_c) / B67_a) + B67_b;
     float ootf_ys = 2000.0f * (0.2627f * rgb[0] + 0.6780f * rgb[1] + 0.0593f * rgb[2]);
     float g = hlsl_pow(ootf_ys, 0.2f);
     for (int i = 0; i < 3; i++) rgb[i] *= g;
@@ -947,7 +955,7 @@ int orc_upscale_weights(int method, float t, float w[6])
         float s = 0;
         for (int i = 0; i < 4; i++) {
             float a = ws[i] * HLSL_PI;
-            w[i] = sinf(a) * sinf(a * .5f) / (ws[i] * ws[i] * HLSL_PI * HLSL_PI * .5f);
+            w[i] = crm_sinf(a) * crm_sinf(a * .5f) / (ws[i] * ws[i] * HLSL_PI * HLSL_PI * .5f);
         }
         s = w[0] + w[1] + w[2] + w[3];              /* dot(1., w) */
         float wc = 1.f - s;
@@ -962,8 +970,8 @@ int orc_upscale_weights(int method, float t, float w[6])
         for (int i = 0; i < 3; i++) {
             float a0 = k0[i] * HLSL_PI + t * HLSL_PI, a1 = k1[i] * HLSL_PI - t * HLSL_PI;
             float a0s = a0 * .5f, a1s = a1 * .5f;
-            w0[i] = sinf(a0) * sinf(a0s) / (a0 * a0s);
-            w1[i] = sinf(a1) * sinf(a1s) / (a1 * a1s);
+            w0[i] = crm_sinf(a0) * crm_sinf(a0s) / (a0 * a0s);
+            w1[i] = crm_sinf(a1) * crm_sinf(a1s) / (a1 * a1s);
         }
         float s = (w0[0] + w1[0]) + (w0[1] + w1[1]) + (w0[2] + w1[2]);   /* dot(1., w0 + w1) */
         float wc = 1.f - s;
@@ -1010,7 +1018,7 @@ float orc_downscale_filter(int method, float x, float *support)
         if (x == 0.0f) return 1.0f;
         if (x >= 1.0f) return 0.0f;
         x *= HLSL_PI;
-        return sinf(x) / x * (0.54f + 0.46f * cosf(x));
+        return crm_sinf(x) / x * (0.54f + 0.46f * crm_cosf(x));
     case ORC_DOWN_BICUBIC:
     case ORC_DOWN_BICUBIC_SHARP: {
         const float A = (method == ORC_DOWN_BICUBIC) ? -0.5f : -1.5f;
@@ -1024,8 +1032,8 @@ float orc_downscale_filter(int method, float x, float *support)
         if (support) *support = 3.0f;
         if (-3.0f <= x && x < 3.0f) {
             float a = x, b = x / 3;
-            float sa = (a == 0.0f) ? 1.0f : sinf(a * HLSL_PI) / (a * HLSL_PI);
-            float sb = (b == 0.0f) ? 1.0f : sinf(b * HLSL_PI) / (b * HLSL_PI);
+            float sa = (a == 0.0f) ? 1.0f : crm_sinf(a * HLSL_PI) / (a * HLSL_PI);
+            float sb = (b == 0.0f) ? 1.0f : crm_sinf(b * HLSL_PI) / (b * HLSL_PI);
             return sa * sb;
         }
         return 0.0f;
@@ -1661,7 +1669,7 @@ static int resize_draw(const img_t *in, const int rect[4], img_t *out, int tex_a
                     for (int i = 0; i < 4; i++) {
                         const float vx = (tcx + (float)(i - 1)) - pcx, vy = (tcy + (float)(j - 1)) - pcy;
                         const float dd = sqrtf(vx * vx + vy * vy);
-                        w[j][i] = (dd == 0.0f) ? wa * wb : sinf(dd * wa) * sinf(dd * wb) / (dd * dd);
+                        w[j][i] = (dd == 0.0f) ? wa * wb : crm_sinf(dd * wa) * crm_sinf(dd * wb) / (dd * dd);
                         rowsum = i == 0 ? w[j][i] : rowsum + w[j][i];
                         const int sx = clampi((int)floorf(tcx) + i - 1, 0, in->w - 1), sy = clampi((int)floorf(tcy) + j - 1, 0, in->h - 1);
                         c[j][i] = in->p + ((size_t)sy * in->w + sx) * 4;

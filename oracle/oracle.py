@@ -207,6 +207,7 @@ def lib():
         L.orc_set_pow_ulp_bias.argtypes = [C.c_int]
         L.orc_set_pow_ulp_noise.argtypes = [C.c_int, C.c_uint32]
         L.orc_set_tex_ulp_bias.argtypes = [C.c_int]
+        L.orc_eval_transcendental.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.orc_hdr10_params.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_uint32)]
         L.orc_specify_extfmt.restype = C.c_uint32
         L.orc_specify_extfmt.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int]
@@ -346,6 +347,15 @@ def process_with_pow_bias(p, frame, pitch, bias, dst=None, seed=0):
         return process(p, frame, pitch, dst=dst)
     finally:
         lib().orc_set_pow_ulp_bias(0)
+
+
+def eval_transcendental(fn, x, y=None):
+    """The oracle's defined transcendentals (crmath.h) over float32 arrays: fn = 'log2' | 'exp2' | 'exp' | 'pow' | 'sin' | 'cos'."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y if y is not None else x, dtype=np.float32)
+    out = np.empty_like(x)
+    lib().orc_eval_transcendental({"log2": 0, "exp2": 1, "exp": 2, "pow": 3, "sin": 4, "cos": 5}[fn], x.ctypes.data, y.ctypes.data, out.ctypes.data, x.size)
+    return out
 
 
 def process_with_tex_bias(p, frame, pitch, bias):

@@ -16,6 +16,8 @@
 #include <cstdint>
 #include <cstring>
 
+#include "../crmath.h"      // the transcendentals as defined functions (correctly rounded fp32 steps): the same definition as the oracle's
+
 // ---- the draw call (C ABI; mirrored by ref_hlsl.py) ----------------------------------------------------------------------
 extern "C" {
 struct RefSurface { float* data; int32_t w, h; };
@@ -41,11 +43,11 @@ typedef unsigned int uint;
 struct float2; struct float3; struct float4;
 
 // ---- scalar intrinsics ---------------------------------------------------------------------------------------------
-inline float h_pow(float x, float y) { return ::exp2f(y * ::log2f(x)); }
+inline float h_pow(float x, float y) { return crm_powf(x, y); }      // exp2(y * log2(x)), each step rounded to fp32 (d3dcompiler's lowering)
 inline float pow(float x, float y) { return h_pow(x, y); }
-inline float exp(float x) { return ::expf(x); }
-inline float sin(float x) { return ::sinf(x); }
-inline float cos(float x) { return ::cosf(x); }
+inline float exp(float x) { return crm_expf(x); }
+inline float sin(float x) { return crm_sinf(x); }
+inline float cos(float x) { return crm_cosf(x); }
 inline float acos(float x) { return ::acosf(x); }
 inline float sqrt(float x) { return ::sqrtf(x); }
 inline float floor(float x) { return ::floorf(x); }

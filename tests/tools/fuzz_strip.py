@@ -3,7 +3,9 @@
 exact-2x kernel, one-kernel same-size convert): n random (source format out of all layouts, chroma setting, size, source rect, ratio
 per axis, scaler, window offset / clipping, internal format, output format, HDR tagging)
 combinations, default planner against the plain kernels (MPCVR_FLAG_NO_FUSED): every channel within 1 LSB (8-bit targets) /
-the 10-bit bars of tests/test_parity_gpu.py.  Prints which kernels the cases went through."""
+the 10-bit bars of tests/test_parity_gpu.py; every fifth case against the CPU oracle as well — the plain tier BIT FOR BIT on every case
+(round 6: behind PQ / HLG / gamma / Dolby Vision tails and through the per-pixel Jinc2m kernel too), the default planner at the fused
+tiers' bar.  Prints which kernels the cases went through."""
 import sys, os, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -20,7 +22,7 @@ sdr = GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]
 # mostly out-of-gamut saturated colour — the worst case for the cancelling 2020 -> 709 row — so the count allowed per frame is the
 # suite's Dolby Vision rate (16 per M pixels, twice what round 3 measured on its hardest frames), at least 3
 FUZZ_CAP = lambda img: max(3, int(np.ceil(16 * img.shape[0] * img.shape[1] / 1e6)))
-paths = collections.Counter(); worst = 0.0; refused = 0; outliers = 0; batches = 0; oracle_cases = 0
+plain_stats = collections.Counter(); paths = collections.Counter(); worst = 0.0; refused = 0; outliers = 0; batches = 0; oracle_cases = 0
 for i in range(n):
     # every source layout: 4:2:0 weighted up, then planar / packed 4:2:2 and 4:4:4, gray, GBRP, one interleaved RGB
     if rng.random() < 0.55:
@@ -141,9 +143,14 @@ for i in range(n):
             return np.abs(a[..., :3].astype(np.int32) - b[..., :3].astype(np.int32))
         dp, dg = dist(plain, want), dist(got, want)
         oracle_cases += 1
+        # round 6: the plain tier evaluates the shader transcendentals as the oracle defines them (csrc/vp_crmath.h), so it is held to the
+        # oracle BIT FOR BIT on every case, behind a PQ / HLG / gamma / Dolby Vision tail and through the per-pixel Jinc2m kernel too
+        if os.environ.get("MPCVR_FUZZ_PLAIN_STATS"):
+            plain_stats[int(dp.max())] += 1
+            if dp.max(): print(f"  plain tier != oracle: max {int(dp.max())}, {int((dp > 0).sum())} channels: {name}")
+        else:
+            assert dp.max() == 0, f"plain tier vs oracle: max {int(dp.max())}, {int((dp > 0).sum())} channels: {name}"
         if not has_tail(c):
-            # (Jinc2m: the plain kernel evaluates the windowed jinc per pixel with the device's sinf, the oracle with the host's: last-ulp weights)
-            assert dp.max() <= (1 if c.get("iUpscaling") == 5 else 0), f"plain tier vs oracle: max {int(dp.max())}, {int((dp > 0).sum())} channels: {name}"
             # (default planner, no tail: within the bar on every channel.  Until round 4 a convert texel one code off the oracle's — the fused tiers
             # contracted a*b + c, 1e-4 of the texels of an 8-bit internal format — could leave a Catmull-Rom / Lanczos tap sum two codes off, 1 - 3
             # channels per ~1e6, and this tool counted them; round 5 gave 8-bit internal formats the exact form of the convert stage
@@ -158,13 +165,11 @@ for i in range(n):
             from tests.test_parity_gpu import compare_behind_tail
             po = oracle_params(oracle, c)
             fr, pit = case_frame(c)
-            compare_behind_tail(oracle, po, fr, pit, plain, want, f"plain tier vs oracle (tail, 10-bit): {name}", min_same=0.97, ten_bit=True, lim=lim, cap=FUZZ_CAP(want))
             compare_behind_tail(oracle, po, fr, pit, got, want, f"default planner vs oracle (tail, 10-bit): {name}", min_same=0.97, ten_bit=True, lim=lim, cap=FUZZ_CAP(want))
         else:                                       # 8-bit targets: <= 1 LSB, or the per-channel witness (the oracle's own +-4 ulp pow() interval)
             from tests.test_parity_gpu import compare_behind_tail
             po = oracle_params(oracle, c)
             fr, pit = case_frame(c)
-            compare_behind_tail(oracle, po, fr, pit, plain, want, f"plain tier vs oracle (tail): {name}", min_same=0.97, cap=FUZZ_CAP(want))
             compare_behind_tail(oracle, po, fr, pit, got, want, f"default planner vs oracle (tail): {name}", min_same=0.97, cap=FUZZ_CAP(want))
     beyond = int((d > lim).sum()); same = float((d == 0).mean())
     worst = max(worst, 1.0 - same)
@@ -178,4 +183,5 @@ for i in range(n):
     if not has_tail(c) and (c.get("output_format", 0) != 1 or internal_is_8bit(c)):
         assert beyond == 0, name          # (round 5: nothing beyond the bar where no transcendental decides the last code)
     assert beyond == 0 or (beyond <= max(4, 2e-5 * d.size) and d.max() <= worst_ok), name
+if plain_stats: print("plain tier vs oracle, max |delta| -> cases:", dict(sorted(plain_stats.items())))
 print("cases", n, "of which also as 3-frame batches", batches, "against the CPU oracle", oracle_cases, "refused", refused, "kernels", dict(paths), "largest differing fraction", round(worst, 5), "cases with an ill-conditioned channel", outliers)

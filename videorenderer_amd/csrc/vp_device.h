@@ -5,6 +5,9 @@
 #include <hip/hip_runtime.h>
 
 #include "vp_params.h"
+#ifdef MPCVR_EXACT_FP
+#include "vp_crmath.h"
+#endif
 
 namespace mpcvr {
 
@@ -30,10 +33,24 @@ __device__ __forceinline__ float unorm_div(float code)
 // translation unit (no FMA contraction): the fused and the pass-per-kernel path then agree bit for bit.
 #pragma clang fp contract(off)
 
-// HLSL pow(x, y) = exp2(y * log2(x)); raw v_log_f32 / v_exp_f32 (≈1 ulp each), log2(0) = -inf -> 0.
+// HLSL pow(x, y) = exp2(y * log2(x)).  The pass-per-kernel tier (vp_kernels.hip, MPCVR_EXACT_FP) takes every step as the correctly
+// rounded fp32 function (vp_crmath.h: the definition the CPU restatement uses, so the two agree bit for bit behind a PQ / HLG / gamma
+// tail too); everywhere else raw v_log_f32 / v_exp_f32 (≈1 ulp each; behind pow(x, 6.28) that is ~35 ulp), log2(0) = -inf -> 0.
 __device__ __forceinline__ float hlsl_pow(float x, float y)
 {
+#ifdef MPCVR_EXACT_FP
+    return crm_powf(x, y);
+#else
     return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+#endif
+}
+__device__ __forceinline__ float hlsl_exp(float x)
+{
+#ifdef MPCVR_EXACT_FP
+    return crm_expf(x);
+#else
+    return __expf(x);
+#endif
 }
 
 // ---- Shaders/convert/st2084.hlsl:1-25 ----
@@ -62,7 +79,7 @@ __device__ __forceinline__ float linear_to_st2084(float x, float divider)
 __device__ __forceinline__ float inverse_hlg(float v)
 {
     const float a = 0.17883277f, b = 0.28466892f, c = 0.55991073f;
-    return (v <= 0.5f) ? v * v * 4.0f : __expf((v - c) / a) + b;
+    return (v <= 0.5f) ? v * v * 4.0f : hlsl_exp((v - c) / a) + b;
 }
 __device__ __forceinline__ f3 hlg_to_linear(f3 v)
 {

@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void k_jinc2(Surface in, DrawCoords dc, const 
         for (int i = 0; i < 4; i++) {
             const float vx = (tcx + (float)(i - 1)) - pcx, vy = (tcy + (float)(j - 1)) - pcy;
             const float dd = sqrtf(vx * vx + vy * vy);
-            w[i] = (dd == 0.0f) ? wa * wb : sinf(dd * wa) * sinf(dd * wb) / (dd * dd);
+            w[i] = (dd == 0.0f) ? wa * wb : crm_sinf(dd * wa) * crm_sinf(dd * wb) / (dd * dd);      // sin as the oracle defines it (vp_crmath.h): the weights carry its bits
             rowsum = i == 0 ? w[i] : rowsum + w[i];
             c[i] = load_surface(in, clampi(bx + i - 1, 0, in.w - 1), clampi(by + j - 1, 0, in.h - 1));
         }
@@ -1046,7 +1046,7 @@ bool BuildJincPhases(const DrawCoords &dc, void *out_table)
                 for (int i = 0; i < 4; i++) {
                     const float vx = (tcx + (float)(i - 1)) - pcx, vy = (tcy + (float)(j - 1)) - pcy;
                     const float dd = sqrtf(vx * vx + vy * vy);
-                    const float w = (dd == 0.0f) ? wa * wb : sinf(dd * wa) * sinf(dd * wb) / (dd * dd);
+                    const float w = (dd == 0.0f) ? wa * wb : crm_sinf(dd * wa) * crm_sinf(dd * wb) / (dd * dd);
                     t.w[py][px][j * 4 + i] = w;
                     rowsum = i == 0 ? w : rowsum + w;
                 }

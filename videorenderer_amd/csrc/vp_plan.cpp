@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "../../include/mpcvr.h"
+#include "vp_crmath.h"      // the shaders' sin / cos as defined functions (the weights the resize shaders compute per pixel are computed here, once)
 
 namespace mpcvr {
 
@@ -407,7 +408,7 @@ int UpscaleWeights(int method, float t, float w[6])
         const float d[4] = {1.f + t, 0.f + t, 1.f - t, 2.f - t};
         for (int i = 0; i < 4; i++) {
             const float a = d[i] * kPi;
-            w[i] = std::sin(a) * std::sin(a * .5f) / (d[i] * d[i] * kPi * kPi * .5f);
+            w[i] = crm_sinf(a) * crm_sinf(a * .5f) / (d[i] * d[i] * kPi * kPi * .5f);
         }
         const float wc = 1.f - (w[0] + w[1] + w[2] + w[3]);
         w[1] += wc * (1.f - t);
@@ -420,8 +421,8 @@ int UpscaleWeights(int method, float t, float w[6])
         for (int i = 0; i < 3; i++) {
             const float a = (float)(2 - i) * kPi + t * kPi, as = a * .5f;
             const float b = (float)(1 + i) * kPi - t * kPi, bs = b * .5f;
-            lo[i] = std::sin(a) * std::sin(as) / (a * as);
-            hi[i] = std::sin(b) * std::sin(bs) / (b * bs);
+            lo[i] = crm_sinf(a) * crm_sinf(as) / (a * as);
+            hi[i] = crm_sinf(b) * crm_sinf(bs) / (b * bs);
         }
         const float wc = 1.f - ((lo[0] + hi[0]) + (lo[1] + hi[1]) + (lo[2] + hi[2]));
         lo[2] += wc * (1.f - t);
@@ -464,7 +465,7 @@ float DownscaleFilter(int method, float x, float *support)
         if (x == 0.0f) return 1.0f;
         if (x >= 1.0f) return 0.0f;
         x *= kPi;
-        return std::sin(x) / x * (0.54f + 0.46f * std::cos(x));
+        return crm_sinf(x) / x * (0.54f + 0.46f * crm_cosf(x));
     case MPCVR_DOWNSCALE_Bicubic:
     case MPCVR_DOWNSCALE_BicubicSharp: {
         const float A = method == MPCVR_DOWNSCALE_Bicubic ? -0.5f : -1.5f;   // compile_shaders.cmd:98-101
@@ -477,7 +478,7 @@ float DownscaleFilter(int method, float x, float *support)
     case MPCVR_DOWNSCALE_Lanczos: {
         sup(3.0f);
         if (!(-3.0f <= x && x < 3.0f)) return 0.0f;
-        auto sinc = [](float v) { if (v == 0.0f) return 1.0f; v *= kPi; return std::sin(v) / v; };
+        auto sinc = [](float v) { if (v == 0.0f) return 1.0f; v *= kPi; return crm_sinf(v) / v; };
         return sinc(x) * sinc(x / 3);
     }
     default:

@@ -10,6 +10,7 @@
 #include <cstdint>
 
 #include "../../include/mpcvr.h"
+#include "vp_crmath.h"
 
 namespace mpcvr {
 namespace {
@@ -21,8 +22,25 @@ __global__ __launch_bounds__(256) void k_probe_shape(const pr_u4 *__restrict__ s
         for (int k = 0; k < fan; k++) dst[(size_t)k * n16_src + i] = pr_u4{s.x + (uint32_t)k, s.y, s.z, s.w};
     }
 }
+// the plain tier's transcendentals over an array (tests: device == the CPU evaluation of the same definition, bit for bit)
+__global__ __launch_bounds__(256) void k_eval_transcendental(int fn, const float *__restrict__ x, const float *__restrict__ y, float *__restrict__ out, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        out[i] = fn == 0 ? crm_log2f(v) : fn == 1 ? crm_exp2f(v) : fn == 2 ? crm_expf(v) : fn == 3 ? crm_powf(v, y[i]) : fn == 4 ? crm_sinf(v) : crm_cosf(v);
+    }
+}
 }  // namespace
 }  // namespace mpcvr
+
+extern "C" int32_t mpcvr_eval_transcendental(int32_t fn, const float *x_dev, const float *y_dev, float *out_dev, size_t n, void *stream)
+{
+    if (!x_dev || !out_dev || (fn == 3 && !y_dev)) return MPCVR_E_POINTER;
+    if (fn < 0 || fn > 5) return MPCVR_E_INVALIDARG;
+    if (n == 0) return MPCVR_S_OK;
+    hipLaunchKernelGGL(mpcvr::k_eval_transcendental, dim3(1024), dim3(256), 0, (hipStream_t)stream, (int)fn, x_dev, y_dev, out_dev, n);
+    return hipGetLastError() == hipSuccess ? MPCVR_S_OK : MPCVR_E_FAIL;
+}
 
 extern "C" int32_t mpcvr_bandwidth_probe(const void *src_dev, void *dst_dev, size_t src_bytes, int32_t fan, void *stream)
 {
@@ -30,4 +48,13 @@ extern "C" int32_t mpcvr_bandwidth_probe(const void *src_dev, void *dst_dev, siz
     if (fan < 1 || fan > 64 || src_bytes < 16 || (((uintptr_t)src_dev | (uintptr_t)dst_dev) & 15)) return MPCVR_E_INVALIDARG;
     hipLaunchKernelGGL(mpcvr::k_probe_shape, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const mpcvr::pr_u4 *)src_dev, (mpcvr::pr_u4 *)dst_dev, src_bytes / 16, (int)fan);
     return hipGetLastError() == hipSuccess ? MPCVR_S_OK : MPCVR_E_FAIL;
+}
+
+extern "C" int32_t mpcvr_eval_transcendental_host(int32_t fn, const float *x, const float *y, float *out, size_t n)
+{
+    if (!x || !out || (fn == 3 && !y)) return MPCVR_E_POINTER;
+    if (fn < 0 || fn > 5) return MPCVR_E_INVALIDARG;
+    for (size_t i = 0; i < n; i++)
+        out[i] = fn == 0 ? mpcvr::crm_log2f(x[i]) : fn == 1 ? mpcvr::crm_exp2f(x[i]) : fn == 2 ? mpcvr::crm_expf(x[i]) : fn == 3 ? mpcvr::crm_powf(x[i], y[i]) : fn == 4 ? mpcvr::crm_sinf(x[i]) : mpcvr::crm_cosf(x[i]);
+    return MPCVR_S_OK;
 }
