@@ -95,7 +95,9 @@ POW_ULPS = 4      # Direct3D's pow is exp2(y * log2 x): with 1-ulp log2 / exp2 t
 # Dolby Vision frames (reshaping + two PQ chains in front of the cancelling 2020 -> 709 row): at most 16 per 2.07 M-pixel frame over the
 # whole round-3 suite (profiles/r03/parity_identical_channels.jsonl: 1-16, 17 of 1,187 comparisons) = 7.7 per million pixels; the cap
 # is twice that.  Every other frame: none — except the cases named here, each with the count it was witnessed with.
-ILL_CONDITIONED_PER_MPX_DOVI = 9
+# Round 6 (the oracle's transcendentals are now defined functions; gpurun_out/r06/parity_log.jsonl -> profiles/r06/): at most 9 per 2.07 M-pixel
+# Dolby Vision frame on the block convert (0 on the plain tier, which is bit-exact) = 4.3 per million pixels; the cap is 1.5 x that.
+ILL_CONDITIONED_PER_MPX_DOVI = 6.5
 KNOWN_ILL_CONDITIONED = {
     # one channel, 2 LSB, on the block-convert kernel only (the plain per-pixel kernel is within 1): a saturated BT.2020 colour whose
     # blue cancels to 2e-4 of its terms behind the 2020 -> 709 row — the table's interpolated tone-map value (5e-7 off the literal chain)
@@ -213,6 +215,41 @@ def test_pass_per_kernel_path_vs_oracle(mpcvr, oracle, torch_cuda, name):
         compare(got, want, name, exact=True)
 
 
+def test_fused_jinc_steps_aside_where_the_device_grants_less_lds(mpcvr, torch_cuda):
+    """The fused Jinc2m kernel claims 114 - 146 KiB of LDS per workgroup; UpdatePlan compares that with what the device grants and keeps the
+    convert + k_jinc2 draws otherwise (advisor, round 5: the launch failed on every frame of such a plan).  MPCVR_LDS_LIMIT plans as if this
+    MI355X granted 64 KiB (the limit is cached per process: a child process), and the frame still equals the default plan's to one code."""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from videorenderer_amd import api\n"
+        "from tests.golden.cases import GOLDEN_CASES\n"
+        "from tests.test_parity_gpu import run_product\n"
+        "c = GOLDEN_CASES['jinc2_p010_2x_dither']\n"
+        "got, info = run_product(api, torch, c)\n"
+        "np.save(sys.argv[1], got)\n"
+        "print('INFO', info)\n" % root)
+    import tempfile
+    outs = {}
+    for limit in ("", "65536"):
+        with tempfile.TemporaryDirectory() as d:
+            env = dict(os.environ)
+            env.pop("MPCVR_LDS_LIMIT", None)
+            if limit:
+                env["MPCVR_LDS_LIMIT"] = limit
+            r = subprocess.run([sys.executable, "-c", code, os.path.join(d, "o.npy")], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+            assert r.returncode == 0, r.stderr[-2000:]
+            info = [l for l in r.stdout.splitlines() if l.startswith("INFO")][0][5:]
+            outs[limit] = (np.load(os.path.join(d, "o.npy")), info)
+    assert outs[""][1] == "fused_jinc2x", outs[""][1]
+    assert outs["65536"][1].startswith("passes:convert,resizeX"), outs["65536"][1]
+    d = np.abs(outs[""][0].astype(np.int16) - outs["65536"][0].astype(np.int16))
+    assert d.max() <= 1, int(d.max())
+
+
 # ---- round 6: the shader transcendentals as DEFINED functions (csrc/vp_crmath.h, oracle/crmath.h, tests/test_crmath.py) ---------------
 def test_defined_transcendentals_device_equals_host(mpcvr, oracle, torch_cuda):
     """log2f / exp2f / expf / pow / sinf / cosf of the plain tier evaluated ON THE GPU (fp64 there) == the oracle's CPU evaluation of the same definition,
@@ -319,10 +356,12 @@ def test_folded_kernels_vs_oracle(mpcvr, oracle, torch_cuda, name):
     want = run_case(oracle, name, background=BG)
     got, info = run_product(mpcvr, torch_cuda, c, extra_flags=api.FLAG_NO_FAST_CONVERT)
     assert info != "fused_up2x"
-    # (round 6: bit-exact behind a PQ / HLG / gamma tail as well — these kernels are built from the plain tier's translation unit and
-    # evaluate the transcendentals as the oracle defines them)
+    # (behind a tail the folded convert — built with the fused tiers' v_log_f32 / v_exp_f32 — keeps the fused tiers' bar; the plain tier
+    # alone evaluates the transcendentals as the oracle defines them and is exact there too: test_pass_per_kernel_path_vs_oracle)
     if c.get("output_format", 0) == 1:
-        compare_rgb10(got, want, name, exact=True)
+        compare_rgb10(got, want, name, exact=not has_tail(c))
+    elif has_tail(c):
+        compare(got, want, f"{name} [{info}]", min_same=0.99)
     else:
         compare(got, want, f"{name} [{info}]", exact=True)
 
@@ -509,12 +548,12 @@ def test_kernel_family_sweep_vs_oracle(mpcvr, oracle, torch_cuda, label):
     got, info = run_product(mpcvr, torch_cuda, c, extra_flags=flags)
     # noise frames of a few thousand pixels: with an 8-bit internal format one code of the texture is four ten-bit codes of the target,
     # so the share of identical channels is held at 0.97 there (0.99 elsewhere); behind a PQ / HLG tail a channel beyond the bar needs
-    # its witness (compare_behind_tail: inside the oracle's own +-4 ulp pow() interval), at most two per frame
+    # its witness (compare_behind_tail: inside the oracle's own +-4 ulp pow() interval), at most one per frame (round 6: what was measured)
     same_floor = 0.97 if internal_is_8bit(c) else 0.99
     if has_tail(c):
         ten = c["output_format"] == 1
         compare_behind_tail(oracle, p, frame, pitch, got, want, f"{label} [{info}]", min_same=same_floor, ten_bit=ten,
-                            lim=(5 if internal_is_8bit(c) else 2) if ten else 1, cap=2)
+                            lim=(5 if internal_is_8bit(c) else 2) if ten else 1, cap=1)       # (measured, round 6: 1 on two of the 2,975 cases)
     elif c["output_format"] == 1:
         # (Jinc2m: a one-code difference of the block convert in the 10-bit texture may come out as two ten-bit codes = half an 8-bit code)
         compare_rgb10(got, want, f"{label} [{info}]", tail=c.get("iUpscaling") == 5, internal8=internal_is_8bit(c), min_same=same_floor)
@@ -1128,8 +1167,8 @@ FULL_SIZE_TIERS = {
 
 # Jinc2m's weights sum to |w| = 1.9 (negative ring): behind a PQ tail, where dark saturated colours sit on pow()'s steep end, what the separable
 # filters keep inside one code comes out at two on a handful of channels per frame — each must be shown ill-conditioned (compare_behind_tail),
-# and their number is capped at twice what was measured (3 of 24.9 M channels on every tier)
-FULL_SIZE_BEHIND_A_TAIL = {"jinc_4k_from_1080_pq": 6}
+# and their number is capped at 1.5 x what was measured (3 of 24.9 M channels on the fused and the tiled tier; the plain tier is bit-identical)
+FULL_SIZE_BEHIND_A_TAIL = {"jinc_4k_from_1080_pq": 4}
 
 
 @pytest.mark.parametrize("name", sorted(FULL_SIZE_TIERS))
@@ -1949,8 +1988,11 @@ def test_full_size_general_ratio_tiers_agree(mpcvr, torch_cuda, label, c):
     default, info_d = run_product(mpcvr, torch_cuda, c)
     # (Jinc2m at exactly 2x: the default tier is the fused kernel since round 5 — a full-size frame of it against the per-pixel kernels)
     assert info_p.startswith("passes:convert") and info_f.startswith("passes:convert") and info_d.startswith("fused_jinc2x" if c.get("iUpscaling") == 5 else "passes:convert")
-    # (Jinc2m: the phase table holds the host's evaluation of the defined sin, k_jinc2 the device's — the same bits since round 6)
-    assert np.array_equal(plain, folded), f"{label}: folded kernels differ from the plain ones in {(plain != folded).sum()} bytes"
+    if c.get("iUpscaling") == 5:     # Jinc2m: the phase table holds the weights of the NOMINAL phases (k + 1/4, k + 3/4), the per-pixel kernel — like
+        # the shader — evaluates them at the interpolated texture coordinate, which sits an ulp beside the nominal position on some columns / rows
+        compare(folded, plain, label + " phase table vs per-pixel weights", min_same=0.999)
+    else:
+        assert np.array_equal(plain, folded), f"{label}: folded kernels differ from the plain ones in {(plain != folded).sum()} bytes"
     compare(default, plain, label + " default vs plain", min_same=WHOLE_FRAME_FLOOR)
 
 

@@ -798,11 +798,13 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         std::vector<float> tab(FusedJincTableBytes() / sizeof(float));
         if (!BuildJincPhases(dc, phases.data())) m_plan.fused_up2x = m_plan.fused_jinc = false;
         else {
-            if (const char *e = std::getenv("MPCVR_JINC_DBG")) {        // (debug: a one-tap filter — which texel does an output pixel read?)
+#ifdef MPCVR_DEBUG_HOOKS        // (debug builds only — tools/debug/jinc_diff.py: a one-tap filter, which texel does an output pixel read?)
+            if (const char *e = std::getenv("MPCVR_JINC_DBG")) {
                 JincPhases &jp = *(JincPhases *)phases.data();
                 const int tap = std::atoi(e);
                 for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) { for (int k = 0; k < 16; k++) jp.w[a][b][k] = k == tap ? 1.0f : 0.0f; jp.wsum[a][b] = 1.0f; }
             }
+#endif
             BuildFusedJincTable(phases.data(), tab.data());
             if ((hr = CheckHip(m_jincFused.CheckCreate(tab.size() * sizeof(float)), "fused jinc table"))) return hr;
             if ((hr = CheckHip(hipMemcpy(m_jincFused.ptr, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice), "fused jinc table upload"))) return hr;
@@ -823,6 +825,8 @@ HRESULT CHipVideoProcessor::UpdatePlan()
         FusedParams fp{};
         FillFusedParams(nullptr, nullptr, 0, &fp);
         m_plan.fused_up2x = FusedUp2xSupported(fp);
+        // the fused Jinc2m kernel wants 114 - 146 KiB of LDS per workgroup: where the device grants less, the convert + k_jinc2 draws (advisor, round 5)
+        if (m_plan.fused_jinc && FusedJincLdsBytes(fp) > DeviceLdsLimit()) m_plan.fused_up2x = false;
         if (!m_plan.fused_up2x) m_plan.fused_jinc = false;
         // experiment knob: exact 2x through the arbitrary-ratio kernel instead (DESIGN.md §4.3 compares the two)
         static const bool no_up2x_env = [] { const char *e = std::getenv("MPCVR_NO_UP2X"); return e && *e && *e != '0'; }();
@@ -1597,9 +1601,9 @@ HRESULT CHipVideoProcessor::ErrDiffPass(int n, const FusedFrame *table, FusedFra
     P.handoff = (uint32_t *)m_edHandoff.ptr; P.status = m_edStatus;
     // the hand-off words carry the launch's generation: rows of the same layout need no clearing from launch to launch (600 MB for a 32-frame
     // batch of 8K frames); another layout, another buffer or a wrapped count: gen = 0 = the launcher clears them and starts at 1
-    const uint64_t key = ((uint64_t)(uint32_t)P.x0 << 48) ^ ((uint64_t)(uint32_t)P.x1 << 32) ^ ((uint64_t)(uint32_t)P.y0 << 16) ^ (uint64_t)(uint32_t)P.y1 ^
-                         ((uint64_t)(uint32_t)n * 0x9E3779B97F4A7C15ull) ^ (uint64_t)(uintptr_t)P.handoff;
-    if (key != m_edKey || m_edGen >= 4095 || m_edGen <= 0 || P.test_stall) { P.gen = 0; m_edGen = 1; m_edKey = P.test_stall ? 0 : key; }
+    // (the layout is compared field by field — round 5 hashed it into 64 bits, and two layouts whose hashes met would have shared uncleared rows)
+    const EdLayout key{P.x0, P.x1, P.y0, P.y1, n, (const void *)P.handoff};
+    if (!(key == m_edKey) || m_edGen >= 4095 || m_edGen <= 0 || P.test_stall) { P.gen = 0; m_edGen = 1; m_edKey = P.test_stall ? EdLayout{} : key; }
     else P.gen = ++m_edGen;
     return CheckHip(LaunchErrorDiffusion(P, table, single, n, s), "k_error_diffusion");
 }

@@ -281,7 +281,11 @@ private:
     // the error-diffusion pass (vp_errdiff.hip) reads them and writes the real render targets
     DevBuffer m_edPost;
     DevBuffer m_edHandoff;         // the pass's hand-off rows between bands of 64 rows (vp_errdiff.hip)
-    int m_edGen = 0; uint64_t m_edKey = 0;   // generation of the hand-off words of the last pass, and what its rows were laid out for (ErrDiffPass)
+    struct EdLayout {              // what the hand-off rows of the last pass were laid out for (ErrDiffPass): compared field by field
+        int x0 = 0, x1 = 0, y0 = 0, y1 = 0, n = 0; const void *rows = nullptr;
+        bool operator==(const EdLayout &o) const { return x0 == o.x0 && x1 == o.x1 && y0 == o.y0 && y1 == o.y1 && n == o.n && rows == o.rows; }
+    };
+    int m_edGen = 0; EdLayout m_edKey;       // generation of the hand-off words of the last pass, and the layout they belong to
     int *m_edStatus = nullptr;     // pinned host word the pass sets when a band gave up waiting (checked at the next pass and in Synchronize)
     uint8_t *m_edBase = nullptr;   // first intermediate (m_edPost.ptr + a margin)
     int m_edPitch = 0;             // bytes per row of an intermediate (a multiple of 256)

@@ -341,6 +341,14 @@ inline auto fused_jinc2x_kernel(bool exact) -> decltype(&k_fused_jinc2x<TAIL, SR
 }  // namespace
 
 size_t FusedJincTableBytes() { return JTAB_FLOATS * sizeof(float); }
+// dynamic LDS one workgroup of the plan's instantiation claims (the ring of converted rows of its waves + the dither tables + the tone-map
+// table of a tail that has one): 114 - 146 KiB.  The planner compares it with DeviceLdsLimit() and keeps the convert + k_jinc2 draws where a
+// device (or partition) grants less — the launch would otherwise fail on every frame of such a plan (advisor, round 5).
+size_t FusedJincLdsBytes(const FusedParams &P)
+{
+    const int tailk = FusedTailKind(P);
+    return (size_t)jinc_ring_bytes(tailk) + LDS_D + LDS_DB + (tail_has_table(tailk) ? LDS_T : 0);
+}
 // The phase table of a 2x draw (BuildJincPhases: [phase y][phase x][j * 4 + i]) in the order stage J reads it.
 void BuildFusedJincTable(const void *phases, float *out)
 {
@@ -382,7 +390,8 @@ hipError_t LaunchFusedJinc2x(const FusedParams &P, const FusedArgs &a_in, const 
     if (seg > c.out_h) seg = c.out_h;
     a.seg_rows = seg;
     const dim3 grid((strips * ((c.out_h + seg - 1) / seg) + jw - 1) / jw, 1, n_frames), block(64 * jw, 1, 1);
-    const size_t lds = jinc_ring_bytes(tailk) + LDS_D + LDS_DB + (tail_has_table(tailk) ? LDS_T : 0);
+    const size_t lds = FusedJincLdsBytes(P);
+    if (lds > DeviceLdsLimit()) return hipErrorInvalidValue;            // (UpdatePlan does not pick this route then)
     const bool aligned = P.dst_aligned16 && (a.off_x & 3) == 0 && (a.dst_pitch & 15) == 0;
     const int epik = !aligned ? EPI_GENERIC
                    : (!a.out10 && a.final_pass && a.epi_mul != 0) ? EPI_DITHER8

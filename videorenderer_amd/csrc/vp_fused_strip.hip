@@ -82,7 +82,10 @@ size_t DeviceLdsLimit()
     int optin = 0, plain = 0;
     (void)hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, dev);
     (void)hipDeviceGetAttribute(&plain, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
-    const size_t v = (size_t)std::max(std::max(optin, plain), 0);
+    size_t v = (size_t)std::max(std::max(optin, plain), 0);
+    // MPCVR_LDS_LIMIT=<bytes>: plan as if the device granted no more (tests: the planners' fallbacks for parts / partitions with less LDS
+    // than an MI355X's 160 KiB run on this box) — it can only lower the limit
+    if (const int cap = EnvInt("MPCVR_LDS_LIMIT", 0); cap >= 32 * 1024 && (size_t)cap < v) v = (size_t)cap;
     if (EnvInt("MPCVR_LOG", 0) >= 2)
         std::fprintf(stderr, "mpcvr: device %d LDS per workgroup: opt-in %d B, default %d B\n", dev, optin, plain);
     return limit[dev] = v >= 32 * 1024 ? v : 160 * 1024;

@@ -102,6 +102,7 @@ hipError_t LaunchErrorDiffusion(const ErrDiffParams &P, const FusedFrame *frames
 bool FusedUp2xSupported(const FusedParams &P);
 // vp_fused_jinc.hip: the weight table of the fused Jinc2m kernel, from BuildJincPhases' table of a 2x draw
 size_t FusedJincTableBytes();
+size_t FusedJincLdsBytes(const FusedParams &P);        // dynamic LDS of the fused Jinc2m kernel this plan would launch (vs DeviceLdsLimit())
 void BuildFusedJincTable(const void *phases, float *out);
 bool BlockConvertLayout(const FusedParams &P, bool catmull_420);       // source layout + chroma filter convert_block serves
 // the fused kernel's convert stage as a kernel of its own: 2x2 blocks, shared chroma fetch, table tone map.  P.store describes
