@@ -475,6 +475,40 @@ def main():
         torch.cuda.synchronize()
         shape_gbps = reps * src16 * (1 + shape_fan) / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
+    # ... and, for the exact-2x workloads on bi-planar 16-bit samples (the headline), the kernel's OWN traffic shape over a whole batch in one
+    # launch (round 6: mpcvr_bandwidth_probe_up2x — strips of 120 source columns marching down a segment, two luma rows + a chroma row read and
+    # four target rows written per step as 16-byte pieces, no arithmetic), plus the same stores alone and the same loads alone
+    up2x_shape = None
+    if rank == 0 and wl["cformat"] == 2 and s == 2 and (dw, dh) == (2 * w, 2 * h):
+        import ctypes as C
+        Lp = api.load_library()
+        nb = min(args.batch, 64)
+        arr_t = C.c_void_p * nb
+        up2x_shape = {}
+        for mode, label, cols in ((0, "read_write", 120), (1, "write_only", 120), (2, "read_only", 120), (0, "read_write_1KiB_aligned_strips", 128), (1, "write_only_1KiB_aligned_strips", 128)):
+            def launch(i):
+                k = (i * nb) % ring
+                idx = [(k + j) % ring for j in range(nb)]
+                hr = Lp.mpcvr_bandwidth_probe_up2x(mode, nb, arr_t(*[srcs[j].data_ptr() for j in idx]), arr_t(*[dsts[j].data_ptr() for j in idx]), w, h, 90, cols,
+                                                   C.c_void_p(stream.cuda_stream))
+                if hr < 0:
+                    raise SystemExit(f"mpcvr_bandwidth_probe_up2x failed: {hr:#x}")
+            for i in range(3):
+                launch(i)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 12
+            e0.record()
+            for i in range(reps):
+                launch(i)
+            e1.record()
+            torch.cuda.synchronize()
+            moved = nb * ((nbytes if mode != 1 else 0) + (out_bytes if mode != 2 else 0))
+            up2x_shape[label + "_GBps"] = round(reps * moved / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            up2x_shape[label + "_ms_per_launch"] = round(e0.elapsed_time(e1) / reps, 4)
+        up2x_shape["shape"] = (f"one launch per {nb}-frame batch; a wavefront = 120 source columns x 90 source rows; per step 3 x 240 B read, 4 rows x 960 B written as "
+                               "16-byte pieces (csrc/vp_probe.hip: k_probe_up2x); *_1KiB_aligned_strips: the same with 128-column strips (whole 1 KiB-aligned row pieces per wavefront); "
+                               "bytes counted = the bytes each mode moves")
+
     # PCIe-inclusive rate of the reference's own calling pattern (CopySample from host memory, then Process), frame by
     # frame through the 3-slot upload ring: reported beside `value`, never as `value` (inputs-resident is the metric)
     host_path = None
@@ -602,7 +636,10 @@ def main():
                          # the same box's rate for this workload's read : write shape with no arithmetic (mpcvr_bandwidth_probe, csrc/vp_probe.hip)
                          "empirical_shape_peak_GBps": round(shape_gbps, 1) if shape_gbps else None,
                          "empirical_shape": f"1 : {shape_fan} bytes read : written, 16-byte accesses, {min(ring, 24)}-frame ring" if shape_gbps else None,
-                         "frac_of_empirical_shape_peak": round(achieved / shape_gbps, 4) if shape_gbps else None},
+                         "frac_of_empirical_shape_peak": round(achieved / shape_gbps, 4) if shape_gbps else None,
+                         # the exact-2x kernel's own access pattern with no arithmetic, whole batch per launch (read + write / stores alone / loads alone)
+                         "empirical_up2x_shape": up2x_shape,
+                         "frac_of_empirical_up2x_shape": round(achieved / up2x_shape["read_write_GBps"], 4) if up2x_shape else None},
         }
         # the fused kernels are bound by VALU issue slots, not by HBM (traffic is ~1.04x algorithmic): the measured occupancy of that
         # roof rides beside the HBM fraction — frac_at_full_issue is what the HBM fraction would be with every issue slot used

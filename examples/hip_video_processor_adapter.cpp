@@ -2,7 +2,8 @@
 // (Source/HipVideoProcessor.cpp): every method of the reference's processor interface (Source/VideoProcessor.h:171-236) that belongs to the
 // shader video-processor path forwards to include/mpcvr.h; the rest (subtitles, OSD, statistics, display switching) keeps the defaults.
 //
-// Compiled (syntax and overrides only, nothing is linked) by tests/test_adapter_compiles.py against the REAL declarations of CVideoProcessor —
+// Compiled by tests/test_adapter_compiles.py — and LINKED with a driver and run on the GPU box (tests/adapter_env/build_adapter.py,
+// adapter_driver.cpp; tests/test_parity_gpu.py::test_one_frame_through_the_adapter_class) — against the REAL declarations of CVideoProcessor —
 // cut out of the reference header at test time — and the REAL Settings_t / enumerators of Source/IVideoRenderer.h, behind stand-ins for the
 // Windows / DirectShow types they mention (tests/adapter_env/): a method the reference adds, renames or re-types, a Settings_t field that
 // disappears, or an enumerator whose value moves away from mpcvr.h's fails that test.  In the reference tree it is built with the real headers.
@@ -32,6 +33,15 @@ class CHipVideoProcessorAdapter : public CVideoProcessor
     mpcvr_ctx *m_ctx = nullptr;
     mpcvr_settings m_cfg{};
     bool m_bInit = false;
+    // displayConfig.HDRSupported() && m_bHdrDisplayModeEnabled (DX11VideoProcessor.cpp:481-493): the display's state, not a setting.  HDR sources
+    // pass through / are tone-mapped for an HDR display only when it is set (:1476, :2948); bHdrPassthrough defaults to TRUE in Settings_t, so
+    // without this gate every PQ frame on an SDR display would leave unconverted (found by RUNNING the adapter: round 6).
+    bool m_bHdrPassthroughSupport = false;
+    HRESULT ApplyHdrOutput(const Settings_t &s)
+    {
+        const bool on = m_bHdrPassthroughSupport && (s.bHdrPassthrough || s.bHdrLocalToneMapping);
+        return mpcvr_set_hdr_output(m_ctx, on, s.bHdrLocalToneMapping ? s.iHdrLocalToneMappingType : 0, (float)s.iHdrDisplayMaxNits);
+    }
 
     static mpcvr_settings FromSettings(const Settings_t &s, bool tenBitOutput)
     {
@@ -56,9 +66,12 @@ public:
     {
         m_cfg = FromSettings(config, /*tenBitOutput*/ false);
         hr = mpcvr_create(&m_cfg, /*device*/ 0, &m_ctx);
-        if (SUCCEEDED(hr)) hr = mpcvr_set_hdr_output(m_ctx, config.bHdrPassthrough, config.bHdrLocalToneMapping ? config.iHdrLocalToneMappingType : 0, (float)config.iHdrDisplayMaxNits);
+        if (SUCCEEDED(hr)) hr = ApplyHdrOutput(config);
     }
     ~CHipVideoProcessorAdapter() override { mpcvr_destroy(m_ctx); }
+
+    // SetDisplayInfo's part that matters here (:481-493): the display entered / left HDR10 mode
+    void SetHdrDisplay(bool hdrSupportedAndEnabled, const Settings_t &s) { m_bHdrPassthroughSupport = hdrSupportedAndEnabled; (void)ApplyHdrOutput(s); }
 
     int Type() override { return VP_HIP; }
     HRESULT Init(const HWND hwnd, bool /*displayHdrChanged*/, bool *pChangeDevice = nullptr) override
@@ -78,7 +91,10 @@ public:
         const BITMAPINFOHEADER &bih = vih2->bmiHeader;
         const mpcvr_rect src{vih2->rcSource.left, vih2->rcSource.top, vih2->rcSource.right, vih2->rcSource.bottom};
         DXVA2_ExtendedFormat ex{};
-        ex.value = (vih2->dwControlFlags & (AMCONTROL_USED | AMCONTROL_COLORINFO_PRESENT)) ? (LONG)vih2->dwControlFlags : 0;
+        if (vih2->dwControlFlags & (AMCONTROL_USED | AMCONTROL_COLORINFO_PRESENT)) {              // :1763-1766 (the decoder's DXVA2_ExtendedFormat bits)
+            ex.value = (LONG)vih2->dwControlFlags;
+            ex.SampleFormat = AMCONTROL_USED | AMCONTROL_COLORINFO_PRESENT;                       // "ignore other flags"
+        }
         const HRESULT hr = mpcvr_set_input(m_ctx, (int32_t)fmt.cformat, bih.biWidth, std::labs(bih.biHeight), /*pitch: the reference's rule*/ 0, &src, (uint32_t)ex.value);
         if (hr != MPCVR_S_OK) return 0;
         m_srcParams = fmt;
@@ -127,7 +143,7 @@ public:
     {
         m_cfg = FromSettings(s, false);
         (void)mpcvr_configure(m_ctx, &m_cfg);
-        (void)mpcvr_set_hdr_output(m_ctx, s.bHdrPassthrough, s.bHdrLocalToneMapping ? s.iHdrLocalToneMappingType : 0, (float)s.iHdrDisplayMaxNits);
+        (void)ApplyHdrOutput(s);
     }
     void SetRotation(int value) override { if (mpcvr_set_rotation(m_ctx, value) == MPCVR_S_OK) m_iRotation = value; }
     void SetFlipForwarded(bool value) { SetFlip(value); (void)mpcvr_set_flip(m_ctx, value); }    // (SetFlip itself is not virtual: VideoProcessor.h:210)
@@ -139,11 +155,28 @@ public:
         if (FAILED(hr)) return hr;
         BITMAPINFOHEADER *bih = (BITMAPINFOHEADER *)pDIBImage;
         std::memset(bih, 0, sizeof(*bih));
-        bih->biSize = sizeof(*bih); bih->biWidth = m_windowRect.Width(); bih->biHeight = -m_windowRect.Height();
+        LONG w = m_srcRect.Width(), h = m_srcRect.Height();                                       // the snapshot is SOURCE-rect sized (:3495-3502), not the window
+        if (m_iRotation == 90 || m_iRotation == 270) { const LONG t = w; w = h; h = t; }
+        bih->biSize = sizeof(*bih); bih->biWidth = w; bih->biHeight = -h;
         bih->biBitCount = 32; bih->biPlanes = 1; bih->biSizeImage = (DWORD)size;
         return mpcvr_get_current_image(m_ctx, bih + 1, &size);
     }
-    HRESULT GetDisplayedImage(BYTE ** /*ppDib*/, unsigned * /*pSize*/) override { return E_NOTIMPL; }
+    HRESULT GetDisplayedImage(BYTE **ppDib, unsigned *pSize) override                             // :3610-3683: header + the back buffer's pixels in a LocalAlloc block
+    {
+        size_t size = 0; int32_t w = 0, h = 0, bits = 0;
+        HRESULT hr = mpcvr_get_displayed_image(m_ctx, nullptr, &size, m_bAllowDeepColorBitmaps, &w, &h, &bits);
+        if (FAILED(hr)) return hr;
+        *pSize = (unsigned)(sizeof(BITMAPINFOHEADER) + size);
+        BYTE *p = (BYTE *)LocalAlloc(LMEM_FIXED, *pSize);                                         // "only this allocator can be used" (:3659); the caller frees it
+        if (!p) return E_OUTOFMEMORY;
+        BITMAPINFOHEADER *bih = (BITMAPINFOHEADER *)p;
+        std::memset(bih, 0, sizeof(*bih));
+        bih->biSize = sizeof(*bih); bih->biWidth = w; bih->biHeight = -h;                         // top-down RGB bitmap
+        bih->biBitCount = (decltype(bih->biBitCount))bits; bih->biPlanes = 1; bih->biSizeImage = (DWORD)size;
+        hr = mpcvr_get_displayed_image(m_ctx, bih + 1, &size, m_bAllowDeepColorBitmaps, nullptr, nullptr, nullptr);
+        if (SUCCEEDED(hr)) *ppDib = p; else LocalFree(p);
+        return hr;
+    }
     HRESULT GetVPInfo(std::wstring &str) override
     {
         char buf[512];

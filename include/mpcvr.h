@@ -275,6 +275,13 @@ int32_t mpcvr_get_backbuffer(mpcvr_ctx *ctx, void **dev_ptr, int32_t *pitch, int
  * Two-call size protocol (VideoRenderer.cpp:979-988): host_bgra == NULL => *size receives the bytes
  * needed (rect_w*rect_h*4); otherwise *size must be >= that.  Synchronous. */
 int32_t mpcvr_get_current_image(mpcvr_ctx *ctx, void *host_bgra, size_t *size);
+/* GetDisplayedImage — DX11VideoProcessor.cpp:3610-3683: the back buffer of the last mpcvr_render as it is (nothing is drawn again), as
+ * the pixels of a top-down DIB in host memory: a B8G8R8A8 buffer as it is; an R10G10B10A2 one as BGR32 (the top eight bits of each channel,
+ * ConvertR10G10B10A2toBGR32, Helper.cpp:805) or, with deep_color != 0 (m_bAllowDeepColorBitmaps), as BGR48 (ConvertR10G10B10A2toBGR48, :836).
+ * Rows are ((width * bits + 31) & ~31) / 8 bytes apart (CalcDibRowPitch).  The BITMAPINFOHEADER and the LocalAlloc block around the pixels
+ * are the caller's: host_pixels == NULL => *size, *width, *height and *bits_per_pixel are reported (any of the last three may be NULL);
+ * otherwise *size must be >= the size reported.  MPCVR_E_NOT_VALID_STATE before the first mpcvr_render.  Synchronous. */
+int32_t mpcvr_get_displayed_image(mpcvr_ctx *ctx, void *host_pixels, size_t *size, int32_t deep_color, int32_t *width, int32_t *height, int32_t *bits_per_pixel);
 
 /* Flush (DX11VideoProcessor.cpp:4074) / Reset (:3453). */
 int32_t mpcvr_flush(mpcvr_ctx *ctx);
@@ -414,6 +421,14 @@ int32_t mpcvr_plan_describe(const mpcvr_settings *s, int32_t cformat, int32_t re
  * 16, 16-byte aligned DEVICE buffers) once and writes fan * src_bytes — the fused kernels' traffic shape (a 4K P010 sample in, an 8K
  * B8G8R8A8 target out is 1 : 5.33) with no arithmetic.  dst holds fan * src_bytes bytes; stream = a hipStream_t or NULL. */
 int32_t mpcvr_bandwidth_probe(const void *src_dev, void *dst_dev, size_t src_bytes, int32_t fan, void *stream);
+/* ... and the exact-2x kernel's own shape over a whole batch in one launch (round 6): n (<= 64) bi-planar 16-bit 4:2:0 samples of src_w x src_h
+ * (P010: src_w * src_h * 3 bytes each) and n targets of 2 src_w x 2 src_h x 4 bytes; a wavefront owns a strip of 120 source columns x
+ * seg_rows source rows, reads two luma rows and a chroma row per step (240 contiguous bytes each) and writes four target rows (960 contiguous
+ * bytes each, one 16-byte piece per lane), like csrc/vp_fused_up2x.h.  mode 0: read + write, 1: write only, 2: read only.  strip_cols (even, <= 128):
+ * source columns per wavefront — 120 is the kernel's, 128 the 1 KiB-aligned variant of the same pattern.  The pointer arrays are
+ * HOST arrays of DEVICE pointers (16-byte aligned). */
+int32_t mpcvr_bandwidth_probe_up2x(int32_t mode, int32_t n, const void *const *srcs_dev, void *const *dsts_dev, int32_t src_w, int32_t src_h,
+                                   int32_t seg_rows, int32_t strip_cols, void *stream);
 
 /* A verification aid, not part of the video path: the transcendentals of the pass-per-kernel tier (csrc/vp_crmath.h — HLSL's
  * pow(x, y) = exp2(y * log2(x)) as d3dcompiler lowers it, Shaders/convert/st2084.hlsl:9-25, with every step the correctly rounded fp32

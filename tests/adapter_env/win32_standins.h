@@ -1,7 +1,7 @@
 // tests/adapter_env/win32_standins.h — TEST INFRASTRUCTURE ONLY (ours): the Windows / DirectShow / ATL names the reference's CVideoProcessor
 // interface (Source/VideoProcessor.h:171-236) mentions, as opaque stand-ins, so that examples/hip_video_processor_adapter.cpp can be
 // compiled here against the REAL method declarations (cut out of the reference header at test time) and the REAL Settings_t
-// (Source/IVideoRenderer.h, included as it is).  Nothing here is linked into anything.
+// (Source/IVideoRenderer.h, included as it is) — and, since round 6, linked with a driver and run (build_adapter.py, adapter_driver.cpp).
 #pragma once
 #include <cstdint>
 #include <cstddef>
@@ -31,9 +31,13 @@ struct CRect : RECT {
 #define E_NOTIMPL ((HRESULT)0x80004001)
 #define E_FAIL ((HRESULT)0x80004005)
 #define E_POINTER ((HRESULT)0x80004003)
+#define E_OUTOFMEMORY ((HRESULT)0x8007000E)
+#define LMEM_FIXED 0
+inline void *LocalAlloc(unsigned, size_t n) { return std::malloc(n); }
+inline void *LocalFree(void *p) { std::free(p); return nullptr; }
 #define SUCCEEDED(hr) (((HRESULT)(hr)) >= 0)
 #define FAILED(hr) (((HRESULT)(hr)) < 0)
-#define AMCONTROL_USED 0x00000080u
+#define AMCONTROL_USED 0x00000001u
 #define AMCONTROL_COLORINFO_PRESENT 0x00000080u
 
 struct GUID { uint32_t a; uint16_t b, c; uint8_t d[8]; };

@@ -215,6 +215,87 @@ def test_pass_per_kernel_path_vs_oracle(mpcvr, oracle, torch_cuda, name):
         compare(got, want, name, exact=True)
 
 
+ADAPTER_DRIVER = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "adapter_driver")
+
+
+@pytest.mark.parametrize("name,window,offset,ten", [("c3hdr_p010_pq_lanczos3_2x", None, None, 0), ("c1_nv12_bt709_passthrough", (160, 96), (12, 6), 0),
+                                                    ("up_1p5x_lanczos3", None, None, 0)])
+def test_one_frame_through_the_adapter_class(mpcvr, oracle, torch_cuda, tmp_path, name, window, offset, ten):
+    """The drop-in boundary exercised AS a CVideoProcessor (review item: the adapter was only ever checked for syntax).
+    examples/hip_video_processor_adapter.cpp — compiled against the reference's own method list (Source/VideoProcessor.h:171-236, cut out of
+    the header when oracle/_ref/adapter_driver was built) and linked with libmpcvr.so — is driven through the BASE-CLASS pointer the way the
+    filter drives a processor: Init -> VerifyMediaType / InitMediaType(CMediaType over a VIDEOINFOHEADER2) -> SetWindowRect / SetVideoRect ->
+    ProcessSample(IMediaSample over a host buffer) -> GetDisplayedImage -> GetCurentImage -> GetVPInfo.  What comes back is compared with the
+    oracle: the displayed image (the back buffer Render drew: the window, black outside the video rect) and the snapshot (source-rect sized)."""
+    import subprocess
+    if not os.path.exists(ADAPTER_DRIVER):
+        pytest.skip("oracle/_ref/adapter_driver is built where /root/reference is mounted (tests/adapter_env/build_adapter.py)")
+    c = dict(GOLDEN_CASES[name])
+    if window:
+        c["window"], c["offset"] = window, offset
+    (ww, wh), vr = case_geometry(c)
+    frame, pitch = case_frame(c)
+    assert pitch > 0
+    sample = tmp_path / "sample.bin"
+    sample.write_bytes(np.ascontiguousarray(frame).tobytes())
+    exf = (c.get("exfmt", 0) & ~0xff) | (0x81 if c.get("exfmt", 0) else 0)      # AMCONTROL_USED | AMCONTROL_COLORINFO_PRESENT: "the bits are valid" (:1763)
+    args = [ADAPTER_DRIVER, str(c["cformat"]), str(c["w"]), str(c["h"]), str(exf), str(ww), str(wh), *(str(v) for v in vr), str(c.get("iUpscaling", 2)), str(ten),
+            str(sample), str(tmp_path / "displayed.bin"), str(tmp_path / "snapshot.bin")]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr[-1500:])
+    out = dict(l.split(" ", 1) for l in r.stdout.splitlines() if " " in l)
+    assert out["DISPLAYED"].split() == [str(ww), str(wh), "32", str(ww * wh * 4)], out
+    assert out["SNAPSHOT"].split() == [str(c["w"]), str(c["h"]), "32", str(c["w"] * c["h"] * 4)], out
+    assert out["VPINFO"].startswith("HIP shader video processor: ") and out["TYPE"].startswith("12 "), out
+    # the displayed image: Render clears the back buffer to black, Process fills the video rect (DX11VideoProcessor.cpp:2622, 3285)
+    shown = np.frombuffer((tmp_path / "displayed.bin").read_bytes(), dtype=np.uint8).reshape(wh, ww, 4)
+    p = oracle_params(oracle, c)
+    want = oracle.process(p, frame, pitch, dst=np.zeros((wh, ww, 4), dtype=np.uint8))
+    d = np.abs(shown[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
+    assert d.max() <= 1, f"{name}: displayed image vs oracle: max {int(d.max())} [{out['VPINFO']}]"
+    inside = np.zeros((wh, ww), bool)
+    inside[max(vr[1], 0):min(vr[3], wh), max(vr[0], 0):min(vr[2], ww)] = True
+    assert not shown[~inside][:, :3].any(), "the letterbox area is black"
+    # the snapshot: the frame at source-rect size into a B8G8R8X8 image (:3493-3608)
+    snap = np.frombuffer((tmp_path / "snapshot.bin").read_bytes(), dtype=np.uint8).reshape(c["h"], c["w"], 4)
+    cs = {k: v for k, v in c.items() if k not in ("window", "offset")}
+    cs["dst"] = (c["w"], c["h"])
+    ps = oracle_params(oracle, cs)
+    want_s = oracle.process(ps, frame, pitch, dst=np.zeros((c["h"], c["w"], 4), dtype=np.uint8))
+    ds = np.abs(snap[..., :3].astype(np.int16) - want_s[..., :3].astype(np.int16))
+    assert ds.max() <= 1, f"{name}: snapshot vs oracle: max {int(ds.max())}"
+
+
+def test_get_displayed_image_formats(mpcvr, oracle, torch_cuda):
+    """mpcvr_get_displayed_image (GetDisplayedImage, DX11VideoProcessor.cpp:3610-3683) on a 10-bit back buffer: BGR32 = the top eight bits of
+    each channel (ConvertR10G10B10A2toBGR32, Helper.cpp:805), BGR48 with deep colour = the ten bits in the top of each word (:836), rows
+    CalcDibRowPitch apart; an 8-bit back buffer comes back as it is; before the first Render the call is refused."""
+    from videorenderer_amd import api
+    c = dict(GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"], output_format=1)
+    vp, (ww, wh) = make_vp(mpcvr, c)
+    with pytest.raises(api.MpcvrError):
+        vp.GetDisplayedImage()
+    frame, pitch = case_frame(c)
+    vp.CopySample(torch_cuda.from_numpy(frame).cuda(), pitch)
+    vp.Render()
+    ptr, bp, bw, bh = vp.GetBackBuffer()
+    assert (bw, bh, bp) == (ww, wh, ww * 4)
+    raw = np.empty((wh, ww), dtype=np.uint32)
+    import ctypes as C
+    vp.Synchronize()
+    assert C.CDLL("libamdhip64.so").hipMemcpy(C.c_void_p(raw.ctypes.data), C.c_void_p(ptr), C.c_size_t(raw.nbytes), 2) == 0      # hipMemcpyDeviceToHost
+    px32, w, h, bits = vp.GetDisplayedImage()
+    assert (w, h, bits) == (ww, wh, 32)
+    want32 = ((raw & 0x3fc00000) >> 22) | ((raw & 0x000ff000) >> 4) | ((raw & 0x000003fc) << 14) | 0xff000000
+    assert np.array_equal(px32.view(np.uint32).reshape(wh, ww), want32)
+    px48, w, h, bits = vp.GetDisplayedImage(deep_color=True)
+    pitch48 = ((ww * 48 + 31) & ~31) // 8
+    assert bits == 48 and px48.size == pitch48 * wh
+    rows = px48.reshape(wh, pitch48)[:, :ww * 6].view(np.uint16).reshape(wh, ww, 3)
+    assert np.array_equal(rows[..., 0], ((raw >> 20) & 1023) << 6) and np.array_equal(rows[..., 1], ((raw >> 10) & 1023) << 6) and np.array_equal(rows[..., 2], (raw & 1023) << 6)
+    vp.close()
+
+
 def test_fused_jinc_steps_aside_where_the_device_grants_less_lds(mpcvr, torch_cuda):
     """The fused Jinc2m kernel claims 114 - 146 KiB of LDS per workgroup; UpdatePlan compares that with what the device grants and keeps the
     convert + k_jinc2 draws otherwise (advisor, round 5: the launch failed on every frame of such a plan).  MPCVR_LDS_LIMIT plans as if this

@@ -155,7 +155,7 @@ EXPORTS = [
     "mpcvr_set_input", "mpcvr_set_video_rect", "mpcvr_set_window_rect", "mpcvr_set_rotation", "mpcvr_set_flip", "mpcvr_set_sample_format", "mpcvr_set_hdr_output", "mpcvr_set_hdr_metadata",
     "mpcvr_set_dovi_metadata", "mpcvr_plan_dovi", "mpcvr_correction_pass", "mpcvr_plan_correction_matrices",
     "mpcvr_configure", "mpcvr_set_procamp", "mpcvr_copy_sample", "mpcvr_process", "mpcvr_render",
-    "mpcvr_get_backbuffer", "mpcvr_get_current_image", "mpcvr_flush", "mpcvr_reset", "mpcvr_process_batch", "mpcvr_process_batch_dovi",
+    "mpcvr_get_backbuffer", "mpcvr_get_current_image", "mpcvr_get_displayed_image", "mpcvr_flush", "mpcvr_reset", "mpcvr_process_batch", "mpcvr_process_batch_dovi",
     "mpcvr_get_param_blob", "mpcvr_set_param_blob", "mpcvr_broadcast_param_blob_begin", "mpcvr_broadcast_param_blob_end",
     "mpcvr_broadcast_param_blob", "mpcvr_get_color_matrix", "mpcvr_get_extfmt",
     "mpcvr_get_frame_bytes", "mpcvr_get_path_info", "mpcvr_get_last_batch_info", "mpcvr_last_error", "mpcvr_version",
@@ -163,7 +163,7 @@ EXPORTS = [
     "mpcvr_plan_frame_layout", "mpcvr_plan_color_matrix", "mpcvr_plan_gamut_2020_to_709", "mpcvr_plan_pq_lut",
     "mpcvr_plan_upscale_weights", "mpcvr_plan_axis_taps", "mpcvr_plan_describe", "mpcvr_plan_final_pass_multiplier",
     "mpcvr_plan_strip", "mpcvr_plan_pq_eotf_table", "mpcvr_bandwidth_probe", "mpcvr_plan_period", "mpcvr_plan_hdr10_params",
-    "mpcvr_eval_transcendental", "mpcvr_eval_transcendental_host",
+    "mpcvr_eval_transcendental", "mpcvr_eval_transcendental_host", "mpcvr_bandwidth_probe_up2x",
 ]
 
 _lib = None
@@ -219,6 +219,7 @@ def load_library():
         "mpcvr_process": [vp, vp, i32, P(Rect), P(Rect), i32],
         "mpcvr_render": [vp, i32],
         "mpcvr_get_backbuffer": [vp, P(vp), P(i32), P(i32), P(i32)],
+        "mpcvr_get_displayed_image": [vp, C.c_void_p, P(C.c_size_t), i32, P(i32), P(i32), P(i32)],
         "mpcvr_get_current_image": [vp, vp, P(C.c_size_t)],
         "mpcvr_flush": [vp],
         "mpcvr_reset": [vp],
@@ -248,6 +249,7 @@ def load_library():
         "mpcvr_plan_period": [i32, i32, i32, i32, i32, u32, P(i32), P(i32), P(f), P(f), P(i32), P(i32)],
         "mpcvr_plan_pq_eotf_table": [P(f), i32, P(i32)],
         "mpcvr_bandwidth_probe": [C.c_void_p, C.c_void_p, C.c_size_t, i32, C.c_void_p],
+        "mpcvr_bandwidth_probe_up2x": [i32, i32, P(C.c_void_p), P(C.c_void_p), i32, i32, i32, i32, C.c_void_p],
         "mpcvr_eval_transcendental": [i32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
         "mpcvr_eval_transcendental_host": [i32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
         "mpcvr_plan_describe": [P(Settings), i32, i32, i32, P(Rect), i32, i32, C.c_char_p, C.c_size_t],
@@ -583,6 +585,15 @@ class VideoProcessor:
         buf = np.empty(size.value, dtype=np.uint8)
         self._check(self._L.mpcvr_get_current_image(self._ctx, C.c_void_p(buf.ctypes.data), C.byref(size)))
         return buf
+
+    def GetDisplayedImage(self, deep_color=False):
+        """GetDisplayedImage (DX11VideoProcessor.cpp:3610): the back buffer of the last Render as DIB pixels -> (numpy bytes, width, height, bits)."""
+        import numpy as np
+        size, w, h, bits = C.c_size_t(0), C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._L.mpcvr_get_displayed_image(self._ctx, None, C.byref(size), int(deep_color), C.byref(w), C.byref(h), C.byref(bits)))
+        buf = np.empty(size.value, dtype=np.uint8)
+        self._check(self._L.mpcvr_get_displayed_image(self._ctx, C.c_void_p(buf.ctypes.data), C.byref(size), int(deep_color), C.byref(w), C.byref(h), C.byref(bits)))
+        return buf, w.value, h.value, bits.value
 
     def ProcessBatch(self, srcs, dsts, rt_pitch):
         if isinstance(srcs, PreparedBatch):          # pointer arrays built once (PrepareBatch): nothing per call but the C call

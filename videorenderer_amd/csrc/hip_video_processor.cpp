@@ -1925,6 +1925,7 @@ HRESULT CHipVideoProcessor::Render(int /*field*/)
     m_clearOnRun = (fresh || m_videoRect != CRect(0, 0, w, h)) ? bytes : 0;     // queued by Process on the stream the frame runs on
     hr = Process(m_BackBuffer.ptr, w * 4, nullptr, nullptr, false);
     m_clearOnRun = 0;
+    if (hr >= 0) { m_backW = w; m_backH = h; m_backFmt = m_cfg.output_format; }        // what GetDisplayedImage will find there
     return hr;
 }
 
@@ -1935,6 +1936,54 @@ HRESULT CHipVideoProcessor::GetBackBuffer(void **ptr, int *pitch, int *w, int *h
     if (pitch) *pitch = m_windowRect.Width() * 4;
     if (w) *w = m_windowRect.Width();
     if (h) *h = m_windowRect.Height();
+    return MPCVR_S_OK;
+}
+
+// GetDisplayedImage — DX11VideoProcessor.cpp:3610-3683: the back buffer as it was last rendered (no new draw), copied to host memory as the
+// pixels of a top-down DIB: B8G8R8A8 as it is (CopyPlaneAsIs); R10G10B10A2 as BGR32 through ConvertR10G10B10A2toBGR32 (Helper.cpp:805-834:
+// the top eight bits of each channel, X = 0xff) or, with m_bAllowDeepColorBitmaps, as BGR48 (ConvertR10G10B10A2toBGR48, :836-857: the ten
+// bits in the top of each 16-bit word).  Rows are CalcDibRowPitch(width, bits) apart.  The BITMAPINFOHEADER and the LocalAlloc block the
+// reference puts around the pixels are the caller's (the adapter's): host_pixels == NULL reports the size and the header's fields.
+HRESULT CHipVideoProcessor::GetDisplayedImage(void *hostPixels, size_t *size, bool deepColor, int *width, int *height, int *bits)
+{
+    if (!size) return Fail(MPCVR_E_POINTER, "null size");
+    if (!m_BackBuffer.ptr || m_backW <= 0 || m_backH <= 0) return Fail(MPCVR_E_NOT_VALID_STATE, "Render has not been called");     // (E_ABORT without a swap chain, :3612-3614)
+    const int w = m_backW, h = m_backH;
+    const bool ten = m_backFmt == MPCVR_OUT_RGB10A2;
+    const int bpp = (ten && deepColor) ? 48 : 32;
+    const size_t dibPitch = (((size_t)w * bpp + 31) & ~(size_t)31) / 8, need = dibPitch * h;      // CalcDibRowPitch
+    if (width) *width = w;
+    if (height) *height = h;
+    if (bits) *bits = bpp;
+    if (!hostPixels) { *size = need; return MPCVR_S_OK; }
+    if (*size < need) { *size = need; return Fail(MPCVR_E_INVALIDARG, "buffer too small"); }
+    HRESULT hr = Synchronize();                     // frames still on the lanes / the context stream write the buffer
+    if (hr) return hr;
+    const size_t srcPitch = (size_t)w * 4;
+    if (!ten) {                                     // 32 bits per pixel: the DIB pitch is the back buffer's
+        if ((hr = CheckHip(hipMemcpy(hostPixels, m_BackBuffer.ptr, need, hipMemcpyDeviceToHost), "displayed image read-back"))) return hr;
+    } else {
+        std::vector<uint32_t> staging((size_t)w * h);
+        if ((hr = CheckHip(hipMemcpy(staging.data(), m_BackBuffer.ptr, srcPitch * h, hipMemcpyDeviceToHost), "displayed image read-back"))) return hr;
+        for (int y = 0; y < h; y++) {
+            const uint32_t *src = staging.data() + (size_t)y * w;
+            uint8_t *row = (uint8_t *)hostPixels + (size_t)y * dibPitch;
+            if (bpp == 32) {
+                uint32_t *d = (uint32_t *)row;
+                for (int x = 0; x < w; x++) {
+                    const uint32_t t = src[x];
+                    d[x] = ((t & 0x3fc00000u) >> 22) | ((t & 0x000ff000u) >> 4) | ((t & 0x000003fcu) << 14) | 0xff000000u;
+                }
+            } else {
+                uint16_t *d = (uint16_t *)row;
+                for (int x = 0; x < w; x++) {
+                    const uint32_t t = src[x];
+                    *d++ = (uint16_t)((t & 0x3ff00000u) >> 14); *d++ = (uint16_t)((t & 0x000ffc00u) >> 4); *d++ = (uint16_t)((t & 0x000003ffu) << 6);
+                }
+            }
+        }
+    }
+    *size = need;
     return MPCVR_S_OK;
 }
 

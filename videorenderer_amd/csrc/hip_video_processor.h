@@ -62,6 +62,7 @@ public:
     HRESULT Render(int field);                                                // :2599 minus Present
     HRESULT GetBackBuffer(void **ptr, int *pitch, int *w, int *h);
     HRESULT GetCurentImage(void *hostBGRA, size_t *size);                     // :3493
+    HRESULT GetDisplayedImage(void *hostPixels, size_t *size, bool deepColor, int *width, int *height, int *bits);     // :3610
     HRESULT ProcessBatch(int n, const void *const *srcs, void *const *dsts, int rtPitch);
     std::string GetLastBatchInfo() const;
     HRESULT ProcessBatchDovi(int n, const void *const *srcs, void *const *dsts, int rtPitch, const mpcvr_dovi_metadata *rpus);
@@ -217,6 +218,7 @@ private:
     void MarkConsumed();
     const uint8_t *m_curSample = nullptr;   // device pointer of the current sample (own buffer or zero-copy)
     DevBuffer m_TexConvertOutput, m_TexResize, m_BackBuffer, m_Snapshot;
+    int m_backW = 0, m_backH = 0, m_backFmt = 0;       // the last frame Render put into m_BackBuffer: size and format (GetDisplayedImage)
     DevBuffer m_dither;
     DevBuffer m_pqLut;             // kPqLutSize floats (fused path tone-map table)
     DevBuffer m_hlgLut;            // kPqLutSize floats: per-channel inverse HLG OETF (fused kernels' HLG -> SDR tail)

@@ -122,6 +122,11 @@ int32_t mpcvr_get_backbuffer(mpcvr_ctx *ctx, void **dev_ptr, int32_t *pitch, int
 }
 
 int32_t mpcvr_get_current_image(mpcvr_ctx *ctx, void *host_bgra, size_t *size) { CTX_OR_FAIL(); return ctx->vp.GetCurentImage(host_bgra, size); }
+int32_t mpcvr_get_displayed_image(mpcvr_ctx *ctx, void *host_pixels, size_t *size, int32_t deep_color, int32_t *width, int32_t *height, int32_t *bits_per_pixel)
+{
+    CTX_OR_FAIL();
+    return ctx->vp.GetDisplayedImage(host_pixels, size, deep_color != 0, width, height, bits_per_pixel);
+}
 int32_t mpcvr_flush(mpcvr_ctx *ctx) { CTX_OR_FAIL(); ctx->vp.Flush(); return MPCVR_S_OK; }
 int32_t mpcvr_reset(mpcvr_ctx *ctx) { CTX_OR_FAIL(); return ctx->vp.Reset(); }
 
