@@ -574,12 +574,28 @@ def main():
             vp2.Synchronize()
             res_pf[label] = nf / (time.perf_counter() - tp)
             res_pf[label + "_last_process_ms"] = round(vp2.GetLastTimings()["process_ms"], 4)
+            # the same frames through ONE call (mpcvr_process_frames: the loop of copy_sample + process inside the library, as a C / C++ render
+            # thread runs it): what the path costs without two ctypes calls per frame
+            arr = C.c_void_p * nf
+            sa = arr(*[sp[i % ring].value for i in range(nf)])
+            da = arr(*[dp[i % ring].value for i in range(nf)])
+            if L.mpcvr_process_frames(ctx, nf, sa, pitch, api.MEM_DEVICE, da, dw * 4) < 0:
+                raise SystemExit("per-frame path (one call): " + L.mpcvr_last_error(ctx).decode())
+            vp2.Synchronize()
+            tp = time.perf_counter()
+            if L.mpcvr_process_frames(ctx, nf, sa, pitch, api.MEM_DEVICE, da, dw * 4) < 0:
+                raise SystemExit("per-frame path (one call): " + L.mpcvr_last_error(ctx).decode())
+            vp2.Synchronize()
+            res_pf[label + "_native_loop"] = nf / (time.perf_counter() - tp)
             vp2.close()
         per_frame = {"frames_per_s": round(res_pf["frame_lanes"], 1), "frames_per_s_one_after_the_other": round(res_pf["one_after_the_other"], 1),
+                     "frames_per_s_native_loop": round(res_pf["frame_lanes_native_loop"], 1),
+                     "frames_per_s_one_after_the_other_native_loop": round(res_pf["one_after_the_other_native_loop"], 1),
                      "last_process_ms": res_pf["frame_lanes_last_process_ms"], "last_process_ms_one_after_the_other": res_pf["one_after_the_other_last_process_ms"],
                      "hbm_frac": round(res_pf["frame_lanes"] * algo_bytes / 1e9 / HBM_PEAK_GBS, 4),
                      "note": "mpcvr_copy_sample(device) + mpcvr_process per frame, wall clock over frames queued back to back, one mpcvr_synchronize at the end; "
-                             "the context owns its stream (no mpcvr_set_stream), so consecutive frames overlap on its frame lanes (MPCVR_FLAG_NO_FRAME_LANES: off)"}
+                             "the context owns its stream (no mpcvr_set_stream), so consecutive frames overlap on its frame lanes (MPCVR_FLAG_NO_FRAME_LANES: off); "
+                             "*_native_loop: the same frames through mpcvr_process_frames (the per-frame loop inside the library: no ctypes call per frame)"}
 
     if rank == 0:
         # one process per GPU means one GPU per process: two ranks on one device would double-count its throughput.

@@ -92,8 +92,8 @@ enum { MPCVR_OUT_BGRA8 = 0, MPCVR_OUT_RGB10A2 = 1 };
                                              path runs instead (debug / A-B) */
 
 #define MPCVR_FLAG_FUSED_VALU       0x10u /* fused 2x kernel with its resize taps as packed-fp32 VALU chains (k_fused_up2x) */
-#define MPCVR_FLAG_FUSED_MFMA       0x20u /* fused 2x kernel with its resize taps on the matrix cores (k_fused_up2x_mx); neither flag:
-                                             the packed-fp32 VALU kernel, unless the environment says MPCVR_FUSED_MX=1 */
+#define MPCVR_FLAG_FUSED_MFMA       0x20u /* accepted and ignored since round 6 (it selected an experiment kernel with the resize taps on the matrix
+                                             cores: parity-green, never faster; kept under profiles/r06/experiments/matrix_core_taps/) */
 #define MPCVR_FLAG_NO_STRIP         0x40u /* arbitrary-ratio resizes of 4:2:0 sources stay on the block convert + tiled two-draw
                                              kernels instead of the one-kernel strip path (k_fused_strip; debug / A-B) */
 #define MPCVR_FLAG_FORCE_PERIOD     0x100u /* take k_fused_period wherever it is built, also where the planner prefers k_fused_strip (SDR content with a
@@ -265,6 +265,12 @@ int32_t mpcvr_copy_sample(mpcvr_ctx *ctx, const void *data, int32_t pitch, int32
  * dst_rect NULL => the context's video rect.  Pixels outside dst_rect are not written. */
 int32_t mpcvr_process(mpcvr_ctx *ctx, void *dst_dev, int32_t dst_pitch, const mpcvr_rect *src_rect,
                       const mpcvr_rect *dst_rect, int32_t second_field);
+
+/* n frames the reference's way — mpcvr_copy_sample(samples[i], pitch, mem_kind) then mpcvr_process(dsts_dev[i], dst_pitch, NULL, NULL, 0), frame
+ * after frame (ProcessSample -> CopySample -> Render -> Process, DX11VideoProcessor.cpp:2143-2200, :2730) — behind one call, so that a caller
+ * in a scripting language measures the path and not its own foreign-function calls.  Not a batch: every frame is its own launch (or lands
+ * on the context's frame lanes); stops at the first failure and returns it. */
+int32_t mpcvr_process_frames(mpcvr_ctx *ctx, int32_t n, const void *const *samples, int32_t pitch, int32_t mem_kind, void *const *dsts_dev, int32_t dst_pitch);
 
 /* Render minus Present — DX11VideoProcessor.cpp:2599-2813: Process into the context-owned back buffer. */
 int32_t mpcvr_render(mpcvr_ctx *ctx, int32_t field);

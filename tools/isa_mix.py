@@ -3,7 +3,7 @@
 
 usage: isa_mix.py listing.s [kernel-substring]
 Finds the longest backward branch inside the (first matching) kernel and counts the instructions of that loop body
-by issue class.  Cost model (tools/ubench/mfma_mix.hip, valu_rate.hip on MI355X): plain wave64 VALU = 1 unit,
+by issue class.  Cost model (tools/ubench/valu_rate.hip, op_rate.hip on MI355X): plain wave64 VALU = 1 unit,
 v_pk_*_f32 = 2 units, transcendental = 4 units.
 """
 import re, sys, collections

@@ -154,7 +154,7 @@ EXPORTS = [
     "mpcvr_settings_default", "mpcvr_create", "mpcvr_destroy", "mpcvr_set_stream", "mpcvr_synchronize",
     "mpcvr_set_input", "mpcvr_set_video_rect", "mpcvr_set_window_rect", "mpcvr_set_rotation", "mpcvr_set_flip", "mpcvr_set_sample_format", "mpcvr_set_hdr_output", "mpcvr_set_hdr_metadata",
     "mpcvr_set_dovi_metadata", "mpcvr_plan_dovi", "mpcvr_correction_pass", "mpcvr_plan_correction_matrices",
-    "mpcvr_configure", "mpcvr_set_procamp", "mpcvr_copy_sample", "mpcvr_process", "mpcvr_render",
+    "mpcvr_configure", "mpcvr_set_procamp", "mpcvr_copy_sample", "mpcvr_process", "mpcvr_process_frames", "mpcvr_render",
     "mpcvr_get_backbuffer", "mpcvr_get_current_image", "mpcvr_get_displayed_image", "mpcvr_flush", "mpcvr_reset", "mpcvr_process_batch", "mpcvr_process_batch_dovi",
     "mpcvr_get_param_blob", "mpcvr_set_param_blob", "mpcvr_broadcast_param_blob_begin", "mpcvr_broadcast_param_blob_end",
     "mpcvr_broadcast_param_blob", "mpcvr_get_color_matrix", "mpcvr_get_extfmt",
@@ -218,6 +218,7 @@ def load_library():
         "mpcvr_copy_sample": [vp, vp, i32, i32],
         "mpcvr_process": [vp, vp, i32, P(Rect), P(Rect), i32],
         "mpcvr_render": [vp, i32],
+        "mpcvr_process_frames": [vp, i32, P(C.c_void_p), i32, i32, P(C.c_void_p), i32],
         "mpcvr_get_backbuffer": [vp, P(vp), P(i32), P(i32), P(i32)],
         "mpcvr_get_displayed_image": [vp, C.c_void_p, P(C.c_size_t), i32, P(i32), P(i32), P(i32)],
         "mpcvr_get_current_image": [vp, vp, P(C.c_size_t)],

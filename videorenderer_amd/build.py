@@ -28,7 +28,6 @@ SOURCES = [
     ("vp_fused_up2x_nt4.hip", []),
     ("vp_fused_up2x_nt5.hip", []),
     ("vp_fused_up2x_nt6.hip", []),
-    ("vp_fused_mx.hip", []),
     ("vp_fused_strip.hip", []),
     ("vp_fused_strip_nt4.hip", []),
     ("vp_fused_strip_nt6.hip", []),

@@ -1029,7 +1029,6 @@ void CHipVideoProcessor::FillFusedParams(const uint8_t *sample, void *rt, int rt
     fp->dovi_cm = (m_doviValid && m_dvTabDev) ? m_dvCmDev : nullptr;
     fp->jinc_tab = m_plan.fused_jinc ? m_jincFusedTab : nullptr;
     fp->exact_wide = m_plan.hdr_tonemap ? 1 : 0;
-    fp->taps_mfma = (m_cfg.flags & MPCVR_FLAG_FUSED_MFMA) ? 1 : (m_cfg.flags & MPCVR_FLAG_FUSED_VALU) ? 0 : -1;
     fp->inflight = m_inflight;
     fp->dst_aligned16 = (((uintptr_t)rt) & 15) == 0;        // batches: ProcessBatch checks every target
     fp->src_aligned16 = (((uintptr_t)sample) & 15) == 0;

@@ -770,14 +770,10 @@ hipError_t LaunchFusedUp2x(const FusedParams &P, const FusedFrame *frames_dev, F
     if (seg > c.out_h) seg = c.out_h;
     a.seg_rows = seg;
 
-    // default: the packed-fp32 VALU kernel (vp_fused_up2x.h).  The matrix-core variant (vp_fused_mx.hip) runs when MPCVR_FLAG_FUSED_MFMA
-    // is set, or — with neither flag — when the environment says MPCVR_FUSED_MX=1; it is parity-green but not faster
-    static const int mx_default = EnvInt("MPCVR_FUSED_MX", 0);
-    if (P.taps_mfma >= 0 ? P.taps_mfma != 0 : mx_default != 0) {
-        const hipError_t e = LaunchFusedUp2xMx(P, a, knt, frames_dev, single, n_frames, s);
-        if (e != hipErrorNotSupported) return e;            // (a combination the experiment kernel is not built for: the default kernel below)
-    }
-
+    // (the matrix-core variant of the taps — k_fused_up2x_mx, MPCVR_FLAG_FUSED_MFMA — left the build in round 6: parity-green, never faster
+    // than the packed-fp32 chains on this part (profiles/r03/mfma_overlap_ubench.txt: the matrix pipe does not overlap v_pk_fma_f32), 16
+    // instantiations and half a CPU-minute of build; its source is kept under profiles/r06/experiments/matrix_core_taps/.  The flag is accepted
+    // and ignored.)
     if (knt == 4) return LaunchFusedUp2xNT<4>(P, a, strips, seg, frames_dev, single, n_frames, s);
     if (knt == 5) return LaunchFusedUp2xNT<5>(P, a, strips, seg, frames_dev, single, n_frames, s);
     return LaunchFusedUp2xNT<6>(P, a, strips, seg, frames_dev, single, n_frames, s);

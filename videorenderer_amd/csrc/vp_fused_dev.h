@@ -1120,7 +1120,6 @@ int FusedSourceKind(const FusedParams &P);
 int FusedDoviKind(const FusedParams &P);          // DV_* for the launch
 // vp_fused_mx.hip: the same launch as LaunchFusedUp2x with the resize taps on the matrix cores; hipErrorNotSupported when the
 // variant does not cover the configuration (the caller then launches the packed-fp32 kernel)
-hipError_t LaunchFusedUp2xMx(const FusedParams &P, const FusedArgs &a, int knt, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
 // dynamic LDS above the default limit needs the function attribute once per kernel (and device); remembered per (kernel, device) (vp_fused_strip.hip)
 hipError_t AllowLargeLds(const void *kern, size_t lds);
 int DeviceCuCount();        // vp_fused.hip: compute units of the current device (256)

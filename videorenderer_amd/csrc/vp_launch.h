@@ -75,7 +75,6 @@ struct FusedParams {
     // ConvertParams::cm); the block convert's Dolby Vision variants index both by the frame.  Null: one RPU for the launch (conv.dovi, conv.cm)
     const float *dovi_cm;
     const float *jinc_tab;    // fused 2x route with the 2-D Jinc2m filter (PassPlan::fused_jinc): the device copy of BuildFusedJincTable's table; null: separable taps (wx, wy)
-    int taps_mfma;            // fused 2x kernel: 1 = resize taps on the matrix cores, 0 = packed-fp32 VALU chains, -1 = library default
     int exact_wide;           // an HDR10 tone-mapping operator follows (PassPlan::hdr_tonemap): its curve multiplies a code of the 10-bit internal format by up
                               // to ~5, so such plans take the exact form of the convert stage for 10-bit internal formats as well
     int exact_convert;        // a resize reads this launch's convert output: 8-bit internal formats then take the exact form of the convert stage
