@@ -1570,6 +1570,16 @@ def _tiers_agree(mpcvr, torch, c, fast_flags, expect):
     assert expect in info, (c, info)
     ref, info_ref = run_product(mpcvr, torch, c, extra_flags=api.FLAG_NO_FUSED)
     assert info_ref.startswith("passes:"), info_ref
+    # Round 6: the plain tier carries the ORACLE's bits (tails included), so "the fast tier within the bar of the plain one" below IS "within the
+    # bar of the oracle" — checked here on every sweep case instead of assumed (round 5's review: ~90 sweep tests compared two GPU tiers only)
+    from oracle import oracle as O
+    frame, pitch = case_frame(c)
+    po = oracle_params(O, c)
+    want = O.process(po, frame, pitch, dst=np.full((po.window_h, po.window_w, 4), BG, dtype=np.uint8))
+    if c.get("output_format", 0) == 1:
+        assert np.array_equal(_codes10(ref), _codes10(want)), (c, info_ref, "plain tier != oracle")
+    else:
+        assert np.array_equal(ref[..., :3], want[..., :3]), (c, info_ref, "plain tier != oracle", int(np.abs(ref[..., :3].astype(int) - want[..., :3].astype(int)).max()))
     if c.get("output_format", 0) == 1:
         g, r = got.view(np.uint32)[..., 0], ref.view(np.uint32)[..., 0]
         lim = 5 if internal_is_8bit(c) else 2 if has_tail(c) else 1
@@ -2795,7 +2805,7 @@ def test_process_frames_equals_frame_by_frame_calls(mpcvr, torch_cuda):
     from videorenderer_amd import api
     torch = torch_cuda
     L = api.load_library()
-    c = GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"]
+    c = GOLDEN_CASES["noise_p010_pq_lanczos3_2x"]
     frames = [torch.from_numpy(case_frame(dict(c, seed=c["seed"] + 5 * k))[0]).cuda() for k in range(6)]
     for extra in (0, api.FLAG_NO_FRAME_LANES):
         vp = api.VideoProcessor(api.default_settings(iUpscaling=c["iUpscaling"], flags=extra), device=0, use_torch_stream=False)
