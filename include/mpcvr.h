@@ -96,8 +96,9 @@ enum { MPCVR_OUT_BGRA8 = 0, MPCVR_OUT_RGB10A2 = 1 };
                                              cores: parity-green, never faster; kept under profiles/r06/experiments/matrix_core_taps/) */
 #define MPCVR_FLAG_NO_STRIP         0x40u /* arbitrary-ratio resizes of 4:2:0 sources stay on the block convert + tiled two-draw
                                              kernels instead of the one-kernel strip path (k_fused_strip; debug / A-B) */
-#define MPCVR_FLAG_FORCE_PERIOD     0x100u /* take k_fused_period wherever it is built, also where the planner prefers k_fused_strip (SDR content with a
-                                              4-tap filter: measured a few % faster there; debug / A-B, and how the suite reaches those instantiations) */
+#define MPCVR_FLAG_FORCE_PERIOD     0x100u /* take k_fused_period wherever it is built (debug / A-B).  Since round 6 that is where the planner takes it
+                                              anyway: the one class it used to add — SDR content with a 4-tap filter, where k_fused_strip is as fast —
+                                              is no longer built (35 instantiations, a tenth of the build) */
 #define MPCVR_FLAG_NO_FRAME_LANES   0x200u /* mpcvr_process strictly one frame after the other.  Default: a context that owns its stream (no
                                               mpcvr_set_stream) deals consecutive single frames to four internal streams so that one frame's drain
                                               overlaps the next one's ramp-up — frames are independent, as the reference's draws into different

@@ -1203,12 +1203,12 @@ FULL_SIZE_TIERS = {
             ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 1.0)),
     "up1440": ((0, "period", 0.99938), ("FLAG_NO_PERIOD", "strip", 0.99938), ("FLAG_NO_STRIP", "passes:convert,resizeX,resizeY", 0.99939), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 1.0)),            # 0.999691 0.999698 0.999963
     "down1440": ((0, "period", 0.99938), ("FLAG_NO_PERIOD", "strip", 0.99938), ("FLAG_NO_STRIP", "passes:convert,resizeX,resizeY", 0.99939), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 1.0)),          # 0.999692 0.999697 0.999965
-    "up1080_from_720_nv12": (("FLAG_FORCE_PERIOD", "period", 0.99996), (0, "strip", 0.99996), ("FLAG_NO_STRIP", "passes:convert,resizeX,resizeY", 0.99998),      # 0.999981 0.999991 1.0
+    "up1080_from_720_nv12": (("FLAG_FORCE_PERIOD", "strip", 0.99996), (0, "strip", 0.99996), ("FLAG_NO_STRIP", "passes:convert,resizeX,resizeY", 0.99998),      # 0.999981 0.999991 1.0
                              ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY", 1.0)),
     "down1080_from_4k_hlg": ((0, "period", 0.99877), ("FLAG_NO_PERIOD", "strip", 0.99877), ("FLAG_NO_STRIP", "passes:convert,resizeX,resizeY", 0.9988), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 1.0)),   # 0.999386 0.999401 0.999695
     # round 3's new paths against the reference text
     "up2160_from_720": ((0, "period", 0.99939), ("FLAG_NO_PERIOD", "strip", 0.99939), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 1.0)),      # 0.999695 0.999695 0.999962
-    "up720_from_240_nv12_catmull": (("FLAG_FORCE_PERIOD", "period", 0.99997), (0, "strip", 0.99997), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY", 1.0)),  # 0.999988 0.999988 1.0
+    "up720_from_240_nv12_catmull": (("FLAG_FORCE_PERIOD", "strip", 0.99997), (0, "strip", 0.99997), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY", 1.0)),  # 0.999988 0.999988 1.0
     "flipped_540_to_720_nv12": ((0, "period", 0.99996), ("FLAG_NO_PERIOD", "strip", 0.99996), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY", 1.0)),          # 0.999984 0.999984 1.0
     "rot180_540_to_720_pq": ((0, "period:surface", 0.99936), ("FLAG_NO_PERIOD", "strip:surface", 0.99936), ("FLAG_NO_FUSED", "passes:convert,resizeX,resizeY+final", 1.0)),   # 0.999683 0.999683 0.999960
     # round 5: the fused Jinc2m kernel (10-bit internal format behind a PQ tail; 8-bit internal format = the exact form of the convert stage)
@@ -1384,7 +1384,8 @@ def test_period_kernel_vs_oracle_and_strip_kernel(mpcvr, oracle, torch_cuda, lab
     want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
     got, info = run_product(mpcvr, torch, c, extra_flags=api.FLAG_FORCE_PERIOD)       # (SDR + 4 taps: the planner's own choice is k_fused_strip)
     P, Q, nt = pqn
-    if nt == 6:     # (round 5: six taps — MPCVR_FLAG_LANCZOS3_FIXED, the Spline36 extension — have no periodic variant any more; the strip kernel draws them)
+    if nt == 6 or (nt == 4 and not has_tail(c)):     # (round 5: six taps — MPCVR_FLAG_LANCZOS3_FIXED, the Spline36 extension — have no periodic variant any
+        # more; round 6: nor have four taps without a tail (SDR through Mitchell / Catmull-Rom / Lanczos2), where the strip kernel was the planner's choice anyway)
         assert "kernel=fused_strip(" in info, info
     else:
         assert f"kernel=fused_period(rows={P}:{Q},taps={nt}," in info, info
@@ -1687,7 +1688,9 @@ def test_sweep_every_fused_period_instantiation(mpcvr, torch_cuda, ratio, tail, 
     for i, (name, (cf, over)) in enumerate(sorted(_SWEEP_PERIOD_SRC.items()) + (sorted(_SWEEP_PERIOD_TWINS.items()) if tail == "none" else [])):
         c = _sweep_case(cf, over, tail, taps, src_wh, dst_wh, 700 + 13 * i + taps)
         # (six taps — the as-intended Lanczos3 of MPCVR_FLAG_LANCZOS3_FIXED, Spline36 — have no periodic variant since round 5: the strip kernel draws them)
-        _tiers_agree(mpcvr, torch_cuda, c, api.FLAG_FORCE_PERIOD, ("kernel=fused_period(rows=" + ratio) if taps != 6 else "kernel=fused_strip(")
+        # (... and four taps without a tail since round 6)
+        periodic = taps == 5 or (taps == 4 and tail != "none")
+        _tiers_agree(mpcvr, torch_cuda, c, api.FLAG_FORCE_PERIOD, ("kernel=fused_period(rows=" + ratio) if periodic else "kernel=fused_strip(")
     if tail == "none":      # SRC_SURFACE (no tail of its own): Catmull-Rom chroma puts the convert into its own kernel; 8-bit surface -> straight store, 10-bit -> final pass
         for i, cf in enumerate((1, 2)):
             c = _sweep_case(cf, {}, "none", taps, src_wh, dst_wh, 800 + i + taps)

@@ -475,6 +475,10 @@ hipError_t LaunchFusedPeriodPQ(const FusedArgs &a, const PeriodArgs &q, int nt, 
 #define MPCVR_PD2(NT) do { if (tailk == TAILK_NONE && srck == SRC_NV12 && epik == EPI_DIRECT8) MPCVR_PD5(NT, TAILK_NONE, SRC_NV12, EPI_DIRECT8); \
                            else if (tailk == TAILK_NONE) MPCVR_PD3(NT, TAILK_NONE); else if (tailk == TAILK_PQ_LUT) MPCVR_PD3(NT, TAILK_PQ_LUT); \
                            else if (tailk == TAILK_HLG) MPCVR_PD3(NT, TAILK_HLG); else return hipErrorNotSupported; } while (0)
+    // four taps without a tail (SDR content through Mitchell / Catmull-Rom / Lanczos2): k_fused_strip is as fast or faster there (FusedPeriodTakes),
+    // so only the table tails are built with four taps
+#define MPCVR_PD2_TAILS(NT) do { if (tailk == TAILK_PQ_LUT) MPCVR_PD3(NT, TAILK_PQ_LUT); else if (tailk == TAILK_HLG) MPCVR_PD3(NT, TAILK_HLG); \
+                                 else return hipErrorNotSupported; } while (0)
     if (srck == SRC_SURFACE) {      // the convert output of another kernel: no tail, both epilogues
 #define MPCVR_PDS(NT) do { if (epik == EPI_DITHER8) MPCVR_PD5(NT, TAILK_NONE, SRC_SURFACE, EPI_DITHER8); else MPCVR_PD5(NT, TAILK_NONE, SRC_SURFACE, EPI_DIRECT8); } while (0)
         if (nt == 4) MPCVR_PDS(4); else if (nt == 5) MPCVR_PDS(5); else return hipErrorNotSupported;
@@ -489,10 +493,11 @@ hipError_t LaunchFusedPeriodPQ(const FusedArgs &a, const PeriodArgs &q, int nt, 
 #else
     // (round 5: the 6-tap variants — Spline36, the as-intended Lanczos3 of MPCVR_FLAG_LANCZOS3_FIXED — are no longer built: 75 instantiations, a
     // fifth of the library's build time, for two settings no reference build offers; k_fused_strip draws those frames)
-    if (nt == 4) MPCVR_PD2(4);
+    if (nt == 4) MPCVR_PD2_TAILS(4);
     else if (nt == 5) MPCVR_PD2(5);
     else return hipErrorNotSupported;
 #endif
+#undef MPCVR_PD2_TAILS
 #undef MPCVR_PD2
 #undef MPCVR_PD3
 #undef MPCVR_PD5

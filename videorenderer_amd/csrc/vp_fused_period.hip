@@ -49,7 +49,8 @@ bool FusedPeriodTakes(const FusedStripParams &S)
     if (S.per_strip_w < 2 || S.per_strip_w > kPeriodStripMax || (S.per_strip_w & 1)) return false;
     // measured (profiles/r03): without a table tail the 4-tap filters run as fast or faster through k_fused_strip (SDR 1080p -> 1440p
     // Catmull-Rom 120.6 k against 115.4 k frames/s: the convert is light, and that is where the register window pays)
-    if (!S.surface_mode && tailk == TAILK_NONE && S.per_nt == 4 && !S.per_force) return false;
+    // (round 6: those instantiations — 35 kernels, a tenth of the library's build time, reachable through MPCVR_FLAG_FORCE_PERIOD only — left the build)
+    if (!S.surface_mode && tailk == TAILK_NONE && S.per_nt == 4) return false;
     const uint32_t epi_mul = FinalPassMultiplier(P.store.quant, (S.surface_mode ? S.surf.fmt : P.conv.out_fmt) == SF_RGB10A2 ? 1023 : 255);
     const int epik = PeriodEpilogue(S, epi_mul);
     if (epik < 0) return false;
