@@ -443,6 +443,11 @@ int32_t mpcvr_bandwidth_probe_up2x(int32_t mode, int32_t n, const void *const *s
  * the windowed sinc / jinc weights of the resize shaders, ps_interpolation_lanczos3.hlsl:50-59, ps_resize_onepass_jinc2.hlsl:44-101); y_dev is read by fn = 3 only.
  * The tests hold the result to a CPU evaluation of the same definition bit for bit.  DEVICE buffers; stream = a hipStream_t or NULL. */
 int32_t mpcvr_eval_transcendental(int32_t fn, const float *x_dev, const float *y_dev, float *out_dev, size_t n, void *stream);
+/* ... and the pass-per-kernel tier's Dolby Vision tail (csrc/vp_device.h: PQ EOTF -> LMS matrix -> PQ OETF, Shaders.cpp:844-859; level-2 trims
+ * :766-773; ST2084ToLinear * scale; Hable; 2020 -> 709; pow 1/2.2, :870-923) over n PQ-coded RGB triples, cut off after `stage` (0 .. 5 in that
+ * order): the tests hold every stage to the oracle's bit for bit.  lms9 / l2k5 as mpcvr_plan_dovi returns them.  DEVICE buffers of 3 n floats. */
+int32_t mpcvr_eval_dovi_tail(int32_t stage, const float *rgb_dev, float *out_dev, size_t n, const float lms9[9], const float l2k5[5], int32_t l2_enabled,
+                             float lum_scale, void *stream);
 /* ... and the same functions compiled for the host, over HOST buffers (no GPU needed: the CPU suite's check of the definition) */
 int32_t mpcvr_eval_transcendental_host(int32_t fn, const float *x, const float *y, float *out, size_t n);
 

@@ -340,8 +340,13 @@ int orc_color_matrix(const orc_params *p, float out[12])
     if (p->dovi) {                                                       /* :817-834 — hue / saturation are not applied */
         for (int i = 0; i < 9; i++) m[i] = (float)p->dovi->ycc_to_rgb_matrix[i] * contrast;
         for (int i = 0; i < 3; i++) {
-            c[i] = brightness;
-            for (int j = 0; j < 3; j++) c[i] = (float)((double)c[i] - (double)m[3 * i + j] * p->dovi->ycc_to_rgb_offset[j]);
+            /* `cmatrix.c[i] -= cmatrix.m[i][j] * offset[j]` (:828-830): float -= float * double, i.e. every step is rounded to float.  The
+               accumulator is volatile on purpose: gcc 11 -O3 vectorises rows 0 and 1 of the plain loop and drops the two intermediate
+               roundings (three subpd, one cvtpd2ps) — one ulp off the reference's arithmetic, found by the round-6 fuzz (case 6375: the plain
+               tier, whose host code clang compiles as written, disagreed with this oracle on two channels of a 54 k-pixel frame). */
+            volatile float acc = brightness;
+            for (int j = 0; j < 3; j++) acc = (float)((double)acc - (double)m[3 * i + j] * p->dovi->ycc_to_rgb_offset[j]);
+            c[i] = acc;
         }
     } else
     orc_csp_matrix(space, levels, f->cdepth, brightness, contrast, hue, p->saturation, f->cstype == CST_GRAY, m, c);
@@ -774,6 +779,25 @@ int orc_dovi_l2_constants(const orc_dovi *d, int display_nits, float k[5])      
 }
 
 /* convert-shader DolbyVisionTrims — Shaders.cpp:766-773 (PQ-coded colour) */
+/* the Dolby Vision tail stage by stage over an array (tests: the product's plain tier against this, bit for bit; stages as mpcvr_eval_dovi_tail) */
+void orc_eval_dovi_tail(int stage, const float *rgb, float *out, size_t n, const float lms[9], const float k[5], int l2, float lum_scale)
+{
+    float gm[9];
+    orc_gamut_2020_to_709(gm);
+    for (size_t i = 0; i < n; i++) {
+        float c[3] = {rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
+        for (int j = 0; j < 3; j++) c[j] = orc_st2084_to_linear(fmaxf(c[j], 0.0f), 1.0f);
+        mat3_apply(lms, c);
+        for (int j = 0; j < 3; j++) c[j] = orc_linear_to_st2084(fmaxf(c[j], 0.0f), 1.0f);
+        if (stage >= 1) { for (int j = 0; j < 3; j++) c[j] = saturatef(c[j]); if (l2) dovi_trims_convert(c, k); }
+        if (stage >= 2) for (int j = 0; j < 3; j++) c[j] = orc_st2084_to_linear(c[j], lum_scale);
+        if (stage >= 3) orc_tonemap_hable(c);
+        if (stage >= 4) mat3_apply(gm, c);
+        if (stage >= 5) for (int j = 0; j < 3; j++) c[j] = hlsl_pow(saturatef(c[j]), 1.0f / 2.2f);
+        out[3 * i] = c[0]; out[3 * i + 1] = c[1]; out[3 * i + 2] = c[2];
+    }
+}
+
 static void dovi_trims_convert(float c[3], const float k[5])
 {
     for (int i = 0; i < 3; i++) c[i] = hlsl_pow((c[i] * k[2]) + k[3], k[4]);

@@ -128,6 +128,7 @@ void orc_set_pow_ulp_noise(int amplitude, uint32_t seed);
 /* the shader transcendentals as this oracle defines them (crmath.h: exp2(y * log2 x) with every step the correctly rounded fp32 function)
  * over an array: fn = 0 log2f, 1 exp2f, 2 expf, 3 powf(x, y), 4 sinf, 5 cosf */
 void orc_eval_transcendental(int fn, const float *x, const float *y, float *out, size_t n);
+void orc_eval_dovi_tail(int stage, const float *rgb, float *out, size_t n, const float lms[9], const float k[5], int l2, float lum_scale);
 void orc_hdr_tail_ex(float rgb[3], int trc, int prim, int convert_to_sdr, float lum_scale, int hdr_output);
 void orc_hdr10_tonemap(float rgb[3], const orc_params *p);
 /* ---- correction passes: the RGB -> RGB shaders of m_pPSCorrection (DX11VideoProcessor.cpp:1893-1930, run by Process at

@@ -208,6 +208,7 @@ def lib():
         L.orc_set_pow_ulp_noise.argtypes = [C.c_int, C.c_uint32]
         L.orc_set_tex_ulp_bias.argtypes = [C.c_int]
         L.orc_eval_transcendental.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_eval_dovi_tail.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, fp, fp, C.c_int, C.c_float]
         L.orc_hdr10_params.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_uint32)]
         L.orc_specify_extfmt.restype = C.c_uint32
         L.orc_specify_extfmt.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int]

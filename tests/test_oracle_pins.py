@@ -783,3 +783,28 @@ def test_texcoord_one_ulp_off_moves_only_the_ill_conditioned_channels(oracle):
     c = dict(cformat=1, w=128, h=96, kind="noise", seed=15, dst=(32, 24), iDownscaling=0, bInterpolateAt50pct=0)
     shares = sorted(float((_tex_probe(oracle, c, bias) > 0).mean()) for bias in (-1, 1))
     assert shares[0] < 0.05 and shares[1] > 0.5, shares
+
+
+def test_dovi_colour_matrix_with_procamp_rounds_every_step(oracle):
+    """SetShaderConvertColorParams, Dolby Vision branch (DX11VideoProcessor.cpp:817-834): `cmatrix.c[i] -= cmatrix.m[i][j] * offset[j]` is
+    float -= float * double — every step rounded to float.  gcc 11 -O3 vectorised the oracle's plain loop and dropped the intermediate
+    roundings of rows 0 and 1 (one ulp; found by the round-6 fuzz, case 6375, as a plain-tier mismatch on 2 channels of 54 k pixels): the
+    oracle's constants against an independent numpy evaluation of the expression as written."""
+    from videorenderer_amd import synth
+    from tests.golden.cases import oracle_params
+    f32 = np.float32
+    rng = np.random.default_rng(6375)
+    for k in range(40):
+        pa = (float(rng.uniform(-20, 20)), float(rng.uniform(0.8, 1.2)), float(rng.uniform(-30, 30)), float(rng.uniform(0.5, 1.5)))
+        kind = ("mmr", "poly", "mixed")[k % 3]
+        c = dict(cformat=2, w=64, h=32, kind="noise", seed=1, dst=(64, 32), exfmt=0x7a420100, procamp=pa, dovi=dict(kind=kind, l2=()))
+        md = synth.dovi_metadata(kind)
+        got = oracle.color_matrix(oracle_params(oracle, c))
+        b, ct = f32(pa[0]) / f32(255), f32(pa[1])
+        for i in range(3):
+            m = [f32(f32(md["ycc_to_rgb_matrix"][3 * i + j]) * ct) for j in range(3)]
+            acc = b
+            for j in range(3):
+                acc = f32(float(acc) - float(m[j]) * float(md["ycc_to_rgb_offset"][j]))
+            assert [float(v) for v in got[3 * i:3 * i + 3]] == [float(v) for v in m], (k, i)
+            assert float(got[9 + i]) == float(acc), (k, i, float(got[9 + i]).hex(), float(acc).hex())

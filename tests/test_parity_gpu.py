@@ -296,6 +296,62 @@ def test_get_displayed_image_formats(mpcvr, oracle, torch_cuda):
     vp.close()
 
 
+# fuzz case 6375 of the round-6 final fuzz run (profiles/r06/fuzz_8000_found_case_6375.txt): Dolby Vision MMR + level-2 trims + ProcAmp, same size —
+# the plain tier differed from the oracle on 2 of 162 k ten-bit channels.  The per-pixel arithmetic was identical (test_dovi_tail_stage_by_stage);
+# the ORACLE's colour-matrix constant was one ulp off the reference's expression (gcc dropped two float roundings of `c -= m * offset`, see
+# tests/test_oracle_pins.py::test_dovi_colour_matrix_with_procamp_rounds_every_step); the product's host code had it right.
+FUZZ_6375 = {'cformat': 2, 'w': 240, 'h': 444, 'kind': 'noise', 'seed': 598584363, 'exfmt': 2051155200, 'iChromaScaling': 1, 'iUpscaling': 1, 'iDownscaling': 3,
+             'bInterpolateAt50pct': 0, 'src_rect': (92, 78, 240, 444), 'dst': (148, 366), 'procamp': (-5.010828386886953, 1.1960476848026689, 26.2518030673696, 0.8615709989981972),
+             'dovi': {'kind': 'mmr', 'l2': (100, 600, 1000)}}
+
+
+def test_fuzz_case_6375_dovi_l2_procamp_plain_tier_is_exact(mpcvr, oracle, torch_cuda):
+    from videorenderer_amd import api
+    for c in (FUZZ_6375, dict(FUZZ_6375, output_format=1, bUseDither=0), dict(FUZZ_6375, output_format=1, bUseDither=0, iChromaScaling=0)):
+        frame, pitch = case_frame(c)
+        p = oracle_params(oracle, c)
+        want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+        plain, info = run_product(mpcvr, torch_cuda, c, extra_flags=api.FLAG_NO_FUSED)
+        if c.get("output_format", 0) == 1:
+            assert np.array_equal(_codes10(plain), _codes10(want)), info
+        else:
+            assert np.array_equal(plain[..., :3], want[..., :3]), info
+        vp, _ = make_vp(mpcvr, c, api.FLAG_NO_FUSED)
+        cm = np.array(vp.GetColorMatrix(), np.float32)
+        vp.close()
+        assert np.array_equal(cm.view(np.uint32), np.asarray(oracle.color_matrix(p), np.float32).view(np.uint32)), "colour matrix: product != oracle"
+
+
+def test_dovi_tail_stage_by_stage(mpcvr, oracle, torch_cuda):
+    """The plain tier's Dolby Vision tail (mpcvr_eval_dovi_tail: k_eval_dovi_tail is compiled in the plain kernels' translation unit) against the
+    oracle's, cut off after each of its six stages — PQ EOTF -> LMS -> PQ OETF; saturate + level-2 trims; ST2084ToLinear * scale; Hable; 2020 -> 709;
+    pow 1/2.2 — on 300 k random PQ-coded triples (some outside 0..1) per metadata kind: bit for bit, NaNs in the same places."""
+    import ctypes as C
+    from videorenderer_amd import api, synth
+    torch = torch_cuda
+    L = api.load_library()
+    rng = np.random.default_rng(11)
+    n = 200_000
+    rgb = np.concatenate([rng.uniform(0, 1, (n, 3)), rng.uniform(-0.05, 1.2, (n // 4, 3)), rng.uniform(0, 0.1, (n // 4, 3))]).astype(np.float32)
+    fp = C.POINTER(C.c_float)
+    d_in = torch.from_numpy(rgb).cuda()
+    for kind, l2 in (("mmr", (100, 600, 1000)), ("poly", ())):
+        pd = api.plan_dovi(synth.dovi_metadata(kind, l2=l2), 1000)
+        lms, k = np.ascontiguousarray(pd["lms"], np.float32), np.ascontiguousarray(pd["l2k"], np.float32)
+        for stage in range(6):
+            d_out = torch.empty_like(d_in)
+            assert L.mpcvr_eval_dovi_tail(stage, C.c_void_p(d_in.data_ptr()), C.c_void_p(d_out.data_ptr()), rgb.shape[0], lms.ctypes.data_as(fp), k.ctypes.data_as(fp),
+                                          int(pd["l2_enabled"]), 80.0, None) == 0
+            torch.cuda.synchronize()
+            got = d_out.cpu().numpy()
+            want = np.empty_like(rgb)
+            oracle.lib().orc_eval_dovi_tail(stage, rgb.ctypes.data, want.ctypes.data, rgb.shape[0], lms.ctypes.data_as(fp), k.ctypes.data_as(fp), int(pd["l2_enabled"]), 80.0)
+            nan = np.isnan(want)
+            assert np.array_equal(np.isnan(got), nan), (kind, stage)
+            bad = (got.view(np.uint32) != want.view(np.uint32)) & ~nan
+            assert not bad.any(), f"{kind} stage {stage}: {int(bad.sum())} values differ, e.g. in {rgb[np.argwhere(bad)[0][0]].tolist()}"
+
+
 def test_fused_jinc_steps_aside_where_the_device_grants_less_lds(mpcvr, torch_cuda):
     """The fused Jinc2m kernel claims 114 - 146 KiB of LDS per workgroup; UpdatePlan compares that with what the device grants and keeps the
     convert + k_jinc2 draws otherwise (advisor, round 5: the launch failed on every frame of such a plan).  MPCVR_LDS_LIMIT plans as if this

@@ -21,7 +21,15 @@ sdr = GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]
 # channels beyond the bar behind a PQ / HLG / Dolby Vision tail: each needs its witness (compare_behind_tail); uniform noise in Y, U, V is
 # mostly out-of-gamut saturated colour — the worst case for the cancelling 2020 -> 709 row — so the count allowed per frame is the
 # suite's Dolby Vision rate (16 per M pixels, twice what round 3 measured on its hardest frames), at least 3
-FUZZ_CAP = lambda img: max(3, int(np.ceil(16 * img.shape[0] * img.shape[1] / 1e6)))
+# Round 6 (the plain tier now carries the oracle's bits, so these counts are the fused tiers' own v_log_f32 / v_exp_f32 error and nothing else;
+# 5 x 8,000 + 3 x 8,000 cases, profiles/r06/fuzz_8000*.txt): the largest counts seen were 5 on a 0.023 M-pixel frame (HLG, 10-bit target),
+# 20 per M pixels behind a 10-bit internal format (Dolby Vision, case 2749 of seed 31337) and 79 per M pixels behind an 8-bit one (PQ, case 6005
+# of seed 2718: the convert's texel is rounded to 8 bits, then each resize pass rounds again — a flipped texel reaches several outputs).
+# The caps are 1.5 x those; the largest count of a run is printed at its end.
+def FUZZ_CAP(img, c=None):
+    rate = 120 if (c is not None and internal_is_8bit(c)) else 30
+    return max(8, int(np.ceil(rate * img.shape[0] * img.shape[1] / 1e6)))
+witnessed = []      # (channels beyond the bar, per M pixels, 8-bit internal format, case index)
 plain_stats = collections.Counter(); paths = collections.Counter(); worst = 0.0; refused = 0; outliers = 0; batches = 0; oracle_cases = 0
 for i in range(n):
     # every source layout: 4:2:0 weighted up, then planar / packed 4:2:2 and 4:4:4, gray, GBRP, one interleaved RGB
@@ -165,12 +173,14 @@ for i in range(n):
             from tests.test_parity_gpu import compare_behind_tail
             po = oracle_params(oracle, c)
             fr, pit = case_frame(c)
-            compare_behind_tail(oracle, po, fr, pit, got, want, f"default planner vs oracle (tail, 10-bit): {name}", min_same=0.97, ten_bit=True, lim=lim, cap=FUZZ_CAP(want))
+            _, nb = compare_behind_tail(oracle, po, fr, pit, got, want, f"default planner vs oracle (tail, 10-bit): {name}", min_same=0.97, ten_bit=True, lim=lim, cap=FUZZ_CAP(want, c))
+            if nb: witnessed.append((nb, nb / (want.shape[0] * want.shape[1] / 1e6), internal_is_8bit(c), i))
         else:                                       # 8-bit targets: <= 1 LSB, or the per-channel witness (the oracle's own +-4 ulp pow() interval)
             from tests.test_parity_gpu import compare_behind_tail
             po = oracle_params(oracle, c)
             fr, pit = case_frame(c)
-            compare_behind_tail(oracle, po, fr, pit, got, want, f"default planner vs oracle (tail): {name}", min_same=0.97, cap=FUZZ_CAP(want))
+            _, nb = compare_behind_tail(oracle, po, fr, pit, got, want, f"default planner vs oracle (tail): {name}", min_same=0.97, cap=FUZZ_CAP(want, c))
+            if nb: witnessed.append((nb, nb / (want.shape[0] * want.shape[1] / 1e6), internal_is_8bit(c), i))
     beyond = int((d > lim).sum()); same = float((d == 0).mean())
     worst = max(worst, 1.0 - same)
     if beyond:
@@ -182,6 +192,24 @@ for i in range(n):
     worst_ok = (8 * (4 if c.get("output_format", 0) == 1 else 1)) if has_tail(c) else lim + 1      # ill-conditioned channels: 8 eight-bit codes
     if not has_tail(c) and (c.get("output_format", 0) != 1 or internal_is_8bit(c)):
         assert beyond == 0, name          # (round 5: nothing beyond the bar where no transcendental decides the last code)
-    assert beyond == 0 or (beyond <= max(4, 2e-5 * d.size) and d.max() <= worst_ok), name
+    if beyond and has_tail(c):
+        # Behind a tail a channel beyond the bar needs its WITNESS, case by case (round 6: until round 5 this was a blanket count — at most 4 per frame —
+        # which held while the plain tier shared the fused tiers' v_log_f32 / v_exp_f32; now that the plain tier carries the oracle's bits the
+        # comparison is made against the oracle itself: every such channel inside the oracle's own +-4 ulp pow() interval, their number capped)
+        from tests.test_parity_gpu import compare_behind_tail
+        po = oracle_params(oracle, c)
+        fr, pit = case_frame(c)
+        want_w = oracle.process(po, fr, pit, dst=np.full((got.shape[0], got.shape[1], 4), BG, dtype=np.uint8))
+        _, nb = compare_behind_tail(oracle, po, fr, pit, got, want_w, f"default planner vs oracle (witness for the outliers): {name}", min_same=0.97,
+                                    ten_bit=c.get("output_format", 0) == 1, lim=lim, cap=FUZZ_CAP(want_w, c))
+        if nb and i % 5: witnessed.append((nb, nb / (want_w.shape[0] * want_w.shape[1] / 1e6), internal_is_8bit(c), i))
+        assert d.max() <= worst_ok, name
+    else:
+        assert beyond == 0 or (beyond <= max(4, 2e-5 * d.size) and d.max() <= worst_ok), name
+if witnessed:
+    for eight in (False, True):
+        w = [t for t in witnessed if t[2] == eight]
+        if w: print(f"channels beyond the bar, each inside the oracle's +-4 ulp pow() interval ({'8' if eight else '10 / 16'}-bit internal format): {len(w)} cases, "
+                    f"largest count {max(w)[0]} (case {max(w)[3]}), largest rate {max(t[1] for t in w if t[0] > 5) if any(t[0] > 5 for t in w) else 0:.1f} per M pixels among counts > 5")
 if plain_stats: print("plain tier vs oracle, max |delta| -> cases:", dict(sorted(plain_stats.items())))
 print("cases", n, "of which also as 3-frame batches", batches, "against the CPU oracle", oracle_cases, "refused", refused, "kernels", dict(paths), "largest differing fraction", round(worst, 5), "cases with an ill-conditioned channel", outliers)

@@ -31,6 +31,14 @@ python bench.py > $O/bench_default.json 2> $O/bench_default.err
 ( time timeout 900 python tests/tools/fuzz_strip.py 8000 ) > $O/fuzz_8000.txt 2>&1; echo "rc=$?" >> $O/fuzz_8000.txt
 ( time timeout 600 python tests/tools/fuzz_strip.py 3000 777 ) > $O/fuzz_3000_seed777.txt 2>&1; echo "rc=$?" >> $O/fuzz_3000_seed777.txt
 ( time MPCVR_FUZZ_JINC=1 timeout 600 python tests/tools/fuzz_strip.py 2000 5 ) > $O/fuzz_2000_jinc.txt 2>&1; echo "rc=$?" >> $O/fuzz_2000_jinc.txt
+# the four combined modes of round 5's last call, same seeds (402 is the run that ended rc = 1 there: case 1820), on the final code: the plain
+# tier is held to the oracle bit for bit in every oracle-compared case
+run() { n=$1; shift; ( time env "$@" timeout 900 python tests/tools/fuzz_strip.py 2500 $SEED ) > $O/$n.txt 2>&1; echo "rc=$?" >> $O/$n.txt; }
+SEED=401 run fuzz_2500_jinc_flags8 MPCVR_FUZZ_JINC=1 MPCVR_FUZZ_FLAGS=8
+SEED=402 run fuzz_2500_jinc_flags64 MPCVR_FUZZ_JINC=1 MPCVR_FUZZ_FLAGS=64
+SEED=403 run fuzz_2500_scalers_unaligned_flags72 MPCVR_FUZZ_SCALERS=1 MPCVR_FUZZ_UNALIGNED=1 MPCVR_FUZZ_FLAGS=72
+SEED=404 run fuzz_2500_host_unaligned_flags4 MPCVR_FUZZ_HOST=1 MPCVR_FUZZ_UNALIGNED=1 MPCVR_FUZZ_FLAGS=4
+SEED=31 run fuzz_2500_periodic MPCVR_FUZZ_PERIODIC=1
 ( timeout 400 python tests/tools/fuzz_errdiff.py 250 1 2>&1 | tail -8; timeout 400 python tests/tools/fuzz_errdiff.py 250 11 2>&1 | tail -8 ) > $O/fuzz_errdiff.txt
 python bench.py --steps 20 --warmup 5 > $O/bench_driver_shape.json 2> $O/bench_driver_shape.err
 # gpurun merges at most 64 MiB back: keep the tables anyone reads (summaries, stats, traffic, bench lines), drop the raw traces

@@ -13,8 +13,8 @@ done
 python - "$W" "$STEPS" "$WARM" <<'PY'
 import csv, glob, sys, json
 w, steps, warm = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-# the library's kernels of the step — not bench.py's own bandwidth probe (mpcvr::k_probe_shape: it moves several steps' worth of bytes)
-ours = lambda name: "mpcvr" in name and "k_probe_shape" not in name
+# the library's kernels of the step — not bench.py's own bandwidth probes (mpcvr::k_probe_shape / k_probe_up2x: they move several steps' worth of bytes)
+ours = lambda name: "mpcvr" in name and "k_probe" not in name
 tot = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     s = 0.0; n = 0

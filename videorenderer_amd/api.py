@@ -163,7 +163,7 @@ EXPORTS = [
     "mpcvr_plan_frame_layout", "mpcvr_plan_color_matrix", "mpcvr_plan_gamut_2020_to_709", "mpcvr_plan_pq_lut",
     "mpcvr_plan_upscale_weights", "mpcvr_plan_axis_taps", "mpcvr_plan_describe", "mpcvr_plan_final_pass_multiplier",
     "mpcvr_plan_strip", "mpcvr_plan_pq_eotf_table", "mpcvr_bandwidth_probe", "mpcvr_plan_period", "mpcvr_plan_hdr10_params",
-    "mpcvr_eval_transcendental", "mpcvr_eval_transcendental_host", "mpcvr_bandwidth_probe_up2x",
+    "mpcvr_eval_transcendental", "mpcvr_eval_transcendental_host", "mpcvr_bandwidth_probe_up2x", "mpcvr_eval_dovi_tail",
 ]
 
 _lib = None
@@ -252,6 +252,7 @@ def load_library():
         "mpcvr_bandwidth_probe": [C.c_void_p, C.c_void_p, C.c_size_t, i32, C.c_void_p],
         "mpcvr_bandwidth_probe_up2x": [i32, i32, P(C.c_void_p), P(C.c_void_p), i32, i32, i32, i32, C.c_void_p],
         "mpcvr_eval_transcendental": [i32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
+        "mpcvr_eval_dovi_tail": [i32, C.c_void_p, C.c_void_p, C.c_size_t, P(f), P(f), i32, f, C.c_void_p],
         "mpcvr_eval_transcendental_host": [i32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
         "mpcvr_plan_describe": [P(Settings), i32, i32, i32, P(Rect), i32, i32, C.c_char_p, C.c_size_t],
     }

@@ -427,3 +427,13 @@ int32_t mpcvr_plan_describe(const mpcvr_settings *s, int32_t cformat, int32_t re
 }
 
 }  // extern "C"
+
+// verification aid: the plain tier's Dolby Vision tail over an array, stage by stage (csrc/vp_kernels.hip: k_eval_dovi_tail)
+int32_t mpcvr_eval_dovi_tail(int32_t stage, const float *rgb_dev, float *out_dev, size_t n, const float lms9[9], const float l2k5[5], int32_t l2_enabled, float lum_scale, void *stream)
+{
+    if (!rgb_dev || !out_dev || !lms9 || !l2k5) return MPCVR_E_POINTER;
+    if (stage < 0 || stage > 5) return MPCVR_E_INVALIDARG;
+    float gamut[9];
+    mpcvr::ComputeGamut2020to709(gamut);
+    return mpcvr::LaunchEvalDoviTail(rgb_dev, out_dev, n, lms9, l2k5, gamut, l2_enabled, lum_scale, stage, (hipStream_t)stream) == hipSuccess ? MPCVR_S_OK : MPCVR_E_FAIL;
+}

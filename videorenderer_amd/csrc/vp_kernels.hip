@@ -1105,4 +1105,40 @@ hipError_t LaunchCopy(const Surface &in, int out_w, int out_h, const StoreParams
     return hipGetLastError();
 }
 
+
+// ---- verification aid (mpcvr_eval_dovi_tail): the plain tier's Dolby Vision tail, stage by stage, over an array of PQ-coded RGB triples ----
+// stage 0: PQ EOTF -> LMS matrix -> PQ OETF (Shaders.cpp:844-859); 1: + saturate + level-2 trims (:870-877); 2: + ST2084ToLinear(., scale);
+// 3: + Hable / hable(4.8); 4: + 2020 -> 709; 5: + saturate, pow 1/2.2 (the whole tail).  Compiled here so that it IS the plain kernels' arithmetic.
+struct DoviTailEval { float lms[9], k[5], gamut[9], lum_scale; int stage, l2; };
+__global__ __launch_bounds__(256) void k_eval_dovi_tail(const float *__restrict__ rgb, float *__restrict__ out, size_t n, DoviTailEval P)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        f3 c = {rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
+        c.x = st2084_to_linear(fmaxf(c.x, 0.0f), 1.0f); c.y = st2084_to_linear(fmaxf(c.y, 0.0f), 1.0f); c.z = st2084_to_linear(fmaxf(c.z, 0.0f), 1.0f);
+        f3 r;
+        r.x = P.lms[0] * c.x + P.lms[1] * c.y + P.lms[2] * c.z;
+        r.y = P.lms[3] * c.x + P.lms[4] * c.y + P.lms[5] * c.z;
+        r.z = P.lms[6] * c.x + P.lms[7] * c.y + P.lms[8] * c.z;
+        c.x = linear_to_st2084(fmaxf(r.x, 0.0f), 1.0f); c.y = linear_to_st2084(fmaxf(r.y, 0.0f), 1.0f); c.z = linear_to_st2084(fmaxf(r.z, 0.0f), 1.0f);
+        if (P.stage >= 1) {
+            c.x = saturate(c.x); c.y = saturate(c.y); c.z = saturate(c.z);
+            if (P.l2) c = dovi_trims(c, P.k);
+        }
+        if (P.stage >= 2) { c.x = st2084_to_linear(c.x, P.lum_scale); c.y = st2084_to_linear(c.y, P.lum_scale); c.z = st2084_to_linear(c.z, P.lum_scale); }
+        if (P.stage >= 3) { const float div = hable_div(); c.x = hable(c.x) / div; c.y = hable(c.y) / div; c.z = hable(c.z) / div; }
+        if (P.stage >= 4) c = mat3_mul(make_mat3(P.gamut), c);
+        if (P.stage >= 5) { c.x = hlsl_pow(saturate(c.x), 1.0f / 2.2f); c.y = hlsl_pow(saturate(c.y), 1.0f / 2.2f); c.z = hlsl_pow(saturate(c.z), 1.0f / 2.2f); }
+        out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
+    }
+}
+hipError_t LaunchEvalDoviTail(const float *rgb_dev, float *out_dev, size_t n, const float lms[9], const float k[5], const float gamut[9], int l2, float lum_scale, int stage, hipStream_t s)
+{
+    DoviTailEval P{};
+    std::memcpy(P.lms, lms, sizeof(P.lms)); std::memcpy(P.k, k, sizeof(P.k));
+    std::memcpy(P.gamut, gamut, sizeof(P.gamut));
+    P.lum_scale = lum_scale; P.stage = stage; P.l2 = l2;
+    hipLaunchKernelGGL(k_eval_dovi_tail, dim3(1024), dim3(256), 0, s, rgb_dev, out_dev, n, P);
+    return hipGetLastError();
+}
+
 }  // namespace mpcvr

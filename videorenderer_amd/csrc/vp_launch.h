@@ -100,6 +100,7 @@ size_t ErrorDiffusionHandoffBytes(const ErrDiffParams &P, int n_frames);
 hipError_t LaunchErrorDiffusion(const ErrDiffParams &P, const FusedFrame *frames_dev, FusedFrame single, int n_frames, hipStream_t s);
 bool FusedUp2xSupported(const FusedParams &P);
 // vp_fused_jinc.hip: the weight table of the fused Jinc2m kernel, from BuildJincPhases' table of a 2x draw
+hipError_t LaunchEvalDoviTail(const float *rgb_dev, float *out_dev, size_t n, const float lms[9], const float k[5], const float gamut[9], int l2, float lum_scale, int stage, hipStream_t s);
 size_t FusedJincTableBytes();
 size_t FusedJincLdsBytes(const FusedParams &P);        // dynamic LDS of the fused Jinc2m kernel this plan would launch (vs DeviceLdsLimit())
 void BuildFusedJincTable(const void *phases, float *out);

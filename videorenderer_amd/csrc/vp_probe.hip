@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_eval_transcendental(int fn, const float
 {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float v = x[i];
-        out[i] = fn == 0 ? crm_log2f(v) : fn == 1 ? crm_exp2f(v) : fn == 2 ? crm_expf(v) : fn == 3 ? crm_powf(v, y[i]) : fn == 4 ? crm_sinf(v) : crm_cosf(v);
+        out[i] = fn == 0 ? crm_log2f(v) : fn == 1 ? crm_exp2f(v) : fn == 2 ? crm_expf(v) : fn == 3 ? crm_powf(v, y[i]) : fn == 4 ? crm_sinf(v) : fn == 5 ? crm_cosf(v) : fn == 6 ? v / y[i] : __builtin_sqrtf(v);
     }
 }
 }  // namespace
@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) void k_eval_transcendental(int fn, const float
 
 extern "C" int32_t mpcvr_eval_transcendental(int32_t fn, const float *x_dev, const float *y_dev, float *out_dev, size_t n, void *stream)
 {
-    if (!x_dev || !out_dev || (fn == 3 && !y_dev)) return MPCVR_E_POINTER;
-    if (fn < 0 || fn > 5) return MPCVR_E_INVALIDARG;
+    if (!x_dev || !out_dev || ((fn == 3 || fn == 6) && !y_dev)) return MPCVR_E_POINTER;
+    if (fn < 0 || fn > 7) return MPCVR_E_INVALIDARG;
     if (n == 0) return MPCVR_S_OK;
     hipLaunchKernelGGL(mpcvr::k_eval_transcendental, dim3(1024), dim3(256), 0, (hipStream_t)stream, (int)fn, x_dev, y_dev, out_dev, n);
     return hipGetLastError() == hipSuccess ? MPCVR_S_OK : MPCVR_E_FAIL;
