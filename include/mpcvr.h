@@ -167,6 +167,10 @@ int32_t mpcvr_set_window_rect(mpcvr_ctx *ctx, const mpcvr_rect *window_rect);
  * horizontal flip of the source, applied in the first resize draw the way FillVertices (:130-179) and ResizeShaderPass
  * (:3112-3137) set it up; the caller sizes the video rect for the rotated picture.  E_INVALIDARG for other angles. */
 int32_t mpcvr_set_rotation(mpcvr_ctx *ctx, int32_t degrees);
+/* (extension, error-diffusion final pass only) how many polls — about a microsecond each — a band grants the band above before the pass is
+ * flagged failed (the next mpcvr_process / mpcvr_synchronize answers MPCVR_E_FAIL instead of hanging); polls <= 0: the default, 2^21.  A host
+ * that shares the GPU or runs under a debugger raises it; the environment variable MPCVR_ERRDIFF_SPIN (tests) overrides it per call. */
+int32_t mpcvr_set_error_diffusion_patience(mpcvr_ctx *ctx, int32_t polls);
 int32_t mpcvr_set_flip(mpcvr_ctx *ctx, int32_t flip);
 /* m_SampleFormat as CopySample derives it from AM_SAMPLE2_PROPERTIES::dwTypeSpecificFlags (DX11VideoProcessor.cpp:2209-2219):
  * 0 progressive, 1 interlaced top field first, 2 interlaced bottom field first.  With bDeintBlend an interlaced 4:2:0

@@ -303,4 +303,15 @@ def test_give_up_path_ends_in_an_error_not_in_a_hang(mpcvr, oracle, monkeypatch)
     again = torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda")
     vp.CopySample(dev, pitch); vp.Process(again, ww * 4); vp.Synchronize()
     assert torch.equal(again, good)
+    # the same deadline through the API (mpcvr_set_error_diffusion_patience: what a host sets instead of the test's environment variable)
+    monkeypatch.setenv("MPCVR_ERRDIFF_TEST_STALL", "1")
+    vp.SetErrorDiffusionPatience(16)
+    vp.CopySample(dev, pitch); vp.Process(bad, ww * 4)
+    with pytest.raises(api.MpcvrError) as e:
+        vp.Synchronize()
+    assert "gave up" in str(e.value), str(e.value)
+    monkeypatch.delenv("MPCVR_ERRDIFF_TEST_STALL")
+    vp.SetErrorDiffusionPatience(0)                  # back to the default
+    vp.CopySample(dev, pitch); vp.Process(again, ww * 4); vp.Synchronize()
+    assert torch.equal(again, good)
     vp.close()

@@ -152,7 +152,7 @@ class MpcvrError(RuntimeError):
 
 EXPORTS = [
     "mpcvr_settings_default", "mpcvr_create", "mpcvr_destroy", "mpcvr_set_stream", "mpcvr_synchronize",
-    "mpcvr_set_input", "mpcvr_set_video_rect", "mpcvr_set_window_rect", "mpcvr_set_rotation", "mpcvr_set_flip", "mpcvr_set_sample_format", "mpcvr_set_hdr_output", "mpcvr_set_hdr_metadata",
+    "mpcvr_set_input", "mpcvr_set_video_rect", "mpcvr_set_window_rect", "mpcvr_set_rotation", "mpcvr_set_error_diffusion_patience", "mpcvr_set_flip", "mpcvr_set_sample_format", "mpcvr_set_hdr_output", "mpcvr_set_hdr_metadata",
     "mpcvr_set_dovi_metadata", "mpcvr_plan_dovi", "mpcvr_correction_pass", "mpcvr_plan_correction_matrices",
     "mpcvr_configure", "mpcvr_set_procamp", "mpcvr_copy_sample", "mpcvr_process", "mpcvr_process_frames", "mpcvr_render",
     "mpcvr_get_backbuffer", "mpcvr_get_current_image", "mpcvr_get_displayed_image", "mpcvr_flush", "mpcvr_reset", "mpcvr_process_batch", "mpcvr_process_batch_dovi",
@@ -205,6 +205,7 @@ def load_library():
         "mpcvr_set_video_rect": [vp, P(Rect)],
         "mpcvr_set_window_rect": [vp, P(Rect)],
         "mpcvr_set_rotation": [vp, i32],
+        "mpcvr_set_error_diffusion_patience": [vp, i32],
         "mpcvr_set_flip": [vp, i32],
         "mpcvr_set_sample_format": [vp, i32],
         "mpcvr_set_hdr_output": [vp, i32, i32, f],
@@ -517,6 +518,10 @@ class VideoProcessor:
 
     def SetRotation(self, value):
         return self._check(self._L.mpcvr_set_rotation(self._ctx, value))
+
+    def SetErrorDiffusionPatience(self, polls):
+        """(extension) polls a band of the error-diffusion pass waits for the band above before the pass fails; <= 0: the default."""
+        return self._check(self._L.mpcvr_set_error_diffusion_patience(self._ctx, int(polls)))
 
     def SetFlip(self, value):
         return self._check(self._L.mpcvr_set_flip(self._ctx, int(bool(value))))

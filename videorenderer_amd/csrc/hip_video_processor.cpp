@@ -1586,7 +1586,7 @@ HRESULT CHipVideoProcessor::ErrDiffPass(int n, const FusedFrame *table, FusedFra
     // (tests: a band that never publishes and a short patience, read per call — the give-up path must end in an error, not in a hang)
     const char *stall = std::getenv("MPCVR_ERRDIFF_TEST_STALL"), *spin = std::getenv("MPCVR_ERRDIFF_SPIN");
     P.test_stall = stall && *stall && *stall != '0' ? 1 : 0;
-    P.spin_limit = spin && *spin ? std::atoi(spin) : 0;
+    P.spin_limit = spin && *spin ? std::atoi(spin) : m_edPatience;      // (0: the launcher's default, 2^21 polls of about a microsecond)
     HRESULT hr;
     if (!m_edStatus) {
         if ((hr = CheckHip(hipHostMalloc((void **)&m_edStatus, sizeof(int), hipHostMallocDefault), "error-diffusion status word"))) return hr;

@@ -49,6 +49,9 @@ public:
     HRESULT SetVideoRect(const CRect &videoRect);                             // :3426
     HRESULT SetWindowRect(const CRect &windowRect);                           // :3433
     HRESULT SetRotation(int value);                                           // :4052
+    // (extension) polls a band of the error-diffusion pass grants the band above before the launch is flagged failed; <= 0: the default (2^21,
+    // about two seconds) — a host that shares the GPU, or runs under a debugger, raises it; one that wants a hard deadline lowers it
+    HRESULT SetErrorDiffusionPatience(int polls) { m_edPatience = polls > 0 ? polls : 0; return MPCVR_S_OK; }
     HRESULT SetFlip(bool value);                                              // VideoProcessor.h:210
     HRESULT SetSampleFormat(int frameFormat);                                 // m_SampleFormat, :2209-2219
     HRESULT SetHdrOutput(bool enable, int toneMapType, float displayMaxNits);  // m_bHdrPassthrough / m_bHdrLocalToneMapping
@@ -288,6 +291,7 @@ private:
         bool operator==(const EdLayout &o) const { return x0 == o.x0 && x1 == o.x1 && y0 == o.y0 && y1 == o.y1 && n == o.n && rows == o.rows; }
     };
     int m_edGen = 0; EdLayout m_edKey;       // generation of the hand-off words of the last pass, and the layout they belong to
+    int m_edPatience = 0;          // SetErrorDiffusionPatience: polls per group before a band gives up (0: the launcher's default)
     int *m_edStatus = nullptr;     // pinned host word the pass sets when a band gave up waiting (checked at the next pass and in Synchronize)
     uint8_t *m_edBase = nullptr;   // first intermediate (m_edPost.ptr + a margin)
     int m_edPitch = 0;             // bytes per row of an intermediate (a multiple of 256)

@@ -76,6 +76,7 @@ int32_t mpcvr_set_input(mpcvr_ctx *ctx, int32_t cformat, int32_t width, int32_t 
 int32_t mpcvr_set_video_rect(mpcvr_ctx *ctx, const mpcvr_rect *r) { CTX_OR_FAIL(); if (!r) return MPCVR_E_POINTER; return ctx->vp.SetVideoRect(ToRect(r)); }
 int32_t mpcvr_set_window_rect(mpcvr_ctx *ctx, const mpcvr_rect *r) { CTX_OR_FAIL(); if (!r) return MPCVR_E_POINTER; return ctx->vp.SetWindowRect(ToRect(r)); }
 int32_t mpcvr_set_rotation(mpcvr_ctx *ctx, int32_t degrees) { CTX_OR_FAIL(); return ctx->vp.SetRotation(degrees); }
+int32_t mpcvr_set_error_diffusion_patience(mpcvr_ctx *ctx, int32_t polls) { CTX_OR_FAIL(); return ctx->vp.SetErrorDiffusionPatience(polls); }
 int32_t mpcvr_set_flip(mpcvr_ctx *ctx, int32_t flip) { CTX_OR_FAIL(); return ctx->vp.SetFlip(flip != 0); }
 int32_t mpcvr_set_sample_format(mpcvr_ctx *ctx, int32_t frame_format) { CTX_OR_FAIL(); return ctx->vp.SetSampleFormat(frame_format); }
 int32_t mpcvr_set_hdr_output(mpcvr_ctx *ctx, int32_t enable, int32_t tone_map_type, float display_max_nits)
