@@ -39,6 +39,29 @@ void orc_set_pow_ulp_bias(int bias) { g_pow_ulp_bias = bias; g_pow_ulp_seed = 0;
 /* seed != 0: every call errs by its own amount in [-amplitude, +amplitude], a hash of (x, y, seed) — independent errors per channel
  * and per pow of the chain, as a real approximate pow has them (a uniform bias cancels in the gamut matrix, whose rows sum to 1) */
 void orc_set_pow_ulp_noise(int amplitude, uint32_t seed) { g_pow_ulp_bias = amplitude; g_pow_ulp_seed = seed; }
+/* Sensitivity probe (tests only): the texture the HDR10 tone-mapping step reads arrives `bias` codes of its UNORM format off — on channel
+ * `channel` (0..2; -1: all three), or (seed != 0) every channel of every texel by its own hash-drawn amount in [-|bias|, +|bias|].  The fused
+ * tiers of the product are held to one code at every stored intermediate; a local operator maps that code with its own slope (operator 6
+ * near black: seven ten-bit codes per code), so a channel beyond the bar behind an operator is shown case by case to lie inside what the
+ * oracle answers for inputs one code either side (tests/test_parity_gpu.py compare_behind_tail, operator_input). */
+static int g_tm_in_bias = 0, g_tm_in_channel = -1;
+static uint32_t g_tm_in_seed = 0;
+void orc_set_tonemap_input_bias(int bias, int channel, uint32_t seed) { g_tm_in_bias = bias; g_tm_in_channel = channel; g_tm_in_seed = seed; }
+static inline float tm_input_probe(float v, float maxv, int x, int y, int ch)
+{
+    if (!g_tm_in_bias || maxv <= 0.0f || (g_tm_in_channel >= 0 && g_tm_in_channel != ch && !g_tm_in_seed)) return v;
+    int bias = g_tm_in_bias;
+    if (g_tm_in_seed) {
+        uint32_t h = ((uint32_t)x * 0x9E3779B9u) ^ ((uint32_t)y * 0x85EBCA6Bu) ^ ((uint32_t)ch * 0xC2B2AE35u) ^ g_tm_in_seed;
+        h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+        const int a = bias < 0 ? -bias : bias;
+        bias = (int)(h % (uint32_t)(2 * a + 1)) - a;
+    }
+    float code = floorf(v * maxv + 0.5f) + (float)bias;
+    if (code < 0.0f) code = 0.0f;
+    if (code > maxv) code = maxv;
+    return code / maxv;
+}
 static inline float hlsl_pow(float x, float y)
 {
     float r = crm_powf(x, y);          /* exp2(y * log2 x), each step the correctly rounded fp32 function (crmath.h) */
@@ -2023,7 +2046,6 @@ int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
                           post.p + ((size_t)y * w2 + x) * 4);
         result = &post; result_fmt = swap_fmt;
     }
-    (void)result_fmt;
     img_t tm = {0};
     if (tonemap) {      /* TextureCopyRect(..., m_pPSHDR10ToneMapping, ...) into the next post-scale texture or the RT */
         const int ox = (result == &conv && srect) ? srect[0] : 0, oy = (result == &conv && srect) ? srect[1] : 0;
@@ -2032,6 +2054,10 @@ int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
             for (int x = 0; x < w2; x++) {
                 const float *q = result->p + ((size_t)(y + oy) * result->w + (x + ox)) * 4;
                 float v[4] = {q[0], q[1], q[2], 1.0f};
+                if (g_tm_in_bias) {
+                    const float in_max = result_fmt == FMT_RGB10A2 ? 1023.0f : result_fmt == FMT_BGRA8 ? 255.0f : 0.0f;
+                    for (int ch = 0; ch < 3; ch++) v[ch] = tm_input_probe(v[ch], in_max, x, y, ch);
+                }
                 orc_hdr10_tonemap(v, p);
                 store_fmt(final_pass ? internal : swap_fmt, v, tm.p + ((size_t)y * w2 + x) * 4);
             }

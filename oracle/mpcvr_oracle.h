@@ -125,6 +125,9 @@ void orc_params_default(orc_params *p);
 void orc_set_pow_ulp_bias(int bias);
 /* ... or by its own amount in [-amplitude, +amplitude] per call (a hash of the operands and `seed`; seed 0 = the uniform bias) */
 void orc_set_pow_ulp_noise(int amplitude, uint32_t seed);
+/* sensitivity probe: the texture the HDR10 tone-mapping step reads arrives `bias` codes of its UNORM format off, on `channel` (0..2, -1 = all),
+ * or — seed != 0 — every channel of every texel by its own hash-drawn amount in [-|bias|, +|bias|]; bias 0 = off */
+void orc_set_tonemap_input_bias(int bias, int channel, uint32_t seed);
 /* the shader transcendentals as this oracle defines them (crmath.h: exp2(y * log2 x) with every step the correctly rounded fp32 function)
  * over an array: fn = 0 log2f, 1 exp2f, 2 expf, 3 powf(x, y), 4 sinf, 5 cosf */
 void orc_eval_transcendental(int fn, const float *x, const float *y, float *out, size_t n);

@@ -207,6 +207,7 @@ def lib():
         L.orc_set_pow_ulp_bias.argtypes = [C.c_int]
         L.orc_set_pow_ulp_noise.argtypes = [C.c_int, C.c_uint32]
         L.orc_set_tex_ulp_bias.argtypes = [C.c_int]
+        L.orc_set_tonemap_input_bias.argtypes = [C.c_int, C.c_int, C.c_uint32]
         L.orc_eval_transcendental.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.orc_eval_dovi_tail.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, fp, fp, C.c_int, C.c_float]
         L.orc_hdr10_params.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_uint32)]
@@ -348,6 +349,16 @@ def process_with_pow_bias(p, frame, pitch, bias, dst=None, seed=0):
         return process(p, frame, pitch, dst=dst)
     finally:
         lib().orc_set_pow_ulp_bias(0)
+
+
+def process_with_tonemap_input_bias(p, frame, pitch, bias, channel=-1, seed=0, dst=None):
+    """process() with the texture in front of the HDR10 tone-mapping step `bias` codes off (channel 0..2 or -1 = all; seed != 0: every channel
+    of every texel by its own draw in [-|bias|, +|bias|]) — what a one-code difference of that intermediate becomes behind the operator."""
+    lib().orc_set_tonemap_input_bias(int(bias), int(channel), int(seed))
+    try:
+        return process(p, frame, pitch, dst=dst)
+    finally:
+        lib().orc_set_tonemap_input_bias(0, -1, 0)
 
 
 def eval_transcendental(fn, x, y=None):

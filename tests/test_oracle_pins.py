@@ -808,3 +808,28 @@ def test_dovi_colour_matrix_with_procamp_rounds_every_step(oracle):
                 acc = f32(float(acc) - float(m[j]) * float(md["ycc_to_rgb_offset"][j]))
             assert [float(v) for v in got[3 * i:3 * i + 3]] == [float(v) for v in m], (k, i)
             assert float(got[9 + i]) == float(acc), (k, i, float(got[9 + i]).hex(), float(acc).hex())
+
+
+def test_tonemap_input_probe_is_off_by_default_and_moves_only_what_it_names(oracle):
+    """orc_set_tonemap_input_bias (the witness for plans with an HDR10 tone-mapping operator, compare_behind_tail operator_input): off = the
+    pinned output; one code up on the blue channel of the operator's input moves the oracle's answer (operator 6 near black: by up to 7
+    ten-bit codes on soak case 2367's frame) and the probe resets; a plan without an operator is not touched by it."""
+    from tests.golden.cases import case_frame, oracle_params
+    from tests.test_parity_gpu import FUZZ_2367, _codes10, BG
+    c = dict(FUZZ_2367, w=96, h=64, dst=(192, 128))
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    bg = lambda: np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8)
+    want = _codes10(oracle.process(p, frame, pitch, dst=bg()))
+    up_b = _codes10(oracle.process_with_tonemap_input_bias(p, frame, pitch, 1, channel=2, dst=bg()))
+    up_all = _codes10(oracle.process_with_tonemap_input_bias(p, frame, pitch, 1, dst=bg()))
+    noise = _codes10(oracle.process_with_tonemap_input_bias(p, frame, pitch, 1, seed=5, dst=bg()))
+    assert np.array_equal(_codes10(oracle.process(p, frame, pitch, dst=bg())), want), "the probe did not reset"
+    assert (up_b != want).any() and (up_all != want).any() and (noise != want).any()
+    assert int(np.abs(up_all - want).max()) >= 2, "a local operator maps a code of its input with its own slope"
+    assert not np.array_equal(up_b, up_all) and not np.array_equal(noise, up_all)
+    c0 = {k: v for k, v in c.items() if k not in ("hdr_tonemap", "hdr_display", "hdr_meta")}
+    p0 = oracle_params(oracle, c0)
+    a = oracle.process(p0, frame, pitch, dst=bg())
+    b = oracle.process_with_tonemap_input_bias(p0, frame, pitch, 1, dst=bg())
+    assert np.array_equal(a, b)

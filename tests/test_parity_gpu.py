@@ -111,7 +111,7 @@ def _codes10(a):
     return np.stack([(u >> sh) & 1023 for sh in (0, 10, 20)], -1).astype(np.int16)
 
 
-def compare_behind_tail(oracle, p, frame, pitch, got, want, name, min_same=0.99, ten_bit=False, lim=1, dovi=False, cap=None):
+def compare_behind_tail(oracle, p, frame, pitch, got, want, name, min_same=0.99, ten_bit=False, lim=1, dovi=False, cap=None, operator_input=False):
     """Frames behind a PQ / HLG / Dolby Vision tail: |delta| <= 1 like everywhere else, EXCEPT on channels where the oracle's own
     answer is not defined to one code — shown per channel, not assumed: the oracle is run again with every pow() of the chain POW_ULPS
     ulps low, POW_ULPS ulps high, and eight times with each call off by its own hash-drawn amount within +-POW_ULPS
@@ -121,6 +121,10 @@ def compare_behind_tail(oracle, p, frame, pitch, got, want, name, min_same=0.99,
     a bright saturated colour whose third channel cancels to ~1e-4 behind the 2020 -> 709 matrix — the PQ EOTF's (c2 - c3 v) term
     amplifies an ulp of pow(x, 1/m2) ~100x, pow(., 1/m1) 6x more, and pow(x, 1/2.2) has a slope of ~70 down there.
     ten_bit: an R10G10B10A2 target, compared code for code with `lim` ten-bit codes in place of the one 8-bit code.
+    operator_input (plans with an HDR10 tone-mapping operator, round 6): the fused tiers are held to ONE code at every stored intermediate, and
+    the operator maps a code of the texture it reads with its own slope (operator 6 near black: seven ten-bit codes per code — soak case 2367,
+    profiles/r06/case2367.txt); the interval then also spans the oracle's answers for that texture one code low / high as a whole, on each
+    channel alone, and in eight per-texel draws (oracle.process_with_tonemap_input_bias).
     Returns (share of identical channels, number of such channels)."""
     codes = _codes10 if ten_bit else (lambda a: a[..., :3].astype(np.int16))
     g3, w3 = codes(got), codes(want)
@@ -137,6 +141,10 @@ def compare_behind_tail(oracle, p, frame, pitch, got, want, name, min_same=0.99,
         for bias, seed in [(-POW_ULPS, 0), (POW_ULPS, 0)] + [(POW_ULPS, k) for k in range(1, 9)]:
             run = codes(oracle.process_with_pow_bias(p, frame, pitch, bias, dst=bg.copy(), seed=seed))
             lo = np.minimum(lo, run); hi = np.maximum(hi, run)
+        if operator_input:
+            for bias, ch, seed in [(b, ch, 0) for b in (-1, 1) for ch in (-1, 0, 1, 2)] + [(1, -1, k) for k in range(1, 9)]:
+                run = codes(oracle.process_with_tonemap_input_bias(p, frame, pitch, bias, channel=ch, seed=seed, dst=bg.copy()))
+                lo = np.minimum(lo, run); hi = np.maximum(hi, run)
         lo -= lim; hi += lim
         inside = (g3 >= lo) & (g3 <= hi)
         worst = np.argwhere(bad & ~inside)
@@ -320,6 +328,39 @@ def test_fuzz_case_6375_dovi_l2_procamp_plain_tier_is_exact(mpcvr, oracle, torch
         cm = np.array(vp.GetColorMatrix(), np.float32)
         vp.close()
         assert np.array_equal(cm.view(np.uint32), np.asarray(oracle.color_matrix(p), np.float32).view(np.uint32)), "colour matrix: product != oracle"
+
+
+# soak case 2367 (profiles/r06/case2367.txt; MPCVR_FUZZ_JINC=1 MPCVR_FUZZ_FLAGS=8, seed 2102): HLG -> one-draw Jinc2m 2x -> HDR10 tone-mapping
+# operator 6 -> R10G10B10A2.  The plain tier equals the oracle bit for bit; every other tier draws Jinc2m from its phase table (weights at the
+# nominal phase, not at the interpolated texture coordinate: one code of the 10-bit post-scale texture on a few texels, its bar) and ONE such
+# texel is a blue of 1 / 1023 where the oracle has 0 — which operator 6 turns into seven ten-bit codes.  The +-4 ulp pow() witness says
+# nothing about that (no pow() moved): the channel is shown to lie inside what the oracle answers for the operator's input one code off.
+FUZZ_2367 = {'cformat': 13, 'w': 290, 'h': 436, 'kind': 'noise', 'seed': 116969516, 'exfmt': 2185372928, 'iChromaScaling': 0, 'iUpscaling': 5, 'iDownscaling': 2,
+             'bInterpolateAt50pct': 1, 'dst': (580, 872), 'iTexFormat': 10, 'hdr_output': 1, 'output_format': 1, 'hdr_tonemap': 6, 'hdr_display': 400.0,
+             'hdr_meta': (0.005, 4000.0, 800.0, 200.0)}
+
+
+def test_soak_case_2367_one_code_in_front_of_tonemap_operator_6(mpcvr, oracle, torch_cuda):
+    from videorenderer_amd import api
+    c = FUZZ_2367
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+    plain, info = run_product(mpcvr, torch_cuda, c, extra_flags=api.FLAG_NO_FUSED)
+    assert np.array_equal(_codes10(plain), _codes10(want)), info
+    for flags in (0, api.FLAG_NO_FAST_CONVERT, api.FLAG_NO_LUT):
+        got, info = run_product(mpcvr, torch_cuda, c, extra_flags=flags)
+        d = np.abs(_codes10(got) - _codes10(want))
+        assert int((d > 4).sum()) >= 1, "the case no longer shows what it was recorded for: tighten this test"
+        # without the operator-input runs the witness must REFUSE the channel (no pow() explains it) ...
+        with pytest.raises(AssertionError, match="NOT explained"):
+            compare_behind_tail(oracle, p, frame, pitch, got, want, f"soak 2367, flags {flags}", min_same=0.97, ten_bit=True, lim=4, cap=1)
+        # ... and with them it lies inside the interval; one channel of 1.5 M, as measured
+        _, n = compare_behind_tail(oracle, p, frame, pitch, got, want, f"soak 2367, flags {flags}", min_same=0.97, ten_bit=True, lim=4, cap=1, operator_input=True)
+        assert n == 1, (n, info)
+    # the operator's input one code off moves the oracle's own answer by that much: the slope the bar has to live with
+    up = oracle.process_with_tonemap_input_bias(p, frame, pitch, 1, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+    assert int(np.abs(_codes10(up) - _codes10(want)).max()) >= 7
 
 
 def test_dovi_tail_stage_by_stage(mpcvr, oracle, torch_cuda):
