@@ -22,13 +22,15 @@ sdr = GOLDEN_CASES["c1_nv12_bt709_passthrough"]["exfmt"]
 # mostly out-of-gamut saturated colour — the worst case for the cancelling 2020 -> 709 row — so the count allowed per frame is the
 # suite's Dolby Vision rate (16 per M pixels, twice what round 3 measured on its hardest frames), at least 3
 # Round 6 (the plain tier now carries the oracle's bits, so these counts are the fused tiers' own v_log_f32 / v_exp_f32 error and nothing else;
-# 5 x 8,000 + 3 x 8,000 cases, profiles/r06/fuzz_8000*.txt): the largest counts seen were 5 on a 0.023 M-pixel frame (HLG, 10-bit target),
-# 20 per M pixels behind a 10-bit internal format (Dolby Vision, case 2749 of seed 31337) and 79 per M pixels behind an 8-bit one (PQ, case 6005
-# of seed 2718: the convert's texel is rounded to 8 bits, then each resize pass rounds again — a flipped texel reaches several outputs).
-# The caps are 1.5 x those; the largest count of a run is printed at its end.
+# 9 x 8,000 cases of the default mode + the soak: 49 runs in every mode, 259,000 cases, profiles/r06/fuzz_8000*.txt, profiles/r06/soak/): the largest counts
+# seen were 5 on a 0.023 M-pixel frame (HLG, 10-bit target), 79 per M pixels behind an 8-bit internal format (PQ, case 6005 of seed 2718: the
+# convert's texel is rounded to 8 bits, then each resize pass rounds again — a flipped texel reaches several outputs) and 70 per M pixels on a
+# rotated Dolby Vision frame with level-2 trims (case 7172 of seed 1017; uniform noise in Y, U, V is mostly saturated out-of-gamut colour, the
+# worst case for the cancelling 2020 -> 709 row).  Every such channel has its witness; the COUNT guards against a systematic offset hiding
+# behind the witness, and is capped at 1.5 x the largest rate seen: 120 per M pixels (4e-5 of the channels), at least 8 per frame.  The
+# largest count of a run is printed at its end.
 def FUZZ_CAP(img, c=None):
-    rate = 120 if (c is not None and internal_is_8bit(c)) else 30
-    return max(8, int(np.ceil(rate * img.shape[0] * img.shape[1] / 1e6)))
+    return max(8, int(np.ceil(120 * img.shape[0] * img.shape[1] / 1e6)))
 witnessed = []      # (channels beyond the bar, per M pixels, 8-bit internal format, case index)
 plain_stats = collections.Counter(); paths = collections.Counter(); worst = 0.0; refused = 0; outliers = 0; batches = 0; oracle_cases = 0
 for i in range(n):

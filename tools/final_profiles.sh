@@ -39,6 +39,8 @@ SEED=402 run fuzz_2500_jinc_flags64 MPCVR_FUZZ_JINC=1 MPCVR_FUZZ_FLAGS=64
 SEED=403 run fuzz_2500_scalers_unaligned_flags72 MPCVR_FUZZ_SCALERS=1 MPCVR_FUZZ_UNALIGNED=1 MPCVR_FUZZ_FLAGS=72
 SEED=404 run fuzz_2500_host_unaligned_flags4 MPCVR_FUZZ_HOST=1 MPCVR_FUZZ_UNALIGNED=1 MPCVR_FUZZ_FLAGS=4
 SEED=31 run fuzz_2500_periodic MPCVR_FUZZ_PERIODIC=1
+# the soak run that ended on the count cap (case 7172: 24 witnessed channels on a rotated Dolby Vision frame), with the cap at 1.5 x that rate
+( time timeout 900 python tests/tools/fuzz_strip.py 8000 1017 ) > $O/fuzz_8000_seed1017.txt 2>&1; echo "rc=$?" >> $O/fuzz_8000_seed1017.txt
 ( timeout 400 python tests/tools/fuzz_errdiff.py 250 1 2>&1 | tail -8; timeout 400 python tests/tools/fuzz_errdiff.py 250 11 2>&1 | tail -8 ) > $O/fuzz_errdiff.txt
 python bench.py --steps 20 --warmup 5 > $O/bench_driver_shape.json 2> $O/bench_driver_shape.err
 # gpurun merges at most 64 MiB back: keep the tables anyone reads (summaries, stats, traffic, bench lines), drop the raw traces
