@@ -309,7 +309,13 @@ int32_t mpcvr_reset(mpcvr_ctx *ctx);
  * draw kernel has a frame dimension; bUseDither = 2: ONE error-diffusion launch behind the batch's 10-bit frames), otherwise frame by
  * frame (samples that do not start on a dword or need a repack of their own outside the v210 / interleaved-RGB batch textures).
  * mpcvr_get_last_batch_info reports the kernel launches a batch took.  The targets must therefore be distinct buffers; completion is
- * in stream order for the batch as a whole. */
+ * in stream order for the batch as a whole.
+ * Round 6: on a context that OWNS its stream (no mpcvr_set_stream) consecutive batches whose plan is one launch with no intermediate
+ * surface (exact 2x, the strip / periodic kernel reading the samples, the same-size block convert; no Dolby Vision, no repack) take turns on
+ * two internal lanes, so that two launches are in flight and fill each other's ramp-up and tail (4K -> 8K: +4 %, 1080p -> 1440p: +13 %).
+ * Batches and single frames that write the same render target (same pointer) stay in the order they were queued; everything that can observe
+ * a result (mpcvr_synchronize, the snapshot, a plan change, mpcvr_set_stream) waits for the lanes.  MPCVR_FLAG_NO_FRAME_LANES (or a caller's
+ * stream) keeps every batch in stream order; mpcvr_get_last_batch_info names the lane ("lane=0|1", -1 = the context stream). */
 int32_t mpcvr_process_batch(mpcvr_ctx *ctx, int32_t n, const void *const *srcs, void *const *dsts,
                             int32_t dst_pitch);
 /* mpcvr_process_batch for a Dolby Vision stream: rpus[i] is the RPU of frame i — the reference reads it from every sample in

@@ -7,6 +7,8 @@ Tighter where the arithmetic allows it:
   * fused 2x kernel (FMA contraction, LDS tone-map LUT): <= 1 LSB, >= 99 % identical.
 """
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -2819,6 +2821,77 @@ def test_single_frames_queued_behind_a_batch_stay_behind_it(mpcvr, torch_cuda):
     info = vp.GetVPInfo()
     vp.close()
     assert info.startswith("fused_up2x"), info
+
+
+@pytest.mark.parametrize("name,size,dst,route,all_routes", [("c3hdr_p010_pq_lanczos3_2x", (1920, 1080), (3840, 2160), "fused_up2x", 0),
+                                                            ("c3hdr_p010_pq_lanczos3_2x", (1920, 1080), (2560, 1440), "kernel=fused_", 0),
+                                                            ("c3hdr_p010_pq_lanczos3_2x", (1920, 1080), (2560, 1440), "kernel=fused_", 1),
+                                                            ("c1_nv12_bt709_passthrough", (1920, 1080), (1920, 1080), "direct:convert", 0)])
+def test_batches_on_the_lanes_equal_batches_in_stream_order(mpcvr, torch_cuda, name, size, dst, route, all_routes):
+    """(round 6) Consecutive mpcvr_process_batch calls of a context that owns its stream take turns on two lanes when the batch is one launch
+    with nothing shared (exact 2x, strip / periodic kernel, same-size block convert): two launches in flight fill each other's ramp-up and
+    tail.  What that must not change: every target holds exactly what the same sequence of calls leaves on a context bound to the caller's
+    stream — also when consecutive batches write the SAME targets (the later batch waits for the earlier one's event), when the ring of
+    targets wraps, and when a single frame follows into a target a batch in flight still writes.  The strip / periodic kernel stays in stream
+    order by default (measured: no gain) and goes on the lanes with MPCVR_BATCH_LANES_ALL=1 (read once per process: a child process)."""
+    if all_routes:
+        code = ("import os, sys\nsys.path.insert(0, os.getcwd())\nimport torch\nfrom videorenderer_amd import api\nimport tests.test_parity_gpu as t\n"
+                f"t.test_batches_on_the_lanes_equal_batches_in_stream_order(api, torch, {name!r}, {size!r}, {dst!r}, {route!r}, 0)\nprint('ok')\n")
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MPCVR_BATCH_LANES_ALL="1"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+        return
+    expect_lanes = {0, 1} if (route != "kernel=fused_" or os.environ.get("MPCVR_BATCH_LANES_ALL") == "1") else {-1}
+    from videorenderer_amd import api, synth
+    torch = torch_cuda
+    c = dict(GOLDEN_CASES[name])
+    c.update(w=size[0], h=size[1], dst=dst)
+    (ww, wh), vr = case_geometry(c)
+    nb, n = 5, 8
+    frames = []
+    for i in range(nb * n + 1):
+        f, pitch = synth.make_frame(c["cformat"], c["w"], c["h"], "noise", seed=900 + i)
+        frames.append(torch.from_numpy(np.ascontiguousarray(f)).cuda())
+    kw = {k: c[k] for k in SETTING_KEYS if k in c}
+
+    def play(own):
+        if not own:
+            with torch.cuda.stream(torch.cuda.Stream()):         # (torch's default stream is NULL = "the context's own stream")
+                return play_on(False)
+        return play_on(True)
+
+    def play_on(own):
+        vp = api.VideoProcessor(api.default_settings(**kw), use_torch_stream=not own)
+        vp.InitMediaType(c["cformat"], c["w"], c["h"], extfmt=c.get("exfmt", 0))
+        vp.SetWindowRect((0, 0, ww, wh)); vp.SetVideoRect(vr)
+        ring = [torch.full((wh, ww, 4), BG, dtype=torch.uint8, device="cuda") for _ in range(3 * n)]
+        lanes = set()
+        torch.cuda.synchronize()
+        # five batches over a ring of three batches' worth of targets (the fourth and fifth write what the first and second wrote), then the
+        # same targets again straight away from other samples, then a single frame into the first target of the batch still in flight
+        for b in range(nb):
+            k = (b * n) % len(ring)
+            vp.ProcessBatch(frames[b * n:(b + 1) * n], ring[k:k + n], ww * 4)
+            lanes.add(vp.GetLastBatchInfo()["lane"])
+        k = ((nb - 1) * n) % len(ring)
+        vp.ProcessBatch(frames[0:n], ring[k:k + n], ww * 4)
+        lanes.add(vp.GetLastBatchInfo()["lane"])
+        vp.CopySample(frames[nb * n], pitch)
+        vp.Process(ring[k], ww * 4)
+        vp.Synchronize()
+        torch.cuda.synchronize()
+        out = [t.clone() for t in ring]
+        info = vp.GetVPInfo()
+        vp.close()
+        return out, lanes, info
+
+    want, lanes_ref, info = play(False)
+    assert route in info, info
+    assert lanes_ref == {-1}, lanes_ref              # a caller's stream promises stream order: no lanes
+    for rep in range(3):
+        got, lanes, _ = play(True)
+        assert lanes == expect_lanes, lanes
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert torch.equal(g, w), f"round {rep}: target {i} differs from the stream-ordered run"
 
 
 def test_bench_through_rccl_in_a_world_of_one(mpcvr, torch_cuda):

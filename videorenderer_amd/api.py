@@ -665,11 +665,11 @@ class VideoProcessor:
         return buf.value.decode()
 
     def GetLastBatchInfo(self):
-        """'frames=<n>;launches=<kernel launches>[;dovi_runs=...]' of the last ProcessBatch / ProcessBatchDovi call, as a dict."""
+        """'frames=<n>;launches=<kernel launches>;lane=<0 | 1: the batch ran on that lane beside its predecessor, -1: on the context stream>[;dovi_runs=...]' of the last ProcessBatch / ProcessBatchDovi call, as a dict."""
         buf = C.create_string_buffer(512)
         self._check(self._L.mpcvr_get_last_batch_info(self._ctx, buf, 512))
         d = dict(kv.split("=", 1) for kv in buf.value.decode().split(";"))
-        return dict(frames=int(d["frames"]), launches=int(d["launches"]), dovi_runs=d.get("dovi_runs", ""))
+        return dict(frames=int(d["frames"]), launches=int(d["launches"]), dovi_runs=d.get("dovi_runs", ""), lane=int(d.get("lane", -1)))
 
     def GetLastProcessMs(self):
         ms = C.c_float()

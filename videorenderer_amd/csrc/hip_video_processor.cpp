@@ -93,6 +93,7 @@ CHipVideoProcessor::~CHipVideoProcessor()
     for (FrameLane &fl : m_flanes) {
         if (fl.stream) { (void)hipStreamSynchronize(fl.stream); (void)hipStreamDestroy(fl.stream); }
         for (LaneFrame &f : fl.ring) if (f.done) (void)hipEventDestroy(f.done);
+        if (fl.batchDone) (void)hipEventDestroy(fl.batchDone);
     }
     for (FrameSlot &fs : m_slots) {
         fs.dev.Release();
@@ -244,7 +245,90 @@ CHipVideoProcessor::FrameLane *CHipVideoProcessor::PickFrameLane(const void *rt)
     if (!pick) { pick = &m_flanes[m_flaneNext]; m_flaneNext = (m_flaneNext + 1) % FrameLaneCount(); }
     if (!pick->stream && hipStreamCreateWithFlags(&pick->stream, hipStreamDefault) != hipSuccess) { pick->stream = nullptr; return nullptr; }
     for (int i = 0; i < n_also; i++) (void)hipStreamWaitEvent(pick->stream, also[i], 0);
+    // ... and behind a whole batch still in flight on another lane that writes this target (the pick's own batches: stream order)
+    for (int li = 0; li < kBatchLanes; li++) {
+        FrameLane &bl = m_flanes[li];
+        if (!bl.batchPending || &bl == pick) continue;
+        if (hipEventQuery(bl.batchDone) == hipSuccess) { bl.batchPending = false; bl.batchRts.clear(); continue; }
+        if (std::binary_search(bl.batchRts.begin(), bl.batchRts.end(), rt)) (void)hipStreamWaitEvent(pick->stream, bl.batchDone, 0);
+    }
     return pick;
+}
+
+// ---- whole batches on the lanes (see FrameLane) ----
+// The same rule as for single frames — nothing a batch touches may be shared with the batch beside it — checked on the route the batch will
+// take: the exact-2x kernel, the strip / periodic kernel reading the samples themselves, the same-size block convert; default tier only.
+bool CHipVideoProcessor::BatchLanesUsable(int n, const void *const *srcs, void *const *dsts, int rtPitch)
+{
+    static const bool off = [] { const char *e = std::getenv("MPCVR_NO_BATCH_LANES"); return e && *e && *e != '0'; }();
+    if (off || !m_ownStream || n < 2 || !m_srcParams || m_doviValid || m_dvFrames) return false;
+    if (m_cfg.flags & (MPCVR_FLAG_NO_FRAME_LANES | MPCVR_FLAG_NO_FUSED | MPCVR_FLAG_NO_FAST_CONVERT | MPCVR_FLAG_NO_STRIP)) return false;
+    if (m_srcParams->cformat == MPCVR_CF_V210 || m_srcParams->layout == LAY_RGB) return false;
+    if (m_plan.errdiff || m_plan.hdr_tonemap || rtPitch < m_windowRect.Width() * 4) return false;
+    bool aligned = true;
+    for (int i = 0; i < n; i++) {
+        if (!srcs[i] || !dsts[i] || ((uintptr_t)srcs[i] & 3) != 0) return false;
+        if (((uintptr_t)dsts[i] & 15) != 0) aligned = false;
+    }
+    // Where two launches in flight were measured to pay (same box, bench.py process_batch_on_lanes against `value`, profiles/r06/
+    // bench_batch_lanes_call26.txt): the same-size block convert (C1: 408 k -> 454 k frames/s) and the exact-2x kernel (C2, one round of waves
+    // per batch: 83.0 k -> 94.8 k; 4K -> 8K, four rounds: 22.27 k -> 22.29 k).  Not the strip / periodic kernel (1080p -> 1440p 99.6 k -> 94.6 k,
+    // 720p -> 2160p -3 %, 4K -> 1440p +3 %, 4K -> 1080p +7 %) nor the fused Jinc2m kernel (-4 %; a workgroup holds 114-146 KiB of LDS):
+    // MPCVR_BATCH_LANES_ALL=1 puts those on the lanes too (tests, A/B).
+    static const bool all = [] { const char *e = std::getenv("MPCVR_BATCH_LANES_ALL"); return e && *e && *e != '0'; }();
+    if (m_plan.fused_up2x) return all || !m_plan.fused_jinc;
+    if (m_strip) {
+        FusedStripParams sp{};
+        return all && FillStripParams((const uint8_t *)srcs[0], dsts[0], rtPitch, MakeStore(dsts[0], rtPitch, m_plan.swap_fmt, true), &sp) && !sp.surface_mode;
+    }
+    if (m_plan.direct_convert) {
+        FusedParams conv{}, direct{};
+        m_batchRepacked = false; m_batchSrc16 = false;           // (BatchPlan reads them; ProcessBatchRoutesOn sets them again)
+        return BatchPlan((const uint8_t *)srcs[0], dsts[0], rtPitch, aligned, &conv, &direct);
+    }
+    return false;
+}
+
+// the lane of the batch about to be queued (the two take turns), ordered behind everything still in flight on OTHER lanes that writes one
+// of its render targets: single frames (their ring entries) and batches
+CHipVideoProcessor::FrameLane *CHipVideoProcessor::PickBatchLane(int n, void *const *dsts)
+{
+    FrameLane *pick = &m_flanes[m_blaneNext];
+    if (!pick->stream && hipStreamCreateWithFlags(&pick->stream, hipStreamDefault) != hipSuccess) { pick->stream = nullptr; return nullptr; }
+    m_blaneNext = (m_blaneNext + 1) % kBatchLanes;
+    std::vector<const void *> rts(dsts, dsts + n);
+    std::sort(rts.begin(), rts.end());
+    for (FrameLane &fl : m_flanes) {
+        if (&fl == pick || !fl.stream) continue;
+        for (LaneFrame &f : fl.ring) {
+            if (!f.pending) continue;
+            if (hipEventQuery(f.done) == hipSuccess) { f.pending = false; continue; }
+            if (std::binary_search(rts.begin(), rts.end(), f.rt)) (void)hipStreamWaitEvent(pick->stream, f.done, 0);
+        }
+        if (!fl.batchPending) continue;
+        if (hipEventQuery(fl.batchDone) == hipSuccess) { fl.batchPending = false; fl.batchRts.clear(); continue; }
+        bool shared = false;
+        for (size_t a = 0, b = 0; a < rts.size() && b < fl.batchRts.size() && !shared;) {
+            if (rts[a] == fl.batchRts[b]) shared = true;
+            else if (rts[a] < fl.batchRts[b]) a++; else b++;
+        }
+        if (shared) (void)hipStreamWaitEvent(pick->stream, fl.batchDone, 0);
+    }
+    return pick;
+}
+
+// the batch just queued on `fl` writes dsts[0..n): its completion event, and its targets joined to those of the lane's batches still in flight
+void CHipVideoProcessor::NoteLaneBatch(FrameLane *fl, int n, void *const *dsts)
+{
+    if (!fl->batchDone && hipEventCreateWithFlags(&fl->batchDone, hipEventDisableTiming) != hipSuccess) { fl->batchDone = nullptr; (void)hipStreamSynchronize(fl->stream); return; }
+    if (fl->batchPending && hipEventQuery(fl->batchDone) == hipSuccess) fl->batchPending = false;
+    if (!fl->batchPending) fl->batchRts.clear();
+    fl->batchRts.insert(fl->batchRts.end(), dsts, dsts + n);
+    std::sort(fl->batchRts.begin(), fl->batchRts.end());
+    fl->batchRts.erase(std::unique(fl->batchRts.begin(), fl->batchRts.end()), fl->batchRts.end());
+    (void)hipEventRecord(fl->batchDone, fl->stream);
+    fl->batchPending = true;
+    fl->last = fl->batchDone;
 }
 
 // the frame just queued on `fl` writes `rt`: its completion event takes the ring's oldest slot (whose frame must have completed)
@@ -287,6 +371,7 @@ HRESULT CHipVideoProcessor::JoinFrameLanes(bool host_wait)
             HRESULT h = CheckHip(hipStreamSynchronize(fl.stream), "frame lane sync");
             if (h) hr = h;
             for (LaneFrame &f : fl.ring) f.pending = false;
+            fl.batchPending = false; fl.batchRts.clear();
             fl.last = nullptr;
         } else if (m_stream) (void)hipStreamWaitEvent(m_stream, fl.last, 0);
     }
@@ -1318,6 +1403,30 @@ HRESULT CHipVideoProcessor::ProcessBatch(int n, const void *const *srcs, void *c
 
 HRESULT CHipVideoProcessor::ProcessBatchRoutes(int n, const void *const *srcs, void *const *dsts, int rtPitch)
 {
+    // a batch that is one launch with nothing shared runs on one of two lanes, beside the batch before it (FrameLane); everything else —
+    // and every batch of a context on a caller's stream — in stream order on the context stream
+    FrameLane *bl = nullptr;
+    if (m_bInit && m_srcParams && n > 1 && srcs && dsts && !m_keepStart) {
+        (void)hipSetDevice(m_device);
+        HRESULT hr;
+        if (m_planDirty && (hr = UpdatePlan())) return hr;
+        if (BatchLanesUsable(n, srcs, dsts, rtPitch)) bl = PickBatchLane(n, dsts);
+    }
+    m_lastBatchLane = bl ? (int)(bl - m_flanes) : -1;
+    if (!bl) return ProcessBatchRoutesOn(n, srcs, dsts, rtPitch);
+    LaneWaitsForStream(bl);                  // behind whatever the context stream was given since the lane last looked
+    hipStream_t const ctx = m_stream;
+    m_stream = bl->stream; m_batchOnLane = true;
+    UseLane(0);
+    const HRESULT hr = ProcessBatchRoutesOn(n, srcs, dsts, rtPitch);
+    m_stream = ctx; m_batchOnLane = false;
+    UseLane(0);
+    NoteLaneBatch(bl, n, dsts);
+    return hr;
+}
+
+HRESULT CHipVideoProcessor::ProcessBatchRoutesOn(int n, const void *const *srcs, void *const *dsts, int rtPitch)
+{
     if (!m_bInit || !m_srcParams) return Fail(MPCVR_E_NOT_VALID_STATE, "InitMediaType has not been called");
     if (n <= 0 || !srcs || !dsts) return Fail(MPCVR_E_INVALIDARG, "empty batch");
     if (rtPitch < m_windowRect.Width() * 4) return Fail(MPCVR_E_INVALIDARG, "render-target pitch smaller than a row");
@@ -1325,8 +1434,10 @@ HRESULT CHipVideoProcessor::ProcessBatchRoutes(int n, const void *const *srcs, v
     HRESULT hr;
     if (!m_keepStart) m_startRecorded = false;
     if (m_planDirty && (hr = UpdatePlan())) return hr;
-    (void)JoinFrameLanes(false);             // a batch runs on the context stream, behind every single frame still in flight
-    NoteStreamWork();                        // ... and single frames queued after it run behind the batch (LaneWaitsForStream)
+    if (!m_batchOnLane) {
+        (void)JoinFrameLanes(false);         // a batch runs on the context stream, behind every single frame still in flight
+        NoteStreamWork();                    // ... and single frames queued after it run behind the batch (LaneWaitsForStream)
+    }
     for (int i = 0; i < n; i++)
         if (!srcs[i] || !dsts[i]) return Fail(MPCVR_E_POINTER, "null frame in batch");
     // v210 samples are repacked into m_TexSrcVideo's layout first (CopyFrameV210, Helper.cpp:709-748): a batch gets one repack launch
@@ -1904,7 +2015,7 @@ HRESULT CHipVideoProcessor::ProcessBatchDovi(int n, const void *const *srcs, voi
 // a batch on a whole-batch route launches a handful of kernels whatever n is, a frame-by-frame one at least n
 std::string CHipVideoProcessor::GetLastBatchInfo() const
 {
-    std::string s = "frames=" + std::to_string(m_lastBatchFrames) + ";launches=" + std::to_string(m_lastBatchLaunches);
+    std::string s = "frames=" + std::to_string(m_lastBatchFrames) + ";launches=" + std::to_string(m_lastBatchLaunches) + ";lane=" + std::to_string(m_lastBatchLane);
     if (!m_dvLastInfo.empty()) s += ";dovi_runs=" + m_dvLastInfo;
     return s;
 }

@@ -168,6 +168,7 @@ private:
     std::string m_dvLastInfo;                         // the runs of the last ProcessBatchDovi call (GetLastBatchInfo: ";dovi_runs=3:tables,1:frames")
     unsigned m_laneFrames = 0;                        // frames queued on the frame lanes (the timing pair is recorded on every n-th)
     unsigned m_launches = 0;                          // kernel launches so far (CheckHip) ...
+    int m_lastBatchLane = -1;                                // the lane the last batch ran on (-1: the context stream)
     int m_lastBatchFrames = 0, m_lastBatchLaunches = 0;      // ... and what the last batch call used
     HRESULT ProcessBatchRoutes(int n, const void *const *srcs, void *const *dsts, int rtPitch);
     bool ToneMapActive() const;
@@ -255,7 +256,19 @@ private:
     // completed, which also bounds how far the host runs ahead (kFrameLanes x kLaneDepth frames)
     static constexpr int kLaneDepth = 8;
     struct LaneFrame { const void *rt = nullptr; hipEvent_t done = nullptr; bool pending = false; };
-    struct FrameLane { hipStream_t stream = nullptr; LaneFrame ring[kLaneDepth]; int head = 0; hipEvent_t last = nullptr; unsigned seenGen = 0; };
+    // (round 6) WHOLE BATCHES take turns on the first two lanes as well (ProcessBatch on a context that owns its stream, a plan that is one
+    // launch per batch with no intermediate surface): two launches in flight fill each other's ramp-up and tail — same box, 32-frame batches:
+    // 4K -> 8K 22.8 k -> 23.8 k frames/s, 1080p -> 1440p 102 k -> 116 k (profiles/r06/batch_overlap.txt).  batchRts: the render targets of
+    // the lane's batches still in flight (sorted), batchDone: the event behind the last of them.
+    struct FrameLane { hipStream_t stream = nullptr; LaneFrame ring[kLaneDepth]; int head = 0; hipEvent_t last = nullptr; unsigned seenGen = 0;
+                       std::vector<const void *> batchRts; hipEvent_t batchDone = nullptr; bool batchPending = false; };
+    static constexpr int kBatchLanes = 2;
+    int m_blaneNext = 0;
+    bool m_batchOnLane = false;               // ProcessBatchRoutesOn runs with m_stream = a lane's stream
+    bool BatchLanesUsable(int n, const void *const *srcs, void *const *dsts, int rtPitch);
+    FrameLane *PickBatchLane(int n, void *const *dsts);
+    void NoteLaneBatch(FrameLane *fl, int n, void *const *dsts);
+    HRESULT ProcessBatchRoutesOn(int n, const void *const *srcs, void *const *dsts, int rtPitch);
     // work queued on the CONTEXT stream (a batch, a frame that ran off the lanes, a sample copy / repack, a read-back) since a lane last
     // waited for it: every such call bumps m_streamGen; a lane whose seenGen is behind waits for an event recorded on the context stream
     // (m_evStreamMark, recorded once per generation) before its next frame — a lane frame into the render target, or out of the sample, that
