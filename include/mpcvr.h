@@ -429,6 +429,10 @@ int32_t mpcvr_plan_hdr10_params(float min_mastering, float max_mastering, float 
  * that is fewer than the table has, nothing is written.  (Replaces mpcvr_plan_pq_eotf_lut(float[4096]) of round 3, whose table grew in
  * place in round 4: a caller that sizes its buffer from an old header can no longer be overrun.) */
 int32_t mpcvr_plan_pq_eotf_table(float *out, int32_t capacity, int32_t *count);
+/* DEPRECATED, one more release: the round-3 entry point with its fixed float[4096] — the same function on that 4096-point grid
+ * (x = (i/4095)^2), so that a caller built against the old header links and is neither overrun nor handed a table of another size.
+ * New code: mpcvr_plan_pq_eotf_table. */
+int32_t mpcvr_plan_pq_eotf_lut(float out[4096]);
 /* which draws Process() would issue (UpdateTexParams :1143, UpdatePostScaleTexures :2894, ResizeShaderPass :3103) */
 int32_t mpcvr_plan_describe(const mpcvr_settings *s, int32_t cformat, int32_t rect_w, int32_t rect_h,
                             const mpcvr_rect *video_rect, int32_t window_w, int32_t window_h,

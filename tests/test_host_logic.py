@@ -495,6 +495,26 @@ def test_pq_eotf_table(mpcvr):
     assert np.abs(got[~vis] - lm[~vis]).max() < 1e-9
 
 
+def test_deprecated_pq_eotf_lut_shim(mpcvr):
+    """mpcvr_plan_pq_eotf_lut(float[4096]) — the round-3 entry point, kept one more release for callers built against the old header: exactly
+    4096 floats are written (the guard words behind them stay), the same function as the table's on the 4096-point grid."""
+    import ctypes as C
+    import numpy as np
+    from videorenderer_amd import api
+    L = api.load_library()
+    buf = np.full(4096 + 64, np.float32(-777.0), dtype=np.float32)
+    assert L.mpcvr_plan_pq_eotf_lut(buf.ctypes.data_as(C.POINTER(C.c_float))) == 0
+    assert (buf[4096:] == np.float32(-777.0)).all()
+    t = buf[:4096].astype(np.float64)
+    x = (np.arange(4096) / 4095) ** 2
+    m1, m2, c1, c2, c3 = 2610 / 16384, 2523 / 4096 * 128, 3424 / 4096, 2413 / 4096 * 32, 2392 / 4096 * 32
+    z = x ** (1 / m2)
+    lin = (np.maximum(z - c1, 0) / (c2 - c3 * z)) ** (1 / m1)
+    live = lin > 1e-30
+    assert np.abs(t[live] - np.log2(lin[live])).max() < 8e-6 and (t[~live] == -150.0).all() and t[-1] == 0.0
+    assert L.mpcvr_plan_pq_eotf_lut(None) < 0
+
+
 # ---- periodic-phase fused kernel (vp_fused_period.h): the planner's side of its compile-time tap rows ----
 def _period_base(P, Q, r):
     return ((2 * r + 1) * Q - P) // (2 * P)            # floor: pos = (r + .5) Q / P - .5

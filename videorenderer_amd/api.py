@@ -162,7 +162,7 @@ EXPORTS = [
     "mpcvr_get_last_process_ms", "mpcvr_get_last_timings",
     "mpcvr_plan_frame_layout", "mpcvr_plan_color_matrix", "mpcvr_plan_gamut_2020_to_709", "mpcvr_plan_pq_lut",
     "mpcvr_plan_upscale_weights", "mpcvr_plan_axis_taps", "mpcvr_plan_describe", "mpcvr_plan_final_pass_multiplier",
-    "mpcvr_plan_strip", "mpcvr_plan_pq_eotf_table", "mpcvr_bandwidth_probe", "mpcvr_plan_period", "mpcvr_plan_hdr10_params",
+    "mpcvr_plan_strip", "mpcvr_plan_pq_eotf_table", "mpcvr_plan_pq_eotf_lut", "mpcvr_bandwidth_probe", "mpcvr_plan_period", "mpcvr_plan_hdr10_params",
     "mpcvr_eval_transcendental", "mpcvr_eval_transcendental_host", "mpcvr_bandwidth_probe_up2x", "mpcvr_eval_dovi_tail",
 ]
 
@@ -250,6 +250,7 @@ def load_library():
         "mpcvr_plan_hdr10_params": [f, f, f, f, f, i32, P(u32)],
         "mpcvr_plan_period": [i32, i32, i32, i32, i32, u32, P(i32), P(i32), P(f), P(f), P(i32), P(i32)],
         "mpcvr_plan_pq_eotf_table": [P(f), i32, P(i32)],
+        "mpcvr_plan_pq_eotf_lut": [P(f)],
         "mpcvr_bandwidth_probe": [C.c_void_p, C.c_void_p, C.c_size_t, i32, C.c_void_p],
         "mpcvr_bandwidth_probe_up2x": [i32, i32, P(C.c_void_p), P(C.c_void_p), i32, i32, i32, i32, C.c_void_p],
         "mpcvr_eval_transcendental": [i32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],

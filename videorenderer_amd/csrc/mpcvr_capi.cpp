@@ -1,4 +1,5 @@
 // mpcvr_capi.cpp — extern "C" surface of libmpcvr.so (include/mpcvr.h) over CHipVideoProcessor.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -403,6 +404,23 @@ int32_t mpcvr_plan_pq_eotf_table(float *out, int32_t capacity, int32_t *count)
     if (!out) return count ? MPCVR_S_OK : MPCVR_E_POINTER;
     if (capacity < n) return MPCVR_E_INVALIDARG;
     mpcvr::BuildPqEotfLut(out);
+    return MPCVR_S_OK;
+}
+
+// DEPRECATED (kept so that a caller built against the round-3 header still links and cannot be overrun): the same function on the 4096-entry
+// grid that header promised, computed from the table's definition (vp_plan.cpp BuildPqEotfLut), not cut out of the larger table
+int32_t mpcvr_plan_pq_eotf_lut(float out[4096])
+{
+    if (!out) return MPCVR_E_POINTER;
+    const double m1 = 2610.0 / (4096.0 * 4.0), m2 = (2523.0 / 4096.0) * 128.0;
+    const double c1 = 3424.0 / 4096.0, c2 = (2413.0 / 4096.0) * 32.0, c3 = (2392.0 / 4096.0) * 32.0;
+    for (int i = 0; i < 4096; i++) {
+        const double t = (double)i / 4095.0;
+        double x = std::pow(t * t, 1.0 / m2);
+        x = std::fmax(x - c1, 0.0) / (c2 - c3 * x);
+        const double l = x > 0.0 ? std::log2(x) / m1 : -1e9;
+        out[i] = l > -150.0 ? (float)l : -150.0f;
+    }
     return MPCVR_S_OK;
 }
 
