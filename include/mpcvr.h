@@ -311,8 +311,9 @@ int32_t mpcvr_reset(mpcvr_ctx *ctx);
  * mpcvr_get_last_batch_info reports the kernel launches a batch took.  The targets must therefore be distinct buffers; completion is
  * in stream order for the batch as a whole.
  * Round 6: on a context that OWNS its stream (no mpcvr_set_stream) consecutive batches whose plan is one launch with no intermediate
- * surface (exact 2x, the strip / periodic kernel reading the samples, the same-size block convert; no Dolby Vision, no repack) take turns on
- * two internal lanes, so that two launches are in flight and fill each other's ramp-up and tail (4K -> 8K: +4 %, 1080p -> 1440p: +13 %).
+ * surface (exact 2x, the strip / periodic kernel reading the samples, the fused Jinc2m kernel, the same-size block convert; no Dolby Vision,
+ * no repack) take turns on two internal lanes, so that two launches are in flight and fill each other's ramp-up and tail (4K -> 8K: +4 %,
+ * 1080p -> 1440p: +16 %; MPCVR_NO_BATCH_LANES=1 in the environment turns it off).
  * Batches and single frames that write the same render target (same pointer) stay in the order they were queued; everything that can observe
  * a result (mpcvr_synchronize, the snapshot, a plan change, mpcvr_set_stream) waits for the lanes.  MPCVR_FLAG_NO_FRAME_LANES (or a caller's
  * stream) keeps every batch in stream order; mpcvr_get_last_batch_info names the lane ("lane=0|1", -1 = the context stream). */

@@ -2823,24 +2823,25 @@ def test_single_frames_queued_behind_a_batch_stay_behind_it(mpcvr, torch_cuda):
     assert info.startswith("fused_up2x"), info
 
 
-@pytest.mark.parametrize("name,size,dst,route,all_routes", [("c3hdr_p010_pq_lanczos3_2x", (1920, 1080), (3840, 2160), "fused_up2x", 0),
-                                                            ("c3hdr_p010_pq_lanczos3_2x", (1920, 1080), (2560, 1440), "kernel=fused_", 0),
-                                                            ("c3hdr_p010_pq_lanczos3_2x", (1920, 1080), (2560, 1440), "kernel=fused_", 1),
-                                                            ("c1_nv12_bt709_passthrough", (1920, 1080), (1920, 1080), "direct:convert", 0)])
-def test_batches_on_the_lanes_equal_batches_in_stream_order(mpcvr, torch_cuda, name, size, dst, route, all_routes):
+@pytest.mark.parametrize("name,size,dst,route,lanes_off", [("c3hdr_p010_pq_lanczos3_2x", (1920, 1080), (3840, 2160), "fused_up2x", 0),
+                                                           ("c3hdr_p010_pq_lanczos3_2x", (1920, 1080), (2560, 1440), "kernel=fused_period", 0),
+                                                           ("c3hdr_p010_pq_lanczos3_2x", (1920, 1080), (2304, 1296), "kernel=fused_strip", 0),
+                                                           ("c3hdr_p010_pq_lanczos3_2x", (1920, 1080), (2560, 1440), "kernel=fused_period", 1),
+                                                           ("c1_nv12_bt709_passthrough", (1920, 1080), (1920, 1080), "direct:convert", 0)])
+def test_batches_on_the_lanes_equal_batches_in_stream_order(mpcvr, torch_cuda, name, size, dst, route, lanes_off):
     """(round 6) Consecutive mpcvr_process_batch calls of a context that owns its stream take turns on two lanes when the batch is one launch
     with nothing shared (exact 2x, strip / periodic kernel, same-size block convert): two launches in flight fill each other's ramp-up and
     tail.  What that must not change: every target holds exactly what the same sequence of calls leaves on a context bound to the caller's
     stream — also when consecutive batches write the SAME targets (the later batch waits for the earlier one's event), when the ring of
-    targets wraps, and when a single frame follows into a target a batch in flight still writes.  The strip / periodic kernel stays in stream
-    order by default (measured: no gain) and goes on the lanes with MPCVR_BATCH_LANES_ALL=1 (read once per process: a child process)."""
-    if all_routes:
+    targets wraps, and when a single frame follows into a target a batch in flight still writes.  MPCVR_NO_BATCH_LANES=1 (read once per
+    process: a child process) keeps every batch on the context stream."""
+    if lanes_off:
         code = ("import os, sys\nsys.path.insert(0, os.getcwd())\nimport torch\nfrom videorenderer_amd import api\nimport tests.test_parity_gpu as t\n"
                 f"t.test_batches_on_the_lanes_equal_batches_in_stream_order(api, torch, {name!r}, {size!r}, {dst!r}, {route!r}, 0)\nprint('ok')\n")
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MPCVR_BATCH_LANES_ALL="1"), capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MPCVR_NO_BATCH_LANES="1"), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
         return
-    expect_lanes = {0, 1} if (route != "kernel=fused_" or os.environ.get("MPCVR_BATCH_LANES_ALL") == "1") else {-1}
+    expect_lanes = {-1} if os.environ.get("MPCVR_NO_BATCH_LANES") == "1" else {0, 1}
     from videorenderer_amd import api, synth
     torch = torch_cuda
     c = dict(GOLDEN_CASES[name])

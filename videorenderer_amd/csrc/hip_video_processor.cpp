@@ -270,16 +270,15 @@ bool CHipVideoProcessor::BatchLanesUsable(int n, const void *const *srcs, void *
         if (!srcs[i] || !dsts[i] || ((uintptr_t)srcs[i] & 3) != 0) return false;
         if (((uintptr_t)dsts[i] & 15) != 0) aligned = false;
     }
-    // Where two launches in flight were measured to pay (same box, bench.py process_batch_on_lanes against `value`, profiles/r06/
-    // bench_batch_lanes_call26.txt): the same-size block convert (C1: 408 k -> 454 k frames/s) and the exact-2x kernel (C2, one round of waves
-    // per batch: 83.0 k -> 94.8 k; 4K -> 8K, four rounds: 22.27 k -> 22.29 k).  Not the strip / periodic kernel (1080p -> 1440p 99.6 k -> 94.6 k,
-    // 720p -> 2160p -3 %, 4K -> 1440p +3 %, 4K -> 1080p +7 %) nor the fused Jinc2m kernel (-4 %; a workgroup holds 114-146 KiB of LDS):
-    // MPCVR_BATCH_LANES_ALL=1 puts those on the lanes too (tests, A/B).
-    static const bool all = [] { const char *e = std::getenv("MPCVR_BATCH_LANES_ALL"); return e && *e && *e != '0'; }();
-    if (m_plan.fused_up2x) return all || !m_plan.fused_jinc;
+    // Two launches in flight were measured to pay on every such route (same box, bench.py process_batch_on_lanes against `value`, a quarter of
+    // a second of batches each; profiles/r06/bench_batch_lanes_all_routes_call32.txt, bench_batch_lanes_call27.txt): same-size block convert
+    // +11-16 %, exact-2x kernel +2-5 % (4K -> 8K, four rounds of waves per batch) to +15 % (1080p -> 4K, one round), strip / periodic kernel
+    // +11-29 % (1080p -> 1440p 99.8 k -> 116.4 k frames/s, 720p -> 1080p 190 k -> 246 k), fused Jinc2m +4 %.  (An earlier table that had
+    // the strip kernels LOSE was a wall clock around 30 launches of 0.3 ms: it measured the closing synchronize.)
+    if (m_plan.fused_up2x) return true;
     if (m_strip) {
         FusedStripParams sp{};
-        return all && FillStripParams((const uint8_t *)srcs[0], dsts[0], rtPitch, MakeStore(dsts[0], rtPitch, m_plan.swap_fmt, true), &sp) && !sp.surface_mode;
+        return FillStripParams((const uint8_t *)srcs[0], dsts[0], rtPitch, MakeStore(dsts[0], rtPitch, m_plan.swap_fmt, true), &sp) && !sp.surface_mode;
     }
     if (m_plan.direct_convert) {
         FusedParams conv{}, direct{};

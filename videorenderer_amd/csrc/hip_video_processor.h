@@ -258,7 +258,7 @@ private:
     struct LaneFrame { const void *rt = nullptr; hipEvent_t done = nullptr; bool pending = false; };
     // (round 6) WHOLE BATCHES take turns on the first two lanes as well (ProcessBatch on a context that owns its stream, a plan that is one
     // launch per batch with no intermediate surface): two launches in flight fill each other's ramp-up and tail — same box, 32-frame batches:
-    // 4K -> 8K 22.8 k -> 23.8 k frames/s, 1080p -> 1440p 102 k -> 116 k (profiles/r06/batch_overlap.txt).  batchRts: the render targets of
+    // 4K -> 8K 22.6 k -> 23.5 k frames/s, 1080p -> 1440p 99.4 k -> 115.6 k (profiles/r06/final4/bench_workloads.jsonl).  batchRts: the render targets of
     // the lane's batches still in flight (sorted), batchDone: the event behind the last of them.
     struct FrameLane { hipStream_t stream = nullptr; LaneFrame ring[kLaneDepth]; int head = 0; hipEvent_t last = nullptr; unsigned seenGen = 0;
                        std::vector<const void *> batchRts; hipEvent_t batchDone = nullptr; bool batchPending = false; };
