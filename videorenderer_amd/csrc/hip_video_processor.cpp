@@ -246,7 +246,7 @@ CHipVideoProcessor::FrameLane *CHipVideoProcessor::PickFrameLane(const void *rt)
     if (!pick->stream && hipStreamCreateWithFlags(&pick->stream, hipStreamDefault) != hipSuccess) { pick->stream = nullptr; return nullptr; }
     for (int i = 0; i < n_also; i++) (void)hipStreamWaitEvent(pick->stream, also[i], 0);
     // ... and behind a whole batch still in flight on another lane that writes this target (the pick's own batches: stream order)
-    for (int li = 0; li < kBatchLanes; li++) {
+    for (int li = 0; li < kFrameLanes; li++) {
         FrameLane &bl = m_flanes[li];
         if (!bl.batchPending || &bl == pick) continue;
         if (hipEventQuery(bl.batchDone) == hipSuccess) { bl.batchPending = false; bl.batchRts.clear(); continue; }
@@ -294,7 +294,9 @@ CHipVideoProcessor::FrameLane *CHipVideoProcessor::PickBatchLane(int n, void *co
 {
     FrameLane *pick = &m_flanes[m_blaneNext];
     if (!pick->stream && hipStreamCreateWithFlags(&pick->stream, hipStreamDefault) != hipSuccess) { pick->stream = nullptr; return nullptr; }
-    m_blaneNext = (m_blaneNext + 1) % kBatchLanes;
+    // (two lanes: MPCVR_BATCH_LANE_COUNT = 2 .. 8 for the A/B — profiles/r06/batch_lane_count_call34.txt)
+    static const int count = [] { const char *e = std::getenv("MPCVR_BATCH_LANE_COUNT"); const int v = e && *e ? std::atoi(e) : kBatchLanes; return v < 2 ? 2 : v > kFrameLanes ? kFrameLanes : v; }();
+    m_blaneNext = (m_blaneNext + 1) % count;
     std::vector<const void *> rts(dsts, dsts + n);
     std::sort(rts.begin(), rts.end());
     for (FrameLane &fl : m_flanes) {
