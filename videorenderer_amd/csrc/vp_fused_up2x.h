@@ -59,17 +59,6 @@ __device__ __forceinline__ void fused_up2x_body(const FusedArgs &P, const FusedF
         }
     __syncthreads();                                   // the only workgroup barrier: tables visible
 
-#ifdef MPCVR_UP2X_STAGGER
-    {   // experiment (-DMPCVR_UP2X_STAGGER=<s_sleep units of 64 cycles>): the workgroups a launch STARTS with share their CUs three by three
-        // and begin in lockstep; the second and third of a CU (ids 256 apart: 8 XCDs x 32 CUs) begin one and two thirds of an iteration later
-        const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        if (id < 768u) {
-            const unsigned ph = (id >> 8) % 3u;
-            if (ph >= 1) __builtin_amdgcn_s_sleep(MPCVR_UP2X_STAGGER);
-            if (ph == 2) __builtin_amdgcn_s_sleep(MPCVR_UP2X_STAGGER);
-        }
-    }
-#endif
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;      // (wave-uniform, and the compiler should know)
     const int W = P.W, H = P.H;
     const int x0 = (blockIdx.x * WAVES + wave) * S;
