@@ -598,3 +598,19 @@ def test_two_step_quotient_of_8bit_codes():
         t = np.float32(code) * np.float32(lo)                                     # rounded product
         got = rn32(Fraction(code) * Fraction(hi) + Fraction(float(t)))            # the FMA: one rounding of the exact sum
         assert got == rn32(Fraction(code, 255)), code
+
+
+def test_committed_traffic_figures_belong_to_the_committed_kernels():
+    """profiles/hbm_traffic.json ties every entry to the sha256 of the kernel sources it was measured on, and bench.py DROPS an entry whose
+    sources changed (roofline.traffic = null, no co_limit): a commit that touches a kernel file has to re-run tools/pmc_traffic.sh for the
+    workloads that file serves (round 6: an experiment's guarded block was committed with a profile set and removed after it — the
+    headline's entry went stale without a byte of the binary changing)."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    t = json.load(open(os.path.join(root, "profiles", "hbm_traffic.json")))
+    stale = [k for k, v in t.items() if isinstance(v, dict) and "csrc_sha256" in v and v["csrc_sha256"] != bench.csrc_digest(v.get("sources"))]
+    assert not stale, f"stale entries (re-run tools/pmc_traffic.sh + tools/update_traffic.py for them): {stale}"
