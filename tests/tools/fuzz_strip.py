@@ -205,7 +205,11 @@ for i in range(n):
         _, nb = compare_behind_tail(oracle, po, fr, pit, got, want_w, f"default planner vs oracle (witness for the outliers): {name}", min_same=0.97,
                                     ten_bit=c.get("output_format", 0) == 1, lim=lim, cap=FUZZ_CAP(want_w, c), operator_input=bool(c.get('hdr_tonemap')))
         if nb and i % 5: witnessed.append((nb, nb / (want_w.shape[0] * want_w.shape[1] / 1e6), internal_is_8bit(c), i))
-        assert d.max() <= worst_ok, name
+        # how FAR such a channel may lie is bounded where a pow() feeds a smooth tail (a few codes: worst_ok).  Behind an HDR10 tone-mapping
+        # operator there is no bound to offer: the operators branch (soak case 3549 of seed 4006, operator 2: the ORACLE's red moves from 511 to
+        # 582 under +-4 ulp of pow(), profiles/r06/case3549.txt) and map a code of their input with any slope near black — the witness is the check
+        if not c.get("hdr_tonemap"):
+            assert d.max() <= worst_ok, name
     else:
         assert beyond == 0 or (beyond <= max(4, 2e-5 * d.size) and d.max() <= worst_ok), name
 if witnessed:
