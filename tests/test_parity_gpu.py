@@ -365,6 +365,33 @@ def test_soak_case_2367_one_code_in_front_of_tonemap_operator_6(mpcvr, oracle, t
     assert int(np.abs(_codes10(up) - _codes10(want)).max()) >= 7
 
 
+# soak case 3549 (profiles/r06/case3549.txt; default mode, seed 4006): HLG -> HDR10 output through tone-mapping operator 2, rotated 270.  One red
+# channel of the default tier is 71 ten-bit codes from the plain tier's — and the ORACLE answers that channel 511 or 582 depending on +-4 ulp of
+# pow(): the operator branches there.  The plain tier is the oracle's exact answer; the default tier's is the oracle's other one.
+FUZZ_3549 = {'cformat': 24, 'w': 606, 'h': 258, 'kind': 'noise', 'seed': 476592806, 'exfmt': 2185372928, 'iChromaScaling': 2, 'iUpscaling': 4, 'iDownscaling': 5,
+             'bInterpolateAt50pct': 0, 'dst': (123, 837), 'rotation': 270, 'hdr_output': 1, 'output_format': 1, 'hdr_tonemap': 2, 'hdr_display': 400.0,
+             'hdr_meta': (0.005, 1000.0, 0.0, 200.0)}
+
+
+def test_soak_case_3549_tonemap_operator_branch(mpcvr, oracle, torch_cuda):
+    from videorenderer_amd import api
+    c = FUZZ_3549
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    bg = lambda: np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8)
+    want = oracle.process(p, frame, pitch, dst=bg())
+    plain, info = run_product(mpcvr, torch_cuda, c, extra_flags=api.FLAG_NO_FUSED)
+    assert np.array_equal(_codes10(plain), _codes10(want)), info
+    got, info = run_product(mpcvr, torch_cuda, c)
+    _, n = compare_behind_tail(oracle, p, frame, pitch, got, want, "soak 3549", min_same=0.97, ten_bit=True, lim=4, cap=1, operator_input=True)
+    assert n <= 1, (n, info)
+    # the oracle's own two answers at the channel the case was recorded for
+    y, x, ch = 700, 34, 0
+    seen = {int(_codes10(oracle.process_with_pow_bias(p, frame, pitch, b, dst=bg(), seed=sd))[y, x, ch]) for b, sd in [(-4, 0), (4, 0), (4, 1), (4, 2), (4, 3), (4, 4)]}
+    assert int(_codes10(want)[y, x, ch]) == 511 and {511, 582} <= seen | {511}, seen
+    assert int(_codes10(got)[y, x, ch]) in seen | {511}
+
+
 def test_dovi_tail_stage_by_stage(mpcvr, oracle, torch_cuda):
     """The plain tier's Dolby Vision tail (mpcvr_eval_dovi_tail: k_eval_dovi_tail is compiled in the plain kernels' translation unit) against the
     oracle's, cut off after each of its six stages — PQ EOTF -> LMS -> PQ OETF; saturate + level-2 trims; ST2084ToLinear * scale; Hable; 2020 -> 709;
