@@ -62,9 +62,42 @@ static inline float tm_input_probe(float v, float maxv, int x, int y, int ch)
     if (code > maxv) code = maxv;
     return code / maxv;
 }
+/* ... and the same one step earlier, where a GPU's pow() actually errs: log2(x) answers up to `amplitude` ulps off (a hash of the operands
+ * and `seed`; seed 0 = every call by +amplitude, or by -amplitude when negative), THEN the product with y and exp2.  Direct3D 11 grants
+ * log2 / exp2 a relative error of 2^-21 (four fp32 ulps), v_log_f32 is specified to one; behind pow(x, 78.8) or pow(x, 6.28) — the PQ
+ * chains — one ulp of log2 is 35-80 ulps of the result, which the +-4 ulp-of-the-result probe above does not span (soak case 1428). */
+static int g_log2_ulp_amp = 0;
+static uint32_t g_log2_ulp_seed = 0;
+void orc_set_pow_log2_noise(int amplitude, uint32_t seed) { g_log2_ulp_amp = amplitude; g_log2_ulp_seed = seed; }
+static inline float pow_with_log2_noise(float x, float y)
+{
+    float l = crm_log2f(x);
+    if (l == l && l != 0.0f && l > -3.0e38f && l < 3.0e38f) {
+        int bias = g_log2_ulp_amp;
+        if (g_log2_ulp_seed) {
+            uint32_t a, b2; memcpy(&a, &x, 4); memcpy(&b2, &y, 4);
+            uint32_t h = (a ^ (b2 * 0x9E3779B9u) ^ g_log2_ulp_seed) * 0x85EBCA6Bu;
+            h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+            const int amp = bias < 0 ? -bias : bias;
+            bias = (int)(h % (uint32_t)(2 * amp + 1)) - amp;
+        }
+        uint32_t u; memcpy(&u, &l, 4);
+        u = (uint32_t)((int32_t)u + ((l < 0.0f) ? -bias : bias));      /* (ulps towards +inf for a positive bias, whatever the sign of l) */
+        memcpy(&l, &u, 4);
+    }
+    return crm_exp2f(y * l);
+}
+/* Sensitivity probe (tests only): every texel of m_TexConvertOutput is stored `bias` codes of its UNORM format off — on `channel` (0..2; -1: all
+ * three), or (seed != 0) every channel of every texel by its own hash-drawn amount in [-|bias|, +|bias|].  The fused tiers' convert stage is held
+ * to one code of that texture; what one code becomes behind the draws is the reference's own business — its Bicubic / Lanczos DOWNSCALE shaders
+ * divide by a weight sum that is small at some phases (soak case 5624: one code of one luma sample moves ONE output pixel of the oracle by 17
+ * ten-bit codes), so a channel beyond the bar behind such a draw is shown to lie inside what the oracle answers for that texture one code off. */
+static int g_cv_out_bias = 0, g_cv_out_channel = -1;
+static uint32_t g_cv_out_seed = 0;
+void orc_set_convert_output_bias(int bias, int channel, uint32_t seed) { g_cv_out_bias = bias; g_cv_out_channel = channel; g_cv_out_seed = seed; }
 static inline float hlsl_pow(float x, float y)
 {
-    float r = crm_powf(x, y);          /* exp2(y * log2 x), each step the correctly rounded fp32 function (crmath.h) */
+    float r = g_log2_ulp_amp ? pow_with_log2_noise(x, y) : crm_powf(x, y);          /* exp2(y * log2 x), each step the correctly rounded fp32 function (crmath.h) */
     if (g_pow_ulp_bias && r > 0.0f && r < 3.0e38f) {
         uint32_t u; memcpy(&u, &r, 4);
         int bias = g_pow_ulp_bias;
@@ -1986,6 +2019,25 @@ int orc_process(const orc_params *p, const uint8_t *src, int src_pitch,
     if (c.enable) {
         if (img_alloc(&conv, w1, h1)) { free(c.owned); return -5; }
         convert_pass(p, &c, &conv);
+        if (g_cv_out_bias && (internal == FMT_RGB10A2 || internal == FMT_BGRA8)) {
+            const float cmax = internal == FMT_RGB10A2 ? 1023.0f : 255.0f;
+            const int amp = g_cv_out_bias < 0 ? -g_cv_out_bias : g_cv_out_bias;
+            for (int y = 0; y < h1; y++)
+                for (int x = 0; x < w1; x++)
+                    for (int ch = 0; ch < 3; ch++) {
+                        if (!g_cv_out_seed && g_cv_out_channel >= 0 && g_cv_out_channel != ch) continue;
+                        int bias = g_cv_out_bias;
+                        if (g_cv_out_seed) {
+                            uint32_t h = ((uint32_t)x * 0x9E3779B9u) ^ ((uint32_t)y * 0x85EBCA6Bu) ^ ((uint32_t)ch * 0xC2B2AE35u) ^ g_cv_out_seed;
+                            h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+                            bias = (int)(h % (uint32_t)(2 * amp + 1)) - amp;
+                        }
+                        float *q = conv.p + ((size_t)y * w1 + x) * 4 + ch;
+                        float code = floorf(*q * cmax + 0.5f) + (float)bias;
+                        code = code < 0.0f ? 0.0f : (code > cmax ? cmax : code);
+                        *q = code / cmax;
+                    }
+        }
     } else {
         if (img_alloc(&conv, p->width, p->height)) { free(c.owned); return -5; }
         for (int y = 0; y < p->height; y++)

@@ -128,6 +128,11 @@ void orc_set_pow_ulp_noise(int amplitude, uint32_t seed);
 /* sensitivity probe: the texture the HDR10 tone-mapping step reads arrives `bias` codes of its UNORM format off, on `channel` (0..2, -1 = all),
  * or — seed != 0 — every channel of every texel by its own hash-drawn amount in [-|bias|, +|bias|]; bias 0 = off */
 void orc_set_tonemap_input_bias(int bias, int channel, uint32_t seed);
+/* sensitivity probe: log2(x) inside every pow() up to `amplitude` ulps off (seed 0: all by +amplitude / -amplitude; else per call, hashed); 0 = off */
+void orc_set_pow_log2_noise(int amplitude, uint32_t seed);
+/* sensitivity probe: m_TexConvertOutput stored `bias` codes off, on `channel` (0..2, -1 = all) or — seed != 0 — every channel of every texel by
+ * its own draw in [-|bias|, +|bias|]; UNORM internal formats only; bias 0 = off */
+void orc_set_convert_output_bias(int bias, int channel, uint32_t seed);
 /* the shader transcendentals as this oracle defines them (crmath.h: exp2(y * log2 x) with every step the correctly rounded fp32 function)
  * over an array: fn = 0 log2f, 1 exp2f, 2 expf, 3 powf(x, y), 4 sinf, 5 cosf */
 void orc_eval_transcendental(int fn, const float *x, const float *y, float *out, size_t n);

@@ -208,6 +208,8 @@ def lib():
         L.orc_set_pow_ulp_noise.argtypes = [C.c_int, C.c_uint32]
         L.orc_set_tex_ulp_bias.argtypes = [C.c_int]
         L.orc_set_tonemap_input_bias.argtypes = [C.c_int, C.c_int, C.c_uint32]
+        L.orc_set_pow_log2_noise.argtypes = [C.c_int, C.c_uint32]
+        L.orc_set_convert_output_bias.argtypes = [C.c_int, C.c_int, C.c_uint32]
         L.orc_eval_transcendental.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.orc_eval_dovi_tail.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, fp, fp, C.c_int, C.c_float]
         L.orc_hdr10_params.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_uint32)]
@@ -359,6 +361,24 @@ def process_with_tonemap_input_bias(p, frame, pitch, bias, channel=-1, seed=0, d
         return process(p, frame, pitch, dst=dst)
     finally:
         lib().orc_set_tonemap_input_bias(0, -1, 0)
+
+
+def process_with_log2_noise(p, frame, pitch, amplitude, seed=0, dst=None):
+    """process() with log2(x) inside every pow() up to `amplitude` ulps off (seed 0: every call by that amount, signed) — where a GPU's pow errs."""
+    lib().orc_set_pow_log2_noise(int(amplitude), int(seed))
+    try:
+        return process(p, frame, pitch, dst=dst)
+    finally:
+        lib().orc_set_pow_log2_noise(0, 0)
+
+
+def process_with_convert_output_bias(p, frame, pitch, bias, channel=-1, seed=0, dst=None):
+    """process() with m_TexConvertOutput `bias` codes off (channel 0..2, -1 = all; seed != 0: per texel and channel, drawn in [-|bias|, +|bias|])."""
+    lib().orc_set_convert_output_bias(int(bias), int(channel), int(seed))
+    try:
+        return process(p, frame, pitch, dst=dst)
+    finally:
+        lib().orc_set_convert_output_bias(0, -1, 0)
 
 
 def eval_transcendental(fn, x, y=None):

@@ -833,3 +833,24 @@ def test_tonemap_input_probe_is_off_by_default_and_moves_only_what_it_names(orac
     a = oracle.process(p0, frame, pitch, dst=bg())
     b = oracle.process_with_tonemap_input_bias(p0, frame, pitch, 1, dst=bg())
     assert np.array_equal(a, b)
+
+
+def test_convert_output_and_log2_probes_are_off_by_default(oracle):
+    """orc_set_convert_output_bias / orc_set_pow_log2_noise (witnesses of the fused tiers' bars): off = the pinned output, on = something else,
+    and both reset; the convert-output probe leaves an fp16 internal format alone."""
+    from tests.golden.cases import GOLDEN_CASES, case_frame, oracle_params
+    from tests.test_parity_gpu import BG
+    c = dict(GOLDEN_CASES["c3hdr_p010_pq_lanczos3_2x"])
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    bg = lambda: np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8)
+    want = oracle.process(p, frame, pitch, dst=bg())
+    a = oracle.process_with_convert_output_bias(p, frame, pitch, 1, dst=bg())
+    b = oracle.process_with_convert_output_bias(p, frame, pitch, 1, seed=3, dst=bg())
+    l = oracle.process_with_log2_noise(p, frame, pitch, 4, seed=2, dst=bg())
+    assert np.array_equal(oracle.process(p, frame, pitch, dst=bg()), want), "a probe did not reset"
+    assert not np.array_equal(a, want) and not np.array_equal(b, want) and not np.array_equal(a, b)
+    assert int(np.abs(l[..., :3].astype(int) - want[..., :3].astype(int)).max()) <= 2        # a smooth tail: an ulp of log2 is no code
+    c16 = dict(c, iTexFormat=16)
+    p16 = oracle_params(oracle, c16)
+    assert np.array_equal(oracle.process(p16, frame, pitch, dst=bg()), oracle.process_with_convert_output_bias(p16, frame, pitch, 1, dst=bg()))

@@ -113,7 +113,7 @@ def _codes10(a):
     return np.stack([(u >> sh) & 1023 for sh in (0, 10, 20)], -1).astype(np.int16)
 
 
-def compare_behind_tail(oracle, p, frame, pitch, got, want, name, min_same=0.99, ten_bit=False, lim=1, dovi=False, cap=None, operator_input=False):
+def compare_behind_tail(oracle, p, frame, pitch, got, want, name, min_same=0.99, ten_bit=False, lim=1, dovi=False, cap=None, operator_input=False, convert_output=False):
     """Frames behind a PQ / HLG / Dolby Vision tail: |delta| <= 1 like everywhere else, EXCEPT on channels where the oracle's own
     answer is not defined to one code — shown per channel, not assumed: the oracle is run again with every pow() of the chain POW_ULPS
     ulps low, POW_ULPS ulps high, and eight times with each call off by its own hash-drawn amount within +-POW_ULPS
@@ -127,6 +127,11 @@ def compare_behind_tail(oracle, p, frame, pitch, got, want, name, min_same=0.99,
     the operator maps a code of the texture it reads with its own slope (operator 6 near black: seven ten-bit codes per code — soak case 2367,
     profiles/r06/case2367.txt); the interval then also spans the oracle's answers for that texture one code low / high as a whole, on each
     channel alone, and in eight per-texel draws (oracle.process_with_tonemap_input_bias).
+    convert_output (fused tiers, UNORM internal formats, round 6): the block convert is held to ONE code of m_TexConvertOutput, and what a code
+    becomes behind the draws is the reference's own business — its Bicubic / Lanczos downscale shaders divide by a weight sum that is small at
+    some phases (soak case 5624, profiles/r06/cases_5624_1428.txt: one code of one luma sample moves one pixel of the ORACLE by 17 ten-bit
+    codes); the interval then also spans the oracle's answers for that texture one code low / high as a whole, per channel, and in sixteen
+    per-texel draws (oracle.process_with_convert_output_bias).
     Returns (share of identical channels, number of such channels)."""
     codes = _codes10 if ten_bit else (lambda a: a[..., :3].astype(np.int16))
     g3, w3 = codes(got), codes(want)
@@ -146,6 +151,10 @@ def compare_behind_tail(oracle, p, frame, pitch, got, want, name, min_same=0.99,
         if operator_input:
             for bias, ch, seed in [(b, ch, 0) for b in (-1, 1) for ch in (-1, 0, 1, 2)] + [(1, -1, k) for k in range(1, 9)]:
                 run = codes(oracle.process_with_tonemap_input_bias(p, frame, pitch, bias, channel=ch, seed=seed, dst=bg.copy()))
+                lo = np.minimum(lo, run); hi = np.maximum(hi, run)
+        if convert_output:
+            for bias, ch, seed in [(b, ch, 0) for b in (-1, 1) for ch in (-1, 0, 1, 2)] + [(1, -1, k) for k in range(1, 17)]:
+                run = codes(oracle.process_with_convert_output_bias(p, frame, pitch, bias, channel=ch, seed=seed, dst=bg.copy()))
                 lo = np.minimum(lo, run); hi = np.maximum(hi, run)
         lo -= lim; hi += lim
         inside = (g3 >= lo) & (g3 <= hi)
@@ -390,6 +399,82 @@ def test_soak_case_3549_tonemap_operator_branch(mpcvr, oracle, torch_cuda):
     seen = {int(_codes10(oracle.process_with_pow_bias(p, frame, pitch, b, dst=bg(), seed=sd))[y, x, ch]) for b, sd in [(-4, 0), (4, 0), (4, 1), (4, 2), (4, 3), (4, 4)]}
     assert int(_codes10(want)[y, x, ch]) == 511 and {511, 582} <= seen | {511}, seen
     assert int(_codes10(got)[y, x, ch]) in seen | {511}
+
+
+# soak case 5624 (profiles/r06/cases_5624_1428.txt; default mode, seed 5001): PQ -> HDR10 passthrough (no transcendental anywhere in the plan),
+# Bicubic downscale across + Mitchell upscale along a frame rotated by 270: two vertically adjacent red channels 7 ten-bit codes from the plain
+# tier.  The block convert's texture differs from the oracle's in 24 texels of 151 k, by one code each (its bar) — and the reference's Bicubic
+# downscale at that output column turns one code into ten (the ORACLE moves by 17 for one code of one luma sample there).
+FUZZ_5624 = {'cformat': 3, 'w': 574, 'h': 264, 'kind': 'noise', 'seed': 931924931, 'exfmt': 2051155200, 'iChromaScaling': 1, 'iUpscaling': 1, 'iDownscaling': 3,
+             'bInterpolateAt50pct': 0, 'dst': (125, 1378), 'rotation': 270, 'hdr_output': 1, 'output_format': 1, 'hdr_tonemap': 0, 'hdr_display': 400.0,
+             'hdr_meta': (0.005, 4000.0, 800.0, 0.0)}
+
+
+def test_soak_case_5624_one_convert_code_in_front_of_a_bicubic_downscale(mpcvr, oracle, torch_cuda):
+    from videorenderer_amd import api
+    c = FUZZ_5624
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    bg = lambda: np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8)
+    want = oracle.process(p, frame, pitch, dst=bg())
+    for flags in (api.FLAG_NO_FUSED, api.FLAG_NO_FAST_CONVERT):          # the per-pixel convert kernel: the oracle's bits all the way
+        plain, info = run_product(mpcvr, torch_cuda, c, extra_flags=flags)
+        assert np.array_equal(_codes10(plain), _codes10(want)), info
+    # the convert texture itself (a rotated copy draw shows it): within one code everywhere
+    same = dict(c, dst=(c["h"], c["w"]))
+    ps = oracle_params(oracle, same)
+    ws = oracle.process(ps, frame, pitch, dst=np.full((ps.window_h, ps.window_w, 4), BG, dtype=np.uint8))
+    gs, _ = run_product(mpcvr, torch_cuda, same)
+    assert int(np.abs(_codes10(gs) - _codes10(ws)).max()) <= 1
+    got, info = run_product(mpcvr, torch_cuda, c)
+    with pytest.raises(AssertionError, match="NOT explained"):
+        compare_behind_tail(oracle, p, frame, pitch, got, want, "soak 5624", min_same=0.97, ten_bit=True, lim=2, cap=2)
+    _, n = compare_behind_tail(oracle, p, frame, pitch, got, want, "soak 5624", min_same=0.97, ten_bit=True, lim=2, cap=2, convert_output=True)
+    assert n == 2, (n, info)
+    # the oracle's own sensitivity there: one code of one luma sample
+    f2 = frame.copy()
+    Y = f2[:c["w"] * c["h"] * 2].view(np.uint16).reshape(c["h"], c["w"])
+    Y[199, 543] = np.uint16(int(Y[199, 543]) + 64)
+    moved = oracle.process(p, f2, pitch, dst=bg())
+    assert int(np.abs(_codes10(moved) - _codes10(want)).max()) >= 10
+
+
+# soak case 1428 (profiles/r06/cases_5624_1428.txt; Jinc2m mode, seed 5102) — OPEN: Dolby Vision (polynomial curves) + level-2 trims + ProcAmp
+# (contrast 1.18, brightness -4) -> Jinc2m 2x -> 8-bit target.  The block convert's table variant (DV_SDR_L2: PQ encode and tone map out of LDS
+# tables) leaves 5 of 233 k channels beyond one code, and two of them — the blue of two saturated yellows, 6 and 16 where the oracle has 0 and 8 —
+# lie outside every interval the oracle spans (+-4 ulp of pow, log2 up to 4 ulps off).  The plain tier equals the oracle; MPCVR_FLAG_NO_LUT and
+# MPCVR_FLAG_NO_FAST_CONVERT are within one code; without the ProcAmp or without the trims the default tier is too.  Found in the round's last
+# hours and not chased to the instruction: the test states the bar and is expected to fail until the table variant meets it.
+FUZZ_1428 = {'cformat': 2, 'w': 90, 'h': 216, 'kind': 'noise', 'seed': 897013636, 'exfmt': 2051155200, 'iChromaScaling': 0, 'iUpscaling': 5, 'iDownscaling': 3,
+             'bInterpolateAt50pct': 0, 'dst': (180, 432), 'window': (171, 432), 'offset': (15, 20),
+             'procamp': (-3.9689549383766405, 1.1823064992043373, -6.779328347755538, 1.053739126351976), 'dovi': {'kind': 'poly', 'l2': (100, 600, 1000)}}
+
+
+def test_soak_case_1428_plain_and_per_pixel_tiers(mpcvr, oracle, torch_cuda):
+    from videorenderer_amd import api
+    c = FUZZ_1428
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+    plain, info = run_product(mpcvr, torch_cuda, c, extra_flags=api.FLAG_NO_FUSED)
+    assert np.array_equal(plain[..., :3], want[..., :3]), info
+    for flags in (api.FLAG_NO_LUT, api.FLAG_NO_FAST_CONVERT):
+        got, info = run_product(mpcvr, torch_cuda, c, extra_flags=flags)
+        assert int(np.abs(got[..., :3].astype(int) - want[..., :3].astype(int)).max()) <= 1, info
+    # the default tier as recorded: a handful of channels, none further than 8 codes (a regression beyond that fails here)
+    got, info = run_product(mpcvr, torch_cuda, c)
+    d = np.abs(got[..., :3].astype(int) - want[..., :3].astype(int))
+    assert int((d > 1).sum()) <= 8 and int(d.max()) <= 8, (int((d > 1).sum()), int(d.max()), info)
+
+
+@pytest.mark.xfail(strict=True, reason="OPEN (round 6, soak case 1428): the Dolby Vision level-2 table variant of the block convert + ProcAmp leaves two channels outside the oracle's intervals")
+def test_soak_case_1428_default_tier_meets_the_witness_bar(mpcvr, oracle, torch_cuda):
+    c = FUZZ_1428
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    want = oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8))
+    got, info = run_product(mpcvr, torch_cuda, c)
+    compare_behind_tail(oracle, p, frame, pitch, got, want, "soak 1428", min_same=0.97, lim=1, cap=8, convert_output=True)
 
 
 def test_dovi_tail_stage_by_stage(mpcvr, oracle, torch_cuda):
