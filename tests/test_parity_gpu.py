@@ -443,8 +443,8 @@ def test_soak_case_5624_one_convert_code_in_front_of_a_bicubic_downscale(mpcvr, 
 # (contrast 1.18, brightness -4) -> Jinc2m 2x -> 8-bit target.  The block convert's table variant (DV_SDR_L2: PQ encode and tone map out of LDS
 # tables) leaves 5 of 233 k channels beyond one code, and two of them — the blue of two saturated yellows, 6 and 16 where the oracle has 0 and 8 —
 # lie outside every interval the oracle spans (+-4 ulp of pow, log2 up to 4 ulps off).  The plain tier equals the oracle; MPCVR_FLAG_NO_LUT and
-# MPCVR_FLAG_NO_FAST_CONVERT are within one code; without the ProcAmp or without the trims the default tier is too.  Found in the round's last
-# hours and not chased to the instruction: the test states the bar and is expected to fail until the table variant meets it.
+# MPCVR_FLAG_NO_FAST_CONVERT are within one code; with contrast 1.0 or without the trims the default tier is too; decoding the over-range PQ codes with
+# the defined pow changes nothing (profiles/r06/case1428.txt).  Found in the round's last hours and not chased to the instruction: the test states the bar and is expected to fail until the table variant meets it.
 FUZZ_1428 = {'cformat': 2, 'w': 90, 'h': 216, 'kind': 'noise', 'seed': 897013636, 'exfmt': 2051155200, 'iChromaScaling': 0, 'iUpscaling': 5, 'iDownscaling': 3,
              'bInterpolateAt50pct': 0, 'dst': (180, 432), 'window': (171, 432), 'offset': (15, 20),
              'procamp': (-3.9689549383766405, 1.1823064992043373, -6.779328347755538, 1.053739126351976), 'dovi': {'kind': 'poly', 'l2': (100, 600, 1000)}}
