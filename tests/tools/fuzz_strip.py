@@ -13,7 +13,7 @@ from videorenderer_amd import api
 from tests.golden.cases import GOLDEN_CASES, case_frame, oracle_params, HDR10, HLG
 from tests.test_parity_gpu import BG
 from oracle import oracle
-from tests.test_parity_gpu import run_product, compare, compare_rgb10, internal_is_8bit, has_tail, make_vp
+from tests.test_parity_gpu import run_product, compare, compare_rgb10, internal_is_8bit, has_tail, make_vp, POW_ULPS_EOTF_TABLE
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20260925)
@@ -175,13 +175,13 @@ for i in range(n):
             from tests.test_parity_gpu import compare_behind_tail
             po = oracle_params(oracle, c)
             fr, pit = case_frame(c)
-            _, nb = compare_behind_tail(oracle, po, fr, pit, got, want, f"default planner vs oracle (tail, 10-bit): {name}", min_same=0.97, ten_bit=True, lim=lim, cap=FUZZ_CAP(want, c), operator_input=bool(c.get('hdr_tonemap')), convert_output=not internal_is_8bit(c))
+            _, nb = compare_behind_tail(oracle, po, fr, pit, got, want, f"default planner vs oracle (tail, 10-bit): {name}", min_same=0.97, ten_bit=True, lim=lim, cap=FUZZ_CAP(want, c), operator_input=bool(c.get('hdr_tonemap')), convert_output=not internal_is_8bit(c), pow_ulps=(POW_ULPS_EOTF_TABLE if 'dovi' in c else None))
             if nb: witnessed.append((nb, nb / (want.shape[0] * want.shape[1] / 1e6), internal_is_8bit(c), i))
         else:                                       # 8-bit targets: <= 1 LSB, or the per-channel witness (the oracle's own +-4 ulp pow() interval)
             from tests.test_parity_gpu import compare_behind_tail
             po = oracle_params(oracle, c)
             fr, pit = case_frame(c)
-            _, nb = compare_behind_tail(oracle, po, fr, pit, got, want, f"default planner vs oracle (tail): {name}", min_same=0.97, cap=FUZZ_CAP(want, c), operator_input=bool(c.get('hdr_tonemap')), convert_output=not internal_is_8bit(c))
+            _, nb = compare_behind_tail(oracle, po, fr, pit, got, want, f"default planner vs oracle (tail): {name}", min_same=0.97, cap=FUZZ_CAP(want, c), operator_input=bool(c.get('hdr_tonemap')), convert_output=not internal_is_8bit(c), pow_ulps=(POW_ULPS_EOTF_TABLE if 'dovi' in c else None))
             if nb: witnessed.append((nb, nb / (want.shape[0] * want.shape[1] / 1e6), internal_is_8bit(c), i))
     beyond = int((d > lim).sum()); same = float((d == 0).mean())
     worst = max(worst, 1.0 - same)
@@ -203,7 +203,7 @@ for i in range(n):
         fr, pit = case_frame(c)
         want_w = oracle.process(po, fr, pit, dst=np.full((got.shape[0], got.shape[1], 4), BG, dtype=np.uint8))
         _, nb = compare_behind_tail(oracle, po, fr, pit, got, want_w, f"default planner vs oracle (witness for the outliers): {name}", min_same=0.97,
-                                    ten_bit=c.get("output_format", 0) == 1, lim=lim, cap=FUZZ_CAP(want_w, c), operator_input=bool(c.get('hdr_tonemap')), convert_output=not internal_is_8bit(c))
+                                    ten_bit=c.get("output_format", 0) == 1, lim=lim, cap=FUZZ_CAP(want_w, c), operator_input=bool(c.get('hdr_tonemap')), convert_output=not internal_is_8bit(c), pow_ulps=(POW_ULPS_EOTF_TABLE if 'dovi' in c else None))
         if nb and i % 5: witnessed.append((nb, nb / (want_w.shape[0] * want_w.shape[1] / 1e6), internal_is_8bit(c), i))
         # how FAR such a channel may lie is bounded where a pow() feeds a smooth tail (a few codes: worst_ok).  Behind an HDR10 tone-mapping
         # operator there is no bound to offer: the operators branch (soak case 3549 of seed 4006, operator 2: the ORACLE's red moves from 511 to
