@@ -490,6 +490,28 @@ def test_soak_case_1428_default_tier_inside_the_eotf_tables_own_accuracy(mpcvr, 
     assert n <= 8, (n, info)
 
 
+# soak5 case 4319 (profiles/r06/case4319.txt; left-out-scalers mode, seed 6701) — RECORDED STATE, not a bar: Dolby Vision MMR + ProcAmp (contrast 1.17,
+# saturation 1.44), 8-bit internal format, nearest 1.7x, 10-bit target, noise.  The plain tier is the oracle's bits; the table tier (the PQ EOTF out of
+# its LDS table: a 14 % faster Dolby Vision convert) leaves 17 of 1.5 M channels beyond five ten-bit codes (max 16; 20 with contrast 1.0), four of them
+# outside even the +-10 ulp interval — at channels the oracle itself spans 128 .. 168 on.  The test pins the plain tier and fences the recorded figures.
+FUZZ_4319 = {'cformat': 3, 'w': 598, 'h': 288, 'kind': 'noise', 'seed': 546315119, 'exfmt': 2051155200, 'iChromaScaling': 0, 'iUpscaling': 0, 'iDownscaling': 2,
+             'bInterpolateAt50pct': 1, 'dst': (1027, 495), 'output_format': 1, 'iTexFormat': 8,
+             'procamp': (-3.8196396258474365, 1.1730855112312484, -6.805298891179945, 1.4386824544891605), 'dovi': {'kind': 'mmr', 'l2': ()}}
+
+
+def test_soak_case_4319_plain_tier_exact_table_tier_as_recorded(mpcvr, oracle, torch_cuda):
+    from videorenderer_amd import api
+    c = FUZZ_4319
+    frame, pitch = case_frame(c)
+    p = oracle_params(oracle, c)
+    want = _codes10(oracle.process(p, frame, pitch, dst=np.full((p.window_h, p.window_w, 4), BG, dtype=np.uint8)))
+    plain, info = run_product(mpcvr, torch_cuda, c, extra_flags=api.FLAG_NO_FUSED)
+    assert np.array_equal(_codes10(plain), want), info
+    got, info = run_product(mpcvr, torch_cuda, c)
+    d = np.abs(_codes10(got) - want)
+    assert float((d == 0).mean()) >= 0.998 and int((d > 5).sum()) <= 34 and int(d.max()) <= 24, (float((d == 0).mean()), int((d > 5).sum()), int(d.max()), info)
+
+
 def test_dovi_tail_stage_by_stage(mpcvr, oracle, torch_cuda):
     """The plain tier's Dolby Vision tail (mpcvr_eval_dovi_tail: k_eval_dovi_tail is compiled in the plain kernels' translation unit) against the
     oracle's, cut off after each of its six stages — PQ EOTF -> LMS -> PQ OETF; saturate + level-2 trims; ST2084ToLinear * scale; Hable; 2020 -> 709;
